@@ -1,0 +1,484 @@
+// See executor.hpp.  Golden behaviour (cycle counts, public values, exit codes)
+// is pinned by SURVEY.md appendix A.4 and checked in tests/test_executor.py.
+#include "executor.hpp"
+
+#include <sys/mman.h>
+
+#include <cstring>
+
+namespace zksp {
+
+// ---------------------------------------------------------------------------
+// hashes
+// ---------------------------------------------------------------------------
+static const uint64_t kKeccakRC[24] = {
+    0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull,
+    0x000000000000808Bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
+    0x000000000000008Aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000Aull,
+    0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull, 0x8000000000008003ull,
+    0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
+    0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+// rotation offset of lane (x, y), indexed [x][y]
+static const int kKeccakRot[5][5] = {{0, 36, 3, 41, 18},
+                                     {1, 44, 10, 45, 2},
+                                     {62, 6, 43, 15, 61},
+                                     {28, 55, 25, 21, 56},
+                                     {27, 20, 39, 8, 14}};
+
+static inline uint64_t rol64(uint64_t v, int n) { return n ? (v << n) | (v >> (64 - n)) : v; }
+
+void keccak_f1600(uint64_t a[25]) {
+  for (int rnd = 0; rnd < 24; ++rnd) {
+    uint64_t c[5], d[5], b[25];
+    for (int x = 0; x < 5; ++x) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+    for (int x = 0; x < 5; ++x) d[x] = c[(x + 4) % 5] ^ rol64(c[(x + 1) % 5], 1);
+    for (int i = 0; i < 25; ++i) a[i] ^= d[i % 5];
+    for (int x = 0; x < 5; ++x)
+      for (int y = 0; y < 5; ++y) b[y + 5 * ((2 * x + 3 * y) % 5)] = rol64(a[x + 5 * y], kKeccakRot[x][y]);
+    for (int y = 0; y < 5; ++y)
+      for (int x = 0; x < 5; ++x) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+    a[0] ^= kKeccakRC[rnd];
+  }
+}
+
+void keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
+  const size_t rate = 136;
+  uint64_t st[25] = {0};
+  uint8_t blk[136];
+  size_t off = 0;
+  for (;;) {
+    size_t n = len - off < rate ? len - off : rate;
+    bool last = n < rate;
+    memset(blk, 0, rate);
+    memcpy(blk, data + off, n);
+    if (last) {
+      blk[n] ^= 0x01;
+      blk[rate - 1] ^= 0x80;
+    }
+    for (size_t i = 0; i < rate / 8; ++i) {
+      uint64_t w;
+      memcpy(&w, blk + 8 * i, 8);
+      st[i] ^= w;
+    }
+    keccak_f1600(st);
+    off += n;
+    if (last) break;
+  }
+  memcpy(out, st, 32);
+}
+
+static inline uint32_t ror32(uint32_t v, int n) { return (v >> n) | (v << (32 - n)); }
+
+void sha256(const uint8_t* data, size_t len, uint8_t out[32]) {
+  static const uint32_t K[64] = {
+      0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+      0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+      0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+      0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+      0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+      0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+      0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+      0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  std::vector<uint8_t> msg(data, data + len);
+  msg.push_back(0x80);
+  while (msg.size() % 64 != 56) msg.push_back(0);
+  uint64_t bits = (uint64_t)len * 8;
+  for (int i = 7; i >= 0; --i) msg.push_back((uint8_t)(bits >> (8 * i)));
+  for (size_t off = 0; off < msg.size(); off += 64) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; ++i)
+      w[i] = (uint32_t)msg[off + 4 * i] << 24 | (uint32_t)msg[off + 4 * i + 1] << 16 |
+             (uint32_t)msg[off + 4 * i + 2] << 8 | msg[off + 4 * i + 3];
+    for (int i = 16; i < 64; ++i) {
+      uint32_t s0 = ror32(w[i - 15], 7) ^ ror32(w[i - 15], 18) ^ (w[i - 15] >> 3);
+      uint32_t s1 = ror32(w[i - 2], 17) ^ ror32(w[i - 2], 19) ^ (w[i - 2] >> 10);
+      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; ++i) {
+      uint32_t S1 = ror32(e, 6) ^ ror32(e, 11) ^ ror32(e, 25);
+      uint32_t ch = (e & f) ^ (~e & g);
+      uint32_t t1 = hh + S1 + ch + K[i] + w[i];
+      uint32_t S0 = ror32(a, 2) ^ ror32(a, 13) ^ ror32(a, 22);
+      uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+      uint32_t t2 = S0 + mj;
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+  for (int i = 0; i < 8; ++i) {
+    out[4 * i] = (uint8_t)(h[i] >> 24);
+    out[4 * i + 1] = (uint8_t)(h[i] >> 16);
+    out[4 * i + 2] = (uint8_t)(h[i] >> 8);
+    out[4 * i + 3] = (uint8_t)h[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// ELF loader
+// ---------------------------------------------------------------------------
+static inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | p[1] << 8); }
+static inline uint32_t rd32(const uint8_t* p) {
+  return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+}
+
+std::string load_elf(const uint8_t* d, size_t len, ElfImage* out) {
+  if (len < 52 || memcmp(d, "\x7f" "ELF", 4) != 0) return "not an ELF file";
+  if (d[4] != 1 || d[5] != 1) return "not ELF32 little-endian";
+  if (rd16(d + 18) != 0xF3) return "not a RISC-V ELF";
+  *out = ElfImage();
+  out->entry = rd32(d + 24);
+  uint32_t phoff = rd32(d + 28), shoff = rd32(d + 32);
+  uint16_t phentsize = rd16(d + 42), phnum = rd16(d + 44);
+  uint16_t shentsize = rd16(d + 46), shnum = rd16(d + 48);
+  bool have_text = false;
+  for (uint16_t i = 0; i < phnum; ++i) {
+    size_t o = (size_t)phoff + (size_t)i * phentsize;
+    if (o + 32 > len) return "program header out of range";
+    const uint8_t* p = d + o;
+    if (rd32(p) != 1) continue;  // PT_LOAD
+    uint32_t off = rd32(p + 4), vaddr = rd32(p + 8), filesz = rd32(p + 16), memsz = rd32(p + 20), flags = rd32(p + 24);
+    if ((size_t)off + filesz > len) return "segment out of range";
+    if (vaddr & 3) return "unaligned segment";
+    ElfImage::Seg s;
+    s.vaddr = vaddr;
+    s.memsz = memsz;
+    s.bytes.assign(d + off, d + off + filesz);
+    if (vaddr + memsz > out->max_addr) out->max_addr = vaddr + memsz;
+    if ((flags & 1) && !have_text) {  // PF_X
+      have_text = true;
+      out->text_base = vaddr;
+      out->text.resize((filesz + 3) / 4);
+      for (size_t w = 0; w < out->text.size(); ++w) {
+        uint8_t tmp[4] = {0, 0, 0, 0};
+        size_t n = filesz - 4 * w < 4 ? filesz - 4 * w : 4;
+        memcpy(tmp, d + off + 4 * w, n);
+        out->text[w] = rd32(tmp);
+      }
+    }
+    out->segs.push_back(std::move(s));
+  }
+  if (!have_text) return "no executable segment";
+  // symbol table: FUNC symbols whose name contains "keccakf"
+  for (uint16_t i = 0; i < shnum; ++i) {
+    size_t o = (size_t)shoff + (size_t)i * shentsize;
+    if (shoff == 0 || o + 40 > len) break;
+    const uint8_t* sh = d + o;
+    if (rd32(sh + 4) != 2) continue;  // SHT_SYMTAB
+    uint32_t symoff = rd32(sh + 16), symsize = rd32(sh + 20), link = rd32(sh + 24), entsize = rd32(sh + 36);
+    if (entsize < 16 || link >= shnum) continue;
+    const uint8_t* strsh = d + shoff + (size_t)link * shentsize;
+    uint32_t stroff = rd32(strsh + 16), strsize = rd32(strsh + 20);
+    if ((size_t)symoff + symsize > len || (size_t)stroff + strsize > len) continue;
+    for (uint32_t s = 0; s + entsize <= symsize; s += entsize) {
+      const uint8_t* sym = d + symoff + s;
+      uint32_t name = rd32(sym), value = rd32(sym + 4);
+      uint8_t info = sym[12];
+      if ((info & 0xf) != 2 || name >= strsize) continue;  // STT_FUNC
+      const char* nm = (const char*)(d + stroff + name);
+      size_t maxn = strsize - name;
+      size_t nl = strnlen(nm, maxn);
+      std::string sname(nm, nl);
+      if (sname.find("keccakf") != std::string::npos && sname.find("closure") == std::string::npos) {
+        bool dup = false;
+        for (uint32_t e : out->keccakf_entries) dup |= (e == value);
+        if (!dup) out->keccakf_entries.push_back(value);
+      }
+    }
+  }
+  uint8_t dg[32];
+  sha256(d, len, dg);
+  memcpy(out->sha256.data(), dg, 32);
+  return "";
+}
+
+// ---------------------------------------------------------------------------
+// decoder
+// ---------------------------------------------------------------------------
+struct Decoded {
+  uint8_t op, rd, rs1, rs2;
+  int32_t imm;
+};
+
+static Decoded decode(uint32_t w) {
+  Decoded r{OP_INVALID, (uint8_t)((w >> 7) & 31), (uint8_t)((w >> 15) & 31), (uint8_t)((w >> 20) & 31), 0};
+  uint32_t opc = w & 0x7f, f3 = (w >> 12) & 7, f7 = w >> 25;
+  int32_t imm_i = (int32_t)w >> 20;
+  int32_t imm_s = ((int32_t)(w & 0xfe000000) >> 20) | ((w >> 7) & 0x1f);
+  int32_t imm_b = ((int32_t)(w & 0x80000000) >> 19) | ((w & 0x80) << 4) | ((w >> 20) & 0x7e0) | ((w >> 7) & 0x1e);
+  int32_t imm_u = (int32_t)(w & 0xfffff000);
+  int32_t imm_j = ((int32_t)(w & 0x80000000) >> 11) | (w & 0xff000) | ((w >> 9) & 0x800) | ((w >> 20) & 0x7fe);
+  switch (opc) {
+    case 0x37: r.op = OP_LUI; r.imm = imm_u; break;
+    case 0x17: r.op = OP_AUIPC; r.imm = imm_u; break;
+    case 0x6f: r.op = OP_JAL; r.imm = imm_j; break;
+    case 0x67: if (f3 == 0) { r.op = OP_JALR; r.imm = imm_i; } break;
+    case 0x63: {
+      static const uint8_t m[8] = {OP_BEQ, OP_BNE, 0, 0, OP_BLT, OP_BGE, OP_BLTU, OP_BGEU};
+      r.op = m[f3]; r.imm = imm_b; break;
+    }
+    case 0x03: {
+      static const uint8_t m[8] = {OP_LB, OP_LH, OP_LW, 0, OP_LBU, OP_LHU, 0, 0};
+      r.op = m[f3]; r.imm = imm_i; break;
+    }
+    case 0x23: {
+      static const uint8_t m[8] = {OP_SB, OP_SH, OP_SW, 0, 0, 0, 0, 0};
+      r.op = m[f3]; r.imm = imm_s; break;
+    }
+    case 0x13:
+      r.imm = imm_i;
+      switch (f3) {
+        case 0: r.op = OP_ADDI; break;
+        case 2: r.op = OP_SLTI; break;
+        case 3: r.op = OP_SLTIU; break;
+        case 4: r.op = OP_XORI; break;
+        case 6: r.op = OP_ORI; break;
+        case 7: r.op = OP_ANDI; break;
+        case 1: if (f7 == 0) { r.op = OP_SLLI; r.imm = r.rs2; } break;
+        case 5:
+          if (f7 == 0) { r.op = OP_SRLI; r.imm = r.rs2; }
+          else if (f7 == 0x20) { r.op = OP_SRAI; r.imm = r.rs2; }
+          break;
+      }
+      break;
+    case 0x33:
+      if (f7 == 0) {
+        static const uint8_t m[8] = {OP_ADD, OP_SLL, OP_SLT, OP_SLTU, OP_XOR, OP_SRL, OP_OR, OP_AND};
+        r.op = m[f3];
+      } else if (f7 == 0x20) {
+        if (f3 == 0) r.op = OP_SUB;
+        else if (f3 == 5) r.op = OP_SRA;
+      } else if (f7 == 1) {
+        static const uint8_t m[8] = {OP_MUL, OP_MULH, OP_MULHSU, OP_MULHU, OP_DIV, OP_DIVU, OP_REM, OP_REMU};
+        r.op = m[f3];
+      }
+      break;
+    case 0x0f: r.op = OP_FENCE; break;
+    case 0x73:
+      if (w == 0x00000073) r.op = OP_ECALL;
+      else if (w == 0xc0001073) r.op = OP_UNIMP;
+      break;
+  }
+  return r;
+}
+
+const char* op_name(int op) {
+  static const char* n[OP_COUNT] = {
+      "invalid", "lui", "auipc", "jal", "jalr", "beq", "bne", "blt", "bge", "bltu", "bgeu",
+      "lb", "lh", "lw", "lbu", "lhu", "sb", "sh", "sw",
+      "addi", "slti", "sltiu", "xori", "ori", "andi", "slli", "srli", "srai",
+      "add", "sub", "sll", "slt", "sltu", "xor", "srl", "sra", "or", "and",
+      "mul", "mulh", "mulhsu", "mulhu", "div", "divu", "rem", "remu",
+      "ecall", "fence", "unimp"};
+  return (op >= 0 && op < OP_COUNT) ? n[op] : "?";
+}
+
+// ---------------------------------------------------------------------------
+// run loop
+// ---------------------------------------------------------------------------
+namespace {
+// Guest address space: SP1 caps guest memory at 0x78000000; map it lazily.
+constexpr uint64_t kMemBytes = 0x78000000ull;
+
+struct Memory {
+  uint8_t* base = nullptr;
+  Memory() {
+    void* p = mmap(nullptr, kMemBytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    base = (p == MAP_FAILED) ? nullptr : (uint8_t*)p;
+  }
+  ~Memory() {
+    if (base) munmap(base, kMemBytes);
+  }
+};
+}  // namespace
+
+ExecutionRecord execute(const ElfImage& elf, const std::vector<std::vector<uint8_t>>& stdin_entries,
+                        const ExecOptions& opt) {
+  ExecutionRecord rec;
+  if (opt.want_hist) rec.opcode_hist.assign(OP_COUNT, 0);
+  Memory mem;
+  if (!mem.base) {
+    rec.error = "mmap of guest memory failed";
+    return rec;
+  }
+  uint8_t* M = mem.base;
+  for (const auto& s : elf.segs) {
+    if ((uint64_t)s.vaddr + s.memsz > kMemBytes) {
+      rec.error = "segment beyond guest memory";
+      return rec;
+    }
+    memcpy(M + s.vaddr, s.bytes.data(), s.bytes.size());
+  }
+  std::vector<Decoded> code(elf.text.size());
+  for (size_t i = 0; i < elf.text.size(); ++i) code[i] = decode(elf.text[i]);
+  const uint32_t text_lo = elf.text_base, text_hi = elf.text_base + 4 * (uint32_t)elf.text.size();
+
+  // mark keccakf entry points in a side table for O(1) checks
+  std::vector<uint8_t> is_keccak;
+  if (opt.keccak_mode != KeccakMode::kSoftware && !elf.keccakf_entries.empty()) {
+    is_keccak.assign(elf.text.size(), 0);
+    for (uint32_t e : elf.keccakf_entries)
+      if (e >= text_lo && e < text_hi) is_keccak[(e - text_lo) >> 2] = 1;
+  }
+
+  uint32_t x[32] = {0};
+  uint32_t pc = elf.entry;
+  size_t stdin_pos = 0;
+  uint64_t cycles = 0, memops = 0;
+  const uint64_t max_cycles = opt.max_cycles;
+
+#define FAULT(msg)          \
+  do {                      \
+    rec.error = (msg);      \
+    goto done;              \
+  } while (0)
+#define CHECK_ADDR(a, n) \
+  if ((uint64_t)(a) + (n) > kMemBytes) FAULT("memory access out of range")
+
+  for (;;) {
+    if (pc < text_lo || pc >= text_hi || (pc & 3)) FAULT("pc outside text segment");
+    size_t idx = (pc - text_lo) >> 2;
+    if (!is_keccak.empty() && is_keccak[idx]) {
+      uint32_t ptr = x[10];
+      if (ptr & 7) FAULT("keccakf state pointer not 8-byte aligned");
+      CHECK_ADDR(ptr, 200);
+      KeccakEvent ev;
+      memcpy(ev.state_in, M + ptr, 200);
+      ev.state_ptr = ptr;
+      ev.cycle = cycles;
+      rec.keccak_events.push_back(ev);
+      if (opt.keccak_mode == KeccakMode::kReplace) {
+        uint64_t st[25];
+        memcpy(st, ev.state_in, 200);
+        keccak_f1600(st);
+        memcpy(M + ptr, st, 200);
+        pc = x[1];  // return to caller; counts as one cycle (the precompile ecall)
+        ++cycles;
+        continue;
+      }
+    }
+    const Decoded& in = code[idx];
+    if (cycles >= max_cycles) FAULT("cycle limit exceeded");
+    ++cycles;
+    if (opt.want_hist) rec.opcode_hist[in.op]++;
+    uint32_t a = x[in.rs1], b = x[in.rs2];
+    uint32_t next = pc + 4;
+    uint32_t res = 0;
+    bool wr = true;
+    switch (in.op) {
+      case OP_LUI: res = (uint32_t)in.imm; break;
+      case OP_AUIPC: res = pc + (uint32_t)in.imm; break;
+      case OP_JAL: res = pc + 4; next = pc + (uint32_t)in.imm; break;
+      case OP_JALR: res = pc + 4; next = (a + (uint32_t)in.imm) & ~1u; break;
+      case OP_BEQ: wr = false; if (a == b) next = pc + (uint32_t)in.imm; break;
+      case OP_BNE: wr = false; if (a != b) next = pc + (uint32_t)in.imm; break;
+      case OP_BLT: wr = false; if ((int32_t)a < (int32_t)b) next = pc + (uint32_t)in.imm; break;
+      case OP_BGE: wr = false; if ((int32_t)a >= (int32_t)b) next = pc + (uint32_t)in.imm; break;
+      case OP_BLTU: wr = false; if (a < b) next = pc + (uint32_t)in.imm; break;
+      case OP_BGEU: wr = false; if (a >= b) next = pc + (uint32_t)in.imm; break;
+      case OP_LB: { uint32_t ad = a + (uint32_t)in.imm; CHECK_ADDR(ad, 1); res = (uint32_t)(int32_t)(int8_t)M[ad]; ++memops; break; }
+      case OP_LBU: { uint32_t ad = a + (uint32_t)in.imm; CHECK_ADDR(ad, 1); res = M[ad]; ++memops; break; }
+      case OP_LH: { uint32_t ad = a + (uint32_t)in.imm; if (ad & 1) FAULT("unaligned lh"); CHECK_ADDR(ad, 2); uint16_t v; memcpy(&v, M + ad, 2); res = (uint32_t)(int32_t)(int16_t)v; ++memops; break; }
+      case OP_LHU: { uint32_t ad = a + (uint32_t)in.imm; if (ad & 1) FAULT("unaligned lhu"); CHECK_ADDR(ad, 2); uint16_t v; memcpy(&v, M + ad, 2); res = v; ++memops; break; }
+      case OP_LW: { uint32_t ad = a + (uint32_t)in.imm; if (ad & 3) FAULT("unaligned lw"); CHECK_ADDR(ad, 4); memcpy(&res, M + ad, 4); ++memops; break; }
+      case OP_SB: { wr = false; uint32_t ad = a + (uint32_t)in.imm; CHECK_ADDR(ad, 1); M[ad] = (uint8_t)b; ++memops; break; }
+      case OP_SH: { wr = false; uint32_t ad = a + (uint32_t)in.imm; if (ad & 1) FAULT("unaligned sh"); CHECK_ADDR(ad, 2); uint16_t v = (uint16_t)b; memcpy(M + ad, &v, 2); ++memops; break; }
+      case OP_SW: { wr = false; uint32_t ad = a + (uint32_t)in.imm; if (ad & 3) FAULT("unaligned sw"); CHECK_ADDR(ad, 4); memcpy(M + ad, &b, 4); ++memops; break; }
+      case OP_ADDI: res = a + (uint32_t)in.imm; break;
+      case OP_SLTI: res = (int32_t)a < in.imm; break;
+      case OP_SLTIU: res = a < (uint32_t)in.imm; break;
+      case OP_XORI: res = a ^ (uint32_t)in.imm; break;
+      case OP_ORI: res = a | (uint32_t)in.imm; break;
+      case OP_ANDI: res = a & (uint32_t)in.imm; break;
+      case OP_SLLI: res = a << in.imm; break;
+      case OP_SRLI: res = a >> in.imm; break;
+      case OP_SRAI: res = (uint32_t)((int32_t)a >> in.imm); break;
+      case OP_ADD: res = a + b; break;
+      case OP_SUB: res = a - b; break;
+      case OP_SLL: res = a << (b & 31); break;
+      case OP_SLT: res = (int32_t)a < (int32_t)b; break;
+      case OP_SLTU: res = a < b; break;
+      case OP_XOR: res = a ^ b; break;
+      case OP_SRL: res = a >> (b & 31); break;
+      case OP_SRA: res = (uint32_t)((int32_t)a >> (b & 31)); break;
+      case OP_OR: res = a | b; break;
+      case OP_AND: res = a & b; break;
+      case OP_MUL: res = a * b; break;
+      case OP_MULH: res = (uint32_t)(((int64_t)(int32_t)a * (int64_t)(int32_t)b) >> 32); break;
+      case OP_MULHSU: res = (uint32_t)(((int64_t)(int32_t)a * (int64_t)(uint64_t)b) >> 32); break;
+      case OP_MULHU: res = (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); break;
+      case OP_DIV:
+        if (b == 0) res = 0xffffffffu;
+        else if (a == 0x80000000u && b == 0xffffffffu) res = a;
+        else res = (uint32_t)((int32_t)a / (int32_t)b);
+        break;
+      case OP_DIVU: res = b ? a / b : 0xffffffffu; break;
+      case OP_REM:
+        if (b == 0) res = a;
+        else if (a == 0x80000000u && b == 0xffffffffu) res = 0;
+        else res = (uint32_t)((int32_t)a % (int32_t)b);
+        break;
+      case OP_REMU: res = b ? a % b : a; break;
+      case OP_FENCE: wr = false; break;
+      case OP_ECALL: {
+        wr = false;
+        uint32_t codeid = x[5], a0 = x[10], a1 = x[11], a2 = x[12];
+        rec.syscall_counts[codeid & 0xff]++;
+        switch (codeid) {
+          case 0x00:  // HALT
+            rec.exit_code = a0;
+            rec.halted = true;
+            goto done;
+          case 0x02: {  // WRITE
+            CHECK_ADDR(a1, a2);
+            const char* p = (const char*)(M + a1);
+            if (a0 == 1) rec.stdout_text.append(p, a2);
+            else if (a0 == 2) rec.stderr_text.append(p, a2);
+            else if (a0 == 3) rec.public_values.insert(rec.public_values.end(), M + a1, M + a1 + a2);
+            else if (a0 == 4) { /* hint-stream write: not used by this guest */ }
+            else FAULT("WRITE to unsupported fd");
+            break;
+          }
+          case 0x10:  // COMMIT
+            if (a0 >= 8) FAULT("COMMIT word index out of range");
+            rec.pv_digest[a0] = a1;
+            break;
+          case 0x1a:  // COMMIT_DEFERRED_PROOFS
+            if (a0 >= 8) FAULT("COMMIT_DEFERRED word index out of range");
+            rec.deferred_digest[a0] = a1;
+            break;
+          case 0xf0:  // HINT_LEN
+            if (stdin_pos >= stdin_entries.size()) FAULT("HINT_LEN: input stream exhausted");
+            x[5] = (uint32_t)stdin_entries[stdin_pos].size();
+            break;
+          case 0xf1: {  // HINT_READ
+            if (stdin_pos >= stdin_entries.size()) FAULT("HINT_READ: input stream exhausted");
+            const auto& e = stdin_entries[stdin_pos];
+            if (a1 != e.size()) FAULT("HINT_READ: length mismatch");
+            if (a0 & 3) FAULT("HINT_READ: unaligned pointer");
+            CHECK_ADDR(a0, (a1 + 3) & ~3u);
+            memcpy(M + a0, e.data(), e.size());
+            ++stdin_pos;
+            break;
+          }
+          default:
+            FAULT("unsupported syscall code");
+        }
+        break;
+      }
+      case OP_UNIMP: FAULT("unimp executed");
+      default: FAULT("illegal instruction");
+    }
+    if (wr && in.rd) x[in.rd] = res;
+    pc = next;
+  }
+done:
+#undef FAULT
+#undef CHECK_ADDR
+  rec.cycles = cycles;
+  rec.memory_ops = memops;
+  return rec;
+}
+
+}  // namespace zksp
