@@ -1,0 +1,177 @@
+/* zksp.h -- C ABI of the MI355X-native STARK prover for the reference's
+ * sp1-merkle-proof guest.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * This is the drop-in boundary of SURVEY.md section 8b.  Each entry point names the
+ * call of the reference's SP1 flow it replaces (reference prover/src/bin/main.rs,
+ * test_generate_ethereum_transaction_zk_proof_sp1, lines 59-87).  The reference
+ * binds sp1-sdk 3.4.0 (prover/Cargo.toml:12) at exactly these calls; a maintainer
+ * switching backends binds these symbols instead (INTEGRATION.md shows the stub).
+ *
+ * Conventions: every function returns 0 on success or a ZKSP_ERR_* code; nothing
+ * aborts or throws across the boundary; the caller owns every returned handle and
+ * frees it with the matching *_free; byte pointers returned by accessors borrow
+ * from their handle.  A client is bound to one GPU and one HIP stream and is not
+ * re-entrant; use one client per GPU.
+ */
+#ifndef ZKSP_H
+#define ZKSP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKSP_OK 0
+#define ZKSP_ERR_INVALID_ARG 1
+#define ZKSP_ERR_NO_DEVICE 2      /* HIP backend requested but no usable GPU */
+#define ZKSP_ERR_HIP 3            /* a HIP runtime call failed */
+#define ZKSP_ERR_ELF 4            /* setup(): not a loadable RV32IM ELF */
+#define ZKSP_ERR_EXECUTOR 5       /* executor fault (illegal instruction, bad syscall ...) */
+#define ZKSP_ERR_GUEST_PANIC 6    /* guest exited with a non-zero code (reference: panic) */
+#define ZKSP_ERR_PROOF_FORMAT 7   /* deserialize(): malformed proof bytes */
+#define ZKSP_ERR_VERIFY 8         /* verify(): proof rejected */
+#define ZKSP_ERR_UNSUPPORTED 9
+
+typedef struct zksp_client zksp_client;
+typedef struct zksp_pk zksp_pk;
+typedef struct zksp_vk zksp_vk;
+typedef struct zksp_stdin zksp_stdin;
+typedef struct zksp_proof zksp_proof;
+
+/* keccak handling inside the executor (SURVEY.md section 0 finding 4 / section 7):
+ * the committed guest runs software keccak-f; the prover needs the permutation
+ * events either way. */
+#define ZKSP_KECCAK_OBSERVE 1 /* run the guest's own keccakf, record its inputs (as-committed cycle counts) */
+#define ZKSP_KECCAK_REPLACE 2 /* intercept keccakf as a precompile call (intended configuration) */
+
+typedef struct {
+  int32_t device_ordinal; /* HIP device index; -1 = verifier/executor only (no GPU touched) */
+  int32_t keccak_mode;    /* ZKSP_KECCAK_*; 0 = default (REPLACE) */
+  uint32_t num_queries;   /* FRI queries; 0 = default 100 */
+  uint32_t pow_bits;      /* proof-of-work bits; 0xffffffff = default 16 */
+  uint32_t max_batch;     /* proofs proven in lockstep per launch group; 0 = default 16 */
+} zksp_options;
+
+/* replaces ProverClient::new()  (main.rs:61).  Fails with ZKSP_ERR_NO_DEVICE when
+ * device_ordinal >= 0 and no GPU is usable: there is no CPU proving fallback. */
+int zksp_client_new(const zksp_options* opts, zksp_client** out);
+void zksp_client_free(zksp_client* c);
+/* last error text of this client ("" if none); never NULL */
+const char* zksp_last_error(const zksp_client* c);
+
+/* replaces client.setup(MERKLE_ELF) -> (pk, vk)  (main.rs:70) */
+int zksp_setup(zksp_client* c, const uint8_t* elf, size_t elf_len, zksp_pk** pk, zksp_vk** vk);
+void zksp_pk_free(zksp_pk* pk);
+void zksp_vk_free(zksp_vk* vk);
+/* 32-byte verifying-key digest (8 little-endian u32 field elements) */
+int zksp_vk_digest(const zksp_vk* vk, const uint8_t** ptr, size_t* len);
+
+/* replaces SP1Stdin::new() / stdin.write(&Vec<u8>)  (main.rs:62, :69).
+ * write() applies the bincode Vec<u8> framing (u64-LE length prefix). */
+zksp_stdin* zksp_stdin_new(void);
+int zksp_stdin_write(zksp_stdin* s, const uint8_t* buf, size_t len);
+void zksp_stdin_free(zksp_stdin* s);
+
+/* replaces client.prove(&pk, stdin).run()  (main.rs:71-74).  `stdin` is consumed
+ * (emptied) as in the reference; pk is borrowed.  A guest panic (reference:
+ * `.expect("Failed to verify Merkle Proof")`, crypto-ops/src/lib.rs:20-22) returns
+ * ZKSP_ERR_GUEST_PANIC with the guest's stderr text in zksp_last_error(). */
+int zksp_prove(zksp_client* c, const zksp_pk* pk, zksp_stdin* stdin_, zksp_proof** out);
+/* n independent proofs proven in lockstep on this client's GPU (throughput path of
+ * BASELINE configs 3-5).  out[i] is NULL and status[i] != 0 for failed inputs. */
+int zksp_prove_batch(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdins, size_t n, zksp_proof** out,
+                     int32_t* status);
+
+/* replaces proof.public_values.to_vec()  (main.rs:75) */
+int zksp_proof_public_values(const zksp_proof* p, const uint8_t** ptr, size_t* len);
+int zksp_proof_serialize(const zksp_proof* p, const uint8_t** ptr, size_t* len);
+int zksp_proof_deserialize(const uint8_t* buf, size_t len, zksp_proof** out);
+void zksp_proof_free(zksp_proof* p);
+
+/* replaces client.verify(&proof, &vk)  (main.rs:80).  Host-only; needs no GPU. */
+int zksp_verify(zksp_client* c, const zksp_proof* p, const zksp_vk* vk);
+
+/* ---- executor report (row a2; acceptance values in SURVEY.md appendix A.4) ---- */
+typedef struct {
+  uint64_t cycles;
+  uint64_t memory_ops;
+  uint32_t exit_code;
+  uint32_t n_keccak;
+  uint32_t pv_len;
+  uint32_t pv_digest[8];
+  uint64_t syscalls[6]; /* HALT, WRITE, COMMIT, COMMIT_DEFERRED, HINT_LEN, HINT_READ */
+  uint64_t opcode_hist[64];
+} zksp_exec_report;
+/* Runs the guest only.  keccak_mode: 0 software, 1 observe, 2 replace.  Does not
+ * consume stdin.  public_values (optional) receives up to pv_cap bytes; stderr_buf
+ * (optional) the guest's fd-2 text, NUL terminated. */
+int zksp_execute(zksp_client* c, const zksp_pk* pk, const zksp_stdin* stdin_, int keccak_mode, zksp_exec_report* report,
+                 uint8_t* public_values, size_t pv_cap, char* stderr_buf, size_t stderr_cap);
+const char* zksp_opcode_name(int index);
+
+/* ---- device-resident hot path (bench.py, parity tests) ---- */
+/* Proof-system parameters this build uses (for sizing buffers). */
+typedef struct {
+  uint32_t trace_width;       /* 2633 */
+  uint32_t num_constraints;   /* 3182 */
+  uint32_t num_queries;
+  uint32_t pow_bits;
+  uint32_t max_batch;
+} zksp_params;
+int zksp_get_params(const zksp_client* c, zksp_params* out);
+size_t zksp_proof_body_words(const zksp_client* c, int log_h);
+
+/* Uploads a batch of keccak-f permutation inputs and transcript headers into the
+ * client's HBM workspace: states [n][max_perms][25] u64 (row-major), n_perms [n],
+ * init_obs [n][44] canonical u32 (vk digest, log_h, n_perms, exit code halves,
+ * pv-digest halves, deferred-digest halves).  After this call the inputs are
+ * resident; zksp_hip_prove_resident() can be timed on its own. */
+int zksp_hip_load_batch(zksp_client* c, int log_h, size_t n, size_t max_perms, const uint64_t* states,
+                        const uint32_t* n_perms, const uint32_t* init_obs);
+/* Enqueues one full proving pass over the resident batch on the client's stream
+ * (trace generation -> proof bodies in HBM).  Asynchronous. */
+int zksp_hip_prove_resident(zksp_client* c);
+/* Copies proof bodies [n][body_words] (canonical u32) to the host; synchronises. */
+int zksp_hip_fetch_bodies(zksp_client* c, uint32_t* out, size_t cap_words);
+int zksp_hip_sync(zksp_client* c);
+/* HIP-event timing on the client's own stream. */
+int zksp_hip_timer_start(zksp_client* c);
+int zksp_hip_timer_stop(zksp_client* c, float* ms); /* synchronises */
+/* Per-kernel HIP-event profile of zksp_hip_prove_resident (enable, run, read). */
+int zksp_hip_profile_enable(zksp_client* c, int on);
+int zksp_hip_profile_read(zksp_client* c, const char* kernel, double* total_ms, uint64_t* launches);
+int zksp_hip_profile_reset(zksp_client* c);
+
+/* ---- kernel-level entry points (parity tests; device pointers from
+ * zksp_dev_malloc or any HIP allocation; field elements are Montgomery
+ * residues x*2^32 mod p) ---- */
+int zksp_dev_malloc(zksp_client* c, size_t bytes, void** out);
+int zksp_dev_free(zksp_client* c, void* p);
+int zksp_dev_upload(zksp_client* c, void* dst, const void* src, size_t bytes);
+int zksp_dev_download(zksp_client* c, void* dst, const void* src, size_t bytes);
+int zksp_dev_memset(zksp_client* c, void* dst, int value, size_t bytes);
+
+/* row a4: in [ncols][H] evaluations over in_shift*K_H (in_shift canonical) ->
+ * coefs_br [ncols][H] (optional, bit-reversed order) and lde [ncols][2][H] */
+int zksp_hip_lde(zksp_client* c, const uint32_t* d_in, int log_h, size_t ncols, uint32_t in_shift, uint32_t* d_coefs_br,
+                 uint32_t* d_lde);
+/* row a5: mat [width][2^log_n] column-major -> tree [(2^(log_n+1)-1)][8] */
+int zksp_hip_merkle_commit(zksp_client* c, const uint32_t* d_mat, int width, int log_n, uint32_t* d_tree);
+int zksp_hip_poseidon2_permute(zksp_client* c, uint32_t* d_states, size_t n);
+/* row a3: states [n_perms][25] u64 -> trace [2633][2^log_h] */
+int zksp_hip_keccak_trace(zksp_client* c, const uint64_t* d_states, uint32_t n_perms, int log_h, uint32_t* d_trace);
+/* row a6: lde [2633][2][H], alpha (4 canonical words) -> quotient values [8][H] */
+int zksp_hip_keccak_quotient(zksp_client* c, const uint32_t* d_lde, int log_h, const uint32_t* alpha,
+                             uint32_t* d_quot);
+/* row a7: one FRI fold of layer [2][Hk][4] with challenge beta (canonical) */
+int zksp_hip_fri_fold(zksp_client* c, const uint32_t* d_in, int log_hk, uint32_t shift_k, const uint32_t* beta,
+                      uint32_t* d_out);
+/* instruction-rate probe used by DESIGN.md's ALU roofline (which: 0 add, 1 mul_lo,
+ * 2 mul_hi, 3 mad_u64_u32, 4 montgomery mul, 5 f64 fma) -> giga wave-instr lanes/s */
+int zksp_hip_microbench(zksp_client* c, int which, double* gops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

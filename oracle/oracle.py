@@ -1,0 +1,319 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+ctypes front-end to ``oracle/_build/libzksp_oracle.so`` (the plain-C CPU
+restatement, see ``zksp_oracle.h``) plus a direct restatement of the reference's
+``crypto_ops::verify_merkle_proof`` (reference crypto-ops/src/lib.rs:8-23).
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg
+may import this module; the product path never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libzksp_oracle.so")
+
+P = 2013265921
+KA_WIDTH = 2633
+KA_NUM_CONSTRAINTS = 3182
+
+
+def build(force: bool = False) -> str:
+    srcs = ["poseidon2.c", "ntt.c", "keccak_air.c", "prover.c", "field.h", "zksp_oracle.h"]
+    stale = force or not os.path.exists(_SO) or any(
+        os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(_SO) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib: Optional[C.CDLL] = None
+
+
+class Header(C.Structure):
+    _fields_ = [("log_h", C.c_uint32), ("n_perms", C.c_uint32), ("exit_code", C.c_uint32), ("pv_len", C.c_uint32),
+                ("pv_digest", C.c_uint32 * 8), ("deferred_digest", C.c_uint32 * 8), ("vk_digest", C.c_uint32 * 8)]
+
+
+class Config(C.Structure):
+    _fields_ = [("num_queries", C.c_uint32), ("pow_bits", C.c_uint32)]
+
+
+class Challenger(C.Structure):
+    _fields_ = [("state", C.c_uint32 * 16), ("inbuf", C.c_uint32 * 8), ("n_in", C.c_int),
+                ("outbuf", C.c_uint32 * 8), ("n_out", C.c_int)]
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_proof_size.restype = C.c_size_t
+        _lib.orc_merkle_layer_offset.restype = C.c_size_t
+        _lib.orc_ch_sample.restype = C.c_uint32
+        _lib.orc_ch_sample_bits.restype = C.c_uint32
+        _lib.orc_ch_grind.restype = C.c_uint32
+    return _lib
+
+
+def _u32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def poseidon2_constants() -> Tuple[np.ndarray, np.ndarray]:
+    ext = np.zeros(128, np.uint32)
+    inn = np.zeros(13, np.uint32)
+    lib().orc_poseidon2_constants(_p(ext), _p(inn))
+    return ext.reshape(8, 16), inn
+
+
+def poseidon2_permute(state: Sequence[int]) -> np.ndarray:
+    s = _u32(state).copy()
+    assert s.shape == (16,)
+    lib().orc_poseidon2_permute(_p(s))
+    return s
+
+
+def hash_elems(v: Sequence[int]) -> np.ndarray:
+    a = _u32(v)
+    out = np.zeros(8, np.uint32)
+    lib().orc_hash_elems(_p(a), C.c_size_t(a.size), _p(out))
+    return out
+
+
+def compress(l: Sequence[int], r: Sequence[int]) -> np.ndarray:
+    out = np.zeros(8, np.uint32)
+    la, ra = _u32(l), _u32(r)
+    lib().orc_compress(_p(la), _p(ra), _p(out))
+    return out
+
+
+def ntt(a: np.ndarray, inverse: bool = False) -> np.ndarray:
+    a = _u32(a).copy()
+    logn = int(a.size).bit_length() - 1
+    assert a.size == 1 << logn
+    lib().orc_ntt(_p(a), logn, int(inverse))
+    return a
+
+
+def dft_naive(a: np.ndarray) -> np.ndarray:
+    a = _u32(a)
+    logn = int(a.size).bit_length() - 1
+    out = np.zeros_like(a)
+    lib().orc_dft_naive(_p(a), _p(out), logn)
+    return out
+
+
+def coset_lde(cols: np.ndarray, in_shift: int = 1, want_coefs: bool = False):
+    """cols: [ncols][H] -> lde [ncols][2][H] (and coefs [ncols][H])."""
+    cols = _u32(cols)
+    ncols, h = cols.shape
+    logh = h.bit_length() - 1
+    out = np.zeros((ncols, 2, h), np.uint32)
+    coefs = np.zeros((ncols, h), np.uint32) if want_coefs else None
+    lib().orc_coset_lde(_p(cols), logh, ncols, C.c_uint32(in_shift), _p(out), _p(coefs) if want_coefs else None)
+    return (out, coefs) if want_coefs else out
+
+
+def merkle_commit(mat: np.ndarray) -> np.ndarray:
+    """mat: column-major [W][N] -> tree digests [(2N-1)][8], leaves first, root last."""
+    mat = _u32(mat)
+    w, n = mat.shape
+    logn = n.bit_length() - 1
+    tree = np.zeros((2 * n - 1, 8), np.uint32)
+    lib().orc_merkle_commit(_p(mat), w, logn, _p(tree))
+    return tree
+
+
+def merkle_layer_offset(logn: int, layer: int) -> int:
+    return int(lib().orc_merkle_layer_offset(logn, layer))
+
+
+def keccak_f(state: Sequence[int]) -> np.ndarray:
+    s = np.ascontiguousarray(state, dtype=np.uint64).copy()
+    lib().orc_keccak_f(_p(s))
+    return s
+
+
+def keccak_trace(states_in: np.ndarray, logh: int) -> np.ndarray:
+    st = np.ascontiguousarray(states_in, dtype=np.uint64).reshape(-1, 25)
+    trace = np.zeros((KA_WIDTH, 1 << logh), np.uint32)
+    lib().orc_keccak_trace(_p(st), int(st.shape[0]), logh, _p(trace))
+    return trace
+
+
+def keccak_constraints(local: np.ndarray, nxt: np.ndarray, is_first: int, is_last: int, is_trans: int) -> np.ndarray:
+    out = np.zeros(KA_NUM_CONSTRAINTS, np.uint32)
+    l, n = _u32(local), _u32(nxt)
+    lib().orc_keccak_constraints(_p(l), _p(n), C.c_uint32(is_first), C.c_uint32(is_last), C.c_uint32(is_trans), _p(out))
+    return out
+
+
+def keccak_quotient(lde: np.ndarray, alpha: Sequence[int]) -> np.ndarray:
+    lde = _u32(lde)
+    w, two, h = lde.shape
+    assert w == KA_WIDTH and two == 2
+    logh = h.bit_length() - 1
+    a = _u32(alpha)
+    out = np.zeros((8, h), np.uint32)
+    lib().orc_keccak_quotient(_p(lde), logh, _p(a), _p(out))
+    return out
+
+
+def fri_fold(layer: np.ndarray, shift_k: int, beta: Sequence[int]) -> np.ndarray:
+    """layer: [2][Hk][4] -> [2][Hk/2][4]."""
+    layer = _u32(layer)
+    _, hk, _ = layer.shape
+    loghk = hk.bit_length() - 1
+    b = _u32(beta)
+    out = np.zeros((2, hk // 2, 4), np.uint32)
+    lib().orc_fri_fold(_p(layer), loghk, C.c_uint32(shift_k), _p(b), _p(out))
+    return out
+
+
+class OracleChallenger:
+    def __init__(self):
+        self.c = Challenger()
+        lib().orc_ch_init(C.byref(self.c))
+
+    def observe(self, xs):
+        for x in np.atleast_1d(_u32(xs)):
+            lib().orc_ch_observe(C.byref(self.c), C.c_uint32(int(x)))
+
+    def sample(self) -> int:
+        return int(lib().orc_ch_sample(C.byref(self.c)))
+
+    def sample_ext(self) -> List[int]:
+        return [self.sample() for _ in range(4)]
+
+    def sample_bits(self, bits: int) -> int:
+        return int(lib().orc_ch_sample_bits(C.byref(self.c), bits))
+
+    def grind(self, bits: int) -> int:
+        return int(lib().orc_ch_grind(C.byref(self.c), bits))
+
+
+def proof_size(logh: int, num_queries: int, pow_bits: int, pv_len: int) -> int:
+    cfg = Config(num_queries, pow_bits)
+    return int(lib().orc_proof_size(logh, C.byref(cfg), C.c_uint32(pv_len)))
+
+
+def prove(states_in: np.ndarray, logh: int, *, exit_code: int = 0, public_values: bytes = b"",
+          pv_digest: Sequence[int] = (0,) * 8, deferred_digest: Sequence[int] = (0,) * 8,
+          vk_digest: Sequence[int] = (0,) * 8, num_queries: int = 100, pow_bits: int = 16) -> bytes:
+    st = np.ascontiguousarray(states_in, dtype=np.uint64).reshape(-1, 25)
+    hdr = Header(logh, int(st.shape[0]), exit_code, len(public_values),
+                 (C.c_uint32 * 8)(*pv_digest), (C.c_uint32 * 8)(*deferred_digest), (C.c_uint32 * 8)(*vk_digest))
+    cfg = Config(num_queries, pow_bits)
+    cap = proof_size(logh, num_queries, pow_bits, len(public_values))
+    buf = (C.c_uint8 * cap)()
+    n = C.c_size_t(0)
+    pv = (C.c_uint8 * max(1, len(public_values))).from_buffer_copy(public_values or b"\0")
+    rc = lib().orc_prove(_p(st), C.byref(hdr), pv, C.byref(cfg), buf, C.c_size_t(cap), C.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"orc_prove failed rc={rc}")
+    return bytes(buf[: n.value])
+
+
+# ---------------------------------------------------------------------------
+# verify_merkle_proof restated (reference crypto-ops/src/lib.rs:8-23):
+# hash every node, require the root node to hash to root_hash, walk the key.
+# Raises on the same three conditions the reference panics on.
+# ---------------------------------------------------------------------------
+def _keccak256(data: bytes) -> bytes:
+    rate = 136
+    msg = bytearray(data)
+    msg.append(0x01)
+    while len(msg) % rate:
+        msg.append(0)
+    msg[-1] |= 0x80
+    st = np.zeros(25, np.uint64)
+    for off in range(0, len(msg), rate):
+        blk = np.frombuffer(bytes(msg[off:off + rate]), dtype="<u8")
+        st[:17] ^= blk
+        st = keccak_f(st)
+    return st[:4].astype("<u8").tobytes()
+
+
+def _rlp_decode(buf: bytes, off: int = 0):
+    b0 = buf[off]
+    if b0 < 0x80:
+        return buf[off:off + 1], off + 1
+    if b0 < 0xB8:
+        n = b0 - 0x80
+        return buf[off + 1:off + 1 + n], off + 1 + n
+    if b0 < 0xC0:
+        ll = b0 - 0xB7
+        n = int.from_bytes(buf[off + 1:off + 1 + ll], "big")
+        return buf[off + 1 + ll:off + 1 + ll + n], off + 1 + ll + n
+    if b0 < 0xF8:
+        n, start = b0 - 0xC0, off + 1
+    else:
+        ll = b0 - 0xF7
+        n = int.from_bytes(buf[off + 1:off + 1 + ll], "big")
+        start = off + 1 + ll
+    items, p = [], start
+    while p < start + n:
+        it, p2 = _rlp_decode(buf, p)
+        # keep raw encoding for embedded (inline) nodes
+        items.append((it, buf[p:p2]))
+        p = p2
+    return items, start + n
+
+
+def verify_merkle_proof(root_hash: bytes, proof: Sequence[bytes], key: bytes) -> bytes:
+    db = {_keccak256(n): n for n in proof}
+    if root_hash not in db:
+        raise ValueError("Invalid merkle proof")  # EthTrie::from / root_hash assert
+    nib = []
+    for b in key:
+        nib += [b >> 4, b & 15]
+    node = db[root_hash]
+    pos = 0
+    while True:
+        items, _ = _rlp_decode(node)
+        if not isinstance(items, list):
+            raise ValueError("Failed to verify Merkle Proof: InvalidProof")
+        if len(items) == 17:
+            if pos == len(nib):
+                val = items[16][0]
+                if not val:
+                    raise KeyError("Key does not exist!")
+                return bytes(val)
+            child, raw = items[nib[pos]]
+            pos += 1
+        elif len(items) == 2:
+            path = items[0][0]
+            flag = path[0] >> 4
+            pn = ([path[0] & 15] if flag & 1 else []) + [x for b in path[1:] for x in (b >> 4, b & 15)]
+            if nib[pos:pos + len(pn)] != pn:
+                raise KeyError("Key does not exist!")
+            pos += len(pn)
+            if flag & 2:
+                if pos != len(nib):
+                    raise KeyError("Key does not exist!")
+                return bytes(items[1][0])
+            child, raw = items[1]
+        else:
+            raise ValueError("Failed to verify Merkle Proof: InvalidProof")
+        if isinstance(child, list):
+            node = raw  # inline node
+        elif len(child) == 32:
+            if bytes(child) not in db:
+                raise ValueError("Failed to verify Merkle Proof: InvalidProof")
+            node = db[bytes(child)]
+        elif len(child) == 0:
+            raise KeyError("Key does not exist!")
+        else:
+            raise ValueError("Failed to verify Merkle Proof: InvalidProof")

@@ -1,0 +1,76 @@
+"""In-tree build of ``libzksp.so`` (HIP kernels + C-ABI host code) for gfx950.
+
+``hipcc`` cross-compiles without a GPU, so this runs in the build container; the
+resulting shared object travels to the GPU box with the repository snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libzksp.so")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+SOURCES = [
+    "device/kernels_ntt.hip",
+    "device/kernels_hash.hip",
+    "device/kernels_stark.hip",
+    "device/kernels_bench.hip",
+    "host/executor.cpp",
+    "host/context.cpp",
+    "host/prover.cpp",
+    "host/verifier.cpp",
+    "host/api.cpp",
+]
+HEADERS = [
+    "device/field.cuh", "device/poseidon2.cuh", "device/air_keccak.cuh", "device/kernels.h",
+    "host/executor.hpp", "host/context.hpp", "host/prover.hpp", "host/verifier.hpp",
+]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.sep not in cand or os.path.exists(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _newest_header() -> float:
+    paths = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "zksp.h"), os.path.abspath(__file__)]
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def _compile(src: str, force: bool, hdr_time: float) -> str:
+    path = os.path.join(CSRC, src)
+    obj = os.path.join(OBJ, src.replace("/", "_") + ".o")
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time):
+        return obj
+    cmd = [_hipcc(), *FLAGS, "-I", INCLUDE]
+    if src.endswith(".cpp") and src != "host/executor.cpp":
+        cmd += ["-x", "hip"]  # host code that shares the __host__ __device__ field/AIR headers
+    cmd += ["-c", path, "-o", obj]
+    subprocess.check_call(cmd)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_time = _newest_header()
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force, hdr_time), SOURCES))
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

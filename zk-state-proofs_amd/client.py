@@ -1,0 +1,306 @@
+"""Host-side mirror of the reference's SP1 flow over the C-ABI (``include/zksp.h``).
+
+The class and method names follow what the reference's tests call
+(reference prover/src/bin/main.rs:59-87)::
+
+    client = ProverClient()                 # ProverClient::new()           :61
+    stdin = SP1Stdin(); stdin.write(buf)    # SP1Stdin::new() / write()     :62, :69
+    pk, vk = client.setup(MERKLE_ELF)       # client.setup(ELF)             :70
+    proof = client.prove(pk, stdin).run()   # client.prove(&pk, stdin).run():71-74
+    proof.public_values                     # proof.public_values.to_vec()  :75
+    client.verify(proof, vk)                # client.verify(&proof, &vk)    :80
+
+Errors follow the reference's behaviour: a guest panic (the ``expect`` sites of
+crypto-ops/src/lib.rs:14-22) surfaces as ``GuestPanic`` from ``run()``, a
+rejected proof as ``VerificationError``.  There is no CPU proving fallback: if
+the HIP library or a GPU is missing, construction/prove fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libzksp.so")
+
+OK = 0
+ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_ELF, ERR_EXECUTOR, ERR_GUEST_PANIC, ERR_PROOF_FORMAT, ERR_VERIFY, \
+    ERR_UNSUPPORTED = range(1, 10)
+KECCAK_SOFTWARE, KECCAK_OBSERVE, KECCAK_REPLACE = 0, 1, 2
+
+
+class ZkspError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"zksp error {code}: {msg}")
+        self.code = code
+
+
+class GuestPanic(ZkspError):
+    """The guest exited non-zero (reference: panic inside verify_merkle_proof)."""
+
+
+class VerificationError(ZkspError):
+    pass
+
+
+class Options(C.Structure):
+    _fields_ = [("device_ordinal", C.c_int32), ("keccak_mode", C.c_int32), ("num_queries", C.c_uint32),
+                ("pow_bits", C.c_uint32), ("max_batch", C.c_uint32)]
+
+
+class ExecReport(C.Structure):
+    _fields_ = [("cycles", C.c_uint64), ("memory_ops", C.c_uint64), ("exit_code", C.c_uint32),
+                ("n_keccak", C.c_uint32), ("pv_len", C.c_uint32), ("pv_digest", C.c_uint32 * 8),
+                ("syscalls", C.c_uint64 * 6), ("opcode_hist", C.c_uint64 * 64)]
+
+
+class Params(C.Structure):
+    _fields_ = [("trace_width", C.c_uint32), ("num_constraints", C.c_uint32), ("num_queries", C.c_uint32),
+                ("pow_bits", C.c_uint32), ("max_batch", C.c_uint32)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library() -> C.CDLL:
+    """Loads the in-tree HIP library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the proving path)")
+    lib = C.CDLL(_LIB_PATH)
+    vp, sz, u8p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint8)
+    lib.zksp_client_new.argtypes = [C.POINTER(Options), C.POINTER(vp)]
+    lib.zksp_client_free.argtypes = [vp]
+    lib.zksp_client_free.restype = None
+    lib.zksp_last_error.argtypes = [vp]
+    lib.zksp_last_error.restype = C.c_char_p
+    lib.zksp_setup.argtypes = [vp, C.c_char_p, sz, C.POINTER(vp), C.POINTER(vp)]
+    lib.zksp_pk_free.argtypes = [vp]
+    lib.zksp_pk_free.restype = None
+    lib.zksp_vk_free.argtypes = [vp]
+    lib.zksp_vk_free.restype = None
+    lib.zksp_vk_digest.argtypes = [vp, C.POINTER(u8p), C.POINTER(sz)]
+    lib.zksp_stdin_new.restype = vp
+    lib.zksp_stdin_write.argtypes = [vp, C.c_char_p, sz]
+    lib.zksp_stdin_free.argtypes = [vp]
+    lib.zksp_stdin_free.restype = None
+    lib.zksp_prove.argtypes = [vp, vp, vp, C.POINTER(vp)]
+    lib.zksp_prove_batch.argtypes = [vp, vp, C.POINTER(vp), sz, C.POINTER(vp), C.POINTER(C.c_int32)]
+    lib.zksp_proof_public_values.argtypes = [vp, C.POINTER(u8p), C.POINTER(sz)]
+    lib.zksp_proof_serialize.argtypes = [vp, C.POINTER(u8p), C.POINTER(sz)]
+    lib.zksp_proof_deserialize.argtypes = [C.c_char_p, sz, C.POINTER(vp)]
+    lib.zksp_proof_free.argtypes = [vp]
+    lib.zksp_proof_free.restype = None
+    lib.zksp_verify.argtypes = [vp, vp, vp]
+    lib.zksp_execute.argtypes = [vp, vp, vp, C.c_int, C.POINTER(ExecReport), C.c_void_p, sz, C.c_void_p, sz]
+    lib.zksp_opcode_name.argtypes = [C.c_int]
+    lib.zksp_opcode_name.restype = C.c_char_p
+    lib.zksp_get_params.argtypes = [vp, C.POINTER(Params)]
+    lib.zksp_proof_body_words.argtypes = [vp, C.c_int]
+    lib.zksp_proof_body_words.restype = sz
+    lib.zksp_hip_load_batch.argtypes = [vp, C.c_int, sz, sz, vp, vp, vp]
+    lib.zksp_hip_prove_resident.argtypes = [vp]
+    lib.zksp_hip_fetch_bodies.argtypes = [vp, vp, sz]
+    lib.zksp_hip_sync.argtypes = [vp]
+    lib.zksp_hip_timer_start.argtypes = [vp]
+    lib.zksp_hip_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.zksp_hip_profile_enable.argtypes = [vp, C.c_int]
+    lib.zksp_hip_profile_reset.argtypes = [vp]
+    lib.zksp_hip_profile_read.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    lib.zksp_dev_malloc.argtypes = [vp, sz, C.POINTER(vp)]
+    lib.zksp_dev_free.argtypes = [vp, vp]
+    lib.zksp_dev_upload.argtypes = [vp, vp, vp, sz]
+    lib.zksp_dev_download.argtypes = [vp, vp, vp, sz]
+    lib.zksp_dev_memset.argtypes = [vp, vp, C.c_int, sz]
+    lib.zksp_hip_lde.argtypes = [vp, vp, C.c_int, sz, C.c_uint32, vp, vp]
+    lib.zksp_hip_merkle_commit.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    lib.zksp_hip_poseidon2_permute.argtypes = [vp, vp, sz]
+    lib.zksp_hip_keccak_trace.argtypes = [vp, vp, C.c_uint32, C.c_int, vp]
+    lib.zksp_hip_keccak_quotient.argtypes = [vp, vp, C.c_int, vp, vp]
+    lib.zksp_hip_fri_fold.argtypes = [vp, vp, C.c_int, C.c_uint32, vp, vp]
+    lib.zksp_hip_microbench.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+    _lib = lib
+    return lib
+
+
+# every symbol include/zksp.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "zksp_client_new", "zksp_client_free", "zksp_last_error", "zksp_setup", "zksp_pk_free", "zksp_vk_free",
+    "zksp_vk_digest", "zksp_stdin_new", "zksp_stdin_write", "zksp_stdin_free", "zksp_prove", "zksp_prove_batch",
+    "zksp_proof_public_values", "zksp_proof_serialize", "zksp_proof_deserialize", "zksp_proof_free", "zksp_verify",
+    "zksp_execute", "zksp_opcode_name", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
+    "zksp_hip_prove_resident", "zksp_hip_fetch_bodies", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
+    "zksp_hip_profile_enable", "zksp_hip_profile_read", "zksp_hip_profile_reset", "zksp_dev_malloc", "zksp_dev_free",
+    "zksp_dev_upload", "zksp_dev_download", "zksp_dev_memset", "zksp_hip_lde", "zksp_hip_merkle_commit",
+    "zksp_hip_poseidon2_permute", "zksp_hip_keccak_trace", "zksp_hip_keccak_quotient", "zksp_hip_fri_fold",
+    "zksp_hip_microbench",
+]
+
+
+class SP1Stdin:
+    """``SP1Stdin`` (reference prover/src/bin/main.rs:62, :69)."""
+
+    def __init__(self):
+        self._lib = load_library()
+        self._h = C.c_void_p(self._lib.zksp_stdin_new())
+        if not self._h:
+            raise MemoryError("zksp_stdin_new")
+
+    def write(self, buf: bytes) -> None:
+        rc = self._lib.zksp_stdin_write(self._h, bytes(buf), len(buf))
+        if rc:
+            raise ZkspError(rc, "stdin.write")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.zksp_stdin_free(self._h)
+            self._h = None
+
+
+class _Handle:
+    def __init__(self, lib, h, free):
+        self._lib, self._h, self._free = lib, h, free
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._free(self._h)
+            self._h = None
+
+
+class ProvingKey(_Handle):
+    pass
+
+
+class VerifyingKey(_Handle):
+    @property
+    def digest(self) -> bytes:
+        p, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        self._lib.zksp_vk_digest(self._h, C.byref(p), C.byref(n))
+        return bytes(p[: n.value])
+
+
+class SP1ProofWithPublicValues(_Handle):
+    @property
+    def public_values(self) -> bytes:
+        p, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        rc = self._lib.zksp_proof_public_values(self._h, C.byref(p), C.byref(n))
+        if rc:
+            raise ZkspError(rc, "public_values")
+        return bytes(p[: n.value])
+
+    def to_bytes(self) -> bytes:
+        p, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        rc = self._lib.zksp_proof_serialize(self._h, C.byref(p), C.byref(n))
+        if rc:
+            raise ZkspError(rc, "serialize")
+        return C.string_at(p, n.value)
+
+    @staticmethod
+    def from_bytes(buf: bytes) -> "SP1ProofWithPublicValues":
+        lib = load_library()
+        h = C.c_void_p()
+        rc = lib.zksp_proof_deserialize(bytes(buf), len(buf), C.byref(h))
+        if rc:
+            raise ZkspError(rc, "malformed proof bytes")
+        return SP1ProofWithPublicValues(lib, h, lib.zksp_proof_free)
+
+
+class _ProveBuilder:
+    """What ``client.prove(&pk, stdin)`` returns; ``.run()`` does the work."""
+
+    def __init__(self, client: "ProverClient", pk: ProvingKey, stdin: SP1Stdin):
+        self._c, self._pk, self._stdin = client, pk, stdin
+
+    def run(self) -> SP1ProofWithPublicValues:
+        lib = self._c._lib
+        h = C.c_void_p()
+        rc = lib.zksp_prove(self._c._h, self._pk._h, self._stdin._h, C.byref(h))
+        if rc == ERR_GUEST_PANIC:
+            raise GuestPanic(rc, self._c.last_error())
+        if rc:
+            raise ZkspError(rc, self._c.last_error())
+        return SP1ProofWithPublicValues(lib, h, lib.zksp_proof_free)
+
+
+class ProverClient:
+    """``ProverClient`` (reference prover/src/bin/main.rs:61).
+
+    ``device`` is the HIP device ordinal; ``device=-1`` builds a verifier/executor-only
+    client that never touches a GPU (and cannot prove).  Environment override:
+    ``ZKSP_DEVICE``.
+    """
+
+    def __init__(self, device: Optional[int] = None, *, keccak_mode: int = KECCAK_REPLACE, num_queries: int = 100,
+                 pow_bits: int = 16, max_batch: int = 16):
+        self._lib = load_library()
+        if device is None:
+            device = int(os.environ.get("ZKSP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        opts = Options(device, keccak_mode, num_queries, pow_bits, max_batch)
+        self._h = C.c_void_p()
+        rc = self._lib.zksp_client_new(C.byref(opts), C.byref(self._h))
+        if rc:
+            raise ZkspError(rc, "client_new failed" + (": no usable GPU (the proving path has no CPU fallback)"
+                                                       if rc == ERR_NO_DEVICE else ""))
+        self.device = device
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.zksp_client_free(self._h)
+            self._h = None
+
+    def last_error(self) -> str:
+        return (self._lib.zksp_last_error(self._h) or b"").decode("utf-8", "replace")
+
+    def params(self) -> Params:
+        p = Params()
+        self._lib.zksp_get_params(self._h, C.byref(p))
+        return p
+
+    def setup(self, elf: bytes) -> Tuple[ProvingKey, VerifyingKey]:
+        pk, vk = C.c_void_p(), C.c_void_p()
+        rc = self._lib.zksp_setup(self._h, bytes(elf), len(elf), C.byref(pk), C.byref(vk))
+        if rc:
+            raise ZkspError(rc, self.last_error())
+        return ProvingKey(self._lib, pk, self._lib.zksp_pk_free), VerifyingKey(self._lib, vk, self._lib.zksp_vk_free)
+
+    def prove(self, pk: ProvingKey, stdin: SP1Stdin) -> _ProveBuilder:
+        return _ProveBuilder(self, pk, stdin)
+
+    def prove_batch(self, pk: ProvingKey, stdins: Sequence[SP1Stdin]):
+        """Independent proofs in lockstep; returns (proofs, status codes)."""
+        n = len(stdins)
+        arr = (C.c_void_p * n)(*[s._h for s in stdins])
+        out = (C.c_void_p * n)()
+        st = (C.c_int32 * n)()
+        rc = self._lib.zksp_prove_batch(self._h, pk._h, arr, n, out, st)
+        if rc:
+            raise ZkspError(rc, self.last_error())
+        proofs: List[Optional[SP1ProofWithPublicValues]] = []
+        for i in range(n):
+            proofs.append(SP1ProofWithPublicValues(self._lib, C.c_void_p(out[i]), self._lib.zksp_proof_free)
+                          if out[i] else None)
+        return proofs, list(st)
+
+    def verify(self, proof: SP1ProofWithPublicValues, vk: VerifyingKey) -> None:
+        rc = self._lib.zksp_verify(self._h, proof._h, vk._h)
+        if rc:
+            raise VerificationError(rc, self.last_error())
+
+    def execute(self, pk: ProvingKey, stdin: SP1Stdin, keccak_mode: int = KECCAK_OBSERVE):
+        """Runs the guest only; returns (ExecReport, public_values, stderr_text, rc)."""
+        rep = ExecReport()
+        pv = (C.c_uint8 * 65536)()
+        err = C.create_string_buffer(8192)
+        rc = self._lib.zksp_execute(self._h, pk._h, stdin._h, keccak_mode, C.byref(rep), pv, 65536, err, 8192)
+        return rep, bytes(pv[: rep.pv_len]), err.value.decode("utf-8", "replace"), rc
+
+    def opcode_histogram(self, rep: ExecReport) -> dict:
+        out = {}
+        for i in range(64):
+            if rep.opcode_hist[i]:
+                out[self._lib.zksp_opcode_name(i).decode()] = int(rep.opcode_hist[i])
+        return out

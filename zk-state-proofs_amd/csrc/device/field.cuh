@@ -1,0 +1,131 @@
+// BabyBear (p = 2^31 - 2^27 + 1) in Montgomery form (R = 2^32) and its quartic
+// binomial extension F_p[x]/(x^4 - 11).  Replaces p3-baby-bear / p3-field
+// 0.1.4-succinct (reference Cargo.lock:5157, :5239) on the device; shared with the
+// host verifier so both sides compute with one definition.
+//
+// All device buffers hold Montgomery residues in [0, p).  Canonical values only
+// exist at the boundary (proof bytes, public inputs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zksp {
+
+#define ZKSP_HD __host__ __device__ __forceinline__
+
+constexpr uint32_t kP = 0x78000001u;        // 2013265921
+constexpr uint32_t kMontyMu = 0x88000001u;  // p^-1 mod 2^32
+constexpr uint32_t kR1 = 0x0ffffffeu;       // 2^32 mod p  (Montgomery form of 1)
+constexpr uint32_t kR2 = 0x45dddde3u;       // 2^64 mod p
+constexpr uint32_t kGen = 31;               // multiplicative generator (canonical)
+constexpr uint32_t kExtW = 11;              // x^4 = 11
+constexpr uint32_t cmonty(uint32_t c) { return (uint32_t)((((uint64_t)c) << 32) % kP); }
+constexpr uint32_t kExtWMonty = cmonty(kExtW);
+constexpr uint32_t kFrobZMonty = cmonty(0x67055c21u);  // 11^((p-1)/4)
+
+struct Fp {
+  uint32_t v;  // Montgomery residue
+
+  ZKSP_HD static Fp raw(uint32_t m) { Fp r; r.v = m; return r; }
+  ZKSP_HD static Fp zero() { return raw(0); }
+  ZKSP_HD static Fp one() { return raw(kR1); }
+
+  // t < p * 2^32  ->  t * 2^-32 mod p
+  ZKSP_HD static uint32_t reduce(uint64_t t) {
+    uint32_t m = (uint32_t)t * kMontyMu;
+    uint32_t u = (uint32_t)(((uint64_t)m * kP) >> 32);
+    uint32_t hi = (uint32_t)(t >> 32);
+    uint32_t r = hi - u;
+    uint32_t r2 = r + kP;
+    return r < r2 ? r : r2;  // unsigned-min trick: picks r+p exactly when hi < u
+  }
+  ZKSP_HD static Fp from_canonical(uint32_t c) { return raw(reduce((uint64_t)c * kR2)); }
+  ZKSP_HD uint32_t to_canonical() const { return reduce((uint64_t)v); }
+
+  ZKSP_HD Fp operator+(Fp o) const {
+    uint32_t s = v + o.v, t = s - kP;
+    return raw(s < t ? s : t);
+  }
+  ZKSP_HD Fp operator-(Fp o) const {
+    uint32_t d = v - o.v, t = d + kP;
+    return raw(d < t ? d : t);
+  }
+  ZKSP_HD Fp operator-() const { return raw(v ? kP - v : 0); }
+  ZKSP_HD Fp operator*(Fp o) const { return raw(reduce((uint64_t)v * o.v)); }
+  ZKSP_HD Fp& operator+=(Fp o) { return *this = *this + o; }
+  ZKSP_HD Fp& operator-=(Fp o) { return *this = *this - o; }
+  ZKSP_HD Fp& operator*=(Fp o) { return *this = *this * o; }
+  ZKSP_HD bool operator==(Fp o) const { return v == o.v; }
+  ZKSP_HD bool operator!=(Fp o) const { return v != o.v; }
+  ZKSP_HD Fp dbl() const { return *this + *this; }
+  ZKSP_HD Fp sqr() const { return *this * *this; }
+
+  ZKSP_HD Fp pow(uint64_t e) const {
+    Fp r = one(), b = *this;
+    while (e) {
+      if (e & 1) r = r * b;
+      b = b.sqr();
+      e >>= 1;
+    }
+    return r;
+  }
+  ZKSP_HD Fp inv() const { return pow(kP - 2); }
+};
+
+ZKSP_HD Fp fp_root_of_unity(int logn) { return Fp::from_canonical(kGen).pow((uint64_t)(kP - 1) >> logn); }
+
+struct Fp4 {
+  Fp c[4];
+
+  ZKSP_HD static Fp4 zero() { Fp4 r; r.c[0] = r.c[1] = r.c[2] = r.c[3] = Fp::zero(); return r; }
+  ZKSP_HD static Fp4 one() { Fp4 r = zero(); r.c[0] = Fp::one(); return r; }
+  ZKSP_HD static Fp4 from_base(Fp a) { Fp4 r = zero(); r.c[0] = a; return r; }
+
+  ZKSP_HD Fp4 operator+(const Fp4& o) const { Fp4 r; for (int i = 0; i < 4; ++i) r.c[i] = c[i] + o.c[i]; return r; }
+  ZKSP_HD Fp4 operator-(const Fp4& o) const { Fp4 r; for (int i = 0; i < 4; ++i) r.c[i] = c[i] - o.c[i]; return r; }
+  ZKSP_HD Fp4 operator-() const { Fp4 r; for (int i = 0; i < 4; ++i) r.c[i] = -c[i]; return r; }
+  ZKSP_HD Fp4 operator*(Fp b) const { Fp4 r; for (int i = 0; i < 4; ++i) r.c[i] = c[i] * b; return r; }
+  ZKSP_HD Fp4 operator*(const Fp4& o) const {
+    const Fp w = Fp::raw(kExtWMonty);
+    Fp4 r;
+    r.c[0] = c[0] * o.c[0] + w * (c[1] * o.c[3] + c[2] * o.c[2] + c[3] * o.c[1]);
+    r.c[1] = c[0] * o.c[1] + c[1] * o.c[0] + w * (c[2] * o.c[3] + c[3] * o.c[2]);
+    r.c[2] = c[0] * o.c[2] + c[1] * o.c[1] + c[2] * o.c[0] + w * (c[3] * o.c[3]);
+    r.c[3] = c[0] * o.c[3] + c[1] * o.c[2] + c[2] * o.c[1] + c[3] * o.c[0];
+    return r;
+  }
+  ZKSP_HD Fp4& operator+=(const Fp4& o) { return *this = *this + o; }
+  ZKSP_HD Fp4& operator-=(const Fp4& o) { return *this = *this - o; }
+  ZKSP_HD Fp4& operator*=(const Fp4& o) { return *this = *this * o; }
+  ZKSP_HD bool operator==(const Fp4& o) const { return c[0] == o.c[0] && c[1] == o.c[1] && c[2] == o.c[2] && c[3] == o.c[3]; }
+  ZKSP_HD bool operator!=(const Fp4& o) const { return !(*this == o); }
+  ZKSP_HD Fp4 sqr() const { return *this * *this; }
+  ZKSP_HD Fp4 dbl() const { return *this + *this; }
+
+  ZKSP_HD Fp4 pow(uint64_t e) const {
+    Fp4 r = one(), b = *this;
+    while (e) {
+      if (e & 1) r = r * b;
+      b = b.sqr();
+      e >>= 1;
+    }
+    return r;
+  }
+  // Frobenius: coefficient i scaled by (11^((p-1)/4))^i
+  ZKSP_HD Fp4 frob() const {
+    const Fp z = Fp::raw(kFrobZMonty);
+    Fp4 r;
+    Fp zi = Fp::one();
+    for (int i = 0; i < 4; ++i) { r.c[i] = c[i] * zi; zi = zi * z; }
+    return r;
+  }
+  // a^-1 = (a^p a^{p^2} a^{p^3}) / Norm(a)
+  ZKSP_HD Fp4 inv() const {
+    Fp4 f1 = frob(), f2 = f1.frob(), f3 = f2.frob();
+    Fp4 t = f1 * f2 * f3;
+    Fp n = ((*this) * t).c[0];
+    return t * n.inv();
+  }
+};
+
+}  // namespace zksp

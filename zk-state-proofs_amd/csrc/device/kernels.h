@@ -1,0 +1,126 @@
+// Host-callable launchers for the HIP kernels of the proving hot path
+// (SURVEY.md section 8a rows a3-a7).  Every launcher enqueues on `stream` and
+// returns immediately; none allocates or synchronises (graph-capturable).
+// All field elements in device buffers are Montgomery residues (field.cuh).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "poseidon2.cuh"
+
+namespace zksp {
+
+// Device-resident challenger state, one per proof in a batch.
+struct DevChallenger {
+  uint32_t state[16];
+  uint32_t inbuf[8];
+  uint32_t outbuf[8];
+  int32_t n_in;
+  int32_t n_out;
+};
+
+// ---- NTT / LDE (row a4) ----
+// ncols contiguous columns of H = 2^logh evaluations -> coefficient columns
+// (bit-reversed order, optional) and blowup-2 coset-major LDE [ncols][2][H].
+// tables: tw_fwd/tw_inv [H/2] powers of w_H / w_H^-1; in_scale_br [ntables][H] and
+// out_scale_br [2][H] are indexed by the bit-reversed coefficient position; column
+// `col` uses input table (col >> scale_sel_shift) & scale_sel_mask.
+void launch_lde(hipStream_t stream, const uint32_t* in, uint32_t* coefs_br, uint32_t* out, const uint32_t* tw_fwd,
+                const uint32_t* tw_inv, const uint32_t* in_scale_br, int scale_sel_shift, int scale_sel_mask,
+                const uint32_t* out_scale_br, int logh, size_t ncols);
+int lde_configure();  // one-time kernel attribute setup; returns a hipError_t
+
+// ---- Poseidon2 Merkle commitment (row a5) ----
+// mat: [batch][width][n_rows] column-major (proof stride mat_stride words);
+// tree: [batch][2*n_rows-1][8], leaves first, root last (stride tree_stride words).
+void launch_merkle_commit(hipStream_t stream, const uint32_t* mat, size_t mat_stride, int width, int logn,
+                          uint32_t* tree, size_t tree_stride, int batch, const P2Consts* consts);
+// states: [n][16] -> permuted in place (test hook)
+void launch_poseidon2_permute(hipStream_t stream, uint32_t* states, size_t n, const P2Consts* consts);
+
+// ---- keccak chip (rows a3, a6) ----
+// states: [batch][max_perms][25] u64; n_perms: [batch]; trace: [batch][2633][H]
+void launch_keccak_trace(hipStream_t stream, const uint64_t* states, int max_perms, const uint32_t* n_perms,
+                         uint32_t* trace, int logh, int batch);
+// lde: [batch][2633][2][H]; alpha_pows: [batch][3182] Fp4; sel_first/sel_trans: [2][H];
+// partial: [batch][62][2H] Fp4 scratch; quot: [batch][8][H]; zh_inv: [2]
+void launch_keccak_quotient(hipStream_t stream, const uint32_t* lde, const uint32_t* alpha_pows,
+                            const uint32_t* sel_first, const uint32_t* sel_trans, const uint32_t* zh_inv,
+                            uint32_t* partial, uint32_t* quot, int logh, int batch);
+
+// ---- openings / FRI (row a7) ----
+// out[b][i] = (base[b]*base_mul)^e, e = i or bitrev(i); Fp4 each, base_mul a Montgomery base-field word
+void launch_ext_powers(hipStream_t stream, const uint32_t* base, size_t base_stride, uint32_t base_mul, uint32_t* out,
+                       size_t out_stride, int n, int bitrev_logn, int batch);
+// coefs_br: [batch][ncols][H] (bit-reversed); zpow_br: [batch][npoints][H] Fp4 (bit-reversed);
+// opened[b][pt*pt_stride + col] (Fp4)
+void launch_open(hipStream_t stream, const uint32_t* coefs_br, size_t coefs_stride, int ncols, int logh,
+                 const uint32_t* zpow_br, size_t zpow_stride, int npoints, uint32_t* opened, size_t opened_stride,
+                 size_t pt_stride, int batch);
+
+struct ReduceArgs {
+  const uint32_t* lde_t;   // [batch][W][2][H]
+  const uint32_t* lde_q;   // [batch][8][2][H]
+  const uint32_t* af_pows; // [batch][2W+8] Fp4
+  const uint32_t* opened;  // [batch][2W+8] Fp4 (local, next, quotient)
+  const uint32_t* zeta;    // [batch] Fp4
+  const uint32_t* xs;      // [2][H] domain points
+  uint32_t* partial;       // [batch][nchunks][2H] Fp4 scratch
+  uint32_t* bsum;          // [batch][3] Fp4 scratch
+  uint32_t* out;           // [batch][2][H] Fp4
+  size_t opened_stride;    // words between consecutive proofs in `opened`
+  size_t out_stride;       // words between consecutive proofs in `out`
+  uint32_t w_h;            // generator of the trace subgroup (Montgomery)
+  int width;               // W
+  int logh;
+  int batch;
+};
+void launch_reduce_openings(hipStream_t stream, const ReduceArgs& a);
+int reduce_nchunks(int width);  // column chunks -> size of ReduceArgs::partial
+
+// layer k: in [batch][2][Hk] Fp4 -> out [batch][2][Hk/2] Fp4; beta: [batch] Fp4;
+// tw_inv: [H/2] (powers of w_H^-1, H the ORIGINAL height); xinv_c[2] = (shift_k * w_{2Hk}^c)^-1
+void launch_fri_fold(hipStream_t stream, const uint32_t* in, size_t in_stride, uint32_t* out, size_t out_stride,
+                     const uint32_t* beta, size_t beta_stride, const uint32_t* tw_inv, int tw_shift, uint32_t xinv0,
+                     uint32_t xinv1, int loghk, int batch);
+// leaves of layer k: (f[c][m], f[c][m+Hk/2]) -> tree [batch][2*Hk-1][8], full tree built
+void launch_fri_commit(hipStream_t stream, const uint32_t* layer, size_t layer_stride, int loghk, uint32_t* tree,
+                       size_t tree_stride, int batch, const P2Consts* consts);
+
+// ---- Fiat-Shamir on the device (row a8, prover side) ----
+void launch_ch_init(hipStream_t stream, DevChallenger* ch, const uint32_t* init_obs, int n_obs, int batch,
+                    const P2Consts* consts);
+// observe `n_obs` words at obs[b*obs_stride ...] (Montgomery), then sample n_ext
+// extension elements to out[b*out_stride ...]
+void launch_ch_observe_sample(hipStream_t stream, DevChallenger* ch, const uint32_t* obs, size_t obs_stride, int n_obs,
+                              uint32_t* out, size_t out_stride, int n_ext, int batch, const P2Consts* consts);
+// proof-of-work search: smallest w with sample_bits(bits) == 0 after observing w
+void launch_ch_grind(hipStream_t stream, DevChallenger* ch, uint32_t* witness, int bits, int batch,
+                     const P2Consts* consts);
+// observe witness, then draw n_queries indices of `index_bits` bits
+void launch_ch_queries(hipStream_t stream, DevChallenger* ch, const uint32_t* witness, uint32_t* indices,
+                       int n_queries, int pow_bits, int index_bits, int batch, const P2Consts* consts);
+
+// ---- proof assembly ----
+struct AssembleArgs {
+  const uint32_t* lde_t;   // [batch][W][2][H]
+  const uint32_t* tree_t;  // [batch][4H-1][8]
+  const uint32_t* lde_q;   // [batch][8][2][H]
+  const uint32_t* tree_q;
+  const uint32_t* opened;  // [batch][2W+8] Fp4
+  const uint32_t* fri_layers;  // [batch][fri_layer_stride]: layers 0..logh-1 back to back, then the final pair
+  const uint32_t* fri_trees;   // [batch][fri_tree_stride]: trees 0..logh-1 back to back
+  const uint32_t* witness;     // [batch]
+  const uint32_t* indices;     // [batch][n_queries]
+  uint32_t* body;              // [batch][body_words] canonical u32
+  size_t lde_t_stride, tree_t_stride, lde_q_stride, tree_q_stride, opened_stride, fri_layer_stride, fri_tree_stride,
+      body_stride;
+  int width, logh, n_queries, batch;
+};
+void launch_assemble(hipStream_t stream, const AssembleArgs& a);
+
+// instruction-rate probe (kernels_bench.hip)
+void launch_rate_kernel(hipStream_t stream, int which, uint32_t* out, int blocks, int iters);
+
+}  // namespace zksp

@@ -1,0 +1,154 @@
+// Poseidon2-BabyBear Merkle commitment (hot-path row a5; replaces p3-merkle-tree /
+// p3-symmetric 0.1.4-succinct, reference Cargo.lock:5336, :5367, reached beneath
+// prover/src/bin/main.rs:71-74).
+//
+// Leaf layer: one lane per matrix row, the 16-word sponge state lives in VGPRs.
+// The matrix is column-major, so at every absorb step the 64 lanes of a wave read
+// 64 consecutive words of one column: each column is streamed from HBM exactly
+// once, fully coalesced.  Upper layers: one lane per parent; once a layer fits one
+// workgroup the rest of the tree is finished in a single launch.
+#include "kernels.h"
+
+namespace zksp {
+
+constexpr int kHashThreads = 256;
+
+__global__ __launch_bounds__(kHashThreads) void leaf_hash_kernel(const uint32_t* __restrict__ mat, size_t mat_stride,
+                                                                int width, int n_rows, uint32_t* __restrict__ tree,
+                                                                size_t tree_stride,
+                                                                const P2Consts* __restrict__ consts) {
+  const int row = blockIdx.x * kHashThreads + threadIdx.x;
+  if (row >= n_rows) return;
+  const uint32_t* m = mat + (size_t)blockIdx.y * mat_stride + row;
+  Fp s[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s[i] = Fp::zero();
+  int c0 = 0;
+  for (; c0 + 8 <= width; c0 += 8) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = Fp::raw(m[(size_t)(c0 + i) * n_rows]);
+    p2_permute(s, consts);
+  }
+  if (c0 < width) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (c0 + i < width) s[i] = Fp::raw(m[(size_t)(c0 + i) * n_rows]);
+    p2_permute(s, consts);
+  }
+  uint4* d = reinterpret_cast<uint4*>(tree + (size_t)blockIdx.y * tree_stride + (size_t)row * 8);
+  d[0] = make_uint4(s[0].v, s[1].v, s[2].v, s[3].v);
+  d[1] = make_uint4(s[4].v, s[5].v, s[6].v, s[7].v);
+}
+
+__device__ __forceinline__ void compress_pair(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                              const P2Consts* __restrict__ consts) {
+  const uint4* p = reinterpret_cast<const uint4*>(src);
+  uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+  Fp s[16] = {Fp::raw(a.x), Fp::raw(a.y), Fp::raw(a.z), Fp::raw(a.w), Fp::raw(b.x), Fp::raw(b.y),
+              Fp::raw(b.z), Fp::raw(b.w), Fp::raw(c.x), Fp::raw(c.y), Fp::raw(c.z), Fp::raw(c.w),
+              Fp::raw(d.x), Fp::raw(d.y), Fp::raw(d.z), Fp::raw(d.w)};
+  p2_permute(s, consts);
+  uint4* q = reinterpret_cast<uint4*>(dst);
+  q[0] = make_uint4(s[0].v, s[1].v, s[2].v, s[3].v);
+  q[1] = make_uint4(s[4].v, s[5].v, s[6].v, s[7].v);
+}
+
+// one layer: parents [count] from children [2*count]
+__global__ __launch_bounds__(kHashThreads) void compress_layer_kernel(uint32_t* __restrict__ tree, size_t tree_stride,
+                                                                     size_t in_off, size_t out_off, int count,
+                                                                     const P2Consts* __restrict__ consts) {
+  const int i = blockIdx.x * kHashThreads + threadIdx.x;
+  if (i >= count) return;
+  uint32_t* t = tree + (size_t)blockIdx.y * tree_stride;
+  compress_pair(t + (in_off + 2 * (size_t)i) * 8, t + (out_off + (size_t)i) * 8, consts);
+}
+
+// finishes the tree from a layer of `count` (<= 2*kHashThreads) digests, one workgroup per proof
+__global__ __launch_bounds__(kHashThreads) void compress_top_kernel(uint32_t* __restrict__ tree, size_t tree_stride,
+                                                                   size_t in_off, int count,
+                                                                   const P2Consts* __restrict__ consts) {
+  uint32_t* t = tree + (size_t)blockIdx.x * tree_stride;
+  while (count > 1) {
+    const int parents = count >> 1;
+    const size_t out_off = in_off + (size_t)count;
+    if ((int)threadIdx.x < parents)
+      compress_pair(t + (in_off + 2 * (size_t)threadIdx.x) * 8, t + (out_off + threadIdx.x) * 8, consts);
+    __syncthreads();
+    in_off = out_off;
+    count = parents;
+  }
+}
+
+static void launch_upper_layers(hipStream_t stream, int logn, uint32_t* tree, size_t tree_stride, int batch,
+                                const P2Consts* consts) {
+  size_t off = 0;
+  int count = 1 << logn;
+  while (count > 2 * kHashThreads) {
+    int parents = count >> 1;
+    hipLaunchKernelGGL(compress_layer_kernel, dim3((parents + kHashThreads - 1) / kHashThreads, batch),
+                       dim3(kHashThreads), 0, stream, tree, tree_stride, off, off + (size_t)count, parents, consts);
+    off += (size_t)count;
+    count = parents;
+  }
+  if (count > 1)
+    hipLaunchKernelGGL(compress_top_kernel, dim3(batch), dim3(kHashThreads), 0, stream, tree, tree_stride, off, count,
+                       consts);
+}
+
+void launch_merkle_commit(hipStream_t stream, const uint32_t* mat, size_t mat_stride, int width, int logn,
+                          uint32_t* tree, size_t tree_stride, int batch, const P2Consts* consts) {
+  const int n = 1 << logn;
+  hipLaunchKernelGGL(leaf_hash_kernel, dim3((n + kHashThreads - 1) / kHashThreads, batch), dim3(kHashThreads), 0,
+                     stream, mat, mat_stride, width, n, tree, tree_stride, consts);
+  launch_upper_layers(stream, logn, tree, tree_stride, batch, consts);
+}
+
+// FRI layer commitment: leaf (c, m) = (f[c][m], f[c][m + Hk/2]), 8 words = one absorb
+__global__ __launch_bounds__(kHashThreads) void fri_leaf_kernel(const uint32_t* __restrict__ layer,
+                                                               size_t layer_stride, int loghk,
+                                                               uint32_t* __restrict__ tree, size_t tree_stride,
+                                                               const P2Consts* __restrict__ consts) {
+  const int hk = 1 << loghk, half = hk >> 1;
+  const int leaf = blockIdx.x * kHashThreads + threadIdx.x;
+  if (leaf >= hk) return;
+  const int c = leaf >= half ? 1 : 0, m = leaf - c * half;
+  const uint4* f = reinterpret_cast<const uint4*>(layer + (size_t)blockIdx.y * layer_stride);
+  uint4 lo = f[(size_t)c * hk + m], hi = f[(size_t)c * hk + m + half];
+  Fp s[16];
+  s[0] = Fp::raw(lo.x); s[1] = Fp::raw(lo.y); s[2] = Fp::raw(lo.z); s[3] = Fp::raw(lo.w);
+  s[4] = Fp::raw(hi.x); s[5] = Fp::raw(hi.y); s[6] = Fp::raw(hi.z); s[7] = Fp::raw(hi.w);
+#pragma unroll
+  for (int i = 8; i < 16; ++i) s[i] = Fp::zero();
+  p2_permute(s, consts);
+  uint4* d = reinterpret_cast<uint4*>(tree + (size_t)blockIdx.y * tree_stride + (size_t)leaf * 8);
+  d[0] = make_uint4(s[0].v, s[1].v, s[2].v, s[3].v);
+  d[1] = make_uint4(s[4].v, s[5].v, s[6].v, s[7].v);
+}
+
+void launch_fri_commit(hipStream_t stream, const uint32_t* layer, size_t layer_stride, int loghk, uint32_t* tree,
+                       size_t tree_stride, int batch, const P2Consts* consts) {
+  const int hk = 1 << loghk;
+  hipLaunchKernelGGL(fri_leaf_kernel, dim3((hk + kHashThreads - 1) / kHashThreads, batch), dim3(kHashThreads), 0,
+                     stream, layer, layer_stride, loghk, tree, tree_stride, consts);
+  launch_upper_layers(stream, loghk, tree, tree_stride, batch, consts);
+}
+
+__global__ __launch_bounds__(kHashThreads) void permute_kernel(uint32_t* __restrict__ states, size_t n,
+                                                              const P2Consts* __restrict__ consts) {
+  size_t i = (size_t)blockIdx.x * kHashThreads + threadIdx.x;
+  if (i >= n) return;
+  Fp s[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s[k] = Fp::raw(states[i * 16 + k]);
+  p2_permute(s, consts);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) states[i * 16 + k] = s[k].v;
+}
+
+void launch_poseidon2_permute(hipStream_t stream, uint32_t* states, size_t n, const P2Consts* consts) {
+  if (!n) return;
+  hipLaunchKernelGGL(permute_kernel, dim3((unsigned)((n + kHashThreads - 1) / kHashThreads)), dim3(kHashThreads), 0,
+                     stream, states, n, consts);
+}
+
+}  // namespace zksp

@@ -1,0 +1,608 @@
+// Device side of the STARK prover around the NTT and Merkle kernels:
+// keccak trace generation (row a3), constraint/quotient evaluation (row a6),
+// out-of-domain openings, reduced openings and FRI folding (row a7), the
+// duplex-sponge Fiat-Shamir transcript (row a8, prover side) and proof assembly.
+// Replaces what sp1-core-machine / p3-uni-stark / p3-fri / p3-challenger do on the
+// host beneath the reference's `client.prove(&pk, stdin).run()`
+// (prover/src/bin/main.rs:71-74; Cargo.lock:7130, :5378, :5253, :5197).
+//
+// Batch convention: the leading (slowest) index of every buffer is the proof in
+// the batch; kernels take it from blockIdx.y (or one lane per proof for the
+// transcript kernels, so that a whole batch of sponges advances in one wave).
+#include "air_keccak.cuh"
+#include "kernels.h"
+
+namespace zksp {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ Fp4 load_fp4(const uint32_t* p) {
+  uint4 v = *reinterpret_cast<const uint4*>(p);
+  Fp4 r;
+  r.c[0] = Fp::raw(v.x); r.c[1] = Fp::raw(v.y); r.c[2] = Fp::raw(v.z); r.c[3] = Fp::raw(v.w);
+  return r;
+}
+__device__ __forceinline__ void store_fp4(uint32_t* p, const Fp4& a) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(a.c[0].v, a.c[1].v, a.c[2].v, a.c[3].v);
+}
+
+// ===========================================================================
+// keccak trace generation: one lane per trace row
+// ===========================================================================
+__device__ __forceinline__ uint64_t rol64(uint64_t v, int n) { return n ? (v << n) | (v >> (64 - n)) : v; }
+
+__global__ __launch_bounds__(kThreads) void keccak_trace_kernel(const uint64_t* __restrict__ states, int max_perms,
+                                                               const uint32_t* __restrict__ n_perms,
+                                                               uint32_t* __restrict__ trace, int logh) {
+  const int h = 1 << logh;
+  const int row = blockIdx.x * kThreads + threadIdx.x;
+  if (row >= h) return;
+  const int b = blockIdx.y;
+  const int perm = row / 24, round = row - perm * 24;
+  const int np = (int)n_perms[b];
+  const ka::Tables& T = ka::tables();
+  uint64_t pre[25], a[25];
+  if (perm < np) {
+    const uint64_t* s = states + ((size_t)b * max_perms + perm) * 25;
+#pragma unroll
+    for (int i = 0; i < 25; ++i) pre[i] = s[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 25; ++i) pre[i] = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < 25; ++i) a[i] = pre[i];
+  uint64_t c[5], cp[5], ap[25], bb[25], app[25];
+  // advance to this row's round; the last iteration's intermediates are the row
+  for (int r = 0;; ++r) {
+#pragma unroll
+    for (int x = 0; x < 5; ++x) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+#pragma unroll
+    for (int x = 0; x < 5; ++x) cp[x] = c[x] ^ c[(x + 4) % 5] ^ rol64(c[(x + 1) % 5], 1);
+#pragma unroll
+    for (int j = 0; j < 25; ++j) ap[j] = a[j] ^ c[j % 5] ^ cp[j % 5];
+#pragma unroll
+    for (int x = 0; x < 5; ++x)
+#pragma unroll
+      for (int y = 0; y < 5; ++y) bb[y + 5 * ((2 * x + 3 * y) % 5)] = rol64(ap[x + 5 * y], T.rot[x][y]);
+#pragma unroll
+    for (int y = 0; y < 5; ++y)
+#pragma unroll
+      for (int x = 0; x < 5; ++x) app[x + 5 * y] = bb[x + 5 * y] ^ (~bb[(x + 1) % 5 + 5 * y] & bb[(x + 2) % 5 + 5 * y]);
+    if (r == round) break;
+#pragma unroll
+    for (int j = 0; j < 25; ++j) a[j] = app[j];
+    a[0] ^= T.rc[r];
+  }
+  const uint64_t appp00 = app[0] ^ T.rc[round];
+  uint32_t* t = trace + (size_t)b * ka::kWidth * h + row;
+  const size_t cs = (size_t)h;
+  const uint32_t one = kR1;
+  for (int i = 0; i < 24; ++i) t[(ka::kFlags + i) * cs] = (i == round) ? one : 0u;
+  t[ka::kExport * cs] = (perm < np && round == 23) ? one : 0u;
+#pragma unroll
+  for (int j = 0; j < 25; ++j)
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      t[(ka::kPreimage + 4 * j + l) * cs] = Fp::from_canonical((uint32_t)((pre[j] >> (16 * l)) & 0xffff)).v;
+      t[(ka::kA + 4 * j + l) * cs] = Fp::from_canonical((uint32_t)((a[j] >> (16 * l)) & 0xffff)).v;
+      t[(ka::kApp + 4 * j + l) * cs] = Fp::from_canonical((uint32_t)((app[j] >> (16 * l)) & 0xffff)).v;
+    }
+#pragma unroll
+  for (int x = 0; x < 5; ++x)
+    for (int z = 0; z < 64; ++z) {
+      t[(ka::kC + 64 * x + z) * cs] = ((c[x] >> z) & 1) ? one : 0u;
+      t[(ka::kCp + 64 * x + z) * cs] = ((cp[x] >> z) & 1) ? one : 0u;
+    }
+#pragma unroll
+  for (int j = 0; j < 25; ++j)
+    for (int z = 0; z < 64; ++z) t[(ka::kAp + 64 * j + z) * cs] = ((ap[j] >> z) & 1) ? one : 0u;
+  for (int z = 0; z < 64; ++z) t[(ka::kApp00 + z) * cs] = ((app[0] >> z) & 1) ? one : 0u;
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+    t[(ka::kAppp00 + l) * cs] = Fp::from_canonical((uint32_t)((appp00 >> (16 * l)) & 0xffff)).v;
+}
+
+void launch_keccak_trace(hipStream_t stream, const uint64_t* states, int max_perms, const uint32_t* n_perms,
+                         uint32_t* trace, int logh, int batch) {
+  const int h = 1 << logh;
+  hipLaunchKernelGGL(keccak_trace_kernel, dim3((h + kThreads - 1) / kThreads, batch), dim3(kThreads), 0, stream,
+                     states, max_perms, n_perms, trace, logh);
+}
+
+// ===========================================================================
+// constraint evaluation on the LDE domain -> quotient values
+// ===========================================================================
+struct QuotCtx {
+  using F = Fp;
+  const uint32_t* loc;
+  const uint32_t* nxt;
+  size_t cs;
+  Fp first, trans;
+  const uint32_t* ap;  // alpha powers from this group's base index on (Fp4 each)
+  Fp4 acc;
+  __device__ __forceinline__ F local(int col) const { return Fp::raw(loc[(size_t)col * cs]); }
+  __device__ __forceinline__ F next(int col) const { return Fp::raw(nxt[(size_t)col * cs]); }
+  __device__ __forceinline__ F is_first() const { return first; }
+  __device__ __forceinline__ F is_trans() const { return trans; }
+  __device__ __forceinline__ F one() const { return Fp::one(); }
+  __device__ __forceinline__ void emit(F v) {
+    Fp4 a;
+    a.c[0] = Fp::raw(ap[0]); a.c[1] = Fp::raw(ap[1]); a.c[2] = Fp::raw(ap[2]); a.c[3] = Fp::raw(ap[3]);
+    ap += 4;
+    acc += a * v;
+  }
+};
+
+__global__ __launch_bounds__(kThreads) void keccak_quotient_kernel(const uint32_t* __restrict__ lde,
+                                                                  const uint32_t* __restrict__ alpha_pows,
+                                                                  const uint32_t* __restrict__ sel_first,
+                                                                  const uint32_t* __restrict__ sel_trans,
+                                                                  uint32_t* __restrict__ partial, int logh) {
+  const int h = 1 << logh, n = 2 * h;
+  const int pt = blockIdx.x * kThreads + threadIdx.x;
+  if (pt >= n) return;
+  const int g = blockIdx.y, b = blockIdx.z;
+  const int c = pt >= h ? 1 : 0, m = pt - c * h;
+  const uint32_t* base = lde + (size_t)b * ka::kWidth * n + (size_t)c * h;
+  QuotCtx ctx;
+  ctx.loc = base + m;
+  ctx.nxt = base + ((m + 1) & (h - 1));
+  ctx.cs = (size_t)n;
+  ctx.first = Fp::raw(sel_first[pt]);
+  ctx.trans = Fp::raw(sel_trans[pt]);
+  ctx.ap = alpha_pows + ((size_t)b * ka::kNumConstraints + ka::group_base(g)) * 4;
+  ctx.acc = Fp4::zero();
+  ka::eval_group(g, ctx);
+  store_fp4(partial + (((size_t)b * ka::kNumGroups + g) * n + pt) * 4, ctx.acc);
+}
+
+__global__ __launch_bounds__(kThreads) void keccak_quotient_combine_kernel(const uint32_t* __restrict__ partial,
+                                                                          const uint32_t* __restrict__ zh_inv,
+                                                                          uint32_t* __restrict__ quot, int logh) {
+  const int h = 1 << logh, n = 2 * h;
+  const int pt = blockIdx.x * kThreads + threadIdx.x;
+  if (pt >= n) return;
+  const int b = blockIdx.y;
+  const int c = pt >= h ? 1 : 0, m = pt - c * h;
+  Fp4 acc = Fp4::zero();
+  for (int g = 0; g < ka::kNumGroups; ++g) acc += load_fp4(partial + (((size_t)b * ka::kNumGroups + g) * n + pt) * 4);
+  acc = acc * Fp::raw(zh_inv[c]);
+  uint32_t* q = quot + (size_t)b * 8 * h + m;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) q[(size_t)(4 * c + j) * h] = acc.c[j].v;
+}
+
+void launch_keccak_quotient(hipStream_t stream, const uint32_t* lde, const uint32_t* alpha_pows,
+                            const uint32_t* sel_first, const uint32_t* sel_trans, const uint32_t* zh_inv,
+                            uint32_t* partial, uint32_t* quot, int logh, int batch) {
+  const int n = 2 << logh;
+  const int blocks = (n + kThreads - 1) / kThreads;
+  hipLaunchKernelGGL(keccak_quotient_kernel, dim3(blocks, ka::kNumGroups, batch), dim3(kThreads), 0, stream, lde,
+                     alpha_pows, sel_first, sel_trans, partial, logh);
+  hipLaunchKernelGGL(keccak_quotient_combine_kernel, dim3(blocks, batch), dim3(kThreads), 0, stream, partial, zh_inv,
+                     quot, logh);
+}
+
+// ===========================================================================
+// powers of an extension element (optionally stored in bit-reversed order)
+// ===========================================================================
+__global__ __launch_bounds__(kThreads) void ext_powers_kernel(const uint32_t* __restrict__ base, size_t base_stride,
+                                                             uint32_t base_mul, uint32_t* __restrict__ out,
+                                                             size_t out_stride, int n, int bitrev_logn) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const int b = blockIdx.y;
+  uint32_t e = (uint32_t)i;
+  if (bitrev_logn > 0) e = __brev(e) >> (32 - bitrev_logn);
+  Fp4 x = load_fp4(base + (size_t)b * base_stride) * Fp::raw(base_mul);
+  Fp4 r = Fp4::one();
+  while (e) {
+    if (e & 1) r = r * x;
+    x = x.sqr();
+    e >>= 1;
+  }
+  store_fp4(out + (size_t)b * out_stride + (size_t)i * 4, r);
+}
+
+void launch_ext_powers(hipStream_t stream, const uint32_t* base, size_t base_stride, uint32_t base_mul, uint32_t* out,
+                       size_t out_stride, int n, int bitrev_logn, int batch) {
+  hipLaunchKernelGGL(ext_powers_kernel, dim3((n + kThreads - 1) / kThreads, batch), dim3(kThreads), 0, stream, base,
+                     base_stride, base_mul, out, out_stride, n, bitrev_logn);
+}
+
+// ===========================================================================
+// out-of-domain openings: p(z) = sum_k coef_k z^k, one workgroup per column
+// ===========================================================================
+__device__ __forceinline__ Fp4 block_sum(Fp4 v, Fp4* red) {
+  // wave reduction by shuffles, then across the 4 waves through LDS
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    Fp4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.c[j] = Fp::raw(__shfl_down(v.c[j].v, off, 64));
+    v += o;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  Fp4 r = red[0];
+  for (int w = 1; w < kThreads / 64; ++w) r += red[w];
+  return r;
+}
+
+__global__ __launch_bounds__(kThreads) void open_kernel(const uint32_t* __restrict__ coefs, size_t coefs_stride,
+                                                       int logh, const uint32_t* __restrict__ zpow,
+                                                       size_t zpow_stride, int npoints, uint32_t* __restrict__ opened,
+                                                       size_t opened_stride, size_t pt_stride) {
+  __shared__ Fp4 red[kThreads / 64];
+  const int h = 1 << logh;
+  const int col = blockIdx.x, b = blockIdx.y;
+  const uint32_t* cf = coefs + (size_t)b * coefs_stride + (size_t)col * h;
+  const uint32_t* z0 = zpow + (size_t)b * zpow_stride;
+  const uint32_t* z1 = z0 + (size_t)h * 4;
+  Fp4 a0 = Fp4::zero(), a1 = Fp4::zero();
+  for (int k = threadIdx.x; k < h; k += kThreads) {
+    Fp cv = Fp::raw(cf[k]);
+    a0 += load_fp4(z0 + (size_t)k * 4) * cv;
+    if (npoints > 1) a1 += load_fp4(z1 + (size_t)k * 4) * cv;
+  }
+  Fp4 s0 = block_sum(a0, red);
+  if (threadIdx.x == 0) store_fp4(opened + (size_t)b * opened_stride + (size_t)col * 4, s0);
+  if (npoints > 1) {
+    Fp4 s1 = block_sum(a1, red);
+    if (threadIdx.x == 0) store_fp4(opened + (size_t)b * opened_stride + (pt_stride + (size_t)col) * 4, s1);
+  }
+}
+
+void launch_open(hipStream_t stream, const uint32_t* coefs_br, size_t coefs_stride, int ncols, int logh,
+                 const uint32_t* zpow_br, size_t zpow_stride, int npoints, uint32_t* opened, size_t opened_stride,
+                 size_t pt_stride, int batch) {
+  hipLaunchKernelGGL(open_kernel, dim3(ncols, batch), dim3(kThreads), 0, stream, coefs_br, coefs_stride, logh, zpow_br,
+                     zpow_stride, npoints, opened, opened_stride, pt_stride);
+}
+
+// ===========================================================================
+// reduced openings (DEEP quotient) over the LDE domain
+// ===========================================================================
+constexpr int kReduceChunk = 128;
+
+__global__ __launch_bounds__(kThreads) void reduce_bsum_kernel(ReduceArgs a) {
+  __shared__ Fp4 red[kThreads / 64];
+  const int b = blockIdx.x, W = a.width;
+  const uint32_t* ap = a.af_pows + (size_t)b * (2 * W + 8) * 4;
+  const uint32_t* op = a.opened + (size_t)b * a.opened_stride;
+  Fp4 s0 = Fp4::zero(), s1 = Fp4::zero(), s2 = Fp4::zero();
+  for (int i = threadIdx.x; i < W; i += kThreads) {
+    Fp4 p = load_fp4(ap + (size_t)i * 4);
+    s0 += p * load_fp4(op + (size_t)i * 4);
+    s1 += p * load_fp4(op + (size_t)(W + i) * 4);
+  }
+  if (threadIdx.x < 8) s2 = load_fp4(ap + (size_t)threadIdx.x * 4) * load_fp4(op + (size_t)(2 * W + threadIdx.x) * 4);
+  Fp4 r0 = block_sum(s0, red), r1 = block_sum(s1, red), r2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    store_fp4(a.bsum + ((size_t)b * 3 + 0) * 4, r0);
+    store_fp4(a.bsum + ((size_t)b * 3 + 1) * 4, r1);
+    store_fp4(a.bsum + ((size_t)b * 3 + 2) * 4, r2);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void reduce_partial_kernel(ReduceArgs a, int nchunks) {
+  const int h = 1 << a.logh, n = 2 * h;
+  const int pt = blockIdx.x * kThreads + threadIdx.x;
+  if (pt >= n) return;
+  const int chunk = blockIdx.y, b = blockIdx.z, W = a.width;
+  const int i0 = chunk * kReduceChunk, i1 = min(W, i0 + kReduceChunk);
+  const uint32_t* col = a.lde_t + (size_t)b * W * n + pt;
+  const uint32_t* ap = a.af_pows + (size_t)b * (2 * W + 8) * 4;
+  Fp4 acc = Fp4::zero();
+  for (int i = i0; i < i1; ++i) acc += load_fp4(ap + (size_t)i * 4) * Fp::raw(col[(size_t)i * n]);
+  store_fp4(a.partial + (((size_t)b * nchunks + chunk) * n + pt) * 4, acc);
+}
+
+__global__ __launch_bounds__(kThreads) void reduce_final_kernel(ReduceArgs a, int nchunks) {
+  const int h = 1 << a.logh, n = 2 * h;
+  const int pt = blockIdx.x * kThreads + threadIdx.x;
+  if (pt >= n) return;
+  const int b = blockIdx.y, W = a.width;
+  const uint32_t* ap = a.af_pows + (size_t)b * (2 * W + 8) * 4;
+  Fp4 st = Fp4::zero();
+  for (int ch = 0; ch < nchunks; ++ch) st += load_fp4(a.partial + (((size_t)b * nchunks + ch) * n + pt) * 4);
+  Fp4 sq = Fp4::zero();
+  const uint32_t* q = a.lde_q + (size_t)b * 8 * n + pt;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sq += load_fp4(ap + (size_t)i * 4) * Fp::raw(q[(size_t)i * n]);
+  const Fp4 b0 = load_fp4(a.bsum + ((size_t)b * 3 + 0) * 4), b1 = load_fp4(a.bsum + ((size_t)b * 3 + 1) * 4),
+            b2 = load_fp4(a.bsum + ((size_t)b * 3 + 2) * 4);
+  const Fp4 zeta = load_fp4(a.zeta + (size_t)b * 4);
+  const Fp4 zeta_next = zeta * Fp::raw(a.w_h);
+  const Fp4 x = Fp4::from_base(Fp::raw(a.xs[pt]));
+  const Fp4 d0 = (x - zeta).inv(), d1 = (x - zeta_next).inv();
+  Fp4 g = (st - b0) * d0;
+  g += load_fp4(ap + (size_t)W * 4) * (st - b1) * d1;
+  g += load_fp4(ap + (size_t)(2 * W) * 4) * (sq - b2) * d0;
+  store_fp4(a.out + (size_t)b * a.out_stride + (size_t)pt * 4, g);
+}
+
+void launch_reduce_openings(hipStream_t stream, const ReduceArgs& a) {
+  const int n = 2 << a.logh;
+  const int blocks = (n + kThreads - 1) / kThreads;
+  const int nchunks = (a.width + kReduceChunk - 1) / kReduceChunk;
+  hipLaunchKernelGGL(reduce_bsum_kernel, dim3(a.batch), dim3(kThreads), 0, stream, a);
+  hipLaunchKernelGGL(reduce_partial_kernel, dim3(blocks, nchunks, a.batch), dim3(kThreads), 0, stream, a, nchunks);
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(blocks, a.batch), dim3(kThreads), 0, stream, a, nchunks);
+}
+int reduce_nchunks(int width) { return (width + kReduceChunk - 1) / kReduceChunk; }
+
+// ===========================================================================
+// FRI fold
+// ===========================================================================
+__global__ __launch_bounds__(kThreads) void fri_fold_kernel(const uint32_t* __restrict__ in, size_t in_stride,
+                                                           uint32_t* __restrict__ out, size_t out_stride,
+                                                           const uint32_t* __restrict__ beta, size_t beta_stride,
+                                                           const uint32_t* __restrict__ tw_inv, int tw_shift,
+                                                           uint32_t xinv0, uint32_t xinv1, int loghk) {
+  const int hk = 1 << loghk, half = hk >> 1;
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= hk) return;  // 2 cosets * half
+  const int b = blockIdx.y;
+  const int c = i >= half ? 1 : 0, m = i - c * half;
+  const uint32_t* f = in + (size_t)b * in_stride;
+  Fp4 lo = load_fp4(f + ((size_t)c * hk + m) * 4), hi = load_fp4(f + ((size_t)c * hk + m + half) * 4);
+  const Fp inv2 = Fp::raw(cmonty((kP + 1) / 2));
+  Fp xinv = Fp::raw(c ? xinv1 : xinv0) * Fp::raw(tw_inv[(size_t)m << tw_shift]);
+  Fp4 be = load_fp4(beta + (size_t)b * beta_stride);
+  Fp4 r = (lo + hi) * inv2 + be * ((lo - hi) * (inv2 * xinv));
+  store_fp4(out + (size_t)b * out_stride + ((size_t)c * half + m) * 4, r);
+}
+
+void launch_fri_fold(hipStream_t stream, const uint32_t* in, size_t in_stride, uint32_t* out, size_t out_stride,
+                     const uint32_t* beta, size_t beta_stride, const uint32_t* tw_inv, int tw_shift, uint32_t xinv0,
+                     uint32_t xinv1, int loghk, int batch) {
+  const int hk = 1 << loghk;
+  hipLaunchKernelGGL(fri_fold_kernel, dim3((hk + kThreads - 1) / kThreads, batch), dim3(kThreads), 0, stream, in,
+                     in_stride, out, out_stride, beta, beta_stride, tw_inv, tw_shift, xinv0, xinv1, loghk);
+}
+
+// ===========================================================================
+// duplex challenger: one lane per proof
+// ===========================================================================
+struct Ch {
+  Fp state[16];
+  Fp inbuf[8];
+  Fp outbuf[8];
+  int n_in, n_out;
+};
+__device__ __forceinline__ void ch_load(const DevChallenger* d, Ch& c) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c.state[i] = Fp::raw(d->state[i]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { c.inbuf[i] = Fp::raw(d->inbuf[i]); c.outbuf[i] = Fp::raw(d->outbuf[i]); }
+  c.n_in = d->n_in;
+  c.n_out = d->n_out;
+}
+__device__ __forceinline__ void ch_store(DevChallenger* d, const Ch& c) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) d->state[i] = c.state[i].v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { d->inbuf[i] = c.inbuf[i].v; d->outbuf[i] = c.outbuf[i].v; }
+  d->n_in = c.n_in;
+  d->n_out = c.n_out;
+}
+__device__ __forceinline__ void ch_duplex(Ch& c, const P2Consts* k) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < c.n_in) c.state[i] = c.inbuf[i];
+  c.n_in = 0;
+  p2_permute(c.state, k);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) c.outbuf[i] = c.state[i];
+  c.n_out = 8;
+}
+__device__ __forceinline__ void ch_observe(Ch& c, Fp x, const P2Consts* k) {
+  c.n_out = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i == c.n_in) c.inbuf[i] = x;
+  c.n_in++;
+  if (c.n_in == 8) ch_duplex(c, k);
+}
+__device__ __forceinline__ Fp ch_sample(Ch& c, const P2Consts* k) {
+  if (c.n_in != 0 || c.n_out == 0) ch_duplex(c, k);
+  c.n_out--;
+  Fp r = c.outbuf[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (i == c.n_out) r = c.outbuf[i];
+  return r;
+}
+
+__global__ void ch_init_kernel(DevChallenger* ch, const uint32_t* __restrict__ init_obs, int n_obs, int batch,
+                               const P2Consts* __restrict__ k) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  Ch c;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c.state[i] = Fp::zero();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { c.inbuf[i] = Fp::zero(); c.outbuf[i] = Fp::zero(); }
+  c.n_in = 0;
+  c.n_out = 0;
+  for (int i = 0; i < n_obs; ++i) ch_observe(c, Fp::from_canonical(init_obs[(size_t)b * n_obs + i]), k);
+  ch_store(ch + b, c);
+}
+
+__global__ void ch_observe_sample_kernel(DevChallenger* ch, const uint32_t* __restrict__ obs, size_t obs_stride,
+                                         int n_obs, uint32_t* __restrict__ out, size_t out_stride, int n_ext,
+                                         int batch, const P2Consts* __restrict__ k) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  Ch c;
+  ch_load(ch + b, c);
+  for (int i = 0; i < n_obs; ++i) ch_observe(c, Fp::raw(obs[(size_t)b * obs_stride + i]), k);
+  for (int i = 0; i < 4 * n_ext; ++i) out[(size_t)b * out_stride + i] = ch_sample(c, k).v;
+  ch_store(ch + b, c);
+}
+
+constexpr uint32_t kGrindChunk = 1u << 18;
+
+__global__ __launch_bounds__(kThreads) void ch_grind_kernel(const DevChallenger* __restrict__ ch,
+                                                           uint32_t* __restrict__ witness, int bits,
+                                                           const P2Consts* __restrict__ k) {
+  const int b = blockIdx.y;
+  const uint32_t w = blockIdx.x * kThreads + threadIdx.x;
+  // a candidate above an already-found witness can never be the minimum
+  if (__hip_atomic_load(&witness[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= w) return;
+  Ch c;
+  ch_load(ch + b, c);
+  ch_observe(c, Fp::from_canonical(w), k);
+  uint32_t s = ch_sample(c, k).to_canonical() & ((1u << bits) - 1);
+  if (s == 0) atomicMin(&witness[b], w);
+}
+
+// rare continuation (probability e^-4 per proof at 16 bits): search on, one workgroup per proof
+__global__ __launch_bounds__(kThreads) void ch_grind_tail_kernel(const DevChallenger* __restrict__ ch,
+                                                                uint32_t* __restrict__ witness, int bits,
+                                                                const P2Consts* __restrict__ k) {
+  __shared__ uint32_t found;
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) found = witness[b];
+  __syncthreads();
+  for (uint32_t base = kGrindChunk; found == 0xffffffffu && base < kP - kThreads; base += kThreads) {
+    Ch c;
+    ch_load(ch + b, c);
+    const uint32_t w = base + threadIdx.x;
+    ch_observe(c, Fp::from_canonical(w), k);
+    uint32_t s = ch_sample(c, k).to_canonical() & ((1u << bits) - 1);
+    __syncthreads();
+    if (s == 0) atomicMin(&found, w);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) witness[b] = found;
+}
+
+__global__ void ch_queries_kernel(DevChallenger* ch, const uint32_t* __restrict__ witness,
+                                  uint32_t* __restrict__ indices, int n_queries, int pow_bits, int index_bits,
+                                  int batch, const P2Consts* __restrict__ k) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  Ch c;
+  ch_load(ch + b, c);
+  ch_observe(c, Fp::from_canonical(witness[b]), k);
+  (void)ch_sample(c, k);  // the proof-of-work sample (zero in its low pow_bits by construction)
+  (void)pow_bits;
+  for (int q = 0; q < n_queries; ++q)
+    indices[(size_t)b * n_queries + q] = ch_sample(c, k).to_canonical() & ((1u << index_bits) - 1);
+  ch_store(ch + b, c);
+}
+
+void launch_ch_init(hipStream_t stream, DevChallenger* ch, const uint32_t* init_obs, int n_obs, int batch,
+                    const P2Consts* consts) {
+  hipLaunchKernelGGL(ch_init_kernel, dim3((batch + 63) / 64), dim3(64), 0, stream, ch, init_obs, n_obs, batch, consts);
+}
+void launch_ch_observe_sample(hipStream_t stream, DevChallenger* ch, const uint32_t* obs, size_t obs_stride, int n_obs,
+                              uint32_t* out, size_t out_stride, int n_ext, int batch, const P2Consts* consts) {
+  hipLaunchKernelGGL(ch_observe_sample_kernel, dim3((batch + 63) / 64), dim3(64), 0, stream, ch, obs, obs_stride,
+                     n_obs, out, out_stride, n_ext, batch, consts);
+}
+void launch_ch_grind(hipStream_t stream, DevChallenger* ch, uint32_t* witness, int bits, int batch,
+                     const P2Consts* consts) {
+  (void)hipMemsetAsync(witness, 0xff, (size_t)batch * 4, stream);
+  hipLaunchKernelGGL(ch_grind_kernel, dim3(kGrindChunk / kThreads, batch), dim3(kThreads), 0, stream, ch, witness,
+                     bits, consts);
+  hipLaunchKernelGGL(ch_grind_tail_kernel, dim3(batch), dim3(kThreads), 0, stream, ch, witness, bits, consts);
+}
+void launch_ch_queries(hipStream_t stream, DevChallenger* ch, const uint32_t* witness, uint32_t* indices,
+                       int n_queries, int pow_bits, int index_bits, int batch, const P2Consts* consts) {
+  hipLaunchKernelGGL(ch_queries_kernel, dim3((batch + 63) / 64), dim3(64), 0, stream, ch, witness, indices, n_queries,
+                     pow_bits, index_bits, batch, consts);
+}
+
+// ===========================================================================
+// proof assembly: everything the verifier reads, canonical u32, one workgroup
+// per query plus one for the fixed part
+// ===========================================================================
+__device__ __forceinline__ size_t layer_off(int logn, int layer) {
+  // digests before `layer` in a tree with 2^logn leaves
+  return ((size_t)2 << logn) - ((size_t)2 << (logn - layer));
+}
+__device__ __forceinline__ void put_path(uint32_t* dst, const uint32_t* tree, int logn, size_t idx) {
+  // 8 * logn words, cooperatively
+  for (int t = threadIdx.x; t < 8 * logn; t += kThreads) {
+    int l = t >> 3, j = t & 7;
+    size_t sib = (idx >> l) ^ 1;
+    dst[t] = Fp::raw(tree[(layer_off(logn, l) + sib) * 8 + j]).to_canonical();
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void assemble_kernel(AssembleArgs a) {
+  const int b = blockIdx.y, q = blockIdx.x;
+  const int W = a.width, logh = a.logh, logn = logh + 1;
+  const size_t h = (size_t)1 << logh, n = 2 * h;
+  uint32_t* body = a.body + (size_t)b * a.body_stride;
+  const uint32_t* tree_t = a.tree_t + (size_t)b * a.tree_t_stride;
+  const uint32_t* tree_q = a.tree_q + (size_t)b * a.tree_q_stride;
+  const uint32_t* fl = a.fri_layers + (size_t)b * a.fri_layer_stride;
+  const uint32_t* ft = a.fri_trees + (size_t)b * a.fri_tree_stride;
+  const size_t n_open_words = (size_t)(2 * W + 8) * 4;
+  const size_t off_opened = 16, off_fri_roots = off_opened + n_open_words, off_final = off_fri_roots + 8 * (size_t)logh,
+               off_witness = off_final + 4, off_queries = off_witness + 1;
+  if (q == a.n_queries) {
+    // fixed part
+    for (int t = threadIdx.x; t < 8; t += kThreads) {
+      body[t] = Fp::raw(tree_t[(2 * n - 2) * 8 + t]).to_canonical();
+      body[8 + t] = Fp::raw(tree_q[(2 * n - 2) * 8 + t]).to_canonical();
+    }
+    const uint32_t* op = a.opened + (size_t)b * a.opened_stride;
+    for (size_t t = threadIdx.x; t < n_open_words; t += kThreads) body[off_opened + t] = Fp::raw(op[t]).to_canonical();
+    size_t toff = 0, loff = 0;
+    for (int k = 0; k < logh; ++k) {
+      size_t hk = h >> k;
+      if (threadIdx.x < 8)
+        body[off_fri_roots + 8 * (size_t)k + threadIdx.x] = Fp::raw(ft[(toff + 2 * hk - 2) * 8 + threadIdx.x]).to_canonical();
+      toff += 2 * hk - 1;
+      loff += 2 * hk * 4;
+    }
+    if (threadIdx.x < 4) body[off_final + threadIdx.x] = Fp::raw(fl[loff + threadIdx.x]).to_canonical();
+    if (threadIdx.x == 0) body[off_witness] = a.witness[b];
+    return;
+  }
+  size_t perq = (size_t)W + 8 * (size_t)logn + 8 + 8 * (size_t)logn;
+  for (int k = 0; k < logh; ++k) perq += 8 + 8 * (size_t)(logh - k);
+  uint32_t* dst = body + off_queries + perq * (size_t)q;
+  const size_t idx = a.indices[(size_t)b * a.n_queries + q];
+  const size_t c = idx >> logh, m = idx & (h - 1);
+  const uint32_t* lt = a.lde_t + (size_t)b * a.lde_t_stride + c * h + m;
+  for (int i = threadIdx.x; i < W; i += kThreads) dst[i] = Fp::raw(lt[(size_t)i * n]).to_canonical();
+  dst += W;
+  put_path(dst, tree_t, logn, idx);
+  dst += 8 * logn;
+  const uint32_t* lq = a.lde_q + (size_t)b * a.lde_q_stride + c * h + m;
+  if (threadIdx.x < 8) dst[threadIdx.x] = Fp::raw(lq[(size_t)threadIdx.x * n]).to_canonical();
+  dst += 8;
+  put_path(dst, tree_q, logn, idx);
+  dst += 8 * logn;
+  size_t toff = 0, loff = 0;
+  for (int k = 0; k < logh; ++k) {
+    const int loghk = logh - k;
+    const size_t hk = h >> k, half = hk >> 1;
+    const size_t mk = m & (half - 1);
+    const size_t leaf = c * half + mk;
+    if (threadIdx.x < 4) {
+      dst[threadIdx.x] = Fp::raw(fl[loff + (c * hk + mk) * 4 + threadIdx.x]).to_canonical();
+      dst[4 + threadIdx.x] = Fp::raw(fl[loff + (c * hk + mk + half) * 4 + threadIdx.x]).to_canonical();
+    }
+    dst += 8;
+    put_path(dst, ft + toff * 8, loghk, leaf);
+    dst += 8 * loghk;
+    toff += 2 * hk - 1;
+    loff += 2 * hk * 4;
+  }
+}
+
+void launch_assemble(hipStream_t stream, const AssembleArgs& a) {
+  hipLaunchKernelGGL(assemble_kernel, dim3(a.n_queries + 1, a.batch), dim3(kThreads), 0, stream, a);
+}
+
+}  // namespace zksp

@@ -1,0 +1,622 @@
+// C ABI of include/zksp.h.  Nothing here throws across the boundary.
+#include "../../../include/zksp.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <map>
+#include <new>
+#include <thread>
+
+#include "context.hpp"
+#include "prover.hpp"
+#include "verifier.hpp"
+
+using namespace zksp;
+
+struct zksp_client { Context ctx; };
+struct zksp_pk { ElfImage elf; uint32_t vk_digest[8]; };
+struct zksp_vk { uint32_t digest[8]; };
+struct zksp_stdin { std::vector<std::vector<uint8_t>> entries; };
+struct zksp_proof { std::vector<uint8_t> bytes; ProofHeader hdr; };
+
+namespace {
+
+void compute_vk_digest(const ElfImage& elf, uint32_t out[8]) {
+  // vk = keccak256(sha256(ELF) || chip/parameter tag), 8 words reduced into the field
+  static const char tag[] = "zksp/vk/keccak-chip/w2633/c3182/blowup2/v1";
+  std::vector<uint8_t> buf(elf.sha256.begin(), elf.sha256.end());
+  buf.insert(buf.end(), tag, tag + sizeof(tag) - 1);
+  uint8_t dg[32];
+  keccak256(buf.data(), buf.size(), dg);
+  for (int i = 0; i < 8; ++i) {
+    uint32_t w;
+    memcpy(&w, dg + 4 * i, 4);
+    out[i] = w % kP;
+  }
+}
+
+int ceil_log2(size_t v) {
+  int l = 0;
+  while (((size_t)1 << l) < v) ++l;
+  return l;
+}
+
+int trace_log_height(size_t n_perms) {
+  int l = ceil_log2(std::max<size_t>(24 * n_perms, 32));
+  return l;
+}
+
+struct Job {
+  size_t index;
+  ExecutionRecord rec;
+  int logh;
+};
+
+}  // namespace
+
+extern "C" {
+
+int zksp_client_new(const zksp_options* opts, zksp_client** out) {
+  if (!out) return ZKSP_ERR_INVALID_ARG;
+  *out = nullptr;
+  zksp_client* c = new (std::nothrow) zksp_client();
+  if (!c) return ZKSP_ERR_INVALID_ARG;
+  Context& ctx = c->ctx;
+  int dev = opts ? opts->device_ordinal : 0;
+  if (opts) {
+    if (opts->keccak_mode) ctx.params.keccak_mode = opts->keccak_mode;
+    if (opts->num_queries) ctx.params.num_queries = opts->num_queries;
+    if (opts->pow_bits != 0xffffffffu) ctx.params.pow_bits = opts->pow_bits;
+    if (opts->max_batch) ctx.params.max_batch = opts->max_batch;
+  }
+  if (ctx.params.keccak_mode != 1 && ctx.params.keccak_mode != 2) { delete c; return ZKSP_ERR_INVALID_ARG; }
+  if (ctx.params.pow_bits > 30 || ctx.params.num_queries > 4096) { delete c; return ZKSP_ERR_INVALID_ARG; }
+  if (dev >= 0) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || dev >= count) { delete c; return ZKSP_ERR_NO_DEVICE; }
+    if (hipSetDevice(dev) != hipSuccess) { delete c; return ZKSP_ERR_NO_DEVICE; }
+    ctx.device = dev;
+    bool ok = hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMalloc(&ctx.d_consts, sizeof(P2Consts)) == hipSuccess;
+    ok = ok && hipMemcpy(ctx.d_consts, &host_p2_consts(), sizeof(P2Consts), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipEventCreate(&ctx.timer_a) == hipSuccess && hipEventCreate(&ctx.timer_b) == hipSuccess;
+    ok = ok && lde_configure() == (int)hipSuccess;
+    if (!ok) { delete c; return ZKSP_ERR_HIP; }
+  }
+  *out = c;
+  return ZKSP_OK;
+}
+
+void zksp_client_free(zksp_client* c) { delete c; }
+
+const char* zksp_last_error(const zksp_client* c) { return c ? c->ctx.error.c_str() : "null client"; }
+
+int zksp_setup(zksp_client* c, const uint8_t* elf, size_t elf_len, zksp_pk** pk, zksp_vk** vk) {
+  if (!c || !elf || !pk || !vk) return ZKSP_ERR_INVALID_ARG;
+  zksp_pk* p = new (std::nothrow) zksp_pk();
+  zksp_vk* v = new (std::nothrow) zksp_vk();
+  if (!p || !v) { delete p; delete v; return ZKSP_ERR_INVALID_ARG; }
+  std::string e = load_elf(elf, elf_len, &p->elf);
+  if (!e.empty()) { delete p; delete v; return c->ctx.fail(ZKSP_ERR_ELF, "setup: " + e); }
+  if (p->elf.keccakf_entries.empty()) {
+    delete p; delete v;
+    return c->ctx.fail(ZKSP_ERR_ELF, "setup: ELF has no keccakf symbol; the keccak chip has nothing to prove");
+  }
+  compute_vk_digest(p->elf, p->vk_digest);
+  memcpy(v->digest, p->vk_digest, 32);
+  *pk = p;
+  *vk = v;
+  return ZKSP_OK;
+}
+void zksp_pk_free(zksp_pk* pk) { delete pk; }
+void zksp_vk_free(zksp_vk* vk) { delete vk; }
+int zksp_vk_digest(const zksp_vk* vk, const uint8_t** ptr, size_t* len) {
+  if (!vk || !ptr || !len) return ZKSP_ERR_INVALID_ARG;
+  *ptr = reinterpret_cast<const uint8_t*>(vk->digest);
+  *len = 32;
+  return ZKSP_OK;
+}
+
+zksp_stdin* zksp_stdin_new(void) { return new (std::nothrow) zksp_stdin(); }
+int zksp_stdin_write(zksp_stdin* s, const uint8_t* buf, size_t len) {
+  if (!s || (!buf && len)) return ZKSP_ERR_INVALID_ARG;
+  std::vector<uint8_t> e(8 + len);
+  uint64_t l = len;
+  memcpy(e.data(), &l, 8);  // bincode Vec<u8>: u64-LE length prefix
+  if (len) memcpy(e.data() + 8, buf, len);
+  s->entries.push_back(std::move(e));
+  return ZKSP_OK;
+}
+void zksp_stdin_free(zksp_stdin* s) { delete s; }
+
+int zksp_execute(zksp_client* c, const zksp_pk* pk, const zksp_stdin* stdin_, int keccak_mode, zksp_exec_report* report,
+                 uint8_t* public_values, size_t pv_cap, char* stderr_buf, size_t stderr_cap) {
+  if (!c || !pk || !stdin_ || !report || keccak_mode < 0 || keccak_mode > 2) return ZKSP_ERR_INVALID_ARG;
+  ExecOptions o;
+  o.keccak_mode = (KeccakMode)keccak_mode;
+  o.want_hist = true;
+  ExecutionRecord r = execute(pk->elf, stdin_->entries, o);
+  memset(report, 0, sizeof *report);
+  report->cycles = r.cycles;
+  report->memory_ops = r.memory_ops;
+  report->exit_code = r.exit_code;
+  report->n_keccak = (uint32_t)r.keccak_events.size();
+  report->pv_len = (uint32_t)r.public_values.size();
+  memcpy(report->pv_digest, r.pv_digest.data(), 32);
+  const int codes[6] = {0x00, 0x02, 0x10, 0x1a, 0xf0, 0xf1};
+  for (int i = 0; i < 6; ++i) report->syscalls[i] = r.syscall_counts[codes[i]];
+  for (size_t i = 0; i < r.opcode_hist.size() && i < 64; ++i) report->opcode_hist[i] = r.opcode_hist[i];
+  if (public_values && pv_cap) memcpy(public_values, r.public_values.data(), std::min(pv_cap, r.public_values.size()));
+  if (stderr_buf && stderr_cap) {
+    size_t m = std::min(stderr_cap - 1, r.stderr_text.size());
+    memcpy(stderr_buf, r.stderr_text.data(), m);
+    stderr_buf[m] = 0;
+  }
+  if (!r.error.empty()) return c->ctx.fail(ZKSP_ERR_EXECUTOR, "executor: " + r.error);
+  if (!r.halted) return c->ctx.fail(ZKSP_ERR_EXECUTOR, "executor: guest did not halt");
+  return ZKSP_OK;
+}
+const char* zksp_opcode_name(int index) { return op_name(index); }
+
+int zksp_get_params(const zksp_client* c, zksp_params* out) {
+  if (!c || !out) return ZKSP_ERR_INVALID_ARG;
+  out->trace_width = kTraceWidth;
+  out->num_constraints = kNumConstraints;
+  out->num_queries = c->ctx.params.num_queries;
+  out->pow_bits = c->ctx.params.pow_bits;
+  out->max_batch = c->ctx.params.max_batch;
+  return ZKSP_OK;
+}
+size_t zksp_proof_body_words(const zksp_client* c, int log_h) {
+  if (!c || log_h < 1 || log_h > 26) return 0;
+  return proof_body_words(log_h, c->ctx.params.num_queries);
+}
+
+// ---------------------------------------------------------------------------
+// device-resident hot path
+// ---------------------------------------------------------------------------
+int zksp_hip_load_batch(zksp_client* c, int log_h, size_t n, size_t max_perms, const uint64_t* states,
+                        const uint32_t* n_perms, const uint32_t* init_obs) {
+  if (!c || !states || !n_perms || !init_obs || n == 0 || max_perms == 0) return ZKSP_ERR_INVALID_ARG;
+  Context* ctx = &c->ctx;
+  if (!ctx->has_device()) return ctx->fail(ZKSP_ERR_NO_DEVICE, "load_batch: client has no GPU");
+  if (log_h < 5 || log_h > 14) return ctx->fail(ZKSP_ERR_UNSUPPORTED, "load_batch: log_h must be in [5, 14]");
+  for (size_t i = 0; i < n; ++i)
+    if ((size_t)n_perms[i] > max_perms || (size_t)n_perms[i] * 24 > ((size_t)1 << log_h))
+      return ctx->fail(ZKSP_ERR_INVALID_ARG, "load_batch: n_perms does not fit the trace height");
+  ZKSP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int rc = workspace_ensure(ctx, log_h, (int)n, (int)max_perms);
+  if (rc) return rc;
+  Workspace* ws = ctx->ws.get();
+  if (!ctx->domain(log_h)) return ZKSP_ERR_HIP;
+  // states arrive [n][max_perms][25]; the workspace may have a larger perm stride
+  if ((size_t)ws->max_perms == max_perms) {
+    ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(ws->states, states, n * max_perms * 200, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    ZKSP_HIP_CHECK(ctx, hipMemcpy2DAsync(ws->states, (size_t)ws->max_perms * 200, states, max_perms * 200,
+                                         max_perms * 200, n, hipMemcpyHostToDevice, ctx->stream));
+  }
+  ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(ws->n_perms, n_perms, n * 4, hipMemcpyHostToDevice, ctx->stream));
+  ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(ws->init_obs, init_obs, n * kInitObs * 4, hipMemcpyHostToDevice, ctx->stream));
+  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ws->n = (int)n;
+  return ZKSP_OK;
+}
+
+int zksp_hip_prove_resident(zksp_client* c) {
+  if (!c) return ZKSP_ERR_INVALID_ARG;
+  if (!c->ctx.has_device()) return c->ctx.fail(ZKSP_ERR_NO_DEVICE, "prove_resident: client has no GPU");
+  ZKSP_HIP_CHECK(&c->ctx, hipSetDevice(c->ctx.device));
+  return prove_resident(&c->ctx);
+}
+
+int zksp_hip_fetch_bodies(zksp_client* c, uint32_t* out, size_t cap_words) {
+  if (!c || !out) return ZKSP_ERR_INVALID_ARG;
+  Context* ctx = &c->ctx;
+  Workspace* ws = ctx->ws.get();
+  if (!ws || ws->n == 0) return ctx->fail(ZKSP_ERR_INVALID_ARG, "fetch_bodies: no batch");
+  size_t words = (size_t)ws->n * ws->body_words;
+  if (cap_words < words) return ctx->fail(ZKSP_ERR_INVALID_ARG, "fetch_bodies: buffer too small");
+  ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(out, ws->body, words * 4, hipMemcpyDeviceToHost, ctx->stream));
+  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return ZKSP_OK;
+}
+
+int zksp_hip_sync(zksp_client* c) {
+  if (!c || !c->ctx.has_device()) return ZKSP_ERR_INVALID_ARG;
+  ZKSP_HIP_CHECK(&c->ctx, hipStreamSynchronize(c->ctx.stream));
+  return ZKSP_OK;
+}
+int zksp_hip_timer_start(zksp_client* c) {
+  if (!c || !c->ctx.has_device()) return ZKSP_ERR_INVALID_ARG;
+  ZKSP_HIP_CHECK(&c->ctx, hipEventRecord(c->ctx.timer_a, c->ctx.stream));
+  return ZKSP_OK;
+}
+int zksp_hip_timer_stop(zksp_client* c, float* ms) {
+  if (!c || !ms || !c->ctx.has_device()) return ZKSP_ERR_INVALID_ARG;
+  ZKSP_HIP_CHECK(&c->ctx, hipEventRecord(c->ctx.timer_b, c->ctx.stream));
+  ZKSP_HIP_CHECK(&c->ctx, hipEventSynchronize(c->ctx.timer_b));
+  ZKSP_HIP_CHECK(&c->ctx, hipEventElapsedTime(ms, c->ctx.timer_a, c->ctx.timer_b));
+  return ZKSP_OK;
+}
+int zksp_hip_profile_enable(zksp_client* c, int on) {
+  if (!c) return ZKSP_ERR_INVALID_ARG;
+  c->ctx.profile = on != 0;
+  return ZKSP_OK;
+}
+int zksp_hip_profile_reset(zksp_client* c) {
+  if (!c) return ZKSP_ERR_INVALID_ARG;
+  c->ctx.spans.clear();
+  c->ctx.event_used = 0;
+  return ZKSP_OK;
+}
+int zksp_hip_profile_read(zksp_client* c, const char* kernel, double* total_ms, uint64_t* launches) {
+  if (!c || !kernel || !total_ms || !launches || !c->ctx.has_device()) return ZKSP_ERR_INVALID_ARG;
+  Context* ctx = &c->ctx;
+  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  double tot = 0;
+  uint64_t cnt = 0;
+  for (auto& sp : ctx->spans)
+    if (sp.name == kernel) {
+      float ms = 0;
+      ZKSP_HIP_CHECK(ctx, hipEventElapsedTime(&ms, sp.a, sp.b));
+      tot += ms;
+      ++cnt;
+    }
+  *total_ms = tot;
+  *launches = cnt;
+  return ZKSP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// prove / verify
+// ---------------------------------------------------------------------------
+int zksp_prove_batch(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdins, size_t n, zksp_proof** out,
+                     int32_t* status) {
+  if (!c || !pk || !stdins || !out || !status || n == 0) return ZKSP_ERR_INVALID_ARG;
+  Context* ctx = &c->ctx;
+  if (!ctx->has_device())
+    return ctx->fail(ZKSP_ERR_NO_DEVICE, "prove: this client was created without a GPU; there is no CPU proving path");
+  for (size_t i = 0; i < n; ++i) { out[i] = nullptr; status[i] = ZKSP_ERR_INVALID_ARG; }
+  // 1. executor (host, one guest run per input, farmed over host threads)
+  std::vector<Job> jobs(n);
+  {
+    std::atomic<size_t> next{0};
+    unsigned nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)n));
+    auto work = [&]() {
+      for (;;) {
+        size_t i = next.fetch_add(1);
+        if (i >= n) break;
+        jobs[i].index = i;
+        if (!stdins[i]) continue;
+        ExecOptions o;
+        o.keccak_mode = (KeccakMode)ctx->params.keccak_mode;
+        jobs[i].rec = execute(pk->elf, stdins[i]->entries, o);
+        stdins[i]->entries.clear();  // consumed, as SP1Stdin is by prove()
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+  }
+  std::map<int, std::vector<size_t>> by_height;
+  std::string first_err;
+  for (size_t i = 0; i < n; ++i) {
+    ExecutionRecord& r = jobs[i].rec;
+    if (!stdins[i]) continue;
+    if (!r.error.empty() || !r.halted) {
+      status[i] = ZKSP_ERR_EXECUTOR;
+      if (first_err.empty()) first_err = "executor: " + (r.error.empty() ? std::string("guest did not halt") : r.error);
+      continue;
+    }
+    if (r.exit_code != 0) {
+      status[i] = ZKSP_ERR_GUEST_PANIC;
+      if (first_err.empty()) first_err = "guest panicked (exit code " + std::to_string(r.exit_code) + "): " + r.stderr_text;
+      continue;
+    }
+    if (r.keccak_events.empty()) {
+      status[i] = ZKSP_ERR_EXECUTOR;
+      if (first_err.empty()) first_err = "guest made no keccak-f calls";
+      continue;
+    }
+    jobs[i].logh = trace_log_height(r.keccak_events.size());
+    if (jobs[i].logh > 14) { status[i] = ZKSP_ERR_UNSUPPORTED; continue; }
+    by_height[jobs[i].logh].push_back(i);
+  }
+  // 2. device proving, grouped by trace height, max_batch proofs in lockstep
+  int rc_all = ZKSP_OK;
+  for (auto& kv : by_height) {
+    const int logh = kv.first;
+    const std::vector<size_t>& idxs = kv.second;
+    for (size_t off = 0; off < idxs.size(); off += ctx->params.max_batch) {
+      const size_t cnt = std::min<size_t>(ctx->params.max_batch, idxs.size() - off);
+      size_t max_perms = 0;
+      for (size_t j = 0; j < cnt; ++j) max_perms = std::max(max_perms, jobs[idxs[off + j]].rec.keccak_events.size());
+      std::vector<uint64_t> states(cnt * max_perms * 25, 0);
+      std::vector<uint32_t> np(cnt), obs(cnt * kInitObs);
+      for (size_t j = 0; j < cnt; ++j) {
+        const ExecutionRecord& r = jobs[idxs[off + j]].rec;
+        for (size_t p = 0; p < r.keccak_events.size(); ++p)
+          memcpy(&states[(j * max_perms + p) * 25], r.keccak_events[p].state_in, 200);
+        np[j] = (uint32_t)r.keccak_events.size();
+        uint32_t* o = &obs[j * kInitObs];
+        memcpy(o, pk->vk_digest, 32);
+        o[8] = (uint32_t)logh;
+        o[9] = np[j];
+        o[10] = r.exit_code & 0xffff;
+        o[11] = r.exit_code >> 16;
+        for (int w = 0; w < 8; ++w) {
+          o[12 + 2 * w] = r.pv_digest[w] & 0xffff;
+          o[13 + 2 * w] = r.pv_digest[w] >> 16;
+          o[28 + 2 * w] = r.deferred_digest[w] & 0xffff;
+          o[29 + 2 * w] = r.deferred_digest[w] >> 16;
+        }
+      }
+      int rc = zksp_hip_load_batch(c, logh, cnt, max_perms, states.data(), np.data(), obs.data());
+      if (rc == ZKSP_OK) rc = zksp_hip_prove_resident(c);
+      const size_t bw = proof_body_words(logh, ctx->params.num_queries);
+      std::vector<uint32_t> bodies(cnt * bw);
+      if (rc == ZKSP_OK) rc = zksp_hip_fetch_bodies(c, bodies.data(), bodies.size());
+      if (rc != ZKSP_OK) {
+        for (size_t j = 0; j < cnt; ++j) status[idxs[off + j]] = rc;
+        rc_all = rc;
+        continue;
+      }
+      for (size_t j = 0; j < cnt; ++j) {
+        const size_t i = idxs[off + j];
+        const ExecutionRecord& r = jobs[i].rec;
+        zksp_proof* p = new (std::nothrow) zksp_proof();
+        if (!p) { status[i] = ZKSP_ERR_INVALID_ARG; continue; }
+        const uint32_t pv_len = (uint32_t)r.public_values.size();
+        const size_t hw = proof_header_words(pv_len);
+        p->bytes.assign((hw + bw) * 4, 0);
+        uint32_t* w = reinterpret_cast<uint32_t*>(p->bytes.data());
+        w[0] = kProofMagic; w[1] = kProofVersion; w[2] = (uint32_t)logh; w[3] = np[j]; w[4] = r.exit_code; w[5] = pv_len;
+        memcpy(w + 6, r.pv_digest.data(), 32);
+        memcpy(w + 14, r.deferred_digest.data(), 32);
+        memcpy(w + 22, pk->vk_digest, 32);
+        if (pv_len) memcpy(p->bytes.data() + 120, r.public_values.data(), pv_len);
+        memcpy(w + hw, &bodies[j * bw], bw * 4);
+        std::string perr;
+        if (!parse_proof_header(p->bytes.data(), p->bytes.size(), &p->hdr, &perr)) {
+          delete p;
+          status[i] = ZKSP_ERR_PROOF_FORMAT;
+          continue;
+        }
+        out[i] = p;
+        status[i] = ZKSP_OK;
+      }
+    }
+  }
+  if (!first_err.empty() && rc_all == ZKSP_OK) ctx->error = first_err;
+  return rc_all;
+}
+
+int zksp_prove(zksp_client* c, const zksp_pk* pk, zksp_stdin* stdin_, zksp_proof** out) {
+  if (!c || !pk || !stdin_ || !out) return ZKSP_ERR_INVALID_ARG;
+  int32_t st = 0;
+  zksp_stdin* arr[1] = {stdin_};
+  int rc = zksp_prove_batch(c, pk, arr, 1, out, &st);
+  return rc != ZKSP_OK ? rc : st;
+}
+
+int zksp_proof_public_values(const zksp_proof* p, const uint8_t** ptr, size_t* len) {
+  if (!p || !ptr || !len) return ZKSP_ERR_INVALID_ARG;
+  *ptr = p->bytes.data() + p->hdr.pv_offset;
+  *len = p->hdr.pv_len;
+  return ZKSP_OK;
+}
+int zksp_proof_serialize(const zksp_proof* p, const uint8_t** ptr, size_t* len) {
+  if (!p || !ptr || !len) return ZKSP_ERR_INVALID_ARG;
+  *ptr = p->bytes.data();
+  *len = p->bytes.size();
+  return ZKSP_OK;
+}
+int zksp_proof_deserialize(const uint8_t* buf, size_t len, zksp_proof** out) {
+  if (!buf || !out) return ZKSP_ERR_INVALID_ARG;
+  zksp_proof* p = new (std::nothrow) zksp_proof();
+  if (!p) return ZKSP_ERR_INVALID_ARG;
+  p->bytes.assign(buf, buf + len);
+  std::string err;
+  if (!parse_proof_header(p->bytes.data(), p->bytes.size(), &p->hdr, &err)) {
+    delete p;
+    return ZKSP_ERR_PROOF_FORMAT;
+  }
+  *out = p;
+  return ZKSP_OK;
+}
+void zksp_proof_free(zksp_proof* p) { delete p; }
+
+int zksp_verify(zksp_client* c, const zksp_proof* p, const zksp_vk* vk) {
+  if (!c || !p || !vk) return ZKSP_ERR_INVALID_ARG;
+  std::string err;
+  int rc = verify_proof(p->bytes.data(), p->bytes.size(), vk->digest, c->ctx.params.num_queries, c->ctx.params.pow_bits,
+                        &err);
+  if (rc) return c->ctx.fail(rc, "verify: " + err);
+  return ZKSP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// kernel-level entry points
+// ---------------------------------------------------------------------------
+#define NEED_GPU(c)                                                                  \
+  if (!(c)) return ZKSP_ERR_INVALID_ARG;                                             \
+  if (!(c)->ctx.has_device()) return (c)->ctx.fail(ZKSP_ERR_NO_DEVICE, "no GPU bound to this client"); \
+  ZKSP_HIP_CHECK(&(c)->ctx, hipSetDevice((c)->ctx.device))
+
+int zksp_dev_malloc(zksp_client* c, size_t bytes, void** out) {
+  NEED_GPU(c);
+  if (!out) return ZKSP_ERR_INVALID_ARG;
+  ZKSP_HIP_CHECK(&c->ctx, hipMalloc(out, bytes));
+  return ZKSP_OK;
+}
+int zksp_dev_free(zksp_client* c, void* p) {
+  NEED_GPU(c);
+  ZKSP_HIP_CHECK(&c->ctx, hipStreamSynchronize(c->ctx.stream));
+  ZKSP_HIP_CHECK(&c->ctx, hipFree(p));
+  return ZKSP_OK;
+}
+int zksp_dev_upload(zksp_client* c, void* dst, const void* src, size_t bytes) {
+  NEED_GPU(c);
+  ZKSP_HIP_CHECK(&c->ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->ctx.stream));
+  ZKSP_HIP_CHECK(&c->ctx, hipStreamSynchronize(c->ctx.stream));
+  return ZKSP_OK;
+}
+int zksp_dev_download(zksp_client* c, void* dst, const void* src, size_t bytes) {
+  NEED_GPU(c);
+  ZKSP_HIP_CHECK(&c->ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->ctx.stream));
+  ZKSP_HIP_CHECK(&c->ctx, hipStreamSynchronize(c->ctx.stream));
+  return ZKSP_OK;
+}
+int zksp_dev_memset(zksp_client* c, void* dst, int value, size_t bytes) {
+  NEED_GPU(c);
+  ZKSP_HIP_CHECK(&c->ctx, hipMemsetAsync(dst, value, bytes, c->ctx.stream));
+  return ZKSP_OK;
+}
+
+static inline uint32_t bitrev32(uint32_t v, int bits) {
+  uint32_t r = 0;
+  for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1u) << (bits - 1 - i);
+  return r;
+}
+
+int zksp_hip_lde(zksp_client* c, const uint32_t* d_in, int log_h, size_t ncols, uint32_t in_shift, uint32_t* d_coefs_br,
+                 uint32_t* d_lde) {
+  NEED_GPU(c);
+  Context* ctx = &c->ctx;
+  if (!d_in || !d_lde || in_shift == 0 || in_shift >= kP) return ZKSP_ERR_INVALID_ARG;
+  const DeviceDomain* dom = ctx->domain(log_h);
+  if (!dom) return ZKSP_ERR_UNSUPPORTED;
+  const size_t h = (size_t)1 << log_h;
+  const uint32_t* table = nullptr;
+  uint32_t* tmp = nullptr;
+  const Fp g = Fp::from_canonical(kGen);
+  if (in_shift == 1) table = dom->in_scale_br;
+  else if (in_shift == g.to_canonical()) table = dom->in_scale_br + h;
+  else if (in_shift == (g * fp_root_of_unity(log_h + 1)).to_canonical()) table = dom->in_scale_br + 2 * h;
+  else {
+    std::vector<uint32_t> nat(h), br(h);
+    const Fp si = Fp::from_canonical(in_shift).inv();
+    Fp p = Fp::from_canonical((uint32_t)(h % kP)).inv();
+    for (size_t k = 0; k < h; ++k) { nat[k] = p.v; p = p * si; }
+    for (size_t pos = 0; pos < h; ++pos) br[pos] = nat[bitrev32((uint32_t)pos, log_h)];
+    ZKSP_HIP_CHECK(ctx, hipMalloc(&tmp, h * 4));
+    ZKSP_HIP_CHECK(ctx, hipMemcpy(tmp, br.data(), h * 4, hipMemcpyHostToDevice));
+    table = tmp;
+  }
+  launch_lde(ctx->stream, d_in, d_coefs_br, d_lde, dom->tw_fwd, dom->tw_inv, table, 0, 0, dom->out_scale_br, log_h, ncols);
+  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (tmp) ZKSP_HIP_CHECK(ctx, hipFree(tmp));
+  ZKSP_HIP_CHECK(ctx, hipGetLastError());
+  return ZKSP_OK;
+}
+
+int zksp_hip_merkle_commit(zksp_client* c, const uint32_t* d_mat, int width, int log_n, uint32_t* d_tree) {
+  NEED_GPU(c);
+  if (!d_mat || !d_tree || width < 0 || log_n < 0 || log_n > 28) return ZKSP_ERR_INVALID_ARG;
+  const size_t n = (size_t)1 << log_n;
+  launch_merkle_commit(c->ctx.stream, d_mat, (size_t)width * n, width, log_n, d_tree, (2 * n - 1) * 8, 1, c->ctx.d_consts);
+  ZKSP_HIP_CHECK(&c->ctx, hipStreamSynchronize(c->ctx.stream));
+  ZKSP_HIP_CHECK(&c->ctx, hipGetLastError());
+  return ZKSP_OK;
+}
+
+int zksp_hip_poseidon2_permute(zksp_client* c, uint32_t* d_states, size_t n) {
+  NEED_GPU(c);
+  if (!d_states) return ZKSP_ERR_INVALID_ARG;
+  launch_poseidon2_permute(c->ctx.stream, d_states, n, c->ctx.d_consts);
+  ZKSP_HIP_CHECK(&c->ctx, hipStreamSynchronize(c->ctx.stream));
+  ZKSP_HIP_CHECK(&c->ctx, hipGetLastError());
+  return ZKSP_OK;
+}
+
+int zksp_hip_keccak_trace(zksp_client* c, const uint64_t* d_states, uint32_t n_perms, int log_h, uint32_t* d_trace) {
+  NEED_GPU(c);
+  Context* ctx = &c->ctx;
+  if (!d_states || !d_trace || log_h < 1 || log_h > 26 || (size_t)n_perms * 24 > ((size_t)1 << log_h)) return ZKSP_ERR_INVALID_ARG;
+  uint32_t* d_np = nullptr;
+  ZKSP_HIP_CHECK(ctx, hipMalloc(&d_np, 4));
+  ZKSP_HIP_CHECK(ctx, hipMemcpy(d_np, &n_perms, 4, hipMemcpyHostToDevice));
+  launch_keccak_trace(ctx->stream, d_states, (int)std::max<uint32_t>(n_perms, 1), d_np, d_trace, log_h, 1);
+  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ZKSP_HIP_CHECK(ctx, hipFree(d_np));
+  ZKSP_HIP_CHECK(ctx, hipGetLastError());
+  return ZKSP_OK;
+}
+
+int zksp_hip_keccak_quotient(zksp_client* c, const uint32_t* d_lde, int log_h, const uint32_t* alpha,
+                             uint32_t* d_quot) {
+  NEED_GPU(c);
+  Context* ctx = &c->ctx;
+  if (!d_lde || !alpha || !d_quot) return ZKSP_ERR_INVALID_ARG;
+  const DeviceDomain* dom = ctx->domain(log_h);
+  if (!dom) return ZKSP_ERR_UNSUPPORTED;
+  const size_t n = (size_t)2 << log_h;
+  uint32_t am[4];
+  for (int i = 0; i < 4; ++i) {
+    if (alpha[i] >= kP) return ZKSP_ERR_INVALID_ARG;
+    am[i] = Fp::from_canonical(alpha[i]).v;
+  }
+  uint32_t *d_alpha = nullptr, *d_pows = nullptr, *d_partial = nullptr;
+  ZKSP_HIP_CHECK(ctx, hipMalloc(&d_alpha, 16));
+  ZKSP_HIP_CHECK(ctx, hipMalloc(&d_pows, (size_t)kNumConstraints * 16));
+  ZKSP_HIP_CHECK(ctx, hipMalloc(&d_partial, (size_t)62 * n * 16));
+  ZKSP_HIP_CHECK(ctx, hipMemcpy(d_alpha, am, 16, hipMemcpyHostToDevice));
+  launch_ext_powers(ctx->stream, d_alpha, 4, kR1, d_pows, (size_t)kNumConstraints * 4, kNumConstraints, 0, 1);
+  launch_keccak_quotient(ctx->stream, d_lde, d_pows, dom->sel_first, dom->sel_trans, dom->zh_inv, d_partial, d_quot, log_h, 1);
+  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ZKSP_HIP_CHECK(ctx, hipFree(d_alpha));
+  ZKSP_HIP_CHECK(ctx, hipFree(d_pows));
+  ZKSP_HIP_CHECK(ctx, hipFree(d_partial));
+  ZKSP_HIP_CHECK(ctx, hipGetLastError());
+  return ZKSP_OK;
+}
+
+int zksp_hip_fri_fold(zksp_client* c, const uint32_t* d_in, int log_hk, uint32_t shift_k, const uint32_t* beta,
+                      uint32_t* d_out) {
+  NEED_GPU(c);
+  Context* ctx = &c->ctx;
+  if (!d_in || !beta || !d_out || shift_k == 0 || shift_k >= kP) return ZKSP_ERR_INVALID_ARG;
+  const DeviceDomain* dom = ctx->domain(log_hk);
+  if (!dom) return ZKSP_ERR_UNSUPPORTED;
+  uint32_t bm[4];
+  for (int i = 0; i < 4; ++i) {
+    if (beta[i] >= kP) return ZKSP_ERR_INVALID_ARG;
+    bm[i] = Fp::from_canonical(beta[i]).v;
+  }
+  uint32_t* d_beta = nullptr;
+  ZKSP_HIP_CHECK(ctx, hipMalloc(&d_beta, 16));
+  ZKSP_HIP_CHECK(ctx, hipMemcpy(d_beta, bm, 16, hipMemcpyHostToDevice));
+  const Fp s = Fp::from_canonical(shift_k);
+  const uint32_t x0 = s.inv().v, x1 = (s * fp_root_of_unity(log_hk + 1)).inv().v;
+  launch_fri_fold(ctx->stream, d_in, 0, d_out, 0, d_beta, 0, dom->tw_inv, 0, x0, x1, log_hk, 1);
+  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ZKSP_HIP_CHECK(ctx, hipFree(d_beta));
+  ZKSP_HIP_CHECK(ctx, hipGetLastError());
+  return ZKSP_OK;
+}
+
+int zksp_hip_microbench(zksp_client* c, int which, double* gops) {
+  NEED_GPU(c);
+  Context* ctx = &c->ctx;
+  if (!gops || which < 0 || which > 5) return ZKSP_ERR_INVALID_ARG;
+  uint32_t* d = nullptr;
+  ZKSP_HIP_CHECK(ctx, hipMalloc(&d, 64));
+  const int blocks = 256 * 16, iters = 2000;
+  launch_rate_kernel(ctx->stream, which, d, blocks, 10);  // warm-up
+  ZKSP_HIP_CHECK(ctx, hipEventRecord(ctx->timer_a, ctx->stream));
+  launch_rate_kernel(ctx->stream, which, d, blocks, iters);
+  ZKSP_HIP_CHECK(ctx, hipEventRecord(ctx->timer_b, ctx->stream));
+  ZKSP_HIP_CHECK(ctx, hipEventSynchronize(ctx->timer_b));
+  float ms = 0;
+  ZKSP_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->timer_a, ctx->timer_b));
+  ZKSP_HIP_CHECK(ctx, hipFree(d));
+  // 4 independent chains x 16 unrolled steps per iteration, one op per step per chain
+  const double ops = (double)blocks * 256.0 * iters * 16.0 * 4.0;
+  *gops = ops / (ms * 1e-3) / 1e9;
+  return ZKSP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+// Per-client state: HIP device + stream, Poseidon2 constants, per-height domain
+// tables and the batch workspace of the device prover.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../device/kernels.h"
+#include "executor.hpp"
+
+namespace zksp {
+
+// Builds this repository's Poseidon2 instance (DESIGN.md "Poseidon2 instance"):
+// SHAKE256("zksp/poseidon2/babybear/w16/v1") -> 141 rejection-sampled words.
+void build_p2_consts(P2Consts* out_monty);
+const P2Consts& host_p2_consts();
+
+struct HostDomain {
+  int logh = 0;
+  std::vector<uint32_t> tw_fwd, tw_inv;          // [H/2]
+  std::vector<uint32_t> in_scale_br[3];          // [H]: trace (shift 1), quotient chunk 0, chunk 1
+  std::vector<uint32_t> out_scale_br;            // [2][H]
+  std::vector<uint32_t> xs, sel_first, sel_trans;  // [2][H]
+  uint32_t zh_inv[2];
+  uint32_t w_h;
+};
+void build_host_domain(int logh, HostDomain* d);
+
+struct DeviceDomain {
+  int logh = 0;
+  uint32_t *tw_fwd = nullptr, *tw_inv = nullptr, *in_scale_br = nullptr /*[3][H]: shift 1, g, g*w_2H*/,
+           *out_scale_br = nullptr, *xs = nullptr, *sel_first = nullptr, *sel_trans = nullptr, *zh_inv = nullptr;
+  uint32_t w_h = 0;
+  std::vector<uint32_t> fold_xinv;  // [logh][2] host copies of (shift_k * w_{2Hk}^c)^-1
+};
+
+struct Params {
+  uint32_t num_queries = 100;
+  uint32_t pow_bits = 16;
+  uint32_t max_batch = 16;
+  int keccak_mode = 2;
+};
+
+struct Workspace;  // prover.cpp
+
+struct Context {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  P2Consts* d_consts = nullptr;
+  Params params;
+  std::map<int, DeviceDomain> domains;
+  std::map<uint32_t, std::vector<uint32_t*>> qscale;  // custom in_shift scale tables for zksp_hip_lde
+  std::unique_ptr<Workspace> ws;
+  std::string error;
+  // profiling
+  bool profile = false;
+  struct Span { std::string name; hipEvent_t a, b; };
+  std::vector<Span> spans;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
+  size_t event_used = 0;
+  hipEvent_t timer_a = nullptr, timer_b = nullptr;
+
+  ~Context();
+  bool has_device() const { return device >= 0; }
+  int fail(int code, const std::string& msg) { error = msg; return code; }
+  const DeviceDomain* domain(int logh);  // builds + uploads on first use; nullptr on error
+};
+
+size_t proof_body_words(int logh, uint32_t num_queries);
+size_t proof_header_words(uint32_t pv_len);
+
+#define ZKSP_HIP_CHECK(ctx, call)                                                         \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return (ctx)->fail(3 /*ZKSP_ERR_HIP*/, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+}  // namespace zksp

@@ -1,0 +1,259 @@
+// Replaces the body of the reference's `client.prove(&pk, stdin).run()`
+// (prover/src/bin/main.rs:71-74) below the executor: sp1-prover / sp1-stark's
+// commit -> quotient -> open -> FRI flow, here as one fixed sequence of HIP kernel
+// launches per batch with the Fiat-Shamir transcript kept on the device.
+#include "prover.hpp"
+
+namespace zksp {
+
+Workspace::~Workspace() {
+  for (void* p : allocs)
+    if (p) (void)hipFree(p);
+}
+
+ProfileSpan::ProfileSpan(Context* c, const char* name) : ctx(c) {
+  if (!c->profile) return;
+  if (c->event_used == c->event_pool.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    c->event_pool.emplace_back(a, b);
+  }
+  auto& ev = c->event_pool[c->event_used++];
+  idx = c->spans.size();
+  c->spans.push_back({name, ev.first, ev.second});
+  (void)hipEventRecord(ev.first, c->stream);
+}
+ProfileSpan::~ProfileSpan() {
+  if (idx != (size_t)-1) (void)hipEventRecord(ctx->spans[idx].b, ctx->stream);
+}
+
+template <class T>
+static bool dalloc(Workspace* ws, T** p, size_t count) {
+  void* q = nullptr;
+  if (hipMalloc(&q, count * sizeof(T)) != hipSuccess) return false;
+  ws->allocs.push_back(q);
+  *p = static_cast<T*>(q);
+  return true;
+}
+
+static int ceil_log2(size_t v) {
+  int l = 0;
+  while (((size_t)1 << l) < v) ++l;
+  return l;
+}
+
+int workspace_ensure(Context* ctx, int logh, int batch, int max_perms) {
+  if (ctx->ws && ctx->ws->logh == logh && ctx->ws->batch >= batch && ctx->ws->max_perms >= max_perms) return 0;
+  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->ws.reset(new Workspace());
+  Workspace* ws = ctx->ws.get();
+  ws->logh = logh;
+  ws->batch = batch;
+  ws->max_perms = max_perms;
+  const size_t B = (size_t)batch, h = (size_t)1 << logh, n = 2 * h, W = kTraceWidth;
+  const uint32_t Q = ctx->params.num_queries;
+  ws->body_words = proof_body_words(logh, Q);
+  const size_t n_open_words = (2 * W + 8) * 4;
+  ws->open_rows_log = (size_t)ceil_log2((n_open_words + 7) / 8);
+  const size_t R = (size_t)1 << ws->open_rows_log;
+  ws->fri_layer_stride = 0;
+  ws->fri_tree_stride = 0;
+  for (int k = 0; k < logh; ++k) {
+    size_t hk = h >> k;
+    ws->fri_layer_stride += 2 * hk * 4;
+    ws->fri_tree_stride += (2 * hk - 1) * 8;
+  }
+  ws->fri_layer_stride += 2 * 4;  // the final 2-point layer
+  const size_t scratch_words = std::max<size_t>(W * h, std::max<size_t>((size_t)62 * n * 4, (size_t)reduce_nchunks((int)W) * n * 4));
+  bool ok = true;
+  ok &= dalloc(ws, &ws->states, B * (size_t)max_perms * 25);
+  ok &= dalloc(ws, &ws->n_perms, B);
+  ok &= dalloc(ws, &ws->init_obs, B * kInitObs);
+  ok &= dalloc(ws, &ws->trace, B * scratch_words);  // also quotient / reduce partial sums once the trace is dead
+  ok &= dalloc(ws, &ws->coef_t, B * W * h);
+  ok &= dalloc(ws, &ws->lde_t, B * W * n);
+  ok &= dalloc(ws, &ws->tree_t, B * (2 * n - 1) * 8);
+  ok &= dalloc(ws, &ws->ch, B);
+  ok &= dalloc(ws, &ws->alpha, B * 4);
+  ok &= dalloc(ws, &ws->alpha_pows, B * (size_t)kNumConstraints * 4);
+  ok &= dalloc(ws, &ws->quot, B * 8 * h);
+  ok &= dalloc(ws, &ws->coef_q, B * 8 * h);
+  ok &= dalloc(ws, &ws->lde_q, B * 8 * n);
+  ok &= dalloc(ws, &ws->tree_q, B * (2 * n - 1) * 8);
+  ok &= dalloc(ws, &ws->zeta, B * 4);
+  ok &= dalloc(ws, &ws->zpow, B * 2 * h * 4);
+  ok &= dalloc(ws, &ws->opened, B * 8 * R);
+  ok &= dalloc(ws, &ws->tree_o, B * (2 * R - 1) * 8);
+  ok &= dalloc(ws, &ws->af, B * 4);
+  ok &= dalloc(ws, &ws->af_pows, B * (2 * W + 8) * 4);
+  ok &= dalloc(ws, &ws->bsum, B * 3 * 4);
+  ok &= dalloc(ws, &ws->fri_layers, B * ws->fri_layer_stride);
+  ok &= dalloc(ws, &ws->fri_trees, B * ws->fri_tree_stride);
+  ok &= dalloc(ws, &ws->betas, B * (size_t)logh * 4);
+  ok &= dalloc(ws, &ws->witness, B);
+  ok &= dalloc(ws, &ws->indices, B * Q);
+  ok &= dalloc(ws, &ws->body, B * ws->body_words);
+  if (!ok) {
+    ctx->ws.reset();
+    return ctx->fail(3, "workspace: hipMalloc failed");
+  }
+  // the zero padding of the opened-value matrix is written once
+  ZKSP_HIP_CHECK(ctx, hipMemsetAsync(ws->opened, 0, B * 8 * R * 4, ctx->stream));
+  return 0;
+}
+
+int prove_resident(Context* ctx) {
+  Workspace* ws = ctx->ws.get();
+  if (!ws || ws->n == 0) return ctx->fail(1, "prove_resident: no batch loaded");
+  const DeviceDomain* dom = ctx->domain(ws->logh);
+  if (!dom) return 3;
+  hipStream_t s = ctx->stream;
+  const P2Consts* kc = ctx->d_consts;
+  const int logh = ws->logh, logn = logh + 1, B = ws->n, W = kTraceWidth;
+  const size_t h = (size_t)1 << logh, n = 2 * h;
+  const int Q = (int)ctx->params.num_queries, pow_bits = (int)ctx->params.pow_bits;
+  const size_t tree_stride = (2 * n - 1) * 8, root_off = (2 * n - 2) * 8;
+  const size_t R = (size_t)1 << ws->open_rows_log;
+
+  {
+    ProfileSpan sp(ctx, "keccak_trace");
+    launch_keccak_trace(s, ws->states, ws->max_perms, ws->n_perms, ws->trace, logh, B);
+  }
+  {
+    ProfileSpan sp(ctx, "lde_trace");
+    launch_lde(s, ws->trace, ws->coef_t, ws->lde_t, dom->tw_fwd, dom->tw_inv, dom->in_scale_br, 0, 0, dom->out_scale_br,
+               logh, (size_t)B * W);
+  }
+  {
+    ProfileSpan sp(ctx, "merkle_trace");
+    launch_merkle_commit(s, ws->lde_t, (size_t)W * n, W, logn, ws->tree_t, tree_stride, B, kc);
+  }
+  {
+    ProfileSpan sp(ctx, "transcript");
+    launch_ch_init(s, ws->ch, ws->init_obs, kInitObs, B, kc);
+    launch_ch_observe_sample(s, ws->ch, ws->tree_t + root_off, tree_stride, 8, ws->alpha, 4, 1, B, kc);
+    launch_ext_powers(s, ws->alpha, 4, kR1, ws->alpha_pows, (size_t)kNumConstraints * 4, kNumConstraints, 0, B);
+  }
+  {
+    ProfileSpan sp(ctx, "quotient");
+    launch_keccak_quotient(s, ws->lde_t, ws->alpha_pows, dom->sel_first, dom->sel_trans, dom->zh_inv, ws->trace,
+                           ws->quot, logh, B);
+  }
+  {
+    ProfileSpan sp(ctx, "lde_quot");
+    // columns 4c..4c+3 of every proof were evaluated over coset c: scale tables 1 and 2
+    launch_lde(s, ws->quot, ws->coef_q, ws->lde_q, dom->tw_fwd, dom->tw_inv, dom->in_scale_br + h, 2, 1,
+               dom->out_scale_br, logh, (size_t)B * 8);
+  }
+  {
+    ProfileSpan sp(ctx, "merkle_quot");
+    launch_merkle_commit(s, ws->lde_q, 8 * n, 8, logn, ws->tree_q, tree_stride, B, kc);
+  }
+  {
+    ProfileSpan sp(ctx, "transcript");
+    launch_ch_observe_sample(s, ws->ch, ws->tree_q + root_off, tree_stride, 8, ws->zeta, 4, 1, B, kc);
+    launch_ext_powers(s, ws->zeta, 4, kR1, ws->zpow, 2 * h * 4, (int)h, logh, B);
+    launch_ext_powers(s, ws->zeta, 4, dom->w_h, ws->zpow + h * 4, 2 * h * 4, (int)h, logh, B);
+  }
+  {
+    ProfileSpan sp(ctx, "open");
+    launch_open(s, ws->coef_t, (size_t)W * h, W, logh, ws->zpow, 2 * h * 4, 2, ws->opened, 8 * R, (size_t)W, B);
+    launch_open(s, ws->coef_q, 8 * h, 8, logh, ws->zpow, 2 * h * 4, 1, ws->opened + (size_t)2 * W * 4, 8 * R, 0, B);
+  }
+  {
+    ProfileSpan sp(ctx, "merkle_open");
+    launch_merkle_commit(s, ws->opened, 8 * R, 8, (int)ws->open_rows_log, ws->tree_o, (2 * R - 1) * 8, B, kc);
+  }
+  {
+    ProfileSpan sp(ctx, "transcript");
+    launch_ch_observe_sample(s, ws->ch, ws->tree_o + (2 * R - 2) * 8, (2 * R - 1) * 8, 8, ws->af, 4, 1, B, kc);
+    launch_ext_powers(s, ws->af, 4, kR1, ws->af_pows, (size_t)(2 * W + 8) * 4, 2 * W + 8, 0, B);
+  }
+  {
+    ProfileSpan sp(ctx, "reduce_openings");
+    ReduceArgs ra;
+    ra.lde_t = ws->lde_t;
+    ra.lde_q = ws->lde_q;
+    ra.af_pows = ws->af_pows;
+    ra.opened = ws->opened;
+    ra.opened_stride = 8 * R;
+    ra.zeta = ws->zeta;
+    ra.xs = dom->xs;
+    ra.partial = ws->trace;
+    ra.bsum = ws->bsum;
+    ra.out = ws->fri_layers;
+    ra.out_stride = ws->fri_layer_stride;
+    ra.w_h = dom->w_h;
+    ra.width = W;
+    ra.logh = logh;
+    ra.batch = B;
+    launch_reduce_openings(s, ra);
+  }
+  size_t loff = 0, toff = 0;
+  for (int k = 0; k < logh; ++k) {
+    const int loghk = logh - k;
+    const size_t hk = h >> k;
+    {
+      ProfileSpan sp(ctx, "fri_commit");
+      launch_fri_commit(s, ws->fri_layers + loff, ws->fri_layer_stride, loghk, ws->fri_trees + toff * 8,
+                        ws->fri_tree_stride, B, kc);
+    }
+    {
+      ProfileSpan sp(ctx, "transcript");
+      launch_ch_observe_sample(s, ws->ch, ws->fri_trees + (toff + 2 * hk - 2) * 8, ws->fri_tree_stride, 8,
+                               ws->betas + (size_t)k * 4, (size_t)logh * 4, 1, B, kc);
+    }
+    {
+      ProfileSpan sp(ctx, "fri_fold");
+      launch_fri_fold(s, ws->fri_layers + loff, ws->fri_layer_stride, ws->fri_layers + loff + 2 * hk * 4,
+                      ws->fri_layer_stride, ws->betas + (size_t)k * 4, (size_t)logh * 4, dom->tw_inv, k,
+                      dom->fold_xinv[2 * k], dom->fold_xinv[2 * k + 1], loghk, B);
+    }
+    loff += 2 * hk * 4;
+    toff += 2 * hk - 1;
+  }
+  {
+    ProfileSpan sp(ctx, "transcript");
+    launch_ch_observe_sample(s, ws->ch, ws->fri_layers + loff, ws->fri_layer_stride, 4, ws->alpha, 4, 0, B, kc);
+  }
+  {
+    ProfileSpan sp(ctx, "grind");
+    launch_ch_grind(s, ws->ch, ws->witness, pow_bits, B, kc);
+  }
+  {
+    ProfileSpan sp(ctx, "transcript");
+    launch_ch_queries(s, ws->ch, ws->witness, ws->indices, Q, pow_bits, logn, B, kc);
+  }
+  {
+    ProfileSpan sp(ctx, "assemble");
+    AssembleArgs aa;
+    aa.lde_t = ws->lde_t;
+    aa.tree_t = ws->tree_t;
+    aa.lde_q = ws->lde_q;
+    aa.tree_q = ws->tree_q;
+    aa.opened = ws->opened;
+    aa.fri_layers = ws->fri_layers;
+    aa.fri_trees = ws->fri_trees;
+    aa.witness = ws->witness;
+    aa.indices = ws->indices;
+    aa.body = ws->body;
+    aa.lde_t_stride = (size_t)W * n;
+    aa.tree_t_stride = tree_stride;
+    aa.lde_q_stride = 8 * n;
+    aa.tree_q_stride = tree_stride;
+    aa.opened_stride = 8 * R;
+    aa.fri_layer_stride = ws->fri_layer_stride;
+    aa.fri_tree_stride = ws->fri_tree_stride;
+    aa.body_stride = ws->body_words;
+    aa.width = W;
+    aa.logh = logh;
+    aa.n_queries = Q;
+    aa.batch = B;
+    launch_assemble(s, aa);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ctx->fail(3, std::string("prove_resident: ") + hipGetErrorString(e));
+  return 0;
+}
+
+}  // namespace zksp
