@@ -109,6 +109,11 @@ typedef struct {
 int zksp_execute(zksp_client* c, const zksp_pk* pk, const zksp_stdin* stdin_, int keccak_mode, zksp_exec_report* report,
                  uint8_t* public_values, size_t pv_cap, char* stderr_buf, size_t stderr_cap);
 const char* zksp_opcode_name(int index);
+/* The keccak-f[1600] permutation inputs the guest run produces (25 u64 each, in call
+ * order): exactly what the keccak chip's trace is generated from.  *n receives the
+ * count; states (optional) up to cap_perms entries. */
+int zksp_execute_keccak(zksp_client* c, const zksp_pk* pk, const zksp_stdin* stdin_, uint64_t* states, size_t cap_perms,
+                        size_t* n);
 
 /* ---- device-resident hot path (bench.py, parity tests) ---- */
 /* Proof-system parameters this build uses (for sizing buffers). */

@@ -1,0 +1,119 @@
+"""Whole-proof parity: the HIP prover must reproduce the CPU oracle's proof bytes
+exactly, and the host verifier must accept honest and reject tampered proofs."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+from util import Gpu, P
+
+pytestmark = pytest.mark.gpu
+
+
+def init_obs(vk, logh, n_perms, exit_code, pv_digest, deferred):
+    o = list(vk) + [logh, n_perms, exit_code & 0xffff, exit_code >> 16]
+    for w in pv_digest:
+        o += [w & 0xffff, w >> 16]
+    for w in deferred:
+        o += [w & 0xffff, w >> 16]
+    assert len(o) == 44
+    return o
+
+
+def device_bodies(g, logh, states_list, obs_list):
+    n = len(states_list)
+    max_perms = max(max(len(s) for s in states_list), 1)
+    st = np.zeros((n, max_perms, 25), np.uint64)
+    for i, s in enumerate(states_list):
+        st[i, :len(s)] = s
+    npm = np.array([len(s) for s in states_list], np.uint32)
+    obs = np.array(obs_list, np.uint32)
+    g.check(g.lib.zksp_hip_load_batch(g.h, logh, n, max_perms, st.ctypes.data_as(C.c_void_p),
+                                      npm.ctypes.data_as(C.c_void_p), obs.ctypes.data_as(C.c_void_p)))
+    g.check(g.lib.zksp_hip_prove_resident(g.h))
+    bw = g.lib.zksp_proof_body_words(g.h, logh)
+    out = np.zeros((n, bw), np.uint32)
+    g.check(g.lib.zksp_hip_fetch_bodies(g.h, out.ctypes.data_as(C.c_void_p), out.size))
+    return out
+
+
+@pytest.mark.parametrize("logh,nq,pow_bits", [(5, 3, 4), (7, 10, 8)])
+def test_device_prover_matches_oracle_small(zk, oracle, logh, nq, pow_bits):
+    g = Gpu(zk, num_queries=nq, pow_bits=pow_bits, max_batch=4)
+    rng = np.random.default_rng(logh)
+    vk = [int(x) for x in rng.integers(0, P, 8)]
+    states, obs, exp = [], [], []
+    for i in range(3):
+        k = int(rng.integers(0, (1 << logh) // 24 + 1))
+        st = rng.integers(0, 2**64, (k, 25), dtype=np.uint64)
+        pvd = [int(x) for x in rng.integers(0, 2**32, 8)]
+        states.append(st)
+        obs.append(init_obs(vk, logh, k, 0, pvd, [0] * 8))
+        exp.append(oracle.prove(st, logh, pv_digest=pvd, vk_digest=vk, num_queries=nq, pow_bits=pow_bits))
+    bodies = device_bodies(g, logh, states, obs)
+    for i in range(3):
+        e = np.frombuffer(exp[i], dtype=np.uint32)[30:]
+        assert e.shape == bodies[i].shape
+        bad = np.nonzero(e != bodies[i])[0]
+        assert bad.size == 0, (i, bad[:8])
+
+
+def test_end_to_end_acct_d8(zk, fx, oracle):
+    """BASELINE config 2 through the reference-shaped flow (prover/src/bin/main.rs:59-87),
+    proof bytes identical to the oracle's, verifier accepts, tampering rejected."""
+    client = zk.ProverClient(device=0)
+    pk, vk = client.setup(zk.merkle_elf())
+    inp = fx.acct_fixture(8)
+    stdin = zk.SP1Stdin()
+    stdin.write(inp.to_borsh())
+    states = client.keccak_states(pk, stdin)
+    assert states.shape == (62, 25)
+    proof = client.prove(pk, stdin).run()
+    assert proof.public_values == fx.ACCOUNT_VALUE
+    client.verify(proof, vk)
+    raw = proof.to_bytes()
+    pvd = np.frombuffer(hashlib.sha256(fx.ACCOUNT_VALUE).digest(), dtype=np.uint32)
+    exp = oracle.prove(states, 11, public_values=fx.ACCOUNT_VALUE, pv_digest=[int(x) for x in pvd],
+                       vk_digest=[int(x) for x in np.frombuffer(vk.digest, dtype=np.uint32)])
+    assert raw == exp
+    # host-only client verifies too; every tampered region is rejected
+    host = zk.ProverClient(device=-1)
+    host.verify(zk.SP1ProofWithPublicValues.from_bytes(raw), vk)
+    for pos in (125, 30 * 4 + 72 + 3, 30 * 4 + 72 + 64 + 8, len(raw) // 2, len(raw) - 3):
+        bad = bytearray(raw)
+        bad[pos] ^= 1
+        with pytest.raises(zk.ZkspError):
+            host.verify(zk.SP1ProofWithPublicValues.from_bytes(bytes(bad)), vk)
+
+
+def test_guest_panic_is_reported(zk, fx):
+    client = zk.ProverClient(device=0)
+    pk, vk = client.setup(zk.merkle_elf())
+    inp = fx.acct_fixture(8)
+    node = bytearray(inp.proof[3])
+    node[-1] ^= 1
+    inp.proof[3] = bytes(node)
+    stdin = zk.SP1Stdin()
+    stdin.write(inp.to_borsh())
+    with pytest.raises(zk.GuestPanic) as ei:
+        client.prove(pk, stdin).run()
+    assert "Failed to verify Merkle Proof" in str(ei.value)
+
+
+def test_batch_mixed_heights(zk, fx):
+    client = zk.ProverClient(device=0, max_batch=3)
+    pk, vk = client.setup(zk.merkle_elf())
+    inputs = [fx.acct_fixture(8), fx.tx_fixture(), fx.slot_fixture(0), fx.slot_fixture(1), fx.receipt_fixture(5),
+              fx.acct_fixture(1)]
+    stdins = []
+    for m in inputs:
+        s = zk.SP1Stdin()
+        s.write(m.to_borsh())
+        stdins.append(s)
+    proofs, status = client.prove_batch(pk, stdins)
+    assert status == [0] * len(inputs)
+    from oracle import verify_merkle_proof
+    for m, p in zip(inputs, proofs):
+        client.verify(p, vk)
+        assert p.public_values == verify_merkle_proof(m.root_hash, m.proof, m.key)

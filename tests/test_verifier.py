@@ -1,0 +1,93 @@
+"""Host verifier (row a8) against proofs made by the independent CPU oracle:
+accepts honest proofs, rejects every kind of tampering, wrong keys and wrong
+parameters.  Runs without a GPU."""
+import hashlib
+
+import numpy as np
+import pytest
+
+P = 2013265921
+NQ, POW = 12, 8
+
+
+@pytest.fixture(scope="module")
+def setup(zk, oracle, built_lib):
+    client = zk.ProverClient(device=-1, num_queries=NQ, pow_bits=POW)
+    pk, vk = client.setup(zk.merkle_elf())
+    vk_words = [int(x) for x in np.frombuffer(vk.digest, dtype=np.uint32)]
+    rng = np.random.default_rng(11)
+    st = rng.integers(0, 2**64, (4, 25), dtype=np.uint64)
+    pv = b"leaf value bytes"
+    pvd = [int(x) for x in np.frombuffer(hashlib.sha256(pv).digest(), dtype=np.uint32)]
+    proof = oracle.prove(st, 7, public_values=pv, pv_digest=pvd, vk_digest=vk_words, num_queries=NQ, pow_bits=POW)
+    return client, vk, vk_words, st, pv, pvd, proof
+
+
+def test_accepts_oracle_proof(zk, setup):
+    client, vk, _, _, pv, _, proof = setup
+    p = zk.SP1ProofWithPublicValues.from_bytes(proof)
+    assert p.public_values == pv
+    client.verify(p, vk)
+    assert p.to_bytes() == proof
+
+
+def test_rejects_tampering_everywhere(zk, setup):
+    client, vk, _, _, pv, _, proof = setup
+    words = len(proof) // 4
+    hdr = 30 + (len(pv) + 3) // 4
+    rng = np.random.default_rng(0)
+    # header fields, public values, roots, opened values, FRI roots, final poly, witness, query data
+    positions = [2, 3, 4, 6, 14, 22, 30, hdr, hdr + 8, hdr + 16, hdr + 16 + 4 * 2633, hdr + 16 + 4 * (2 * 2633 + 8),
+                 hdr + 16 + 4 * (2 * 2633 + 8) + 8 * 7, hdr + 16 + 4 * (2 * 2633 + 8) + 8 * 7 + 4, words - 1]
+    positions += [int(x) for x in rng.integers(hdr, words, 25)]
+    for w in positions:
+        bad = bytearray(proof)
+        bad[4 * w] ^= 1
+        try:
+            q = zk.SP1ProofWithPublicValues.from_bytes(bytes(bad))
+        except zk.ZkspError:
+            continue  # malformed header is rejected at deserialisation
+        with pytest.raises(zk.ZkspError):
+            client.verify(q, vk)
+
+
+def test_rejects_wrong_parameters_and_keys(zk, setup, oracle):
+    client, vk, vk_words, st, pv, pvd, proof = setup
+    p = zk.SP1ProofWithPublicValues.from_bytes(proof)
+    other = zk.ProverClient(device=-1, num_queries=NQ + 1, pow_bits=POW)
+    with pytest.raises(zk.ZkspError):
+        other.verify(p, vk)
+    harder = zk.ProverClient(device=-1, num_queries=NQ, pow_bits=POW + 9)
+    with pytest.raises(zk.ZkspError):
+        harder.verify(p, vk)
+    # a proof bound to another verifying key
+    wrong_vk = [(w + 1) % P for w in vk_words]
+    q = oracle.prove(st, 7, public_values=pv, pv_digest=pvd, vk_digest=wrong_vk, num_queries=NQ, pow_bits=POW)
+    with pytest.raises(zk.VerificationError):
+        client.verify(zk.SP1ProofWithPublicValues.from_bytes(q), vk)
+    # public values that do not match the committed digest
+    bad_pv = oracle.prove(st, 7, public_values=b"another value   ", pv_digest=pvd, vk_digest=vk_words, num_queries=NQ,
+                          pow_bits=POW)
+    with pytest.raises(zk.VerificationError):
+        client.verify(zk.SP1ProofWithPublicValues.from_bytes(bad_pv), vk)
+
+
+def test_rejects_truncated_and_garbage(zk, setup):
+    client, vk, *_, proof = setup
+    for blob in (b"", b"ZKSP", proof[:100], proof[:-4], proof + b"\0\0\0\0", bytes(len(proof))):
+        try:
+            q = zk.SP1ProofWithPublicValues.from_bytes(blob)
+        except zk.ZkspError:
+            continue
+        with pytest.raises(zk.ZkspError):
+            client.verify(q, vk)
+
+
+def test_heights_and_empty_trace(zk, oracle, setup):
+    client, vk, vk_words, *_ = setup
+    pvd = [int(x) for x in np.frombuffer(hashlib.sha256(b"").digest(), dtype=np.uint32)]
+    rng = np.random.default_rng(3)
+    for logh, k in ((5, 0), (5, 1), (6, 2), (8, 10)):
+        st = rng.integers(0, 2**64, (k, 25), dtype=np.uint64)
+        pr = oracle.prove(st, logh, pv_digest=pvd, vk_digest=vk_words, num_queries=NQ, pow_bits=POW)
+        client.verify(zk.SP1ProofWithPublicValues.from_bytes(pr), vk)

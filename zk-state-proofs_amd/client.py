@@ -97,6 +97,7 @@ def load_library() -> C.CDLL:
     lib.zksp_proof_free.restype = None
     lib.zksp_verify.argtypes = [vp, vp, vp]
     lib.zksp_execute.argtypes = [vp, vp, vp, C.c_int, C.POINTER(ExecReport), C.c_void_p, sz, C.c_void_p, sz]
+    lib.zksp_execute_keccak.argtypes = [vp, vp, vp, vp, sz, C.POINTER(sz)]
     lib.zksp_opcode_name.argtypes = [C.c_int]
     lib.zksp_opcode_name.restype = C.c_char_p
     lib.zksp_get_params.argtypes = [vp, C.POINTER(Params)]
@@ -132,7 +133,7 @@ ABI_SYMBOLS = [
     "zksp_client_new", "zksp_client_free", "zksp_last_error", "zksp_setup", "zksp_pk_free", "zksp_vk_free",
     "zksp_vk_digest", "zksp_stdin_new", "zksp_stdin_write", "zksp_stdin_free", "zksp_prove", "zksp_prove_batch",
     "zksp_proof_public_values", "zksp_proof_serialize", "zksp_proof_deserialize", "zksp_proof_free", "zksp_verify",
-    "zksp_execute", "zksp_opcode_name", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
+    "zksp_execute", "zksp_execute_keccak", "zksp_opcode_name", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
     "zksp_hip_prove_resident", "zksp_hip_fetch_bodies", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
     "zksp_hip_profile_enable", "zksp_hip_profile_read", "zksp_hip_profile_reset", "zksp_dev_malloc", "zksp_dev_free",
     "zksp_dev_upload", "zksp_dev_download", "zksp_dev_memset", "zksp_hip_lde", "zksp_hip_merkle_commit",
@@ -297,6 +298,19 @@ class ProverClient:
         err = C.create_string_buffer(8192)
         rc = self._lib.zksp_execute(self._h, pk._h, stdin._h, keccak_mode, C.byref(rep), pv, 65536, err, 8192)
         return rep, bytes(pv[: rep.pv_len]), err.value.decode("utf-8", "replace"), rc
+
+    def keccak_states(self, pk: ProvingKey, stdin: SP1Stdin):
+        """keccak-f inputs of one guest run as a numpy [n][25] uint64 array."""
+        import numpy as np
+        n = C.c_size_t()
+        rc = self._lib.zksp_execute_keccak(self._h, pk._h, stdin._h, None, 0, C.byref(n))
+        if rc:
+            raise ZkspError(rc, self.last_error())
+        out = np.zeros((n.value, 25), dtype=np.uint64)
+        rc = self._lib.zksp_execute_keccak(self._h, pk._h, stdin._h, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
+        if rc:
+            raise ZkspError(rc, self.last_error())
+        return out
 
     def opcode_histogram(self, rep: ExecReport) -> dict:
         out = {}

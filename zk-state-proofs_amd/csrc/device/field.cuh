@@ -15,6 +15,7 @@ namespace zksp {
 
 constexpr uint32_t kP = 0x78000001u;        // 2013265921
 constexpr uint32_t kMontyMu = 0x88000001u;  // p^-1 mod 2^32
+constexpr uint32_t kMontyNegMu = 0x77ffffffu;  // -p^-1 mod 2^32
 constexpr uint32_t kR1 = 0x0ffffffeu;       // 2^32 mod p  (Montgomery form of 1)
 constexpr uint32_t kR2 = 0x45dddde3u;       // 2^64 mod p
 constexpr uint32_t kGen = 31;               // multiplicative generator (canonical)
@@ -32,12 +33,14 @@ struct Fp {
 
   // t < p * 2^32  ->  t * 2^-32 mod p
   ZKSP_HD static uint32_t reduce(uint64_t t) {
-    uint32_t m = (uint32_t)t * kMontyMu;
-    uint32_t u = (uint32_t)(((uint64_t)m * kP) >> 32);
-    uint32_t hi = (uint32_t)(t >> 32);
-    uint32_t r = hi - u;
-    uint32_t r2 = r + kP;
-    return r < r2 ? r : r2;  // unsigned-min trick: picks r+p exactly when hi < u
+    // m*p == -t (mod 2^32): the low word of t + m*p cancels, the high word is the
+    // result in [0, 2p).  One v_mul_lo_u32 + one v_mad_u64_u32 (measured on gfx950:
+    // both run at about half the v_add_u32 rate, v_mul_hi_u32 at about 3/8).
+    uint32_t m = (uint32_t)t * kMontyNegMu;
+    uint64_t u = t + (uint64_t)m * kP;
+    uint32_t r = (uint32_t)(u >> 32);
+    uint32_t r2 = r - kP;
+    return r < r2 ? r : r2;  // unsigned min: r - p wraps high exactly when r < p
   }
   ZKSP_HD static Fp from_canonical(uint32_t c) { return raw(reduce((uint64_t)c * kR2)); }
   ZKSP_HD uint32_t to_canonical() const { return reduce((uint64_t)v); }

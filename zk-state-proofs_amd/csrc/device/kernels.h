@@ -34,8 +34,11 @@ int lde_configure();  // one-time kernel attribute setup; returns a hipError_t
 // ---- Poseidon2 Merkle commitment (row a5) ----
 // mat: [batch][width][n_rows] column-major (proof stride mat_stride words);
 // tree: [batch][2*n_rows-1][8], leaves first, root last (stride tree_stride words).
+// upper = false hashes the leaf layer only (finish with launch_merkle_upper).
 void launch_merkle_commit(hipStream_t stream, const uint32_t* mat, size_t mat_stride, int width, int logn,
-                          uint32_t* tree, size_t tree_stride, int batch, const P2Consts* consts);
+                          uint32_t* tree, size_t tree_stride, int batch, const P2Consts* consts, bool upper = true);
+void launch_merkle_upper(hipStream_t stream, int logn, uint32_t* tree, size_t tree_stride, int batch,
+                         const P2Consts* consts);
 // states: [n][16] -> permuted in place (test hook)
 void launch_poseidon2_permute(hipStream_t stream, uint32_t* states, size_t n, const P2Consts* consts);
 

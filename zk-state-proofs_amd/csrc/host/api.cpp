@@ -159,6 +159,19 @@ int zksp_execute(zksp_client* c, const zksp_pk* pk, const zksp_stdin* stdin_, in
 }
 const char* zksp_opcode_name(int index) { return op_name(index); }
 
+int zksp_execute_keccak(zksp_client* c, const zksp_pk* pk, const zksp_stdin* stdin_, uint64_t* states, size_t cap_perms,
+                        size_t* n) {
+  if (!c || !pk || !stdin_ || !n) return ZKSP_ERR_INVALID_ARG;
+  ExecOptions o;
+  o.keccak_mode = (KeccakMode)c->ctx.params.keccak_mode;
+  ExecutionRecord r = execute(pk->elf, stdin_->entries, o);
+  if (!r.error.empty() || !r.halted) return c->ctx.fail(ZKSP_ERR_EXECUTOR, "executor: " + r.error);
+  *n = r.keccak_events.size();
+  if (states)
+    for (size_t i = 0; i < r.keccak_events.size() && i < cap_perms; ++i) memcpy(states + 25 * i, r.keccak_events[i].state_in, 200);
+  return ZKSP_OK;
+}
+
 int zksp_get_params(const zksp_client* c, zksp_params* out) {
   if (!c || !out) return ZKSP_ERR_INVALID_ARG;
   out->trace_width = kTraceWidth;

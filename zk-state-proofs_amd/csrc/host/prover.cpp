@@ -125,8 +125,12 @@ int prove_resident(Context* ctx) {
                logh, (size_t)B * W);
   }
   {
-    ProfileSpan sp(ctx, "merkle_trace");
-    launch_merkle_commit(s, ws->lde_t, (size_t)W * n, W, logn, ws->tree_t, tree_stride, B, kc);
+    ProfileSpan sp(ctx, "leaf_hash_trace");  // exactly one launch of leaf_hash_trace_kernel
+    launch_merkle_commit(s, ws->lde_t, (size_t)W * n, W, logn, ws->tree_t, tree_stride, B, kc, false);
+  }
+  {
+    ProfileSpan sp(ctx, "merkle_upper");
+    launch_merkle_upper(s, logn, ws->tree_t, tree_stride, B, kc);
   }
   {
     ProfileSpan sp(ctx, "transcript");
