@@ -44,13 +44,26 @@ def init_obs(vk_words, logh, n_perms, exit_code, pv_digest, deferred):
     return o
 
 
+def usable_cores():
+    """CPU share of this process: affinity mask capped by the cgroup quota and by the
+    GPU box's stated per-GPU share (16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("ZKSP_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(states, vk_words, pv, seconds=10.0):
     """Times the oracle's whole-proof CPU restatement ("port") on this host."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     oracle.build()
     pvd = [int(x) for x in np.frombuffer(hashlib.sha256(pv).digest(), dtype=np.uint32)]
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     n, t0 = 0, time.perf_counter()
     while True:
@@ -72,6 +85,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="proofs proven in lockstep per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-single", action="store_true", help="skip the batch-of-1 latency section (profiling runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -180,21 +194,23 @@ def main():
         return
 
     # ---- single-proof numbers (rank 0, after the timed region) ----
-    check(lib.zksp_hip_load_batch(h, LOG_H, 1, 62, states.ctypes.data_as(C.c_void_p),
-                                  n_perms.ctypes.data_as(C.c_void_p), obs.ctypes.data_as(C.c_void_p)))
-    check(lib.zksp_hip_prove_resident(h))
-    sync()
-    t1 = time.perf_counter()
-    for _ in range(5):
+    single_ms = e2e_ms = None
+    if not args.skip_single:
+        check(lib.zksp_hip_load_batch(h, LOG_H, 1, 62, states.ctypes.data_as(C.c_void_p),
+                                      n_perms.ctypes.data_as(C.c_void_p), obs.ctypes.data_as(C.c_void_p)))
         check(lib.zksp_hip_prove_resident(h))
-    sync()
-    single_ms = (time.perf_counter() - t1) * 1e3 / 5
-    stdin = zk.SP1Stdin()
-    stdin.write(fx.acct_fixture(8, seed=1).to_borsh())
-    t2 = time.perf_counter()
-    proof = client.prove(pk, stdin).run()
-    e2e_ms = (time.perf_counter() - t2) * 1e3
-    client.verify(proof, vk)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            check(lib.zksp_hip_prove_resident(h))
+        sync()
+        single_ms = (time.perf_counter() - t1) * 1e3 / 5
+        stdin = zk.SP1Stdin()
+        stdin.write(fx.acct_fixture(8, seed=1).to_borsh())
+        t2 = time.perf_counter()
+        proof = client.prove(pk, stdin).run()
+        e2e_ms = (time.perf_counter() - t2) * 1e3
+        client.verify(proof, vk)
 
     total_proofs = world * B * args.steps
     out = {

@@ -125,5 +125,6 @@ void launch_assemble(hipStream_t stream, const AssembleArgs& a);
 
 // instruction-rate probe (kernels_bench.hip)
 void launch_rate_kernel(hipStream_t stream, int which, uint32_t* out, int blocks, int iters);
+void launch_perm_rate_kernel(hipStream_t stream, uint32_t* out, int blocks, int iters, const P2Consts* consts);
 
 }  // namespace zksp

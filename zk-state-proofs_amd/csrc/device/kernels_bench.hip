@@ -30,6 +30,22 @@ __global__ __launch_bounds__(256) void rate_kernel(uint32_t* out, uint32_t seed,
   if (r == 0x12345678u) out[0] = r;  // keeps the chains alive
 }
 
+// Poseidon2 permutation throughput at a chosen residency: every thread runs
+// `iters` dependent permutations on a register-resident state.
+__global__ __launch_bounds__(256) void perm_rate_kernel(uint32_t* out, int iters, const P2Consts* __restrict__ k) {
+  Fp s[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s[i] = Fp::raw((threadIdx.x * 16 + i + blockIdx.x) % kP);
+  for (int it = 0; it < iters; ++it) p2_permute(s, k);
+  uint32_t r = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r ^= s[i].v;
+  if (r == 0x12345678u) out[0] = r;
+}
+void launch_perm_rate_kernel(hipStream_t stream, uint32_t* out, int blocks, int iters, const P2Consts* k) {
+  hipLaunchKernelGGL(perm_rate_kernel, dim3(blocks), dim3(256), 0, stream, out, iters, k);
+}
+
 void launch_rate_kernel(hipStream_t stream, int which, uint32_t* out, int blocks, int iters) {
   dim3 g(blocks), b(256);
   switch (which) {

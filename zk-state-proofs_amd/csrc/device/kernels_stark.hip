@@ -12,6 +12,8 @@
 #include "air_keccak.cuh"
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace zksp {
 
 constexpr int kThreads = 256;
@@ -445,23 +447,48 @@ __global__ void ch_observe_sample_kernel(DevChallenger* ch, const uint32_t* __re
   ch_store(ch + b, c);
 }
 
-constexpr uint32_t kGrindChunk = 1u << 18;
+// Proof-of-work search: smallest w such that, after observing w, the next sample
+// has `bits` low zero bits.  observe(w) then sample() on a duplex sponge always
+// amounts to: overlay the pending inputs and w on the rate part, permute once,
+// read word 7.
+//
+// The candidates are covered by a FIXED sequence of launches, one 2^14-wide range
+// per launch for every proof of the batch; a workgroup returns at once when a
+// smaller witness is already known, so once a proof is done its share of the later
+// launches costs a load and a compare.  Every candidate below the final minimum
+// has been tested by construction, hence the result is the same smallest witness
+// the sequential CPU search returns, whatever the scheduling.  Expected work is
+// 2^bits + 2^13 permutations per proof.
+constexpr uint32_t kGrindRange = 1u << 14;
+constexpr int kGrindLaunches = 64;  // covers 2^20 candidates: miss probability e^-16 at 16 bits
 
-__global__ __launch_bounds__(kThreads) void ch_grind_kernel(const DevChallenger* __restrict__ ch,
-                                                           uint32_t* __restrict__ witness, int bits,
-                                                           const P2Consts* __restrict__ k) {
-  const int b = blockIdx.y;
-  const uint32_t w = blockIdx.x * kThreads + threadIdx.x;
-  // a candidate above an already-found witness can never be the minimum
-  if (__hip_atomic_load(&witness[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= w) return;
-  Ch c;
-  ch_load(ch + b, c);
-  ch_observe(c, Fp::from_canonical(w), k);
-  uint32_t s = ch_sample(c, k).to_canonical() & ((1u << bits) - 1);
-  if (s == 0) atomicMin(&witness[b], w);
+__device__ __forceinline__ bool grind_try(const DevChallenger* d, uint32_t w, uint32_t mask, const P2Consts* k) {
+  const int pos = d->n_in;  // 0..7
+  Fp st[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) st[i] = Fp::raw(d->state[i]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < pos) st[i] = Fp::raw(d->inbuf[i]);
+  const Fp wm = Fp::from_canonical(w);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i == pos) st[i] = wm;
+  p2_permute(st, k);
+  return (st[7].to_canonical() & mask) == 0;
 }
 
-// rare continuation (probability e^-4 per proof at 16 bits): search on, one workgroup per proof
+__global__ __launch_bounds__(kThreads) void ch_grind_kernel(const DevChallenger* __restrict__ ch,
+                                                           uint32_t* __restrict__ witness, int bits, uint32_t range_lo,
+                                                           const P2Consts* __restrict__ k) {
+  const int b = blockIdx.y;
+  const uint32_t lo = range_lo + blockIdx.x * kThreads;
+  if (witness[b] < lo) return;  // settled by an earlier launch (or an earlier chunk of this one)
+  const uint32_t w = lo + threadIdx.x;
+  if (grind_try(ch + b, w, (1u << bits) - 1, k)) atomicMin(&witness[b], w);
+}
+
+// continuation for the (practically unreachable) case that 2^20 candidates all failed
 __global__ __launch_bounds__(kThreads) void ch_grind_tail_kernel(const DevChallenger* __restrict__ ch,
                                                                 uint32_t* __restrict__ witness, int bits,
                                                                 const P2Consts* __restrict__ k) {
@@ -469,14 +496,11 @@ __global__ __launch_bounds__(kThreads) void ch_grind_tail_kernel(const DevChalle
   const int b = blockIdx.x;
   if (threadIdx.x == 0) found = witness[b];
   __syncthreads();
-  for (uint32_t base = kGrindChunk; found == 0xffffffffu && base < kP - kThreads; base += kThreads) {
-    Ch c;
-    ch_load(ch + b, c);
-    const uint32_t w = base + threadIdx.x;
-    ch_observe(c, Fp::from_canonical(w), k);
-    uint32_t s = ch_sample(c, k).to_canonical() & ((1u << bits) - 1);
+  for (uint32_t lo = kGrindRange * (uint32_t)kGrindLaunches; found == 0xffffffffu && lo < kP - kThreads; lo += kThreads) {
+    const uint32_t w = lo + threadIdx.x;
+    const bool ok = grind_try(ch + b, w, (1u << bits) - 1, k);
     __syncthreads();
-    if (s == 0) atomicMin(&found, w);
+    if (ok) atomicMin(&found, w);
     __syncthreads();
   }
   if (threadIdx.x == 0) witness[b] = found;
@@ -509,8 +533,9 @@ void launch_ch_observe_sample(hipStream_t stream, DevChallenger* ch, const uint3
 void launch_ch_grind(hipStream_t stream, DevChallenger* ch, uint32_t* witness, int bits, int batch,
                      const P2Consts* consts) {
   (void)hipMemsetAsync(witness, 0xff, (size_t)batch * 4, stream);
-  hipLaunchKernelGGL(ch_grind_kernel, dim3(kGrindChunk / kThreads, batch), dim3(kThreads), 0, stream, ch, witness,
-                     bits, consts);
+  for (int r = 0; r < kGrindLaunches; ++r)
+    hipLaunchKernelGGL(ch_grind_kernel, dim3(kGrindRange / kThreads, batch), dim3(kThreads), 0, stream, ch, witness, bits,
+                       kGrindRange * (uint32_t)r, consts);
   hipLaunchKernelGGL(ch_grind_tail_kernel, dim3(batch), dim3(kThreads), 0, stream, ch, witness, bits, consts);
 }
 void launch_ch_queries(hipStream_t stream, DevChallenger* ch, const uint32_t* witness, uint32_t* indices,

@@ -14,9 +14,53 @@ struct P2Consts {
   uint32_t diag[16];    // internal diagonal [-2, 1, 2, 4, ..., 8192, 32768]
 };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZKSP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ZKSP_SCHED_FENCE() ((void)0)
+#endif
+
+// Montgomery products of N independent pairs, written stage by stage with the
+// instruction order pinned: hipcc otherwise emits each product as one serial
+// mad -> mul_lo -> mad -> add -> min chain through a shared temporary, which
+// leaves a wave stalled on its own previous result at the 4-5 waves per SIMD
+// these kernels run at.  N independent chains per stage cover that latency.
+template <int N>
+ZKSP_HD void fp_mul_batch(Fp* out, const Fp* a, const Fp* b) {
+  uint64_t t[N];
+  uint32_t m[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) t[i] = (uint64_t)a[i].v * b[i].v;
+  ZKSP_SCHED_FENCE();
+#pragma unroll
+  for (int i = 0; i < N; ++i) m[i] = (uint32_t)t[i] * kMontyNegMu;
+  ZKSP_SCHED_FENCE();
+#pragma unroll
+  for (int i = 0; i < N; ++i) t[i] = t[i] + (uint64_t)m[i] * kP;
+  ZKSP_SCHED_FENCE();
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    uint32_t r = (uint32_t)(t[i] >> 32), r2 = r - kP;
+    out[i] = Fp::raw(r < r2 ? r : r2);
+  }
+  ZKSP_SCHED_FENCE();
+}
+
 ZKSP_HD Fp p2_sbox(Fp x) {
   Fp x2 = x.sqr(), x3 = x2 * x, x4 = x2.sqr();
   return x3 * x4;
+}
+
+// x -> (x + rc)^7 on N lanes
+template <int N>
+ZKSP_HD void p2_sbox_layer(Fp* s, const uint32_t* __restrict__ rc) {
+  Fp x2[N], x3[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) s[i] = s[i] + Fp::raw(rc[i]);
+  fp_mul_batch<N>(x2, s, s);
+  fp_mul_batch<N>(x3, x2, s);
+  fp_mul_batch<N>(x2, x2, x2);
+  fp_mul_batch<N>(s, x3, x2);
 }
 
 // circ(2*M4, M4, M4, M4) with M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]]
@@ -42,16 +86,21 @@ ZKSP_HD void p2_internal_linear(Fp* s, const P2Consts* __restrict__ k) {
   Fp sum = s[0];
 #pragma unroll
   for (int i = 1; i < 16; ++i) sum = sum + s[i];
+  Fp d[16], prod[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) s[i] = s[i] * Fp::raw(k->diag[i]) + sum;
+  for (int i = 0; i < 16; ++i) d[i] = Fp::raw(k->diag[i]);
+  fp_mul_batch<8>(prod, s, d);
+  fp_mul_batch<8>(prod + 8, s + 8, d + 8);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s[i] = prod[i] + sum;
 }
 
 ZKSP_HD void p2_permute(Fp* s, const P2Consts* __restrict__ k) {
   p2_external_linear(s);
 #pragma unroll 1
   for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s[i] = p2_sbox(s[i] + Fp::raw(k->ext[r][i]));
+    p2_sbox_layer<8>(s, k->ext[r]);
+    p2_sbox_layer<8>(s + 8, k->ext[r] + 8);
     p2_external_linear(s);
   }
 #pragma unroll 1
@@ -61,8 +110,8 @@ ZKSP_HD void p2_permute(Fp* s, const P2Consts* __restrict__ k) {
   }
 #pragma unroll 1
   for (int r = 4; r < 8; ++r) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s[i] = p2_sbox(s[i] + Fp::raw(k->ext[r][i]));
+    p2_sbox_layer<8>(s, k->ext[r]);
+    p2_sbox_layer<8>(s + 8, k->ext[r] + 8);
     p2_external_linear(s);
   }
 }

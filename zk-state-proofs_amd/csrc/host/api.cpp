@@ -614,9 +614,23 @@ int zksp_hip_fri_fold(zksp_client* c, const uint32_t* d_in, int log_hk, uint32_t
 int zksp_hip_microbench(zksp_client* c, int which, double* gops) {
   NEED_GPU(c);
   Context* ctx = &c->ctx;
-  if (!gops || which < 0 || which > 5) return ZKSP_ERR_INVALID_ARG;
+  if (!gops || which < 0 || which > 5 + 64) return ZKSP_ERR_INVALID_ARG;
   uint32_t* d = nullptr;
   ZKSP_HIP_CHECK(ctx, hipMalloc(&d, 64));
+  if (which > 5) {
+    // 6 + k: Poseidon2 permutations per second with k+1 workgroups of 256 per CU (result in G perms/s)
+    const int per_cu = which - 5, blocks_p = 256 * per_cu, iters_p = 64;
+    launch_perm_rate_kernel(ctx->stream, d, blocks_p, 2, ctx->d_consts);
+    ZKSP_HIP_CHECK(ctx, hipEventRecord(ctx->timer_a, ctx->stream));
+    launch_perm_rate_kernel(ctx->stream, d, blocks_p, iters_p, ctx->d_consts);
+    ZKSP_HIP_CHECK(ctx, hipEventRecord(ctx->timer_b, ctx->stream));
+    ZKSP_HIP_CHECK(ctx, hipEventSynchronize(ctx->timer_b));
+    float msp = 0;
+    ZKSP_HIP_CHECK(ctx, hipEventElapsedTime(&msp, ctx->timer_a, ctx->timer_b));
+    ZKSP_HIP_CHECK(ctx, hipFree(d));
+    *gops = (double)blocks_p * 256.0 * iters_p / (msp * 1e-3) / 1e9;
+    return ZKSP_OK;
+  }
   const int blocks = 256 * 16, iters = 2000;
   launch_rate_kernel(ctx->stream, which, d, blocks, 10);  // warm-up
   ZKSP_HIP_CHECK(ctx, hipEventRecord(ctx->timer_a, ctx->stream));
