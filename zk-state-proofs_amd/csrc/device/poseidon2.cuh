@@ -21,16 +21,20 @@ struct P2Consts {
 #endif
 
 // Montgomery products of N independent pairs, written stage by stage with the
-// instruction order pinned: hipcc otherwise emits each product as one serial
-// mad -> mul_lo -> mad -> add -> min chain through a shared temporary, which
-// leaves a wave stalled on its own previous result at the 4-5 waves per SIMD
-// these kernels run at.  N independent chains per stage cover that latency.
+// instruction order pinned (hipcc otherwise emits each product as one serial
+// mad -> mul_lo -> mad chain through a shared temporary).
+//
+// "Raw" products skip the final conditional subtraction: for operands a, b the
+// result is < a*b/2^32 + p.  With A = p/2^32 = 0.46875: reduced x reduced gives
+// < 1.469p, and the S-box below keeps every intermediate inside the two
+// conditions that matter: a*b + m*p < 2^64 (a*b < 1.1333 * 2^32 * p) and the
+// result < 2^32.
 template <int N>
-ZKSP_HD void fp_mul_batch(Fp* out, const Fp* a, const Fp* b) {
+ZKSP_HD void fp_mul_batch_raw(uint32_t* out, const uint32_t* a, const uint32_t* b) {
   uint64_t t[N];
   uint32_t m[N];
 #pragma unroll
-  for (int i = 0; i < N; ++i) t[i] = (uint64_t)a[i].v * b[i].v;
+  for (int i = 0; i < N; ++i) t[i] = (uint64_t)a[i] * b[i];
   ZKSP_SCHED_FENCE();
 #pragma unroll
   for (int i = 0; i < N; ++i) m[i] = (uint32_t)t[i] * kMontyNegMu;
@@ -39,10 +43,23 @@ ZKSP_HD void fp_mul_batch(Fp* out, const Fp* a, const Fp* b) {
   for (int i = 0; i < N; ++i) t[i] = t[i] + (uint64_t)m[i] * kP;
   ZKSP_SCHED_FENCE();
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    uint32_t r = (uint32_t)(t[i] >> 32), r2 = r - kP;
-    out[i] = Fp::raw(r < r2 ? r : r2);
-  }
+  for (int i = 0; i < N; ++i) out[i] = (uint32_t)(t[i] >> 32);
+}
+
+// v < 2p  ->  v mod p
+ZKSP_HD uint32_t fp_correct(uint32_t v) {
+  uint32_t w = v - kP;
+  return v < w ? v : w;
+}
+
+template <int N>
+ZKSP_HD void fp_mul_batch(Fp* out, const Fp* a, const Fp* b) {
+  uint32_t r[N], av[N], bv[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { av[i] = a[i].v; bv[i] = b[i].v; }
+  fp_mul_batch_raw<N>(r, av, bv);
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[i] = Fp::raw(fp_correct(r[i]));
   ZKSP_SCHED_FENCE();
 }
 
@@ -51,48 +68,66 @@ ZKSP_HD Fp p2_sbox(Fp x) {
   return x3 * x4;
 }
 
-// x -> (x + rc)^7 on N lanes
+// x -> (x + rc)^7 on N lanes with lazy reduction:
+//   x  < p            (reduced sum)
+//   x2 = x*x   raw  < 1.469p
+//   x3 = x2*x  raw  < 1.689p      (1.469 p^2 < 1.1333 * 2^32 p)
+//   x4 = x2*x2 raw  < 2.012p      (2.158 p^2 = 1.0116 * 2^32 p < 1.1333 * 2^32 p; 2.012p < 2^32)
+//   x4 corrected once < 1.012p
+//   x7 = x3*x4 raw  < 1.801p      (1.709 p^2 < 1.1333 * 2^32 p), corrected once -> < p
 template <int N>
 ZKSP_HD void p2_sbox_layer(Fp* s, const uint32_t* __restrict__ rc) {
-  Fp x2[N], x3[N];
+  uint32_t x[N], x2[N], x3[N];
 #pragma unroll
-  for (int i = 0; i < N; ++i) s[i] = s[i] + Fp::raw(rc[i]);
-  fp_mul_batch<N>(x2, s, s);
-  fp_mul_batch<N>(x3, x2, s);
-  fp_mul_batch<N>(x2, x2, x2);
-  fp_mul_batch<N>(s, x3, x2);
+  for (int i = 0; i < N; ++i) x[i] = (s[i] + Fp::raw(rc[i])).v;
+  fp_mul_batch_raw<N>(x2, x, x);
+  ZKSP_SCHED_FENCE();
+  fp_mul_batch_raw<N>(x3, x2, x);
+  ZKSP_SCHED_FENCE();
+  fp_mul_batch_raw<N>(x2, x2, x2);
+#pragma unroll
+  for (int i = 0; i < N; ++i) x2[i] = fp_correct(x2[i]);
+  ZKSP_SCHED_FENCE();
+  fp_mul_batch_raw<N>(x, x3, x2);
+#pragma unroll
+  for (int i = 0; i < N; ++i) s[i] = Fp::raw(fp_correct(x[i]));
+  ZKSP_SCHED_FENCE();
 }
 
 // circ(2*M4, M4, M4, M4) with M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]]
 ZKSP_HD void p2_external_linear(Fp* s) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    Fp a = s[4 * c], b = s[4 * c + 1], cc = s[4 * c + 2], d = s[4 * c + 3];
-    Fp t = a + b + cc + d;
-    // row i of M4 . v = t + v_i + 2 v_{i+1}
-    s[4 * c] = t + a + b.dbl();
-    s[4 * c + 1] = t + b + cc.dbl();
-    s[4 * c + 2] = t + cc + d.dbl();
-    s[4 * c + 3] = t + d + a.dbl();
+    // 11 additions per 4x4 block (the evaluation order Plonky3's apply_mat4 uses)
+    Fp x0 = s[4 * c], x1 = s[4 * c + 1], x2 = s[4 * c + 2], x3 = s[4 * c + 3];
+    Fp t01 = x0 + x1, t23 = x2 + x3;
+    Fp t0123 = t01 + t23;
+    Fp t01123 = t0123 + x1, t01233 = t0123 + x3;
+    s[4 * c + 3] = t01233 + x0.dbl();  // 3 x0 + x1 + x2 + 2 x3
+    s[4 * c + 1] = t01123 + x2.dbl();  // x0 + 2 x1 + 3 x2 + x3
+    s[4 * c] = t01123 + t01;           // 2 x0 + 3 x1 + x2 + x3
+    s[4 * c + 2] = t01233 + t23;       // x0 + x1 + 2 x2 + 3 x3
   }
   Fp sums[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) sums[j] = s[j] + s[4 + j] + s[8 + j] + s[12 + j];
+  for (int j = 0; j < 4; ++j) sums[j] = (s[j] + s[4 + j]) + (s[8 + j] + s[12 + j]);
 #pragma unroll
   for (int i = 0; i < 16; ++i) s[i] = s[i] + sums[i & 3];
 }
 
+// y_i = d_i * x_i + sum(x), d = [-2, 1, 2, 4, ..., 8192, 32768]
 ZKSP_HD void p2_internal_linear(Fp* s, const P2Consts* __restrict__ k) {
-  Fp sum = s[0];
+  Fp sum = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  sum = sum + (((s[8] + s[9]) + (s[10] + s[11])) + ((s[12] + s[13]) + (s[14] + s[15])));
+  Fp d[13], prod[13];
 #pragma unroll
-  for (int i = 1; i < 16; ++i) sum = sum + s[i];
-  Fp d[16], prod[16];
+  for (int i = 0; i < 13; ++i) d[i] = Fp::raw(k->diag[3 + i]);
+  fp_mul_batch<13>(prod, s + 3, d);
+  s[0] = sum - s[0].dbl();   // d_0 = -2
+  s[1] = sum + s[1];         // d_1 = 1
+  s[2] = sum + s[2].dbl();   // d_2 = 2
 #pragma unroll
-  for (int i = 0; i < 16; ++i) d[i] = Fp::raw(k->diag[i]);
-  fp_mul_batch<8>(prod, s, d);
-  fp_mul_batch<8>(prod + 8, s + 8, d + 8);
-#pragma unroll
-  for (int i = 0; i < 16; ++i) s[i] = prod[i] + sum;
+  for (int i = 0; i < 13; ++i) s[3 + i] = prod[i] + sum;
 }
 
 ZKSP_HD void p2_permute(Fp* s, const P2Consts* __restrict__ k) {
