@@ -8,6 +8,7 @@
 // once, fully coalesced.  Upper layers: one lane per parent; once a layer fits one
 // workgroup the rest of the tree is finished in a single launch.
 #include "kernels.h"
+#include "poseidon2_coop.cuh"
 
 namespace zksp {
 
@@ -77,20 +78,62 @@ __global__ __launch_bounds__(kHashThreads) void compress_layer_kernel(uint32_t* 
   compress_pair(t + (in_off + 2 * (size_t)i) * 8, t + (out_off + (size_t)i) * 8, consts);
 }
 
-// finishes the tree from a layer of `count` (<= 2*kHashThreads) digests, one workgroup per proof
-__global__ __launch_bounds__(kHashThreads) void compress_top_kernel(uint32_t* __restrict__ tree, size_t tree_stride,
-                                                                   size_t in_off, int count,
-                                                                   const P2Consts* __restrict__ consts) {
-  uint32_t* t = tree + (size_t)blockIdx.x * tree_stride;
+// Finishes a tree from a layer of `count` (<= 2*kHashThreads) digests, one workgroup
+// per proof.  These levels are a chain of dependent permutations with little
+// width, so they use the cooperative 16-lane permutation: 64 compressions in
+// flight per workgroup, each about 5x shorter than the lane-per-state form.
+constexpr int kTopThreads = 1024;
+constexpr int kTopGroups = kTopThreads / 16;
+
+__device__ __forceinline__ void coop_tree_levels(uint32_t* __restrict__ t, size_t in_off, int count,
+                                                 const CoopConsts& cc, const P2Consts* __restrict__ consts) {
+  const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
   while (count > 1) {
     const int parents = count >> 1;
     const size_t out_off = in_off + (size_t)count;
-    if ((int)threadIdx.x < parents)
-      compress_pair(t + (in_off + 2 * (size_t)threadIdx.x) * 8, t + (out_off + threadIdx.x) * 8, consts);
+    for (int p0 = 0; p0 < parents; p0 += kTopGroups) {
+      const int p = p0 + grp;
+      const bool act = p < parents;
+      // children 2p and 2p+1 are adjacent: lane e takes word e of the 16-word pair
+      Fp x = act ? Fp::raw(t[(in_off + 2 * (size_t)p) * 8 + e]) : Fp::zero();
+      x = p2_permute_coop(x, cc, consts);
+      if (act && e < 8) t[(out_off + (size_t)p) * 8 + e] = x.v;
+    }
     __syncthreads();
     in_off = out_off;
     count = parents;
   }
+}
+
+__global__ __launch_bounds__(kTopThreads) void compress_top_kernel(uint32_t* __restrict__ tree, size_t tree_stride,
+                                                                  size_t in_off, int count,
+                                                                  const P2Consts* __restrict__ consts) {
+  const CoopConsts cc = coop_load_consts(consts, threadIdx.x & 15);
+  coop_tree_levels(tree + (size_t)blockIdx.x * tree_stride, in_off, count, cc, consts);
+}
+
+// Whole commitment of a small FRI layer (<= 2*kHashThreads leaves) in one launch:
+// leaf (c, m) = (f[c][m], f[c][m + Hk/2]) absorbed into a zero state, then the tree.
+__global__ __launch_bounds__(kTopThreads) void fri_commit_small_kernel(const uint32_t* __restrict__ layer,
+                                                                      size_t layer_stride, int loghk,
+                                                                      uint32_t* __restrict__ tree, size_t tree_stride,
+                                                                      const P2Consts* __restrict__ consts) {
+  const int hk = 1 << loghk, half = hk >> 1;
+  const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const CoopConsts cc = coop_load_consts(consts, e);
+  const uint32_t* f = layer + (size_t)blockIdx.x * layer_stride;
+  uint32_t* t = tree + (size_t)blockIdx.x * tree_stride;
+  for (int l0 = 0; l0 < hk; l0 += kTopGroups) {
+    const int leaf = l0 + grp;
+    const bool act = leaf < hk;
+    const int c = leaf >= half ? 1 : 0, m = leaf - c * half;
+    Fp x = Fp::zero();
+    if (act && e < 8) x = Fp::raw(f[((size_t)c * hk + m + (e >= 4 ? half : 0)) * 4 + (e & 3)]);
+    x = p2_permute_coop(x, cc, consts);
+    if (act && e < 8) t[(size_t)leaf * 8 + e] = x.v;
+  }
+  __syncthreads();
+  coop_tree_levels(t, 0, hk, cc, consts);
 }
 
 static void launch_upper_layers(hipStream_t stream, int logn, uint32_t* tree, size_t tree_stride, int batch,
@@ -105,7 +148,7 @@ static void launch_upper_layers(hipStream_t stream, int logn, uint32_t* tree, si
     count = parents;
   }
   if (count > 1)
-    hipLaunchKernelGGL(compress_top_kernel, dim3(batch), dim3(kHashThreads), 0, stream, tree, tree_stride, off, count,
+    hipLaunchKernelGGL(compress_top_kernel, dim3(batch), dim3(kTopThreads), 0, stream, tree, tree_stride, off, count,
                        consts);
 }
 
@@ -152,6 +195,11 @@ __global__ __launch_bounds__(kHashThreads) void fri_leaf_kernel(const uint32_t* 
 void launch_fri_commit(hipStream_t stream, const uint32_t* layer, size_t layer_stride, int loghk, uint32_t* tree,
                        size_t tree_stride, int batch, const P2Consts* consts) {
   const int hk = 1 << loghk;
+  if (hk <= 2 * kHashThreads) {
+    hipLaunchKernelGGL(fri_commit_small_kernel, dim3(batch), dim3(kTopThreads), 0, stream, layer, layer_stride, loghk,
+                       tree, tree_stride, consts);
+    return;
+  }
   hipLaunchKernelGGL(fri_leaf_kernel, dim3((hk + kHashThreads - 1) / kHashThreads, batch), dim3(kHashThreads), 0,
                      stream, layer, layer_stride, loghk, tree, tree_stride, consts);
   launch_upper_layers(stream, loghk, tree, tree_stride, batch, consts);

@@ -140,11 +140,26 @@ __global__ __launch_bounds__(kThreads) void keccak_quotient_kernel(const uint32_
                                                                   const uint32_t* __restrict__ alpha_pows,
                                                                   const uint32_t* __restrict__ sel_first,
                                                                   const uint32_t* __restrict__ sel_trans,
-                                                                  uint32_t* __restrict__ partial, int logh) {
+                                                                  uint32_t* __restrict__ partial, int logh,
+                                                                  int tiles_per_proof, int total_tiles) {
   const int h = 1 << logh, n = 2 * h;
-  const int pt = blockIdx.x * kThreads + threadIdx.x;
+  // A tile = 256 consecutive LDE points of one proof; its 62 constraint groups read
+  // overlapping column sets (about 5x re-use).  Workgroups are dealt round-robin
+  // over the 8 XCDs, so give every XCD whole tiles: all 62 groups of a tile run
+  // back to back behind ONE L2, and each column slice leaves HBM once.  (Placement
+  // only affects speed; any mapping is correct.)
+  int tile, g;
+  if ((total_tiles & 7) == 0) {
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    tile = (seq / ka::kNumGroups) * 8 + xcd;
+    g = seq % ka::kNumGroups;
+  } else {
+    tile = blockIdx.x / ka::kNumGroups;
+    g = blockIdx.x % ka::kNumGroups;
+  }
+  const int b = tile / tiles_per_proof;
+  const int pt = (tile - b * tiles_per_proof) * kThreads + threadIdx.x;
   if (pt >= n) return;
-  const int g = blockIdx.y, b = blockIdx.z;
   const int c = pt >= h ? 1 : 0, m = pt - c * h;
   const uint32_t* base = lde + (size_t)b * ka::kWidth * n + (size_t)c * h;
   QuotCtx ctx;
@@ -180,8 +195,9 @@ void launch_keccak_quotient(hipStream_t stream, const uint32_t* lde, const uint3
                             uint32_t* partial, uint32_t* quot, int logh, int batch) {
   const int n = 2 << logh;
   const int blocks = (n + kThreads - 1) / kThreads;
-  hipLaunchKernelGGL(keccak_quotient_kernel, dim3(blocks, ka::kNumGroups, batch), dim3(kThreads), 0, stream, lde,
-                     alpha_pows, sel_first, sel_trans, partial, logh);
+  const int total_tiles = blocks * batch;
+  hipLaunchKernelGGL(keccak_quotient_kernel, dim3((unsigned)total_tiles * ka::kNumGroups), dim3(kThreads), 0, stream,
+                     lde, alpha_pows, sel_first, sel_trans, partial, logh, blocks, total_tiles);
   hipLaunchKernelGGL(keccak_quotient_combine_kernel, dim3(blocks, batch), dim3(kThreads), 0, stream, partial, zh_inv,
                      quot, logh);
 }
