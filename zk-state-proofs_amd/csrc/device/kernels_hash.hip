@@ -136,6 +136,28 @@ __global__ __launch_bounds__(kTopThreads) void fri_commit_small_kernel(const uin
   coop_tree_levels(t, 0, hk, cc, consts);
 }
 
+// Latency form of the leaf layer for small batches: 16 lanes per matrix row, four
+// rows per wave.  With few rows the lane-per-row kernel leaves most SIMDs idle and
+// each lane walks its ceil(W/8) dependent permutations at full latency; here the
+// same rows spread over 16x more lanes and every permutation is about 5x shorter.
+// About 2x more VALU work in total, so it only pays while the chip is not full.
+__global__ __launch_bounds__(kHashThreads) void leaf_hash_coop_kernel(const uint32_t* __restrict__ mat,
+                                                                     size_t mat_stride, int width, int n_rows,
+                                                                     uint32_t* __restrict__ tree, size_t tree_stride,
+                                                                     const P2Consts* __restrict__ consts) {
+  const int e = threadIdx.x & 15;
+  const int row = blockIdx.x * (kHashThreads / 16) + (threadIdx.x >> 4);
+  const bool act = row < n_rows;
+  const CoopConsts cc = coop_load_consts(consts, e);
+  const uint32_t* m = mat + (size_t)blockIdx.y * mat_stride + (act ? row : 0);
+  Fp x = Fp::zero();
+  for (int c0 = 0; c0 < width; c0 += 8) {
+    if (e < 8 && c0 + e < width) x = Fp::raw(m[(size_t)(c0 + e) * n_rows]);
+    x = p2_permute_coop(x, cc, consts);
+  }
+  if (act && e < 8) tree[(size_t)blockIdx.y * tree_stride + (size_t)row * 8 + e] = x.v;
+}
+
 static void launch_upper_layers(hipStream_t stream, int logn, uint32_t* tree, size_t tree_stride, int batch,
                                 const P2Consts* consts) {
   size_t off = 0;
@@ -161,7 +183,12 @@ void launch_merkle_commit(hipStream_t stream, const uint32_t* mat, size_t mat_st
                           uint32_t* tree, size_t tree_stride, int batch, const P2Consts* consts, bool upper) {
   const int n = 1 << logn;
   const dim3 grid((n + kHashThreads - 1) / kHashThreads, batch);
-  if (width >= 64)
+  // fewer than 8 waves per CU of lane-per-row work: take the latency form
+  if (width >= 64 && (size_t)n * (size_t)batch <= 32768) {
+    const int rows_per_block = kHashThreads / 16;
+    hipLaunchKernelGGL(leaf_hash_coop_kernel, dim3((n + rows_per_block - 1) / rows_per_block, batch),
+                       dim3(kHashThreads), 0, stream, mat, mat_stride, width, n, tree, tree_stride, consts);
+  } else if (width >= 64)
     hipLaunchKernelGGL(leaf_hash_trace_kernel, grid, dim3(kHashThreads), 0, stream, mat, mat_stride, width, n, tree,
                        tree_stride, consts);
   else

@@ -11,6 +11,7 @@
 // transcript kernels, so that a whole batch of sponges advances in one wave).
 #include "air_keccak.cuh"
 #include "kernels.h"
+#include "poseidon2_coop.cuh"
 
 #include <cstdlib>
 
@@ -386,80 +387,85 @@ void launch_fri_fold(hipStream_t stream, const uint32_t* in, size_t in_stride, u
 // ===========================================================================
 // duplex challenger: one lane per proof
 // ===========================================================================
+// The sponge of one proof lives on 16 adjacent lanes (element e of the state, of
+// the input buffer and of the output buffer in lane e), so that every permutation
+// of this strictly sequential part runs in its cooperative, short-latency form.
 struct Ch {
-  Fp state[16];
-  Fp inbuf[8];
-  Fp outbuf[8];
-  int n_in, n_out;
+  Fp st, in, out;
+  int n_in, n_out;  // identical on the 16 lanes of a row
+  int e;
+  CoopConsts cc;
 };
-__device__ __forceinline__ void ch_load(const DevChallenger* d, Ch& c) {
-#pragma unroll
-  for (int i = 0; i < 16; ++i) c.state[i] = Fp::raw(d->state[i]);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { c.inbuf[i] = Fp::raw(d->inbuf[i]); c.outbuf[i] = Fp::raw(d->outbuf[i]); }
+__device__ __forceinline__ void ch_load(const DevChallenger* d, Ch& c, int e, const P2Consts* k) {
+  c.e = e;
+  c.cc = coop_load_consts(k, e);
+  c.st = Fp::raw(d->state[e]);
+  c.in = Fp::raw(d->inbuf[e & 7]);
+  c.out = Fp::raw(d->outbuf[e & 7]);
   c.n_in = d->n_in;
   c.n_out = d->n_out;
 }
 __device__ __forceinline__ void ch_store(DevChallenger* d, const Ch& c) {
-#pragma unroll
-  for (int i = 0; i < 16; ++i) d->state[i] = c.state[i].v;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { d->inbuf[i] = c.inbuf[i].v; d->outbuf[i] = c.outbuf[i].v; }
-  d->n_in = c.n_in;
-  d->n_out = c.n_out;
+  d->state[c.e] = c.st.v;
+  if (c.e < 8) {
+    d->inbuf[c.e] = c.in.v;
+    d->outbuf[c.e] = c.out.v;
+  }
+  if (c.e == 0) {
+    d->n_in = c.n_in;
+    d->n_out = c.n_out;
+  }
 }
 __device__ __forceinline__ void ch_duplex(Ch& c, const P2Consts* k) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-    if (i < c.n_in) c.state[i] = c.inbuf[i];
+  if (c.e < c.n_in) c.st = c.in;
   c.n_in = 0;
-  p2_permute(c.state, k);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) c.outbuf[i] = c.state[i];
+  c.st = p2_permute_coop(c.st, c.cc, k);
+  c.out = c.st;
   c.n_out = 8;
 }
 __device__ __forceinline__ void ch_observe(Ch& c, Fp x, const P2Consts* k) {
   c.n_out = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-    if (i == c.n_in) c.inbuf[i] = x;
+  if (c.e == c.n_in) c.in = x;
   c.n_in++;
   if (c.n_in == 8) ch_duplex(c, k);
 }
 __device__ __forceinline__ Fp ch_sample(Ch& c, const P2Consts* k) {
   if (c.n_in != 0 || c.n_out == 0) ch_duplex(c, k);
   c.n_out--;
-  Fp r = c.outbuf[0];
-#pragma unroll
-  for (int i = 1; i < 8; ++i)
-    if (i == c.n_out) r = c.outbuf[i];
-  return r;
+  return Fp::raw((uint32_t)__shfl((int)c.out.v, c.n_out, 16));
 }
 
-__global__ void ch_init_kernel(DevChallenger* ch, const uint32_t* __restrict__ init_obs, int n_obs, int batch,
-                               const P2Consts* __restrict__ k) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+constexpr int kChThreads = 64;  // four proofs per wave
+
+__global__ __launch_bounds__(kChThreads) void ch_init_kernel(DevChallenger* ch, const uint32_t* __restrict__ init_obs,
+                                                            int n_obs, int batch, const P2Consts* __restrict__ k) {
+  const int t = blockIdx.x * kChThreads + threadIdx.x, b = t >> 4, e = t & 15;
   if (b >= batch) return;
   Ch c;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) c.state[i] = Fp::zero();
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { c.inbuf[i] = Fp::zero(); c.outbuf[i] = Fp::zero(); }
+  c.e = e;
+  c.cc = coop_load_consts(k, e);
+  c.st = c.in = c.out = Fp::zero();
   c.n_in = 0;
   c.n_out = 0;
   for (int i = 0; i < n_obs; ++i) ch_observe(c, Fp::from_canonical(init_obs[(size_t)b * n_obs + i]), k);
   ch_store(ch + b, c);
 }
 
-__global__ void ch_observe_sample_kernel(DevChallenger* ch, const uint32_t* __restrict__ obs, size_t obs_stride,
-                                         int n_obs, uint32_t* __restrict__ out, size_t out_stride, int n_ext,
-                                         int batch, const P2Consts* __restrict__ k) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(kChThreads) void ch_observe_sample_kernel(DevChallenger* ch,
+                                                                      const uint32_t* __restrict__ obs,
+                                                                      size_t obs_stride, int n_obs,
+                                                                      uint32_t* __restrict__ out, size_t out_stride,
+                                                                      int n_ext, int batch,
+                                                                      const P2Consts* __restrict__ k) {
+  const int t = blockIdx.x * kChThreads + threadIdx.x, b = t >> 4, e = t & 15;
   if (b >= batch) return;
   Ch c;
-  ch_load(ch + b, c);
+  ch_load(ch + b, c, e, k);
   for (int i = 0; i < n_obs; ++i) ch_observe(c, Fp::raw(obs[(size_t)b * obs_stride + i]), k);
-  for (int i = 0; i < 4 * n_ext; ++i) out[(size_t)b * out_stride + i] = ch_sample(c, k).v;
+  for (int i = 0; i < 4 * n_ext; ++i) {
+    Fp v = ch_sample(c, k);
+    if (e == 0) out[(size_t)b * out_stride + i] = v.v;
+  }
   ch_store(ch + b, c);
 }
 
@@ -522,28 +528,31 @@ __global__ __launch_bounds__(kThreads) void ch_grind_tail_kernel(const DevChalle
   if (threadIdx.x == 0) witness[b] = found;
 }
 
-__global__ void ch_queries_kernel(DevChallenger* ch, const uint32_t* __restrict__ witness,
-                                  uint32_t* __restrict__ indices, int n_queries, int pow_bits, int index_bits,
-                                  int batch, const P2Consts* __restrict__ k) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(kChThreads) void ch_queries_kernel(DevChallenger* ch, const uint32_t* __restrict__ witness,
+                                                               uint32_t* __restrict__ indices, int n_queries,
+                                                               int pow_bits, int index_bits, int batch,
+                                                               const P2Consts* __restrict__ k) {
+  const int t = blockIdx.x * kChThreads + threadIdx.x, b = t >> 4, e = t & 15;
   if (b >= batch) return;
   Ch c;
-  ch_load(ch + b, c);
+  ch_load(ch + b, c, e, k);
   ch_observe(c, Fp::from_canonical(witness[b]), k);
   (void)ch_sample(c, k);  // the proof-of-work sample (zero in its low pow_bits by construction)
   (void)pow_bits;
-  for (int q = 0; q < n_queries; ++q)
-    indices[(size_t)b * n_queries + q] = ch_sample(c, k).to_canonical() & ((1u << index_bits) - 1);
+  for (int q = 0; q < n_queries; ++q) {
+    uint32_t v = ch_sample(c, k).to_canonical() & ((1u << index_bits) - 1);
+    if (e == 0) indices[(size_t)b * n_queries + q] = v;
+  }
   ch_store(ch + b, c);
 }
 
 void launch_ch_init(hipStream_t stream, DevChallenger* ch, const uint32_t* init_obs, int n_obs, int batch,
                     const P2Consts* consts) {
-  hipLaunchKernelGGL(ch_init_kernel, dim3((batch + 63) / 64), dim3(64), 0, stream, ch, init_obs, n_obs, batch, consts);
+  hipLaunchKernelGGL(ch_init_kernel, dim3((batch * 16 + kChThreads - 1) / kChThreads), dim3(kChThreads), 0, stream, ch, init_obs, n_obs, batch, consts);
 }
 void launch_ch_observe_sample(hipStream_t stream, DevChallenger* ch, const uint32_t* obs, size_t obs_stride, int n_obs,
                               uint32_t* out, size_t out_stride, int n_ext, int batch, const P2Consts* consts) {
-  hipLaunchKernelGGL(ch_observe_sample_kernel, dim3((batch + 63) / 64), dim3(64), 0, stream, ch, obs, obs_stride,
+  hipLaunchKernelGGL(ch_observe_sample_kernel, dim3((batch * 16 + kChThreads - 1) / kChThreads), dim3(kChThreads), 0, stream, ch, obs, obs_stride,
                      n_obs, out, out_stride, n_ext, batch, consts);
 }
 void launch_ch_grind(hipStream_t stream, DevChallenger* ch, uint32_t* witness, int bits, int batch,
@@ -556,7 +565,7 @@ void launch_ch_grind(hipStream_t stream, DevChallenger* ch, uint32_t* witness, i
 }
 void launch_ch_queries(hipStream_t stream, DevChallenger* ch, const uint32_t* witness, uint32_t* indices,
                        int n_queries, int pow_bits, int index_bits, int batch, const P2Consts* consts) {
-  hipLaunchKernelGGL(ch_queries_kernel, dim3((batch + 63) / 64), dim3(64), 0, stream, ch, witness, indices, n_queries,
+  hipLaunchKernelGGL(ch_queries_kernel, dim3((batch * 16 + kChThreads - 1) / kChThreads), dim3(kChThreads), 0, stream, ch, witness, indices, n_queries,
                      pow_bits, index_bits, batch, consts);
 }
 
