@@ -44,6 +44,23 @@ def init_obs(vk_words, logh, n_perms, exit_code, pv_digest, deferred):
     return o
 
 
+def measured_hbm_traffic(batch):
+    """HBM bytes per launch of leaf_hash_trace_kernel from the committed rocprofv3 PMC
+    collection (profiles/collect_r01.sh: FETCH_SIZE and WRITE_SIZE in separate passes,
+    KB units; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None
+    when no collection for this batch size is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_counters.json")
+    try:
+        d = json.load(open(path))
+        if int(d.get("batch", 64)) != batch:
+            return None
+        fetch = d["FETCH_SIZE"]["zksp::leaf_hash_trace_kernel"][0]
+        write = d["WRITE_SIZE"]["zksp::leaf_hash_trace_kernel"][0]
+        return (2.0 * fetch + write) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def usable_cores():
     """CPU share of this process: affinity mask capped by the cgroup quota and by the
     GPU box's stated per-GPU share (16)."""
@@ -241,7 +258,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": measured_hbm_traffic(B),
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_ms": leaf_ms,
             "note": "integer-ALU bound in practice (about 18 modular multiplies per byte absorbed); see DESIGN.md",

@@ -64,6 +64,52 @@ def test_keccak_quotient(gpu, oracle):
     assert (gpu.keccak_quotient(lde, alpha) == oracle.keccak_quotient(lde, alpha)).all()
 
 
+@pytest.mark.parametrize("logh,ncols,shifts", [(15, 3, (1, 31)), (16, 2, (1,)), (17, 1, (12345,)), (21, 2, (1,)),
+                                               (22, 1, (31,))])
+def test_lde_tall_columns(gpu, oracle, logh, ncols, shifts):
+    """Heights above 2^14 take the two-pass (strided + chunk) path; 2^21 is the
+    as-committed guest's CPU-chip height."""
+    rng = np.random.default_rng(100 + logh)
+    cols = rnd(rng, (ncols, 1 << logh))
+    for shift in shifts:
+        lde, coefs = gpu.lde(cols, shift)
+        elde, ecoefs = oracle.coset_lde(cols, shift, True)
+        assert (coefs == ecoefs).all(), (logh, shift)
+        assert (lde == elde).all(), (logh, shift)
+
+
+def test_lde_roundtrip_property_2p20(gpu):
+    """Size-independent check without the oracle: LDE of a low-degree column agrees
+    with direct evaluation at a few points of both cosets."""
+    logh = 20
+    h = 1 << logh
+    rng = np.random.default_rng(5)
+    deg = 7
+    coef = [int(x) for x in rng.integers(0, P, deg)]
+    w = pow(31, (P - 1) >> logh, P)
+    # evaluations of a degree-6 polynomial over the subgroup, built with numpy modular arithmetic
+    xs = np.ones(h, dtype=np.uint64)
+    acc = np.uint64(1)
+    pw = np.empty(h, dtype=np.uint64)
+    cur = 1
+    for i in range(h):
+        pw[i] = cur
+        cur = cur * w % P
+    col = np.zeros(h, dtype=np.uint64)
+    xp = np.ones(h, dtype=np.uint64)
+    for c in coef:
+        col = (col + np.uint64(c) * xp) % np.uint64(P)
+        xp = xp * pw % np.uint64(P)
+    lde, coefs = gpu.lde(col.astype(np.uint32).reshape(1, h), 1)
+    assert coefs[0, :deg].tolist() == coef and not coefs[0, deg:].any()
+    w2 = pow(31, (P - 1) >> (logh + 1), P)
+    ev = lambda x: sum(c * pow(x, k, P) for k, c in enumerate(coef)) % P
+    for c in range(2):
+        shift = 31 * (w2 if c else 1) % P
+        for m in (0, 1, 12345, h // 2, h - 1):
+            assert int(lde[0, c, m]) == ev(shift * pow(w, m, P) % P)
+
+
 @pytest.mark.parametrize("loghk", [1, 2, 6, 11])
 def test_fri_fold(gpu, oracle, loghk):
     rng = np.random.default_rng(loghk)

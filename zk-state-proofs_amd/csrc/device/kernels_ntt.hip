@@ -43,8 +43,8 @@ struct PassIo {
 //   DIF: stages s, s-1, .., s-R+1 (block sizes 2^s ..); group stride q = 2^(s-R)
 //   DIT: stages s, s+1, .., s+R-1;                      group stride q = 2^(s-1)
 template <int R, bool DIF, int NC>
-__device__ __forceinline__ void ntt_pass(const PassIo& io, const uint32_t* __restrict__ tw, int logh, int s, int ncols,
-                                         int tid) {
+__device__ __forceinline__ void ntt_pass(const PassIo& io, const uint32_t* __restrict__ tw, int logh, int tw_logh,
+                                         int s, int ncols, int tid) {
   constexpr int E = 1 << R;
   const int qlog = DIF ? s - R : s - 1;
   const int q = 1 << qlog;
@@ -75,7 +75,7 @@ __device__ __forceinline__ void ntt_pass(const PassIo& io, const uint32_t* __res
       // DIF walks from the widest pairing (k, k + E/2) down, DIT from (k, k+1) up
       const int hk = DIF ? (E >> (st + 1)) : (1 << st);
       const int stage = DIF ? s - st : s + st;
-      const int tw_shift = logh - stage;
+      const int tw_shift = tw_logh - stage;  // tw holds powers of the 2^tw_logh-th root
 #pragma unroll
       for (int k = 0; k < E; ++k) {
         if ((k & hk) != 0) continue;  // k is the lower element of its pair
@@ -114,11 +114,11 @@ __device__ __forceinline__ void ntt_pass(const PassIo& io, const uint32_t* __res
 }
 
 template <bool DIF, int NC>
-__device__ __forceinline__ void ntt_pass_r(int r, const PassIo& io, const uint32_t* tw, int logh, int s, int ncols,
-                                           int tid) {
-  if (r == 3) ntt_pass<3, DIF, NC>(io, tw, logh, s, ncols, tid);
-  else if (r == 2) ntt_pass<2, DIF, NC>(io, tw, logh, s, ncols, tid);
-  else ntt_pass<1, DIF, NC>(io, tw, logh, s, ncols, tid);
+__device__ __forceinline__ void ntt_pass_r(int r, const PassIo& io, const uint32_t* tw, int logh, int tw_logh, int s,
+                                           int ncols, int tid) {
+  if (r == 3) ntt_pass<3, DIF, NC>(io, tw, logh, tw_logh, s, ncols, tid);
+  else if (r == 2) ntt_pass<2, DIF, NC>(io, tw, logh, tw_logh, s, ncols, tid);
+  else ntt_pass<1, DIF, NC>(io, tw, logh, tw_logh, s, ncols, tid);
 }
 
 template <int NC>
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kLdeThreads) void lde_lds_kernel(const uint32_t* __
         io.src_glb_stride = (size_t)h;
         io.dst_glb_stride = (size_t)h;
         io.lds_stride = padded;
-        ntt_pass_r<true, NC>(r, io, tw_inv, logh, s, nc, tid);
+        ntt_pass_r<true, NC>(r, io, tw_inv, logh, logh, s, nc, tid);
         __syncthreads();
         s -= r;
         first = false;
@@ -189,12 +189,146 @@ __global__ __launch_bounds__(kLdeThreads) void lde_lds_kernel(const uint32_t* __
         io.src_glb_stride = 0;
         io.dst_glb_stride = (size_t)2 * h;  // adjacent columns are 2 cosets apart in the LDE
         io.lds_stride = padded;
-        ntt_pass_r<false, NC>(r, io, tw_fwd, logh, s, nc, tid);
+        ntt_pass_r<false, NC>(r, io, tw_fwd, logh, logh, s, nc, tid);
         __syncthreads();
         s += r;
         first = false;
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Heights above 2^14 (the as-committed guest's 2^21-row chips, SURVEY.md section 8
+// row f1): the column no longer fits LDS, so the H = H1*H2 transform is split the
+// four-step way into two LDS-staged passes per direction:
+//   "chunk" pass  : the low l2 stages, independent inside each contiguous run of
+//                   H2 = 2^l2 elements (the same register passes as above);
+//   "strided" pass: the high l1 stages, which couple elements H2 apart; a workgroup
+//                   stages an H1 x 16 tile (16 adjacent n2, so every row is a 64-byte
+//                   segment) and runs the l1 stages on it with the full-size twiddles.
+// DIF runs strided then chunk (natural -> bit-reversed), DIT chunk then strided.
+// ---------------------------------------------------------------------------
+constexpr int kStrideTile = 16;
+
+template <bool DIF>
+__global__ __launch_bounds__(kLdeThreads) void ntt_chunk_kernel(const uint32_t* __restrict__ src,
+                                                               uint32_t* __restrict__ dst, size_t src_col_stride,
+                                                               size_t dst_col_stride,
+                                                               const uint32_t* __restrict__ tw,
+                                                               const uint32_t* __restrict__ pre_scale,
+                                                               const uint32_t* __restrict__ post_scale, int logh,
+                                                               int l2) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  Fp* buf = reinterpret_cast<Fp*>(smem);
+  const size_t h2 = (size_t)1 << l2;
+  const size_t chunk = blockIdx.x, col = blockIdx.y;
+  const uint32_t* s0 = src + col * src_col_stride + chunk * h2;
+  uint32_t* d0 = dst + col * dst_col_stride + chunk * h2;
+  const uint32_t* pre = pre_scale ? pre_scale + chunk * h2 : nullptr;
+  const uint32_t* post = post_scale ? post_scale + chunk * h2 : nullptr;
+  const int tid = threadIdx.x;
+  int s = DIF ? l2 : 1;
+  bool first = true;
+  while (DIF ? s > 0 : s <= l2) {
+    int r;
+    bool last;
+    if (DIF) {
+      r = s >= 3 ? 3 : s;
+      last = (s - r) == 0;
+    } else {
+      const int rem = l2 - s + 1;
+      r = first ? ((rem % 3) ? (rem % 3) : 3) : 3;
+      last = (s + r) > l2;
+    }
+    PassIo io;
+    io.src_lds = buf;
+    io.src_glb = first ? s0 : nullptr;
+    io.pre_scale = first ? pre : nullptr;
+    io.dst_lds = last ? nullptr : buf;
+    io.dst_glb = last ? d0 : nullptr;
+    io.post_scale = last ? post : nullptr;
+    io.src_glb_stride = io.dst_glb_stride = 0;
+    io.lds_stride = 0;
+    ntt_pass_r<DIF, 1>(r, io, tw, l2, logh, s, 1, tid);
+    __syncthreads();
+    s = DIF ? s - r : s + r;
+    first = false;
+  }
+}
+
+// in place on `data`: the l1 = logh - l2 high stages of every column
+template <bool DIF>
+__global__ __launch_bounds__(kLdeThreads) void ntt_strided_kernel(uint32_t* __restrict__ data, size_t col_stride,
+                                                                 const uint32_t* __restrict__ tw, int logh, int l2) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  Fp* buf = reinterpret_cast<Fp*>(smem);
+  const int l1 = logh - l2;
+  const int h1 = 1 << l1;
+  const size_t h2 = (size_t)1 << l2;
+  const size_t n2_base = (size_t)blockIdx.x * kStrideTile;
+  uint32_t* d = data + (size_t)blockIdx.y * col_stride + n2_base;
+  const int tid = threadIdx.x;
+  // LDS image [n1][t] with one pad word per row (17-word rows: conflict-free column walks)
+  constexpr int kRow = kStrideTile + 1;
+  for (int i = tid; i < h1 * kStrideTile; i += kLdeThreads) {
+    const int n1 = i / kStrideTile, t = i % kStrideTile;
+    buf[n1 * kRow + t] = Fp::raw(d[(size_t)n1 * h2 + t]);
+  }
+  __syncthreads();
+  const int nbf = (h1 >> 1) * kStrideTile;
+  for (int st = 0; st < l1; ++st) {
+    const int s1 = DIF ? l1 - st : st + 1;  // stage inside the H1 transform; full-size stage = l2 + s1
+    const int half1 = 1 << (s1 - 1);
+    const int tw_shift = logh - (l2 + s1);
+    for (int i = tid; i < nbf; i += kLdeThreads) {
+      const int t = i % kStrideTile, b = i / kStrideTile;
+      const int j1 = b & (half1 - 1);
+      const int lo = ((b >> (s1 - 1)) << s1) | j1, hi = lo + half1;
+      // position inside the half block of the full-size stage: j1*H2 + n2
+      const size_t j = ((size_t)j1 << l2) + n2_base + t;
+      const Fp w = Fp::raw(tw[j << tw_shift]);
+      Fp u = buf[lo * kRow + t], v = buf[hi * kRow + t];
+      if (DIF) {
+        buf[lo * kRow + t] = u + v;
+        buf[hi * kRow + t] = (u - v) * w;
+      } else {
+        Fp x = v * w;
+        buf[lo * kRow + t] = u + x;
+        buf[hi * kRow + t] = u - x;
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < h1 * kStrideTile; i += kLdeThreads) {
+    const int n1 = i / kStrideTile, t = i % kStrideTile;
+    d[(size_t)n1 * h2 + t] = buf[n1 * kRow + t].v;
+  }
+}
+
+static void launch_lde_large(hipStream_t stream, const uint32_t* in, uint32_t* coefs_br, uint32_t* out,
+                             const uint32_t* tw_fwd, const uint32_t* tw_inv, const uint32_t* in_scale_br,
+                             const uint32_t* out_scale_br, int logh, size_t ncols) {
+  const size_t h = (size_t)1 << logh;
+  const int l2 = logh - logh / 2;  // low (contiguous) stages: 2^l2 <= 2^11 per chunk for logh <= 22
+  const int l1 = logh - l2;        // high (strided) stages: an H1 x 16 tile is at most 2^11 x 17 words of LDS
+  const size_t chunk_smem = sizeof(uint32_t) * (((size_t)1 << l2) + ((size_t)1 << l2 >> 3) + 4);
+  const size_t strided_smem = sizeof(uint32_t) * ((size_t)1 << l1) * (kStrideTile + 1);
+  const dim3 chunk_grid((unsigned)(h >> l2), (unsigned)ncols);
+  const dim3 sgrid((unsigned)(((size_t)1 << l2) / kStrideTile), (unsigned)ncols);
+  // inverse: copy into the second coset slot of the output as scratch, strided DIF in place, chunk DIF -> coefs
+  uint32_t* scratch = out + h;  // out[col][1]
+  (void)hipMemcpy2DAsync(scratch, 2 * h * 4, in, h * 4, h * 4, ncols, hipMemcpyDeviceToDevice, stream);
+  hipLaunchKernelGGL(ntt_strided_kernel<true>, sgrid, dim3(kLdeThreads), strided_smem, stream, scratch, 2 * h, tw_inv,
+                     logh, l2);
+  hipLaunchKernelGGL(ntt_chunk_kernel<true>, chunk_grid, dim3(kLdeThreads), chunk_smem, stream, scratch, coefs_br,
+                     2 * h, h, tw_inv, (const uint32_t*)nullptr, in_scale_br, logh, l2);
+  for (int cs = 0; cs < 2; ++cs) {
+    uint32_t* dst = out + (size_t)cs * h;
+    hipLaunchKernelGGL(ntt_chunk_kernel<false>, chunk_grid, dim3(kLdeThreads), chunk_smem, stream, coefs_br, dst, h,
+                       2 * h, tw_fwd, out_scale_br + (size_t)cs * h, (const uint32_t*)nullptr, logh, l2);
+    hipLaunchKernelGGL(ntt_strided_kernel<false>, sgrid, dim3(kLdeThreads), strided_smem, stream, dst, 2 * h, tw_fwd,
+                       logh, l2);
   }
 }
 
@@ -208,6 +342,11 @@ void launch_lde(hipStream_t stream, const uint32_t* in, uint32_t* coefs_br, uint
                 const uint32_t* tw_inv, const uint32_t* in_scale_br, int scale_sel_shift, int scale_sel_mask,
                 const uint32_t* out_scale_br, int logh, size_t ncols) {
   if (ncols == 0) return;
+  if (logh > 14) {
+    // scale-table selection is a quotient-chunk feature of the LDS path; tall columns all use table 0
+    launch_lde_large(stream, in, coefs_br, out, tw_fwd, tw_inv, in_scale_br, out_scale_br, logh, ncols);
+    return;
+  }
   const size_t h = (size_t)1 << logh;
   const int nc = lde_cols_per_block(logh);
   const size_t smem = (size_t)nc * 2 * sizeof(uint32_t) * (h + (h >> 3) + 4);
@@ -232,6 +371,14 @@ int lde_configure() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(lde_lds_kernel<4>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return (int)e;
+  const void* big[] = {reinterpret_cast<const void*>(ntt_chunk_kernel<true>),
+                       reinterpret_cast<const void*>(ntt_chunk_kernel<false>),
+                       reinterpret_cast<const void*>(ntt_strided_kernel<true>),
+                       reinterpret_cast<const void*>(ntt_strided_kernel<false>)};
+  for (const void* f : big) {
+    e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+  }
   return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(lde_lds_kernel<2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }

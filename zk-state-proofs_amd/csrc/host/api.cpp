@@ -519,9 +519,15 @@ int zksp_hip_lde(zksp_client* c, const uint32_t* d_in, int log_h, size_t ncols, 
     ZKSP_HIP_CHECK(ctx, hipMemcpy(tmp, br.data(), h * 4, hipMemcpyHostToDevice));
     table = tmp;
   }
+  uint32_t* tmp_coefs = nullptr;
+  if (log_h > 14 && !d_coefs_br) {  // the two-pass path stages coefficients in HBM
+    ZKSP_HIP_CHECK(ctx, hipMalloc(&tmp_coefs, ncols * h * 4));
+    d_coefs_br = tmp_coefs;
+  }
   launch_lde(ctx->stream, d_in, d_coefs_br, d_lde, dom->tw_fwd, dom->tw_inv, table, 0, 0, dom->out_scale_br, log_h, ncols);
   ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (tmp) ZKSP_HIP_CHECK(ctx, hipFree(tmp));
+  if (tmp_coefs) ZKSP_HIP_CHECK(ctx, hipFree(tmp_coefs));
   ZKSP_HIP_CHECK(ctx, hipGetLastError());
   return ZKSP_OK;
 }
@@ -564,6 +570,7 @@ int zksp_hip_keccak_quotient(zksp_client* c, const uint32_t* d_lde, int log_h, c
   NEED_GPU(c);
   Context* ctx = &c->ctx;
   if (!d_lde || !alpha || !d_quot) return ZKSP_ERR_INVALID_ARG;
+  if (log_h > 14) return ctx->fail(ZKSP_ERR_UNSUPPORTED, "keccak_quotient: log_h must be <= 14");
   const DeviceDomain* dom = ctx->domain(log_h);
   if (!dom) return ZKSP_ERR_UNSUPPORTED;
   const size_t n = (size_t)2 << log_h;

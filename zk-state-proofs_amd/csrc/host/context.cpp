@@ -62,7 +62,7 @@ static inline uint32_t bitrev32(uint32_t v, int bits) {
   return r;
 }
 
-void build_host_domain(int logh, HostDomain* d) {
+void build_host_domain(int logh, HostDomain* d, bool full) {
   const size_t h = (size_t)1 << logh;
   d->logh = logh;
   const Fp g = Fp::from_canonical(kGen);
@@ -93,9 +93,11 @@ void build_host_domain(int logh, HostDomain* d) {
     for (size_t pos = 0; pos < h; ++pos) d->in_scale_br[t][pos] = nat[bitrev32((uint32_t)pos, logh)];
   }
   d->out_scale_br.resize(2 * h);
-  d->xs.resize(2 * h);
-  d->sel_first.resize(2 * h);
-  d->sel_trans.resize(2 * h);
+  if (full) {
+    d->xs.resize(2 * h);
+    d->sel_first.resize(2 * h);
+    d->sel_trans.resize(2 * h);
+  }
   for (int c = 0; c < 2; ++c) {
     std::vector<uint32_t> nat(h);
     Fp p = Fp::one();
@@ -107,7 +109,7 @@ void build_host_domain(int logh, HostDomain* d) {
     const Fp zh = shifts[c].pow(h) - Fp::one();
     d->zh_inv[c] = zh.inv().v;
     Fp x = shifts[c];
-    for (size_t m = 0; m < h; ++m) {
+    for (size_t m = 0; full && m < h; ++m) {
       d->xs[c * h + m] = x.v;
       d->sel_first[c * h + m] = (zh * (x - Fp::one()).inv()).v;
       d->sel_trans[c * h + m] = (x - wh_inv).v;
@@ -154,12 +156,14 @@ static uint32_t* upload(Context* ctx, const uint32_t* src, size_t words, bool* o
 const DeviceDomain* Context::domain(int logh) {
   auto it = domains.find(logh);
   if (it != domains.end()) return &it->second;
-  if (!has_device() || logh < 1 || logh > 14) {
+  if (!has_device() || logh < 1 || logh > 22) {
     fail(9, "domain: unsupported log height");
     return nullptr;
   }
+  // heights above 2^14 are NTT-only (two-pass path): no constraint selectors
+  const bool full = logh <= 14;
   HostDomain hd;
-  build_host_domain(logh, &hd);
+  build_host_domain(logh, &hd, full);
   DeviceDomain dd;
   dd.logh = logh;
   dd.w_h = hd.w_h;
@@ -173,9 +177,11 @@ const DeviceDomain* Context::domain(int logh) {
     if (hipStreamSynchronize(stream) != hipSuccess) ok = false;
   }
   dd.out_scale_br = upload(this, hd.out_scale_br.data(), hd.out_scale_br.size(), &ok);
-  dd.xs = upload(this, hd.xs.data(), hd.xs.size(), &ok);
-  dd.sel_first = upload(this, hd.sel_first.data(), hd.sel_first.size(), &ok);
-  dd.sel_trans = upload(this, hd.sel_trans.data(), hd.sel_trans.size(), &ok);
+  if (full) {
+    dd.xs = upload(this, hd.xs.data(), hd.xs.size(), &ok);
+    dd.sel_first = upload(this, hd.sel_first.data(), hd.sel_first.size(), &ok);
+    dd.sel_trans = upload(this, hd.sel_trans.data(), hd.sel_trans.size(), &ok);
+  }
   dd.zh_inv = upload(this, hd.zh_inv, 2, &ok);
   // (shift_k * w_{2Hk}^c)^-1 for every fold round
   Fp shift = Fp::from_canonical(kGen);

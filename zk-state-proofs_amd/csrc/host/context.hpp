@@ -27,7 +27,7 @@ struct HostDomain {
   uint32_t zh_inv[2];
   uint32_t w_h;
 };
-void build_host_domain(int logh, HostDomain* d);
+void build_host_domain(int logh, HostDomain* d, bool full = true);
 
 struct DeviceDomain {
   int logh = 0;
