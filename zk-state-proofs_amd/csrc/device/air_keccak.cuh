@@ -28,16 +28,22 @@ constexpr int kNumConstraints = 3182;
 // Columns of the NEXT row that any constraint reads: flags, preimage, a.
 constexpr int kNextCols = 225;
 
-// Constraint groups (one GPU task each): MISC, C(x) x5, A(j) x25, P(x) x5,
-// CHI(j) x25, IOTA.
-constexpr int kNumGroups = 62;
-ZKSP_HD constexpr int group_base(int g) {
-  return g == 0 ? 0 : g <= 5 ? 250 + 128 * (g - 1) : g <= 30 ? 890 + 68 * (g - 6) : g <= 35 ? 2590 + 64 * (g - 31)
-                                                              : g <= 60 ? 2910 + 4 * (g - 36) : 3010;
-}
-ZKSP_HD constexpr int group_size(int g) {
-  return g == 0 ? 250 : g <= 5 ? 128 : g <= 30 ? 68 : g <= 35 ? 64 : g <= 60 ? 4 : 172;
-}
+// Constraint INDEX space (fixes which power of alpha multiplies which constraint):
+//   MISC 0..249, C(x) 250+128x (+2z bool, +2z+1 xor), A(j) 890+68j (+z bool, +64+l limb),
+//   P(x) 2590+64x (+z), CHI(j) 2910+4j (+l), IOTA 3010..3181;  j = 5y+x.
+// Evaluation SCHEDULE (which constraints one task evaluates together) is chosen for
+// the GPU: constraints that read the same columns share a task, so a lane loads
+// each column value once per task instead of once per constraint family:
+//   task 0        MISC
+//   task 1+x      S_x: C(x), A(5y+x) for y=0..4, P(x)   (c[x], c[x-1], c[x+1], c'[x], a'[.][x])
+//   task 6+Y      T_Y: CHI(5Y+X) for X=0..4             (the five rho-pi planes of row Y)
+//   task 11       IOTA
+constexpr int kNumTasks = 12;
+ZKSP_HD constexpr int base_c(int x) { return 250 + 128 * x; }
+ZKSP_HD constexpr int base_a(int j) { return 890 + 68 * j; }
+ZKSP_HD constexpr int base_p(int x) { return 2590 + 64 * x; }
+ZKSP_HD constexpr int base_chi(int j) { return 2910 + 4 * j; }
+constexpr int kBaseIota = 3010;
 
 struct Tables {
   uint64_t rc[24];
@@ -55,13 +61,16 @@ __host__ __device__ inline const Tables& tables() {
   return t;
 }
 
-// xor of three boolean-valued field elements as a degree-3 polynomial
+// xor of boolean-valued field elements as polynomials: a + b - 2ab, and
+// xor3 = xor(xor(a, b), c) = a+b+c - 2(ab+ac+bc) + 4abc (the same degree-3
+// polynomial as the expanded form, two multiplications instead of four)
+template <class F>
+ZKSP_HD F xor2(F a, F b) {
+  return a + b - (a * b).dbl();
+}
 template <class F>
 ZKSP_HD F xor3(F a, F b, F c) {
-  F ab = a * b;
-  F s2 = ab + a * c + b * c;
-  F abc = ab * c;
-  return a + b + c - s2.dbl() + abc.dbl().dbl();
+  return xor2(xor2(a, b), c);
 }
 
 // Column of bit z of B[X,Y] = rotl(A'[(X+3Y)%5, X], rot[(X+3Y)%5][X])
@@ -73,101 +82,112 @@ ZKSP_HD int b_col(int X, int Y, int z) {
 
 // Ctx interface:
 //   using F;  F local(int col); F next(int col);  F is_first(); F is_trans();
-//   F one();  void emit(F v);   (emit folds v with the next power of alpha)
+//   F one();  void emit_at(int k, F v);   (adds alpha^k * v to the folded sum)
 template <class Ctx>
-ZKSP_HD void eval_group(int g, Ctx& ctx) {
+ZKSP_HD void eval_task(int task, Ctx& ctx) {
   using F = typename Ctx::F;
   const F one = ctx.one();
-  if (g == 0) {
+  const F zero = one - one;
+  if (task == 0) {
     // ---- MISC: round flags, preimage bookkeeping, export ----
     const F is_first = ctx.is_first(), is_trans = ctx.is_trans();
     const F f0 = ctx.local(kFlags), f23 = ctx.local(kFlags + 23);
-    ctx.emit(is_first * (f0 - one));
-    for (int i = 1; i < 24; ++i) ctx.emit(is_first * ctx.local(kFlags + i));
-    for (int i = 0; i < 24; ++i) ctx.emit(is_trans * (ctx.next(kFlags + (i + 1) % 24) - ctx.local(kFlags + i)));
-    for (int j = 0; j < 100; ++j) ctx.emit(f0 * (ctx.local(kPreimage + j) - ctx.local(kA + j)));
+    int k = 0;
+    ctx.emit_at(k++, is_first * (f0 - one));
+    for (int i = 1; i < 24; ++i) ctx.emit_at(k++, is_first * ctx.local(kFlags + i));
+    for (int i = 0; i < 24; ++i) ctx.emit_at(k++, is_trans * (ctx.next(kFlags + (i + 1) % 24) - ctx.local(kFlags + i)));
+    for (int j = 0; j < 100; ++j) ctx.emit_at(k++, f0 * (ctx.local(kPreimage + j) - ctx.local(kA + j)));
     const F trans_nf = is_trans * (one - f23);
-    for (int j = 0; j < 100; ++j) ctx.emit(trans_nf * (ctx.next(kPreimage + j) - ctx.local(kPreimage + j)));
+    for (int j = 0; j < 100; ++j) ctx.emit_at(k++, trans_nf * (ctx.next(kPreimage + j) - ctx.local(kPreimage + j)));
     const F ex = ctx.local(kExport);
-    ctx.emit(ex * (ex - one));
-    ctx.emit((one - f23) * ex);
-  } else if (g <= 5) {
-    // ---- C(x): c bits boolean; c' = c[x] ^ c[x-1] ^ rotl(c[x+1], 1) ----
-    const int x = g - 1;
+    ctx.emit_at(k++, ex * (ex - one));
+    ctx.emit_at(k++, (one - f23) * ex);
+  } else if (task <= 5) {
+    // ---- S_x: theta for column x ----
+    //   C(x): c bits boolean; c' = c[x] ^ c[x-1] ^ rotl(c[x+1], 1)
+    //   A(j): a' bits boolean; a limbs = recompose(a' ^ c ^ c')
+    //   P(x): c'[x][z] is the parity of the a'[.][x][z] column
+    const int x = task - 1;
     const int xm = (x + 4) % 5, xp = (x + 1) % 5;
-    for (int z = 0; z < 64; ++z) {
-      F c = ctx.local(kC + 64 * x + z);
-      ctx.emit(c * (c - one));
-      F t = xor3(c, ctx.local(kC + 64 * xm + z), ctx.local(kC + 64 * xp + ((z + 63) & 63)));
-      ctx.emit(ctx.local(kCp + 64 * x + z) - t);
-    }
-  } else if (g <= 30) {
-    // ---- A(j): a' bits boolean; a limbs = recompose(a' ^ c ^ c') ----
-    const int j = g - 6, x = j % 5;
-    for (int z = 0; z < 64; ++z) {
-      F v = ctx.local(kAp + 64 * j + z);
-      ctx.emit(v * (v - one));
-    }
-    for (int l = 0; l < 4; ++l) {
-      F acc = xor3(ctx.local(kAp + 64 * j + 16 * l + 15), ctx.local(kC + 64 * x + 16 * l + 15),
-                   ctx.local(kCp + 64 * x + 16 * l + 15));
-      for (int z = 16 * l + 14; z >= 16 * l; --z)
-        acc = acc.dbl() + xor3(ctx.local(kAp + 64 * j + z), ctx.local(kC + 64 * x + z), ctx.local(kCp + 64 * x + z));
-      ctx.emit(ctx.local(kA + 4 * j + l) - acc);
-    }
-  } else if (g <= 35) {
-    // ---- P(x): c'[x][z] is the parity of the a'[.][x][z] column ----
-    const int x = g - 31;
     const F two = one.dbl(), four = two.dbl();
-    for (int z = 0; z < 64; ++z) {
-      F s = ctx.local(kAp + 64 * x + z);
-      for (int y = 1; y < 5; ++y) s = s + ctx.local(kAp + 64 * (5 * y + x) + z);
-      F d = s - ctx.local(kCp + 64 * x + z);
-      ctx.emit(d * (d - two) * (d - four));
-    }
-  } else if (g <= 60) {
-    // ---- CHI(j): a'' limbs = recompose(b ^ (~b[x+1] & b[x+2])) ----
-    const int j = g - 36, X = j % 5, Y = j / 5;
-    for (int l = 0; l < 4; ++l) {
-      F acc = one - one;
+    for (int l = 3; l >= 0; --l) {
+      F acc[5] = {zero, zero, zero, zero, zero};
       for (int z = 16 * l + 15; z >= 16 * l; --z) {
-        F b0 = ctx.local(b_col(X, Y, z));
-        F b1 = ctx.local(b_col((X + 1) % 5, Y, z));
-        F b2 = ctx.local(b_col((X + 2) % 5, Y, z));
-        F andn = (one - b1) * b2;
-        F t = b0 * andn;
-        acc = acc.dbl() + (b0 + andn - t.dbl());
+        const F c = ctx.local(kC + 64 * x + z);
+        const F cp = ctx.local(kCp + 64 * x + z);
+        ctx.emit_at(base_c(x) + 2 * z, c * (c - one));
+        ctx.emit_at(base_c(x) + 2 * z + 1,
+                    cp - xor3(c, ctx.local(kC + 64 * xm + z), ctx.local(kC + 64 * xp + ((z + 63) & 63))));
+        const F ccp = xor2(c, cp);  // bit z of D[x] = C[x] ^ C'[x], shared by the five lanes of the column
+        F s = zero;
+#pragma unroll
+        for (int y = 0; y < 5; ++y) {
+          const int j = 5 * y + x;
+          const F v = ctx.local(kAp + 64 * j + z);
+          ctx.emit_at(base_a(j) + z, v * (v - one));
+          acc[y] = acc[y].dbl() + xor2(v, ccp);
+          s = s + v;
+        }
+        const F d = s - cp;
+        ctx.emit_at(base_p(x) + z, d * (d - two) * (d - four));
       }
-      ctx.emit(ctx.local(kApp + 4 * j + l) - acc);
+#pragma unroll
+      for (int y = 0; y < 5; ++y) {
+        const int j = 5 * y + x;
+        ctx.emit_at(base_a(j) + 64 + l, ctx.local(kA + 4 * j + l) - acc[y]);
+      }
+    }
+  } else if (task <= 10) {
+    // ---- T_Y: chi for row Y: a'' limbs = recompose(b ^ (~b[x+1] & b[x+2])) ----
+    const int Y = task - 6;
+    for (int l = 0; l < 4; ++l) {
+      F acc[5] = {zero, zero, zero, zero, zero};
+      for (int z = 16 * l + 15; z >= 16 * l; --z) {
+        F bb[5];
+#pragma unroll
+        for (int X = 0; X < 5; ++X) bb[X] = ctx.local(b_col(X, Y, z));
+#pragma unroll
+        for (int X = 0; X < 5; ++X) {
+          const F andn = (one - bb[(X + 1) % 5]) * bb[(X + 2) % 5];
+          const F t = bb[X] * andn;
+          acc[X] = acc[X].dbl() + (bb[X] + andn - t.dbl());
+        }
+      }
+#pragma unroll
+      for (int X = 0; X < 5; ++X) {
+        const int j = 5 * Y + X;
+        ctx.emit_at(base_chi(j) + l, ctx.local(kApp + 4 * j + l) - acc[X]);
+      }
     }
   } else {
     // ---- IOTA: a''[0][0] bits, round constant, hand-over to the next row ----
+    int k = kBaseIota;
     for (int z = 0; z < 64; ++z) {
       F v = ctx.local(kApp00 + z);
-      ctx.emit(v * (v - one));
+      ctx.emit_at(k++, v * (v - one));
     }
     for (int l = 0; l < 4; ++l) {
       F acc = ctx.local(kApp00 + 16 * l + 15);
       for (int z = 16 * l + 14; z >= 16 * l; --z) acc = acc.dbl() + ctx.local(kApp00 + z);
-      ctx.emit(ctx.local(kApp + l) - acc);
+      ctx.emit_at(k++, ctx.local(kApp + l) - acc);
     }
     for (int l = 0; l < 4; ++l) {
-      F acc = one - one;
+      F acc = zero;
       for (int z = 16 * l + 15; z >= 16 * l; --z) {
-        F rc = one - one;
+        F rc = zero;
         for (int r = 0; r < 24; ++r)
           if ((tables().rc[r] >> z) & 1) rc = rc + ctx.local(kFlags + r);
         F v = ctx.local(kApp00 + z);
         F t = v * rc;
         acc = acc.dbl() + (v + rc - t.dbl());
       }
-      ctx.emit(ctx.local(kAppp00 + l) - acc);
+      ctx.emit_at(k++, ctx.local(kAppp00 + l) - acc);
     }
     const F trans_nf = ctx.is_trans() * (one - ctx.local(kFlags + 23));
     for (int j = 0; j < 25; ++j)
       for (int l = 0; l < 4; ++l) {
         F o = (j == 0) ? ctx.local(kAppp00 + l) : ctx.local(kApp + 4 * j + l);
-        ctx.emit(trans_nf * (ctx.next(kA + 4 * j + l) - o));
+        ctx.emit_at(k++, trans_nf * (ctx.next(kA + 4 * j + l) - o));
       }
   }
 }

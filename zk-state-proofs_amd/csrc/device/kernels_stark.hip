@@ -122,18 +122,32 @@ struct QuotCtx {
   const uint32_t* nxt;
   size_t cs;
   Fp first, trans;
-  const uint32_t* ap;  // alpha powers from this group's base index on (Fp4 each)
+  const uint32_t* ap;  // this proof's alpha powers (Fp4 each), indexed by constraint
   Fp4 acc;
+  uint64_t lazy[4];    // unreduced sum of up to two alpha^k_i * c_k products per coordinate
+  int pending;
   __device__ __forceinline__ F local(int col) const { return Fp::raw(loc[(size_t)col * cs]); }
   __device__ __forceinline__ F next(int col) const { return Fp::raw(nxt[(size_t)col * cs]); }
   __device__ __forceinline__ F is_first() const { return first; }
   __device__ __forceinline__ F is_trans() const { return trans; }
   __device__ __forceinline__ F one() const { return Fp::one(); }
-  __device__ __forceinline__ void emit(F v) {
-    Fp4 a;
-    a.c[0] = Fp::raw(ap[0]); a.c[1] = Fp::raw(ap[1]); a.c[2] = Fp::raw(ap[2]); a.c[3] = Fp::raw(ap[3]);
-    ap += 4;
-    acc += a * v;
+  // acc += alpha^k * v, coordinate by coordinate.  The four products are
+  // accumulated unreduced (one v_mad_u64_u32 each); two products stay below the
+  // Montgomery-reduction input bound (2 p^2 < 2^64 - 2^32 p), so one reduction
+  // serves two constraints.
+  __device__ __forceinline__ void emit_at(int k, F v) {
+    const uint32_t* p = ap + 4 * (size_t)k;  // wave-uniform address: scalar loads
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lazy[i] += (uint64_t)p[i] * v.v;
+    if (++pending == 2) flush();
+  }
+  __device__ __forceinline__ void flush() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc.c[i] = acc.c[i] + Fp::raw(Fp::reduce(lazy[i]));
+      lazy[i] = 0;
+    }
+    pending = 0;
   }
 };
 
@@ -144,19 +158,19 @@ __global__ __launch_bounds__(kThreads) void keccak_quotient_kernel(const uint32_
                                                                   uint32_t* __restrict__ partial, int logh,
                                                                   int tiles_per_proof, int total_tiles) {
   const int h = 1 << logh, n = 2 * h;
-  // A tile = 256 consecutive LDE points of one proof; its 62 constraint groups read
-  // overlapping column sets (about 5x re-use).  Workgroups are dealt round-robin
-  // over the 8 XCDs, so give every XCD whole tiles: all 62 groups of a tile run
-  // back to back behind ONE L2, and each column slice leaves HBM once.  (Placement
-  // only affects speed; any mapping is correct.)
+  // A tile = 256 consecutive LDE points of one proof; its 12 evaluation tasks read
+  // overlapping column sets.  Workgroups are dealt round-robin over the 8 XCDs, so
+  // give every XCD whole tiles: all tasks of a tile run back to back behind ONE L2
+  // and each column slice leaves HBM once.  (Placement only affects speed; any
+  // mapping is correct.)
   int tile, g;
   if ((total_tiles & 7) == 0) {
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-    tile = (seq / ka::kNumGroups) * 8 + xcd;
-    g = seq % ka::kNumGroups;
+    tile = (seq / ka::kNumTasks) * 8 + xcd;
+    g = seq % ka::kNumTasks;
   } else {
-    tile = blockIdx.x / ka::kNumGroups;
-    g = blockIdx.x % ka::kNumGroups;
+    tile = blockIdx.x / ka::kNumTasks;
+    g = blockIdx.x % ka::kNumTasks;
   }
   const int b = tile / tiles_per_proof;
   const int pt = (tile - b * tiles_per_proof) * kThreads + threadIdx.x;
@@ -169,10 +183,13 @@ __global__ __launch_bounds__(kThreads) void keccak_quotient_kernel(const uint32_
   ctx.cs = (size_t)n;
   ctx.first = Fp::raw(sel_first[pt]);
   ctx.trans = Fp::raw(sel_trans[pt]);
-  ctx.ap = alpha_pows + ((size_t)b * ka::kNumConstraints + ka::group_base(g)) * 4;
+  ctx.ap = alpha_pows + (size_t)b * ka::kNumConstraints * 4;
   ctx.acc = Fp4::zero();
-  ka::eval_group(g, ctx);
-  store_fp4(partial + (((size_t)b * ka::kNumGroups + g) * n + pt) * 4, ctx.acc);
+  ctx.lazy[0] = ctx.lazy[1] = ctx.lazy[2] = ctx.lazy[3] = 0;
+  ctx.pending = 0;
+  ka::eval_task(g, ctx);
+  ctx.flush();
+  store_fp4(partial + (((size_t)b * ka::kNumTasks + g) * n + pt) * 4, ctx.acc);
 }
 
 __global__ __launch_bounds__(kThreads) void keccak_quotient_combine_kernel(const uint32_t* __restrict__ partial,
@@ -184,7 +201,7 @@ __global__ __launch_bounds__(kThreads) void keccak_quotient_combine_kernel(const
   const int b = blockIdx.y;
   const int c = pt >= h ? 1 : 0, m = pt - c * h;
   Fp4 acc = Fp4::zero();
-  for (int g = 0; g < ka::kNumGroups; ++g) acc += load_fp4(partial + (((size_t)b * ka::kNumGroups + g) * n + pt) * 4);
+  for (int g = 0; g < ka::kNumTasks; ++g) acc += load_fp4(partial + (((size_t)b * ka::kNumTasks + g) * n + pt) * 4);
   acc = acc * Fp::raw(zh_inv[c]);
   uint32_t* q = quot + (size_t)b * 8 * h + m;
 #pragma unroll
@@ -197,7 +214,7 @@ void launch_keccak_quotient(hipStream_t stream, const uint32_t* lde, const uint3
   const int n = 2 << logh;
   const int blocks = (n + kThreads - 1) / kThreads;
   const int total_tiles = blocks * batch;
-  hipLaunchKernelGGL(keccak_quotient_kernel, dim3((unsigned)total_tiles * ka::kNumGroups), dim3(kThreads), 0, stream,
+  hipLaunchKernelGGL(keccak_quotient_kernel, dim3((unsigned)total_tiles * ka::kNumTasks), dim3(kThreads), 0, stream,
                      lde, alpha_pows, sel_first, sel_trans, partial, logh, blocks, total_tiles);
   hipLaunchKernelGGL(keccak_quotient_combine_kernel, dim3(blocks, batch), dim3(kThreads), 0, stream, partial, zh_inv,
                      quot, logh);

@@ -98,7 +98,7 @@ struct VerifyCtx {
   F is_first() const { return first; }
   F is_trans() const { return trans; }
   F one() const { return Fp4::one(); }
-  void emit(F v) { acc += (*ap++) * v; }
+  void emit_at(int k, F v) { acc += ap[k] * v; }
 };
 
 bool all_canonical(const uint32_t* w, size_t n) {
@@ -224,10 +224,8 @@ int verify_proof(const uint8_t* bytes, size_t len, const uint32_t vk_digest[8], 
     vc.first = zh * (zeta - Fp4::one()).inv();
     vc.trans = zeta - Fp4::from_base(wh_inv);
     vc.acc = Fp4::zero();
-    for (int grp = 0; grp < ka::kNumGroups; ++grp) {
-      vc.ap = apow.data() + ka::group_base(grp);
-      ka::eval_group(grp, vc);
-    }
+    vc.ap = apow.data();
+    for (int task = 0; task < ka::kNumTasks; ++task) ka::eval_task(task, vc);
     // quotient(zeta) from its two chunk polynomials
     Fp4 q[2];
     for (int c = 0; c < 2; ++c) {
