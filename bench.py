@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-single", action="store_true", help="skip the batch-of-1 latency section (profiling runs)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + ZKSP_BENCH_SAME_DEVICE=1 rehearses the N>1 path on a one-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -114,12 +116,18 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and the proving path has no CPU fallback")
+    if os.environ.get("ZKSP_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0  # rehearsal: every rank on cuda:0 (RCCL refuses that, hence gloo)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    coll_device = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else None
 
     zk = importlib.import_module("zk-state-proofs_amd")
     fx = importlib.import_module("zk-state-proofs_amd.fixtures")
@@ -175,19 +183,18 @@ def main():
     sync()
     if dist is not None:
         # the one exchange the path has: 32-byte trace commitments of every proof to every rank
-        bw = lib.zksp_proof_body_words(h, LOG_H)
-        bodies = np.zeros((B, bw), np.uint32)
-        check(lib.zksp_hip_fetch_bodies(h, bodies.ctypes.data_as(C.c_void_p), bodies.size))
+        local_roots = np.zeros((B, 8), np.uint32)
+        check(lib.zksp_hip_fetch_roots(h, local_roots.ctypes.data_as(C.c_void_p), local_roots.size))
         n_total = world * B
         mine = farm.shard_indices(n_total, rank, world)
-        roots = farm.gather_roots(bodies[:, :8], n_total, rank, world, device=torch.device("cuda", local_rank))
-        assert roots.shape == (n_total, 8) and np.array_equal(roots[mine], bodies[:, :8])
+        roots = farm.gather_roots(local_roots, n_total, rank, world, device=coll_device)
+        assert roots.shape == (n_total, 8) and np.array_equal(roots[mine], local_roots)
     barrier()
     sync()
     elapsed = time.perf_counter() - t0
     lib.zksp_hip_profile_enable(h, 0)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device if coll_device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

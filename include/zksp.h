@@ -139,6 +139,9 @@ int zksp_hip_load_batch(zksp_client* c, int log_h, size_t n, size_t max_perms, c
 int zksp_hip_prove_resident(zksp_client* c);
 /* Copies proof bodies [n][body_words] (canonical u32) to the host; synchronises. */
 int zksp_hip_fetch_bodies(zksp_client* c, uint32_t* out, size_t cap_words);
+/* Copies only the 8-word main-trace commitment of every resident proof ([n][8],
+ * canonical u32): the 32 bytes per proof the multi-GPU farm all-gathers. */
+int zksp_hip_fetch_roots(zksp_client* c, uint32_t* out, size_t cap_words);
 int zksp_hip_sync(zksp_client* c);
 /* HIP-event timing on the client's own stream. */
 int zksp_hip_timer_start(zksp_client* c);

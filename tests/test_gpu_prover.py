@@ -35,6 +35,9 @@ def device_bodies(g, logh, states_list, obs_list):
     bw = g.lib.zksp_proof_body_words(g.h, logh)
     out = np.zeros((n, bw), np.uint32)
     g.check(g.lib.zksp_hip_fetch_bodies(g.h, out.ctypes.data_as(C.c_void_p), out.size))
+    roots = np.zeros((n, 8), np.uint32)
+    g.check(g.lib.zksp_hip_fetch_roots(g.h, roots.ctypes.data_as(C.c_void_p), roots.size))
+    assert np.array_equal(roots, out[:, :8])
     return out
 
 

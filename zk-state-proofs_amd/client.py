@@ -106,6 +106,7 @@ def load_library() -> C.CDLL:
     lib.zksp_hip_load_batch.argtypes = [vp, C.c_int, sz, sz, vp, vp, vp]
     lib.zksp_hip_prove_resident.argtypes = [vp]
     lib.zksp_hip_fetch_bodies.argtypes = [vp, vp, sz]
+    lib.zksp_hip_fetch_roots.argtypes = [vp, vp, sz]
     lib.zksp_hip_sync.argtypes = [vp]
     lib.zksp_hip_timer_start.argtypes = [vp]
     lib.zksp_hip_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
@@ -134,7 +135,7 @@ ABI_SYMBOLS = [
     "zksp_vk_digest", "zksp_stdin_new", "zksp_stdin_write", "zksp_stdin_free", "zksp_prove", "zksp_prove_batch",
     "zksp_proof_public_values", "zksp_proof_serialize", "zksp_proof_deserialize", "zksp_proof_free", "zksp_verify",
     "zksp_execute", "zksp_execute_keccak", "zksp_opcode_name", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
-    "zksp_hip_prove_resident", "zksp_hip_fetch_bodies", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
+    "zksp_hip_prove_resident", "zksp_hip_fetch_bodies", "zksp_hip_fetch_roots", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
     "zksp_hip_profile_enable", "zksp_hip_profile_read", "zksp_hip_profile_reset", "zksp_dev_malloc", "zksp_dev_free",
     "zksp_dev_upload", "zksp_dev_download", "zksp_dev_memset", "zksp_hip_lde", "zksp_hip_merkle_commit",
     "zksp_hip_poseidon2_permute", "zksp_hip_keccak_trace", "zksp_hip_keccak_quotient", "zksp_hip_fri_fold",

@@ -236,6 +236,19 @@ int zksp_hip_fetch_bodies(zksp_client* c, uint32_t* out, size_t cap_words) {
   return ZKSP_OK;
 }
 
+int zksp_hip_fetch_roots(zksp_client* c, uint32_t* out, size_t cap_words) {
+  if (!c || !out) return ZKSP_ERR_INVALID_ARG;
+  Context* ctx = &c->ctx;
+  Workspace* ws = ctx->ws.get();
+  if (!ws || ws->n == 0) return ctx->fail(ZKSP_ERR_INVALID_ARG, "fetch_roots: no batch");
+  if (cap_words < (size_t)ws->n * 8) return ctx->fail(ZKSP_ERR_INVALID_ARG, "fetch_roots: buffer too small");
+  // the trace commitment is the first 8 words of every proof body
+  ZKSP_HIP_CHECK(ctx, hipMemcpy2DAsync(out, 32, ws->body, ws->body_words * 4, 32, (size_t)ws->n, hipMemcpyDeviceToHost,
+                                       ctx->stream));
+  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return ZKSP_OK;
+}
+
 int zksp_hip_sync(zksp_client* c) {
   if (!c || !c->ctx.has_device()) return ZKSP_ERR_INVALID_ARG;
   ZKSP_HIP_CHECK(&c->ctx, hipStreamSynchronize(c->ctx.stream));
