@@ -1,0 +1,93 @@
+// Sanitiser harness for the host side of the boundary (CPU build only; GPU ASan is not
+// available on this pool): mutates ELF images, stdin buffers and proof bytes and drives
+// load_elf / execute / parse_proof_header / verify_proof under ASan + UBSan.
+// Built and run by tests/test_host_sanitizers.py.  Exit code 0 = no finding.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <random>
+#include <vector>
+
+#include "executor.hpp"
+#include "verifier.hpp"
+
+using namespace zksp;
+
+static std::vector<uint8_t> slurp(const char* p) {
+  std::ifstream f(p, std::ios::binary);
+  return {std::istreambuf_iterator<char>(f), {}};
+}
+
+int main(int argc, char** argv) {
+  if (argc < 4) {
+    fprintf(stderr, "usage: host_fuzz ELF STDIN PROOF [iters]\n");
+    return 2;
+  }
+  const std::vector<uint8_t> elf = slurp(argv[1]), input = slurp(argv[2]), proof = slurp(argv[3]);
+  const int iters = argc > 4 ? atoi(argv[4]) : 200;
+  std::mt19937_64 rng(12345);
+  ElfImage good;
+  if (!load_elf(elf.data(), elf.size(), &good).empty()) return 3;
+  uint32_t vk[8];
+  memcpy(vk, proof.data() + 22 * 4, 32);
+  std::string err;
+  if (verify_proof(proof.data(), proof.size(), vk, 12, 8, &err) != 0) {
+    fprintf(stderr, "baseline proof rejected: %s\n", err.c_str());
+    return 4;
+  }
+  size_t elf_ok = 0, exec_halt = 0, ver_ok = 0;
+  for (int it = 0; it < iters; ++it) {
+    // 1. corrupted ELF headers / bodies
+    {
+      std::vector<uint8_t> e = elf;
+      int n = 1 + (int)(rng() % 8);
+      for (int k = 0; k < n; ++k) {
+        size_t pos = (it % 3 == 0) ? rng() % 256 : rng() % e.size();  // bias towards the headers
+        e[pos] = (uint8_t)rng();
+      }
+      if (it % 7 == 0) e.resize(rng() % e.size());
+      ElfImage img;
+      if (load_elf(e.data(), e.size(), &img).empty()) {
+        ++elf_ok;
+        ExecOptions o;
+        o.max_cycles = 200000;
+        o.keccak_mode = (KeccakMode)(it % 3);
+        ExecutionRecord r = execute(img, {input}, o);
+        exec_halt += r.halted;
+      }
+    }
+    // 2. corrupted stdin
+    {
+      std::vector<uint8_t> s = input;
+      int n = 1 + (int)(rng() % 4);
+      for (int k = 0; k < n; ++k) s[rng() % s.size()] = (uint8_t)rng();
+      if (it % 5 == 0) s.resize(rng() % s.size());
+      ExecOptions o;
+      o.max_cycles = 3000000;
+      o.keccak_mode = (KeccakMode)(it % 3);
+      ExecutionRecord r = execute(good, {s}, o);
+      exec_halt += r.halted;
+    }
+    // 3. corrupted proofs
+    {
+      std::vector<uint8_t> p = proof;
+      int n = 1 + (int)(rng() % 4);
+      for (int k = 0; k < n; ++k) {
+        size_t pos = (it % 2 == 0) ? rng() % 200 : rng() % p.size();
+        p[pos] ^= (uint8_t)(1u << (rng() % 8));
+      }
+      if (it % 11 == 0) p.resize(rng() % p.size());
+      ProofHeader h;
+      std::string e2;
+      if (parse_proof_header(p.data(), p.size(), &h, &e2)) {
+        int rc = verify_proof(p.data(), p.size(), vk, 12, 8, &e2);
+        if (rc == 0) ++ver_ok;
+      }
+    }
+  }
+  printf("fuzz ok: %d iterations, %zu mutated ELFs loaded, %zu guest runs halted, %zu mutated proofs accepted\n", iters,
+         elf_ok, exec_halt, ver_ok);
+  return ver_ok == 0 ? 0 : 5;  // a mutated proof must never verify
+}

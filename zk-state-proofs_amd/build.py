@@ -22,6 +22,7 @@ SOURCES = [
     "device/kernels_stark.hip",
     "device/kernels_bench.hip",
     "host/executor.cpp",
+    "host/params.cpp",
     "host/context.cpp",
     "host/prover.cpp",
     "host/verifier.cpp",

@@ -304,11 +304,12 @@ ExecutionRecord execute(const ElfImage& elf, const std::vector<std::vector<uint8
   }
   uint8_t* M = mem.base;
   for (const auto& s : elf.segs) {
-    if ((uint64_t)s.vaddr + s.memsz > kMemBytes) {
+    const uint64_t extent = s.bytes.size() > s.memsz ? s.bytes.size() : s.memsz;  // a hostile p_filesz > p_memsz
+    if ((uint64_t)s.vaddr + extent > kMemBytes) {
       rec.error = "segment beyond guest memory";
       return rec;
     }
-    memcpy(M + s.vaddr, s.bytes.data(), s.bytes.size());
+    if (!s.bytes.empty()) memcpy(M + s.vaddr, s.bytes.data(), s.bytes.size());
   }
   std::vector<Decoded> code(elf.text.size());
   for (size_t i = 0; i < elf.text.size(); ++i) code[i] = decode(elf.text[i]);
