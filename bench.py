@@ -218,7 +218,7 @@ def main():
         return
 
     # ---- single-proof numbers (rank 0, after the timed region) ----
-    single_ms = e2e_ms = None
+    single_ms = e2e_ms = e2e_batch_rate = None
     if not args.skip_single:
         check(lib.zksp_hip_load_batch(h, LOG_H, 1, 62, states.ctypes.data_as(C.c_void_p),
                                       n_perms.ctypes.data_as(C.c_void_p), obs.ctypes.data_as(C.c_void_p)))
@@ -235,6 +235,18 @@ def main():
         proof = client.prove(pk, stdin).run()
         e2e_ms = (time.perf_counter() - t2) * 1e3
         client.verify(proof, vk)
+        # the drop-in call on a whole batch: executor + H2D + proving + D2H + proof objects
+        nb = 2 * B if B >= 64 else B
+        stdins = []
+        for i in range(nb):
+            sdin = zk.SP1Stdin()
+            sdin.write(fx.acct_fixture(8, seed=1000 + i).to_borsh())
+            stdins.append(sdin)
+        t3 = time.perf_counter()
+        proofs, status = client.prove_batch(pk, stdins)
+        e2e_batch_s = time.perf_counter() - t3
+        assert status == [0] * nb
+        e2e_batch_rate = nb / e2e_batch_s
 
     total_proofs = world * B * args.steps
     out = {
@@ -274,6 +286,7 @@ def main():
         "single_proof_device_ms": single_ms,
         "single_proof_end_to_end_ms": e2e_ms,
         "host_executor_ms_per_proof": exec_ms_per_proof,
+        "prove_batch_end_to_end_proofs_per_s": e2e_batch_rate,
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(states[0], vk_words, pv, args.cpu_seconds)

@@ -27,10 +27,11 @@ SOURCES = [
     "host/prover.cpp",
     "host/verifier.cpp",
     "host/api.cpp",
+    "host/api_prove.cpp",
 ]
 HEADERS = [
     "device/field.cuh", "device/poseidon2.cuh", "device/air_keccak.cuh", "device/kernels.h",
-    "host/executor.hpp", "host/context.hpp", "host/prover.hpp", "host/verifier.hpp",
+    "host/executor.hpp", "host/context.hpp", "host/prover.hpp", "host/verifier.hpp", "host/api_types.hpp",
 ]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

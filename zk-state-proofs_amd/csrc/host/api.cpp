@@ -12,13 +12,9 @@
 #include "prover.hpp"
 #include "verifier.hpp"
 
-using namespace zksp;
+#include "api_types.hpp"
 
-struct zksp_client { Context ctx; };
-struct zksp_pk { ElfImage elf; uint32_t vk_digest[8]; };
-struct zksp_vk { uint32_t digest[8]; };
-struct zksp_stdin { std::vector<std::vector<uint8_t>> entries; };
-struct zksp_proof { std::vector<uint8_t> bytes; ProofHeader hdr; };
+using namespace zksp;
 
 namespace {
 
@@ -35,23 +31,6 @@ void compute_vk_digest(const ElfImage& elf, uint32_t out[8]) {
     out[i] = w % kP;
   }
 }
-
-int ceil_log2(size_t v) {
-  int l = 0;
-  while (((size_t)1 << l) < v) ++l;
-  return l;
-}
-
-int trace_log_height(size_t n_perms) {
-  int l = ceil_log2(std::max<size_t>(24 * n_perms, 32));
-  return l;
-}
-
-struct Job {
-  size_t index;
-  ExecutionRecord rec;
-  int logh;
-};
 
 }  // namespace
 
@@ -298,136 +277,6 @@ int zksp_hip_profile_read(zksp_client* c, const char* kernel, double* total_ms, 
 // ---------------------------------------------------------------------------
 // prove / verify
 // ---------------------------------------------------------------------------
-int zksp_prove_batch(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdins, size_t n, zksp_proof** out,
-                     int32_t* status) {
-  if (!c || !pk || !stdins || !out || !status || n == 0) return ZKSP_ERR_INVALID_ARG;
-  Context* ctx = &c->ctx;
-  if (!ctx->has_device())
-    return ctx->fail(ZKSP_ERR_NO_DEVICE, "prove: this client was created without a GPU; there is no CPU proving path");
-  for (size_t i = 0; i < n; ++i) { out[i] = nullptr; status[i] = ZKSP_ERR_INVALID_ARG; }
-  // 1. executor (host, one guest run per input, farmed over host threads)
-  std::vector<Job> jobs(n);
-  {
-    std::atomic<size_t> next{0};
-    unsigned nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)n));
-    auto work = [&]() {
-      for (;;) {
-        size_t i = next.fetch_add(1);
-        if (i >= n) break;
-        jobs[i].index = i;
-        if (!stdins[i]) continue;
-        ExecOptions o;
-        o.keccak_mode = (KeccakMode)ctx->params.keccak_mode;
-        jobs[i].rec = execute(pk->elf, stdins[i]->entries, o);
-        stdins[i]->entries.clear();  // consumed, as SP1Stdin is by prove()
-      }
-    };
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
-    work();
-    for (auto& t : th) t.join();
-  }
-  std::map<int, std::vector<size_t>> by_height;
-  std::string first_err;
-  for (size_t i = 0; i < n; ++i) {
-    ExecutionRecord& r = jobs[i].rec;
-    if (!stdins[i]) continue;
-    if (!r.error.empty() || !r.halted) {
-      status[i] = ZKSP_ERR_EXECUTOR;
-      if (first_err.empty()) first_err = "executor: " + (r.error.empty() ? std::string("guest did not halt") : r.error);
-      continue;
-    }
-    if (r.exit_code != 0) {
-      status[i] = ZKSP_ERR_GUEST_PANIC;
-      if (first_err.empty()) first_err = "guest panicked (exit code " + std::to_string(r.exit_code) + "): " + r.stderr_text;
-      continue;
-    }
-    if (r.keccak_events.empty()) {
-      status[i] = ZKSP_ERR_EXECUTOR;
-      if (first_err.empty()) first_err = "guest made no keccak-f calls";
-      continue;
-    }
-    jobs[i].logh = trace_log_height(r.keccak_events.size());
-    if (jobs[i].logh > 14) { status[i] = ZKSP_ERR_UNSUPPORTED; continue; }
-    by_height[jobs[i].logh].push_back(i);
-  }
-  // 2. device proving, grouped by trace height, max_batch proofs in lockstep
-  int rc_all = ZKSP_OK;
-  for (auto& kv : by_height) {
-    const int logh = kv.first;
-    const std::vector<size_t>& idxs = kv.second;
-    for (size_t off = 0; off < idxs.size(); off += ctx->params.max_batch) {
-      const size_t cnt = std::min<size_t>(ctx->params.max_batch, idxs.size() - off);
-      size_t max_perms = 0;
-      for (size_t j = 0; j < cnt; ++j) max_perms = std::max(max_perms, jobs[idxs[off + j]].rec.keccak_events.size());
-      std::vector<uint64_t> states(cnt * max_perms * 25, 0);
-      std::vector<uint32_t> np(cnt), obs(cnt * kInitObs);
-      for (size_t j = 0; j < cnt; ++j) {
-        const ExecutionRecord& r = jobs[idxs[off + j]].rec;
-        for (size_t p = 0; p < r.keccak_events.size(); ++p)
-          memcpy(&states[(j * max_perms + p) * 25], r.keccak_events[p].state_in, 200);
-        np[j] = (uint32_t)r.keccak_events.size();
-        uint32_t* o = &obs[j * kInitObs];
-        memcpy(o, pk->vk_digest, 32);
-        o[8] = (uint32_t)logh;
-        o[9] = np[j];
-        o[10] = r.exit_code & 0xffff;
-        o[11] = r.exit_code >> 16;
-        for (int w = 0; w < 8; ++w) {
-          o[12 + 2 * w] = r.pv_digest[w] & 0xffff;
-          o[13 + 2 * w] = r.pv_digest[w] >> 16;
-          o[28 + 2 * w] = r.deferred_digest[w] & 0xffff;
-          o[29 + 2 * w] = r.deferred_digest[w] >> 16;
-        }
-      }
-      int rc = zksp_hip_load_batch(c, logh, cnt, max_perms, states.data(), np.data(), obs.data());
-      if (rc == ZKSP_OK) rc = zksp_hip_prove_resident(c);
-      const size_t bw = proof_body_words(logh, ctx->params.num_queries);
-      std::vector<uint32_t> bodies(cnt * bw);
-      if (rc == ZKSP_OK) rc = zksp_hip_fetch_bodies(c, bodies.data(), bodies.size());
-      if (rc != ZKSP_OK) {
-        for (size_t j = 0; j < cnt; ++j) status[idxs[off + j]] = rc;
-        rc_all = rc;
-        continue;
-      }
-      for (size_t j = 0; j < cnt; ++j) {
-        const size_t i = idxs[off + j];
-        const ExecutionRecord& r = jobs[i].rec;
-        zksp_proof* p = new (std::nothrow) zksp_proof();
-        if (!p) { status[i] = ZKSP_ERR_INVALID_ARG; continue; }
-        const uint32_t pv_len = (uint32_t)r.public_values.size();
-        const size_t hw = proof_header_words(pv_len);
-        p->bytes.assign((hw + bw) * 4, 0);
-        uint32_t* w = reinterpret_cast<uint32_t*>(p->bytes.data());
-        w[0] = kProofMagic; w[1] = kProofVersion; w[2] = (uint32_t)logh; w[3] = np[j]; w[4] = r.exit_code; w[5] = pv_len;
-        memcpy(w + 6, r.pv_digest.data(), 32);
-        memcpy(w + 14, r.deferred_digest.data(), 32);
-        memcpy(w + 22, pk->vk_digest, 32);
-        if (pv_len) memcpy(p->bytes.data() + 120, r.public_values.data(), pv_len);
-        memcpy(w + hw, &bodies[j * bw], bw * 4);
-        std::string perr;
-        if (!parse_proof_header(p->bytes.data(), p->bytes.size(), &p->hdr, &perr)) {
-          delete p;
-          status[i] = ZKSP_ERR_PROOF_FORMAT;
-          continue;
-        }
-        out[i] = p;
-        status[i] = ZKSP_OK;
-      }
-    }
-  }
-  if (!first_err.empty() && rc_all == ZKSP_OK) ctx->error = first_err;
-  return rc_all;
-}
-
-int zksp_prove(zksp_client* c, const zksp_pk* pk, zksp_stdin* stdin_, zksp_proof** out) {
-  if (!c || !pk || !stdin_ || !out) return ZKSP_ERR_INVALID_ARG;
-  int32_t st = 0;
-  zksp_stdin* arr[1] = {stdin_};
-  int rc = zksp_prove_batch(c, pk, arr, 1, out, &st);
-  return rc != ZKSP_OK ? rc : st;
-}
-
 int zksp_proof_public_values(const zksp_proof* p, const uint8_t** ptr, size_t* len) {
   if (!p || !ptr || !len) return ZKSP_ERR_INVALID_ARG;
   *ptr = p->bytes.data() + p->hdr.pv_offset;

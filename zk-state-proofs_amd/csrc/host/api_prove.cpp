@@ -1,0 +1,247 @@
+// zksp_prove / zksp_prove_batch: replaces `client.prove(&pk, stdin).run()`
+// (reference prover/src/bin/main.rs:71-74) for one input or many.
+//
+// The batch path is a three-stage pipeline over "waves" of inputs:
+//   host threads   run the guest (RV32IM executor) for wave k+1
+//   the GPU        proves wave k (one fixed launch sequence, bodies -> pinned staging)
+//   host threads   build the proof objects of wave k-1
+// so that neither the executor nor the proof assembly sits on the critical path
+// once a few waves are in flight.
+#include "../../../include/zksp.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <new>
+#include <thread>
+
+#include "api_types.hpp"
+#include "prover.hpp"
+
+using namespace zksp;
+
+namespace {
+
+int ceil_log2(size_t v) {
+  int l = 0;
+  while (((size_t)1 << l) < v) ++l;
+  return l;
+}
+
+int trace_log_height(size_t n_perms) { return ceil_log2(std::max<size_t>(24 * n_perms, 32)); }
+
+struct Job {
+  ExecutionRecord rec;
+  int logh = 0;
+};
+
+// one launch group: proofs of one trace height proven in lockstep
+struct Group {
+  int logh = 0;
+  std::vector<size_t> idxs;   // input indices
+  std::vector<uint32_t> np;   // permutations per proof
+  size_t bw = 0;              // body words per proof
+  int slot = 0;               // staging buffer holding its bodies
+};
+
+void parallel_for(size_t count, unsigned max_threads, const std::function<void(size_t)>& fn) {
+  std::atomic<size_t> next{0};
+  unsigned nt = std::max(1u, std::min<unsigned>(std::min(max_threads, std::thread::hardware_concurrency()), (unsigned)count));
+  auto work = [&]() {
+    for (size_t j; (j = next.fetch_add(1)) < count;) fn(j);
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+  work();
+  for (auto& t : th) t.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+int zksp_prove_batch(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdins, size_t n, zksp_proof** out,
+                     int32_t* status) {
+  if (!c || !pk || !stdins || !out || !status || n == 0) return ZKSP_ERR_INVALID_ARG;
+  Context* ctx = &c->ctx;
+  if (!ctx->has_device())
+    return ctx->fail(ZKSP_ERR_NO_DEVICE, "prove: this client was created without a GPU; there is no CPU proving path");
+  if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(ZKSP_ERR_HIP, "prove: hipSetDevice failed");
+  for (size_t i = 0; i < n; ++i) { out[i] = nullptr; status[i] = ZKSP_ERR_INVALID_ARG; }
+
+  // ---- stage 1: executor workers (run ahead of the GPU, in input order) ----
+  std::vector<Job> jobs(n);
+  std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[n]);
+  for (size_t i = 0; i < n; ++i) done[i].store(0, std::memory_order_relaxed);
+  std::atomic<size_t> next_job{0};
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const unsigned n_workers = std::max(1u, std::min<unsigned>(hw > 2 ? hw - 1 : hw, (unsigned)n));
+  auto worker = [&]() {
+    for (size_t i; (i = next_job.fetch_add(1)) < n;) {
+      if (stdins[i]) {
+        ExecOptions o;
+        o.keccak_mode = (KeccakMode)ctx->params.keccak_mode;
+        jobs[i].rec = execute(pk->elf, stdins[i]->entries, o);
+        stdins[i]->entries.clear();  // consumed, as SP1Stdin is by prove()
+      }
+      done[i].store(1, std::memory_order_release);
+    }
+  };
+  std::vector<std::thread> workers;
+  for (unsigned t = 0; t < n_workers; ++t) workers.emplace_back(worker);
+
+  // ---- stages 2 and 3, driven from this thread ----
+  const size_t max_batch = ctx->params.max_batch;
+  size_t wave = n <= 32 ? n : std::max<size_t>(16, std::min(max_batch, (n + 3) / 4));
+  std::string first_err;
+  int rc_all = ZKSP_OK;
+  Group pending;          // proven (or being proven) on the GPU, not yet assembled
+  bool have_pending = false;
+  int next_slot = 0;
+
+  auto assemble_group = [&](const Group& g) {
+    const uint32_t* bodies = ctx->h_stage2[g.slot];
+    parallel_for(g.idxs.size(), 8, [&](size_t j) {
+      const size_t i = g.idxs[j];
+      const ExecutionRecord& r = jobs[i].rec;
+      zksp_proof* p = new (std::nothrow) zksp_proof();
+      if (!p) { status[i] = ZKSP_ERR_INVALID_ARG; return; }
+      const uint32_t pv_len = (uint32_t)r.public_values.size();
+      const size_t hwords = proof_header_words(pv_len);
+      std::vector<uint8_t> head(hwords * 4, 0);
+      uint32_t* w = reinterpret_cast<uint32_t*>(head.data());
+      w[0] = kProofMagic; w[1] = kProofVersion; w[2] = (uint32_t)g.logh; w[3] = g.np[j]; w[4] = r.exit_code; w[5] = pv_len;
+      memcpy(w + 6, r.pv_digest.data(), 32);
+      memcpy(w + 14, r.deferred_digest.data(), 32);
+      memcpy(w + 22, pk->vk_digest, 32);
+      if (pv_len) memcpy(head.data() + 120, r.public_values.data(), pv_len);
+      p->bytes.reserve((hwords + g.bw) * 4);
+      p->bytes.insert(p->bytes.end(), head.begin(), head.end());
+      const uint8_t* body = reinterpret_cast<const uint8_t*>(bodies + j * g.bw);
+      p->bytes.insert(p->bytes.end(), body, body + g.bw * 4);
+      std::string perr;
+      if (!parse_proof_header(p->bytes.data(), p->bytes.size(), &p->hdr, &perr)) {
+        delete p;
+        status[i] = ZKSP_ERR_PROOF_FORMAT;
+        return;
+      }
+      out[i] = p;
+      status[i] = ZKSP_OK;
+    });
+  };
+  auto fail_group = [&](const Group& g, int rc) {
+    for (size_t i : g.idxs) status[i] = rc;
+    rc_all = rc;
+  };
+
+  for (size_t w0 = 0; w0 < n; w0 += wave) {
+    const size_t w1 = std::min(n, w0 + wave);
+    for (size_t i = w0; i < w1; ++i)
+      while (!done[i].load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    std::map<int, std::vector<size_t>> by_height;
+    for (size_t i = w0; i < w1; ++i) {
+      ExecutionRecord& r = jobs[i].rec;
+      if (!stdins[i]) continue;
+      if (!r.error.empty() || !r.halted) {
+        status[i] = ZKSP_ERR_EXECUTOR;
+        if (first_err.empty()) first_err = "executor: " + (r.error.empty() ? std::string("guest did not halt") : r.error);
+        continue;
+      }
+      if (r.exit_code != 0) {
+        status[i] = ZKSP_ERR_GUEST_PANIC;
+        if (first_err.empty()) first_err = "guest panicked (exit code " + std::to_string(r.exit_code) + "): " + r.stderr_text;
+        continue;
+      }
+      if (r.keccak_events.empty()) {
+        status[i] = ZKSP_ERR_EXECUTOR;
+        if (first_err.empty()) first_err = "guest made no keccak-f calls";
+        continue;
+      }
+      jobs[i].logh = trace_log_height(r.keccak_events.size());
+      if (jobs[i].logh > 14) { status[i] = ZKSP_ERR_UNSUPPORTED; continue; }
+      by_height[jobs[i].logh].push_back(i);
+    }
+    for (auto& kv : by_height) {
+      for (size_t off = 0; off < kv.second.size(); off += max_batch) {
+        Group g;
+        g.logh = kv.first;
+        const size_t cnt = std::min(max_batch, kv.second.size() - off);
+        g.idxs.assign(kv.second.begin() + off, kv.second.begin() + off + cnt);
+        g.bw = proof_body_words(g.logh, ctx->params.num_queries);
+        g.slot = next_slot;
+        size_t max_perms = 0;
+        for (size_t i : g.idxs) max_perms = std::max(max_perms, jobs[i].rec.keccak_events.size());
+        std::vector<uint64_t> states(cnt * max_perms * 25, 0);
+        std::vector<uint32_t> obs(cnt * kInitObs);
+        g.np.resize(cnt);
+        for (size_t j = 0; j < cnt; ++j) {
+          const ExecutionRecord& r = jobs[g.idxs[j]].rec;
+          for (size_t p = 0; p < r.keccak_events.size(); ++p)
+            memcpy(&states[(j * max_perms + p) * 25], r.keccak_events[p].state_in, 200);
+          g.np[j] = (uint32_t)r.keccak_events.size();
+          uint32_t* o = &obs[j * kInitObs];
+          memcpy(o, pk->vk_digest, 32);
+          o[8] = (uint32_t)g.logh;
+          o[9] = g.np[j];
+          o[10] = r.exit_code & 0xffff;
+          o[11] = r.exit_code >> 16;
+          for (int k = 0; k < 8; ++k) {
+            o[12 + 2 * k] = r.pv_digest[k] & 0xffff;
+            o[13 + 2 * k] = r.pv_digest[k] >> 16;
+            o[28 + 2 * k] = r.deferred_digest[k] & 0xffff;
+            o[29 + 2 * k] = r.deferred_digest[k] >> 16;
+          }
+        }
+        // load_batch synchronises the stream: the previous group's proving and its
+        // device-to-host copy are complete when it returns
+        int rc = zksp_hip_load_batch(c, g.logh, cnt, max_perms, states.data(), g.np.data(), obs.data());
+        if (rc == ZKSP_OK) rc = zksp_hip_prove_resident(c);
+        if (rc == ZKSP_OK && ctx->h_stage2_words[g.slot] < cnt * g.bw) {
+          if (ctx->h_stage2[g.slot]) (void)hipHostFree(ctx->h_stage2[g.slot]);
+          ctx->h_stage2[g.slot] = nullptr;
+          ctx->h_stage2_words[g.slot] = 0;
+          if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage2[g.slot]), cnt * g.bw * 4, hipHostMallocDefault) == hipSuccess)
+            ctx->h_stage2_words[g.slot] = cnt * g.bw;
+          else
+            rc = ctx->fail(ZKSP_ERR_HIP, "prove: pinned staging allocation failed");
+        }
+        if (rc == ZKSP_OK && hipMemcpyAsync(ctx->h_stage2[g.slot], ctx->ws->body, cnt * g.bw * 4, hipMemcpyDeviceToHost,
+                                            ctx->stream) != hipSuccess)
+          rc = ctx->fail(ZKSP_ERR_HIP, "prove: device-to-host copy failed");
+        // while the GPU works on this group, build the previous group's proof objects
+        if (have_pending) {
+          assemble_group(pending);
+          have_pending = false;
+        }
+        if (rc != ZKSP_OK) {
+          fail_group(g, rc);
+          continue;
+        }
+        pending = std::move(g);
+        have_pending = true;
+        next_slot ^= 1;
+      }
+    }
+  }
+  if (have_pending) {
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) fail_group(pending, ctx->fail(ZKSP_ERR_HIP, "prove: stream sync failed"));
+    else assemble_group(pending);
+  }
+  for (auto& t : workers) t.join();
+  if (!first_err.empty() && rc_all == ZKSP_OK) ctx->error = first_err;
+  return rc_all;
+}
+
+int zksp_prove(zksp_client* c, const zksp_pk* pk, zksp_stdin* stdin_, zksp_proof** out) {
+  if (!c || !pk || !stdin_ || !out) return ZKSP_ERR_INVALID_ARG;
+  int32_t st = 0;
+  zksp_stdin* arr[1] = {stdin_};
+  int rc = zksp_prove_batch(c, pk, arr, 1, out, &st);
+  return rc != ZKSP_OK ? rc : st;
+}
+
+}  // extern "C"

@@ -1,0 +1,14 @@
+// Concrete layouts of the opaque C-ABI handles (include/zksp.h), shared by the
+// translation units that implement the ABI.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "context.hpp"
+#include "verifier.hpp"
+
+struct zksp_client { zksp::Context ctx; };
+struct zksp_pk { zksp::ElfImage elf; uint32_t vk_digest[8]; };
+struct zksp_vk { uint32_t digest[8]; };
+struct zksp_stdin { std::vector<std::vector<uint8_t>> entries; };
+struct zksp_proof { std::vector<uint8_t> bytes; zksp::ProofHeader hdr; };

@@ -20,6 +20,8 @@ Context::~Context() {
       for (uint32_t* p : kv.second)
         if (p) (void)hipFree(p);
     if (d_consts) (void)hipFree(d_consts);
+    for (uint32_t* hs : h_stage2)
+      if (hs) (void)hipHostFree(hs);
     for (auto& e : event_pool) {
       (void)hipEventDestroy(e.first);
       (void)hipEventDestroy(e.second);

@@ -54,6 +54,8 @@ struct Context {
   std::map<int, DeviceDomain> domains;
   std::map<uint32_t, std::vector<uint32_t*>> qscale;  // custom in_shift scale tables for zksp_hip_lde
   std::unique_ptr<Workspace> ws;
+  uint32_t* h_stage2[2] = {nullptr, nullptr};  // pinned host staging for proof bodies (double buffered)
+  size_t h_stage2_words[2] = {0, 0};
   std::string error;
   // profiling
   bool profile = false;
