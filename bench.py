@@ -61,6 +61,14 @@ def measured_hbm_traffic(batch):
         return None
 
 
+def alu_roofline(lib, h, perms_per_launch, launch_ms):
+    peak = C.c_double()
+    if lib.zksp_hip_microbench(h, 5 + 8, C.byref(peak)) != 0:
+        return None
+    achieved = perms_per_launch / (launch_ms * 1e-3) / 1e9
+    return {"achieved": achieved, "peak": peak.value, "unit": "Gperm/s (Poseidon2 width 16)", "frac": achieved / peak.value}
+
+
 def usable_cores():
     """CPU share of this process: affinity mask capped by the cgroup quota and by the
     GPU box's stated per-GPU share (16)."""
@@ -281,6 +289,9 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_ms": leaf_ms,
             "note": "integer-ALU bound in practice (about 18 modular multiplies per byte absorbed); see DESIGN.md",
+            # the limit that actually binds: Poseidon2 permutations/s of this kernel against the chip's measured
+            # rate for a register-resident permutation loop with no memory traffic (perm_rate_kernel, 8 workgroups/CU)
+            "alu": alu_roofline(lib, h, B * n_rows * ((TRACE_WIDTH + 7) // 8), leaf_ms),
         },
         "device_ms_per_step_by_stage": spans,
         "single_proof_device_ms": single_ms,
