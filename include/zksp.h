@@ -169,9 +169,14 @@ int zksp_hip_merkle_commit(zksp_client* c, const uint32_t* d_mat, int width, int
 int zksp_hip_poseidon2_permute(zksp_client* c, uint32_t* d_states, size_t n);
 /* row a3: states [n_perms][25] u64 -> trace [2633][2^log_h] */
 int zksp_hip_keccak_trace(zksp_client* c, const uint64_t* d_states, uint32_t n_perms, int log_h, uint32_t* d_trace);
-/* row a6: lde [2633][2][H], alpha (4 canonical words) -> quotient values [8][H] */
-int zksp_hip_keccak_quotient(zksp_client* c, const uint32_t* d_lde, int log_h, const uint32_t* alpha,
-                             uint32_t* d_quot);
+/* row a6: lde [2633][2][H], running-sum lde_p [4][2][H], challenges = alpha, gamma, beta,
+ * cumulative sum (4 canonical words each) -> quotient values [8][H] */
+int zksp_hip_keccak_quotient(zksp_client* c, const uint32_t* d_lde, const uint32_t* d_lde_p, int log_h,
+                             const uint32_t* challenges, uint32_t* d_quot);
+/* row a6, lookup argument: trace [2633][H], gamma_beta (8 canonical words) -> running sum
+ * phi [4][H] and the cumulative sum (4 words) */
+int zksp_hip_bus_perm_trace(zksp_client* c, const uint32_t* d_trace, int log_h, const uint32_t* gamma_beta, uint32_t* d_phi,
+                            uint32_t* d_cum_sum);
 /* row a7: one FRI fold of layer [2][Hk][4] with challenge beta (canonical) */
 int zksp_hip_fri_fold(zksp_client* c, const uint32_t* d_in, int log_hk, uint32_t shift_k, const uint32_t* beta,
                       uint32_t* d_out);

@@ -24,7 +24,7 @@ KA_NUM_CONSTRAINTS = 3182
 
 
 def build(force: bool = False) -> str:
-    srcs = ["poseidon2.c", "ntt.c", "keccak_air.c", "prover.c", "field.h", "zksp_oracle.h"]
+    srcs = ["poseidon2.c", "ntt.c", "keccak_air.c", "bus.c", "prover.c", "field.h", "zksp_oracle.h", "Makefile"]
     stale = force or not os.path.exists(_SO) or any(
         os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(_SO) for s in srcs)
     if stale:
@@ -56,6 +56,7 @@ def lib() -> C.CDLL:
             build()
         _lib = C.CDLL(_SO)
         _lib.orc_proof_size.restype = C.c_size_t
+        _lib.orc_proof_header_words.restype = C.c_size_t
         _lib.orc_merkle_layer_offset.restype = C.c_size_t
         _lib.orc_ch_sample.restype = C.c_uint32
         _lib.orc_ch_sample_bits.restype = C.c_uint32
@@ -204,9 +205,55 @@ class OracleChallenger:
         return int(lib().orc_ch_grind(C.byref(self.c), bits))
 
 
-def proof_size(logh: int, num_queries: int, pow_bits: int, pv_len: int) -> int:
+def proof_size(logh: int, num_queries: int, pow_bits: int, pv_len: int, n_perms: int = 0) -> int:
     cfg = Config(num_queries, pow_bits)
-    return int(lib().orc_proof_size(logh, C.byref(cfg), C.c_uint32(pv_len)))
+    return int(lib().orc_proof_size(logh, C.byref(cfg), C.c_uint32(pv_len), C.c_uint32(n_perms)))
+
+
+def proof_header_words(pv_len: int, n_perms: int) -> int:
+    return int(lib().orc_proof_header_words(C.c_uint32(pv_len), C.c_uint32(n_perms)))
+
+
+# ---- LogUp bus ----
+def bus_io_limbs(states_in: np.ndarray) -> np.ndarray:
+    st = np.ascontiguousarray(states_in, dtype=np.uint64).reshape(-1, 25)
+    out = np.zeros((max(st.shape[0], 1), 200), np.uint32)
+    lib().orc_bus_io_limbs(_p(st), int(st.shape[0]), _p(out))
+    return out[: st.shape[0]]
+
+
+def bus_io_log_rows(logh: int) -> int:
+    return int(lib().orc_bus_io_log_rows(logh))
+
+
+def bus_perm_trace(trace: np.ndarray, gamma: Sequence[int], beta: Sequence[int]):
+    trace = _u32(trace)
+    w, h = trace.shape
+    logh = h.bit_length() - 1
+    g, b = _u32(gamma), _u32(beta)
+    phi = np.zeros((4, h), np.uint32)
+    cum = np.zeros(4, np.uint32)
+    lib().orc_bus_perm_trace(_p(trace), logh, _p(g), _p(b), _p(phi), _p(cum))
+    return phi, cum
+
+
+def bus_expected_sum(io_limbs: np.ndarray, gamma: Sequence[int], beta: Sequence[int]) -> np.ndarray:
+    io = _u32(io_limbs).reshape(-1, 200)
+    g, b = _u32(gamma), _u32(beta)
+    out = np.zeros(4, np.uint32)
+    lib().orc_bus_expected_sum(_p(io), int(io.shape[0]), _p(g), _p(b), _p(out))
+    return out
+
+
+def keccak_quotient_bus(lde: np.ndarray, lde_p: np.ndarray, alpha, gamma, beta, cum_sum) -> np.ndarray:
+    lde, lde_p = _u32(lde), _u32(lde_p)
+    w, two, h = lde.shape
+    assert w == KA_WIDTH and two == 2 and lde_p.shape == (4, 2, h)
+    logh = h.bit_length() - 1
+    a, g, b, c = _u32(alpha), _u32(gamma), _u32(beta), _u32(cum_sum)
+    out = np.zeros((8, h), np.uint32)
+    lib().orc_keccak_quotient_bus(_p(lde), _p(lde_p), logh, _p(a), _p(g), _p(b), _p(c), _p(out))
+    return out
 
 
 def prove(states_in: np.ndarray, logh: int, *, exit_code: int = 0, public_values: bytes = b"",
@@ -216,7 +263,7 @@ def prove(states_in: np.ndarray, logh: int, *, exit_code: int = 0, public_values
     hdr = Header(logh, int(st.shape[0]), exit_code, len(public_values),
                  (C.c_uint32 * 8)(*pv_digest), (C.c_uint32 * 8)(*deferred_digest), (C.c_uint32 * 8)(*vk_digest))
     cfg = Config(num_queries, pow_bits)
-    cap = proof_size(logh, num_queries, pow_bits, len(public_values))
+    cap = proof_size(logh, num_queries, pow_bits, len(public_values), int(st.shape[0]))
     buf = (C.c_uint8 * cap)()
     n = C.c_size_t(0)
     pv = (C.c_uint8 * max(1, len(public_values))).from_buffer_copy(public_values or b"\0")

@@ -53,11 +53,17 @@ static int ceil_log2(size_t v) {
   return l;
 }
 
-size_t orc_proof_size(int logh, const orc_config* cfg, uint32_t pv_len) {
+size_t orc_proof_header_words(uint32_t pv_len, uint32_t n_perms) {
+  /* 30 fixed words, public values, then the public I/O list: 50 u64 per permutation */
+  return 30 + (pv_len + 3) / 4 + (size_t)100 * n_perms;
+}
+
+size_t orc_proof_size(int logh, const orc_config* cfg, uint32_t pv_len, uint32_t n_perms) {
   size_t logn = (size_t)logh + 1;
-  size_t words = 30 + (pv_len + 3) / 4;
-  words += 8 + 8 + (2 * KA_WIDTH + 8) * 4 + 8 * (size_t)logh + 4 + 1;
-  size_t perq = KA_WIDTH + 8 * logn + 8 + 8 * logn;
+  size_t words = orc_proof_header_words(pv_len, n_perms);
+  /* trace root, perm root, cumulative sum, quotient root, opened values, FRI roots, final, witness */
+  words += 8 + 8 + 4 + 8 + (2 * KA_WIDTH + 8 + 2 * KA_PERM_WIDTH) * 4 + 8 * (size_t)logh + 4 + 1;
+  size_t perq = KA_WIDTH + 8 * logn + KA_PERM_WIDTH + 8 * logn + 8 + 8 * logn;
   for (int k = 0; k < logh; ++k) perq += 8 + 8 * (size_t)(logh - k);
   words += perq * cfg->num_queries;
   return words * 4;
@@ -83,20 +89,32 @@ static void observe_word_halves(orc_challenger* ch, const uint32_t* w, int n) {
     orc_ch_observe(ch, w[i] >> 16);
   }
 }
+/* Merkle root of a flat word list laid out column-major as [8][2^logr], zero padded:
+ * the parallel-friendly way this format absorbs long lists into the transcript */
+static void observe_list_root(orc_challenger* ch, const uint32_t* words, size_t n_words, int logr) {
+  size_t r = (size_t)1 << logr;
+  uint32_t* vpad = (uint32_t*)calloc(8 * r, 4);
+  memcpy(vpad, words, n_words * 4);
+  uint32_t* tree = (uint32_t*)malloc(8 * (2 * r - 1) * 4);
+  orc_merkle_commit(vpad, 8, logr, tree);
+  orc_ch_observe_many(ch, tree + 8 * (2 * r - 2), 8);
+  free(vpad);
+  free(tree);
+}
 
 int orc_prove(const uint64_t* states_in, const orc_header* hdr, const uint8_t* public_values, const orc_config* cfg,
               uint8_t* out, size_t cap, size_t* out_len) {
   const int logh = (int)hdr->log_h, logn = logh + 1;
   const size_t h = (size_t)1 << logh, n = h * 2;
-  const int W = KA_WIDTH;
+  const int W = KA_WIDTH, PW = KA_PERM_WIDTH;
   if (logh < 1 || logh > 26 || 24 * (size_t)hdr->n_perms > h) return 1;
-  size_t need = orc_proof_size(logh, cfg, hdr->pv_len);
+  size_t need = orc_proof_size(logh, cfg, hdr->pv_len, hdr->n_perms);
   *out_len = need;
   if (cap < need) return 2;
   wbuf pb = {(uint32_t*)out, 0, cap / 4};
   double t0_ = now_s();
 
-  /* header */
+  /* header: fixed words, public values, public I/O list (input || output state per permutation) */
   uint32_t head[6] = {ZKSP_MAGIC, ZKSP_VERSION, hdr->log_h, hdr->n_perms, hdr->exit_code, hdr->pv_len};
   put(&pb, head, 6);
   put(&pb, hdr->pv_digest, 8);
@@ -109,6 +127,15 @@ int orc_prove(const uint64_t* states_in, const orc_header* hdr, const uint8_t* p
     put(&pb, tmp, pw);
     free(tmp);
   }
+  for (uint32_t p = 0; p < hdr->n_perms; ++p) {
+    uint64_t io[50];
+    memcpy(io, states_in + 25 * (size_t)p, 200);
+    memcpy(io + 25, io, 200);
+    orc_keccak_f(io + 25);
+    put(&pb, (const uint32_t*)io, 100);
+  }
+  uint32_t* io_limbs = (uint32_t*)calloc((size_t)KA_BUS_TUPLE * (hdr->n_perms ? hdr->n_perms : 1), 4);
+  orc_bus_io_limbs(states_in, (int)hdr->n_perms, io_limbs);
 
   /* 1. main trace commitment */
   uint32_t* trace = (uint32_t*)malloc((size_t)W * h * 4);
@@ -116,7 +143,6 @@ int orc_prove(const uint64_t* states_in, const orc_header* hdr, const uint8_t* p
   uint32_t* coef_t = (uint32_t*)malloc((size_t)W * h * 4);
   orc_keccak_trace(states_in, (int)hdr->n_perms, logh, trace);
   orc_coset_lde(trace, logh, W, 1, lde_t, coef_t);
-  free(trace);
   uint32_t* tree_t = (uint32_t*)malloc(8 * (2 * n - 1) * 4);
   orc_merkle_commit(lde_t, W, logn, tree_t);
   const uint32_t* root_t = tree_t + 8 * (2 * n - 2);
@@ -131,14 +157,40 @@ int orc_prove(const uint64_t* states_in, const orc_header* hdr, const uint8_t* p
   orc_ch_observe(&ch, hdr->exit_code >> 16);
   observe_word_halves(&ch, hdr->pv_digest, 8);
   observe_word_halves(&ch, hdr->deferred_digest, 8);
+  observe_list_root(&ch, io_limbs, (size_t)KA_BUS_TUPLE * hdr->n_perms, orc_bus_io_log_rows(logh));
   orc_ch_observe_many(&ch, root_t, 8);
   put(&pb, root_t, 8);
 
-  /* 2. quotient */
+  /* 2. LogUp bus: running-sum trace, committed after gamma and beta are drawn */
+  uint32_t gamma[4], beta[4], cum_sum[4];
+  orc_ch_sample_ext(&ch, gamma);
+  orc_ch_sample_ext(&ch, beta);
+  uint32_t* phi = (uint32_t*)malloc((size_t)PW * h * 4);
+  orc_bus_perm_trace(trace, logh, gamma, beta, phi, cum_sum);
+  free(trace);
+  {
+    uint32_t expect[4];
+    orc_bus_expected_sum(io_limbs, (int)hdr->n_perms, gamma, beta, expect);
+    if (memcmp(expect, cum_sum, 16) != 0) return 5; /* the chip did not receive exactly the public list */
+  }
+  free(io_limbs);
+  uint32_t* lde_p = (uint32_t*)malloc((size_t)PW * n * 4);
+  uint32_t* coef_p = (uint32_t*)malloc((size_t)PW * h * 4);
+  orc_coset_lde(phi, logh, PW, 1, lde_p, coef_p);
+  free(phi);
+  uint32_t* tree_p = (uint32_t*)malloc(8 * (2 * n - 1) * 4);
+  orc_merkle_commit(lde_p, PW, logn, tree_p);
+  const uint32_t* root_p = tree_p + 8 * (2 * n - 2);
+  orc_ch_observe_many(&ch, root_p, 8);
+  orc_ch_observe_many(&ch, cum_sum, 4);
+  put(&pb, root_p, 8);
+  put(&pb, cum_sum, 4);
+
+  /* 3. quotient */
   uint32_t alpha[4];
   orc_ch_sample_ext(&ch, alpha);
   uint32_t* quot = (uint32_t*)malloc(8 * h * 4);
-  orc_keccak_quotient(lde_t, logh, alpha, quot);
+  orc_keccak_quotient_bus(lde_t, lde_p, logh, alpha, gamma, beta, cum_sum, quot);
   uint32_t* lde_q = (uint32_t*)malloc(8 * n * 4);
   uint32_t* coef_q = (uint32_t*)malloc(8 * h * 4);
   fe w2h = f_root_of_unity(logn), wh = f_root_of_unity(logh);
@@ -154,11 +206,11 @@ int orc_prove(const uint64_t* states_in, const orc_header* hdr, const uint8_t* p
   put(&pb, root_q, 8);
 
   TICK("quotient");
-  /* 3. openings at zeta and zeta*w_H */
+  /* 4. openings at zeta and zeta*w_H: trace (local, next), quotient, running sum (local, next) */
   fe4 zeta, zeta_next;
   orc_ch_sample_ext(&ch, zeta.c);
   zeta_next = e_mul_base(zeta, wh);
-  const size_t n_open = (size_t)(2 * W + 8);
+  const size_t n_open = (size_t)(2 * W + 8 + 2 * PW);
   fe4* opened = (fe4*)malloc(n_open * sizeof(fe4));
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < W; ++i) {
@@ -166,47 +218,47 @@ int orc_prove(const uint64_t* states_in, const orc_header* hdr, const uint8_t* p
     opened[W + i] = eval_poly(coef_t + (size_t)i * h, h, zeta_next);
   }
   for (int i = 0; i < 8; ++i) opened[2 * W + i] = eval_poly(coef_q + (size_t)i * h, h, zeta);
-  put(&pb, (const uint32_t*)opened, n_open * 4);
-  {
-    /* Merkle-ised digest of the opened values: column-major [8][R], zero padded */
-    int logr = ceil_log2((n_open * 4 + 7) / 8);
-    size_t r = (size_t)1 << logr;
-    uint32_t* vpad = (uint32_t*)calloc(8 * r, 4);
-    memcpy(vpad, opened, n_open * 16);
-    uint32_t* tree_o = (uint32_t*)malloc(8 * (2 * r - 1) * 4);
-    orc_merkle_commit(vpad, 8, logr, tree_o);
-    orc_ch_observe_many(&ch, tree_o + 8 * (2 * r - 2), 8);
-    free(vpad);
-    free(tree_o);
+  for (int i = 0; i < PW; ++i) {
+    opened[2 * W + 8 + i] = eval_poly(coef_p + (size_t)i * h, h, zeta);
+    opened[2 * W + 8 + PW + i] = eval_poly(coef_p + (size_t)i * h, h, zeta_next);
   }
+  put(&pb, (const uint32_t*)opened, n_open * 4);
+  observe_list_root(&ch, (const uint32_t*)opened, n_open * 4, ceil_log2((n_open * 4 + 7) / 8));
 
   TICK("open");
-  /* 4. reduced openings */
+  /* 5. reduced openings */
   fe4 af;
   orc_ch_sample_ext(&ch, af.c);
-  fe4* afpow = (fe4*)malloc((size_t)(2 * W + 8) * sizeof(fe4));
+  fe4* afpow = (fe4*)malloc(n_open * sizeof(fe4));
   afpow[0] = e_one();
-  for (size_t i = 1; i < (size_t)(2 * W + 8); ++i) afpow[i] = e_mul(afpow[i - 1], af);
-  fe4 b0 = e_zero(), b1 = e_zero(), b2 = e_zero();
+  for (size_t i = 1; i < n_open; ++i) afpow[i] = e_mul(afpow[i - 1], af);
+  fe4 b0 = e_zero(), b1 = e_zero(), b2 = e_zero(), b3 = e_zero(), b4 = e_zero();
   for (int i = 0; i < W; ++i) {
     b0 = e_add(b0, e_mul(afpow[i], opened[i]));
     b1 = e_add(b1, e_mul(afpow[i], opened[W + i]));
   }
   for (int i = 0; i < 8; ++i) b2 = e_add(b2, e_mul(afpow[i], opened[2 * W + i]));
+  for (int i = 0; i < PW; ++i) {
+    b3 = e_add(b3, e_mul(afpow[i], opened[2 * W + 8 + i]));
+    b4 = e_add(b4, e_mul(afpow[i], opened[2 * W + 8 + PW + i]));
+  }
   uint32_t* layer = (uint32_t*)malloc(n * 16);
   for (int c = 0; c < 2; ++c) {
     fe shift_c = c ? f_mul(F_GEN, w2h) : F_GEN;
 #pragma omp parallel for schedule(static)
     for (size_t m = 0; m < h; ++m) {
       fe x = f_mul(shift_c, f_pow(wh, m));
-      fe4 st = e_zero(), sq = e_zero();
+      fe4 st = e_zero(), sq = e_zero(), sp = e_zero();
       for (int i = 0; i < W; ++i) st = e_add(st, e_mul_base(afpow[i], lde_t[((size_t)i * 2 + c) * h + m]));
       for (int i = 0; i < 8; ++i) sq = e_add(sq, e_mul_base(afpow[i], lde_q[((size_t)i * 2 + c) * h + m]));
+      for (int i = 0; i < PW; ++i) sp = e_add(sp, e_mul_base(afpow[i], lde_p[((size_t)i * 2 + c) * h + m]));
       fe4 d0 = e_inv(e_sub(e_from(x), zeta));
       fe4 d1 = e_inv(e_sub(e_from(x), zeta_next));
       fe4 g = e_mul(e_sub(st, b0), d0);
       g = e_add(g, e_mul(e_mul(afpow[W], e_sub(st, b1)), d1));
       g = e_add(g, e_mul(e_mul(afpow[2 * W], e_sub(sq, b2)), d0));
+      g = e_add(g, e_mul(e_mul(afpow[2 * W + 8], e_sub(sp, b3)), d0));
+      g = e_add(g, e_mul(e_mul(afpow[2 * W + 8 + PW], e_sub(sp, b4)), d1));
       memcpy(layer + 4 * ((size_t)c * h + m), g.c, 16);
     }
   }
@@ -214,7 +266,7 @@ int orc_prove(const uint64_t* states_in, const orc_header* hdr, const uint8_t* p
   free(opened);
 
   TICK("reduce");
-  /* 5. FRI commit phase */
+  /* 6. FRI commit phase */
   uint32_t** fri_tree = (uint32_t**)malloc((size_t)logh * sizeof(uint32_t*));
   uint32_t** fri_layer = (uint32_t**)malloc((size_t)logh * sizeof(uint32_t*));
   fe shift_k = F_GEN;
@@ -235,10 +287,10 @@ int orc_prove(const uint64_t* states_in, const orc_header* hdr, const uint8_t* p
     const uint32_t* root = fri_tree[k] + 8 * (2 * hk - 2);
     orc_ch_observe_many(&ch, root, 8);
     put(&pb, root, 8);
-    uint32_t beta[4];
-    orc_ch_sample_ext(&ch, beta);
+    uint32_t fbeta[4];
+    orc_ch_sample_ext(&ch, fbeta);
     uint32_t* nxt = (uint32_t*)malloc(hk * 16);
-    orc_fri_fold(layer, loghk, shift_k, beta, nxt);
+    orc_fri_fold(layer, loghk, shift_k, fbeta, nxt);
     fri_layer[k] = layer;
     layer = nxt;
     shift_k = f_mul(shift_k, shift_k);
@@ -250,7 +302,7 @@ int orc_prove(const uint64_t* states_in, const orc_header* hdr, const uint8_t* p
   free(layer);
 
   TICK("fri");
-  /* 6. proof of work, 7. queries */
+  /* 7. proof of work, 8. queries */
   uint32_t witness = orc_ch_grind(&ch, (int)cfg->pow_bits);
   put(&pb, &witness, 1);
   TICK("grind");
@@ -261,6 +313,9 @@ int orc_prove(const uint64_t* states_in, const orc_header* hdr, const uint8_t* p
     for (int i = 0; i < W; ++i) row[i] = lde_t[((size_t)i * 2 + c) * h + m];
     put(&pb, row, (size_t)W);
     put_path(&pb, tree_t, logn, idx);
+    for (int i = 0; i < PW; ++i) row[i] = lde_p[((size_t)i * 2 + c) * h + m];
+    put(&pb, row, (size_t)PW);
+    put_path(&pb, tree_p, logn, idx);
     for (int i = 0; i < 8; ++i) row[i] = lde_q[((size_t)i * 2 + c) * h + m];
     put(&pb, row, 8);
     put_path(&pb, tree_q, logn, idx);
@@ -284,6 +339,9 @@ int orc_prove(const uint64_t* states_in, const orc_header* hdr, const uint8_t* p
   free(lde_t);
   free(coef_t);
   free(tree_t);
+  free(lde_p);
+  free(coef_p);
+  free(tree_p);
   free(lde_q);
   free(coef_q);
   free(tree_q);

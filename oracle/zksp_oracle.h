@@ -74,7 +74,10 @@ uint32_t orc_ch_grind(orc_challenger* c, int bits);
 #define KA_APP00 2565
 #define KA_APPP00 2629
 #define KA_WIDTH 2633
-#define KA_NUM_CONSTRAINTS 3182
+#define KA_NUM_CONSTRAINTS 3182     /* base-field AIR constraints */
+#define KA_NUM_BUS_CONSTRAINTS 3    /* extension-valued LogUp constraints, indices 3182..3184 */
+#define KA_BUS_TUPLE 200            /* input limbs (100) || output limbs (100) of one permutation */
+#define KA_PERM_WIDTH 4             /* the running sum phi: one extension column = 4 base columns */
 void orc_keccak_f(uint64_t* st /*[25]*/);
 /* trace: column-major [KA_WIDTH][H], H = 2^logh >= 24*n_perms */
 void orc_keccak_trace(const uint64_t* states_in, int n_perms, int logh, uint32_t* trace);
@@ -84,6 +87,25 @@ void orc_keccak_constraints(const uint32_t* local, const uint32_t* next, uint32_
 /* quotient values over the 2H-point LDE domain; lde: [W][2][H]; out: [8][H]
  * (column 4c+j = coefficient j of the extension value on coset c) */
 void orc_keccak_quotient(const uint32_t* lde, int logh, const uint32_t* alpha4, uint32_t* out);
+
+/* ---- LogUp bus: the chip RECEIVES (input limbs || output limbs) of every real
+ * permutation with multiplicity `export`; the verifier sums the same tuples from the
+ * public I/O list.  (Row a6 "lookup-argument constraints"; SP1 wires its precompile
+ * chips to the CPU with the same argument.) ---- */
+/* limbs of the public I/O list: out[p*200 + j], j < 100 input, j >= 100 keccak-f(input) */
+void orc_bus_io_limbs(const uint64_t* states_in, int n_perms, uint32_t* out);
+/* rows of the io matrix for a trace height (column-major [8][R], zero padded) */
+int orc_bus_io_log_rows(int logh);
+/* phi columns [4][H] (exclusive running sum of export/f over the trace rows) and the
+ * cumulative sum S (4 words) for challenges gamma, beta */
+void orc_bus_perm_trace(const uint32_t* trace, int logh, const uint32_t* gamma4, const uint32_t* beta4,
+                        uint32_t* phi, uint32_t* cum_sum4);
+/* sum over the public list of 1/(gamma + sum_j beta^j t_j): what S must equal */
+void orc_bus_expected_sum(const uint32_t* io_limbs, int n_perms, const uint32_t* gamma4, const uint32_t* beta4,
+                          uint32_t* out4);
+/* quotient with the bus constraints: lde [W][2][H], lde_p [4][2][H] */
+void orc_keccak_quotient_bus(const uint32_t* lde, const uint32_t* lde_p, int logh, const uint32_t* alpha4,
+                             const uint32_t* gamma4, const uint32_t* beta4, const uint32_t* cum_sum4, uint32_t* out);
 
 /* ---- FRI ---- */
 /* one fold: in [2][Hk] ext (coset-major, 4 words per element) -> out [2][Hk/2] */
@@ -104,8 +126,9 @@ typedef struct {
   uint32_t pow_bits;
 } orc_config;
 #define ZKSP_MAGIC 0x50534B5Au
-#define ZKSP_VERSION 1u
-size_t orc_proof_size(int logh, const orc_config* cfg, uint32_t pv_len);
+#define ZKSP_VERSION 2u
+size_t orc_proof_size(int logh, const orc_config* cfg, uint32_t pv_len, uint32_t n_perms);
+size_t orc_proof_header_words(uint32_t pv_len, uint32_t n_perms);
 /* returns 0 on success */
 int orc_prove(const uint64_t* states_in, const orc_header* hdr, const uint8_t* public_values, const orc_config* cfg,
               uint8_t* out, size_t cap, size_t* out_len);

@@ -56,12 +56,31 @@ def test_keccak_quotient(gpu, oracle):
     logh = 6
     trace = oracle.keccak_trace(st, logh)
     lde = oracle.coset_lde(trace, 1)
-    alpha = rnd(rng, 4)
-    assert (gpu.keccak_quotient(lde, alpha) == oracle.keccak_quotient(lde, alpha)).all()
-    # a corrupted trace gives a (non-polynomial) quotient too: values must still agree
+    alpha, gamma, beta = rnd(rng, 4), rnd(rng, 4), rnd(rng, 4)
+    phi, cum = oracle.bus_perm_trace(trace, gamma, beta)
+    lde_p = oracle.coset_lde(phi, 1)
+    exp = oracle.keccak_quotient_bus(lde, lde_p, alpha, gamma, beta, cum)
+    assert (gpu.keccak_quotient(lde, lde_p, alpha, gamma, beta, cum) == exp).all()
+    # a corrupted trace / running sum gives a (non-polynomial) quotient too: values must still agree
     trace[900, 5] ^= 1
     lde = oracle.coset_lde(trace, 1)
-    assert (gpu.keccak_quotient(lde, alpha) == oracle.keccak_quotient(lde, alpha)).all()
+    lde_p[2, 1, 7] = (int(lde_p[2, 1, 7]) + 5) % P
+    bad_cum = rnd(rng, 4)
+    exp = oracle.keccak_quotient_bus(lde, lde_p, alpha, gamma, beta, bad_cum)
+    assert (gpu.keccak_quotient(lde, lde_p, alpha, gamma, beta, bad_cum) == exp).all()
+
+
+@pytest.mark.parametrize("logh,nperms", [(5, 1), (7, 4), (9, 21), (11, 62)])
+def test_bus_perm_trace(gpu, oracle, logh, nperms):
+    """LogUp running sum (row a6, lookup argument): phi columns and cumulative sum."""
+    rng = np.random.default_rng(50 + logh)
+    st = rng.integers(0, 2**64, (nperms, 25), dtype=np.uint64)
+    trace = oracle.keccak_trace(st, logh)
+    gamma, beta = rnd(rng, 4), rnd(rng, 4)
+    phi, cum = gpu.bus_perm_trace(trace, gamma, beta)
+    ephi, ecum = oracle.bus_perm_trace(trace, gamma, beta)
+    assert (phi == ephi).all() and (cum == ecum).all()
+    assert (cum == oracle.bus_expected_sum(oracle.bus_io_limbs(st), gamma, beta)).all()
 
 
 @pytest.mark.parametrize("logh,ncols,shifts", [(15, 3, (1, 31)), (16, 2, (1,)), (17, 1, (12345,)), (21, 2, (1,)),

@@ -56,7 +56,7 @@ def test_device_prover_matches_oracle_small(zk, oracle, logh, nq, pow_bits):
         exp.append(oracle.prove(st, logh, pv_digest=pvd, vk_digest=vk, num_queries=nq, pow_bits=pow_bits))
     bodies = device_bodies(g, logh, states, obs)
     for i in range(3):
-        e = np.frombuffer(exp[i], dtype=np.uint32)[30:]
+        e = np.frombuffer(exp[i], dtype=np.uint32)[oracle.proof_header_words(0, len(states[i])):]
         assert e.shape == bodies[i].shape
         bad = np.nonzero(e != bodies[i])[0]
         assert bad.size == 0, (i, bad[:8])

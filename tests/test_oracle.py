@@ -160,7 +160,36 @@ def test_quotient_is_a_polynomial_only_for_valid_traces(oracle):
     rng = np.random.default_rng(5)
     st = rng.integers(0, 2**64, (1, 25), dtype=np.uint64)
     proof = oracle.prove(st, 5, num_queries=2, pow_bits=2)
-    assert len(proof) == oracle.proof_size(5, 2, 2, 0)
+    assert len(proof) == oracle.proof_size(5, 2, 2, 0, 1)
+
+
+def test_logup_bus_running_sum(oracle):
+    """phi is the exclusive running sum of export/f, its total equals the sum over the public
+    I/O list, and the three bus constraints hold on the trace rows (a tampered multiplicity or
+    output limb breaks the total)."""
+    rng = np.random.default_rng(6)
+    st = rng.integers(0, 2**64, (4, 25), dtype=np.uint64)
+    logh, h = 7, 128
+    tr = oracle.keccak_trace(st, logh)
+    gamma, beta = rng.integers(0, P, 4, dtype=np.uint32), rng.integers(0, P, 4, dtype=np.uint32)
+    phi, cum = oracle.bus_perm_trace(tr, gamma, beta)
+    io = oracle.bus_io_limbs(st)
+    assert io.shape == (4, 200)
+    # the I/O limbs are the input state and keccak-f of it
+    out0 = oracle.keccak_f(st[0])
+    assert [int(x) for x in io[0, 100:104]] == [(int(out0[0]) >> (16 * l)) & 0xFFFF for l in range(4)]
+    assert (cum == oracle.bus_expected_sum(io, gamma, beta)).all()
+    assert not phi[:, 0].any()  # phi_0 = 0
+    # phi only moves after rows with export = 1 (the last round of each real permutation)
+    changes = [r for r in range(h - 1) if (phi[:, r + 1] != phi[:, r]).any()]
+    assert changes == [23, 47, 71, 95]  # phi steps right after each real permutation's export row
+    tr2 = tr.copy()
+    tr2[24, 23] = 0  # drop one export flag: the chip no longer receives that tuple
+    assert (oracle.bus_perm_trace(tr2, gamma, beta)[1] != cum).any()
+    io2 = io.copy()
+    io2[2, 150] ^= 1  # a wrong public output limb
+    assert (oracle.bus_expected_sum(io2, gamma, beta) != cum).any()
+    assert oracle.bus_io_log_rows(11) == 12 and oracle.bus_io_log_rows(5) == 5
 
 
 def test_verify_merkle_proof_restatement(oracle, fx):

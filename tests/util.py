@@ -113,16 +113,31 @@ class Gpu:
         s.free(); t.free()
         return out
 
-    def keccak_quotient(self, lde, alpha):
+    def keccak_quotient(self, lde, lde_p, alpha, gamma, beta, cum_sum):
         lde = np.ascontiguousarray(lde, dtype=np.uint32)
+        lde_p = np.ascontiguousarray(lde_p, dtype=np.uint32)
         w, two, h = lde.shape
         logh = h.bit_length() - 1
         l = self.buf(to_monty(lde))
+        lp = self.buf(to_monty(lde_p))
         q = self.buf(nbytes=8 * h * 4)
-        a = np.ascontiguousarray(alpha, dtype=np.uint32)
-        self.check(self.lib.zksp_hip_keccak_quotient(self.h, l.ptr, logh, a.ctypes.data_as(C.c_void_p), q.ptr))
+        ch = np.ascontiguousarray(np.concatenate([alpha, gamma, beta, cum_sum]), dtype=np.uint32)
+        self.check(self.lib.zksp_hip_keccak_quotient(self.h, l.ptr, lp.ptr, logh, ch.ctypes.data_as(C.c_void_p), q.ptr))
         out = from_monty(q.download(np.uint32, (8, h)))
-        l.free(); q.free()
+        l.free(); lp.free(); q.free()
+        return out
+
+    def bus_perm_trace(self, trace, gamma, beta):
+        trace = np.ascontiguousarray(trace, dtype=np.uint32)
+        w, h = trace.shape
+        logh = h.bit_length() - 1
+        t = self.buf(to_monty(trace))
+        phi = self.buf(nbytes=4 * h * 4)
+        cum = self.buf(nbytes=16)
+        gb = np.ascontiguousarray(np.concatenate([gamma, beta]), dtype=np.uint32)
+        self.check(self.lib.zksp_hip_bus_perm_trace(self.h, t.ptr, logh, gb.ctypes.data_as(C.c_void_p), phi.ptr, cum.ptr))
+        out = from_monty(phi.download(np.uint32, (4, h))), from_monty(cum.download(np.uint32, (4,)))
+        t.free(); phi.free(); cum.free()
         return out
 
     def fri_fold(self, layer, shift_k, beta):

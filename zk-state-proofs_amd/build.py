@@ -20,6 +20,7 @@ SOURCES = [
     "device/kernels_ntt.hip",
     "device/kernels_hash.hip",
     "device/kernels_stark.hip",
+    "device/kernels_bus.hip",
     "device/kernels_bench.hip",
     "host/executor.cpp",
     "host/params.cpp",

@@ -38,7 +38,13 @@ constexpr int kNextCols = 225;
 //   task 1+x      S_x: C(x), A(5y+x) for y=0..4, P(x)   (c[x], c[x-1], c[x+1], c'[x], a'[.][x])
 //   task 6+Y      T_Y: CHI(5Y+X) for X=0..4             (the five rho-pi planes of row Y)
 //   task 11       IOTA
-constexpr int kNumTasks = 12;
+//   task 12       BUS: the three extension-valued LogUp constraints (indices 3182..3184)
+constexpr int kNumTasks = 13;
+constexpr int kBusTask = 12;
+constexpr int kNumBusConstraints = 3;
+constexpr int kNumAllConstraints = kNumConstraints + kNumBusConstraints;  // powers of alpha needed
+constexpr int kBusTuple = 200;   // input limbs (100) || output limbs (100) of one permutation
+constexpr int kPermWidth = 4;    // the running sum phi: one extension column = 4 base columns
 ZKSP_HD constexpr int base_c(int x) { return 250 + 128 * x; }
 ZKSP_HD constexpr int base_a(int j) { return 890 + 68 * j; }
 ZKSP_HD constexpr int base_p(int x) { return 2590 + 64 * x; }
@@ -78,6 +84,34 @@ ZKSP_HD int b_col(int X, int Y, int z) {
   int xa = (X + 3 * Y) % 5, ya = X;
   int rot = tables().rot[xa][ya];
   return kAp + 64 * (5 * ya + xa) + ((z + 64 - rot) & 63);
+}
+
+// Column of element j of the LogUp tuple a trace row carries: the 100 preimage limbs,
+// then the 100 limbs of the round's output state (a''' for lane 0, a'' for lanes 1..24).
+ZKSP_HD int bus_tuple_col(int j) {
+  if (j < 100) return kPreimage + j;
+  const int o = j - 100, lane = o >> 2, l = o & 3;
+  return lane == 0 ? kAppp00 + l : kApp + 4 * lane + l;
+}
+
+// LogUp bus (row a6 "lookup-argument constraints"): the chip receives its tuple with
+// multiplicity `export`; phi is the exclusive running sum of export / f over the rows and
+// S its total, which the verifier recomputes from the public I/O list.
+//   f = gamma + sum_j beta^j t_j
+//   L0 = is_first * phi,  L1 = is_trans * ((phi_next - phi) f - m),  L2 = is_last * ((S - phi) f - m)
+// Ctx additionally provides:  using E (extension type, E*F and E*E defined);
+//   E gamma(); E beta_pow(int j); E cum_sum(); E phi_local(); E phi_next(); F is_last();
+//   E lift(F); void emit_ext_at(int k, E v);
+template <class Ctx>
+ZKSP_HD void eval_bus(Ctx& ctx) {
+  using E = typename Ctx::E;
+  E f = ctx.gamma();
+  for (int j = 0; j < kBusTuple; ++j) f = f + ctx.beta_pow(j) * ctx.local(bus_tuple_col(j));
+  const E m = ctx.lift(ctx.local(kExport));
+  const E phi = ctx.phi_local();
+  ctx.emit_ext_at(kNumConstraints + 0, phi * ctx.is_first());
+  ctx.emit_ext_at(kNumConstraints + 1, ((ctx.phi_next() - phi) * f - m) * ctx.is_trans());
+  ctx.emit_ext_at(kNumConstraints + 2, ((ctx.cum_sum() - phi) * f - m) * ctx.is_last());
 }
 
 // Ctx interface:
@@ -159,7 +193,7 @@ ZKSP_HD void eval_task(int task, Ctx& ctx) {
         ctx.emit_at(base_chi(j) + l, ctx.local(kApp + 4 * j + l) - acc[X]);
       }
     }
-  } else {
+  } else if (task == 11) {
     // ---- IOTA: a''[0][0] bits, round constant, hand-over to the next row ----
     int k = kBaseIota;
     for (int z = 0; z < 64; ++z) {

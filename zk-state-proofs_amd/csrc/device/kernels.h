@@ -46,11 +46,29 @@ void launch_poseidon2_permute(hipStream_t stream, uint32_t* states, size_t n, co
 // states: [batch][max_perms][25] u64; n_perms: [batch]; trace: [batch][2633][H]
 void launch_keccak_trace(hipStream_t stream, const uint64_t* states, int max_perms, const uint32_t* n_perms,
                          uint32_t* trace, int logh, int batch);
-// lde: [batch][2633][2][H]; alpha_pows: [batch][3182] Fp4; sel_first/sel_trans: [2][H];
-// partial: [batch][62][2H] Fp4 scratch; quot: [batch][8][H]; zh_inv: [2]
-void launch_keccak_quotient(hipStream_t stream, const uint32_t* lde, const uint32_t* alpha_pows,
-                            const uint32_t* sel_first, const uint32_t* sel_trans, const uint32_t* zh_inv,
-                            uint32_t* partial, uint32_t* quot, int logh, int batch);
+struct QuotientArgs {
+  const uint32_t* lde;         // [batch][2633][2][H]
+  const uint32_t* lde_p;       // [batch][4][2][H] running-sum columns
+  const uint32_t* alpha_pows;  // [batch][3185] Fp4
+  const uint32_t* bus_ch;      // [batch][2] Fp4: gamma, beta
+  const uint32_t* beta_pows;   // [batch][200] Fp4
+  const uint32_t* cum_sum;     // [batch] Fp4
+  const uint32_t *sel_first, *sel_trans, *sel_last;  // [2][H]
+  const uint32_t* zh_inv;      // [2]
+  uint32_t* partial;           // [batch][13][2H] Fp4 scratch
+  uint32_t* quot;              // [batch][8][H]
+  int logh, batch;
+};
+void launch_keccak_quotient(hipStream_t stream, const QuotientArgs& a);
+
+// ---- LogUp bus (row a6, lookup argument) ----
+// io: [batch][8*R] limbs of the public I/O list (input || keccak-f(input)), zero padded
+void launch_keccak_io(hipStream_t stream, const uint64_t* states, int max_perms, const uint32_t* n_perms, uint32_t* io,
+                      size_t io_stride, int batch);
+// trace [batch][2633][H], bus_ch [batch][2] Fp4, beta_pows [batch][200] Fp4 ->
+// phi [batch][4][H] (exclusive running sum of export/f), cum_sum [batch] Fp4; terms: [batch][H] Fp4 scratch
+void launch_bus_perm_trace(hipStream_t stream, const uint32_t* trace, const uint32_t* bus_ch, const uint32_t* beta_pows,
+                           uint32_t* terms, uint32_t* phi, uint32_t* cum_sum, int logh, int batch);
 
 // ---- openings / FRI (row a7) ----
 // out[b][i] = (base[b]*base_mul)^e, e = i or bitrev(i); Fp4 each, base_mul a Montgomery base-field word
@@ -65,12 +83,13 @@ void launch_open(hipStream_t stream, const uint32_t* coefs_br, size_t coefs_stri
 struct ReduceArgs {
   const uint32_t* lde_t;   // [batch][W][2][H]
   const uint32_t* lde_q;   // [batch][8][2][H]
-  const uint32_t* af_pows; // [batch][2W+8] Fp4
-  const uint32_t* opened;  // [batch][2W+8] Fp4 (local, next, quotient)
+  const uint32_t* lde_p;   // [batch][4][2][H]
+  const uint32_t* af_pows; // [batch][2W+16] Fp4
+  const uint32_t* opened;  // [batch][2W+16] Fp4 (trace local, trace next, quotient, running sum local, next)
   const uint32_t* zeta;    // [batch] Fp4
   const uint32_t* xs;      // [2][H] domain points
   uint32_t* partial;       // [batch][nchunks][2H] Fp4 scratch
-  uint32_t* bsum;          // [batch][3] Fp4 scratch
+  uint32_t* bsum;          // [batch][5] Fp4 scratch
   uint32_t* out;           // [batch][2][H] Fp4
   size_t opened_stride;    // words between consecutive proofs in `opened`
   size_t out_stride;       // words between consecutive proofs in `out`
@@ -111,14 +130,17 @@ struct AssembleArgs {
   const uint32_t* tree_t;  // [batch][4H-1][8]
   const uint32_t* lde_q;   // [batch][8][2][H]
   const uint32_t* tree_q;
-  const uint32_t* opened;  // [batch][2W+8] Fp4
+  const uint32_t* lde_p;   // [batch][4][2][H]
+  const uint32_t* tree_p;
+  const uint32_t* cum_sum; // [batch] Fp4
+  const uint32_t* opened;  // [batch][2W+16] Fp4
   const uint32_t* fri_layers;  // [batch][fri_layer_stride]: layers 0..logh-1 back to back, then the final pair
   const uint32_t* fri_trees;   // [batch][fri_tree_stride]: trees 0..logh-1 back to back
   const uint32_t* witness;     // [batch]
   const uint32_t* indices;     // [batch][n_queries]
   uint32_t* body;              // [batch][body_words] canonical u32
-  size_t lde_t_stride, tree_t_stride, lde_q_stride, tree_q_stride, opened_stride, fri_layer_stride, fri_tree_stride,
-      body_stride;
+  size_t lde_t_stride, tree_t_stride, lde_q_stride, tree_q_stride, lde_p_stride, tree_p_stride, opened_stride,
+      fri_layer_stride, fri_tree_stride, body_stride;
   int width, logh, n_queries, batch;
 };
 void launch_assemble(hipStream_t stream, const AssembleArgs& a);

@@ -118,18 +118,26 @@ void launch_keccak_trace(hipStream_t stream, const uint64_t* states, int max_per
 // ===========================================================================
 struct QuotCtx {
   using F = Fp;
+  using E = Fp4;
   const uint32_t* loc;
   const uint32_t* nxt;
   size_t cs;
-  Fp first, trans;
+  Fp first, trans, last;
   const uint32_t* ap;  // this proof's alpha powers (Fp4 each), indexed by constraint
   Fp4 acc;
   uint64_t lazy[4];    // unreduced sum of up to two alpha^k_i * c_k products per coordinate
   int pending;
+  // LogUp bus
+  const uint32_t* ploc;  // running-sum columns at this point / the next row (stride cs)
+  const uint32_t* pnxt;
+  const uint32_t* bus_ch;     // gamma, beta
+  const uint32_t* beta_pows;  // [200] Fp4
+  const uint32_t* cum;        // Fp4
   __device__ __forceinline__ F local(int col) const { return Fp::raw(loc[(size_t)col * cs]); }
   __device__ __forceinline__ F next(int col) const { return Fp::raw(nxt[(size_t)col * cs]); }
   __device__ __forceinline__ F is_first() const { return first; }
   __device__ __forceinline__ F is_trans() const { return trans; }
+  __device__ __forceinline__ F is_last() const { return last; }
   __device__ __forceinline__ F one() const { return Fp::one(); }
   // acc += alpha^k * v, coordinate by coordinate.  The four products are
   // accumulated unreduced (one v_mad_u64_u32 each); two products stay below the
@@ -149,16 +157,29 @@ struct QuotCtx {
     }
     pending = 0;
   }
+  // extension-valued constraints of the bus
+  __device__ __forceinline__ E gamma() const { return load_fp4(bus_ch); }
+  __device__ __forceinline__ E beta_pow(int j) const { return load_fp4(beta_pows + 4 * (size_t)j); }
+  __device__ __forceinline__ E cum_sum() const { return load_fp4(cum); }
+  __device__ __forceinline__ E phi_local() const {
+    Fp4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.c[j] = Fp::raw(ploc[(size_t)j * cs]);
+    return r;
+  }
+  __device__ __forceinline__ E phi_next() const {
+    Fp4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.c[j] = Fp::raw(pnxt[(size_t)j * cs]);
+    return r;
+  }
+  __device__ __forceinline__ E lift(F v) const { return Fp4::from_base(v); }
+  __device__ __forceinline__ void emit_ext_at(int k, E v) { acc += load_fp4(ap + 4 * (size_t)k) * v; }
 };
 
-__global__ __launch_bounds__(kThreads) void keccak_quotient_kernel(const uint32_t* __restrict__ lde,
-                                                                  const uint32_t* __restrict__ alpha_pows,
-                                                                  const uint32_t* __restrict__ sel_first,
-                                                                  const uint32_t* __restrict__ sel_trans,
-                                                                  uint32_t* __restrict__ partial, int logh,
-                                                                  int tiles_per_proof, int total_tiles) {
-  const int h = 1 << logh, n = 2 * h;
-  // A tile = 256 consecutive LDE points of one proof; its 12 evaluation tasks read
+__global__ __launch_bounds__(kThreads) void keccak_quotient_kernel(QuotientArgs a, int tiles_per_proof, int total_tiles) {
+  const int h = 1 << a.logh, n = 2 * h;
+  // A tile = 256 consecutive LDE points of one proof; its evaluation tasks read
   // overlapping column sets.  Workgroups are dealt round-robin over the 8 XCDs, so
   // give every XCD whole tiles: all tasks of a tile run back to back behind ONE L2
   // and each column slice leaves HBM once.  (Placement only affects speed; any
@@ -176,20 +197,29 @@ __global__ __launch_bounds__(kThreads) void keccak_quotient_kernel(const uint32_
   const int pt = (tile - b * tiles_per_proof) * kThreads + threadIdx.x;
   if (pt >= n) return;
   const int c = pt >= h ? 1 : 0, m = pt - c * h;
-  const uint32_t* base = lde + (size_t)b * ka::kWidth * n + (size_t)c * h;
+  const int mn = (m + 1) & (h - 1);
+  const uint32_t* base = a.lde + (size_t)b * ka::kWidth * n + (size_t)c * h;
+  const uint32_t* pbase = a.lde_p + (size_t)b * ka::kPermWidth * n + (size_t)c * h;
   QuotCtx ctx;
   ctx.loc = base + m;
-  ctx.nxt = base + ((m + 1) & (h - 1));
+  ctx.nxt = base + mn;
   ctx.cs = (size_t)n;
-  ctx.first = Fp::raw(sel_first[pt]);
-  ctx.trans = Fp::raw(sel_trans[pt]);
-  ctx.ap = alpha_pows + (size_t)b * ka::kNumConstraints * 4;
+  ctx.first = Fp::raw(a.sel_first[pt]);
+  ctx.trans = Fp::raw(a.sel_trans[pt]);
+  ctx.last = Fp::raw(a.sel_last[pt]);
+  ctx.ap = a.alpha_pows + (size_t)b * ka::kNumAllConstraints * 4;
+  ctx.ploc = pbase + m;
+  ctx.pnxt = pbase + mn;
+  ctx.bus_ch = a.bus_ch + (size_t)b * 8;
+  ctx.beta_pows = a.beta_pows + (size_t)b * ka::kBusTuple * 4;
+  ctx.cum = a.cum_sum + (size_t)b * 4;
   ctx.acc = Fp4::zero();
   ctx.lazy[0] = ctx.lazy[1] = ctx.lazy[2] = ctx.lazy[3] = 0;
   ctx.pending = 0;
-  ka::eval_task(g, ctx);
+  if (g == ka::kBusTask) ka::eval_bus(ctx);
+  else ka::eval_task(g, ctx);
   ctx.flush();
-  store_fp4(partial + (((size_t)b * ka::kNumTasks + g) * n + pt) * 4, ctx.acc);
+  store_fp4(a.partial + (((size_t)b * ka::kNumTasks + g) * n + pt) * 4, ctx.acc);
 }
 
 __global__ __launch_bounds__(kThreads) void keccak_quotient_combine_kernel(const uint32_t* __restrict__ partial,
@@ -208,16 +238,14 @@ __global__ __launch_bounds__(kThreads) void keccak_quotient_combine_kernel(const
   for (int j = 0; j < 4; ++j) q[(size_t)(4 * c + j) * h] = acc.c[j].v;
 }
 
-void launch_keccak_quotient(hipStream_t stream, const uint32_t* lde, const uint32_t* alpha_pows,
-                            const uint32_t* sel_first, const uint32_t* sel_trans, const uint32_t* zh_inv,
-                            uint32_t* partial, uint32_t* quot, int logh, int batch) {
-  const int n = 2 << logh;
+void launch_keccak_quotient(hipStream_t stream, const QuotientArgs& a) {
+  const int n = 2 << a.logh;
   const int blocks = (n + kThreads - 1) / kThreads;
-  const int total_tiles = blocks * batch;
-  hipLaunchKernelGGL(keccak_quotient_kernel, dim3((unsigned)total_tiles * ka::kNumTasks), dim3(kThreads), 0, stream,
-                     lde, alpha_pows, sel_first, sel_trans, partial, logh, blocks, total_tiles);
-  hipLaunchKernelGGL(keccak_quotient_combine_kernel, dim3(blocks, batch), dim3(kThreads), 0, stream, partial, zh_inv,
-                     quot, logh);
+  const int total_tiles = blocks * a.batch;
+  hipLaunchKernelGGL(keccak_quotient_kernel, dim3((unsigned)total_tiles * ka::kNumTasks), dim3(kThreads), 0, stream, a,
+                     blocks, total_tiles);
+  hipLaunchKernelGGL(keccak_quotient_combine_kernel, dim3(blocks, a.batch), dim3(kThreads), 0, stream, a.partial,
+                     a.zh_inv, a.quot, a.logh);
 }
 
 // ===========================================================================
@@ -307,20 +335,27 @@ constexpr int kReduceChunk = 128;
 __global__ __launch_bounds__(kThreads) void reduce_bsum_kernel(ReduceArgs a) {
   __shared__ Fp4 red[kThreads / 64];
   const int b = blockIdx.x, W = a.width;
-  const uint32_t* ap = a.af_pows + (size_t)b * (2 * W + 8) * 4;
+  const uint32_t* ap = a.af_pows + (size_t)b * (2 * W + 16) * 4;
   const uint32_t* op = a.opened + (size_t)b * a.opened_stride;
-  Fp4 s0 = Fp4::zero(), s1 = Fp4::zero(), s2 = Fp4::zero();
+  Fp4 s0 = Fp4::zero(), s1 = Fp4::zero(), s2 = Fp4::zero(), s3 = Fp4::zero(), s4 = Fp4::zero();
   for (int i = threadIdx.x; i < W; i += kThreads) {
     Fp4 p = load_fp4(ap + (size_t)i * 4);
     s0 += p * load_fp4(op + (size_t)i * 4);
     s1 += p * load_fp4(op + (size_t)(W + i) * 4);
   }
   if (threadIdx.x < 8) s2 = load_fp4(ap + (size_t)threadIdx.x * 4) * load_fp4(op + (size_t)(2 * W + threadIdx.x) * 4);
-  Fp4 r0 = block_sum(s0, red), r1 = block_sum(s1, red), r2 = block_sum(s2, red);
+  if (threadIdx.x < 4) {
+    s3 = load_fp4(ap + (size_t)threadIdx.x * 4) * load_fp4(op + (size_t)(2 * W + 8 + threadIdx.x) * 4);
+    s4 = load_fp4(ap + (size_t)threadIdx.x * 4) * load_fp4(op + (size_t)(2 * W + 12 + threadIdx.x) * 4);
+  }
+  Fp4 r0 = block_sum(s0, red), r1 = block_sum(s1, red), r2 = block_sum(s2, red), r3 = block_sum(s3, red),
+      r4 = block_sum(s4, red);
   if (threadIdx.x == 0) {
-    store_fp4(a.bsum + ((size_t)b * 3 + 0) * 4, r0);
-    store_fp4(a.bsum + ((size_t)b * 3 + 1) * 4, r1);
-    store_fp4(a.bsum + ((size_t)b * 3 + 2) * 4, r2);
+    store_fp4(a.bsum + ((size_t)b * 5 + 0) * 4, r0);
+    store_fp4(a.bsum + ((size_t)b * 5 + 1) * 4, r1);
+    store_fp4(a.bsum + ((size_t)b * 5 + 2) * 4, r2);
+    store_fp4(a.bsum + ((size_t)b * 5 + 3) * 4, r3);
+    store_fp4(a.bsum + ((size_t)b * 5 + 4) * 4, r4);
   }
 }
 
@@ -331,7 +366,7 @@ __global__ __launch_bounds__(kThreads) void reduce_partial_kernel(ReduceArgs a, 
   const int chunk = blockIdx.y, b = blockIdx.z, W = a.width;
   const int i0 = chunk * kReduceChunk, i1 = min(W, i0 + kReduceChunk);
   const uint32_t* col = a.lde_t + (size_t)b * W * n + pt;
-  const uint32_t* ap = a.af_pows + (size_t)b * (2 * W + 8) * 4;
+  const uint32_t* ap = a.af_pows + (size_t)b * (2 * W + 16) * 4;
   Fp4 acc = Fp4::zero();
   for (int i = i0; i < i1; ++i) acc += load_fp4(ap + (size_t)i * 4) * Fp::raw(col[(size_t)i * n]);
   store_fp4(a.partial + (((size_t)b * nchunks + chunk) * n + pt) * 4, acc);
@@ -342,15 +377,20 @@ __global__ __launch_bounds__(kThreads) void reduce_final_kernel(ReduceArgs a, in
   const int pt = blockIdx.x * kThreads + threadIdx.x;
   if (pt >= n) return;
   const int b = blockIdx.y, W = a.width;
-  const uint32_t* ap = a.af_pows + (size_t)b * (2 * W + 8) * 4;
+  const uint32_t* ap = a.af_pows + (size_t)b * (2 * W + 16) * 4;
   Fp4 st = Fp4::zero();
   for (int ch = 0; ch < nchunks; ++ch) st += load_fp4(a.partial + (((size_t)b * nchunks + ch) * n + pt) * 4);
   Fp4 sq = Fp4::zero();
   const uint32_t* q = a.lde_q + (size_t)b * 8 * n + pt;
 #pragma unroll
   for (int i = 0; i < 8; ++i) sq += load_fp4(ap + (size_t)i * 4) * Fp::raw(q[(size_t)i * n]);
-  const Fp4 b0 = load_fp4(a.bsum + ((size_t)b * 3 + 0) * 4), b1 = load_fp4(a.bsum + ((size_t)b * 3 + 1) * 4),
-            b2 = load_fp4(a.bsum + ((size_t)b * 3 + 2) * 4);
+  Fp4 sp = Fp4::zero();
+  const uint32_t* pp = a.lde_p + (size_t)b * 4 * n + pt;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sp += load_fp4(ap + (size_t)i * 4) * Fp::raw(pp[(size_t)i * n]);
+  const Fp4 b0 = load_fp4(a.bsum + ((size_t)b * 5 + 0) * 4), b1 = load_fp4(a.bsum + ((size_t)b * 5 + 1) * 4),
+            b2 = load_fp4(a.bsum + ((size_t)b * 5 + 2) * 4), b3 = load_fp4(a.bsum + ((size_t)b * 5 + 3) * 4),
+            b4 = load_fp4(a.bsum + ((size_t)b * 5 + 4) * 4);
   const Fp4 zeta = load_fp4(a.zeta + (size_t)b * 4);
   const Fp4 zeta_next = zeta * Fp::raw(a.w_h);
   const Fp4 x = Fp4::from_base(Fp::raw(a.xs[pt]));
@@ -358,6 +398,8 @@ __global__ __launch_bounds__(kThreads) void reduce_final_kernel(ReduceArgs a, in
   Fp4 g = (st - b0) * d0;
   g += load_fp4(ap + (size_t)W * 4) * (st - b1) * d1;
   g += load_fp4(ap + (size_t)(2 * W) * 4) * (sq - b2) * d0;
+  g += load_fp4(ap + (size_t)(2 * W + 8) * 4) * (sp - b3) * d0;
+  g += load_fp4(ap + (size_t)(2 * W + 12) * 4) * (sp - b4) * d1;
   store_fp4(a.out + (size_t)b * a.out_stride + (size_t)pt * 4, g);
 }
 
@@ -610,17 +652,21 @@ __global__ __launch_bounds__(kThreads) void assemble_kernel(AssembleArgs a) {
   uint32_t* body = a.body + (size_t)b * a.body_stride;
   const uint32_t* tree_t = a.tree_t + (size_t)b * a.tree_t_stride;
   const uint32_t* tree_q = a.tree_q + (size_t)b * a.tree_q_stride;
+  const uint32_t* tree_p = a.tree_p + (size_t)b * a.tree_p_stride;
   const uint32_t* fl = a.fri_layers + (size_t)b * a.fri_layer_stride;
   const uint32_t* ft = a.fri_trees + (size_t)b * a.fri_tree_stride;
-  const size_t n_open_words = (size_t)(2 * W + 8) * 4;
-  const size_t off_opened = 16, off_fri_roots = off_opened + n_open_words, off_final = off_fri_roots + 8 * (size_t)logh,
+  // body: trace root 8 | running-sum root 8 | cumulative sum 4 | quotient root 8 | opened | FRI roots | final | witness | queries
+  const size_t n_open_words = (size_t)(2 * W + 8 + 2 * ka::kPermWidth) * 4;
+  const size_t off_opened = 28, off_fri_roots = off_opened + n_open_words, off_final = off_fri_roots + 8 * (size_t)logh,
                off_witness = off_final + 4, off_queries = off_witness + 1;
   if (q == a.n_queries) {
     // fixed part
     for (int t = threadIdx.x; t < 8; t += kThreads) {
       body[t] = Fp::raw(tree_t[(2 * n - 2) * 8 + t]).to_canonical();
-      body[8 + t] = Fp::raw(tree_q[(2 * n - 2) * 8 + t]).to_canonical();
+      body[8 + t] = Fp::raw(tree_p[(2 * n - 2) * 8 + t]).to_canonical();
+      body[20 + t] = Fp::raw(tree_q[(2 * n - 2) * 8 + t]).to_canonical();
     }
+    if (threadIdx.x < 4) body[16 + threadIdx.x] = Fp::raw(a.cum_sum[(size_t)b * 4 + threadIdx.x]).to_canonical();
     const uint32_t* op = a.opened + (size_t)b * a.opened_stride;
     for (size_t t = threadIdx.x; t < n_open_words; t += kThreads) body[off_opened + t] = Fp::raw(op[t]).to_canonical();
     size_t toff = 0, loff = 0;
@@ -635,7 +681,7 @@ __global__ __launch_bounds__(kThreads) void assemble_kernel(AssembleArgs a) {
     if (threadIdx.x == 0) body[off_witness] = a.witness[b];
     return;
   }
-  size_t perq = (size_t)W + 8 * (size_t)logn + 8 + 8 * (size_t)logn;
+  size_t perq = (size_t)W + 8 * (size_t)logn + ka::kPermWidth + 8 * (size_t)logn + 8 + 8 * (size_t)logn;
   for (int k = 0; k < logh; ++k) perq += 8 + 8 * (size_t)(logh - k);
   uint32_t* dst = body + off_queries + perq * (size_t)q;
   const size_t idx = a.indices[(size_t)b * a.n_queries + q];
@@ -644,6 +690,11 @@ __global__ __launch_bounds__(kThreads) void assemble_kernel(AssembleArgs a) {
   for (int i = threadIdx.x; i < W; i += kThreads) dst[i] = Fp::raw(lt[(size_t)i * n]).to_canonical();
   dst += W;
   put_path(dst, tree_t, logn, idx);
+  dst += 8 * logn;
+  const uint32_t* lp = a.lde_p + (size_t)b * a.lde_p_stride + c * h + m;
+  if (threadIdx.x < ka::kPermWidth) dst[threadIdx.x] = Fp::raw(lp[(size_t)threadIdx.x * n]).to_canonical();
+  dst += ka::kPermWidth;
+  put_path(dst, tree_p, logn, idx);
   dst += 8 * logn;
   const uint32_t* lq = a.lde_q + (size_t)b * a.lde_q_stride + c * h + m;
   if (threadIdx.x < 8) dst[threadIdx.x] = Fp::raw(lq[(size_t)threadIdx.x * n]).to_canonical();

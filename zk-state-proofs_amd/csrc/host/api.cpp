@@ -427,31 +427,76 @@ int zksp_hip_keccak_trace(zksp_client* c, const uint64_t* d_states, uint32_t n_p
   return ZKSP_OK;
 }
 
-int zksp_hip_keccak_quotient(zksp_client* c, const uint32_t* d_lde, int log_h, const uint32_t* alpha,
-                             uint32_t* d_quot) {
+int zksp_hip_keccak_quotient(zksp_client* c, const uint32_t* d_lde, const uint32_t* d_lde_p, int log_h,
+                             const uint32_t* challenges, uint32_t* d_quot) {
   NEED_GPU(c);
   Context* ctx = &c->ctx;
-  if (!d_lde || !alpha || !d_quot) return ZKSP_ERR_INVALID_ARG;
+  if (!d_lde || !d_lde_p || !challenges || !d_quot) return ZKSP_ERR_INVALID_ARG;
   if (log_h > 14) return ctx->fail(ZKSP_ERR_UNSUPPORTED, "keccak_quotient: log_h must be <= 14");
   const DeviceDomain* dom = ctx->domain(log_h);
   if (!dom) return ZKSP_ERR_UNSUPPORTED;
   const size_t n = (size_t)2 << log_h;
-  uint32_t am[4];
-  for (int i = 0; i < 4; ++i) {
-    if (alpha[i] >= kP) return ZKSP_ERR_INVALID_ARG;
-    am[i] = Fp::from_canonical(alpha[i]).v;
+  // challenges: alpha, gamma, beta, cumulative sum (4 canonical words each)
+  uint32_t cm[16];
+  for (int i = 0; i < 16; ++i) {
+    if (challenges[i] >= kP) return ZKSP_ERR_INVALID_ARG;
+    cm[i] = Fp::from_canonical(challenges[i]).v;
   }
-  uint32_t *d_alpha = nullptr, *d_pows = nullptr, *d_partial = nullptr;
-  ZKSP_HIP_CHECK(ctx, hipMalloc(&d_alpha, 16));
-  ZKSP_HIP_CHECK(ctx, hipMalloc(&d_pows, (size_t)kNumConstraints * 16));
-  ZKSP_HIP_CHECK(ctx, hipMalloc(&d_partial, (size_t)62 * n * 16));
-  ZKSP_HIP_CHECK(ctx, hipMemcpy(d_alpha, am, 16, hipMemcpyHostToDevice));
-  launch_ext_powers(ctx->stream, d_alpha, 4, kR1, d_pows, (size_t)kNumConstraints * 4, kNumConstraints, 0, 1);
-  launch_keccak_quotient(ctx->stream, d_lde, d_pows, dom->sel_first, dom->sel_trans, dom->zh_inv, d_partial, d_quot, log_h, 1);
+  uint32_t *d_ch = nullptr, *d_pows = nullptr, *d_bpows = nullptr, *d_partial = nullptr;
+  ZKSP_HIP_CHECK(ctx, hipMalloc(&d_ch, 64));
+  ZKSP_HIP_CHECK(ctx, hipMalloc(&d_pows, (size_t)kNumAllConstraints * 16));
+  ZKSP_HIP_CHECK(ctx, hipMalloc(&d_bpows, (size_t)kBusTuple * 16));
+  ZKSP_HIP_CHECK(ctx, hipMalloc(&d_partial, (size_t)13 * n * 16));
+  ZKSP_HIP_CHECK(ctx, hipMemcpy(d_ch, cm, 64, hipMemcpyHostToDevice));
+  launch_ext_powers(ctx->stream, d_ch, 4, kR1, d_pows, (size_t)kNumAllConstraints * 4, kNumAllConstraints, 0, 1);
+  launch_ext_powers(ctx->stream, d_ch + 8, 4, kR1, d_bpows, (size_t)kBusTuple * 4, kBusTuple, 0, 1);
+  QuotientArgs qa;
+  qa.lde = d_lde;
+  qa.lde_p = d_lde_p;
+  qa.alpha_pows = d_pows;
+  qa.bus_ch = d_ch + 4;  // gamma, beta
+  qa.beta_pows = d_bpows;
+  qa.cum_sum = d_ch + 12;
+  qa.sel_first = dom->sel_first;
+  qa.sel_trans = dom->sel_trans;
+  qa.sel_last = dom->sel_last;
+  qa.zh_inv = dom->zh_inv;
+  qa.partial = d_partial;
+  qa.quot = d_quot;
+  qa.logh = log_h;
+  qa.batch = 1;
+  launch_keccak_quotient(ctx->stream, qa);
   ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  ZKSP_HIP_CHECK(ctx, hipFree(d_alpha));
+  ZKSP_HIP_CHECK(ctx, hipFree(d_ch));
   ZKSP_HIP_CHECK(ctx, hipFree(d_pows));
+  ZKSP_HIP_CHECK(ctx, hipFree(d_bpows));
   ZKSP_HIP_CHECK(ctx, hipFree(d_partial));
+  ZKSP_HIP_CHECK(ctx, hipGetLastError());
+  return ZKSP_OK;
+}
+
+// trace [2633][H], gamma/beta (4 canonical words each) -> phi [4][H], cumulative sum (4 Montgomery words on device)
+int zksp_hip_bus_perm_trace(zksp_client* c, const uint32_t* d_trace, int log_h, const uint32_t* gamma_beta, uint32_t* d_phi,
+                            uint32_t* d_cum_sum) {
+  NEED_GPU(c);
+  Context* ctx = &c->ctx;
+  if (!d_trace || !gamma_beta || !d_phi || !d_cum_sum || log_h < 1 || log_h > 20) return ZKSP_ERR_INVALID_ARG;
+  uint32_t cm[8];
+  for (int i = 0; i < 8; ++i) {
+    if (gamma_beta[i] >= kP) return ZKSP_ERR_INVALID_ARG;
+    cm[i] = Fp::from_canonical(gamma_beta[i]).v;
+  }
+  uint32_t *d_ch = nullptr, *d_bpows = nullptr, *d_terms = nullptr;
+  ZKSP_HIP_CHECK(ctx, hipMalloc(&d_ch, 32));
+  ZKSP_HIP_CHECK(ctx, hipMalloc(&d_bpows, (size_t)kBusTuple * 16));
+  ZKSP_HIP_CHECK(ctx, hipMalloc(&d_terms, ((size_t)16) << log_h));
+  ZKSP_HIP_CHECK(ctx, hipMemcpy(d_ch, cm, 32, hipMemcpyHostToDevice));
+  launch_ext_powers(ctx->stream, d_ch + 4, 4, kR1, d_bpows, (size_t)kBusTuple * 4, kBusTuple, 0, 1);
+  launch_bus_perm_trace(ctx->stream, d_trace, d_ch, d_bpows, d_terms, d_phi, d_cum_sum, log_h, 1);
+  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ZKSP_HIP_CHECK(ctx, hipFree(d_ch));
+  ZKSP_HIP_CHECK(ctx, hipFree(d_bpows));
+  ZKSP_HIP_CHECK(ctx, hipFree(d_terms));
   ZKSP_HIP_CHECK(ctx, hipGetLastError());
   return ZKSP_OK;
 }

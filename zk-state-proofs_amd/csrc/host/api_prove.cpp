@@ -111,8 +111,19 @@ int zksp_prove_batch(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdin
       zksp_proof* p = new (std::nothrow) zksp_proof();
       if (!p) { status[i] = ZKSP_ERR_INVALID_ARG; return; }
       const uint32_t pv_len = (uint32_t)r.public_values.size();
-      const size_t hwords = proof_header_words(pv_len);
+      const size_t hwords = proof_header_words(pv_len, g.np[j]);
       std::vector<uint8_t> head(hwords * 4, 0);
+      {
+        // public I/O list: every permutation's input state and keccak-f of it
+        uint8_t* io = head.data() + (30 + (pv_len + 3) / 4) * 4;
+        for (size_t p = 0; p < r.keccak_events.size(); ++p) {
+          uint64_t st[25];
+          memcpy(st, r.keccak_events[p].state_in, 200);
+          memcpy(io + p * 400, st, 200);
+          keccak_f1600(st);
+          memcpy(io + p * 400 + 200, st, 200);
+        }
+      }
       uint32_t* w = reinterpret_cast<uint32_t*>(head.data());
       w[0] = kProofMagic; w[1] = kProofVersion; w[2] = (uint32_t)g.logh; w[3] = g.np[j]; w[4] = r.exit_code; w[5] = pv_len;
       memcpy(w + 6, r.pv_digest.data(), 32);

@@ -12,7 +12,7 @@ Context::~Context() {
     for (auto& kv : domains) {
       DeviceDomain& d = kv.second;
       uint32_t* ptrs[] = {d.tw_fwd, d.tw_inv, d.in_scale_br, d.out_scale_br,
-                          d.xs, d.sel_first, d.sel_trans, d.zh_inv};
+                          d.xs, d.sel_first, d.sel_trans, d.sel_last, d.zh_inv};
       for (uint32_t* p : ptrs)
         if (p) (void)hipFree(p);
     }
@@ -71,6 +71,7 @@ const DeviceDomain* Context::domain(int logh) {
     dd.xs = upload(this, hd.xs.data(), hd.xs.size(), &ok);
     dd.sel_first = upload(this, hd.sel_first.data(), hd.sel_first.size(), &ok);
     dd.sel_trans = upload(this, hd.sel_trans.data(), hd.sel_trans.size(), &ok);
+    dd.sel_last = upload(this, hd.sel_last.data(), hd.sel_last.size(), &ok);
   }
   dd.zh_inv = upload(this, hd.zh_inv, 2, &ok);
   // (shift_k * w_{2Hk}^c)^-1 for every fold round

@@ -23,7 +23,7 @@ struct HostDomain {
   std::vector<uint32_t> tw_fwd, tw_inv;          // [H/2]
   std::vector<uint32_t> in_scale_br[3];          // [H]: trace (shift 1), quotient chunk 0, chunk 1
   std::vector<uint32_t> out_scale_br;            // [2][H]
-  std::vector<uint32_t> xs, sel_first, sel_trans;  // [2][H]
+  std::vector<uint32_t> xs, sel_first, sel_trans, sel_last;  // [2][H]
   uint32_t zh_inv[2];
   uint32_t w_h;
 };
@@ -32,7 +32,8 @@ void build_host_domain(int logh, HostDomain* d, bool full = true);
 struct DeviceDomain {
   int logh = 0;
   uint32_t *tw_fwd = nullptr, *tw_inv = nullptr, *in_scale_br = nullptr /*[3][H]: shift 1, g, g*w_2H*/,
-           *out_scale_br = nullptr, *xs = nullptr, *sel_first = nullptr, *sel_trans = nullptr, *zh_inv = nullptr;
+           *out_scale_br = nullptr, *xs = nullptr, *sel_first = nullptr, *sel_trans = nullptr, *sel_last = nullptr,
+           *zh_inv = nullptr;
   uint32_t w_h = 0;
   std::vector<uint32_t> fold_xinv;  // [logh][2] host copies of (shift_k * w_{2Hk}^c)^-1
 };
@@ -72,7 +73,8 @@ struct Context {
 };
 
 size_t proof_body_words(int logh, uint32_t num_queries);
-size_t proof_header_words(uint32_t pv_len);
+size_t proof_header_words(uint32_t pv_len, uint32_t n_perms);
+int bus_io_log_rows(int logh);
 
 #define ZKSP_HIP_CHECK(ctx, call)                                                         \
   do {                                                                                    \

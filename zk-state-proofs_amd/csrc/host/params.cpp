@@ -99,6 +99,7 @@ void build_host_domain(int logh, HostDomain* d, bool full) {
     d->xs.resize(2 * h);
     d->sel_first.resize(2 * h);
     d->sel_trans.resize(2 * h);
+    d->sel_last.resize(2 * h);
   }
   for (int c = 0; c < 2; ++c) {
     std::vector<uint32_t> nat(h);
@@ -115,19 +116,31 @@ void build_host_domain(int logh, HostDomain* d, bool full) {
       d->xs[c * h + m] = x.v;
       d->sel_first[c * h + m] = (zh * (x - Fp::one()).inv()).v;
       d->sel_trans[c * h + m] = (x - wh_inv).v;
+      d->sel_last[c * h + m] = (zh * (x - wh_inv).inv()).v;
       x = x * wh;
     }
   }
 }
 
 size_t proof_body_words(int logh, uint32_t num_queries) {
-  const size_t logn = (size_t)logh + 1, W = 2633;
-  size_t words = 8 + 8 + (2 * W + 8) * 4 + 8 * (size_t)logh + 4 + 1;
-  size_t perq = W + 8 * logn + 8 + 8 * logn;
+  const size_t logn = (size_t)logh + 1, W = 2633, PW = 4;
+  // trace root, running-sum root, cumulative sum, quotient root, opened values, FRI roots, final, witness
+  size_t words = 8 + 8 + 4 + 8 + (2 * W + 8 + 2 * PW) * 4 + 8 * (size_t)logh + 4 + 1;
+  size_t perq = W + 8 * logn + PW + 8 * logn + 8 + 8 * logn;
   for (int k = 0; k < logh; ++k) perq += 8 + 8 * (size_t)(logh - k);
   return words + perq * num_queries;
 }
 
-size_t proof_header_words(uint32_t pv_len) { return 30 + (pv_len + 3) / 4; }
+// 30 fixed words, the public values, then the public I/O list (50 u64 per permutation)
+size_t proof_header_words(uint32_t pv_len, uint32_t n_perms) { return 30 + (pv_len + 3) / 4 + (size_t)100 * n_perms; }
+
+// rows of the column-major [8][R] matrix that carries the I/O limbs of a trace height
+int bus_io_log_rows(int logh) {
+  const size_t max_perms = ((size_t)1 << logh) / 24;
+  const size_t rows = (max_perms * 200 + 7) / 8;
+  int l = 0;
+  while (((size_t)1 << l) < rows) ++l;
+  return l;
+}
 
 }  // namespace zksp

@@ -53,7 +53,9 @@ int workspace_ensure(Context* ctx, int logh, int batch, int max_perms) {
   const size_t B = (size_t)batch, h = (size_t)1 << logh, n = 2 * h, W = kTraceWidth;
   const uint32_t Q = ctx->params.num_queries;
   ws->body_words = proof_body_words(logh, Q);
-  const size_t n_open_words = (2 * W + 8) * 4;
+  const size_t n_open_words = (2 * W + 8 + 2 * kPermWidth) * 4;
+  ws->io_rows_log = (size_t)bus_io_log_rows(logh);
+  const size_t RIO = (size_t)1 << ws->io_rows_log;
   ws->open_rows_log = (size_t)ceil_log2((n_open_words + 7) / 8);
   const size_t R = (size_t)1 << ws->open_rows_log;
   ws->fri_layer_stride = 0;
@@ -64,7 +66,7 @@ int workspace_ensure(Context* ctx, int logh, int batch, int max_perms) {
     ws->fri_tree_stride += (2 * hk - 1) * 8;
   }
   ws->fri_layer_stride += 2 * 4;  // the final 2-point layer
-  const size_t scratch_words = std::max<size_t>(W * h, std::max<size_t>((size_t)62 * n * 4, (size_t)reduce_nchunks((int)W) * n * 4));
+  const size_t scratch_words = std::max<size_t>(W * h, std::max<size_t>((size_t)13 * n * 4, (size_t)reduce_nchunks((int)W) * n * 4));
   bool ok = true;
   ok &= dalloc(ws, &ws->states, B * (size_t)max_perms * 25);
   ok &= dalloc(ws, &ws->n_perms, B);
@@ -75,7 +77,17 @@ int workspace_ensure(Context* ctx, int logh, int batch, int max_perms) {
   ok &= dalloc(ws, &ws->tree_t, B * (2 * n - 1) * 8);
   ok &= dalloc(ws, &ws->ch, B);
   ok &= dalloc(ws, &ws->alpha, B * 4);
-  ok &= dalloc(ws, &ws->alpha_pows, B * (size_t)kNumConstraints * 4);
+  ok &= dalloc(ws, &ws->alpha_pows, B * (size_t)kNumAllConstraints * 4);
+  ok &= dalloc(ws, &ws->io, B * 8 * RIO);
+  ok &= dalloc(ws, &ws->tree_io, B * (2 * RIO - 1) * 8);
+  ok &= dalloc(ws, &ws->bus_ch, B * 8);
+  ok &= dalloc(ws, &ws->beta_pows, B * (size_t)kBusTuple * 4);
+  ok &= dalloc(ws, &ws->bus_terms, B * h * 4);
+  ok &= dalloc(ws, &ws->phi, B * kPermWidth * h);
+  ok &= dalloc(ws, &ws->coef_p, B * kPermWidth * h);
+  ok &= dalloc(ws, &ws->lde_p, B * kPermWidth * n);
+  ok &= dalloc(ws, &ws->tree_p, B * (2 * n - 1) * 8);
+  ok &= dalloc(ws, &ws->cum_sum, B * 4);
   ok &= dalloc(ws, &ws->quot, B * 8 * h);
   ok &= dalloc(ws, &ws->coef_q, B * 8 * h);
   ok &= dalloc(ws, &ws->lde_q, B * 8 * n);
@@ -85,8 +97,8 @@ int workspace_ensure(Context* ctx, int logh, int batch, int max_perms) {
   ok &= dalloc(ws, &ws->opened, B * 8 * R);
   ok &= dalloc(ws, &ws->tree_o, B * (2 * R - 1) * 8);
   ok &= dalloc(ws, &ws->af, B * 4);
-  ok &= dalloc(ws, &ws->af_pows, B * (2 * W + 8) * 4);
-  ok &= dalloc(ws, &ws->bsum, B * 3 * 4);
+  ok &= dalloc(ws, &ws->af_pows, B * (2 * W + 16) * 4);
+  ok &= dalloc(ws, &ws->bsum, B * 5 * 4);
   ok &= dalloc(ws, &ws->fri_layers, B * ws->fri_layer_stride);
   ok &= dalloc(ws, &ws->fri_trees, B * ws->fri_tree_stride);
   ok &= dalloc(ws, &ws->betas, B * (size_t)logh * 4);
@@ -132,16 +144,53 @@ int prove_resident(Context* ctx) {
     ProfileSpan sp(ctx, "merkle_upper");
     launch_merkle_upper(s, logn, ws->tree_t, tree_stride, B, kc);
   }
+  const size_t RIO = (size_t)1 << ws->io_rows_log;
+  {
+    ProfileSpan sp(ctx, "bus_io");
+    // public I/O limbs (input || keccak-f(input)) and their Merkle root, absorbed before the trace root
+    launch_keccak_io(s, ws->states, ws->max_perms, ws->n_perms, ws->io, 8 * RIO, B);
+    launch_merkle_commit(s, ws->io, 8 * RIO, 8, (int)ws->io_rows_log, ws->tree_io, (2 * RIO - 1) * 8, B, kc);
+  }
   {
     ProfileSpan sp(ctx, "transcript");
     launch_ch_init(s, ws->ch, ws->init_obs, kInitObs, B, kc);
-    launch_ch_observe_sample(s, ws->ch, ws->tree_t + root_off, tree_stride, 8, ws->alpha, 4, 1, B, kc);
-    launch_ext_powers(s, ws->alpha, 4, kR1, ws->alpha_pows, (size_t)kNumConstraints * 4, kNumConstraints, 0, B);
+    launch_ch_observe_sample(s, ws->ch, ws->tree_io + (2 * RIO - 2) * 8, (2 * RIO - 1) * 8, 8, ws->bus_ch, 8, 0, B, kc);
+    // trace root -> gamma, beta
+    launch_ch_observe_sample(s, ws->ch, ws->tree_t + root_off, tree_stride, 8, ws->bus_ch, 8, 2, B, kc);
+    launch_ext_powers(s, ws->bus_ch + 4, 8, kR1, ws->beta_pows, (size_t)kBusTuple * 4, kBusTuple, 0, B);
+  }
+  {
+    ProfileSpan sp(ctx, "bus_trace");
+    launch_bus_perm_trace(s, ws->trace, ws->bus_ch, ws->beta_pows, ws->bus_terms, ws->phi, ws->cum_sum, logh, B);
+    launch_lde(s, ws->phi, ws->coef_p, ws->lde_p, dom->tw_fwd, dom->tw_inv, dom->in_scale_br, 0, 0, dom->out_scale_br,
+               logh, (size_t)B * kPermWidth);
+    launch_merkle_commit(s, ws->lde_p, (size_t)kPermWidth * n, kPermWidth, logn, ws->tree_p, tree_stride, B, kc);
+  }
+  {
+    ProfileSpan sp(ctx, "transcript");
+    // running-sum root, cumulative sum -> alpha
+    launch_ch_observe_sample(s, ws->ch, ws->tree_p + root_off, tree_stride, 8, ws->alpha, 4, 0, B, kc);
+    launch_ch_observe_sample(s, ws->ch, ws->cum_sum, 4, 4, ws->alpha, 4, 1, B, kc);
+    launch_ext_powers(s, ws->alpha, 4, kR1, ws->alpha_pows, (size_t)kNumAllConstraints * 4, kNumAllConstraints, 0, B);
   }
   {
     ProfileSpan sp(ctx, "quotient");
-    launch_keccak_quotient(s, ws->lde_t, ws->alpha_pows, dom->sel_first, dom->sel_trans, dom->zh_inv, ws->trace,
-                           ws->quot, logh, B);
+    QuotientArgs qa;
+    qa.lde = ws->lde_t;
+    qa.lde_p = ws->lde_p;
+    qa.alpha_pows = ws->alpha_pows;
+    qa.bus_ch = ws->bus_ch;
+    qa.beta_pows = ws->beta_pows;
+    qa.cum_sum = ws->cum_sum;
+    qa.sel_first = dom->sel_first;
+    qa.sel_trans = dom->sel_trans;
+    qa.sel_last = dom->sel_last;
+    qa.zh_inv = dom->zh_inv;
+    qa.partial = ws->trace;
+    qa.quot = ws->quot;
+    qa.logh = logh;
+    qa.batch = B;
+    launch_keccak_quotient(s, qa);
   }
   {
     ProfileSpan sp(ctx, "lde_quot");
@@ -163,6 +212,8 @@ int prove_resident(Context* ctx) {
     ProfileSpan sp(ctx, "open");
     launch_open(s, ws->coef_t, (size_t)W * h, W, logh, ws->zpow, 2 * h * 4, 2, ws->opened, 8 * R, (size_t)W, B);
     launch_open(s, ws->coef_q, 8 * h, 8, logh, ws->zpow, 2 * h * 4, 1, ws->opened + (size_t)2 * W * 4, 8 * R, 0, B);
+    launch_open(s, ws->coef_p, (size_t)kPermWidth * h, kPermWidth, logh, ws->zpow, 2 * h * 4, 2,
+                ws->opened + (size_t)(2 * W + 8) * 4, 8 * R, (size_t)kPermWidth, B);
   }
   {
     ProfileSpan sp(ctx, "merkle_open");
@@ -171,13 +222,14 @@ int prove_resident(Context* ctx) {
   {
     ProfileSpan sp(ctx, "transcript");
     launch_ch_observe_sample(s, ws->ch, ws->tree_o + (2 * R - 2) * 8, (2 * R - 1) * 8, 8, ws->af, 4, 1, B, kc);
-    launch_ext_powers(s, ws->af, 4, kR1, ws->af_pows, (size_t)(2 * W + 8) * 4, 2 * W + 8, 0, B);
+    launch_ext_powers(s, ws->af, 4, kR1, ws->af_pows, (size_t)(2 * W + 16) * 4, 2 * W + 16, 0, B);
   }
   {
     ProfileSpan sp(ctx, "reduce_openings");
     ReduceArgs ra;
     ra.lde_t = ws->lde_t;
     ra.lde_q = ws->lde_q;
+    ra.lde_p = ws->lde_p;
     ra.af_pows = ws->af_pows;
     ra.opened = ws->opened;
     ra.opened_stride = 8 * R;
@@ -235,6 +287,9 @@ int prove_resident(Context* ctx) {
     aa.tree_t = ws->tree_t;
     aa.lde_q = ws->lde_q;
     aa.tree_q = ws->tree_q;
+    aa.lde_p = ws->lde_p;
+    aa.tree_p = ws->tree_p;
+    aa.cum_sum = ws->cum_sum;
     aa.opened = ws->opened;
     aa.fri_layers = ws->fri_layers;
     aa.fri_trees = ws->fri_trees;
@@ -245,6 +300,8 @@ int prove_resident(Context* ctx) {
     aa.tree_t_stride = tree_stride;
     aa.lde_q_stride = 8 * n;
     aa.tree_q_stride = tree_stride;
+    aa.lde_p_stride = (size_t)kPermWidth * n;
+    aa.tree_p_stride = tree_stride;
     aa.opened_stride = 8 * R;
     aa.fri_layer_stride = ws->fri_layer_stride;
     aa.fri_tree_stride = ws->fri_tree_stride;

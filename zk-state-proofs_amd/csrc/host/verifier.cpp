@@ -1,8 +1,9 @@
 // Host verifier: replaces `client.verify(&proof, &vk)` (reference
 // prover/src/bin/main.rs:80; sp1-stark 3.4.0 + p3-uni-stark / p3-fri verifiers,
-// Cargo.lock:7485, :5378, :5253).  Re-derives the Fiat-Shamir transcript, checks
-// the constraint identity at zeta with the SAME AIR template the device quotient
-// kernel instantiates (air_keccak.cuh), then the FRI queries.  Needs no GPU.
+// Cargo.lock:7485, :5378, :5253).  Re-derives the Fiat-Shamir transcript, recomputes
+// the LogUp bus sum from the public I/O list, checks the constraint identity at zeta
+// with the SAME AIR template the device quotient kernel instantiates (air_keccak.cuh),
+// then the FRI queries.  Needs no GPU.
 #include "verifier.hpp"
 
 #include <cstring>
@@ -86,19 +87,51 @@ bool verify_path(const Fp leaf[8], size_t idx, const uint32_t* path_canon, int d
   return true;
 }
 
+// Merkle root of a flat word list laid out column-major as [8][2^logr], zero padded: the
+// form in which long lists (opened values, the public I/O limbs) enter the transcript.
+void list_root(const std::vector<Fp>& words, int logr, Fp out[8], const P2Consts* kc) {
+  const size_t R = (size_t)1 << logr;
+  std::vector<Fp> pad(8 * R, Fp::zero());
+  for (size_t t = 0; t < words.size() && t < 8 * R; ++t) pad[t] = words[t];
+  std::vector<Fp> layer(8 * R), nxt;
+  for (size_t r = 0; r < R; ++r) {
+    Fp row[8];
+    for (int c = 0; c < 8; ++c) row[c] = pad[(size_t)c * R + r];
+    hash_elems(row, 8, &layer[8 * r], kc);
+  }
+  for (size_t cnt = R; cnt > 1; cnt >>= 1) {
+    nxt.assign(8 * (cnt / 2), Fp::zero());
+    for (size_t i = 0; i < cnt / 2; ++i) compress(&layer[16 * i], &layer[16 * i + 8], &nxt[8 * i], kc);
+    layer.swap(nxt);
+  }
+  for (int i = 0; i < 8; ++i) out[i] = layer[i];
+}
+
 struct VerifyCtx {
   using F = Fp4;
+  using E = Fp4;
   const Fp4* loc;
   const Fp4* nxt;
-  Fp4 first, trans;
+  Fp4 first, trans, last;
   const Fp4* ap;
   Fp4 acc;
+  // bus
+  Fp4 gamma_, cum_, phi_, phi_next_;
+  const Fp4* bpow;
   F local(int col) const { return loc[col]; }
   F next(int col) const { return nxt[col]; }
   F is_first() const { return first; }
   F is_trans() const { return trans; }
+  F is_last() const { return last; }
   F one() const { return Fp4::one(); }
   void emit_at(int k, F v) { acc += ap[k] * v; }
+  E gamma() const { return gamma_; }
+  E beta_pow(int j) const { return bpow[j]; }
+  E cum_sum() const { return cum_; }
+  E phi_local() const { return phi_; }
+  E phi_next() const { return phi_next_; }
+  E lift(F v) const { return v; }
+  void emit_ext_at(int k, E v) { acc += ap[k] * v; }
 };
 
 bool all_canonical(const uint32_t* w, size_t n) {
@@ -135,9 +168,11 @@ bool parse_proof_header(const uint8_t* bytes, size_t len, ProofHeader* h, std::s
   memcpy(h->vk_digest, w + 22, 32);
   if (h->log_h < 1 || h->log_h > 26) { *err = "log_h out of range"; return false; }
   if (h->pv_len > (1u << 24)) { *err = "public values too long"; return false; }
-  size_t hw = proof_header_words(h->pv_len);
+  if ((uint64_t)h->n_perms * 24 > ((uint64_t)1 << h->log_h)) { *err = "n_perms exceeds trace height"; return false; }
+  size_t hw = proof_header_words(h->pv_len, h->n_perms);
   if (len < hw * 4) { *err = "proof truncated in header"; return false; }
   h->pv_offset = 30 * 4;
+  h->io_offset = (30 + (h->pv_len + 3) / 4) * 4;
   h->body_offset = hw * 4;
   return true;
 }
@@ -146,11 +181,10 @@ int verify_proof(const uint8_t* bytes, size_t len, const uint32_t vk_digest[8], 
                  std::string* err) {
   ProofHeader hd;
   if (!parse_proof_header(bytes, len, &hd, err)) return 7;
-  const int logh = (int)hd.log_h, logn = logh + 1, W = ka::kWidth;
+  const int logh = (int)hd.log_h, logn = logh + 1, W = ka::kWidth, PW = ka::kPermWidth;
   const size_t h = (size_t)1 << logh;
   if (len != hd.body_offset + proof_body_words(logh, num_queries) * 4) { *err = "proof length mismatch"; return 7; }
   if (memcmp(hd.vk_digest, vk_digest, 32) != 0) { *err = "verifying key mismatch"; return 8; }
-  if ((size_t)hd.n_perms * 24 > h) { *err = "n_perms exceeds trace height"; return 8; }
   // the guest commits sha256(public values) word by word
   {
     uint8_t dg[32];
@@ -162,14 +196,31 @@ int verify_proof(const uint8_t* bytes, size_t len, const uint32_t vk_digest[8], 
   if (!all_canonical(body, body_words)) { *err = "non-canonical field element"; return 7; }
 
   const P2Consts* kc = &host_p2_consts();
-  const size_t n_open = (size_t)(2 * W + 8);
+  const size_t n_open = (size_t)(2 * W + 8 + 2 * PW);
   const uint32_t* p_root_t = body;
-  const uint32_t* p_root_q = body + 8;
-  const uint32_t* p_opened = body + 16;
+  const uint32_t* p_root_p = body + 8;
+  const uint32_t* p_cum = body + 16;
+  const uint32_t* p_root_q = body + 20;
+  const uint32_t* p_opened = body + 28;
   const uint32_t* p_fri_roots = p_opened + n_open * 4;
   const uint32_t* p_final = p_fri_roots + 8 * (size_t)logh;
   const uint32_t* p_witness = p_final + 4;
   const uint32_t* p_queries = p_witness + 1;
+
+  // public I/O list -> limbs (input 100, output 100 per permutation)
+  std::vector<Fp> io_limbs((size_t)ka::kBusTuple * hd.n_perms);
+  {
+    const uint8_t* io = bytes + hd.io_offset;
+    for (uint32_t p = 0; p < hd.n_perms; ++p)
+      for (int half = 0; half < 2; ++half)
+        for (int lane = 0; lane < 25; ++lane) {
+          uint64_t v;
+          memcpy(&v, io + ((size_t)p * 50 + half * 25 + lane) * 8, 8);
+          for (int l = 0; l < 4; ++l)
+            io_limbs[(size_t)p * ka::kBusTuple + 100 * half + 4 * lane + l] =
+                Fp::from_canonical((uint32_t)((v >> (16 * l)) & 0xffff));
+        }
+  }
 
   HostChallenger ch(kc);
   for (int i = 0; i < 8; ++i) ch.observe_canon(hd.vk_digest[i]);
@@ -179,32 +230,44 @@ int verify_proof(const uint8_t* bytes, size_t len, const uint32_t vk_digest[8], 
   ch.observe_canon(hd.exit_code >> 16);
   for (int i = 0; i < 8; ++i) { ch.observe_canon(hd.pv_digest[i] & 0xffff); ch.observe_canon(hd.pv_digest[i] >> 16); }
   for (int i = 0; i < 8; ++i) { ch.observe_canon(hd.deferred_digest[i] & 0xffff); ch.observe_canon(hd.deferred_digest[i] >> 16); }
-  Fp root_t[8], root_q[8];
+  {
+    Fp io_root[8];
+    list_root(io_limbs, bus_io_log_rows(logh), io_root, kc);
+    for (int i = 0; i < 8; ++i) ch.observe(io_root[i]);
+  }
+  Fp root_t[8], root_p[8], root_q[8];
   for (int i = 0; i < 8; ++i) { root_t[i] = Fp::from_canonical(p_root_t[i]); ch.observe(root_t[i]); }
+  const Fp4 gamma = ch.sample_ext();
+  const Fp4 beta = ch.sample_ext();
+  for (int i = 0; i < 8; ++i) { root_p[i] = Fp::from_canonical(p_root_p[i]); ch.observe(root_p[i]); }
+  const Fp4 cum_sum = read_fp4(p_cum);
+  for (int i = 0; i < 4; ++i) ch.observe(cum_sum.c[i]);
   const Fp4 alpha = ch.sample_ext();
   for (int i = 0; i < 8; ++i) { root_q[i] = Fp::from_canonical(p_root_q[i]); ch.observe(root_q[i]); }
   const Fp4 zeta = ch.sample_ext();
 
+  // ---- LogUp bus: the chip must have received exactly the public list ----
+  std::vector<Fp4> bpow(ka::kBusTuple);
+  bpow[0] = Fp4::one();
+  for (int j = 1; j < ka::kBusTuple; ++j) bpow[j] = bpow[j - 1] * beta;
+  {
+    Fp4 expect = Fp4::zero();
+    for (uint32_t p = 0; p < hd.n_perms; ++p) {
+      Fp4 f = gamma;
+      for (int j = 0; j < ka::kBusTuple; ++j) f += bpow[j] * io_limbs[(size_t)p * ka::kBusTuple + j];
+      expect += f.inv();
+    }
+    if (expect != cum_sum) { *err = "LogUp bus sum does not match the public I/O list"; return 8; }
+  }
+
   std::vector<Fp4> opened(n_open);
   for (size_t i = 0; i < n_open; ++i) opened[i] = read_fp4(p_opened + 4 * i);
   {
-    // Merkle-ised digest of the opened values (column-major [8][R], zero padded)
-    const int logr = ceil_log2((n_open * 4 + 7) / 8);
-    const size_t R = (size_t)1 << logr;
-    std::vector<Fp> pad(8 * R, Fp::zero());
-    for (size_t t = 0; t < n_open * 4; ++t) pad[t] = Fp::from_canonical(p_opened[t]);
-    std::vector<Fp> layer(8 * R), nxt;
-    for (size_t r = 0; r < R; ++r) {
-      Fp row[8];
-      for (int c = 0; c < 8; ++c) row[c] = pad[(size_t)c * R + r];
-      hash_elems(row, 8, &layer[8 * r], kc);
-    }
-    for (size_t cnt = R; cnt > 1; cnt >>= 1) {
-      nxt.assign(8 * (cnt / 2), Fp::zero());
-      for (size_t i = 0; i < cnt / 2; ++i) compress(&layer[16 * i], &layer[16 * i + 8], &nxt[8 * i], kc);
-      layer.swap(nxt);
-    }
-    for (int i = 0; i < 8; ++i) ch.observe(layer[i]);
+    std::vector<Fp> words(n_open * 4);
+    for (size_t t = 0; t < n_open * 4; ++t) words[t] = Fp::from_canonical(p_opened[t]);
+    Fp open_root[8];
+    list_root(words, ceil_log2((n_open * 4 + 7) / 8), open_root, kc);
+    for (int i = 0; i < 8; ++i) ch.observe(open_root[i]);
   }
   const Fp4 af = ch.sample_ext();
 
@@ -214,18 +277,31 @@ int verify_proof(const uint8_t* bytes, size_t len, const uint32_t vk_digest[8], 
   const Fp wh_inv = wh.inv();
   const Fp4 zeta_h = zeta.pow(h);
   const Fp4 zh = zeta_h - Fp4::one();
+  const size_t o_pl = (size_t)2 * W + 8, o_pn = o_pl + PW;
   {
-    std::vector<Fp4> apow(ka::kNumConstraints);
+    std::vector<Fp4> apow(ka::kNumAllConstraints);
     apow[0] = Fp4::one();
-    for (int k = 1; k < ka::kNumConstraints; ++k) apow[k] = apow[k - 1] * alpha;
+    for (int k = 1; k < ka::kNumAllConstraints; ++k) apow[k] = apow[k - 1] * alpha;
     VerifyCtx vc;
     vc.loc = opened.data();
     vc.nxt = opened.data() + W;
     vc.first = zh * (zeta - Fp4::one()).inv();
     vc.trans = zeta - Fp4::from_base(wh_inv);
+    vc.last = zh * (zeta - Fp4::from_base(wh_inv)).inv();
     vc.acc = Fp4::zero();
     vc.ap = apow.data();
-    for (int task = 0; task < ka::kNumTasks; ++task) ka::eval_task(task, vc);
+    vc.gamma_ = gamma;
+    vc.cum_ = cum_sum;
+    vc.bpow = bpow.data();
+    vc.phi_ = vc.phi_next_ = Fp4::zero();
+    for (int j = 0; j < PW; ++j) {
+      Fp4 basis = Fp4::zero();
+      basis.c[j] = Fp::one();
+      vc.phi_ += basis * opened[o_pl + j];
+      vc.phi_next_ += basis * opened[o_pn + j];
+    }
+    for (int task = 0; task < ka::kBusTask; ++task) ka::eval_task(task, vc);
+    ka::eval_bus(vc);
     // quotient(zeta) from its two chunk polynomials
     Fp4 q[2];
     for (int c = 0; c < 2; ++c) {
@@ -258,16 +334,20 @@ int verify_proof(const uint8_t* bytes, size_t len, const uint32_t vk_digest[8], 
   std::vector<Fp4> afpow(n_open);
   afpow[0] = Fp4::one();
   for (size_t i = 1; i < n_open; ++i) afpow[i] = afpow[i - 1] * af;
-  Fp4 b0 = Fp4::zero(), b1 = Fp4::zero(), b2 = Fp4::zero();
+  Fp4 b0 = Fp4::zero(), b1 = Fp4::zero(), b2 = Fp4::zero(), b3 = Fp4::zero(), b4 = Fp4::zero();
   for (int i = 0; i < W; ++i) {
     b0 += afpow[i] * opened[i];
     b1 += afpow[i] * opened[W + i];
   }
   for (int i = 0; i < 8; ++i) b2 += afpow[i] * opened[2 * W + i];
+  for (int i = 0; i < PW; ++i) {
+    b3 += afpow[i] * opened[o_pl + i];
+    b4 += afpow[i] * opened[o_pn + i];
+  }
   const Fp4 zeta_next = zeta * wh;
   const Fp inv2 = Fp::from_canonical(2).inv();
 
-  size_t perq = (size_t)W + 8 * (size_t)logn + 8 + 8 * (size_t)logn;
+  size_t perq = (size_t)W + 8 * (size_t)logn + PW + 8 * (size_t)logn + 8 + 8 * (size_t)logn;
   for (int k = 0; k < logh; ++k) perq += 8 + 8 * (size_t)(logh - k);
   std::vector<Fp> row(W);
   for (uint32_t qi = 0; qi < num_queries; ++qi) {
@@ -282,6 +362,14 @@ int verify_proof(const uint8_t* bytes, size_t len, const uint32_t vk_digest[8], 
     Fp4 st = Fp4::zero();
     for (int i = 0; i < W; ++i) st += afpow[i] * row[i];
     q += W + 8 * logn;
+    // running-sum row
+    Fp prow[4];
+    for (int i = 0; i < PW; ++i) prow[i] = Fp::from_canonical(q[i]);
+    hash_elems(prow, PW, leaf, kc);
+    if (!verify_path(leaf, idx, q + PW, logn, root_p, kc)) { *err = "running-sum Merkle path rejected"; return 8; }
+    Fp4 sp = Fp4::zero();
+    for (int i = 0; i < PW; ++i) sp += afpow[i] * prow[i];
+    q += PW + 8 * logn;
     // quotient row
     Fp qrow[8];
     for (int i = 0; i < 8; ++i) qrow[i] = Fp::from_canonical(q[i]);
@@ -293,7 +381,8 @@ int verify_proof(const uint8_t* bytes, size_t len, const uint32_t vk_digest[8], 
     const Fp shift_c = c ? g * w2h : g;
     const Fp x = shift_c * wh.pow(m);
     const Fp4 d0 = (Fp4::from_base(x) - zeta).inv(), d1 = (Fp4::from_base(x) - zeta_next).inv();
-    Fp4 expect = (st - b0) * d0 + afpow[W] * (st - b1) * d1 + afpow[2 * W] * (sq - b2) * d0;
+    Fp4 expect = (st - b0) * d0 + afpow[W] * (st - b1) * d1 + afpow[2 * W] * (sq - b2) * d0 +
+                 afpow[o_pl] * (sp - b3) * d0 + afpow[o_pn] * (sp - b4) * d1;
     // FRI layers
     Fp shift_k = g;
     for (int k = 0; k < logh; ++k) {

@@ -10,12 +10,12 @@
 namespace zksp {
 
 constexpr uint32_t kProofMagic = 0x50534B5Au;  // "ZKSP"
-constexpr uint32_t kProofVersion = 1;
+constexpr uint32_t kProofVersion = 2;  // 2: LogUp bus + public I/O list
 
 struct ProofHeader {
   uint32_t log_h, n_perms, exit_code, pv_len;
   uint32_t pv_digest[8], deferred_digest[8], vk_digest[8];
-  size_t pv_offset, body_offset;  // bytes
+  size_t pv_offset, io_offset, body_offset;  // bytes; io = n_perms * (25 u64 in || 25 u64 out)
 };
 
 bool parse_proof_header(const uint8_t* bytes, size_t len, ProofHeader* h, std::string* err);
