@@ -66,7 +66,12 @@ def alu_roofline(lib, h, perms_per_launch, launch_ms):
     if lib.zksp_hip_microbench(h, 5 + 8, C.byref(peak)) != 0:
         return None
     achieved = perms_per_launch / (launch_ms * 1e-3) / 1e9
-    return {"achieved": achieved, "peak": peak.value, "unit": "Gperm/s (Poseidon2 width 16)", "frac": achieved / peak.value}
+    # The microbenchmark is a comparator measured in this process, not a hardware ceiling: it is
+    # the same permutation in a register-resident loop, so clock and occupancy differences between
+    # the two launches can put the ratio slightly above 1.  It is deliberately not called peak/frac.
+    return {"achieved": achieved, "microbench_rate": peak.value, "unit": "Gperm/s (Poseidon2 width 16)",
+            "ratio_to_microbench": achieved / peak.value,
+            "note": "comparator, not a ceiling: standalone register-resident Poseidon2 loop, same process"}
 
 
 def usable_cores():
@@ -214,7 +219,7 @@ def main():
     leaf_ms = tot.value / max(1, cnt.value)
     achieved = alg_bytes / (leaf_ms * 1e-3) / 1e9
     spans = {}
-    for name in (b"keccak_trace", b"lde_trace", b"leaf_hash_trace", b"merkle_upper", b"quotient", b"lde_quot",
+    for name in (b"keccak_trace", b"lde_trace", b"leaf_hash_trace", b"merkle_upper", b"bus_io", b"bus_trace", b"quotient", b"lde_quot",
                  b"merkle_quot", b"open", b"merkle_open", b"reduce_openings", b"fri_commit", b"fri_fold", b"grind",
                  b"transcript", b"assemble"):
         check(lib.zksp_hip_profile_read(h, name, C.byref(tot), C.byref(cnt)))
@@ -289,8 +294,8 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_ms": leaf_ms,
             "note": "integer-ALU bound in practice (about 18 modular multiplies per byte absorbed); see DESIGN.md",
-            # the limit that actually binds: Poseidon2 permutations/s of this kernel against the chip's measured
-            # rate for a register-resident permutation loop with no memory traffic (perm_rate_kernel, 8 workgroups/CU)
+            # what actually binds is integer issue rate: Poseidon2 permutations/s of this kernel beside the rate of
+            # a register-resident permutation loop with no memory traffic (perm_rate_kernel, 8 workgroups/CU)
             "alu": alu_roofline(lib, h, B * n_rows * ((TRACE_WIDTH + 7) // 8), leaf_ms),
         },
         "device_ms_per_step_by_stage": spans,
