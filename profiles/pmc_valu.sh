@@ -1,0 +1,35 @@
+#!/bin/bash
+# VALU issue-slot utilisation of the bench kernels (run on the GPU box via gpurun from the
+# repository root).  Counter passes only: no trace options next to --pmc.
+#   util = SQ_ACTIVE_INST_VALU * 4 / (n_simd * GRBM_GUI_ACTIVE / n_xcd)
+# SQ_ACTIVE_INST_VALU counts quad-cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs (for the leaf
+# kernel it reads 8 x duration x 2.4 GHz), so it is divided by n_xcd to get the kernel's cycles.
+set -e
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/pmc_valu
+mkdir -p $O
+cd /tmp
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --skip-single"
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/a -- python3 $R/bench.py $ARGS > $O/a.json 2> $O/a.err
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d $O/b -- python3 $R/bench.py $ARGS > $O/b.json 2> $O/b.err
+python3 - <<PY
+import csv, glob, json, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for sub in ("a", "b"):
+    for f in glob.glob("$O/" + sub + "/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+n_simd, n_xcd = 256 * 4, 8
+for k, c in acc.items():
+    avg = {n: sum(v) / len(v) for n, v in c.items()}
+    if "GRBM_GUI_ACTIVE" in avg and avg["GRBM_GUI_ACTIVE"] > 0:
+        avg["valu_util"] = avg.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (n_simd * avg["GRBM_GUI_ACTIVE"] / n_xcd)
+    avg["dispatches"] = len(next(iter(c.values())))
+    out[k] = avg
+json.dump({"batch": 256, "n_simd": n_simd, "n_xcd": n_xcd, "note": "per-dispatch averages; valu_util = SQ_ACTIVE_INST_VALU*4/(n_simd*GRBM_GUI_ACTIVE/n_xcd)",
+           "kernels": out}, open("$O/valu_counters.json", "w"), indent=1)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0))[:12]:
+    print("%-44s cycles %.4g valu_insts %.4g util %.3f" % (k[:44], v.get("GRBM_GUI_ACTIVE", 0), v.get("SQ_INSTS_VALU", 0), v.get("valu_util", 0)))
+PY

@@ -8,7 +8,10 @@ from util import Gpu
 zk = importlib.import_module("zk-state-proofs_amd")
 g = Gpu(zk)
 lib, h = g.lib, g.h
-for logh, ncols in ((10, 2633 * 16), (11, 2633 * 16), (12, 2633 * 4), (14, 2048), (16, 1024), (18, 256), (20, 128), (21, 64), (22, 32)):
+SIZES = ((10, 2633 * 16), (11, 2633 * 16), (12, 2633 * 4), (14, 2048), (16, 1024), (18, 256), (20, 128), (21, 64), (22, 32))
+if os.environ.get("ZKSP_NTT_LOGH"):
+    SIZES = tuple(x for x in SIZES if x[0] == int(os.environ["ZKSP_NTT_LOGH"]))
+for logh, ncols in SIZES:
     H = 1 << logh
     rng = np.random.default_rng(logh)
     src = g.buf(rng.integers(0, 2013265921, (min(ncols, 64), H), dtype=np.uint32))

@@ -23,7 +23,7 @@ struct DevChallenger {
 // ---- NTT / LDE (row a4) ----
 // ncols contiguous columns of H = 2^logh evaluations -> coefficient columns
 // (bit-reversed order, optional) and blowup-2 coset-major LDE [ncols][2][H].
-// tables: tw_fwd/tw_inv [H/2] powers of w_H / w_H^-1; in_scale_br [ntables][H] and
+// tables: tw_fwd/tw_inv [H] per-stage twiddles, [2^(t-1) + j] = w_{2^t}^(+-j) (DeviceDomain::twc_*); in_scale_br [ntables][H] and
 // out_scale_br [2][H] are indexed by the bit-reversed coefficient position; column
 // `col` uses input table (col >> scale_sel_shift) & scale_sel_mask.
 void launch_lde(hipStream_t stream, const uint32_t* in, uint32_t* coefs_br, uint32_t* out, const uint32_t* tw_fwd,

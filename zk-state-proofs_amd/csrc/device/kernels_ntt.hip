@@ -29,20 +29,24 @@ constexpr int kLdeThreads = 256;
 __device__ __forceinline__ int lds_idx(int i) { return i + ((i >> 5) << 2); }
 
 struct PassIo {
-  const Fp* src_lds;             // padded LDS image of column 0 (nullptr: read global)
-  const uint32_t* src_glb;       // column 0 in global memory
-  const uint32_t* pre_scale;     // applied after the load (indexed by position)
-  Fp* dst_lds;                   // padded LDS image of column 0 (nullptr: none)
-  uint32_t* dst_glb;             // column 0 in global memory (nullptr: none)
-  const uint32_t* post_scale;    // applied before the store
+  const Fp* src_lds;             // padded LDS image of column 0 (used unless kSrcGlb)
+  const uint32_t* src_glb;       // column 0 in global memory (kSrcGlb)
+  const uint32_t* pre_scale;     // applied after the load, indexed by position (kPre)
+  Fp* dst_lds;                   // padded LDS image of column 0 (kDstLds)
+  uint32_t* dst_glb;             // column 0 in global memory (kDstGlb)
+  const uint32_t* post_scale;    // applied before the store (kPost)
   size_t src_glb_stride, dst_glb_stride;  // words between adjacent columns
   int lds_stride;                // words between adjacent columns' LDS images
 };
 
+// Which of PassIo's endpoints a pass uses.  Compile-time, so that the unrolled element
+// loops carry no branches and LDS accesses are ds_* instructions rather than flat ones.
+constexpr int kSrcGlb = 1, kPre = 2, kDstLds = 4, kDstGlb = 8, kPost = 16;
+
 // One pass of R radix-2 stages, in registers, on NC columns at once.
 //   DIF: stages s, s-1, .., s-R+1 (block sizes 2^s ..); group stride q = 2^(s-R)
 //   DIT: stages s, s+1, .., s+R-1;                      group stride q = 2^(s-1)
-template <int R, bool DIF, int NC>
+template <int R, bool DIF, int NC, int F, bool FULL>
 __device__ __forceinline__ void ntt_pass(const PassIo& io, const uint32_t* __restrict__ tw, int logh, int tw_logh,
                                          int s, int ncols, int tid) {
   constexpr int E = 1 << R;
@@ -58,13 +62,13 @@ __device__ __forceinline__ void ntt_pass(const PassIo& io, const uint32_t* __res
       const int pos = base + (k << qlog);
       const int li = lds_idx(pos);
       Fp sc = Fp::one();
-      if (io.pre_scale) sc = Fp::raw(io.pre_scale[pos]);
+      if (F & kPre) sc = Fp::raw(io.pre_scale[pos]);
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        if (c < ncols) {
-          x[c][k] = io.src_glb ? Fp::raw(io.src_glb[(size_t)c * io.src_glb_stride + pos])
-                               : io.src_lds[c * io.lds_stride + li];
-          if (io.pre_scale) x[c][k] = x[c][k] * sc;
+        if (FULL || c < ncols) {
+          if (F & kSrcGlb) x[c][k] = Fp::raw(io.src_glb[(size_t)c * io.src_glb_stride + pos]);
+          else x[c][k] = io.src_lds[c * io.lds_stride + li];
+          if (F & kPre) x[c][k] = x[c][k] * sc;
         } else {
           x[c][k] = Fp::zero();
         }
@@ -75,12 +79,11 @@ __device__ __forceinline__ void ntt_pass(const PassIo& io, const uint32_t* __res
       // DIF walks from the widest pairing (k, k + E/2) down, DIT from (k, k+1) up
       const int hk = DIF ? (E >> (st + 1)) : (1 << st);
       const int stage = DIF ? s - st : s + st;
-      const int tw_shift = tw_logh - stage;  // tw holds powers of the 2^tw_logh-th root
 #pragma unroll
       for (int k = 0; k < E; ++k) {
         if ((k & hk) != 0) continue;  // k is the lower element of its pair
         const int j = ((k & (hk - 1)) << qlog) + g_lo;
-        const Fp w = Fp::raw(tw[j << tw_shift]);
+        const Fp w = Fp::raw(tw[(1 << (stage - 1)) + j]);  // per-stage table: consecutive across lanes
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           if (DIF) {
@@ -100,25 +103,47 @@ __device__ __forceinline__ void ntt_pass(const PassIo& io, const uint32_t* __res
       const int pos = base + (k << qlog);
       const int li = lds_idx(pos);
       Fp sc = Fp::one();
-      if (io.post_scale) sc = Fp::raw(io.post_scale[pos]);
+      if (F & kPost) sc = Fp::raw(io.post_scale[pos]);
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        if (c >= ncols) continue;
+        if (!FULL && c >= ncols) continue;
         Fp v = x[c][k];
-        if (io.post_scale) v = v * sc;
-        if (io.dst_lds) io.dst_lds[c * io.lds_stride + li] = v;
-        if (io.dst_glb) io.dst_glb[(size_t)c * io.dst_glb_stride + pos] = v.v;
+        if (F & kPost) v = v * sc;
+        if (F & kDstLds) io.dst_lds[c * io.lds_stride + li] = v;
+        if (F & kDstGlb) io.dst_glb[(size_t)c * io.dst_glb_stride + pos] = v.v;
       }
     }
   }
 }
 
-template <bool DIF, int NC>
-__device__ __forceinline__ void ntt_pass_r(int r, const PassIo& io, const uint32_t* tw, int logh, int tw_logh, int s,
+template <bool DIF, int NC, int F>
+__device__ __forceinline__ void ntt_pass_f(int r, const PassIo& io, const uint32_t* tw, int logh, int tw_logh, int s,
                                            int ncols, int tid) {
-  if (r == 3) ntt_pass<3, DIF, NC>(io, tw, logh, tw_logh, s, ncols, tid);
-  else if (r == 2) ntt_pass<2, DIF, NC>(io, tw, logh, tw_logh, s, ncols, tid);
-  else ntt_pass<1, DIF, NC>(io, tw, logh, tw_logh, s, ncols, tid);
+  if (ncols == NC) {
+    if (r == 3) ntt_pass<3, DIF, NC, F, true>(io, tw, logh, tw_logh, s, ncols, tid);
+    else if (r == 2) ntt_pass<2, DIF, NC, F, true>(io, tw, logh, tw_logh, s, ncols, tid);
+    else ntt_pass<1, DIF, NC, F, true>(io, tw, logh, tw_logh, s, ncols, tid);
+  } else {
+    if (r == 3) ntt_pass<3, DIF, NC, F, false>(io, tw, logh, tw_logh, s, ncols, tid);
+    else if (r == 2) ntt_pass<2, DIF, NC, F, false>(io, tw, logh, tw_logh, s, ncols, tid);
+    else ntt_pass<1, DIF, NC, F, false>(io, tw, logh, tw_logh, s, ncols, tid);
+  }
+}
+
+// Runtime flags -> the compile-time variant, over the list of combinations a caller can
+// produce (the flags are uniform, so this is a scalar branch chain).  A combination outside
+// the list is a programming error and traps.
+template <bool DIF, int NC, int F0, int... Fs>
+__device__ __forceinline__ void ntt_pass_sel(int flags, int r, const PassIo& io, const uint32_t* tw, int logh,
+                                             int tw_logh, int s, int ncols, int tid) {
+  if (flags == F0) ntt_pass_f<DIF, NC, F0>(r, io, tw, logh, tw_logh, s, ncols, tid);
+  else if constexpr (sizeof...(Fs) > 0) ntt_pass_sel<DIF, NC, Fs...>(flags, r, io, tw, logh, tw_logh, s, ncols, tid);
+  else __builtin_trap();
+}
+
+__device__ __forceinline__ int pass_flags(const PassIo& io) {
+  return (io.src_glb ? kSrcGlb : 0) | (io.pre_scale ? kPre : 0) | (io.dst_lds ? kDstLds : 0) |
+         (io.dst_glb ? kDstGlb : 0) | (io.post_scale ? kPost : 0);
 }
 
 template <int NC>
@@ -158,12 +183,14 @@ __global__ __launch_bounds__(kLdeThreads) void lde_lds_kernel(const uint32_t* __
         io.src_glb = first ? src : nullptr;
         io.pre_scale = nullptr;
         io.dst_lds = coef;
-        io.dst_glb = last ? cdst : nullptr;
+        io.dst_glb = last ? cdst : nullptr;  // cdst may be null: the caller does not want coefficients
         io.post_scale = last ? isc : nullptr;
         io.src_glb_stride = (size_t)h;
         io.dst_glb_stride = (size_t)h;
         io.lds_stride = padded;
-        ntt_pass_r<true, NC>(r, io, tw_inv, logh, logh, s, nc, tid);
+        ntt_pass_sel<true, NC, kDstLds, kSrcGlb | kDstLds, kDstLds | kDstGlb | kPost, kDstLds | kPost,
+                     kSrcGlb | kDstLds | kDstGlb | kPost, kSrcGlb | kDstLds | kPost>(pass_flags(io), r, io, tw_inv, logh,
+                                                                                    logh, s, nc, tid);
         __syncthreads();
         s -= r;
         first = false;
@@ -189,7 +216,8 @@ __global__ __launch_bounds__(kLdeThreads) void lde_lds_kernel(const uint32_t* __
         io.src_glb_stride = 0;
         io.dst_glb_stride = (size_t)2 * h;  // adjacent columns are 2 cosets apart in the LDE
         io.lds_stride = padded;
-        ntt_pass_r<false, NC>(r, io, tw_fwd, logh, logh, s, nc, tid);
+        ntt_pass_sel<false, NC, kDstLds, kPre | kDstLds, kDstGlb, kPre | kDstGlb>(pass_flags(io), r, io, tw_fwd, logh, logh,
+                                                                                  s, nc, tid);
         __syncthreads();
         s += r;
         first = false;
@@ -250,7 +278,9 @@ __global__ __launch_bounds__(kLdeThreads) void ntt_chunk_kernel(const uint32_t* 
     io.post_scale = last ? post : nullptr;
     io.src_glb_stride = io.dst_glb_stride = 0;
     io.lds_stride = 0;
-    ntt_pass_r<DIF, 1>(r, io, tw, l2, logh, s, 1, tid);
+    ntt_pass_sel<DIF, 1, kDstLds, kSrcGlb | kDstLds, kSrcGlb | kPre | kDstLds, kDstGlb, kDstGlb | kPost, kSrcGlb | kDstGlb,
+                 kSrcGlb | kDstGlb | kPost, kSrcGlb | kPre | kDstGlb, kSrcGlb | kPre | kDstGlb | kPost>(
+        pass_flags(io), r, io, tw, l2, logh, s, 1, tid);
     __syncthreads();
     s = DIF ? s - r : s + r;
     first = false;
@@ -280,14 +310,14 @@ __global__ __launch_bounds__(kLdeThreads) void ntt_strided_kernel(uint32_t* __re
   for (int st = 0; st < l1; ++st) {
     const int s1 = DIF ? l1 - st : st + 1;  // stage inside the H1 transform; full-size stage = l2 + s1
     const int half1 = 1 << (s1 - 1);
-    const int tw_shift = logh - (l2 + s1);
+    const size_t tw_base = (size_t)1 << (l2 + s1 - 1);  // per-stage table of the full-size stage l2 + s1
     for (int i = tid; i < nbf; i += kLdeThreads) {
       const int t = i % kStrideTile, b = i / kStrideTile;
       const int j1 = b & (half1 - 1);
       const int lo = ((b >> (s1 - 1)) << s1) | j1, hi = lo + half1;
       // position inside the half block of the full-size stage: j1*H2 + n2
       const size_t j = ((size_t)j1 << l2) + n2_base + t;
-      const Fp w = Fp::raw(tw[j << tw_shift]);
+      const Fp w = Fp::raw(tw[tw_base + j]);
       Fp u = buf[lo * kRow + t], v = buf[hi * kRow + t];
       if (DIF) {
         buf[lo * kRow + t] = u + v;

@@ -386,7 +386,7 @@ int zksp_hip_lde(zksp_client* c, const uint32_t* d_in, int log_h, size_t ncols, 
     ZKSP_HIP_CHECK(ctx, hipMalloc(&tmp_coefs, ncols * h * 4));
     d_coefs_br = tmp_coefs;
   }
-  launch_lde(ctx->stream, d_in, d_coefs_br, d_lde, dom->tw_fwd, dom->tw_inv, table, 0, 0, dom->out_scale_br, log_h, ncols);
+  launch_lde(ctx->stream, d_in, d_coefs_br, d_lde, dom->twc_fwd, dom->twc_inv, table, 0, 0, dom->out_scale_br, log_h, ncols);
   ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (tmp) ZKSP_HIP_CHECK(ctx, hipFree(tmp));
   if (tmp_coefs) ZKSP_HIP_CHECK(ctx, hipFree(tmp_coefs));

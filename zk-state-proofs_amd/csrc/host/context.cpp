@@ -11,7 +11,7 @@ Context::~Context() {
     (void)hipSetDevice(device);
     for (auto& kv : domains) {
       DeviceDomain& d = kv.second;
-      uint32_t* ptrs[] = {d.tw_fwd, d.tw_inv, d.in_scale_br, d.out_scale_br,
+      uint32_t* ptrs[] = {d.tw_fwd, d.tw_inv, d.twc_fwd, d.twc_inv, d.in_scale_br, d.out_scale_br,
                           d.xs, d.sel_first, d.sel_trans, d.sel_last, d.zh_inv};
       for (uint32_t* p : ptrs)
         if (p) (void)hipFree(p);
@@ -60,6 +60,8 @@ const DeviceDomain* Context::domain(int logh) {
   bool ok = true;
   dd.tw_fwd = upload(this, hd.tw_fwd.data(), hd.tw_fwd.size(), &ok);
   dd.tw_inv = upload(this, hd.tw_inv.data(), hd.tw_inv.size(), &ok);
+  dd.twc_fwd = upload(this, hd.twc_fwd.data(), hd.twc_fwd.size(), &ok);
+  dd.twc_inv = upload(this, hd.twc_inv.data(), hd.twc_inv.size(), &ok);
   {
     std::vector<uint32_t> all;
     for (int t = 0; t < 3; ++t) all.insert(all.end(), hd.in_scale_br[t].begin(), hd.in_scale_br[t].end());

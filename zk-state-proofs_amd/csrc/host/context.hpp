@@ -20,7 +20,8 @@ const P2Consts& host_p2_consts();
 
 struct HostDomain {
   int logh = 0;
-  std::vector<uint32_t> tw_fwd, tw_inv;          // [H/2]
+  std::vector<uint32_t> tw_fwd, tw_inv;          // [H/2] powers of w_H, w_H^-1
+  std::vector<uint32_t> twc_fwd, twc_inv;        // [H] per-stage: [2^(t-1) + j] = w_{2^t}^(+-j), j < 2^(t-1)
   std::vector<uint32_t> in_scale_br[3];          // [H]: trace (shift 1), quotient chunk 0, chunk 1
   std::vector<uint32_t> out_scale_br;            // [2][H]
   std::vector<uint32_t> xs, sel_first, sel_trans, sel_last;  // [2][H]
@@ -31,7 +32,7 @@ void build_host_domain(int logh, HostDomain* d, bool full = true);
 
 struct DeviceDomain {
   int logh = 0;
-  uint32_t *tw_fwd = nullptr, *tw_inv = nullptr, *in_scale_br = nullptr /*[3][H]: shift 1, g, g*w_2H*/,
+  uint32_t *tw_fwd = nullptr, *tw_inv = nullptr, *twc_fwd = nullptr, *twc_inv = nullptr, *in_scale_br = nullptr /*[3][H]: shift 1, g, g*w_2H*/,
            *out_scale_br = nullptr, *xs = nullptr, *sel_first = nullptr, *sel_trans = nullptr, *sel_last = nullptr,
            *zh_inv = nullptr;
   uint32_t w_h = 0;

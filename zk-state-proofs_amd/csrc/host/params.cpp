@@ -80,6 +80,14 @@ void build_host_domain(int logh, HostDomain* d, bool full) {
     a = a * wh;
     b = b * wh_inv;
   }
+  // per-stage copies: the butterflies of stage t read consecutive words instead of a stride of 2^(logh-t)
+  d->twc_fwd.assign(h > 1 ? h : 2, Fp::one().v);
+  d->twc_inv.assign(h > 1 ? h : 2, Fp::one().v);
+  for (int t = 1; t <= logh; ++t)
+    for (size_t j = 0; j < ((size_t)1 << (t - 1)); ++j) {
+      d->twc_fwd[((size_t)1 << (t - 1)) + j] = d->tw_fwd[j << (logh - t)];
+      d->twc_inv[((size_t)1 << (t - 1)) + j] = d->tw_inv[j << (logh - t)];
+    }
   const Fp shifts[2] = {g, g * w2h};
   const Fp hinv = Fp::from_canonical((uint32_t)(h % kP)).inv();
   const Fp in_shifts[3] = {Fp::one(), shifts[0], shifts[1]};

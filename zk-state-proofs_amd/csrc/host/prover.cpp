@@ -133,7 +133,7 @@ int prove_resident(Context* ctx) {
   }
   {
     ProfileSpan sp(ctx, "lde_trace");
-    launch_lde(s, ws->trace, ws->coef_t, ws->lde_t, dom->tw_fwd, dom->tw_inv, dom->in_scale_br, 0, 0, dom->out_scale_br,
+    launch_lde(s, ws->trace, ws->coef_t, ws->lde_t, dom->twc_fwd, dom->twc_inv, dom->in_scale_br, 0, 0, dom->out_scale_br,
                logh, (size_t)B * W);
   }
   {
@@ -162,7 +162,7 @@ int prove_resident(Context* ctx) {
   {
     ProfileSpan sp(ctx, "bus_trace");
     launch_bus_perm_trace(s, ws->trace, ws->bus_ch, ws->beta_pows, ws->bus_terms, ws->phi, ws->cum_sum, logh, B);
-    launch_lde(s, ws->phi, ws->coef_p, ws->lde_p, dom->tw_fwd, dom->tw_inv, dom->in_scale_br, 0, 0, dom->out_scale_br,
+    launch_lde(s, ws->phi, ws->coef_p, ws->lde_p, dom->twc_fwd, dom->twc_inv, dom->in_scale_br, 0, 0, dom->out_scale_br,
                logh, (size_t)B * kPermWidth);
     launch_merkle_commit(s, ws->lde_p, (size_t)kPermWidth * n, kPermWidth, logn, ws->tree_p, tree_stride, B, kc);
   }
@@ -195,7 +195,7 @@ int prove_resident(Context* ctx) {
   {
     ProfileSpan sp(ctx, "lde_quot");
     // columns 4c..4c+3 of every proof were evaluated over coset c: scale tables 1 and 2
-    launch_lde(s, ws->quot, ws->coef_q, ws->lde_q, dom->tw_fwd, dom->tw_inv, dom->in_scale_br + h, 2, 1,
+    launch_lde(s, ws->quot, ws->coef_q, ws->lde_q, dom->twc_fwd, dom->twc_inv, dom->in_scale_br + h, 2, 1,
                dom->out_scale_br, logh, (size_t)B * 8);
   }
   {
