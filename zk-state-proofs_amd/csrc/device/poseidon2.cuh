@@ -12,6 +12,13 @@ struct P2Consts {
   uint32_t ext[8][16];  // external round constants (4 initial, 4 terminal)
   uint32_t internal[13];
   uint32_t diag[16];    // internal diagonal [-2, 1, 2, 4, ..., 8192, 32768]
+  // Derived tables of the signed lazy permutation below (built by build_p2_consts).
+  // Every round constant is added inside the reduction that closes the linear layer
+  // before it, as rc * R^2 mod p (the reduction divides by R = 2^32):
+  int32_t sdiag[16];       // diag centred into (-p/2, p/2]
+  int64_t lin_add[9][16];  // layer 0 = initial linear layer, layer r+1 closes external round r
+  int64_t int_add[13];     // element 0 after internal round r (r = 0..11)
+  int64_t int_last[16];    // all elements after internal round 12
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -94,61 +101,134 @@ ZKSP_HD void p2_sbox_layer(Fp* s, const uint32_t* __restrict__ rc) {
   ZKSP_SCHED_FENCE();
 }
 
-// circ(2*M4, M4, M4, M4) with M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]]
-ZKSP_HD void p2_external_linear(Fp* s) {
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    // 11 additions per 4x4 block (the evaluation order Plonky3's apply_mat4 uses)
-    Fp x0 = s[4 * c], x1 = s[4 * c + 1], x2 = s[4 * c + 2], x3 = s[4 * c + 3];
-    Fp t01 = x0 + x1, t23 = x2 + x3;
-    Fp t0123 = t01 + t23;
-    Fp t01123 = t0123 + x1, t01233 = t0123 + x3;
-    s[4 * c + 3] = t01233 + x0.dbl();  // 3 x0 + x1 + x2 + 2 x3
-    s[4 * c + 1] = t01123 + x2.dbl();  // x0 + 2 x1 + 3 x2 + x3
-    s[4 * c] = t01123 + t01;           // 2 x0 + 3 x1 + x2 + x3
-    s[4 * c + 2] = t01233 + t23;       // x0 + x1 + 2 x2 + 3 x3
-  }
-  Fp sums[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) sums[j] = (s[j] + s[4 + j]) + (s[8 + j] + s[12 + j]);
-#pragma unroll
-  for (int i = 0; i < 16; ++i) s[i] = s[i] + sums[i & 3];
+// ---------------------------------------------------------------------------
+// Signed lazy permutation.
+//
+// The permutation is bound by vector-ALU issue, and with canonical residues half of
+// its instructions are modular additions (add, subtract p, min) because p = 0.94 * 2^31
+// leaves no headroom in a 32-bit lane.  Here a state element is instead ANY int32 t
+// congruent to the value (Montgomery form), |t| < 2^31 = 1.0667p, and:
+//
+//  * products use a centred Montgomery reduction: m = lo(T) * (-p^-1) taken as a SIGNED
+//    word, t = (T + m p) / 2^32, so |t| <= |T| / 2^32 + p/2.  For |a|, |b| < 1.0667p this
+//    gives |t| < 1.034p with |T + m p| < 2^63: closed under multiplication with no
+//    conditional subtraction at all (3 instructions: mad_i64_i32, mul_lo, mad_i64_i32);
+//  * the linear layers accumulate in 64 bits (|y| < 36.2p, one instruction per term) and
+//    each output is brought back by ONE reduction: with y = hi * 2^32 + lo, c = 2^32 mod p
+//    and K = c^2 mod p,  T = lo * c + hi * K + rc * R^2  ==  (y + rc~) * R  (mod p), |T| < 2^60.1,
+//    so t = redc(T) = y + rc~ with -0.5p < t < 0.634p.  The next round constant rides along
+//    as the addend;
+//  * an internal round is sum = sum of the 16 words (64-bit), SR = sum * R as above, and
+//    out_i = redc(x_i * d_i~ + SR) with d_i~ centred: |T| < 0.517 p^2 + 2^60.1, |t| < 0.876p.
+//
+// Outputs are canonicalised only where a canonical word is needed (digests); a sponge
+// keeps its state signed between permutations.  Results are bit-identical to the
+// canonical implementation after canonicalisation (tests/test_gpu_kernels.py and the
+// host verifier, which runs this same code).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kRModP = (uint32_t)((((uint64_t)1) << 32) % kP);  // c = 268435454
+constexpr int32_t p2s_centre(uint32_t v) { return v > kP / 2 ? (int32_t)(v - kP) : (int32_t)v; }
+constexpr int32_t kR2Centred = p2s_centre((uint32_t)(((uint64_t)kRModP * kRModP) % kP));  // K
+
+// |t| < 0.5667 * 2^32 * p  ->  t / 2^32 mod p, |result| <= |t| / 2^32 + p/2
+ZKSP_HD int32_t p2s_redc(int64_t t) {
+  const int32_t m = (int32_t)((uint32_t)t * kMontyNegMu);
+  return (int32_t)((t + (int64_t)m * (int64_t)kP) >> 32);
 }
 
-// y_i = d_i * x_i + sum(x), d = [-2, 1, 2, 4, ..., 8192, 32768]
-ZKSP_HD void p2_internal_linear(Fp* s, const P2Consts* __restrict__ k) {
-  Fp sum = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-  sum = sum + (((s[8] + s[9]) + (s[10] + s[11])) + ((s[12] + s[13]) + (s[14] + s[15])));
-  Fp d[13], prod[13];
+ZKSP_HD int32_t p2s_mul(int32_t a, int32_t b) { return p2s_redc((int64_t)a * (int64_t)b); }
+
+ZKSP_HD int32_t p2s_sbox(int32_t x) {
+  const int32_t x2 = p2s_mul(x, x), x3 = p2s_mul(x2, x), x4 = p2s_mul(x2, x2);
+  return p2s_mul(x3, x4);
+}
+
+// 64-bit sum y of Montgomery-form words (|y| < 2^31 * 2^32) -> y + rc~, add = rc * R^2 mod p
+ZKSP_HD int32_t p2s_reduce_wide(int64_t y, int64_t add) {
+  const uint32_t lo = (uint32_t)y;
+  const int32_t hi = (int32_t)(y >> 32);
+  int64_t t = (int64_t)hi * (int64_t)kR2Centred + add;
+  t += (int64_t)((uint64_t)lo * kRModP);
+  return p2s_redc(t);
+}
+
+// signed word, |t| < p  ->  canonical residue
+ZKSP_HD uint32_t p2s_canon(int32_t t) {
+  const uint32_t u = (uint32_t)t, w = u + kP;
+  return u < w ? u : w;
+}
+
+// circ(2*M4, M4, M4, M4), M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]], then + next constants
+ZKSP_HD void p2s_external_linear(int32_t* s, const int64_t* __restrict__ add) {
+  int64_t y[16];
 #pragma unroll
-  for (int i = 0; i < 13; ++i) d[i] = Fp::raw(k->diag[3 + i]);
-  fp_mul_batch<13>(prod, s + 3, d);
-  s[0] = sum - s[0].dbl();   // d_0 = -2
-  s[1] = sum + s[1];         // d_1 = 1
-  s[2] = sum + s[2].dbl();   // d_2 = 2
+  for (int c = 0; c < 4; ++c) {
+    const int64_t x0 = s[4 * c], x1 = s[4 * c + 1], x2 = s[4 * c + 2], x3 = s[4 * c + 3];
+    const int64_t sum = (x0 + x1) + (x2 + x3);
+    y[4 * c] = sum + x0 + 2 * x1;      // 2 x0 + 3 x1 + x2 + x3
+    y[4 * c + 1] = sum + x1 + 2 * x2;  // x0 + 2 x1 + 3 x2 + x3
+    y[4 * c + 2] = sum + x2 + 2 * x3;  // x0 + x1 + 2 x2 + 3 x3
+    y[4 * c + 3] = sum + x3 + 2 * x0;  // 3 x0 + x1 + x2 + 2 x3
+  }
 #pragma unroll
-  for (int i = 0; i < 13; ++i) s[3 + i] = prod[i] + sum;
+  for (int j = 0; j < 4; ++j) {
+    const int64_t col = (y[j] + y[4 + j]) + (y[8 + j] + y[12 + j]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[4 * c + j] = p2s_reduce_wide(y[4 * c + j] + col, add[4 * c + j]);
+  }
+}
+
+// x0 -> x0^7 (its constant was added by the previous reduction), then y_i = d_i x_i + sum(x).
+// FULL: every output gets an addend (the layer before the terminal external rounds);
+// otherwise only element 0 does.
+template <bool FULL>
+ZKSP_HD void p2s_internal_round(int32_t* s, const P2Consts* __restrict__ k, const int64_t* __restrict__ add) {
+  s[0] = p2s_sbox(s[0]);
+  int64_t sum_a = (int64_t)s[0] + s[1], sum_b = (int64_t)s[2] + s[3];
+#pragma unroll
+  for (int i = 4; i < 16; i += 2) {
+    sum_a += s[i];
+    sum_b += s[i + 1];
+  }
+  const int64_t sum = sum_a + sum_b;
+  const uint32_t lo = (uint32_t)sum;
+  const int32_t hi = (int32_t)(sum >> 32);
+  const int64_t sr = (int64_t)hi * (int64_t)kR2Centred + (int64_t)((uint64_t)lo * kRModP);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int64_t t = (int64_t)s[i] * (int64_t)k->sdiag[i] + sr;
+    if (FULL || i == 0) t += add[FULL ? i : 0];
+    s[i] = p2s_redc(t);
+  }
+}
+
+// state: signed words, |s_i| < 1.034p (canonical residues qualify); same on exit
+ZKSP_HD void p2_permute_signed(int32_t* s, const P2Consts* __restrict__ k) {
+  p2s_external_linear(s, k->lin_add[0]);
+#pragma unroll 1
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = p2s_sbox(s[i]);
+    p2s_external_linear(s, k->lin_add[r + 1]);
+  }
+#pragma unroll 1
+  for (int r = 0; r < 12; ++r) p2s_internal_round<false>(s, k, &k->int_add[r]);
+  p2s_internal_round<true>(s, k, k->int_last);
+#pragma unroll 1
+  for (int r = 4; r < 8; ++r) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = p2s_sbox(s[i]);
+    p2s_external_linear(s, k->lin_add[r + 1]);
+  }
 }
 
 ZKSP_HD void p2_permute(Fp* s, const P2Consts* __restrict__ k) {
-  p2_external_linear(s);
-#pragma unroll 1
-  for (int r = 0; r < 4; ++r) {
-    p2_sbox_layer<8>(s, k->ext[r]);
-    p2_sbox_layer<8>(s + 8, k->ext[r] + 8);
-    p2_external_linear(s);
-  }
-#pragma unroll 1
-  for (int r = 0; r < 13; ++r) {
-    s[0] = p2_sbox(s[0] + Fp::raw(k->internal[r]));
-    p2_internal_linear(s, k);
-  }
-#pragma unroll 1
-  for (int r = 4; r < 8; ++r) {
-    p2_sbox_layer<8>(s, k->ext[r]);
-    p2_sbox_layer<8>(s + 8, k->ext[r] + 8);
-    p2_external_linear(s);
-  }
+  int32_t t[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t[i] = (int32_t)s[i].v;
+  p2_permute_signed(t, k);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s[i] = Fp::raw(p2s_canon(t[i]));
 }
 
 }  // namespace zksp

@@ -47,6 +47,19 @@ void build_p2_consts(P2Consts* out) {
   out->diag[0] = Fp::from_canonical(kP - 2).v;
   for (int i = 1; i < 15; ++i) out->diag[i] = Fp::from_canonical(1u << (i - 1)).v;
   out->diag[15] = Fp::from_canonical(1u << 15).v;
+  // derived tables of the signed lazy permutation (poseidon2.cuh): constants times R^2,
+  // attached to the linear layer that precedes their round
+  auto times_r = [](uint32_t monty) { return (int64_t)(((uint64_t)monty * kRModP) % kP); };
+  for (int i = 0; i < 16; ++i) out->sdiag[i] = p2s_centre(out->diag[i]);
+  for (int l = 0; l < 9; ++l)
+    for (int i = 0; i < 16; ++i) {
+      int64_t v = 0;
+      if (l == 4) v = i == 0 ? times_r(out->internal[0]) : 0;  // external round 3 -> internal round 0
+      else if (l < 8) v = times_r(out->ext[l][i]);              // layer l precedes external round l
+      out->lin_add[l][i] = v;                                   // layer 8 closes the permutation
+    }
+  for (int r = 0; r < 13; ++r) out->int_add[r] = r < 12 ? times_r(out->internal[r + 1]) : 0;
+  for (int i = 0; i < 16; ++i) out->int_last[i] = times_r(out->ext[4][i]);
 }
 
 const P2Consts& host_p2_consts() {
