@@ -62,19 +62,21 @@ def measured_hbm_traffic(batch):
 
 
 def measured_valu_issue(batch, perms_per_launch):
-    """VALU issue-slot utilisation of leaf_hash_trace_kernel from the committed rocprofv3 PMC
-    collection (profiles/pmc_valu.sh -> profiles/r01_valu_counters.json): the share of the
-    kernel's cycles in which each SIMD issues a vector-ALU instruction.  This, not HBM, is the
-    resource the kernel saturates.  Not measured live: None when no collection for this batch
-    size is committed."""
+    """Vector-ALU instruction counts of leaf_hash_trace_kernel from the committed rocprofv3 PMC
+    collection (profiles/pmc_valu.sh -> profiles/r01_valu_counters.json): instructions per
+    permutation per lane and SIMD cycles per instruction.  The kernel is bound by instruction
+    issue, whose cost depends on the opcode, so this is evidence to read
+    against that cost model, not a utilisation fraction.  Not measured live: None when no
+    collection for this batch size is committed."""
     path = os.path.join(ROOT, "profiles", "r01_valu_counters.json")
     try:
         d = json.load(open(path))
         if int(d.get("batch", 0)) != batch:
             return None
         k = d["kernels"]["zksp::leaf_hash_trace_kernel"]
-        return {"util": k["valu_util"], "valu_insts_per_permutation_per_lane": k["SQ_INSTS_VALU"] * 64.0 / perms_per_launch,
-                "source": "profiles/r01_valu_counters.json (SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE; committed collection, not live)"}
+        return {"valu_insts_per_permutation_per_lane": k["SQ_INSTS_VALU"] * 64.0 / perms_per_launch,
+                "simd_cycles_per_valu_inst": k["cycles_per_valu_inst"],
+                "source": "profiles/r01_valu_counters.json (SQ_INSTS_VALU, GRBM_GUI_ACTIVE; committed collection, not live)"}
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None
 
@@ -311,7 +313,7 @@ def main():
             "traffic": measured_hbm_traffic(B),
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_ms": leaf_ms,
-            "note": "bound by vector-ALU instruction issue, not HBM (about 18 modular multiplies per byte absorbed); see DESIGN.md",
+            "note": "bound by vector-ALU instruction issue, not HBM (about 23 modular multiplies per byte absorbed); see DESIGN.md",
             "valu_issue": measured_valu_issue(B, B * n_rows * ((TRACE_WIDTH + 7) // 8)),
             # what actually binds is integer issue rate: Poseidon2 permutations/s of this kernel beside the rate of
             # a register-resident permutation loop with no memory traffic (perm_rate_kernel, 8 workgroups/CU)

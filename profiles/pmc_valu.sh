@@ -1,9 +1,11 @@
 #!/bin/bash
-# VALU issue-slot utilisation of the bench kernels (run on the GPU box via gpurun from the
+# Vector-ALU instruction counts of the bench kernels (run on the GPU box via gpurun from the
 # repository root).  Counter passes only: no trace options next to --pmc.
-#   util = SQ_ACTIVE_INST_VALU * 4 / (n_simd * GRBM_GUI_ACTIVE / n_xcd)
-# SQ_ACTIVE_INST_VALU counts quad-cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs (for the leaf
-# kernel it reads 8 x duration x 2.4 GHz), so it is divided by n_xcd to get the kernel's cycles.
+#   cycles_per_valu_inst = n_simd * (GRBM_GUI_ACTIVE / n_xcd) / SQ_INSTS_VALU
+# GRBM_GUI_ACTIVE is summed over the 8 XCDs (for the leaf kernel it reads 8 x duration x 2.4 GHz).
+# SQ_ACTIVE_INST_VALU is collected too but equals SQ_INSTS_VALU on these kernels, so it is NOT an
+# independent busy measure; what the pass gives is instructions and cycles per instruction, to be
+# read against per-opcode issue costs (SIMD-32: 2 cycles at best, multiplies 4-5).
 set -e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -25,11 +27,12 @@ n_simd, n_xcd = 256 * 4, 8
 for k, c in acc.items():
     avg = {n: sum(v) / len(v) for n, v in c.items()}
     if "GRBM_GUI_ACTIVE" in avg and avg["GRBM_GUI_ACTIVE"] > 0:
-        avg["valu_util"] = avg.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (n_simd * avg["GRBM_GUI_ACTIVE"] / n_xcd)
+        if avg.get("SQ_INSTS_VALU", 0) > 0:
+            avg["cycles_per_valu_inst"] = n_simd * avg["GRBM_GUI_ACTIVE"] / n_xcd / avg["SQ_INSTS_VALU"]
     avg["dispatches"] = len(next(iter(c.values())))
     out[k] = avg
-json.dump({"batch": 256, "n_simd": n_simd, "n_xcd": n_xcd, "note": "per-dispatch averages; valu_util = SQ_ACTIVE_INST_VALU*4/(n_simd*GRBM_GUI_ACTIVE/n_xcd)",
+json.dump({"batch": 256, "n_simd": n_simd, "n_xcd": n_xcd, "note": "per-dispatch averages; cycles_per_valu_inst = n_simd*(GRBM_GUI_ACTIVE/n_xcd)/SQ_INSTS_VALU",
            "kernels": out}, open("$O/valu_counters.json", "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0))[:12]:
-    print("%-44s cycles %.4g valu_insts %.4g util %.3f" % (k[:44], v.get("GRBM_GUI_ACTIVE", 0), v.get("SQ_INSTS_VALU", 0), v.get("valu_util", 0)))
+    print("%-44s cycles %.4g valu_insts %.4g cycles/inst %.2f" % (k[:44], v.get("GRBM_GUI_ACTIVE", 0), v.get("SQ_INSTS_VALU", 0), v.get("cycles_per_valu_inst", 0)))
 PY
