@@ -131,4 +131,46 @@ struct Fp4 {
   }
 };
 
+// ---------------------------------------------------------------------------
+// Signed lazy arithmetic.  A "signed word" is ANY int32 congruent to a Montgomery-form
+// value; canonical residues qualify.  The kernels are bound by vector-ALU issue and with
+// p = 0.94 * 2^31 a canonical modular addition costs three instructions, so hot loops keep
+// sums in 64-bit accumulators and reduce rarely:
+//   fps_redc(T)        |T| < 0.5667 * 2^32 p : T / 2^32 mod p, |result| <= |T| / 2^32 + p/2
+//                      (centred Montgomery reduction: m = lo(T) * (-p^-1) taken as signed)
+//   fps_fold(T)        any |T| < 2^63        : T / 2^32 mod p, |result| < 0.57p
+//                      (2^32 == c mod p, so T == hi * c + lo first)
+//   fps_reduce_wide(y) |y| < 2^63            : y mod p (same form as y), in (-0.5p, 0.634p)
+//                      (y * R == lo * c + hi * K, K = c^2 mod p centred, then fps_redc)
+//   fps_canon(t)       |t| < p               : the canonical residue
+// A product of two signed words with |a|, |b| < 2^31 satisfies the fps_redc bound and
+// comes back below 1.034p: closed under multiplication with no conditional subtraction.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kRModP = kR1;  // c = 2^32 mod p = 268435454
+constexpr int32_t fps_centre_const(uint32_t v) { return v > kP / 2 ? (int32_t)(v - kP) : (int32_t)v; }
+constexpr int32_t kR2Centred = fps_centre_const(kR2);  // K
+
+ZKSP_HD int32_t fps_redc(int64_t t) {
+  const int32_t m = (int32_t)((uint32_t)t * kMontyNegMu);
+  return (int32_t)((t + (int64_t)m * (int64_t)kP) >> 32);
+}
+ZKSP_HD int32_t fps_mul(int32_t a, int32_t b) { return fps_redc((int64_t)a * (int64_t)b); }
+ZKSP_HD int32_t fps_fold(int64_t t) {
+  const int32_t hi = (int32_t)(t >> 32);
+  return fps_redc((int64_t)hi * (int64_t)kRModP + (int64_t)(uint32_t)t);
+}
+ZKSP_HD int32_t fps_reduce_wide(int64_t y, int64_t add = 0) {
+  const uint32_t lo = (uint32_t)y;
+  const int32_t hi = (int32_t)(y >> 32);
+  int64_t t = (int64_t)hi * (int64_t)kR2Centred + add;
+  t += (int64_t)((uint64_t)lo * kRModP);
+  return fps_redc(t);
+}
+ZKSP_HD uint32_t fps_canon(int32_t t) {
+  const uint32_t u = (uint32_t)t, w = u + kP;
+  return u < w ? u : w;
+}
+// canonical residue -> the congruent word in (-p/2, p/2]
+ZKSP_HD int32_t fps_centre(uint32_t v) { return v > kP / 2 ? (int32_t)(v - kP) : (int32_t)v; }
+
 }  // namespace zksp

@@ -73,7 +73,7 @@ void launch_bus_perm_trace(hipStream_t stream, const uint32_t* trace, const uint
 // ---- openings / FRI (row a7) ----
 // out[b][i] = (base[b]*base_mul)^e, e = i or bitrev(i); Fp4 each, base_mul a Montgomery base-field word
 void launch_ext_powers(hipStream_t stream, const uint32_t* base, size_t base_stride, uint32_t base_mul, uint32_t* out,
-                       size_t out_stride, int n, int bitrev_logn, int batch);
+                       size_t out_stride, int n, int bitrev_logn, int batch, int centred = 0);
 // coefs_br: [batch][ncols][H] (bit-reversed); zpow_br: [batch][npoints][H] Fp4 (bit-reversed);
 // opened[b][pt*pt_stride + col] (Fp4)
 void launch_open(hipStream_t stream, const uint32_t* coefs_br, size_t coefs_stride, int ncols, int logh,

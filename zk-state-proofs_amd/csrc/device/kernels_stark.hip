@@ -253,7 +253,7 @@ void launch_keccak_quotient(hipStream_t stream, const QuotientArgs& a) {
 // ===========================================================================
 __global__ __launch_bounds__(kThreads) void ext_powers_kernel(const uint32_t* __restrict__ base, size_t base_stride,
                                                              uint32_t base_mul, uint32_t* __restrict__ out,
-                                                             size_t out_stride, int n, int bitrev_logn) {
+                                                             size_t out_stride, int n, int bitrev_logn, int centred) {
   const int i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= n) return;
   const int b = blockIdx.y;
@@ -266,13 +266,18 @@ __global__ __launch_bounds__(kThreads) void ext_powers_kernel(const uint32_t* __
     x = x.sqr();
     e >>= 1;
   }
+  if (centred) {
+    // signed words in (-p/2, p/2] for consumers that accumulate lazily (open_kernel)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.c[j] = Fp::raw((uint32_t)fps_centre(r.c[j].v));
+  }
   store_fp4(out + (size_t)b * out_stride + (size_t)i * 4, r);
 }
 
 void launch_ext_powers(hipStream_t stream, const uint32_t* base, size_t base_stride, uint32_t base_mul, uint32_t* out,
-                       size_t out_stride, int n, int bitrev_logn, int batch) {
+                       size_t out_stride, int n, int bitrev_logn, int batch, int centred) {
   hipLaunchKernelGGL(ext_powers_kernel, dim3((n + kThreads - 1) / kThreads, batch), dim3(kThreads), 0, stream, base,
-                     base_stride, base_mul, out, out_stride, n, bitrev_logn);
+                     base_stride, base_mul, out, out_stride, n, bitrev_logn, centred);
 }
 
 // ===========================================================================
@@ -296,35 +301,170 @@ __device__ __forceinline__ Fp4 block_sum(Fp4 v, Fp4* red) {
   return r;
 }
 
+// A signed 64-bit accumulator brought back to a few bits above 2^58 without changing its
+// residue: fold divides by 2^32, the multiplication by c = 2^32 mod p undoes that.
+__device__ __forceinline__ int64_t lazy_shrink(int64_t t) { return (int64_t)fps_fold(t) * (int64_t)kRModP; }
+
+// One workgroup opens kOpenCols columns, so a table of powers (64 KB for two points at
+// H = 2^11) is read from L2 once per kOpenCols columns instead of once per column.  zpow holds
+// CENTRED signed words (launch_ext_powers(.., centred = 1)); the coefficient is centred here,
+// so |term| < p^2 / 4 and eight terms fit a signed 64-bit accumulator between shrinks.
+constexpr int kOpenCols = 4;
+
 __global__ __launch_bounds__(kThreads) void open_kernel(const uint32_t* __restrict__ coefs, size_t coefs_stride,
-                                                       int logh, const uint32_t* __restrict__ zpow,
+                                                       int ncols, int logh, const uint32_t* __restrict__ zpow,
                                                        size_t zpow_stride, int npoints, uint32_t* __restrict__ opened,
                                                        size_t opened_stride, size_t pt_stride) {
   __shared__ Fp4 red[kThreads / 64];
   const int h = 1 << logh;
-  const int col = blockIdx.x, b = blockIdx.y;
-  const uint32_t* cf = coefs + (size_t)b * coefs_stride + (size_t)col * h;
+  const int col0 = blockIdx.x * kOpenCols, b = blockIdx.y;
+  const int nc = min(kOpenCols, ncols - col0);
+  const uint32_t* cf = coefs + (size_t)b * coefs_stride + (size_t)col0 * h;
   const uint32_t* z0 = zpow + (size_t)b * zpow_stride;
   const uint32_t* z1 = z0 + (size_t)h * 4;
-  Fp4 a0 = Fp4::zero(), a1 = Fp4::zero();
+  int64_t acc[kOpenCols][2][4];
+#pragma unroll
+  for (int c = 0; c < kOpenCols; ++c)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[c][q][j] = 0;
+  int pending = 0;
   for (int k = threadIdx.x; k < h; k += kThreads) {
-    Fp cv = Fp::raw(cf[k]);
-    a0 += load_fp4(z0 + (size_t)k * 4) * cv;
-    if (npoints > 1) a1 += load_fp4(z1 + (size_t)k * 4) * cv;
+    const uint4 p0 = *reinterpret_cast<const uint4*>(z0 + (size_t)k * 4);
+    uint4 p1 = make_uint4(0, 0, 0, 0);
+    if (npoints > 1) p1 = *reinterpret_cast<const uint4*>(z1 + (size_t)k * 4);
+    const int32_t zz[2][4] = {{(int32_t)p0.x, (int32_t)p0.y, (int32_t)p0.z, (int32_t)p0.w},
+                              {(int32_t)p1.x, (int32_t)p1.y, (int32_t)p1.z, (int32_t)p1.w}};
+#pragma unroll
+    for (int c = 0; c < kOpenCols; ++c) {
+      if (c < nc) {
+        const int32_t cv = fps_centre(cf[(size_t)c * h + k]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[c][0][j] += (int64_t)cv * (int64_t)zz[0][j];
+          if (npoints > 1) acc[c][1][j] += (int64_t)cv * (int64_t)zz[1][j];
+        }
+      }
+    }
+    if (++pending == 8) {
+#pragma unroll
+      for (int c = 0; c < kOpenCols; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[c][q][j] = lazy_shrink(acc[c][q][j]);
+      pending = 0;
+    }
   }
-  Fp4 s0 = block_sum(a0, red);
-  if (threadIdx.x == 0) store_fp4(opened + (size_t)b * opened_stride + (size_t)col * 4, s0);
-  if (npoints > 1) {
-    Fp4 s1 = block_sum(a1, red);
-    if (threadIdx.x == 0) store_fp4(opened + (size_t)b * opened_stride + (pt_stride + (size_t)col) * 4, s1);
+#pragma unroll
+  for (int c = 0; c < kOpenCols; ++c) {
+    if (c >= nc) break;  // uniform: nc depends on blockIdx only
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (q >= npoints) break;
+      Fp4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v.c[j] = Fp::raw(fps_canon(fps_fold(acc[c][q][j])));
+      const Fp4 sum = block_sum(v, red);
+      if (threadIdx.x == 0)
+        store_fp4(opened + (size_t)b * opened_stride + ((size_t)q * pt_stride + (size_t)(col0 + c)) * 4, sum);
+    }
+  }
+}
+
+// Wide matrices (the 2633-column trace): lane = column.  A workgroup stages a
+// [kOpenTileCols columns] x [kOpenTileK coefficients] tile through LDS: the global read is
+// coalesced along k (one 128-byte line per column and tile), the LDS read-back is transposed, so
+// every lane walks the coefficients of its own column while the powers of zeta are uniform
+// scalar operands.  No cross-lane reduction is needed at all; the next tile's global loads are
+// issued before the current tile is consumed.  Row pitch kOpenTileK + 1 words keeps both the
+// column-wise writes and the row-wise reads free of bank conflicts.
+constexpr int kOpenTileCols = kThreads, kOpenTileK = 32, kOpenPitch = kOpenTileK + 1;
+
+__global__ __launch_bounds__(kThreads) void open_wide_kernel(const uint32_t* __restrict__ coefs, size_t coefs_stride,
+                                                            int ncols, int logh, const uint32_t* __restrict__ zpow,
+                                                            size_t zpow_stride, int npoints,
+                                                            uint32_t* __restrict__ opened, size_t opened_stride,
+                                                            size_t pt_stride) {
+  __shared__ uint32_t tile[kOpenTileCols * kOpenPitch];
+  const int h = 1 << logh;
+  const int col0 = blockIdx.x * kOpenTileCols, b = blockIdx.y, tid = threadIdx.x;
+  const uint32_t* cf = coefs + (size_t)b * coefs_stride + (size_t)col0 * h;
+  const int4* z0 = reinterpret_cast<const int4*>(zpow + (size_t)b * zpow_stride);
+  const int4* z1 = z0 + h;
+  // loader role: 8 threads cover one column's 32 coefficients (16 bytes each), 32 columns per pass
+  const int lq = tid & 7, lr = tid >> 3;
+  constexpr int kPasses = kOpenTileCols / (kThreads / 8);
+  uint4 stage[kPasses];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int ps = 0; ps < kPasses; ++ps) {
+      const int c = ps * (kThreads / 8) + lr;
+      stage[ps] = col0 + c < ncols ? *reinterpret_cast<const uint4*>(cf + (size_t)c * h + k0 + lq * 4)
+                                   : make_uint4(0, 0, 0, 0);
+    }
+  };
+  int64_t acc[2][4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[q][j] = 0;
+  fetch(0);
+  for (int k0 = 0; k0 < h; k0 += kOpenTileK) {
+    __syncthreads();  // the previous tile has been consumed
+#pragma unroll
+    for (int ps = 0; ps < kPasses; ++ps) {
+      uint32_t* d = tile + (ps * (kThreads / 8) + lr) * kOpenPitch + lq * 4;
+      d[0] = stage[ps].x; d[1] = stage[ps].y; d[2] = stage[ps].z; d[3] = stage[ps].w;
+    }
+    __syncthreads();
+    if (k0 + kOpenTileK < h) fetch(k0 + kOpenTileK);
+    const uint32_t* mine = tile + tid * kOpenPitch;
+#pragma unroll
+    for (int kk = 0; kk < kOpenTileK; ++kk) {
+      const int32_t cv = fps_centre(mine[kk]);
+      const int4 p0 = z0[k0 + kk];  // uniform: scalar loads
+      acc[0][0] += (int64_t)cv * (int64_t)p0.x;
+      acc[0][1] += (int64_t)cv * (int64_t)p0.y;
+      acc[0][2] += (int64_t)cv * (int64_t)p0.z;
+      acc[0][3] += (int64_t)cv * (int64_t)p0.w;
+      if (npoints > 1) {
+        const int4 p1 = z1[k0 + kk];
+        acc[1][0] += (int64_t)cv * (int64_t)p1.x;
+        acc[1][1] += (int64_t)cv * (int64_t)p1.y;
+        acc[1][2] += (int64_t)cv * (int64_t)p1.z;
+        acc[1][3] += (int64_t)cv * (int64_t)p1.w;
+      }
+      if ((kk & 7) == 7) {  // eight terms of at most p^2 / 4 since the last shrink
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[q][j] = lazy_shrink(acc[q][j]);
+      }
+    }
+  }
+  if (col0 + tid < ncols) {
+    for (int q = 0; q < npoints; ++q) {
+      Fp4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v.c[j] = Fp::raw(fps_canon(fps_fold(acc[q][j])));
+      store_fp4(opened + (size_t)b * opened_stride + ((size_t)q * pt_stride + (size_t)(col0 + tid)) * 4, v);
+    }
   }
 }
 
 void launch_open(hipStream_t stream, const uint32_t* coefs_br, size_t coefs_stride, int ncols, int logh,
                  const uint32_t* zpow_br, size_t zpow_stride, int npoints, uint32_t* opened, size_t opened_stride,
                  size_t pt_stride, int batch) {
-  hipLaunchKernelGGL(open_kernel, dim3(ncols, batch), dim3(kThreads), 0, stream, coefs_br, coefs_stride, logh, zpow_br,
-                     zpow_stride, npoints, opened, opened_stride, pt_stride);
+  if (ncols >= 64 && logh >= 5) {
+    hipLaunchKernelGGL(open_wide_kernel, dim3((ncols + kOpenTileCols - 1) / kOpenTileCols, batch), dim3(kThreads), 0,
+                       stream, coefs_br, coefs_stride, ncols, logh, zpow_br, zpow_stride, npoints, opened, opened_stride,
+                       pt_stride);
+    return;
+  }
+  hipLaunchKernelGGL(open_kernel, dim3((ncols + kOpenCols - 1) / kOpenCols, batch), dim3(kThreads), 0, stream, coefs_br,
+                     coefs_stride, ncols, logh, zpow_br, zpow_stride, npoints, opened, opened_stride, pt_stride);
 }
 
 // ===========================================================================
@@ -359,17 +499,51 @@ __global__ __launch_bounds__(kThreads) void reduce_bsum_kernel(ReduceArgs a) {
   }
 }
 
+// Lane = four consecutive LDE points (one 16-byte load per column, so a wave keeps 1 KB per
+// load in flight); blockIdx.y = a chunk of kReduceChunk columns.  Lazy dot product: the powers
+// of alpha are uniform, so centring them is scalar work; the LDE words stay canonical,
+// |term| < p^2 / 2, four terms between shrinks.
 __global__ __launch_bounds__(kThreads) void reduce_partial_kernel(ReduceArgs a, int nchunks) {
   const int h = 1 << a.logh, n = 2 * h;
-  const int pt = blockIdx.x * kThreads + threadIdx.x;
+  const int pt = (blockIdx.x * kThreads + threadIdx.x) * 4;
   if (pt >= n) return;
   const int chunk = blockIdx.y, b = blockIdx.z, W = a.width;
   const int i0 = chunk * kReduceChunk, i1 = min(W, i0 + kReduceChunk);
   const uint32_t* col = a.lde_t + (size_t)b * W * n + pt;
   const uint32_t* ap = a.af_pows + (size_t)b * (2 * W + 16) * 4;
-  Fp4 acc = Fp4::zero();
-  for (int i = i0; i < i1; ++i) acc += load_fp4(ap + (size_t)i * 4) * Fp::raw(col[(size_t)i * n]);
-  store_fp4(a.partial + (((size_t)b * nchunks + chunk) * n + pt) * 4, acc);
+  int64_t acc[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[q][j] = 0;
+  for (int i = i0; i < i1; i += 4) {
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      v[u] = i + u < i1 ? *reinterpret_cast<const uint4*>(col + (size_t)(i + u) * n) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t* al = ap + (size_t)min(i + u, i1 - 1) * 4;
+      const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int32_t alpha = fps_centre(al[j]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q][j] += (int64_t)alpha * (int64_t)w[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[q][j] = lazy_shrink(acc[q][j]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    Fp4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.c[j] = Fp::raw(fps_canon(fps_fold(acc[q][j])));
+    store_fp4(a.partial + (((size_t)b * nchunks + chunk) * n + pt + q) * 4, r);
+  }
 }
 
 __global__ __launch_bounds__(kThreads) void reduce_final_kernel(ReduceArgs a, int nchunks) {
@@ -408,7 +582,8 @@ void launch_reduce_openings(hipStream_t stream, const ReduceArgs& a) {
   const int blocks = (n + kThreads - 1) / kThreads;
   const int nchunks = (a.width + kReduceChunk - 1) / kReduceChunk;
   hipLaunchKernelGGL(reduce_bsum_kernel, dim3(a.batch), dim3(kThreads), 0, stream, a);
-  hipLaunchKernelGGL(reduce_partial_kernel, dim3(blocks, nchunks, a.batch), dim3(kThreads), 0, stream, a, nchunks);
+  hipLaunchKernelGGL(reduce_partial_kernel, dim3((n / 4 + kThreads - 1) / kThreads, nchunks, a.batch), dim3(kThreads), 0,
+                     stream, a, nchunks);
   hipLaunchKernelGGL(reduce_final_kernel, dim3(blocks, a.batch), dim3(kThreads), 0, stream, a, nchunks);
 }
 int reduce_nchunks(int width) { return (width + kReduceChunk - 1) / kReduceChunk; }

@@ -126,37 +126,15 @@ ZKSP_HD void p2_sbox_layer(Fp* s, const uint32_t* __restrict__ rc) {
 // canonical implementation after canonicalisation (tests/test_gpu_kernels.py and the
 // host verifier, which runs this same code).
 // ---------------------------------------------------------------------------
-constexpr uint32_t kRModP = (uint32_t)((((uint64_t)1) << 32) % kP);  // c = 268435454
-constexpr int32_t p2s_centre(uint32_t v) { return v > kP / 2 ? (int32_t)(v - kP) : (int32_t)v; }
-constexpr int32_t kR2Centred = p2s_centre((uint32_t)(((uint64_t)kRModP * kRModP) % kP));  // K
-
-// |t| < 0.5667 * 2^32 * p  ->  t / 2^32 mod p, |result| <= |t| / 2^32 + p/2
-ZKSP_HD int32_t p2s_redc(int64_t t) {
-  const int32_t m = (int32_t)((uint32_t)t * kMontyNegMu);
-  return (int32_t)((t + (int64_t)m * (int64_t)kP) >> 32);
-}
-
-ZKSP_HD int32_t p2s_mul(int32_t a, int32_t b) { return p2s_redc((int64_t)a * (int64_t)b); }
-
+// the arithmetic itself is field.cuh's signed lazy layer
+constexpr int32_t p2s_centre(uint32_t v) { return fps_centre_const(v); }
+ZKSP_HD int32_t p2s_redc(int64_t t) { return fps_redc(t); }
 ZKSP_HD int32_t p2s_sbox(int32_t x) {
-  const int32_t x2 = p2s_mul(x, x), x3 = p2s_mul(x2, x), x4 = p2s_mul(x2, x2);
-  return p2s_mul(x3, x4);
+  const int32_t x2 = fps_mul(x, x), x3 = fps_mul(x2, x), x4 = fps_mul(x2, x2);
+  return fps_mul(x3, x4);
 }
-
-// 64-bit sum y of Montgomery-form words (|y| < 2^31 * 2^32) -> y + rc~, add = rc * R^2 mod p
-ZKSP_HD int32_t p2s_reduce_wide(int64_t y, int64_t add) {
-  const uint32_t lo = (uint32_t)y;
-  const int32_t hi = (int32_t)(y >> 32);
-  int64_t t = (int64_t)hi * (int64_t)kR2Centred + add;
-  t += (int64_t)((uint64_t)lo * kRModP);
-  return p2s_redc(t);
-}
-
-// signed word, |t| < p  ->  canonical residue
-ZKSP_HD uint32_t p2s_canon(int32_t t) {
-  const uint32_t u = (uint32_t)t, w = u + kP;
-  return u < w ? u : w;
-}
+ZKSP_HD int32_t p2s_reduce_wide(int64_t y, int64_t add) { return fps_reduce_wide(y, add); }
+ZKSP_HD uint32_t p2s_canon(int32_t t) { return fps_canon(t); }
 
 // circ(2*M4, M4, M4, M4), M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]], then + next constants
 ZKSP_HD void p2s_external_linear(int32_t* s, const int64_t* __restrict__ add) {

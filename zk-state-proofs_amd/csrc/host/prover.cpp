@@ -205,8 +205,8 @@ int prove_resident(Context* ctx) {
   {
     ProfileSpan sp(ctx, "transcript");
     launch_ch_observe_sample(s, ws->ch, ws->tree_q + root_off, tree_stride, 8, ws->zeta, 4, 1, B, kc);
-    launch_ext_powers(s, ws->zeta, 4, kR1, ws->zpow, 2 * h * 4, (int)h, logh, B);
-    launch_ext_powers(s, ws->zeta, 4, dom->w_h, ws->zpow + h * 4, 2 * h * 4, (int)h, logh, B);
+    launch_ext_powers(s, ws->zeta, 4, kR1, ws->zpow, 2 * h * 4, (int)h, logh, B, /*centred=*/1);
+    launch_ext_powers(s, ws->zeta, 4, dom->w_h, ws->zpow + h * 4, 2 * h * 4, (int)h, logh, B, /*centred=*/1);
   }
   {
     ProfileSpan sp(ctx, "open");
