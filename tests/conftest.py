@@ -9,6 +9,15 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
+# The oracle's C restatement is OpenMP code.  A GPU box shows every core of its host (256) but
+# grants one GPU's share of them (16): without a cap each oracle call starts 256 threads on 16
+# cores and slows down by orders of magnitude.  Must be set before libgomp is first loaded.
+try:
+    _cores = len(os.sched_getaffinity(0))
+except AttributeError:
+    _cores = os.cpu_count() or 1
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, _cores))))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

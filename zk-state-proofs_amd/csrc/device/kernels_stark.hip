@@ -457,7 +457,11 @@ __global__ __launch_bounds__(kThreads) void open_wide_kernel(const uint32_t* __r
 void launch_open(hipStream_t stream, const uint32_t* coefs_br, size_t coefs_stride, int ncols, int logh,
                  const uint32_t* zpow_br, size_t zpow_stride, int npoints, uint32_t* opened, size_t opened_stride,
                  size_t pt_stride, int batch) {
-  if (ncols >= 64 && logh >= 5) {
+  // The transposed kernel runs few, long workgroups (one per 256 columns, every tile in
+  // sequence): it wins once those fill the chip several times over (large batches) and loses
+  // badly on a single proof, where the lane-per-k kernel offers 60x more workgroups.
+  const long wide_blocks = (long)((ncols + kOpenTileCols - 1) / kOpenTileCols) * batch;
+  if (ncols >= 64 && logh >= 5 && wide_blocks >= 4 * 256) {
     hipLaunchKernelGGL(open_wide_kernel, dim3((ncols + kOpenTileCols - 1) / kOpenTileCols, batch), dim3(kThreads), 0,
                        stream, coefs_br, coefs_stride, ncols, logh, zpow_br, zpow_stride, npoints, opened, opened_stride,
                        pt_stride);
