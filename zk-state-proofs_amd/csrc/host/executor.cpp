@@ -123,6 +123,8 @@ static inline uint32_t rd32(const uint8_t* p) {
   return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
 }
 
+void predecode(ElfImage* elf);
+
 std::string load_elf(const uint8_t* d, size_t len, ElfImage* out) {
   if (len < 52 || memcmp(d, "\x7f" "ELF", 4) != 0) return "not an ELF file";
   if (d[4] != 1 || d[5] != 1) return "not ELF32 little-endian";
@@ -190,6 +192,7 @@ std::string load_elf(const uint8_t* d, size_t len, ElfImage* out) {
   uint8_t dg[32];
   sha256(d, len, dg);
   memcpy(out->sha256.data(), dg, 32);
+  predecode(out);
   return "";
 }
 
@@ -293,10 +296,253 @@ struct Memory {
 };
 }  // namespace
 
+// internal op id of the sentinel behind the last instruction
+constexpr uint8_t kOpEndOfText = OP_COUNT;
+constexpr uint8_t kHookBit = 0x80;
+
+void predecode(ElfImage* elf) {
+  elf->code.resize(elf->text.size() + 1);
+  for (size_t i = 0; i < elf->text.size(); ++i) {
+    const Decoded d = decode(elf->text[i]);
+    elf->code[i] = {d.op, (uint8_t)(d.rd ? d.rd : 32), d.rs1, d.rs2, d.imm};
+  }
+  // the sentinel takes the rare path too: its fault precedes the cycle-limit check, as a fetch fault does
+  elf->code[elf->text.size()] = {(uint8_t)(kOpEndOfText | kHookBit), 32, 0, 0, 0};
+  const uint32_t lo = elf->text_base, hi = elf->text_base + 4 * (uint32_t)elf->text.size();
+  for (uint32_t e : elf->keccakf_entries)
+    if (e >= lo && e < hi && !(e & 3)) elf->code[(e - lo) >> 2].op |= kHookBit;
+}
+
+namespace {
+
+// The run loop.  Threaded dispatch (one indirect jump per handler), the program counter kept as
+// an index into the decoded text and range-checked only where control is transferred, x0 writes
+// sent to a sink register, the keccakf hook carried by the decoded op.  Cycle, memory-operation
+// and histogram accounting and every fault message are those of the plain switch interpreter
+// this replaces (tests/test_executor.py pins them against SURVEY.md appendix A.4).
+template <bool HIST>
+void run(const ElfImage& elf, const std::vector<std::vector<uint8_t>>& stdin_entries, const ExecOptions& opt,
+         uint8_t* M, ExecutionRecord& rec) {
+  const ElfImage::Insn* code = elf.code.data();
+  const uint32_t text_lo = elf.text_base, text_bytes = 4 * (uint32_t)elf.text.size();
+  const bool hooks = opt.keccak_mode != KeccakMode::kSoftware;
+  const bool replace = opt.keccak_mode == KeccakMode::kReplace;
+  uint32_t x[33] = {0};
+  size_t stdin_pos = 0;
+  uint64_t cycles = 0, memops = 0;
+  const uint64_t max_cycles = opt.max_cycles;
+  size_t idx = 0;
+  const ElfImage::Insn* in = code;
+  uint32_t a = 0, b = 0, pc = 0;
+
+  static const void* const kTable[OP_COUNT + 1] = {
+      &&op_invalid, &&op_lui, &&op_auipc, &&op_jal, &&op_jalr, &&op_beq, &&op_bne, &&op_blt, &&op_bge, &&op_bltu,
+      &&op_bgeu, &&op_lb, &&op_lh, &&op_lw, &&op_lbu, &&op_lhu, &&op_sb, &&op_sh, &&op_sw, &&op_addi, &&op_slti,
+      &&op_sltiu, &&op_xori, &&op_ori, &&op_andi, &&op_slli, &&op_srli, &&op_srai, &&op_add, &&op_sub, &&op_sll,
+      &&op_slt, &&op_sltu, &&op_xor, &&op_srl, &&op_sra, &&op_or, &&op_and, &&op_mul, &&op_mulh, &&op_mulhsu,
+      &&op_mulhu, &&op_div, &&op_divu, &&op_rem, &&op_remu, &&op_ecall, &&op_fence, &&op_unimp, &&op_end_of_text};
+
+#define FAULT(msg)     \
+  do {                 \
+    rec.error = (msg); \
+    goto done;         \
+  } while (0)
+#define CHECK_ADDR(ad, n) \
+  if ((uint64_t)(ad) + (n) > kMemBytes) FAULT("memory access out of range")
+// transfer to guest address t (taken branch, jump): the fetch check of the next instruction
+#define JUMP(t)                                                                      \
+  do {                                                                               \
+    const uint32_t t_ = (uint32_t)(t), off_ = t_ - text_lo;                          \
+    if (off_ >= text_bytes || (t_ & 3)) FAULT("pc outside text segment");            \
+    idx = off_ >> 2;                                                                 \
+  } while (0)
+// fetch + dispatch, replicated in every handler so each has its own indirect jump
+#define FETCH()                                                                      \
+  do {                                                                               \
+    in = &code[idx];                                                                 \
+    op = in->op;                                                                     \
+    if (__builtin_expect(op & kHookBit, 0)) goto rare;                               \
+    if (__builtin_expect(cycles >= max_cycles, 0)) FAULT("cycle limit exceeded");    \
+    ++cycles;                                                                        \
+    if (HIST) rec.opcode_hist[op]++;                                                 \
+    a = x[in->rs1];                                                                  \
+    b = x[in->rs2];                                                                  \
+    goto* kTable[op];                                                                \
+  } while (0)
+#define NEXT() \
+  do {         \
+    ++idx;     \
+    FETCH();   \
+  } while (0)
+
+  uint8_t op = 0;
+  JUMP(elf.entry);
+  FETCH();
+
+rare:  // a keccakf entry point, or the sentinel behind the last instruction
+  op &= (uint8_t)~kHookBit;
+  if (op == kOpEndOfText) FAULT("pc outside text segment");
+  if (hooks) {
+    const uint32_t ptr = x[10];
+    if (ptr & 7) FAULT("keccakf state pointer not 8-byte aligned");
+    CHECK_ADDR(ptr, 200);
+    KeccakEvent ev;
+    memcpy(ev.state_in, M + ptr, 200);
+    ev.state_ptr = ptr;
+    ev.cycle = cycles;
+    rec.keccak_events.push_back(ev);
+    if (replace) {
+      uint64_t st[25];
+      memcpy(st, ev.state_in, 200);
+      keccak_f1600(st);
+      memcpy(M + ptr, st, 200);
+      ++cycles;  // the precompile ecall; control returns to the caller
+      JUMP(x[1]);
+      FETCH();
+    }
+  }
+  if (__builtin_expect(cycles >= max_cycles, 0)) FAULT("cycle limit exceeded");
+  ++cycles;
+  if (HIST) rec.opcode_hist[op]++;
+  a = x[in->rs1];
+  b = x[in->rs2];
+  goto* kTable[op];
+
+op_lui: x[in->rd] = (uint32_t)in->imm; NEXT();
+op_auipc: x[in->rd] = text_lo + 4 * (uint32_t)idx + (uint32_t)in->imm; NEXT();
+op_jal:
+  pc = text_lo + 4 * (uint32_t)idx;
+  x[in->rd] = pc + 4;
+  JUMP(pc + (uint32_t)in->imm);
+  FETCH();
+op_jalr:
+  pc = text_lo + 4 * (uint32_t)idx;
+  x[in->rd] = pc + 4;
+  JUMP((a + (uint32_t)in->imm) & ~1u);
+  FETCH();
+#define BRANCH(cond)                                              \
+  if (cond) {                                                     \
+    JUMP(text_lo + 4 * (uint32_t)idx + (uint32_t)in->imm);        \
+    FETCH();                                                      \
+  }                                                               \
+  NEXT()
+op_beq: BRANCH(a == b);
+op_bne: BRANCH(a != b);
+op_blt: BRANCH((int32_t)a < (int32_t)b);
+op_bge: BRANCH((int32_t)a >= (int32_t)b);
+op_bltu: BRANCH(a < b);
+op_bgeu: BRANCH(a >= b);
+#undef BRANCH
+op_lb: { const uint32_t ad = a + (uint32_t)in->imm; CHECK_ADDR(ad, 1); x[in->rd] = (uint32_t)(int32_t)(int8_t)M[ad]; ++memops; NEXT(); }
+op_lbu: { const uint32_t ad = a + (uint32_t)in->imm; CHECK_ADDR(ad, 1); x[in->rd] = M[ad]; ++memops; NEXT(); }
+op_lh: { const uint32_t ad = a + (uint32_t)in->imm; if (ad & 1) FAULT("unaligned lh"); CHECK_ADDR(ad, 2); uint16_t v; memcpy(&v, M + ad, 2); x[in->rd] = (uint32_t)(int32_t)(int16_t)v; ++memops; NEXT(); }
+op_lhu: { const uint32_t ad = a + (uint32_t)in->imm; if (ad & 1) FAULT("unaligned lhu"); CHECK_ADDR(ad, 2); uint16_t v; memcpy(&v, M + ad, 2); x[in->rd] = v; ++memops; NEXT(); }
+op_lw: { const uint32_t ad = a + (uint32_t)in->imm; if (ad & 3) FAULT("unaligned lw"); CHECK_ADDR(ad, 4); uint32_t v; memcpy(&v, M + ad, 4); x[in->rd] = v; ++memops; NEXT(); }
+op_sb: { const uint32_t ad = a + (uint32_t)in->imm; CHECK_ADDR(ad, 1); M[ad] = (uint8_t)b; ++memops; NEXT(); }
+op_sh: { const uint32_t ad = a + (uint32_t)in->imm; if (ad & 1) FAULT("unaligned sh"); CHECK_ADDR(ad, 2); const uint16_t v = (uint16_t)b; memcpy(M + ad, &v, 2); ++memops; NEXT(); }
+op_sw: { const uint32_t ad = a + (uint32_t)in->imm; if (ad & 3) FAULT("unaligned sw"); CHECK_ADDR(ad, 4); memcpy(M + ad, &b, 4); ++memops; NEXT(); }
+op_addi: x[in->rd] = a + (uint32_t)in->imm; NEXT();
+op_slti: x[in->rd] = (int32_t)a < in->imm; NEXT();
+op_sltiu: x[in->rd] = a < (uint32_t)in->imm; NEXT();
+op_xori: x[in->rd] = a ^ (uint32_t)in->imm; NEXT();
+op_ori: x[in->rd] = a | (uint32_t)in->imm; NEXT();
+op_andi: x[in->rd] = a & (uint32_t)in->imm; NEXT();
+op_slli: x[in->rd] = a << in->imm; NEXT();
+op_srli: x[in->rd] = a >> in->imm; NEXT();
+op_srai: x[in->rd] = (uint32_t)((int32_t)a >> in->imm); NEXT();
+op_add: x[in->rd] = a + b; NEXT();
+op_sub: x[in->rd] = a - b; NEXT();
+op_sll: x[in->rd] = a << (b & 31); NEXT();
+op_slt: x[in->rd] = (int32_t)a < (int32_t)b; NEXT();
+op_sltu: x[in->rd] = a < b; NEXT();
+op_xor: x[in->rd] = a ^ b; NEXT();
+op_srl: x[in->rd] = a >> (b & 31); NEXT();
+op_sra: x[in->rd] = (uint32_t)((int32_t)a >> (b & 31)); NEXT();
+op_or: x[in->rd] = a | b; NEXT();
+op_and: x[in->rd] = a & b; NEXT();
+op_mul: x[in->rd] = a * b; NEXT();
+op_mulh: x[in->rd] = (uint32_t)(((int64_t)(int32_t)a * (int64_t)(int32_t)b) >> 32); NEXT();
+op_mulhsu: x[in->rd] = (uint32_t)(((int64_t)(int32_t)a * (int64_t)(uint64_t)b) >> 32); NEXT();
+op_mulhu: x[in->rd] = (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); NEXT();
+op_div:
+  if (b == 0) x[in->rd] = 0xffffffffu;
+  else if (a == 0x80000000u && b == 0xffffffffu) x[in->rd] = a;
+  else x[in->rd] = (uint32_t)((int32_t)a / (int32_t)b);
+  NEXT();
+op_divu: x[in->rd] = b ? a / b : 0xffffffffu; NEXT();
+op_rem:
+  if (b == 0) x[in->rd] = a;
+  else if (a == 0x80000000u && b == 0xffffffffu) x[in->rd] = 0;
+  else x[in->rd] = (uint32_t)((int32_t)a % (int32_t)b);
+  NEXT();
+op_remu: x[in->rd] = b ? a % b : a; NEXT();
+op_fence: NEXT();
+op_ecall: {
+  const uint32_t codeid = x[5], a0 = x[10], a1 = x[11], a2 = x[12];
+  rec.syscall_counts[codeid & 0xff]++;
+  switch (codeid) {
+    case 0x00:  // HALT
+      rec.exit_code = a0;
+      rec.halted = true;
+      goto done;
+    case 0x02: {  // WRITE
+      CHECK_ADDR(a1, a2);
+      const char* p = (const char*)(M + a1);
+      if (a0 == 1) rec.stdout_text.append(p, a2);
+      else if (a0 == 2) rec.stderr_text.append(p, a2);
+      else if (a0 == 3) rec.public_values.insert(rec.public_values.end(), M + a1, M + a1 + a2);
+      else if (a0 == 4) { /* hint-stream write: not used by this guest */ }
+      else FAULT("WRITE to unsupported fd");
+      break;
+    }
+    case 0x10:  // COMMIT
+      if (a0 >= 8) FAULT("COMMIT word index out of range");
+      rec.pv_digest[a0] = a1;
+      break;
+    case 0x1a:  // COMMIT_DEFERRED_PROOFS
+      if (a0 >= 8) FAULT("COMMIT_DEFERRED word index out of range");
+      rec.deferred_digest[a0] = a1;
+      break;
+    case 0xf0:  // HINT_LEN
+      if (stdin_pos >= stdin_entries.size()) FAULT("HINT_LEN: input stream exhausted");
+      x[5] = (uint32_t)stdin_entries[stdin_pos].size();
+      break;
+    case 0xf1: {  // HINT_READ
+      if (stdin_pos >= stdin_entries.size()) FAULT("HINT_READ: input stream exhausted");
+      const auto& e = stdin_entries[stdin_pos];
+      if (a1 != e.size()) FAULT("HINT_READ: length mismatch");
+      if (a0 & 3) FAULT("HINT_READ: unaligned pointer");
+      CHECK_ADDR(a0, (a1 + 3) & ~3u);
+      memcpy(M + a0, e.data(), e.size());
+      ++stdin_pos;
+      break;
+    }
+    default:
+      FAULT("unsupported syscall code");
+  }
+  NEXT();
+}
+op_unimp: FAULT("unimp executed");
+op_invalid: FAULT("illegal instruction");
+op_end_of_text:  // not reachable through the table (the sentinel takes the rare path)
+  FAULT("pc outside text segment");
+
+done:
+#undef FAULT
+#undef CHECK_ADDR
+#undef JUMP
+#undef FETCH
+#undef NEXT
+  rec.cycles = cycles;
+  rec.memory_ops = memops;
+}
+
+}  // namespace
+
 ExecutionRecord execute(const ElfImage& elf, const std::vector<std::vector<uint8_t>>& stdin_entries,
                         const ExecOptions& opt) {
   ExecutionRecord rec;
-  if (opt.want_hist) rec.opcode_hist.assign(OP_COUNT, 0);
+  if (opt.want_hist) rec.opcode_hist.assign(OP_COUNT + 1, 0);  // + the sentinel's slot, dropped below
   Memory mem;
   if (!mem.base) {
     rec.error = "mmap of guest memory failed";
@@ -311,174 +557,13 @@ ExecutionRecord execute(const ElfImage& elf, const std::vector<std::vector<uint8
     }
     if (!s.bytes.empty()) memcpy(M + s.vaddr, s.bytes.data(), s.bytes.size());
   }
-  std::vector<Decoded> code(elf.text.size());
-  for (size_t i = 0; i < elf.text.size(); ++i) code[i] = decode(elf.text[i]);
-  const uint32_t text_lo = elf.text_base, text_hi = elf.text_base + 4 * (uint32_t)elf.text.size();
-
-  // mark keccakf entry points in a side table for O(1) checks
-  std::vector<uint8_t> is_keccak;
-  if (opt.keccak_mode != KeccakMode::kSoftware && !elf.keccakf_entries.empty()) {
-    is_keccak.assign(elf.text.size(), 0);
-    for (uint32_t e : elf.keccakf_entries)
-      if (e >= text_lo && e < text_hi) is_keccak[(e - text_lo) >> 2] = 1;
+  if (elf.code.size() != elf.text.size() + 1) {
+    rec.error = "ELF image was not decoded (load_elf)";
+    return rec;
   }
-
-  uint32_t x[32] = {0};
-  uint32_t pc = elf.entry;
-  size_t stdin_pos = 0;
-  uint64_t cycles = 0, memops = 0;
-  const uint64_t max_cycles = opt.max_cycles;
-
-#define FAULT(msg)          \
-  do {                      \
-    rec.error = (msg);      \
-    goto done;              \
-  } while (0)
-#define CHECK_ADDR(a, n) \
-  if ((uint64_t)(a) + (n) > kMemBytes) FAULT("memory access out of range")
-
-  for (;;) {
-    if (pc < text_lo || pc >= text_hi || (pc & 3)) FAULT("pc outside text segment");
-    size_t idx = (pc - text_lo) >> 2;
-    if (!is_keccak.empty() && is_keccak[idx]) {
-      uint32_t ptr = x[10];
-      if (ptr & 7) FAULT("keccakf state pointer not 8-byte aligned");
-      CHECK_ADDR(ptr, 200);
-      KeccakEvent ev;
-      memcpy(ev.state_in, M + ptr, 200);
-      ev.state_ptr = ptr;
-      ev.cycle = cycles;
-      rec.keccak_events.push_back(ev);
-      if (opt.keccak_mode == KeccakMode::kReplace) {
-        uint64_t st[25];
-        memcpy(st, ev.state_in, 200);
-        keccak_f1600(st);
-        memcpy(M + ptr, st, 200);
-        pc = x[1];  // return to caller; counts as one cycle (the precompile ecall)
-        ++cycles;
-        continue;
-      }
-    }
-    const Decoded& in = code[idx];
-    if (cycles >= max_cycles) FAULT("cycle limit exceeded");
-    ++cycles;
-    if (opt.want_hist) rec.opcode_hist[in.op]++;
-    uint32_t a = x[in.rs1], b = x[in.rs2];
-    uint32_t next = pc + 4;
-    uint32_t res = 0;
-    bool wr = true;
-    switch (in.op) {
-      case OP_LUI: res = (uint32_t)in.imm; break;
-      case OP_AUIPC: res = pc + (uint32_t)in.imm; break;
-      case OP_JAL: res = pc + 4; next = pc + (uint32_t)in.imm; break;
-      case OP_JALR: res = pc + 4; next = (a + (uint32_t)in.imm) & ~1u; break;
-      case OP_BEQ: wr = false; if (a == b) next = pc + (uint32_t)in.imm; break;
-      case OP_BNE: wr = false; if (a != b) next = pc + (uint32_t)in.imm; break;
-      case OP_BLT: wr = false; if ((int32_t)a < (int32_t)b) next = pc + (uint32_t)in.imm; break;
-      case OP_BGE: wr = false; if ((int32_t)a >= (int32_t)b) next = pc + (uint32_t)in.imm; break;
-      case OP_BLTU: wr = false; if (a < b) next = pc + (uint32_t)in.imm; break;
-      case OP_BGEU: wr = false; if (a >= b) next = pc + (uint32_t)in.imm; break;
-      case OP_LB: { uint32_t ad = a + (uint32_t)in.imm; CHECK_ADDR(ad, 1); res = (uint32_t)(int32_t)(int8_t)M[ad]; ++memops; break; }
-      case OP_LBU: { uint32_t ad = a + (uint32_t)in.imm; CHECK_ADDR(ad, 1); res = M[ad]; ++memops; break; }
-      case OP_LH: { uint32_t ad = a + (uint32_t)in.imm; if (ad & 1) FAULT("unaligned lh"); CHECK_ADDR(ad, 2); uint16_t v; memcpy(&v, M + ad, 2); res = (uint32_t)(int32_t)(int16_t)v; ++memops; break; }
-      case OP_LHU: { uint32_t ad = a + (uint32_t)in.imm; if (ad & 1) FAULT("unaligned lhu"); CHECK_ADDR(ad, 2); uint16_t v; memcpy(&v, M + ad, 2); res = v; ++memops; break; }
-      case OP_LW: { uint32_t ad = a + (uint32_t)in.imm; if (ad & 3) FAULT("unaligned lw"); CHECK_ADDR(ad, 4); memcpy(&res, M + ad, 4); ++memops; break; }
-      case OP_SB: { wr = false; uint32_t ad = a + (uint32_t)in.imm; CHECK_ADDR(ad, 1); M[ad] = (uint8_t)b; ++memops; break; }
-      case OP_SH: { wr = false; uint32_t ad = a + (uint32_t)in.imm; if (ad & 1) FAULT("unaligned sh"); CHECK_ADDR(ad, 2); uint16_t v = (uint16_t)b; memcpy(M + ad, &v, 2); ++memops; break; }
-      case OP_SW: { wr = false; uint32_t ad = a + (uint32_t)in.imm; if (ad & 3) FAULT("unaligned sw"); CHECK_ADDR(ad, 4); memcpy(M + ad, &b, 4); ++memops; break; }
-      case OP_ADDI: res = a + (uint32_t)in.imm; break;
-      case OP_SLTI: res = (int32_t)a < in.imm; break;
-      case OP_SLTIU: res = a < (uint32_t)in.imm; break;
-      case OP_XORI: res = a ^ (uint32_t)in.imm; break;
-      case OP_ORI: res = a | (uint32_t)in.imm; break;
-      case OP_ANDI: res = a & (uint32_t)in.imm; break;
-      case OP_SLLI: res = a << in.imm; break;
-      case OP_SRLI: res = a >> in.imm; break;
-      case OP_SRAI: res = (uint32_t)((int32_t)a >> in.imm); break;
-      case OP_ADD: res = a + b; break;
-      case OP_SUB: res = a - b; break;
-      case OP_SLL: res = a << (b & 31); break;
-      case OP_SLT: res = (int32_t)a < (int32_t)b; break;
-      case OP_SLTU: res = a < b; break;
-      case OP_XOR: res = a ^ b; break;
-      case OP_SRL: res = a >> (b & 31); break;
-      case OP_SRA: res = (uint32_t)((int32_t)a >> (b & 31)); break;
-      case OP_OR: res = a | b; break;
-      case OP_AND: res = a & b; break;
-      case OP_MUL: res = a * b; break;
-      case OP_MULH: res = (uint32_t)(((int64_t)(int32_t)a * (int64_t)(int32_t)b) >> 32); break;
-      case OP_MULHSU: res = (uint32_t)(((int64_t)(int32_t)a * (int64_t)(uint64_t)b) >> 32); break;
-      case OP_MULHU: res = (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); break;
-      case OP_DIV:
-        if (b == 0) res = 0xffffffffu;
-        else if (a == 0x80000000u && b == 0xffffffffu) res = a;
-        else res = (uint32_t)((int32_t)a / (int32_t)b);
-        break;
-      case OP_DIVU: res = b ? a / b : 0xffffffffu; break;
-      case OP_REM:
-        if (b == 0) res = a;
-        else if (a == 0x80000000u && b == 0xffffffffu) res = 0;
-        else res = (uint32_t)((int32_t)a % (int32_t)b);
-        break;
-      case OP_REMU: res = b ? a % b : a; break;
-      case OP_FENCE: wr = false; break;
-      case OP_ECALL: {
-        wr = false;
-        uint32_t codeid = x[5], a0 = x[10], a1 = x[11], a2 = x[12];
-        rec.syscall_counts[codeid & 0xff]++;
-        switch (codeid) {
-          case 0x00:  // HALT
-            rec.exit_code = a0;
-            rec.halted = true;
-            goto done;
-          case 0x02: {  // WRITE
-            CHECK_ADDR(a1, a2);
-            const char* p = (const char*)(M + a1);
-            if (a0 == 1) rec.stdout_text.append(p, a2);
-            else if (a0 == 2) rec.stderr_text.append(p, a2);
-            else if (a0 == 3) rec.public_values.insert(rec.public_values.end(), M + a1, M + a1 + a2);
-            else if (a0 == 4) { /* hint-stream write: not used by this guest */ }
-            else FAULT("WRITE to unsupported fd");
-            break;
-          }
-          case 0x10:  // COMMIT
-            if (a0 >= 8) FAULT("COMMIT word index out of range");
-            rec.pv_digest[a0] = a1;
-            break;
-          case 0x1a:  // COMMIT_DEFERRED_PROOFS
-            if (a0 >= 8) FAULT("COMMIT_DEFERRED word index out of range");
-            rec.deferred_digest[a0] = a1;
-            break;
-          case 0xf0:  // HINT_LEN
-            if (stdin_pos >= stdin_entries.size()) FAULT("HINT_LEN: input stream exhausted");
-            x[5] = (uint32_t)stdin_entries[stdin_pos].size();
-            break;
-          case 0xf1: {  // HINT_READ
-            if (stdin_pos >= stdin_entries.size()) FAULT("HINT_READ: input stream exhausted");
-            const auto& e = stdin_entries[stdin_pos];
-            if (a1 != e.size()) FAULT("HINT_READ: length mismatch");
-            if (a0 & 3) FAULT("HINT_READ: unaligned pointer");
-            CHECK_ADDR(a0, (a1 + 3) & ~3u);
-            memcpy(M + a0, e.data(), e.size());
-            ++stdin_pos;
-            break;
-          }
-          default:
-            FAULT("unsupported syscall code");
-        }
-        break;
-      }
-      case OP_UNIMP: FAULT("unimp executed");
-      default: FAULT("illegal instruction");
-    }
-    if (wr && in.rd) x[in.rd] = res;
-    pc = next;
-  }
-done:
-#undef FAULT
-#undef CHECK_ADDR
-  rec.cycles = cycles;
-  rec.memory_ops = memops;
+  if (opt.want_hist) run<true>(elf, stdin_entries, opt, M, rec);
+  else run<false>(elf, stdin_entries, opt, M, rec);
+  if (opt.want_hist) rec.opcode_hist.resize(OP_COUNT);
   return rec;
 }
 

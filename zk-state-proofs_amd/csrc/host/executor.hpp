@@ -29,6 +29,11 @@ struct ElfImage {
   std::vector<uint32_t> keccakf_entries;  // FUNC symbols whose name contains "keccakf"
   uint32_t max_addr = 0;
   std::array<uint8_t, 32> sha256{};   // digest of the file bytes
+  // Decoded once by load_elf (text.size() + 1 entries, the last a sentinel that faults when
+  // execution runs off the end): {op | 0x80 at keccakf entry points, rd (0 -> 32, a sink
+  // register), rs1, rs2, imm}.  Decoding 39 k words per run was a quarter of a run.
+  struct Insn { uint8_t op, rd, rs1, rs2; int32_t imm; };
+  std::vector<Insn> code;
 };
 
 // Parses an ELF32 little-endian RISC-V executable. Returns "" on success.
