@@ -11,6 +11,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
+#include <cstdio>
 #include <chrono>
 #include <cstring>
 #include <functional>
@@ -48,9 +50,35 @@ struct Group {
   int slot = 0;               // staging buffer holding its bodies
 };
 
+// Host threads this process may use for guest execution and proof assembly.  A GPU box shows
+// every core of its host (hardware_concurrency() = 256) while one process per GPU owns a share of
+// them, so the default is bounded; ZKSP_HOST_THREADS overrides it.
+unsigned host_threads() {
+  static const unsigned n = [] {
+    if (const char* e = getenv("ZKSP_HOST_THREADS")) {
+      const int v = atoi(e);
+      if (v > 0) return (unsigned)v;
+    }
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return std::min(hw, 16u);
+  }();
+  return n;
+}
+
+// ZKSP_TRACE_BATCH=1: wall-clock marks of the batch pipeline on stderr (debugging aid)
+struct BatchTrace {
+  bool on = getenv("ZKSP_TRACE_BATCH") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void mark(const char* what, size_t k) const {
+    if (!on) return;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "[zksp batch] %8.2f ms  %s %zu\n", ms, what, k);
+  }
+};
+
 void parallel_for(size_t count, unsigned max_threads, const std::function<void(size_t)>& fn) {
   std::atomic<size_t> next{0};
-  unsigned nt = std::max(1u, std::min<unsigned>(std::min(max_threads, std::thread::hardware_concurrency()), (unsigned)count));
+  unsigned nt = std::max(1u, std::min<unsigned>(std::min(max_threads, host_threads()), (unsigned)count));
   auto work = [&]() {
     for (size_t j; (j = next.fetch_add(1)) < count;) fn(j);
   };
@@ -78,8 +106,9 @@ int zksp_prove_batch(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdin
   std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[n]);
   for (size_t i = 0; i < n; ++i) done[i].store(0, std::memory_order_relaxed);
   std::atomic<size_t> next_job{0};
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const unsigned hw = host_threads();
   const unsigned n_workers = std::max(1u, std::min<unsigned>(hw > 2 ? hw - 1 : hw, (unsigned)n));
+  const BatchTrace trace;
   auto worker = [&]() {
     for (size_t i; (i = next_job.fetch_add(1)) < n;) {
       if (stdins[i]) {
@@ -96,7 +125,10 @@ int zksp_prove_batch(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdin
 
   // ---- stages 2 and 3, driven from this thread ----
   const size_t max_batch = ctx->params.max_batch;
-  size_t wave = n <= 32 ? n : std::max<size_t>(16, std::min(max_batch, (n + 3) / 4));
+  // The first wave is small so that the GPU starts while the executor workers are still
+  // running ahead; later waves are as large as the workspace allows (larger groups use the
+  // GPU better, and the executor is several waves ahead by then).
+  const size_t first_wave = n <= 32 ? n : std::max<size_t>(16, std::min(n, max_batch / 4));
   std::string first_err;
   int rc_all = ZKSP_OK;
   Group pending;          // proven (or being proven) on the GPU, not yet assembled
@@ -149,10 +181,22 @@ int zksp_prove_batch(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdin
     rc_all = rc;
   };
 
-  for (size_t w0 = 0; w0 < n; w0 += wave) {
+  // copy stream and events (created on first use, owned by the context)
+  bool overlap = true;
+  if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) overlap = false;
+  for (int k = 0; k < 2 && overlap; ++k) {
+    if (!ctx->ev_proved[k] && hipEventCreateWithFlags(&ctx->ev_proved[k], hipEventDisableTiming) != hipSuccess) overlap = false;
+    if (!ctx->ev_copied[k] && hipEventCreateWithFlags(&ctx->ev_copied[k], hipEventDisableTiming) != hipSuccess) overlap = false;
+  }
+  if (!overlap) return ctx->fail(ZKSP_ERR_HIP, "prove: could not create the copy stream");
+  ctx->body_free = nullptr;
+  ctx->batch_hint = (int)std::min(max_batch, n);
+
+  for (size_t w0 = 0, wave = first_wave; w0 < n; w0 += wave, wave = max_batch) {
     const size_t w1 = std::min(n, w0 + wave);
     for (size_t i = w0; i < w1; ++i)
       while (!done[i].load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    trace.mark("wave executed, first index", w0);
     std::map<int, std::vector<size_t>> by_height;
     for (size_t i = w0; i < w1; ++i) {
       ExecutionRecord& r = jobs[i].rec;
@@ -207,9 +251,22 @@ int zksp_prove_batch(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdin
             o[29 + 2 * k] = r.deferred_digest[k] >> 16;
           }
         }
-        // load_batch synchronises the stream: the previous group's proving and its
-        // device-to-host copy are complete when it returns
+        // load_batch synchronises the proving stream, so the previous pass is complete when it
+        // returns; that pass's device-to-host copy runs on the copy stream and may still be in
+        // flight.  If this group makes the workspace reallocate (another trace height, a larger
+        // group) the copy's source would be freed under it: wait for the copy first.
+        {
+          const Workspace* w = ctx->ws.get();
+          const int want = std::max((int)cnt, ctx->batch_hint);
+          const bool realloc = !w || w->logh != g.logh || want > w->batch || (int)max_perms > w->max_perms;
+          if (realloc && ctx->body_free && hipEventSynchronize(ctx->body_free) != hipSuccess) {
+            fail_group(g, ctx->fail(ZKSP_ERR_HIP, "prove: waiting for the device-to-host copy failed"));
+            continue;
+          }
+          if (realloc) ctx->body_free = nullptr;
+        }
         int rc = zksp_hip_load_batch(c, g.logh, cnt, max_perms, states.data(), g.np.data(), obs.data());
+        trace.mark("previous group finished on the GPU; loaded group of", cnt);
         if (rc == ZKSP_OK) rc = zksp_hip_prove_resident(c);
         if (rc == ZKSP_OK && ctx->h_stage2_words[g.slot] < cnt * g.bw) {
           if (ctx->h_stage2[g.slot]) (void)hipHostFree(ctx->h_stage2[g.slot]);
@@ -220,12 +277,23 @@ int zksp_prove_batch(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdin
           else
             rc = ctx->fail(ZKSP_ERR_HIP, "prove: pinned staging allocation failed");
         }
-        if (rc == ZKSP_OK && hipMemcpyAsync(ctx->h_stage2[g.slot], ctx->ws->body, cnt * g.bw * 4, hipMemcpyDeviceToHost,
-                                            ctx->stream) != hipSuccess)
+        // the copy runs on its own stream behind this pass; the NEXT pass waits for it only before
+        // its assemble kernel (Context::body_free), so it overlaps that pass's other kernels
+        if (rc == ZKSP_OK &&
+            (hipEventRecord(ctx->ev_proved[g.slot], ctx->stream) != hipSuccess ||
+             hipStreamWaitEvent(ctx->copy_stream, ctx->ev_proved[g.slot], 0) != hipSuccess ||
+             hipMemcpyAsync(ctx->h_stage2[g.slot], ctx->ws->body, cnt * g.bw * 4, hipMemcpyDeviceToHost,
+                            ctx->copy_stream) != hipSuccess ||
+             hipEventRecord(ctx->ev_copied[g.slot], ctx->copy_stream) != hipSuccess))
           rc = ctx->fail(ZKSP_ERR_HIP, "prove: device-to-host copy failed");
+        if (rc == ZKSP_OK) ctx->body_free = ctx->ev_copied[g.slot];
         // while the GPU works on this group, build the previous group's proof objects
         if (have_pending) {
+          if (hipEventSynchronize(ctx->ev_copied[pending.slot]) != hipSuccess)
+            fail_group(pending, ctx->fail(ZKSP_ERR_HIP, "prove: waiting for the device-to-host copy failed"));
+          else
           assemble_group(pending);
+          trace.mark("assembled group of", pending.idxs.size());
           have_pending = false;
         }
         if (rc != ZKSP_OK) {
@@ -239,9 +307,16 @@ int zksp_prove_batch(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdin
     }
   }
   if (have_pending) {
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) fail_group(pending, ctx->fail(ZKSP_ERR_HIP, "prove: stream sync failed"));
-    else assemble_group(pending);
+    if (hipEventSynchronize(ctx->ev_copied[pending.slot]) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+      fail_group(pending, ctx->fail(ZKSP_ERR_HIP, "prove: stream sync failed"));
+    else {
+      trace.mark("last group finished on the GPU, size", pending.idxs.size());
+      assemble_group(pending);
+    }
   }
+  ctx->body_free = nullptr;  // every copy has completed: later passes on this client need no wait
+  ctx->batch_hint = 0;
+  trace.mark("all assembled", n);
   for (auto& t : workers) t.join();
   if (!first_err.empty() && rc_all == ZKSP_OK) ctx->error = first_err;
   return rc_all;

@@ -26,6 +26,11 @@ Context::~Context() {
       (void)hipEventDestroy(e.first);
       (void)hipEventDestroy(e.second);
     }
+    for (hipEvent_t e : ev_proved)
+      if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_copied)
+      if (e) (void)hipEventDestroy(e);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (timer_a) (void)hipEventDestroy(timer_a);
     if (timer_b) (void)hipEventDestroy(timer_b);
     ws.reset();

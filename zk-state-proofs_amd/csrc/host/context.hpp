@@ -58,6 +58,14 @@ struct Context {
   std::unique_ptr<Workspace> ws;
   uint32_t* h_stage2[2] = {nullptr, nullptr};  // pinned host staging for proof bodies (double buffered)
   size_t h_stage2_words[2] = {0, 0};
+  // prove_batch copies a group's bodies to the host on its own stream while the next group is
+  // proven: ev_proved[slot] marks the end of a pass, ev_copied[slot] the end of its copy.  The next
+  // pass waits for body_free (the last copy) only right before its assemble kernel, the one launch
+  // that overwrites the body buffer.
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_proved[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+  hipEvent_t body_free = nullptr;  // not owned: one of ev_copied, or null
+  int batch_hint = 0;  // prove_batch: the largest group it will load, so the workspace is sized once
   std::string error;
   // profiling
   bool profile = false;

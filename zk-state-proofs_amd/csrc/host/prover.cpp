@@ -43,6 +43,7 @@ static int ceil_log2(size_t v) {
 }
 
 int workspace_ensure(Context* ctx, int logh, int batch, int max_perms) {
+  batch = std::max(batch, ctx->batch_hint);
   if (ctx->ws && ctx->ws->logh == logh && ctx->ws->batch >= batch && ctx->ws->max_perms >= max_perms) return 0;
   ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->ws.reset(new Workspace());
@@ -310,6 +311,8 @@ int prove_resident(Context* ctx) {
     aa.logh = logh;
     aa.n_queries = Q;
     aa.batch = B;
+    // the body buffer may still be the source of the previous group's device-to-host copy
+    if (ctx->body_free) (void)hipStreamWaitEvent(s, ctx->body_free, 0);
     launch_assemble(s, aa);
   }
   hipError_t e = hipGetLastError();
