@@ -171,20 +171,25 @@ def main():
     pk, vk = client.setup(zk.merkle_elf())
     vk_words = [int(x) for x in np.frombuffer(vk.digest, dtype=np.uint32)]
 
-    # ---- inputs: B distinct synthetic depth-8 account proofs per rank (host executor, untimed) ----
-    t_exec = time.perf_counter()
+    # ---- inputs: B distinct synthetic depth-8 account proofs per rank (outside the timed region) ----
     states = np.zeros((B, 62, 25), np.uint64)
     obs = np.zeros((B, 44), np.uint32)
     pv = fx.ACCOUNT_VALUE
     pvd = [int(x) for x in np.frombuffer(hashlib.sha256(pv).digest(), dtype=np.uint32)]
+    # synthetic inputs first (pure-Python trie construction, not part of the path), then the
+    # executor alone under the clock
+    inputs = [fx.acct_fixture(8, seed=1 + rank * B + i).to_borsh() for i in range(B)]
+    exec_s = 0.0
     for i in range(B):
         stdin = zk.SP1Stdin()
-        stdin.write(fx.acct_fixture(8, seed=1 + rank * B + i).to_borsh())
+        stdin.write(inputs[i])
+        t_exec = time.perf_counter()
         st = client.keccak_states(pk, stdin)
+        exec_s += time.perf_counter() - t_exec
         assert st.shape == (62, 25)
         states[i] = st
         obs[i] = init_obs(vk_words, LOG_H, 62, 0, pvd, [0] * 8)
-    exec_ms_per_proof = (time.perf_counter() - t_exec) * 1e3 / B
+    exec_ms_per_proof = exec_s * 1e3 / B
     n_perms = np.full(B, 62, np.uint32)
 
     def check(rc):
@@ -262,19 +267,38 @@ def main():
             check(lib.zksp_hip_prove_resident(h))
         sync()
         single_ms = (time.perf_counter() - t1) * 1e3 / 5
+        one = fx.acct_fixture(8, seed=1).to_borsh()
+        # first call untimed (creates the copy stream, events and pinned staging of this client)
         stdin = zk.SP1Stdin()
-        stdin.write(fx.acct_fixture(8, seed=1).to_borsh())
-        t2 = time.perf_counter()
-        proof = client.prove(pk, stdin).run()
-        e2e_ms = (time.perf_counter() - t2) * 1e3
+        stdin.write(one)
+        client.verify(client.prove(pk, stdin).run(), vk)
+        e2e = []
+        for _ in range(5):
+            stdin = zk.SP1Stdin()
+            stdin.write(one)
+            t2 = time.perf_counter()
+            proof = client.prove(pk, stdin).run()
+            e2e.append((time.perf_counter() - t2) * 1e3)
+        e2e_ms = sorted(e2e)[len(e2e) // 2]  # median of 5: guest execution, H2D, proving, D2H, proof object
         client.verify(proof, vk)
         # the drop-in call on a whole batch: executor + H2D + proving + D2H + proof objects
         nb = 2 * B if B >= 64 else B
-        stdins = []
-        for i in range(nb):
-            sdin = zk.SP1Stdin()
-            sdin.write(fx.acct_fixture(8, seed=1000 + i).to_borsh())
-            stdins.append(sdin)
+        payloads = [fx.acct_fixture(8, seed=1000 + i).to_borsh() for i in range(nb)]
+
+        def make_stdins():
+            out = []
+            for buf in payloads:
+                sdin = zk.SP1Stdin()
+                sdin.write(buf)
+                out.append(sdin)
+            return out
+
+        # one untimed call first: the first use allocates the pinned staging buffers and the copy
+        # stream; the figure reported is the steady-state rate of a service that keeps its client
+        proofs, status = client.prove_batch(pk, make_stdins())
+        assert status == [0] * nb
+        del proofs
+        stdins = make_stdins()
         t3 = time.perf_counter()
         proofs, status = client.prove_batch(pk, stdins)
         e2e_batch_s = time.perf_counter() - t3
@@ -322,7 +346,7 @@ def main():
         "device_ms_per_step_by_stage": spans,
         "single_proof_device_ms": single_ms,
         "single_proof_end_to_end_ms": e2e_ms,
-        "host_executor_ms_per_proof": exec_ms_per_proof,
+        "host_executor_ms_per_proof": exec_ms_per_proof,  # one core, keccak precompile shape (the client default)
         "prove_batch_end_to_end_proofs_per_s": e2e_batch_rate,
     }
     if not args.no_cpu_baseline:
