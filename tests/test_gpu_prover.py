@@ -62,6 +62,33 @@ def test_device_prover_matches_oracle_small(zk, oracle, logh, nq, pow_bits):
         assert bad.size == 0, (i, bad[:8])
 
 
+@pytest.mark.parametrize("logh,n", [(13, 2), (14, 1)])
+def test_device_prover_matches_oracle_tall(zk, oracle, logh, n):
+    """Whole-proof parity at the largest supported trace heights (2^14 is the limit of load_batch):
+    other LDE workgroup shapes, more tiles and shrinks in the opening kernels, deeper trees and
+    more FRI layers than the 2^11 workload."""
+    nq, pow_bits = 5, 6
+    g = Gpu(zk, num_queries=nq, pow_bits=pow_bits, max_batch=n)
+    rng = np.random.default_rng(200 + logh)
+    vk = [int(x) for x in rng.integers(0, P, 8)]
+    cap = (1 << logh) // 24
+    states, obs, pvds = [], [], []
+    for i in range(n):
+        k = cap - 3 * i  # a full trace first, then a few padding permutations
+        st = rng.integers(0, 2**64, (k, 25), dtype=np.uint64)
+        pvd = [int(x) for x in rng.integers(0, 2**32, 8)]
+        states.append(st)
+        pvds.append(pvd)
+        obs.append(init_obs(vk, logh, k, 0, pvd, [0] * 8))
+    bodies = device_bodies(g, logh, states, obs)
+    for i in range(n):
+        exp = oracle.prove(states[i], logh, pv_digest=pvds[i], vk_digest=vk, num_queries=nq, pow_bits=pow_bits)
+        e = np.frombuffer(exp, dtype=np.uint32)[oracle.proof_header_words(0, len(states[i])):]
+        assert e.shape == bodies[i].shape
+        bad = np.nonzero(e != bodies[i])[0]
+        assert bad.size == 0, (i, bad[:8])
+
+
 @pytest.mark.parametrize("logh,n", [(5, 128), (6, 96)])
 def test_device_prover_matches_oracle_large_batch(zk, oracle, logh, n):
     """Large batches take different kernels from small ones (the LDS-transposed opening kernel
