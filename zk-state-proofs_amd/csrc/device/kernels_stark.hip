@@ -796,9 +796,19 @@ void launch_ch_observe_sample(hipStream_t stream, DevChallenger* ch, const uint3
 void launch_ch_grind(hipStream_t stream, DevChallenger* ch, uint32_t* witness, int bits, int batch,
                      const P2Consts* consts) {
   (void)hipMemsetAsync(witness, 0xff, (size_t)batch * 4, stream);
-  for (int r = 0; r < kGrindLaunches; ++r)
-    hipLaunchKernelGGL(ch_grind_kernel, dim3(kGrindRange / kThreads, batch), dim3(kThreads), 0, stream, ch, witness, bits,
-                       kGrindRange * (uint32_t)r, consts);
+  // The first kGrindRange * kGrindLaunches = 2^20 candidates are covered by launches of equal
+  // ranges; a later launch returns at once for a proof whose witness is already known.  The
+  // range grows as the batch shrinks (about 2^22 lanes per launch, at most 2^18 per proof): a
+  // single proof needs 4 launches instead of 64, a batch of 256 keeps 64 launches of 2^14.
+  // Every candidate below the witness found is tested either way, so the result is the
+  // minimal witness regardless of the split.
+  int log_range = 14;
+  while (log_range < 18 && ((size_t)batch << (log_range + 1)) <= ((size_t)1 << 22)) ++log_range;
+  const uint32_t range = 1u << log_range;
+  const int launches = (int)((kGrindRange * (uint32_t)kGrindLaunches) >> log_range);
+  for (int r = 0; r < launches; ++r)
+    hipLaunchKernelGGL(ch_grind_kernel, dim3(range / kThreads, batch), dim3(kThreads), 0, stream, ch, witness, bits,
+                       range * (uint32_t)r, consts);
   hipLaunchKernelGGL(ch_grind_tail_kernel, dim3(batch), dim3(kThreads), 0, stream, ch, witness, bits, consts);
 }
 void launch_ch_queries(hipStream_t stream, DevChallenger* ch, const uint32_t* witness, uint32_t* indices,
