@@ -47,8 +47,8 @@ constexpr int kSrcGlb = 1, kPre = 2, kDstLds = 4, kDstGlb = 8, kPost = 16;
 //   DIF: stages s, s-1, .., s-R+1 (block sizes 2^s ..); group stride q = 2^(s-R)
 //   DIT: stages s, s+1, .., s+R-1;                      group stride q = 2^(s-1)
 template <int R, bool DIF, int NC, int F, bool FULL>
-__device__ __forceinline__ void ntt_pass(const PassIo& io, const uint32_t* __restrict__ tw, int logh, int tw_logh,
-                                         int s, int ncols, int tid) {
+__device__ __forceinline__ void ntt_pass(const PassIo& io, const uint32_t* __restrict__ tw, int logh, int s,
+                                         int ncols, int tid) {
   constexpr int E = 1 << R;
   const int qlog = DIF ? s - R : s - 1;
   const int q = 1 << qlog;
@@ -117,16 +117,16 @@ __device__ __forceinline__ void ntt_pass(const PassIo& io, const uint32_t* __res
 }
 
 template <bool DIF, int NC, int F>
-__device__ __forceinline__ void ntt_pass_f(int r, const PassIo& io, const uint32_t* tw, int logh, int tw_logh, int s,
-                                           int ncols, int tid) {
+__device__ __forceinline__ void ntt_pass_f(int r, const PassIo& io, const uint32_t* tw, int logh, int s, int ncols,
+                                           int tid) {
   if (ncols == NC) {
-    if (r == 3) ntt_pass<3, DIF, NC, F, true>(io, tw, logh, tw_logh, s, ncols, tid);
-    else if (r == 2) ntt_pass<2, DIF, NC, F, true>(io, tw, logh, tw_logh, s, ncols, tid);
-    else ntt_pass<1, DIF, NC, F, true>(io, tw, logh, tw_logh, s, ncols, tid);
+    if (r == 3) ntt_pass<3, DIF, NC, F, true>(io, tw, logh, s, ncols, tid);
+    else if (r == 2) ntt_pass<2, DIF, NC, F, true>(io, tw, logh, s, ncols, tid);
+    else ntt_pass<1, DIF, NC, F, true>(io, tw, logh, s, ncols, tid);
   } else {
-    if (r == 3) ntt_pass<3, DIF, NC, F, false>(io, tw, logh, tw_logh, s, ncols, tid);
-    else if (r == 2) ntt_pass<2, DIF, NC, F, false>(io, tw, logh, tw_logh, s, ncols, tid);
-    else ntt_pass<1, DIF, NC, F, false>(io, tw, logh, tw_logh, s, ncols, tid);
+    if (r == 3) ntt_pass<3, DIF, NC, F, false>(io, tw, logh, s, ncols, tid);
+    else if (r == 2) ntt_pass<2, DIF, NC, F, false>(io, tw, logh, s, ncols, tid);
+    else ntt_pass<1, DIF, NC, F, false>(io, tw, logh, s, ncols, tid);
   }
 }
 
@@ -135,9 +135,9 @@ __device__ __forceinline__ void ntt_pass_f(int r, const PassIo& io, const uint32
 // the list is a programming error and traps.
 template <bool DIF, int NC, int F0, int... Fs>
 __device__ __forceinline__ void ntt_pass_sel(int flags, int r, const PassIo& io, const uint32_t* tw, int logh,
-                                             int tw_logh, int s, int ncols, int tid) {
-  if (flags == F0) ntt_pass_f<DIF, NC, F0>(r, io, tw, logh, tw_logh, s, ncols, tid);
-  else if constexpr (sizeof...(Fs) > 0) ntt_pass_sel<DIF, NC, Fs...>(flags, r, io, tw, logh, tw_logh, s, ncols, tid);
+                                             int s, int ncols, int tid) {
+  if (flags == F0) ntt_pass_f<DIF, NC, F0>(r, io, tw, logh, s, ncols, tid);
+  else if constexpr (sizeof...(Fs) > 0) ntt_pass_sel<DIF, NC, Fs...>(flags, r, io, tw, logh, s, ncols, tid);
   else __builtin_trap();
 }
 
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kLdeThreads) void lde_lds_kernel(const uint32_t* __
         io.lds_stride = padded;
         ntt_pass_sel<true, NC, kDstLds, kSrcGlb | kDstLds, kDstLds | kDstGlb | kPost, kDstLds | kPost,
                      kSrcGlb | kDstLds | kDstGlb | kPost, kSrcGlb | kDstLds | kPost>(pass_flags(io), r, io, tw_inv, logh,
-                                                                                    logh, s, nc, tid);
+                                                                                    s, nc, tid);
         __syncthreads();
         s -= r;
         first = false;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kLdeThreads) void lde_lds_kernel(const uint32_t* __
         io.src_glb_stride = 0;
         io.dst_glb_stride = (size_t)2 * h;  // adjacent columns are 2 cosets apart in the LDE
         io.lds_stride = padded;
-        ntt_pass_sel<false, NC, kDstLds, kPre | kDstLds, kDstGlb, kPre | kDstGlb>(pass_flags(io), r, io, tw_fwd, logh, logh,
+        ntt_pass_sel<false, NC, kDstLds, kPre | kDstLds, kDstGlb, kPre | kDstGlb>(pass_flags(io), r, io, tw_fwd, logh,
                                                                                   s, nc, tid);
         __syncthreads();
         s += r;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kLdeThreads) void ntt_chunk_kernel(const uint32_t* 
     io.lds_stride = 0;
     ntt_pass_sel<DIF, 1, kDstLds, kSrcGlb | kDstLds, kSrcGlb | kPre | kDstLds, kDstGlb, kDstGlb | kPost, kSrcGlb | kDstGlb,
                  kSrcGlb | kDstGlb | kPost, kSrcGlb | kPre | kDstGlb, kSrcGlb | kPre | kDstGlb | kPost>(
-        pass_flags(io), r, io, tw, l2, logh, s, 1, tid);
+        pass_flags(io), r, io, tw, l2, s, 1, tid);
     __syncthreads();
     s = DIF ? s - r : s + r;
     first = false;

@@ -21,86 +21,6 @@ struct P2Consts {
   int64_t int_last[16];    // all elements after internal round 12
 };
 
-#if defined(__HIP_DEVICE_COMPILE__)
-#define ZKSP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define ZKSP_SCHED_FENCE() ((void)0)
-#endif
-
-// Montgomery products of N independent pairs, written stage by stage with the
-// instruction order pinned (hipcc otherwise emits each product as one serial
-// mad -> mul_lo -> mad chain through a shared temporary).
-//
-// "Raw" products skip the final conditional subtraction: for operands a, b the
-// result is < a*b/2^32 + p.  With A = p/2^32 = 0.46875: reduced x reduced gives
-// < 1.469p, and the S-box below keeps every intermediate inside the two
-// conditions that matter: a*b + m*p < 2^64 (a*b < 1.1333 * 2^32 * p) and the
-// result < 2^32.
-template <int N>
-ZKSP_HD void fp_mul_batch_raw(uint32_t* out, const uint32_t* a, const uint32_t* b) {
-  uint64_t t[N];
-  uint32_t m[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) t[i] = (uint64_t)a[i] * b[i];
-  ZKSP_SCHED_FENCE();
-#pragma unroll
-  for (int i = 0; i < N; ++i) m[i] = (uint32_t)t[i] * kMontyNegMu;
-  ZKSP_SCHED_FENCE();
-#pragma unroll
-  for (int i = 0; i < N; ++i) t[i] = t[i] + (uint64_t)m[i] * kP;
-  ZKSP_SCHED_FENCE();
-#pragma unroll
-  for (int i = 0; i < N; ++i) out[i] = (uint32_t)(t[i] >> 32);
-}
-
-// v < 2p  ->  v mod p
-ZKSP_HD uint32_t fp_correct(uint32_t v) {
-  uint32_t w = v - kP;
-  return v < w ? v : w;
-}
-
-template <int N>
-ZKSP_HD void fp_mul_batch(Fp* out, const Fp* a, const Fp* b) {
-  uint32_t r[N], av[N], bv[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) { av[i] = a[i].v; bv[i] = b[i].v; }
-  fp_mul_batch_raw<N>(r, av, bv);
-#pragma unroll
-  for (int i = 0; i < N; ++i) out[i] = Fp::raw(fp_correct(r[i]));
-  ZKSP_SCHED_FENCE();
-}
-
-ZKSP_HD Fp p2_sbox(Fp x) {
-  Fp x2 = x.sqr(), x3 = x2 * x, x4 = x2.sqr();
-  return x3 * x4;
-}
-
-// x -> (x + rc)^7 on N lanes with lazy reduction:
-//   x  < p            (reduced sum)
-//   x2 = x*x   raw  < 1.469p
-//   x3 = x2*x  raw  < 1.689p      (1.469 p^2 < 1.1333 * 2^32 p)
-//   x4 = x2*x2 raw  < 2.012p      (2.158 p^2 = 1.0116 * 2^32 p < 1.1333 * 2^32 p; 2.012p < 2^32)
-//   x4 corrected once < 1.012p
-//   x7 = x3*x4 raw  < 1.801p      (1.709 p^2 < 1.1333 * 2^32 p), corrected once -> < p
-template <int N>
-ZKSP_HD void p2_sbox_layer(Fp* s, const uint32_t* __restrict__ rc) {
-  uint32_t x[N], x2[N], x3[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) x[i] = (s[i] + Fp::raw(rc[i])).v;
-  fp_mul_batch_raw<N>(x2, x, x);
-  ZKSP_SCHED_FENCE();
-  fp_mul_batch_raw<N>(x3, x2, x);
-  ZKSP_SCHED_FENCE();
-  fp_mul_batch_raw<N>(x2, x2, x2);
-#pragma unroll
-  for (int i = 0; i < N; ++i) x2[i] = fp_correct(x2[i]);
-  ZKSP_SCHED_FENCE();
-  fp_mul_batch_raw<N>(x, x3, x2);
-#pragma unroll
-  for (int i = 0; i < N; ++i) s[i] = Fp::raw(fp_correct(x[i]));
-  ZKSP_SCHED_FENCE();
-}
-
 // ---------------------------------------------------------------------------
 // Signed lazy permutation.
 //
@@ -128,13 +48,11 @@ ZKSP_HD void p2_sbox_layer(Fp* s, const uint32_t* __restrict__ rc) {
 // ---------------------------------------------------------------------------
 // the arithmetic itself is field.cuh's signed lazy layer
 constexpr int32_t p2s_centre(uint32_t v) { return fps_centre_const(v); }
-ZKSP_HD int32_t p2s_redc(int64_t t) { return fps_redc(t); }
 ZKSP_HD int32_t p2s_sbox(int32_t x) {
   const int32_t x2 = fps_mul(x, x), x3 = fps_mul(x2, x), x4 = fps_mul(x2, x2);
   return fps_mul(x3, x4);
 }
 ZKSP_HD int32_t p2s_reduce_wide(int64_t y, int64_t add) { return fps_reduce_wide(y, add); }
-ZKSP_HD uint32_t p2s_canon(int32_t t) { return fps_canon(t); }
 
 // circ(2*M4, M4, M4, M4), M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]], then + next constants
 ZKSP_HD void p2s_external_linear(int32_t* s, const int64_t* __restrict__ add) {
@@ -176,7 +94,7 @@ ZKSP_HD void p2s_internal_round(int32_t* s, const P2Consts* __restrict__ k, cons
   for (int i = 0; i < 16; ++i) {
     int64_t t = (int64_t)s[i] * (int64_t)k->sdiag[i] + sr;
     if (FULL || i == 0) t += add[FULL ? i : 0];
-    s[i] = p2s_redc(t);
+    s[i] = fps_redc(t);
   }
 }
 
@@ -206,7 +124,7 @@ ZKSP_HD void p2_permute(Fp* s, const P2Consts* __restrict__ k) {
   for (int i = 0; i < 16; ++i) t[i] = (int32_t)s[i].v;
   p2_permute_signed(t, k);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) s[i] = Fp::raw(p2s_canon(t[i]));
+  for (int i = 0; i < 16; ++i) s[i] = Fp::raw(fps_canon(t[i]));
 }
 
 }  // namespace zksp
