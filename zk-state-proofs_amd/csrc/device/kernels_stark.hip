@@ -124,8 +124,8 @@ struct QuotCtx {
   size_t cs;
   Fp first, trans, last;
   const uint32_t* ap;  // this proof's alpha powers (Fp4 each), indexed by constraint
-  Fp4 acc;
-  uint64_t lazy[4];    // unreduced sum of up to two alpha^k_i * c_k products per coordinate
+  Fp4 acc;             // extension-valued constraints, and the folded total at the end
+  int64_t lazy[4];     // signed lazy sum of alpha^k_i * c_k per coordinate (field.cuh)
   int pending;
   // LogUp bus
   const uint32_t* ploc;  // running-sum columns at this point / the next row (stride cs)
@@ -139,20 +139,24 @@ struct QuotCtx {
   __device__ __forceinline__ F is_trans() const { return trans; }
   __device__ __forceinline__ F is_last() const { return last; }
   __device__ __forceinline__ F one() const { return Fp::one(); }
-  // acc += alpha^k * v, coordinate by coordinate.  The four products are
-  // accumulated unreduced (one v_mad_u64_u32 each); two products stay below the
-  // Montgomery-reduction input bound (2 p^2 < 2^64 - 2^32 p), so one reduction
-  // serves two constraints.
+  // acc += alpha^k * v, coordinate by coordinate: one multiply-add each into a signed 64-bit
+  // accumulator.  alpha^k is uniform, so centring it is scalar work; v is canonical, so
+  // |term| < p^2 / 2 and four terms fit between shrinks (a shrink keeps the residue and
+  // brings the accumulator below 2^59).  One reduction per coordinate at the very end.
   __device__ __forceinline__ void emit_at(int k, F v) {
     const uint32_t* p = ap + 4 * (size_t)k;  // wave-uniform address: scalar loads
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lazy[i] += (uint64_t)p[i] * v.v;
-    if (++pending == 2) flush();
+    for (int i = 0; i < 4; ++i) lazy[i] += (int64_t)fps_centre(p[i]) * (int64_t)v.v;
+    if (++pending == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lazy[i] = (int64_t)fps_fold(lazy[i]) * (int64_t)kRModP;
+      pending = 0;
+    }
   }
   __device__ __forceinline__ void flush() {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      acc.c[i] = acc.c[i] + Fp::raw(Fp::reduce(lazy[i]));
+      acc.c[i] = acc.c[i] + Fp::raw(fps_canon(fps_fold(lazy[i])));
       lazy[i] = 0;
     }
     pending = 0;
