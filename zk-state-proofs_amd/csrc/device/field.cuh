@@ -142,6 +142,7 @@ struct Fp4 {
 //                      (2^32 == c mod p, so T == hi * c + lo first)
 //   fps_reduce_wide(y) |y| < 2^63            : y mod p (same form as y), in (-0.5p, 0.634p)
 //                      (y * R == lo * c + hi * K, K = c^2 mod p centred, then fps_redc)
+//   fps_reduce_small(y) |y| < 2^37           : y mod p, |result| < 0.55p, one multiplication
 //   fps_canon(t)       |t| < p               : the canonical residue
 // A product of two signed words with |a|, |b| < 2^31 satisfies the fps_redc bound and
 // comes back below 1.034p: closed under multiplication with no conditional subtraction.
@@ -165,6 +166,19 @@ ZKSP_HD int32_t fps_reduce_wide(int64_t y, int64_t add = 0) {
   int64_t t = (int64_t)hi * (int64_t)kR2Centred + add;
   t += (int64_t)((uint64_t)lo * kRModP);
   return fps_redc(t);
+}
+// |y| < 2^37 (a 64-bit sum of a few dozen words) -> y mod p as a signed word, |t| < 0.55p, with
+// ONE multiplication: q = round(y / p) is estimated from the top bits, s = y >> 26 (|s| < 2^11),
+// q = (s * 2185 + 2^15) >> 16 (2185 / 2^16 equals 2^26 / p to 2e-4, so |q - y/p| < 0.55), and
+// t = y - q p is taken in 32 bits.  Same residue class as y (no factor of R involved).
+ZKSP_HD int32_t fps_reduce_small(int64_t y) {
+  const int32_t s = (int32_t)(y >> 26);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int32_t q = (__mul24(s, 2185) + 32768) >> 16;
+#else
+  const int32_t q = (s * 2185 + 32768) >> 16;
+#endif
+  return (int32_t)((uint32_t)y - (uint32_t)q * kP);
 }
 ZKSP_HD uint32_t fps_canon(int32_t t) {
   const uint32_t u = (uint32_t)t, w = u + kP;

@@ -17,6 +17,7 @@ struct P2Consts {
   // before it, as rc * R^2 mod p (the reduction divides by R = 2^32):
   int32_t sdiag[16];       // diag centred into (-p/2, p/2]
   int64_t lin_add[9][16];  // layer 0 = initial linear layer, layer r+1 closes external round r
+  uint32_t lin_rc[9][16];  // the same constants as plain Montgomery-form words (joined to a wide sum)
   int64_t int_add[13];     // element 0 after internal round r (r = 0..11)
   int64_t int_last[16];    // all elements after internal round 12
 };
@@ -54,8 +55,10 @@ ZKSP_HD int32_t p2s_sbox(int32_t x) {
 }
 ZKSP_HD int32_t p2s_reduce_wide(int64_t y, int64_t add) { return fps_reduce_wide(y, add); }
 
-// circ(2*M4, M4, M4, M4), M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]], then + next constants
-ZKSP_HD void p2s_external_linear(int32_t* s, const int64_t* __restrict__ add) {
+// circ(2*M4, M4, M4, M4), M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]], then + next constants.
+// rc[i]: the next round's constant as a canonical Montgomery-form word; it joins the 64-bit sum,
+// |sum| < 36.2p + p < 2^36.2, which fps_reduce_small brings back below 0.55p with one multiply.
+ZKSP_HD void p2s_external_linear(int32_t* s, const uint32_t* __restrict__ rc) {
   int64_t y[16];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -70,7 +73,7 @@ ZKSP_HD void p2s_external_linear(int32_t* s, const int64_t* __restrict__ add) {
   for (int j = 0; j < 4; ++j) {
     const int64_t col = (y[j] + y[4 + j]) + (y[8 + j] + y[12 + j]);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) s[4 * c + j] = p2s_reduce_wide(y[4 * c + j] + col, add[4 * c + j]);
+    for (int c = 0; c < 4; ++c) s[4 * c + j] = fps_reduce_small(y[4 * c + j] + col + (int64_t)rc[4 * c + j]);
   }
 }
 
@@ -100,12 +103,12 @@ ZKSP_HD void p2s_internal_round(int32_t* s, const P2Consts* __restrict__ k, cons
 
 // state: signed words, |s_i| < 1.034p (canonical residues qualify); same on exit
 ZKSP_HD void p2_permute_signed(int32_t* s, const P2Consts* __restrict__ k) {
-  p2s_external_linear(s, k->lin_add[0]);
+  p2s_external_linear(s, k->lin_rc[0]);
 #pragma unroll 1
   for (int r = 0; r < 4; ++r) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) s[i] = p2s_sbox(s[i]);
-    p2s_external_linear(s, k->lin_add[r + 1]);
+    p2s_external_linear(s, k->lin_rc[r + 1]);
   }
 #pragma unroll 1
   for (int r = 0; r < 12; ++r) p2s_internal_round<false>(s, k, &k->int_add[r]);
@@ -114,7 +117,7 @@ ZKSP_HD void p2_permute_signed(int32_t* s, const P2Consts* __restrict__ k) {
   for (int r = 4; r < 8; ++r) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) s[i] = p2s_sbox(s[i]);
-    p2s_external_linear(s, k->lin_add[r + 1]);
+    p2s_external_linear(s, k->lin_rc[r + 1]);
   }
 }
 

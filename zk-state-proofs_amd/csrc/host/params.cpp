@@ -53,10 +53,11 @@ void build_p2_consts(P2Consts* out) {
   for (int i = 0; i < 16; ++i) out->sdiag[i] = p2s_centre(out->diag[i]);
   for (int l = 0; l < 9; ++l)
     for (int i = 0; i < 16; ++i) {
-      int64_t v = 0;
-      if (l == 4) v = i == 0 ? times_r(out->internal[0]) : 0;  // external round 3 -> internal round 0
-      else if (l < 8) v = times_r(out->ext[l][i]);              // layer l precedes external round l
-      out->lin_add[l][i] = v;                                   // layer 8 closes the permutation
+      uint32_t v = 0;
+      if (l == 4) v = i == 0 ? out->internal[0] : 0;  // external round 3 -> internal round 0
+      else if (l < 8) v = out->ext[l][i];              // layer l precedes external round l
+      out->lin_rc[l][i] = v;                           // layer 8 closes the permutation
+      out->lin_add[l][i] = v ? times_r(v) : 0;         // R^2-scaled form for the cooperative variant
     }
   for (int r = 0; r < 13; ++r) out->int_add[r] = r < 12 ? times_r(out->internal[r + 1]) : 0;
   for (int i = 0; i < 16; ++i) out->int_last[i] = times_r(out->ext[4][i]);
