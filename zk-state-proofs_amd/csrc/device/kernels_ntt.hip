@@ -227,6 +227,164 @@ __global__ __launch_bounds__(kLdeThreads) void lde_lds_kernel(const uint32_t* __
 }
 
 // ---------------------------------------------------------------------------
+// Heights 2^9 .. 2^11 (the bench workload is 2^11): ONE LDS image per column.
+//
+// The last inverse pass and the first forward pass both have unit group stride and the same
+// radix RB = ((logh - 1) mod 3) + 1, so they work on the same groups of 2^RB consecutive
+// elements, and at these heights a thread owns at most 16 of them per NC = 2 columns.  The
+// coefficients therefore stay in registers across the boundary, for both cosets: the workspace
+// image of lde_lds_kernel disappears, workgroups per CU double (LDS was the limiter: 4 -> 8), the
+// last inverse pass writes no LDS and the two first forward passes read none.  The height is a
+// template parameter, so every stage number, stride and padded LDS offset below is a constant.
+// ---------------------------------------------------------------------------
+template <int LOGH, int NC, bool FULL>
+__device__ __forceinline__ void lde_fixed_group(const uint32_t* __restrict__ src, uint32_t* __restrict__ cdst,
+                                                uint32_t* __restrict__ dst, const uint32_t* __restrict__ tw_fwd,
+                                                const uint32_t* __restrict__ tw_inv, const uint32_t* __restrict__ isc,
+                                                const uint32_t* __restrict__ out_scale_br, Fp* buf, int nc, int tid) {
+  constexpr int H = 1 << LOGH, PADDED = H + (H >> 3) + 4;
+  constexpr int RB = ((LOGH - 1) % 3) + 1, EB = 1 << RB, NGB = H >> RB;
+  constexpr int ITERS = NGB > kLdeThreads ? NGB / kLdeThreads : 1;
+  static_assert((LOGH - RB) % 3 == 0 && LOGH - RB >= 3, "pass schedule");
+  static_assert(ITERS * NC * EB <= 16, "coefficients held per thread");
+  PassIo io;
+  io.src_lds = buf;
+  io.dst_lds = buf;
+  io.src_glb = src;
+  io.dst_glb = nullptr;
+  io.pre_scale = io.post_scale = nullptr;
+  io.src_glb_stride = (size_t)H;
+  io.dst_glb_stride = (size_t)2 * H;  // adjacent columns are 2 cosets apart in the LDE
+  io.lds_stride = PADDED;
+  // ---- inverse transform, all passes but the last: DIF stages LOGH .. RB + 1 ----
+  ntt_pass<3, true, NC, kSrcGlb | kDstLds, FULL>(io, tw_inv, LOGH, LOGH, nc, tid);
+  __syncthreads();
+#pragma unroll
+  for (int s = LOGH - 3; s > RB; s -= 3) {
+    ntt_pass<3, true, NC, kDstLds, FULL>(io, tw_inv, LOGH, s, nc, tid);
+    __syncthreads();
+  }
+  // ---- boundary: last inverse pass in registers (stages RB .. 1, unit stride: the twiddles are
+  // the same for every group), rescale, optionally publish the coefficients ----
+  Fp keep[ITERS][NC][EB];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int g = tid + it * kLdeThreads;
+    const bool act = NGB >= kLdeThreads || g < NGB;
+    const int base = g << RB;
+#pragma unroll
+    for (int k = 0; k < EB; ++k)
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        keep[it][c][k] = (act && (FULL || c < nc)) ? buf[c * PADDED + lds_idx(base + k)] : Fp::zero();
+#pragma unroll
+    for (int st = 0; st < RB; ++st) {
+      const int hk = EB >> (st + 1), stage = RB - st;
+#pragma unroll
+      for (int k = 0; k < EB; ++k) {
+        if ((k & hk) != 0) continue;
+        const Fp w = Fp::raw(tw_inv[(1 << (stage - 1)) + (k & (hk - 1))]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const Fp u = keep[it][c][k], v = keep[it][c][k + hk];
+          keep[it][c][k] = u + v;
+          keep[it][c][k + hk] = (u - v) * w;
+        }
+      }
+    }
+    if (act) {
+#pragma unroll
+      for (int k = 0; k < EB; ++k) {
+        const Fp sc = Fp::raw(isc[base + k]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          keep[it][c][k] = keep[it][c][k] * sc;
+          if (cdst && (FULL || c < nc)) cdst[(size_t)c * H + base + k] = keep[it][c][k].v;
+        }
+      }
+    }
+  }
+  __syncthreads();  // every thread has taken its coefficients out of the image
+  // ---- two forward transforms: DIT stages 1 .. LOGH, the first pass from registers ----
+#pragma unroll 1
+  for (int cs = 0; cs < 2; ++cs) {
+    const uint32_t* osc = out_scale_br + (size_t)cs * H;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int g = tid + it * kLdeThreads;
+      const bool act = NGB >= kLdeThreads || g < NGB;
+      const int base = g << RB;
+      Fp y[NC][EB];
+#pragma unroll
+      for (int k = 0; k < EB; ++k) {
+        const Fp sc = act ? Fp::raw(osc[base + k]) : Fp::zero();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) y[c][k] = keep[it][c][k] * sc;
+      }
+#pragma unroll
+      for (int st = 0; st < RB; ++st) {
+        const int hk = 1 << st, stage = 1 + st;
+#pragma unroll
+        for (int k = 0; k < EB; ++k) {
+          if ((k & hk) != 0) continue;
+          const Fp w = Fp::raw(tw_fwd[(1 << (stage - 1)) + (k & (hk - 1))]);
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const Fp u = y[c][k], t = y[c][k + hk] * w;
+            y[c][k] = u + t;
+            y[c][k + hk] = u - t;
+          }
+        }
+      }
+      if (act) {
+#pragma unroll
+        for (int k = 0; k < EB; ++k)
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+            if (FULL || c < nc) buf[c * PADDED + lds_idx(base + k)] = y[c][k];
+      }
+    }
+    __syncthreads();
+    io.src_glb = nullptr;
+#pragma unroll
+    for (int s = 1 + RB; s + 3 <= LOGH; s += 3) {
+      io.dst_glb = nullptr;
+      ntt_pass<3, false, NC, kDstLds, FULL>(io, tw_fwd, LOGH, s, nc, tid);
+      __syncthreads();
+    }
+    io.dst_glb = dst + (size_t)cs * H;
+    ntt_pass<3, false, NC, kDstGlb, FULL>(io, tw_fwd, LOGH, LOGH - 2, nc, tid);
+    __syncthreads();  // the image is rewritten by the next coset / the next column group
+  }
+}
+
+template <int LOGH, int NC>
+__global__ __launch_bounds__(kLdeThreads) void lde_fixed_kernel(const uint32_t* __restrict__ in,
+                                                                uint32_t* __restrict__ coefs_br,
+                                                                uint32_t* __restrict__ out,
+                                                                const uint32_t* __restrict__ tw_fwd,
+                                                                const uint32_t* __restrict__ tw_inv,
+                                                                const uint32_t* __restrict__ in_scale_br,
+                                                                int scale_sel_shift, int scale_sel_mask,
+                                                                const uint32_t* __restrict__ out_scale_br, size_t ncols) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  constexpr int H = 1 << LOGH;
+  Fp* buf = reinterpret_cast<Fp*>(smem);  // NC images
+  const int tid = threadIdx.x;
+  const size_t ngroups = (ncols + NC - 1) / NC;
+  for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const size_t col = grp * NC;
+    const int nc = (int)((ncols - col) < (size_t)NC ? (ncols - col) : (size_t)NC);
+    const uint32_t* src = in + col * (size_t)H;
+    const uint32_t* isc = in_scale_br + (size_t)((col >> scale_sel_shift) & (size_t)scale_sel_mask) * H;
+    uint32_t* cdst = coefs_br ? coefs_br + col * (size_t)H : nullptr;
+    uint32_t* dst = out + col * 2 * (size_t)H;
+    if (nc == NC) lde_fixed_group<LOGH, NC, true>(src, cdst, dst, tw_fwd, tw_inv, isc, out_scale_br, buf, nc, tid);
+    else lde_fixed_group<LOGH, NC, false>(src, cdst, dst, tw_fwd, tw_inv, isc, out_scale_br, buf, nc, tid);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Heights above 2^14 (the as-committed guest's 2^21-row chips, SURVEY.md section 8
 // row f1): the column no longer fits LDS, so the H = H1*H2 transform is split the
 // four-step way into two LDS-staged passes per direction:
@@ -379,9 +537,23 @@ void launch_lde(hipStream_t stream, const uint32_t* in, uint32_t* coefs_br, uint
   }
   const size_t h = (size_t)1 << logh;
   const int nc = lde_cols_per_block(logh);
-  const size_t smem = (size_t)nc * 2 * sizeof(uint32_t) * (h + (h >> 3) + 4);
   const size_t groups = (ncols + nc - 1) / nc;
   const unsigned grid = (unsigned)(groups < 65536 ? groups : 65536);
+  static const bool fixed_off = getenv("ZKSP_LDE_GENERIC") != nullptr;  // debugging switch
+  if (nc == 2 && logh >= 9 && logh <= 11 && !fixed_off) {
+    const size_t smem1 = (size_t)2 * sizeof(uint32_t) * (h + (h >> 3) + 4);  // one image per column
+    if (logh == 11)
+      hipLaunchKernelGGL((lde_fixed_kernel<11, 2>), dim3(grid), dim3(kLdeThreads), smem1, stream, in, coefs_br, out, tw_fwd,
+                         tw_inv, in_scale_br, scale_sel_shift, scale_sel_mask, out_scale_br, ncols);
+    else if (logh == 10)
+      hipLaunchKernelGGL((lde_fixed_kernel<10, 2>), dim3(grid), dim3(kLdeThreads), smem1, stream, in, coefs_br, out, tw_fwd,
+                         tw_inv, in_scale_br, scale_sel_shift, scale_sel_mask, out_scale_br, ncols);
+    else
+      hipLaunchKernelGGL((lde_fixed_kernel<9, 2>), dim3(grid), dim3(kLdeThreads), smem1, stream, in, coefs_br, out, tw_fwd,
+                         tw_inv, in_scale_br, scale_sel_shift, scale_sel_mask, out_scale_br, ncols);
+    return;
+  }
+  const size_t smem = (size_t)nc * 2 * sizeof(uint32_t) * (h + (h >> 3) + 4);
   if (nc == 4)
     hipLaunchKernelGGL(lde_lds_kernel<4>, dim3(grid), dim3(kLdeThreads), smem, stream, in, coefs_br, out, tw_fwd, tw_inv,
                        in_scale_br, scale_sel_shift, scale_sel_mask, out_scale_br, logh, ncols);
