@@ -132,7 +132,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="proofs proven in lockstep per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024,
+                    help="proofs proven in lockstep per GPU per step (1024 uses 92 GB of the 288 GB; measured 3600 / 3710 / 3800 proofs/s at 256 / 512 / 1024)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-single", action="store_true", help="skip the batch-of-1 latency section (profiling runs)")

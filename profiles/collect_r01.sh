@@ -27,7 +27,8 @@ def counter(name, sub):
             acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), max(v), len(v)) for k, v in acc.items()}
 open(o + "/kernel_stats.csv", "w").write(open(glob.glob(o + "/stats/*/*kernel_stats.csv")[0]).read())
-out = {"batch": 256, "units": "KB per dispatch (avg, max, dispatches); FETCH_SIZE reads half the streamed bytes on gfx950",
+batch = json.load(open(o + "/bench_stats.json"))["config"]["batch_per_gpu"]
+out = {"batch": batch, "units": "KB per dispatch (avg, max, dispatches); FETCH_SIZE reads half the streamed bytes on gfx950",
        "FETCH_SIZE": counter("FETCH_SIZE", "fetch"), "WRITE_SIZE": counter("WRITE_SIZE", "write")}
 json.dump(out, open(o + "/hbm_counters.json", "w"), indent=1)
 for k in ("FETCH_SIZE", "WRITE_SIZE"):

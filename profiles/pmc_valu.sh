@@ -31,7 +31,8 @@ for k, c in acc.items():
             avg["cycles_per_valu_inst"] = n_simd * avg["GRBM_GUI_ACTIVE"] / n_xcd / avg["SQ_INSTS_VALU"]
     avg["dispatches"] = len(next(iter(c.values())))
     out[k] = avg
-json.dump({"batch": 256, "n_simd": n_simd, "n_xcd": n_xcd, "note": "per-dispatch averages; cycles_per_valu_inst = n_simd*(GRBM_GUI_ACTIVE/n_xcd)/SQ_INSTS_VALU",
+batch = json.load(open("$O/a.json"))["config"]["batch_per_gpu"]
+json.dump({"batch": batch, "n_simd": n_simd, "n_xcd": n_xcd, "note": "per-dispatch averages; cycles_per_valu_inst = n_simd*(GRBM_GUI_ACTIVE/n_xcd)/SQ_INSTS_VALU",
            "kernels": out}, open("$O/valu_counters.json", "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0))[:12]:
     print("%-44s cycles %.4g valu_insts %.4g cycles/inst %.2f" % (k[:44], v.get("GRBM_GUI_ACTIVE", 0), v.get("SQ_INSTS_VALU", 0), v.get("cycles_per_valu_inst", 0)))
