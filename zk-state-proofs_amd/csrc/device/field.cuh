@@ -140,8 +140,6 @@ struct Fp4 {
 //                      (centred Montgomery reduction: m = lo(T) * (-p^-1) taken as signed)
 //   fps_fold(T)        any |T| < 2^63        : T / 2^32 mod p, |result| < 0.57p
 //                      (2^32 == c mod p, so T == hi * c + lo first)
-//   fps_reduce_wide(y) |y| < 2^63            : y mod p (same form as y), in (-0.5p, 0.634p)
-//                      (y * R == lo * c + hi * K, K = c^2 mod p centred, then fps_redc)
 //   fps_reduce_small(y) |y| < 2^37           : y mod p, |result| < 0.55p, one multiplication
 //   fps_canon(t)       |t| < p               : the canonical residue
 // A product of two signed words with |a|, |b| < 2^31 satisfies the fps_redc bound and
@@ -159,13 +157,6 @@ ZKSP_HD int32_t fps_mul(int32_t a, int32_t b) { return fps_redc((int64_t)a * (in
 ZKSP_HD int32_t fps_fold(int64_t t) {
   const int32_t hi = (int32_t)(t >> 32);
   return fps_redc((int64_t)hi * (int64_t)kRModP + (int64_t)(uint32_t)t);
-}
-ZKSP_HD int32_t fps_reduce_wide(int64_t y, int64_t add = 0) {
-  const uint32_t lo = (uint32_t)y;
-  const int32_t hi = (int32_t)(y >> 32);
-  int64_t t = (int64_t)hi * (int64_t)kR2Centred + add;
-  t += (int64_t)((uint64_t)lo * kRModP);
-  return fps_redc(t);
 }
 // |y| < 2^37 (a 64-bit sum of a few dozen words) -> y mod p as a signed word, |t| < 0.55p, with
 // ONE multiplication: q = round(y / p) is estimated from the top bits, s = y >> 26 (|s| < 2^11),

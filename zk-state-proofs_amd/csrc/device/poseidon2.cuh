@@ -53,7 +53,6 @@ ZKSP_HD int32_t p2s_sbox(int32_t x) {
   const int32_t x2 = fps_mul(x, x), x3 = fps_mul(x2, x), x4 = fps_mul(x2, x2);
   return fps_mul(x3, x4);
 }
-ZKSP_HD int32_t p2s_reduce_wide(int64_t y, int64_t add) { return fps_reduce_wide(y, add); }
 
 // circ(2*M4, M4, M4, M4), M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]], then + next constants.
 // rc[i]: the next round's constant as a canonical Montgomery-form word; it joins the 64-bit sum,
