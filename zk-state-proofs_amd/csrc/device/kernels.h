@@ -107,6 +107,24 @@ void launch_fri_fold(hipStream_t stream, const uint32_t* in, size_t in_stride, u
                      const uint32_t* beta, size_t beta_stride, const uint32_t* tw_inv, int tw_shift, uint32_t xinv0,
                      uint32_t xinv1, int loghk, int batch);
 // leaves of layer k: (f[c][m], f[c][m+Hk/2]) -> tree [batch][2*Hk-1][8], full tree built
+// Commit, transcript and fold of the FRI layers k_start .. logh-1 (each of at most 512 leaves)
+// in one launch, one workgroup per proof.  loff_start / toff_start: words into a proof's layer
+// buffer / digests into its tree buffer where layer k_start begins; xinv[2k + c] as launch_fri_fold.
+struct FriTailArgs {
+  uint32_t* layers;
+  size_t layer_stride;
+  uint32_t* trees;
+  size_t tree_stride;
+  DevChallenger* ch;
+  uint32_t* betas;
+  size_t beta_stride;
+  const uint32_t* tw_inv;
+  uint32_t xinv[32];
+  int logh, k_start;
+  size_t loff_start, toff_start;
+};
+constexpr int kFriTailMaxLogLeaves = 9;
+void launch_fri_tail(hipStream_t stream, const FriTailArgs& a, int batch, const P2Consts* consts);
 void launch_fri_commit(hipStream_t stream, const uint32_t* layer, size_t layer_stride, int loghk, uint32_t* tree,
                        size_t tree_stride, int batch, const P2Consts* consts);
 

@@ -8,7 +8,7 @@
 // once, fully coalesced.  Upper layers: one lane per parent; once a layer fits one
 // workgroup the rest of the tree is finished in a single launch.
 #include "kernels.h"
-#include "poseidon2_coop.cuh"
+#include "merkle_coop.cuh"
 
 namespace zksp {
 
@@ -78,33 +78,8 @@ __global__ __launch_bounds__(kHashThreads) void compress_layer_kernel(uint32_t* 
   compress_pair(t + (in_off + 2 * (size_t)i) * 8, t + (out_off + (size_t)i) * 8, consts);
 }
 
-// Finishes a tree from a layer of `count` (<= 2*kHashThreads) digests, one workgroup
-// per proof.  These levels are a chain of dependent permutations with little
-// width, so they use the cooperative 16-lane permutation: 64 compressions in
-// flight per workgroup, each about 5x shorter than the lane-per-state form.
-constexpr int kTopThreads = 1024;
-constexpr int kTopGroups = kTopThreads / 16;
-
-__device__ __forceinline__ void coop_tree_levels(uint32_t* __restrict__ t, size_t in_off, int count,
-                                                 const CoopConsts& cc, const P2Consts* __restrict__ consts) {
-  const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  while (count > 1) {
-    const int parents = count >> 1;
-    const size_t out_off = in_off + (size_t)count;
-    for (int p0 = 0; p0 < parents; p0 += kTopGroups) {
-      const int p = p0 + grp;
-      const bool act = p < parents;
-      // children 2p and 2p+1 are adjacent: lane e takes word e of the 16-word pair
-      Fp x = act ? Fp::raw(t[(in_off + 2 * (size_t)p) * 8 + e]) : Fp::zero();
-      x = p2_permute_coop(x, cc, consts);
-      if (act && e < 8) t[(out_off + (size_t)p) * 8 + e] = x.v;
-    }
-    __syncthreads();
-    in_off = out_off;
-    count = parents;
-  }
-}
-
+// Finishes a tree from a layer of `count` (<= 2*kHashThreads) digests, one workgroup per proof
+// (merkle_coop.cuh).
 __global__ __launch_bounds__(kTopThreads) void compress_top_kernel(uint32_t* __restrict__ tree, size_t tree_stride,
                                                                   size_t in_off, int count,
                                                                   const P2Consts* __restrict__ consts) {
@@ -118,22 +93,9 @@ __global__ __launch_bounds__(kTopThreads) void fri_commit_small_kernel(const uin
                                                                       size_t layer_stride, int loghk,
                                                                       uint32_t* __restrict__ tree, size_t tree_stride,
                                                                       const P2Consts* __restrict__ consts) {
-  const int hk = 1 << loghk, half = hk >> 1;
-  const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  const CoopConsts cc = coop_load_consts(consts, e);
-  const uint32_t* f = layer + (size_t)blockIdx.x * layer_stride;
-  uint32_t* t = tree + (size_t)blockIdx.x * tree_stride;
-  for (int l0 = 0; l0 < hk; l0 += kTopGroups) {
-    const int leaf = l0 + grp;
-    const bool act = leaf < hk;
-    const int c = leaf >= half ? 1 : 0, m = leaf - c * half;
-    Fp x = Fp::zero();
-    if (act && e < 8) x = Fp::raw(f[((size_t)c * hk + m + (e >= 4 ? half : 0)) * 4 + (e & 3)]);
-    x = p2_permute_coop(x, cc, consts);
-    if (act && e < 8) t[(size_t)leaf * 8 + e] = x.v;
-  }
-  __syncthreads();
-  coop_tree_levels(t, 0, hk, cc, consts);
+  const CoopConsts cc = coop_load_consts(consts, threadIdx.x & 15);
+  coop_fri_commit_block(layer + (size_t)blockIdx.x * layer_stride, tree + (size_t)blockIdx.x * tree_stride, loghk, cc,
+                        consts);
 }
 
 // Latency form of the leaf layer for small batches: 16 lanes per matrix row, four

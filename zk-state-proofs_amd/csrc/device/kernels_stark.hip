@@ -11,7 +11,7 @@
 // transcript kernels, so that a whole batch of sponges advances in one wave).
 #include "air_keccak.cuh"
 #include "kernels.h"
-#include "poseidon2_coop.cuh"
+#include "merkle_coop.cuh"
 
 #include <cstdlib>
 
@@ -709,6 +709,62 @@ __global__ __launch_bounds__(kChThreads) void ch_observe_sample_kernel(DevChalle
     if (e == 0) out[(size_t)b * out_stride + i] = v.v;
   }
   ch_store(ch + b, c);
+}
+
+// ===========================================================================
+// FRI commit phase, layers of at most 512 leaves: commit, transcript and fold of EVERY such
+// layer in one launch, one workgroup per proof.  Separately these are three launches per layer
+// (27 for a 2^11 trace), each a short dependent step; a single proof spent a quarter of its time
+// there.  The work is unchanged: coop_fri_commit_block per layer, the proof's sponge advanced by
+// the first 16 lanes (which keep its state in registers across layers), the fold by all threads.
+// ===========================================================================
+__global__ __launch_bounds__(kTopThreads) void fri_tail_kernel(FriTailArgs a, const P2Consts* __restrict__ k) {
+  __shared__ uint32_t beta_s[4];
+  const int b = blockIdx.x, tid = threadIdx.x, e = tid & 15;
+  const CoopConsts cc = coop_load_consts(k, e);
+  Ch c;
+  if (tid < 16) ch_load(a.ch + b, c, e, k);
+  uint32_t* layers = a.layers + (size_t)b * a.layer_stride;
+  uint32_t* trees = a.trees + (size_t)b * a.tree_stride;
+  size_t loff = a.loff_start, toff = a.toff_start;
+  for (int kk = a.k_start; kk < a.logh; ++kk) {
+    const int loghk = a.logh - kk, hk = 1 << loghk, half = hk >> 1;
+    uint32_t* f = layers + loff;
+    uint32_t* t = trees + toff * 8;
+    coop_fri_commit_block(f, t, loghk, cc, k);  // ends with a barrier: the root is visible
+    if (tid < 16) {
+      const uint32_t* root = t + (size_t)(2 * hk - 2) * 8;
+      for (int i = 0; i < 8; ++i) ch_observe(c, Fp::raw(root[i]), k);
+      for (int i = 0; i < 4; ++i) {
+        const Fp v = ch_sample(c, k);
+        if (e == 0) {
+          beta_s[i] = v.v;
+          a.betas[(size_t)b * a.beta_stride + (size_t)kk * 4 + i] = v.v;
+        }
+      }
+    }
+    __syncthreads();
+    Fp4 be;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) be.c[j] = Fp::raw(beta_s[j]);
+    const Fp inv2 = Fp::raw(cmonty((kP + 1) / 2));
+    uint32_t* out = f + (size_t)2 * hk * 4;
+    for (int i = tid; i < hk; i += kTopThreads) {  // 2 cosets * half outputs (fri_fold_kernel's arithmetic)
+      const int cset = i >= half ? 1 : 0, m = i - cset * half;
+      const Fp4 lo = load_fp4(f + ((size_t)cset * hk + m) * 4), hi = load_fp4(f + ((size_t)cset * hk + m + half) * 4);
+      const Fp xinv = Fp::raw(a.xinv[2 * kk + cset]) * Fp::raw(a.tw_inv[(size_t)m << kk]);
+      const Fp4 r = (lo + hi) * inv2 + be * ((lo - hi) * (inv2 * xinv));
+      store_fp4(out + ((size_t)cset * half + m) * 4, r);
+    }
+    __syncthreads();  // the next layer is complete, and beta_s may be rewritten
+    loff += (size_t)2 * hk * 4;
+    toff += (size_t)2 * hk - 1;
+  }
+  if (tid < 16) ch_store(a.ch + b, c);
+}
+
+void launch_fri_tail(hipStream_t stream, const FriTailArgs& a, int batch, const P2Consts* consts) {
+  hipLaunchKernelGGL(fri_tail_kernel, dim3(batch), dim3(kTopThreads), 0, stream, a, consts);
 }
 
 // Proof-of-work search: smallest w such that, after observing w, the next sample

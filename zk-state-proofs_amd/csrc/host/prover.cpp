@@ -4,6 +4,8 @@
 // launches per batch with the Fiat-Shamir transcript kept on the device.
 #include "prover.hpp"
 
+#include <algorithm>
+
 namespace zksp {
 
 Workspace::~Workspace() {
@@ -247,7 +249,9 @@ int prove_resident(Context* ctx) {
     launch_reduce_openings(s, ra);
   }
   size_t loff = 0, toff = 0;
-  for (int k = 0; k < logh; ++k) {
+  // layers of more than 512 leaves: commit, transcript and fold as separate launches
+  const int k_tail = std::max(0, logh - kFriTailMaxLogLeaves);
+  for (int k = 0; k < k_tail; ++k) {
     const int loghk = logh - k;
     const size_t hk = h >> k;
     {
@@ -268,6 +272,30 @@ int prove_resident(Context* ctx) {
     }
     loff += 2 * hk * 4;
     toff += 2 * hk - 1;
+  }
+  // the remaining layers in one launch
+  {
+    ProfileSpan sp(ctx, "fri_commit");
+    FriTailArgs ta;
+    ta.layers = ws->fri_layers;
+    ta.layer_stride = ws->fri_layer_stride;
+    ta.trees = ws->fri_trees;
+    ta.tree_stride = ws->fri_tree_stride;
+    ta.ch = ws->ch;
+    ta.betas = ws->betas;
+    ta.beta_stride = (size_t)logh * 4;
+    ta.tw_inv = dom->tw_inv;
+    for (int i = 0; i < 32; ++i) ta.xinv[i] = i < 2 * logh ? dom->fold_xinv[i] : 0;
+    ta.logh = logh;
+    ta.k_start = k_tail;
+    ta.loff_start = loff;
+    ta.toff_start = toff;
+    launch_fri_tail(s, ta, B, kc);
+    for (int k = k_tail; k < logh; ++k) {
+      const size_t hk = h >> k;
+      loff += 2 * hk * 4;
+      toff += 2 * hk - 1;
+    }
   }
   {
     ProfileSpan sp(ctx, "transcript");
