@@ -29,6 +29,37 @@ def test_merkle_commit(gpu, oracle, width, logn):
     assert (gpu.merkle_commit(mat) == oracle.merkle_commit(mat)).all()
 
 
+def extreme_words(rng, shape):
+    """Canonical values whose MONTGOMERY-form words (what the device holds) are extreme: 0, 1, p-1,
+    p-2 and the two words around p/2, where the signed lazy arithmetic's bounds are tightest."""
+    from util import from_monty
+    words = np.array([0, 1, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2], dtype=np.uint32)
+    return from_monty(words[rng.integers(0, len(words), shape)])
+
+
+def test_poseidon2_permute_extreme_words(gpu, oracle):
+    rng = np.random.default_rng(90)
+    from util import from_monty
+    st = extreme_words(rng, (600, 16))
+    for i, w in enumerate((0, 1, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2)):
+        st[i] = from_monty(np.full(16, w, np.uint32))  # every word the same extreme
+    got = gpu.permute(st)
+    exp = np.stack([oracle.poseidon2_permute(s) for s in st])
+    assert (got == exp).all()
+
+
+@pytest.mark.parametrize("width,logn,extreme", [(70, 16, False), (300, 16, True), (2633, 16, False)])
+def test_merkle_commit_throughput_kernel(gpu, oracle, width, logn, extreme):
+    """More than 32768 rows and at least 64 columns select leaf_hash_trace_kernel, the kernel that
+    dominates a proof (one lane per row, the signed lazy permutation, state kept signed between
+    absorbs); small inputs take the cooperative kernel instead.  Ragged last absorb included."""
+    rng = np.random.default_rng(width + logn)
+    mat = extreme_words(rng, (width, 1 << logn)) if extreme else rnd(rng, (width, 1 << logn))
+    got = gpu.merkle_commit(mat)
+    exp = oracle.merkle_commit(mat)
+    assert (got == exp).all()
+
+
 @pytest.mark.parametrize("logh", [1, 2, 3, 5, 8, 10, 11, 13, 14])
 def test_lde(gpu, oracle, logh):
     rng = np.random.default_rng(logh)
