@@ -145,7 +145,10 @@ static void launch_upper_layers(hipStream_t stream, int logn, uint32_t* tree, si
                                 const P2Consts* consts) {
   size_t off = 0;
   int count = 1 << logn;
-  while (count > 2 * kHashThreads) {
+  // One lane per parent while a level is wide: always above 512 digests, and in a large batch for
+  // as long as the level has 16 K parents batch-wide (the cooperative form below does about twice
+  // the arithmetic; it is for the narrow, latency-bound levels).
+  while (count > 2 * kHashThreads || (count > 32 && (size_t)(count >> 1) * (size_t)batch >= 16384)) {
     int parents = count >> 1;
     hipLaunchKernelGGL(compress_layer_kernel, dim3((parents + kHashThreads - 1) / kHashThreads, batch),
                        dim3(kHashThreads), 0, stream, tree, tree_stride, off, off + (size_t)count, parents, consts);
