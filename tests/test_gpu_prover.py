@@ -89,11 +89,13 @@ def test_device_prover_matches_oracle_tall(zk, oracle, logh, n):
         assert bad.size == 0, (i, bad[:8])
 
 
-@pytest.mark.parametrize("logh,n", [(5, 128), (6, 96)])
+@pytest.mark.parametrize("logh,n", [(5, 128), (6, 96), (9, 128)])
 def test_device_prover_matches_oracle_large_batch(zk, oracle, logh, n):
-    """Large batches take different kernels from small ones (the LDS-transposed opening kernel
-    needs ceil(2633 / 256) * batch >= 1024 workgroups): every proof of a wide batch must still
-    equal the oracle's, including empty and full traces."""
+    """Large batches take different kernels from small ones: the LDS-transposed opening kernel needs
+    ceil(2633 / 256) * batch >= 1024 workgroups; from 64 proofs on the FRI layers are committed
+    one by one, and a layer with leaves * batch >= 32768 (2^9 x 128) and the tree levels that are
+    wide across the batch use the lane-per-leaf / lane-per-parent kernels.  Every proof sampled
+    from a wide batch must still equal the oracle's, including empty and full traces."""
     nq, pow_bits = 3, 4
     g = Gpu(zk, num_queries=nq, pow_bits=pow_bits, max_batch=n)
     rng = np.random.default_rng(100 + logh)

@@ -208,7 +208,9 @@ __global__ __launch_bounds__(kHashThreads) void fri_leaf_kernel(const uint32_t* 
 void launch_fri_commit(hipStream_t stream, const uint32_t* layer, size_t layer_stride, int loghk, uint32_t* tree,
                        size_t tree_stride, int batch, const P2Consts* consts) {
   const int hk = 1 << loghk;
-  if (hk <= 2 * kHashThreads) {
+  // small layer: one cooperative workgroup per proof, unless the batch makes it wide (then one lane
+  // per leaf / per parent does half the arithmetic and fills the chip)
+  if (hk <= 2 * kHashThreads && (size_t)hk * (size_t)batch < 32768) {
     hipLaunchKernelGGL(fri_commit_small_kernel, dim3(batch), dim3(kTopThreads), 0, stream, layer, layer_stride, loghk,
                        tree, tree_stride, consts);
     return;

@@ -250,7 +250,8 @@ int prove_resident(Context* ctx) {
   }
   size_t loff = 0, toff = 0;
   // layers of more than 512 leaves: commit, transcript and fold as separate launches
-  const int k_tail = std::max(0, logh - kFriTailMaxLogLeaves);
+  // ... and in a large batch every layer: the fused tail is one workgroup per proof, a latency form
+  const int k_tail = B >= 64 ? logh : std::max(0, logh - kFriTailMaxLogLeaves);
   for (int k = 0; k < k_tail; ++k) {
     const int loghk = logh - k;
     const size_t hk = h >> k;
@@ -274,7 +275,7 @@ int prove_resident(Context* ctx) {
     toff += 2 * hk - 1;
   }
   // the remaining layers in one launch
-  {
+  if (k_tail < logh) {
     ProfileSpan sp(ctx, "fri_commit");
     FriTailArgs ta;
     ta.layers = ws->fri_layers;
