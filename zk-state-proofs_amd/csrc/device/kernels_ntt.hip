@@ -445,9 +445,11 @@ __global__ __launch_bounds__(kLdeThreads) void ntt_chunk_kernel(const uint32_t* 
   }
 }
 
-// in place on `data`: the l1 = logh - l2 high stages of every column
+// the l1 = logh - l2 high stages of every column, from `src` to `dst` (which may be the same
+// buffer: a tile is read completely before any of it is written back)
 template <bool DIF>
-__global__ __launch_bounds__(kLdeThreads) void ntt_strided_kernel(uint32_t* __restrict__ data, size_t col_stride,
+__global__ __launch_bounds__(kLdeThreads) void ntt_strided_kernel(const uint32_t* src, size_t src_col_stride,
+                                                                 uint32_t* dst, size_t dst_col_stride,
                                                                  const uint32_t* __restrict__ tw, int logh, int l2) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   Fp* buf = reinterpret_cast<Fp*>(smem);
@@ -455,13 +457,14 @@ __global__ __launch_bounds__(kLdeThreads) void ntt_strided_kernel(uint32_t* __re
   const int h1 = 1 << l1;
   const size_t h2 = (size_t)1 << l2;
   const size_t n2_base = (size_t)blockIdx.x * kStrideTile;
-  uint32_t* d = data + (size_t)blockIdx.y * col_stride + n2_base;
+  const uint32_t* sp = src + (size_t)blockIdx.y * src_col_stride + n2_base;
+  uint32_t* d = dst + (size_t)blockIdx.y * dst_col_stride + n2_base;
   const int tid = threadIdx.x;
   // LDS image [n1][t] with one pad word per row (17-word rows: conflict-free column walks)
   constexpr int kRow = kStrideTile + 1;
   for (int i = tid; i < h1 * kStrideTile; i += kLdeThreads) {
     const int n1 = i / kStrideTile, t = i % kStrideTile;
-    buf[n1 * kRow + t] = Fp::raw(d[(size_t)n1 * h2 + t]);
+    buf[n1 * kRow + t] = Fp::raw(sp[(size_t)n1 * h2 + t]);
   }
   __syncthreads();
   const int nbf = (h1 >> 1) * kStrideTile;
@@ -504,19 +507,18 @@ static void launch_lde_large(hipStream_t stream, const uint32_t* in, uint32_t* c
   const size_t strided_smem = sizeof(uint32_t) * ((size_t)1 << l1) * (kStrideTile + 1);
   const dim3 chunk_grid((unsigned)(h >> l2), (unsigned)ncols);
   const dim3 sgrid((unsigned)(((size_t)1 << l2) / kStrideTile), (unsigned)ncols);
-  // inverse: copy into the second coset slot of the output as scratch, strided DIF in place, chunk DIF -> coefs
+  // inverse: strided DIF from the input into the second coset slot of the output (scratch), chunk DIF -> coefs
   uint32_t* scratch = out + h;  // out[col][1]
-  (void)hipMemcpy2DAsync(scratch, 2 * h * 4, in, h * 4, h * 4, ncols, hipMemcpyDeviceToDevice, stream);
-  hipLaunchKernelGGL(ntt_strided_kernel<true>, sgrid, dim3(kLdeThreads), strided_smem, stream, scratch, 2 * h, tw_inv,
-                     logh, l2);
+  hipLaunchKernelGGL(ntt_strided_kernel<true>, sgrid, dim3(kLdeThreads), strided_smem, stream, in, h, scratch, 2 * h,
+                     tw_inv, logh, l2);
   hipLaunchKernelGGL(ntt_chunk_kernel<true>, chunk_grid, dim3(kLdeThreads), chunk_smem, stream, scratch, coefs_br,
                      2 * h, h, tw_inv, (const uint32_t*)nullptr, in_scale_br, logh, l2);
   for (int cs = 0; cs < 2; ++cs) {
     uint32_t* dst = out + (size_t)cs * h;
     hipLaunchKernelGGL(ntt_chunk_kernel<false>, chunk_grid, dim3(kLdeThreads), chunk_smem, stream, coefs_br, dst, h,
                        2 * h, tw_fwd, out_scale_br + (size_t)cs * h, (const uint32_t*)nullptr, logh, l2);
-    hipLaunchKernelGGL(ntt_strided_kernel<false>, sgrid, dim3(kLdeThreads), strided_smem, stream, dst, 2 * h, tw_fwd,
-                       logh, l2);
+    hipLaunchKernelGGL(ntt_strided_kernel<false>, sgrid, dim3(kLdeThreads), strided_smem, stream, dst, 2 * h, dst, 2 * h,
+                       tw_fwd, logh, l2);
   }
 }
 
