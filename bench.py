@@ -108,23 +108,60 @@ def usable_cores():
 
 
 def cpu_baseline(states, vk_words, pv, seconds=10.0):
-    """Times the oracle's whole-proof CPU restatement ("port") on this host."""
+    """Times the oracle's whole-proof CPU restatement ("port") on this host: at least five
+    repetitions and `seconds` of work; value = proofs / elapsed, median and min per proof beside it
+    (SURVEY.md section 8d)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     oracle.build()
     pvd = [int(x) for x in np.frombuffer(hashlib.sha256(pv).digest(), dtype=np.uint32)]
     cores = usable_cores()
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    n, t0 = 0, time.perf_counter()
+    oracle.prove(states, LOG_H, public_values=pv, pv_digest=pvd, vk_digest=vk_words)  # untimed: page-in, thread pool
+    times, t0 = [], time.perf_counter()
     while True:
+        t1 = time.perf_counter()
         oracle.prove(states, LOG_H, public_values=pv, pv_digest=pvd, vk_digest=vk_words)
-        n += 1
+        times.append(time.perf_counter() - t1)
         el = time.perf_counter() - t0
-        if el >= seconds and n >= 2:
+        if el >= seconds and len(times) >= 5:
             break
+    n = len(times)
+    med = sorted(times)[n // 2]
     return {"value": n / el, "unit": "proofs/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
-            "sample": f"{n} acct-d8 proofs (62 keccak-f perms, 2^11 x 2633 trace) in {el:.1f} s; reference SP1 CPU "
-                      "prover unavailable offline, CPU baseline is this repository's oracle/ restatement"}
+            "repetitions": n, "median_s_per_proof": med, "min_s_per_proof": min(times),
+            "sample": f"{n} acct-d8 keccak-chip proofs (62 keccak-f perms, 2^11 x 2633 trace) in {el:.1f} s; reference "
+                      "SP1 CPU prover unavailable offline, CPU baseline is this repository's oracle/ restatement"}
+
+
+def verify_resident_batch(zk, lib, h, vk, vk_words, states, n_perms, pv, pvd, B, with_oracle, n_check=6):
+    """Fetches the bodies the last timed step left in HBM, wraps `n_check` of them (spread over the
+    batch) into complete proofs and verifies them on the host; optionally compares one with the CPU
+    oracle's proof bytes.  Raises on any mismatch."""
+    bw = lib.zksp_proof_body_words(h, LOG_H)
+    bodies = np.zeros((B, bw), np.uint32)
+    rc = lib.zksp_hip_fetch_bodies(h, bodies.ctypes.data_as(C.c_void_p), bodies.size)
+    if rc:
+        raise RuntimeError(f"fetch_bodies rc={rc}")
+    host = zk.ProverClient(device=-1)
+    idx = sorted({int(round(k * (B - 1) / max(1, n_check - 1))) for k in range(n_check)})
+    for i in idx:
+        proof = zk.proof_from_body(bodies[i], LOG_H, states[i, :n_perms[i]], 0, pv, pvd, [0] * 8, vk_words)
+        if proof.public_values != pv:
+            raise RuntimeError(f"bench: proof {i} carries wrong public values")
+        host.verify(proof, vk)  # raises VerificationError
+    oracle_equal = None
+    if with_oracle:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle
+        oracle.build()
+        i = idx[len(idx) // 2]
+        exp = oracle.prove(states[i, :n_perms[i]], LOG_H, public_values=pv, pv_digest=pvd, vk_digest=vk_words)
+        got = zk.proof_from_body(bodies[i], LOG_H, states[i, :n_perms[i]], 0, pv, pvd, [0] * 8, vk_words).to_bytes()
+        if got != exp:
+            raise RuntimeError(f"bench: proof {i} of the timed batch differs from the CPU oracle's bytes")
+        oracle_equal = i
+    return {"verified_indices": idx, "oracle_byte_equal_index": oracle_equal}
 
 
 def main():
@@ -141,11 +178,27 @@ def main():
                     help="gloo + ZKSP_BENCH_SAME_DEVICE=1 rehearses the N>1 path on a one-GPU box")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves.  Nothing in this process has
+        # touched HIP or torch yet, and the ranks are CHILD processes (never an exec of this one);
+        # rank 0's JSON line passes through on stdout and the launcher's exit code becomes ours.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # the oracle's C restatement is OpenMP code; the thread count must be fixed before libgomp loads
+    os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))
 
     import torch
     if not torch.cuda.is_available():
@@ -236,6 +289,12 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device if coll_device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- the timed batch is checked, not just timed: sampled proofs of the LAST timed step are fetched,
+    # completed with their headers, run through the host verifier, and one is compared byte for byte with
+    # the CPU oracle.  A mismatch fails the benchmark.
+    checked = verify_resident_batch(zk, lib, h, vk, vk_words, states, n_perms, pv, pvd, B,
+                                    with_oracle=(rank == 0 and not args.no_cpu_baseline))
 
     # ---- dominant kernel: Poseidon2 leaf hash of the trace LDE, HIP events on the client's stream ----
     tot, cnt = C.c_double(), C.c_uint64()
@@ -330,7 +389,9 @@ def main():
         },
         "roofline": {
             "kernel": "leaf_hash_trace_kernel (Poseidon2 sponge over the trace LDE rows)",
-            "bound": "hbm",
+            # bound by vector-ALU issue; achieved/peak/frac are the contractual HBM figures (algorithmic bytes
+            # over the launch time against the 8 TB/s peak), kept so that rounds stay comparable
+            "bound": "valu",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -344,6 +405,7 @@ def main():
             # a register-resident permutation loop with no memory traffic (perm_rate_kernel, 8 workgroups/CU)
             "alu": alu_roofline(lib, h, B * n_rows * ((TRACE_WIDTH + 7) // 8), leaf_ms),
         },
+        "timed_batch_checked": checked,
         "device_ms_per_step_by_stage": spans,
         "single_proof_device_ms": single_ms,
         "single_proof_end_to_end_ms": e2e_ms,

@@ -54,7 +54,10 @@ typedef struct {
 } zksp_options;
 
 /* replaces ProverClient::new()  (main.rs:61).  Fails with ZKSP_ERR_NO_DEVICE when
- * device_ordinal >= 0 and no GPU is usable: there is no CPU proving fallback. */
+ * device_ordinal >= 0 and no GPU is usable: there is no CPU proving fallback.
+ * Environment override ZKSP_PROVER (the counterpart of SP1_PROVER, reference
+ * .env.example:1-2): "hip"/"local" = prove on the GPU, "host" = executor/verifier
+ * only (as device_ordinal -1); any other value is ZKSP_ERR_UNSUPPORTED. */
 int zksp_client_new(const zksp_options* opts, zksp_client** out);
 void zksp_client_free(zksp_client* c);
 /* last error text of this client ("" if none); never NULL */
@@ -142,6 +145,14 @@ int zksp_hip_fetch_bodies(zksp_client* c, uint32_t* out, size_t cap_words);
 /* Copies only the 8-word main-trace commitment of every resident proof ([n][8],
  * canonical u32): the 32 bytes per proof the multi-GPU farm all-gathers. */
 int zksp_hip_fetch_roots(zksp_client* c, uint32_t* out, size_t cap_words);
+/* Wraps one fetched body (zksp_hip_fetch_bodies) into a complete proof object: header,
+ * public values and the public I/O list (input state and keccak-f of it per permutation)
+ * are rebuilt from the same inputs zksp_hip_load_batch was given.  What zksp_prove does
+ * for its own batches, exposed so that callers of the resident path (bench.py, tests) can
+ * run zksp_verify on what they timed. */
+int zksp_proof_from_body(const uint32_t* body, size_t body_words, uint32_t log_h, const uint64_t* states, uint32_t n_perms,
+                         uint32_t exit_code, const uint8_t* public_values, size_t pv_len, const uint32_t* pv_digest,
+                         const uint32_t* deferred_digest, const uint32_t* vk_digest, zksp_proof** out);
 int zksp_hip_sync(zksp_client* c);
 /* HIP-event timing on the client's own stream. */
 int zksp_hip_timer_start(zksp_client* c);

@@ -58,6 +58,28 @@ int main(int argc, char** argv) {
         exec_halt += r.halted;
       }
     }
+    // 1b. hostile section-header table: e_shoff / e_shentsize / e_shnum and the symtab's sh_link are
+    // attacker-controlled; the loader must not read a linked string-table header outside the file
+    {
+      std::vector<uint8_t> e = elf;
+      auto put16 = [&](size_t o, uint16_t v) { e[o] = (uint8_t)v; e[o + 1] = (uint8_t)(v >> 8); };
+      auto put32 = [&](size_t o, uint32_t v) { for (int k = 0; k < 4; ++k) e[o + k] = (uint8_t)(v >> (8 * k)); };
+      const uint32_t shoff = (uint32_t)e[32] | (uint32_t)e[33] << 8 | (uint32_t)e[34] << 16 | (uint32_t)e[35] << 24;
+      const uint16_t shentsize = (uint16_t)(e[46] | e[47] << 8), shnum = (uint16_t)(e[48] | e[49] << 8);
+      switch (it % 4) {
+        case 0: put16(48, 0xffff); break;                         // e_shnum far beyond the table
+        case 1: put16(46, (uint16_t)(rng() | 0x8000)); break;     // huge e_shentsize
+        case 2: put32(32, (uint32_t)(e.size() - (rng() % 64))); break;  // table starts at the end of the file
+        case 3:                                                   // every symtab links to a far section
+          for (uint16_t i = 0; i < shnum; ++i) {
+            size_t o = (size_t)shoff + (size_t)i * shentsize;
+            if (o + 40 <= e.size() && e[o + 4] == 2) { put32(o + 24, 0xfff0 + (uint32_t)(rng() % 15)); put16(48, 0xffff); }
+          }
+          break;
+      }
+      ElfImage img;
+      if (load_elf(e.data(), e.size(), &img).empty()) ++elf_ok;
+    }
     // 2. corrupted stdin
     {
       std::vector<uint8_t> s = input;

@@ -57,3 +57,18 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".cuh", ".h")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "import oracle" not in text and "oracle/" not in text.replace("oracle/ restatement", ""), f
+
+
+def test_zksp_prover_env_selects_the_backend(zk, built_lib, monkeypatch):
+    """ZKSP_PROVER mirrors SP1_PROVER (reference .env.example:1-2): 'host' never touches a GPU,
+    unknown backends (cpu, mock, network) are refused instead of silently falling back."""
+    monkeypatch.setenv("ZKSP_PROVER", "host")
+    c = zk.ProverClient(device=0)  # the override wins over the requested ordinal
+    lib = zk.load_library()
+    p = C.c_void_p()
+    assert lib.zksp_dev_malloc(c._h, 16, C.byref(p)) == 2  # ZKSP_ERR_NO_DEVICE: no GPU bound
+    for backend in ("cpu", "mock", "network"):
+        monkeypatch.setenv("ZKSP_PROVER", backend)
+        with pytest.raises(zk.ZkspError) as ei:
+            zk.ProverClient(device=-1)
+        assert ei.value.code == 9  # ZKSP_ERR_UNSUPPORTED

@@ -143,3 +143,28 @@ def test_malformed_inputs(zk, host_client):
     assert rc != 0 and "input stream exhausted" in host_client.last_error()
     with pytest.raises(zk.ZkspError):
         host_client.setup(b"not an elf")
+
+
+def test_stale_json_guest_is_a_second_regression_input(zk, fx, host_client):
+    """The reference also commits an older build of the same guest that takes serde_json input
+    (reference elf/riscv32im-succinct-zkvm-elf, the source shown in README.md:101-116; SURVEY.md
+    section 2 row 4): 2 203 254 cycles on the depth-8 account fixture, same public values."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(zk.MERKLE_ELF_PATH), "sp1-merkle-proof-json.elf")
+    elf = open(path, "rb").read()
+    assert hashlib.sha256(elf).hexdigest() == "0d9935d51e05c09e6e0f89d6055c62f493c82608b0f850138e73dbd27469d5c1"
+    pk, _ = host_client.setup(elf)
+    m = fx.acct_fixture(8)
+    js = json.dumps({"proof": [list(n) for n in m.proof], "root_hash": list(m.root_hash), "key": list(m.key)},
+                    separators=(",", ":")).encode()
+    s = zk.SP1Stdin()
+    s.write(js)
+    rep, pv, _, rc = host_client.execute(pk, s, zk.KECCAK_OBSERVE)
+    assert rc == 0 and rep.exit_code == 0
+    assert rep.cycles == 2203254
+    assert pv == fx.ACCOUNT_VALUE
+    assert bytes(np.array(list(rep.pv_digest), np.uint32).tobytes()) == hashlib.sha256(pv).digest()
+    # software and observed runs execute the same instruction stream
+    rep0, _, _, _ = host_client.execute(pk, s, zk.KECCAK_SOFTWARE)
+    assert rep0.cycles == rep.cycles

@@ -179,3 +179,45 @@ def test_batch_mixed_heights(zk, fx):
     for m, p in zip(inputs, proofs):
         client.verify(p, vk)
         assert p.public_values == verify_merkle_proof(m.root_hash, m.proof, m.key)
+
+
+def test_benchmarked_configuration_matches_oracle_and_verifies(zk, fx, oracle):
+    """The configuration bench.py times: trace height 2^11, a batch large enough (>= 64) to select the
+    throughput kernels (lane-per-row leaf hash, lde_fixed_kernel<11, 2>, the LDS-transposed opening,
+    per-layer FRI), full-size parameters (100 queries, 16 PoW bits), loaded through
+    zksp_hip_load_batch / zksp_hip_prove_resident exactly as the benchmark does.  Sampled bodies are
+    byte-identical to the oracle's and complete proofs built from them pass the host verifier."""
+    n, logh = 64, 11
+    client = zk.ProverClient(device=0, max_batch=n)
+    g = Gpu.__new__(Gpu)
+    g.zk, g.client, g.lib, g.h = zk, client, client._lib, client._h
+    pk, vk = client.setup(zk.merkle_elf())
+    vkw = [int(x) for x in np.frombuffer(vk.digest, dtype=np.uint32)]
+    pv = fx.ACCOUNT_VALUE
+    pvd = [int(x) for x in np.frombuffer(hashlib.sha256(pv).digest(), dtype=np.uint32)]
+    states, obs = [], []
+    rng = np.random.default_rng(77)
+    for i in range(n):
+        if i < 4:  # real guest runs: distinct depth-8 account proofs, 62 permutations each
+            s = zk.SP1Stdin()
+            s.write(fx.acct_fixture(8, seed=100 + i).to_borsh())
+            st = client.keccak_states(pk, s)
+            assert st.shape == (62, 25)
+        else:      # random states, ragged permutation counts up to the capacity of the trace (85)
+            st = rng.integers(0, 2**64, (int(rng.integers(1, 86)), 25), dtype=np.uint64)
+        states.append(st)
+        obs.append(init_obs(vkw, logh, len(st), 0, pvd, [0] * 8))
+    bodies = device_bodies(g, logh, states, obs)
+    for i in (0, 3, 17, n - 1):
+        exp = oracle.prove(states[i], logh, public_values=pv, pv_digest=pvd, vk_digest=vkw)
+        e = np.frombuffer(exp, dtype=np.uint32)[oracle.proof_header_words(len(pv), len(states[i])):]
+        bad = np.nonzero(e != bodies[i])[0]
+        assert bad.size == 0, (i, bad[:8])
+    host = zk.ProverClient(device=-1)
+    for i in (0, 1, 2, 3, 9, 17, 31, 40, 55, n - 1):
+        proof = zk.proof_from_body(bodies[i], logh, states[i], 0, pv, pvd, [0] * 8, vkw)
+        assert proof.public_values == pv
+        host.verify(proof, vk)
+    # a body attached to another proof's inputs must not verify
+    with pytest.raises(zk.ZkspError):
+        host.verify(zk.proof_from_body(bodies[5], logh, states[6], 0, pv, pvd, [0] * 8, vkw), vk)

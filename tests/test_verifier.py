@@ -91,3 +91,20 @@ def test_heights_and_empty_trace(zk, oracle, setup):
         st = rng.integers(0, 2**64, (k, 25), dtype=np.uint64)
         pr = oracle.prove(st, logh, pv_digest=pvd, vk_digest=vk_words, num_queries=NQ, pow_bits=POW)
         client.verify(zk.SP1ProofWithPublicValues.from_bytes(pr), vk)
+
+
+def test_rejects_nonzero_exit_code_and_oversized_height(zk, oracle, setup):
+    """A panicked guest has no proof in the reference (run() fails, prover/src/bin/main.rs:71-74): an
+    otherwise valid proof whose header carries exit code 1 is rejected.  A header claiming a height
+    the prover never emits is refused at parse time, before any hashing."""
+    client, vk, vk_words, st, pv, pvd, proof = setup
+    bad = oracle.prove(st, 7, exit_code=1, public_values=pv, pv_digest=pvd, vk_digest=vk_words, num_queries=NQ,
+                       pow_bits=POW)
+    with pytest.raises(zk.VerificationError) as ei:
+        client.verify(zk.SP1ProofWithPublicValues.from_bytes(bad), vk)
+    assert "exit code" in str(ei.value)
+    tall = bytearray(proof)
+    tall[8:12] = (26).to_bytes(4, "little")   # log_h
+    tall[12:16] = (0).to_bytes(4, "little")   # n_perms
+    with pytest.raises(zk.ZkspError):
+        zk.SP1ProofWithPublicValues.from_bytes(bytes(tall))

@@ -107,6 +107,8 @@ def load_library() -> C.CDLL:
     lib.zksp_hip_prove_resident.argtypes = [vp]
     lib.zksp_hip_fetch_bodies.argtypes = [vp, vp, sz]
     lib.zksp_hip_fetch_roots.argtypes = [vp, vp, sz]
+    lib.zksp_proof_from_body.argtypes = [vp, sz, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_char_p, sz, vp, vp, vp,
+                                         C.POINTER(vp)]
     lib.zksp_hip_sync.argtypes = [vp]
     lib.zksp_hip_timer_start.argtypes = [vp]
     lib.zksp_hip_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
@@ -136,7 +138,7 @@ ABI_SYMBOLS = [
     "zksp_vk_digest", "zksp_stdin_new", "zksp_stdin_write", "zksp_stdin_free", "zksp_prove", "zksp_prove_batch",
     "zksp_proof_public_values", "zksp_proof_serialize", "zksp_proof_deserialize", "zksp_proof_free", "zksp_verify",
     "zksp_execute", "zksp_execute_keccak", "zksp_opcode_name", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
-    "zksp_hip_prove_resident", "zksp_hip_fetch_bodies", "zksp_hip_fetch_roots", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
+    "zksp_hip_prove_resident", "zksp_proof_from_body", "zksp_hip_fetch_bodies", "zksp_hip_fetch_roots", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
     "zksp_hip_profile_enable", "zksp_hip_profile_read", "zksp_hip_profile_reset", "zksp_dev_malloc", "zksp_dev_free",
     "zksp_dev_upload", "zksp_dev_download", "zksp_dev_memset", "zksp_hip_lde", "zksp_hip_merkle_commit",
     "zksp_hip_poseidon2_permute", "zksp_hip_keccak_trace", "zksp_hip_keccak_quotient", "zksp_hip_bus_perm_trace", "zksp_hip_fri_fold",
@@ -210,6 +212,27 @@ class SP1ProofWithPublicValues(_Handle):
         if rc:
             raise ZkspError(rc, "malformed proof bytes")
         return SP1ProofWithPublicValues(lib, h, lib.zksp_proof_free)
+
+
+def proof_from_body(body, log_h: int, states, exit_code: int, public_values: bytes, pv_digest, deferred_digest,
+                    vk_digest) -> SP1ProofWithPublicValues:
+    """Complete proof object from one body fetched off the resident path (``zksp_hip_fetch_bodies``)
+    and the inputs that batch was loaded with; see ``zksp_proof_from_body``."""
+    import numpy as np
+    lib = load_library()
+    body = np.ascontiguousarray(body, dtype=np.uint32)
+    st = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, 25)
+    pvd = np.ascontiguousarray(pv_digest, dtype=np.uint32)
+    dfd = np.ascontiguousarray(deferred_digest, dtype=np.uint32)
+    vkd = np.ascontiguousarray(vk_digest, dtype=np.uint32)
+    h = C.c_void_p()
+    rc = lib.zksp_proof_from_body(body.ctypes.data_as(C.c_void_p), body.size, log_h, st.ctypes.data_as(C.c_void_p),
+                                  st.shape[0], exit_code, bytes(public_values), len(public_values),
+                                  pvd.ctypes.data_as(C.c_void_p), dfd.ctypes.data_as(C.c_void_p),
+                                  vkd.ctypes.data_as(C.c_void_p), C.byref(h))
+    if rc:
+        raise ZkspError(rc, "proof_from_body")
+    return SP1ProofWithPublicValues(lib, h, lib.zksp_proof_free)
 
 
 class _ProveBuilder:

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -48,6 +49,16 @@ int zksp_client_new(const zksp_options* opts, zksp_client** out) {
     if (opts->num_queries) ctx.params.num_queries = opts->num_queries;
     if (opts->pow_bits != 0xffffffffu) ctx.params.pow_bits = opts->pow_bits;
     if (opts->max_batch) ctx.params.max_batch = opts->max_batch;
+  }
+  // Run-time backend selection, the counterpart of SP1_PROVER (reference .env.example:1-2) next to
+  // the compile-time features of prover/Cargo.toml:32-35.  ZKSP_PROVER = "hip" | "local": prove on the
+  // GPU (an ordinal of -1 becomes 0); "host": executor/verifier only, no GPU touched; "cpu", "mock",
+  // "network": refused, this library has no CPU, mock or remote proving backend.
+  if (const char* e = getenv("ZKSP_PROVER")) {
+    const std::string v(e);
+    if (v == "hip" || v == "local") { if (dev < 0) dev = 0; }
+    else if (v == "host") dev = -1;
+    else if (!v.empty()) { delete c; return ZKSP_ERR_UNSUPPORTED; }
   }
   if (ctx.params.keccak_mode != 1 && ctx.params.keccak_mode != 2) { delete c; return ZKSP_ERR_INVALID_ARG; }
   if (ctx.params.pow_bits > 30 || ctx.params.num_queries > 4096) { delete c; return ZKSP_ERR_INVALID_ARG; }
@@ -303,6 +314,45 @@ int zksp_proof_deserialize(const uint8_t* buf, size_t len, zksp_proof** out) {
   return ZKSP_OK;
 }
 void zksp_proof_free(zksp_proof* p) { delete p; }
+
+int zksp_proof_from_body(const uint32_t* body, size_t body_words, uint32_t log_h, const uint64_t* states, uint32_t n_perms,
+                         uint32_t exit_code, const uint8_t* public_values, size_t pv_len, const uint32_t* pv_digest,
+                         const uint32_t* deferred_digest, const uint32_t* vk_digest, zksp_proof** out) {
+  if (!body || (!states && n_perms) || (!public_values && pv_len) || !pv_digest || !deferred_digest || !vk_digest || !out)
+    return ZKSP_ERR_INVALID_ARG;
+  if (pv_len > (1u << 24)) return ZKSP_ERR_INVALID_ARG;
+  zksp_proof* p = new (std::nothrow) zksp_proof();
+  if (!p) return ZKSP_ERR_INVALID_ARG;
+  try {
+    const size_t hwords = proof_header_words((uint32_t)pv_len, n_perms);
+    p->bytes.assign((hwords + body_words) * 4, 0);
+    uint32_t* w = reinterpret_cast<uint32_t*>(p->bytes.data());
+    w[0] = kProofMagic; w[1] = kProofVersion; w[2] = log_h; w[3] = n_perms; w[4] = exit_code; w[5] = (uint32_t)pv_len;
+    memcpy(w + 6, pv_digest, 32);
+    memcpy(w + 14, deferred_digest, 32);
+    memcpy(w + 22, vk_digest, 32);
+    if (pv_len) memcpy(p->bytes.data() + 120, public_values, pv_len);
+    uint8_t* io = p->bytes.data() + (30 + (pv_len + 3) / 4) * 4;
+    for (uint32_t k = 0; k < n_perms; ++k) {  // the public I/O list: input state, keccak-f of it
+      uint64_t st[25];
+      memcpy(st, states + 25 * (size_t)k, 200);
+      memcpy(io + (size_t)k * 400, st, 200);
+      keccak_f1600(st);
+      memcpy(io + (size_t)k * 400 + 200, st, 200);
+    }
+    memcpy(p->bytes.data() + hwords * 4, body, body_words * 4);
+  } catch (...) {
+    delete p;
+    return ZKSP_ERR_INVALID_ARG;
+  }
+  std::string err;
+  if (!parse_proof_header(p->bytes.data(), p->bytes.size(), &p->hdr, &err)) {
+    delete p;
+    return ZKSP_ERR_PROOF_FORMAT;
+  }
+  *out = p;
+  return ZKSP_OK;
+}
 
 int zksp_verify(zksp_client* c, const zksp_proof* p, const zksp_vk* vk) {
   if (!c || !p || !vk) return ZKSP_ERR_INVALID_ARG;

@@ -92,14 +92,24 @@ void parallel_for(size_t count, unsigned max_threads, const std::function<void(s
 
 extern "C" {
 
-int zksp_prove_batch(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdins, size_t n, zksp_proof** out,
-                     int32_t* status) {
+static int prove_batch_impl(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdins, size_t n, zksp_proof** out,
+                            int32_t* status) {
   if (!c || !pk || !stdins || !out || !status || n == 0) return ZKSP_ERR_INVALID_ARG;
   Context* ctx = &c->ctx;
   if (!ctx->has_device())
     return ctx->fail(ZKSP_ERR_NO_DEVICE, "prove: this client was created without a GPU; there is no CPU proving path");
   if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(ZKSP_ERR_HIP, "prove: hipSetDevice failed");
   for (size_t i = 0; i < n; ++i) { out[i] = nullptr; status[i] = ZKSP_ERR_INVALID_ARG; }
+
+  // copy stream and events (created on first use, owned by the context); before any thread
+  // is started, so that no early return can leave a joinable std::thread behind
+  bool overlap = true;
+  if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) overlap = false;
+  for (int k = 0; k < 2 && overlap; ++k) {
+    if (!ctx->ev_proved[k] && hipEventCreateWithFlags(&ctx->ev_proved[k], hipEventDisableTiming) != hipSuccess) overlap = false;
+    if (!ctx->ev_copied[k] && hipEventCreateWithFlags(&ctx->ev_copied[k], hipEventDisableTiming) != hipSuccess) overlap = false;
+  }
+  if (!overlap) return ctx->fail(ZKSP_ERR_HIP, "prove: could not create the copy stream");
 
   // ---- stage 1: executor workers (run ahead of the GPU, in input order) ----
   std::vector<Job> jobs(n);
@@ -112,16 +122,36 @@ int zksp_prove_batch(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdin
   auto worker = [&]() {
     for (size_t i; (i = next_job.fetch_add(1)) < n;) {
       if (stdins[i]) {
-        ExecOptions o;
-        o.keccak_mode = (KeccakMode)ctx->params.keccak_mode;
-        jobs[i].rec = execute(pk->elf, stdins[i]->entries, o);
-        stdins[i]->entries.clear();  // consumed, as SP1Stdin is by prove()
+        try {
+          ExecOptions o;
+          o.keccak_mode = (KeccakMode)ctx->params.keccak_mode;
+          jobs[i].rec = execute(pk->elf, stdins[i]->entries, o);
+          stdins[i]->entries.clear();  // consumed, as SP1Stdin is by prove()
+        } catch (...) {  // an exception leaving a thread would terminate the process
+          jobs[i].rec = ExecutionRecord();
+          jobs[i].rec.error = "out of memory while executing the guest";
+        }
       }
       done[i].store(1, std::memory_order_release);
     }
   };
-  std::vector<std::thread> workers;
-  for (unsigned t = 0; t < n_workers; ++t) workers.emplace_back(worker);
+  // Joins the workers on every way out of this function (normal return, early return, exception):
+  // a joinable std::thread destroyed unjoined calls std::terminate, which would abort across the C ABI.
+  struct WorkerGuard {
+    std::vector<std::thread> th;
+    std::atomic<size_t>* next;
+    size_t n;
+    ~WorkerGuard() {
+      next->store(n);  // no further jobs are claimed
+      for (auto& t : th)
+        if (t.joinable()) t.join();
+    }
+  } guard{{}, &next_job, n};
+  try {
+    for (unsigned t = 0; t < n_workers; ++t) guard.th.emplace_back(worker);
+  } catch (...) {
+    return ctx->fail(ZKSP_ERR_HIP, "prove: could not start the executor threads");
+  }
 
   // ---- stages 2 and 3, driven from this thread ----
   const size_t max_batch = ctx->params.max_batch;
@@ -181,14 +211,6 @@ int zksp_prove_batch(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdin
     rc_all = rc;
   };
 
-  // copy stream and events (created on first use, owned by the context)
-  bool overlap = true;
-  if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) overlap = false;
-  for (int k = 0; k < 2 && overlap; ++k) {
-    if (!ctx->ev_proved[k] && hipEventCreateWithFlags(&ctx->ev_proved[k], hipEventDisableTiming) != hipSuccess) overlap = false;
-    if (!ctx->ev_copied[k] && hipEventCreateWithFlags(&ctx->ev_copied[k], hipEventDisableTiming) != hipSuccess) overlap = false;
-  }
-  if (!overlap) return ctx->fail(ZKSP_ERR_HIP, "prove: could not create the copy stream");
   ctx->body_free = nullptr;
   ctx->batch_hint = (int)std::min(max_batch, n);
 
@@ -317,9 +339,20 @@ int zksp_prove_batch(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdin
   ctx->body_free = nullptr;  // every copy has completed: later passes on this client need no wait
   ctx->batch_hint = 0;
   trace.mark("all assembled", n);
-  for (auto& t : workers) t.join();
   if (!first_err.empty() && rc_all == ZKSP_OK) ctx->error = first_err;
   return rc_all;
+}
+
+int zksp_prove_batch(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdins, size_t n, zksp_proof** out,
+                     int32_t* status) {
+  // nothing unwinds past extern "C": allocation failures inside the pipeline become an error code
+  try {
+    return prove_batch_impl(c, pk, stdins, n, out, status);
+  } catch (const std::exception& e) {
+    return c ? c->ctx.fail(ZKSP_ERR_INVALID_ARG, std::string("prove: ") + e.what()) : ZKSP_ERR_INVALID_ARG;
+  } catch (...) {
+    return c ? c->ctx.fail(ZKSP_ERR_INVALID_ARG, "prove: unknown exception") : ZKSP_ERR_INVALID_ARG;
+  }
 }
 
 int zksp_prove(zksp_client* c, const zksp_pk* pk, zksp_stdin* stdin_, zksp_proof** out) {

@@ -170,6 +170,7 @@ std::string load_elf(const uint8_t* d, size_t len, ElfImage* out) {
     if (rd32(sh + 4) != 2) continue;  // SHT_SYMTAB
     uint32_t symoff = rd32(sh + 16), symsize = rd32(sh + 20), link = rd32(sh + 24), entsize = rd32(sh + 36);
     if (entsize < 16 || link >= shnum) continue;
+    if ((size_t)shoff + (size_t)link * shentsize + 40 > len) continue;  // linked string-table header outside the file
     const uint8_t* strsh = d + shoff + (size_t)link * shentsize;
     uint32_t stroff = rd32(strsh + 16), strsize = rd32(strsh + 20);
     if ((size_t)symoff + symsize > len || (size_t)stroff + strsize > len) continue;

@@ -166,7 +166,9 @@ bool parse_proof_header(const uint8_t* bytes, size_t len, ProofHeader* h, std::s
   memcpy(h->pv_digest, w + 6, 32);
   memcpy(h->deferred_digest, w + 14, 32);
   memcpy(h->vk_digest, w + 22, 32);
-  if (h->log_h < 1 || h->log_h > 26) { *err = "log_h out of range"; return false; }
+  // the prover emits 2^5..2^14 (load_batch); a larger claimed height would only make the verifier
+  // hash a huge zero-padded I/O matrix before any check can reject the proof
+  if (h->log_h < 5 || h->log_h > 14) { *err = "log_h out of range"; return false; }
   if (h->pv_len > (1u << 24)) { *err = "public values too long"; return false; }
   if ((uint64_t)h->n_perms * 24 > ((uint64_t)1 << h->log_h)) { *err = "n_perms exceeds trace height"; return false; }
   size_t hw = proof_header_words(h->pv_len, h->n_perms);
@@ -185,6 +187,8 @@ int verify_proof(const uint8_t* bytes, size_t len, const uint32_t vk_digest[8], 
   const size_t h = (size_t)1 << logh;
   if (len != hd.body_offset + proof_body_words(logh, num_queries) * 4) { *err = "proof length mismatch"; return 7; }
   if (memcmp(hd.vk_digest, vk_digest, 32) != 0) { *err = "verifying key mismatch"; return 8; }
+  // a guest that panicked has no proof in the reference either (run() fails, main.rs:71-74)
+  if (hd.exit_code != 0) { *err = "guest exit code is not zero"; return 8; }
   // the guest commits sha256(public values) word by word
   {
     uint8_t dg[32];
