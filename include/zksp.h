@@ -118,6 +118,37 @@ const char* zksp_opcode_name(int index);
 int zksp_execute_keccak(zksp_client* c, const zksp_pk* pk, const zksp_stdin* stdin_, uint64_t* states, size_t cap_perms,
                         size_t* n);
 
+/* ---- machine proof: traced execution records ----
+ * The multi-chip proof binds a proof to the guest's execution: CPU, memory, program, keccak and
+ * multiplier chips joined by LogUp buses.  These entry points expose what the chips are
+ * generated from, as flat arrays (layouts: csrc/host/machine.hpp), for tests and the oracle. */
+typedef struct zksp_mtrace zksp_mtrace;
+#define ZKSP_MT_CYCLES 0        /* 12 u32 per executed cycle */
+#define ZKSP_MT_KECCAK 1        /* 408 bytes per precompile call: ts, ptr, 25 u64 in, 50 u32 previous times */
+#define ZKSP_MT_MEMFINAL 2      /* 5 u32 per touched address: addr, init, fin, fin_ts, is_init */
+#define ZKSP_MT_MULS 3          /* 3 u32 per mul/mulhu: hi, b, c */
+#define ZKSP_MT_PROG_MULT 4     /* u32 per Program-table row */
+#define ZKSP_MT_IMAGE_USED 5    /* u32 per Image-table row */
+#define ZKSP_MT_PROGRAM 6       /* 9 u32 per row: pc, op, wr, use2, rd, rs1, rs2, imm, tgt */
+#define ZKSP_MT_IMAGE 7         /* 2 u32 per row: addr, value */
+#define ZKSP_MT_PUBLIC_VALUES 8 /* bytes */
+typedef struct {
+  uint64_t cycles;
+  uint64_t memory_ops;
+  uint32_t exit_code;
+  uint32_t entry;
+  uint32_t log_prog, log_image;
+  uint32_t keccak_mode;
+  uint32_t pv_digest[8];
+  uint32_t deferred_digest[8];
+} zksp_mtrace_info_t;
+/* Runs the guest with full tracing under the client's keccak mode (does not consume stdin). */
+int zksp_machine_trace(zksp_client* c, const zksp_pk* pk, const zksp_stdin* stdin_, zksp_mtrace** out);
+void zksp_mtrace_free(zksp_mtrace* t);
+/* Borrowed pointer into the handle. */
+int zksp_mtrace_section(const zksp_mtrace* t, int which, const void** ptr, size_t* bytes);
+int zksp_mtrace_info(const zksp_mtrace* t, zksp_mtrace_info_t* info);
+
 /* ---- device-resident hot path (bench.py, parity tests) ---- */
 /* Proof-system parameters this build uses (for sizing buffers). */
 typedef struct {

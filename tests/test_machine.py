@@ -1,0 +1,98 @@
+"""Traced execution (machine.cpp) against the fast executor's goldens, and the offline memory
+argument replayed in numpy: every (address, value, time) tuple that is consumed was produced."""
+import hashlib
+
+import numpy as np
+import pytest
+
+
+def trace_of(zk, client, fixture):
+    pk, _ = client.setup(zk.merkle_elf())
+    s = zk.SP1Stdin()
+    s.write(fixture.to_borsh())
+    return client.machine_trace(pk, s), pk, s
+
+
+@pytest.mark.parametrize("mode,name,cycles", [(2, "acct8", 391400), (1, "acct8", 1406960), (2, "tx", 130629)])
+def test_trace_agrees_with_executor(zk, fx, built_lib, mode, name, cycles):
+    client = zk.ProverClient(device=-1, keccak_mode=mode)
+    m = fx.acct_fixture(8) if name == "acct8" else fx.tx_fixture()
+    t, pk, s = trace_of(zk, client, m)
+    rep, pv, _, rc = client.execute(pk, s, mode)
+    assert rc == 0
+    assert t["info"].cycles == rep.cycles == cycles == len(t["cycles"])
+    assert t["info"].memory_ops == rep.memory_ops
+    assert t["public_values"] == pv
+    assert bytes(np.array(list(t["info"].pv_digest), np.uint32).tobytes()) == hashlib.sha256(pv).digest()
+    assert len(t["keccak"]) == (rep.n_keccak if mode == 2 else 0)
+    assert int(t["prog_mult"].sum()) == cycles
+
+
+@pytest.mark.parametrize("mode", [2, 1])
+def test_memory_argument_balances(zk, fx, built_lib, mode):
+    """Multiset check of the memory bus exactly as the chips will post it: produce = Image rows in use,
+    MemFinal inits, and every slot's write-back; consume = every slot's read and the MemFinal rows."""
+    client = zk.ProverClient(device=-1, keccak_mode=mode)
+    t, _, _ = trace_of(zk, client, fx.tx_fixture())
+    cyc, prog, img = t["cycles"].astype(np.int64), t["program"].astype(np.int64), t["image"].astype(np.int64)
+    n = len(cyc)
+    rows = prog[(cyc[:, 0] - prog[0, 0]) // 4]
+    assert np.array_equal(rows[:, 0], cyc[:, 0])
+    op, wr, use2, rd, rs1, rs2, imm = (rows[:, i] for i in range(1, 8))
+    ts = 4 * (np.arange(n, dtype=np.int64) + 1)
+    a, b, c, m, mv, wprev, r1p, r2p, mp, wp = (cyc[:, i] for i in range(1, 11))
+    prod, cons = [], []
+
+    def tup(addr, val, t_):
+        return np.stack([addr, val, t_], axis=1)
+
+    # R1 / R2 / W slots
+    cons.append(tup(rs1, b, r1p)); prod.append(tup(rs1, b, ts))
+    u = use2 == 1
+    cons.append(tup(rs2[u], c[u], r2p[u])); prod.append(tup(rs2[u], c[u], ts[u] + 1))
+    w = wr == 1
+    cons.append(tup(rd[w], wprev[w], wp[w])); prod.append(tup(rd[w], a[w], ts[w] + 3))
+    # memory slot: loads 19..23, stores 24..26 at (rs1 + imm) & ~3; ecall 29 at register address 11
+    ls = (op >= 19) & (op <= 26)
+    addr = ((b + imm) & 0xFFFFFFFF) & ~3
+    cons.append(tup(addr[ls], m[ls], mp[ls])); prod.append(tup(addr[ls], mv[ls], ts[ls] + 2))
+    ec = op == 29
+    cons.append(tup(np.full(ec.sum(), 11), m[ec], mp[ec])); prod.append(tup(np.full(ec.sum(), 11), mv[ec], ts[ec] + 2))
+    # keccak precompile calls: 50 words each, read-modify-write at ts + 2
+    if len(t["keccak"]):
+        P = 2**64
+        for k in t["keccak"]:
+            st = [int(v) for v in k["in"]]
+            out = fx.keccak_f1600(st)
+            w_in = np.array([(st[i // 2] >> (32 * (i % 2))) & 0xFFFFFFFF for i in range(50)], np.int64)
+            w_out = np.array([(out[i // 2] >> (32 * (i % 2))) & 0xFFFFFFFF for i in range(50)], np.int64)
+            ad = int(k["ptr"]) + 4 * np.arange(50, dtype=np.int64)
+            cons.append(tup(ad, w_in, k["pts"].astype(np.int64)))
+            prod.append(tup(ad, w_out, np.full(50, int(k["ts"]) + 2)))
+    # boundary chips
+    mf = t["memfinal"].astype(np.int64)
+    assert np.all(np.diff(mf[:, 0]) > 0)
+    cons.append(tup(mf[:, 0], mf[:, 2], mf[:, 3]))
+    ini = mf[:, 4] == 1
+    prod.append(tup(mf[ini, 0], mf[ini, 1], np.zeros(ini.sum(), np.int64)))
+    used = t["image_used"] == 1
+    prod.append(tup(img[used, 0], img[used, 1], np.zeros(used.sum(), np.int64)))
+    # image addresses in use are exactly the touched addresses that are not free-initialised
+    assert np.array_equal(np.sort(img[used, 0]), mf[~ini, 0])
+    P_, C_ = np.concatenate(prod), np.concatenate(cons)
+    assert len(P_) == len(C_)
+    key = lambda z: z[np.lexsort((z[:, 2], z[:, 1], z[:, 0]))]
+    assert np.array_equal(key(P_), key(C_))
+    # every consumed time is strictly older than the time of the access that consumes it
+    assert np.all(r1p < ts) and np.all(r2p[u] < ts[u] + 1) and np.all(mp[ls | ec] < ts[ls | ec] + 2) and np.all(wp[w] < ts[w] + 3)
+
+
+def test_unsupported_instruction_is_reported(zk, fx, built_lib):
+    """A guest that panics executes `unimp`; the tracer reports executor faults like the fast executor."""
+    client = zk.ProverClient(device=-1)
+    pk, _ = client.setup(zk.merkle_elf())
+    m = fx.acct_fixture(8)
+    node = bytearray(m.proof[3]); node[-1] ^= 1; m.proof[3] = bytes(node)
+    s = zk.SP1Stdin(); s.write(m.to_borsh())
+    t = client.machine_trace(pk, s)  # the guest panics through HALT(1): a complete trace with exit code 1
+    assert t["info"].exit_code == 1

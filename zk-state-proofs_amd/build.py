@@ -23,16 +23,18 @@ SOURCES = [
     "device/kernels_bus.hip",
     "device/kernels_bench.hip",
     "host/executor.cpp",
+    "host/machine.cpp",
     "host/params.cpp",
     "host/context.cpp",
     "host/prover.cpp",
     "host/verifier.cpp",
     "host/api.cpp",
     "host/api_prove.cpp",
+    "host/api_machine.cpp",
 ]
 HEADERS = [
     "device/field.cuh", "device/poseidon2.cuh", "device/air_keccak.cuh", "device/kernels.h",
-    "host/executor.hpp", "host/context.hpp", "host/prover.hpp", "host/verifier.hpp", "host/api_types.hpp",
+    "host/executor.hpp", "host/machine.hpp", "host/context.hpp", "host/prover.hpp", "host/verifier.hpp", "host/api_types.hpp",
 ]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -55,7 +57,7 @@ def _compile(src: str, force: bool, hdr_time: float) -> str:
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time):
         return obj
     cmd = [_hipcc(), *FLAGS, "-I", INCLUDE]
-    if src.endswith(".cpp") and src != "host/executor.cpp":
+    if src.endswith(".cpp") and src not in ("host/executor.cpp", "host/machine.cpp"):
         cmd += ["-x", "hip"]  # host code that shares the __host__ __device__ field/AIR headers
     cmd += ["-c", path, "-o", obj]
     subprocess.check_call(cmd)

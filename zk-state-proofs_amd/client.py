@@ -55,6 +55,12 @@ class ExecReport(C.Structure):
                 ("syscalls", C.c_uint64 * 6), ("opcode_hist", C.c_uint64 * 64)]
 
 
+class MTraceInfo(C.Structure):
+    _fields_ = [("cycles", C.c_uint64), ("memory_ops", C.c_uint64), ("exit_code", C.c_uint32), ("entry", C.c_uint32),
+                ("log_prog", C.c_uint32), ("log_image", C.c_uint32), ("keccak_mode", C.c_uint32),
+                ("pv_digest", C.c_uint32 * 8), ("deferred_digest", C.c_uint32 * 8)]
+
+
 class Params(C.Structure):
     _fields_ = [("trace_width", C.c_uint32), ("num_constraints", C.c_uint32), ("num_queries", C.c_uint32),
                 ("pow_bits", C.c_uint32), ("max_batch", C.c_uint32)]
@@ -100,6 +106,11 @@ def load_library() -> C.CDLL:
     lib.zksp_execute_keccak.argtypes = [vp, vp, vp, vp, sz, C.POINTER(sz)]
     lib.zksp_opcode_name.argtypes = [C.c_int]
     lib.zksp_opcode_name.restype = C.c_char_p
+    lib.zksp_machine_trace.argtypes = [vp, vp, vp, C.POINTER(vp)]
+    lib.zksp_mtrace_free.argtypes = [vp]
+    lib.zksp_mtrace_free.restype = None
+    lib.zksp_mtrace_section.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(sz)]
+    lib.zksp_mtrace_info.argtypes = [vp, C.POINTER(MTraceInfo)]
     lib.zksp_get_params.argtypes = [vp, C.POINTER(Params)]
     lib.zksp_proof_body_words.argtypes = [vp, C.c_int]
     lib.zksp_proof_body_words.restype = sz
@@ -137,7 +148,8 @@ ABI_SYMBOLS = [
     "zksp_client_new", "zksp_client_free", "zksp_last_error", "zksp_setup", "zksp_pk_free", "zksp_vk_free",
     "zksp_vk_digest", "zksp_stdin_new", "zksp_stdin_write", "zksp_stdin_free", "zksp_prove", "zksp_prove_batch",
     "zksp_proof_public_values", "zksp_proof_serialize", "zksp_proof_deserialize", "zksp_proof_free", "zksp_verify",
-    "zksp_execute", "zksp_execute_keccak", "zksp_opcode_name", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
+    "zksp_execute", "zksp_execute_keccak", "zksp_opcode_name", "zksp_machine_trace", "zksp_mtrace_free",
+    "zksp_mtrace_section", "zksp_mtrace_info", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
     "zksp_hip_prove_resident", "zksp_proof_from_body", "zksp_hip_fetch_bodies", "zksp_hip_fetch_roots", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
     "zksp_hip_profile_enable", "zksp_hip_profile_read", "zksp_hip_profile_reset", "zksp_dev_malloc", "zksp_dev_free",
     "zksp_dev_upload", "zksp_dev_download", "zksp_dev_memset", "zksp_hip_lde", "zksp_hip_merkle_commit",
@@ -336,6 +348,32 @@ class ProverClient:
         if rc:
             raise ZkspError(rc, self.last_error())
         return out
+
+    def machine_trace(self, pk: ProvingKey, stdin: SP1Stdin) -> dict:
+        """Traced execution (``zksp_machine_trace``) as numpy arrays: ``cycles`` [n][12], ``keccak`` (structured:
+        ts, ptr, in[25], pts[50]), ``memfinal`` [n][5], ``muls`` [n][3], ``prog_mult``, ``image_used``,
+        ``program`` [n][9], ``image`` [n][2], ``public_values`` (bytes), ``info`` (MTraceInfo)."""
+        import numpy as np
+        h = C.c_void_p()
+        rc = self._lib.zksp_machine_trace(self._h, pk._h, stdin._h, C.byref(h))
+        if rc:
+            raise ZkspError(rc, self.last_error())
+        try:
+            def sec(which, dtype, cols=None):
+                p, n = C.c_void_p(), C.c_size_t()
+                self._lib.zksp_mtrace_section(h, which, C.byref(p), C.byref(n))
+                raw = C.string_at(p, n.value) if n.value else b""
+                a = np.frombuffer(raw, dtype=dtype).copy()
+                return a.reshape(-1, cols) if cols else a
+            kdt = np.dtype([("ts", "<u4"), ("ptr", "<u4"), ("in", "<u8", (25,)), ("pts", "<u4", (50,))])
+            info = MTraceInfo()
+            self._lib.zksp_mtrace_info(h, C.byref(info))
+            return {"cycles": sec(0, np.uint32, 12), "keccak": sec(1, kdt), "memfinal": sec(2, np.uint32, 5),
+                    "muls": sec(3, np.uint32, 3), "prog_mult": sec(4, np.uint32), "image_used": sec(5, np.uint32),
+                    "program": sec(6, np.uint32, 9), "image": sec(7, np.uint32, 2),
+                    "public_values": bytes(sec(8, np.uint8)), "info": info}
+        finally:
+            self._lib.zksp_mtrace_free(h)
 
     def opcode_histogram(self, rep: ExecReport) -> dict:
         out = {}

@@ -93,6 +93,10 @@ int zksp_setup(zksp_client* c, const uint8_t* elf, size_t elf_len, zksp_pk** pk,
     delete p; delete v;
     return c->ctx.fail(ZKSP_ERR_ELF, "setup: ELF has no keccakf symbol; the keccak chip has nothing to prove");
   }
+  {
+    std::string me = build_machine_program(p->elf, (KeccakMode)c->ctx.params.keccak_mode, &p->mprog);
+    if (!me.empty()) { delete p; delete v; return c->ctx.fail(ZKSP_ERR_ELF, "setup: " + me); }
+  }
   compute_vk_digest(p->elf, p->vk_digest);
   memcpy(v->digest, p->vk_digest, 32);
   *pk = p;

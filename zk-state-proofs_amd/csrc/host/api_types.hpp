@@ -5,10 +5,12 @@
 #include <vector>
 
 #include "context.hpp"
+#include "machine.hpp"
 #include "verifier.hpp"
 
 struct zksp_client { zksp::Context ctx; };
-struct zksp_pk { zksp::ElfImage elf; uint32_t vk_digest[8]; };
+struct zksp_pk { zksp::ElfImage elf; uint32_t vk_digest[8]; zksp::MachineProgram mprog; };
+struct zksp_mtrace { zksp::MachineTrace t; const zksp::MachineProgram* prog; };
 struct zksp_vk { uint32_t digest[8]; };
 struct zksp_stdin { std::vector<std::vector<uint8_t>> entries; };
 struct zksp_proof { std::vector<uint8_t> bytes; zksp::ProofHeader hdr; };

@@ -1,0 +1,378 @@
+// See machine.hpp.  The traced interpreter is the plain, one-switch form of executor.cpp's
+// threaded run loop (same faults, same cycle accounting: tests/test_machine.py compares them on
+// every golden fixture) plus the bookkeeping of the offline memory argument: the previous access
+// time of every register and memory word, the set of touched addresses with their first and last
+// values, multiplicities of the Program and Image tables.
+#include "machine.hpp"
+
+#include <sys/mman.h>
+
+#include <algorithm>
+#include <cstring>
+
+namespace zksp {
+
+namespace {
+
+constexpr uint64_t kMemBytes = 0x78000000ull;
+constexpr uint32_t kRegSpace = 0x1000;  // guest accesses below this are refused: addresses 0..31 name registers
+
+struct Map {
+  uint8_t* base = nullptr;
+  uint64_t len;
+  explicit Map(uint64_t n) : len(n) {
+    void* p = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    base = (p == MAP_FAILED) ? nullptr : (uint8_t*)p;
+  }
+  ~Map() {
+    if (base) munmap(base, len);
+  }
+};
+
+struct SegRange {
+  uint32_t lo, hi, row0;  // byte range [lo, hi), first image row
+};
+
+}  // namespace
+
+std::string build_machine_program(const ElfImage& elf, KeccakMode mode, MachineProgram* out) {
+  *out = MachineProgram();
+  out->entry = elf.entry;
+  out->text_base = elf.text_base;
+  out->keccak_mode = (int)mode;
+  if (elf.code.size() != elf.text.size() + 1) return "ELF image was not decoded";
+  const size_t n = elf.text.size();
+  out->rows.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    const ElfImage::Insn& in = elf.code[i];
+    const uint32_t pc = elf.text_base + 4 * (uint32_t)i;
+    const uint8_t op = in.op & 0x7f;
+    const bool hook = (in.op & 0x80) != 0;
+    ProgramRow r{pc, AIR_NONE, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t rd = in.rd == 32 ? 0 : in.rd, imm = (uint32_t)in.imm;
+    auto alu = [&](uint32_t a, bool has_imm) {
+      r.op = a; r.rd = rd; r.wr = rd != 0; r.rs1 = in.rs1;
+      if (has_imm) { r.use2 = 0; r.imm = imm; } else { r.use2 = 1; r.rs2 = in.rs2; }
+    };
+    auto branch = [&](uint32_t a) { r.op = a; r.rs1 = in.rs1; r.rs2 = in.rs2; r.use2 = 1; r.tgt = pc + imm; };
+    auto load = [&](uint32_t a) { r.op = a; r.rd = rd; r.wr = rd != 0; r.rs1 = in.rs1; r.imm = imm; };
+    auto store = [&](uint32_t a) { r.op = a; r.rs1 = in.rs1; r.rs2 = in.rs2; r.use2 = 1; r.imm = imm; };
+    if (hook && mode == KeccakMode::kReplace) {
+      // the keccakf entry point as the precompile call the `sp1` feature of crypto-ops would compile to
+      // (reference crypto-ops/src/keccak.rs:1-4): permute the 25 lanes at a0 in place, return to ra
+      r.op = AIR_KECCAK; r.rs1 = 1; r.rs2 = 10; r.use2 = 1;
+    } else {
+      switch (op) {
+        case OP_LUI: r.op = AIR_ADD; r.rd = rd; r.wr = rd != 0; r.imm = imm; break;
+        case OP_AUIPC: r.op = AIR_ADD; r.rd = rd; r.wr = rd != 0; r.imm = pc + imm; break;
+        case OP_JAL: r.op = AIR_JAL; r.rd = rd; r.wr = rd != 0; r.imm = pc + 4; r.tgt = pc + imm; break;
+        case OP_JALR: r.op = AIR_JALR; r.rd = rd; r.wr = rd != 0; r.rs1 = in.rs1; r.imm = imm; r.tgt = pc + 4; break;
+        case OP_BEQ: branch(AIR_BEQ); break;
+        case OP_BNE: branch(AIR_BNE); break;
+        case OP_BLT: branch(AIR_BLT); break;
+        case OP_BGE: branch(AIR_BGE); break;
+        case OP_BLTU: branch(AIR_BLTU); break;
+        case OP_BGEU: branch(AIR_BGEU); break;
+        case OP_LB: load(AIR_LB); break;
+        case OP_LH: load(AIR_LH); break;
+        case OP_LW: load(AIR_LW); break;
+        case OP_LBU: load(AIR_LBU); break;
+        case OP_LHU: load(AIR_LHU); break;
+        case OP_SB: store(AIR_SB); break;
+        case OP_SH: store(AIR_SH); break;
+        case OP_SW: store(AIR_SW); break;
+        case OP_ADDI: alu(AIR_ADD, true); break;
+        case OP_SLTI: alu(AIR_SLT, true); break;
+        case OP_SLTIU: alu(AIR_SLTU, true); break;
+        case OP_XORI: alu(AIR_XOR, true); break;
+        case OP_ORI: alu(AIR_OR, true); break;
+        case OP_ANDI: alu(AIR_AND, true); break;
+        case OP_SLLI: alu(AIR_SLL, true); break;
+        case OP_SRLI: alu(AIR_SRL, true); break;
+        case OP_SRAI: alu(AIR_SRA, true); break;
+        case OP_ADD: alu(AIR_ADD, false); break;
+        case OP_SUB: alu(AIR_SUB, false); break;
+        case OP_SLL: alu(AIR_SLL, false); break;
+        case OP_SLT: alu(AIR_SLT, false); break;
+        case OP_SLTU: alu(AIR_SLTU, false); break;
+        case OP_XOR: alu(AIR_XOR, false); break;
+        case OP_SRL: alu(AIR_SRL, false); break;
+        case OP_SRA: alu(AIR_SRA, false); break;
+        case OP_OR: alu(AIR_OR, false); break;
+        case OP_AND: alu(AIR_AND, false); break;
+        case OP_MUL: alu(AIR_MUL, false); break;
+        case OP_MULHU: alu(AIR_MULHU, false); break;
+        case OP_ECALL: r.op = AIR_ECALL; r.rd = 5; r.wr = 1; r.rs1 = 5; r.rs2 = 10; r.use2 = 1; break;
+        case OP_FENCE: r.op = AIR_ADD; break;  // no architectural effect: x0 = x0 + 0, not written
+        default: break;  // mulh, mulhsu, div, divu, rem, remu, unimp, invalid: no AIR row can match
+      }
+    }
+    out->rows[i] = r;
+  }
+  for (uint32_t i = 0; i < 32; ++i) out->image.push_back({i, 0});
+  std::vector<const ElfImage::Seg*> segs;
+  for (const auto& s : elf.segs) segs.push_back(&s);
+  std::sort(segs.begin(), segs.end(), [](const ElfImage::Seg* a, const ElfImage::Seg* b) { return a->vaddr < b->vaddr; });
+  uint32_t prev_end = kRegSpace;
+  for (const ElfImage::Seg* s : segs) {
+    const uint64_t extent = std::max<uint64_t>(s->bytes.size(), s->memsz);
+    if (extent == 0) continue;
+    if (s->vaddr < prev_end) return "segments overlap or start inside the register space";
+    if ((uint64_t)s->vaddr + extent > kMemBytes) return "segment beyond guest memory";
+    const uint32_t end = (uint32_t)((s->vaddr + extent + 3) & ~3ull);
+    for (uint32_t a = s->vaddr; a < end; a += 4) {
+      uint32_t v = 0;
+      for (int k = 0; k < 4; ++k) {
+        const uint64_t off = (uint64_t)(a - s->vaddr) + k;
+        if (off < s->bytes.size()) v |= (uint32_t)s->bytes[off] << (8 * k);
+      }
+      out->image.push_back({a, v});
+    }
+    prev_end = end;
+  }
+  auto clog2 = [](size_t v) { int l = 0; while (((size_t)1 << l) < v) ++l; return l; };
+  out->log_prog = std::max(5, clog2(out->rows.size()));
+  out->log_image = std::max(5, clog2(out->image.size()));
+  return "";
+}
+
+void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::vector<std::vector<uint8_t>>& stdin_entries,
+                   uint64_t max_cycles, MachineTrace* out) {
+  *out = MachineTrace();
+  ExecutionRecord& rec = out->rec;
+  Map mem(kMemBytes), shadow(kMemBytes);  // shadow: one u32 per word = 1 + index into `touched`
+  if (!mem.base || !shadow.base) { rec.error = "mmap of guest memory failed"; return; }
+  uint8_t* M = mem.base;
+  uint32_t* SH = reinterpret_cast<uint32_t*>(shadow.base);
+  std::vector<SegRange> ranges;
+  {
+    // image rows after the 32 registers are the segments' words in address order
+    size_t row = 32;
+    while (row < prog.image.size()) {
+      size_t e = row;
+      while (e + 1 < prog.image.size() && prog.image[e + 1].addr == prog.image[e].addr + 4) ++e;
+      ranges.push_back({prog.image[row].addr, prog.image[e].addr + 4, (uint32_t)row});
+      row = e + 1;
+    }
+    for (size_t r = 32; r < prog.image.size(); ++r) memcpy(M + prog.image[r].addr, &prog.image[r].val, 4);
+  }
+  auto image_row = [&](uint32_t w) -> int64_t {
+    for (const SegRange& s : ranges)
+      if (w >= s.lo && w < s.hi) return (int64_t)s.row0 + ((w - s.lo) >> 2);
+    return -1;
+  };
+  struct Touched { uint32_t addr, init, last_ts, is_init; };
+  std::vector<Touched> touched;
+  out->prog_mult.assign(prog.rows.size(), 0);
+  out->image_used.assign(prog.image.size(), 0);
+  uint32_t x[32] = {0}, reg_ts[32] = {0};
+  bool reg_touched[32] = {false};
+  const uint32_t text_lo = prog.text_base, text_bytes = 4 * (uint32_t)prog.rows.size();
+  size_t stdin_pos = 0;
+  uint64_t cycles = 0;
+
+#define FAULT(msg) do { rec.error = (msg); goto done; } while (0)
+#define CHECK_ADDR(ad, n) if ((uint64_t)(ad) + (n) > kMemBytes) FAULT("memory access out of range")
+
+  // previous access time of word w, which is touched at time `now`
+  auto touch = [&](uint32_t w, uint32_t now) -> uint32_t {
+    uint32_t id = SH[w >> 2];
+    if (id == 0) {
+      uint32_t v;
+      memcpy(&v, M + w, 4);
+      const int64_t ir = image_row(w);
+      if (ir >= 0) out->image_used[(size_t)ir] = 1;
+      touched.push_back({w, v, 0, ir < 0 ? 1u : 0u});
+      id = (uint32_t)touched.size();
+      SH[w >> 2] = id;
+    }
+    Touched& t = touched[id - 1];
+    const uint32_t prev = t.last_ts;
+    t.last_ts = now;
+    return prev;
+  };
+
+  {
+    uint32_t pc = prog.entry;
+    for (;;) {
+      const uint32_t off = pc - text_lo;
+      if (off >= text_bytes || (pc & 3)) FAULT("pc outside text segment");
+      const size_t idx = off >> 2;
+      const ProgramRow& r = prog.rows[idx];
+      if (cycles >= max_cycles) FAULT("cycle limit exceeded");
+      if (r.op == AIR_NONE) {
+        const uint8_t eop = elf.code[idx].op & 0x7f;
+        if (eop == OP_UNIMP) FAULT("unimp executed");
+        if (eop == OP_INVALID) FAULT("illegal instruction");
+        FAULT(std::string("instruction not covered by the machine AIR: ") + op_name(eop));
+      }
+      const uint32_t ts = 4 * (uint32_t)(cycles + 1);
+      ++cycles;
+      out->prog_mult[idx]++;
+      CycleRec c{};
+      c.pc = pc;
+      c.b = x[r.rs1];
+      c.r1_pts = reg_ts[r.rs1]; reg_ts[r.rs1] = ts; reg_touched[r.rs1] = true;
+      if (r.use2) {
+        c.c = x[r.rs2];
+        c.r2_pts = reg_ts[r.rs2]; reg_ts[r.rs2] = ts + 1; reg_touched[r.rs2] = true;
+      } else {
+        c.c = r.imm;
+      }
+      const uint32_t a = c.b, b = c.c;
+      uint32_t res = 0, next = pc + 4;
+      bool halt = false;
+      switch (r.op) {
+        case AIR_ADD: res = a + b; break;
+        case AIR_SUB: res = a - b; break;
+        case AIR_XOR: res = a ^ b; break;
+        case AIR_OR: res = a | b; break;
+        case AIR_AND: res = a & b; break;
+        case AIR_SLL: res = a << (b & 31); break;
+        case AIR_SRL: res = a >> (b & 31); break;
+        case AIR_SRA: res = (uint32_t)((int32_t)a >> (b & 31)); break;
+        case AIR_SLT: res = (int32_t)a < (int32_t)b; break;
+        case AIR_SLTU: res = a < b; break;
+        case AIR_JAL: res = r.imm; next = r.tgt; break;
+        case AIR_JALR: res = r.tgt; next = (a + r.imm) & ~1u; break;
+        case AIR_BEQ: if (a == b) next = r.tgt; break;
+        case AIR_BNE: if (a != b) next = r.tgt; break;
+        case AIR_BLT: if ((int32_t)a < (int32_t)b) next = r.tgt; break;
+        case AIR_BGE: if ((int32_t)a >= (int32_t)b) next = r.tgt; break;
+        case AIR_BLTU: if (a < b) next = r.tgt; break;
+        case AIR_BGEU: if (a >= b) next = r.tgt; break;
+        case AIR_MUL: res = a * b; out->muls.push_back({0, a, b}); break;
+        case AIR_MULHU: res = (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); out->muls.push_back({1, a, b}); break;
+        case AIR_LB: case AIR_LH: case AIR_LW: case AIR_LBU: case AIR_LHU: {
+          const uint32_t ad = a + r.imm;
+          const int sz = (r.op == AIR_LW) ? 4 : (r.op == AIR_LH || r.op == AIR_LHU) ? 2 : 1;
+          if (ad & (sz - 1)) FAULT(sz == 4 ? "unaligned lw" : (r.op == AIR_LH ? "unaligned lh" : "unaligned lhu"));
+          CHECK_ADDR(ad, sz);
+          if (ad < kRegSpace) FAULT("guest access below 0x1000 (register-mapped addresses)");
+          const uint32_t w = ad & ~3u;
+          c.m_pts = touch(w, ts + 2);
+          memcpy(&c.m, M + w, 4);
+          c.mv = c.m;
+          const uint32_t sh = 8 * (ad & 3);
+          if (r.op == AIR_LW) res = c.m;
+          else if (r.op == AIR_LHU) res = (c.m >> sh) & 0xffff;
+          else if (r.op == AIR_LH) res = (uint32_t)(int32_t)(int16_t)((c.m >> sh) & 0xffff);
+          else if (r.op == AIR_LBU) res = (c.m >> sh) & 0xff;
+          else res = (uint32_t)(int32_t)(int8_t)((c.m >> sh) & 0xff);
+          ++rec.memory_ops;
+          break;
+        }
+        case AIR_SB: case AIR_SH: case AIR_SW: {
+          const uint32_t ad = a + r.imm;
+          const int sz = (r.op == AIR_SW) ? 4 : (r.op == AIR_SH) ? 2 : 1;
+          if (ad & (sz - 1)) FAULT(sz == 4 ? "unaligned sw" : "unaligned sh");
+          CHECK_ADDR(ad, sz);
+          if (ad < kRegSpace) FAULT("guest access below 0x1000 (register-mapped addresses)");
+          const uint32_t w = ad & ~3u;
+          c.m_pts = touch(w, ts + 2);
+          memcpy(&c.m, M + w, 4);
+          const uint32_t sh = 8 * (ad & 3);
+          if (r.op == AIR_SW) c.mv = b;
+          else if (r.op == AIR_SH) c.mv = (c.m & ~(0xffffu << sh)) | ((b & 0xffff) << sh);
+          else c.mv = (c.m & ~(0xffu << sh)) | ((b & 0xff) << sh);
+          memcpy(M + w, &c.mv, 4);
+          ++rec.memory_ops;
+          break;
+        }
+        case AIR_ECALL: {
+          // t0 = a (code), a0 = b; a1 is read through the memory slot (register address 11)
+          const uint32_t codeid = a, a0 = b, a1 = x[11], a2 = x[12];
+          c.m = a1; c.mv = a1;
+          c.m_pts = reg_ts[11]; reg_ts[11] = ts + 2; reg_touched[11] = true;
+          rec.syscall_counts[codeid & 0xff]++;
+          res = a;  // t0 is rewritten with itself except by HINT_LEN
+          switch (codeid) {
+            case 0x00: rec.exit_code = a0; rec.halted = true; halt = true; break;
+            case 0x02: {
+              CHECK_ADDR(a1, a2);
+              const char* p = (const char*)(M + a1);
+              if (a0 == 1) rec.stdout_text.append(p, a2);
+              else if (a0 == 2) rec.stderr_text.append(p, a2);
+              else if (a0 == 3) rec.public_values.insert(rec.public_values.end(), M + a1, M + a1 + a2);
+              else if (a0 == 4) {}
+              else FAULT("WRITE to unsupported fd");
+              break;
+            }
+            case 0x10: if (a0 >= 8) FAULT("COMMIT word index out of range"); rec.pv_digest[a0] = a1; break;
+            case 0x1a: if (a0 >= 8) FAULT("COMMIT_DEFERRED word index out of range"); rec.deferred_digest[a0] = a1; break;
+            case 0xf0:
+              if (stdin_pos >= stdin_entries.size()) FAULT("HINT_LEN: input stream exhausted");
+              res = (uint32_t)stdin_entries[stdin_pos].size();
+              break;
+            case 0xf1: {
+              if (stdin_pos >= stdin_entries.size()) FAULT("HINT_READ: input stream exhausted");
+              const auto& e = stdin_entries[stdin_pos];
+              if (a1 != e.size()) FAULT("HINT_READ: length mismatch");
+              if (a0 & 3) FAULT("HINT_READ: unaligned pointer");
+              CHECK_ADDR(a0, (a1 + 3) & ~3u);
+              // hinted words become the INITIAL memory contents of the proof (SP1 treats hint_read the same
+              // way): they must not have been accessed before, and must lie outside the program image
+              for (uint32_t w = a0; w < a0 + ((a1 + 3) & ~3u); w += 4)
+                if (SH[w >> 2] != 0 || image_row(w) >= 0 || w < kRegSpace) FAULT("HINT_READ into memory that is already in use");
+              memcpy(M + a0, e.data(), e.size());
+              ++stdin_pos;
+              break;
+            }
+            default: FAULT("unsupported syscall code");
+          }
+          break;
+        }
+        case AIR_KECCAK: {
+          const uint32_t ptr = b;  // a0
+          if (ptr & 7) FAULT("keccakf state pointer not 8-byte aligned");
+          CHECK_ADDR(ptr, 200);
+          if (ptr < kRegSpace) FAULT("guest access below 0x1000 (register-mapped addresses)");
+          KeccakCall k;
+          k.ts = ts; k.ptr = ptr;
+          memcpy(k.in, M + ptr, 200);
+          for (int i = 0; i < 50; ++i) k.pts[i] = touch(ptr + 4 * (uint32_t)i, ts + 2);
+          uint64_t st[25];
+          memcpy(st, k.in, 200);
+          keccak_f1600(st);
+          memcpy(M + ptr, st, 200);
+          out->keccak.push_back(k);
+          KeccakEvent ev;
+          memcpy(ev.state_in, k.in, 200);
+          ev.state_ptr = ptr; ev.cycle = cycles - 1;
+          rec.keccak_events.push_back(ev);
+          next = a;  // return to ra
+          break;
+        }
+        default: FAULT("internal: unknown AIR op");
+      }
+      c.a = res;
+      if (r.wr) {
+        c.w_prev = x[r.rd];
+        c.w_pts = reg_ts[r.rd]; reg_ts[r.rd] = ts + 3; reg_touched[r.rd] = true;
+        x[r.rd] = res;
+      }
+      out->cycles.push_back(c);
+      if (halt) break;
+      pc = next;
+    }
+  }
+done:
+#undef FAULT
+#undef CHECK_ADDR
+  rec.cycles = cycles;
+  if (!rec.error.empty()) return;
+  // every touched address, strictly increasing: registers first (addresses 0..31), then memory words
+  for (uint32_t i = 0; i < 32; ++i)
+    if (reg_touched[i]) {
+      out->memfinal.push_back({i, 0, x[i], reg_ts[i], 0});
+      out->image_used[i] = 1;
+    }
+  std::sort(touched.begin(), touched.end(), [](const Touched& p, const Touched& q) { return p.addr < q.addr; });
+  for (const Touched& t : touched) {
+    uint32_t fin;
+    memcpy(&fin, M + t.addr, 4);
+    out->memfinal.push_back({t.addr, t.init, fin, t.last_ts, t.is_init});
+  }
+}
+
+}  // namespace zksp

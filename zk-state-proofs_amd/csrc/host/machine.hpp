@@ -1,0 +1,95 @@
+// The RISC-V machine the multi-chip proof is about: program and
+// memory-image tables derived from the guest ELF, and the traced execution that feeds every chip.
+//
+// Replaces, for this repository's own proof system, what sp1-core-executor's ExecutionRecord and
+// sp1-core-machine's Program / MemoryProgram tables are to SP1 (reference Cargo.lock:7096, :7130;
+// reached only beneath `client.prove(&pk, stdin).run()`, prover/src/bin/main.rs:71-74).  The
+// statement a machine proof establishes is the reference's: the committed guest
+// (circuits/sp1-merkle-proof/src/main.rs:4-14) ran crypto_ops::verify_merkle_proof
+// (crypto-ops/src/lib.rs:8-23) to HALT(0) and committed these public values.
+//
+// Record layouts are plain arrays of u32/u64 because the same bytes go to the device (trace
+// expansion kernels) and, in tests, to the CPU oracle.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "executor.hpp"
+
+namespace zksp {
+
+// AIR opcodes (one selector column each in the CPU chip; 0 = not provable)
+enum AirOp : uint32_t {
+  AIR_NONE = 0,
+  AIR_ADD, AIR_SUB, AIR_XOR, AIR_OR, AIR_AND, AIR_SLL, AIR_SRL, AIR_SRA, AIR_SLT, AIR_SLTU,
+  AIR_JAL, AIR_JALR, AIR_BEQ, AIR_BNE, AIR_BLT, AIR_BGE, AIR_BLTU, AIR_BGEU,
+  AIR_LB, AIR_LH, AIR_LW, AIR_LBU, AIR_LHU, AIR_SB, AIR_SH, AIR_SW,
+  AIR_MUL, AIR_MULHU, AIR_ECALL, AIR_KECCAK,
+  AIR_NUM_OPS  // 31: ops are 1..30
+};
+
+// One row of the preprocessed Program table (9 u32).
+struct ProgramRow {
+  uint32_t pc, op, wr, use2, rd, rs1, rs2, imm, tgt;
+};
+// One row of the preprocessed memory-image table: registers x0..x31 at addresses 0..31 (value 0),
+// then every word of every PT_LOAD segment (p_memsz extent, zero beyond p_filesz).
+struct ImageRow {
+  uint32_t addr, val;
+};
+
+struct MachineProgram {
+  std::vector<ProgramRow> rows;  // one per instruction word of the text segment, in address order
+  std::vector<ImageRow> image;   // sorted by addr
+  uint32_t entry = 0;
+  uint32_t text_base = 0;
+  int keccak_mode = 2;           // KeccakMode: kReplace patches keccakf entry points to AIR_KECCAK
+  int log_prog = 0, log_image = 0;  // table heights (powers of two covering rows / image)
+};
+
+// One executed cycle (12 u32).  Everything else a CPU-chip row holds follows from the Program
+// table row of `pc` and the row index (ts = 4 * (index + 1)).
+struct CycleRec {
+  uint32_t pc;
+  uint32_t a;       // value written to rd (or the op's result when rd = x0)
+  uint32_t b;       // reg[rs1]
+  uint32_t c;       // reg[rs2], or the immediate when the instruction has one
+  uint32_t m;       // memory slot: word read (loads, stores: the old word; ecall: x11)
+  uint32_t mv;      // memory slot: word left behind
+  uint32_t w_prev;  // previous value of rd
+  uint32_t r1_pts, r2_pts, m_pts, w_pts;  // previous access time of each slot's address
+  uint32_t pad;
+};
+// One keccak precompile call: 25 u64 in, previous access times of its 50 words.
+struct KeccakCall {
+  uint32_t ts, ptr;
+  uint64_t in[25];
+  uint32_t pts[50];
+};
+struct MemFinalRec {
+  uint32_t addr, init, fin, fin_ts, is_init;
+};
+struct MulRec {
+  uint32_t hi, b, c;
+};
+
+struct MachineTrace {
+  ExecutionRecord rec;  // cycles, exit code, public values, digests, error text
+  std::vector<CycleRec> cycles;
+  std::vector<KeccakCall> keccak;
+  std::vector<MemFinalRec> memfinal;  // every touched address, strictly increasing
+  std::vector<MulRec> muls;
+  std::vector<uint32_t> prog_mult;    // per Program row
+  std::vector<uint32_t> image_used;   // per Image row: 0 / 1
+};
+
+// Builds the two preprocessed tables.  Returns "" or an error.
+std::string build_machine_program(const ElfImage& elf, KeccakMode mode, MachineProgram* out);
+
+// Executes the guest and records what every chip needs.  rec.error is set (and the trace is
+// unusable) on executor faults and on instructions the AIR does not cover.
+void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::vector<std::vector<uint8_t>>& stdin_entries,
+                   uint64_t max_cycles, MachineTrace* out);
+
+}  // namespace zksp
