@@ -1,0 +1,647 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY (see field.h and machine.h).
+ *
+ * Whole machine proof on the CPU: the multi-table STARK that sp1-stark / sp1-prover 3.4.0 build over
+ * p3-uni-stark, p3-fri, p3-merkle-tree (mixed-height MMCS) and p3-challenger (reference
+ * Cargo.lock:7485, :7273, :5378, :5253, :5336, :5197) beneath `client.prove(&pk, stdin).run()`
+ * (prover/src/bin/main.rs:71-74), restated under this repository's own format "ZKSP v3"
+ * (DESIGN.md "Machine proof").  PARITY UNPINNED vs SP1 proof bytes.  The HIP prover must
+ * reproduce these bytes exactly.
+ *
+ *   rounds      0 preprocessed (Program, Image; part of the verifying key), 1 main traces,
+ *               2 LogUp permutation traces (helper columns + running sum), 3 quotient chunks
+ *   commitment  one Poseidon2 Merkle tree per round over ALL chips: a leaf is the hash of the rows
+ *               of the tallest matrices; a shorter matrix is injected one level up per halving,
+ *               node = compress(compress(left, right), hash(rows)).  Tree position of LDE point
+ *               (coset c, index m) of a height-H matrix: c * H + bitreverse(m), so that position >> d
+ *               is the matching point (c, m mod H / 2^d) of a matrix 2^d times shorter.
+ *   FRI         input of height 2^k joins the folding when the folded layer reaches 2^k points per
+ *               coset (index-aligned addition), as in p3-fri's multi-height commit phase
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "machine.h"
+
+static uint32_t bitrev32(uint32_t v, int bits) {
+  uint32_t r = 0;
+  for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1u) << (bits - 1 - i);
+  return r;
+}
+static int ceil_log2(size_t v) {
+  int l = 0;
+  while (((size_t)1 << l) < v) ++l;
+  return l;
+}
+static fe4 eval_poly(const uint32_t* coef, size_t n, fe4 z) {
+  fe4 acc = e_zero();
+  for (size_t k = n; k-- > 0;) acc = e_add(e_mul(acc, z), e_from(coef[k]));
+  return acc;
+}
+
+typedef struct { uint32_t* w; size_t n, cap; } wbuf;
+static void put(wbuf* b, const uint32_t* v, size_t n) {
+  if (b->n + n <= b->cap) memcpy(b->w + b->n, v, n * 4);
+  b->n += n;
+}
+static void observe_word_halves(orc_challenger* ch, const uint32_t* w, int n) {
+  for (int i = 0; i < n; ++i) { orc_ch_observe(ch, w[i] & 0xffff); orc_ch_observe(ch, w[i] >> 16); }
+}
+static void observe_list_root(orc_challenger* ch, const uint32_t* words, size_t n_words, int logr) {
+  size_t r = (size_t)1 << logr;
+  uint32_t* vpad = (uint32_t*)calloc(8 * r, 4);
+  memcpy(vpad, words, n_words * 4);
+  uint32_t* tree = (uint32_t*)malloc(8 * (2 * r - 1) * 4);
+  orc_merkle_commit(vpad, 8, logr, tree);
+  orc_ch_observe_many(ch, tree + 8 * (2 * r - 2), 8);
+  free(vpad);
+  free(tree);
+}
+
+/* ---- per-chip working set ---- */
+enum { R_PREP = 0, R_MAIN, R_PERM, R_QUOT, N_ROUNDS };
+typedef struct {
+  const orc_chip* def;
+  int logh;
+  size_t h;
+  int w[N_ROUNDS];
+  uint32_t* tr[N_ROUNDS];    /* traces / quotient values [w][H] */
+  uint32_t* lde[N_ROUNDS];   /* [w][2][H] */
+  uint32_t* coef[N_ROUNDS];  /* [w][H] */
+  fe4 cum;
+} chipd;
+
+/* ---- mixed-height commitment ---- */
+typedef struct { int logn; uint32_t** level; } mmcs;
+
+static void group_hash(const chipd* cd, int round, int group_logn, size_t pos, uint32_t* out8, uint32_t* rowbuf) {
+  size_t n = 0;
+  for (int c = 0; c < N_CHIPS; ++c) {
+    const chipd* d = &cd[c];
+    if (d->w[round] == 0 || d->logh + 1 != group_logn) continue;
+    const size_t cs = pos >> d->logh, m = bitrev32((uint32_t)(pos & (d->h - 1)), d->logh);
+    for (int col = 0; col < d->w[round]; ++col) rowbuf[n++] = d->lde[round][((size_t)col * 2 + cs) * d->h + m];
+  }
+  orc_hash_elems(rowbuf, n, out8);
+}
+static int group_exists(const chipd* cd, int round, int group_logn) {
+  for (int c = 0; c < N_CHIPS; ++c)
+    if (cd[c].w[round] && cd[c].logh + 1 == group_logn) return 1;
+  return 0;
+}
+static int round_width(const chipd* cd, int round) {
+  int w = 0;
+  for (int c = 0; c < N_CHIPS; ++c) w += cd[c].w[round];
+  return w;
+}
+
+static void mmcs_commit(const chipd* cd, int round, mmcs* t) {
+  int lm = 0;
+  for (int c = 0; c < N_CHIPS; ++c)
+    if (cd[c].w[round] && cd[c].logh > lm) lm = cd[c].logh;
+  t->logn = lm + 1;
+  t->level = (uint32_t**)calloc((size_t)t->logn + 1, sizeof(uint32_t*));
+  const int wmax = round_width(cd, round);
+  for (int l = 0; l <= t->logn; ++l) {
+    const size_t cnt = (size_t)1 << (t->logn - l);
+    t->level[l] = (uint32_t*)malloc(8 * cnt * 4);
+    const int inject = group_exists(cd, round, t->logn - l);
+#pragma omp parallel
+    {
+      uint32_t* rowbuf = (uint32_t*)malloc((size_t)(wmax + 1) * 4);
+#pragma omp for schedule(static)
+      for (size_t p = 0; p < cnt; ++p) {
+        uint32_t* d = t->level[l] + 8 * p;
+        if (l == 0) {
+          group_hash(cd, round, t->logn, p, d, rowbuf);
+        } else {
+          orc_compress(t->level[l - 1] + 16 * p, t->level[l - 1] + 16 * p + 8, d);
+          if (inject) {
+            uint32_t g[8], r[8];
+            group_hash(cd, round, t->logn - l, p, g, rowbuf);
+            orc_compress(d, g, r);
+            memcpy(d, r, 32);
+          }
+        }
+      }
+      free(rowbuf);
+    }
+  }
+}
+static const uint32_t* mmcs_root(const mmcs* t) { return t->level[t->logn]; }
+static void mmcs_free(mmcs* t) {
+  for (int l = 0; l <= t->logn; ++l) free(t->level[l]);
+  free(t->level);
+}
+/* rows of every chip in the round at the query point, then the path */
+static void mmcs_open(const chipd* cd, int round, const mmcs* t, size_t cs, size_t m_max, wbuf* pb) {
+  const int lm = t->logn - 1;
+  for (int c = 0; c < N_CHIPS; ++c) {
+    const chipd* d = &cd[c];
+    if (!d->w[round]) continue;
+    const size_t m = m_max & (d->h - 1);
+    for (int col = 0; col < d->w[round]; ++col) put(pb, &d->lde[round][((size_t)col * 2 + cs) * d->h + m], 1);
+  }
+  const size_t hm = (size_t)1 << lm;
+  const size_t pos = cs * hm + bitrev32((uint32_t)(m_max & (hm - 1)), lm);
+  for (int l = 0; l < t->logn; ++l) put(pb, t->level[l] + 8 * ((pos >> l) ^ 1), 8);
+}
+
+/* ---- LogUp: fingerprints as sparse affine extension-field forms of the row ---- */
+typedef struct { int n; int col[LF_MAX * INTER_MAX_ELEMS]; fe4 coef[LF_MAX * INTER_MAX_ELEMS]; fe4 c0; } aff;
+
+static void aff_add(aff* a, int col, fe4 v) {
+  for (int i = 0; i < a->n; ++i)
+    if (a->col[i] == col) { a->coef[i] = e_add(a->coef[i], v); return; }
+  a->col[a->n] = col;
+  a->coef[a->n] = v;
+  a->n++;
+}
+static void build_aff(const orc_inter* it, fe4 gamma, const fe4* bpow, aff* a) {
+  a->n = 0;
+  a->c0 = e_add(gamma, e_from((fe)it->bus));
+  for (int j = 0; j < it->n_el; ++j) {
+    const orc_lf* f = &it->el[j];
+    a->c0 = e_add(a->c0, e_mul_base(bpow[j + 1], f->c0));
+    for (int t = 0; t < f->n; ++t) aff_add(a, f->col[t], e_mul_base(bpow[j + 1], f->coef[t]));
+  }
+}
+static inline fe4 aff_eval(const aff* a, const uint32_t* row) {
+  fe4 f = a->c0;
+  for (int i = 0; i < a->n; ++i) f = e_add(f, e_mul_base(a->coef[i], row[a->col[i]]));
+  return f;
+}
+static inline fe lf_eval(const orc_lf* f, const uint32_t* row) {
+  fe v = f->c0;
+  for (int i = 0; i < f->n; ++i) v = f_add(v, f_mul(f->coef[i], row[f->col[i]]));
+  return v;
+}
+/* extension-field versions for rows of extension elements are not needed by the prover */
+
+static void gather_row(const chipd* d, const uint32_t* const* src, int is_lde, size_t cs, size_t m, uint32_t* row) {
+  /* row = [prep | main]; src[R_PREP], src[R_MAIN] are traces ([w][H]) or LDEs ([w][2][H]) */
+  int n = 0;
+  for (int r = R_PREP; r <= R_MAIN; ++r)
+    for (int col = 0; col < d->w[r]; ++col)
+      row[n++] = is_lde ? src[r][((size_t)col * 2 + cs) * d->h + m] : src[r][(size_t)col * d->h + m];
+}
+
+static void perm_trace(chipd* d, fe4 gamma, const fe4* bpow) {
+  const orc_chip* def = d->def;
+  const int ni = def->n_inter, nh = orc_chip_helpers(def), rw = d->w[R_PREP] + d->w[R_MAIN];
+  const size_t h = d->h;
+  aff* af = (aff*)malloc((size_t)ni * sizeof(aff));
+  for (int i = 0; i < ni; ++i) build_aff(&def->inter[i], gamma, bpow, &af[i]);
+  uint32_t* p = d->tr[R_PERM];
+  fe4* rowsum = (fe4*)malloc(h * sizeof(fe4));
+  const uint32_t* src[2] = {d->tr[R_PREP], d->tr[R_MAIN]};
+#pragma omp parallel
+  {
+    uint32_t* row = (uint32_t*)malloc((size_t)rw * 4);
+#pragma omp for schedule(static)
+    for (size_t r = 0; r < h; ++r) {
+      gather_row(d, src, 0, 0, r, row);
+      fe4 tot = e_zero();
+      for (int j = 0; j < nh; ++j) {
+        fe4 hj = e_zero();
+        for (int k = 2 * j; k < 2 * j + 2 && k < ni; ++k) {
+          fe m = lf_eval(&def->inter[k].mult, row);
+          if (m == 0) continue;
+          if (def->inter[k].sign < 0) m = f_neg(m);
+          hj = e_add(hj, e_mul_base(e_inv(aff_eval(&af[k], row)), m));
+        }
+        for (int t = 0; t < 4; ++t) p[(size_t)(4 * j + t) * h + r] = hj.c[t];
+        tot = e_add(tot, hj);
+      }
+      rowsum[r] = tot;
+    }
+    free(row);
+  }
+  fe4 acc = e_zero();
+  for (size_t r = 0; r < h; ++r) {
+    for (int t = 0; t < 4; ++t) p[(size_t)(4 * nh + t) * h + r] = acc.c[t];
+    acc = e_add(acc, rowsum[r]);
+  }
+  d->cum = acc;
+  free(rowsum);
+  free(af);
+}
+
+/* ---- quotient of one chip ---- */
+static void chip_quotient(chipd* d, int chip, fe4 alpha, fe4 gamma, const fe4* bpow, uint32_t pub) {
+  const orc_chip* def = d->def;
+  const int ni = def->n_inter, nh = orc_chip_helpers(def), nb = def->n_constraints, total = nb + nh + 3;
+  const int rw = d->w[R_PREP] + d->w[R_MAIN], pw = d->w[R_PREP];
+  const size_t h = d->h;
+  fe4* apow = (fe4*)malloc((size_t)total * sizeof(fe4));
+  apow[0] = e_one();
+  for (int k = 1; k < total; ++k) apow[k] = e_mul(apow[k - 1], alpha);
+  aff* af = (aff*)malloc((size_t)ni * sizeof(aff));
+  for (int i = 0; i < ni; ++i) build_aff(&def->inter[i], gamma, bpow, &af[i]);
+  const fe wh = f_root_of_unity(d->logh), w2h = f_root_of_unity(d->logh + 1), wh_inv = f_inv(wh);
+  const uint32_t* src[2] = {d->lde[R_PREP], d->lde[R_MAIN]};
+  const uint32_t* lp = d->lde[R_PERM];
+  uint32_t* out = d->tr[R_QUOT];
+  for (int cs = 0; cs < 2; ++cs) {
+    const fe shift = cs ? f_mul(F_GEN, w2h) : F_GEN;
+    const fe zh = f_sub(f_pow(shift, h), 1), zh_inv = f_inv(zh);
+#pragma omp parallel
+    {
+      uint32_t* loc = (uint32_t*)malloc((size_t)rw * 4 * 2);
+      uint32_t* nxt = loc + rw;
+      uint32_t* cons = (uint32_t*)malloc((size_t)(nb + 1) * 4);
+#pragma omp for schedule(static)
+      for (size_t m = 0; m < h; ++m) {
+        const size_t mn = (m + 1) & (h - 1);
+        gather_row(d, src, 1, (size_t)cs, m, loc);
+        gather_row(d, src, 1, (size_t)cs, mn, nxt);
+        const fe x = f_mul(shift, f_pow(wh, m));
+        const fe is_first = f_mul(zh, f_inv(f_sub(x, 1)));
+        const fe is_last = f_mul(zh, f_inv(f_sub(x, wh_inv)));
+        const fe is_trans = f_sub(x, wh_inv);
+        orc_machine_constraints(chip, loc, loc + pw, nxt + pw, is_first, is_last, is_trans, pub, cons);
+        fe4 acc = e_zero();
+        for (int k = 0; k < nb; ++k) acc = e_add(acc, e_mul_base(apow[k], cons[k]));
+        /* LogUp: helpers, then the running sum */
+        fe4 hsum = e_zero();
+        for (int j = 0; j < nh; ++j) {
+          fe4 hj;
+          for (int t = 0; t < 4; ++t) hj.c[t] = lp[((size_t)(4 * j + t) * 2 + cs) * h + m];
+          hsum = e_add(hsum, hj);
+          const int ka = 2 * j, kb = 2 * j + 1;
+          fe ma = lf_eval(&def->inter[ka].mult, loc);
+          if (def->inter[ka].sign < 0) ma = f_neg(ma);
+          const fe4 fa = aff_eval(&af[ka], loc);
+          fe4 v;
+          if (kb < ni) {
+            fe mb = lf_eval(&def->inter[kb].mult, loc);
+            if (def->inter[kb].sign < 0) mb = f_neg(mb);
+            const fe4 fb = aff_eval(&af[kb], loc);
+            v = e_sub(e_mul(e_mul(hj, fa), fb), e_add(e_mul_base(fb, ma), e_mul_base(fa, mb)));
+          } else {
+            v = e_sub(e_mul(hj, fa), e_from(ma));
+          }
+          acc = e_add(acc, e_mul(apow[nb + j], v));
+        }
+        fe4 phi, phin;
+        for (int t = 0; t < 4; ++t) {
+          phi.c[t] = lp[((size_t)(4 * nh + t) * 2 + cs) * h + m];
+          phin.c[t] = lp[((size_t)(4 * nh + t) * 2 + cs) * h + mn];
+        }
+        acc = e_add(acc, e_mul(apow[nb + nh], e_mul_base(phi, is_first)));
+        acc = e_add(acc, e_mul(apow[nb + nh + 1], e_mul_base(e_sub(e_sub(phin, phi), hsum), is_trans)));
+        acc = e_add(acc, e_mul(apow[nb + nh + 2], e_mul_base(e_sub(e_sub(d->cum, phi), hsum), is_last)));
+        acc = e_mul_base(acc, zh_inv);
+        for (int t = 0; t < 4; ++t) out[(size_t)(4 * cs + t) * h + m] = acc.c[t];
+      }
+      free(loc);
+      free(cons);
+    }
+  }
+  free(apow);
+  free(af);
+}
+
+static void lde_round(chipd* d, int round) {
+  const size_t h = d->h;
+  const int w = d->w[round];
+  if (!w) return;
+  d->lde[round] = (uint32_t*)malloc((size_t)w * 2 * h * 4);
+  d->coef[round] = (uint32_t*)malloc((size_t)w * h * 4);
+  if (round != R_QUOT) {
+    orc_coset_lde(d->tr[round], d->logh, w, 1, d->lde[round], d->coef[round]);
+  } else {
+    const fe w2h = f_root_of_unity(d->logh + 1);
+    for (int cs = 0; cs < 2; ++cs)
+      orc_coset_lde(d->tr[round] + (size_t)4 * cs * h, d->logh, 4, cs ? f_mul(F_GEN, w2h) : F_GEN,
+                    d->lde[round] + (size_t)4 * cs * 2 * h, d->coef[round] + (size_t)4 * cs * h);
+  }
+}
+
+static void init_chips(const orc_machine_input* in, chipd* cd, int only_prep) {
+  int logh[N_CHIPS];
+  orc_machine_heights(in, logh);
+  for (int c = 0; c < N_CHIPS; ++c) {
+    chipd* d = &cd[c];
+    memset(d, 0, sizeof *d);
+    d->def = orc_machine_chip(c);
+    d->logh = logh[c];
+    d->h = (size_t)1 << logh[c];
+    d->w[R_PREP] = d->def->prep_width;
+    if (only_prep && !d->w[R_PREP]) continue;
+    d->w[R_MAIN] = d->def->main_width;
+    if (d->w[R_PREP]) d->tr[R_PREP] = (uint32_t*)malloc((size_t)d->w[R_PREP] * d->h * 4);
+    d->tr[R_MAIN] = (uint32_t*)malloc((size_t)d->w[R_MAIN] * d->h * 4);
+    orc_machine_fill(in, c, d->logh, d->tr[R_PREP], d->tr[R_MAIN]);
+    lde_round(d, R_PREP);
+    if (only_prep) { d->w[R_MAIN] = 0; continue; }
+    d->w[R_PERM] = orc_chip_perm_width(d->def);
+    d->w[R_QUOT] = 8;
+  }
+}
+static void free_chips(chipd* cd) {
+  for (int c = 0; c < N_CHIPS; ++c)
+    for (int r = 0; r < N_ROUNDS; ++r) { free(cd[c].tr[r]); free(cd[c].lde[r]); free(cd[c].coef[r]); }
+}
+
+static void vk_digest_of(const uint32_t root[8], const orc_machine_input* in, int keccak_mode, uint32_t out[8]) {
+  uint32_t v[16];
+  memcpy(v, root, 32);
+  v[8] = in->entry & 0xffff; v[9] = in->entry >> 16;
+  v[10] = (uint32_t)in->log_prog; v[11] = (uint32_t)in->log_image; v[12] = (uint32_t)keccak_mode;
+  v[13] = ZKSP_VERSION_MACHINE; v[14] = CPU_WIDTH; v[15] = N_CHIPS;
+  orc_hash_elems(v, 16, out);
+}
+
+void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t prep_root[8], uint32_t vk_digest[8]) {
+  chipd cd[N_CHIPS];
+  orc_machine_input tmp = *in;
+  tmp.prog_mult = NULL;
+  tmp.image_used = NULL;
+  tmp.n_cycles = tmp.n_keccak = tmp.n_memfinal = tmp.n_muls = 0;
+  init_chips(&tmp, cd, 1);
+  mmcs t;
+  mmcs_commit(cd, R_PREP, &t);
+  memcpy(prep_root, mmcs_root(&t), 32);
+  vk_digest_of(prep_root, in, keccak_mode, vk_digest);
+  mmcs_free(&t);
+  free_chips(cd);
+}
+
+#define HEADER_WORDS (2 + N_CHIPS + 2 + 24)
+
+size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_image, const orc_config* cfg, uint32_t pv_len) {
+  (void)log_prog; (void)log_image;
+  size_t words = HEADER_WORDS + (pv_len + 3) / 4;
+  int lm = 0, lm_prep = 0;
+  size_t opened = 0, rw[N_ROUNDS] = {0, 0, 0, 0};
+  for (int c = 0; c < N_CHIPS; ++c) {
+    const orc_chip* d = orc_machine_chip(c);
+    const size_t e = (size_t)orc_chip_perm_width(d);
+    if (logh[c] > lm) lm = logh[c];
+    if (d->prep_width && logh[c] > lm_prep) lm_prep = logh[c];
+    opened += (size_t)d->prep_width + 2 * (size_t)d->main_width + 2 * e + 8;
+    rw[R_PREP] += (size_t)d->prep_width; rw[R_MAIN] += (size_t)d->main_width; rw[R_PERM] += e; rw[R_QUOT] += 8;
+  }
+  words += 8 + 8 + 4 * N_CHIPS + 8 + 4 * opened + 8 * (size_t)lm + 4 + 1;
+  size_t perq = rw[R_PREP] + 8 * ((size_t)lm_prep + 1);
+  for (int r = R_MAIN; r <= R_QUOT; ++r) perq += rw[r] + 8 * ((size_t)lm + 1);
+  for (int k = 0; k < lm; ++k) perq += 8 + 8 * (size_t)(lm - k);
+  words += perq * cfg->num_queries;
+  return words * 4;
+}
+
+int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_machine_public* pub, const uint8_t* public_values,
+                      const orc_config* cfg, uint8_t* out, size_t cap, size_t* out_len) {
+  chipd cd[N_CHIPS];
+  int logh[N_CHIPS];
+  orc_machine_heights(in, logh);
+  if (in->n_cycles == 0 || logh[CH_CPU] > 21) return 1;
+  for (int c = 0; c < N_CHIPS; ++c)
+    if (logh[c] > logh[CH_CPU]) return 1; /* the CPU chip is the tallest: every tree and FRI start from it */
+  const size_t need = orc_machine_proof_size(logh, in->log_prog, in->log_image, cfg, pub->pv_len);
+  *out_len = need;
+  if (cap < need) return 2;
+  wbuf pb = {(uint32_t*)out, 0, cap / 4};
+  const int lm = logh[CH_CPU];
+
+  /* ---- rounds 0 and 1: preprocessed and main traces ---- */
+  init_chips(in, cd, 0);
+  mmcs t_prep, t_main, t_perm, t_quot;
+  mmcs_commit(cd, R_PREP, &t_prep);
+  uint32_t vk[8];
+  vk_digest_of(mmcs_root(&t_prep), in, keccak_mode, vk);
+  for (int c = 0; c < N_CHIPS; ++c) lde_round(&cd[c], R_MAIN);
+  mmcs_commit(cd, R_MAIN, &t_main);
+
+  /* header */
+  {
+    uint32_t head[2] = {ZKSP_MAGIC, ZKSP_VERSION_MACHINE};
+    put(&pb, head, 2);
+    for (int c = 0; c < N_CHIPS; ++c) { uint32_t v = (uint32_t)logh[c]; put(&pb, &v, 1); }
+    put(&pb, &pub->exit_code, 1);
+    put(&pb, &pub->pv_len, 1);
+    put(&pb, pub->pv_digest, 8);
+    put(&pb, pub->deferred_digest, 8);
+    put(&pb, vk, 8);
+    size_t pw = (pub->pv_len + 3) / 4;
+    uint32_t* tmp = (uint32_t*)calloc(pw ? pw : 1, 4);
+    memcpy(tmp, public_values, pub->pv_len);
+    put(&pb, tmp, pw);
+    free(tmp);
+  }
+  orc_challenger ch;
+  orc_ch_init(&ch);
+  orc_ch_observe_many(&ch, vk, 8);
+  for (int c = 0; c < N_CHIPS; ++c) orc_ch_observe(&ch, (uint32_t)logh[c]);
+  orc_ch_observe(&ch, pub->exit_code & 0xffff);
+  orc_ch_observe(&ch, pub->exit_code >> 16);
+  observe_word_halves(&ch, pub->pv_digest, 8);
+  observe_word_halves(&ch, pub->deferred_digest, 8);
+  orc_ch_observe_many(&ch, mmcs_root(&t_main), 8);
+  put(&pb, mmcs_root(&t_main), 8);
+
+  /* ---- round 2: LogUp ---- */
+  fe4 gamma, beta, bpow[INTER_MAX_ELEMS + 1];
+  orc_ch_sample_ext(&ch, gamma.c);
+  orc_ch_sample_ext(&ch, beta.c);
+  bpow[0] = e_one();
+  for (int j = 1; j <= INTER_MAX_ELEMS; ++j) bpow[j] = e_mul(bpow[j - 1], beta);
+  fe4 total = e_zero();
+  for (int c = 0; c < N_CHIPS; ++c) {
+    chipd* d = &cd[c];
+    d->tr[R_PERM] = (uint32_t*)calloc((size_t)d->w[R_PERM] * d->h, 4);
+    perm_trace(d, gamma, bpow);
+    total = e_add(total, d->cum);
+    lde_round(d, R_PERM);
+  }
+  /* the verifier closes the two public buses: digest words and exit code */
+  {
+    aff a;
+    orc_inter it;
+    memset(&it, 0, sizeof it);
+    for (int kind = 1; kind <= 2; ++kind)
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t w = kind == 1 ? pub->pv_digest[i] : pub->deferred_digest[i];
+        it.bus = BUS_PUBC; it.n_el = 4;
+        it.el[0].n = 0; it.el[0].c0 = (uint32_t)kind;
+        it.el[1].n = 0; it.el[1].c0 = (uint32_t)i;
+        it.el[2].n = 0; it.el[2].c0 = w & 0xffff;
+        it.el[3].n = 0; it.el[3].c0 = w >> 16;
+        build_aff(&it, gamma, bpow, &a);
+        total = e_sub(total, e_inv(a.c0));
+      }
+    it.bus = BUS_PUBH; it.n_el = 2;
+    it.el[0].n = 0; it.el[0].c0 = pub->exit_code & 0xffff;
+    it.el[1].n = 0; it.el[1].c0 = pub->exit_code >> 16;
+    build_aff(&it, gamma, bpow, &a);
+    total = e_sub(total, e_inv(a.c0));
+  }
+  if (!e_eq(total, e_zero())) {
+    if (getenv("ZKSP_ORACLE_TIMING")) {
+      for (int c = 0; c < N_CHIPS; ++c)
+        fprintf(stderr, "[oracle] chip %-10s cumulative sum %u %u %u %u\n", cd[c].def->name, cd[c].cum.c[0], cd[c].cum.c[1],
+                cd[c].cum.c[2], cd[c].cum.c[3]);
+    }
+    return 5; /* the buses do not balance: the records are inconsistent */
+  }
+  mmcs_commit(cd, R_PERM, &t_perm);
+  orc_ch_observe_many(&ch, mmcs_root(&t_perm), 8);
+  put(&pb, mmcs_root(&t_perm), 8);
+  for (int c = 0; c < N_CHIPS; ++c) {
+    orc_ch_observe_many(&ch, cd[c].cum.c, 4);
+    put(&pb, cd[c].cum.c, 4);
+  }
+
+  /* ---- round 3: quotients ---- */
+  fe4 alpha;
+  orc_ch_sample_ext(&ch, alpha.c);
+  for (int c = 0; c < N_CHIPS; ++c) {
+    chipd* d = &cd[c];
+    d->tr[R_QUOT] = (uint32_t*)malloc((size_t)8 * d->h * 4);
+    chip_quotient(d, c, alpha, gamma, bpow, in->entry);
+    lde_round(d, R_QUOT);
+  }
+  mmcs_commit(cd, R_QUOT, &t_quot);
+  orc_ch_observe_many(&ch, mmcs_root(&t_quot), 8);
+  put(&pb, mmcs_root(&t_quot), 8);
+
+  /* ---- openings at zeta (everything) and zeta * w_H (main, permutation) ---- */
+  fe4 zeta;
+  orc_ch_sample_ext(&ch, zeta.c);
+  size_t n_open = 0;
+  for (int c = 0; c < N_CHIPS; ++c) n_open += (size_t)cd[c].w[R_PREP] + 2 * (size_t)cd[c].w[R_MAIN] + 2 * (size_t)cd[c].w[R_PERM] + 8;
+  fe4* opened = (fe4*)malloc(n_open * sizeof(fe4));
+  size_t chip_open_off[N_CHIPS];
+  {
+    size_t o = 0;
+    for (int c = 0; c < N_CHIPS; ++c) {
+      chipd* d = &cd[c];
+      chip_open_off[c] = o;
+      const fe4 zn = e_mul_base(zeta, f_root_of_unity(d->logh));
+      for (int pass = 0; pass < 2; ++pass)
+        for (int r = (pass ? R_MAIN : R_PREP); r <= (pass ? R_PERM : R_QUOT); ++r) {
+          const int w = d->w[r];
+          fe4* dst = opened + o;
+#pragma omp parallel for schedule(static)
+          for (int i = 0; i < w; ++i) dst[i] = eval_poly(d->coef[r] + (size_t)i * d->h, d->h, pass ? zn : zeta);
+          o += (size_t)w;
+        }
+    }
+  }
+  put(&pb, (const uint32_t*)opened, n_open * 4);
+  observe_list_root(&ch, (const uint32_t*)opened, n_open * 4, ceil_log2((n_open * 4 + 7) / 8));
+
+  /* ---- reduced openings, one input per height ---- */
+  fe4 af;
+  orc_ch_sample_ext(&ch, af.c);
+  fe4* afpow = (fe4*)malloc(n_open * sizeof(fe4));
+  afpow[0] = e_one();
+  for (size_t i = 1; i < n_open; ++i) afpow[i] = e_mul(afpow[i - 1], af);
+  fe4* G[32];
+  memset(G, 0, sizeof G);
+  for (int c = 0; c < N_CHIPS; ++c) {
+    chipd* d = &cd[c];
+    const size_t h = d->h, o = chip_open_off[c];
+    const size_t n1 = (size_t)d->w[R_PREP] + d->w[R_MAIN] + d->w[R_PERM] + 8, n2 = (size_t)d->w[R_MAIN] + d->w[R_PERM];
+    fe4 b1 = e_zero(), b2 = e_zero();
+    for (size_t i = 0; i < n1; ++i) b1 = e_add(b1, e_mul(afpow[o + i], opened[o + i]));
+    for (size_t i = 0; i < n2; ++i) b2 = e_add(b2, e_mul(afpow[o + n1 + i], opened[o + n1 + i]));
+    if (!G[d->logh]) G[d->logh] = (fe4*)calloc(2 * h, sizeof(fe4));
+    fe4* g = G[d->logh];
+    const fe wh = f_root_of_unity(d->logh), w2h = f_root_of_unity(d->logh + 1);
+    const fe4 zn = e_mul_base(zeta, wh);
+    for (int cs = 0; cs < 2; ++cs) {
+      const fe shift = cs ? f_mul(F_GEN, w2h) : F_GEN;
+#pragma omp parallel for schedule(static)
+      for (size_t m = 0; m < h; ++m) {
+        const fe x = f_mul(shift, f_pow(wh, m));
+        fe4 s1 = e_zero(), s2 = e_zero();
+        size_t i = 0, j = 0;
+        for (int r = R_PREP; r <= R_QUOT; ++r)
+          for (int col = 0; col < d->w[r]; ++col, ++i) {
+            const fe v = d->lde[r][((size_t)col * 2 + cs) * h + m];
+            s1 = e_add(s1, e_mul_base(afpow[o + i], v));
+            if (r == R_MAIN || r == R_PERM) { s2 = e_add(s2, e_mul_base(afpow[o + n1 + j], v)); ++j; }
+          }
+        const fe4 d0 = e_inv(e_sub(e_from(x), zeta)), d1 = e_inv(e_sub(e_from(x), zn));
+        fe4 v = e_add(e_mul(e_sub(s1, b1), d0), e_mul(e_sub(s2, b2), d1));
+        g[(size_t)cs * h + m] = e_add(g[(size_t)cs * h + m], v);
+      }
+    }
+  }
+  free(afpow);
+  free(opened);
+
+  /* ---- FRI commit phase with inputs joining at their height ---- */
+  uint32_t** fri_tree = (uint32_t**)malloc((size_t)lm * sizeof(uint32_t*));
+  uint32_t** fri_layer = (uint32_t**)malloc((size_t)lm * sizeof(uint32_t*));
+  uint32_t* layer = (uint32_t*)malloc(((size_t)2 << lm) * 16);
+  memcpy(layer, G[lm], ((size_t)2 << lm) * 16);
+  fe shift_k = F_GEN;
+  for (int k = 0; k < lm; ++k) {
+    const int loghk = lm - k;
+    const size_t hk = (size_t)1 << loghk, half = hk >> 1;
+    uint32_t* mat = (uint32_t*)malloc(8 * hk * 4);
+    for (int cs = 0; cs < 2; ++cs)
+      for (size_t m = 0; m < half; ++m)
+        for (int j = 0; j < 4; ++j) {
+          mat[(size_t)j * hk + cs * half + m] = layer[4 * ((size_t)cs * hk + m) + j];
+          mat[(size_t)(4 + j) * hk + cs * half + m] = layer[4 * ((size_t)cs * hk + m + half) + j];
+        }
+    fri_tree[k] = (uint32_t*)malloc(8 * (2 * hk - 1) * 4);
+    orc_merkle_commit(mat, 8, loghk, fri_tree[k]);
+    free(mat);
+    const uint32_t* root = fri_tree[k] + 8 * (2 * hk - 2);
+    orc_ch_observe_many(&ch, root, 8);
+    put(&pb, root, 8);
+    uint32_t fbeta[4];
+    orc_ch_sample_ext(&ch, fbeta);
+    uint32_t* nxt = (uint32_t*)malloc(hk * 16);
+    orc_fri_fold(layer, loghk, shift_k, fbeta, nxt);
+    if (loghk - 1 >= 0 && G[loghk - 1]) {
+      const fe4* g = G[loghk - 1];
+      for (size_t i = 0; i < hk; ++i) {
+        fe4 v;
+        memcpy(v.c, nxt + 4 * i, 16);
+        v = e_add(v, g[i]);
+        memcpy(nxt + 4 * i, v.c, 16);
+      }
+    }
+    fri_layer[k] = layer;
+    layer = nxt;
+    shift_k = f_mul(shift_k, shift_k);
+  }
+  if (memcmp(layer, layer + 4, 16) != 0) return 3;
+  orc_ch_observe_many(&ch, layer, 4);
+  put(&pb, layer, 4);
+  free(layer);
+  for (int l = 0; l < 32; ++l) free(G[l]);
+
+  /* ---- proof of work, queries ---- */
+  uint32_t witness = orc_ch_grind(&ch, (int)cfg->pow_bits);
+  put(&pb, &witness, 1);
+  const size_t hmax = (size_t)1 << lm;
+  for (uint32_t q = 0; q < cfg->num_queries; ++q) {
+    const size_t idx = orc_ch_sample_bits(&ch, lm + 1);
+    const size_t cs = idx >> lm, m = idx & (hmax - 1);
+    mmcs_open(cd, R_PREP, &t_prep, cs, m, &pb);
+    mmcs_open(cd, R_MAIN, &t_main, cs, m, &pb);
+    mmcs_open(cd, R_PERM, &t_perm, cs, m, &pb);
+    mmcs_open(cd, R_QUOT, &t_quot, cs, m, &pb);
+    for (int k = 0; k < lm; ++k) {
+      const int loghk = lm - k;
+      const size_t hk = (size_t)1 << loghk, half = hk >> 1, mk = m & (half - 1), leaf = cs * half + mk;
+      put(&pb, fri_layer[k] + 4 * (cs * hk + mk), 4);
+      put(&pb, fri_layer[k] + 4 * (cs * hk + mk + half), 4);
+      for (int l = 0; l < loghk; ++l) put(&pb, fri_tree[k] + 8 * (orc_merkle_layer_offset(loghk, l) + ((leaf >> l) ^ 1)), 8);
+    }
+  }
+  for (int k = 0; k < lm; ++k) { free(fri_tree[k]); free(fri_layer[k]); }
+  free(fri_tree);
+  free(fri_layer);
+  mmcs_free(&t_prep); mmcs_free(&t_main); mmcs_free(&t_perm); mmcs_free(&t_quot);
+  free_chips(cd);
+  if (pb.n * 4 != need) return 4;
+  return 0;
+}

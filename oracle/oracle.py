@@ -24,7 +24,8 @@ KA_NUM_CONSTRAINTS = 3182
 
 
 def build(force: bool = False) -> str:
-    srcs = ["poseidon2.c", "ntt.c", "keccak_air.c", "bus.c", "prover.c", "field.h", "zksp_oracle.h", "Makefile"]
+    srcs = ["poseidon2.c", "ntt.c", "keccak_air.c", "bus.c", "prover.c", "machine.c", "mprover.c", "machine.h", "field.h",
+            "zksp_oracle.h", "Makefile"]
     stale = force or not os.path.exists(_SO) or any(
         os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(_SO) for s in srcs)
     if stale:
@@ -61,6 +62,8 @@ def lib() -> C.CDLL:
         _lib.orc_ch_sample.restype = C.c_uint32
         _lib.orc_ch_sample_bits.restype = C.c_uint32
         _lib.orc_ch_grind.restype = C.c_uint32
+        _lib.orc_machine_proof_size.restype = C.c_size_t
+        _lib.orc_machine_chip.restype = C.POINTER(MachineChip)
     return _lib
 
 
@@ -270,6 +273,105 @@ def prove(states_in: np.ndarray, logh: int, *, exit_code: int = 0, public_values
     rc = lib().orc_prove(_p(st), C.byref(hdr), pv, C.byref(cfg), buf, C.c_size_t(cap), C.byref(n))
     if rc != 0:
         raise RuntimeError(f"orc_prove failed rc={rc}")
+    return bytes(buf[: n.value])
+
+
+# ---------------------------------------------------------------------------
+# machine proof (oracle/machine.h): inputs are the arrays ProverClient.machine_trace() returns
+# ---------------------------------------------------------------------------
+N_CHIPS = 7
+CHIP_NAMES = ["cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul"]
+
+
+class MachineChip(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("prep_width", C.c_int), ("main_width", C.c_int), ("n_inter", C.c_int),
+                ("inter", C.c_void_p), ("n_constraints", C.c_int)]
+
+
+class MachineInput(C.Structure):
+    _fields_ = [("program", C.c_void_p), ("n_program", C.c_size_t), ("image", C.c_void_p), ("n_image", C.c_size_t),
+                ("entry", C.c_uint32), ("text_base", C.c_uint32), ("log_prog", C.c_int), ("log_image", C.c_int),
+                ("cycles", C.c_void_p), ("n_cycles", C.c_size_t), ("keccak", C.c_void_p), ("n_keccak", C.c_size_t),
+                ("memfinal", C.c_void_p), ("n_memfinal", C.c_size_t), ("muls", C.c_void_p), ("n_muls", C.c_size_t),
+                ("prog_mult", C.c_void_p), ("image_used", C.c_void_p)]
+
+
+class MachinePublic(C.Structure):
+    _fields_ = [("exit_code", C.c_uint32), ("pv_len", C.c_uint32), ("pv_digest", C.c_uint32 * 8),
+                ("deferred_digest", C.c_uint32 * 8)]
+
+
+def machine_input(t: dict):
+    """MachineInput over the arrays of a machine trace; returns (struct, keep-alive list)."""
+    keep = {k: np.ascontiguousarray(t[k]) for k in ("program", "image", "cycles", "keccak", "memfinal", "muls",
+                                                    "prog_mult", "image_used")}
+    info = t["info"]
+    mi = MachineInput(_p(keep["program"]), len(keep["program"]), _p(keep["image"]), len(keep["image"]),
+                      info.entry, int(keep["program"][0, 0]), info.log_prog, info.log_image,
+                      _p(keep["cycles"]), len(keep["cycles"]), _p(keep["keccak"]), len(keep["keccak"]),
+                      _p(keep["memfinal"]), len(keep["memfinal"]), _p(keep["muls"]), len(keep["muls"]),
+                      _p(keep["prog_mult"]), _p(keep["image_used"]))
+    return mi, keep
+
+
+def machine_chip(chip: int):
+    c = lib().orc_machine_chip(chip).contents
+    return {"name": c.name.decode(), "prep_width": c.prep_width, "main_width": c.main_width, "n_inter": c.n_inter,
+            "n_constraints": c.n_constraints}
+
+
+def machine_heights(t: dict) -> List[int]:
+    mi, _keep = machine_input(t)
+    out = (C.c_int * N_CHIPS)()
+    lib().orc_machine_heights(C.byref(mi), out)
+    return list(out)
+
+
+def machine_fill(t: dict, chip: int):
+    """(prep [pw][H] or None, main [mw][H]) canonical traces of one chip."""
+    mi, _keep = machine_input(t)
+    logh = machine_heights(t)[chip]
+    d = machine_chip(chip)
+    h = 1 << logh
+    prep = np.zeros((d["prep_width"], h), np.uint32) if d["prep_width"] else None
+    main = np.zeros((d["main_width"], h), np.uint32)
+    lib().orc_machine_fill(C.byref(mi), chip, logh, _p(prep) if prep is not None else None, _p(main))
+    return prep, main
+
+
+def machine_constraints(chip: int, prep_row, loc, nxt, is_first: int, is_last: int, is_trans: int, pub: int) -> np.ndarray:
+    d = machine_chip(chip)
+    out = np.zeros(max(d["n_constraints"], 1), np.uint32)
+    pr = _u32(prep_row) if prep_row is not None else np.zeros(1, np.uint32)
+    l, n = _u32(loc), _u32(nxt)
+    lib().orc_machine_constraints(chip, _p(pr), _p(l), _p(n), C.c_uint32(is_first), C.c_uint32(is_last),
+                                  C.c_uint32(is_trans), C.c_uint32(pub), _p(out))
+    return out[: d["n_constraints"]]
+
+
+def machine_setup(t: dict):
+    """(preprocessed commitment root, verifying-key digest) as lists of 8 canonical words."""
+    mi, _keep = machine_input(t)
+    root, vk = np.zeros(8, np.uint32), np.zeros(8, np.uint32)
+    lib().orc_machine_setup(C.byref(mi), int(t["info"].keccak_mode), _p(root), _p(vk))
+    return [int(x) for x in root], [int(x) for x in vk]
+
+
+def machine_prove(t: dict, *, num_queries: int = 100, pow_bits: int = 16) -> bytes:
+    mi, _keep = machine_input(t)
+    info = t["info"]
+    pv = t["public_values"]
+    pub = MachinePublic(info.exit_code, len(pv), info.pv_digest, info.deferred_digest)
+    cfg = Config(num_queries, pow_bits)
+    logh = (C.c_int * N_CHIPS)(*machine_heights(t))
+    cap = int(lib().orc_machine_proof_size(logh, info.log_prog, info.log_image, C.byref(cfg), C.c_uint32(len(pv))))
+    buf = (C.c_uint8 * cap)()
+    n = C.c_size_t(0)
+    pvb = (C.c_uint8 * max(1, len(pv))).from_buffer_copy(pv or b"\0")
+    rc = lib().orc_machine_prove(C.byref(mi), int(info.keccak_mode), C.byref(pub), pvb, C.byref(cfg), buf, C.c_size_t(cap),
+                                 C.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"orc_machine_prove failed rc={rc}")
     return bytes(buf[: n.value])
 
 
