@@ -148,6 +148,10 @@ void zksp_mtrace_free(zksp_mtrace* t);
 /* Borrowed pointer into the handle. */
 int zksp_mtrace_section(const zksp_mtrace* t, int which, const void** ptr, size_t* bytes);
 int zksp_mtrace_info(const zksp_mtrace* t, zksp_mtrace_info_t* info);
+/* The machine-proof part of the verifying key: Merkle root of the preprocessed Program / Image
+ * tables and the digest that binds it to the entry point, table heights and keccak mode
+ * (8 canonical u32 each). */
+int zksp_vk_machine(const zksp_vk* vk, uint32_t* prep_root8, uint32_t* digest8);
 
 /* ---- device-resident hot path (bench.py, parity tests) ---- */
 /* Proof-system parameters this build uses (for sizing buffers). */

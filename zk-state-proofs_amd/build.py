@@ -28,12 +28,15 @@ SOURCES = [
     "host/context.cpp",
     "host/prover.cpp",
     "host/verifier.cpp",
+    "host/machine_defs.cpp",
+    "host/mverifier.cpp",
     "host/api.cpp",
     "host/api_prove.cpp",
     "host/api_machine.cpp",
 ]
 HEADERS = [
-    "device/field.cuh", "device/poseidon2.cuh", "device/air_keccak.cuh", "device/kernels.h",
+    "device/field.cuh", "device/poseidon2.cuh", "device/air_keccak.cuh", "device/air_machine.cuh", "device/kernels.h",
+    "host/machine_defs.hpp", "host/mverifier.hpp", "host/host_hash.hpp",
     "host/executor.hpp", "host/machine.hpp", "host/context.hpp", "host/prover.hpp", "host/verifier.hpp", "host/api_types.hpp",
 ]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

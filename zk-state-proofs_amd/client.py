@@ -111,6 +111,7 @@ def load_library() -> C.CDLL:
     lib.zksp_mtrace_free.restype = None
     lib.zksp_mtrace_section.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(sz)]
     lib.zksp_mtrace_info.argtypes = [vp, C.POINTER(MTraceInfo)]
+    lib.zksp_vk_machine.argtypes = [vp, vp, vp]
     lib.zksp_get_params.argtypes = [vp, C.POINTER(Params)]
     lib.zksp_proof_body_words.argtypes = [vp, C.c_int]
     lib.zksp_proof_body_words.restype = sz
@@ -149,7 +150,7 @@ ABI_SYMBOLS = [
     "zksp_vk_digest", "zksp_stdin_new", "zksp_stdin_write", "zksp_stdin_free", "zksp_prove", "zksp_prove_batch",
     "zksp_proof_public_values", "zksp_proof_serialize", "zksp_proof_deserialize", "zksp_proof_free", "zksp_verify",
     "zksp_execute", "zksp_execute_keccak", "zksp_opcode_name", "zksp_machine_trace", "zksp_mtrace_free",
-    "zksp_mtrace_section", "zksp_mtrace_info", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
+    "zksp_mtrace_section", "zksp_mtrace_info", "zksp_vk_machine", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
     "zksp_hip_prove_resident", "zksp_proof_from_body", "zksp_hip_fetch_bodies", "zksp_hip_fetch_roots", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
     "zksp_hip_profile_enable", "zksp_hip_profile_read", "zksp_hip_profile_reset", "zksp_dev_malloc", "zksp_dev_free",
     "zksp_dev_upload", "zksp_dev_download", "zksp_dev_memset", "zksp_hip_lde", "zksp_hip_merkle_commit",
@@ -198,6 +199,14 @@ class VerifyingKey(_Handle):
         p, n = C.POINTER(C.c_uint8)(), C.c_size_t()
         self._lib.zksp_vk_digest(self._h, C.byref(p), C.byref(n))
         return bytes(p[: n.value])
+
+
+    @property
+    def machine(self):
+        """(preprocessed-table commitment root, machine verifying-key digest): 8 canonical words each."""
+        r, d = (C.c_uint32 * 8)(), (C.c_uint32 * 8)()
+        self._lib.zksp_vk_machine(self._h, r, d)
+        return list(r), list(d)
 
 
 class SP1ProofWithPublicValues(_Handle):

@@ -12,6 +12,7 @@
 #include "context.hpp"
 #include "prover.hpp"
 #include "verifier.hpp"
+#include "machine_defs.hpp"
 
 #include "api_types.hpp"
 
@@ -99,6 +100,13 @@ int zksp_setup(zksp_client* c, const uint8_t* elf, size_t elf_len, zksp_pk** pk,
   }
   compute_vk_digest(p->elf, p->vk_digest);
   memcpy(v->digest, p->vk_digest, 32);
+  try {
+    machine_host_setup(p->mprog, &p->mvk);  // commitment of the preprocessed Program / Image tables
+  } catch (...) {
+    delete p; delete v;
+    return c->ctx.fail(ZKSP_ERR_ELF, "setup: out of memory while committing the preprocessed tables");
+  }
+  v->machine = p->mvk;
   *pk = p;
   *vk = v;
   return ZKSP_OK;
@@ -294,6 +302,11 @@ int zksp_hip_profile_read(zksp_client* c, const char* kernel, double* total_ms, 
 // ---------------------------------------------------------------------------
 int zksp_proof_public_values(const zksp_proof* p, const uint8_t** ptr, size_t* len) {
   if (!p || !ptr || !len) return ZKSP_ERR_INVALID_ARG;
+  if (p->version == mach::kMachineVersion) {
+    *ptr = p->bytes.data() + p->mhdr.pv_offset;
+    *len = p->mhdr.pv_len;
+    return ZKSP_OK;
+  }
   *ptr = p->bytes.data() + p->hdr.pv_offset;
   *len = p->hdr.pv_len;
   return ZKSP_OK;
@@ -310,7 +323,10 @@ int zksp_proof_deserialize(const uint8_t* buf, size_t len, zksp_proof** out) {
   if (!p) return ZKSP_ERR_INVALID_ARG;
   p->bytes.assign(buf, buf + len);
   std::string err;
-  if (!parse_proof_header(p->bytes.data(), p->bytes.size(), &p->hdr, &err)) {
+  const bool machine = len >= 8 && reinterpret_cast<const uint32_t*>(p->bytes.data())[1] == mach::kMachineVersion;
+  p->version = machine ? mach::kMachineVersion : kProofVersion;
+  if (!(machine ? parse_machine_header(p->bytes.data(), p->bytes.size(), &p->mhdr, &err)
+                : parse_proof_header(p->bytes.data(), p->bytes.size(), &p->hdr, &err))) {
     delete p;
     return ZKSP_ERR_PROOF_FORMAT;
   }
@@ -361,8 +377,16 @@ int zksp_proof_from_body(const uint32_t* body, size_t body_words, uint32_t log_h
 int zksp_verify(zksp_client* c, const zksp_proof* p, const zksp_vk* vk) {
   if (!c || !p || !vk) return ZKSP_ERR_INVALID_ARG;
   std::string err;
-  int rc = verify_proof(p->bytes.data(), p->bytes.size(), vk->digest, c->ctx.params.num_queries, c->ctx.params.pow_bits,
-                        &err);
+  int rc;
+  try {
+    rc = p->version == mach::kMachineVersion
+             ? verify_machine_proof(p->bytes.data(), p->bytes.size(), vk->machine, c->ctx.params.num_queries,
+                                    c->ctx.params.pow_bits, &err)
+             : verify_proof(p->bytes.data(), p->bytes.size(), vk->digest, c->ctx.params.num_queries, c->ctx.params.pow_bits,
+                            &err);
+  } catch (...) {
+    return c->ctx.fail(ZKSP_ERR_VERIFY, "verify: out of memory");
+  }
   if (rc) return c->ctx.fail(rc, "verify: " + err);
   return ZKSP_OK;
 }

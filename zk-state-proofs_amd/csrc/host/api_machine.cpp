@@ -71,4 +71,11 @@ int zksp_mtrace_info(const zksp_mtrace* t, zksp_mtrace_info_t* info) {
   return ZKSP_OK;
 }
 
+int zksp_vk_machine(const zksp_vk* vk, uint32_t* prep_root8, uint32_t* digest8) {
+  if (!vk || !prep_root8 || !digest8) return ZKSP_ERR_INVALID_ARG;
+  memcpy(prep_root8, vk->machine.prep_root, 32);
+  memcpy(digest8, vk->machine.digest, 32);
+  return ZKSP_OK;
+}
+
 }  // extern "C"

@@ -6,11 +6,12 @@
 
 #include "context.hpp"
 #include "machine.hpp"
+#include "mverifier.hpp"
 #include "verifier.hpp"
 
 struct zksp_client { zksp::Context ctx; };
-struct zksp_pk { zksp::ElfImage elf; uint32_t vk_digest[8]; zksp::MachineProgram mprog; };
+struct zksp_pk { zksp::ElfImage elf; uint32_t vk_digest[8]; zksp::MachineProgram mprog; zksp::MachineVk mvk; };
 struct zksp_mtrace { zksp::MachineTrace t; const zksp::MachineProgram* prog; };
-struct zksp_vk { uint32_t digest[8]; };
+struct zksp_vk { uint32_t digest[8]; zksp::MachineVk machine; };
 struct zksp_stdin { std::vector<std::vector<uint8_t>> entries; };
-struct zksp_proof { std::vector<uint8_t> bytes; zksp::ProofHeader hdr; };
+struct zksp_proof { std::vector<uint8_t> bytes; zksp::ProofHeader hdr; zksp::MachineHeader mhdr; uint32_t version = 2; };

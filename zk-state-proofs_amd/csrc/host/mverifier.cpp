@@ -1,0 +1,552 @@
+// Host verifier of the machine proof ("ZKSP v3"): replaces `client.verify(&proof, &vk)` (reference
+// prover/src/bin/main.rs:80; sp1-stark 3.4.0's multi-chip verifier over p3-uni-stark / p3-fri,
+// Cargo.lock:7485, :5378, :5253) for proofs that bind the guest's whole execution.  Also the
+// host half of `client.setup(ELF)` (main.rs:70): the commitment to the preprocessed Program and
+// Image tables that the verifying key carries.  Needs no GPU.
+//
+// Checks, in order: header sanity and key; sha256(public values) = committed digest; exit code 0;
+// the LogUp buses balance (chips' cumulative sums + the public COMMIT / HALT terms = 0); for every
+// chip the constraint identity at zeta with the SAME templates the device quotient kernels
+// instantiate (air_machine.cuh, air_keccak.cuh); proof of work; every FRI query: the four
+// mixed-height Merkle openings, the reduced openings per height, the folding chain.
+#include "mverifier.hpp"
+
+#include <array>
+#include <cstring>
+
+#include "host_hash.hpp"
+#include "machine_defs.hpp"
+
+namespace zksp {
+
+using namespace hosthash;
+using namespace mach;
+
+namespace {
+
+inline uint32_t bitrev32(uint32_t v, int bits) {
+  uint32_t r = 0;
+  for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1u) << (bits - 1 - i);
+  return r;
+}
+int ceil_log2(size_t v) {
+  int l = 0;
+  while (((size_t)1 << l) < v) ++l;
+  return l;
+}
+Fp4 read_fp4(const uint32_t* w) {
+  Fp4 r;
+  for (int i = 0; i < 4; ++i) r.c[i] = Fp::from_canonical(w[i]);
+  return r;
+}
+Fp4 from_basis(const Fp4* v) {  // four opened base columns = one extension column
+  Fp4 r = Fp4::zero();
+  for (int j = 0; j < 4; ++j) {
+    Fp4 basis = Fp4::zero();
+    basis.c[j] = Fp::one();
+    r += basis * v[j];
+  }
+  return r;
+}
+
+// ---- host NTT / LDE for the preprocessed tables (setup only) ----
+void host_ntt(std::vector<Fp>& a, int logn, bool inverse) {
+  const size_t n = (size_t)1 << logn;
+  for (size_t i = 0; i < n; ++i) {
+    size_t j = bitrev32((uint32_t)i, logn);
+    if (i < j) std::swap(a[i], a[j]);
+  }
+  for (int s = 1; s <= logn; ++s) {
+    const size_t m = (size_t)1 << s, half = m >> 1;
+    Fp wm = fp_root_of_unity(s);
+    if (inverse) wm = wm.inv();
+    for (size_t k = 0; k < n; k += m) {
+      Fp w = Fp::one();
+      for (size_t j = 0; j < half; ++j) {
+        const Fp t = w * a[k + j + half], u = a[k + j];
+        a[k + j] = u + t;
+        a[k + j + half] = u - t;
+        w = w * wm;
+      }
+    }
+  }
+  if (inverse) {
+    const Fp ninv = Fp::from_canonical((uint32_t)(n % kP)).inv();
+    for (auto& x : a) x = x * ninv;
+  }
+}
+// column of H evaluations -> [2][H] evaluations over g*K_H and g*w_2H*K_H
+void host_lde(const std::vector<Fp>& col, int logh, std::vector<Fp>* out) {
+  const size_t h = (size_t)1 << logh;
+  std::vector<Fp> c = col;
+  host_ntt(c, logh, true);
+  out->assign(2 * h, Fp::zero());
+  const Fp g = Fp::from_canonical(kGen), w2h = fp_root_of_unity(logh + 1);
+  for (int cs = 0; cs < 2; ++cs) {
+    const Fp shift = cs ? g * w2h : g;
+    std::vector<Fp> t(h);
+    Fp p = Fp::one();
+    for (size_t k = 0; k < h; ++k) { t[k] = c[k] * p; p = p * shift; }
+    host_ntt(t, logh, false);
+    for (size_t k = 0; k < h; ++k) (*out)[(size_t)cs * h + k] = t[k];
+  }
+}
+
+struct RoundShape {
+  int width[kNumChips];
+  int lm;  // tallest log height in the round
+};
+
+// Recomputes the root of one mixed-height opening.  rows[c]: opened row of chip c (width[c] words).
+bool mmcs_verify(const RoundShape& sh, const int* logh, const std::vector<std::vector<Fp>>& rows, size_t cs, size_t m_max,
+                 const uint32_t* path_canon, const Fp root[8], const P2Consts* kc) {
+  const int logn = sh.lm + 1;
+  const size_t hm = (size_t)1 << sh.lm;
+  const size_t pos = cs * hm + bitrev32((uint32_t)(m_max & (hm - 1)), sh.lm);
+  auto group_hash = [&](int group_logn, Fp out[8]) -> bool {
+    std::vector<Fp> cat;
+    for (int c = 0; c < kNumChips; ++c)
+      if (sh.width[c] && logh[c] + 1 == group_logn) cat.insert(cat.end(), rows[c].begin(), rows[c].end());
+    if (cat.empty()) return false;
+    hash_elems(cat.data(), cat.size(), out, kc);
+    return true;
+  };
+  Fp cur[8];
+  if (!group_hash(logn, cur)) return false;
+  for (int l = 0; l < logn; ++l) {
+    Fp sib[8], nxt[8];
+    for (int i = 0; i < 8; ++i) sib[i] = Fp::from_canonical(path_canon[8 * l + i]);
+    if ((pos >> l) & 1) compress(sib, cur, nxt, kc);
+    else compress(cur, sib, nxt, kc);
+    Fp g[8];
+    if (group_hash(logn - l - 1, g)) compress(nxt, g, cur, kc);
+    else for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+  }
+  for (int i = 0; i < 8; ++i)
+    if (cur[i] != root[i]) return false;
+  return true;
+}
+
+// constraint evaluation at zeta: values are extension elements
+struct ZetaCtx {
+  using F = Fp4;
+  const Fp4* loc;  // main columns at zeta
+  const Fp4* nxt;  // main columns at zeta * w
+  Fp4 first, trans, last, pub_;
+  const Fp4* ap;
+  int k_ = 0;
+  Fp4 acc = Fp4::zero();
+  F local(int col) const { return loc[col]; }
+  F next(int col) const { return nxt[col]; }
+  F is_first() const { return first; }
+  F is_trans() const { return trans; }
+  F is_last() const { return last; }
+  F pub() const { return pub_; }
+  F one() const { return Fp4::one(); }
+  F k(uint32_t monty) const { return Fp4::from_base(Fp::raw(monty)); }
+  void emit(F v) { acc += ap[k_++] * v; }
+  void emit_at(int idx, F v) { acc += ap[idx] * v; }  // keccak template (fixed index space)
+};
+
+Fp4 lf_eval(const LinForm& f, const Fp4* row) {
+  Fp4 v = Fp4::from_base(Fp::raw(f.c0));
+  for (int i = 0; i < f.n; ++i) v += row[f.col[i]] * Fp::raw(f.coef[i]);
+  return v;
+}
+Fp4 fingerprint(const Interaction& it, const Fp4* row, const Fp4& gamma, const Fp4* bpow) {
+  Fp4 f = gamma + Fp4::from_base(Fp::from_canonical((uint32_t)it.bus));
+  for (int j = 0; j < it.n_el; ++j) f += bpow[j + 1] * lf_eval(it.el[j], row);
+  return f;
+}
+
+void vk_digest_of(const uint32_t root_canon[8], uint32_t entry, int log_prog, int log_image, int mode, uint32_t out[8]) {
+  Fp v[16];
+  for (int i = 0; i < 8; ++i) v[i] = Fp::from_canonical(root_canon[i]);
+  const uint32_t rest[8] = {entry & 0xffff, entry >> 16, (uint32_t)log_prog, (uint32_t)log_image, (uint32_t)mode,
+                            kMachineVersion, (uint32_t)kCpuWidth, (uint32_t)kNumChips};
+  for (int i = 0; i < 8; ++i) v[8 + i] = Fp::from_canonical(rest[i]);
+  Fp d[8];
+  hash_elems(v, 16, d, &host_p2_consts());
+  for (int i = 0; i < 8; ++i) out[i] = d[i].to_canonical();
+}
+
+}  // namespace
+
+void machine_prep_traces(const MachineProgram& prog, std::vector<uint32_t>* image_prep, std::vector<uint32_t>* program_prep) {
+  const size_t hi = (size_t)1 << prog.log_image, hp = (size_t)1 << prog.log_prog;
+  image_prep->assign((size_t)kImagePrepWidth * hi, 0);
+  program_prep->assign((size_t)kProgramPrepWidth * hp, 0);
+  for (size_t r = 0; r < prog.image.size(); ++r) {
+    (*image_prep)[(size_t)IMG_P_ADDR * hi + r] = prog.image[r].addr;
+    (*image_prep)[(size_t)IMG_P_LO * hi + r] = prog.image[r].val & 0xffff;
+    (*image_prep)[(size_t)IMG_P_HI * hi + r] = prog.image[r].val >> 16;
+  }
+  for (size_t r = 0; r < prog.rows.size(); ++r) {
+    const ProgramRow& p = prog.rows[r];
+    uint32_t* q = program_prep->data() + r;
+    q[(size_t)PR_PC * hp] = p.pc; q[(size_t)PR_OP * hp] = p.op; q[(size_t)PR_WR * hp] = p.wr; q[(size_t)PR_USE2 * hp] = p.use2;
+    q[(size_t)PR_RD * hp] = p.rd; q[(size_t)PR_RS1 * hp] = p.rs1; q[(size_t)PR_RS2 * hp] = p.rs2;
+    q[(size_t)PR_IMM_LO * hp] = p.imm & 0xffff; q[(size_t)PR_IMM_HI * hp] = p.imm >> 16; q[(size_t)PR_TGT * hp] = p.tgt;
+  }
+}
+
+void machine_host_setup(const MachineProgram& prog, MachineVk* vk) {
+  const P2Consts* kc = &host_p2_consts();
+  std::vector<uint32_t> tr[2];
+  machine_prep_traces(prog, &tr[0], &tr[1]);
+  const int logs[2] = {prog.log_image, prog.log_prog}, widths[2] = {kImagePrepWidth, kProgramPrepWidth};
+  std::vector<std::vector<Fp>> lde[2];  // [matrix][col] -> [2][H]
+  for (int mtx = 0; mtx < 2; ++mtx) {
+    const size_t h = (size_t)1 << logs[mtx];
+    lde[mtx].resize(widths[mtx]);
+    for (int c = 0; c < widths[mtx]; ++c) {
+      std::vector<Fp> col(h);
+      for (size_t r = 0; r < h; ++r) col[r] = Fp::from_canonical(tr[mtx][(size_t)c * h + r]);
+      host_lde(col, logs[mtx], &lde[mtx][c]);
+    }
+  }
+  // mixed-height tree over (image, program) in chip order
+  const int lm = std::max(logs[0], logs[1]), logn = lm + 1;
+  auto group_hash = [&](int group_logn, size_t pos, Fp out[8]) -> bool {
+    std::vector<Fp> cat;
+    for (int mtx = 0; mtx < 2; ++mtx) {
+      if (logs[mtx] + 1 != group_logn) continue;
+      const size_t h = (size_t)1 << logs[mtx], cs = pos >> logs[mtx], m = bitrev32((uint32_t)(pos & (h - 1)), logs[mtx]);
+      for (int c = 0; c < widths[mtx]; ++c) cat.push_back(lde[mtx][c][cs * h + m]);
+    }
+    if (cat.empty()) return false;
+    hash_elems(cat.data(), cat.size(), out, kc);
+    return true;
+  };
+  std::vector<Fp> level((size_t)8 << logn), nxt;
+  for (size_t p = 0; p < ((size_t)1 << logn); ++p) group_hash(logn, p, &level[8 * p]);
+  for (int l = 1; l <= logn; ++l) {
+    const size_t cnt = (size_t)1 << (logn - l);
+    nxt.assign(8 * cnt, Fp::zero());
+    for (size_t p = 0; p < cnt; ++p) {
+      Fp d[8], g[8];
+      compress(&level[16 * p], &level[16 * p + 8], d, kc);
+      if (group_hash(logn - l, p, g)) compress(d, g, &nxt[8 * p], kc);
+      else for (int i = 0; i < 8; ++i) nxt[8 * p + i] = d[i];
+    }
+    level.swap(nxt);
+  }
+  for (int i = 0; i < 8; ++i) vk->prep_root[i] = level[i].to_canonical();
+  vk->entry = prog.entry;
+  vk->log_prog = prog.log_prog;
+  vk->log_image = prog.log_image;
+  vk->keccak_mode = prog.keccak_mode;
+  vk_digest_of(vk->prep_root, vk->entry, vk->log_prog, vk->log_image, vk->keccak_mode, vk->digest);
+}
+
+size_t machine_proof_body_words(const int* logh, uint32_t num_queries) {
+  int lm = 0, lm_prep = 0;
+  size_t opened = 0, rw[4] = {0, 0, 0, 0};
+  for (int c = 0; c < kNumChips; ++c) {
+    const ChipDef& d = chip_def(c);
+    const size_t e = (size_t)d.perm_width();
+    lm = std::max(lm, logh[c]);
+    if (d.prep_w) lm_prep = std::max(lm_prep, logh[c]);
+    opened += (size_t)d.prep_w + 2 * (size_t)d.main_w + 2 * e + 8;
+    rw[0] += (size_t)d.prep_w; rw[1] += (size_t)d.main_w; rw[2] += e; rw[3] += 8;
+  }
+  size_t words = 8 + 8 + 4 * (size_t)kNumChips + 8 + 4 * opened + 8 * (size_t)lm + 4 + 1;
+  size_t perq = rw[0] + 8 * ((size_t)lm_prep + 1);
+  for (int r = 1; r < 4; ++r) perq += rw[r] + 8 * ((size_t)lm + 1);
+  for (int k = 0; k < lm; ++k) perq += 8 + 8 * (size_t)(lm - k);
+  return words + perq * num_queries;
+}
+
+bool parse_machine_header(const uint8_t* bytes, size_t len, MachineHeader* h, std::string* err) {
+  if (len < (size_t)kHeaderWords * 4 || (len & 3)) { *err = "proof too short"; return false; }
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(bytes);
+  if (w[0] != kProofMagic) { *err = "bad magic"; return false; }
+  if (w[1] != kMachineVersion) { *err = "unsupported proof version"; return false; }
+  for (int c = 0; c < kNumChips; ++c) {
+    h->logh[c] = (int)w[2 + c];
+    if (w[2 + c] < 5 || w[2 + c] > 21) { *err = "chip height out of range"; return false; }
+  }
+  for (int c = 1; c < kNumChips; ++c)
+    if (h->logh[c] > h->logh[kCpu]) { *err = "a chip is taller than the CPU chip"; return false; }
+  h->exit_code = w[2 + kNumChips];
+  h->pv_len = w[3 + kNumChips];
+  memcpy(h->pv_digest, w + 4 + kNumChips, 32);
+  memcpy(h->deferred_digest, w + 12 + kNumChips, 32);
+  memcpy(h->vk_digest, w + 20 + kNumChips, 32);
+  if (h->pv_len > (1u << 24)) { *err = "public values too long"; return false; }
+  h->pv_offset = (size_t)kHeaderWords * 4;
+  h->body_offset = ((size_t)kHeaderWords + (h->pv_len + 3) / 4) * 4;
+  if (len < h->body_offset) { *err = "proof truncated in header"; return false; }
+  for (size_t i = h->pv_offset + h->pv_len; i < h->body_offset; ++i)
+    if (bytes[i] != 0) { *err = "non-zero padding after the public values"; return false; }
+  return true;
+}
+
+int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, uint32_t num_queries, uint32_t pow_bits,
+                         std::string* err) {
+  MachineHeader hd;
+  if (!parse_machine_header(bytes, len, &hd, err)) return 7;
+  const int* logh = hd.logh;
+  const size_t body_words = machine_proof_body_words(logh, num_queries);
+  if (len != hd.body_offset + body_words * 4) { *err = "proof length mismatch"; return 7; }
+  if (memcmp(hd.vk_digest, vk.digest, 32) != 0) { *err = "verifying key mismatch"; return 8; }
+  if (logh[kImage] != vk.log_image || logh[kProgram] != vk.log_prog) { *err = "preprocessed table heights differ from the key"; return 8; }
+  {
+    uint8_t dg[32];
+    sha256(bytes + hd.pv_offset, hd.pv_len, dg);
+    if (memcmp(dg, hd.pv_digest, 32) != 0) { *err = "public-values digest mismatch"; return 8; }
+  }
+  if (hd.exit_code != 0) { *err = "guest exit code is not zero"; return 8; }
+  const uint32_t* body = reinterpret_cast<const uint32_t*>(bytes + hd.body_offset);
+  for (size_t i = 0; i < body_words; ++i)
+    if (body[i] >= kP) { *err = "non-canonical field element"; return 7; }
+
+  const P2Consts* kc = &host_p2_consts();
+  const int lm = logh[kCpu];
+  // shapes
+  RoundShape shape[4];
+  size_t open_off[kNumChips], n_open = 0;
+  for (int r = 0; r < 4; ++r) shape[r].lm = 0;
+  for (int c = 0; c < kNumChips; ++c) {
+    const ChipDef& d = chip_def(c);
+    const int w[4] = {d.prep_w, d.main_w, d.perm_width(), 8};
+    for (int r = 0; r < 4; ++r) {
+      shape[r].width[c] = w[r];
+      if (w[r]) shape[r].lm = std::max(shape[r].lm, logh[c]);
+    }
+    open_off[c] = n_open;
+    n_open += (size_t)d.prep_w + 2 * (size_t)d.main_w + 2 * (size_t)d.perm_width() + 8;
+  }
+  const uint32_t* p_root_main = body;
+  const uint32_t* p_root_perm = body + 8;
+  const uint32_t* p_cum = body + 16;
+  const uint32_t* p_root_quot = p_cum + 4 * kNumChips;
+  const uint32_t* p_opened = p_root_quot + 8;
+  const uint32_t* p_fri_roots = p_opened + 4 * n_open;
+  const uint32_t* p_final = p_fri_roots + 8 * (size_t)lm;
+  const uint32_t* p_witness = p_final + 4;
+  const uint32_t* p_queries = p_witness + 1;
+
+  // ---- transcript ----
+  HostChallenger ch(kc);
+  for (int i = 0; i < 8; ++i) ch.observe_canon(hd.vk_digest[i]);
+  for (int c = 0; c < kNumChips; ++c) ch.observe_canon((uint32_t)logh[c]);
+  ch.observe_canon(hd.exit_code & 0xffff);
+  ch.observe_canon(hd.exit_code >> 16);
+  for (int i = 0; i < 8; ++i) { ch.observe_canon(hd.pv_digest[i] & 0xffff); ch.observe_canon(hd.pv_digest[i] >> 16); }
+  for (int i = 0; i < 8; ++i) { ch.observe_canon(hd.deferred_digest[i] & 0xffff); ch.observe_canon(hd.deferred_digest[i] >> 16); }
+  Fp root[4][8];
+  for (int i = 0; i < 8; ++i) root[0][i] = Fp::from_canonical(vk.prep_root[i]);
+  for (int i = 0; i < 8; ++i) { root[1][i] = Fp::from_canonical(p_root_main[i]); ch.observe(root[1][i]); }
+  const Fp4 gamma = ch.sample_ext(), beta = ch.sample_ext();
+  for (int i = 0; i < 8; ++i) { root[2][i] = Fp::from_canonical(p_root_perm[i]); ch.observe(root[2][i]); }
+  Fp4 cum[kNumChips];
+  for (int c = 0; c < kNumChips; ++c) {
+    cum[c] = read_fp4(p_cum + 4 * c);
+    for (int i = 0; i < 4; ++i) ch.observe(cum[c].c[i]);
+  }
+  const Fp4 alpha = ch.sample_ext();
+  for (int i = 0; i < 8; ++i) { root[3][i] = Fp::from_canonical(p_root_quot[i]); ch.observe(root[3][i]); }
+  const Fp4 zeta = ch.sample_ext();
+
+  // ---- the buses balance: chips + the public COMMIT / COMMIT_DEFERRED / HALT terms ----
+  Fp4 bpow[kInterMaxElems + 1];
+  bpow[0] = Fp4::one();
+  for (int j = 1; j <= kInterMaxElems; ++j) bpow[j] = bpow[j - 1] * beta;
+  {
+    Fp4 total = Fp4::zero();
+    for (int c = 0; c < kNumChips; ++c) total += cum[c];
+    auto fc = [](uint32_t v) { return Fp4::from_base(Fp::from_canonical(v)); };
+    for (uint32_t kind = 1; kind <= 2; ++kind)
+      for (uint32_t i = 0; i < 8; ++i) {
+        const uint32_t w = kind == 1 ? hd.pv_digest[i] : hd.deferred_digest[i];
+        const Fp4 f = gamma + fc(BUS_PUBC) + bpow[1] * fc(kind) + bpow[2] * fc(i) + bpow[3] * fc(w & 0xffff) + bpow[4] * fc(w >> 16);
+        total -= f.inv();
+      }
+    const Fp4 fh = gamma + fc(BUS_PUBH) + bpow[1] * fc(hd.exit_code & 0xffff) + bpow[2] * fc(hd.exit_code >> 16);
+    total -= fh.inv();
+    if (total != Fp4::zero()) { *err = "LogUp buses do not balance against the public values and exit code"; return 8; }
+  }
+
+  std::vector<Fp4> opened(n_open);
+  for (size_t i = 0; i < n_open; ++i) opened[i] = read_fp4(p_opened + 4 * i);
+  {
+    std::vector<Fp> words(n_open * 4);
+    for (size_t t = 0; t < n_open * 4; ++t) words[t] = Fp::from_canonical(p_opened[t]);
+    Fp open_root[8];
+    list_root(words, ceil_log2((n_open * 4 + 7) / 8), open_root, kc);
+    for (int i = 0; i < 8; ++i) ch.observe(open_root[i]);
+  }
+  const Fp4 af = ch.sample_ext();
+
+  // ---- constraint identity of every chip at zeta ----
+  const Fp g = Fp::from_canonical(kGen);
+  for (int c = 0; c < kNumChips; ++c) {
+    const ChipDef& d = chip_def(c);
+    const int pw = d.prep_w, mw = d.main_w, ew = d.perm_width(), nh = d.helpers(), nb = d.n_constraints;
+    const size_t h = (size_t)1 << logh[c];
+    const Fp4* o_prep = opened.data() + open_off[c];
+    const Fp4* o_main = o_prep + pw;
+    const Fp4* o_perm = o_main + mw;
+    const Fp4* o_quot = o_perm + ew;
+    const Fp4* o_main_n = o_quot + 8;
+    const Fp4* o_perm_n = o_main_n + mw;
+    const Fp wh = fp_root_of_unity(logh[c]), wh_inv = wh.inv();
+    const Fp4 zeta_h = zeta.pow(h), zh = zeta_h - Fp4::one();
+    std::vector<Fp4> apow(d.total_constraints());
+    apow[0] = Fp4::one();
+    for (size_t k = 1; k < apow.size(); ++k) apow[k] = apow[k - 1] * alpha;
+    ZetaCtx zc;
+    zc.loc = o_main;
+    zc.nxt = o_main_n;
+    zc.first = zh * (zeta - Fp4::one()).inv();
+    zc.trans = zeta - Fp4::from_base(wh_inv);
+    zc.last = zh * (zeta - Fp4::from_base(wh_inv)).inv();
+    zc.pub_ = Fp4::from_base(Fp::from_canonical(vk.entry));
+    zc.ap = apow.data();
+    switch (c) {
+      case kCpu: eval_cpu(zc); break;
+      case kKeccak:
+        for (int task = 0; task < ka::kBusTask; ++task) ka::eval_task(task, zc);
+        zc.k_ = ka::kNumConstraints;
+        eval_keccak_ts(zc);
+        break;
+      case kKmem: eval_kmem(zc); break;
+      case kMemFinal: eval_memfinal(zc); break;
+      case kImage: eval_image(zc); break;
+      case kProgram: break;
+      case kMul: eval_mul(zc); break;
+    }
+    if (zc.k_ != nb) { *err = "internal: constraint count"; return 7; }
+    // LogUp: row = [prep | main] at zeta
+    std::vector<Fp4> row(o_prep, o_prep + pw + mw);
+    Fp4 hsum = Fp4::zero();
+    for (int j = 0; j < nh; ++j) {
+      const Fp4 hj = from_basis(o_perm + 4 * j);
+      hsum += hj;
+      const Interaction& ia = d.inter[2 * j];
+      Fp4 ma = lf_eval(ia.mult, row.data());
+      if (ia.sign < 0) ma = -ma;
+      const Fp4 fa = fingerprint(ia, row.data(), gamma, bpow);
+      Fp4 v;
+      if (2 * j + 1 < d.n_inter) {
+        const Interaction& ib = d.inter[2 * j + 1];
+        Fp4 mb = lf_eval(ib.mult, row.data());
+        if (ib.sign < 0) mb = -mb;
+        const Fp4 fb = fingerprint(ib, row.data(), gamma, bpow);
+        v = hj * fa * fb - (fb * ma + fa * mb);
+      } else {
+        v = hj * fa - ma;
+      }
+      zc.acc += apow[nb + j] * v;
+    }
+    const Fp4 phi = from_basis(o_perm + 4 * nh), phin = from_basis(o_perm_n + 4 * nh);
+    zc.acc += apow[nb + nh] * (phi * zc.first);
+    zc.acc += apow[nb + nh + 1] * ((phin - phi - hsum) * zc.trans);
+    zc.acc += apow[nb + nh + 2] * ((cum[c] - phi - hsum) * zc.last);
+    const Fp4 q0 = from_basis(o_quot), q1 = from_basis(o_quot + 4);
+    const Fp sh = g.pow(h), inv_2sh = (sh + sh).inv();
+    const Fp4 quot = q0 * (zeta_h + Fp4::from_base(sh)) * inv_2sh - q1 * (zeta_h - Fp4::from_base(sh)) * inv_2sh;
+    if (zc.acc != quot * zh) { *err = std::string("constraint identity fails at zeta for chip ") + d.name; return 8; }
+  }
+
+  // ---- FRI transcript ----
+  std::vector<Fp4> betas(lm);
+  std::vector<std::array<Fp, 8>> fri_roots(lm);
+  for (int k = 0; k < lm; ++k) {
+    for (int i = 0; i < 8; ++i) { fri_roots[k][i] = Fp::from_canonical(p_fri_roots[8 * k + i]); ch.observe(fri_roots[k][i]); }
+    betas[k] = ch.sample_ext();
+  }
+  const Fp4 final_poly = read_fp4(p_final);
+  for (int i = 0; i < 4; ++i) ch.observe(final_poly.c[i]);
+  ch.observe_canon(p_witness[0]);
+  if (ch.sample_bits((int)pow_bits) != 0) { *err = "proof-of-work witness rejected"; return 8; }
+
+  // ---- reduced-opening constants per chip ----
+  std::vector<Fp4> afpow(n_open);
+  afpow[0] = Fp4::one();
+  for (size_t i = 1; i < n_open; ++i) afpow[i] = afpow[i - 1] * af;
+  Fp4 b1[kNumChips], b2[kNumChips];
+  size_t n1[kNumChips], n2[kNumChips];
+  for (int c = 0; c < kNumChips; ++c) {
+    const ChipDef& d = chip_def(c);
+    n1[c] = (size_t)d.prep_w + d.main_w + d.perm_width() + 8;
+    n2[c] = (size_t)d.main_w + d.perm_width();
+    b1[c] = b2[c] = Fp4::zero();
+    for (size_t i = 0; i < n1[c]; ++i) b1[c] += afpow[open_off[c] + i] * opened[open_off[c] + i];
+    for (size_t i = 0; i < n2[c]; ++i) b2[c] += afpow[open_off[c] + n1[c] + i] * opened[open_off[c] + n1[c] + i];
+  }
+  const Fp inv2 = Fp::from_canonical(2).inv();
+
+  size_t perq = 0;
+  for (int r = 0; r < 4; ++r) {
+    for (int c = 0; c < kNumChips; ++c) perq += (size_t)shape[r].width[c];
+    perq += 8 * ((size_t)shape[r].lm + 1);
+  }
+  for (int k = 0; k < lm; ++k) perq += 8 + 8 * (size_t)(lm - k);
+  const size_t hmax = (size_t)1 << lm;
+  std::vector<std::vector<Fp>> rows[4];
+  for (int r = 0; r < 4; ++r) rows[r].resize(kNumChips);
+  for (uint32_t qi = 0; qi < num_queries; ++qi) {
+    const uint32_t* q = p_queries + perq * qi;
+    const size_t idx = ch.sample_bits(lm + 1);
+    const size_t cs = idx >> lm, m = idx & (hmax - 1);
+    for (int r = 0; r < 4; ++r) {
+      for (int c = 0; c < kNumChips; ++c) {
+        rows[r][c].resize(shape[r].width[c]);
+        for (int i = 0; i < shape[r].width[c]; ++i) rows[r][c][i] = Fp::from_canonical(q[i]);
+        q += shape[r].width[c];
+      }
+      if (!mmcs_verify(shape[r], logh, rows[r], cs, m, q, root[r], kc)) {
+        static const char* names[4] = {"preprocessed", "main", "permutation", "quotient"};
+        *err = std::string(names[r]) + " Merkle opening rejected";
+        return 8;
+      }
+      q += 8 * ((size_t)shape[r].lm + 1);
+    }
+    // reduced openings per height
+    auto reduced = [&](int lh) -> Fp4 {
+      Fp4 gsum = Fp4::zero();
+      for (int c = 0; c < kNumChips; ++c) {
+        if (logh[c] != lh) continue;
+        const size_t h = (size_t)1 << lh, mm = m & (h - 1);
+        const Fp wh = fp_root_of_unity(lh), w2h = fp_root_of_unity(lh + 1);
+        const Fp x = (cs ? g * w2h : g) * wh.pow(mm);
+        Fp4 s1 = Fp4::zero(), s2 = Fp4::zero();
+        size_t i = 0, j = 0;
+        for (int r = 0; r < 4; ++r)
+          for (int col = 0; col < shape[r].width[c]; ++col, ++i) {
+            const Fp v = rows[r][c][col];
+            s1 += afpow[open_off[c] + i] * v;
+            if (r == 1 || r == 2) { s2 += afpow[open_off[c] + n1[c] + j] * v; ++j; }
+          }
+        const Fp4 d0 = (Fp4::from_base(x) - zeta).inv(), d1 = (Fp4::from_base(x) - zeta * wh).inv();
+        gsum += (s1 - b1[c]) * d0 + (s2 - b2[c]) * d1;
+      }
+      return gsum;
+    };
+    auto height_present = [&](int lh) { for (int c = 0; c < kNumChips; ++c) if (logh[c] == lh) return true; return false; };
+    Fp4 expect = reduced(lm);
+    Fp shift_k = g;
+    for (int k = 0; k < lm; ++k) {
+      const int loghk = lm - k;
+      const size_t hk = (size_t)1 << loghk, half = hk >> 1;
+      const size_t mk = m & (hk - 1), mlo = mk & (half - 1);
+      const Fp4 lo = read_fp4(q), hi = read_fp4(q + 4);
+      if ((mk >= half ? hi : lo) != expect) { *err = "FRI layer value inconsistent with previous fold"; return 8; }
+      Fp pair[8], leaf[8];
+      for (int i = 0; i < 4; ++i) { pair[i] = lo.c[i]; pair[4 + i] = hi.c[i]; }
+      hash_elems(pair, 8, leaf, kc);
+      if (!verify_path(leaf, cs * half + mlo, q + 8, loghk, fri_roots[k].data(), kc)) { *err = "FRI Merkle path rejected"; return 8; }
+      const Fp xk = (cs ? shift_k * fp_root_of_unity(loghk + 1) : shift_k) * fp_root_of_unity(loghk).pow(mlo);
+      expect = (lo + hi) * inv2 + betas[k] * ((lo - hi) * (inv2 * xk.inv()));
+      if (height_present(loghk - 1)) expect += reduced(loghk - 1);
+      q += 8 + 8 * loghk;
+      shift_k = shift_k * shift_k;
+    }
+    if (expect != final_poly) { *err = "FRI final value mismatch"; return 8; }
+  }
+  return 0;
+}
+
+}  // namespace zksp
