@@ -51,7 +51,15 @@ typedef struct {
   uint32_t num_queries;   /* FRI queries; 0 = default 100 */
   uint32_t pow_bits;      /* proof-of-work bits; 0xffffffff = default 16 */
   uint32_t max_batch;     /* proofs proven in lockstep per launch group; 0 = default 16 */
+  int32_t proof_mode;     /* ZKSP_PROOF_*; 0 = default (MACHINE) */
 } zksp_options;
+/* What zksp_prove / zksp_prove_batch establish:
+ * MACHINE      the guest's whole execution (CPU, memory, program, keccak, multiplier chips joined by
+ *              LogUp buses; proof format v3): the statement of the reference's client.prove().
+ * KECCAK_CHIP  only "these keccak-f outputs belong to these inputs" (round-1 format v2, a component
+ *              benchmark; NOT a proof that the guest ran). */
+#define ZKSP_PROOF_MACHINE 1
+#define ZKSP_PROOF_KECCAK_CHIP 2
 
 /* replaces ProverClient::new()  (main.rs:61).  Fails with ZKSP_ERR_NO_DEVICE when
  * device_ordinal >= 0 and no GPU is usable: there is no CPU proving fallback.
@@ -148,6 +156,17 @@ void zksp_mtrace_free(zksp_mtrace* t);
 /* Borrowed pointer into the handle. */
 int zksp_mtrace_section(const zksp_mtrace* t, int which, const void** ptr, size_t* bytes);
 int zksp_mtrace_info(const zksp_mtrace* t, zksp_mtrace_info_t* info);
+/* Device-resident machine proving (bench.py, parity tests): upload the records of n traced runs
+ * with identical chip heights, enqueue one proving pass, fetch the proof bodies ([n][body_words]
+ * canonical u32; body_words = zksp_machine_body_words of the traces' heights). */
+int zksp_mtrace_heights(const zksp_mtrace* t, int32_t* log_heights7);
+size_t zksp_machine_body_words(const zksp_client* c, const int32_t* log_heights7);
+int zksp_hip_machine_load(zksp_client* c, const zksp_pk* pk, const zksp_mtrace* const* traces, size_t n);
+int zksp_hip_machine_prove(zksp_client* c);
+int zksp_hip_machine_fetch_bodies(zksp_client* c, uint32_t* out, size_t cap_words);
+/* Complete v3 proof object from one fetched body and the trace it belongs to. */
+int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const uint32_t* body, size_t body_words,
+                                 zksp_proof** out);
 /* The machine-proof part of the verifying key: Merkle root of the preprocessed Program / Image
  * tables and the digest that binds it to the entry point, table heights and keccak mode
  * (8 canonical u32 each). */

@@ -21,12 +21,14 @@ SOURCES = [
     "device/kernels_hash.hip",
     "device/kernels_stark.hip",
     "device/kernels_bus.hip",
+    "device/kernels_machine.hip",
     "device/kernels_bench.hip",
     "host/executor.cpp",
     "host/machine.cpp",
     "host/params.cpp",
     "host/context.cpp",
     "host/prover.cpp",
+    "host/mprover.cpp",
     "host/verifier.cpp",
     "host/machine_defs.cpp",
     "host/mverifier.cpp",
@@ -35,8 +37,8 @@ SOURCES = [
     "host/api_machine.cpp",
 ]
 HEADERS = [
-    "device/field.cuh", "device/poseidon2.cuh", "device/air_keccak.cuh", "device/air_machine.cuh", "device/kernels.h",
-    "host/machine_defs.hpp", "host/mverifier.hpp", "host/host_hash.hpp",
+    "device/field.cuh", "device/poseidon2.cuh", "device/air_keccak.cuh", "device/air_machine.cuh", "device/kernels.h", "device/kernels_machine.h",
+    "host/machine_defs.hpp", "host/mverifier.hpp", "host/mprover.hpp", "host/host_hash.hpp",
     "host/executor.hpp", "host/machine.hpp", "host/context.hpp", "host/prover.hpp", "host/verifier.hpp", "host/api_types.hpp",
 ]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

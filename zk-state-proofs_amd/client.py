@@ -28,6 +28,7 @@ OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_ELF, ERR_EXECUTOR, ERR_GUEST_PANIC, ERR_PROOF_FORMAT, ERR_VERIFY, \
     ERR_UNSUPPORTED = range(1, 10)
 KECCAK_SOFTWARE, KECCAK_OBSERVE, KECCAK_REPLACE = 0, 1, 2
+PROOF_MACHINE, PROOF_KECCAK_CHIP = 1, 2
 
 
 class ZkspError(RuntimeError):
@@ -46,7 +47,7 @@ class VerificationError(ZkspError):
 
 class Options(C.Structure):
     _fields_ = [("device_ordinal", C.c_int32), ("keccak_mode", C.c_int32), ("num_queries", C.c_uint32),
-                ("pow_bits", C.c_uint32), ("max_batch", C.c_uint32)]
+                ("pow_bits", C.c_uint32), ("max_batch", C.c_uint32), ("proof_mode", C.c_int32)]
 
 
 class ExecReport(C.Structure):
@@ -112,6 +113,13 @@ def load_library() -> C.CDLL:
     lib.zksp_mtrace_section.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(sz)]
     lib.zksp_mtrace_info.argtypes = [vp, C.POINTER(MTraceInfo)]
     lib.zksp_vk_machine.argtypes = [vp, vp, vp]
+    lib.zksp_mtrace_heights.argtypes = [vp, vp]
+    lib.zksp_machine_body_words.argtypes = [vp, vp]
+    lib.zksp_machine_body_words.restype = sz
+    lib.zksp_hip_machine_load.argtypes = [vp, vp, C.POINTER(vp), sz]
+    lib.zksp_hip_machine_prove.argtypes = [vp]
+    lib.zksp_hip_machine_fetch_bodies.argtypes = [vp, vp, sz]
+    lib.zksp_machine_proof_from_body.argtypes = [vp, vp, vp, sz, C.POINTER(vp)]
     lib.zksp_get_params.argtypes = [vp, C.POINTER(Params)]
     lib.zksp_proof_body_words.argtypes = [vp, C.c_int]
     lib.zksp_proof_body_words.restype = sz
@@ -150,7 +158,8 @@ ABI_SYMBOLS = [
     "zksp_vk_digest", "zksp_stdin_new", "zksp_stdin_write", "zksp_stdin_free", "zksp_prove", "zksp_prove_batch",
     "zksp_proof_public_values", "zksp_proof_serialize", "zksp_proof_deserialize", "zksp_proof_free", "zksp_verify",
     "zksp_execute", "zksp_execute_keccak", "zksp_opcode_name", "zksp_machine_trace", "zksp_mtrace_free",
-    "zksp_mtrace_section", "zksp_mtrace_info", "zksp_vk_machine", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
+    "zksp_mtrace_section", "zksp_mtrace_info", "zksp_vk_machine", "zksp_mtrace_heights", "zksp_machine_body_words",
+    "zksp_hip_machine_load", "zksp_hip_machine_prove", "zksp_hip_machine_fetch_bodies", "zksp_machine_proof_from_body", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
     "zksp_hip_prove_resident", "zksp_proof_from_body", "zksp_hip_fetch_bodies", "zksp_hip_fetch_roots", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
     "zksp_hip_profile_enable", "zksp_hip_profile_read", "zksp_hip_profile_reset", "zksp_dev_malloc", "zksp_dev_free",
     "zksp_dev_upload", "zksp_dev_download", "zksp_dev_memset", "zksp_hip_lde", "zksp_hip_merkle_commit",
@@ -256,6 +265,24 @@ def proof_from_body(body, log_h: int, states, exit_code: int, public_values: byt
     return SP1ProofWithPublicValues(lib, h, lib.zksp_proof_free)
 
 
+class MachineTraceHandle(_Handle):
+    """A traced guest run kept on the C side (``zksp_mtrace``)."""
+
+    def heights(self):
+        lh = (C.c_int32 * 7)()
+        self._lib.zksp_mtrace_heights(self._h, lh)
+        return list(lh)
+
+    def proof_from_body(self, pk: "ProvingKey", body) -> "SP1ProofWithPublicValues":
+        import numpy as np
+        body = np.ascontiguousarray(body, dtype=np.uint32)
+        h = C.c_void_p()
+        rc = self._lib.zksp_machine_proof_from_body(pk._h, self._h, body.ctypes.data_as(C.c_void_p), body.size, C.byref(h))
+        if rc:
+            raise ZkspError(rc, "machine_proof_from_body")
+        return SP1ProofWithPublicValues(self._lib, h, self._lib.zksp_proof_free)
+
+
 class _ProveBuilder:
     """What ``client.prove(&pk, stdin)`` returns; ``.run()`` does the work."""
 
@@ -282,11 +309,11 @@ class ProverClient:
     """
 
     def __init__(self, device: Optional[int] = None, *, keccak_mode: int = KECCAK_REPLACE, num_queries: int = 100,
-                 pow_bits: int = 16, max_batch: int = 16):
+                 pow_bits: int = 16, max_batch: int = 16, proof_mode: int = PROOF_MACHINE):
         self._lib = load_library()
         if device is None:
             device = int(os.environ.get("ZKSP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-        opts = Options(device, keccak_mode, num_queries, pow_bits, max_batch)
+        opts = Options(device, keccak_mode, num_queries, pow_bits, max_batch, proof_mode)
         self._h = C.c_void_p()
         rc = self._lib.zksp_client_new(C.byref(opts), C.byref(self._h))
         if rc:
@@ -383,6 +410,32 @@ class ProverClient:
                     "public_values": bytes(sec(8, np.uint8)), "info": info}
         finally:
             self._lib.zksp_mtrace_free(h)
+
+    def machine_trace_handle(self, pk: ProvingKey, stdin: SP1Stdin) -> "MachineTraceHandle":
+        h = C.c_void_p()
+        rc = self._lib.zksp_machine_trace(self._h, pk._h, stdin._h, C.byref(h))
+        if rc:
+            raise ZkspError(rc, self.last_error())
+        return MachineTraceHandle(self._lib, h, self._lib.zksp_mtrace_free)
+
+    def machine_prove_resident(self, pk: ProvingKey, traces):
+        """Loads traced runs (MachineTraceHandle, identical chip heights), proves them in lockstep on the
+        GPU and returns the proof bodies as a numpy array [n][body_words]."""
+        import numpy as np
+        n = len(traces)
+        arr = (C.c_void_p * n)(*[t._h for t in traces])
+        rc = self._lib.zksp_hip_machine_load(self._h, pk._h, arr, n)
+        if rc == 0:
+            rc = self._lib.zksp_hip_machine_prove(self._h)
+        if rc:
+            raise ZkspError(rc, self.last_error())
+        lh = (C.c_int32 * 7)(*traces[0].heights())
+        bw = self._lib.zksp_machine_body_words(self._h, lh)
+        out = np.zeros((n, bw), np.uint32)
+        rc = self._lib.zksp_hip_machine_fetch_bodies(self._h, out.ctypes.data_as(C.c_void_p), out.size)
+        if rc:
+            raise ZkspError(rc, self.last_error())
+        return out
 
     def opcode_histogram(self, rep: ExecReport) -> dict:
         out = {}

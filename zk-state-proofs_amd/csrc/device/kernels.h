@@ -46,6 +46,8 @@ void launch_poseidon2_permute(hipStream_t stream, uint32_t* states, size_t n, co
 // states: [batch][max_perms][25] u64; n_perms: [batch]; trace: [batch][2633][H]
 void launch_keccak_trace(hipStream_t stream, const uint64_t* states, int max_perms, const uint32_t* n_perms,
                          uint32_t* trace, int logh, int batch);
+void launch_keccak_trace_strided(hipStream_t stream, const uint64_t* states, int max_perms, const uint32_t* n_perms,
+                                 uint32_t* trace, size_t trace_bstride, int logh, int batch);
 struct QuotientArgs {
   const uint32_t* lde;         // [batch][2633][2][H]
   const uint32_t* lde_p;       // [batch][4][2][H] running-sum columns

@@ -1,0 +1,140 @@
+// Launchers of the machine-proof kernels: trace expansion of every
+// chip from the executor's records, the generic LogUp permutation trace, per-chip quotient
+// evaluation, the mixed-height Merkle commitment, reduced openings per height, proof assembly.
+// Same conventions as kernels.h: everything is enqueued on `stream`, nothing allocates or
+// synchronises, field elements in device buffers are Montgomery residues, the leading index of
+// every per-proof buffer is the proof in the batch.
+#pragma once
+#include "../host/machine_defs.hpp"
+#include "kernels.h"
+
+namespace zksp {
+
+// One matrix of a batch: column-major [width][rows] per proof, proofs `bstride` words apart
+// (bstride = 0: one matrix shared by the whole batch, e.g. the preprocessed tables).
+struct Seg {
+  const uint32_t* p;
+  size_t bstride;
+  int width;
+};
+constexpr int kMaxSegs = 8;
+
+// ---- trace expansion (row a3 of the machine proof) ----
+struct MachineRecords {
+  const uint32_t* cycles;      // [B][cap_cycles][12]
+  const uint8_t* kcalls;       // [B][cap_keccak][408]
+  const uint32_t* memfinal;    // [B][cap_memfinal][5]
+  const uint32_t* muls;        // [B][cap_muls][3]
+  const uint32_t* prog_mult;   // [B][2^log_prog]
+  const uint32_t* image_used;  // [B][2^log_image]
+  const uint32_t* counts;      // [B][4]: cycles, keccak calls, memfinal rows, muls
+  size_t cap_cycles, cap_keccak, cap_memfinal, cap_muls;
+  const uint32_t* program;     // [n_program][9] (shared)
+  uint32_t text_base, n_program;
+};
+// trace: [B][main_width][2^logh] of the given chip (kCpu, kKmem, kMemFinal, kImage, kProgram, kMul)
+void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& rec, uint32_t* trace, int logh, int batch);
+// keccak chip: p3-keccak-air's columns by launch_keccak_trace (kernels.h, with a batch stride), then the call time
+void launch_keccak_ts(hipStream_t stream, const MachineRecords& rec, uint32_t* trace, size_t trace_bstride, int logh,
+                      int batch);
+
+// ---- mixed-height Merkle commitment (row a5) ----
+// Leaf digests of one height group: rows of `nseg` LDE matrices ([w][2H] each) concatenated, written to
+// digests[b][c * H + bitrev(m)] (8 words each; `out_bstride` words between proofs).
+void launch_mmcs_leaves(hipStream_t stream, const Seg* segs, int nseg, int logh, uint32_t* digests, size_t out_bstride,
+                        int batch, const P2Consts* consts);
+// One level: out[i] = compress(in[2i], in[2i+1]), then compress(out[i], inject[i]) when inject != null.
+void launch_mmcs_level(hipStream_t stream, const uint32_t* in, size_t in_bstride, uint32_t* out, size_t out_bstride,
+                       const uint32_t* inject, size_t inject_bstride, size_t count, int batch, const P2Consts* consts);
+
+// ---- LogUp (row a6, lookup argument) ----
+struct PermArgs {
+  const mach::Interaction* inter;  // device copy of the chip's interactions
+  int n_inter;
+  Seg prep, main_;                 // traces [w][H]
+  const uint32_t* bus_ch;          // [B][8]: gamma, beta
+  const uint32_t* bpow;            // [B][11] Fp4: powers of beta
+  uint32_t* perm;                  // [B][perm_width][H]
+  size_t perm_bstride;
+  uint32_t* rowsum;                // [B][H] Fp4 scratch
+  uint32_t* cum;                   // [B] Fp4 (this chip's cumulative sum)
+  size_t cum_bstride;
+  int logh, batch;
+};
+void launch_perm_trace(hipStream_t stream, const PermArgs& a);
+// public terms of the two verifier-closed buses: out[b] = -(sum over the 16 digest words and the exit code of 1/f)
+void launch_public_bus(hipStream_t stream, const uint32_t* pub_words /*[B][17]: pv digest 8, deferred 8, exit code*/,
+                       const uint32_t* bus_ch, const uint32_t* bpow, uint32_t* out, size_t out_bstride, int batch);
+
+// ---- quotient (row a6) ----
+struct MQuotArgs {
+  int chip;
+  const mach::Interaction* inter;
+  int n_inter, n_base;          // base constraints; helpers and the 3 running-sum constraints follow
+  Seg prep, main_, perm;        // LDEs [w][2H]
+  const uint32_t* alpha_pows;   // [B][alpha_stride] Fp4
+  size_t alpha_bstride;
+  const uint32_t* bus_ch;       // [B][8]
+  const uint32_t* bpow;         // [B][11] Fp4
+  const uint32_t* cum;          // [B] Fp4, stride cum_bstride
+  size_t cum_bstride;
+  const uint32_t* tw_fwd;       // [H/2] powers of w_H
+  uint32_t shift[2];            // g, g * w_2H  (Montgomery)
+  uint32_t zh_inv[2];
+  uint32_t wh_inv;
+  uint32_t pub;                 // entry pc (Montgomery)
+  uint32_t* quot;               // [B][8][H]
+  uint32_t* partial;            // keccak chip only: [B][13][2H] Fp4 scratch
+  int logh, batch;
+};
+void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a);
+
+// ---- reduced openings per chip (row a7) ----
+struct MReduceArgs {
+  Seg mats[4];                 // prep, main, perm, quot LDEs ([w][2H]); width 0 = absent
+  const uint32_t* af_pows;     // [B][n_open] Fp4, this chip's first power at `pow_off`
+  size_t af_bstride;
+  size_t pow_off;
+  const uint32_t* opened;      // [B][..] Fp4, this chip's first value at `open_off` (same order as the powers)
+  size_t opened_bstride, open_off;
+  const uint32_t* zeta;        // [B] Fp4
+  const uint32_t* tw_fwd;      // [H/2]
+  uint32_t shift[2], w_h;
+  uint32_t* partial;           // [B][nchunks][2][2H] Fp4 scratch
+  uint32_t* bsum;              // [B][2] Fp4 scratch
+  uint32_t* out;               // [B][2H] Fp4: G of this height
+  size_t out_bstride;
+  int accumulate;              // add to `out` instead of overwriting (another chip of the same height)
+  int logh, batch;
+};
+int mreduce_nchunks(int total_width);
+void launch_machine_reduce(hipStream_t stream, const MReduceArgs& a);
+// layer[i] += g[i] (Fp4), n elements per proof
+void launch_fri_add(hipStream_t stream, uint32_t* layer, size_t layer_bstride, const uint32_t* g, size_t g_bstride, size_t n,
+                    int batch);
+
+// ---- proof assembly ----
+struct MRound {
+  Seg seg[mach::kNumChips][2];   // LDE matrices of each chip in the round (quotient: two 4-column chunks); width 0 = absent
+  int logh[mach::kNumChips];
+  const uint32_t* tree;          // [B][(2N - 1) * 8], levels back to back, N = 2 * 2^lm
+  size_t tree_bstride;
+  int lm;
+};
+struct MAssembleArgs {
+  MRound round[4];
+  const uint32_t* cum;         // [B][7] Fp4
+  const uint32_t* opened;      // [B][n_open] Fp4
+  size_t opened_bstride, n_open;
+  const uint32_t* fri_layers;  // as in AssembleArgs
+  const uint32_t* fri_trees;
+  size_t fri_layer_stride, fri_tree_stride;
+  const uint32_t* witness;
+  const uint32_t* indices;
+  uint32_t* body;
+  size_t body_stride;
+  int lm, n_queries, batch;
+};
+void launch_machine_assemble(hipStream_t stream, const MAssembleArgs& a);
+
+}  // namespace zksp

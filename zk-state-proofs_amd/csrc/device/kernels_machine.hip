@@ -1,0 +1,958 @@
+// Device side of the machine proof (kernels_machine.h): what
+// sp1-core-machine / sp1-stark do on the host for the CPU, memory, program and ALU chips beneath
+// the reference's `client.prove(&pk, stdin).run()` (prover/src/bin/main.rs:71-74; Cargo.lock:7130,
+// :7485), here as HIP kernels over a batch of proofs that share one program.
+//
+// Data layout: every matrix is column-major, so in trace expansion (lane = row), leaf hashing
+// (lane = LDE row), quotient evaluation and reduced openings (lane = LDE point) a wave reads or
+// writes 64 consecutive words of one column at every step.  Tree positions are bit-reversed
+// relative to the LDE index (position >> d addresses the matching row of a 2^d times shorter
+// matrix); the leaf kernel keeps lanes on consecutive LDE rows and scatters only its 32-byte
+// digest.
+#include "kernels_machine.h"
+
+namespace zksp {
+
+using namespace mach;
+
+constexpr int kMT = 256;
+
+__device__ __forceinline__ uint32_t mont(uint32_t canonical) { return Fp::from_canonical(canonical).v; }
+__device__ __forceinline__ Fp4 m_load_fp4(const uint32_t* p) {
+  uint4 v = *reinterpret_cast<const uint4*>(p);
+  Fp4 r;
+  r.c[0] = Fp::raw(v.x); r.c[1] = Fp::raw(v.y); r.c[2] = Fp::raw(v.z); r.c[3] = Fp::raw(v.w);
+  return r;
+}
+__device__ __forceinline__ void m_store_fp4(uint32_t* p, const Fp4& a) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(a.c[0].v, a.c[1].v, a.c[2].v, a.c[3].v);
+}
+
+// ===========================================================================================
+// trace expansion: one lane per row, records in, Montgomery columns out
+// ===========================================================================================
+struct Col {
+  uint32_t* t;
+  size_t cs;
+  __device__ __forceinline__ void put(int col, uint32_t monty) const { t[(size_t)col * cs] = monty; }
+  __device__ __forceinline__ void val(int col, uint32_t canonical) const { t[(size_t)col * cs] = mont(canonical); }
+  __device__ __forceinline__ void bits(int col, uint32_t v, int n) const {
+    for (int i = 0; i < n; ++i) t[(size_t)(col + i) * cs] = ((v >> i) & 1u) ? kR1 : 0u;
+  }
+  __device__ __forceinline__ void zero(int col, int n) const {
+    for (int i = 0; i < n; ++i) t[(size_t)(col + i) * cs] = 0u;
+  }
+};
+
+__global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh) {
+  const size_t h = (size_t)1 << logh;
+  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (r >= h) return;
+  const int b = blockIdx.y;
+  const Col o{trace + (size_t)b * kCpuWidth * h + r, h};
+  const uint32_t ts = 4 * ((uint32_t)r + 1);
+  if (r >= rec.counts[4 * b]) {  // padding: only the clock runs on
+    o.zero(0, kCpuWidth);
+    o.val(C_TS, ts);
+    return;
+  }
+  const uint32_t* cy = rec.cycles + ((size_t)b * rec.cap_cycles + r) * 12;
+  const uint32_t pc = cy[0], a = cy[1], bb = cy[2], c = cy[3], m = cy[4], mv = cy[5], wprev = cy[6];
+  const uint32_t* p = rec.program + 9 * (size_t)((pc - rec.text_base) >> 2);
+  const uint32_t op = p[1], wr = p[2], use2 = p[3], rd = p[4], rs1 = p[5], rs2 = p[6], imm = p[7], tgt = p[8];
+  o.put(C_IS_REAL, kR1);
+  o.val(C_PC, pc);
+  o.val(C_TS, ts);
+  for (int k = 0; k < kNumOps; ++k) o.put(C_OP + k, (uint32_t)k + 1 == op ? kR1 : 0u);
+  o.put(C_WR, wr ? kR1 : 0u);
+  o.put(C_USE2, use2 ? kR1 : 0u);
+  o.val(C_RD, rd); o.val(C_RS1, rs1); o.val(C_RS2, rs2);
+  o.val(C_IMM_LO, imm & 0xffff); o.val(C_IMM_HI, imm >> 16); o.val(C_TGT, tgt);
+  o.bits(C_A, a, 32); o.bits(C_B, bb, 32); o.bits(C_C, c, 32); o.bits(C_M, m, 32);
+  o.val(C_MV_LO, mv & 0xffff); o.val(C_MV_HI, mv >> 16);
+  uint32_t x = 0, next = pc + 4, k0 = 0, k1 = 0, k2 = 0, k3 = 0, eq = 0, inv = 0, off = 4, sc = 6;
+  const uint32_t blo = bb & 0xffff, bhi = bb >> 16, clo = c & 0xffff, chi = c >> 16, alo = a & 0xffff, ahi = a >> 16;
+  switch (op) {
+    case ADD: k0 = (blo + clo) >> 16; k1 = (bhi + chi + k0) >> 16; break;
+    case SUB: k0 = (alo + clo) >> 16; k1 = (ahi + chi + k0) >> 16; break;
+    case SLL: case SRL: case SRA: x = 1u << (c & 31); break;
+    case SLT: case SLTU: case BEQ: case BNE: case BLT: case BGE: case BLTU: case BGEU: {
+      const bool sgn = (op == SLT || op == BLT || op == BGE);
+      k0 = blo < clo;
+      const uint32_t dlo = blo - clo + 65536 * k0;
+      const uint32_t lt = sgn ? ((int32_t)bb < (int32_t)c) : (bb < c);
+      const int32_t dhi = (int32_t)bhi - (int32_t)chi - (int32_t)k0 + 65536 * (int32_t)lt +
+                          (sgn ? 65536 * ((int32_t)(c >> 31) - (int32_t)(bb >> 31)) : 0);
+      x = dlo | ((uint32_t)dhi << 16);
+      k1 = lt;
+      if (op == BEQ || op == BNE) {
+        const uint32_t z = dlo + (uint32_t)dhi;
+        eq = z == 0;
+        inv = z ? Fp::from_canonical(z).inv().v : 0u;  // Montgomery form already
+        if ((op == BEQ) == (z == 0)) next = tgt;
+      } else if (op == BLT || op == BLTU) { if (lt) next = tgt; }
+      else if (op == BGE || op == BGEU) { if (!lt) next = tgt; }
+      break;
+    }
+    case JAL: next = tgt; break;
+    case JALR: case LB: case LH: case LW: case LBU: case LHU: case SB: case SH: case SW: {
+      const uint32_t ilo = imm & 0xffff, ihi = imm >> 16;
+      k2 = (blo + ilo) >> 16;
+      k3 = (bhi + ihi + k2) >> 16;
+      x = bb + imm;
+      if (op == JALR) next = x & ~1u;
+      else off = x & 3;
+      break;
+    }
+    case ECALL:
+      x = 11; off = 0;
+      sc = bb == 0x00 ? 0 : bb == 0x02 ? 1 : bb == 0x10 ? 2 : bb == 0x1a ? 3 : bb == 0xf0 ? 4 : bb == 0xf1 ? 5 : 6;
+      break;
+    case KECCAK: next = bb; break;
+    default: break;
+  }
+  o.bits(C_X, x, 32);
+  o.val(C_NEXT_PC, next);
+  o.put(C_K0, k0 ? kR1 : 0u); o.put(C_K1, k1 ? kR1 : 0u); o.put(C_K2, k2 ? kR1 : 0u); o.put(C_K3, k3 ? kR1 : 0u);
+  o.put(C_EQ, eq ? kR1 : 0u);
+  o.put(C_INV, inv);
+  for (uint32_t i = 0; i < 4; ++i) o.put(C_O0 + i, i == off ? kR1 : 0u);
+  for (uint32_t i = 0; i < 6; ++i) o.put(C_SC + i, i == sc ? kR1 : 0u);
+  const bool memq = (op >= LB && op <= SW) || op == ECALL;
+  o.val(C_R1_PTS, cy[7]);
+  o.bits(C_R1_D, ts - cy[7] - 1, kTsBits);
+  o.val(C_R2_PTS, use2 ? cy[8] : 0u);
+  o.bits(C_R2_D, use2 ? ts - cy[8] : 0u, kTsBits);
+  o.val(C_M_PTS, memq ? cy[9] : 0u);
+  o.bits(C_M_D, memq ? ts + 1 - cy[9] : 0u, kTsBits);
+  o.val(C_W_PTS, wr ? cy[10] : 0u);
+  o.bits(C_W_D, wr ? ts + 2 - cy[10] : 0u, kTsBits);
+  o.val(C_W_PLO, wr ? wprev & 0xffff : 0u);
+  o.val(C_W_PHI, wr ? wprev >> 16 : 0u);
+}
+
+__device__ __forceinline__ uint64_t m_rol64(uint64_t v, int n) { return n ? (v << n) | (v >> (64 - n)) : v; }
+__device__ void m_keccak_f(uint64_t* a) {
+  const ka::Tables& T = ka::tables();
+  for (int r = 0; r < 24; ++r) {
+    uint64_t c[5], d[5], bb[25];
+#pragma unroll
+    for (int x = 0; x < 5; ++x) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+#pragma unroll
+    for (int x = 0; x < 5; ++x) d[x] = c[(x + 4) % 5] ^ m_rol64(c[(x + 1) % 5], 1);
+#pragma unroll
+    for (int j = 0; j < 25; ++j) a[j] ^= d[j % 5];
+#pragma unroll
+    for (int x = 0; x < 5; ++x)
+#pragma unroll
+      for (int y = 0; y < 5; ++y) bb[y + 5 * ((2 * x + 3 * y) % 5)] = m_rol64(a[x + 5 * y], T.rot[x][y]);
+#pragma unroll
+    for (int y = 0; y < 5; ++y)
+#pragma unroll
+      for (int x = 0; x < 5; ++x) a[x + 5 * y] = bb[x + 5 * y] ^ (~bb[(x + 1) % 5 + 5 * y] & bb[(x + 2) % 5 + 5 * y]);
+    a[0] ^= T.rc[r];
+  }
+}
+
+struct KCall {
+  uint32_t ts, ptr;
+  uint64_t in[25];
+  uint32_t pts[50];
+};
+static_assert(sizeof(KCall) == 408, "keccak call record layout");
+
+__global__ __launch_bounds__(64) void kmem_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh) {
+  const size_t h = (size_t)1 << logh;
+  const size_t r = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (r >= h) return;
+  const int b = blockIdx.y;
+  const Col o{trace + (size_t)b * kKmemWidth * h + r, h};
+  const uint32_t p = (uint32_t)(r / 50), i = (uint32_t)(r % 50);
+  o.zero(0, kKmemWidth);
+  o.val(KM_IDX, i);
+  o.put(KM_ISF, i == 0 ? kR1 : 0u);
+  o.put(KM_ISL, i == 49 ? kR1 : 0u);
+  if (p >= rec.counts[4 * b + 1]) return;
+  const KCall* k = reinterpret_cast<const KCall*>(rec.kcalls + ((size_t)b * rec.cap_keccak + p) * 408);
+  uint64_t st[25];
+#pragma unroll
+  for (int j = 0; j < 25; ++j) st[j] = k->in[j];
+  const uint32_t wi = (uint32_t)(k->in[i >> 1] >> (32 * (i & 1)));
+  m_keccak_f(st);
+  uint64_t lane = 0;
+#pragma unroll
+  for (int j = 0; j < 25; ++j) lane = (uint32_t)j == (i >> 1) ? st[j] : lane;
+  const uint32_t wo = (uint32_t)(lane >> (32 * (i & 1)));
+  o.put(KM_IS_REAL, kR1);
+  o.val(KM_TS, k->ts);
+  o.val(KM_PTR_LO, k->ptr & 0xffff); o.val(KM_PTR_HI, k->ptr >> 16);
+  o.put(KM_CALL, i == 0 ? kR1 : 0u);
+  o.val(KM_ADDR, k->ptr + 4 * i);
+  o.val(KM_OLD_LO, wi & 0xffff); o.val(KM_OLD_HI, wi >> 16);
+  o.val(KM_NEW_LO, wo & 0xffff); o.val(KM_NEW_HI, wo >> 16);
+  o.val(KM_PTS, k->pts[i]);
+  o.bits(KM_D, k->ts + 1 - k->pts[i], kTsBits);
+}
+
+__global__ __launch_bounds__(kMT) void memfinal_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh) {
+  const size_t h = (size_t)1 << logh;
+  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (r >= h) return;
+  const int b = blockIdx.y;
+  const Col o{trace + (size_t)b * kMemFinalWidth * h + r, h};
+  const uint32_t n = rec.counts[4 * b + 2];
+  if (r >= n) { o.zero(0, kMemFinalWidth); return; }
+  const uint32_t* f = rec.memfinal + ((size_t)b * rec.cap_memfinal + r) * 5;
+  o.put(MF_IS_REAL, kR1);
+  o.val(MF_ADDR, f[0]);
+  o.put(MF_IS_INIT, f[4] ? kR1 : 0u);
+  o.val(MF_FIN_LO, f[2] & 0xffff); o.val(MF_FIN_HI, f[2] >> 16);
+  o.val(MF_FIN_TS, f[3]);
+  o.bits(MF_DIFF, r + 1 < n ? f[5] - f[0] - 1 : 0u, 32);
+  o.bits(MF_INIT, f[4] ? f[1] : 0u, 32);
+}
+
+__global__ __launch_bounds__(64) void mul_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh) {
+  const size_t h = (size_t)1 << logh;
+  const size_t r = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (r >= h) return;
+  const int b = blockIdx.y;
+  const Col o{trace + (size_t)b * kMulWidth * h + r, h};
+  if (r >= rec.counts[4 * b + 3]) { o.zero(0, kMulWidth); return; }
+  const uint32_t* mu = rec.muls + ((size_t)b * rec.cap_muls + r) * 3;
+  const uint32_t bb = mu[1], c = mu[2];
+  const uint64_t prod = (uint64_t)bb * c;
+  o.put(MU_IS_REAL, kR1);
+  o.put(MU_HI, mu[0] ? kR1 : 0u);
+  o.bits(MU_B, bb, 32); o.bits(MU_C, c, 32);
+  o.bits(MU_P, (uint32_t)prod, 32); o.bits(MU_P + 32, (uint32_t)(prod >> 32), 32);
+  uint64_t s[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) s[i + j] += (uint64_t)((bb >> (8 * i)) & 0xff) * ((c >> (8 * j)) & 0xff);
+  const uint64_t q0 = (s[0] + 256 * s[1]) >> 16, q1 = (s[2] + 256 * s[3] + q0) >> 16, q2 = (s[4] + 256 * s[5] + q1) >> 16;
+  o.bits(MU_Q0, (uint32_t)q0, 10); o.bits(MU_Q1, (uint32_t)q1, 11); o.bits(MU_Q2, (uint32_t)q2, 10);
+}
+
+// one main column: multiplicities of the Program table / use flags of the Image table
+__global__ __launch_bounds__(kMT) void count_column_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ trace,
+                                                          size_t n) {
+  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (r >= n) return;
+  trace[(size_t)blockIdx.y * n + r] = mont(src[(size_t)blockIdx.y * n + r]);
+}
+
+void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& rec, uint32_t* trace, int logh, int batch) {
+  const size_t h = (size_t)1 << logh;
+  switch (chip) {
+    case kCpu:
+      hipLaunchKernelGGL(cpu_trace_kernel, dim3((unsigned)((h + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec, trace, logh);
+      break;
+    case kKmem:
+      hipLaunchKernelGGL(kmem_trace_kernel, dim3((unsigned)((h + 63) / 64), batch), dim3(64), 0, stream, rec, trace, logh);
+      break;
+    case kMemFinal:
+      hipLaunchKernelGGL(memfinal_trace_kernel, dim3((unsigned)((h + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec, trace, logh);
+      break;
+    case kMul:
+      hipLaunchKernelGGL(mul_trace_kernel, dim3((unsigned)((h + 63) / 64), batch), dim3(64), 0, stream, rec, trace, logh);
+      break;
+    case kImage:
+      hipLaunchKernelGGL(count_column_kernel, dim3((unsigned)((h + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec.image_used, trace, h);
+      break;
+    case kProgram:
+      hipLaunchKernelGGL(count_column_kernel, dim3((unsigned)((h + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec.prog_mult, trace, h);
+      break;
+    default: break;
+  }
+}
+
+__global__ __launch_bounds__(kMT) void keccak_ts_kernel(MachineRecords rec, uint32_t* __restrict__ trace, size_t bstride, int logh) {
+  const size_t h = (size_t)1 << logh;
+  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (r >= h) return;
+  const int b = blockIdx.y;
+  const uint32_t p = (uint32_t)(r / 24);
+  uint32_t v = 0;
+  if (p < rec.counts[4 * b + 1]) v = mont(reinterpret_cast<const KCall*>(rec.kcalls + ((size_t)b * rec.cap_keccak + p) * 408)->ts);
+  trace[(size_t)b * bstride + (size_t)KC_TS * h + r] = v;
+}
+void launch_keccak_ts(hipStream_t stream, const MachineRecords& rec, uint32_t* trace, size_t trace_bstride, int logh, int batch) {
+  const size_t h = (size_t)1 << logh;
+  hipLaunchKernelGGL(keccak_ts_kernel, dim3((unsigned)((h + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec, trace, trace_bstride, logh);
+}
+
+// ===========================================================================================
+// mixed-height Merkle commitment
+// ===========================================================================================
+struct LeafArgs {
+  Seg seg[kMaxSegs];
+  int start[kMaxSegs + 1];  // first virtual column of each segment; start[nseg] = total width
+  int nseg, logh;
+  uint32_t* out;
+  size_t out_bstride;
+};
+
+__global__ __launch_bounds__(kMT) void mmcs_leaf_kernel(LeafArgs a, const P2Consts* __restrict__ consts) {
+  const size_t h = (size_t)1 << a.logh, n = 2 * h;
+  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (r >= n) return;
+  const int b = blockIdx.y;
+  Fp s[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s[i] = Fp::zero();
+  const int total = a.start[a.nseg];
+  int sg = 0;
+  const uint32_t* base = a.seg[0].p + (size_t)b * a.seg[0].bstride + r;
+  for (int c0 = 0; c0 < total; c0 += 8) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int vc = c0 + i;
+      if (vc < total) {
+        while (vc >= a.start[sg + 1]) {  // uniform across the grid
+          ++sg;
+          base = a.seg[sg].p + (size_t)b * a.seg[sg].bstride + r;
+        }
+        s[i] = Fp::raw(base[(size_t)(vc - a.start[sg]) * n]);
+      }
+    }
+    p2_permute(s, consts);
+  }
+  const size_t c = r >> a.logh, m = r & (h - 1);
+  const size_t pos = c * h + (a.logh ? (size_t)(__brev((uint32_t)m) >> (32 - a.logh)) : 0);
+  uint4* d = reinterpret_cast<uint4*>(a.out + (size_t)b * a.out_bstride + pos * 8);
+  d[0] = make_uint4(s[0].v, s[1].v, s[2].v, s[3].v);
+  d[1] = make_uint4(s[4].v, s[5].v, s[6].v, s[7].v);
+}
+
+void launch_mmcs_leaves(hipStream_t stream, const Seg* segs, int nseg, int logh, uint32_t* digests, size_t out_bstride,
+                        int batch, const P2Consts* consts) {
+  LeafArgs a;
+  a.nseg = 0;
+  a.start[0] = 0;
+  for (int i = 0; i < nseg && a.nseg < kMaxSegs; ++i) {
+    if (segs[i].width == 0) continue;
+    a.seg[a.nseg] = segs[i];
+    a.start[a.nseg + 1] = a.start[a.nseg] + segs[i].width;
+    a.nseg++;
+  }
+  for (int i = a.nseg; i < kMaxSegs; ++i) { a.seg[i] = Seg{nullptr, 0, 0}; a.start[i + 1] = a.start[a.nseg]; }
+  a.logh = logh;
+  a.out = digests;
+  a.out_bstride = out_bstride;
+  const size_t n = (size_t)2 << logh;
+  hipLaunchKernelGGL(mmcs_leaf_kernel, dim3((unsigned)((n + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, a, consts);
+}
+
+__device__ __forceinline__ void m_compress(const uint4* l, const uint4* r, uint4* out, const P2Consts* __restrict__ consts) {
+  const uint4 a = l[0], b = l[1], c = r[0], d = r[1];
+  Fp s[16] = {Fp::raw(a.x), Fp::raw(a.y), Fp::raw(a.z), Fp::raw(a.w), Fp::raw(b.x), Fp::raw(b.y), Fp::raw(b.z), Fp::raw(b.w),
+              Fp::raw(c.x), Fp::raw(c.y), Fp::raw(c.z), Fp::raw(c.w), Fp::raw(d.x), Fp::raw(d.y), Fp::raw(d.z), Fp::raw(d.w)};
+  p2_permute(s, consts);
+  out[0] = make_uint4(s[0].v, s[1].v, s[2].v, s[3].v);
+  out[1] = make_uint4(s[4].v, s[5].v, s[6].v, s[7].v);
+}
+
+__global__ __launch_bounds__(kMT) void mmcs_level_kernel(const uint32_t* __restrict__ in, size_t in_bstride,
+                                                        uint32_t* __restrict__ out, size_t out_bstride,
+                                                        const uint32_t* __restrict__ inject, size_t inject_bstride, size_t count,
+                                                        const P2Consts* __restrict__ consts) {
+  const size_t i = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (i >= count) return;
+  const int b = blockIdx.y;
+  const uint4* src = reinterpret_cast<const uint4*>(in + (size_t)b * in_bstride + 16 * i);
+  uint4 d[2];
+  m_compress(src, src + 2, d, consts);
+  if (inject) {
+    const uint4* g = reinterpret_cast<const uint4*>(inject + (size_t)b * inject_bstride + 8 * i);
+    uint4 e[2];
+    m_compress(d, g, e, consts);
+    d[0] = e[0];
+    d[1] = e[1];
+  }
+  uint4* dst = reinterpret_cast<uint4*>(out + (size_t)b * out_bstride + 8 * i);
+  dst[0] = d[0];
+  dst[1] = d[1];
+}
+
+void launch_mmcs_level(hipStream_t stream, const uint32_t* in, size_t in_bstride, uint32_t* out, size_t out_bstride,
+                       const uint32_t* inject, size_t inject_bstride, size_t count, int batch, const P2Consts* consts) {
+  hipLaunchKernelGGL(mmcs_level_kernel, dim3((unsigned)((count + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, in, in_bstride,
+                     out, out_bstride, inject, inject_bstride, count, consts);
+}
+
+// ===========================================================================================
+// LogUp: fingerprints and the permutation trace
+// ===========================================================================================
+struct RowView {
+  const uint32_t* prep;
+  const uint32_t* main_;
+  int prep_w;
+  size_t cs;
+  __device__ __forceinline__ Fp at(int col) const {
+    return Fp::raw(col < prep_w ? prep[(size_t)col * cs] : main_[(size_t)(col - prep_w) * cs]);
+  }
+};
+__device__ __forceinline__ Fp m_lf_eval(const LinForm& f, const RowView& rv) {
+  Fp v = Fp::raw(f.c0);
+  for (int i = 0; i < f.n; ++i) v += Fp::raw(f.coef[i]) * rv.at(f.col[i]);
+  return v;
+}
+__device__ __forceinline__ Fp4 m_fingerprint(const Interaction& it, const RowView& rv, const Fp4& gamma, const uint32_t* bpow) {
+  Fp4 f = gamma;
+  f.c[0] += Fp::from_canonical((uint32_t)it.bus);
+  for (int j = 0; j < it.n_el; ++j) f += m_load_fp4(bpow + 4 * (size_t)(j + 1)) * m_lf_eval(it.el[j], rv);
+  return f;
+}
+
+__global__ __launch_bounds__(kMT) void perm_terms_kernel(PermArgs a) {
+  const size_t h = (size_t)1 << a.logh;
+  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (r >= h) return;
+  const int b = blockIdx.y;
+  RowView rv{a.prep.width ? a.prep.p + (size_t)b * a.prep.bstride + r : nullptr, a.main_.p + (size_t)b * a.main_.bstride + r,
+             a.prep.width, h};
+  const Fp4 gamma = m_load_fp4(a.bus_ch + (size_t)b * 8);
+  const uint32_t* bpow = a.bpow + (size_t)b * (kInterMaxElems + 1) * 4;
+  const int nh = (a.n_inter + 1) / 2;
+  uint32_t* p = a.perm + (size_t)b * a.perm_bstride + r;
+  Fp4 tot = Fp4::zero();
+  for (int j = 0; j < nh; ++j) {
+    Fp4 hj = Fp4::zero();
+    for (int k = 2 * j; k < 2 * j + 2 && k < a.n_inter; ++k) {
+      const Interaction& it = a.inter[k];
+      Fp m = m_lf_eval(it.mult, rv);
+      if (m.v == 0) continue;
+      if (it.sign < 0) m = -m;
+      hj += m_fingerprint(it, rv, gamma, bpow).inv() * m;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) p[(size_t)(4 * j + t) * h] = hj.c[t].v;
+    tot += hj;
+  }
+  m_store_fp4(a.rowsum + ((size_t)b * h + r) * 4, tot);
+}
+
+// one workgroup per proof: exclusive running sum of the row sums -> the phi columns, total -> cum
+__global__ __launch_bounds__(kMT) void perm_scan_kernel(PermArgs a) {
+  __shared__ Fp4 part[kMT];
+  const size_t h = (size_t)1 << a.logh;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const size_t chunk = (h + kMT - 1) / kMT;
+  const size_t r0 = (size_t)tid * chunk, r1 = r0 + chunk < h ? r0 + chunk : h;
+  const uint32_t* tm = a.rowsum + (size_t)b * h * 4;
+  Fp4 local = Fp4::zero();
+  for (size_t r = r0; r < r1; ++r) local += m_load_fp4(tm + r * 4);
+  part[tid] = local;
+  __syncthreads();
+  for (int off = 1; off < kMT; off <<= 1) {
+    Fp4 v = part[tid];
+    if (tid >= off) v += part[tid - off];
+    __syncthreads();
+    part[tid] = v;
+    __syncthreads();
+  }
+  Fp4 acc = tid ? part[tid - 1] : Fp4::zero();
+  const int nh = (a.n_inter + 1) / 2;
+  uint32_t* ph = a.perm + (size_t)b * a.perm_bstride + (size_t)4 * nh * h;
+  for (size_t r = r0; r < r1; ++r) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ph[(size_t)j * h + r] = acc.c[j].v;
+    acc += m_load_fp4(tm + r * 4);
+  }
+  if (tid == kMT - 1) m_store_fp4(a.cum + (size_t)b * a.cum_bstride, part[kMT - 1]);
+}
+
+void launch_perm_trace(hipStream_t stream, const PermArgs& a) {
+  const size_t h = (size_t)1 << a.logh;
+  hipLaunchKernelGGL(perm_terms_kernel, dim3((unsigned)((h + kMT - 1) / kMT), a.batch), dim3(kMT), 0, stream, a);
+  hipLaunchKernelGGL(perm_scan_kernel, dim3(a.batch), dim3(kMT), 0, stream, a);
+}
+
+__global__ __launch_bounds__(64) void public_bus_kernel(const uint32_t* __restrict__ pub, const uint32_t* __restrict__ bus_ch,
+                                                       const uint32_t* __restrict__ bpow_all, uint32_t* __restrict__ out,
+                                                       size_t out_bstride, int batch) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= batch) return;
+  const Fp4 gamma = m_load_fp4(bus_ch + (size_t)b * 8);
+  const uint32_t* bp = bpow_all + (size_t)b * (kInterMaxElems + 1) * 4;
+  const Fp4 b1 = m_load_fp4(bp + 4), b2 = m_load_fp4(bp + 8), b3 = m_load_fp4(bp + 12), b4 = m_load_fp4(bp + 16);
+  const uint32_t* w = pub + (size_t)b * 17;
+  Fp4 total = Fp4::zero();
+  for (uint32_t kind = 1; kind <= 2; ++kind)
+    for (uint32_t i = 0; i < 8; ++i) {
+      const uint32_t v = w[(kind - 1) * 8 + i];
+      Fp4 f = gamma;
+      f.c[0] += Fp::from_canonical((uint32_t)BUS_PUBC);
+      f += b1 * Fp::from_canonical(kind) + b2 * Fp::from_canonical(i) + b3 * Fp::from_canonical(v & 0xffff) +
+           b4 * Fp::from_canonical(v >> 16);
+      total -= f.inv();
+    }
+  Fp4 fh = gamma;
+  fh.c[0] += Fp::from_canonical((uint32_t)BUS_PUBH);
+  fh += b1 * Fp::from_canonical(w[16] & 0xffff) + b2 * Fp::from_canonical(w[16] >> 16);
+  total -= fh.inv();
+  m_store_fp4(out + (size_t)b * out_bstride, total);
+}
+void launch_public_bus(hipStream_t stream, const uint32_t* pub_words, const uint32_t* bus_ch, const uint32_t* bpow, uint32_t* out,
+                       size_t out_bstride, int batch) {
+  hipLaunchKernelGGL(public_bus_kernel, dim3((batch + 63) / 64), dim3(64), 0, stream, pub_words, bus_ch, bpow, out, out_bstride, batch);
+}
+
+// ===========================================================================================
+// quotient evaluation
+// ===========================================================================================
+struct MQCtx {
+  using F = Fp;
+  const uint32_t* loc;
+  const uint32_t* nxt;
+  size_t cs;
+  Fp first, trans, last, pub_;
+  const uint32_t* ap;
+  int k_;
+  Fp4 acc;
+  int64_t lazy[4];
+  int pending;
+  __device__ __forceinline__ F local(int col) const { return Fp::raw(loc[(size_t)col * cs]); }
+  __device__ __forceinline__ F next(int col) const { return Fp::raw(nxt[(size_t)col * cs]); }
+  __device__ __forceinline__ F is_first() const { return first; }
+  __device__ __forceinline__ F is_trans() const { return trans; }
+  __device__ __forceinline__ F is_last() const { return last; }
+  __device__ __forceinline__ F pub() const { return pub_; }
+  __device__ __forceinline__ F one() const { return Fp::one(); }
+  __device__ __forceinline__ F k(uint32_t monty) const { return Fp::raw(monty); }
+  // acc += alpha^k * v through signed 64-bit lazy sums (field.cuh), as in the keccak quotient kernel
+  __device__ __forceinline__ void emit_at(int idx, F v) {
+    const uint32_t* p = ap + 4 * (size_t)idx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lazy[i] += (int64_t)fps_centre(p[i]) * (int64_t)v.v;
+    if (++pending == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lazy[i] = (int64_t)fps_fold(lazy[i]) * (int64_t)kRModP;
+      pending = 0;
+    }
+  }
+  __device__ __forceinline__ void emit(F v) { emit_at(k_++, v); }
+  __device__ __forceinline__ void flush() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc.c[i] = acc.c[i] + Fp::raw(fps_canon(fps_fold(lazy[i])));
+      lazy[i] = 0;
+    }
+    pending = 0;
+  }
+};
+
+struct PointInfo {
+  int b, c;
+  size_t m, mn, pt;
+  Fp first, trans, last;
+};
+// domain point (coset c, index m) of an LDE of height H and the three selectors there
+__device__ __forceinline__ void point_selectors(const MQuotArgs& a, size_t pt, PointInfo* pi) {
+  const size_t h = (size_t)1 << a.logh;
+  pi->pt = pt;
+  pi->c = pt >= h ? 1 : 0;
+  pi->m = pt - (size_t)pi->c * h;
+  pi->mn = (pi->m + 1) & (h - 1);
+  const size_t half = h >> 1;
+  const Fp wm = pi->m < half ? Fp::raw(a.tw_fwd[pi->m]) : -Fp::raw(a.tw_fwd[pi->m - half]);
+  const Fp x = Fp::raw(a.shift[pi->c]) * wm;
+  const Fp zh = Fp::raw(a.zh_inv[pi->c]).inv();
+  const Fp whi = Fp::raw(a.wh_inv);
+  pi->trans = x - whi;
+  pi->first = zh * (x - Fp::one()).inv();
+  pi->last = zh * pi->trans.inv();
+}
+
+// the LogUp constraints of a chip at one point, folded with their powers of alpha into `acc`
+__device__ __forceinline__ void logup_constraints(const MQuotArgs& a, const PointInfo& pi, Fp4* acc) {
+  const size_t h = (size_t)1 << a.logh, n = 2 * h;
+  const int b = pi.b;
+  RowView rv{a.prep.width ? a.prep.p + (size_t)b * a.prep.bstride + pi.pt : nullptr,
+             a.main_.p + (size_t)b * a.main_.bstride + pi.pt, a.prep.width, n};
+  const Fp4 gamma = m_load_fp4(a.bus_ch + (size_t)b * 8);
+  const uint32_t* bpow = a.bpow + (size_t)b * (kInterMaxElems + 1) * 4;
+  const uint32_t* ap = a.alpha_pows + (size_t)b * a.alpha_bstride;
+  const int nh = (a.n_inter + 1) / 2;
+  const uint32_t* pl = a.perm.p + (size_t)b * a.perm.bstride + (size_t)pi.c * h;
+  Fp4 hsum = Fp4::zero();
+  for (int j = 0; j < nh; ++j) {
+    Fp4 hj;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) hj.c[t] = Fp::raw(pl[(size_t)(4 * j + t) * n + pi.m]);
+    hsum += hj;
+    const Interaction& ia = a.inter[2 * j];
+    Fp ma = m_lf_eval(ia.mult, rv);
+    if (ia.sign < 0) ma = -ma;
+    const Fp4 fa = m_fingerprint(ia, rv, gamma, bpow);
+    Fp4 v;
+    if (2 * j + 1 < a.n_inter) {
+      const Interaction& ib = a.inter[2 * j + 1];
+      Fp mb = m_lf_eval(ib.mult, rv);
+      if (ib.sign < 0) mb = -mb;
+      const Fp4 fb = m_fingerprint(ib, rv, gamma, bpow);
+      v = hj * fa * fb - (fb * ma + fa * mb);
+    } else {
+      v = hj * fa;
+      v.c[0] -= ma;
+    }
+    *acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + j)) * v;
+  }
+  Fp4 phi, phin;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    phi.c[t] = Fp::raw(pl[(size_t)(4 * nh + t) * n + pi.m]);
+    phin.c[t] = Fp::raw(pl[(size_t)(4 * nh + t) * n + pi.mn]);
+  }
+  const Fp4 cum = m_load_fp4(a.cum + (size_t)b * a.cum_bstride);
+  *acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh)) * (phi * pi.first);
+  *acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh + 1)) * ((phin - phi - hsum) * pi.trans);
+  *acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh + 2)) * ((cum - phi - hsum) * pi.last);
+}
+
+__device__ __forceinline__ void init_ctx(const MQuotArgs& a, const PointInfo& pi, MQCtx* ctx) {
+  const size_t h = (size_t)1 << a.logh, n = 2 * h;
+  const uint32_t* base = a.main_.p + (size_t)pi.b * a.main_.bstride + (size_t)pi.c * h;
+  ctx->loc = base + pi.m;
+  ctx->nxt = base + pi.mn;
+  ctx->cs = n;
+  ctx->first = pi.first;
+  ctx->trans = pi.trans;
+  ctx->last = pi.last;
+  ctx->pub_ = Fp::raw(a.pub);
+  ctx->ap = a.alpha_pows + (size_t)pi.b * a.alpha_bstride;
+  ctx->k_ = 0;
+  ctx->acc = Fp4::zero();
+  ctx->lazy[0] = ctx->lazy[1] = ctx->lazy[2] = ctx->lazy[3] = 0;
+  ctx->pending = 0;
+}
+
+template <int CHIP>
+__global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
+  const size_t h = (size_t)1 << a.logh, n = 2 * h;
+  const size_t pt = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (pt >= n) return;
+  PointInfo pi;
+  pi.b = blockIdx.y;
+  point_selectors(a, pt, &pi);
+  MQCtx ctx;
+  init_ctx(a, pi, &ctx);
+  if (CHIP == kCpu) eval_cpu(ctx);
+  else if (CHIP == kKmem) eval_kmem(ctx);
+  else if (CHIP == kMemFinal) eval_memfinal(ctx);
+  else if (CHIP == kImage) eval_image(ctx);
+  else if (CHIP == kMul) eval_mul(ctx);
+  ctx.flush();
+  logup_constraints(a, pi, &ctx.acc);
+  const Fp4 q = ctx.acc * Fp::raw(a.zh_inv[pi.c]);
+  uint32_t* dst = a.quot + (size_t)pi.b * 8 * h + pi.m;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dst[(size_t)(4 * pi.c + j) * h] = q.c[j].v;
+}
+
+// keccak chip: p3-keccak-air's 12 evaluation tasks (air_keccak.cuh) plus one task for the call-time
+// constraint and the LogUp constraints; XCD-aware tile order as in keccak_quotient_kernel
+__global__ __launch_bounds__(kMT) void keccak_machine_quotient_kernel(MQuotArgs a, int tiles_per_proof, int total_tiles) {
+  const size_t h = (size_t)1 << a.logh, n = 2 * h;
+  int tile, g;
+  if ((total_tiles & 7) == 0) {
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    tile = (seq / ka::kNumTasks) * 8 + xcd;
+    g = seq % ka::kNumTasks;
+  } else {
+    tile = blockIdx.x / ka::kNumTasks;
+    g = blockIdx.x % ka::kNumTasks;
+  }
+  const int b = tile / tiles_per_proof;
+  const size_t pt = (size_t)(tile - b * tiles_per_proof) * kMT + threadIdx.x;
+  if (pt >= n) return;
+  PointInfo pi;
+  pi.b = b;
+  point_selectors(a, pt, &pi);
+  MQCtx ctx;
+  init_ctx(a, pi, &ctx);
+  if (g == ka::kBusTask) {
+    ctx.k_ = ka::kNumConstraints;
+    eval_keccak_ts(ctx);
+    ctx.flush();
+    logup_constraints(a, pi, &ctx.acc);
+  } else {
+    ka::eval_task(g, ctx);
+    ctx.flush();
+  }
+  m_store_fp4(a.partial + (((size_t)b * ka::kNumTasks + g) * n + pt) * 4, ctx.acc);
+}
+__global__ __launch_bounds__(kMT) void keccak_machine_combine_kernel(MQuotArgs a) {
+  const size_t h = (size_t)1 << a.logh, n = 2 * h;
+  const size_t pt = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (pt >= n) return;
+  const int b = blockIdx.y;
+  const int c = pt >= h ? 1 : 0;
+  const size_t m = pt - (size_t)c * h;
+  Fp4 acc = Fp4::zero();
+  for (int g = 0; g < ka::kNumTasks; ++g) acc += m_load_fp4(a.partial + (((size_t)b * ka::kNumTasks + g) * n + pt) * 4);
+  acc = acc * Fp::raw(a.zh_inv[c]);
+  uint32_t* q = a.quot + (size_t)b * 8 * h + m;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) q[(size_t)(4 * c + j) * h] = acc.c[j].v;
+}
+
+void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a) {
+  const size_t n = (size_t)2 << a.logh;
+  const dim3 grid((unsigned)((n + kMT - 1) / kMT), a.batch), block(kMT);
+  switch (a.chip) {
+    case kCpu: hipLaunchKernelGGL(machine_quotient_kernel<kCpu>, grid, block, 0, stream, a); break;
+    case kKmem: hipLaunchKernelGGL(machine_quotient_kernel<kKmem>, grid, block, 0, stream, a); break;
+    case kMemFinal: hipLaunchKernelGGL(machine_quotient_kernel<kMemFinal>, grid, block, 0, stream, a); break;
+    case kImage: hipLaunchKernelGGL(machine_quotient_kernel<kImage>, grid, block, 0, stream, a); break;
+    case kProgram: hipLaunchKernelGGL(machine_quotient_kernel<kProgram>, grid, block, 0, stream, a); break;
+    case kMul: hipLaunchKernelGGL(machine_quotient_kernel<kMul>, grid, block, 0, stream, a); break;
+    case kKeccak: {
+      const int blocks = (int)((n + kMT - 1) / kMT), total_tiles = blocks * a.batch;
+      hipLaunchKernelGGL(keccak_machine_quotient_kernel, dim3((unsigned)total_tiles * ka::kNumTasks), block, 0, stream, a, blocks,
+                         total_tiles);
+      hipLaunchKernelGGL(keccak_machine_combine_kernel, grid, block, 0, stream, a);
+      break;
+    }
+  }
+}
+
+// ===========================================================================================
+// reduced openings of one chip
+// ===========================================================================================
+constexpr int kMReduceChunk = 128;
+int mreduce_nchunks(int total_width) { return (total_width + kMReduceChunk - 1) / kMReduceChunk; }
+
+__device__ __forceinline__ Fp4 m_block_sum(Fp4 v, Fp4* red) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    Fp4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.c[j] = Fp::raw(__shfl_down(v.c[j].v, off, 64));
+    v += o;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  Fp4 r = red[0];
+  for (int w = 1; w < kMT / 64; ++w) r += red[w];
+  return r;
+}
+
+__global__ __launch_bounds__(kMT) void mreduce_bsum_kernel(MReduceArgs a, int n1, int n2) {
+  __shared__ Fp4 red[kMT / 64];
+  const int b = blockIdx.x;
+  const uint32_t* ap = a.af_pows + (size_t)b * a.af_bstride + a.pow_off * 4;
+  const uint32_t* op = a.opened + (size_t)b * a.opened_bstride + a.open_off * 4;
+  Fp4 s1 = Fp4::zero(), s2 = Fp4::zero();
+  for (int i = threadIdx.x; i < n1; i += kMT) s1 += m_load_fp4(ap + (size_t)i * 4) * m_load_fp4(op + (size_t)i * 4);
+  for (int i = threadIdx.x; i < n2; i += kMT) s2 += m_load_fp4(ap + (size_t)(n1 + i) * 4) * m_load_fp4(op + (size_t)(n1 + i) * 4);
+  const Fp4 r1 = m_block_sum(s1, red), r2 = m_block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    m_store_fp4(a.bsum + ((size_t)b * 2 + 0) * 4, r1);
+    m_store_fp4(a.bsum + ((size_t)b * 2 + 1) * 4, r2);
+  }
+}
+
+__device__ __forceinline__ int64_t m_lazy_shrink(int64_t t) { return (int64_t)fps_fold(t) * (int64_t)kRModP; }
+
+// lane = four consecutive LDE points; blockIdx.y = a chunk of kMReduceChunk columns of [prep | main | perm | quot]
+__global__ __launch_bounds__(kMT) void mreduce_partial_kernel(MReduceArgs a, int nchunks, int n1) {
+  const size_t h = (size_t)1 << a.logh, n = 2 * h;
+  const size_t pt = ((size_t)blockIdx.x * kMT + threadIdx.x) * 4;
+  if (pt >= n) return;
+  const int chunk = blockIdx.y, b = blockIdx.z;
+  const int i0 = chunk * kMReduceChunk, i1 = min(n1, i0 + kMReduceChunk);
+  const int w0 = a.mats[0].width, w01 = w0 + a.mats[1].width, w012 = w01 + a.mats[2].width;
+  const uint32_t* ap = a.af_pows + (size_t)b * a.af_bstride + a.pow_off * 4;
+  int64_t acc1[4][4], acc2[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc1[q][j] = acc2[q][j] = 0;
+  int pending = 0;
+  for (int i = i0; i < i1; ++i) {
+    const int mi = i < w0 ? 0 : i < w01 ? 1 : i < w012 ? 2 : 3;
+    const int col = i - (mi == 0 ? 0 : mi == 1 ? w0 : mi == 2 ? w01 : w012);
+    const Seg& sg = a.mats[mi];
+    const uint4 v = *reinterpret_cast<const uint4*>(sg.p + (size_t)b * sg.bstride + (size_t)col * n + pt);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t* al = ap + (size_t)i * 4;
+    const bool two = mi == 1 || mi == 2;
+    const uint32_t* al2 = ap + (size_t)(n1 + i - w0) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int32_t alpha = fps_centre(al[j]);
+      const int32_t alpha2 = two ? fps_centre(al2[j]) : 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc1[q][j] += (int64_t)alpha * (int64_t)w[q];
+        acc2[q][j] += (int64_t)alpha2 * (int64_t)w[q];
+      }
+    }
+    if (++pending == 4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc1[q][j] = m_lazy_shrink(acc1[q][j]); acc2[q][j] = m_lazy_shrink(acc2[q][j]); }
+      pending = 0;
+    }
+  }
+  uint32_t* p1 = a.partial + ((((size_t)b * nchunks + chunk) * 2 + 0) * n + pt) * 4;
+  uint32_t* p2 = a.partial + ((((size_t)b * nchunks + chunk) * 2 + 1) * n + pt) * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    Fp4 r1, r2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      r1.c[j] = Fp::raw(fps_canon(fps_fold(acc1[q][j])));
+      r2.c[j] = Fp::raw(fps_canon(fps_fold(acc2[q][j])));
+    }
+    m_store_fp4(p1 + 4 * q, r1);
+    m_store_fp4(p2 + 4 * q, r2);
+  }
+}
+
+__global__ __launch_bounds__(kMT) void mreduce_final_kernel(MReduceArgs a, int nchunks) {
+  const size_t h = (size_t)1 << a.logh, n = 2 * h;
+  const size_t pt = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (pt >= n) return;
+  const int b = blockIdx.y;
+  Fp4 s1 = Fp4::zero(), s2 = Fp4::zero();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    s1 += m_load_fp4(a.partial + ((((size_t)b * nchunks + ch) * 2 + 0) * n + pt) * 4);
+    s2 += m_load_fp4(a.partial + ((((size_t)b * nchunks + ch) * 2 + 1) * n + pt) * 4);
+  }
+  const Fp4 b1 = m_load_fp4(a.bsum + ((size_t)b * 2 + 0) * 4), b2 = m_load_fp4(a.bsum + ((size_t)b * 2 + 1) * 4);
+  const Fp4 zeta = m_load_fp4(a.zeta + (size_t)b * 4), zn = zeta * Fp::raw(a.w_h);
+  const int c = pt >= h ? 1 : 0;
+  const size_t m = pt - (size_t)c * h, half = h >> 1;
+  const Fp wm = m < half ? Fp::raw(a.tw_fwd[m]) : -Fp::raw(a.tw_fwd[m - half]);
+  Fp4 x = Fp4::from_base(Fp::raw(a.shift[c]) * wm);
+  const Fp4 d0 = (x - zeta).inv(), d1 = (x - zn).inv();
+  Fp4 g = (s1 - b1) * d0 + (s2 - b2) * d1;
+  uint32_t* o = a.out + (size_t)b * a.out_bstride + pt * 4;
+  if (a.accumulate) g += m_load_fp4(o);
+  m_store_fp4(o, g);
+}
+
+void launch_machine_reduce(hipStream_t stream, const MReduceArgs& a) {
+  const size_t n = (size_t)2 << a.logh;
+  const int n1 = a.mats[0].width + a.mats[1].width + a.mats[2].width + a.mats[3].width;
+  const int n2 = a.mats[1].width + a.mats[2].width;
+  const int nchunks = mreduce_nchunks(n1);
+  hipLaunchKernelGGL(mreduce_bsum_kernel, dim3(a.batch), dim3(kMT), 0, stream, a, n1, n2);
+  hipLaunchKernelGGL(mreduce_partial_kernel, dim3((unsigned)((n / 4 + kMT - 1) / kMT), nchunks, a.batch), dim3(kMT), 0, stream, a,
+                     nchunks, n1);
+  hipLaunchKernelGGL(mreduce_final_kernel, dim3((unsigned)((n + kMT - 1) / kMT), a.batch), dim3(kMT), 0, stream, a, nchunks);
+}
+
+__global__ __launch_bounds__(kMT) void fri_add_kernel(uint32_t* __restrict__ layer, size_t layer_bstride,
+                                                     const uint32_t* __restrict__ g, size_t g_bstride, size_t n) {
+  const size_t i = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (i >= n) return;
+  uint32_t* p = layer + (size_t)blockIdx.y * layer_bstride + i * 4;
+  m_store_fp4(p, m_load_fp4(p) + m_load_fp4(g + (size_t)blockIdx.y * g_bstride + i * 4));
+}
+void launch_fri_add(hipStream_t stream, uint32_t* layer, size_t layer_bstride, const uint32_t* g, size_t g_bstride, size_t n,
+                    int batch) {
+  hipLaunchKernelGGL(fri_add_kernel, dim3((unsigned)((n + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, layer, layer_bstride, g,
+                     g_bstride, n);
+}
+
+// ===========================================================================================
+// proof assembly
+// ===========================================================================================
+__device__ __forceinline__ size_t m_layer_off(int logn, int layer) { return ((size_t)2 << logn) - ((size_t)2 << (logn - layer)); }
+__device__ __forceinline__ uint32_t canon(uint32_t monty) { return Fp::raw(monty).to_canonical(); }
+
+__global__ __launch_bounds__(kMT) void machine_assemble_kernel(MAssembleArgs a) {
+  const int b = blockIdx.y, q = blockIdx.x, lm = a.lm, tid = threadIdx.x;
+  uint32_t* body = a.body + (size_t)b * a.body_stride;
+  const uint32_t* fl = a.fri_layers + (size_t)b * a.fri_layer_stride;
+  const uint32_t* ft = a.fri_trees + (size_t)b * a.fri_tree_stride;
+  const size_t n_open_words = a.n_open * 4;
+  // main root 8 | perm root 8 | cumulative sums 4 * 7 | quotient root 8 | opened | FRI roots | final | witness | queries
+  const size_t off_cum = 16, off_qroot = off_cum + 4 * kNumChips, off_opened = off_qroot + 8,
+               off_fri_roots = off_opened + n_open_words, off_final = off_fri_roots + 8 * (size_t)lm, off_witness = off_final + 4,
+               off_queries = off_witness + 1;
+  const size_t hmax = (size_t)1 << lm;
+  if (q == a.n_queries) {
+    if (tid < 8) {
+      for (int r = 1; r < 4; ++r) {
+        const MRound& R = a.round[r];
+        const size_t nr = (size_t)2 << R.lm;
+        const uint32_t v = canon(R.tree[(size_t)b * R.tree_bstride + (2 * nr - 2) * 8 + tid]);
+        body[(r == 1 ? 0 : r == 2 ? 8 : off_qroot) + tid] = v;
+      }
+    }
+    for (int t = tid; t < 4 * kNumChips; t += kMT) body[off_cum + t] = canon(a.cum[(size_t)b * 4 * kNumChips + t]);
+    const uint32_t* op = a.opened + (size_t)b * a.opened_bstride;
+    for (size_t t = tid; t < n_open_words; t += kMT) body[off_opened + t] = canon(op[t]);
+    size_t toff = 0, loff = 0;
+    for (int k = 0; k < lm; ++k) {
+      const size_t hk = hmax >> k;
+      if (tid < 8) body[off_fri_roots + 8 * (size_t)k + tid] = canon(ft[(toff + 2 * hk - 2) * 8 + tid]);
+      toff += 2 * hk - 1;
+      loff += 2 * hk * 4;
+    }
+    if (tid < 4) body[off_final + tid] = canon(fl[loff + tid]);
+    if (tid == 0) body[off_witness] = a.witness[b];
+    return;
+  }
+  size_t perq = 0;
+  for (int r = 0; r < 4; ++r) {
+    for (int c = 0; c < kNumChips; ++c) perq += (size_t)(a.round[r].seg[c][0].width + a.round[r].seg[c][1].width);
+    perq += 8 * ((size_t)a.round[r].lm + 1);
+  }
+  for (int k = 0; k < lm; ++k) perq += 8 + 8 * (size_t)(lm - k);
+  uint32_t* dst = body + off_queries + perq * (size_t)q;
+  const size_t idx = a.indices[(size_t)b * a.n_queries + q];
+  const size_t cs = idx >> lm, m = idx & (hmax - 1);
+  for (int r = 0; r < 4; ++r) {
+    const MRound& R = a.round[r];
+    for (int c = 0; c < kNumChips; ++c) {
+      const size_t h = (size_t)1 << R.logh[c], mm = m & (h - 1);
+      for (int s = 0; s < 2; ++s) {
+        const Seg& sg = R.seg[c][s];
+        if (!sg.width) continue;
+        const uint32_t* src = sg.p + (size_t)b * sg.bstride + cs * h + mm;
+        for (int i = tid; i < sg.width; i += kMT) dst[i] = canon(src[(size_t)i * 2 * h]);
+        dst += sg.width;
+      }
+    }
+    const int logn = R.lm + 1;
+    const size_t hm = (size_t)1 << R.lm;
+    const size_t pos = cs * hm + (R.lm ? (size_t)(__brev((uint32_t)(m & (hm - 1))) >> (32 - R.lm)) : 0);
+    const uint32_t* tree = R.tree + (size_t)b * R.tree_bstride;
+    for (int t = tid; t < 8 * logn; t += kMT) {
+      const int l = t >> 3, j = t & 7;
+      dst[t] = canon(tree[(m_layer_off(logn, l) + ((pos >> l) ^ 1)) * 8 + j]);
+    }
+    dst += 8 * logn;
+  }
+  size_t toff = 0, loff = 0;
+  for (int k = 0; k < lm; ++k) {
+    const int loghk = lm - k;
+    const size_t hk = hmax >> k, half = hk >> 1, mk = m & (half - 1), leaf = cs * half + mk;
+    if (tid < 4) {
+      dst[tid] = canon(fl[loff + (cs * hk + mk) * 4 + tid]);
+      dst[4 + tid] = canon(fl[loff + (cs * hk + mk + half) * 4 + tid]);
+    }
+    dst += 8;
+    for (int t = tid; t < 8 * loghk; t += kMT) {
+      const int l = t >> 3, j = t & 7;
+      dst[t] = canon(ft[(toff + m_layer_off(loghk, l) + ((leaf >> l) ^ 1)) * 8 + j]);
+    }
+    dst += 8 * loghk;
+    toff += 2 * hk - 1;
+    loff += 2 * hk * 4;
+  }
+}
+
+void launch_machine_assemble(hipStream_t stream, const MAssembleArgs& a) {
+  hipLaunchKernelGGL(machine_assemble_kernel, dim3(a.n_queries + 1, a.batch), dim3(kMT), 0, stream, a);
+}
+
+}  // namespace zksp

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kLdeThreads) void ntt_chunk_kernel(const uint32_t* 
                                                                const uint32_t* __restrict__ tw,
                                                                const uint32_t* __restrict__ pre_scale,
                                                                const uint32_t* __restrict__ post_scale, int logh,
-                                                               int l2) {
+                                                               int l2, int post_sel_shift, int post_sel_mask) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   Fp* buf = reinterpret_cast<Fp*>(smem);
   const size_t h2 = (size_t)1 << l2;
@@ -412,7 +412,9 @@ __global__ __launch_bounds__(kLdeThreads) void ntt_chunk_kernel(const uint32_t* 
   const uint32_t* s0 = src + col * src_col_stride + chunk * h2;
   uint32_t* d0 = dst + col * dst_col_stride + chunk * h2;
   const uint32_t* pre = pre_scale ? pre_scale + chunk * h2 : nullptr;
-  const uint32_t* post = post_scale ? post_scale + chunk * h2 : nullptr;
+  // the post-scale table may be chosen per column (quotient chunks were evaluated over different cosets)
+  const uint32_t* post =
+      post_scale ? post_scale + ((size_t)((col >> post_sel_shift) & (size_t)post_sel_mask) << logh) + chunk * h2 : nullptr;
   const int tid = threadIdx.x;
   int s = DIF ? l2 : 1;
   bool first = true;
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(kLdeThreads) void ntt_strided_kernel(const uint32_t
 
 static void launch_lde_large(hipStream_t stream, const uint32_t* in, uint32_t* coefs_br, uint32_t* out,
                              const uint32_t* tw_fwd, const uint32_t* tw_inv, const uint32_t* in_scale_br,
-                             const uint32_t* out_scale_br, int logh, size_t ncols) {
+                             int scale_sel_shift, int scale_sel_mask, const uint32_t* out_scale_br, int logh, size_t ncols) {
   const size_t h = (size_t)1 << logh;
   const int l2 = logh - logh / 2;  // low (contiguous) stages: 2^l2 <= 2^11 per chunk for logh <= 22
   const int l1 = logh - l2;        // high (strided) stages: an H1 x 16 tile is at most 2^11 x 17 words of LDS
@@ -512,11 +514,11 @@ static void launch_lde_large(hipStream_t stream, const uint32_t* in, uint32_t* c
   hipLaunchKernelGGL(ntt_strided_kernel<true>, sgrid, dim3(kLdeThreads), strided_smem, stream, in, h, scratch, 2 * h,
                      tw_inv, logh, l2);
   hipLaunchKernelGGL(ntt_chunk_kernel<true>, chunk_grid, dim3(kLdeThreads), chunk_smem, stream, scratch, coefs_br,
-                     2 * h, h, tw_inv, (const uint32_t*)nullptr, in_scale_br, logh, l2);
+                     2 * h, h, tw_inv, (const uint32_t*)nullptr, in_scale_br, logh, l2, scale_sel_shift, scale_sel_mask);
   for (int cs = 0; cs < 2; ++cs) {
     uint32_t* dst = out + (size_t)cs * h;
     hipLaunchKernelGGL(ntt_chunk_kernel<false>, chunk_grid, dim3(kLdeThreads), chunk_smem, stream, coefs_br, dst, h,
-                       2 * h, tw_fwd, out_scale_br + (size_t)cs * h, (const uint32_t*)nullptr, logh, l2);
+                       2 * h, tw_fwd, out_scale_br + (size_t)cs * h, (const uint32_t*)nullptr, logh, l2, 0, 0);
     hipLaunchKernelGGL(ntt_strided_kernel<false>, sgrid, dim3(kLdeThreads), strided_smem, stream, dst, 2 * h, dst, 2 * h,
                        tw_fwd, logh, l2);
   }
@@ -533,8 +535,8 @@ void launch_lde(hipStream_t stream, const uint32_t* in, uint32_t* coefs_br, uint
                 const uint32_t* out_scale_br, int logh, size_t ncols) {
   if (ncols == 0) return;
   if (logh > 14) {
-    // scale-table selection is a quotient-chunk feature of the LDS path; tall columns all use table 0
-    launch_lde_large(stream, in, coefs_br, out, tw_fwd, tw_inv, in_scale_br, out_scale_br, logh, ncols);
+    launch_lde_large(stream, in, coefs_br, out, tw_fwd, tw_inv, in_scale_br, scale_sel_shift, scale_sel_mask, out_scale_br,
+                     logh, ncols);
     return;
   }
   const size_t h = (size_t)1 << logh;

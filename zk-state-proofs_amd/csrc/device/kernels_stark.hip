@@ -36,7 +36,7 @@ __device__ __forceinline__ uint64_t rol64(uint64_t v, int n) { return n ? (v << 
 
 __global__ __launch_bounds__(kThreads) void keccak_trace_kernel(const uint64_t* __restrict__ states, int max_perms,
                                                                const uint32_t* __restrict__ n_perms,
-                                                               uint32_t* __restrict__ trace, int logh) {
+                                                               uint32_t* __restrict__ trace, size_t trace_bstride, int logh) {
   const int h = 1 << logh;
   const int row = blockIdx.x * kThreads + threadIdx.x;
   if (row >= h) return;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kThreads) void keccak_trace_kernel(const uint64_t* 
     a[0] ^= T.rc[r];
   }
   const uint64_t appp00 = app[0] ^ T.rc[round];
-  uint32_t* t = trace + (size_t)b * ka::kWidth * h + row;
+  uint32_t* t = trace + (size_t)b * trace_bstride + row;
   const size_t cs = (size_t)h;
   const uint32_t one = kR1;
   for (int i = 0; i < 24; ++i) t[(ka::kFlags + i) * cs] = (i == round) ? one : 0u;
@@ -110,7 +110,14 @@ void launch_keccak_trace(hipStream_t stream, const uint64_t* states, int max_per
                          uint32_t* trace, int logh, int batch) {
   const int h = 1 << logh;
   hipLaunchKernelGGL(keccak_trace_kernel, dim3((h + kThreads - 1) / kThreads, batch), dim3(kThreads), 0, stream,
-                     states, max_perms, n_perms, trace, logh);
+                     states, max_perms, n_perms, trace, (size_t)ka::kWidth * h, logh);
+}
+// the same columns inside a wider per-proof matrix (the machine proof's keccak chip adds a column)
+void launch_keccak_trace_strided(hipStream_t stream, const uint64_t* states, int max_perms, const uint32_t* n_perms,
+                                 uint32_t* trace, size_t trace_bstride, int logh, int batch) {
+  const int h = 1 << logh;
+  hipLaunchKernelGGL(keccak_trace_kernel, dim3((h + kThreads - 1) / kThreads, batch), dim3(kThreads), 0, stream,
+                     states, max_perms, n_perms, trace, trace_bstride, logh);
 }
 
 // ===========================================================================

@@ -50,6 +50,7 @@ int zksp_client_new(const zksp_options* opts, zksp_client** out) {
     if (opts->num_queries) ctx.params.num_queries = opts->num_queries;
     if (opts->pow_bits != 0xffffffffu) ctx.params.pow_bits = opts->pow_bits;
     if (opts->max_batch) ctx.params.max_batch = opts->max_batch;
+    if (opts->proof_mode) ctx.params.proof_mode = opts->proof_mode;
   }
   // Run-time backend selection, the counterpart of SP1_PROVER (reference .env.example:1-2) next to
   // the compile-time features of prover/Cargo.toml:32-35.  ZKSP_PROVER = "hip" | "local": prove on the
@@ -63,6 +64,7 @@ int zksp_client_new(const zksp_options* opts, zksp_client** out) {
   }
   if (ctx.params.keccak_mode != 1 && ctx.params.keccak_mode != 2) { delete c; return ZKSP_ERR_INVALID_ARG; }
   if (ctx.params.pow_bits > 30 || ctx.params.num_queries > 4096) { delete c; return ZKSP_ERR_INVALID_ARG; }
+  if (ctx.params.proof_mode != ZKSP_PROOF_MACHINE && ctx.params.proof_mode != ZKSP_PROOF_KECCAK_CHIP) { delete c; return ZKSP_ERR_INVALID_ARG; }
   if (dev >= 0) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || dev >= count) { delete c; return ZKSP_ERR_NO_DEVICE; }

@@ -6,6 +6,8 @@
 #include <new>
 
 #include "api_types.hpp"
+#include "machine_defs.hpp"
+#include "mprover.hpp"
 
 using namespace zksp;
 
@@ -68,6 +70,96 @@ int zksp_mtrace_info(const zksp_mtrace* t, zksp_mtrace_info_t* info) {
   info->keccak_mode = (uint32_t)t->prog->keccak_mode;
   memcpy(info->pv_digest, t->t.rec.pv_digest.data(), 32);
   memcpy(info->deferred_digest, t->t.rec.deferred_digest.data(), 32);
+  return ZKSP_OK;
+}
+
+int zksp_mtrace_heights(const zksp_mtrace* t, int32_t* lh) {
+  if (!t || !lh) return ZKSP_ERR_INVALID_ARG;
+  int v[mach::kNumChips];
+  machine_heights(*t->prog, t->t, v);
+  for (int c = 0; c < mach::kNumChips; ++c) lh[c] = v[c];
+  return ZKSP_OK;
+}
+
+size_t zksp_machine_body_words(const zksp_client* c, const int32_t* lh) {
+  if (!c || !lh) return 0;
+  int v[mach::kNumChips];
+  for (int k = 0; k < mach::kNumChips; ++k) {
+    if (lh[k] < 5 || lh[k] > 21) return 0;
+    v[k] = lh[k];
+  }
+  return machine_proof_body_words(v, c->ctx.params.num_queries);
+}
+
+int zksp_hip_machine_load(zksp_client* c, const zksp_pk* pk, const zksp_mtrace* const* traces, size_t n) {
+  if (!c || !pk || !traces || n == 0) return ZKSP_ERR_INVALID_ARG;
+  Context* ctx = &c->ctx;
+  if (!ctx->has_device()) return ctx->fail(ZKSP_ERR_NO_DEVICE, "machine_load: client has no GPU");
+  ZKSP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  try {
+    std::vector<const MachineTrace*> ts(n);
+    for (size_t i = 0; i < n; ++i) {
+      if (!traces[i] || traces[i]->prog != &pk->mprog) return ctx->fail(ZKSP_ERR_INVALID_ARG, "machine_load: trace of another key");
+      ts[i] = &traces[i]->t;
+    }
+    return machine_load(ctx, pk->mprog, pk->mvk, ts.data(), n);
+  } catch (...) {
+    return ctx->fail(ZKSP_ERR_HIP, "machine_load: out of memory");
+  }
+}
+
+int zksp_hip_machine_prove(zksp_client* c) {
+  if (!c) return ZKSP_ERR_INVALID_ARG;
+  if (!c->ctx.has_device()) return c->ctx.fail(ZKSP_ERR_NO_DEVICE, "machine_prove: client has no GPU");
+  ZKSP_HIP_CHECK(&c->ctx, hipSetDevice(c->ctx.device));
+  return machine_prove_resident(&c->ctx);
+}
+
+int zksp_hip_machine_fetch_bodies(zksp_client* c, uint32_t* out, size_t cap_words) {
+  if (!c || !out) return ZKSP_ERR_INVALID_ARG;
+  Context* ctx = &c->ctx;
+  MachineWorkspace* w = ctx->mws.get();
+  if (!w || w->n == 0) return ctx->fail(ZKSP_ERR_INVALID_ARG, "machine_fetch_bodies: no batch");
+  const size_t words = (size_t)w->n * w->body_words;
+  if (cap_words < words) return ctx->fail(ZKSP_ERR_INVALID_ARG, "machine_fetch_bodies: buffer too small");
+  ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(out, w->body, words * 4, hipMemcpyDeviceToHost, ctx->stream));
+  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return ZKSP_OK;
+}
+
+int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const uint32_t* body, size_t body_words,
+                                 zksp_proof** out) {
+  if (!pk || !t || !body || !out) return ZKSP_ERR_INVALID_ARG;
+  zksp_proof* p = new (std::nothrow) zksp_proof();
+  if (!p) return ZKSP_ERR_INVALID_ARG;
+  try {
+    const ExecutionRecord& r = t->t.rec;
+    const size_t pvw = (r.public_values.size() + 3) / 4;
+    p->bytes.assign(((size_t)mach::kHeaderWords + pvw + body_words) * 4, 0);
+    uint32_t* w = reinterpret_cast<uint32_t*>(p->bytes.data());
+    int lh[mach::kNumChips];
+    machine_heights(*t->prog, t->t, lh);
+    w[0] = kProofMagic;
+    w[1] = mach::kMachineVersion;
+    for (int c = 0; c < mach::kNumChips; ++c) w[2 + c] = (uint32_t)lh[c];
+    w[2 + mach::kNumChips] = r.exit_code;
+    w[3 + mach::kNumChips] = (uint32_t)r.public_values.size();
+    memcpy(w + 4 + mach::kNumChips, r.pv_digest.data(), 32);
+    memcpy(w + 12 + mach::kNumChips, r.deferred_digest.data(), 32);
+    memcpy(w + 20 + mach::kNumChips, pk->mvk.digest, 32);
+    if (!r.public_values.empty()) memcpy(w + mach::kHeaderWords, r.public_values.data(), r.public_values.size());
+    memcpy(w + mach::kHeaderWords + pvw, body, body_words * 4);
+  } catch (...) {
+    delete p;
+    return ZKSP_ERR_INVALID_ARG;
+  }
+  std::string err;
+  p->version = mach::kMachineVersion;
+  if (!parse_machine_header(p->bytes.data(), p->bytes.size(), &p->mhdr, &err)) {
+    delete p;
+    return ZKSP_ERR_PROOF_FORMAT;
+  }
+  *out = p;
   return ZKSP_OK;
 }
 

@@ -1,10 +1,13 @@
 #include "context.hpp"
 
+#include "mprover.hpp"  // MachineWorkspace, PrepDevice
 #include "prover.hpp"  // Workspace must be complete for ~Context
 
 #include <cstring>
 
 namespace zksp {
+
+Context::Context() = default;
 
 Context::~Context() {
   if (device >= 0) {
@@ -34,6 +37,13 @@ Context::~Context() {
     if (timer_a) (void)hipEventDestroy(timer_a);
     if (timer_b) (void)hipEventDestroy(timer_b);
     ws.reset();
+    mws.reset();
+    for (auto& kv : prep)
+      for (void* p : kv.second->allocs)
+        if (p) (void)hipFree(p);
+    prep.clear();
+    for (void* p : d_inter)
+      if (p) (void)hipFree(p);
     if (stream) (void)hipStreamDestroy(stream);
   }
 }

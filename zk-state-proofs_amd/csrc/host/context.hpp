@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <map>
 #include <memory>
 #include <string>
@@ -44,9 +45,12 @@ struct Params {
   uint32_t pow_bits = 16;
   uint32_t max_batch = 16;
   int keccak_mode = 2;
+  int proof_mode = 1;  // ZKSP_PROOF_MACHINE
 };
 
 struct Workspace;  // prover.cpp
+struct MachineWorkspace;  // mprover.cpp
+struct PrepDevice;
 
 struct Context {
   int device = -1;
@@ -56,6 +60,11 @@ struct Context {
   std::map<int, DeviceDomain> domains;
   std::map<uint32_t, std::vector<uint32_t*>> qscale;  // custom in_shift scale tables for zksp_hip_lde
   std::unique_ptr<Workspace> ws;
+  // machine proof: batch workspace, per-program preprocessed tables (by verifying-key digest),
+  // device copies of the chips' bus interactions
+  std::unique_ptr<MachineWorkspace> mws;
+  std::map<std::array<uint32_t, 8>, std::unique_ptr<PrepDevice>> prep;
+  void* d_inter[8] = {nullptr};
   uint32_t* h_stage2[2] = {nullptr, nullptr};  // pinned host staging for proof bodies (double buffered)
   size_t h_stage2_words[2] = {0, 0};
   // prove_batch copies a group's bodies to the host on its own stream while the next group is
@@ -75,6 +84,7 @@ struct Context {
   size_t event_used = 0;
   hipEvent_t timer_a = nullptr, timer_b = nullptr;
 
+  Context();  // out of line: members hold types that are incomplete here
   ~Context();
   bool has_device() const { return device >= 0; }
   int fail(int code, const std::string& msg) { error = msg; return code; }

@@ -1,0 +1,637 @@
+// Replaces the body of the reference's `client.prove(&pk, stdin).run()` (prover/src/bin/main.rs:71-74)
+// below the executor for the full statement: sp1-prover / sp1-stark's multi-chip commit -> LogUp ->
+// quotient -> open -> FRI flow over the CPU, keccak, keccak-memory, memory-boundary, image, program
+// and multiplier chips, as one fixed sequence of HIP kernel launches per batch with the Fiat-Shamir
+// transcript kept on the device.  Byte-for-byte the oracle's orc_machine_prove (tests).
+#include "mprover.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+#include "prover.hpp"
+
+namespace zksp {
+
+using namespace mach;
+
+MachineWorkspace::~MachineWorkspace() {
+  for (void* p : allocs)
+    if (p) (void)hipFree(p);
+}
+
+namespace {
+
+int ceil_log2(size_t v) {
+  int l = 0;
+  while (((size_t)1 << l) < v) ++l;
+  return l;
+}
+int at_least5(int l) { return l < 5 ? 5 : l; }
+
+template <class T>
+bool dalloc(std::vector<void*>* allocs, T** p, size_t count) {
+  void* q = nullptr;
+  if (hipMalloc(&q, std::max<size_t>(count, 4) * sizeof(T)) != hipSuccess) return false;
+  allocs->push_back(q);
+  *p = static_cast<T*>(q);
+  return true;
+}
+size_t layer_off(int logn, int layer) { return ((size_t)2 << logn) - ((size_t)2 << (logn - layer)); }
+
+struct RoundMats {
+  Seg seg[kNumChips][2];
+  int logh[kNumChips];
+};
+
+// Mixed-height commitment of one round (kernels_machine.h).  tree: [(2N - 1) * 8] words per proof with
+// N = 2 * 2^lm; inj[g]: scratch for the leaf digests of the group whose LDE has 2^g rows.
+int mmcs_commit(hipStream_t s, const RoundMats& rm, uint32_t* tree, size_t tree_bstride, uint32_t* const* inj, int batch,
+                const P2Consts* kc) {
+  int lm = 0;
+  for (int c = 0; c < kNumChips; ++c)
+    if (rm.seg[c][0].width) lm = std::max(lm, rm.logh[c]);
+  const int logn = lm + 1;
+  auto group = [&](int g_logn, Seg* out) {
+    int n = 0;
+    for (int c = 0; c < kNumChips; ++c)
+      for (int k = 0; k < 2; ++k)
+        if (rm.seg[c][k].width && rm.logh[c] + 1 == g_logn) out[n++] = rm.seg[c][k];
+    return n;
+  };
+  Seg segs[2 * kNumChips];
+  int ns = group(logn, segs);
+  launch_mmcs_leaves(s, segs, ns, lm, tree, tree_bstride, batch, kc);
+  for (int l = 1; l <= logn; ++l) {
+    const size_t count = (size_t)1 << (logn - l);
+    const uint32_t* injp = nullptr;
+    size_t inj_bstride = 0;
+    ns = l < logn ? group(logn - l, segs) : 0;
+    if (ns) {
+      inj_bstride = (size_t)8 << (logn - l);
+      launch_mmcs_leaves(s, segs, ns, logn - l - 1, inj[logn - l], inj_bstride, batch, kc);
+      injp = inj[logn - l];
+    }
+    launch_mmcs_level(s, tree + layer_off(logn, l - 1) * 8, tree_bstride, tree + layer_off(logn, l) * 8, tree_bstride, injp,
+                      inj_bstride, count, batch, kc);
+  }
+  return lm;
+}
+
+}  // namespace
+
+void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh[kNumChips]) {
+  logh[kCpu] = at_least5(ceil_log2(t.cycles.size()));
+  logh[kKeccak] = at_least5(ceil_log2(24 * t.keccak.size()));
+  logh[kKmem] = at_least5(ceil_log2(50 * t.keccak.size()));
+  logh[kMemFinal] = at_least5(ceil_log2(t.memfinal.size()));
+  logh[kImage] = prog.log_image;
+  logh[kProgram] = prog.log_prog;
+  logh[kMul] = at_least5(ceil_log2(t.muls.size()));
+}
+
+int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const PrepDevice** out) {
+  std::array<uint32_t, 8> key;
+  memcpy(key.data(), vk.digest, 32);
+  auto it = ctx->prep.find(key);
+  if (it != ctx->prep.end()) { *out = it->second.get(); return 0; }
+  std::unique_ptr<PrepDevice> pd(new PrepDevice());
+  hipStream_t s = ctx->stream;
+  std::vector<uint32_t> tr[2];
+  machine_prep_traces(prog, &tr[0], &tr[1]);
+  pd->logh[0] = prog.log_image;
+  pd->logh[1] = prog.log_prog;
+  const int widths[2] = {kImagePrepWidth, kProgramPrepWidth};
+  bool ok = true;
+  for (int i = 0; i < 2 && ok; ++i) {
+    const size_t h = (size_t)1 << pd->logh[i];
+    for (auto& v : tr[i]) v = Fp::from_canonical(v).v;
+    ok = ok && dalloc(&pd->allocs, &pd->tr[i], tr[i].size());
+    uint32_t* d_tr = pd->tr[i];
+    ok = ok && dalloc(&pd->allocs, &pd->coef[i], (size_t)widths[i] * h);
+    ok = ok && dalloc(&pd->allocs, &pd->lde[i], (size_t)widths[i] * 2 * h);
+    if (!ok) break;
+    const DeviceDomain* dom = ctx->domain(pd->logh[i]);
+    if (!dom) return 3;
+    ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(d_tr, tr[i].data(), tr[i].size() * 4, hipMemcpyHostToDevice, s));
+    launch_lde(s, d_tr, pd->coef[i], pd->lde[i], dom->twc_fwd, dom->twc_inv, dom->in_scale_br, 0, 0, dom->out_scale_br,
+               pd->logh[i], (size_t)widths[i]);
+    ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // tr[i] goes out of use
+  }
+  pd->lm = std::max(pd->logh[0], pd->logh[1]);
+  const size_t N = (size_t)2 << pd->lm;
+  ok = ok && dalloc(&pd->allocs, &pd->tree, (2 * N - 1) * 8);
+  ok = ok && dalloc(&pd->allocs, &pd->inj, N * 8);
+  ok = ok && dalloc(&pd->allocs, &pd->program, prog.rows.size() * 9);
+  if (!ok) return ctx->fail(3, "machine: allocation of the preprocessed tables failed");
+  RoundMats rm;
+  memset(&rm, 0, sizeof rm);
+  rm.seg[kImage][0] = Seg{pd->lde[0], 0, kImagePrepWidth};
+  rm.seg[kProgram][0] = Seg{pd->lde[1], 0, kProgramPrepWidth};
+  rm.logh[kImage] = pd->logh[0];
+  rm.logh[kProgram] = pd->logh[1];
+  uint32_t* inj[32];
+  for (auto& p : inj) p = pd->inj;  // at most one shorter group
+  mmcs_commit(s, rm, pd->tree, 0, inj, 1, ctx->d_consts);
+  static_assert(sizeof(ProgramRow) == 36, "program row layout");
+  ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(pd->program, prog.rows.data(), prog.rows.size() * 36, hipMemcpyHostToDevice, s));
+  uint32_t root[8];
+  ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(root, pd->tree + (2 * N - 2) * 8, 32, hipMemcpyDeviceToHost, s));
+  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  ZKSP_HIP_CHECK(ctx, hipGetLastError());
+  for (int i = 0; i < 8; ++i)
+    if (Fp::raw(root[i]).to_canonical() != vk.prep_root[i])
+      return ctx->fail(3, "machine: the device commitment of the preprocessed tables differs from the verifying key");
+  pd->n_program = (uint32_t)prog.rows.size();
+  pd->text_base = prog.text_base;
+  pd->entry = prog.entry;
+  *out = pd.get();
+  ctx->prep.emplace(key, std::move(pd));
+  return 0;
+}
+
+static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap_cycles, size_t cap_keccak, size_t cap_memfinal,
+                            size_t cap_muls) {
+  MachineWorkspace* w = ctx->mws.get();
+  if (w && memcmp(w->logh, logh, sizeof w->logh) == 0 && w->batch >= batch && w->cap_cycles >= cap_cycles &&
+      w->cap_keccak >= cap_keccak && w->cap_memfinal >= cap_memfinal && w->cap_muls >= cap_muls)
+    return 0;
+  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->mws.reset(new MachineWorkspace());
+  w = ctx->mws.get();
+  memcpy(w->logh, logh, sizeof w->logh);
+  w->batch = batch;
+  w->cap_cycles = cap_cycles; w->cap_keccak = std::max<size_t>(cap_keccak, 1); w->cap_memfinal = cap_memfinal;
+  w->cap_muls = std::max<size_t>(cap_muls, 1);
+  const size_t B = (size_t)batch;
+  const uint32_t Q = ctx->params.num_queries;
+  bool ok = true;
+  auto A = [&](auto** p, size_t count) { ok = ok && dalloc(&w->allocs, p, count); };
+  A(&w->cycles, B * w->cap_cycles * 12);
+  A(&w->kcalls, B * w->cap_keccak * 408);
+  A(&w->kstates, B * w->cap_keccak * 25);
+  A(&w->memfinal, B * w->cap_memfinal * 5);
+  A(&w->muls, B * w->cap_muls * 3);
+  A(&w->prog_mult, B << logh[kProgram]);
+  A(&w->image_used, B << logh[kImage]);
+  A(&w->counts, B * 4);
+  A(&w->n_perms, B);
+  A(&w->init_obs, B * kMachineInitObs);
+  A(&w->pub_words, B * 17);
+  int lm = 0;
+  size_t n_open = 0, max_total = 0, max_h = 0;
+  for (int c = 0; c < kNumChips; ++c) {
+    const ChipDef& d = chip_def(c);
+    const size_t h = (size_t)1 << logh[c];
+    lm = std::max(lm, logh[c]);
+    max_h = std::max(max_h, h);
+    const int widths[3] = {d.main_w, d.perm_width(), 8};
+    for (int r = 0; r < 3; ++r) {
+      w->mat[c][r].w = widths[r];
+      A(&w->mat[c][r].tr, B * widths[r] * h);
+      A(&w->mat[c][r].coef, B * widths[r] * h);
+      A(&w->mat[c][r].lde, B * widths[r] * 2 * h);
+    }
+    A(&w->zpow[c], B * 2 * h * 4);
+    w->open_off[c] = n_open;
+    n_open += (size_t)d.prep_w + 2 * (size_t)d.main_w + 2 * (size_t)d.perm_width() + 8;
+    max_total = std::max<size_t>(max_total, (size_t)d.total_constraints());
+  }
+  w->lm = lm;
+  w->n_open = n_open;
+  w->alpha_stride = max_total * 4;
+  const size_t N = (size_t)2 << lm;
+  for (int r = 1; r < 4; ++r) {
+    A(&w->tree[r], B * (2 * N - 1) * 8);
+    for (int c = 0; c < kNumChips; ++c)
+      if (logh[c] < lm && !w->inj[r][logh[c] + 1]) A(&w->inj[r][logh[c] + 1], (B * 8) << (logh[c] + 1));
+  }
+  for (int c = 0; c < kNumChips; ++c)
+    if (logh[c] < lm && !w->G[logh[c]]) A(&w->G[logh[c]], (B * 2 * 4) << logh[c]);
+  A(&w->ch, B);
+  A(&w->bus_ch, B * 8);
+  A(&w->bpow, B * (kInterMaxElems + 1) * 4);
+  A(&w->cum, B * kNumChips * 4);
+  A(&w->pubsum, B * 4);
+  A(&w->rowsum, B * max_h * 4);
+  A(&w->alpha, B * 4);
+  A(&w->alpha_pows, B * w->alpha_stride);
+  A(&w->zeta, B * 4);
+  w->open_rows_log = (size_t)ceil_log2((n_open * 4 + 7) / 8);
+  const size_t R = (size_t)1 << w->open_rows_log;
+  A(&w->opened, B * 8 * R);
+  A(&w->tree_o, B * (2 * R - 1) * 8);
+  A(&w->af, B * 4);
+  A(&w->af_pows, B * n_open * 4);
+  A(&w->bsum, B * 2 * 4);
+  {
+    size_t need = 0;  // partial sums of the reduced openings: [nchunks][2][2H] Fp4 per proof, largest chip
+    for (int c = 0; c < kNumChips; ++c) {
+      const ChipDef& d = chip_def(c);
+      need = std::max(need, (size_t)mreduce_nchunks(d.prep_w + d.main_w + d.perm_width() + 8) * 16 * ((size_t)1 << logh[c]));
+    }
+    A(&w->reduce_scratch, B * need);
+  }
+  A(&w->kpartial, B * 13 * (((size_t)2 << logh[kKeccak]) * 4));
+  w->fri_layer_stride = 0;
+  w->fri_tree_stride = 0;
+  for (int k = 0; k < lm; ++k) {
+    const size_t hk = ((size_t)1 << lm) >> k;
+    w->fri_layer_stride += 2 * hk * 4;
+    w->fri_tree_stride += (2 * hk - 1) * 8;
+  }
+  w->fri_layer_stride += 2 * 4;
+  A(&w->fri_layers, B * w->fri_layer_stride);
+  A(&w->fri_trees, B * w->fri_tree_stride);
+  A(&w->betas, B * (size_t)lm * 4);
+  A(&w->witness, B);
+  A(&w->indices, B * Q);
+  w->body_words = machine_proof_body_words(logh, Q);
+  A(&w->body, B * w->body_words);
+  if (!ok) {
+    ctx->mws.reset();
+    return ctx->fail(3, "machine workspace: hipMalloc failed");
+  }
+  ZKSP_HIP_CHECK(ctx, hipMemsetAsync(w->opened, 0, B * 8 * R * 4, ctx->stream));
+  return 0;
+}
+
+int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const MachineTrace* const* traces, size_t n) {
+  if (n == 0) return ctx->fail(1, "machine_load: empty batch");
+  const PrepDevice* prep = nullptr;
+  int rc = machine_prep_ensure(ctx, prog, vk, &prep);
+  if (rc) return rc;
+  int logh[kNumChips];
+  machine_heights(prog, *traces[0], logh);
+  size_t cc = 0, ck = 0, cm = 0, cu = 0;
+  for (size_t i = 0; i < n; ++i) {
+    int li[kNumChips];
+    machine_heights(prog, *traces[i], li);
+    if (memcmp(li, logh, sizeof li) != 0) return ctx->fail(1, "machine_load: traces of one batch must have identical chip heights");
+    cc = std::max(cc, traces[i]->cycles.size()); ck = std::max(ck, traces[i]->keccak.size());
+    cm = std::max(cm, traces[i]->memfinal.size()); cu = std::max(cu, traces[i]->muls.size());
+  }
+  if (logh[kCpu] > 21) return ctx->fail(9, "machine_load: more than 2^21 cycles");
+  for (int c = 1; c < kNumChips; ++c)
+    if (logh[c] > logh[kCpu]) return ctx->fail(9, "machine_load: a chip is taller than the CPU chip");
+  rc = workspace_ensure(ctx, logh, (int)std::max<size_t>(n, (size_t)ctx->batch_hint), cc, ck, cm, cu);
+  if (rc) return rc;
+  MachineWorkspace* w = ctx->mws.get();
+  w->prep = prep;
+  hipStream_t s = ctx->stream;
+  std::vector<uint32_t> counts(n * 4), nperms(n), obs(n * kMachineInitObs), pubw(n * 17);
+  std::vector<uint64_t> kst(n * w->cap_keccak * 25, 0);
+  const size_t hp = (size_t)1 << logh[kProgram], hi = (size_t)1 << logh[kImage];
+  for (size_t i = 0; i < n; ++i) {
+    const MachineTrace& t = *traces[i];
+    counts[4 * i] = (uint32_t)t.cycles.size(); counts[4 * i + 1] = (uint32_t)t.keccak.size();
+    counts[4 * i + 2] = (uint32_t)t.memfinal.size(); counts[4 * i + 3] = (uint32_t)t.muls.size();
+    nperms[i] = (uint32_t)t.keccak.size();
+    ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->cycles + i * w->cap_cycles * 12, t.cycles.data(), t.cycles.size() * 48, hipMemcpyHostToDevice, s));
+    if (!t.keccak.empty())
+      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->kcalls + i * w->cap_keccak * 408, t.keccak.data(), t.keccak.size() * 408, hipMemcpyHostToDevice, s));
+    for (size_t p = 0; p < t.keccak.size(); ++p) memcpy(&kst[(i * w->cap_keccak + p) * 25], t.keccak[p].in, 200);
+    ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->memfinal + i * w->cap_memfinal * 5, t.memfinal.data(), t.memfinal.size() * 20, hipMemcpyHostToDevice, s));
+    if (!t.muls.empty())
+      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->muls + i * w->cap_muls * 3, t.muls.data(), t.muls.size() * 12, hipMemcpyHostToDevice, s));
+    ZKSP_HIP_CHECK(ctx, hipMemsetAsync(w->prog_mult + i * hp, 0, hp * 4, s));
+    ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->prog_mult + i * hp, t.prog_mult.data(), t.prog_mult.size() * 4, hipMemcpyHostToDevice, s));
+    ZKSP_HIP_CHECK(ctx, hipMemsetAsync(w->image_used + i * hi, 0, hi * 4, s));
+    ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->image_used + i * hi, t.image_used.data(), t.image_used.size() * 4, hipMemcpyHostToDevice, s));
+    uint32_t* o = &obs[i * kMachineInitObs];
+    memcpy(o, vk.digest, 32);
+    for (int c = 0; c < kNumChips; ++c) o[8 + c] = (uint32_t)logh[c];
+    o[8 + kNumChips] = t.rec.exit_code & 0xffff;
+    o[9 + kNumChips] = t.rec.exit_code >> 16;
+    for (int k = 0; k < 8; ++k) {
+      o[10 + kNumChips + 2 * k] = t.rec.pv_digest[k] & 0xffff;
+      o[11 + kNumChips + 2 * k] = t.rec.pv_digest[k] >> 16;
+      o[26 + kNumChips + 2 * k] = t.rec.deferred_digest[k] & 0xffff;
+      o[27 + kNumChips + 2 * k] = t.rec.deferred_digest[k] >> 16;
+      pubw[i * 17 + k] = t.rec.pv_digest[k];
+      pubw[i * 17 + 8 + k] = t.rec.deferred_digest[k];
+    }
+    pubw[i * 17 + 16] = t.rec.exit_code;
+  }
+  ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->kstates, kst.data(), kst.size() * 8, hipMemcpyHostToDevice, s));
+  ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->counts, counts.data(), counts.size() * 4, hipMemcpyHostToDevice, s));
+  ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->n_perms, nperms.data(), nperms.size() * 4, hipMemcpyHostToDevice, s));
+  ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->init_obs, obs.data(), obs.size() * 4, hipMemcpyHostToDevice, s));
+  ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->pub_words, pubw.data(), pubw.size() * 4, hipMemcpyHostToDevice, s));
+  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // host vectors go out of scope
+  w->n = (int)n;
+  return 0;
+}
+
+static int upload_interactions(Context* ctx) {
+  for (int c = 0; c < kNumChips; ++c) {
+    if (ctx->d_inter[c]) continue;
+    const ChipDef& d = chip_def(c);
+    void* p = nullptr;
+    ZKSP_HIP_CHECK(ctx, hipMalloc(&p, sizeof(Interaction) * (size_t)d.n_inter));
+    ZKSP_HIP_CHECK(ctx, hipMemcpy(p, d.inter, sizeof(Interaction) * (size_t)d.n_inter, hipMemcpyHostToDevice));
+    ctx->d_inter[c] = p;
+  }
+  return 0;
+}
+
+int machine_prove_resident(Context* ctx) {
+  MachineWorkspace* w = ctx->mws.get();
+  if (!w || w->n == 0 || !w->prep) return ctx->fail(1, "machine_prove_resident: no batch loaded");
+  int rc = upload_interactions(ctx);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  const P2Consts* kc = ctx->d_consts;
+  const PrepDevice* prep = w->prep;
+  const int B = w->n, lm = w->lm;
+  const int* logh = w->logh;
+  const int Q = (int)ctx->params.num_queries, pow_bits = (int)ctx->params.pow_bits;
+  const DeviceDomain* dom[kNumChips];
+  for (int c = 0; c < kNumChips; ++c) {
+    dom[c] = ctx->domain(logh[c]);
+    if (!dom[c]) return 3;
+  }
+  const size_t N = (size_t)2 << lm, tree_stride = (2 * N - 1) * 8, root_off = (2 * N - 2) * 8;
+  auto H = [&](int c) { return (size_t)1 << logh[c]; };
+  auto prep_seg = [&](int c, bool lde) -> Seg {
+    if (c == kImage) return Seg{lde ? prep->lde[0] : nullptr, 0, kImagePrepWidth};
+    if (c == kProgram) return Seg{lde ? prep->lde[1] : nullptr, 0, kProgramPrepWidth};
+    return Seg{nullptr, 0, 0};
+  };
+
+  // ---- main traces ----
+  MachineRecords rec;
+  rec.cycles = w->cycles; rec.kcalls = w->kcalls; rec.memfinal = w->memfinal; rec.muls = w->muls;
+  rec.prog_mult = w->prog_mult; rec.image_used = w->image_used; rec.counts = w->counts;
+  rec.cap_cycles = w->cap_cycles; rec.cap_keccak = w->cap_keccak; rec.cap_memfinal = w->cap_memfinal; rec.cap_muls = w->cap_muls;
+  rec.program = prep->program; rec.text_base = prep->text_base; rec.n_program = prep->n_program;
+  {
+    ProfileSpan sp(ctx, "m_trace");
+    for (int c = 0; c < kNumChips; ++c) {
+      if (c == kKeccak) {
+        const size_t bs = (size_t)kKeccakWidth * H(c);
+        launch_keccak_trace_strided(s, w->kstates, (int)w->cap_keccak, w->n_perms, w->mat[c][0].tr, bs, logh[c], B);
+        launch_keccak_ts(s, rec, w->mat[c][0].tr, bs, logh[c], B);
+      } else {
+        launch_machine_trace(s, c, rec, w->mat[c][0].tr, logh[c], B);
+      }
+    }
+  }
+  {
+    ProfileSpan sp(ctx, "m_lde_main");
+    for (int c = 0; c < kNumChips; ++c)
+      launch_lde(s, w->mat[c][0].tr, w->mat[c][0].coef, w->mat[c][0].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br, 0,
+                 0, dom[c]->out_scale_br, logh[c], (size_t)B * w->mat[c][0].w);
+  }
+  RoundMats rm[4];
+  memset(rm, 0, sizeof rm);
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < kNumChips; ++c) rm[r].logh[c] = logh[c];
+  for (int c = 0; c < kNumChips; ++c) {
+    rm[0].seg[c][0] = prep_seg(c, true);
+    for (int r = 1; r <= 2; ++r)
+      rm[r].seg[c][0] = Seg{w->mat[c][r - 1].lde, (size_t)w->mat[c][r - 1].w * 2 * H(c), w->mat[c][r - 1].w};
+    rm[3].seg[c][0] = Seg{w->mat[c][2].lde, (size_t)8 * 2 * H(c), 8};
+  }
+  {
+    ProfileSpan sp(ctx, "m_commit_main");
+    mmcs_commit(s, rm[1], w->tree[1], tree_stride, w->inj[1], B, kc);
+  }
+  {
+    ProfileSpan sp(ctx, "transcript");
+    launch_ch_init(s, w->ch, w->init_obs, kMachineInitObs, B, kc);
+    launch_ch_observe_sample(s, w->ch, w->tree[1] + root_off, tree_stride, 8, w->bus_ch, 8, 2, B, kc);
+    launch_ext_powers(s, w->bus_ch + 4, 8, kR1, w->bpow, (size_t)(kInterMaxElems + 1) * 4, kInterMaxElems + 1, 0, B);
+  }
+  // ---- LogUp permutation traces ----
+  {
+    ProfileSpan sp(ctx, "m_perm");
+    for (int c = 0; c < kNumChips; ++c) {
+      const ChipDef& d = chip_def(c);
+      PermArgs pa;
+      pa.inter = static_cast<const Interaction*>(ctx->d_inter[c]);
+      pa.n_inter = d.n_inter;
+      pa.prep = Seg{c == kImage ? prep->tr[0] : c == kProgram ? prep->tr[1] : nullptr, 0, d.prep_w};
+      pa.main_ = Seg{w->mat[c][0].tr, (size_t)d.main_w * H(c), d.main_w};
+      pa.bus_ch = w->bus_ch;
+      pa.bpow = w->bpow;
+      pa.perm = w->mat[c][1].tr;
+      pa.perm_bstride = (size_t)d.perm_width() * H(c);
+      pa.rowsum = w->rowsum;
+      pa.cum = w->cum + 4 * c;
+      pa.cum_bstride = (size_t)4 * kNumChips;
+      pa.logh = logh[c];
+      pa.batch = B;
+      launch_perm_trace(s, pa);
+    }
+  }
+  {
+    ProfileSpan sp(ctx, "m_lde_perm");
+    for (int c = 0; c < kNumChips; ++c)
+      launch_lde(s, w->mat[c][1].tr, w->mat[c][1].coef, w->mat[c][1].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br, 0,
+                 0, dom[c]->out_scale_br, logh[c], (size_t)B * w->mat[c][1].w);
+  }
+  {
+    ProfileSpan sp(ctx, "m_commit_perm");
+    mmcs_commit(s, rm[2], w->tree[2], tree_stride, w->inj[2], B, kc);
+  }
+  {
+    ProfileSpan sp(ctx, "transcript");
+    launch_ch_observe_sample(s, w->ch, w->tree[2] + root_off, tree_stride, 8, w->alpha, 4, 0, B, kc);
+    launch_ch_observe_sample(s, w->ch, w->cum, (size_t)4 * kNumChips, 4 * kNumChips, w->alpha, 4, 1, B, kc);
+    launch_ext_powers(s, w->alpha, 4, kR1, w->alpha_pows, w->alpha_stride, (int)(w->alpha_stride / 4), 0, B);
+  }
+  // ---- quotients ----
+  const Fp g = Fp::from_canonical(kGen);
+  {
+    ProfileSpan sp(ctx, "m_quotient");
+    for (int c = 0; c < kNumChips; ++c) {
+      const ChipDef& d = chip_def(c);
+      const size_t h = H(c);
+      MQuotArgs qa;
+      qa.chip = c;
+      qa.inter = static_cast<const Interaction*>(ctx->d_inter[c]);
+      qa.n_inter = d.n_inter;
+      qa.n_base = d.n_constraints;
+      qa.prep = prep_seg(c, true);
+      qa.main_ = rm[1].seg[c][0];
+      qa.perm = rm[2].seg[c][0];
+      qa.alpha_pows = w->alpha_pows;
+      qa.alpha_bstride = w->alpha_stride;
+      qa.bus_ch = w->bus_ch;
+      qa.bpow = w->bpow;
+      qa.cum = w->cum + 4 * c;
+      qa.cum_bstride = (size_t)4 * kNumChips;
+      qa.tw_fwd = dom[c]->tw_fwd;
+      const Fp w2h = fp_root_of_unity(logh[c] + 1), wh = fp_root_of_unity(logh[c]);
+      const Fp sh[2] = {g, g * w2h};
+      for (int k = 0; k < 2; ++k) {
+        qa.shift[k] = sh[k].v;
+        qa.zh_inv[k] = (sh[k].pow(h) - Fp::one()).inv().v;
+      }
+      qa.wh_inv = wh.inv().v;
+      qa.pub = Fp::from_canonical(prep->entry).v;
+      qa.quot = w->mat[c][2].tr;
+      qa.partial = w->kpartial;
+      qa.logh = logh[c];
+      qa.batch = B;
+      launch_machine_quotient(s, qa);
+    }
+  }
+  {
+    ProfileSpan sp(ctx, "m_lde_quot");
+    // columns 4c..4c+3 of every proof were evaluated over coset c: scale tables 1 and 2
+    for (int c = 0; c < kNumChips; ++c)
+      launch_lde(s, w->mat[c][2].tr, w->mat[c][2].coef, w->mat[c][2].lde, dom[c]->twc_fwd, dom[c]->twc_inv,
+                 dom[c]->in_scale_br + H(c), 2, 1, dom[c]->out_scale_br, logh[c], (size_t)B * 8);
+  }
+  {
+    ProfileSpan sp(ctx, "m_commit_quot");
+    mmcs_commit(s, rm[3], w->tree[3], tree_stride, w->inj[3], B, kc);
+  }
+  const size_t R = (size_t)1 << w->open_rows_log;
+  {
+    ProfileSpan sp(ctx, "transcript");
+    launch_ch_observe_sample(s, w->ch, w->tree[3] + root_off, tree_stride, 8, w->zeta, 4, 1, B, kc);
+  }
+  // ---- openings at zeta and zeta * w_H ----
+  {
+    ProfileSpan sp(ctx, "m_open");
+    for (int c = 0; c < kNumChips; ++c) {
+      const ChipDef& d = chip_def(c);
+      const size_t h = H(c);
+      const int pw = d.prep_w, mw = d.main_w, ew = d.perm_width();
+      launch_ext_powers(s, w->zeta, 4, kR1, w->zpow[c], 2 * h * 4, (int)h, logh[c], B, /*centred=*/1);
+      launch_ext_powers(s, w->zeta, 4, dom[c]->w_h, w->zpow[c] + h * 4, 2 * h * 4, (int)h, logh[c], B, /*centred=*/1);
+      uint32_t* base = w->opened + w->open_off[c] * 4;
+      const size_t pt_stride = (size_t)mw + ew + 8;
+      if (pw)
+        launch_open(s, c == kImage ? prep->coef[0] : prep->coef[1], 0, pw, logh[c], w->zpow[c], 2 * h * 4, 1, base, 8 * R, 0, B);
+      launch_open(s, w->mat[c][0].coef, (size_t)mw * h, mw, logh[c], w->zpow[c], 2 * h * 4, 2, base + (size_t)pw * 4, 8 * R,
+                  pt_stride, B);
+      launch_open(s, w->mat[c][1].coef, (size_t)ew * h, ew, logh[c], w->zpow[c], 2 * h * 4, 2, base + (size_t)(pw + mw) * 4, 8 * R,
+                  pt_stride, B);
+      launch_open(s, w->mat[c][2].coef, 8 * h, 8, logh[c], w->zpow[c], 2 * h * 4, 1, base + (size_t)(pw + mw + ew) * 4, 8 * R, 0,
+                  B);
+    }
+  }
+  {
+    ProfileSpan sp(ctx, "merkle_open");
+    launch_merkle_commit(s, w->opened, 8 * R, 8, (int)w->open_rows_log, w->tree_o, (2 * R - 1) * 8, B, kc);
+  }
+  {
+    ProfileSpan sp(ctx, "transcript");
+    launch_ch_observe_sample(s, w->ch, w->tree_o + (2 * R - 2) * 8, (2 * R - 1) * 8, 8, w->af, 4, 1, B, kc);
+    launch_ext_powers(s, w->af, 4, kR1, w->af_pows, w->n_open * 4, (int)w->n_open, 0, B);
+  }
+  // ---- reduced openings: one FRI input per height; the tallest is layer 0 ----
+  {
+    ProfileSpan sp(ctx, "m_reduce");
+    bool seen[32] = {false};
+    for (int c = 0; c < kNumChips; ++c) {
+      const ChipDef& d = chip_def(c);
+      const size_t h = H(c);
+      MReduceArgs ra;
+      ra.mats[0] = prep_seg(c, true);
+      ra.mats[1] = rm[1].seg[c][0];
+      ra.mats[2] = rm[2].seg[c][0];
+      ra.mats[3] = rm[3].seg[c][0];
+      ra.af_pows = w->af_pows;
+      ra.af_bstride = w->n_open * 4;
+      ra.pow_off = w->open_off[c];
+      ra.opened = w->opened;
+      ra.opened_bstride = 8 * R;
+      ra.open_off = w->open_off[c];
+      ra.zeta = w->zeta;
+      ra.tw_fwd = dom[c]->tw_fwd;
+      ra.shift[0] = g.v;
+      ra.shift[1] = (g * fp_root_of_unity(logh[c] + 1)).v;
+      ra.w_h = dom[c]->w_h;
+      ra.partial = w->reduce_scratch;
+      ra.bsum = w->bsum;
+      if (logh[c] == lm) { ra.out = w->fri_layers; ra.out_bstride = w->fri_layer_stride; }
+      else { ra.out = w->G[logh[c]]; ra.out_bstride = 2 * h * 4; }
+      ra.accumulate = seen[logh[c]] ? 1 : 0;
+      seen[logh[c]] = true;
+      ra.logh = logh[c];
+      ra.batch = B;
+      (void)d;
+      launch_machine_reduce(s, ra);
+    }
+  }
+  // ---- FRI commit phase; an input of height 2^k joins when the folded layer reaches that height ----
+  size_t loff = 0, toff = 0;
+  const size_t hmax = (size_t)1 << lm;
+  for (int k = 0; k < lm; ++k) {
+    const int loghk = lm - k;
+    const size_t hk = hmax >> k;
+    {
+      ProfileSpan sp(ctx, "fri_commit");
+      launch_fri_commit(s, w->fri_layers + loff, w->fri_layer_stride, loghk, w->fri_trees + toff * 8, w->fri_tree_stride, B, kc);
+    }
+    {
+      ProfileSpan sp(ctx, "transcript");
+      launch_ch_observe_sample(s, w->ch, w->fri_trees + (toff + 2 * hk - 2) * 8, w->fri_tree_stride, 8, w->betas + (size_t)k * 4,
+                               (size_t)lm * 4, 1, B, kc);
+    }
+    {
+      ProfileSpan sp(ctx, "fri_fold");
+      uint32_t* nxt = w->fri_layers + loff + 2 * hk * 4;
+      launch_fri_fold(s, w->fri_layers + loff, w->fri_layer_stride, nxt, w->fri_layer_stride, w->betas + (size_t)k * 4,
+                      (size_t)lm * 4, dom[kCpu]->tw_inv, k, dom[kCpu]->fold_xinv[2 * k], dom[kCpu]->fold_xinv[2 * k + 1], loghk, B);
+      if (loghk - 1 >= 0 && w->G[loghk - 1]) launch_fri_add(s, nxt, w->fri_layer_stride, w->G[loghk - 1], hk * 4, hk, B);
+    }
+    loff += 2 * hk * 4;
+    toff += 2 * hk - 1;
+  }
+  {
+    ProfileSpan sp(ctx, "transcript");
+    launch_ch_observe_sample(s, w->ch, w->fri_layers + loff, w->fri_layer_stride, 4, w->alpha, 4, 0, B, kc);
+  }
+  {
+    ProfileSpan sp(ctx, "grind");
+    launch_ch_grind(s, w->ch, w->witness, pow_bits, B, kc);
+  }
+  {
+    ProfileSpan sp(ctx, "transcript");
+    launch_ch_queries(s, w->ch, w->witness, w->indices, Q, pow_bits, lm + 1, B, kc);
+  }
+  {
+    ProfileSpan sp(ctx, "m_assemble");
+    MAssembleArgs aa;
+    memset(&aa, 0, sizeof aa);
+    for (int r = 0; r < 4; ++r) {
+      MRound& mr = aa.round[r];
+      mr.lm = 0;
+      for (int c = 0; c < kNumChips; ++c) {
+        mr.logh[c] = logh[c];
+        mr.seg[c][0] = rm[r].seg[c][0];
+        mr.seg[c][1] = Seg{nullptr, 0, 0};
+        if (mr.seg[c][0].width) mr.lm = std::max(mr.lm, logh[c]);
+      }
+      if (r == 0) { mr.tree = prep->tree; mr.tree_bstride = 0; }
+      else { mr.tree = w->tree[r]; mr.tree_bstride = tree_stride; }
+    }
+    aa.cum = w->cum;
+    aa.opened = w->opened;
+    aa.opened_bstride = 8 * R;
+    aa.n_open = w->n_open;
+    aa.fri_layers = w->fri_layers;
+    aa.fri_trees = w->fri_trees;
+    aa.fri_layer_stride = w->fri_layer_stride;
+    aa.fri_tree_stride = w->fri_tree_stride;
+    aa.witness = w->witness;
+    aa.indices = w->indices;
+    aa.body = w->body;
+    aa.body_stride = w->body_words;
+    aa.lm = lm;
+    aa.n_queries = Q;
+    aa.batch = B;
+    if (ctx->body_free) (void)hipStreamWaitEvent(s, ctx->body_free, 0);
+    launch_machine_assemble(s, aa);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ctx->fail(3, std::string("machine_prove_resident: ") + hipGetErrorString(e));
+  return 0;
+}
+
+}  // namespace zksp

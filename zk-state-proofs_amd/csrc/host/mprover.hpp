@@ -1,0 +1,67 @@
+// Device prover of the machine proof: batch workspace in HBM and the launch sequence that turns
+// traced executions into proof bodies ("ZKSP v3") without a host round trip.  See mprover.cpp.
+#pragma once
+#include <array>
+#include <vector>
+
+#include "../device/kernels_machine.h"
+#include "context.hpp"
+#include "machine.hpp"
+#include "mverifier.hpp"
+
+namespace zksp {
+
+constexpr int kMachineInitObs = 8 + mach::kNumChips + 2 + 16 + 16;  // vk digest, heights, exit halves, digest halves
+
+// Preprocessed tables of one program on the device (built once per verifying key).
+struct PrepDevice {
+  int logh[2] = {0, 0};            // image, program
+  uint32_t* tr[2] = {nullptr, nullptr};     // traces (the permutation trace is built from trace rows)
+  uint32_t* coef[2] = {nullptr, nullptr};
+  uint32_t* lde[2] = {nullptr, nullptr};
+  uint32_t* tree = nullptr;        // mixed-height tree over (image, program)
+  uint32_t* inj = nullptr;         // leaf digests of the shorter of the two tables, if heights differ
+  uint32_t* program = nullptr;     // [n][9] rows for trace expansion
+  uint32_t n_program = 0, text_base = 0, entry = 0;
+  int lm = 0;
+  std::vector<void*> allocs;
+};
+
+struct MachineWorkspace {
+  int logh[mach::kNumChips] = {0};
+  int batch = 0, n = 0;
+  size_t cap_cycles = 0, cap_keccak = 0, cap_memfinal = 0, cap_muls = 0;
+  const PrepDevice* prep = nullptr;
+  // records
+  uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *image_used = nullptr, *counts = nullptr;
+  uint8_t* kcalls = nullptr;
+  uint64_t* kstates = nullptr;
+  uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;
+  // per chip: [0] main, [1] permutation, [2] quotient
+  struct Mat { uint32_t *tr = nullptr, *coef = nullptr, *lde = nullptr; int w = 0; };
+  Mat mat[mach::kNumChips][3];
+  uint32_t* zpow[mach::kNumChips] = {nullptr};
+  uint32_t* tree[4] = {nullptr, nullptr, nullptr, nullptr};  // rounds 1..3 (0 is the PrepDevice's)
+  uint32_t* inj[4][32] = {{nullptr}};                         // leaf digests of the shorter groups, by log LDE size
+  uint32_t* G[32] = {nullptr};                                // reduced openings per log height (the tallest lives in fri_layers)
+  DevChallenger* ch = nullptr;
+  uint32_t *bus_ch = nullptr, *bpow = nullptr, *cum = nullptr, *pubsum = nullptr, *rowsum = nullptr;
+  uint32_t *alpha = nullptr, *alpha_pows = nullptr, *zeta = nullptr, *opened = nullptr, *tree_o = nullptr;
+  uint32_t *af = nullptr, *af_pows = nullptr, *bsum = nullptr, *kpartial = nullptr, *reduce_scratch = nullptr;
+  uint32_t *fri_layers = nullptr, *fri_trees = nullptr, *betas = nullptr, *witness = nullptr, *indices = nullptr, *body = nullptr;
+  size_t n_open = 0, open_off[mach::kNumChips] = {0}, open_rows_log = 0, alpha_stride = 0;
+  size_t fri_layer_stride = 0, fri_tree_stride = 0, body_words = 0;
+  int lm = 0;
+  std::vector<void*> allocs;
+  ~MachineWorkspace();
+};
+
+// uploads the preprocessed tables of `prog` and commits them; the root must equal vk.prep_root
+int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const PrepDevice** out);
+// sizes the workspace for `n` traces of identical chip heights and uploads their records
+int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const MachineTrace* const* traces, size_t n);
+// enqueues the whole proving pass over the resident batch
+int machine_prove_resident(Context* ctx);
+void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh[mach::kNumChips]);
+
+}  // namespace zksp
