@@ -33,3 +33,74 @@ def test_machine_proof_matches_oracle(zk, fx, oracle, depth, nq, pow_bits):
         proof = handles[i].proof_from_body(pk, bodies[i])
         assert proof.to_bytes() == exp
         host.verify(proof, vk)
+
+
+def test_reference_flow_acct_d8_full_size(zk, fx, oracle):
+    """BASELINE config 2 through the reference's own call sequence (prover/src/bin/main.rs:59-87) with the
+    default client: setup -> prove(..).run() -> public_values -> verify, at full parameters (100 queries,
+    16 proof-of-work bits).  The proof is the machine proof of the 391 400-cycle precompile-shape run
+    (CPU chip 2^19 x 322): byte-identical to the oracle's, accepted by a host-only verifier, every
+    tampered region rejected, and another public value cannot be attached."""
+    client = zk.ProverClient(device=0)
+    pk, vk = client.setup(zk.merkle_elf())
+    inp = fx.acct_fixture(8)
+    stdin = zk.SP1Stdin()
+    stdin.write(inp.to_borsh())
+    trace = client.machine_trace(pk, stdin)
+    proof = client.prove(pk, stdin).run()
+    assert proof.public_values == fx.ACCOUNT_VALUE
+    client.verify(proof, vk)
+    raw = proof.to_bytes()
+    assert int.from_bytes(raw[4:8], "little") == 3 and int.from_bytes(raw[8:12], "little") == 19
+    assert raw == oracle.machine_prove(trace)
+    host = zk.ProverClient(device=-1)
+    host.verify(zk.SP1ProofWithPublicValues.from_bytes(raw), vk)
+    rng = np.random.default_rng(3)
+    for pos in [9 * 4, 10 * 4, 11 * 4 + 1, 35 * 4 + 5, 35 * 4 + 72 + 3] + [int(x) for x in rng.integers(35 * 4 + 72, len(raw), 12)]:
+        bad = bytearray(raw)
+        bad[pos] ^= 1
+        with pytest.raises(zk.ZkspError):
+            host.verify(zk.SP1ProofWithPublicValues.from_bytes(bytes(bad)), vk)
+
+
+def test_as_committed_instruction_stream(zk, fx):
+    """The guest exactly as committed (software keccak, no precompile): 359 949 cycles for the depth-2
+    transaction proof, all of them in the CPU chip (2^19 rows), keccak chips empty."""
+    client = zk.ProverClient(device=0, keccak_mode=zk.KECCAK_OBSERVE, num_queries=20, pow_bits=8)
+    pk, vk = client.setup(zk.merkle_elf())
+    inp = fx.tx_fixture()
+    stdin = zk.SP1Stdin()
+    stdin.write(inp.to_borsh())
+    proof = client.prove(pk, stdin).run()
+    from oracle import verify_merkle_proof
+    assert proof.public_values == verify_merkle_proof(inp.root_hash, inp.proof, inp.key)
+    zk.ProverClient(device=-1, keccak_mode=zk.KECCAK_OBSERVE, num_queries=20, pow_bits=8).verify(proof, vk)
+    # the precompile-shape key is another program: it must not accept this proof
+    other = zk.ProverClient(device=-1, num_queries=20, pow_bits=8)
+    _, vk2 = other.setup(zk.merkle_elf())
+    with pytest.raises(zk.ZkspError):
+        other.verify(proof, vk2)
+
+
+def test_batch_of_machine_proofs(zk, fx, oracle):
+    """Several guest runs proven in lockstep (prove_batch): mixed heights fall into separate groups, every
+    proof verifies, one proof of the largest group equals the oracle's bytes."""
+    nq, pw = 6, 5
+    client = zk.ProverClient(device=0, num_queries=nq, pow_bits=pw, max_batch=4)
+    pk, vk = client.setup(zk.merkle_elf())
+    inputs = [fx.acct_fixture(1, seed=s) for s in range(1, 7)] + [fx.tx_fixture(), fx.slot_fixture(0)]
+    stdins = []
+    for m in inputs:
+        s = zk.SP1Stdin()
+        s.write(m.to_borsh())
+        stdins.append(s)
+    s3 = zk.SP1Stdin()
+    s3.write(inputs[3].to_borsh())
+    trace3 = client.machine_trace(pk, s3)
+    proofs, status = client.prove_batch(pk, stdins)
+    assert status == [0] * len(inputs)
+    from oracle import verify_merkle_proof
+    for m, p in zip(inputs, proofs):
+        assert p.public_values == verify_merkle_proof(m.root_hash, m.proof, m.key)
+        client.verify(p, vk)
+    assert proofs[3].to_bytes() == oracle.machine_prove(trace3, num_queries=nq, pow_bits=pw)

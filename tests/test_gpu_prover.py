@@ -122,9 +122,10 @@ def test_device_prover_matches_oracle_large_batch(zk, oracle, logh, n):
 
 
 def test_end_to_end_acct_d8(zk, fx, oracle):
-    """BASELINE config 2 through the reference-shaped flow (prover/src/bin/main.rs:59-87),
-    proof bytes identical to the oracle's, verifier accepts, tampering rejected."""
-    client = zk.ProverClient(device=0)
+    """The keccak-chip component proof (format v2, proof_mode KECCAK_CHIP) through the reference-shaped
+    flow: proof bytes identical to the oracle's, verifier accepts, tampering rejected.  The full statement
+    (machine proof, the default mode) is tests/test_gpu_machine.py."""
+    client = zk.ProverClient(device=0, proof_mode=zk.PROOF_KECCAK_CHIP)
     pk, vk = client.setup(zk.merkle_elf())
     inp = fx.acct_fixture(8)
     stdin = zk.SP1Stdin()

@@ -10,6 +10,7 @@
 #include "../../../include/zksp.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cstdlib>
 #include <cstdio>
@@ -22,6 +23,8 @@
 #include <thread>
 
 #include "api_types.hpp"
+#include "machine_defs.hpp"
+#include "mprover.hpp"
 #include "prover.hpp"
 
 using namespace zksp;
@@ -92,9 +95,86 @@ void parallel_for(size_t count, unsigned max_threads, const std::function<void(s
 
 extern "C" {
 
+// Machine proofs (the full statement): trace every guest run on the host threads, group runs of equal chip
+// heights, prove each group in lockstep on the GPU, wrap the bodies into proof objects.
+static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdins, size_t n, zksp_proof** out,
+                               int32_t* status) {
+  Context* ctx = &c->ctx;
+  for (size_t i = 0; i < n; ++i) { out[i] = nullptr; status[i] = ZKSP_ERR_INVALID_ARG; }
+  std::vector<std::unique_ptr<zksp_mtrace>> traces(n);
+  parallel_for(n, 64, [&](size_t i) {
+    if (!stdins[i]) return;
+    try {
+      traces[i].reset(new zksp_mtrace());
+      traces[i]->prog = &pk->mprog;
+      trace_execute(pk->elf, pk->mprog, stdins[i]->entries, (uint64_t)1 << 21, &traces[i]->t);
+      stdins[i]->entries.clear();  // consumed, as SP1Stdin is by prove()
+    } catch (...) {
+      traces[i].reset(new zksp_mtrace());
+      traces[i]->t.rec.error = "out of memory while tracing the guest";
+    }
+  });
+  std::string first_err;
+  std::map<std::array<int, mach::kNumChips>, std::vector<size_t>> groups;
+  for (size_t i = 0; i < n; ++i) {
+    if (!stdins[i] || !traces[i]) continue;
+    const ExecutionRecord& r = traces[i]->t.rec;
+    if (!r.error.empty() || !r.halted) {
+      status[i] = ZKSP_ERR_EXECUTOR;
+      if (first_err.empty()) first_err = "executor: " + (r.error.empty() ? std::string("guest did not halt") : r.error);
+      continue;
+    }
+    if (r.exit_code != 0) {
+      status[i] = ZKSP_ERR_GUEST_PANIC;
+      if (first_err.empty()) first_err = "guest panicked (exit code " + std::to_string(r.exit_code) + "): " + r.stderr_text;
+      continue;
+    }
+    std::array<int, mach::kNumChips> lh;
+    machine_heights(pk->mprog, traces[i]->t, lh.data());
+    groups[lh].push_back(i);
+  }
+  int rc_all = ZKSP_OK;
+  for (auto& kv : groups) {
+    // bytes of HBM one proof of these heights needs (traces, coefficients, LDEs of the three rounds, scratch)
+    size_t per_proof = 0;
+    for (int ch = 0; ch < mach::kNumChips; ++ch) {
+      const mach::ChipDef& d = mach::chip_def(ch);
+      per_proof += ((size_t)(d.main_w + d.perm_width() + 8) * 16 + 64) << kv.first[ch];
+    }
+    const size_t cap = std::max<size_t>(1, std::min<size_t>(ctx->params.max_batch, ((size_t)150 << 30) / std::max<size_t>(per_proof, 1)));
+    for (size_t off = 0; off < kv.second.size(); off += cap) {
+      const size_t cnt = std::min(cap, kv.second.size() - off);
+      std::vector<const MachineTrace*> ts(cnt);
+      for (size_t j = 0; j < cnt; ++j) ts[j] = &traces[kv.second[off + j]]->t;
+      int rc = machine_load(ctx, pk->mprog, pk->mvk, ts.data(), cnt);
+      if (rc == ZKSP_OK) rc = machine_prove_resident(ctx);
+      const size_t bw = ctx->mws ? ctx->mws->body_words : 0;
+      std::vector<uint32_t> bodies(rc == ZKSP_OK ? cnt * bw : 0);
+      if (rc == ZKSP_OK &&
+          (hipMemcpyAsync(bodies.data(), ctx->mws->body, bodies.size() * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+           hipStreamSynchronize(ctx->stream) != hipSuccess))
+        rc = ctx->fail(ZKSP_ERR_HIP, "prove: device-to-host copy failed");
+      for (size_t j = 0; j < cnt; ++j) {
+        const size_t i = kv.second[off + j];
+        if (rc != ZKSP_OK) { status[i] = rc; rc_all = rc; continue; }
+        const int prc = zksp_machine_proof_from_body(pk, traces[i].get(), bodies.data() + j * bw, bw, &out[i]);
+        status[i] = prc;
+      }
+    }
+  }
+  if (!first_err.empty() && rc_all == ZKSP_OK) ctx->error = first_err;
+  return rc_all;
+}
+
 static int prove_batch_impl(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdins, size_t n, zksp_proof** out,
                             int32_t* status) {
   if (!c || !pk || !stdins || !out || !status || n == 0) return ZKSP_ERR_INVALID_ARG;
+  if (c->ctx.params.proof_mode == ZKSP_PROOF_MACHINE) {
+    if (!c->ctx.has_device())
+      return c->ctx.fail(ZKSP_ERR_NO_DEVICE, "prove: this client was created without a GPU; there is no CPU proving path");
+    if (hipSetDevice(c->ctx.device) != hipSuccess) return c->ctx.fail(ZKSP_ERR_HIP, "prove: hipSetDevice failed");
+    return prove_batch_machine(c, pk, stdins, n, out, status);
+  }
   Context* ctx = &c->ctx;
   if (!ctx->has_device())
     return ctx->fail(ZKSP_ERR_NO_DEVICE, "prove: this client was created without a GPU; there is no CPU proving path");

@@ -26,6 +26,9 @@ def shard_indices(n_total: int, rank: int, world: int) -> List[int]:
 def trace_root_of(proof_bytes: bytes) -> np.ndarray:
     """The 8-word main-trace commitment of a serialized proof (first body words)."""
     words = np.frombuffer(proof_bytes, dtype="<u4")
+    if int(words[1]) == 3:  # machine proof: 35 header words (7 chip heights), public values, then the main root
+        off = 35 + (int(words[10]) + 3) // 4
+        return words[off:off + 8].copy()
     n_perms, pv_len = int(words[3]), int(words[5])
     off = 30 + (pv_len + 3) // 4 + 100 * n_perms  # fixed header, public values, public I/O list
     return words[off:off + 8].copy()
