@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
 """Headline benchmark: Ethereum-MPT STARK proofs/sec on MI355X (BASELINE.json).
 
-One "step" = one pass of the device hot path over one resident batch of synthetic
-acct-d8 proofs (BASELINE configs[1]: single account-trie proof, 62 keccak-f
-permutations -> keccak chip of height 2^11 x 2633 columns): trace generation ->
-LDE -> Poseidon2 Merkle commitments -> quotient -> openings -> FRI -> proof bytes
-in HBM, Fiat-Shamir on the device, no host round trip.  Inputs (keccak-f states +
-transcript headers, produced once by the host executor from the committed guest
-ELF) are resident in HBM before the timed region.
+One "step" = one pass of the device hot path over one resident batch of synthetic acct-d8 proofs
+(BASELINE configs[1]: single account-trie proof, depth 8).  A proof is the MACHINE proof of the
+committed sp1-merkle-proof guest in the keccak-precompile shape: 391 400 RV32IM cycles in a
+2^19 x 322 CPU chip, 62 keccak-f permutations in a 2^11 x 2634 keccak chip, keccak-memory,
+memory-boundary, image, program and multiplier chips, joined by LogUp buses -- i.e. the statement
+the reference's client.prove() establishes, not a component.  The step runs trace expansion ->
+LDE -> Poseidon2 mixed-height Merkle commitments -> LogUp -> quotients -> openings -> FRI -> proof
+bytes in HBM, Fiat-Shamir on the device, no host round trip.  The executor's records (48 bytes per
+cycle) are resident in HBM before the timed region.
 
     python bench.py --gpus N --steps K --warmup W [--batch B]
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); every rank
-proves its own B proofs (weak scaling, no data-path collective) and the ranks
-all-gather the 32-byte trace commitments once at the end of the timed region.
-Rank 0 prints ONE JSON line.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); `python bench.py --gpus N`
+starts its own ranks.  Every rank proves its own B proofs (weak scaling, no data-path collective)
+and the ranks all-gather the 32-byte main-trace commitments once at the end of the timed region.
+Rank 0 prints ONE JSON line.  Sampled proofs of the last timed step are verified on the host and
+one is compared byte for byte with the CPU oracle; a mismatch fails the benchmark.
 """
 import argparse
 import ctypes as C
@@ -31,72 +34,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable)
-TRACE_WIDTH = 2633
-LOG_H = 11
 
-
-def init_obs(vk_words, logh, n_perms, exit_code, pv_digest, deferred):
-    o = list(vk_words) + [logh, n_perms, exit_code & 0xFFFF, exit_code >> 16]
-    for w in pv_digest:
-        o += [w & 0xFFFF, w >> 16]
-    for w in deferred:
-        o += [w & 0xFFFF, w >> 16]
-    return o
-
-
-def measured_hbm_traffic(batch):
-    """HBM bytes per launch of leaf_hash_trace_kernel from the committed rocprofv3 PMC
-    collection (profiles/collect_r01.sh: FETCH_SIZE and WRITE_SIZE in separate passes,
-    KB units; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None
-    when no collection for this batch size is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_counters.json")
-    try:
-        d = json.load(open(path))
-        if int(d.get("batch", 64)) != batch:
-            return None
-        fetch = d["FETCH_SIZE"]["zksp::leaf_hash_trace_kernel"][0]
-        write = d["WRITE_SIZE"]["zksp::leaf_hash_trace_kernel"][0]
-        return (2.0 * fetch + write) * 1024.0
-    except (OSError, KeyError, ValueError):
-        return None
-
-
-def measured_valu_issue(batch, perms_per_launch):
-    """Vector-ALU instruction counts of leaf_hash_trace_kernel from the committed rocprofv3 PMC
-    collection (profiles/pmc_valu.sh -> profiles/r01_valu_counters.json): instructions per
-    permutation per lane and SIMD cycles per instruction.  The kernel is bound by instruction
-    issue, whose cost depends on the opcode, so this is evidence to read
-    against that cost model, not a utilisation fraction.  Not measured live: None when no
-    collection for this batch size is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_valu_counters.json")
-    try:
-        d = json.load(open(path))
-        if int(d.get("batch", 0)) != batch:
-            return None
-        k = d["kernels"]["zksp::leaf_hash_trace_kernel"]
-        return {"valu_insts_per_permutation_per_lane": k["SQ_INSTS_VALU"] * 64.0 / perms_per_launch,
-                "simd_cycles_per_valu_inst": k["cycles_per_valu_inst"],
-                "source": "profiles/r01_valu_counters.json (SQ_INSTS_VALU, GRBM_GUI_ACTIVE; committed collection, not live)"}
-    except (OSError, KeyError, ValueError, ZeroDivisionError):
-        return None
-
-
-def alu_roofline(lib, h, perms_per_launch, launch_ms):
-    peak = C.c_double()
-    if lib.zksp_hip_microbench(h, 5 + 8, C.byref(peak)) != 0:
-        return None
-    achieved = perms_per_launch / (launch_ms * 1e-3) / 1e9
-    # The microbenchmark is a comparator measured in this process, not a hardware ceiling: it is
-    # the same permutation in a register-resident loop, so clock and occupancy differences between
-    # the two launches can put the ratio slightly above 1.  It is deliberately not called peak/frac.
-    return {"achieved": achieved, "microbench_rate": peak.value, "unit": "Gperm/s (Poseidon2 width 16)",
-            "ratio_to_microbench": achieved / peak.value,
-            "note": "comparator, not a ceiling: standalone register-resident Poseidon2 loop, same process"}
+# chip widths of the machine proof (zk-state-proofs_amd/csrc/device/air_machine.cuh): (preprocessed, main, permutation)
+CHIPS = [("cpu", 0, 322, 32), ("keccak", 0, 2634, 104), ("keccak-mem", 0, 38, 12), ("mem-final", 0, 70, 8),
+         ("image", 3, 1, 8), ("program", 10, 1, 8), ("mul", 0, 161, 8)]
 
 
 def usable_cores():
-    """CPU share of this process: affinity mask capped by the cgroup quota and by the
-    GPU box's stated per-GPU share (16)."""
+    """CPU share of this process: affinity mask capped by the cgroup quota and by the GPU box's stated
+    per-GPU share (16)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -107,73 +53,124 @@ def usable_cores():
     return max(1, min(n, int(os.environ.get("ZKSP_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(states, vk_words, pv, seconds=10.0):
-    """Times the oracle's whole-proof CPU restatement ("port") on this host: at least five
-    repetitions and `seconds` of work; value = proofs / elapsed, median and min per proof beside it
-    (SURVEY.md section 8d)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle
-    oracle.build()
-    pvd = [int(x) for x in np.frombuffer(hashlib.sha256(pv).digest(), dtype=np.uint32)]
-    cores = usable_cores()
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    oracle.prove(states, LOG_H, public_values=pv, pv_digest=pvd, vk_digest=vk_words)  # untimed: page-in, thread pool
-    times, t0 = [], time.perf_counter()
-    while True:
-        t1 = time.perf_counter()
-        oracle.prove(states, LOG_H, public_values=pv, pv_digest=pvd, vk_digest=vk_words)
-        times.append(time.perf_counter() - t1)
-        el = time.perf_counter() - t0
-        if el >= seconds and len(times) >= 5:
-            break
-    n = len(times)
-    med = sorted(times)[n // 2]
-    return {"value": n / el, "unit": "proofs/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
-            "repetitions": n, "median_s_per_proof": med, "min_s_per_proof": min(times),
-            "sample": f"{n} acct-d8 keccak-chip proofs (62 keccak-f perms, 2^11 x 2633 trace) in {el:.1f} s; reference "
-                      "SP1 CPU prover unavailable offline, CPU baseline is this repository's oracle/ restatement"}
+def stage_bytes(heights):
+    """Algorithmic HBM bytes per proof of every stage (SURVEY.md section 8d formulas, this build's widths):
+    a stage reads its inputs once and writes its outputs once."""
+    out = {k: 0 for k in ("m_trace", "m_lde_main", "m_leaf_main", "m_perm", "m_lde_perm", "m_quotient", "m_lde_quot",
+                          "m_open", "m_reduce")}
+    for (name, p, w, e), lh in zip(CHIPS, heights):
+        h = 1 << lh
+        out["m_trace"] += 4 * h * w
+        out["m_lde_main"] += 4 * h * w * 4                      # read H, write coefficients H, write LDE 2H
+        out["m_leaf_main"] += 4 * 2 * h * w + 32 * 2 * h        # read every LDE cell once, one digest per row
+        out["m_perm"] += 4 * h * (p + w) + 4 * h * e
+        out["m_lde_perm"] += 4 * h * e * 4
+        out["m_quotient"] += 4 * 2 * h * (p + w + e) + 4 * 8 * h
+        out["m_lde_quot"] += 4 * h * 8 * 4
+        out["m_open"] += 4 * h * (p + w + e + 8)
+        out["m_reduce"] += 4 * 2 * h * (p + w + e + 8) + 16 * 2 * h
+    return out
 
 
-def verify_resident_batch(zk, lib, h, vk, vk_words, states, n_perms, pv, pvd, B, with_oracle, n_check=6):
-    """Fetches the bodies the last timed step left in HBM, wraps `n_check` of them (spread over the
-    batch) into complete proofs and verifies them on the host; optionally compares one with the CPU
-    oracle's proof bytes.  Raises on any mismatch."""
-    bw = lib.zksp_proof_body_words(h, LOG_H)
+def verify_resident_batch(zk, client, pk, vk, handles, traces, with_oracle, n_check=4):
+    """Fetches the bodies the last timed step left in HBM, completes `n_check` of them (spread over the
+    batch) into proofs and verifies them on the host; optionally compares one with the CPU oracle's
+    bytes.  Raises on any mismatch."""
+    lib, h = client._lib, client._h
+    B = len(handles)
+    lh = (C.c_int32 * 7)(*handles[0].heights())
+    bw = lib.zksp_machine_body_words(h, lh)
     bodies = np.zeros((B, bw), np.uint32)
-    rc = lib.zksp_hip_fetch_bodies(h, bodies.ctypes.data_as(C.c_void_p), bodies.size)
+    rc = lib.zksp_hip_machine_fetch_bodies(h, bodies.ctypes.data_as(C.c_void_p), bodies.size)
     if rc:
-        raise RuntimeError(f"fetch_bodies rc={rc}")
+        raise RuntimeError(f"fetch_bodies rc={rc}: {client.last_error()}")
     host = zk.ProverClient(device=-1)
     idx = sorted({int(round(k * (B - 1) / max(1, n_check - 1))) for k in range(n_check)})
     for i in idx:
-        proof = zk.proof_from_body(bodies[i], LOG_H, states[i, :n_perms[i]], 0, pv, pvd, [0] * 8, vk_words)
-        if proof.public_values != pv:
+        proof = handles[i].proof_from_body(pk, bodies[i])
+        if proof.public_values != traces[i]:
             raise RuntimeError(f"bench: proof {i} carries wrong public values")
         host.verify(proof, vk)  # raises VerificationError
-    oracle_equal = None
+    oracle_equal, oracle_s = None, None
     if with_oracle:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle
         oracle.build()
         i = idx[len(idx) // 2]
-        exp = oracle.prove(states[i, :n_perms[i]], LOG_H, public_values=pv, pv_digest=pvd, vk_digest=vk_words)
-        got = zk.proof_from_body(bodies[i], LOG_H, states[i, :n_perms[i]], 0, pv, pvd, [0] * 8, vk_words).to_bytes()
-        if got != exp:
+        t0 = time.perf_counter()
+        exp = oracle.machine_prove(with_oracle(i))
+        oracle_s = time.perf_counter() - t0
+        if handles[i].proof_from_body(pk, bodies[i]).to_bytes() != exp:
             raise RuntimeError(f"bench: proof {i} of the timed batch differs from the CPU oracle's bytes")
         oracle_equal = i
-    return {"verified_indices": idx, "oracle_byte_equal_index": oracle_equal}
+    return {"verified_indices": idx, "oracle_byte_equal_index": oracle_equal, "proof_bytes": int(bw * 4 + 35 * 4 + 72)}, oracle_s
+
+
+def cpu_baseline(trace_of, first_s, seconds):
+    """The oracle's whole machine-proof CPU restatement ("port") on this host, OpenMP over the granted
+    cores.  One acct-d8 proof is 10-60 s of CPU work, so the sample is bounded: repetitions until
+    `seconds` have passed (at least one beyond the run the verification step already timed)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    times = [first_s] if first_s else []
+    t0 = time.perf_counter()
+    while not times or (sum(times) < seconds and len(times) < 5):
+        t1 = time.perf_counter()
+        oracle.machine_prove(trace_of(0))
+        times.append(time.perf_counter() - t1)
+    el = sum(times)
+    n = len(times)
+    return {"value": n / el, "unit": "proofs/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
+            "repetitions": n, "median_s_per_proof": sorted(times)[n // 2], "min_s_per_proof": min(times),
+            "sample": f"{n} acct-d8 machine proofs (391 400 cycles, 2^19 x 322 CPU chip + 6 chips, 100 queries) in {el:.1f} s; "
+                      "reference SP1 CPU prover unavailable offline, CPU baseline is this repository's oracle/ restatement"}
+
+
+def keccak_chip_component(zk, fx, client_opts, pk_elf, seconds_budget=20.0):
+    """Secondary figure kept for continuity with round 1: the keccak-chip-only proof (format v2), which
+    is NOT a proof of execution.  Batch 256, 3 timed steps."""
+    B, logh = 256, 11
+    client = zk.ProverClient(device=client_opts["device"], max_batch=B, proof_mode=zk.PROOF_KECCAK_CHIP)
+    lib, h = client._lib, client._h
+    pk, vk = client.setup(pk_elf)
+    vkw = [int(x) for x in np.frombuffer(vk.digest, dtype=np.uint32)]
+    s = zk.SP1Stdin()
+    s.write(fx.acct_fixture(8, seed=1).to_borsh())
+    st1 = client.keccak_states(pk, s)
+    rng = np.random.default_rng(9)
+    states = rng.integers(0, 2**64, (B, 62, 25), dtype=np.uint64)
+    states[0] = st1
+    pvd = [int(x) for x in np.frombuffer(hashlib.sha256(fx.ACCOUNT_VALUE).digest(), dtype=np.uint32)]
+    obs = np.zeros((B, 44), np.uint32)
+    row = vkw + [logh, 62, 0, 0]
+    for w in pvd:
+        row += [w & 0xFFFF, w >> 16]
+    row += [0] * 16
+    obs[:] = row
+    n_perms = np.full(B, 62, np.uint32)
+    if lib.zksp_hip_load_batch(h, logh, B, 62, states.ctypes.data_as(C.c_void_p), n_perms.ctypes.data_as(C.c_void_p),
+                               obs.ctypes.data_as(C.c_void_p)):
+        return None
+    lib.zksp_hip_prove_resident(h)
+    lib.zksp_hip_sync(h)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        lib.zksp_hip_prove_resident(h)
+    lib.zksp_hip_sync(h)
+    return {"value": 3 * B / (time.perf_counter() - t0), "unit": "keccak-chip proofs/s", "batch": B,
+            "note": "component only (round-1 format v2): binds keccak-f inputs to outputs, does not prove execution"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1024,
-                    help="proofs proven in lockstep per GPU per step (1024 uses 92 GB of the 288 GB; measured 3600 / 3710 / 3800 proofs/s at 256 / 512 / 1024)")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16,
+                    help="machine proofs proven in lockstep per GPU per step (about 3.2 GB of HBM each at acct-d8)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--skip-single", action="store_true", help="skip the batch-of-1 latency section (profiling runs)")
+    ap.add_argument("--skip-single", action="store_true", help="skip latency / end-to-end / component sections (profiling runs)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + ZKSP_BENCH_SAME_DEVICE=1 rehearses the N>1 path on a one-GPU box")
     args = ap.parse_args()
@@ -222,36 +219,32 @@ def main():
     B = args.batch
     client = zk.ProverClient(device=local_rank, max_batch=B)
     lib, h = client._lib, client._h
+    t_setup = time.perf_counter()
     pk, vk = client.setup(zk.merkle_elf())
-    vk_words = [int(x) for x in np.frombuffer(vk.digest, dtype=np.uint32)]
-
-    # ---- inputs: B distinct synthetic depth-8 account proofs per rank (outside the timed region) ----
-    states = np.zeros((B, 62, 25), np.uint64)
-    obs = np.zeros((B, 44), np.uint32)
-    pv = fx.ACCOUNT_VALUE
-    pvd = [int(x) for x in np.frombuffer(hashlib.sha256(pv).digest(), dtype=np.uint32)]
-    # synthetic inputs first (pure-Python trie construction, not part of the path), then the
-    # executor alone under the clock
-    inputs = [fx.acct_fixture(8, seed=1 + rank * B + i).to_borsh() for i in range(B)]
-    exec_s = 0.0
-    for i in range(B):
-        stdin = zk.SP1Stdin()
-        stdin.write(inputs[i])
-        t_exec = time.perf_counter()
-        st = client.keccak_states(pk, stdin)
-        exec_s += time.perf_counter() - t_exec
-        assert st.shape == (62, 25)
-        states[i] = st
-        obs[i] = init_obs(vk_words, LOG_H, 62, 0, pvd, [0] * 8)
-    exec_ms_per_proof = exec_s * 1e3 / B
-    n_perms = np.full(B, 62, np.uint32)
+    setup_s = time.perf_counter() - t_setup
 
     def check(rc):
         if rc:
             raise RuntimeError(f"zksp rc={rc}: {client.last_error()}")
 
-    check(lib.zksp_hip_load_batch(h, LOG_H, B, 62, states.ctypes.data_as(C.c_void_p),
-                                  n_perms.ctypes.data_as(C.c_void_p), obs.ctypes.data_as(C.c_void_p)))
+    # ---- inputs: B distinct synthetic depth-8 account proofs per rank, traced on the host (outside the timed region) ----
+    payloads = [fx.acct_fixture(8, seed=1 + rank * B + i).to_borsh() for i in range(B)]
+    handles, stdins_keep = [], []
+    exec_s = 0.0
+    for buf in payloads:
+        s = zk.SP1Stdin()
+        s.write(buf)
+        t_exec = time.perf_counter()
+        handles.append(client.machine_trace_handle(pk, s))
+        exec_s += time.perf_counter() - t_exec
+        stdins_keep.append(s)
+    heights = handles[0].heights()
+    assert all(hd.heights() == heights for hd in handles), "acct-d8 fixtures must share one height vector"
+    trace_ms_per_proof = exec_s * 1e3 / B
+    arr = (C.c_void_p * B)(*[t._h for t in handles])
+    t_load = time.perf_counter()
+    check(lib.zksp_hip_machine_load(h, pk._h, arr, B))
+    load_ms = (time.perf_counter() - t_load) * 1e3
 
     def sync():
         check(lib.zksp_hip_sync(h))
@@ -262,7 +255,7 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        check(lib.zksp_hip_prove_resident(h))
+        check(lib.zksp_hip_machine_prove(h))
     sync()
 
     lib.zksp_hip_profile_reset(h)
@@ -271,12 +264,12 @@ def main():
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        check(lib.zksp_hip_prove_resident(h))
+        check(lib.zksp_hip_machine_prove(h))
     sync()
     if dist is not None:
-        # the one exchange the path has: 32-byte trace commitments of every proof to every rank
+        # the one exchange the path has: 32-byte main-trace commitments of every proof to every rank
         local_roots = np.zeros((B, 8), np.uint32)
-        check(lib.zksp_hip_fetch_roots(h, local_roots.ctypes.data_as(C.c_void_p), local_roots.size))
+        check(lib.zksp_hip_machine_fetch_roots(h, local_roots.ctypes.data_as(C.c_void_p), local_roots.size))
         n_total = world * B
         mine = farm.shard_indices(n_total, rank, world)
         roots = farm.gather_roots(local_roots, n_total, rank, world, device=coll_device)
@@ -290,80 +283,78 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- the timed batch is checked, not just timed: sampled proofs of the LAST timed step are fetched,
-    # completed with their headers, run through the host verifier, and one is compared byte for byte with
-    # the CPU oracle.  A mismatch fails the benchmark.
-    checked = verify_resident_batch(zk, lib, h, vk, vk_words, states, n_perms, pv, pvd, B,
-                                    with_oracle=(rank == 0 and not args.no_cpu_baseline))
+    # ---- the timed batch is checked, not just timed ----
+    def trace_of(i):
+        return client.machine_trace(pk, stdins_keep[i])
 
-    # ---- dominant kernel: Poseidon2 leaf hash of the trace LDE, HIP events on the client's stream ----
+    pvs = [fx.ACCOUNT_VALUE] * B
+    checked, oracle_s = verify_resident_batch(zk, client, pk, vk, handles, pvs,
+                                              trace_of if (rank == 0 and not args.no_cpu_baseline) else None)
+
+    # ---- per-stage spans (HIP events on the client's own stream) ----
     tot, cnt = C.c_double(), C.c_uint64()
-    check(lib.zksp_hip_profile_read(h, b"leaf_hash_trace", C.byref(tot), C.byref(cnt)))
-    n_rows = 2 << LOG_H
-    alg_bytes = B * (4 * n_rows * TRACE_WIDTH + 32 * n_rows)  # read every LDE cell once, write one digest per row
-    leaf_ms = tot.value / max(1, cnt.value)
+    names = ["m_trace", "m_lde_main", "m_commit_main", "m_leaf_main", "m_perm", "m_lde_perm", "m_commit_perm", "m_quotient",
+             "m_lde_quot", "m_commit_quot", "m_open", "merkle_open", "m_reduce", "fri_commit", "fri_fold", "grind", "transcript",
+             "m_assemble"]
+    spans, launches = {}, {}
+    for name in names:
+        check(lib.zksp_hip_profile_read(h, name.encode(), C.byref(tot), C.byref(cnt)))
+        spans[name] = tot.value / args.steps
+        launches[name] = cnt.value
+    sb = stage_bytes(heights)
+    stage_gbs = {k: round(B * v / (spans[k] * 1e-3) / 1e9, 1) for k, v in sb.items() if spans.get(k)}
+    # dominant kernel: the leaf hash of the main commitment (one launch per step: mmcs_leaf_kernel over the tallest group)
+    leaf_ms = spans["m_leaf_main"]
+    leaf_group = [(w, lh) for (name, p, w, e), lh in zip(CHIPS, heights) if lh == max(heights)]
+    alg_bytes = B * sum(4 * (2 << lh) * w for w, lh in leaf_group) + B * 32 * (2 << max(heights))
     achieved = alg_bytes / (leaf_ms * 1e-3) / 1e9
-    spans = {}
-    for name in (b"keccak_trace", b"lde_trace", b"leaf_hash_trace", b"merkle_upper", b"bus_io", b"bus_trace", b"quotient", b"lde_quot",
-                 b"merkle_quot", b"open", b"merkle_open", b"reduce_openings", b"fri_commit", b"fri_fold", b"grind",
-                 b"transcript", b"assemble"):
-        check(lib.zksp_hip_profile_read(h, name, C.byref(tot), C.byref(cnt)))
-        spans[name.decode()] = round(tot.value / args.steps, 4)
+    perms = B * (2 << max(heights)) * ((sum(w for w, _ in leaf_group) + 7) // 8)
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    # ---- single-proof numbers (rank 0, after the timed region) ----
-    single_ms = e2e_ms = e2e_batch_rate = None
+    # ---- latency, end-to-end and component figures (rank 0, after the timed region) ----
+    single_ms = e2e_ms = e2e_batch_rate = component = None
     if not args.skip_single:
-        check(lib.zksp_hip_load_batch(h, LOG_H, 1, 62, states.ctypes.data_as(C.c_void_p),
-                                      n_perms.ctypes.data_as(C.c_void_p), obs.ctypes.data_as(C.c_void_p)))
-        check(lib.zksp_hip_prove_resident(h))
+        one = (C.c_void_p * 1)(handles[0]._h)
+        check(lib.zksp_hip_machine_load(h, pk._h, one, 1))
+        check(lib.zksp_hip_machine_prove(h))
         sync()
         t1 = time.perf_counter()
-        for _ in range(5):
-            check(lib.zksp_hip_prove_resident(h))
+        for _ in range(3):
+            check(lib.zksp_hip_machine_prove(h))
         sync()
-        single_ms = (time.perf_counter() - t1) * 1e3 / 5
-        one = fx.acct_fixture(8, seed=1).to_borsh()
-        # first call untimed (creates the copy stream, events and pinned staging of this client)
-        stdin = zk.SP1Stdin()
-        stdin.write(one)
-        client.verify(client.prove(pk, stdin).run(), vk)
+        single_ms = (time.perf_counter() - t1) * 1e3 / 3
         e2e = []
-        for _ in range(5):
-            stdin = zk.SP1Stdin()
-            stdin.write(one)
+        for _ in range(3):
+            s = zk.SP1Stdin()
+            s.write(payloads[0])
             t2 = time.perf_counter()
-            proof = client.prove(pk, stdin).run()
+            proof = client.prove(pk, s).run()
             e2e.append((time.perf_counter() - t2) * 1e3)
-        e2e_ms = sorted(e2e)[len(e2e) // 2]  # median of 5: guest execution, H2D, proving, D2H, proof object
+        e2e_ms = sorted(e2e)[1]  # median of 3: guest tracing, H2D, proving, D2H, proof object
         client.verify(proof, vk)
-        # the drop-in call on a whole batch: executor + H2D + proving + D2H + proof objects
-        nb = 2 * B if B >= 64 else B
-        payloads = [fx.acct_fixture(8, seed=1000 + i).to_borsh() for i in range(nb)]
+        nb = 2 * B
+        more = [fx.acct_fixture(8, seed=1000 + i).to_borsh() for i in range(nb)]
 
         def make_stdins():
             out = []
-            for buf in payloads:
+            for buf in more:
                 sdin = zk.SP1Stdin()
                 sdin.write(buf)
                 out.append(sdin)
             return out
 
-        # one untimed call first: the first use allocates the pinned staging buffers and the copy
-        # stream; the figure reported is the steady-state rate of a service that keeps its client
-        proofs, status = client.prove_batch(pk, make_stdins())
-        assert status == [0] * nb
-        del proofs
         stdins = make_stdins()
         t3 = time.perf_counter()
         proofs, status = client.prove_batch(pk, stdins)
         e2e_batch_s = time.perf_counter() - t3
         assert status == [0] * nb
         e2e_batch_rate = nb / e2e_batch_s
+        del proofs
+        component = keccak_chip_component(zk, fx, {"device": local_rank}, zk.merkle_elf())
 
     total_proofs = world * B * args.steps
     out = {
@@ -380,40 +371,44 @@ def main():
         "dtype": "u32 (BabyBear mod 2^31-2^27+1, Montgomery)",
         "data": "synthetic",
         "config": {
-            "workload": "acct-d8: depth-8 account-trie MPT proof of the committed sp1-merkle-proof guest, keccak "
-                        "precompile shape (62 keccak-f perms -> keccak chip 2^11 rows x 2633 cols, blowup 2, 100 FRI "
-                        "queries, 16 PoW bits)",
+            "workload": "acct-d8 machine proof: depth-8 account-trie MPT proof of the committed sp1-merkle-proof guest, whole "
+                        "execution proven (keccak precompile shape: 391 400 cycles -> CPU chip 2^19 x 322, keccak chip 2^11 x 2634, "
+                        "keccak-mem 2^12, mem-final 2^15, image / program 2^16, mul 2^9; LogUp buses; blowup 2, 100 FRI queries, "
+                        "16 PoW bits)",
+            "statement": "guest executed from its entry point to HALT(0) with these public values (machine proof, format v3)",
+            "chip_log_heights": heights,
             "batch_per_gpu": B,
             "proofs_per_step": world * B,
             "parallelism": f"proof-farm x{world} (independent proofs, all-gather of 32-byte roots only)",
         },
         "roofline": {
-            "kernel": "leaf_hash_trace_kernel (Poseidon2 sponge over the trace LDE rows)",
-            # bound by vector-ALU issue; achieved/peak/frac are the contractual HBM figures (algorithmic bytes
-            # over the launch time against the 8 TB/s peak), kept so that rounds stay comparable
+            "kernel": "mmcs_leaf_kernel over the CPU chip's main LDE (Poseidon2 sponge, 41 permutations per row, 2^20 rows per proof)",
+            # bound by vector-ALU issue (one Poseidon2 permutation per 32 bytes absorbed); achieved / peak / frac are the
+            # contractual HBM figures: algorithmic bytes over the launch time against the 8 TB/s peak
             "bound": "valu",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": measured_hbm_traffic(B),
+            "traffic": None,
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_ms": leaf_ms,
-            "note": "bound by vector-ALU instruction issue, not HBM (about 23 modular multiplies per byte absorbed); see DESIGN.md",
-            "valu_issue": measured_valu_issue(B, B * n_rows * ((TRACE_WIDTH + 7) // 8)),
-            # what actually binds is integer issue rate: Poseidon2 permutations/s of this kernel beside the rate of
-            # a register-resident permutation loop with no memory traffic (perm_rate_kernel, 8 workgroups/CU)
-            "alu": alu_roofline(lib, h, B * n_rows * ((TRACE_WIDTH + 7) // 8), leaf_ms),
+            "launches_per_step": launches["m_leaf_main"] / max(1, args.steps),
+            "poseidon2_gperm_per_s": perms / (leaf_ms * 1e-3) / 1e9,
         },
         "timed_batch_checked": checked,
-        "device_ms_per_step_by_stage": spans,
+        "device_ms_per_step_by_stage": {k: round(v, 3) for k, v in spans.items()},
+        "stage_algorithmic_gbs": stage_gbs,
         "single_proof_device_ms": single_ms,
         "single_proof_end_to_end_ms": e2e_ms,
-        "host_executor_ms_per_proof": exec_ms_per_proof,  # one core, keccak precompile shape (the client default)
+        "host_trace_ms_per_proof": trace_ms_per_proof,  # one core: traced execution with memory-argument bookkeeping
+        "records_h2d_ms_per_batch": load_ms,
+        "setup_s": setup_s,
         "prove_batch_end_to_end_proofs_per_s": e2e_batch_rate,
+        "keccak_chip_component": component,
     }
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(states[0], vk_words, pv, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(trace_of, oracle_s, args.cpu_seconds)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -164,6 +164,8 @@ size_t zksp_machine_body_words(const zksp_client* c, const int32_t* log_heights7
 int zksp_hip_machine_load(zksp_client* c, const zksp_pk* pk, const zksp_mtrace* const* traces, size_t n);
 int zksp_hip_machine_prove(zksp_client* c);
 int zksp_hip_machine_fetch_bodies(zksp_client* c, uint32_t* out, size_t cap_words);
+/* Only the 8-word main-trace commitment of every resident proof ([n][8]): what the proof farm all-gathers. */
+int zksp_hip_machine_fetch_roots(zksp_client* c, uint32_t* out, size_t cap_words);
 /* Complete v3 proof object from one fetched body and the trace it belongs to. */
 int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const uint32_t* body, size_t body_words,
                                  zksp_proof** out);

@@ -127,6 +127,18 @@ int zksp_hip_machine_fetch_bodies(zksp_client* c, uint32_t* out, size_t cap_word
   return ZKSP_OK;
 }
 
+int zksp_hip_machine_fetch_roots(zksp_client* c, uint32_t* out, size_t cap_words) {
+  if (!c || !out) return ZKSP_ERR_INVALID_ARG;
+  Context* ctx = &c->ctx;
+  MachineWorkspace* w = ctx->mws.get();
+  if (!w || w->n == 0) return ctx->fail(ZKSP_ERR_INVALID_ARG, "machine_fetch_roots: no batch");
+  if (cap_words < (size_t)w->n * 8) return ctx->fail(ZKSP_ERR_INVALID_ARG, "machine_fetch_roots: buffer too small");
+  // the main-trace commitment is the first 8 words of every proof body
+  ZKSP_HIP_CHECK(ctx, hipMemcpy2DAsync(out, 32, w->body, w->body_words * 4, 32, (size_t)w->n, hipMemcpyDeviceToHost, ctx->stream));
+  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return ZKSP_OK;
+}
+
 int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const uint32_t* body, size_t body_words,
                                  zksp_proof** out) {
   if (!pk || !t || !body || !out) return ZKSP_ERR_INVALID_ARG;

@@ -46,7 +46,7 @@ struct RoundMats {
 // Mixed-height commitment of one round (kernels_machine.h).  tree: [(2N - 1) * 8] words per proof with
 // N = 2 * 2^lm; inj[g]: scratch for the leaf digests of the group whose LDE has 2^g rows.
 int mmcs_commit(hipStream_t s, const RoundMats& rm, uint32_t* tree, size_t tree_bstride, uint32_t* const* inj, int batch,
-                const P2Consts* kc) {
+                const P2Consts* kc, Context* span_ctx = nullptr, const char* leaf_span = nullptr) {
   int lm = 0;
   for (int c = 0; c < kNumChips; ++c)
     if (rm.seg[c][0].width) lm = std::max(lm, rm.logh[c]);
@@ -60,7 +60,12 @@ int mmcs_commit(hipStream_t s, const RoundMats& rm, uint32_t* tree, size_t tree_
   };
   Seg segs[2 * kNumChips];
   int ns = group(logn, segs);
-  launch_mmcs_leaves(s, segs, ns, lm, tree, tree_bstride, batch, kc);
+  if (span_ctx && leaf_span) {
+    ProfileSpan sp(span_ctx, leaf_span);  // exactly one launch: the leaf layer of the tallest matrices
+    launch_mmcs_leaves(s, segs, ns, lm, tree, tree_bstride, batch, kc);
+  } else {
+    launch_mmcs_leaves(s, segs, ns, lm, tree, tree_bstride, batch, kc);
+  }
   for (int l = 1; l <= logn; ++l) {
     const size_t count = (size_t)1 << (logn - l);
     const uint32_t* injp = nullptr;
@@ -394,7 +399,7 @@ int machine_prove_resident(Context* ctx) {
   }
   {
     ProfileSpan sp(ctx, "m_commit_main");
-    mmcs_commit(s, rm[1], w->tree[1], tree_stride, w->inj[1], B, kc);
+    mmcs_commit(s, rm[1], w->tree[1], tree_stride, w->inj[1], B, kc, ctx, "m_leaf_main");
   }
   {
     ProfileSpan sp(ctx, "transcript");
