@@ -58,7 +58,9 @@ enum Bus { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_MUL, BUS_PUBC, BUS_PUB
 
 // Ctx interface:
 //   using F;  F local(int col); F next(int col); F is_first(); F is_trans(); F is_last(); F pub();
-//   F k(uint32_t montgomery_word)  (a constant);  void emit(F v)  (appends the next constraint)
+//   F k(uint32_t montgomery_word)  (a constant);  void emit(F v)  (appends the next constraint);
+//   void emit_at(int index, F v);  void set_count(int n)  (index of the next emit());
+//   F sum_prod(const F* x, const F* y, int ystep, int n)  (eval_cpu only)
 #define ZKSP_K(c) ctx.k(cmonty(c))
 
 template <class F, class Ctx>
@@ -84,205 +86,357 @@ ZKSP_HD F bool_c(F v, F one) {
   return v * (v - one);
 }
 
-template <class Ctx>
-ZKSP_HD void eval_cpu(Ctx& ctx) {
+// Constraint index space of the CPU chip (fixes which power of alpha multiplies which constraint):
+//   0..303 booleans (IS_REAL, OP[30], WR, USE2, A/B/C/M/X bits, K0..3, EQ, O0..3, SC[6], the four
+//   24-bit time differences), 304..313 row structure, 314..315 immediate operand, 316..319 add/sub,
+//   320..325 xor/or/and, 326..333 shifts, 334..339 comparisons, 340..352 next pc, 353..354 address
+//   adder, 355..360 byte offset, 361..383 loads/stores, 384..387 ecall, 388..391 access times.
+// The evaluation below walks the columns block by block (each column is read once, its block's
+// arrays die before the next block is loaded) and emits by index, so the device kernel keeps a few
+// dozen live values instead of reloading 5 000 operands per point.
+// Ctx additionally provides  F sum_prod(const F* x, const F* y, int ystep, int n) = sum x[i] * y[i * ystep].
+namespace cpuidx {
+constexpr int kBoolA = 33, kBoolB = 65, kBoolC = 97, kBoolM = 129, kBoolX = 161, kBoolK = 193, kBoolEq = 197, kBoolO = 198,
+              kBoolSc = 202, kBoolD = 208, kStruct = 304, kImm = 314, kAddSub = 316, kBitwise = 320, kShift = 326, kCmp = 334,
+              kNextPc = 340, kAddr = 353, kOff = 355, kLoadStore = 361, kEcall = 384, kTimes = 388;
+}
+
+ZKSP_HD constexpr uint32_t pow2_mod(int n) { return (uint32_t)(((uint64_t)1 << n) % kP); }
+ZKSP_HD constexpr uint32_t inv_pow2_mod(int n) {  // 2^-n mod p
+  uint64_t r = 1;
+  for (int i = 0; i < n; ++i) r = r * ((kP + 1) / 2) % kP;
+  return (uint32_t)r;
+}
+
+template <class F>
+ZKSP_HD F limb16(const F* bits, int limb) {
+  F s = bits[16 * limb + 15];
+#pragma unroll
+  for (int i = 14; i >= 0; --i) s = s.dbl() + bits[16 * limb + i];
+  return s;
+}
+template <class F>
+ZKSP_HD F byte8(const F* bits, int byte) {
+  F s = bits[8 * byte + 7];
+#pragma unroll
+  for (int i = 6; i >= 0; --i) s = s.dbl() + bits[8 * byte + i];
+  return s;
+}
+
+// The 392 constraints in four independent tasks, each reading only the column blocks it needs (a block
+// that two tasks need is read by both): the device runs a task per workgroup, so a lane holds a few
+// dozen live values instead of the whole 322-column row; the verifier runs all four in sequence.
+//   task 0  selectors, row structure, the four access-time decompositions        (scalars, D bits)
+//   task 1  A, B, C: immediate operand, add / sub, bitwise, jal / jalr link, ecall, keccak return
+//   task 2  X with A, B, C: shifts, comparisons, branches, jalr target, address adder, byte offset
+//   task 3  M with A, C: loads and stores
+constexpr int kCpuTasks = 4;
+
+template <class F, class Ctx>
+ZKSP_HD void load_bits(Ctx& ctx, int col, F* out) {
+#pragma unroll
+  for (int i = 0; i < 32; ++i) out[i] = ctx.local(col + i);
+}
+template <class F, class Ctx>
+ZKSP_HD void limbs_of_block(Ctx& ctx, int col, F* lo, F* hi) {  // streams the block: no array kept
+  F l = ctx.local(col + 15), h = ctx.local(col + 31);
+#pragma unroll
+  for (int i = 14; i >= 0; --i) {
+    l = l.dbl() + ctx.local(col + i);
+    h = h.dbl() + ctx.local(col + 16 + i);
+  }
+  *lo = l;
+  *hi = h;
+}
+
+template <int TASK, class Ctx>
+ZKSP_HD void eval_cpu_task(Ctx& ctx) {
   using F = typename Ctx::F;
-  const F one = ctx.k(kR1);
+  using namespace cpuidx;
+  const F one = ctx.k(kR1), zero = one - one;
   const F k65536 = ZKSP_K(65536);
 #define L(c) ctx.local(c)
-#define OPF(op) ctx.local(C_OP + (op) - 1)
-  // ---- booleans ----
-  ctx.emit(bool_c(L(C_IS_REAL), one));
-  for (int k = 0; k < kNumOps; ++k) ctx.emit(bool_c(L(C_OP + k), one));
-  ctx.emit(bool_c(L(C_WR), one));
-  ctx.emit(bool_c(L(C_USE2), one));
-  for (int i = 0; i < 160; ++i) ctx.emit(bool_c(L(C_A + i), one));  // A, B, C, M, X
-  for (int i = 0; i < 4; ++i) ctx.emit(bool_c(L(C_K0 + i), one));
-  ctx.emit(bool_c(L(C_EQ), one));
-  for (int i = 0; i < 4; ++i) ctx.emit(bool_c(L(C_O0 + i), one));
-  for (int i = 0; i < 6; ++i) ctx.emit(bool_c(L(C_SC + i), one));
-  for (int i = 0; i < 4 * kTsBits; ++i) ctx.emit(bool_c(L(C_R1_D + i), one));
-  // ---- row structure ----
-  const F is_real = L(C_IS_REAL), is_first = ctx.is_first(), is_trans = ctx.is_trans();
-  {
-    F opsum = L(C_OP);
-    for (int k = 1; k < kNumOps; ++k) opsum = opsum + L(C_OP + k);
-    ctx.emit(opsum - is_real);
-    ctx.emit(L(C_WR) * (one - is_real));
-    ctx.emit(L(C_USE2) * (one - is_real));
-    ctx.emit(is_first * (is_real - one));
-    ctx.emit(is_first * (L(C_PC) - ctx.pub()));
-    ctx.emit(is_first * (L(C_TS) - ZKSP_K(4)));
-    ctx.emit(is_trans * (ctx.next(C_TS) - L(C_TS) - ZKSP_K(4)));
-    ctx.emit(is_trans * ctx.next(C_IS_REAL) * (ctx.next(C_PC) - L(C_NEXT_PC)));
-    ctx.emit(is_trans * (ctx.next(C_IS_REAL) - is_real + L(C_SC + SC_HALT)));
-    F scsum = L(C_SC);
-    for (int k = 1; k < 6; ++k) scsum = scsum + L(C_SC + k);
-    ctx.emit(scsum - OPF(ECALL));
-  }
-  // ---- limbs ----
-  const F a_lo = limb_of<F>(ctx, C_A, 0), a_hi = limb_of<F>(ctx, C_A, 1), b_lo = limb_of<F>(ctx, C_B, 0),
-          b_hi = limb_of<F>(ctx, C_B, 1), c_lo = limb_of<F>(ctx, C_C, 0), c_hi = limb_of<F>(ctx, C_C, 1),
-          m_lo = limb_of<F>(ctx, C_M, 0), m_hi = limb_of<F>(ctx, C_M, 1), x_lo = limb_of<F>(ctx, C_X, 0),
-          x_hi = limb_of<F>(ctx, C_X, 1);
-  const F k0 = L(C_K0), k1 = L(C_K1), k2 = L(C_K2), k3 = L(C_K3);
-  // ---- operand C is the immediate ----
-  {
-    const F immc = is_real - L(C_USE2);
-    ctx.emit(immc * (c_lo - L(C_IMM_LO)));
-    ctx.emit(immc * (c_hi - L(C_IMM_HI)));
-  }
-  // ---- add / sub ----
-  ctx.emit(OPF(ADD) * (b_lo + c_lo - (a_lo + k65536 * k0)));
-  ctx.emit(OPF(ADD) * (b_hi + c_hi + k0 - (a_hi + k65536 * k1)));
-  ctx.emit(OPF(SUB) * (a_lo + c_lo - (b_lo + k65536 * k0)));
-  ctx.emit(OPF(SUB) * (a_hi + c_hi + k0 - (b_hi + k65536 * k1)));
-  // ---- bitwise ----
-  for (int op = XOR; op <= AND; ++op)
-    for (int h = 0; h < 2; ++h) {
-      F acc = one - one;
-      for (int i = 15; i >= 0; --i) {
-        const F b = L(C_B + 16 * h + i), c = L(C_C + 16 * h + i), bc = b * c;
-        const F bit = op == AND ? bc : op == OR ? b + c - bc : b + c - bc.dbl();
+#define OPF(o) ctx.local(C_OP + (o) - 1)
+  if (TASK == 0) {
+    const F is_real = L(C_IS_REAL);
+    ctx.emit_at(0, bool_c(is_real, one));
+    F opsum = zero, ld_st_ecall = zero;
+#pragma unroll
+    for (int k = 1; k <= kNumOps; ++k) {
+      const F o = L(C_OP + k - 1);
+      ctx.emit_at(k, bool_c(o, one));
+      opsum = opsum + o;
+      if ((k >= LB && k <= SW) || k == ECALL) ld_st_ecall = ld_st_ecall + o;
+    }
+    const F wr = L(C_WR), use2 = L(C_USE2), is_first = ctx.is_first(), is_trans = ctx.is_trans();
+    ctx.emit_at(31, bool_c(wr, one));
+    ctx.emit_at(32, bool_c(use2, one));
+    const F pc = L(C_PC), ts = L(C_TS), np = L(C_NEXT_PC);
+    F scsum = zero, sc_halt = zero;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const F v = L(C_SC + k);
+      ctx.emit_at(kBoolSc + k, bool_c(v, one));
+      scsum = scsum + v;
+      if (k == SC_HALT) sc_halt = v;
+    }
+    ctx.emit_at(kStruct + 0, opsum - is_real);
+    ctx.emit_at(kStruct + 1, wr * (one - is_real));
+    ctx.emit_at(kStruct + 2, use2 * (one - is_real));
+    ctx.emit_at(kStruct + 3, is_first * (is_real - one));
+    ctx.emit_at(kStruct + 4, is_first * (pc - ctx.pub()));
+    ctx.emit_at(kStruct + 5, is_first * (ts - ZKSP_K(4)));
+    ctx.emit_at(kStruct + 6, is_trans * (ctx.next(C_TS) - ts - ZKSP_K(4)));
+    const F nreal = ctx.next(C_IS_REAL);
+    ctx.emit_at(kStruct + 7, is_trans * nreal * (ctx.next(C_PC) - np));
+    ctx.emit_at(kStruct + 8, is_trans * (nreal - is_real + sc_halt));
+    ctx.emit_at(kStruct + 9, scsum - OPF(ECALL));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ctx.emit_at(kBoolK + i, bool_c(L(C_K0 + i), one));
+    ctx.emit_at(kBoolEq, bool_c(L(C_EQ), one));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ctx.emit_at(kBoolO + i, bool_c(L(C_O0 + i), one));
+    // access times: stream the four 24-bit differences
+    const int dcol[4] = {C_R1_D, C_R2_D, C_M_D, C_W_D};
+    F dv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      F acc = zero;
+#pragma unroll
+      for (int i = kTsBits - 1; i >= 0; --i) {
+        const F bit = L(dcol[q] + i);
+        ctx.emit_at(kBoolD + q * kTsBits + i, bool_c(bit, one));
         acc = acc.dbl() + bit;
       }
-      ctx.emit(OPF(op) * ((h ? a_hi : a_lo) - acc));
+      dv[q] = acc;
     }
-  // ---- shifts: X is the one-hot of the amount ----
-  {
-    const F sh = OPF(SLL) + OPF(SRL) + OPF(SRA);
-    F sum = L(C_X), idx = one - one;
-    for (int k = 1; k < 32; ++k) {
-      sum = sum + L(C_X + k);
-      idx = idx + ctx.k(cmonty((uint32_t)k)) * L(C_X + k);
-    }
-    ctx.emit(sh * (sum - one));
-    ctx.emit(sh * (idx - bits_val<F>(ctx, C_C, 5)));
-    for (int kind = 0; kind < 3; ++kind) {
-      const F sel = OPF(kind == 0 ? SLL : kind == 1 ? SRL : SRA);
-      for (int h = 0; h < 2; ++h) {
-        F acc = one - one;
-        for (int i = 15; i >= 0; --i) {
-          const int j = 16 * h + i;
-          F t = one - one;
-          for (int k = 0; k < 32; ++k) {
-            int src;
-            if (kind == 0) { if (k > j) continue; src = j - k; }
-            else if (kind == 1) { if (j + k > 31) continue; src = j + k; }
-            else src = j + k > 31 ? 31 : j + k;
-            t = t + L(C_X + k) * L(C_B + src);
-          }
-          acc = acc.dbl() + t;
-        }
-        ctx.emit(sel * ((h ? a_hi : a_lo) - acc));
+    ctx.emit_at(kTimes + 0, is_real * (ts - L(C_R1_PTS) - one - dv[0]));
+    ctx.emit_at(kTimes + 1, use2 * (ts - L(C_R2_PTS) - dv[1]));
+    ctx.emit_at(kTimes + 2, ld_st_ecall * (ts + one - L(C_M_PTS) - dv[2]));
+    ctx.emit_at(kTimes + 3, wr * (ts + ZKSP_K(2) - L(C_W_PTS) - dv[3]));
+  }
+  if (TASK == 1) {
+    // A, then B and C bit by bit (top bit first): limbs by Horner, the three bitwise results per half
+    F a_lo = zero, a_hi = zero, b_lo = zero, b_hi = zero, c_lo = zero, c_hi = zero;
+    F ax[2] = {zero, zero}, ao[2] = {zero, zero}, aa[2] = {zero, zero};
+#pragma unroll
+    for (int h = 1; h >= 0; --h) {
+      for (int i = 15; i >= 0; --i) {
+        const int col = 16 * h + i;
+        const F a = L(C_A + col), b = L(C_B + col), c = L(C_C + col);
+        ctx.emit_at(kBoolA + col, bool_c(a, one));
+        ctx.emit_at(kBoolB + col, bool_c(b, one));
+        ctx.emit_at(kBoolC + col, bool_c(c, one));
+        const F bc = b * c, sm = b + c;
+        if (h) { a_hi = a_hi.dbl() + a; b_hi = b_hi.dbl() + b; c_hi = c_hi.dbl() + c; }
+        else { a_lo = a_lo.dbl() + a; b_lo = b_lo.dbl() + b; c_lo = c_lo.dbl() + c; }
+        ax[h] = ax[h].dbl() + (sm - bc.dbl());
+        ao[h] = ao[h].dbl() + (sm - bc);
+        aa[h] = aa[h].dbl() + bc;
       }
     }
-  }
-  // ---- comparisons: X = B - C (sign bits flipped for the signed orders), K1 = "less than" ----
-  {
-    const F sgn = OPF(SLT) + OPF(BLT) + OPF(BGE);
-    const F cmp = OPF(SLT) + OPF(SLTU) + OPF(BEQ) + OPF(BNE) + OPF(BLT) + OPF(BGE) + OPF(BLTU) + OPF(BGEU);
-    ctx.emit(cmp * (b_lo - c_lo + k65536 * k0 - x_lo));
-    ctx.emit(cmp * (b_hi - c_hi - k0 + k65536 * k1 - x_hi) + k65536 * (sgn * (L(C_C + 31) - L(C_B + 31))));
-    const F bq = OPF(BEQ) + OPF(BNE), z = x_lo + x_hi;
-    ctx.emit(bq * (z * L(C_INV) - one + L(C_EQ)));
-    ctx.emit(bq * (z * L(C_EQ)));
-    const F slt = OPF(SLT) + OPF(SLTU);
-    ctx.emit(slt * (a_lo - k1));
-    ctx.emit(slt * a_hi);
-  }
-  // ---- next pc ----
-  {
-    const F pc4 = L(C_PC) + ZKSP_K(4), np = L(C_NEXT_PC), tgt = L(C_TGT);
-    const F def = is_real - OPF(JAL) - OPF(JALR) - OPF(BEQ) - OPF(BNE) - OPF(BLT) - OPF(BGE) - OPF(BLTU) - OPF(BGEU) - OPF(KECCAK);
-    ctx.emit(def * (np - pc4));
-    ctx.emit(OPF(JAL) * (np - tgt));
-    ctx.emit(OPF(JAL) * (a_lo - c_lo));
-    ctx.emit(OPF(JAL) * (a_hi - c_hi));
-    ctx.emit(OPF(JALR) * (a_lo + k65536 * a_hi - tgt));
-    ctx.emit(OPF(JALR) * (np - (x_lo + k65536 * x_hi - L(C_X))));
-    const F eq = L(C_EQ), d = tgt - pc4, base = np - pc4;
-    ctx.emit(OPF(BEQ) * (base - eq * d));
-    ctx.emit(OPF(BNE) * (base - (one - eq) * d));
-    ctx.emit(OPF(BLT) * (base - k1 * d));
-    ctx.emit(OPF(BGE) * (base - (one - k1) * d));
-    ctx.emit(OPF(BLTU) * (base - k1 * d));
-    ctx.emit(OPF(BGEU) * (base - (one - k1) * d));
-    ctx.emit(OPF(KECCAK) * (np - (b_lo + k65536 * b_hi)));
-  }
-  // ---- address adder: X = B + imm ----
-  const F loads = OPF(LB) + OPF(LH) + OPF(LW) + OPF(LBU) + OPF(LHU), stores = OPF(SB) + OPF(SH) + OPF(SW);
-  {
-    const F ad = loads + stores + OPF(JALR);
-    ctx.emit(ad * (b_lo + L(C_IMM_LO) - (x_lo + k65536 * k2)));
-    ctx.emit(ad * (b_hi + L(C_IMM_HI) + k2 - (x_hi + k65536 * k3)));
-  }
-  // ---- byte offset one-hot ----
-  const F o0 = L(C_O0), o1 = L(C_O1), o2 = L(C_O2), o3 = L(C_O3);
-  {
-    const F ls = loads + stores;
-    ctx.emit(ls * (o0 + o1 + (o2 + o3) - one));
-    ctx.emit(ls * (o1 + o2.dbl() + ZKSP_K(3) * o3 - (L(C_X) + L(C_X + 1).dbl())));
-    ctx.emit(OPF(ECALL) * (o0 - one));
-    ctx.emit(OPF(ECALL) * (o1 + o2 + o3));
-    ctx.emit(OPF(ECALL) * (x_lo - ZKSP_K(11)));
-    ctx.emit(OPF(ECALL) * x_hi);
-  }
-  // ---- loads and stores ----
-  {
-    const F mb[4] = {byte_of<F>(ctx, C_M, 0), byte_of<F>(ctx, C_M, 1), byte_of<F>(ctx, C_M, 2), byte_of<F>(ctx, C_M, 3)};
-    const F k65535 = ZKSP_K(65535);
-    ctx.emit(OPF(LW) * (o0 - one));
-    ctx.emit(OPF(LW) * (a_lo - m_lo));
-    ctx.emit(OPF(LW) * (a_hi - m_hi));
-    const F hv = o0 * m_lo + o2 * m_hi, hs = o0 * L(C_M + 15) + o2 * L(C_M + 31);
-    ctx.emit(OPF(LHU) * (o1 + o3));
-    ctx.emit(OPF(LHU) * (a_lo - hv));
-    ctx.emit(OPF(LHU) * a_hi);
-    ctx.emit(OPF(LH) * (o1 + o3));
-    ctx.emit(OPF(LH) * (a_lo - hv));
-    ctx.emit(OPF(LH) * (a_hi - k65535 * hs));
-    F bv = one - one, bs = one - one;
-    for (int p = 0; p < 4; ++p) {
-      bv = bv + L(C_O0 + p) * mb[p];
-      bs = bs + L(C_O0 + p) * L(C_M + 8 * p + 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const F al = h ? a_hi : a_lo;
+      ctx.emit_at(kBitwise + 0 + h, OPF(XOR) * (al - ax[h]));
+      ctx.emit_at(kBitwise + 2 + h, OPF(OR) * (al - ao[h]));
+      ctx.emit_at(kBitwise + 4 + h, OPF(AND) * (al - aa[h]));
     }
-    ctx.emit(OPF(LBU) * (a_lo - bv));
-    ctx.emit(OPF(LBU) * a_hi);
-    ctx.emit(OPF(LB) * (a_lo - (bv + ZKSP_K(0xff00) * bs)));
-    ctx.emit(OPF(LB) * (a_hi - k65535 * bs));
-    const F keep = loads + OPF(ECALL);
-    ctx.emit(keep * (L(C_MV_LO) - m_lo));
-    ctx.emit(keep * (L(C_MV_HI) - m_hi));
-    ctx.emit(OPF(SW) * (o0 - one));
-    ctx.emit(OPF(SW) * (L(C_MV_LO) - c_lo));
-    ctx.emit(OPF(SW) * (L(C_MV_HI) - c_hi));
-    ctx.emit(OPF(SH) * (o1 + o3));
-    ctx.emit(OPF(SH) * (L(C_MV_LO) - m_lo - o0 * (c_lo - m_lo)));
-    ctx.emit(OPF(SH) * (L(C_MV_HI) - m_hi - o2 * (c_lo - m_hi)));
-    const F cb = byte_of<F>(ctx, C_C, 0), k256 = ZKSP_K(256);
-    ctx.emit(OPF(SB) * (L(C_MV_LO) - m_lo - (o0 * (cb - mb[0]) + k256 * (o1 * (cb - mb[1])))));
-    ctx.emit(OPF(SB) * (L(C_MV_HI) - m_hi - (o2 * (cb - mb[2]) + k256 * (o3 * (cb - mb[3])))));
-  }
-  // ---- ecall ----
-  {
+    const F k0 = L(C_K0), k1 = L(C_K1);
+    const F immc = L(C_IS_REAL) - L(C_USE2);
+    ctx.emit_at(kImm + 0, immc * (c_lo - L(C_IMM_LO)));
+    ctx.emit_at(kImm + 1, immc * (c_hi - L(C_IMM_HI)));
+    ctx.emit_at(kAddSub + 0, OPF(ADD) * (b_lo + c_lo - (a_lo + k65536 * k0)));
+    ctx.emit_at(kAddSub + 1, OPF(ADD) * (b_hi + c_hi + k0 - (a_hi + k65536 * k1)));
+    ctx.emit_at(kAddSub + 2, OPF(SUB) * (a_lo + c_lo - (b_lo + k65536 * k0)));
+    ctx.emit_at(kAddSub + 3, OPF(SUB) * (a_hi + c_hi + k0 - (b_hi + k65536 * k1)));
+    const F slt = OPF(SLT) + OPF(SLTU);
+    ctx.emit_at(kCmp + 4, slt * (a_lo - k1));
+    ctx.emit_at(kCmp + 5, slt * a_hi);
+    const F np = L(C_NEXT_PC), tgt = L(C_TGT);
+    ctx.emit_at(kNextPc + 2, OPF(JAL) * (a_lo - c_lo));
+    ctx.emit_at(kNextPc + 3, OPF(JAL) * (a_hi - c_hi));
+    ctx.emit_at(kNextPc + 4, OPF(JALR) * (a_lo + k65536 * a_hi - tgt));
+    ctx.emit_at(kNextPc + 12, OPF(KECCAK) * (np - (b_lo + k65536 * b_hi)));
     const F code = ZKSP_K(0x02) * L(C_SC + SC_WRITE) + ZKSP_K(0x10) * L(C_SC + SC_COMMIT) + ZKSP_K(0x1a) * L(C_SC + SC_DEFER) +
                    ZKSP_K(0xf0) * L(C_SC + SC_HINT_LEN) + ZKSP_K(0xf1) * L(C_SC + SC_HINT_READ);
-    ctx.emit(OPF(ECALL) * (b_lo - code));
-    ctx.emit(OPF(ECALL) * b_hi);
+    ctx.emit_at(kEcall + 0, OPF(ECALL) * (b_lo - code));
+    ctx.emit_at(kEcall + 1, OPF(ECALL) * b_hi);
     const F same = OPF(ECALL) - L(C_SC + SC_HINT_LEN);
-    ctx.emit(same * (a_lo - b_lo));
-    ctx.emit(same * (a_hi - b_hi));
+    ctx.emit_at(kEcall + 2, same * (a_lo - b_lo));
+    ctx.emit_at(kEcall + 3, same * (a_hi - b_hi));
   }
-  // ---- previous access times are older ----
-  {
-    const F memq = loads + stores + OPF(ECALL), ts = L(C_TS);
-    ctx.emit(is_real * (ts - L(C_R1_PTS) - one - bits_val<F>(ctx, C_R1_D, kTsBits)));
-    ctx.emit(L(C_USE2) * (ts - L(C_R2_PTS) - bits_val<F>(ctx, C_R2_D, kTsBits)));
-    ctx.emit(memq * (ts + one - L(C_M_PTS) - bits_val<F>(ctx, C_M_D, kTsBits)));
-    ctx.emit(L(C_WR) * (ts + ZKSP_K(2) - L(C_W_PTS) - bits_val<F>(ctx, C_W_D, kTsBits)));
+  if (TASK == 2) {
+    F a_lo, a_hi, c_lo, c_hi;
+    limbs_of_block<F>(ctx, C_A, &a_lo, &a_hi);
+    limbs_of_block<F>(ctx, C_C, &c_lo, &c_hi);
+    F samt = L(C_C + 4);
+#pragma unroll
+    for (int i = 3; i >= 0; --i) samt = samt.dbl() + L(C_C + i);
+    const F c31 = L(C_C + 31);
+    // X: booleans, limbs, one-hot sums.  Shifts through the prefix values P_n = sum_{i<n} 2^i b_i of B:
+    //   sll  lo = sum_{k<16} x_k 2^k P_{16-k}               hi = sum_k x_k 2^(k-16) (P_{32-k} - P_{max(16-k,0)})
+    //   srl  lo = sum_k x_k 2^-k (P_{min(16+k,32)} - P_k)    hi = sum_{k<16} x_k 2^-(16+k) (P_32 - P_{16+k})
+    //   sra  = srl + b_31 sum_k x_k * (the 1-bits shifted in)
+    // (the polynomials sum_j 2^j sum_k x_k b_{j -+ k} regrouped: 200 products instead of 2 100).  One loop over k
+    // carries the four prefix values and the powers of two by recurrence, so nothing is indexed out of an array.
+    F p16 = zero, p32 = zero, b31 = zero;
+    {
+      F pw = one;
+      for (int i = 0; i < 32; ++i) {
+        const F bi = L(C_B + i);
+        p32 = p32 + pw * bi;
+        if (i == 15) p16 = p32;
+        if (i == 31) b31 = bi;
+        pw = pw.dbl();
+      }
+    }
+    const F inv2 = ctx.k(cmonty(inv_pow2_mod(1))), inv2_16 = ctx.k(cmonty(inv_pow2_mod(16)));
+    const F b_lo = p16, b_hi = (p32 - p16) * inv2_16;
+    F sum = zero, idx = zero, x_lo = zero, x_hi = zero, x0 = zero, x1 = zero;
+    F sll_lo = zero, sll_hi = zero, srl_lo = zero, srl_hi = zero, fill_lo = zero, fill_hi = zero;
+    {
+      F pa = zero, pb = p16, pc = p16, pd = p32;        // P_k, P_min(16+k,32), P_max(16-k,0), P_(32-k)
+      F pw = one, ipw = one, kf = zero;                  // 2^k, 2^-k, k
+      F d15 = ctx.k(cmonty(pow2_mod(15))), d31 = ctx.k(cmonty(pow2_mod(31)));  // 2^(15-k), 2^(31-k)
+      for (int k = 0; k < 32; ++k) {
+        const F xk = L(C_X + k);
+        ctx.emit_at(kBoolX + k, bool_c(xk, one));
+        sum = sum + xk;
+        idx = idx + kf * xk;
+        if (k == 0) x0 = xk;
+        if (k == 1) x1 = xk;
+        if (k < 16) {
+          x_lo = x_lo + pw * xk;
+          sll_lo = sll_lo + xk * (pw * pc);
+          srl_hi = srl_hi + xk * ((p32 - pb) * (ipw * inv2_16));
+        } else {
+          x_hi = x_hi + (pw * inv2_16) * xk;
+        }
+        sll_hi = sll_hi + xk * ((pd - pc) * (pw * inv2_16));
+        srl_lo = srl_lo + xk * ((pb - pa) * ipw);
+        if (k >= 17) fill_lo = fill_lo + xk * (k65536 - d31.dbl());
+        if (k >= 16) fill_hi = fill_hi + xk * ZKSP_K(65535);
+        else if (k >= 1) fill_hi = fill_hi + xk * (k65536 - d15.dbl());
+        // step the recurrences to k + 1
+        pa = pa + pw * L(C_B + k);
+        if (k < 16) {
+          pb = pb + (pw * k65536) * L(C_B + 16 + k);
+          pc = pc - d15 * L(C_B + 15 - k);
+          d15 = d15 * inv2;
+        }
+        pd = pd - d31 * L(C_B + 31 - k);
+        d31 = d31 * inv2;
+        pw = pw.dbl();
+        ipw = ipw * inv2;
+        kf = kf + one;
+      }
+    }
+    const F sh = OPF(SLL) + OPF(SRL) + OPF(SRA);
+    ctx.emit_at(kShift + 0, sh * (sum - one));
+    ctx.emit_at(kShift + 1, sh * (idx - samt));
+    ctx.emit_at(kShift + 2, OPF(SLL) * (a_lo - sll_lo));
+    ctx.emit_at(kShift + 3, OPF(SLL) * (a_hi - sll_hi));
+    ctx.emit_at(kShift + 4, OPF(SRL) * (a_lo - srl_lo));
+    ctx.emit_at(kShift + 5, OPF(SRL) * (a_hi - srl_hi));
+    ctx.emit_at(kShift + 6, OPF(SRA) * (a_lo - (srl_lo + b31 * fill_lo)));
+    ctx.emit_at(kShift + 7, OPF(SRA) * (a_hi - (srl_hi + b31 * fill_hi)));
+    const F k0 = L(C_K0), k1 = L(C_K1), k2 = L(C_K2), k3 = L(C_K3), eq = L(C_EQ);
+    {
+      const F sgn = OPF(SLT) + OPF(BLT) + OPF(BGE);
+      const F cmp = OPF(SLT) + OPF(SLTU) + OPF(BEQ) + OPF(BNE) + OPF(BLT) + OPF(BGE) + OPF(BLTU) + OPF(BGEU);
+      ctx.emit_at(kCmp + 0, cmp * (b_lo - c_lo + k65536 * k0 - x_lo));
+      ctx.emit_at(kCmp + 1, cmp * (b_hi - c_hi - k0 + k65536 * k1 - x_hi) + k65536 * (sgn * (c31 - b31)));
+      const F bq = OPF(BEQ) + OPF(BNE), z = x_lo + x_hi;
+      ctx.emit_at(kCmp + 2, bq * (z * L(C_INV) - one + eq));
+      ctx.emit_at(kCmp + 3, bq * (z * eq));
+    }
+    {
+      const F pc4 = L(C_PC) + ZKSP_K(4), np = L(C_NEXT_PC), tgt = L(C_TGT);
+      const F def = L(C_IS_REAL) - OPF(JAL) - OPF(JALR) - OPF(BEQ) - OPF(BNE) - OPF(BLT) - OPF(BGE) - OPF(BLTU) - OPF(BGEU) - OPF(KECCAK);
+      ctx.emit_at(kNextPc + 0, def * (np - pc4));
+      ctx.emit_at(kNextPc + 1, OPF(JAL) * (np - tgt));
+      ctx.emit_at(kNextPc + 5, OPF(JALR) * (np - (x_lo + k65536 * x_hi - x0)));
+      const F d = tgt - pc4, base = np - pc4;
+      ctx.emit_at(kNextPc + 6, OPF(BEQ) * (base - eq * d));
+      ctx.emit_at(kNextPc + 7, OPF(BNE) * (base - (one - eq) * d));
+      ctx.emit_at(kNextPc + 8, OPF(BLT) * (base - k1 * d));
+      ctx.emit_at(kNextPc + 9, OPF(BGE) * (base - (one - k1) * d));
+      ctx.emit_at(kNextPc + 10, OPF(BLTU) * (base - k1 * d));
+      ctx.emit_at(kNextPc + 11, OPF(BGEU) * (base - (one - k1) * d));
+    }
+    const F loads = OPF(LB) + OPF(LH) + OPF(LW) + OPF(LBU) + OPF(LHU), stores = OPF(SB) + OPF(SH) + OPF(SW);
+    const F ad = loads + stores + OPF(JALR);
+    ctx.emit_at(kAddr + 0, ad * (b_lo + L(C_IMM_LO) - (x_lo + k65536 * k2)));
+    ctx.emit_at(kAddr + 1, ad * (b_hi + L(C_IMM_HI) + k2 - (x_hi + k65536 * k3)));
+    const F o0 = L(C_O0), o1 = L(C_O1), o2 = L(C_O2), o3 = L(C_O3), ls = loads + stores;
+    ctx.emit_at(kOff + 0, ls * (o0 + o1 + (o2 + o3) - one));
+    ctx.emit_at(kOff + 1, ls * (o1 + o2.dbl() + ZKSP_K(3) * o3 - (x0 + x1.dbl())));
+    ctx.emit_at(kOff + 2, OPF(ECALL) * (o0 - one));
+    ctx.emit_at(kOff + 3, OPF(ECALL) * (o1 + o2 + o3));
+    ctx.emit_at(kOff + 4, OPF(ECALL) * (x_lo - ZKSP_K(11)));
+    ctx.emit_at(kOff + 5, OPF(ECALL) * x_hi);
+  }
+  if (TASK == 3) {
+    F a_lo, a_hi, c_lo, c_hi;
+    limbs_of_block<F>(ctx, C_A, &a_lo, &a_hi);
+    limbs_of_block<F>(ctx, C_C, &c_lo, &c_hi);
+    F cb = L(C_C + 7);
+#pragma unroll
+    for (int i = 6; i >= 0; --i) cb = cb.dbl() + L(C_C + i);
+    F m[32];
+    load_bits(ctx, C_M, m);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) ctx.emit_at(kBoolM + i, bool_c(m[i], one));
+    const F m_lo = limb16(m, 0), m_hi = limb16(m, 1);
+    const F mb[4] = {byte8(m, 0), byte8(m, 1), byte8(m, 2), byte8(m, 3)};
+    const F mv_lo = L(C_MV_LO), mv_hi = L(C_MV_HI);
+    const F k65535 = ZKSP_K(65535), k256 = ZKSP_K(256);
+    const F o0 = L(C_O0), o1 = L(C_O1), o2 = L(C_O2), o3 = L(C_O3);
+    const F oo[4] = {o0, o1, o2, o3};
+    ctx.emit_at(kLoadStore + 0, OPF(LW) * (o0 - one));
+    ctx.emit_at(kLoadStore + 1, OPF(LW) * (a_lo - m_lo));
+    ctx.emit_at(kLoadStore + 2, OPF(LW) * (a_hi - m_hi));
+    const F hv = o0 * m_lo + o2 * m_hi, hs = o0 * m[15] + o2 * m[31];
+    ctx.emit_at(kLoadStore + 3, OPF(LHU) * (o1 + o3));
+    ctx.emit_at(kLoadStore + 4, OPF(LHU) * (a_lo - hv));
+    ctx.emit_at(kLoadStore + 5, OPF(LHU) * a_hi);
+    ctx.emit_at(kLoadStore + 6, OPF(LH) * (o1 + o3));
+    ctx.emit_at(kLoadStore + 7, OPF(LH) * (a_lo - hv));
+    ctx.emit_at(kLoadStore + 8, OPF(LH) * (a_hi - k65535 * hs));
+    F bv = zero, bs = zero;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      bv = bv + oo[p] * mb[p];
+      bs = bs + oo[p] * m[8 * p + 7];
+    }
+    ctx.emit_at(kLoadStore + 9, OPF(LBU) * (a_lo - bv));
+    ctx.emit_at(kLoadStore + 10, OPF(LBU) * a_hi);
+    ctx.emit_at(kLoadStore + 11, OPF(LB) * (a_lo - (bv + ZKSP_K(0xff00) * bs)));
+    ctx.emit_at(kLoadStore + 12, OPF(LB) * (a_hi - k65535 * bs));
+    const F loads = OPF(LB) + OPF(LH) + OPF(LW) + OPF(LBU) + OPF(LHU);
+    const F keep = loads + OPF(ECALL);
+    ctx.emit_at(kLoadStore + 13, keep * (mv_lo - m_lo));
+    ctx.emit_at(kLoadStore + 14, keep * (mv_hi - m_hi));
+    ctx.emit_at(kLoadStore + 15, OPF(SW) * (o0 - one));
+    ctx.emit_at(kLoadStore + 16, OPF(SW) * (mv_lo - c_lo));
+    ctx.emit_at(kLoadStore + 17, OPF(SW) * (mv_hi - c_hi));
+    ctx.emit_at(kLoadStore + 18, OPF(SH) * (o1 + o3));
+    ctx.emit_at(kLoadStore + 19, OPF(SH) * (mv_lo - m_lo - o0 * (c_lo - m_lo)));
+    ctx.emit_at(kLoadStore + 20, OPF(SH) * (mv_hi - m_hi - o2 * (c_lo - m_hi)));
+    ctx.emit_at(kLoadStore + 21, OPF(SB) * (mv_lo - m_lo - (o0 * (cb - mb[0]) + k256 * (o1 * (cb - mb[1])))));
+    ctx.emit_at(kLoadStore + 22, OPF(SB) * (mv_hi - m_hi - (o2 * (cb - mb[2]) + k256 * (o3 * (cb - mb[3])))));
   }
 #undef OPF
+}
+
+template <class Ctx>
+ZKSP_HD void eval_cpu(Ctx& ctx) {
+  eval_cpu_task<0>(ctx);
+  eval_cpu_task<1>(ctx);
+  eval_cpu_task<2>(ctx);
+  eval_cpu_task<3>(ctx);
+  ctx.set_count(392);
 }
 constexpr int kCpuConstraints = 392;
 

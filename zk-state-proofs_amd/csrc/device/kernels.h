@@ -82,6 +82,13 @@ void launch_open(hipStream_t stream, const uint32_t* coefs_br, size_t coefs_stri
                  const uint32_t* zpow_br, size_t zpow_stride, int npoints, uint32_t* opened, size_t opened_stride,
                  size_t pt_stride, int batch);
 
+// The same for tall matrices (log_h >= 12): the coefficient range is split over workgroups; `scratch` holds
+// open_tall_scratch_words(ncols, logh, batch) words of partial sums.
+size_t open_tall_scratch_words(int ncols, int logh, int batch);
+void launch_open_tall(hipStream_t stream, const uint32_t* coefs_br, size_t coefs_stride, int ncols, int logh,
+                      const uint32_t* zpow_br, size_t zpow_stride, int npoints, uint32_t* opened, size_t opened_stride,
+                      size_t pt_stride, uint32_t* scratch, int batch);
+
 struct ReduceArgs {
   const uint32_t* lde_t;   // [batch][W][2][H]
   const uint32_t* lde_q;   // [batch][8][2][H]

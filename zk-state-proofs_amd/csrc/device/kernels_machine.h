@@ -84,7 +84,7 @@ struct MQuotArgs {
   uint32_t wh_inv;
   uint32_t pub;                 // entry pc (Montgomery)
   uint32_t* quot;               // [B][8][H]
-  uint32_t* partial;            // keccak chip only: [B][13][2H] Fp4 scratch
+  uint32_t* partial;            // keccak chip: [B][13][2H] Fp4 scratch; CPU chip: [B][5][2H] Fp4
   int logh, batch;
 };
 void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a);

@@ -532,6 +532,20 @@ struct MQCtx {
     }
   }
   __device__ __forceinline__ void emit(F v) { emit_at(k_++, v); }
+  __device__ __forceinline__ void set_count(int n) { k_ = n; }
+  // sum x[i] * y[i * ystep] through a signed 64-bit lazy sum: x is centred (|x| <= p/2), y canonical,
+  // |term| < p^2 / 2, four terms between shrinks (field.cuh)
+  __device__ __forceinline__ F sum_prod(const F* x, const F* y, int ystep, int n) const {
+    int64_t t = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      if (i < n) {
+        t += (int64_t)fps_centre(x[i].v) * (int64_t)y[i * ystep].v;
+        if ((i & 3) == 3) t = (int64_t)fps_fold(t) * (int64_t)kRModP;
+      }
+    }
+    return Fp::raw(fps_canon(fps_fold(t)));
+  }
   __device__ __forceinline__ void flush() {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -556,8 +570,8 @@ __device__ __forceinline__ void point_selectors(const MQuotArgs& a, size_t pt, P
   pi->mn = (pi->m + 1) & (h - 1);
   const size_t half = h >> 1;
   const Fp wm = pi->m < half ? Fp::raw(a.tw_fwd[pi->m]) : -Fp::raw(a.tw_fwd[pi->m - half]);
-  const Fp x = Fp::raw(a.shift[pi->c]) * wm;
-  const Fp zh = Fp::raw(a.zh_inv[pi->c]).inv();
+  const Fp x = Fp::raw(pi->c ? a.shift[1] : a.shift[0]) * wm;  // (no dynamic index into kernel arguments: that would spill them)
+  const Fp zh = Fp::raw(pi->c ? a.zh_inv[1] : a.zh_inv[0]).inv();
   const Fp whi = Fp::raw(a.wh_inv);
   pi->trans = x - whi;
   pi->first = zh * (x - Fp::one()).inv();
@@ -637,17 +651,52 @@ __global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
   point_selectors(a, pt, &pi);
   MQCtx ctx;
   init_ctx(a, pi, &ctx);
-  if (CHIP == kCpu) eval_cpu(ctx);
-  else if (CHIP == kKmem) eval_kmem(ctx);
+  if (CHIP == kKmem) eval_kmem(ctx);
   else if (CHIP == kMemFinal) eval_memfinal(ctx);
   else if (CHIP == kImage) eval_image(ctx);
   else if (CHIP == kMul) eval_mul(ctx);
   ctx.flush();
   logup_constraints(a, pi, &ctx.acc);
-  const Fp4 q = ctx.acc * Fp::raw(a.zh_inv[pi.c]);
+  const Fp4 q = ctx.acc * Fp::raw(pi.c ? a.zh_inv[1] : a.zh_inv[0]);
   uint32_t* dst = a.quot + (size_t)pi.b * 8 * h + pi.m;
 #pragma unroll
   for (int j = 0; j < 4; ++j) dst[(size_t)(4 * pi.c + j) * h] = q.c[j].v;
+}
+
+// CPU chip: its four constraint tasks (air_machine.cuh) and the LogUp constraints as five launches, each
+// with its own register budget; every launch leaves one partial extension-field sum per point.
+template <int TASK>
+__global__ __launch_bounds__(kMT) void cpu_quotient_task_kernel(MQuotArgs a) {
+  const size_t h = (size_t)1 << a.logh, n = 2 * h;
+  const size_t pt = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (pt >= n) return;
+  PointInfo pi;
+  pi.b = blockIdx.y;
+  point_selectors(a, pt, &pi);
+  MQCtx ctx;
+  init_ctx(a, pi, &ctx);
+  if (TASK < kCpuTasks) {
+    eval_cpu_task<TASK>(ctx);
+    ctx.flush();
+  } else {
+    logup_constraints(a, pi, &ctx.acc);
+  }
+  m_store_fp4(a.partial + (((size_t)pi.b * (kCpuTasks + 1) + TASK) * n + pt) * 4, ctx.acc);
+}
+__global__ __launch_bounds__(kMT) void cpu_quotient_combine_kernel(MQuotArgs a) {
+  const size_t h = (size_t)1 << a.logh, n = 2 * h;
+  const size_t pt = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (pt >= n) return;
+  const int b = blockIdx.y;
+  const int c = pt >= h ? 1 : 0;
+  const size_t m = pt - (size_t)c * h;
+  Fp4 acc = Fp4::zero();
+#pragma unroll
+  for (int g = 0; g <= kCpuTasks; ++g) acc += m_load_fp4(a.partial + (((size_t)b * (kCpuTasks + 1) + g) * n + pt) * 4);
+  acc = acc * Fp::raw(c ? a.zh_inv[1] : a.zh_inv[0]);
+  uint32_t* q = a.quot + (size_t)b * 8 * h + m;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) q[(size_t)(4 * c + j) * h] = acc.c[j].v;
 }
 
 // keccak chip: p3-keccak-air's 12 evaluation tasks (air_keccak.cuh) plus one task for the call-time
@@ -691,7 +740,7 @@ __global__ __launch_bounds__(kMT) void keccak_machine_combine_kernel(MQuotArgs a
   const size_t m = pt - (size_t)c * h;
   Fp4 acc = Fp4::zero();
   for (int g = 0; g < ka::kNumTasks; ++g) acc += m_load_fp4(a.partial + (((size_t)b * ka::kNumTasks + g) * n + pt) * 4);
-  acc = acc * Fp::raw(a.zh_inv[c]);
+  acc = acc * Fp::raw(c ? a.zh_inv[1] : a.zh_inv[0]);
   uint32_t* q = a.quot + (size_t)b * 8 * h + m;
 #pragma unroll
   for (int j = 0; j < 4; ++j) q[(size_t)(4 * c + j) * h] = acc.c[j].v;
@@ -701,7 +750,14 @@ void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a) {
   const size_t n = (size_t)2 << a.logh;
   const dim3 grid((unsigned)((n + kMT - 1) / kMT), a.batch), block(kMT);
   switch (a.chip) {
-    case kCpu: hipLaunchKernelGGL(machine_quotient_kernel<kCpu>, grid, block, 0, stream, a); break;
+    case kCpu:
+      hipLaunchKernelGGL(cpu_quotient_task_kernel<0>, grid, block, 0, stream, a);
+      hipLaunchKernelGGL(cpu_quotient_task_kernel<1>, grid, block, 0, stream, a);
+      hipLaunchKernelGGL(cpu_quotient_task_kernel<2>, grid, block, 0, stream, a);
+      hipLaunchKernelGGL(cpu_quotient_task_kernel<3>, grid, block, 0, stream, a);
+      hipLaunchKernelGGL(cpu_quotient_task_kernel<4>, grid, block, 0, stream, a);
+      hipLaunchKernelGGL(cpu_quotient_combine_kernel, grid, block, 0, stream, a);
+      break;
     case kKmem: hipLaunchKernelGGL(machine_quotient_kernel<kKmem>, grid, block, 0, stream, a); break;
     case kMemFinal: hipLaunchKernelGGL(machine_quotient_kernel<kMemFinal>, grid, block, 0, stream, a); break;
     case kImage: hipLaunchKernelGGL(machine_quotient_kernel<kImage>, grid, block, 0, stream, a); break;
@@ -829,7 +885,7 @@ __global__ __launch_bounds__(kMT) void mreduce_final_kernel(MReduceArgs a, int n
   const int c = pt >= h ? 1 : 0;
   const size_t m = pt - (size_t)c * h, half = h >> 1;
   const Fp wm = m < half ? Fp::raw(a.tw_fwd[m]) : -Fp::raw(a.tw_fwd[m - half]);
-  Fp4 x = Fp4::from_base(Fp::raw(a.shift[c]) * wm);
+  Fp4 x = Fp4::from_base(Fp::raw(c ? a.shift[1] : a.shift[0]) * wm);
   const Fp4 d0 = (x - zeta).inv(), d1 = (x - zn).inv();
   Fp4 g = (s1 - b1) * d0 + (s2 - b2) * d1;
   uint32_t* o = a.out + (size_t)b * a.out_bstride + pt * 4;

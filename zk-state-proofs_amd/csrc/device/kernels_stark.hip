@@ -13,6 +13,7 @@
 #include "kernels.h"
 #include "merkle_coop.cuh"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace zksp {
@@ -463,6 +464,185 @@ __global__ __launch_bounds__(kThreads) void open_wide_kernel(const uint32_t* __r
       store_fp4(opened + (size_t)b * opened_stride + ((size_t)q * pt_stride + (size_t)(col0 + tid)) * 4, v);
     }
   }
+}
+
+// Tall matrices (the machine proof's 2^15..2^21-row chips): the transposed kernel above, with the
+// coefficient range split over blockIdx.y so that a few hundred columns still make a thousand
+// workgroups.  Every workgroup covers 256 columns x `klen` coefficients and leaves one partial
+// extension-field sum per column and point; open_combine_kernel adds the partials (exact field
+// additions, so the split does not change the result).
+__global__ __launch_bounds__(kThreads) void open_tall_kernel(const uint32_t* __restrict__ coefs, size_t coefs_stride,
+                                                            int ncols, int logh, const uint32_t* __restrict__ zpow,
+                                                            size_t zpow_stride, int npoints, int klen,
+                                                            uint32_t* __restrict__ partial, int nsplit) {
+  __shared__ uint32_t tile[kOpenTileCols * kOpenPitch];
+  // the powers of zeta of the current 32 coefficients: a 16 MB table per proof no longer lives in the
+  // scalar cache, so a tile's 64 values are fetched by 64 lanes (coalesced) and broadcast from LDS
+  __shared__ int4 ztile[2][kOpenTileK];
+  const int h = 1 << logh;
+  const int col0 = blockIdx.x * kOpenTileCols, split = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int kbeg = split * klen, kend = kbeg + klen;
+  const uint32_t* cf = coefs + (size_t)b * coefs_stride + (size_t)col0 * h;
+  const int4* z0 = reinterpret_cast<const int4*>(zpow + (size_t)b * zpow_stride);
+  const int4* z1 = z0 + h;
+  const int lq = tid & 7, lr = tid >> 3;
+  constexpr int kPasses = kOpenTileCols / (kThreads / 8);
+  uint4 stage[kPasses];
+  int4 zstage = make_int4(0, 0, 0, 0);
+  const int zq = tid >> 5, zk = tid & 31;  // threads 0..63: point zq, coefficient zk of the tile
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int ps = 0; ps < kPasses; ++ps) {
+      const int c = ps * (kThreads / 8) + lr;
+      stage[ps] = col0 + c < ncols ? *reinterpret_cast<const uint4*>(cf + (size_t)c * h + k0 + lq * 4)
+                                   : make_uint4(0, 0, 0, 0);
+    }
+    if (tid < 2 * kOpenTileK && zq < npoints) zstage = (zq ? z1 : z0)[k0 + zk];
+  };
+  int64_t acc[2][4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[q][j] = 0;
+  fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += kOpenTileK) {
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < kPasses; ++ps) {
+      uint32_t* d = tile + (ps * (kThreads / 8) + lr) * kOpenPitch + lq * 4;
+      d[0] = stage[ps].x; d[1] = stage[ps].y; d[2] = stage[ps].z; d[3] = stage[ps].w;
+    }
+    if (tid < 2 * kOpenTileK) ztile[zq][zk] = zstage;
+    __syncthreads();
+    if (k0 + kOpenTileK < kend) fetch(k0 + kOpenTileK);
+    const uint32_t* mine = tile + tid * kOpenPitch;
+#pragma unroll
+    for (int kk = 0; kk < kOpenTileK; ++kk) {
+      const int32_t cv = fps_centre(mine[kk]);
+      const int4 p0 = ztile[0][kk];
+      acc[0][0] += (int64_t)cv * (int64_t)p0.x;
+      acc[0][1] += (int64_t)cv * (int64_t)p0.y;
+      acc[0][2] += (int64_t)cv * (int64_t)p0.z;
+      acc[0][3] += (int64_t)cv * (int64_t)p0.w;
+      if (npoints > 1) {
+        const int4 p1 = ztile[1][kk];
+        acc[1][0] += (int64_t)cv * (int64_t)p1.x;
+        acc[1][1] += (int64_t)cv * (int64_t)p1.y;
+        acc[1][2] += (int64_t)cv * (int64_t)p1.z;
+        acc[1][3] += (int64_t)cv * (int64_t)p1.w;
+      }
+      if ((kk & 7) == 7) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[q][j] = lazy_shrink(acc[q][j]);
+      }
+    }
+  }
+  if (col0 + tid < ncols) {
+    for (int q = 0; q < npoints; ++q) {
+      Fp4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v.c[j] = Fp::raw(fps_canon(fps_fold(acc[q][j])));
+      store_fp4(partial + ((((size_t)b * 2 + q) * nsplit + split) * ncols + col0 + tid) * 4, v);
+    }
+  }
+}
+__global__ __launch_bounds__(kThreads) void open_combine_kernel(const uint32_t* __restrict__ partial, int ncols, int npoints,
+                                                               int nsplit, uint32_t* __restrict__ opened,
+                                                               size_t opened_stride, size_t pt_stride) {
+  const int col = blockIdx.x * kThreads + threadIdx.x, b = blockIdx.y;
+  if (col >= ncols) return;
+  for (int q = 0; q < npoints; ++q) {
+    Fp4 s = Fp4::zero();
+    for (int sp = 0; sp < nsplit; ++sp) s += load_fp4(partial + ((((size_t)b * 2 + q) * nsplit + sp) * ncols + col) * 4);
+    store_fp4(opened + (size_t)b * opened_stride + ((size_t)q * pt_stride + (size_t)col) * 4, s);
+  }
+}
+// Narrow tall matrices (a 2^19-row permutation trace has 32 columns, a quotient 8): the lane-per-coefficient kernel
+// with the coefficient range split over blockIdx.y, partial sums in open_tall_kernel's layout.
+__global__ __launch_bounds__(kThreads) void open_split_kernel(const uint32_t* __restrict__ coefs, size_t coefs_stride,
+                                                             int ncols, int logh, const uint32_t* __restrict__ zpow,
+                                                             size_t zpow_stride, int npoints, int klen,
+                                                             uint32_t* __restrict__ partial, int nsplit) {
+  __shared__ Fp4 red[kThreads / 64];
+  const int h = 1 << logh;
+  const int col0 = blockIdx.x * kOpenCols, split = blockIdx.y, b = blockIdx.z;
+  const int nc = min(kOpenCols, ncols - col0);
+  const int kbeg = split * klen, kend = kbeg + klen;
+  const uint32_t* cf = coefs + (size_t)b * coefs_stride + (size_t)col0 * h;
+  const uint32_t* z0 = zpow + (size_t)b * zpow_stride;
+  const uint32_t* z1 = z0 + (size_t)h * 4;
+  int64_t acc[kOpenCols][2][4];
+#pragma unroll
+  for (int c = 0; c < kOpenCols; ++c)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[c][q][j] = 0;
+  int pending = 0;
+  for (int k = kbeg + threadIdx.x; k < kend; k += kThreads) {
+    const uint4 p0 = *reinterpret_cast<const uint4*>(z0 + (size_t)k * 4);
+    uint4 p1 = make_uint4(0, 0, 0, 0);
+    if (npoints > 1) p1 = *reinterpret_cast<const uint4*>(z1 + (size_t)k * 4);
+    const int32_t zz[2][4] = {{(int32_t)p0.x, (int32_t)p0.y, (int32_t)p0.z, (int32_t)p0.w},
+                              {(int32_t)p1.x, (int32_t)p1.y, (int32_t)p1.z, (int32_t)p1.w}};
+#pragma unroll
+    for (int c = 0; c < kOpenCols; ++c) {
+      if (c < nc) {
+        const int32_t cv = fps_centre(cf[(size_t)c * h + k]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[c][0][j] += (int64_t)cv * (int64_t)zz[0][j];
+          if (npoints > 1) acc[c][1][j] += (int64_t)cv * (int64_t)zz[1][j];
+        }
+      }
+    }
+    if (++pending == 8) {
+#pragma unroll
+      for (int c = 0; c < kOpenCols; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[c][q][j] = lazy_shrink(acc[c][q][j]);
+      pending = 0;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < kOpenCols; ++c) {
+    if (c >= nc) break;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (q >= npoints) break;
+      Fp4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v.c[j] = Fp::raw(fps_canon(fps_fold(acc[c][q][j])));
+      const Fp4 sum = block_sum(v, red);
+      if (threadIdx.x == 0) store_fp4(partial + ((((size_t)b * 2 + q) * nsplit + split) * ncols + col0 + c) * 4, sum);
+    }
+  }
+}
+
+static int open_nsplit(int ncols, int logh) {
+  const int h = 1 << logh;
+  return ncols >= 64 ? std::max(1, std::min(128, h / 4096)) : std::max(1, std::min(128, h / 2048));
+}
+size_t open_tall_scratch_words(int ncols, int logh, int batch) {
+  return (size_t)batch * 2 * open_nsplit(ncols, logh) * ncols * 4;
+}
+void launch_open_tall(hipStream_t stream, const uint32_t* coefs_br, size_t coefs_stride, int ncols, int logh,
+                      const uint32_t* zpow_br, size_t zpow_stride, int npoints, uint32_t* opened, size_t opened_stride,
+                      size_t pt_stride, uint32_t* scratch, int batch) {
+  const int h = 1 << logh;
+  const int nsplit = open_nsplit(ncols, logh), klen = h / nsplit;
+  if (ncols >= 64)
+    hipLaunchKernelGGL(open_tall_kernel, dim3((ncols + kOpenTileCols - 1) / kOpenTileCols, nsplit, batch), dim3(kThreads), 0,
+                       stream, coefs_br, coefs_stride, ncols, logh, zpow_br, zpow_stride, npoints, klen, scratch, nsplit);
+  else
+    hipLaunchKernelGGL(open_split_kernel, dim3((ncols + kOpenCols - 1) / kOpenCols, nsplit, batch), dim3(kThreads), 0, stream,
+                       coefs_br, coefs_stride, ncols, logh, zpow_br, zpow_stride, npoints, klen, scratch, nsplit);
+  hipLaunchKernelGGL(open_combine_kernel, dim3((ncols + kThreads - 1) / kThreads, batch), dim3(kThreads), 0, stream, scratch,
+                     ncols, npoints, nsplit, opened, opened_stride, pt_stride);
 }
 
 void launch_open(hipStream_t stream, const uint32_t* coefs_br, size_t coefs_stride, int ncols, int logh,

@@ -234,6 +234,9 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
       const ChipDef& d = chip_def(c);
       need = std::max(need, (size_t)mreduce_nchunks(d.prep_w + d.main_w + d.perm_width() + 8) * 16 * ((size_t)1 << logh[c]));
     }
+    for (int c = 0; c < kNumChips; ++c)  // ... and of the tall openings
+      for (int wdt : {chip_def(c).prep_w, chip_def(c).main_w, chip_def(c).perm_width(), 8})
+        if (wdt) need = std::max(need, open_tall_scratch_words(wdt, logh[c], 1));
     A(&w->reduce_scratch, B * need);
   }
   A(&w->kpartial, B * 13 * (((size_t)2 << logh[kKeccak]) * 4));
@@ -476,7 +479,7 @@ int machine_prove_resident(Context* ctx) {
       qa.wh_inv = wh.inv().v;
       qa.pub = Fp::from_canonical(prep->entry).v;
       qa.quot = w->mat[c][2].tr;
-      qa.partial = w->kpartial;
+      qa.partial = c == kCpu ? w->reduce_scratch : w->kpartial;  // 40 H words per proof of the CPU chip <= 48 H
       qa.logh = logh[c];
       qa.batch = B;
       launch_machine_quotient(s, qa);
@@ -509,14 +512,16 @@ int machine_prove_resident(Context* ctx) {
       launch_ext_powers(s, w->zeta, 4, dom[c]->w_h, w->zpow[c] + h * 4, 2 * h * 4, (int)h, logh[c], B, /*centred=*/1);
       uint32_t* base = w->opened + w->open_off[c] * 4;
       const size_t pt_stride = (size_t)mw + ew + 8;
-      if (pw)
-        launch_open(s, c == kImage ? prep->coef[0] : prep->coef[1], 0, pw, logh[c], w->zpow[c], 2 * h * 4, 1, base, 8 * R, 0, B);
-      launch_open(s, w->mat[c][0].coef, (size_t)mw * h, mw, logh[c], w->zpow[c], 2 * h * 4, 2, base + (size_t)pw * 4, 8 * R,
-                  pt_stride, B);
-      launch_open(s, w->mat[c][1].coef, (size_t)ew * h, ew, logh[c], w->zpow[c], 2 * h * 4, 2, base + (size_t)(pw + mw) * 4, 8 * R,
-                  pt_stride, B);
-      launch_open(s, w->mat[c][2].coef, 8 * h, 8, logh[c], w->zpow[c], 2 * h * 4, 1, base + (size_t)(pw + mw + ew) * 4, 8 * R, 0,
-                  B);
+      // tall columns: split the coefficient range over workgroups (the partial sums live in the reduce scratch,
+      // which is not in use yet)
+      auto open = [&](const uint32_t* coefs, size_t cstride, int ncols, int npts, uint32_t* dst, size_t pts) {
+        if (logh[c] >= 12) launch_open_tall(s, coefs, cstride, ncols, logh[c], w->zpow[c], 2 * h * 4, npts, dst, 8 * R, pts, w->reduce_scratch, B);
+        else launch_open(s, coefs, cstride, ncols, logh[c], w->zpow[c], 2 * h * 4, npts, dst, 8 * R, pts, B);
+      };
+      if (pw) open(c == kImage ? prep->coef[0] : prep->coef[1], 0, pw, 1, base, 0);
+      open(w->mat[c][0].coef, (size_t)mw * h, mw, 2, base + (size_t)pw * 4, pt_stride);
+      open(w->mat[c][1].coef, (size_t)ew * h, ew, 2, base + (size_t)(pw + mw) * 4, pt_stride);
+      open(w->mat[c][2].coef, 8 * h, 8, 1, base + (size_t)(pw + mw + ew) * 4, 0);
     }
   }
   {

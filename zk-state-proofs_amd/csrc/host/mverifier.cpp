@@ -145,7 +145,13 @@ struct ZetaCtx {
   F one() const { return Fp4::one(); }
   F k(uint32_t monty) const { return Fp4::from_base(Fp::raw(monty)); }
   void emit(F v) { acc += ap[k_++] * v; }
-  void emit_at(int idx, F v) { acc += ap[idx] * v; }  // keccak template (fixed index space)
+  void emit_at(int idx, F v) { acc += ap[idx] * v; }  // fixed index spaces (keccak, CPU)
+  void set_count(int n) { k_ = n; }
+  F sum_prod(const F* x, const F* y, int ystep, int n) const {
+    F s = Fp4::zero();
+    for (int i = 0; i < n; ++i) s += x[i] * y[i * ystep];
+    return s;
+  }
 };
 
 Fp4 lf_eval(const LinForm& f, const Fp4* row) {
