@@ -48,12 +48,12 @@ constexpr int kSrcGlb = 1, kPre = 2, kDstLds = 4, kDstGlb = 8, kPost = 16;
 //   DIT: stages s, s+1, .., s+R-1;                      group stride q = 2^(s-1)
 template <int R, bool DIF, int NC, int F, bool FULL>
 __device__ __forceinline__ void ntt_pass(const PassIo& io, const uint32_t* __restrict__ tw, int logh, int s,
-                                         int ncols, int tid) {
+                                         int ncols, int tid, int g_step = kLdeThreads) {
   constexpr int E = 1 << R;
   const int qlog = DIF ? s - R : s - 1;
   const int q = 1 << qlog;
   const int ngroups = (1 << logh) >> R;
-  for (int g = tid; g < ngroups; g += kLdeThreads) {
+  for (int g = tid; g < ngroups; g += g_step) {
     const int g_lo = g & (q - 1), g_hi = g >> qlog;
     const int base = (g_hi << (qlog + R)) | g_lo;
     Fp x[NC][E];
@@ -499,6 +499,136 @@ __global__ __launch_bounds__(kLdeThreads) void ntt_strided_kernel(const uint32_t
   }
 }
 
+// ---------------------------------------------------------------------------
+// Heights 2^15 .. 2^21, second form (the machine proof's CPU chip lives here): H = 2^l1 * 2^l2.
+//   ntt_top_kernel   the l1 stages that couple elements 2^l2 apart, all in ONE pass in registers: a
+//                    thread owns the 2^l1 elements of one residue n2 (stride 2^l2), so a wave's loads
+//                    and stores are 64 consecutive words at every step; no LDS, no barrier
+//   lde_chunk_kernel the l2 low stages of the inverse transform on one contiguous run of 2^l2
+//                    elements in LDS, rescale, publish the coefficients, then the l2 low stages of
+//                    BOTH forward transforms from the same LDS image
+// Per column: inverse top (read H, write H), chunks (read H, write H coefficients + 2H), forward top
+// in place (read 2H, write 2H): 10 column units instead of the 12 of the strided/chunk pairs above,
+// every access a full line.
+// ---------------------------------------------------------------------------
+template <int R, bool DIF>
+__global__ __launch_bounds__(kLdeThreads) void ntt_top_kernel(const uint32_t* src, size_t src_col_stride, uint32_t* dst,
+                                                             size_t dst_col_stride, const uint32_t* __restrict__ tw,
+                                                             int logh) {
+  PassIo io;
+  io.src_lds = nullptr;
+  io.dst_lds = nullptr;
+  io.src_glb = src + (size_t)blockIdx.y * src_col_stride;
+  io.dst_glb = dst + (size_t)blockIdx.y * dst_col_stride;
+  io.pre_scale = io.post_scale = nullptr;
+  io.src_glb_stride = io.dst_glb_stride = 0;
+  io.lds_stride = 0;
+  // DIF: stages logh .. logh - R + 1; DIT: stages logh - R + 1 .. logh; either way the group stride is 2^(logh - R)
+  ntt_pass<R, DIF, 1, kSrcGlb | kDstGlb, true>(io, tw, logh, DIF ? logh : logh - R + 1, 1,
+                                              (int)(blockIdx.x * kLdeThreads + threadIdx.x), (int)(gridDim.x * kLdeThreads));
+}
+
+__global__ __launch_bounds__(kLdeThreads) void lde_chunk_kernel(const uint32_t* __restrict__ scratch, size_t scratch_col_stride,
+                                                               uint32_t* __restrict__ coefs_br, uint32_t* __restrict__ out,
+                                                               const uint32_t* __restrict__ tw_fwd,
+                                                               const uint32_t* __restrict__ tw_inv,
+                                                               const uint32_t* __restrict__ in_scale_br, int scale_sel_shift,
+                                                               int scale_sel_mask, const uint32_t* __restrict__ out_scale_br,
+                                                               int logh, int l2) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const size_t h = (size_t)1 << logh, h2 = (size_t)1 << l2;
+  const int padded = (int)(h2 + (h2 >> 3) + 4);
+  Fp* coef = reinterpret_cast<Fp*>(smem);
+  Fp* work = coef + padded;
+  const int tid = threadIdx.x;
+  const size_t chunk = blockIdx.x, col = blockIdx.y, off = chunk * h2;
+  const uint32_t* src = scratch + col * scratch_col_stride + off;
+  const uint32_t* isc = in_scale_br + (((col >> scale_sel_shift) & (size_t)scale_sel_mask) << logh) + off;
+  uint32_t* cdst = coefs_br + col * h + off;
+  {
+    int s = l2;
+    bool first = true;
+    while (s > 0) {
+      const int r = s >= 3 ? 3 : s;
+      const bool last = (s - r) == 0;
+      PassIo io;
+      io.src_lds = coef;
+      io.src_glb = first ? src : nullptr;
+      io.pre_scale = nullptr;
+      io.dst_lds = coef;
+      io.dst_glb = last ? cdst : nullptr;
+      io.post_scale = last ? isc : nullptr;
+      io.src_glb_stride = io.dst_glb_stride = 0;
+      io.lds_stride = padded;
+      ntt_pass_sel<true, 1, kDstLds, kSrcGlb | kDstLds, kDstLds | kDstGlb | kPost, kSrcGlb | kDstLds | kDstGlb | kPost>(
+          pass_flags(io), r, io, tw_inv, l2, s, 1, tid);
+      __syncthreads();
+      s -= r;
+      first = false;
+    }
+  }
+  for (int cs = 0; cs < 2; ++cs) {
+    const uint32_t* osc = out_scale_br + (size_t)cs * h + off;
+    uint32_t* dst = out + (col * 2 + cs) * h + off;
+    int s = 1;
+    bool first = true;
+    while (s <= l2) {
+      const int rem = l2 - s + 1;
+      const int r = first ? ((rem % 3) ? (rem % 3) : 3) : 3;
+      const bool last = (s + r) > l2;
+      PassIo io;
+      io.src_lds = first ? coef : work;
+      io.src_glb = nullptr;
+      io.pre_scale = first ? osc : nullptr;
+      io.dst_lds = last ? nullptr : work;
+      io.dst_glb = last ? dst : nullptr;
+      io.post_scale = nullptr;
+      io.src_glb_stride = io.dst_glb_stride = 0;
+      io.lds_stride = padded;
+      ntt_pass_sel<false, 1, kDstLds, kPre | kDstLds, kDstGlb, kPre | kDstGlb>(pass_flags(io), r, io, tw_fwd, l2, s, 1, tid);
+      __syncthreads();
+      s += r;
+      first = false;
+    }
+  }
+}
+
+template <bool DIF>
+static void launch_ntt_top(hipStream_t stream, int r, const uint32_t* src, size_t src_stride, uint32_t* dst, size_t dst_stride,
+                           const uint32_t* tw, int logh, size_t ncols) {
+  const unsigned groups = (unsigned)(((size_t)1 << (logh - r)) / kLdeThreads);
+  const dim3 grid(groups ? groups : 1, (unsigned)ncols), block(kLdeThreads);
+  switch (r) {
+    case 1: hipLaunchKernelGGL((ntt_top_kernel<1, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh); break;
+    case 2: hipLaunchKernelGGL((ntt_top_kernel<2, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh); break;
+    case 3: hipLaunchKernelGGL((ntt_top_kernel<3, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh); break;
+    case 4: hipLaunchKernelGGL((ntt_top_kernel<4, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh); break;
+    case 5: hipLaunchKernelGGL((ntt_top_kernel<5, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh); break;
+    case 6: hipLaunchKernelGGL((ntt_top_kernel<6, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh); break;
+    default: hipLaunchKernelGGL((ntt_top_kernel<7, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh); break;
+  }
+}
+
+static void launch_lde_tall(hipStream_t stream, const uint32_t* in, uint32_t* coefs_br, uint32_t* out, const uint32_t* tw_fwd,
+                            const uint32_t* tw_inv, const uint32_t* in_scale_br, int scale_sel_shift, int scale_sel_mask,
+                            const uint32_t* out_scale_br, int logh, size_t ncols) {
+  const size_t h = (size_t)1 << logh;
+  const int l2 = logh <= 19 ? 13 : 14, l1 = logh - l2;
+  const size_t h2 = (size_t)1 << l2;
+  const size_t smem = 2 * sizeof(uint32_t) * (h2 + (h2 >> 3) + 4);
+  uint32_t* scratch = out + h;  // out[col][1]: every chunk of it is read, then rewritten, by the same workgroup
+  // grid.y is limited to 65535: columns in slabs
+  for (size_t c0 = 0; c0 < ncols; c0 += 16384) {
+    const size_t nc = ncols - c0 < 16384 ? ncols - c0 : 16384;
+    launch_ntt_top<true>(stream, l1, in + c0 * h, h, scratch + c0 * 2 * h, 2 * h, tw_inv, logh, nc);
+    hipLaunchKernelGGL(lde_chunk_kernel, dim3((unsigned)(h >> l2), (unsigned)nc), dim3(kLdeThreads), smem, stream,
+                       scratch + c0 * 2 * h, 2 * h, coefs_br + c0 * h, out + c0 * 2 * h, tw_fwd, tw_inv, in_scale_br, scale_sel_shift,
+                       scale_sel_mask, out_scale_br, logh, l2);
+    // forward top stages in place, both cosets: (column, coset) pairs are h words apart
+    launch_ntt_top<false>(stream, l1, out + c0 * 2 * h, h, out + c0 * 2 * h, h, tw_fwd, logh, 2 * nc);
+  }
+}
+
 static void launch_lde_large(hipStream_t stream, const uint32_t* in, uint32_t* coefs_br, uint32_t* out,
                              const uint32_t* tw_fwd, const uint32_t* tw_inv, const uint32_t* in_scale_br,
                              int scale_sel_shift, int scale_sel_mask, const uint32_t* out_scale_br, int logh, size_t ncols) {
@@ -535,8 +665,13 @@ void launch_lde(hipStream_t stream, const uint32_t* in, uint32_t* coefs_br, uint
                 const uint32_t* out_scale_br, int logh, size_t ncols) {
   if (ncols == 0) return;
   if (logh > 14) {
-    launch_lde_large(stream, in, coefs_br, out, tw_fwd, tw_inv, in_scale_br, scale_sel_shift, scale_sel_mask, out_scale_br,
-                     logh, ncols);
+    static const bool old_tall = getenv("ZKSP_LDE_OLD_TALL") != nullptr;  // debugging switch: the strided/chunk form
+    if (logh <= 21 && coefs_br && !old_tall)
+      launch_lde_tall(stream, in, coefs_br, out, tw_fwd, tw_inv, in_scale_br, scale_sel_shift, scale_sel_mask, out_scale_br, logh,
+                      ncols);
+    else
+      launch_lde_large(stream, in, coefs_br, out, tw_fwd, tw_inv, in_scale_br, scale_sel_shift, scale_sel_mask, out_scale_br,
+                       logh, ncols);
     return;
   }
   const size_t h = (size_t)1 << logh;
@@ -576,6 +711,8 @@ int lde_configure() {
   if (e != hipSuccess) return (int)e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(lde_lds_kernel<4>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return (int)e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(lde_chunk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return (int)e;
   const void* big[] = {reinterpret_cast<const void*>(ntt_chunk_kernel<true>),
                        reinterpret_cast<const void*>(ntt_chunk_kernel<false>),
