@@ -248,7 +248,8 @@ int zksp_hip_bus_perm_trace(zksp_client* c, const uint32_t* d_trace, int log_h, 
 int zksp_hip_fri_fold(zksp_client* c, const uint32_t* d_in, int log_hk, uint32_t shift_k, const uint32_t* beta,
                       uint32_t* d_out);
 /* instruction-rate probe used by DESIGN.md's ALU roofline (which: 0 add, 1 mul_lo,
- * 2 mul_hi, 3 mad_u64_u32, 4 montgomery mul, 5 f64 fma) -> giga wave-instr lanes/s */
+ * 2 mul_hi, 3 mad_u64_u32, 4 montgomery mul, 5 f64 fma, 100 64-bit shift-add) -> giga lane-ops/s;
+ * 6 + k: Poseidon2 permutations per second with k + 1 workgroups per CU */
 int zksp_hip_microbench(zksp_client* c, int which, double* gops);
 
 #ifdef __cplusplus

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void rate_kernel(uint32_t* out, uint32_t seed,
       }
       if (WHICH == 4) { ma = ma * mb; mb = mb * mc; mc = mc * md; md = md * ma; }
       if (WHICH == 5) { fa = fa * fb + fc; fb = fb * fc + fd; fc = fc * fd + fa; fd = fd * fa + fb; }
+      if (WHICH == 6) { qa += qb << 1; qb += qc << 1; qc += qd << 1; qd += qa << 1; }  // v_lshl_add_u64
     }
   }
   uint32_t r = a ^ b ^ c ^ d ^ (uint32_t)(fa + fb + fc + fd) ^ (uint32_t)(qa ^ qb ^ qc ^ qd) ^ ma.v ^ mb.v ^ mc.v ^ md.v;
@@ -54,7 +55,8 @@ void launch_rate_kernel(hipStream_t stream, int which, uint32_t* out, int blocks
     case 2: hipLaunchKernelGGL(rate_kernel<2>, g, b, 0, stream, out, 12345u, iters); break;
     case 3: hipLaunchKernelGGL(rate_kernel<3>, g, b, 0, stream, out, 12345u, iters); break;
     case 4: hipLaunchKernelGGL(rate_kernel<4>, g, b, 0, stream, out, 12345u, iters); break;
-    default: hipLaunchKernelGGL(rate_kernel<5>, g, b, 0, stream, out, 12345u, iters); break;
+    case 5: hipLaunchKernelGGL(rate_kernel<5>, g, b, 0, stream, out, 12345u, iters); break;
+    default: hipLaunchKernelGGL(rate_kernel<6>, g, b, 0, stream, out, 12345u, iters); break;
   }
 }
 

@@ -608,9 +608,10 @@ int zksp_hip_fri_fold(zksp_client* c, const uint32_t* d_in, int log_hk, uint32_t
 int zksp_hip_microbench(zksp_client* c, int which, double* gops) {
   NEED_GPU(c);
   Context* ctx = &c->ctx;
-  if (!gops || which < 0 || which > 5 + 64) return ZKSP_ERR_INVALID_ARG;
+  if (!gops || which < 0 || (which > 5 + 64 && which != 100)) return ZKSP_ERR_INVALID_ARG;
   uint32_t* d = nullptr;
   ZKSP_HIP_CHECK(ctx, hipMalloc(&d, 64));
+  if (which == 100) which = -6;  // the 64-bit shift-add chain: rate_kernel<6>
   if (which > 5) {
     // 6 + k: Poseidon2 permutations per second with k+1 workgroups of 256 per CU (result in G perms/s)
     const int per_cu = which - 5, blocks_p = 256 * per_cu, iters_p = 64;
@@ -626,6 +627,7 @@ int zksp_hip_microbench(zksp_client* c, int which, double* gops) {
     return ZKSP_OK;
   }
   const int blocks = 256 * 16, iters = 2000;
+  if (which < 0) which = -which;
   launch_rate_kernel(ctx->stream, which, d, blocks, 10);  // warm-up
   ZKSP_HIP_CHECK(ctx, hipEventRecord(ctx->timer_a, ctx->stream));
   launch_rate_kernel(ctx->stream, which, d, blocks, iters);
