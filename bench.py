@@ -110,11 +110,17 @@ def valu_model(lib, h, achieved_gperm):
         if lib.zksp_hip_microbench(h, which, C.byref(g)) != 0:
             return None
         rates[cls] = g.value * 1e9  # lane-operations per second, whole chip
-    sec_per_perm = sum(mix[c] / rates[c] for c in mix)
-    ceiling = 1.0 / sec_per_perm / 1e9
+    t = {c: mix[c] / rates[c] for c in mix}
+    # two brackets: every class on one issue port (the classes' times add), or the multiply classes and the
+    # add/move classes on ports that overlap perfectly (the longer of the two); the hardware is in between
+    serial = 1.0 / sum(t.values()) / 1e9
+    overlapped = 1.0 / max(t["mad64"] + t["mul_lo"], t["add64"] + t["simple32"]) / 1e9
     return {"opcode_mix_per_permutation_per_lane": mix, "measured_lane_ops_per_s": {k: round(v / 1e12, 2) for k, v in rates.items()},
-            "unit_rates": "T lane-ops/s", "ceiling_gperm_per_s": ceiling, "achieved_gperm_per_s": achieved_gperm,
-            "frac_of_valu_ceiling": achieved_gperm / ceiling}
+            "unit_rates": "T lane-ops/s", "ceiling_gperm_per_s": overlapped, "ceiling_one_port_gperm_per_s": serial,
+            "achieved_gperm_per_s": achieved_gperm, "frac_of_valu_ceiling": achieved_gperm / overlapped,
+            "note": "ceiling = multiply-class and add-class instructions overlapping perfectly; with all classes on one issue "
+                    "port the model gives ceiling_one_port, which the kernel exceeds: it runs at the issue limit within the "
+                    "precision of these per-class rates"}
 
 
 def verify_resident_batch(zk, client, pk, vk, handles, traces, with_oracle, n_check=4):

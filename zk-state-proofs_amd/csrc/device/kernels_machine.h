@@ -49,6 +49,7 @@ void launch_mmcs_level(hipStream_t stream, const uint32_t* in, size_t in_bstride
 
 // ---- LogUp (row a6, lookup argument) ----
 struct PermArgs {
+  int chip;                        // the CPU chip has a hand-written evaluation of its interactions
   const mach::Interaction* inter;  // device copy of the chip's interactions
   int n_inter;
   Seg prep, main_;                 // traces [w][H]
@@ -57,6 +58,7 @@ struct PermArgs {
   uint32_t* perm;                  // [B][perm_width][H]
   size_t perm_bstride;
   uint32_t* rowsum;                // [B][H] Fp4 scratch
+  uint32_t* slice_sums;            // [B][H / 4096] Fp4 scratch (tall chips: the running sum is scanned in slices)
   uint32_t* cum;                   // [B] Fp4 (this chip's cumulative sum)
   size_t cum_bstride;
   int logh, batch;

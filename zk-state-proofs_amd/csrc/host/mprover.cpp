@@ -218,6 +218,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   A(&w->cum, B * kNumChips * 4);
   A(&w->pubsum, B * 4);
   A(&w->rowsum, B * max_h * 4);
+  A(&w->slice_sums, B * (max_h / 4096 + 1) * 4);
   A(&w->alpha, B * 4);
   A(&w->alpha_pows, B * w->alpha_stride);
   A(&w->zeta, B * 4);
@@ -416,6 +417,7 @@ int machine_prove_resident(Context* ctx) {
     for (int c = 0; c < kNumChips; ++c) {
       const ChipDef& d = chip_def(c);
       PermArgs pa;
+      pa.chip = c;
       pa.inter = static_cast<const Interaction*>(ctx->d_inter[c]);
       pa.n_inter = d.n_inter;
       pa.prep = Seg{c == kImage ? prep->tr[0] : c == kProgram ? prep->tr[1] : nullptr, 0, d.prep_w};
@@ -425,6 +427,7 @@ int machine_prove_resident(Context* ctx) {
       pa.perm = w->mat[c][1].tr;
       pa.perm_bstride = (size_t)d.perm_width() * H(c);
       pa.rowsum = w->rowsum;
+      pa.slice_sums = w->slice_sums;
       pa.cum = w->cum + 4 * c;
       pa.cum_bstride = (size_t)4 * kNumChips;
       pa.logh = logh[c];

@@ -45,7 +45,7 @@ struct MachineWorkspace {
   uint32_t* inj[4][32] = {{nullptr}};                         // leaf digests of the shorter groups, by log LDE size
   uint32_t* G[32] = {nullptr};                                // reduced openings per log height (the tallest lives in fri_layers)
   DevChallenger* ch = nullptr;
-  uint32_t *bus_ch = nullptr, *bpow = nullptr, *cum = nullptr, *pubsum = nullptr, *rowsum = nullptr;
+  uint32_t *bus_ch = nullptr, *bpow = nullptr, *cum = nullptr, *pubsum = nullptr, *rowsum = nullptr, *slice_sums = nullptr;
   uint32_t *alpha = nullptr, *alpha_pows = nullptr, *zeta = nullptr, *opened = nullptr, *tree_o = nullptr;
   uint32_t *af = nullptr, *af_pows = nullptr, *bsum = nullptr, *kpartial = nullptr, *reduce_scratch = nullptr;
   uint32_t *fri_layers = nullptr, *fri_trees = nullptr, *betas = nullptr, *witness = nullptr, *indices = nullptr, *body = nullptr;
