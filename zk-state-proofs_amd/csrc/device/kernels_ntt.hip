@@ -237,24 +237,32 @@ __global__ __launch_bounds__(kLdeThreads) void lde_lds_kernel(const uint32_t* __
 // last inverse pass writes no LDS and the two first forward passes read none.  The height is a
 // template parameter, so every stage number, stride and padded LDS offset below is a constant.
 // ---------------------------------------------------------------------------
+// Where the NC columns of a group and the two cosets of the result lie in global memory (words).  A whole
+// column of height H uses {H, H, 2H, H}; a 2^LOGH chunk of a taller column (lde_chunk_fixed_kernel) has
+// its cosets a full column apart.
+struct LdeGeom {
+  size_t src_col, coef_col, dst_col, coset;
+};
+
 template <int LOGH, int NC, bool FULL>
 __device__ __forceinline__ void lde_fixed_group(const uint32_t* __restrict__ src, uint32_t* __restrict__ cdst,
                                                 uint32_t* __restrict__ dst, const uint32_t* __restrict__ tw_fwd,
                                                 const uint32_t* __restrict__ tw_inv, const uint32_t* __restrict__ isc,
-                                                const uint32_t* __restrict__ out_scale_br, Fp* buf, int nc, int tid) {
+                                                const uint32_t* __restrict__ out_scale_br, Fp* buf, int nc, int tid,
+                                                const LdeGeom geom) {
   constexpr int H = 1 << LOGH, PADDED = H + (H >> 3) + 4;
   constexpr int RB = ((LOGH - 1) % 3) + 1, EB = 1 << RB, NGB = H >> RB;
   constexpr int ITERS = NGB > kLdeThreads ? NGB / kLdeThreads : 1;
   static_assert((LOGH - RB) % 3 == 0 && LOGH - RB >= 3, "pass schedule");
-  static_assert(ITERS * NC * EB <= 16, "coefficients held per thread");
+  static_assert(ITERS * NC * EB <= 32, "coefficients held per thread");
   PassIo io;
   io.src_lds = buf;
   io.dst_lds = buf;
   io.src_glb = src;
   io.dst_glb = nullptr;
   io.pre_scale = io.post_scale = nullptr;
-  io.src_glb_stride = (size_t)H;
-  io.dst_glb_stride = (size_t)2 * H;  // adjacent columns are 2 cosets apart in the LDE
+  io.src_glb_stride = geom.src_col;
+  io.dst_glb_stride = geom.dst_col;  // adjacent columns are 2 cosets apart in the LDE
   io.lds_stride = PADDED;
   // ---- inverse transform, all passes but the last: DIF stages LOGH .. RB + 1 ----
   ntt_pass<3, true, NC, kSrcGlb | kDstLds, FULL>(io, tw_inv, LOGH, LOGH, nc, tid);
@@ -299,7 +307,7 @@ __device__ __forceinline__ void lde_fixed_group(const uint32_t* __restrict__ src
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           keep[it][c][k] = keep[it][c][k] * sc;
-          if (cdst && (FULL || c < nc)) cdst[(size_t)c * H + base + k] = keep[it][c][k].v;
+          if (cdst && (FULL || c < nc)) cdst[(size_t)c * geom.coef_col + base + k] = keep[it][c][k].v;
         }
       }
     }
@@ -308,7 +316,7 @@ __device__ __forceinline__ void lde_fixed_group(const uint32_t* __restrict__ src
   // ---- two forward transforms: DIT stages 1 .. LOGH, the first pass from registers ----
 #pragma unroll 1
   for (int cs = 0; cs < 2; ++cs) {
-    const uint32_t* osc = out_scale_br + (size_t)cs * H;
+    const uint32_t* osc = out_scale_br + (size_t)cs * geom.coset;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int g = tid + it * kLdeThreads;
@@ -352,7 +360,7 @@ __device__ __forceinline__ void lde_fixed_group(const uint32_t* __restrict__ src
       ntt_pass<3, false, NC, kDstLds, FULL>(io, tw_fwd, LOGH, s, nc, tid);
       __syncthreads();
     }
-    io.dst_glb = dst + (size_t)cs * H;
+    io.dst_glb = dst + (size_t)cs * geom.coset;
     ntt_pass<3, false, NC, kDstGlb, FULL>(io, tw_fwd, LOGH, LOGH - 2, nc, tid);
     __syncthreads();  // the image is rewritten by the next coset / the next column group
   }
@@ -379,8 +387,9 @@ __global__ __launch_bounds__(kLdeThreads) void lde_fixed_kernel(const uint32_t* 
     const uint32_t* isc = in_scale_br + (size_t)((col >> scale_sel_shift) & (size_t)scale_sel_mask) * H;
     uint32_t* cdst = coefs_br ? coefs_br + col * (size_t)H : nullptr;
     uint32_t* dst = out + col * 2 * (size_t)H;
-    if (nc == NC) lde_fixed_group<LOGH, NC, true>(src, cdst, dst, tw_fwd, tw_inv, isc, out_scale_br, buf, nc, tid);
-    else lde_fixed_group<LOGH, NC, false>(src, cdst, dst, tw_fwd, tw_inv, isc, out_scale_br, buf, nc, tid);
+    const LdeGeom geom{(size_t)H, (size_t)H, (size_t)2 * H, (size_t)H};
+    if (nc == NC) lde_fixed_group<LOGH, NC, true>(src, cdst, dst, tw_fwd, tw_inv, isc, out_scale_br, buf, nc, tid, geom);
+    else lde_fixed_group<LOGH, NC, false>(src, cdst, dst, tw_fwd, tw_inv, isc, out_scale_br, buf, nc, tid, geom);
   }
 }
 
@@ -593,6 +602,27 @@ __global__ __launch_bounds__(kLdeThreads) void lde_chunk_kernel(const uint32_t* 
   }
 }
 
+// The same chunk work for l2 = 11 .. 13 with the chunk length a template constant: one LDS image, the
+// boundary pass in registers (lde_fixed_group), so twice the workgroups per CU and one LDS round trip
+// less per transform than lde_chunk_kernel.
+template <int L2>
+__global__ __launch_bounds__(kLdeThreads) void lde_chunk_fixed_kernel(const uint32_t* __restrict__ scratch, size_t scratch_col_stride,
+                                                                     uint32_t* __restrict__ coefs_br, uint32_t* __restrict__ out,
+                                                                     const uint32_t* __restrict__ tw_fwd,
+                                                                     const uint32_t* __restrict__ tw_inv,
+                                                                     const uint32_t* __restrict__ in_scale_br, int scale_sel_shift,
+                                                                     int scale_sel_mask, const uint32_t* __restrict__ out_scale_br,
+                                                                     int logh) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const size_t h = (size_t)1 << logh;
+  const size_t col = blockIdx.y, off = (size_t)blockIdx.x << L2;
+  const uint32_t* src = scratch + col * scratch_col_stride + off;
+  const uint32_t* isc = in_scale_br + (((col >> scale_sel_shift) & (size_t)scale_sel_mask) << logh) + off;
+  const LdeGeom geom{0, 0, 0, h};
+  lde_fixed_group<L2, 1, true>(src, coefs_br + col * h + off, out + col * 2 * h + off, tw_fwd, tw_inv, isc, out_scale_br + off,
+                               reinterpret_cast<Fp*>(smem), 1, threadIdx.x, geom);
+}
+
 template <bool DIF>
 static void launch_ntt_top(hipStream_t stream, int r, const uint32_t* src, size_t src_stride, uint32_t* dst, size_t dst_stride,
                            const uint32_t* tw, int logh, size_t ncols) {
@@ -613,17 +643,24 @@ static void launch_lde_tall(hipStream_t stream, const uint32_t* in, uint32_t* co
                             const uint32_t* tw_inv, const uint32_t* in_scale_br, int scale_sel_shift, int scale_sel_mask,
                             const uint32_t* out_scale_br, int logh, size_t ncols) {
   const size_t h = (size_t)1 << logh;
+  static const bool generic_chunk = getenv("ZKSP_LDE_GENERIC_CHUNK") != nullptr;  // debugging switch
+  const bool fixed = logh <= 19 && !generic_chunk;
   const int l2 = logh <= 19 ? 13 : 14, l1 = logh - l2;
   const size_t h2 = (size_t)1 << l2;
-  const size_t smem = 2 * sizeof(uint32_t) * (h2 + (h2 >> 3) + 4);
+  const size_t smem = (fixed ? 1 : 2) * sizeof(uint32_t) * (h2 + (h2 >> 3) + 4);
   uint32_t* scratch = out + h;  // out[col][1]: every chunk of it is read, then rewritten, by the same workgroup
   // grid.y is limited to 65535: columns in slabs
   for (size_t c0 = 0; c0 < ncols; c0 += 16384) {
     const size_t nc = ncols - c0 < 16384 ? ncols - c0 : 16384;
     launch_ntt_top<true>(stream, l1, in + c0 * h, h, scratch + c0 * 2 * h, 2 * h, tw_inv, logh, nc);
-    hipLaunchKernelGGL(lde_chunk_kernel, dim3((unsigned)(h >> l2), (unsigned)nc), dim3(kLdeThreads), smem, stream,
-                       scratch + c0 * 2 * h, 2 * h, coefs_br + c0 * h, out + c0 * 2 * h, tw_fwd, tw_inv, in_scale_br, scale_sel_shift,
-                       scale_sel_mask, out_scale_br, logh, l2);
+    if (fixed)
+      hipLaunchKernelGGL(lde_chunk_fixed_kernel<13>, dim3((unsigned)(h >> l2), (unsigned)nc), dim3(kLdeThreads), smem, stream,
+                         scratch + c0 * 2 * h, 2 * h, coefs_br + c0 * h, out + c0 * 2 * h, tw_fwd, tw_inv, in_scale_br,
+                         scale_sel_shift, scale_sel_mask, out_scale_br, logh);
+    else
+      hipLaunchKernelGGL(lde_chunk_kernel, dim3((unsigned)(h >> l2), (unsigned)nc), dim3(kLdeThreads), smem, stream,
+                         scratch + c0 * 2 * h, 2 * h, coefs_br + c0 * h, out + c0 * 2 * h, tw_fwd, tw_inv, in_scale_br,
+                         scale_sel_shift, scale_sel_mask, out_scale_br, logh, l2);
     // forward top stages in place, both cosets: (column, coset) pairs are h words apart
     launch_ntt_top<false>(stream, l1, out + c0 * 2 * h, h, out + c0 * 2 * h, h, tw_fwd, logh, 2 * nc);
   }

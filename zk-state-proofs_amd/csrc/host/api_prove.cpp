@@ -102,6 +102,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   Context* ctx = &c->ctx;
   for (size_t i = 0; i < n; ++i) { out[i] = nullptr; status[i] = ZKSP_ERR_INVALID_ARG; }
   std::vector<std::unique_ptr<zksp_mtrace>> traces(n);
+  const BatchTrace mark;
   parallel_for(n, 64, [&](size_t i) {
     if (!stdins[i]) return;
     try {
@@ -114,6 +115,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       traces[i]->t.rec.error = "out of memory while tracing the guest";
     }
   });
+  mark.mark("traced", n);
   std::string first_err;
   std::map<std::array<int, mach::kNumChips>, std::vector<size_t>> groups;
   for (size_t i = 0; i < n; ++i) {
@@ -147,6 +149,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       std::vector<const MachineTrace*> ts(cnt);
       for (size_t j = 0; j < cnt; ++j) ts[j] = &traces[kv.second[off + j]]->t;
       int rc = machine_load(ctx, pk->mprog, pk->mvk, ts.data(), cnt);
+      mark.mark("loaded", cnt);
       if (rc == ZKSP_OK) rc = machine_prove_resident(ctx);
       const size_t bw = ctx->mws ? ctx->mws->body_words : 0;
       std::vector<uint32_t> bodies(rc == ZKSP_OK ? cnt * bw : 0);
@@ -154,12 +157,14 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
           (hipMemcpyAsync(bodies.data(), ctx->mws->body, bodies.size() * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
            hipStreamSynchronize(ctx->stream) != hipSuccess))
         rc = ctx->fail(ZKSP_ERR_HIP, "prove: device-to-host copy failed");
+      mark.mark("proved and fetched", cnt);
       for (size_t j = 0; j < cnt; ++j) {
         const size_t i = kv.second[off + j];
         if (rc != ZKSP_OK) { status[i] = rc; rc_all = rc; continue; }
         const int prc = zksp_machine_proof_from_body(pk, traces[i].get(), bodies.data() + j * bw, bw, &out[i]);
         status[i] = prc;
       }
+      mark.mark("wrapped", cnt);
     }
   }
   if (!first_err.empty() && rc_all == ZKSP_OK) ctx->error = first_err;
