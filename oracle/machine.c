@@ -14,7 +14,8 @@
  * 0..31.  Memory consistency is the offline argument: every access consumes the tuple
  * (addr, value, time) its predecessor produced and produces its own; Image (preprocessed program
  * image + zeroed registers) and MemFinal (every touched address once, strictly increasing) open
- * and close each address; "previous time < time" is a 24-bit decomposition.  Instruction fetch is
+ * and close each address; "previous time < time": the difference is two 12-bit limbs, each looked
+ * up in the Range table (a preprocessed column 0..4095 with a multiplicity column).  Instruction fetch is
  * a lookup into the preprocessed Program table.  The keccak precompile call hands (time, pointer)
  * to KeccakMem, which moves the 50 state words through the memory bus and matches them, word by
  * word, against what the keccak-f chip exports.  mul / mulhu go to a multiplier chip.  COMMIT and
@@ -46,7 +47,7 @@ static orc_lf lf_limb(int bits, int limb) {
 }
 static orc_lf lf_plus(orc_lf f, uint32_t c) { f.c0 = f_add(f.c0, c % FP); return f; }
 
-static orc_inter g_cpu[13], g_keccak[50], g_kmem[4], g_memfinal[2], g_image[1], g_program[1], g_mul[2];
+static orc_inter g_cpu[21], g_keccak[50], g_kmem[6], g_memfinal[2], g_image[1], g_program[1], g_mul[2], g_range[1];
 static orc_chip g_chips[N_CHIPS];
 static int g_ready = 0;
 
@@ -54,6 +55,13 @@ static orc_inter mem_inter(int sign, orc_lf mult, orc_lf addr, orc_lf lo, orc_lf
   orc_inter it;
   it.bus = BUS_MEM; it.sign = sign; it.mult = mult; it.n_el = 4;
   it.el[0] = addr; it.el[1] = lo; it.el[2] = hi; it.el[3] = ts;
+  return it;
+}
+
+static orc_inter range_inter(int sign, orc_lf mult, orc_lf value) {
+  orc_inter it;
+  it.bus = BUS_RANGE; it.sign = sign; it.mult = mult; it.n_el = 1;
+  it.el[0] = value;
   return it;
 }
 
@@ -93,6 +101,13 @@ static void build(void) {
     lf_add(&maddr, C_O1, FP - 1); lf_add(&maddr, C_O2, FP - 2); lf_add(&maddr, C_O3, FP - 3);
     g_cpu[5] = mem_inter(-1, memq, maddr, m_lo, m_hi, lf_col(C_M_PTS));
     g_cpu[6] = mem_inter(+1, memq, maddr, lf_col(C_MV_LO), lf_col(C_MV_HI), lf_plus(ts, 2));
+    /* the limbs of the four access-time differences are looked up when their access is live */
+    for (int j = 0; j < TS_LIMBS; ++j) {
+      g_cpu[13 + j] = range_inter(-1, is_real, lf_col(C_R1_D + j));
+      g_cpu[15 + j] = range_inter(-1, lf_col(C_USE2), lf_col(C_R2_D + j));
+      g_cpu[17 + j] = range_inter(-1, memq, lf_col(C_M_D + j));
+      g_cpu[19 + j] = range_inter(-1, lf_col(C_WR), lf_col(C_W_D + j));
+    }
   }
   g_cpu[7] = mem_inter(-1, lf_col(C_WR), lf_col(C_RD), lf_col(C_W_PLO), lf_col(C_W_PHI), lf_col(C_W_PTS));
   g_cpu[8] = mem_inter(+1, lf_col(C_WR), lf_col(C_RD), a_lo, a_hi, lf_plus(ts, 3));
@@ -135,6 +150,7 @@ static void build(void) {
     g_kmem[2] = mem_inter(-1, lf_col(KM_IS_REAL), lf_col(KM_ADDR), lf_col(KM_OLD_LO), lf_col(KM_OLD_HI), lf_col(KM_PTS));
     g_kmem[3] = mem_inter(+1, lf_col(KM_IS_REAL), lf_col(KM_ADDR), lf_col(KM_NEW_LO), lf_col(KM_NEW_HI),
                           lf_plus(lf_col(KM_TS), 2));
+    for (int j = 0; j < TS_LIMBS; ++j) g_kmem[4 + j] = range_inter(-1, lf_col(KM_IS_REAL), lf_col(KM_D + j));
   }
   g_memfinal[0] = mem_inter(-1, lf_col(MF_IS_REAL), lf_col(MF_ADDR), lf_col(MF_FIN_LO), lf_col(MF_FIN_HI), lf_col(MF_FIN_TS));
   g_memfinal[1] = mem_inter(+1, lf_col(MF_IS_INIT), lf_col(MF_ADDR), lf_limb(MF_INIT, 0), lf_limb(MF_INIT, 1), lf_const(0));
@@ -154,9 +170,11 @@ static void build(void) {
     it->el[1] = lf_limb(MU_P, 2 * hi); it->el[2] = lf_limb(MU_P, 2 * hi + 1);
     it->el[3] = lf_limb(MU_B, 0); it->el[4] = lf_limb(MU_B, 1); it->el[5] = lf_limb(MU_C, 0); it->el[6] = lf_limb(MU_C, 1);
   }
-  g_chips[CH_CPU] = (orc_chip){"cpu", 0, CPU_WIDTH, 13, g_cpu, 0};
+  g_range[0] = range_inter(+1, lf_col(RANGE_PREP_WIDTH + 0), lf_col(0));
+  g_chips[CH_RANGE] = (orc_chip){"range", RANGE_PREP_WIDTH, RANGE_WIDTH, 1, g_range, 0};
+  g_chips[CH_CPU] = (orc_chip){"cpu", 0, CPU_WIDTH, 21, g_cpu, 0};
   g_chips[CH_KECCAK] = (orc_chip){"keccak", 0, KECCAK_WIDTH, 50, g_keccak, 0};
-  g_chips[CH_KMEM] = (orc_chip){"keccak-mem", 0, KMEM_WIDTH, 4, g_kmem, 0};
+  g_chips[CH_KMEM] = (orc_chip){"keccak-mem", 0, KMEM_WIDTH, 6, g_kmem, 0};
   g_chips[CH_MEMFINAL] = (orc_chip){"mem-final", 0, MEMFINAL_WIDTH, 2, g_memfinal, 0};
   g_chips[CH_IMAGE] = (orc_chip){"image", IMAGE_PREP_WIDTH, IMAGE_WIDTH, 1, g_image, 0};
   g_chips[CH_PROGRAM] = (orc_chip){"program", PROGRAM_PREP_WIDTH, PROGRAM_WIDTH, 1, g_program, 0};
@@ -188,6 +206,7 @@ void orc_machine_heights(const orc_machine_input* in, int logh[N_CHIPS]) {
   logh[CH_IMAGE] = in->log_image;
   logh[CH_PROGRAM] = in->log_prog;
   logh[CH_MUL] = at_least5(clog2(in->n_muls));
+  logh[CH_RANGE] = RANGE_LOG_H;
 }
 
 static void put_bits(uint32_t* t, size_t h, size_t r, int col, uint32_t v, int n) {
@@ -195,6 +214,22 @@ static void put_bits(uint32_t* t, size_t h, size_t r, int col, uint32_t v, int n
 }
 
 typedef struct { uint32_t ts, ptr; uint64_t in[25]; uint32_t pts[50]; } kcall_t;
+
+/* an access-time difference as its two limbs */
+static void put_gap(uint32_t* t, size_t h, size_t r, int col, uint32_t gap) {
+  t[(size_t)col * h + r] = gap & ((1u << TS_LIMB_BITS) - 1);
+  t[(size_t)(col + 1) * h + r] = gap >> TS_LIMB_BITS;
+}
+/* the four differences of one cycle (0 where the access is not live), as fill_cpu writes them */
+static void cycle_gaps(const orc_machine_input* in, size_t r, uint32_t gap[4], int live[4]) {
+  const uint32_t* cy = in->cycles + 12 * r;
+  const uint32_t* p = in->program + 9 * (size_t)((cy[0] - in->text_base) >> 2);
+  const uint32_t op = p[1], ts = 4 * ((uint32_t)r + 1);
+  live[0] = 1; gap[0] = ts - cy[7] - 1;
+  live[1] = p[3] != 0; gap[1] = ts - cy[8];
+  live[2] = (op >= OP_LB && op <= OP_SW) || op == OP_ECALL; gap[2] = ts + 1 - cy[9];
+  live[3] = p[2] != 0; gap[3] = ts + 2 - cy[10];
+}
 
 static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t) {
 #pragma omp parallel for schedule(static)
@@ -256,11 +291,14 @@ static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t) {
     }
     put_bits(t, h, r, C_X, x, 32);
     T(C_NEXT_PC) = next;
-    T(C_R1_PTS) = cy[7]; put_bits(t, h, r, C_R1_D, ts - cy[7] - 1, TS_BITS);
-    if (use2) { T(C_R2_PTS) = cy[8]; put_bits(t, h, r, C_R2_D, ts - cy[8], TS_BITS); }
-    if ((op >= OP_LB && op <= OP_SW) || op == OP_ECALL) { T(C_M_PTS) = cy[9]; put_bits(t, h, r, C_M_D, ts + 1 - cy[9], TS_BITS); }
-    if (wr) {
-      T(C_W_PTS) = cy[10]; put_bits(t, h, r, C_W_D, ts + 2 - cy[10], TS_BITS);
+    uint32_t gap[4];
+    int live[4];
+    cycle_gaps(in, r, gap, live);
+    T(C_R1_PTS) = cy[7]; put_gap(t, h, r, C_R1_D, gap[0]);
+    if (live[1]) { T(C_R2_PTS) = cy[8]; put_gap(t, h, r, C_R2_D, gap[1]); }
+    if (live[2]) { T(C_M_PTS) = cy[9]; put_gap(t, h, r, C_M_D, gap[2]); }
+    if (live[3]) {
+      T(C_W_PTS) = cy[10]; put_gap(t, h, r, C_W_D, gap[3]);
       T(C_W_PLO) = wprev & 0xffff; T(C_W_PHI) = wprev >> 16;
     }
 #undef T
@@ -299,7 +337,7 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
         T(KM_CALL) = i == 0; T(KM_ADDR) = k->ptr + 4 * (uint32_t)i;
         T(KM_OLD_LO) = wi & 0xffff; T(KM_OLD_HI) = wi >> 16; T(KM_NEW_LO) = wo & 0xffff; T(KM_NEW_HI) = wo >> 16;
         T(KM_PTS) = k->pts[i];
-        put_bits(t, h, r, KM_D, k->ts + 1 - k->pts[i], TS_BITS);
+        put_gap(t, h, r, KM_D, k->ts + 1 - k->pts[i]);
       }
       break;
     case CH_MEMFINAL:
@@ -344,6 +382,26 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
         put_bits(t, h, r, MU_Q0, (uint32_t)q0, 10); put_bits(t, h, r, MU_Q1, (uint32_t)q1, 11); put_bits(t, h, r, MU_Q2, (uint32_t)q2, 10);
       }
       break;
+    case CH_RANGE: {
+      const uint32_t mask = (1u << TS_LIMB_BITS) - 1;
+      for (size_t r = 0; r < h; ++r) prep[r] = (uint32_t)r;
+      /* multiplicity of a value = the live limbs equal to it, over the CPU and keccak-memory chips */
+      for (size_t r = 0; r < in->n_cycles; ++r) {
+        uint32_t gap[4];
+        int live[4];
+        cycle_gaps(in, r, gap, live);
+        for (int q = 0; q < 4; ++q)
+          if (live[q] && (gap[q] >> TS_LIMB_BITS) <= mask) { t[gap[q] & mask]++; t[gap[q] >> TS_LIMB_BITS]++; }
+      }
+      for (size_t p = 0; p < in->n_keccak; ++p) {
+        const kcall_t* k = (const kcall_t*)(in->keccak + 408 * p);
+        for (int i = 0; i < 50; ++i) {
+          const uint32_t gap = k->ts + 1 - k->pts[i];
+          if ((gap >> TS_LIMB_BITS) <= mask) { t[gap & mask]++; t[gap >> TS_LIMB_BITS]++; }
+        }
+      }
+      break;
+    }
   }
 #undef T
 }
@@ -372,6 +430,8 @@ static inline fe bits_val(const uint32_t* row, int bits, int n) {
   for (int i = n - 1; i >= 0; --i) s = f_add(f_add(s, s), row[bits + i]);
   return s;
 }
+/* an access-time difference from its two range-checked limbs */
+static inline fe gap_val(const uint32_t* row, int col) { return f_add(row[col], f_mul(1u << TS_LIMB_BITS, row[col + 1])); }
 #define F65536 65536u
 
 static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe is_trans, fe entry, sink* s) {
@@ -386,7 +446,6 @@ static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, f
   emit(s, bool_c(l[C_EQ]));
   for (int i = 0; i < 4; ++i) emit(s, bool_c(l[C_O0 + i]));
   for (int i = 0; i < 6; ++i) emit(s, bool_c(l[C_SC + i]));
-  for (int i = 0; i < 4 * TS_BITS; ++i) emit(s, bool_c(l[C_R1_D + i]));
   /* ---- row structure ---- */
 #define OPF(k) l[C_OP + (k) - 1]
   const fe is_real = l[C_IS_REAL];
@@ -565,10 +624,10 @@ static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, f
   {
     fe memq = f_add(f_add(loads, stores), OPF(OP_ECALL));
     const fe ts = l[C_TS];
-    emit(s, f_mul(is_real, f_sub(f_sub(f_sub(ts, l[C_R1_PTS]), one), bits_val(l, C_R1_D, TS_BITS))));
-    emit(s, f_mul(l[C_USE2], f_sub(f_sub(ts, l[C_R2_PTS]), bits_val(l, C_R2_D, TS_BITS))));
-    emit(s, f_mul(memq, f_sub(f_sub(f_add(ts, one), l[C_M_PTS]), bits_val(l, C_M_D, TS_BITS))));
-    emit(s, f_mul(l[C_WR], f_sub(f_sub(f_add(ts, 2), l[C_W_PTS]), bits_val(l, C_W_D, TS_BITS))));
+    emit(s, f_mul(is_real, f_sub(f_sub(f_sub(ts, l[C_R1_PTS]), one), gap_val(l, C_R1_D))));
+    emit(s, f_mul(l[C_USE2], f_sub(f_sub(ts, l[C_R2_PTS]), gap_val(l, C_R2_D))));
+    emit(s, f_mul(memq, f_sub(f_sub(f_add(ts, one), l[C_M_PTS]), gap_val(l, C_M_D))));
+    emit(s, f_mul(l[C_WR], f_sub(f_sub(f_add(ts, 2), l[C_W_PTS]), gap_val(l, C_W_D))));
   }
 #undef OPF
 }
@@ -576,7 +635,6 @@ static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, f
 static void kmem_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe is_trans, sink* s) {
   const fe one = 1;
   emit(s, bool_c(l[KM_IS_REAL])); emit(s, bool_c(l[KM_ISF])); emit(s, bool_c(l[KM_ISL]));
-  for (int i = 0; i < TS_BITS; ++i) emit(s, bool_c(l[KM_D + i]));
   emit(s, f_sub(l[KM_CALL], f_mul(l[KM_ISF], l[KM_IS_REAL])));
   emit(s, f_mul(is_first, l[KM_IDX]));
   emit(s, f_mul(is_first, f_sub(l[KM_ISF], one)));
@@ -590,7 +648,7 @@ static void kmem_constraints(const uint32_t* l, const uint32_t* n, fe is_first, 
   emit(s, f_mul(f_mul(is_trans, nl), f_sub(n[KM_PTR_LO], l[KM_PTR_LO])));
   emit(s, f_mul(f_mul(is_trans, nl), f_sub(n[KM_PTR_HI], l[KM_PTR_HI])));
   emit(s, f_mul(l[KM_IS_REAL], f_sub(l[KM_ADDR], f_add(f_add(l[KM_PTR_LO], f_mul(F65536, l[KM_PTR_HI])), f_mul(4, l[KM_IDX])))));
-  emit(s, f_mul(l[KM_IS_REAL], f_sub(f_sub(f_add(l[KM_TS], one), l[KM_PTS]), bits_val(l, KM_D, TS_BITS))));
+  emit(s, f_mul(l[KM_IS_REAL], f_sub(f_sub(f_add(l[KM_TS], one), l[KM_PTS]), gap_val(l, KM_D))));
 }
 
 static void memfinal_constraints(const uint32_t* l, const uint32_t* n, fe is_trans, sink* s) {
@@ -637,6 +695,7 @@ static void run_constraints(int chip, const uint32_t* prep, const uint32_t* loc,
     case CH_IMAGE: emit(s, bool_c(loc[0])); break;
     case CH_PROGRAM: break;
     case CH_MUL: mul_constraints(loc, s); break;
+    case CH_RANGE: break;
   }
 }
 

@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 /* ---- chips, in proof order ---- */
-enum { CH_CPU = 0, CH_KECCAK, CH_KMEM, CH_MEMFINAL, CH_IMAGE, CH_PROGRAM, CH_MUL, N_CHIPS };
+enum { CH_CPU = 0, CH_KECCAK, CH_KMEM, CH_MEMFINAL, CH_IMAGE, CH_PROGRAM, CH_MUL, CH_RANGE, N_CHIPS };
 
 /* ---- AIR opcodes (Program table column OP; CPU selector k-1) ---- */
 enum {
@@ -32,7 +32,9 @@ enum {
   OP_ECALL, OP_KECCAK, N_OPS_P1
 };
 #define N_OPS 30
-#define TS_BITS 24
+/* access-time differences: two limbs of TS_LIMB_BITS bits, each looked up in the range table */
+#define TS_LIMB_BITS 12
+#define TS_LIMBS 2
 
 /* ---- CPU chip main columns ---- */
 enum {
@@ -45,8 +47,8 @@ enum {
   C_O0, C_O1, C_O2, C_O3,
   C_SC,                        /* 6 syscall flags: HALT, WRITE, COMMIT, DEFER, HINT_LEN, HINT_READ */
   C_R1_PTS = C_SC + 6, C_R2_PTS, C_M_PTS, C_W_PTS, C_W_PLO, C_W_PHI,
-  C_R1_D, C_R2_D = C_R1_D + TS_BITS, C_M_D = C_R2_D + TS_BITS, C_W_D = C_M_D + TS_BITS,
-  CPU_WIDTH = C_W_D + TS_BITS
+  C_R1_D, C_R2_D = C_R1_D + TS_LIMBS, C_M_D = C_R2_D + TS_LIMBS, C_W_D = C_M_D + TS_LIMBS,
+  CPU_WIDTH = C_W_D + TS_LIMBS
 };
 enum { SC_HALT = 0, SC_WRITE, SC_COMMIT, SC_DEFER, SC_HINT_LEN, SC_HINT_READ };
 
@@ -57,7 +59,7 @@ enum { SC_HALT = 0, SC_WRITE, SC_COMMIT, SC_DEFER, SC_HINT_LEN, SC_HINT_READ };
 /* ---- keccak-memory chip: 50 rows per call, one state word each ---- */
 enum {
   KM_IS_REAL = 0, KM_TS, KM_PTR_LO, KM_PTR_HI, KM_IDX, KM_ISF, KM_ISL, KM_CALL, KM_ADDR, KM_OLD_LO, KM_OLD_HI, KM_NEW_LO,
-  KM_NEW_HI, KM_PTS, KM_D, KMEM_WIDTH = KM_D + TS_BITS
+  KM_NEW_HI, KM_PTS, KM_D, KMEM_WIDTH = KM_D + TS_LIMBS
 };
 /* ---- memory boundary chip: every touched address once, strictly increasing ---- */
 enum { MF_IS_REAL = 0, MF_ADDR, MF_IS_INIT, MF_FIN_LO, MF_FIN_HI, MF_FIN_TS, MF_DIFF, MF_INIT = MF_DIFF + 32, MEMFINAL_WIDTH = MF_INIT + 32 };
@@ -70,8 +72,13 @@ enum { PR_PC = 0, PR_OP, PR_WR, PR_USE2, PR_RD, PR_RS1, PR_RS2, PR_IMM_LO, PR_IM
 /* ---- multiplier chip ---- */
 enum { MU_IS_REAL = 0, MU_HI, MU_B, MU_C = MU_B + 32, MU_P = MU_C + 32, MU_Q0 = MU_P + 64, MU_Q1 = MU_Q0 + 10, MU_Q2 = MU_Q1 + 11, MUL_WIDTH = MU_Q2 + 10 };
 
+/* ---- range table: preprocessed (value = row index), main (multiplicity); always 2^TS_LIMB_BITS rows ---- */
+#define RANGE_PREP_WIDTH 1
+#define RANGE_WIDTH 1
+#define RANGE_LOG_H TS_LIMB_BITS
+
 /* ---- buses ---- */
-enum { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_MUL, BUS_PUBC, BUS_PUBH };
+enum { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_MUL, BUS_PUBC, BUS_PUBH, BUS_RANGE };
 
 /* A linear form over the row [preprocessed | main]: c0 + sum coef[i] * row[col[i]] (canonical words). */
 #define LF_MAX 40
@@ -119,7 +126,7 @@ typedef struct {
   uint32_t pv_digest[8];
   uint32_t deferred_digest[8];
 } orc_machine_public;
-#define ZKSP_VERSION_MACHINE 3u
+#define ZKSP_VERSION_MACHINE 4u
 /* vk: preprocessed commitment root + digest binding entry pc, table heights and keccak mode */
 void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t prep_root[8], uint32_t vk_digest[8]);
 size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_image, const orc_config* cfg, uint32_t pv_len);

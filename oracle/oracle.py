@@ -279,8 +279,8 @@ def prove(states_in: np.ndarray, logh: int, *, exit_code: int = 0, public_values
 # ---------------------------------------------------------------------------
 # machine proof (oracle/machine.h): inputs are the arrays ProverClient.machine_trace() returns
 # ---------------------------------------------------------------------------
-N_CHIPS = 7
-CHIP_NAMES = ["cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul"]
+N_CHIPS = 8
+CHIP_NAMES = ["cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "range"]
 
 
 class MachineChip(C.Structure):

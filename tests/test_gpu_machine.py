@@ -26,7 +26,7 @@ def test_machine_proof_matches_oracle(zk, fx, oracle, depth, nq, pow_bits):
     host = zk.ProverClient(device=-1, num_queries=nq, pow_bits=pow_bits)
     for i in range(2):
         exp = oracle.machine_prove(traces[i], num_queries=nq, pow_bits=pow_bits)
-        hw = 35 + (len(traces[i]["public_values"]) + 3) // 4
+        hw = zk.MACHINE_HEADER_WORDS + (len(traces[i]["public_values"]) + 3) // 4
         e = np.frombuffer(exp, dtype=np.uint32)[hw:]
         assert e.shape == bodies[i].shape
         assert first_difference(bodies[i], e) is None, first_difference(bodies[i], e)
@@ -39,7 +39,7 @@ def test_reference_flow_acct_d8_full_size(zk, fx, oracle):
     """BASELINE config 2 through the reference's own call sequence (prover/src/bin/main.rs:59-87) with the
     default client: setup -> prove(..).run() -> public_values -> verify, at full parameters (100 queries,
     16 proof-of-work bits).  The proof is the machine proof of the 391 400-cycle precompile-shape run
-    (CPU chip 2^19 x 322): byte-identical to the oracle's, accepted by a host-only verifier, every
+    (CPU chip 2^19 x 234): byte-identical to the oracle's, accepted by a host-only verifier, every
     tampered region rejected, and another public value cannot be attached."""
     client = zk.ProverClient(device=0)
     pk, vk = client.setup(zk.merkle_elf())
@@ -51,12 +51,13 @@ def test_reference_flow_acct_d8_full_size(zk, fx, oracle):
     assert proof.public_values == fx.ACCOUNT_VALUE
     client.verify(proof, vk)
     raw = proof.to_bytes()
-    assert int.from_bytes(raw[4:8], "little") == 3 and int.from_bytes(raw[8:12], "little") == 19
+    assert int.from_bytes(raw[4:8], "little") == zk.MACHINE_VERSION and int.from_bytes(raw[8:12], "little") == 19
     assert raw == oracle.machine_prove(trace)
     host = zk.ProverClient(device=-1)
     host.verify(zk.SP1ProofWithPublicValues.from_bytes(raw), vk)
     rng = np.random.default_rng(3)
-    for pos in [9 * 4, 10 * 4, 11 * 4 + 1, 35 * 4 + 5, 35 * 4 + 72 + 3] + [int(x) for x in rng.integers(35 * 4 + 72, len(raw), 12)]:
+    hb = zk.MACHINE_HEADER_WORDS * 4  # exit code, public-values length, their digest, the values, the body
+    for pos in [10 * 4, 11 * 4, 12 * 4 + 1, hb + 5, hb + 72 + 3] + [int(x) for x in rng.integers(hb + 72, len(raw), 12)]:
         bad = bytearray(raw)
         bad[pos] ^= 1
         with pytest.raises(zk.ZkspError):

@@ -48,8 +48,9 @@ def test_every_region_is_bound(zk, setup):
     client, vk, t, proof = setup
     rng = np.random.default_rng(5)
     words = len(proof) // 4
-    positions = [2, 5, 9, 10, 11, 19, 27, 35, 36, 35 + 18, 35 + 18 + 8, 35 + 18 + 16, 35 + 18 + 44, 35 + 18 + 52, words - 1]
-    positions += [int(x) for x in rng.integers(35, words, 40)]
+    hw = zk.MACHINE_HEADER_WORDS  # heights 2..9, exit code 10, pv length 11, digests 12 / 20, vk 28, then 18 words of values
+    positions = [2, 5, 9, 10, 11, 12, 20, 28, hw, hw + 1, hw + 18, hw + 18 + 8, hw + 18 + 16, hw + 18 + 48, hw + 18 + 56, words - 1]
+    positions += [int(x) for x in rng.integers(hw, words, 40)]
     for w in positions:
         bad = bytearray(proof)
         bad[4 * w] ^= 1
@@ -61,7 +62,7 @@ def test_every_region_is_bound(zk, setup):
             client.verify(q, vk)
     # padding behind the public values is not free either
     bad = bytearray(proof)
-    bad[35 * 4 + 70] = 1
+    bad[zk.MACHINE_HEADER_WORDS * 4 + 70] = 1
     with pytest.raises(zk.ZkspError):
         zk.SP1ProofWithPublicValues.from_bytes(bytes(bad))
 
@@ -117,6 +118,27 @@ def test_wrong_alu_result_is_rejected(zk, oracle, setup):
         oracle.machine_prove(t2, num_queries=NQ, pow_bits=POW)
     with pytest.raises(zk.VerificationError):
         client.verify(zk.SP1ProofWithPublicValues.from_bytes(forced_proof(oracle, t2)), vk)
+
+
+def test_read_from_the_future_is_rejected(zk, oracle, setup):
+    """Two reads of one register swap their predecessors: the memory bus still balances (the same tuples are
+    consumed), but the earlier read now consumes a tuple that is not older than itself.  Only the range
+    lookups of the access-time difference catch it."""
+    client, vk, t, _ = setup
+    cyc = t["cycles"]
+    # j reads (slot 0) what cycle i's slot-0 read produced: previous time = 4 (i + 1)
+    j = int(np.nonzero((cyc[:, 7] % 4 == 0) & (cyc[:, 7] > 0))[0][50])
+    i = int(cyc[j, 7]) // 4 - 1
+    assert i < j and cyc[i, 2] == cyc[j, 2]  # same register value
+    c2 = cyc.copy()
+    c2[i, 7], c2[j, 7] = cyc[j, 7], cyc[i, 7]
+    t2 = dict(t)
+    t2["cycles"] = c2
+    with pytest.raises(RuntimeError):
+        oracle.machine_prove(t2, num_queries=NQ, pow_bits=POW)
+    with pytest.raises(zk.VerificationError) as ei:
+        client.verify(zk.SP1ProofWithPublicValues.from_bytes(forced_proof(oracle, t2)), vk)
+    assert "balance" in str(ei.value)
 
 
 def test_exit_code_is_bound_to_halt(zk, oracle, setup):

@@ -29,6 +29,11 @@ ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_ELF, ERR_EXECUTOR, ERR_GUEST_PANIC,
     ERR_UNSUPPORTED = range(1, 10)
 KECCAK_SOFTWARE, KECCAK_OBSERVE, KECCAK_REPLACE = 0, 1, 2
 PROOF_MACHINE, PROOF_KECCAK_CHIP = 1, 2
+# machine proof (format version 4): chips in proof order and the fixed header in front of the public values
+MACHINE_VERSION = 4
+MACHINE_CHIP_NAMES = ("cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "range")
+MACHINE_CHIPS = len(MACHINE_CHIP_NAMES)
+MACHINE_HEADER_WORDS = 2 + MACHINE_CHIPS + 2 + 24
 
 
 class ZkspError(RuntimeError):
@@ -270,7 +275,7 @@ class MachineTraceHandle(_Handle):
     """A traced guest run kept on the C side (``zksp_mtrace``)."""
 
     def heights(self):
-        lh = (C.c_int32 * 7)()
+        lh = (C.c_int32 * MACHINE_CHIPS)()
         self._lib.zksp_mtrace_heights(self._h, lh)
         return list(lh)
 
@@ -430,7 +435,7 @@ class ProverClient:
             rc = self._lib.zksp_hip_machine_prove(self._h)
         if rc:
             raise ZkspError(rc, self.last_error())
-        lh = (C.c_int32 * 7)(*traces[0].heights())
+        lh = (C.c_int32 * MACHINE_CHIPS)(*traces[0].heights())
         bw = self._lib.zksp_machine_body_words(self._h, lh)
         out = np.zeros((n, bw), np.uint32)
         rc = self._lib.zksp_hip_machine_fetch_bodies(self._h, out.ctypes.data_as(C.c_void_p), out.size)

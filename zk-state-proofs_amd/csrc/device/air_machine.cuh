@@ -15,7 +15,7 @@
 namespace zksp {
 namespace mach {
 
-enum Chip { kCpu = 0, kKeccak, kKmem, kMemFinal, kImage, kProgram, kMul, kNumChips };
+enum Chip { kCpu = 0, kKeccak, kKmem, kMemFinal, kImage, kProgram, kMul, kRange, kNumChips };
 
 // AIR opcodes = Program-table column OP = 1 + index of the CPU selector column
 enum Op {
@@ -23,7 +23,8 @@ enum Op {
   SB, SH, SW, MUL, MULHU, ECALL, KECCAK
 };
 constexpr int kNumOps = 30;
-constexpr int kTsBits = 24;
+// access-time differences: two limbs of kTsLimbBits bits, each looked up in the range table
+constexpr int kTsLimbBits = 12, kTsLimbs = 2;
 
 // ---- CPU chip ----
 constexpr int C_IS_REAL = 0, C_PC = 1, C_TS = 2, C_NEXT_PC = 3, C_OP = 4, C_WR = C_OP + kNumOps, C_USE2 = C_WR + 1,
@@ -32,17 +33,17 @@ constexpr int C_IS_REAL = 0, C_PC = 1, C_TS = 2, C_NEXT_PC = 3, C_OP = 4, C_WR =
               C_MV_HI = C_MV_LO + 1, C_K0 = C_MV_LO + 2, C_K1 = C_K0 + 1, C_K2 = C_K0 + 2, C_K3 = C_K0 + 3, C_EQ = C_K0 + 4,
               C_INV = C_K0 + 5, C_O0 = C_K0 + 6, C_O1 = C_O0 + 1, C_O2 = C_O0 + 2, C_O3 = C_O0 + 3, C_SC = C_O0 + 4,
               C_R1_PTS = C_SC + 6, C_R2_PTS = C_R1_PTS + 1, C_M_PTS = C_R1_PTS + 2, C_W_PTS = C_R1_PTS + 3,
-              C_W_PLO = C_R1_PTS + 4, C_W_PHI = C_R1_PTS + 5, C_R1_D = C_R1_PTS + 6, C_R2_D = C_R1_D + kTsBits,
-              C_M_D = C_R2_D + kTsBits, C_W_D = C_M_D + kTsBits, kCpuWidth = C_W_D + kTsBits;
+              C_W_PLO = C_R1_PTS + 4, C_W_PHI = C_R1_PTS + 5, C_R1_D = C_R1_PTS + 6, C_R2_D = C_R1_D + kTsLimbs,
+              C_M_D = C_R2_D + kTsLimbs, C_W_D = C_M_D + kTsLimbs, kCpuWidth = C_W_D + kTsLimbs;
 enum { SC_HALT = 0, SC_WRITE, SC_COMMIT, SC_DEFER, SC_HINT_LEN, SC_HINT_READ };
-static_assert(kCpuWidth == 322, "CPU chip layout");
+static_assert(kCpuWidth == 234, "CPU chip layout");
 
 // ---- keccak chip: p3-keccak-air's columns + the call time ----
 constexpr int KC_TS = ka::kWidth, kKeccakWidth = ka::kWidth + 1;
 // ---- keccak-memory chip ----
 constexpr int KM_IS_REAL = 0, KM_TS = 1, KM_PTR_LO = 2, KM_PTR_HI = 3, KM_IDX = 4, KM_ISF = 5, KM_ISL = 6, KM_CALL = 7,
               KM_ADDR = 8, KM_OLD_LO = 9, KM_OLD_HI = 10, KM_NEW_LO = 11, KM_NEW_HI = 12, KM_PTS = 13, KM_D = 14,
-              kKmemWidth = KM_D + kTsBits;
+              kKmemWidth = KM_D + kTsLimbs;
 // ---- memory boundary chip ----
 constexpr int MF_IS_REAL = 0, MF_ADDR = 1, MF_IS_INIT = 2, MF_FIN_LO = 3, MF_FIN_HI = 4, MF_FIN_TS = 5, MF_DIFF = 6,
               MF_INIT = MF_DIFF + 32, kMemFinalWidth = MF_INIT + 32;
@@ -54,7 +55,10 @@ constexpr int PR_PC = 0, PR_OP = 1, PR_WR = 2, PR_USE2 = 3, PR_RD = 4, PR_RS1 = 
 constexpr int MU_IS_REAL = 0, MU_HI = 1, MU_B = 2, MU_C = MU_B + 32, MU_P = MU_C + 32, MU_Q0 = MU_P + 64, MU_Q1 = MU_Q0 + 10,
               MU_Q2 = MU_Q1 + 11, kMulWidth = MU_Q2 + 10;
 
-enum Bus { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_MUL, BUS_PUBC, BUS_PUBH };
+// ---- range table: preprocessed (value = row index), main (multiplicity); always 2^kTsLimbBits rows ----
+constexpr int kRangePrepWidth = 1, kRangeWidth = 1, kRangeLogH = kTsLimbBits;
+
+enum Bus { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_MUL, BUS_PUBC, BUS_PUBH, BUS_RANGE };
 
 // Ctx interface:
 //   using F;  F local(int col); F next(int col); F is_first(); F is_trans(); F is_last(); F pub();
@@ -87,18 +91,18 @@ ZKSP_HD F bool_c(F v, F one) {
 }
 
 // Constraint index space of the CPU chip (fixes which power of alpha multiplies which constraint):
-//   0..303 booleans (IS_REAL, OP[30], WR, USE2, A/B/C/M/X bits, K0..3, EQ, O0..3, SC[6], the four
-//   24-bit time differences), 304..313 row structure, 314..315 immediate operand, 316..319 add/sub,
-//   320..325 xor/or/and, 326..333 shifts, 334..339 comparisons, 340..352 next pc, 353..354 address
-//   adder, 355..360 byte offset, 361..383 loads/stores, 384..387 ecall, 388..391 access times.
+//   0..207 booleans (IS_REAL, OP[30], WR, USE2, A/B/C/M/X bits, K0..3, EQ, O0..3, SC[6]),
+//   208..217 row structure, 218..219 immediate operand, 220..223 add/sub, 224..229 xor/or/and,
+//   230..237 shifts, 238..243 comparisons, 244..256 next pc, 257..258 address adder, 259..264 byte
+//   offset, 265..287 loads/stores, 288..291 ecall, 292..295 access times.
 // The evaluation below walks the columns block by block (each column is read once, its block's
 // arrays die before the next block is loaded) and emits by index, so the device kernel keeps a few
 // dozen live values instead of reloading 5 000 operands per point.
 // Ctx additionally provides  F sum_prod(const F* x, const F* y, int ystep, int n) = sum x[i] * y[i * ystep].
 namespace cpuidx {
 constexpr int kBoolA = 33, kBoolB = 65, kBoolC = 97, kBoolM = 129, kBoolX = 161, kBoolK = 193, kBoolEq = 197, kBoolO = 198,
-              kBoolSc = 202, kBoolD = 208, kStruct = 304, kImm = 314, kAddSub = 316, kBitwise = 320, kShift = 326, kCmp = 334,
-              kNextPc = 340, kAddr = 353, kOff = 355, kLoadStore = 361, kEcall = 384, kTimes = 388;
+              kBoolSc = 202, kStruct = 208, kImm = 218, kAddSub = 220, kBitwise = 224, kShift = 230, kCmp = 238,
+              kNextPc = 244, kAddr = 257, kOff = 259, kLoadStore = 265, kEcall = 288, kTimes = 292;
 }
 
 ZKSP_HD constexpr uint32_t pow2_mod(int n) { return (uint32_t)(((uint64_t)1 << n) % kP); }
@@ -123,10 +127,10 @@ ZKSP_HD F byte8(const F* bits, int byte) {
   return s;
 }
 
-// The 392 constraints in four independent tasks, each reading only the column blocks it needs (a block
+// The 296 constraints in four independent tasks, each reading only the column blocks it needs (a block
 // that two tasks need is read by both): the device runs a task per workgroup, so a lane holds a few
-// dozen live values instead of the whole 322-column row; the verifier runs all four in sequence.
-//   task 0  selectors, row structure, the four access-time decompositions        (scalars, D bits)
+// dozen live values instead of the whole 234-column row; the verifier runs all four in sequence.
+//   task 0  selectors, row structure, the four access-time differences           (scalars)
 //   task 1  A, B, C: immediate operand, add / sub, bitwise, jal / jalr link, ecall, keccak return
 //   task 2  X with A, B, C: shifts, comparisons, branches, jalr target, address adder, byte offset
 //   task 3  M with A, C: loads and stores
@@ -196,20 +200,12 @@ ZKSP_HD void eval_cpu_task(Ctx& ctx) {
     ctx.emit_at(kBoolEq, bool_c(L(C_EQ), one));
 #pragma unroll
     for (int i = 0; i < 4; ++i) ctx.emit_at(kBoolO + i, bool_c(L(C_O0 + i), one));
-    // access times: stream the four 24-bit differences
+    // access times: a difference is limb 0 + 2^12 limb 1; the limbs' ranges come from the RANGE bus
     const int dcol[4] = {C_R1_D, C_R2_D, C_M_D, C_W_D};
+    const F klimb = ZKSP_K(1u << kTsLimbBits);
     F dv[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      F acc = zero;
-#pragma unroll
-      for (int i = kTsBits - 1; i >= 0; --i) {
-        const F bit = L(dcol[q] + i);
-        ctx.emit_at(kBoolD + q * kTsBits + i, bool_c(bit, one));
-        acc = acc.dbl() + bit;
-      }
-      dv[q] = acc;
-    }
+    for (int q = 0; q < 4; ++q) dv[q] = L(dcol[q]) + klimb * L(dcol[q] + 1);
     ctx.emit_at(kTimes + 0, is_real * (ts - L(C_R1_PTS) - one - dv[0]));
     ctx.emit_at(kTimes + 1, use2 * (ts - L(C_R2_PTS) - dv[1]));
     ctx.emit_at(kTimes + 2, ld_st_ecall * (ts + one - L(C_M_PTS) - dv[2]));
@@ -436,9 +432,9 @@ ZKSP_HD void eval_cpu(Ctx& ctx) {
   eval_cpu_task<1>(ctx);
   eval_cpu_task<2>(ctx);
   eval_cpu_task<3>(ctx);
-  ctx.set_count(392);
+  ctx.set_count(296);
 }
-constexpr int kCpuConstraints = 392;
+constexpr int kCpuConstraints = 296;
 
 template <class Ctx>
 ZKSP_HD void eval_kmem(Ctx& ctx) {
@@ -447,7 +443,6 @@ ZKSP_HD void eval_kmem(Ctx& ctx) {
   ctx.emit(bool_c(L(KM_IS_REAL), one));
   ctx.emit(bool_c(L(KM_ISF), one));
   ctx.emit(bool_c(L(KM_ISL), one));
-  for (int i = 0; i < kTsBits; ++i) ctx.emit(bool_c(L(KM_D + i), one));
   ctx.emit(L(KM_CALL) - L(KM_ISF) * L(KM_IS_REAL));
   ctx.emit(is_first * L(KM_IDX));
   ctx.emit(is_first * (L(KM_ISF) - one));
@@ -461,9 +456,9 @@ ZKSP_HD void eval_kmem(Ctx& ctx) {
   ctx.emit(is_trans * nl * (ctx.next(KM_PTR_LO) - L(KM_PTR_LO)));
   ctx.emit(is_trans * nl * (ctx.next(KM_PTR_HI) - L(KM_PTR_HI)));
   ctx.emit(L(KM_IS_REAL) * (L(KM_ADDR) - (L(KM_PTR_LO) + ZKSP_K(65536) * L(KM_PTR_HI) + ZKSP_K(4) * L(KM_IDX))));
-  ctx.emit(L(KM_IS_REAL) * (L(KM_TS) + one - L(KM_PTS) - bits_val<F>(ctx, KM_D, kTsBits)));
+  ctx.emit(L(KM_IS_REAL) * (L(KM_TS) + one - L(KM_PTS) - (L(KM_D) + ZKSP_K(1u << kTsLimbBits) * L(KM_D + 1))));
 }
-constexpr int kKmemConstraints = 40;
+constexpr int kKmemConstraints = 16;
 
 template <class Ctx>
 ZKSP_HD void eval_memfinal(Ctx& ctx) {
@@ -519,7 +514,7 @@ constexpr int kKeccakConstraints = ka::kNumConstraints + 1;
 
 ZKSP_HD constexpr int num_constraints(int chip) {
   return chip == kCpu ? kCpuConstraints : chip == kKeccak ? kKeccakConstraints : chip == kKmem ? kKmemConstraints
-       : chip == kMemFinal ? kMemFinalConstraints : chip == kImage ? 1 : chip == kProgram ? 0 : kMulConstraints;
+       : chip == kMemFinal ? kMemFinalConstraints : chip == kImage ? 1 : chip == kProgram ? 0 : chip == kMul ? kMulConstraints : 0;
 }
 
 }  // namespace mach

@@ -28,11 +28,12 @@ struct MachineRecords {
   const uint32_t* prog_mult;   // [B][2^log_prog]
   const uint32_t* image_used;  // [B][2^log_image]
   const uint32_t* counts;      // [B][4]: cycles, keccak calls, memfinal rows, muls
+  uint32_t* range_hist;        // [B][2^kRangeLogH] scratch: multiplicities of the range table, counted on the device
   size_t cap_cycles, cap_keccak, cap_memfinal, cap_muls;
   const uint32_t* program;     // [n_program][9] (shared)
   uint32_t text_base, n_program;
 };
-// trace: [B][main_width][2^logh] of the given chip (kCpu, kKmem, kMemFinal, kImage, kProgram, kMul)
+// trace: [B][main_width][2^logh] of the given chip (kCpu, kKmem, kMemFinal, kImage, kProgram, kMul, kRange)
 void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& rec, uint32_t* trace, int logh, int batch);
 // keccak chip: p3-keccak-air's columns by launch_keccak_trace (kernels.h, with a batch stride), then the call time
 void launch_keccak_ts(hipStream_t stream, const MachineRecords& rec, uint32_t* trace, size_t trace_bstride, int logh,

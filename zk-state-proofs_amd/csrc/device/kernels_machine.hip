@@ -42,6 +42,11 @@ struct Col {
   __device__ __forceinline__ void zero(int col, int n) const {
     for (int i = 0; i < n; ++i) t[(size_t)(col + i) * cs] = 0u;
   }
+  // an access-time difference as its two range-checked limbs
+  __device__ __forceinline__ void gap(int col, uint32_t v) const {
+    val(col, v & ((1u << kTsLimbBits) - 1));
+    val(col + 1, v >> kTsLimbBits);
+  }
 };
 
 __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh) {
@@ -120,13 +125,13 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
   for (uint32_t i = 0; i < 6; ++i) o.put(C_SC + i, i == sc ? kR1 : 0u);
   const bool memq = (op >= LB && op <= SW) || op == ECALL;
   o.val(C_R1_PTS, cy[7]);
-  o.bits(C_R1_D, ts - cy[7] - 1, kTsBits);
+  o.gap(C_R1_D, ts - cy[7] - 1);
   o.val(C_R2_PTS, use2 ? cy[8] : 0u);
-  o.bits(C_R2_D, use2 ? ts - cy[8] : 0u, kTsBits);
+  o.gap(C_R2_D, use2 ? ts - cy[8] : 0u);
   o.val(C_M_PTS, memq ? cy[9] : 0u);
-  o.bits(C_M_D, memq ? ts + 1 - cy[9] : 0u, kTsBits);
+  o.gap(C_M_D, memq ? ts + 1 - cy[9] : 0u);
   o.val(C_W_PTS, wr ? cy[10] : 0u);
-  o.bits(C_W_D, wr ? ts + 2 - cy[10] : 0u, kTsBits);
+  o.gap(C_W_D, wr ? ts + 2 - cy[10] : 0u);
   o.val(C_W_PLO, wr ? wprev & 0xffff : 0u);
   o.val(C_W_PHI, wr ? wprev >> 16 : 0u);
 }
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(64) void kmem_trace_kernel(MachineRecords rec, uint
   o.val(KM_OLD_LO, wi & 0xffff); o.val(KM_OLD_HI, wi >> 16);
   o.val(KM_NEW_LO, wo & 0xffff); o.val(KM_NEW_HI, wo >> 16);
   o.val(KM_PTS, k->pts[i]);
-  o.bits(KM_D, k->ts + 1 - k->pts[i], kTsBits);
+  o.gap(KM_D, k->ts + 1 - k->pts[i]);
 }
 
 __global__ __launch_bounds__(kMT) void memfinal_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh) {
@@ -241,9 +246,49 @@ __global__ __launch_bounds__(kMT) void count_column_kernel(const uint32_t* __res
   trace[(size_t)blockIdx.y * n + r] = mont(src[(size_t)blockIdx.y * n + r]);
 }
 
+// Range table multiplicities: how often each 12-bit value occurs among the live access-time limbs of the CPU and
+// keccak-memory chips.  A workgroup counts its slice of the records in LDS, then adds its non-zero bins to
+// hist[b][.] (zeroed by the launcher).
+constexpr int kRangeBlocks = 64;
+__global__ __launch_bounds__(kMT) void range_count_kernel(MachineRecords rec, uint32_t* __restrict__ hist) {
+  constexpr uint32_t kBins = 1u << kTsLimbBits;
+  __shared__ uint32_t bins[kBins];
+  const int b = blockIdx.y;
+  for (uint32_t i = threadIdx.x; i < kBins; i += kMT) bins[i] = 0;
+  __syncthreads();
+  auto count = [&](uint32_t gap) {
+    if ((gap >> kTsLimbBits) >= kBins) return;  // no valid proof exists for such a run; the prover still terminates
+    atomicAdd(&bins[gap & (kBins - 1)], 1u);
+    atomicAdd(&bins[gap >> kTsLimbBits], 1u);
+  };
+  const uint32_t n = rec.counts[4 * b];
+  for (uint32_t r = blockIdx.x * kMT + threadIdx.x; r < n; r += gridDim.x * kMT) {
+    const uint32_t* cy = rec.cycles + ((size_t)b * rec.cap_cycles + r) * 12;
+    const uint32_t* p = rec.program + 9 * (size_t)((cy[0] - rec.text_base) >> 2);
+    const uint32_t op = p[1], ts = 4 * (r + 1);
+    count(ts - cy[7] - 1);
+    if (p[3]) count(ts - cy[8]);
+    if ((op >= LB && op <= SW) || op == ECALL) count(ts + 1 - cy[9]);
+    if (p[2]) count(ts + 2 - cy[10]);
+  }
+  const uint32_t nk = rec.counts[4 * b + 1] * 50;
+  for (uint32_t j = blockIdx.x * kMT + threadIdx.x; j < nk; j += gridDim.x * kMT) {
+    const KCall* k = reinterpret_cast<const KCall*>(rec.kcalls + ((size_t)b * rec.cap_keccak + j / 50) * 408);
+    count(k->ts + 1 - k->pts[j % 50]);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < kBins; i += kMT)
+    if (bins[i]) atomicAdd(&hist[(size_t)b * kBins + i], bins[i]);
+}
+
 void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& rec, uint32_t* trace, int logh, int batch) {
   const size_t h = (size_t)1 << logh;
   switch (chip) {
+    case kRange:
+      (void)hipMemsetAsync(rec.range_hist, 0, (size_t)batch * h * 4, stream);
+      hipLaunchKernelGGL(range_count_kernel, dim3(kRangeBlocks, batch), dim3(kMT), 0, stream, rec, rec.range_hist);
+      hipLaunchKernelGGL(count_column_kernel, dim3((unsigned)((h + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec.range_hist, trace, h);
+      break;
     case kCpu:
       hipLaunchKernelGGL(cpu_trace_kernel, dim3((unsigned)((h + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec, trace, logh);
       break;
@@ -468,7 +513,14 @@ __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, 
     const Fp scc = col(C_SC + SC_COMMIT), scd = col(C_SC + SC_DEFER);
     visit(5, mulsel, fm, scc + scd, busc(BUS_PUBC) + b1 * (scc + scd.dbl()) + b2 * c_lo + b3 * m_lo + b4 * m_hi, true);
   }
-  visit(6, col(C_SC + SC_HALT), busc(BUS_PUBH) + b1 * c_lo + b2 * c_hi, Fp::zero(), gamma, false);
+  // the limbs of the four access-time differences, looked up in the range table while their access is live
+  const Fp4 grng = busc(BUS_RANGE);
+  auto rng = [&](int c) { return grng + b1 * col(c); };
+  visit(6, col(C_SC + SC_HALT), busc(BUS_PUBH) + b1 * c_lo + b2 * c_hi, -is_real, rng(C_R1_D), true);
+  visit(7, -is_real, rng(C_R1_D + 1), -use2, rng(C_R2_D), true);
+  visit(8, -use2, rng(C_R2_D + 1), -memq, rng(C_M_D), true);
+  visit(9, -memq, rng(C_M_D + 1), -wr, rng(C_W_D), true);
+  visit(10, -wr, rng(C_W_D + 1), Fp::zero(), gamma, false);
 }
 
 __global__ __launch_bounds__(kMT) void perm_terms_cpu_kernel(PermArgs a) {
@@ -853,7 +905,7 @@ __global__ __launch_bounds__(kMT) void cpu_quotient_task_kernel(MQuotArgs a) {
     const uint32_t* bpow = a.bpow + (size_t)b * (kInterMaxElems + 1) * 4;
     const uint32_t* ap = a.alpha_pows + (size_t)b * a.alpha_bstride;
     const uint32_t* pl = a.perm.p + (size_t)b * a.perm.bstride + (size_t)pi.c * h;
-    constexpr int nh = 7;
+    constexpr int nh = 11;
     Fp4 hsum = Fp4::zero(), acc = Fp4::zero();
     cpu_bus_pairs(a.main_.p + (size_t)b * a.main_.bstride + pt, n, gamma, bpow,
                   [&](int j, Fp ma, const Fp4& fa, Fp mb, const Fp4& fb, bool pair) {
@@ -964,6 +1016,7 @@ void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a) {
     case kImage: hipLaunchKernelGGL(machine_quotient_kernel<kImage>, grid, block, 0, stream, a); break;
     case kProgram: hipLaunchKernelGGL(machine_quotient_kernel<kProgram>, grid, block, 0, stream, a); break;
     case kMul: hipLaunchKernelGGL(machine_quotient_kernel<kMul>, grid, block, 0, stream, a); break;
+    case kRange: hipLaunchKernelGGL(machine_quotient_kernel<kRange>, grid, block, 0, stream, a); break;
     case kKeccak: {
       const int blocks = (int)((n + kMT - 1) / kMT), total_tiles = blocks * a.batch;
       hipLaunchKernelGGL(keccak_machine_quotient_kernel, dim3((unsigned)total_tiles * ka::kNumTasks), block, 0, stream, a, blocks,

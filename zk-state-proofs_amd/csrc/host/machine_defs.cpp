@@ -5,6 +5,7 @@
 //   KIO    (time, word index, in_lo, in_hi, out_lo, out_hi)   keccak-f chip -> keccak-memory
 //   MUL    (hi, a_lo, a_hi, b_lo, b_hi, c_lo, c_hi)   CPU -> multiplier
 //   PUBC   (kind, index, lo, hi), PUBH (exit_lo, exit_hi)   CPU -> verifier
+//   RANGE  (value)   a 12-bit limb of an access-time difference, looked up in the range table
 #include "machine_defs.hpp"
 
 #include <cstdlib>
@@ -53,7 +54,14 @@ Interaction mem_inter(int sign, const LinForm& mult, const LinForm& addr, const 
   return it;
 }
 
-Interaction g_cpu[13], g_keccak[50], g_kmem[4], g_memfinal[2], g_image[1], g_program[1], g_mul[2];
+Interaction range_inter(int sign, const LinForm& mult, const LinForm& value) {
+  Interaction it{};
+  it.bus = BUS_RANGE; it.sign = sign; it.mult = mult; it.n_el = 1;
+  it.el[0] = value;
+  return it;
+}
+
+Interaction g_cpu[21], g_keccak[50], g_kmem[6], g_memfinal[2], g_image[1], g_program[1], g_mul[2], g_range[1];
 ChipDef g_chips[kNumChips];
 
 void build() {
@@ -83,6 +91,13 @@ void build() {
     lf_add(maddr, C_O1, kP - 1); lf_add(maddr, C_O2, kP - 2); lf_add(maddr, C_O3, kP - 3);
     g_cpu[5] = mem_inter(-1, memq, maddr, m_lo, m_hi, lf_col(C_M_PTS));
     g_cpu[6] = mem_inter(+1, memq, maddr, lf_col(C_MV_LO), lf_col(C_MV_HI), lf_plus(ts, 2));
+    // the limbs of the four access-time differences are looked up when their access is live
+    for (int j = 0; j < kTsLimbs; ++j) {
+      g_cpu[13 + j] = range_inter(-1, is_real, lf_col(C_R1_D + j));
+      g_cpu[15 + j] = range_inter(-1, lf_col(C_USE2), lf_col(C_R2_D + j));
+      g_cpu[17 + j] = range_inter(-1, memq, lf_col(C_M_D + j));
+      g_cpu[19 + j] = range_inter(-1, lf_col(C_WR), lf_col(C_W_D + j));
+    }
   }
   g_cpu[7] = mem_inter(-1, lf_col(C_WR), lf_col(C_RD), lf_col(C_W_PLO), lf_col(C_W_PHI), lf_col(C_W_PTS));
   g_cpu[8] = mem_inter(+1, lf_col(C_WR), lf_col(C_RD), a_lo, a_hi, lf_plus(ts, 3));
@@ -130,6 +145,7 @@ void build() {
     io.el[4] = lf_col(KM_NEW_LO); io.el[5] = lf_col(KM_NEW_HI);
     g_kmem[2] = mem_inter(-1, lf_col(KM_IS_REAL), lf_col(KM_ADDR), lf_col(KM_OLD_LO), lf_col(KM_OLD_HI), lf_col(KM_PTS));
     g_kmem[3] = mem_inter(+1, lf_col(KM_IS_REAL), lf_col(KM_ADDR), lf_col(KM_NEW_LO), lf_col(KM_NEW_HI), lf_plus(lf_col(KM_TS), 2));
+    for (int j = 0; j < kTsLimbs; ++j) g_kmem[4 + j] = range_inter(-1, lf_col(KM_IS_REAL), lf_col(KM_D + j));
   }
   g_memfinal[0] = mem_inter(-1, lf_col(MF_IS_REAL), lf_col(MF_ADDR), lf_col(MF_FIN_LO), lf_col(MF_FIN_HI), lf_col(MF_FIN_TS));
   g_memfinal[1] = mem_inter(+1, lf_col(MF_IS_INIT), lf_col(MF_ADDR), lf_limb(MF_INIT, 0), lf_limb(MF_INIT, 1), lf_const(0));
@@ -150,9 +166,11 @@ void build() {
     it.el[1] = lf_limb(MU_P, 2 * hi); it.el[2] = lf_limb(MU_P, 2 * hi + 1);
     it.el[3] = lf_limb(MU_B, 0); it.el[4] = lf_limb(MU_B, 1); it.el[5] = lf_limb(MU_C, 0); it.el[6] = lf_limb(MU_C, 1);
   }
-  g_chips[kCpu] = {"cpu", 0, kCpuWidth, 13, g_cpu, kCpuConstraints};
+  g_range[0] = range_inter(+1, lf_col(kRangePrepWidth + 0), lf_col(0));
+  g_chips[kRange] = {"range", kRangePrepWidth, kRangeWidth, 1, g_range, 0};
+  g_chips[kCpu] = {"cpu", 0, kCpuWidth, 21, g_cpu, kCpuConstraints};
   g_chips[kKeccak] = {"keccak", 0, kKeccakWidth, 50, g_keccak, kKeccakConstraints};
-  g_chips[kKmem] = {"keccak-mem", 0, kKmemWidth, 4, g_kmem, kKmemConstraints};
+  g_chips[kKmem] = {"keccak-mem", 0, kKmemWidth, 6, g_kmem, kKmemConstraints};
   g_chips[kMemFinal] = {"mem-final", 0, kMemFinalWidth, 2, g_memfinal, kMemFinalConstraints};
   g_chips[kImage] = {"image", kImagePrepWidth, kImageWidth, 1, g_image, 1};
   g_chips[kProgram] = {"program", kProgramPrepWidth, kProgramWidth, 1, g_program, 0};

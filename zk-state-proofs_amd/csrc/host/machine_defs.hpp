@@ -35,7 +35,7 @@ struct ChipDef {
 const ChipDef& chip_def(int chip);
 
 constexpr int kHeaderWords = 2 + kNumChips + 2 + 24;
-constexpr uint32_t kMachineVersion = 3;
+constexpr uint32_t kMachineVersion = 4;
 
 }  // namespace mach
 }  // namespace zksp

@@ -92,6 +92,7 @@ void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh
   logh[kImage] = prog.log_image;
   logh[kProgram] = prog.log_prog;
   logh[kMul] = at_least5(ceil_log2(t.muls.size()));
+  logh[kRange] = kRangeLogH;
 }
 
 int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const PrepDevice** out) {
@@ -101,13 +102,14 @@ int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineV
   if (it != ctx->prep.end()) { *out = it->second.get(); return 0; }
   std::unique_ptr<PrepDevice> pd(new PrepDevice());
   hipStream_t s = ctx->stream;
-  std::vector<uint32_t> tr[2];
-  machine_prep_traces(prog, &tr[0], &tr[1]);
+  std::vector<uint32_t> tr[PrepDevice::kMats];
+  machine_prep_traces(prog, &tr[0], &tr[1], &tr[2]);
   pd->logh[0] = prog.log_image;
   pd->logh[1] = prog.log_prog;
-  const int widths[2] = {kImagePrepWidth, kProgramPrepWidth};
+  pd->logh[2] = kRangeLogH;
+  const int widths[PrepDevice::kMats] = {kImagePrepWidth, kProgramPrepWidth, kRangePrepWidth};
   bool ok = true;
-  for (int i = 0; i < 2 && ok; ++i) {
+  for (int i = 0; i < PrepDevice::kMats && ok; ++i) {
     const size_t h = (size_t)1 << pd->logh[i];
     for (auto& v : tr[i]) v = Fp::from_canonical(v).v;
     ok = ok && dalloc(&pd->allocs, &pd->tr[i], tr[i].size());
@@ -122,7 +124,7 @@ int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineV
                pd->logh[i], (size_t)widths[i]);
     ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // tr[i] goes out of use
   }
-  pd->lm = std::max(pd->logh[0], pd->logh[1]);
+  pd->lm = std::max(std::max(pd->logh[0], pd->logh[1]), pd->logh[2]);
   const size_t N = (size_t)2 << pd->lm;
   ok = ok && dalloc(&pd->allocs, &pd->tree, (2 * N - 1) * 8);
   ok = ok && dalloc(&pd->allocs, &pd->inj, N * 8);
@@ -132,10 +134,12 @@ int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineV
   memset(&rm, 0, sizeof rm);
   rm.seg[kImage][0] = Seg{pd->lde[0], 0, kImagePrepWidth};
   rm.seg[kProgram][0] = Seg{pd->lde[1], 0, kProgramPrepWidth};
+  rm.seg[kRange][0] = Seg{pd->lde[2], 0, kRangePrepWidth};
   rm.logh[kImage] = pd->logh[0];
   rm.logh[kProgram] = pd->logh[1];
+  rm.logh[kRange] = pd->logh[2];
   uint32_t* inj[32];
-  for (auto& p : inj) p = pd->inj;  // at most one shorter group
+  for (auto& p : inj) p = pd->inj;  // a level's injected digests are consumed before the next level writes its own
   mmcs_commit(s, rm, pd->tree, 0, inj, 1, ctx->d_consts);
   static_assert(sizeof(ProgramRow) == 36, "program row layout");
   ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(pd->program, prog.rows.data(), prog.rows.size() * 36, hipMemcpyHostToDevice, s));
@@ -178,6 +182,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   A(&w->muls, B * w->cap_muls * 3);
   A(&w->prog_mult, B << logh[kProgram]);
   A(&w->image_used, B << logh[kImage]);
+  A(&w->range_hist, B << kRangeLogH);
   A(&w->counts, B * 4);
   A(&w->n_perms, B);
   A(&w->init_obs, B * kMachineInitObs);
@@ -362,15 +367,15 @@ int machine_prove_resident(Context* ctx) {
   const size_t N = (size_t)2 << lm, tree_stride = (2 * N - 1) * 8, root_off = (2 * N - 2) * 8;
   auto H = [&](int c) { return (size_t)1 << logh[c]; };
   auto prep_seg = [&](int c, bool lde) -> Seg {
-    if (c == kImage) return Seg{lde ? prep->lde[0] : nullptr, 0, kImagePrepWidth};
-    if (c == kProgram) return Seg{lde ? prep->lde[1] : nullptr, 0, kProgramPrepWidth};
-    return Seg{nullptr, 0, 0};
+    const int pi = PrepDevice::index_of(c);
+    if (pi < 0) return Seg{nullptr, 0, 0};
+    return Seg{lde ? prep->lde[pi] : nullptr, 0, chip_def(c).prep_w};
   };
 
   // ---- main traces ----
   MachineRecords rec;
   rec.cycles = w->cycles; rec.kcalls = w->kcalls; rec.memfinal = w->memfinal; rec.muls = w->muls;
-  rec.prog_mult = w->prog_mult; rec.image_used = w->image_used; rec.counts = w->counts;
+  rec.prog_mult = w->prog_mult; rec.image_used = w->image_used; rec.counts = w->counts; rec.range_hist = w->range_hist;
   rec.cap_cycles = w->cap_cycles; rec.cap_keccak = w->cap_keccak; rec.cap_memfinal = w->cap_memfinal; rec.cap_muls = w->cap_muls;
   rec.program = prep->program; rec.text_base = prep->text_base; rec.n_program = prep->n_program;
   {
@@ -420,7 +425,7 @@ int machine_prove_resident(Context* ctx) {
       pa.chip = c;
       pa.inter = static_cast<const Interaction*>(ctx->d_inter[c]);
       pa.n_inter = d.n_inter;
-      pa.prep = Seg{c == kImage ? prep->tr[0] : c == kProgram ? prep->tr[1] : nullptr, 0, d.prep_w};
+      pa.prep = Seg{d.prep_w ? prep->tr[PrepDevice::index_of(c)] : nullptr, 0, d.prep_w};
       pa.main_ = Seg{w->mat[c][0].tr, (size_t)d.main_w * H(c), d.main_w};
       pa.bus_ch = w->bus_ch;
       pa.bpow = w->bpow;
@@ -521,7 +526,7 @@ int machine_prove_resident(Context* ctx) {
         if (logh[c] >= 12) launch_open_tall(s, coefs, cstride, ncols, logh[c], w->zpow[c], 2 * h * 4, npts, dst, 8 * R, pts, w->reduce_scratch, B);
         else launch_open(s, coefs, cstride, ncols, logh[c], w->zpow[c], 2 * h * 4, npts, dst, 8 * R, pts, B);
       };
-      if (pw) open(c == kImage ? prep->coef[0] : prep->coef[1], 0, pw, 1, base, 0);
+      if (pw) open(prep->coef[PrepDevice::index_of(c)], 0, pw, 1, base, 0);
       open(w->mat[c][0].coef, (size_t)mw * h, mw, 2, base + (size_t)pw * 4, pt_stride);
       open(w->mat[c][1].coef, (size_t)ew * h, ew, 2, base + (size_t)(pw + mw) * 4, pt_stride);
       open(w->mat[c][2].coef, 8 * h, 8, 1, base + (size_t)(pw + mw + ew) * 4, 0);

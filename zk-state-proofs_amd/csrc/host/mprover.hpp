@@ -1,5 +1,5 @@
 // Device prover of the machine proof: batch workspace in HBM and the launch sequence that turns
-// traced executions into proof bodies ("ZKSP v3") without a host round trip.  See mprover.cpp.
+// traced executions into proof bodies ("ZKSP v4") without a host round trip.  See mprover.cpp.
 #pragma once
 #include <array>
 #include <vector>
@@ -15,12 +15,14 @@ constexpr int kMachineInitObs = 8 + mach::kNumChips + 2 + 16 + 16;  // vk digest
 
 // Preprocessed tables of one program on the device (built once per verifying key).
 struct PrepDevice {
-  int logh[2] = {0, 0};            // image, program
-  uint32_t* tr[2] = {nullptr, nullptr};     // traces (the permutation trace is built from trace rows)
-  uint32_t* coef[2] = {nullptr, nullptr};
-  uint32_t* lde[2] = {nullptr, nullptr};
-  uint32_t* tree = nullptr;        // mixed-height tree over (image, program)
-  uint32_t* inj = nullptr;         // leaf digests of the shorter of the two tables, if heights differ
+  static constexpr int kMats = 3;   // image, program, range (chip order)
+  static int index_of(int chip) { return chip == mach::kImage ? 0 : chip == mach::kProgram ? 1 : chip == mach::kRange ? 2 : -1; }
+  int logh[kMats] = {0, 0, 0};
+  uint32_t* tr[kMats] = {nullptr, nullptr, nullptr};     // traces (the permutation trace is built from trace rows)
+  uint32_t* coef[kMats] = {nullptr, nullptr, nullptr};
+  uint32_t* lde[kMats] = {nullptr, nullptr, nullptr};
+  uint32_t* tree = nullptr;        // mixed-height tree over the three tables
+  uint32_t* inj = nullptr;         // leaf digests of a shorter group (one level at a time, in stream order)
   uint32_t* program = nullptr;     // [n][9] rows for trace expansion
   uint32_t n_program = 0, text_base = 0, entry = 0;
   int lm = 0;
@@ -33,7 +35,8 @@ struct MachineWorkspace {
   size_t cap_cycles = 0, cap_keccak = 0, cap_memfinal = 0, cap_muls = 0;
   const PrepDevice* prep = nullptr;
   // records
-  uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *image_used = nullptr, *counts = nullptr;
+  uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *image_used = nullptr, *counts = nullptr,
+           *range_hist = nullptr;
   uint8_t* kcalls = nullptr;
   uint64_t* kstates = nullptr;
   uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;

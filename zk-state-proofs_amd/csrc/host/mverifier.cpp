@@ -1,4 +1,4 @@
-// Host verifier of the machine proof ("ZKSP v3"): replaces `client.verify(&proof, &vk)` (reference
+// Host verifier of the machine proof ("ZKSP v4"): replaces `client.verify(&proof, &vk)` (reference
 // prover/src/bin/main.rs:80; sp1-stark 3.4.0's multi-chip verifier over p3-uni-stark / p3-fri,
 // Cargo.lock:7485, :5378, :5253) for proofs that bind the guest's whole execution.  Also the
 // host half of `client.setup(ELF)` (main.rs:70): the commitment to the preprocessed Program and
@@ -178,10 +178,13 @@ void vk_digest_of(const uint32_t root_canon[8], uint32_t entry, int log_prog, in
 
 }  // namespace
 
-void machine_prep_traces(const MachineProgram& prog, std::vector<uint32_t>* image_prep, std::vector<uint32_t>* program_prep) {
+void machine_prep_traces(const MachineProgram& prog, std::vector<uint32_t>* image_prep, std::vector<uint32_t>* program_prep,
+                         std::vector<uint32_t>* range_prep) {
   const size_t hi = (size_t)1 << prog.log_image, hp = (size_t)1 << prog.log_prog;
   image_prep->assign((size_t)kImagePrepWidth * hi, 0);
   program_prep->assign((size_t)kProgramPrepWidth * hp, 0);
+  range_prep->resize((size_t)1 << kRangeLogH);
+  for (size_t r = 0; r < range_prep->size(); ++r) (*range_prep)[r] = (uint32_t)r;
   for (size_t r = 0; r < prog.image.size(); ++r) {
     (*image_prep)[(size_t)IMG_P_ADDR * hi + r] = prog.image[r].addr;
     (*image_prep)[(size_t)IMG_P_LO * hi + r] = prog.image[r].val & 0xffff;
@@ -198,11 +201,13 @@ void machine_prep_traces(const MachineProgram& prog, std::vector<uint32_t>* imag
 
 void machine_host_setup(const MachineProgram& prog, MachineVk* vk) {
   const P2Consts* kc = &host_p2_consts();
-  std::vector<uint32_t> tr[2];
-  machine_prep_traces(prog, &tr[0], &tr[1]);
-  const int logs[2] = {prog.log_image, prog.log_prog}, widths[2] = {kImagePrepWidth, kProgramPrepWidth};
-  std::vector<std::vector<Fp>> lde[2];  // [matrix][col] -> [2][H]
-  for (int mtx = 0; mtx < 2; ++mtx) {
+  constexpr int kPrepMats = 3;
+  std::vector<uint32_t> tr[kPrepMats];
+  machine_prep_traces(prog, &tr[0], &tr[1], &tr[2]);
+  const int logs[kPrepMats] = {prog.log_image, prog.log_prog, kRangeLogH},
+            widths[kPrepMats] = {kImagePrepWidth, kProgramPrepWidth, kRangePrepWidth};
+  std::vector<std::vector<Fp>> lde[kPrepMats];  // [matrix][col] -> [2][H]
+  for (int mtx = 0; mtx < kPrepMats; ++mtx) {
     const size_t h = (size_t)1 << logs[mtx];
     lde[mtx].resize(widths[mtx]);
     for (int c = 0; c < widths[mtx]; ++c) {
@@ -211,11 +216,11 @@ void machine_host_setup(const MachineProgram& prog, MachineVk* vk) {
       host_lde(col, logs[mtx], &lde[mtx][c]);
     }
   }
-  // mixed-height tree over (image, program) in chip order
-  const int lm = std::max(logs[0], logs[1]), logn = lm + 1;
+  // mixed-height tree over (image, program, range) in chip order
+  const int lm = std::max(std::max(logs[0], logs[1]), logs[2]), logn = lm + 1;
   auto group_hash = [&](int group_logn, size_t pos, Fp out[8]) -> bool {
     std::vector<Fp> cat;
-    for (int mtx = 0; mtx < 2; ++mtx) {
+    for (int mtx = 0; mtx < kPrepMats; ++mtx) {
       if (logs[mtx] + 1 != group_logn) continue;
       const size_t h = (size_t)1 << logs[mtx], cs = pos >> logs[mtx], m = bitrev32((uint32_t)(pos & (h - 1)), logs[mtx]);
       for (int c = 0; c < widths[mtx]; ++c) cat.push_back(lde[mtx][c][cs * h + m]);
@@ -296,7 +301,10 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   const size_t body_words = machine_proof_body_words(logh, num_queries);
   if (len != hd.body_offset + body_words * 4) { *err = "proof length mismatch"; return 7; }
   if (memcmp(hd.vk_digest, vk.digest, 32) != 0) { *err = "verifying key mismatch"; return 8; }
-  if (logh[kImage] != vk.log_image || logh[kProgram] != vk.log_prog) { *err = "preprocessed table heights differ from the key"; return 8; }
+  if (logh[kImage] != vk.log_image || logh[kProgram] != vk.log_prog || logh[kRange] != kRangeLogH) {
+    *err = "preprocessed table heights differ from the key";
+    return 8;
+  }
   {
     uint8_t dg[32];
     sha256(bytes + hd.pv_offset, hd.pv_len, dg);
@@ -422,6 +430,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       case kImage: eval_image(zc); break;
       case kProgram: break;
       case kMul: eval_mul(zc); break;
+      case kRange: break;
     }
     if (zc.k_ != nb) { *err = "internal: constraint count"; return 7; }
     // LogUp: row = [prep | main] at zeta

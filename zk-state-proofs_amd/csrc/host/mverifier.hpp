@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "machine.hpp"
+#include "machine_defs.hpp"
 #include "verifier.hpp"
 
 namespace zksp {
@@ -21,14 +22,15 @@ struct MachineVk {
 };
 
 struct MachineHeader {
-  int logh[7];
+  int logh[mach::kNumChips];
   uint32_t exit_code, pv_len;
   uint32_t pv_digest[8], deferred_digest[8], vk_digest[8];
   size_t pv_offset, body_offset;
 };
 
 // preprocessed traces, canonical, column-major: image [3][2^log_image], program [10][2^log_prog]
-void machine_prep_traces(const MachineProgram& prog, std::vector<uint32_t>* image_prep, std::vector<uint32_t>* program_prep);
+void machine_prep_traces(const MachineProgram& prog, std::vector<uint32_t>* image_prep, std::vector<uint32_t>* program_prep,
+                         std::vector<uint32_t>* range_prep);
 // host-side commitment of the preprocessed tables (setup; no GPU)
 void machine_host_setup(const MachineProgram& prog, MachineVk* vk);
 size_t machine_proof_body_words(const int* logh, uint32_t num_queries);

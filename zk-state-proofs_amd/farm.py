@@ -14,6 +14,8 @@ from typing import List, Sequence
 
 import numpy as np
 
+from .client import MACHINE_CHIPS, MACHINE_HEADER_WORDS, MACHINE_VERSION
+
 
 def shard_indices(n_total: int, rank: int, world: int) -> List[int]:
     """Block-cyclic: proof i goes to rank i % world (costs are near-uniform within a
@@ -26,8 +28,8 @@ def shard_indices(n_total: int, rank: int, world: int) -> List[int]:
 def trace_root_of(proof_bytes: bytes) -> np.ndarray:
     """The 8-word main-trace commitment of a serialized proof (first body words)."""
     words = np.frombuffer(proof_bytes, dtype="<u4")
-    if int(words[1]) == 3:  # machine proof: 35 header words (7 chip heights), public values, then the main root
-        off = 35 + (int(words[10]) + 3) // 4
+    if int(words[1]) == MACHINE_VERSION:  # machine proof: fixed header (chip heights ..), public values, then the main root
+        off = MACHINE_HEADER_WORDS + (int(words[3 + MACHINE_CHIPS]) + 3) // 4
         return words[off:off + 8].copy()
     n_perms, pv_len = int(words[3]), int(words[5])
     off = 30 + (pv_len + 3) // 4 + 100 * n_perms  # fixed header, public values, public I/O list
