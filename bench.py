@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable)
 
-# chip widths of the machine proof (zk-state-proofs_amd/csrc/device/air_machine.cuh): (preprocessed, main, permutation)
+# chip widths of the machine proof (zk-state-proofs_amd/csrc/device/air_machine.hpp): (preprocessed, main, permutation)
 CHIPS = [("cpu", 0, 234, 48), ("keccak", 0, 2634, 104), ("keccak-mem", 0, 16, 16), ("mem-final", 0, 70, 8),
          ("image", 3, 1, 8), ("program", 10, 1, 8), ("mul", 0, 161, 8), ("range", 1, 1, 8)]
 
@@ -250,8 +250,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16,
-                    help="machine proofs proven in lockstep per GPU per step (about 3.2 GB of HBM each at acct-d8)")
+    ap.add_argument("--batch", type=int, default=32,
+                    help="machine proofs proven in lockstep per GPU per step (about 2.7 GB of HBM each at acct-d8)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-single", action="store_true", help="skip latency / end-to-end / component sections (profiling runs)")
@@ -471,7 +471,8 @@ def main():
             "parallelism": f"proof-farm x{world} (independent proofs, all-gather of 32-byte roots only)",
         },
         "roofline": {
-            "kernel": "mmcs_leaf_kernel over the CPU chip's main LDE (Poseidon2 sponge, 41 permutations per row, 2^20 rows per proof)",
+            "kernel": f"mmcs_leaf_kernel over the CPU chip's main LDE (Poseidon2 sponge, {(sum(w for w, _ in leaf_group) + 7) // 8} "
+                      f"permutations per row, 2^{max(heights) + 1} rows per proof)",
             # bound by vector-ALU issue (one Poseidon2 permutation per 32 bytes absorbed); achieved / peak / frac are the
             # contractual HBM figures: algorithmic bytes over the launch time against the 8 TB/s peak
             "bound": "valu",

@@ -37,7 +37,7 @@ SOURCES = [
     "host/api_machine.cpp",
 ]
 HEADERS = [
-    "device/field.cuh", "device/poseidon2.cuh", "device/air_keccak.cuh", "device/air_machine.cuh", "device/kernels.h", "device/kernels_machine.h",
+    "device/field.hpp", "device/poseidon2.hpp", "device/air_keccak.hpp", "device/air_machine.hpp", "device/kernels.h", "device/kernels_machine.h",
     "host/machine_defs.hpp", "host/mverifier.hpp", "host/mprover.hpp", "host/host_hash.hpp",
     "host/executor.hpp", "host/machine.hpp", "host/context.hpp", "host/prover.hpp", "host/verifier.hpp", "host/api_types.hpp",
 ]

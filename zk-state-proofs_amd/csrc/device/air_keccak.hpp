@@ -8,7 +8,7 @@
 // permutation, 2633 columns, 64-bit lanes as 4 x u16 limbs, degree-3 constraints.
 // Constraint ORDER and grouping are this repository's own (DESIGN.md "Keccak AIR").
 #pragma once
-#include "field.cuh"
+#include "field.hpp"
 
 namespace zksp {
 namespace ka {

@@ -10,7 +10,7 @@
 // entry point to HALT with the committed public values.  DESIGN.md "Machine proof" describes the
 // construction; constraint ORDER here is normative for the proof bytes.
 #pragma once
-#include "air_keccak.cuh"
+#include "air_keccak.hpp"
 
 namespace zksp {
 namespace mach {

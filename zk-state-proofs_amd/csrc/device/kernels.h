@@ -1,13 +1,13 @@
 // Host-callable launchers for the HIP kernels of the proving hot path
 // (SURVEY.md section 8a rows a3-a7).  Every launcher enqueues on `stream` and
 // returns immediately; none allocates or synchronises (graph-capturable).
-// All field elements in device buffers are Montgomery residues (field.cuh).
+// All field elements in device buffers are Montgomery residues (field.hpp).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
 
-#include "poseidon2.cuh"
+#include "poseidon2.hpp"
 
 namespace zksp {
 

@@ -5,7 +5,7 @@
 //     sums over),
 //   * the running-sum trace phi: phi_0 = 0, phi_{i+1} = phi_i + export_i / f_i with
 //     f = gamma + sum_j beta^j t_j over the row's 200-limb tuple, and its total S.
-#include "air_keccak.cuh"
+#include "air_keccak.hpp"
 #include "kernels.h"
 
 namespace zksp {

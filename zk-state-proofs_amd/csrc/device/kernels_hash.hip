@@ -8,7 +8,7 @@
 // once, fully coalesced.  Upper layers: one lane per parent; once a layer fits one
 // workgroup the rest of the tree is finished in a single launch.
 #include "kernels.h"
-#include "merkle_coop.cuh"
+#include "merkle_coop.hpp"
 
 namespace zksp {
 
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kHashThreads) void compress_layer_kernel(uint32_t* 
 }
 
 // Finishes a tree from a layer of `count` (<= 2*kHashThreads) digests, one workgroup per proof
-// (merkle_coop.cuh).
+// (merkle_coop.hpp).
 __global__ __launch_bounds__(kTopThreads) void compress_top_kernel(uint32_t* __restrict__ tree, size_t tree_stride,
                                                                   size_t in_off, int count,
                                                                   const P2Consts* __restrict__ consts) {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kHashThreads) void leaf_hash_coop_kernel(const uint
   uint32_t ahead[kPrefetch];
 #pragma unroll
   for (int j = 0; j < kPrefetch; ++j) ahead[j] = fetch(8 * j);
-  int32_t x = 0;  // signed lazy word between permutations (poseidon2_coop.cuh)
+  int32_t x = 0;  // signed lazy word between permutations (poseidon2_coop.hpp)
   for (int c0 = 0; c0 < width; c0 += 8 * kPrefetch) {
     uint32_t cur[kPrefetch];
 #pragma unroll

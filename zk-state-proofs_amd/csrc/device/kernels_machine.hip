@@ -740,7 +740,7 @@ struct MQCtx {
   __device__ __forceinline__ F pub() const { return pub_; }
   __device__ __forceinline__ F one() const { return Fp::one(); }
   __device__ __forceinline__ F k(uint32_t monty) const { return Fp::raw(monty); }
-  // acc += alpha^k * v through signed 64-bit lazy sums (field.cuh), as in the keccak quotient kernel
+  // acc += alpha^k * v through signed 64-bit lazy sums (field.hpp), as in the keccak quotient kernel
   __device__ __forceinline__ void emit_at(int idx, F v) {
     const uint32_t* p = ap + 4 * (size_t)idx;
 #pragma unroll
@@ -754,7 +754,7 @@ struct MQCtx {
   __device__ __forceinline__ void emit(F v) { emit_at(k_++, v); }
   __device__ __forceinline__ void set_count(int n) { k_ = n; }
   // sum x[i] * y[i * ystep] through a signed 64-bit lazy sum: x is centred (|x| <= p/2), y canonical,
-  // |term| < p^2 / 2, four terms between shrinks (field.cuh)
+  // |term| < p^2 / 2, four terms between shrinks (field.hpp)
   __device__ __forceinline__ F sum_prod(const F* x, const F* y, int ystep, int n) const {
     int64_t t = 0;
 #pragma unroll
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
   for (int j = 0; j < 4; ++j) dst[(size_t)(4 * pi.c + j) * h] = q.c[j].v;
 }
 
-// CPU chip: its four constraint tasks (air_machine.cuh) and the LogUp constraints as five launches, each
+// CPU chip: its four constraint tasks (air_machine.hpp) and the LogUp constraints as five launches, each
 // with its own register budget; every launch leaves one partial extension-field sum per point.
 template <int TASK>
 __global__ __launch_bounds__(kMT) void cpu_quotient_task_kernel(MQuotArgs a) {
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(kMT) void cpu_quotient_combine_kernel(MQuotArgs a) 
   for (int j = 0; j < 4; ++j) q[(size_t)(4 * c + j) * h] = acc.c[j].v;
 }
 
-// keccak chip: p3-keccak-air's 12 evaluation tasks (air_keccak.cuh) plus one task for the call-time
+// keccak chip: p3-keccak-air's 12 evaluation tasks (air_keccak.hpp) plus one task for the call-time
 // constraint and the LogUp constraints; XCD-aware tile order as in keccak_quotient_kernel
 __global__ __launch_bounds__(kMT) void keccak_machine_quotient_kernel(MQuotArgs a, int tiles_per_proof, int total_tiles) {
   const size_t h = (size_t)1 << a.logh, n = 2 * h;

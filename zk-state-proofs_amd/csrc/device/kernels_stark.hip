@@ -9,9 +9,9 @@
 // Batch convention: the leading (slowest) index of every buffer is the proof in
 // the batch; kernels take it from blockIdx.y (or one lane per proof for the
 // transcript kernels, so that a whole batch of sponges advances in one wave).
-#include "air_keccak.cuh"
+#include "air_keccak.hpp"
 #include "kernels.h"
-#include "merkle_coop.cuh"
+#include "merkle_coop.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -133,7 +133,7 @@ struct QuotCtx {
   Fp first, trans, last;
   const uint32_t* ap;  // this proof's alpha powers (Fp4 each), indexed by constraint
   Fp4 acc;             // extension-valued constraints, and the folded total at the end
-  int64_t lazy[4];     // signed lazy sum of alpha^k_i * c_k per coordinate (field.cuh)
+  int64_t lazy[4];     // signed lazy sum of alpha^k_i * c_k per coordinate (field.hpp)
   int pending;
   // LogUp bus
   const uint32_t* ploc;  // running-sum columns at this point / the next row (stride cs)

@@ -3,7 +3,7 @@
 // workgroup of kTopThreads threads.  Replaces the corresponding parts of p3-merkle-tree / p3-fri
 // 0.1.4-succinct (reference Cargo.lock:5336, :5253).
 #pragma once
-#include "poseidon2_coop.cuh"
+#include "poseidon2_coop.hpp"
 
 namespace zksp {
 

@@ -4,7 +4,7 @@
 // this repository's own (DESIGN.md "Poseidon2 instance"); constants arrive in
 // Montgomery form through a P2Consts table built on the host.
 #pragma once
-#include "field.cuh"
+#include "field.hpp"
 
 namespace zksp {
 
@@ -47,7 +47,7 @@ struct P2Consts {
 // canonical implementation after canonicalisation (tests/test_gpu_kernels.py and the
 // host verifier, which runs this same code).
 // ---------------------------------------------------------------------------
-// the arithmetic itself is field.cuh's signed lazy layer
+// the arithmetic itself is field.hpp's signed lazy layer
 constexpr int32_t p2s_centre(uint32_t v) { return fps_centre_const(v); }
 ZKSP_HD int32_t p2s_sbox(int32_t x) {
   const int32_t x2 = fps_mul(x, x), x3 = fps_mul(x2, x), x4 = fps_mul(x2, x2);

@@ -1,7 +1,7 @@
 // Cooperative Poseidon2: ONE permutation spread over 16 adjacent lanes (one DPP
 // "row"), state element i in lane i of the row, four permutations per wave.
 //
-// The lane-per-state form (poseidon2.cuh) is the throughput form: 64 permutations
+// The lane-per-state form (poseidon2.hpp) is the throughput form: 64 permutations
 // per wave, about 5 000 VALU instructions each.  Tree tops, FRI tails, the
 // Fiat-Shamir sponge and a single proof's leaf hashing are chains of DEPENDENT
 // permutations with almost no parallelism, so their cost is the length of the
@@ -9,7 +9,7 @@
 // the linear layers are cross-lane DPP adds (quad_perm inside a 4-chunk, row_ror
 // across chunks).
 //
-// Arithmetic is the signed lazy layer of field.cuh, which roughly halves the chain
+// Arithmetic is the signed lazy layer of field.hpp, which roughly halves the chain
 // (about 450 dependent instructions instead of 870 with canonical residues):
 //  * a product is mad, mul_lo, mad with no correction;
 //  * a word x is split as x = xh * 2^16 + xl (xh signed, xl in [0, 2^16)) before a linear
@@ -20,7 +20,7 @@
 //  * internal rounds: T = x * d~ + (sum_h * (2^16 c) + sum_l * c) [+ rc R^2 on element 0].
 // Same function, same constants, bit-identical results after canonicalisation.
 #pragma once
-#include "poseidon2.cuh"
+#include "poseidon2.hpp"
 
 namespace zksp {
 

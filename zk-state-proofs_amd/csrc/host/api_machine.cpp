@@ -11,6 +11,39 @@
 
 using namespace zksp;
 
+// Header (version, chip heights, exit code, digests, key digest), public values, body: the v4 proof object.
+int machine_proof_from_parts(const zksp_pk* pk, const ExecutionRecord& r, const int* lh, const uint32_t* body, size_t body_words,
+                             zksp_proof** out) {
+  zksp_proof* p = new (std::nothrow) zksp_proof();
+  if (!p) return ZKSP_ERR_INVALID_ARG;
+  try {
+    const size_t pvw = (r.public_values.size() + 3) / 4;
+    p->bytes.assign(((size_t)mach::kHeaderWords + pvw + body_words) * 4, 0);
+    uint32_t* w = reinterpret_cast<uint32_t*>(p->bytes.data());
+    w[0] = kProofMagic;
+    w[1] = mach::kMachineVersion;
+    for (int c = 0; c < mach::kNumChips; ++c) w[2 + c] = (uint32_t)lh[c];
+    w[2 + mach::kNumChips] = r.exit_code;
+    w[3 + mach::kNumChips] = (uint32_t)r.public_values.size();
+    memcpy(w + 4 + mach::kNumChips, r.pv_digest.data(), 32);
+    memcpy(w + 12 + mach::kNumChips, r.deferred_digest.data(), 32);
+    memcpy(w + 20 + mach::kNumChips, pk->mvk.digest, 32);
+    if (!r.public_values.empty()) memcpy(w + mach::kHeaderWords, r.public_values.data(), r.public_values.size());
+    memcpy(w + mach::kHeaderWords + pvw, body, body_words * 4);
+  } catch (...) {
+    delete p;
+    return ZKSP_ERR_INVALID_ARG;
+  }
+  std::string err;
+  p->version = mach::kMachineVersion;
+  if (!parse_machine_header(p->bytes.data(), p->bytes.size(), &p->mhdr, &err)) {
+    delete p;
+    return ZKSP_ERR_PROOF_FORMAT;
+  }
+  *out = p;
+  return ZKSP_OK;
+}
+
 extern "C" {
 
 int zksp_machine_trace(zksp_client* c, const zksp_pk* pk, const zksp_stdin* stdin_, zksp_mtrace** out) {
@@ -142,37 +175,9 @@ int zksp_hip_machine_fetch_roots(zksp_client* c, uint32_t* out, size_t cap_words
 int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const uint32_t* body, size_t body_words,
                                  zksp_proof** out) {
   if (!pk || !t || !body || !out) return ZKSP_ERR_INVALID_ARG;
-  zksp_proof* p = new (std::nothrow) zksp_proof();
-  if (!p) return ZKSP_ERR_INVALID_ARG;
-  try {
-    const ExecutionRecord& r = t->t.rec;
-    const size_t pvw = (r.public_values.size() + 3) / 4;
-    p->bytes.assign(((size_t)mach::kHeaderWords + pvw + body_words) * 4, 0);
-    uint32_t* w = reinterpret_cast<uint32_t*>(p->bytes.data());
-    int lh[mach::kNumChips];
-    machine_heights(*t->prog, t->t, lh);
-    w[0] = kProofMagic;
-    w[1] = mach::kMachineVersion;
-    for (int c = 0; c < mach::kNumChips; ++c) w[2 + c] = (uint32_t)lh[c];
-    w[2 + mach::kNumChips] = r.exit_code;
-    w[3 + mach::kNumChips] = (uint32_t)r.public_values.size();
-    memcpy(w + 4 + mach::kNumChips, r.pv_digest.data(), 32);
-    memcpy(w + 12 + mach::kNumChips, r.deferred_digest.data(), 32);
-    memcpy(w + 20 + mach::kNumChips, pk->mvk.digest, 32);
-    if (!r.public_values.empty()) memcpy(w + mach::kHeaderWords, r.public_values.data(), r.public_values.size());
-    memcpy(w + mach::kHeaderWords + pvw, body, body_words * 4);
-  } catch (...) {
-    delete p;
-    return ZKSP_ERR_INVALID_ARG;
-  }
-  std::string err;
-  p->version = mach::kMachineVersion;
-  if (!parse_machine_header(p->bytes.data(), p->bytes.size(), &p->mhdr, &err)) {
-    delete p;
-    return ZKSP_ERR_PROOF_FORMAT;
-  }
-  *out = p;
-  return ZKSP_OK;
+  int lh[mach::kNumChips];
+  machine_heights(*t->prog, t->t, lh);
+  return machine_proof_from_parts(pk, t->t.rec, lh, body, body_words, out);
 }
 
 int zksp_vk_machine(const zksp_vk* vk, uint32_t* prep_root8, uint32_t* digest8) {

@@ -101,6 +101,8 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
                                int32_t* status) {
   Context* ctx = &c->ctx;
   for (size_t i = 0; i < n; ++i) { out[i] = nullptr; status[i] = ZKSP_ERR_INVALID_ARG; }
+  if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess)
+    return ctx->fail(ZKSP_ERR_HIP, "prove: could not create the copy stream");
   std::vector<std::unique_ptr<zksp_mtrace>> traces(n);
   const BatchTrace mark;
   parallel_for(n, 64, [&](size_t i) {
@@ -135,6 +137,15 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     machine_heights(pk->mprog, traces[i]->t, lh.data());
     groups[lh].push_back(i);
   }
+  // Traces whose records are on the device are torn down by a helper thread (tens of megabytes each) while
+  // this thread keeps the GPU fed; joined on every way out.
+  struct Reaper {
+    std::vector<std::thread> th;
+    ~Reaper() {
+      for (auto& t : th)
+        if (t.joinable()) t.join();
+    }
+  } reaper;
   int rc_all = ZKSP_OK;
   for (auto& kv : groups) {
     // bytes of HBM one proof of these heights needs (traces, coefficients, LDEs of the three rounds, scratch)
@@ -144,27 +155,64 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       per_proof += ((size_t)(d.main_w + d.perm_width() + 8) * 16 + 64) << kv.first[ch];
     }
     const size_t cap = std::max<size_t>(1, std::min<size_t>(ctx->params.max_batch, ((size_t)150 << 30) / std::max<size_t>(per_proof, 1)));
-    for (size_t off = 0; off < kv.second.size(); off += cap) {
-      const size_t cnt = std::min(cap, kv.second.size() - off);
+    const std::vector<size_t>& idx = kv.second;
+    const size_t n_chunks = (idx.size() + cap - 1) / cap;
+    auto chunk_traces = [&](size_t k) {
+      const size_t off = k * cap, cnt = std::min(cap, idx.size() - off);
       std::vector<const MachineTrace*> ts(cnt);
-      for (size_t j = 0; j < cnt; ++j) ts[j] = &traces[kv.second[off + j]]->t;
-      int rc = machine_load(ctx, pk->mprog, pk->mvk, ts.data(), cnt);
-      mark.mark("loaded", cnt);
-      if (rc == ZKSP_OK) rc = machine_prove_resident(ctx);
-      const size_t bw = ctx->mws ? ctx->mws->body_words : 0;
-      std::vector<uint32_t> bodies(rc == ZKSP_OK ? cnt * bw : 0);
-      if (rc == ZKSP_OK &&
-          (hipMemcpyAsync(bodies.data(), ctx->mws->body, bodies.size() * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-           hipStreamSynchronize(ctx->stream) != hipSuccess))
-        rc = ctx->fail(ZKSP_ERR_HIP, "prove: device-to-host copy failed");
+      for (size_t j = 0; j < cnt; ++j) ts[j] = &traces[idx[off + j]]->t;
+      return ts;
+    };
+    auto fail_from = [&](size_t k, int rc) {
+      for (size_t j = k * cap; j < idx.size(); ++j) status[idx[j]] = rc;
+      rc_all = rc;
+    };
+    // chunk k is proven while chunk k + 1 is uploaded into the spare record set and chunk k - 1 is wrapped
+    ctx->batch_hint = (int)std::min(cap, idx.size());
+    std::vector<const MachineTrace*> cur = chunk_traces(0);
+    int rc = machine_load(ctx, pk->mprog, pk->mvk, cur.data(), cur.size());
+    mark.mark("loaded", cur.size());
+    if (rc == ZKSP_OK) rc = machine_prove_resident(ctx);
+    if (rc != ZKSP_OK) { fail_from(0, rc); continue; }
+    for (size_t k = 0; k < n_chunks; ++k) {
+      const size_t off = k * cap, cnt = std::min(cap, idx.size() - off);
+      const bool more = k + 1 < n_chunks;
+      std::vector<const MachineTrace*> nxt;
+      int rc_next = ZKSP_OK;
+      if (more) {
+        nxt = chunk_traces(k + 1);
+        rc_next = machine_load(ctx, pk->mprog, pk->mvk, nxt.data(), nxt.size(), /*into_spare=*/true);
+        mark.mark("next loaded", nxt.size());
+      }
+      const size_t bw = ctx->mws->body_words;
+      std::vector<uint32_t> bodies(cnt * bw);
+      if (hipMemcpyAsync(bodies.data(), ctx->mws->body, bodies.size() * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        fail_from(k, ctx->fail(ZKSP_ERR_HIP, "prove: device-to-host copy failed"));
+        break;
+      }
       mark.mark("proved and fetched", cnt);
+      if (more) {  // the GPU goes on with the next chunk while this one is wrapped
+        if (rc_next == ZKSP_OK) rc_next = machine_activate_spare(ctx);
+        if (rc_next == ZKSP_OK) rc_next = machine_prove_resident(ctx);
+      }
+      // the proof objects need the execution record and the heights only: hand the bulky vectors to the reaper
+      std::vector<MachineTrace> dead(cnt);
       for (size_t j = 0; j < cnt; ++j) {
-        const size_t i = kv.second[off + j];
-        if (rc != ZKSP_OK) { status[i] = rc; rc_all = rc; continue; }
-        const int prc = zksp_machine_proof_from_body(pk, traces[i].get(), bodies.data() + j * bw, bw, &out[i]);
-        status[i] = prc;
+        MachineTrace& t = traces[idx[off + j]]->t;
+        dead[j].cycles.swap(t.cycles); dead[j].keccak.swap(t.keccak); dead[j].memfinal.swap(t.memfinal);
+        dead[j].muls.swap(t.muls); dead[j].prog_mult.swap(t.prog_mult); dead[j].image_used.swap(t.image_used);
+      }
+      try {
+        reaper.th.emplace_back([d = std::move(dead)]() mutable { d.clear(); });
+      } catch (...) {
+      }  // no thread: `dead` is destroyed here instead
+      for (size_t j = 0; j < cnt; ++j) {
+        const size_t i = idx[off + j];
+        status[i] = machine_proof_from_parts(pk, traces[i]->t.rec, kv.first.data(), bodies.data() + j * bw, bw, &out[i]);
       }
       mark.mark("wrapped", cnt);
+      if (more && rc_next != ZKSP_OK) { fail_from(k + 1, rc_next); break; }
     }
   }
   if (!first_err.empty() && rc_all == ZKSP_OK) ctx->error = first_err;

@@ -1,11 +1,11 @@
 // Host-side Poseidon2 sponge, compression, duplex challenger and Merkle helpers shared by the two
 // verifiers (verifier.cpp: keccak-chip proofs, mverifier.cpp: machine proofs).  Same definitions the
-// device uses (poseidon2.cuh), instantiated on the host.
+// device uses (poseidon2.hpp), instantiated on the host.
 #pragma once
 #include <cstddef>
 #include <vector>
 
-#include "../device/poseidon2.cuh"
+#include "../device/poseidon2.hpp"
 
 namespace zksp {
 namespace hosthash {

@@ -1,12 +1,12 @@
 // Static description of the machine proof's chips for the host (verifier, prover orchestration)
 // and, flattened, for the device's generic LogUp kernels: widths, bus interactions as linear forms
 // over the row [preprocessed | main], constraint counts.  Column layouts and constraints live in
-// ../device/air_machine.cuh.  (sp1-core-machine's chip registry + interaction builder in SP1,
+// ../device/air_machine.hpp.  (sp1-core-machine's chip registry + interaction builder in SP1,
 // reference Cargo.lock:7130.)
 #pragma once
 #include <cstdint>
 
-#include "../device/air_machine.cuh"
+#include "../device/air_machine.hpp"
 
 namespace zksp {
 namespace mach {

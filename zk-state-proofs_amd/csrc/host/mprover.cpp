@@ -187,6 +187,17 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   A(&w->n_perms, B);
   A(&w->init_obs, B * kMachineInitObs);
   A(&w->pub_words, B * 17);
+  A(&w->spare.cycles, B * w->cap_cycles * 12);
+  A(&w->spare.kcalls, B * w->cap_keccak * 408);
+  A(&w->spare.kstates, B * w->cap_keccak * 25);
+  A(&w->spare.memfinal, B * w->cap_memfinal * 5);
+  A(&w->spare.muls, B * w->cap_muls * 3);
+  A(&w->spare.prog_mult, B << logh[kProgram]);
+  A(&w->spare.image_used, B << logh[kImage]);
+  A(&w->spare.counts, B * 4);
+  A(&w->spare.n_perms, B);
+  A(&w->spare.init_obs, B * kMachineInitObs);
+  A(&w->spare.pub_words, B * 17);
   int lm = 0;
   size_t n_open = 0, max_total = 0, max_h = 0;
   for (int c = 0; c < kNumChips; ++c) {
@@ -269,29 +280,61 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   return 0;
 }
 
-int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const MachineTrace* const* traces, size_t n) {
+namespace {
+void swap_records(MachineWorkspace* w) {
+  MachineWorkspace::SpareRecords& p = w->spare;
+  std::swap(w->cycles, p.cycles); std::swap(w->memfinal, p.memfinal); std::swap(w->muls, p.muls);
+  std::swap(w->prog_mult, p.prog_mult); std::swap(w->image_used, p.image_used); std::swap(w->counts, p.counts);
+  std::swap(w->kcalls, p.kcalls); std::swap(w->kstates, p.kstates); std::swap(w->n_perms, p.n_perms);
+  std::swap(w->init_obs, p.init_obs); std::swap(w->pub_words, p.pub_words); std::swap(w->n, p.n);
+}
+}  // namespace
+
+int machine_activate_spare(Context* ctx) {
+  MachineWorkspace* w = ctx->mws.get();
+  if (!w || w->spare.n == 0) return ctx->fail(1, "machine_activate_spare: nothing was loaded into the spare set");
+  swap_records(w);
+  w->spare.n = 0;
+  return 0;
+}
+
+int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const MachineTrace* const* traces, size_t n,
+                 bool into_spare) {
   if (n == 0) return ctx->fail(1, "machine_load: empty batch");
   const PrepDevice* prep = nullptr;
   int rc = machine_prep_ensure(ctx, prog, vk, &prep);
   if (rc) return rc;
   int logh[kNumChips];
   machine_heights(prog, *traces[0], logh);
-  size_t cc = 0, ck = 0, cm = 0, cu = 0;
-  for (size_t i = 0; i < n; ++i) {
+  for (size_t i = 1; i < n; ++i) {
     int li[kNumChips];
     machine_heights(prog, *traces[i], li);
     if (memcmp(li, logh, sizeof li) != 0) return ctx->fail(1, "machine_load: traces of one batch must have identical chip heights");
-    cc = std::max(cc, traces[i]->cycles.size()); ck = std::max(ck, traces[i]->keccak.size());
-    cm = std::max(cm, traces[i]->memfinal.size()); cu = std::max(cu, traces[i]->muls.size());
   }
+  // record capacities follow from the heights alone, so every batch of these heights fits the same workspace
+  const size_t cc = (size_t)1 << logh[kCpu], cm = (size_t)1 << logh[kMemFinal], cu = (size_t)1 << logh[kMul],
+               ck = std::min(((size_t)1 << logh[kKeccak]) / 24, ((size_t)1 << logh[kKmem]) / 50);
   if (logh[kCpu] > 21) return ctx->fail(9, "machine_load: more than 2^21 cycles");
   for (int c = 1; c < kNumChips; ++c)
     if (logh[c] > logh[kCpu]) return ctx->fail(9, "machine_load: a chip is taller than the CPU chip");
-  rc = workspace_ensure(ctx, logh, (int)std::max<size_t>(n, (size_t)ctx->batch_hint), cc, ck, cm, cu);
-  if (rc) return rc;
+  if (into_spare) {
+    MachineWorkspace* w0 = ctx->mws.get();
+    if (!w0 || memcmp(w0->logh, logh, sizeof w0->logh) != 0 || (size_t)w0->batch < n || !ctx->copy_stream)
+      return ctx->fail(1, "machine_load: the spare set takes batches of the resident heights only");
+  } else {
+    rc = workspace_ensure(ctx, logh, (int)std::max<size_t>(n, (size_t)ctx->batch_hint), cc, ck, cm, cu);
+    if (rc) return rc;
+  }
   MachineWorkspace* w = ctx->mws.get();
   w->prep = prep;
-  hipStream_t s = ctx->stream;
+  hipStream_t s = into_spare ? ctx->copy_stream : ctx->stream;
+  // from here to the end of the function the named record pointers are the set being written
+  struct SwapBack {
+    MachineWorkspace* w;
+    bool on;
+    ~SwapBack() { if (on) swap_records(w); }
+  } swap_back{w, into_spare};
+  if (into_spare) swap_records(w);
   std::vector<uint32_t> counts(n * 4), nperms(n), obs(n * kMachineInitObs), pubw(n * 17);
   std::vector<uint64_t> kst(n * w->cap_keccak * 25, 0);
   const size_t hp = (size_t)1 << logh[kProgram], hi = (size_t)1 << logh[kImage];

@@ -40,6 +40,15 @@ struct MachineWorkspace {
   uint8_t* kcalls = nullptr;
   uint64_t* kstates = nullptr;
   uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;
+  // A second set of record buffers: the next batch is uploaded (copy stream) while the current one is
+  // being proven, then machine_activate_spare() swaps the sets.
+  struct SpareRecords {
+    uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *image_used = nullptr, *counts = nullptr;
+    uint8_t* kcalls = nullptr;
+    uint64_t* kstates = nullptr;
+    uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;
+    int n = 0;
+  } spare;
   // per chip: [0] main, [1] permutation, [2] quotient
   struct Mat { uint32_t *tr = nullptr, *coef = nullptr, *lde = nullptr; int w = 0; };
   Mat mat[mach::kNumChips][3];
@@ -61,8 +70,13 @@ struct MachineWorkspace {
 
 // uploads the preprocessed tables of `prog` and commits them; the root must equal vk.prep_root
 int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const PrepDevice** out);
-// sizes the workspace for `n` traces of identical chip heights and uploads their records
-int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const MachineTrace* const* traces, size_t n);
+// sizes the workspace for `n` traces of identical chip heights and uploads their records; with `into_spare`
+// the upload goes to the spare record set on the copy stream (the resident batch and a proving pass in
+// flight are untouched; the heights must be the resident batch's)
+int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const MachineTrace* const* traces, size_t n,
+                 bool into_spare = false);
+// makes the spare record set the resident batch (call when no proving pass is in flight)
+int machine_activate_spare(Context* ctx);
 // enqueues the whole proving pass over the resident batch
 int machine_prove_resident(Context* ctx);
 void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh[mach::kNumChips]);

@@ -7,7 +7,7 @@
 // Checks, in order: header sanity and key; sha256(public values) = committed digest; exit code 0;
 // the LogUp buses balance (chips' cumulative sums + the public COMMIT / HALT terms = 0); for every
 // chip the constraint identity at zeta with the SAME templates the device quotient kernels
-// instantiate (air_machine.cuh, air_keccak.cuh); proof of work; every FRI query: the four
+// instantiate (air_machine.hpp, air_keccak.hpp); proof of work; every FRI query: the four
 // mixed-height Merkle openings, the reduced openings per height, the folding chain.
 #include "mverifier.hpp"
 

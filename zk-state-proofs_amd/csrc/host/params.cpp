@@ -47,7 +47,7 @@ void build_p2_consts(P2Consts* out) {
   out->diag[0] = Fp::from_canonical(kP - 2).v;
   for (int i = 1; i < 15; ++i) out->diag[i] = Fp::from_canonical(1u << (i - 1)).v;
   out->diag[15] = Fp::from_canonical(1u << 15).v;
-  // derived tables of the signed lazy permutation (poseidon2.cuh): constants times R^2,
+  // derived tables of the signed lazy permutation (poseidon2.hpp): constants times R^2,
   // attached to the linear layer that precedes their round
   auto times_r = [](uint32_t monty) { return (int64_t)(((uint64_t)monty * kRModP) % kP); };
   for (int i = 0; i < 16; ++i) out->sdiag[i] = p2s_centre(out->diag[i]);

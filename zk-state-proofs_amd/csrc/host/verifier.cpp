@@ -2,14 +2,14 @@
 // prover/src/bin/main.rs:80; sp1-stark 3.4.0 + p3-uni-stark / p3-fri verifiers,
 // Cargo.lock:7485, :5378, :5253).  Re-derives the Fiat-Shamir transcript, recomputes
 // the LogUp bus sum from the public I/O list, checks the constraint identity at zeta
-// with the SAME AIR template the device quotient kernel instantiates (air_keccak.cuh),
+// with the SAME AIR template the device quotient kernel instantiates (air_keccak.hpp),
 // then the FRI queries.  Needs no GPU.
 #include "verifier.hpp"
 
 #include <cstring>
 
-#include "../device/air_keccak.cuh"
-#include "../device/poseidon2.cuh"
+#include "../device/air_keccak.hpp"
+#include "../device/poseidon2.hpp"
 #include "executor.hpp"
 #include "host_hash.hpp"
 
