@@ -1081,32 +1081,45 @@ __global__ __launch_bounds__(kMT) void mreduce_partial_kernel(MReduceArgs a, int
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc1[q][j] = acc2[q][j] = 0;
-  int pending = 0;
-  for (int i = i0; i < i1; ++i) {
-    const int mi = i < w0 ? 0 : i < w01 ? 1 : i < w012 ? 2 : 3;
-    const int col = i - (mi == 0 ? 0 : mi == 1 ? w0 : mi == 2 ? w01 : w012);
-    const Seg& sg = a.mats[mi];
-    const uint4 v = *reinterpret_cast<const uint4*>(sg.p + (size_t)b * sg.bstride + (size_t)col * n + pt);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    const uint32_t* al = ap + (size_t)i * 4;
-    const bool two = mi == 1 || mi == 2;
-    const uint32_t* al2 = ap + (size_t)(n1 + i - w0) * 4;
+  // four columns per trip: their loads are issued together, then the 2 x 16 signed 64-bit sums take the four products
+  // each; every second trip brings the sums back to range
+  for (int i = i0; i < i1; i += 4) {
+    uint4 v[4];
+    const uint32_t *al[4], *al2[4];
+    bool two[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int32_t alpha = fps_centre(al[j]);
-      const int32_t alpha2 = two ? fps_centre(al2[j]) : 0;
+    for (int u = 0; u < 4; ++u) {
+      const int iu = min(i + u, i1 - 1);
+      const int mi = iu < w0 ? 0 : iu < w01 ? 1 : iu < w012 ? 2 : 3;
+      const int col = iu - (mi == 0 ? 0 : mi == 1 ? w0 : mi == 2 ? w01 : w012);
+      const Seg& sg = a.mats[mi];
+      v[u] = *reinterpret_cast<const uint4*>(sg.p + (size_t)b * sg.bstride + (size_t)col * n + pt);
+      if (i + u >= i1) v[u] = make_uint4(0u, 0u, 0u, 0u);
+      al[u] = ap + (size_t)iu * 4;
+      two[u] = mi == 1 || mi == 2;
+      al2[u] = ap + (size_t)(n1 + iu - w0) * 4;
+    }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc1[q][j] += (int64_t)alpha * (int64_t)w[q];
-        acc2[q][j] += (int64_t)alpha2 * (int64_t)w[q];
+    for (int u = 0; u < 4; ++u) {
+      // both factors centred: a 32 x 32 -> 64-bit signed multiply-add is one instruction (v_mad_i64_i32)
+      const int32_t w[4] = {fps_centre(v[u].x), fps_centre(v[u].y), fps_centre(v[u].z), fps_centre(v[u].w)};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int32_t alpha = fps_centre(al[u][j]);
+        const int32_t alpha2 = two[u] ? fps_centre(al2[u][j]) : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc1[q][j] += (int64_t)alpha * (int64_t)w[q];
+          acc2[q][j] += (int64_t)alpha2 * (int64_t)w[q];
+        }
       }
     }
-    if (++pending == 4) {
+    // |alpha|, |w| <= (p - 1) / 2: eight products and a shrunk sum (< 2^58.2) stay below 2^63
+    if ((i - i0) & 4) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { acc1[q][j] = m_lazy_shrink(acc1[q][j]); acc2[q][j] = m_lazy_shrink(acc2[q][j]); }
-      pending = 0;
     }
   }
   uint32_t* p1 = a.partial + ((((size_t)b * nchunks + chunk) * 2 + 0) * n + pt) * 4;

@@ -286,8 +286,46 @@ __global__ __launch_bounds__(kThreads) void ext_powers_kernel(const uint32_t* __
   store_fp4(out + (size_t)b * out_stride + (size_t)i * 4, r);
 }
 
+// The bit-reversed table for n = 2^logn >= 64: a lane writes 16 consecutive entries i = 16 t + j, whose exponents are
+// brev(i) = brev_4(j) * 2^(logn-4) + brev_(logn-4)(t).  One square-and-multiply chain gives both x^brev(t) and
+// y = x^(2^(logn-4)); the 16 entries are x^brev(t) * y^k: about 3 extension products per entry instead of 1.5 logn.
+__global__ __launch_bounds__(kThreads) void ext_powers_brev_kernel(const uint32_t* __restrict__ base, size_t base_stride,
+                                                                  uint32_t base_mul, uint32_t* __restrict__ out,
+                                                                  size_t out_stride, int logn, int centred) {
+  const int t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= (1 << (logn - 4))) return;
+  const int b = blockIdx.y;
+  Fp4 x = load_fp4(base + (size_t)b * base_stride) * Fp::raw(base_mul);
+  Fp4 r = Fp4::one();
+  uint32_t e = __brev((uint32_t)t) >> (32 - (logn - 4));
+  for (int k = 0; k < logn - 4; ++k) {
+    if (e & 1) r = r * x;
+    x = x.sqr();
+    e >>= 1;
+  }
+  Fp4 yk = Fp4::one();  // y^k, k = 0..15; entry j takes k = brev_4(j)
+  uint32_t* o = out + (size_t)b * out_stride + (size_t)t * 64;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    Fp4 v = r * yk;
+    if (centred) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v.c[j] = Fp::raw((uint32_t)fps_centre(v.c[j].v));
+    }
+    const int j = ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3);
+    store_fp4(o + 4 * j, v);
+    yk = yk * x;
+  }
+}
+
 void launch_ext_powers(hipStream_t stream, const uint32_t* base, size_t base_stride, uint32_t base_mul, uint32_t* out,
                        size_t out_stride, int n, int bitrev_logn, int batch, int centred) {
+  if (bitrev_logn >= 6 && n == (1 << bitrev_logn)) {
+    const int lanes = n >> 4;
+    hipLaunchKernelGGL(ext_powers_brev_kernel, dim3((lanes + kThreads - 1) / kThreads, batch), dim3(kThreads), 0, stream, base,
+                       base_stride, base_mul, out, out_stride, bitrev_logn, centred);
+    return;
+  }
   hipLaunchKernelGGL(ext_powers_kernel, dim3((n + kThreads - 1) / kThreads, batch), dim3(kThreads), 0, stream, base,
                      base_stride, base_mul, out, out_stride, n, bitrev_logn, centred);
 }
