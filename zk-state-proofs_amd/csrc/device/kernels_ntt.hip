@@ -510,9 +510,11 @@ __global__ __launch_bounds__(kLdeThreads) void ntt_strided_kernel(const uint32_t
 
 // ---------------------------------------------------------------------------
 // Heights 2^15 .. 2^21, second form (the machine proof's CPU chip lives here): H = 2^l1 * 2^l2.
-//   ntt_top_kernel   the l1 stages that couple elements 2^l2 apart, all in ONE pass in registers: a
-//                    thread owns the 2^l1 elements of one residue n2 (stride 2^l2), so a wave's loads
-//                    and stores are 64 consecutive words at every step; no LDS, no barrier
+//   ntt_top_kernel   the l1 stages that couple elements 2^l2 apart, in ONE register pass for l1 <= 6 (a
+//                    thread owns the 2^l1 elements of one residue n2, stride 2^l2, so a wave's loads
+//                    and stores are 64 consecutive words at every step; no LDS, no barrier); for
+//                    2^20 and 2^21 (l1 = 7, 8) in two passes of 4 and l1 - 4 stages, since 128 elements
+//                    per lane do not stay in registers
 //   lde_chunk_kernel the l2 low stages of the inverse transform on one contiguous run of 2^l2
 //                    elements in LDS, rescale, publish the coefficients, then the l2 low stages of
 //                    BOTH forward transforms from the same LDS image
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(kLdeThreads) void ntt_strided_kernel(const uint32_t
 template <int R, bool DIF>
 __global__ __launch_bounds__(kLdeThreads) void ntt_top_kernel(const uint32_t* src, size_t src_col_stride, uint32_t* dst,
                                                              size_t dst_col_stride, const uint32_t* __restrict__ tw,
-                                                             int logh) {
+                                                             int logh, int s) {
   PassIo io;
   io.src_lds = nullptr;
   io.dst_lds = nullptr;
@@ -532,8 +534,8 @@ __global__ __launch_bounds__(kLdeThreads) void ntt_top_kernel(const uint32_t* sr
   io.pre_scale = io.post_scale = nullptr;
   io.src_glb_stride = io.dst_glb_stride = 0;
   io.lds_stride = 0;
-  // DIF: stages logh .. logh - R + 1; DIT: stages logh - R + 1 .. logh; either way the group stride is 2^(logh - R)
-  ntt_pass<R, DIF, 1, kSrcGlb | kDstGlb, true>(io, tw, logh, DIF ? logh : logh - R + 1, 1,
+  // DIF: stages s .. s - R + 1 (group stride 2^(s - R)); DIT: stages s .. s + R - 1 (group stride 2^(s - 1))
+  ntt_pass<R, DIF, 1, kSrcGlb | kDstGlb, true>(io, tw, logh, s, 1,
                                               (int)(blockIdx.x * kLdeThreads + threadIdx.x), (int)(gridDim.x * kLdeThreads));
 }
 
@@ -624,18 +626,18 @@ __global__ __launch_bounds__(kLdeThreads) void lde_chunk_fixed_kernel(const uint
 }
 
 template <bool DIF>
-static void launch_ntt_top(hipStream_t stream, int r, const uint32_t* src, size_t src_stride, uint32_t* dst, size_t dst_stride,
-                           const uint32_t* tw, int logh, size_t ncols) {
+static void launch_ntt_top(hipStream_t stream, int r, int s, const uint32_t* src, size_t src_stride, uint32_t* dst,
+                           size_t dst_stride, const uint32_t* tw, int logh, size_t ncols) {
   const unsigned groups = (unsigned)(((size_t)1 << (logh - r)) / kLdeThreads);
   const dim3 grid(groups ? groups : 1, (unsigned)ncols), block(kLdeThreads);
   switch (r) {
-    case 1: hipLaunchKernelGGL((ntt_top_kernel<1, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh); break;
-    case 2: hipLaunchKernelGGL((ntt_top_kernel<2, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh); break;
-    case 3: hipLaunchKernelGGL((ntt_top_kernel<3, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh); break;
-    case 4: hipLaunchKernelGGL((ntt_top_kernel<4, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh); break;
-    case 5: hipLaunchKernelGGL((ntt_top_kernel<5, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh); break;
-    case 6: hipLaunchKernelGGL((ntt_top_kernel<6, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh); break;
-    default: hipLaunchKernelGGL((ntt_top_kernel<7, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh); break;
+    case 1: hipLaunchKernelGGL((ntt_top_kernel<1, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh, s); break;
+    case 2: hipLaunchKernelGGL((ntt_top_kernel<2, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh, s); break;
+    case 3: hipLaunchKernelGGL((ntt_top_kernel<3, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh, s); break;
+    case 4: hipLaunchKernelGGL((ntt_top_kernel<4, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh, s); break;
+    case 5: hipLaunchKernelGGL((ntt_top_kernel<5, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh, s); break;
+    case 6: hipLaunchKernelGGL((ntt_top_kernel<6, DIF>), grid, block, 0, stream, src, src_stride, dst, dst_stride, tw, logh, s); break;
+    default: break;  // launch_lde_tall never asks for more than 6 stages in one pass
   }
 }
 
@@ -644,15 +646,19 @@ static void launch_lde_tall(hipStream_t stream, const uint32_t* in, uint32_t* co
                             const uint32_t* out_scale_br, int logh, size_t ncols) {
   const size_t h = (size_t)1 << logh;
   static const bool generic_chunk = getenv("ZKSP_LDE_GENERIC_CHUNK") != nullptr;  // debugging switch
-  const bool fixed = logh <= 19 && !generic_chunk;
-  const int l2 = logh <= 19 ? 13 : 14, l1 = logh - l2;
+  const bool fixed = !generic_chunk;
+  // 2^13-point chunks; the l1 = logh - 13 strided stages in one register pass of at most 6 stages, or in two
+  // (2^20, 2^21: a pass of 7 stages would hold 128 elements per lane)
+  const int l2 = fixed ? 13 : (logh <= 19 ? 13 : 14), l1 = logh - l2;
+  const int r_hi = l1 <= 6 ? l1 : 4, r_lo = l1 - r_hi;
   const size_t h2 = (size_t)1 << l2;
   const size_t smem = (fixed ? 1 : 2) * sizeof(uint32_t) * (h2 + (h2 >> 3) + 4);
   uint32_t* scratch = out + h;  // out[col][1]: every chunk of it is read, then rewritten, by the same workgroup
   // grid.y is limited to 65535: columns in slabs
   for (size_t c0 = 0; c0 < ncols; c0 += 16384) {
     const size_t nc = ncols - c0 < 16384 ? ncols - c0 : 16384;
-    launch_ntt_top<true>(stream, l1, in + c0 * h, h, scratch + c0 * 2 * h, 2 * h, tw_inv, logh, nc);
+    launch_ntt_top<true>(stream, r_hi, logh, in + c0 * h, h, scratch + c0 * 2 * h, 2 * h, tw_inv, logh, nc);
+    if (r_lo) launch_ntt_top<true>(stream, r_lo, logh - r_hi, scratch + c0 * 2 * h, 2 * h, scratch + c0 * 2 * h, 2 * h, tw_inv, logh, nc);
     if (fixed)
       hipLaunchKernelGGL(lde_chunk_fixed_kernel<13>, dim3((unsigned)(h >> l2), (unsigned)nc), dim3(kLdeThreads), smem, stream,
                          scratch + c0 * 2 * h, 2 * h, coefs_br + c0 * h, out + c0 * 2 * h, tw_fwd, tw_inv, in_scale_br,
@@ -662,7 +668,8 @@ static void launch_lde_tall(hipStream_t stream, const uint32_t* in, uint32_t* co
                          scratch + c0 * 2 * h, 2 * h, coefs_br + c0 * h, out + c0 * 2 * h, tw_fwd, tw_inv, in_scale_br,
                          scale_sel_shift, scale_sel_mask, out_scale_br, logh, l2);
     // forward top stages in place, both cosets: (column, coset) pairs are h words apart
-    launch_ntt_top<false>(stream, l1, out + c0 * 2 * h, h, out + c0 * 2 * h, h, tw_fwd, logh, 2 * nc);
+    if (r_lo) launch_ntt_top<false>(stream, r_lo, l2 + 1, out + c0 * 2 * h, h, out + c0 * 2 * h, h, tw_fwd, logh, 2 * nc);
+    launch_ntt_top<false>(stream, r_hi, l2 + 1 + r_lo, out + c0 * 2 * h, h, out + c0 * 2 * h, h, tw_fwd, logh, 2 * nc);
   }
 }
 
