@@ -4,7 +4,7 @@
 One "step" = one pass of the device hot path over one resident batch of synthetic acct-d8 proofs
 (BASELINE configs[1]: single account-trie proof, depth 8).  A proof is the MACHINE proof of the
 committed sp1-merkle-proof guest in the keccak-precompile shape: 391 400 RV32IM cycles in a
-2^19 x 234 CPU chip, 62 keccak-f permutations in a 2^11 x 2634 keccak chip, keccak-memory,
+2^19 x 204 CPU chip, 62 keccak-f permutations in a 2^11 x 2634 keccak chip, keccak-memory,
 memory-boundary, image, program and multiplier chips, joined by LogUp buses -- i.e. the statement
 the reference's client.prove() establishes, not a component.  The step runs trace expansion ->
 LDE -> Poseidon2 mixed-height Merkle commitments -> LogUp -> quotients -> openings -> FRI -> proof
@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable)
 
 # chip widths of the machine proof (zk-state-proofs_amd/csrc/device/air_machine.hpp): (preprocessed, main, permutation)
-CHIPS = [("cpu", 0, 234, 48), ("keccak", 0, 2634, 104), ("keccak-mem", 0, 16, 16), ("mem-final", 0, 70, 8),
+CHIPS = [("cpu", 0, 204, 48), ("keccak", 0, 2634, 104), ("keccak-mem", 0, 16, 16), ("mem-final", 0, 70, 8),
          ("image", 3, 1, 8), ("program", 10, 1, 8), ("mul", 0, 161, 8), ("range", 1, 1, 8)]
 
 
@@ -173,7 +173,7 @@ def cpu_baseline(trace_of, first_s, seconds):
     n = len(times)
     return {"value": n / el, "unit": "proofs/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
             "repetitions": n, "median_s_per_proof": sorted(times)[n // 2], "min_s_per_proof": min(times),
-            "sample": f"{n} acct-d8 machine proofs (391 400 cycles, 2^19 x 234 CPU chip + 7 chips, 100 queries) in {el:.1f} s; "
+            "sample": f"{n} acct-d8 machine proofs (391 400 cycles, 2^19 x 204 CPU chip + 7 chips, 100 queries) in {el:.1f} s; "
                       "reference SP1 CPU prover unavailable offline, CPU baseline is this repository's oracle/ restatement"}
 
 
@@ -214,7 +214,7 @@ def keccak_chip_component(zk, fx, client_opts, pk_elf, seconds_budget=20.0):
 
 def as_committed_mode(zk, fx, device):
     """The same acct-d8 input with the guest exactly as committed (software keccak, no precompile): 1 406 960
-    cycles, CPU chip 2^21 x 234, keccak chips empty.  Batch 4 resident, 2 timed steps; one proof verified."""
+    cycles, CPU chip 2^21 x 204, keccak chips empty.  Batch 4 resident, 2 timed steps; one proof verified."""
     NB = 4
     client = zk.ProverClient(device=device, keccak_mode=zk.KECCAK_OBSERVE, max_batch=NB)
     lib, h = client._lib, client._h
@@ -462,7 +462,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "acct-d8 machine proof: depth-8 account-trie MPT proof of the committed sp1-merkle-proof guest, whole "
-                        "execution proven (keccak precompile shape: 391 400 cycles -> CPU chip 2^19 x 234, keccak chip 2^11 x 2634, "
+                        "execution proven (keccak precompile shape: 391 400 cycles -> CPU chip 2^19 x 204, keccak chip 2^11 x 2634, "
                         "keccak-mem 2^12, mem-final 2^15, image / program 2^16, mul 2^9; LogUp buses; blowup 2, 100 FRI queries, "
                         "16 PoW bits)",
             "statement": "guest executed from its entry point to HALT(0) with these public values (machine proof, format v4)",

@@ -71,7 +71,7 @@ static void build(void) {
   if (g_ready) return;
   /* in the CPU chip there are no preprocessed columns: linear forms index main columns directly */
   orc_lf is_real = lf_col(C_IS_REAL), ts = lf_col(C_TS);
-  orc_lf a_lo = lf_limb(C_A, 0), a_hi = lf_limb(C_A, 1), b_lo = lf_limb(C_B, 0), b_hi = lf_limb(C_B, 1);
+  orc_lf a_lo = lf_col(C_A), a_hi = lf_col(C_A + 1), b_lo = lf_limb(C_B, 0), b_hi = lf_limb(C_B, 1);
   orc_lf c_lo = lf_limb(C_C, 0), c_hi = lf_limb(C_C, 1), m_lo = lf_limb(C_M, 0), m_hi = lf_limb(C_M, 1);
   {
     orc_inter* it = &g_cpu[0];
@@ -246,12 +246,26 @@ static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t) {
     T(C_OP + op - 1) = 1;
     T(C_WR) = wr; T(C_USE2) = use2; T(C_RD) = rd; T(C_RS1) = rs1; T(C_RS2) = rs2;
     T(C_IMM_LO) = imm & 0xffff; T(C_IMM_HI) = imm >> 16; T(C_TGT) = tgt;
-    put_bits(t, h, r, C_A, a, 32); put_bits(t, h, r, C_B, b, 32); put_bits(t, h, r, C_C, c, 32); put_bits(t, h, r, C_M, m, 32);
+    T(C_A) = a & 0xffff; T(C_A + 1) = a >> 16; put_bits(t, h, r, C_B, b, 32); put_bits(t, h, r, C_C, c, 32); put_bits(t, h, r, C_M, m, 32);
     T(C_MV_LO) = mv & 0xffff; T(C_MV_HI) = mv >> 16;
     uint32_t x = 0, next = pc + 4;
     const uint32_t blo = b & 0xffff, bhi = b >> 16, clo = c & 0xffff, chi = c >> 16, alo = a & 0xffff, ahi = a >> 16;
     switch (op) {
-      case OP_ADD: { uint32_t k0 = (blo + clo) >> 16; T(C_K0) = k0; T(C_K1) = (bhi + chi + k0) >> 16; break; }
+      case OP_ADD: {
+        uint32_t k0 = (blo + clo) >> 16;
+        const uint32_t k1 = (bhi + chi + k0) >> 16;
+        T(C_K0) = k0; T(C_K1) = k1;
+        /* soundness tests: ZKSP_ORACLE_NONCANON=<row> makes that addition claim the other carry, i.e. write the
+         * same sum with limbs out of range.  The row's constraints still hold; nothing can read the value back. */
+        const char* nc = getenv("ZKSP_ORACLE_NONCANON");
+        if (nc && r == (size_t)strtoull(nc, NULL, 10)) {
+          k0 ^= 1u;
+          T(C_K0) = k0;
+          T(C_A) = f_sub(f_add(blo, clo), k0 ? 65536u : 0u);
+          T(C_A + 1) = f_sub(f_add(f_add(bhi, chi), k0), k1 ? 65536u : 0u);
+        }
+        break;
+      }
       case OP_SUB: { uint32_t k0 = (alo + clo) >> 16; T(C_K0) = k0; T(C_K1) = (ahi + chi + k0) >> 16; break; }
       case OP_SLL: case OP_SRL: case OP_SRA: x = 1u << (c & 31); break;
       case OP_SLT: case OP_SLTU: case OP_BEQ: case OP_BNE: case OP_BLT: case OP_BGE: case OP_BLTU: case OP_BGEU: {
@@ -441,7 +455,7 @@ static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, f
   for (int k = 0; k < N_OPS; ++k) emit(s, bool_c(l[C_OP + k]));
   emit(s, bool_c(l[C_WR]));
   emit(s, bool_c(l[C_USE2]));
-  for (int i = 0; i < 160; ++i) emit(s, bool_c(l[C_A + i])); /* A, B, C, M, X */
+  for (int i = 0; i < 128; ++i) emit(s, bool_c(l[C_B + i])); /* B, C, M, X */
   for (int i = 0; i < 4; ++i) emit(s, bool_c(l[C_K0 + i]));
   emit(s, bool_c(l[C_EQ]));
   for (int i = 0; i < 4; ++i) emit(s, bool_c(l[C_O0 + i]));
@@ -464,7 +478,7 @@ static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, f
   for (int k = 0; k < 6; ++k) scsum = f_add(scsum, l[C_SC + k]);
   emit(s, f_sub(scsum, OPF(OP_ECALL)));
   /* ---- limbs ---- */
-  const fe a_lo = limb_of(l, C_A, 0), a_hi = limb_of(l, C_A, 1), b_lo = limb_of(l, C_B, 0), b_hi = limb_of(l, C_B, 1);
+  const fe a_lo = l[C_A], a_hi = l[C_A + 1], b_lo = limb_of(l, C_B, 0), b_hi = limb_of(l, C_B, 1);
   const fe c_lo = limb_of(l, C_C, 0), c_hi = limb_of(l, C_C, 1), m_lo = limb_of(l, C_M, 0), m_hi = limb_of(l, C_M, 1);
   const fe x_lo = limb_of(l, C_X, 0), x_hi = limb_of(l, C_X, 1);
   const fe k0 = l[C_K0], k1 = l[C_K1], k2 = l[C_K2], k3 = l[C_K3];

@@ -41,7 +41,8 @@ enum {
   C_IS_REAL = 0, C_PC, C_TS, C_NEXT_PC,
   C_OP = 4,                    /* 30 selectors: column C_OP + (op - 1) */
   C_WR = C_OP + N_OPS, C_USE2, C_RD, C_RS1, C_RS2, C_IMM_LO, C_IMM_HI, C_TGT,
-  C_A, C_B = C_A + 32, C_C = C_B + 32, C_M = C_C + 32, C_X = C_M + 32,
+  C_A, /* value written: two 16-bit limbs (read back only through the bits of B, C or M) */
+  C_B = C_A + 2, C_C = C_B + 32, C_M = C_C + 32, C_X = C_M + 32,
   C_MV_LO = C_X + 32, C_MV_HI,
   C_K0, C_K1, C_K2, C_K3, C_EQ, C_INV,
   C_O0, C_O1, C_O2, C_O3,

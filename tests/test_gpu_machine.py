@@ -39,7 +39,7 @@ def test_reference_flow_acct_d8_full_size(zk, fx, oracle):
     """BASELINE config 2 through the reference's own call sequence (prover/src/bin/main.rs:59-87) with the
     default client: setup -> prove(..).run() -> public_values -> verify, at full parameters (100 queries,
     16 proof-of-work bits).  The proof is the machine proof of the 391 400-cycle precompile-shape run
-    (CPU chip 2^19 x 234): byte-identical to the oracle's, accepted by a host-only verifier, every
+    (CPU chip 2^19 x 204): byte-identical to the oracle's, accepted by a host-only verifier, every
     tampered region rejected, and another public value cannot be attached."""
     client = zk.ProverClient(device=0)
     pk, vk = client.setup(zk.merkle_elf())

@@ -141,6 +141,27 @@ def test_read_from_the_future_is_rejected(zk, oracle, setup):
     assert "balance" in str(ei.value)
 
 
+def test_out_of_range_result_limbs_cannot_be_read_back(zk, oracle, setup):
+    """The value an instruction writes is kept as two limb columns without a range check of its own.  An addition
+    that claims the wrong carry writes the right sum with limbs out of range: its own constraints hold, but the
+    next read of that register goes through bit columns, whose limbs are in range, so the memory bus cannot
+    balance."""
+    client, vk, t, _ = setup
+    cyc, prog = t["cycles"], t["program"]
+    rows = prog[(cyc[:, 0] - prog[0, 0]) // 4]
+    i = int(np.nonzero((rows[:, 1] == 1) & (rows[:, 2] == 1) & (rows[:, 4] != 0))[0][100])  # an `add` that writes rd != x0
+    os.environ["ZKSP_ORACLE_NONCANON"] = str(i)
+    try:
+        with pytest.raises(RuntimeError):
+            oracle.machine_prove(t, num_queries=NQ, pow_bits=POW)
+        forged = forced_proof(oracle, t)
+    finally:
+        del os.environ["ZKSP_ORACLE_NONCANON"]
+    with pytest.raises(zk.VerificationError) as ei:
+        client.verify(zk.SP1ProofWithPublicValues.from_bytes(forged), vk)
+    assert "balance" in str(ei.value)
+
+
 def test_exit_code_is_bound_to_halt(zk, oracle, setup):
     client, vk, t, _ = setup
     t2 = dict(t)

@@ -29,14 +29,14 @@ constexpr int kTsLimbBits = 12, kTsLimbs = 2;
 // ---- CPU chip ----
 constexpr int C_IS_REAL = 0, C_PC = 1, C_TS = 2, C_NEXT_PC = 3, C_OP = 4, C_WR = C_OP + kNumOps, C_USE2 = C_WR + 1,
               C_RD = C_WR + 2, C_RS1 = C_WR + 3, C_RS2 = C_WR + 4, C_IMM_LO = C_WR + 5, C_IMM_HI = C_WR + 6, C_TGT = C_WR + 7,
-              C_A = C_WR + 8, C_B = C_A + 32, C_C = C_B + 32, C_M = C_C + 32, C_X = C_M + 32, C_MV_LO = C_X + 32,
+              C_A = C_WR + 8, C_B = C_A + 2, C_C = C_B + 32, C_M = C_C + 32, C_X = C_M + 32, C_MV_LO = C_X + 32,
               C_MV_HI = C_MV_LO + 1, C_K0 = C_MV_LO + 2, C_K1 = C_K0 + 1, C_K2 = C_K0 + 2, C_K3 = C_K0 + 3, C_EQ = C_K0 + 4,
               C_INV = C_K0 + 5, C_O0 = C_K0 + 6, C_O1 = C_O0 + 1, C_O2 = C_O0 + 2, C_O3 = C_O0 + 3, C_SC = C_O0 + 4,
               C_R1_PTS = C_SC + 6, C_R2_PTS = C_R1_PTS + 1, C_M_PTS = C_R1_PTS + 2, C_W_PTS = C_R1_PTS + 3,
               C_W_PLO = C_R1_PTS + 4, C_W_PHI = C_R1_PTS + 5, C_R1_D = C_R1_PTS + 6, C_R2_D = C_R1_D + kTsLimbs,
               C_M_D = C_R2_D + kTsLimbs, C_W_D = C_M_D + kTsLimbs, kCpuWidth = C_W_D + kTsLimbs;
 enum { SC_HALT = 0, SC_WRITE, SC_COMMIT, SC_DEFER, SC_HINT_LEN, SC_HINT_READ };
-static_assert(kCpuWidth == 234, "CPU chip layout");
+static_assert(kCpuWidth == 204, "CPU chip layout");
 
 // ---- keccak chip: p3-keccak-air's columns + the call time ----
 constexpr int KC_TS = ka::kWidth, kKeccakWidth = ka::kWidth + 1;
@@ -91,18 +91,18 @@ ZKSP_HD F bool_c(F v, F one) {
 }
 
 // Constraint index space of the CPU chip (fixes which power of alpha multiplies which constraint):
-//   0..207 booleans (IS_REAL, OP[30], WR, USE2, A/B/C/M/X bits, K0..3, EQ, O0..3, SC[6]),
-//   208..217 row structure, 218..219 immediate operand, 220..223 add/sub, 224..229 xor/or/and,
-//   230..237 shifts, 238..243 comparisons, 244..256 next pc, 257..258 address adder, 259..264 byte
-//   offset, 265..287 loads/stores, 288..291 ecall, 292..295 access times.
+//   0..175 booleans (IS_REAL, OP[30], WR, USE2, B/C/M/X bits, K0..3, EQ, O0..3, SC[6]),
+//   176..185 row structure, 186..187 immediate operand, 188..191 add/sub, 192..197 xor/or/and,
+//   198..205 shifts, 206..211 comparisons, 212..224 next pc, 225..226 address adder, 227..232 byte
+//   offset, 233..255 loads/stores, 256..259 ecall, 260..263 access times.
 // The evaluation below walks the columns block by block (each column is read once, its block's
 // arrays die before the next block is loaded) and emits by index, so the device kernel keeps a few
 // dozen live values instead of reloading 5 000 operands per point.
 // Ctx additionally provides  F sum_prod(const F* x, const F* y, int ystep, int n) = sum x[i] * y[i * ystep].
 namespace cpuidx {
-constexpr int kBoolA = 33, kBoolB = 65, kBoolC = 97, kBoolM = 129, kBoolX = 161, kBoolK = 193, kBoolEq = 197, kBoolO = 198,
-              kBoolSc = 202, kStruct = 208, kImm = 218, kAddSub = 220, kBitwise = 224, kShift = 230, kCmp = 238,
-              kNextPc = 244, kAddr = 257, kOff = 259, kLoadStore = 265, kEcall = 288, kTimes = 292;
+constexpr int kBoolB = 33, kBoolC = 65, kBoolM = 97, kBoolX = 129, kBoolK = 161, kBoolEq = 165, kBoolO = 166,
+              kBoolSc = 170, kStruct = 176, kImm = 186, kAddSub = 188, kBitwise = 192, kShift = 198, kCmp = 206,
+              kNextPc = 212, kAddr = 225, kOff = 227, kLoadStore = 233, kEcall = 256, kTimes = 260;
 }
 
 ZKSP_HD constexpr uint32_t pow2_mod(int n) { return (uint32_t)(((uint64_t)1 << n) % kP); }
@@ -127,9 +127,9 @@ ZKSP_HD F byte8(const F* bits, int byte) {
   return s;
 }
 
-// The 296 constraints in four independent tasks, each reading only the column blocks it needs (a block
+// The 264 constraints in four independent tasks, each reading only the column blocks it needs (a block
 // that two tasks need is read by both): the device runs a task per workgroup, so a lane holds a few
-// dozen live values instead of the whole 234-column row; the verifier runs all four in sequence.
+// dozen live values instead of the whole 204-column row; the verifier runs all four in sequence.
 //   task 0  selectors, row structure, the four access-time differences           (scalars)
 //   task 1  A, B, C: immediate operand, add / sub, bitwise, jal / jalr link, ecall, keccak return
 //   task 2  X with A, B, C: shifts, comparisons, branches, jalr target, address adder, byte offset
@@ -212,20 +212,22 @@ ZKSP_HD void eval_cpu_task(Ctx& ctx) {
     ctx.emit_at(kTimes + 3, wr * (ts + ZKSP_K(2) - L(C_W_PTS) - dv[3]));
   }
   if (TASK == 1) {
-    // A, then B and C bit by bit (top bit first): limbs by Horner, the three bitwise results per half
-    F a_lo = zero, a_hi = zero, b_lo = zero, b_hi = zero, c_lo = zero, c_hi = zero;
+    // B and C bit by bit (top bit first): limbs by Horner, the three bitwise results per half.  A is its two limbs:
+    // whatever is read back from a register or from memory is read through bits (B, C, M), so a written value
+    // whose limbs were out of range could never be consumed; it needs no range check of its own.
+    const F a_lo = L(C_A), a_hi = L(C_A + 1);
+    F b_lo = zero, b_hi = zero, c_lo = zero, c_hi = zero;
     F ax[2] = {zero, zero}, ao[2] = {zero, zero}, aa[2] = {zero, zero};
 #pragma unroll
     for (int h = 1; h >= 0; --h) {
       for (int i = 15; i >= 0; --i) {
         const int col = 16 * h + i;
-        const F a = L(C_A + col), b = L(C_B + col), c = L(C_C + col);
-        ctx.emit_at(kBoolA + col, bool_c(a, one));
+        const F b = L(C_B + col), c = L(C_C + col);
         ctx.emit_at(kBoolB + col, bool_c(b, one));
         ctx.emit_at(kBoolC + col, bool_c(c, one));
         const F bc = b * c, sm = b + c;
-        if (h) { a_hi = a_hi.dbl() + a; b_hi = b_hi.dbl() + b; c_hi = c_hi.dbl() + c; }
-        else { a_lo = a_lo.dbl() + a; b_lo = b_lo.dbl() + b; c_lo = c_lo.dbl() + c; }
+        if (h) { b_hi = b_hi.dbl() + b; c_hi = c_hi.dbl() + c; }
+        else { b_lo = b_lo.dbl() + b; c_lo = c_lo.dbl() + c; }
         ax[h] = ax[h].dbl() + (sm - bc.dbl());
         ao[h] = ao[h].dbl() + (sm - bc);
         aa[h] = aa[h].dbl() + bc;
@@ -264,7 +266,8 @@ ZKSP_HD void eval_cpu_task(Ctx& ctx) {
   }
   if (TASK == 2) {
     F a_lo, a_hi, c_lo, c_hi;
-    limbs_of_block<F>(ctx, C_A, &a_lo, &a_hi);
+    a_lo = L(C_A);
+    a_hi = L(C_A + 1);
     limbs_of_block<F>(ctx, C_C, &c_lo, &c_hi);
     F samt = L(C_C + 4);
 #pragma unroll
@@ -375,7 +378,8 @@ ZKSP_HD void eval_cpu_task(Ctx& ctx) {
   }
   if (TASK == 3) {
     F a_lo, a_hi, c_lo, c_hi;
-    limbs_of_block<F>(ctx, C_A, &a_lo, &a_hi);
+    a_lo = L(C_A);
+    a_hi = L(C_A + 1);
     limbs_of_block<F>(ctx, C_C, &c_lo, &c_hi);
     F cb = L(C_C + 7);
 #pragma unroll
@@ -432,9 +436,9 @@ ZKSP_HD void eval_cpu(Ctx& ctx) {
   eval_cpu_task<1>(ctx);
   eval_cpu_task<2>(ctx);
   eval_cpu_task<3>(ctx);
-  ctx.set_count(296);
+  ctx.set_count(264);
 }
-constexpr int kCpuConstraints = 296;
+constexpr int kCpuConstraints = 264;
 
 template <class Ctx>
 ZKSP_HD void eval_kmem(Ctx& ctx) {

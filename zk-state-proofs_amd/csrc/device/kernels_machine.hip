@@ -73,7 +73,8 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
   o.put(C_USE2, use2 ? kR1 : 0u);
   o.val(C_RD, rd); o.val(C_RS1, rs1); o.val(C_RS2, rs2);
   o.val(C_IMM_LO, imm & 0xffff); o.val(C_IMM_HI, imm >> 16); o.val(C_TGT, tgt);
-  o.bits(C_A, a, 32); o.bits(C_B, bb, 32); o.bits(C_C, c, 32); o.bits(C_M, m, 32);
+  o.val(C_A, a & 0xffff); o.val(C_A + 1, a >> 16);
+  o.bits(C_B, bb, 32); o.bits(C_C, c, 32); o.bits(C_M, m, 32);
   o.val(C_MV_LO, mv & 0xffff); o.val(C_MV_HI, mv >> 16);
   uint32_t x = 0, next = pc + 4, k0 = 0, k1 = 0, k2 = 0, k3 = 0, eq = 0, inv = 0, off = 4, sc = 6;
   const uint32_t blo = bb & 0xffff, bhi = bb >> 16, clo = c & 0xffff, chi = c >> 16, alo = a & 0xffff, ahi = a >> 16;
@@ -467,7 +468,8 @@ __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, 
     *hi = h;
   };
   Fp a_lo, a_hi, b_lo, b_hi, c_lo, c_hi, m_lo, m_hi, x_lo, x_hi;
-  limbs(C_A, &a_lo, &a_hi);
+  a_lo = col(C_A);
+  a_hi = col(C_A + 1);
   limbs(C_B, &b_lo, &b_hi);
   limbs(C_C, &c_lo, &c_hi);
   limbs(C_M, &m_lo, &m_hi);

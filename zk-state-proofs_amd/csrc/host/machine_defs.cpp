@@ -66,7 +66,7 @@ ChipDef g_chips[kNumChips];
 
 void build() {
   const LinForm is_real = lf_col(C_IS_REAL), ts = lf_col(C_TS);
-  const LinForm a_lo = lf_limb(C_A, 0), a_hi = lf_limb(C_A, 1), b_lo = lf_limb(C_B, 0), b_hi = lf_limb(C_B, 1),
+  const LinForm a_lo = lf_col(C_A), a_hi = lf_col(C_A + 1), b_lo = lf_limb(C_B, 0), b_hi = lf_limb(C_B, 1),
                 c_lo = lf_limb(C_C, 0), c_hi = lf_limb(C_C, 1), m_lo = lf_limb(C_M, 0), m_hi = lf_limb(C_M, 1);
   {
     Interaction& it = g_cpu[0];
