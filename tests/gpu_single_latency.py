@@ -1,0 +1,41 @@
+"""Scratch timing (not a test): device time per pass of a small resident batch of machine proofs (default one
+proof), profiling spans off; the proof it leaves is checked by the host verifier."""
+import ctypes as C
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+zk = importlib.import_module("zk-state-proofs_amd")
+fx = importlib.import_module("zk-state-proofs_amd.fixtures")
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+client = zk.ProverClient(device=0, max_batch=B)
+lib, h = client._lib, client._h
+pk, vk = client.setup(zk.merkle_elf())
+handles = []
+for i in range(B):
+    s = zk.SP1Stdin()
+    s.write(fx.acct_fixture(8, seed=1 + i).to_borsh())
+    handles.append(client.machine_trace_handle(pk, s))
+arr = (C.c_void_p * B)(*[t._h for t in handles])
+assert lib.zksp_hip_machine_load(h, pk._h, arr, B) == 0, client.last_error()
+for _ in range(3):
+    assert lib.zksp_hip_machine_prove(h) == 0, client.last_error()
+lib.zksp_hip_sync(h)
+steps = 20
+t0 = time.perf_counter()
+for _ in range(steps):
+    assert lib.zksp_hip_machine_prove(h) == 0, client.last_error()
+lib.zksp_hip_sync(h)
+el = time.perf_counter() - t0
+print(f"batch {B}: {el * 1e3 / steps:.2f} ms/step", flush=True)
+lh = (C.c_int32 * zk.MACHINE_CHIPS)(*handles[0].heights())
+bw = lib.zksp_machine_body_words(h, lh)
+bodies = np.zeros((B, bw), np.uint32)
+assert lib.zksp_hip_machine_fetch_bodies(h, bodies.ctypes.data_as(C.c_void_p), bodies.size) == 0
+zk.ProverClient(device=-1).verify(handles[0].proof_from_body(pk, bodies[0]), vk)
+print("verified")

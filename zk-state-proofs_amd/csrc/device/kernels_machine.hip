@@ -10,6 +10,7 @@
 // matrix); the leaf kernel keeps lanes on consecutive LDE rows and scatters only its 32-byte
 // digest.
 #include "kernels_machine.h"
+#include "poseidon2_coop.hpp"
 
 namespace zksp {
 
@@ -370,6 +371,55 @@ __global__ __launch_bounds__(kMT) void mmcs_leaf_kernel(LeafArgs a, const P2Cons
   d[1] = make_uint4(s[4].v, s[5].v, s[6].v, s[7].v);
 }
 
+// Latency form for groups with few rows (the 2 634-column keccak chip of a single proof has 4 096 of them and
+// 330 dependent permutations per row): 16 lanes per row, one sponge word each (poseidon2_coop.hpp), absorbed
+// words fetched four steps ahead.  About twice the arithmetic of the lane-per-row kernel, so it is used only
+// while that kernel could not fill the chip.
+__global__ __launch_bounds__(kMT) void mmcs_leaf_coop_kernel(LeafArgs a, const P2Consts* __restrict__ consts) {
+  const size_t h = (size_t)1 << a.logh, n = 2 * h;
+  const int e = threadIdx.x & 15;
+  const size_t row = (size_t)blockIdx.x * (kMT / 16) + (threadIdx.x >> 4);
+  const bool act = row < n;
+  const size_t r = act ? row : 0;
+  const int b = blockIdx.y;
+  const CoopConsts cc = coop_load_consts(consts, e);
+  const int total = a.start[a.nseg];
+  auto fetch = [&](int c) -> uint32_t {
+    const int vc = c + e;
+    const uint32_t* p = nullptr;  // constant indices into the kernel arguments: no copy of them to scratch
+#pragma unroll
+    for (int sg = 0; sg < kMaxSegs; ++sg)
+      if (e < 8 && vc >= a.start[sg] && vc < a.start[sg + 1])
+        p = a.seg[sg].p + (size_t)b * a.seg[sg].bstride + (size_t)(vc - a.start[sg]) * n + r;
+    return p ? *p : 0u;
+  };
+  constexpr int kPrefetch = 4;
+  uint32_t ahead[kPrefetch];
+#pragma unroll
+  for (int j = 0; j < kPrefetch; ++j) ahead[j] = fetch(8 * j);
+  int32_t x = 0;
+  for (int c0 = 0; c0 < total; c0 += 8 * kPrefetch) {
+    uint32_t cur[kPrefetch];
+#pragma unroll
+    for (int j = 0; j < kPrefetch; ++j) cur[j] = ahead[j];
+#pragma unroll
+    for (int j = 0; j < kPrefetch; ++j) ahead[j] = fetch(c0 + 8 * (kPrefetch + j));
+#pragma unroll
+    for (int j = 0; j < kPrefetch; ++j) {
+      const int c = c0 + 8 * j;
+      if (c < total) {  // uniform
+        if (e < 8 && c + e < total) x = (int32_t)cur[j];
+        x = p2_permute_coop_signed(x, cc, consts);
+      }
+    }
+  }
+  if (act && e < 8) {
+    const size_t c = row >> a.logh, m = row & (h - 1);
+    const size_t pos = c * h + (a.logh ? (size_t)(__brev((uint32_t)m) >> (32 - a.logh)) : 0);
+    a.out[(size_t)b * a.out_bstride + pos * 8 + e] = fps_canon(x);
+  }
+}
+
 void launch_mmcs_leaves(hipStream_t stream, const Seg* segs, int nseg, int logh, uint32_t* digests, size_t out_bstride,
                         int batch, const P2Consts* consts) {
   LeafArgs a;
@@ -386,6 +436,13 @@ void launch_mmcs_leaves(hipStream_t stream, const Seg* segs, int nseg, int logh,
   a.out = digests;
   a.out_bstride = out_bstride;
   const size_t n = (size_t)2 << logh;
+  // fewer than 64 K rows batch-wide (1 024 waves, one per SIMD) and more than a few permutations each: latency form
+  if (n * (size_t)batch < 65536 && a.start[a.nseg] > 32) {
+    constexpr int rows_per_block = kMT / 16;
+    hipLaunchKernelGGL(mmcs_leaf_coop_kernel, dim3((unsigned)((n + rows_per_block - 1) / rows_per_block), batch), dim3(kMT), 0,
+                       stream, a, consts);
+    return;
+  }
   hipLaunchKernelGGL(mmcs_leaf_kernel, dim3((unsigned)((n + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, a, consts);
 }
 
