@@ -1,6 +1,7 @@
 // Sanitiser harness for the host side of the boundary (CPU build only; GPU ASan is not
 // available on this pool): mutates ELF images, stdin buffers and proof bytes and drives
-// load_elf / execute / parse_proof_header / verify_proof under ASan + UBSan.
+// load_elf / execute / parse_proof_header / verify_proof and, for machine proofs, parse_machine_header /
+// verify_machine_proof under ASan + UBSan.
 // Built and run by tests/test_host_sanitizers.py.  Exit code 0 = no finding.
 #include <cstdio>
 #include <cstdlib>
@@ -11,6 +12,8 @@
 #include <vector>
 
 #include "executor.hpp"
+#include "machine.hpp"
+#include "mverifier.hpp"
 #include "verifier.hpp"
 
 using namespace zksp;
@@ -22,7 +25,7 @@ static std::vector<uint8_t> slurp(const char* p) {
 
 int main(int argc, char** argv) {
   if (argc < 4) {
-    fprintf(stderr, "usage: host_fuzz ELF STDIN PROOF [iters]\n");
+    fprintf(stderr, "usage: host_fuzz ELF STDIN PROOF [iters [MACHINE_PROOF queries pow_bits]]\n");
     return 2;
   }
   const std::vector<uint8_t> elf = slurp(argv[1]), input = slurp(argv[2]), proof = slurp(argv[3]);
@@ -38,6 +41,22 @@ int main(int argc, char** argv) {
     return 4;
   }
   size_t elf_ok = 0, exec_halt = 0, ver_ok = 0;
+  // machine proofs (format v4): the verifying key is rebuilt from the ELF, the baseline proof must verify
+  std::vector<uint8_t> mproof;
+  MachineVk mvk{};
+  uint32_t mq = 0, mpow = 0;
+  if (argc > 7) {
+    mproof = slurp(argv[5]);
+    mq = (uint32_t)atoi(argv[6]);
+    mpow = (uint32_t)atoi(argv[7]);
+    MachineProgram prog;
+    if (!build_machine_program(good, KeccakMode::kReplace, &prog).empty()) return 6;
+    machine_host_setup(prog, &mvk);
+    if (verify_machine_proof(mproof.data(), mproof.size(), mvk, mq, mpow, &err) != 0) {
+      fprintf(stderr, "baseline machine proof rejected: %s\n", err.c_str());
+      return 7;
+    }
+  }
   for (int it = 0; it < iters; ++it) {
     // 1. corrupted ELF headers / bodies
     {
@@ -107,6 +126,21 @@ int main(int argc, char** argv) {
         int rc = verify_proof(p.data(), p.size(), vk, 12, 8, &e2);
         if (rc == 0) ++ver_ok;
       }
+    }
+    // 4. corrupted machine proofs: header words (heights, lengths), body words, truncations
+    if (!mproof.empty() && it % 3 == 0) {  // a third of the iterations: one verification costs ~1 s under ASan
+      std::vector<uint8_t> p = mproof;
+      int n = 1 + (int)(rng() % 4);
+      for (int k = 0; k < n; ++k) {
+        size_t pos = (it % 2 == 0) ? rng() % 256 : rng() % p.size();
+        p[pos] ^= (uint8_t)(1u << (rng() % 8));
+      }
+      if (it % 12 == 0) p.resize(rng() % p.size());
+      if (it % 15 == 0) p.resize(p.size() + 4 * (rng() % 64), 0);
+      MachineHeader h;
+      std::string e2;
+      if (parse_machine_header(p.data(), p.size(), &h, &e2) && verify_machine_proof(p.data(), p.size(), mvk, mq, mpow, &e2) == 0)
+        ++ver_ok;
     }
   }
   printf("fuzz ok: %d iterations, %zu mutated ELFs loaded, %zu guest runs halted, %zu mutated proofs accepted\n", iters,
