@@ -80,6 +80,23 @@ def lib_sha256():
         return None
 
 
+def source_sha256():
+    """Content hash of everything the library is built from (csrc/, include/zksp.h, build.py).  The counter
+    collection records it; a library rebuilt elsewhere from the same sources still matches (the .so bytes embed
+    the build path), an edited kernel does not."""
+    h = hashlib.sha256()
+    top = os.path.join(ROOT, "zk-state-proofs_amd", "csrc")
+    files = [os.path.join(ROOT, "include", "zksp.h"), os.path.join(ROOT, "zk-state-proofs_amd", "build.py")]
+    for d, _, names in os.walk(top):
+        if os.path.basename(d) == "_obj":
+            continue
+        files += [os.path.join(d, n) for n in names if n.endswith((".hip", ".hpp", ".h", ".cpp"))]
+    for f in sorted(files):
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def measured_hbm_traffic(batch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC collection
     (profiles/collect_r02.sh -> profiles/r02_hbm_counters.json: FETCH_SIZE and WRITE_SIZE in separate passes,
@@ -88,7 +105,7 @@ def measured_hbm_traffic(batch):
     and this returns None."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_counters.json")))
-        if int(d.get("batch", -1)) != batch or d.get("lib_sha256") != lib_sha256():
+        if int(d.get("batch", -1)) != batch or (d.get("lib_sha256") != lib_sha256() and d.get("source_sha256") != source_sha256()):
             return None
         return (2.0 * d["FETCH_SIZE"]["zksp::mmcs_leaf_kernel"][1] + d["WRITE_SIZE"]["zksp::mmcs_leaf_kernel"][1]) * 1024.0
     except (OSError, KeyError, ValueError, TypeError):

@@ -32,11 +32,15 @@ def counter(name, sub):
 open(o + "/kernel_stats.csv", "w").write(open(glob.glob(o + "/stats/*/*kernel_stats.csv")[0]).read())
 b = json.load(open(o + "/bench_stats.json"))
 lib = hashlib.sha256(open("$R/zk-state-proofs_amd/libzksp.so", "rb").read()).hexdigest()
-out = {"batch": b["config"]["batch_per_gpu"], "lib_sha256": lib,
+import sys
+sys.path.insert(0, "$R")
+import bench
+src = bench.source_sha256()
+out = {"batch": b["config"]["batch_per_gpu"], "lib_sha256": lib, "source_sha256": src,
        "units": "KB per dispatch (avg, max, dispatches); the max of mmcs_leaf_kernel is the CPU chip's main-trace launch; FETCH_SIZE reads half the streamed bytes on gfx950",
        "FETCH_SIZE": counter("FETCH_SIZE", "fetch"), "WRITE_SIZE": counter("WRITE_SIZE", "write")}
 json.dump(out, open(o + "/hbm_counters.json", "w"), indent=1)
-valu = {"batch": out["batch"], "lib_sha256": lib, "note": "per dispatch (avg, max, n); GRBM_GUI_ACTIVE is summed over the 8 XCDs",
+valu = {"batch": out["batch"], "lib_sha256": lib, "source_sha256": src, "note": "per dispatch (avg, max, n); GRBM_GUI_ACTIVE is summed over the 8 XCDs",
         "SQ_INSTS_VALU": counter("SQ_INSTS_VALU", "valu"), "GRBM_GUI_ACTIVE": counter("GRBM_GUI_ACTIVE", "valu")}
 json.dump(valu, open(o + "/valu_counters.json", "w"), indent=1)
 for k in ("FETCH_SIZE", "WRITE_SIZE"):
