@@ -799,12 +799,14 @@ struct MQCtx {
   __device__ __forceinline__ F pub() const { return pub_; }
   __device__ __forceinline__ F one() const { return Fp::one(); }
   __device__ __forceinline__ F k(uint32_t monty) const { return Fp::raw(monty); }
-  // acc += alpha^k * v through signed 64-bit lazy sums (field.hpp), as in the keccak quotient kernel
+  // acc += alpha^k * v through signed 64-bit lazy sums (field.hpp): both factors centred, so a product is one
+  // v_mad_i64_i32 and eight of them (< 2^62.8) fit between two range reductions
   __device__ __forceinline__ void emit_at(int idx, F v) {
     const uint32_t* p = ap + 4 * (size_t)idx;
+    const int32_t vc = fps_centre(v.v);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lazy[i] += (int64_t)fps_centre(p[i]) * (int64_t)v.v;
-    if (++pending == 4) {
+    for (int i = 0; i < 4; ++i) lazy[i] += (int64_t)fps_centre(p[i]) * (int64_t)vc;
+    if (++pending == 8) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) lazy[i] = (int64_t)fps_fold(lazy[i]) * (int64_t)kRModP;
       pending = 0;
@@ -812,15 +814,15 @@ struct MQCtx {
   }
   __device__ __forceinline__ void emit(F v) { emit_at(k_++, v); }
   __device__ __forceinline__ void set_count(int n) { k_ = n; }
-  // sum x[i] * y[i * ystep] through a signed 64-bit lazy sum: x is centred (|x| <= p/2), y canonical,
-  // |term| < p^2 / 2, four terms between shrinks (field.hpp)
+  // sum x[i] * y[i * ystep] through a signed 64-bit lazy sum: both centred (|.| <= p/2), eight terms between
+  // shrinks (field.hpp)
   __device__ __forceinline__ F sum_prod(const F* x, const F* y, int ystep, int n) const {
     int64_t t = 0;
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
       if (i < n) {
-        t += (int64_t)fps_centre(x[i].v) * (int64_t)y[i * ystep].v;
-        if ((i & 3) == 3) t = (int64_t)fps_fold(t) * (int64_t)kRModP;
+        t += (int64_t)fps_centre(x[i].v) * (int64_t)fps_centre(y[i * ystep].v);
+        if ((i & 7) == 7) t = (int64_t)fps_fold(t) * (int64_t)kRModP;
       }
     }
     return Fp::raw(fps_canon(fps_fold(t)));
