@@ -582,7 +582,9 @@ __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, 
   visit(10, -wr, rng(C_W_D + 1), Fp::zero(), gamma, false);
 }
 
-__global__ __launch_bounds__(kMT) void perm_terms_cpu_kernel(PermArgs a) {
+// Four waves per SIMD (128 VGPRs, a few dozen spilled): the 21 inversions are long dependent chains and the
+// kernel issued at half rate with two waves (11.1 -> 9.2 ms per 32 proofs).
+__global__ __launch_bounds__(kMT, 4) void perm_terms_cpu_kernel(PermArgs a) {
   const size_t h = (size_t)1 << a.logh;
   const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
   if (r >= h) return;
