@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kThreads) void open_tall_kernel(const uint32_t* __r
     __syncthreads();
     if (k0 + kOpenTileK < kend) fetch(k0 + kOpenTileK);
     const uint32_t* mine = tile + tid * kOpenPitch;
-#pragma unroll
+#pragma unroll 8
     for (int kk = 0; kk < kOpenTileK; ++kk) {
       const int32_t cv = fps_centre(mine[kk]);
       const int4 p0 = ztile[0][kk];
