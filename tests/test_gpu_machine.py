@@ -105,3 +105,30 @@ def test_batch_of_machine_proofs(zk, fx, oracle):
         assert p.public_values == verify_merkle_proof(m.root_hash, m.proof, m.key)
         client.verify(p, vk)
     assert proofs[3].to_bytes() == oracle.machine_prove(trace3, num_queries=nq, pow_bits=pw)
+
+
+def test_chunked_batch_equals_single_proofs(zk, fx):
+    """prove_batch with more inputs than max_batch proves chunk k while chunk k + 1 uploads into the spare record
+    set and chunk k - 1 is wrapped on the host: every proof must be byte-identical to the one a single prove()
+    call makes (the prover is deterministic), including the short last chunk."""
+    nq, pw = 6, 5
+    client = zk.ProverClient(device=0, num_queries=nq, pow_bits=pw, max_batch=2)
+    pk, vk = client.setup(zk.merkle_elf())
+    inputs = [fx.acct_fixture(1, seed=s) for s in range(11, 16)]  # five runs of equal heights: chunks of 2, 2, 1
+    stdins = []
+    for m in inputs:
+        s = zk.SP1Stdin()
+        s.write(m.to_borsh())
+        stdins.append(s)
+    proofs, status = client.prove_batch(pk, stdins)
+    assert status == [0] * len(inputs)
+    heights = {p.to_bytes()[8:8 + 4 * zk.MACHINE_CHIPS] for p in proofs}
+    assert len(heights) == 1, "fixture seeds were meant to give one height group"
+    single = zk.ProverClient(device=0, num_queries=nq, pow_bits=pw, max_batch=1)
+    pk1, vk1 = single.setup(zk.merkle_elf())
+    for m, p in zip(inputs, proofs):
+        s = zk.SP1Stdin()
+        s.write(m.to_borsh())
+        q = single.prove(pk1, s).run()
+        assert q.to_bytes() == p.to_bytes()
+        client.verify(p, vk)
