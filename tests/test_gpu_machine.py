@@ -132,3 +132,23 @@ def test_chunked_batch_equals_single_proofs(zk, fx):
         q = single.prove(pk1, s).run()
         assert q.to_bytes() == p.to_bytes()
         client.verify(p, vk)
+
+
+def test_device_proof_matches_the_frozen_pins(zk, fx):
+    """The device prover against tests/golden/machine_kat.json directly (no oracle in the loop): SHA-256 of the proof
+    bytes of two small fixtures at 8 queries / 6 proof-of-work bits."""
+    import hashlib
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "machine_kat.json")) as f:
+        kat = json.load(f)
+    client = zk.ProverClient(device=0, num_queries=kat["num_queries"], pow_bits=kat["pow_bits"], max_batch=2)
+    pk, vk = client.setup(zk.merkle_elf())
+    assert [int(x) for x in vk.machine[1]] == kat["vk_digest"]
+    for name, m in (("acct-d1", fx.acct_fixture(1)), ("tx-d2", fx.tx_fixture())):
+        s = zk.SP1Stdin()
+        s.write(m.to_borsh())
+        proof = client.prove(pk, s).run().to_bytes()
+        case = kat["cases"][name]
+        assert len(proof) == case["proof_bytes"]
+        assert hashlib.sha256(proof).hexdigest() == case["proof_sha256"], name

@@ -30,6 +30,22 @@ def forced_proof(oracle, t):
         del os.environ["ZKSP_ORACLE_FORCE"]
 
 
+def test_oracle_matches_the_frozen_pins(zk, setup, oracle):
+    """tests/golden/machine_kat.json (made by tests/golden/gen_machine_golden.py): heights, verifying key and the
+    SHA-256 of the oracle's proof bytes, frozen.  A change of arithmetisation, transcript order or layout that the
+    oracle and the device prover made together would otherwise pass every parity test."""
+    import json
+    client, vk, t, proof = setup
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "machine_kat.json")) as f:
+        kat = json.load(f)
+    assert kat["format_version"] == zk.MACHINE_VERSION and (kat["num_queries"], kat["pow_bits"]) == (NQ, POW)
+    assert [int(x) for x in vk.machine[0]] == kat["vk_prep_root"] and [int(x) for x in vk.machine[1]] == kat["vk_digest"]
+    case = kat["cases"]["acct-d1"]
+    assert oracle.machine_heights(t) == case["chip_log_heights"] and int(t["cycles"].shape[0]) == case["cycles"]
+    assert len(proof) == case["proof_bytes"] and hashlib.sha256(proof).hexdigest() == case["proof_sha256"]
+    assert hashlib.sha256(t["public_values"]).hexdigest() == case["public_values_sha256"]
+
+
 def test_key_matches_oracle_setup(setup, oracle):
     client, vk, t, _ = setup
     root, digest = oracle.machine_setup(t)
