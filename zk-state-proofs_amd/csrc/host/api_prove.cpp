@@ -86,7 +86,11 @@ void parallel_for(size_t count, unsigned max_threads, const std::function<void(s
     for (size_t j; (j = next.fetch_add(1)) < count;) fn(j);
   };
   std::vector<std::thread> th;
-  for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+  try {
+    th.reserve(nt);
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+  } catch (...) {
+  }  // fewer threads than asked for: the items are claimed from one counter, so the ones that exist finish the job
   work();
   for (auto& t : th) t.join();
 }
@@ -105,7 +109,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     return ctx->fail(ZKSP_ERR_HIP, "prove: could not create the copy stream");
   std::vector<std::unique_ptr<zksp_mtrace>> traces(n);
   const BatchTrace mark;
-  parallel_for(n, 64, [&](size_t i) {
+  auto trace_one = [&](size_t i) {
     if (!stdins[i]) return;
     try {
       traces[i].reset(new zksp_mtrace());
@@ -116,11 +120,26 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       traces[i].reset(new zksp_mtrace());
       traces[i]->t.rec.error = "out of memory while tracing the guest";
     }
-  });
-  mark.mark("traced", n);
+  };
+  // The first max_batch inputs are traced before anything else so that the GPU starts early; the rest are traced
+  // by host threads while it proves them.
+  const size_t w0 = std::min<size_t>(n, std::max<size_t>(1, ctx->params.max_batch));
+  parallel_for(w0, 64, trace_one);
+  mark.mark("traced", w0);
   std::string first_err;
+  int rc_all = ZKSP_OK;
+  // Traces whose records are on the device are torn down by a helper thread (tens of megabytes each) while
+  // this thread keeps the GPU fed; joined on every way out.
+  struct Reaper {
+    std::vector<std::thread> th;
+    ~Reaper() {
+      for (auto& t : th)
+        if (t.joinable()) t.join();
+    }
+  } reaper;
+  auto prove_range = [&](size_t lo, size_t hi) {
   std::map<std::array<int, mach::kNumChips>, std::vector<size_t>> groups;
-  for (size_t i = 0; i < n; ++i) {
+  for (size_t i = lo; i < hi; ++i) {
     if (!stdins[i] || !traces[i]) continue;
     const ExecutionRecord& r = traces[i]->t.rec;
     if (!r.error.empty() || !r.halted) {
@@ -137,16 +156,6 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     machine_heights(pk->mprog, traces[i]->t, lh.data());
     groups[lh].push_back(i);
   }
-  // Traces whose records are on the device are torn down by a helper thread (tens of megabytes each) while
-  // this thread keeps the GPU fed; joined on every way out.
-  struct Reaper {
-    std::vector<std::thread> th;
-    ~Reaper() {
-      for (auto& t : th)
-        if (t.joinable()) t.join();
-    }
-  } reaper;
-  int rc_all = ZKSP_OK;
   for (auto& kv : groups) {
     // bytes of HBM one proof of these heights needs (traces, coefficients, LDEs of the three rounds, scratch)
     size_t per_proof = 0;
@@ -163,6 +172,21 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       for (size_t j = 0; j < cnt; ++j) ts[j] = &traces[idx[off + j]]->t;
       return ts;
     };
+    // once a chunk's records are on the device its traces keep only the execution record (the proof objects need
+    // nothing else): the bulky vectors go to the reaper, which frees them while the GPU works
+    auto release_chunk = [&](size_t k) {
+      const size_t off = k * cap, cnt = std::min(cap, idx.size() - off);
+      std::vector<MachineTrace> dead(cnt);
+      for (size_t j = 0; j < cnt; ++j) {
+        MachineTrace& t = traces[idx[off + j]]->t;
+        dead[j].cycles.swap(t.cycles); dead[j].keccak.swap(t.keccak); dead[j].memfinal.swap(t.memfinal);
+        dead[j].muls.swap(t.muls); dead[j].prog_mult.swap(t.prog_mult); dead[j].image_used.swap(t.image_used);
+      }
+      try {
+        reaper.th.emplace_back([d = std::move(dead)]() mutable { d.clear(); });
+      } catch (...) {
+      }  // no thread: `dead` is destroyed here instead
+    };
     auto fail_from = [&](size_t k, int rc) {
       for (size_t j = k * cap; j < idx.size(); ++j) status[idx[j]] = rc;
       rc_all = rc;
@@ -174,6 +198,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     mark.mark("loaded", cur.size());
     if (rc == ZKSP_OK) rc = machine_prove_resident(ctx);
     if (rc != ZKSP_OK) { fail_from(0, rc); continue; }
+    release_chunk(0);
     for (size_t k = 0; k < n_chunks; ++k) {
       const size_t off = k * cap, cnt = std::min(cap, idx.size() - off);
       const bool more = k + 1 < n_chunks;
@@ -183,6 +208,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
         nxt = chunk_traces(k + 1);
         rc_next = machine_load(ctx, pk->mprog, pk->mvk, nxt.data(), nxt.size(), /*into_spare=*/true);
         mark.mark("next loaded", nxt.size());
+        if (rc_next == ZKSP_OK) release_chunk(k + 1);
       }
       const size_t bw = ctx->mws->body_words;
       std::vector<uint32_t> bodies(cnt * bw);
@@ -196,17 +222,6 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
         if (rc_next == ZKSP_OK) rc_next = machine_activate_spare(ctx);
         if (rc_next == ZKSP_OK) rc_next = machine_prove_resident(ctx);
       }
-      // the proof objects need the execution record and the heights only: hand the bulky vectors to the reaper
-      std::vector<MachineTrace> dead(cnt);
-      for (size_t j = 0; j < cnt; ++j) {
-        MachineTrace& t = traces[idx[off + j]]->t;
-        dead[j].cycles.swap(t.cycles); dead[j].keccak.swap(t.keccak); dead[j].memfinal.swap(t.memfinal);
-        dead[j].muls.swap(t.muls); dead[j].prog_mult.swap(t.prog_mult); dead[j].image_used.swap(t.image_used);
-      }
-      try {
-        reaper.th.emplace_back([d = std::move(dead)]() mutable { d.clear(); });
-      } catch (...) {
-      }  // no thread: `dead` is destroyed here instead
       for (size_t j = 0; j < cnt; ++j) {
         const size_t i = idx[off + j];
         status[i] = machine_proof_from_parts(pk, traces[i]->t.rec, kv.first.data(), bodies.data() + j * bw, bw, &out[i]);
@@ -214,6 +229,27 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       mark.mark("wrapped", cnt);
       if (more && rc_next != ZKSP_OK) { fail_from(k + 1, rc_next); break; }
     }
+  }
+  };  // prove_range
+  // declared after `traces` and `reaper`: joined before either is destroyed, on every way out
+  struct Joiner {
+    std::thread t;
+    ~Joiner() {
+      if (t.joinable()) t.join();
+    }
+  } rest;
+  if (w0 < n) {
+    try {
+      rest.t = std::thread([&]() { parallel_for(n - w0, 64, [&](size_t j) { trace_one(w0 + j); }); });
+    } catch (...) {
+      parallel_for(n - w0, 64, [&](size_t j) { trace_one(w0 + j); });  // no thread to spare: trace them here
+    }
+  }
+  prove_range(0, w0);
+  if (w0 < n) {
+    if (rest.t.joinable()) rest.t.join();
+    mark.mark("rest traced", n - w0);
+    prove_range(w0, n);
   }
   if (!first_err.empty() && rc_all == ZKSP_OK) ctx->error = first_err;
   return rc_all;
