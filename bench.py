@@ -81,16 +81,13 @@ def lib_sha256():
 
 
 def source_sha256():
-    """Content hash of everything the library is built from (csrc/, include/zksp.h, build.py).  The counter
-    collection records it; a library rebuilt elsewhere from the same sources still matches (the .so bytes embed
-    the build path), an edited kernel does not."""
+    """Content hash of the device code the library is built from (csrc/device/, build.py with its compiler flags).
+    The counter collection records it; a library rebuilt elsewhere from the same sources still matches (the .so
+    bytes embed the build path), an edited kernel does not, a host-only change does not invalidate the counters."""
     h = hashlib.sha256()
-    top = os.path.join(ROOT, "zk-state-proofs_amd", "csrc")
-    files = [os.path.join(ROOT, "include", "zksp.h"), os.path.join(ROOT, "zk-state-proofs_amd", "build.py")]
-    for d, _, names in os.walk(top):
-        if os.path.basename(d) == "_obj":
-            continue
-        files += [os.path.join(d, n) for n in names if n.endswith((".hip", ".hpp", ".h", ".cpp"))]
+    top = os.path.join(ROOT, "zk-state-proofs_amd", "csrc", "device")
+    files = [os.path.join(ROOT, "zk-state-proofs_amd", "build.py")]
+    files += [os.path.join(top, n) for n in os.listdir(top) if n.endswith((".hip", ".hpp", ".h"))]
     for f in sorted(files):
         h.update(os.path.relpath(f, ROOT).encode())
         h.update(open(f, "rb").read())
