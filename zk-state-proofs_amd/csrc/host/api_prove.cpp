@@ -128,8 +128,54 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   mark.mark("traced", w0);
   std::string first_err;
   int rc_all = ZKSP_OK;
-  // Traces whose records are on the device are torn down by a helper thread (tens of megabytes each) while
-  // this thread keeps the GPU fed; joined on every way out.
+
+  // A chunk: at most `cap` runs of identical chip heights, proven in lockstep.
+  struct Chunk {
+    std::array<int, mach::kNumChips> lh;
+    std::vector<size_t> idx;
+    size_t group_size;  // runs of these heights in the same window (sizes the workspace once)
+  };
+  std::vector<Chunk> chunks;
+  auto build_chunks = [&](size_t lo, size_t hi) {
+    std::map<std::array<int, mach::kNumChips>, std::vector<size_t>> groups;
+    for (size_t i = lo; i < hi; ++i) {
+      if (!stdins[i] || !traces[i]) continue;
+      const ExecutionRecord& r = traces[i]->t.rec;
+      if (!r.error.empty() || !r.halted) {
+        status[i] = ZKSP_ERR_EXECUTOR;
+        if (first_err.empty()) first_err = "executor: " + (r.error.empty() ? std::string("guest did not halt") : r.error);
+        continue;
+      }
+      if (r.exit_code != 0) {
+        status[i] = ZKSP_ERR_GUEST_PANIC;
+        if (first_err.empty()) first_err = "guest panicked (exit code " + std::to_string(r.exit_code) + "): " + r.stderr_text;
+        continue;
+      }
+      std::array<int, mach::kNumChips> lh;
+      machine_heights(pk->mprog, traces[i]->t, lh.data());
+      groups[lh].push_back(i);
+    }
+    for (auto& kv : groups) {
+      // bytes of HBM one proof of these heights needs (traces, coefficients, LDEs of the three rounds, scratch)
+      size_t per_proof = 0;
+      for (int ch = 0; ch < mach::kNumChips; ++ch) {
+        const mach::ChipDef& d = mach::chip_def(ch);
+        per_proof += ((size_t)(d.main_w + d.perm_width() + 8) * 16 + 64) << kv.first[ch];
+      }
+      const size_t cap =
+          std::max<size_t>(1, std::min<size_t>(ctx->params.max_batch, ((size_t)150 << 30) / std::max<size_t>(per_proof, 1)));
+      for (size_t off = 0; off < kv.second.size(); off += cap) {
+        Chunk ck;
+        ck.lh = kv.first;
+        ck.group_size = std::min(cap, kv.second.size());
+        ck.idx.assign(kv.second.begin() + off, kv.second.begin() + std::min(off + cap, kv.second.size()));
+        chunks.push_back(std::move(ck));
+      }
+    }
+  };
+
+  // Traces whose records are on the device keep only the execution record (the proof objects need nothing else):
+  // the bulky vectors go to a helper thread that frees them (tens of megabytes each) while the GPU works.
   struct Reaper {
     std::vector<std::thread> th;
     ~Reaper() {
@@ -137,100 +183,32 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
         if (t.joinable()) t.join();
     }
   } reaper;
-  auto prove_range = [&](size_t lo, size_t hi) {
-  std::map<std::array<int, mach::kNumChips>, std::vector<size_t>> groups;
-  for (size_t i = lo; i < hi; ++i) {
-    if (!stdins[i] || !traces[i]) continue;
-    const ExecutionRecord& r = traces[i]->t.rec;
-    if (!r.error.empty() || !r.halted) {
-      status[i] = ZKSP_ERR_EXECUTOR;
-      if (first_err.empty()) first_err = "executor: " + (r.error.empty() ? std::string("guest did not halt") : r.error);
-      continue;
+  auto release_chunk = [&](const Chunk& ck) {
+    std::vector<MachineTrace> dead(ck.idx.size());
+    for (size_t j = 0; j < ck.idx.size(); ++j) {
+      MachineTrace& t = traces[ck.idx[j]]->t;
+      dead[j].cycles.swap(t.cycles); dead[j].keccak.swap(t.keccak); dead[j].memfinal.swap(t.memfinal);
+      dead[j].muls.swap(t.muls); dead[j].prog_mult.swap(t.prog_mult); dead[j].image_used.swap(t.image_used);
     }
-    if (r.exit_code != 0) {
-      status[i] = ZKSP_ERR_GUEST_PANIC;
-      if (first_err.empty()) first_err = "guest panicked (exit code " + std::to_string(r.exit_code) + "): " + r.stderr_text;
-      continue;
-    }
-    std::array<int, mach::kNumChips> lh;
-    machine_heights(pk->mprog, traces[i]->t, lh.data());
-    groups[lh].push_back(i);
-  }
-  for (auto& kv : groups) {
-    // bytes of HBM one proof of these heights needs (traces, coefficients, LDEs of the three rounds, scratch)
-    size_t per_proof = 0;
-    for (int ch = 0; ch < mach::kNumChips; ++ch) {
-      const mach::ChipDef& d = mach::chip_def(ch);
-      per_proof += ((size_t)(d.main_w + d.perm_width() + 8) * 16 + 64) << kv.first[ch];
-    }
-    const size_t cap = std::max<size_t>(1, std::min<size_t>(ctx->params.max_batch, ((size_t)150 << 30) / std::max<size_t>(per_proof, 1)));
-    const std::vector<size_t>& idx = kv.second;
-    const size_t n_chunks = (idx.size() + cap - 1) / cap;
-    auto chunk_traces = [&](size_t k) {
-      const size_t off = k * cap, cnt = std::min(cap, idx.size() - off);
-      std::vector<const MachineTrace*> ts(cnt);
-      for (size_t j = 0; j < cnt; ++j) ts[j] = &traces[idx[off + j]]->t;
-      return ts;
-    };
-    // once a chunk's records are on the device its traces keep only the execution record (the proof objects need
-    // nothing else): the bulky vectors go to the reaper, which frees them while the GPU works
-    auto release_chunk = [&](size_t k) {
-      const size_t off = k * cap, cnt = std::min(cap, idx.size() - off);
-      std::vector<MachineTrace> dead(cnt);
-      for (size_t j = 0; j < cnt; ++j) {
-        MachineTrace& t = traces[idx[off + j]]->t;
-        dead[j].cycles.swap(t.cycles); dead[j].keccak.swap(t.keccak); dead[j].memfinal.swap(t.memfinal);
-        dead[j].muls.swap(t.muls); dead[j].prog_mult.swap(t.prog_mult); dead[j].image_used.swap(t.image_used);
-      }
-      try {
-        reaper.th.emplace_back([d = std::move(dead)]() mutable { d.clear(); });
-      } catch (...) {
-      }  // no thread: `dead` is destroyed here instead
-    };
-    auto fail_from = [&](size_t k, int rc) {
-      for (size_t j = k * cap; j < idx.size(); ++j) status[idx[j]] = rc;
-      rc_all = rc;
-    };
-    // chunk k is proven while chunk k + 1 is uploaded into the spare record set and chunk k - 1 is wrapped
-    ctx->batch_hint = (int)std::min(cap, idx.size());
-    std::vector<const MachineTrace*> cur = chunk_traces(0);
-    int rc = machine_load(ctx, pk->mprog, pk->mvk, cur.data(), cur.size());
-    mark.mark("loaded", cur.size());
-    if (rc == ZKSP_OK) rc = machine_prove_resident(ctx);
-    if (rc != ZKSP_OK) { fail_from(0, rc); continue; }
-    release_chunk(0);
-    for (size_t k = 0; k < n_chunks; ++k) {
-      const size_t off = k * cap, cnt = std::min(cap, idx.size() - off);
-      const bool more = k + 1 < n_chunks;
-      std::vector<const MachineTrace*> nxt;
-      int rc_next = ZKSP_OK;
-      if (more) {
-        nxt = chunk_traces(k + 1);
-        rc_next = machine_load(ctx, pk->mprog, pk->mvk, nxt.data(), nxt.size(), /*into_spare=*/true);
-        mark.mark("next loaded", nxt.size());
-        if (rc_next == ZKSP_OK) release_chunk(k + 1);
-      }
-      const size_t bw = ctx->mws->body_words;
-      std::vector<uint32_t> bodies(cnt * bw);
-      if (hipMemcpyAsync(bodies.data(), ctx->mws->body, bodies.size() * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-          hipStreamSynchronize(ctx->stream) != hipSuccess) {
-        fail_from(k, ctx->fail(ZKSP_ERR_HIP, "prove: device-to-host copy failed"));
-        break;
-      }
-      mark.mark("proved and fetched", cnt);
-      if (more) {  // the GPU goes on with the next chunk while this one is wrapped
-        if (rc_next == ZKSP_OK) rc_next = machine_activate_spare(ctx);
-        if (rc_next == ZKSP_OK) rc_next = machine_prove_resident(ctx);
-      }
-      for (size_t j = 0; j < cnt; ++j) {
-        const size_t i = idx[off + j];
-        status[i] = machine_proof_from_parts(pk, traces[i]->t.rec, kv.first.data(), bodies.data() + j * bw, bw, &out[i]);
-      }
-      mark.mark("wrapped", cnt);
-      if (more && rc_next != ZKSP_OK) { fail_from(k + 1, rc_next); break; }
-    }
-  }
-  };  // prove_range
+    try {
+      reaper.th.emplace_back([d = std::move(dead)]() mutable { d.clear(); });
+    } catch (...) {
+    }  // no thread: `dead` is destroyed here instead
+  };
+  auto load_chunk = [&](const Chunk& ck, bool into_spare) {
+    std::vector<const MachineTrace*> ts(ck.idx.size());
+    for (size_t j = 0; j < ck.idx.size(); ++j) ts[j] = &traces[ck.idx[j]]->t;
+    if (!into_spare) ctx->batch_hint = (int)ck.group_size;
+    const int rc = machine_load(ctx, pk->mprog, pk->mvk, ts.data(), ts.size(), into_spare);
+    mark.mark(into_spare ? "next loaded" : "loaded", ts.size());
+    if (rc == ZKSP_OK) release_chunk(ck);
+    return rc;
+  };
+  auto fail_chunk = [&](const Chunk& ck, int rc) {
+    for (size_t i : ck.idx) status[i] = rc;
+    rc_all = rc;
+  };
+
   // declared after `traces` and `reaper`: joined before either is destroyed, on every way out
   struct Joiner {
     std::thread t;
@@ -245,13 +223,63 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       parallel_for(n - w0, 64, [&](size_t j) { trace_one(w0 + j); });  // no thread to spare: trace them here
     }
   }
-  prove_range(0, w0);
-  if (w0 < n) {
-    if (rest.t.joinable()) rest.t.join();
-    mark.mark("rest traced", n - w0);
-    prove_range(w0, n);
+  build_chunks(0, w0);
+  bool rest_built = w0 == n;
+  auto have_chunk = [&](size_t k) {  // does chunk k exist?  (the rest is grouped once its traces are complete)
+    if (k >= chunks.size() && !rest_built) {
+      if (rest.t.joinable()) rest.t.join();
+      mark.mark("rest traced", n - w0);
+      build_chunks(w0, n);
+      rest_built = true;
+    }
+    return k < chunks.size();
+  };
+
+  // Chunk k is proven while chunk k + 1 (same heights) is uploaded into the spare record set and chunk k - 1 is
+  // wrapped into proof objects; a chunk of other heights waits for the GPU and takes the plain path.
+  bool in_flight = false;  // chunk k's records are resident and its proving pass is enqueued
+  for (size_t k = 0; have_chunk(k); ++k) {
+    const Chunk ck = chunks[k];  // a copy: grouping the rest may reallocate `chunks`
+    if (!in_flight) {
+      int rc = load_chunk(ck, false);
+      if (rc == ZKSP_OK) rc = machine_prove_resident(ctx);
+      if (rc != ZKSP_OK) { fail_chunk(ck, rc); continue; }
+    }
+    in_flight = false;
+    const bool more = have_chunk(k + 1);
+    const bool piggyback = more && chunks[k + 1].lh == ck.lh && ctx->mws && (size_t)ctx->mws->batch >= chunks[k + 1].idx.size();
+    int rc_next = ZKSP_OK;
+    if (piggyback) rc_next = load_chunk(chunks[k + 1], true);
+    const size_t cnt = ck.idx.size(), bw = ctx->mws->body_words;
+    std::vector<uint32_t> bodies(cnt * bw);
+    if (hipMemcpyAsync(bodies.data(), ctx->mws->body, bodies.size() * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      fail_chunk(ck, ctx->fail(ZKSP_ERR_HIP, "prove: device-to-host copy failed"));
+      continue;
+    }
+    mark.mark("proved and fetched", cnt);
+    if (piggyback) {  // the GPU goes on with the next chunk while this one is wrapped
+      if (rc_next == ZKSP_OK) rc_next = machine_activate_spare(ctx);
+      if (rc_next == ZKSP_OK) rc_next = machine_prove_resident(ctx);
+      if (rc_next == ZKSP_OK) in_flight = true;
+    }
+    for (size_t j = 0; j < cnt; ++j) {
+      const size_t i = ck.idx[j];
+      status[i] = machine_proof_from_parts(pk, traces[i]->t.rec, ck.lh.data(), bodies.data() + j * bw, bw, &out[i]);
+    }
+    mark.mark("wrapped", cnt);
+    if (piggyback && rc_next != ZKSP_OK) {
+      fail_chunk(chunks[k + 1], rc_next);
+      ++k;  // that chunk is lost (its traces may already be released): go on with the one after it
+    }
   }
   if (!first_err.empty() && rc_all == ZKSP_OK) ctx->error = first_err;
+  mark.mark("done", n);
+  for (auto& t : reaper.th)
+    if (t.joinable()) t.join();
+  mark.mark("reaper joined", reaper.th.size());
+  traces.clear();
+  mark.mark("traces dropped", n);
   return rc_all;
 }
 

@@ -9,8 +9,18 @@
 
 #include <algorithm>
 #include <cstring>
+#include <new>
 
 namespace zksp {
+
+void* page_alloc(size_t bytes) {
+  void* p = mmap(nullptr, bytes ? bytes : 1, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (p == MAP_FAILED) throw std::bad_alloc();
+  return p;
+}
+void page_free(void* p, size_t bytes) noexcept {
+  if (p) (void)munmap(p, bytes ? bytes : 1);
+}
 
 namespace {
 
@@ -163,6 +173,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
   };
   struct Touched { uint32_t addr, init, last_ts, is_init; };
   std::vector<Touched> touched;
+  out->cycles.reserve((size_t)1 << 19);  // virtual pages only: what is not written is never touched
   out->prog_mult.assign(prog.rows.size(), 0);
   out->image_used.assign(prog.image.size(), 0);
   uint32_t x[32] = {0}, reg_ts[32] = {0};

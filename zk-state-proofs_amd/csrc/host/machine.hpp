@@ -74,9 +74,32 @@ struct MulRec {
   uint32_t hi, b, c;
 };
 
+// Page-backed storage for the per-cycle records (19 MB and more per run): mapped and unmapped directly.  With
+// the default allocator such blocks end up in malloc's arenas (its mmap threshold adapts upwards after the first
+// free), and returning hundreds of megabytes from there stalls whichever thread frees next.
+template <class T>
+struct PageAllocator {
+  using value_type = T;
+  PageAllocator() = default;
+  template <class U>
+  PageAllocator(const PageAllocator<U>&) {}
+  T* allocate(size_t n);
+  void deallocate(T* p, size_t n) noexcept;
+  template <class U>
+  bool operator==(const PageAllocator<U>&) const { return true; }
+  template <class U>
+  bool operator!=(const PageAllocator<U>&) const { return false; }
+};
+void* page_alloc(size_t bytes);              // throws std::bad_alloc
+void page_free(void* p, size_t bytes) noexcept;
+template <class T>
+T* PageAllocator<T>::allocate(size_t n) { return static_cast<T*>(page_alloc(n * sizeof(T))); }
+template <class T>
+void PageAllocator<T>::deallocate(T* p, size_t n) noexcept { page_free(p, n * sizeof(T)); }
+
 struct MachineTrace {
   ExecutionRecord rec;  // cycles, exit code, public values, digests, error text
-  std::vector<CycleRec> cycles;
+  std::vector<CycleRec, PageAllocator<CycleRec>> cycles;
   std::vector<KeccakCall> keccak;
   std::vector<MemFinalRec> memfinal;  // every touched address, strictly increasing
   std::vector<MulRec> muls;
