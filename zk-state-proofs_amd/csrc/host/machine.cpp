@@ -9,17 +9,56 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <utility>
+#include <vector>
 
 namespace zksp {
 
+// Mapped regions are recycled through a small pool (at most kPagePoolLimit bytes, exact sizes): a region that comes
+// back from the pool is already faulted in, so tracing the next run does not pay 5 000 page faults again, and
+// giving a region back is a push instead of an munmap.
+namespace {
+constexpr size_t kPagePoolLimit = (size_t)1 << 30;
+std::mutex g_page_mu;
+std::vector<std::pair<void*, size_t>> g_page_pool;
+size_t g_page_pool_bytes = 0;
+size_t page_round(size_t bytes) { return ((bytes ? bytes : 1) + 4095) & ~(size_t)4095; }
+}  // namespace
+
 void* page_alloc(size_t bytes) {
-  void* p = mmap(nullptr, bytes ? bytes : 1, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  const size_t sz = page_round(bytes);
+  {
+    std::lock_guard<std::mutex> lk(g_page_mu);
+    for (size_t i = g_page_pool.size(); i-- > 0;)
+      if (g_page_pool[i].second == sz) {
+        void* p = g_page_pool[i].first;
+        g_page_pool[i] = g_page_pool.back();
+        g_page_pool.pop_back();
+        g_page_pool_bytes -= sz;
+        return p;
+      }
+  }
+  void* p = mmap(nullptr, sz, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
   if (p == MAP_FAILED) throw std::bad_alloc();
   return p;
 }
 void page_free(void* p, size_t bytes) noexcept {
-  if (p) (void)munmap(p, bytes ? bytes : 1);
+  if (!p) return;
+  const size_t sz = page_round(bytes);
+  {
+    std::lock_guard<std::mutex> lk(g_page_mu);
+    if (g_page_pool_bytes + sz <= kPagePoolLimit) {
+      try {
+        g_page_pool.emplace_back(p, sz);
+        g_page_pool_bytes += sz;
+        return;
+      } catch (...) {
+      }
+    }
+  }
+  (void)munmap(p, sz);
 }
 
 namespace {
