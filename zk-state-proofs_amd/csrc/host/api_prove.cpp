@@ -254,8 +254,12 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     std::vector<uint32_t> bodies(cnt * bw);
     if (hipMemcpyAsync(bodies.data(), ctx->mws->body, bodies.size() * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) {
-      fail_chunk(ck, ctx->fail(ZKSP_ERR_HIP, "prove: device-to-host copy failed"));
-      continue;
+      // the device is gone: nothing after this chunk can be proven either (the next chunk's traces may already
+      // have been released to the spare upload)
+      const int rc = ctx->fail(ZKSP_ERR_HIP, "prove: device-to-host copy failed");
+      (void)have_chunk(chunks.size());  // group whatever was traced later, so that it gets a status too
+      for (size_t j = k; j < chunks.size(); ++j) fail_chunk(chunks[j], rc);
+      break;
     }
     mark.mark("proved and fetched", cnt);
     if (piggyback) {  // the GPU goes on with the next chunk while this one is wrapped
