@@ -65,6 +65,8 @@ enum Bus { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_MUL, BUS_PUBC, BUS_PUB
 //   F k(uint32_t montgomery_word)  (a constant);  void emit(F v)  (appends the next constraint);
 //   void emit_at(int index, F v);  void set_count(int n)  (index of the next emit());
 //   F sum_prod(const F* x, const F* y, int ystep, int n)  (eval_cpu only)
+//   void note_limbs(int block, F lo, F hi)  (eval_cpu only): the 16-bit limbs of bit block B (0), C (1), M (2), X (3)
+//     as the task that streams the block has them; the device keeps them so that the LogUp task need not read the bits
 #define ZKSP_K(c) ctx.k(cmonty(c))
 
 template <class F, class Ctx>
@@ -240,6 +242,8 @@ ZKSP_HD void eval_cpu_task(Ctx& ctx) {
       ctx.emit_at(kBitwise + 2 + h, OPF(OR) * (al - ao[h]));
       ctx.emit_at(kBitwise + 4 + h, OPF(AND) * (al - aa[h]));
     }
+    ctx.note_limbs(0, b_lo, b_hi);
+    ctx.note_limbs(1, c_lo, c_hi);
     const F k0 = L(C_K0), k1 = L(C_K1);
     const F immc = L(C_IS_REAL) - L(C_USE2);
     ctx.emit_at(kImm + 0, immc * (c_lo - L(C_IMM_LO)));
@@ -375,6 +379,7 @@ ZKSP_HD void eval_cpu_task(Ctx& ctx) {
     ctx.emit_at(kOff + 3, OPF(ECALL) * (o1 + o2 + o3));
     ctx.emit_at(kOff + 4, OPF(ECALL) * (x_lo - ZKSP_K(11)));
     ctx.emit_at(kOff + 5, OPF(ECALL) * x_hi);
+    ctx.note_limbs(3, x_lo, x_hi);
   }
   if (TASK == 3) {
     F a_lo, a_hi, c_lo, c_hi;
@@ -389,6 +394,7 @@ ZKSP_HD void eval_cpu_task(Ctx& ctx) {
 #pragma unroll
     for (int i = 0; i < 32; ++i) ctx.emit_at(kBoolM + i, bool_c(m[i], one));
     const F m_lo = limb16(m, 0), m_hi = limb16(m, 1);
+    ctx.note_limbs(2, m_lo, m_hi);
     const F mb[4] = {byte8(m, 0), byte8(m, 1), byte8(m, 2), byte8(m, 3)};
     const F mv_lo = L(C_MV_LO), mv_hi = L(C_MV_HI);
     const F k65535 = ZKSP_K(65535), k256 = ZKSP_K(256);

@@ -29,6 +29,7 @@ struct MachineRecords {
   const uint32_t* image_used;  // [B][2^log_image]
   const uint32_t* counts;      // [B][4]: cycles, keccak calls, memfinal rows, muls
   uint32_t* range_hist;        // [B][2^kRangeLogH] scratch: multiplicities of the range table, counted on the device
+  uint32_t* cpu_limbs;         // [B][8][H_cpu] scratch: limbs of the CPU chip's B, C, M, X per trace row (for the LogUp trace)
   size_t cap_cycles, cap_keccak, cap_memfinal, cap_muls;
   const uint32_t* program;     // [n_program][9] (shared)
   uint32_t text_base, n_program;
@@ -60,6 +61,7 @@ struct PermArgs {
   size_t perm_bstride;
   uint32_t* rowsum;                // [B][H] Fp4 scratch
   uint32_t* slice_sums;            // [B][H / 4096] Fp4 scratch (tall chips: the running sum is scanned in slices)
+  const uint32_t* limbs;           // CPU chip: [B][8][H] limbs of B, C, M, X per row (MachineRecords::cpu_limbs)
   uint32_t* cum;                   // [B] Fp4 (this chip's cumulative sum)
   size_t cum_bstride;
   int logh, batch;
@@ -88,6 +90,7 @@ struct MQuotArgs {
   uint32_t pub;                 // entry pc (Montgomery)
   uint32_t* quot;               // [B][8][H]
   uint32_t* partial;            // keccak chip: [B][13][2H] Fp4 scratch; CPU chip: [B][5][2H] Fp4
+  uint32_t* limbs;              // CPU chip: [B][8][2H] scratch, limbs of B, C, M, X (written by tasks 1-3, read by the LogUp task)
   int logh, batch;
 };
 void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a);

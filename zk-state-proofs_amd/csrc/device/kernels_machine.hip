@@ -60,6 +60,8 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
   if (r >= rec.counts[4 * b]) {  // padding: only the clock runs on
     o.zero(0, kCpuWidth);
     o.val(C_TS, ts);
+    const Col lim0{rec.cpu_limbs + (size_t)b * 8 * h + r, h};
+    lim0.zero(0, 8);
     return;
   }
   const uint32_t* cy = rec.cycles + ((size_t)b * rec.cap_cycles + r) * 12;
@@ -76,6 +78,9 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
   o.val(C_IMM_LO, imm & 0xffff); o.val(C_IMM_HI, imm >> 16); o.val(C_TGT, tgt);
   o.val(C_A, a & 0xffff); o.val(C_A + 1, a >> 16);
   o.bits(C_B, bb, 32); o.bits(C_C, c, 32); o.bits(C_M, m, 32);
+  const Col lim{rec.cpu_limbs + (size_t)b * 8 * h + r, h};  // limbs of B, C, M (X below) for the LogUp trace
+  lim.val(0, bb & 0xffff); lim.val(1, bb >> 16); lim.val(2, c & 0xffff); lim.val(3, c >> 16);
+  lim.val(4, m & 0xffff); lim.val(5, m >> 16);
   o.val(C_MV_LO, mv & 0xffff); o.val(C_MV_HI, mv >> 16);
   uint32_t x = 0, next = pc + 4, k0 = 0, k1 = 0, k2 = 0, k3 = 0, eq = 0, inv = 0, off = 4, sc = 6;
   const uint32_t blo = bb & 0xffff, bhi = bb >> 16, clo = c & 0xffff, chi = c >> 16, alo = a & 0xffff, ahi = a >> 16;
@@ -119,6 +124,7 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
     default: break;
   }
   o.bits(C_X, x, 32);
+  lim.val(6, x & 0xffff); lim.val(7, x >> 16);
   o.val(C_NEXT_PC, next);
   o.put(C_K0, k0 ? kR1 : 0u); o.put(C_K1, k1 ? kR1 : 0u); o.put(C_K2, k2 ? kR1 : 0u); o.put(C_K3, k3 ? kR1 : 0u);
   o.put(C_EQ, eq ? kR1 : 0u);
@@ -512,25 +518,14 @@ __device__ __forceinline__ Fp4 m_fingerprint(const Interaction& it, const RowVie
 // reload and rescale every bit for every tuple): the same field elements, about a fifth of the work.
 // visit(j, ma, fa, mb, fb, pair) is called for the helper columns j = 0..6 in order; multiplicities are signed.
 template <class V>
-__device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, size_t cs, const Fp4& gamma,
-                                              const uint32_t* __restrict__ bpow, V&& visit) {
+__device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, size_t cs, const uint32_t* __restrict__ limbs,
+                                              const Fp4& gamma, const uint32_t* __restrict__ bpow, V&& visit) {
   auto col = [&](int c) { return Fp::raw(row[(size_t)c * cs]); };
-  auto limbs = [&](int bits, Fp* lo, Fp* hi) {
-    Fp l = col(bits + 15), h = col(bits + 31);
-    for (int i = 14; i >= 0; --i) {
-      l = l.dbl() + col(bits + i);
-      h = h.dbl() + col(bits + 16 + i);
-    }
-    *lo = l;
-    *hi = h;
-  };
-  Fp a_lo, a_hi, b_lo, b_hi, c_lo, c_hi, m_lo, m_hi, x_lo, x_hi;
-  a_lo = col(C_A);
-  a_hi = col(C_A + 1);
-  limbs(C_B, &b_lo, &b_hi);
-  limbs(C_C, &c_lo, &c_hi);
-  limbs(C_M, &m_lo, &m_hi);
-  limbs(C_X, &x_lo, &x_hi);
+  // the 16-bit limbs of the bit blocks B, C, M, X were left by whoever streamed the bits (trace expansion, quotient
+  // tasks 1-3): 8 column reads here instead of 128
+  auto limb = [&](int k) { return Fp::raw(limbs[(size_t)k * cs]); };
+  const Fp a_lo = col(C_A), a_hi = col(C_A + 1), b_lo = limb(0), b_hi = limb(1), c_lo = limb(2), c_hi = limb(3), m_lo = limb(4),
+           m_hi = limb(5), x_lo = limb(6), x_hi = limb(7);
   const Fp k65536 = Fp::raw(cmonty(65536));
   const Fp maddr = x_lo + k65536 * x_hi - (col(C_O1) + col(C_O2).dbl() + Fp::raw(cmonty(3)) * col(C_O3));
   Fp opid = Fp::zero(), memq = Fp::zero();
@@ -593,7 +588,7 @@ __global__ __launch_bounds__(kMT, 4) void perm_terms_cpu_kernel(PermArgs a) {
   const uint32_t* bpow = a.bpow + (size_t)b * (kInterMaxElems + 1) * 4;
   uint32_t* p = a.perm + (size_t)b * a.perm_bstride + r;
   Fp4 tot = Fp4::zero();
-  cpu_bus_pairs(a.main_.p + (size_t)b * a.main_.bstride + r, h, gamma, bpow,
+  cpu_bus_pairs(a.main_.p + (size_t)b * a.main_.bstride + r, h, a.limbs + (size_t)b * 8 * h + r, gamma, bpow,
                 [&](int j, Fp ma, const Fp4& fa, Fp mb, const Fp4& fb, bool pair) {
                   Fp4 hj = Fp4::zero();
                   if (ma.v != 0) hj += fa.inv() * ma;
@@ -793,6 +788,13 @@ struct MQCtx {
   Fp4 acc;
   int64_t lazy[4];
   int pending;
+  uint32_t* limb_out;  // CPU chip: this point's slot in MQuotArgs::limbs (stride cs), or null
+  __device__ __forceinline__ void note_limbs(int block, F lo, F hi) const {
+    if (limb_out) {
+      limb_out[(size_t)(2 * block) * cs] = lo.v;
+      limb_out[(size_t)(2 * block + 1) * cs] = hi.v;
+    }
+  }
   __device__ __forceinline__ F local(int col) const { return Fp::raw(loc[(size_t)col * cs]); }
   __device__ __forceinline__ F next(int col) const { return Fp::raw(nxt[(size_t)col * cs]); }
   __device__ __forceinline__ F is_first() const { return first; }
@@ -922,6 +924,7 @@ __device__ __forceinline__ void init_ctx(const MQuotArgs& a, const PointInfo& pi
   ctx->acc = Fp4::zero();
   ctx->lazy[0] = ctx->lazy[1] = ctx->lazy[2] = ctx->lazy[3] = 0;
   ctx->pending = 0;
+  ctx->limb_out = a.limbs ? a.limbs + (size_t)pi.b * 8 * n + (size_t)pi.c * h + pi.m : nullptr;
 }
 
 template <int CHIP>
@@ -970,7 +973,7 @@ __global__ __launch_bounds__(kMT) void cpu_quotient_task_kernel(MQuotArgs a) {
     const uint32_t* pl = a.perm.p + (size_t)b * a.perm.bstride + (size_t)pi.c * h;
     constexpr int nh = 11;
     Fp4 hsum = Fp4::zero(), acc = Fp4::zero();
-    cpu_bus_pairs(a.main_.p + (size_t)b * a.main_.bstride + pt, n, gamma, bpow,
+    cpu_bus_pairs(a.main_.p + (size_t)b * a.main_.bstride + pt, n, a.limbs + (size_t)b * 8 * n + pt, gamma, bpow,
                   [&](int j, Fp ma, const Fp4& fa, Fp mb, const Fp4& fb, bool pair) {
                     Fp4 hj;
 #pragma unroll

@@ -183,6 +183,8 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   A(&w->prog_mult, B << logh[kProgram]);
   A(&w->image_used, B << logh[kImage]);
   A(&w->range_hist, B << kRangeLogH);
+  A(&w->cpu_limbs_tr, (B * 8) << logh[kCpu]);
+  A(&w->cpu_limbs_lde, (B * 16) << logh[kCpu]);
   A(&w->counts, B * 4);
   A(&w->n_perms, B);
   A(&w->init_obs, B * kMachineInitObs);
@@ -419,6 +421,7 @@ int machine_prove_resident(Context* ctx) {
   MachineRecords rec;
   rec.cycles = w->cycles; rec.kcalls = w->kcalls; rec.memfinal = w->memfinal; rec.muls = w->muls;
   rec.prog_mult = w->prog_mult; rec.image_used = w->image_used; rec.counts = w->counts; rec.range_hist = w->range_hist;
+  rec.cpu_limbs = w->cpu_limbs_tr;
   rec.cap_cycles = w->cap_cycles; rec.cap_keccak = w->cap_keccak; rec.cap_memfinal = w->cap_memfinal; rec.cap_muls = w->cap_muls;
   rec.program = prep->program; rec.text_base = prep->text_base; rec.n_program = prep->n_program;
   {
@@ -476,6 +479,7 @@ int machine_prove_resident(Context* ctx) {
       pa.perm_bstride = (size_t)d.perm_width() * H(c);
       pa.rowsum = w->rowsum;
       pa.slice_sums = w->slice_sums;
+      pa.limbs = c == kCpu ? w->cpu_limbs_tr : nullptr;
       pa.cum = w->cum + 4 * c;
       pa.cum_bstride = (size_t)4 * kNumChips;
       pa.logh = logh[c];
@@ -531,6 +535,7 @@ int machine_prove_resident(Context* ctx) {
       qa.pub = Fp::from_canonical(prep->entry).v;
       qa.quot = w->mat[c][2].tr;
       qa.partial = c == kCpu ? w->reduce_scratch : w->kpartial;  // 40 H words per proof of the CPU chip <= 48 H
+      qa.limbs = c == kCpu ? w->cpu_limbs_lde : nullptr;
       qa.logh = logh[c];
       qa.batch = B;
       launch_machine_quotient(s, qa);

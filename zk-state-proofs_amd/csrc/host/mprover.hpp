@@ -36,7 +36,7 @@ struct MachineWorkspace {
   const PrepDevice* prep = nullptr;
   // records
   uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *image_used = nullptr, *counts = nullptr,
-           *range_hist = nullptr;
+           *range_hist = nullptr, *cpu_limbs_tr = nullptr, *cpu_limbs_lde = nullptr;  // limbs of the CPU chip's bit blocks
   uint8_t* kcalls = nullptr;
   uint64_t* kstates = nullptr;
   uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;

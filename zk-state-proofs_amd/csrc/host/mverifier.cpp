@@ -147,6 +147,7 @@ struct ZetaCtx {
   void emit(F v) { acc += ap[k_++] * v; }
   void emit_at(int idx, F v) { acc += ap[idx] * v; }  // fixed index spaces (keccak, CPU)
   void set_count(int n) { k_ = n; }
+  void note_limbs(int, F, F) {}
   F sum_prod(const F* x, const F* y, int ystep, int n) const {
     F s = Fp4::zero();
     for (int i = 0; i < n; ++i) s += x[i] * y[i * ystep];
