@@ -65,6 +65,9 @@ enum Bus { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_MUL, BUS_PUBC, BUS_PUB
 //   F k(uint32_t montgomery_word)  (a constant);  void emit(F v)  (appends the next constraint);
 //   void emit_at(int index, F v);  void set_count(int n)  (index of the next emit());
 //   F sum_prod(const F* x, const F* y, int ystep, int n)  (eval_cpu only)
+//   void stash(int i, F v); F stashed(int i)  (eval_cpu only): 32 values parked by index and read back by index (the
+//     shift constraints revisit B's bits in a loop the device compiler keeps rolled: the device parks them in LDS
+//     instead of going back to HBM three more times per bit)
 //   void note_limbs(int block, F lo, F hi)  (eval_cpu only): the 16-bit limbs of bit block B (0), C (1), M (2), X (3)
 //     as the task that streams the block has them; the device keeps them so that the LogUp task need not read the bits
 #define ZKSP_K(c) ctx.k(cmonty(c))
@@ -288,6 +291,7 @@ ZKSP_HD void eval_cpu_task(Ctx& ctx) {
       F pw = one;
       for (int i = 0; i < 32; ++i) {
         const F bi = L(C_B + i);
+        ctx.stash(i, bi);
         p32 = p32 + pw * bi;
         if (i == 15) p16 = p32;
         if (i == 31) b31 = bi;
@@ -322,13 +326,13 @@ ZKSP_HD void eval_cpu_task(Ctx& ctx) {
         if (k >= 16) fill_hi = fill_hi + xk * ZKSP_K(65535);
         else if (k >= 1) fill_hi = fill_hi + xk * (k65536 - d15.dbl());
         // step the recurrences to k + 1
-        pa = pa + pw * L(C_B + k);
+        pa = pa + pw * ctx.stashed(k);
         if (k < 16) {
-          pb = pb + (pw * k65536) * L(C_B + 16 + k);
-          pc = pc - d15 * L(C_B + 15 - k);
+          pb = pb + (pw * k65536) * ctx.stashed(16 + k);
+          pc = pc - d15 * ctx.stashed(15 - k);
           d15 = d15 * inv2;
         }
-        pd = pd - d31 * L(C_B + 31 - k);
+        pd = pd - d31 * ctx.stashed(31 - k);
         d31 = d31 * inv2;
         pw = pw.dbl();
         ipw = ipw * inv2;

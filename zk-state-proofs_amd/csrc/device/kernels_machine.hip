@@ -788,6 +788,9 @@ struct MQCtx {
   Fp4 acc;
   int64_t lazy[4];
   int pending;
+  uint32_t* stash_;    // CPU task 2: this lane's column of a [32][kMT] LDS array
+  __device__ __forceinline__ void stash(int i, F v) const { stash_[i * kMT] = v.v; }
+  __device__ __forceinline__ F stashed(int i) const { return Fp::raw(stash_[i * kMT]); }
   uint32_t* limb_out;  // CPU chip: this point's slot in MQuotArgs::limbs (stride cs), or null
   __device__ __forceinline__ void note_limbs(int block, F lo, F hi) const {
     if (limb_out) {
@@ -925,6 +928,7 @@ __device__ __forceinline__ void init_ctx(const MQuotArgs& a, const PointInfo& pi
   ctx->lazy[0] = ctx->lazy[1] = ctx->lazy[2] = ctx->lazy[3] = 0;
   ctx->pending = 0;
   ctx->limb_out = a.limbs ? a.limbs + (size_t)pi.b * 8 * n + (size_t)pi.c * h + pi.m : nullptr;
+  ctx->stash_ = nullptr;
 }
 
 template <int CHIP>
@@ -961,6 +965,8 @@ __global__ __launch_bounds__(kMT) void cpu_quotient_task_kernel(MQuotArgs a) {
   point_selectors(a, pt, &pi);
   MQCtx ctx;
   init_ctx(a, pi, &ctx);
+  __shared__ uint32_t stash[TASK == 2 ? 32 * kMT : 1];  // task 2 parks B's 32 bits per lane (MQCtx::stash)
+  ctx.stash_ = stash + (TASK == 2 ? threadIdx.x : 0);
   if (TASK < kCpuTasks) {
     eval_cpu_task<TASK>(ctx);
     ctx.flush();

@@ -148,6 +148,9 @@ struct ZetaCtx {
   void emit_at(int idx, F v) { acc += ap[idx] * v; }  // fixed index spaces (keccak, CPU)
   void set_count(int n) { k_ = n; }
   void note_limbs(int, F, F) {}
+  Fp4 stash_[32];
+  void stash(int i, F v) { stash_[i] = v; }
+  F stashed(int i) const { return stash_[i]; }
   F sum_prod(const F* x, const F* y, int ystep, int n) const {
     F s = Fp4::zero();
     for (int i = 0; i < n; ++i) s += x[i] * y[i * ystep];
