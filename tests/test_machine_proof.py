@@ -178,6 +178,65 @@ def test_out_of_range_result_limbs_cannot_be_read_back(zk, oracle, setup):
     assert "balance" in str(ei.value)
 
 
+def _rejected(zk, oracle, client, vk, t2):
+    with pytest.raises(RuntimeError):  # an honest prover cannot even build it
+        oracle.machine_prove(t2, num_queries=NQ, pow_bits=POW)
+    with pytest.raises(zk.VerificationError):
+        client.verify(zk.SP1ProofWithPublicValues.from_bytes(forced_proof(oracle, t2)), vk)
+
+
+def test_second_initial_value_is_rejected(zk, oracle, setup):
+    """An address listed twice in the memory-boundary chip would let the prover open it with a second initial
+    value: the chip's addresses must strictly increase (the 32-bit difference minus one has no decomposition)."""
+    client, vk, t, _ = setup
+    mf = t["memfinal"]
+    k = int(np.nonzero(mf[:, 4] == 1)[0][10])  # a freely initialised (hinted / heap) word
+    t2 = dict(t)
+    t2["memfinal"] = np.insert(mf, k, mf[k], axis=0)
+    _rejected(zk, oracle, client, vk, t2)
+
+
+def test_unfetched_instruction_is_rejected(zk, oracle, setup):
+    """Every CPU row consumes its instruction from the Program table; a row whose fetch the table does not
+    count (or a row executing something the table does not hold) leaves the PROG bus unbalanced."""
+    client, vk, t, _ = setup
+    t2 = dict(t)
+    pm = t["prog_mult"].copy()
+    k = int(np.nonzero(pm > 3)[0][0])
+    pm[k] -= 1
+    t2["prog_mult"] = pm
+    _rejected(zk, oracle, client, vk, t2)
+
+
+def test_wrong_loaded_value_is_rejected(zk, oracle, setup):
+    """A load that claims another memory word than the one last written there consumes a tuple nobody produced."""
+    client, vk, t, _ = setup
+    cyc, prog = t["cycles"], t["program"]
+    rows = prog[(cyc[:, 0] - prog[0, 0]) // 4]
+    i = int(np.nonzero(rows[:, 1] == 21)[0][200])  # an `lw` (AIR opcode 21)
+    c2 = cyc.copy()
+    c2[i, 4] ^= 0x100  # the word read
+    c2[i, 5] ^= 0x100  # ... and written back
+    c2[i, 1] ^= 0x100  # ... and the register result: the row itself stays consistent
+    t2 = dict(t)
+    t2["cycles"] = c2
+    _rejected(zk, oracle, client, vk, t2)
+
+
+def test_wrong_product_is_rejected(zk, oracle, setup):
+    """mul results come from the multiplier chip: a CPU row with another product finds no matching tuple there."""
+    client, vk, t, _ = setup
+    cyc, prog = t["cycles"], t["program"]
+    rows = prog[(cyc[:, 0] - prog[0, 0]) // 4]
+    sel = np.nonzero((rows[:, 1] == 27) | (rows[:, 1] == 28))[0]  # mul / mulhu
+    assert len(sel) > 0
+    c2 = cyc.copy()
+    c2[int(sel[0]), 1] ^= 2
+    t2 = dict(t)
+    t2["cycles"] = c2
+    _rejected(zk, oracle, client, vk, t2)
+
+
 def test_exit_code_is_bound_to_halt(zk, oracle, setup):
     client, vk, t, _ = setup
     t2 = dict(t)
