@@ -124,6 +124,13 @@ def valu_model(lib, h, achieved_gperm):
         if lib.zksp_hip_microbench(h, which, C.byref(g)) != 0:
             return None
         rates[cls] = g.value * 1e9  # lane-operations per second, whole chip
+    # the same permutation code on a register-resident state, no memory traffic at all: what this implementation can do
+    # at most (best of 4 and 8 workgroups of 256 per CU)
+    resident = 0.0
+    for which in (6 + 3, 6 + 7):
+        g = C.c_double()
+        if lib.zksp_hip_microbench(h, which, C.byref(g)) == 0:
+            resident = max(resident, g.value)
     t = {c: mix[c] / rates[c] for c in mix}
     # two brackets: every class on one issue port (the classes' times add), or the multiply classes and the
     # add/move classes on ports that overlap perfectly (the longer of the two); the hardware is in between
@@ -132,6 +139,8 @@ def valu_model(lib, h, achieved_gperm):
     return {"opcode_mix_per_permutation_per_lane": mix, "measured_lane_ops_per_s": {k: round(v / 1e12, 2) for k, v in rates.items()},
             "unit_rates": "T lane-ops/s", "ceiling_gperm_per_s": overlapped, "ceiling_one_port_gperm_per_s": serial,
             "achieved_gperm_per_s": achieved_gperm, "frac_of_valu_ceiling": achieved_gperm / overlapped,
+            "register_resident_gperm_per_s": resident or None,
+            "frac_of_register_resident_rate": (achieved_gperm / resident) if resident else None,
             "note": "ceiling = multiply-class and add-class instructions overlapping perfectly; with all classes on one issue "
                     "port the model gives ceiling_one_port, which the kernel exceeds: it runs at the issue limit within the "
                     "precision of these per-class rates"}
