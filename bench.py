@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/
 
 # chip widths of the machine proof (zk-state-proofs_amd/csrc/device/air_machine.hpp): (preprocessed, main, permutation)
 CHIPS = [("cpu", 0, 204, 48), ("keccak", 0, 2634, 104), ("keccak-mem", 0, 16, 16), ("mem-final", 0, 70, 8),
-         ("image", 3, 1, 8), ("program", 10, 1, 8), ("mul", 0, 161, 8), ("range", 1, 1, 8)]
+         ("image", 3, 1, 8), ("program", 10, 1, 8), ("mul", 0, 161, 8), ("range", 1, 1, 8), ("cpu2", 0, 204, 48)]
 
 
 def usable_cores():

@@ -159,7 +159,7 @@ int zksp_mtrace_info(const zksp_mtrace* t, zksp_mtrace_info_t* info);
 /* Device-resident machine proving (bench.py, parity tests): upload the records of n traced runs
  * with identical chip heights, enqueue one proving pass, fetch the proof bodies ([n][body_words]
  * canonical u32; body_words = zksp_machine_body_words of the traces' heights). */
-#define ZKSP_MACHINE_CHIPS 8    /* cpu, keccak, keccak-mem, mem-final, image, program, mul, range */
+#define ZKSP_MACHINE_CHIPS 9    /* cpu, keccak, keccak-mem, mem-final, image, program, mul, range, cpu2 */
 int zksp_mtrace_heights(const zksp_mtrace* t, int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 size_t zksp_machine_body_words(const zksp_client* c, const int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 int zksp_hip_machine_load(zksp_client* c, const zksp_pk* pk, const zksp_mtrace* const* traces, size_t n);

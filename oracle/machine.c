@@ -173,6 +173,7 @@ static void build(void) {
   g_range[0] = range_inter(+1, lf_col(RANGE_PREP_WIDTH + 0), lf_col(0));
   g_chips[CH_RANGE] = (orc_chip){"range", RANGE_PREP_WIDTH, RANGE_WIDTH, 1, g_range, 0};
   g_chips[CH_CPU] = (orc_chip){"cpu", 0, CPU_WIDTH, 21, g_cpu, 0};
+  g_chips[CH_CPU2] = (orc_chip){"cpu2", 0, CPU_WIDTH, 21, g_cpu, 0};
   g_chips[CH_KECCAK] = (orc_chip){"keccak", 0, KECCAK_WIDTH, 50, g_keccak, 0};
   g_chips[CH_KMEM] = (orc_chip){"keccak-mem", 0, KMEM_WIDTH, 6, g_kmem, 0};
   g_chips[CH_MEMFINAL] = (orc_chip){"mem-final", 0, MEMFINAL_WIDTH, 2, g_memfinal, 0};
@@ -198,8 +199,27 @@ static int clog2(size_t v) {
 }
 static int at_least5(int l) { return l < 5 ? 5 : l; }
 
+/* rows of the first CPU instance: the largest power of two strictly below the cycle count (at least 32) */
+static size_t cpu_split(size_t n_cycles) {
+  size_t h0 = 32;
+  while (2 * h0 < n_cycles) h0 *= 2;
+  return h0;
+}
+
+void orc_machine_cpu_pub(const orc_machine_input* in, int chip, uint32_t pub[CPUPUB_N]) {
+  const size_t h0 = cpu_split(in->n_cycles);
+  const uint32_t handover = h0 < in->n_cycles ? in->cycles[12 * h0] : 0;
+  if (chip == CH_CPU) {
+    pub[CPUPUB_START_PC] = in->entry; pub[CPUPUB_START_TS] = 4; pub[CPUPUB_HAS_SUCC] = 1; pub[CPUPUB_END_PC] = handover;
+  } else {
+    pub[CPUPUB_START_PC] = handover; pub[CPUPUB_START_TS] = 4 * ((uint32_t)h0 + 1); pub[CPUPUB_HAS_SUCC] = 0; pub[CPUPUB_END_PC] = 0;
+  }
+}
+
 void orc_machine_heights(const orc_machine_input* in, int logh[N_CHIPS]) {
-  logh[CH_CPU] = at_least5(clog2(in->n_cycles));
+  const size_t h0 = cpu_split(in->n_cycles);
+  logh[CH_CPU] = clog2(h0);
+  logh[CH_CPU2] = at_least5(clog2(in->n_cycles > h0 ? in->n_cycles - h0 : 1));
   logh[CH_KECCAK] = at_least5(clog2(24 * in->n_keccak));
   logh[CH_KMEM] = at_least5(clog2(50 * in->n_keccak));
   logh[CH_MEMFINAL] = at_least5(clog2(in->n_memfinal));
@@ -231,14 +251,16 @@ static void cycle_gaps(const orc_machine_input* in, size_t r, uint32_t gap[4], i
   live[3] = p[2] != 0; gap[3] = ts + 2 - cy[10];
 }
 
-static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t) {
+/* rows [0, h) of the instance whose first row is cycle `row0` */
+static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t, size_t row0) {
 #pragma omp parallel for schedule(static)
   for (size_t r = 0; r < h; ++r) {
 #define T(col) t[(size_t)(col) * h + r]
-    const uint32_t ts = 4 * ((uint32_t)r + 1);
+    const size_t g = row0 + r;  /* cycle index */
+    const uint32_t ts = 4 * ((uint32_t)g + 1);
     T(C_TS) = ts;
-    if (r >= in->n_cycles) continue;
-    const uint32_t* cy = in->cycles + 12 * r;
+    if (g >= in->n_cycles) continue;
+    const uint32_t* cy = in->cycles + 12 * g;
     const uint32_t pc = cy[0], a = cy[1], b = cy[2], c = cy[3], m = cy[4], mv = cy[5], wprev = cy[6];
     const uint32_t* p = in->program + 9 * (size_t)((pc - in->text_base) >> 2);
     const uint32_t op = p[1], wr = p[2], use2 = p[3], rd = p[4], rs1 = p[5], rs2 = p[6], imm = p[7], tgt = p[8];
@@ -307,7 +329,7 @@ static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t) {
     T(C_NEXT_PC) = next;
     uint32_t gap[4];
     int live[4];
-    cycle_gaps(in, r, gap, live);
+    cycle_gaps(in, g, gap, live);
     T(C_R1_PTS) = cy[7]; put_gap(t, h, r, C_R1_D, gap[0]);
     if (live[1]) { T(C_R2_PTS) = cy[8]; put_gap(t, h, r, C_R2_D, gap[1]); }
     if (live[2]) { T(C_M_PTS) = cy[9]; put_gap(t, h, r, C_M_D, gap[2]); }
@@ -327,7 +349,8 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
   if (prep) memset(prep, 0, (size_t)ch->prep_width * h * 4);
 #define T(col) t[(size_t)(col) * h + r]
   switch (chip) {
-    case CH_CPU: fill_cpu(in, h, t); break;
+    case CH_CPU: fill_cpu(in, h, t, 0); break;
+    case CH_CPU2: fill_cpu(in, h, t, cpu_split(in->n_cycles)); break;
     case CH_KECCAK: {
       uint64_t* st = (uint64_t*)calloc(25 * (in->n_keccak ? in->n_keccak : 1), 8);
       for (size_t p = 0; p < in->n_keccak; ++p) memcpy(st + 25 * p, ((const kcall_t*)(in->keccak + 408 * p))->in, 200);
@@ -448,7 +471,8 @@ static inline fe bits_val(const uint32_t* row, int bits, int n) {
 static inline fe gap_val(const uint32_t* row, int col) { return f_add(row[col], f_mul(1u << TS_LIMB_BITS, row[col + 1])); }
 #define F65536 65536u
 
-static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe is_trans, fe entry, sink* s) {
+static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe is_last, fe is_trans, const uint32_t* pub,
+                            sink* s) {
   const fe one = 1;
   /* ---- booleans ---- */
   emit(s, bool_c(l[C_IS_REAL]));
@@ -469,8 +493,8 @@ static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, f
   emit(s, f_mul(l[C_WR], f_sub(one, is_real)));
   emit(s, f_mul(l[C_USE2], f_sub(one, is_real)));
   emit(s, f_mul(is_first, f_sub(is_real, one)));
-  emit(s, f_mul(is_first, f_sub(l[C_PC], entry)));
-  emit(s, f_mul(is_first, f_sub(l[C_TS], 4)));
+  emit(s, f_mul(is_first, f_sub(l[C_PC], pub[CPUPUB_START_PC] % FP)));
+  emit(s, f_mul(is_first, f_sub(l[C_TS], pub[CPUPUB_START_TS] % FP)));
   emit(s, f_mul(is_trans, f_sub(f_sub(n[C_TS], l[C_TS]), 4)));
   emit(s, f_mul(f_mul(is_trans, n[C_IS_REAL]), f_sub(n[C_PC], l[C_NEXT_PC])));
   emit(s, f_mul(is_trans, f_add(f_sub(n[C_IS_REAL], is_real), l[C_SC + SC_HALT])));
@@ -643,6 +667,13 @@ static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, f
     emit(s, f_mul(memq, f_sub(f_sub(f_add(ts, one), l[C_M_PTS]), gap_val(l, C_M_D))));
     emit(s, f_mul(l[C_WR], f_sub(f_sub(f_add(ts, 2), l[C_W_PTS]), gap_val(l, C_W_D))));
   }
+  /* ---- hand-over to the next instance: its last row is a real row that does not halt, and names the pc the next
+   * instance starts at ---- */
+  {
+    const fe succ = f_mul(is_last, pub[CPUPUB_HAS_SUCC] % FP);
+    emit(s, f_mul(succ, f_add(f_sub(one, is_real), l[C_SC + SC_HALT])));
+    emit(s, f_mul(succ, f_sub(l[C_NEXT_PC], pub[CPUPUB_END_PC] % FP)));
+  }
 #undef OPF
 }
 
@@ -694,10 +725,12 @@ static void mul_constraints(const uint32_t* l, sink* s) {
 }
 
 static void run_constraints(int chip, const uint32_t* prep, const uint32_t* loc, const uint32_t* nxt, uint32_t is_first,
-                            uint32_t is_last, uint32_t is_trans, uint32_t pub, sink* s) {
+                            uint32_t is_last, uint32_t is_trans, const uint32_t* pub, sink* s) {
   (void)prep;
+  static const uint32_t no_pub[CPUPUB_N] = {0, 0, 0, 0};
   switch (chip) {
-    case CH_CPU: cpu_constraints(loc, nxt, is_first, is_trans, pub, s); break;
+    case CH_CPU:
+    case CH_CPU2: cpu_constraints(loc, nxt, is_first, is_last, is_trans, pub ? pub : no_pub, s); break;
     case CH_KECCAK:
       if (s->out) orc_keccak_constraints(loc, nxt, is_first, is_last, is_trans, s->out + s->k);
       s->k += KA_NUM_CONSTRAINTS;
@@ -716,12 +749,12 @@ static void run_constraints(int chip, const uint32_t* prep, const uint32_t* loc,
 static int count_constraints(int chip) {
   sink s = {NULL, 0};
   static uint32_t zeros[KECCAK_WIDTH + 8];
-  run_constraints(chip, zeros, zeros, zeros, 0, 0, 0, 0, &s);
+  run_constraints(chip, zeros, zeros, zeros, 0, 0, 0, NULL, &s);
   return s.k;
 }
 
 void orc_machine_constraints(int chip, const uint32_t* prep, const uint32_t* loc, const uint32_t* nxt, uint32_t is_first,
-                             uint32_t is_last, uint32_t is_trans, uint32_t pub, uint32_t* out) {
+                             uint32_t is_last, uint32_t is_trans, const uint32_t* pub, uint32_t* out) {
   build();
   sink s = {out, 0};
   run_constraints(chip, prep, loc, nxt, is_first, is_last, is_trans, pub, &s);

@@ -23,7 +23,9 @@ extern "C" {
 #endif
 
 /* ---- chips, in proof order ---- */
-enum { CH_CPU = 0, CH_KECCAK, CH_KMEM, CH_MEMFINAL, CH_IMAGE, CH_PROGRAM, CH_MUL, CH_RANGE, N_CHIPS };
+/* The execution is split over two instances of the CPU chip: cycles [0, H0) in CH_CPU with H0 the largest power of two
+ * below the cycle count, the rest in CH_CPU2 (a power of two again): 391 400 cycles take 2^18 + 2^17 rows, not 2^19. */
+enum { CH_CPU = 0, CH_KECCAK, CH_KMEM, CH_MEMFINAL, CH_IMAGE, CH_PROGRAM, CH_MUL, CH_RANGE, CH_CPU2, N_CHIPS };
 
 /* ---- AIR opcodes (Program table column OP; CPU selector k-1) ---- */
 enum {
@@ -116,9 +118,13 @@ typedef struct {
 void orc_machine_heights(const orc_machine_input* in, int logh[N_CHIPS]);
 /* column-major traces: prep [prep_width][H] (NULL when the chip has none), main [main_width][H] */
 void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t* prep, uint32_t* main_);
-/* base constraints of one chip at one row pair; `pub` = entry pc for the CPU chip */
+/* Public scalars of a CPU instance: pc and time of its first row, whether another instance continues it, and the pc
+ * that one starts at (the hand-over pc, a proof-header word the transcript absorbs). */
+enum { CPUPUB_START_PC = 0, CPUPUB_START_TS, CPUPUB_HAS_SUCC, CPUPUB_END_PC, CPUPUB_N };
+void orc_machine_cpu_pub(const orc_machine_input* in, int chip, uint32_t pub[CPUPUB_N]);
+/* base constraints of one chip at one row pair; `pub` = the CPUPUB_* words for the CPU instances (ignored elsewhere) */
 void orc_machine_constraints(int chip, const uint32_t* prep, const uint32_t* loc, const uint32_t* nxt, uint32_t is_first,
-                             uint32_t is_last, uint32_t is_trans, uint32_t pub, uint32_t* out);
+                             uint32_t is_last, uint32_t is_trans, const uint32_t* pub, uint32_t* out);
 
 /* ---- whole machine proof ---- */
 typedef struct {
@@ -127,7 +133,7 @@ typedef struct {
   uint32_t pv_digest[8];
   uint32_t deferred_digest[8];
 } orc_machine_public;
-#define ZKSP_VERSION_MACHINE 4u
+#define ZKSP_VERSION_MACHINE 5u
 /* vk: preprocessed commitment root + digest binding entry pc, table heights and keccak mode */
 void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t prep_root[8], uint32_t vk_digest[8]);
 size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_image, const orc_config* cfg, uint32_t pv_len);

@@ -228,7 +228,7 @@ static void perm_trace(chipd* d, fe4 gamma, const fe4* bpow) {
 }
 
 /* ---- quotient of one chip ---- */
-static void chip_quotient(chipd* d, int chip, fe4 alpha, fe4 gamma, const fe4* bpow, uint32_t pub) {
+static void chip_quotient(chipd* d, int chip, fe4 alpha, fe4 gamma, const fe4* bpow, const uint32_t* pub) {
   const orc_chip* def = d->def;
   const int ni = def->n_inter, nh = orc_chip_helpers(def), nb = def->n_constraints, total = nb + nh + 3;
   const int rw = d->w[R_PREP] + d->w[R_MAIN], pw = d->w[R_PREP];
@@ -368,7 +368,7 @@ void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t pr
   free_chips(cd);
 }
 
-#define HEADER_WORDS (2 + N_CHIPS + 2 + 24)
+#define HEADER_WORDS (2 + N_CHIPS + 2 + 24 + 1) /* magic, version, heights, exit code, pv length, 3 digests, hand-over pc */
 
 size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_image, const orc_config* cfg, uint32_t pv_len) {
   (void)log_prog; (void)log_image;
@@ -396,14 +396,18 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   chipd cd[N_CHIPS];
   int logh[N_CHIPS];
   orc_machine_heights(in, logh);
-  if (in->n_cycles == 0 || logh[CH_CPU] > 21) return 1;
-  for (int c = 0; c < N_CHIPS; ++c)
-    if (logh[c] > logh[CH_CPU]) return 1; /* the CPU chip is the tallest: every tree and FRI start from it */
+  if (in->n_cycles < 33 || logh[CH_CPU] > 20) return 1; /* two CPU instances of at most 2^20 rows each */
   const size_t need = orc_machine_proof_size(logh, in->log_prog, in->log_image, cfg, pub->pv_len);
   *out_len = need;
   if (cap < need) return 2;
   wbuf pb = {(uint32_t*)out, 0, cap / 4};
-  const int lm = logh[CH_CPU];
+  int lm = 0; /* the tallest chip: every tree and the FRI start from its height */
+  for (int c = 0; c < N_CHIPS; ++c)
+    if (logh[c] > lm) lm = logh[c];
+  uint32_t cpu_pub[N_CHIPS][CPUPUB_N];
+  memset(cpu_pub, 0, sizeof cpu_pub);
+  orc_machine_cpu_pub(in, CH_CPU, cpu_pub[CH_CPU]);
+  orc_machine_cpu_pub(in, CH_CPU2, cpu_pub[CH_CPU2]);
 
   /* ---- rounds 0 and 1: preprocessed and main traces ---- */
   init_chips(in, cd, 0);
@@ -424,6 +428,7 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
     put(&pb, pub->pv_digest, 8);
     put(&pb, pub->deferred_digest, 8);
     put(&pb, vk, 8);
+    put(&pb, &cpu_pub[CH_CPU][CPUPUB_END_PC], 1);
     size_t pw = (pub->pv_len + 3) / 4;
     uint32_t* tmp = (uint32_t*)calloc(pw ? pw : 1, 4);
     memcpy(tmp, public_values, pub->pv_len);
@@ -438,6 +443,7 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   orc_ch_observe(&ch, pub->exit_code >> 16);
   observe_word_halves(&ch, pub->pv_digest, 8);
   observe_word_halves(&ch, pub->deferred_digest, 8);
+  observe_word_halves(&ch, &cpu_pub[CH_CPU][CPUPUB_END_PC], 1);
   orc_ch_observe_many(&ch, mmcs_root(&t_main), 8);
   put(&pb, mmcs_root(&t_main), 8);
 
@@ -501,7 +507,7 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   for (int c = 0; c < N_CHIPS; ++c) {
     chipd* d = &cd[c];
     d->tr[R_QUOT] = (uint32_t*)malloc((size_t)8 * d->h * 4);
-    chip_quotient(d, c, alpha, gamma, bpow, in->entry);
+    chip_quotient(d, c, alpha, gamma, bpow, cpu_pub[c]);
     lde_round(d, R_QUOT);
   }
   mmcs_commit(cd, R_QUOT, &t_quot);

@@ -279,8 +279,8 @@ def prove(states_in: np.ndarray, logh: int, *, exit_code: int = 0, public_values
 # ---------------------------------------------------------------------------
 # machine proof (oracle/machine.h): inputs are the arrays ProverClient.machine_trace() returns
 # ---------------------------------------------------------------------------
-N_CHIPS = 8
-CHIP_NAMES = ["cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "range"]
+N_CHIPS = 9
+CHIP_NAMES = ["cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "range", "cpu2"]
 
 
 class MachineChip(C.Structure):
@@ -339,13 +339,14 @@ def machine_fill(t: dict, chip: int):
     return prep, main
 
 
-def machine_constraints(chip: int, prep_row, loc, nxt, is_first: int, is_last: int, is_trans: int, pub: int) -> np.ndarray:
+def machine_constraints(chip: int, prep_row, loc, nxt, is_first: int, is_last: int, is_trans: int, pub=(0, 0, 0, 0)) -> np.ndarray:
+    """`pub`: the four CPUPUB_* words (first pc, first time, has a successor, hand-over pc) for the CPU instances."""
     d = machine_chip(chip)
     out = np.zeros(max(d["n_constraints"], 1), np.uint32)
     pr = _u32(prep_row) if prep_row is not None else np.zeros(1, np.uint32)
     l, n = _u32(loc), _u32(nxt)
     lib().orc_machine_constraints(chip, _p(pr), _p(l), _p(n), C.c_uint32(is_first), C.c_uint32(is_last),
-                                  C.c_uint32(is_trans), C.c_uint32(pub), _p(out))
+                                  C.c_uint32(is_trans), _p(_u32(list(pub))), _p(out))
     return out[: d["n_constraints"]]
 
 

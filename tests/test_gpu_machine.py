@@ -39,7 +39,7 @@ def test_reference_flow_acct_d8_full_size(zk, fx, oracle):
     """BASELINE config 2 through the reference's own call sequence (prover/src/bin/main.rs:59-87) with the
     default client: setup -> prove(..).run() -> public_values -> verify, at full parameters (100 queries,
     16 proof-of-work bits).  The proof is the machine proof of the 391 400-cycle precompile-shape run
-    (CPU chip 2^19 x 204): byte-identical to the oracle's, accepted by a host-only verifier, every
+    (CPU chip 2^18 + 2^17 rows x 204): byte-identical to the oracle's, accepted by a host-only verifier, every
     tampered region rejected, and another public value cannot be attached."""
     client = zk.ProverClient(device=0)
     pk, vk = client.setup(zk.merkle_elf())
@@ -51,7 +51,9 @@ def test_reference_flow_acct_d8_full_size(zk, fx, oracle):
     assert proof.public_values == fx.ACCOUNT_VALUE
     client.verify(proof, vk)
     raw = proof.to_bytes()
-    assert int.from_bytes(raw[4:8], "little") == zk.MACHINE_VERSION and int.from_bytes(raw[8:12], "little") == 19
+    heights = [int.from_bytes(raw[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
+    # 391 400 cycles: 2^18 rows in the first CPU instance, 2^17 in the second
+    assert int.from_bytes(raw[4:8], "little") == zk.MACHINE_VERSION and heights[0] == 18 and heights[-1] == 17
     assert raw == oracle.machine_prove(trace)
     host = zk.ProverClient(device=-1)
     host.verify(zk.SP1ProofWithPublicValues.from_bytes(raw), vk)

@@ -64,8 +64,8 @@ def test_every_region_is_bound(zk, setup):
     client, vk, t, proof = setup
     rng = np.random.default_rng(5)
     words = len(proof) // 4
-    hw = zk.MACHINE_HEADER_WORDS  # heights 2..9, exit code 10, pv length 11, digests 12 / 20, vk 28, then 18 words of values
-    positions = [2, 5, 9, 10, 11, 12, 20, 28, hw, hw + 1, hw + 18, hw + 18 + 8, hw + 18 + 16, hw + 18 + 48, hw + 18 + 56, words - 1]
+    hw = zk.MACHINE_HEADER_WORDS  # heights 2..10, exit code 11, pv length 12, digests 13 / 21, vk 29, hand-over pc hw - 1, then the values
+    positions = [2, 5, 9, 10, 11, 12, 20, 28, hw - 1, hw, hw + 1, hw + 18, hw + 18 + 8, hw + 18 + 16, hw + 18 + 48, hw + 18 + 56, words - 1]
     positions += [int(x) for x in rng.integers(hw, words, 40)]
     for w in positions:
         bad = bytearray(proof)

@@ -29,11 +29,11 @@ ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_ELF, ERR_EXECUTOR, ERR_GUEST_PANIC,
     ERR_UNSUPPORTED = range(1, 10)
 KECCAK_SOFTWARE, KECCAK_OBSERVE, KECCAK_REPLACE = 0, 1, 2
 PROOF_MACHINE, PROOF_KECCAK_CHIP = 1, 2
-# machine proof (format version 4): chips in proof order and the fixed header in front of the public values
-MACHINE_VERSION = 4
-MACHINE_CHIP_NAMES = ("cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "range")
+# machine proof (format version 5): chips in proof order and the fixed header in front of the public values
+MACHINE_VERSION = 5
+MACHINE_CHIP_NAMES = ("cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "range", "cpu2")
 MACHINE_CHIPS = len(MACHINE_CHIP_NAMES)
-MACHINE_HEADER_WORDS = 2 + MACHINE_CHIPS + 2 + 24
+MACHINE_HEADER_WORDS = 2 + MACHINE_CHIPS + 2 + 24 + 1  # .. the last word is the hand-over pc of the two CPU instances
 
 
 class ZkspError(RuntimeError):

@@ -15,7 +15,13 @@
 namespace zksp {
 namespace mach {
 
-enum Chip { kCpu = 0, kKeccak, kKmem, kMemFinal, kImage, kProgram, kMul, kRange, kNumChips };
+// The execution is split over two instances of the CPU chip: cycles [0, H0) in kCpu, H0 the largest power of two below
+// the cycle count, the rest in kCpu2 (a power of two again): 391 400 cycles take 2^18 + 2^17 rows instead of 2^19.
+enum Chip { kCpu = 0, kKeccak, kKmem, kMemFinal, kImage, kProgram, kMul, kRange, kCpu2, kNumChips };
+// public scalars of a CPU instance: pc and time of its first row, whether another instance continues it, and the pc
+// that one starts at (the hand-over pc: a proof-header word the transcript absorbs)
+enum CpuPub { kPubStartPc = 0, kPubStartTs, kPubHasSucc, kPubEndPc, kNumCpuPub };
+ZKSP_HD constexpr bool is_cpu_chip(int chip) { return chip == kCpu || chip == kCpu2; }
 
 // AIR opcodes = Program-table column OP = 1 + index of the CPU selector column
 enum Op {
@@ -61,7 +67,7 @@ constexpr int kRangePrepWidth = 1, kRangeWidth = 1, kRangeLogH = kTsLimbBits;
 enum Bus { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_MUL, BUS_PUBC, BUS_PUBH, BUS_RANGE };
 
 // Ctx interface:
-//   using F;  F local(int col); F next(int col); F is_first(); F is_trans(); F is_last(); F pub();
+//   using F;  F local(int col); F next(int col); F is_first(); F is_trans(); F is_last(); F pub(int which)  (CpuPub);
 //   F k(uint32_t montgomery_word)  (a constant);  void emit(F v)  (appends the next constraint);
 //   void emit_at(int index, F v);  void set_count(int n)  (index of the next emit());
 //   F sum_prod(const F* x, const F* y, int ystep, int n)  (eval_cpu only)
@@ -99,7 +105,7 @@ ZKSP_HD F bool_c(F v, F one) {
 //   0..175 booleans (IS_REAL, OP[30], WR, USE2, B/C/M/X bits, K0..3, EQ, O0..3, SC[6]),
 //   176..185 row structure, 186..187 immediate operand, 188..191 add/sub, 192..197 xor/or/and,
 //   198..205 shifts, 206..211 comparisons, 212..224 next pc, 225..226 address adder, 227..232 byte
-//   offset, 233..255 loads/stores, 256..259 ecall, 260..263 access times.
+//   offset, 233..255 loads/stores, 256..259 ecall, 260..263 access times, 264..265 hand-over to the next instance.
 // The evaluation below walks the columns block by block (each column is read once, its block's
 // arrays die before the next block is loaded) and emits by index, so the device kernel keeps a few
 // dozen live values instead of reloading 5 000 operands per point.
@@ -107,7 +113,7 @@ ZKSP_HD F bool_c(F v, F one) {
 namespace cpuidx {
 constexpr int kBoolB = 33, kBoolC = 65, kBoolM = 97, kBoolX = 129, kBoolK = 161, kBoolEq = 165, kBoolO = 166,
               kBoolSc = 170, kStruct = 176, kImm = 186, kAddSub = 188, kBitwise = 192, kShift = 198, kCmp = 206,
-              kNextPc = 212, kAddr = 225, kOff = 227, kLoadStore = 233, kEcall = 256, kTimes = 260;
+              kNextPc = 212, kAddr = 225, kOff = 227, kLoadStore = 233, kEcall = 256, kTimes = 260, kHandOver = 264;
 }
 
 ZKSP_HD constexpr uint32_t pow2_mod(int n) { return (uint32_t)(((uint64_t)1 << n) % kP); }
@@ -132,7 +138,7 @@ ZKSP_HD F byte8(const F* bits, int byte) {
   return s;
 }
 
-// The 264 constraints in four independent tasks, each reading only the column blocks it needs (a block
+// The 266 constraints in four independent tasks, each reading only the column blocks it needs (a block
 // that two tasks need is read by both): the device runs a task per workgroup, so a lane holds a few
 // dozen live values instead of the whole 204-column row; the verifier runs all four in sequence.
 //   task 0  selectors, row structure, the four access-time differences           (scalars)
@@ -193,8 +199,8 @@ ZKSP_HD void eval_cpu_task(Ctx& ctx) {
     ctx.emit_at(kStruct + 1, wr * (one - is_real));
     ctx.emit_at(kStruct + 2, use2 * (one - is_real));
     ctx.emit_at(kStruct + 3, is_first * (is_real - one));
-    ctx.emit_at(kStruct + 4, is_first * (pc - ctx.pub()));
-    ctx.emit_at(kStruct + 5, is_first * (ts - ZKSP_K(4)));
+    ctx.emit_at(kStruct + 4, is_first * (pc - ctx.pub(kPubStartPc)));
+    ctx.emit_at(kStruct + 5, is_first * (ts - ctx.pub(kPubStartTs)));
     ctx.emit_at(kStruct + 6, is_trans * (ctx.next(C_TS) - ts - ZKSP_K(4)));
     const F nreal = ctx.next(C_IS_REAL);
     ctx.emit_at(kStruct + 7, is_trans * nreal * (ctx.next(C_PC) - np));
@@ -215,6 +221,11 @@ ZKSP_HD void eval_cpu_task(Ctx& ctx) {
     ctx.emit_at(kTimes + 1, use2 * (ts - L(C_R2_PTS) - dv[1]));
     ctx.emit_at(kTimes + 2, ld_st_ecall * (ts + one - L(C_M_PTS) - dv[2]));
     ctx.emit_at(kTimes + 3, wr * (ts + ZKSP_K(2) - L(C_W_PTS) - dv[3]));
+    // hand-over to the next instance: its last row is a real row that does not halt and names the pc the next
+    // instance starts at
+    const F succ = ctx.is_last() * ctx.pub(kPubHasSucc);
+    ctx.emit_at(kHandOver + 0, succ * (one - is_real + sc_halt));
+    ctx.emit_at(kHandOver + 1, succ * (L(C_NEXT_PC) - ctx.pub(kPubEndPc)));
   }
   if (TASK == 1) {
     // B and C bit by bit (top bit first): limbs by Horner, the three bitwise results per half.  A is its two limbs:
@@ -446,9 +457,9 @@ ZKSP_HD void eval_cpu(Ctx& ctx) {
   eval_cpu_task<1>(ctx);
   eval_cpu_task<2>(ctx);
   eval_cpu_task<3>(ctx);
-  ctx.set_count(264);
+  ctx.set_count(266);
 }
-constexpr int kCpuConstraints = 264;
+constexpr int kCpuConstraints = 266;
 
 template <class Ctx>
 ZKSP_HD void eval_kmem(Ctx& ctx) {
@@ -527,7 +538,7 @@ constexpr int kKeccakConstraints = ka::kNumConstraints + 1;
 #undef L
 
 ZKSP_HD constexpr int num_constraints(int chip) {
-  return chip == kCpu ? kCpuConstraints : chip == kKeccak ? kKeccakConstraints : chip == kKmem ? kKmemConstraints
+  return is_cpu_chip(chip) ? kCpuConstraints : chip == kKeccak ? kKeccakConstraints : chip == kKmem ? kKmemConstraints
        : chip == kMemFinal ? kMemFinalConstraints : chip == kImage ? 1 : chip == kProgram ? 0 : chip == kMul ? kMulConstraints : 0;
 }
 

@@ -17,7 +17,7 @@ struct Seg {
   size_t bstride;
   int width;
 };
-constexpr int kMaxSegs = 8;
+constexpr int kMaxSegs = 12;  // at least kNumChips: every chip could have the same height
 
 // ---- trace expansion (row a3 of the machine proof) ----
 struct MachineRecords {
@@ -29,12 +29,13 @@ struct MachineRecords {
   const uint32_t* image_used;  // [B][2^log_image]
   const uint32_t* counts;      // [B][4]: cycles, keccak calls, memfinal rows, muls
   uint32_t* range_hist;        // [B][2^kRangeLogH] scratch: multiplicities of the range table, counted on the device
-  uint32_t* cpu_limbs;         // [B][8][H_cpu] scratch: limbs of the CPU chip's B, C, M, X per trace row (for the LogUp trace)
+  uint32_t* cpu_limbs[2];      // per CPU instance: [B][8][H] scratch, limbs of B, C, M, X per trace row (for the LogUp trace)
+  uint32_t cpu2_row0;          // first cycle of the second CPU instance (= rows of the first)
   size_t cap_cycles, cap_keccak, cap_memfinal, cap_muls;
   const uint32_t* program;     // [n_program][9] (shared)
   uint32_t text_base, n_program;
 };
-// trace: [B][main_width][2^logh] of the given chip (kCpu, kKmem, kMemFinal, kImage, kProgram, kMul, kRange)
+// trace: [B][main_width][2^logh] of the given chip (kCpu, kCpu2, kKmem, kMemFinal, kImage, kProgram, kMul, kRange)
 void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& rec, uint32_t* trace, int logh, int batch);
 // keccak chip: p3-keccak-air's columns by launch_keccak_trace (kernels.h, with a batch stride), then the call time
 void launch_keccak_ts(hipStream_t stream, const MachineRecords& rec, uint32_t* trace, size_t trace_bstride, int logh,
@@ -68,7 +69,9 @@ struct PermArgs {
 };
 void launch_perm_trace(hipStream_t stream, const PermArgs& a);
 // public terms of the two verifier-closed buses: out[b] = -(sum over the 16 digest words and the exit code of 1/f)
-void launch_public_bus(hipStream_t stream, const uint32_t* pub_words /*[B][17]: pv digest 8, deferred 8, exit code*/,
+// per proof: pv digest 8, deferred digest 8, exit code (canonical), then the CpuPub words of the two CPU instances (Montgomery)
+constexpr int kPubWords = 17 + 2 * 4;
+void launch_public_bus(hipStream_t stream, const uint32_t* pub_words /*[B][kPubWords]*/,
                        const uint32_t* bus_ch, const uint32_t* bpow, uint32_t* out, size_t out_bstride, int batch);
 
 // ---- quotient (row a6) ----
@@ -87,7 +90,8 @@ struct MQuotArgs {
   uint32_t shift[2];            // g, g * w_2H  (Montgomery)
   uint32_t zh_inv[2];
   uint32_t wh_inv;
-  uint32_t pub;                 // entry pc (Montgomery)
+  const uint32_t* pubs;         // CPU instances: this instance's CpuPub words per proof (Montgomery), stride pubs_bstride
+  size_t pubs_bstride;
   uint32_t* quot;               // [B][8][H]
   uint32_t* partial;            // keccak chip: [B][13][2H] Fp4 scratch; CPU chip: [B][5][2H] Fp4
   uint32_t* limbs;              // CPU chip: [B][8][2H] scratch, limbs of B, C, M, X (written by tasks 1-3, read by the LogUp task)

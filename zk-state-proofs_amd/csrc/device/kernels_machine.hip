@@ -50,21 +50,24 @@ struct Col {
   }
 };
 
-__global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh) {
+// One CPU instance: row r is cycle row0 + r (row0 = 0 for the first instance, its height for the second).
+__global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh, uint32_t row0,
+                                                       uint32_t* __restrict__ limbs) {
   const size_t h = (size_t)1 << logh;
   const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
   if (r >= h) return;
   const int b = blockIdx.y;
   const Col o{trace + (size_t)b * kCpuWidth * h + r, h};
-  const uint32_t ts = 4 * ((uint32_t)r + 1);
-  if (r >= rec.counts[4 * b]) {  // padding: only the clock runs on
+  const size_t cyc = (size_t)row0 + r;
+  const uint32_t ts = 4 * ((uint32_t)cyc + 1);
+  if (cyc >= rec.counts[4 * b]) {  // padding: only the clock runs on
     o.zero(0, kCpuWidth);
     o.val(C_TS, ts);
-    const Col lim0{rec.cpu_limbs + (size_t)b * 8 * h + r, h};
+    const Col lim0{limbs + (size_t)b * 8 * h + r, h};
     lim0.zero(0, 8);
     return;
   }
-  const uint32_t* cy = rec.cycles + ((size_t)b * rec.cap_cycles + r) * 12;
+  const uint32_t* cy = rec.cycles + ((size_t)b * rec.cap_cycles + cyc) * 12;
   const uint32_t pc = cy[0], a = cy[1], bb = cy[2], c = cy[3], m = cy[4], mv = cy[5], wprev = cy[6];
   const uint32_t* p = rec.program + 9 * (size_t)((pc - rec.text_base) >> 2);
   const uint32_t op = p[1], wr = p[2], use2 = p[3], rd = p[4], rs1 = p[5], rs2 = p[6], imm = p[7], tgt = p[8];
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
   o.val(C_IMM_LO, imm & 0xffff); o.val(C_IMM_HI, imm >> 16); o.val(C_TGT, tgt);
   o.val(C_A, a & 0xffff); o.val(C_A + 1, a >> 16);
   o.bits(C_B, bb, 32); o.bits(C_C, c, 32); o.bits(C_M, m, 32);
-  const Col lim{rec.cpu_limbs + (size_t)b * 8 * h + r, h};  // limbs of B, C, M (X below) for the LogUp trace
+  const Col lim{limbs + (size_t)b * 8 * h + r, h};  // limbs of B, C, M (X below) for the LogUp trace
   lim.val(0, bb & 0xffff); lim.val(1, bb >> 16); lim.val(2, c & 0xffff); lim.val(3, c >> 16);
   lim.val(4, m & 0xffff); lim.val(5, m >> 16);
   o.val(C_MV_LO, mv & 0xffff); o.val(C_MV_HI, mv >> 16);
@@ -298,7 +301,12 @@ void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& re
       hipLaunchKernelGGL(count_column_kernel, dim3((unsigned)((h + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec.range_hist, trace, h);
       break;
     case kCpu:
-      hipLaunchKernelGGL(cpu_trace_kernel, dim3((unsigned)((h + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec, trace, logh);
+      hipLaunchKernelGGL(cpu_trace_kernel, dim3((unsigned)((h + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec, trace, logh, 0u,
+                         rec.cpu_limbs[0]);
+      break;
+    case kCpu2:
+      hipLaunchKernelGGL(cpu_trace_kernel, dim3((unsigned)((h + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec, trace, logh,
+                         rec.cpu2_row0, rec.cpu_limbs[1]);
       break;
     case kKmem:
       hipLaunchKernelGGL(kmem_trace_kernel, dim3((unsigned)((h + 63) / 64), batch), dim3(64), 0, stream, rec, trace, logh);
@@ -731,7 +739,7 @@ __global__ __launch_bounds__(kMT) void perm_slice_scan_kernel(PermArgs a, const 
 
 void launch_perm_trace(hipStream_t stream, const PermArgs& a) {
   const size_t h = (size_t)1 << a.logh;
-  if (a.chip == kCpu)
+  if (is_cpu_chip(a.chip))
     hipLaunchKernelGGL(perm_terms_cpu_kernel, dim3((unsigned)((h + kMT - 1) / kMT), a.batch), dim3(kMT), 0, stream, a);
   else
     hipLaunchKernelGGL(perm_terms_kernel, dim3((unsigned)((h + kMT - 1) / kMT), a.batch), dim3(kMT), 0, stream, a);
@@ -752,7 +760,7 @@ __global__ __launch_bounds__(64) void public_bus_kernel(const uint32_t* __restri
   const Fp4 gamma = m_load_fp4(bus_ch + (size_t)b * 8);
   const uint32_t* bp = bpow_all + (size_t)b * (kInterMaxElems + 1) * 4;
   const Fp4 b1 = m_load_fp4(bp + 4), b2 = m_load_fp4(bp + 8), b3 = m_load_fp4(bp + 12), b4 = m_load_fp4(bp + 16);
-  const uint32_t* w = pub + (size_t)b * 17;
+  const uint32_t* w = pub + (size_t)b * kPubWords;
   Fp4 total = Fp4::zero();
   for (uint32_t kind = 1; kind <= 2; ++kind)
     for (uint32_t i = 0; i < 8; ++i) {
@@ -782,7 +790,8 @@ struct MQCtx {
   const uint32_t* loc;
   const uint32_t* nxt;
   size_t cs;
-  Fp first, trans, last, pub_;
+  Fp first, trans, last;
+  uint32_t pub_[4];
   const uint32_t* ap;
   int k_;
   Fp4 acc;
@@ -803,7 +812,7 @@ struct MQCtx {
   __device__ __forceinline__ F is_first() const { return first; }
   __device__ __forceinline__ F is_trans() const { return trans; }
   __device__ __forceinline__ F is_last() const { return last; }
-  __device__ __forceinline__ F pub() const { return pub_; }
+  __device__ __forceinline__ F pub(int which) const { return Fp::raw(pub_[which]); }
   __device__ __forceinline__ F one() const { return Fp::one(); }
   __device__ __forceinline__ F k(uint32_t monty) const { return Fp::raw(monty); }
   // acc += alpha^k * v through signed 64-bit lazy sums (field.hpp): both factors centred, so a product is one
@@ -921,7 +930,8 @@ __device__ __forceinline__ void init_ctx(const MQuotArgs& a, const PointInfo& pi
   ctx->first = pi.first;
   ctx->trans = pi.trans;
   ctx->last = pi.last;
-  ctx->pub_ = Fp::raw(a.pub);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ctx->pub_[i] = a.pubs ? a.pubs[(size_t)pi.b * a.pubs_bstride + i] : 0u;
   ctx->ap = a.alpha_pows + (size_t)pi.b * a.alpha_bstride;
   ctx->k_ = 0;
   ctx->acc = Fp4::zero();
@@ -1076,6 +1086,7 @@ void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a) {
   const dim3 grid((unsigned)((n + kMT - 1) / kMT), a.batch), block(kMT);
   switch (a.chip) {
     case kCpu:
+    case kCpu2:
       hipLaunchKernelGGL(cpu_quotient_task_kernel<0>, grid, block, 0, stream, a);
       hipLaunchKernelGGL(cpu_quotient_task_kernel<1>, grid, block, 0, stream, a);
       hipLaunchKernelGGL(cpu_quotient_task_kernel<2>, grid, block, 0, stream, a);

@@ -12,8 +12,8 @@
 using namespace zksp;
 
 // Header (version, chip heights, exit code, digests, key digest), public values, body: the v4 proof object.
-int machine_proof_from_parts(const zksp_pk* pk, const ExecutionRecord& r, const int* lh, const uint32_t* body, size_t body_words,
-                             zksp_proof** out) {
+int machine_proof_from_parts(const zksp_pk* pk, const ExecutionRecord& r, const int* lh, uint32_t handover_pc, const uint32_t* body,
+                             size_t body_words, zksp_proof** out) {
   zksp_proof* p = new (std::nothrow) zksp_proof();
   if (!p) return ZKSP_ERR_INVALID_ARG;
   try {
@@ -28,6 +28,7 @@ int machine_proof_from_parts(const zksp_pk* pk, const ExecutionRecord& r, const 
     memcpy(w + 4 + mach::kNumChips, r.pv_digest.data(), 32);
     memcpy(w + 12 + mach::kNumChips, r.deferred_digest.data(), 32);
     memcpy(w + 20 + mach::kNumChips, pk->mvk.digest, 32);
+    w[28 + mach::kNumChips] = handover_pc;
     if (!r.public_values.empty()) memcpy(w + mach::kHeaderWords, r.public_values.data(), r.public_values.size());
     memcpy(w + mach::kHeaderWords + pvw, body, body_words * 4);
   } catch (...) {
@@ -177,7 +178,7 @@ int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const 
   if (!pk || !t || !body || !out) return ZKSP_ERR_INVALID_ARG;
   int lh[mach::kNumChips];
   machine_heights(*t->prog, t->t, lh);
-  return machine_proof_from_parts(pk, t->t.rec, lh, body, body_words, out);
+  return machine_proof_from_parts(pk, t->t.rec, lh, machine_handover_pc(t->t), body, body_words, out);
 }
 
 int zksp_vk_machine(const zksp_vk* vk, uint32_t* prep_root8, uint32_t* digest8) {

@@ -115,6 +115,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       traces[i].reset(new zksp_mtrace());
       traces[i]->prog = &pk->mprog;
       trace_execute(pk->elf, pk->mprog, stdins[i]->entries, (uint64_t)1 << 21, &traces[i]->t);
+      traces[i]->handover_pc = machine_handover_pc(traces[i]->t);
       stdins[i]->entries.clear();  // consumed, as SP1Stdin is by prove()
     } catch (...) {
       traces[i].reset(new zksp_mtrace());
@@ -269,7 +270,8 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     }
     for (size_t j = 0; j < cnt; ++j) {
       const size_t i = ck.idx[j];
-      status[i] = machine_proof_from_parts(pk, traces[i]->t.rec, ck.lh.data(), bodies.data() + j * bw, bw, &out[i]);
+      status[i] = machine_proof_from_parts(pk, traces[i]->t.rec, ck.lh.data(), traces[i]->handover_pc, bodies.data() + j * bw, bw,
+                                           &out[i]);
     }
     mark.mark("wrapped", cnt);
     if (piggyback && rc_next != ZKSP_OK) {

@@ -64,7 +64,7 @@ struct Context {
   // device copies of the chips' bus interactions
   std::unique_ptr<MachineWorkspace> mws;
   std::map<std::array<uint32_t, 8>, std::unique_ptr<PrepDevice>> prep;
-  void* d_inter[8] = {nullptr};
+  void* d_inter[16] = {nullptr};  // indexed by chip (mach::kNumChips <= 16)
   uint32_t* h_stage2[2] = {nullptr, nullptr};  // pinned host staging for proof bodies (double buffered)
   size_t h_stage2_words[2] = {0, 0};
   // prove_batch copies a group's bodies to the host on its own stream while the next group is

@@ -169,6 +169,7 @@ void build() {
   g_range[0] = range_inter(+1, lf_col(kRangePrepWidth + 0), lf_col(0));
   g_chips[kRange] = {"range", kRangePrepWidth, kRangeWidth, 1, g_range, 0};
   g_chips[kCpu] = {"cpu", 0, kCpuWidth, 21, g_cpu, kCpuConstraints};
+  g_chips[kCpu2] = {"cpu2", 0, kCpuWidth, 21, g_cpu, kCpuConstraints};
   g_chips[kKeccak] = {"keccak", 0, kKeccakWidth, 50, g_keccak, kKeccakConstraints};
   g_chips[kKmem] = {"keccak-mem", 0, kKmemWidth, 6, g_kmem, kKmemConstraints};
   g_chips[kMemFinal] = {"mem-final", 0, kMemFinalWidth, 2, g_memfinal, kMemFinalConstraints};

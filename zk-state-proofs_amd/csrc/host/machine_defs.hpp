@@ -34,8 +34,15 @@ struct ChipDef {
 };
 const ChipDef& chip_def(int chip);
 
-constexpr int kHeaderWords = 2 + kNumChips + 2 + 24;
-constexpr uint32_t kMachineVersion = 4;
+constexpr int kHeaderWords = 2 + kNumChips + 2 + 24 + 1;  // magic, version, heights, exit code, pv length, 3 digests, hand-over pc
+constexpr uint32_t kMachineVersion = 5;
+
+// rows of the first CPU instance: the largest power of two strictly below the cycle count (at least 32)
+inline size_t cpu_split(size_t n_cycles) {
+  size_t h0 = 32;
+  while (2 * h0 < n_cycles) h0 *= 2;
+  return h0;
+}
 
 }  // namespace mach
 }  // namespace zksp

@@ -84,8 +84,15 @@ int mmcs_commit(hipStream_t s, const RoundMats& rm, uint32_t* tree, size_t tree_
 
 }  // namespace
 
+uint32_t machine_handover_pc(const MachineTrace& t) {
+  const size_t h0 = cpu_split(t.cycles.size());
+  return h0 < t.cycles.size() ? t.cycles[h0].pc : 0;
+}
+
 void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh[kNumChips]) {
-  logh[kCpu] = at_least5(ceil_log2(t.cycles.size()));
+  const size_t h0 = cpu_split(t.cycles.size());
+  logh[kCpu] = ceil_log2(h0);
+  logh[kCpu2] = at_least5(ceil_log2(t.cycles.size() > h0 ? t.cycles.size() - h0 : 1));
   logh[kKeccak] = at_least5(ceil_log2(24 * t.keccak.size()));
   logh[kKmem] = at_least5(ceil_log2(50 * t.keccak.size()));
   logh[kMemFinal] = at_least5(ceil_log2(t.memfinal.size()));
@@ -183,12 +190,14 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   A(&w->prog_mult, B << logh[kProgram]);
   A(&w->image_used, B << logh[kImage]);
   A(&w->range_hist, B << kRangeLogH);
-  A(&w->cpu_limbs_tr, (B * 8) << logh[kCpu]);
-  A(&w->cpu_limbs_lde, (B * 16) << logh[kCpu]);
+  A(&w->cpu_limbs_tr[0], (B * 8) << logh[kCpu]);
+  A(&w->cpu_limbs_lde[0], (B * 16) << logh[kCpu]);
+  A(&w->cpu_limbs_tr[1], (B * 8) << logh[kCpu2]);
+  A(&w->cpu_limbs_lde[1], (B * 16) << logh[kCpu2]);
   A(&w->counts, B * 4);
   A(&w->n_perms, B);
   A(&w->init_obs, B * kMachineInitObs);
-  A(&w->pub_words, B * 17);
+  A(&w->pub_words, B * kPubWords);
   A(&w->spare.cycles, B * w->cap_cycles * 12);
   A(&w->spare.kcalls, B * w->cap_keccak * 408);
   A(&w->spare.kstates, B * w->cap_keccak * 25);
@@ -199,7 +208,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   A(&w->spare.counts, B * 4);
   A(&w->spare.n_perms, B);
   A(&w->spare.init_obs, B * kMachineInitObs);
-  A(&w->spare.pub_words, B * 17);
+  A(&w->spare.pub_words, B * kPubWords);
   int lm = 0;
   size_t n_open = 0, max_total = 0, max_h = 0;
   for (int c = 0; c < kNumChips; ++c) {
@@ -314,11 +323,11 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     if (memcmp(li, logh, sizeof li) != 0) return ctx->fail(1, "machine_load: traces of one batch must have identical chip heights");
   }
   // record capacities follow from the heights alone, so every batch of these heights fits the same workspace
-  const size_t cc = (size_t)1 << logh[kCpu], cm = (size_t)1 << logh[kMemFinal], cu = (size_t)1 << logh[kMul],
+  const size_t cc = ((size_t)1 << logh[kCpu]) + ((size_t)1 << logh[kCpu2]), cm = (size_t)1 << logh[kMemFinal], cu = (size_t)1 << logh[kMul],
                ck = std::min(((size_t)1 << logh[kKeccak]) / 24, ((size_t)1 << logh[kKmem]) / 50);
-  if (logh[kCpu] > 21) return ctx->fail(9, "machine_load: more than 2^21 cycles");
-  for (int c = 1; c < kNumChips; ++c)
-    if (logh[c] > logh[kCpu]) return ctx->fail(9, "machine_load: a chip is taller than the CPU chip");
+  if (logh[kCpu] > 20) return ctx->fail(9, "machine_load: more than 2^21 cycles");
+  for (size_t i = 0; i < n; ++i)
+    if (traces[i]->cycles.size() < 33) return ctx->fail(9, "machine_load: fewer than 33 cycles");
   if (into_spare) {
     MachineWorkspace* w0 = ctx->mws.get();
     if (!w0 || memcmp(w0->logh, logh, sizeof w0->logh) != 0 || (size_t)w0->batch < n || !ctx->copy_stream)
@@ -337,7 +346,7 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     ~SwapBack() { if (on) swap_records(w); }
   } swap_back{w, into_spare};
   if (into_spare) swap_records(w);
-  std::vector<uint32_t> counts(n * 4), nperms(n), obs(n * kMachineInitObs), pubw(n * 17);
+  std::vector<uint32_t> counts(n * 4), nperms(n), obs(n * kMachineInitObs), pubw(n * kPubWords);
   std::vector<uint64_t> kst(n * w->cap_keccak * 25, 0);
   const size_t hp = (size_t)1 << logh[kProgram], hi = (size_t)1 << logh[kImage];
   for (size_t i = 0; i < n; ++i) {
@@ -366,10 +375,22 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
       o[11 + kNumChips + 2 * k] = t.rec.pv_digest[k] >> 16;
       o[26 + kNumChips + 2 * k] = t.rec.deferred_digest[k] & 0xffff;
       o[27 + kNumChips + 2 * k] = t.rec.deferred_digest[k] >> 16;
-      pubw[i * 17 + k] = t.rec.pv_digest[k];
-      pubw[i * 17 + 8 + k] = t.rec.deferred_digest[k];
+      pubw[i * kPubWords + k] = t.rec.pv_digest[k];
+      pubw[i * kPubWords + 8 + k] = t.rec.deferred_digest[k];
     }
-    pubw[i * 17 + 16] = t.rec.exit_code;
+    pubw[i * kPubWords + 16] = t.rec.exit_code;
+    {
+      // the two CPU instances: first pc, first time, has a successor, hand-over pc (air_machine.hpp CpuPub)
+      const size_t h0 = (size_t)1 << logh[kCpu];
+      const uint32_t handover = machine_handover_pc(t);
+      o[42 + kNumChips] = handover & 0xffff;
+      o[43 + kNumChips] = handover >> 16;
+      uint32_t* cp = &pubw[i * kPubWords + 17];
+      cp[kPubStartPc] = Fp::from_canonical(prog.entry).v; cp[kPubStartTs] = Fp::from_canonical(4).v;
+      cp[kPubHasSucc] = Fp::one().v; cp[kPubEndPc] = Fp::from_canonical(handover).v;
+      cp[4 + kPubStartPc] = Fp::from_canonical(handover).v; cp[4 + kPubStartTs] = Fp::from_canonical((uint32_t)(4 * (h0 + 1))).v;
+      cp[4 + kPubHasSucc] = 0; cp[4 + kPubEndPc] = 0;
+    }
   }
   ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->kstates, kst.data(), kst.size() * 8, hipMemcpyHostToDevice, s));
   ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->counts, counts.data(), counts.size() * 4, hipMemcpyHostToDevice, s));
@@ -421,7 +442,9 @@ int machine_prove_resident(Context* ctx) {
   MachineRecords rec;
   rec.cycles = w->cycles; rec.kcalls = w->kcalls; rec.memfinal = w->memfinal; rec.muls = w->muls;
   rec.prog_mult = w->prog_mult; rec.image_used = w->image_used; rec.counts = w->counts; rec.range_hist = w->range_hist;
-  rec.cpu_limbs = w->cpu_limbs_tr;
+  rec.cpu_limbs[0] = w->cpu_limbs_tr[0];
+  rec.cpu_limbs[1] = w->cpu_limbs_tr[1];
+  rec.cpu2_row0 = (uint32_t)1 << logh[kCpu];
   rec.cap_cycles = w->cap_cycles; rec.cap_keccak = w->cap_keccak; rec.cap_memfinal = w->cap_memfinal; rec.cap_muls = w->cap_muls;
   rec.program = prep->program; rec.text_base = prep->text_base; rec.n_program = prep->n_program;
   {
@@ -479,7 +502,7 @@ int machine_prove_resident(Context* ctx) {
       pa.perm_bstride = (size_t)d.perm_width() * H(c);
       pa.rowsum = w->rowsum;
       pa.slice_sums = w->slice_sums;
-      pa.limbs = c == kCpu ? w->cpu_limbs_tr : nullptr;
+      pa.limbs = c == kCpu ? w->cpu_limbs_tr[0] : c == kCpu2 ? w->cpu_limbs_tr[1] : nullptr;
       pa.cum = w->cum + 4 * c;
       pa.cum_bstride = (size_t)4 * kNumChips;
       pa.logh = logh[c];
@@ -532,10 +555,11 @@ int machine_prove_resident(Context* ctx) {
         qa.zh_inv[k] = (sh[k].pow(h) - Fp::one()).inv().v;
       }
       qa.wh_inv = wh.inv().v;
-      qa.pub = Fp::from_canonical(prep->entry).v;
+      qa.pubs = is_cpu_chip(c) ? w->pub_words + 17 + (c == kCpu2 ? 4 : 0) : nullptr;
+      qa.pubs_bstride = kPubWords;
       qa.quot = w->mat[c][2].tr;
-      qa.partial = c == kCpu ? w->reduce_scratch : w->kpartial;  // 40 H words per proof of the CPU chip <= 48 H
-      qa.limbs = c == kCpu ? w->cpu_limbs_lde : nullptr;
+      qa.partial = is_cpu_chip(c) ? w->reduce_scratch : w->kpartial;  // 40 H words per proof of a CPU instance <= 48 H
+      qa.limbs = c == kCpu ? w->cpu_limbs_lde[0] : c == kCpu2 ? w->cpu_limbs_lde[1] : nullptr;
       qa.logh = logh[c];
       qa.batch = B;
       launch_machine_quotient(s, qa);
@@ -627,6 +651,8 @@ int machine_prove_resident(Context* ctx) {
   // ---- FRI commit phase; an input of height 2^k joins when the folded layer reaches that height ----
   size_t loff = 0, toff = 0;
   const size_t hmax = (size_t)1 << lm;
+  const DeviceDomain* dmax = ctx->domain(lm);  // the tallest chip's domain (any chip may be the tallest)
+  if (!dmax) return 3;
   for (int k = 0; k < lm; ++k) {
     const int loghk = lm - k;
     const size_t hk = hmax >> k;
@@ -643,7 +669,7 @@ int machine_prove_resident(Context* ctx) {
       ProfileSpan sp(ctx, "fri_fold");
       uint32_t* nxt = w->fri_layers + loff + 2 * hk * 4;
       launch_fri_fold(s, w->fri_layers + loff, w->fri_layer_stride, nxt, w->fri_layer_stride, w->betas + (size_t)k * 4,
-                      (size_t)lm * 4, dom[kCpu]->tw_inv, k, dom[kCpu]->fold_xinv[2 * k], dom[kCpu]->fold_xinv[2 * k + 1], loghk, B);
+                      (size_t)lm * 4, dmax->tw_inv, k, dmax->fold_xinv[2 * k], dmax->fold_xinv[2 * k + 1], loghk, B);
       if (loghk - 1 >= 0 && w->G[loghk - 1]) launch_fri_add(s, nxt, w->fri_layer_stride, w->G[loghk - 1], hk * 4, hk, B);
     }
     loff += 2 * hk * 4;

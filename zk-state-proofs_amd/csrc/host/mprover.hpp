@@ -11,7 +11,7 @@
 
 namespace zksp {
 
-constexpr int kMachineInitObs = 8 + mach::kNumChips + 2 + 16 + 16;  // vk digest, heights, exit halves, digest halves
+constexpr int kMachineInitObs = 8 + mach::kNumChips + 2 + 16 + 16 + 2;  // vk digest, heights, exit halves, digest halves, hand-over pc halves
 
 // Preprocessed tables of one program on the device (built once per verifying key).
 struct PrepDevice {
@@ -36,7 +36,8 @@ struct MachineWorkspace {
   const PrepDevice* prep = nullptr;
   // records
   uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *image_used = nullptr, *counts = nullptr,
-           *range_hist = nullptr, *cpu_limbs_tr = nullptr, *cpu_limbs_lde = nullptr;  // limbs of the CPU chip's bit blocks
+           *range_hist = nullptr;
+  uint32_t *cpu_limbs_tr[2] = {nullptr, nullptr}, *cpu_limbs_lde[2] = {nullptr, nullptr};  // limbs of the CPU instances' bit blocks
   uint8_t* kcalls = nullptr;
   uint64_t* kstates = nullptr;
   uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;
@@ -80,5 +81,7 @@ int machine_activate_spare(Context* ctx);
 // enqueues the whole proving pass over the resident batch
 int machine_prove_resident(Context* ctx);
 void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh[mach::kNumChips]);
+// pc of the first cycle of the second CPU instance (a proof-header word)
+uint32_t machine_handover_pc(const MachineTrace& t);
 
 }  // namespace zksp

@@ -132,7 +132,7 @@ struct ZetaCtx {
   using F = Fp4;
   const Fp4* loc;  // main columns at zeta
   const Fp4* nxt;  // main columns at zeta * w
-  Fp4 first, trans, last, pub_;
+  Fp4 first, trans, last, pub_[kNumCpuPub];
   const Fp4* ap;
   int k_ = 0;
   Fp4 acc = Fp4::zero();
@@ -141,7 +141,7 @@ struct ZetaCtx {
   F is_first() const { return first; }
   F is_trans() const { return trans; }
   F is_last() const { return last; }
-  F pub() const { return pub_; }
+  F pub(int which) const { return pub_[which]; }
   F one() const { return Fp4::one(); }
   F k(uint32_t monty) const { return Fp4::from_base(Fp::raw(monty)); }
   void emit(F v) { acc += ap[k_++] * v; }
@@ -281,13 +281,13 @@ bool parse_machine_header(const uint8_t* bytes, size_t len, MachineHeader* h, st
     h->logh[c] = (int)w[2 + c];
     if (w[2 + c] < 5 || w[2 + c] > 21) { *err = "chip height out of range"; return false; }
   }
-  for (int c = 1; c < kNumChips; ++c)
-    if (h->logh[c] > h->logh[kCpu]) { *err = "a chip is taller than the CPU chip"; return false; }
+  if (h->logh[kCpu] > 20 || h->logh[kCpu2] > h->logh[kCpu]) { *err = "CPU instance heights out of range"; return false; }
   h->exit_code = w[2 + kNumChips];
   h->pv_len = w[3 + kNumChips];
   memcpy(h->pv_digest, w + 4 + kNumChips, 32);
   memcpy(h->deferred_digest, w + 12 + kNumChips, 32);
   memcpy(h->vk_digest, w + 20 + kNumChips, 32);
+  h->handover_pc = w[28 + kNumChips];
   if (h->pv_len > (1u << 24)) { *err = "public values too long"; return false; }
   h->pv_offset = (size_t)kHeaderWords * 4;
   h->body_offset = ((size_t)kHeaderWords + (h->pv_len + 3) / 4) * 4;
@@ -320,7 +320,8 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     if (body[i] >= kP) { *err = "non-canonical field element"; return 7; }
 
   const P2Consts* kc = &host_p2_consts();
-  const int lm = logh[kCpu];
+  int lm = 0;  // the tallest chip: every tree and the FRI start from its height
+  for (int c = 0; c < kNumChips; ++c) lm = std::max(lm, logh[c]);
   // shapes
   RoundShape shape[4];
   size_t open_off[kNumChips], n_open = 0;
@@ -353,6 +354,8 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   ch.observe_canon(hd.exit_code >> 16);
   for (int i = 0; i < 8; ++i) { ch.observe_canon(hd.pv_digest[i] & 0xffff); ch.observe_canon(hd.pv_digest[i] >> 16); }
   for (int i = 0; i < 8; ++i) { ch.observe_canon(hd.deferred_digest[i] & 0xffff); ch.observe_canon(hd.deferred_digest[i] >> 16); }
+  ch.observe_canon(hd.handover_pc & 0xffff);
+  ch.observe_canon(hd.handover_pc >> 16);
   Fp root[4][8];
   for (int i = 0; i < 8; ++i) root[0][i] = Fp::from_canonical(vk.prep_root[i]);
   for (int i = 0; i < 8; ++i) { root[1][i] = Fp::from_canonical(p_root_main[i]); ch.observe(root[1][i]); }
@@ -420,10 +423,22 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     zc.first = zh * (zeta - Fp4::one()).inv();
     zc.trans = zeta - Fp4::from_base(wh_inv);
     zc.last = zh * (zeta - Fp4::from_base(wh_inv)).inv();
-    zc.pub_ = Fp4::from_base(Fp::from_canonical(vk.entry));
+    // the CPU instances' public scalars: the first starts at the entry point at time 4 and hands over to the second,
+    // which starts at the hand-over pc (a header word, absorbed into the transcript) right after the first's last row
+    for (int i = 0; i < kNumCpuPub; ++i) zc.pub_[i] = Fp4::zero();
+    if (c == kCpu) {
+      zc.pub_[kPubStartPc] = Fp4::from_base(Fp::from_canonical(vk.entry));
+      zc.pub_[kPubStartTs] = Fp4::from_base(Fp::from_canonical(4));
+      zc.pub_[kPubHasSucc] = Fp4::one();
+      zc.pub_[kPubEndPc] = Fp4::from_base(Fp::from_canonical(hd.handover_pc % kP));
+    } else if (c == kCpu2) {
+      zc.pub_[kPubStartPc] = Fp4::from_base(Fp::from_canonical(hd.handover_pc % kP));
+      zc.pub_[kPubStartTs] = Fp4::from_base(Fp::from_canonical((uint32_t)(4 * (((uint64_t)1 << logh[kCpu]) + 1))));
+    }
     zc.ap = apow.data();
     switch (c) {
-      case kCpu: eval_cpu(zc); break;
+      case kCpu:
+      case kCpu2: eval_cpu(zc); break;
       case kKeccak:
         for (int task = 0; task < ka::kBusTask; ++task) ka::eval_task(task, zc);
         zc.k_ = ka::kNumConstraints;

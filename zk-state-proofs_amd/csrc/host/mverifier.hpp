@@ -23,7 +23,7 @@ struct MachineVk {
 
 struct MachineHeader {
   int logh[mach::kNumChips];
-  uint32_t exit_code, pv_len;
+  uint32_t exit_code, pv_len, handover_pc;
   uint32_t pv_digest[8], deferred_digest[8], vk_digest[8];
   size_t pv_offset, body_offset;
 };
