@@ -55,7 +55,7 @@ typedef struct {
 } zksp_options;
 /* What zksp_prove / zksp_prove_batch establish:
  * MACHINE      the guest's whole execution (CPU, memory, program, keccak, multiplier chips joined by
- *              LogUp buses; proof format v4): the statement of the reference's client.prove().
+ *              LogUp buses; proof format v5): the statement of the reference's client.prove().
  * KECCAK_CHIP  only "these keccak-f outputs belong to these inputs" (round-1 format v2, a component
  *              benchmark; NOT a proof that the guest ran). */
 #define ZKSP_PROOF_MACHINE 1
@@ -167,7 +167,7 @@ int zksp_hip_machine_prove(zksp_client* c);
 int zksp_hip_machine_fetch_bodies(zksp_client* c, uint32_t* out, size_t cap_words);
 /* Only the 8-word main-trace commitment of every resident proof ([n][8]): what the proof farm all-gathers. */
 int zksp_hip_machine_fetch_roots(zksp_client* c, uint32_t* out, size_t cap_words);
-/* Complete v4 proof object from one fetched body and the trace it belongs to. */
+/* Complete v5 proof object from one fetched body and the trace it belongs to. */
 int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const uint32_t* body, size_t body_words,
                                  zksp_proof** out);
 /* The machine-proof part of the verifying key: Merkle root of the preprocessed Program / Image
