@@ -237,6 +237,28 @@ def test_wrong_product_is_rejected(zk, oracle, setup):
     _rejected(zk, oracle, client, vk, t2)
 
 
+def test_second_cpu_instance_must_continue_the_first(zk, oracle, setup):
+    """The execution is split over two instances of the CPU chip; the second must start at the pc the first one's
+    last row hands over (a header word both instances' boundary constraints use).  A run whose second half starts
+    somewhere else is rejected, and so is a proof whose header names another hand-over pc."""
+    client, vk, t, proof = setup
+    cyc = t["cycles"]
+    h0 = 32
+    while 2 * h0 < len(cyc):
+        h0 *= 2
+    hw = zk.MACHINE_HEADER_WORDS
+    assert int.from_bytes(proof[4 * (hw - 1):4 * hw], "little") == int(cyc[h0, 0])  # the header's hand-over pc
+    c2 = cyc.copy()
+    c2[h0, 0] = cyc[h0 + 7, 0]  # the second instance starts at another instruction
+    t2 = dict(t)
+    t2["cycles"] = c2
+    _rejected(zk, oracle, client, vk, t2)
+    bad = bytearray(proof)
+    bad[4 * (hw - 1)] ^= 4
+    with pytest.raises(zk.ZkspError):
+        client.verify(zk.SP1ProofWithPublicValues.from_bytes(bytes(bad)), vk)
+
+
 def test_exit_code_is_bound_to_halt(zk, oracle, setup):
     client, vk, t, _ = setup
     t2 = dict(t)
