@@ -141,7 +141,7 @@ def test_end_to_end_acct_d8(zk, fx, oracle):
                        vk_digest=[int(x) for x in np.frombuffer(vk.digest, dtype=np.uint32)])
     assert raw == exp
     # host-only client verifies too; every tampered region is rejected
-    host = zk.ProverClient(device=-1)
+    host = zk.ProverClient(device=-1, proof_mode=zk.PROOF_KECCAK_CHIP)
     host.verify(zk.SP1ProofWithPublicValues.from_bytes(raw), vk)
     for pos in (125, 30 * 4 + 72 + 3, 30 * 4 + 72 + 64 + 8, len(raw) // 2, len(raw) - 3):
         bad = bytearray(raw)
@@ -214,7 +214,7 @@ def test_benchmarked_configuration_matches_oracle_and_verifies(zk, fx, oracle):
         e = np.frombuffer(exp, dtype=np.uint32)[oracle.proof_header_words(len(pv), len(states[i])):]
         bad = np.nonzero(e != bodies[i])[0]
         assert bad.size == 0, (i, bad[:8])
-    host = zk.ProverClient(device=-1)
+    host = zk.ProverClient(device=-1, proof_mode=zk.PROOF_KECCAK_CHIP)
     for i in (0, 1, 2, 3, 9, 17, 31, 40, 55, n - 1):
         proof = zk.proof_from_body(bodies[i], logh, states[i], 0, pv, pvd, [0] * 8, vkw)
         assert proof.public_values == pv

@@ -1,6 +1,8 @@
-"""Host verifier (row a8) against proofs made by the independent CPU oracle:
-accepts honest proofs, rejects every kind of tampering, wrong keys and wrong
-parameters.  Runs without a GPU."""
+"""Host verifier of the keccak-chip COMPONENT proof (format v2; a kernel benchmark, not a proof of execution)
+against proofs made by the CPU oracle: accepts honest proofs, rejects every kind of tampering, wrong keys and
+wrong parameters.  Such proofs verify only on a client created with proof_mode=PROOF_KECCAK_CHIP: the default
+(MACHINE) client of the reference-shaped flow refuses them (test_default_client_rejects_component_proofs).
+Runs without a GPU."""
 import hashlib
 
 import numpy as np
@@ -12,7 +14,7 @@ NQ, POW = 12, 8
 
 @pytest.fixture(scope="module")
 def setup(zk, oracle, built_lib):
-    client = zk.ProverClient(device=-1, num_queries=NQ, pow_bits=POW)
+    client = zk.ProverClient(device=-1, num_queries=NQ, pow_bits=POW, proof_mode=zk.PROOF_KECCAK_CHIP)
     pk, vk = client.setup(zk.merkle_elf())
     vk_words = [int(x) for x in np.frombuffer(vk.digest, dtype=np.uint32)]
     rng = np.random.default_rng(11)
@@ -29,6 +31,17 @@ def test_accepts_oracle_proof(zk, setup):
     assert p.public_values == pv
     client.verify(p, vk)
     assert p.to_bytes() == proof
+
+
+def test_default_client_rejects_component_proofs(zk, setup):
+    """The drop-in `client.verify(&proof, &vk)` (reference prover/src/bin/main.rs:80) accepts proofs of the guest's
+    execution only: a default client must refuse a keccak-chip component proof, whose public values are arbitrary
+    bytes, whatever version word the proof carries."""
+    _, vk, _, _, _, _, proof = setup
+    default = zk.ProverClient(device=-1, num_queries=NQ, pow_bits=POW)
+    with pytest.raises(zk.VerificationError) as ei:
+        default.verify(zk.SP1ProofWithPublicValues.from_bytes(proof), vk)
+    assert "not a machine proof" in str(ei.value)
 
 
 def test_rejects_tampering_everywhere(zk, setup):
@@ -54,10 +67,10 @@ def test_rejects_tampering_everywhere(zk, setup):
 def test_rejects_wrong_parameters_and_keys(zk, setup, oracle):
     client, vk, vk_words, st, pv, pvd, proof = setup
     p = zk.SP1ProofWithPublicValues.from_bytes(proof)
-    other = zk.ProverClient(device=-1, num_queries=NQ + 1, pow_bits=POW)
+    other = zk.ProverClient(device=-1, num_queries=NQ + 1, pow_bits=POW, proof_mode=zk.PROOF_KECCAK_CHIP)
     with pytest.raises(zk.ZkspError):
         other.verify(p, vk)
-    harder = zk.ProverClient(device=-1, num_queries=NQ, pow_bits=POW + 9)
+    harder = zk.ProverClient(device=-1, num_queries=NQ, pow_bits=POW + 9, proof_mode=zk.PROOF_KECCAK_CHIP)
     with pytest.raises(zk.ZkspError):
         harder.verify(p, vk)
     # a proof bound to another verifying key

@@ -381,11 +381,18 @@ int zksp_verify(zksp_client* c, const zksp_proof* p, const zksp_vk* vk) {
   std::string err;
   int rc;
   try {
-    rc = p->version == mach::kMachineVersion
-             ? verify_machine_proof(p->bytes.data(), p->bytes.size(), vk->machine, c->ctx.params.num_queries,
-                                    c->ctx.params.pow_bits, &err)
-             : verify_proof(p->bytes.data(), p->bytes.size(), vk->digest, c->ctx.params.num_queries, c->ctx.params.pow_bits,
-                            &err);
+    // The client's proof_mode decides which statement is being checked, never the proof's own version word: a
+    // default (MACHINE) client must not accept a keccak-chip component proof, which says nothing about the guest's
+    // execution (reference: `client.verify(&proof, &vk)`, prover/src/bin/main.rs:80, accepts proofs of execution only).
+    const bool want_machine = c->ctx.params.proof_mode == ZKSP_PROOF_MACHINE;
+    if (want_machine != (p->version == mach::kMachineVersion))
+      return c->ctx.fail(ZKSP_ERR_VERIFY, want_machine
+                                              ? "verify: not a machine proof (this client verifies proofs of execution only)"
+                                              : "verify: not a keccak-chip component proof (client created with ZKSP_PROOF_KECCAK_CHIP)");
+    rc = want_machine ? verify_machine_proof(p->bytes.data(), p->bytes.size(), vk->machine, c->ctx.params.num_queries,
+                                             c->ctx.params.pow_bits, &err)
+                      : verify_proof(p->bytes.data(), p->bytes.size(), vk->digest, c->ctx.params.num_queries,
+                                     c->ctx.params.pow_bits, &err);
   } catch (...) {
     return c->ctx.fail(ZKSP_ERR_VERIFY, "verify: out of memory");
   }
