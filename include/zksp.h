@@ -133,13 +133,14 @@ int zksp_execute_keccak(zksp_client* c, const zksp_pk* pk, const zksp_stdin* std
 typedef struct zksp_mtrace zksp_mtrace;
 #define ZKSP_MT_CYCLES 0        /* 12 u32 per executed cycle */
 #define ZKSP_MT_KECCAK 1        /* 408 bytes per precompile call: ts, ptr, 25 u64 in, 50 u32 previous times */
-#define ZKSP_MT_MEMFINAL 2      /* 5 u32 per touched address: addr, init, fin, fin_ts, is_init */
+#define ZKSP_MT_MEMFINAL 2      /* 5 u32 per image address and per other touched address: addr, init, fin, fin_ts, is_init */
 #define ZKSP_MT_MULS 3          /* 3 u32 per mul/mulhu: hi, b, c */
 #define ZKSP_MT_PROG_MULT 4     /* u32 per Program-table row */
-#define ZKSP_MT_IMAGE_USED 5    /* u32 per Image-table row */
-#define ZKSP_MT_PROGRAM 6       /* 9 u32 per row: pc, op, wr, use2, rd, rs1, rs2, imm, tgt */
+#define ZKSP_MT_ALU_IDX 5       /* u32 per ALU-chip row: index of the cycle (xor .. sltu, blt .. bgeu) */
+#define ZKSP_MT_PROGRAM 6       /* 9 u32 per row: pc, op, wr, use2, rd, rs1, rs2, imm, tgt; the last row is the padding instruction */
 #define ZKSP_MT_IMAGE 7         /* 2 u32 per row: addr, value */
 #define ZKSP_MT_PUBLIC_VALUES 8 /* bytes */
+#define ZKSP_MT_SUB_IDX 9       /* u32 per sub-word-chip row: index of the cycle (lb lh lbu lhu sb sh) */
 typedef struct {
   uint64_t cycles;
   uint64_t memory_ops;

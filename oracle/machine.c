@@ -1,30 +1,74 @@
 /* ORACLE -- TEST INFRASTRUCTURE ONLY (see field.h and machine.h).
  *
- * Chips of the machine proof: bus interactions, trace generation from the executor's records and
- * base-field constraints.  This repository's own arithmetisation (machine.h header note); what it
- * must reproduce is the reference's statement: the committed RV32IM guest
+ * Chips of the machine proof (format v6): bus interactions, trace generation from the executor's
+ * records and base-field constraints.  This repository's own arithmetisation (machine.h header
+ * note); what it must reproduce is the reference's statement: the committed RV32IM guest
  * (circuits/sp1-merkle-proof/src/main.rs:4-14 running crypto-ops/src/lib.rs:8-23) executed from its
  * entry point to HALT with the committed public values.  PARITY UNPINNED vs sp1-core-machine 3.4.0
  * (reference Cargo.lock:7130; sources absent).
  *
- * Design in one paragraph.  One CPU row per cycle; operands live as BITS (A = value written, B =
- * reg[rs1], C = reg[rs2] or the immediate, M = memory word read), so bitwise operations, shifts,
- * comparisons, byte/half selection and every range check are polynomial identities of degree <= 3
- * inside the row and no byte-lookup or ALU tables are needed.  Registers are memory addresses
- * 0..31.  Memory consistency is the offline argument: every access consumes the tuple
- * (addr, value, time) its predecessor produced and produces its own; Image (preprocessed program
- * image + zeroed registers) and MemFinal (every touched address once, strictly increasing) open
- * and close each address; "previous time < time": the difference is two 12-bit limbs, each looked
- * up in the Range table (a preprocessed column 0..4095 with a multiplicity column).  Instruction fetch is
- * a lookup into the preprocessed Program table.  The keccak precompile call hands (time, pointer)
- * to KeccakMem, which moves the 50 state words through the memory bus and matches them, word by
- * word, against what the keccak-f chip exports.  mul / mulhu go to a multiplier chip.  COMMIT and
- * HALT post the public digest words and the exit code on a bus the verifier closes.
+ * Design in one paragraph.  One CPU row per cycle and every row is an instruction: after HALT the
+ * rows execute the padding instruction the Program table ends with (a jump to itself), so the
+ * instruction fetch - a lookup into the preprocessed Program table - vouches for every decoded
+ * field of every row.  Operands are 16-bit limbs.  The row adds, subtracts, tests equality, moves
+ * words and forms addresses; xor / or / and / shifts / less-than go to the ALU chip, sub-word loads
+ * and stores to the sub-word chip, mul / mulhu to the multiplier (one row per such instruction,
+ * bits inside), keccak-f calls to keccak-memory + keccak.  Registers are memory addresses 0..31.
+ * Memory consistency is the offline argument: every access consumes the tuple (addr, value, time)
+ * its predecessor produced and produces its own; the memory-boundary chip lists EVERY address of
+ * the program image and every other touched address exactly once, in strictly increasing order
+ * (compared limb-wise over the integers), opens each with its initial value (image addresses: by
+ * lookup into the preprocessed Image table, which sends every word exactly once; others: a free,
+ * range-checked value - SP1's treatment of uninitialised / hinted memory) and closes it with its
+ * final one.  "previous time < time": the difference is a 16-bit and an 8-bit limb looked up in the
+ * table chip (2^16 rows: range16, 4-aligned range16, byte pairs).  COMMIT and HALT post the public
+ * digest words and the exit code on buses the verifier closes.
  */
 #include <stdlib.h>
 #include <string.h>
 
 #include "machine.h"
+
+/* ------------------------------------------------------------------------------------------
+ * opcodes and classes
+ * ---------------------------------------------------------------------------------------- */
+int orc_class_of(uint32_t op) {
+  switch (op) {
+    case OP_ADD: return CL_ADD;
+    case OP_SUB: return CL_SUB;
+    case OP_XOR: case OP_OR: case OP_AND: case OP_SLL: case OP_SRL: case OP_SRA: case OP_SLT: case OP_SLTU:
+    case OP_MUL: case OP_MULHU: return CL_ALU;
+    case OP_JAL: return CL_JAL;
+    case OP_JALR: return CL_JALR;
+    case OP_BEQ: return CL_BEQ;
+    case OP_BNE: return CL_BNE;
+    case OP_BLT: case OP_BLTU: return CL_BLT;
+    case OP_BGE: case OP_BGEU: return CL_BGE;
+    case OP_LW: return CL_LW;
+    case OP_SW: return CL_SW;
+    case OP_LB: case OP_LH: case OP_LBU: case OP_LHU: return CL_LDS;
+    case OP_SB: case OP_SH: return CL_STS;
+    case OP_ECALL: return CL_ECALL;
+    case OP_KECCAK: return CL_KECCAK;
+    default: return 0;
+  }
+}
+uint32_t orc_code_of(uint32_t op) {
+  switch (op) {
+    case OP_XOR: case OP_OR: case OP_AND: case OP_SLL: case OP_SRL: case OP_SRA: case OP_SLT: case OP_SLTU:
+    case OP_MUL: case OP_MULHU: case OP_LB: case OP_LH: case OP_LBU: case OP_LHU: case OP_SB: case OP_SH: return op;
+    case OP_BLT: case OP_BGE: return OP_SLT;
+    case OP_BLTU: case OP_BGEU: return OP_SLTU;
+    default: return 0;
+  }
+}
+/* does a cycle of this op occupy a row of the ALU chip (0) / the sub-word chip (1)? */
+static int event_kind(uint32_t op) {
+  const uint32_t code = orc_code_of(op);
+  if (code >= OP_XOR && code <= OP_SLTU) return 0;
+  if (code == OP_LB || code == OP_LH || code == OP_LBU || code == OP_LHU || code == OP_SB || code == OP_SH) return 1;
+  return -1;
+}
 
 /* ------------------------------------------------------------------------------------------
  * linear forms and interactions
@@ -38,30 +82,48 @@ static void lf_add(orc_lf* f, int col, uint32_t coef) {
 }
 static orc_lf lf_col(int col) { orc_lf f; lf_zero(&f); lf_add(&f, col, 1); return f; }
 static orc_lf lf_const(uint32_t c) { orc_lf f; lf_zero(&f); f.c0 = c % FP; return f; }
-/* 16-bit limb of a little-endian bit block starting at column `bits` */
-static orc_lf lf_limb(int bits, int limb) {
+static orc_lf lf_plus(orc_lf f, uint32_t c) { f.c0 = f_add(f.c0, c % FP); return f; }
+/* a + k * b */
+static orc_lf lf_pair(int a, int b, uint32_t k) { orc_lf f; lf_zero(&f); lf_add(&f, a, 1); lf_add(&f, b, k); return f; }
+/* sum of the given columns */
+static orc_lf lf_sum(const int* cols, int n) { orc_lf f; lf_zero(&f); for (int i = 0; i < n; ++i) lf_add(&f, cols[i], 1); return f; }
+/* c - col */
+static orc_lf lf_const_minus(uint32_t c, int col) { orc_lf f; lf_zero(&f); lf_add(&f, col, FP - 1); f.c0 = c % FP; return f; }
+/* n-bit little-endian value of the bit columns starting at `bits` */
+static orc_lf lf_bits(int bits, int n) {
   orc_lf f;
   lf_zero(&f);
-  for (int i = 0; i < 16; ++i) lf_add(&f, bits + 16 * limb + i, 1u << i);
+  for (int i = 0; i < n; ++i) lf_add(&f, bits + i, 1u << i);
   return f;
 }
-static orc_lf lf_plus(orc_lf f, uint32_t c) { f.c0 = f_add(f.c0, c % FP); return f; }
+#define SELC(cls) (C_SEL + (cls) - 1)
 
-static orc_inter g_cpu[21], g_keccak[50], g_kmem[6], g_memfinal[2], g_image[1], g_program[1], g_mul[2], g_range[1];
+#define CPU_INTER 23
+static orc_inter g_cpu[CPU_INTER], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[3],
+    g_alu[1], g_sub[1];
 static orc_chip g_chips[N_CHIPS];
 static int g_ready = 0;
 
 static orc_inter mem_inter(int sign, orc_lf mult, orc_lf addr, orc_lf lo, orc_lf hi, orc_lf ts) {
   orc_inter it;
+  memset(&it, 0, sizeof it);
   it.bus = BUS_MEM; it.sign = sign; it.mult = mult; it.n_el = 4;
   it.el[0] = addr; it.el[1] = lo; it.el[2] = hi; it.el[3] = ts;
   return it;
 }
-
-static orc_inter range_inter(int sign, orc_lf mult, orc_lf value) {
+/* table lookups: range16 (kind 0: any 16-bit value; kind 1: a multiple of 4) and byte pairs */
+static orc_inter range_inter(int sign, orc_lf mult, orc_lf kind, orc_lf value) {
   orc_inter it;
-  it.bus = BUS_RANGE; it.sign = sign; it.mult = mult; it.n_el = 1;
-  it.el[0] = value;
+  memset(&it, 0, sizeof it);
+  it.bus = BUS_RANGE; it.sign = sign; it.mult = mult; it.n_el = 2;
+  it.el[0] = kind; it.el[1] = value;
+  return it;
+}
+static orc_inter bytes_inter(int sign, orc_lf mult, orc_lf x, orc_lf y) {
+  orc_inter it;
+  memset(&it, 0, sizeof it);
+  it.bus = BUS_BYTES; it.sign = sign; it.mult = mult; it.n_el = 2;
+  it.el[0] = x; it.el[1] = y;
   return it;
 }
 
@@ -69,69 +131,86 @@ static int count_constraints(int chip);
 
 static void build(void) {
   if (g_ready) return;
-  /* in the CPU chip there are no preprocessed columns: linear forms index main columns directly */
-  orc_lf is_real = lf_col(C_IS_REAL), ts = lf_col(C_TS);
-  orc_lf a_lo = lf_col(C_A), a_hi = lf_col(C_A + 1), b_lo = lf_limb(C_B, 0), b_hi = lf_limb(C_B, 1);
-  orc_lf c_lo = lf_limb(C_C, 0), c_hi = lf_limb(C_C, 1), m_lo = lf_limb(C_M, 0), m_hi = lf_limb(C_M, 1);
+  const orc_lf one = lf_const(1), zero = lf_const(0), ts = lf_col(C_TS);
+  const orc_lf a_lo = lf_col(C_A), a_hi = lf_col(C_A + 1), b_lo = lf_col(C_B), b_hi = lf_col(C_B + 1), c_lo = lf_col(C_C),
+               c_hi = lf_col(C_C + 1), m_lo = lf_col(C_M), m_hi = lf_col(C_M + 1);
+  /* ---- CPU ---- */
   {
     orc_inter* it = &g_cpu[0];
-    it->bus = BUS_PROG; it->sign = -1; it->mult = is_real; it->n_el = 10;
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_PROG; it->sign = -1; it->mult = one; it->n_el = 12;
     it->el[0] = lf_col(C_PC);
     lf_zero(&it->el[1]);
-    for (int k = 1; k <= N_OPS; ++k) lf_add(&it->el[1], C_OP + k - 1, (uint32_t)k);
-    it->el[2] = lf_col(C_WR); it->el[3] = lf_col(C_USE2); it->el[4] = lf_col(C_RD); it->el[5] = lf_col(C_RS1);
-    it->el[6] = lf_col(C_RS2); it->el[7] = lf_col(C_IMM_LO); it->el[8] = lf_col(C_IMM_HI); it->el[9] = lf_col(C_TGT);
+    for (int k = 1; k <= N_CLS; ++k) lf_add(&it->el[1], SELC(k), (uint32_t)k);
+    it->el[2] = lf_col(C_CODE); it->el[3] = lf_col(C_WR); it->el[4] = lf_col(C_USE2); it->el[5] = lf_col(C_RD);
+    it->el[6] = lf_col(C_RS1); it->el[7] = lf_col(C_RS2); it->el[8] = lf_col(C_IMM_LO); it->el[9] = lf_col(C_IMM_HI);
+    it->el[10] = lf_col(C_TGT_LO); it->el[11] = lf_col(C_TGT_HI);
   }
-  g_cpu[1] = mem_inter(-1, is_real, lf_col(C_RS1), b_lo, b_hi, lf_col(C_R1_PTS));
-  g_cpu[2] = mem_inter(+1, is_real, lf_col(C_RS1), b_lo, b_hi, ts);
+  g_cpu[1] = mem_inter(-1, one, lf_col(C_RS1), b_lo, b_hi, lf_col(C_R1_PTS));
+  g_cpu[2] = mem_inter(+1, one, lf_col(C_RS1), b_lo, b_hi, ts);
   g_cpu[3] = mem_inter(-1, lf_col(C_USE2), lf_col(C_RS2), c_lo, c_hi, lf_col(C_R2_PTS));
   g_cpu[4] = mem_inter(+1, lf_col(C_USE2), lf_col(C_RS2), c_lo, c_hi, lf_plus(ts, 1));
   {
-    orc_lf memq, maddr;
-    lf_zero(&memq);
-    for (int k = OP_LB; k <= OP_SW; ++k) lf_add(&memq, C_OP + k - 1, 1);
-    lf_add(&memq, C_OP + OP_ECALL - 1, 1);
-    /* word address = (X as a value) - byte offset */
-    lf_zero(&maddr);
-    for (int i = 0; i < 16; ++i) lf_add(&maddr, C_X + i, 1u << i);
-    for (int i = 0; i < 15; ++i) lf_add(&maddr, C_X + 16 + i, (uint32_t)(((uint64_t)65536 << i) % FP));
-    /* bit 31 would exceed LF_MAX with the offsets; guest addresses stay below 0x78000000, so it is
-     * folded in as 2^31 mod p like the others */
-    lf_add(&maddr, C_X + 31, (uint32_t)(((uint64_t)1 << 31) % FP));
-    lf_add(&maddr, C_O1, FP - 1); lf_add(&maddr, C_O2, FP - 2); lf_add(&maddr, C_O3, FP - 3);
-    g_cpu[5] = mem_inter(-1, memq, maddr, m_lo, m_hi, lf_col(C_M_PTS));
-    g_cpu[6] = mem_inter(+1, memq, maddr, lf_col(C_MV_LO), lf_col(C_MV_HI), lf_plus(ts, 2));
-    /* the limbs of the four access-time differences are looked up when their access is live */
-    for (int j = 0; j < TS_LIMBS; ++j) {
-      g_cpu[13 + j] = range_inter(-1, is_real, lf_col(C_R1_D + j));
-      g_cpu[15 + j] = range_inter(-1, lf_col(C_USE2), lf_col(C_R2_D + j));
-      g_cpu[17 + j] = range_inter(-1, memq, lf_col(C_M_D + j));
-      g_cpu[19 + j] = range_inter(-1, lf_col(C_WR), lf_col(C_W_D + j));
-    }
+    const int memq_c[5] = {SELC(CL_LW), SELC(CL_SW), SELC(CL_LDS), SELC(CL_STS), SELC(CL_ECALL)};
+    const orc_lf memq = lf_sum(memq_c, 5);
+    g_cpu[5] = mem_inter(-1, memq, lf_col(C_MADDR), m_lo, m_hi, lf_col(C_M_PTS));
+    g_cpu[6] = mem_inter(+1, memq, lf_col(C_MADDR), lf_col(C_MV), lf_col(C_MV + 1), lf_plus(ts, 2));
   }
   g_cpu[7] = mem_inter(-1, lf_col(C_WR), lf_col(C_RD), lf_col(C_W_PLO), lf_col(C_W_PHI), lf_col(C_W_PTS));
   g_cpu[8] = mem_inter(+1, lf_col(C_WR), lf_col(C_RD), a_lo, a_hi, lf_plus(ts, 3));
+  /* access-time differences: every row looks up its four low limbs and the two pairs of high bytes (zero where the
+   * access is not live) */
+  for (int q = 0; q < 4; ++q) g_cpu[9 + q] = range_inter(-1, one, zero, lf_col(C_GAP + 2 * q));
+  g_cpu[13] = bytes_inter(-1, one, lf_col(C_GAP + 1), lf_col(C_GAP + 3));
+  g_cpu[14] = bytes_inter(-1, one, lf_col(C_GAP + 5), lf_col(C_GAP + 7));
   {
-    orc_inter* it = &g_cpu[9];
-    it->bus = BUS_KCALL; it->sign = +1; it->mult = lf_col(C_OP + OP_KECCAK - 1); it->n_el = 3;
-    it->el[0] = ts; it->el[1] = c_lo; it->el[2] = c_hi;
-    it = &g_cpu[10];
-    it->bus = BUS_MUL; it->sign = +1; it->n_el = 7;
-    lf_zero(&it->mult); lf_add(&it->mult, C_OP + OP_MUL - 1, 1); lf_add(&it->mult, C_OP + OP_MULHU - 1, 1);
-    it->el[0] = lf_col(C_OP + OP_MULHU - 1);
+    /* the adder output is canonical, an address is word-aligned once its byte offset is taken off, and addresses,
+     * jump targets and the keccak call's return address stay below 0x78000000 */
+    const int chk_c[10] = {SELC(CL_ADD), SELC(CL_SUB), SELC(CL_JALR), SELC(CL_LW), SELC(CL_SW), SELC(CL_LDS), SELC(CL_STS),
+                           SELC(CL_ECALL), SELC(CL_KECCAK), 0};
+    const int al_c[5] = {SELC(CL_JALR), SELC(CL_LW), SELC(CL_SW), SELC(CL_LDS), SELC(CL_STS)};
+    const int top_c[6] = {SELC(CL_JALR), SELC(CL_LW), SELC(CL_SW), SELC(CL_LDS), SELC(CL_STS), SELC(CL_KECCAK)};
+    const orc_lf chk = lf_sum(chk_c, 9);
+    orc_lf xoff = lf_col(C_X);
+    lf_add(&xoff, C_O1, FP - 1); lf_add(&xoff, C_O2, FP - 2); lf_add(&xoff, C_O3, FP - 3);
+    g_cpu[15] = range_inter(-1, chk, zero, lf_col(C_X + 1));
+    g_cpu[16] = range_inter(-1, chk, lf_sum(al_c, 5), xoff);
+    g_cpu[17] = range_inter(-1, lf_sum(top_c, 6), zero, lf_const_minus(ADDR_HI_MAX, C_X + 1));
+  }
+  {
+    orc_inter* it = &g_cpu[18];
+    memset(it, 0, sizeof *it);
+    const int alu_c[3] = {SELC(CL_ALU), SELC(CL_BLT), SELC(CL_BGE)};
+    it->bus = BUS_ALU; it->sign = +1; it->mult = lf_sum(alu_c, 3); it->n_el = 7;
+    it->el[0] = lf_col(C_CODE);
     it->el[1] = a_lo; it->el[2] = a_hi; it->el[3] = b_lo; it->el[4] = b_hi; it->el[5] = c_lo; it->el[6] = c_hi;
-    it = &g_cpu[11];
+    it = &g_cpu[19];
+    memset(it, 0, sizeof *it);
+    const int sub_c[2] = {SELC(CL_LDS), SELC(CL_STS)};
+    it->bus = BUS_SUB; it->sign = +1; it->mult = lf_sum(sub_c, 2); it->n_el = 9;
+    it->el[0] = lf_col(C_CODE);
+    lf_zero(&it->el[1]); lf_add(&it->el[1], C_O1, 1); lf_add(&it->el[1], C_O2, 2); lf_add(&it->el[1], C_O3, 3);
+    it->el[2] = a_lo; it->el[3] = a_hi; it->el[4] = m_lo; it->el[5] = m_hi; it->el[6] = c_lo;
+    it->el[7] = lf_col(C_MV); it->el[8] = lf_col(C_MV + 1);
+    it = &g_cpu[20];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_KCALL; it->sign = +1; it->mult = lf_col(SELC(CL_KECCAK)); it->n_el = 3;
+    it->el[0] = ts; it->el[1] = c_lo; it->el[2] = c_hi;
+    it = &g_cpu[21];
+    memset(it, 0, sizeof *it);
     it->bus = BUS_PUBC; it->sign = +1; it->n_el = 4;
-    lf_zero(&it->mult); lf_add(&it->mult, C_SC + SC_COMMIT, 1); lf_add(&it->mult, C_SC + SC_DEFER, 1);
-    lf_zero(&it->el[0]); lf_add(&it->el[0], C_SC + SC_COMMIT, 1); lf_add(&it->el[0], C_SC + SC_DEFER, 2);
+    it->mult = lf_pair(C_SC + SC_COMMIT, C_SC + SC_DEFER, 1);
+    it->el[0] = lf_pair(C_SC + SC_COMMIT, C_SC + SC_DEFER, 2);
     it->el[1] = c_lo; it->el[2] = m_lo; it->el[3] = m_hi;
-    it = &g_cpu[12];
+    it = &g_cpu[22];
+    memset(it, 0, sizeof *it);
     it->bus = BUS_PUBH; it->sign = +1; it->mult = lf_col(C_SC + SC_HALT); it->n_el = 2;
     it->el[0] = c_lo; it->el[1] = c_hi;
   }
-  /* keccak chip: on an export row, word i of the input and of the output state, i = 0..49 */
+  /* ---- keccak chip: on an export row, word i of the input and of the output state, i = 0..49 ---- */
   for (int i = 0; i < 50; ++i) {
     orc_inter* it = &g_keccak[i];
+    memset(it, 0, sizeof *it);
     const int lane = i >> 1, half = i & 1;
     const int out = lane == 0 ? KA_APPP00 + 2 * half : KA_APP + 4 * lane + 2 * half;
     it->bus = BUS_KIO; it->sign = +1; it->mult = lf_col(KA_EXPORT); it->n_el = 6;
@@ -139,47 +218,105 @@ static void build(void) {
     it->el[2] = lf_col(KA_PREIMAGE + 4 * lane + 2 * half); it->el[3] = lf_col(KA_PREIMAGE + 4 * lane + 2 * half + 1);
     it->el[4] = lf_col(out); it->el[5] = lf_col(out + 1);
   }
+  /* ---- keccak-memory ---- */
   {
     orc_inter* it = &g_kmem[0];
+    memset(it, 0, sizeof *it);
     it->bus = BUS_KCALL; it->sign = -1; it->mult = lf_col(KM_CALL); it->n_el = 3;
     it->el[0] = lf_col(KM_TS); it->el[1] = lf_col(KM_PTR_LO); it->el[2] = lf_col(KM_PTR_HI);
     it = &g_kmem[1];
+    memset(it, 0, sizeof *it);
     it->bus = BUS_KIO; it->sign = -1; it->mult = lf_col(KM_IS_REAL); it->n_el = 6;
     it->el[0] = lf_col(KM_TS); it->el[1] = lf_col(KM_IDX); it->el[2] = lf_col(KM_OLD_LO); it->el[3] = lf_col(KM_OLD_HI);
     it->el[4] = lf_col(KM_NEW_LO); it->el[5] = lf_col(KM_NEW_HI);
     g_kmem[2] = mem_inter(-1, lf_col(KM_IS_REAL), lf_col(KM_ADDR), lf_col(KM_OLD_LO), lf_col(KM_OLD_HI), lf_col(KM_PTS));
     g_kmem[3] = mem_inter(+1, lf_col(KM_IS_REAL), lf_col(KM_ADDR), lf_col(KM_NEW_LO), lf_col(KM_NEW_HI),
                           lf_plus(lf_col(KM_TS), 2));
-    for (int j = 0; j < TS_LIMBS; ++j) g_kmem[4 + j] = range_inter(-1, lf_col(KM_IS_REAL), lf_col(KM_D + j));
+    g_kmem[4] = range_inter(-1, lf_col(KM_IS_REAL), zero, lf_col(KM_GL));
+    g_kmem[5] = bytes_inter(-1, lf_col(KM_IS_REAL), lf_col(KM_GH), zero);
+    /* the state pointer is word-aligned and the 200 bytes end below 0x78000000 */
+    g_kmem[6] = range_inter(-1, lf_col(KM_CALL), one, lf_col(KM_PTR_LO));
+    g_kmem[7] = range_inter(-1, lf_col(KM_CALL), zero, lf_const_minus(ADDR_HI_MAX - 1, KM_PTR_HI));
   }
-  g_memfinal[0] = mem_inter(-1, lf_col(MF_IS_REAL), lf_col(MF_ADDR), lf_col(MF_FIN_LO), lf_col(MF_FIN_HI), lf_col(MF_FIN_TS));
-  g_memfinal[1] = mem_inter(+1, lf_col(MF_IS_INIT), lf_col(MF_ADDR), lf_limb(MF_INIT, 0), lf_limb(MF_INIT, 1), lf_const(0));
-  /* image / program: the row is [preprocessed | main] */
-  g_image[0] = mem_inter(+1, lf_col(IMAGE_PREP_WIDTH + 0), lf_col(IMG_P_ADDR), lf_col(IMG_P_LO), lf_col(IMG_P_HI), lf_const(0));
+  /* ---- memory boundary ---- */
   {
-    orc_inter* it = &g_program[0];
-    it->bus = BUS_PROG; it->sign = +1; it->mult = lf_col(PROGRAM_PREP_WIDTH + 0); it->n_el = 10;
-    for (int j = 0; j < 10; ++j) it->el[j] = lf_col(j);
+    const orc_lf real = lf_col(MF_IS_REAL), init = lf_col(MF_IS_INIT), addr = lf_pair(MF_LO, MF_HI, 65536);
+    g_memfinal[0] = mem_inter(-1, real, addr, lf_col(MF_FIN_LO), lf_col(MF_FIN_HI), lf_col(MF_FIN_TS));
+    g_memfinal[1] = mem_inter(+1, real, addr, lf_col(MF_INIT_LO), lf_col(MF_INIT_HI), zero);
+    orc_inter* it = &g_memfinal[2];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_IMG; it->sign = -1; it->mult = lf_pair(MF_IS_REAL, MF_IS_INIT, FP - 1); it->n_el = 3;
+    it->el[0] = addr; it->el[1] = lf_col(MF_INIT_LO); it->el[2] = lf_col(MF_INIT_HI);
+    g_memfinal[3] = range_inter(-1, real, zero, lf_col(MF_LO));
+    g_memfinal[4] = range_inter(-1, real, zero, lf_col(MF_HI));
+    g_memfinal[5] = range_inter(-1, real, zero, lf_const_minus(ADDR_HI_MAX, MF_HI));
+    g_memfinal[6] = range_inter(-1, real, zero, lf_col(MF_D_LO));
+    g_memfinal[7] = range_inter(-1, real, zero, lf_col(MF_D_HI));
+    g_memfinal[8] = range_inter(-1, init, zero, lf_col(MF_INIT_LO));
+    g_memfinal[9] = range_inter(-1, init, zero, lf_col(MF_INIT_HI));
   }
+  /* ---- image / program / table: the row is [preprocessed | main] ---- */
+  {
+    orc_inter* it = &g_image[0];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_IMG; it->sign = +1; it->mult = lf_col(IMAGE_PREP_WIDTH + 0); it->n_el = 3;
+    it->el[0] = lf_col(IMG_P_ADDR); it->el[1] = lf_col(IMG_P_LO); it->el[2] = lf_col(IMG_P_HI);
+    it = &g_program[0];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_PROG; it->sign = +1; it->mult = lf_col(PROGRAM_PREP_WIDTH + 0); it->n_el = 12;
+    for (int j = 0; j < 12; ++j) it->el[j] = lf_col(j);
+    const orc_lf idx = lf_pair(TB_P_X, TB_P_Y, 256);
+    g_table[0] = range_inter(+1, lf_col(TABLE_PREP_WIDTH + TB_M_R16), zero, idx);
+    g_table[1] = range_inter(+1, lf_col(TABLE_PREP_WIDTH + TB_M_AL), one, idx);
+    g_table[2] = bytes_inter(+1, lf_col(TABLE_PREP_WIDTH + TB_M_BY), lf_col(TB_P_X), lf_col(TB_P_Y));
+  }
+  /* ---- multiplier ---- */
   for (int hi = 0; hi < 2; ++hi) {
     orc_inter* it = &g_mul[hi];
-    it->bus = BUS_MUL; it->sign = -1; it->n_el = 7;
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_ALU; it->sign = -1; it->n_el = 7;
     if (hi) it->mult = lf_col(MU_HI);
-    else { lf_zero(&it->mult); lf_add(&it->mult, MU_IS_REAL, 1); lf_add(&it->mult, MU_HI, FP - 1); }
-    it->el[0] = lf_const((uint32_t)hi);
-    it->el[1] = lf_limb(MU_P, 2 * hi); it->el[2] = lf_limb(MU_P, 2 * hi + 1);
-    it->el[3] = lf_limb(MU_B, 0); it->el[4] = lf_limb(MU_B, 1); it->el[5] = lf_limb(MU_C, 0); it->el[6] = lf_limb(MU_C, 1);
+    else it->mult = lf_pair(MU_IS_REAL, MU_HI, FP - 1);
+    it->el[0] = lf_const(hi ? OP_MULHU : OP_MUL);
+    it->el[1] = lf_bits(MU_P + 32 * hi, 16); it->el[2] = lf_bits(MU_P + 32 * hi + 16, 16);
+    it->el[3] = lf_bits(MU_B, 16); it->el[4] = lf_bits(MU_B + 16, 16); it->el[5] = lf_bits(MU_C, 16); it->el[6] = lf_bits(MU_C + 16, 16);
   }
-  g_range[0] = range_inter(+1, lf_col(RANGE_PREP_WIDTH + 0), lf_col(0));
-  g_chips[CH_RANGE] = (orc_chip){"range", RANGE_PREP_WIDTH, RANGE_WIDTH, 1, g_range, 0};
-  g_chips[CH_CPU] = (orc_chip){"cpu", 0, CPU_WIDTH, 21, g_cpu, 0};
-  g_chips[CH_CPU2] = (orc_chip){"cpu2", 0, CPU_WIDTH, 21, g_cpu, 0};
+  /* ---- ALU ---- */
+  {
+    orc_inter* it = &g_alu[0];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_ALU; it->sign = -1; it->mult = lf_col(AL_IS_REAL); it->n_el = 7;
+    lf_zero(&it->el[0]);
+    for (int k = 0; k < 8; ++k) lf_add(&it->el[0], AL_SEL + k, (uint32_t)(OP_XOR + k));
+    it->el[1] = lf_col(AL_A); it->el[2] = lf_col(AL_A + 1);
+    it->el[3] = lf_bits(AL_B, 16); it->el[4] = lf_bits(AL_B + 16, 16); it->el[5] = lf_bits(AL_C, 16); it->el[6] = lf_bits(AL_C + 16, 16);
+  }
+  /* ---- sub-word ---- */
+  {
+    static const uint32_t codes[6] = {OP_LB, OP_LH, OP_LBU, OP_LHU, OP_SB, OP_SH};
+    orc_inter* it = &g_sub[0];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_SUB; it->sign = -1; it->mult = lf_col(SW_IS_REAL); it->n_el = 9;
+    lf_zero(&it->el[0]);
+    for (int k = 0; k < 6; ++k) lf_add(&it->el[0], SW_SEL + k, codes[k]);
+    lf_zero(&it->el[1]); lf_add(&it->el[1], SW_O + 1, 1); lf_add(&it->el[1], SW_O + 2, 2); lf_add(&it->el[1], SW_O + 3, 3);
+    it->el[2] = lf_col(SW_A); it->el[3] = lf_col(SW_A + 1);
+    it->el[4] = lf_bits(SW_M, 16); it->el[5] = lf_bits(SW_M + 16, 16); it->el[6] = lf_bits(SW_C, 16);
+    it->el[7] = lf_col(SW_MV); it->el[8] = lf_col(SW_MV + 1);
+  }
+  g_chips[CH_TABLE] = (orc_chip){"table", TABLE_PREP_WIDTH, TABLE_WIDTH, 3, g_table, 0};
+  g_chips[CH_CPU] = (orc_chip){"cpu", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0};
+  g_chips[CH_CPU2] = (orc_chip){"cpu2", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0};
   g_chips[CH_KECCAK] = (orc_chip){"keccak", 0, KECCAK_WIDTH, 50, g_keccak, 0};
-  g_chips[CH_KMEM] = (orc_chip){"keccak-mem", 0, KMEM_WIDTH, 6, g_kmem, 0};
-  g_chips[CH_MEMFINAL] = (orc_chip){"mem-final", 0, MEMFINAL_WIDTH, 2, g_memfinal, 0};
+  g_chips[CH_KMEM] = (orc_chip){"keccak-mem", 0, KMEM_WIDTH, 8, g_kmem, 0};
+  g_chips[CH_MEMFINAL] = (orc_chip){"mem-final", 0, MEMFINAL_WIDTH, 10, g_memfinal, 0};
   g_chips[CH_IMAGE] = (orc_chip){"image", IMAGE_PREP_WIDTH, IMAGE_WIDTH, 1, g_image, 0};
   g_chips[CH_PROGRAM] = (orc_chip){"program", PROGRAM_PREP_WIDTH, PROGRAM_WIDTH, 1, g_program, 0};
   g_chips[CH_MUL] = (orc_chip){"mul", 0, MUL_WIDTH, 2, g_mul, 0};
+  g_chips[CH_ALU] = (orc_chip){"alu", 0, ALU_WIDTH, 1, g_alu, 0};
+  g_chips[CH_ALU2] = (orc_chip){"alu2", 0, ALU_WIDTH, 1, g_alu, 0};
+  g_chips[CH_SUB] = (orc_chip){"subword", 0, SUB_WIDTH, 1, g_sub, 0};
+  g_chips[CH_SUB2] = (orc_chip){"subword2", 0, SUB_WIDTH, 1, g_sub, 0};
   g_ready = 1;
   for (int c = 0; c < N_CHIPS; ++c) g_chips[c].n_constraints = count_constraints(c);
 }
@@ -190,7 +327,7 @@ const orc_chip* orc_machine_chip(int chip) {
 }
 
 /* ------------------------------------------------------------------------------------------
- * heights and trace generation
+ * heights, event lists
  * ---------------------------------------------------------------------------------------- */
 static int clog2(size_t v) {
   int l = 0;
@@ -199,16 +336,43 @@ static int clog2(size_t v) {
 }
 static int at_least5(int l) { return l < 5 ? 5 : l; }
 
-/* rows of the first CPU instance: the largest power of two strictly below the cycle count (at least 32) */
-static size_t cpu_split(size_t n_cycles) {
+/* rows of the first of two instances: the largest power of two strictly below the count (at least 32) */
+static size_t split_rows(size_t n) {
   size_t h0 = 32;
-  while (2 * h0 < n_cycles) h0 *= 2;
+  while (2 * h0 < n) h0 *= 2;
   return h0;
 }
+static int second_logh(size_t n) {
+  const size_t h0 = split_rows(n);
+  return at_least5(clog2(n > h0 ? n - h0 : 1));
+}
+static const uint32_t* prog_row(const orc_machine_input* in, uint32_t pc) { return in->program + 9 * (size_t)((pc - in->text_base) >> 2); }
+
+size_t orc_machine_events(const orc_machine_input* in, int which, uint32_t* out) {
+  size_t n = 0;
+  for (size_t g = 0; g < in->n_cycles; ++g)
+    if (event_kind(prog_row(in, in->cycles[12 * g])[1]) == which) {
+      if (out) out[n] = (uint32_t)g;
+      ++n;
+    }
+  return n;
+}
+uint32_t orc_machine_x0_last(const orc_machine_input* in) {
+  for (size_t g = in->n_cycles; g-- > 0;) {
+    const uint32_t* p = prog_row(in, in->cycles[12 * g]);
+    const uint32_t ts = 4 * ((uint32_t)g + 1);
+    if (p[3] && p[6] == 0) return ts + 1; /* rs2 = x0 is read after rs1 */
+    if (p[5] == 0) return ts;
+  }
+  return 0;
+}
+static uint32_t pad_pc_of(const orc_machine_input* in) { return in->text_base + 4 * (uint32_t)(in->n_program - 1); }
 
 void orc_machine_cpu_pub(const orc_machine_input* in, int chip, uint32_t pub[CPUPUB_N]) {
-  const size_t h0 = cpu_split(in->n_cycles);
-  const uint32_t handover = h0 < in->n_cycles ? in->cycles[12 * h0] : 0;
+  const size_t h0 = split_rows(in->n_cycles);
+  const uint32_t pad = pad_pc_of(in);
+  const uint32_t handover = h0 < in->n_cycles ? in->cycles[12 * h0] : pad;
+  pub[CPUPUB_PAD_PC] = pad;
   if (chip == CH_CPU) {
     pub[CPUPUB_START_PC] = in->entry; pub[CPUPUB_START_TS] = 4; pub[CPUPUB_HAS_SUCC] = 1; pub[CPUPUB_END_PC] = handover;
   } else {
@@ -217,127 +381,231 @@ void orc_machine_cpu_pub(const orc_machine_input* in, int chip, uint32_t pub[CPU
 }
 
 void orc_machine_heights(const orc_machine_input* in, int logh[N_CHIPS]) {
-  const size_t h0 = cpu_split(in->n_cycles);
-  logh[CH_CPU] = clog2(h0);
-  logh[CH_CPU2] = at_least5(clog2(in->n_cycles > h0 ? in->n_cycles - h0 : 1));
+  const size_t na = orc_machine_events(in, 0, NULL), ns = orc_machine_events(in, 1, NULL);
+  logh[CH_CPU] = clog2(split_rows(in->n_cycles));
+  logh[CH_CPU2] = second_logh(in->n_cycles);
+  logh[CH_ALU] = clog2(split_rows(na));
+  logh[CH_ALU2] = second_logh(na);
+  logh[CH_SUB] = clog2(split_rows(ns));
+  logh[CH_SUB2] = second_logh(ns);
   logh[CH_KECCAK] = at_least5(clog2(24 * in->n_keccak));
   logh[CH_KMEM] = at_least5(clog2(50 * in->n_keccak));
   logh[CH_MEMFINAL] = at_least5(clog2(in->n_memfinal));
   logh[CH_IMAGE] = in->log_image;
   logh[CH_PROGRAM] = in->log_prog;
   logh[CH_MUL] = at_least5(clog2(in->n_muls));
-  logh[CH_RANGE] = RANGE_LOG_H;
+  logh[CH_TABLE] = TABLE_LOG_H;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * trace generation
+ * ---------------------------------------------------------------------------------------- */
 static void put_bits(uint32_t* t, size_t h, size_t r, int col, uint32_t v, int n) {
   for (int i = 0; i < n; ++i) t[(size_t)(col + i) * h + r] = (v >> i) & 1u;
+}
+static void put_limbs(uint32_t* t, size_t h, size_t r, int col, uint32_t v) {
+  t[(size_t)col * h + r] = v & 0xffff;
+  t[(size_t)(col + 1) * h + r] = v >> 16;
 }
 
 typedef struct { uint32_t ts, ptr; uint64_t in[25]; uint32_t pts[50]; } kcall_t;
 
-/* an access-time difference as its two limbs */
-static void put_gap(uint32_t* t, size_t h, size_t r, int col, uint32_t gap) {
-  t[(size_t)col * h + r] = gap & ((1u << TS_LIMB_BITS) - 1);
-  t[(size_t)(col + 1) * h + r] = gap >> TS_LIMB_BITS;
-}
-/* the four differences of one cycle (0 where the access is not live), as fill_cpu writes them */
-static void cycle_gaps(const orc_machine_input* in, size_t r, uint32_t gap[4], int live[4]) {
-  const uint32_t* cy = in->cycles + 12 * r;
-  const uint32_t* p = in->program + 9 * (size_t)((cy[0] - in->text_base) >> 2);
-  const uint32_t op = p[1], ts = 4 * ((uint32_t)r + 1);
-  live[0] = 1; gap[0] = ts - cy[7] - 1;
-  live[1] = p[3] != 0; gap[1] = ts - cy[8];
-  live[2] = (op >= OP_LB && op <= OP_SW) || op == OP_ECALL; gap[2] = ts + 1 - cy[9];
-  live[3] = p[2] != 0; gap[3] = ts + 2 - cy[10];
-}
+/* the flag a branch / set-less-than leaves: signed or unsigned b < c */
+static uint32_t less_than(uint32_t code, uint32_t b, uint32_t c) { return code == OP_SLT ? ((int32_t)b < (int32_t)c) : (b < c); }
 
-/* rows [0, h) of the instance whose first row is cycle `row0` */
+/* rows [0, h) of the instance whose first row is cycle `row0`; rows past the last cycle run the padding instruction */
 static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t, size_t row0) {
+  const uint32_t pad_pc = pad_pc_of(in), x0_last = orc_machine_x0_last(in);
 #pragma omp parallel for schedule(static)
   for (size_t r = 0; r < h; ++r) {
 #define T(col) t[(size_t)(col) * h + r]
     const size_t g = row0 + r;  /* cycle index */
     const uint32_t ts = 4 * ((uint32_t)g + 1);
     T(C_TS) = ts;
-    if (g >= in->n_cycles) continue;
-    const uint32_t* cy = in->cycles + 12 * g;
-    const uint32_t pc = cy[0], a = cy[1], b = cy[2], c = cy[3], m = cy[4], mv = cy[5], wprev = cy[6];
-    const uint32_t* p = in->program + 9 * (size_t)((pc - in->text_base) >> 2);
-    const uint32_t op = p[1], wr = p[2], use2 = p[3], rd = p[4], rs1 = p[5], rs2 = p[6], imm = p[7], tgt = p[8];
-    T(C_IS_REAL) = 1; T(C_PC) = pc;
-    T(C_OP + op - 1) = 1;
-    T(C_WR) = wr; T(C_USE2) = use2; T(C_RD) = rd; T(C_RS1) = rs1; T(C_RS2) = rs2;
-    T(C_IMM_LO) = imm & 0xffff; T(C_IMM_HI) = imm >> 16; T(C_TGT) = tgt;
-    T(C_A) = a & 0xffff; T(C_A + 1) = a >> 16; put_bits(t, h, r, C_B, b, 32); put_bits(t, h, r, C_C, c, 32); put_bits(t, h, r, C_M, m, 32);
-    T(C_MV_LO) = mv & 0xffff; T(C_MV_HI) = mv >> 16;
-    uint32_t x = 0, next = pc + 4;
-    const uint32_t blo = b & 0xffff, bhi = b >> 16, clo = c & 0xffff, chi = c >> 16, alo = a & 0xffff, ahi = a >> 16;
-    switch (op) {
-      case OP_ADD: {
-        uint32_t k0 = (blo + clo) >> 16;
-        const uint32_t k1 = (bhi + chi + k0) >> 16;
-        T(C_K0) = k0; T(C_K1) = k1;
-        /* soundness tests: ZKSP_ORACLE_NONCANON=<row> makes that addition claim the other carry, i.e. write the
-         * same sum with limbs out of range.  The row's constraints still hold; nothing can read the value back. */
-        const char* nc = getenv("ZKSP_ORACLE_NONCANON");
-        if (nc && r == (size_t)strtoull(nc, NULL, 10)) {
-          k0 ^= 1u;
-          T(C_K0) = k0;
-          T(C_A) = f_sub(f_add(blo, clo), k0 ? 65536u : 0u);
-          T(C_A + 1) = f_sub(f_add(f_add(bhi, chi), k0), k1 ? 65536u : 0u);
+    uint32_t gap[4] = {0, 0, 0, 0};
+    if (g >= in->n_cycles) {
+      /* jal x0, 0 at the padding pc: reads x0 (rs1 = 0), writes nothing, jumps to itself */
+      const uint32_t pts = g == in->n_cycles ? x0_last : ts - 4;
+      T(C_PC) = pad_pc; T(C_NEXT_PC) = pad_pc; T(SELC(CL_JAL)) = 1;
+      put_limbs(t, h, r, C_TGT_LO, pad_pc);
+      T(C_R1_PTS) = pts;
+      gap[0] = ts - pts - 1;
+    } else {
+      const uint32_t* cy = in->cycles + 12 * g;
+      const uint32_t pc = cy[0], b = cy[2], c = cy[3], m = cy[4], mv = cy[5], wprev = cy[6];
+      uint32_t a = cy[1];
+      const uint32_t* p = prog_row(in, pc);
+      const uint32_t op = p[1], wr = p[2], use2 = p[3], rd = p[4], rs1 = p[5], rs2 = p[6], imm = p[7], tgt = p[8];
+      const int cls = orc_class_of(op);
+      const uint32_t code = orc_code_of(op);
+      T(C_PC) = pc;
+      T(SELC(cls)) = 1;
+      T(C_CODE) = code; T(C_WR) = wr; T(C_USE2) = use2; T(C_RD) = rd; T(C_RS1) = rs1; T(C_RS2) = rs2;
+      put_limbs(t, h, r, C_IMM_LO, imm); put_limbs(t, h, r, C_TGT_LO, tgt);
+      uint32_t x = 0, next = pc + 4, k0 = 0, k1 = 0, maddr = 0;
+      int off = -1;
+      const uint32_t blo = b & 0xffff, bhi = b >> 16, clo = c & 0xffff, chi = c >> 16;
+      switch (cls) {
+        case CL_ADD: x = a; k0 = (blo + clo) >> 16; k1 = (bhi + chi + k0) >> 16; break;
+        case CL_SUB: x = a; k0 = ((a & 0xffff) + clo) >> 16; k1 = ((a >> 16) + chi + k0) >> 16; break;
+        case CL_JAL: next = tgt; break;
+        case CL_JALR: case CL_LW: case CL_LDS:
+          x = b + c; k0 = (blo + clo) >> 16; k1 = (bhi + chi + k0) >> 16;
+          if (cls == CL_JALR) { off = (int)(x & 1); next = x & ~1u; }
+          else { off = (int)(x & 3); maddr = x & ~3u; }
+          break;
+        case CL_SW: case CL_STS:
+          x = b + imm; k0 = (blo + (imm & 0xffff)) >> 16; k1 = (bhi + (imm >> 16) + k0) >> 16;
+          off = (int)(x & 3); maddr = x & ~3u;
+          break;
+        case CL_BEQ: case CL_BNE: {
+          k0 = blo == clo; k1 = bhi == chi;
+          T(C_X) = k0 ? 0 : f_inv(f_sub(blo, clo));
+          T(C_X + 1) = k1 ? 0 : f_inv(f_sub(bhi, chi));
+          a = k0 & k1;
+          if ((cls == CL_BEQ) == (a != 0)) next = tgt;
+          break;
         }
-        break;
+        case CL_BLT: case CL_BGE:
+          a = less_than(code, b, c);
+          if ((cls == CL_BLT) == (a != 0)) next = tgt;
+          break;
+        case CL_ECALL: {
+          static const uint32_t codes[6] = {0x00, 0x02, 0x10, 0x1a, 0xf0, 0xf1};
+          for (int k = 0; k < 6; ++k) if (b == codes[k]) T(C_SC + k) = 1;
+          x = a; maddr = 11;
+          if (b == 0x00) next = pad_pc;
+          break;
+        }
+        case CL_KECCAK: x = b; next = b; break;
+        default: break;
       }
-      case OP_SUB: { uint32_t k0 = (alo + clo) >> 16; T(C_K0) = k0; T(C_K1) = (ahi + chi + k0) >> 16; break; }
-      case OP_SLL: case OP_SRL: case OP_SRA: x = 1u << (c & 31); break;
-      case OP_SLT: case OP_SLTU: case OP_BEQ: case OP_BNE: case OP_BLT: case OP_BGE: case OP_BLTU: case OP_BGEU: {
-        const int sgn = (op == OP_SLT || op == OP_BLT || op == OP_BGE);
-        const uint32_t k0 = blo < clo;
-        const uint32_t dlo = blo - clo + 65536 * k0;
-        const uint32_t lt = sgn ? ((int32_t)b < (int32_t)c) : (b < c);
-        const int64_t dhi = (int64_t)bhi - chi - k0 + 65536 * (int64_t)lt + (sgn ? 65536 * ((int64_t)(c >> 31) - (int64_t)(b >> 31)) : 0);
-        x = dlo | ((uint32_t)dhi << 16);
-        T(C_K0) = k0; T(C_K1) = lt;
-        if (op == OP_BEQ || op == OP_BNE) {
-          const uint32_t z = dlo + (uint32_t)dhi;
-          T(C_EQ) = z == 0; T(C_INV) = z ? f_inv(z) : 0;
-          if ((op == OP_BEQ) == (z == 0)) next = tgt;
-        } else if (op == OP_BLT || op == OP_BLTU) { if (lt) next = tgt; }
-        else if (op == OP_BGE || op == OP_BGEU) { if (!lt) next = tgt; }
-        break;
+      if (cls != CL_BEQ && cls != CL_BNE) put_limbs(t, h, r, C_X, x);
+      put_limbs(t, h, r, C_A, a); put_limbs(t, h, r, C_B, b); put_limbs(t, h, r, C_C, c);
+      put_limbs(t, h, r, C_M, m); put_limbs(t, h, r, C_MV, mv);
+      T(C_K0) = k0; T(C_K1) = k1;
+      if (off >= 0) T(C_O0 + off) = 1;
+      T(C_MADDR) = maddr;
+      T(C_NEXT_PC) = next;
+      const int memq = cls == CL_LW || cls == CL_SW || cls == CL_LDS || cls == CL_STS || cls == CL_ECALL;
+      T(C_R1_PTS) = cy[7]; gap[0] = ts - cy[7] - 1;
+      if (use2) { T(C_R2_PTS) = cy[8]; gap[1] = ts - cy[8]; }
+      if (memq) { T(C_M_PTS) = cy[9]; gap[2] = ts + 1 - cy[9]; }
+      if (wr) { T(C_W_PTS) = cy[10]; gap[3] = ts + 2 - cy[10]; T(C_W_PLO) = wprev & 0xffff; T(C_W_PHI) = wprev >> 16; }
+      /* soundness tests: ZKSP_ORACLE_NONCANON=<row> makes that addition claim the other carry, i.e. write the same
+       * sum with limbs out of range.  The adder constraints still hold; the range lookup cannot. */
+      const char* nc = getenv("ZKSP_ORACLE_NONCANON");
+      if (nc && cls == CL_ADD && r == (size_t)strtoull(nc, NULL, 10)) {
+        k0 ^= 1u;
+        T(C_K0) = k0;
+        T(C_X) = f_sub(f_add(blo, clo), k0 ? 65536u : 0u);
+        T(C_X + 1) = f_sub(f_add(f_add(bhi, chi), k0), k1 ? 65536u : 0u);
+        T(C_A) = T(C_X); T(C_A + 1) = T(C_X + 1);
       }
-      case OP_JAL: next = tgt; break;
-      case OP_JALR: case OP_LB: case OP_LH: case OP_LW: case OP_LBU: case OP_LHU: case OP_SB: case OP_SH: case OP_SW: {
-        const uint32_t ilo = imm & 0xffff, ihi = imm >> 16;
-        const uint32_t k2 = (blo + ilo) >> 16;
-        T(C_K2) = k2; T(C_K3) = (bhi + ihi + k2) >> 16;
-        x = b + imm;
-        if (op == OP_JALR) next = x & ~1u;
-        else T(C_O0 + (x & 3)) = 1;
-        break;
-      }
-      case OP_ECALL: {
-        x = 11; T(C_O0) = 1;
-        static const uint32_t codes[6] = {0x00, 0x02, 0x10, 0x1a, 0xf0, 0xf1};
-        for (int k = 0; k < 6; ++k) if (b == codes[k]) T(C_SC + k) = 1;
-        break;
-      }
-      case OP_KECCAK: next = b; break;
-      default: break;
     }
-    put_bits(t, h, r, C_X, x, 32);
-    T(C_NEXT_PC) = next;
-    uint32_t gap[4];
-    int live[4];
-    cycle_gaps(in, g, gap, live);
-    T(C_R1_PTS) = cy[7]; put_gap(t, h, r, C_R1_D, gap[0]);
-    if (live[1]) { T(C_R2_PTS) = cy[8]; put_gap(t, h, r, C_R2_D, gap[1]); }
-    if (live[2]) { T(C_M_PTS) = cy[9]; put_gap(t, h, r, C_M_D, gap[2]); }
-    if (live[3]) {
-      T(C_W_PTS) = cy[10]; put_gap(t, h, r, C_W_D, gap[3]);
-      T(C_W_PLO) = wprev & 0xffff; T(C_W_PHI) = wprev >> 16;
-    }
+    for (int q = 0; q < 4; ++q) { T(C_GAP + 2 * q) = gap[q] & 0xffff; T(C_GAP + 2 * q + 1) = gap[q] >> 16; }
 #undef T
+  }
+}
+
+/* rows [0, h) of an ALU / sub-word instance whose first row is event `row0` */
+static void fill_alu(const orc_machine_input* in, size_t h, uint32_t* t, size_t row0) {
+  const size_t n = orc_machine_events(in, 0, NULL);
+  uint32_t* ev = (uint32_t*)malloc((n ? n : 1) * 4);
+  orc_machine_events(in, 0, ev);
+  for (size_t r = 0; r < h && row0 + r < n; ++r) {
+#define T(col) t[(size_t)(col) * h + r]
+    const uint32_t* cy = in->cycles + 12 * (size_t)ev[row0 + r];
+    const uint32_t code = orc_code_of(prog_row(in, cy[0])[1]), b = cy[2], c = cy[3];
+    uint32_t a = cy[1], x = 0, k0 = 0, k1 = 0;
+    if (code == OP_SLL || code == OP_SRL || code == OP_SRA) x = 1u << (c & 31);
+    if (code == OP_SLT || code == OP_SLTU) {
+      /* X = B - C + 2^32 * [less than], the sign bits swapped for the signed order */
+      const uint32_t blo = b & 0xffff, bhi = b >> 16, clo = c & 0xffff, chi = c >> 16;
+      const int sgn = code == OP_SLT;
+      k0 = blo < clo;
+      k1 = less_than(code, b, c);
+      const uint32_t dlo = blo - clo + 65536 * k0;
+      const int64_t dhi = (int64_t)bhi - chi - k0 + 65536 * (int64_t)k1 + (sgn ? 65536 * ((int64_t)(c >> 31) - (int64_t)(b >> 31)) : 0);
+      x = dlo | ((uint32_t)dhi << 16);
+      a = k1; /* branches: the record's a is 0, the flag is what the CPU row sends */
+    }
+    T(AL_IS_REAL) = 1;
+    T(AL_SEL + (code - OP_XOR)) = 1;
+    put_limbs(t, h, r, AL_A, a);
+    put_bits(t, h, r, AL_B, b, 32); put_bits(t, h, r, AL_C, c, 32); put_bits(t, h, r, AL_X, x, 32);
+    T(AL_K0) = k0; T(AL_K1) = k1;
+    const char* wa = getenv("ZKSP_ORACLE_WRONG_ALU");
+    if (wa && row0 + r == (size_t)strtoull(wa, NULL, 10)) T(AL_A) = (a & 0xffff) ^ 1u; /* soundness tests: a wrong result */
+#undef T
+  }
+  free(ev);
+}
+static int sub_sel(uint32_t code) {
+  return code == OP_LB ? 0 : code == OP_LH ? 1 : code == OP_LBU ? 2 : code == OP_LHU ? 3 : code == OP_SB ? 4 : 5;
+}
+static void fill_sub(const orc_machine_input* in, size_t h, uint32_t* t, size_t row0) {
+  const size_t n = orc_machine_events(in, 1, NULL);
+  uint32_t* ev = (uint32_t*)malloc((n ? n : 1) * 4);
+  orc_machine_events(in, 1, ev);
+  for (size_t r = 0; r < h && row0 + r < n; ++r) {
+#define T(col) t[(size_t)(col) * h + r]
+    const uint32_t* cy = in->cycles + 12 * (size_t)ev[row0 + r];
+    const uint32_t* p = prog_row(in, cy[0]);
+    const uint32_t code = p[1], a = cy[1], b = cy[2], c = cy[3], m = cy[4], mv = cy[5];
+    const int store = code == OP_SB || code == OP_SH;
+    const uint32_t off = (b + p[7]) & 3; /* loads: c is the immediate as well */
+    T(SW_IS_REAL) = 1;
+    T(SW_SEL + sub_sel(code)) = 1;
+    T(SW_O + off) = 1;
+    put_limbs(t, h, r, SW_A, store ? 0 : a);
+    put_bits(t, h, r, SW_M, m, 32);
+    put_bits(t, h, r, SW_C, c & 0xffff, 16);
+    put_limbs(t, h, r, SW_MV, mv);
+#undef T
+  }
+  free(ev);
+}
+
+/* multiplicities of the table chip: whatever the other chips' rows look up (their receives on the RANGE and BYTES
+ * buses, evaluated on their own traces, so that by construction the buses balance when every value is in range) */
+static void fill_table_mults(const orc_machine_input* in, uint32_t* t) {
+  const size_t ht = (size_t)1 << TABLE_LOG_H;
+  int logh[N_CHIPS];
+  orc_machine_heights(in, logh);
+  static const int users[4] = {CH_CPU, CH_CPU2, CH_KMEM, CH_MEMFINAL};
+  for (int u = 0; u < 4; ++u) {
+    const int chip = users[u];
+    const orc_chip* ch = &g_chips[chip];
+    const size_t h = (size_t)1 << logh[chip];
+    uint32_t* tr = (uint32_t*)malloc((size_t)ch->main_width * h * 4);
+    orc_machine_fill(in, chip, logh[chip], NULL, tr);
+    uint32_t* row = (uint32_t*)malloc((size_t)ch->main_width * 4);
+    for (size_t r = 0; r < h; ++r) {
+      for (int c = 0; c < ch->main_width; ++c) row[c] = tr[(size_t)c * h + r];
+      for (int k = 0; k < ch->n_inter; ++k) {
+        const orc_inter* it = &ch->inter[k];
+        if (it->sign > 0 || (it->bus != BUS_RANGE && it->bus != BUS_BYTES)) continue;
+        uint32_t v[3];
+        const orc_lf* f[3] = {&it->mult, &it->el[0], &it->el[1]};
+        for (int j = 0; j < 3; ++j) {
+          v[j] = f[j]->c0;
+          for (int i = 0; i < f[j]->n; ++i) v[j] = f_add(v[j], f_mul(f[j]->coef[i], row[f[j]->col[i]]));
+        }
+        if (v[0] == 0) continue;
+        if (it->bus == BUS_RANGE) {
+          if (v[2] >= ht || v[1] > 1 || (v[1] == 1 && (v[2] & 3))) continue; /* no table row: the buses will not balance */
+          uint32_t* dst = &t[(size_t)(v[1] ? TB_M_AL : TB_M_R16) * ht + v[2]];
+          *dst = f_add(*dst, v[0]);
+        } else {
+          if (v[1] > 255 || v[2] > 255) continue;
+          uint32_t* dst = &t[(size_t)TB_M_BY * ht + v[1] + 256 * v[2]];
+          *dst = f_add(*dst, v[0]);
+        }
+      }
+    }
+    free(row);
+    free(tr);
   }
 }
 
@@ -350,7 +618,11 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
 #define T(col) t[(size_t)(col) * h + r]
   switch (chip) {
     case CH_CPU: fill_cpu(in, h, t, 0); break;
-    case CH_CPU2: fill_cpu(in, h, t, cpu_split(in->n_cycles)); break;
+    case CH_CPU2: fill_cpu(in, h, t, split_rows(in->n_cycles)); break;
+    case CH_ALU: fill_alu(in, h, t, 0); break;
+    case CH_ALU2: fill_alu(in, h, t, split_rows(orc_machine_events(in, 0, NULL))); break;
+    case CH_SUB: fill_sub(in, h, t, 0); break;
+    case CH_SUB2: fill_sub(in, h, t, split_rows(orc_machine_events(in, 1, NULL))); break;
     case CH_KECCAK: {
       uint64_t* st = (uint64_t*)calloc(25 * (in->n_keccak ? in->n_keccak : 1), 8);
       for (size_t p = 0; p < in->n_keccak; ++p) memcpy(st + 25 * p, ((const kcall_t*)(in->keccak + 408 * p))->in, 200);
@@ -374,33 +646,55 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
         T(KM_CALL) = i == 0; T(KM_ADDR) = k->ptr + 4 * (uint32_t)i;
         T(KM_OLD_LO) = wi & 0xffff; T(KM_OLD_HI) = wi >> 16; T(KM_NEW_LO) = wo & 0xffff; T(KM_NEW_HI) = wo >> 16;
         T(KM_PTS) = k->pts[i];
-        put_gap(t, h, r, KM_D, k->ts + 1 - k->pts[i]);
+        const uint32_t gap = k->ts + 1 - k->pts[i];
+        T(KM_GL) = gap & 0xffff; T(KM_GH) = gap >> 16;
       }
       break;
-    case CH_MEMFINAL:
+    case CH_MEMFINAL: {
+      /* soundness tests: ZKSP_ORACLE_MF_WRAP=<row> claims the difference to the next row's address that only holds
+       * mod p when that address does not increase (DIFF = p - 1 for a repeated address, as limbs) */
+      const char* wrap = getenv("ZKSP_ORACLE_MF_WRAP");
       for (size_t r = 0; r < in->n_memfinal; ++r) {
         const uint32_t* f = in->memfinal + 5 * r;
-        T(MF_IS_REAL) = 1; T(MF_ADDR) = f[0]; T(MF_IS_INIT) = f[4];
+        T(MF_IS_REAL) = 1; T(MF_LO) = f[0] & 0xffff; T(MF_HI) = f[0] >> 16; T(MF_IS_INIT) = f[4];
+        T(MF_INIT_LO) = f[1] & 0xffff; T(MF_INIT_HI) = f[1] >> 16;
         T(MF_FIN_LO) = f[2] & 0xffff; T(MF_FIN_HI) = f[2] >> 16; T(MF_FIN_TS) = f[3];
-        if (r + 1 < in->n_memfinal) put_bits(t, h, r, MF_DIFF, in->memfinal[5 * (r + 1)] - f[0] - 1, 32);
-        if (f[4]) put_bits(t, h, r, MF_INIT, f[1], 32);
+        if (r + 1 < in->n_memfinal) {
+          const uint32_t nx = in->memfinal[5 * (r + 1)];
+          const uint32_t bw = (nx & 0xffff) < (f[0] & 0xffff) + 1;
+          T(MF_BW) = bw;
+          T(MF_D_LO) = (nx & 0xffff) + 65536 * bw - (f[0] & 0xffff) - 1;
+          T(MF_D_HI) = f_sub(f_sub(nx >> 16, f[0] >> 16), bw);
+          if (wrap && r == (size_t)strtoull(wrap, NULL, 10)) {
+            const uint32_t d = f_sub(f_sub(nx % FP, f[0] % FP), 1); /* the difference mod p */
+            T(MF_BW) = 0; T(MF_D_LO) = d & 0xffff; T(MF_D_HI) = d >> 16;
+          }
+        }
       }
       break;
-    case CH_IMAGE:
+    }
+    case CH_IMAGE: {
+      /* soundness tests: ZKSP_ORACLE_IMG_UNUSED=<row> withholds that image word from the IMG bus (the v5 attack: the
+       * word is then free-initialised by the memory-boundary chip); the chip's constraint USED = is_real forbids it */
+      const char* unused = getenv("ZKSP_ORACLE_IMG_UNUSED");
       for (size_t r = 0; r < in->n_image; ++r) {
         prep[(size_t)IMG_P_ADDR * h + r] = in->image[2 * r];
         prep[(size_t)IMG_P_LO * h + r] = in->image[2 * r + 1] & 0xffff;
         prep[(size_t)IMG_P_HI * h + r] = in->image[2 * r + 1] >> 16;
-        if (in->image_used) T(0) = in->image_used[r];
+        prep[(size_t)IMG_P_REAL * h + r] = 1;
+        T(0) = !(unused && r == (size_t)strtoull(unused, NULL, 10));
       }
       break;
+    }
     case CH_PROGRAM:
       for (size_t r = 0; r < in->n_program; ++r) {
         const uint32_t* p = in->program + 9 * r;
         uint32_t* q = prep + r;
-        q[(size_t)PR_PC * h] = p[0]; q[(size_t)PR_OP * h] = p[1]; q[(size_t)PR_WR * h] = p[2]; q[(size_t)PR_USE2 * h] = p[3];
+        q[(size_t)PR_PC * h] = p[0]; q[(size_t)PR_CLS * h] = (uint32_t)orc_class_of(p[1]); q[(size_t)PR_CODE * h] = orc_code_of(p[1]);
+        q[(size_t)PR_WR * h] = p[2]; q[(size_t)PR_USE2 * h] = p[3];
         q[(size_t)PR_RD * h] = p[4]; q[(size_t)PR_RS1 * h] = p[5]; q[(size_t)PR_RS2 * h] = p[6];
-        q[(size_t)PR_IMM_LO * h] = p[7] & 0xffff; q[(size_t)PR_IMM_HI * h] = p[7] >> 16; q[(size_t)PR_TGT * h] = p[8];
+        q[(size_t)PR_IMM_LO * h] = p[7] & 0xffff; q[(size_t)PR_IMM_HI * h] = p[7] >> 16;
+        q[(size_t)PR_TGT_LO * h] = p[8] & 0xffff; q[(size_t)PR_TGT_HI * h] = p[8] >> 16;
         if (in->prog_mult) T(0) = in->prog_mult[r] % FP;
       }
       break;
@@ -419,26 +713,14 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
         put_bits(t, h, r, MU_Q0, (uint32_t)q0, 10); put_bits(t, h, r, MU_Q1, (uint32_t)q1, 11); put_bits(t, h, r, MU_Q2, (uint32_t)q2, 10);
       }
       break;
-    case CH_RANGE: {
-      const uint32_t mask = (1u << TS_LIMB_BITS) - 1;
-      for (size_t r = 0; r < h; ++r) prep[r] = (uint32_t)r;
-      /* multiplicity of a value = the live limbs equal to it, over the CPU and keccak-memory chips */
-      for (size_t r = 0; r < in->n_cycles; ++r) {
-        uint32_t gap[4];
-        int live[4];
-        cycle_gaps(in, r, gap, live);
-        for (int q = 0; q < 4; ++q)
-          if (live[q] && (gap[q] >> TS_LIMB_BITS) <= mask) { t[gap[q] & mask]++; t[gap[q] >> TS_LIMB_BITS]++; }
+    case CH_TABLE:
+      for (size_t r = 0; r < h; ++r) {
+        prep[(size_t)TB_P_X * h + r] = (uint32_t)(r & 255);
+        prep[(size_t)TB_P_Y * h + r] = (uint32_t)(r >> 8);
+        prep[(size_t)TB_P_NA * h + r] = (r & 3) != 0;
       }
-      for (size_t p = 0; p < in->n_keccak; ++p) {
-        const kcall_t* k = (const kcall_t*)(in->keccak + 408 * p);
-        for (int i = 0; i < 50; ++i) {
-          const uint32_t gap = k->ts + 1 - k->pts[i];
-          if ((gap >> TS_LIMB_BITS) <= mask) { t[gap & mask]++; t[gap >> TS_LIMB_BITS]++; }
-        }
-      }
+      if (in->n_cycles) fill_table_mults(in, t); /* setup passes no cycles: only the preprocessed columns are wanted */
       break;
-    }
   }
 #undef T
 }
@@ -467,214 +749,132 @@ static inline fe bits_val(const uint32_t* row, int bits, int n) {
   for (int i = n - 1; i >= 0; --i) s = f_add(f_add(s, s), row[bits + i]);
   return s;
 }
-/* an access-time difference from its two range-checked limbs */
-static inline fe gap_val(const uint32_t* row, int col) { return f_add(row[col], f_mul(1u << TS_LIMB_BITS, row[col + 1])); }
 #define F65536 65536u
+static inline fe word_of(const uint32_t* row, int col) { return f_add(row[col], f_mul(F65536, row[col + 1])); }
 
 static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe is_last, fe is_trans, const uint32_t* pub,
                             sink* s) {
   const fe one = 1;
-  /* ---- booleans ---- */
-  emit(s, bool_c(l[C_IS_REAL]));
-  for (int k = 0; k < N_OPS; ++k) emit(s, bool_c(l[C_OP + k]));
-  emit(s, bool_c(l[C_WR]));
-  emit(s, bool_c(l[C_USE2]));
-  for (int i = 0; i < 128; ++i) emit(s, bool_c(l[C_B + i])); /* B, C, M, X */
-  for (int i = 0; i < 4; ++i) emit(s, bool_c(l[C_K0 + i]));
-  emit(s, bool_c(l[C_EQ]));
+#define S(cls) l[SELC(cls)]
+  /* ---- booleans: class selectors, carries, byte offset, syscall flags (WR, USE2 are Program-table values) ---- */
+  fe selsum = 0;
+  for (int k = 0; k < N_CLS; ++k) { emit(s, bool_c(l[C_SEL + k])); selsum = f_add(selsum, l[C_SEL + k]); }
+  emit(s, bool_c(l[C_K0])); emit(s, bool_c(l[C_K1]));
   for (int i = 0; i < 4; ++i) emit(s, bool_c(l[C_O0 + i]));
-  for (int i = 0; i < 6; ++i) emit(s, bool_c(l[C_SC + i]));
-  /* ---- row structure ---- */
-#define OPF(k) l[C_OP + (k) - 1]
-  const fe is_real = l[C_IS_REAL];
-  fe opsum = 0;
-  for (int k = 0; k < N_OPS; ++k) opsum = f_add(opsum, l[C_OP + k]);
-  emit(s, f_sub(opsum, is_real));
-  emit(s, f_mul(l[C_WR], f_sub(one, is_real)));
-  emit(s, f_mul(l[C_USE2], f_sub(one, is_real)));
-  emit(s, f_mul(is_first, f_sub(is_real, one)));
+  fe scsum = 0;
+  for (int i = 0; i < 6; ++i) { emit(s, bool_c(l[C_SC + i])); scsum = f_add(scsum, l[C_SC + i]); }
+  /* ---- row structure: exactly one class; the clock; the chain of pcs; the instance's first and last rows ---- */
+  emit(s, f_sub(selsum, one));
+  emit(s, f_sub(scsum, S(CL_ECALL)));
   emit(s, f_mul(is_first, f_sub(l[C_PC], pub[CPUPUB_START_PC] % FP)));
   emit(s, f_mul(is_first, f_sub(l[C_TS], pub[CPUPUB_START_TS] % FP)));
   emit(s, f_mul(is_trans, f_sub(f_sub(n[C_TS], l[C_TS]), 4)));
-  emit(s, f_mul(f_mul(is_trans, n[C_IS_REAL]), f_sub(n[C_PC], l[C_NEXT_PC])));
-  emit(s, f_mul(is_trans, f_add(f_sub(n[C_IS_REAL], is_real), l[C_SC + SC_HALT])));
-  fe scsum = 0;
-  for (int k = 0; k < 6; ++k) scsum = f_add(scsum, l[C_SC + k]);
-  emit(s, f_sub(scsum, OPF(OP_ECALL)));
-  /* ---- limbs ---- */
-  const fe a_lo = l[C_A], a_hi = l[C_A + 1], b_lo = limb_of(l, C_B, 0), b_hi = limb_of(l, C_B, 1);
-  const fe c_lo = limb_of(l, C_C, 0), c_hi = limb_of(l, C_C, 1), m_lo = limb_of(l, C_M, 0), m_hi = limb_of(l, C_M, 1);
-  const fe x_lo = limb_of(l, C_X, 0), x_hi = limb_of(l, C_X, 1);
-  const fe k0 = l[C_K0], k1 = l[C_K1], k2 = l[C_K2], k3 = l[C_K3];
-  /* ---- operand C is the immediate ---- */
-  const fe immc = f_sub(is_real, l[C_USE2]);
-  emit(s, f_mul(immc, f_sub(c_lo, l[C_IMM_LO])));
-  emit(s, f_mul(immc, f_sub(c_hi, l[C_IMM_HI])));
-  /* ---- add / sub ---- */
-  emit(s, f_mul(OPF(OP_ADD), f_sub(f_add(b_lo, c_lo), f_add(a_lo, f_mul(F65536, k0)))));
-  emit(s, f_mul(OPF(OP_ADD), f_sub(f_add(f_add(b_hi, c_hi), k0), f_add(a_hi, f_mul(F65536, k1)))));
-  emit(s, f_mul(OPF(OP_SUB), f_sub(f_add(a_lo, c_lo), f_add(b_lo, f_mul(F65536, k0)))));
-  emit(s, f_mul(OPF(OP_SUB), f_sub(f_add(f_add(a_hi, c_hi), k0), f_add(b_hi, f_mul(F65536, k1)))));
-  /* ---- bitwise ---- */
-  for (int op = OP_XOR; op <= OP_AND; ++op)
-    for (int h = 0; h < 2; ++h) {
-      fe acc = 0;
-      for (int i = 15; i >= 0; --i) {
-        const fe b = l[C_B + 16 * h + i], c = l[C_C + 16 * h + i], bc = f_mul(b, c);
-        fe bit = op == OP_AND ? bc : op == OP_OR ? f_sub(f_add(b, c), bc) : f_sub(f_add(b, c), f_add(bc, bc));
-        acc = f_add(f_add(acc, acc), bit);
-      }
-      emit(s, f_mul(OPF(op), f_sub(h ? a_hi : a_lo, acc)));
-    }
-  /* ---- shifts: X is the one-hot of the amount ---- */
+  emit(s, f_mul(is_trans, f_sub(n[C_PC], l[C_NEXT_PC])));
   {
-    const fe sh = f_add(f_add(OPF(OP_SLL), OPF(OP_SRL)), OPF(OP_SRA));
-    fe sum = 0, idx = 0;
-    for (int k = 0; k < 32; ++k) { sum = f_add(sum, l[C_X + k]); idx = f_add(idx, f_mul((fe)k, l[C_X + k])); }
-    emit(s, f_mul(sh, f_sub(sum, one)));
-    emit(s, f_mul(sh, f_sub(idx, bits_val(l, C_C, 5))));
-    for (int kind = 0; kind < 3; ++kind) {
-      fe t[32];
-      for (int j = 0; j < 32; ++j) {
-        fe acc = 0;
-        for (int k = 0; k < 32; ++k) {
-          int src;
-          if (kind == 0) { if (k > j) continue; src = j - k; }
-          else if (kind == 1) { if (j + k > 31) continue; src = j + k; }
-          else src = j + k > 31 ? 31 : j + k;
-          acc = f_add(acc, f_mul(l[C_X + k], l[C_B + src]));
-        }
-        t[j] = acc;
-      }
-      const fe sel = OPF(kind == 0 ? OP_SLL : kind == 1 ? OP_SRL : OP_SRA);
-      for (int h = 0; h < 2; ++h) {
-        fe acc = 0;
-        for (int i = 15; i >= 0; --i) acc = f_add(f_add(acc, acc), t[16 * h + i]);
-        emit(s, f_mul(sel, f_sub(h ? a_hi : a_lo, acc)));
-      }
-    }
+    const fe succ = pub[CPUPUB_HAS_SUCC] % FP;
+    emit(s, f_mul(f_mul(is_last, succ), f_sub(l[C_NEXT_PC], pub[CPUPUB_END_PC] % FP)));
+    emit(s, f_mul(f_mul(is_last, f_sub(one, succ)), f_sub(l[C_NEXT_PC], pub[CPUPUB_PAD_PC] % FP)));
   }
-  /* ---- comparisons: X = B - C (mod 2^32, the sign bits flipped for signed orders), K1 = "less than" ---- */
+  const fe a_lo = l[C_A], a_hi = l[C_A + 1], b_lo = l[C_B], b_hi = l[C_B + 1], c_lo = l[C_C], c_hi = l[C_C + 1];
+  const fe m_lo = l[C_M], m_hi = l[C_M + 1], mv_lo = l[C_MV], mv_hi = l[C_MV + 1], x_lo = l[C_X], x_hi = l[C_X + 1];
+  const fe k0 = l[C_K0], k1 = l[C_K1], imm_lo = l[C_IMM_LO], imm_hi = l[C_IMM_HI];
+  /* ---- operand C is the immediate ---- */
   {
-    fe cmp = 0, sgn = f_add(f_add(OPF(OP_SLT), OPF(OP_BLT)), OPF(OP_BGE));
-    const int ops[8] = {OP_SLT, OP_SLTU, OP_BEQ, OP_BNE, OP_BLT, OP_BGE, OP_BLTU, OP_BGEU};
-    for (int i = 0; i < 8; ++i) cmp = f_add(cmp, OPF(ops[i]));
-    emit(s, f_mul(cmp, f_sub(f_add(f_sub(b_lo, c_lo), f_mul(F65536, k0)), x_lo)));
-    emit(s, f_add(f_mul(cmp, f_sub(f_add(f_sub(f_sub(b_hi, c_hi), k0), f_mul(F65536, k1)), x_hi)),
-                  f_mul(F65536, f_mul(sgn, f_sub(l[C_C + 31], l[C_B + 31])))));
-    const fe bq = f_add(OPF(OP_BEQ), OPF(OP_BNE)), z = f_add(x_lo, x_hi);
-    emit(s, f_mul(bq, f_add(f_sub(f_mul(z, l[C_INV]), one), l[C_EQ])));
-    emit(s, f_mul(bq, f_mul(z, l[C_EQ])));
-    const fe slt = f_add(OPF(OP_SLT), OPF(OP_SLTU));
-    emit(s, f_mul(slt, f_sub(a_lo, k1)));
-    emit(s, f_mul(slt, a_hi));
+    const fe immc = f_sub(one, l[C_USE2]);
+    emit(s, f_mul(immc, f_sub(c_lo, imm_lo)));
+    emit(s, f_mul(immc, f_sub(c_hi, imm_hi)));
+  }
+  /* ---- the adder: X = B + C (add, jalr, lw, sub-word loads), X = B + imm (stores), X + C = B (sub) ---- */
+  {
+    const fe addc = f_add(f_add(S(CL_ADD), S(CL_JALR)), f_add(S(CL_LW), S(CL_LDS))), addi = f_add(S(CL_SW), S(CL_STS));
+    emit(s, f_mul(addc, f_sub(f_add(b_lo, c_lo), f_add(x_lo, f_mul(F65536, k0)))));
+    emit(s, f_mul(addc, f_sub(f_add(f_add(b_hi, c_hi), k0), f_add(x_hi, f_mul(F65536, k1)))));
+    emit(s, f_mul(addi, f_sub(f_add(b_lo, imm_lo), f_add(x_lo, f_mul(F65536, k0)))));
+    emit(s, f_mul(addi, f_sub(f_add(f_add(b_hi, imm_hi), k0), f_add(x_hi, f_mul(F65536, k1)))));
+    emit(s, f_mul(S(CL_SUB), f_sub(f_add(x_lo, c_lo), f_add(b_lo, f_mul(F65536, k0)))));
+    emit(s, f_mul(S(CL_SUB), f_sub(f_add(f_add(x_hi, c_hi), k0), f_add(b_hi, f_mul(F65536, k1)))));
+    /* what the range lookups check is X: the sum / difference written (add, sub), the value an ecall leaves in t0
+     * (HINT_LEN: prover-supplied), the return address of a keccak call */
+    const fe cpa = f_add(f_add(S(CL_ADD), S(CL_SUB)), S(CL_ECALL));
+    emit(s, f_mul(cpa, f_sub(a_lo, x_lo)));
+    emit(s, f_mul(cpa, f_sub(a_hi, x_hi)));
+    emit(s, f_mul(S(CL_KECCAK), f_sub(x_lo, b_lo)));
+    emit(s, f_mul(S(CL_KECCAK), f_sub(x_hi, b_hi)));
+  }
+  /* ---- byte offset and the word address ---- */
+  const fe o0 = l[C_O0], o1 = l[C_O1], o2 = l[C_O2], o3 = l[C_O3];
+  const fe off = f_add(o1, f_add(f_add(o2, o2), f_mul(3, o3)));
+  const fe xaddr = f_sub(f_add(x_lo, f_mul(F65536, x_hi)), off);
+  {
+    const fe noff = f_add(f_add(f_add(S(CL_ADD), S(CL_SUB)), f_add(S(CL_ECALL), S(CL_KECCAK))), f_add(S(CL_LW), S(CL_SW)));
+    const fe memw = f_add(f_add(S(CL_LW), S(CL_SW)), f_add(S(CL_LDS), S(CL_STS)));
+    emit(s, f_mul(noff, f_add(o1, f_add(o2, o3))));
+    emit(s, f_mul(f_add(memw, S(CL_JALR)), f_sub(f_add(f_add(o0, o1), f_add(o2, o3)), one)));
+    emit(s, f_mul(S(CL_JALR), f_add(o2, o3)));
+    emit(s, f_mul(memw, f_sub(l[C_MADDR], xaddr)));
+    emit(s, f_mul(S(CL_ECALL), f_sub(l[C_MADDR], 11)));
   }
   /* ---- next pc ---- */
   {
-    const fe pc4 = f_add(l[C_PC], 4), np = l[C_NEXT_PC], tgt = l[C_TGT];
-    fe def = is_real;
-    const int nd[9] = {OP_JAL, OP_JALR, OP_BEQ, OP_BNE, OP_BLT, OP_BGE, OP_BLTU, OP_BGEU, OP_KECCAK};
-    for (int i = 0; i < 9; ++i) def = f_sub(def, OPF(nd[i]));
+    const fe pc4 = f_add(l[C_PC], 4), np = l[C_NEXT_PC], tgt = word_of(l, C_TGT_LO);
+    fe def = one;
+    const int nd[9] = {CL_JAL, CL_JALR, CL_BEQ, CL_BNE, CL_BLT, CL_BGE, CL_KECCAK, CL_ECALL, 0};
+    for (int i = 0; i < 8; ++i) def = f_sub(def, S(nd[i]));
     emit(s, f_mul(def, f_sub(np, pc4)));
-    emit(s, f_mul(OPF(OP_JAL), f_sub(np, tgt)));
-    emit(s, f_mul(OPF(OP_JAL), f_sub(a_lo, c_lo)));
-    emit(s, f_mul(OPF(OP_JAL), f_sub(a_hi, c_hi)));
-    emit(s, f_mul(OPF(OP_JALR), f_sub(f_add(a_lo, f_mul(F65536, a_hi)), tgt)));
-    emit(s, f_mul(OPF(OP_JALR), f_sub(np, f_sub(f_add(x_lo, f_mul(F65536, x_hi)), l[C_X]))));
-    const fe eq = l[C_EQ];
-    /* taken -> tgt, else pc + 4:  np - pc4 - taken * (tgt - pc4) */
+    emit(s, f_mul(S(CL_JAL), f_sub(np, tgt)));
+    emit(s, f_mul(S(CL_JAL), f_sub(a_lo, c_lo)));
+    emit(s, f_mul(S(CL_JAL), f_sub(a_hi, c_hi)));
+    emit(s, f_mul(S(CL_JALR), f_sub(a_lo, l[C_TGT_LO])));
+    emit(s, f_mul(S(CL_JALR), f_sub(a_hi, l[C_TGT_HI])));
+    emit(s, f_mul(S(CL_JALR), f_sub(np, xaddr)));
+    /* beq / bne: a limb difference is zero or has the inverse X holds; the flag is "both limbs equal" */
+    const fe bq = f_add(S(CL_BEQ), S(CL_BNE)), d_lo = f_sub(b_lo, c_lo), d_hi = f_sub(b_hi, c_hi);
+    emit(s, f_mul(bq, f_add(f_sub(f_mul(d_lo, x_lo), one), k0)));
+    emit(s, f_mul(bq, f_mul(d_lo, k0)));
+    emit(s, f_mul(bq, f_add(f_sub(f_mul(d_hi, x_hi), one), k1)));
+    emit(s, f_mul(bq, f_mul(d_hi, k1)));
+    emit(s, f_mul(bq, f_sub(a_lo, f_mul(k0, k1))));
+    const fe brs = f_add(bq, f_add(S(CL_BLT), S(CL_BGE)));
+    emit(s, f_mul(brs, a_hi));
+    /* taken -> tgt, else pc + 4 */
     const fe d = f_sub(tgt, pc4), base = f_sub(np, pc4);
-    emit(s, f_mul(OPF(OP_BEQ), f_sub(base, f_mul(eq, d))));
-    emit(s, f_mul(OPF(OP_BNE), f_sub(base, f_mul(f_sub(one, eq), d))));
-    emit(s, f_mul(OPF(OP_BLT), f_sub(base, f_mul(k1, d))));
-    emit(s, f_mul(OPF(OP_BGE), f_sub(base, f_mul(f_sub(one, k1), d))));
-    emit(s, f_mul(OPF(OP_BLTU), f_sub(base, f_mul(k1, d))));
-    emit(s, f_mul(OPF(OP_BGEU), f_sub(base, f_mul(f_sub(one, k1), d))));
-    emit(s, f_mul(OPF(OP_KECCAK), f_sub(np, f_add(b_lo, f_mul(F65536, b_hi)))));
+    emit(s, f_mul(f_add(S(CL_BEQ), S(CL_BLT)), f_sub(base, f_mul(a_lo, d))));
+    emit(s, f_mul(f_add(S(CL_BNE), S(CL_BGE)), f_sub(base, f_mul(f_sub(one, a_lo), d))));
+    emit(s, f_mul(S(CL_KECCAK), f_sub(np, f_add(b_lo, f_mul(F65536, b_hi)))));
+    /* ecall: the next instruction, except that HALT goes to the padding instruction */
+    emit(s, f_sub(f_mul(S(CL_ECALL), f_sub(np, pc4)), f_mul(l[C_SC + SC_HALT], f_sub(pub[CPUPUB_PAD_PC] % FP, pc4))));
   }
-  /* ---- address adder: X = B + imm ---- */
-  fe loads = 0, stores = 0;
-  for (int k = OP_LB; k <= OP_LHU; ++k) loads = f_add(loads, OPF(k));
-  for (int k = OP_SB; k <= OP_SW; ++k) stores = f_add(stores, OPF(k));
+  /* ---- word loads and stores; what the memory slot leaves behind ---- */
   {
-    const fe ad = f_add(f_add(loads, stores), OPF(OP_JALR));
-    emit(s, f_mul(ad, f_sub(f_add(b_lo, l[C_IMM_LO]), f_add(x_lo, f_mul(F65536, k2)))));
-    emit(s, f_mul(ad, f_sub(f_add(f_add(b_hi, l[C_IMM_HI]), k2), f_add(x_hi, f_mul(F65536, k3)))));
+    emit(s, f_mul(S(CL_LW), f_sub(a_lo, m_lo)));
+    emit(s, f_mul(S(CL_LW), f_sub(a_hi, m_hi)));
+    const fe keep = f_add(f_add(S(CL_LW), S(CL_LDS)), S(CL_ECALL));
+    emit(s, f_mul(keep, f_sub(mv_lo, m_lo)));
+    emit(s, f_mul(keep, f_sub(mv_hi, m_hi)));
+    emit(s, f_mul(S(CL_SW), f_sub(mv_lo, c_lo)));
+    emit(s, f_mul(S(CL_SW), f_sub(mv_hi, c_hi)));
   }
-  /* ---- byte offset one-hot ---- */
-  const fe o0 = l[C_O0], o1 = l[C_O1], o2 = l[C_O2], o3 = l[C_O3];
-  {
-    const fe ls = f_add(loads, stores);
-    emit(s, f_mul(ls, f_sub(f_add(f_add(o0, o1), f_add(o2, o3)), one)));
-    emit(s, f_mul(ls, f_sub(f_add(f_add(o1, f_add(o2, o2)), f_mul(3, o3)), f_add(l[C_X], f_add(l[C_X + 1], l[C_X + 1])))));
-    emit(s, f_mul(OPF(OP_ECALL), f_sub(o0, one)));
-    emit(s, f_mul(OPF(OP_ECALL), f_add(f_add(o1, o2), o3)));
-    emit(s, f_mul(OPF(OP_ECALL), f_sub(x_lo, 11)));
-    emit(s, f_mul(OPF(OP_ECALL), x_hi));
-  }
-  /* ---- loads ---- */
-  {
-    const fe mb[4] = {byte_of(l, C_M, 0), byte_of(l, C_M, 1), byte_of(l, C_M, 2), byte_of(l, C_M, 3)};
-    emit(s, f_mul(OPF(OP_LW), f_sub(o0, one)));
-    emit(s, f_mul(OPF(OP_LW), f_sub(a_lo, m_lo)));
-    emit(s, f_mul(OPF(OP_LW), f_sub(a_hi, m_hi)));
-    const fe hv = f_add(f_mul(o0, m_lo), f_mul(o2, m_hi)), hs = f_add(f_mul(o0, l[C_M + 15]), f_mul(o2, l[C_M + 31]));
-    emit(s, f_mul(OPF(OP_LHU), f_add(o1, o3)));
-    emit(s, f_mul(OPF(OP_LHU), f_sub(a_lo, hv)));
-    emit(s, f_mul(OPF(OP_LHU), a_hi));
-    emit(s, f_mul(OPF(OP_LH), f_add(o1, o3)));
-    emit(s, f_mul(OPF(OP_LH), f_sub(a_lo, hv)));
-    emit(s, f_mul(OPF(OP_LH), f_sub(a_hi, f_mul(65535, hs))));
-    fe bv = 0, bs = 0;
-    for (int p = 0; p < 4; ++p) { bv = f_add(bv, f_mul(l[C_O0 + p], mb[p])); bs = f_add(bs, f_mul(l[C_O0 + p], l[C_M + 8 * p + 7])); }
-    emit(s, f_mul(OPF(OP_LBU), f_sub(a_lo, bv)));
-    emit(s, f_mul(OPF(OP_LBU), a_hi));
-    emit(s, f_mul(OPF(OP_LB), f_sub(a_lo, f_add(bv, f_mul(0xff00, bs)))));
-    emit(s, f_mul(OPF(OP_LB), f_sub(a_hi, f_mul(65535, bs))));
-    const fe keep = f_add(loads, OPF(OP_ECALL));
-    emit(s, f_mul(keep, f_sub(l[C_MV_LO], m_lo)));
-    emit(s, f_mul(keep, f_sub(l[C_MV_HI], m_hi)));
-    /* ---- stores ---- */
-    emit(s, f_mul(OPF(OP_SW), f_sub(o0, one)));
-    emit(s, f_mul(OPF(OP_SW), f_sub(l[C_MV_LO], c_lo)));
-    emit(s, f_mul(OPF(OP_SW), f_sub(l[C_MV_HI], c_hi)));
-    emit(s, f_mul(OPF(OP_SH), f_add(o1, o3)));
-    emit(s, f_mul(OPF(OP_SH), f_sub(f_sub(l[C_MV_LO], m_lo), f_mul(o0, f_sub(c_lo, m_lo)))));
-    emit(s, f_mul(OPF(OP_SH), f_sub(f_sub(l[C_MV_HI], m_hi), f_mul(o2, f_sub(c_lo, m_hi)))));
-    const fe cb = byte_of(l, C_C, 0);
-    emit(s, f_mul(OPF(OP_SB), f_sub(f_sub(l[C_MV_LO], m_lo),
-                                    f_add(f_mul(o0, f_sub(cb, mb[0])), f_mul(256, f_mul(o1, f_sub(cb, mb[1])))))));
-    emit(s, f_mul(OPF(OP_SB), f_sub(f_sub(l[C_MV_HI], m_hi),
-                                    f_add(f_mul(o2, f_sub(cb, mb[2])), f_mul(256, f_mul(o3, f_sub(cb, mb[3])))))));
-  }
-  /* ---- ecall ---- */
+  /* ---- ecall: t0 holds one of the six codes and is rewritten with itself, except by HINT_LEN ---- */
   {
     static const uint32_t codes[6] = {0x00, 0x02, 0x10, 0x1a, 0xf0, 0xf1};
     fe code = 0;
     for (int k = 0; k < 6; ++k) code = f_add(code, f_mul(codes[k], l[C_SC + k]));
-    emit(s, f_mul(OPF(OP_ECALL), f_sub(b_lo, code)));
-    emit(s, f_mul(OPF(OP_ECALL), b_hi));
-    const fe same = f_sub(OPF(OP_ECALL), l[C_SC + SC_HINT_LEN]);
+    emit(s, f_mul(S(CL_ECALL), f_sub(b_lo, code)));
+    emit(s, f_mul(S(CL_ECALL), b_hi));
+    const fe same = f_sub(S(CL_ECALL), l[C_SC + SC_HINT_LEN]);
     emit(s, f_mul(same, f_sub(a_lo, b_lo)));
     emit(s, f_mul(same, f_sub(a_hi, b_hi)));
   }
-  /* ---- previous access times are older ---- */
+  /* ---- previous access times are older: difference = low limb + 2^16 * high byte ---- */
   {
-    fe memq = f_add(f_add(loads, stores), OPF(OP_ECALL));
+    const fe memq = f_add(f_add(f_add(S(CL_LW), S(CL_SW)), f_add(S(CL_LDS), S(CL_STS))), S(CL_ECALL));
     const fe ts = l[C_TS];
-    emit(s, f_mul(is_real, f_sub(f_sub(f_sub(ts, l[C_R1_PTS]), one), gap_val(l, C_R1_D))));
-    emit(s, f_mul(l[C_USE2], f_sub(f_sub(ts, l[C_R2_PTS]), gap_val(l, C_R2_D))));
-    emit(s, f_mul(memq, f_sub(f_sub(f_add(ts, one), l[C_M_PTS]), gap_val(l, C_M_D))));
-    emit(s, f_mul(l[C_WR], f_sub(f_sub(f_add(ts, 2), l[C_W_PTS]), gap_val(l, C_W_D))));
+    emit(s, f_sub(f_sub(f_sub(ts, l[C_R1_PTS]), one), word_of(l, C_GAP)));
+    emit(s, f_mul(l[C_USE2], f_sub(f_sub(ts, l[C_R2_PTS]), word_of(l, C_GAP + 2))));
+    emit(s, f_mul(memq, f_sub(f_sub(f_add(ts, one), l[C_M_PTS]), word_of(l, C_GAP + 4))));
+    emit(s, f_mul(l[C_WR], f_sub(f_sub(f_add(ts, 2), l[C_W_PTS]), word_of(l, C_GAP + 6))));
   }
-  /* ---- hand-over to the next instance: its last row is a real row that does not halt, and names the pc the next
-   * instance starts at ---- */
-  {
-    const fe succ = f_mul(is_last, pub[CPUPUB_HAS_SUCC] % FP);
-    emit(s, f_mul(succ, f_add(f_sub(one, is_real), l[C_SC + SC_HALT])));
-    emit(s, f_mul(succ, f_sub(l[C_NEXT_PC], pub[CPUPUB_END_PC] % FP)));
-  }
-#undef OPF
+#undef S
 }
 
 static void kmem_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe is_trans, sink* s) {
@@ -693,20 +893,19 @@ static void kmem_constraints(const uint32_t* l, const uint32_t* n, fe is_first, 
   emit(s, f_mul(f_mul(is_trans, nl), f_sub(n[KM_PTR_LO], l[KM_PTR_LO])));
   emit(s, f_mul(f_mul(is_trans, nl), f_sub(n[KM_PTR_HI], l[KM_PTR_HI])));
   emit(s, f_mul(l[KM_IS_REAL], f_sub(l[KM_ADDR], f_add(f_add(l[KM_PTR_LO], f_mul(F65536, l[KM_PTR_HI])), f_mul(4, l[KM_IDX])))));
-  emit(s, f_mul(l[KM_IS_REAL], f_sub(f_sub(f_add(l[KM_TS], one), l[KM_PTS]), gap_val(l, KM_D))));
+  emit(s, f_mul(l[KM_IS_REAL], f_sub(f_sub(f_add(l[KM_TS], one), l[KM_PTS]), f_add(l[KM_GL], f_mul(F65536, l[KM_GH])))));
 }
 
 static void memfinal_constraints(const uint32_t* l, const uint32_t* n, fe is_trans, sink* s) {
   const fe one = 1;
-  emit(s, bool_c(l[MF_IS_REAL])); emit(s, bool_c(l[MF_IS_INIT]));
-  for (int i = 0; i < 64; ++i) emit(s, bool_c(l[MF_DIFF + i])); /* DIFF, INIT */
+  emit(s, bool_c(l[MF_IS_REAL])); emit(s, bool_c(l[MF_IS_INIT])); emit(s, bool_c(l[MF_BW]));
   emit(s, f_mul(l[MF_IS_INIT], f_sub(one, l[MF_IS_REAL])));
   const fe tn = f_mul(is_trans, n[MF_IS_REAL]);
   emit(s, f_mul(tn, f_sub(one, l[MF_IS_REAL])));
-  /* 32-bit difference as a field element: addresses stay below 0x78000000 < p */
-  fe diff = 0;
-  for (int i = 31; i >= 0; --i) diff = f_add(f_add(diff, diff), l[MF_DIFF + i]);
-  emit(s, f_mul(tn, f_sub(f_sub(f_sub(n[MF_ADDR], l[MF_ADDR]), one), diff)));
+  /* next address - address - 1 = D >= 0, limb by limb with a borrow: every term stays far below p, so this is a
+   * statement about integers (all six limbs are looked up in the range table) */
+  emit(s, f_mul(tn, f_sub(f_add(f_sub(f_sub(n[MF_LO], l[MF_LO]), one), f_mul(F65536, l[MF_BW])), l[MF_D_LO])));
+  emit(s, f_mul(tn, f_sub(f_sub(f_sub(n[MF_HI], l[MF_HI]), l[MF_BW]), l[MF_D_HI])));
 }
 
 static void mul_constraints(const uint32_t* l, sink* s) {
@@ -724,10 +923,114 @@ static void mul_constraints(const uint32_t* l, sink* s) {
   emit(s, f_sub(f_add(sk[6], q2), limb_of(l, MU_P, 3)));
 }
 
+/* ALU chip: operands as bits; X is the one-hot shift amount or the comparison difference */
+static void alu_constraints(const uint32_t* l, sink* s) {
+  const fe one = 1;
+#define OPF(op) l[AL_SEL + (op) - OP_XOR]
+  emit(s, bool_c(l[AL_IS_REAL]));
+  fe selsum = 0;
+  for (int k = 0; k < 8; ++k) { emit(s, bool_c(l[AL_SEL + k])); selsum = f_add(selsum, l[AL_SEL + k]); }
+  for (int i = 0; i < 96; ++i) emit(s, bool_c(l[AL_B + i])); /* B, C, X */
+  emit(s, bool_c(l[AL_K0])); emit(s, bool_c(l[AL_K1]));
+  emit(s, f_sub(selsum, l[AL_IS_REAL]));
+  const fe a_lo = l[AL_A], a_hi = l[AL_A + 1], b_lo = limb_of(l, AL_B, 0), b_hi = limb_of(l, AL_B, 1);
+  const fe c_lo = limb_of(l, AL_C, 0), c_hi = limb_of(l, AL_C, 1), x_lo = limb_of(l, AL_X, 0), x_hi = limb_of(l, AL_X, 1);
+  /* ---- bitwise ---- */
+  for (int op = OP_XOR; op <= OP_AND; ++op)
+    for (int h = 0; h < 2; ++h) {
+      fe acc = 0;
+      for (int i = 15; i >= 0; --i) {
+        const fe b = l[AL_B + 16 * h + i], c = l[AL_C + 16 * h + i], bc = f_mul(b, c);
+        fe bit = op == OP_AND ? bc : op == OP_OR ? f_sub(f_add(b, c), bc) : f_sub(f_add(b, c), f_add(bc, bc));
+        acc = f_add(f_add(acc, acc), bit);
+      }
+      emit(s, f_mul(OPF(op), f_sub(h ? a_hi : a_lo, acc)));
+    }
+  /* ---- shifts: X is the one-hot of the amount ---- */
+  {
+    const fe sh = f_add(f_add(OPF(OP_SLL), OPF(OP_SRL)), OPF(OP_SRA));
+    fe sum = 0, idx = 0;
+    for (int k = 0; k < 32; ++k) { sum = f_add(sum, l[AL_X + k]); idx = f_add(idx, f_mul((fe)k, l[AL_X + k])); }
+    emit(s, f_mul(sh, f_sub(sum, one)));
+    emit(s, f_mul(sh, f_sub(idx, bits_val(l, AL_C, 5))));
+    for (int kind = 0; kind < 3; ++kind) {
+      fe t[32];
+      for (int j = 0; j < 32; ++j) {
+        fe acc = 0;
+        for (int k = 0; k < 32; ++k) {
+          int src;
+          if (kind == 0) { if (k > j) continue; src = j - k; }
+          else if (kind == 1) { if (j + k > 31) continue; src = j + k; }
+          else src = j + k > 31 ? 31 : j + k;
+          acc = f_add(acc, f_mul(l[AL_X + k], l[AL_B + src]));
+        }
+        t[j] = acc;
+      }
+      const fe sel = OPF(kind == 0 ? OP_SLL : kind == 1 ? OP_SRL : OP_SRA);
+      for (int h = 0; h < 2; ++h) {
+        fe acc = 0;
+        for (int i = 15; i >= 0; --i) acc = f_add(f_add(acc, acc), t[16 * h + i]);
+        emit(s, f_mul(sel, f_sub(h ? a_hi : a_lo, acc)));
+      }
+    }
+  }
+  /* ---- less-than: X = B - C (mod 2^32, the sign bits swapped for the signed order), K1 = "less than" ---- */
+  {
+    const fe cmp = f_add(OPF(OP_SLT), OPF(OP_SLTU));
+    emit(s, f_mul(cmp, f_sub(f_add(f_sub(b_lo, c_lo), f_mul(F65536, l[AL_K0])), x_lo)));
+    emit(s, f_add(f_mul(cmp, f_sub(f_add(f_sub(f_sub(b_hi, c_hi), l[AL_K0]), f_mul(F65536, l[AL_K1])), x_hi)),
+                  f_mul(F65536, f_mul(OPF(OP_SLT), f_sub(l[AL_C + 31], l[AL_B + 31])))));
+    emit(s, f_mul(cmp, f_sub(a_lo, l[AL_K1])));
+    emit(s, f_mul(cmp, a_hi));
+  }
+#undef OPF
+}
+
+/* sub-word chip: M is the memory word, C the low limb of the stored register, both as bits */
+static void sub_constraints(const uint32_t* l, sink* s) {
+  enum { LB = 0, LH, LBU, LHU, SB, SH };
+#define SF(k) l[SW_SEL + (k)]
+  emit(s, bool_c(l[SW_IS_REAL]));
+  fe selsum = 0, osum = 0;
+  for (int k = 0; k < 6; ++k) { emit(s, bool_c(SF(k))); selsum = f_add(selsum, SF(k)); }
+  for (int k = 0; k < 4; ++k) { emit(s, bool_c(l[SW_O + k])); osum = f_add(osum, l[SW_O + k]); }
+  for (int i = 0; i < 48; ++i) emit(s, bool_c(l[SW_M + i])); /* M, C */
+  emit(s, f_sub(selsum, l[SW_IS_REAL]));
+  emit(s, f_sub(osum, l[SW_IS_REAL]));
+  const fe a_lo = l[SW_A], a_hi = l[SW_A + 1], m_lo = limb_of(l, SW_M, 0), m_hi = limb_of(l, SW_M, 1), c_lo = limb_of(l, SW_C, 0);
+  const fe mv_lo = l[SW_MV], mv_hi = l[SW_MV + 1];
+  const fe o0 = l[SW_O], o1 = l[SW_O + 1], o2 = l[SW_O + 2], o3 = l[SW_O + 3];
+  const fe mb[4] = {byte_of(l, SW_M, 0), byte_of(l, SW_M, 1), byte_of(l, SW_M, 2), byte_of(l, SW_M, 3)};
+  /* half-word accesses are 2-aligned */
+  emit(s, f_mul(f_add(f_add(SF(LH), SF(LHU)), SF(SH)), f_add(o1, o3)));
+  const fe hv = f_add(f_mul(o0, m_lo), f_mul(o2, m_hi)), hs = f_add(f_mul(o0, l[SW_M + 15]), f_mul(o2, l[SW_M + 31]));
+  emit(s, f_mul(SF(LHU), f_sub(a_lo, hv)));
+  emit(s, f_mul(SF(LHU), a_hi));
+  emit(s, f_mul(SF(LH), f_sub(a_lo, hv)));
+  emit(s, f_mul(SF(LH), f_sub(a_hi, f_mul(65535, hs))));
+  fe bv = 0, bs = 0;
+  for (int p = 0; p < 4; ++p) { bv = f_add(bv, f_mul(l[SW_O + p], mb[p])); bs = f_add(bs, f_mul(l[SW_O + p], l[SW_M + 8 * p + 7])); }
+  emit(s, f_mul(SF(LBU), f_sub(a_lo, bv)));
+  emit(s, f_mul(SF(LBU), a_hi));
+  emit(s, f_mul(SF(LB), f_sub(a_lo, f_add(bv, f_mul(0xff00, bs)))));
+  emit(s, f_mul(SF(LB), f_sub(a_hi, f_mul(65535, bs))));
+  /* loads leave the word as it was; stores write nothing to a register */
+  const fe loads = f_add(f_add(SF(LB), SF(LH)), f_add(SF(LBU), SF(LHU))), stores = f_add(SF(SB), SF(SH));
+  emit(s, f_mul(loads, f_sub(mv_lo, m_lo)));
+  emit(s, f_mul(loads, f_sub(mv_hi, m_hi)));
+  emit(s, f_mul(stores, a_lo));
+  emit(s, f_mul(stores, a_hi));
+  emit(s, f_mul(SF(SH), f_sub(f_sub(mv_lo, m_lo), f_mul(o0, f_sub(c_lo, m_lo)))));
+  emit(s, f_mul(SF(SH), f_sub(f_sub(mv_hi, m_hi), f_mul(o2, f_sub(c_lo, m_hi)))));
+  const fe cb = byte_of(l, SW_C, 0);
+  emit(s, f_mul(SF(SB), f_sub(f_sub(mv_lo, m_lo), f_add(f_mul(o0, f_sub(cb, mb[0])), f_mul(256, f_mul(o1, f_sub(cb, mb[1])))))));
+  emit(s, f_mul(SF(SB), f_sub(f_sub(mv_hi, m_hi), f_add(f_mul(o2, f_sub(cb, mb[2])), f_mul(256, f_mul(o3, f_sub(cb, mb[3])))))));
+#undef SF
+}
+
 static void run_constraints(int chip, const uint32_t* prep, const uint32_t* loc, const uint32_t* nxt, uint32_t is_first,
                             uint32_t is_last, uint32_t is_trans, const uint32_t* pub, sink* s) {
-  (void)prep;
-  static const uint32_t no_pub[CPUPUB_N] = {0, 0, 0, 0};
+  static const uint32_t no_pub[CPUPUB_N] = {0, 0, 0, 0, 0};
   switch (chip) {
     case CH_CPU:
     case CH_CPU2: cpu_constraints(loc, nxt, is_first, is_last, is_trans, pub ? pub : no_pub, s); break;
@@ -739,10 +1042,14 @@ static void run_constraints(int chip, const uint32_t* prep, const uint32_t* loc,
       break;
     case CH_KMEM: kmem_constraints(loc, nxt, is_first, is_trans, s); break;
     case CH_MEMFINAL: memfinal_constraints(loc, nxt, is_trans, s); break;
-    case CH_IMAGE: emit(s, bool_c(loc[0])); break;
+    case CH_IMAGE: emit(s, f_sub(loc[0], prep[IMG_P_REAL])); break; /* every image word is sent exactly once */
     case CH_PROGRAM: break;
     case CH_MUL: mul_constraints(loc, s); break;
-    case CH_RANGE: break;
+    case CH_TABLE: emit(s, f_mul(loc[TB_M_AL], prep[TB_P_NA])); break; /* only multiples of 4 answer aligned lookups */
+    case CH_ALU:
+    case CH_ALU2: alu_constraints(loc, s); break;
+    case CH_SUB:
+    case CH_SUB2: sub_constraints(loc, s); break;
   }
 }
 

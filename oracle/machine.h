@@ -10,6 +10,17 @@
  * "Machine proof").  The statement is the reference's: the committed guest
  * (circuits/sp1-merkle-proof/src/main.rs:4-14, crypto-ops/src/lib.rs:8-23) ran to HALT(0) and
  * committed these public values.
+ *
+ * Format v6 (round 3).  The CPU row no longer carries its operands as bits: it holds 16-bit limbs,
+ * adds / subtracts / compares for equality / moves words itself, and sends everything bitwise
+ * (xor, or, and, shifts, signed and unsigned less-than) to an ALU chip and every sub-word load or
+ * store to a sub-word chip, each with one row per such instruction (SP1's split of the CPU chip
+ * from its event-sized ALU chips).  Range discipline: every tuple on the memory bus carries
+ * canonical 16-bit limbs because every producer guarantees it (image: preprocessed; free
+ * initial values, sums, differences and the hinted length: looked up in a 2^16-row table; ALU,
+ * sub-word, multiplier and keccak results: bits), so readers need no decomposition.  Memory
+ * addresses and jump targets are kept below 0x78000000 < p by the same table, so the map from
+ * 32-bit values to field elements is injective wherever a bus compares them.
  */
 #ifndef ZKSP_ORACLE_MACHINE_H
 #define ZKSP_ORACLE_MACHINE_H
@@ -23,35 +34,47 @@ extern "C" {
 #endif
 
 /* ---- chips, in proof order ---- */
-/* The execution is split over two instances of the CPU chip: cycles [0, H0) in CH_CPU with H0 the largest power of two
- * below the cycle count, the rest in CH_CPU2 (a power of two again): 391 400 cycles take 2^18 + 2^17 rows, not 2^19. */
-enum { CH_CPU = 0, CH_KECCAK, CH_KMEM, CH_MEMFINAL, CH_IMAGE, CH_PROGRAM, CH_MUL, CH_RANGE, CH_CPU2, N_CHIPS };
+/* CPU, ALU and sub-word rows are each split over two instances of one AIR: the first has the largest power of two
+ * of rows strictly below the count (at least 32), the second the rest rounded up to a power of two:
+ * 391 400 cycles take 2^18 + 2^17 rows, not 2^19. */
+enum {
+  CH_CPU = 0, CH_KECCAK, CH_KMEM, CH_MEMFINAL, CH_IMAGE, CH_PROGRAM, CH_MUL, CH_TABLE, CH_CPU2, CH_ALU, CH_ALU2, CH_SUB,
+  CH_SUB2, N_CHIPS
+};
 
-/* ---- AIR opcodes (Program table column OP; CPU selector k-1) ---- */
+/* ---- opcodes: Program table column CODE, and the op element of the ALU / sub-word bus tuples ---- */
 enum {
   OP_ADD = 1, OP_SUB, OP_XOR, OP_OR, OP_AND, OP_SLL, OP_SRL, OP_SRA, OP_SLT, OP_SLTU, OP_JAL, OP_JALR, OP_BEQ, OP_BNE,
   OP_BLT, OP_BGE, OP_BLTU, OP_BGEU, OP_LB, OP_LH, OP_LW, OP_LBU, OP_LHU, OP_SB, OP_SH, OP_SW, OP_MUL, OP_MULHU,
   OP_ECALL, OP_KECCAK, N_OPS_P1
 };
-#define N_OPS 30
-/* access-time differences: two limbs of TS_LIMB_BITS bits, each looked up in the range table */
-#define TS_LIMB_BITS 12
-#define TS_LIMBS 2
+/* ---- instruction classes: one selector column each in the CPU row; Program table column CLS ---- */
+enum {
+  CL_ADD = 1, CL_SUB, CL_ALU, CL_JAL, CL_JALR, CL_BEQ, CL_BNE, CL_BLT, CL_BGE, CL_LW, CL_SW, CL_LDS, CL_STS, CL_ECALL,
+  CL_KECCAK, N_CLS_P1
+};
+#define N_CLS 15
+int orc_class_of(uint32_t op);   /* CL_* of an OP_* */
+uint32_t orc_code_of(uint32_t op); /* the op a row of that instruction puts on the ALU / sub-word bus (0: none) */
 
 /* ---- CPU chip main columns ---- */
 enum {
-  C_IS_REAL = 0, C_PC, C_TS, C_NEXT_PC,
-  C_OP = 4,                    /* 30 selectors: column C_OP + (op - 1) */
-  C_WR = C_OP + N_OPS, C_USE2, C_RD, C_RS1, C_RS2, C_IMM_LO, C_IMM_HI, C_TGT,
-  C_A, /* value written: two 16-bit limbs (read back only through the bits of B, C or M) */
-  C_B = C_A + 2, C_C = C_B + 32, C_M = C_C + 32, C_X = C_M + 32,
-  C_MV_LO = C_X + 32, C_MV_HI,
-  C_K0, C_K1, C_K2, C_K3, C_EQ, C_INV,
-  C_O0, C_O1, C_O2, C_O3,
+  C_PC = 0, C_TS, C_NEXT_PC,
+  C_SEL = 3,                   /* N_CLS class selectors: column C_SEL + (class - 1) */
+  C_CODE = C_SEL + N_CLS, C_WR, C_USE2, C_RD, C_RS1, C_RS2, C_IMM_LO, C_IMM_HI, C_TGT_LO, C_TGT_HI,
+  C_A,                         /* value written to rd (stores: unused; branches: the taken / less-than flag) */
+  C_B = C_A + 2,               /* reg[rs1] */
+  C_C = C_B + 2,               /* reg[rs2], or the immediate */
+  C_M = C_C + 2,               /* memory slot: word read */
+  C_MV = C_M + 2,              /* memory slot: word left behind */
+  C_X = C_MV + 2,              /* adder output: sum / difference / effective address; beq, bne: the limb differences' inverses */
+  C_K0 = C_X + 2, C_K1,        /* carries; beq, bne: "limb equal" flags */
+  C_O0, C_O1, C_O2, C_O3,      /* byte offset of the effective address, one-hot */
+  C_MADDR,                     /* word address on the memory bus (ecall: 11, the register a1) */
   C_SC,                        /* 6 syscall flags: HALT, WRITE, COMMIT, DEFER, HINT_LEN, HINT_READ */
   C_R1_PTS = C_SC + 6, C_R2_PTS, C_M_PTS, C_W_PTS, C_W_PLO, C_W_PHI,
-  C_R1_D, C_R2_D = C_R1_D + TS_LIMBS, C_M_D = C_R2_D + TS_LIMBS, C_W_D = C_M_D + TS_LIMBS,
-  CPU_WIDTH = C_W_D + TS_LIMBS
+  C_GAP,                       /* 4 access-time differences: low 16 bits, high 8 bits each */
+  CPU_WIDTH = C_GAP + 8
 };
 enum { SC_HALT = 0, SC_WRITE, SC_COMMIT, SC_DEFER, SC_HINT_LEN, SC_HINT_READ };
 
@@ -62,31 +85,46 @@ enum { SC_HALT = 0, SC_WRITE, SC_COMMIT, SC_DEFER, SC_HINT_LEN, SC_HINT_READ };
 /* ---- keccak-memory chip: 50 rows per call, one state word each ---- */
 enum {
   KM_IS_REAL = 0, KM_TS, KM_PTR_LO, KM_PTR_HI, KM_IDX, KM_ISF, KM_ISL, KM_CALL, KM_ADDR, KM_OLD_LO, KM_OLD_HI, KM_NEW_LO,
-  KM_NEW_HI, KM_PTS, KM_D, KMEM_WIDTH = KM_D + TS_LIMBS
+  KM_NEW_HI, KM_PTS, KM_GL, KM_GH, KMEM_WIDTH
 };
-/* ---- memory boundary chip: every touched address once, strictly increasing ---- */
-enum { MF_IS_REAL = 0, MF_ADDR, MF_IS_INIT, MF_FIN_LO, MF_FIN_HI, MF_FIN_TS, MF_DIFF, MF_INIT = MF_DIFF + 32, MEMFINAL_WIDTH = MF_INIT + 32 };
-/* ---- image chip: preprocessed (addr, lo, hi), main (used) ---- */
-enum { IMG_P_ADDR = 0, IMG_P_LO, IMG_P_HI, IMAGE_PREP_WIDTH };
+/* ---- memory boundary chip: EVERY image address and every other touched address once, strictly increasing ---- */
+enum {
+  MF_IS_REAL = 0, MF_LO, MF_HI, MF_IS_INIT /* free initial value (not an image address) */, MF_INIT_LO, MF_INIT_HI,
+  MF_FIN_LO, MF_FIN_HI, MF_FIN_TS, MF_D_LO, MF_D_HI, MF_BW, MEMFINAL_WIDTH
+};
+/* ---- image chip: preprocessed (addr, lo, hi, is_real), main (used = is_real) ---- */
+enum { IMG_P_ADDR = 0, IMG_P_LO, IMG_P_HI, IMG_P_REAL, IMAGE_PREP_WIDTH };
 #define IMAGE_WIDTH 1
 /* ---- program chip: preprocessed instruction fields, main (multiplicity) ---- */
-enum { PR_PC = 0, PR_OP, PR_WR, PR_USE2, PR_RD, PR_RS1, PR_RS2, PR_IMM_LO, PR_IMM_HI, PR_TGT, PROGRAM_PREP_WIDTH };
+enum { PR_PC = 0, PR_CLS, PR_CODE, PR_WR, PR_USE2, PR_RD, PR_RS1, PR_RS2, PR_IMM_LO, PR_IMM_HI, PR_TGT_LO, PR_TGT_HI, PROGRAM_PREP_WIDTH };
 #define PROGRAM_WIDTH 1
 /* ---- multiplier chip ---- */
 enum { MU_IS_REAL = 0, MU_HI, MU_B, MU_C = MU_B + 32, MU_P = MU_C + 32, MU_Q0 = MU_P + 64, MU_Q1 = MU_Q0 + 10, MU_Q2 = MU_Q1 + 11, MUL_WIDTH = MU_Q2 + 10 };
-
-/* ---- range table: preprocessed (value = row index), main (multiplicity); always 2^TS_LIMB_BITS rows ---- */
-#define RANGE_PREP_WIDTH 1
-#define RANGE_WIDTH 1
-#define RANGE_LOG_H TS_LIMB_BITS
+/* ---- ALU chip: xor or and sll srl sra slt sltu over bits ---- */
+enum {
+  AL_IS_REAL = 0, AL_SEL /* 8 selectors, OP_XOR..OP_SLTU */, AL_A = AL_SEL + 8, AL_B = AL_A + 2, AL_C = AL_B + 32,
+  AL_X = AL_C + 32 /* one-hot shift amount / comparison difference */, AL_K0 = AL_X + 32, AL_K1, ALU_WIDTH
+};
+/* ---- sub-word chip: lb lh lbu lhu sb sh ---- */
+enum {
+  SW_IS_REAL = 0, SW_SEL /* 6 selectors: LB LH LBU LHU SB SH */, SW_O = SW_SEL + 6 /* 4: byte offset, one-hot */,
+  SW_A = SW_O + 4, SW_M = SW_A + 2 /* 32 bits */, SW_C = SW_M + 32 /* 16 bits: low limb of the stored register */,
+  SW_MV = SW_C + 16, SUB_WIDTH = SW_MV + 2
+};
+/* ---- table chip: 2^16 rows; preprocessed (x = low byte, y = high byte, na = row index not a multiple of 4);
+ *      main: multiplicities of range16, aligned range16, byte pair ---- */
+enum { TB_P_X = 0, TB_P_Y, TB_P_NA, TABLE_PREP_WIDTH };
+enum { TB_M_R16 = 0, TB_M_AL, TB_M_BY, TABLE_WIDTH };
+#define TABLE_LOG_H 16
+#define ADDR_HI_MAX 0x77FFu /* high limb of the largest address / jump target: values stay below 0x78000000 < p */
 
 /* ---- buses ---- */
-enum { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_MUL, BUS_PUBC, BUS_PUBH, BUS_RANGE };
+enum { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG };
 
 /* A linear form over the row [preprocessed | main]: c0 + sum coef[i] * row[col[i]] (canonical words). */
 #define LF_MAX 40
 typedef struct { int n; int col[LF_MAX]; uint32_t coef[LF_MAX]; uint32_t c0; } orc_lf;
-#define INTER_MAX_ELEMS 10
+#define INTER_MAX_ELEMS 12
 typedef struct { int bus; int sign; /* +1 send / produce, -1 receive / consume */ orc_lf mult; int n_el; orc_lf el[INTER_MAX_ELEMS]; } orc_inter;
 
 typedef struct {
@@ -102,25 +140,29 @@ static inline int orc_chip_perm_width(const orc_chip* c) { return 4 * (orc_chip_
 
 /* ---- inputs: exactly the arrays zksp_mtrace_section() exposes ---- */
 typedef struct {
-  const uint32_t* program; size_t n_program;   /* 9 u32 per row */
+  const uint32_t* program; size_t n_program;   /* 9 u32 per row; the last row is the padding instruction (jal to itself) */
   const uint32_t* image; size_t n_image;       /* 2 u32 per row */
   uint32_t entry, text_base;
   int log_prog, log_image;
   const uint32_t* cycles; size_t n_cycles;     /* 12 u32 per cycle */
   const uint8_t* keccak; size_t n_keccak;      /* 408 bytes per call */
-  const uint32_t* memfinal; size_t n_memfinal; /* 5 u32 */
+  const uint32_t* memfinal; size_t n_memfinal; /* 5 u32: addr, init, fin, fin_ts, is_init */
   const uint32_t* muls; size_t n_muls;         /* 3 u32 */
   const uint32_t* prog_mult;                   /* n_program */
-  const uint32_t* image_used;                  /* n_image */
 } orc_machine_input;
+
+/* The oracle's own event lists (cycle indices of the ALU-chip and sub-word-chip rows, in execution order) and the
+ * last access time of x0 by a real cycle; the product's tracer emits the same lists and tests compare them. */
+size_t orc_machine_events(const orc_machine_input* in, int which /* 0 alu, 1 sub-word */, uint32_t* out /* may be NULL */);
+uint32_t orc_machine_x0_last(const orc_machine_input* in);
 
 /* log2 trace height of every chip for this input (minimum 5) */
 void orc_machine_heights(const orc_machine_input* in, int logh[N_CHIPS]);
 /* column-major traces: prep [prep_width][H] (NULL when the chip has none), main [main_width][H] */
 void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t* prep, uint32_t* main_);
-/* Public scalars of a CPU instance: pc and time of its first row, whether another instance continues it, and the pc
- * that one starts at (the hand-over pc, a proof-header word the transcript absorbs). */
-enum { CPUPUB_START_PC = 0, CPUPUB_START_TS, CPUPUB_HAS_SUCC, CPUPUB_END_PC, CPUPUB_N };
+/* Public scalars of a CPU instance: pc and time of its first row, whether another instance continues it, the pc
+ * that one starts at (the hand-over pc, a proof-header word the transcript absorbs), and the padding pc. */
+enum { CPUPUB_START_PC = 0, CPUPUB_START_TS, CPUPUB_HAS_SUCC, CPUPUB_END_PC, CPUPUB_PAD_PC, CPUPUB_N };
 void orc_machine_cpu_pub(const orc_machine_input* in, int chip, uint32_t pub[CPUPUB_N]);
 /* base constraints of one chip at one row pair; `pub` = the CPUPUB_* words for the CPU instances (ignored elsewhere) */
 void orc_machine_constraints(int chip, const uint32_t* prep, const uint32_t* loc, const uint32_t* nxt, uint32_t is_first,
@@ -133,7 +175,7 @@ typedef struct {
   uint32_t pv_digest[8];
   uint32_t deferred_digest[8];
 } orc_machine_public;
-#define ZKSP_VERSION_MACHINE 5u
+#define ZKSP_VERSION_MACHINE 6u
 /* vk: preprocessed commitment root + digest binding entry pc, table heights and keccak mode */
 void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t prep_root[8], uint32_t vk_digest[8]);
 size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_image, const orc_config* cfg, uint32_t pv_len);

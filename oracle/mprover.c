@@ -3,7 +3,7 @@
  * Whole machine proof on the CPU: the multi-table STARK that sp1-stark / sp1-prover 3.4.0 build over
  * p3-uni-stark, p3-fri, p3-merkle-tree (mixed-height MMCS) and p3-challenger (reference
  * Cargo.lock:7485, :7273, :5378, :5253, :5336, :5197) beneath `client.prove(&pk, stdin).run()`
- * (prover/src/bin/main.rs:71-74), restated under this repository's own format "ZKSP v5"
+ * (prover/src/bin/main.rs:71-74), restated under this repository's own format "ZKSP v6"
  * (DESIGN.md "Machine proof").  PARITY UNPINNED vs SP1 proof bytes.  The HIP prover must
  * reproduce these bytes exactly.
  *
@@ -345,19 +345,20 @@ static void free_chips(chipd* cd) {
 }
 
 static void vk_digest_of(const uint32_t root[8], const orc_machine_input* in, int keccak_mode, uint32_t out[8]) {
-  uint32_t v[16];
+  uint32_t v[18];
+  const uint32_t pad_pc = in->text_base + 4 * (uint32_t)(in->n_program - 1); /* the padding instruction: last Program row */
   memcpy(v, root, 32);
   v[8] = in->entry & 0xffff; v[9] = in->entry >> 16;
   v[10] = (uint32_t)in->log_prog; v[11] = (uint32_t)in->log_image; v[12] = (uint32_t)keccak_mode;
   v[13] = ZKSP_VERSION_MACHINE; v[14] = CPU_WIDTH; v[15] = N_CHIPS;
-  orc_hash_elems(v, 16, out);
+  v[16] = pad_pc & 0xffff; v[17] = pad_pc >> 16;
+  orc_hash_elems(v, 18, out);
 }
 
 void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t prep_root[8], uint32_t vk_digest[8]) {
   chipd cd[N_CHIPS];
   orc_machine_input tmp = *in;
   tmp.prog_mult = NULL;
-  tmp.image_used = NULL;
   tmp.n_cycles = tmp.n_keccak = tmp.n_memfinal = tmp.n_muls = 0;
   init_chips(&tmp, cd, 1);
   mmcs t;
@@ -396,7 +397,7 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   chipd cd[N_CHIPS];
   int logh[N_CHIPS];
   orc_machine_heights(in, logh);
-  if (in->n_cycles < 33 || logh[CH_CPU] > 20) return 1; /* two CPU instances of at most 2^20 rows each */
+  if (in->n_cycles < 1 || logh[CH_CPU] > 20) return 1; /* two CPU instances of at most 2^20 rows each */
   const size_t need = orc_machine_proof_size(logh, in->log_prog, in->log_image, cfg, pub->pv_len);
   *out_len = need;
   if (cap < need) return 2;

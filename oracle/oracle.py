@@ -63,6 +63,7 @@ def lib() -> C.CDLL:
         _lib.orc_ch_sample_bits.restype = C.c_uint32
         _lib.orc_ch_grind.restype = C.c_uint32
         _lib.orc_machine_proof_size.restype = C.c_size_t
+        _lib.orc_machine_events.restype = C.c_size_t
         _lib.orc_machine_chip.restype = C.POINTER(MachineChip)
     return _lib
 
@@ -279,8 +280,10 @@ def prove(states_in: np.ndarray, logh: int, *, exit_code: int = 0, public_values
 # ---------------------------------------------------------------------------
 # machine proof (oracle/machine.h): inputs are the arrays ProverClient.machine_trace() returns
 # ---------------------------------------------------------------------------
-N_CHIPS = 9
-CHIP_NAMES = ["cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "range", "cpu2"]
+N_CHIPS = 13
+CHIP_NAMES = ["cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "table", "cpu2", "alu", "alu2",
+              "subword", "subword2"]
+CPUPUB_N = 5
 
 
 class MachineChip(C.Structure):
@@ -293,7 +296,7 @@ class MachineInput(C.Structure):
                 ("entry", C.c_uint32), ("text_base", C.c_uint32), ("log_prog", C.c_int), ("log_image", C.c_int),
                 ("cycles", C.c_void_p), ("n_cycles", C.c_size_t), ("keccak", C.c_void_p), ("n_keccak", C.c_size_t),
                 ("memfinal", C.c_void_p), ("n_memfinal", C.c_size_t), ("muls", C.c_void_p), ("n_muls", C.c_size_t),
-                ("prog_mult", C.c_void_p), ("image_used", C.c_void_p)]
+                ("prog_mult", C.c_void_p)]
 
 
 class MachinePublic(C.Structure):
@@ -304,13 +307,13 @@ class MachinePublic(C.Structure):
 def machine_input(t: dict):
     """MachineInput over the arrays of a machine trace; returns (struct, keep-alive list)."""
     keep = {k: np.ascontiguousarray(t[k]) for k in ("program", "image", "cycles", "keccak", "memfinal", "muls",
-                                                    "prog_mult", "image_used")}
+                                                    "prog_mult")}
     info = t["info"]
     mi = MachineInput(_p(keep["program"]), len(keep["program"]), _p(keep["image"]), len(keep["image"]),
                       info.entry, int(keep["program"][0, 0]), info.log_prog, info.log_image,
                       _p(keep["cycles"]), len(keep["cycles"]), _p(keep["keccak"]), len(keep["keccak"]),
                       _p(keep["memfinal"]), len(keep["memfinal"]), _p(keep["muls"]), len(keep["muls"]),
-                      _p(keep["prog_mult"]), _p(keep["image_used"]))
+                      _p(keep["prog_mult"]))
     return mi, keep
 
 
@@ -339,8 +342,9 @@ def machine_fill(t: dict, chip: int):
     return prep, main
 
 
-def machine_constraints(chip: int, prep_row, loc, nxt, is_first: int, is_last: int, is_trans: int, pub=(0, 0, 0, 0)) -> np.ndarray:
-    """`pub`: the four CPUPUB_* words (first pc, first time, has a successor, hand-over pc) for the CPU instances."""
+def machine_constraints(chip: int, prep_row, loc, nxt, is_first: int, is_last: int, is_trans: int, pub=(0, 0, 0, 0, 0)) -> np.ndarray:
+    """`pub`: the five CPUPUB_* words (first pc, first time, has a successor, hand-over pc, padding pc) for the CPU
+    instances."""
     d = machine_chip(chip)
     out = np.zeros(max(d["n_constraints"], 1), np.uint32)
     pr = _u32(prep_row) if prep_row is not None else np.zeros(1, np.uint32)
@@ -348,6 +352,22 @@ def machine_constraints(chip: int, prep_row, loc, nxt, is_first: int, is_last: i
     lib().orc_machine_constraints(chip, _p(pr), _p(l), _p(n), C.c_uint32(is_first), C.c_uint32(is_last),
                                   C.c_uint32(is_trans), _p(_u32(list(pub))), _p(out))
     return out[: d["n_constraints"]]
+
+
+def machine_cpu_pub(t: dict, chip: int):
+    mi, _keep = machine_input(t)
+    out = (C.c_uint32 * CPUPUB_N)()
+    lib().orc_machine_cpu_pub(C.byref(mi), chip, out)
+    return [int(x) for x in out]
+
+
+def machine_events(t: dict, which: int) -> np.ndarray:
+    """The oracle's own list of cycle indices that occupy ALU-chip (0) / sub-word-chip (1) rows."""
+    mi, _keep = machine_input(t)
+    n = int(lib().orc_machine_events(C.byref(mi), which, None))
+    out = np.zeros(max(n, 1), np.uint32)
+    lib().orc_machine_events(C.byref(mi), which, _p(out))
+    return out[:n]
 
 
 def machine_setup(t: dict):

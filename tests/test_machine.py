@@ -25,7 +25,15 @@ def test_trace_agrees_with_executor(zk, fx, built_lib, mode, name, cycles):
     assert t["public_values"] == pv
     assert bytes(np.array(list(t["info"].pv_digest), np.uint32).tobytes()) == hashlib.sha256(pv).digest()
     assert len(t["keccak"]) == (rep.n_keccak if mode == 2 else 0)
-    assert int(t["prog_mult"].sum()) == cycles
+    # the last Program row is the padding instruction: it is fetched by the CPU rows after the last cycle
+    h0 = 32
+    while 2 * h0 < cycles:
+        h0 *= 2
+    h1 = 32
+    while h1 < cycles - h0:
+        h1 *= 2
+    assert int(t["prog_mult"][:-1].sum()) == cycles and int(t["prog_mult"][-1]) == h0 + h1 - cycles
+    assert t["program"][-1].tolist() == [int(t["program"][-2, 0]) + 4, 11, 0, 0, 0, 0, 0, 0, int(t["program"][-2, 0]) + 4]
 
 
 @pytest.mark.parametrize("mode", [2, 1])
@@ -69,22 +77,69 @@ def test_memory_argument_balances(zk, fx, built_lib, mode):
             ad = int(k["ptr"]) + 4 * np.arange(50, dtype=np.int64)
             cons.append(tup(ad, w_in, k["pts"].astype(np.int64)))
             prod.append(tup(ad, w_out, np.full(50, int(k["ts"]) + 2)))
-    # boundary chips
+    # the CPU rows after the last cycle run the padding instruction, which reads x0 once per row
+    pad = int(t["prog_mult"][-1])
+    if pad:
+        pts_ = 4 * (n + np.arange(pad, dtype=np.int64) + 1)
+        x0_last = max([int(ts[i]) + (0 if rs1[i] == 0 else 1) for i in range(n - 1, -1, -1)
+                       if rs1[i] == 0 or (use2[i] == 1 and rs2[i] == 0)][:1] or [0])
+        prev = np.concatenate([[x0_last], pts_[:-1]])
+        z = np.zeros(pad, np.int64)
+        cons.append(tup(z, z, prev)); prod.append(tup(z, z, pts_))
+    # boundary chip: EVERY image address and every other touched address exactly once, strictly increasing; each is
+    # opened at time 0 with its initial value (image addresses: the image's word) and closed with its final tuple
     mf = t["memfinal"].astype(np.int64)
     assert np.all(np.diff(mf[:, 0]) > 0)
     cons.append(tup(mf[:, 0], mf[:, 2], mf[:, 3]))
+    prod.append(tup(mf[:, 0], mf[:, 1], np.zeros(len(mf), np.int64)))
     ini = mf[:, 4] == 1
-    prod.append(tup(mf[ini, 0], mf[ini, 1], np.zeros(ini.sum(), np.int64)))
-    used = t["image_used"] == 1
-    prod.append(tup(img[used, 0], img[used, 1], np.zeros(used.sum(), np.int64)))
-    # image addresses in use are exactly the touched addresses that are not free-initialised
-    assert np.array_equal(np.sort(img[used, 0]), mf[~ini, 0])
+    assert np.array_equal(mf[~ini, 0], img[:, 0]) and np.array_equal(mf[~ini, 1], img[:, 1])
+    assert not np.intersect1d(mf[ini, 0], img[:, 0]).size
+    untouched = (~ini) & (mf[:, 3] == 0)
+    assert np.array_equal(mf[untouched, 1], mf[untouched, 2])
     P_, C_ = np.concatenate(prod), np.concatenate(cons)
     assert len(P_) == len(C_)
     key = lambda z: z[np.lexsort((z[:, 2], z[:, 1], z[:, 0]))]
     assert np.array_equal(key(P_), key(C_))
     # every consumed time is strictly older than the time of the access that consumes it
     assert np.all(r1p < ts) and np.all(r2p[u] < ts[u] + 1) and np.all(mp[ls | ec] < ts[ls | ec] + 2) and np.all(wp[w] < ts[w] + 3)
+
+
+def test_records_replay_against_the_instruction_semantics(zk, fx, built_lib, oracle):
+    """The per-cycle records recomputed from RV32IM semantics in numpy, independently of machine.cpp: the value every
+    cycle writes follows from its operands (and, for loads, from the memory word read), the word a store leaves
+    behind from the old word and the stored register, and the event lists of the ALU and sub-word chips are the
+    cycles of those instructions - as the oracle derives them on its own (orc_machine_events)."""
+    client = zk.ProverClient(device=-1)
+    t, _, _ = trace_of(zk, client, fx.acct_fixture(2))
+    cyc, prog = t["cycles"].astype(np.int64), t["program"].astype(np.int64)
+    rows = prog[(cyc[:, 0] - prog[0, 0]) // 4]
+    op, imm, tgt = rows[:, 1], rows[:, 7], rows[:, 8]
+    a, b, c, m, mv = (cyc[:, i] for i in range(1, 6))
+    M32 = 0xFFFFFFFF
+    sgn = lambda v: np.where(v >= 2**31, v - 2**32, v)
+    sh = c & 31
+    exp = {1: (b + c) & M32, 2: (b - c) & M32, 3: b ^ c, 4: b | c, 5: b & c, 6: (b << sh) & M32, 7: b >> sh,
+           8: (sgn(b) >> sh) & M32, 9: (sgn(b) < sgn(c)).astype(np.int64), 10: (b < c).astype(np.int64), 11: imm, 12: tgt,
+           27: (b * c) & M32, 28: (b.astype(object) * c.astype(object)) >> 32}
+    for k, v in exp.items():
+        sel = op == k
+        assert np.array_equal(a[sel], np.asarray(v)[sel].astype(np.int64)), k
+    off8 = 8 * ((b + imm) & 3)
+    byte, half = (m >> off8) & 0xFF, (m >> off8) & 0xFFFF
+    loads = {19: np.where(byte >= 128, byte | 0xFFFFFF00, byte), 20: np.where(half >= 32768, half | 0xFFFF0000, half), 21: m,
+             22: byte, 23: half}
+    for k, v in loads.items():
+        sel = op == k
+        assert np.array_equal(a[sel], v[sel]) and np.array_equal(mv[sel], m[sel]), k
+    stores = {24: (m & ~(0xFF << off8)) | ((c & 0xFF) << off8), 25: (m & ~(0xFFFF << off8)) | ((c & 0xFFFF) << off8), 26: c}
+    for k, v in stores.items():
+        sel = op == k
+        assert np.array_equal(mv[sel], v[sel] & M32), k
+    alu = np.isin(op, [3, 4, 5, 6, 7, 8, 9, 10, 15, 16, 17, 18])
+    sub = np.isin(op, [19, 20, 22, 23, 24, 25])
+    assert np.array_equal(np.nonzero(alu)[0], t["alu_idx"]) and np.array_equal(np.nonzero(sub)[0], t["sub_idx"])
+    assert np.array_equal(oracle.machine_events(t, 0), t["alu_idx"]) and np.array_equal(oracle.machine_events(t, 1), t["sub_idx"])
 
 
 def test_unsupported_instruction_is_reported(zk, fx, built_lib):

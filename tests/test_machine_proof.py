@@ -1,6 +1,7 @@
 """Machine proof on the CPU: the oracle proves the traced guest, the product's host verifier
 accepts it; proofs a cheating prover could send (another public value, a dropped keccak call, a
-wrong ALU result, an unreported memory write) are rejected.  Runs without a GPU."""
+wrong ALU result, an unreported memory write, a re-initialised image word, a repeated address in the
+memory-boundary chip, values that alias mod p) are rejected.  Runs without a GPU."""
 import copy
 import hashlib
 import os
@@ -64,8 +65,9 @@ def test_every_region_is_bound(zk, setup):
     client, vk, t, proof = setup
     rng = np.random.default_rng(5)
     words = len(proof) // 4
-    hw = zk.MACHINE_HEADER_WORDS  # heights 2..10, exit code 11, pv length 12, digests 13 / 21, vk 29, hand-over pc hw - 1, then the values
-    positions = [2, 5, 9, 10, 11, 12, 20, 28, hw - 1, hw, hw + 1, hw + 18, hw + 18 + 8, hw + 18 + 16, hw + 18 + 48, hw + 18 + 56, words - 1]
+    hw = zk.MACHINE_HEADER_WORDS  # heights 2..14, exit code 15, pv length 16, digests 17 / 25, vk 33, hand-over pc hw - 1, then the values
+    nc = zk.MACHINE_CHIPS
+    positions = [2, 5, 9, 1 + nc, 2 + nc, 3 + nc, 11 + nc, 19 + nc, hw - 1, hw, hw + 1, hw + 18, hw + 18 + 8, hw + 18 + 16, hw + 18 + 48, hw + 18 + 56, words - 1]
     positions += [int(x) for x in rng.integers(hw, words, 40)]
     for w in positions:
         bad = bytearray(proof)
@@ -117,23 +119,49 @@ def test_dropped_keccak_call_is_rejected(zk, oracle, setup):
 
 
 def test_wrong_alu_result_is_rejected(zk, oracle, setup):
-    """One addition yields a wrong sum; registers and memory stay consistent with the wrong value (so the
-    buses still balance) and only the CPU chip's constraint is violated."""
+    """One addition yields a wrong sum (the CPU row's adder constraint is violated), one xor a wrong result (the CPU
+    row and the ALU chip agree on the tuple, so the ALU bus balances; the ALU chip's own constraint is violated)."""
     client, vk, t, _ = setup
     cyc, prog = t["cycles"], t["program"]
     rows = prog[(cyc[:, 0] - prog[0, 0]) // 4]
-    # an `add` whose destination is overwritten before it is read again would be hard to find; instead
-    # corrupt the A bits and the produced register value together with the next consumer's w_prev /
-    # operand: simplest faithful cheat is to change only this row and let the bus go out of balance too
-    i = int(np.nonzero((rows[:, 1] == 1) & (rows[:, 2] == 1))[0][100])
-    t2 = dict(t)
-    c2 = cyc.copy()
-    c2[i, 1] ^= 4
-    t2["cycles"] = c2
-    with pytest.raises(RuntimeError):
-        oracle.machine_prove(t2, num_queries=NQ, pow_bits=POW)
+    for op in (1, 3):  # add, xor
+        i = int(np.nonzero((rows[:, 1] == op) & (rows[:, 2] == 1))[0][100])
+        t2 = dict(t)
+        c2 = cyc.copy()
+        c2[i, 1] ^= 4
+        t2["cycles"] = c2
+        with pytest.raises(RuntimeError):
+            oracle.machine_prove(t2, num_queries=NQ, pow_bits=POW)
+        with pytest.raises(zk.VerificationError):
+            client.verify(zk.SP1ProofWithPublicValues.from_bytes(forced_proof(oracle, t2)), vk)
+
+
+def test_wrong_alu_chip_row_alone_is_rejected(zk, oracle, setup):
+    """Only the ALU chip's row carries a wrong result (low limb flipped): its constraint fails and the ALU bus, on
+    which the CPU row sent the right tuple, does not balance."""
+    client, vk, t, _ = setup
+    os.environ["ZKSP_ORACLE_WRONG_ALU"] = "77"
+    try:
+        with pytest.raises(RuntimeError):
+            oracle.machine_prove(t, num_queries=NQ, pow_bits=POW)
+        forged = forced_proof(oracle, t)
+    finally:
+        del os.environ["ZKSP_ORACLE_WRONG_ALU"]
     with pytest.raises(zk.VerificationError):
-        client.verify(zk.SP1ProofWithPublicValues.from_bytes(forced_proof(oracle, t2)), vk)
+        client.verify(zk.SP1ProofWithPublicValues.from_bytes(forged), vk)
+
+
+def test_wrong_subword_store_is_rejected(zk, oracle, setup):
+    """A byte store that leaves another word behind than the old word with one byte replaced."""
+    client, vk, t, _ = setup
+    cyc, prog = t["cycles"], t["program"]
+    rows = prog[(cyc[:, 0] - prog[0, 0]) // 4]
+    i = int(np.nonzero(rows[:, 1] == 24)[0][50])  # sb
+    c2 = cyc.copy()
+    c2[i, 5] ^= 0x01000000  # the word left behind: a byte the store does not touch, or the stored byte itself
+    t2 = dict(t)
+    t2["cycles"] = c2
+    _rejected(zk, oracle, client, vk, t2)
 
 
 def test_read_from_the_future_is_rejected(zk, oracle, setup):
@@ -158,10 +186,9 @@ def test_read_from_the_future_is_rejected(zk, oracle, setup):
 
 
 def test_out_of_range_result_limbs_cannot_be_read_back(zk, oracle, setup):
-    """The value an instruction writes is kept as two limb columns without a range check of its own.  An addition
-    that claims the wrong carry writes the right sum with limbs out of range: its own constraints hold, but the
-    next read of that register goes through bit columns, whose limbs are in range, so the memory bus cannot
-    balance."""
+    """An addition that claims the wrong carry writes the right sum (mod p) with limbs out of range: the adder's
+    constraints hold, but the sum's limbs are looked up in the 2^16-row table, which has no such row, so the RANGE bus
+    cannot balance - no tuple with out-of-range limbs ever reaches the memory bus."""
     client, vk, t, _ = setup
     cyc, prog = t["cycles"], t["program"]
     rows = prog[(cyc[:, 0] - prog[0, 0]) // 4]
@@ -186,13 +213,75 @@ def _rejected(zk, oracle, client, vk, t2):
 
 
 def test_second_initial_value_is_rejected(zk, oracle, setup):
-    """An address listed twice in the memory-boundary chip would let the prover open it with a second initial
-    value: the chip's addresses must strictly increase (the 32-bit difference minus one has no decomposition)."""
+    """An address listed twice in the memory-boundary chip would let the prover open it with a second initial value
+    and serve loads from a thread the program never wrote.  Addresses must strictly increase OVER THE INTEGERS: the
+    difference to the next address, minus one, is two range-checked 16-bit limbs with a borrow.  Both fillers are
+    tried: the honest one (the limb equations have no solution for a repeated address) and the round-2 attack, which
+    writes the difference that holds mod p (p - 1 = 0x78000000 for a repeated address, as limbs 0 and 0x7800)."""
     client, vk, t, _ = setup
     mf = t["memfinal"]
     k = int(np.nonzero(mf[:, 4] == 1)[0][10])  # a freely initialised (hinted / heap) word
+    dup = mf[k].copy()
+    dup[1], dup[2], dup[3] = 0xDEADBEEF, 0xDEADBEEF, 0  # a second initial value, closed at time 0
     t2 = dict(t)
-    t2["memfinal"] = np.insert(mf, k, mf[k], axis=0)
+    t2["memfinal"] = np.insert(mf, k, dup, axis=0)
+    _rejected(zk, oracle, client, vk, t2)
+    os.environ["ZKSP_ORACLE_MF_WRAP"] = str(k)
+    try:
+        forged = forced_proof(oracle, t2)
+    finally:
+        del os.environ["ZKSP_ORACLE_MF_WRAP"]
+    with pytest.raises(zk.VerificationError) as ei:
+        client.verify(zk.SP1ProofWithPublicValues.from_bytes(forged), vk)
+    assert "mem-final" in str(ei.value) or "balance" in str(ei.value)
+
+
+def test_image_word_cannot_be_reinitialised(zk, oracle, setup):
+    """The round-2 attack on the memory image: withhold a .rodata word (the stack-top constant at 0x228398, SURVEY
+    appendix A.1) from the image chip and let the memory-boundary chip initialise it with a value of the prover's
+    choice.  Now every image word is sent exactly once, unconditionally (the image chip's only main column must equal
+    the preprocessed is-real flag), and the memory-boundary chip lists every image address, so a free initial value
+    for an image address either leaves the image's tuple unclaimed (IMG bus) or repeats the address."""
+    client, vk, t, _ = setup
+    img, mf = t["image"], t["memfinal"]
+    r = int(np.nonzero(img[:, 0] == 0x228398)[0][0])
+    k = int(np.nonzero(mf[:, 0] == 0x228398)[0][0])
+    assert mf[k, 4] == 0 and mf[k, 3] > 0  # an image word the guest reads
+    m2 = mf.copy()
+    m2[k, 4] = 1           # "free initial value" ...
+    m2[k, 1] ^= 0x40       # ... of the prover's choice (the guest would start with another stack pointer)
+    t2 = dict(t)
+    t2["memfinal"] = m2
+    _rejected(zk, oracle, client, vk, t2)  # the image chip's tuple for this address is never received
+    os.environ["ZKSP_ORACLE_IMG_UNUSED"] = str(r)  # ... and a prover that also withholds it breaks the image chip's constraint
+    try:
+        forged = forced_proof(oracle, t2)
+    finally:
+        del os.environ["ZKSP_ORACLE_IMG_UNUSED"]
+    with pytest.raises(zk.VerificationError) as ei:
+        client.verify(zk.SP1ProofWithPublicValues.from_bytes(forged), vk)
+    assert "image" in str(ei.value) or "balance" in str(ei.value)
+    # an image word that the run never touches is still listed by the memory-boundary chip: dropping its row leaves
+    # the image's tuple unclaimed
+    k2 = int(np.nonzero((mf[:, 4] == 0) & (mf[:, 3] == 0) & (mf[:, 0] > 31))[0][5])
+    t3 = dict(t)
+    t3["memfinal"] = np.delete(mf, k2, axis=0)
+    _rejected(zk, oracle, client, vk, t3)
+
+
+def test_link_value_that_aliases_mod_p_is_rejected(zk, oracle, setup):
+    """jalr writes pc + 4 to rd.  In round 2 the link was one field equation, so pc + 4 + p (a second 32-bit value
+    with in-range limbs) satisfied it; the link is now compared limb by limb with the Program table's two limbs."""
+    client, vk, t, _ = setup
+    cyc, prog = t["cycles"], t["program"]
+    rows = prog[(cyc[:, 0] - prog[0, 0]) // 4]
+    i = int(np.nonzero((rows[:, 1] == 12) & (rows[:, 2] == 1))[0][20])  # a jalr that writes its link
+    P = 2013265921
+    assert int(cyc[i, 1]) + P < 2**32
+    c2 = cyc.copy()
+    c2[i, 1] = int(cyc[i, 1]) + P
+    t2 = dict(t)
+    t2["cycles"] = c2
     _rejected(zk, oracle, client, vk, t2)
 
 

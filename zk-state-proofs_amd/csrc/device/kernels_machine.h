@@ -17,7 +17,7 @@ struct Seg {
   size_t bstride;
   int width;
 };
-constexpr int kMaxSegs = 12;  // at least kNumChips: every chip could have the same height
+constexpr int kMaxSegs = 16;  // at least kNumChips: every chip could have the same height
 
 // ---- trace expansion (row a3 of the machine proof) ----
 struct MachineRecords {
@@ -25,21 +25,31 @@ struct MachineRecords {
   const uint8_t* kcalls;       // [B][cap_keccak][408]
   const uint32_t* memfinal;    // [B][cap_memfinal][5]
   const uint32_t* muls;        // [B][cap_muls][3]
+  const uint32_t* alu_idx;     // [B][cap_alu]: cycle index of every ALU-chip row
+  const uint32_t* sub_idx;     // [B][cap_sub]: cycle index of every sub-word-chip row
   const uint32_t* prog_mult;   // [B][2^log_prog]
-  const uint32_t* image_used;  // [B][2^log_image]
-  const uint32_t* counts;      // [B][4]: cycles, keccak calls, memfinal rows, muls
-  uint32_t* range_hist;        // [B][2^kRangeLogH] scratch: multiplicities of the range table, counted on the device
-  uint32_t* cpu_limbs[2];      // per CPU instance: [B][8][H] scratch, limbs of B, C, M, X per trace row (for the LogUp trace)
-  uint32_t cpu2_row0;          // first cycle of the second CPU instance (= rows of the first)
-  size_t cap_cycles, cap_keccak, cap_memfinal, cap_muls;
-  const uint32_t* program;     // [n_program][9] (shared)
-  uint32_t text_base, n_program;
+  const uint32_t* counts;      // [B][8]: cycles, keccak calls, memfinal rows, muls, ALU rows, sub-word rows, last time x0 was
+                               //         accessed by a real cycle, 0
+  uint32_t* table_hist;        // [B][3][2^16] scratch: multiplicities of the table chip, counted on the device
+  uint32_t row0[mach::kNumChips];  // first cycle / event of the chip's instance (second instances: rows of the first)
+  size_t cap_cycles, cap_keccak, cap_memfinal, cap_muls, cap_alu, cap_sub;
+  const uint32_t* program;     // [n_program][9] (shared); the last row is the padding instruction
+  uint32_t text_base, n_program, n_image;
 };
-// trace: [B][main_width][2^logh] of the given chip (kCpu, kCpu2, kKmem, kMemFinal, kImage, kProgram, kMul, kRange)
+constexpr int kCountWords = 8;
+// trace: [B][main_width][2^logh] of the given chip (every chip but kKeccak and kTable)
 void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& rec, uint32_t* trace, int logh, int batch);
 // keccak chip: p3-keccak-air's columns by launch_keccak_trace (kernels.h, with a batch stride), then the call time
 void launch_keccak_ts(hipStream_t stream, const MachineRecords& rec, uint32_t* trace, size_t trace_bstride, int logh,
                       int batch);
+// Table chip multiplicities: what the rows of `chip` (its main trace [B][w][2^logh], Montgomery) look up on the RANGE and
+// BYTES buses is added to rec.table_hist (zero it first: launch_table_clear), by evaluating the chip's own receives -
+// so the buses balance by construction whenever every looked-up value has a table row.  launch_table_trace then
+// writes the table chip's three main columns.
+void launch_table_clear(hipStream_t stream, const MachineRecords& rec, int batch);
+void launch_table_count(hipStream_t stream, const mach::Interaction* inter, int n_inter, const uint32_t* trace, int width, int logh,
+                        const MachineRecords& rec, int batch);
+void launch_table_trace(hipStream_t stream, const MachineRecords& rec, uint32_t* trace, int batch);
 
 // ---- mixed-height Merkle commitment (row a5) ----
 // Leaf digests of one height group: rows of `nseg` LDE matrices ([w][2H] each) concatenated, written to
@@ -52,17 +62,16 @@ void launch_mmcs_level(hipStream_t stream, const uint32_t* in, size_t in_bstride
 
 // ---- LogUp (row a6, lookup argument) ----
 struct PermArgs {
-  int chip;                        // the CPU chip has a hand-written evaluation of its interactions
+  int chip;
   const mach::Interaction* inter;  // device copy of the chip's interactions
   int n_inter;
   Seg prep, main_;                 // traces [w][H]
   const uint32_t* bus_ch;          // [B][8]: gamma, beta
-  const uint32_t* bpow;            // [B][11] Fp4: powers of beta
+  const uint32_t* bpow;            // [B][kInterMaxElems + 1] Fp4: powers of beta
   uint32_t* perm;                  // [B][perm_width][H]
   size_t perm_bstride;
   uint32_t* rowsum;                // [B][H] Fp4 scratch
   uint32_t* slice_sums;            // [B][H / 4096] Fp4 scratch (tall chips: the running sum is scanned in slices)
-  const uint32_t* limbs;           // CPU chip: [B][8][H] limbs of B, C, M, X per row (MachineRecords::cpu_limbs)
   uint32_t* cum;                   // [B] Fp4 (this chip's cumulative sum)
   size_t cum_bstride;
   int logh, batch;
@@ -70,7 +79,7 @@ struct PermArgs {
 void launch_perm_trace(hipStream_t stream, const PermArgs& a);
 // public terms of the two verifier-closed buses: out[b] = -(sum over the 16 digest words and the exit code of 1/f)
 // per proof: pv digest 8, deferred digest 8, exit code (canonical), then the CpuPub words of the two CPU instances (Montgomery)
-constexpr int kPubWords = 17 + 2 * 4;
+constexpr int kPubWords = 17 + 2 * mach::kNumCpuPub;
 void launch_public_bus(hipStream_t stream, const uint32_t* pub_words /*[B][kPubWords]*/,
                        const uint32_t* bus_ch, const uint32_t* bpow, uint32_t* out, size_t out_bstride, int batch);
 
@@ -83,7 +92,7 @@ struct MQuotArgs {
   const uint32_t* alpha_pows;   // [B][alpha_stride] Fp4
   size_t alpha_bstride;
   const uint32_t* bus_ch;       // [B][8]
-  const uint32_t* bpow;         // [B][11] Fp4
+  const uint32_t* bpow;         // [B][kInterMaxElems + 1] Fp4
   const uint32_t* cum;          // [B] Fp4, stride cum_bstride
   size_t cum_bstride;
   const uint32_t* tw_fwd;       // [H/2] powers of w_H
@@ -93,8 +102,7 @@ struct MQuotArgs {
   const uint32_t* pubs;         // CPU instances: this instance's CpuPub words per proof (Montgomery), stride pubs_bstride
   size_t pubs_bstride;
   uint32_t* quot;               // [B][8][H]
-  uint32_t* partial;            // keccak chip: [B][13][2H] Fp4 scratch; CPU chip: [B][5][2H] Fp4
-  uint32_t* limbs;              // CPU chip: [B][8][2H] scratch, limbs of B, C, M, X (written by tasks 1-3, read by the LogUp task)
+  uint32_t* partial;            // keccak chip: [B][13][2H] Fp4 scratch
   int logh, batch;
 };
 void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a);

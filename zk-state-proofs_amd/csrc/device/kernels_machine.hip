@@ -37,22 +37,27 @@ struct Col {
   size_t cs;
   __device__ __forceinline__ void put(int col, uint32_t monty) const { t[(size_t)col * cs] = monty; }
   __device__ __forceinline__ void val(int col, uint32_t canonical) const { t[(size_t)col * cs] = mont(canonical); }
+  __device__ __forceinline__ void flag(int col, bool on) const { t[(size_t)col * cs] = on ? kR1 : 0u; }
   __device__ __forceinline__ void bits(int col, uint32_t v, int n) const {
     for (int i = 0; i < n; ++i) t[(size_t)(col + i) * cs] = ((v >> i) & 1u) ? kR1 : 0u;
   }
   __device__ __forceinline__ void zero(int col, int n) const {
     for (int i = 0; i < n; ++i) t[(size_t)(col + i) * cs] = 0u;
   }
-  // an access-time difference as its two range-checked limbs
-  __device__ __forceinline__ void gap(int col, uint32_t v) const {
-    val(col, v & ((1u << kTsLimbBits) - 1));
-    val(col + 1, v >> kTsLimbBits);
+  // a 32-bit word as its two 16-bit limbs
+  __device__ __forceinline__ void limbs(int col, uint32_t v) const {
+    val(col, v & 0xffff);
+    val(col + 1, v >> 16);
   }
 };
 
-// One CPU instance: row r is cycle row0 + r (row0 = 0 for the first instance, its height for the second).
-__global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh, uint32_t row0,
-                                                       uint32_t* __restrict__ limbs) {
+__device__ __forceinline__ uint32_t less_than(uint32_t code, uint32_t b, uint32_t c) {
+  return code == SLT ? (uint32_t)((int32_t)b < (int32_t)c) : (uint32_t)(b < c);
+}
+
+// One CPU instance: row r is cycle row0 + r (row0 = 0 for the first instance, its height for the second); rows past
+// the last cycle execute the padding instruction (jal x0, 0 at the padding pc: reads x0, jumps to itself).
+__global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh, uint32_t row0) {
   const size_t h = (size_t)1 << logh;
   const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
   if (r >= h) return;
@@ -60,91 +65,149 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
   const Col o{trace + (size_t)b * kCpuWidth * h + r, h};
   const size_t cyc = (size_t)row0 + r;
   const uint32_t ts = 4 * ((uint32_t)cyc + 1);
-  if (cyc >= rec.counts[4 * b]) {  // padding: only the clock runs on
+  const uint32_t n_cycles = rec.counts[kCountWords * b];
+  const uint32_t pad_pc = rec.text_base + 4 * (rec.n_program - 1);
+  uint32_t gap[4] = {0, 0, 0, 0};
+  if (cyc >= n_cycles) {
+    const uint32_t pts = cyc == n_cycles ? rec.counts[kCountWords * b + 6] : ts - 4;
     o.zero(0, kCpuWidth);
+    o.val(C_PC, pad_pc);
     o.val(C_TS, ts);
-    const Col lim0{limbs + (size_t)b * 8 * h + r, h};
-    lim0.zero(0, 8);
+    o.val(C_NEXT_PC, pad_pc);
+    o.put(selc(CL_JAL), kR1);
+    o.limbs(C_TGT_LO, pad_pc);
+    o.val(C_R1_PTS, pts);
+    o.limbs(C_GAP, ts - pts - 1);
     return;
   }
   const uint32_t* cy = rec.cycles + ((size_t)b * rec.cap_cycles + cyc) * 12;
-  const uint32_t pc = cy[0], a = cy[1], bb = cy[2], c = cy[3], m = cy[4], mv = cy[5], wprev = cy[6];
+  const uint32_t pc = cy[0], bb = cy[2], c = cy[3], m = cy[4], mv = cy[5], wprev = cy[6];
+  uint32_t a = cy[1];
   const uint32_t* p = rec.program + 9 * (size_t)((pc - rec.text_base) >> 2);
   const uint32_t op = p[1], wr = p[2], use2 = p[3], rd = p[4], rs1 = p[5], rs2 = p[6], imm = p[7], tgt = p[8];
-  o.put(C_IS_REAL, kR1);
+  const int cls = class_of(op);
+  const uint32_t code = code_of(op);
   o.val(C_PC, pc);
   o.val(C_TS, ts);
-  for (int k = 0; k < kNumOps; ++k) o.put(C_OP + k, (uint32_t)k + 1 == op ? kR1 : 0u);
-  o.put(C_WR, wr ? kR1 : 0u);
-  o.put(C_USE2, use2 ? kR1 : 0u);
+  for (int k = 1; k <= kNumCls; ++k) o.flag(selc(k), k == cls);
+  o.val(C_CODE, code);
+  o.flag(C_WR, wr != 0);
+  o.flag(C_USE2, use2 != 0);
   o.val(C_RD, rd); o.val(C_RS1, rs1); o.val(C_RS2, rs2);
-  o.val(C_IMM_LO, imm & 0xffff); o.val(C_IMM_HI, imm >> 16); o.val(C_TGT, tgt);
-  o.val(C_A, a & 0xffff); o.val(C_A + 1, a >> 16);
-  o.bits(C_B, bb, 32); o.bits(C_C, c, 32); o.bits(C_M, m, 32);
-  const Col lim{limbs + (size_t)b * 8 * h + r, h};  // limbs of B, C, M (X below) for the LogUp trace
-  lim.val(0, bb & 0xffff); lim.val(1, bb >> 16); lim.val(2, c & 0xffff); lim.val(3, c >> 16);
-  lim.val(4, m & 0xffff); lim.val(5, m >> 16);
-  o.val(C_MV_LO, mv & 0xffff); o.val(C_MV_HI, mv >> 16);
-  uint32_t x = 0, next = pc + 4, k0 = 0, k1 = 0, k2 = 0, k3 = 0, eq = 0, inv = 0, off = 4, sc = 6;
-  const uint32_t blo = bb & 0xffff, bhi = bb >> 16, clo = c & 0xffff, chi = c >> 16, alo = a & 0xffff, ahi = a >> 16;
-  switch (op) {
-    case ADD: k0 = (blo + clo) >> 16; k1 = (bhi + chi + k0) >> 16; break;
-    case SUB: k0 = (alo + clo) >> 16; k1 = (ahi + chi + k0) >> 16; break;
-    case SLL: case SRL: case SRA: x = 1u << (c & 31); break;
-    case SLT: case SLTU: case BEQ: case BNE: case BLT: case BGE: case BLTU: case BGEU: {
-      const bool sgn = (op == SLT || op == BLT || op == BGE);
-      k0 = blo < clo;
-      const uint32_t dlo = blo - clo + 65536 * k0;
-      const uint32_t lt = sgn ? ((int32_t)bb < (int32_t)c) : (bb < c);
-      const int32_t dhi = (int32_t)bhi - (int32_t)chi - (int32_t)k0 + 65536 * (int32_t)lt +
-                          (sgn ? 65536 * ((int32_t)(c >> 31) - (int32_t)(bb >> 31)) : 0);
-      x = dlo | ((uint32_t)dhi << 16);
-      k1 = lt;
-      if (op == BEQ || op == BNE) {
-        const uint32_t z = dlo + (uint32_t)dhi;
-        eq = z == 0;
-        inv = z ? Fp::from_canonical(z).inv().v : 0u;  // Montgomery form already
-        if ((op == BEQ) == (z == 0)) next = tgt;
-      } else if (op == BLT || op == BLTU) { if (lt) next = tgt; }
-      else if (op == BGE || op == BGEU) { if (!lt) next = tgt; }
+  o.limbs(C_IMM_LO, imm);
+  o.limbs(C_TGT_LO, tgt);
+  uint32_t x = 0, next = pc + 4, k0 = 0, k1 = 0, maddr = 0, off = 4, sc = 6;
+  uint32_t x_lo_m = 0, x_hi_m = 0;  // beq / bne: the two limbs of X are inverses (Montgomery words)
+  const uint32_t blo = bb & 0xffff, bhi = bb >> 16, clo = c & 0xffff, chi = c >> 16;
+  switch (cls) {
+    case CL_ADD: x = a; k0 = (blo + clo) >> 16; k1 = (bhi + chi + k0) >> 16; break;
+    case CL_SUB: x = a; k0 = ((a & 0xffff) + clo) >> 16; k1 = ((a >> 16) + chi + k0) >> 16; break;
+    case CL_JAL: next = tgt; break;
+    case CL_JALR: case CL_LW: case CL_LDS:
+      x = bb + c; k0 = (blo + clo) >> 16; k1 = (bhi + chi + k0) >> 16;
+      if (cls == CL_JALR) { off = x & 1; next = x & ~1u; }
+      else { off = x & 3; maddr = x & ~3u; }
       break;
-    }
-    case JAL: next = tgt; break;
-    case JALR: case LB: case LH: case LW: case LBU: case LHU: case SB: case SH: case SW: {
-      const uint32_t ilo = imm & 0xffff, ihi = imm >> 16;
-      k2 = (blo + ilo) >> 16;
-      k3 = (bhi + ihi + k2) >> 16;
-      x = bb + imm;
-      if (op == JALR) next = x & ~1u;
-      else off = x & 3;
+    case CL_SW: case CL_STS:
+      x = bb + imm; k0 = (blo + (imm & 0xffff)) >> 16; k1 = (bhi + (imm >> 16) + k0) >> 16;
+      off = x & 3; maddr = x & ~3u;
       break;
-    }
-    case ECALL:
-      x = 11; off = 0;
+    case CL_BEQ: case CL_BNE:
+      k0 = blo == clo; k1 = bhi == chi;
+      x_lo_m = k0 ? 0u : (Fp::from_canonical(blo) - Fp::from_canonical(clo)).inv().v;
+      x_hi_m = k1 ? 0u : (Fp::from_canonical(bhi) - Fp::from_canonical(chi)).inv().v;
+      a = k0 & k1;
+      if ((cls == CL_BEQ) == (a != 0)) next = tgt;
+      break;
+    case CL_BLT: case CL_BGE:
+      a = less_than(code, bb, c);
+      if ((cls == CL_BLT) == (a != 0)) next = tgt;
+      break;
+    case CL_ECALL:
       sc = bb == 0x00 ? 0 : bb == 0x02 ? 1 : bb == 0x10 ? 2 : bb == 0x1a ? 3 : bb == 0xf0 ? 4 : bb == 0xf1 ? 5 : 6;
+      x = a; maddr = 11;
+      if (bb == 0x00) next = pad_pc;
       break;
-    case KECCAK: next = bb; break;
+    case CL_KECCAK: x = bb; next = bb; break;
     default: break;
   }
-  o.bits(C_X, x, 32);
-  lim.val(6, x & 0xffff); lim.val(7, x >> 16);
+  if (cls == CL_BEQ || cls == CL_BNE) { o.put(C_X, x_lo_m); o.put(C_X + 1, x_hi_m); }
+  else o.limbs(C_X, x);
+  o.limbs(C_A, a); o.limbs(C_B, bb); o.limbs(C_C, c); o.limbs(C_M, m); o.limbs(C_MV, mv);
+  o.flag(C_K0, k0 != 0); o.flag(C_K1, k1 != 0);
+  for (uint32_t i = 0; i < 4; ++i) o.flag(C_O0 + i, i == off);
+  o.val(C_MADDR, maddr);
+  for (uint32_t i = 0; i < 6; ++i) o.flag(C_SC + i, i == sc);
   o.val(C_NEXT_PC, next);
-  o.put(C_K0, k0 ? kR1 : 0u); o.put(C_K1, k1 ? kR1 : 0u); o.put(C_K2, k2 ? kR1 : 0u); o.put(C_K3, k3 ? kR1 : 0u);
-  o.put(C_EQ, eq ? kR1 : 0u);
-  o.put(C_INV, inv);
-  for (uint32_t i = 0; i < 4; ++i) o.put(C_O0 + i, i == off ? kR1 : 0u);
-  for (uint32_t i = 0; i < 6; ++i) o.put(C_SC + i, i == sc ? kR1 : 0u);
-  const bool memq = (op >= LB && op <= SW) || op == ECALL;
+  const bool memq = cls == CL_LW || cls == CL_SW || cls == CL_LDS || cls == CL_STS || cls == CL_ECALL;
   o.val(C_R1_PTS, cy[7]);
-  o.gap(C_R1_D, ts - cy[7] - 1);
+  gap[0] = ts - cy[7] - 1;
   o.val(C_R2_PTS, use2 ? cy[8] : 0u);
-  o.gap(C_R2_D, use2 ? ts - cy[8] : 0u);
+  if (use2) gap[1] = ts - cy[8];
   o.val(C_M_PTS, memq ? cy[9] : 0u);
-  o.gap(C_M_D, memq ? ts + 1 - cy[9] : 0u);
+  if (memq) gap[2] = ts + 1 - cy[9];
   o.val(C_W_PTS, wr ? cy[10] : 0u);
-  o.gap(C_W_D, wr ? ts + 2 - cy[10] : 0u);
+  if (wr) gap[3] = ts + 2 - cy[10];
   o.val(C_W_PLO, wr ? wprev & 0xffff : 0u);
   o.val(C_W_PHI, wr ? wprev >> 16 : 0u);
+  for (int q = 0; q < 4; ++q) o.limbs(C_GAP + 2 * q, gap[q]);
+}
+
+// One ALU-chip instance: row r is event row0 + r of the list alu_idx (cycle indices)
+__global__ __launch_bounds__(kMT) void alu_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh, uint32_t row0) {
+  const size_t h = (size_t)1 << logh;
+  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (r >= h) return;
+  const int b = blockIdx.y;
+  const Col o{trace + (size_t)b * kAluWidth * h + r, h};
+  const size_t ev = (size_t)row0 + r;
+  if (ev >= rec.counts[kCountWords * b + 4]) { o.zero(0, kAluWidth); return; }
+  const uint32_t cyc = rec.alu_idx[(size_t)b * rec.cap_alu + ev];
+  const uint32_t* cy = rec.cycles + ((size_t)b * rec.cap_cycles + cyc) * 12;
+  const uint32_t code = code_of(rec.program[9 * (size_t)((cy[0] - rec.text_base) >> 2) + 1]), bb = cy[2], c = cy[3];
+  uint32_t a = cy[1], x = 0, k0 = 0, k1 = 0;
+  if (code == SLL || code == SRL || code == SRA) x = 1u << (c & 31);
+  if (code == SLT || code == SLTU) {
+    const uint32_t blo = bb & 0xffff, bhi = bb >> 16, clo = c & 0xffff, chi = c >> 16;
+    const bool sgn = code == SLT;
+    k0 = blo < clo;
+    k1 = less_than(code, bb, c);
+    const uint32_t dlo = blo - clo + 65536 * k0;
+    const int32_t dhi = (int32_t)bhi - (int32_t)chi - (int32_t)k0 + 65536 * (int32_t)k1 +
+                        (sgn ? 65536 * ((int32_t)(c >> 31) - (int32_t)(bb >> 31)) : 0);
+    x = dlo | ((uint32_t)dhi << 16);
+    a = k1;
+  }
+  o.put(AL_IS_REAL, kR1);
+  for (uint32_t k = 0; k < 8; ++k) o.flag(AL_SEL + k, XOR + k == code);
+  o.limbs(AL_A, a);
+  o.bits(AL_B, bb, 32); o.bits(AL_C, c, 32); o.bits(AL_X, x, 32);
+  o.flag(AL_K0, k0 != 0); o.flag(AL_K1, k1 != 0);
+}
+
+// One sub-word-chip instance: row r is event row0 + r of the list sub_idx
+__global__ __launch_bounds__(kMT) void sub_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh, uint32_t row0) {
+  const size_t h = (size_t)1 << logh;
+  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (r >= h) return;
+  const int b = blockIdx.y;
+  const Col o{trace + (size_t)b * kSubWidth * h + r, h};
+  const size_t ev = (size_t)row0 + r;
+  if (ev >= rec.counts[kCountWords * b + 5]) { o.zero(0, kSubWidth); return; }
+  const uint32_t cyc = rec.sub_idx[(size_t)b * rec.cap_sub + ev];
+  const uint32_t* cy = rec.cycles + ((size_t)b * rec.cap_cycles + cyc) * 12;
+  const uint32_t* p = rec.program + 9 * (size_t)((cy[0] - rec.text_base) >> 2);
+  const uint32_t code = p[1], a = cy[1], bb = cy[2], c = cy[3], m = cy[4], mv = cy[5];
+  const bool store = code == SB || code == SH;
+  const uint32_t off = (bb + p[7]) & 3;
+  const uint32_t sel = code == LB ? 0 : code == LH ? 1 : code == LBU ? 2 : code == LHU ? 3 : code == SB ? 4 : 5;
+  o.put(SW_IS_REAL, kR1);
+  for (uint32_t k = 0; k < 6; ++k) o.flag(SW_SEL + k, k == sel);
+  for (uint32_t k = 0; k < 4; ++k) o.flag(SW_O + k, k == off);
+  o.limbs(SW_A, store ? 0u : a);
+  o.bits(SW_M, m, 32);
+  o.bits(SW_C, c & 0xffff, 16);
+  o.limbs(SW_MV, mv);
 }
 
 __device__ __forceinline__ uint64_t m_rol64(uint64_t v, int n) { return n ? (v << n) | (v >> (64 - n)) : v; }
@@ -188,7 +251,7 @@ __global__ __launch_bounds__(64) void kmem_trace_kernel(MachineRecords rec, uint
   o.val(KM_IDX, i);
   o.put(KM_ISF, i == 0 ? kR1 : 0u);
   o.put(KM_ISL, i == 49 ? kR1 : 0u);
-  if (p >= rec.counts[4 * b + 1]) return;
+  if (p >= rec.counts[kCountWords * b + 1]) return;
   const KCall* k = reinterpret_cast<const KCall*>(rec.kcalls + ((size_t)b * rec.cap_keccak + p) * 408);
   uint64_t st[25];
 #pragma unroll
@@ -207,7 +270,7 @@ __global__ __launch_bounds__(64) void kmem_trace_kernel(MachineRecords rec, uint
   o.val(KM_OLD_LO, wi & 0xffff); o.val(KM_OLD_HI, wi >> 16);
   o.val(KM_NEW_LO, wo & 0xffff); o.val(KM_NEW_HI, wo >> 16);
   o.val(KM_PTS, k->pts[i]);
-  o.gap(KM_D, k->ts + 1 - k->pts[i]);
+  o.limbs(KM_GL, k->ts + 1 - k->pts[i]);
 }
 
 __global__ __launch_bounds__(kMT) void memfinal_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh) {
@@ -216,16 +279,25 @@ __global__ __launch_bounds__(kMT) void memfinal_trace_kernel(MachineRecords rec,
   if (r >= h) return;
   const int b = blockIdx.y;
   const Col o{trace + (size_t)b * kMemFinalWidth * h + r, h};
-  const uint32_t n = rec.counts[4 * b + 2];
+  const uint32_t n = rec.counts[kCountWords * b + 2];
   if (r >= n) { o.zero(0, kMemFinalWidth); return; }
   const uint32_t* f = rec.memfinal + ((size_t)b * rec.cap_memfinal + r) * 5;
   o.put(MF_IS_REAL, kR1);
-  o.val(MF_ADDR, f[0]);
-  o.put(MF_IS_INIT, f[4] ? kR1 : 0u);
-  o.val(MF_FIN_LO, f[2] & 0xffff); o.val(MF_FIN_HI, f[2] >> 16);
+  o.limbs(MF_LO, f[0]);
+  o.flag(MF_IS_INIT, f[4] != 0);
+  o.limbs(MF_INIT_LO, f[1]);
+  o.limbs(MF_FIN_LO, f[2]);
   o.val(MF_FIN_TS, f[3]);
-  o.bits(MF_DIFF, r + 1 < n ? f[5] - f[0] - 1 : 0u, 32);
-  o.bits(MF_INIT, f[4] ? f[1] : 0u, 32);
+  uint32_t d_lo = 0, d_hi = 0, bw = 0;
+  if (r + 1 < n) {  // next address - address - 1, limb-wise with a borrow
+    const uint32_t nx = f[5];
+    bw = (nx & 0xffff) < (f[0] & 0xffff) + 1;
+    d_lo = (nx & 0xffff) + 65536 * bw - (f[0] & 0xffff) - 1;
+    d_hi = (nx >> 16) - (f[0] >> 16) - bw;
+  }
+  o.val(MF_D_LO, d_lo);
+  o.val(MF_D_HI, d_hi);
+  o.flag(MF_BW, bw != 0);
 }
 
 __global__ __launch_bounds__(64) void mul_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh) {
@@ -234,7 +306,7 @@ __global__ __launch_bounds__(64) void mul_trace_kernel(MachineRecords rec, uint3
   if (r >= h) return;
   const int b = blockIdx.y;
   const Col o{trace + (size_t)b * kMulWidth * h + r, h};
-  if (r >= rec.counts[4 * b + 3]) { o.zero(0, kMulWidth); return; }
+  if (r >= rec.counts[kCountWords * b + 3]) { o.zero(0, kMulWidth); return; }
   const uint32_t* mu = rec.muls + ((size_t)b * rec.cap_muls + r) * 3;
   const uint32_t bb = mu[1], c = mu[2];
   const uint64_t prod = (uint64_t)bb * c;
@@ -257,72 +329,32 @@ __global__ __launch_bounds__(kMT) void count_column_kernel(const uint32_t* __res
   trace[(size_t)blockIdx.y * n + r] = mont(src[(size_t)blockIdx.y * n + r]);
 }
 
-// Range table multiplicities: how often each 12-bit value occurs among the live access-time limbs of the CPU and
-// keccak-memory chips.  A workgroup counts its slice of the records in LDS, then adds its non-zero bins to
-// hist[b][.] (zeroed by the launcher).
-constexpr int kRangeBlocks = 64;
-__global__ __launch_bounds__(kMT) void range_count_kernel(MachineRecords rec, uint32_t* __restrict__ hist) {
-  constexpr uint32_t kBins = 1u << kTsLimbBits;
-  __shared__ uint32_t bins[kBins];
-  const int b = blockIdx.y;
-  for (uint32_t i = threadIdx.x; i < kBins; i += kMT) bins[i] = 0;
-  __syncthreads();
-  auto count = [&](uint32_t gap) {
-    if ((gap >> kTsLimbBits) >= kBins) return;  // no valid proof exists for such a run; the prover still terminates
-    atomicAdd(&bins[gap & (kBins - 1)], 1u);
-    atomicAdd(&bins[gap >> kTsLimbBits], 1u);
-  };
-  const uint32_t n = rec.counts[4 * b];
-  for (uint32_t r = blockIdx.x * kMT + threadIdx.x; r < n; r += gridDim.x * kMT) {
-    const uint32_t* cy = rec.cycles + ((size_t)b * rec.cap_cycles + r) * 12;
-    const uint32_t* p = rec.program + 9 * (size_t)((cy[0] - rec.text_base) >> 2);
-    const uint32_t op = p[1], ts = 4 * (r + 1);
-    count(ts - cy[7] - 1);
-    if (p[3]) count(ts - cy[8]);
-    if ((op >= LB && op <= SW) || op == ECALL) count(ts + 1 - cy[9]);
-    if (p[2]) count(ts + 2 - cy[10]);
-  }
-  const uint32_t nk = rec.counts[4 * b + 1] * 50;
-  for (uint32_t j = blockIdx.x * kMT + threadIdx.x; j < nk; j += gridDim.x * kMT) {
-    const KCall* k = reinterpret_cast<const KCall*>(rec.kcalls + ((size_t)b * rec.cap_keccak + j / 50) * 408);
-    count(k->ts + 1 - k->pts[j % 50]);
-  }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < kBins; i += kMT)
-    if (bins[i]) atomicAdd(&hist[(size_t)b * kBins + i], bins[i]);
+// image chip: every word of the image is sent once (the main column repeats the preprocessed is-real flag)
+__global__ __launch_bounds__(kMT) void image_used_kernel(uint32_t* __restrict__ trace, size_t n, uint32_t n_image) {
+  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (r >= n) return;
+  trace[(size_t)blockIdx.y * n + r] = r < n_image ? kR1 : 0u;
 }
 
 void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& rec, uint32_t* trace, int logh, int batch) {
   const size_t h = (size_t)1 << logh;
+  const dim3 grid((unsigned)((h + kMT - 1) / kMT), batch), block(kMT);
   switch (chip) {
-    case kRange:
-      (void)hipMemsetAsync(rec.range_hist, 0, (size_t)batch * h * 4, stream);
-      hipLaunchKernelGGL(range_count_kernel, dim3(kRangeBlocks, batch), dim3(kMT), 0, stream, rec, rec.range_hist);
-      hipLaunchKernelGGL(count_column_kernel, dim3((unsigned)((h + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec.range_hist, trace, h);
-      break;
     case kCpu:
-      hipLaunchKernelGGL(cpu_trace_kernel, dim3((unsigned)((h + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec, trace, logh, 0u,
-                         rec.cpu_limbs[0]);
-      break;
-    case kCpu2:
-      hipLaunchKernelGGL(cpu_trace_kernel, dim3((unsigned)((h + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec, trace, logh,
-                         rec.cpu2_row0, rec.cpu_limbs[1]);
-      break;
+    case kCpu2: hipLaunchKernelGGL(cpu_trace_kernel, grid, block, 0, stream, rec, trace, logh, rec.row0[chip]); break;
+    case kAlu:
+    case kAlu2: hipLaunchKernelGGL(alu_trace_kernel, grid, block, 0, stream, rec, trace, logh, rec.row0[chip]); break;
+    case kSub:
+    case kSub2: hipLaunchKernelGGL(sub_trace_kernel, grid, block, 0, stream, rec, trace, logh, rec.row0[chip]); break;
     case kKmem:
       hipLaunchKernelGGL(kmem_trace_kernel, dim3((unsigned)((h + 63) / 64), batch), dim3(64), 0, stream, rec, trace, logh);
       break;
-    case kMemFinal:
-      hipLaunchKernelGGL(memfinal_trace_kernel, dim3((unsigned)((h + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec, trace, logh);
-      break;
+    case kMemFinal: hipLaunchKernelGGL(memfinal_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
     case kMul:
       hipLaunchKernelGGL(mul_trace_kernel, dim3((unsigned)((h + 63) / 64), batch), dim3(64), 0, stream, rec, trace, logh);
       break;
-    case kImage:
-      hipLaunchKernelGGL(count_column_kernel, dim3((unsigned)((h + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec.image_used, trace, h);
-      break;
-    case kProgram:
-      hipLaunchKernelGGL(count_column_kernel, dim3((unsigned)((h + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec.prog_mult, trace, h);
-      break;
+    case kImage: hipLaunchKernelGGL(image_used_kernel, grid, block, 0, stream, trace, h, rec.n_image); break;
+    case kProgram: hipLaunchKernelGGL(count_column_kernel, grid, block, 0, stream, rec.prog_mult, trace, h); break;
     default: break;
   }
 }
@@ -334,7 +366,7 @@ __global__ __launch_bounds__(kMT) void keccak_ts_kernel(MachineRecords rec, uint
   const int b = blockIdx.y;
   const uint32_t p = (uint32_t)(r / 24);
   uint32_t v = 0;
-  if (p < rec.counts[4 * b + 1]) v = mont(reinterpret_cast<const KCall*>(rec.kcalls + ((size_t)b * rec.cap_keccak + p) * 408)->ts);
+  if (p < rec.counts[kCountWords * b + 1]) v = mont(reinterpret_cast<const KCall*>(rec.kcalls + ((size_t)b * rec.cap_keccak + p) * 408)->ts);
   trace[(size_t)b * bstride + (size_t)KC_TS * h + r] = v;
 }
 void launch_keccak_ts(hipStream_t stream, const MachineRecords& rec, uint32_t* trace, size_t trace_bstride, int logh, int batch) {
@@ -521,91 +553,62 @@ __device__ __forceinline__ Fp4 m_fingerprint(const Interaction& it, const RowVie
   return f;
 }
 
-// The CPU chip's 13 bus interactions evaluated from values a row holds once (limbs by Horner from the bit
-// columns, the packed opcode, the effective address), instead of through the generic linear forms (which
-// reload and rescale every bit for every tuple): the same field elements, about a fifth of the work.
-// visit(j, ma, fa, mb, fb, pair) is called for the helper columns j = 0..6 in order; multiplicities are signed.
-template <class V>
-__device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, size_t cs, const uint32_t* __restrict__ limbs,
-                                              const Fp4& gamma, const uint32_t* __restrict__ bpow, V&& visit) {
-  auto col = [&](int c) { return Fp::raw(row[(size_t)c * cs]); };
-  // the 16-bit limbs of the bit blocks B, C, M, X were left by whoever streamed the bits (trace expansion, quotient
-  // tasks 1-3): 8 column reads here instead of 128
-  auto limb = [&](int k) { return Fp::raw(limbs[(size_t)k * cs]); };
-  const Fp a_lo = col(C_A), a_hi = col(C_A + 1), b_lo = limb(0), b_hi = limb(1), c_lo = limb(2), c_hi = limb(3), m_lo = limb(4),
-           m_hi = limb(5), x_lo = limb(6), x_hi = limb(7);
-  const Fp k65536 = Fp::raw(cmonty(65536));
-  const Fp maddr = x_lo + k65536 * x_hi - (col(C_O1) + col(C_O2).dbl() + Fp::raw(cmonty(3)) * col(C_O3));
-  Fp opid = Fp::zero(), memq = Fp::zero();
-  Fp kf = Fp::zero();
-  for (int k = 1; k <= kNumOps; ++k) {
-    kf = kf + Fp::one();
-    const Fp o = col(C_OP + k - 1);
-    opid = opid + kf * o;
-    if ((k >= LB && k <= SW) || k == ECALL) memq = memq + o;
-  }
-  const Fp is_real = col(C_IS_REAL), ts = col(C_TS), wr = col(C_WR), use2 = col(C_USE2), rd = col(C_RD), rs1 = col(C_RS1),
-           rs2 = col(C_RS2);
-  const Fp4 b1 = m_load_fp4(bpow + 4), b2 = m_load_fp4(bpow + 8), b3 = m_load_fp4(bpow + 12), b4 = m_load_fp4(bpow + 16);
-  auto busc = [&](int bus) {
-    Fp4 f = gamma;
-    f.c[0] += Fp::raw(cmonty((uint32_t)bus));
-    return f;
-  };
-  const Fp4 gmem = busc(BUS_MEM);
-  auto mem = [&](Fp addr, Fp lo, Fp hi, Fp t) { return gmem + b1 * addr + b2 * lo + b3 * hi + b4 * t; };
-  const Fp one = Fp::one(), two = Fp::raw(cmonty(2)), three = Fp::raw(cmonty(3));
-  {  // helper 0: instruction fetch (receive), rs1 consume
-    Fp4 f = busc(BUS_PROG) + b1 * col(C_PC) + b2 * opid + b3 * wr + b4 * use2;
-    f += m_load_fp4(bpow + 20) * rd + m_load_fp4(bpow + 24) * rs1 + m_load_fp4(bpow + 28) * rs2 +
-         m_load_fp4(bpow + 32) * col(C_IMM_LO) + m_load_fp4(bpow + 36) * col(C_IMM_HI) + m_load_fp4(bpow + 40) * col(C_TGT);
-    visit(0, -is_real, f, -is_real, mem(rs1, b_lo, b_hi, col(C_R1_PTS)), true);
-  }
-  visit(1, is_real, mem(rs1, b_lo, b_hi, ts), -use2, mem(rs2, c_lo, c_hi, col(C_R2_PTS)), true);
-  visit(2, use2, mem(rs2, c_lo, c_hi, ts + one), -memq, mem(maddr, m_lo, m_hi, col(C_M_PTS)), true);
-  visit(3, memq, mem(maddr, col(C_MV_LO), col(C_MV_HI), ts + two), -wr, mem(rd, col(C_W_PLO), col(C_W_PHI), col(C_W_PTS)), true);
-  {
-    const Fp kecc = col(C_OP + KECCAK - 1);
-    visit(4, wr, mem(rd, a_lo, a_hi, ts + three), kecc, busc(BUS_KCALL) + b1 * ts + b2 * c_lo + b3 * c_hi, true);
-  }
-  {
-    const Fp mulhu = col(C_OP + MULHU - 1), mulsel = col(C_OP + MUL - 1) + mulhu;
-    const Fp4 fm = busc(BUS_MUL) + b1 * mulhu + b2 * a_lo + b3 * a_hi + b4 * b_lo + m_load_fp4(bpow + 20) * b_hi +
-                   m_load_fp4(bpow + 24) * c_lo + m_load_fp4(bpow + 28) * c_hi;
-    const Fp scc = col(C_SC + SC_COMMIT), scd = col(C_SC + SC_DEFER);
-    visit(5, mulsel, fm, scc + scd, busc(BUS_PUBC) + b1 * (scc + scd.dbl()) + b2 * c_lo + b3 * m_lo + b4 * m_hi, true);
-  }
-  // the limbs of the four access-time differences, looked up in the range table while their access is live
-  const Fp4 grng = busc(BUS_RANGE);
-  auto rng = [&](int c) { return grng + b1 * col(c); };
-  visit(6, col(C_SC + SC_HALT), busc(BUS_PUBH) + b1 * c_lo + b2 * c_hi, -is_real, rng(C_R1_D), true);
-  visit(7, -is_real, rng(C_R1_D + 1), -use2, rng(C_R2_D), true);
-  visit(8, -use2, rng(C_R2_D + 1), -memq, rng(C_M_D), true);
-  visit(9, -memq, rng(C_M_D + 1), -wr, rng(C_W_D), true);
-  visit(10, -wr, rng(C_W_D + 1), Fp::zero(), gamma, false);
-}
-
-// Four waves per SIMD (128 VGPRs, a few dozen spilled): the 21 inversions are long dependent chains and the
-// kernel issued at half rate with two waves (11.1 -> 9.2 ms per 32 proofs).
-__global__ __launch_bounds__(kMT, 4) void perm_terms_cpu_kernel(PermArgs a) {
-  const size_t h = (size_t)1 << a.logh;
-  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
-  if (r >= h) return;
+// ===========================================================================================
+// table chip multiplicities: the RANGE / BYTES receives of a chip's rows, counted per table row
+// ===========================================================================================
+constexpr int kTableRowsPerBlock = 2048;
+constexpr uint32_t kTableLdsBins = 8192;  // the low range16 values and the byte pairs with a small second byte are hot
+constexpr size_t kTableRows = (size_t)1 << kTableLogH;
+__global__ __launch_bounds__(kMT) void table_count_kernel(const Interaction* __restrict__ inter, int n_inter,
+                                                         const uint32_t* __restrict__ trace, int width, int logh,
+                                                         uint32_t* __restrict__ hist) {
+  __shared__ uint32_t lds[2 * kTableLdsBins];
+  const size_t h = (size_t)1 << logh;
   const int b = blockIdx.y;
-  const Fp4 gamma = m_load_fp4(a.bus_ch + (size_t)b * 8);
-  const uint32_t* bpow = a.bpow + (size_t)b * (kInterMaxElems + 1) * 4;
-  uint32_t* p = a.perm + (size_t)b * a.perm_bstride + r;
-  Fp4 tot = Fp4::zero();
-  cpu_bus_pairs(a.main_.p + (size_t)b * a.main_.bstride + r, h, a.limbs + (size_t)b * 8 * h + r, gamma, bpow,
-                [&](int j, Fp ma, const Fp4& fa, Fp mb, const Fp4& fb, bool pair) {
-                  Fp4 hj = Fp4::zero();
-                  if (ma.v != 0) hj += fa.inv() * ma;
-                  if (pair && mb.v != 0) hj += fb.inv() * mb;
-#pragma unroll
-                  for (int t = 0; t < 4; ++t) p[(size_t)(4 * j + t) * h] = hj.c[t].v;
-                  tot += hj;
-                });
-  m_store_fp4(a.rowsum + ((size_t)b * h + r) * 4, tot);
+  for (uint32_t i = threadIdx.x; i < 2 * kTableLdsBins; i += kMT) lds[i] = 0;
+  __syncthreads();
+  uint32_t* hb = hist + (size_t)b * 3 * kTableRows;
+  const size_t r0 = (size_t)blockIdx.x * kTableRowsPerBlock;
+  const size_t r1 = r0 + kTableRowsPerBlock < h ? r0 + kTableRowsPerBlock : h;
+  for (size_t r = r0 + threadIdx.x; r < r1; r += kMT) {
+    const RowView rv{nullptr, trace + (size_t)b * width * h + r, 0, h};
+    for (int k = 0; k < n_inter; ++k) {
+      const Interaction& it = inter[k];
+      if (it.sign > 0 || (it.bus != BUS_RANGE && it.bus != BUS_BYTES)) continue;
+      const uint32_t m = m_lf_eval(it.mult, rv).to_canonical();
+      if (m == 0) continue;
+      const uint32_t v1 = m_lf_eval(it.el[0], rv).to_canonical(), v2 = m_lf_eval(it.el[1], rv).to_canonical();
+      if (it.bus == BUS_RANGE) {
+        // a value without a table row is not counted: the buses of such a (dishonest or unprovable) run do not balance
+        if (v2 >= kTableRows || v1 > 1 || (v1 == 1 && (v2 & 3))) continue;
+        if (v1 == 0 && v2 < kTableLdsBins) atomicAdd(&lds[v2], m);
+        else atomicAdd(&hb[(size_t)(v1 ? TB_M_AL : TB_M_R16) * kTableRows + v2], m);
+      } else {
+        if (v1 > 255 || v2 > 255) continue;
+        const uint32_t idx = v1 + 256 * v2;
+        if (idx < kTableLdsBins) atomicAdd(&lds[kTableLdsBins + idx], m);
+        else atomicAdd(&hb[(size_t)TB_M_BY * kTableRows + idx], m);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < kTableLdsBins; i += kMT) {
+    if (lds[i]) atomicAdd(&hb[(size_t)TB_M_R16 * kTableRows + i], lds[i]);
+    if (lds[kTableLdsBins + i]) atomicAdd(&hb[(size_t)TB_M_BY * kTableRows + i], lds[kTableLdsBins + i]);
+  }
+}
+void launch_table_clear(hipStream_t stream, const MachineRecords& rec, int batch) {
+  (void)hipMemsetAsync(rec.table_hist, 0, (size_t)batch * 3 * kTableRows * 4, stream);
+}
+void launch_table_count(hipStream_t stream, const Interaction* inter, int n_inter, const uint32_t* trace, int width, int logh,
+                        const MachineRecords& rec, int batch) {
+  const size_t h = (size_t)1 << logh;
+  hipLaunchKernelGGL(table_count_kernel, dim3((unsigned)((h + kTableRowsPerBlock - 1) / kTableRowsPerBlock), batch), dim3(kMT), 0, stream,
+                     inter, n_inter, trace, width, logh, rec.table_hist);
+}
+void launch_table_trace(hipStream_t stream, const MachineRecords& rec, uint32_t* trace, int batch) {
+  const size_t n = 3 * kTableRows;
+  hipLaunchKernelGGL(count_column_kernel, dim3((unsigned)((n + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec.table_hist, trace, n);
 }
 
 __global__ __launch_bounds__(kMT) void perm_terms_kernel(PermArgs a) {
@@ -739,10 +742,7 @@ __global__ __launch_bounds__(kMT) void perm_slice_scan_kernel(PermArgs a, const 
 
 void launch_perm_trace(hipStream_t stream, const PermArgs& a) {
   const size_t h = (size_t)1 << a.logh;
-  if (is_cpu_chip(a.chip))
-    hipLaunchKernelGGL(perm_terms_cpu_kernel, dim3((unsigned)((h + kMT - 1) / kMT), a.batch), dim3(kMT), 0, stream, a);
-  else
-    hipLaunchKernelGGL(perm_terms_kernel, dim3((unsigned)((h + kMT - 1) / kMT), a.batch), dim3(kMT), 0, stream, a);
+  hipLaunchKernelGGL(perm_terms_kernel, dim3((unsigned)((h + kMT - 1) / kMT), a.batch), dim3(kMT), 0, stream, a);
   if (h >= (size_t)4 * kScanSlice && a.slice_sums) {
     const int nslices = (int)(h / kScanSlice);
     hipLaunchKernelGGL(perm_slice_sum_kernel, dim3(nslices, a.batch), dim3(kMT), 0, stream, a, a.slice_sums, nslices);
@@ -789,25 +789,20 @@ struct MQCtx {
   using F = Fp;
   const uint32_t* loc;
   const uint32_t* nxt;
+  const uint32_t* prp;  // this point of the preprocessed LDE (same column stride), or null
   size_t cs;
   Fp first, trans, last;
-  uint32_t pub_[4];
+  uint32_t pub_[kNumCpuPub];
   const uint32_t* ap;
   int k_;
   Fp4 acc;
   int64_t lazy[4];
   int pending;
-  uint32_t* stash_;    // CPU task 2: this lane's column of a [32][kMT] LDS array
+  uint32_t* stash_;    // ALU task 1: this lane's column of a [32][kMT] LDS array
   __device__ __forceinline__ void stash(int i, F v) const { stash_[i * kMT] = v.v; }
   __device__ __forceinline__ F stashed(int i) const { return Fp::raw(stash_[i * kMT]); }
-  uint32_t* limb_out;  // CPU chip: this point's slot in MQuotArgs::limbs (stride cs), or null
-  __device__ __forceinline__ void note_limbs(int block, F lo, F hi) const {
-    if (limb_out) {
-      limb_out[(size_t)(2 * block) * cs] = lo.v;
-      limb_out[(size_t)(2 * block + 1) * cs] = hi.v;
-    }
-  }
   __device__ __forceinline__ F local(int col) const { return Fp::raw(loc[(size_t)col * cs]); }
+  __device__ __forceinline__ F prep(int col) const { return Fp::raw(prp[(size_t)col * cs]); }
   __device__ __forceinline__ F next(int col) const { return Fp::raw(nxt[(size_t)col * cs]); }
   __device__ __forceinline__ F is_first() const { return first; }
   __device__ __forceinline__ F is_trans() const { return trans; }
@@ -830,19 +825,6 @@ struct MQCtx {
   }
   __device__ __forceinline__ void emit(F v) { emit_at(k_++, v); }
   __device__ __forceinline__ void set_count(int n) { k_ = n; }
-  // sum x[i] * y[i * ystep] through a signed 64-bit lazy sum: both centred (|.| <= p/2), eight terms between
-  // shrinks (field.hpp)
-  __device__ __forceinline__ F sum_prod(const F* x, const F* y, int ystep, int n) const {
-    int64_t t = 0;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      if (i < n) {
-        t += (int64_t)fps_centre(x[i].v) * (int64_t)fps_centre(y[i * ystep].v);
-        if ((i & 7) == 7) t = (int64_t)fps_fold(t) * (int64_t)kRModP;
-      }
-    }
-    return Fp::raw(fps_canon(fps_fold(t)));
-  }
   __device__ __forceinline__ void flush() {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -930,14 +912,14 @@ __device__ __forceinline__ void init_ctx(const MQuotArgs& a, const PointInfo& pi
   ctx->first = pi.first;
   ctx->trans = pi.trans;
   ctx->last = pi.last;
+  ctx->prp = a.prep.width ? a.prep.p + (size_t)pi.b * a.prep.bstride + (size_t)pi.c * h + pi.m : nullptr;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) ctx->pub_[i] = a.pubs ? a.pubs[(size_t)pi.b * a.pubs_bstride + i] : 0u;
+  for (int i = 0; i < kNumCpuPub; ++i) ctx->pub_[i] = a.pubs ? a.pubs[(size_t)pi.b * a.pubs_bstride + i] : 0u;
   ctx->ap = a.alpha_pows + (size_t)pi.b * a.alpha_bstride;
   ctx->k_ = 0;
   ctx->acc = Fp4::zero();
   ctx->lazy[0] = ctx->lazy[1] = ctx->lazy[2] = ctx->lazy[3] = 0;
   ctx->pending = 0;
-  ctx->limb_out = a.limbs ? a.limbs + (size_t)pi.b * 8 * n + (size_t)pi.c * h + pi.m : nullptr;
   ctx->stash_ = nullptr;
 }
 
@@ -951,87 +933,22 @@ __global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
   point_selectors(a, pt, &pi);
   MQCtx ctx;
   init_ctx(a, pi, &ctx);
-  if (CHIP == kKmem) eval_kmem(ctx);
-  else if (CHIP == kMemFinal) eval_memfinal(ctx);
-  else if (CHIP == kImage) eval_image(ctx);
-  else if (CHIP == kMul) eval_mul(ctx);
+  __shared__ uint32_t stash[is_alu_chip(CHIP) ? 32 * kMT : 1];  // the ALU chip parks B's 32 bits per lane (MQCtx::stash)
+  ctx.stash_ = stash + (is_alu_chip(CHIP) ? threadIdx.x : 0);
+  if constexpr (is_cpu_chip(CHIP)) eval_cpu(ctx);
+  else if constexpr (CHIP == kKmem) eval_kmem(ctx);
+  else if constexpr (CHIP == kMemFinal) eval_memfinal(ctx);
+  else if constexpr (CHIP == kImage) eval_image(ctx);
+  else if constexpr (CHIP == kMul) eval_mul(ctx);
+  else if constexpr (CHIP == kTable) eval_table(ctx);
+  else if constexpr (is_alu_chip(CHIP)) eval_alu(ctx);
+  else if constexpr (is_sub_chip(CHIP)) eval_sub(ctx);
   ctx.flush();
   logup_constraints(a, pi, &ctx.acc);
   const Fp4 q = ctx.acc * Fp::raw(pi.c ? a.zh_inv[1] : a.zh_inv[0]);
   uint32_t* dst = a.quot + (size_t)pi.b * 8 * h + pi.m;
 #pragma unroll
   for (int j = 0; j < 4; ++j) dst[(size_t)(4 * pi.c + j) * h] = q.c[j].v;
-}
-
-// CPU chip: its four constraint tasks (air_machine.hpp) and the LogUp constraints as five launches, each
-// with its own register budget; every launch leaves one partial extension-field sum per point.
-template <int TASK>
-__global__ __launch_bounds__(kMT) void cpu_quotient_task_kernel(MQuotArgs a) {
-  const size_t h = (size_t)1 << a.logh, n = 2 * h;
-  const size_t pt = (size_t)blockIdx.x * kMT + threadIdx.x;
-  if (pt >= n) return;
-  PointInfo pi;
-  pi.b = blockIdx.y;
-  point_selectors(a, pt, &pi);
-  MQCtx ctx;
-  init_ctx(a, pi, &ctx);
-  __shared__ uint32_t stash[TASK == 2 ? 32 * kMT : 1];  // task 2 parks B's 32 bits per lane (MQCtx::stash)
-  ctx.stash_ = stash + (TASK == 2 ? threadIdx.x : 0);
-  if (TASK < kCpuTasks) {
-    eval_cpu_task<TASK>(ctx);
-    ctx.flush();
-  } else {
-    // the LogUp constraints with the CPU chip's fingerprints computed by cpu_bus_pairs
-    const int b = pi.b;
-    const Fp4 gamma = m_load_fp4(a.bus_ch + (size_t)b * 8);
-    const uint32_t* bpow = a.bpow + (size_t)b * (kInterMaxElems + 1) * 4;
-    const uint32_t* ap = a.alpha_pows + (size_t)b * a.alpha_bstride;
-    const uint32_t* pl = a.perm.p + (size_t)b * a.perm.bstride + (size_t)pi.c * h;
-    constexpr int nh = 11;
-    Fp4 hsum = Fp4::zero(), acc = Fp4::zero();
-    cpu_bus_pairs(a.main_.p + (size_t)b * a.main_.bstride + pt, n, a.limbs + (size_t)b * 8 * n + pt, gamma, bpow,
-                  [&](int j, Fp ma, const Fp4& fa, Fp mb, const Fp4& fb, bool pair) {
-                    Fp4 hj;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) hj.c[t] = Fp::raw(pl[(size_t)(4 * j + t) * n + pi.m]);
-                    hsum += hj;
-                    Fp4 v;
-                    if (pair) {
-                      v = hj * fa * fb - (fb * ma + fa * mb);
-                    } else {
-                      v = hj * fa;
-                      v.c[0] -= ma;
-                    }
-                    acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + j)) * v;
-                  });
-    Fp4 phi, phin;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      phi.c[t] = Fp::raw(pl[(size_t)(4 * nh + t) * n + pi.m]);
-      phin.c[t] = Fp::raw(pl[(size_t)(4 * nh + t) * n + pi.mn]);
-    }
-    const Fp4 cum = m_load_fp4(a.cum + (size_t)b * a.cum_bstride);
-    acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh)) * (phi * pi.first);
-    acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh + 1)) * ((phin - phi - hsum) * pi.trans);
-    acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh + 2)) * ((cum - phi - hsum) * pi.last);
-    ctx.acc = acc;
-  }
-  m_store_fp4(a.partial + (((size_t)pi.b * (kCpuTasks + 1) + TASK) * n + pt) * 4, ctx.acc);
-}
-__global__ __launch_bounds__(kMT) void cpu_quotient_combine_kernel(MQuotArgs a) {
-  const size_t h = (size_t)1 << a.logh, n = 2 * h;
-  const size_t pt = (size_t)blockIdx.x * kMT + threadIdx.x;
-  if (pt >= n) return;
-  const int b = blockIdx.y;
-  const int c = pt >= h ? 1 : 0;
-  const size_t m = pt - (size_t)c * h;
-  Fp4 acc = Fp4::zero();
-#pragma unroll
-  for (int g = 0; g <= kCpuTasks; ++g) acc += m_load_fp4(a.partial + (((size_t)b * (kCpuTasks + 1) + g) * n + pt) * 4);
-  acc = acc * Fp::raw(c ? a.zh_inv[1] : a.zh_inv[0]);
-  uint32_t* q = a.quot + (size_t)b * 8 * h + m;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) q[(size_t)(4 * c + j) * h] = acc.c[j].v;
 }
 
 // keccak chip: p3-keccak-air's 12 evaluation tasks (air_keccak.hpp) plus one task for the call-time
@@ -1086,20 +1003,17 @@ void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a) {
   const dim3 grid((unsigned)((n + kMT - 1) / kMT), a.batch), block(kMT);
   switch (a.chip) {
     case kCpu:
-    case kCpu2:
-      hipLaunchKernelGGL(cpu_quotient_task_kernel<0>, grid, block, 0, stream, a);
-      hipLaunchKernelGGL(cpu_quotient_task_kernel<1>, grid, block, 0, stream, a);
-      hipLaunchKernelGGL(cpu_quotient_task_kernel<2>, grid, block, 0, stream, a);
-      hipLaunchKernelGGL(cpu_quotient_task_kernel<3>, grid, block, 0, stream, a);
-      hipLaunchKernelGGL(cpu_quotient_task_kernel<4>, grid, block, 0, stream, a);
-      hipLaunchKernelGGL(cpu_quotient_combine_kernel, grid, block, 0, stream, a);
-      break;
+    case kCpu2: hipLaunchKernelGGL(machine_quotient_kernel<kCpu>, grid, block, 0, stream, a); break;
+    case kAlu:
+    case kAlu2: hipLaunchKernelGGL(machine_quotient_kernel<kAlu>, grid, block, 0, stream, a); break;
+    case kSub:
+    case kSub2: hipLaunchKernelGGL(machine_quotient_kernel<kSub>, grid, block, 0, stream, a); break;
     case kKmem: hipLaunchKernelGGL(machine_quotient_kernel<kKmem>, grid, block, 0, stream, a); break;
     case kMemFinal: hipLaunchKernelGGL(machine_quotient_kernel<kMemFinal>, grid, block, 0, stream, a); break;
     case kImage: hipLaunchKernelGGL(machine_quotient_kernel<kImage>, grid, block, 0, stream, a); break;
     case kProgram: hipLaunchKernelGGL(machine_quotient_kernel<kProgram>, grid, block, 0, stream, a); break;
     case kMul: hipLaunchKernelGGL(machine_quotient_kernel<kMul>, grid, block, 0, stream, a); break;
-    case kRange: hipLaunchKernelGGL(machine_quotient_kernel<kRange>, grid, block, 0, stream, a); break;
+    case kTable: hipLaunchKernelGGL(machine_quotient_kernel<kTable>, grid, block, 0, stream, a); break;
     case kKeccak: {
       const int blocks = (int)((n + kMT - 1) / kMT), total_tiles = blocks * a.batch;
       hipLaunchKernelGGL(keccak_machine_quotient_kernel, dim3((unsigned)total_tiles * ka::kNumTasks), block, 0, stream, a, blocks,

@@ -11,7 +11,7 @@
 
 using namespace zksp;
 
-// Header (version, chip heights, exit code, digests, key digest), public values, body: the v5 proof object.
+// Header (version, chip heights, exit code, digests, key digest), public values, body: the v6 proof object.
 int machine_proof_from_parts(const zksp_pk* pk, const ExecutionRecord& r, const int* lh, uint32_t handover_pc, const uint32_t* body,
                              size_t body_words, zksp_proof** out) {
   zksp_proof* p = new (std::nothrow) zksp_proof();
@@ -83,7 +83,8 @@ int zksp_mtrace_section(const zksp_mtrace* t, int which, const void** ptr, size_
     case ZKSP_MT_MEMFINAL: *ptr = m.memfinal.data(); *bytes = m.memfinal.size() * sizeof(MemFinalRec); break;
     case ZKSP_MT_MULS: *ptr = m.muls.data(); *bytes = m.muls.size() * sizeof(MulRec); break;
     case ZKSP_MT_PROG_MULT: *ptr = m.prog_mult.data(); *bytes = m.prog_mult.size() * 4; break;
-    case ZKSP_MT_IMAGE_USED: *ptr = m.image_used.data(); *bytes = m.image_used.size() * 4; break;
+    case ZKSP_MT_ALU_IDX: *ptr = m.alu_idx.data(); *bytes = m.alu_idx.size() * 4; break;
+    case ZKSP_MT_SUB_IDX: *ptr = m.sub_idx.data(); *bytes = m.sub_idx.size() * 4; break;
     case ZKSP_MT_PROGRAM: *ptr = t->prog->rows.data(); *bytes = t->prog->rows.size() * sizeof(ProgramRow); break;
     case ZKSP_MT_IMAGE: *ptr = t->prog->image.data(); *bytes = t->prog->image.size() * sizeof(ImageRow); break;
     case ZKSP_MT_PUBLIC_VALUES: *ptr = m.rec.public_values.data(); *bytes = m.rec.public_values.size(); break;
@@ -178,7 +179,7 @@ int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const 
   if (!pk || !t || !body || !out) return ZKSP_ERR_INVALID_ARG;
   int lh[mach::kNumChips];
   machine_heights(*t->prog, t->t, lh);
-  return machine_proof_from_parts(pk, t->t.rec, lh, machine_handover_pc(t->t), body, body_words, out);
+  return machine_proof_from_parts(pk, t->t.rec, lh, machine_handover_pc(*t->prog, t->t), body, body_words, out);
 }
 
 int zksp_vk_machine(const zksp_vk* vk, uint32_t* prep_root8, uint32_t* digest8) {

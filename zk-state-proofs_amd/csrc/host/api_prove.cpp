@@ -115,7 +115,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       traces[i].reset(new zksp_mtrace());
       traces[i]->prog = &pk->mprog;
       trace_execute(pk->elf, pk->mprog, stdins[i]->entries, (uint64_t)1 << 21, &traces[i]->t);
-      traces[i]->handover_pc = machine_handover_pc(traces[i]->t);
+      traces[i]->handover_pc = machine_handover_pc(pk->mprog, traces[i]->t);
       stdins[i]->entries.clear();  // consumed, as SP1Stdin is by prove()
     } catch (...) {
       traces[i].reset(new zksp_mtrace());
@@ -189,7 +189,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     for (size_t j = 0; j < ck.idx.size(); ++j) {
       MachineTrace& t = traces[ck.idx[j]]->t;
       dead[j].cycles.swap(t.cycles); dead[j].keccak.swap(t.keccak); dead[j].memfinal.swap(t.memfinal);
-      dead[j].muls.swap(t.muls); dead[j].prog_mult.swap(t.prog_mult); dead[j].image_used.swap(t.image_used);
+      dead[j].muls.swap(t.muls); dead[j].prog_mult.swap(t.prog_mult); dead[j].alu_idx.swap(t.alu_idx); dead[j].sub_idx.swap(t.sub_idx);
     }
     try {
       reaper.th.emplace_back([d = std::move(dead)]() mutable { d.clear(); });

@@ -158,6 +158,11 @@ std::string build_machine_program(const ElfImage& elf, KeccakMode mode, MachineP
     }
     out->rows[i] = r;
   }
+  {
+    // the padding instruction: jal x0, 0 right after the text segment
+    const uint32_t pc = elf.text_base + 4 * (uint32_t)n;
+    out->rows.push_back(ProgramRow{pc, AIR_JAL, 0, 0, 0, 0, 0, 0, pc});
+  }
   for (uint32_t i = 0; i < 32; ++i) out->image.push_back({i, 0});
   std::vector<const ElfImage::Seg*> segs;
   for (const auto& s : elf.segs) segs.push_back(&s);
@@ -214,10 +219,8 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
   std::vector<Touched> touched;
   out->cycles.reserve((size_t)1 << 19);  // virtual pages only: what is not written is never touched
   out->prog_mult.assign(prog.rows.size(), 0);
-  out->image_used.assign(prog.image.size(), 0);
   uint32_t x[32] = {0}, reg_ts[32] = {0};
-  bool reg_touched[32] = {false};
-  const uint32_t text_lo = prog.text_base, text_bytes = 4 * (uint32_t)prog.rows.size();
+  const uint32_t text_lo = prog.text_base, text_bytes = 4 * (uint32_t)(prog.rows.size() - 1);  // the padding row is not code
   size_t stdin_pos = 0;
   uint64_t cycles = 0;
 
@@ -231,7 +234,6 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
       uint32_t v;
       memcpy(&v, M + w, 4);
       const int64_t ir = image_row(w);
-      if (ir >= 0) out->image_used[(size_t)ir] = 1;
       touched.push_back({w, v, 0, ir < 0 ? 1u : 0u});
       id = (uint32_t)touched.size();
       SH[w >> 2] = id;
@@ -262,35 +264,35 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
       CycleRec c{};
       c.pc = pc;
       c.b = x[r.rs1];
-      c.r1_pts = reg_ts[r.rs1]; reg_ts[r.rs1] = ts; reg_touched[r.rs1] = true;
+      c.r1_pts = reg_ts[r.rs1]; reg_ts[r.rs1] = ts;
       if (r.use2) {
         c.c = x[r.rs2];
-        c.r2_pts = reg_ts[r.rs2]; reg_ts[r.rs2] = ts + 1; reg_touched[r.rs2] = true;
+        c.r2_pts = reg_ts[r.rs2]; reg_ts[r.rs2] = ts + 1;
       } else {
         c.c = r.imm;
       }
       const uint32_t a = c.b, b = c.c;
       uint32_t res = 0, next = pc + 4;
-      bool halt = false;
+      bool halt = false, alu_event = false;
       switch (r.op) {
         case AIR_ADD: res = a + b; break;
         case AIR_SUB: res = a - b; break;
-        case AIR_XOR: res = a ^ b; break;
-        case AIR_OR: res = a | b; break;
-        case AIR_AND: res = a & b; break;
-        case AIR_SLL: res = a << (b & 31); break;
-        case AIR_SRL: res = a >> (b & 31); break;
-        case AIR_SRA: res = (uint32_t)((int32_t)a >> (b & 31)); break;
-        case AIR_SLT: res = (int32_t)a < (int32_t)b; break;
-        case AIR_SLTU: res = a < b; break;
+        case AIR_XOR: res = a ^ b; alu_event = true; break;
+        case AIR_OR: res = a | b; alu_event = true; break;
+        case AIR_AND: res = a & b; alu_event = true; break;
+        case AIR_SLL: res = a << (b & 31); alu_event = true; break;
+        case AIR_SRL: res = a >> (b & 31); alu_event = true; break;
+        case AIR_SRA: res = (uint32_t)((int32_t)a >> (b & 31)); alu_event = true; break;
+        case AIR_SLT: res = (int32_t)a < (int32_t)b; alu_event = true; break;
+        case AIR_SLTU: res = a < b; alu_event = true; break;
         case AIR_JAL: res = r.imm; next = r.tgt; break;
         case AIR_JALR: res = r.tgt; next = (a + r.imm) & ~1u; break;
         case AIR_BEQ: if (a == b) next = r.tgt; break;
         case AIR_BNE: if (a != b) next = r.tgt; break;
-        case AIR_BLT: if ((int32_t)a < (int32_t)b) next = r.tgt; break;
-        case AIR_BGE: if ((int32_t)a >= (int32_t)b) next = r.tgt; break;
-        case AIR_BLTU: if (a < b) next = r.tgt; break;
-        case AIR_BGEU: if (a >= b) next = r.tgt; break;
+        case AIR_BLT: if ((int32_t)a < (int32_t)b) next = r.tgt; alu_event = true; break;
+        case AIR_BGE: if ((int32_t)a >= (int32_t)b) next = r.tgt; alu_event = true; break;
+        case AIR_BLTU: if (a < b) next = r.tgt; alu_event = true; break;
+        case AIR_BGEU: if (a >= b) next = r.tgt; alu_event = true; break;
         case AIR_MUL: res = a * b; out->muls.push_back({0, a, b}); break;
         case AIR_MULHU: res = (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); out->muls.push_back({1, a, b}); break;
         case AIR_LB: case AIR_LH: case AIR_LW: case AIR_LBU: case AIR_LHU: {
@@ -309,6 +311,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
           else if (r.op == AIR_LH) res = (uint32_t)(int32_t)(int16_t)((c.m >> sh) & 0xffff);
           else if (r.op == AIR_LBU) res = (c.m >> sh) & 0xff;
           else res = (uint32_t)(int32_t)(int8_t)((c.m >> sh) & 0xff);
+          if (r.op != AIR_LW) out->sub_idx.push_back((uint32_t)(cycles - 1));
           ++rec.memory_ops;
           break;
         }
@@ -326,6 +329,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
           else if (r.op == AIR_SH) c.mv = (c.m & ~(0xffffu << sh)) | ((b & 0xffff) << sh);
           else c.mv = (c.m & ~(0xffu << sh)) | ((b & 0xff) << sh);
           memcpy(M + w, &c.mv, 4);
+          if (r.op != AIR_SW) out->sub_idx.push_back((uint32_t)(cycles - 1));
           ++rec.memory_ops;
           break;
         }
@@ -333,7 +337,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
           // t0 = a (code), a0 = b; a1 is read through the memory slot (register address 11)
           const uint32_t codeid = a, a0 = b, a1 = x[11], a2 = x[12];
           c.m = a1; c.mv = a1;
-          c.m_pts = reg_ts[11]; reg_ts[11] = ts + 2; reg_touched[11] = true;
+          c.m_pts = reg_ts[11]; reg_ts[11] = ts + 2;
           rec.syscall_counts[codeid & 0xff]++;
           res = a;  // t0 is rewritten with itself except by HINT_LEN
           switch (codeid) {
@@ -396,9 +400,10 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
         default: FAULT("internal: unknown AIR op");
       }
       c.a = res;
+      if (alu_event) out->alu_idx.push_back((uint32_t)(cycles - 1));
       if (r.wr) {
         c.w_prev = x[r.rd];
-        c.w_pts = reg_ts[r.rd]; reg_ts[r.rd] = ts + 3; reg_touched[r.rd] = true;
+        c.w_pts = reg_ts[r.rd]; reg_ts[r.rd] = ts + 3;
         x[r.rd] = res;
       }
       out->cycles.push_back(c);
@@ -411,17 +416,34 @@ done:
 #undef CHECK_ADDR
   rec.cycles = cycles;
   if (!rec.error.empty()) return;
-  // every touched address, strictly increasing: registers first (addresses 0..31), then memory words
-  for (uint32_t i = 0; i < 32; ++i)
-    if (reg_touched[i]) {
-      out->memfinal.push_back({i, 0, x[i], reg_ts[i], 0});
-      out->image_used[i] = 1;
+  {
+    // the CPU rows after the last cycle execute the padding instruction, which reads x0 once per row
+    const size_t rows = split_rows((size_t)cycles) + split_rest_rows((size_t)cycles);
+    out->x0_last = reg_ts[0];
+    if (rows > cycles) {
+      out->prog_mult.back() = (uint32_t)(rows - cycles);
+      reg_ts[0] = 4 * (uint32_t)rows;
     }
+  }
+  // every image address (registers first: addresses 0..31) and every other touched address once, strictly increasing:
+  // an untouched image word is closed with the value and the time (0) it was opened with
   std::sort(touched.begin(), touched.end(), [](const Touched& p, const Touched& q) { return p.addr < q.addr; });
-  for (const Touched& t : touched) {
-    uint32_t fin;
-    memcpy(&fin, M + t.addr, 4);
-    out->memfinal.push_back({t.addr, t.init, fin, t.last_ts, t.is_init});
+  out->memfinal.reserve(prog.image.size() + touched.size());
+  for (uint32_t i = 0; i < 32; ++i) out->memfinal.push_back({i, 0, x[i], reg_ts[i], 0});
+  {
+    size_t ti = 0;
+    auto emit_touched = [&](const Touched& t) {
+      uint32_t fin;
+      memcpy(&fin, M + t.addr, 4);
+      out->memfinal.push_back({t.addr, t.init, fin, t.last_ts, t.is_init});
+    };
+    for (size_t r = 32; r < prog.image.size(); ++r) {
+      const ImageRow& im = prog.image[r];
+      while (ti < touched.size() && touched[ti].addr < im.addr) emit_touched(touched[ti++]);
+      if (ti < touched.size() && touched[ti].addr == im.addr) emit_touched(touched[ti++]);
+      else out->memfinal.push_back({im.addr, im.val, im.val, 0, 0});
+    }
+    while (ti < touched.size()) emit_touched(touched[ti++]);
   }
 }
 

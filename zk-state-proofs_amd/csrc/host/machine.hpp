@@ -29,7 +29,8 @@ enum AirOp : uint32_t {
   AIR_NUM_OPS  // 31: ops are 1..30
 };
 
-// One row of the preprocessed Program table (9 u32).
+// One row of the preprocessed Program table (9 u32).  The table ends with the padding instruction: `jal x0, 0` at
+// the first address after the text segment, which the CPU rows after HALT execute (it jumps to itself).
 struct ProgramRow {
   uint32_t pc, op, wr, use2, rd, rs1, rs2, imm, tgt;
 };
@@ -40,7 +41,8 @@ struct ImageRow {
 };
 
 struct MachineProgram {
-  std::vector<ProgramRow> rows;  // one per instruction word of the text segment, in address order
+  std::vector<ProgramRow> rows;  // one per instruction word of the text segment, in address order, then the padding row
+  uint32_t pad_pc() const { return rows.empty() ? 0 : rows.back().pc; }
   std::vector<ImageRow> image;   // sorted by addr
   uint32_t entry = 0;
   uint32_t text_base = 0;
@@ -101,11 +103,27 @@ struct MachineTrace {
   ExecutionRecord rec;  // cycles, exit code, public values, digests, error text
   std::vector<CycleRec, PageAllocator<CycleRec>> cycles;
   std::vector<KeccakCall> keccak;
-  std::vector<MemFinalRec> memfinal;  // every touched address, strictly increasing
+  std::vector<MemFinalRec> memfinal;  // every image address and every other touched address, strictly increasing
   std::vector<MulRec> muls;
-  std::vector<uint32_t> prog_mult;    // per Program row
-  std::vector<uint32_t> image_used;   // per Image row: 0 / 1
+  std::vector<uint32_t> prog_mult;    // per Program row (the padding row: the CPU rows after the last cycle)
+  std::vector<uint32_t> alu_idx;      // cycles that occupy a row of the ALU chip (xor .. sltu, blt .. bgeu), in order
+  std::vector<uint32_t> sub_idx;      // cycles that occupy a row of the sub-word chip (lb lh lbu lhu sb sh), in order
+  uint32_t x0_last = 0;               // last access time of x0 by a real cycle (the first padding row consumes it)
 };
+
+// rows of the first of two instances of a chip: the largest power of two strictly below the count (at least 32);
+// the second instance takes the rest, rounded up to a power of two (at least 32)
+inline size_t split_rows(size_t n) {
+  size_t h0 = 32;
+  while (2 * h0 < n) h0 *= 2;
+  return h0;
+}
+inline size_t split_rest_rows(size_t n) {
+  const size_t h0 = split_rows(n);
+  size_t h1 = 32;
+  while (h1 < (n > h0 ? n - h0 : 1)) h1 *= 2;
+  return h1;
+}
 
 // Builds the two preprocessed tables.  Returns "" or an error.
 std::string build_machine_program(const ElfImage& elf, KeccakMode mode, MachineProgram* out);

@@ -1,11 +1,14 @@
-// See machine_defs.hpp.  Bus protocol (DESIGN.md "Machine proof"):
+// See machine_defs.hpp.  Bus protocol (DESIGN.md "Machine proof", format v6):
 //   MEM    (addr, lo, hi, time)   every access consumes its predecessor's tuple and produces its own
-//   PROG   (pc, op, wr, use2, rd, rs1, rs2, imm_lo, imm_hi, tgt)   instruction fetch
+//   PROG   (pc, class, code, wr, use2, rd, rs1, rs2, imm_lo, imm_hi, tgt_lo, tgt_hi)   instruction fetch, every CPU row
 //   KCALL  (time, ptr_lo, ptr_hi)   CPU -> keccak-memory: one precompile call
 //   KIO    (time, word index, in_lo, in_hi, out_lo, out_hi)   keccak-f chip -> keccak-memory
-//   MUL    (hi, a_lo, a_hi, b_lo, b_hi, c_lo, c_hi)   CPU -> multiplier
+//   ALU    (op, a_lo, a_hi, b_lo, b_hi, c_lo, c_hi)   CPU -> ALU chip / multiplier
+//   SUB    (op, byte offset, a_lo, a_hi, m_lo, m_hi, c_lo, mv_lo, mv_hi)   CPU -> sub-word chip
 //   PUBC   (kind, index, lo, hi), PUBH (exit_lo, exit_hi)   CPU -> verifier
-//   RANGE  (value)   a 12-bit limb of an access-time difference, looked up in the range table
+//   RANGE  (kind, value)   value < 2^16 (kind 0), and a multiple of 4 (kind 1): table chip
+//   BYTES  (x, y)   two bytes: table chip
+//   IMG    (addr, lo, hi)   image chip -> memory boundary: the initial value of an image address
 #include "machine_defs.hpp"
 
 #include <cstdlib>
@@ -38,13 +41,30 @@ LinForm lf_const(uint32_t c) {
   f.c0 = mont(c);
   return f;
 }
-LinForm lf_limb(int bits, int limb) {
-  LinForm f = lf_zero();
-  for (int i = 0; i < 16; ++i) lf_add(f, bits + 16 * limb + i, (uint64_t)1 << i);
-  return f;
-}
 LinForm lf_plus(LinForm f, uint32_t c) {
   f.c0 = (Fp::raw(f.c0) + Fp::raw(mont(c))).v;
+  return f;
+}
+LinForm lf_pair(int a, int b, uint64_t k) {  // a + k * b
+  LinForm f = lf_zero();
+  lf_add(f, a, 1);
+  lf_add(f, b, k);
+  return f;
+}
+LinForm lf_sum(std::initializer_list<int> cols) {
+  LinForm f = lf_zero();
+  for (int c : cols) lf_add(f, c, 1);
+  return f;
+}
+LinForm lf_const_minus(uint32_t c, int col) {  // c - col
+  LinForm f = lf_zero();
+  lf_add(f, col, kP - 1);
+  f.c0 = mont(c);
+  return f;
+}
+LinForm lf_bits(int bits, int n) {
+  LinForm f = lf_zero();
+  for (int i = 0; i < n; ++i) lf_add(f, bits + i, (uint64_t)1 << i);
   return f;
 }
 Interaction mem_inter(int sign, const LinForm& mult, const LinForm& addr, const LinForm& lo, const LinForm& hi, const LinForm& ts) {
@@ -53,72 +73,89 @@ Interaction mem_inter(int sign, const LinForm& mult, const LinForm& addr, const 
   it.el[0] = addr; it.el[1] = lo; it.el[2] = hi; it.el[3] = ts;
   return it;
 }
-
-Interaction range_inter(int sign, const LinForm& mult, const LinForm& value) {
+Interaction range_inter(int sign, const LinForm& mult, const LinForm& kind, const LinForm& value) {
   Interaction it{};
-  it.bus = BUS_RANGE; it.sign = sign; it.mult = mult; it.n_el = 1;
-  it.el[0] = value;
+  it.bus = BUS_RANGE; it.sign = sign; it.mult = mult; it.n_el = 2;
+  it.el[0] = kind; it.el[1] = value;
+  return it;
+}
+Interaction bytes_inter(int sign, const LinForm& mult, const LinForm& x, const LinForm& y) {
+  Interaction it{};
+  it.bus = BUS_BYTES; it.sign = sign; it.mult = mult; it.n_el = 2;
+  it.el[0] = x; it.el[1] = y;
   return it;
 }
 
-Interaction g_cpu[21], g_keccak[50], g_kmem[6], g_memfinal[2], g_image[1], g_program[1], g_mul[2], g_range[1];
+constexpr int kCpuInter = 23;
+Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[3], g_alu[1], g_sub[1];
 ChipDef g_chips[kNumChips];
 
 void build() {
-  const LinForm is_real = lf_col(C_IS_REAL), ts = lf_col(C_TS);
-  const LinForm a_lo = lf_col(C_A), a_hi = lf_col(C_A + 1), b_lo = lf_limb(C_B, 0), b_hi = lf_limb(C_B, 1),
-                c_lo = lf_limb(C_C, 0), c_hi = lf_limb(C_C, 1), m_lo = lf_limb(C_M, 0), m_hi = lf_limb(C_M, 1);
+  const LinForm one = lf_const(1), zero = lf_const(0), ts = lf_col(C_TS);
+  const LinForm a_lo = lf_col(C_A), a_hi = lf_col(C_A + 1), b_lo = lf_col(C_B), b_hi = lf_col(C_B + 1), c_lo = lf_col(C_C),
+                c_hi = lf_col(C_C + 1), m_lo = lf_col(C_M), m_hi = lf_col(C_M + 1);
   {
     Interaction& it = g_cpu[0];
     it = Interaction{};
-    it.bus = BUS_PROG; it.sign = -1; it.mult = is_real; it.n_el = 10;
+    it.bus = BUS_PROG; it.sign = -1; it.mult = one; it.n_el = 12;
     it.el[0] = lf_col(C_PC);
     it.el[1] = lf_zero();
-    for (int k = 1; k <= kNumOps; ++k) lf_add(it.el[1], C_OP + k - 1, (uint64_t)k);
-    it.el[2] = lf_col(C_WR); it.el[3] = lf_col(C_USE2); it.el[4] = lf_col(C_RD); it.el[5] = lf_col(C_RS1);
-    it.el[6] = lf_col(C_RS2); it.el[7] = lf_col(C_IMM_LO); it.el[8] = lf_col(C_IMM_HI); it.el[9] = lf_col(C_TGT);
+    for (int k = 1; k <= kNumCls; ++k) lf_add(it.el[1], selc(k), (uint64_t)k);
+    it.el[2] = lf_col(C_CODE); it.el[3] = lf_col(C_WR); it.el[4] = lf_col(C_USE2); it.el[5] = lf_col(C_RD);
+    it.el[6] = lf_col(C_RS1); it.el[7] = lf_col(C_RS2); it.el[8] = lf_col(C_IMM_LO); it.el[9] = lf_col(C_IMM_HI);
+    it.el[10] = lf_col(C_TGT_LO); it.el[11] = lf_col(C_TGT_HI);
   }
-  g_cpu[1] = mem_inter(-1, is_real, lf_col(C_RS1), b_lo, b_hi, lf_col(C_R1_PTS));
-  g_cpu[2] = mem_inter(+1, is_real, lf_col(C_RS1), b_lo, b_hi, ts);
+  g_cpu[1] = mem_inter(-1, one, lf_col(C_RS1), b_lo, b_hi, lf_col(C_R1_PTS));
+  g_cpu[2] = mem_inter(+1, one, lf_col(C_RS1), b_lo, b_hi, ts);
   g_cpu[3] = mem_inter(-1, lf_col(C_USE2), lf_col(C_RS2), c_lo, c_hi, lf_col(C_R2_PTS));
   g_cpu[4] = mem_inter(+1, lf_col(C_USE2), lf_col(C_RS2), c_lo, c_hi, lf_plus(ts, 1));
   {
-    LinForm memq = lf_zero(), maddr = lf_zero();
-    for (int k = LB; k <= SW; ++k) lf_add(memq, C_OP + k - 1, 1);
-    lf_add(memq, C_OP + ECALL - 1, 1);
-    // word address = X as a value (mod p: guest addresses stay below 0x78000000 < p) - byte offset
-    for (int i = 0; i < 32; ++i) lf_add(maddr, C_X + i, (uint64_t)1 << i);
-    lf_add(maddr, C_O1, kP - 1); lf_add(maddr, C_O2, kP - 2); lf_add(maddr, C_O3, kP - 3);
-    g_cpu[5] = mem_inter(-1, memq, maddr, m_lo, m_hi, lf_col(C_M_PTS));
-    g_cpu[6] = mem_inter(+1, memq, maddr, lf_col(C_MV_LO), lf_col(C_MV_HI), lf_plus(ts, 2));
-    // the limbs of the four access-time differences are looked up when their access is live
-    for (int j = 0; j < kTsLimbs; ++j) {
-      g_cpu[13 + j] = range_inter(-1, is_real, lf_col(C_R1_D + j));
-      g_cpu[15 + j] = range_inter(-1, lf_col(C_USE2), lf_col(C_R2_D + j));
-      g_cpu[17 + j] = range_inter(-1, memq, lf_col(C_M_D + j));
-      g_cpu[19 + j] = range_inter(-1, lf_col(C_WR), lf_col(C_W_D + j));
-    }
+    const LinForm memq = lf_sum({selc(CL_LW), selc(CL_SW), selc(CL_LDS), selc(CL_STS), selc(CL_ECALL)});
+    g_cpu[5] = mem_inter(-1, memq, lf_col(C_MADDR), m_lo, m_hi, lf_col(C_M_PTS));
+    g_cpu[6] = mem_inter(+1, memq, lf_col(C_MADDR), lf_col(C_MV), lf_col(C_MV + 1), lf_plus(ts, 2));
   }
   g_cpu[7] = mem_inter(-1, lf_col(C_WR), lf_col(C_RD), lf_col(C_W_PLO), lf_col(C_W_PHI), lf_col(C_W_PTS));
   g_cpu[8] = mem_inter(+1, lf_col(C_WR), lf_col(C_RD), a_lo, a_hi, lf_plus(ts, 3));
+  // access-time differences: every row looks up its four low limbs and the two pairs of high bytes
+  for (int q = 0; q < 4; ++q) g_cpu[9 + q] = range_inter(-1, one, zero, lf_col(C_GAP + 2 * q));
+  g_cpu[13] = bytes_inter(-1, one, lf_col(C_GAP + 1), lf_col(C_GAP + 3));
+  g_cpu[14] = bytes_inter(-1, one, lf_col(C_GAP + 5), lf_col(C_GAP + 7));
   {
-    Interaction& kc = g_cpu[9];
+    // the adder output is canonical, an address is word-aligned once its byte offset is taken off, and addresses,
+    // jump targets and the keccak call's return address stay below 0x78000000
+    const LinForm chk = lf_sum({selc(CL_ADD), selc(CL_SUB), selc(CL_JALR), selc(CL_LW), selc(CL_SW), selc(CL_LDS), selc(CL_STS),
+                                selc(CL_ECALL), selc(CL_KECCAK)});
+    LinForm xoff = lf_col(C_X);
+    lf_add(xoff, C_O1, kP - 1); lf_add(xoff, C_O2, kP - 2); lf_add(xoff, C_O3, kP - 3);
+    g_cpu[15] = range_inter(-1, chk, zero, lf_col(C_X + 1));
+    g_cpu[16] = range_inter(-1, chk, lf_sum({selc(CL_JALR), selc(CL_LW), selc(CL_SW), selc(CL_LDS), selc(CL_STS)}), xoff);
+    g_cpu[17] = range_inter(-1, lf_sum({selc(CL_JALR), selc(CL_LW), selc(CL_SW), selc(CL_LDS), selc(CL_STS), selc(CL_KECCAK)}), zero,
+                            lf_const_minus(kAddrHiMax, C_X + 1));
+  }
+  {
+    Interaction& al = g_cpu[18];
+    al = Interaction{};
+    al.bus = BUS_ALU; al.sign = +1; al.mult = lf_sum({selc(CL_ALU), selc(CL_BLT), selc(CL_BGE)}); al.n_el = 7;
+    al.el[0] = lf_col(C_CODE);
+    al.el[1] = a_lo; al.el[2] = a_hi; al.el[3] = b_lo; al.el[4] = b_hi; al.el[5] = c_lo; al.el[6] = c_hi;
+    Interaction& sb = g_cpu[19];
+    sb = Interaction{};
+    sb.bus = BUS_SUB; sb.sign = +1; sb.mult = lf_sum({selc(CL_LDS), selc(CL_STS)}); sb.n_el = 9;
+    sb.el[0] = lf_col(C_CODE);
+    sb.el[1] = lf_zero(); lf_add(sb.el[1], C_O1, 1); lf_add(sb.el[1], C_O2, 2); lf_add(sb.el[1], C_O3, 3);
+    sb.el[2] = a_lo; sb.el[3] = a_hi; sb.el[4] = m_lo; sb.el[5] = m_hi; sb.el[6] = c_lo;
+    sb.el[7] = lf_col(C_MV); sb.el[8] = lf_col(C_MV + 1);
+    Interaction& kc = g_cpu[20];
     kc = Interaction{};
-    kc.bus = BUS_KCALL; kc.sign = +1; kc.mult = lf_col(C_OP + KECCAK - 1); kc.n_el = 3;
+    kc.bus = BUS_KCALL; kc.sign = +1; kc.mult = lf_col(selc(CL_KECCAK)); kc.n_el = 3;
     kc.el[0] = ts; kc.el[1] = c_lo; kc.el[2] = c_hi;
-    Interaction& mu = g_cpu[10];
-    mu = Interaction{};
-    mu.bus = BUS_MUL; mu.sign = +1; mu.n_el = 7;
-    mu.mult = lf_zero(); lf_add(mu.mult, C_OP + MUL - 1, 1); lf_add(mu.mult, C_OP + MULHU - 1, 1);
-    mu.el[0] = lf_col(C_OP + MULHU - 1);
-    mu.el[1] = a_lo; mu.el[2] = a_hi; mu.el[3] = b_lo; mu.el[4] = b_hi; mu.el[5] = c_lo; mu.el[6] = c_hi;
-    Interaction& pc = g_cpu[11];
+    Interaction& pc = g_cpu[21];
     pc = Interaction{};
     pc.bus = BUS_PUBC; pc.sign = +1; pc.n_el = 4;
-    pc.mult = lf_zero(); lf_add(pc.mult, C_SC + SC_COMMIT, 1); lf_add(pc.mult, C_SC + SC_DEFER, 1);
-    pc.el[0] = lf_zero(); lf_add(pc.el[0], C_SC + SC_COMMIT, 1); lf_add(pc.el[0], C_SC + SC_DEFER, 2);
+    pc.mult = lf_pair(C_SC + SC_COMMIT, C_SC + SC_DEFER, 1);
+    pc.el[0] = lf_pair(C_SC + SC_COMMIT, C_SC + SC_DEFER, 2);
     pc.el[1] = c_lo; pc.el[2] = m_lo; pc.el[3] = m_hi;
-    Interaction& ph = g_cpu[12];
+    Interaction& ph = g_cpu[22];
     ph = Interaction{};
     ph.bus = BUS_PUBH; ph.sign = +1; ph.mult = lf_col(C_SC + SC_HALT); ph.n_el = 2;
     ph.el[0] = c_lo; ph.el[1] = c_hi;
@@ -145,37 +182,85 @@ void build() {
     io.el[4] = lf_col(KM_NEW_LO); io.el[5] = lf_col(KM_NEW_HI);
     g_kmem[2] = mem_inter(-1, lf_col(KM_IS_REAL), lf_col(KM_ADDR), lf_col(KM_OLD_LO), lf_col(KM_OLD_HI), lf_col(KM_PTS));
     g_kmem[3] = mem_inter(+1, lf_col(KM_IS_REAL), lf_col(KM_ADDR), lf_col(KM_NEW_LO), lf_col(KM_NEW_HI), lf_plus(lf_col(KM_TS), 2));
-    for (int j = 0; j < kTsLimbs; ++j) g_kmem[4 + j] = range_inter(-1, lf_col(KM_IS_REAL), lf_col(KM_D + j));
+    g_kmem[4] = range_inter(-1, lf_col(KM_IS_REAL), zero, lf_col(KM_GL));
+    g_kmem[5] = bytes_inter(-1, lf_col(KM_IS_REAL), lf_col(KM_GH), zero);
+    // the state pointer is word-aligned and the 200 bytes end below 0x78000000
+    g_kmem[6] = range_inter(-1, lf_col(KM_CALL), one, lf_col(KM_PTR_LO));
+    g_kmem[7] = range_inter(-1, lf_col(KM_CALL), zero, lf_const_minus(kAddrHiMax - 1, KM_PTR_HI));
   }
-  g_memfinal[0] = mem_inter(-1, lf_col(MF_IS_REAL), lf_col(MF_ADDR), lf_col(MF_FIN_LO), lf_col(MF_FIN_HI), lf_col(MF_FIN_TS));
-  g_memfinal[1] = mem_inter(+1, lf_col(MF_IS_INIT), lf_col(MF_ADDR), lf_limb(MF_INIT, 0), lf_limb(MF_INIT, 1), lf_const(0));
-  g_image[0] = mem_inter(+1, lf_col(kImagePrepWidth + 0), lf_col(IMG_P_ADDR), lf_col(IMG_P_LO), lf_col(IMG_P_HI), lf_const(0));
   {
-    Interaction& it = g_program[0];
-    it = Interaction{};
-    it.bus = BUS_PROG; it.sign = +1; it.mult = lf_col(kProgramPrepWidth + 0); it.n_el = 10;
-    for (int j = 0; j < 10; ++j) it.el[j] = lf_col(j);
+    const LinForm real = lf_col(MF_IS_REAL), init = lf_col(MF_IS_INIT), addr = lf_pair(MF_LO, MF_HI, 65536);
+    g_memfinal[0] = mem_inter(-1, real, addr, lf_col(MF_FIN_LO), lf_col(MF_FIN_HI), lf_col(MF_FIN_TS));
+    g_memfinal[1] = mem_inter(+1, real, addr, lf_col(MF_INIT_LO), lf_col(MF_INIT_HI), zero);
+    Interaction& im = g_memfinal[2];
+    im = Interaction{};
+    im.bus = BUS_IMG; im.sign = -1; im.mult = lf_pair(MF_IS_REAL, MF_IS_INIT, kP - 1); im.n_el = 3;
+    im.el[0] = addr; im.el[1] = lf_col(MF_INIT_LO); im.el[2] = lf_col(MF_INIT_HI);
+    g_memfinal[3] = range_inter(-1, real, zero, lf_col(MF_LO));
+    g_memfinal[4] = range_inter(-1, real, zero, lf_col(MF_HI));
+    g_memfinal[5] = range_inter(-1, real, zero, lf_const_minus(kAddrHiMax, MF_HI));
+    g_memfinal[6] = range_inter(-1, real, zero, lf_col(MF_D_LO));
+    g_memfinal[7] = range_inter(-1, real, zero, lf_col(MF_D_HI));
+    g_memfinal[8] = range_inter(-1, init, zero, lf_col(MF_INIT_LO));
+    g_memfinal[9] = range_inter(-1, init, zero, lf_col(MF_INIT_HI));
+  }
+  {
+    Interaction& im = g_image[0];
+    im = Interaction{};
+    im.bus = BUS_IMG; im.sign = +1; im.mult = lf_col(kImagePrepWidth + 0); im.n_el = 3;
+    im.el[0] = lf_col(IMG_P_ADDR); im.el[1] = lf_col(IMG_P_LO); im.el[2] = lf_col(IMG_P_HI);
+    Interaction& pr = g_program[0];
+    pr = Interaction{};
+    pr.bus = BUS_PROG; pr.sign = +1; pr.mult = lf_col(kProgramPrepWidth + 0); pr.n_el = 12;
+    for (int j = 0; j < 12; ++j) pr.el[j] = lf_col(j);
+    const LinForm idx = lf_pair(TB_P_X, TB_P_Y, 256);
+    g_table[0] = range_inter(+1, lf_col(kTablePrepWidth + TB_M_R16), zero, idx);
+    g_table[1] = range_inter(+1, lf_col(kTablePrepWidth + TB_M_AL), one, idx);
+    g_table[2] = bytes_inter(+1, lf_col(kTablePrepWidth + TB_M_BY), lf_col(TB_P_X), lf_col(TB_P_Y));
   }
   for (int hi = 0; hi < 2; ++hi) {
     Interaction& it = g_mul[hi];
     it = Interaction{};
-    it.bus = BUS_MUL; it.sign = -1; it.n_el = 7;
-    if (hi) it.mult = lf_col(MU_HI);
-    else { it.mult = lf_zero(); lf_add(it.mult, MU_IS_REAL, 1); lf_add(it.mult, MU_HI, kP - 1); }
-    it.el[0] = lf_const((uint32_t)hi);
-    it.el[1] = lf_limb(MU_P, 2 * hi); it.el[2] = lf_limb(MU_P, 2 * hi + 1);
-    it.el[3] = lf_limb(MU_B, 0); it.el[4] = lf_limb(MU_B, 1); it.el[5] = lf_limb(MU_C, 0); it.el[6] = lf_limb(MU_C, 1);
+    it.bus = BUS_ALU; it.sign = -1; it.n_el = 7;
+    it.mult = hi ? lf_col(MU_HI) : lf_pair(MU_IS_REAL, MU_HI, kP - 1);
+    it.el[0] = lf_const(hi ? (uint32_t)MULHU : (uint32_t)MUL);
+    it.el[1] = lf_bits(MU_P + 32 * hi, 16); it.el[2] = lf_bits(MU_P + 32 * hi + 16, 16);
+    it.el[3] = lf_bits(MU_B, 16); it.el[4] = lf_bits(MU_B + 16, 16); it.el[5] = lf_bits(MU_C, 16); it.el[6] = lf_bits(MU_C + 16, 16);
   }
-  g_range[0] = range_inter(+1, lf_col(kRangePrepWidth + 0), lf_col(0));
-  g_chips[kRange] = {"range", kRangePrepWidth, kRangeWidth, 1, g_range, 0};
-  g_chips[kCpu] = {"cpu", 0, kCpuWidth, 21, g_cpu, kCpuConstraints};
-  g_chips[kCpu2] = {"cpu2", 0, kCpuWidth, 21, g_cpu, kCpuConstraints};
+  {
+    Interaction& it = g_alu[0];
+    it = Interaction{};
+    it.bus = BUS_ALU; it.sign = -1; it.mult = lf_col(AL_IS_REAL); it.n_el = 7;
+    it.el[0] = lf_zero();
+    for (int k = 0; k < 8; ++k) lf_add(it.el[0], AL_SEL + k, (uint64_t)(XOR + k));
+    it.el[1] = lf_col(AL_A); it.el[2] = lf_col(AL_A + 1);
+    it.el[3] = lf_bits(AL_B, 16); it.el[4] = lf_bits(AL_B + 16, 16); it.el[5] = lf_bits(AL_C, 16); it.el[6] = lf_bits(AL_C + 16, 16);
+  }
+  {
+    static const uint32_t codes[6] = {LB, LH, LBU, LHU, SB, SH};
+    Interaction& it = g_sub[0];
+    it = Interaction{};
+    it.bus = BUS_SUB; it.sign = -1; it.mult = lf_col(SW_IS_REAL); it.n_el = 9;
+    it.el[0] = lf_zero();
+    for (int k = 0; k < 6; ++k) lf_add(it.el[0], SW_SEL + k, codes[k]);
+    it.el[1] = lf_zero(); lf_add(it.el[1], SW_O + 1, 1); lf_add(it.el[1], SW_O + 2, 2); lf_add(it.el[1], SW_O + 3, 3);
+    it.el[2] = lf_col(SW_A); it.el[3] = lf_col(SW_A + 1);
+    it.el[4] = lf_bits(SW_M, 16); it.el[5] = lf_bits(SW_M + 16, 16); it.el[6] = lf_bits(SW_C, 16);
+    it.el[7] = lf_col(SW_MV); it.el[8] = lf_col(SW_MV + 1);
+  }
+  g_chips[kTable] = {"table", kTablePrepWidth, kTableWidth, 3, g_table, 1};
+  g_chips[kCpu] = {"cpu", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints};
+  g_chips[kCpu2] = {"cpu2", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints};
   g_chips[kKeccak] = {"keccak", 0, kKeccakWidth, 50, g_keccak, kKeccakConstraints};
-  g_chips[kKmem] = {"keccak-mem", 0, kKmemWidth, 6, g_kmem, kKmemConstraints};
-  g_chips[kMemFinal] = {"mem-final", 0, kMemFinalWidth, 2, g_memfinal, kMemFinalConstraints};
+  g_chips[kKmem] = {"keccak-mem", 0, kKmemWidth, 8, g_kmem, kKmemConstraints};
+  g_chips[kMemFinal] = {"mem-final", 0, kMemFinalWidth, 10, g_memfinal, kMemFinalConstraints};
   g_chips[kImage] = {"image", kImagePrepWidth, kImageWidth, 1, g_image, 1};
   g_chips[kProgram] = {"program", kProgramPrepWidth, kProgramWidth, 1, g_program, 0};
   g_chips[kMul] = {"mul", 0, kMulWidth, 2, g_mul, kMulConstraints};
+  g_chips[kAlu] = {"alu", 0, kAluWidth, 1, g_alu, kAluConstraints};
+  g_chips[kAlu2] = {"alu2", 0, kAluWidth, 1, g_alu, kAluConstraints};
+  g_chips[kSub] = {"subword", 0, kSubWidth, 1, g_sub, kSubConstraints};
+  g_chips[kSub2] = {"subword2", 0, kSubWidth, 1, g_sub, kSubConstraints};
 }
 
 }  // namespace

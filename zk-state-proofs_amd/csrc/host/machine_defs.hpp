@@ -11,7 +11,7 @@
 namespace zksp {
 namespace mach {
 
-constexpr int kLfMax = 40, kInterMaxElems = 10;
+constexpr int kLfMax = 16, kInterMaxElems = 12;
 struct LinForm {
   int32_t n;
   int32_t col[kLfMax];
@@ -35,14 +35,7 @@ struct ChipDef {
 const ChipDef& chip_def(int chip);
 
 constexpr int kHeaderWords = 2 + kNumChips + 2 + 24 + 1;  // magic, version, heights, exit code, pv length, 3 digests, hand-over pc
-constexpr uint32_t kMachineVersion = 5;
-
-// rows of the first CPU instance: the largest power of two strictly below the cycle count (at least 32)
-inline size_t cpu_split(size_t n_cycles) {
-  size_t h0 = 32;
-  while (2 * h0 < n_cycles) h0 *= 2;
-  return h0;
-}
+constexpr uint32_t kMachineVersion = 6;
 
 }  // namespace mach
 }  // namespace zksp

@@ -84,22 +84,25 @@ int mmcs_commit(hipStream_t s, const RoundMats& rm, uint32_t* tree, size_t tree_
 
 }  // namespace
 
-uint32_t machine_handover_pc(const MachineTrace& t) {
-  const size_t h0 = cpu_split(t.cycles.size());
-  return h0 < t.cycles.size() ? t.cycles[h0].pc : 0;
+uint32_t machine_handover_pc(const MachineProgram& prog, const MachineTrace& t) {
+  const size_t h0 = split_rows(t.cycles.size());
+  return h0 < t.cycles.size() ? t.cycles[h0].pc : prog.pad_pc();
 }
 
 void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh[kNumChips]) {
-  const size_t h0 = cpu_split(t.cycles.size());
-  logh[kCpu] = ceil_log2(h0);
-  logh[kCpu2] = at_least5(ceil_log2(t.cycles.size() > h0 ? t.cycles.size() - h0 : 1));
+  logh[kCpu] = ceil_log2(split_rows(t.cycles.size()));
+  logh[kCpu2] = ceil_log2(split_rest_rows(t.cycles.size()));
+  logh[kAlu] = ceil_log2(split_rows(t.alu_idx.size()));
+  logh[kAlu2] = ceil_log2(split_rest_rows(t.alu_idx.size()));
+  logh[kSub] = ceil_log2(split_rows(t.sub_idx.size()));
+  logh[kSub2] = ceil_log2(split_rest_rows(t.sub_idx.size()));
   logh[kKeccak] = at_least5(ceil_log2(24 * t.keccak.size()));
   logh[kKmem] = at_least5(ceil_log2(50 * t.keccak.size()));
   logh[kMemFinal] = at_least5(ceil_log2(t.memfinal.size()));
   logh[kImage] = prog.log_image;
   logh[kProgram] = prog.log_prog;
   logh[kMul] = at_least5(ceil_log2(t.muls.size()));
-  logh[kRange] = kRangeLogH;
+  logh[kTable] = kTableLogH;
 }
 
 int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const PrepDevice** out) {
@@ -113,8 +116,8 @@ int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineV
   machine_prep_traces(prog, &tr[0], &tr[1], &tr[2]);
   pd->logh[0] = prog.log_image;
   pd->logh[1] = prog.log_prog;
-  pd->logh[2] = kRangeLogH;
-  const int widths[PrepDevice::kMats] = {kImagePrepWidth, kProgramPrepWidth, kRangePrepWidth};
+  pd->logh[2] = kTableLogH;
+  const int widths[PrepDevice::kMats] = {kImagePrepWidth, kProgramPrepWidth, kTablePrepWidth};
   bool ok = true;
   for (int i = 0; i < PrepDevice::kMats && ok; ++i) {
     const size_t h = (size_t)1 << pd->logh[i];
@@ -141,10 +144,10 @@ int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineV
   memset(&rm, 0, sizeof rm);
   rm.seg[kImage][0] = Seg{pd->lde[0], 0, kImagePrepWidth};
   rm.seg[kProgram][0] = Seg{pd->lde[1], 0, kProgramPrepWidth};
-  rm.seg[kRange][0] = Seg{pd->lde[2], 0, kRangePrepWidth};
+  rm.seg[kTable][0] = Seg{pd->lde[2], 0, kTablePrepWidth};
   rm.logh[kImage] = pd->logh[0];
   rm.logh[kProgram] = pd->logh[1];
-  rm.logh[kRange] = pd->logh[2];
+  rm.logh[kTable] = pd->logh[2];
   uint32_t* inj[32];
   for (auto& p : inj) p = pd->inj;  // a level's injected digests are consumed before the next level writes its own
   mmcs_commit(s, rm, pd->tree, 0, inj, 1, ctx->d_consts);
@@ -158,6 +161,7 @@ int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineV
     if (Fp::raw(root[i]).to_canonical() != vk.prep_root[i])
       return ctx->fail(3, "machine: the device commitment of the preprocessed tables differs from the verifying key");
   pd->n_program = (uint32_t)prog.rows.size();
+  pd->n_image = (uint32_t)prog.image.size();
   pd->text_base = prog.text_base;
   pd->entry = prog.entry;
   *out = pd.get();
@@ -166,10 +170,11 @@ int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineV
 }
 
 static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap_cycles, size_t cap_keccak, size_t cap_memfinal,
-                            size_t cap_muls) {
+                            size_t cap_muls, size_t cap_alu, size_t cap_sub) {
   MachineWorkspace* w = ctx->mws.get();
   if (w && memcmp(w->logh, logh, sizeof w->logh) == 0 && w->batch >= batch && w->cap_cycles >= cap_cycles &&
-      w->cap_keccak >= cap_keccak && w->cap_memfinal >= cap_memfinal && w->cap_muls >= cap_muls)
+      w->cap_keccak >= cap_keccak && w->cap_memfinal >= cap_memfinal && w->cap_muls >= cap_muls && w->cap_alu >= cap_alu &&
+      w->cap_sub >= cap_sub)
     return 0;
   ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->mws.reset(new MachineWorkspace());
@@ -178,6 +183,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   w->batch = batch;
   w->cap_cycles = cap_cycles; w->cap_keccak = std::max<size_t>(cap_keccak, 1); w->cap_memfinal = cap_memfinal;
   w->cap_muls = std::max<size_t>(cap_muls, 1);
+  w->cap_alu = std::max<size_t>(cap_alu, 1); w->cap_sub = std::max<size_t>(cap_sub, 1);
   const size_t B = (size_t)batch;
   const uint32_t Q = ctx->params.num_queries;
   bool ok = true;
@@ -187,14 +193,11 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   A(&w->kstates, B * w->cap_keccak * 25);
   A(&w->memfinal, B * w->cap_memfinal * 5);
   A(&w->muls, B * w->cap_muls * 3);
+  A(&w->alu_idx, B * w->cap_alu);
+  A(&w->sub_idx, B * w->cap_sub);
   A(&w->prog_mult, B << logh[kProgram]);
-  A(&w->image_used, B << logh[kImage]);
-  A(&w->range_hist, B << kRangeLogH);
-  A(&w->cpu_limbs_tr[0], (B * 8) << logh[kCpu]);
-  A(&w->cpu_limbs_lde[0], (B * 16) << logh[kCpu]);
-  A(&w->cpu_limbs_tr[1], (B * 8) << logh[kCpu2]);
-  A(&w->cpu_limbs_lde[1], (B * 16) << logh[kCpu2]);
-  A(&w->counts, B * 4);
+  A(&w->table_hist, (B * 3) << kTableLogH);
+  A(&w->counts, B * kCountWords);
   A(&w->n_perms, B);
   A(&w->init_obs, B * kMachineInitObs);
   A(&w->pub_words, B * kPubWords);
@@ -203,9 +206,10 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   A(&w->spare.kstates, B * w->cap_keccak * 25);
   A(&w->spare.memfinal, B * w->cap_memfinal * 5);
   A(&w->spare.muls, B * w->cap_muls * 3);
+  A(&w->spare.alu_idx, B * w->cap_alu);
+  A(&w->spare.sub_idx, B * w->cap_sub);
   A(&w->spare.prog_mult, B << logh[kProgram]);
-  A(&w->spare.image_used, B << logh[kImage]);
-  A(&w->spare.counts, B * 4);
+  A(&w->spare.counts, B * kCountWords);
   A(&w->spare.n_perms, B);
   A(&w->spare.init_obs, B * kMachineInitObs);
   A(&w->spare.pub_words, B * kPubWords);
@@ -295,7 +299,8 @@ namespace {
 void swap_records(MachineWorkspace* w) {
   MachineWorkspace::SpareRecords& p = w->spare;
   std::swap(w->cycles, p.cycles); std::swap(w->memfinal, p.memfinal); std::swap(w->muls, p.muls);
-  std::swap(w->prog_mult, p.prog_mult); std::swap(w->image_used, p.image_used); std::swap(w->counts, p.counts);
+  std::swap(w->prog_mult, p.prog_mult); std::swap(w->alu_idx, p.alu_idx); std::swap(w->sub_idx, p.sub_idx);
+  std::swap(w->counts, p.counts);
   std::swap(w->kcalls, p.kcalls); std::swap(w->kstates, p.kstates); std::swap(w->n_perms, p.n_perms);
   std::swap(w->init_obs, p.init_obs); std::swap(w->pub_words, p.pub_words); std::swap(w->n, p.n);
 }
@@ -324,16 +329,15 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
   }
   // record capacities follow from the heights alone, so every batch of these heights fits the same workspace
   const size_t cc = ((size_t)1 << logh[kCpu]) + ((size_t)1 << logh[kCpu2]), cm = (size_t)1 << logh[kMemFinal], cu = (size_t)1 << logh[kMul],
-               ck = std::min(((size_t)1 << logh[kKeccak]) / 24, ((size_t)1 << logh[kKmem]) / 50);
+               ck = std::min(((size_t)1 << logh[kKeccak]) / 24, ((size_t)1 << logh[kKmem]) / 50),
+               ca = ((size_t)1 << logh[kAlu]) + ((size_t)1 << logh[kAlu2]), cs = ((size_t)1 << logh[kSub]) + ((size_t)1 << logh[kSub2]);
   if (logh[kCpu] > 20) return ctx->fail(9, "machine_load: more than 2^21 cycles");
-  for (size_t i = 0; i < n; ++i)
-    if (traces[i]->cycles.size() < 33) return ctx->fail(9, "machine_load: fewer than 33 cycles");
   if (into_spare) {
     MachineWorkspace* w0 = ctx->mws.get();
     if (!w0 || memcmp(w0->logh, logh, sizeof w0->logh) != 0 || (size_t)w0->batch < n || !ctx->copy_stream)
       return ctx->fail(1, "machine_load: the spare set takes batches of the resident heights only");
   } else {
-    rc = workspace_ensure(ctx, logh, (int)std::max<size_t>(n, (size_t)ctx->batch_hint), cc, ck, cm, cu);
+    rc = workspace_ensure(ctx, logh, (int)std::max<size_t>(n, (size_t)ctx->batch_hint), cc, ck, cm, cu, ca, cs);
     if (rc) return rc;
   }
   MachineWorkspace* w = ctx->mws.get();
@@ -346,13 +350,19 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     ~SwapBack() { if (on) swap_records(w); }
   } swap_back{w, into_spare};
   if (into_spare) swap_records(w);
-  std::vector<uint32_t> counts(n * 4), nperms(n), obs(n * kMachineInitObs), pubw(n * kPubWords);
+  std::vector<uint32_t> counts(n * kCountWords, 0), nperms(n), obs(n * kMachineInitObs), pubw(n * kPubWords);
   std::vector<uint64_t> kst(n * w->cap_keccak * 25, 0);
-  const size_t hp = (size_t)1 << logh[kProgram], hi = (size_t)1 << logh[kImage];
+  const size_t hp = (size_t)1 << logh[kProgram];
   for (size_t i = 0; i < n; ++i) {
     const MachineTrace& t = *traces[i];
-    counts[4 * i] = (uint32_t)t.cycles.size(); counts[4 * i + 1] = (uint32_t)t.keccak.size();
-    counts[4 * i + 2] = (uint32_t)t.memfinal.size(); counts[4 * i + 3] = (uint32_t)t.muls.size();
+    uint32_t* cn = &counts[kCountWords * i];
+    cn[0] = (uint32_t)t.cycles.size(); cn[1] = (uint32_t)t.keccak.size();
+    cn[2] = (uint32_t)t.memfinal.size(); cn[3] = (uint32_t)t.muls.size();
+    cn[4] = (uint32_t)t.alu_idx.size(); cn[5] = (uint32_t)t.sub_idx.size(); cn[6] = t.x0_last;
+    if (!t.alu_idx.empty())
+      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->alu_idx + i * w->cap_alu, t.alu_idx.data(), t.alu_idx.size() * 4, hipMemcpyHostToDevice, s));
+    if (!t.sub_idx.empty())
+      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->sub_idx + i * w->cap_sub, t.sub_idx.data(), t.sub_idx.size() * 4, hipMemcpyHostToDevice, s));
     nperms[i] = (uint32_t)t.keccak.size();
     ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->cycles + i * w->cap_cycles * 12, t.cycles.data(), t.cycles.size() * 48, hipMemcpyHostToDevice, s));
     if (!t.keccak.empty())
@@ -363,8 +373,6 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
       ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->muls + i * w->cap_muls * 3, t.muls.data(), t.muls.size() * 12, hipMemcpyHostToDevice, s));
     ZKSP_HIP_CHECK(ctx, hipMemsetAsync(w->prog_mult + i * hp, 0, hp * 4, s));
     ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->prog_mult + i * hp, t.prog_mult.data(), t.prog_mult.size() * 4, hipMemcpyHostToDevice, s));
-    ZKSP_HIP_CHECK(ctx, hipMemsetAsync(w->image_used + i * hi, 0, hi * 4, s));
-    ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->image_used + i * hi, t.image_used.data(), t.image_used.size() * 4, hipMemcpyHostToDevice, s));
     uint32_t* o = &obs[i * kMachineInitObs];
     memcpy(o, vk.digest, 32);
     for (int c = 0; c < kNumChips; ++c) o[8 + c] = (uint32_t)logh[c];
@@ -382,14 +390,16 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     {
       // the two CPU instances: first pc, first time, has a successor, hand-over pc (air_machine.hpp CpuPub)
       const size_t h0 = (size_t)1 << logh[kCpu];
-      const uint32_t handover = machine_handover_pc(t);
+      const uint32_t handover = machine_handover_pc(prog, t);
       o[42 + kNumChips] = handover & 0xffff;
       o[43 + kNumChips] = handover >> 16;
       uint32_t* cp = &pubw[i * kPubWords + 17];
+      uint32_t* cp2 = cp + kNumCpuPub;
       cp[kPubStartPc] = Fp::from_canonical(prog.entry).v; cp[kPubStartTs] = Fp::from_canonical(4).v;
       cp[kPubHasSucc] = Fp::one().v; cp[kPubEndPc] = Fp::from_canonical(handover).v;
-      cp[4 + kPubStartPc] = Fp::from_canonical(handover).v; cp[4 + kPubStartTs] = Fp::from_canonical((uint32_t)(4 * (h0 + 1))).v;
-      cp[4 + kPubHasSucc] = 0; cp[4 + kPubEndPc] = 0;
+      cp2[kPubStartPc] = Fp::from_canonical(handover).v; cp2[kPubStartTs] = Fp::from_canonical((uint32_t)(4 * (h0 + 1))).v;
+      cp2[kPubHasSucc] = 0; cp2[kPubEndPc] = 0;
+      cp[kPubPadPc] = cp2[kPubPadPc] = Fp::from_canonical(prog.pad_pc()).v;
     }
   }
   ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->kstates, kst.data(), kst.size() * 8, hipMemcpyHostToDevice, s));
@@ -441,12 +451,13 @@ int machine_prove_resident(Context* ctx) {
   // ---- main traces ----
   MachineRecords rec;
   rec.cycles = w->cycles; rec.kcalls = w->kcalls; rec.memfinal = w->memfinal; rec.muls = w->muls;
-  rec.prog_mult = w->prog_mult; rec.image_used = w->image_used; rec.counts = w->counts; rec.range_hist = w->range_hist;
-  rec.cpu_limbs[0] = w->cpu_limbs_tr[0];
-  rec.cpu_limbs[1] = w->cpu_limbs_tr[1];
-  rec.cpu2_row0 = (uint32_t)1 << logh[kCpu];
+  rec.alu_idx = w->alu_idx; rec.sub_idx = w->sub_idx;
+  rec.prog_mult = w->prog_mult; rec.counts = w->counts; rec.table_hist = w->table_hist;
+  memset(rec.row0, 0, sizeof rec.row0);
+  rec.row0[kCpu2] = (uint32_t)1 << logh[kCpu]; rec.row0[kAlu2] = (uint32_t)1 << logh[kAlu]; rec.row0[kSub2] = (uint32_t)1 << logh[kSub];
   rec.cap_cycles = w->cap_cycles; rec.cap_keccak = w->cap_keccak; rec.cap_memfinal = w->cap_memfinal; rec.cap_muls = w->cap_muls;
-  rec.program = prep->program; rec.text_base = prep->text_base; rec.n_program = prep->n_program;
+  rec.cap_alu = w->cap_alu; rec.cap_sub = w->cap_sub;
+  rec.program = prep->program; rec.text_base = prep->text_base; rec.n_program = prep->n_program; rec.n_image = prep->n_image;
   {
     ProfileSpan sp(ctx, "m_trace");
     for (int c = 0; c < kNumChips; ++c) {
@@ -454,10 +465,16 @@ int machine_prove_resident(Context* ctx) {
         const size_t bs = (size_t)kKeccakWidth * H(c);
         launch_keccak_trace_strided(s, w->kstates, (int)w->cap_keccak, w->n_perms, w->mat[c][0].tr, bs, logh[c], B);
         launch_keccak_ts(s, rec, w->mat[c][0].tr, bs, logh[c], B);
-      } else {
+      } else if (c != kTable) {
         launch_machine_trace(s, c, rec, w->mat[c][0].tr, logh[c], B);
       }
     }
+    // the table chip answers what the others look up: count their RANGE / BYTES receives on their finished traces
+    launch_table_clear(s, rec, B);
+    for (int c : {(int)kCpu, (int)kCpu2, (int)kKmem, (int)kMemFinal})
+      launch_table_count(s, static_cast<const Interaction*>(ctx->d_inter[c]), chip_def(c).n_inter, w->mat[c][0].tr, chip_def(c).main_w,
+                         logh[c], rec, B);
+    launch_table_trace(s, rec, w->mat[kTable][0].tr, B);
   }
   {
     ProfileSpan sp(ctx, "m_lde_main");
@@ -502,7 +519,6 @@ int machine_prove_resident(Context* ctx) {
       pa.perm_bstride = (size_t)d.perm_width() * H(c);
       pa.rowsum = w->rowsum;
       pa.slice_sums = w->slice_sums;
-      pa.limbs = c == kCpu ? w->cpu_limbs_tr[0] : c == kCpu2 ? w->cpu_limbs_tr[1] : nullptr;
       pa.cum = w->cum + 4 * c;
       pa.cum_bstride = (size_t)4 * kNumChips;
       pa.logh = logh[c];
@@ -555,11 +571,10 @@ int machine_prove_resident(Context* ctx) {
         qa.zh_inv[k] = (sh[k].pow(h) - Fp::one()).inv().v;
       }
       qa.wh_inv = wh.inv().v;
-      qa.pubs = is_cpu_chip(c) ? w->pub_words + 17 + (c == kCpu2 ? 4 : 0) : nullptr;
+      qa.pubs = is_cpu_chip(c) ? w->pub_words + 17 + (c == kCpu2 ? kNumCpuPub : 0) : nullptr;
       qa.pubs_bstride = kPubWords;
       qa.quot = w->mat[c][2].tr;
-      qa.partial = is_cpu_chip(c) ? w->reduce_scratch : w->kpartial;  // 40 H words per proof of a CPU instance <= 48 H
-      qa.limbs = c == kCpu ? w->cpu_limbs_lde[0] : c == kCpu2 ? w->cpu_limbs_lde[1] : nullptr;
+      qa.partial = w->kpartial;
       qa.logh = logh[c];
       qa.batch = B;
       launch_machine_quotient(s, qa);

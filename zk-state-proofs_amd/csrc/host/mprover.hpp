@@ -1,5 +1,5 @@
 // Device prover of the machine proof: batch workspace in HBM and the launch sequence that turns
-// traced executions into proof bodies ("ZKSP v5") without a host round trip.  See mprover.cpp.
+// traced executions into proof bodies ("ZKSP v6") without a host round trip.  See mprover.cpp.
 #pragma once
 #include <array>
 #include <vector>
@@ -15,8 +15,8 @@ constexpr int kMachineInitObs = 8 + mach::kNumChips + 2 + 16 + 16 + 2;  // vk di
 
 // Preprocessed tables of one program on the device (built once per verifying key).
 struct PrepDevice {
-  static constexpr int kMats = 3;   // image, program, range (chip order)
-  static int index_of(int chip) { return chip == mach::kImage ? 0 : chip == mach::kProgram ? 1 : chip == mach::kRange ? 2 : -1; }
+  static constexpr int kMats = 3;   // image, program, table (chip order)
+  static int index_of(int chip) { return chip == mach::kImage ? 0 : chip == mach::kProgram ? 1 : chip == mach::kTable ? 2 : -1; }
   int logh[kMats] = {0, 0, 0};
   uint32_t* tr[kMats] = {nullptr, nullptr, nullptr};     // traces (the permutation trace is built from trace rows)
   uint32_t* coef[kMats] = {nullptr, nullptr, nullptr};
@@ -24,7 +24,7 @@ struct PrepDevice {
   uint32_t* tree = nullptr;        // mixed-height tree over the three tables
   uint32_t* inj = nullptr;         // leaf digests of a shorter group (one level at a time, in stream order)
   uint32_t* program = nullptr;     // [n][9] rows for trace expansion
-  uint32_t n_program = 0, text_base = 0, entry = 0;
+  uint32_t n_program = 0, n_image = 0, text_base = 0, entry = 0;
   int lm = 0;
   std::vector<void*> allocs;
 };
@@ -32,19 +32,19 @@ struct PrepDevice {
 struct MachineWorkspace {
   int logh[mach::kNumChips] = {0};
   int batch = 0, n = 0;
-  size_t cap_cycles = 0, cap_keccak = 0, cap_memfinal = 0, cap_muls = 0;
+  size_t cap_cycles = 0, cap_keccak = 0, cap_memfinal = 0, cap_muls = 0, cap_alu = 0, cap_sub = 0;
   const PrepDevice* prep = nullptr;
   // records
-  uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *image_used = nullptr, *counts = nullptr,
-           *range_hist = nullptr;
-  uint32_t *cpu_limbs_tr[2] = {nullptr, nullptr}, *cpu_limbs_lde[2] = {nullptr, nullptr};  // limbs of the CPU instances' bit blocks
+  uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *alu_idx = nullptr, *sub_idx = nullptr,
+           *counts = nullptr, *table_hist = nullptr;
   uint8_t* kcalls = nullptr;
   uint64_t* kstates = nullptr;
   uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;
   // A second set of record buffers: the next batch is uploaded (copy stream) while the current one is
   // being proven, then machine_activate_spare() swaps the sets.
   struct SpareRecords {
-    uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *image_used = nullptr, *counts = nullptr;
+    uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *alu_idx = nullptr, *sub_idx = nullptr,
+             *counts = nullptr;
     uint8_t* kcalls = nullptr;
     uint64_t* kstates = nullptr;
     uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;
@@ -82,6 +82,6 @@ int machine_activate_spare(Context* ctx);
 int machine_prove_resident(Context* ctx);
 void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh[mach::kNumChips]);
 // pc of the first cycle of the second CPU instance (a proof-header word)
-uint32_t machine_handover_pc(const MachineTrace& t);
+uint32_t machine_handover_pc(const MachineProgram& prog, const MachineTrace& t);
 
 }  // namespace zksp

@@ -1,4 +1,4 @@
-// Host verifier of the machine proof ("ZKSP v5"): replaces `client.verify(&proof, &vk)` (reference
+// Host verifier of the machine proof ("ZKSP v6"): replaces `client.verify(&proof, &vk)` (reference
 // prover/src/bin/main.rs:80; sp1-stark 3.4.0's multi-chip verifier over p3-uni-stark / p3-fri,
 // Cargo.lock:7485, :5378, :5253) for proofs that bind the guest's whole execution.  Also the
 // host half of `client.setup(ELF)` (main.rs:70): the commitment to the preprocessed Program and
@@ -132,6 +132,8 @@ struct ZetaCtx {
   using F = Fp4;
   const Fp4* loc;  // main columns at zeta
   const Fp4* nxt;  // main columns at zeta * w
+  const Fp4* prp;  // preprocessed columns at zeta
+  F prep(int col) const { return prp[col]; }
   Fp4 first, trans, last, pub_[kNumCpuPub];
   const Fp4* ap;
   int k_ = 0;
@@ -147,15 +149,9 @@ struct ZetaCtx {
   void emit(F v) { acc += ap[k_++] * v; }
   void emit_at(int idx, F v) { acc += ap[idx] * v; }  // fixed index spaces (keccak, CPU)
   void set_count(int n) { k_ = n; }
-  void note_limbs(int, F, F) {}
   Fp4 stash_[32];
   void stash(int i, F v) { stash_[i] = v; }
   F stashed(int i) const { return stash_[i]; }
-  F sum_prod(const F* x, const F* y, int ystep, int n) const {
-    F s = Fp4::zero();
-    for (int i = 0; i < n; ++i) s += x[i] * y[i * ystep];
-    return s;
-  }
 };
 
 Fp4 lf_eval(const LinForm& f, const Fp4* row) {
@@ -169,37 +165,45 @@ Fp4 fingerprint(const Interaction& it, const Fp4* row, const Fp4& gamma, const F
   return f;
 }
 
-void vk_digest_of(const uint32_t root_canon[8], uint32_t entry, int log_prog, int log_image, int mode, uint32_t out[8]) {
-  Fp v[16];
+void vk_digest_of(const uint32_t root_canon[8], uint32_t entry, uint32_t pad_pc, int log_prog, int log_image, int mode,
+                  uint32_t out[8]) {
+  Fp v[18];
   for (int i = 0; i < 8; ++i) v[i] = Fp::from_canonical(root_canon[i]);
-  const uint32_t rest[8] = {entry & 0xffff, entry >> 16, (uint32_t)log_prog, (uint32_t)log_image, (uint32_t)mode,
-                            kMachineVersion, (uint32_t)kCpuWidth, (uint32_t)kNumChips};
-  for (int i = 0; i < 8; ++i) v[8 + i] = Fp::from_canonical(rest[i]);
+  const uint32_t rest[10] = {entry & 0xffff, entry >> 16, (uint32_t)log_prog, (uint32_t)log_image, (uint32_t)mode,
+                             kMachineVersion, (uint32_t)kCpuWidth, (uint32_t)kNumChips, pad_pc & 0xffff, pad_pc >> 16};
+  for (int i = 0; i < 10; ++i) v[8 + i] = Fp::from_canonical(rest[i]);
   Fp d[8];
-  hash_elems(v, 16, d, &host_p2_consts());
+  hash_elems(v, 18, d, &host_p2_consts());
   for (int i = 0; i < 8; ++i) out[i] = d[i].to_canonical();
 }
 
 }  // namespace
 
 void machine_prep_traces(const MachineProgram& prog, std::vector<uint32_t>* image_prep, std::vector<uint32_t>* program_prep,
-                         std::vector<uint32_t>* range_prep) {
-  const size_t hi = (size_t)1 << prog.log_image, hp = (size_t)1 << prog.log_prog;
+                         std::vector<uint32_t>* table_prep) {
+  const size_t hi = (size_t)1 << prog.log_image, hp = (size_t)1 << prog.log_prog, ht = (size_t)1 << kTableLogH;
   image_prep->assign((size_t)kImagePrepWidth * hi, 0);
   program_prep->assign((size_t)kProgramPrepWidth * hp, 0);
-  range_prep->resize((size_t)1 << kRangeLogH);
-  for (size_t r = 0; r < range_prep->size(); ++r) (*range_prep)[r] = (uint32_t)r;
+  table_prep->assign((size_t)kTablePrepWidth * ht, 0);
+  for (size_t r = 0; r < ht; ++r) {
+    (*table_prep)[(size_t)TB_P_X * ht + r] = (uint32_t)(r & 255);
+    (*table_prep)[(size_t)TB_P_Y * ht + r] = (uint32_t)(r >> 8);
+    (*table_prep)[(size_t)TB_P_NA * ht + r] = (r & 3) != 0;
+  }
   for (size_t r = 0; r < prog.image.size(); ++r) {
     (*image_prep)[(size_t)IMG_P_ADDR * hi + r] = prog.image[r].addr;
     (*image_prep)[(size_t)IMG_P_LO * hi + r] = prog.image[r].val & 0xffff;
     (*image_prep)[(size_t)IMG_P_HI * hi + r] = prog.image[r].val >> 16;
+    (*image_prep)[(size_t)IMG_P_REAL * hi + r] = 1;
   }
   for (size_t r = 0; r < prog.rows.size(); ++r) {
     const ProgramRow& p = prog.rows[r];
     uint32_t* q = program_prep->data() + r;
-    q[(size_t)PR_PC * hp] = p.pc; q[(size_t)PR_OP * hp] = p.op; q[(size_t)PR_WR * hp] = p.wr; q[(size_t)PR_USE2 * hp] = p.use2;
+    q[(size_t)PR_PC * hp] = p.pc; q[(size_t)PR_CLS * hp] = (uint32_t)class_of(p.op); q[(size_t)PR_CODE * hp] = code_of(p.op);
+    q[(size_t)PR_WR * hp] = p.wr; q[(size_t)PR_USE2 * hp] = p.use2;
     q[(size_t)PR_RD * hp] = p.rd; q[(size_t)PR_RS1 * hp] = p.rs1; q[(size_t)PR_RS2 * hp] = p.rs2;
-    q[(size_t)PR_IMM_LO * hp] = p.imm & 0xffff; q[(size_t)PR_IMM_HI * hp] = p.imm >> 16; q[(size_t)PR_TGT * hp] = p.tgt;
+    q[(size_t)PR_IMM_LO * hp] = p.imm & 0xffff; q[(size_t)PR_IMM_HI * hp] = p.imm >> 16;
+    q[(size_t)PR_TGT_LO * hp] = p.tgt & 0xffff; q[(size_t)PR_TGT_HI * hp] = p.tgt >> 16;
   }
 }
 
@@ -208,8 +212,8 @@ void machine_host_setup(const MachineProgram& prog, MachineVk* vk) {
   constexpr int kPrepMats = 3;
   std::vector<uint32_t> tr[kPrepMats];
   machine_prep_traces(prog, &tr[0], &tr[1], &tr[2]);
-  const int logs[kPrepMats] = {prog.log_image, prog.log_prog, kRangeLogH},
-            widths[kPrepMats] = {kImagePrepWidth, kProgramPrepWidth, kRangePrepWidth};
+  const int logs[kPrepMats] = {prog.log_image, prog.log_prog, kTableLogH},
+            widths[kPrepMats] = {kImagePrepWidth, kProgramPrepWidth, kTablePrepWidth};
   std::vector<std::vector<Fp>> lde[kPrepMats];  // [matrix][col] -> [2][H]
   for (int mtx = 0; mtx < kPrepMats; ++mtx) {
     const size_t h = (size_t)1 << logs[mtx];
@@ -220,7 +224,7 @@ void machine_host_setup(const MachineProgram& prog, MachineVk* vk) {
       host_lde(col, logs[mtx], &lde[mtx][c]);
     }
   }
-  // mixed-height tree over (image, program, range) in chip order
+  // mixed-height tree over (image, program, table) in chip order
   const int lm = std::max(std::max(logs[0], logs[1]), logs[2]), logn = lm + 1;
   auto group_hash = [&](int group_logn, size_t pos, Fp out[8]) -> bool {
     std::vector<Fp> cat;
@@ -248,10 +252,11 @@ void machine_host_setup(const MachineProgram& prog, MachineVk* vk) {
   }
   for (int i = 0; i < 8; ++i) vk->prep_root[i] = level[i].to_canonical();
   vk->entry = prog.entry;
+  vk->pad_pc = prog.pad_pc();
   vk->log_prog = prog.log_prog;
   vk->log_image = prog.log_image;
   vk->keccak_mode = prog.keccak_mode;
-  vk_digest_of(vk->prep_root, vk->entry, vk->log_prog, vk->log_image, vk->keccak_mode, vk->digest);
+  vk_digest_of(vk->prep_root, vk->entry, vk->pad_pc, vk->log_prog, vk->log_image, vk->keccak_mode, vk->digest);
 }
 
 size_t machine_proof_body_words(const int* logh, uint32_t num_queries) {
@@ -305,7 +310,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   const size_t body_words = machine_proof_body_words(logh, num_queries);
   if (len != hd.body_offset + body_words * 4) { *err = "proof length mismatch"; return 7; }
   if (memcmp(hd.vk_digest, vk.digest, 32) != 0) { *err = "verifying key mismatch"; return 8; }
-  if (logh[kImage] != vk.log_image || logh[kProgram] != vk.log_prog || logh[kRange] != kRangeLogH) {
+  if (logh[kImage] != vk.log_image || logh[kProgram] != vk.log_prog || logh[kTable] != kTableLogH) {
     *err = "preprocessed table heights differ from the key";
     return 8;
   }
@@ -420,12 +425,15 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     ZetaCtx zc;
     zc.loc = o_main;
     zc.nxt = o_main_n;
+    zc.prp = o_prep;
     zc.first = zh * (zeta - Fp4::one()).inv();
     zc.trans = zeta - Fp4::from_base(wh_inv);
     zc.last = zh * (zeta - Fp4::from_base(wh_inv)).inv();
     // the CPU instances' public scalars: the first starts at the entry point at time 4 and hands over to the second,
     // which starts at the hand-over pc (a header word, absorbed into the transcript) right after the first's last row
+    // and ends on the padding instruction (reached through HALT only: the exit code bus would not balance otherwise)
     for (int i = 0; i < kNumCpuPub; ++i) zc.pub_[i] = Fp4::zero();
+    zc.pub_[kPubPadPc] = Fp4::from_base(Fp::from_canonical(vk.pad_pc));
     if (c == kCpu) {
       zc.pub_[kPubStartPc] = Fp4::from_base(Fp::from_canonical(vk.entry));
       zc.pub_[kPubStartTs] = Fp4::from_base(Fp::from_canonical(4));
@@ -449,7 +457,11 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       case kImage: eval_image(zc); break;
       case kProgram: break;
       case kMul: eval_mul(zc); break;
-      case kRange: break;
+      case kTable: eval_table(zc); break;
+      case kAlu:
+      case kAlu2: eval_alu(zc); break;
+      case kSub:
+      case kSub2: eval_sub(zc); break;
     }
     if (zc.k_ != nb) { *err = "internal: constraint count"; return 7; }
     // LogUp: row = [prep | main] at zeta

@@ -18,6 +18,7 @@ struct MachineVk {
   uint32_t prep_root[8];  // canonical
   uint32_t digest[8];     // canonical
   uint32_t entry;
+  uint32_t pad_pc;        // the padding instruction (last Program row): where HALT goes and where every proof ends
   int log_prog, log_image, keccak_mode;
 };
 
@@ -28,9 +29,9 @@ struct MachineHeader {
   size_t pv_offset, body_offset;
 };
 
-// preprocessed traces, canonical, column-major: image [3][2^log_image], program [10][2^log_prog]
+// preprocessed traces, canonical, column-major: image [4][2^log_image], program [12][2^log_prog], table [3][2^16]
 void machine_prep_traces(const MachineProgram& prog, std::vector<uint32_t>* image_prep, std::vector<uint32_t>* program_prep,
-                         std::vector<uint32_t>* range_prep);
+                         std::vector<uint32_t>* table_prep);
 // host-side commitment of the preprocessed tables (setup; no GPU)
 void machine_host_setup(const MachineProgram& prog, MachineVk* vk);
 size_t machine_proof_body_words(const int* logh, uint32_t num_queries);
