@@ -35,9 +35,17 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable)
 
-# chip widths of the machine proof (zk-state-proofs_amd/csrc/device/air_machine.hpp): (preprocessed, main, permutation)
-CHIPS = [("cpu", 0, 204, 48), ("keccak", 0, 2634, 104), ("keccak-mem", 0, 16, 16), ("mem-final", 0, 70, 8),
-         ("image", 3, 1, 8), ("program", 10, 1, 8), ("mul", 0, 161, 8), ("range", 1, 1, 8), ("cpu2", 0, 204, 48)]
+# chip widths of the machine proof (zk-state-proofs_amd/csrc/device/air_machine.hpp): (name, preprocessed, main, permutation),
+# read from the library at start-up (zksp_machine_chip_widths)
+CHIPS = []
+
+
+def load_chip_widths():
+    global CHIPS
+    if not CHIPS:
+        client_mod = importlib.import_module("zk-state-proofs_amd.client")
+        CHIPS = client_mod.machine_chip_widths()
+    return CHIPS
 
 
 def usable_cores():
@@ -58,7 +66,7 @@ def stage_bytes(heights):
     a stage reads its inputs once and writes its outputs once."""
     out = {k: 0 for k in ("m_trace", "m_lde_main", "m_leaf_main", "m_perm", "m_lde_perm", "m_quotient", "m_lde_quot",
                           "m_open", "m_reduce")}
-    for (name, p, w, e), lh in zip(CHIPS, heights):
+    for (name, p, w, e), lh in zip(load_chip_widths(), heights):
         h = 1 << lh
         out["m_trace"] += 4 * h * w
         out["m_lde_main"] += 4 * h * w * 4                      # read H, write coefficients H, write LDE 2H
@@ -152,7 +160,8 @@ def verify_resident_batch(zk, client, pk, vk, handles, traces, with_oracle, n_ch
     bytes.  Raises on any mismatch."""
     lib, h = client._lib, client._h
     B = len(handles)
-    lh = (C.c_int32 * zk.MACHINE_CHIPS)(*handles[0].heights())
+    shape = zk.machine_cover_heights(handles)  # the batch is proven with one shape: the heights of its largest counts
+    lh = (C.c_int32 * zk.MACHINE_CHIPS)(*shape)
     bw = lib.zksp_machine_body_words(h, lh)
     bodies = np.zeros((B, bw), np.uint32)
     rc = lib.zksp_hip_machine_fetch_bodies(h, bodies.ctypes.data_as(C.c_void_p), bodies.size)
@@ -161,7 +170,7 @@ def verify_resident_batch(zk, client, pk, vk, handles, traces, with_oracle, n_ch
     host = zk.ProverClient(device=-1)
     idx = sorted({int(round(k * (B - 1) / max(1, n_check - 1))) for k in range(n_check)})
     for i in idx:
-        proof = handles[i].proof_from_body(pk, bodies[i])
+        proof = handles[i].proof_from_body(pk, bodies[i], shape)
         if proof.public_values != traces[i]:
             raise RuntimeError(f"bench: proof {i} carries wrong public values")
         host.verify(proof, vk)  # raises VerificationError
@@ -172,9 +181,9 @@ def verify_resident_batch(zk, client, pk, vk, handles, traces, with_oracle, n_ch
         oracle.build()
         i = idx[len(idx) // 2]
         t0 = time.perf_counter()
-        exp = oracle.machine_prove(with_oracle(i))
+        exp = oracle.machine_prove(dict(with_oracle(i), shape=shape))
         oracle_s = time.perf_counter() - t0
-        if handles[i].proof_from_body(pk, bodies[i]).to_bytes() != exp:
+        if handles[i].proof_from_body(pk, bodies[i], shape).to_bytes() != exp:
             raise RuntimeError(f"bench: proof {i} of the timed batch differs from the CPU oracle's bytes")
         oracle_equal = i
     return {"verified_indices": idx, "oracle_byte_equal_index": oracle_equal, "proof_bytes": int(bw * 4 + zk.MACHINE_HEADER_WORDS * 4 + 72)}, oracle_s
@@ -258,13 +267,14 @@ def as_committed_mode(zk, fx, device):
         lib.zksp_hip_machine_prove(h)
     lib.zksp_hip_sync(h)
     el = time.perf_counter() - t0
-    lh = (C.c_int32 * zk.MACHINE_CHIPS)(*handles[0].heights())
+    shape = zk.machine_cover_heights(handles)
+    lh = (C.c_int32 * zk.MACHINE_CHIPS)(*shape)
     bw = lib.zksp_machine_body_words(h, lh)
     bodies = np.zeros((NB, bw), np.uint32)
     if lib.zksp_hip_machine_fetch_bodies(h, bodies.ctypes.data_as(C.c_void_p), bodies.size):
         return {"error": client.last_error()}
-    zk.ProverClient(device=-1, keccak_mode=zk.KECCAK_OBSERVE).verify(handles[1].proof_from_body(pk, bodies[1]), vk)
-    return {"value": 2 * NB / el, "unit": "proofs/s", "batch": NB, "ms_per_proof": el * 1e3 / (2 * NB), "chip_log_heights": handles[0].heights(),
+    zk.ProverClient(device=-1, keccak_mode=zk.KECCAK_OBSERVE).verify(handles[1].proof_from_body(pk, bodies[1], shape), vk)
+    return {"value": 2 * NB / el, "unit": "proofs/s", "batch": NB, "ms_per_proof": el * 1e3 / (2 * NB), "chip_log_heights": shape,
             "host_trace_ms_per_proof": trace_ms,
             "note": "guest as committed: software keccak-f inside the CPU chip (1 406 960 cycles); verified on the host"}
 
@@ -349,8 +359,7 @@ def main():
         handles.append(client.machine_trace_handle(pk, s))
         exec_s += time.perf_counter() - t_exec
         stdins_keep.append(s)
-    heights = handles[0].heights()
-    assert all(hd.heights() == heights for hd in handles), "acct-d8 fixtures must share one height vector"
+    heights = zk.machine_cover_heights(handles)  # one shape per batch: the heights that cover the largest counts
     trace_ms_per_proof = exec_s * 1e3 / B
     arr = (C.c_void_p * B)(*[t._h for t in handles])
     t_load = time.perf_counter()
@@ -418,7 +427,7 @@ def main():
     stage_gbs = {k: round(B * v / (spans[k] * 1e-3) / 1e9, 1) for k, v in sb.items() if spans.get(k)}
     # dominant kernel: the leaf hash of the main commitment (one launch per step: mmcs_leaf_kernel over the tallest group)
     leaf_ms = spans["m_leaf_main"]
-    leaf_group = [(w, lh) for (name, p, w, e), lh in zip(CHIPS, heights) if lh == max(heights)]
+    leaf_group = [(w, lh) for (name, p, w, e), lh in zip(load_chip_widths(), heights) if lh == max(heights)]
     alg_bytes = B * sum(4 * (2 << lh) * w for w, lh in leaf_group) + B * 32 * (2 << max(heights))
     achieved = alg_bytes / (leaf_ms * 1e-3) / 1e9
     stage_gbs["m_leaf_main"] = round(achieved, 1)  # this span is the tallest group's launch only

@@ -55,7 +55,7 @@ typedef struct {
 } zksp_options;
 /* What zksp_prove / zksp_prove_batch establish:
  * MACHINE      the guest's whole execution (CPU, memory, program, keccak, multiplier chips joined by
- *              LogUp buses; proof format v5): the statement of the reference's client.prove().
+ *              LogUp buses; proof format v6): the statement of the reference's client.prove().
  * KECCAK_CHIP  only "these keccak-f outputs belong to these inputs" (round-1 format v2, a component
  *              benchmark; NOT a proof that the guest ran). */
 #define ZKSP_PROOF_MACHINE 1
@@ -157,20 +157,28 @@ void zksp_mtrace_free(zksp_mtrace* t);
 /* Borrowed pointer into the handle. */
 int zksp_mtrace_section(const zksp_mtrace* t, int which, const void** ptr, size_t* bytes);
 int zksp_mtrace_info(const zksp_mtrace* t, zksp_mtrace_info_t* info);
-/* Device-resident machine proving (bench.py, parity tests): upload the records of n traced runs
- * with identical chip heights, enqueue one proving pass, fetch the proof bodies ([n][body_words]
- * canonical u32; body_words = zksp_machine_body_words of the traces' heights). */
-#define ZKSP_MACHINE_CHIPS 9    /* cpu, keccak, keccak-mem, mem-final, image, program, mul, range, cpu2 */
+/* Device-resident machine proving (bench.py, parity tests): upload the records of n traced runs (they are proven
+ * with one shape: zksp_machine_cover_heights), enqueue one proving pass, fetch the proof bodies ([n][body_words]
+ * canonical u32; body_words = zksp_machine_body_words of that shape). */
+#define ZKSP_MACHINE_CHIPS 13   /* cpu, keccak, keccak-mem, mem-final, image, program, mul, table, cpu2, alu, alu2, subword, subword2 */
 int zksp_mtrace_heights(const zksp_mtrace* t, int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 size_t zksp_machine_body_words(const zksp_client* c, const int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
+/* The shape a batch of these runs is proven with: the chip heights that cover the largest cycle / event / address
+ * counts among them (zksp_hip_machine_load uses exactly this).  A run can be proven with any shape it fits. */
+int zksp_machine_cover_heights(const zksp_mtrace* const* traces, size_t n, int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
+/* Column widths of chip `chip` (0 .. ZKSP_MACHINE_CHIPS - 1, proof order): preprocessed, main, permutation (LogUp helper and
+ * running-sum columns as base-field columns).  Returns the chip's name, NULL for an unknown chip.  (What bench.py prices its
+ * algorithmic bytes with; sp1-core-machine's chip registry in SP1, reference Cargo.lock:7130.) */
+const char* zksp_machine_chip_widths(int chip, int32_t* widths3);
 int zksp_hip_machine_load(zksp_client* c, const zksp_pk* pk, const zksp_mtrace* const* traces, size_t n);
 int zksp_hip_machine_prove(zksp_client* c);
 int zksp_hip_machine_fetch_bodies(zksp_client* c, uint32_t* out, size_t cap_words);
 /* Only the 8-word main-trace commitment of every resident proof ([n][8]): what the proof farm all-gathers. */
 int zksp_hip_machine_fetch_roots(zksp_client* c, uint32_t* out, size_t cap_words);
-/* Complete v5 proof object from one fetched body and the trace it belongs to. */
-int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const uint32_t* body, size_t body_words,
-                                 zksp_proof** out);
+/* Complete v6 proof object from one fetched body and the trace it belongs to.  log_heights: the shape the batch was
+ * proven with (zksp_machine_cover_heights of the loaded traces), NULL = the trace's own minimal heights. */
+int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] or NULL */,
+                                 const uint32_t* body, size_t body_words, zksp_proof** out);
 /* The machine-proof part of the verifying key: Merkle root of the preprocessed Program / Image
  * tables and the digest that binds it to the entry point, table heights and keccak mode
  * (8 canonical u32 each). */

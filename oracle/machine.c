@@ -368,8 +368,19 @@ uint32_t orc_machine_x0_last(const orc_machine_input* in) {
 }
 static uint32_t pad_pc_of(const orc_machine_input* in) { return in->text_base + 4 * (uint32_t)(in->n_program - 1); }
 
+/* rows of the first instance of a split chip */
+static size_t first_rows(const orc_machine_input* in, int chip, size_t n) {
+  return in->shape ? (size_t)1 << in->shape[chip] : split_rows(n);
+}
+/* rows of the two CPU instances together */
+static size_t cpu_rows(const orc_machine_input* in) {
+  int logh[N_CHIPS];
+  orc_machine_heights(in, logh);
+  return ((size_t)1 << logh[CH_CPU]) + ((size_t)1 << logh[CH_CPU2]);
+}
+
 void orc_machine_cpu_pub(const orc_machine_input* in, int chip, uint32_t pub[CPUPUB_N]) {
-  const size_t h0 = split_rows(in->n_cycles);
+  const size_t h0 = first_rows(in, CH_CPU, in->n_cycles);
   const uint32_t pad = pad_pc_of(in);
   const uint32_t handover = h0 < in->n_cycles ? in->cycles[12 * h0] : pad;
   pub[CPUPUB_PAD_PC] = pad;
@@ -381,6 +392,7 @@ void orc_machine_cpu_pub(const orc_machine_input* in, int chip, uint32_t pub[CPU
 }
 
 void orc_machine_heights(const orc_machine_input* in, int logh[N_CHIPS]) {
+  if (in->shape) { memcpy(logh, in->shape, N_CHIPS * sizeof(int)); return; }
   const size_t na = orc_machine_events(in, 0, NULL), ns = orc_machine_events(in, 1, NULL);
   logh[CH_CPU] = clog2(split_rows(in->n_cycles));
   logh[CH_CPU2] = second_logh(in->n_cycles);
@@ -618,11 +630,11 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
 #define T(col) t[(size_t)(col) * h + r]
   switch (chip) {
     case CH_CPU: fill_cpu(in, h, t, 0); break;
-    case CH_CPU2: fill_cpu(in, h, t, split_rows(in->n_cycles)); break;
+    case CH_CPU2: fill_cpu(in, h, t, first_rows(in, CH_CPU, in->n_cycles)); break;
     case CH_ALU: fill_alu(in, h, t, 0); break;
-    case CH_ALU2: fill_alu(in, h, t, split_rows(orc_machine_events(in, 0, NULL))); break;
+    case CH_ALU2: fill_alu(in, h, t, first_rows(in, CH_ALU, orc_machine_events(in, 0, NULL))); break;
     case CH_SUB: fill_sub(in, h, t, 0); break;
-    case CH_SUB2: fill_sub(in, h, t, split_rows(orc_machine_events(in, 1, NULL))); break;
+    case CH_SUB2: fill_sub(in, h, t, first_rows(in, CH_SUB, orc_machine_events(in, 1, NULL))); break;
     case CH_KECCAK: {
       uint64_t* st = (uint64_t*)calloc(25 * (in->n_keccak ? in->n_keccak : 1), 8);
       for (size_t p = 0; p < in->n_keccak; ++p) memcpy(st + 25 * p, ((const kcall_t*)(in->keccak + 408 * p))->in, 200);
@@ -654,11 +666,14 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
       /* soundness tests: ZKSP_ORACLE_MF_WRAP=<row> claims the difference to the next row's address that only holds
        * mod p when that address does not increase (DIFF = p - 1 for a repeated address, as limbs) */
       const char* wrap = getenv("ZKSP_ORACLE_MF_WRAP");
+      const size_t crows = in->n_cycles ? cpu_rows(in) : 0;
       for (size_t r = 0; r < in->n_memfinal; ++r) {
         const uint32_t* f = in->memfinal + 5 * r;
         T(MF_IS_REAL) = 1; T(MF_LO) = f[0] & 0xffff; T(MF_HI) = f[0] >> 16; T(MF_IS_INIT) = f[4];
         T(MF_INIT_LO) = f[1] & 0xffff; T(MF_INIT_HI) = f[1] >> 16;
         T(MF_FIN_LO) = f[2] & 0xffff; T(MF_FIN_HI) = f[2] >> 16; T(MF_FIN_TS) = f[3];
+        /* x0 (row 0) is read once more by every CPU row after the last cycle: its last access is the last row's */
+        if (r == 0 && crows > in->n_cycles) T(MF_FIN_TS) = 4 * (uint32_t)crows;
         if (r + 1 < in->n_memfinal) {
           const uint32_t nx = in->memfinal[5 * (r + 1)];
           const uint32_t bw = (nx & 0xffff) < (f[0] & 0xffff) + 1;
@@ -697,6 +712,8 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
         q[(size_t)PR_TGT_LO * h] = p[8] & 0xffff; q[(size_t)PR_TGT_HI * h] = p[8] >> 16;
         if (in->prog_mult) T(0) = in->prog_mult[r] % FP;
       }
+      /* the padding instruction (last row) is fetched by every CPU row after the last cycle */
+      if (in->prog_mult && in->n_cycles) { const size_t r = in->n_program - 1; T(0) = (uint32_t)(cpu_rows(in) - in->n_cycles); }
       break;
     case CH_MUL:
       for (size_t r = 0; r < in->n_muls; ++r) {

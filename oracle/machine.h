@@ -146,9 +146,11 @@ typedef struct {
   int log_prog, log_image;
   const uint32_t* cycles; size_t n_cycles;     /* 12 u32 per cycle */
   const uint8_t* keccak; size_t n_keccak;      /* 408 bytes per call */
-  const uint32_t* memfinal; size_t n_memfinal; /* 5 u32: addr, init, fin, fin_ts, is_init */
+  const uint32_t* memfinal; size_t n_memfinal; /* 5 u32: addr, init, fin, fin_ts, is_init; row 0 is x0, closed at its last real access */
   const uint32_t* muls; size_t n_muls;         /* 3 u32 */
-  const uint32_t* prog_mult;                   /* n_program */
+  const uint32_t* prog_mult;                   /* n_program; the padding row holds 0 (its fetches depend on the heights) */
+  const int* shape;                            /* NULL: the minimal heights; else N_CHIPS log heights the run fits (a batch of
+                                                  runs is proven with one shape: the heights of their largest counts) */
 } orc_machine_input;
 
 /* The oracle's own event lists (cycle indices of the ALU-chip and sub-word-chip rows, in execution order) and the

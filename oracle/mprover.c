@@ -359,6 +359,7 @@ void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t pr
   chipd cd[N_CHIPS];
   orc_machine_input tmp = *in;
   tmp.prog_mult = NULL;
+  tmp.shape = NULL;
   tmp.n_cycles = tmp.n_keccak = tmp.n_memfinal = tmp.n_muls = 0;
   init_chips(&tmp, cd, 1);
   mmcs t;

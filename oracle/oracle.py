@@ -296,7 +296,7 @@ class MachineInput(C.Structure):
                 ("entry", C.c_uint32), ("text_base", C.c_uint32), ("log_prog", C.c_int), ("log_image", C.c_int),
                 ("cycles", C.c_void_p), ("n_cycles", C.c_size_t), ("keccak", C.c_void_p), ("n_keccak", C.c_size_t),
                 ("memfinal", C.c_void_p), ("n_memfinal", C.c_size_t), ("muls", C.c_void_p), ("n_muls", C.c_size_t),
-                ("prog_mult", C.c_void_p)]
+                ("prog_mult", C.c_void_p), ("shape", C.c_void_p)]
 
 
 class MachinePublic(C.Structure):
@@ -305,7 +305,8 @@ class MachinePublic(C.Structure):
 
 
 def machine_input(t: dict):
-    """MachineInput over the arrays of a machine trace; returns (struct, keep-alive list)."""
+    """MachineInput over the arrays of a machine trace; returns (struct, keep-alive list).  ``t["shape"]`` (optional):
+    the chip log-heights to prove the run with (a batch shares one shape); default: the run's own minimal heights."""
     keep = {k: np.ascontiguousarray(t[k]) for k in ("program", "image", "cycles", "keccak", "memfinal", "muls",
                                                     "prog_mult")}
     info = t["info"]
@@ -313,7 +314,11 @@ def machine_input(t: dict):
                       info.entry, int(keep["program"][0, 0]), info.log_prog, info.log_image,
                       _p(keep["cycles"]), len(keep["cycles"]), _p(keep["keccak"]), len(keep["keccak"]),
                       _p(keep["memfinal"]), len(keep["memfinal"]), _p(keep["muls"]), len(keep["muls"]),
-                      _p(keep["prog_mult"]))
+                      _p(keep["prog_mult"]), None)
+    if t.get("shape") is not None:
+        keep["shape"] = np.ascontiguousarray(t["shape"], dtype=np.int32)
+        assert len(keep["shape"]) == N_CHIPS
+        mi.shape = keep["shape"].ctypes.data
     return mi, keep
 
 

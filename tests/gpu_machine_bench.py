@@ -45,12 +45,13 @@ for name in (b"m_trace", b"m_lde_main", b"m_commit_main", b"m_perm", b"m_lde_per
              b"m_commit_quot", b"m_open", b"merkle_open", b"m_reduce", b"fri_commit", b"fri_fold", b"grind", b"transcript", b"m_assemble"):
     lib.zksp_hip_profile_read(h, name, C.byref(tot), C.byref(cnt))
     print(f"  {name.decode():16s} {tot.value / steps:9.2f} ms/step")
-lh = (C.c_int32 * zk.MACHINE_CHIPS)(*handles[0].heights())
+shape = zk.machine_cover_heights(handles)
+lh = (C.c_int32 * zk.MACHINE_CHIPS)(*shape)
 bw = lib.zksp_machine_body_words(h, lh)
 bodies = np.zeros((B, bw), np.uint32)
 assert lib.zksp_hip_machine_fetch_bodies(h, bodies.ctypes.data_as(C.c_void_p), bodies.size) == 0
 host = zk.ProverClient(device=-1, keccak_mode=mode)
 t0 = time.perf_counter()
 for i in range(min(B, 3)):
-    host.verify(handles[i].proof_from_body(pk, bodies[i]), vk)
+    host.verify(handles[i].proof_from_body(pk, bodies[i], shape), vk)
 print("verified; verify ms/proof", (time.perf_counter() - t0) * 1e3 / min(B, 3), "proof bytes", bw * 4)

@@ -33,9 +33,10 @@ for _ in range(steps):
 lib.zksp_hip_sync(h)
 el = time.perf_counter() - t0
 print(f"batch {B}: {el * 1e3 / steps:.2f} ms/step", flush=True)
-lh = (C.c_int32 * zk.MACHINE_CHIPS)(*handles[0].heights())
+shape = zk.machine_cover_heights(handles)
+lh = (C.c_int32 * zk.MACHINE_CHIPS)(*shape)
 bw = lib.zksp_machine_body_words(h, lh)
 bodies = np.zeros((B, bw), np.uint32)
 assert lib.zksp_hip_machine_fetch_bodies(h, bodies.ctypes.data_as(C.c_void_p), bodies.size) == 0
-zk.ProverClient(device=-1).verify(handles[0].proof_from_body(pk, bodies[0]), vk)
+zk.ProverClient(device=-1).verify(handles[0].proof_from_body(pk, bodies[0], shape), vk)
 print("verified")

@@ -11,6 +11,11 @@ def first_difference(body, expected):
     return None if bad.size == 0 else (int(bad[0]), int(bad.size))
 
 
+def shape_of(zk, raw):
+    """The chip log-heights a proof was made with (its header): a batch shares one shape."""
+    return [int.from_bytes(raw[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
+
+
 @pytest.mark.parametrize("depth,nq,pow_bits", [(1, 8, 6)])
 def test_machine_proof_matches_oracle(zk, fx, oracle, depth, nq, pow_bits):
     client = zk.ProverClient(device=0, num_queries=nq, pow_bits=pow_bits, max_batch=2)
@@ -21,16 +26,19 @@ def test_machine_proof_matches_oracle(zk, fx, oracle, depth, nq, pow_bits):
         s.write(fx.acct_fixture(depth, seed=seed).to_borsh())
         handles.append(client.machine_trace_handle(pk, s))
         traces.append(client.machine_trace(pk, s))
-    assert handles[0].heights() == handles[1].heights() == oracle.machine_heights(traces[0])
+    assert handles[0].heights() == oracle.machine_heights(traces[0]) and handles[1].heights() == oracle.machine_heights(traces[1])
+    # a batch is proven with ONE shape: the chip heights that cover the largest counts among its runs
+    shape = zk.machine_cover_heights(handles)
+    assert all(a >= b for hd in handles for a, b in zip(shape, hd.heights()))
     bodies = client.machine_prove_resident(pk, handles)
     host = zk.ProverClient(device=-1, num_queries=nq, pow_bits=pow_bits)
     for i in range(2):
-        exp = oracle.machine_prove(traces[i], num_queries=nq, pow_bits=pow_bits)
+        exp = oracle.machine_prove(dict(traces[i], shape=shape), num_queries=nq, pow_bits=pow_bits)
         hw = zk.MACHINE_HEADER_WORDS + (len(traces[i]["public_values"]) + 3) // 4
         e = np.frombuffer(exp, dtype=np.uint32)[hw:]
         assert e.shape == bodies[i].shape
         assert first_difference(bodies[i], e) is None, first_difference(bodies[i], e)
-        proof = handles[i].proof_from_body(pk, bodies[i])
+        proof = handles[i].proof_from_body(pk, bodies[i], shape)
         assert proof.to_bytes() == exp
         host.verify(proof, vk)
 
@@ -39,7 +47,7 @@ def test_reference_flow_acct_d8_full_size(zk, fx, oracle):
     """BASELINE config 2 through the reference's own call sequence (prover/src/bin/main.rs:59-87) with the
     default client: setup -> prove(..).run() -> public_values -> verify, at full parameters (100 queries,
     16 proof-of-work bits).  The proof is the machine proof of the 391 400-cycle precompile-shape run
-    (CPU chip 2^18 + 2^17 rows x 204): byte-identical to the oracle's, accepted by a host-only verifier, every
+    (CPU chip 2^18 + 2^17 rows x 67, ALU and sub-word chips beside it): byte-identical to the oracle's, accepted by a host-only verifier, every
     tampered region rejected, and another public value cannot be attached."""
     client = zk.ProverClient(device=0)
     pk, vk = client.setup(zk.merkle_elf())
@@ -53,13 +61,13 @@ def test_reference_flow_acct_d8_full_size(zk, fx, oracle):
     raw = proof.to_bytes()
     heights = [int.from_bytes(raw[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
     # 391 400 cycles: 2^18 rows in the first CPU instance, 2^17 in the second
-    assert int.from_bytes(raw[4:8], "little") == zk.MACHINE_VERSION and heights[0] == 18 and heights[-1] == 17
+    assert int.from_bytes(raw[4:8], "little") == zk.MACHINE_VERSION and heights[0] == 18 and heights[zk.MACHINE_CHIP_NAMES.index("cpu2")] == 17
     assert raw == oracle.machine_prove(trace)
     host = zk.ProverClient(device=-1)
     host.verify(zk.SP1ProofWithPublicValues.from_bytes(raw), vk)
     rng = np.random.default_rng(3)
     hb = zk.MACHINE_HEADER_WORDS * 4  # exit code, public-values length, their digest, the values, the body
-    for pos in [10 * 4, 11 * 4, 12 * 4 + 1, hb + 5, hb + 72 + 3] + [int(x) for x in rng.integers(hb + 72, len(raw), 12)]:
+    for pos in [(2 + zk.MACHINE_CHIPS) * 4, (3 + zk.MACHINE_CHIPS) * 4, (4 + zk.MACHINE_CHIPS) * 4 + 1, hb + 5, hb + 72 + 3] + [int(x) for x in rng.integers(hb + 72, len(raw), 12)]:
         bad = bytearray(raw)
         bad[pos] ^= 1
         with pytest.raises(zk.ZkspError):
@@ -86,8 +94,9 @@ def test_as_committed_instruction_stream(zk, fx):
 
 
 def test_batch_of_machine_proofs(zk, fx, oracle):
-    """Several guest runs proven in lockstep (prove_batch): mixed heights fall into separate groups, every
-    proof verifies, one proof of the largest group equals the oracle's bytes."""
+    """Several guest runs proven in lockstep (prove_batch): runs of different size classes fall into separate groups,
+    runs of one class share the shape that covers the largest of them, every proof verifies, one proof of the largest
+    group equals the oracle's bytes for that shape."""
     nq, pw = 6, 5
     client = zk.ProverClient(device=0, num_queries=nq, pow_bits=pw, max_batch=4)
     pk, vk = client.setup(zk.merkle_elf())
@@ -106,13 +115,16 @@ def test_batch_of_machine_proofs(zk, fx, oracle):
     for m, p in zip(inputs, proofs):
         assert p.public_values == verify_merkle_proof(m.root_hash, m.proof, m.key)
         client.verify(p, vk)
-    assert proofs[3].to_bytes() == oracle.machine_prove(trace3, num_queries=nq, pow_bits=pw)
+    raw3 = proofs[3].to_bytes()
+    assert raw3 == oracle.machine_prove(dict(trace3, shape=shape_of(zk, raw3)), num_queries=nq, pow_bits=pw)
+    assert len({tuple(shape_of(zk, p.to_bytes())) for p in proofs}) >= 2
 
 
-def test_chunked_batch_equals_single_proofs(zk, fx):
+def test_chunked_batch_equals_single_proofs(zk, fx, oracle):
     """prove_batch with more inputs than max_batch proves chunk k while chunk k + 1 uploads into the spare record
     set and chunk k - 1 is wrapped on the host: every proof must be byte-identical to the one a single prove()
-    call makes (the prover is deterministic), including the short last chunk."""
+    call makes when the shapes agree (the prover is deterministic), and to the oracle's for its shape otherwise,
+    including the short last chunk."""
     nq, pw = 6, 5
     client = zk.ProverClient(device=0, num_queries=nq, pow_bits=pw, max_batch=2)
     pk, vk = client.setup(zk.merkle_elf())
@@ -124,15 +136,18 @@ def test_chunked_batch_equals_single_proofs(zk, fx):
         stdins.append(s)
     proofs, status = client.prove_batch(pk, stdins)
     assert status == [0] * len(inputs)
-    heights = {p.to_bytes()[8:8 + 4 * zk.MACHINE_CHIPS] for p in proofs}
-    assert len(heights) == 1, "fixture seeds were meant to give one height group"
     single = zk.ProverClient(device=0, num_queries=nq, pow_bits=pw, max_batch=1)
     pk1, vk1 = single.setup(zk.merkle_elf())
     for m, p in zip(inputs, proofs):
         s = zk.SP1Stdin()
         s.write(m.to_borsh())
+        trace = single.machine_trace(pk1, s)
         q = single.prove(pk1, s).run()
-        assert q.to_bytes() == p.to_bytes()
+        raw = p.to_bytes()
+        if shape_of(zk, raw) == shape_of(zk, q.to_bytes()):
+            assert q.to_bytes() == raw
+        else:
+            assert raw == oracle.machine_prove(dict(trace, shape=shape_of(zk, raw)), num_queries=nq, pow_bits=pw)
         client.verify(p, vk)
 
 

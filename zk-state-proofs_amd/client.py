@@ -122,11 +122,14 @@ def load_library() -> C.CDLL:
     lib.zksp_mtrace_heights.argtypes = [vp, vp]
     lib.zksp_machine_body_words.argtypes = [vp, vp]
     lib.zksp_machine_body_words.restype = sz
+    lib.zksp_machine_chip_widths.argtypes = [C.c_int, vp]
+    lib.zksp_machine_chip_widths.restype = C.c_char_p
     lib.zksp_hip_machine_load.argtypes = [vp, vp, C.POINTER(vp), sz]
     lib.zksp_hip_machine_prove.argtypes = [vp]
     lib.zksp_hip_machine_fetch_bodies.argtypes = [vp, vp, sz]
     lib.zksp_hip_machine_fetch_roots.argtypes = [vp, vp, sz]
-    lib.zksp_machine_proof_from_body.argtypes = [vp, vp, vp, sz, C.POINTER(vp)]
+    lib.zksp_machine_proof_from_body.argtypes = [vp, vp, vp, vp, sz, C.POINTER(vp)]
+    lib.zksp_machine_cover_heights.argtypes = [vp, sz, vp]
     lib.zksp_get_params.argtypes = [vp, C.POINTER(Params)]
     lib.zksp_proof_body_words.argtypes = [vp, C.c_int]
     lib.zksp_proof_body_words.restype = sz
@@ -166,7 +169,7 @@ ABI_SYMBOLS = [
     "zksp_proof_public_values", "zksp_proof_serialize", "zksp_proof_deserialize", "zksp_proof_free", "zksp_verify",
     "zksp_execute", "zksp_execute_keccak", "zksp_opcode_name", "zksp_machine_trace", "zksp_mtrace_free",
     "zksp_mtrace_section", "zksp_mtrace_info", "zksp_vk_machine", "zksp_mtrace_heights", "zksp_machine_body_words",
-    "zksp_hip_machine_load", "zksp_hip_machine_prove", "zksp_hip_machine_fetch_bodies", "zksp_hip_machine_fetch_roots", "zksp_machine_proof_from_body", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
+    "zksp_machine_chip_widths", "zksp_machine_cover_heights", "zksp_hip_machine_load", "zksp_hip_machine_prove", "zksp_hip_machine_fetch_bodies", "zksp_hip_machine_fetch_roots", "zksp_machine_proof_from_body", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
     "zksp_hip_prove_resident", "zksp_proof_from_body", "zksp_hip_fetch_bodies", "zksp_hip_fetch_roots", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
     "zksp_hip_profile_enable", "zksp_hip_profile_read", "zksp_hip_profile_reset", "zksp_dev_malloc", "zksp_dev_free",
     "zksp_dev_upload", "zksp_dev_download", "zksp_dev_memset", "zksp_hip_lde", "zksp_hip_merkle_commit",
@@ -272,6 +275,17 @@ def proof_from_body(body, log_h: int, states, exit_code: int, public_values: byt
     return SP1ProofWithPublicValues(lib, h, lib.zksp_proof_free)
 
 
+def machine_chip_widths():
+    """[(name, preprocessed, main, permutation widths)] of the machine proof's chips, in proof order."""
+    lib = load_library()
+    out = []
+    for c in range(MACHINE_CHIPS):
+        w = (C.c_int32 * 3)()
+        name = lib.zksp_machine_chip_widths(c, w)
+        out.append((name.decode(), int(w[0]), int(w[1]), int(w[2])))
+    return out
+
+
 class MachineTraceHandle(_Handle):
     """A traced guest run kept on the C side (``zksp_mtrace``)."""
 
@@ -280,14 +294,28 @@ class MachineTraceHandle(_Handle):
         self._lib.zksp_mtrace_heights(self._h, lh)
         return list(lh)
 
-    def proof_from_body(self, pk: "ProvingKey", body) -> "SP1ProofWithPublicValues":
+    def proof_from_body(self, pk: "ProvingKey", body, heights=None) -> "SP1ProofWithPublicValues":
+        """The proof object of this run from a fetched body; ``heights``: the shape the batch was proven with
+        (``machine_cover_heights`` of the loaded traces), None = this run's own minimal heights."""
         import numpy as np
         body = np.ascontiguousarray(body, dtype=np.uint32)
         h = C.c_void_p()
-        rc = self._lib.zksp_machine_proof_from_body(pk._h, self._h, body.ctypes.data_as(C.c_void_p), body.size, C.byref(h))
+        lh = (C.c_int32 * MACHINE_CHIPS)(*heights) if heights is not None else None
+        rc = self._lib.zksp_machine_proof_from_body(pk._h, self._h, lh, body.ctypes.data_as(C.c_void_p), body.size, C.byref(h))
         if rc:
             raise ZkspError(rc, "machine_proof_from_body")
         return SP1ProofWithPublicValues(self._lib, h, self._lib.zksp_proof_free)
+
+
+def machine_cover_heights(traces):
+    """The shape (chip log-heights) a batch of these traced runs (MachineTraceHandle) is proven with."""
+    n = len(traces)
+    arr = (C.c_void_p * n)(*[t._h for t in traces])
+    lh = (C.c_int32 * MACHINE_CHIPS)()
+    rc = traces[0]._lib.zksp_machine_cover_heights(arr, n, lh)
+    if rc:
+        raise ZkspError(rc, "machine_cover_heights")
+    return list(lh)
 
 
 class _ProveBuilder:
@@ -427,8 +455,8 @@ class ProverClient:
         return MachineTraceHandle(self._lib, h, self._lib.zksp_mtrace_free)
 
     def machine_prove_resident(self, pk: ProvingKey, traces):
-        """Loads traced runs (MachineTraceHandle, identical chip heights), proves them in lockstep on the
-        GPU and returns the proof bodies as a numpy array [n][body_words]."""
+        """Loads traced runs (MachineTraceHandle), proves them in lockstep on the GPU with one shape
+        (``machine_cover_heights(traces)``) and returns the proof bodies as a numpy array [n][body_words]."""
         import numpy as np
         n = len(traces)
         arr = (C.c_void_p * n)(*[t._h for t in traces])
@@ -437,7 +465,7 @@ class ProverClient:
             rc = self._lib.zksp_hip_machine_prove(self._h)
         if rc:
             raise ZkspError(rc, self.last_error())
-        lh = (C.c_int32 * MACHINE_CHIPS)(*traces[0].heights())
+        lh = (C.c_int32 * MACHINE_CHIPS)(*machine_cover_heights(traces))
         bw = self._lib.zksp_machine_body_words(self._h, lh)
         out = np.zeros((n, bw), np.uint32)
         rc = self._lib.zksp_hip_machine_fetch_bodies(self._h, out.ctypes.data_as(C.c_void_p), out.size)

@@ -23,11 +23,11 @@ constexpr int kMaxSegs = 16;  // at least kNumChips: every chip could have the s
 struct MachineRecords {
   const uint32_t* cycles;      // [B][cap_cycles][12]
   const uint8_t* kcalls;       // [B][cap_keccak][408]
-  const uint32_t* memfinal;    // [B][cap_memfinal][5]
+  const uint32_t* memfinal;    // [B][cap_memfinal][5]; row 0 is x0, closed at its last real access (the padding rows move that)
   const uint32_t* muls;        // [B][cap_muls][3]
   const uint32_t* alu_idx;     // [B][cap_alu]: cycle index of every ALU-chip row
   const uint32_t* sub_idx;     // [B][cap_sub]: cycle index of every sub-word-chip row
-  const uint32_t* prog_mult;   // [B][2^log_prog]
+  const uint32_t* prog_mult;   // [B][2^log_prog]; the padding row (n_program - 1) holds 0: its fetches follow from cpu_rows
   const uint32_t* counts;      // [B][8]: cycles, keccak calls, memfinal rows, muls, ALU rows, sub-word rows, last time x0 was
                                //         accessed by a real cycle, 0
   uint32_t* table_hist;        // [B][3][2^16] scratch: multiplicities of the table chip, counted on the device
@@ -35,6 +35,7 @@ struct MachineRecords {
   size_t cap_cycles, cap_keccak, cap_memfinal, cap_muls, cap_alu, cap_sub;
   const uint32_t* program;     // [n_program][9] (shared); the last row is the padding instruction
   uint32_t text_base, n_program, n_image;
+  uint32_t cpu_rows;           // rows of the two CPU instances together: the rows past the last cycle fetch the padding instruction
 };
 constexpr int kCountWords = 8;
 // trace: [B][main_width][2^logh] of the given chip (every chip but kKeccak and kTable)

@@ -287,7 +287,8 @@ __global__ __launch_bounds__(kMT) void memfinal_trace_kernel(MachineRecords rec,
   o.flag(MF_IS_INIT, f[4] != 0);
   o.limbs(MF_INIT_LO, f[1]);
   o.limbs(MF_FIN_LO, f[2]);
-  o.val(MF_FIN_TS, f[3]);
+  // x0 (row 0) is read once more by every CPU row after the last cycle: its last access is the last row's
+  o.val(MF_FIN_TS, r == 0 && rec.cpu_rows > rec.counts[kCountWords * b] ? 4 * rec.cpu_rows : f[3]);
   uint32_t d_lo = 0, d_hi = 0, bw = 0;
   if (r + 1 < n) {  // next address - address - 1, limb-wise with a borrow
     const uint32_t nx = f[5];
@@ -329,6 +330,16 @@ __global__ __launch_bounds__(kMT) void count_column_kernel(const uint32_t* __res
   trace[(size_t)blockIdx.y * n + r] = mont(src[(size_t)blockIdx.y * n + r]);
 }
 
+// program chip: multiplicities; the padding instruction (last row) is fetched by every CPU row after the last cycle
+__global__ __launch_bounds__(kMT) void prog_mult_kernel(MachineRecords rec, uint32_t* __restrict__ trace, size_t n) {
+  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (r >= n) return;
+  const int b = blockIdx.y;
+  uint32_t v = rec.prog_mult[(size_t)b * n + r];
+  if (r == rec.n_program - 1) v = rec.cpu_rows - rec.counts[kCountWords * b];
+  trace[(size_t)b * n + r] = mont(v);
+}
+
 // image chip: every word of the image is sent once (the main column repeats the preprocessed is-real flag)
 __global__ __launch_bounds__(kMT) void image_used_kernel(uint32_t* __restrict__ trace, size_t n, uint32_t n_image) {
   const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
@@ -354,7 +365,7 @@ void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& re
       hipLaunchKernelGGL(mul_trace_kernel, dim3((unsigned)((h + 63) / 64), batch), dim3(64), 0, stream, rec, trace, logh);
       break;
     case kImage: hipLaunchKernelGGL(image_used_kernel, grid, block, 0, stream, trace, h, rec.n_image); break;
-    case kProgram: hipLaunchKernelGGL(count_column_kernel, grid, block, 0, stream, rec.prog_mult, trace, h); break;
+    case kProgram: hipLaunchKernelGGL(prog_mult_kernel, grid, block, 0, stream, rec, trace, h); break;
     default: break;
   }
 }

@@ -116,6 +116,26 @@ int zksp_mtrace_heights(const zksp_mtrace* t, int32_t* lh) {
   return ZKSP_OK;
 }
 
+const char* zksp_machine_chip_widths(int chip, int32_t* widths3) {
+  if (chip < 0 || chip >= mach::kNumChips || !widths3) return nullptr;
+  const mach::ChipDef& d = mach::chip_def(chip);
+  widths3[0] = d.prep_w; widths3[1] = d.main_w; widths3[2] = d.perm_width();
+  return d.name;
+}
+
+int zksp_machine_cover_heights(const zksp_mtrace* const* traces, size_t n, int32_t* lh) {
+  if (!traces || n == 0 || !lh) return ZKSP_ERR_INVALID_ARG;
+  MachineCounts cover;
+  for (size_t i = 0; i < n; ++i) {
+    if (!traces[i] || traces[i]->prog != traces[0]->prog) return ZKSP_ERR_INVALID_ARG;
+    cover.cover(traces[i]->t);
+  }
+  int v[mach::kNumChips];
+  machine_heights(*traces[0]->prog, cover, v);
+  for (int c = 0; c < mach::kNumChips; ++c) lh[c] = v[c];
+  return ZKSP_OK;
+}
+
 size_t zksp_machine_body_words(const zksp_client* c, const int32_t* lh) {
   if (!c || !lh) return 0;
   int v[mach::kNumChips];
@@ -174,12 +194,20 @@ int zksp_hip_machine_fetch_roots(zksp_client* c, uint32_t* out, size_t cap_words
   return ZKSP_OK;
 }
 
-int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const uint32_t* body, size_t body_words,
-                                 zksp_proof** out) {
+int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const int32_t* log_heights, const uint32_t* body,
+                                 size_t body_words, zksp_proof** out) {
   if (!pk || !t || !body || !out) return ZKSP_ERR_INVALID_ARG;
   int lh[mach::kNumChips];
-  machine_heights(*t->prog, t->t, lh);
-  return machine_proof_from_parts(pk, t->t.rec, lh, machine_handover_pc(*t->prog, t->t), body, body_words, out);
+  if (log_heights) {
+    for (int c = 0; c < mach::kNumChips; ++c) {
+      if (log_heights[c] < 5 || log_heights[c] > 21) return ZKSP_ERR_INVALID_ARG;
+      lh[c] = log_heights[c];
+    }
+    if (!machine_fits(t->t, lh)) return ZKSP_ERR_INVALID_ARG;
+  } else {
+    machine_heights(*t->prog, t->t, lh);
+  }
+  return machine_proof_from_parts(pk, t->t.rec, lh, machine_handover_pc(*t->prog, t->t, lh[mach::kCpu]), body, body_words, out);
 }
 
 int zksp_vk_machine(const zksp_vk* vk, uint32_t* prep_root8, uint32_t* digest8) {

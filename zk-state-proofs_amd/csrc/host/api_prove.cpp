@@ -99,8 +99,9 @@ void parallel_for(size_t count, unsigned max_threads, const std::function<void(s
 
 extern "C" {
 
-// Machine proofs (the full statement): trace every guest run on the host threads, group runs of equal chip
-// heights, prove each group in lockstep on the GPU, wrap the bodies into proof objects.
+// Machine proofs (the full statement): trace every guest run on the host threads, group runs of similar size
+// (one shape - the chip heights of the group's largest counts - per group), prove each group in lockstep on the GPU,
+// wrap the bodies into proof objects.
 static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdins, size_t n, zksp_proof** out,
                                int32_t* status) {
   Context* ctx = &c->ctx;
@@ -115,7 +116,6 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       traces[i].reset(new zksp_mtrace());
       traces[i]->prog = &pk->mprog;
       trace_execute(pk->elf, pk->mprog, stdins[i]->entries, (uint64_t)1 << 21, &traces[i]->t);
-      traces[i]->handover_pc = machine_handover_pc(pk->mprog, traces[i]->t);
       stdins[i]->entries.clear();  // consumed, as SP1Stdin is by prove()
     } catch (...) {
       traces[i].reset(new zksp_mtrace());
@@ -130,7 +130,9 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   std::string first_err;
   int rc_all = ZKSP_OK;
 
-  // A chunk: at most `cap` runs of identical chip heights, proven in lockstep.
+  // A chunk: at most `cap` runs proven in lockstep with one shape.  Runs are grouped by size class (the heights of the
+  // chips that are not split, and the binary order of magnitude of the cycle / ALU / sub-word counts); a group's shape
+  // covers its largest counts, so runs whose counts straddle a power of two still share a batch.
   struct Chunk {
     std::array<int, mach::kNumChips> lh;
     std::vector<size_t> idx;
@@ -139,6 +141,8 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   std::vector<Chunk> chunks;
   auto build_chunks = [&](size_t lo, size_t hi) {
     std::map<std::array<int, mach::kNumChips>, std::vector<size_t>> groups;
+    std::map<std::array<int, mach::kNumChips>, MachineCounts> covers;
+    auto clog2 = [](size_t v) { int l = 0; while (((size_t)1 << l) < v) ++l; return l; };
     for (size_t i = lo; i < hi; ++i) {
       if (!stdins[i] || !traces[i]) continue;
       const ExecutionRecord& r = traces[i]->t.rec;
@@ -154,9 +158,17 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       }
       std::array<int, mach::kNumChips> lh;
       machine_heights(pk->mprog, traces[i]->t, lh.data());
+      const MachineTrace& t = traces[i]->t;
+      lh[mach::kCpu] = clog2(t.cycles.size()); lh[mach::kCpu2] = 0;
+      lh[mach::kAlu] = clog2(t.alu_idx.size()); lh[mach::kAlu2] = 0;
+      lh[mach::kSub] = clog2(t.sub_idx.size()); lh[mach::kSub2] = 0;
       groups[lh].push_back(i);
+      covers[lh].cover(t);
     }
-    for (auto& kv : groups) {
+    for (auto& kv0 : groups) {
+      std::pair<std::array<int, mach::kNumChips>, std::vector<size_t>> kv;
+      machine_heights(pk->mprog, covers[kv0.first], kv.first.data());
+      kv.second = kv0.second;
       // bytes of HBM one proof of these heights needs (traces, coefficients, LDEs of the three rounds, scratch)
       size_t per_proof = 0;
       for (int ch = 0; ch < mach::kNumChips; ++ch) {
@@ -198,9 +210,12 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   };
   auto load_chunk = [&](const Chunk& ck, bool into_spare) {
     std::vector<const MachineTrace*> ts(ck.idx.size());
-    for (size_t j = 0; j < ck.idx.size(); ++j) ts[j] = &traces[ck.idx[j]]->t;
+    for (size_t j = 0; j < ck.idx.size(); ++j) {
+      ts[j] = &traces[ck.idx[j]]->t;
+      traces[ck.idx[j]]->handover_pc = machine_handover_pc(pk->mprog, *ts[j], ck.lh[mach::kCpu]);
+    }
     if (!into_spare) ctx->batch_hint = (int)ck.group_size;
-    const int rc = machine_load(ctx, pk->mprog, pk->mvk, ts.data(), ts.size(), into_spare);
+    const int rc = machine_load(ctx, pk->mprog, pk->mvk, ts.data(), ts.size(), into_spare, ck.lh.data());
     mark.mark(into_spare ? "next loaded" : "loaded", ts.size());
     if (rc == ZKSP_OK) release_chunk(ck);
     return rc;

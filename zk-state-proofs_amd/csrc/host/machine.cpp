@@ -416,15 +416,12 @@ done:
 #undef CHECK_ADDR
   rec.cycles = cycles;
   if (!rec.error.empty()) return;
-  {
-    // the CPU rows after the last cycle execute the padding instruction, which reads x0 once per row
-    const size_t rows = split_rows((size_t)cycles) + split_rest_rows((size_t)cycles);
-    out->x0_last = reg_ts[0];
-    if (rows > cycles) {
-      out->prog_mult.back() = (uint32_t)(rows - cycles);
-      reg_ts[0] = 4 * (uint32_t)rows;
-    }
-  }
+  // The CPU rows after the last cycle execute the padding instruction, which reads x0 once per row.  How many such rows
+  // there are depends on the chip heights the run is proven with (a batch shares one shape), so the records stay
+  // height-independent: the Program row of the padding instruction carries multiplicity 0 here and x0 is closed at
+  // its last real access; whoever expands the records for given heights adds the padding rows' fetches and moves
+  // x0's final time to the last row's (the trace expansion kernels).
+  out->x0_last = reg_ts[0];
   // every image address (registers first: addresses 0..31) and every other touched address once, strictly increasing:
   // an untouched image word is closed with the value and the time (0) it was opened with
   std::sort(touched.begin(), touched.end(), [](const Touched& p, const Touched& q) { return p.addr < q.addr; });

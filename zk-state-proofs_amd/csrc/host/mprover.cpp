@@ -84,25 +84,37 @@ int mmcs_commit(hipStream_t s, const RoundMats& rm, uint32_t* tree, size_t tree_
 
 }  // namespace
 
-uint32_t machine_handover_pc(const MachineProgram& prog, const MachineTrace& t) {
-  const size_t h0 = split_rows(t.cycles.size());
+uint32_t machine_handover_pc(const MachineProgram& prog, const MachineTrace& t, int logh_cpu) {
+  const size_t h0 = (size_t)1 << logh_cpu;
   return h0 < t.cycles.size() ? t.cycles[h0].pc : prog.pad_pc();
 }
 
-void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh[kNumChips]) {
-  logh[kCpu] = ceil_log2(split_rows(t.cycles.size()));
-  logh[kCpu2] = ceil_log2(split_rest_rows(t.cycles.size()));
-  logh[kAlu] = ceil_log2(split_rows(t.alu_idx.size()));
-  logh[kAlu2] = ceil_log2(split_rest_rows(t.alu_idx.size()));
-  logh[kSub] = ceil_log2(split_rows(t.sub_idx.size()));
-  logh[kSub2] = ceil_log2(split_rest_rows(t.sub_idx.size()));
-  logh[kKeccak] = at_least5(ceil_log2(24 * t.keccak.size()));
-  logh[kKmem] = at_least5(ceil_log2(50 * t.keccak.size()));
-  logh[kMemFinal] = at_least5(ceil_log2(t.memfinal.size()));
+void machine_heights(const MachineProgram& prog, const MachineCounts& n, int logh[kNumChips]) {
+  logh[kCpu] = ceil_log2(split_rows(n.cycles));
+  logh[kCpu2] = ceil_log2(split_rest_rows(n.cycles));
+  logh[kAlu] = ceil_log2(split_rows(n.alu));
+  logh[kAlu2] = ceil_log2(split_rest_rows(n.alu));
+  logh[kSub] = ceil_log2(split_rows(n.sub));
+  logh[kSub2] = ceil_log2(split_rest_rows(n.sub));
+  logh[kKeccak] = at_least5(ceil_log2(24 * n.keccak));
+  logh[kKmem] = at_least5(ceil_log2(50 * n.keccak));
+  logh[kMemFinal] = at_least5(ceil_log2(n.memfinal));
   logh[kImage] = prog.log_image;
   logh[kProgram] = prog.log_prog;
-  logh[kMul] = at_least5(ceil_log2(t.muls.size()));
+  logh[kMul] = at_least5(ceil_log2(n.muls));
   logh[kTable] = kTableLogH;
+}
+void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh[kNumChips]) {
+  MachineCounts n;
+  n.cover(t);
+  machine_heights(prog, n, logh);
+}
+bool machine_fits(const MachineTrace& t, const int* logh) {
+  auto two = [&](int a, int b) { return ((size_t)1 << logh[a]) + ((size_t)1 << logh[b]); };
+  auto one = [&](int a) { return (size_t)1 << logh[a]; };
+  return t.cycles.size() <= two(kCpu, kCpu2) && t.alu_idx.size() <= two(kAlu, kAlu2) && t.sub_idx.size() <= two(kSub, kSub2) &&
+         24 * t.keccak.size() <= one(kKeccak) && 50 * t.keccak.size() <= one(kKmem) && t.memfinal.size() <= one(kMemFinal) &&
+         t.muls.size() <= one(kMul);
 }
 
 int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const PrepDevice** out) {
@@ -315,18 +327,23 @@ int machine_activate_spare(Context* ctx) {
 }
 
 int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const MachineTrace* const* traces, size_t n,
-                 bool into_spare) {
+                 bool into_spare, const int* shape) {
   if (n == 0) return ctx->fail(1, "machine_load: empty batch");
   const PrepDevice* prep = nullptr;
   int rc = machine_prep_ensure(ctx, prog, vk, &prep);
   if (rc) return rc;
   int logh[kNumChips];
-  machine_heights(prog, *traces[0], logh);
-  for (size_t i = 1; i < n; ++i) {
-    int li[kNumChips];
-    machine_heights(prog, *traces[i], li);
-    if (memcmp(li, logh, sizeof li) != 0) return ctx->fail(1, "machine_load: traces of one batch must have identical chip heights");
+  if (shape) {
+    memcpy(logh, shape, sizeof logh);
+    if (logh[kImage] != prog.log_image || logh[kProgram] != prog.log_prog || logh[kTable] != kTableLogH)
+      return ctx->fail(1, "machine_load: the shape's preprocessed table heights differ from the program's");
+  } else {
+    MachineCounts cover;
+    for (size_t i = 0; i < n; ++i) cover.cover(*traces[i]);
+    machine_heights(prog, cover, logh);
   }
+  for (size_t i = 0; i < n; ++i)
+    if (!machine_fits(*traces[i], logh)) return ctx->fail(1, "machine_load: a trace does not fit the batch's chip heights");
   // record capacities follow from the heights alone, so every batch of these heights fits the same workspace
   const size_t cc = ((size_t)1 << logh[kCpu]) + ((size_t)1 << logh[kCpu2]), cm = (size_t)1 << logh[kMemFinal], cu = (size_t)1 << logh[kMul],
                ck = std::min(((size_t)1 << logh[kKeccak]) / 24, ((size_t)1 << logh[kKmem]) / 50),
@@ -390,7 +407,7 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     {
       // the two CPU instances: first pc, first time, has a successor, hand-over pc (air_machine.hpp CpuPub)
       const size_t h0 = (size_t)1 << logh[kCpu];
-      const uint32_t handover = machine_handover_pc(prog, t);
+      const uint32_t handover = machine_handover_pc(prog, t, logh[kCpu]);
       o[42 + kNumChips] = handover & 0xffff;
       o[43 + kNumChips] = handover >> 16;
       uint32_t* cp = &pubw[i * kPubWords + 17];
@@ -458,6 +475,7 @@ int machine_prove_resident(Context* ctx) {
   rec.cap_cycles = w->cap_cycles; rec.cap_keccak = w->cap_keccak; rec.cap_memfinal = w->cap_memfinal; rec.cap_muls = w->cap_muls;
   rec.cap_alu = w->cap_alu; rec.cap_sub = w->cap_sub;
   rec.program = prep->program; rec.text_base = prep->text_base; rec.n_program = prep->n_program; rec.n_image = prep->n_image;
+  rec.cpu_rows = ((uint32_t)1 << logh[kCpu]) + ((uint32_t)1 << logh[kCpu2]);
   {
     ProfileSpan sp(ctx, "m_trace");
     for (int c = 0; c < kNumChips; ++c) {

@@ -71,17 +71,21 @@ struct MachineWorkspace {
 
 // uploads the preprocessed tables of `prog` and commits them; the root must equal vk.prep_root
 int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const PrepDevice** out);
-// sizes the workspace for `n` traces of identical chip heights and uploads their records; with `into_spare`
-// the upload goes to the spare record set on the copy stream (the resident batch and a proving pass in
-// flight are untouched; the heights must be the resident batch's)
+// sizes the workspace for `n` traces and uploads their records.  The batch is proven with ONE shape (chip heights):
+// `shape` if given (every trace must fit it), else the heights of the element-wise maximum of the traces' counts.
+// With `into_spare` the upload goes to the spare record set on the copy stream (the resident batch and a proving pass
+// in flight are untouched; the shape must be the resident batch's).
 int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const MachineTrace* const* traces, size_t n,
-                 bool into_spare = false);
+                 bool into_spare = false, const int* shape = nullptr);
 // makes the spare record set the resident batch (call when no proving pass is in flight)
 int machine_activate_spare(Context* ctx);
 // enqueues the whole proving pass over the resident batch
 int machine_prove_resident(Context* ctx);
+// minimal chip heights of one run / of the runs `counts` covers
 void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh[mach::kNumChips]);
-// pc of the first cycle of the second CPU instance (a proof-header word)
-uint32_t machine_handover_pc(const MachineProgram& prog, const MachineTrace& t);
+void machine_heights(const MachineProgram& prog, const MachineCounts& counts, int logh[mach::kNumChips]);
+bool machine_fits(const MachineTrace& t, const int* logh);
+// pc of the first row of the second CPU instance when the first has 2^logh_cpu rows (a proof-header word)
+uint32_t machine_handover_pc(const MachineProgram& prog, const MachineTrace& t, int logh_cpu);
 
 }  // namespace zksp
