@@ -4,8 +4,9 @@
 One "step" = one pass of the device hot path over one resident batch of synthetic acct-d8 proofs
 (BASELINE configs[1]: single account-trie proof, depth 8).  A proof is the MACHINE proof of the
 committed sp1-merkle-proof guest in the keccak-precompile shape: 391 400 RV32IM cycles in a
-(2^18 + 2^17) x 204 CPU chip rows in two instances, 62 keccak-f permutations in a 2^11 x 2634 keccak chip, keccak-memory,
-memory-boundary, image, program and multiplier chips, joined by LogUp buses -- i.e. the statement
+(2^18 + 2^17) x 62 CPU chip rows in two instances, the ALU and sub-word chips beside it (one row per bitwise / shift /
+compare / sub-word instruction), 62 keccak-f permutations in a 2^11 x 2634 keccak chip, keccak-memory, memory-boundary,
+image, program, table and multiplier chips, joined by LogUp buses -- i.e. the statement
 the reference's client.prove() establishes, not a component.  The step runs trace expansion ->
 LDE -> Poseidon2 mixed-height Merkle commitments -> LogUp -> quotients -> openings -> FRI -> proof
 bytes in HBM, Fiat-Shamir on the device, no host round trip.  The executor's records (48 bytes per
@@ -205,7 +206,7 @@ def cpu_baseline(trace_of, first_s, seconds):
     n = len(times)
     return {"value": n / el, "unit": "proofs/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
             "repetitions": n, "median_s_per_proof": sorted(times)[n // 2], "min_s_per_proof": min(times),
-            "sample": f"{n} acct-d8 machine proofs (391 400 cycles, two CPU instances of 2^18 and 2^17 rows x 204 + 7 chips, 100 queries) in {el:.1f} s; "
+            "sample": f"{n} acct-d8 machine proofs (391 400 cycles, two CPU instances of 2^18 and 2^17 rows x 62 + 11 chips, 100 queries) in {el:.1f} s; "
                       "reference SP1 CPU prover unavailable offline, CPU baseline is this repository's oracle/ restatement"}
 
 
@@ -246,7 +247,7 @@ def keccak_chip_component(zk, fx, client_opts, pk_elf, seconds_budget=20.0):
 
 def as_committed_mode(zk, fx, device):
     """The same acct-d8 input with the guest exactly as committed (software keccak, no precompile): 1 406 960
-    cycles, CPU instances 2^20 and 2^19 rows x 204, keccak chips empty.  Batch 4 resident, 2 timed steps; one proof verified."""
+    cycles, CPU instances 2^20 and 2^19 rows x 62 + ALU instances 2^19 and 2^18 x 109, keccak chips empty.  Batch 4 resident, 2 timed steps; one proof verified."""
     NB = 4
     client = zk.ProverClient(device=device, keccak_mode=zk.KECCAK_OBSERVE, max_batch=NB)
     lib, h = client._lib, client._h
@@ -279,6 +280,54 @@ def as_committed_mode(zk, fx, device):
             "note": "guest as committed: software keccak-f inside the CPU chip (1 406 960 cycles); verified on the host"}
 
 
+def workload_stdins(zk, fx, name):
+    """The stdin buffers of one of BASELINE.json's throughput workloads, and what every proof's
+    public values must be.  slot-d5x256: config 3 as 256 independent runs of the committed guest (no sp1-storage-proof
+    circuit exists); rcptx300: config 4, every receipt of a 300-receipt block-shaped trie; acct-d8x1024: config 5's
+    substitute (the reference's recursion circuit is a todo!()): 1024 leaf proofs whose 32-byte commitments are what a
+    recursion tree would take in."""
+    if name == "slot-d5x256":
+        ins = [fx.slot_fixture(i) for i in range(256)]
+        return [m.to_borsh() for m in ins], None
+    if name == "rcptx300":
+        mpt = importlib.import_module("zk-state-proofs_amd.mpt")
+        receipts = mpt.synthetic_block_receipts(300, seed=12)
+        trie = mpt.block_trie(receipts)
+        return [mpt.block_proof_input(trie, i).to_borsh() for i in range(300)], receipts
+    if name == "acct-d8x1024":
+        return [fx.acct_fixture(8, seed=5000 + i).to_borsh() for i in range(1024)], [fx.ACCOUNT_VALUE] * 1024
+    raise SystemExit(f"unknown workload {name}")
+
+
+def pipelined_workload(zk, fx, client, pk, vk, name, n_verify=6):
+    """One drop-in prove_batch call over a whole workload (host buffers in, proof objects out: guest tracing on the host
+    threads, record upload, proving and download overlapped by the library), a spread of the proofs verified on the
+    host afterwards.  The rate includes everything; the verification is outside the clock."""
+    bufs, expect = workload_stdins(zk, fx, name)
+    stdins = []
+    for b in bufs:
+        sdin = zk.SP1Stdin()
+        sdin.write(b)
+        stdins.append(sdin)
+    t0 = time.perf_counter()
+    proofs, status = client.prove_batch(pk, stdins)
+    el = time.perf_counter() - t0
+    if status != [0] * len(bufs):
+        return {"error": f"{sum(1 for x in status if x)} of {len(bufs)} runs failed: {client.last_error()}"}
+    host = zk.ProverClient(device=-1)
+    idx = sorted({int(round(k * (len(bufs) - 1) / (n_verify - 1))) for k in range(n_verify)})
+    shapes = set()
+    for i, p in enumerate(proofs):
+        raw = p.to_bytes()
+        shapes.add(raw[8:8 + 4 * zk.MACHINE_CHIPS])
+        if expect is not None and p.public_values != expect[i]:
+            return {"error": f"proof {i} carries wrong public values"}
+    for i in idx:
+        host.verify(proofs[i], vk)
+    return {"proofs": len(bufs), "seconds": el, "proofs_per_s": len(bufs) / el, "shapes": len(shapes), "verified_indices": idx,
+            "includes": "guest tracing, H2D, proving, D2H, proof objects (prove_batch end to end, one GPU)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -290,6 +339,9 @@ def main():
                     help="budget of the CPU baseline: repetitions until it is spent, at most 5 (SURVEY 8d: 5 repetitions, median and min)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-single", action="store_true", help="skip latency / end-to-end / component sections (profiling runs)")
+    ap.add_argument("--workload", default="acct-d8", choices=["acct-d8", "slot-d5x256", "rcptx300", "acct-d8x1024", "all"],
+                    help="acct-d8 (default): the metric's configuration, plus the pipelined workloads of BASELINE configs 3-5 as "
+                         "secondary figures; a named workload: only that one's pipelined prove_batch figure is added; all = default")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + ZKSP_BENCH_SAME_DEVICE=1 rehearses the N>1 path on a one-GPU box")
     args = ap.parse_args()
@@ -440,6 +492,7 @@ def main():
 
     # ---- latency, end-to-end and component figures (rank 0, after the timed region) ----
     single_ms = e2e_ms = e2e_batch_rate = component = as_committed = None
+    pipelined = {}
     if not args.skip_single:
         # device time of one resident proof, on a client of its own sized for one proof (what zksp_prove uses)
         sc = zk.ProverClient(device=local_rank, max_batch=1)
@@ -487,6 +540,9 @@ def main():
         del proofs
         component = keccak_chip_component(zk, fx, {"device": local_rank}, zk.merkle_elf())
         as_committed = as_committed_mode(zk, fx, local_rank)
+        wanted = ["slot-d5x256", "rcptx300", "acct-d8x1024"] if args.workload in ("acct-d8", "all") else [args.workload]
+        for wname in wanted:
+            pipelined[wname] = pipelined_workload(zk, fx, client, pk, vk, wname)
 
     total_proofs = world * B * args.steps
     out = {
@@ -504,10 +560,10 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "acct-d8 machine proof: depth-8 account-trie MPT proof of the committed sp1-merkle-proof guest, whole "
-                        "execution proven (keccak precompile shape: 391 400 cycles -> CPU instances 2^18 + 2^17 rows x 204, keccak chip 2^11 x 2634, "
-                        "keccak-mem 2^12, mem-final 2^15, image / program 2^16, mul 2^9; LogUp buses; blowup 2, 100 FRI queries, "
-                        "16 PoW bits)",
-            "statement": "guest executed from its entry point to HALT(0) with these public values (machine proof, format v5)",
+                        "execution proven (keccak precompile shape: 391 400 cycles -> CPU instances 2^18 + 2^17 rows x 62 limb columns, ALU chip "
+                        "2^16 + 2^15 x 109, sub-word chip 2 x 2^15 x 63, keccak chip 2^11 x 2634, keccak-mem 2^12, mem-final / image / "
+                        "program / table 2^16, mul 2^9; LogUp buses; blowup 2, 100 FRI queries, 16 PoW bits)",
+            "statement": "guest executed from its entry point to HALT(0) with these public values (machine proof, format v6)",
             "chip_log_heights": heights,
             "batch_per_gpu": B,
             "proofs_per_step": world * B,
@@ -539,6 +595,8 @@ def main():
         "records_h2d_ms_per_batch": load_ms,
         "setup_s": setup_s,
         "prove_batch_end_to_end_proofs_per_s": e2e_batch_rate,
+        # BASELINE configs 3, 4, 5 as one prove_batch call each on this GPU (host buffers in, proof objects out)
+        "pipelined_workloads": pipelined,
         "keccak_chip_component": component,
         "as_committed_2p21": as_committed,
     }

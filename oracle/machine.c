@@ -98,8 +98,8 @@ static orc_lf lf_bits(int bits, int n) {
 }
 #define SELC(cls) (C_SEL + (cls) - 1)
 
-#define CPU_INTER 23
-static orc_inter g_cpu[CPU_INTER], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[3],
+#define CPU_INTER 22
+static orc_inter g_cpu[CPU_INTER], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[4],
     g_alu[1], g_sub[1];
 static orc_chip g_chips[N_CHIPS];
 static int g_ready = 0;
@@ -146,17 +146,24 @@ static void build(void) {
     it->el[6] = lf_col(C_RS1); it->el[7] = lf_col(C_RS2); it->el[8] = lf_col(C_IMM_LO); it->el[9] = lf_col(C_IMM_HI);
     it->el[10] = lf_col(C_TGT_LO); it->el[11] = lf_col(C_TGT_HI);
   }
-  g_cpu[1] = mem_inter(-1, one, lf_col(C_RS1), b_lo, b_hi, lf_col(C_R1_PTS));
+  /* previous access time of slot q (accessed at ts + q): ts + q - 1 - (gap_lo + 2^16 gap_hi) */
+  orc_lf pts[4];
+  for (int q = 0; q < 4; ++q) {
+    lf_zero(&pts[q]);
+    lf_add(&pts[q], C_TS, 1); lf_add(&pts[q], C_GAP + 2 * q, FP - 1); lf_add(&pts[q], C_GAP + 2 * q + 1, FP - 65536);
+    pts[q].c0 = f_sub((uint32_t)q, 1);
+  }
+  g_cpu[1] = mem_inter(-1, one, lf_col(C_RS1), b_lo, b_hi, pts[0]);
   g_cpu[2] = mem_inter(+1, one, lf_col(C_RS1), b_lo, b_hi, ts);
-  g_cpu[3] = mem_inter(-1, lf_col(C_USE2), lf_col(C_RS2), c_lo, c_hi, lf_col(C_R2_PTS));
+  g_cpu[3] = mem_inter(-1, lf_col(C_USE2), lf_col(C_RS2), c_lo, c_hi, pts[1]);
   g_cpu[4] = mem_inter(+1, lf_col(C_USE2), lf_col(C_RS2), c_lo, c_hi, lf_plus(ts, 1));
   {
     const int memq_c[5] = {SELC(CL_LW), SELC(CL_SW), SELC(CL_LDS), SELC(CL_STS), SELC(CL_ECALL)};
     const orc_lf memq = lf_sum(memq_c, 5);
-    g_cpu[5] = mem_inter(-1, memq, lf_col(C_MADDR), m_lo, m_hi, lf_col(C_M_PTS));
+    g_cpu[5] = mem_inter(-1, memq, lf_col(C_MADDR), m_lo, m_hi, pts[2]);
     g_cpu[6] = mem_inter(+1, memq, lf_col(C_MADDR), lf_col(C_MV), lf_col(C_MV + 1), lf_plus(ts, 2));
   }
-  g_cpu[7] = mem_inter(-1, lf_col(C_WR), lf_col(C_RD), lf_col(C_W_PLO), lf_col(C_W_PHI), lf_col(C_W_PTS));
+  g_cpu[7] = mem_inter(-1, lf_col(C_WR), lf_col(C_RD), lf_col(C_W_PLO), lf_col(C_W_PHI), pts[3]);
   g_cpu[8] = mem_inter(+1, lf_col(C_WR), lf_col(C_RD), a_lo, a_hi, lf_plus(ts, 3));
   /* access-time differences: every row looks up its four low limbs and the two pairs of high bytes (zero where the
    * access is not live) */
@@ -165,7 +172,7 @@ static void build(void) {
   g_cpu[14] = bytes_inter(-1, one, lf_col(C_GAP + 5), lf_col(C_GAP + 7));
   {
     /* the adder output is canonical, an address is word-aligned once its byte offset is taken off, and addresses,
-     * jump targets and the keccak call's return address stay below 0x78000000 */
+     * jump targets and the keccak call's return address stay below 0x78000000 (their high limb is looked up as kind 2) */
     const int chk_c[10] = {SELC(CL_ADD), SELC(CL_SUB), SELC(CL_JALR), SELC(CL_LW), SELC(CL_SW), SELC(CL_LDS), SELC(CL_STS),
                            SELC(CL_ECALL), SELC(CL_KECCAK), 0};
     const int al_c[5] = {SELC(CL_JALR), SELC(CL_LW), SELC(CL_SW), SELC(CL_LDS), SELC(CL_STS)};
@@ -173,18 +180,19 @@ static void build(void) {
     const orc_lf chk = lf_sum(chk_c, 9);
     orc_lf xoff = lf_col(C_X);
     lf_add(&xoff, C_O1, FP - 1); lf_add(&xoff, C_O2, FP - 2); lf_add(&xoff, C_O3, FP - 3);
-    g_cpu[15] = range_inter(-1, chk, zero, lf_col(C_X + 1));
+    orc_lf top = lf_sum(top_c, 6);
+    for (int i = 0; i < top.n; ++i) top.coef[i] = 2; /* kind 2: the high limb of an address is at most ADDR_HI_MAX */
+    g_cpu[15] = range_inter(-1, chk, top, lf_col(C_X + 1));
     g_cpu[16] = range_inter(-1, chk, lf_sum(al_c, 5), xoff);
-    g_cpu[17] = range_inter(-1, lf_sum(top_c, 6), zero, lf_const_minus(ADDR_HI_MAX, C_X + 1));
   }
   {
-    orc_inter* it = &g_cpu[18];
+    orc_inter* it = &g_cpu[17];
     memset(it, 0, sizeof *it);
     const int alu_c[3] = {SELC(CL_ALU), SELC(CL_BLT), SELC(CL_BGE)};
     it->bus = BUS_ALU; it->sign = +1; it->mult = lf_sum(alu_c, 3); it->n_el = 7;
     it->el[0] = lf_col(C_CODE);
     it->el[1] = a_lo; it->el[2] = a_hi; it->el[3] = b_lo; it->el[4] = b_hi; it->el[5] = c_lo; it->el[6] = c_hi;
-    it = &g_cpu[19];
+    it = &g_cpu[18];
     memset(it, 0, sizeof *it);
     const int sub_c[2] = {SELC(CL_LDS), SELC(CL_STS)};
     it->bus = BUS_SUB; it->sign = +1; it->mult = lf_sum(sub_c, 2); it->n_el = 9;
@@ -192,17 +200,17 @@ static void build(void) {
     lf_zero(&it->el[1]); lf_add(&it->el[1], C_O1, 1); lf_add(&it->el[1], C_O2, 2); lf_add(&it->el[1], C_O3, 3);
     it->el[2] = a_lo; it->el[3] = a_hi; it->el[4] = m_lo; it->el[5] = m_hi; it->el[6] = c_lo;
     it->el[7] = lf_col(C_MV); it->el[8] = lf_col(C_MV + 1);
-    it = &g_cpu[20];
+    it = &g_cpu[19];
     memset(it, 0, sizeof *it);
     it->bus = BUS_KCALL; it->sign = +1; it->mult = lf_col(SELC(CL_KECCAK)); it->n_el = 3;
     it->el[0] = ts; it->el[1] = c_lo; it->el[2] = c_hi;
-    it = &g_cpu[21];
+    it = &g_cpu[20];
     memset(it, 0, sizeof *it);
     it->bus = BUS_PUBC; it->sign = +1; it->n_el = 4;
     it->mult = lf_pair(C_SC + SC_COMMIT, C_SC + SC_DEFER, 1);
     it->el[0] = lf_pair(C_SC + SC_COMMIT, C_SC + SC_DEFER, 2);
     it->el[1] = c_lo; it->el[2] = m_lo; it->el[3] = m_hi;
-    it = &g_cpu[22];
+    it = &g_cpu[21];
     memset(it, 0, sizeof *it);
     it->bus = BUS_PUBH; it->sign = +1; it->mult = lf_col(C_SC + SC_HALT); it->n_el = 2;
     it->el[0] = c_lo; it->el[1] = c_hi;
@@ -268,7 +276,8 @@ static void build(void) {
     const orc_lf idx = lf_pair(TB_P_X, TB_P_Y, 256);
     g_table[0] = range_inter(+1, lf_col(TABLE_PREP_WIDTH + TB_M_R16), zero, idx);
     g_table[1] = range_inter(+1, lf_col(TABLE_PREP_WIDTH + TB_M_AL), one, idx);
-    g_table[2] = bytes_inter(+1, lf_col(TABLE_PREP_WIDTH + TB_M_BY), lf_col(TB_P_X), lf_col(TB_P_Y));
+    g_table[2] = range_inter(+1, lf_col(TABLE_PREP_WIDTH + TB_M_TOP), lf_const(2), idx);
+    g_table[3] = bytes_inter(+1, lf_col(TABLE_PREP_WIDTH + TB_M_BY), lf_col(TB_P_X), lf_col(TB_P_Y));
   }
   /* ---- multiplier ---- */
   for (int hi = 0; hi < 2; ++hi) {
@@ -304,7 +313,7 @@ static void build(void) {
     it->el[4] = lf_bits(SW_M, 16); it->el[5] = lf_bits(SW_M + 16, 16); it->el[6] = lf_bits(SW_C, 16);
     it->el[7] = lf_col(SW_MV); it->el[8] = lf_col(SW_MV + 1);
   }
-  g_chips[CH_TABLE] = (orc_chip){"table", TABLE_PREP_WIDTH, TABLE_WIDTH, 3, g_table, 0};
+  g_chips[CH_TABLE] = (orc_chip){"table", TABLE_PREP_WIDTH, TABLE_WIDTH, 4, g_table, 0};
   g_chips[CH_CPU] = (orc_chip){"cpu", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0};
   g_chips[CH_CPU2] = (orc_chip){"cpu2", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0};
   g_chips[CH_KECCAK] = (orc_chip){"keccak", 0, KECCAK_WIDTH, 50, g_keccak, 0};
@@ -440,7 +449,6 @@ static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
       const uint32_t pts = g == in->n_cycles ? x0_last : ts - 4;
       T(C_PC) = pad_pc; T(C_NEXT_PC) = pad_pc; T(SELC(CL_JAL)) = 1;
       put_limbs(t, h, r, C_TGT_LO, pad_pc);
-      T(C_R1_PTS) = pts;
       gap[0] = ts - pts - 1;
     } else {
       const uint32_t* cy = in->cycles + 12 * g;
@@ -496,14 +504,14 @@ static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
       put_limbs(t, h, r, C_A, a); put_limbs(t, h, r, C_B, b); put_limbs(t, h, r, C_C, c);
       put_limbs(t, h, r, C_M, m); put_limbs(t, h, r, C_MV, mv);
       T(C_K0) = k0; T(C_K1) = k1;
-      if (off >= 0) T(C_O0 + off) = 1;
+      if (off > 0) T(C_O1 + off - 1) = 1;
       T(C_MADDR) = maddr;
       T(C_NEXT_PC) = next;
       const int memq = cls == CL_LW || cls == CL_SW || cls == CL_LDS || cls == CL_STS || cls == CL_ECALL;
-      T(C_R1_PTS) = cy[7]; gap[0] = ts - cy[7] - 1;
-      if (use2) { T(C_R2_PTS) = cy[8]; gap[1] = ts - cy[8]; }
-      if (memq) { T(C_M_PTS) = cy[9]; gap[2] = ts + 1 - cy[9]; }
-      if (wr) { T(C_W_PTS) = cy[10]; gap[3] = ts + 2 - cy[10]; T(C_W_PLO) = wprev & 0xffff; T(C_W_PHI) = wprev >> 16; }
+      gap[0] = ts - cy[7] - 1;
+      if (use2) gap[1] = ts - cy[8];
+      if (memq) gap[2] = ts + 1 - cy[9];
+      if (wr) { gap[3] = ts + 2 - cy[10]; T(C_W_PLO) = wprev & 0xffff; T(C_W_PHI) = wprev >> 16; }
       /* soundness tests: ZKSP_ORACLE_NONCANON=<row> makes that addition claim the other carry, i.e. write the same
        * sum with limbs out of range.  The adder constraints still hold; the range lookup cannot. */
       const char* nc = getenv("ZKSP_ORACLE_NONCANON");
@@ -606,8 +614,8 @@ static void fill_table_mults(const orc_machine_input* in, uint32_t* t) {
         }
         if (v[0] == 0) continue;
         if (it->bus == BUS_RANGE) {
-          if (v[2] >= ht || v[1] > 1 || (v[1] == 1 && (v[2] & 3))) continue; /* no table row: the buses will not balance */
-          uint32_t* dst = &t[(size_t)(v[1] ? TB_M_AL : TB_M_R16) * ht + v[2]];
+          if (v[2] >= ht || v[1] > 2 || (v[1] == 1 && (v[2] & 3)) || (v[1] == 2 && v[2] > ADDR_HI_MAX)) continue; /* no table row: the buses will not balance */
+          uint32_t* dst = &t[(size_t)(v[1] == 0 ? TB_M_R16 : v[1] == 1 ? TB_M_AL : TB_M_TOP) * ht + v[2]];
           *dst = f_add(*dst, v[0]);
         } else {
           if (v[1] > 255 || v[2] > 255) continue;
@@ -735,6 +743,7 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
         prep[(size_t)TB_P_X * h + r] = (uint32_t)(r & 255);
         prep[(size_t)TB_P_Y * h + r] = (uint32_t)(r >> 8);
         prep[(size_t)TB_P_NA * h + r] = (r & 3) != 0;
+        prep[(size_t)TB_P_NT * h + r] = r > ADDR_HI_MAX;
       }
       if (in->n_cycles) fill_table_mults(in, t); /* setup passes no cycles: only the preprocessed columns are wanted */
       break;
@@ -777,7 +786,7 @@ static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, f
   fe selsum = 0;
   for (int k = 0; k < N_CLS; ++k) { emit(s, bool_c(l[C_SEL + k])); selsum = f_add(selsum, l[C_SEL + k]); }
   emit(s, bool_c(l[C_K0])); emit(s, bool_c(l[C_K1]));
-  for (int i = 0; i < 4; ++i) emit(s, bool_c(l[C_O0 + i]));
+  for (int i = 0; i < 3; ++i) emit(s, bool_c(l[C_O1 + i]));
   fe scsum = 0;
   for (int i = 0; i < 6; ++i) { emit(s, bool_c(l[C_SC + i])); scsum = f_add(scsum, l[C_SC + i]); }
   /* ---- row structure: exactly one class; the clock; the chain of pcs; the instance's first and last rows ---- */
@@ -819,14 +828,14 @@ static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, f
     emit(s, f_mul(S(CL_KECCAK), f_sub(x_hi, b_hi)));
   }
   /* ---- byte offset and the word address ---- */
-  const fe o0 = l[C_O0], o1 = l[C_O1], o2 = l[C_O2], o3 = l[C_O3];
+  const fe o1 = l[C_O1], o2 = l[C_O2], o3 = l[C_O3], osum = f_add(o1, f_add(o2, o3));
   const fe off = f_add(o1, f_add(f_add(o2, o2), f_mul(3, o3)));
   const fe xaddr = f_sub(f_add(x_lo, f_mul(F65536, x_hi)), off);
   {
     const fe noff = f_add(f_add(f_add(S(CL_ADD), S(CL_SUB)), f_add(S(CL_ECALL), S(CL_KECCAK))), f_add(S(CL_LW), S(CL_SW)));
     const fe memw = f_add(f_add(S(CL_LW), S(CL_SW)), f_add(S(CL_LDS), S(CL_STS)));
-    emit(s, f_mul(noff, f_add(o1, f_add(o2, o3))));
-    emit(s, f_mul(f_add(memw, S(CL_JALR)), f_sub(f_add(f_add(o0, o1), f_add(o2, o3)), one)));
+    emit(s, f_mul(noff, osum));
+    emit(s, bool_c(osum)); /* at most one of the three offset flags */
     emit(s, f_mul(S(CL_JALR), f_add(o2, o3)));
     emit(s, f_mul(memw, f_sub(l[C_MADDR], xaddr)));
     emit(s, f_mul(S(CL_ECALL), f_sub(l[C_MADDR], 11)));
@@ -882,15 +891,8 @@ static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, f
     emit(s, f_mul(same, f_sub(a_lo, b_lo)));
     emit(s, f_mul(same, f_sub(a_hi, b_hi)));
   }
-  /* ---- previous access times are older: difference = low limb + 2^16 * high byte ---- */
-  {
-    const fe memq = f_add(f_add(f_add(S(CL_LW), S(CL_SW)), f_add(S(CL_LDS), S(CL_STS))), S(CL_ECALL));
-    const fe ts = l[C_TS];
-    emit(s, f_sub(f_sub(f_sub(ts, l[C_R1_PTS]), one), word_of(l, C_GAP)));
-    emit(s, f_mul(l[C_USE2], f_sub(f_sub(ts, l[C_R2_PTS]), word_of(l, C_GAP + 2))));
-    emit(s, f_mul(memq, f_sub(f_sub(f_add(ts, one), l[C_M_PTS]), word_of(l, C_GAP + 4))));
-    emit(s, f_mul(l[C_WR], f_sub(f_sub(f_add(ts, 2), l[C_W_PTS]), word_of(l, C_GAP + 6))));
-  }
+  /* previous access times are older by construction: a slot's previous time IS its time - 1 - difference (a linear
+   * form in the memory-bus tuples), the difference's low limb and high byte are looked up in the table chip */
 #undef S
 }
 
@@ -1062,7 +1064,10 @@ static void run_constraints(int chip, const uint32_t* prep, const uint32_t* loc,
     case CH_IMAGE: emit(s, f_sub(loc[0], prep[IMG_P_REAL])); break; /* every image word is sent exactly once */
     case CH_PROGRAM: break;
     case CH_MUL: mul_constraints(loc, s); break;
-    case CH_TABLE: emit(s, f_mul(loc[TB_M_AL], prep[TB_P_NA])); break; /* only multiples of 4 answer aligned lookups */
+    case CH_TABLE: /* only multiples of 4 answer aligned lookups, only values up to ADDR_HI_MAX high-address-limb lookups */
+      emit(s, f_mul(loc[TB_M_AL], prep[TB_P_NA]));
+      emit(s, f_mul(loc[TB_M_TOP], prep[TB_P_NT]));
+      break;
     case CH_ALU:
     case CH_ALU2: alu_constraints(loc, s); break;
     case CH_SUB:

@@ -69,11 +69,12 @@ enum {
   C_MV = C_M + 2,              /* memory slot: word left behind */
   C_X = C_MV + 2,              /* adder output: sum / difference / effective address; beq, bne: the limb differences' inverses */
   C_K0 = C_X + 2, C_K1,        /* carries; beq, bne: "limb equal" flags */
-  C_O0, C_O1, C_O2, C_O3,      /* byte offset of the effective address, one-hot */
+  C_O1, C_O2, C_O3,            /* byte offset of the effective address 1, 2, 3: at most one is set (offset 0: none) */
   C_MADDR,                     /* word address on the memory bus (ecall: 11, the register a1) */
   C_SC,                        /* 6 syscall flags: HALT, WRITE, COMMIT, DEFER, HINT_LEN, HINT_READ */
-  C_R1_PTS = C_SC + 6, C_R2_PTS, C_M_PTS, C_W_PTS, C_W_PLO, C_W_PHI,
-  C_GAP,                       /* 4 access-time differences: low 16 bits, high 8 bits each */
+  C_W_PLO = C_SC + 6, C_W_PHI, /* previous value of rd */
+  C_GAP,                       /* 4 access-time differences (rs1, rs2, memory slot, rd): low 16 bits, high 8 bits each; the
+                                  previous access time of a slot is its access time - 1 - difference, a linear form */
   CPU_WIDTH = C_GAP + 8
 };
 enum { SC_HALT = 0, SC_WRITE, SC_COMMIT, SC_DEFER, SC_HINT_LEN, SC_HINT_READ };
@@ -111,10 +112,11 @@ enum {
   SW_A = SW_O + 4, SW_M = SW_A + 2 /* 32 bits */, SW_C = SW_M + 32 /* 16 bits: low limb of the stored register */,
   SW_MV = SW_C + 16, SUB_WIDTH = SW_MV + 2
 };
-/* ---- table chip: 2^16 rows; preprocessed (x = low byte, y = high byte, na = row index not a multiple of 4);
- *      main: multiplicities of range16, aligned range16, byte pair ---- */
-enum { TB_P_X = 0, TB_P_Y, TB_P_NA, TABLE_PREP_WIDTH };
-enum { TB_M_R16 = 0, TB_M_AL, TB_M_BY, TABLE_WIDTH };
+/* ---- table chip: 2^16 rows; preprocessed (x = low byte, y = high byte, na = row index not a multiple of 4,
+ *      nt = row index above ADDR_HI_MAX); main: multiplicities of range16 (kind 0), 4-aligned range16 (kind 1),
+ *      high address limb (kind 2: at most ADDR_HI_MAX), byte pair ---- */
+enum { TB_P_X = 0, TB_P_Y, TB_P_NA, TB_P_NT, TABLE_PREP_WIDTH };
+enum { TB_M_R16 = 0, TB_M_AL, TB_M_TOP, TB_M_BY, TABLE_WIDTH };
 #define TABLE_LOG_H 16
 #define ADDR_HI_MAX 0x77FFu /* high limb of the largest address / jump target: values stay below 0x78000000 < p */
 

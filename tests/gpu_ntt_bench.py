@@ -11,6 +11,8 @@ lib, h = g.lib, g.h
 SIZES = ((10, 2633 * 16), (11, 2633 * 16), (12, 2633 * 4), (14, 2048), (16, 1024), (18, 256), (20, 128), (21, 64), (22, 32))
 if os.environ.get("ZKSP_NTT_LOGH"):
     SIZES = tuple(x for x in SIZES if x[0] == int(os.environ["ZKSP_NTT_LOGH"]))
+if os.environ.get("ZKSP_NTT_NCOLS"):
+    SIZES = tuple((l, int(os.environ["ZKSP_NTT_NCOLS"])) for l, _ in SIZES)
 for logh, ncols in SIZES:
     H = 1 << logh
     rng = np.random.default_rng(logh)

@@ -63,12 +63,11 @@ ZKSP_HD constexpr int event_kind(uint32_t op) {
 constexpr int C_PC = 0, C_TS = 1, C_NEXT_PC = 2, C_SEL = 3, C_CODE = C_SEL + kNumCls, C_WR = C_CODE + 1, C_USE2 = C_CODE + 2,
               C_RD = C_CODE + 3, C_RS1 = C_CODE + 4, C_RS2 = C_CODE + 5, C_IMM_LO = C_CODE + 6, C_IMM_HI = C_CODE + 7,
               C_TGT_LO = C_CODE + 8, C_TGT_HI = C_CODE + 9, C_A = C_CODE + 10, C_B = C_A + 2, C_C = C_B + 2, C_M = C_C + 2,
-              C_MV = C_M + 2, C_X = C_MV + 2, C_K0 = C_X + 2, C_K1 = C_K0 + 1, C_O0 = C_K0 + 2, C_O1 = C_O0 + 1, C_O2 = C_O0 + 2,
-              C_O3 = C_O0 + 3, C_MADDR = C_O0 + 4, C_SC = C_MADDR + 1, C_R1_PTS = C_SC + 6, C_R2_PTS = C_R1_PTS + 1,
-              C_M_PTS = C_R1_PTS + 2, C_W_PTS = C_R1_PTS + 3, C_W_PLO = C_R1_PTS + 4, C_W_PHI = C_R1_PTS + 5,
-              C_GAP = C_R1_PTS + 6, kCpuWidth = C_GAP + 8;
+              C_MV = C_M + 2, C_X = C_MV + 2, C_K0 = C_X + 2, C_K1 = C_K0 + 1, C_O1 = C_K0 + 2, C_O2 = C_O1 + 1, C_O3 = C_O1 + 2,
+              C_MADDR = C_O1 + 3, C_SC = C_MADDR + 1, C_W_PLO = C_SC + 6, C_W_PHI = C_W_PLO + 1, C_GAP = C_W_PLO + 2,
+              kCpuWidth = C_GAP + 8;
 enum { SC_HALT = 0, SC_WRITE, SC_COMMIT, SC_DEFER, SC_HINT_LEN, SC_HINT_READ };
-static_assert(kCpuWidth == 67, "CPU chip layout");
+static_assert(kCpuWidth == 62, "CPU chip layout");
 ZKSP_HD constexpr int selc(int cls) { return C_SEL + cls - 1; }
 
 // ---- keccak chip: p3-keccak-air's columns + the call time ----
@@ -95,10 +94,10 @@ static_assert(kAluWidth == 109, "ALU chip layout");
 constexpr int SW_IS_REAL = 0, SW_SEL = 1, SW_O = SW_SEL + 6, SW_A = SW_O + 4, SW_M = SW_A + 2, SW_C = SW_M + 32, SW_MV = SW_C + 16,
               kSubWidth = SW_MV + 2;
 static_assert(kSubWidth == 63, "sub-word chip layout");
-// ---- table chip: 2^16 rows; preprocessed (x, y: the row index's bytes; na: index not a multiple of 4);
-//      main: multiplicities of range16, 4-aligned range16, byte pair ----
-constexpr int TB_P_X = 0, TB_P_Y = 1, TB_P_NA = 2, kTablePrepWidth = 3, TB_M_R16 = 0, TB_M_AL = 1, TB_M_BY = 2, kTableWidth = 3,
-              kTableLogH = 16;
+// ---- table chip: 2^16 rows; preprocessed (x, y: the row index's bytes; na: index not a multiple of 4; nt: index above
+//      kAddrHiMax); main: multiplicities of range16 (kind 0), 4-aligned range16 (kind 1), high address limb (kind 2), byte pair ----
+constexpr int TB_P_X = 0, TB_P_Y = 1, TB_P_NA = 2, TB_P_NT = 3, kTablePrepWidth = 4, TB_M_R16 = 0, TB_M_AL = 1, TB_M_TOP = 2, TB_M_BY = 3,
+              kTableWidth = 4, kTableLogH = 16;
 constexpr uint32_t kAddrHiMax = 0x77FFu;  // high limb of the largest address / jump target
 
 enum Bus { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG };
@@ -145,7 +144,7 @@ ZKSP_HD constexpr uint32_t inv_pow2_mod(int n) {  // 2^-n mod p
 
 #define L(c) ctx.local(c)
 
-// ---- CPU chip: 83 constraints, emitted in order ----
+// ---- CPU chip: 78 constraints, emitted in order ----
 template <class Ctx>
 ZKSP_HD void eval_cpu(Ctx& ctx) {
   using F = typename Ctx::F;
@@ -163,8 +162,8 @@ ZKSP_HD void eval_cpu(Ctx& ctx) {
   const F k0 = L(C_K0), k1 = L(C_K1);
   ctx.emit(bool_c(k0, one));
   ctx.emit(bool_c(k1, one));
-  const F o0 = L(C_O0), o1 = L(C_O1), o2 = L(C_O2), o3 = L(C_O3);
-  ctx.emit(bool_c(o0, one)); ctx.emit(bool_c(o1, one)); ctx.emit(bool_c(o2, one)); ctx.emit(bool_c(o3, one));
+  const F o1 = L(C_O1), o2 = L(C_O2), o3 = L(C_O3), osum = o1 + o2 + o3;
+  ctx.emit(bool_c(o1, one)); ctx.emit(bool_c(o2, one)); ctx.emit(bool_c(o3, one));
   F scsum = zero;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
@@ -217,8 +216,8 @@ ZKSP_HD void eval_cpu(Ctx& ctx) {
   {
     const F noff = S(CL_ADD) + S(CL_SUB) + S(CL_ECALL) + S(CL_KECCAK) + S(CL_LW) + S(CL_SW);
     const F memw = S(CL_LW) + S(CL_SW) + S(CL_LDS) + S(CL_STS);
-    ctx.emit(noff * (o1 + o2 + o3));
-    ctx.emit((memw + S(CL_JALR)) * (o0 + o1 + o2 + o3 - one));
+    ctx.emit(noff * osum);
+    ctx.emit(bool_c(osum, one));  // at most one of the three offset flags
     ctx.emit(S(CL_JALR) * (o2 + o3));
     ctx.emit(memw * (L(C_MADDR) - xaddr));
     ctx.emit(S(CL_ECALL) * (L(C_MADDR) - ZKSP_K(11)));
@@ -270,17 +269,11 @@ ZKSP_HD void eval_cpu(Ctx& ctx) {
     ctx.emit(same * (a_lo - b_lo));
     ctx.emit(same * (a_hi - b_hi));
   }
-  // previous access times are older: difference = low limb + 2^16 * high byte (both looked up in the table chip)
-  {
-    const F memq = S(CL_LW) + S(CL_SW) + S(CL_LDS) + S(CL_STS) + S(CL_ECALL);
-    ctx.emit(ts - L(C_R1_PTS) - one - (L(C_GAP) + k65536 * L(C_GAP + 1)));
-    ctx.emit(L(C_USE2) * (ts - L(C_R2_PTS) - (L(C_GAP + 2) + k65536 * L(C_GAP + 3))));
-    ctx.emit(memq * (ts + one - L(C_M_PTS) - (L(C_GAP + 4) + k65536 * L(C_GAP + 5))));
-    ctx.emit(L(C_WR) * (ts + ZKSP_K(2) - L(C_W_PTS) - (L(C_GAP + 6) + k65536 * L(C_GAP + 7))));
-  }
+  // previous access times are older by construction: a slot's previous time IS its time - 1 - difference (a linear form in
+  // the memory-bus tuples), and the difference's low limb and high byte are looked up in the table chip
 #undef S
 }
-constexpr int kCpuConstraints = 83;
+constexpr int kCpuConstraints = 78;
 
 template <class Ctx>
 ZKSP_HD void eval_kmem(Ctx& ctx) {
@@ -586,10 +579,11 @@ template <class Ctx>
 ZKSP_HD void eval_image(Ctx& ctx) {
   ctx.emit(L(0) - ctx.prep(IMG_P_REAL));
 }
-// only multiples of 4 answer aligned lookups
+// only multiples of 4 answer aligned lookups, only values up to kAddrHiMax high-address-limb lookups
 template <class Ctx>
 ZKSP_HD void eval_table(Ctx& ctx) {
   ctx.emit(L(TB_M_AL) * ctx.prep(TB_P_NA));
+  ctx.emit(L(TB_M_TOP) * ctx.prep(TB_P_NT));
 }
 // the keccak chip's extra constraint after p3-keccak-air's 3182: the call time is constant inside
 // a permutation's 24 rows
@@ -603,7 +597,7 @@ constexpr int kKeccakConstraints = ka::kNumConstraints + 1;
 ZKSP_HD constexpr int num_constraints(int chip) {
   return is_cpu_chip(chip) ? kCpuConstraints : chip == kKeccak ? kKeccakConstraints : chip == kKmem ? kKmemConstraints
        : chip == kMemFinal ? kMemFinalConstraints : chip == kImage ? 1 : chip == kProgram ? 0 : chip == kMul ? kMulConstraints
-       : chip == kTable ? 1 : is_alu_chip(chip) ? kAluConstraints : is_sub_chip(chip) ? kSubConstraints : 0;
+       : chip == kTable ? 2 : is_alu_chip(chip) ? kAluConstraints : is_sub_chip(chip) ? kSubConstraints : 0;
 }
 
 }  // namespace mach

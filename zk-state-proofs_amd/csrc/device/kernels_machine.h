@@ -30,7 +30,7 @@ struct MachineRecords {
   const uint32_t* prog_mult;   // [B][2^log_prog]; the padding row (n_program - 1) holds 0: its fetches follow from cpu_rows
   const uint32_t* counts;      // [B][8]: cycles, keccak calls, memfinal rows, muls, ALU rows, sub-word rows, last time x0 was
                                //         accessed by a real cycle, 0
-  uint32_t* table_hist;        // [B][3][2^16] scratch: multiplicities of the table chip, counted on the device
+  uint32_t* table_hist;        // [B][kTableWidth][2^16] scratch: multiplicities of the table chip, counted on the device
   uint32_t row0[mach::kNumChips];  // first cycle / event of the chip's instance (second instances: rows of the first)
   size_t cap_cycles, cap_keccak, cap_memfinal, cap_muls, cap_alu, cap_sub;
   const uint32_t* program;     // [n_program][9] (shared); the last row is the padding instruction

@@ -76,7 +76,6 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
     o.val(C_NEXT_PC, pad_pc);
     o.put(selc(CL_JAL), kR1);
     o.limbs(C_TGT_LO, pad_pc);
-    o.val(C_R1_PTS, pts);
     o.limbs(C_GAP, ts - pts - 1);
     return;
   }
@@ -135,18 +134,14 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
   else o.limbs(C_X, x);
   o.limbs(C_A, a); o.limbs(C_B, bb); o.limbs(C_C, c); o.limbs(C_M, m); o.limbs(C_MV, mv);
   o.flag(C_K0, k0 != 0); o.flag(C_K1, k1 != 0);
-  for (uint32_t i = 0; i < 4; ++i) o.flag(C_O0 + i, i == off);
+  for (uint32_t i = 1; i < 4; ++i) o.flag(C_O1 + i - 1, i == off);
   o.val(C_MADDR, maddr);
   for (uint32_t i = 0; i < 6; ++i) o.flag(C_SC + i, i == sc);
   o.val(C_NEXT_PC, next);
   const bool memq = cls == CL_LW || cls == CL_SW || cls == CL_LDS || cls == CL_STS || cls == CL_ECALL;
-  o.val(C_R1_PTS, cy[7]);
   gap[0] = ts - cy[7] - 1;
-  o.val(C_R2_PTS, use2 ? cy[8] : 0u);
   if (use2) gap[1] = ts - cy[8];
-  o.val(C_M_PTS, memq ? cy[9] : 0u);
   if (memq) gap[2] = ts + 1 - cy[9];
-  o.val(C_W_PTS, wr ? cy[10] : 0u);
   if (wr) gap[3] = ts + 2 - cy[10];
   o.val(C_W_PLO, wr ? wprev & 0xffff : 0u);
   o.val(C_W_PHI, wr ? wprev >> 16 : 0u);
@@ -567,49 +562,66 @@ __device__ __forceinline__ Fp4 m_fingerprint(const Interaction& it, const RowVie
 // ===========================================================================================
 // table chip multiplicities: the RANGE / BYTES receives of a chip's rows, counted per table row
 // ===========================================================================================
-constexpr int kTableRowsPerBlock = 2048;
-constexpr uint32_t kTableLdsBins = 8192;  // the low range16 values and the byte pairs with a small second byte are hot
+constexpr int kTableRowsPerBlock = 4096;
+constexpr uint32_t kTableLdsBins = 4096;  // the low range16 values, the small high address limbs and the byte pairs with a
+                                          // small second byte are hot: counted in LDS, flushed once per workgroup
 constexpr size_t kTableRows = (size_t)1 << kTableLogH;
+// bins[idx] += m for the active lanes of a wave; the lanes that share the first active lane's bin (in these histograms
+// most of the wave: a zero high byte, a gap of 3) are added with one atomic
+__device__ __forceinline__ void wave_hist_add(uint32_t* bins, uint32_t idx, uint32_t m, bool active) {
+  const unsigned long long act = __ballot(active);
+  if (act == 0) return;
+  const int leader = __ffsll((long long)act) - 1;
+  const uint32_t k0 = __shfl(idx, leader, 64), m0 = __shfl(m, leader, 64);
+  const bool same = active && idx == k0 && m == m0;
+  const unsigned long long sm = __ballot(same);
+  const int lane = threadIdx.x & 63;
+  if (lane == leader) atomicAdd(&bins[k0], m0 * (uint32_t)__popcll(sm));
+  else if (active && !same) atomicAdd(&bins[idx], m);
+}
 __global__ __launch_bounds__(kMT) void table_count_kernel(const Interaction* __restrict__ inter, int n_inter,
                                                          const uint32_t* __restrict__ trace, int width, int logh,
                                                          uint32_t* __restrict__ hist) {
-  __shared__ uint32_t lds[2 * kTableLdsBins];
+  __shared__ uint32_t lds[3 * kTableLdsBins];  // range16, high address limb, byte pair
   const size_t h = (size_t)1 << logh;
   const int b = blockIdx.y;
-  for (uint32_t i = threadIdx.x; i < 2 * kTableLdsBins; i += kMT) lds[i] = 0;
+  for (uint32_t i = threadIdx.x; i < 3 * kTableLdsBins; i += kMT) lds[i] = 0;
   __syncthreads();
-  uint32_t* hb = hist + (size_t)b * 3 * kTableRows;
+  uint32_t* hb = hist + (size_t)b * kTableWidth * kTableRows;
   const size_t r0 = (size_t)blockIdx.x * kTableRowsPerBlock;
-  const size_t r1 = r0 + kTableRowsPerBlock < h ? r0 + kTableRowsPerBlock : h;
-  for (size_t r = r0 + threadIdx.x; r < r1; r += kMT) {
-    const RowView rv{nullptr, trace + (size_t)b * width * h + r, 0, h};
+  for (size_t rr = threadIdx.x; rr < kTableRowsPerBlock; rr += kMT) {  // every lane of a wave takes every trip: the
+    const size_t r = r0 + rr;                                            // wave-level aggregation needs converged lanes
+    const bool in_range = r < h;
+    const RowView rv{nullptr, trace + (size_t)b * width * h + (in_range ? r : 0), 0, h};
     for (int k = 0; k < n_inter; ++k) {
       const Interaction& it = inter[k];
       if (it.sign > 0 || (it.bus != BUS_RANGE && it.bus != BUS_BYTES)) continue;
-      const uint32_t m = m_lf_eval(it.mult, rv).to_canonical();
-      if (m == 0) continue;
+      const uint32_t m = in_range ? m_lf_eval(it.mult, rv).to_canonical() : 0u;
       const uint32_t v1 = m_lf_eval(it.el[0], rv).to_canonical(), v2 = m_lf_eval(it.el[1], rv).to_canonical();
+      // a value without a table row is not counted: the buses of such a (dishonest or unprovable) run do not balance
       if (it.bus == BUS_RANGE) {
-        // a value without a table row is not counted: the buses of such a (dishonest or unprovable) run do not balance
-        if (v2 >= kTableRows || v1 > 1 || (v1 == 1 && (v2 & 3))) continue;
-        if (v1 == 0 && v2 < kTableLdsBins) atomicAdd(&lds[v2], m);
-        else atomicAdd(&hb[(size_t)(v1 ? TB_M_AL : TB_M_R16) * kTableRows + v2], m);
+        const bool ok = m != 0 && v2 < kTableRows && v1 <= 2 && !(v1 == 1 && (v2 & 3)) && !(v1 == 2 && v2 > kAddrHiMax);
+        const bool hot = v1 != 1 && v2 < kTableLdsBins;
+        wave_hist_add(lds, (v1 == 2 ? kTableLdsBins : 0) + v2, m, ok && hot);  // (the kind differs between lanes)
+        if (ok && !hot) atomicAdd(&hb[(size_t)(v1 == 0 ? TB_M_R16 : v1 == 1 ? TB_M_AL : TB_M_TOP) * kTableRows + v2], m);
       } else {
-        if (v1 > 255 || v2 > 255) continue;
+        const bool ok = m != 0 && v1 <= 255 && v2 <= 255;
         const uint32_t idx = v1 + 256 * v2;
-        if (idx < kTableLdsBins) atomicAdd(&lds[kTableLdsBins + idx], m);
-        else atomicAdd(&hb[(size_t)TB_M_BY * kTableRows + idx], m);
+        const bool hot = idx < kTableLdsBins;
+        wave_hist_add(lds, 2 * kTableLdsBins + idx, m, ok && hot);
+        if (ok && !hot) atomicAdd(&hb[(size_t)TB_M_BY * kTableRows + idx], m);
       }
     }
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < kTableLdsBins; i += kMT) {
     if (lds[i]) atomicAdd(&hb[(size_t)TB_M_R16 * kTableRows + i], lds[i]);
-    if (lds[kTableLdsBins + i]) atomicAdd(&hb[(size_t)TB_M_BY * kTableRows + i], lds[kTableLdsBins + i]);
+    if (lds[kTableLdsBins + i]) atomicAdd(&hb[(size_t)TB_M_TOP * kTableRows + i], lds[kTableLdsBins + i]);
+    if (lds[2 * kTableLdsBins + i]) atomicAdd(&hb[(size_t)TB_M_BY * kTableRows + i], lds[2 * kTableLdsBins + i]);
   }
 }
 void launch_table_clear(hipStream_t stream, const MachineRecords& rec, int batch) {
-  (void)hipMemsetAsync(rec.table_hist, 0, (size_t)batch * 3 * kTableRows * 4, stream);
+  (void)hipMemsetAsync(rec.table_hist, 0, (size_t)batch * kTableWidth * kTableRows * 4, stream);
 }
 void launch_table_count(hipStream_t stream, const Interaction* inter, int n_inter, const uint32_t* trace, int width, int logh,
                         const MachineRecords& rec, int batch) {
@@ -618,8 +630,133 @@ void launch_table_count(hipStream_t stream, const Interaction* inter, int n_inte
                      inter, n_inter, trace, width, logh, rec.table_hist);
 }
 void launch_table_trace(hipStream_t stream, const MachineRecords& rec, uint32_t* trace, int batch) {
-  const size_t n = 3 * kTableRows;
+  const size_t n = kTableWidth * kTableRows;
   hipLaunchKernelGGL(count_column_kernel, dim3((unsigned)((n + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec.table_hist, trace, n);
+}
+
+// The CPU chip's 22 bus interactions evaluated from values a row holds once (the class id, the selector sums, the word
+// address, the four previous access times), instead of through the generic linear forms (which reload and rescale every
+// column for every tuple): the same field elements, a fraction of the work.  visit(j, ma, fa, mb, fb) is called for the
+// helper columns j = 0..10 in order with the two fractions of each; multiplicities are signed.  Must restate
+// machine_defs.cpp's g_cpu[] exactly: the whole-proof parity tests compare against the oracle's generic evaluation.
+template <class V>
+__device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, size_t cs, const Fp4& gamma,
+                                              const uint32_t* __restrict__ bpow, V&& visit) {
+  auto col = [&](int c) { return Fp::raw(row[(size_t)c * cs]); };
+  const Fp one = Fp::one(), two = Fp::raw(cmonty(2)), three = Fp::raw(cmonty(3)), k65536 = Fp::raw(cmonty(65536));
+  Fp sel[kNumCls + 1];
+  Fp clsid = Fp::zero(), kf = Fp::zero();
+#pragma unroll
+  for (int k = 1; k <= kNumCls; ++k) {
+    kf = kf + one;
+    sel[k] = col(selc(k));
+    clsid = clsid + kf * sel[k];
+  }
+  const Fp memw = sel[CL_LW] + sel[CL_SW] + sel[CL_LDS] + sel[CL_STS], memq = memw + sel[CL_ECALL];
+  const Fp al = memw + sel[CL_JALR], top = al + sel[CL_KECCAK];
+  const Fp chk = top + sel[CL_ADD] + sel[CL_SUB] + sel[CL_ECALL];
+  const Fp alu = sel[CL_ALU] + sel[CL_BLT] + sel[CL_BGE], sub = sel[CL_LDS] + sel[CL_STS];
+  const Fp ts = col(C_TS), wr = col(C_WR), use2 = col(C_USE2), rd = col(C_RD), rs1 = col(C_RS1), rs2 = col(C_RS2), code = col(C_CODE);
+  const Fp a_lo = col(C_A), a_hi = col(C_A + 1), b_lo = col(C_B), b_hi = col(C_B + 1), c_lo = col(C_C), c_hi = col(C_C + 1),
+           m_lo = col(C_M), m_hi = col(C_M + 1), mv_lo = col(C_MV), mv_hi = col(C_MV + 1), x_lo = col(C_X), x_hi = col(C_X + 1);
+  const Fp o1 = col(C_O1), o2 = col(C_O2), o3 = col(C_O3), off = o1 + o2.dbl() + three * o3;
+  Fp g[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) g[i] = col(C_GAP + i);
+  const Fp4 b1 = m_load_fp4(bpow + 4), b2 = m_load_fp4(bpow + 8), b3 = m_load_fp4(bpow + 12), b4 = m_load_fp4(bpow + 16);
+  auto busc = [&](int bus) {
+    Fp4 f = gamma;
+    f.c[0] += Fp::raw(cmonty((uint32_t)bus));
+    return f;
+  };
+  const Fp4 gmem = busc(BUS_MEM), grng = busc(BUS_RANGE), gbyt = busc(BUS_BYTES);
+  auto mem = [&](Fp addr, Fp lo, Fp hi, Fp t) { return gmem + b1 * addr + b2 * lo + b3 * hi + b4 * t; };
+  // previous access time of slot q (accessed at ts + q): ts + q - 1 - (gap_lo + 2^16 gap_hi)
+  auto pts = [&](int q) { return ts - (g[2 * q] + k65536 * g[2 * q + 1]) + (q == 0 ? -one : q == 1 ? Fp::zero() : q == 2 ? one : two); };
+  {  // helper 0: instruction fetch (receive), rs1 consume
+    Fp4 f = busc(BUS_PROG) + b1 * col(C_PC) + b2 * clsid + b3 * code + b4 * wr;
+    f += m_load_fp4(bpow + 20) * use2 + m_load_fp4(bpow + 24) * rd + m_load_fp4(bpow + 28) * rs1 + m_load_fp4(bpow + 32) * rs2 +
+         m_load_fp4(bpow + 36) * col(C_IMM_LO) + m_load_fp4(bpow + 40) * col(C_IMM_HI) + m_load_fp4(bpow + 44) * col(C_TGT_LO) +
+         m_load_fp4(bpow + 48) * col(C_TGT_HI);
+    visit(0, -one, f, -one, mem(rs1, b_lo, b_hi, pts(0)));
+  }
+  visit(1, one, mem(rs1, b_lo, b_hi, ts), -use2, mem(rs2, c_lo, c_hi, pts(1)));
+  {
+    const Fp maddr = col(C_MADDR);
+    visit(2, use2, mem(rs2, c_lo, c_hi, ts + one), -memq, mem(maddr, m_lo, m_hi, pts(2)));
+    visit(3, memq, mem(maddr, mv_lo, mv_hi, ts + two), -wr, mem(rd, col(C_W_PLO), col(C_W_PHI), pts(3)));
+  }
+  // the low limbs of the four access-time differences (range16), the two pairs of high bytes
+  visit(4, wr, mem(rd, a_lo, a_hi, ts + three), -one, grng + b2 * g[0]);
+  visit(5, -one, grng + b2 * g[2], -one, grng + b2 * g[4]);
+  visit(6, -one, grng + b2 * g[6], -one, gbyt + b1 * g[1] + b2 * g[3]);
+  // the adder output: high limb (kind 2 where it is an address), low limb less the byte offset (kind 1 where aligned)
+  visit(7, -one, gbyt + b1 * g[5] + b2 * g[7], -chk, grng + b1 * top.dbl() + b2 * x_hi);
+  {
+    const Fp4 falu = busc(BUS_ALU) + b1 * code + b2 * a_lo + b3 * a_hi + b4 * b_lo + m_load_fp4(bpow + 20) * b_hi +
+                     m_load_fp4(bpow + 24) * c_lo + m_load_fp4(bpow + 28) * c_hi;
+    visit(8, -chk, grng + b1 * al + b2 * (x_lo - off), alu, falu);
+  }
+  {
+    const Fp4 fsub = busc(BUS_SUB) + b1 * code + b2 * off + b3 * a_lo + b4 * a_hi + m_load_fp4(bpow + 20) * m_lo +
+                     m_load_fp4(bpow + 24) * m_hi + m_load_fp4(bpow + 28) * c_lo + m_load_fp4(bpow + 32) * mv_lo +
+                     m_load_fp4(bpow + 36) * mv_hi;
+    visit(9, sub, fsub, sel[CL_KECCAK], busc(BUS_KCALL) + b1 * ts + b2 * c_lo + b3 * c_hi);
+  }
+  {
+    const Fp scc = col(C_SC + SC_COMMIT), scd = col(C_SC + SC_DEFER);
+    visit(10, scc + scd, busc(BUS_PUBC) + b1 * (scc + scd.dbl()) + b2 * c_lo + b3 * m_lo + b4 * m_hi, col(C_SC + SC_HALT),
+          busc(BUS_PUBH) + b1 * c_lo + b2 * c_hi);
+  }
+}
+constexpr int kCpuHelpers = 11;
+
+// inverses of n extension elements with one inversion (Montgomery's trick); the elements are fingerprints, non-zero
+// except with negligible probability
+template <int N>
+__device__ __forceinline__ void batch_inverse(Fp4* f) {
+  Fp4 pre[N];
+  pre[0] = f[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i) pre[i] = pre[i - 1] * f[i];
+  Fp4 inv = pre[N - 1].inv();
+#pragma unroll
+  for (int i = N - 1; i >= 1; --i) {
+    const Fp4 fi = f[i];
+    f[i] = inv * pre[i - 1];
+    inv = inv * fi;
+  }
+  f[0] = inv;
+}
+
+__global__ __launch_bounds__(kMT) void perm_terms_cpu_kernel(PermArgs a) {
+  const size_t h = (size_t)1 << a.logh;
+  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (r >= h) return;
+  const int b = blockIdx.y;
+  const Fp4 gamma = m_load_fp4(a.bus_ch + (size_t)b * 8);
+  const uint32_t* bpow = a.bpow + (size_t)b * (kInterMaxElems + 1) * 4;
+  uint32_t* p = a.perm + (size_t)b * a.perm_bstride + r;
+  Fp4 f[2 * kCpuHelpers];
+  Fp m[2 * kCpuHelpers];
+  cpu_bus_pairs(a.main_.p + (size_t)b * a.main_.bstride + r, h, gamma, bpow,
+                [&](int j, Fp ma, const Fp4& fa, Fp mb, const Fp4& fb) {
+                  f[2 * j] = fa; f[2 * j + 1] = fb;
+                  m[2 * j] = ma; m[2 * j + 1] = mb;
+                });
+  // three groups (8, 8, 6 fractions): one inversion each
+  batch_inverse<8>(f);
+  batch_inverse<8>(f + 8);
+  batch_inverse<6>(f + 16);
+  Fp4 tot = Fp4::zero();
+#pragma unroll
+  for (int j = 0; j < kCpuHelpers; ++j) {
+    const Fp4 hj = f[2 * j] * m[2 * j] + f[2 * j + 1] * m[2 * j + 1];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) p[(size_t)(4 * j + t) * h] = hj.c[t].v;
+    tot += hj;
+  }
+  m_store_fp4(a.rowsum + ((size_t)b * h + r) * 4, tot);
 }
 
 __global__ __launch_bounds__(kMT) void perm_terms_kernel(PermArgs a) {
@@ -753,7 +890,10 @@ __global__ __launch_bounds__(kMT) void perm_slice_scan_kernel(PermArgs a, const 
 
 void launch_perm_trace(hipStream_t stream, const PermArgs& a) {
   const size_t h = (size_t)1 << a.logh;
-  hipLaunchKernelGGL(perm_terms_kernel, dim3((unsigned)((h + kMT - 1) / kMT), a.batch), dim3(kMT), 0, stream, a);
+  if (is_cpu_chip(a.chip))
+    hipLaunchKernelGGL(perm_terms_cpu_kernel, dim3((unsigned)((h + kMT - 1) / kMT), a.batch), dim3(kMT), 0, stream, a);
+  else
+    hipLaunchKernelGGL(perm_terms_kernel, dim3((unsigned)((h + kMT - 1) / kMT), a.batch), dim3(kMT), 0, stream, a);
   if (h >= (size_t)4 * kScanSlice && a.slice_sums) {
     const int nslices = (int)(h / kScanSlice);
     hipLaunchKernelGGL(perm_slice_sum_kernel, dim3(nslices, a.batch), dim3(kMT), 0, stream, a, a.slice_sums, nslices);
@@ -914,6 +1054,37 @@ __device__ __forceinline__ void logup_constraints(const MQuotArgs& a, const Poin
   *acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh + 2)) * ((cum - phi - hsum) * pi.last);
 }
 
+// the CPU chip's LogUp constraints with its fingerprints computed by cpu_bus_pairs
+__device__ __forceinline__ void cpu_logup_constraints(const MQuotArgs& a, const PointInfo& pi, Fp4* acc_out) {
+  const size_t h = (size_t)1 << a.logh, n = 2 * h;
+  const int b = pi.b;
+  const Fp4 gamma = m_load_fp4(a.bus_ch + (size_t)b * 8);
+  const uint32_t* bpow = a.bpow + (size_t)b * (kInterMaxElems + 1) * 4;
+  const uint32_t* ap = a.alpha_pows + (size_t)b * a.alpha_bstride;
+  const uint32_t* pl = a.perm.p + (size_t)b * a.perm.bstride + (size_t)pi.c * h;
+  constexpr int nh = kCpuHelpers;
+  Fp4 hsum = Fp4::zero(), acc = *acc_out;
+  cpu_bus_pairs(a.main_.p + (size_t)b * a.main_.bstride + pi.pt, n, gamma, bpow,
+                [&](int j, Fp ma, const Fp4& fa, Fp mb, const Fp4& fb) {
+                  Fp4 hj;
+#pragma unroll
+                  for (int t = 0; t < 4; ++t) hj.c[t] = Fp::raw(pl[(size_t)(4 * j + t) * n + pi.m]);
+                  hsum += hj;
+                  acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + j)) * (hj * fa * fb - (fb * ma + fa * mb));
+                });
+  Fp4 phi, phin;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    phi.c[t] = Fp::raw(pl[(size_t)(4 * nh + t) * n + pi.m]);
+    phin.c[t] = Fp::raw(pl[(size_t)(4 * nh + t) * n + pi.mn]);
+  }
+  const Fp4 cum = m_load_fp4(a.cum + (size_t)b * a.cum_bstride);
+  acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh)) * (phi * pi.first);
+  acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh + 1)) * ((phin - phi - hsum) * pi.trans);
+  acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh + 2)) * ((cum - phi - hsum) * pi.last);
+  *acc_out = acc;
+}
+
 __device__ __forceinline__ void init_ctx(const MQuotArgs& a, const PointInfo& pi, MQCtx* ctx) {
   const size_t h = (size_t)1 << a.logh, n = 2 * h;
   const uint32_t* base = a.main_.p + (size_t)pi.b * a.main_.bstride + (size_t)pi.c * h;
@@ -955,7 +1126,8 @@ __global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
   else if constexpr (is_alu_chip(CHIP)) eval_alu(ctx);
   else if constexpr (is_sub_chip(CHIP)) eval_sub(ctx);
   ctx.flush();
-  logup_constraints(a, pi, &ctx.acc);
+  if constexpr (is_cpu_chip(CHIP)) cpu_logup_constraints(a, pi, &ctx.acc);
+  else logup_constraints(a, pi, &ctx.acc);
   const Fp4 q = ctx.acc * Fp::raw(pi.c ? a.zh_inv[1] : a.zh_inv[0]);
   uint32_t* dst = a.quot + (size_t)pi.b * 8 * h + pi.m;
 #pragma unroll

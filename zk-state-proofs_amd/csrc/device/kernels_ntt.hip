@@ -20,6 +20,7 @@
 // of the instruction stream) between them.
 #include "kernels.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace zksp {
@@ -654,9 +655,16 @@ static void launch_lde_tall(hipStream_t stream, const uint32_t* in, uint32_t* co
   const size_t h2 = (size_t)1 << l2;
   const size_t smem = (fixed ? 1 : 2) * sizeof(uint32_t) * (h2 + (h2 >> 3) + 4);
   uint32_t* scratch = out + h;  // out[col][1]: every chunk of it is read, then rewritten, by the same workgroup
-  // grid.y is limited to 65535: columns in slabs
-  for (size_t c0 = 0; c0 < ncols; c0 += 16384) {
-    const size_t nc = ncols - c0 < 16384 ? ncols - c0 : 16384;
+  // Columns in slabs: grid.y is limited to 65535, and a slab whose working set (input, scratch / LDE, coefficients: 16 H
+  // bytes per column) fits the 256 MB Infinity Cache lets the four passes of a column hand their intermediates over
+  // on-die instead of through HBM (ZKSP_LDE_SLAB_MB: the working set of a slab in MB; default 0 = no blocking: measured on MI355X at 2^16 and 2^18, slabs of 96-224 MB ran 2-25 % SLOWER than one launch over all columns - the passes are bound by butterfly issue and LDS, not by HBM).
+  static const size_t slab_mb = getenv("ZKSP_LDE_SLAB_MB") ? (size_t)atoi(getenv("ZKSP_LDE_SLAB_MB")) : 0;
+  size_t slab = 16384;
+  // (a multiple of 8 columns: the chunk kernel picks the input scale table from the column index inside the slab, and
+  // quotient chunks alternate tables every 4 columns)
+  if (slab_mb) slab = std::min<size_t>(slab, std::max<size_t>(8, ((slab_mb << 20) / (16 * h)) & ~(size_t)7));
+  for (size_t c0 = 0; c0 < ncols; c0 += slab) {
+    const size_t nc = ncols - c0 < slab ? ncols - c0 : slab;
     launch_ntt_top<true>(stream, r_hi, logh, in + c0 * h, h, scratch + c0 * 2 * h, 2 * h, tw_inv, logh, nc);
     if (r_lo) launch_ntt_top<true>(stream, r_lo, logh - r_hi, scratch + c0 * 2 * h, 2 * h, scratch + c0 * 2 * h, 2 * h, tw_inv, logh, nc);
     if (fixed)

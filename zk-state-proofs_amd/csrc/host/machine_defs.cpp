@@ -6,7 +6,7 @@
 //   ALU    (op, a_lo, a_hi, b_lo, b_hi, c_lo, c_hi)   CPU -> ALU chip / multiplier
 //   SUB    (op, byte offset, a_lo, a_hi, m_lo, m_hi, c_lo, mv_lo, mv_hi)   CPU -> sub-word chip
 //   PUBC   (kind, index, lo, hi), PUBH (exit_lo, exit_hi)   CPU -> verifier
-//   RANGE  (kind, value)   value < 2^16 (kind 0), and a multiple of 4 (kind 1): table chip
+//   RANGE  (kind, value)   value < 2^16 (kind 0), and a multiple of 4 (kind 1), or at most 0x77FF (kind 2): table chip
 //   BYTES  (x, y)   two bytes: table chip
 //   IMG    (addr, lo, hi)   image chip -> memory boundary: the initial value of an image address
 #include "machine_defs.hpp"
@@ -86,8 +86,8 @@ Interaction bytes_inter(int sign, const LinForm& mult, const LinForm& x, const L
   return it;
 }
 
-constexpr int kCpuInter = 23;
-Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[3], g_alu[1], g_sub[1];
+constexpr int kCpuInter = 22;
+Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[4], g_alu[1], g_sub[1];
 ChipDef g_chips[kNumChips];
 
 void build() {
@@ -105,16 +105,23 @@ void build() {
     it.el[6] = lf_col(C_RS1); it.el[7] = lf_col(C_RS2); it.el[8] = lf_col(C_IMM_LO); it.el[9] = lf_col(C_IMM_HI);
     it.el[10] = lf_col(C_TGT_LO); it.el[11] = lf_col(C_TGT_HI);
   }
-  g_cpu[1] = mem_inter(-1, one, lf_col(C_RS1), b_lo, b_hi, lf_col(C_R1_PTS));
+  // previous access time of slot q (accessed at ts + q): ts + q - 1 - (gap_lo + 2^16 gap_hi)
+  LinForm pts[4];
+  for (int q = 0; q < 4; ++q) {
+    pts[q] = lf_zero();
+    lf_add(pts[q], C_TS, 1); lf_add(pts[q], C_GAP + 2 * q, kP - 1); lf_add(pts[q], C_GAP + 2 * q + 1, kP - 65536);
+    pts[q].c0 = mont((uint64_t)(kP + q - 1));
+  }
+  g_cpu[1] = mem_inter(-1, one, lf_col(C_RS1), b_lo, b_hi, pts[0]);
   g_cpu[2] = mem_inter(+1, one, lf_col(C_RS1), b_lo, b_hi, ts);
-  g_cpu[3] = mem_inter(-1, lf_col(C_USE2), lf_col(C_RS2), c_lo, c_hi, lf_col(C_R2_PTS));
+  g_cpu[3] = mem_inter(-1, lf_col(C_USE2), lf_col(C_RS2), c_lo, c_hi, pts[1]);
   g_cpu[4] = mem_inter(+1, lf_col(C_USE2), lf_col(C_RS2), c_lo, c_hi, lf_plus(ts, 1));
   {
     const LinForm memq = lf_sum({selc(CL_LW), selc(CL_SW), selc(CL_LDS), selc(CL_STS), selc(CL_ECALL)});
-    g_cpu[5] = mem_inter(-1, memq, lf_col(C_MADDR), m_lo, m_hi, lf_col(C_M_PTS));
+    g_cpu[5] = mem_inter(-1, memq, lf_col(C_MADDR), m_lo, m_hi, pts[2]);
     g_cpu[6] = mem_inter(+1, memq, lf_col(C_MADDR), lf_col(C_MV), lf_col(C_MV + 1), lf_plus(ts, 2));
   }
-  g_cpu[7] = mem_inter(-1, lf_col(C_WR), lf_col(C_RD), lf_col(C_W_PLO), lf_col(C_W_PHI), lf_col(C_W_PTS));
+  g_cpu[7] = mem_inter(-1, lf_col(C_WR), lf_col(C_RD), lf_col(C_W_PLO), lf_col(C_W_PHI), pts[3]);
   g_cpu[8] = mem_inter(+1, lf_col(C_WR), lf_col(C_RD), a_lo, a_hi, lf_plus(ts, 3));
   // access-time differences: every row looks up its four low limbs and the two pairs of high bytes
   for (int q = 0; q < 4; ++q) g_cpu[9 + q] = range_inter(-1, one, zero, lf_col(C_GAP + 2 * q));
@@ -127,35 +134,35 @@ void build() {
                                 selc(CL_ECALL), selc(CL_KECCAK)});
     LinForm xoff = lf_col(C_X);
     lf_add(xoff, C_O1, kP - 1); lf_add(xoff, C_O2, kP - 2); lf_add(xoff, C_O3, kP - 3);
-    g_cpu[15] = range_inter(-1, chk, zero, lf_col(C_X + 1));
+    LinForm top = lf_zero();  // kind 2: the high limb of an address is at most kAddrHiMax
+    for (int c : {selc(CL_JALR), selc(CL_LW), selc(CL_SW), selc(CL_LDS), selc(CL_STS), selc(CL_KECCAK)}) lf_add(top, c, 2);
+    g_cpu[15] = range_inter(-1, chk, top, lf_col(C_X + 1));
     g_cpu[16] = range_inter(-1, chk, lf_sum({selc(CL_JALR), selc(CL_LW), selc(CL_SW), selc(CL_LDS), selc(CL_STS)}), xoff);
-    g_cpu[17] = range_inter(-1, lf_sum({selc(CL_JALR), selc(CL_LW), selc(CL_SW), selc(CL_LDS), selc(CL_STS), selc(CL_KECCAK)}), zero,
-                            lf_const_minus(kAddrHiMax, C_X + 1));
   }
   {
-    Interaction& al = g_cpu[18];
+    Interaction& al = g_cpu[17];
     al = Interaction{};
     al.bus = BUS_ALU; al.sign = +1; al.mult = lf_sum({selc(CL_ALU), selc(CL_BLT), selc(CL_BGE)}); al.n_el = 7;
     al.el[0] = lf_col(C_CODE);
     al.el[1] = a_lo; al.el[2] = a_hi; al.el[3] = b_lo; al.el[4] = b_hi; al.el[5] = c_lo; al.el[6] = c_hi;
-    Interaction& sb = g_cpu[19];
+    Interaction& sb = g_cpu[18];
     sb = Interaction{};
     sb.bus = BUS_SUB; sb.sign = +1; sb.mult = lf_sum({selc(CL_LDS), selc(CL_STS)}); sb.n_el = 9;
     sb.el[0] = lf_col(C_CODE);
     sb.el[1] = lf_zero(); lf_add(sb.el[1], C_O1, 1); lf_add(sb.el[1], C_O2, 2); lf_add(sb.el[1], C_O3, 3);
     sb.el[2] = a_lo; sb.el[3] = a_hi; sb.el[4] = m_lo; sb.el[5] = m_hi; sb.el[6] = c_lo;
     sb.el[7] = lf_col(C_MV); sb.el[8] = lf_col(C_MV + 1);
-    Interaction& kc = g_cpu[20];
+    Interaction& kc = g_cpu[19];
     kc = Interaction{};
     kc.bus = BUS_KCALL; kc.sign = +1; kc.mult = lf_col(selc(CL_KECCAK)); kc.n_el = 3;
     kc.el[0] = ts; kc.el[1] = c_lo; kc.el[2] = c_hi;
-    Interaction& pc = g_cpu[21];
+    Interaction& pc = g_cpu[20];
     pc = Interaction{};
     pc.bus = BUS_PUBC; pc.sign = +1; pc.n_el = 4;
     pc.mult = lf_pair(C_SC + SC_COMMIT, C_SC + SC_DEFER, 1);
     pc.el[0] = lf_pair(C_SC + SC_COMMIT, C_SC + SC_DEFER, 2);
     pc.el[1] = c_lo; pc.el[2] = m_lo; pc.el[3] = m_hi;
-    Interaction& ph = g_cpu[22];
+    Interaction& ph = g_cpu[21];
     ph = Interaction{};
     ph.bus = BUS_PUBH; ph.sign = +1; ph.mult = lf_col(C_SC + SC_HALT); ph.n_el = 2;
     ph.el[0] = c_lo; ph.el[1] = c_hi;
@@ -216,7 +223,8 @@ void build() {
     const LinForm idx = lf_pair(TB_P_X, TB_P_Y, 256);
     g_table[0] = range_inter(+1, lf_col(kTablePrepWidth + TB_M_R16), zero, idx);
     g_table[1] = range_inter(+1, lf_col(kTablePrepWidth + TB_M_AL), one, idx);
-    g_table[2] = bytes_inter(+1, lf_col(kTablePrepWidth + TB_M_BY), lf_col(TB_P_X), lf_col(TB_P_Y));
+    g_table[2] = range_inter(+1, lf_col(kTablePrepWidth + TB_M_TOP), lf_const(2), idx);
+    g_table[3] = bytes_inter(+1, lf_col(kTablePrepWidth + TB_M_BY), lf_col(TB_P_X), lf_col(TB_P_Y));
   }
   for (int hi = 0; hi < 2; ++hi) {
     Interaction& it = g_mul[hi];
@@ -248,7 +256,7 @@ void build() {
     it.el[4] = lf_bits(SW_M, 16); it.el[5] = lf_bits(SW_M + 16, 16); it.el[6] = lf_bits(SW_C, 16);
     it.el[7] = lf_col(SW_MV); it.el[8] = lf_col(SW_MV + 1);
   }
-  g_chips[kTable] = {"table", kTablePrepWidth, kTableWidth, 3, g_table, 1};
+  g_chips[kTable] = {"table", kTablePrepWidth, kTableWidth, 4, g_table, 2};
   g_chips[kCpu] = {"cpu", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints};
   g_chips[kCpu2] = {"cpu2", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints};
   g_chips[kKeccak] = {"keccak", 0, kKeccakWidth, 50, g_keccak, kKeccakConstraints};

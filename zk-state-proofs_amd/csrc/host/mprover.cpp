@@ -208,7 +208,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   A(&w->alu_idx, B * w->cap_alu);
   A(&w->sub_idx, B * w->cap_sub);
   A(&w->prog_mult, B << logh[kProgram]);
-  A(&w->table_hist, (B * 3) << kTableLogH);
+  A(&w->table_hist, (B * kTableWidth) << kTableLogH);
   A(&w->counts, B * kCountWords);
   A(&w->n_perms, B);
   A(&w->init_obs, B * kMachineInitObs);

@@ -189,6 +189,7 @@ void machine_prep_traces(const MachineProgram& prog, std::vector<uint32_t>* imag
     (*table_prep)[(size_t)TB_P_X * ht + r] = (uint32_t)(r & 255);
     (*table_prep)[(size_t)TB_P_Y * ht + r] = (uint32_t)(r >> 8);
     (*table_prep)[(size_t)TB_P_NA * ht + r] = (r & 3) != 0;
+    (*table_prep)[(size_t)TB_P_NT * ht + r] = r > kAddrHiMax;
   }
   for (size_t r = 0; r < prog.image.size(); ++r) {
     (*image_prep)[(size_t)IMG_P_ADDR * hi + r] = prog.image[r].addr;
