@@ -175,6 +175,13 @@ int zksp_hip_machine_prove(zksp_client* c);
 int zksp_hip_machine_fetch_bodies(zksp_client* c, uint32_t* out, size_t cap_words);
 /* Only the 8-word main-trace commitment of every resident proof ([n][8]): what the proof farm all-gathers. */
 int zksp_hip_machine_fetch_roots(zksp_client* c, uint32_t* out, size_t cap_words);
+/* Kernel-level parity (tests): after zksp_hip_machine_prove, one intermediate matrix of resident proof `proof_index`, as
+ * canonical u32, column-major [width][2^log_height]: stage 0 = a chip's main trace (trace expansion kernels; table chip:
+ * the counted multiplicities), 1 = its LogUp permutation trace (helper columns + running sum), 2 = its quotient values
+ * over the two cosets ([8][H]).  zksp_hip_machine_fetch_challenges: gamma, beta, alpha, zeta (4 words each), then the chips'
+ * cumulative sums (4 words each), as the device's transcript sampled / computed them. */
+int zksp_hip_machine_fetch_stage(zksp_client* c, int chip, int stage, size_t proof_index, uint32_t* out, size_t cap_words);
+int zksp_hip_machine_fetch_challenges(zksp_client* c, size_t proof_index, uint32_t* out /* [16 + 4 * ZKSP_MACHINE_CHIPS] */);
 /* Complete v6 proof object from one fetched body and the trace it belongs to.  log_heights: the shape the batch was
  * proven with (zksp_machine_cover_heights of the loaded traces), NULL = the trace's own minimal heights. */
 int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] or NULL */,

@@ -172,6 +172,14 @@ void orc_machine_cpu_pub(const orc_machine_input* in, int chip, uint32_t pub[CPU
 void orc_machine_constraints(int chip, const uint32_t* prep, const uint32_t* loc, const uint32_t* nxt, uint32_t is_first,
                              uint32_t is_last, uint32_t is_trans, const uint32_t* pub, uint32_t* out);
 
+/* ---- kernel-level parity: one chip's stages for given challenges (4 canonical words each) ---- */
+/* LogUp permutation trace [perm_width][H] (helper columns, then the running sum) and the chip's cumulative sum */
+void orc_machine_stage_perm(const orc_machine_input* in, int chip, const uint32_t gamma[4], const uint32_t beta[4], uint32_t* perm,
+                            uint32_t cum[4]);
+/* quotient values [8][H]: columns 4c..4c+3 = the extension element over coset c */
+void orc_machine_stage_quotient(const orc_machine_input* in, int chip, const uint32_t alpha[4], const uint32_t gamma[4],
+                                const uint32_t beta[4], uint32_t* quot);
+
 /* ---- whole machine proof ---- */
 typedef struct {
   uint32_t exit_code;

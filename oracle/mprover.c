@@ -344,6 +344,61 @@ static void free_chips(chipd* cd) {
     for (int r = 0; r < N_ROUNDS; ++r) { free(cd[c].tr[r]); free(cd[c].lde[r]); free(cd[c].coef[r]); }
 }
 
+/* ---- kernel-level parity: one chip's LogUp permutation trace and quotient values for given challenges ---- */
+static void one_chip(const orc_machine_input* in, int chip, chipd* d) {
+  int logh[N_CHIPS];
+  orc_machine_heights(in, logh);
+  memset(d, 0, sizeof *d);
+  d->def = orc_machine_chip(chip);
+  d->logh = logh[chip];
+  d->h = (size_t)1 << logh[chip];
+  d->w[R_PREP] = d->def->prep_width; d->w[R_MAIN] = d->def->main_width; d->w[R_PERM] = orc_chip_perm_width(d->def); d->w[R_QUOT] = 8;
+  if (d->w[R_PREP]) d->tr[R_PREP] = (uint32_t*)malloc((size_t)d->w[R_PREP] * d->h * 4);
+  d->tr[R_MAIN] = (uint32_t*)malloc((size_t)d->w[R_MAIN] * d->h * 4);
+  orc_machine_fill(in, chip, d->logh, d->tr[R_PREP], d->tr[R_MAIN]);
+}
+static void free_one(chipd* d) {
+  for (int r = 0; r < N_ROUNDS; ++r) { free(d->tr[r]); free(d->lde[r]); free(d->coef[r]); }
+}
+static void challenge_powers(const uint32_t gamma4[4], const uint32_t beta4[4], fe4* gamma, fe4* bpow) {
+  fe4 beta;
+  memcpy(gamma->c, gamma4, 16);
+  memcpy(beta.c, beta4, 16);
+  bpow[0] = e_one();
+  for (int j = 1; j <= INTER_MAX_ELEMS; ++j) bpow[j] = e_mul(bpow[j - 1], beta);
+}
+void orc_machine_stage_perm(const orc_machine_input* in, int chip, const uint32_t gamma4[4], const uint32_t beta4[4], uint32_t* perm,
+                            uint32_t cum[4]) {
+  chipd d;
+  fe4 gamma, bpow[INTER_MAX_ELEMS + 1];
+  one_chip(in, chip, &d);
+  challenge_powers(gamma4, beta4, &gamma, bpow);
+  d.tr[R_PERM] = (uint32_t*)calloc((size_t)d.w[R_PERM] * d.h, 4);
+  perm_trace(&d, gamma, bpow);
+  memcpy(perm, d.tr[R_PERM], (size_t)d.w[R_PERM] * d.h * 4);
+  memcpy(cum, d.cum.c, 16);
+  free_one(&d);
+}
+void orc_machine_stage_quotient(const orc_machine_input* in, int chip, const uint32_t alpha4[4], const uint32_t gamma4[4],
+                                const uint32_t beta4[4], uint32_t* quot) {
+  chipd d;
+  fe4 gamma, alpha, bpow[INTER_MAX_ELEMS + 1];
+  uint32_t pub[CPUPUB_N] = {0, 0, 0, 0, 0};
+  one_chip(in, chip, &d);
+  challenge_powers(gamma4, beta4, &gamma, bpow);
+  memcpy(alpha.c, alpha4, 16);
+  if (chip == CH_CPU || chip == CH_CPU2) orc_machine_cpu_pub(in, chip, pub);
+  lde_round(&d, R_PREP);
+  lde_round(&d, R_MAIN);
+  d.tr[R_PERM] = (uint32_t*)calloc((size_t)d.w[R_PERM] * d.h, 4);
+  perm_trace(&d, gamma, bpow);
+  lde_round(&d, R_PERM);
+  d.tr[R_QUOT] = (uint32_t*)malloc((size_t)8 * d.h * 4);
+  chip_quotient(&d, chip, alpha, gamma, bpow, pub);
+  memcpy(quot, d.tr[R_QUOT], (size_t)8 * d.h * 4);
+  free_one(&d);
+}
+
 static void vk_digest_of(const uint32_t root[8], const orc_machine_input* in, int keccak_mode, uint32_t out[8]) {
   uint32_t v[18];
   const uint32_t pad_pc = in->text_base + 4 * (uint32_t)(in->n_program - 1); /* the padding instruction: last Program row */

@@ -375,6 +375,26 @@ def machine_events(t: dict, which: int) -> np.ndarray:
     return out[:n]
 
 
+def machine_stage_perm(t: dict, chip: int, gamma, beta):
+    """(permutation trace [perm_width][H], cumulative sum) of one chip for the given LogUp challenges."""
+    mi, _keep = machine_input(t)
+    d = machine_chip(chip)
+    h = 1 << machine_heights(t)[chip]
+    pw = 4 * ((d["n_inter"] + 1) // 2 + 1)
+    perm, cum = np.zeros((pw, h), np.uint32), np.zeros(4, np.uint32)
+    lib().orc_machine_stage_perm(C.byref(mi), chip, _p(_u32(gamma)), _p(_u32(beta)), _p(perm), _p(cum))
+    return perm, [int(x) for x in cum]
+
+
+def machine_stage_quotient(t: dict, chip: int, alpha, gamma, beta) -> np.ndarray:
+    """Quotient values [8][H] of one chip for the given challenges."""
+    mi, _keep = machine_input(t)
+    h = 1 << machine_heights(t)[chip]
+    quot = np.zeros((8, h), np.uint32)
+    lib().orc_machine_stage_quotient(C.byref(mi), chip, _p(_u32(alpha)), _p(_u32(gamma)), _p(_u32(beta)), _p(quot))
+    return quot
+
+
 def machine_setup(t: dict):
     """(preprocessed commitment root, verifying-key digest) as lists of 8 canonical words."""
     mi, _keep = machine_input(t)

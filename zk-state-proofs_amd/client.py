@@ -130,6 +130,8 @@ def load_library() -> C.CDLL:
     lib.zksp_hip_machine_fetch_roots.argtypes = [vp, vp, sz]
     lib.zksp_machine_proof_from_body.argtypes = [vp, vp, vp, vp, sz, C.POINTER(vp)]
     lib.zksp_machine_cover_heights.argtypes = [vp, sz, vp]
+    lib.zksp_hip_machine_fetch_stage.argtypes = [vp, C.c_int, C.c_int, sz, vp, sz]
+    lib.zksp_hip_machine_fetch_challenges.argtypes = [vp, sz, vp]
     lib.zksp_get_params.argtypes = [vp, C.POINTER(Params)]
     lib.zksp_proof_body_words.argtypes = [vp, C.c_int]
     lib.zksp_proof_body_words.restype = sz
@@ -169,7 +171,8 @@ ABI_SYMBOLS = [
     "zksp_proof_public_values", "zksp_proof_serialize", "zksp_proof_deserialize", "zksp_proof_free", "zksp_verify",
     "zksp_execute", "zksp_execute_keccak", "zksp_opcode_name", "zksp_machine_trace", "zksp_mtrace_free",
     "zksp_mtrace_section", "zksp_mtrace_info", "zksp_vk_machine", "zksp_mtrace_heights", "zksp_machine_body_words",
-    "zksp_machine_chip_widths", "zksp_machine_cover_heights", "zksp_hip_machine_load", "zksp_hip_machine_prove", "zksp_hip_machine_fetch_bodies", "zksp_hip_machine_fetch_roots", "zksp_machine_proof_from_body", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
+    "zksp_machine_chip_widths", "zksp_machine_cover_heights", "zksp_hip_machine_fetch_stage", "zksp_hip_machine_fetch_challenges",
+    "zksp_hip_machine_load", "zksp_hip_machine_prove", "zksp_hip_machine_fetch_bodies", "zksp_hip_machine_fetch_roots", "zksp_machine_proof_from_body", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
     "zksp_hip_prove_resident", "zksp_proof_from_body", "zksp_hip_fetch_bodies", "zksp_hip_fetch_roots", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
     "zksp_hip_profile_enable", "zksp_hip_profile_read", "zksp_hip_profile_reset", "zksp_dev_malloc", "zksp_dev_free",
     "zksp_dev_upload", "zksp_dev_download", "zksp_dev_memset", "zksp_hip_lde", "zksp_hip_merkle_commit",
@@ -472,6 +475,27 @@ class ProverClient:
         if rc:
             raise ZkspError(rc, self.last_error())
         return out
+
+    def machine_stage(self, chip: int, stage: int, proof_index: int, width: int, log_height: int):
+        """One intermediate matrix of a resident proof after ``machine_prove_resident`` (kernel-level parity tests):
+        stage 0 main trace, 1 LogUp permutation trace, 2 quotient values; canonical u32 [width][2^log_height]."""
+        import numpy as np
+        out = np.zeros((width, 1 << log_height), np.uint32)
+        rc = self._lib.zksp_hip_machine_fetch_stage(self._h, chip, stage, proof_index, out.ctypes.data_as(C.c_void_p), out.size)
+        if rc:
+            raise ZkspError(rc, self.last_error())
+        return out
+
+    def machine_challenges(self, proof_index: int) -> dict:
+        """gamma, beta, alpha, zeta (lists of 4 canonical words) and the chips' cumulative sums of a resident proof."""
+        import numpy as np
+        out = np.zeros(16 + 4 * MACHINE_CHIPS, np.uint32)
+        rc = self._lib.zksp_hip_machine_fetch_challenges(self._h, proof_index, out.ctypes.data_as(C.c_void_p))
+        if rc:
+            raise ZkspError(rc, self.last_error())
+        v = [int(x) for x in out]
+        return {"gamma": v[0:4], "beta": v[4:8], "alpha": v[8:12], "zeta": v[12:16],
+                "cum": [v[16 + 4 * c:20 + 4 * c] for c in range(MACHINE_CHIPS)]}
 
     def opcode_histogram(self, rep: ExecReport) -> dict:
         out = {}

@@ -103,7 +103,7 @@ struct MQuotArgs {
   const uint32_t* pubs;         // CPU instances: this instance's CpuPub words per proof (Montgomery), stride pubs_bstride
   size_t pubs_bstride;
   uint32_t* quot;               // [B][8][H]
-  uint32_t* partial;            // keccak chip: [B][13][2H] Fp4 scratch
+  uint32_t* partial;            // keccak chip: [B][13][2H] Fp4 scratch; CPU chip: [B][2H] Fp4
   int logh, batch;
 };
 void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a);

@@ -639,9 +639,18 @@ void launch_table_trace(hipStream_t stream, const MachineRecords& rec, uint32_t*
 // column for every tuple): the same field elements, a fraction of the work.  visit(j, ma, fa, mb, fb) is called for the
 // helper columns j = 0..10 in order with the two fractions of each; multiplicities are signed.  Must restate
 // machine_defs.cpp's g_cpu[] exactly: the whole-proof parity tests compare against the oracle's generic evaluation.
-template <class V>
+// J0, J1: only the helper columns J0 <= j < J1 are visited (the loads the others need are dead code): the kernels below
+// evaluate the 11 pairs in three launches, because all 22 extension-field fingerprints at once do not fit the register
+// file (256 VGPRs and one wave per SIMD when they are evaluated together).
+constexpr int kCpuHelpers = 11, kCpuBusGroups = 3;
+__host__ __device__ constexpr int cpu_group_lo(int g) { return g == 0 ? 0 : g == 1 ? 4 : 8; }
+__host__ __device__ constexpr int cpu_group_hi(int g) { return g == 0 ? 4 : g == 1 ? 8 : kCpuHelpers; }
+template <int J0, int J1, class V>
 __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, size_t cs, const Fp4& gamma,
-                                              const uint32_t* __restrict__ bpow, V&& visit) {
+                                              const uint32_t* __restrict__ bpow, V&& visit_all) {
+  auto visit = [&](int j, Fp ma, const Fp4& fa, Fp mb, const Fp4& fb) {
+    if (j >= J0 && j < J1) visit_all(j, ma, fa, mb, fb);
+  };
   auto col = [&](int c) { return Fp::raw(row[(size_t)c * cs]); };
   const Fp one = Fp::one(), two = Fp::raw(cmonty(2)), three = Fp::raw(cmonty(3)), k65536 = Fp::raw(cmonty(65536));
   Fp sel[kNumCls + 1];
@@ -673,43 +682,42 @@ __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, 
   auto mem = [&](Fp addr, Fp lo, Fp hi, Fp t) { return gmem + b1 * addr + b2 * lo + b3 * hi + b4 * t; };
   // previous access time of slot q (accessed at ts + q): ts + q - 1 - (gap_lo + 2^16 gap_hi)
   auto pts = [&](int q) { return ts - (g[2 * q] + k65536 * g[2 * q + 1]) + (q == 0 ? -one : q == 1 ? Fp::zero() : q == 2 ? one : two); };
-  {  // helper 0: instruction fetch (receive), rs1 consume
+  if (J0 <= 0 && 0 < J1) {  // helper 0: instruction fetch (receive), rs1 consume
     Fp4 f = busc(BUS_PROG) + b1 * col(C_PC) + b2 * clsid + b3 * code + b4 * wr;
     f += m_load_fp4(bpow + 20) * use2 + m_load_fp4(bpow + 24) * rd + m_load_fp4(bpow + 28) * rs1 + m_load_fp4(bpow + 32) * rs2 +
          m_load_fp4(bpow + 36) * col(C_IMM_LO) + m_load_fp4(bpow + 40) * col(C_IMM_HI) + m_load_fp4(bpow + 44) * col(C_TGT_LO) +
          m_load_fp4(bpow + 48) * col(C_TGT_HI);
     visit(0, -one, f, -one, mem(rs1, b_lo, b_hi, pts(0)));
   }
-  visit(1, one, mem(rs1, b_lo, b_hi, ts), -use2, mem(rs2, c_lo, c_hi, pts(1)));
-  {
+  if (J0 <= 1 && 1 < J1) visit(1, one, mem(rs1, b_lo, b_hi, ts), -use2, mem(rs2, c_lo, c_hi, pts(1)));
+  if (J0 <= 3 && 2 < J1) {
     const Fp maddr = col(C_MADDR);
     visit(2, use2, mem(rs2, c_lo, c_hi, ts + one), -memq, mem(maddr, m_lo, m_hi, pts(2)));
     visit(3, memq, mem(maddr, mv_lo, mv_hi, ts + two), -wr, mem(rd, col(C_W_PLO), col(C_W_PHI), pts(3)));
   }
   // the low limbs of the four access-time differences (range16), the two pairs of high bytes
-  visit(4, wr, mem(rd, a_lo, a_hi, ts + three), -one, grng + b2 * g[0]);
-  visit(5, -one, grng + b2 * g[2], -one, grng + b2 * g[4]);
-  visit(6, -one, grng + b2 * g[6], -one, gbyt + b1 * g[1] + b2 * g[3]);
+  if (J0 <= 4 && 4 < J1) visit(4, wr, mem(rd, a_lo, a_hi, ts + three), -one, grng + b2 * g[0]);
+  if (J0 <= 5 && 5 < J1) visit(5, -one, grng + b2 * g[2], -one, grng + b2 * g[4]);
+  if (J0 <= 6 && 6 < J1) visit(6, -one, grng + b2 * g[6], -one, gbyt + b1 * g[1] + b2 * g[3]);
   // the adder output: high limb (kind 2 where it is an address), low limb less the byte offset (kind 1 where aligned)
-  visit(7, -one, gbyt + b1 * g[5] + b2 * g[7], -chk, grng + b1 * top.dbl() + b2 * x_hi);
-  {
+  if (J0 <= 7 && 7 < J1) visit(7, -one, gbyt + b1 * g[5] + b2 * g[7], -chk, grng + b1 * top.dbl() + b2 * x_hi);
+  if (J0 <= 8 && 8 < J1) {
     const Fp4 falu = busc(BUS_ALU) + b1 * code + b2 * a_lo + b3 * a_hi + b4 * b_lo + m_load_fp4(bpow + 20) * b_hi +
                      m_load_fp4(bpow + 24) * c_lo + m_load_fp4(bpow + 28) * c_hi;
     visit(8, -chk, grng + b1 * al + b2 * (x_lo - off), alu, falu);
   }
-  {
+  if (J0 <= 9 && 9 < J1) {
     const Fp4 fsub = busc(BUS_SUB) + b1 * code + b2 * off + b3 * a_lo + b4 * a_hi + m_load_fp4(bpow + 20) * m_lo +
                      m_load_fp4(bpow + 24) * m_hi + m_load_fp4(bpow + 28) * c_lo + m_load_fp4(bpow + 32) * mv_lo +
                      m_load_fp4(bpow + 36) * mv_hi;
     visit(9, sub, fsub, sel[CL_KECCAK], busc(BUS_KCALL) + b1 * ts + b2 * c_lo + b3 * c_hi);
   }
-  {
+  if (J0 <= 10 && 10 < J1) {
     const Fp scc = col(C_SC + SC_COMMIT), scd = col(C_SC + SC_DEFER);
     visit(10, scc + scd, busc(BUS_PUBC) + b1 * (scc + scd.dbl()) + b2 * c_lo + b3 * m_lo + b4 * m_hi, col(C_SC + SC_HALT),
           busc(BUS_PUBH) + b1 * c_lo + b2 * c_hi);
   }
 }
-constexpr int kCpuHelpers = 11;
 
 // inverses of n extension elements with one inversion (Montgomery's trick); the elements are fingerprints, non-zero
 // except with negligible probability
@@ -729,7 +737,10 @@ __device__ __forceinline__ void batch_inverse(Fp4* f) {
   f[0] = inv;
 }
 
+// helper columns of group G (cpu_group_lo .. cpu_group_hi); the row sum accumulates over the three launches
+template <int G>
 __global__ __launch_bounds__(kMT) void perm_terms_cpu_kernel(PermArgs a) {
+  constexpr int J0 = cpu_group_lo(G), J1 = cpu_group_hi(G), NF = 2 * (J1 - J0);
   const size_t h = (size_t)1 << a.logh;
   const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
   if (r >= h) return;
@@ -737,26 +748,24 @@ __global__ __launch_bounds__(kMT) void perm_terms_cpu_kernel(PermArgs a) {
   const Fp4 gamma = m_load_fp4(a.bus_ch + (size_t)b * 8);
   const uint32_t* bpow = a.bpow + (size_t)b * (kInterMaxElems + 1) * 4;
   uint32_t* p = a.perm + (size_t)b * a.perm_bstride + r;
-  Fp4 f[2 * kCpuHelpers];
-  Fp m[2 * kCpuHelpers];
-  cpu_bus_pairs(a.main_.p + (size_t)b * a.main_.bstride + r, h, gamma, bpow,
-                [&](int j, Fp ma, const Fp4& fa, Fp mb, const Fp4& fb) {
-                  f[2 * j] = fa; f[2 * j + 1] = fb;
-                  m[2 * j] = ma; m[2 * j + 1] = mb;
-                });
-  // three groups (8, 8, 6 fractions): one inversion each
-  batch_inverse<8>(f);
-  batch_inverse<8>(f + 8);
-  batch_inverse<6>(f + 16);
-  Fp4 tot = Fp4::zero();
+  Fp4 f[NF];
+  Fp m[NF];
+  cpu_bus_pairs<J0, J1>(a.main_.p + (size_t)b * a.main_.bstride + r, h, gamma, bpow,
+                        [&](int j, Fp ma, const Fp4& fa, Fp mb, const Fp4& fb) {
+                          f[2 * (j - J0)] = fa; f[2 * (j - J0) + 1] = fb;
+                          m[2 * (j - J0)] = ma; m[2 * (j - J0) + 1] = mb;
+                        });
+  batch_inverse<NF>(f);  // one inversion for the group's fractions
+  uint32_t* rs = a.rowsum + ((size_t)b * h + r) * 4;
+  Fp4 tot = G == 0 ? Fp4::zero() : m_load_fp4(rs);
 #pragma unroll
-  for (int j = 0; j < kCpuHelpers; ++j) {
-    const Fp4 hj = f[2 * j] * m[2 * j] + f[2 * j + 1] * m[2 * j + 1];
+  for (int j = J0; j < J1; ++j) {
+    const Fp4 hj = f[2 * (j - J0)] * m[2 * (j - J0)] + f[2 * (j - J0) + 1] * m[2 * (j - J0) + 1];
 #pragma unroll
     for (int t = 0; t < 4; ++t) p[(size_t)(4 * j + t) * h] = hj.c[t].v;
     tot += hj;
   }
-  m_store_fp4(a.rowsum + ((size_t)b * h + r) * 4, tot);
+  m_store_fp4(rs, tot);
 }
 
 __global__ __launch_bounds__(kMT) void perm_terms_kernel(PermArgs a) {
@@ -890,9 +899,12 @@ __global__ __launch_bounds__(kMT) void perm_slice_scan_kernel(PermArgs a, const 
 
 void launch_perm_trace(hipStream_t stream, const PermArgs& a) {
   const size_t h = (size_t)1 << a.logh;
-  if (is_cpu_chip(a.chip))
-    hipLaunchKernelGGL(perm_terms_cpu_kernel, dim3((unsigned)((h + kMT - 1) / kMT), a.batch), dim3(kMT), 0, stream, a);
-  else
+  if (is_cpu_chip(a.chip)) {
+    const dim3 grid((unsigned)((h + kMT - 1) / kMT), a.batch);
+    hipLaunchKernelGGL(perm_terms_cpu_kernel<0>, grid, dim3(kMT), 0, stream, a);
+    hipLaunchKernelGGL(perm_terms_cpu_kernel<1>, grid, dim3(kMT), 0, stream, a);
+    hipLaunchKernelGGL(perm_terms_cpu_kernel<2>, grid, dim3(kMT), 0, stream, a);
+  } else
     hipLaunchKernelGGL(perm_terms_kernel, dim3((unsigned)((h + kMT - 1) / kMT), a.batch), dim3(kMT), 0, stream, a);
   if (h >= (size_t)4 * kScanSlice && a.slice_sums) {
     const int nslices = (int)(h / kScanSlice);
@@ -1054,37 +1066,6 @@ __device__ __forceinline__ void logup_constraints(const MQuotArgs& a, const Poin
   *acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh + 2)) * ((cum - phi - hsum) * pi.last);
 }
 
-// the CPU chip's LogUp constraints with its fingerprints computed by cpu_bus_pairs
-__device__ __forceinline__ void cpu_logup_constraints(const MQuotArgs& a, const PointInfo& pi, Fp4* acc_out) {
-  const size_t h = (size_t)1 << a.logh, n = 2 * h;
-  const int b = pi.b;
-  const Fp4 gamma = m_load_fp4(a.bus_ch + (size_t)b * 8);
-  const uint32_t* bpow = a.bpow + (size_t)b * (kInterMaxElems + 1) * 4;
-  const uint32_t* ap = a.alpha_pows + (size_t)b * a.alpha_bstride;
-  const uint32_t* pl = a.perm.p + (size_t)b * a.perm.bstride + (size_t)pi.c * h;
-  constexpr int nh = kCpuHelpers;
-  Fp4 hsum = Fp4::zero(), acc = *acc_out;
-  cpu_bus_pairs(a.main_.p + (size_t)b * a.main_.bstride + pi.pt, n, gamma, bpow,
-                [&](int j, Fp ma, const Fp4& fa, Fp mb, const Fp4& fb) {
-                  Fp4 hj;
-#pragma unroll
-                  for (int t = 0; t < 4; ++t) hj.c[t] = Fp::raw(pl[(size_t)(4 * j + t) * n + pi.m]);
-                  hsum += hj;
-                  acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + j)) * (hj * fa * fb - (fb * ma + fa * mb));
-                });
-  Fp4 phi, phin;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    phi.c[t] = Fp::raw(pl[(size_t)(4 * nh + t) * n + pi.m]);
-    phin.c[t] = Fp::raw(pl[(size_t)(4 * nh + t) * n + pi.mn]);
-  }
-  const Fp4 cum = m_load_fp4(a.cum + (size_t)b * a.cum_bstride);
-  acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh)) * (phi * pi.first);
-  acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh + 1)) * ((phin - phi - hsum) * pi.trans);
-  acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh + 2)) * ((cum - phi - hsum) * pi.last);
-  *acc_out = acc;
-}
-
 __device__ __forceinline__ void init_ctx(const MQuotArgs& a, const PointInfo& pi, MQCtx* ctx) {
   const size_t h = (size_t)1 << a.logh, n = 2 * h;
   const uint32_t* base = a.main_.p + (size_t)pi.b * a.main_.bstride + (size_t)pi.c * h;
@@ -1117,8 +1098,7 @@ __global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
   init_ctx(a, pi, &ctx);
   __shared__ uint32_t stash[is_alu_chip(CHIP) ? 32 * kMT : 1];  // the ALU chip parks B's 32 bits per lane (MQCtx::stash)
   ctx.stash_ = stash + (is_alu_chip(CHIP) ? threadIdx.x : 0);
-  if constexpr (is_cpu_chip(CHIP)) eval_cpu(ctx);
-  else if constexpr (CHIP == kKmem) eval_kmem(ctx);
+  if constexpr (CHIP == kKmem) eval_kmem(ctx);
   else if constexpr (CHIP == kMemFinal) eval_memfinal(ctx);
   else if constexpr (CHIP == kImage) eval_image(ctx);
   else if constexpr (CHIP == kMul) eval_mul(ctx);
@@ -1126,12 +1106,69 @@ __global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
   else if constexpr (is_alu_chip(CHIP)) eval_alu(ctx);
   else if constexpr (is_sub_chip(CHIP)) eval_sub(ctx);
   ctx.flush();
-  if constexpr (is_cpu_chip(CHIP)) cpu_logup_constraints(a, pi, &ctx.acc);
-  else logup_constraints(a, pi, &ctx.acc);
+  logup_constraints(a, pi, &ctx.acc);
   const Fp4 q = ctx.acc * Fp::raw(pi.c ? a.zh_inv[1] : a.zh_inv[0]);
   uint32_t* dst = a.quot + (size_t)pi.b * 8 * h + pi.m;
 #pragma unroll
   for (int j = 0; j < 4; ++j) dst[(size_t)(4 * pi.c + j) * h] = q.c[j].v;
+}
+
+// CPU chip: the base constraints (task 0) and the LogUp constraints with the fingerprints of cpu_bus_pairs, one launch
+// per group of helper columns (tasks 1..3), each with its own register budget.  A point's partial sum travels through
+// a.partial ([B][2H] Fp4): task 0 writes it, the others add, the last one divides by the vanishing polynomial.
+template <int TASK>
+__global__ __launch_bounds__(kMT) void cpu_quotient_task_kernel(MQuotArgs a) {
+  const size_t h = (size_t)1 << a.logh, n = 2 * h;
+  const size_t pt = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (pt >= n) return;
+  PointInfo pi;
+  pi.b = blockIdx.y;
+  point_selectors(a, pt, &pi);
+  uint32_t* part = a.partial + ((size_t)pi.b * n + pt) * 4;
+  if constexpr (TASK == 0) {
+    MQCtx ctx;
+    init_ctx(a, pi, &ctx);
+    eval_cpu(ctx);
+    ctx.flush();
+    m_store_fp4(part, ctx.acc);
+  } else {
+    constexpr int G = TASK - 1, J0 = cpu_group_lo(G), J1 = cpu_group_hi(G), nh = kCpuHelpers;
+    const int b = pi.b;
+    const Fp4 gamma = m_load_fp4(a.bus_ch + (size_t)b * 8);
+    const uint32_t* bpow = a.bpow + (size_t)b * (kInterMaxElems + 1) * 4;
+    const uint32_t* ap = a.alpha_pows + (size_t)b * a.alpha_bstride;
+    const uint32_t* pl = a.perm.p + (size_t)b * a.perm.bstride + (size_t)pi.c * h;
+    Fp4 acc = m_load_fp4(part);
+    cpu_bus_pairs<J0, J1>(a.main_.p + (size_t)b * a.main_.bstride + pt, n, gamma, bpow,
+                          [&](int j, Fp ma, const Fp4& fa, Fp mb, const Fp4& fb) {
+                            Fp4 hj;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) hj.c[t] = Fp::raw(pl[(size_t)(4 * j + t) * n + pi.m]);
+                            acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + j)) * (hj * fa * fb - (fb * ma + fa * mb));
+                          });
+    if constexpr (G == kCpuBusGroups - 1) {
+      // the running sum: phi starts at 0, grows by the row's helper columns, ends at the cumulative sum
+      Fp4 hsum = Fp4::zero(), phi, phin;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        Fp sacc = Fp::zero();
+        for (int j = 0; j < nh; ++j) sacc += Fp::raw(pl[(size_t)(4 * j + t) * n + pi.m]);
+        hsum.c[t] = sacc;
+        phi.c[t] = Fp::raw(pl[(size_t)(4 * nh + t) * n + pi.m]);
+        phin.c[t] = Fp::raw(pl[(size_t)(4 * nh + t) * n + pi.mn]);
+      }
+      const Fp4 cum = m_load_fp4(a.cum + (size_t)b * a.cum_bstride);
+      acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh)) * (phi * pi.first);
+      acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh + 1)) * ((phin - phi - hsum) * pi.trans);
+      acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh + 2)) * ((cum - phi - hsum) * pi.last);
+      const Fp4 q = acc * Fp::raw(pi.c ? a.zh_inv[1] : a.zh_inv[0]);
+      uint32_t* dst = a.quot + (size_t)b * 8 * h + pi.m;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dst[(size_t)(4 * pi.c + j) * h] = q.c[j].v;
+    } else {
+      m_store_fp4(part, acc);
+    }
+  }
 }
 
 // keccak chip: p3-keccak-air's 12 evaluation tasks (air_keccak.hpp) plus one task for the call-time
@@ -1186,7 +1223,12 @@ void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a) {
   const dim3 grid((unsigned)((n + kMT - 1) / kMT), a.batch), block(kMT);
   switch (a.chip) {
     case kCpu:
-    case kCpu2: hipLaunchKernelGGL(machine_quotient_kernel<kCpu>, grid, block, 0, stream, a); break;
+    case kCpu2:
+      hipLaunchKernelGGL(cpu_quotient_task_kernel<0>, grid, block, 0, stream, a);
+      hipLaunchKernelGGL(cpu_quotient_task_kernel<1>, grid, block, 0, stream, a);
+      hipLaunchKernelGGL(cpu_quotient_task_kernel<2>, grid, block, 0, stream, a);
+      hipLaunchKernelGGL(cpu_quotient_task_kernel<3>, grid, block, 0, stream, a);
+      break;
     case kAlu:
     case kAlu2: hipLaunchKernelGGL(machine_quotient_kernel<kAlu>, grid, block, 0, stream, a); break;
     case kSub:

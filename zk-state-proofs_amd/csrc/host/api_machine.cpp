@@ -194,6 +194,36 @@ int zksp_hip_machine_fetch_roots(zksp_client* c, uint32_t* out, size_t cap_words
   return ZKSP_OK;
 }
 
+int zksp_hip_machine_fetch_stage(zksp_client* c, int chip, int stage, size_t proof_index, uint32_t* out, size_t cap_words) {
+  if (!c || !out || chip < 0 || chip >= mach::kNumChips || stage < 0 || stage > 2) return ZKSP_ERR_INVALID_ARG;
+  Context* ctx = &c->ctx;
+  MachineWorkspace* w = ctx->mws.get();
+  if (!w || w->n == 0 || proof_index >= (size_t)w->n) return ctx->fail(ZKSP_ERR_INVALID_ARG, "machine_fetch_stage: no such resident proof");
+  const size_t words = (size_t)w->mat[chip][stage].w << w->logh[chip];
+  if (cap_words < words) return ctx->fail(ZKSP_ERR_INVALID_ARG, "machine_fetch_stage: buffer too small");
+  ZKSP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(out, w->mat[chip][stage].tr + proof_index * words, words * 4, hipMemcpyDeviceToHost, ctx->stream));
+  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < words; ++i) out[i] = Fp::raw(out[i]).to_canonical();
+  return ZKSP_OK;
+}
+
+int zksp_hip_machine_fetch_challenges(zksp_client* c, size_t proof_index, uint32_t* out) {
+  if (!c || !out) return ZKSP_ERR_INVALID_ARG;
+  Context* ctx = &c->ctx;
+  MachineWorkspace* w = ctx->mws.get();
+  if (!w || w->n == 0 || proof_index >= (size_t)w->n) return ctx->fail(ZKSP_ERR_INVALID_ARG, "machine_fetch_challenges: no such resident proof");
+  ZKSP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  // alpha's buffer is reused for the last transcript squeeze: the powers table still starts with 1, alpha
+  ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(out, w->bus_ch + proof_index * 8, 32, hipMemcpyDeviceToHost, ctx->stream));
+  ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(out + 8, w->alpha_pows + proof_index * w->alpha_stride + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
+  ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(out + 12, w->zeta + proof_index * 4, 16, hipMemcpyDeviceToHost, ctx->stream));
+  ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(out + 16, w->cum + proof_index * 4 * mach::kNumChips, 16 * mach::kNumChips, hipMemcpyDeviceToHost, ctx->stream));
+  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 16 + 4 * mach::kNumChips; ++i) out[i] = Fp::raw(out[i]).to_canonical();
+  return ZKSP_OK;
+}
+
 int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const int32_t* log_heights, const uint32_t* body,
                                  size_t body_words, zksp_proof** out) {
   if (!pk || !t || !body || !out) return ZKSP_ERR_INVALID_ARG;

@@ -592,7 +592,7 @@ int machine_prove_resident(Context* ctx) {
       qa.pubs = is_cpu_chip(c) ? w->pub_words + 17 + (c == kCpu2 ? kNumCpuPub : 0) : nullptr;
       qa.pubs_bstride = kPubWords;
       qa.quot = w->mat[c][2].tr;
-      qa.partial = w->kpartial;
+      qa.partial = is_cpu_chip(c) ? w->reduce_scratch : w->kpartial;  // CPU: 8 H words per proof of the scratch's >= 16 H
       qa.logh = logh[c];
       qa.batch = B;
       launch_machine_quotient(s, qa);
