@@ -136,11 +136,12 @@ typedef struct zksp_mtrace zksp_mtrace;
 #define ZKSP_MT_MEMFINAL 2      /* 5 u32 per image address and per other touched address: addr, init, fin, fin_ts, is_init */
 #define ZKSP_MT_MULS 3          /* 3 u32 per mul/mulhu: hi, b, c */
 #define ZKSP_MT_PROG_MULT 4     /* u32 per Program-table row */
-#define ZKSP_MT_ALU_IDX 5       /* u32 per ALU-chip row: index of the cycle (xor .. sltu, blt .. bgeu) */
+#define ZKSP_MT_ALU_IDX 5       /* u32 per ALU-chip row: index of the cycle (sll srl sra slt, blt bge) */
 #define ZKSP_MT_PROGRAM 6       /* 9 u32 per row: pc, op, wr, use2, rd, rs1, rs2, imm, tgt; the last row is the padding instruction */
 #define ZKSP_MT_IMAGE 7         /* 2 u32 per row: addr, value */
 #define ZKSP_MT_PUBLIC_VALUES 8 /* bytes */
 #define ZKSP_MT_SUB_IDX 9       /* u32 per sub-word-chip row: index of the cycle (lb lh lbu lhu sb sh) */
+#define ZKSP_MT_BW_IDX 10       /* u32 per bitwise-chip row: index of the cycle (xor or and) */
 typedef struct {
   uint64_t cycles;
   uint64_t memory_ops;
@@ -160,7 +161,7 @@ int zksp_mtrace_info(const zksp_mtrace* t, zksp_mtrace_info_t* info);
 /* Device-resident machine proving (bench.py, parity tests): upload the records of n traced runs (they are proven
  * with one shape: zksp_machine_cover_heights), enqueue one proving pass, fetch the proof bodies ([n][body_words]
  * canonical u32; body_words = zksp_machine_body_words of that shape). */
-#define ZKSP_MACHINE_CHIPS 13   /* cpu, keccak, keccak-mem, mem-final, image, program, mul, table, cpu2, alu, alu2, subword, subword2 */
+#define ZKSP_MACHINE_CHIPS 15   /* cpu, keccak, keccak-mem, mem-final, image, program, mul, table, cpu2, alu, alu2, subword, subword2, bitwise, bitwise2 */
 int zksp_mtrace_heights(const zksp_mtrace* t, int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 size_t zksp_machine_body_words(const zksp_client* c, const int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 /* The shape a batch of these runs is proven with: the chip heights that cover the largest cycle / event / address

@@ -62,11 +62,13 @@ uint32_t orc_code_of(uint32_t op) {
     default: return 0;
   }
 }
-/* does a cycle of this op occupy a row of the ALU chip (0) / the sub-word chip (1)? */
+int orc_ucmp_of(uint32_t op) { return op == OP_SLTU || op == OP_BLTU || op == OP_BGEU; }
+/* does a cycle of this op occupy a row of the ALU chip (0) / the sub-word chip (1) / the bitwise chip (2)? */
 static int event_kind(uint32_t op) {
   const uint32_t code = orc_code_of(op);
-  if (code >= OP_XOR && code <= OP_SLTU) return 0;
+  if (code >= OP_SLL && code <= OP_SLT) return 0;
   if (code == OP_LB || code == OP_LH || code == OP_LBU || code == OP_LHU || code == OP_SB || code == OP_SH) return 1;
+  if (code >= OP_XOR && code <= OP_AND) return 2;
   return -1;
 }
 
@@ -99,8 +101,8 @@ static orc_lf lf_bits(int bits, int n) {
 #define SELC(cls) (C_SEL + (cls) - 1)
 
 #define CPU_INTER 22
-static orc_inter g_cpu[CPU_INTER], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[4],
-    g_alu[1], g_sub[1];
+static orc_inter g_cpu[CPU_INTER], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7],
+    g_alu[1], g_sub[1], g_bw[5];
 static orc_chip g_chips[N_CHIPS];
 static int g_ready = 0;
 
@@ -138,13 +140,13 @@ static void build(void) {
   {
     orc_inter* it = &g_cpu[0];
     memset(it, 0, sizeof *it);
-    it->bus = BUS_PROG; it->sign = -1; it->mult = one; it->n_el = 12;
+    it->bus = BUS_PROG; it->sign = -1; it->mult = one; it->n_el = 13;
     it->el[0] = lf_col(C_PC);
     lf_zero(&it->el[1]);
     for (int k = 1; k <= N_CLS; ++k) lf_add(&it->el[1], SELC(k), (uint32_t)k);
-    it->el[2] = lf_col(C_CODE); it->el[3] = lf_col(C_WR); it->el[4] = lf_col(C_USE2); it->el[5] = lf_col(C_RD);
-    it->el[6] = lf_col(C_RS1); it->el[7] = lf_col(C_RS2); it->el[8] = lf_col(C_IMM_LO); it->el[9] = lf_col(C_IMM_HI);
-    it->el[10] = lf_col(C_TGT_LO); it->el[11] = lf_col(C_TGT_HI);
+    it->el[2] = lf_col(C_CODE); it->el[3] = lf_col(C_UC); it->el[4] = lf_col(C_WR); it->el[5] = lf_col(C_USE2); it->el[6] = lf_col(C_RD);
+    it->el[7] = lf_col(C_RS1); it->el[8] = lf_col(C_RS2); it->el[9] = lf_col(C_IMM_LO); it->el[10] = lf_col(C_IMM_HI);
+    it->el[11] = lf_col(C_TGT_LO); it->el[12] = lf_col(C_TGT_HI);
   }
   /* previous access time of slot q (accessed at ts + q): ts + q - 1 - (gap_lo + 2^16 gap_hi) */
   orc_lf pts[4];
@@ -173,11 +175,12 @@ static void build(void) {
   {
     /* the adder output is canonical, an address is word-aligned once its byte offset is taken off, and addresses,
      * jump targets and the keccak call's return address stay below 0x78000000 (their high limb is looked up as kind 2) */
+    /* ... and so is the difference of an unsigned comparison (UC) */
     const int chk_c[10] = {SELC(CL_ADD), SELC(CL_SUB), SELC(CL_JALR), SELC(CL_LW), SELC(CL_SW), SELC(CL_LDS), SELC(CL_STS),
-                           SELC(CL_ECALL), SELC(CL_KECCAK), 0};
+                           SELC(CL_ECALL), SELC(CL_KECCAK), C_UC};
     const int al_c[5] = {SELC(CL_JALR), SELC(CL_LW), SELC(CL_SW), SELC(CL_LDS), SELC(CL_STS)};
     const int top_c[6] = {SELC(CL_JALR), SELC(CL_LW), SELC(CL_SW), SELC(CL_LDS), SELC(CL_STS), SELC(CL_KECCAK)};
-    const orc_lf chk = lf_sum(chk_c, 9);
+    const orc_lf chk = lf_sum(chk_c, 10);
     orc_lf xoff = lf_col(C_X);
     lf_add(&xoff, C_O1, FP - 1); lf_add(&xoff, C_O2, FP - 2); lf_add(&xoff, C_O3, FP - 3);
     orc_lf top = lf_sum(top_c, 6);
@@ -188,8 +191,9 @@ static void build(void) {
   {
     orc_inter* it = &g_cpu[17];
     memset(it, 0, sizeof *it);
+    /* every ALU-class instruction and every ordered branch, except the unsigned comparisons the row does itself */
     const int alu_c[3] = {SELC(CL_ALU), SELC(CL_BLT), SELC(CL_BGE)};
-    it->bus = BUS_ALU; it->sign = +1; it->mult = lf_sum(alu_c, 3); it->n_el = 7;
+    it->bus = BUS_ALU; it->sign = +1; it->mult = lf_sum(alu_c, 3); lf_add(&it->mult, C_UC, FP - 1); it->n_el = 7;
     it->el[0] = lf_col(C_CODE);
     it->el[1] = a_lo; it->el[2] = a_hi; it->el[3] = b_lo; it->el[4] = b_hi; it->el[5] = c_lo; it->el[6] = c_hi;
     it = &g_cpu[18];
@@ -271,13 +275,23 @@ static void build(void) {
     it->el[0] = lf_col(IMG_P_ADDR); it->el[1] = lf_col(IMG_P_LO); it->el[2] = lf_col(IMG_P_HI);
     it = &g_program[0];
     memset(it, 0, sizeof *it);
-    it->bus = BUS_PROG; it->sign = +1; it->mult = lf_col(PROGRAM_PREP_WIDTH + 0); it->n_el = 12;
-    for (int j = 0; j < 12; ++j) it->el[j] = lf_col(j);
+    it->bus = BUS_PROG; it->sign = +1; it->mult = lf_col(PROGRAM_PREP_WIDTH + 0); it->n_el = 13;
+    for (int j = 0; j < 13; ++j) it->el[j] = lf_col(j);
     const orc_lf idx = lf_pair(TB_P_X, TB_P_Y, 256);
     g_table[0] = range_inter(+1, lf_col(TABLE_PREP_WIDTH + TB_M_R16), zero, idx);
     g_table[1] = range_inter(+1, lf_col(TABLE_PREP_WIDTH + TB_M_AL), one, idx);
     g_table[2] = range_inter(+1, lf_col(TABLE_PREP_WIDTH + TB_M_TOP), lf_const(2), idx);
     g_table[3] = bytes_inter(+1, lf_col(TABLE_PREP_WIDTH + TB_M_BY), lf_col(TB_P_X), lf_col(TB_P_Y));
+    /* byte operations (kind, x, y, z): 1 xor, 2 or (= x + y - and), 3 and */
+    for (int k = 0; k < 3; ++k) {
+      it = &g_table[4 + k];
+      memset(it, 0, sizeof *it);
+      it->bus = BUS_BYTEOP; it->sign = +1; it->mult = lf_col(TABLE_PREP_WIDTH + TB_M_XOR + k); it->n_el = 4;
+      it->el[0] = lf_const((uint32_t)k + 1); it->el[1] = lf_col(TB_P_X); it->el[2] = lf_col(TB_P_Y);
+      if (k == 0) it->el[3] = lf_col(TB_P_XOR);
+      else if (k == 2) it->el[3] = lf_col(TB_P_AND);
+      else { it->el[3] = lf_pair(TB_P_X, TB_P_Y, 1); lf_add(&it->el[3], TB_P_AND, FP - 1); }
+    }
   }
   /* ---- multiplier ---- */
   for (int hi = 0; hi < 2; ++hi) {
@@ -296,9 +310,30 @@ static void build(void) {
     memset(it, 0, sizeof *it);
     it->bus = BUS_ALU; it->sign = -1; it->mult = lf_col(AL_IS_REAL); it->n_el = 7;
     lf_zero(&it->el[0]);
-    for (int k = 0; k < 8; ++k) lf_add(&it->el[0], AL_SEL + k, (uint32_t)(OP_XOR + k));
+    for (int k = 0; k < 4; ++k) lf_add(&it->el[0], AL_SEL + k, (uint32_t)(OP_SLL + k));
     it->el[1] = lf_col(AL_A); it->el[2] = lf_col(AL_A + 1);
     it->el[3] = lf_bits(AL_B, 16); it->el[4] = lf_bits(AL_B + 16, 16); it->el[5] = lf_bits(AL_C, 16); it->el[6] = lf_bits(AL_C + 16, 16);
+  }
+  /* ---- bitwise: the word tuple from the CPU row, and one byte-operation lookup per byte ---- */
+  {
+    orc_inter* it = &g_bw[0];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_ALU; it->sign = -1; it->mult = lf_col(BW_IS_REAL); it->n_el = 7;
+    lf_zero(&it->el[0]);
+    for (int k = 0; k < 3; ++k) lf_add(&it->el[0], BW_SEL + k, (uint32_t)(OP_XOR + k));
+    for (int w = 0; w < 3; ++w) { /* a, b, c as limbs of two bytes */
+      const int base = w == 0 ? BW_A : w == 1 ? BW_B : BW_C;
+      it->el[1 + 2 * w] = lf_pair(base, base + 1, 256);
+      it->el[2 + 2 * w] = lf_pair(base + 2, base + 3, 256);
+    }
+    for (int i = 0; i < 4; ++i) {
+      it = &g_bw[1 + i];
+      memset(it, 0, sizeof *it);
+      it->bus = BUS_BYTEOP; it->sign = -1; it->mult = lf_col(BW_IS_REAL); it->n_el = 4;
+      lf_zero(&it->el[0]);
+      for (int k = 0; k < 3; ++k) lf_add(&it->el[0], BW_SEL + k, (uint32_t)k + 1);
+      it->el[1] = lf_col(BW_B + i); it->el[2] = lf_col(BW_C + i); it->el[3] = lf_col(BW_A + i);
+    }
   }
   /* ---- sub-word ---- */
   {
@@ -313,7 +348,7 @@ static void build(void) {
     it->el[4] = lf_bits(SW_M, 16); it->el[5] = lf_bits(SW_M + 16, 16); it->el[6] = lf_bits(SW_C, 16);
     it->el[7] = lf_col(SW_MV); it->el[8] = lf_col(SW_MV + 1);
   }
-  g_chips[CH_TABLE] = (orc_chip){"table", TABLE_PREP_WIDTH, TABLE_WIDTH, 4, g_table, 0};
+  g_chips[CH_TABLE] = (orc_chip){"table", TABLE_PREP_WIDTH, TABLE_WIDTH, 7, g_table, 0};
   g_chips[CH_CPU] = (orc_chip){"cpu", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0};
   g_chips[CH_CPU2] = (orc_chip){"cpu2", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0};
   g_chips[CH_KECCAK] = (orc_chip){"keccak", 0, KECCAK_WIDTH, 50, g_keccak, 0};
@@ -326,6 +361,8 @@ static void build(void) {
   g_chips[CH_ALU2] = (orc_chip){"alu2", 0, ALU_WIDTH, 1, g_alu, 0};
   g_chips[CH_SUB] = (orc_chip){"subword", 0, SUB_WIDTH, 1, g_sub, 0};
   g_chips[CH_SUB2] = (orc_chip){"subword2", 0, SUB_WIDTH, 1, g_sub, 0};
+  g_chips[CH_BW] = (orc_chip){"bitwise", 0, BW_WIDTH, 5, g_bw, 0};
+  g_chips[CH_BW2] = (orc_chip){"bitwise2", 0, BW_WIDTH, 5, g_bw, 0};
   g_ready = 1;
   for (int c = 0; c < N_CHIPS; ++c) g_chips[c].n_constraints = count_constraints(c);
 }
@@ -402,7 +439,9 @@ void orc_machine_cpu_pub(const orc_machine_input* in, int chip, uint32_t pub[CPU
 
 void orc_machine_heights(const orc_machine_input* in, int logh[N_CHIPS]) {
   if (in->shape) { memcpy(logh, in->shape, N_CHIPS * sizeof(int)); return; }
-  const size_t na = orc_machine_events(in, 0, NULL), ns = orc_machine_events(in, 1, NULL);
+  const size_t na = orc_machine_events(in, 0, NULL), ns = orc_machine_events(in, 1, NULL), nb = orc_machine_events(in, 2, NULL);
+  logh[CH_BW] = clog2(split_rows(nb));
+  logh[CH_BW2] = second_logh(nb);
   logh[CH_CPU] = clog2(split_rows(in->n_cycles));
   logh[CH_CPU2] = second_logh(in->n_cycles);
   logh[CH_ALU] = clog2(split_rows(na));
@@ -460,7 +499,8 @@ static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
       const uint32_t code = orc_code_of(op);
       T(C_PC) = pc;
       T(SELC(cls)) = 1;
-      T(C_CODE) = code; T(C_WR) = wr; T(C_USE2) = use2; T(C_RD) = rd; T(C_RS1) = rs1; T(C_RS2) = rs2;
+      const int uc = orc_ucmp_of(op);
+      T(C_CODE) = code; T(C_UC) = (uint32_t)uc; T(C_WR) = wr; T(C_USE2) = use2; T(C_RD) = rd; T(C_RS1) = rs1; T(C_RS2) = rs2;
       put_limbs(t, h, r, C_IMM_LO, imm); put_limbs(t, h, r, C_TGT_LO, tgt);
       uint32_t x = 0, next = pc + 4, k0 = 0, k1 = 0, maddr = 0;
       int off = -1;
@@ -490,6 +530,7 @@ static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
           a = less_than(code, b, c);
           if ((cls == CL_BLT) == (a != 0)) next = tgt;
           break;
+        case CL_ALU: break; /* (sltu: below) */
         case CL_ECALL: {
           static const uint32_t codes[6] = {0x00, 0x02, 0x10, 0x1a, 0xf0, 0xf1};
           for (int k = 0; k < 6; ++k) if (b == codes[k]) T(C_SC + k) = 1;
@@ -499,6 +540,11 @@ static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
         }
         case CL_KECCAK: x = b; next = b; break;
         default: break;
+      }
+      if (uc) { /* the row's own unsigned comparison: X = B - C + 2^32 [B < C], limb by limb with borrows K0, K1 */
+        k0 = blo < clo;
+        k1 = b < c;
+        x = b - c;
       }
       if (cls != CL_BEQ && cls != CL_BNE) put_limbs(t, h, r, C_X, x);
       put_limbs(t, h, r, C_A, a); put_limbs(t, h, r, C_B, b); put_limbs(t, h, r, C_C, c);
@@ -539,24 +585,41 @@ static void fill_alu(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
     const uint32_t code = orc_code_of(prog_row(in, cy[0])[1]), b = cy[2], c = cy[3];
     uint32_t a = cy[1], x = 0, k0 = 0, k1 = 0;
     if (code == OP_SLL || code == OP_SRL || code == OP_SRA) x = 1u << (c & 31);
-    if (code == OP_SLT || code == OP_SLTU) {
+    if (code == OP_SLT) {
       /* X = B - C + 2^32 * [less than], the sign bits swapped for the signed order */
       const uint32_t blo = b & 0xffff, bhi = b >> 16, clo = c & 0xffff, chi = c >> 16;
-      const int sgn = code == OP_SLT;
       k0 = blo < clo;
       k1 = less_than(code, b, c);
       const uint32_t dlo = blo - clo + 65536 * k0;
-      const int64_t dhi = (int64_t)bhi - chi - k0 + 65536 * (int64_t)k1 + (sgn ? 65536 * ((int64_t)(c >> 31) - (int64_t)(b >> 31)) : 0);
+      const int64_t dhi = (int64_t)bhi - chi - k0 + 65536 * (int64_t)k1 + 65536 * ((int64_t)(c >> 31) - (int64_t)(b >> 31));
       x = dlo | ((uint32_t)dhi << 16);
       a = k1; /* branches: the record's a is 0, the flag is what the CPU row sends */
     }
     T(AL_IS_REAL) = 1;
-    T(AL_SEL + (code - OP_XOR)) = 1;
+    T(AL_SEL + (code - OP_SLL)) = 1;
     put_limbs(t, h, r, AL_A, a);
     put_bits(t, h, r, AL_B, b, 32); put_bits(t, h, r, AL_C, c, 32); put_bits(t, h, r, AL_X, x, 32);
     T(AL_K0) = k0; T(AL_K1) = k1;
     const char* wa = getenv("ZKSP_ORACLE_WRONG_ALU");
     if (wa && row0 + r == (size_t)strtoull(wa, NULL, 10)) T(AL_A) = (a & 0xffff) ^ 1u; /* soundness tests: a wrong result */
+#undef T
+  }
+  free(ev);
+}
+/* rows [0, h) of a bitwise instance whose first row is event `row0` */
+static void fill_bw(const orc_machine_input* in, size_t h, uint32_t* t, size_t row0) {
+  const size_t n = orc_machine_events(in, 2, NULL);
+  uint32_t* ev = (uint32_t*)malloc((n ? n : 1) * 4);
+  orc_machine_events(in, 2, ev);
+  for (size_t r = 0; r < h && row0 + r < n; ++r) {
+#define T(col) t[(size_t)(col) * h + r]
+    const uint32_t* cy = in->cycles + 12 * (size_t)ev[row0 + r];
+    const uint32_t code = orc_code_of(prog_row(in, cy[0])[1]), a = cy[1], b = cy[2], c = cy[3];
+    T(BW_IS_REAL) = 1;
+    T(BW_SEL + (code - OP_XOR)) = 1;
+    for (int i = 0; i < 4; ++i) { T(BW_A + i) = (a >> (8 * i)) & 0xff; T(BW_B + i) = (b >> (8 * i)) & 0xff; T(BW_C + i) = (c >> (8 * i)) & 0xff; }
+    const char* wa = getenv("ZKSP_ORACLE_WRONG_BW");
+    if (wa && row0 + r == (size_t)strtoull(wa, NULL, 10)) T(BW_A) = ((a & 0xff) ^ 1u); /* soundness tests: a wrong result byte */
 #undef T
   }
   free(ev);
@@ -593,8 +656,8 @@ static void fill_table_mults(const orc_machine_input* in, uint32_t* t) {
   const size_t ht = (size_t)1 << TABLE_LOG_H;
   int logh[N_CHIPS];
   orc_machine_heights(in, logh);
-  static const int users[4] = {CH_CPU, CH_CPU2, CH_KMEM, CH_MEMFINAL};
-  for (int u = 0; u < 4; ++u) {
+  static const int users[6] = {CH_CPU, CH_CPU2, CH_KMEM, CH_MEMFINAL, CH_BW, CH_BW2};
+  for (int u = 0; u < 6; ++u) {
     const int chip = users[u];
     const orc_chip* ch = &g_chips[chip];
     const size_t h = (size_t)1 << logh[chip];
@@ -605,10 +668,10 @@ static void fill_table_mults(const orc_machine_input* in, uint32_t* t) {
       for (int c = 0; c < ch->main_width; ++c) row[c] = tr[(size_t)c * h + r];
       for (int k = 0; k < ch->n_inter; ++k) {
         const orc_inter* it = &ch->inter[k];
-        if (it->sign > 0 || (it->bus != BUS_RANGE && it->bus != BUS_BYTES)) continue;
-        uint32_t v[3];
-        const orc_lf* f[3] = {&it->mult, &it->el[0], &it->el[1]};
-        for (int j = 0; j < 3; ++j) {
+        if (it->sign > 0 || (it->bus != BUS_RANGE && it->bus != BUS_BYTES && it->bus != BUS_BYTEOP)) continue;
+        uint32_t v[5] = {0, 0, 0, 0, 0};
+        const orc_lf* f[5] = {&it->mult, &it->el[0], &it->el[1], &it->el[2], &it->el[3]};
+        for (int j = 0; j < 1 + it->n_el; ++j) {
           v[j] = f[j]->c0;
           for (int i = 0; i < f[j]->n; ++i) v[j] = f_add(v[j], f_mul(f[j]->coef[i], row[f[j]->col[i]]));
         }
@@ -617,9 +680,15 @@ static void fill_table_mults(const orc_machine_input* in, uint32_t* t) {
           if (v[2] >= ht || v[1] > 2 || (v[1] == 1 && (v[2] & 3)) || (v[1] == 2 && v[2] > ADDR_HI_MAX)) continue; /* no table row: the buses will not balance */
           uint32_t* dst = &t[(size_t)(v[1] == 0 ? TB_M_R16 : v[1] == 1 ? TB_M_AL : TB_M_TOP) * ht + v[2]];
           *dst = f_add(*dst, v[0]);
-        } else {
+        } else if (it->bus == BUS_BYTES) {
           if (v[1] > 255 || v[2] > 255) continue;
           uint32_t* dst = &t[(size_t)TB_M_BY * ht + v[1] + 256 * v[2]];
+          *dst = f_add(*dst, v[0]);
+        } else { /* (kind, x, y, z): counted only if z is the table's answer */
+          if (v[1] < 1 || v[1] > 3 || v[2] > 255 || v[3] > 255) continue;
+          const uint32_t z = v[1] == 1 ? (v[2] ^ v[3]) : v[1] == 2 ? (v[2] | v[3]) : (v[2] & v[3]);
+          if (v[4] != z) continue;
+          uint32_t* dst = &t[(size_t)(TB_M_XOR + v[1] - 1) * ht + v[2] + 256 * v[3]];
           *dst = f_add(*dst, v[0]);
         }
       }
@@ -643,6 +712,8 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
     case CH_ALU2: fill_alu(in, h, t, first_rows(in, CH_ALU, orc_machine_events(in, 0, NULL))); break;
     case CH_SUB: fill_sub(in, h, t, 0); break;
     case CH_SUB2: fill_sub(in, h, t, first_rows(in, CH_SUB, orc_machine_events(in, 1, NULL))); break;
+    case CH_BW: fill_bw(in, h, t, 0); break;
+    case CH_BW2: fill_bw(in, h, t, first_rows(in, CH_BW, orc_machine_events(in, 2, NULL))); break;
     case CH_KECCAK: {
       uint64_t* st = (uint64_t*)calloc(25 * (in->n_keccak ? in->n_keccak : 1), 8);
       for (size_t p = 0; p < in->n_keccak; ++p) memcpy(st + 25 * p, ((const kcall_t*)(in->keccak + 408 * p))->in, 200);
@@ -714,6 +785,7 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
         const uint32_t* p = in->program + 9 * r;
         uint32_t* q = prep + r;
         q[(size_t)PR_PC * h] = p[0]; q[(size_t)PR_CLS * h] = (uint32_t)orc_class_of(p[1]); q[(size_t)PR_CODE * h] = orc_code_of(p[1]);
+        q[(size_t)PR_UC * h] = (uint32_t)orc_ucmp_of(p[1]);
         q[(size_t)PR_WR * h] = p[2]; q[(size_t)PR_USE2 * h] = p[3];
         q[(size_t)PR_RD * h] = p[4]; q[(size_t)PR_RS1 * h] = p[5]; q[(size_t)PR_RS2 * h] = p[6];
         q[(size_t)PR_IMM_LO * h] = p[7] & 0xffff; q[(size_t)PR_IMM_HI * h] = p[7] >> 16;
@@ -744,6 +816,8 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
         prep[(size_t)TB_P_Y * h + r] = (uint32_t)(r >> 8);
         prep[(size_t)TB_P_NA * h + r] = (r & 3) != 0;
         prep[(size_t)TB_P_NT * h + r] = r > ADDR_HI_MAX;
+        prep[(size_t)TB_P_XOR * h + r] = (uint32_t)((r & 255) ^ (r >> 8));
+        prep[(size_t)TB_P_AND * h + r] = (uint32_t)((r & 255) & (r >> 8));
       }
       if (in->n_cycles) fill_table_mults(in, t); /* setup passes no cycles: only the preprocessed columns are wanted */
       break;
@@ -826,13 +900,20 @@ static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, f
     emit(s, f_mul(cpa, f_sub(a_hi, x_hi)));
     emit(s, f_mul(S(CL_KECCAK), f_sub(x_lo, b_lo)));
     emit(s, f_mul(S(CL_KECCAK), f_sub(x_hi, b_hi)));
+    /* unsigned comparison in the row (sltu, bltu, bgeu): X = B - C + 2^32 K1 limb by limb, so K1 = [B < C] because both
+     * limbs of X are looked up in the range table; the flag goes where the ALU chip's answer would */
+    const fe uc = l[C_UC];
+    emit(s, f_mul(uc, f_sub(f_add(f_sub(b_lo, c_lo), f_mul(F65536, k0)), x_lo)));
+    emit(s, f_mul(uc, f_sub(f_add(f_sub(f_sub(b_hi, c_hi), k0), f_mul(F65536, k1)), x_hi)));
+    emit(s, f_mul(uc, f_sub(a_lo, k1)));
+    emit(s, f_mul(uc, a_hi));
   }
   /* ---- byte offset and the word address ---- */
   const fe o1 = l[C_O1], o2 = l[C_O2], o3 = l[C_O3], osum = f_add(o1, f_add(o2, o3));
   const fe off = f_add(o1, f_add(f_add(o2, o2), f_mul(3, o3)));
   const fe xaddr = f_sub(f_add(x_lo, f_mul(F65536, x_hi)), off);
   {
-    const fe noff = f_add(f_add(f_add(S(CL_ADD), S(CL_SUB)), f_add(S(CL_ECALL), S(CL_KECCAK))), f_add(S(CL_LW), S(CL_SW)));
+    const fe noff = f_add(f_add(f_add(f_add(S(CL_ADD), S(CL_SUB)), f_add(S(CL_ECALL), S(CL_KECCAK))), f_add(S(CL_LW), S(CL_SW))), l[C_UC]);
     const fe memw = f_add(f_add(S(CL_LW), S(CL_SW)), f_add(S(CL_LDS), S(CL_STS)));
     emit(s, f_mul(noff, osum));
     emit(s, bool_c(osum)); /* at most one of the three offset flags */
@@ -945,26 +1026,15 @@ static void mul_constraints(const uint32_t* l, sink* s) {
 /* ALU chip: operands as bits; X is the one-hot shift amount or the comparison difference */
 static void alu_constraints(const uint32_t* l, sink* s) {
   const fe one = 1;
-#define OPF(op) l[AL_SEL + (op) - OP_XOR]
+#define OPF(op) l[AL_SEL + (op) - OP_SLL]
   emit(s, bool_c(l[AL_IS_REAL]));
   fe selsum = 0;
-  for (int k = 0; k < 8; ++k) { emit(s, bool_c(l[AL_SEL + k])); selsum = f_add(selsum, l[AL_SEL + k]); }
+  for (int k = 0; k < 4; ++k) { emit(s, bool_c(l[AL_SEL + k])); selsum = f_add(selsum, l[AL_SEL + k]); }
   for (int i = 0; i < 96; ++i) emit(s, bool_c(l[AL_B + i])); /* B, C, X */
   emit(s, bool_c(l[AL_K0])); emit(s, bool_c(l[AL_K1]));
   emit(s, f_sub(selsum, l[AL_IS_REAL]));
   const fe a_lo = l[AL_A], a_hi = l[AL_A + 1], b_lo = limb_of(l, AL_B, 0), b_hi = limb_of(l, AL_B, 1);
   const fe c_lo = limb_of(l, AL_C, 0), c_hi = limb_of(l, AL_C, 1), x_lo = limb_of(l, AL_X, 0), x_hi = limb_of(l, AL_X, 1);
-  /* ---- bitwise ---- */
-  for (int op = OP_XOR; op <= OP_AND; ++op)
-    for (int h = 0; h < 2; ++h) {
-      fe acc = 0;
-      for (int i = 15; i >= 0; --i) {
-        const fe b = l[AL_B + 16 * h + i], c = l[AL_C + 16 * h + i], bc = f_mul(b, c);
-        fe bit = op == OP_AND ? bc : op == OP_OR ? f_sub(f_add(b, c), bc) : f_sub(f_add(b, c), f_add(bc, bc));
-        acc = f_add(f_add(acc, acc), bit);
-      }
-      emit(s, f_mul(OPF(op), f_sub(h ? a_hi : a_lo, acc)));
-    }
   /* ---- shifts: X is the one-hot of the amount ---- */
   {
     const fe sh = f_add(f_add(OPF(OP_SLL), OPF(OP_SRL)), OPF(OP_SRA));
@@ -993,16 +1063,24 @@ static void alu_constraints(const uint32_t* l, sink* s) {
       }
     }
   }
-  /* ---- less-than: X = B - C (mod 2^32, the sign bits swapped for the signed order), K1 = "less than" ---- */
+  /* ---- signed less-than: X = B - C (mod 2^32) with the sign bits swapped, K1 = "less than" ---- */
   {
-    const fe cmp = f_add(OPF(OP_SLT), OPF(OP_SLTU));
+    const fe cmp = OPF(OP_SLT);
     emit(s, f_mul(cmp, f_sub(f_add(f_sub(b_lo, c_lo), f_mul(F65536, l[AL_K0])), x_lo)));
-    emit(s, f_add(f_mul(cmp, f_sub(f_add(f_sub(f_sub(b_hi, c_hi), l[AL_K0]), f_mul(F65536, l[AL_K1])), x_hi)),
-                  f_mul(F65536, f_mul(OPF(OP_SLT), f_sub(l[AL_C + 31], l[AL_B + 31])))));
+    emit(s, f_mul(cmp, f_add(f_sub(f_add(f_sub(f_sub(b_hi, c_hi), l[AL_K0]), f_mul(F65536, l[AL_K1])), x_hi),
+                             f_mul(F65536, f_sub(l[AL_C + 31], l[AL_B + 31])))));
     emit(s, f_mul(cmp, f_sub(a_lo, l[AL_K1])));
     emit(s, f_mul(cmp, a_hi));
   }
 #undef OPF
+}
+
+/* bitwise chip: one operation per real row; the byte lookups do the rest */
+static void bw_constraints(const uint32_t* l, sink* s) {
+  emit(s, bool_c(l[BW_IS_REAL]));
+  fe selsum = 0;
+  for (int k = 0; k < 3; ++k) { emit(s, bool_c(l[BW_SEL + k])); selsum = f_add(selsum, l[BW_SEL + k]); }
+  emit(s, f_sub(selsum, l[BW_IS_REAL]));
 }
 
 /* sub-word chip: M is the memory word, C the low limb of the stored register, both as bits */
@@ -1064,6 +1142,8 @@ static void run_constraints(int chip, const uint32_t* prep, const uint32_t* loc,
     case CH_IMAGE: emit(s, f_sub(loc[0], prep[IMG_P_REAL])); break; /* every image word is sent exactly once */
     case CH_PROGRAM: break;
     case CH_MUL: mul_constraints(loc, s); break;
+    case CH_BW:
+    case CH_BW2: bw_constraints(loc, s); break;
     case CH_TABLE: /* only multiples of 4 answer aligned lookups, only values up to ADDR_HI_MAX high-address-limb lookups */
       emit(s, f_mul(loc[TB_M_AL], prep[TB_P_NA]));
       emit(s, f_mul(loc[TB_M_TOP], prep[TB_P_NT]));

@@ -12,10 +12,10 @@
  * committed these public values.
  *
  * Format v6 (round 3).  The CPU row no longer carries its operands as bits: it holds 16-bit limbs,
- * adds / subtracts / compares for equality / moves words itself, and sends everything bitwise
- * (xor, or, and, shifts, signed and unsigned less-than) to an ALU chip and every sub-word load or
- * store to a sub-word chip, each with one row per such instruction (SP1's split of the CPU chip
- * from its event-sized ALU chips).  Range discipline: every tuple on the memory bus carries
+ * adds / subtracts / compares (equality, unsigned order) / moves words itself, and sends xor / or /
+ * and to a bitwise chip (bytes, looked up in a byte-operation table), shifts and signed less-than to
+ * an ALU chip (bits) and every sub-word load or store to a sub-word chip, each with one row per such
+ * instruction (SP1's split of the CPU chip from its event-sized ALU chips).  Range discipline: every tuple on the memory bus carries
  * canonical 16-bit limbs because every producer guarantees it (image: preprocessed; free
  * initial values, sums, differences and the hinted length: looked up in a 2^16-row table; ALU,
  * sub-word, multiplier and keccak results: bits), so readers need no decomposition.  Memory
@@ -39,7 +39,7 @@ extern "C" {
  * 391 400 cycles take 2^18 + 2^17 rows, not 2^19. */
 enum {
   CH_CPU = 0, CH_KECCAK, CH_KMEM, CH_MEMFINAL, CH_IMAGE, CH_PROGRAM, CH_MUL, CH_TABLE, CH_CPU2, CH_ALU, CH_ALU2, CH_SUB,
-  CH_SUB2, N_CHIPS
+  CH_SUB2, CH_BW, CH_BW2, N_CHIPS
 };
 
 /* ---- opcodes: Program table column CODE, and the op element of the ALU / sub-word bus tuples ---- */
@@ -56,19 +56,22 @@ enum {
 #define N_CLS 15
 int orc_class_of(uint32_t op);   /* CL_* of an OP_* */
 uint32_t orc_code_of(uint32_t op); /* the op a row of that instruction puts on the ALU / sub-word bus (0: none) */
+int orc_ucmp_of(uint32_t op);    /* sltu, bltu, bgeu: the unsigned comparison the CPU row does itself (Program column UC) */
 
 /* ---- CPU chip main columns ---- */
 enum {
   C_PC = 0, C_TS, C_NEXT_PC,
   C_SEL = 3,                   /* N_CLS class selectors: column C_SEL + (class - 1) */
-  C_CODE = C_SEL + N_CLS, C_WR, C_USE2, C_RD, C_RS1, C_RS2, C_IMM_LO, C_IMM_HI, C_TGT_LO, C_TGT_HI,
+  C_CODE = C_SEL + N_CLS, C_UC /* unsigned comparison done in this row */, C_WR, C_USE2, C_RD, C_RS1, C_RS2, C_IMM_LO, C_IMM_HI,
+  C_TGT_LO, C_TGT_HI,
   C_A,                         /* value written to rd (stores: unused; branches: the taken / less-than flag) */
   C_B = C_A + 2,               /* reg[rs1] */
   C_C = C_B + 2,               /* reg[rs2], or the immediate */
   C_M = C_C + 2,               /* memory slot: word read */
   C_MV = C_M + 2,              /* memory slot: word left behind */
-  C_X = C_MV + 2,              /* adder output: sum / difference / effective address; beq, bne: the limb differences' inverses */
-  C_K0 = C_X + 2, C_K1,        /* carries; beq, bne: "limb equal" flags */
+  C_X = C_MV + 2,              /* adder output: sum / difference / effective address; sltu, bltu, bgeu: B - C + 2^32 [B < C];
+                                  beq, bne: the limb differences' inverses */
+  C_K0 = C_X + 2, C_K1,        /* carries / borrows (K1 of an unsigned comparison: B < C); beq, bne: "limb equal" flags */
   C_O1, C_O2, C_O3,            /* byte offset of the effective address 1, 2, 3: at most one is set (offset 0: none) */
   C_MADDR,                     /* word address on the memory bus (ecall: 11, the register a1) */
   C_SC,                        /* 6 syscall flags: HALT, WRITE, COMMIT, DEFER, HINT_LEN, HINT_READ */
@@ -97,15 +100,17 @@ enum {
 enum { IMG_P_ADDR = 0, IMG_P_LO, IMG_P_HI, IMG_P_REAL, IMAGE_PREP_WIDTH };
 #define IMAGE_WIDTH 1
 /* ---- program chip: preprocessed instruction fields, main (multiplicity) ---- */
-enum { PR_PC = 0, PR_CLS, PR_CODE, PR_WR, PR_USE2, PR_RD, PR_RS1, PR_RS2, PR_IMM_LO, PR_IMM_HI, PR_TGT_LO, PR_TGT_HI, PROGRAM_PREP_WIDTH };
+enum { PR_PC = 0, PR_CLS, PR_CODE, PR_UC, PR_WR, PR_USE2, PR_RD, PR_RS1, PR_RS2, PR_IMM_LO, PR_IMM_HI, PR_TGT_LO, PR_TGT_HI, PROGRAM_PREP_WIDTH };
 #define PROGRAM_WIDTH 1
 /* ---- multiplier chip ---- */
 enum { MU_IS_REAL = 0, MU_HI, MU_B, MU_C = MU_B + 32, MU_P = MU_C + 32, MU_Q0 = MU_P + 64, MU_Q1 = MU_Q0 + 10, MU_Q2 = MU_Q1 + 11, MUL_WIDTH = MU_Q2 + 10 };
-/* ---- ALU chip: xor or and sll srl sra slt sltu over bits ---- */
+/* ---- ALU chip: sll srl sra and the signed slt (slt, blt, bge) over bits ---- */
 enum {
-  AL_IS_REAL = 0, AL_SEL /* 8 selectors, OP_XOR..OP_SLTU */, AL_A = AL_SEL + 8, AL_B = AL_A + 2, AL_C = AL_B + 32,
+  AL_IS_REAL = 0, AL_SEL /* 4 selectors, OP_SLL..OP_SLT */, AL_A = AL_SEL + 4, AL_B = AL_A + 2, AL_C = AL_B + 32,
   AL_X = AL_C + 32 /* one-hot shift amount / comparison difference */, AL_K0 = AL_X + 32, AL_K1, ALU_WIDTH
 };
+/* ---- bitwise chip: xor or and byte by byte, every (b, c, a) byte triple looked up in the table chip ---- */
+enum { BW_IS_REAL = 0, BW_SEL /* 3 selectors: XOR OR AND */, BW_A = BW_SEL + 3, BW_B = BW_A + 4, BW_C = BW_B + 4, BW_WIDTH = BW_C + 4 };
 /* ---- sub-word chip: lb lh lbu lhu sb sh ---- */
 enum {
   SW_IS_REAL = 0, SW_SEL /* 6 selectors: LB LH LBU LHU SB SH */, SW_O = SW_SEL + 6 /* 4: byte offset, one-hot */,
@@ -113,20 +118,20 @@ enum {
   SW_MV = SW_C + 16, SUB_WIDTH = SW_MV + 2
 };
 /* ---- table chip: 2^16 rows; preprocessed (x = low byte, y = high byte, na = row index not a multiple of 4,
- *      nt = row index above ADDR_HI_MAX); main: multiplicities of range16 (kind 0), 4-aligned range16 (kind 1),
- *      high address limb (kind 2: at most ADDR_HI_MAX), byte pair ---- */
-enum { TB_P_X = 0, TB_P_Y, TB_P_NA, TB_P_NT, TABLE_PREP_WIDTH };
-enum { TB_M_R16 = 0, TB_M_AL, TB_M_TOP, TB_M_BY, TABLE_WIDTH };
+ *      nt = row index above ADDR_HI_MAX, x ^ y, x & y); main: multiplicities of range16 (kind 0), 4-aligned range16
+ *      (kind 1), high address limb (kind 2: at most ADDR_HI_MAX), byte pair, and the byte operations xor / or / and ---- */
+enum { TB_P_X = 0, TB_P_Y, TB_P_NA, TB_P_NT, TB_P_XOR, TB_P_AND, TABLE_PREP_WIDTH };
+enum { TB_M_R16 = 0, TB_M_AL, TB_M_TOP, TB_M_BY, TB_M_XOR, TB_M_OR, TB_M_AND, TABLE_WIDTH };
 #define TABLE_LOG_H 16
 #define ADDR_HI_MAX 0x77FFu /* high limb of the largest address / jump target: values stay below 0x78000000 < p */
 
 /* ---- buses ---- */
-enum { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG };
+enum { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP };
 
 /* A linear form over the row [preprocessed | main]: c0 + sum coef[i] * row[col[i]] (canonical words). */
 #define LF_MAX 40
 typedef struct { int n; int col[LF_MAX]; uint32_t coef[LF_MAX]; uint32_t c0; } orc_lf;
-#define INTER_MAX_ELEMS 12
+#define INTER_MAX_ELEMS 13
 typedef struct { int bus; int sign; /* +1 send / produce, -1 receive / consume */ orc_lf mult; int n_el; orc_lf el[INTER_MAX_ELEMS]; } orc_inter;
 
 typedef struct {
@@ -157,7 +162,7 @@ typedef struct {
 
 /* The oracle's own event lists (cycle indices of the ALU-chip and sub-word-chip rows, in execution order) and the
  * last access time of x0 by a real cycle; the product's tracer emits the same lists and tests compare them. */
-size_t orc_machine_events(const orc_machine_input* in, int which /* 0 alu, 1 sub-word */, uint32_t* out /* may be NULL */);
+size_t orc_machine_events(const orc_machine_input* in, int which /* 0 alu, 1 sub-word, 2 bitwise */, uint32_t* out /* may be NULL */);
 uint32_t orc_machine_x0_last(const orc_machine_input* in);
 
 /* log2 trace height of every chip for this input (minimum 5) */

@@ -280,9 +280,9 @@ def prove(states_in: np.ndarray, logh: int, *, exit_code: int = 0, public_values
 # ---------------------------------------------------------------------------
 # machine proof (oracle/machine.h): inputs are the arrays ProverClient.machine_trace() returns
 # ---------------------------------------------------------------------------
-N_CHIPS = 13
+N_CHIPS = 15
 CHIP_NAMES = ["cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "table", "cpu2", "alu", "alu2",
-              "subword", "subword2"]
+              "subword", "subword2", "bitwise", "bitwise2"]
 CPUPUB_N = 5
 
 
@@ -367,7 +367,7 @@ def machine_cpu_pub(t: dict, chip: int):
 
 
 def machine_events(t: dict, which: int) -> np.ndarray:
-    """The oracle's own list of cycle indices that occupy ALU-chip (0) / sub-word-chip (1) rows."""
+    """The oracle's own list of cycle indices that occupy ALU-chip (0) / sub-word-chip (1) / bitwise-chip (2) rows."""
     mi, _keep = machine_input(t)
     n = int(lib().orc_machine_events(C.byref(mi), which, None))
     out = np.zeros(max(n, 1), np.uint32)

@@ -120,15 +120,16 @@ def test_dropped_keccak_call_is_rejected(zk, oracle, setup):
 
 def test_wrong_alu_result_is_rejected(zk, oracle, setup):
     """One addition yields a wrong sum (the CPU row's adder constraint is violated), one xor a wrong result (the CPU
-    row and the ALU chip agree on the tuple, so the ALU bus balances; the ALU chip's own constraint is violated)."""
+    row and the bitwise chip agree on the tuple, so the ALU bus balances; the byte-operation table has no such row),
+    one shift a wrong result (the ALU chip's constraint), one sltu a wrong flag (the CPU row's own comparison)."""
     client, vk, t, _ = setup
     cyc, prog = t["cycles"], t["program"]
     rows = prog[(cyc[:, 0] - prog[0, 0]) // 4]
-    for op in (1, 3):  # add, xor
+    for op in (1, 3, 6, 10):  # add, xor, sll, sltu
         i = int(np.nonzero((rows[:, 1] == op) & (rows[:, 2] == 1))[0][100])
         t2 = dict(t)
         c2 = cyc.copy()
-        c2[i, 1] ^= 4
+        c2[i, 1] ^= 4 if op != 10 else 1
         t2["cycles"] = c2
         with pytest.raises(RuntimeError):
             oracle.machine_prove(t2, num_queries=NQ, pow_bits=POW)
@@ -149,6 +150,21 @@ def test_wrong_alu_chip_row_alone_is_rejected(zk, oracle, setup):
         del os.environ["ZKSP_ORACLE_WRONG_ALU"]
     with pytest.raises(zk.VerificationError):
         client.verify(zk.SP1ProofWithPublicValues.from_bytes(forged), vk)
+
+
+def test_wrong_bitwise_chip_row_alone_is_rejected(zk, oracle, setup):
+    """Only the bitwise chip's row carries a wrong result byte: the table chip has no (kind, b, c, a) row for it."""
+    client, vk, t, _ = setup
+    os.environ["ZKSP_ORACLE_WRONG_BW"] = "123"
+    try:
+        with pytest.raises(RuntimeError):
+            oracle.machine_prove(t, num_queries=NQ, pow_bits=POW)
+        forged = forced_proof(oracle, t)
+    finally:
+        del os.environ["ZKSP_ORACLE_WRONG_BW"]
+    with pytest.raises(zk.VerificationError) as ei:
+        client.verify(zk.SP1ProofWithPublicValues.from_bytes(forged), vk)
+    assert "balance" in str(ei.value)
 
 
 def test_wrong_subword_store_is_rejected(zk, oracle, setup):

@@ -10,9 +10,10 @@
 // entry point to HALT with the committed public values.  DESIGN.md "Machine proof" describes the
 // construction; constraint ORDER here is normative for the proof bytes.
 //
-// v6: the CPU row holds 16-bit limbs and no bits.  It adds, subtracts, tests equality, moves words and forms
-// addresses; xor / or / and / shifts / less-than go to the ALU chip, sub-word loads and stores to the sub-word
-// chip, mul / mulhu to the multiplier, one row per such instruction.  Every row is an instruction (after HALT:
+// v6: the CPU row holds 16-bit limbs and no bits.  It adds, subtracts, tests equality and unsigned order, moves words
+// and forms addresses; xor / or / and go to the bitwise chip (bytes, looked up in the table chip's byte-operation
+// columns), shifts and signed less-than to the ALU chip (bits), sub-word loads and stores to the sub-word chip,
+// mul / mulhu to the multiplier, one row per such instruction.  Every row is an instruction (after HALT:
 // the padding instruction the Program table ends with), so the Program lookup vouches for every decoded field.
 // Range discipline: every producer of a memory-bus tuple guarantees canonical limbs (table lookups or bits), and
 // addresses / jump targets stay below 0x78000000 < p, so no bus compares two 32-bit values that alias mod p.
@@ -24,13 +25,14 @@ namespace mach {
 
 // CPU, ALU and sub-word rows are each split over two instances of one AIR: the first has the largest power of two of
 // rows strictly below the count, the second the rest (a power of two again): 391 400 cycles take 2^18 + 2^17 rows.
-enum Chip { kCpu = 0, kKeccak, kKmem, kMemFinal, kImage, kProgram, kMul, kTable, kCpu2, kAlu, kAlu2, kSub, kSub2, kNumChips };
+enum Chip { kCpu = 0, kKeccak, kKmem, kMemFinal, kImage, kProgram, kMul, kTable, kCpu2, kAlu, kAlu2, kSub, kSub2, kBw, kBw2, kNumChips };
 // public scalars of a CPU instance: pc and time of its first row, whether another instance continues it, the pc
 // that one starts at (the hand-over pc: a proof-header word the transcript absorbs), the padding pc (verifying key)
 enum CpuPub { kPubStartPc = 0, kPubStartTs, kPubHasSucc, kPubEndPc, kPubPadPc, kNumCpuPub };
 ZKSP_HD constexpr bool is_cpu_chip(int chip) { return chip == kCpu || chip == kCpu2; }
 ZKSP_HD constexpr bool is_alu_chip(int chip) { return chip == kAlu || chip == kAlu2; }
 ZKSP_HD constexpr bool is_sub_chip(int chip) { return chip == kSub || chip == kSub2; }
+ZKSP_HD constexpr bool is_bw_chip(int chip) { return chip == kBw || chip == kBw2; }
 
 // opcodes: Program table column CODE and the op element of the ALU / sub-word bus tuples
 enum Op {
@@ -53,21 +55,25 @@ ZKSP_HD constexpr uint32_t code_of(uint32_t op) {
           op == SH) ? op
        : (op == BLT || op == BGE) ? (uint32_t)SLT : (op == BLTU || op == BGEU) ? (uint32_t)SLTU : 0u;
 }
-// does a cycle of this op occupy a row of the ALU chip (0) / the sub-word chip (1)?  (-1: neither)
+// sltu, bltu, bgeu: the unsigned comparison the CPU row does itself (Program column UC)
+ZKSP_HD constexpr bool ucmp_of(uint32_t op) { return op == SLTU || op == BLTU || op == BGEU; }
+// does a cycle of this op occupy a row of the ALU chip (0) / the sub-word chip (1) / the bitwise chip (2)?  (-1: none)
 ZKSP_HD constexpr int event_kind(uint32_t op) {
-  return (code_of(op) >= XOR && code_of(op) <= SLTU) ? 0
-       : (op == LB || op == LH || op == LBU || op == LHU || op == SB || op == SH) ? 1 : -1;
+  return (code_of(op) >= SLL && code_of(op) <= SLT) ? 0
+       : (op == LB || op == LH || op == LBU || op == LHU || op == SB || op == SH) ? 1
+       : (op >= XOR && op <= AND) ? 2 : -1;
 }
 
 // ---- CPU chip ----
-constexpr int C_PC = 0, C_TS = 1, C_NEXT_PC = 2, C_SEL = 3, C_CODE = C_SEL + kNumCls, C_WR = C_CODE + 1, C_USE2 = C_CODE + 2,
-              C_RD = C_CODE + 3, C_RS1 = C_CODE + 4, C_RS2 = C_CODE + 5, C_IMM_LO = C_CODE + 6, C_IMM_HI = C_CODE + 7,
-              C_TGT_LO = C_CODE + 8, C_TGT_HI = C_CODE + 9, C_A = C_CODE + 10, C_B = C_A + 2, C_C = C_B + 2, C_M = C_C + 2,
+constexpr int C_PC = 0, C_TS = 1, C_NEXT_PC = 2, C_SEL = 3, C_CODE = C_SEL + kNumCls, C_UC = C_CODE + 1, C_WR = C_CODE + 2,
+              C_USE2 = C_CODE + 3, C_RD = C_CODE + 4, C_RS1 = C_CODE + 5, C_RS2 = C_CODE + 6, C_IMM_LO = C_CODE + 7,
+              C_IMM_HI = C_CODE + 8, C_TGT_LO = C_CODE + 9, C_TGT_HI = C_CODE + 10, C_A = C_CODE + 11, C_B = C_A + 2, C_C = C_B + 2,
+              C_M = C_C + 2,
               C_MV = C_M + 2, C_X = C_MV + 2, C_K0 = C_X + 2, C_K1 = C_K0 + 1, C_O1 = C_K0 + 2, C_O2 = C_O1 + 1, C_O3 = C_O1 + 2,
               C_MADDR = C_O1 + 3, C_SC = C_MADDR + 1, C_W_PLO = C_SC + 6, C_W_PHI = C_W_PLO + 1, C_GAP = C_W_PLO + 2,
               kCpuWidth = C_GAP + 8;
 enum { SC_HALT = 0, SC_WRITE, SC_COMMIT, SC_DEFER, SC_HINT_LEN, SC_HINT_READ };
-static_assert(kCpuWidth == 62, "CPU chip layout");
+static_assert(kCpuWidth == 63, "CPU chip layout");
 ZKSP_HD constexpr int selc(int cls) { return C_SEL + cls - 1; }
 
 // ---- keccak chip: p3-keccak-air's columns + the call time ----
@@ -81,26 +87,30 @@ constexpr int MF_IS_REAL = 0, MF_LO = 1, MF_HI = 2, MF_IS_INIT = 3, MF_INIT_LO =
               MF_FIN_TS = 8, MF_D_LO = 9, MF_D_HI = 10, MF_BW = 11, kMemFinalWidth = 12;
 // ---- image / program chips: preprocessed columns, one main column ----
 constexpr int IMG_P_ADDR = 0, IMG_P_LO = 1, IMG_P_HI = 2, IMG_P_REAL = 3, kImagePrepWidth = 4, kImageWidth = 1;
-constexpr int PR_PC = 0, PR_CLS = 1, PR_CODE = 2, PR_WR = 3, PR_USE2 = 4, PR_RD = 5, PR_RS1 = 6, PR_RS2 = 7, PR_IMM_LO = 8,
-              PR_IMM_HI = 9, PR_TGT_LO = 10, PR_TGT_HI = 11, kProgramPrepWidth = 12, kProgramWidth = 1;
+constexpr int PR_PC = 0, PR_CLS = 1, PR_CODE = 2, PR_UC = 3, PR_WR = 4, PR_USE2 = 5, PR_RD = 6, PR_RS1 = 7, PR_RS2 = 8, PR_IMM_LO = 9,
+              PR_IMM_HI = 10, PR_TGT_LO = 11, PR_TGT_HI = 12, kProgramPrepWidth = 13, kProgramWidth = 1;
 // ---- multiplier chip ----
 constexpr int MU_IS_REAL = 0, MU_HI = 1, MU_B = 2, MU_C = MU_B + 32, MU_P = MU_C + 32, MU_Q0 = MU_P + 64, MU_Q1 = MU_Q0 + 10,
               MU_Q2 = MU_Q1 + 11, kMulWidth = MU_Q2 + 10;
-// ---- ALU chip: xor or and sll srl sra slt sltu over bits ----
-constexpr int AL_IS_REAL = 0, AL_SEL = 1, AL_A = AL_SEL + 8, AL_B = AL_A + 2, AL_C = AL_B + 32, AL_X = AL_C + 32, AL_K0 = AL_X + 32,
+// ---- ALU chip: sll srl sra and the signed slt (slt, blt, bge) over bits ----
+constexpr int AL_IS_REAL = 0, AL_SEL = 1, AL_A = AL_SEL + 4, AL_B = AL_A + 2, AL_C = AL_B + 32, AL_X = AL_C + 32, AL_K0 = AL_X + 32,
               AL_K1 = AL_K0 + 1, kAluWidth = AL_K1 + 1;
-static_assert(kAluWidth == 109, "ALU chip layout");
+static_assert(kAluWidth == 105, "ALU chip layout");
+// ---- bitwise chip: xor or and byte by byte, every (b, c, a) byte triple looked up in the table chip ----
+constexpr int BW_IS_REAL = 0, BW_SEL = 1, BW_A = BW_SEL + 3, BW_B = BW_A + 4, BW_C = BW_B + 4, kBwWidth = BW_C + 4;
+static_assert(kBwWidth == 16, "bitwise chip layout");
 // ---- sub-word chip: lb lh lbu lhu sb sh ----
 constexpr int SW_IS_REAL = 0, SW_SEL = 1, SW_O = SW_SEL + 6, SW_A = SW_O + 4, SW_M = SW_A + 2, SW_C = SW_M + 32, SW_MV = SW_C + 16,
               kSubWidth = SW_MV + 2;
 static_assert(kSubWidth == 63, "sub-word chip layout");
 // ---- table chip: 2^16 rows; preprocessed (x, y: the row index's bytes; na: index not a multiple of 4; nt: index above
-//      kAddrHiMax); main: multiplicities of range16 (kind 0), 4-aligned range16 (kind 1), high address limb (kind 2), byte pair ----
-constexpr int TB_P_X = 0, TB_P_Y = 1, TB_P_NA = 2, TB_P_NT = 3, kTablePrepWidth = 4, TB_M_R16 = 0, TB_M_AL = 1, TB_M_TOP = 2, TB_M_BY = 3,
-              kTableWidth = 4, kTableLogH = 16;
+//      kAddrHiMax; x ^ y; x & y); main: multiplicities of range16 (kind 0), 4-aligned range16 (kind 1), high address limb
+//      (kind 2), byte pair, and the byte operations xor / or / and ----
+constexpr int TB_P_X = 0, TB_P_Y = 1, TB_P_NA = 2, TB_P_NT = 3, TB_P_XOR = 4, TB_P_AND = 5, kTablePrepWidth = 6, TB_M_R16 = 0,
+              TB_M_AL = 1, TB_M_TOP = 2, TB_M_BY = 3, TB_M_XOR = 4, TB_M_OR = 5, TB_M_AND = 6, kTableWidth = 7, kTableLogH = 16;
 constexpr uint32_t kAddrHiMax = 0x77FFu;  // high limb of the largest address / jump target
 
-enum Bus { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG };
+enum Bus { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP };
 
 // Ctx interface:
 //   using F;  F local(int col); F next(int col); F prep(int col) (preprocessed column of the row);
@@ -144,7 +154,7 @@ ZKSP_HD constexpr uint32_t inv_pow2_mod(int n) {  // 2^-n mod p
 
 #define L(c) ctx.local(c)
 
-// ---- CPU chip: 78 constraints, emitted in order ----
+// ---- CPU chip: 82 constraints, emitted in order ----
 template <class Ctx>
 ZKSP_HD void eval_cpu(Ctx& ctx) {
   using F = typename Ctx::F;
@@ -209,12 +219,19 @@ ZKSP_HD void eval_cpu(Ctx& ctx) {
     ctx.emit(cpa * (a_hi - x_hi));
     ctx.emit(S(CL_KECCAK) * (x_lo - b_lo));
     ctx.emit(S(CL_KECCAK) * (x_hi - b_hi));
+    // unsigned comparison in the row (sltu, bltu, bgeu): X = B - C + 2^32 K1 limb by limb, so K1 = [B < C] because both
+    // limbs of X are looked up in the range table; the flag goes where the ALU chip's answer would
+    const F uc = L(C_UC);
+    ctx.emit(uc * (b_lo - c_lo + k65536 * k0 - x_lo));
+    ctx.emit(uc * (b_hi - c_hi - k0 + k65536 * k1 - x_hi));
+    ctx.emit(uc * (a_lo - k1));
+    ctx.emit(uc * a_hi);
   }
   // byte offset and the word address
   const F off = o1 + o2.dbl() + ZKSP_K(3) * o3;
   const F xaddr = x_lo + k65536 * x_hi - off;
   {
-    const F noff = S(CL_ADD) + S(CL_SUB) + S(CL_ECALL) + S(CL_KECCAK) + S(CL_LW) + S(CL_SW);
+    const F noff = S(CL_ADD) + S(CL_SUB) + S(CL_ECALL) + S(CL_KECCAK) + S(CL_LW) + S(CL_SW) + L(C_UC);
     const F memw = S(CL_LW) + S(CL_SW) + S(CL_LDS) + S(CL_STS);
     ctx.emit(noff * osum);
     ctx.emit(bool_c(osum, one));  // at most one of the three offset flags
@@ -273,7 +290,7 @@ ZKSP_HD void eval_cpu(Ctx& ctx) {
   // the memory-bus tuples), and the difference's low limb and high byte are looked up in the table chip
 #undef S
 }
-constexpr int kCpuConstraints = 78;
+constexpr int kCpuConstraints = 82;
 
 template <class Ctx>
 ZKSP_HD void eval_kmem(Ctx& ctx) {
@@ -341,13 +358,13 @@ ZKSP_HD void eval_mul(Ctx& ctx) {
 }
 constexpr int kMulConstraints = 166;
 
-// ---- ALU chip: 126 constraints in a fixed index space, evaluated as two tasks over disjoint work ----
-//   0 is_real, 1..8 selectors, 9..40 B bits, 41..72 C bits, 73..104 X bits, 105..106 K0 K1, 107 one selector per real row,
-//   108..113 xor / or / and (low, high limb each), 114..121 shifts, 122..125 less-than
-//   task 0  selectors, B and C bit by bit: booleans, bitwise results
+// ---- ALU chip: 116 constraints in a fixed index space, evaluated as two tasks over disjoint work ----
+//   0 is_real, 1..4 selectors, 5..36 B bits, 37..68 C bits, 69..100 X bits, 101..102 K0 K1, 103 one selector per real row,
+//   104..111 shifts, 112..115 signed less-than
+//   task 0  selectors, C bit by bit: booleans
 //   task 1  X with B, C: shifts, less-than
 namespace aluidx {
-constexpr int kSel = 1, kBoolB = 9, kBoolC = 41, kBoolX = 73, kBoolK = 105, kSelSum = 107, kBitwise = 108, kShift = 114, kCmp = 122;
+constexpr int kSel = 1, kBoolB = 5, kBoolC = 37, kBoolX = 69, kBoolK = 101, kSelSum = 103, kShift = 104, kCmp = 112;
 }
 constexpr int kAluTasks = 2;
 template <int TASK, class Ctx>
@@ -356,14 +373,14 @@ ZKSP_HD void eval_alu_task(Ctx& ctx) {
   using namespace aluidx;
   const F one = ctx.k(kR1), zero = one - one;
   const F k65536 = ZKSP_K(65536);
-#define OPF(o) ctx.local(AL_SEL + (o) - XOR)
+#define OPF(o) ctx.local(AL_SEL + (o) - SLL)
   const F a_lo = L(AL_A), a_hi = L(AL_A + 1);
   if (TASK == 0) {
     const F is_real = L(AL_IS_REAL);
     ctx.emit_at(0, bool_c(is_real, one));
     F selsum = zero;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 4; ++k) {
       const F v = L(AL_SEL + k);
       ctx.emit_at(kSel + k, bool_c(v, one));
       selsum = selsum + v;
@@ -371,27 +388,8 @@ ZKSP_HD void eval_alu_task(Ctx& ctx) {
     ctx.emit_at(kSelSum, selsum - is_real);
     ctx.emit_at(kBoolK, bool_c(L(AL_K0), one));
     ctx.emit_at(kBoolK + 1, bool_c(L(AL_K1), one));
-    F ax[2] = {zero, zero}, ao[2] = {zero, zero}, aa[2] = {zero, zero};
 #pragma unroll
-    for (int h = 1; h >= 0; --h) {
-      for (int i = 15; i >= 0; --i) {
-        const int col = 16 * h + i;
-        const F b = L(AL_B + col), c = L(AL_C + col);
-        ctx.emit_at(kBoolB + col, bool_c(b, one));
-        ctx.emit_at(kBoolC + col, bool_c(c, one));
-        const F bc = b * c, sm = b + c;
-        ax[h] = ax[h].dbl() + (sm - bc.dbl());
-        ao[h] = ao[h].dbl() + (sm - bc);
-        aa[h] = aa[h].dbl() + bc;
-      }
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const F al = h ? a_hi : a_lo;
-      ctx.emit_at(kBitwise + 0 + h, OPF(XOR) * (al - ax[h]));
-      ctx.emit_at(kBitwise + 2 + h, OPF(OR) * (al - ao[h]));
-      ctx.emit_at(kBitwise + 4 + h, OPF(AND) * (al - aa[h]));
-    }
+    for (int i = 0; i < 32; ++i) ctx.emit_at(kBoolC + i, bool_c(L(AL_C + i), one));
   }
   if (TASK == 1) {
     F samt = L(AL_C + 4);
@@ -415,6 +413,7 @@ ZKSP_HD void eval_alu_task(Ctx& ctx) {
       F pw = one;
       for (int i = 0; i < 32; ++i) {
         const F bi = L(AL_B + i);
+        ctx.emit_at(kBoolB + i, bool_c(bi, one));
         ctx.stash(i, bi);
         p32 = p32 + pw * bi;
         if (i == 15) p16 = p32;
@@ -470,22 +469,39 @@ ZKSP_HD void eval_alu_task(Ctx& ctx) {
     ctx.emit_at(kShift + 5, OPF(SRL) * (a_hi - srl_hi));
     ctx.emit_at(kShift + 6, OPF(SRA) * (a_lo - (srl_lo + b31 * fill_lo)));
     ctx.emit_at(kShift + 7, OPF(SRA) * (a_hi - (srl_hi + b31 * fill_hi)));
-    // less-than: X = B - C (mod 2^32, the sign bits swapped for the signed order), K1 = "less than"
-    const F k0 = L(AL_K0), k1 = L(AL_K1), cmp = OPF(SLT) + OPF(SLTU);
+    // signed less-than: X = B - C (mod 2^32) with the sign bits swapped, K1 = "less than"
+    const F k0 = L(AL_K0), k1 = L(AL_K1), cmp = OPF(SLT);
     ctx.emit_at(kCmp + 0, cmp * (b_lo - c_lo + k65536 * k0 - x_lo));
-    ctx.emit_at(kCmp + 1, cmp * (b_hi - c_hi - k0 + k65536 * k1 - x_hi) + k65536 * (OPF(SLT) * (c31 - b31)));
+    ctx.emit_at(kCmp + 1, cmp * (b_hi - c_hi - k0 + k65536 * k1 - x_hi + k65536 * (c31 - b31)));
     ctx.emit_at(kCmp + 2, cmp * (a_lo - k1));
     ctx.emit_at(kCmp + 3, cmp * a_hi);
   }
 #undef OPF
 }
-constexpr int kAluConstraints = 126;
+constexpr int kAluConstraints = 116;
 template <class Ctx>
 ZKSP_HD void eval_alu(Ctx& ctx) {
   eval_alu_task<0>(ctx);
   eval_alu_task<1>(ctx);
   ctx.set_count(kAluConstraints);
 }
+
+// ---- bitwise chip: one operation per real row; the byte lookups do the rest ----
+template <class Ctx>
+ZKSP_HD void eval_bw(Ctx& ctx) {
+  using F = typename Ctx::F;
+  const F one = ctx.k(kR1), is_real = L(BW_IS_REAL);
+  ctx.emit(bool_c(is_real, one));
+  F selsum = one - one;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const F v = L(BW_SEL + k);
+    ctx.emit(bool_c(v, one));
+    selsum = selsum + v;
+  }
+  ctx.emit(selsum - is_real);
+}
+constexpr int kBwConstraints = 5;
 
 // ---- sub-word chip: M is the memory word, C the low limb of the stored register, both as bits ----
 template <class Ctx>
@@ -597,7 +613,7 @@ constexpr int kKeccakConstraints = ka::kNumConstraints + 1;
 ZKSP_HD constexpr int num_constraints(int chip) {
   return is_cpu_chip(chip) ? kCpuConstraints : chip == kKeccak ? kKeccakConstraints : chip == kKmem ? kKmemConstraints
        : chip == kMemFinal ? kMemFinalConstraints : chip == kImage ? 1 : chip == kProgram ? 0 : chip == kMul ? kMulConstraints
-       : chip == kTable ? 2 : is_alu_chip(chip) ? kAluConstraints : is_sub_chip(chip) ? kSubConstraints : 0;
+       : chip == kTable ? 2 : is_alu_chip(chip) ? kAluConstraints : is_sub_chip(chip) ? kSubConstraints : is_bw_chip(chip) ? kBwConstraints : 0;
 }
 
 }  // namespace mach

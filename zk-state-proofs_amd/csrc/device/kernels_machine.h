@@ -27,12 +27,13 @@ struct MachineRecords {
   const uint32_t* muls;        // [B][cap_muls][3]
   const uint32_t* alu_idx;     // [B][cap_alu]: cycle index of every ALU-chip row
   const uint32_t* sub_idx;     // [B][cap_sub]: cycle index of every sub-word-chip row
+  const uint32_t* bw_idx;      // [B][cap_bw]: cycle index of every bitwise-chip row
   const uint32_t* prog_mult;   // [B][2^log_prog]; the padding row (n_program - 1) holds 0: its fetches follow from cpu_rows
   const uint32_t* counts;      // [B][8]: cycles, keccak calls, memfinal rows, muls, ALU rows, sub-word rows, last time x0 was
-                               //         accessed by a real cycle, 0
+                               //         accessed by a real cycle, bitwise rows
   uint32_t* table_hist;        // [B][kTableWidth][2^16] scratch: multiplicities of the table chip, counted on the device
   uint32_t row0[mach::kNumChips];  // first cycle / event of the chip's instance (second instances: rows of the first)
-  size_t cap_cycles, cap_keccak, cap_memfinal, cap_muls, cap_alu, cap_sub;
+  size_t cap_cycles, cap_keccak, cap_memfinal, cap_muls, cap_alu, cap_sub, cap_bw;
   const uint32_t* program;     // [n_program][9] (shared); the last row is the padding instruction
   uint32_t text_base, n_program, n_image;
   uint32_t cpu_rows;           // rows of the two CPU instances together: the rows past the last cycle fetch the padding instruction
@@ -43,10 +44,10 @@ void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& re
 // keccak chip: p3-keccak-air's columns by launch_keccak_trace (kernels.h, with a batch stride), then the call time
 void launch_keccak_ts(hipStream_t stream, const MachineRecords& rec, uint32_t* trace, size_t trace_bstride, int logh,
                       int batch);
-// Table chip multiplicities: what the rows of `chip` (its main trace [B][w][2^logh], Montgomery) look up on the RANGE and
-// BYTES buses is added to rec.table_hist (zero it first: launch_table_clear), by evaluating the chip's own receives -
+// Table chip multiplicities: what the rows of `chip` (its main trace [B][w][2^logh], Montgomery) look up on the RANGE,
+// BYTES and BYTEOP buses is added to rec.table_hist (zero it first: launch_table_clear), by evaluating the chip's own receives -
 // so the buses balance by construction whenever every looked-up value has a table row.  launch_table_trace then
-// writes the table chip's three main columns.
+// writes the table chip's main columns.
 void launch_table_clear(hipStream_t stream, const MachineRecords& rec, int batch);
 void launch_table_count(hipStream_t stream, const mach::Interaction* inter, int n_inter, const uint32_t* trace, int width, int logh,
                         const MachineRecords& rec, int batch);

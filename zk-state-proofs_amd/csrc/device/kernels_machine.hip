@@ -89,7 +89,9 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
   o.val(C_PC, pc);
   o.val(C_TS, ts);
   for (int k = 1; k <= kNumCls; ++k) o.flag(selc(k), k == cls);
+  const bool uc = ucmp_of(op);
   o.val(C_CODE, code);
+  o.flag(C_UC, uc);
   o.flag(C_WR, wr != 0);
   o.flag(C_USE2, use2 != 0);
   o.val(C_RD, rd); o.val(C_RS1, rs1); o.val(C_RS2, rs2);
@@ -130,6 +132,11 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
     case CL_KECCAK: x = bb; next = bb; break;
     default: break;
   }
+  if (uc) {  // the row's own unsigned comparison: X = B - C + 2^32 [B < C], limb by limb with borrows K0, K1
+    k0 = blo < clo;
+    k1 = bb < c;
+    x = bb - c;
+  }
   if (cls == CL_BEQ || cls == CL_BNE) { o.put(C_X, x_lo_m); o.put(C_X + 1, x_hi_m); }
   else o.limbs(C_X, x);
   o.limbs(C_A, a); o.limbs(C_B, bb); o.limbs(C_C, c); o.limbs(C_M, m); o.limbs(C_MV, mv);
@@ -162,22 +169,42 @@ __global__ __launch_bounds__(kMT) void alu_trace_kernel(MachineRecords rec, uint
   const uint32_t code = code_of(rec.program[9 * (size_t)((cy[0] - rec.text_base) >> 2) + 1]), bb = cy[2], c = cy[3];
   uint32_t a = cy[1], x = 0, k0 = 0, k1 = 0;
   if (code == SLL || code == SRL || code == SRA) x = 1u << (c & 31);
-  if (code == SLT || code == SLTU) {
+  if (code == SLT) {
     const uint32_t blo = bb & 0xffff, bhi = bb >> 16, clo = c & 0xffff, chi = c >> 16;
-    const bool sgn = code == SLT;
     k0 = blo < clo;
     k1 = less_than(code, bb, c);
     const uint32_t dlo = blo - clo + 65536 * k0;
     const int32_t dhi = (int32_t)bhi - (int32_t)chi - (int32_t)k0 + 65536 * (int32_t)k1 +
-                        (sgn ? 65536 * ((int32_t)(c >> 31) - (int32_t)(bb >> 31)) : 0);
+                        65536 * ((int32_t)(c >> 31) - (int32_t)(bb >> 31));
     x = dlo | ((uint32_t)dhi << 16);
     a = k1;
   }
   o.put(AL_IS_REAL, kR1);
-  for (uint32_t k = 0; k < 8; ++k) o.flag(AL_SEL + k, XOR + k == code);
+  for (uint32_t k = 0; k < 4; ++k) o.flag(AL_SEL + k, SLL + k == code);
   o.limbs(AL_A, a);
   o.bits(AL_B, bb, 32); o.bits(AL_C, c, 32); o.bits(AL_X, x, 32);
   o.flag(AL_K0, k0 != 0); o.flag(AL_K1, k1 != 0);
+}
+
+// One bitwise-chip instance: row r is event row0 + r of the list bw_idx
+__global__ __launch_bounds__(kMT) void bw_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh, uint32_t row0) {
+  const size_t h = (size_t)1 << logh;
+  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (r >= h) return;
+  const int b = blockIdx.y;
+  const Col o{trace + (size_t)b * kBwWidth * h + r, h};
+  const size_t ev = (size_t)row0 + r;
+  if (ev >= rec.counts[kCountWords * b + 7]) { o.zero(0, kBwWidth); return; }
+  const uint32_t cyc = rec.bw_idx[(size_t)b * rec.cap_bw + ev];
+  const uint32_t* cy = rec.cycles + ((size_t)b * rec.cap_cycles + cyc) * 12;
+  const uint32_t code = rec.program[9 * (size_t)((cy[0] - rec.text_base) >> 2) + 1], a = cy[1], bb = cy[2], c = cy[3];
+  o.put(BW_IS_REAL, kR1);
+  for (uint32_t k = 0; k < 3; ++k) o.flag(BW_SEL + k, XOR + k == code);
+  for (int i = 0; i < 4; ++i) {
+    o.val(BW_A + i, (a >> (8 * i)) & 0xff);
+    o.val(BW_B + i, (bb >> (8 * i)) & 0xff);
+    o.val(BW_C + i, (c >> (8 * i)) & 0xff);
+  }
 }
 
 // One sub-word-chip instance: row r is event row0 + r of the list sub_idx
@@ -352,6 +379,8 @@ void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& re
     case kAlu2: hipLaunchKernelGGL(alu_trace_kernel, grid, block, 0, stream, rec, trace, logh, rec.row0[chip]); break;
     case kSub:
     case kSub2: hipLaunchKernelGGL(sub_trace_kernel, grid, block, 0, stream, rec, trace, logh, rec.row0[chip]); break;
+    case kBw:
+    case kBw2: hipLaunchKernelGGL(bw_trace_kernel, grid, block, 0, stream, rec, trace, logh, rec.row0[chip]); break;
     case kKmem:
       hipLaunchKernelGGL(kmem_trace_kernel, dim3((unsigned)((h + 63) / 64), batch), dim3(64), 0, stream, rec, trace, logh);
       break;
@@ -595,9 +624,16 @@ __global__ __launch_bounds__(kMT) void table_count_kernel(const Interaction* __r
     const RowView rv{nullptr, trace + (size_t)b * width * h + (in_range ? r : 0), 0, h};
     for (int k = 0; k < n_inter; ++k) {
       const Interaction& it = inter[k];
-      if (it.sign > 0 || (it.bus != BUS_RANGE && it.bus != BUS_BYTES)) continue;
+      if (it.sign > 0 || (it.bus != BUS_RANGE && it.bus != BUS_BYTES && it.bus != BUS_BYTEOP)) continue;
       const uint32_t m = in_range ? m_lf_eval(it.mult, rv).to_canonical() : 0u;
       const uint32_t v1 = m_lf_eval(it.el[0], rv).to_canonical(), v2 = m_lf_eval(it.el[1], rv).to_canonical();
+      if (it.bus == BUS_BYTEOP) {  // (kind, x, y, z): counted only if z is the table's answer; byte pairs are spread out
+        const uint32_t y = m_lf_eval(it.el[2], rv).to_canonical(), z = m_lf_eval(it.el[3], rv).to_canonical();
+        const uint32_t want = v1 == 1 ? (v2 ^ y) : v1 == 2 ? (v2 | y) : (v2 & y);
+        const bool ok = m != 0 && v1 >= 1 && v1 <= 3 && v2 <= 255 && y <= 255 && z == want;
+        wave_hist_add(hb + (size_t)TB_M_XOR * kTableRows, (v1 - 1) * (uint32_t)kTableRows + v2 + 256 * y, m, ok);
+        continue;
+      }
       // a value without a table row is not counted: the buses of such a (dishonest or unprovable) run do not balance
       if (it.bus == BUS_RANGE) {
         const bool ok = m != 0 && v2 < kTableRows && v1 <= 2 && !(v1 == 1 && (v2 & 3)) && !(v1 == 2 && v2 > kAddrHiMax);
@@ -663,8 +699,9 @@ __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, 
   }
   const Fp memw = sel[CL_LW] + sel[CL_SW] + sel[CL_LDS] + sel[CL_STS], memq = memw + sel[CL_ECALL];
   const Fp al = memw + sel[CL_JALR], top = al + sel[CL_KECCAK];
-  const Fp chk = top + sel[CL_ADD] + sel[CL_SUB] + sel[CL_ECALL];
-  const Fp alu = sel[CL_ALU] + sel[CL_BLT] + sel[CL_BGE], sub = sel[CL_LDS] + sel[CL_STS];
+  const Fp uc = col(C_UC);
+  const Fp chk = top + sel[CL_ADD] + sel[CL_SUB] + sel[CL_ECALL] + uc;
+  const Fp alu = sel[CL_ALU] + sel[CL_BLT] + sel[CL_BGE] - uc, sub = sel[CL_LDS] + sel[CL_STS];
   const Fp ts = col(C_TS), wr = col(C_WR), use2 = col(C_USE2), rd = col(C_RD), rs1 = col(C_RS1), rs2 = col(C_RS2), code = col(C_CODE);
   const Fp a_lo = col(C_A), a_hi = col(C_A + 1), b_lo = col(C_B), b_hi = col(C_B + 1), c_lo = col(C_C), c_hi = col(C_C + 1),
            m_lo = col(C_M), m_hi = col(C_M + 1), mv_lo = col(C_MV), mv_hi = col(C_MV + 1), x_lo = col(C_X), x_hi = col(C_X + 1);
@@ -683,10 +720,10 @@ __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, 
   // previous access time of slot q (accessed at ts + q): ts + q - 1 - (gap_lo + 2^16 gap_hi)
   auto pts = [&](int q) { return ts - (g[2 * q] + k65536 * g[2 * q + 1]) + (q == 0 ? -one : q == 1 ? Fp::zero() : q == 2 ? one : two); };
   if (J0 <= 0 && 0 < J1) {  // helper 0: instruction fetch (receive), rs1 consume
-    Fp4 f = busc(BUS_PROG) + b1 * col(C_PC) + b2 * clsid + b3 * code + b4 * wr;
-    f += m_load_fp4(bpow + 20) * use2 + m_load_fp4(bpow + 24) * rd + m_load_fp4(bpow + 28) * rs1 + m_load_fp4(bpow + 32) * rs2 +
-         m_load_fp4(bpow + 36) * col(C_IMM_LO) + m_load_fp4(bpow + 40) * col(C_IMM_HI) + m_load_fp4(bpow + 44) * col(C_TGT_LO) +
-         m_load_fp4(bpow + 48) * col(C_TGT_HI);
+    Fp4 f = busc(BUS_PROG) + b1 * col(C_PC) + b2 * clsid + b3 * code + b4 * uc;
+    f += m_load_fp4(bpow + 20) * wr + m_load_fp4(bpow + 24) * use2 + m_load_fp4(bpow + 28) * rd + m_load_fp4(bpow + 32) * rs1 +
+         m_load_fp4(bpow + 36) * rs2 + m_load_fp4(bpow + 40) * col(C_IMM_LO) + m_load_fp4(bpow + 44) * col(C_IMM_HI) +
+         m_load_fp4(bpow + 48) * col(C_TGT_LO) + m_load_fp4(bpow + 52) * col(C_TGT_HI);
     visit(0, -one, f, -one, mem(rs1, b_lo, b_hi, pts(0)));
   }
   if (J0 <= 1 && 1 < J1) visit(1, one, mem(rs1, b_lo, b_hi, ts), -use2, mem(rs2, c_lo, c_hi, pts(1)));
@@ -1105,6 +1142,7 @@ __global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
   else if constexpr (CHIP == kTable) eval_table(ctx);
   else if constexpr (is_alu_chip(CHIP)) eval_alu(ctx);
   else if constexpr (is_sub_chip(CHIP)) eval_sub(ctx);
+  else if constexpr (is_bw_chip(CHIP)) eval_bw(ctx);
   ctx.flush();
   logup_constraints(a, pi, &ctx.acc);
   const Fp4 q = ctx.acc * Fp::raw(pi.c ? a.zh_inv[1] : a.zh_inv[0]);
@@ -1233,6 +1271,8 @@ void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a) {
     case kAlu2: hipLaunchKernelGGL(machine_quotient_kernel<kAlu>, grid, block, 0, stream, a); break;
     case kSub:
     case kSub2: hipLaunchKernelGGL(machine_quotient_kernel<kSub>, grid, block, 0, stream, a); break;
+    case kBw:
+    case kBw2: hipLaunchKernelGGL(machine_quotient_kernel<kBw>, grid, block, 0, stream, a); break;
     case kKmem: hipLaunchKernelGGL(machine_quotient_kernel<kKmem>, grid, block, 0, stream, a); break;
     case kMemFinal: hipLaunchKernelGGL(machine_quotient_kernel<kMemFinal>, grid, block, 0, stream, a); break;
     case kImage: hipLaunchKernelGGL(machine_quotient_kernel<kImage>, grid, block, 0, stream, a); break;

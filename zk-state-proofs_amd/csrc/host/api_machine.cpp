@@ -85,6 +85,7 @@ int zksp_mtrace_section(const zksp_mtrace* t, int which, const void** ptr, size_
     case ZKSP_MT_PROG_MULT: *ptr = m.prog_mult.data(); *bytes = m.prog_mult.size() * 4; break;
     case ZKSP_MT_ALU_IDX: *ptr = m.alu_idx.data(); *bytes = m.alu_idx.size() * 4; break;
     case ZKSP_MT_SUB_IDX: *ptr = m.sub_idx.data(); *bytes = m.sub_idx.size() * 4; break;
+    case ZKSP_MT_BW_IDX: *ptr = m.bw_idx.data(); *bytes = m.bw_idx.size() * 4; break;
     case ZKSP_MT_PROGRAM: *ptr = t->prog->rows.data(); *bytes = t->prog->rows.size() * sizeof(ProgramRow); break;
     case ZKSP_MT_IMAGE: *ptr = t->prog->image.data(); *bytes = t->prog->image.size() * sizeof(ImageRow); break;
     case ZKSP_MT_PUBLIC_VALUES: *ptr = m.rec.public_values.data(); *bytes = m.rec.public_values.size(); break;

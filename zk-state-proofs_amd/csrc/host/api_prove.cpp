@@ -162,6 +162,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       lh[mach::kCpu] = clog2(t.cycles.size()); lh[mach::kCpu2] = 0;
       lh[mach::kAlu] = clog2(t.alu_idx.size()); lh[mach::kAlu2] = 0;
       lh[mach::kSub] = clog2(t.sub_idx.size()); lh[mach::kSub2] = 0;
+      lh[mach::kBw] = clog2(t.bw_idx.size()); lh[mach::kBw2] = 0;
       groups[lh].push_back(i);
       covers[lh].cover(t);
     }
@@ -201,7 +202,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     for (size_t j = 0; j < ck.idx.size(); ++j) {
       MachineTrace& t = traces[ck.idx[j]]->t;
       dead[j].cycles.swap(t.cycles); dead[j].keccak.swap(t.keccak); dead[j].memfinal.swap(t.memfinal);
-      dead[j].muls.swap(t.muls); dead[j].prog_mult.swap(t.prog_mult); dead[j].alu_idx.swap(t.alu_idx); dead[j].sub_idx.swap(t.sub_idx);
+      dead[j].muls.swap(t.muls); dead[j].prog_mult.swap(t.prog_mult); dead[j].alu_idx.swap(t.alu_idx); dead[j].sub_idx.swap(t.sub_idx); dead[j].bw_idx.swap(t.bw_idx);
     }
     try {
       reaper.th.emplace_back([d = std::move(dead)]() mutable { d.clear(); });

@@ -273,26 +273,26 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
       }
       const uint32_t a = c.b, b = c.c;
       uint32_t res = 0, next = pc + 4;
-      bool halt = false, alu_event = false;
+      bool halt = false, alu_event = false, bw_event = false;
       switch (r.op) {
         case AIR_ADD: res = a + b; break;
         case AIR_SUB: res = a - b; break;
-        case AIR_XOR: res = a ^ b; alu_event = true; break;
-        case AIR_OR: res = a | b; alu_event = true; break;
-        case AIR_AND: res = a & b; alu_event = true; break;
+        case AIR_XOR: res = a ^ b; bw_event = true; break;
+        case AIR_OR: res = a | b; bw_event = true; break;
+        case AIR_AND: res = a & b; bw_event = true; break;
         case AIR_SLL: res = a << (b & 31); alu_event = true; break;
         case AIR_SRL: res = a >> (b & 31); alu_event = true; break;
         case AIR_SRA: res = (uint32_t)((int32_t)a >> (b & 31)); alu_event = true; break;
         case AIR_SLT: res = (int32_t)a < (int32_t)b; alu_event = true; break;
-        case AIR_SLTU: res = a < b; alu_event = true; break;
+        case AIR_SLTU: res = a < b; break;  // an unsigned comparison: the CPU row does it itself
         case AIR_JAL: res = r.imm; next = r.tgt; break;
         case AIR_JALR: res = r.tgt; next = (a + r.imm) & ~1u; break;
         case AIR_BEQ: if (a == b) next = r.tgt; break;
         case AIR_BNE: if (a != b) next = r.tgt; break;
         case AIR_BLT: if ((int32_t)a < (int32_t)b) next = r.tgt; alu_event = true; break;
         case AIR_BGE: if ((int32_t)a >= (int32_t)b) next = r.tgt; alu_event = true; break;
-        case AIR_BLTU: if (a < b) next = r.tgt; alu_event = true; break;
-        case AIR_BGEU: if (a >= b) next = r.tgt; alu_event = true; break;
+        case AIR_BLTU: if (a < b) next = r.tgt; break;
+        case AIR_BGEU: if (a >= b) next = r.tgt; break;
         case AIR_MUL: res = a * b; out->muls.push_back({0, a, b}); break;
         case AIR_MULHU: res = (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); out->muls.push_back({1, a, b}); break;
         case AIR_LB: case AIR_LH: case AIR_LW: case AIR_LBU: case AIR_LHU: {
@@ -401,6 +401,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
       }
       c.a = res;
       if (alu_event) out->alu_idx.push_back((uint32_t)(cycles - 1));
+      if (bw_event) out->bw_idx.push_back((uint32_t)(cycles - 1));
       if (r.wr) {
         c.w_prev = x[r.rd];
         c.w_pts = reg_ts[r.rd]; reg_ts[r.rd] = ts + 3;

@@ -107,16 +107,18 @@ struct MachineTrace {
   std::vector<MemFinalRec> memfinal;  // every image address and every other touched address, strictly increasing
   std::vector<MulRec> muls;
   std::vector<uint32_t> prog_mult;    // per Program row (the padding row: 0 here; its fetches depend on the chip heights)
-  std::vector<uint32_t> alu_idx;      // cycles that occupy a row of the ALU chip (xor .. sltu, blt .. bgeu), in order
+  std::vector<uint32_t> alu_idx;      // cycles that occupy a row of the ALU chip (sll srl sra slt, blt bge), in order
+  std::vector<uint32_t> bw_idx;       // cycles that occupy a row of the bitwise chip (xor or and), in order
   std::vector<uint32_t> sub_idx;      // cycles that occupy a row of the sub-word chip (lb lh lbu lhu sb sh), in order
   uint32_t x0_last = 0;               // last access time of x0 by a real cycle (the first padding row consumes it)
 };
 
 // How many rows of each event-sized chip a run needs; a batch is proven with the heights of the element-wise maximum.
 struct MachineCounts {
-  size_t cycles = 0, alu = 0, sub = 0, keccak = 0, memfinal = 0, muls = 0;
+  size_t cycles = 0, alu = 0, sub = 0, bw = 0, keccak = 0, memfinal = 0, muls = 0;
   void cover(const MachineTrace& t) {
     cycles = std::max(cycles, t.cycles.size()); alu = std::max(alu, t.alu_idx.size()); sub = std::max(sub, t.sub_idx.size());
+    bw = std::max(bw, t.bw_idx.size());
     keccak = std::max(keccak, t.keccak.size()); memfinal = std::max(memfinal, t.memfinal.size()); muls = std::max(muls, t.muls.size());
   }
 };

@@ -1,13 +1,14 @@
 // See machine_defs.hpp.  Bus protocol (DESIGN.md "Machine proof", format v6):
 //   MEM    (addr, lo, hi, time)   every access consumes its predecessor's tuple and produces its own
-//   PROG   (pc, class, code, wr, use2, rd, rs1, rs2, imm_lo, imm_hi, tgt_lo, tgt_hi)   instruction fetch, every CPU row
+//   PROG   (pc, class, code, uc, wr, use2, rd, rs1, rs2, imm_lo, imm_hi, tgt_lo, tgt_hi)   instruction fetch, every CPU row
 //   KCALL  (time, ptr_lo, ptr_hi)   CPU -> keccak-memory: one precompile call
 //   KIO    (time, word index, in_lo, in_hi, out_lo, out_hi)   keccak-f chip -> keccak-memory
-//   ALU    (op, a_lo, a_hi, b_lo, b_hi, c_lo, c_hi)   CPU -> ALU chip / multiplier
+//   ALU    (op, a_lo, a_hi, b_lo, b_hi, c_lo, c_hi)   CPU -> ALU chip / bitwise chip / multiplier
 //   SUB    (op, byte offset, a_lo, a_hi, m_lo, m_hi, c_lo, mv_lo, mv_hi)   CPU -> sub-word chip
 //   PUBC   (kind, index, lo, hi), PUBH (exit_lo, exit_hi)   CPU -> verifier
 //   RANGE  (kind, value)   value < 2^16 (kind 0), and a multiple of 4 (kind 1), or at most 0x77FF (kind 2): table chip
 //   BYTES  (x, y)   two bytes: table chip
+//   BYTEOP (kind, x, y, z)   z = x xor y (1), x or y (2), x and y (3): table chip <- bitwise chip
 //   IMG    (addr, lo, hi)   image chip -> memory boundary: the initial value of an image address
 #include "machine_defs.hpp"
 
@@ -87,7 +88,7 @@ Interaction bytes_inter(int sign, const LinForm& mult, const LinForm& x, const L
 }
 
 constexpr int kCpuInter = 22;
-Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[4], g_alu[1], g_sub[1];
+Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7], g_alu[1], g_sub[1], g_bw[5];
 ChipDef g_chips[kNumChips];
 
 void build() {
@@ -97,13 +98,13 @@ void build() {
   {
     Interaction& it = g_cpu[0];
     it = Interaction{};
-    it.bus = BUS_PROG; it.sign = -1; it.mult = one; it.n_el = 12;
+    it.bus = BUS_PROG; it.sign = -1; it.mult = one; it.n_el = 13;
     it.el[0] = lf_col(C_PC);
     it.el[1] = lf_zero();
     for (int k = 1; k <= kNumCls; ++k) lf_add(it.el[1], selc(k), (uint64_t)k);
-    it.el[2] = lf_col(C_CODE); it.el[3] = lf_col(C_WR); it.el[4] = lf_col(C_USE2); it.el[5] = lf_col(C_RD);
-    it.el[6] = lf_col(C_RS1); it.el[7] = lf_col(C_RS2); it.el[8] = lf_col(C_IMM_LO); it.el[9] = lf_col(C_IMM_HI);
-    it.el[10] = lf_col(C_TGT_LO); it.el[11] = lf_col(C_TGT_HI);
+    it.el[2] = lf_col(C_CODE); it.el[3] = lf_col(C_UC); it.el[4] = lf_col(C_WR); it.el[5] = lf_col(C_USE2); it.el[6] = lf_col(C_RD);
+    it.el[7] = lf_col(C_RS1); it.el[8] = lf_col(C_RS2); it.el[9] = lf_col(C_IMM_LO); it.el[10] = lf_col(C_IMM_HI);
+    it.el[11] = lf_col(C_TGT_LO); it.el[12] = lf_col(C_TGT_HI);
   }
   // previous access time of slot q (accessed at ts + q): ts + q - 1 - (gap_lo + 2^16 gap_hi)
   LinForm pts[4];
@@ -130,8 +131,9 @@ void build() {
   {
     // the adder output is canonical, an address is word-aligned once its byte offset is taken off, and addresses,
     // jump targets and the keccak call's return address stay below 0x78000000
+    // ... and so is the difference of an unsigned comparison (UC)
     const LinForm chk = lf_sum({selc(CL_ADD), selc(CL_SUB), selc(CL_JALR), selc(CL_LW), selc(CL_SW), selc(CL_LDS), selc(CL_STS),
-                                selc(CL_ECALL), selc(CL_KECCAK)});
+                                selc(CL_ECALL), selc(CL_KECCAK), C_UC});
     LinForm xoff = lf_col(C_X);
     lf_add(xoff, C_O1, kP - 1); lf_add(xoff, C_O2, kP - 2); lf_add(xoff, C_O3, kP - 3);
     LinForm top = lf_zero();  // kind 2: the high limb of an address is at most kAddrHiMax
@@ -142,7 +144,8 @@ void build() {
   {
     Interaction& al = g_cpu[17];
     al = Interaction{};
-    al.bus = BUS_ALU; al.sign = +1; al.mult = lf_sum({selc(CL_ALU), selc(CL_BLT), selc(CL_BGE)}); al.n_el = 7;
+    // every ALU-class instruction and every ordered branch, except the unsigned comparisons the row does itself
+    al.bus = BUS_ALU; al.sign = +1; al.mult = lf_sum({selc(CL_ALU), selc(CL_BLT), selc(CL_BGE)}); lf_add(al.mult, C_UC, kP - 1); al.n_el = 7;
     al.el[0] = lf_col(C_CODE);
     al.el[1] = a_lo; al.el[2] = a_hi; al.el[3] = b_lo; al.el[4] = b_hi; al.el[5] = c_lo; al.el[6] = c_hi;
     Interaction& sb = g_cpu[18];
@@ -218,13 +221,23 @@ void build() {
     im.el[0] = lf_col(IMG_P_ADDR); im.el[1] = lf_col(IMG_P_LO); im.el[2] = lf_col(IMG_P_HI);
     Interaction& pr = g_program[0];
     pr = Interaction{};
-    pr.bus = BUS_PROG; pr.sign = +1; pr.mult = lf_col(kProgramPrepWidth + 0); pr.n_el = 12;
-    for (int j = 0; j < 12; ++j) pr.el[j] = lf_col(j);
+    pr.bus = BUS_PROG; pr.sign = +1; pr.mult = lf_col(kProgramPrepWidth + 0); pr.n_el = 13;
+    for (int j = 0; j < 13; ++j) pr.el[j] = lf_col(j);
     const LinForm idx = lf_pair(TB_P_X, TB_P_Y, 256);
     g_table[0] = range_inter(+1, lf_col(kTablePrepWidth + TB_M_R16), zero, idx);
     g_table[1] = range_inter(+1, lf_col(kTablePrepWidth + TB_M_AL), one, idx);
     g_table[2] = range_inter(+1, lf_col(kTablePrepWidth + TB_M_TOP), lf_const(2), idx);
     g_table[3] = bytes_inter(+1, lf_col(kTablePrepWidth + TB_M_BY), lf_col(TB_P_X), lf_col(TB_P_Y));
+    // byte operations (kind, x, y, z): 1 xor, 2 or (= x + y - and), 3 and
+    for (int k = 0; k < 3; ++k) {
+      Interaction& it = g_table[4 + k];
+      it = Interaction{};
+      it.bus = BUS_BYTEOP; it.sign = +1; it.mult = lf_col(kTablePrepWidth + TB_M_XOR + k); it.n_el = 4;
+      it.el[0] = lf_const((uint32_t)k + 1); it.el[1] = lf_col(TB_P_X); it.el[2] = lf_col(TB_P_Y);
+      if (k == 0) it.el[3] = lf_col(TB_P_XOR);
+      else if (k == 2) it.el[3] = lf_col(TB_P_AND);
+      else { it.el[3] = lf_pair(TB_P_X, TB_P_Y, 1); lf_add(it.el[3], TB_P_AND, kP - 1); }
+    }
   }
   for (int hi = 0; hi < 2; ++hi) {
     Interaction& it = g_mul[hi];
@@ -240,9 +253,30 @@ void build() {
     it = Interaction{};
     it.bus = BUS_ALU; it.sign = -1; it.mult = lf_col(AL_IS_REAL); it.n_el = 7;
     it.el[0] = lf_zero();
-    for (int k = 0; k < 8; ++k) lf_add(it.el[0], AL_SEL + k, (uint64_t)(XOR + k));
+    for (int k = 0; k < 4; ++k) lf_add(it.el[0], AL_SEL + k, (uint64_t)(SLL + k));
     it.el[1] = lf_col(AL_A); it.el[2] = lf_col(AL_A + 1);
     it.el[3] = lf_bits(AL_B, 16); it.el[4] = lf_bits(AL_B + 16, 16); it.el[5] = lf_bits(AL_C, 16); it.el[6] = lf_bits(AL_C + 16, 16);
+  }
+  {
+    // bitwise: the word tuple from the CPU row, and one byte-operation lookup per byte
+    Interaction& it = g_bw[0];
+    it = Interaction{};
+    it.bus = BUS_ALU; it.sign = -1; it.mult = lf_col(BW_IS_REAL); it.n_el = 7;
+    it.el[0] = lf_zero();
+    for (int k = 0; k < 3; ++k) lf_add(it.el[0], BW_SEL + k, (uint64_t)(XOR + k));
+    for (int w = 0; w < 3; ++w) {  // a, b, c as limbs of two bytes
+      const int base = w == 0 ? BW_A : w == 1 ? BW_B : BW_C;
+      it.el[1 + 2 * w] = lf_pair(base, base + 1, 256);
+      it.el[2 + 2 * w] = lf_pair(base + 2, base + 3, 256);
+    }
+    for (int i = 0; i < 4; ++i) {
+      Interaction& op = g_bw[1 + i];
+      op = Interaction{};
+      op.bus = BUS_BYTEOP; op.sign = -1; op.mult = lf_col(BW_IS_REAL); op.n_el = 4;
+      op.el[0] = lf_zero();
+      for (int k = 0; k < 3; ++k) lf_add(op.el[0], BW_SEL + k, (uint64_t)k + 1);
+      op.el[1] = lf_col(BW_B + i); op.el[2] = lf_col(BW_C + i); op.el[3] = lf_col(BW_A + i);
+    }
   }
   {
     static const uint32_t codes[6] = {LB, LH, LBU, LHU, SB, SH};
@@ -256,7 +290,7 @@ void build() {
     it.el[4] = lf_bits(SW_M, 16); it.el[5] = lf_bits(SW_M + 16, 16); it.el[6] = lf_bits(SW_C, 16);
     it.el[7] = lf_col(SW_MV); it.el[8] = lf_col(SW_MV + 1);
   }
-  g_chips[kTable] = {"table", kTablePrepWidth, kTableWidth, 4, g_table, 2};
+  g_chips[kTable] = {"table", kTablePrepWidth, kTableWidth, 7, g_table, 2};
   g_chips[kCpu] = {"cpu", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints};
   g_chips[kCpu2] = {"cpu2", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints};
   g_chips[kKeccak] = {"keccak", 0, kKeccakWidth, 50, g_keccak, kKeccakConstraints};
@@ -269,6 +303,8 @@ void build() {
   g_chips[kAlu2] = {"alu2", 0, kAluWidth, 1, g_alu, kAluConstraints};
   g_chips[kSub] = {"subword", 0, kSubWidth, 1, g_sub, kSubConstraints};
   g_chips[kSub2] = {"subword2", 0, kSubWidth, 1, g_sub, kSubConstraints};
+  g_chips[kBw] = {"bitwise", 0, kBwWidth, 5, g_bw, kBwConstraints};
+  g_chips[kBw2] = {"bitwise2", 0, kBwWidth, 5, g_bw, kBwConstraints};
 }
 
 }  // namespace

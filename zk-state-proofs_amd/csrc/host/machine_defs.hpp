@@ -11,7 +11,7 @@
 namespace zksp {
 namespace mach {
 
-constexpr int kLfMax = 16, kInterMaxElems = 12;
+constexpr int kLfMax = 16, kInterMaxElems = 13;
 struct LinForm {
   int32_t n;
   int32_t col[kLfMax];

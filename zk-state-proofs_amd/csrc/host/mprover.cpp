@@ -96,6 +96,8 @@ void machine_heights(const MachineProgram& prog, const MachineCounts& n, int log
   logh[kAlu2] = ceil_log2(split_rest_rows(n.alu));
   logh[kSub] = ceil_log2(split_rows(n.sub));
   logh[kSub2] = ceil_log2(split_rest_rows(n.sub));
+  logh[kBw] = ceil_log2(split_rows(n.bw));
+  logh[kBw2] = ceil_log2(split_rest_rows(n.bw));
   logh[kKeccak] = at_least5(ceil_log2(24 * n.keccak));
   logh[kKmem] = at_least5(ceil_log2(50 * n.keccak));
   logh[kMemFinal] = at_least5(ceil_log2(n.memfinal));
@@ -113,6 +115,7 @@ bool machine_fits(const MachineTrace& t, const int* logh) {
   auto two = [&](int a, int b) { return ((size_t)1 << logh[a]) + ((size_t)1 << logh[b]); };
   auto one = [&](int a) { return (size_t)1 << logh[a]; };
   return t.cycles.size() <= two(kCpu, kCpu2) && t.alu_idx.size() <= two(kAlu, kAlu2) && t.sub_idx.size() <= two(kSub, kSub2) &&
+         t.bw_idx.size() <= two(kBw, kBw2) &&
          24 * t.keccak.size() <= one(kKeccak) && 50 * t.keccak.size() <= one(kKmem) && t.memfinal.size() <= one(kMemFinal) &&
          t.muls.size() <= one(kMul);
 }
@@ -182,11 +185,11 @@ int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineV
 }
 
 static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap_cycles, size_t cap_keccak, size_t cap_memfinal,
-                            size_t cap_muls, size_t cap_alu, size_t cap_sub) {
+                            size_t cap_muls, size_t cap_alu, size_t cap_sub, size_t cap_bw) {
   MachineWorkspace* w = ctx->mws.get();
   if (w && memcmp(w->logh, logh, sizeof w->logh) == 0 && w->batch >= batch && w->cap_cycles >= cap_cycles &&
       w->cap_keccak >= cap_keccak && w->cap_memfinal >= cap_memfinal && w->cap_muls >= cap_muls && w->cap_alu >= cap_alu &&
-      w->cap_sub >= cap_sub)
+      w->cap_sub >= cap_sub && w->cap_bw >= cap_bw)
     return 0;
   ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->mws.reset(new MachineWorkspace());
@@ -195,7 +198,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   w->batch = batch;
   w->cap_cycles = cap_cycles; w->cap_keccak = std::max<size_t>(cap_keccak, 1); w->cap_memfinal = cap_memfinal;
   w->cap_muls = std::max<size_t>(cap_muls, 1);
-  w->cap_alu = std::max<size_t>(cap_alu, 1); w->cap_sub = std::max<size_t>(cap_sub, 1);
+  w->cap_alu = std::max<size_t>(cap_alu, 1); w->cap_sub = std::max<size_t>(cap_sub, 1); w->cap_bw = std::max<size_t>(cap_bw, 1);
   const size_t B = (size_t)batch;
   const uint32_t Q = ctx->params.num_queries;
   bool ok = true;
@@ -207,6 +210,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   A(&w->muls, B * w->cap_muls * 3);
   A(&w->alu_idx, B * w->cap_alu);
   A(&w->sub_idx, B * w->cap_sub);
+  A(&w->bw_idx, B * w->cap_bw);
   A(&w->prog_mult, B << logh[kProgram]);
   A(&w->table_hist, (B * kTableWidth) << kTableLogH);
   A(&w->counts, B * kCountWords);
@@ -220,6 +224,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   A(&w->spare.muls, B * w->cap_muls * 3);
   A(&w->spare.alu_idx, B * w->cap_alu);
   A(&w->spare.sub_idx, B * w->cap_sub);
+  A(&w->spare.bw_idx, B * w->cap_bw);
   A(&w->spare.prog_mult, B << logh[kProgram]);
   A(&w->spare.counts, B * kCountWords);
   A(&w->spare.n_perms, B);
@@ -311,7 +316,7 @@ namespace {
 void swap_records(MachineWorkspace* w) {
   MachineWorkspace::SpareRecords& p = w->spare;
   std::swap(w->cycles, p.cycles); std::swap(w->memfinal, p.memfinal); std::swap(w->muls, p.muls);
-  std::swap(w->prog_mult, p.prog_mult); std::swap(w->alu_idx, p.alu_idx); std::swap(w->sub_idx, p.sub_idx);
+  std::swap(w->prog_mult, p.prog_mult); std::swap(w->alu_idx, p.alu_idx); std::swap(w->sub_idx, p.sub_idx); std::swap(w->bw_idx, p.bw_idx);
   std::swap(w->counts, p.counts);
   std::swap(w->kcalls, p.kcalls); std::swap(w->kstates, p.kstates); std::swap(w->n_perms, p.n_perms);
   std::swap(w->init_obs, p.init_obs); std::swap(w->pub_words, p.pub_words); std::swap(w->n, p.n);
@@ -347,14 +352,15 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
   // record capacities follow from the heights alone, so every batch of these heights fits the same workspace
   const size_t cc = ((size_t)1 << logh[kCpu]) + ((size_t)1 << logh[kCpu2]), cm = (size_t)1 << logh[kMemFinal], cu = (size_t)1 << logh[kMul],
                ck = std::min(((size_t)1 << logh[kKeccak]) / 24, ((size_t)1 << logh[kKmem]) / 50),
-               ca = ((size_t)1 << logh[kAlu]) + ((size_t)1 << logh[kAlu2]), cs = ((size_t)1 << logh[kSub]) + ((size_t)1 << logh[kSub2]);
+               ca = ((size_t)1 << logh[kAlu]) + ((size_t)1 << logh[kAlu2]), cs = ((size_t)1 << logh[kSub]) + ((size_t)1 << logh[kSub2]),
+               cb = ((size_t)1 << logh[kBw]) + ((size_t)1 << logh[kBw2]);
   if (logh[kCpu] > 20) return ctx->fail(9, "machine_load: more than 2^21 cycles");
   if (into_spare) {
     MachineWorkspace* w0 = ctx->mws.get();
     if (!w0 || memcmp(w0->logh, logh, sizeof w0->logh) != 0 || (size_t)w0->batch < n || !ctx->copy_stream)
       return ctx->fail(1, "machine_load: the spare set takes batches of the resident heights only");
   } else {
-    rc = workspace_ensure(ctx, logh, (int)std::max<size_t>(n, (size_t)ctx->batch_hint), cc, ck, cm, cu, ca, cs);
+    rc = workspace_ensure(ctx, logh, (int)std::max<size_t>(n, (size_t)ctx->batch_hint), cc, ck, cm, cu, ca, cs, cb);
     if (rc) return rc;
   }
   MachineWorkspace* w = ctx->mws.get();
@@ -375,7 +381,9 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     uint32_t* cn = &counts[kCountWords * i];
     cn[0] = (uint32_t)t.cycles.size(); cn[1] = (uint32_t)t.keccak.size();
     cn[2] = (uint32_t)t.memfinal.size(); cn[3] = (uint32_t)t.muls.size();
-    cn[4] = (uint32_t)t.alu_idx.size(); cn[5] = (uint32_t)t.sub_idx.size(); cn[6] = t.x0_last;
+    cn[4] = (uint32_t)t.alu_idx.size(); cn[5] = (uint32_t)t.sub_idx.size(); cn[6] = t.x0_last; cn[7] = (uint32_t)t.bw_idx.size();
+    if (!t.bw_idx.empty())
+      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->bw_idx + i * w->cap_bw, t.bw_idx.data(), t.bw_idx.size() * 4, hipMemcpyHostToDevice, s));
     if (!t.alu_idx.empty())
       ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->alu_idx + i * w->cap_alu, t.alu_idx.data(), t.alu_idx.size() * 4, hipMemcpyHostToDevice, s));
     if (!t.sub_idx.empty())
@@ -468,12 +476,12 @@ int machine_prove_resident(Context* ctx) {
   // ---- main traces ----
   MachineRecords rec;
   rec.cycles = w->cycles; rec.kcalls = w->kcalls; rec.memfinal = w->memfinal; rec.muls = w->muls;
-  rec.alu_idx = w->alu_idx; rec.sub_idx = w->sub_idx;
+  rec.alu_idx = w->alu_idx; rec.sub_idx = w->sub_idx; rec.bw_idx = w->bw_idx;
   rec.prog_mult = w->prog_mult; rec.counts = w->counts; rec.table_hist = w->table_hist;
   memset(rec.row0, 0, sizeof rec.row0);
-  rec.row0[kCpu2] = (uint32_t)1 << logh[kCpu]; rec.row0[kAlu2] = (uint32_t)1 << logh[kAlu]; rec.row0[kSub2] = (uint32_t)1 << logh[kSub];
+  rec.row0[kCpu2] = (uint32_t)1 << logh[kCpu]; rec.row0[kAlu2] = (uint32_t)1 << logh[kAlu]; rec.row0[kSub2] = (uint32_t)1 << logh[kSub]; rec.row0[kBw2] = (uint32_t)1 << logh[kBw];
   rec.cap_cycles = w->cap_cycles; rec.cap_keccak = w->cap_keccak; rec.cap_memfinal = w->cap_memfinal; rec.cap_muls = w->cap_muls;
-  rec.cap_alu = w->cap_alu; rec.cap_sub = w->cap_sub;
+  rec.cap_alu = w->cap_alu; rec.cap_sub = w->cap_sub; rec.cap_bw = w->cap_bw;
   rec.program = prep->program; rec.text_base = prep->text_base; rec.n_program = prep->n_program; rec.n_image = prep->n_image;
   rec.cpu_rows = ((uint32_t)1 << logh[kCpu]) + ((uint32_t)1 << logh[kCpu2]);
   {
@@ -489,7 +497,7 @@ int machine_prove_resident(Context* ctx) {
     }
     // the table chip answers what the others look up: count their RANGE / BYTES receives on their finished traces
     launch_table_clear(s, rec, B);
-    for (int c : {(int)kCpu, (int)kCpu2, (int)kKmem, (int)kMemFinal})
+    for (int c : {(int)kCpu, (int)kCpu2, (int)kKmem, (int)kMemFinal, (int)kBw, (int)kBw2})
       launch_table_count(s, static_cast<const Interaction*>(ctx->d_inter[c]), chip_def(c).n_inter, w->mat[c][0].tr, chip_def(c).main_w,
                          logh[c], rec, B);
     launch_table_trace(s, rec, w->mat[kTable][0].tr, B);

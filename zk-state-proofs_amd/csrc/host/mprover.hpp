@@ -32,11 +32,11 @@ struct PrepDevice {
 struct MachineWorkspace {
   int logh[mach::kNumChips] = {0};
   int batch = 0, n = 0;
-  size_t cap_cycles = 0, cap_keccak = 0, cap_memfinal = 0, cap_muls = 0, cap_alu = 0, cap_sub = 0;
+  size_t cap_cycles = 0, cap_keccak = 0, cap_memfinal = 0, cap_muls = 0, cap_alu = 0, cap_sub = 0, cap_bw = 0;
   const PrepDevice* prep = nullptr;
   // records
   uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *alu_idx = nullptr, *sub_idx = nullptr,
-           *counts = nullptr, *table_hist = nullptr;
+           *bw_idx = nullptr, *counts = nullptr, *table_hist = nullptr;
   uint8_t* kcalls = nullptr;
   uint64_t* kstates = nullptr;
   uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;
@@ -44,7 +44,7 @@ struct MachineWorkspace {
   // being proven, then machine_activate_spare() swaps the sets.
   struct SpareRecords {
     uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *alu_idx = nullptr, *sub_idx = nullptr,
-             *counts = nullptr;
+             *bw_idx = nullptr, *counts = nullptr;
     uint8_t* kcalls = nullptr;
     uint64_t* kstates = nullptr;
     uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;

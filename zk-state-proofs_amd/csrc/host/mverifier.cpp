@@ -190,6 +190,8 @@ void machine_prep_traces(const MachineProgram& prog, std::vector<uint32_t>* imag
     (*table_prep)[(size_t)TB_P_Y * ht + r] = (uint32_t)(r >> 8);
     (*table_prep)[(size_t)TB_P_NA * ht + r] = (r & 3) != 0;
     (*table_prep)[(size_t)TB_P_NT * ht + r] = r > kAddrHiMax;
+    (*table_prep)[(size_t)TB_P_XOR * ht + r] = (uint32_t)((r & 255) ^ (r >> 8));
+    (*table_prep)[(size_t)TB_P_AND * ht + r] = (uint32_t)((r & 255) & (r >> 8));
   }
   for (size_t r = 0; r < prog.image.size(); ++r) {
     (*image_prep)[(size_t)IMG_P_ADDR * hi + r] = prog.image[r].addr;
@@ -201,6 +203,7 @@ void machine_prep_traces(const MachineProgram& prog, std::vector<uint32_t>* imag
     const ProgramRow& p = prog.rows[r];
     uint32_t* q = program_prep->data() + r;
     q[(size_t)PR_PC * hp] = p.pc; q[(size_t)PR_CLS * hp] = (uint32_t)class_of(p.op); q[(size_t)PR_CODE * hp] = code_of(p.op);
+    q[(size_t)PR_UC * hp] = ucmp_of(p.op) ? 1u : 0u;
     q[(size_t)PR_WR * hp] = p.wr; q[(size_t)PR_USE2 * hp] = p.use2;
     q[(size_t)PR_RD * hp] = p.rd; q[(size_t)PR_RS1 * hp] = p.rs1; q[(size_t)PR_RS2 * hp] = p.rs2;
     q[(size_t)PR_IMM_LO * hp] = p.imm & 0xffff; q[(size_t)PR_IMM_HI * hp] = p.imm >> 16;
@@ -463,6 +466,8 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       case kAlu2: eval_alu(zc); break;
       case kSub:
       case kSub2: eval_sub(zc); break;
+      case kBw:
+      case kBw2: eval_bw(zc); break;
     }
     if (zc.k_ != nb) { *err = "internal: constraint count"; return 7; }
     // LogUp: row = [prep | main] at zeta
