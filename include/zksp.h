@@ -83,6 +83,12 @@ int zksp_vk_digest(const zksp_vk* vk, const uint8_t** ptr, size_t* len);
 zksp_stdin* zksp_stdin_new(void);
 int zksp_stdin_write(zksp_stdin* s, const uint8_t* buf, size_t len);
 void zksp_stdin_free(zksp_stdin* s);
+/* Aggregation payload (stage 1; the reference's circuits/sp1-merkle-proof-recursive/src/main.rs:3-5
+ * is a todo!()): besides the guest's run, the proof made from this stdin establishes the Poseidon2 Merkle root (2-to-1
+ * compressions) of `n` digests of 8 canonical field words each - e.g. the main-trace commitments of n leaf proofs, as the
+ * proof farm all-gathers them.  n: a power of two >= 2 (0 clears the payload).  The leaves are not part of the proof: the
+ * verifier names them (zksp_verify_aggregate) and the proof carries their root (zksp_proof_aggregation). */
+int zksp_stdin_set_aggregation(zksp_stdin* s, const uint32_t* leaves /* [n][8] */, size_t n);
 
 /* replaces client.prove(&pk, stdin).run()  (main.rs:71-74).  `stdin` is consumed
  * (emptied) as in the reference; pk is borrowed.  A guest panic (reference:
@@ -161,7 +167,7 @@ int zksp_mtrace_info(const zksp_mtrace* t, zksp_mtrace_info_t* info);
 /* Device-resident machine proving (bench.py, parity tests): upload the records of n traced runs (they are proven
  * with one shape: zksp_machine_cover_heights), enqueue one proving pass, fetch the proof bodies ([n][body_words]
  * canonical u32; body_words = zksp_machine_body_words of that shape). */
-#define ZKSP_MACHINE_CHIPS 15   /* cpu, keccak, keccak-mem, mem-final, image, program, mul, table, cpu2, alu, alu2, subword, subword2, bitwise, bitwise2 */
+#define ZKSP_MACHINE_CHIPS 16   /* cpu, keccak, keccak-mem, mem-final, image, program, mul, table, cpu2, alu, alu2, subword, subword2, bitwise, bitwise2, poseidon2 */
 int zksp_mtrace_heights(const zksp_mtrace* t, int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 size_t zksp_machine_body_words(const zksp_client* c, const int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 /* The shape a batch of these runs is proven with: the chip heights that cover the largest cycle / event / address
@@ -176,6 +182,11 @@ int zksp_hip_machine_prove(zksp_client* c);
 int zksp_hip_machine_fetch_bodies(zksp_client* c, uint32_t* out, size_t cap_words);
 /* Only the 8-word main-trace commitment of every resident proof ([n][8]): what the proof farm all-gathers. */
 int zksp_hip_machine_fetch_roots(zksp_client* c, uint32_t* out, size_t cap_words);
+/* The aggregation payload of a machine proof: leaf count (0: none) and the proven Merkle root. */
+int zksp_proof_aggregation(const zksp_proof* p, uint32_t* n_leaves, uint32_t* root8);
+/* client.verify for a proof with an aggregation payload: additionally, the root in the proof is the Poseidon2 Merkle root of
+ * exactly these leaves.  (zksp_verify refuses such a proof: it cannot vouch for a root whose leaves it was not given.) */
+int zksp_verify_aggregate(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const uint32_t* leaves /* [n][8] */, size_t n);
 /* Kernel-level parity (tests): after zksp_hip_machine_prove, one intermediate matrix of resident proof `proof_index`, as
  * canonical u32, column-major [width][2^log_height]: stage 0 = a chip's main trace (trace expansion kernels; table chip:
  * the counted multiplicities), 1 = its LogUp permutation trace (helper columns + running sum), 2 = its quotient values

@@ -102,7 +102,7 @@ static orc_lf lf_bits(int bits, int n) {
 
 #define CPU_INTER 22
 static orc_inter g_cpu[CPU_INTER], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7],
-    g_alu[1], g_sub[1], g_bw[5];
+    g_alu[1], g_sub[1], g_bw[5], g_p2[3];
 static orc_chip g_chips[N_CHIPS];
 static int g_ready = 0;
 
@@ -335,6 +335,27 @@ static void build(void) {
       it->el[1] = lf_col(BW_B + i); it->el[2] = lf_col(BW_C + i); it->el[3] = lf_col(BW_A + i);
     }
   }
+  /* ---- Poseidon2: children in, parent out; the output digest is the external linear layer applied to the last round's
+   * S-box outputs (circ(2 M4, M4, M4, M4), M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]]) ---- */
+  {
+    static const uint32_t m4[4][4] = {{2, 3, 1, 1}, {1, 2, 3, 1}, {1, 1, 2, 3}, {3, 1, 1, 2}};
+    const int ylast = P2_EXT + 32 * 7 + 16;
+    for (int side = 0; side < 2; ++side) {
+      orc_inter* it = &g_p2[side];
+      memset(it, 0, sizeof *it);
+      it->bus = BUS_DIGEST; it->sign = -1; it->mult = lf_col(P2_IS_REAL); it->n_el = 9;
+      lf_zero(&it->el[0]); lf_add(&it->el[0], P2_K, 2); it->el[0].c0 = (uint32_t)side;
+      for (int j = 0; j < 8; ++j) it->el[1 + j] = lf_col(P2_IN + 8 * side + j);
+    }
+    orc_inter* it = &g_p2[2];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_DIGEST; it->sign = +1; it->mult = lf_col(P2_IS_REAL); it->n_el = 9;
+    it->el[0] = lf_col(P2_K);
+    for (int j = 0; j < 8; ++j) {
+      lf_zero(&it->el[1 + j]);
+      for (int i = 0; i < 16; ++i) lf_add(&it->el[1 + j], ylast + i, m4[j & 3][i & 3] * ((i >> 2) == (j >> 2) ? 2u : 1u));
+    }
+  }
   /* ---- sub-word ---- */
   {
     static const uint32_t codes[6] = {OP_LB, OP_LH, OP_LBU, OP_LHU, OP_SB, OP_SH};
@@ -363,6 +384,7 @@ static void build(void) {
   g_chips[CH_SUB2] = (orc_chip){"subword2", 0, SUB_WIDTH, 1, g_sub, 0};
   g_chips[CH_BW] = (orc_chip){"bitwise", 0, BW_WIDTH, 5, g_bw, 0};
   g_chips[CH_BW2] = (orc_chip){"bitwise2", 0, BW_WIDTH, 5, g_bw, 0};
+  g_chips[CH_P2] = (orc_chip){"poseidon2", 0, P2CHIP_WIDTH, 3, g_p2, 0};
   g_ready = 1;
   for (int c = 0; c < N_CHIPS; ++c) g_chips[c].n_constraints = count_constraints(c);
 }
@@ -455,6 +477,7 @@ void orc_machine_heights(const orc_machine_input* in, int logh[N_CHIPS]) {
   logh[CH_PROGRAM] = in->log_prog;
   logh[CH_MUL] = at_least5(clog2(in->n_muls));
   logh[CH_TABLE] = TABLE_LOG_H;
+  logh[CH_P2] = at_least5(clog2(in->n_agg > 1 ? in->n_agg - 1 : 1));
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -810,6 +833,43 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
         put_bits(t, h, r, MU_Q0, (uint32_t)q0, 10); put_bits(t, h, r, MU_Q1, (uint32_t)q1, 11); put_bits(t, h, r, MU_Q2, (uint32_t)q2, 10);
       }
       break;
+    case CH_P2: {
+      /* heap of digests: leaves at n .. 2n - 1, node K = compress(2K, 2K + 1) */
+      const size_t na = in->n_agg;
+      uint32_t* heap = (uint32_t*)calloc(16 * (na ? na : 1), 4);
+      if (na) {
+        memcpy(heap + 8 * na, in->agg_leaves, 32 * na);
+        for (size_t k = na - 1; k >= 1; --k) orc_compress(heap + 16 * k, heap + 16 * k + 8, heap + 8 * k);
+      }
+      uint32_t ext_rc[8][16], int_rc[13];
+      orc_poseidon2_constants(&ext_rc[0][0], int_rc);
+      for (size_t r = 0; r < h; ++r) {
+        const size_t k = r + 1;
+        uint32_t st[16] = {0};
+        T(P2_K) = (uint32_t)k;
+        if (na && k < na) { T(P2_IS_REAL) = 1; memcpy(st, heap + 16 * k, 64); }
+        for (int i = 0; i < 16; ++i) T(P2_IN + i) = st[i];
+        orc_p2_external_linear(st);
+        for (int rd = 0; rd < 8; ++rd) {
+          if (rd == 4) /* the 13 internal rounds sit between the two halves of the external ones */
+            for (int ir = 0; ir < 13; ++ir) {
+              const fe x = f_add(st[0], int_rc[ir]), x3 = f_mul(f_mul(x, x), x), y = f_mul(f_mul(x3, x3), x);
+              T(P2_INT + 2 * ir) = x3; T(P2_INT + 2 * ir + 1) = y;
+              st[0] = y;
+              orc_p2_internal_linear(st);
+            }
+          for (int i = 0; i < 16; ++i) {
+            const fe x = f_add(st[i], ext_rc[rd][i]), x3 = f_mul(f_mul(x, x), x), y = f_mul(f_mul(x3, x3), x);
+            T(P2_EXT + 32 * rd + i) = x3; T(P2_EXT + 32 * rd + 16 + i) = y;
+            st[i] = y;
+          }
+          orc_p2_external_linear(st);
+        }
+        if (na && k < na && memcmp(st, heap + 8 * k, 32) != 0) abort(); /* the row's permutation is the node's compression */
+      }
+      free(heap);
+      break;
+    }
     case CH_TABLE:
       for (size_t r = 0; r < h; ++r) {
         prep[(size_t)TB_P_X * h + r] = (uint32_t)(r & 255);
@@ -1083,6 +1143,36 @@ static void bw_constraints(const uint32_t* l, sink* s) {
   emit(s, f_sub(selsum, l[BW_IS_REAL]));
 }
 
+/* Poseidon2 chip: every S-box through its cube; the state between S-boxes is linear in the columns */
+static void p2_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe is_trans, sink* s) {
+  uint32_t ext_rc[8][16], int_rc[13];
+  orc_poseidon2_constants(&ext_rc[0][0], int_rc);
+  emit(s, bool_c(l[P2_IS_REAL]));
+  emit(s, f_mul(is_first, f_sub(l[P2_K], 1)));
+  emit(s, f_mul(is_trans, f_sub(f_sub(n[P2_K], l[P2_K]), 1)));
+  emit(s, f_mul(f_mul(is_trans, n[P2_IS_REAL]), f_sub(1, l[P2_IS_REAL]))); /* the real rows are a prefix */
+  fe st[16];
+  for (int i = 0; i < 16; ++i) st[i] = l[P2_IN + i];
+  orc_p2_external_linear(st);
+  for (int rd = 0; rd < 8; ++rd) {
+    if (rd == 4)
+      for (int ir = 0; ir < 13; ++ir) {
+        const fe x = f_add(st[0], int_rc[ir]), x3 = l[P2_INT + 2 * ir], y = l[P2_INT + 2 * ir + 1];
+        emit(s, f_sub(x3, f_mul(f_mul(x, x), x)));
+        emit(s, f_sub(y, f_mul(f_mul(x3, x3), x)));
+        st[0] = y;
+        orc_p2_internal_linear(st);
+      }
+    for (int i = 0; i < 16; ++i) {
+      const fe x = f_add(st[i], ext_rc[rd][i]), x3 = l[P2_EXT + 32 * rd + i], y = l[P2_EXT + 32 * rd + 16 + i];
+      emit(s, f_sub(x3, f_mul(f_mul(x, x), x)));
+      emit(s, f_sub(y, f_mul(f_mul(x3, x3), x)));
+      st[i] = y;
+    }
+    orc_p2_external_linear(st);
+  }
+}
+
 /* sub-word chip: M is the memory word, C the low limb of the stored register, both as bits */
 static void sub_constraints(const uint32_t* l, sink* s) {
   enum { LB = 0, LH, LBU, LHU, SB, SH };
@@ -1144,6 +1234,7 @@ static void run_constraints(int chip, const uint32_t* prep, const uint32_t* loc,
     case CH_MUL: mul_constraints(loc, s); break;
     case CH_BW:
     case CH_BW2: bw_constraints(loc, s); break;
+    case CH_P2: p2_constraints(loc, nxt, is_first, is_trans, s); break;
     case CH_TABLE: /* only multiples of 4 answer aligned lookups, only values up to ADDR_HI_MAX high-address-limb lookups */
       emit(s, f_mul(loc[TB_M_AL], prep[TB_P_NA]));
       emit(s, f_mul(loc[TB_M_TOP], prep[TB_P_NT]));

@@ -39,7 +39,7 @@ extern "C" {
  * 391 400 cycles take 2^18 + 2^17 rows, not 2^19. */
 enum {
   CH_CPU = 0, CH_KECCAK, CH_KMEM, CH_MEMFINAL, CH_IMAGE, CH_PROGRAM, CH_MUL, CH_TABLE, CH_CPU2, CH_ALU, CH_ALU2, CH_SUB,
-  CH_SUB2, CH_BW, CH_BW2, N_CHIPS
+  CH_SUB2, CH_BW, CH_BW2, CH_P2, N_CHIPS
 };
 
 /* ---- opcodes: Program table column CODE, and the op element of the ALU / sub-word bus tuples ---- */
@@ -117,6 +117,14 @@ enum {
   SW_A = SW_O + 4, SW_M = SW_A + 2 /* 32 bits */, SW_C = SW_M + 32 /* 16 bits: low limb of the stored register */,
   SW_MV = SW_C + 16, SUB_WIDTH = SW_MV + 2
 };
+/* ---- Poseidon2 chip (row f4, stage 1): one width-16 permutation per row = one 2-to-1 compression of a Merkle tree of
+ *      8-word digests.  Row r holds heap node K = r + 1 (root 1, children 2K and 2K + 1, the n leaves at n .. 2n - 1): it
+ *      consumes its children's digests from the DIGEST bus and produces its own; the verifier supplies the leaves and
+ *      takes the root.  Columns: the input state, and per S-box its cube and its seventh power (degree <= 3). ---- */
+enum {
+  P2_IS_REAL = 0, P2_K, P2_IN /* 16 */, P2_EXT = P2_IN + 16 /* 8 external rounds x (16 cubes, 16 outputs) */,
+  P2_INT = P2_EXT + 256 /* 13 internal rounds x (cube, output) */, P2CHIP_WIDTH = P2_INT + 26
+};
 /* ---- table chip: 2^16 rows; preprocessed (x = low byte, y = high byte, na = row index not a multiple of 4,
  *      nt = row index above ADDR_HI_MAX, x ^ y, x & y); main: multiplicities of range16 (kind 0), 4-aligned range16
  *      (kind 1), high address limb (kind 2: at most ADDR_HI_MAX), byte pair, and the byte operations xor / or / and ---- */
@@ -126,7 +134,7 @@ enum { TB_M_R16 = 0, TB_M_AL, TB_M_TOP, TB_M_BY, TB_M_XOR, TB_M_OR, TB_M_AND, TA
 #define ADDR_HI_MAX 0x77FFu /* high limb of the largest address / jump target: values stay below 0x78000000 < p */
 
 /* ---- buses ---- */
-enum { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP };
+enum { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP, BUS_DIGEST };
 
 /* A linear form over the row [preprocessed | main]: c0 + sum coef[i] * row[col[i]] (canonical words). */
 #define LF_MAX 40
@@ -158,6 +166,8 @@ typedef struct {
   const uint32_t* prog_mult;                   /* n_program; the padding row holds 0 (its fetches depend on the heights) */
   const int* shape;                            /* NULL: the minimal heights; else N_CHIPS log heights the run fits (a batch of
                                                   runs is proven with one shape: the heights of their largest counts) */
+  const uint32_t* agg_leaves; size_t n_agg;    /* aggregation payload: n_agg (0, or a power of two >= 2) digests of 8 words
+                                                  whose Poseidon2 Merkle root the proof also establishes */
 } orc_machine_input;
 
 /* The oracle's own event lists (cycle indices of the ALU-chip and sub-word-chip rows, in execution order) and the
@@ -192,6 +202,9 @@ typedef struct {
   uint32_t pv_digest[8];
   uint32_t deferred_digest[8];
 } orc_machine_public;
+/* the aggregation payload's public part: Merkle root of the leaves (2-to-1 Poseidon2 compressions) and the sponge hash
+ * of the leaf list, which stands for the list in the transcript */
+void orc_machine_agg_public(const uint32_t* leaves, size_t n, uint32_t root[8], uint32_t list_digest[8]);
 #define ZKSP_VERSION_MACHINE 6u
 /* vk: preprocessed commitment root + digest binding entry pc, table heights and keccak mode */
 void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t prep_root[8], uint32_t vk_digest[8]);

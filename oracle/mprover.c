@@ -415,6 +415,8 @@ void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t pr
   orc_machine_input tmp = *in;
   tmp.prog_mult = NULL;
   tmp.shape = NULL;
+  tmp.agg_leaves = NULL;
+  tmp.n_agg = 0;
   tmp.n_cycles = tmp.n_keccak = tmp.n_memfinal = tmp.n_muls = 0;
   init_chips(&tmp, cd, 1);
   mmcs t;
@@ -425,7 +427,25 @@ void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t pr
   free_chips(cd);
 }
 
-#define HEADER_WORDS (2 + N_CHIPS + 2 + 24 + 1) /* magic, version, heights, exit code, pv length, 3 digests, hand-over pc */
+/* magic, version, heights, exit code, pv length, 3 digests, hand-over pc; aggregation: leaf count, root, digest of the leaf list */
+#define HEADER_WORDS (2 + N_CHIPS + 2 + 24 + 1 + 17)
+
+void orc_machine_agg_public(const uint32_t* leaves, size_t n, uint32_t root[8], uint32_t list_digest[8]) {
+  memset(root, 0, 32);
+  memset(list_digest, 0, 32);
+  if (n == 0) return;
+  uint32_t* level = (uint32_t*)malloc(32 * n);
+  memcpy(level, leaves, 32 * n);
+  for (size_t cnt = n; cnt > 1; cnt >>= 1)
+    for (size_t i = 0; i < cnt / 2; ++i) {
+      uint32_t d[8];
+      orc_compress(level + 16 * i, level + 16 * i + 8, d);
+      memcpy(level + 8 * i, d, 32);
+    }
+  memcpy(root, level, 32);
+  free(level);
+  orc_hash_elems(leaves, 8 * n, list_digest);
+}
 
 size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_image, const orc_config* cfg, uint32_t pv_len) {
   (void)log_prog; (void)log_image;
@@ -461,6 +481,9 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   int lm = 0; /* the tallest chip: every tree and the FRI start from its height */
   for (int c = 0; c < N_CHIPS; ++c)
     if (logh[c] > lm) lm = logh[c];
+  if (in->n_agg == 1 || (in->n_agg & (in->n_agg - 1))) return 1; /* the aggregation payload is a power of two of leaves, or empty */
+  uint32_t agg_n = (uint32_t)in->n_agg, agg_root[8], agg_digest[8];
+  orc_machine_agg_public(in->agg_leaves, in->n_agg, agg_root, agg_digest);
   uint32_t cpu_pub[N_CHIPS][CPUPUB_N];
   memset(cpu_pub, 0, sizeof cpu_pub);
   orc_machine_cpu_pub(in, CH_CPU, cpu_pub[CH_CPU]);
@@ -486,6 +509,9 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
     put(&pb, pub->deferred_digest, 8);
     put(&pb, vk, 8);
     put(&pb, &cpu_pub[CH_CPU][CPUPUB_END_PC], 1);
+    put(&pb, &agg_n, 1);
+    put(&pb, agg_root, 8);
+    put(&pb, agg_digest, 8);
     size_t pw = (pub->pv_len + 3) / 4;
     uint32_t* tmp = (uint32_t*)calloc(pw ? pw : 1, 4);
     memcpy(tmp, public_values, pub->pv_len);
@@ -501,6 +527,9 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   observe_word_halves(&ch, pub->pv_digest, 8);
   observe_word_halves(&ch, pub->deferred_digest, 8);
   observe_word_halves(&ch, &cpu_pub[CH_CPU][CPUPUB_END_PC], 1);
+  orc_ch_observe(&ch, agg_n);
+  orc_ch_observe_many(&ch, agg_root, 8);
+  orc_ch_observe_many(&ch, agg_digest, 8);
   orc_ch_observe_many(&ch, mmcs_root(&t_main), 8);
   put(&pb, mmcs_root(&t_main), 8);
 
@@ -539,6 +568,16 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
     it.el[1].n = 0; it.el[1].c0 = pub->exit_code >> 16;
     build_aff(&it, gamma, bpow, &a);
     total = e_sub(total, e_inv(a.c0));
+    /* ... and the digest bus of the aggregation payload: the verifier hands in the leaves (heap nodes n .. 2n - 1) and
+     * takes the root (node 1) */
+    it.bus = BUS_DIGEST; it.n_el = 9;
+    for (size_t i = 0; i <= in->n_agg && in->n_agg; ++i) {
+      const uint32_t* d = i < in->n_agg ? in->agg_leaves + 8 * i : agg_root;
+      it.el[0].n = 0; it.el[0].c0 = i < in->n_agg ? (uint32_t)(in->n_agg + i) : 1u;
+      for (int j = 0; j < 8; ++j) { it.el[1 + j].n = 0; it.el[1 + j].c0 = d[j]; }
+      build_aff(&it, gamma, bpow, &a);
+      total = i < in->n_agg ? e_add(total, e_inv(a.c0)) : e_sub(total, e_inv(a.c0));
+    }
   }
   if (!e_eq(total, e_zero())) {
     if (getenv("ZKSP_ORACLE_TIMING")) {

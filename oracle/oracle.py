@@ -280,9 +280,9 @@ def prove(states_in: np.ndarray, logh: int, *, exit_code: int = 0, public_values
 # ---------------------------------------------------------------------------
 # machine proof (oracle/machine.h): inputs are the arrays ProverClient.machine_trace() returns
 # ---------------------------------------------------------------------------
-N_CHIPS = 15
+N_CHIPS = 16
 CHIP_NAMES = ["cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "table", "cpu2", "alu", "alu2",
-              "subword", "subword2", "bitwise", "bitwise2"]
+              "subword", "subword2", "bitwise", "bitwise2", "poseidon2"]
 CPUPUB_N = 5
 
 
@@ -296,7 +296,7 @@ class MachineInput(C.Structure):
                 ("entry", C.c_uint32), ("text_base", C.c_uint32), ("log_prog", C.c_int), ("log_image", C.c_int),
                 ("cycles", C.c_void_p), ("n_cycles", C.c_size_t), ("keccak", C.c_void_p), ("n_keccak", C.c_size_t),
                 ("memfinal", C.c_void_p), ("n_memfinal", C.c_size_t), ("muls", C.c_void_p), ("n_muls", C.c_size_t),
-                ("prog_mult", C.c_void_p), ("shape", C.c_void_p)]
+                ("prog_mult", C.c_void_p), ("shape", C.c_void_p), ("agg_leaves", C.c_void_p), ("n_agg", C.c_size_t)]
 
 
 class MachinePublic(C.Structure):
@@ -306,7 +306,8 @@ class MachinePublic(C.Structure):
 
 def machine_input(t: dict):
     """MachineInput over the arrays of a machine trace; returns (struct, keep-alive list).  ``t["shape"]`` (optional):
-    the chip log-heights to prove the run with (a batch shares one shape); default: the run's own minimal heights."""
+    the chip log-heights to prove the run with (a batch shares one shape); default: the run's own minimal heights.
+    ``t["agg_leaves"]`` (optional, [n][8] canonical words, n a power of two): the aggregation payload."""
     keep = {k: np.ascontiguousarray(t[k]) for k in ("program", "image", "cycles", "keccak", "memfinal", "muls",
                                                     "prog_mult")}
     info = t["info"]
@@ -314,7 +315,11 @@ def machine_input(t: dict):
                       info.entry, int(keep["program"][0, 0]), info.log_prog, info.log_image,
                       _p(keep["cycles"]), len(keep["cycles"]), _p(keep["keccak"]), len(keep["keccak"]),
                       _p(keep["memfinal"]), len(keep["memfinal"]), _p(keep["muls"]), len(keep["muls"]),
-                      _p(keep["prog_mult"]), None)
+                      _p(keep["prog_mult"]), None, None, 0)
+    if t.get("agg_leaves") is not None and len(t["agg_leaves"]):
+        keep["agg_leaves"] = np.ascontiguousarray(t["agg_leaves"], dtype=np.uint32).reshape(-1, 8)
+        mi.agg_leaves = keep["agg_leaves"].ctypes.data
+        mi.n_agg = len(keep["agg_leaves"])
     if t.get("shape") is not None:
         keep["shape"] = np.ascontiguousarray(t["shape"], dtype=np.int32)
         assert len(keep["shape"]) == N_CHIPS
@@ -393,6 +398,14 @@ def machine_stage_quotient(t: dict, chip: int, alpha, gamma, beta) -> np.ndarray
     quot = np.zeros((8, h), np.uint32)
     lib().orc_machine_stage_quotient(C.byref(mi), chip, _p(_u32(alpha)), _p(_u32(gamma)), _p(_u32(beta)), _p(quot))
     return quot
+
+
+def machine_agg_public(leaves):
+    """(Merkle root, digest of the leaf list) of an aggregation payload [n][8]."""
+    lv = np.ascontiguousarray(leaves, dtype=np.uint32).reshape(-1, 8)
+    root, dg = np.zeros(8, np.uint32), np.zeros(8, np.uint32)
+    lib().orc_machine_agg_public(_p(lv), C.c_size_t(len(lv)), _p(root), _p(dg))
+    return [int(x) for x in root], [int(x) for x in dg]
 
 
 def machine_setup(t: dict):

@@ -125,6 +125,10 @@ static void internal_linear(fe* s) {
   for (int i = 0; i < 16; ++i) s[i] = f_add(f_mul(s[i], g_int_diag[i]), sum);
 }
 
+/* the two linear layers, for the Poseidon2 chip of the machine proof (machine.c) */
+void orc_p2_external_linear(uint32_t* s) { external_linear(s); }
+void orc_p2_internal_linear(uint32_t* s) { init_constants(); internal_linear(s); }
+
 void orc_poseidon2_permute(uint32_t* s) {
   init_constants();
   external_linear(s);

@@ -203,3 +203,66 @@ def test_prove_batch_of_128_acct_d8(zk, fx, oracle):
     roots = np.array([farm.trace_root_of(p.to_bytes()) for p in proofs], np.uint32)
     assert roots.shape == (n, 8) and len({tuple(r) for r in roots}) == n
     assert np.array_equal(farm.gather_roots(roots, n, 0, 1), roots)
+
+
+def test_aggregation_payload_matches_oracle(zk, fx, oracle):
+    """Row f4, stage 1 on the device: proofs with an aggregation payload (the Poseidon2 chip: p2_trace_kernel,
+    machine_quotient_kernel<poseidon2>, the DIGEST bus) byte-identical to the oracle's, in one batch with a proof that has
+    none (one shape covers both), verified with and only with their leaves."""
+    nq, pw = 8, 6
+    client = zk.ProverClient(device=0, num_queries=nq, pow_bits=pw, max_batch=3)
+    pk, vk = client.setup(zk.merkle_elf())
+    rng = np.random.default_rng(21)
+    payloads = [rng.integers(0, 2013265921, (64, 8), dtype=np.uint32), None, rng.integers(0, 2013265921, (2, 8), dtype=np.uint32)]
+    handles, traces = [], []
+    for i, lv in enumerate(payloads):
+        s = zk.SP1Stdin()
+        s.write(fx.acct_fixture(1, seed=30 + i).to_borsh())
+        if lv is not None:
+            s.set_aggregation(lv)
+        handles.append(client.machine_trace_handle(pk, s))
+        t = client.machine_trace(pk, s)
+        if lv is not None:
+            t["agg_leaves"] = lv
+        traces.append(t)
+    shape = zk.machine_cover_heights(handles)
+    assert shape[zk.MACHINE_CHIP_NAMES.index("poseidon2")] == 6  # 63 inner nodes of the 64-leaf tree
+    bodies = client.machine_prove_resident(pk, handles)
+    host = zk.ProverClient(device=-1, num_queries=nq, pow_bits=pw)
+    for i, lv in enumerate(payloads):
+        proof = handles[i].proof_from_body(pk, bodies[i], shape)
+        assert proof.to_bytes() == oracle.machine_prove(dict(traces[i], shape=shape), num_queries=nq, pow_bits=pw), i
+        if lv is None:
+            host.verify(proof, vk)
+        else:
+            assert proof.aggregation == (len(lv), oracle.machine_agg_public(lv)[0])
+            host.verify_aggregate(proof, vk, lv)
+            with pytest.raises(zk.VerificationError):
+                host.verify(proof, vk)
+
+
+def test_aggregate_1024_commitments(zk, fx, oracle):
+    """BASELINE config 5's shape end to end through the drop-in calls: prove leaf proofs, gather their 32-byte main-trace
+    commitments in proof order (what the farm all-gathers), and prove ONE more run whose aggregation payload is the whole
+    list - its root is then a proven Poseidon2 Merkle root of the 1024 commitments (here: 32 real commitments repeated,
+    to keep the test short; bench.py does it with 1024 proofs)."""
+    farm = __import__("importlib").import_module("zk-state-proofs_amd.farm")
+    client = zk.ProverClient(device=0, max_batch=32)
+    pk, vk = client.setup(zk.merkle_elf())
+    stdins = []
+    for i in range(32):
+        s = zk.SP1Stdin()
+        s.write(fx.acct_fixture(1, seed=900 + i).to_borsh())
+        stdins.append(s)
+    proofs, status = client.prove_batch(pk, stdins)
+    assert status == [0] * 32
+    roots = np.array([farm.trace_root_of(p.to_bytes()) for p in proofs], np.uint32)
+    leaves = np.tile(roots, (32, 1))
+    assert leaves.shape == (1024, 8)
+    s = zk.SP1Stdin()
+    s.write(fx.acct_fixture(1, seed=999).to_borsh())
+    s.set_aggregation(leaves)
+    agg = client.prove(pk, s).run()
+    n, root = agg.aggregation
+    assert n == 1024 and root == oracle.machine_agg_public(leaves)[0]
+    zk.ProverClient(device=-1).verify_aggregate(agg, vk, leaves)

@@ -32,9 +32,11 @@ PROOF_MACHINE, PROOF_KECCAK_CHIP = 1, 2
 # machine proof (format version 6): chips in proof order and the fixed header in front of the public values
 MACHINE_VERSION = 6
 MACHINE_CHIP_NAMES = ("cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "table", "cpu2", "alu", "alu2",
-                      "subword", "subword2", "bitwise", "bitwise2")
+                      "subword", "subword2", "bitwise", "bitwise2", "poseidon2")
 MACHINE_CHIPS = len(MACHINE_CHIP_NAMES)
-MACHINE_HEADER_WORDS = 2 + MACHINE_CHIPS + 2 + 24 + 1  # .. the last word is the hand-over pc of the two CPU instances
+# magic, version, heights, exit code, pv length, three digests, the hand-over pc of the two CPU instances, the aggregation
+# payload's leaf count, root and leaf-list digest
+MACHINE_HEADER_WORDS = 2 + MACHINE_CHIPS + 2 + 24 + 1 + 17
 
 
 class ZkspError(RuntimeError):
@@ -130,6 +132,9 @@ def load_library() -> C.CDLL:
     lib.zksp_hip_machine_fetch_roots.argtypes = [vp, vp, sz]
     lib.zksp_machine_proof_from_body.argtypes = [vp, vp, vp, vp, sz, C.POINTER(vp)]
     lib.zksp_machine_cover_heights.argtypes = [vp, sz, vp]
+    lib.zksp_stdin_set_aggregation.argtypes = [vp, vp, sz]
+    lib.zksp_proof_aggregation.argtypes = [vp, vp, vp]
+    lib.zksp_verify_aggregate.argtypes = [vp, vp, vp, vp, sz]
     lib.zksp_hip_machine_fetch_stage.argtypes = [vp, C.c_int, C.c_int, sz, vp, sz]
     lib.zksp_hip_machine_fetch_challenges.argtypes = [vp, sz, vp]
     lib.zksp_get_params.argtypes = [vp, C.POINTER(Params)]
@@ -171,7 +176,7 @@ ABI_SYMBOLS = [
     "zksp_proof_public_values", "zksp_proof_serialize", "zksp_proof_deserialize", "zksp_proof_free", "zksp_verify",
     "zksp_execute", "zksp_execute_keccak", "zksp_opcode_name", "zksp_machine_trace", "zksp_mtrace_free",
     "zksp_mtrace_section", "zksp_mtrace_info", "zksp_vk_machine", "zksp_mtrace_heights", "zksp_machine_body_words",
-    "zksp_machine_chip_widths", "zksp_machine_cover_heights", "zksp_hip_machine_fetch_stage", "zksp_hip_machine_fetch_challenges",
+    "zksp_machine_chip_widths", "zksp_machine_cover_heights", "zksp_stdin_set_aggregation", "zksp_proof_aggregation", "zksp_verify_aggregate", "zksp_hip_machine_fetch_stage", "zksp_hip_machine_fetch_challenges",
     "zksp_hip_machine_load", "zksp_hip_machine_prove", "zksp_hip_machine_fetch_bodies", "zksp_hip_machine_fetch_roots", "zksp_machine_proof_from_body", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
     "zksp_hip_prove_resident", "zksp_proof_from_body", "zksp_hip_fetch_bodies", "zksp_hip_fetch_roots", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
     "zksp_hip_profile_enable", "zksp_hip_profile_read", "zksp_hip_profile_reset", "zksp_dev_malloc", "zksp_dev_free",
@@ -194,6 +199,15 @@ class SP1Stdin:
         rc = self._lib.zksp_stdin_write(self._h, bytes(buf), len(buf))
         if rc:
             raise ZkspError(rc, "stdin.write")
+
+    def set_aggregation(self, leaves) -> None:
+        """Aggregation payload (``zksp_stdin_set_aggregation``): the proof made from this stdin also establishes the
+        Poseidon2 Merkle root of ``leaves`` ([n][8] canonical field words, n a power of two >= 2)."""
+        import numpy as np
+        lv = np.ascontiguousarray(leaves, dtype=np.uint32).reshape(-1, 8)
+        rc = self._lib.zksp_stdin_set_aggregation(self._h, lv.ctypes.data_as(C.c_void_p), len(lv))
+        if rc:
+            raise ZkspError(rc, "stdin_set_aggregation")
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -239,6 +253,15 @@ class SP1ProofWithPublicValues(_Handle):
         if rc:
             raise ZkspError(rc, "public_values")
         return bytes(p[: n.value])
+
+    @property
+    def aggregation(self):
+        """(number of leaves, proven Merkle root as 8 canonical words) of the aggregation payload; (0, zeros) if none."""
+        n, root = C.c_uint32(), (C.c_uint32 * 8)()
+        rc = self._lib.zksp_proof_aggregation(self._h, C.byref(n), root)
+        if rc:
+            raise ZkspError(rc, "proof_aggregation")
+        return int(n.value), [int(x) for x in root]
 
     def to_bytes(self) -> bytes:
         p, n = C.POINTER(C.c_uint8)(), C.c_size_t()
@@ -399,6 +422,15 @@ class ProverClient:
 
     def verify(self, proof: SP1ProofWithPublicValues, vk: VerifyingKey) -> None:
         rc = self._lib.zksp_verify(self._h, proof._h, vk._h)
+        if rc:
+            raise VerificationError(rc, self.last_error())
+
+    def verify_aggregate(self, proof: SP1ProofWithPublicValues, vk: VerifyingKey, leaves) -> None:
+        """``verify`` for a proof with an aggregation payload: additionally, ``proof.aggregation``'s root is the Poseidon2
+        Merkle root of exactly these leaves ([n][8] canonical words)."""
+        import numpy as np
+        lv = np.ascontiguousarray(leaves, dtype=np.uint32).reshape(-1, 8)
+        rc = self._lib.zksp_verify_aggregate(self._h, proof._h, vk._h, lv.ctypes.data_as(C.c_void_p), len(lv))
         if rc:
             raise VerificationError(rc, self.last_error())
 

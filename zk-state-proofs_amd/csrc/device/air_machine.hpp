@@ -19,13 +19,14 @@
 // addresses / jump targets stay below 0x78000000 < p, so no bus compares two 32-bit values that alias mod p.
 #pragma once
 #include "air_keccak.hpp"
+#include "poseidon2.hpp"
 
 namespace zksp {
 namespace mach {
 
 // CPU, ALU and sub-word rows are each split over two instances of one AIR: the first has the largest power of two of
 // rows strictly below the count, the second the rest (a power of two again): 391 400 cycles take 2^18 + 2^17 rows.
-enum Chip { kCpu = 0, kKeccak, kKmem, kMemFinal, kImage, kProgram, kMul, kTable, kCpu2, kAlu, kAlu2, kSub, kSub2, kBw, kBw2, kNumChips };
+enum Chip { kCpu = 0, kKeccak, kKmem, kMemFinal, kImage, kProgram, kMul, kTable, kCpu2, kAlu, kAlu2, kSub, kSub2, kBw, kBw2, kP2, kNumChips };
 // public scalars of a CPU instance: pc and time of its first row, whether another instance continues it, the pc
 // that one starts at (the hand-over pc: a proof-header word the transcript absorbs), the padding pc (verifying key)
 enum CpuPub { kPubStartPc = 0, kPubStartTs, kPubHasSucc, kPubEndPc, kPubPadPc, kNumCpuPub };
@@ -103,6 +104,12 @@ static_assert(kBwWidth == 16, "bitwise chip layout");
 constexpr int SW_IS_REAL = 0, SW_SEL = 1, SW_O = SW_SEL + 6, SW_A = SW_O + 4, SW_M = SW_A + 2, SW_C = SW_M + 32, SW_MV = SW_C + 16,
               kSubWidth = SW_MV + 2;
 static_assert(kSubWidth == 63, "sub-word chip layout");
+// ---- Poseidon2 chip (stage 1): one width-16 permutation per row = one 2-to-1 compression of
+//      a Merkle tree of 8-word digests.  Row r holds heap node K = r + 1 (root 1, children 2K and 2K + 1, the n leaves at
+//      n .. 2n - 1): it consumes its children's digests from the DIGEST bus and produces its own; the verifier supplies
+//      the leaves and takes the root.  Columns: the input state, and per S-box its cube and its seventh power. ----
+constexpr int P2_IS_REAL = 0, P2_K = 1, P2_IN = 2, P2_EXT = P2_IN + 16, P2_INT = P2_EXT + 256, kP2Width = P2_INT + 26;
+static_assert(kP2Width == 300, "Poseidon2 chip layout");
 // ---- table chip: 2^16 rows; preprocessed (x, y: the row index's bytes; na: index not a multiple of 4; nt: index above
 //      kAddrHiMax; x ^ y; x & y); main: multiplicities of range16 (kind 0), 4-aligned range16 (kind 1), high address limb
 //      (kind 2), byte pair, and the byte operations xor / or / and ----
@@ -110,11 +117,11 @@ constexpr int TB_P_X = 0, TB_P_Y = 1, TB_P_NA = 2, TB_P_NT = 3, TB_P_XOR = 4, TB
               TB_M_AL = 1, TB_M_TOP = 2, TB_M_BY = 3, TB_M_XOR = 4, TB_M_OR = 5, TB_M_AND = 6, kTableWidth = 7, kTableLogH = 16;
 constexpr uint32_t kAddrHiMax = 0x77FFu;  // high limb of the largest address / jump target
 
-enum Bus { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP };
+enum Bus { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP, BUS_DIGEST };
 
 // Ctx interface:
 //   using F;  F local(int col); F next(int col); F prep(int col) (preprocessed column of the row);
-//   F is_first(); F is_trans(); F is_last(); F pub(int which)  (CpuPub);
+//   F is_first(); F is_trans(); F is_last(); F pub(int which)  (CpuPub);  const P2Consts* p2()  (eval_p2 only);
 //   F k(uint32_t montgomery_word)  (a constant);  void emit(F v)  (appends the next constraint);
 //   void emit_at(int index, F v);  void set_count(int n)  (index of the next emit());
 //   void stash(int i, F v); F stashed(int i)  (eval_alu_task<1> only): 32 values parked by index and read back by
@@ -590,6 +597,65 @@ ZKSP_HD void eval_sub(Ctx& ctx) {
 }
 constexpr int kSubConstraints = 78;
 
+// ---- Poseidon2 chip: every S-box through its cube (x^3, then x^7 = (x^3)^2 x: degree 3); between S-boxes the state is
+// linear in the columns.  Ctx::p2(): the permutation's constants (Montgomery words).  286 constraints. ----
+template <class F>
+ZKSP_HD void p2air_external_linear(F* s) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const F a = s[4 * c], b = s[4 * c + 1], cc = s[4 * c + 2], d = s[4 * c + 3];
+    const F sum = (a + b) + (cc + d);
+    s[4 * c] = sum + a + b.dbl();       // 2a + 3b + c + d
+    s[4 * c + 1] = sum + b + cc.dbl();  // a + 2b + 3c + d
+    s[4 * c + 2] = sum + cc + d.dbl();  // a + b + 2c + 3d
+    s[4 * c + 3] = sum + d + a.dbl();   // 3a + b + c + 2d
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const F col = (s[j] + s[4 + j]) + (s[8 + j] + s[12 + j]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[4 * c + j] = s[4 * c + j] + col;
+  }
+}
+template <class Ctx>
+ZKSP_HD void eval_p2(Ctx& ctx) {
+  using F = typename Ctx::F;
+  const P2Consts* kc = ctx.p2();
+  const F one = ctx.k(kR1);
+  ctx.emit(bool_c(L(P2_IS_REAL), one));
+  ctx.emit(ctx.is_first() * (L(P2_K) - one));
+  ctx.emit(ctx.is_trans() * (ctx.next(P2_K) - L(P2_K) - one));
+  ctx.emit(ctx.is_trans() * ctx.next(P2_IS_REAL) * (one - L(P2_IS_REAL)));  // the real rows are a prefix
+  F st[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) st[i] = L(P2_IN + i);
+  p2air_external_linear(st);
+  for (int rd = 0; rd < 8; ++rd) {
+    if (rd == 4) {  // the 13 internal rounds sit between the two halves of the external ones
+      for (int ir = 0; ir < 13; ++ir) {
+        const F x = st[0] + ctx.k(kc->internal[ir]), x3 = L(P2_INT + 2 * ir), y = L(P2_INT + 2 * ir + 1);
+        ctx.emit(x3 - x * x * x);
+        ctx.emit(y - x3 * x3 * x);
+        st[0] = y;
+        F sum = st[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) sum = sum + st[i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[i] = st[i] * ctx.k(kc->diag[i]) + sum;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const F x = st[i] + ctx.k(kc->ext[rd][i]), x3 = L(P2_EXT + 32 * rd + i), y = L(P2_EXT + 32 * rd + 16 + i);
+      ctx.emit(x3 - x * x * x);
+      ctx.emit(y - x3 * x3 * x);
+      st[i] = y;
+    }
+    p2air_external_linear(st);
+  }
+}
+constexpr int kP2Constraints = 4 + 8 * 32 + 13 * 2;
+
 // every image word is sent exactly once
 template <class Ctx>
 ZKSP_HD void eval_image(Ctx& ctx) {
@@ -613,7 +679,7 @@ constexpr int kKeccakConstraints = ka::kNumConstraints + 1;
 ZKSP_HD constexpr int num_constraints(int chip) {
   return is_cpu_chip(chip) ? kCpuConstraints : chip == kKeccak ? kKeccakConstraints : chip == kKmem ? kKmemConstraints
        : chip == kMemFinal ? kMemFinalConstraints : chip == kImage ? 1 : chip == kProgram ? 0 : chip == kMul ? kMulConstraints
-       : chip == kTable ? 2 : is_alu_chip(chip) ? kAluConstraints : is_sub_chip(chip) ? kSubConstraints : is_bw_chip(chip) ? kBwConstraints : 0;
+       : chip == kTable ? 2 : is_alu_chip(chip) ? kAluConstraints : is_sub_chip(chip) ? kSubConstraints : is_bw_chip(chip) ? kBwConstraints : chip == kP2 ? kP2Constraints : 0;
 }
 
 }  // namespace mach

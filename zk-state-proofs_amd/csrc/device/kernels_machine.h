@@ -28,17 +28,19 @@ struct MachineRecords {
   const uint32_t* alu_idx;     // [B][cap_alu]: cycle index of every ALU-chip row
   const uint32_t* sub_idx;     // [B][cap_sub]: cycle index of every sub-word-chip row
   const uint32_t* bw_idx;      // [B][cap_bw]: cycle index of every bitwise-chip row
+  const uint32_t* agg_heap;    // [B][cap_agg][8]: aggregation payload, digest of heap node k (canonical; leaves at n .. 2n - 1)
+  const P2Consts* consts;      // Poseidon2 constants (the Poseidon2 chip's rows are permutations)
   const uint32_t* prog_mult;   // [B][2^log_prog]; the padding row (n_program - 1) holds 0: its fetches follow from cpu_rows
-  const uint32_t* counts;      // [B][8]: cycles, keccak calls, memfinal rows, muls, ALU rows, sub-word rows, last time x0 was
-                               //         accessed by a real cycle, bitwise rows
+  const uint32_t* counts;      // [B][12]: cycles, keccak calls, memfinal rows, muls, ALU rows, sub-word rows, last time x0 was
+                               //          accessed by a real cycle, bitwise rows, aggregation leaves, 0, 0, 0
   uint32_t* table_hist;        // [B][kTableWidth][2^16] scratch: multiplicities of the table chip, counted on the device
   uint32_t row0[mach::kNumChips];  // first cycle / event of the chip's instance (second instances: rows of the first)
-  size_t cap_cycles, cap_keccak, cap_memfinal, cap_muls, cap_alu, cap_sub, cap_bw;
+  size_t cap_cycles, cap_keccak, cap_memfinal, cap_muls, cap_alu, cap_sub, cap_bw, cap_agg;
   const uint32_t* program;     // [n_program][9] (shared); the last row is the padding instruction
   uint32_t text_base, n_program, n_image;
   uint32_t cpu_rows;           // rows of the two CPU instances together: the rows past the last cycle fetch the padding instruction
 };
-constexpr int kCountWords = 8;
+constexpr int kCountWords = 12;
 // trace: [B][main_width][2^logh] of the given chip (every chip but kKeccak and kTable)
 void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& rec, uint32_t* trace, int logh, int batch);
 // keccak chip: p3-keccak-air's columns by launch_keccak_trace (kernels.h, with a batch stride), then the call time
@@ -101,6 +103,7 @@ struct MQuotArgs {
   uint32_t shift[2];            // g, g * w_2H  (Montgomery)
   uint32_t zh_inv[2];
   uint32_t wh_inv;
+  const P2Consts* consts;       // Poseidon2 constants (the Poseidon2 chip's constraints)
   const uint32_t* pubs;         // CPU instances: this instance's CpuPub words per proof (Montgomery), stride pubs_bstride
   size_t pubs_bstride;
   uint32_t* quot;               // [B][8][H]

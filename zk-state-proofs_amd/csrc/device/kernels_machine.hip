@@ -207,6 +207,51 @@ __global__ __launch_bounds__(kMT) void bw_trace_kernel(MachineRecords rec, uint3
   }
 }
 
+// Poseidon2 chip: row r is heap node K = r + 1 of the aggregation payload (real while K < n): its input state is its two
+// children's digests, its columns the cubes and seventh powers of every S-box of the permutation
+__global__ __launch_bounds__(64) void p2_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh) {
+  const size_t h = (size_t)1 << logh;
+  const size_t r = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (r >= h) return;
+  const int b = blockIdx.y;
+  const Col o{trace + (size_t)b * kP2Width * h + r, h};
+  const P2Consts* kc = rec.consts;
+  const uint32_t n = rec.counts[kCountWords * b + 8], k = (uint32_t)r + 1;
+  const bool real = n != 0 && k < n;
+  Fp st[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    st[i] = real ? Fp::from_canonical(rec.agg_heap[((size_t)b * rec.cap_agg + 2 * k) * 8 + i]) : Fp::zero();
+    o.put(P2_IN + i, st[i].v);
+  }
+  o.flag(P2_IS_REAL, real);
+  o.val(P2_K, k);
+  p2air_external_linear(st);
+  for (int rd = 0; rd < 8; ++rd) {
+    if (rd == 4) {
+      for (int ir = 0; ir < 13; ++ir) {
+        const Fp x = st[0] + Fp::raw(kc->internal[ir]), x3 = x * x * x, y = x3 * x3 * x;
+        o.put(P2_INT + 2 * ir, x3.v);
+        o.put(P2_INT + 2 * ir + 1, y.v);
+        st[0] = y;
+        Fp sum = st[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) sum = sum + st[i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[i] = st[i] * Fp::raw(kc->diag[i]) + sum;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const Fp x = st[i] + Fp::raw(kc->ext[rd][i]), x3 = x * x * x, y = x3 * x3 * x;
+      o.put(P2_EXT + 32 * rd + i, x3.v);
+      o.put(P2_EXT + 32 * rd + 16 + i, y.v);
+      st[i] = y;
+    }
+    p2air_external_linear(st);
+  }
+}
+
 // One sub-word-chip instance: row r is event row0 + r of the list sub_idx
 __global__ __launch_bounds__(kMT) void sub_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh, uint32_t row0) {
   const size_t h = (size_t)1 << logh;
@@ -383,6 +428,9 @@ void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& re
     case kBw2: hipLaunchKernelGGL(bw_trace_kernel, grid, block, 0, stream, rec, trace, logh, rec.row0[chip]); break;
     case kKmem:
       hipLaunchKernelGGL(kmem_trace_kernel, dim3((unsigned)((h + 63) / 64), batch), dim3(64), 0, stream, rec, trace, logh);
+      break;
+    case kP2:
+      hipLaunchKernelGGL(p2_trace_kernel, dim3((unsigned)((h + 63) / 64), batch), dim3(64), 0, stream, rec, trace, logh);
       break;
     case kMemFinal: hipLaunchKernelGGL(memfinal_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
     case kMul:
@@ -998,6 +1046,8 @@ struct MQCtx {
   Fp4 acc;
   int64_t lazy[4];
   int pending;
+  const P2Consts* p2_;  // Poseidon2 chip: the permutation's constants
+  __device__ __forceinline__ const P2Consts* p2() const { return p2_; }
   uint32_t* stash_;    // ALU task 1: this lane's column of a [32][kMT] LDS array
   __device__ __forceinline__ void stash(int i, F v) const { stash_[i * kMT] = v.v; }
   __device__ __forceinline__ F stashed(int i) const { return Fp::raw(stash_[i * kMT]); }
@@ -1121,6 +1171,7 @@ __device__ __forceinline__ void init_ctx(const MQuotArgs& a, const PointInfo& pi
   ctx->lazy[0] = ctx->lazy[1] = ctx->lazy[2] = ctx->lazy[3] = 0;
   ctx->pending = 0;
   ctx->stash_ = nullptr;
+  ctx->p2_ = a.consts;
 }
 
 template <int CHIP>
@@ -1143,6 +1194,7 @@ __global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
   else if constexpr (is_alu_chip(CHIP)) eval_alu(ctx);
   else if constexpr (is_sub_chip(CHIP)) eval_sub(ctx);
   else if constexpr (is_bw_chip(CHIP)) eval_bw(ctx);
+  else if constexpr (CHIP == kP2) eval_p2(ctx);
   ctx.flush();
   logup_constraints(a, pi, &ctx.acc);
   const Fp4 q = ctx.acc * Fp::raw(pi.c ? a.zh_inv[1] : a.zh_inv[0]);
@@ -1273,6 +1325,7 @@ void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a) {
     case kSub2: hipLaunchKernelGGL(machine_quotient_kernel<kSub>, grid, block, 0, stream, a); break;
     case kBw:
     case kBw2: hipLaunchKernelGGL(machine_quotient_kernel<kBw>, grid, block, 0, stream, a); break;
+    case kP2: hipLaunchKernelGGL(machine_quotient_kernel<kP2>, grid, block, 0, stream, a); break;
     case kKmem: hipLaunchKernelGGL(machine_quotient_kernel<kKmem>, grid, block, 0, stream, a); break;
     case kMemFinal: hipLaunchKernelGGL(machine_quotient_kernel<kMemFinal>, grid, block, 0, stream, a); break;
     case kImage: hipLaunchKernelGGL(machine_quotient_kernel<kImage>, grid, block, 0, stream, a); break;

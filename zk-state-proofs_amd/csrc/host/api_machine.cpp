@@ -12,8 +12,8 @@
 using namespace zksp;
 
 // Header (version, chip heights, exit code, digests, key digest), public values, body: the v6 proof object.
-int machine_proof_from_parts(const zksp_pk* pk, const ExecutionRecord& r, const int* lh, uint32_t handover_pc, const uint32_t* body,
-                             size_t body_words, zksp_proof** out) {
+int machine_proof_from_parts(const zksp_pk* pk, const ExecutionRecord& r, const int* lh, uint32_t handover_pc,
+                             const std::vector<uint32_t>& agg_leaves, const uint32_t* body, size_t body_words, zksp_proof** out) {
   zksp_proof* p = new (std::nothrow) zksp_proof();
   if (!p) return ZKSP_ERR_INVALID_ARG;
   try {
@@ -29,6 +29,11 @@ int machine_proof_from_parts(const zksp_pk* pk, const ExecutionRecord& r, const 
     memcpy(w + 12 + mach::kNumChips, r.deferred_digest.data(), 32);
     memcpy(w + 20 + mach::kNumChips, pk->mvk.digest, 32);
     w[28 + mach::kNumChips] = handover_pc;
+    w[29 + mach::kNumChips] = (uint32_t)(agg_leaves.size() / 8);
+    if (!machine_agg_public(agg_leaves.data(), agg_leaves.size() / 8, w + 30 + mach::kNumChips, w + 38 + mach::kNumChips, nullptr)) {
+      delete p;
+      return ZKSP_ERR_INVALID_ARG;
+    }
     if (!r.public_values.empty()) memcpy(w + mach::kHeaderWords, r.public_values.data(), r.public_values.size());
     memcpy(w + mach::kHeaderWords + pvw, body, body_words * 4);
   } catch (...) {
@@ -55,6 +60,7 @@ int zksp_machine_trace(zksp_client* c, const zksp_pk* pk, const zksp_stdin* stdi
   t->prog = &pk->mprog;
   try {
     trace_execute(pk->elf, pk->mprog, stdin_->entries, (uint64_t)1 << 21, &t->t);
+    t->t.agg_leaves = stdin_->agg_leaves;
   } catch (...) {
     delete t;
     return c->ctx.fail(ZKSP_ERR_EXECUTOR, "executor: out of memory while tracing the guest");
@@ -238,7 +244,43 @@ int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const 
   } else {
     machine_heights(*t->prog, t->t, lh);
   }
-  return machine_proof_from_parts(pk, t->t.rec, lh, machine_handover_pc(*t->prog, t->t, lh[mach::kCpu]), body, body_words, out);
+  return machine_proof_from_parts(pk, t->t.rec, lh, machine_handover_pc(*t->prog, t->t, lh[mach::kCpu]), t->t.agg_leaves, body, body_words,
+                                  out);
+}
+
+int zksp_stdin_set_aggregation(zksp_stdin* s, const uint32_t* leaves, size_t n) {
+  if (!s || (n && !leaves) || n == 1 || (n & (n - 1)) || n > ((size_t)1 << 20)) return ZKSP_ERR_INVALID_ARG;
+  for (size_t i = 0; i < 8 * n; ++i)
+    if (leaves[i] >= kP) return ZKSP_ERR_INVALID_ARG;
+  try {
+    s->agg_leaves.assign(leaves, leaves + 8 * n);
+  } catch (...) {
+    return ZKSP_ERR_INVALID_ARG;
+  }
+  return ZKSP_OK;
+}
+
+int zksp_proof_aggregation(const zksp_proof* p, uint32_t* n_leaves, uint32_t* root8) {
+  if (!p || !n_leaves || !root8 || p->version != mach::kMachineVersion) return ZKSP_ERR_INVALID_ARG;
+  *n_leaves = p->mhdr.agg_n;
+  memcpy(root8, p->mhdr.agg_root, 32);
+  return ZKSP_OK;
+}
+
+int zksp_verify_aggregate(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const uint32_t* leaves, size_t n) {
+  if (!c || !p || !vk || (n && !leaves)) return ZKSP_ERR_INVALID_ARG;
+  if (c->ctx.params.proof_mode != ZKSP_PROOF_MACHINE || p->version != mach::kMachineVersion)
+    return c->ctx.fail(ZKSP_ERR_VERIFY, "verify: not a machine proof");
+  std::string err;
+  int rc;
+  try {
+    rc = verify_machine_proof(p->bytes.data(), p->bytes.size(), vk->machine, c->ctx.params.num_queries, c->ctx.params.pow_bits, &err,
+                              leaves, n);
+  } catch (...) {
+    return c->ctx.fail(ZKSP_ERR_VERIFY, "verify: out of memory");
+  }
+  if (rc) return c->ctx.fail(rc, "verify: " + err);
+  return ZKSP_OK;
 }
 
 int zksp_vk_machine(const zksp_vk* vk, uint32_t* prep_root8, uint32_t* digest8) {

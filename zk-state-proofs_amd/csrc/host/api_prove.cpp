@@ -116,6 +116,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       traces[i].reset(new zksp_mtrace());
       traces[i]->prog = &pk->mprog;
       trace_execute(pk->elf, pk->mprog, stdins[i]->entries, (uint64_t)1 << 21, &traces[i]->t);
+      traces[i]->t.agg_leaves.swap(stdins[i]->agg_leaves);
       stdins[i]->entries.clear();  // consumed, as SP1Stdin is by prove()
     } catch (...) {
       traces[i].reset(new zksp_mtrace());
@@ -163,6 +164,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       lh[mach::kAlu] = clog2(t.alu_idx.size()); lh[mach::kAlu2] = 0;
       lh[mach::kSub] = clog2(t.sub_idx.size()); lh[mach::kSub2] = 0;
       lh[mach::kBw] = clog2(t.bw_idx.size()); lh[mach::kBw2] = 0;
+      lh[mach::kP2] = clog2(t.agg_leaves.size() / 8 + 1);
       groups[lh].push_back(i);
       covers[lh].cover(t);
     }
@@ -286,8 +288,8 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     }
     for (size_t j = 0; j < cnt; ++j) {
       const size_t i = ck.idx[j];
-      status[i] = machine_proof_from_parts(pk, traces[i]->t.rec, ck.lh.data(), traces[i]->handover_pc, bodies.data() + j * bw, bw,
-                                           &out[i]);
+      status[i] = machine_proof_from_parts(pk, traces[i]->t.rec, ck.lh.data(), traces[i]->handover_pc, traces[i]->t.agg_leaves,
+                                           bodies.data() + j * bw, bw, &out[i]);
     }
     mark.mark("wrapped", cnt);
     if (piggyback && rc_next != ZKSP_OK) {

@@ -10,6 +10,7 @@
 //   BYTES  (x, y)   two bytes: table chip
 //   BYTEOP (kind, x, y, z)   z = x xor y (1), x or y (2), x and y (3): table chip <- bitwise chip
 //   IMG    (addr, lo, hi)   image chip -> memory boundary: the initial value of an image address
+//   DIGEST (heap index, 8 words)   Poseidon2 chip: children in, parent out; verifier: the leaves in, the root out
 #include "machine_defs.hpp"
 
 #include <cstdlib>
@@ -88,7 +89,7 @@ Interaction bytes_inter(int sign, const LinForm& mult, const LinForm& x, const L
 }
 
 constexpr int kCpuInter = 22;
-Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7], g_alu[1], g_sub[1], g_bw[5];
+Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7], g_alu[1], g_sub[1], g_bw[5], g_p2[3];
 ChipDef g_chips[kNumChips];
 
 void build() {
@@ -290,6 +291,28 @@ void build() {
     it.el[4] = lf_bits(SW_M, 16); it.el[5] = lf_bits(SW_M + 16, 16); it.el[6] = lf_bits(SW_C, 16);
     it.el[7] = lf_col(SW_MV); it.el[8] = lf_col(SW_MV + 1);
   }
+  {
+    // Poseidon2: children in, parent out; the output digest is the external linear layer applied to the last round's
+    // S-box outputs (circ(2 M4, M4, M4, M4), M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]])
+    static const uint32_t m4[4][4] = {{2, 3, 1, 1}, {1, 2, 3, 1}, {1, 1, 2, 3}, {3, 1, 1, 2}};
+    const int ylast = P2_EXT + 32 * 7 + 16;
+    for (int side = 0; side < 2; ++side) {
+      Interaction& it = g_p2[side];
+      it = Interaction{};
+      it.bus = BUS_DIGEST; it.sign = -1; it.mult = lf_col(P2_IS_REAL); it.n_el = 9;
+      it.el[0] = lf_zero(); lf_add(it.el[0], P2_K, 2); it.el[0].c0 = mont((uint64_t)side);
+      for (int j = 0; j < 8; ++j) it.el[1 + j] = lf_col(P2_IN + 8 * side + j);
+    }
+    Interaction& out = g_p2[2];
+    out = Interaction{};
+    out.bus = BUS_DIGEST; out.sign = +1; out.mult = lf_col(P2_IS_REAL); out.n_el = 9;
+    out.el[0] = lf_col(P2_K);
+    for (int j = 0; j < 8; ++j) {
+      out.el[1 + j] = lf_zero();
+      for (int i = 0; i < 16; ++i) lf_add(out.el[1 + j], ylast + i, (uint64_t)m4[j & 3][i & 3] * ((i >> 2) == (j >> 2) ? 2u : 1u));
+    }
+  }
+  g_chips[kP2] = {"poseidon2", 0, kP2Width, 3, g_p2, kP2Constraints};
   g_chips[kTable] = {"table", kTablePrepWidth, kTableWidth, 7, g_table, 2};
   g_chips[kCpu] = {"cpu", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints};
   g_chips[kCpu2] = {"cpu2", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints};

@@ -34,7 +34,8 @@ struct ChipDef {
 };
 const ChipDef& chip_def(int chip);
 
-constexpr int kHeaderWords = 2 + kNumChips + 2 + 24 + 1;  // magic, version, heights, exit code, pv length, 3 digests, hand-over pc
+// magic, version, heights, exit code, pv length, 3 digests, hand-over pc; aggregation payload: leaf count, root, digest of the leaf list
+constexpr int kHeaderWords = 2 + kNumChips + 2 + 24 + 1 + 17;
 constexpr uint32_t kMachineVersion = 6;
 
 }  // namespace mach

@@ -105,6 +105,7 @@ void machine_heights(const MachineProgram& prog, const MachineCounts& n, int log
   logh[kProgram] = prog.log_prog;
   logh[kMul] = at_least5(ceil_log2(n.muls));
   logh[kTable] = kTableLogH;
+  logh[kP2] = at_least5(ceil_log2(n.agg > 1 ? n.agg - 1 : 1));  // one row per inner node of the aggregation tree
 }
 void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh[kNumChips]) {
   MachineCounts n;
@@ -115,7 +116,7 @@ bool machine_fits(const MachineTrace& t, const int* logh) {
   auto two = [&](int a, int b) { return ((size_t)1 << logh[a]) + ((size_t)1 << logh[b]); };
   auto one = [&](int a) { return (size_t)1 << logh[a]; };
   return t.cycles.size() <= two(kCpu, kCpu2) && t.alu_idx.size() <= two(kAlu, kAlu2) && t.sub_idx.size() <= two(kSub, kSub2) &&
-         t.bw_idx.size() <= two(kBw, kBw2) &&
+         t.bw_idx.size() <= two(kBw, kBw2) && t.agg_leaves.size() / 8 <= one(kP2) + 1 &&
          24 * t.keccak.size() <= one(kKeccak) && 50 * t.keccak.size() <= one(kKmem) && t.memfinal.size() <= one(kMemFinal) &&
          t.muls.size() <= one(kMul);
 }
@@ -185,11 +186,11 @@ int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineV
 }
 
 static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap_cycles, size_t cap_keccak, size_t cap_memfinal,
-                            size_t cap_muls, size_t cap_alu, size_t cap_sub, size_t cap_bw) {
+                            size_t cap_muls, size_t cap_alu, size_t cap_sub, size_t cap_bw, size_t cap_agg) {
   MachineWorkspace* w = ctx->mws.get();
   if (w && memcmp(w->logh, logh, sizeof w->logh) == 0 && w->batch >= batch && w->cap_cycles >= cap_cycles &&
       w->cap_keccak >= cap_keccak && w->cap_memfinal >= cap_memfinal && w->cap_muls >= cap_muls && w->cap_alu >= cap_alu &&
-      w->cap_sub >= cap_sub && w->cap_bw >= cap_bw)
+      w->cap_sub >= cap_sub && w->cap_bw >= cap_bw && w->cap_agg >= cap_agg)
     return 0;
   ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->mws.reset(new MachineWorkspace());
@@ -199,6 +200,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   w->cap_cycles = cap_cycles; w->cap_keccak = std::max<size_t>(cap_keccak, 1); w->cap_memfinal = cap_memfinal;
   w->cap_muls = std::max<size_t>(cap_muls, 1);
   w->cap_alu = std::max<size_t>(cap_alu, 1); w->cap_sub = std::max<size_t>(cap_sub, 1); w->cap_bw = std::max<size_t>(cap_bw, 1);
+  w->cap_agg = std::max<size_t>(cap_agg, 2);
   const size_t B = (size_t)batch;
   const uint32_t Q = ctx->params.num_queries;
   bool ok = true;
@@ -211,6 +213,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   A(&w->alu_idx, B * w->cap_alu);
   A(&w->sub_idx, B * w->cap_sub);
   A(&w->bw_idx, B * w->cap_bw);
+  A(&w->agg_heap, B * w->cap_agg * 8);
   A(&w->prog_mult, B << logh[kProgram]);
   A(&w->table_hist, (B * kTableWidth) << kTableLogH);
   A(&w->counts, B * kCountWords);
@@ -225,6 +228,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   A(&w->spare.alu_idx, B * w->cap_alu);
   A(&w->spare.sub_idx, B * w->cap_sub);
   A(&w->spare.bw_idx, B * w->cap_bw);
+  A(&w->spare.agg_heap, B * w->cap_agg * 8);
   A(&w->spare.prog_mult, B << logh[kProgram]);
   A(&w->spare.counts, B * kCountWords);
   A(&w->spare.n_perms, B);
@@ -316,7 +320,7 @@ namespace {
 void swap_records(MachineWorkspace* w) {
   MachineWorkspace::SpareRecords& p = w->spare;
   std::swap(w->cycles, p.cycles); std::swap(w->memfinal, p.memfinal); std::swap(w->muls, p.muls);
-  std::swap(w->prog_mult, p.prog_mult); std::swap(w->alu_idx, p.alu_idx); std::swap(w->sub_idx, p.sub_idx); std::swap(w->bw_idx, p.bw_idx);
+  std::swap(w->prog_mult, p.prog_mult); std::swap(w->alu_idx, p.alu_idx); std::swap(w->sub_idx, p.sub_idx); std::swap(w->bw_idx, p.bw_idx); std::swap(w->agg_heap, p.agg_heap);
   std::swap(w->counts, p.counts);
   std::swap(w->kcalls, p.kcalls); std::swap(w->kstates, p.kstates); std::swap(w->n_perms, p.n_perms);
   std::swap(w->init_obs, p.init_obs); std::swap(w->pub_words, p.pub_words); std::swap(w->n, p.n);
@@ -353,14 +357,15 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
   const size_t cc = ((size_t)1 << logh[kCpu]) + ((size_t)1 << logh[kCpu2]), cm = (size_t)1 << logh[kMemFinal], cu = (size_t)1 << logh[kMul],
                ck = std::min(((size_t)1 << logh[kKeccak]) / 24, ((size_t)1 << logh[kKmem]) / 50),
                ca = ((size_t)1 << logh[kAlu]) + ((size_t)1 << logh[kAlu2]), cs = ((size_t)1 << logh[kSub]) + ((size_t)1 << logh[kSub2]),
-               cb = ((size_t)1 << logh[kBw]) + ((size_t)1 << logh[kBw2]);
+               cb = ((size_t)1 << logh[kBw]) + ((size_t)1 << logh[kBw2]),
+               cg = 2 * (((size_t)1 << logh[kP2]) + 1);  // heap nodes 0 .. 2n - 1 of at most 2^logh + 1 leaves
   if (logh[kCpu] > 20) return ctx->fail(9, "machine_load: more than 2^21 cycles");
   if (into_spare) {
     MachineWorkspace* w0 = ctx->mws.get();
     if (!w0 || memcmp(w0->logh, logh, sizeof w0->logh) != 0 || (size_t)w0->batch < n || !ctx->copy_stream)
       return ctx->fail(1, "machine_load: the spare set takes batches of the resident heights only");
   } else {
-    rc = workspace_ensure(ctx, logh, (int)std::max<size_t>(n, (size_t)ctx->batch_hint), cc, ck, cm, cu, ca, cs, cb);
+    rc = workspace_ensure(ctx, logh, (int)std::max<size_t>(n, (size_t)ctx->batch_hint), cc, ck, cm, cu, ca, cs, cb, cg);
     if (rc) return rc;
   }
   MachineWorkspace* w = ctx->mws.get();
@@ -375,6 +380,7 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
   if (into_spare) swap_records(w);
   std::vector<uint32_t> counts(n * kCountWords, 0), nperms(n), obs(n * kMachineInitObs), pubw(n * kPubWords);
   std::vector<uint64_t> kst(n * w->cap_keccak * 25, 0);
+  std::vector<std::vector<uint32_t>> agg_heaps(n);  // alive until the stream has been synchronised
   const size_t hp = (size_t)1 << logh[kProgram];
   for (size_t i = 0; i < n; ++i) {
     const MachineTrace& t = *traces[i];
@@ -384,6 +390,15 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     cn[4] = (uint32_t)t.alu_idx.size(); cn[5] = (uint32_t)t.sub_idx.size(); cn[6] = t.x0_last; cn[7] = (uint32_t)t.bw_idx.size();
     if (!t.bw_idx.empty())
       ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->bw_idx + i * w->cap_bw, t.bw_idx.data(), t.bw_idx.size() * 4, hipMemcpyHostToDevice, s));
+    // aggregation payload: the heap of digests (node k = compress(2k, 2k + 1), leaves at n .. 2n - 1) the Poseidon2 chip's
+    // rows are expanded from, and its public part
+    uint32_t agg_root[8], agg_digest[8];
+    const size_t n_agg = t.agg_leaves.size() / 8;
+    if (!machine_agg_public(t.agg_leaves.data(), n_agg, agg_root, agg_digest, &agg_heaps[i]))
+      return ctx->fail(1, "machine_load: malformed aggregation leaves");
+    cn[8] = (uint32_t)n_agg;
+    if (n_agg)
+      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->agg_heap + i * w->cap_agg * 8, agg_heaps[i].data(), agg_heaps[i].size() * 4, hipMemcpyHostToDevice, s));
     if (!t.alu_idx.empty())
       ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->alu_idx + i * w->cap_alu, t.alu_idx.data(), t.alu_idx.size() * 4, hipMemcpyHostToDevice, s));
     if (!t.sub_idx.empty())
@@ -418,6 +433,9 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
       const uint32_t handover = machine_handover_pc(prog, t, logh[kCpu]);
       o[42 + kNumChips] = handover & 0xffff;
       o[43 + kNumChips] = handover >> 16;
+      o[44 + kNumChips] = (uint32_t)n_agg;
+      memcpy(o + 45 + kNumChips, agg_root, 32);
+      memcpy(o + 53 + kNumChips, agg_digest, 32);
       uint32_t* cp = &pubw[i * kPubWords + 17];
       uint32_t* cp2 = cp + kNumCpuPub;
       cp[kPubStartPc] = Fp::from_canonical(prog.entry).v; cp[kPubStartTs] = Fp::from_canonical(4).v;
@@ -476,12 +494,12 @@ int machine_prove_resident(Context* ctx) {
   // ---- main traces ----
   MachineRecords rec;
   rec.cycles = w->cycles; rec.kcalls = w->kcalls; rec.memfinal = w->memfinal; rec.muls = w->muls;
-  rec.alu_idx = w->alu_idx; rec.sub_idx = w->sub_idx; rec.bw_idx = w->bw_idx;
+  rec.alu_idx = w->alu_idx; rec.sub_idx = w->sub_idx; rec.bw_idx = w->bw_idx; rec.agg_heap = w->agg_heap; rec.consts = kc;
   rec.prog_mult = w->prog_mult; rec.counts = w->counts; rec.table_hist = w->table_hist;
   memset(rec.row0, 0, sizeof rec.row0);
   rec.row0[kCpu2] = (uint32_t)1 << logh[kCpu]; rec.row0[kAlu2] = (uint32_t)1 << logh[kAlu]; rec.row0[kSub2] = (uint32_t)1 << logh[kSub]; rec.row0[kBw2] = (uint32_t)1 << logh[kBw];
   rec.cap_cycles = w->cap_cycles; rec.cap_keccak = w->cap_keccak; rec.cap_memfinal = w->cap_memfinal; rec.cap_muls = w->cap_muls;
-  rec.cap_alu = w->cap_alu; rec.cap_sub = w->cap_sub; rec.cap_bw = w->cap_bw;
+  rec.cap_alu = w->cap_alu; rec.cap_sub = w->cap_sub; rec.cap_bw = w->cap_bw; rec.cap_agg = w->cap_agg;
   rec.program = prep->program; rec.text_base = prep->text_base; rec.n_program = prep->n_program; rec.n_image = prep->n_image;
   rec.cpu_rows = ((uint32_t)1 << logh[kCpu]) + ((uint32_t)1 << logh[kCpu2]);
   {
@@ -597,6 +615,7 @@ int machine_prove_resident(Context* ctx) {
         qa.zh_inv[k] = (sh[k].pow(h) - Fp::one()).inv().v;
       }
       qa.wh_inv = wh.inv().v;
+      qa.consts = kc;
       qa.pubs = is_cpu_chip(c) ? w->pub_words + 17 + (c == kCpu2 ? kNumCpuPub : 0) : nullptr;
       qa.pubs_bstride = kPubWords;
       qa.quot = w->mat[c][2].tr;

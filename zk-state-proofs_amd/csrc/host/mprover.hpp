@@ -11,7 +11,8 @@
 
 namespace zksp {
 
-constexpr int kMachineInitObs = 8 + mach::kNumChips + 2 + 16 + 16 + 2;  // vk digest, heights, exit halves, digest halves, hand-over pc halves
+// vk digest, heights, exit halves, digest halves, hand-over pc halves, aggregation: leaf count, root, digest of the leaf list
+constexpr int kMachineInitObs = 8 + mach::kNumChips + 2 + 16 + 16 + 2 + 17;
 
 // Preprocessed tables of one program on the device (built once per verifying key).
 struct PrepDevice {
@@ -32,11 +33,11 @@ struct PrepDevice {
 struct MachineWorkspace {
   int logh[mach::kNumChips] = {0};
   int batch = 0, n = 0;
-  size_t cap_cycles = 0, cap_keccak = 0, cap_memfinal = 0, cap_muls = 0, cap_alu = 0, cap_sub = 0, cap_bw = 0;
+  size_t cap_cycles = 0, cap_keccak = 0, cap_memfinal = 0, cap_muls = 0, cap_alu = 0, cap_sub = 0, cap_bw = 0, cap_agg = 0;
   const PrepDevice* prep = nullptr;
   // records
   uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *alu_idx = nullptr, *sub_idx = nullptr,
-           *bw_idx = nullptr, *counts = nullptr, *table_hist = nullptr;
+           *bw_idx = nullptr, *agg_heap = nullptr, *counts = nullptr, *table_hist = nullptr;
   uint8_t* kcalls = nullptr;
   uint64_t* kstates = nullptr;
   uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;
@@ -44,7 +45,7 @@ struct MachineWorkspace {
   // being proven, then machine_activate_spare() swaps the sets.
   struct SpareRecords {
     uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *alu_idx = nullptr, *sub_idx = nullptr,
-             *bw_idx = nullptr, *counts = nullptr;
+             *bw_idx = nullptr, *agg_heap = nullptr, *counts = nullptr;
     uint8_t* kcalls = nullptr;
     uint64_t* kstates = nullptr;
     uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;

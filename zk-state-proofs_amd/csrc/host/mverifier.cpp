@@ -134,6 +134,7 @@ struct ZetaCtx {
   const Fp4* nxt;  // main columns at zeta * w
   const Fp4* prp;  // preprocessed columns at zeta
   F prep(int col) const { return prp[col]; }
+  const P2Consts* p2() const { return &host_p2_consts(); }
   Fp4 first, trans, last, pub_[kNumCpuPub];
   const Fp4* ap;
   int k_ = 0;
@@ -178,6 +179,29 @@ void vk_digest_of(const uint32_t root_canon[8], uint32_t entry, uint32_t pad_pc,
 }
 
 }  // namespace
+
+bool machine_agg_public(const uint32_t* leaves, size_t n, uint32_t root[8], uint32_t list_digest[8], std::vector<uint32_t>* heap) {
+  memset(root, 0, 32);
+  memset(list_digest, 0, 32);
+  if (heap) heap->clear();
+  if (n == 0) return true;
+  if (n == 1 || (n & (n - 1)) || !leaves) return false;  // a power of two of leaves, at least 2
+  for (size_t i = 0; i < 8 * n; ++i)
+    if (leaves[i] >= kP) return false;
+  const P2Consts* kc = &host_p2_consts();
+  std::vector<Fp> hp(16 * n, Fp::zero());
+  for (size_t i = 0; i < 8 * n; ++i) hp[8 * n + i] = Fp::from_canonical(leaves[i]);
+  for (size_t k = n - 1; k >= 1; --k) compress(&hp[16 * k], &hp[16 * k + 8], &hp[8 * k], kc);
+  for (int i = 0; i < 8; ++i) root[i] = hp[8 + i].to_canonical();
+  Fp dg[8];
+  hash_elems(&hp[8 * n], 8 * n, dg, kc);
+  for (int i = 0; i < 8; ++i) list_digest[i] = dg[i].to_canonical();
+  if (heap) {
+    heap->resize(16 * n);
+    for (size_t i = 0; i < 16 * n; ++i) (*heap)[i] = hp[i].to_canonical();
+  }
+  return true;
+}
 
 void machine_prep_traces(const MachineProgram& prog, std::vector<uint32_t>* image_prep, std::vector<uint32_t>* program_prep,
                          std::vector<uint32_t>* table_prep) {
@@ -297,6 +321,12 @@ bool parse_machine_header(const uint8_t* bytes, size_t len, MachineHeader* h, st
   memcpy(h->deferred_digest, w + 12 + kNumChips, 32);
   memcpy(h->vk_digest, w + 20 + kNumChips, 32);
   h->handover_pc = w[28 + kNumChips];
+  h->agg_n = w[29 + kNumChips];
+  memcpy(h->agg_root, w + 30 + kNumChips, 32);
+  memcpy(h->agg_digest, w + 38 + kNumChips, 32);
+  if (h->agg_n == 1 || (h->agg_n & (h->agg_n - 1)) || h->agg_n > (1u << 20)) { *err = "aggregation leaf count is not a power of two"; return false; }
+  for (int i = 0; i < 8; ++i)
+    if (h->agg_root[i] >= kP || h->agg_digest[i] >= kP) { *err = "non-canonical aggregation digest"; return false; }
   if (h->pv_len > (1u << 24)) { *err = "public values too long"; return false; }
   h->pv_offset = (size_t)kHeaderWords * 4;
   h->body_offset = ((size_t)kHeaderWords + (h->pv_len + 3) / 4) * 4;
@@ -307,9 +337,19 @@ bool parse_machine_header(const uint8_t* bytes, size_t len, MachineHeader* h, st
 }
 
 int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, uint32_t num_queries, uint32_t pow_bits,
-                         std::string* err) {
+                         std::string* err, const uint32_t* agg_leaves, size_t n_agg) {
   MachineHeader hd;
   if (!parse_machine_header(bytes, len, &hd, err)) return 7;
+  // the aggregation payload: the caller names the leaves the proof's root is claimed for; the transcript holds their digest
+  if (hd.agg_n != n_agg) {
+    *err = n_agg ? "the proof does not aggregate this many leaves" : "the proof carries an aggregation payload: verify it with its leaves";
+    return 8;
+  }
+  if (n_agg) {
+    uint32_t r[8], dg[8];
+    if (!machine_agg_public(agg_leaves, n_agg, r, dg, nullptr)) { *err = "malformed aggregation leaves"; return 7; }
+    if (memcmp(dg, hd.agg_digest, 32) != 0) { *err = "the proof aggregates another list of leaves"; return 8; }
+  }
   const int* logh = hd.logh;
   const size_t body_words = machine_proof_body_words(logh, num_queries);
   if (len != hd.body_offset + body_words * 4) { *err = "proof length mismatch"; return 7; }
@@ -365,6 +405,9 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   for (int i = 0; i < 8; ++i) { ch.observe_canon(hd.deferred_digest[i] & 0xffff); ch.observe_canon(hd.deferred_digest[i] >> 16); }
   ch.observe_canon(hd.handover_pc & 0xffff);
   ch.observe_canon(hd.handover_pc >> 16);
+  ch.observe_canon(hd.agg_n);
+  for (int i = 0; i < 8; ++i) ch.observe_canon(hd.agg_root[i]);
+  for (int i = 0; i < 8; ++i) ch.observe_canon(hd.agg_digest[i]);
   Fp root[4][8];
   for (int i = 0; i < 8; ++i) root[0][i] = Fp::from_canonical(vk.prep_root[i]);
   for (int i = 0; i < 8; ++i) { root[1][i] = Fp::from_canonical(p_root_main[i]); ch.observe(root[1][i]); }
@@ -395,6 +438,14 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       }
     const Fp4 fh = gamma + fc(BUS_PUBH) + bpow[1] * fc(hd.exit_code & 0xffff) + bpow[2] * fc(hd.exit_code >> 16);
     total -= fh.inv();
+    // ... and the digest bus of the aggregation payload: the leaves go in at heap nodes n .. 2n - 1, the root comes out at 1
+    for (size_t i = 0; i <= n_agg && n_agg; ++i) {
+      const uint32_t* d = i < n_agg ? agg_leaves + 8 * i : hd.agg_root;
+      Fp4 f = gamma + fc(BUS_DIGEST) + bpow[1] * fc(i < n_agg ? (uint32_t)(n_agg + i) : 1u);
+      for (int j = 0; j < 8; ++j) f += bpow[2 + j] * fc(d[j]);
+      if (i < n_agg) total += f.inv();
+      else total -= f.inv();
+    }
     if (total != Fp4::zero()) { *err = "LogUp buses do not balance against the public values and exit code"; return 8; }
   }
 
@@ -468,6 +519,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       case kSub2: eval_sub(zc); break;
       case kBw:
       case kBw2: eval_bw(zc); break;
+      case kP2: eval_p2(zc); break;
     }
     if (zc.k_ != nb) { *err = "internal: constraint count"; return 7; }
     // LogUp: row = [prep | main] at zeta

@@ -26,6 +26,7 @@ struct MachineHeader {
   int logh[mach::kNumChips];
   uint32_t exit_code, pv_len, handover_pc;
   uint32_t pv_digest[8], deferred_digest[8], vk_digest[8];
+  uint32_t agg_n, agg_root[8], agg_digest[8];  // aggregation payload: leaf count (0: none), Merkle root, digest of the leaf list
   size_t pv_offset, body_offset;
 };
 
@@ -36,8 +37,12 @@ void machine_prep_traces(const MachineProgram& prog, std::vector<uint32_t>* imag
 void machine_host_setup(const MachineProgram& prog, MachineVk* vk);
 size_t machine_proof_body_words(const int* logh, uint32_t num_queries);
 bool parse_machine_header(const uint8_t* bytes, size_t len, MachineHeader* h, std::string* err);
-// 0 = accepted; 7 = malformed; 8 = rejected
+// 0 = accepted; 7 = malformed; 8 = rejected.  agg_leaves / n_agg: the leaves ([n][8] canonical words) of the aggregation
+// payload the proof must carry (n_agg = 0: it must carry none).
 int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, uint32_t num_queries, uint32_t pow_bits,
-                         std::string* err);
+                         std::string* err, const uint32_t* agg_leaves = nullptr, size_t n_agg = 0);
+// The aggregation payload's public part and the heap of digests the Poseidon2 chip's rows are expanded from:
+// heap[8 k ..] = node k (root 1, children 2k and 2k + 1, leaf i at n + i; node 0 unused), canonical words.
+bool machine_agg_public(const uint32_t* leaves, size_t n, uint32_t root[8], uint32_t list_digest[8], std::vector<uint32_t>* heap);
 
 }  // namespace zksp
