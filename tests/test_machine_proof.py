@@ -351,7 +351,7 @@ def test_second_cpu_instance_must_continue_the_first(zk, oracle, setup):
     h0 = 32
     while 2 * h0 < len(cyc):
         h0 *= 2
-    hw = zk.MACHINE_HEADER_WORDS
+    hw = zk.MACHINE_HEADER_WORDS - 17  # the 17 aggregation words follow the hand-over pc
     assert int.from_bytes(proof[4 * (hw - 1):4 * hw], "little") == int(cyc[h0, 0])  # the header's hand-over pc
     c2 = cyc.copy()
     c2[h0, 0] = cyc[h0 + 7, 0]  # the second instance starts at another instruction

@@ -38,6 +38,7 @@ Context::~Context() {
     if (timer_b) (void)hipEventDestroy(timer_b);
     ws.reset();
     mws.reset();
+    if (arena) (void)hipFree(arena);
     for (auto& kv : prep)
       for (void* p : kv.second->allocs)
         if (p) (void)hipFree(p);

@@ -63,6 +63,8 @@ struct Context {
   // machine proof: batch workspace, per-program preprocessed tables (by verifying-key digest),
   // device copies of the chips' bus interactions
   std::unique_ptr<MachineWorkspace> mws;
+  void* arena = nullptr;   // the machine workspace's device memory: laid out again per shape, grown when too small
+  size_t arena_bytes = 0;
   std::map<std::array<uint32_t, 8>, std::unique_ptr<PrepDevice>> prep;
   void* d_inter[16] = {nullptr};  // indexed by chip (mach::kNumChips <= 16)
   uint32_t* h_stage2[2] = {nullptr, nullptr};  // pinned host staging for proof bodies (double buffered)

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 #include "prover.hpp"
 
@@ -203,116 +204,138 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   w->cap_agg = std::max<size_t>(cap_agg, 2);
   const size_t B = (size_t)batch;
   const uint32_t Q = ctx->params.num_queries;
+  // The workspace lives in ONE device arena that survives re-shaping: a batch of other chip heights only lays the same
+  // memory out again (pass 0 sizes it, pass 1 hands out the pointers), instead of freeing and re-allocating tens of
+  // gigabytes per shape - a block of receipts (BASELINE config 4) goes through a dozen shapes in one prove_batch call.
   bool ok = true;
-  auto A = [&](auto** p, size_t count) { ok = ok && dalloc(&w->allocs, p, count); };
-  A(&w->cycles, B * w->cap_cycles * 12);
-  A(&w->kcalls, B * w->cap_keccak * 408);
-  A(&w->kstates, B * w->cap_keccak * 25);
-  A(&w->memfinal, B * w->cap_memfinal * 5);
-  A(&w->muls, B * w->cap_muls * 3);
-  A(&w->alu_idx, B * w->cap_alu);
-  A(&w->sub_idx, B * w->cap_sub);
-  A(&w->bw_idx, B * w->cap_bw);
-  A(&w->agg_heap, B * w->cap_agg * 8);
-  A(&w->prog_mult, B << logh[kProgram]);
-  A(&w->table_hist, (B * kTableWidth) << kTableLogH);
-  A(&w->counts, B * kCountWords);
-  A(&w->n_perms, B);
-  A(&w->init_obs, B * kMachineInitObs);
-  A(&w->pub_words, B * kPubWords);
-  A(&w->spare.cycles, B * w->cap_cycles * 12);
-  A(&w->spare.kcalls, B * w->cap_keccak * 408);
-  A(&w->spare.kstates, B * w->cap_keccak * 25);
-  A(&w->spare.memfinal, B * w->cap_memfinal * 5);
-  A(&w->spare.muls, B * w->cap_muls * 3);
-  A(&w->spare.alu_idx, B * w->cap_alu);
-  A(&w->spare.sub_idx, B * w->cap_sub);
-  A(&w->spare.bw_idx, B * w->cap_bw);
-  A(&w->spare.agg_heap, B * w->cap_agg * 8);
-  A(&w->spare.prog_mult, B << logh[kProgram]);
-  A(&w->spare.counts, B * kCountWords);
-  A(&w->spare.n_perms, B);
-  A(&w->spare.init_obs, B * kMachineInitObs);
-  A(&w->spare.pub_words, B * kPubWords);
-  int lm = 0;
-  size_t n_open = 0, max_total = 0, max_h = 0;
-  for (int c = 0; c < kNumChips; ++c) {
-    const ChipDef& d = chip_def(c);
-    const size_t h = (size_t)1 << logh[c];
-    lm = std::max(lm, logh[c]);
-    max_h = std::max(max_h, h);
-    const int widths[3] = {d.main_w, d.perm_width(), 8};
-    for (int r = 0; r < 3; ++r) {
-      w->mat[c][r].w = widths[r];
-      A(&w->mat[c][r].tr, B * widths[r] * h);
-      A(&w->mat[c][r].coef, B * widths[r] * h);
-      A(&w->mat[c][r].lde, B * widths[r] * 2 * h);
-    }
-    A(&w->zpow[c], B * 2 * h * 4);
-    w->open_off[c] = n_open;
-    n_open += (size_t)d.prep_w + 2 * (size_t)d.main_w + 2 * (size_t)d.perm_width() + 8;
-    max_total = std::max<size_t>(max_total, (size_t)d.total_constraints());
-  }
-  w->lm = lm;
-  w->n_open = n_open;
-  w->alpha_stride = max_total * 4;
-  const size_t N = (size_t)2 << lm;
-  for (int r = 1; r < 4; ++r) {
-    A(&w->tree[r], B * (2 * N - 1) * 8);
-    for (int c = 0; c < kNumChips; ++c)
-      if (logh[c] < lm && !w->inj[r][logh[c] + 1]) A(&w->inj[r][logh[c] + 1], (B * 8) << (logh[c] + 1));
-  }
-  for (int c = 0; c < kNumChips; ++c)
-    if (logh[c] < lm && !w->G[logh[c]]) A(&w->G[logh[c]], (B * 2 * 4) << logh[c]);
-  A(&w->ch, B);
-  A(&w->bus_ch, B * 8);
-  A(&w->bpow, B * (kInterMaxElems + 1) * 4);
-  A(&w->cum, B * kNumChips * 4);
-  A(&w->pubsum, B * 4);
-  A(&w->rowsum, B * max_h * 4);
-  A(&w->slice_sums, B * (max_h / 4096 + 1) * 4);
-  A(&w->alpha, B * 4);
-  A(&w->alpha_pows, B * w->alpha_stride);
-  A(&w->zeta, B * 4);
-  w->open_rows_log = (size_t)ceil_log2((n_open * 4 + 7) / 8);
-  const size_t R = (size_t)1 << w->open_rows_log;
-  A(&w->opened, B * 8 * R);
-  A(&w->tree_o, B * (2 * R - 1) * 8);
-  A(&w->af, B * 4);
-  A(&w->af_pows, B * n_open * 4);
-  A(&w->bsum, B * 2 * 4);
-  {
-    size_t need = 0;  // partial sums of the reduced openings: [nchunks][2][2H] Fp4 per proof, largest chip
+  size_t arena_need = 0;
+  for (int pass = 0; pass < 2 && ok; ++pass) {
+    size_t off = 0;
+    auto A = [&](auto** p, size_t count) {
+      using T = std::remove_pointer_t<std::remove_reference_t<decltype(*p)>>;
+      const size_t bytes = (std::max<size_t>(count, 4) * sizeof(T) + 255) & ~(size_t)255;
+      if (pass == 1) *p = reinterpret_cast<T*>(static_cast<char*>(ctx->arena) + off);
+      off += bytes;
+    };
+    A(&w->cycles, B * w->cap_cycles * 12);
+    A(&w->kcalls, B * w->cap_keccak * 408);
+    A(&w->kstates, B * w->cap_keccak * 25);
+    A(&w->memfinal, B * w->cap_memfinal * 5);
+    A(&w->muls, B * w->cap_muls * 3);
+    A(&w->alu_idx, B * w->cap_alu);
+    A(&w->sub_idx, B * w->cap_sub);
+    A(&w->bw_idx, B * w->cap_bw);
+    A(&w->agg_heap, B * w->cap_agg * 8);
+    A(&w->prog_mult, B << logh[kProgram]);
+    A(&w->table_hist, (B * kTableWidth) << kTableLogH);
+    A(&w->counts, B * kCountWords);
+    A(&w->n_perms, B);
+    A(&w->init_obs, B * kMachineInitObs);
+    A(&w->pub_words, B * kPubWords);
+    A(&w->spare.cycles, B * w->cap_cycles * 12);
+    A(&w->spare.kcalls, B * w->cap_keccak * 408);
+    A(&w->spare.kstates, B * w->cap_keccak * 25);
+    A(&w->spare.memfinal, B * w->cap_memfinal * 5);
+    A(&w->spare.muls, B * w->cap_muls * 3);
+    A(&w->spare.alu_idx, B * w->cap_alu);
+    A(&w->spare.sub_idx, B * w->cap_sub);
+    A(&w->spare.bw_idx, B * w->cap_bw);
+    A(&w->spare.agg_heap, B * w->cap_agg * 8);
+    A(&w->spare.prog_mult, B << logh[kProgram]);
+    A(&w->spare.counts, B * kCountWords);
+    A(&w->spare.n_perms, B);
+    A(&w->spare.init_obs, B * kMachineInitObs);
+    A(&w->spare.pub_words, B * kPubWords);
+    int lm = 0;
+    size_t n_open = 0, max_total = 0, max_h = 0;
     for (int c = 0; c < kNumChips; ++c) {
       const ChipDef& d = chip_def(c);
-      need = std::max(need, (size_t)mreduce_nchunks(d.prep_w + d.main_w + d.perm_width() + 8) * 16 * ((size_t)1 << logh[c]));
+      const size_t h = (size_t)1 << logh[c];
+      lm = std::max(lm, logh[c]);
+      max_h = std::max(max_h, h);
+      const int widths[3] = {d.main_w, d.perm_width(), 8};
+      for (int r = 0; r < 3; ++r) {
+        w->mat[c][r].w = widths[r];
+        A(&w->mat[c][r].tr, B * widths[r] * h);
+        A(&w->mat[c][r].coef, B * widths[r] * h);
+        A(&w->mat[c][r].lde, B * widths[r] * 2 * h);
+      }
+      A(&w->zpow[c], B * 2 * h * 4);
+      w->open_off[c] = n_open;
+      n_open += (size_t)d.prep_w + 2 * (size_t)d.main_w + 2 * (size_t)d.perm_width() + 8;
+      max_total = std::max<size_t>(max_total, (size_t)d.total_constraints());
     }
-    for (int c = 0; c < kNumChips; ++c)  // ... and of the tall openings
-      for (int wdt : {chip_def(c).prep_w, chip_def(c).main_w, chip_def(c).perm_width(), 8})
-        if (wdt) need = std::max(need, open_tall_scratch_words(wdt, logh[c], 1));
-    A(&w->reduce_scratch, B * need);
+    w->lm = lm;
+    w->n_open = n_open;
+    w->alpha_stride = max_total * 4;
+    const size_t N = (size_t)2 << lm;
+    for (int r = 1; r < 4; ++r) {
+      A(&w->tree[r], B * (2 * N - 1) * 8);
+      for (int c = 0; c < kNumChips; ++c)
+        if (logh[c] < lm && !w->inj[r][logh[c] + 1]) A(&w->inj[r][logh[c] + 1], (B * 8) << (logh[c] + 1));
+    }
+    for (int c = 0; c < kNumChips; ++c)
+      if (logh[c] < lm && !w->G[logh[c]]) A(&w->G[logh[c]], (B * 2 * 4) << logh[c]);
+    A(&w->ch, B);
+    A(&w->bus_ch, B * 8);
+    A(&w->bpow, B * (kInterMaxElems + 1) * 4);
+    A(&w->cum, B * kNumChips * 4);
+    A(&w->pubsum, B * 4);
+    A(&w->rowsum, B * max_h * 4);
+    A(&w->slice_sums, B * (max_h / 4096 + 1) * 4);
+    A(&w->alpha, B * 4);
+    A(&w->alpha_pows, B * w->alpha_stride);
+    A(&w->zeta, B * 4);
+    w->open_rows_log = (size_t)ceil_log2((n_open * 4 + 7) / 8);
+    const size_t R = (size_t)1 << w->open_rows_log;
+    A(&w->opened, B * 8 * R);
+    A(&w->tree_o, B * (2 * R - 1) * 8);
+    A(&w->af, B * 4);
+    A(&w->af_pows, B * n_open * 4);
+    A(&w->bsum, B * 2 * 4);
+    {
+      size_t need = 0;  // partial sums of the reduced openings: [nchunks][2][2H] Fp4 per proof, largest chip
+      for (int c = 0; c < kNumChips; ++c) {
+        const ChipDef& d = chip_def(c);
+        need = std::max(need, (size_t)mreduce_nchunks(d.prep_w + d.main_w + d.perm_width() + 8) * 16 * ((size_t)1 << logh[c]));
+      }
+      for (int c = 0; c < kNumChips; ++c)  // ... and of the tall openings
+        for (int wdt : {chip_def(c).prep_w, chip_def(c).main_w, chip_def(c).perm_width(), 8})
+          if (wdt) need = std::max(need, open_tall_scratch_words(wdt, logh[c], 1));
+      A(&w->reduce_scratch, B * need);
+    }
+    A(&w->kpartial, B * 13 * (((size_t)2 << logh[kKeccak]) * 4));
+    w->fri_layer_stride = 0;
+    w->fri_tree_stride = 0;
+    for (int k = 0; k < lm; ++k) {
+      const size_t hk = ((size_t)1 << lm) >> k;
+      w->fri_layer_stride += 2 * hk * 4;
+      w->fri_tree_stride += (2 * hk - 1) * 8;
+    }
+    w->fri_layer_stride += 2 * 4;
+    A(&w->fri_layers, B * w->fri_layer_stride);
+    A(&w->fri_trees, B * w->fri_tree_stride);
+    A(&w->betas, B * (size_t)lm * 4);
+    A(&w->witness, B);
+    A(&w->indices, B * Q);
+    w->body_words = machine_proof_body_words(logh, Q);
+    A(&w->body, B * w->body_words);
+    if (pass == 0) {
+      arena_need = off;
+      if (ctx->arena_bytes < arena_need) {
+        if (ctx->arena) (void)hipFree(ctx->arena);
+        ctx->arena = nullptr;
+        ctx->arena_bytes = 0;
+        if (hipMalloc(&ctx->arena, arena_need) != hipSuccess) { ok = false; break; }
+        ctx->arena_bytes = arena_need;
+      }
+    }
   }
-  A(&w->kpartial, B * 13 * (((size_t)2 << logh[kKeccak]) * 4));
-  w->fri_layer_stride = 0;
-  w->fri_tree_stride = 0;
-  for (int k = 0; k < lm; ++k) {
-    const size_t hk = ((size_t)1 << lm) >> k;
-    w->fri_layer_stride += 2 * hk * 4;
-    w->fri_tree_stride += (2 * hk - 1) * 8;
-  }
-  w->fri_layer_stride += 2 * 4;
-  A(&w->fri_layers, B * w->fri_layer_stride);
-  A(&w->fri_trees, B * w->fri_tree_stride);
-  A(&w->betas, B * (size_t)lm * 4);
-  A(&w->witness, B);
-  A(&w->indices, B * Q);
-  w->body_words = machine_proof_body_words(logh, Q);
-  A(&w->body, B * w->body_words);
   if (!ok) {
     ctx->mws.reset();
-    return ctx->fail(3, "machine workspace: hipMalloc failed");
+    return ctx->fail(3, "machine workspace: hipMalloc of " + std::to_string(arena_need >> 20) + " MiB failed");
   }
-  ZKSP_HIP_CHECK(ctx, hipMemsetAsync(w->opened, 0, B * 8 * R * 4, ctx->stream));
+  ZKSP_HIP_CHECK(ctx, hipMemsetAsync(w->opened, 0, (B * 8 * 4) << w->open_rows_log, ctx->stream));
   return 0;
 }
 
