@@ -473,9 +473,9 @@ __global__ __launch_bounds__(kMT) void mmcs_leaf_kernel(LeafArgs a, const P2Cons
   const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
   if (r >= n) return;
   const int b = blockIdx.y;
-  Fp s[16];
+  int32_t s[16];  // the sponge state stays in signed lazy form between permutations (poseidon2.hpp)
 #pragma unroll
-  for (int i = 0; i < 16; ++i) s[i] = Fp::zero();
+  for (int i = 0; i < 16; ++i) s[i] = 0;
   const int total = a.start[a.nseg];
   int sg = 0;
   const uint32_t* base = a.seg[0].p + (size_t)b * a.seg[0].bstride + r;
@@ -488,16 +488,16 @@ __global__ __launch_bounds__(kMT) void mmcs_leaf_kernel(LeafArgs a, const P2Cons
           ++sg;
           base = a.seg[sg].p + (size_t)b * a.seg[sg].bstride + r;
         }
-        s[i] = Fp::raw(base[(size_t)(vc - a.start[sg]) * n]);
+        s[i] = (int32_t)base[(size_t)(vc - a.start[sg]) * n];
       }
     }
-    p2_permute(s, consts);
+    p2_permute_signed(s, consts);
   }
   const size_t c = r >> a.logh, m = r & (h - 1);
   const size_t pos = c * h + (a.logh ? (size_t)(__brev((uint32_t)m) >> (32 - a.logh)) : 0);
   uint4* d = reinterpret_cast<uint4*>(a.out + (size_t)b * a.out_bstride + pos * 8);
-  d[0] = make_uint4(s[0].v, s[1].v, s[2].v, s[3].v);
-  d[1] = make_uint4(s[4].v, s[5].v, s[6].v, s[7].v);
+  d[0] = make_uint4(fps_canon(s[0]), fps_canon(s[1]), fps_canon(s[2]), fps_canon(s[3]));
+  d[1] = make_uint4(fps_canon(s[4]), fps_canon(s[5]), fps_canon(s[6]), fps_canon(s[7]));
 }
 
 // Latency form for groups with few rows (the 2 634-column keccak chip of a single proof has 4 096 of them and

@@ -292,12 +292,13 @@ __device__ __forceinline__ void lde_fixed_group(const uint32_t* __restrict__ src
 #pragma unroll
       for (int k = 0; k < EB; ++k) {
         if ((k & hk) != 0) continue;
-        const Fp w = Fp::raw(tw_inv[(1 << (stage - 1)) + (k & (hk - 1))]);
+        const bool unit = (k & (hk - 1)) == 0;  // twiddle w^0 = 1 (every pair of stage 1): no multiplication
+        const Fp w = unit ? Fp::one() : Fp::raw(tw_inv[(1 << (stage - 1)) + (k & (hk - 1))]);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           const Fp u = keep[it][c][k], v = keep[it][c][k + hk];
           keep[it][c][k] = u + v;
-          keep[it][c][k + hk] = (u - v) * w;
+          keep[it][c][k + hk] = unit ? u - v : (u - v) * w;
         }
       }
     }
@@ -336,10 +337,11 @@ __device__ __forceinline__ void lde_fixed_group(const uint32_t* __restrict__ src
 #pragma unroll
         for (int k = 0; k < EB; ++k) {
           if ((k & hk) != 0) continue;
-          const Fp w = Fp::raw(tw_fwd[(1 << (stage - 1)) + (k & (hk - 1))]);
+          const bool unit = (k & (hk - 1)) == 0;
+          const Fp w = unit ? Fp::one() : Fp::raw(tw_fwd[(1 << (stage - 1)) + (k & (hk - 1))]);
 #pragma unroll
           for (int c = 0; c < NC; ++c) {
-            const Fp u = y[c][k], t = y[c][k + hk] * w;
+            const Fp u = y[c][k], t = unit ? y[c][k + hk] : y[c][k + hk] * w;
             y[c][k] = u + t;
             y[c][k + hk] = u - t;
           }

@@ -34,13 +34,12 @@ struct P2Consts {
 //    word, t = (T + m p) / 2^32, so |t| <= |T| / 2^32 + p/2.  For |a|, |b| < 1.0667p this
 //    gives |t| < 1.034p with |T + m p| < 2^63: closed under multiplication with no
 //    conditional subtraction at all (3 instructions: mad_i64_i32, mul_lo, mad_i64_i32);
-//  * the linear layers accumulate in 64 bits (|y| < 36.2p, one instruction per term) and
-//    each output is brought back by ONE reduction: with y = hi * 2^32 + lo, c = 2^32 mod p
-//    and K = c^2 mod p,  T = lo * c + hi * K + rc * R^2  ==  (y + rc~) * R  (mod p), |T| < 2^60.1,
-//    so t = redc(T) = y + rc~ with -0.5p < t < 0.634p.  The next round constant rides along
-//    as the addend;
-//  * an internal round is sum = sum of the 16 words (64-bit), SR = sum * R as above, and
-//    out_i = redc(x_i * d_i~ + SR) with d_i~ centred: |T| < 0.517 p^2 + 2^60.1, |t| < 0.876p.
+//  * the external layers accumulate in 64 bits (|y| < 36.8p, one instruction per term) and each
+//    output is brought back below 0.55p by an estimate of y / p from its top bits and one
+//    multiplication (fps_reduce_small); the next round's constant is added to the reduced word;
+//  * an internal round is sum = sum of the 16 words (64-bit, = hi * 2^32 + lo), SR = lo * c + hi * K
+//    == sum * R (mod p) with c = 2^32 mod p and K = c^2 mod p, and out_i = redc(x_i * d_i~ + SR)
+//    with d_i~ centred: |T| < 0.525 p^2 + 2^60.1, |t| < 0.88p.
 //
 // Outputs are canonicalised only where a canonical word is needed (digests); a sponge
 // keeps its state signed between permutations.  Results are bit-identical to the
@@ -55,24 +54,27 @@ ZKSP_HD int32_t p2s_sbox(int32_t x) {
 }
 
 // circ(2*M4, M4, M4, M4), M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]], then + next constants.
-// rc[i]: the next round's constant as a canonical Montgomery-form word; it joins the 64-bit sum,
-// |sum| < 36.2p + p < 2^36.2, which fps_reduce_small brings back below 0.55p with one multiply.
+// The sums run in 64 bits (|y| < 36.8p < 2^36.2; a 64-bit addition issues at the rate of any other VOP3
+// instruction on gfx950, see profiles/r03_opcode_rates.txt), nine additions per 4-block; fps_reduce_small brings
+// each back below 0.55p with one multiply, and rc[i], the next round's constant (a canonical Montgomery-form
+// word), joins the reduced word centred, with a 32-bit addition: |out| < 1.05p, inside what the S-box and
+// the internal round accept (|x| < 2^31 = 1.0667p; x * x stays below the 1.209 p^2 fps_redc needs).
 ZKSP_HD void p2s_external_linear(int32_t* s, const uint32_t* __restrict__ rc) {
   int64_t y[16];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int64_t x0 = s[4 * c], x1 = s[4 * c + 1], x2 = s[4 * c + 2], x3 = s[4 * c + 3];
-    const int64_t sum = (x0 + x1) + (x2 + x3);
-    y[4 * c] = sum + x0 + 2 * x1;      // 2 x0 + 3 x1 + x2 + x3
-    y[4 * c + 1] = sum + x1 + 2 * x2;  // x0 + 2 x1 + 3 x2 + x3
-    y[4 * c + 2] = sum + x2 + 2 * x3;  // x0 + x1 + 2 x2 + 3 x3
-    y[4 * c + 3] = sum + x3 + 2 * x0;  // 3 x0 + x1 + x2 + 2 x3
+    const int64_t t01 = x0 + x1, t23 = x2 + x3, sum = t01 + t23, a = sum + x1, b = sum + x3;
+    y[4 * c] = a + t01;         // 2 x0 + 3 x1 + x2 + x3
+    y[4 * c + 1] = a + 2 * x2;  // x0 + 2 x1 + 3 x2 + x3
+    y[4 * c + 2] = b + t23;     // x0 + x1 + 2 x2 + 3 x3
+    y[4 * c + 3] = b + 2 * x0;  // 3 x0 + x1 + x2 + 2 x3
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int64_t col = (y[j] + y[4 + j]) + (y[8 + j] + y[12 + j]);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) s[4 * c + j] = fps_reduce_small(y[4 * c + j] + col + (int64_t)rc[4 * c + j]);
+    for (int c = 0; c < 4; ++c) s[4 * c + j] = fps_reduce_small(y[4 * c + j] + col) + fps_centre(rc[4 * c + j]);
   }
 }
 
@@ -100,7 +102,7 @@ ZKSP_HD void p2s_internal_round(int32_t* s, const P2Consts* __restrict__ k, cons
   }
 }
 
-// state: signed words, |s_i| < 1.034p (canonical residues qualify); same on exit
+// state: signed words, |s_i| < 1.05p (canonical residues qualify); |s_i| < 0.55p on exit
 ZKSP_HD void p2_permute_signed(int32_t* s, const P2Consts* __restrict__ k) {
   p2s_external_linear(s, k->lin_rc[0]);
 #pragma unroll 1

@@ -178,8 +178,13 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
         const mach::ChipDef& d = mach::chip_def(ch);
         per_proof += ((size_t)(d.main_w + d.perm_width() + 8) * 16 + 64) << kv.first[ch];
       }
-      const size_t cap =
-          std::max<size_t>(1, std::min<size_t>(ctx->params.max_batch, ((size_t)150 << 30) / std::max<size_t>(per_proof, 1)));
+      // trees, digests of injected groups, FRI layers and scratch come to about a third more; the budget is what the
+      // device has free right now plus what this client's arena already holds, less a fifth for everybody else
+      per_proof += per_proof / 2;
+      size_t mem_free = 0, mem_total = 0;
+      if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = (size_t)64 << 30;
+      const size_t budget = (mem_free + ctx->arena_bytes) / 5 * 4;
+      const size_t cap = std::max<size_t>(1, std::min<size_t>(ctx->params.max_batch, budget / std::max<size_t>(per_proof, 1)));
       for (size_t off = 0; off < kv.second.size(); off += cap) {
         Chunk ck;
         ck.lh = kv.first;
