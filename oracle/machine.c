@@ -1,6 +1,6 @@
 /* ORACLE -- TEST INFRASTRUCTURE ONLY (see field.h and machine.h).
  *
- * Chips of the machine proof (format v6): bus interactions, trace generation from the executor's
+ * Chips of the machine proof (format v7): bus interactions, trace generation from the executor's
  * records and base-field constraints.  This repository's own arithmetisation (machine.h header
  * note); what it must reproduce is the reference's statement: the committed RV32IM guest
  * (circuits/sp1-merkle-proof/src/main.rs:4-14 running crypto-ops/src/lib.rs:8-23) executed from its
@@ -369,22 +369,22 @@ static void build(void) {
     it->el[4] = lf_bits(SW_M, 16); it->el[5] = lf_bits(SW_M + 16, 16); it->el[6] = lf_bits(SW_C, 16);
     it->el[7] = lf_col(SW_MV); it->el[8] = lf_col(SW_MV + 1);
   }
-  g_chips[CH_TABLE] = (orc_chip){"table", TABLE_PREP_WIDTH, TABLE_WIDTH, 7, g_table, 0};
-  g_chips[CH_CPU] = (orc_chip){"cpu", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0};
-  g_chips[CH_CPU2] = (orc_chip){"cpu2", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0};
-  g_chips[CH_KECCAK] = (orc_chip){"keccak", 0, KECCAK_WIDTH, 50, g_keccak, 0};
-  g_chips[CH_KMEM] = (orc_chip){"keccak-mem", 0, KMEM_WIDTH, 8, g_kmem, 0};
-  g_chips[CH_MEMFINAL] = (orc_chip){"mem-final", 0, MEMFINAL_WIDTH, 10, g_memfinal, 0};
-  g_chips[CH_IMAGE] = (orc_chip){"image", IMAGE_PREP_WIDTH, IMAGE_WIDTH, 1, g_image, 0};
-  g_chips[CH_PROGRAM] = (orc_chip){"program", PROGRAM_PREP_WIDTH, PROGRAM_WIDTH, 1, g_program, 0};
-  g_chips[CH_MUL] = (orc_chip){"mul", 0, MUL_WIDTH, 2, g_mul, 0};
-  g_chips[CH_ALU] = (orc_chip){"alu", 0, ALU_WIDTH, 1, g_alu, 0};
-  g_chips[CH_ALU2] = (orc_chip){"alu2", 0, ALU_WIDTH, 1, g_alu, 0};
-  g_chips[CH_SUB] = (orc_chip){"subword", 0, SUB_WIDTH, 1, g_sub, 0};
-  g_chips[CH_SUB2] = (orc_chip){"subword2", 0, SUB_WIDTH, 1, g_sub, 0};
-  g_chips[CH_BW] = (orc_chip){"bitwise", 0, BW_WIDTH, 5, g_bw, 0};
-  g_chips[CH_BW2] = (orc_chip){"bitwise2", 0, BW_WIDTH, 5, g_bw, 0};
-  g_chips[CH_P2] = (orc_chip){"poseidon2", 0, P2CHIP_WIDTH, 3, g_p2, 0};
+  g_chips[CH_TABLE] = (orc_chip){"table", TABLE_PREP_WIDTH, TABLE_WIDTH, 7, g_table, 0, 0};
+  g_chips[CH_CPU] = (orc_chip){"cpu", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0, 5};   /* ALU, SUB, KCALL, PUBC, PUBH: one class each */
+  g_chips[CH_CPU2] = (orc_chip){"cpu2", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0, 5};
+  g_chips[CH_KECCAK] = (orc_chip){"keccak", 0, KECCAK_WIDTH, 50, g_keccak, 0, 0};
+  g_chips[CH_KMEM] = (orc_chip){"keccak-mem", 0, KMEM_WIDTH, 8, g_kmem, 0, 0};
+  g_chips[CH_MEMFINAL] = (orc_chip){"mem-final", 0, MEMFINAL_WIDTH, 10, g_memfinal, 0, 0};
+  g_chips[CH_IMAGE] = (orc_chip){"image", IMAGE_PREP_WIDTH, IMAGE_WIDTH, 1, g_image, 0, 0};
+  g_chips[CH_PROGRAM] = (orc_chip){"program", PROGRAM_PREP_WIDTH, PROGRAM_WIDTH, 1, g_program, 0, 0};
+  g_chips[CH_MUL] = (orc_chip){"mul", 0, MUL_WIDTH, 2, g_mul, 0, 0};
+  g_chips[CH_ALU] = (orc_chip){"alu", 0, ALU_WIDTH, 1, g_alu, 0, 0};
+  g_chips[CH_ALU2] = (orc_chip){"alu2", 0, ALU_WIDTH, 1, g_alu, 0, 0};
+  g_chips[CH_SUB] = (orc_chip){"subword", 0, SUB_WIDTH, 1, g_sub, 0, 0};
+  g_chips[CH_SUB2] = (orc_chip){"subword2", 0, SUB_WIDTH, 1, g_sub, 0, 0};
+  g_chips[CH_BW] = (orc_chip){"bitwise", 0, BW_WIDTH, 5, g_bw, 0, 0};
+  g_chips[CH_BW2] = (orc_chip){"bitwise2", 0, BW_WIDTH, 5, g_bw, 0, 0};
+  g_chips[CH_P2] = (orc_chip){"poseidon2", 0, P2CHIP_WIDTH, 3, g_p2, 0, 0};
   g_ready = 1;
   for (int c = 0; c < N_CHIPS; ++c) g_chips[c].n_constraints = count_constraints(c);
 }

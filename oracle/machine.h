@@ -11,7 +11,7 @@
  * (circuits/sp1-merkle-proof/src/main.rs:4-14, crypto-ops/src/lib.rs:8-23) ran to HALT(0) and
  * committed these public values.
  *
- * Format v6 (round 3).  The CPU row no longer carries its operands as bits: it holds 16-bit limbs,
+ * Format v7 (round 3).  The CPU row no longer carries its operands as bits: it holds 16-bit limbs,
  * adds / subtracts / compares (equality, unsigned order) / moves words itself, and sends xor / or /
  * and to a bitwise chip (bytes, looked up in a byte-operation table), shifts and signed less-than to
  * an ALU chip (bits) and every sub-word load or store to a sub-word chip, each with one row per such
@@ -148,10 +148,19 @@ typedef struct {
   int n_inter;
   const orc_inter* inter;
   int n_constraints;  /* base-field constraints; the LogUp constraints follow */
+  int n_merged;       /* the last n_merged interactions are sends with boolean, mutually exclusive multiplicities (one
+                         instruction class each): they share ONE fraction, (sum m_k) / (sum m_k f_k + 1 - sum m_k) */
 } orc_chip;
 const orc_chip* orc_machine_chip(int chip);
-static inline int orc_chip_helpers(const orc_chip* c) { return (c->n_inter + 1) / 2; }
-static inline int orc_chip_perm_width(const orc_chip* c) { return 4 * (orc_chip_helpers(c) + 1); }
+/* LogUp layout.  The interactions before the merged ones are taken two at a time; every such pair (or last single one),
+ * and the merged group, is a SLOT whose value at a row is the sum of its fractions.  All slots but the last have a helper
+ * column (an extension element, 4 base columns) constrained to the slot's value; the last slot has none: its value is
+ * phi_next - phi + cum / H - (sum of the helper columns), where phi is the running-sum column, cum the chip's cumulative
+ * sum (a proof word) and H the height, on EVERY row, cyclically (no boundary rows: summing the rows gives
+ * cum = sum of all fractions).  Every LogUp constraint has degree <= 3. */
+static inline int orc_chip_slots(const orc_chip* c) { return (c->n_inter - c->n_merged + 1) / 2 + (c->n_merged ? 1 : 0); }
+static inline int orc_chip_helpers(const orc_chip* c) { return orc_chip_slots(c) - 1; }
+static inline int orc_chip_perm_width(const orc_chip* c) { return 4 * orc_chip_slots(c); }
 
 /* ---- inputs: exactly the arrays zksp_mtrace_section() exposes ---- */
 typedef struct {
@@ -188,7 +197,7 @@ void orc_machine_constraints(int chip, const uint32_t* prep, const uint32_t* loc
                              uint32_t is_last, uint32_t is_trans, const uint32_t* pub, uint32_t* out);
 
 /* ---- kernel-level parity: one chip's stages for given challenges (4 canonical words each) ---- */
-/* LogUp permutation trace [perm_width][H] (helper columns, then the running sum) and the chip's cumulative sum */
+/* LogUp permutation trace [perm_width][H] (helper columns, then the running sum phi, phi_0 = 0) and the chip's cumulative sum */
 void orc_machine_stage_perm(const orc_machine_input* in, int chip, const uint32_t gamma[4], const uint32_t beta[4], uint32_t* perm,
                             uint32_t cum[4]);
 /* quotient values [8][H]: columns 4c..4c+3 = the extension element over coset c */
@@ -205,7 +214,7 @@ typedef struct {
 /* the aggregation payload's public part: Merkle root of the leaves (2-to-1 Poseidon2 compressions) and the sponge hash
  * of the leaf list, which stands for the list in the transcript */
 void orc_machine_agg_public(const uint32_t* leaves, size_t n, uint32_t root[8], uint32_t list_digest[8]);
-#define ZKSP_VERSION_MACHINE 6u
+#define ZKSP_VERSION_MACHINE 7u
 /* vk: preprocessed commitment root + digest binding entry pc, table heights and keccak mode */
 void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t prep_root[8], uint32_t vk_digest[8]);
 size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_image, const orc_config* cfg, uint32_t pv_len);

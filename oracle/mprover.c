@@ -3,7 +3,7 @@
  * Whole machine proof on the CPU: the multi-table STARK that sp1-stark / sp1-prover 3.4.0 build over
  * p3-uni-stark, p3-fri, p3-merkle-tree (mixed-height MMCS) and p3-challenger (reference
  * Cargo.lock:7485, :7273, :5378, :5253, :5336, :5197) beneath `client.prove(&pk, stdin).run()`
- * (prover/src/bin/main.rs:71-74), restated under this repository's own format "ZKSP v6"
+ * (prover/src/bin/main.rs:71-74), restated under this repository's own format "ZKSP v7"
  * (DESIGN.md "Machine proof").  PARITY UNPINNED vs SP1 proof bytes.  The HIP prover must
  * reproduce these bytes exactly.
  *
@@ -186,9 +186,55 @@ static void gather_row(const chipd* d, const uint32_t* const* src, int is_lde, s
       row[n++] = is_lde ? src[r][((size_t)col * 2 + cs) * d->h + m] : src[r][(size_t)col * d->h + m];
 }
 
+/* ---- LogUp slots (machine.h "LogUp layout") ---- */
+static fe signed_mult(const orc_inter* it, const uint32_t* row) {
+  const fe m = lf_eval(&it->mult, row);
+  return it->sign < 0 ? f_neg(m) : m;
+}
+/* denominators and numerators of slot s: a regular pair / single gives (ma, fa, mb, fb) with (0, 1) for a missing second
+ * fraction; the merged slot gives (M, F, 0, 1) */
+static void slot_terms(const orc_chip* def, const aff* af, int s, const uint32_t* row, fe* ma, fe4* fa, fe* mb, fe4* fb) {
+  const int nr = def->n_inter - def->n_merged, np = (nr + 1) / 2;
+  *mb = 0;
+  *fb = e_one();
+  if (s < np) {
+    *ma = signed_mult(&def->inter[2 * s], row);
+    *fa = aff_eval(&af[2 * s], row);
+    if (2 * s + 1 < nr) {
+      *mb = signed_mult(&def->inter[2 * s + 1], row);
+      *fb = aff_eval(&af[2 * s + 1], row);
+    }
+    return;
+  }
+  fe msum = 0;
+  fe4 f = e_zero();
+  for (int k = nr; k < def->n_inter; ++k) {
+    const fe m = signed_mult(&def->inter[k], row);
+    msum = f_add(msum, m);
+    if (m) f = e_add(f, e_mul_base(aff_eval(&af[k], row), m));
+  }
+  *ma = msum;
+  *fa = e_add(f, e_from(f_sub(1, msum)));
+}
+static fe4 slot_value(const orc_chip* def, const aff* af, int s, const uint32_t* row) {
+  fe ma, mb;
+  fe4 fa, fb, v = e_zero();
+  slot_terms(def, af, s, row, &ma, &fa, &mb, &fb);
+  if (ma) v = e_add(v, e_mul_base(e_inv(fa), ma));
+  if (mb) v = e_add(v, e_mul_base(e_inv(fb), mb));
+  return v;
+}
+/* v fa fb - (ma fb + mb fa): zero exactly when v is the slot's value */
+static fe4 slot_constraint(const orc_chip* def, const aff* af, int s, const uint32_t* row, fe4 v) {
+  fe ma, mb;
+  fe4 fa, fb;
+  slot_terms(def, af, s, row, &ma, &fa, &mb, &fb);
+  return e_sub(e_mul(e_mul(v, fa), fb), e_add(e_mul_base(fb, ma), e_mul_base(fa, mb)));
+}
+
 static void perm_trace(chipd* d, fe4 gamma, const fe4* bpow) {
   const orc_chip* def = d->def;
-  const int ni = def->n_inter, nh = orc_chip_helpers(def), rw = d->w[R_PREP] + d->w[R_MAIN];
+  const int ni = def->n_inter, ns = orc_chip_slots(def), nh = ns - 1, rw = d->w[R_PREP] + d->w[R_MAIN];
   const size_t h = d->h;
   aff* af = (aff*)malloc((size_t)ni * sizeof(aff));
   for (int i = 0; i < ni; ++i) build_aff(&def->inter[i], gamma, bpow, &af[i]);
@@ -202,27 +248,26 @@ static void perm_trace(chipd* d, fe4 gamma, const fe4* bpow) {
     for (size_t r = 0; r < h; ++r) {
       gather_row(d, src, 0, 0, r, row);
       fe4 tot = e_zero();
-      for (int j = 0; j < nh; ++j) {
-        fe4 hj = e_zero();
-        for (int k = 2 * j; k < 2 * j + 2 && k < ni; ++k) {
-          fe m = lf_eval(&def->inter[k].mult, row);
-          if (m == 0) continue;
-          if (def->inter[k].sign < 0) m = f_neg(m);
-          hj = e_add(hj, e_mul_base(e_inv(aff_eval(&af[k], row)), m));
-        }
-        for (int t = 0; t < 4; ++t) p[(size_t)(4 * j + t) * h + r] = hj.c[t];
+      for (int j = 0; j < ns; ++j) {
+        const fe4 hj = slot_value(def, af, j, row);
+        if (j < nh)
+          for (int t = 0; t < 4; ++t) p[(size_t)(4 * j + t) * h + r] = hj.c[t];
         tot = e_add(tot, hj);
       }
       rowsum[r] = tot;
     }
     free(row);
   }
+  fe4 cum = e_zero();
+  for (size_t r = 0; r < h; ++r) cum = e_add(cum, rowsum[r]);
+  d->cum = cum;
+  /* phi_0 = 0, phi_{r+1} = phi_r + rowsum_r - cum / H: back at 0 after the last row */
+  const fe4 step = e_mul_base(cum, f_inv((fe)(h % FP)));
   fe4 acc = e_zero();
   for (size_t r = 0; r < h; ++r) {
     for (int t = 0; t < 4; ++t) p[(size_t)(4 * nh + t) * h + r] = acc.c[t];
-    acc = e_add(acc, rowsum[r]);
+    acc = e_sub(e_add(acc, rowsum[r]), step);
   }
-  d->cum = acc;
   free(rowsum);
   free(af);
 }
@@ -230,7 +275,8 @@ static void perm_trace(chipd* d, fe4 gamma, const fe4* bpow) {
 /* ---- quotient of one chip ---- */
 static void chip_quotient(chipd* d, int chip, fe4 alpha, fe4 gamma, const fe4* bpow, const uint32_t* pub) {
   const orc_chip* def = d->def;
-  const int ni = def->n_inter, nh = orc_chip_helpers(def), nb = def->n_constraints, total = nb + nh + 3;
+  const int ni = def->n_inter, nh = orc_chip_helpers(def), nb = def->n_constraints, total = nb + nh + 1;
+  const fe4 cum_step = e_mul_base(d->cum, f_inv((fe)(d->h % FP)));
   const int rw = d->w[R_PREP] + d->w[R_MAIN], pw = d->w[R_PREP];
   const size_t h = d->h;
   fe4* apow = (fe4*)malloc((size_t)total * sizeof(fe4));
@@ -262,35 +308,21 @@ static void chip_quotient(chipd* d, int chip, fe4 alpha, fe4 gamma, const fe4* b
         orc_machine_constraints(chip, loc, loc + pw, nxt + pw, is_first, is_last, is_trans, pub, cons);
         fe4 acc = e_zero();
         for (int k = 0; k < nb; ++k) acc = e_add(acc, e_mul_base(apow[k], cons[k]));
-        /* LogUp: helpers, then the running sum */
+        /* LogUp: the helper columns' slots, then the last slot, whose value is phi_next - phi + cum / H - sum of helpers */
         fe4 hsum = e_zero();
         for (int j = 0; j < nh; ++j) {
           fe4 hj;
           for (int t = 0; t < 4; ++t) hj.c[t] = lp[((size_t)(4 * j + t) * 2 + cs) * h + m];
           hsum = e_add(hsum, hj);
-          const int ka = 2 * j, kb = 2 * j + 1;
-          fe ma = lf_eval(&def->inter[ka].mult, loc);
-          if (def->inter[ka].sign < 0) ma = f_neg(ma);
-          const fe4 fa = aff_eval(&af[ka], loc);
-          fe4 v;
-          if (kb < ni) {
-            fe mb = lf_eval(&def->inter[kb].mult, loc);
-            if (def->inter[kb].sign < 0) mb = f_neg(mb);
-            const fe4 fb = aff_eval(&af[kb], loc);
-            v = e_sub(e_mul(e_mul(hj, fa), fb), e_add(e_mul_base(fb, ma), e_mul_base(fa, mb)));
-          } else {
-            v = e_sub(e_mul(hj, fa), e_from(ma));
-          }
-          acc = e_add(acc, e_mul(apow[nb + j], v));
+          acc = e_add(acc, e_mul(apow[nb + j], slot_constraint(def, af, j, loc, hj)));
         }
         fe4 phi, phin;
         for (int t = 0; t < 4; ++t) {
           phi.c[t] = lp[((size_t)(4 * nh + t) * 2 + cs) * h + m];
           phin.c[t] = lp[((size_t)(4 * nh + t) * 2 + cs) * h + mn];
         }
-        acc = e_add(acc, e_mul(apow[nb + nh], e_mul_base(phi, is_first)));
-        acc = e_add(acc, e_mul(apow[nb + nh + 1], e_mul_base(e_sub(e_sub(phin, phi), hsum), is_trans)));
-        acc = e_add(acc, e_mul(apow[nb + nh + 2], e_mul_base(e_sub(e_sub(d->cum, phi), hsum), is_last)));
+        const fe4 last = e_sub(e_add(e_sub(phin, phi), cum_step), hsum);
+        acc = e_add(acc, e_mul(apow[nb + nh], slot_constraint(def, af, nh, loc, last)));
         acc = e_mul_base(acc, zh_inv);
         for (int t = 0; t < 4; ++t) out[(size_t)(4 * cs + t) * h + m] = acc.c[t];
       }

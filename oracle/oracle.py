@@ -288,7 +288,7 @@ CPUPUB_N = 5
 
 class MachineChip(C.Structure):
     _fields_ = [("name", C.c_char_p), ("prep_width", C.c_int), ("main_width", C.c_int), ("n_inter", C.c_int),
-                ("inter", C.c_void_p), ("n_constraints", C.c_int)]
+                ("inter", C.c_void_p), ("n_constraints", C.c_int), ("n_merged", C.c_int)]
 
 
 class MachineInput(C.Structure):
@@ -330,7 +330,8 @@ def machine_input(t: dict):
 def machine_chip(chip: int):
     c = lib().orc_machine_chip(chip).contents
     return {"name": c.name.decode(), "prep_width": c.prep_width, "main_width": c.main_width, "n_inter": c.n_inter,
-            "n_constraints": c.n_constraints}
+            "n_constraints": c.n_constraints, "n_merged": c.n_merged,
+            "perm_width": 4 * ((c.n_inter - c.n_merged + 1) // 2 + (1 if c.n_merged else 0))}
 
 
 def machine_heights(t: dict) -> List[int]:
@@ -385,7 +386,7 @@ def machine_stage_perm(t: dict, chip: int, gamma, beta):
     mi, _keep = machine_input(t)
     d = machine_chip(chip)
     h = 1 << machine_heights(t)[chip]
-    pw = 4 * ((d["n_inter"] + 1) // 2 + 1)
+    pw = d["perm_width"]
     perm, cum = np.zeros((pw, h), np.uint32), np.zeros(4, np.uint32)
     lib().orc_machine_stage_perm(C.byref(mi), chip, _p(_u32(gamma)), _p(_u32(beta)), _p(perm), _p(cum))
     return perm, [int(x) for x in cum]

@@ -72,12 +72,14 @@ struct PermArgs {
   Seg prep, main_;                 // traces [w][H]
   const uint32_t* bus_ch;          // [B][8]: gamma, beta
   const uint32_t* bpow;            // [B][kInterMaxElems + 1] Fp4: powers of beta
-  uint32_t* perm;                  // [B][perm_width][H]
+  uint32_t* perm;                  // [B][perm_width][H]: the helper columns, then the running sum phi
+  int perm_width;
   size_t perm_bstride;
   uint32_t* rowsum;                // [B][H] Fp4 scratch
   uint32_t* slice_sums;            // [B][H / 4096] Fp4 scratch (tall chips: the running sum is scanned in slices)
   uint32_t* cum;                   // [B] Fp4 (this chip's cumulative sum)
   size_t cum_bstride;
+  uint32_t h_inv;                  // 1 / H (Montgomery): the running sum steps by rowsum - cum / H, cyclically
   int logh, batch;
 };
 void launch_perm_trace(hipStream_t stream, const PermArgs& a);
@@ -91,7 +93,7 @@ void launch_public_bus(hipStream_t stream, const uint32_t* pub_words /*[B][kPubW
 struct MQuotArgs {
   int chip;
   const mach::Interaction* inter;
-  int n_inter, n_base;          // base constraints; helpers and the 3 running-sum constraints follow
+  int n_inter, n_base;          // base constraints; one LogUp constraint per slot follows (machine_defs.hpp "LogUp layout")
   Seg prep, main_, perm;        // LDEs [w][2H]
   const uint32_t* alpha_pows;   // [B][alpha_stride] Fp4
   size_t alpha_bstride;
@@ -103,6 +105,7 @@ struct MQuotArgs {
   uint32_t shift[2];            // g, g * w_2H  (Montgomery)
   uint32_t zh_inv[2];
   uint32_t wh_inv;
+  uint32_t h_inv;               // 1 / H (Montgomery)
   const P2Consts* consts;       // Poseidon2 constants (the Poseidon2 chip's constraints)
   const uint32_t* pubs;         // CPU instances: this instance's CpuPub words per proof (Montgomery), stride pubs_bstride
   size_t pubs_bstride;

@@ -721,14 +721,16 @@ void launch_table_trace(hipStream_t stream, const MachineRecords& rec, uint32_t*
 // The CPU chip's 22 bus interactions evaluated from values a row holds once (the class id, the selector sums, the word
 // address, the four previous access times), instead of through the generic linear forms (which reload and rescale every
 // column for every tuple): the same field elements, a fraction of the work.  visit(j, ma, fa, mb, fb) is called for the
-// helper columns j = 0..10 in order with the two fractions of each; multiplicities are signed.  Must restate
-// machine_defs.cpp's g_cpu[] exactly: the whole-proof parity tests compare against the oracle's generic evaluation.
-// J0, J1: only the helper columns J0 <= j < J1 are visited (the loads the others need are dead code): the kernels below
-// evaluate the 11 pairs in three launches, because all 22 extension-field fingerprints at once do not fit the register
+// LogUp slots j = 0..9 in order (machine_defs.hpp "LogUp layout") with the slot's value ma / fa + mb / fb: slots 0..7 are
+// pairs, slot 8 the last single receive (mb = 0, fb = 1), slot 9 the five merged sends, M / F with M = sum m_k and
+// F = sum m_k f_k + 1 - M.  Multiplicities are signed.  Must restate machine_defs.cpp's g_cpu[] exactly: the whole-proof
+// parity tests compare against the oracle's generic evaluation.
+// J0, J1: only the slots J0 <= j < J1 are visited (the loads the others need are dead code): the kernels below
+// evaluate the slots in three launches, because all 22 extension-field fingerprints at once do not fit the register
 // file (256 VGPRs and one wave per SIMD when they are evaluated together).
-constexpr int kCpuHelpers = 11, kCpuBusGroups = 3;
+constexpr int kCpuSlots = 10, kCpuHelpers = kCpuSlots - 1, kCpuBusGroups = 3;
 __host__ __device__ constexpr int cpu_group_lo(int g) { return g == 0 ? 0 : g == 1 ? 4 : 8; }
-__host__ __device__ constexpr int cpu_group_hi(int g) { return g == 0 ? 4 : g == 1 ? 8 : kCpuHelpers; }
+__host__ __device__ constexpr int cpu_group_hi(int g) { return g == 0 ? 4 : g == 1 ? 8 : kCpuSlots; }
 template <int J0, int J1, class V>
 __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, size_t cs, const Fp4& gamma,
                                               const uint32_t* __restrict__ bpow, V&& visit_all) {
@@ -786,21 +788,23 @@ __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, 
   if (J0 <= 6 && 6 < J1) visit(6, -one, grng + b2 * g[6], -one, gbyt + b1 * g[1] + b2 * g[3]);
   // the adder output: high limb (kind 2 where it is an address), low limb less the byte offset (kind 1 where aligned)
   if (J0 <= 7 && 7 < J1) visit(7, -one, gbyt + b1 * g[5] + b2 * g[7], -chk, grng + b1 * top.dbl() + b2 * x_hi);
-  if (J0 <= 8 && 8 < J1) {
+  if (J0 <= 8 && 8 < J1) visit(8, -chk, grng + b1 * al + b2 * (x_lo - off), Fp::zero(), Fp4::one());
+  if (J0 <= 9 && 9 < J1) {
+    // one instruction class each: ALU-chip sends, sub-word sends, the keccak call, COMMIT / COMMIT_DEFERRED, HALT
     const Fp4 falu = busc(BUS_ALU) + b1 * code + b2 * a_lo + b3 * a_hi + b4 * b_lo + m_load_fp4(bpow + 20) * b_hi +
                      m_load_fp4(bpow + 24) * c_lo + m_load_fp4(bpow + 28) * c_hi;
-    visit(8, -chk, grng + b1 * al + b2 * (x_lo - off), alu, falu);
-  }
-  if (J0 <= 9 && 9 < J1) {
+    Fp4 f = falu * alu;
     const Fp4 fsub = busc(BUS_SUB) + b1 * code + b2 * off + b3 * a_lo + b4 * a_hi + m_load_fp4(bpow + 20) * m_lo +
                      m_load_fp4(bpow + 24) * m_hi + m_load_fp4(bpow + 28) * c_lo + m_load_fp4(bpow + 32) * mv_lo +
                      m_load_fp4(bpow + 36) * mv_hi;
-    visit(9, sub, fsub, sel[CL_KECCAK], busc(BUS_KCALL) + b1 * ts + b2 * c_lo + b3 * c_hi);
-  }
-  if (J0 <= 10 && 10 < J1) {
-    const Fp scc = col(C_SC + SC_COMMIT), scd = col(C_SC + SC_DEFER);
-    visit(10, scc + scd, busc(BUS_PUBC) + b1 * (scc + scd.dbl()) + b2 * c_lo + b3 * m_lo + b4 * m_hi, col(C_SC + SC_HALT),
-          busc(BUS_PUBH) + b1 * c_lo + b2 * c_hi);
+    f += fsub * sub;
+    const Fp kec = sel[CL_KECCAK], scc = col(C_SC + SC_COMMIT), scd = col(C_SC + SC_DEFER), halt = col(C_SC + SC_HALT);
+    f += (busc(BUS_KCALL) + b1 * ts + b2 * c_lo + b3 * c_hi) * kec;
+    f += (busc(BUS_PUBC) + b1 * (scc + scd.dbl()) + b2 * c_lo + b3 * m_lo + b4 * m_hi) * (scc + scd);
+    f += (busc(BUS_PUBH) + b1 * c_lo + b2 * c_hi) * halt;
+    const Fp msum = alu + sub + kec + scc + scd + halt;
+    f.c[0] += one - msum;
+    visit(9, msum, f, Fp::zero(), Fp4::one());
   }
 }
 
@@ -822,7 +826,8 @@ __device__ __forceinline__ void batch_inverse(Fp4* f) {
   f[0] = inv;
 }
 
-// helper columns of group G (cpu_group_lo .. cpu_group_hi); the row sum accumulates over the three launches
+// slots of group G (cpu_group_lo .. cpu_group_hi): their helper columns (the last slot has none) and their share of the
+// row sum, which accumulates over the three launches
 template <int G>
 __global__ __launch_bounds__(kMT) void perm_terms_cpu_kernel(PermArgs a) {
   constexpr int J0 = cpu_group_lo(G), J1 = cpu_group_hi(G), NF = 2 * (J1 - J0);
@@ -846,8 +851,10 @@ __global__ __launch_bounds__(kMT) void perm_terms_cpu_kernel(PermArgs a) {
 #pragma unroll
   for (int j = J0; j < J1; ++j) {
     const Fp4 hj = f[2 * (j - J0)] * m[2 * (j - J0)] + f[2 * (j - J0) + 1] * m[2 * (j - J0) + 1];
+    if (j < kCpuHelpers) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) p[(size_t)(4 * j + t) * h] = hj.c[t].v;
+      for (int t = 0; t < 4; ++t) p[(size_t)(4 * j + t) * h] = hj.c[t].v;
+    }
     tot += hj;
   }
   m_store_fp4(rs, tot);
@@ -862,10 +869,10 @@ __global__ __launch_bounds__(kMT) void perm_terms_kernel(PermArgs a) {
              a.prep.width, h};
   const Fp4 gamma = m_load_fp4(a.bus_ch + (size_t)b * 8);
   const uint32_t* bpow = a.bpow + (size_t)b * (kInterMaxElems + 1) * 4;
-  const int nh = (a.n_inter + 1) / 2;
+  const int ns = (a.n_inter + 1) / 2;  // slots (no merged interactions outside the CPU chip); the last has no column
   uint32_t* p = a.perm + (size_t)b * a.perm_bstride + r;
   Fp4 tot = Fp4::zero();
-  for (int j = 0; j < nh; ++j) {
+  for (int j = 0; j < ns; ++j) {
     Fp4 hj = Fp4::zero();
     for (int k = 2 * j; k < 2 * j + 2 && k < a.n_inter; ++k) {
       const Interaction& it = a.inter[k];
@@ -874,14 +881,16 @@ __global__ __launch_bounds__(kMT) void perm_terms_kernel(PermArgs a) {
       if (it.sign < 0) m = -m;
       hj += m_fingerprint(it, rv, gamma, bpow).inv() * m;
     }
+    if (j < ns - 1) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) p[(size_t)(4 * j + t) * h] = hj.c[t].v;
+      for (int t = 0; t < 4; ++t) p[(size_t)(4 * j + t) * h] = hj.c[t].v;
+    }
     tot += hj;
   }
   m_store_fp4(a.rowsum + ((size_t)b * h + r) * 4, tot);
 }
 
-// one workgroup per proof: exclusive running sum of the row sums -> the phi columns, total -> cum
+// one workgroup per proof: total of the row sums -> cum; phi_0 = 0, phi_{r+1} = phi_r + rowsum_r - cum / H
 __global__ __launch_bounds__(kMT) void perm_scan_kernel(PermArgs a) {
   __shared__ Fp4 part[kMT];
   const size_t h = (size_t)1 << a.logh;
@@ -900,13 +909,13 @@ __global__ __launch_bounds__(kMT) void perm_scan_kernel(PermArgs a) {
     part[tid] = v;
     __syncthreads();
   }
-  Fp4 acc = tid ? part[tid - 1] : Fp4::zero();
-  const int nh = (a.n_inter + 1) / 2;
-  uint32_t* ph = a.perm + (size_t)b * a.perm_bstride + (size_t)4 * nh * h;
+  const Fp4 step = part[kMT - 1] * Fp::raw(a.h_inv);
+  Fp4 acc = (tid ? part[tid - 1] : Fp4::zero()) - step * Fp::from_canonical((uint32_t)r0);
+  uint32_t* ph = a.perm + (size_t)b * a.perm_bstride + (size_t)(a.perm_width - 4) * h;
   for (size_t r = r0; r < r1; ++r) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) ph[(size_t)j * h + r] = acc.c[j].v;
-    acc += m_load_fp4(tm + r * 4);
+    acc += m_load_fp4(tm + r * 4) - step;
   }
   if (tid == kMT - 1) m_store_fp4(a.cum + (size_t)b * a.cum_bstride, part[kMT - 1]);
 }
@@ -929,7 +938,7 @@ __device__ __forceinline__ Fp4 m_block_sum_fwd(Fp4 v, Fp4* red) {
 }
 
 // Tall chips: the running sum in slices.  Pass 1 sums every slice of kScanSlice rows (one workgroup each);
-// pass 2 gives a workgroup the total of the slices before its own and scans the slice.  Field addition is
+// pass 2 gives a workgroup the total of the slices before its own (and of all, for the step cum / H) and scans the slice.  Field addition is
 // exact and associative, so the columns equal the single-workgroup scan's.
 constexpr int kScanSlice = 4096;
 __global__ __launch_bounds__(kMT) void perm_slice_sum_kernel(PermArgs a, uint32_t* __restrict__ slice_sums, int nslices) {
@@ -946,9 +955,13 @@ __global__ __launch_bounds__(kMT) void perm_slice_scan_kernel(PermArgs a, const 
   __shared__ Fp4 part[kMT];
   const size_t h = (size_t)1 << a.logh;
   const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  // offset = total of the slices before this one (at most 512 of them: one strided pass + a block sum)
-  Fp4 before = Fp4::zero();
-  for (int i = tid; i < g; i += kMT) before += m_load_fp4(slice_sums + ((size_t)b * nslices + i) * 4);
+  // offset = total of the slices before this one, total = of all of them (at most 512: one strided pass + a block sum each)
+  Fp4 before = Fp4::zero(), all = Fp4::zero();
+  for (int i = tid; i < nslices; i += kMT) {
+    const Fp4 v = m_load_fp4(slice_sums + ((size_t)b * nslices + i) * 4);
+    all += v;
+    if (i < g) before += v;
+  }
   part[tid] = before;
   __syncthreads();
   for (int off = kMT / 2; off >= 1; off >>= 1) {
@@ -956,6 +969,14 @@ __global__ __launch_bounds__(kMT) void perm_slice_scan_kernel(PermArgs a, const 
     __syncthreads();
   }
   const Fp4 offset = part[0];
+  __syncthreads();
+  part[tid] = all;
+  __syncthreads();
+  for (int off = kMT / 2; off >= 1; off >>= 1) {
+    if (tid < off) part[tid] += part[tid + off];
+    __syncthreads();
+  }
+  const Fp4 total = part[0], step = total * Fp::raw(a.h_inv);
   __syncthreads();
   constexpr int chunk = kScanSlice / kMT;
   const size_t r0 = (size_t)g * kScanSlice + (size_t)tid * chunk;
@@ -971,15 +992,14 @@ __global__ __launch_bounds__(kMT) void perm_slice_scan_kernel(PermArgs a, const 
     part[tid] = v;
     __syncthreads();
   }
-  Fp4 acc = offset + (tid ? part[tid - 1] : Fp4::zero());
-  const int nh = (a.n_inter + 1) / 2;
-  uint32_t* ph = a.perm + (size_t)b * a.perm_bstride + (size_t)4 * nh * h;
+  Fp4 acc = offset + (tid ? part[tid - 1] : Fp4::zero()) - step * Fp::from_canonical((uint32_t)r0);
+  uint32_t* ph = a.perm + (size_t)b * a.perm_bstride + (size_t)(a.perm_width - 4) * h;
   for (int r = 0; r < chunk; ++r) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) ph[(size_t)j * h + r0 + r] = acc.c[j].v;
-    acc += m_load_fp4(tm + (r0 + r) * 4);
+    acc += m_load_fp4(tm + (r0 + r) * 4) - step;
   }
-  if (g == nslices - 1 && tid == kMT - 1) m_store_fp4(a.cum + (size_t)b * a.cum_bstride, acc);
+  if (g == 0 && tid == 0) m_store_fp4(a.cum + (size_t)b * a.cum_bstride, total);
 }
 
 void launch_perm_trace(hipStream_t stream, const PermArgs& a) {
@@ -1107,7 +1127,8 @@ __device__ __forceinline__ void point_selectors(const MQuotArgs& a, size_t pt, P
   pi->last = zh * pi->trans.inv();
 }
 
-// the LogUp constraints of a chip at one point, folded with their powers of alpha into `acc`
+// the LogUp constraints of a chip at one point (one per slot: machine_defs.hpp "LogUp layout"), folded with their powers
+// of alpha into `acc`.  No merged interactions here: the CPU chip has its own kernels.
 __device__ __forceinline__ void logup_constraints(const MQuotArgs& a, const PointInfo& pi, Fp4* acc) {
   const size_t h = (size_t)1 << a.logh, n = 2 * h;
   const int b = pi.b;
@@ -1116,14 +1137,24 @@ __device__ __forceinline__ void logup_constraints(const MQuotArgs& a, const Poin
   const Fp4 gamma = m_load_fp4(a.bus_ch + (size_t)b * 8);
   const uint32_t* bpow = a.bpow + (size_t)b * (kInterMaxElems + 1) * 4;
   const uint32_t* ap = a.alpha_pows + (size_t)b * a.alpha_bstride;
-  const int nh = (a.n_inter + 1) / 2;
+  const int ns = (a.n_inter + 1) / 2, nh = ns - 1;
   const uint32_t* pl = a.perm.p + (size_t)b * a.perm.bstride + (size_t)pi.c * h;
   Fp4 hsum = Fp4::zero();
-  for (int j = 0; j < nh; ++j) {
+  for (int j = 0; j < ns; ++j) {
     Fp4 hj;
+    if (j < nh) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) hj.c[t] = Fp::raw(pl[(size_t)(4 * j + t) * n + pi.m]);
-    hsum += hj;
+      for (int t = 0; t < 4; ++t) hj.c[t] = Fp::raw(pl[(size_t)(4 * j + t) * n + pi.m]);
+      hsum += hj;
+    } else {  // the last slot's value: phi_next - phi + cum / H - the helper columns
+      Fp4 phi, phin;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        phi.c[t] = Fp::raw(pl[(size_t)(4 * nh + t) * n + pi.m]);
+        phin.c[t] = Fp::raw(pl[(size_t)(4 * nh + t) * n + pi.mn]);
+      }
+      hj = phin - phi + m_load_fp4(a.cum + (size_t)b * a.cum_bstride) * Fp::raw(a.h_inv) - hsum;
+    }
     const Interaction& ia = a.inter[2 * j];
     Fp ma = m_lf_eval(ia.mult, rv);
     if (ia.sign < 0) ma = -ma;
@@ -1141,16 +1172,6 @@ __device__ __forceinline__ void logup_constraints(const MQuotArgs& a, const Poin
     }
     *acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + j)) * v;
   }
-  Fp4 phi, phin;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    phi.c[t] = Fp::raw(pl[(size_t)(4 * nh + t) * n + pi.m]);
-    phin.c[t] = Fp::raw(pl[(size_t)(4 * nh + t) * n + pi.mn]);
-  }
-  const Fp4 cum = m_load_fp4(a.cum + (size_t)b * a.cum_bstride);
-  *acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh)) * (phi * pi.first);
-  *acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh + 1)) * ((phin - phi - hsum) * pi.trans);
-  *acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh + 2)) * ((cum - phi - hsum) * pi.last);
 }
 
 __device__ __forceinline__ void init_ctx(const MQuotArgs& a, const PointInfo& pi, MQCtx* ctx) {
@@ -1204,7 +1225,7 @@ __global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
 }
 
 // CPU chip: the base constraints (task 0) and the LogUp constraints with the fingerprints of cpu_bus_pairs, one launch
-// per group of helper columns (tasks 1..3), each with its own register budget.  A point's partial sum travels through
+// per group of slots (tasks 1..3), each with its own register budget.  A point's partial sum travels through
 // a.partial ([B][2H] Fp4): task 0 writes it, the others add, the last one divides by the vanishing polynomial.
 template <int TASK>
 __global__ __launch_bounds__(kMT) void cpu_quotient_task_kernel(MQuotArgs a) {
@@ -1232,25 +1253,22 @@ __global__ __launch_bounds__(kMT) void cpu_quotient_task_kernel(MQuotArgs a) {
     cpu_bus_pairs<J0, J1>(a.main_.p + (size_t)b * a.main_.bstride + pt, n, gamma, bpow,
                           [&](int j, Fp ma, const Fp4& fa, Fp mb, const Fp4& fb) {
                             Fp4 hj;
+                            if (j < nh) {
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) hj.c[t] = Fp::raw(pl[(size_t)(4 * j + t) * n + pi.m]);
+                              for (int t = 0; t < 4; ++t) hj.c[t] = Fp::raw(pl[(size_t)(4 * j + t) * n + pi.m]);
+                            } else {
+                              // the last slot has no column: its value is phi_next - phi + cum / H - the helper columns
+#pragma unroll
+                              for (int t = 0; t < 4; ++t) {
+                                Fp sacc = Fp::zero();
+                                for (int i = 0; i < nh; ++i) sacc += Fp::raw(pl[(size_t)(4 * i + t) * n + pi.m]);
+                                hj.c[t] = Fp::raw(pl[(size_t)(4 * nh + t) * n + pi.mn]) - Fp::raw(pl[(size_t)(4 * nh + t) * n + pi.m]) - sacc;
+                              }
+                              hj += m_load_fp4(a.cum + (size_t)b * a.cum_bstride) * Fp::raw(a.h_inv);
+                            }
                             acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + j)) * (hj * fa * fb - (fb * ma + fa * mb));
                           });
     if constexpr (G == kCpuBusGroups - 1) {
-      // the running sum: phi starts at 0, grows by the row's helper columns, ends at the cumulative sum
-      Fp4 hsum = Fp4::zero(), phi, phin;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        Fp sacc = Fp::zero();
-        for (int j = 0; j < nh; ++j) sacc += Fp::raw(pl[(size_t)(4 * j + t) * n + pi.m]);
-        hsum.c[t] = sacc;
-        phi.c[t] = Fp::raw(pl[(size_t)(4 * nh + t) * n + pi.m]);
-        phin.c[t] = Fp::raw(pl[(size_t)(4 * nh + t) * n + pi.mn]);
-      }
-      const Fp4 cum = m_load_fp4(a.cum + (size_t)b * a.cum_bstride);
-      acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh)) * (phi * pi.first);
-      acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh + 1)) * ((phin - phi - hsum) * pi.trans);
-      acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + nh + 2)) * ((cum - phi - hsum) * pi.last);
       const Fp4 q = acc * Fp::raw(pi.c ? a.zh_inv[1] : a.zh_inv[0]);
       uint32_t* dst = a.quot + (size_t)b * 8 * h + pi.m;
 #pragma unroll

@@ -1,4 +1,4 @@
-// See machine_defs.hpp.  Bus protocol (DESIGN.md "Machine proof", format v6):
+// See machine_defs.hpp.  Bus protocol (DESIGN.md "Machine proof", format v7):
 //   MEM    (addr, lo, hi, time)   every access consumes its predecessor's tuple and produces its own
 //   PROG   (pc, class, code, uc, wr, use2, rd, rs1, rs2, imm_lo, imm_hi, tgt_lo, tgt_hi)   instruction fetch, every CPU row
 //   KCALL  (time, ptr_lo, ptr_hi)   CPU -> keccak-memory: one precompile call
@@ -312,22 +312,22 @@ void build() {
       for (int i = 0; i < 16; ++i) lf_add(out.el[1 + j], ylast + i, (uint64_t)m4[j & 3][i & 3] * ((i >> 2) == (j >> 2) ? 2u : 1u));
     }
   }
-  g_chips[kP2] = {"poseidon2", 0, kP2Width, 3, g_p2, kP2Constraints};
-  g_chips[kTable] = {"table", kTablePrepWidth, kTableWidth, 7, g_table, 2};
-  g_chips[kCpu] = {"cpu", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints};
-  g_chips[kCpu2] = {"cpu2", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints};
-  g_chips[kKeccak] = {"keccak", 0, kKeccakWidth, 50, g_keccak, kKeccakConstraints};
-  g_chips[kKmem] = {"keccak-mem", 0, kKmemWidth, 8, g_kmem, kKmemConstraints};
-  g_chips[kMemFinal] = {"mem-final", 0, kMemFinalWidth, 10, g_memfinal, kMemFinalConstraints};
-  g_chips[kImage] = {"image", kImagePrepWidth, kImageWidth, 1, g_image, 1};
-  g_chips[kProgram] = {"program", kProgramPrepWidth, kProgramWidth, 1, g_program, 0};
-  g_chips[kMul] = {"mul", 0, kMulWidth, 2, g_mul, kMulConstraints};
-  g_chips[kAlu] = {"alu", 0, kAluWidth, 1, g_alu, kAluConstraints};
-  g_chips[kAlu2] = {"alu2", 0, kAluWidth, 1, g_alu, kAluConstraints};
-  g_chips[kSub] = {"subword", 0, kSubWidth, 1, g_sub, kSubConstraints};
-  g_chips[kSub2] = {"subword2", 0, kSubWidth, 1, g_sub, kSubConstraints};
-  g_chips[kBw] = {"bitwise", 0, kBwWidth, 5, g_bw, kBwConstraints};
-  g_chips[kBw2] = {"bitwise2", 0, kBwWidth, 5, g_bw, kBwConstraints};
+  g_chips[kP2] = {"poseidon2", 0, kP2Width, 3, g_p2, kP2Constraints, 0};
+  g_chips[kTable] = {"table", kTablePrepWidth, kTableWidth, 7, g_table, 2, 0};
+  g_chips[kCpu] = {"cpu", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 5};
+  g_chips[kCpu2] = {"cpu2", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 5};
+  g_chips[kKeccak] = {"keccak", 0, kKeccakWidth, 50, g_keccak, kKeccakConstraints, 0};
+  g_chips[kKmem] = {"keccak-mem", 0, kKmemWidth, 8, g_kmem, kKmemConstraints, 0};
+  g_chips[kMemFinal] = {"mem-final", 0, kMemFinalWidth, 10, g_memfinal, kMemFinalConstraints, 0};
+  g_chips[kImage] = {"image", kImagePrepWidth, kImageWidth, 1, g_image, 1, 0};
+  g_chips[kProgram] = {"program", kProgramPrepWidth, kProgramWidth, 1, g_program, 0, 0};
+  g_chips[kMul] = {"mul", 0, kMulWidth, 2, g_mul, kMulConstraints, 0};
+  g_chips[kAlu] = {"alu", 0, kAluWidth, 1, g_alu, kAluConstraints, 0};
+  g_chips[kAlu2] = {"alu2", 0, kAluWidth, 1, g_alu, kAluConstraints, 0};
+  g_chips[kSub] = {"subword", 0, kSubWidth, 1, g_sub, kSubConstraints, 0};
+  g_chips[kSub2] = {"subword2", 0, kSubWidth, 1, g_sub, kSubConstraints, 0};
+  g_chips[kBw] = {"bitwise", 0, kBwWidth, 5, g_bw, kBwConstraints, 0};
+  g_chips[kBw2] = {"bitwise2", 0, kBwWidth, 5, g_bw, kBwConstraints, 0};
 }
 
 }  // namespace

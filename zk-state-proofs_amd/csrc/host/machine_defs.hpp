@@ -28,15 +28,22 @@ struct ChipDef {
   int prep_w, main_w, n_inter;
   const Interaction* inter;
   int n_constraints;
-  int helpers() const { return (n_inter + 1) / 2; }
-  int perm_width() const { return 4 * (helpers() + 1); }
-  int total_constraints() const { return n_constraints + helpers() + 3; }
+  // The last n_merged interactions are sends with boolean, mutually exclusive multiplicities (one instruction class
+  // each): they share one fraction, (sum m_k) / (sum m_k f_k + 1 - sum m_k).
+  int n_merged;
+  // LogUp layout: the interactions before the merged ones two at a time, then the merged group: SLOTS.  Every slot but
+  // the last has a helper column (4 base columns) constrained to the slot's value; the last slot's value is
+  // phi_next - phi + cum / H - (sum of the helpers) on every row, cyclically (phi: the running sum, phi_0 = 0).
+  int slots() const { return (n_inter - n_merged + 1) / 2 + (n_merged ? 1 : 0); }
+  int helpers() const { return slots() - 1; }
+  int perm_width() const { return 4 * slots(); }
+  int total_constraints() const { return n_constraints + slots(); }
 };
 const ChipDef& chip_def(int chip);
 
 // magic, version, heights, exit code, pv length, 3 digests, hand-over pc; aggregation payload: leaf count, root, digest of the leaf list
 constexpr int kHeaderWords = 2 + kNumChips + 2 + 24 + 1 + 17;
-constexpr uint32_t kMachineVersion = 6;
+constexpr uint32_t kMachineVersion = 7;
 
 }  // namespace mach
 }  // namespace zksp

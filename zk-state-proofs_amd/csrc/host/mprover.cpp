@@ -583,7 +583,9 @@ int machine_prove_resident(Context* ctx) {
       pa.bus_ch = w->bus_ch;
       pa.bpow = w->bpow;
       pa.perm = w->mat[c][1].tr;
+      pa.perm_width = d.perm_width();
       pa.perm_bstride = (size_t)d.perm_width() * H(c);
+      pa.h_inv = Fp::from_canonical((uint32_t)(H(c) % kP)).inv().v;
       pa.rowsum = w->rowsum;
       pa.slice_sums = w->slice_sums;
       pa.cum = w->cum + 4 * c;
@@ -638,6 +640,7 @@ int machine_prove_resident(Context* ctx) {
         qa.zh_inv[k] = (sh[k].pow(h) - Fp::one()).inv().v;
       }
       qa.wh_inv = wh.inv().v;
+      qa.h_inv = Fp::from_canonical((uint32_t)(H(c) % kP)).inv().v;
       qa.consts = kc;
       qa.pubs = is_cpu_chip(c) ? w->pub_words + 17 + (c == kCpu2 ? kNumCpuPub : 0) : nullptr;
       qa.pubs_bstride = kPubWords;

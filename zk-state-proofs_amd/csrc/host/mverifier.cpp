@@ -1,4 +1,4 @@
-// Host verifier of the machine proof ("ZKSP v6"): replaces `client.verify(&proof, &vk)` (reference
+// Host verifier of the machine proof ("ZKSP v7"): replaces `client.verify(&proof, &vk)` (reference
 // prover/src/bin/main.rs:80; sp1-stark 3.4.0's multi-chip verifier over p3-uni-stark / p3-fri,
 // Cargo.lock:7485, :5378, :5253) for proofs that bind the guest's whole execution.  Also the
 // host half of `client.setup(ELF)` (main.rs:70): the commitment to the preprocessed Program and
@@ -522,32 +522,44 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       case kP2: eval_p2(zc); break;
     }
     if (zc.k_ != nb) { *err = "internal: constraint count"; return 7; }
-    // LogUp: row = [prep | main] at zeta
+    // LogUp (machine_defs.hpp "LogUp layout"): row = [prep | main] at zeta
     std::vector<Fp4> row(o_prep, o_prep + pw + mw);
+    const int nr = d.n_inter - d.n_merged, npairs = (nr + 1) / 2;
+    auto signed_mult = [&](const Interaction& it) {
+      const Fp4 m = lf_eval(it.mult, row.data());
+      return it.sign < 0 ? -m : m;
+    };
+    // v fa fb - (ma fb + mb fa) for slot s and a candidate value v
+    auto slot_constraint = [&](int s, const Fp4& v) {
+      Fp4 ma, fa, mb = Fp4::zero(), fb = Fp4::one();
+      if (s < npairs) {
+        ma = signed_mult(d.inter[2 * s]);
+        fa = fingerprint(d.inter[2 * s], row.data(), gamma, bpow);
+        if (2 * s + 1 < nr) {
+          mb = signed_mult(d.inter[2 * s + 1]);
+          fb = fingerprint(d.inter[2 * s + 1], row.data(), gamma, bpow);
+        }
+      } else {  // the merged sends: (sum m_k) / (sum m_k f_k + 1 - sum m_k)
+        ma = Fp4::zero();
+        fa = Fp4::zero();
+        for (int k = nr; k < d.n_inter; ++k) {
+          const Fp4 m = signed_mult(d.inter[k]);
+          ma += m;
+          fa += m * fingerprint(d.inter[k], row.data(), gamma, bpow);
+        }
+        fa += Fp4::one() - ma;
+      }
+      return v * fa * fb - (fb * ma + fa * mb);
+    };
     Fp4 hsum = Fp4::zero();
     for (int j = 0; j < nh; ++j) {
       const Fp4 hj = from_basis(o_perm + 4 * j);
       hsum += hj;
-      const Interaction& ia = d.inter[2 * j];
-      Fp4 ma = lf_eval(ia.mult, row.data());
-      if (ia.sign < 0) ma = -ma;
-      const Fp4 fa = fingerprint(ia, row.data(), gamma, bpow);
-      Fp4 v;
-      if (2 * j + 1 < d.n_inter) {
-        const Interaction& ib = d.inter[2 * j + 1];
-        Fp4 mb = lf_eval(ib.mult, row.data());
-        if (ib.sign < 0) mb = -mb;
-        const Fp4 fb = fingerprint(ib, row.data(), gamma, bpow);
-        v = hj * fa * fb - (fb * ma + fa * mb);
-      } else {
-        v = hj * fa - ma;
-      }
-      zc.acc += apow[nb + j] * v;
+      zc.acc += apow[nb + j] * slot_constraint(j, hj);
     }
     const Fp4 phi = from_basis(o_perm + 4 * nh), phin = from_basis(o_perm_n + 4 * nh);
-    zc.acc += apow[nb + nh] * (phi * zc.first);
-    zc.acc += apow[nb + nh + 1] * ((phin - phi - hsum) * zc.trans);
-    zc.acc += apow[nb + nh + 2] * ((cum[c] - phi - hsum) * zc.last);
+    const Fp4 cum_step = cum[c] * Fp::from_canonical((uint32_t)(h % kP)).inv();
+    zc.acc += apow[nb + nh] * slot_constraint(nh, phin - phi + cum_step - hsum);
     const Fp4 q0 = from_basis(o_quot), q1 = from_basis(o_quot + 4);
     const Fp sh = g.pow(h), inv_2sh = (sh + sh).inv();
     const Fp4 quot = q0 * (zeta_h + Fp4::from_base(sh)) * inv_2sh - q1 * (zeta_h - Fp4::from_base(sh)) * inv_2sh;
