@@ -3,10 +3,10 @@
 
 One "step" = one pass of the device hot path over one resident batch of synthetic acct-d8 proofs
 (BASELINE configs[1]: single account-trie proof, depth 8).  A proof is the MACHINE proof of the
-committed sp1-merkle-proof guest in the keccak-precompile shape: 391 400 RV32IM cycles in a
-(2^18 + 2^17) x 62 CPU chip rows in two instances, the ALU and sub-word chips beside it (one row per bitwise / shift /
-compare / sub-word instruction), 62 keccak-f permutations in a 2^11 x 2634 keccak chip, keccak-memory, memory-boundary,
-image, program, table and multiplier chips, joined by LogUp buses -- i.e. the statement
+committed sp1-merkle-proof guest in the keccak-precompile shape: 391 400 RV32IM cycles in two CPU chip instances of
+2^18 + 2^17 rows, the ALU, bitwise and sub-word chips beside them (one row per shift / signed compare, per xor / or / and,
+per sub-word access), 62 keccak-f permutations in a 2^11 x 2634 keccak chip, keccak-memory, memory-boundary,
+image, program, table, multiplier and Poseidon2 chips, joined by LogUp buses -- i.e. the statement
 the reference's client.prove() establishes, not a component.  The step runs trace expansion ->
 LDE -> Poseidon2 mixed-height Merkle commitments -> LogUp -> quotients -> openings -> FRI -> proof
 bytes in HBM, Fiat-Shamir on the device, no host round trip.  The executor's records (48 bytes per
@@ -105,12 +105,12 @@ def source_sha256():
 
 def measured_hbm_traffic(batch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC collection
-    (profiles/collect_r02.sh -> profiles/r02_hbm_counters.json: FETCH_SIZE and WRITE_SIZE in separate passes,
+    (profiles/collect_r03.sh -> profiles/r03_hbm_counters.json: FETCH_SIZE and WRITE_SIZE in separate passes,
     KB units, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  The collection records the
     sha256 of the libzksp.so it ran and its batch size: any other library or batch makes the figure stale
     and this returns None."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_counters.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_counters.json")))
         if int(d.get("batch", -1)) != batch or (d.get("lib_sha256") != lib_sha256() and d.get("source_sha256") != source_sha256()):
             return None
         return (2.0 * d["FETCH_SIZE"]["zksp::mmcs_leaf_kernel"][1] + d["WRITE_SIZE"]["zksp::mmcs_leaf_kernel"][1]) * 1024.0
@@ -119,40 +119,30 @@ def measured_hbm_traffic(batch):
 
 
 def valu_model(lib, h, achieved_gperm):
-    """What binds the leaf hash is vector-ALU issue.  Ceiling = 1 / sum over opcode classes of
-    (instructions per permutation, profiles/r02_leaf_opcode_mix.json, from the kernel's ISA) / (that class's
-    saturated rate, measured live with zksp_hip_microbench in this process).  A model: the classes issue
-    on one port here, real hardware overlaps some of them, so the achieved rate can sit a little above it."""
+    """What binds the leaf hash is vector-ALU issue.  A CDNA4 SIMD retires 32 lanes per clock of the plain 32-bit VOP1/VOP2
+    instructions (add, shift, move, logic: the rate behind the 157 TFLOP/s fp32 figure) and 16 lanes per clock of every
+    other vector instruction (64-bit multiply-adds and additions, v_mul_lo_u32, three-operand adds ...): 78.6 and 39.3 T
+    lane-ops/s on 256 CUs x 4 SIMDs at 2.4 GHz.  Ceiling = 1 / (full-rate instructions per permutation / 78.6 T +
+    half-rate instructions / 39.3 T), instruction counts from the kernel's ISA (profiles/r03_leaf_opcode_mix.json,
+    cross-checked there against SQ_INSTS_VALU).  Saturated single-opcode chains measured live are reported beside it
+    (they reach 75-90 % of these rates: profiles/r03_opcode_rates.txt has every opcode the kernel uses)."""
     try:
-        mix = json.load(open(os.path.join(ROOT, "profiles", "r02_leaf_opcode_mix.json")))["per_permutation_per_lane"]
+        mix = json.load(open(os.path.join(ROOT, "profiles", "r03_leaf_opcode_mix.json")))["per_permutation_per_lane"]
     except (OSError, KeyError, ValueError):
         return None
-    rates = {}
-    for cls, which in (("simple32", 0), ("mul_lo", 1), ("mad64", 3), ("add64", 100)):
-        g = C.c_double()
-        if lib.zksp_hip_microbench(h, which, C.byref(g)) != 0:
-            return None
-        rates[cls] = g.value * 1e9  # lane-operations per second, whole chip
-    # the same permutation code on a register-resident state, no memory traffic at all: what this implementation can do
-    # at most (best of 4 and 8 workgroups of 256 per CU)
-    resident = 0.0
-    for which in (6 + 3, 6 + 7):
+    simd_clocks = 256 * 4 * 2.4e9
+    peak = {"full_rate": 32 * simd_clocks, "half_rate": 16 * simd_clocks}
+    measured = {}
+    for cls, which in (("full_rate", 0), ("half_rate", 1)):  # chains of v_add_u32 / of v_mul_lo_u32
         g = C.c_double()
         if lib.zksp_hip_microbench(h, which, C.byref(g)) == 0:
-            resident = max(resident, g.value)
-    t = {c: mix[c] / rates[c] for c in mix}
-    # two brackets: every class on one issue port (the classes' times add), or the multiply classes and the
-    # add/move classes on ports that overlap perfectly (the longer of the two); the hardware is in between
-    serial = 1.0 / sum(t.values()) / 1e9
-    overlapped = 1.0 / max(t["mad64"] + t["mul_lo"], t["add64"] + t["simple32"]) / 1e9
-    return {"opcode_mix_per_permutation_per_lane": mix, "measured_lane_ops_per_s": {k: round(v / 1e12, 2) for k, v in rates.items()},
-            "unit_rates": "T lane-ops/s", "ceiling_gperm_per_s": overlapped, "ceiling_one_port_gperm_per_s": serial,
-            "achieved_gperm_per_s": achieved_gperm, "frac_of_valu_ceiling": achieved_gperm / overlapped,
-            "register_resident_gperm_per_s": resident or None,
-            "frac_of_register_resident_rate": (achieved_gperm / resident) if resident else None,
-            "note": "ceiling = multiply-class and add-class instructions overlapping perfectly; with all classes on one issue "
-                    "port the model gives ceiling_one_port, which the kernel exceeds: it runs at the issue limit within the "
-                    "precision of these per-class rates"}
+            measured[cls] = round(g.value / 1e3, 2)
+    ceiling = 1.0 / sum(mix[c] / peak[c] for c in mix) / 1e9
+    return {"opcode_mix_per_permutation_per_lane": mix, "peak_lane_ops_per_s": {k: round(v / 1e12, 1) for k, v in peak.items()},
+            "measured_chain_lane_ops_per_s": measured, "unit_rates": "T lane-ops/s", "ceiling_gperm_per_s": ceiling,
+            "achieved_gperm_per_s": achieved_gperm, "frac_of_valu_ceiling": achieved_gperm / ceiling,
+            "note": "one issue port per SIMD: the two classes' times add.  The contractual roofline fraction above is against "
+                    "HBM, which this kernel does not load"}
 
 
 def verify_resident_batch(zk, client, pk, vk, handles, traces, with_oracle, n_check=4):
@@ -206,7 +196,7 @@ def cpu_baseline(trace_of, first_s, seconds):
     n = len(times)
     return {"value": n / el, "unit": "proofs/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
             "repetitions": n, "median_s_per_proof": sorted(times)[n // 2], "min_s_per_proof": min(times),
-            "sample": f"{n} acct-d8 machine proofs (391 400 cycles, two CPU instances of 2^18 and 2^17 rows x 62 + 11 chips, 100 queries) in {el:.1f} s; "
+            "sample": f"{n} acct-d8 machine proofs (391 400 cycles, 16 chips, two CPU instances of 2^18 and 2^17 rows, 100 queries) in {el:.1f} s; "
                       "reference SP1 CPU prover unavailable offline, CPU baseline is this repository's oracle/ restatement"}
 
 
@@ -247,7 +237,7 @@ def keccak_chip_component(zk, fx, client_opts, pk_elf, seconds_budget=20.0):
 
 def as_committed_mode(zk, fx, device):
     """The same acct-d8 input with the guest exactly as committed (software keccak, no precompile): 1 406 960
-    cycles, CPU instances 2^20 and 2^19 rows x 62 + ALU instances 2^19 and 2^18 x 109, keccak chips empty.  Batch 4 resident, 2 timed steps; one proof verified."""
+    cycles, CPU instances of 2^20 and 2^19 rows, keccak chips empty.  Batch 4 resident, 2 timed steps; one proof verified."""
     NB = 4
     client = zk.ProverClient(device=device, keccak_mode=zk.KECCAK_OBSERVE, max_batch=NB)
     lib, h = client._lib, client._h
@@ -498,6 +488,7 @@ def main():
     heights = zk.machine_cover_heights(handles)  # one shape per batch: the heights that cover the largest counts
     trace_ms_per_proof = exec_s * 1e3 / B
     arr = (C.c_void_p * B)(*[t._h for t in handles])
+    check(lib.zksp_hip_machine_load(h, pk._h, arr, B))  # the first load also sizes the device arena
     t_load = time.perf_counter()
     check(lib.zksp_hip_machine_load(h, pk._h, arr, B))
     load_ms = (time.perf_counter() - t_load) * 1e3
@@ -644,10 +635,12 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "acct-d8 machine proof: depth-8 account-trie MPT proof of the committed sp1-merkle-proof guest, whole "
-                        "execution proven (keccak precompile shape: 391 400 cycles -> CPU instances 2^18 + 2^17 rows x 62 limb columns, ALU chip "
-                        "2^16 + 2^15 x 109, sub-word chip 2 x 2^15 x 63, keccak chip 2^11 x 2634, keccak-mem 2^12, mem-final / image / "
-                        "program / table 2^16, mul 2^9; LogUp buses; blowup 2, 100 FRI queries, 16 PoW bits)",
-            "statement": "guest executed from its entry point to HALT(0) with these public values (machine proof, format v6)",
+                        "execution proven (keccak precompile shape, 391 400 cycles; chips as name 2^log-height x "
+                        "(preprocessed + main + permutation + quotient columns): "
+                        + ", ".join(f"{n} 2^{lh} x ({p}+{w}+{e}+8)" for (n, p, w, e), lh in zip(load_chip_widths(), heights))
+                        + "; LogUp buses; blowup 2, 100 FRI queries, 16 PoW bits)",
+            "statement": f"guest executed from its entry point to HALT(0) with these public values (machine proof, format v{zk.MACHINE_VERSION})",
+            "cells_per_proof": sum((w + e + 8) << lh for (n, p, w, e), lh in zip(load_chip_widths(), heights)),
             "chip_log_heights": heights,
             "batch_per_gpu": B,
             "proofs_per_step": world * B,

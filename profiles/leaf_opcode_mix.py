@@ -1,14 +1,12 @@
 #!/usr/bin/env python3
 """Static opcode mix of one Poseidon2 permutation inside mmcs_leaf_kernel (the dominant kernel of the
 machine proof), from the gfx950 ISA hipcc emits for kernels_machine.hip.  Runs anywhere hipcc does
-(no GPU needed).  Output: profiles/r02_leaf_opcode_mix.json + the raw per-block histogram.
+(no GPU needed).  Output: profiles/r03_leaf_opcode_mix.json + the raw per-block histogram.
 
-The permutation is four loops (basic blocks with a back edge) plus straight-line pieces:
-  initial linear layer (x1), external rounds 0-3 (one S-box layer + linear layer per iteration, x4),
-  internal rounds (the compiler keeps three rounds per iteration, x4, the thirteenth round is folded
-  into the surrounding code), external rounds 4-7 (x4).
-Weights are therefore 1 / 4 / 4 / 4 on the four largest VALU blocks in program order; the total is
-checked against the PMC count of round 1 (4 853 VALU instructions per permutation per lane).
+The permutation is three loops (basic blocks that branch back to themselves) and two straight-line pieces:
+  initial linear layer (x1), external rounds 0-3 (one S-box layer + linear layer per trip, x4), internal rounds 0-11
+  (one round per trip, x12), internal round 12 (x1), external rounds 4-7 (x4).
+The total is cross-checked against the PMC count of the same build (profiles/r03_valu_counters.json).
 """
 import collections
 import json
@@ -25,33 +23,58 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-
 s = open(asm).read()
 m = re.search(r"^_ZN4zksp16mmcs_leaf_kernelENS_8LeafArgsEPKNS_8P2ConstsE:", s, re.M)
 body = s[m.end():s.find("s_endpgm", m.end())].split("\n")
-blocks, cur = collections.OrderedDict(), "entry"
-blocks[cur] = collections.Counter()
+# basic blocks: a label starts one, and so does the instruction after a conditional branch (the fall-through of a loop)
+blocks, cur, serial = collections.OrderedDict(), "entry", 0
+blocks[cur] = {"ops": collections.Counter(), "self_loop": False}
 for line in body:
     lm = re.match(r"^(\.LBB\d+_\d+):", line)
     if lm:
         cur = lm.group(1)
-        blocks[cur] = collections.Counter()
+        blocks[cur] = {"ops": collections.Counter(), "self_loop": False}
         continue
-    mm = re.match(r"\s+([a-z]+_[a-z0-9_]+)", line)
-    if mm:
-        blocks[cur][mm.group(1)] += 1
-big = [(b, c) for b, c in blocks.items() if sum(v for k, v in c.items() if k.startswith("v_")) >= 150]
-assert len(big) == 4, [b for b, _ in big]
-weights = [1, 4, 4, 4]
-CLASSES = {"mad64": ("v_mad_i64_i32", "v_mad_u64_u32"), "mul_lo": ("v_mul_lo_u32",), "add64": ("v_lshl_add_u64",)}
+    mm = re.match(r"\s+([a-z]+_[a-z0-9_]+)\s*(\S*)", line)
+    if not mm:
+        continue
+    blocks[cur]["ops"][mm.group(1)] += 1
+    if mm.group(1).startswith("s_cbranch"):
+        if mm.group(2) == cur:
+            blocks[cur]["self_loop"] = True
+        serial += 1
+        cur = f"{cur}+{serial}"
+        blocks[cur] = {"ops": collections.Counter(), "self_loop": False}
+valu = lambda c: sum(v for k, v in c.items() if k.startswith("v_"))
+# the permutation: the initial linear layer (straight line), external rounds 0-3 (loop, 4 trips), internal rounds 0-11
+# (loop, 12 trips), internal round 12 (straight line), external rounds 4-7 (loop, 4 trips)
+loops = [(b, d) for b, d in blocks.items() if d["self_loop"] and valu(d["ops"]) >= 80]
+assert len(loops) == 3, [(b, valu(d["ops"])) for b, d in loops]
+names = list(blocks)
+first, mid = names.index(loops[0][0]), names.index(loops[1][0])
+straight = [(b, blocks[b]) for b in (names[first - 1], names[mid + 1])]
+assert all(valu(d["ops"]) >= 100 for _, d in straight), [(b, valu(d["ops"])) for b, d in straight]
+big = [straight[0], loops[0], loops[1], straight[1], loops[2]]
+weights = [1, 4, 12, 1, 4]
+FULL_RATE = ("v_add_u32_e32", "v_sub_u32_e32", "v_subrev_u32_e32", "v_ashrrev_i32_e32", "v_lshrrev_b32_e32", "v_lshlrev_b32_e32",
+             "v_and_b32_e32", "v_or_b32_e32", "v_xor_b32_e32", "v_mov_b32_e32", "v_cndmask_b32_e32", "v_not_b32_e32")
 mix = collections.Counter()
-for (b, c), w in zip(big, weights):
-    for op, n in c.items():
-        if not op.startswith("v_"):
-            continue
-        cls = next((k for k, ops in CLASSES.items() if op in ops), "simple32")
-        mix[cls] += w * n
+for (b, d), w in zip(big, weights):
+    for op, n in d["ops"].items():
+        if op.startswith("v_"):
+            mix["full_rate" if op in FULL_RATE else "half_rate"] += w * n
 total = sum(mix.values())
+# cross-check with the counter collection of the same build, when there is one: VALU instructions of the largest launch
+# (the CPU chip's main trace: 8 permutations per row) per lane per permutation
+pmc = None
+try:
+    v = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_counters.json")))
+    pmc = v["SQ_INSTS_VALU"]["zksp::mmcs_leaf_kernel"][1] / (v["batch"] * (1 << 19) / 64) / 8
+except (OSError, KeyError, ValueError):
+    pass
 out = {"kernel": "mmcs_leaf_kernel", "per_permutation_per_lane": dict(mix), "total_valu": total,
        "block_weights": {b: w for (b, _), w in zip(big, weights)},
-       "blocks": {b: dict(c) for b, c in big},
-       "note": "mad64 = v_mad_i64_i32 / v_mad_u64_u32 (Montgomery products and reductions), add64 = v_lshl_add_u64 "
-               "(64-bit sums of the linear layers), simple32 = moves, shifts, 24-bit multiply-adds, lane reads"}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_leaf_opcode_mix.json"), "w"), indent=1)
-print(json.dumps({k: out[k] for k in ("per_permutation_per_lane", "total_valu")}))
+       "blocks": {b: dict(d["ops"]) for b, d in big},
+       "pmc_valu_per_permutation_per_lane": pmc,
+       "note": "full_rate = plain 32-bit VOP1/VOP2 instructions (additions, shifts, moves, logic); half_rate = every other "
+               "vector instruction (v_mad_i64_i32 / v_mad_u64_u32 of the Montgomery products, v_mul_lo_u32, v_lshl_add_u64 of the "
+               "linear layers' 64-bit sums, v_alignbit, v_mad_i32_i24, v_add3, v_min, lane reads)"}
+json.dump(out, open(os.path.join(ROOT, "profiles", "r03_leaf_opcode_mix.json"), "w"), indent=1)
+print(json.dumps({k: out[k] for k in ("per_permutation_per_lane", "total_valu", "pmc_valu_per_permutation_per_lane")}))
