@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cstring>
 #include <functional>
+#include <future>
 #include <map>
 #include <memory>
 #include <new>
@@ -233,6 +234,8 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     rc_all = rc;
   };
 
+  std::promise<void> wave_done;  // (declared before the thread that sets it: destroyed after that thread is joined)
+  std::future<void> wave_ready = wave_done.get_future();
   // declared after `traces` and `reaper`: joined before either is destroyed, on every way out
   struct Joiner {
     std::thread t;
@@ -240,25 +243,42 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       if (t.joinable()) t.join();
     }
   } rest;
+  build_chunks(0, w0);
+  // A large batch whose first wave came out with one shape (a homogeneous workload): the next wave is traced and
+  // grouped on its own, before the rest, so that the GPU has a second chunk waiting when the first is proven - tracing
+  // several hundred runs takes longer than proving 64.  A mixed workload keeps one global grouping of the rest (waves
+  // grouped one by one would fragment into small chunks).
+  const size_t w1 = (chunks.size() == 1 && n >= 4 * w0) ? 2 * w0 : w0;
+  auto trace_rest = [&]() {
+    if (w1 > w0) parallel_for(w1 - w0, 64, [&](size_t j) { trace_one(w0 + j); });
+    wave_done.set_value();
+    if (n > w1) parallel_for(n - w1, 64, [&](size_t j) { trace_one(w1 + j); });
+  };
   if (w0 < n) {
     try {
-      rest.t = std::thread([&]() { parallel_for(n - w0, 64, [&](size_t j) { trace_one(w0 + j); }); });
+      rest.t = std::thread(trace_rest);
     } catch (...) {
-      parallel_for(n - w0, 64, [&](size_t j) { trace_one(w0 + j); });  // no thread to spare: trace them here
+      trace_rest();  // no thread to spare: trace them here
     }
+  } else {
+    wave_done.set_value();
   }
-  build_chunks(0, w0);
-  bool rest_built = w0 == n;
-  auto have_chunk = [&](size_t k) {  // does chunk k exist?  (the rest is grouped once its traces are complete)
+  bool wave_built = w1 == w0, rest_built = w0 == n;
+  auto have_chunk = [&](size_t k) {  // does chunk k exist?  (later runs are grouped once their traces are complete)
+    if (k >= chunks.size() && !wave_built) {
+      wave_ready.wait();
+      mark.mark("second wave traced", w1 - w0);
+      build_chunks(w0, w1);
+      wave_built = true;
+    }
     if (k >= chunks.size() && !rest_built) {
       if (rest.t.joinable()) rest.t.join();
-      mark.mark("rest traced", n - w0);
-      build_chunks(w0, n);
+      mark.mark("rest traced", n - w1);
+      build_chunks(w1, n);
       rest_built = true;
     }
     return k < chunks.size();
   };
-
   // Chunk k is proven while chunk k + 1 (same heights) is uploaded into the spare record set and chunk k - 1 is
   // wrapped into proof objects; a chunk of other heights waits for the GPU and takes the plain path.
   bool in_flight = false;  // chunk k's records are resident and its proving pass is enqueued
@@ -307,8 +327,16 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   for (auto& t : reaper.th)
     if (t.joinable()) t.join();
   mark.mark("reaper joined", reaper.th.size());
-  traces.clear();
-  mark.mark("traces dropped", n);
+  // what is left of the traces (execution records: a few hundred kilobytes each) is freed by a helper thread the next
+  // call, or the client's destruction, joins: a tenth of a second per 512 runs that the caller does not wait for
+  if (ctx->cleanup.joinable()) ctx->cleanup.join();
+  auto* dead = new std::vector<std::unique_ptr<zksp_mtrace>>(std::move(traces));
+  try {
+    ctx->cleanup = std::thread([dead]() { delete dead; });
+  } catch (...) {
+    delete dead;
+  }
+  mark.mark("traces handed over", n);
   return rc_all;
 }
 

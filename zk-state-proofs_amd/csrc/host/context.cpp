@@ -10,6 +10,7 @@ namespace zksp {
 Context::Context() = default;
 
 Context::~Context() {
+  if (cleanup.joinable()) cleanup.join();
   if (device >= 0) {
     (void)hipSetDevice(device);
     for (auto& kv : domains) {

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <thread>
+
 #include <array>
 #include <map>
 #include <memory>
@@ -87,6 +89,7 @@ struct Context {
   hipEvent_t timer_a = nullptr, timer_b = nullptr;
 
   Context();  // out of line: members hold types that are incomplete here
+  std::thread cleanup;  // frees the last prove_batch call's execution records off the caller's clock
   ~Context();
   bool has_device() const { return device >= 0; }
   int fail(int code, const std::string& msg) { error = msg; return code; }
