@@ -1,6 +1,6 @@
 /* ORACLE -- TEST INFRASTRUCTURE ONLY (see field.h and machine.h).
  *
- * Chips of the machine proof (format v7): bus interactions, trace generation from the executor's
+ * Chips of the machine proof (format v8): bus interactions, trace generation from the executor's
  * records and base-field constraints.  This repository's own arithmetisation (machine.h header
  * note); what it must reproduce is the reference's statement: the committed RV32IM guest
  * (circuits/sp1-merkle-proof/src/main.rs:4-14 running crypto-ops/src/lib.rs:8-23) executed from its
@@ -102,7 +102,7 @@ static orc_lf lf_bits(int bits, int n) {
 
 #define CPU_INTER 22
 static orc_inter g_cpu[CPU_INTER], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7],
-    g_alu[1], g_sub[1], g_bw[5], g_p2[3];
+    g_alu[1], g_sub[5], g_bw[5], g_p2[3];
 static orc_chip g_chips[N_CHIPS];
 static int g_ready = 0;
 
@@ -366,8 +366,18 @@ static void build(void) {
     for (int k = 0; k < 6; ++k) lf_add(&it->el[0], SW_SEL + k, codes[k]);
     lf_zero(&it->el[1]); lf_add(&it->el[1], SW_O + 1, 1); lf_add(&it->el[1], SW_O + 2, 2); lf_add(&it->el[1], SW_O + 3, 3);
     it->el[2] = lf_col(SW_A); it->el[3] = lf_col(SW_A + 1);
-    it->el[4] = lf_bits(SW_M, 16); it->el[5] = lf_bits(SW_M + 16, 16); it->el[6] = lf_bits(SW_C, 16);
+    it->el[4] = lf_pair(SW_MB, SW_MB + 1, 256); it->el[5] = lf_pair(SW_MB + 2, SW_MB + 3, 256); it->el[6] = lf_pair(SW_CB, SW_CB + 1, 256);
     it->el[7] = lf_col(SW_MV); it->el[8] = lf_col(SW_MV + 1);
+    /* the bytes are bytes; the sign bit of a signed load is bit 7 of the byte it extends */
+    g_sub[1] = bytes_inter(-1, lf_col(SW_IS_REAL), lf_col(SW_MB), lf_col(SW_MB + 1));
+    g_sub[2] = bytes_inter(-1, lf_col(SW_IS_REAL), lf_col(SW_MB + 2), lf_col(SW_MB + 3));
+    g_sub[3] = bytes_inter(-1, lf_col(SW_IS_REAL), lf_col(SW_CB), lf_col(SW_CB + 1));
+    it = &g_sub[4];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_BYTEOP; it->sign = -1; it->mult = lf_pair(SW_SEL + 0, SW_SEL + 1, 1); it->n_el = 4;
+    it->el[0] = lf_const(3); /* and */
+    it->el[1] = lf_col(SW_SELB); it->el[2] = lf_const(0x80);
+    lf_zero(&it->el[3]); lf_add(&it->el[3], SW_S, 128);
   }
   g_chips[CH_TABLE] = (orc_chip){"table", TABLE_PREP_WIDTH, TABLE_WIDTH, 7, g_table, 0, 0};
   g_chips[CH_CPU] = (orc_chip){"cpu", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0, 5};   /* ALU, SUB, KCALL, PUBC, PUBH: one class each */
@@ -380,8 +390,8 @@ static void build(void) {
   g_chips[CH_MUL] = (orc_chip){"mul", 0, MUL_WIDTH, 2, g_mul, 0, 0};
   g_chips[CH_ALU] = (orc_chip){"alu", 0, ALU_WIDTH, 1, g_alu, 0, 0};
   g_chips[CH_ALU2] = (orc_chip){"alu2", 0, ALU_WIDTH, 1, g_alu, 0, 0};
-  g_chips[CH_SUB] = (orc_chip){"subword", 0, SUB_WIDTH, 1, g_sub, 0, 0};
-  g_chips[CH_SUB2] = (orc_chip){"subword2", 0, SUB_WIDTH, 1, g_sub, 0, 0};
+  g_chips[CH_SUB] = (orc_chip){"subword", 0, SUB_WIDTH, 5, g_sub, 0, 0};
+  g_chips[CH_SUB2] = (orc_chip){"subword2", 0, SUB_WIDTH, 5, g_sub, 0, 0};
   g_chips[CH_BW] = (orc_chip){"bitwise", 0, BW_WIDTH, 5, g_bw, 0, 0};
   g_chips[CH_BW2] = (orc_chip){"bitwise2", 0, BW_WIDTH, 5, g_bw, 0, 0};
   g_chips[CH_P2] = (orc_chip){"poseidon2", 0, P2CHIP_WIDTH, 3, g_p2, 0, 0};
@@ -665,9 +675,14 @@ static void fill_sub(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
     T(SW_SEL + sub_sel(code)) = 1;
     T(SW_O + off) = 1;
     put_limbs(t, h, r, SW_A, store ? 0 : a);
-    put_bits(t, h, r, SW_M, m, 32);
-    put_bits(t, h, r, SW_C, c & 0xffff, 16);
+    for (int k = 0; k < 4; ++k) T(SW_MB + k) = (m >> (8 * k)) & 0xff;
+    T(SW_CB) = c & 0xff; T(SW_CB + 1) = (c >> 8) & 0xff;
     put_limbs(t, h, r, SW_MV, mv);
+    if (code == OP_LB || code == OP_LH) {
+      const uint32_t sb = code == OP_LB ? (m >> (8 * off)) & 0xff : (m >> (8 * (off | 1))) & 0xff;
+      T(SW_SELB) = sb;
+      T(SW_S) = sb >> 7;
+    }
 #undef T
   }
   free(ev);
@@ -679,8 +694,8 @@ static void fill_table_mults(const orc_machine_input* in, uint32_t* t) {
   const size_t ht = (size_t)1 << TABLE_LOG_H;
   int logh[N_CHIPS];
   orc_machine_heights(in, logh);
-  static const int users[6] = {CH_CPU, CH_CPU2, CH_KMEM, CH_MEMFINAL, CH_BW, CH_BW2};
-  for (int u = 0; u < 6; ++u) {
+  static const int users[8] = {CH_CPU, CH_CPU2, CH_KMEM, CH_MEMFINAL, CH_BW, CH_BW2, CH_SUB, CH_SUB2};
+  for (int u = 0; u < 8; ++u) {
     const int chip = users[u];
     const orc_chip* ch = &g_chips[chip];
     const size_t h = (size_t)1 << logh[chip];
@@ -1181,26 +1196,31 @@ static void sub_constraints(const uint32_t* l, sink* s) {
   fe selsum = 0, osum = 0;
   for (int k = 0; k < 6; ++k) { emit(s, bool_c(SF(k))); selsum = f_add(selsum, SF(k)); }
   for (int k = 0; k < 4; ++k) { emit(s, bool_c(l[SW_O + k])); osum = f_add(osum, l[SW_O + k]); }
-  for (int i = 0; i < 48; ++i) emit(s, bool_c(l[SW_M + i])); /* M, C */
+  emit(s, bool_c(l[SW_S]));
   emit(s, f_sub(selsum, l[SW_IS_REAL]));
   emit(s, f_sub(osum, l[SW_IS_REAL]));
-  const fe a_lo = l[SW_A], a_hi = l[SW_A + 1], m_lo = limb_of(l, SW_M, 0), m_hi = limb_of(l, SW_M, 1), c_lo = limb_of(l, SW_C, 0);
-  const fe mv_lo = l[SW_MV], mv_hi = l[SW_MV + 1];
+  const fe a_lo = l[SW_A], a_hi = l[SW_A + 1], mv_lo = l[SW_MV], mv_hi = l[SW_MV + 1], sgn = l[SW_S], selb = l[SW_SELB];
   const fe o0 = l[SW_O], o1 = l[SW_O + 1], o2 = l[SW_O + 2], o3 = l[SW_O + 3];
-  const fe mb[4] = {byte_of(l, SW_M, 0), byte_of(l, SW_M, 1), byte_of(l, SW_M, 2), byte_of(l, SW_M, 3)};
+  const fe mb[4] = {l[SW_MB], l[SW_MB + 1], l[SW_MB + 2], l[SW_MB + 3]}, cb = l[SW_CB];
+  const fe m_lo = f_add(mb[0], f_mul(256, mb[1])), m_hi = f_add(mb[2], f_mul(256, mb[3])), c_lo = f_add(cb, f_mul(256, l[SW_CB + 1]));
   /* half-word accesses are 2-aligned */
   emit(s, f_mul(f_add(f_add(SF(LH), SF(LHU)), SF(SH)), f_add(o1, o3)));
-  const fe hv = f_add(f_mul(o0, m_lo), f_mul(o2, m_hi)), hs = f_add(f_mul(o0, l[SW_M + 15]), f_mul(o2, l[SW_M + 31]));
+  /* the sign: only signed loads have one, and it is bit 7 (byte-operation lookup) of the accessed byte / of the
+   * accessed half-word's upper byte */
+  fe bv = 0;
+  for (int p = 0; p < 4; ++p) bv = f_add(bv, f_mul(l[SW_O + p], mb[p]));
+  const fe hv = f_add(f_mul(o0, m_lo), f_mul(o2, m_hi)), hb = f_add(f_mul(o0, mb[1]), f_mul(o2, mb[3]));
+  emit(s, f_mul(f_sub(f_sub(1, SF(LB)), SF(LH)), sgn));
+  emit(s, f_mul(SF(LB), f_sub(selb, bv)));
+  emit(s, f_mul(SF(LH), f_sub(selb, hb)));
   emit(s, f_mul(SF(LHU), f_sub(a_lo, hv)));
   emit(s, f_mul(SF(LHU), a_hi));
   emit(s, f_mul(SF(LH), f_sub(a_lo, hv)));
-  emit(s, f_mul(SF(LH), f_sub(a_hi, f_mul(65535, hs))));
-  fe bv = 0, bs = 0;
-  for (int p = 0; p < 4; ++p) { bv = f_add(bv, f_mul(l[SW_O + p], mb[p])); bs = f_add(bs, f_mul(l[SW_O + p], l[SW_M + 8 * p + 7])); }
+  emit(s, f_mul(SF(LH), f_sub(a_hi, f_mul(65535, sgn))));
   emit(s, f_mul(SF(LBU), f_sub(a_lo, bv)));
   emit(s, f_mul(SF(LBU), a_hi));
-  emit(s, f_mul(SF(LB), f_sub(a_lo, f_add(bv, f_mul(0xff00, bs)))));
-  emit(s, f_mul(SF(LB), f_sub(a_hi, f_mul(65535, bs))));
+  emit(s, f_mul(SF(LB), f_sub(a_lo, f_add(bv, f_mul(0xff00, sgn)))));
+  emit(s, f_mul(SF(LB), f_sub(a_hi, f_mul(65535, sgn))));
   /* loads leave the word as it was; stores write nothing to a register */
   const fe loads = f_add(f_add(SF(LB), SF(LH)), f_add(SF(LBU), SF(LHU))), stores = f_add(SF(SB), SF(SH));
   emit(s, f_mul(loads, f_sub(mv_lo, m_lo)));
@@ -1209,7 +1229,6 @@ static void sub_constraints(const uint32_t* l, sink* s) {
   emit(s, f_mul(stores, a_hi));
   emit(s, f_mul(SF(SH), f_sub(f_sub(mv_lo, m_lo), f_mul(o0, f_sub(c_lo, m_lo)))));
   emit(s, f_mul(SF(SH), f_sub(f_sub(mv_hi, m_hi), f_mul(o2, f_sub(c_lo, m_hi)))));
-  const fe cb = byte_of(l, SW_C, 0);
   emit(s, f_mul(SF(SB), f_sub(f_sub(mv_lo, m_lo), f_add(f_mul(o0, f_sub(cb, mb[0])), f_mul(256, f_mul(o1, f_sub(cb, mb[1])))))));
   emit(s, f_mul(SF(SB), f_sub(f_sub(mv_hi, m_hi), f_add(f_mul(o2, f_sub(cb, mb[2])), f_mul(256, f_mul(o3, f_sub(cb, mb[3])))))));
 #undef SF

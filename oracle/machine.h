@@ -11,7 +11,7 @@
  * (circuits/sp1-merkle-proof/src/main.rs:4-14, crypto-ops/src/lib.rs:8-23) ran to HALT(0) and
  * committed these public values.
  *
- * Format v7 (round 3).  The CPU row no longer carries its operands as bits: it holds 16-bit limbs,
+ * Format v8 (round 3).  The CPU row no longer carries its operands as bits: it holds 16-bit limbs,
  * adds / subtracts / compares (equality, unsigned order) / moves words itself, and sends xor / or /
  * and to a bitwise chip (bytes, looked up in a byte-operation table), shifts and signed less-than to
  * an ALU chip (bits) and every sub-word load or store to a sub-word chip, each with one row per such
@@ -111,11 +111,14 @@ enum {
 };
 /* ---- bitwise chip: xor or and byte by byte, every (b, c, a) byte triple looked up in the table chip ---- */
 enum { BW_IS_REAL = 0, BW_SEL /* 3 selectors: XOR OR AND */, BW_A = BW_SEL + 3, BW_B = BW_A + 4, BW_C = BW_B + 4, BW_WIDTH = BW_C + 4 };
-/* ---- sub-word chip: lb lh lbu lhu sb sh ---- */
+/* ---- sub-word chip: lb lh lbu lhu sb sh; the memory word and the stored limb as bytes (range-checked through the table
+ *      chip's byte-pair rows), the sign bit a signed load extends bound to its byte by a byte-operation lookup
+ *      (byte AND 0x80 = 128 * sign) ---- */
 enum {
   SW_IS_REAL = 0, SW_SEL /* 6 selectors: LB LH LBU LHU SB SH */, SW_O = SW_SEL + 6 /* 4: byte offset, one-hot */,
-  SW_A = SW_O + 4, SW_M = SW_A + 2 /* 32 bits */, SW_C = SW_M + 32 /* 16 bits: low limb of the stored register */,
-  SW_MV = SW_C + 16, SUB_WIDTH = SW_MV + 2
+  SW_A = SW_O + 4, SW_MB = SW_A + 2 /* the memory word's 4 bytes */, SW_CB = SW_MB + 4 /* the 2 bytes of the stored register's low limb */,
+  SW_MV = SW_CB + 2, SW_S = SW_MV + 2 /* sign bit a signed load extends */, SW_SELB /* the byte that carries it */,
+  SUB_WIDTH = SW_SELB + 1
 };
 /* ---- Poseidon2 chip (row f4, stage 1): one width-16 permutation per row = one 2-to-1 compression of a Merkle tree of
  *      8-word digests.  Row r holds heap node K = r + 1 (root 1, children 2K and 2K + 1, the n leaves at n .. 2n - 1): it
@@ -214,7 +217,7 @@ typedef struct {
 /* the aggregation payload's public part: Merkle root of the leaves (2-to-1 Poseidon2 compressions) and the sponge hash
  * of the leaf list, which stands for the list in the transcript */
 void orc_machine_agg_public(const uint32_t* leaves, size_t n, uint32_t root[8], uint32_t list_digest[8]);
-#define ZKSP_VERSION_MACHINE 7u
+#define ZKSP_VERSION_MACHINE 8u
 /* vk: preprocessed commitment root + digest binding entry pc, table heights and keccak mode */
 void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t prep_root[8], uint32_t vk_digest[8]);
 size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_image, const orc_config* cfg, uint32_t pv_len);

@@ -101,9 +101,9 @@ static_assert(kAluWidth == 105, "ALU chip layout");
 constexpr int BW_IS_REAL = 0, BW_SEL = 1, BW_A = BW_SEL + 3, BW_B = BW_A + 4, BW_C = BW_B + 4, kBwWidth = BW_C + 4;
 static_assert(kBwWidth == 16, "bitwise chip layout");
 // ---- sub-word chip: lb lh lbu lhu sb sh ----
-constexpr int SW_IS_REAL = 0, SW_SEL = 1, SW_O = SW_SEL + 6, SW_A = SW_O + 4, SW_M = SW_A + 2, SW_C = SW_M + 32, SW_MV = SW_C + 16,
-              kSubWidth = SW_MV + 2;
-static_assert(kSubWidth == 63, "sub-word chip layout");
+constexpr int SW_IS_REAL = 0, SW_SEL = 1, SW_O = SW_SEL + 6, SW_A = SW_O + 4, SW_MB = SW_A + 2, SW_CB = SW_MB + 4, SW_MV = SW_CB + 2,
+              SW_S = SW_MV + 2, SW_SELB = SW_S + 1, kSubWidth = SW_SELB + 1;
+static_assert(kSubWidth == 23, "sub-word chip layout");
 // ---- Poseidon2 chip (stage 1): one width-16 permutation per row = one 2-to-1 compression of
 //      a Merkle tree of 8-word digests.  Row r holds heap node K = r + 1 (root 1, children 2K and 2K + 1, the n leaves at
 //      n .. 2n - 1): it consumes its children's digests from the DIGEST bus and produces its own; the verifier supplies
@@ -510,7 +510,8 @@ ZKSP_HD void eval_bw(Ctx& ctx) {
 }
 constexpr int kBwConstraints = 5;
 
-// ---- sub-word chip: M is the memory word, C the low limb of the stored register, both as bits ----
+// ---- sub-word chip: M is the memory word, C the low limb of the stored register, both as bytes (looked up in the table
+// chip's byte-pair rows); S the sign bit a signed load extends, bit 7 of the byte SELB (byte-operation lookup) ----
 template <class Ctx>
 ZKSP_HD void eval_sub(Ctx& ctx) {
   using F = typename Ctx::F;
@@ -533,56 +534,32 @@ ZKSP_HD void eval_sub(Ctx& ctx) {
     ctx.emit(bool_c(o[k], one));
     osum = osum + o[k];
   }
-  // M, C bit by bit: booleans, limbs, bytes, the sign bits a load may extend
-  F mb[4] = {zero, zero, zero, zero}, msb[4];
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    const F v = L(SW_M + i);
-    ctx.emit(bool_c(v, one));
-  }
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    msb[p] = L(SW_M + 8 * p + 7);
-    F sacc = msb[p];
-#pragma unroll
-    for (int i = 6; i >= 0; --i) sacc = sacc.dbl() + L(SW_M + 8 * p + i);
-    mb[p] = sacc;
-  }
-  F cb = zero, c_hi8 = zero;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) ctx.emit(bool_c(L(SW_C + i), one));
-  {
-    F s0 = L(SW_C + 7), s1 = L(SW_C + 15);
-#pragma unroll
-    for (int i = 6; i >= 0; --i) {
-      s0 = s0.dbl() + L(SW_C + i);
-      s1 = s1.dbl() + L(SW_C + 8 + i);
-    }
-    cb = s0;
-    c_hi8 = s1;
-  }
-  const F k256 = ZKSP_K(256), k65535 = ZKSP_K(65535);
-  const F m_lo = mb[0] + k256 * mb[1], m_hi = mb[2] + k256 * mb[3], c_lo = cb + k256 * c_hi8;
+  const F sgn = L(SW_S), selb = L(SW_SELB);
+  ctx.emit(bool_c(sgn, one));
   ctx.emit(selsum - is_real);
   ctx.emit(osum - is_real);
+  const F mb[4] = {L(SW_MB), L(SW_MB + 1), L(SW_MB + 2), L(SW_MB + 3)}, cb = L(SW_CB);
+  const F k256 = ZKSP_K(256), k65535 = ZKSP_K(65535);
+  const F m_lo = mb[0] + k256 * mb[1], m_hi = mb[2] + k256 * mb[3], c_lo = cb + k256 * L(SW_CB + 1);
   const F a_lo = L(SW_A), a_hi = L(SW_A + 1), mv_lo = L(SW_MV), mv_hi = L(SW_MV + 1);
   // half-word accesses are 2-aligned
   ctx.emit((SF(kLH) + SF(kLHU) + SF(kSH)) * (o[1] + o[3]));
-  const F hv = o[0] * m_lo + o[2] * m_hi, hs = o[0] * msb[1] + o[2] * msb[3];
+  // the sign: only signed loads have one; it belongs to the accessed byte / the accessed half-word's upper byte
+  F bv = zero;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) bv = bv + o[p] * mb[p];
+  const F hv = o[0] * m_lo + o[2] * m_hi, hb = o[0] * mb[1] + o[2] * mb[3];
+  ctx.emit((one - SF(kLB) - SF(kLH)) * sgn);
+  ctx.emit(SF(kLB) * (selb - bv));
+  ctx.emit(SF(kLH) * (selb - hb));
   ctx.emit(SF(kLHU) * (a_lo - hv));
   ctx.emit(SF(kLHU) * a_hi);
   ctx.emit(SF(kLH) * (a_lo - hv));
-  ctx.emit(SF(kLH) * (a_hi - k65535 * hs));
-  F bv = zero, bs = zero;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    bv = bv + o[p] * mb[p];
-    bs = bs + o[p] * msb[p];
-  }
+  ctx.emit(SF(kLH) * (a_hi - k65535 * sgn));
   ctx.emit(SF(kLBU) * (a_lo - bv));
   ctx.emit(SF(kLBU) * a_hi);
-  ctx.emit(SF(kLB) * (a_lo - (bv + ZKSP_K(0xff00) * bs)));
-  ctx.emit(SF(kLB) * (a_hi - k65535 * bs));
+  ctx.emit(SF(kLB) * (a_lo - (bv + ZKSP_K(0xff00) * sgn)));
+  ctx.emit(SF(kLB) * (a_hi - k65535 * sgn));
   // loads leave the word as it was; stores write nothing to a register
   const F loads = SF(kLB) + SF(kLH) + SF(kLBU) + SF(kLHU), stores = SF(kSB) + SF(kSH);
   ctx.emit(loads * (mv_lo - m_lo));
@@ -595,7 +572,7 @@ ZKSP_HD void eval_sub(Ctx& ctx) {
   ctx.emit(SF(kSB) * (mv_hi - m_hi - (o[2] * (cb - mb[2]) + k256 * (o[3] * (cb - mb[3])))));
 #undef SF
 }
-constexpr int kSubConstraints = 78;
+constexpr int kSubConstraints = 34;
 
 // ---- Poseidon2 chip: every S-box through its cube (x^3, then x^7 = (x^3)^2 x: degree 3); between S-boxes the state is
 // linear in the columns.  Ctx::p2(): the permutation's constants (Montgomery words).  286 constraints. ----

@@ -272,9 +272,14 @@ __global__ __launch_bounds__(kMT) void sub_trace_kernel(MachineRecords rec, uint
   for (uint32_t k = 0; k < 6; ++k) o.flag(SW_SEL + k, k == sel);
   for (uint32_t k = 0; k < 4; ++k) o.flag(SW_O + k, k == off);
   o.limbs(SW_A, store ? 0u : a);
-  o.bits(SW_M, m, 32);
-  o.bits(SW_C, c & 0xffff, 16);
+  for (uint32_t k = 0; k < 4; ++k) o.put(SW_MB + k, mont((m >> (8 * k)) & 0xff));
+  o.put(SW_CB, mont(c & 0xff));
+  o.put(SW_CB + 1, mont((c >> 8) & 0xff));
   o.limbs(SW_MV, mv);
+  const bool sl = code == LB || code == LH;
+  const uint32_t sb = sl ? (m >> (8 * (code == LB ? off : (off | 1)))) & 0xff : 0u;
+  o.flag(SW_S, (sb >> 7) != 0);
+  o.put(SW_SELB, mont(sb));
 }
 
 __device__ __forceinline__ uint64_t m_rol64(uint64_t v, int n) { return n ? (v << n) | (v >> (64 - n)) : v; }

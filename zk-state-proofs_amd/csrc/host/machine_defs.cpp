@@ -1,4 +1,4 @@
-// See machine_defs.hpp.  Bus protocol (DESIGN.md "Machine proof", format v7):
+// See machine_defs.hpp.  Bus protocol (DESIGN.md "Machine proof", format v8):
 //   MEM    (addr, lo, hi, time)   every access consumes its predecessor's tuple and produces its own
 //   PROG   (pc, class, code, uc, wr, use2, rd, rs1, rs2, imm_lo, imm_hi, tgt_lo, tgt_hi)   instruction fetch, every CPU row
 //   KCALL  (time, ptr_lo, ptr_hi)   CPU -> keccak-memory: one precompile call
@@ -89,7 +89,7 @@ Interaction bytes_inter(int sign, const LinForm& mult, const LinForm& x, const L
 }
 
 constexpr int kCpuInter = 22;
-Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7], g_alu[1], g_sub[1], g_bw[5], g_p2[3];
+Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7], g_alu[1], g_sub[5], g_bw[5], g_p2[3];
 ChipDef g_chips[kNumChips];
 
 void build() {
@@ -288,8 +288,18 @@ void build() {
     for (int k = 0; k < 6; ++k) lf_add(it.el[0], SW_SEL + k, codes[k]);
     it.el[1] = lf_zero(); lf_add(it.el[1], SW_O + 1, 1); lf_add(it.el[1], SW_O + 2, 2); lf_add(it.el[1], SW_O + 3, 3);
     it.el[2] = lf_col(SW_A); it.el[3] = lf_col(SW_A + 1);
-    it.el[4] = lf_bits(SW_M, 16); it.el[5] = lf_bits(SW_M + 16, 16); it.el[6] = lf_bits(SW_C, 16);
+    it.el[4] = lf_pair(SW_MB, SW_MB + 1, 256); it.el[5] = lf_pair(SW_MB + 2, SW_MB + 3, 256); it.el[6] = lf_pair(SW_CB, SW_CB + 1, 256);
     it.el[7] = lf_col(SW_MV); it.el[8] = lf_col(SW_MV + 1);
+    // the bytes are bytes; the sign bit of a signed load is bit 7 of the byte it extends (byte AND 0x80 = 128 * sign)
+    g_sub[1] = bytes_inter(-1, lf_col(SW_IS_REAL), lf_col(SW_MB), lf_col(SW_MB + 1));
+    g_sub[2] = bytes_inter(-1, lf_col(SW_IS_REAL), lf_col(SW_MB + 2), lf_col(SW_MB + 3));
+    g_sub[3] = bytes_inter(-1, lf_col(SW_IS_REAL), lf_col(SW_CB), lf_col(SW_CB + 1));
+    Interaction& sg = g_sub[4];
+    sg = Interaction{};
+    sg.bus = BUS_BYTEOP; sg.sign = -1; sg.mult = lf_pair(SW_SEL + 0, SW_SEL + 1, 1); sg.n_el = 4;
+    sg.el[0] = lf_const(3);  // and
+    sg.el[1] = lf_col(SW_SELB); sg.el[2] = lf_const(0x80);
+    sg.el[3] = lf_zero(); lf_add(sg.el[3], SW_S, 128);
   }
   {
     // Poseidon2: children in, parent out; the output digest is the external linear layer applied to the last round's
@@ -324,8 +334,8 @@ void build() {
   g_chips[kMul] = {"mul", 0, kMulWidth, 2, g_mul, kMulConstraints, 0};
   g_chips[kAlu] = {"alu", 0, kAluWidth, 1, g_alu, kAluConstraints, 0};
   g_chips[kAlu2] = {"alu2", 0, kAluWidth, 1, g_alu, kAluConstraints, 0};
-  g_chips[kSub] = {"subword", 0, kSubWidth, 1, g_sub, kSubConstraints, 0};
-  g_chips[kSub2] = {"subword2", 0, kSubWidth, 1, g_sub, kSubConstraints, 0};
+  g_chips[kSub] = {"subword", 0, kSubWidth, 5, g_sub, kSubConstraints, 0};
+  g_chips[kSub2] = {"subword2", 0, kSubWidth, 5, g_sub, kSubConstraints, 0};
   g_chips[kBw] = {"bitwise", 0, kBwWidth, 5, g_bw, kBwConstraints, 0};
   g_chips[kBw2] = {"bitwise2", 0, kBwWidth, 5, g_bw, kBwConstraints, 0};
 }
