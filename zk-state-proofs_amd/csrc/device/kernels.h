@@ -76,7 +76,14 @@ void launch_bus_perm_trace(hipStream_t stream, const uint32_t* trace, const uint
 // out[b][i] = (base[b]*base_mul)^e, e = i or bitrev(i); Fp4 each, base_mul a Montgomery base-field word
 void launch_ext_powers(hipStream_t stream, const uint32_t* base, size_t base_stride, uint32_t base_mul, uint32_t* out,
                        size_t out_stride, int n, int bitrev_logn, int batch, int centred = 0);
-// coefs_br: [batch][ncols][H] (bit-reversed); zpow_br: [batch][npoints][H] Fp4 (bit-reversed);
+// Barycentric weight tables out[b][4][H] (Fp4, centred words): table t opens a column given by its evaluations on
+// sigma_t <w> at zeta[b]: entry i = ((y^H - 1) / H) w^i / (y - w^i), y = zeta[b] / sigma_t.  Table 0: sigma = 1 / sigma_inv[0];
+// table 1: table 0 moved by one place (opens at zeta * w); tables 2, 3: sigma = 1 / sigma_inv[1], 1 / sigma_inv[2].
+// tw_fwd: [H/2] powers of w; H = 2^logh >= 16.
+void launch_bary_weights(hipStream_t stream, const uint32_t* zeta, size_t zeta_stride, const uint32_t sigma_inv[3], const uint32_t* tw_fwd,
+                         uint32_t h_inv, uint32_t* out, size_t out_stride, int logh, int batch);
+// coefs_br: [batch][ncols][H]; zpow_br: [batch][npoints][H] Fp4: coefficients with powers (both bit-reversed), or
+// evaluations with barycentric weights (both in natural order);
 // opened[b][pt*pt_stride + col] (Fp4)
 void launch_open(hipStream_t stream, const uint32_t* coefs_br, size_t coefs_stride, int ncols, int logh,
                  const uint32_t* zpow_br, size_t zpow_stride, int npoints, uint32_t* opened, size_t opened_stride,

@@ -624,7 +624,7 @@ __global__ __launch_bounds__(kLdeThreads) void lde_chunk_fixed_kernel(const uint
   const uint32_t* src = scratch + col * scratch_col_stride + off;
   const uint32_t* isc = in_scale_br + (((col >> scale_sel_shift) & (size_t)scale_sel_mask) << logh) + off;
   const LdeGeom geom{0, 0, 0, h};
-  lde_fixed_group<L2, 1, true>(src, coefs_br + col * h + off, out + col * 2 * h + off, tw_fwd, tw_inv, isc, out_scale_br + off,
+  lde_fixed_group<L2, 1, true>(src, coefs_br ? coefs_br + col * h + off : nullptr, out + col * 2 * h + off, tw_fwd, tw_inv, isc, out_scale_br + off,
                                reinterpret_cast<Fp*>(smem), 1, threadIdx.x, geom);
 }
 
@@ -649,7 +649,7 @@ static void launch_lde_tall(hipStream_t stream, const uint32_t* in, uint32_t* co
                             const uint32_t* out_scale_br, int logh, size_t ncols) {
   const size_t h = (size_t)1 << logh;
   static const bool generic_chunk = getenv("ZKSP_LDE_GENERIC_CHUNK") != nullptr;  // debugging switch
-  const bool fixed = !generic_chunk;
+  const bool fixed = !generic_chunk || !coefs_br;  // (the generic chunk kernel always writes the coefficients)
   // 2^13-point chunks; the l1 = logh - 13 strided stages in one register pass of at most 6 stages, or in two
   // (2^20, 2^21: a pass of 7 stages would hold 128 elements per lane)
   const int l2 = fixed ? 13 : (logh <= 19 ? 13 : 14), l1 = logh - l2;
@@ -671,7 +671,7 @@ static void launch_lde_tall(hipStream_t stream, const uint32_t* in, uint32_t* co
     if (r_lo) launch_ntt_top<true>(stream, r_lo, logh - r_hi, scratch + c0 * 2 * h, 2 * h, scratch + c0 * 2 * h, 2 * h, tw_inv, logh, nc);
     if (fixed)
       hipLaunchKernelGGL(lde_chunk_fixed_kernel<13>, dim3((unsigned)(h >> l2), (unsigned)nc), dim3(kLdeThreads), smem, stream,
-                         scratch + c0 * 2 * h, 2 * h, coefs_br + c0 * h, out + c0 * 2 * h, tw_fwd, tw_inv, in_scale_br,
+                         scratch + c0 * 2 * h, 2 * h, coefs_br ? coefs_br + c0 * h : nullptr, out + c0 * 2 * h, tw_fwd, tw_inv, in_scale_br,
                          scale_sel_shift, scale_sel_mask, out_scale_br, logh);
     else
       hipLaunchKernelGGL(lde_chunk_kernel, dim3((unsigned)(h >> l2), (unsigned)nc), dim3(kLdeThreads), smem, stream,
@@ -720,7 +720,7 @@ void launch_lde(hipStream_t stream, const uint32_t* in, uint32_t* coefs_br, uint
   if (ncols == 0) return;
   if (logh > 14) {
     static const bool old_tall = getenv("ZKSP_LDE_OLD_TALL") != nullptr;  // debugging switch: the strided/chunk form
-    if (logh <= 21 && coefs_br && !old_tall)
+    if (logh <= 21 && (!coefs_br || !old_tall))
       launch_lde_tall(stream, in, coefs_br, out, tw_fwd, tw_inv, in_scale_br, scale_sel_shift, scale_sel_mask, out_scale_br, logh,
                       ncols);
     else

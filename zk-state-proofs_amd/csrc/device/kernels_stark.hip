@@ -331,6 +331,67 @@ void launch_ext_powers(hipStream_t stream, const uint32_t* base, size_t base_str
 }
 
 // ===========================================================================
+// barycentric weights: opening a column from its EVALUATIONS v_i = p(sigma w^i) on a coset of the height-H subgroup,
+//   p(z) = ((y^H - 1) / H) * sum_i v_i w^i / (y - w^i),   y = z / sigma,
+// is the same dot product the opening kernels compute against a table of powers, with the table
+//   W_i = ((y^H - 1) / H) * w^i / (y - w^i)
+// instead (so no coefficient array has to be kept).  The table for z * w is the same table moved by one place,
+// W'_i = W_{i-1}: written here as a second copy.  Entries are centred signed words like the power tables'.
+// A lane inverts kBaryK denominators with one extension-field inversion (Montgomery's trick).
+// ===========================================================================
+constexpr int kBaryK = 16;
+struct BarySigma { uint32_t inv[3]; };
+// tables [4][H] per proof: 0 = the subgroup itself (sigma = 1), 1 = table 0 moved by one place, 2 and 3 = the cosets
+// sigma.inv[1], sigma.inv[2] (given as 1 / sigma).  blockIdx.z picks the coset; a lane's kBaryK entries are kThreads
+// apart, so that adjacent lanes read and write adjacent entries.
+__global__ __launch_bounds__(kThreads) void bary_weights_kernel(const uint32_t* __restrict__ zeta, size_t zeta_stride, BarySigma sigma,
+                                                               const uint32_t* __restrict__ tw_fwd, uint32_t h_inv,
+                                                               uint32_t* __restrict__ out, size_t out_stride, int logh) {
+  const int h = 1 << logh, half = h >> 1;
+  const int per_block = kThreads * kBaryK;
+  const int i0 = blockIdx.x * per_block + threadIdx.x;  // entries i0 + k * step
+  const int step = h < per_block ? h / kBaryK : kThreads;
+  if (threadIdx.x >= step) return;
+  const int b = blockIdx.y, which = blockIdx.z;
+  const uint32_t sinv = which == 0 ? sigma.inv[0] : which == 1 ? sigma.inv[1] : sigma.inv[2];
+  const Fp4 y = load_fp4(zeta + (size_t)b * zeta_stride) * Fp::raw(sinv);
+  Fp4 yn = y;
+  for (int k = 0; k < logh; ++k) yn = yn.sqr();
+  const Fp4 scal = (yn - Fp4::one()) * Fp::raw(h_inv);
+  Fp w[kBaryK];
+  Fp4 pre[kBaryK];
+#pragma unroll
+  for (int k = 0; k < kBaryK; ++k) {
+    const int i = i0 + k * step;
+    w[k] = i < half ? Fp::raw(tw_fwd[i]) : -Fp::raw(tw_fwd[i - half]);
+    Fp4 d = y;
+    d.c[0] -= w[k];
+    pre[k] = k ? pre[k - 1] * d : d;
+  }
+  Fp4 inv = pre[kBaryK - 1].inv() * scal;  // the common factor rides on the one inversion
+  uint32_t* o = out + (size_t)b * out_stride + (size_t)(which == 0 ? 0 : which + 1) * h * 4;
+#pragma unroll
+  for (int k = kBaryK - 1; k >= 0; --k) {
+    Fp4 v = (k ? inv * pre[k - 1] : inv) * w[k];
+    Fp4 d = y;
+    d.c[0] -= w[k];
+    inv = inv * d;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v.c[j] = Fp::raw((uint32_t)fps_centre(v.c[j].v));
+    const int i = i0 + k * step;
+    store_fp4(o + (size_t)i * 4, v);
+    if (which == 0) store_fp4(o + (size_t)h * 4 + (size_t)((i + 1) & (h - 1)) * 4, v);
+  }
+}
+void launch_bary_weights(hipStream_t stream, const uint32_t* zeta, size_t zeta_stride, const uint32_t sigma_inv[3], const uint32_t* tw_fwd,
+                         uint32_t h_inv, uint32_t* out, size_t out_stride, int logh, int batch) {
+  const int h = 1 << logh, per_block = kThreads * kBaryK;
+  BarySigma sg{{sigma_inv[0], sigma_inv[1], sigma_inv[2]}};
+  hipLaunchKernelGGL(bary_weights_kernel, dim3((h + per_block - 1) / per_block, batch, 3), dim3(kThreads), 0, stream, zeta, zeta_stride,
+                     sg, tw_fwd, h_inv, out, out_stride, logh);
+}
+
+// ===========================================================================
 // out-of-domain openings: p(z) = sum_k coef_k z^k, one workgroup per column
 // ===========================================================================
 __device__ __forceinline__ Fp4 block_sum(Fp4 v, Fp4* red) {

@@ -141,13 +141,12 @@ int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineV
     for (auto& v : tr[i]) v = Fp::from_canonical(v).v;
     ok = ok && dalloc(&pd->allocs, &pd->tr[i], tr[i].size());
     uint32_t* d_tr = pd->tr[i];
-    ok = ok && dalloc(&pd->allocs, &pd->coef[i], (size_t)widths[i] * h);
     ok = ok && dalloc(&pd->allocs, &pd->lde[i], (size_t)widths[i] * 2 * h);
     if (!ok) break;
     const DeviceDomain* dom = ctx->domain(pd->logh[i]);
     if (!dom) return 3;
     ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(d_tr, tr[i].data(), tr[i].size() * 4, hipMemcpyHostToDevice, s));
-    launch_lde(s, d_tr, pd->coef[i], pd->lde[i], dom->twc_fwd, dom->twc_inv, dom->in_scale_br, 0, 0, dom->out_scale_br,
+    launch_lde(s, d_tr, nullptr, pd->lde[i], dom->twc_fwd, dom->twc_inv, dom->in_scale_br, 0, 0, dom->out_scale_br,
                pd->logh[i], (size_t)widths[i]);
     ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // tr[i] goes out of use
   }
@@ -257,10 +256,14 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
       for (int r = 0; r < 3; ++r) {
         w->mat[c][r].w = widths[r];
         A(&w->mat[c][r].tr, B * widths[r] * h);
-        A(&w->mat[c][r].coef, B * widths[r] * h);
-        A(&w->mat[c][r].lde, B * widths[r] * 2 * h);
+        A(&w->mat[c][r].lde, B * widths[r] * 2 * h);  // (no coefficient arrays: columns are opened from their evaluations)
       }
-      A(&w->zpow[c], B * 2 * h * 4);
+      // barycentric weights: at zeta, at zeta * w_H, and for the two quotient cosets; one set per height
+      int first = c;
+      for (int c2 = c - 1; c2 >= 0; --c2)
+        if (logh[c2] == logh[c]) first = c2;
+      if (first == c) A(&w->zpow[c], B * 4 * h * 4);
+      else w->zpow[c] = w->zpow[first];
       w->open_off[c] = n_open;
       n_open += (size_t)d.prep_w + 2 * (size_t)d.main_w + 2 * (size_t)d.perm_width() + 8;
       max_total = std::max<size_t>(max_total, (size_t)d.total_constraints());
@@ -546,7 +549,7 @@ int machine_prove_resident(Context* ctx) {
   {
     ProfileSpan sp(ctx, "m_lde_main");
     for (int c = 0; c < kNumChips; ++c)
-      launch_lde(s, w->mat[c][0].tr, w->mat[c][0].coef, w->mat[c][0].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br, 0,
+      launch_lde(s, w->mat[c][0].tr, nullptr, w->mat[c][0].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br, 0,
                  0, dom[c]->out_scale_br, logh[c], (size_t)B * w->mat[c][0].w);
   }
   RoundMats rm[4];
@@ -598,7 +601,7 @@ int machine_prove_resident(Context* ctx) {
   {
     ProfileSpan sp(ctx, "m_lde_perm");
     for (int c = 0; c < kNumChips; ++c)
-      launch_lde(s, w->mat[c][1].tr, w->mat[c][1].coef, w->mat[c][1].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br, 0,
+      launch_lde(s, w->mat[c][1].tr, nullptr, w->mat[c][1].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br, 0,
                  0, dom[c]->out_scale_br, logh[c], (size_t)B * w->mat[c][1].w);
   }
   {
@@ -655,7 +658,7 @@ int machine_prove_resident(Context* ctx) {
     ProfileSpan sp(ctx, "m_lde_quot");
     // columns 4c..4c+3 of every proof were evaluated over coset c: scale tables 1 and 2
     for (int c = 0; c < kNumChips; ++c)
-      launch_lde(s, w->mat[c][2].tr, w->mat[c][2].coef, w->mat[c][2].lde, dom[c]->twc_fwd, dom[c]->twc_inv,
+      launch_lde(s, w->mat[c][2].tr, nullptr, w->mat[c][2].lde, dom[c]->twc_fwd, dom[c]->twc_inv,
                  dom[c]->in_scale_br + H(c), 2, 1, dom[c]->out_scale_br, logh[c], (size_t)B * 8);
   }
   {
@@ -674,20 +677,31 @@ int machine_prove_resident(Context* ctx) {
       const ChipDef& d = chip_def(c);
       const size_t h = H(c);
       const int pw = d.prep_w, mw = d.main_w, ew = d.perm_width();
-      launch_ext_powers(s, w->zeta, 4, kR1, w->zpow[c], 2 * h * 4, (int)h, logh[c], B, /*centred=*/1);
-      launch_ext_powers(s, w->zeta, 4, dom[c]->w_h, w->zpow[c] + h * 4, 2 * h * 4, (int)h, logh[c], B, /*centred=*/1);
+      // Columns are opened from their evaluations (the traces, and the quotient values over their cosets) against
+      // barycentric weights: table 0 at zeta, table 1 at zeta * w_H (table 0 moved by one place), tables 2 and 3 at zeta
+      // for columns given on the cosets g<w_H> and g w_2H <w_H> (the two quotient chunks).  No coefficient arrays.
+      const size_t zs = 4 * h * 4;
+      const uint32_t h_inv = Fp::from_canonical((uint32_t)(h % kP)).inv().v;
+      const Fp g = Fp::from_canonical(kGen), gw = g * fp_root_of_unity(logh[c] + 1);
+      bool have = false;  // chips of one height share their tables
+      for (int c2 = 0; c2 < c; ++c2) have = have || logh[c2] == logh[c];
+      if (!have) {
+        const uint32_t sinv[3] = {kR1, g.inv().v, gw.inv().v};
+        launch_bary_weights(s, w->zeta, 4, sinv, dom[c]->tw_fwd, h_inv, w->zpow[c], zs, logh[c], B);
+      }
       uint32_t* base = w->opened + w->open_off[c] * 4;
       const size_t pt_stride = (size_t)mw + ew + 8;
-      // tall columns: split the coefficient range over workgroups (the partial sums live in the reduce scratch,
-      // which is not in use yet)
-      auto open = [&](const uint32_t* coefs, size_t cstride, int ncols, int npts, uint32_t* dst, size_t pts) {
-        if (logh[c] >= 12) launch_open_tall(s, coefs, cstride, ncols, logh[c], w->zpow[c], 2 * h * 4, npts, dst, 8 * R, pts, w->reduce_scratch, B);
-        else launch_open(s, coefs, cstride, ncols, logh[c], w->zpow[c], 2 * h * 4, npts, dst, 8 * R, pts, B);
+      // tall columns: split the rows over workgroups (the partial sums live in the reduce scratch, which is not in
+      // use yet)
+      auto open = [&](const uint32_t* evals, size_t cstride, int ncols, int npts, const uint32_t* table, uint32_t* dst, size_t pts) {
+        if (logh[c] >= 12) launch_open_tall(s, evals, cstride, ncols, logh[c], table, zs, npts, dst, 8 * R, pts, w->reduce_scratch, B);
+        else launch_open(s, evals, cstride, ncols, logh[c], table, zs, npts, dst, 8 * R, pts, B);
       };
-      if (pw) open(prep->coef[PrepDevice::index_of(c)], 0, pw, 1, base, 0);
-      open(w->mat[c][0].coef, (size_t)mw * h, mw, 2, base + (size_t)pw * 4, pt_stride);
-      open(w->mat[c][1].coef, (size_t)ew * h, ew, 2, base + (size_t)(pw + mw) * 4, pt_stride);
-      open(w->mat[c][2].coef, 8 * h, 8, 1, base + (size_t)(pw + mw + ew) * 4, 0);
+      if (pw) open(prep->tr[PrepDevice::index_of(c)], 0, pw, 1, w->zpow[c], base, 0);
+      open(w->mat[c][0].tr, (size_t)mw * h, mw, 2, w->zpow[c], base + (size_t)pw * 4, pt_stride);
+      open(w->mat[c][1].tr, (size_t)ew * h, ew, 2, w->zpow[c], base + (size_t)(pw + mw) * 4, pt_stride);
+      open(w->mat[c][2].tr, 8 * h, 4, 1, w->zpow[c] + 2 * h * 4, base + (size_t)(pw + mw + ew) * 4, 0);
+      open(w->mat[c][2].tr + 4 * h, 8 * h, 4, 1, w->zpow[c] + 3 * h * 4, base + (size_t)(pw + mw + ew + 4) * 4, 0);
     }
   }
   {
