@@ -55,7 +55,7 @@ typedef struct {
 } zksp_options;
 /* What zksp_prove / zksp_prove_batch establish:
  * MACHINE      the guest's whole execution (CPU, memory, program, keccak, multiplier chips joined by
- *              LogUp buses; proof format v8): the statement of the reference's client.prove().
+ *              LogUp buses; proof format v9): the statement of the reference's client.prove().
  * KECCAK_CHIP  only "these keccak-f outputs belong to these inputs" (round-1 format v2, a component
  *              benchmark; NOT a proof that the guest ran). */
 #define ZKSP_PROOF_MACHINE 1
@@ -148,6 +148,7 @@ typedef struct zksp_mtrace zksp_mtrace;
 #define ZKSP_MT_PUBLIC_VALUES 8 /* bytes */
 #define ZKSP_MT_SUB_IDX 9       /* u32 per sub-word-chip row: index of the cycle (lb lh lbu lhu sb sh) */
 #define ZKSP_MT_BW_IDX 10       /* u32 per bitwise-chip row: index of the cycle (xor or and) */
+#define ZKSP_MT_ECALL_IDX 11    /* u32 per ecall-chip row: index of the ecall cycle */
 typedef struct {
   uint64_t cycles;
   uint64_t memory_ops;
@@ -167,7 +168,7 @@ int zksp_mtrace_info(const zksp_mtrace* t, zksp_mtrace_info_t* info);
 /* Device-resident machine proving (bench.py, parity tests): upload the records of n traced runs (they are proven
  * with one shape: zksp_machine_cover_heights), enqueue one proving pass, fetch the proof bodies ([n][body_words]
  * canonical u32; body_words = zksp_machine_body_words of that shape). */
-#define ZKSP_MACHINE_CHIPS 16   /* cpu, keccak, keccak-mem, mem-final, image, program, mul, table, cpu2, alu, alu2, subword, subword2, bitwise, bitwise2, poseidon2 */
+#define ZKSP_MACHINE_CHIPS 17   /* cpu, keccak, keccak-mem, mem-final, image, program, mul, table, cpu2, alu, alu2, subword, subword2, bitwise, bitwise2, poseidon2, ecall */
 int zksp_mtrace_heights(const zksp_mtrace* t, int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 size_t zksp_machine_body_words(const zksp_client* c, const int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 /* The shape a batch of these runs is proven with: the chip heights that cover the largest cycle / event / address
@@ -194,7 +195,7 @@ int zksp_verify_aggregate(zksp_client* c, const zksp_proof* p, const zksp_vk* vk
  * cumulative sums (4 words each), as the device's transcript sampled / computed them. */
 int zksp_hip_machine_fetch_stage(zksp_client* c, int chip, int stage, size_t proof_index, uint32_t* out, size_t cap_words);
 int zksp_hip_machine_fetch_challenges(zksp_client* c, size_t proof_index, uint32_t* out /* [16 + 4 * ZKSP_MACHINE_CHIPS] */);
-/* Complete v8 proof object from one fetched body and the trace it belongs to.  log_heights: the shape the batch was
+/* Complete v9 proof object from one fetched body and the trace it belongs to.  log_heights: the shape the batch was
  * proven with (zksp_machine_cover_heights of the loaded traces), NULL = the trace's own minimal heights. */
 int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] or NULL */,
                                  const uint32_t* body, size_t body_words, zksp_proof** out);

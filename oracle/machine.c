@@ -1,6 +1,6 @@
 /* ORACLE -- TEST INFRASTRUCTURE ONLY (see field.h and machine.h).
  *
- * Chips of the machine proof (format v8): bus interactions, trace generation from the executor's
+ * Chips of the machine proof (format v9): bus interactions, trace generation from the executor's
  * records and base-field constraints.  This repository's own arithmetisation (machine.h header
  * note); what it must reproduce is the reference's statement: the committed RV32IM guest
  * (circuits/sp1-merkle-proof/src/main.rs:4-14 running crypto-ops/src/lib.rs:8-23) executed from its
@@ -69,6 +69,7 @@ static int event_kind(uint32_t op) {
   if (code >= OP_SLL && code <= OP_SLT) return 0;
   if (code == OP_LB || code == OP_LH || code == OP_LBU || code == OP_LHU || code == OP_SB || code == OP_SH) return 1;
   if (code >= OP_XOR && code <= OP_AND) return 2;
+  if (op == OP_ECALL) return 3;
   return -1;
 }
 
@@ -100,9 +101,9 @@ static orc_lf lf_bits(int bits, int n) {
 }
 #define SELC(cls) (C_SEL + (cls) - 1)
 
-#define CPU_INTER 22
+#define CPU_INTER 21
 static orc_inter g_cpu[CPU_INTER], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7],
-    g_alu[1], g_sub[5], g_bw[5], g_p2[3];
+    g_alu[1], g_sub[5], g_bw[5], g_p2[3], g_ecall[10];
 static orc_chip g_chips[N_CHIPS];
 static int g_ready = 0;
 
@@ -160,10 +161,13 @@ static void build(void) {
   g_cpu[3] = mem_inter(-1, lf_col(C_USE2), lf_col(C_RS2), c_lo, c_hi, pts[1]);
   g_cpu[4] = mem_inter(+1, lf_col(C_USE2), lf_col(C_RS2), c_lo, c_hi, lf_plus(ts, 1));
   {
-    const int memq_c[5] = {SELC(CL_LW), SELC(CL_SW), SELC(CL_LDS), SELC(CL_STS), SELC(CL_ECALL)};
-    const orc_lf memq = lf_sum(memq_c, 5);
-    g_cpu[5] = mem_inter(-1, memq, lf_col(C_MADDR), m_lo, m_hi, pts[2]);
-    g_cpu[6] = mem_inter(+1, memq, lf_col(C_MADDR), lf_col(C_MV), lf_col(C_MV + 1), lf_plus(ts, 2));
+    /* the word address is the adder output less the byte offset: a linear form (below 0x78000000: X's lookups) */
+    const int memq_c[4] = {SELC(CL_LW), SELC(CL_SW), SELC(CL_LDS), SELC(CL_STS)};
+    const orc_lf memq = lf_sum(memq_c, 4);
+    orc_lf maddr = lf_pair(C_X, C_X + 1, 65536);
+    lf_add(&maddr, C_O1, FP - 1); lf_add(&maddr, C_O2, FP - 2); lf_add(&maddr, C_O3, FP - 3);
+    g_cpu[5] = mem_inter(-1, memq, maddr, m_lo, m_hi, pts[2]);
+    g_cpu[6] = mem_inter(+1, memq, maddr, lf_col(C_MV), lf_col(C_MV + 1), lf_plus(ts, 2));
   }
   g_cpu[7] = mem_inter(-1, lf_col(C_WR), lf_col(C_RD), lf_col(C_W_PLO), lf_col(C_W_PHI), pts[3]);
   g_cpu[8] = mem_inter(+1, lf_col(C_WR), lf_col(C_RD), a_lo, a_hi, lf_plus(ts, 3));
@@ -210,14 +214,43 @@ static void build(void) {
     it->el[0] = ts; it->el[1] = c_lo; it->el[2] = c_hi;
     it = &g_cpu[20];
     memset(it, 0, sizeof *it);
-    it->bus = BUS_PUBC; it->sign = +1; it->n_el = 4;
-    it->mult = lf_pair(C_SC + SC_COMMIT, C_SC + SC_DEFER, 1);
-    it->el[0] = lf_pair(C_SC + SC_COMMIT, C_SC + SC_DEFER, 2);
-    it->el[1] = c_lo; it->el[2] = m_lo; it->el[3] = m_hi;
-    it = &g_cpu[21];
+    /* an ecall: the ecall chip takes it from here (time, pc, next pc, the code in t0, the value left in t0) */
+    it->bus = BUS_ECALL; it->sign = +1; it->mult = lf_col(SELC(CL_ECALL)); it->n_el = 6;
+    it->el[0] = ts; it->el[1] = lf_col(C_PC); it->el[2] = lf_col(C_NEXT_PC); it->el[3] = b_lo; it->el[4] = a_lo; it->el[5] = a_hi;
+  }
+  /* ---- ecall chip ---- */
+  {
+    const orc_lf real = lf_col(EC_IS_REAL), ets = lf_col(EC_TS);
+    const orc_lf ec_lo = lf_col(EC_C_LO), ec_hi = lf_col(EC_C_HI), em_lo = lf_col(EC_M_LO), em_hi = lf_col(EC_M_HI);
+    orc_inter* it = &g_ecall[0];
     memset(it, 0, sizeof *it);
-    it->bus = BUS_PUBH; it->sign = +1; it->mult = lf_col(C_SC + SC_HALT); it->n_el = 2;
-    it->el[0] = c_lo; it->el[1] = c_hi;
+    it->bus = BUS_ECALL; it->sign = -1; it->mult = real; it->n_el = 6;
+    it->el[0] = ets; it->el[1] = lf_col(EC_PC); it->el[2] = lf_col(EC_NP); it->el[3] = lf_col(EC_B_LO);
+    it->el[4] = lf_col(EC_A_LO); it->el[5] = lf_col(EC_A_HI);
+    /* a0 is read at ts + 1, a1 at ts + 2: previous access times ts + q - 1 - difference */
+    orc_lf epts[2];
+    for (int q = 0; q < 2; ++q) {
+      lf_zero(&epts[q]);
+      lf_add(&epts[q], EC_TS, 1); lf_add(&epts[q], EC_GAP + 2 * q, FP - 1); lf_add(&epts[q], EC_GAP + 2 * q + 1, FP - 65536);
+      epts[q].c0 = (uint32_t)q;
+    }
+    g_ecall[1] = mem_inter(-1, real, lf_const(10), ec_lo, ec_hi, epts[0]);
+    g_ecall[2] = mem_inter(+1, real, lf_const(10), ec_lo, ec_hi, lf_plus(ets, 1));
+    g_ecall[3] = mem_inter(-1, real, lf_const(11), em_lo, em_hi, epts[1]);
+    g_ecall[4] = mem_inter(+1, real, lf_const(11), em_lo, em_hi, lf_plus(ets, 2));
+    g_ecall[5] = range_inter(-1, real, lf_const(0), lf_col(EC_GAP));
+    g_ecall[6] = range_inter(-1, real, lf_const(0), lf_col(EC_GAP + 2));
+    g_ecall[7] = bytes_inter(-1, real, lf_col(EC_GAP + 1), lf_col(EC_GAP + 3));
+    it = &g_ecall[8];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_PUBC; it->sign = +1; it->n_el = 4;
+    it->mult = lf_pair(EC_SC + SC_COMMIT, EC_SC + SC_DEFER, 1);
+    it->el[0] = lf_pair(EC_SC + SC_COMMIT, EC_SC + SC_DEFER, 2);
+    it->el[1] = ec_lo; it->el[2] = em_lo; it->el[3] = em_hi;
+    it = &g_ecall[9];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_PUBH; it->sign = +1; it->mult = lf_col(EC_SC + SC_HALT); it->n_el = 2;
+    it->el[0] = ec_lo; it->el[1] = ec_hi;
   }
   /* ---- keccak chip: on an export row, word i of the input and of the output state, i = 0..49 ---- */
   for (int i = 0; i < 50; ++i) {
@@ -380,8 +413,8 @@ static void build(void) {
     lf_zero(&it->el[3]); lf_add(&it->el[3], SW_S, 128);
   }
   g_chips[CH_TABLE] = (orc_chip){"table", TABLE_PREP_WIDTH, TABLE_WIDTH, 7, g_table, 0, 0};
-  g_chips[CH_CPU] = (orc_chip){"cpu", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0, 5};   /* ALU, SUB, KCALL, PUBC, PUBH: one class each */
-  g_chips[CH_CPU2] = (orc_chip){"cpu2", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0, 5};
+  g_chips[CH_CPU] = (orc_chip){"cpu", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0, 4};   /* ALU, SUB, KCALL, ECALL: one class each */
+  g_chips[CH_CPU2] = (orc_chip){"cpu2", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0, 4};
   g_chips[CH_KECCAK] = (orc_chip){"keccak", 0, KECCAK_WIDTH, 50, g_keccak, 0, 0};
   g_chips[CH_KMEM] = (orc_chip){"keccak-mem", 0, KMEM_WIDTH, 8, g_kmem, 0, 0};
   g_chips[CH_MEMFINAL] = (orc_chip){"mem-final", 0, MEMFINAL_WIDTH, 10, g_memfinal, 0, 0};
@@ -395,6 +428,7 @@ static void build(void) {
   g_chips[CH_BW] = (orc_chip){"bitwise", 0, BW_WIDTH, 5, g_bw, 0, 0};
   g_chips[CH_BW2] = (orc_chip){"bitwise2", 0, BW_WIDTH, 5, g_bw, 0, 0};
   g_chips[CH_P2] = (orc_chip){"poseidon2", 0, P2CHIP_WIDTH, 3, g_p2, 0, 0};
+  g_chips[CH_ECALL] = (orc_chip){"ecall", 0, ECALL_WIDTH, 10, g_ecall, 0, 0};
   g_ready = 1;
   for (int c = 0; c < N_CHIPS; ++c) g_chips[c].n_constraints = count_constraints(c);
 }
@@ -488,6 +522,7 @@ void orc_machine_heights(const orc_machine_input* in, int logh[N_CHIPS]) {
   logh[CH_MUL] = at_least5(clog2(in->n_muls));
   logh[CH_TABLE] = TABLE_LOG_H;
   logh[CH_P2] = at_least5(clog2(in->n_agg > 1 ? in->n_agg - 1 : 1));
+  logh[CH_ECALL] = at_least5(clog2(orc_machine_events(in, 3, NULL)));
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -524,18 +559,20 @@ static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
       gap[0] = ts - pts - 1;
     } else {
       const uint32_t* cy = in->cycles + 12 * g;
-      const uint32_t pc = cy[0], b = cy[2], c = cy[3], m = cy[4], mv = cy[5], wprev = cy[6];
-      uint32_t a = cy[1];
+      const uint32_t pc = cy[0], b = cy[2], wprev = cy[6];
+      uint32_t a = cy[1], c = cy[3], m = cy[4], mv = cy[5];
       const uint32_t* p = prog_row(in, pc);
-      const uint32_t op = p[1], wr = p[2], use2 = p[3], rd = p[4], rs1 = p[5], rs2 = p[6], imm = p[7], tgt = p[8];
+      const uint32_t op = p[1], wr = p[2], rd = p[4], rs1 = p[5], imm = p[7], tgt = p[8];
+      uint32_t use2 = p[3], rs2 = p[6];
       const int cls = orc_class_of(op);
+      if (cls == CL_ECALL) { use2 = 0; rs2 = 0; c = 0; m = 0; mv = 0; } /* a0 and a1 are read by the ecall chip */
       const uint32_t code = orc_code_of(op);
       T(C_PC) = pc;
       T(SELC(cls)) = 1;
       const int uc = orc_ucmp_of(op);
       T(C_CODE) = code; T(C_UC) = (uint32_t)uc; T(C_WR) = wr; T(C_USE2) = use2; T(C_RD) = rd; T(C_RS1) = rs1; T(C_RS2) = rs2;
       put_limbs(t, h, r, C_IMM_LO, imm); put_limbs(t, h, r, C_TGT_LO, tgt);
-      uint32_t x = 0, next = pc + 4, k0 = 0, k1 = 0, maddr = 0;
+      uint32_t x = 0, next = pc + 4, k0 = 0, k1 = 0;
       int off = -1;
       const uint32_t blo = b & 0xffff, bhi = b >> 16, clo = c & 0xffff, chi = c >> 16;
       switch (cls) {
@@ -545,11 +582,11 @@ static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
         case CL_JALR: case CL_LW: case CL_LDS:
           x = b + c; k0 = (blo + clo) >> 16; k1 = (bhi + chi + k0) >> 16;
           if (cls == CL_JALR) { off = (int)(x & 1); next = x & ~1u; }
-          else { off = (int)(x & 3); maddr = x & ~3u; }
+          else off = (int)(x & 3);
           break;
         case CL_SW: case CL_STS:
           x = b + imm; k0 = (blo + (imm & 0xffff)) >> 16; k1 = (bhi + (imm >> 16) + k0) >> 16;
-          off = (int)(x & 3); maddr = x & ~3u;
+          off = (int)(x & 3);
           break;
         case CL_BEQ: case CL_BNE: {
           k0 = blo == clo; k1 = bhi == chi;
@@ -564,13 +601,10 @@ static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
           if ((cls == CL_BLT) == (a != 0)) next = tgt;
           break;
         case CL_ALU: break; /* (sltu: below) */
-        case CL_ECALL: {
-          static const uint32_t codes[6] = {0x00, 0x02, 0x10, 0x1a, 0xf0, 0xf1};
-          for (int k = 0; k < 6; ++k) if (b == codes[k]) T(C_SC + k) = 1;
-          x = a; maddr = 11;
+        case CL_ECALL:
+          x = a;
           if (b == 0x00) next = pad_pc;
           break;
-        }
         case CL_KECCAK: x = b; next = b; break;
         default: break;
       }
@@ -584,9 +618,8 @@ static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
       put_limbs(t, h, r, C_M, m); put_limbs(t, h, r, C_MV, mv);
       T(C_K0) = k0; T(C_K1) = k1;
       if (off > 0) T(C_O1 + off - 1) = 1;
-      T(C_MADDR) = maddr;
       T(C_NEXT_PC) = next;
-      const int memq = cls == CL_LW || cls == CL_SW || cls == CL_LDS || cls == CL_STS || cls == CL_ECALL;
+      const int memq = cls == CL_LW || cls == CL_SW || cls == CL_LDS || cls == CL_STS;
       gap[0] = ts - cy[7] - 1;
       if (use2) gap[1] = ts - cy[8];
       if (memq) gap[2] = ts + 1 - cy[9];
@@ -635,6 +668,29 @@ static void fill_alu(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
     T(AL_K0) = k0; T(AL_K1) = k1;
     const char* wa = getenv("ZKSP_ORACLE_WRONG_ALU");
     if (wa && row0 + r == (size_t)strtoull(wa, NULL, 10)) T(AL_A) = (a & 0xffff) ^ 1u; /* soundness tests: a wrong result */
+#undef T
+  }
+  free(ev);
+}
+/* the ecall chip: row r is the r-th ecall of the run */
+static void fill_ecall(const orc_machine_input* in, size_t h, uint32_t* t) {
+  const size_t n = orc_machine_events(in, 3, NULL);
+  uint32_t* ev = (uint32_t*)malloc((n ? n : 1) * 4);
+  orc_machine_events(in, 3, ev);
+  const uint32_t pad_pc = pad_pc_of(in);
+  for (size_t r = 0; r < h && r < n; ++r) {
+#define T(col) t[(size_t)(col) * h + r]
+    static const uint32_t codes[6] = {0x00, 0x02, 0x10, 0x1a, 0xf0, 0xf1};
+    const uint32_t g = ev[r], ts = 4 * (g + 1);
+    const uint32_t* cy = in->cycles + 12 * (size_t)g;
+    const uint32_t pc = cy[0], a = cy[1], b = cy[2], c = cy[3], m = cy[4];
+    T(EC_IS_REAL) = 1;
+    for (int k = 0; k < 6; ++k) if (b == codes[k]) T(EC_SC + k) = 1;
+    T(EC_TS) = ts; T(EC_PC) = pc; T(EC_NP) = b == 0x00 ? pad_pc : pc + 4;
+    T(EC_B_LO) = b & 0xffff; T(EC_A_LO) = a & 0xffff; T(EC_A_HI) = a >> 16;
+    T(EC_C_LO) = c & 0xffff; T(EC_C_HI) = c >> 16; T(EC_M_LO) = m & 0xffff; T(EC_M_HI) = m >> 16;
+    const uint32_t g0 = ts - cy[8], g1 = ts + 1 - cy[9];
+    T(EC_GAP) = g0 & 0xffff; T(EC_GAP + 1) = g0 >> 16; T(EC_GAP + 2) = g1 & 0xffff; T(EC_GAP + 3) = g1 >> 16;
 #undef T
   }
   free(ev);
@@ -694,8 +750,8 @@ static void fill_table_mults(const orc_machine_input* in, uint32_t* t) {
   const size_t ht = (size_t)1 << TABLE_LOG_H;
   int logh[N_CHIPS];
   orc_machine_heights(in, logh);
-  static const int users[8] = {CH_CPU, CH_CPU2, CH_KMEM, CH_MEMFINAL, CH_BW, CH_BW2, CH_SUB, CH_SUB2};
-  for (int u = 0; u < 8; ++u) {
+  static const int users[9] = {CH_CPU, CH_CPU2, CH_KMEM, CH_MEMFINAL, CH_BW, CH_BW2, CH_SUB, CH_SUB2, CH_ECALL};
+  for (int u = 0; u < 9; ++u) {
     const int chip = users[u];
     const orc_chip* ch = &g_chips[chip];
     const size_t h = (size_t)1 << logh[chip];
@@ -750,6 +806,7 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
     case CH_ALU2: fill_alu(in, h, t, first_rows(in, CH_ALU, orc_machine_events(in, 0, NULL))); break;
     case CH_SUB: fill_sub(in, h, t, 0); break;
     case CH_SUB2: fill_sub(in, h, t, first_rows(in, CH_SUB, orc_machine_events(in, 1, NULL))); break;
+    case CH_ECALL: fill_ecall(in, h, t); break;
     case CH_BW: fill_bw(in, h, t, 0); break;
     case CH_BW2: fill_bw(in, h, t, first_rows(in, CH_BW, orc_machine_events(in, 2, NULL))); break;
     case CH_KECCAK: {
@@ -824,8 +881,9 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
         uint32_t* q = prep + r;
         q[(size_t)PR_PC * h] = p[0]; q[(size_t)PR_CLS * h] = (uint32_t)orc_class_of(p[1]); q[(size_t)PR_CODE * h] = orc_code_of(p[1]);
         q[(size_t)PR_UC * h] = (uint32_t)orc_ucmp_of(p[1]);
-        q[(size_t)PR_WR * h] = p[2]; q[(size_t)PR_USE2 * h] = p[3];
-        q[(size_t)PR_RD * h] = p[4]; q[(size_t)PR_RS1 * h] = p[5]; q[(size_t)PR_RS2 * h] = p[6];
+        const int ecall = p[1] == OP_ECALL; /* its CPU row moves t0 only: a0 and a1 are the ecall chip's reads */
+        q[(size_t)PR_WR * h] = p[2]; q[(size_t)PR_USE2 * h] = ecall ? 0 : p[3];
+        q[(size_t)PR_RD * h] = p[4]; q[(size_t)PR_RS1 * h] = p[5]; q[(size_t)PR_RS2 * h] = ecall ? 0 : p[6];
         q[(size_t)PR_IMM_LO * h] = p[7] & 0xffff; q[(size_t)PR_IMM_HI * h] = p[7] >> 16;
         q[(size_t)PR_TGT_LO * h] = p[8] & 0xffff; q[(size_t)PR_TGT_HI * h] = p[8] >> 16;
         if (in->prog_mult) T(0) = in->prog_mult[r] % FP;
@@ -931,16 +989,13 @@ static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, f
                             sink* s) {
   const fe one = 1;
 #define S(cls) l[SELC(cls)]
-  /* ---- booleans: class selectors, carries, byte offset, syscall flags (WR, USE2 are Program-table values) ---- */
+  /* ---- booleans: class selectors, carries, byte offset (WR, USE2 are Program-table values) ---- */
   fe selsum = 0;
   for (int k = 0; k < N_CLS; ++k) { emit(s, bool_c(l[C_SEL + k])); selsum = f_add(selsum, l[C_SEL + k]); }
   emit(s, bool_c(l[C_K0])); emit(s, bool_c(l[C_K1]));
   for (int i = 0; i < 3; ++i) emit(s, bool_c(l[C_O1 + i]));
-  fe scsum = 0;
-  for (int i = 0; i < 6; ++i) { emit(s, bool_c(l[C_SC + i])); scsum = f_add(scsum, l[C_SC + i]); }
   /* ---- row structure: exactly one class; the clock; the chain of pcs; the instance's first and last rows ---- */
   emit(s, f_sub(selsum, one));
-  emit(s, f_sub(scsum, S(CL_ECALL)));
   emit(s, f_mul(is_first, f_sub(l[C_PC], pub[CPUPUB_START_PC] % FP)));
   emit(s, f_mul(is_first, f_sub(l[C_TS], pub[CPUPUB_START_TS] % FP)));
   emit(s, f_mul(is_trans, f_sub(f_sub(n[C_TS], l[C_TS]), 4)));
@@ -989,12 +1044,9 @@ static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, f
   const fe xaddr = f_sub(f_add(x_lo, f_mul(F65536, x_hi)), off);
   {
     const fe noff = f_add(f_add(f_add(f_add(S(CL_ADD), S(CL_SUB)), f_add(S(CL_ECALL), S(CL_KECCAK))), f_add(S(CL_LW), S(CL_SW))), l[C_UC]);
-    const fe memw = f_add(f_add(S(CL_LW), S(CL_SW)), f_add(S(CL_LDS), S(CL_STS)));
     emit(s, f_mul(noff, osum));
     emit(s, bool_c(osum)); /* at most one of the three offset flags */
     emit(s, f_mul(S(CL_JALR), f_add(o2, o3)));
-    emit(s, f_mul(memw, f_sub(l[C_MADDR], xaddr)));
-    emit(s, f_mul(S(CL_ECALL), f_sub(l[C_MADDR], 11)));
   }
   /* ---- next pc ---- */
   {
@@ -1023,30 +1075,20 @@ static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, f
     emit(s, f_mul(f_add(S(CL_BEQ), S(CL_BLT)), f_sub(base, f_mul(a_lo, d))));
     emit(s, f_mul(f_add(S(CL_BNE), S(CL_BGE)), f_sub(base, f_mul(f_sub(one, a_lo), d))));
     emit(s, f_mul(S(CL_KECCAK), f_sub(np, f_add(b_lo, f_mul(F65536, b_hi)))));
-    /* ecall: the next instruction, except that HALT goes to the padding instruction */
-    emit(s, f_sub(f_mul(S(CL_ECALL), f_sub(np, pc4)), f_mul(l[C_SC + SC_HALT], f_sub(pub[CPUPUB_PAD_PC] % FP, pc4))));
+    /* (ecall: the ecall chip decides the next pc - the next instruction, or the padding instruction after HALT) */
   }
   /* ---- word loads and stores; what the memory slot leaves behind ---- */
   {
     emit(s, f_mul(S(CL_LW), f_sub(a_lo, m_lo)));
     emit(s, f_mul(S(CL_LW), f_sub(a_hi, m_hi)));
-    const fe keep = f_add(f_add(S(CL_LW), S(CL_LDS)), S(CL_ECALL));
+    const fe keep = f_add(S(CL_LW), S(CL_LDS));
     emit(s, f_mul(keep, f_sub(mv_lo, m_lo)));
     emit(s, f_mul(keep, f_sub(mv_hi, m_hi)));
     emit(s, f_mul(S(CL_SW), f_sub(mv_lo, c_lo)));
     emit(s, f_mul(S(CL_SW), f_sub(mv_hi, c_hi)));
   }
-  /* ---- ecall: t0 holds one of the six codes and is rewritten with itself, except by HINT_LEN ---- */
-  {
-    static const uint32_t codes[6] = {0x00, 0x02, 0x10, 0x1a, 0xf0, 0xf1};
-    fe code = 0;
-    for (int k = 0; k < 6; ++k) code = f_add(code, f_mul(codes[k], l[C_SC + k]));
-    emit(s, f_mul(S(CL_ECALL), f_sub(b_lo, code)));
-    emit(s, f_mul(S(CL_ECALL), b_hi));
-    const fe same = f_sub(S(CL_ECALL), l[C_SC + SC_HINT_LEN]);
-    emit(s, f_mul(same, f_sub(a_lo, b_lo)));
-    emit(s, f_mul(same, f_sub(a_hi, b_hi)));
-  }
+  /* ---- ecall: the code in t0 is a 16-bit value (decoded, and the value left behind checked, by the ecall chip) ---- */
+  emit(s, f_mul(S(CL_ECALL), b_hi));
   /* previous access times are older by construction: a slot's previous time IS its time - 1 - difference (a linear
    * form in the memory-bus tuples), the difference's low limb and high byte are looked up in the table chip */
 #undef S
@@ -1234,6 +1276,27 @@ static void sub_constraints(const uint32_t* l, sink* s) {
 #undef SF
 }
 
+static void ecall_constraints(const uint32_t* l, const uint32_t* pub, sink* s) {
+  static const uint32_t codes[6] = {0x00, 0x02, 0x10, 0x1a, 0xf0, 0xf1};
+  const fe real = l[EC_IS_REAL];
+  emit(s, bool_c(real));
+  fe scsum = 0, code = 0;
+  for (int k = 0; k < 6; ++k) {
+    emit(s, bool_c(l[EC_SC + k]));
+    scsum = f_add(scsum, l[EC_SC + k]);
+    code = f_add(code, f_mul(codes[k], l[EC_SC + k]));
+  }
+  emit(s, f_sub(scsum, real));
+  /* t0 holds one of the six codes and is rewritten with itself, except by HINT_LEN (whose answer the CPU row range-checks) */
+  emit(s, f_sub(l[EC_B_LO], code));
+  const fe same = f_sub(real, l[EC_SC + SC_HINT_LEN]);
+  emit(s, f_mul(same, f_sub(l[EC_A_LO], l[EC_B_LO])));
+  emit(s, f_mul(same, l[EC_A_HI]));
+  /* the next instruction, except that HALT goes to the padding instruction */
+  const fe pc4 = f_add(l[EC_PC], 4);
+  emit(s, f_sub(f_mul(real, f_sub(l[EC_NP], pc4)), f_mul(l[EC_SC + SC_HALT], f_sub(pub[CPUPUB_PAD_PC] % FP, pc4))));
+}
+
 static void run_constraints(int chip, const uint32_t* prep, const uint32_t* loc, const uint32_t* nxt, uint32_t is_first,
                             uint32_t is_last, uint32_t is_trans, const uint32_t* pub, sink* s) {
   static const uint32_t no_pub[CPUPUB_N] = {0, 0, 0, 0, 0};
@@ -1262,6 +1325,7 @@ static void run_constraints(int chip, const uint32_t* prep, const uint32_t* loc,
     case CH_ALU2: alu_constraints(loc, s); break;
     case CH_SUB:
     case CH_SUB2: sub_constraints(loc, s); break;
+    case CH_ECALL: ecall_constraints(loc, pub ? pub : no_pub, s); break;
   }
 }
 

@@ -11,7 +11,7 @@
  * (circuits/sp1-merkle-proof/src/main.rs:4-14, crypto-ops/src/lib.rs:8-23) ran to HALT(0) and
  * committed these public values.
  *
- * Format v8 (round 3).  The CPU row no longer carries its operands as bits: it holds 16-bit limbs,
+ * Format v9 (round 3).  The CPU row no longer carries its operands as bits: it holds 16-bit limbs,
  * adds / subtracts / compares (equality, unsigned order) / moves words itself, and sends xor / or /
  * and to a bitwise chip (bytes, looked up in a byte-operation table), shifts and signed less-than to
  * an ALU chip (bits) and every sub-word load or store to a sub-word chip, each with one row per such
@@ -39,7 +39,7 @@ extern "C" {
  * 391 400 cycles take 2^18 + 2^17 rows, not 2^19. */
 enum {
   CH_CPU = 0, CH_KECCAK, CH_KMEM, CH_MEMFINAL, CH_IMAGE, CH_PROGRAM, CH_MUL, CH_TABLE, CH_CPU2, CH_ALU, CH_ALU2, CH_SUB,
-  CH_SUB2, CH_BW, CH_BW2, CH_P2, N_CHIPS
+  CH_SUB2, CH_BW, CH_BW2, CH_P2, CH_ECALL, N_CHIPS
 };
 
 /* ---- opcodes: Program table column CODE, and the op element of the ALU / sub-word bus tuples ---- */
@@ -72,15 +72,23 @@ enum {
   C_X = C_MV + 2,              /* adder output: sum / difference / effective address; sltu, bltu, bgeu: B - C + 2^32 [B < C];
                                   beq, bne: the limb differences' inverses */
   C_K0 = C_X + 2, C_K1,        /* carries / borrows (K1 of an unsigned comparison: B < C); beq, bne: "limb equal" flags */
-  C_O1, C_O2, C_O3,            /* byte offset of the effective address 1, 2, 3: at most one is set (offset 0: none) */
-  C_MADDR,                     /* word address on the memory bus (ecall: 11, the register a1) */
-  C_SC,                        /* 6 syscall flags: HALT, WRITE, COMMIT, DEFER, HINT_LEN, HINT_READ */
-  C_W_PLO = C_SC + 6, C_W_PHI, /* previous value of rd */
+  C_O1, C_O2, C_O3,            /* byte offset of the effective address 1, 2, 3: at most one is set (offset 0: none); the word
+                                  address on the memory bus is the linear form X - offset */
+  C_W_PLO, C_W_PHI,            /* previous value of rd */
   C_GAP,                       /* 4 access-time differences (rs1, rs2, memory slot, rd): low 16 bits, high 8 bits each; the
                                   previous access time of a slot is its access time - 1 - difference, a linear form */
   CPU_WIDTH = C_GAP + 8
 };
+/* ---- ecall chip: one row per ecall.  The CPU row of an ecall only moves t0 (reads the code, writes the value left
+ *      behind) and hands (time, pc, next pc, code, new t0) over on the ECALL bus; this chip decodes the code into six
+ *      flags, reads a0 and a1 itself (memory bus, at the times the CPU row's idle slots would have), sends COMMIT /
+ *      COMMIT_DEFERRED words and HALT's exit code to the verifier's buses and decides the next pc ---- */
 enum { SC_HALT = 0, SC_WRITE, SC_COMMIT, SC_DEFER, SC_HINT_LEN, SC_HINT_READ };
+enum {
+  EC_IS_REAL = 0, EC_SC /* 6 flags */, EC_TS = EC_SC + 6, EC_PC, EC_NP, EC_B_LO /* t0: the code */, EC_A_LO, EC_A_HI /* t0 afterwards */,
+  EC_C_LO, EC_C_HI /* a0 */, EC_M_LO, EC_M_HI /* a1 */, EC_GAP /* a0, a1: access-time differences, low 16 bits and high 8 */,
+  ECALL_WIDTH = EC_GAP + 4
+};
 
 /* ---- keccak chip: p3-keccak-air's 2633 columns (zksp_oracle.h KA_*) + the call time ---- */
 #define KC_TS KA_WIDTH
@@ -137,7 +145,7 @@ enum { TB_M_R16 = 0, TB_M_AL, TB_M_TOP, TB_M_BY, TB_M_XOR, TB_M_OR, TB_M_AND, TA
 #define ADDR_HI_MAX 0x77FFu /* high limb of the largest address / jump target: values stay below 0x78000000 < p */
 
 /* ---- buses ---- */
-enum { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP, BUS_DIGEST };
+enum { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP, BUS_DIGEST, BUS_ECALL };
 
 /* A linear form over the row [preprocessed | main]: c0 + sum coef[i] * row[col[i]] (canonical words). */
 #define LF_MAX 40
@@ -184,7 +192,7 @@ typedef struct {
 
 /* The oracle's own event lists (cycle indices of the ALU-chip and sub-word-chip rows, in execution order) and the
  * last access time of x0 by a real cycle; the product's tracer emits the same lists and tests compare them. */
-size_t orc_machine_events(const orc_machine_input* in, int which /* 0 alu, 1 sub-word, 2 bitwise */, uint32_t* out /* may be NULL */);
+size_t orc_machine_events(const orc_machine_input* in, int which /* 0 alu, 1 sub-word, 2 bitwise, 3 ecall */, uint32_t* out /* may be NULL */);
 uint32_t orc_machine_x0_last(const orc_machine_input* in);
 
 /* log2 trace height of every chip for this input (minimum 5) */
@@ -217,7 +225,7 @@ typedef struct {
 /* the aggregation payload's public part: Merkle root of the leaves (2-to-1 Poseidon2 compressions) and the sponge hash
  * of the leaf list, which stands for the list in the transcript */
 void orc_machine_agg_public(const uint32_t* leaves, size_t n, uint32_t root[8], uint32_t list_digest[8]);
-#define ZKSP_VERSION_MACHINE 8u
+#define ZKSP_VERSION_MACHINE 9u
 /* vk: preprocessed commitment root + digest binding entry pc, table heights and keccak mode */
 void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t prep_root[8], uint32_t vk_digest[8]);
 size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_image, const orc_config* cfg, uint32_t pv_len);

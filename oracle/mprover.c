@@ -3,7 +3,7 @@
  * Whole machine proof on the CPU: the multi-table STARK that sp1-stark / sp1-prover 3.4.0 build over
  * p3-uni-stark, p3-fri, p3-merkle-tree (mixed-height MMCS) and p3-challenger (reference
  * Cargo.lock:7485, :7273, :5378, :5253, :5336, :5197) beneath `client.prove(&pk, stdin).run()`
- * (prover/src/bin/main.rs:71-74), restated under this repository's own format "ZKSP v8"
+ * (prover/src/bin/main.rs:71-74), restated under this repository's own format "ZKSP v9"
  * (DESIGN.md "Machine proof").  PARITY UNPINNED vs SP1 proof bytes.  The HIP prover must
  * reproduce these bytes exactly.
  *
@@ -420,6 +420,7 @@ void orc_machine_stage_quotient(const orc_machine_input* in, int chip, const uin
   challenge_powers(gamma4, beta4, &gamma, bpow);
   memcpy(alpha.c, alpha4, 16);
   if (chip == CH_CPU || chip == CH_CPU2) orc_machine_cpu_pub(in, chip, pub);
+  if (chip == CH_ECALL) orc_machine_cpu_pub(in, CH_CPU, pub); /* (the padding pc) */
   lde_round(&d, R_PREP);
   lde_round(&d, R_MAIN);
   d.tr[R_PERM] = (uint32_t*)calloc((size_t)d.w[R_PERM] * d.h, 4);
@@ -520,6 +521,7 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   memset(cpu_pub, 0, sizeof cpu_pub);
   orc_machine_cpu_pub(in, CH_CPU, cpu_pub[CH_CPU]);
   orc_machine_cpu_pub(in, CH_CPU2, cpu_pub[CH_CPU2]);
+  orc_machine_cpu_pub(in, CH_CPU, cpu_pub[CH_ECALL]); /* the ecall chip's constraints use the padding pc */
 
   /* ---- rounds 0 and 1: preprocessed and main traces ---- */
   init_chips(in, cd, 0);

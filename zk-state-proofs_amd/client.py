@@ -29,10 +29,10 @@ ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_ELF, ERR_EXECUTOR, ERR_GUEST_PANIC,
     ERR_UNSUPPORTED = range(1, 10)
 KECCAK_SOFTWARE, KECCAK_OBSERVE, KECCAK_REPLACE = 0, 1, 2
 PROOF_MACHINE, PROOF_KECCAK_CHIP = 1, 2
-# machine proof (format version 8): chips in proof order and the fixed header in front of the public values
-MACHINE_VERSION = 8
+# machine proof (format version 9): chips in proof order and the fixed header in front of the public values
+MACHINE_VERSION = 9
 MACHINE_CHIP_NAMES = ("cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "table", "cpu2", "alu", "alu2",
-                      "subword", "subword2", "bitwise", "bitwise2", "poseidon2")
+                      "subword", "subword2", "bitwise", "bitwise2", "poseidon2", "ecall")
 MACHINE_CHIPS = len(MACHINE_CHIP_NAMES)
 # magic, version, heights, exit code, pv length, three digests, the hand-over pc of the two CPU instances, the aggregation
 # payload's leaf count, root and leaf-list digest
@@ -457,7 +457,7 @@ class ProverClient:
 
     def machine_trace(self, pk: ProvingKey, stdin: SP1Stdin) -> dict:
         """Traced execution (``zksp_machine_trace``) as numpy arrays: ``cycles`` [n][12], ``keccak`` (structured:
-        ts, ptr, in[25], pts[50]), ``memfinal`` [n][5], ``muls`` [n][3], ``prog_mult``, ``alu_idx``, ``sub_idx``, ``bw_idx``,
+        ts, ptr, in[25], pts[50]), ``memfinal`` [n][5], ``muls`` [n][3], ``prog_mult``, ``alu_idx``, ``sub_idx``, ``bw_idx``, ``ecall_idx``,
         ``program`` [n][9] (last row: the padding instruction), ``image`` [n][2], ``public_values`` (bytes), ``info``
         (MTraceInfo)."""
         import numpy as np
@@ -477,7 +477,7 @@ class ProverClient:
             self._lib.zksp_mtrace_info(h, C.byref(info))
             return {"cycles": sec(0, np.uint32, 12), "keccak": sec(1, kdt), "memfinal": sec(2, np.uint32, 5),
                     "muls": sec(3, np.uint32, 3), "prog_mult": sec(4, np.uint32), "alu_idx": sec(5, np.uint32),
-                    "sub_idx": sec(9, np.uint32), "bw_idx": sec(10, np.uint32), "program": sec(6, np.uint32, 9), "image": sec(7, np.uint32, 2),
+                    "sub_idx": sec(9, np.uint32), "bw_idx": sec(10, np.uint32), "ecall_idx": sec(11, np.uint32), "program": sec(6, np.uint32, 9), "image": sec(7, np.uint32, 2),
                     "public_values": bytes(sec(8, np.uint8)), "info": info}
         finally:
             self._lib.zksp_mtrace_free(h)

@@ -26,7 +26,7 @@ namespace mach {
 
 // CPU, ALU and sub-word rows are each split over two instances of one AIR: the first has the largest power of two of
 // rows strictly below the count, the second the rest (a power of two again): 391 400 cycles take 2^18 + 2^17 rows.
-enum Chip { kCpu = 0, kKeccak, kKmem, kMemFinal, kImage, kProgram, kMul, kTable, kCpu2, kAlu, kAlu2, kSub, kSub2, kBw, kBw2, kP2, kNumChips };
+enum Chip { kCpu = 0, kKeccak, kKmem, kMemFinal, kImage, kProgram, kMul, kTable, kCpu2, kAlu, kAlu2, kSub, kSub2, kBw, kBw2, kP2, kEcall, kNumChips };
 // public scalars of a CPU instance: pc and time of its first row, whether another instance continues it, the pc
 // that one starts at (the hand-over pc: a proof-header word the transcript absorbs), the padding pc (verifying key)
 enum CpuPub { kPubStartPc = 0, kPubStartTs, kPubHasSucc, kPubEndPc, kPubPadPc, kNumCpuPub };
@@ -58,11 +58,12 @@ ZKSP_HD constexpr uint32_t code_of(uint32_t op) {
 }
 // sltu, bltu, bgeu: the unsigned comparison the CPU row does itself (Program column UC)
 ZKSP_HD constexpr bool ucmp_of(uint32_t op) { return op == SLTU || op == BLTU || op == BGEU; }
-// does a cycle of this op occupy a row of the ALU chip (0) / the sub-word chip (1) / the bitwise chip (2)?  (-1: none)
+// does a cycle of this op occupy a row of the ALU chip (0) / the sub-word chip (1) / the bitwise chip (2) / the ecall
+// chip (3)?  (-1: none)
 ZKSP_HD constexpr int event_kind(uint32_t op) {
   return (code_of(op) >= SLL && code_of(op) <= SLT) ? 0
        : (op == LB || op == LH || op == LBU || op == LHU || op == SB || op == SH) ? 1
-       : (op >= XOR && op <= AND) ? 2 : -1;
+       : (op >= XOR && op <= AND) ? 2 : op == ECALL ? 3 : -1;
 }
 
 // ---- CPU chip ----
@@ -71,10 +72,14 @@ constexpr int C_PC = 0, C_TS = 1, C_NEXT_PC = 2, C_SEL = 3, C_CODE = C_SEL + kNu
               C_IMM_HI = C_CODE + 8, C_TGT_LO = C_CODE + 9, C_TGT_HI = C_CODE + 10, C_A = C_CODE + 11, C_B = C_A + 2, C_C = C_B + 2,
               C_M = C_C + 2,
               C_MV = C_M + 2, C_X = C_MV + 2, C_K0 = C_X + 2, C_K1 = C_K0 + 1, C_O1 = C_K0 + 2, C_O2 = C_O1 + 1, C_O3 = C_O1 + 2,
-              C_MADDR = C_O1 + 3, C_SC = C_MADDR + 1, C_W_PLO = C_SC + 6, C_W_PHI = C_W_PLO + 1, C_GAP = C_W_PLO + 2,
-              kCpuWidth = C_GAP + 8;
+              C_W_PLO = C_O1 + 3, C_W_PHI = C_W_PLO + 1, C_GAP = C_W_PLO + 2, kCpuWidth = C_GAP + 8;
+static_assert(kCpuWidth == 56, "CPU chip layout: seven Poseidon2 absorptions per row");
+// ---- ecall chip: one row per ecall (the CPU row of an ecall moves t0 only and hands the rest over on the ECALL bus) ----
 enum { SC_HALT = 0, SC_WRITE, SC_COMMIT, SC_DEFER, SC_HINT_LEN, SC_HINT_READ };
-static_assert(kCpuWidth == 63, "CPU chip layout");
+constexpr int EC_IS_REAL = 0, EC_SC = 1, EC_TS = EC_SC + 6, EC_PC = EC_TS + 1, EC_NP = EC_TS + 2, EC_B_LO = EC_TS + 3, EC_A_LO = EC_TS + 4,
+              EC_A_HI = EC_TS + 5, EC_C_LO = EC_TS + 6, EC_C_HI = EC_TS + 7, EC_M_LO = EC_TS + 8, EC_M_HI = EC_TS + 9, EC_GAP = EC_TS + 10,
+              kEcallWidth = EC_GAP + 4;
+static_assert(kEcallWidth == 21, "ecall chip layout");
 ZKSP_HD constexpr int selc(int cls) { return C_SEL + cls - 1; }
 
 // ---- keccak chip: p3-keccak-air's columns + the call time ----
@@ -117,7 +122,7 @@ constexpr int TB_P_X = 0, TB_P_Y = 1, TB_P_NA = 2, TB_P_NT = 3, TB_P_XOR = 4, TB
               TB_M_AL = 1, TB_M_TOP = 2, TB_M_BY = 3, TB_M_XOR = 4, TB_M_OR = 5, TB_M_AND = 6, kTableWidth = 7, kTableLogH = 16;
 constexpr uint32_t kAddrHiMax = 0x77FFu;  // high limb of the largest address / jump target
 
-enum Bus { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP, BUS_DIGEST };
+enum Bus { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP, BUS_DIGEST, BUS_ECALL };
 
 // Ctx interface:
 //   using F;  F local(int col); F next(int col); F prep(int col) (preprocessed column of the row);
@@ -161,14 +166,14 @@ ZKSP_HD constexpr uint32_t inv_pow2_mod(int n) {  // 2^-n mod p
 
 #define L(c) ctx.local(c)
 
-// ---- CPU chip: 82 constraints, emitted in order ----
+// ---- CPU chip: 69 constraints, emitted in order ----
 template <class Ctx>
 ZKSP_HD void eval_cpu(Ctx& ctx) {
   using F = typename Ctx::F;
   const F one = ctx.k(kR1), zero = one - one;
   const F k65536 = ZKSP_K(65536);
 #define S(cls) ctx.local(selc(cls))
-  // booleans: class selectors, carries, byte offset, syscall flags (WR, USE2 are Program-table values)
+  // booleans: class selectors, carries, byte offset (WR, USE2 are Program-table values)
   F selsum = zero;
 #pragma unroll
   for (int k = 0; k < kNumCls; ++k) {
@@ -181,17 +186,9 @@ ZKSP_HD void eval_cpu(Ctx& ctx) {
   ctx.emit(bool_c(k1, one));
   const F o1 = L(C_O1), o2 = L(C_O2), o3 = L(C_O3), osum = o1 + o2 + o3;
   ctx.emit(bool_c(o1, one)); ctx.emit(bool_c(o2, one)); ctx.emit(bool_c(o3, one));
-  F scsum = zero;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const F v = L(C_SC + i);
-    ctx.emit(bool_c(v, one));
-    scsum = scsum + v;
-  }
   // row structure: exactly one class; the clock; the chain of pcs; the instance's first and last rows
   const F pc = L(C_PC), ts = L(C_TS), np = L(C_NEXT_PC), pad_pc = ctx.pub(kPubPadPc);
   ctx.emit(selsum - one);
-  ctx.emit(scsum - S(CL_ECALL));
   ctx.emit(ctx.is_first() * (pc - ctx.pub(kPubStartPc)));
   ctx.emit(ctx.is_first() * (ts - ctx.pub(kPubStartTs)));
   ctx.emit(ctx.is_trans() * (ctx.next(C_TS) - ts - ZKSP_K(4)));
@@ -239,12 +236,9 @@ ZKSP_HD void eval_cpu(Ctx& ctx) {
   const F xaddr = x_lo + k65536 * x_hi - off;
   {
     const F noff = S(CL_ADD) + S(CL_SUB) + S(CL_ECALL) + S(CL_KECCAK) + S(CL_LW) + S(CL_SW) + L(C_UC);
-    const F memw = S(CL_LW) + S(CL_SW) + S(CL_LDS) + S(CL_STS);
     ctx.emit(noff * osum);
     ctx.emit(bool_c(osum, one));  // at most one of the three offset flags
     ctx.emit(S(CL_JALR) * (o2 + o3));
-    ctx.emit(memw * (L(C_MADDR) - xaddr));
-    ctx.emit(S(CL_ECALL) * (L(C_MADDR) - ZKSP_K(11)));
   }
   // next pc
   {
@@ -270,34 +264,51 @@ ZKSP_HD void eval_cpu(Ctx& ctx) {
     ctx.emit((S(CL_BEQ) + S(CL_BLT)) * (base - a_lo * d));
     ctx.emit((S(CL_BNE) + S(CL_BGE)) * (base - (one - a_lo) * d));
     ctx.emit(S(CL_KECCAK) * (np - (b_lo + k65536 * b_hi)));
-    // ecall: the next instruction, except that HALT goes to the padding instruction
-    ctx.emit(S(CL_ECALL) * (np - pc4) - L(C_SC + SC_HALT) * (pad_pc - pc4));
+    // (ecall: the ecall chip decides the next pc - the next instruction, or the padding instruction after HALT)
   }
   // word loads and stores; what the memory slot leaves behind
   {
     ctx.emit(S(CL_LW) * (a_lo - m_lo));
     ctx.emit(S(CL_LW) * (a_hi - m_hi));
-    const F keep = S(CL_LW) + S(CL_LDS) + S(CL_ECALL);
+    const F keep = S(CL_LW) + S(CL_LDS);
     ctx.emit(keep * (mv_lo - m_lo));
     ctx.emit(keep * (mv_hi - m_hi));
     ctx.emit(S(CL_SW) * (mv_lo - c_lo));
     ctx.emit(S(CL_SW) * (mv_hi - c_hi));
   }
-  // ecall: t0 holds one of the six codes and is rewritten with itself, except by HINT_LEN
-  {
-    const F code = ZKSP_K(0x02) * L(C_SC + SC_WRITE) + ZKSP_K(0x10) * L(C_SC + SC_COMMIT) + ZKSP_K(0x1a) * L(C_SC + SC_DEFER) +
-                   ZKSP_K(0xf0) * L(C_SC + SC_HINT_LEN) + ZKSP_K(0xf1) * L(C_SC + SC_HINT_READ);
-    ctx.emit(S(CL_ECALL) * (b_lo - code));
-    ctx.emit(S(CL_ECALL) * b_hi);
-    const F same = S(CL_ECALL) - L(C_SC + SC_HINT_LEN);
-    ctx.emit(same * (a_lo - b_lo));
-    ctx.emit(same * (a_hi - b_hi));
-  }
+  // ecall: the code in t0 is a 16-bit value (decoded, and the value left behind checked, by the ecall chip)
+  ctx.emit(S(CL_ECALL) * b_hi);
   // previous access times are older by construction: a slot's previous time IS its time - 1 - difference (a linear form in
   // the memory-bus tuples), and the difference's low limb and high byte are looked up in the table chip
 #undef S
 }
-constexpr int kCpuConstraints = 82;
+constexpr int kCpuConstraints = 69;
+
+// ---- ecall chip: the code in t0 decoded into six flags; t0 rewritten with itself except by HINT_LEN (whose answer the CPU
+// row range-checks); the next pc: the next instruction, or the padding instruction after HALT ----
+template <class Ctx>
+ZKSP_HD void eval_ecall(Ctx& ctx) {
+  using F = typename Ctx::F;
+  const F one = ctx.k(kR1), zero = one - one, real = L(EC_IS_REAL);
+  ctx.emit(bool_c(real, one));
+  F scsum = zero;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const F v = L(EC_SC + k);
+    ctx.emit(bool_c(v, one));
+    scsum = scsum + v;
+  }
+  const F code = ZKSP_K(0x02) * L(EC_SC + SC_WRITE) + ZKSP_K(0x10) * L(EC_SC + SC_COMMIT) + ZKSP_K(0x1a) * L(EC_SC + SC_DEFER) +
+                 ZKSP_K(0xf0) * L(EC_SC + SC_HINT_LEN) + ZKSP_K(0xf1) * L(EC_SC + SC_HINT_READ);
+  ctx.emit(scsum - real);
+  ctx.emit(L(EC_B_LO) - code);
+  const F same = real - L(EC_SC + SC_HINT_LEN);
+  ctx.emit(same * (L(EC_A_LO) - L(EC_B_LO)));
+  ctx.emit(same * L(EC_A_HI));
+  const F pc4 = L(EC_PC) + ZKSP_K(4);
+  ctx.emit(real * (L(EC_NP) - pc4) - L(EC_SC + SC_HALT) * (ctx.pub(kPubPadPc) - pc4));
+}
+constexpr int kEcallConstraints = 12;
 
 template <class Ctx>
 ZKSP_HD void eval_kmem(Ctx& ctx) {
@@ -656,7 +667,7 @@ constexpr int kKeccakConstraints = ka::kNumConstraints + 1;
 ZKSP_HD constexpr int num_constraints(int chip) {
   return is_cpu_chip(chip) ? kCpuConstraints : chip == kKeccak ? kKeccakConstraints : chip == kKmem ? kKmemConstraints
        : chip == kMemFinal ? kMemFinalConstraints : chip == kImage ? 1 : chip == kProgram ? 0 : chip == kMul ? kMulConstraints
-       : chip == kTable ? 2 : is_alu_chip(chip) ? kAluConstraints : is_sub_chip(chip) ? kSubConstraints : is_bw_chip(chip) ? kBwConstraints : chip == kP2 ? kP2Constraints : 0;
+       : chip == kTable ? 2 : is_alu_chip(chip) ? kAluConstraints : is_sub_chip(chip) ? kSubConstraints : is_bw_chip(chip) ? kBwConstraints : chip == kP2 ? kP2Constraints : chip == kEcall ? kEcallConstraints : 0;
 }
 
 }  // namespace mach

@@ -80,11 +80,13 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
     return;
   }
   const uint32_t* cy = rec.cycles + ((size_t)b * rec.cap_cycles + cyc) * 12;
-  const uint32_t pc = cy[0], bb = cy[2], c = cy[3], m = cy[4], mv = cy[5], wprev = cy[6];
-  uint32_t a = cy[1];
+  const uint32_t pc = cy[0], bb = cy[2], wprev = cy[6];
+  uint32_t a = cy[1], c = cy[3], m = cy[4], mv = cy[5];
   const uint32_t* p = rec.program + 9 * (size_t)((pc - rec.text_base) >> 2);
-  const uint32_t op = p[1], wr = p[2], use2 = p[3], rd = p[4], rs1 = p[5], rs2 = p[6], imm = p[7], tgt = p[8];
+  const uint32_t op = p[1], wr = p[2], rd = p[4], rs1 = p[5], imm = p[7], tgt = p[8];
+  uint32_t use2 = p[3], rs2 = p[6];
   const int cls = class_of(op);
+  if (cls == CL_ECALL) { use2 = 0; rs2 = 0; c = 0; m = 0; mv = 0; }  // a0 and a1 are read by the ecall chip
   const uint32_t code = code_of(op);
   o.val(C_PC, pc);
   o.val(C_TS, ts);
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
   o.val(C_RD, rd); o.val(C_RS1, rs1); o.val(C_RS2, rs2);
   o.limbs(C_IMM_LO, imm);
   o.limbs(C_TGT_LO, tgt);
-  uint32_t x = 0, next = pc + 4, k0 = 0, k1 = 0, maddr = 0, off = 4, sc = 6;
+  uint32_t x = 0, next = pc + 4, k0 = 0, k1 = 0, off = 4;
   uint32_t x_lo_m = 0, x_hi_m = 0;  // beq / bne: the two limbs of X are inverses (Montgomery words)
   const uint32_t blo = bb & 0xffff, bhi = bb >> 16, clo = c & 0xffff, chi = c >> 16;
   switch (cls) {
@@ -107,11 +109,11 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
     case CL_JALR: case CL_LW: case CL_LDS:
       x = bb + c; k0 = (blo + clo) >> 16; k1 = (bhi + chi + k0) >> 16;
       if (cls == CL_JALR) { off = x & 1; next = x & ~1u; }
-      else { off = x & 3; maddr = x & ~3u; }
+      else off = x & 3;
       break;
     case CL_SW: case CL_STS:
       x = bb + imm; k0 = (blo + (imm & 0xffff)) >> 16; k1 = (bhi + (imm >> 16) + k0) >> 16;
-      off = x & 3; maddr = x & ~3u;
+      off = x & 3;
       break;
     case CL_BEQ: case CL_BNE:
       k0 = blo == clo; k1 = bhi == chi;
@@ -125,8 +127,7 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
       if ((cls == CL_BLT) == (a != 0)) next = tgt;
       break;
     case CL_ECALL:
-      sc = bb == 0x00 ? 0 : bb == 0x02 ? 1 : bb == 0x10 ? 2 : bb == 0x1a ? 3 : bb == 0xf0 ? 4 : bb == 0xf1 ? 5 : 6;
-      x = a; maddr = 11;
+      x = a;
       if (bb == 0x00) next = pad_pc;
       break;
     case CL_KECCAK: x = bb; next = bb; break;
@@ -142,10 +143,8 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
   o.limbs(C_A, a); o.limbs(C_B, bb); o.limbs(C_C, c); o.limbs(C_M, m); o.limbs(C_MV, mv);
   o.flag(C_K0, k0 != 0); o.flag(C_K1, k1 != 0);
   for (uint32_t i = 1; i < 4; ++i) o.flag(C_O1 + i - 1, i == off);
-  o.val(C_MADDR, maddr);
-  for (uint32_t i = 0; i < 6; ++i) o.flag(C_SC + i, i == sc);
   o.val(C_NEXT_PC, next);
-  const bool memq = cls == CL_LW || cls == CL_SW || cls == CL_LDS || cls == CL_STS || cls == CL_ECALL;
+  const bool memq = cls == CL_LW || cls == CL_SW || cls == CL_LDS || cls == CL_STS;
   gap[0] = ts - cy[7] - 1;
   if (use2) gap[1] = ts - cy[8];
   if (memq) gap[2] = ts + 1 - cy[9];
@@ -153,6 +152,32 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
   o.val(C_W_PLO, wr ? wprev & 0xffff : 0u);
   o.val(C_W_PHI, wr ? wprev >> 16 : 0u);
   for (int q = 0; q < 4; ++q) o.limbs(C_GAP + 2 * q, gap[q]);
+}
+
+// The ecall chip: row r is the r-th ecall of the run
+__global__ __launch_bounds__(kMT) void ecall_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh) {
+  const size_t h = (size_t)1 << logh;
+  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (r >= h) return;
+  const int b = blockIdx.y;
+  const Col o{trace + (size_t)b * kEcallWidth * h + r, h};
+  if (r >= rec.counts[kCountWords * b + 9]) { o.zero(0, kEcallWidth); return; }
+  const uint32_t cyc = rec.ecall_idx[(size_t)b * rec.cap_ecall + r], ts = 4 * (cyc + 1);
+  const uint32_t* cy = rec.cycles + ((size_t)b * rec.cap_cycles + cyc) * 12;
+  const uint32_t pc = cy[0], a = cy[1], bb = cy[2], c = cy[3], m = cy[4];
+  const uint32_t pad_pc = rec.text_base + 4 * (rec.n_program - 1);
+  const uint32_t sc = bb == 0x00 ? 0 : bb == 0x02 ? 1 : bb == 0x10 ? 2 : bb == 0x1a ? 3 : bb == 0xf0 ? 4 : bb == 0xf1 ? 5 : 6;
+  o.put(EC_IS_REAL, kR1);
+  for (uint32_t i = 0; i < 6; ++i) o.flag(EC_SC + i, i == sc);
+  o.val(EC_TS, ts);
+  o.val(EC_PC, pc);
+  o.val(EC_NP, bb == 0x00 ? pad_pc : pc + 4);
+  o.val(EC_B_LO, bb & 0xffff);
+  o.limbs(EC_A_LO, a);
+  o.limbs(EC_C_LO, c);
+  o.limbs(EC_M_LO, m);
+  o.limbs(EC_GAP, ts - cy[8]);
+  o.limbs(EC_GAP + 2, ts + 1 - cy[9]);
 }
 
 // One ALU-chip instance: row r is event row0 + r of the list alu_idx (cycle indices)
@@ -437,6 +462,7 @@ void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& re
     case kP2:
       hipLaunchKernelGGL(p2_trace_kernel, dim3((unsigned)((h + 63) / 64), batch), dim3(64), 0, stream, rec, trace, logh);
       break;
+    case kEcall: hipLaunchKernelGGL(ecall_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
     case kMemFinal: hipLaunchKernelGGL(memfinal_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
     case kMul:
       hipLaunchKernelGGL(mul_trace_kernel, dim3((unsigned)((h + 63) / 64), batch), dim3(64), 0, stream, rec, trace, logh);
@@ -723,11 +749,11 @@ void launch_table_trace(hipStream_t stream, const MachineRecords& rec, uint32_t*
   hipLaunchKernelGGL(count_column_kernel, dim3((unsigned)((n + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec.table_hist, trace, n);
 }
 
-// The CPU chip's 22 bus interactions evaluated from values a row holds once (the class id, the selector sums, the word
+// The CPU chip's 21 bus interactions evaluated from values a row holds once (the class id, the selector sums, the word
 // address, the four previous access times), instead of through the generic linear forms (which reload and rescale every
 // column for every tuple): the same field elements, a fraction of the work.  visit(j, ma, fa, mb, fb) is called for the
 // LogUp slots j = 0..9 in order (machine_defs.hpp "LogUp layout") with the slot's value ma / fa + mb / fb: slots 0..7 are
-// pairs, slot 8 the last single receive (mb = 0, fb = 1), slot 9 the five merged sends, M / F with M = sum m_k and
+// pairs, slot 8 the last single receive (mb = 0, fb = 1), slot 9 the four merged sends, M / F with M = sum m_k and
 // F = sum m_k f_k + 1 - M.  Multiplicities are signed.  Must restate machine_defs.cpp's g_cpu[] exactly: the whole-proof
 // parity tests compare against the oracle's generic evaluation.
 // J0, J1: only the slots J0 <= j < J1 are visited (the loads the others need are dead code): the kernels below
@@ -752,7 +778,7 @@ __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, 
     sel[k] = col(selc(k));
     clsid = clsid + kf * sel[k];
   }
-  const Fp memw = sel[CL_LW] + sel[CL_SW] + sel[CL_LDS] + sel[CL_STS], memq = memw + sel[CL_ECALL];
+  const Fp memw = sel[CL_LW] + sel[CL_SW] + sel[CL_LDS] + sel[CL_STS], memq = memw;
   const Fp al = memw + sel[CL_JALR], top = al + sel[CL_KECCAK];
   const Fp uc = col(C_UC);
   const Fp chk = top + sel[CL_ADD] + sel[CL_SUB] + sel[CL_ECALL] + uc;
@@ -783,7 +809,7 @@ __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, 
   }
   if (J0 <= 1 && 1 < J1) visit(1, one, mem(rs1, b_lo, b_hi, ts), -use2, mem(rs2, c_lo, c_hi, pts(1)));
   if (J0 <= 3 && 2 < J1) {
-    const Fp maddr = col(C_MADDR);
+    const Fp maddr = x_lo + k65536 * x_hi - off;  // the word address: the adder output less the byte offset
     visit(2, use2, mem(rs2, c_lo, c_hi, ts + one), -memq, mem(maddr, m_lo, m_hi, pts(2)));
     visit(3, memq, mem(maddr, mv_lo, mv_hi, ts + two), -wr, mem(rd, col(C_W_PLO), col(C_W_PHI), pts(3)));
   }
@@ -795,7 +821,7 @@ __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, 
   if (J0 <= 7 && 7 < J1) visit(7, -one, gbyt + b1 * g[5] + b2 * g[7], -chk, grng + b1 * top.dbl() + b2 * x_hi);
   if (J0 <= 8 && 8 < J1) visit(8, -chk, grng + b1 * al + b2 * (x_lo - off), Fp::zero(), Fp4::one());
   if (J0 <= 9 && 9 < J1) {
-    // one instruction class each: ALU-chip sends, sub-word sends, the keccak call, COMMIT / COMMIT_DEFERRED, HALT
+    // one instruction class each: ALU-chip sends, sub-word sends, the keccak call, the ecall hand-over
     const Fp4 falu = busc(BUS_ALU) + b1 * code + b2 * a_lo + b3 * a_hi + b4 * b_lo + m_load_fp4(bpow + 20) * b_hi +
                      m_load_fp4(bpow + 24) * c_lo + m_load_fp4(bpow + 28) * c_hi;
     Fp4 f = falu * alu;
@@ -803,11 +829,11 @@ __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, 
                      m_load_fp4(bpow + 24) * m_hi + m_load_fp4(bpow + 28) * c_lo + m_load_fp4(bpow + 32) * mv_lo +
                      m_load_fp4(bpow + 36) * mv_hi;
     f += fsub * sub;
-    const Fp kec = sel[CL_KECCAK], scc = col(C_SC + SC_COMMIT), scd = col(C_SC + SC_DEFER), halt = col(C_SC + SC_HALT);
+    const Fp kec = sel[CL_KECCAK], ecl = sel[CL_ECALL];
     f += (busc(BUS_KCALL) + b1 * ts + b2 * c_lo + b3 * c_hi) * kec;
-    f += (busc(BUS_PUBC) + b1 * (scc + scd.dbl()) + b2 * c_lo + b3 * m_lo + b4 * m_hi) * (scc + scd);
-    f += (busc(BUS_PUBH) + b1 * c_lo + b2 * c_hi) * halt;
-    const Fp msum = alu + sub + kec + scc + scd + halt;
+    f += (busc(BUS_ECALL) + b1 * ts + b2 * col(C_PC) + b3 * col(C_NEXT_PC) + b4 * b_lo + m_load_fp4(bpow + 20) * a_lo +
+          m_load_fp4(bpow + 24) * a_hi) * ecl;
+    const Fp msum = alu + sub + kec + ecl;
     f.c[0] += one - msum;
     visit(9, msum, f, Fp::zero(), Fp4::one());
   }
@@ -1221,6 +1247,7 @@ __global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
   else if constexpr (is_sub_chip(CHIP)) eval_sub(ctx);
   else if constexpr (is_bw_chip(CHIP)) eval_bw(ctx);
   else if constexpr (CHIP == kP2) eval_p2(ctx);
+  else if constexpr (CHIP == kEcall) eval_ecall(ctx);
   ctx.flush();
   logup_constraints(a, pi, &ctx.acc);
   const Fp4 q = ctx.acc * Fp::raw(pi.c ? a.zh_inv[1] : a.zh_inv[0]);
@@ -1349,6 +1376,7 @@ void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a) {
     case kBw:
     case kBw2: hipLaunchKernelGGL(machine_quotient_kernel<kBw>, grid, block, 0, stream, a); break;
     case kP2: hipLaunchKernelGGL(machine_quotient_kernel<kP2>, grid, block, 0, stream, a); break;
+    case kEcall: hipLaunchKernelGGL(machine_quotient_kernel<kEcall>, grid, block, 0, stream, a); break;
     case kKmem: hipLaunchKernelGGL(machine_quotient_kernel<kKmem>, grid, block, 0, stream, a); break;
     case kMemFinal: hipLaunchKernelGGL(machine_quotient_kernel<kMemFinal>, grid, block, 0, stream, a); break;
     case kImage: hipLaunchKernelGGL(machine_quotient_kernel<kImage>, grid, block, 0, stream, a); break;

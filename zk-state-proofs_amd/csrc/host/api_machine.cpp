@@ -11,7 +11,7 @@
 
 using namespace zksp;
 
-// Header (version, chip heights, exit code, digests, key digest), public values, body: the v8 proof object.
+// Header (version, chip heights, exit code, digests, key digest), public values, body: the v9 proof object.
 int machine_proof_from_parts(const zksp_pk* pk, const ExecutionRecord& r, const int* lh, uint32_t handover_pc,
                              const std::vector<uint32_t>& agg_leaves, const uint32_t* body, size_t body_words, zksp_proof** out) {
   zksp_proof* p = new (std::nothrow) zksp_proof();
@@ -92,6 +92,7 @@ int zksp_mtrace_section(const zksp_mtrace* t, int which, const void** ptr, size_
     case ZKSP_MT_ALU_IDX: *ptr = m.alu_idx.data(); *bytes = m.alu_idx.size() * 4; break;
     case ZKSP_MT_SUB_IDX: *ptr = m.sub_idx.data(); *bytes = m.sub_idx.size() * 4; break;
     case ZKSP_MT_BW_IDX: *ptr = m.bw_idx.data(); *bytes = m.bw_idx.size() * 4; break;
+    case ZKSP_MT_ECALL_IDX: *ptr = m.ecall_idx.data(); *bytes = m.ecall_idx.size() * 4; break;
     case ZKSP_MT_PROGRAM: *ptr = t->prog->rows.data(); *bytes = t->prog->rows.size() * sizeof(ProgramRow); break;
     case ZKSP_MT_IMAGE: *ptr = t->prog->image.data(); *bytes = t->prog->image.size() * sizeof(ImageRow); break;
     case ZKSP_MT_PUBLIC_VALUES: *ptr = m.rec.public_values.data(); *bytes = m.rec.public_values.size(); break;

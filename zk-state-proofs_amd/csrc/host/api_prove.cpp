@@ -166,6 +166,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       lh[mach::kSub] = clog2(t.sub_idx.size()); lh[mach::kSub2] = 0;
       lh[mach::kBw] = clog2(t.bw_idx.size()); lh[mach::kBw2] = 0;
       lh[mach::kP2] = clog2(t.agg_leaves.size() / 8 + 1);
+      lh[mach::kEcall] = clog2(t.ecall_idx.size());
       groups[lh].push_back(i);
       covers[lh].cover(t);
     }

@@ -339,6 +339,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
           c.m = a1; c.mv = a1;
           c.m_pts = reg_ts[11]; reg_ts[11] = ts + 2;
           rec.syscall_counts[codeid & 0xff]++;
+          out->ecall_idx.push_back((uint32_t)(cycles - 1));
           res = a;  // t0 is rewritten with itself except by HINT_LEN
           switch (codeid) {
             case 0x00: rec.exit_code = a0; rec.halted = true; halt = true; break;

@@ -1,4 +1,4 @@
-// See machine_defs.hpp.  Bus protocol (DESIGN.md "Machine proof", format v8):
+// See machine_defs.hpp.  Bus protocol (DESIGN.md "Machine proof", format v9):
 //   MEM    (addr, lo, hi, time)   every access consumes its predecessor's tuple and produces its own
 //   PROG   (pc, class, code, uc, wr, use2, rd, rs1, rs2, imm_lo, imm_hi, tgt_lo, tgt_hi)   instruction fetch, every CPU row
 //   KCALL  (time, ptr_lo, ptr_hi)   CPU -> keccak-memory: one precompile call
@@ -88,8 +88,8 @@ Interaction bytes_inter(int sign, const LinForm& mult, const LinForm& x, const L
   return it;
 }
 
-constexpr int kCpuInter = 22;
-Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7], g_alu[1], g_sub[5], g_bw[5], g_p2[3];
+constexpr int kCpuInter = 21;
+Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7], g_alu[1], g_sub[5], g_bw[5], g_p2[3], g_ecall[10];
 ChipDef g_chips[kNumChips];
 
 void build() {
@@ -119,9 +119,12 @@ void build() {
   g_cpu[3] = mem_inter(-1, lf_col(C_USE2), lf_col(C_RS2), c_lo, c_hi, pts[1]);
   g_cpu[4] = mem_inter(+1, lf_col(C_USE2), lf_col(C_RS2), c_lo, c_hi, lf_plus(ts, 1));
   {
-    const LinForm memq = lf_sum({selc(CL_LW), selc(CL_SW), selc(CL_LDS), selc(CL_STS), selc(CL_ECALL)});
-    g_cpu[5] = mem_inter(-1, memq, lf_col(C_MADDR), m_lo, m_hi, pts[2]);
-    g_cpu[6] = mem_inter(+1, memq, lf_col(C_MADDR), lf_col(C_MV), lf_col(C_MV + 1), lf_plus(ts, 2));
+    // the word address is the adder output less the byte offset: a linear form (below 0x78000000: X's lookups)
+    const LinForm memq = lf_sum({selc(CL_LW), selc(CL_SW), selc(CL_LDS), selc(CL_STS)});
+    LinForm maddr = lf_pair(C_X, C_X + 1, 65536);
+    lf_add(maddr, C_O1, kP - 1); lf_add(maddr, C_O2, kP - 2); lf_add(maddr, C_O3, kP - 3);
+    g_cpu[5] = mem_inter(-1, memq, maddr, m_lo, m_hi, pts[2]);
+    g_cpu[6] = mem_inter(+1, memq, maddr, lf_col(C_MV), lf_col(C_MV + 1), lf_plus(ts, 2));
   }
   g_cpu[7] = mem_inter(-1, lf_col(C_WR), lf_col(C_RD), lf_col(C_W_PLO), lf_col(C_W_PHI), pts[3]);
   g_cpu[8] = mem_inter(+1, lf_col(C_WR), lf_col(C_RD), a_lo, a_hi, lf_plus(ts, 3));
@@ -160,16 +163,45 @@ void build() {
     kc = Interaction{};
     kc.bus = BUS_KCALL; kc.sign = +1; kc.mult = lf_col(selc(CL_KECCAK)); kc.n_el = 3;
     kc.el[0] = ts; kc.el[1] = c_lo; kc.el[2] = c_hi;
-    Interaction& pc = g_cpu[20];
+    // an ecall: the ecall chip takes it from here (time, pc, next pc, the code in t0, the value left in t0)
+    Interaction& ec = g_cpu[20];
+    ec = Interaction{};
+    ec.bus = BUS_ECALL; ec.sign = +1; ec.mult = lf_col(selc(CL_ECALL)); ec.n_el = 6;
+    ec.el[0] = ts; ec.el[1] = lf_col(C_PC); ec.el[2] = lf_col(C_NEXT_PC); ec.el[3] = b_lo; ec.el[4] = a_lo; ec.el[5] = a_hi;
+  }
+  {
+    // ecall chip: receives the CPU row's hand-over, reads a0 (at ts + 1) and a1 (at ts + 2) itself, sends the COMMIT /
+    // COMMIT_DEFERRED words and HALT's exit code to the buses the verifier closes
+    const LinForm real = lf_col(EC_IS_REAL), ets = lf_col(EC_TS);
+    const LinForm ec_lo = lf_col(EC_C_LO), ec_hi = lf_col(EC_C_HI), em_lo = lf_col(EC_M_LO), em_hi = lf_col(EC_M_HI);
+    Interaction& rc = g_ecall[0];
+    rc = Interaction{};
+    rc.bus = BUS_ECALL; rc.sign = -1; rc.mult = real; rc.n_el = 6;
+    rc.el[0] = ets; rc.el[1] = lf_col(EC_PC); rc.el[2] = lf_col(EC_NP); rc.el[3] = lf_col(EC_B_LO);
+    rc.el[4] = lf_col(EC_A_LO); rc.el[5] = lf_col(EC_A_HI);
+    LinForm epts[2];
+    for (int q = 0; q < 2; ++q) {
+      epts[q] = lf_zero();
+      lf_add(epts[q], EC_TS, 1); lf_add(epts[q], EC_GAP + 2 * q, kP - 1); lf_add(epts[q], EC_GAP + 2 * q + 1, kP - 65536);
+      epts[q].c0 = mont((uint64_t)q);
+    }
+    g_ecall[1] = mem_inter(-1, real, lf_const(10), ec_lo, ec_hi, epts[0]);
+    g_ecall[2] = mem_inter(+1, real, lf_const(10), ec_lo, ec_hi, lf_plus(ets, 1));
+    g_ecall[3] = mem_inter(-1, real, lf_const(11), em_lo, em_hi, epts[1]);
+    g_ecall[4] = mem_inter(+1, real, lf_const(11), em_lo, em_hi, lf_plus(ets, 2));
+    g_ecall[5] = range_inter(-1, real, lf_const(0), lf_col(EC_GAP));
+    g_ecall[6] = range_inter(-1, real, lf_const(0), lf_col(EC_GAP + 2));
+    g_ecall[7] = bytes_inter(-1, real, lf_col(EC_GAP + 1), lf_col(EC_GAP + 3));
+    Interaction& pc = g_ecall[8];
     pc = Interaction{};
     pc.bus = BUS_PUBC; pc.sign = +1; pc.n_el = 4;
-    pc.mult = lf_pair(C_SC + SC_COMMIT, C_SC + SC_DEFER, 1);
-    pc.el[0] = lf_pair(C_SC + SC_COMMIT, C_SC + SC_DEFER, 2);
-    pc.el[1] = c_lo; pc.el[2] = m_lo; pc.el[3] = m_hi;
-    Interaction& ph = g_cpu[21];
+    pc.mult = lf_pair(EC_SC + SC_COMMIT, EC_SC + SC_DEFER, 1);
+    pc.el[0] = lf_pair(EC_SC + SC_COMMIT, EC_SC + SC_DEFER, 2);
+    pc.el[1] = ec_lo; pc.el[2] = em_lo; pc.el[3] = em_hi;
+    Interaction& ph = g_ecall[9];
     ph = Interaction{};
-    ph.bus = BUS_PUBH; ph.sign = +1; ph.mult = lf_col(C_SC + SC_HALT); ph.n_el = 2;
-    ph.el[0] = c_lo; ph.el[1] = c_hi;
+    ph.bus = BUS_PUBH; ph.sign = +1; ph.mult = lf_col(EC_SC + SC_HALT); ph.n_el = 2;
+    ph.el[0] = ec_lo; ph.el[1] = ec_hi;
   }
   for (int i = 0; i < 50; ++i) {
     Interaction& it = g_keccak[i];
@@ -324,8 +356,9 @@ void build() {
   }
   g_chips[kP2] = {"poseidon2", 0, kP2Width, 3, g_p2, kP2Constraints, 0};
   g_chips[kTable] = {"table", kTablePrepWidth, kTableWidth, 7, g_table, 2, 0};
-  g_chips[kCpu] = {"cpu", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 5};
-  g_chips[kCpu2] = {"cpu2", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 5};
+  g_chips[kCpu] = {"cpu", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 4};
+  g_chips[kCpu2] = {"cpu2", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 4};
+  g_chips[kEcall] = {"ecall", 0, kEcallWidth, 10, g_ecall, kEcallConstraints, 0};
   g_chips[kKeccak] = {"keccak", 0, kKeccakWidth, 50, g_keccak, kKeccakConstraints, 0};
   g_chips[kKmem] = {"keccak-mem", 0, kKmemWidth, 8, g_kmem, kKmemConstraints, 0};
   g_chips[kMemFinal] = {"mem-final", 0, kMemFinalWidth, 10, g_memfinal, kMemFinalConstraints, 0};

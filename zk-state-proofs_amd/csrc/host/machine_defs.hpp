@@ -43,7 +43,7 @@ const ChipDef& chip_def(int chip);
 
 // magic, version, heights, exit code, pv length, 3 digests, hand-over pc; aggregation payload: leaf count, root, digest of the leaf list
 constexpr int kHeaderWords = 2 + kNumChips + 2 + 24 + 1 + 17;
-constexpr uint32_t kMachineVersion = 8;
+constexpr uint32_t kMachineVersion = 9;
 
 }  // namespace mach
 }  // namespace zksp

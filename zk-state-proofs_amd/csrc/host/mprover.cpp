@@ -107,6 +107,7 @@ void machine_heights(const MachineProgram& prog, const MachineCounts& n, int log
   logh[kMul] = at_least5(ceil_log2(n.muls));
   logh[kTable] = kTableLogH;
   logh[kP2] = at_least5(ceil_log2(n.agg > 1 ? n.agg - 1 : 1));  // one row per inner node of the aggregation tree
+  logh[kEcall] = at_least5(ceil_log2(n.ecall));
 }
 void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh[kNumChips]) {
   MachineCounts n;
@@ -119,7 +120,7 @@ bool machine_fits(const MachineTrace& t, const int* logh) {
   return t.cycles.size() <= two(kCpu, kCpu2) && t.alu_idx.size() <= two(kAlu, kAlu2) && t.sub_idx.size() <= two(kSub, kSub2) &&
          t.bw_idx.size() <= two(kBw, kBw2) && t.agg_leaves.size() / 8 <= one(kP2) + 1 &&
          24 * t.keccak.size() <= one(kKeccak) && 50 * t.keccak.size() <= one(kKmem) && t.memfinal.size() <= one(kMemFinal) &&
-         t.muls.size() <= one(kMul);
+         t.muls.size() <= one(kMul) && t.ecall_idx.size() <= one(kEcall);
 }
 
 int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const PrepDevice** out) {
@@ -224,6 +225,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
     A(&w->alu_idx, B * w->cap_alu);
     A(&w->sub_idx, B * w->cap_sub);
     A(&w->bw_idx, B * w->cap_bw);
+    A(&w->ecall_idx, B << logh[kEcall]);  // (an ecall list is as long as the ecall chip is tall, at most)
     A(&w->agg_heap, B * w->cap_agg * 8);
     A(&w->prog_mult, B << logh[kProgram]);
     A(&w->table_hist, (B * kTableWidth) << kTableLogH);
@@ -239,6 +241,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
     A(&w->spare.alu_idx, B * w->cap_alu);
     A(&w->spare.sub_idx, B * w->cap_sub);
     A(&w->spare.bw_idx, B * w->cap_bw);
+    A(&w->spare.ecall_idx, B << logh[kEcall]);
     A(&w->spare.agg_heap, B * w->cap_agg * 8);
     A(&w->spare.prog_mult, B << logh[kProgram]);
     A(&w->spare.counts, B * kCountWords);
@@ -346,7 +349,7 @@ namespace {
 void swap_records(MachineWorkspace* w) {
   MachineWorkspace::SpareRecords& p = w->spare;
   std::swap(w->cycles, p.cycles); std::swap(w->memfinal, p.memfinal); std::swap(w->muls, p.muls);
-  std::swap(w->prog_mult, p.prog_mult); std::swap(w->alu_idx, p.alu_idx); std::swap(w->sub_idx, p.sub_idx); std::swap(w->bw_idx, p.bw_idx); std::swap(w->agg_heap, p.agg_heap);
+  std::swap(w->prog_mult, p.prog_mult); std::swap(w->alu_idx, p.alu_idx); std::swap(w->sub_idx, p.sub_idx); std::swap(w->bw_idx, p.bw_idx); std::swap(w->ecall_idx, p.ecall_idx); std::swap(w->agg_heap, p.agg_heap);
   std::swap(w->counts, p.counts);
   std::swap(w->kcalls, p.kcalls); std::swap(w->kstates, p.kstates); std::swap(w->n_perms, p.n_perms);
   std::swap(w->init_obs, p.init_obs); std::swap(w->pub_words, p.pub_words); std::swap(w->n, p.n);
@@ -416,6 +419,9 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     cn[4] = (uint32_t)t.alu_idx.size(); cn[5] = (uint32_t)t.sub_idx.size(); cn[6] = t.x0_last; cn[7] = (uint32_t)t.bw_idx.size();
     if (!t.bw_idx.empty())
       ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->bw_idx + i * w->cap_bw, t.bw_idx.data(), t.bw_idx.size() * 4, hipMemcpyHostToDevice, s));
+    cn[9] = (uint32_t)t.ecall_idx.size();
+    if (!t.ecall_idx.empty())
+      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->ecall_idx + (i << logh[kEcall]), t.ecall_idx.data(), t.ecall_idx.size() * 4, hipMemcpyHostToDevice, s));
     // aggregation payload: the heap of digests (node k = compress(2k, 2k + 1), leaves at n .. 2n - 1) the Poseidon2 chip's
     // rows are expanded from, and its public part
     uint32_t agg_root[8], agg_digest[8];
@@ -520,12 +526,12 @@ int machine_prove_resident(Context* ctx) {
   // ---- main traces ----
   MachineRecords rec;
   rec.cycles = w->cycles; rec.kcalls = w->kcalls; rec.memfinal = w->memfinal; rec.muls = w->muls;
-  rec.alu_idx = w->alu_idx; rec.sub_idx = w->sub_idx; rec.bw_idx = w->bw_idx; rec.agg_heap = w->agg_heap; rec.consts = kc;
+  rec.alu_idx = w->alu_idx; rec.sub_idx = w->sub_idx; rec.bw_idx = w->bw_idx; rec.ecall_idx = w->ecall_idx; rec.agg_heap = w->agg_heap; rec.consts = kc;
   rec.prog_mult = w->prog_mult; rec.counts = w->counts; rec.table_hist = w->table_hist;
   memset(rec.row0, 0, sizeof rec.row0);
   rec.row0[kCpu2] = (uint32_t)1 << logh[kCpu]; rec.row0[kAlu2] = (uint32_t)1 << logh[kAlu]; rec.row0[kSub2] = (uint32_t)1 << logh[kSub]; rec.row0[kBw2] = (uint32_t)1 << logh[kBw];
   rec.cap_cycles = w->cap_cycles; rec.cap_keccak = w->cap_keccak; rec.cap_memfinal = w->cap_memfinal; rec.cap_muls = w->cap_muls;
-  rec.cap_alu = w->cap_alu; rec.cap_sub = w->cap_sub; rec.cap_bw = w->cap_bw; rec.cap_agg = w->cap_agg;
+  rec.cap_alu = w->cap_alu; rec.cap_sub = w->cap_sub; rec.cap_bw = w->cap_bw; rec.cap_agg = w->cap_agg; rec.cap_ecall = (size_t)1 << logh[kEcall];
   rec.program = prep->program; rec.text_base = prep->text_base; rec.n_program = prep->n_program; rec.n_image = prep->n_image;
   rec.cpu_rows = ((uint32_t)1 << logh[kCpu]) + ((uint32_t)1 << logh[kCpu2]);
   {
@@ -541,7 +547,7 @@ int machine_prove_resident(Context* ctx) {
     }
     // the table chip answers what the others look up: count their RANGE / BYTES receives on their finished traces
     launch_table_clear(s, rec, B);
-    for (int c : {(int)kCpu, (int)kCpu2, (int)kKmem, (int)kMemFinal, (int)kBw, (int)kBw2, (int)kSub, (int)kSub2})
+    for (int c : {(int)kCpu, (int)kCpu2, (int)kKmem, (int)kMemFinal, (int)kBw, (int)kBw2, (int)kSub, (int)kSub2, (int)kEcall})
       launch_table_count(s, static_cast<const Interaction*>(ctx->d_inter[c]), chip_def(c).n_inter, w->mat[c][0].tr, chip_def(c).main_w,
                          logh[c], rec, B);
     launch_table_trace(s, rec, w->mat[kTable][0].tr, B);
@@ -645,7 +651,7 @@ int machine_prove_resident(Context* ctx) {
       qa.wh_inv = wh.inv().v;
       qa.h_inv = Fp::from_canonical((uint32_t)(H(c) % kP)).inv().v;
       qa.consts = kc;
-      qa.pubs = is_cpu_chip(c) ? w->pub_words + 17 + (c == kCpu2 ? kNumCpuPub : 0) : nullptr;
+      qa.pubs = is_cpu_chip(c) || c == kEcall ? w->pub_words + 17 + (c == kCpu2 ? kNumCpuPub : 0) : nullptr;  // (ecall chip: the padding pc)
       qa.pubs_bstride = kPubWords;
       qa.quot = w->mat[c][2].tr;
       qa.partial = is_cpu_chip(c) ? w->reduce_scratch : w->kpartial;  // CPU: 8 H words per proof of the scratch's >= 16 H

@@ -1,4 +1,4 @@
-// Host verifier of the machine proof ("ZKSP v8"): replaces `client.verify(&proof, &vk)` (reference
+// Host verifier of the machine proof ("ZKSP v9"): replaces `client.verify(&proof, &vk)` (reference
 // prover/src/bin/main.rs:80; sp1-stark 3.4.0's multi-chip verifier over p3-uni-stark / p3-fri,
 // Cargo.lock:7485, :5378, :5253) for proofs that bind the guest's whole execution.  Also the
 // host half of `client.setup(ELF)` (main.rs:70): the commitment to the preprocessed Program and
@@ -228,8 +228,9 @@ void machine_prep_traces(const MachineProgram& prog, std::vector<uint32_t>* imag
     uint32_t* q = program_prep->data() + r;
     q[(size_t)PR_PC * hp] = p.pc; q[(size_t)PR_CLS * hp] = (uint32_t)class_of(p.op); q[(size_t)PR_CODE * hp] = code_of(p.op);
     q[(size_t)PR_UC * hp] = ucmp_of(p.op) ? 1u : 0u;
-    q[(size_t)PR_WR * hp] = p.wr; q[(size_t)PR_USE2 * hp] = p.use2;
-    q[(size_t)PR_RD * hp] = p.rd; q[(size_t)PR_RS1 * hp] = p.rs1; q[(size_t)PR_RS2 * hp] = p.rs2;
+    const bool ecall = p.op == ECALL;  // its CPU row moves t0 only: a0 and a1 are the ecall chip's reads
+    q[(size_t)PR_WR * hp] = p.wr; q[(size_t)PR_USE2 * hp] = ecall ? 0 : p.use2;
+    q[(size_t)PR_RD * hp] = p.rd; q[(size_t)PR_RS1 * hp] = p.rs1; q[(size_t)PR_RS2 * hp] = ecall ? 0 : p.rs2;
     q[(size_t)PR_IMM_LO * hp] = p.imm & 0xffff; q[(size_t)PR_IMM_HI * hp] = p.imm >> 16;
     q[(size_t)PR_TGT_LO * hp] = p.tgt & 0xffff; q[(size_t)PR_TGT_HI * hp] = p.tgt >> 16;
   }
@@ -520,6 +521,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       case kBw:
       case kBw2: eval_bw(zc); break;
       case kP2: eval_p2(zc); break;
+      case kEcall: eval_ecall(zc); break;
     }
     if (zc.k_ != nb) { *err = "internal: constraint count"; return 7; }
     // LogUp (machine_defs.hpp "LogUp layout"): row = [prep | main] at zeta
