@@ -62,11 +62,13 @@ for (b, d), w in zip(big, weights):
             mix["full_rate" if op in FULL_RATE else "half_rate"] += w * n
 total = sum(mix.values())
 # cross-check with the counter collection of the same build, when there is one: VALU instructions of the largest launch
-# (the CPU chip's main trace: 8 permutations per row) per lane per permutation
+# (the CPU chip's main trace) per lane per permutation
 pmc = None
 try:
     v = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_counters.json")))
-    pmc = v["SQ_INSTS_VALU"]["zksp::mmcs_leaf_kernel"][1] / (v["batch"] * (1 << 19) / 64) / 8
+    air = open(os.path.join(ROOT, "zk-state-proofs_amd", "csrc", "device", "air_machine.hpp")).read()
+    absorptions = (int(re.search(r"static_assert\(kCpuWidth == (\d+)", air).group(1)) + 7) // 8  # per row of the CPU chip's main trace
+    pmc = v["SQ_INSTS_VALU"]["zksp::mmcs_leaf_kernel"][1] / (v["batch"] * (1 << 19) / 64) / absorptions
 except (OSError, KeyError, ValueError):
     pass
 out = {"kernel": "mmcs_leaf_kernel", "per_permutation_per_lane": dict(mix), "total_valu": total,
