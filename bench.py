@@ -67,17 +67,18 @@ def stage_bytes(heights):
     a stage reads its inputs once and writes its outputs once."""
     out = {k: 0 for k in ("m_trace", "m_lde_main", "m_leaf_main", "m_perm", "m_lde_perm", "m_quotient", "m_lde_quot",
                           "m_open", "m_reduce")}
-    for (name, p, w, e), lh in zip(load_chip_widths(), heights):
+    for c, ((name, p, w, e), lh) in enumerate(zip(load_chip_widths(), heights)):
         h = 1 << lh
+        q = 8 if list(heights).index(lh) == c else 0            # the chips of a height share a quotient: its first chip's
         out["m_trace"] += 4 * h * w
-        out["m_lde_main"] += 4 * h * w * 4                      # read H, write coefficients H, write LDE 2H
+        out["m_lde_main"] += 4 * h * w * 3                      # read H, write LDE 2H (no coefficient arrays)
         out["m_leaf_main"] += 4 * 2 * h * w + 32 * 2 * h        # read every LDE cell once, one digest per row
         out["m_perm"] += 4 * h * (p + w) + 4 * h * e
-        out["m_lde_perm"] += 4 * h * e * 4
-        out["m_quotient"] += 4 * 2 * h * (p + w + e) + 4 * 8 * h
-        out["m_lde_quot"] += 4 * h * 8 * 4
-        out["m_open"] += 4 * h * (p + w + e + 8)
-        out["m_reduce"] += 4 * 2 * h * (p + w + e + 8) + 16 * 2 * h
+        out["m_lde_perm"] += 4 * h * e * 3
+        out["m_quotient"] += 4 * 2 * h * (p + w + e) + 4 * q * h
+        out["m_lde_quot"] += 4 * h * q * 3
+        out["m_open"] += 4 * h * (p + w + e + q)
+        out["m_reduce"] += 4 * 2 * h * (p + w + e + q) + 16 * 2 * h
     return out
 
 
@@ -636,11 +637,12 @@ def main():
         "config": {
             "workload": "acct-d8 machine proof: depth-8 account-trie MPT proof of the committed sp1-merkle-proof guest, whole "
                         "execution proven (keccak precompile shape, 391 400 cycles; chips as name 2^log-height x "
-                        "(preprocessed + main + permutation + quotient columns): "
-                        + ", ".join(f"{n} 2^{lh} x ({p}+{w}+{e}+8)" for (n, p, w, e), lh in zip(load_chip_widths(), heights))
-                        + "; LogUp buses; blowup 2, 100 FRI queries, 16 PoW bits)",
+                        "(preprocessed + main + permutation columns): "
+                        + ", ".join(f"{n} 2^{lh} x ({p}+{w}+{e})" for (n, p, w, e), lh in zip(load_chip_widths(), heights))
+                        + "; one quotient of 8 columns per height; LogUp buses; blowup 2, 100 FRI queries, 16 PoW bits)",
             "statement": f"guest executed from its entry point to HALT(0) with these public values (machine proof, format v{zk.MACHINE_VERSION})",
-            "cells_per_proof": sum((w + e + 8) << lh for (n, p, w, e), lh in zip(load_chip_widths(), heights)),
+            "cells_per_proof": sum((w + e + (8 if list(heights).index(lh) == c else 0)) << lh
+                                   for c, ((n, p, w, e), lh) in enumerate(zip(load_chip_widths(), heights))),
             "chip_log_heights": heights,
             "batch_per_gpu": B,
             "proofs_per_step": world * B,

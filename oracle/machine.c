@@ -1,6 +1,6 @@
 /* ORACLE -- TEST INFRASTRUCTURE ONLY (see field.h and machine.h).
  *
- * Chips of the machine proof (format v9): bus interactions, trace generation from the executor's
+ * Chips of the machine proof (format v10): bus interactions, trace generation from the executor's
  * records and base-field constraints.  This repository's own arithmetisation (machine.h header
  * note); what it must reproduce is the reference's statement: the committed RV32IM guest
  * (circuits/sp1-merkle-proof/src/main.rs:4-14 running crypto-ops/src/lib.rs:8-23) executed from its

@@ -11,7 +11,7 @@
  * (circuits/sp1-merkle-proof/src/main.rs:4-14, crypto-ops/src/lib.rs:8-23) ran to HALT(0) and
  * committed these public values.
  *
- * Format v9 (round 3).  The CPU row no longer carries its operands as bits: it holds 16-bit limbs,
+ * Format v10 (round 3).  The CPU row no longer carries its operands as bits: it holds 16-bit limbs,
  * adds / subtracts / compares (equality, unsigned order) / moves words itself, and sends xor / or /
  * and to a bitwise chip (bytes, looked up in a byte-operation table), shifts and signed less-than to
  * an ALU chip (bits) and every sub-word load or store to a sub-word chip, each with one row per such
@@ -169,6 +169,23 @@ const orc_chip* orc_machine_chip(int chip);
  * phi_next - phi + cum / H - (sum of the helper columns), where phi is the running-sum column, cum the chip's cumulative
  * sum (a proof word) and H the height, on EVERY row, cyclically (no boundary rows: summing the rows gives
  * cum = sum of all fractions).  Every LogUp constraint has degree <= 3. */
+/* Quotients.  The chips of one height share ONE quotient: with total_c = n_constraints + slots the number of constraints of
+ * chip c (base constraints, then one LogUp constraint per slot), chip c's constraints are folded with the powers
+ * alpha^(off_c + k), off_c = the sum of total_c' over the chips c' < c of the same height, and the sum over the height's
+ * chips is divided by the vanishing polynomial once.  The first chip of a height (its "leader") carries the quotient's
+ * 8 columns (two chunks of one extension element each); the others have none. */
+static inline int orc_quot_leader(const int* logh, int c) {
+  for (int c2 = 0; c2 < c; ++c2)
+    if (logh[c2] == logh[c]) return c2;
+  return c;
+}
+static inline int orc_chip_slots(const orc_chip* c);
+static inline int orc_quot_alpha_offset(const int* logh, int c) {
+  int off = 0;
+  for (int c2 = 0; c2 < c; ++c2)
+    if (logh[c2] == logh[c]) off += orc_machine_chip(c2)->n_constraints + orc_chip_slots(orc_machine_chip(c2));
+  return off;
+}
 static inline int orc_chip_slots(const orc_chip* c) { return (c->n_inter - c->n_merged + 1) / 2 + (c->n_merged ? 1 : 0); }
 static inline int orc_chip_helpers(const orc_chip* c) { return orc_chip_slots(c) - 1; }
 static inline int orc_chip_perm_width(const orc_chip* c) { return 4 * orc_chip_slots(c); }
@@ -211,7 +228,8 @@ void orc_machine_constraints(int chip, const uint32_t* prep, const uint32_t* loc
 /* LogUp permutation trace [perm_width][H] (helper columns, then the running sum phi, phi_0 = 0) and the chip's cumulative sum */
 void orc_machine_stage_perm(const orc_machine_input* in, int chip, const uint32_t gamma[4], const uint32_t beta[4], uint32_t* perm,
                             uint32_t cum[4]);
-/* quotient values [8][H]: columns 4c..4c+3 = the extension element over coset c */
+/* this chip's share of its height's quotient, [8][H]: columns 4c..4c+3 = the extension element over coset c; the
+ * quotient the height's first chip commits is the sum of the shares of the chips of that height */
 void orc_machine_stage_quotient(const orc_machine_input* in, int chip, const uint32_t alpha[4], const uint32_t gamma[4],
                                 const uint32_t beta[4], uint32_t* quot);
 
@@ -225,7 +243,7 @@ typedef struct {
 /* the aggregation payload's public part: Merkle root of the leaves (2-to-1 Poseidon2 compressions) and the sponge hash
  * of the leaf list, which stands for the list in the transcript */
 void orc_machine_agg_public(const uint32_t* leaves, size_t n, uint32_t root[8], uint32_t list_digest[8]);
-#define ZKSP_VERSION_MACHINE 9u
+#define ZKSP_VERSION_MACHINE 10u
 /* vk: preprocessed commitment root + digest binding entry pc, table heights and keccak mode */
 void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t prep_root[8], uint32_t vk_digest[8]);
 size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_image, const orc_config* cfg, uint32_t pv_len);

@@ -3,7 +3,7 @@
  * Whole machine proof on the CPU: the multi-table STARK that sp1-stark / sp1-prover 3.4.0 build over
  * p3-uni-stark, p3-fri, p3-merkle-tree (mixed-height MMCS) and p3-challenger (reference
  * Cargo.lock:7485, :7273, :5378, :5253, :5336, :5197) beneath `client.prove(&pk, stdin).run()`
- * (prover/src/bin/main.rs:71-74), restated under this repository's own format "ZKSP v9"
+ * (prover/src/bin/main.rs:71-74), restated under this repository's own format "ZKSP v10"
  * (DESIGN.md "Machine proof").  PARITY UNPINNED vs SP1 proof bytes.  The HIP prover must
  * reproduce these bytes exactly.
  *
@@ -273,7 +273,8 @@ static void perm_trace(chipd* d, fe4 gamma, const fe4* bpow) {
 }
 
 /* ---- quotient of one chip ---- */
-static void chip_quotient(chipd* d, int chip, fe4 alpha, fe4 gamma, const fe4* bpow, const uint32_t* pub) {
+/* adds the chip's constraints, folded with alpha^(alpha_off + k) and divided by the vanishing polynomial, to out [8][H] */
+static void chip_quotient(chipd* d, int chip, fe4 alpha, int alpha_off, fe4 gamma, const fe4* bpow, const uint32_t* pub, uint32_t* out) {
   const orc_chip* def = d->def;
   const int ni = def->n_inter, nh = orc_chip_helpers(def), nb = def->n_constraints, total = nb + nh + 1;
   const fe4 cum_step = e_mul_base(d->cum, f_inv((fe)(d->h % FP)));
@@ -281,13 +282,13 @@ static void chip_quotient(chipd* d, int chip, fe4 alpha, fe4 gamma, const fe4* b
   const size_t h = d->h;
   fe4* apow = (fe4*)malloc((size_t)total * sizeof(fe4));
   apow[0] = e_one();
+  for (int k = 0; k < alpha_off; ++k) apow[0] = e_mul(apow[0], alpha);
   for (int k = 1; k < total; ++k) apow[k] = e_mul(apow[k - 1], alpha);
   aff* af = (aff*)malloc((size_t)ni * sizeof(aff));
   for (int i = 0; i < ni; ++i) build_aff(&def->inter[i], gamma, bpow, &af[i]);
   const fe wh = f_root_of_unity(d->logh), w2h = f_root_of_unity(d->logh + 1), wh_inv = f_inv(wh);
   const uint32_t* src[2] = {d->lde[R_PREP], d->lde[R_MAIN]};
   const uint32_t* lp = d->lde[R_PERM];
-  uint32_t* out = d->tr[R_QUOT];
   for (int cs = 0; cs < 2; ++cs) {
     const fe shift = cs ? f_mul(F_GEN, w2h) : F_GEN;
     const fe zh = f_sub(f_pow(shift, h), 1), zh_inv = f_inv(zh);
@@ -324,7 +325,7 @@ static void chip_quotient(chipd* d, int chip, fe4 alpha, fe4 gamma, const fe4* b
         const fe4 last = e_sub(e_add(e_sub(phin, phi), cum_step), hsum);
         acc = e_add(acc, e_mul(apow[nb + nh], slot_constraint(def, af, nh, loc, last)));
         acc = e_mul_base(acc, zh_inv);
-        for (int t = 0; t < 4; ++t) out[(size_t)(4 * cs + t) * h + m] = acc.c[t];
+        for (int t = 0; t < 4; ++t) out[(size_t)(4 * cs + t) * h + m] = f_add(out[(size_t)(4 * cs + t) * h + m], acc.c[t]);
       }
       free(loc);
       free(cons);
@@ -368,7 +369,7 @@ static void init_chips(const orc_machine_input* in, chipd* cd, int only_prep) {
     lde_round(d, R_PREP);
     if (only_prep) { d->w[R_MAIN] = 0; continue; }
     d->w[R_PERM] = orc_chip_perm_width(d->def);
-    d->w[R_QUOT] = 8;
+    d->w[R_QUOT] = orc_quot_leader(logh, c) == c ? 8 : 0; /* one quotient per height */
   }
 }
 static void free_chips(chipd* cd) {
@@ -426,8 +427,10 @@ void orc_machine_stage_quotient(const orc_machine_input* in, int chip, const uin
   d.tr[R_PERM] = (uint32_t*)calloc((size_t)d.w[R_PERM] * d.h, 4);
   perm_trace(&d, gamma, bpow);
   lde_round(&d, R_PERM);
-  d.tr[R_QUOT] = (uint32_t*)malloc((size_t)8 * d.h * 4);
-  chip_quotient(&d, chip, alpha, gamma, bpow, pub);
+  int logh[N_CHIPS];
+  orc_machine_heights(in, logh);
+  d.tr[R_QUOT] = (uint32_t*)calloc((size_t)8 * d.h, 4);
+  chip_quotient(&d, chip, alpha, orc_quot_alpha_offset(logh, chip), gamma, bpow, pub, d.tr[R_QUOT]);
   memcpy(quot, d.tr[R_QUOT], (size_t)8 * d.h * 4);
   free_one(&d);
 }
@@ -490,8 +493,9 @@ size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_ima
     const size_t e = (size_t)orc_chip_perm_width(d);
     if (logh[c] > lm) lm = logh[c];
     if (d->prep_width && logh[c] > lm_prep) lm_prep = logh[c];
-    opened += (size_t)d->prep_width + 2 * (size_t)d->main_width + 2 * e + 8;
-    rw[R_PREP] += (size_t)d->prep_width; rw[R_MAIN] += (size_t)d->main_width; rw[R_PERM] += e; rw[R_QUOT] += 8;
+    const size_t q = orc_quot_leader(logh, c) == c ? 8 : 0;
+    opened += (size_t)d->prep_width + 2 * (size_t)d->main_width + 2 * e + q;
+    rw[R_PREP] += (size_t)d->prep_width; rw[R_MAIN] += (size_t)d->main_width; rw[R_PERM] += e; rw[R_QUOT] += q;
   }
   words += 8 + 8 + 4 * N_CHIPS + 8 + 4 * opened + 8 * (size_t)lm + 4 + 1;
   size_t perq = rw[R_PREP] + 8 * ((size_t)lm_prep + 1);
@@ -634,12 +638,12 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   /* ---- round 3: quotients ---- */
   fe4 alpha;
   orc_ch_sample_ext(&ch, alpha.c);
-  for (int c = 0; c < N_CHIPS; ++c) {
+  for (int c = 0; c < N_CHIPS; ++c) { /* every chip adds its share to the quotient of its height's first chip */
     chipd* d = &cd[c];
-    d->tr[R_QUOT] = (uint32_t*)malloc((size_t)8 * d->h * 4);
-    chip_quotient(d, c, alpha, gamma, bpow, cpu_pub[c]);
-    lde_round(d, R_QUOT);
+    if (d->w[R_QUOT]) d->tr[R_QUOT] = (uint32_t*)calloc((size_t)8 * d->h, 4);
+    chip_quotient(d, c, alpha, orc_quot_alpha_offset(logh, c), gamma, bpow, cpu_pub[c], cd[orc_quot_leader(logh, c)].tr[R_QUOT]);
   }
+  for (int c = 0; c < N_CHIPS; ++c) lde_round(&cd[c], R_QUOT);
   mmcs_commit(cd, R_QUOT, &t_quot);
   orc_ch_observe_many(&ch, mmcs_root(&t_quot), 8);
   put(&pb, mmcs_root(&t_quot), 8);
@@ -648,7 +652,7 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   fe4 zeta;
   orc_ch_sample_ext(&ch, zeta.c);
   size_t n_open = 0;
-  for (int c = 0; c < N_CHIPS; ++c) n_open += (size_t)cd[c].w[R_PREP] + 2 * (size_t)cd[c].w[R_MAIN] + 2 * (size_t)cd[c].w[R_PERM] + 8;
+  for (int c = 0; c < N_CHIPS; ++c) n_open += (size_t)cd[c].w[R_PREP] + 2 * (size_t)cd[c].w[R_MAIN] + 2 * (size_t)cd[c].w[R_PERM] + (size_t)cd[c].w[R_QUOT];
   fe4* opened = (fe4*)malloc(n_open * sizeof(fe4));
   size_t chip_open_off[N_CHIPS];
   {
@@ -681,7 +685,7 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   for (int c = 0; c < N_CHIPS; ++c) {
     chipd* d = &cd[c];
     const size_t h = d->h, o = chip_open_off[c];
-    const size_t n1 = (size_t)d->w[R_PREP] + d->w[R_MAIN] + d->w[R_PERM] + 8, n2 = (size_t)d->w[R_MAIN] + d->w[R_PERM];
+    const size_t n1 = (size_t)d->w[R_PREP] + d->w[R_MAIN] + d->w[R_PERM] + d->w[R_QUOT], n2 = (size_t)d->w[R_MAIN] + d->w[R_PERM];
     fe4 b1 = e_zero(), b2 = e_zero();
     for (size_t i = 0; i < n1; ++i) b1 = e_add(b1, e_mul(afpow[o + i], opened[o + i]));
     for (size_t i = 0; i < n2; ++i) b2 = e_add(b2, e_mul(afpow[o + n1 + i], opened[o + n1 + i]));

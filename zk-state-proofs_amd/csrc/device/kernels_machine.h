@@ -110,7 +110,8 @@ struct MQuotArgs {
   const P2Consts* consts;       // Poseidon2 constants (the Poseidon2 chip's constraints)
   const uint32_t* pubs;         // CPU instances: this instance's CpuPub words per proof (Montgomery), stride pubs_bstride
   size_t pubs_bstride;
-  uint32_t* quot;               // [B][8][H]
+  uint32_t* quot;               // [B][8][H]: the quotient of this chip's height (its first chip's buffer)
+  int accumulate;               // add to `quot` instead of overwriting (another chip of the same height wrote first)
   uint32_t* partial;            // keccak chip: [B][13][2H] Fp4 scratch; CPU chip: [B][2H] Fp4
   int logh, batch;
 };

@@ -1253,7 +1253,10 @@ __global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
   const Fp4 q = ctx.acc * Fp::raw(pi.c ? a.zh_inv[1] : a.zh_inv[0]);
   uint32_t* dst = a.quot + (size_t)pi.b * 8 * h + pi.m;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) dst[(size_t)(4 * pi.c + j) * h] = q.c[j].v;
+  for (int j = 0; j < 4; ++j) {
+    uint32_t* qd = dst + (size_t)(4 * pi.c + j) * h;
+    *qd = a.accumulate ? (q.c[j] + Fp::raw(*qd)).v : q.c[j].v;
+  }
 }
 
 // CPU chip: the base constraints (task 0) and the LogUp constraints with the fingerprints of cpu_bus_pairs, one launch
@@ -1304,7 +1307,10 @@ __global__ __launch_bounds__(kMT) void cpu_quotient_task_kernel(MQuotArgs a) {
       const Fp4 q = acc * Fp::raw(pi.c ? a.zh_inv[1] : a.zh_inv[0]);
       uint32_t* dst = a.quot + (size_t)b * 8 * h + pi.m;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dst[(size_t)(4 * pi.c + j) * h] = q.c[j].v;
+      for (int j = 0; j < 4; ++j) {
+    uint32_t* qd = dst + (size_t)(4 * pi.c + j) * h;
+    *qd = a.accumulate ? (q.c[j] + Fp::raw(*qd)).v : q.c[j].v;
+  }
     } else {
       m_store_fp4(part, acc);
     }
@@ -1355,7 +1361,10 @@ __global__ __launch_bounds__(kMT) void keccak_machine_combine_kernel(MQuotArgs a
   acc = acc * Fp::raw(c ? a.zh_inv[1] : a.zh_inv[0]);
   uint32_t* q = a.quot + (size_t)b * 8 * h + m;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) q[(size_t)(4 * c + j) * h] = acc.c[j].v;
+  for (int j = 0; j < 4; ++j) {
+    uint32_t* qd = q + (size_t)(4 * c + j) * h;
+    *qd = a.accumulate ? (acc.c[j] + Fp::raw(*qd)).v : acc.c[j].v;
+  }
 }
 
 void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a) {

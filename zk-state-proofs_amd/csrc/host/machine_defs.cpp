@@ -1,4 +1,4 @@
-// See machine_defs.hpp.  Bus protocol (DESIGN.md "Machine proof", format v9):
+// See machine_defs.hpp.  Bus protocol (DESIGN.md "Machine proof", format v10):
 //   MEM    (addr, lo, hi, time)   every access consumes its predecessor's tuple and produces its own
 //   PROG   (pc, class, code, uc, wr, use2, rd, rs1, rs2, imm_lo, imm_hi, tgt_lo, tgt_hi)   instruction fetch, every CPU row
 //   KCALL  (time, ptr_lo, ptr_hi)   CPU -> keccak-memory: one precompile call

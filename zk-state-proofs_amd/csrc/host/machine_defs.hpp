@@ -41,9 +41,26 @@ struct ChipDef {
 };
 const ChipDef& chip_def(int chip);
 
+// Quotients.  The chips of one height share ONE quotient: chip c's constraints are folded with the powers
+// alpha^(off_c + k), off_c = the sum of total_constraints() over the chips c' < c of the same height, and the sum over the
+// height's chips is divided by the vanishing polynomial once.  The first chip of a height (its "leader") carries the
+// quotient's 8 columns (two chunks of one extension element each); the others have none.
+inline int quot_leader(const int* logh, int c) {
+  for (int c2 = 0; c2 < c; ++c2)
+    if (logh[c2] == logh[c]) return c2;
+  return c;
+}
+inline int quot_width(const int* logh, int c) { return quot_leader(logh, c) == c ? 8 : 0; }
+inline int quot_alpha_offset(const int* logh, int c) {
+  int off = 0;
+  for (int c2 = 0; c2 < c; ++c2)
+    if (logh[c2] == logh[c]) off += chip_def(c2).total_constraints();
+  return off;
+}
+
 // magic, version, heights, exit code, pv length, 3 digests, hand-over pc; aggregation payload: leaf count, root, digest of the leaf list
 constexpr int kHeaderWords = 2 + kNumChips + 2 + 24 + 1 + 17;
-constexpr uint32_t kMachineVersion = 9;
+constexpr uint32_t kMachineVersion = 10;
 
 }  // namespace mach
 }  // namespace zksp

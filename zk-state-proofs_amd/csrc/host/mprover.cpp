@@ -255,7 +255,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
       const size_t h = (size_t)1 << logh[c];
       lm = std::max(lm, logh[c]);
       max_h = std::max(max_h, h);
-      const int widths[3] = {d.main_w, d.perm_width(), 8};
+      const int widths[3] = {d.main_w, d.perm_width(), quot_width(logh, c)};  // (one quotient per height: its first chip's)
       for (int r = 0; r < 3; ++r) {
         w->mat[c][r].w = widths[r];
         A(&w->mat[c][r].tr, B * widths[r] * h);
@@ -268,8 +268,8 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
       if (first == c) A(&w->zpow[c], B * 4 * h * 4);
       else w->zpow[c] = w->zpow[first];
       w->open_off[c] = n_open;
-      n_open += (size_t)d.prep_w + 2 * (size_t)d.main_w + 2 * (size_t)d.perm_width() + 8;
-      max_total = std::max<size_t>(max_total, (size_t)d.total_constraints());
+      n_open += (size_t)d.prep_w + 2 * (size_t)d.main_w + 2 * (size_t)d.perm_width() + (size_t)quot_width(logh, c);
+      max_total = std::max<size_t>(max_total, (size_t)quot_alpha_offset(logh, c) + (size_t)d.total_constraints());
     }
     w->lm = lm;
     w->n_open = n_open;
@@ -303,7 +303,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
       size_t need = 0;  // partial sums of the reduced openings: [nchunks][2][2H] Fp4 per proof, largest chip
       for (int c = 0; c < kNumChips; ++c) {
         const ChipDef& d = chip_def(c);
-        need = std::max(need, (size_t)mreduce_nchunks(d.prep_w + d.main_w + d.perm_width() + 8) * 16 * ((size_t)1 << logh[c]));
+        need = std::max(need, (size_t)mreduce_nchunks(d.prep_w + d.main_w + d.perm_width() + quot_width(logh, c)) * 16 * ((size_t)1 << logh[c]));
       }
       for (int c = 0; c < kNumChips; ++c)  // ... and of the tall openings
         for (int wdt : {chip_def(c).prep_w, chip_def(c).main_w, chip_def(c).perm_width(), 8})
@@ -566,7 +566,7 @@ int machine_prove_resident(Context* ctx) {
     rm[0].seg[c][0] = prep_seg(c, true);
     for (int r = 1; r <= 2; ++r)
       rm[r].seg[c][0] = Seg{w->mat[c][r - 1].lde, (size_t)w->mat[c][r - 1].w * 2 * H(c), w->mat[c][r - 1].w};
-    rm[3].seg[c][0] = Seg{w->mat[c][2].lde, (size_t)8 * 2 * H(c), 8};
+    rm[3].seg[c][0] = Seg{w->mat[c][2].lde, (size_t)w->mat[c][2].w * 2 * H(c), w->mat[c][2].w};
   }
   {
     ProfileSpan sp(ctx, "m_commit_main");
@@ -635,7 +635,7 @@ int machine_prove_resident(Context* ctx) {
       qa.prep = prep_seg(c, true);
       qa.main_ = rm[1].seg[c][0];
       qa.perm = rm[2].seg[c][0];
-      qa.alpha_pows = w->alpha_pows;
+      qa.alpha_pows = w->alpha_pows + 4 * (size_t)quot_alpha_offset(logh, c);  // the chips of a height share a quotient
       qa.alpha_bstride = w->alpha_stride;
       qa.bus_ch = w->bus_ch;
       qa.bpow = w->bpow;
@@ -653,7 +653,8 @@ int machine_prove_resident(Context* ctx) {
       qa.consts = kc;
       qa.pubs = is_cpu_chip(c) || c == kEcall ? w->pub_words + 17 + (c == kCpu2 ? kNumCpuPub : 0) : nullptr;  // (ecall chip: the padding pc)
       qa.pubs_bstride = kPubWords;
-      qa.quot = w->mat[c][2].tr;
+      qa.quot = w->mat[quot_leader(logh, c)][2].tr;
+      qa.accumulate = quot_leader(logh, c) != c;
       qa.partial = is_cpu_chip(c) ? w->reduce_scratch : w->kpartial;  // CPU: 8 H words per proof of the scratch's >= 16 H
       qa.logh = logh[c];
       qa.batch = B;
@@ -664,8 +665,9 @@ int machine_prove_resident(Context* ctx) {
     ProfileSpan sp(ctx, "m_lde_quot");
     // columns 4c..4c+3 of every proof were evaluated over coset c: scale tables 1 and 2
     for (int c = 0; c < kNumChips; ++c)
-      launch_lde(s, w->mat[c][2].tr, nullptr, w->mat[c][2].lde, dom[c]->twc_fwd, dom[c]->twc_inv,
-                 dom[c]->in_scale_br + H(c), 2, 1, dom[c]->out_scale_br, logh[c], (size_t)B * 8);
+      if (w->mat[c][2].w)
+        launch_lde(s, w->mat[c][2].tr, nullptr, w->mat[c][2].lde, dom[c]->twc_fwd, dom[c]->twc_inv,
+                   dom[c]->in_scale_br + H(c), 2, 1, dom[c]->out_scale_br, logh[c], (size_t)B * 8);
   }
   {
     ProfileSpan sp(ctx, "m_commit_quot");
@@ -696,7 +698,7 @@ int machine_prove_resident(Context* ctx) {
         launch_bary_weights(s, w->zeta, 4, sinv, dom[c]->tw_fwd, h_inv, w->zpow[c], zs, logh[c], B);
       }
       uint32_t* base = w->opened + w->open_off[c] * 4;
-      const size_t pt_stride = (size_t)mw + ew + 8;
+      const size_t pt_stride = (size_t)mw + ew + (size_t)w->mat[c][2].w;
       // tall columns: split the rows over workgroups (the partial sums live in the reduce scratch, which is not in
       // use yet)
       auto open = [&](const uint32_t* evals, size_t cstride, int ncols, int npts, const uint32_t* table, uint32_t* dst, size_t pts) {
@@ -706,8 +708,10 @@ int machine_prove_resident(Context* ctx) {
       if (pw) open(prep->tr[PrepDevice::index_of(c)], 0, pw, 1, w->zpow[c], base, 0);
       open(w->mat[c][0].tr, (size_t)mw * h, mw, 2, w->zpow[c], base + (size_t)pw * 4, pt_stride);
       open(w->mat[c][1].tr, (size_t)ew * h, ew, 2, w->zpow[c], base + (size_t)(pw + mw) * 4, pt_stride);
-      open(w->mat[c][2].tr, 8 * h, 4, 1, w->zpow[c] + 2 * h * 4, base + (size_t)(pw + mw + ew) * 4, 0);
-      open(w->mat[c][2].tr + 4 * h, 8 * h, 4, 1, w->zpow[c] + 3 * h * 4, base + (size_t)(pw + mw + ew + 4) * 4, 0);
+      if (w->mat[c][2].w) {
+        open(w->mat[c][2].tr, 8 * h, 4, 1, w->zpow[c] + 2 * h * 4, base + (size_t)(pw + mw + ew) * 4, 0);
+        open(w->mat[c][2].tr + 4 * h, 8 * h, 4, 1, w->zpow[c] + 3 * h * 4, base + (size_t)(pw + mw + ew + 4) * 4, 0);
+      }
     }
   }
   {

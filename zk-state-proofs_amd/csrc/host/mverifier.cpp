@@ -1,4 +1,4 @@
-// Host verifier of the machine proof ("ZKSP v9"): replaces `client.verify(&proof, &vk)` (reference
+// Host verifier of the machine proof ("ZKSP v10"): replaces `client.verify(&proof, &vk)` (reference
 // prover/src/bin/main.rs:80; sp1-stark 3.4.0's multi-chip verifier over p3-uni-stark / p3-fri,
 // Cargo.lock:7485, :5378, :5253) for proofs that bind the guest's whole execution.  Also the
 // host half of `client.setup(ELF)` (main.rs:70): the commitment to the preprocessed Program and
@@ -296,8 +296,9 @@ size_t machine_proof_body_words(const int* logh, uint32_t num_queries) {
     const size_t e = (size_t)d.perm_width();
     lm = std::max(lm, logh[c]);
     if (d.prep_w) lm_prep = std::max(lm_prep, logh[c]);
-    opened += (size_t)d.prep_w + 2 * (size_t)d.main_w + 2 * e + 8;
-    rw[0] += (size_t)d.prep_w; rw[1] += (size_t)d.main_w; rw[2] += e; rw[3] += 8;
+    const size_t q = (size_t)quot_width(logh, c);  // one quotient per height: its first chip's
+    opened += (size_t)d.prep_w + 2 * (size_t)d.main_w + 2 * e + q;
+    rw[0] += (size_t)d.prep_w; rw[1] += (size_t)d.main_w; rw[2] += e; rw[3] += q;
   }
   size_t words = 8 + 8 + 4 * (size_t)kNumChips + 8 + 4 * opened + 8 * (size_t)lm + 4 + 1;
   size_t perq = rw[0] + 8 * ((size_t)lm_prep + 1);
@@ -378,13 +379,13 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   for (int r = 0; r < 4; ++r) shape[r].lm = 0;
   for (int c = 0; c < kNumChips; ++c) {
     const ChipDef& d = chip_def(c);
-    const int w[4] = {d.prep_w, d.main_w, d.perm_width(), 8};
+    const int w[4] = {d.prep_w, d.main_w, d.perm_width(), quot_width(logh, c)};
     for (int r = 0; r < 4; ++r) {
       shape[r].width[c] = w[r];
       if (w[r]) shape[r].lm = std::max(shape[r].lm, logh[c]);
     }
     open_off[c] = n_open;
-    n_open += (size_t)d.prep_w + 2 * (size_t)d.main_w + 2 * (size_t)d.perm_width() + 8;
+    n_open += (size_t)d.prep_w + 2 * (size_t)d.main_w + 2 * (size_t)d.perm_width() + (size_t)quot_width(logh, c);
   }
   const uint32_t* p_root_main = body;
   const uint32_t* p_root_perm = body + 8;
@@ -461,22 +462,24 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   }
   const Fp4 af = ch.sample_ext();
 
-  // ---- constraint identity of every chip at zeta ----
+  // ---- constraint identity at zeta: one per height (the chips of a height share a quotient: machine_defs.hpp) ----
   const Fp g = Fp::from_canonical(kGen);
+  Fp4 group_acc[kNumChips];  // indexed by the height's first chip
+  for (int c = 0; c < kNumChips; ++c) group_acc[c] = Fp4::zero();
   for (int c = 0; c < kNumChips; ++c) {
     const ChipDef& d = chip_def(c);
-    const int pw = d.prep_w, mw = d.main_w, ew = d.perm_width(), nh = d.helpers(), nb = d.n_constraints;
+    const int pw = d.prep_w, mw = d.main_w, ew = d.perm_width(), nh = d.helpers(), nb = d.n_constraints, qw = quot_width(logh, c);
     const size_t h = (size_t)1 << logh[c];
     const Fp4* o_prep = opened.data() + open_off[c];
     const Fp4* o_main = o_prep + pw;
     const Fp4* o_perm = o_main + mw;
     const Fp4* o_quot = o_perm + ew;
-    const Fp4* o_main_n = o_quot + 8;
+    const Fp4* o_main_n = o_quot + qw;
     const Fp4* o_perm_n = o_main_n + mw;
     const Fp wh = fp_root_of_unity(logh[c]), wh_inv = wh.inv();
     const Fp4 zeta_h = zeta.pow(h), zh = zeta_h - Fp4::one();
     std::vector<Fp4> apow(d.total_constraints());
-    apow[0] = Fp4::one();
+    apow[0] = alpha.pow((uint64_t)quot_alpha_offset(logh, c));
     for (size_t k = 1; k < apow.size(); ++k) apow[k] = apow[k - 1] * alpha;
     ZetaCtx zc;
     zc.loc = o_main;
@@ -562,10 +565,21 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     const Fp4 phi = from_basis(o_perm + 4 * nh), phin = from_basis(o_perm_n + 4 * nh);
     const Fp4 cum_step = cum[c] * Fp::from_canonical((uint32_t)(h % kP)).inv();
     zc.acc += apow[nb + nh] * slot_constraint(nh, phin - phi + cum_step - hsum);
+    group_acc[quot_leader(logh, c)] += zc.acc;
+  }
+  for (int c = 0; c < kNumChips; ++c) {
+    if (!quot_width(logh, c)) continue;
+    const ChipDef& d = chip_def(c);
+    const size_t h = (size_t)1 << logh[c];
+    const Fp4* o_quot = opened.data() + open_off[c] + d.prep_w + d.main_w + d.perm_width();
+    const Fp4 zeta_h = zeta.pow(h), zh = zeta_h - Fp4::one();
     const Fp4 q0 = from_basis(o_quot), q1 = from_basis(o_quot + 4);
     const Fp sh = g.pow(h), inv_2sh = (sh + sh).inv();
     const Fp4 quot = q0 * (zeta_h + Fp4::from_base(sh)) * inv_2sh - q1 * (zeta_h - Fp4::from_base(sh)) * inv_2sh;
-    if (zc.acc != quot * zh) { *err = std::string("constraint identity fails at zeta for chip ") + d.name; return 8; }
+    if (group_acc[c] != quot * zh) {
+      *err = std::string("constraint identity fails at zeta for the chips of height 2^") + std::to_string(logh[c]) + " (first: " + d.name + ")";
+      return 8;
+    }
   }
 
   // ---- FRI transcript ----
@@ -588,7 +602,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   size_t n1[kNumChips], n2[kNumChips];
   for (int c = 0; c < kNumChips; ++c) {
     const ChipDef& d = chip_def(c);
-    n1[c] = (size_t)d.prep_w + d.main_w + d.perm_width() + 8;
+    n1[c] = (size_t)d.prep_w + d.main_w + d.perm_width() + (size_t)quot_width(logh, c);
     n2[c] = (size_t)d.main_w + d.perm_width();
     b1[c] = b2[c] = Fp4::zero();
     for (size_t i = 0; i < n1[c]; ++i) b1[c] += afpow[open_off[c] + i] * opened[open_off[c] + i];
