@@ -660,21 +660,22 @@ __global__ __launch_bounds__(kThreads) void open_combine_kernel(const uint32_t* 
 }
 // Narrow tall matrices (a 2^19-row permutation trace has 32 columns, a quotient 8): the lane-per-coefficient kernel
 // with the coefficient range split over blockIdx.y, partial sums in open_tall_kernel's layout.
+template <int NC>
 __global__ __launch_bounds__(kThreads) void open_split_kernel(const uint32_t* __restrict__ coefs, size_t coefs_stride,
                                                              int ncols, int logh, const uint32_t* __restrict__ zpow,
                                                              size_t zpow_stride, int npoints, int klen,
                                                              uint32_t* __restrict__ partial, int nsplit) {
   __shared__ Fp4 red[kThreads / 64];
   const int h = 1 << logh;
-  const int col0 = blockIdx.x * kOpenCols, split = blockIdx.y, b = blockIdx.z;
-  const int nc = min(kOpenCols, ncols - col0);
+  const int col0 = blockIdx.x * NC, split = blockIdx.y, b = blockIdx.z;
+  const int nc = min(NC, ncols - col0);
   const int kbeg = split * klen, kend = kbeg + klen;
   const uint32_t* cf = coefs + (size_t)b * coefs_stride + (size_t)col0 * h;
   const uint32_t* z0 = zpow + (size_t)b * zpow_stride;
   const uint32_t* z1 = z0 + (size_t)h * 4;
-  int64_t acc[kOpenCols][2][4];
+  int64_t acc[NC][2][4];
 #pragma unroll
-  for (int c = 0; c < kOpenCols; ++c)
+  for (int c = 0; c < NC; ++c)
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(kThreads) void open_split_kernel(const uint32_t* __
     const int32_t zz[2][4] = {{(int32_t)p0.x, (int32_t)p0.y, (int32_t)p0.z, (int32_t)p0.w},
                               {(int32_t)p1.x, (int32_t)p1.y, (int32_t)p1.z, (int32_t)p1.w}};
 #pragma unroll
-    for (int c = 0; c < kOpenCols; ++c) {
+    for (int c = 0; c < NC; ++c) {
       if (c < nc) {
         const int32_t cv = fps_centre(cf[(size_t)c * h + k]);
 #pragma unroll
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(kThreads) void open_split_kernel(const uint32_t* __
     }
     if (++pending == 8) {
 #pragma unroll
-      for (int c = 0; c < kOpenCols; ++c)
+      for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(kThreads) void open_split_kernel(const uint32_t* __
     }
   }
 #pragma unroll
-  for (int c = 0; c < kOpenCols; ++c) {
+  for (int c = 0; c < NC; ++c) {
     if (c >= nc) break;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -738,7 +739,9 @@ void launch_open_tall(hipStream_t stream, const uint32_t* coefs_br, size_t coefs
     hipLaunchKernelGGL(open_tall_kernel, dim3((ncols + kOpenTileCols - 1) / kOpenTileCols, nsplit, batch), dim3(kThreads), 0,
                        stream, coefs_br, coefs_stride, ncols, logh, zpow_br, zpow_stride, npoints, klen, scratch, nsplit);
   else
-    hipLaunchKernelGGL(open_split_kernel, dim3((ncols + kOpenCols - 1) / kOpenCols, nsplit, batch), dim3(kThreads), 0, stream,
+    // (eight columns per workgroup would halve the reads of the weight table, but measured 20 % slower on the CPU chip's
+    // 40- and 56-column matrices: 64 64-bit accumulators per lane)
+    hipLaunchKernelGGL(open_split_kernel<kOpenCols>, dim3((ncols + kOpenCols - 1) / kOpenCols, nsplit, batch), dim3(kThreads), 0, stream,
                        coefs_br, coefs_stride, ncols, logh, zpow_br, zpow_stride, npoints, klen, scratch, nsplit);
   hipLaunchKernelGGL(open_combine_kernel, dim3((ncols + kThreads - 1) / kThreads, batch), dim3(kThreads), 0, stream, scratch,
                      ncols, npoints, nsplit, opened, opened_stride, pt_stride);

@@ -126,7 +126,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   };
   // The first max_batch inputs are traced before anything else so that the GPU starts early; the rest are traced
   // by host threads while it proves them.
-  const size_t w0 = std::min<size_t>(n, std::max<size_t>(1, ctx->params.max_batch));
+  const size_t w0 = std::min<size_t>(n, std::max<size_t>(1, std::min<size_t>(ctx->params.max_batch, std::max<size_t>(16, (n + 3) / 4))));
   parallel_for(w0, 64, trace_one);
   mark.mark("traced", w0);
   std::string first_err;
@@ -186,7 +186,10 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       size_t mem_free = 0, mem_total = 0;
       if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = (size_t)64 << 30;
       const size_t budget = (mem_free + ctx->arena_bytes) / 5 * 4;
-      const size_t cap = std::max<size_t>(1, std::min<size_t>(ctx->params.max_batch, budget / std::max<size_t>(per_proof, 1)));
+      // ... and at least four chunks per call where the call is large enough, so that the upload of one chunk, the proving
+      // of another and the wrapping of a third overlap (256 runs with max_batch 128 go as four chunks of 64)
+      const size_t pipe = std::max<size_t>(16, (n + 3) / 4);
+      const size_t cap = std::max<size_t>(1, std::min({(size_t)ctx->params.max_batch, budget / std::max<size_t>(per_proof, 1), pipe}));
       for (size_t off = 0; off < kv.second.size(); off += cap) {
         Chunk ck;
         ck.lh = kv.first;
