@@ -197,7 +197,7 @@ def cpu_baseline(trace_of, first_s, seconds):
     n = len(times)
     return {"value": n / el, "unit": "proofs/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
             "repetitions": n, "median_s_per_proof": sorted(times)[n // 2], "min_s_per_proof": min(times),
-            "sample": f"{n} acct-d8 machine proofs (391 400 cycles, {zk.MACHINE_CHIPS} chips, two CPU instances of 2^18 and 2^17 rows, 100 queries) in {el:.1f} s; "
+            "sample": f"{n} acct-d8 machine proofs (391 400 cycles, {oracle.N_CHIPS} chips, two CPU instances of 2^18 and 2^17 rows, 100 queries) in {el:.1f} s; "
                       "reference SP1 CPU prover unavailable offline, CPU baseline is this repository's oracle/ restatement"}
 
 
