@@ -691,6 +691,14 @@ static void fill_ecall(const orc_machine_input* in, size_t h, uint32_t* t) {
     T(EC_C_LO) = c & 0xffff; T(EC_C_HI) = c >> 16; T(EC_M_LO) = m & 0xffff; T(EC_M_HI) = m >> 16;
     const uint32_t g0 = ts - cy[8], g1 = ts + 1 - cy[9];
     T(EC_GAP) = g0 & 0xffff; T(EC_GAP + 1) = g0 >> 16; T(EC_GAP + 2) = g1 & 0xffff; T(EC_GAP + 3) = g1 >> 16;
+    /* soundness tests: ZKSP_ORACLE_ECALL_NP=<row> sends that (non-HALT) ecall to the padding instruction - the CPU row
+     * goes on at pc + 4, so the ECALL bus cannot balance; ZKSP_ORACLE_ECALL_FLAG=<row> decodes that ecall as the next
+     * syscall in the list - the code in t0 no longer matches the flags */
+    const char* hk = getenv("ZKSP_ORACLE_ECALL_NP");
+    if (hk && r == (size_t)strtoull(hk, NULL, 10) && b != 0x00) T(EC_NP) = pad_pc;
+    hk = getenv("ZKSP_ORACLE_ECALL_FLAG");
+    if (hk && r == (size_t)strtoull(hk, NULL, 10))
+      for (int k = 0; k < 6; ++k) if (b == codes[k]) { T(EC_SC + k) = 0; T(EC_SC + (k + 1) % 6) = 1; }
 #undef T
   }
   free(ev);
@@ -738,6 +746,14 @@ static void fill_sub(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
       const uint32_t sb = code == OP_LB ? (m >> (8 * off)) & 0xff : (m >> (8 * (off | 1))) & 0xff;
       T(SW_SELB) = sb;
       T(SW_S) = sb >> 7;
+      /* soundness tests: ZKSP_ORACLE_SUB_SIGN=<row> claims the other sign for that signed load (and extends it): the
+       * table chip has no byte-operation row (and, byte, 0x80, 128 * sign) for it */
+      const char* hk = getenv("ZKSP_ORACLE_SUB_SIGN");
+      if (hk && row0 + r == (size_t)strtoull(hk, NULL, 10)) {
+        const uint32_t s2 = (sb >> 7) ^ 1u, lo = code == OP_LB ? (sb | (s2 ? 0xff00u : 0u)) : (a & 0xffff);
+        T(SW_S) = s2;
+        T(SW_A) = lo; T(SW_A + 1) = s2 ? 0xffffu : 0u;
+      }
     }
 #undef T
   }

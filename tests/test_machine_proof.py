@@ -167,6 +167,41 @@ def test_wrong_bitwise_chip_row_alone_is_rejected(zk, oracle, setup):
     assert "balance" in str(ei.value)
 
 
+def _hook_rejected(zk, oracle, client, vk, t, name, value, needle=None):
+    os.environ[name] = value
+    try:
+        with pytest.raises(RuntimeError):
+            oracle.machine_prove(t, num_queries=NQ, pow_bits=POW)
+        forged = forced_proof(oracle, t)
+    finally:
+        del os.environ[name]
+    with pytest.raises(zk.VerificationError) as ei:
+        client.verify(zk.SP1ProofWithPublicValues.from_bytes(forged), vk)
+    if needle:
+        assert needle in str(ei.value), str(ei.value)
+
+
+def test_ecall_chip_cannot_redirect_or_redecode(zk, oracle, setup):
+    """The ecall chip decides an ecall's next pc and decodes its code, but both are tied to the CPU row: an ecall chip
+    row that sends a COMMIT to the padding instruction (as if it were HALT) leaves the ECALL bus unbalanced - the CPU
+    row went on at pc + 4 -, and one that raises another syscall's flag contradicts the code in t0."""
+    client, vk, t, _ = setup
+    _hook_rejected(zk, oracle, client, vk, t, "ZKSP_ORACLE_ECALL_NP", "3", "balance")
+    _hook_rejected(zk, oracle, client, vk, t, "ZKSP_ORACLE_ECALL_FLAG", "3")  # (the buses or the constraint, whichever is checked first)
+
+
+def test_subword_sign_is_bound_to_its_byte(zk, oracle, setup):
+    """A signed byte load that extends the wrong sign: the sub-word chip's sign column is only as free as the table
+    chip's byte-operation rows allow (byte AND 0x80 = 128 * sign), so the lookup has no row to meet."""
+    client, vk, t, _ = setup
+    cyc, prog = t["cycles"], t["program"]
+    rows = prog[(cyc[:, 0] - prog[0, 0]) // 4]
+    sub = np.nonzero(np.isin(rows[:, 1], (19, 20, 22, 23, 24, 25)))[0]  # lb lh lbu lhu sb sh: the sub-word chip's rows
+    signed = [k for k, i in enumerate(sub) if rows[i, 1] in (19, 20)]
+    assert signed, "the fixture executes no signed sub-word load"
+    _hook_rejected(zk, oracle, client, vk, t, "ZKSP_ORACLE_SUB_SIGN", str(signed[0]), "balance")
+
+
 def test_wrong_subword_store_is_rejected(zk, oracle, setup):
     """A byte store that leaves another word behind than the old word with one byte replaced."""
     client, vk, t, _ = setup
