@@ -55,7 +55,7 @@ typedef struct {
 } zksp_options;
 /* What zksp_prove / zksp_prove_batch establish:
  * MACHINE      the guest's whole execution (CPU, memory, program, keccak, multiplier chips joined by
- *              LogUp buses; proof format v10): the statement of the reference's client.prove().
+ *              LogUp buses; proof format v11): the statement of the reference's client.prove().
  * KECCAK_CHIP  only "these keccak-f outputs belong to these inputs" (round-1 format v2, a component
  *              benchmark; NOT a proof that the guest ran). */
 #define ZKSP_PROOF_MACHINE 1
@@ -188,6 +188,14 @@ int zksp_proof_aggregation(const zksp_proof* p, uint32_t* n_leaves, uint32_t* ro
 /* client.verify for a proof with an aggregation payload: additionally, the root in the proof is the Poseidon2 Merkle root of
  * exactly these leaves.  (zksp_verify refuses such a proof: it cannot vouch for a root whose leaves it was not given.) */
 int zksp_verify_aggregate(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const uint32_t* leaves /* [n][8] */, size_t n);
+/* The same payload with the digests supplied at heap keys of the caller's choice (root 1, children 2K and 2K + 1; keys
+ * below 2^30, none an ancestor of another, every ancestor with both children supplied or derived): keys NULL means n + j, the
+ * leaves of a full tree; a leaf at key 2^d + i with sibling j at key ((2^d + i) >> j) ^ 1 makes the proof establish a
+ * MERKLE PATH - "this leaf, hashed up along these siblings at position i, gives the header's root" (the building block of
+ * an in-circuit FRI / MMCS verifier; reference stub: circuits/sp1-merkle-proof-recursive/src/main.rs:3-5). */
+int zksp_stdin_set_aggregation_keyed(zksp_stdin* s, const uint32_t* keys /* [n] or NULL */, const uint32_t* digests /* [n][8] */, size_t n);
+int zksp_verify_aggregate_keyed(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const uint32_t* keys /* [n] or NULL */,
+                                const uint32_t* digests /* [n][8] */, size_t n);
 /* Kernel-level parity (tests): after zksp_hip_machine_prove, one intermediate matrix of resident proof `proof_index`, as
  * canonical u32, column-major [width][2^log_height]: stage 0 = a chip's main trace (trace expansion kernels; table chip:
  * the counted multiplicities), 1 = its LogUp permutation trace (helper columns + running sum), 2 = its quotient values
@@ -195,7 +203,7 @@ int zksp_verify_aggregate(zksp_client* c, const zksp_proof* p, const zksp_vk* vk
  * cumulative sums (4 words each), as the device's transcript sampled / computed them. */
 int zksp_hip_machine_fetch_stage(zksp_client* c, int chip, int stage, size_t proof_index, uint32_t* out, size_t cap_words);
 int zksp_hip_machine_fetch_challenges(zksp_client* c, size_t proof_index, uint32_t* out /* [16 + 4 * ZKSP_MACHINE_CHIPS] */);
-/* Complete v10 proof object from one fetched body and the trace it belongs to.  log_heights: the shape the batch was
+/* Complete v11 proof object from one fetched body and the trace it belongs to.  log_heights: the shape the batch was
  * proven with (zksp_machine_cover_heights of the loaded traces), NULL = the trace's own minimal heights. */
 int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] or NULL */,
                                  const uint32_t* body, size_t body_words, zksp_proof** out);

@@ -1,6 +1,6 @@
 /* ORACLE -- TEST INFRASTRUCTURE ONLY (see field.h and machine.h).
  *
- * Chips of the machine proof (format v10): bus interactions, trace generation from the executor's
+ * Chips of the machine proof (format v11): bus interactions, trace generation from the executor's
  * records and base-field constraints.  This repository's own arithmetisation (machine.h header
  * note); what it must reproduce is the reference's statement: the committed RV32IM guest
  * (circuits/sp1-merkle-proof/src/main.rs:4-14 running crypto-ops/src/lib.rs:8-23) executed from its
@@ -103,7 +103,7 @@ static orc_lf lf_bits(int bits, int n) {
 
 #define CPU_INTER 21
 static orc_inter g_cpu[CPU_INTER], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7],
-    g_alu[1], g_sub[5], g_bw[5], g_p2[3], g_ecall[10];
+    g_alu[1], g_sub[5], g_bw[5], g_p2[5], g_ecall[10];
 static orc_chip g_chips[N_CHIPS];
 static int g_ready = 0;
 
@@ -377,17 +377,21 @@ static void build(void) {
       orc_inter* it = &g_p2[side];
       memset(it, 0, sizeof *it);
       it->bus = BUS_DIGEST; it->sign = -1; it->mult = lf_col(P2_IS_REAL); it->n_el = 9;
-      lf_zero(&it->el[0]); lf_add(&it->el[0], P2_K, 2); it->el[0].c0 = (uint32_t)side;
+      lf_zero(&it->el[0]); lf_add(&it->el[0], P2_KL, 2); lf_add(&it->el[0], P2_KH, 2 * 65536); it->el[0].c0 = (uint32_t)side;
       for (int j = 0; j < 8; ++j) it->el[1 + j] = lf_col(P2_IN + 8 * side + j);
     }
     orc_inter* it = &g_p2[2];
     memset(it, 0, sizeof *it);
     it->bus = BUS_DIGEST; it->sign = +1; it->mult = lf_col(P2_IS_REAL); it->n_el = 9;
-    it->el[0] = lf_col(P2_K);
+    it->el[0] = lf_pair(P2_KL, P2_KH, 65536);
     for (int j = 0; j < 8; ++j) {
       lf_zero(&it->el[1 + j]);
       for (int i = 0; i < 16; ++i) lf_add(&it->el[1 + j], ylast + i, m4[j & 3][i & 3] * ((i >> 2) == (j >> 2) ? 2u : 1u));
     }
+    /* the key's limbs: 16 bits, and twice the high limb at most ADDR_HI_MAX (kind 2): the key stays below 0x3C000000 and
+     * its children's keys 2K, 2K + 1 below 0x78000000 < p - no key aliases another mod p */
+    g_p2[3] = range_inter(-1, lf_col(P2_IS_REAL), lf_const(0), lf_col(P2_KL));
+    { orc_lf kh2; lf_zero(&kh2); lf_add(&kh2, P2_KH, 2); g_p2[4] = range_inter(-1, lf_col(P2_IS_REAL), lf_const(2), kh2); }
   }
   /* ---- sub-word ---- */
   {
@@ -427,7 +431,7 @@ static void build(void) {
   g_chips[CH_SUB2] = (orc_chip){"subword2", 0, SUB_WIDTH, 5, g_sub, 0, 0};
   g_chips[CH_BW] = (orc_chip){"bitwise", 0, BW_WIDTH, 5, g_bw, 0, 0};
   g_chips[CH_BW2] = (orc_chip){"bitwise2", 0, BW_WIDTH, 5, g_bw, 0, 0};
-  g_chips[CH_P2] = (orc_chip){"poseidon2", 0, P2CHIP_WIDTH, 3, g_p2, 0, 0};
+  g_chips[CH_P2] = (orc_chip){"poseidon2", 0, P2CHIP_WIDTH, 5, g_p2, 0, 0};
   g_chips[CH_ECALL] = (orc_chip){"ecall", 0, ECALL_WIDTH, 10, g_ecall, 0, 0};
   g_ready = 1;
   for (int c = 0; c < N_CHIPS; ++c) g_chips[c].n_constraints = count_constraints(c);
@@ -521,7 +525,10 @@ void orc_machine_heights(const orc_machine_input* in, int logh[N_CHIPS]) {
   logh[CH_PROGRAM] = in->log_prog;
   logh[CH_MUL] = at_least5(clog2(in->n_muls));
   logh[CH_TABLE] = TABLE_LOG_H;
-  logh[CH_P2] = at_least5(clog2(in->n_agg > 1 ? in->n_agg - 1 : 1));
+  {
+    const size_t rows = orc_machine_agg_rows(in->agg_keys, in->agg_leaves, in->n_agg, NULL); /* one per ancestor of a supplied key */
+    logh[CH_P2] = at_least5(clog2(rows == (size_t)-1 || rows == 0 ? 1 : rows));
+  }
   logh[CH_ECALL] = at_least5(clog2(orc_machine_events(in, 3, NULL)));
 }
 
@@ -766,8 +773,8 @@ static void fill_table_mults(const orc_machine_input* in, uint32_t* t) {
   const size_t ht = (size_t)1 << TABLE_LOG_H;
   int logh[N_CHIPS];
   orc_machine_heights(in, logh);
-  static const int users[9] = {CH_CPU, CH_CPU2, CH_KMEM, CH_MEMFINAL, CH_BW, CH_BW2, CH_SUB, CH_SUB2, CH_ECALL};
-  for (int u = 0; u < 9; ++u) {
+  static const int users[10] = {CH_CPU, CH_CPU2, CH_KMEM, CH_MEMFINAL, CH_BW, CH_BW2, CH_SUB, CH_SUB2, CH_ECALL, CH_P2};
+  for (int u = 0; u < 10; ++u) {
     const int chip = users[u];
     const orc_chip* ch = &g_chips[chip];
     const size_t h = (size_t)1 << logh[chip];
@@ -923,20 +930,19 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
       }
       break;
     case CH_P2: {
-      /* heap of digests: leaves at n .. 2n - 1, node K = compress(2K, 2K + 1) */
-      const size_t na = in->n_agg;
-      uint32_t* heap = (uint32_t*)calloc(16 * (na ? na : 1), 4);
-      if (na) {
-        memcpy(heap + 8 * na, in->agg_leaves, 32 * na);
-        for (size_t k = na - 1; k >= 1; --k) orc_compress(heap + 16 * k, heap + 16 * k + 8, heap + 8 * k);
-      }
+      /* one row per ancestor of a supplied key, ascending: the node's key, its children's digests in, its own out */
+      size_t nr = orc_machine_agg_rows(in->agg_keys, in->agg_leaves, in->n_agg, NULL);
+      if (nr == (size_t)-1) nr = 0;
+      uint32_t* rows = (uint32_t*)calloc(25 * (nr ? nr : 1), 4);
+      if (nr) orc_machine_agg_rows(in->agg_keys, in->agg_leaves, in->n_agg, rows);
       uint32_t ext_rc[8][16], int_rc[13];
       orc_poseidon2_constants(&ext_rc[0][0], int_rc);
       for (size_t r = 0; r < h; ++r) {
-        const size_t k = r + 1;
         uint32_t st[16] = {0};
-        T(P2_K) = (uint32_t)k;
-        if (na && k < na) { T(P2_IS_REAL) = 1; memcpy(st, heap + 16 * k, 64); }
+        if (r < nr) {
+          T(P2_IS_REAL) = 1; T(P2_KL) = rows[25 * r] & 0xffff; T(P2_KH) = rows[25 * r] >> 16;
+          memcpy(st, rows + 25 * r + 1, 64);
+        }
         for (int i = 0; i < 16; ++i) T(P2_IN + i) = st[i];
         orc_p2_external_linear(st);
         for (int rd = 0; rd < 8; ++rd) {
@@ -954,9 +960,9 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
           }
           orc_p2_external_linear(st);
         }
-        if (na && k < na && memcmp(st, heap + 8 * k, 32) != 0) abort(); /* the row's permutation is the node's compression */
+        if (r < nr && memcmp(st, rows + 25 * r + 17, 32) != 0) abort(); /* the row's permutation is the node's compression */
       }
-      free(heap);
+      free(rows);
       break;
     }
     case CH_TABLE:
@@ -1220,9 +1226,8 @@ static void bw_constraints(const uint32_t* l, sink* s) {
 static void p2_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe is_trans, sink* s) {
   uint32_t ext_rc[8][16], int_rc[13];
   orc_poseidon2_constants(&ext_rc[0][0], int_rc);
+  (void)is_first;
   emit(s, bool_c(l[P2_IS_REAL]));
-  emit(s, f_mul(is_first, f_sub(l[P2_K], 1)));
-  emit(s, f_mul(is_trans, f_sub(f_sub(n[P2_K], l[P2_K]), 1)));
   emit(s, f_mul(f_mul(is_trans, n[P2_IS_REAL]), f_sub(1, l[P2_IS_REAL]))); /* the real rows are a prefix */
   fe st[16];
   for (int i = 0; i < 16; ++i) st[i] = l[P2_IN + i];

@@ -11,7 +11,7 @@
  * (circuits/sp1-merkle-proof/src/main.rs:4-14, crypto-ops/src/lib.rs:8-23) ran to HALT(0) and
  * committed these public values.
  *
- * Format v10 (round 3).  The CPU row no longer carries its operands as bits: it holds 16-bit limbs,
+ * Format v11 (round 3).  The CPU row no longer carries its operands as bits: it holds 16-bit limbs,
  * adds / subtracts / compares (equality, unsigned order) / moves words itself, and sends xor / or /
  * and to a bitwise chip (bytes, looked up in a byte-operation table), shifts and signed less-than to
  * an ALU chip (bits) and every sub-word load or store to a sub-word chip, each with one row per such
@@ -129,11 +129,13 @@ enum {
   SUB_WIDTH = SW_SELB + 1
 };
 /* ---- Poseidon2 chip (row f4, stage 1): one width-16 permutation per row = one 2-to-1 compression of a Merkle tree of
- *      8-word digests.  Row r holds heap node K = r + 1 (root 1, children 2K and 2K + 1, the n leaves at n .. 2n - 1): it
- *      consumes its children's digests from the DIGEST bus and produces its own; the verifier supplies the leaves and
- *      takes the root.  Columns: the input state, and per S-box its cube and its seventh power (degree <= 3). ---- */
+ *      8-word digests.  A row holds a node K of a binary heap (root 1, children 2K and 2K + 1; K as two range-checked limbs,
+ *      below 0x78000000): it consumes its children's digests from the DIGEST bus and produces its own.  The verifier
+ *      supplies digests at keys of its choice and takes the root: all n leaves of a tree (keys n .. 2n - 1: the aggregation
+ *      root), or one leaf and the siblings along its path (a Merkle path).  The rows are the ancestors of the supplied
+ *      keys, in ascending order.  Columns: the input state, and per S-box its cube and its seventh power (degree <= 3). ---- */
 enum {
-  P2_IS_REAL = 0, P2_K, P2_IN /* 16 */, P2_EXT = P2_IN + 16 /* 8 external rounds x (16 cubes, 16 outputs) */,
+  P2_IS_REAL = 0, P2_KL, P2_KH /* the node's key, two limbs */, P2_IN /* 16 */, P2_EXT = P2_IN + 16 /* 8 external rounds x (16 cubes, 16 outputs) */,
   P2_INT = P2_EXT + 256 /* 13 internal rounds x (cube, output) */, P2CHIP_WIDTH = P2_INT + 26
 };
 /* ---- table chip: 2^16 rows; preprocessed (x = low byte, y = high byte, na = row index not a multiple of 4,
@@ -203,6 +205,7 @@ typedef struct {
   const uint32_t* prog_mult;                   /* n_program; the padding row holds 0 (its fetches depend on the heights) */
   const int* shape;                            /* NULL: the minimal heights; else N_CHIPS log heights the run fits (a batch of
                                                   runs is proven with one shape: the heights of their largest counts) */
+  const uint32_t* agg_keys;                    /* heap keys of the payload's digests (NULL: n_agg + j, the leaves of a full tree) */
   const uint32_t* agg_leaves; size_t n_agg;    /* aggregation payload: n_agg (0, or a power of two >= 2) digests of 8 words
                                                   whose Poseidon2 Merkle root the proof also establishes */
 } orc_machine_input;
@@ -243,7 +246,15 @@ typedef struct {
 /* the aggregation payload's public part: Merkle root of the leaves (2-to-1 Poseidon2 compressions) and the sponge hash
  * of the leaf list, which stands for the list in the transcript */
 void orc_machine_agg_public(const uint32_t* leaves, size_t n, uint32_t root[8], uint32_t list_digest[8]);
-#define ZKSP_VERSION_MACHINE 10u
+/* the same for digests supplied at heap keys (keys NULL: n + j): the root is node 1's digest, the list digest covers keys and
+ * digests.  Returns 0 if the supplied set is malformed (a repeated or out-of-range key, an ancestor that is itself supplied
+ * or lacks a child). */
+int orc_machine_nodes_public(const uint32_t* keys, const uint32_t* digests, size_t n, uint32_t root[8], uint32_t list_digest[8]);
+/* the rows of the Poseidon2 chip for a supplied set: every ancestor of a supplied key in ascending order, 25 words each
+ * (key, left child's digest, right child's digest, own digest).  Returns the number of rows, (size_t)-1 if malformed;
+ * rows may be NULL. */
+size_t orc_machine_agg_rows(const uint32_t* keys, const uint32_t* digests, size_t n, uint32_t* rows);
+#define ZKSP_VERSION_MACHINE 11u
 /* vk: preprocessed commitment root + digest binding entry pc, table heights and keccak mode */
 void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t prep_root[8], uint32_t vk_digest[8]);
 size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_image, const orc_config* cfg, uint32_t pv_len);

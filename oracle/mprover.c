@@ -3,7 +3,7 @@
  * Whole machine proof on the CPU: the multi-table STARK that sp1-stark / sp1-prover 3.4.0 build over
  * p3-uni-stark, p3-fri, p3-merkle-tree (mixed-height MMCS) and p3-challenger (reference
  * Cargo.lock:7485, :7273, :5378, :5253, :5336, :5197) beneath `client.prove(&pk, stdin).run()`
- * (prover/src/bin/main.rs:71-74), restated under this repository's own format "ZKSP v10"
+ * (prover/src/bin/main.rs:71-74), restated under this repository's own format "ZKSP v11"
  * (DESIGN.md "Machine proof").  PARITY UNPINNED vs SP1 proof bytes.  The HIP prover must
  * reproduce these bytes exactly.
  *
@@ -452,6 +452,7 @@ void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t pr
   tmp.prog_mult = NULL;
   tmp.shape = NULL;
   tmp.agg_leaves = NULL;
+  tmp.agg_keys = NULL;
   tmp.n_agg = 0;
   tmp.n_cycles = tmp.n_keccak = tmp.n_memfinal = tmp.n_muls = 0;
   init_chips(&tmp, cd, 1);
@@ -466,21 +467,93 @@ void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t pr
 /* magic, version, heights, exit code, pv length, 3 digests, hand-over pc; aggregation: leaf count, root, digest of the leaf list */
 #define HEADER_WORDS (2 + N_CHIPS + 2 + 24 + 1 + 17)
 
-void orc_machine_agg_public(const uint32_t* leaves, size_t n, uint32_t root[8], uint32_t list_digest[8]) {
+typedef struct { uint32_t key; int have; uint32_t d[8]; } agg_node;
+static int agg_node_cmp(const void* x, const void* y) {
+  const uint32_t a = ((const agg_node*)x)->key, b = ((const agg_node*)y)->key;
+  return a < b ? -1 : a > b;
+}
+static agg_node* agg_find(agg_node* v, size_t n, uint32_t key) {
+  agg_node probe;
+  probe.key = key;
+  return (agg_node*)bsearch(&probe, v, n, sizeof(agg_node), agg_node_cmp);
+}
+size_t orc_machine_agg_rows(const uint32_t* keys, const uint32_t* digests, size_t n, uint32_t* rows) {
+  if (n == 0) return 0;
+  /* supplied nodes and their ancestors, one entry per key */
+  size_t cap = n * 32 + 1, cnt = 0;
+  agg_node* v = (agg_node*)malloc(cap * sizeof(agg_node));
+  for (size_t j = 0; j < n; ++j) {
+    const uint32_t key = keys ? keys[j] : (uint32_t)(n + j);
+    if (key < 2 || key >= (1u << 30)) { free(v); return (size_t)-1; }
+    v[cnt].key = key; v[cnt].have = 1; memcpy(v[cnt].d, digests + 8 * j, 32); ++cnt;
+  }
+  qsort(v, cnt, sizeof(agg_node), agg_node_cmp);
+  for (size_t j = 1; j < cnt; ++j) if (v[j].key == v[j - 1].key) { free(v); return (size_t)-1; }
+  const size_t n_sup = cnt;
+  for (size_t j = 0; j < n_sup; ++j)
+    for (uint32_t k = v[j].key >> 1; k >= 1; k >>= 1) {
+      /* (ancestors are appended unsorted, duplicates and all, then sorted and deduplicated) */
+      if (cnt == cap) { cap *= 2; v = (agg_node*)realloc(v, cap * sizeof(agg_node)); }
+      v[cnt].key = k; v[cnt].have = 0; ++cnt;
+      if (k == 1) break;
+    }
+  /* supplied entries first among equal keys: a supplied key that is also an ancestor is malformed */
+  qsort(v, cnt, sizeof(agg_node), agg_node_cmp);
+  size_t m = 0;
+  for (size_t j = 0; j < cnt; ++j) {
+    if (m && v[m - 1].key == v[j].key) {
+      if (v[j].have || v[m - 1].have) { free(v); return (size_t)-1; }
+      continue;
+    }
+    v[m++] = v[j];
+  }
+  cnt = m;
+  size_t n_rows = 0;
+  for (size_t j = cnt; j-- > 0;) { /* descending keys: children before parents */
+    if (v[j].have) continue;
+    agg_node *l = agg_find(v, cnt, 2 * v[j].key), *r = agg_find(v, cnt, 2 * v[j].key + 1);
+    if (!l || !r || !l->have || !r->have) { free(v); return (size_t)-1; }
+    orc_compress(l->d, r->d, v[j].d);
+    v[j].have = 2; /* computed */
+    ++n_rows;
+  }
+  if (rows) {
+    size_t r = 0;
+    for (size_t j = 0; j < cnt; ++j) { /* ascending keys: the root first */
+      if (v[j].have != 2) continue;
+      uint32_t* o = rows + 25 * r++;
+      o[0] = v[j].key;
+      memcpy(o + 1, agg_find(v, cnt, 2 * v[j].key)->d, 32);
+      memcpy(o + 9, agg_find(v, cnt, 2 * v[j].key + 1)->d, 32);
+      memcpy(o + 17, v[j].d, 32);
+    }
+  }
+  free(v);
+  return n_rows;
+}
+int orc_machine_nodes_public(const uint32_t* keys, const uint32_t* digests, size_t n, uint32_t root[8], uint32_t list_digest[8]) {
   memset(root, 0, 32);
   memset(list_digest, 0, 32);
-  if (n == 0) return;
-  uint32_t* level = (uint32_t*)malloc(32 * n);
-  memcpy(level, leaves, 32 * n);
-  for (size_t cnt = n; cnt > 1; cnt >>= 1)
-    for (size_t i = 0; i < cnt / 2; ++i) {
-      uint32_t d[8];
-      orc_compress(level + 16 * i, level + 16 * i + 8, d);
-      memcpy(level + 8 * i, d, 32);
-    }
-  memcpy(root, level, 32);
-  free(level);
-  orc_hash_elems(leaves, 8 * n, list_digest);
+  if (n == 0) return 1;
+  const size_t n_rows = orc_machine_agg_rows(keys, digests, n, NULL);
+  if (n_rows == (size_t)-1 || n_rows == 0) return 0;
+  uint32_t* rows = (uint32_t*)malloc(n_rows * 25 * 4);
+  orc_machine_agg_rows(keys, digests, n, rows);
+  memcpy(root, rows + 17, 32); /* row 0 is key 1 */
+  const int ok = rows[0] == 1;
+  free(rows);
+  /* the list in the transcript: every key with its digest */
+  uint32_t* flat = (uint32_t*)malloc(n * 9 * 4);
+  for (size_t j = 0; j < n; ++j) {
+    flat[9 * j] = keys ? keys[j] : (uint32_t)(n + j);
+    memcpy(flat + 9 * j + 1, digests + 8 * j, 32);
+  }
+  orc_hash_elems(flat, 9 * n, list_digest);
+  free(flat);
+  return ok;
+}
+void orc_machine_agg_public(const uint32_t* leaves, size_t n, uint32_t root[8], uint32_t list_digest[8]) {
+  if (!orc_machine_nodes_public(NULL, leaves, n, root, list_digest)) { memset(root, 0, 32); memset(list_digest, 0, 32); }
 }
 
 size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_image, const orc_config* cfg, uint32_t pv_len) {
@@ -518,9 +591,8 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   int lm = 0; /* the tallest chip: every tree and the FRI start from its height */
   for (int c = 0; c < N_CHIPS; ++c)
     if (logh[c] > lm) lm = logh[c];
-  if (in->n_agg == 1 || (in->n_agg & (in->n_agg - 1))) return 1; /* the aggregation payload is a power of two of leaves, or empty */
   uint32_t agg_n = (uint32_t)in->n_agg, agg_root[8], agg_digest[8];
-  orc_machine_agg_public(in->agg_leaves, in->n_agg, agg_root, agg_digest);
+  if (!orc_machine_nodes_public(in->agg_keys, in->agg_leaves, in->n_agg, agg_root, agg_digest)) return 1; /* malformed payload */
   uint32_t cpu_pub[N_CHIPS][CPUPUB_N];
   memset(cpu_pub, 0, sizeof cpu_pub);
   orc_machine_cpu_pub(in, CH_CPU, cpu_pub[CH_CPU]);
@@ -606,12 +678,12 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
     it.el[1].n = 0; it.el[1].c0 = pub->exit_code >> 16;
     build_aff(&it, gamma, bpow, &a);
     total = e_sub(total, e_inv(a.c0));
-    /* ... and the digest bus of the aggregation payload: the verifier hands in the leaves (heap nodes n .. 2n - 1) and
-     * takes the root (node 1) */
+    /* ... and the digest bus of the aggregation payload: the verifier hands in the supplied nodes (the leaves of a full tree
+     * at heap nodes n .. 2n - 1, or a leaf and the siblings along its path) and takes the root (node 1) */
     it.bus = BUS_DIGEST; it.n_el = 9;
     for (size_t i = 0; i <= in->n_agg && in->n_agg; ++i) {
       const uint32_t* d = i < in->n_agg ? in->agg_leaves + 8 * i : agg_root;
-      it.el[0].n = 0; it.el[0].c0 = i < in->n_agg ? (uint32_t)(in->n_agg + i) : 1u;
+      it.el[0].n = 0; it.el[0].c0 = i < in->n_agg ? (in->agg_keys ? in->agg_keys[i] : (uint32_t)(in->n_agg + i)) : 1u;
       for (int j = 0; j < 8; ++j) { it.el[1 + j].n = 0; it.el[1 + j].c0 = d[j]; }
       build_aff(&it, gamma, bpow, &a);
       total = i < in->n_agg ? e_add(total, e_inv(a.c0)) : e_sub(total, e_inv(a.c0));

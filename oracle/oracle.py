@@ -296,7 +296,7 @@ class MachineInput(C.Structure):
                 ("entry", C.c_uint32), ("text_base", C.c_uint32), ("log_prog", C.c_int), ("log_image", C.c_int),
                 ("cycles", C.c_void_p), ("n_cycles", C.c_size_t), ("keccak", C.c_void_p), ("n_keccak", C.c_size_t),
                 ("memfinal", C.c_void_p), ("n_memfinal", C.c_size_t), ("muls", C.c_void_p), ("n_muls", C.c_size_t),
-                ("prog_mult", C.c_void_p), ("shape", C.c_void_p), ("agg_leaves", C.c_void_p), ("n_agg", C.c_size_t)]
+                ("prog_mult", C.c_void_p), ("shape", C.c_void_p), ("agg_keys", C.c_void_p), ("agg_leaves", C.c_void_p), ("n_agg", C.c_size_t)]
 
 
 class MachinePublic(C.Structure):
@@ -320,6 +320,10 @@ def machine_input(t: dict):
         keep["agg_leaves"] = np.ascontiguousarray(t["agg_leaves"], dtype=np.uint32).reshape(-1, 8)
         mi.agg_leaves = keep["agg_leaves"].ctypes.data
         mi.n_agg = len(keep["agg_leaves"])
+        if t.get("agg_keys") is not None and len(t["agg_keys"]):
+            keep["agg_keys"] = np.ascontiguousarray(t["agg_keys"], dtype=np.uint32)
+            assert len(keep["agg_keys"]) == mi.n_agg
+            mi.agg_keys = keep["agg_keys"].ctypes.data
     if t.get("shape") is not None:
         keep["shape"] = np.ascontiguousarray(t["shape"], dtype=np.int32)
         assert len(keep["shape"]) == N_CHIPS
@@ -407,6 +411,25 @@ def machine_agg_public(leaves):
     root, dg = np.zeros(8, np.uint32), np.zeros(8, np.uint32)
     lib().orc_machine_agg_public(_p(lv), C.c_size_t(len(lv)), _p(root), _p(dg))
     return [int(x) for x in root], [int(x) for x in dg]
+
+
+def machine_nodes_public(keys, digests):
+    """(root, digest of the list) for digests supplied at heap keys, e.g. a leaf and the siblings along its Merkle path;
+    raises ValueError if the set is malformed."""
+    dv = np.ascontiguousarray(digests, dtype=np.uint32).reshape(-1, 8)
+    kv = np.ascontiguousarray(keys, dtype=np.uint32)
+    root, dg = np.zeros(8, np.uint32), np.zeros(8, np.uint32)
+    if not lib().orc_machine_nodes_public(_p(kv), _p(dv), C.c_size_t(len(dv)), _p(root), _p(dg)):
+        raise ValueError("malformed set of supplied nodes")
+    return [int(x) for x in root], [int(x) for x in dg]
+
+
+def merkle_path_nodes(index: int, leaf, siblings):
+    """Heap keys and digests of a Merkle path: the leaf at key 2^d + index, sibling j at key ((2^d + index) >> j) ^ 1."""
+    d = len(siblings)
+    k0 = (1 << d) + index
+    keys = [k0] + [(k0 >> j) ^ 1 for j in range(d)]
+    return np.array(keys, np.uint32), np.array([leaf] + list(siblings), np.uint32).reshape(-1, 8)
 
 
 def machine_setup(t: dict):

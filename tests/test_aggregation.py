@@ -98,3 +98,81 @@ def test_payload_sizes(zk, oracle, setup):
             s.set_aggregation(np.zeros((bad_n, 8), np.uint32))
     with pytest.raises(zk.ZkspError):
         s.set_aggregation(np.full((2, 8), P, np.uint32))  # not a canonical field word
+
+
+# ---- Merkle path: the same chip with digests supplied at heap keys of the caller's choice ----
+def _tree(oracle, leaves):
+    """heap of digests (dict key -> list of 8 ints) of the full tree over `leaves`"""
+    n = len(leaves)
+    heap = {n + i: [int(x) for x in leaves[i]] for i in range(n)}
+    for k in range(n - 1, 0, -1):
+        heap[k] = [int(x) for x in oracle.compress(np.array(heap[2 * k], np.uint32), np.array(heap[2 * k + 1], np.uint32))]
+    return heap
+
+
+@pytest.fixture(scope="module")
+def path_setup(zk, fx, oracle, setup):
+    client, vk, t, leaves, _ = setup
+    heap = _tree(oracle, leaves)
+    index, depth = 11, 4
+    k0 = (1 << depth) + index
+    siblings = [heap[(k0 >> j) ^ 1] for j in range(depth)]
+    keys, digests = zk.merkle_path_nodes(index, heap[k0], siblings)
+    t2 = dict(t, agg_leaves=digests, agg_keys=keys)
+    proof = oracle.machine_prove(t2, num_queries=NQ, pow_bits=POW)
+    return client, vk, t2, heap, index, siblings, proof
+
+
+def test_merkle_path_gives_the_tree_root(zk, oracle, path_setup):
+    """A leaf and the siblings along its path are enough: the proof's root is the root of the tree the path was cut
+    from (four rows of the Poseidon2 chip instead of fifteen), and the host verifier accepts it with that path only."""
+    client, vk, t2, heap, index, siblings, proof = path_setup
+    p = zk.SP1ProofWithPublicValues.from_bytes(proof)
+    n, root = p.aggregation
+    assert n == 5 and root == heap[1]
+    assert oracle.machine_heights(t2)[zk.MACHINE_CHIP_NAMES.index("poseidon2")] == 5
+    client.verify_merkle_path(p, vk, index, heap[16 + index], siblings)
+    assert p.public_values == t2["public_values"]
+
+
+def test_merkle_path_binds_leaf_position_and_siblings(zk, path_setup):
+    client, vk, t2, heap, index, siblings, proof = path_setup
+    p = zk.SP1ProofWithPublicValues.from_bytes(proof)
+    leaf = heap[16 + index]
+    with pytest.raises(zk.VerificationError):
+        client.verify(p, vk)
+    with pytest.raises(zk.VerificationError):
+        client.verify_merkle_path(p, vk, index ^ 1, leaf, siblings)  # the neighbouring position
+    with pytest.raises(zk.VerificationError):
+        client.verify_merkle_path(p, vk, index, heap[16 + (index ^ 1)], siblings)  # another leaf
+    bad = [list(s) for s in siblings]
+    bad[2][0] ^= 1
+    with pytest.raises(zk.VerificationError):
+        client.verify_merkle_path(p, vk, index, leaf, bad)
+    with pytest.raises(zk.VerificationError):
+        client.verify_merkle_path(p, vk, index & 7, leaf, siblings[:3])  # a shorter path
+    with pytest.raises(zk.VerificationError):
+        client.verify_aggregate(p, vk, np.array([leaf] + siblings, np.uint32)[:4])  # the digests read as tree leaves
+
+
+def test_malformed_node_sets_are_refused(zk, path_setup):
+    """Every ancestor of a supplied key needs both children, and no supplied node may be another's ancestor."""
+    client, vk, t2, heap, index, siblings, _ = path_setup
+    s = zk.SP1Stdin()
+    leaf = heap[16 + index]
+    keys, digests = zk.merkle_path_nodes(index, leaf, siblings)
+    lib = s._lib
+    C = __import__("ctypes")
+
+    def rc_of(k, d):
+        k, d = np.ascontiguousarray(k, np.uint32), np.ascontiguousarray(d, np.uint32)
+        return lib.zksp_stdin_set_aggregation_keyed(s._h, k.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), len(k))
+
+    assert rc_of(keys, digests) == 0
+    assert rc_of(keys[:-1], digests[:-1]) != 0  # the top sibling is missing: node 1 lacks a child
+    k2 = keys.copy()
+    k2[1] = k2[0]
+    assert rc_of(k2, digests) != 0  # a repeated key
+    k3 = keys.copy()
+    k3[2] = keys[0] >> 1
+    assert rc_of(k3, digests) != 0  # a supplied node that is the leaf's parent

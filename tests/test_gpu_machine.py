@@ -241,6 +241,46 @@ def test_aggregation_payload_matches_oracle(zk, fx, oracle):
                 host.verify(proof, vk)
 
 
+def test_merkle_path_payload_matches_oracle(zk, fx, oracle):
+    """The same chip with digests supplied at heap keys: a Merkle path (leaf 37 of a depth-7 tree: seven rows) proven on
+    the device next to a full-tree payload, both byte-identical to the oracle's and verified with their own inputs."""
+    nq, pw = 8, 6
+    client = zk.ProverClient(device=0, num_queries=nq, pow_bits=pw, max_batch=2)
+    pk, vk = client.setup(zk.merkle_elf())
+    rng = np.random.default_rng(5)
+    leaves = rng.integers(0, 2013265921, (128, 8), dtype=np.uint32)
+    heap = {128 + i: leaves[i] for i in range(128)}
+    for k in range(127, 0, -1):
+        heap[k] = np.array(oracle.compress(heap[2 * k], heap[2 * k + 1]), np.uint32)
+    index, depth = 37, 7
+    k0 = (1 << depth) + index
+    siblings = [heap[(k0 >> j) ^ 1] for j in range(depth)]
+    keys, digests = zk.merkle_path_nodes(index, heap[k0], siblings)
+    handles, traces = [], []
+    for i in range(2):
+        s = zk.SP1Stdin()
+        s.write(fx.acct_fixture(1, seed=40 + i).to_borsh())
+        if i == 0:
+            s.set_merkle_path(index, heap[k0], siblings)
+        else:
+            s.set_aggregation(leaves[:8])
+        handles.append(client.machine_trace_handle(pk, s))
+        t = client.machine_trace(pk, s)
+        traces.append(dict(t, agg_leaves=digests, agg_keys=keys) if i == 0 else dict(t, agg_leaves=leaves[:8]))
+    shape = zk.machine_cover_heights(handles)
+    bodies = client.machine_prove_resident(pk, handles)
+    host = zk.ProverClient(device=-1, num_queries=nq, pow_bits=pw)
+    proofs = [handles[i].proof_from_body(pk, bodies[i], shape) for i in range(2)]
+    for i in range(2):
+        assert proofs[i].to_bytes() == oracle.machine_prove(dict(traces[i], shape=shape), num_queries=nq, pow_bits=pw), i
+    assert proofs[0].aggregation == (depth + 1, [int(x) for x in heap[1]])
+    host.verify_merkle_path(proofs[0], vk, index, heap[k0], siblings)
+    with pytest.raises(zk.VerificationError):
+        host.verify_merkle_path(proofs[0], vk, index + 1, heap[k0], siblings)
+    host.verify_aggregate(proofs[1], vk, leaves[:8])
+
+
+
 def test_aggregate_1024_commitments(zk, fx, oracle):
     """BASELINE config 5's shape end to end through the drop-in calls: prove leaf proofs, gather their 32-byte main-trace
     commitments in proof order (what the farm all-gathers), and prove ONE more run whose aggregation payload is the whole

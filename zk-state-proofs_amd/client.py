@@ -29,14 +29,28 @@ ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_ELF, ERR_EXECUTOR, ERR_GUEST_PANIC,
     ERR_UNSUPPORTED = range(1, 10)
 KECCAK_SOFTWARE, KECCAK_OBSERVE, KECCAK_REPLACE = 0, 1, 2
 PROOF_MACHINE, PROOF_KECCAK_CHIP = 1, 2
-# machine proof (format version 10): chips in proof order and the fixed header in front of the public values
-MACHINE_VERSION = 10
+# machine proof (format version 11): chips in proof order and the fixed header in front of the public values
+MACHINE_VERSION = 11
 MACHINE_CHIP_NAMES = ("cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "table", "cpu2", "alu", "alu2",
                       "subword", "subword2", "bitwise", "bitwise2", "poseidon2", "ecall")
 MACHINE_CHIPS = len(MACHINE_CHIP_NAMES)
 # magic, version, heights, exit code, pv length, three digests, the hand-over pc of the two CPU instances, the aggregation
 # payload's leaf count, root and leaf-list digest
 MACHINE_HEADER_WORDS = 2 + MACHINE_CHIPS + 2 + 24 + 1 + 17
+
+
+def merkle_path_nodes(index: int, leaf, siblings):
+    """Heap keys and digests of a Merkle path: the leaf at key 2^d + index, sibling j (from the leaf's level up) at key
+    ((2^d + index) >> j) ^ 1 - what ``zksp_stdin_set_aggregation_keyed`` / ``zksp_verify_aggregate_keyed`` take."""
+    import numpy as np
+    sib = np.ascontiguousarray(siblings, dtype=np.uint32).reshape(-1, 8)
+    d = len(sib)
+    if not 0 <= index < (1 << d):
+        raise ValueError("index outside the tree")
+    k0 = (1 << d) + index
+    keys = np.array([k0] + [(k0 >> j) ^ 1 for j in range(d)], np.uint32)
+    digests = np.ascontiguousarray(np.vstack([np.asarray(leaf, np.uint32).reshape(1, 8), sib]), dtype=np.uint32)
+    return keys, digests
 
 
 class ZkspError(RuntimeError):
@@ -135,6 +149,8 @@ def load_library() -> C.CDLL:
     lib.zksp_stdin_set_aggregation.argtypes = [vp, vp, sz]
     lib.zksp_proof_aggregation.argtypes = [vp, vp, vp]
     lib.zksp_verify_aggregate.argtypes = [vp, vp, vp, vp, sz]
+    lib.zksp_stdin_set_aggregation_keyed.argtypes = [vp, vp, vp, sz]
+    lib.zksp_verify_aggregate_keyed.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.zksp_hip_machine_fetch_stage.argtypes = [vp, C.c_int, C.c_int, sz, vp, sz]
     lib.zksp_hip_machine_fetch_challenges.argtypes = [vp, sz, vp]
     lib.zksp_get_params.argtypes = [vp, C.POINTER(Params)]
@@ -176,7 +192,8 @@ ABI_SYMBOLS = [
     "zksp_proof_public_values", "zksp_proof_serialize", "zksp_proof_deserialize", "zksp_proof_free", "zksp_verify",
     "zksp_execute", "zksp_execute_keccak", "zksp_opcode_name", "zksp_machine_trace", "zksp_mtrace_free",
     "zksp_mtrace_section", "zksp_mtrace_info", "zksp_vk_machine", "zksp_mtrace_heights", "zksp_machine_body_words",
-    "zksp_machine_chip_widths", "zksp_machine_cover_heights", "zksp_stdin_set_aggregation", "zksp_proof_aggregation", "zksp_verify_aggregate", "zksp_hip_machine_fetch_stage", "zksp_hip_machine_fetch_challenges",
+    "zksp_machine_chip_widths", "zksp_machine_cover_heights", "zksp_stdin_set_aggregation", "zksp_proof_aggregation", "zksp_verify_aggregate",
+    "zksp_stdin_set_aggregation_keyed", "zksp_verify_aggregate_keyed", "zksp_hip_machine_fetch_stage", "zksp_hip_machine_fetch_challenges",
     "zksp_hip_machine_load", "zksp_hip_machine_prove", "zksp_hip_machine_fetch_bodies", "zksp_hip_machine_fetch_roots", "zksp_machine_proof_from_body", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
     "zksp_hip_prove_resident", "zksp_proof_from_body", "zksp_hip_fetch_bodies", "zksp_hip_fetch_roots", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
     "zksp_hip_profile_enable", "zksp_hip_profile_read", "zksp_hip_profile_reset", "zksp_dev_malloc", "zksp_dev_free",
@@ -208,6 +225,16 @@ class SP1Stdin:
         rc = self._lib.zksp_stdin_set_aggregation(self._h, lv.ctypes.data_as(C.c_void_p), len(lv))
         if rc:
             raise ZkspError(rc, "stdin_set_aggregation")
+
+    def set_merkle_path(self, index: int, leaf, siblings) -> None:
+        """Merkle-path payload (``zksp_stdin_set_aggregation_keyed``): the proof made from this stdin also establishes that
+        ``leaf`` (8 canonical words), hashed up along ``siblings`` ([d][8], from the leaf's level to just below the root)
+        at position ``index`` of a depth-d Poseidon2 Merkle tree, gives the root ``proof.aggregation`` reports."""
+        keys, digests = merkle_path_nodes(index, leaf, siblings)
+        rc = self._lib.zksp_stdin_set_aggregation_keyed(self._h, keys.ctypes.data_as(C.c_void_p), digests.ctypes.data_as(C.c_void_p),
+                                                        len(keys))
+        if rc:
+            raise ZkspError(rc, "stdin_set_aggregation_keyed")
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -431,6 +458,15 @@ class ProverClient:
         import numpy as np
         lv = np.ascontiguousarray(leaves, dtype=np.uint32).reshape(-1, 8)
         rc = self._lib.zksp_verify_aggregate(self._h, proof._h, vk._h, lv.ctypes.data_as(C.c_void_p), len(lv))
+        if rc:
+            raise VerificationError(rc, self.last_error())
+
+    def verify_merkle_path(self, proof: SP1ProofWithPublicValues, vk: VerifyingKey, index: int, leaf, siblings) -> None:
+        """``verify`` for a proof with a Merkle-path payload: additionally, ``proof.aggregation``'s root is what this leaf
+        gives when hashed up along these siblings at this position."""
+        keys, digests = merkle_path_nodes(index, leaf, siblings)
+        rc = self._lib.zksp_verify_aggregate_keyed(self._h, proof._h, vk._h, keys.ctypes.data_as(C.c_void_p),
+                                                   digests.ctypes.data_as(C.c_void_p), len(keys))
         if rc:
             raise VerificationError(rc, self.last_error())
 

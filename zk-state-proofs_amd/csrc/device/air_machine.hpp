@@ -113,8 +113,8 @@ static_assert(kSubWidth == 23, "sub-word chip layout");
 //      a Merkle tree of 8-word digests.  Row r holds heap node K = r + 1 (root 1, children 2K and 2K + 1, the n leaves at
 //      n .. 2n - 1): it consumes its children's digests from the DIGEST bus and produces its own; the verifier supplies
 //      the leaves and takes the root.  Columns: the input state, and per S-box its cube and its seventh power. ----
-constexpr int P2_IS_REAL = 0, P2_K = 1, P2_IN = 2, P2_EXT = P2_IN + 16, P2_INT = P2_EXT + 256, kP2Width = P2_INT + 26;
-static_assert(kP2Width == 300, "Poseidon2 chip layout");
+constexpr int P2_IS_REAL = 0, P2_KL = 1, P2_KH = 2, P2_IN = 3, P2_EXT = P2_IN + 16, P2_INT = P2_EXT + 256, kP2Width = P2_INT + 26;
+static_assert(kP2Width == 301, "Poseidon2 chip layout");
 // ---- table chip: 2^16 rows; preprocessed (x, y: the row index's bytes; na: index not a multiple of 4; nt: index above
 //      kAddrHiMax; x ^ y; x & y); main: multiplicities of range16 (kind 0), 4-aligned range16 (kind 1), high address limb
 //      (kind 2), byte pair, and the byte operations xor / or / and ----
@@ -611,9 +611,8 @@ ZKSP_HD void eval_p2(Ctx& ctx) {
   const P2Consts* kc = ctx.p2();
   const F one = ctx.k(kR1);
   ctx.emit(bool_c(L(P2_IS_REAL), one));
-  ctx.emit(ctx.is_first() * (L(P2_K) - one));
-  ctx.emit(ctx.is_trans() * (ctx.next(P2_K) - L(P2_K) - one));
   ctx.emit(ctx.is_trans() * ctx.next(P2_IS_REAL) * (one - L(P2_IS_REAL)));  // the real rows are a prefix
+  // (the node's key is free: two limbs, range-checked by lookups; the DIGEST bus ties the nodes together)
   F st[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) st[i] = L(P2_IN + i);
@@ -642,7 +641,7 @@ ZKSP_HD void eval_p2(Ctx& ctx) {
     p2air_external_linear(st);
   }
 }
-constexpr int kP2Constraints = 4 + 8 * 32 + 13 * 2;
+constexpr int kP2Constraints = 2 + 8 * 32 + 13 * 2;
 
 // every image word is sent exactly once
 template <class Ctx>

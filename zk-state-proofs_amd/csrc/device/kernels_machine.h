@@ -29,11 +29,12 @@ struct MachineRecords {
   const uint32_t* sub_idx;     // [B][cap_sub]: cycle index of every sub-word-chip row
   const uint32_t* bw_idx;      // [B][cap_bw]: cycle index of every bitwise-chip row
   const uint32_t* ecall_idx;   // [B][cap_ecall]: cycle index of every ecall
-  const uint32_t* agg_heap;    // [B][cap_agg][8]: aggregation payload, digest of heap node k (canonical; leaves at n .. 2n - 1)
+  const uint32_t* agg_heap;    // [B][cap_agg][17]: aggregation payload, one record per row of the Poseidon2 chip (an ancestor of
+                               //          the supplied nodes, ascending keys): key, left child's digest, right child's (canonical)
   const P2Consts* consts;      // Poseidon2 constants (the Poseidon2 chip's rows are permutations)
   const uint32_t* prog_mult;   // [B][2^log_prog]; the padding row (n_program - 1) holds 0: its fetches follow from cpu_rows
   const uint32_t* counts;      // [B][12]: cycles, keccak calls, memfinal rows, muls, ALU rows, sub-word rows, last time x0 was
-                               //          accessed by a real cycle, bitwise rows, aggregation leaves, ecalls, 0, 0
+                               //          accessed by a real cycle, bitwise rows, Poseidon2-chip rows, ecalls, 0, 0
   uint32_t* table_hist;        // [B][kTableWidth][2^16] scratch: multiplicities of the table chip, counted on the device
   uint32_t row0[mach::kNumChips];  // first cycle / event of the chip's instance (second instances: rows of the first)
   size_t cap_cycles, cap_keccak, cap_memfinal, cap_muls, cap_alu, cap_sub, cap_bw, cap_agg, cap_ecall;

@@ -241,16 +241,18 @@ __global__ __launch_bounds__(64) void p2_trace_kernel(MachineRecords rec, uint32
   const int b = blockIdx.y;
   const Col o{trace + (size_t)b * kP2Width * h + r, h};
   const P2Consts* kc = rec.consts;
-  const uint32_t n = rec.counts[kCountWords * b + 8], k = (uint32_t)r + 1;
-  const bool real = n != 0 && k < n;
+  // row r: the r-th ancestor (ascending keys) of the supplied nodes: its key and its children's digests
+  const bool real = r < rec.counts[kCountWords * b + 8];
+  const uint32_t* row = rec.agg_heap + ((size_t)b * rec.cap_agg + (real ? r : 0)) * 17;
   Fp st[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    st[i] = real ? Fp::from_canonical(rec.agg_heap[((size_t)b * rec.cap_agg + 2 * k) * 8 + i]) : Fp::zero();
+    st[i] = real ? Fp::from_canonical(row[1 + i]) : Fp::zero();
     o.put(P2_IN + i, st[i].v);
   }
   o.flag(P2_IS_REAL, real);
-  o.val(P2_K, k);
+  o.val(P2_KL, real ? row[0] & 0xffff : 0u);
+  o.val(P2_KH, real ? row[0] >> 16 : 0u);
   p2air_external_linear(st);
   for (int rd = 0; rd < 8; ++rd) {
     if (rd == 4) {

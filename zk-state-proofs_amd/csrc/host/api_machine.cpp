@@ -11,9 +11,10 @@
 
 using namespace zksp;
 
-// Header (version, chip heights, exit code, digests, key digest), public values, body: the v10 proof object.
+// Header (version, chip heights, exit code, digests, key digest), public values, body: the v11 proof object.
 int machine_proof_from_parts(const zksp_pk* pk, const ExecutionRecord& r, const int* lh, uint32_t handover_pc,
-                             const std::vector<uint32_t>& agg_leaves, const uint32_t* body, size_t body_words, zksp_proof** out) {
+                             const std::vector<uint32_t>& agg_leaves, const std::vector<uint32_t>& agg_keys, const uint32_t* body,
+                             size_t body_words, zksp_proof** out) {
   zksp_proof* p = new (std::nothrow) zksp_proof();
   if (!p) return ZKSP_ERR_INVALID_ARG;
   try {
@@ -30,7 +31,8 @@ int machine_proof_from_parts(const zksp_pk* pk, const ExecutionRecord& r, const 
     memcpy(w + 20 + mach::kNumChips, pk->mvk.digest, 32);
     w[28 + mach::kNumChips] = handover_pc;
     w[29 + mach::kNumChips] = (uint32_t)(agg_leaves.size() / 8);
-    if (!machine_agg_public(agg_leaves.data(), agg_leaves.size() / 8, w + 30 + mach::kNumChips, w + 38 + mach::kNumChips, nullptr)) {
+    if (!machine_nodes_public(agg_keys.empty() ? nullptr : agg_keys.data(), agg_leaves.data(), agg_leaves.size() / 8,
+                              w + 30 + mach::kNumChips, w + 38 + mach::kNumChips, nullptr)) {
       delete p;
       return ZKSP_ERR_INVALID_ARG;
     }
@@ -61,6 +63,8 @@ int zksp_machine_trace(zksp_client* c, const zksp_pk* pk, const zksp_stdin* stdi
   try {
     trace_execute(pk->elf, pk->mprog, stdin_->entries, (uint64_t)1 << 21, &t->t);
     t->t.agg_leaves = stdin_->agg_leaves;
+    t->t.agg_keys = stdin_->agg_keys;
+    t->t.agg_rows = machine_agg_row_count(t->t.agg_keys.empty() ? nullptr : t->t.agg_keys.data(), t->t.agg_leaves.size() / 8);
   } catch (...) {
     delete t;
     return c->ctx.fail(ZKSP_ERR_EXECUTOR, "executor: out of memory while tracing the guest");
@@ -245,16 +249,24 @@ int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const 
   } else {
     machine_heights(*t->prog, t->t, lh);
   }
-  return machine_proof_from_parts(pk, t->t.rec, lh, machine_handover_pc(*t->prog, t->t, lh[mach::kCpu]), t->t.agg_leaves, body, body_words,
-                                  out);
+  return machine_proof_from_parts(pk, t->t.rec, lh, machine_handover_pc(*t->prog, t->t, lh[mach::kCpu]), t->t.agg_leaves, t->t.agg_keys,
+                                  body, body_words, out);
 }
 
 int zksp_stdin_set_aggregation(zksp_stdin* s, const uint32_t* leaves, size_t n) {
-  if (!s || (n && !leaves) || n == 1 || (n & (n - 1)) || n > ((size_t)1 << 20)) return ZKSP_ERR_INVALID_ARG;
+  if (n == 1 || (n & (n - 1))) return ZKSP_ERR_INVALID_ARG;  // the leaves of a full tree: a power of two of them
+  return zksp_stdin_set_aggregation_keyed(s, nullptr, leaves, n);
+}
+
+int zksp_stdin_set_aggregation_keyed(zksp_stdin* s, const uint32_t* keys, const uint32_t* digests, size_t n) {
+  if (!s || (n && !digests) || n == 1 || n > ((size_t)1 << 20)) return ZKSP_ERR_INVALID_ARG;
   for (size_t i = 0; i < 8 * n; ++i)
-    if (leaves[i] >= kP) return ZKSP_ERR_INVALID_ARG;
+    if (digests[i] >= kP) return ZKSP_ERR_INVALID_ARG;
+  if (n && machine_agg_row_count(keys, n) == SIZE_MAX) return ZKSP_ERR_INVALID_ARG;  // (every ancestor needs both children)
   try {
-    s->agg_leaves.assign(leaves, leaves + 8 * n);
+    s->agg_leaves.assign(digests, digests + 8 * n);
+    if (keys) s->agg_keys.assign(keys, keys + n);
+    else s->agg_keys.clear();
   } catch (...) {
     return ZKSP_ERR_INVALID_ARG;
   }
@@ -269,14 +281,19 @@ int zksp_proof_aggregation(const zksp_proof* p, uint32_t* n_leaves, uint32_t* ro
 }
 
 int zksp_verify_aggregate(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const uint32_t* leaves, size_t n) {
-  if (!c || !p || !vk || (n && !leaves)) return ZKSP_ERR_INVALID_ARG;
+  return zksp_verify_aggregate_keyed(c, p, vk, nullptr, leaves, n);
+}
+
+int zksp_verify_aggregate_keyed(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const uint32_t* keys, const uint32_t* digests,
+                                size_t n) {
+  if (!c || !p || !vk || (n && !digests)) return ZKSP_ERR_INVALID_ARG;
   if (c->ctx.params.proof_mode != ZKSP_PROOF_MACHINE || p->version != mach::kMachineVersion)
     return c->ctx.fail(ZKSP_ERR_VERIFY, "verify: not a machine proof");
   std::string err;
   int rc;
   try {
     rc = verify_machine_proof(p->bytes.data(), p->bytes.size(), vk->machine, c->ctx.params.num_queries, c->ctx.params.pow_bits, &err,
-                              leaves, n);
+                              digests, n, keys);
   } catch (...) {
     return c->ctx.fail(ZKSP_ERR_VERIFY, "verify: out of memory");
   }

@@ -118,6 +118,9 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       traces[i]->prog = &pk->mprog;
       trace_execute(pk->elf, pk->mprog, stdins[i]->entries, (uint64_t)1 << 21, &traces[i]->t);
       traces[i]->t.agg_leaves.swap(stdins[i]->agg_leaves);
+      traces[i]->t.agg_keys.swap(stdins[i]->agg_keys);
+      traces[i]->t.agg_rows = machine_agg_row_count(traces[i]->t.agg_keys.empty() ? nullptr : traces[i]->t.agg_keys.data(),
+                                                    traces[i]->t.agg_leaves.size() / 8);
       stdins[i]->entries.clear();  // consumed, as SP1Stdin is by prove()
     } catch (...) {
       traces[i].reset(new zksp_mtrace());
@@ -165,7 +168,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       lh[mach::kAlu] = clog2(t.alu_idx.size()); lh[mach::kAlu2] = 0;
       lh[mach::kSub] = clog2(t.sub_idx.size()); lh[mach::kSub2] = 0;
       lh[mach::kBw] = clog2(t.bw_idx.size()); lh[mach::kBw2] = 0;
-      lh[mach::kP2] = clog2(t.agg_leaves.size() / 8 + 1);
+      lh[mach::kP2] = clog2(t.agg_rows + 1);
       lh[mach::kEcall] = clog2(t.ecall_idx.size());
       groups[lh].push_back(i);
       covers[lh].cover(t);
@@ -317,7 +320,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     }
     for (size_t j = 0; j < cnt; ++j) {
       const size_t i = ck.idx[j];
-      status[i] = machine_proof_from_parts(pk, traces[i]->t.rec, ck.lh.data(), traces[i]->handover_pc, traces[i]->t.agg_leaves,
+      status[i] = machine_proof_from_parts(pk, traces[i]->t.rec, ck.lh.data(), traces[i]->handover_pc, traces[i]->t.agg_leaves, traces[i]->t.agg_keys,
                                            bodies.data() + j * bw, bw, &out[i]);
     }
     mark.mark("wrapped", cnt);

@@ -19,10 +19,12 @@ struct zksp_mtrace {
 struct zksp_vk { uint32_t digest[8]; zksp::MachineVk machine; };
 struct zksp_stdin {
   std::vector<std::vector<uint8_t>> entries;
-  std::vector<uint32_t> agg_leaves;  // aggregation payload to prove beside the run (zksp_stdin_set_aggregation), 8 words per leaf
+  std::vector<uint32_t> agg_leaves;  // aggregation payload to prove beside the run (zksp_stdin_set_aggregation), 8 words per digest
+  std::vector<uint32_t> agg_keys;    // heap keys of those digests (empty: the leaves of a full tree)
 };
 struct zksp_proof { std::vector<uint8_t> bytes; zksp::ProofHeader hdr; zksp::MachineHeader mhdr; uint32_t version = 2; };
 
-// api_machine.cpp: the v10 proof object from an execution record, the chip heights, the aggregation leaves and a fetched body
+// api_machine.cpp: the v11 proof object from an execution record, the chip heights, the aggregation leaves and a fetched body
 int machine_proof_from_parts(const zksp_pk* pk, const zksp::ExecutionRecord& r, const int* log_heights, uint32_t handover_pc,
-                             const std::vector<uint32_t>& agg_leaves, const uint32_t* body, size_t body_words, zksp_proof** out);
+                             const std::vector<uint32_t>& agg_leaves, const std::vector<uint32_t>& agg_keys, const uint32_t* body,
+                             size_t body_words, zksp_proof** out);

@@ -112,7 +112,9 @@ struct MachineTrace {
   std::vector<uint32_t> sub_idx;      // cycles that occupy a row of the sub-word chip (lb lh lbu lhu sb sh), in order
   std::vector<uint32_t> ecall_idx;    // the ecall cycles (one row of the ecall chip each), in order
   uint32_t x0_last = 0;               // last access time of x0 by a real cycle (the first padding row consumes it)
-  std::vector<uint32_t> agg_leaves;   // aggregation payload (row f4): 8 canonical words per leaf, a power of two of leaves or none
+  std::vector<uint32_t> agg_leaves;   // aggregation payload (row f4): 8 canonical words per supplied digest, or none
+  std::vector<uint32_t> agg_keys;     // their heap keys (empty: n + j, the leaves of a full tree of n = a power of two)
+  size_t agg_rows = 0;                // rows of the Poseidon2 chip: the ancestors of the supplied keys (set with the payload)
 };
 
 // How many rows of each event-sized chip a run needs; a batch is proven with the heights of the element-wise maximum.
@@ -120,7 +122,7 @@ struct MachineCounts {
   size_t cycles = 0, alu = 0, sub = 0, bw = 0, keccak = 0, memfinal = 0, muls = 0, agg = 0, ecall = 0;
   void cover(const MachineTrace& t) {
     cycles = std::max(cycles, t.cycles.size()); alu = std::max(alu, t.alu_idx.size()); sub = std::max(sub, t.sub_idx.size());
-    bw = std::max(bw, t.bw_idx.size()); agg = std::max(agg, t.agg_leaves.size() / 8); ecall = std::max(ecall, t.ecall_idx.size());
+    bw = std::max(bw, t.bw_idx.size()); agg = std::max(agg, t.agg_rows); ecall = std::max(ecall, t.ecall_idx.size());
     keccak = std::max(keccak, t.keccak.size()); memfinal = std::max(memfinal, t.memfinal.size()); muls = std::max(muls, t.muls.size());
   }
 };

@@ -1,4 +1,4 @@
-// See machine_defs.hpp.  Bus protocol (DESIGN.md "Machine proof", format v10):
+// See machine_defs.hpp.  Bus protocol (DESIGN.md "Machine proof", format v11):
 //   MEM    (addr, lo, hi, time)   every access consumes its predecessor's tuple and produces its own
 //   PROG   (pc, class, code, uc, wr, use2, rd, rs1, rs2, imm_lo, imm_hi, tgt_lo, tgt_hi)   instruction fetch, every CPU row
 //   KCALL  (time, ptr_lo, ptr_hi)   CPU -> keccak-memory: one precompile call
@@ -89,7 +89,7 @@ Interaction bytes_inter(int sign, const LinForm& mult, const LinForm& x, const L
 }
 
 constexpr int kCpuInter = 21;
-Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7], g_alu[1], g_sub[5], g_bw[5], g_p2[3], g_ecall[10];
+Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7], g_alu[1], g_sub[5], g_bw[5], g_p2[5], g_ecall[10];
 ChipDef g_chips[kNumChips];
 
 void build() {
@@ -342,19 +342,27 @@ void build() {
       Interaction& it = g_p2[side];
       it = Interaction{};
       it.bus = BUS_DIGEST; it.sign = -1; it.mult = lf_col(P2_IS_REAL); it.n_el = 9;
-      it.el[0] = lf_zero(); lf_add(it.el[0], P2_K, 2); it.el[0].c0 = mont((uint64_t)side);
+      it.el[0] = lf_zero(); lf_add(it.el[0], P2_KL, 2); lf_add(it.el[0], P2_KH, 2 * 65536); it.el[0].c0 = mont((uint64_t)side);
       for (int j = 0; j < 8; ++j) it.el[1 + j] = lf_col(P2_IN + 8 * side + j);
     }
     Interaction& out = g_p2[2];
     out = Interaction{};
     out.bus = BUS_DIGEST; out.sign = +1; out.mult = lf_col(P2_IS_REAL); out.n_el = 9;
-    out.el[0] = lf_col(P2_K);
+    out.el[0] = lf_pair(P2_KL, P2_KH, 65536);
     for (int j = 0; j < 8; ++j) {
       out.el[1 + j] = lf_zero();
       for (int i = 0; i < 16; ++i) lf_add(out.el[1 + j], ylast + i, (uint64_t)m4[j & 3][i & 3] * ((i >> 2) == (j >> 2) ? 2u : 1u));
     }
   }
-  g_chips[kP2] = {"poseidon2", 0, kP2Width, 3, g_p2, kP2Constraints, 0};
+  // the key's limbs: 16 bits, and twice the high limb at most kAddrHiMax (kind 2): the key stays below 0x3C000000 and its
+  // children's keys 2K, 2K + 1 below 0x78000000 < p - no key aliases another mod p
+  g_p2[3] = range_inter(-1, lf_col(P2_IS_REAL), lf_const(0), lf_col(P2_KL));
+  {
+    LinForm kh2 = lf_zero();
+    lf_add(kh2, P2_KH, 2);
+    g_p2[4] = range_inter(-1, lf_col(P2_IS_REAL), lf_const(2), kh2);
+  }
+  g_chips[kP2] = {"poseidon2", 0, kP2Width, 5, g_p2, kP2Constraints, 0};
   g_chips[kTable] = {"table", kTablePrepWidth, kTableWidth, 7, g_table, 2, 0};
   g_chips[kCpu] = {"cpu", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 4};
   g_chips[kCpu2] = {"cpu2", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 4};

@@ -106,7 +106,7 @@ void machine_heights(const MachineProgram& prog, const MachineCounts& n, int log
   logh[kProgram] = prog.log_prog;
   logh[kMul] = at_least5(ceil_log2(n.muls));
   logh[kTable] = kTableLogH;
-  logh[kP2] = at_least5(ceil_log2(n.agg > 1 ? n.agg - 1 : 1));  // one row per inner node of the aggregation tree
+  logh[kP2] = at_least5(ceil_log2(n.agg ? n.agg : 1));  // one row per ancestor of the payload's supplied nodes
   logh[kEcall] = at_least5(ceil_log2(n.ecall));
 }
 void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh[kNumChips]) {
@@ -118,7 +118,7 @@ bool machine_fits(const MachineTrace& t, const int* logh) {
   auto two = [&](int a, int b) { return ((size_t)1 << logh[a]) + ((size_t)1 << logh[b]); };
   auto one = [&](int a) { return (size_t)1 << logh[a]; };
   return t.cycles.size() <= two(kCpu, kCpu2) && t.alu_idx.size() <= two(kAlu, kAlu2) && t.sub_idx.size() <= two(kSub, kSub2) &&
-         t.bw_idx.size() <= two(kBw, kBw2) && t.agg_leaves.size() / 8 <= one(kP2) + 1 &&
+         t.bw_idx.size() <= two(kBw, kBw2) && t.agg_rows <= one(kP2) &&
          24 * t.keccak.size() <= one(kKeccak) && 50 * t.keccak.size() <= one(kKmem) && t.memfinal.size() <= one(kMemFinal) &&
          t.muls.size() <= one(kMul) && t.ecall_idx.size() <= one(kEcall);
 }
@@ -226,7 +226,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
     A(&w->sub_idx, B * w->cap_sub);
     A(&w->bw_idx, B * w->cap_bw);
     A(&w->ecall_idx, B << logh[kEcall]);  // (an ecall list is as long as the ecall chip is tall, at most)
-    A(&w->agg_heap, B * w->cap_agg * 8);
+    A(&w->agg_heap, B * w->cap_agg * 17);
     A(&w->prog_mult, B << logh[kProgram]);
     A(&w->table_hist, (B * kTableWidth) << kTableLogH);
     A(&w->counts, B * kCountWords);
@@ -242,7 +242,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
     A(&w->spare.sub_idx, B * w->cap_sub);
     A(&w->spare.bw_idx, B * w->cap_bw);
     A(&w->spare.ecall_idx, B << logh[kEcall]);
-    A(&w->spare.agg_heap, B * w->cap_agg * 8);
+    A(&w->spare.agg_heap, B * w->cap_agg * 17);
     A(&w->spare.prog_mult, B << logh[kProgram]);
     A(&w->spare.counts, B * kCountWords);
     A(&w->spare.n_perms, B);
@@ -387,7 +387,7 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
                ck = std::min(((size_t)1 << logh[kKeccak]) / 24, ((size_t)1 << logh[kKmem]) / 50),
                ca = ((size_t)1 << logh[kAlu]) + ((size_t)1 << logh[kAlu2]), cs = ((size_t)1 << logh[kSub]) + ((size_t)1 << logh[kSub2]),
                cb = ((size_t)1 << logh[kBw]) + ((size_t)1 << logh[kBw2]),
-               cg = 2 * (((size_t)1 << logh[kP2]) + 1);  // heap nodes 0 .. 2n - 1 of at most 2^logh + 1 leaves
+               cg = (size_t)1 << logh[kP2];  // one record per row of the Poseidon2 chip
   if (logh[kCpu] > 20) return ctx->fail(9, "machine_load: more than 2^21 cycles");
   if (into_spare) {
     MachineWorkspace* w0 = ctx->mws.get();
@@ -422,15 +422,15 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     cn[9] = (uint32_t)t.ecall_idx.size();
     if (!t.ecall_idx.empty())
       ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->ecall_idx + (i << logh[kEcall]), t.ecall_idx.data(), t.ecall_idx.size() * 4, hipMemcpyHostToDevice, s));
-    // aggregation payload: the heap of digests (node k = compress(2k, 2k + 1), leaves at n .. 2n - 1) the Poseidon2 chip's
+    // aggregation payload: the rows (ancestors of the supplied nodes: key, children's digests) the Poseidon2 chip's
     // rows are expanded from, and its public part
     uint32_t agg_root[8], agg_digest[8];
     const size_t n_agg = t.agg_leaves.size() / 8;
-    if (!machine_agg_public(t.agg_leaves.data(), n_agg, agg_root, agg_digest, &agg_heaps[i]))
-      return ctx->fail(1, "machine_load: malformed aggregation leaves");
-    cn[8] = (uint32_t)n_agg;
+    if (!machine_nodes_public(t.agg_keys.empty() ? nullptr : t.agg_keys.data(), t.agg_leaves.data(), n_agg, agg_root, agg_digest, &agg_heaps[i]))
+      return ctx->fail(1, "machine_load: malformed aggregation payload");
+    cn[8] = (uint32_t)(agg_heaps[i].size() / 17);
     if (n_agg)
-      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->agg_heap + i * w->cap_agg * 8, agg_heaps[i].data(), agg_heaps[i].size() * 4, hipMemcpyHostToDevice, s));
+      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->agg_heap + i * w->cap_agg * 17, agg_heaps[i].data(), agg_heaps[i].size() * 4, hipMemcpyHostToDevice, s));
     if (!t.alu_idx.empty())
       ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->alu_idx + i * w->cap_alu, t.alu_idx.data(), t.alu_idx.size() * 4, hipMemcpyHostToDevice, s));
     if (!t.sub_idx.empty())
@@ -547,7 +547,7 @@ int machine_prove_resident(Context* ctx) {
     }
     // the table chip answers what the others look up: count their RANGE / BYTES receives on their finished traces
     launch_table_clear(s, rec, B);
-    for (int c : {(int)kCpu, (int)kCpu2, (int)kKmem, (int)kMemFinal, (int)kBw, (int)kBw2, (int)kSub, (int)kSub2, (int)kEcall})
+    for (int c : {(int)kCpu, (int)kCpu2, (int)kKmem, (int)kMemFinal, (int)kBw, (int)kBw2, (int)kSub, (int)kSub2, (int)kEcall, (int)kP2})
       launch_table_count(s, static_cast<const Interaction*>(ctx->d_inter[c]), chip_def(c).n_inter, w->mat[c][0].tr, chip_def(c).main_w,
                          logh[c], rec, B);
     launch_table_trace(s, rec, w->mat[kTable][0].tr, B);

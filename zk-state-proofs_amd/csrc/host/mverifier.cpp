@@ -1,4 +1,4 @@
-// Host verifier of the machine proof ("ZKSP v10"): replaces `client.verify(&proof, &vk)` (reference
+// Host verifier of the machine proof ("ZKSP v11"): replaces `client.verify(&proof, &vk)` (reference
 // prover/src/bin/main.rs:80; sp1-stark 3.4.0's multi-chip verifier over p3-uni-stark / p3-fri,
 // Cargo.lock:7485, :5378, :5253) for proofs that bind the guest's whole execution.  Also the
 // host half of `client.setup(ELF)` (main.rs:70): the commitment to the preprocessed Program and
@@ -180,25 +180,111 @@ void vk_digest_of(const uint32_t root_canon[8], uint32_t entry, uint32_t pad_pc,
 
 }  // namespace
 
-bool machine_agg_public(const uint32_t* leaves, size_t n, uint32_t root[8], uint32_t list_digest[8], std::vector<uint32_t>* heap) {
+namespace {
+struct AggNode {
+  uint32_t key;
+  int have;  // 1 supplied, 2 computed, 0 pending
+  Fp d[8];
+};
+// supplied keys and their ancestors, one entry per key, ascending; false if malformed
+bool agg_collect(const uint32_t* keys, size_t n, std::vector<AggNode>* out) {
+  std::vector<AggNode>& v = *out;
+  v.clear();
+  v.reserve(2 * n + 64);
+  for (size_t j = 0; j < n; ++j) {
+    const uint32_t key = keys ? keys[j] : (uint32_t)(n + j);
+    if (key < 2 || key >= (1u << 30)) return false;
+    AggNode a{};
+    a.key = key; a.have = 1;
+    v.push_back(a);
+  }
+  std::sort(v.begin(), v.end(), [](const AggNode& x, const AggNode& y) { return x.key < y.key; });
+  for (size_t j = 1; j < v.size(); ++j)
+    if (v[j].key == v[j - 1].key) return false;
+  std::vector<uint32_t> anc;
+  for (size_t j = 0; j < n; ++j)
+    for (uint32_t k = v[j].key >> 1; k >= 1; k >>= 1) {
+      anc.push_back(k);
+      if (k == 1) break;
+    }
+  std::sort(anc.begin(), anc.end());
+  anc.erase(std::unique(anc.begin(), anc.end()), anc.end());
+  for (uint32_t k : anc) {
+    if (std::binary_search(v.begin(), v.begin() + n, AggNode{k, 0, {}}, [](const AggNode& x, const AggNode& y) { return x.key < y.key; }))
+      return false;  // a supplied node may not be an ancestor of another
+    AggNode a{};
+    a.key = k; a.have = 0;
+    v.push_back(a);
+  }
+  std::sort(v.begin(), v.end(), [](const AggNode& x, const AggNode& y) { return x.key < y.key; });
+  return true;
+}
+AggNode* agg_find(std::vector<AggNode>& v, uint32_t key) {
+  auto it = std::lower_bound(v.begin(), v.end(), key, [](const AggNode& x, uint32_t k) { return x.key < k; });
+  return it != v.end() && it->key == key ? &*it : nullptr;
+}
+}  // namespace
+
+size_t machine_agg_row_count(const uint32_t* keys, size_t n) {
+  if (n == 0) return 0;
+  std::vector<AggNode> v;
+  if (!agg_collect(keys, n, &v)) return SIZE_MAX;
+  size_t rows = 0;
+  for (AggNode& a : v) {
+    if (a.have) continue;
+    const AggNode *l = agg_find(v, 2 * a.key), *r = agg_find(v, 2 * a.key + 1);
+    if (!l || !r) return SIZE_MAX;
+    ++rows;
+  }
+  return rows;
+}
+
+bool machine_nodes_public(const uint32_t* keys, const uint32_t* digests, size_t n, uint32_t root[8], uint32_t list_digest[8],
+                          std::vector<uint32_t>* rows) {
   memset(root, 0, 32);
   memset(list_digest, 0, 32);
-  if (heap) heap->clear();
+  if (rows) rows->clear();
   if (n == 0) return true;
-  if (n == 1 || (n & (n - 1)) || !leaves) return false;  // a power of two of leaves, at least 2
+  if (!digests) return false;
   for (size_t i = 0; i < 8 * n; ++i)
-    if (leaves[i] >= kP) return false;
+    if (digests[i] >= kP) return false;
+  std::vector<AggNode> v;
+  if (!agg_collect(keys, n, &v)) return false;
+  for (size_t j = 0; j < n; ++j) {
+    AggNode* a = agg_find(v, keys ? keys[j] : (uint32_t)(n + j));
+    for (int i = 0; i < 8; ++i) a->d[i] = Fp::from_canonical(digests[8 * j + i]);
+  }
   const P2Consts* kc = &host_p2_consts();
-  std::vector<Fp> hp(16 * n, Fp::zero());
-  for (size_t i = 0; i < 8 * n; ++i) hp[8 * n + i] = Fp::from_canonical(leaves[i]);
-  for (size_t k = n - 1; k >= 1; --k) compress(&hp[16 * k], &hp[16 * k + 8], &hp[8 * k], kc);
-  for (int i = 0; i < 8; ++i) root[i] = hp[8 + i].to_canonical();
+  size_t n_rows = 0;
+  for (size_t j = v.size(); j-- > 0;) {  // descending keys: children before parents
+    if (v[j].have) continue;
+    AggNode *l = agg_find(v, 2 * v[j].key), *r = agg_find(v, 2 * v[j].key + 1);
+    if (!l || !r || !l->have || !r->have) return false;
+    Fp in[16];
+    for (int i = 0; i < 8; ++i) { in[i] = l->d[i]; in[8 + i] = r->d[i]; }
+    compress(in, in + 8, v[j].d, kc);
+    v[j].have = 2;
+    ++n_rows;
+  }
+  if (n_rows == 0 || v[0].key != 1) return false;
+  for (int i = 0; i < 8; ++i) root[i] = v[0].d[i].to_canonical();
+  std::vector<Fp> flat(9 * n);
+  for (size_t j = 0; j < n; ++j) {
+    flat[9 * j] = Fp::from_canonical(keys ? keys[j] : (uint32_t)(n + j));
+    for (int i = 0; i < 8; ++i) flat[9 * j + 1 + i] = Fp::from_canonical(digests[8 * j + i]);
+  }
   Fp dg[8];
-  hash_elems(&hp[8 * n], 8 * n, dg, kc);
+  hash_elems(flat.data(), 9 * n, dg, kc);
   for (int i = 0; i < 8; ++i) list_digest[i] = dg[i].to_canonical();
-  if (heap) {
-    heap->resize(16 * n);
-    for (size_t i = 0; i < 16 * n; ++i) (*heap)[i] = hp[i].to_canonical();
+  if (rows) {
+    rows->reserve(17 * n_rows);
+    for (AggNode& a : v) {  // ascending keys: the root first
+      if (a.have != 2) continue;
+      rows->push_back(a.key);
+      const AggNode *l = agg_find(v, 2 * a.key), *r = agg_find(v, 2 * a.key + 1);
+      for (int i = 0; i < 8; ++i) rows->push_back(l->d[i].to_canonical());
+      for (int i = 0; i < 8; ++i) rows->push_back(r->d[i].to_canonical());
+    }
   }
   return true;
 }
@@ -326,7 +412,7 @@ bool parse_machine_header(const uint8_t* bytes, size_t len, MachineHeader* h, st
   h->agg_n = w[29 + kNumChips];
   memcpy(h->agg_root, w + 30 + kNumChips, 32);
   memcpy(h->agg_digest, w + 38 + kNumChips, 32);
-  if (h->agg_n == 1 || (h->agg_n & (h->agg_n - 1)) || h->agg_n > (1u << 20)) { *err = "aggregation leaf count is not a power of two"; return false; }
+  if (h->agg_n == 1 || h->agg_n > (1u << 20)) { *err = "aggregation payload of an impossible size"; return false; }
   for (int i = 0; i < 8; ++i)
     if (h->agg_root[i] >= kP || h->agg_digest[i] >= kP) { *err = "non-canonical aggregation digest"; return false; }
   if (h->pv_len > (1u << 24)) { *err = "public values too long"; return false; }
@@ -339,7 +425,7 @@ bool parse_machine_header(const uint8_t* bytes, size_t len, MachineHeader* h, st
 }
 
 int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, uint32_t num_queries, uint32_t pow_bits,
-                         std::string* err, const uint32_t* agg_leaves, size_t n_agg) {
+                         std::string* err, const uint32_t* agg_leaves, size_t n_agg, const uint32_t* agg_keys) {
   MachineHeader hd;
   if (!parse_machine_header(bytes, len, &hd, err)) return 7;
   // the aggregation payload: the caller names the leaves the proof's root is claimed for; the transcript holds their digest
@@ -349,7 +435,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   }
   if (n_agg) {
     uint32_t r[8], dg[8];
-    if (!machine_agg_public(agg_leaves, n_agg, r, dg, nullptr)) { *err = "malformed aggregation leaves"; return 7; }
+    if (!machine_nodes_public(agg_keys, agg_leaves, n_agg, r, dg, nullptr)) { *err = "malformed aggregation leaves"; return 7; }
     if (memcmp(dg, hd.agg_digest, 32) != 0) { *err = "the proof aggregates another list of leaves"; return 8; }
   }
   const int* logh = hd.logh;
@@ -440,10 +526,11 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       }
     const Fp4 fh = gamma + fc(BUS_PUBH) + bpow[1] * fc(hd.exit_code & 0xffff) + bpow[2] * fc(hd.exit_code >> 16);
     total -= fh.inv();
-    // ... and the digest bus of the aggregation payload: the leaves go in at heap nodes n .. 2n - 1, the root comes out at 1
+    // ... and the digest bus of the aggregation payload: the supplied digests go in at their heap keys (the leaves of a full
+    // tree at n .. 2n - 1, or a leaf and the siblings of its path), the root comes out at 1
     for (size_t i = 0; i <= n_agg && n_agg; ++i) {
       const uint32_t* d = i < n_agg ? agg_leaves + 8 * i : hd.agg_root;
-      Fp4 f = gamma + fc(BUS_DIGEST) + bpow[1] * fc(i < n_agg ? (uint32_t)(n_agg + i) : 1u);
+      Fp4 f = gamma + fc(BUS_DIGEST) + bpow[1] * fc(i < n_agg ? (agg_keys ? agg_keys[i] : (uint32_t)(n_agg + i)) : 1u);
       for (int j = 0; j < 8; ++j) f += bpow[2 + j] * fc(d[j]);
       if (i < n_agg) total += f.inv();
       else total -= f.inv();

@@ -40,9 +40,17 @@ bool parse_machine_header(const uint8_t* bytes, size_t len, MachineHeader* h, st
 // 0 = accepted; 7 = malformed; 8 = rejected.  agg_leaves / n_agg: the leaves ([n][8] canonical words) of the aggregation
 // payload the proof must carry (n_agg = 0: it must carry none).
 int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, uint32_t num_queries, uint32_t pow_bits,
-                         std::string* err, const uint32_t* agg_leaves = nullptr, size_t n_agg = 0);
+                         std::string* err, const uint32_t* agg_leaves = nullptr, size_t n_agg = 0, const uint32_t* agg_keys = nullptr);
 // The aggregation payload's public part and the heap of digests the Poseidon2 chip's rows are expanded from:
 // heap[8 k ..] = node k (root 1, children 2k and 2k + 1, leaf i at n + i; node 0 unused), canonical words.
-bool machine_agg_public(const uint32_t* leaves, size_t n, uint32_t root[8], uint32_t list_digest[8], std::vector<uint32_t>* heap);
+// Aggregation payload: n digests supplied at heap keys (keys == nullptr: n + j, the leaves of a full tree; otherwise e.g. a
+// leaf and the siblings along its Merkle path).  Root (node 1), the digest of the list (keys and digests) that stands for
+// it in the transcript, and the Poseidon2 chip's rows: every ancestor of a supplied key in ascending order, 17 words each
+// (key, left child's digest, right child's digest).  False if the set is malformed: a repeated or out-of-range key, a
+// non-canonical word, an ancestor that is itself supplied or lacks a child.
+bool machine_nodes_public(const uint32_t* keys, const uint32_t* digests, size_t n, uint32_t root[8], uint32_t list_digest[8],
+                          std::vector<uint32_t>* rows);
+// number of those rows without hashing anything (SIZE_MAX if malformed)
+size_t machine_agg_row_count(const uint32_t* keys, size_t n);
 
 }  // namespace zksp
