@@ -886,7 +886,7 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
       break;
     }
     case CH_IMAGE: {
-      /* soundness tests: ZKSP_ORACLE_IMG_UNUSED=<row> withholds that image word from the IMG bus (the v5 attack: the
+      /* soundness tests: ZKSP_ORACLE_IMG_UNUSED=<row> withholds that image word from the IMG bus (the round-2 attack: the
        * word is then free-initialised by the memory-boundary chip); the chip's constraint USED = is_real forbids it */
       const char* unused = getenv("ZKSP_ORACLE_IMG_UNUSED");
       for (size_t r = 0; r < in->n_image; ++r) {

@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
     return 4;
   }
   size_t elf_ok = 0, exec_halt = 0, ver_ok = 0;
-  // machine proofs (format v5): the verifying key is rebuilt from the ELF, the baseline proof must verify
+  // machine proofs: the verifying key is rebuilt from the ELF, the baseline proof must verify
   std::vector<uint8_t> mproof;
   MachineVk mvk{};
   uint32_t mq = 0, mpow = 0;

@@ -41,7 +41,7 @@ def test_host_code_under_asan_ubsan(tmp_path, zk, fx, oracle, host_client):
     pvd = [int(x) for x in np.frombuffer(hashlib.sha256(pv).digest(), dtype=np.uint32)]
     (tmp_path / "proof.bin").write_bytes(
         oracle.prove(st, 6, public_values=pv, pv_digest=pvd, vk_digest=vk_words, num_queries=12, pow_bits=8))
-    # a machine proof (format v5) of a short guest run, proven by the oracle
+    # a machine proof of a short guest run, proven by the oracle
     s = zk.SP1Stdin()
     s.write(fx.acct_fixture(1).to_borsh())
     (tmp_path / "mproof.bin").write_bytes(oracle.machine_prove(host_client.machine_trace(pk, s), num_queries=6, pow_bits=4))

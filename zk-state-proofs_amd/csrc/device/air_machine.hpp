@@ -10,10 +10,10 @@
 // entry point to HALT with the committed public values.  DESIGN.md "Machine proof" describes the
 // construction; constraint ORDER here is normative for the proof bytes.
 //
-// v6: the CPU row holds 16-bit limbs and no bits.  It adds, subtracts, tests equality and unsigned order, moves words
+// The CPU row holds 16-bit limbs and no bits (since format v6).  It adds, subtracts, tests equality and unsigned order, moves words
 // and forms addresses; xor / or / and go to the bitwise chip (bytes, looked up in the table chip's byte-operation
-// columns), shifts and signed less-than to the ALU chip (bits), sub-word loads and stores to the sub-word chip,
-// mul / mulhu to the multiplier, one row per such instruction.  Every row is an instruction (after HALT:
+// columns), shifts and signed less-than to the ALU chip (bits), sub-word loads and stores to the sub-word chip (bytes),
+// mul / mulhu to the multiplier, ecalls to the ecall chip, one row per such instruction.  Every row is an instruction (after HALT:
 // the padding instruction the Program table ends with), so the Program lookup vouches for every decoded field.
 // Range discipline: every producer of a memory-bus tuple guarantees canonical limbs (table lookups or bits), and
 // addresses / jump targets stay below 0x78000000 < p, so no bus compares two 32-bit values that alias mod p.
