@@ -1,6 +1,6 @@
 /* ORACLE -- TEST INFRASTRUCTURE ONLY (see field.h and machine.h).
  *
- * Chips of the machine proof (format v11): bus interactions, trace generation from the executor's
+ * Chips of the machine proof (format v12): bus interactions, trace generation from the executor's
  * records and base-field constraints.  This repository's own arithmetisation (machine.h header
  * note); what it must reproduce is the reference's statement: the committed RV32IM guest
  * (circuits/sp1-merkle-proof/src/main.rs:4-14 running crypto-ops/src/lib.rs:8-23) executed from its
@@ -101,7 +101,7 @@ static orc_lf lf_bits(int bits, int n) {
 }
 #define SELC(cls) (C_SEL + (cls) - 1)
 
-#define CPU_INTER 21
+#define CPU_INTER 19
 static orc_inter g_cpu[CPU_INTER], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7],
     g_alu[1], g_sub[5], g_bw[5], g_p2[5], g_ecall[10];
 static orc_chip g_chips[N_CHIPS];
@@ -136,7 +136,7 @@ static void build(void) {
   if (g_ready) return;
   const orc_lf one = lf_const(1), zero = lf_const(0), ts = lf_col(C_TS);
   const orc_lf a_lo = lf_col(C_A), a_hi = lf_col(C_A + 1), b_lo = lf_col(C_B), b_hi = lf_col(C_B + 1), c_lo = lf_col(C_C),
-               c_hi = lf_col(C_C + 1), m_lo = lf_col(C_M), m_hi = lf_col(C_M + 1);
+               c_hi = lf_col(C_C + 1);
   /* ---- CPU ---- */
   {
     orc_inter* it = &g_cpu[0];
@@ -149,33 +149,33 @@ static void build(void) {
     it->el[7] = lf_col(C_RS1); it->el[8] = lf_col(C_RS2); it->el[9] = lf_col(C_IMM_LO); it->el[10] = lf_col(C_IMM_HI);
     it->el[11] = lf_col(C_TGT_LO); it->el[12] = lf_col(C_TGT_HI);
   }
-  /* previous access time of slot q (accessed at ts + q): ts + q - 1 - (gap_lo + 2^16 gap_hi) */
-  orc_lf pts[4];
-  for (int q = 0; q < 4; ++q) {
+  /* Three accesses per row: rs1 at ts, the second operand (rs2, or a load's memory word) at ts + 1, the written location
+   * (rd, or a store's memory word) at ts + 2.  Previous access time of slot q: ts + q - 1 - (gap_lo + 2^16 gap_hi). */
+  orc_lf pts[3];
+  for (int q = 0; q < 3; ++q) {
     lf_zero(&pts[q]);
     lf_add(&pts[q], C_TS, 1); lf_add(&pts[q], C_GAP + 2 * q, FP - 1); lf_add(&pts[q], C_GAP + 2 * q + 1, FP - 65536);
     pts[q].c0 = f_sub((uint32_t)q, 1);
   }
   g_cpu[1] = mem_inter(-1, one, lf_col(C_RS1), b_lo, b_hi, pts[0]);
   g_cpu[2] = mem_inter(+1, one, lf_col(C_RS1), b_lo, b_hi, ts);
-  g_cpu[3] = mem_inter(-1, lf_col(C_USE2), lf_col(C_RS2), c_lo, c_hi, pts[1]);
-  g_cpu[4] = mem_inter(+1, lf_col(C_USE2), lf_col(C_RS2), c_lo, c_hi, lf_plus(ts, 1));
   {
-    /* the word address is the adder output less the byte offset: a linear form (below 0x78000000: X's lookups) */
-    const int memq_c[4] = {SELC(CL_LW), SELC(CL_SW), SELC(CL_LDS), SELC(CL_STS)};
-    const orc_lf memq = lf_sum(memq_c, 4);
-    orc_lf maddr = lf_pair(C_X, C_X + 1, 65536);
-    lf_add(&maddr, C_O1, FP - 1); lf_add(&maddr, C_O2, FP - 2); lf_add(&maddr, C_O3, FP - 3);
-    g_cpu[5] = mem_inter(-1, memq, maddr, m_lo, m_hi, pts[2]);
-    g_cpu[6] = mem_inter(+1, memq, maddr, lf_col(C_MV), lf_col(C_MV + 1), lf_plus(ts, 2));
+    /* rs2 (USE2) or a load: exclusive by the Program table (a load's second operand is its immediate) */
+    const int m2_c[3] = {C_USE2, SELC(CL_LW), SELC(CL_LDS)};
+    const orc_lf m2 = lf_sum(m2_c, 3);
+    g_cpu[3] = mem_inter(-1, m2, lf_col(C_ADDR2), c_lo, c_hi, pts[1]);
+    g_cpu[4] = mem_inter(+1, m2, lf_col(C_ADDR2), c_lo, c_hi, lf_plus(ts, 1));
+    /* rd (WR) or a store (which writes no register) */
+    const int m3_c[3] = {C_WR, SELC(CL_SW), SELC(CL_STS)};
+    const orc_lf m3 = lf_sum(m3_c, 3);
+    g_cpu[5] = mem_inter(-1, m3, lf_col(C_ADDR3), lf_col(C_W_PLO), lf_col(C_W_PHI), pts[2]);
+    g_cpu[6] = mem_inter(+1, m3, lf_col(C_ADDR3), a_lo, a_hi, lf_plus(ts, 2));
   }
-  g_cpu[7] = mem_inter(-1, lf_col(C_WR), lf_col(C_RD), lf_col(C_W_PLO), lf_col(C_W_PHI), pts[3]);
-  g_cpu[8] = mem_inter(+1, lf_col(C_WR), lf_col(C_RD), a_lo, a_hi, lf_plus(ts, 3));
-  /* access-time differences: every row looks up its four low limbs and the two pairs of high bytes (zero where the
-   * access is not live) */
-  for (int q = 0; q < 4; ++q) g_cpu[9 + q] = range_inter(-1, one, zero, lf_col(C_GAP + 2 * q));
-  g_cpu[13] = bytes_inter(-1, one, lf_col(C_GAP + 1), lf_col(C_GAP + 3));
-  g_cpu[14] = bytes_inter(-1, one, lf_col(C_GAP + 5), lf_col(C_GAP + 7));
+  /* access-time differences: every row looks up its three low limbs and the high bytes (zero where the access is not
+   * live) */
+  for (int q = 0; q < 3; ++q) g_cpu[7 + q] = range_inter(-1, one, zero, lf_col(C_GAP + 2 * q));
+  g_cpu[10] = bytes_inter(-1, one, lf_col(C_GAP + 1), lf_col(C_GAP + 3));
+  g_cpu[11] = bytes_inter(-1, one, lf_col(C_GAP + 5), zero);
   {
     /* the adder output is canonical, an address is word-aligned once its byte offset is taken off, and addresses,
      * jump targets and the keccak call's return address stay below 0x78000000 (their high limb is looked up as kind 2) */
@@ -189,30 +189,34 @@ static void build(void) {
     lf_add(&xoff, C_O1, FP - 1); lf_add(&xoff, C_O2, FP - 2); lf_add(&xoff, C_O3, FP - 3);
     orc_lf top = lf_sum(top_c, 6);
     for (int i = 0; i < top.n; ++i) top.coef[i] = 2; /* kind 2: the high limb of an address is at most ADDR_HI_MAX */
-    g_cpu[15] = range_inter(-1, chk, top, lf_col(C_X + 1));
-    g_cpu[16] = range_inter(-1, chk, lf_sum(al_c, 5), xoff);
+    g_cpu[12] = range_inter(-1, chk, top, lf_col(C_X + 1));
+    g_cpu[13] = range_inter(-1, chk, lf_sum(al_c, 5), xoff);
   }
   {
-    orc_inter* it = &g_cpu[17];
+    orc_inter* it = &g_cpu[14];
     memset(it, 0, sizeof *it);
     /* every ALU-class instruction and every ordered branch, except the unsigned comparisons the row does itself */
     const int alu_c[3] = {SELC(CL_ALU), SELC(CL_BLT), SELC(CL_BGE)};
     it->bus = BUS_ALU; it->sign = +1; it->mult = lf_sum(alu_c, 3); lf_add(&it->mult, C_UC, FP - 1); it->n_el = 7;
     it->el[0] = lf_col(C_CODE);
     it->el[1] = a_lo; it->el[2] = a_hi; it->el[3] = b_lo; it->el[4] = b_hi; it->el[5] = c_lo; it->el[6] = c_hi;
-    it = &g_cpu[18];
-    memset(it, 0, sizeof *it);
-    const int sub_c[2] = {SELC(CL_LDS), SELC(CL_STS)};
-    it->bus = BUS_SUB; it->sign = +1; it->mult = lf_sum(sub_c, 2); it->n_el = 9;
-    it->el[0] = lf_col(C_CODE);
-    lf_zero(&it->el[1]); lf_add(&it->el[1], C_O1, 1); lf_add(&it->el[1], C_O2, 2); lf_add(&it->el[1], C_O3, 3);
-    it->el[2] = a_lo; it->el[3] = a_hi; it->el[4] = m_lo; it->el[5] = m_hi; it->el[6] = c_lo;
-    it->el[7] = lf_col(C_MV); it->el[8] = lf_col(C_MV + 1);
-    it = &g_cpu[19];
+    /* sub-word loads: (op, offset, value loaded, memory word, 0); sub-word stores: (op, offset, word left behind, word
+     * before, low limb of the stored register) - one tuple layout, two sends because the word sits in other columns */
+    for (int st = 0; st < 2; ++st) {
+      it = &g_cpu[15 + st];
+      memset(it, 0, sizeof *it);
+      it->bus = BUS_SUB; it->sign = +1; it->mult = lf_col(SELC(st ? CL_STS : CL_LDS)); it->n_el = 7;
+      it->el[0] = lf_col(C_CODE);
+      lf_zero(&it->el[1]); lf_add(&it->el[1], C_O1, 1); lf_add(&it->el[1], C_O2, 2); lf_add(&it->el[1], C_O3, 3);
+      it->el[2] = a_lo; it->el[3] = a_hi;
+      it->el[4] = st ? lf_col(C_W_PLO) : c_lo; it->el[5] = st ? lf_col(C_W_PHI) : c_hi;
+      it->el[6] = st ? c_lo : zero;
+    }
+    it = &g_cpu[17];
     memset(it, 0, sizeof *it);
     it->bus = BUS_KCALL; it->sign = +1; it->mult = lf_col(SELC(CL_KECCAK)); it->n_el = 3;
     it->el[0] = ts; it->el[1] = c_lo; it->el[2] = c_hi;
-    it = &g_cpu[20];
+    it = &g_cpu[18];
     memset(it, 0, sizeof *it);
     /* an ecall: the ecall chip takes it from here (time, pc, next pc, the code in t0, the value left in t0) */
     it->bus = BUS_ECALL; it->sign = +1; it->mult = lf_col(SELC(CL_ECALL)); it->n_el = 6;
@@ -398,13 +402,12 @@ static void build(void) {
     static const uint32_t codes[6] = {OP_LB, OP_LH, OP_LBU, OP_LHU, OP_SB, OP_SH};
     orc_inter* it = &g_sub[0];
     memset(it, 0, sizeof *it);
-    it->bus = BUS_SUB; it->sign = -1; it->mult = lf_col(SW_IS_REAL); it->n_el = 9;
+    it->bus = BUS_SUB; it->sign = -1; it->mult = lf_col(SW_IS_REAL); it->n_el = 7;
     lf_zero(&it->el[0]);
     for (int k = 0; k < 6; ++k) lf_add(&it->el[0], SW_SEL + k, codes[k]);
     lf_zero(&it->el[1]); lf_add(&it->el[1], SW_O + 1, 1); lf_add(&it->el[1], SW_O + 2, 2); lf_add(&it->el[1], SW_O + 3, 3);
     it->el[2] = lf_col(SW_A); it->el[3] = lf_col(SW_A + 1);
     it->el[4] = lf_pair(SW_MB, SW_MB + 1, 256); it->el[5] = lf_pair(SW_MB + 2, SW_MB + 3, 256); it->el[6] = lf_pair(SW_CB, SW_CB + 1, 256);
-    it->el[7] = lf_col(SW_MV); it->el[8] = lf_col(SW_MV + 1);
     /* the bytes are bytes; the sign bit of a signed load is bit 7 of the byte it extends */
     g_sub[1] = bytes_inter(-1, lf_col(SW_IS_REAL), lf_col(SW_MB), lf_col(SW_MB + 1));
     g_sub[2] = bytes_inter(-1, lf_col(SW_IS_REAL), lf_col(SW_MB + 2), lf_col(SW_MB + 3));
@@ -417,8 +420,8 @@ static void build(void) {
     lf_zero(&it->el[3]); lf_add(&it->el[3], SW_S, 128);
   }
   g_chips[CH_TABLE] = (orc_chip){"table", TABLE_PREP_WIDTH, TABLE_WIDTH, 7, g_table, 0, 0};
-  g_chips[CH_CPU] = (orc_chip){"cpu", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0, 4};   /* ALU, SUB, KCALL, ECALL: one class each */
-  g_chips[CH_CPU2] = (orc_chip){"cpu2", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0, 4};
+  g_chips[CH_CPU] = (orc_chip){"cpu", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0, 5};   /* ALU, SUB (loads), SUB (stores), KCALL, ECALL: one class each */
+  g_chips[CH_CPU2] = (orc_chip){"cpu2", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0, 5};
   g_chips[CH_KECCAK] = (orc_chip){"keccak", 0, KECCAK_WIDTH, 50, g_keccak, 0, 0};
   g_chips[CH_KMEM] = (orc_chip){"keccak-mem", 0, KMEM_WIDTH, 8, g_kmem, 0, 0};
   g_chips[CH_MEMFINAL] = (orc_chip){"mem-final", 0, MEMFINAL_WIDTH, 10, g_memfinal, 0, 0};
@@ -557,7 +560,7 @@ static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
     const size_t g = row0 + r;  /* cycle index */
     const uint32_t ts = 4 * ((uint32_t)g + 1);
     T(C_TS) = ts;
-    uint32_t gap[4] = {0, 0, 0, 0};
+    uint32_t gap[3] = {0, 0, 0};
     if (g >= in->n_cycles) {
       /* jal x0, 0 at the padding pc: reads x0 (rs1 = 0), writes nothing, jumps to itself */
       const uint32_t pts = g == in->n_cycles ? x0_last : ts - 4;
@@ -573,6 +576,7 @@ static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
       uint32_t use2 = p[3], rs2 = p[6];
       const int cls = orc_class_of(op);
       if (cls == CL_ECALL) { use2 = 0; rs2 = 0; c = 0; m = 0; mv = 0; } /* a0 and a1 are read by the ecall chip */
+      const int load = cls == CL_LW || cls == CL_LDS, store = cls == CL_SW || cls == CL_STS;
       const uint32_t code = orc_code_of(op);
       T(C_PC) = pc;
       T(SELC(cls)) = 1;
@@ -586,12 +590,11 @@ static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
         case CL_ADD: x = a; k0 = (blo + clo) >> 16; k1 = (bhi + chi + k0) >> 16; break;
         case CL_SUB: x = a; k0 = ((a & 0xffff) + clo) >> 16; k1 = ((a >> 16) + chi + k0) >> 16; break;
         case CL_JAL: next = tgt; break;
-        case CL_JALR: case CL_LW: case CL_LDS:
+        case CL_JALR:
           x = b + c; k0 = (blo + clo) >> 16; k1 = (bhi + chi + k0) >> 16;
-          if (cls == CL_JALR) { off = (int)(x & 1); next = x & ~1u; }
-          else off = (int)(x & 3);
+          off = (int)(x & 1); next = x & ~1u;
           break;
-        case CL_SW: case CL_STS:
+        case CL_LW: case CL_LDS: case CL_SW: case CL_STS: /* the address is rs1 + immediate */
           x = b + imm; k0 = (blo + (imm & 0xffff)) >> 16; k1 = (bhi + (imm >> 16) + k0) >> 16;
           off = (int)(x & 3);
           break;
@@ -621,16 +624,19 @@ static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
         x = b - c;
       }
       if (cls != CL_BEQ && cls != CL_BNE) put_limbs(t, h, r, C_X, x);
-      put_limbs(t, h, r, C_A, a); put_limbs(t, h, r, C_B, b); put_limbs(t, h, r, C_C, c);
-      put_limbs(t, h, r, C_M, m); put_limbs(t, h, r, C_MV, mv);
+      /* second access: rs2, or the word a load reads (which then sits in C); written location: rd, or the word a store
+       * leaves behind (in A, its old value in W_P) */
+      put_limbs(t, h, r, C_A, store ? mv : a); put_limbs(t, h, r, C_B, b); put_limbs(t, h, r, C_C, load ? m : c);
       T(C_K0) = k0; T(C_K1) = k1;
       if (off > 0) T(C_O1 + off - 1) = 1;
       T(C_NEXT_PC) = next;
-      const int memq = cls == CL_LW || cls == CL_SW || cls == CL_LDS || cls == CL_STS;
+      T(C_ADDR2) = use2 ? rs2 : load ? (x & ~3u) : 0;
+      T(C_ADDR3) = wr ? rd : store ? (x & ~3u) : 0;
       gap[0] = ts - cy[7] - 1;
       if (use2) gap[1] = ts - cy[8];
-      if (memq) gap[2] = ts + 1 - cy[9];
-      if (wr) { gap[3] = ts + 2 - cy[10]; T(C_W_PLO) = wprev & 0xffff; T(C_W_PHI) = wprev >> 16; }
+      if (load) gap[1] = ts - cy[9];
+      if (wr) { gap[2] = ts + 1 - cy[10]; T(C_W_PLO) = wprev & 0xffff; T(C_W_PHI) = wprev >> 16; }
+      if (store) { gap[2] = ts + 1 - cy[9]; T(C_W_PLO) = m & 0xffff; T(C_W_PHI) = m >> 16; }
       /* soundness tests: ZKSP_ORACLE_NONCANON=<row> makes that addition claim the other carry, i.e. write the same
        * sum with limbs out of range.  The adder constraints still hold; the range lookup cannot. */
       const char* nc = getenv("ZKSP_ORACLE_NONCANON");
@@ -642,7 +648,7 @@ static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
         T(C_A) = T(C_X); T(C_A + 1) = T(C_X + 1);
       }
     }
-    for (int q = 0; q < 4; ++q) { T(C_GAP + 2 * q) = gap[q] & 0xffff; T(C_GAP + 2 * q + 1) = gap[q] >> 16; }
+    for (int q = 0; q < 3; ++q) { T(C_GAP + 2 * q) = gap[q] & 0xffff; T(C_GAP + 2 * q + 1) = gap[q] >> 16; }
 #undef T
   }
 }
@@ -745,10 +751,9 @@ static void fill_sub(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
     T(SW_IS_REAL) = 1;
     T(SW_SEL + sub_sel(code)) = 1;
     T(SW_O + off) = 1;
-    put_limbs(t, h, r, SW_A, store ? 0 : a);
+    put_limbs(t, h, r, SW_A, store ? mv : a); /* loads: the value loaded; stores: the word left behind */
     for (int k = 0; k < 4; ++k) T(SW_MB + k) = (m >> (8 * k)) & 0xff;
-    T(SW_CB) = c & 0xff; T(SW_CB + 1) = (c >> 8) & 0xff;
-    put_limbs(t, h, r, SW_MV, mv);
+    if (store) { T(SW_CB) = c & 0xff; T(SW_CB + 1) = (c >> 8) & 0xff; }
     if (code == OP_LB || code == OP_LH) {
       const uint32_t sb = code == OP_LB ? (m >> (8 * off)) & 0xff : (m >> (8 * (off | 1))) & 0xff;
       T(SW_SELB) = sb;
@@ -1028,17 +1033,18 @@ static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, f
     emit(s, f_mul(f_mul(is_last, f_sub(one, succ)), f_sub(l[C_NEXT_PC], pub[CPUPUB_PAD_PC] % FP)));
   }
   const fe a_lo = l[C_A], a_hi = l[C_A + 1], b_lo = l[C_B], b_hi = l[C_B + 1], c_lo = l[C_C], c_hi = l[C_C + 1];
-  const fe m_lo = l[C_M], m_hi = l[C_M + 1], mv_lo = l[C_MV], mv_hi = l[C_MV + 1], x_lo = l[C_X], x_hi = l[C_X + 1];
+  const fe x_lo = l[C_X], x_hi = l[C_X + 1];
   const fe k0 = l[C_K0], k1 = l[C_K1], imm_lo = l[C_IMM_LO], imm_hi = l[C_IMM_HI];
-  /* ---- operand C is the immediate ---- */
+  /* ---- operand C is the immediate, unless it is reg[rs2] or the word a load reads ---- */
+  const fe loadw = f_add(S(CL_LW), S(CL_LDS)), storew = f_add(S(CL_SW), S(CL_STS));
   {
-    const fe immc = f_sub(one, l[C_USE2]);
+    const fe immc = f_sub(f_sub(one, l[C_USE2]), loadw);
     emit(s, f_mul(immc, f_sub(c_lo, imm_lo)));
     emit(s, f_mul(immc, f_sub(c_hi, imm_hi)));
   }
-  /* ---- the adder: X = B + C (add, jalr, lw, sub-word loads), X = B + imm (stores), X + C = B (sub) ---- */
+  /* ---- the adder: X = B + C (add, jalr), X = B + imm (loads, stores), X + C = B (sub) ---- */
   {
-    const fe addc = f_add(f_add(S(CL_ADD), S(CL_JALR)), f_add(S(CL_LW), S(CL_LDS))), addi = f_add(S(CL_SW), S(CL_STS));
+    const fe addc = f_add(S(CL_ADD), S(CL_JALR)), addi = f_add(loadw, storew);
     emit(s, f_mul(addc, f_sub(f_add(b_lo, c_lo), f_add(x_lo, f_mul(F65536, k0)))));
     emit(s, f_mul(addc, f_sub(f_add(f_add(b_hi, c_hi), k0), f_add(x_hi, f_mul(F65536, k1)))));
     emit(s, f_mul(addi, f_sub(f_add(b_lo, imm_lo), f_add(x_lo, f_mul(F65536, k0)))));
@@ -1069,6 +1075,11 @@ static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, f
     emit(s, f_mul(noff, osum));
     emit(s, bool_c(osum)); /* at most one of the three offset flags */
     emit(s, f_mul(S(CL_JALR), f_add(o2, o3)));
+    /* the second access is rs2 or a load's word, the written location rd or a store's word */
+    emit(s, f_mul(l[C_USE2], f_sub(l[C_ADDR2], l[C_RS2])));
+    emit(s, f_mul(loadw, f_sub(l[C_ADDR2], xaddr)));
+    emit(s, f_mul(l[C_WR], f_sub(l[C_ADDR3], l[C_RD])));
+    emit(s, f_mul(storew, f_sub(l[C_ADDR3], xaddr)));
   }
   /* ---- next pc ---- */
   {
@@ -1099,15 +1110,11 @@ static void cpu_constraints(const uint32_t* l, const uint32_t* n, fe is_first, f
     emit(s, f_mul(S(CL_KECCAK), f_sub(np, f_add(b_lo, f_mul(F65536, b_hi)))));
     /* (ecall: the ecall chip decides the next pc - the next instruction, or the padding instruction after HALT) */
   }
-  /* ---- word loads and stores; what the memory slot leaves behind ---- */
+  /* ---- word loads and stores: the register gets the word read (C), the memory the register's value (C) ---- */
   {
-    emit(s, f_mul(S(CL_LW), f_sub(a_lo, m_lo)));
-    emit(s, f_mul(S(CL_LW), f_sub(a_hi, m_hi)));
-    const fe keep = f_add(S(CL_LW), S(CL_LDS));
-    emit(s, f_mul(keep, f_sub(mv_lo, m_lo)));
-    emit(s, f_mul(keep, f_sub(mv_hi, m_hi)));
-    emit(s, f_mul(S(CL_SW), f_sub(mv_lo, c_lo)));
-    emit(s, f_mul(S(CL_SW), f_sub(mv_hi, c_hi)));
+    const fe mov = f_add(S(CL_LW), S(CL_SW));
+    emit(s, f_mul(mov, f_sub(a_lo, c_lo)));
+    emit(s, f_mul(mov, f_sub(a_hi, c_hi)));
   }
   /* ---- ecall: the code in t0 is a 16-bit value (decoded, and the value left behind checked, by the ecall chip) ---- */
   emit(s, f_mul(S(CL_ECALL), b_hi));
@@ -1262,7 +1269,7 @@ static void sub_constraints(const uint32_t* l, sink* s) {
   emit(s, bool_c(l[SW_S]));
   emit(s, f_sub(selsum, l[SW_IS_REAL]));
   emit(s, f_sub(osum, l[SW_IS_REAL]));
-  const fe a_lo = l[SW_A], a_hi = l[SW_A + 1], mv_lo = l[SW_MV], mv_hi = l[SW_MV + 1], sgn = l[SW_S], selb = l[SW_SELB];
+  const fe a_lo = l[SW_A], a_hi = l[SW_A + 1], sgn = l[SW_S], selb = l[SW_SELB];
   const fe o0 = l[SW_O], o1 = l[SW_O + 1], o2 = l[SW_O + 2], o3 = l[SW_O + 3];
   const fe mb[4] = {l[SW_MB], l[SW_MB + 1], l[SW_MB + 2], l[SW_MB + 3]}, cb = l[SW_CB];
   const fe m_lo = f_add(mb[0], f_mul(256, mb[1])), m_hi = f_add(mb[2], f_mul(256, mb[3])), c_lo = f_add(cb, f_mul(256, l[SW_CB + 1]));
@@ -1284,16 +1291,13 @@ static void sub_constraints(const uint32_t* l, sink* s) {
   emit(s, f_mul(SF(LBU), a_hi));
   emit(s, f_mul(SF(LB), f_sub(a_lo, f_add(bv, f_mul(0xff00, sgn)))));
   emit(s, f_mul(SF(LB), f_sub(a_hi, f_mul(65535, sgn))));
-  /* loads leave the word as it was; stores write nothing to a register */
-  const fe loads = f_add(f_add(SF(LB), SF(LH)), f_add(SF(LBU), SF(LHU))), stores = f_add(SF(SB), SF(SH));
-  emit(s, f_mul(loads, f_sub(mv_lo, m_lo)));
-  emit(s, f_mul(loads, f_sub(mv_hi, m_hi)));
-  emit(s, f_mul(stores, a_lo));
-  emit(s, f_mul(stores, a_hi));
-  emit(s, f_mul(SF(SH), f_sub(f_sub(mv_lo, m_lo), f_mul(o0, f_sub(c_lo, m_lo)))));
-  emit(s, f_mul(SF(SH), f_sub(f_sub(mv_hi, m_hi), f_mul(o2, f_sub(c_lo, m_hi)))));
-  emit(s, f_mul(SF(SB), f_sub(f_sub(mv_lo, m_lo), f_add(f_mul(o0, f_sub(cb, mb[0])), f_mul(256, f_mul(o1, f_sub(cb, mb[1])))))));
-  emit(s, f_mul(SF(SB), f_sub(f_sub(mv_hi, m_hi), f_add(f_mul(o2, f_sub(cb, mb[2])), f_mul(256, f_mul(o3, f_sub(cb, mb[3])))))));
+  /* stores: A is the word left behind - the old word with the low half-word / byte of the stored register put in */
+  emit(s, f_mul(SF(SH), f_sub(f_sub(a_lo, m_lo), f_mul(o0, f_sub(c_lo, m_lo)))));
+  emit(s, f_mul(SF(SH), f_sub(f_sub(a_hi, m_hi), f_mul(o2, f_sub(c_lo, m_hi)))));
+  emit(s, f_mul(SF(SB), f_sub(f_sub(a_lo, m_lo), f_add(f_mul(o0, f_sub(cb, mb[0])), f_mul(256, f_mul(o1, f_sub(cb, mb[1])))))));
+  emit(s, f_mul(SF(SB), f_sub(f_sub(a_hi, m_hi), f_add(f_mul(o2, f_sub(cb, mb[2])), f_mul(256, f_mul(o3, f_sub(cb, mb[3])))))));
+  /* loads put no register limb on the bus */
+  emit(s, f_mul(f_add(f_add(SF(LB), SF(LH)), f_add(SF(LBU), SF(LHU))), c_lo));
 #undef SF
 }
 

@@ -11,7 +11,7 @@
  * (circuits/sp1-merkle-proof/src/main.rs:4-14, crypto-ops/src/lib.rs:8-23) ran to HALT(0) and
  * committed these public values.
  *
- * Format v11 (round 3).  The CPU row no longer carries its operands as bits: it holds 16-bit limbs,
+ * Format v12 (round 3).  The CPU row no longer carries its operands as bits: it holds 16-bit limbs,
  * adds / subtracts / compares (equality, unsigned order) / moves words itself, and sends xor / or /
  * and to a bitwise chip (bytes, looked up in a byte-operation table), shifts and signed less-than to
  * an ALU chip (bits) and every sub-word load or store to a sub-word chip, each with one row per such
@@ -64,20 +64,20 @@ enum {
   C_SEL = 3,                   /* N_CLS class selectors: column C_SEL + (class - 1) */
   C_CODE = C_SEL + N_CLS, C_UC /* unsigned comparison done in this row */, C_WR, C_USE2, C_RD, C_RS1, C_RS2, C_IMM_LO, C_IMM_HI,
   C_TGT_LO, C_TGT_HI,
-  C_A,                         /* value written to rd (stores: unused; branches: the taken / less-than flag) */
+  C_A,                         /* value written: rd's new value (branches: the taken / less-than flag), a store's new memory word */
   C_B = C_A + 2,               /* reg[rs1] */
-  C_C = C_B + 2,               /* reg[rs2], or the immediate */
-  C_M = C_C + 2,               /* memory slot: word read */
-  C_MV = C_M + 2,              /* memory slot: word left behind */
-  C_X = C_MV + 2,              /* adder output: sum / difference / effective address; sltu, bltu, bgeu: B - C + 2^32 [B < C];
+  C_C = C_B + 2,               /* second operand: reg[rs2], the immediate, or (loads) the memory word read */
+  C_X = C_C + 2,               /* adder output: sum / difference / effective address; sltu, bltu, bgeu: B - C + 2^32 [B < C];
                                   beq, bne: the limb differences' inverses */
   C_K0 = C_X + 2, C_K1,        /* carries / borrows (K1 of an unsigned comparison: B < C); beq, bne: "limb equal" flags */
   C_O1, C_O2, C_O3,            /* byte offset of the effective address 1, 2, 3: at most one is set (offset 0: none); the word
-                                  address on the memory bus is the linear form X - offset */
-  C_W_PLO, C_W_PHI,            /* previous value of rd */
-  C_GAP,                       /* 4 access-time differences (rs1, rs2, memory slot, rd): low 16 bits, high 8 bits each; the
+                                  address of a load or store is the linear form X - offset */
+  C_ADDR2,                     /* address of the second access: the register rs2, or a load's word address */
+  C_ADDR3,                     /* address of the written location: the register rd, or a store's word address */
+  C_W_PLO, C_W_PHI,            /* previous value of the written location */
+  C_GAP,                       /* 3 access-time differences (rs1; rs2 or load; rd or store): low 16 bits, high 8 bits each; the
                                   previous access time of a slot is its access time - 1 - difference, a linear form */
-  CPU_WIDTH = C_GAP + 8
+  CPU_WIDTH = C_GAP + 6
 };
 /* ---- ecall chip: one row per ecall.  The CPU row of an ecall only moves t0 (reads the code, writes the value left
  *      behind) and hands (time, pc, next pc, code, new t0) over on the ECALL bus; this chip decodes the code into six
@@ -124,8 +124,9 @@ enum { BW_IS_REAL = 0, BW_SEL /* 3 selectors: XOR OR AND */, BW_A = BW_SEL + 3, 
  *      (byte AND 0x80 = 128 * sign) ---- */
 enum {
   SW_IS_REAL = 0, SW_SEL /* 6 selectors: LB LH LBU LHU SB SH */, SW_O = SW_SEL + 6 /* 4: byte offset, one-hot */,
-  SW_A = SW_O + 4, SW_MB = SW_A + 2 /* the memory word's 4 bytes */, SW_CB = SW_MB + 4 /* the 2 bytes of the stored register's low limb */,
-  SW_MV = SW_CB + 2, SW_S = SW_MV + 2 /* sign bit a signed load extends */, SW_SELB /* the byte that carries it */,
+  SW_A = SW_O + 4 /* loads: the value loaded; stores: the word left behind */, SW_MB = SW_A + 2 /* the memory word's 4 bytes (stores: before) */,
+  SW_CB = SW_MB + 4 /* the 2 bytes of the stored register's low limb */,
+  SW_S = SW_CB + 2 /* sign bit a signed load extends */, SW_SELB /* the byte that carries it */,
   SUB_WIDTH = SW_SELB + 1
 };
 /* ---- Poseidon2 chip (row f4, stage 1): one width-16 permutation per row = one 2-to-1 compression of a Merkle tree of
@@ -254,7 +255,7 @@ int orc_machine_nodes_public(const uint32_t* keys, const uint32_t* digests, size
  * (key, left child's digest, right child's digest, own digest).  Returns the number of rows, (size_t)-1 if malformed;
  * rows may be NULL. */
 size_t orc_machine_agg_rows(const uint32_t* keys, const uint32_t* digests, size_t n, uint32_t* rows);
-#define ZKSP_VERSION_MACHINE 11u
+#define ZKSP_VERSION_MACHINE 12u
 /* vk: preprocessed commitment root + digest binding entry pc, table heights and keccak mode */
 void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t prep_root[8], uint32_t vk_digest[8]);
 size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_image, const orc_config* cfg, uint32_t pv_len);

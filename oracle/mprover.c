@@ -3,7 +3,7 @@
  * Whole machine proof on the CPU: the multi-table STARK that sp1-stark / sp1-prover 3.4.0 build over
  * p3-uni-stark, p3-fri, p3-merkle-tree (mixed-height MMCS) and p3-challenger (reference
  * Cargo.lock:7485, :7273, :5378, :5253, :5336, :5197) beneath `client.prove(&pk, stdin).run()`
- * (prover/src/bin/main.rs:71-74), restated under this repository's own format "ZKSP v11"
+ * (prover/src/bin/main.rs:71-74), restated under this repository's own format "ZKSP v12"
  * (DESIGN.md "Machine proof").  PARITY UNPINNED vs SP1 proof bytes.  The HIP prover must
  * reproduce these bytes exactly.
  *

@@ -49,16 +49,17 @@ def test_memory_argument_balances(zk, fx, built_lib, mode):
     def tup(addr, val, t_):
         return np.stack([addr, val, t_], axis=1)
 
-    # R1 / R2 / W slots
+    # the row's three accesses: rs1 at ts, rs2 or a load's word at ts + 1, rd or a store's word at ts + 2
     cons.append(tup(rs1, b, r1p)); prod.append(tup(rs1, b, ts))
     u = use2 == 1
     cons.append(tup(rs2[u], c[u], r2p[u])); prod.append(tup(rs2[u], c[u], ts[u] + 1))
     w = wr == 1
-    cons.append(tup(rd[w], wprev[w], wp[w])); prod.append(tup(rd[w], a[w], ts[w] + 3))
+    cons.append(tup(rd[w], wprev[w], wp[w])); prod.append(tup(rd[w], a[w], ts[w] + 2))
     # memory slot: loads 19..23, stores 24..26 at (rs1 + imm) & ~3; ecall 29 at register address 11
     ls = (op >= 19) & (op <= 26)
+    ld = op <= 23
     addr = ((b + imm) & 0xFFFFFFFF) & ~3
-    cons.append(tup(addr[ls], m[ls], mp[ls])); prod.append(tup(addr[ls], mv[ls], ts[ls] + 2))
+    cons.append(tup(addr[ls], m[ls], mp[ls])); prod.append(tup(addr[ls], mv[ls], ts[ls] + np.where(ld[ls], 1, 2)))
     ec = op == 29
     cons.append(tup(np.full(ec.sum(), 11), m[ec], mp[ec])); prod.append(tup(np.full(ec.sum(), 11), mv[ec], ts[ec] + 2))
     # keccak precompile calls: 50 words each, read-modify-write at ts + 2
@@ -90,7 +91,7 @@ def test_memory_argument_balances(zk, fx, built_lib, mode):
     key = lambda z: z[np.lexsort((z[:, 2], z[:, 1], z[:, 0]))]
     assert np.array_equal(key(P_), key(C_))
     # every consumed time is strictly older than the time of the access that consumes it
-    assert np.all(r1p < ts) and np.all(r2p[u] < ts[u] + 1) and np.all(mp[ls | ec] < ts[ls | ec] + 2) and np.all(wp[w] < ts[w] + 3)
+    assert np.all(r1p < ts) and np.all(r2p[u] < ts[u] + 1) and np.all(mp[ls | ec] < ts[ls | ec] + np.where(ld[ls | ec], 1, 2)) and np.all(wp[w] < ts[w] + 2)
 
 
 def test_records_replay_against_the_instruction_semantics(zk, fx, built_lib, oracle):

@@ -29,8 +29,8 @@ ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_ELF, ERR_EXECUTOR, ERR_GUEST_PANIC,
     ERR_UNSUPPORTED = range(1, 10)
 KECCAK_SOFTWARE, KECCAK_OBSERVE, KECCAK_REPLACE = 0, 1, 2
 PROOF_MACHINE, PROOF_KECCAK_CHIP = 1, 2
-# machine proof (format version 11): chips in proof order and the fixed header in front of the public values
-MACHINE_VERSION = 11
+# machine proof (format version 12): chips in proof order and the fixed header in front of the public values
+MACHINE_VERSION = 12
 MACHINE_CHIP_NAMES = ("cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "table", "cpu2", "alu", "alu2",
                       "subword", "subword2", "bitwise", "bitwise2", "poseidon2", "ecall")
 MACHINE_CHIPS = len(MACHINE_CHIP_NAMES)

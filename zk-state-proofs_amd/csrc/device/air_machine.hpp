@@ -70,10 +70,10 @@ ZKSP_HD constexpr int event_kind(uint32_t op) {
 constexpr int C_PC = 0, C_TS = 1, C_NEXT_PC = 2, C_SEL = 3, C_CODE = C_SEL + kNumCls, C_UC = C_CODE + 1, C_WR = C_CODE + 2,
               C_USE2 = C_CODE + 3, C_RD = C_CODE + 4, C_RS1 = C_CODE + 5, C_RS2 = C_CODE + 6, C_IMM_LO = C_CODE + 7,
               C_IMM_HI = C_CODE + 8, C_TGT_LO = C_CODE + 9, C_TGT_HI = C_CODE + 10, C_A = C_CODE + 11, C_B = C_A + 2, C_C = C_B + 2,
-              C_M = C_C + 2,
-              C_MV = C_M + 2, C_X = C_MV + 2, C_K0 = C_X + 2, C_K1 = C_K0 + 1, C_O1 = C_K0 + 2, C_O2 = C_O1 + 1, C_O3 = C_O1 + 2,
-              C_W_PLO = C_O1 + 3, C_W_PHI = C_W_PLO + 1, C_GAP = C_W_PLO + 2, kCpuWidth = C_GAP + 8;
-static_assert(kCpuWidth == 56, "CPU chip layout: seven Poseidon2 absorptions per row");
+              C_X = C_C + 2, C_K0 = C_X + 2, C_K1 = C_K0 + 1, C_O1 = C_K0 + 2, C_O2 = C_O1 + 1, C_O3 = C_O1 + 2,
+              C_ADDR2 = C_O1 + 3, C_ADDR3 = C_ADDR2 + 1, C_W_PLO = C_ADDR3 + 1, C_W_PHI = C_W_PLO + 1, C_GAP = C_W_PLO + 2,
+              kCpuWidth = C_GAP + 6;
+static_assert(kCpuWidth == 52, "CPU chip layout: three accesses per row, seven Poseidon2 absorptions");
 // ---- ecall chip: one row per ecall (the CPU row of an ecall moves t0 only and hands the rest over on the ECALL bus) ----
 enum { SC_HALT = 0, SC_WRITE, SC_COMMIT, SC_DEFER, SC_HINT_LEN, SC_HINT_READ };
 constexpr int EC_IS_REAL = 0, EC_SC = 1, EC_TS = EC_SC + 6, EC_PC = EC_TS + 1, EC_NP = EC_TS + 2, EC_B_LO = EC_TS + 3, EC_A_LO = EC_TS + 4,
@@ -106,9 +106,9 @@ static_assert(kAluWidth == 105, "ALU chip layout");
 constexpr int BW_IS_REAL = 0, BW_SEL = 1, BW_A = BW_SEL + 3, BW_B = BW_A + 4, BW_C = BW_B + 4, kBwWidth = BW_C + 4;
 static_assert(kBwWidth == 16, "bitwise chip layout");
 // ---- sub-word chip: lb lh lbu lhu sb sh ----
-constexpr int SW_IS_REAL = 0, SW_SEL = 1, SW_O = SW_SEL + 6, SW_A = SW_O + 4, SW_MB = SW_A + 2, SW_CB = SW_MB + 4, SW_MV = SW_CB + 2,
-              SW_S = SW_MV + 2, SW_SELB = SW_S + 1, kSubWidth = SW_SELB + 1;
-static_assert(kSubWidth == 23, "sub-word chip layout");
+constexpr int SW_IS_REAL = 0, SW_SEL = 1, SW_O = SW_SEL + 6, SW_A = SW_O + 4, SW_MB = SW_A + 2, SW_CB = SW_MB + 4,
+              SW_S = SW_CB + 2, SW_SELB = SW_S + 1, kSubWidth = SW_SELB + 1;
+static_assert(kSubWidth == 21, "sub-word chip layout");
 // ---- Poseidon2 chip (stage 1): one width-16 permutation per row = one 2-to-1 compression of
 //      a Merkle tree of 8-word digests.  Row r holds heap node K = r + 1 (root 1, children 2K and 2K + 1, the n leaves at
 //      n .. 2n - 1): it consumes its children's digests from the DIGEST bus and produces its own; the verifier supplies
@@ -166,7 +166,7 @@ ZKSP_HD constexpr uint32_t inv_pow2_mod(int n) {  // 2^-n mod p
 
 #define L(c) ctx.local(c)
 
-// ---- CPU chip: 69 constraints, emitted in order ----
+// ---- CPU chip: 69 constraints, emitted in order (three accesses per row) ----
 template <class Ctx>
 ZKSP_HD void eval_cpu(Ctx& ctx) {
   using F = typename Ctx::F;
@@ -199,17 +199,18 @@ ZKSP_HD void eval_cpu(Ctx& ctx) {
     ctx.emit(ctx.is_last() * (one - succ) * (np - pad_pc));
   }
   const F a_lo = L(C_A), a_hi = L(C_A + 1), b_lo = L(C_B), b_hi = L(C_B + 1), c_lo = L(C_C), c_hi = L(C_C + 1);
-  const F m_lo = L(C_M), m_hi = L(C_M + 1), mv_lo = L(C_MV), mv_hi = L(C_MV + 1), x_lo = L(C_X), x_hi = L(C_X + 1);
+  const F x_lo = L(C_X), x_hi = L(C_X + 1);
   const F imm_lo = L(C_IMM_LO), imm_hi = L(C_IMM_HI);
+  const F loadw = S(CL_LW) + S(CL_LDS), storew = S(CL_SW) + S(CL_STS);
   // operand C is the immediate
   {
-    const F immc = one - L(C_USE2);
+    const F immc = one - L(C_USE2) - loadw;
     ctx.emit(immc * (c_lo - imm_lo));
     ctx.emit(immc * (c_hi - imm_hi));
   }
   // the adder: X = B + C (add, jalr, lw, sub-word loads), X = B + imm (stores), X + C = B (sub)
   {
-    const F addc = S(CL_ADD) + S(CL_JALR) + S(CL_LW) + S(CL_LDS), addi = S(CL_SW) + S(CL_STS);
+    const F addc = S(CL_ADD) + S(CL_JALR), addi = loadw + storew;
     ctx.emit(addc * (b_lo + c_lo - (x_lo + k65536 * k0)));
     ctx.emit(addc * (b_hi + c_hi + k0 - (x_hi + k65536 * k1)));
     ctx.emit(addi * (b_lo + imm_lo - (x_lo + k65536 * k0)));
@@ -239,6 +240,11 @@ ZKSP_HD void eval_cpu(Ctx& ctx) {
     ctx.emit(noff * osum);
     ctx.emit(bool_c(osum, one));  // at most one of the three offset flags
     ctx.emit(S(CL_JALR) * (o2 + o3));
+    // the second access is rs2 or a load's word, the written location rd or a store's word
+    ctx.emit(L(C_USE2) * (L(C_ADDR2) - L(C_RS2)));
+    ctx.emit(loadw * (L(C_ADDR2) - xaddr));
+    ctx.emit(L(C_WR) * (L(C_ADDR3) - L(C_RD)));
+    ctx.emit(storew * (L(C_ADDR3) - xaddr));
   }
   // next pc
   {
@@ -266,15 +272,11 @@ ZKSP_HD void eval_cpu(Ctx& ctx) {
     ctx.emit(S(CL_KECCAK) * (np - (b_lo + k65536 * b_hi)));
     // (ecall: the ecall chip decides the next pc - the next instruction, or the padding instruction after HALT)
   }
-  // word loads and stores; what the memory slot leaves behind
+  // word loads and stores: the register gets the word read (C), the memory the register's value (C)
   {
-    ctx.emit(S(CL_LW) * (a_lo - m_lo));
-    ctx.emit(S(CL_LW) * (a_hi - m_hi));
-    const F keep = S(CL_LW) + S(CL_LDS);
-    ctx.emit(keep * (mv_lo - m_lo));
-    ctx.emit(keep * (mv_hi - m_hi));
-    ctx.emit(S(CL_SW) * (mv_lo - c_lo));
-    ctx.emit(S(CL_SW) * (mv_hi - c_hi));
+    const F mov = S(CL_LW) + S(CL_SW);
+    ctx.emit(mov * (a_lo - c_lo));
+    ctx.emit(mov * (a_hi - c_hi));
   }
   // ecall: the code in t0 is a 16-bit value (decoded, and the value left behind checked, by the ecall chip)
   ctx.emit(S(CL_ECALL) * b_hi);
@@ -282,7 +284,7 @@ ZKSP_HD void eval_cpu(Ctx& ctx) {
   // the memory-bus tuples), and the difference's low limb and high byte are looked up in the table chip
 #undef S
 }
-constexpr int kCpuConstraints = 69;
+constexpr int kCpuConstraints = 69 - 6 + 4 + 2;
 
 // ---- ecall chip: the code in t0 decoded into six flags; t0 rewritten with itself except by HINT_LEN (whose answer the CPU
 // row range-checks); the next pc: the next instruction, or the padding instruction after HALT ----
@@ -552,7 +554,7 @@ ZKSP_HD void eval_sub(Ctx& ctx) {
   const F mb[4] = {L(SW_MB), L(SW_MB + 1), L(SW_MB + 2), L(SW_MB + 3)}, cb = L(SW_CB);
   const F k256 = ZKSP_K(256), k65535 = ZKSP_K(65535);
   const F m_lo = mb[0] + k256 * mb[1], m_hi = mb[2] + k256 * mb[3], c_lo = cb + k256 * L(SW_CB + 1);
-  const F a_lo = L(SW_A), a_hi = L(SW_A + 1), mv_lo = L(SW_MV), mv_hi = L(SW_MV + 1);
+  const F a_lo = L(SW_A), a_hi = L(SW_A + 1);
   // half-word accesses are 2-aligned
   ctx.emit((SF(kLH) + SF(kLHU) + SF(kSH)) * (o[1] + o[3]));
   // the sign: only signed loads have one; it belongs to the accessed byte / the accessed half-word's upper byte
@@ -571,19 +573,16 @@ ZKSP_HD void eval_sub(Ctx& ctx) {
   ctx.emit(SF(kLBU) * a_hi);
   ctx.emit(SF(kLB) * (a_lo - (bv + ZKSP_K(0xff00) * sgn)));
   ctx.emit(SF(kLB) * (a_hi - k65535 * sgn));
-  // loads leave the word as it was; stores write nothing to a register
-  const F loads = SF(kLB) + SF(kLH) + SF(kLBU) + SF(kLHU), stores = SF(kSB) + SF(kSH);
-  ctx.emit(loads * (mv_lo - m_lo));
-  ctx.emit(loads * (mv_hi - m_hi));
-  ctx.emit(stores * a_lo);
-  ctx.emit(stores * a_hi);
-  ctx.emit(SF(kSH) * (mv_lo - m_lo - o[0] * (c_lo - m_lo)));
-  ctx.emit(SF(kSH) * (mv_hi - m_hi - o[2] * (c_lo - m_hi)));
-  ctx.emit(SF(kSB) * (mv_lo - m_lo - (o[0] * (cb - mb[0]) + k256 * (o[1] * (cb - mb[1])))));
-  ctx.emit(SF(kSB) * (mv_hi - m_hi - (o[2] * (cb - mb[2]) + k256 * (o[3] * (cb - mb[3])))));
+  // stores: A is the word left behind - the old word with the low half-word / byte of the stored register put in
+  ctx.emit(SF(kSH) * (a_lo - m_lo - o[0] * (c_lo - m_lo)));
+  ctx.emit(SF(kSH) * (a_hi - m_hi - o[2] * (c_lo - m_hi)));
+  ctx.emit(SF(kSB) * (a_lo - m_lo - (o[0] * (cb - mb[0]) + k256 * (o[1] * (cb - mb[1])))));
+  ctx.emit(SF(kSB) * (a_hi - m_hi - (o[2] * (cb - mb[2]) + k256 * (o[3] * (cb - mb[3])))));
+  // loads put no register limb on the bus
+  ctx.emit((SF(kLB) + SF(kLH) + SF(kLBU) + SF(kLHU)) * c_lo);
 #undef SF
 }
-constexpr int kSubConstraints = 34;
+constexpr int kSubConstraints = 31;
 
 // ---- Poseidon2 chip: every S-box through its cube (x^3, then x^7 = (x^3)^2 x: degree 3); between S-boxes the state is
 // linear in the columns.  Ctx::p2(): the permutation's constants (Montgomery words).  286 constraints. ----

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
   const uint32_t ts = 4 * ((uint32_t)cyc + 1);
   const uint32_t n_cycles = rec.counts[kCountWords * b];
   const uint32_t pad_pc = rec.text_base + 4 * (rec.n_program - 1);
-  uint32_t gap[4] = {0, 0, 0, 0};
+  uint32_t gap[3] = {0, 0, 0};
   if (cyc >= n_cycles) {
     const uint32_t pts = cyc == n_cycles ? rec.counts[kCountWords * b + 6] : ts - 4;
     o.zero(0, kCpuWidth);
@@ -106,12 +106,11 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
     case CL_ADD: x = a; k0 = (blo + clo) >> 16; k1 = (bhi + chi + k0) >> 16; break;
     case CL_SUB: x = a; k0 = ((a & 0xffff) + clo) >> 16; k1 = ((a >> 16) + chi + k0) >> 16; break;
     case CL_JAL: next = tgt; break;
-    case CL_JALR: case CL_LW: case CL_LDS:
+    case CL_JALR:
       x = bb + c; k0 = (blo + clo) >> 16; k1 = (bhi + chi + k0) >> 16;
-      if (cls == CL_JALR) { off = x & 1; next = x & ~1u; }
-      else off = x & 3;
+      off = x & 1; next = x & ~1u;
       break;
-    case CL_SW: case CL_STS:
+    case CL_LW: case CL_LDS: case CL_SW: case CL_STS:  // the address is rs1 + immediate
       x = bb + imm; k0 = (blo + (imm & 0xffff)) >> 16; k1 = (bhi + (imm >> 16) + k0) >> 16;
       off = x & 3;
       break;
@@ -140,18 +139,23 @@ __global__ __launch_bounds__(kMT) void cpu_trace_kernel(MachineRecords rec, uint
   }
   if (cls == CL_BEQ || cls == CL_BNE) { o.put(C_X, x_lo_m); o.put(C_X + 1, x_hi_m); }
   else o.limbs(C_X, x);
-  o.limbs(C_A, a); o.limbs(C_B, bb); o.limbs(C_C, c); o.limbs(C_M, m); o.limbs(C_MV, mv);
+  // second access: rs2, or the word a load reads (which then sits in C); written location: rd, or the word a store
+  // leaves behind (in A, its old value in W_P)
+  const bool load = cls == CL_LW || cls == CL_LDS, store = cls == CL_SW || cls == CL_STS;
+  o.limbs(C_A, store ? mv : a); o.limbs(C_B, bb); o.limbs(C_C, load ? m : c);
   o.flag(C_K0, k0 != 0); o.flag(C_K1, k1 != 0);
   for (uint32_t i = 1; i < 4; ++i) o.flag(C_O1 + i - 1, i == off);
   o.val(C_NEXT_PC, next);
-  const bool memq = cls == CL_LW || cls == CL_SW || cls == CL_LDS || cls == CL_STS;
+  o.val(C_ADDR2, use2 ? rs2 : load ? (x & ~3u) : 0u);
+  o.val(C_ADDR3, wr ? rd : store ? (x & ~3u) : 0u);
   gap[0] = ts - cy[7] - 1;
   if (use2) gap[1] = ts - cy[8];
-  if (memq) gap[2] = ts + 1 - cy[9];
-  if (wr) gap[3] = ts + 2 - cy[10];
-  o.val(C_W_PLO, wr ? wprev & 0xffff : 0u);
-  o.val(C_W_PHI, wr ? wprev >> 16 : 0u);
-  for (int q = 0; q < 4; ++q) o.limbs(C_GAP + 2 * q, gap[q]);
+  if (load) gap[1] = ts - cy[9];
+  uint32_t wp = 0;
+  if (wr) { gap[2] = ts + 1 - cy[10]; wp = wprev; }
+  if (store) { gap[2] = ts + 1 - cy[9]; wp = m; }
+  o.limbs(C_W_PLO, wp);
+  for (int q = 0; q < 3; ++q) o.limbs(C_GAP + 2 * q, gap[q]);
 }
 
 // The ecall chip: row r is the r-th ecall of the run
@@ -298,11 +302,10 @@ __global__ __launch_bounds__(kMT) void sub_trace_kernel(MachineRecords rec, uint
   o.put(SW_IS_REAL, kR1);
   for (uint32_t k = 0; k < 6; ++k) o.flag(SW_SEL + k, k == sel);
   for (uint32_t k = 0; k < 4; ++k) o.flag(SW_O + k, k == off);
-  o.limbs(SW_A, store ? 0u : a);
+  o.limbs(SW_A, store ? mv : a);  // loads: the value loaded; stores: the word left behind
   for (uint32_t k = 0; k < 4; ++k) o.put(SW_MB + k, mont((m >> (8 * k)) & 0xff));
-  o.put(SW_CB, mont(c & 0xff));
-  o.put(SW_CB + 1, mont((c >> 8) & 0xff));
-  o.limbs(SW_MV, mv);
+  o.put(SW_CB, store ? mont(c & 0xff) : 0u);
+  o.put(SW_CB + 1, store ? mont((c >> 8) & 0xff) : 0u);
   const bool sl = code == LB || code == LH;
   const uint32_t sb = sl ? (m >> (8 * (code == LB ? off : (off | 1)))) & 0xff : 0u;
   o.flag(SW_S, (sb >> 7) != 0);
@@ -751,19 +754,19 @@ void launch_table_trace(hipStream_t stream, const MachineRecords& rec, uint32_t*
   hipLaunchKernelGGL(count_column_kernel, dim3((unsigned)((n + kMT - 1) / kMT), batch), dim3(kMT), 0, stream, rec.table_hist, trace, n);
 }
 
-// The CPU chip's 21 bus interactions evaluated from values a row holds once (the class id, the selector sums, the word
-// address, the four previous access times), instead of through the generic linear forms (which reload and rescale every
-// column for every tuple): the same field elements, a fraction of the work.  visit(j, ma, fa, mb, fb) is called for the
-// LogUp slots j = 0..9 in order (machine_defs.hpp "LogUp layout") with the slot's value ma / fa + mb / fb: slots 0..7 are
-// pairs, slot 8 the last single receive (mb = 0, fb = 1), slot 9 the four merged sends, M / F with M = sum m_k and
-// F = sum m_k f_k + 1 - M.  Multiplicities are signed.  Must restate machine_defs.cpp's g_cpu[] exactly: the whole-proof
-// parity tests compare against the oracle's generic evaluation.
+// The CPU chip's 19 bus interactions evaluated from values a row holds once (the class id, the selector sums, the
+// three previous access times), instead of through the generic linear forms (which reload and rescale every column for
+// every tuple): the same field elements, a fraction of the work.  visit(j, ma, fa, mb, fb) is called for the LogUp
+// slots j = 0..7 in order (machine_defs.hpp "LogUp layout") with the slot's value ma / fa + mb / fb: slots 0..6 are
+// pairs, slot 7 the five merged sends, M / F with M = sum m_k and F = sum m_k f_k + 1 - M.  Multiplicities are signed.
+// Must restate machine_defs.cpp's g_cpu[] exactly: the whole-proof parity tests compare against the oracle's generic
+// evaluation.
 // J0, J1: only the slots J0 <= j < J1 are visited (the loads the others need are dead code): the kernels below
-// evaluate the slots in three launches, because all 22 extension-field fingerprints at once do not fit the register
-// file (256 VGPRs and one wave per SIMD when they are evaluated together).
-constexpr int kCpuSlots = 10, kCpuHelpers = kCpuSlots - 1, kCpuBusGroups = 3;
-__host__ __device__ constexpr int cpu_group_lo(int g) { return g == 0 ? 0 : g == 1 ? 4 : 8; }
-__host__ __device__ constexpr int cpu_group_hi(int g) { return g == 0 ? 4 : g == 1 ? 8 : kCpuSlots; }
+// evaluate the slots in kCpuBusGroups launches, because all the extension-field fingerprints at once do not fit the
+// register file (256 VGPRs and one wave per SIMD when they are evaluated together).
+constexpr int kCpuSlots = 8, kCpuHelpers = kCpuSlots - 1, kCpuBusGroups = 2;
+__host__ __device__ constexpr int cpu_group_lo(int g) { return g == 0 ? 0 : 4; }
+__host__ __device__ constexpr int cpu_group_hi(int g) { return g == 0 ? 4 : kCpuSlots; }
 template <int J0, int J1, class V>
 __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, size_t cs, const Fp4& gamma,
                                               const uint32_t* __restrict__ bpow, V&& visit_all) {
@@ -771,7 +774,7 @@ __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, 
     if (j >= J0 && j < J1) visit_all(j, ma, fa, mb, fb);
   };
   auto col = [&](int c) { return Fp::raw(row[(size_t)c * cs]); };
-  const Fp one = Fp::one(), two = Fp::raw(cmonty(2)), three = Fp::raw(cmonty(3)), k65536 = Fp::raw(cmonty(65536));
+  const Fp one = Fp::one(), three = Fp::raw(cmonty(3)), k65536 = Fp::raw(cmonty(65536));
   Fp sel[kNumCls + 1];
   Fp clsid = Fp::zero(), kf = Fp::zero();
 #pragma unroll
@@ -780,18 +783,18 @@ __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, 
     sel[k] = col(selc(k));
     clsid = clsid + kf * sel[k];
   }
-  const Fp memw = sel[CL_LW] + sel[CL_SW] + sel[CL_LDS] + sel[CL_STS], memq = memw;
+  const Fp memw = sel[CL_LW] + sel[CL_SW] + sel[CL_LDS] + sel[CL_STS];
   const Fp al = memw + sel[CL_JALR], top = al + sel[CL_KECCAK];
   const Fp uc = col(C_UC);
   const Fp chk = top + sel[CL_ADD] + sel[CL_SUB] + sel[CL_ECALL] + uc;
-  const Fp alu = sel[CL_ALU] + sel[CL_BLT] + sel[CL_BGE] - uc, sub = sel[CL_LDS] + sel[CL_STS];
+  const Fp alu = sel[CL_ALU] + sel[CL_BLT] + sel[CL_BGE] - uc;
   const Fp ts = col(C_TS), wr = col(C_WR), use2 = col(C_USE2), rd = col(C_RD), rs1 = col(C_RS1), rs2 = col(C_RS2), code = col(C_CODE);
   const Fp a_lo = col(C_A), a_hi = col(C_A + 1), b_lo = col(C_B), b_hi = col(C_B + 1), c_lo = col(C_C), c_hi = col(C_C + 1),
-           m_lo = col(C_M), m_hi = col(C_M + 1), mv_lo = col(C_MV), mv_hi = col(C_MV + 1), x_lo = col(C_X), x_hi = col(C_X + 1);
+           x_lo = col(C_X), x_hi = col(C_X + 1);
   const Fp o1 = col(C_O1), o2 = col(C_O2), o3 = col(C_O3), off = o1 + o2.dbl() + three * o3;
-  Fp g[8];
+  Fp g[6];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) g[i] = col(C_GAP + i);
+  for (int i = 0; i < 6; ++i) g[i] = col(C_GAP + i);
   const Fp4 b1 = m_load_fp4(bpow + 4), b2 = m_load_fp4(bpow + 8), b3 = m_load_fp4(bpow + 12), b4 = m_load_fp4(bpow + 16);
   auto busc = [&](int bus) {
     Fp4 f = gamma;
@@ -801,43 +804,40 @@ __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, 
   const Fp4 gmem = busc(BUS_MEM), grng = busc(BUS_RANGE), gbyt = busc(BUS_BYTES);
   auto mem = [&](Fp addr, Fp lo, Fp hi, Fp t) { return gmem + b1 * addr + b2 * lo + b3 * hi + b4 * t; };
   // previous access time of slot q (accessed at ts + q): ts + q - 1 - (gap_lo + 2^16 gap_hi)
-  auto pts = [&](int q) { return ts - (g[2 * q] + k65536 * g[2 * q + 1]) + (q == 0 ? -one : q == 1 ? Fp::zero() : q == 2 ? one : two); };
-  if (J0 <= 0 && 0 < J1) {  // helper 0: instruction fetch (receive), rs1 consume
+  auto pts = [&](int q) { return ts - (g[2 * q] + k65536 * g[2 * q + 1]) + (q == 0 ? -one : q == 1 ? Fp::zero() : one); };
+  // the second access (rs2, or a load's word, whose value sits in C) and the written location (rd, or a store's word:
+  // new value in A, old value in W_P)
+  const Fp m2 = use2 + sel[CL_LW] + sel[CL_LDS], m3 = wr + sel[CL_SW] + sel[CL_STS];
+  const Fp ad2 = col(C_ADDR2), ad3 = col(C_ADDR3);
+  if (J0 <= 0 && 0 < J1) {  // instruction fetch (receive), rs1 consume
     Fp4 f = busc(BUS_PROG) + b1 * col(C_PC) + b2 * clsid + b3 * code + b4 * uc;
     f += m_load_fp4(bpow + 20) * wr + m_load_fp4(bpow + 24) * use2 + m_load_fp4(bpow + 28) * rd + m_load_fp4(bpow + 32) * rs1 +
          m_load_fp4(bpow + 36) * rs2 + m_load_fp4(bpow + 40) * col(C_IMM_LO) + m_load_fp4(bpow + 44) * col(C_IMM_HI) +
          m_load_fp4(bpow + 48) * col(C_TGT_LO) + m_load_fp4(bpow + 52) * col(C_TGT_HI);
     visit(0, -one, f, -one, mem(rs1, b_lo, b_hi, pts(0)));
   }
-  if (J0 <= 1 && 1 < J1) visit(1, one, mem(rs1, b_lo, b_hi, ts), -use2, mem(rs2, c_lo, c_hi, pts(1)));
-  if (J0 <= 3 && 2 < J1) {
-    const Fp maddr = x_lo + k65536 * x_hi - off;  // the word address: the adder output less the byte offset
-    visit(2, use2, mem(rs2, c_lo, c_hi, ts + one), -memq, mem(maddr, m_lo, m_hi, pts(2)));
-    visit(3, memq, mem(maddr, mv_lo, mv_hi, ts + two), -wr, mem(rd, col(C_W_PLO), col(C_W_PHI), pts(3)));
-  }
-  // the low limbs of the four access-time differences (range16), the two pairs of high bytes
-  if (J0 <= 4 && 4 < J1) visit(4, wr, mem(rd, a_lo, a_hi, ts + three), -one, grng + b2 * g[0]);
-  if (J0 <= 5 && 5 < J1) visit(5, -one, grng + b2 * g[2], -one, grng + b2 * g[4]);
-  if (J0 <= 6 && 6 < J1) visit(6, -one, grng + b2 * g[6], -one, gbyt + b1 * g[1] + b2 * g[3]);
+  if (J0 <= 1 && 1 < J1) visit(1, one, mem(rs1, b_lo, b_hi, ts), -m2, mem(ad2, c_lo, c_hi, pts(1)));
+  if (J0 <= 2 && 2 < J1) visit(2, m2, mem(ad2, c_lo, c_hi, ts + one), -m3, mem(ad3, col(C_W_PLO), col(C_W_PHI), pts(2)));
+  // the low limbs of the three access-time differences (range16), their high bytes
+  if (J0 <= 3 && 3 < J1) visit(3, m3, mem(ad3, a_lo, a_hi, ts + one.dbl()), -one, grng + b2 * g[0]);
+  if (J0 <= 4 && 4 < J1) visit(4, -one, grng + b2 * g[2], -one, grng + b2 * g[4]);
+  if (J0 <= 5 && 5 < J1) visit(5, -one, gbyt + b1 * g[1] + b2 * g[3], -one, gbyt + b1 * g[5]);
   // the adder output: high limb (kind 2 where it is an address), low limb less the byte offset (kind 1 where aligned)
-  if (J0 <= 7 && 7 < J1) visit(7, -one, gbyt + b1 * g[5] + b2 * g[7], -chk, grng + b1 * top.dbl() + b2 * x_hi);
-  if (J0 <= 8 && 8 < J1) visit(8, -chk, grng + b1 * al + b2 * (x_lo - off), Fp::zero(), Fp4::one());
-  if (J0 <= 9 && 9 < J1) {
-    // one instruction class each: ALU-chip sends, sub-word sends, the keccak call, the ecall hand-over
-    const Fp4 falu = busc(BUS_ALU) + b1 * code + b2 * a_lo + b3 * a_hi + b4 * b_lo + m_load_fp4(bpow + 20) * b_hi +
-                     m_load_fp4(bpow + 24) * c_lo + m_load_fp4(bpow + 28) * c_hi;
-    Fp4 f = falu * alu;
-    const Fp4 fsub = busc(BUS_SUB) + b1 * code + b2 * off + b3 * a_lo + b4 * a_hi + m_load_fp4(bpow + 20) * m_lo +
-                     m_load_fp4(bpow + 24) * m_hi + m_load_fp4(bpow + 28) * c_lo + m_load_fp4(bpow + 32) * mv_lo +
-                     m_load_fp4(bpow + 36) * mv_hi;
-    f += fsub * sub;
+  if (J0 <= 6 && 6 < J1) visit(6, -chk, grng + b1 * top.dbl() + b2 * x_hi, -chk, grng + b1 * al + b2 * (x_lo - off));
+  if (J0 <= 7 && 7 < J1) {
+    // one instruction class each: ALU-chip sends, sub-word loads and stores, the keccak call, the ecall hand-over
+    const Fp4 b5 = m_load_fp4(bpow + 20), b6 = m_load_fp4(bpow + 24), b7 = m_load_fp4(bpow + 28);
+    Fp4 f = (busc(BUS_ALU) + b1 * code + b2 * a_lo + b3 * a_hi + b4 * b_lo + b5 * b_hi + b6 * c_lo + b7 * c_hi) * alu;
+    // (op, offset, A, the memory word before, the stored register's low limb): a load has the word in C, a store in W_P
+    const Fp lds = sel[CL_LDS], sts = sel[CL_STS], sub = lds + sts;
+    const Fp w_lo = lds * c_lo + sts * col(C_W_PLO), w_hi = lds * c_hi + sts * col(C_W_PHI);
+    f += (busc(BUS_SUB) + b1 * code + b2 * off + b3 * a_lo + b4 * a_hi) * sub + b5 * w_lo + b6 * w_hi + b7 * (sts * c_lo);
     const Fp kec = sel[CL_KECCAK], ecl = sel[CL_ECALL];
     f += (busc(BUS_KCALL) + b1 * ts + b2 * c_lo + b3 * c_hi) * kec;
-    f += (busc(BUS_ECALL) + b1 * ts + b2 * col(C_PC) + b3 * col(C_NEXT_PC) + b4 * b_lo + m_load_fp4(bpow + 20) * a_lo +
-          m_load_fp4(bpow + 24) * a_hi) * ecl;
+    f += (busc(BUS_ECALL) + b1 * ts + b2 * col(C_PC) + b3 * col(C_NEXT_PC) + b4 * b_lo + b5 * a_lo + b6 * a_hi) * ecl;
     const Fp msum = alu + sub + kec + ecl;
     f.c[0] += one - msum;
-    visit(9, msum, f, Fp::zero(), Fp4::one());
+    visit(7, msum, f, Fp::zero(), Fp4::one());
   }
 }
 
@@ -1041,7 +1041,7 @@ void launch_perm_trace(hipStream_t stream, const PermArgs& a) {
     const dim3 grid((unsigned)((h + kMT - 1) / kMT), a.batch);
     hipLaunchKernelGGL(perm_terms_cpu_kernel<0>, grid, dim3(kMT), 0, stream, a);
     hipLaunchKernelGGL(perm_terms_cpu_kernel<1>, grid, dim3(kMT), 0, stream, a);
-    hipLaunchKernelGGL(perm_terms_cpu_kernel<2>, grid, dim3(kMT), 0, stream, a);
+    static_assert(kCpuBusGroups == 2, "one launch per group of slots");
   } else
     hipLaunchKernelGGL(perm_terms_kernel, dim3((unsigned)((h + kMT - 1) / kMT), a.batch), dim3(kMT), 0, stream, a);
   if (h >= (size_t)4 * kScanSlice && a.slice_sums) {
@@ -1262,7 +1262,7 @@ __global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
 }
 
 // CPU chip: the base constraints (task 0) and the LogUp constraints with the fingerprints of cpu_bus_pairs, one launch
-// per group of slots (tasks 1..3), each with its own register budget.  A point's partial sum travels through
+// per group of slots (tasks 1..2), each with its own register budget.  A point's partial sum travels through
 // a.partial ([B][2H] Fp4): task 0 writes it, the others add, the last one divides by the vanishing polynomial.
 template <int TASK>
 __global__ __launch_bounds__(kMT) void cpu_quotient_task_kernel(MQuotArgs a) {
@@ -1378,7 +1378,6 @@ void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a) {
       hipLaunchKernelGGL(cpu_quotient_task_kernel<0>, grid, block, 0, stream, a);
       hipLaunchKernelGGL(cpu_quotient_task_kernel<1>, grid, block, 0, stream, a);
       hipLaunchKernelGGL(cpu_quotient_task_kernel<2>, grid, block, 0, stream, a);
-      hipLaunchKernelGGL(cpu_quotient_task_kernel<3>, grid, block, 0, stream, a);
       break;
     case kAlu:
     case kAlu2: hipLaunchKernelGGL(machine_quotient_kernel<kAlu>, grid, block, 0, stream, a); break;

@@ -11,7 +11,7 @@
 
 using namespace zksp;
 
-// Header (version, chip heights, exit code, digests, key digest), public values, body: the v11 proof object.
+// Header (version, chip heights, exit code, digests, key digest), public values, body: the v12 proof object.
 int machine_proof_from_parts(const zksp_pk* pk, const ExecutionRecord& r, const int* lh, uint32_t handover_pc,
                              const std::vector<uint32_t>& agg_leaves, const std::vector<uint32_t>& agg_keys, const uint32_t* body,
                              size_t body_words, zksp_proof** out) {

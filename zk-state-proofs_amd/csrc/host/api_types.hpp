@@ -24,7 +24,7 @@ struct zksp_stdin {
 };
 struct zksp_proof { std::vector<uint8_t> bytes; zksp::ProofHeader hdr; zksp::MachineHeader mhdr; uint32_t version = 2; };
 
-// api_machine.cpp: the v11 proof object from an execution record, the chip heights, the aggregation leaves and a fetched body
+// api_machine.cpp: the v12 proof object from an execution record, the chip heights, the aggregation leaves and a fetched body
 int machine_proof_from_parts(const zksp_pk* pk, const zksp::ExecutionRecord& r, const int* log_heights, uint32_t handover_pc,
                              const std::vector<uint32_t>& agg_leaves, const std::vector<uint32_t>& agg_keys, const uint32_t* body,
                              size_t body_words, zksp_proof** out);

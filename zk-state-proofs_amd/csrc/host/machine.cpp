@@ -302,7 +302,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
           CHECK_ADDR(ad, sz);
           if (ad < kRegSpace) FAULT("guest access below 0x1000 (register-mapped addresses)");
           const uint32_t w = ad & ~3u;
-          c.m_pts = touch(w, ts + 2);
+          c.m_pts = touch(w, ts + 1);  // a load reads its word as the row's second access
           memcpy(&c.m, M + w, 4);
           c.mv = c.m;
           const uint32_t sh = 8 * (ad & 3);
@@ -405,7 +405,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
       if (bw_event) out->bw_idx.push_back((uint32_t)(cycles - 1));
       if (r.wr) {
         c.w_prev = x[r.rd];
-        c.w_pts = reg_ts[r.rd]; reg_ts[r.rd] = ts + 3;
+        c.w_pts = reg_ts[r.rd]; reg_ts[r.rd] = ts + 2;  // the written location is the row's third access
         x[r.rd] = res;
       }
       out->cycles.push_back(c);

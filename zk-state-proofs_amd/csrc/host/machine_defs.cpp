@@ -1,4 +1,4 @@
-// See machine_defs.hpp.  Bus protocol (DESIGN.md "Machine proof", format v11):
+// See machine_defs.hpp.  Bus protocol (DESIGN.md "Machine proof", format v12):
 //   MEM    (addr, lo, hi, time)   every access consumes its predecessor's tuple and produces its own
 //   PROG   (pc, class, code, uc, wr, use2, rd, rs1, rs2, imm_lo, imm_hi, tgt_lo, tgt_hi)   instruction fetch, every CPU row
 //   KCALL  (time, ptr_lo, ptr_hi)   CPU -> keccak-memory: one precompile call
@@ -88,14 +88,14 @@ Interaction bytes_inter(int sign, const LinForm& mult, const LinForm& x, const L
   return it;
 }
 
-constexpr int kCpuInter = 21;
+constexpr int kCpuInter = 19;
 Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7], g_alu[1], g_sub[5], g_bw[5], g_p2[5], g_ecall[10];
 ChipDef g_chips[kNumChips];
 
 void build() {
   const LinForm one = lf_const(1), zero = lf_const(0), ts = lf_col(C_TS);
   const LinForm a_lo = lf_col(C_A), a_hi = lf_col(C_A + 1), b_lo = lf_col(C_B), b_hi = lf_col(C_B + 1), c_lo = lf_col(C_C),
-                c_hi = lf_col(C_C + 1), m_lo = lf_col(C_M), m_hi = lf_col(C_M + 1);
+                c_hi = lf_col(C_C + 1);
   {
     Interaction& it = g_cpu[0];
     it = Interaction{};
@@ -107,31 +107,30 @@ void build() {
     it.el[7] = lf_col(C_RS1); it.el[8] = lf_col(C_RS2); it.el[9] = lf_col(C_IMM_LO); it.el[10] = lf_col(C_IMM_HI);
     it.el[11] = lf_col(C_TGT_LO); it.el[12] = lf_col(C_TGT_HI);
   }
-  // previous access time of slot q (accessed at ts + q): ts + q - 1 - (gap_lo + 2^16 gap_hi)
-  LinForm pts[4];
-  for (int q = 0; q < 4; ++q) {
+  // Three accesses per row: rs1 at ts, the second operand (rs2, or a load's memory word) at ts + 1, the written location
+  // (rd, or a store's memory word) at ts + 2.  Previous access time of slot q: ts + q - 1 - (gap_lo + 2^16 gap_hi).
+  LinForm pts[3];
+  for (int q = 0; q < 3; ++q) {
     pts[q] = lf_zero();
     lf_add(pts[q], C_TS, 1); lf_add(pts[q], C_GAP + 2 * q, kP - 1); lf_add(pts[q], C_GAP + 2 * q + 1, kP - 65536);
     pts[q].c0 = mont((uint64_t)(kP + q - 1));
   }
   g_cpu[1] = mem_inter(-1, one, lf_col(C_RS1), b_lo, b_hi, pts[0]);
   g_cpu[2] = mem_inter(+1, one, lf_col(C_RS1), b_lo, b_hi, ts);
-  g_cpu[3] = mem_inter(-1, lf_col(C_USE2), lf_col(C_RS2), c_lo, c_hi, pts[1]);
-  g_cpu[4] = mem_inter(+1, lf_col(C_USE2), lf_col(C_RS2), c_lo, c_hi, lf_plus(ts, 1));
   {
-    // the word address is the adder output less the byte offset: a linear form (below 0x78000000: X's lookups)
-    const LinForm memq = lf_sum({selc(CL_LW), selc(CL_SW), selc(CL_LDS), selc(CL_STS)});
-    LinForm maddr = lf_pair(C_X, C_X + 1, 65536);
-    lf_add(maddr, C_O1, kP - 1); lf_add(maddr, C_O2, kP - 2); lf_add(maddr, C_O3, kP - 3);
-    g_cpu[5] = mem_inter(-1, memq, maddr, m_lo, m_hi, pts[2]);
-    g_cpu[6] = mem_inter(+1, memq, maddr, lf_col(C_MV), lf_col(C_MV + 1), lf_plus(ts, 2));
+    // rs2 (USE2) or a load: exclusive by the Program table (a load's second operand is its immediate)
+    const LinForm m2 = lf_sum({C_USE2, selc(CL_LW), selc(CL_LDS)});
+    g_cpu[3] = mem_inter(-1, m2, lf_col(C_ADDR2), c_lo, c_hi, pts[1]);
+    g_cpu[4] = mem_inter(+1, m2, lf_col(C_ADDR2), c_lo, c_hi, lf_plus(ts, 1));
+    // rd (WR) or a store (which writes no register)
+    const LinForm m3 = lf_sum({C_WR, selc(CL_SW), selc(CL_STS)});
+    g_cpu[5] = mem_inter(-1, m3, lf_col(C_ADDR3), lf_col(C_W_PLO), lf_col(C_W_PHI), pts[2]);
+    g_cpu[6] = mem_inter(+1, m3, lf_col(C_ADDR3), a_lo, a_hi, lf_plus(ts, 2));
   }
-  g_cpu[7] = mem_inter(-1, lf_col(C_WR), lf_col(C_RD), lf_col(C_W_PLO), lf_col(C_W_PHI), pts[3]);
-  g_cpu[8] = mem_inter(+1, lf_col(C_WR), lf_col(C_RD), a_lo, a_hi, lf_plus(ts, 3));
-  // access-time differences: every row looks up its four low limbs and the two pairs of high bytes
-  for (int q = 0; q < 4; ++q) g_cpu[9 + q] = range_inter(-1, one, zero, lf_col(C_GAP + 2 * q));
-  g_cpu[13] = bytes_inter(-1, one, lf_col(C_GAP + 1), lf_col(C_GAP + 3));
-  g_cpu[14] = bytes_inter(-1, one, lf_col(C_GAP + 5), lf_col(C_GAP + 7));
+  // access-time differences: every row looks up its three low limbs and the high bytes
+  for (int q = 0; q < 3; ++q) g_cpu[7 + q] = range_inter(-1, one, zero, lf_col(C_GAP + 2 * q));
+  g_cpu[10] = bytes_inter(-1, one, lf_col(C_GAP + 1), lf_col(C_GAP + 3));
+  g_cpu[11] = bytes_inter(-1, one, lf_col(C_GAP + 5), zero);
   {
     // the adder output is canonical, an address is word-aligned once its byte offset is taken off, and addresses,
     // jump targets and the keccak call's return address stay below 0x78000000
@@ -142,29 +141,34 @@ void build() {
     lf_add(xoff, C_O1, kP - 1); lf_add(xoff, C_O2, kP - 2); lf_add(xoff, C_O3, kP - 3);
     LinForm top = lf_zero();  // kind 2: the high limb of an address is at most kAddrHiMax
     for (int c : {selc(CL_JALR), selc(CL_LW), selc(CL_SW), selc(CL_LDS), selc(CL_STS), selc(CL_KECCAK)}) lf_add(top, c, 2);
-    g_cpu[15] = range_inter(-1, chk, top, lf_col(C_X + 1));
-    g_cpu[16] = range_inter(-1, chk, lf_sum({selc(CL_JALR), selc(CL_LW), selc(CL_SW), selc(CL_LDS), selc(CL_STS)}), xoff);
+    g_cpu[12] = range_inter(-1, chk, top, lf_col(C_X + 1));
+    g_cpu[13] = range_inter(-1, chk, lf_sum({selc(CL_JALR), selc(CL_LW), selc(CL_SW), selc(CL_LDS), selc(CL_STS)}), xoff);
   }
   {
-    Interaction& al = g_cpu[17];
+    Interaction& al = g_cpu[14];
     al = Interaction{};
     // every ALU-class instruction and every ordered branch, except the unsigned comparisons the row does itself
     al.bus = BUS_ALU; al.sign = +1; al.mult = lf_sum({selc(CL_ALU), selc(CL_BLT), selc(CL_BGE)}); lf_add(al.mult, C_UC, kP - 1); al.n_el = 7;
     al.el[0] = lf_col(C_CODE);
     al.el[1] = a_lo; al.el[2] = a_hi; al.el[3] = b_lo; al.el[4] = b_hi; al.el[5] = c_lo; al.el[6] = c_hi;
-    Interaction& sb = g_cpu[18];
-    sb = Interaction{};
-    sb.bus = BUS_SUB; sb.sign = +1; sb.mult = lf_sum({selc(CL_LDS), selc(CL_STS)}); sb.n_el = 9;
-    sb.el[0] = lf_col(C_CODE);
-    sb.el[1] = lf_zero(); lf_add(sb.el[1], C_O1, 1); lf_add(sb.el[1], C_O2, 2); lf_add(sb.el[1], C_O3, 3);
-    sb.el[2] = a_lo; sb.el[3] = a_hi; sb.el[4] = m_lo; sb.el[5] = m_hi; sb.el[6] = c_lo;
-    sb.el[7] = lf_col(C_MV); sb.el[8] = lf_col(C_MV + 1);
-    Interaction& kc = g_cpu[19];
+    // sub-word loads: (op, offset, value loaded, memory word, 0); sub-word stores: (op, offset, word left behind, word
+    // before, low limb of the stored register) - one tuple layout, two sends because the word sits in other columns
+    for (int st = 0; st < 2; ++st) {
+      Interaction& sb = g_cpu[15 + st];
+      sb = Interaction{};
+      sb.bus = BUS_SUB; sb.sign = +1; sb.mult = lf_col(selc(st ? CL_STS : CL_LDS)); sb.n_el = 7;
+      sb.el[0] = lf_col(C_CODE);
+      sb.el[1] = lf_zero(); lf_add(sb.el[1], C_O1, 1); lf_add(sb.el[1], C_O2, 2); lf_add(sb.el[1], C_O3, 3);
+      sb.el[2] = a_lo; sb.el[3] = a_hi;
+      sb.el[4] = st ? lf_col(C_W_PLO) : c_lo; sb.el[5] = st ? lf_col(C_W_PHI) : c_hi;
+      sb.el[6] = st ? c_lo : zero;
+    }
+    Interaction& kc = g_cpu[17];
     kc = Interaction{};
     kc.bus = BUS_KCALL; kc.sign = +1; kc.mult = lf_col(selc(CL_KECCAK)); kc.n_el = 3;
     kc.el[0] = ts; kc.el[1] = c_lo; kc.el[2] = c_hi;
     // an ecall: the ecall chip takes it from here (time, pc, next pc, the code in t0, the value left in t0)
-    Interaction& ec = g_cpu[20];
+    Interaction& ec = g_cpu[18];
     ec = Interaction{};
     ec.bus = BUS_ECALL; ec.sign = +1; ec.mult = lf_col(selc(CL_ECALL)); ec.n_el = 6;
     ec.el[0] = ts; ec.el[1] = lf_col(C_PC); ec.el[2] = lf_col(C_NEXT_PC); ec.el[3] = b_lo; ec.el[4] = a_lo; ec.el[5] = a_hi;
@@ -315,13 +319,12 @@ void build() {
     static const uint32_t codes[6] = {LB, LH, LBU, LHU, SB, SH};
     Interaction& it = g_sub[0];
     it = Interaction{};
-    it.bus = BUS_SUB; it.sign = -1; it.mult = lf_col(SW_IS_REAL); it.n_el = 9;
+    it.bus = BUS_SUB; it.sign = -1; it.mult = lf_col(SW_IS_REAL); it.n_el = 7;
     it.el[0] = lf_zero();
     for (int k = 0; k < 6; ++k) lf_add(it.el[0], SW_SEL + k, codes[k]);
     it.el[1] = lf_zero(); lf_add(it.el[1], SW_O + 1, 1); lf_add(it.el[1], SW_O + 2, 2); lf_add(it.el[1], SW_O + 3, 3);
     it.el[2] = lf_col(SW_A); it.el[3] = lf_col(SW_A + 1);
     it.el[4] = lf_pair(SW_MB, SW_MB + 1, 256); it.el[5] = lf_pair(SW_MB + 2, SW_MB + 3, 256); it.el[6] = lf_pair(SW_CB, SW_CB + 1, 256);
-    it.el[7] = lf_col(SW_MV); it.el[8] = lf_col(SW_MV + 1);
     // the bytes are bytes; the sign bit of a signed load is bit 7 of the byte it extends (byte AND 0x80 = 128 * sign)
     g_sub[1] = bytes_inter(-1, lf_col(SW_IS_REAL), lf_col(SW_MB), lf_col(SW_MB + 1));
     g_sub[2] = bytes_inter(-1, lf_col(SW_IS_REAL), lf_col(SW_MB + 2), lf_col(SW_MB + 3));
@@ -364,8 +367,8 @@ void build() {
   }
   g_chips[kP2] = {"poseidon2", 0, kP2Width, 5, g_p2, kP2Constraints, 0};
   g_chips[kTable] = {"table", kTablePrepWidth, kTableWidth, 7, g_table, 2, 0};
-  g_chips[kCpu] = {"cpu", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 4};
-  g_chips[kCpu2] = {"cpu2", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 4};
+  g_chips[kCpu] = {"cpu", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 5};
+  g_chips[kCpu2] = {"cpu2", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 5};
   g_chips[kEcall] = {"ecall", 0, kEcallWidth, 10, g_ecall, kEcallConstraints, 0};
   g_chips[kKeccak] = {"keccak", 0, kKeccakWidth, 50, g_keccak, kKeccakConstraints, 0};
   g_chips[kKmem] = {"keccak-mem", 0, kKmemWidth, 8, g_kmem, kKmemConstraints, 0};

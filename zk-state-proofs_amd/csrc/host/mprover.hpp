@@ -1,5 +1,5 @@
 // Device prover of the machine proof: batch workspace in HBM and the launch sequence that turns
-// traced executions into proof bodies ("ZKSP v11") without a host round trip.  See mprover.cpp.
+// traced executions into proof bodies ("ZKSP v12") without a host round trip.  See mprover.cpp.
 #pragma once
 #include <array>
 #include <vector>
