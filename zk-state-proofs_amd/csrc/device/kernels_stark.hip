@@ -658,67 +658,101 @@ __global__ __launch_bounds__(kThreads) void open_combine_kernel(const uint32_t* 
     store_fp4(opened + (size_t)b * opened_stride + ((size_t)q * pt_stride + (size_t)col) * 4, s);
   }
 }
-// Narrow tall matrices (a 2^19-row permutation trace has 32 columns, a quotient 8): the lane-per-coefficient kernel
-// with the coefficient range split over blockIdx.y, partial sums in open_tall_kernel's layout.
-template <int NC>
-__global__ __launch_bounds__(kThreads) void open_split_kernel(const uint32_t* __restrict__ coefs, size_t coefs_stride,
-                                                             int ncols, int logh, const uint32_t* __restrict__ zpow,
-                                                             size_t zpow_stride, int npoints, int klen,
-                                                             uint32_t* __restrict__ partial, int nsplit) {
-  __shared__ Fp4 red[kThreads / 64];
+// Narrow tall matrices, tiled: a workgroup covers CW columns (the whole matrix when it has at most 64) x `klen`
+// evaluations, so the two weight tables are read once per matrix instead of once per four columns (a lane-per-evaluation
+// kernel reads 32 bytes of weights for every 16 bytes of columns; at batch 128 the tables are 2 GB and live in HBM).  A tile is
+// [CW columns][TK = 2048 / CW evaluations] in LDS; lane (c = tid % CW, phase = tid / CW) walks column c's eight
+// evaluations phase, phase + 256 / CW, ... of the tile with the weights broadcast from LDS; the phases of a column are
+// added at the end.  Partial sums in open_tall_kernel's layout.
+template <int CW>
+__global__ __launch_bounds__(kThreads) void open_narrow_kernel(const uint32_t* __restrict__ coefs, size_t coefs_stride,
+                                                              int ncols, int logh, const uint32_t* __restrict__ zpow,
+                                                              size_t zpow_stride, int npoints, int klen,
+                                                              uint32_t* __restrict__ partial, int nsplit) {
+  constexpr int TK = 2048 / CW, kPitch = TK + 1, kPhases = kThreads / CW, kQuads = TK / 4;
+  static_assert(kThreads == 256 && CW >= 8 && CW <= 64, "tile geometry");
+  __shared__ uint32_t tile[CW * kPitch];
+  __shared__ int4 ztile[2][TK];
+  __shared__ uint32_t red[2][kThreads][4];
   const int h = 1 << logh;
-  const int col0 = blockIdx.x * NC, split = blockIdx.y, b = blockIdx.z;
-  const int nc = min(NC, ncols - col0);
+  const int col0 = blockIdx.x * CW, split = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
   const int kbeg = split * klen, kend = kbeg + klen;
   const uint32_t* cf = coefs + (size_t)b * coefs_stride + (size_t)col0 * h;
-  const uint32_t* z0 = zpow + (size_t)b * zpow_stride;
-  const uint32_t* z1 = z0 + (size_t)h * 4;
-  int64_t acc[NC][2][4];
+  const int4* z0 = reinterpret_cast<const int4*>(zpow + (size_t)b * zpow_stride);
+  const int4* z1 = z0 + h;
+  uint4 stage[2];
+  int4 zstage[2] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
+  auto fetch = [&](int k0) {
 #pragma unroll
-  for (int c = 0; c < NC; ++c)
+    for (int ps = 0; ps < 2; ++ps) {
+      const int e = ps * kThreads + tid, c = e / kQuads, q4 = e % kQuads;
+      stage[ps] = col0 + c < ncols ? *reinterpret_cast<const uint4*>(cf + (size_t)c * h + k0 + q4 * 4) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int e = ps * kThreads + tid;  // point e / TK, evaluation e % TK
+      if (e < 2 * TK && e / TK < npoints) zstage[ps] = (e / TK ? z1 : z0)[k0 + e % TK];
+    }
+  };
+  int64_t acc[2][4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[q][j] = 0;
+  const int c = tid % CW, ph = tid / CW;
+  fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += TK) {
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int e = ps * kThreads + tid;
+      uint32_t* d = tile + (e / kQuads) * kPitch + (e % kQuads) * 4;
+      d[0] = stage[ps].x; d[1] = stage[ps].y; d[2] = stage[ps].z; d[3] = stage[ps].w;
+      if (e < 2 * TK) ztile[e / TK][e % TK] = zstage[ps];
+    }
+    __syncthreads();
+    if (k0 + TK < kend) fetch(k0 + TK);
+    const uint32_t* mine = tile + c * kPitch;
+#pragma unroll
+    for (int i = 0; i < TK / kPhases; ++i) {
+      const int kk = ph + i * kPhases;
+      const int32_t cv = fps_centre(mine[kk]);
+      const int4 p0 = ztile[0][kk];
+      acc[0][0] += (int64_t)cv * (int64_t)p0.x;
+      acc[0][1] += (int64_t)cv * (int64_t)p0.y;
+      acc[0][2] += (int64_t)cv * (int64_t)p0.z;
+      acc[0][3] += (int64_t)cv * (int64_t)p0.w;
+      if (npoints > 1) {
+        const int4 p1 = ztile[1][kk];
+        acc[1][0] += (int64_t)cv * (int64_t)p1.x;
+        acc[1][1] += (int64_t)cv * (int64_t)p1.y;
+        acc[1][2] += (int64_t)cv * (int64_t)p1.z;
+        acc[1][3] += (int64_t)cv * (int64_t)p1.w;
+      }
+    }
+    static_assert(TK / kPhases == 8, "eight terms between shrinks");
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[c][q][j] = 0;
-  int pending = 0;
-  for (int k = kbeg + threadIdx.x; k < kend; k += kThreads) {
-    const uint4 p0 = *reinterpret_cast<const uint4*>(z0 + (size_t)k * 4);
-    uint4 p1 = make_uint4(0, 0, 0, 0);
-    if (npoints > 1) p1 = *reinterpret_cast<const uint4*>(z1 + (size_t)k * 4);
-    const int32_t zz[2][4] = {{(int32_t)p0.x, (int32_t)p0.y, (int32_t)p0.z, (int32_t)p0.w},
-                              {(int32_t)p1.x, (int32_t)p1.y, (int32_t)p1.z, (int32_t)p1.w}};
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      if (c < nc) {
-        const int32_t cv = fps_centre(cf[(size_t)c * h + k]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[c][0][j] += (int64_t)cv * (int64_t)zz[0][j];
-          if (npoints > 1) acc[c][1][j] += (int64_t)cv * (int64_t)zz[1][j];
-        }
-      }
-    }
-    if (++pending == 8) {
-#pragma unroll
-      for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[c][q][j] = lazy_shrink(acc[c][q][j]);
-      pending = 0;
-    }
+      for (int j = 0; j < 4; ++j) acc[q][j] = lazy_shrink(acc[q][j]);
   }
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    if (c >= nc) break;
+  for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (q >= npoints) break;
+    for (int j = 0; j < 4; ++j) red[q][tid][j] = fps_canon(fps_fold(acc[q][j]));
+  __syncthreads();
+  if (ph == 0 && col0 + c < ncols) {
+    for (int q = 0; q < npoints; ++q) {
       Fp4 v;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v.c[j] = Fp::raw(fps_canon(fps_fold(acc[c][q][j])));
-      const Fp4 sum = block_sum(v, red);
-      if (threadIdx.x == 0) store_fp4(partial + ((((size_t)b * 2 + q) * nsplit + split) * ncols + col0 + c) * 4, sum);
+      for (int j = 0; j < 4; ++j) v.c[j] = Fp::raw(red[q][c][j]);
+      for (int o = 1; o < kPhases; ++o) {
+        Fp4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w.c[j] = Fp::raw(red[q][o * CW + c][j]);
+        v += w;
+      }
+      store_fp4(partial + ((((size_t)b * 2 + q) * nsplit + split) * ncols + col0 + c) * 4, v);
     }
   }
 }
@@ -738,11 +772,17 @@ void launch_open_tall(hipStream_t stream, const uint32_t* coefs_br, size_t coefs
   if (ncols >= 64)
     hipLaunchKernelGGL(open_tall_kernel, dim3((ncols + kOpenTileCols - 1) / kOpenTileCols, nsplit, batch), dim3(kThreads), 0,
                        stream, coefs_br, coefs_stride, ncols, logh, zpow_br, zpow_stride, npoints, klen, scratch, nsplit);
-  else
-    // (eight columns per workgroup would halve the reads of the weight table, but measured 20 % slower on the CPU chip's
-    // 40- and 56-column matrices: 64 64-bit accumulators per lane)
-    hipLaunchKernelGGL(open_split_kernel<kOpenCols>, dim3((ncols + kOpenCols - 1) / kOpenCols, nsplit, batch), dim3(kThreads), 0, stream,
-                       coefs_br, coefs_stride, ncols, logh, zpow_br, zpow_stride, npoints, klen, scratch, nsplit);
+  else {
+    const dim3 grid(1, nsplit, batch), block(kThreads);
+#define ZKSP_OPEN_NARROW(CW) \
+  hipLaunchKernelGGL(open_narrow_kernel<CW>, grid, block, 0, stream, coefs_br, coefs_stride, ncols, logh, zpow_br, zpow_stride, \
+                     npoints, klen, scratch, nsplit)
+    if (ncols > 32) ZKSP_OPEN_NARROW(64);
+    else if (ncols > 16) ZKSP_OPEN_NARROW(32);
+    else if (ncols > 8) ZKSP_OPEN_NARROW(16);
+    else ZKSP_OPEN_NARROW(8);
+#undef ZKSP_OPEN_NARROW
+  }
   hipLaunchKernelGGL(open_combine_kernel, dim3((ncols + kThreads - 1) / kThreads, batch), dim3(kThreads), 0, stream, scratch,
                      ncols, npoints, nsplit, opened, opened_stride, pt_stride);
 }
