@@ -1513,27 +1513,41 @@ __global__ __launch_bounds__(kMT) void mreduce_partial_kernel(MReduceArgs a, int
   }
 }
 
+// Lane = four consecutive LDE points: their eight denominators (x - zeta, x - zeta w) are inverted with one
+// extension-field inversion (an inversion is ~700 instructions, most of this kernel's work when taken per point)
 __global__ __launch_bounds__(kMT) void mreduce_final_kernel(MReduceArgs a, int nchunks) {
   const size_t h = (size_t)1 << a.logh, n = 2 * h;
-  const size_t pt = (size_t)blockIdx.x * kMT + threadIdx.x;
-  if (pt >= n) return;
+  const size_t pt0 = ((size_t)blockIdx.x * kMT + threadIdx.x) * 4;
+  if (pt0 >= n) return;
   const int b = blockIdx.y;
-  Fp4 s1 = Fp4::zero(), s2 = Fp4::zero();
-  for (int ch = 0; ch < nchunks; ++ch) {
-    s1 += m_load_fp4(a.partial + ((((size_t)b * nchunks + ch) * 2 + 0) * n + pt) * 4);
-    s2 += m_load_fp4(a.partial + ((((size_t)b * nchunks + ch) * 2 + 1) * n + pt) * 4);
-  }
   const Fp4 b1 = m_load_fp4(a.bsum + ((size_t)b * 2 + 0) * 4), b2 = m_load_fp4(a.bsum + ((size_t)b * 2 + 1) * 4);
   const Fp4 zeta = m_load_fp4(a.zeta + (size_t)b * 4), zn = zeta * Fp::raw(a.w_h);
-  const int c = pt >= h ? 1 : 0;
-  const size_t m = pt - (size_t)c * h, half = h >> 1;
-  const Fp wm = m < half ? Fp::raw(a.tw_fwd[m]) : -Fp::raw(a.tw_fwd[m - half]);
-  Fp4 x = Fp4::from_base(Fp::raw(c ? a.shift[1] : a.shift[0]) * wm);
-  const Fp4 d0 = (x - zeta).inv(), d1 = (x - zn).inv();
-  Fp4 g = (s1 - b1) * d0 + (s2 - b2) * d1;
-  uint32_t* o = a.out + (size_t)b * a.out_bstride + pt * 4;
-  if (a.accumulate) g += m_load_fp4(o);
-  m_store_fp4(o, g);
+  const int c = pt0 >= h ? 1 : 0;  // (h is a multiple of four: the four points lie on one coset)
+  const size_t half = h >> 1;
+  const Fp sh = Fp::raw(c ? a.shift[1] : a.shift[0]);
+  Fp4 d[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const size_t m = pt0 + i - (size_t)c * h;
+    const Fp wm = m < half ? Fp::raw(a.tw_fwd[m]) : -Fp::raw(a.tw_fwd[m - half]);
+    const Fp4 x = Fp4::from_base(sh * wm);
+    d[2 * i] = x - zeta;
+    d[2 * i + 1] = x - zn;
+  }
+  batch_inverse<8>(d);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const size_t pt = pt0 + i;
+    Fp4 s1 = Fp4::zero(), s2 = Fp4::zero();
+    for (int ch = 0; ch < nchunks; ++ch) {
+      s1 += m_load_fp4(a.partial + ((((size_t)b * nchunks + ch) * 2 + 0) * n + pt) * 4);
+      s2 += m_load_fp4(a.partial + ((((size_t)b * nchunks + ch) * 2 + 1) * n + pt) * 4);
+    }
+    Fp4 g = (s1 - b1) * d[2 * i] + (s2 - b2) * d[2 * i + 1];
+    uint32_t* o = a.out + (size_t)b * a.out_bstride + pt * 4;
+    if (a.accumulate) g += m_load_fp4(o);
+    m_store_fp4(o, g);
+  }
 }
 
 void launch_machine_reduce(hipStream_t stream, const MReduceArgs& a) {
@@ -1544,7 +1558,7 @@ void launch_machine_reduce(hipStream_t stream, const MReduceArgs& a) {
   hipLaunchKernelGGL(mreduce_bsum_kernel, dim3(a.batch), dim3(kMT), 0, stream, a, n1, n2);
   hipLaunchKernelGGL(mreduce_partial_kernel, dim3((unsigned)((n / 4 + kMT - 1) / kMT), nchunks, a.batch), dim3(kMT), 0, stream, a,
                      nchunks, n1);
-  hipLaunchKernelGGL(mreduce_final_kernel, dim3((unsigned)((n + kMT - 1) / kMT), a.batch), dim3(kMT), 0, stream, a, nchunks);
+  hipLaunchKernelGGL(mreduce_final_kernel, dim3((unsigned)((n / 4 + kMT - 1) / kMT), a.batch), dim3(kMT), 0, stream, a, nchunks);
 }
 
 __global__ __launch_bounds__(kMT) void fri_add_kernel(uint32_t* __restrict__ layer, size_t layer_bstride,
