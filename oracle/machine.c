@@ -637,6 +637,14 @@ static void fill_cpu(const orc_machine_input* in, size_t h, uint32_t* t, size_t 
       if (load) gap[1] = ts - cy[9];
       if (wr) { gap[2] = ts + 1 - cy[10]; T(C_W_PLO) = wprev & 0xffff; T(C_W_PHI) = wprev >> 16; }
       if (store) { gap[2] = ts + 1 - cy[9]; T(C_W_PLO) = m & 0xffff; T(C_W_PHI) = m >> 16; }
+      /* soundness tests: ZKSP_ORACLE_ADDR=<row> moves that row's memory slot (a load reads the next word, anything
+       * else writes its result to another register): the address columns are tied to the instruction's register
+       * fields or to the adder output by constraints of their own */
+      const char* ah = getenv("ZKSP_ORACLE_ADDR");
+      if (ah && r == (size_t)strtoull(ah, NULL, 10)) {
+        if (load) T(C_ADDR2) += 4;
+        else if (wr) T(C_ADDR3) ^= 1;
+      }
       /* soundness tests: ZKSP_ORACLE_NONCANON=<row> makes that addition claim the other carry, i.e. write the same
        * sum with limbs out of range.  The adder constraints still hold; the range lookup cannot. */
       const char* nc = getenv("ZKSP_ORACLE_NONCANON");

@@ -190,6 +190,19 @@ def test_ecall_chip_cannot_redirect_or_redecode(zk, oracle, setup):
     _hook_rejected(zk, oracle, client, vk, t, "ZKSP_ORACLE_ECALL_FLAG", "3")  # (the buses or the constraint, whichever is checked first)
 
 
+def test_access_addresses_are_bound_to_the_instruction(zk, oracle, setup):
+    """Format v12: a row's second and third access carry their address in columns of their own.  A load that reads
+    the word after the one its adder output names, and a result written to a register the instruction does not
+    name, are both refused."""
+    client, vk, t, _ = setup
+    cyc, prog = t["cycles"], t["program"]
+    rows = prog[(cyc[:, 0] - prog[0, 0]) // 4]
+    load = int(np.nonzero(rows[:, 1] == 21)[0][10])  # lw
+    write = int(np.nonzero((rows[:, 1] == 1) & (rows[:, 2] == 1))[0][10])  # an add that writes a register
+    _hook_rejected(zk, oracle, client, vk, t, "ZKSP_ORACLE_ADDR", str(load))
+    _hook_rejected(zk, oracle, client, vk, t, "ZKSP_ORACLE_ADDR", str(write))
+
+
 def test_subword_sign_is_bound_to_its_byte(zk, oracle, setup):
     """A signed byte load that extends the wrong sign: the sub-word chip's sign column is only as free as the table
     chip's byte-operation rows allow (byte AND 0x80 = 128 * sign), so the lookup has no row to meet."""
