@@ -53,6 +53,7 @@ void launch_keccak_ts(hipStream_t stream, const MachineRecords& rec, uint32_t* t
 // so the buses balance by construction whenever every looked-up value has a table row.  launch_table_trace then
 // writes the table chip's main columns.
 void launch_table_clear(hipStream_t stream, const MachineRecords& rec, int batch);
+void launch_cpu_table_count(hipStream_t stream, const uint32_t* trace, int logh, const MachineRecords& rec, int batch);
 void launch_table_count(hipStream_t stream, const mach::Interaction* inter, int n_inter, const uint32_t* trace, int width, int logh,
                         const MachineRecords& rec, int batch);
 void launch_table_trace(hipStream_t stream, const MachineRecords& rec, uint32_t* trace, int batch);

@@ -740,6 +740,62 @@ __global__ __launch_bounds__(kMT) void table_count_kernel(const Interaction* __r
     if (lds[2 * kTableLdsBins + i]) atomicAdd(&hb[(size_t)TB_M_BY * kTableRows + i], lds[2 * kTableLdsBins + i]);
   }
 }
+// The CPU chip's seven lookups (machine_defs.cpp g_cpu[7..13]) read from the columns that hold them, instead of through
+// the generic linear forms: three range16 gaps, two pairs of high bytes, the adder output's high limb (kind 2 where it
+// is an address) and its low limb less the byte offset (kind 1 where aligned), the last two on the rows that check X.
+__global__ __launch_bounds__(kMT) void cpu_table_count_kernel(const uint32_t* __restrict__ trace, int logh, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t lds[3 * kTableLdsBins];
+  const size_t h = (size_t)1 << logh;
+  const int b = blockIdx.y;
+  for (uint32_t i = threadIdx.x; i < 3 * kTableLdsBins; i += kMT) lds[i] = 0;
+  __syncthreads();
+  uint32_t* hb = hist + (size_t)b * kTableWidth * kTableRows;
+  const size_t r0 = (size_t)blockIdx.x * kTableRowsPerBlock;
+  auto range = [&](uint32_t kind, uint32_t v, uint32_t m) {
+    const bool ok = m != 0 && v < kTableRows && kind <= 2 && !(kind == 1 && (v & 3)) && !(kind == 2 && v > kAddrHiMax);
+    const bool hot = kind != 1 && v < kTableLdsBins;
+    wave_hist_add(lds, (kind == 2 ? kTableLdsBins : 0) + v, m, ok && hot);
+    if (ok && !hot) atomicAdd(&hb[(size_t)(kind == 0 ? TB_M_R16 : kind == 1 ? TB_M_AL : TB_M_TOP) * kTableRows + v], m);
+  };
+  auto bytes = [&](uint32_t v1, uint32_t v2, bool in_range) {
+    const bool ok = in_range && v1 <= 255 && v2 <= 255;
+    const uint32_t idx = v1 + 256 * v2;
+    const bool hot = idx < kTableLdsBins;
+    wave_hist_add(lds, 2 * kTableLdsBins + idx, 1u, ok && hot);
+    if (ok && !hot) atomicAdd(&hb[(size_t)TB_M_BY * kTableRows + idx], 1u);
+  };
+  for (size_t rr = threadIdx.x; rr < kTableRowsPerBlock; rr += kMT) {  // (converged lanes, as in table_count_kernel)
+    const size_t r = r0 + rr;
+    const bool in_range = r < h;
+    const uint32_t* row = trace + (size_t)b * kCpuWidth * h + (in_range ? r : 0);
+    auto col = [&](int c) { return Fp::raw(row[(size_t)c * h]); };
+    auto can = [&](int c) { return col(c).to_canonical(); };
+    uint32_t g[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g[i] = can(C_GAP + i);
+    const uint32_t one = in_range ? 1u : 0u;
+    range(0, g[0], one); range(0, g[2], one); range(0, g[4], one);
+    bytes(g[1], g[3], in_range); bytes(g[5], 0, in_range);
+    const Fp al = col(selc(CL_JALR)) + col(selc(CL_LW)) + col(selc(CL_SW)) + col(selc(CL_LDS)) + col(selc(CL_STS));
+    const Fp top = al + col(selc(CL_KECCAK));
+    const Fp chk = top + col(selc(CL_ADD)) + col(selc(CL_SUB)) + col(selc(CL_ECALL)) + col(C_UC);
+    const Fp off = col(C_O1) + col(C_O2).dbl() + Fp::raw(cmonty(3)) * col(C_O3);
+    const uint32_t m = in_range ? chk.to_canonical() : 0u;
+    range(top.dbl().to_canonical(), can(C_X + 1), m);
+    range(al.to_canonical(), (col(C_X) - off).to_canonical(), m);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < kTableLdsBins; i += kMT) {
+    if (lds[i]) atomicAdd(&hb[(size_t)TB_M_R16 * kTableRows + i], lds[i]);
+    if (lds[kTableLdsBins + i]) atomicAdd(&hb[(size_t)TB_M_TOP * kTableRows + i], lds[kTableLdsBins + i]);
+    if (lds[2 * kTableLdsBins + i]) atomicAdd(&hb[(size_t)TB_M_BY * kTableRows + i], lds[2 * kTableLdsBins + i]);
+  }
+}
+void launch_cpu_table_count(hipStream_t stream, const uint32_t* trace, int logh, const MachineRecords& rec, int batch) {
+  const size_t h = (size_t)1 << logh;
+  hipLaunchKernelGGL(cpu_table_count_kernel, dim3((unsigned)((h + kTableRowsPerBlock - 1) / kTableRowsPerBlock), batch), dim3(kMT), 0,
+                     stream, trace, logh, rec.table_hist);
+}
 void launch_table_clear(hipStream_t stream, const MachineRecords& rec, int batch) {
   (void)hipMemsetAsync(rec.table_hist, 0, (size_t)batch * kTableWidth * kTableRows * 4, stream);
 }

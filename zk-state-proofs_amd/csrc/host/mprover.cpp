@@ -547,7 +547,8 @@ int machine_prove_resident(Context* ctx) {
     }
     // the table chip answers what the others look up: count their RANGE / BYTES receives on their finished traces
     launch_table_clear(s, rec, B);
-    for (int c : {(int)kCpu, (int)kCpu2, (int)kKmem, (int)kMemFinal, (int)kBw, (int)kBw2, (int)kSub, (int)kSub2, (int)kEcall, (int)kP2})
+    for (int c : {(int)kCpu, (int)kCpu2}) launch_cpu_table_count(s, w->mat[c][0].tr, logh[c], rec, B);
+    for (int c : {(int)kKmem, (int)kMemFinal, (int)kBw, (int)kBw2, (int)kSub, (int)kSub2, (int)kEcall, (int)kP2})
       launch_table_count(s, static_cast<const Interaction*>(ctx->d_inter[c]), chip_def(c).n_inter, w->mat[c][0].tr, chip_def(c).main_w,
                          logh[c], rec, B);
     launch_table_trace(s, rec, w->mat[kTable][0].tr, B);
