@@ -1320,6 +1320,7 @@ __global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
 // CPU chip: the base constraints (task 0) and the LogUp constraints with the fingerprints of cpu_bus_pairs, one launch
 // per group of slots (tasks 1..2), each with its own register budget.  A point's partial sum travels through
 // a.partial ([B][2H] Fp4): task 0 writes it, the others add, the last one divides by the vanishing polynomial.
+constexpr int kCpuQuotSplit = kCpuSlots;  // slots [0, split) in task 1, [split, 8) in task 2 (none: task 1 is the last)
 template <int TASK>
 __global__ __launch_bounds__(kMT) void cpu_quotient_task_kernel(MQuotArgs a) {
   const size_t h = (size_t)1 << a.logh, n = 2 * h;
@@ -1336,7 +1337,7 @@ __global__ __launch_bounds__(kMT) void cpu_quotient_task_kernel(MQuotArgs a) {
     ctx.flush();
     m_store_fp4(part, ctx.acc);
   } else {
-    constexpr int G = TASK - 1, J0 = cpu_group_lo(G), J1 = cpu_group_hi(G), nh = kCpuHelpers;
+    constexpr int J0 = TASK == 1 ? 0 : kCpuQuotSplit, J1 = TASK == 1 ? kCpuQuotSplit : kCpuSlots, nh = kCpuHelpers;
     const int b = pi.b;
     const Fp4 gamma = m_load_fp4(a.bus_ch + (size_t)b * 8);
     const uint32_t* bpow = a.bpow + (size_t)b * (kInterMaxElems + 1) * 4;
@@ -1361,7 +1362,7 @@ __global__ __launch_bounds__(kMT) void cpu_quotient_task_kernel(MQuotArgs a) {
                             }
                             acc += m_load_fp4(ap + 4 * (size_t)(a.n_base + j)) * (hj * fa * fb - (fb * ma + fa * mb));
                           });
-    if constexpr (G == kCpuBusGroups - 1) {
+    if constexpr (J1 == kCpuSlots) {
       const Fp4 q = acc * Fp::raw(pi.c ? a.zh_inv[1] : a.zh_inv[0]);
       uint32_t* dst = a.quot + (size_t)b * 8 * h + pi.m;
 #pragma unroll
@@ -1433,7 +1434,7 @@ void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a) {
     case kCpu2:
       hipLaunchKernelGGL(cpu_quotient_task_kernel<0>, grid, block, 0, stream, a);
       hipLaunchKernelGGL(cpu_quotient_task_kernel<1>, grid, block, 0, stream, a);
-      hipLaunchKernelGGL(cpu_quotient_task_kernel<2>, grid, block, 0, stream, a);
+      if (kCpuQuotSplit < kCpuSlots) hipLaunchKernelGGL(cpu_quotient_task_kernel<2>, grid, block, 0, stream, a);
       break;
     case kAlu:
     case kAlu2: hipLaunchKernelGGL(machine_quotient_kernel<kAlu>, grid, block, 0, stream, a); break;
