@@ -340,8 +340,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=128,
-                    help="machine proofs proven in lockstep per GPU per step (about 1.1 GB of HBM each at acct-d8)")
+    ap.add_argument("--batch", type=int, default=192,
+                    help="machine proofs proven in lockstep per GPU per step (about 1.0 GB of HBM each at acct-d8)")
     ap.add_argument("--cpu-seconds", type=float, default=40.0,
                     help="budget of the CPU baseline: repetitions until it is spent, at most 5 (SURVEY 8d: 5 repetitions, median and min)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
