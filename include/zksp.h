@@ -168,7 +168,7 @@ int zksp_mtrace_info(const zksp_mtrace* t, zksp_mtrace_info_t* info);
 /* Device-resident machine proving (bench.py, parity tests): upload the records of n traced runs (they are proven
  * with one shape: zksp_machine_cover_heights), enqueue one proving pass, fetch the proof bodies ([n][body_words]
  * canonical u32; body_words = zksp_machine_body_words of that shape). */
-#define ZKSP_MACHINE_CHIPS 17   /* cpu, keccak, keccak-mem, mem-final, image, program, mul, table, cpu2, alu, alu2, subword, subword2, bitwise, bitwise2, poseidon2, ecall */
+#define ZKSP_MACHINE_CHIPS 23   /* cpu, keccak, keccak-mem, mem-final, image, program, mul, table, cpu2, alu, alu2, subword, subword2, bitwise, bitwise2, poseidon2, ecall, cpu3 .. cpu8 */
 int zksp_mtrace_heights(const zksp_mtrace* t, int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 size_t zksp_machine_body_words(const zksp_client* c, const int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 /* The shape a batch of these runs is proven with: the chip heights that cover the largest cycle / event / address

@@ -422,6 +422,10 @@ static void build(void) {
   g_chips[CH_TABLE] = (orc_chip){"table", TABLE_PREP_WIDTH, TABLE_WIDTH, 7, g_table, 0, 0};
   g_chips[CH_CPU] = (orc_chip){"cpu", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0, 5};   /* ALU, SUB (loads), SUB (stores), KCALL, ECALL: one class each */
   g_chips[CH_CPU2] = (orc_chip){"cpu2", 0, CPU_WIDTH, CPU_INTER, g_cpu, 0, 5};
+  {
+    static const char* names[CPU_INST] = {"cpu", "cpu2", "cpu3", "cpu4", "cpu5", "cpu6", "cpu7", "cpu8"};
+    for (int i = 2; i < CPU_INST; ++i) g_chips[orc_cpu_chip(i)] = (orc_chip){names[i], 0, CPU_WIDTH, CPU_INTER, g_cpu, 0, 5};
+  }
   g_chips[CH_KECCAK] = (orc_chip){"keccak", 0, KECCAK_WIDTH, 50, g_keccak, 0, 0};
   g_chips[CH_KMEM] = (orc_chip){"keccak-mem", 0, KMEM_WIDTH, 8, g_kmem, 0, 0};
   g_chips[CH_MEMFINAL] = (orc_chip){"mem-final", 0, MEMFINAL_WIDTH, 10, g_memfinal, 0, 0};
@@ -491,23 +495,30 @@ static uint32_t pad_pc_of(const orc_machine_input* in) { return in->text_base + 
 static size_t first_rows(const orc_machine_input* in, int chip, size_t n) {
   return in->shape ? (size_t)1 << in->shape[chip] : split_rows(n);
 }
-/* rows of the two CPU instances together */
+/* rows of the CPU instances together; first cycle (row0) of instance i */
+static size_t cpu_row0(const int logh[N_CHIPS], int inst) {
+  size_t r = 0;
+  for (int i = 0; i < inst; ++i) r += (size_t)1 << logh[orc_cpu_chip(i)];
+  return r;
+}
 static size_t cpu_rows(const orc_machine_input* in) {
   int logh[N_CHIPS];
   orc_machine_heights(in, logh);
-  return ((size_t)1 << logh[CH_CPU]) + ((size_t)1 << logh[CH_CPU2]);
+  return cpu_row0(logh, CPU_INST);
 }
-
+/* public scalars of CPU instance `chip`: where it starts (pc, time), whether another instance follows and at which pc
+ * (the hand-over pcs are header words) */
 void orc_machine_cpu_pub(const orc_machine_input* in, int chip, uint32_t pub[CPUPUB_N]) {
-  const size_t h0 = first_rows(in, CH_CPU, in->n_cycles);
+  int logh[N_CHIPS];
+  orc_machine_heights(in, logh);
+  const int inst = orc_cpu_instance(chip);
+  const size_t r0 = cpu_row0(logh, inst), r1 = cpu_row0(logh, inst + 1);
   const uint32_t pad = pad_pc_of(in);
-  const uint32_t handover = h0 < in->n_cycles ? in->cycles[12 * h0] : pad;
   pub[CPUPUB_PAD_PC] = pad;
-  if (chip == CH_CPU) {
-    pub[CPUPUB_START_PC] = in->entry; pub[CPUPUB_START_TS] = 4; pub[CPUPUB_HAS_SUCC] = 1; pub[CPUPUB_END_PC] = handover;
-  } else {
-    pub[CPUPUB_START_PC] = handover; pub[CPUPUB_START_TS] = 4 * ((uint32_t)h0 + 1); pub[CPUPUB_HAS_SUCC] = 0; pub[CPUPUB_END_PC] = 0;
-  }
+  pub[CPUPUB_START_PC] = inst == 0 ? in->entry : r0 < in->n_cycles ? in->cycles[12 * r0] : pad;
+  pub[CPUPUB_START_TS] = 4 * ((uint32_t)r0 + 1);
+  pub[CPUPUB_HAS_SUCC] = inst + 1 < CPU_INST;
+  pub[CPUPUB_END_PC] = inst + 1 < CPU_INST ? (r1 < in->n_cycles ? in->cycles[12 * r1] : pad) : 0;
 }
 
 void orc_machine_heights(const orc_machine_input* in, int logh[N_CHIPS]) {
@@ -515,8 +526,10 @@ void orc_machine_heights(const orc_machine_input* in, int logh[N_CHIPS]) {
   const size_t na = orc_machine_events(in, 0, NULL), ns = orc_machine_events(in, 1, NULL), nb = orc_machine_events(in, 2, NULL);
   logh[CH_BW] = clog2(split_rows(nb));
   logh[CH_BW2] = second_logh(nb);
-  logh[CH_CPU] = clog2(split_rows(in->n_cycles));
-  logh[CH_CPU2] = second_logh(in->n_cycles);
+  {
+    const int hc = at_least5(clog2((in->n_cycles + CPU_INST - 1) / CPU_INST));
+    for (int i = 0; i < CPU_INST; ++i) logh[orc_cpu_chip(i)] = ((size_t)i << hc) < in->n_cycles || i == 0 ? hc : 5;
+  }
   logh[CH_ALU] = clog2(split_rows(na));
   logh[CH_ALU2] = second_logh(na);
   logh[CH_SUB] = clog2(split_rows(ns));
@@ -786,8 +799,9 @@ static void fill_table_mults(const orc_machine_input* in, uint32_t* t) {
   const size_t ht = (size_t)1 << TABLE_LOG_H;
   int logh[N_CHIPS];
   orc_machine_heights(in, logh);
-  static const int users[10] = {CH_CPU, CH_CPU2, CH_KMEM, CH_MEMFINAL, CH_BW, CH_BW2, CH_SUB, CH_SUB2, CH_ECALL, CH_P2};
-  for (int u = 0; u < 10; ++u) {
+  static const int users[8 + CPU_INST] = {CH_CPU, CH_CPU2, CH_KMEM, CH_MEMFINAL, CH_BW, CH_BW2, CH_SUB, CH_SUB2, CH_ECALL, CH_P2,
+                                          CH_CPU3, CH_CPU4, CH_CPU5, CH_CPU6, CH_CPU7, CH_CPU8};
+  for (int u = 0; u < 8 + CPU_INST; ++u) {
     const int chip = users[u];
     const orc_chip* ch = &g_chips[chip];
     const size_t h = (size_t)1 << logh[chip];
@@ -836,8 +850,12 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
   if (prep) memset(prep, 0, (size_t)ch->prep_width * h * 4);
 #define T(col) t[(size_t)(col) * h + r]
   switch (chip) {
-    case CH_CPU: fill_cpu(in, h, t, 0); break;
-    case CH_CPU2: fill_cpu(in, h, t, first_rows(in, CH_CPU, in->n_cycles)); break;
+    case CH_CPU: case CH_CPU2: case CH_CPU3: case CH_CPU4: case CH_CPU5: case CH_CPU6: case CH_CPU7: case CH_CPU8: {
+      int lh[N_CHIPS];
+      orc_machine_heights(in, lh);
+      fill_cpu(in, h, t, cpu_row0(lh, orc_cpu_instance(chip)));
+      break;
+    }
     case CH_ALU: fill_alu(in, h, t, 0); break;
     case CH_ALU2: fill_alu(in, h, t, first_rows(in, CH_ALU, orc_machine_events(in, 0, NULL))); break;
     case CH_SUB: fill_sub(in, h, t, 0); break;
@@ -1334,8 +1352,8 @@ static void run_constraints(int chip, const uint32_t* prep, const uint32_t* loc,
                             uint32_t is_last, uint32_t is_trans, const uint32_t* pub, sink* s) {
   static const uint32_t no_pub[CPUPUB_N] = {0, 0, 0, 0, 0};
   switch (chip) {
-    case CH_CPU:
-    case CH_CPU2: cpu_constraints(loc, nxt, is_first, is_last, is_trans, pub ? pub : no_pub, s); break;
+    case CH_CPU: case CH_CPU2: case CH_CPU3: case CH_CPU4: case CH_CPU5: case CH_CPU6: case CH_CPU7: case CH_CPU8:
+      cpu_constraints(loc, nxt, is_first, is_last, is_trans, pub ? pub : no_pub, s); break;
     case CH_KECCAK:
       if (s->out) orc_keccak_constraints(loc, nxt, is_first, is_last, is_trans, s->out + s->k);
       s->k += KA_NUM_CONSTRAINTS;

@@ -34,13 +34,20 @@ extern "C" {
 #endif
 
 /* ---- chips, in proof order ---- */
-/* CPU, ALU and sub-word rows are each split over two instances of one AIR: the first has the largest power of two
- * of rows strictly below the count (at least 32), the second the rest rounded up to a power of two:
- * 391 400 cycles take 2^18 + 2^17 rows, not 2^19. */
+/* ALU, sub-word and bitwise rows are each split over two instances of one AIR: the first has the largest power of two
+ * of rows strictly below the count (at least 32), the second the rest rounded up to a power of two.
+ * The CPU rows (format v13) are spread over CPU_INST instances of one height, 2^ceil(log2(cycles / CPU_INST)): as many
+ * as the cycles need, the others at the minimum height (all padding).  391 400 cycles take 6 x 2^16 rows: the same
+ * cells as 2^18 + 2^17, but in rows six times as wide - a Merkle tree, a quotient and a FRI domain of a quarter of
+ * the height, and the per-row costs of the commitments (node compressions, the quotient's leaf) shared by six. */
+#define CPU_INST 8
 enum {
   CH_CPU = 0, CH_KECCAK, CH_KMEM, CH_MEMFINAL, CH_IMAGE, CH_PROGRAM, CH_MUL, CH_TABLE, CH_CPU2, CH_ALU, CH_ALU2, CH_SUB,
-  CH_SUB2, CH_BW, CH_BW2, CH_P2, CH_ECALL, N_CHIPS
+  CH_SUB2, CH_BW, CH_BW2, CH_P2, CH_ECALL, CH_CPU3, CH_CPU4, CH_CPU5, CH_CPU6, CH_CPU7, CH_CPU8, N_CHIPS
 };
+/* CPU instance i = 0 .. CPU_INST - 1 <-> chip (the first two keep their old places in the proof order) */
+static inline int orc_cpu_chip(int i) { return i == 0 ? CH_CPU : i == 1 ? CH_CPU2 : CH_CPU3 + (i - 2); }
+static inline int orc_cpu_instance(int chip) { return chip == CH_CPU ? 0 : chip == CH_CPU2 ? 1 : chip >= CH_CPU3 && chip <= CH_CPU8 ? chip - CH_CPU3 + 2 : -1; }
 
 /* ---- opcodes: Program table column CODE, and the op element of the ALU / sub-word bus tuples ---- */
 enum {
@@ -255,7 +262,7 @@ int orc_machine_nodes_public(const uint32_t* keys, const uint32_t* digests, size
  * (key, left child's digest, right child's digest, own digest).  Returns the number of rows, (size_t)-1 if malformed;
  * rows may be NULL. */
 size_t orc_machine_agg_rows(const uint32_t* keys, const uint32_t* digests, size_t n, uint32_t* rows);
-#define ZKSP_VERSION_MACHINE 12u
+#define ZKSP_VERSION_MACHINE 13u
 /* vk: preprocessed commitment root + digest binding entry pc, table heights and keccak mode */
 void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t prep_root[8], uint32_t vk_digest[8]);
 size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_image, const orc_config* cfg, uint32_t pv_len);

@@ -420,7 +420,7 @@ void orc_machine_stage_quotient(const orc_machine_input* in, int chip, const uin
   one_chip(in, chip, &d);
   challenge_powers(gamma4, beta4, &gamma, bpow);
   memcpy(alpha.c, alpha4, 16);
-  if (chip == CH_CPU || chip == CH_CPU2) orc_machine_cpu_pub(in, chip, pub);
+  if (orc_cpu_instance(chip) >= 0) orc_machine_cpu_pub(in, chip, pub);
   if (chip == CH_ECALL) orc_machine_cpu_pub(in, CH_CPU, pub); /* (the padding pc) */
   lde_round(&d, R_PREP);
   lde_round(&d, R_MAIN);
@@ -465,7 +465,7 @@ void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t pr
 }
 
 /* magic, version, heights, exit code, pv length, 3 digests, hand-over pc; aggregation: leaf count, root, digest of the leaf list */
-#define HEADER_WORDS (2 + N_CHIPS + 2 + 24 + 1 + 17)
+#define HEADER_WORDS (2 + N_CHIPS + 2 + 24 + (CPU_INST - 1) + 17)
 
 typedef struct { uint32_t key; int have; uint32_t d[8]; } agg_node;
 static int agg_node_cmp(const void* x, const void* y) {
@@ -583,7 +583,7 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   chipd cd[N_CHIPS];
   int logh[N_CHIPS];
   orc_machine_heights(in, logh);
-  if (in->n_cycles < 1 || logh[CH_CPU] > 20) return 1; /* two CPU instances of at most 2^20 rows each */
+  if (in->n_cycles < 1 || logh[CH_CPU] > 20) return 1; /* CPU instances of at most 2^20 rows each */
   const size_t need = orc_machine_proof_size(logh, in->log_prog, in->log_image, cfg, pub->pv_len);
   *out_len = need;
   if (cap < need) return 2;
@@ -595,8 +595,11 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   if (!orc_machine_nodes_public(in->agg_keys, in->agg_leaves, in->n_agg, agg_root, agg_digest)) return 1; /* malformed payload */
   uint32_t cpu_pub[N_CHIPS][CPUPUB_N];
   memset(cpu_pub, 0, sizeof cpu_pub);
-  orc_machine_cpu_pub(in, CH_CPU, cpu_pub[CH_CPU]);
-  orc_machine_cpu_pub(in, CH_CPU2, cpu_pub[CH_CPU2]);
+  uint32_t handover[CPU_INST - 1]; /* the pc every later CPU instance starts at: header words, absorbed into the transcript */
+  for (int i = 0; i < CPU_INST; ++i) {
+    orc_machine_cpu_pub(in, orc_cpu_chip(i), cpu_pub[orc_cpu_chip(i)]);
+    if (i + 1 < CPU_INST) handover[i] = cpu_pub[orc_cpu_chip(i)][CPUPUB_END_PC];
+  }
   orc_machine_cpu_pub(in, CH_CPU, cpu_pub[CH_ECALL]); /* the ecall chip's constraints use the padding pc */
 
   /* ---- rounds 0 and 1: preprocessed and main traces ---- */
@@ -618,7 +621,7 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
     put(&pb, pub->pv_digest, 8);
     put(&pb, pub->deferred_digest, 8);
     put(&pb, vk, 8);
-    put(&pb, &cpu_pub[CH_CPU][CPUPUB_END_PC], 1);
+    put(&pb, handover, CPU_INST - 1);
     put(&pb, &agg_n, 1);
     put(&pb, agg_root, 8);
     put(&pb, agg_digest, 8);
@@ -636,7 +639,7 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   orc_ch_observe(&ch, pub->exit_code >> 16);
   observe_word_halves(&ch, pub->pv_digest, 8);
   observe_word_halves(&ch, pub->deferred_digest, 8);
-  observe_word_halves(&ch, &cpu_pub[CH_CPU][CPUPUB_END_PC], 1);
+  observe_word_halves(&ch, handover, CPU_INST - 1);
   orc_ch_observe(&ch, agg_n);
   orc_ch_observe_many(&ch, agg_root, 8);
   orc_ch_observe_many(&ch, agg_digest, 8);

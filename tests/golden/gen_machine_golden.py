@@ -1,4 +1,4 @@
-"""Regression pins of the machine proof (format v12): for two small fixtures, the chip heights, the verifying key
+"""Regression pins of the machine proof (format v13): for two small fixtures, the chip heights, the verifying key
 and the SHA-256 of the oracle's proof bytes at 8 queries / 6 proof-of-work bits.
 
     python tests/golden/gen_machine_golden.py        # rewrites tests/golden/machine_kat.json

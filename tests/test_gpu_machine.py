@@ -47,7 +47,7 @@ def test_reference_flow_acct_d8_full_size(zk, fx, oracle):
     """BASELINE config 2 through the reference's own call sequence (prover/src/bin/main.rs:59-87) with the
     default client: setup -> prove(..).run() -> public_values -> verify, at full parameters (100 queries,
     16 proof-of-work bits).  The proof is the machine proof of the 391 400-cycle precompile-shape run
-    (CPU chip 2^18 + 2^17 rows x 67, ALU and sub-word chips beside it): byte-identical to the oracle's, accepted by a host-only verifier, every
+    (six CPU instances of 2^16 rows x 52, ALU, bitwise and sub-word chips beside them): byte-identical to the oracle's, accepted by a host-only verifier, every
     tampered region rejected, and another public value cannot be attached."""
     client = zk.ProverClient(device=0)
     pk, vk = client.setup(zk.merkle_elf())
@@ -60,8 +60,9 @@ def test_reference_flow_acct_d8_full_size(zk, fx, oracle):
     client.verify(proof, vk)
     raw = proof.to_bytes()
     heights = [int.from_bytes(raw[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
-    # 391 400 cycles: 2^18 rows in the first CPU instance, 2^17 in the second
-    assert int.from_bytes(raw[4:8], "little") == zk.MACHINE_VERSION and heights[0] == 18 and heights[zk.MACHINE_CHIP_NAMES.index("cpu2")] == 17
+    # 391 400 cycles: six CPU instances of 2^16 rows, the last two all padding at the minimum height
+    cpu = [heights[zk.MACHINE_CHIP_NAMES.index(n)] for n in ("cpu", "cpu2", "cpu3", "cpu4", "cpu5", "cpu6", "cpu7", "cpu8")]
+    assert int.from_bytes(raw[4:8], "little") == zk.MACHINE_VERSION and cpu == [16] * 6 + [5] * 2
     assert raw == oracle.machine_prove(trace)
     host = zk.ProverClient(device=-1)
     host.verify(zk.SP1ProofWithPublicValues.from_bytes(raw), vk)

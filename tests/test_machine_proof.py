@@ -65,9 +65,9 @@ def test_every_region_is_bound(zk, setup):
     client, vk, t, proof = setup
     rng = np.random.default_rng(5)
     words = len(proof) // 4
-    hw = zk.MACHINE_HEADER_WORDS  # heights 2..14, exit code 15, pv length 16, digests 17 / 25, vk 33, hand-over pc hw - 1, then the values
+    hw = zk.MACHINE_HEADER_WORDS  # heights from word 2, exit code, pv length, three digests, hand-over pcs hw - 24 .. hw - 18, aggregation words, then the values
     nc = zk.MACHINE_CHIPS
-    positions = [2, 5, 9, 1 + nc, 2 + nc, 3 + nc, 11 + nc, 19 + nc, hw - 1, hw, hw + 1, hw + 18, hw + 18 + 8, hw + 18 + 16, hw + 18 + 48, hw + 18 + 56, words - 1]
+    positions = [2, 5, 9, 1 + nc, 2 + nc, 3 + nc, 11 + nc, 19 + nc, hw - 24, hw - 20, hw - 18, hw - 1, hw, hw + 1, hw + 18, hw + 18 + 8, hw + 18 + 16, hw + 18 + 48, hw + 18 + 56, words - 1]
     positions += [int(x) for x in rng.integers(hw, words, 40)]
     for w in positions:
         bad = bytearray(proof)
@@ -390,26 +390,34 @@ def test_wrong_product_is_rejected(zk, oracle, setup):
     _rejected(zk, oracle, client, vk, t2)
 
 
-def test_second_cpu_instance_must_continue_the_first(zk, oracle, setup):
-    """The execution is split over two instances of the CPU chip; the second must start at the pc the first one's
-    last row hands over (a header word both instances' boundary constraints use).  A run whose second half starts
-    somewhere else is rejected, and so is a proof whose header names another hand-over pc."""
+def test_cpu_instances_must_continue_one_another(zk, oracle, setup):
+    """The execution is spread over the instances of the CPU chip; every later one must start at the pc its
+    predecessor's last row hands over (header words both instances' boundary constraints use).  A run whose next
+    stretch starts somewhere else is rejected, and so is a proof whose header names another hand-over pc."""
     client, vk, t, proof = setup
     cyc = t["cycles"]
-    h0 = 32
-    while 2 * h0 < len(cyc):
-        h0 *= 2
-    hw = zk.MACHINE_HEADER_WORDS - 17  # the 17 aggregation words follow the hand-over pc
-    assert int.from_bytes(proof[4 * (hw - 1):4 * hw], "little") == int(cyc[h0, 0])  # the header's hand-over pc
-    c2 = cyc.copy()
-    c2[h0, 0] = cyc[h0 + 7, 0]  # the second instance starts at another instruction
-    t2 = dict(t)
-    t2["cycles"] = c2
-    _rejected(zk, oracle, client, vk, t2)
-    bad = bytearray(proof)
-    bad[4 * (hw - 1)] ^= 4
-    with pytest.raises(zk.ZkspError):
-        client.verify(zk.SP1ProofWithPublicValues.from_bytes(bytes(bad)), vk)
+    heights = [int.from_bytes(proof[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
+    cpu = [0, 8] + list(range(17, 23))  # cpu, cpu2, cpu3 .. cpu8 in proof order
+    assert len({heights[c] for c in cpu}) <= 2 and heights[0] == max(heights[c] for c in cpu)
+    h0 = 1 << heights[0]
+    used = -(-len(cyc) // h0)
+    assert 2 <= used <= 8 and all(heights[cpu[i]] == heights[0] for i in range(used))
+    hw = zk.MACHINE_HEADER_WORDS - 17 - 7  # seven hand-over pcs, then the 17 aggregation words
+    for k in (1, used - 1):
+        assert int.from_bytes(proof[4 * (hw + k - 1):4 * (hw + k)], "little") == int(cyc[k * h0, 0])
+        c2 = cyc.copy()
+        c2[k * h0, 0] = cyc[k * h0 + 7, 0]  # instance k starts at another instruction
+        t2 = dict(t)
+        t2["cycles"] = c2
+        _rejected(zk, oracle, client, vk, t2)
+        bad = bytearray(proof)
+        bad[4 * (hw + k - 1)] ^= 4
+        with pytest.raises(zk.ZkspError):
+            client.verify(zk.SP1ProofWithPublicValues.from_bytes(bytes(bad)), vk)
+    # the instances behind the last cycle are all padding: they start at the padding pc
+    pad = int(t["program"][-1, 0])
+    for k in range(used, 8):
+        assert int.from_bytes(proof[4 * (hw + k - 1):4 * (hw + k)], "little") == pad
 
 
 def test_exit_code_is_bound_to_halt(zk, oracle, setup):

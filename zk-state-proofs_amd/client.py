@@ -29,14 +29,16 @@ ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_ELF, ERR_EXECUTOR, ERR_GUEST_PANIC,
     ERR_UNSUPPORTED = range(1, 10)
 KECCAK_SOFTWARE, KECCAK_OBSERVE, KECCAK_REPLACE = 0, 1, 2
 PROOF_MACHINE, PROOF_KECCAK_CHIP = 1, 2
-# machine proof (format version 12): chips in proof order and the fixed header in front of the public values
-MACHINE_VERSION = 12
+# machine proof (format version 13): chips in proof order and the fixed header in front of the public values
+MACHINE_VERSION = 13
 MACHINE_CHIP_NAMES = ("cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "table", "cpu2", "alu", "alu2",
-                      "subword", "subword2", "bitwise", "bitwise2", "poseidon2", "ecall")
+                      "subword", "subword2", "bitwise", "bitwise2", "poseidon2", "ecall", "cpu3", "cpu4", "cpu5", "cpu6", "cpu7",
+                      "cpu8")
 MACHINE_CHIPS = len(MACHINE_CHIP_NAMES)
-# magic, version, heights, exit code, pv length, three digests, the hand-over pc of the two CPU instances, the aggregation
-# payload's leaf count, root and leaf-list digest
-MACHINE_HEADER_WORDS = 2 + MACHINE_CHIPS + 2 + 24 + 1 + 17
+MACHINE_CPU_INSTANCES = 8  # cpu, cpu2 .. cpu8: one AIR, consecutive stretches of the run
+# magic, version, heights, exit code, pv length, three digests, the pcs at which the later CPU instances start, the
+# aggregation payload's leaf count, root and leaf-list digest
+MACHINE_HEADER_WORDS = 2 + MACHINE_CHIPS + 2 + 24 + (MACHINE_CPU_INSTANCES - 1) + 17
 
 
 def merkle_path_nodes(index: int, leaf, siblings):

@@ -24,13 +24,22 @@
 namespace zksp {
 namespace mach {
 
-// CPU, ALU and sub-word rows are each split over two instances of one AIR: the first has the largest power of two of
-// rows strictly below the count, the second the rest (a power of two again): 391 400 cycles take 2^18 + 2^17 rows.
-enum Chip { kCpu = 0, kKeccak, kKmem, kMemFinal, kImage, kProgram, kMul, kTable, kCpu2, kAlu, kAlu2, kSub, kSub2, kBw, kBw2, kP2, kEcall, kNumChips };
+// ALU, sub-word and bitwise rows are each split over two instances of one AIR: the first has the largest power of two of
+// rows strictly below the count, the second the rest (a power of two again).  The CPU rows (format v13) are spread over
+// kNumCpuInst instances of one height, 2^ceil(log2(cycles / kNumCpuInst)): as many as the cycles need, the others at the
+// minimum height (all padding): 391 400 cycles take 6 x 2^16 rows - the cells of 2^18 + 2^17, in rows six times as wide,
+// so the trees, the quotient and the FRI domain have a quarter of the height and the per-row costs of a commitment are
+// shared by six instances.
+enum Chip { kCpu = 0, kKeccak, kKmem, kMemFinal, kImage, kProgram, kMul, kTable, kCpu2, kAlu, kAlu2, kSub, kSub2, kBw, kBw2, kP2, kEcall,
+            kCpu3, kCpu4, kCpu5, kCpu6, kCpu7, kCpu8, kNumChips };
+constexpr int kNumCpuInst = 8;
+// CPU instance i <-> chip (the first two keep their old places in the proof order)
+ZKSP_HD constexpr int cpu_chip(int i) { return i == 0 ? kCpu : i == 1 ? kCpu2 : kCpu3 + (i - 2); }
+ZKSP_HD constexpr int cpu_instance(int chip) { return chip == kCpu ? 0 : chip == kCpu2 ? 1 : chip >= kCpu3 && chip <= kCpu8 ? chip - kCpu3 + 2 : -1; }
 // public scalars of a CPU instance: pc and time of its first row, whether another instance continues it, the pc
 // that one starts at (the hand-over pc: a proof-header word the transcript absorbs), the padding pc (verifying key)
 enum CpuPub { kPubStartPc = 0, kPubStartTs, kPubHasSucc, kPubEndPc, kPubPadPc, kNumCpuPub };
-ZKSP_HD constexpr bool is_cpu_chip(int chip) { return chip == kCpu || chip == kCpu2; }
+ZKSP_HD constexpr bool is_cpu_chip(int chip) { return cpu_instance(chip) >= 0; }
 ZKSP_HD constexpr bool is_alu_chip(int chip) { return chip == kAlu || chip == kAlu2; }
 ZKSP_HD constexpr bool is_sub_chip(int chip) { return chip == kSub || chip == kSub2; }
 ZKSP_HD constexpr bool is_bw_chip(int chip) { return chip == kBw || chip == kBw2; }

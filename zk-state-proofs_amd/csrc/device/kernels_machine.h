@@ -17,7 +17,7 @@ struct Seg {
   size_t bstride;
   int width;
 };
-constexpr int kMaxSegs = 20;  // at least kNumChips: every chip could have the same height
+constexpr int kMaxSegs = 24;  // at least kNumChips: every chip could have the same height
 
 // ---- trace expansion (row a3 of the machine proof) ----
 struct MachineRecords {
@@ -88,7 +88,7 @@ struct PermArgs {
 void launch_perm_trace(hipStream_t stream, const PermArgs& a);
 // public terms of the two verifier-closed buses: out[b] = -(sum over the 16 digest words and the exit code of 1/f)
 // per proof: pv digest 8, deferred digest 8, exit code (canonical), then the CpuPub words of the two CPU instances (Montgomery)
-constexpr int kPubWords = 17 + 2 * mach::kNumCpuPub;
+constexpr int kPubWords = 17 + mach::kNumCpuInst * mach::kNumCpuPub;
 void launch_public_bus(hipStream_t stream, const uint32_t* pub_words /*[B][kPubWords]*/,
                        const uint32_t* bus_ch, const uint32_t* bpow, uint32_t* out, size_t out_bstride, int batch);
 
@@ -145,7 +145,7 @@ void launch_fri_add(hipStream_t stream, uint32_t* layer, size_t layer_bstride, c
 
 // ---- proof assembly ----
 struct MRound {
-  Seg seg[mach::kNumChips][2];   // LDE matrices of each chip in the round (quotient: two 4-column chunks); width 0 = absent
+  Seg seg[mach::kNumChips];      // LDE matrix of each chip in the round; width 0 = absent (the kernel's arguments stay below 4 KB)
   int logh[mach::kNumChips];
   const uint32_t* tree;          // [B][(2N - 1) * 8], levels back to back, N = 2 * 2^lm
   size_t tree_bstride;
@@ -165,6 +165,7 @@ struct MAssembleArgs {
   size_t body_stride;
   int lm, n_queries, batch;
 };
+static_assert(sizeof(MAssembleArgs) <= 4096, "kernel argument segment");
 void launch_machine_assemble(hipStream_t stream, const MAssembleArgs& a);
 
 }  // namespace zksp

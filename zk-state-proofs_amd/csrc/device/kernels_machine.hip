@@ -454,7 +454,7 @@ void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& re
   const dim3 grid((unsigned)((h + kMT - 1) / kMT), batch), block(kMT);
   switch (chip) {
     case kCpu:
-    case kCpu2: hipLaunchKernelGGL(cpu_trace_kernel, grid, block, 0, stream, rec, trace, logh, rec.row0[chip]); break;
+    case kCpu2: case kCpu3: case kCpu4: case kCpu5: case kCpu6: case kCpu7: case kCpu8: hipLaunchKernelGGL(cpu_trace_kernel, grid, block, 0, stream, rec, trace, logh, rec.row0[chip]); break;
     case kAlu:
     case kAlu2: hipLaunchKernelGGL(alu_trace_kernel, grid, block, 0, stream, rec, trace, logh, rec.row0[chip]); break;
     case kSub:
@@ -1431,7 +1431,7 @@ void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a) {
   const dim3 grid((unsigned)((n + kMT - 1) / kMT), a.batch), block(kMT);
   switch (a.chip) {
     case kCpu:
-    case kCpu2:
+    case kCpu2: case kCpu3: case kCpu4: case kCpu5: case kCpu6: case kCpu7: case kCpu8:
       hipLaunchKernelGGL(cpu_quotient_task_kernel<0>, grid, block, 0, stream, a);
       hipLaunchKernelGGL(cpu_quotient_task_kernel<1>, grid, block, 0, stream, a);
       if (kCpuQuotSplit < kCpuSlots) hipLaunchKernelGGL(cpu_quotient_task_kernel<2>, grid, block, 0, stream, a);
@@ -1673,7 +1673,7 @@ __global__ __launch_bounds__(kMT) void machine_assemble_kernel(MAssembleArgs a) 
   }
   size_t perq = 0;
   for (int r = 0; r < 4; ++r) {
-    for (int c = 0; c < kNumChips; ++c) perq += (size_t)(a.round[r].seg[c][0].width + a.round[r].seg[c][1].width);
+    for (int c = 0; c < kNumChips; ++c) perq += (size_t)a.round[r].seg[c].width;
     perq += 8 * ((size_t)a.round[r].lm + 1);
   }
   for (int k = 0; k < lm; ++k) perq += 8 + 8 * (size_t)(lm - k);
@@ -1684,13 +1684,11 @@ __global__ __launch_bounds__(kMT) void machine_assemble_kernel(MAssembleArgs a) 
     const MRound& R = a.round[r];
     for (int c = 0; c < kNumChips; ++c) {
       const size_t h = (size_t)1 << R.logh[c], mm = m & (h - 1);
-      for (int s = 0; s < 2; ++s) {
-        const Seg& sg = R.seg[c][s];
-        if (!sg.width) continue;
-        const uint32_t* src = sg.p + (size_t)b * sg.bstride + cs * h + mm;
-        for (int i = tid; i < sg.width; i += kMT) dst[i] = canon(src[(size_t)i * 2 * h]);
-        dst += sg.width;
-      }
+      const Seg& sg = R.seg[c];
+      if (!sg.width) continue;
+      const uint32_t* src = sg.p + (size_t)b * sg.bstride + cs * h + mm;
+      for (int i = tid; i < sg.width; i += kMT) dst[i] = canon(src[(size_t)i * 2 * h]);
+      dst += sg.width;
     }
     const int logn = R.lm + 1;
     const size_t hm = (size_t)1 << R.lm;

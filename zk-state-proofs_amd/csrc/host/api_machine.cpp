@@ -12,7 +12,7 @@
 using namespace zksp;
 
 // Header (version, chip heights, exit code, digests, key digest), public values, body: the v12 proof object.
-int machine_proof_from_parts(const zksp_pk* pk, const ExecutionRecord& r, const int* lh, uint32_t handover_pc,
+int machine_proof_from_parts(const zksp_pk* pk, const ExecutionRecord& r, const int* lh, const uint32_t* handover_pc,
                              const std::vector<uint32_t>& agg_leaves, const std::vector<uint32_t>& agg_keys, const uint32_t* body,
                              size_t body_words, zksp_proof** out) {
   zksp_proof* p = new (std::nothrow) zksp_proof();
@@ -29,10 +29,11 @@ int machine_proof_from_parts(const zksp_pk* pk, const ExecutionRecord& r, const 
     memcpy(w + 4 + mach::kNumChips, r.pv_digest.data(), 32);
     memcpy(w + 12 + mach::kNumChips, r.deferred_digest.data(), 32);
     memcpy(w + 20 + mach::kNumChips, pk->mvk.digest, 32);
-    w[28 + mach::kNumChips] = handover_pc;
-    w[29 + mach::kNumChips] = (uint32_t)(agg_leaves.size() / 8);
+    constexpr int kHo = mach::kNumCpuInst - 1;
+    for (int i = 0; i < kHo; ++i) w[28 + mach::kNumChips + i] = handover_pc[i];
+    w[28 + mach::kNumChips + kHo] = (uint32_t)(agg_leaves.size() / 8);
     if (!machine_nodes_public(agg_keys.empty() ? nullptr : agg_keys.data(), agg_leaves.data(), agg_leaves.size() / 8,
-                              w + 30 + mach::kNumChips, w + 38 + mach::kNumChips, nullptr)) {
+                              w + 29 + mach::kNumChips + kHo, w + 37 + mach::kNumChips + kHo, nullptr)) {
       delete p;
       return ZKSP_ERR_INVALID_ARG;
     }
@@ -249,8 +250,9 @@ int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const 
   } else {
     machine_heights(*t->prog, t->t, lh);
   }
-  return machine_proof_from_parts(pk, t->t.rec, lh, machine_handover_pc(*t->prog, t->t, lh[mach::kCpu]), t->t.agg_leaves, t->t.agg_keys,
-                                  body, body_words, out);
+  uint32_t handover[mach::kNumCpuInst - 1];
+  for (int k = 1; k < mach::kNumCpuInst; ++k) handover[k - 1] = machine_handover_pc(*t->prog, t->t, lh, k);
+  return machine_proof_from_parts(pk, t->t.rec, lh, handover, t->t.agg_leaves, t->t.agg_keys, body, body_words, out);
 }
 
 int zksp_stdin_set_aggregation(zksp_stdin* s, const uint32_t* leaves, size_t n) {

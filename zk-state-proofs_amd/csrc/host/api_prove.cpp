@@ -164,7 +164,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       std::array<int, mach::kNumChips> lh;
       machine_heights(pk->mprog, traces[i]->t, lh.data());
       const MachineTrace& t = traces[i]->t;
-      lh[mach::kCpu] = clog2(t.cycles.size()); lh[mach::kCpu2] = 0;
+      for (int k = 1; k < mach::kNumCpuInst; ++k) lh[mach::cpu_chip(k)] = 0;  // (the key: the instances' common height)
       lh[mach::kAlu] = clog2(t.alu_idx.size()); lh[mach::kAlu2] = 0;
       lh[mach::kSub] = clog2(t.sub_idx.size()); lh[mach::kSub2] = 0;
       lh[mach::kBw] = clog2(t.bw_idx.size()); lh[mach::kBw2] = 0;
@@ -228,7 +228,8 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     std::vector<const MachineTrace*> ts(ck.idx.size());
     for (size_t j = 0; j < ck.idx.size(); ++j) {
       ts[j] = &traces[ck.idx[j]]->t;
-      traces[ck.idx[j]]->handover_pc = machine_handover_pc(pk->mprog, *ts[j], ck.lh[mach::kCpu]);
+      for (int k = 1; k < mach::kNumCpuInst; ++k)
+        traces[ck.idx[j]]->handover_pc[k - 1] = machine_handover_pc(pk->mprog, *ts[j], ck.lh.data(), k);
     }
     if (!into_spare) ctx->batch_hint = (int)ck.group_size;
     const int rc = machine_load(ctx, pk->mprog, pk->mvk, ts.data(), ts.size(), into_spare, ck.lh.data());

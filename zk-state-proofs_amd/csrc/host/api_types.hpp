@@ -14,7 +14,7 @@ struct zksp_pk { zksp::ElfImage elf; uint32_t vk_digest[8]; zksp::MachineProgram
 struct zksp_mtrace {
   zksp::MachineTrace t;
   const zksp::MachineProgram* prog;
-  uint32_t handover_pc = 0;  // pc of the first cycle of the second CPU instance (kept when the cycle records are released)
+  uint32_t handover_pc[zksp::mach::kNumCpuInst - 1] = {};  // pc of the first cycle of every later CPU instance (kept when the cycle records are released)
 };
 struct zksp_vk { uint32_t digest[8]; zksp::MachineVk machine; };
 struct zksp_stdin {
@@ -25,6 +25,6 @@ struct zksp_stdin {
 struct zksp_proof { std::vector<uint8_t> bytes; zksp::ProofHeader hdr; zksp::MachineHeader mhdr; uint32_t version = 2; };
 
 // api_machine.cpp: the v12 proof object from an execution record, the chip heights, the aggregation leaves and a fetched body
-int machine_proof_from_parts(const zksp_pk* pk, const zksp::ExecutionRecord& r, const int* log_heights, uint32_t handover_pc,
+int machine_proof_from_parts(const zksp_pk* pk, const zksp::ExecutionRecord& r, const int* log_heights, const uint32_t* handover_pc /* [kNumCpuInst - 1] */,
                              const std::vector<uint32_t>& agg_leaves, const std::vector<uint32_t>& agg_keys, const uint32_t* body,
                              size_t body_words, zksp_proof** out);

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "../device/air_machine.hpp"
 #include "../device/kernels.h"
 #include "executor.hpp"
 
@@ -68,7 +69,7 @@ struct Context {
   void* arena = nullptr;   // the machine workspace's device memory: laid out again per shape, grown when too small
   size_t arena_bytes = 0;
   std::map<std::array<uint32_t, 8>, std::unique_ptr<PrepDevice>> prep;
-  void* d_inter[16] = {nullptr};  // indexed by chip (mach::kNumChips <= 16)
+  void* d_inter[mach::kNumChips] = {nullptr};  // indexed by chip
   uint32_t* h_stage2[2] = {nullptr, nullptr};  // pinned host staging for proof bodies (double buffered)
   size_t h_stage2_words[2] = {0, 0};
   // prove_batch copies a group's bodies to the host on its own stream while the next group is

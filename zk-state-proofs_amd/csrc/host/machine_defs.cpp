@@ -369,6 +369,10 @@ void build() {
   g_chips[kTable] = {"table", kTablePrepWidth, kTableWidth, 7, g_table, 2, 0};
   g_chips[kCpu] = {"cpu", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 5};
   g_chips[kCpu2] = {"cpu2", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 5};
+  {
+    static const char* const names[kNumCpuInst] = {"cpu", "cpu2", "cpu3", "cpu4", "cpu5", "cpu6", "cpu7", "cpu8"};
+    for (int i = 2; i < kNumCpuInst; ++i) g_chips[cpu_chip(i)] = {names[i], 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 5};
+  }
   g_chips[kEcall] = {"ecall", 0, kEcallWidth, 10, g_ecall, kEcallConstraints, 0};
   g_chips[kKeccak] = {"keccak", 0, kKeccakWidth, 50, g_keccak, kKeccakConstraints, 0};
   g_chips[kKmem] = {"keccak-mem", 0, kKmemWidth, 8, g_kmem, kKmemConstraints, 0};

@@ -59,8 +59,8 @@ inline int quot_alpha_offset(const int* logh, int c) {
 }
 
 // magic, version, heights, exit code, pv length, 3 digests, hand-over pc; aggregation payload: leaf count, root, digest of the leaf list
-constexpr int kHeaderWords = 2 + kNumChips + 2 + 24 + 1 + 17;
-constexpr uint32_t kMachineVersion = 12;
+constexpr int kHeaderWords = 2 + kNumChips + 2 + 24 + (kNumCpuInst - 1) + 17;
+constexpr uint32_t kMachineVersion = 13;
 
 }  // namespace mach
 }  // namespace zksp

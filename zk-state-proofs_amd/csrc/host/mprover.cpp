@@ -85,14 +85,22 @@ int mmcs_commit(hipStream_t s, const RoundMats& rm, uint32_t* tree, size_t tree_
 
 }  // namespace
 
-uint32_t machine_handover_pc(const MachineProgram& prog, const MachineTrace& t, int logh_cpu) {
-  const size_t h0 = (size_t)1 << logh_cpu;
-  return h0 < t.cycles.size() ? t.cycles[h0].pc : prog.pad_pc();
+size_t machine_cpu_row0(const int* logh, int inst) {
+  size_t r = 0;
+  for (int i = 0; i < inst; ++i) r += (size_t)1 << logh[cpu_chip(i)];
+  return r;
+}
+uint32_t machine_handover_pc(const MachineProgram& prog, const MachineTrace& t, const int* logh, int inst) {
+  const size_t r0 = machine_cpu_row0(logh, inst);
+  return r0 < t.cycles.size() ? t.cycles[r0].pc : prog.pad_pc();
 }
 
 void machine_heights(const MachineProgram& prog, const MachineCounts& n, int logh[kNumChips]) {
-  logh[kCpu] = ceil_log2(split_rows(n.cycles));
-  logh[kCpu2] = ceil_log2(split_rest_rows(n.cycles));
+  {
+    // CPU instances of one height, as many as the cycles need; the others all padding at the minimum height
+    const int hc = at_least5(ceil_log2((n.cycles + kNumCpuInst - 1) / kNumCpuInst));
+    for (int i = 0; i < kNumCpuInst; ++i) logh[cpu_chip(i)] = i == 0 || ((size_t)i << hc) < n.cycles ? hc : 5;
+  }
   logh[kAlu] = ceil_log2(split_rows(n.alu));
   logh[kAlu2] = ceil_log2(split_rest_rows(n.alu));
   logh[kSub] = ceil_log2(split_rows(n.sub));
@@ -117,7 +125,7 @@ void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh
 bool machine_fits(const MachineTrace& t, const int* logh) {
   auto two = [&](int a, int b) { return ((size_t)1 << logh[a]) + ((size_t)1 << logh[b]); };
   auto one = [&](int a) { return (size_t)1 << logh[a]; };
-  return t.cycles.size() <= two(kCpu, kCpu2) && t.alu_idx.size() <= two(kAlu, kAlu2) && t.sub_idx.size() <= two(kSub, kSub2) &&
+  return t.cycles.size() <= machine_cpu_row0(logh, kNumCpuInst) && t.alu_idx.size() <= two(kAlu, kAlu2) && t.sub_idx.size() <= two(kSub, kSub2) &&
          t.bw_idx.size() <= two(kBw, kBw2) && t.agg_rows <= one(kP2) &&
          24 * t.keccak.size() <= one(kKeccak) && 50 * t.keccak.size() <= one(kKmem) && t.memfinal.size() <= one(kMemFinal) &&
          t.muls.size() <= one(kMul) && t.ecall_idx.size() <= one(kEcall);
@@ -383,7 +391,7 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
   for (size_t i = 0; i < n; ++i)
     if (!machine_fits(*traces[i], logh)) return ctx->fail(1, "machine_load: a trace does not fit the batch's chip heights");
   // record capacities follow from the heights alone, so every batch of these heights fits the same workspace
-  const size_t cc = ((size_t)1 << logh[kCpu]) + ((size_t)1 << logh[kCpu2]), cm = (size_t)1 << logh[kMemFinal], cu = (size_t)1 << logh[kMul],
+  const size_t cc = machine_cpu_row0(logh, kNumCpuInst), cm = (size_t)1 << logh[kMemFinal], cu = (size_t)1 << logh[kMul],
                ck = std::min(((size_t)1 << logh[kKeccak]) / 24, ((size_t)1 << logh[kKmem]) / 50),
                ca = ((size_t)1 << logh[kAlu]) + ((size_t)1 << logh[kAlu2]), cs = ((size_t)1 << logh[kSub]) + ((size_t)1 << logh[kSub2]),
                cb = ((size_t)1 << logh[kBw]) + ((size_t)1 << logh[kBw2]),
@@ -460,21 +468,27 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     }
     pubw[i * kPubWords + 16] = t.rec.exit_code;
     {
-      // the two CPU instances: first pc, first time, has a successor, hand-over pc (air_machine.hpp CpuPub)
-      const size_t h0 = (size_t)1 << logh[kCpu];
-      const uint32_t handover = machine_handover_pc(prog, t, logh[kCpu]);
-      o[42 + kNumChips] = handover & 0xffff;
-      o[43 + kNumChips] = handover >> 16;
-      o[44 + kNumChips] = (uint32_t)n_agg;
-      memcpy(o + 45 + kNumChips, agg_root, 32);
-      memcpy(o + 53 + kNumChips, agg_digest, 32);
-      uint32_t* cp = &pubw[i * kPubWords + 17];
-      uint32_t* cp2 = cp + kNumCpuPub;
-      cp[kPubStartPc] = Fp::from_canonical(prog.entry).v; cp[kPubStartTs] = Fp::from_canonical(4).v;
-      cp[kPubHasSucc] = Fp::one().v; cp[kPubEndPc] = Fp::from_canonical(handover).v;
-      cp2[kPubStartPc] = Fp::from_canonical(handover).v; cp2[kPubStartTs] = Fp::from_canonical((uint32_t)(4 * (h0 + 1))).v;
-      cp2[kPubHasSucc] = 0; cp2[kPubEndPc] = 0;
-      cp[kPubPadPc] = cp2[kPubPadPc] = Fp::from_canonical(prog.pad_pc()).v;
+      // the CPU instances: first pc, first time, has a successor, hand-over pc (air_machine.hpp CpuPub)
+      constexpr int kHo = 2 * (kNumCpuInst - 1);
+      uint32_t start_pc = prog.entry;
+      for (int k = 0; k < kNumCpuInst; ++k) {
+        uint32_t* cp = &pubw[i * kPubWords + 17 + k * kNumCpuPub];
+        const bool succ = k + 1 < kNumCpuInst;
+        const uint32_t handover = succ ? machine_handover_pc(prog, t, logh, k + 1) : 0;
+        if (succ) {
+          o[42 + kNumChips + 2 * k] = handover & 0xffff;
+          o[43 + kNumChips + 2 * k] = handover >> 16;
+        }
+        cp[kPubStartPc] = Fp::from_canonical(start_pc).v;
+        cp[kPubStartTs] = Fp::from_canonical((uint32_t)(4 * (machine_cpu_row0(logh, k) + 1))).v;
+        cp[kPubHasSucc] = succ ? Fp::one().v : 0u;
+        cp[kPubEndPc] = Fp::from_canonical(handover).v;
+        cp[kPubPadPc] = Fp::from_canonical(prog.pad_pc()).v;
+        start_pc = handover;
+      }
+      o[42 + kNumChips + kHo] = (uint32_t)n_agg;
+      memcpy(o + 43 + kNumChips + kHo, agg_root, 32);
+      memcpy(o + 51 + kNumChips + kHo, agg_digest, 32);
     }
   }
   ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->kstates, kst.data(), kst.size() * 8, hipMemcpyHostToDevice, s));
@@ -529,11 +543,12 @@ int machine_prove_resident(Context* ctx) {
   rec.alu_idx = w->alu_idx; rec.sub_idx = w->sub_idx; rec.bw_idx = w->bw_idx; rec.ecall_idx = w->ecall_idx; rec.agg_heap = w->agg_heap; rec.consts = kc;
   rec.prog_mult = w->prog_mult; rec.counts = w->counts; rec.table_hist = w->table_hist;
   memset(rec.row0, 0, sizeof rec.row0);
-  rec.row0[kCpu2] = (uint32_t)1 << logh[kCpu]; rec.row0[kAlu2] = (uint32_t)1 << logh[kAlu]; rec.row0[kSub2] = (uint32_t)1 << logh[kSub]; rec.row0[kBw2] = (uint32_t)1 << logh[kBw];
+  for (int k = 1; k < kNumCpuInst; ++k) rec.row0[cpu_chip(k)] = (uint32_t)machine_cpu_row0(logh, k);
+  rec.row0[kAlu2] = (uint32_t)1 << logh[kAlu]; rec.row0[kSub2] = (uint32_t)1 << logh[kSub]; rec.row0[kBw2] = (uint32_t)1 << logh[kBw];
   rec.cap_cycles = w->cap_cycles; rec.cap_keccak = w->cap_keccak; rec.cap_memfinal = w->cap_memfinal; rec.cap_muls = w->cap_muls;
   rec.cap_alu = w->cap_alu; rec.cap_sub = w->cap_sub; rec.cap_bw = w->cap_bw; rec.cap_agg = w->cap_agg; rec.cap_ecall = (size_t)1 << logh[kEcall];
   rec.program = prep->program; rec.text_base = prep->text_base; rec.n_program = prep->n_program; rec.n_image = prep->n_image;
-  rec.cpu_rows = ((uint32_t)1 << logh[kCpu]) + ((uint32_t)1 << logh[kCpu2]);
+  rec.cpu_rows = (uint32_t)machine_cpu_row0(logh, kNumCpuInst);
   {
     ProfileSpan sp(ctx, "m_trace");
     for (int c = 0; c < kNumChips; ++c) {
@@ -547,7 +562,7 @@ int machine_prove_resident(Context* ctx) {
     }
     // the table chip answers what the others look up: count their RANGE / BYTES receives on their finished traces
     launch_table_clear(s, rec, B);
-    for (int c : {(int)kCpu, (int)kCpu2}) launch_cpu_table_count(s, w->mat[c][0].tr, logh[c], rec, B);
+    for (int k = 0; k < kNumCpuInst; ++k) launch_cpu_table_count(s, w->mat[cpu_chip(k)][0].tr, logh[cpu_chip(k)], rec, B);
     for (int c : {(int)kKmem, (int)kMemFinal, (int)kBw, (int)kBw2, (int)kSub, (int)kSub2, (int)kEcall, (int)kP2})
       launch_table_count(s, static_cast<const Interaction*>(ctx->d_inter[c]), chip_def(c).n_inter, w->mat[c][0].tr, chip_def(c).main_w,
                          logh[c], rec, B);
@@ -652,7 +667,7 @@ int machine_prove_resident(Context* ctx) {
       qa.wh_inv = wh.inv().v;
       qa.h_inv = Fp::from_canonical((uint32_t)(H(c) % kP)).inv().v;
       qa.consts = kc;
-      qa.pubs = is_cpu_chip(c) || c == kEcall ? w->pub_words + 17 + (c == kCpu2 ? kNumCpuPub : 0) : nullptr;  // (ecall chip: the padding pc)
+      qa.pubs = is_cpu_chip(c) || c == kEcall ? w->pub_words + 17 + (is_cpu_chip(c) ? cpu_instance(c) * kNumCpuPub : 0) : nullptr;  // (ecall chip: the padding pc)
       qa.pubs_bstride = kPubWords;
       qa.quot = w->mat[quot_leader(logh, c)][2].tr;
       qa.accumulate = quot_leader(logh, c) != c;
@@ -807,9 +822,8 @@ int machine_prove_resident(Context* ctx) {
       mr.lm = 0;
       for (int c = 0; c < kNumChips; ++c) {
         mr.logh[c] = logh[c];
-        mr.seg[c][0] = rm[r].seg[c][0];
-        mr.seg[c][1] = Seg{nullptr, 0, 0};
-        if (mr.seg[c][0].width) mr.lm = std::max(mr.lm, logh[c]);
+        mr.seg[c] = rm[r].seg[c][0];
+        if (mr.seg[c].width) mr.lm = std::max(mr.lm, logh[c]);
       }
       if (r == 0) { mr.tree = prep->tree; mr.tree_bstride = 0; }
       else { mr.tree = w->tree[r]; mr.tree_bstride = tree_stride; }

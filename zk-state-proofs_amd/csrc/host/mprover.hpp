@@ -12,7 +12,7 @@
 namespace zksp {
 
 // vk digest, heights, exit halves, digest halves, hand-over pc halves, aggregation: leaf count, root, digest of the leaf list
-constexpr int kMachineInitObs = 8 + mach::kNumChips + 2 + 16 + 16 + 2 + 17;
+constexpr int kMachineInitObs = 8 + mach::kNumChips + 2 + 16 + 16 + 2 * (mach::kNumCpuInst - 1) + 17;
 
 // Preprocessed tables of one program on the device (built once per verifying key).
 struct PrepDevice {
@@ -87,6 +87,10 @@ void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh
 void machine_heights(const MachineProgram& prog, const MachineCounts& counts, int logh[mach::kNumChips]);
 bool machine_fits(const MachineTrace& t, const int* logh);
 // pc of the first row of the second CPU instance when the first has 2^logh_cpu rows (a proof-header word)
-uint32_t machine_handover_pc(const MachineProgram& prog, const MachineTrace& t, int logh_cpu);
+// pc at which CPU instance `inst` (1 .. kNumCpuInst - 1) starts under the chip heights `logh`: the pc of its first cycle, or the
+// padding pc when the run has ended before
+uint32_t machine_handover_pc(const MachineProgram& prog, const MachineTrace& t, const int* logh, int inst);
+// first cycle of CPU instance `inst` (inst = kNumCpuInst: the rows of all instances)
+size_t machine_cpu_row0(const int* logh, int inst);
 
 }  // namespace zksp

@@ -402,16 +402,22 @@ bool parse_machine_header(const uint8_t* bytes, size_t len, MachineHeader* h, st
     h->logh[c] = (int)w[2 + c];
     if (w[2 + c] < 5 || w[2 + c] > 21) { *err = "chip height out of range"; return false; }
   }
-  if (h->logh[kCpu] > 20 || h->logh[kCpu2] > h->logh[kCpu]) { *err = "CPU instance heights out of range"; return false; }
+  {
+    // at most 2^21 CPU rows, as the time limbs of the memory argument assume (times stay below 2^24)
+    size_t rows = 0;
+    for (int i = 0; i < kNumCpuInst; ++i) rows += (size_t)1 << h->logh[cpu_chip(i)];
+    if (rows > ((size_t)1 << 21)) { *err = "CPU instance heights out of range"; return false; }
+  }
   h->exit_code = w[2 + kNumChips];
   h->pv_len = w[3 + kNumChips];
   memcpy(h->pv_digest, w + 4 + kNumChips, 32);
   memcpy(h->deferred_digest, w + 12 + kNumChips, 32);
   memcpy(h->vk_digest, w + 20 + kNumChips, 32);
-  h->handover_pc = w[28 + kNumChips];
-  h->agg_n = w[29 + kNumChips];
-  memcpy(h->agg_root, w + 30 + kNumChips, 32);
-  memcpy(h->agg_digest, w + 38 + kNumChips, 32);
+  constexpr int kHo = kNumCpuInst - 1;
+  for (int i = 0; i < kHo; ++i) h->handover_pc[i] = w[28 + kNumChips + i];
+  h->agg_n = w[28 + kNumChips + kHo];
+  memcpy(h->agg_root, w + 29 + kNumChips + kHo, 32);
+  memcpy(h->agg_digest, w + 37 + kNumChips + kHo, 32);
   if (h->agg_n == 1 || h->agg_n > (1u << 20)) { *err = "aggregation payload of an impossible size"; return false; }
   for (int i = 0; i < 8; ++i)
     if (h->agg_root[i] >= kP || h->agg_digest[i] >= kP) { *err = "non-canonical aggregation digest"; return false; }
@@ -491,8 +497,10 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   ch.observe_canon(hd.exit_code >> 16);
   for (int i = 0; i < 8; ++i) { ch.observe_canon(hd.pv_digest[i] & 0xffff); ch.observe_canon(hd.pv_digest[i] >> 16); }
   for (int i = 0; i < 8; ++i) { ch.observe_canon(hd.deferred_digest[i] & 0xffff); ch.observe_canon(hd.deferred_digest[i] >> 16); }
-  ch.observe_canon(hd.handover_pc & 0xffff);
-  ch.observe_canon(hd.handover_pc >> 16);
+  for (int i = 0; i < kNumCpuInst - 1; ++i) {
+    ch.observe_canon(hd.handover_pc[i] & 0xffff);
+    ch.observe_canon(hd.handover_pc[i] >> 16);
+  }
   ch.observe_canon(hd.agg_n);
   for (int i = 0; i < 8; ++i) ch.observe_canon(hd.agg_root[i]);
   for (int i = 0; i < 8; ++i) ch.observe_canon(hd.agg_digest[i]);
@@ -580,19 +588,21 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     // and ends on the padding instruction (reached through HALT only: the exit code bus would not balance otherwise)
     for (int i = 0; i < kNumCpuPub; ++i) zc.pub_[i] = Fp4::zero();
     zc.pub_[kPubPadPc] = Fp4::from_base(Fp::from_canonical(vk.pad_pc));
-    if (c == kCpu) {
-      zc.pub_[kPubStartPc] = Fp4::from_base(Fp::from_canonical(vk.entry));
-      zc.pub_[kPubStartTs] = Fp4::from_base(Fp::from_canonical(4));
-      zc.pub_[kPubHasSucc] = Fp4::one();
-      zc.pub_[kPubEndPc] = Fp4::from_base(Fp::from_canonical(hd.handover_pc % kP));
-    } else if (c == kCpu2) {
-      zc.pub_[kPubStartPc] = Fp4::from_base(Fp::from_canonical(hd.handover_pc % kP));
-      zc.pub_[kPubStartTs] = Fp4::from_base(Fp::from_canonical((uint32_t)(4 * (((uint64_t)1 << logh[kCpu]) + 1))));
+    if (is_cpu_chip(c)) {
+      const int inst = cpu_instance(c);
+      size_t r0 = 0;
+      for (int i = 0; i < inst; ++i) r0 += (size_t)1 << logh[cpu_chip(i)];
+      zc.pub_[kPubStartPc] = Fp4::from_base(Fp::from_canonical(inst == 0 ? vk.entry : hd.handover_pc[inst - 1] % kP));
+      zc.pub_[kPubStartTs] = Fp4::from_base(Fp::from_canonical((uint32_t)(4 * (r0 + 1))));
+      if (inst + 1 < kNumCpuInst) {
+        zc.pub_[kPubHasSucc] = Fp4::one();
+        zc.pub_[kPubEndPc] = Fp4::from_base(Fp::from_canonical(hd.handover_pc[inst] % kP));
+      }
     }
     zc.ap = apow.data();
     switch (c) {
       case kCpu:
-      case kCpu2: eval_cpu(zc); break;
+      case kCpu2: case kCpu3: case kCpu4: case kCpu5: case kCpu6: case kCpu7: case kCpu8: eval_cpu(zc); break;
       case kKeccak:
         for (int task = 0; task < ka::kBusTask; ++task) ka::eval_task(task, zc);
         zc.k_ = ka::kNumConstraints;

@@ -24,7 +24,8 @@ struct MachineVk {
 
 struct MachineHeader {
   int logh[mach::kNumChips];
-  uint32_t exit_code, pv_len, handover_pc;
+  uint32_t exit_code, pv_len;
+  uint32_t handover_pc[mach::kNumCpuInst - 1];  // the pc CPU instance i + 1 starts at
   uint32_t pv_digest[8], deferred_digest[8], vk_digest[8];
   uint32_t agg_n, agg_root[8], agg_digest[8];  // aggregation payload: leaf count (0: none), Merkle root, digest of the leaf list
   size_t pv_offset, body_offset;
