@@ -3,8 +3,8 @@
 
 One "step" = one pass of the device hot path over one resident batch of synthetic acct-d8 proofs
 (BASELINE configs[1]: single account-trie proof, depth 8).  A proof is the MACHINE proof of the
-committed sp1-merkle-proof guest in the keccak-precompile shape: 391 400 RV32IM cycles in two CPU chip instances of
-2^18 + 2^17 rows, the ALU, bitwise and sub-word chips beside them (one row per shift / signed compare, per xor / or / and,
+committed sp1-merkle-proof guest in the keccak-precompile shape: 391 400 RV32IM cycles in six CPU chip instances of
+2^16 rows (of eight), the ALU, bitwise and sub-word chips beside them (one row per shift / signed compare, per xor / or / and,
 per sub-word access), 62 keccak-f permutations in a 2^11 x 2634 keccak chip, keccak-memory, memory-boundary,
 image, program, table, multiplier and Poseidon2 chips, joined by LogUp buses -- i.e. the statement
 the reference's client.prove() establishes, not a component.  The step runs trace expansion ->
@@ -197,7 +197,7 @@ def cpu_baseline(trace_of, first_s, seconds):
     n = len(times)
     return {"value": n / el, "unit": "proofs/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
             "repetitions": n, "median_s_per_proof": sorted(times)[n // 2], "min_s_per_proof": min(times),
-            "sample": f"{n} acct-d8 machine proofs (391 400 cycles, {oracle.N_CHIPS} chips, two CPU instances of 2^18 and 2^17 rows, 100 queries) in {el:.1f} s; "
+            "sample": f"{n} acct-d8 machine proofs (391 400 cycles, {oracle.N_CHIPS} chips, six CPU instances of 2^16 rows, 100 queries) in {el:.1f} s; "
                       "reference SP1 CPU prover unavailable offline, CPU baseline is this repository's oracle/ restatement"}
 
 
@@ -649,7 +649,8 @@ def main():
             "parallelism": f"proof-farm x{world} (independent proofs, all-gather of 32-byte roots only)",
         },
         "roofline": {
-            "kernel": f"mmcs_leaf_kernel over the first CPU instance's main LDE (Poseidon2 sponge, {(sum(w for w, _ in leaf_group) + 7) // 8} "
+            "kernel": f"mmcs_leaf_kernel over the main LDE of the tallest chips ({len(leaf_group)} matrices, {sum(w for w, _ in leaf_group)} columns: the CPU instances and "
+                      f"the table-sized chips; Poseidon2 sponge, {(sum(w for w, _ in leaf_group) + 7) // 8} "
                       f"permutations per row, 2^{max(heights) + 1} rows per proof)",
             # bound by vector-ALU issue (one Poseidon2 permutation per 32 bytes absorbed); achieved / peak / frac are the
             # contractual HBM figures: algorithmic bytes over the launch time against the 8 TB/s peak
