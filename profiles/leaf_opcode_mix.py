@@ -62,14 +62,19 @@ for (b, d), w in zip(big, weights):
             mix["full_rate" if op in FULL_RATE else "half_rate"] += w * n
 total = sum(mix.values())
 # cross-check with the counter collection of the same build, when there is one: VALU instructions of the largest launch
-# (the CPU chip's main trace) per lane per permutation
+# (the main LDE of the tallest chips: heights from the bench line of that collection, widths from the library) per lane per
+# permutation
 pmc = None
 try:
+    import importlib
+    sys.path.insert(0, ROOT)
     v = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_counters.json")))
-    air = open(os.path.join(ROOT, "zk-state-proofs_amd", "csrc", "device", "air_machine.hpp")).read()
-    absorptions = (int(re.search(r"static_assert\(kCpuWidth == (\d+)", air).group(1)) + 7) // 8  # per row of the CPU chip's main trace
-    pmc = v["SQ_INSTS_VALU"]["zksp::mmcs_leaf_kernel"][1] / (v["batch"] * (1 << 19) / 64) / absorptions
-except (OSError, KeyError, ValueError):
+    heights = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_under_rocprof.json")))["config"]["chip_log_heights"]
+    widths = importlib.import_module("zk-state-proofs_amd.client").machine_chip_widths()
+    top = max(heights)
+    absorptions = (sum(w for (_, _, w, _), lh in zip(widths, heights) if lh == top) + 7) // 8
+    pmc = v["SQ_INSTS_VALU"]["zksp::mmcs_leaf_kernel"][1] / (v["batch"] * (2 << top) / 64) / absorptions
+except (OSError, KeyError, ValueError, ImportError):
     pass
 out = {"kernel": "mmcs_leaf_kernel", "per_permutation_per_lane": dict(mix), "total_valu": total,
        "block_weights": {b: w for (b, _), w in zip(big, weights)},
