@@ -851,14 +851,48 @@ __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, 
   Fp g[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) g[i] = col(C_GAP + i);
-  const Fp4 b1 = m_load_fp4(bpow + 4), b2 = m_load_fp4(bpow + 8), b3 = m_load_fp4(bpow + 12), b4 = m_load_fp4(bpow + 16);
+  // A fingerprint gamma + bus + sum_j beta^(j+1) t_j is a dot product of uniform extension elements with the row's base-field
+  // values: four signed 64-bit accumulators, one multiply-add per term and coordinate (the powers of beta and the
+  // values centred into (-p/2, p/2], so up to nine terms fit), folded once - instead of a canonical extension-by-base
+  // product and an extension addition per term (32 instructions against 4).
+  struct Beta { int32_t c[4]; };
+  auto beta = [&](int j) {  // beta^j, centred (uniform: scalar loads and scalar arithmetic)
+    Beta r;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) r.c[t] = fps_centre(bpow[4 * j + t]);
+    return r;
+  };
+  struct Acc {
+    int64_t a[4] = {0, 0, 0, 0};
+    __device__ __forceinline__ void mad(const Beta& bt, Fp x) {
+      const int32_t xc = fps_centre(x.v);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] += (int64_t)bt.c[t] * (int64_t)xc;
+    }
+    __device__ __forceinline__ Fp4 plus(const Fp4& g) const {
+      Fp4 r;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) r.c[t] = Fp::raw(fps_canon(fps_fold(a[t]))) + g.c[t];
+      return r;
+    }
+  };
+  const Beta b1 = beta(1), b2 = beta(2), b3 = beta(3), b4 = beta(4);
   auto busc = [&](int bus) {
     Fp4 f = gamma;
     f.c[0] += Fp::raw(cmonty((uint32_t)bus));
     return f;
   };
   const Fp4 gmem = busc(BUS_MEM), grng = busc(BUS_RANGE), gbyt = busc(BUS_BYTES);
-  auto mem = [&](Fp addr, Fp lo, Fp hi, Fp t) { return gmem + b1 * addr + b2 * lo + b3 * hi + b4 * t; };
+  auto mem = [&](Fp addr, Fp lo, Fp hi, Fp t) {
+    Acc f;
+    f.mad(b1, addr); f.mad(b2, lo); f.mad(b3, hi); f.mad(b4, t);
+    return f.plus(gmem);
+  };
+  auto pair = [&](const Fp4& g0, Fp v1, Fp v2) {  // (kind, value) or (x, y)
+    Acc f;
+    f.mad(b1, v1); f.mad(b2, v2);
+    return f.plus(g0);
+  };
   // previous access time of slot q (accessed at ts + q): ts + q - 1 - (gap_lo + 2^16 gap_hi)
   auto pts = [&](int q) { return ts - (g[2 * q] + k65536 * g[2 * q + 1]) + (q == 0 ? -one : q == 1 ? Fp::zero() : one); };
   // the second access (rs2, or a load's word, whose value sits in C) and the written location (rd, or a store's word:
@@ -866,34 +900,44 @@ __device__ __forceinline__ void cpu_bus_pairs(const uint32_t* __restrict__ row, 
   const Fp m2 = use2 + sel[CL_LW] + sel[CL_LDS], m3 = wr + sel[CL_SW] + sel[CL_STS];
   const Fp ad2 = col(C_ADDR2), ad3 = col(C_ADDR3);
   if (J0 <= 0 && 0 < J1) {  // instruction fetch (receive), rs1 consume
-    Fp4 f = busc(BUS_PROG) + b1 * col(C_PC) + b2 * clsid + b3 * code + b4 * uc;
-    f += m_load_fp4(bpow + 20) * wr + m_load_fp4(bpow + 24) * use2 + m_load_fp4(bpow + 28) * rd + m_load_fp4(bpow + 32) * rs1 +
-         m_load_fp4(bpow + 36) * rs2 + m_load_fp4(bpow + 40) * col(C_IMM_LO) + m_load_fp4(bpow + 44) * col(C_IMM_HI) +
-         m_load_fp4(bpow + 48) * col(C_TGT_LO) + m_load_fp4(bpow + 52) * col(C_TGT_HI);
-    visit(0, -one, f, -one, mem(rs1, b_lo, b_hi, pts(0)));
+    Acc f0, f1;
+    f0.mad(b1, col(C_PC)); f0.mad(b2, clsid); f0.mad(b3, code); f0.mad(b4, uc);
+    f0.mad(beta(5), wr); f0.mad(beta(6), use2); f0.mad(beta(7), rd);
+    f1.mad(beta(8), rs1); f1.mad(beta(9), rs2); f1.mad(beta(10), col(C_IMM_LO)); f1.mad(beta(11), col(C_IMM_HI));
+    f1.mad(beta(12), col(C_TGT_LO)); f1.mad(beta(13), col(C_TGT_HI));
+    visit(0, -one, f0.plus(f1.plus(busc(BUS_PROG))), -one, mem(rs1, b_lo, b_hi, pts(0)));
   }
   if (J0 <= 1 && 1 < J1) visit(1, one, mem(rs1, b_lo, b_hi, ts), -m2, mem(ad2, c_lo, c_hi, pts(1)));
   if (J0 <= 2 && 2 < J1) visit(2, m2, mem(ad2, c_lo, c_hi, ts + one), -m3, mem(ad3, col(C_W_PLO), col(C_W_PHI), pts(2)));
   // the low limbs of the three access-time differences (range16), their high bytes
-  if (J0 <= 3 && 3 < J1) visit(3, m3, mem(ad3, a_lo, a_hi, ts + one.dbl()), -one, grng + b2 * g[0]);
-  if (J0 <= 4 && 4 < J1) visit(4, -one, grng + b2 * g[2], -one, grng + b2 * g[4]);
-  if (J0 <= 5 && 5 < J1) visit(5, -one, gbyt + b1 * g[1] + b2 * g[3], -one, gbyt + b1 * g[5]);
+  if (J0 <= 3 && 3 < J1) visit(3, m3, mem(ad3, a_lo, a_hi, ts + one.dbl()), -one, pair(grng, Fp::zero(), g[0]));
+  if (J0 <= 4 && 4 < J1) visit(4, -one, pair(grng, Fp::zero(), g[2]), -one, pair(grng, Fp::zero(), g[4]));
+  if (J0 <= 5 && 5 < J1) visit(5, -one, pair(gbyt, g[1], g[3]), -one, pair(gbyt, g[5], Fp::zero()));
   // the adder output: high limb (kind 2 where it is an address), low limb less the byte offset (kind 1 where aligned)
-  if (J0 <= 6 && 6 < J1) visit(6, -chk, grng + b1 * top.dbl() + b2 * x_hi, -chk, grng + b1 * al + b2 * (x_lo - off));
+  if (J0 <= 6 && 6 < J1) visit(6, -chk, pair(grng, top.dbl(), x_hi), -chk, pair(grng, al, x_lo - off));
   if (J0 <= 7 && 7 < J1) {
-    // one instruction class each: ALU-chip sends, sub-word loads and stores, the keccak call, the ecall hand-over
-    const Fp4 b5 = m_load_fp4(bpow + 20), b6 = m_load_fp4(bpow + 24), b7 = m_load_fp4(bpow + 28);
-    Fp4 f = (busc(BUS_ALU) + b1 * code + b2 * a_lo + b3 * a_hi + b4 * b_lo + b5 * b_hi + b6 * c_lo + b7 * c_hi) * alu;
-    // (op, offset, A, the memory word before, the stored register's low limb): a load has the word in C, a store in W_P
-    const Fp lds = sel[CL_LDS], sts = sel[CL_STS], sub = lds + sts;
+    // one instruction class each: ALU-chip sends, sub-word loads and stores, the keccak call, the ecall hand-over.
+    // F = sum_k m_k f_k + 1 - M with f_k = gamma + bus_k + sum_j beta^(j+1) t_kj: the tuples are blended in the base
+    // field first (T_j = sum_k m_k t_kj, the m_k boolean and exclusive), then ONE fingerprint is accumulated.
+    //   ALU   (op, a_lo, a_hi, b_lo, b_hi, c_lo, c_hi)
+    //   SUB   (op, offset, a_lo, a_hi, w_lo, w_hi, c_lo of a store): a load has the word in C, a store in W_P
+    //   KCALL (ts, c_lo, c_hi)      ECALL (ts, pc, next pc, b_lo, a_lo, a_hi)
+    const Fp lds = sel[CL_LDS], sts = sel[CL_STS], sub = lds + sts, kec = sel[CL_KECCAK], ecl = sel[CL_ECALL];
     const Fp w_lo = lds * c_lo + sts * col(C_W_PLO), w_hi = lds * c_hi + sts * col(C_W_PHI);
-    f += (busc(BUS_SUB) + b1 * code + b2 * off + b3 * a_lo + b4 * a_hi) * sub + b5 * w_lo + b6 * w_hi + b7 * (sts * c_lo);
-    const Fp kec = sel[CL_KECCAK], ecl = sel[CL_ECALL];
-    f += (busc(BUS_KCALL) + b1 * ts + b2 * c_lo + b3 * c_hi) * kec;
-    f += (busc(BUS_ECALL) + b1 * ts + b2 * col(C_PC) + b3 * col(C_NEXT_PC) + b4 * b_lo + b5 * a_lo + b6 * a_hi) * ecl;
     const Fp msum = alu + sub + kec + ecl;
-    f.c[0] += one - msum;
-    visit(7, msum, f, Fp::zero(), Fp4::one());
+    Acc f;
+    f.mad(b1, (alu + sub) * code + (kec + ecl) * ts);
+    f.mad(b2, alu * a_lo + sub * off + kec * c_lo + ecl * col(C_PC));
+    f.mad(b3, (alu * a_hi + sub * a_lo) + (kec * c_hi + ecl * col(C_NEXT_PC)));
+    f.mad(b4, (alu + ecl) * b_lo + sub * a_hi);
+    f.mad(beta(5), alu * b_hi + w_lo + ecl * a_lo);
+    f.mad(beta(6), alu * c_lo + w_hi + ecl * a_hi);
+    f.mad(beta(7), (alu * c_hi) + (sts * c_lo));
+    // sum_k m_k (gamma + bus_k) + 1 - M
+    Fp4 g0 = gamma * msum;
+    g0.c[0] += alu * Fp::raw(cmonty((uint32_t)BUS_ALU)) + sub * Fp::raw(cmonty((uint32_t)BUS_SUB)) +
+               kec * Fp::raw(cmonty((uint32_t)BUS_KCALL)) + ecl * Fp::raw(cmonty((uint32_t)BUS_ECALL)) + one - msum;
+    visit(7, msum, f.plus(g0), Fp::zero(), Fp4::one());
   }
 }
 
