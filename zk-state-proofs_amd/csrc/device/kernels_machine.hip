@@ -1366,7 +1366,7 @@ __global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
 // a.partial ([B][2H] Fp4): task 0 writes it, the others add, the last one divides by the vanishing polynomial.
 constexpr int kCpuQuotSplit = kCpuSlots;  // slots [0, split) in task 1, [split, 8) in task 2 (none: task 1 is the last)
 template <int TASK>
-__global__ __launch_bounds__(kMT) void cpu_quotient_task_kernel(MQuotArgs a) {
+__global__ __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(4))) void cpu_quotient_task_kernel(MQuotArgs a) {
   const size_t h = (size_t)1 << a.logh, n = 2 * h;
   const size_t pt = (size_t)blockIdx.x * kMT + threadIdx.x;
   if (pt >= n) return;
