@@ -667,19 +667,19 @@ static void launch_lde_tall(hipStream_t stream, const uint32_t* in, uint32_t* co
   if (slab_mb) slab = std::min<size_t>(slab, std::max<size_t>(8, ((slab_mb << 20) / (16 * h)) & ~(size_t)7));
   for (size_t c0 = 0; c0 < ncols; c0 += slab) {
     const size_t nc = ncols - c0 < slab ? ncols - c0 : slab;
-    launch_ntt_top<true>(stream, r_hi, logh, in + c0 * h, h, scratch + c0 * 2 * h, 2 * h, tw_inv, logh, nc);
+    if (r_hi) launch_ntt_top<true>(stream, r_hi, logh, in + c0 * h, h, scratch + c0 * 2 * h, 2 * h, tw_inv, logh, nc);
     if (r_lo) launch_ntt_top<true>(stream, r_lo, logh - r_hi, scratch + c0 * 2 * h, 2 * h, scratch + c0 * 2 * h, 2 * h, tw_inv, logh, nc);
-    if (fixed)
+    if (fixed)  // (a 2^13 column is one chunk: no top passes, the chunk kernel reads the input itself)
       hipLaunchKernelGGL(lde_chunk_fixed_kernel<13>, dim3((unsigned)(h >> l2), (unsigned)nc), dim3(kLdeThreads), smem, stream,
-                         scratch + c0 * 2 * h, 2 * h, coefs_br ? coefs_br + c0 * h : nullptr, out + c0 * 2 * h, tw_fwd, tw_inv, in_scale_br,
-                         scale_sel_shift, scale_sel_mask, out_scale_br, logh);
+                         l1 ? scratch + c0 * 2 * h : in + c0 * h, l1 ? 2 * h : h, coefs_br ? coefs_br + c0 * h : nullptr, out + c0 * 2 * h,
+                         tw_fwd, tw_inv, in_scale_br, scale_sel_shift, scale_sel_mask, out_scale_br, logh);
     else
       hipLaunchKernelGGL(lde_chunk_kernel, dim3((unsigned)(h >> l2), (unsigned)nc), dim3(kLdeThreads), smem, stream,
                          scratch + c0 * 2 * h, 2 * h, coefs_br + c0 * h, out + c0 * 2 * h, tw_fwd, tw_inv, in_scale_br,
                          scale_sel_shift, scale_sel_mask, out_scale_br, logh, l2);
     // forward top stages in place, both cosets: (column, coset) pairs are h words apart
     if (r_lo) launch_ntt_top<false>(stream, r_lo, l2 + 1, out + c0 * 2 * h, h, out + c0 * 2 * h, h, tw_fwd, logh, 2 * nc);
-    launch_ntt_top<false>(stream, r_hi, l2 + 1 + r_lo, out + c0 * 2 * h, h, out + c0 * 2 * h, h, tw_fwd, logh, 2 * nc);
+    if (r_hi) launch_ntt_top<false>(stream, r_hi, l2 + 1 + r_lo, out + c0 * 2 * h, h, out + c0 * 2 * h, h, tw_fwd, logh, 2 * nc);
   }
 }
 
@@ -718,7 +718,8 @@ void launch_lde(hipStream_t stream, const uint32_t* in, uint32_t* coefs_br, uint
                 const uint32_t* tw_inv, const uint32_t* in_scale_br, int scale_sel_shift, int scale_sel_mask,
                 const uint32_t* out_scale_br, int logh, size_t ncols) {
   if (ncols == 0) return;
-  if (logh > 14) {
+  static const bool mid_generic = getenv("ZKSP_LDE_MID_GENERIC") != nullptr;  // debugging switch: 2^13, 2^14 through lde_lds_kernel
+  if (logh > 14 || (logh >= 13 && !coefs_br && !mid_generic)) {
     static const bool old_tall = getenv("ZKSP_LDE_OLD_TALL") != nullptr;  // debugging switch: the strided/chunk form
     if (logh <= 21 && (!coefs_br || !old_tall))
       launch_lde_tall(stream, in, coefs_br, out, tw_fwd, tw_inv, in_scale_br, scale_sel_shift, scale_sel_mask, out_scale_br, logh,
