@@ -109,6 +109,11 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   for (size_t i = 0; i < n; ++i) { out[i] = nullptr; status[i] = ZKSP_ERR_INVALID_ARG; }
   if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess)
     return ctx->fail(ZKSP_ERR_HIP, "prove: could not create the copy stream");
+  for (int k = 0; k < 2; ++k)
+    if ((!ctx->ev_proved[k] && hipEventCreateWithFlags(&ctx->ev_proved[k], hipEventDisableTiming) != hipSuccess) ||
+        (!ctx->ev_copied[k] && hipEventCreateWithFlags(&ctx->ev_copied[k], hipEventDisableTiming) != hipSuccess))
+      return ctx->fail(ZKSP_ERR_HIP, "prove: could not create the copy events");
+  ctx->body_free = nullptr;
   std::vector<std::unique_ptr<zksp_mtrace>> traces(n);
   const BatchTrace mark;
   auto trace_one = [&](size_t i) {
@@ -127,9 +132,9 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       traces[i]->t.rec.error = "out of memory while tracing the guest";
     }
   };
-  // The first max_batch inputs are traced before anything else so that the GPU starts early; the rest are traced
-  // by host threads while it proves them.
-  const size_t w0 = std::min<size_t>(n, std::max<size_t>(1, std::min<size_t>(ctx->params.max_batch, std::max<size_t>(16, (n + 3) / 4))));
+  // A first wave (an eighth of the call, at most max_batch) is traced before anything else so that the GPU starts early;
+  // the rest are traced by host threads while it proves them.
+  const size_t w0 = std::min<size_t>(n, std::max<size_t>(1, std::min<size_t>(ctx->params.max_batch, std::max<size_t>(16, (n + 7) / 8))));
   parallel_for(w0, 64, trace_one);
   mark.mark("traced", w0);
   std::string first_err;
@@ -169,7 +174,10 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       lh[mach::kSub] = clog2(t.sub_idx.size()); lh[mach::kSub2] = 0;
       lh[mach::kBw] = clog2(t.bw_idx.size()); lh[mach::kBw2] = 0;
       lh[mach::kP2] = clog2(t.agg_rows + 1);
-      lh[mach::kEcall] = clog2(t.ecall_idx.size());
+      // (the small chips do not split a group: a run with 513 multiplications shares the shape of one with 511, the
+      // cover gives both the taller multiplier chip)
+      lh[mach::kEcall] = 0;
+      lh[mach::kMul] = 0;
       groups[lh].push_back(i);
       covers[lh].cover(t);
     }
@@ -193,11 +201,14 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       // of another and the wrapping of a third overlap (256 runs with max_batch 128 go as four chunks of 64)
       const size_t pipe = std::max<size_t>(16, (n + 3) / 4);
       const size_t cap = std::max<size_t>(1, std::min({(size_t)ctx->params.max_batch, budget / std::max<size_t>(per_proof, 1), pipe}));
-      for (size_t off = 0; off < kv.second.size(); off += cap) {
+      // chunks of equal size (576 runs under a cap of 174 go as 4 x 144, not 3 x 174 + 54: a small last chunk proves at a
+      // poor rate)
+      const size_t m = kv.second.size(), nck = (m + cap - 1) / cap, per = (m + nck - 1) / nck;
+      for (size_t off = 0; off < m; off += per) {
         Chunk ck;
         ck.lh = kv.first;
-        ck.group_size = std::min(cap, kv.second.size());
-        ck.idx.assign(kv.second.begin() + off, kv.second.begin() + std::min(off + cap, kv.second.size()));
+        ck.group_size = std::min(per, m);
+        ck.idx.assign(kv.second.begin() + off, kv.second.begin() + std::min(off + per, m));
         chunks.push_back(std::move(ck));
       }
     }
@@ -302,27 +313,46 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     const bool piggyback = more && chunks[k + 1].lh == ck.lh && ctx->mws && (size_t)ctx->mws->batch >= chunks[k + 1].idx.size();
     int rc_next = ZKSP_OK;
     if (piggyback) rc_next = load_chunk(chunks[k + 1], true);
+    // The bodies of this pass go to pinned host memory on the copy stream, behind the pass; the NEXT pass is enqueued at
+    // once and waits for the copy only before its assemble kernel (Context::body_free), so the GPU does not idle while
+    // half a gigabyte of proof bodies crosses PCIe.
     const size_t cnt = ck.idx.size(), bw = ctx->mws->body_words;
-    std::vector<uint32_t> bodies(cnt * bw);
-    if (hipMemcpyAsync(bodies.data(), ctx->mws->body, bodies.size() * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    const int slot = (int)(k & 1);
+    bool copy_ok = true;
+    if (ctx->h_stage2_words[slot] < cnt * bw) {
+      if (ctx->h_stage2[slot]) (void)hipHostFree(ctx->h_stage2[slot]);
+      ctx->h_stage2[slot] = nullptr;
+      ctx->h_stage2_words[slot] = 0;
+      if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage2[slot]), cnt * bw * 4, hipHostMallocDefault) == hipSuccess)
+        ctx->h_stage2_words[slot] = cnt * bw;
+      else
+        copy_ok = false;
+    }
+    copy_ok = copy_ok && hipEventRecord(ctx->ev_proved[slot], ctx->stream) == hipSuccess &&
+              hipStreamWaitEvent(ctx->copy_stream, ctx->ev_proved[slot], 0) == hipSuccess &&
+              hipMemcpyAsync(ctx->h_stage2[slot], ctx->mws->body, cnt * bw * 4, hipMemcpyDeviceToHost, ctx->copy_stream) == hipSuccess &&
+              hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream) == hipSuccess;
+    if (copy_ok) ctx->body_free = ctx->ev_copied[slot];
+    if (copy_ok && piggyback) {  // the GPU goes on with the next chunk while this one is fetched and wrapped
+      if (rc_next == ZKSP_OK) rc_next = machine_activate_spare(ctx);
+      if (rc_next == ZKSP_OK) rc_next = machine_prove_resident(ctx);
+      if (rc_next == ZKSP_OK) in_flight = true;
+    }
+    if (!copy_ok || hipEventSynchronize(ctx->ev_copied[slot]) != hipSuccess) {
       // the device is gone: nothing after this chunk can be proven either (the next chunk's traces may already
       // have been released to the spare upload)
+      ctx->body_free = nullptr;
       const int rc = ctx->fail(ZKSP_ERR_HIP, "prove: device-to-host copy failed");
       (void)have_chunk(chunks.size());  // group whatever was traced later, so that it gets a status too
       for (size_t j = k; j < chunks.size(); ++j) fail_chunk(chunks[j], rc);
       break;
     }
     mark.mark("proved and fetched", cnt);
-    if (piggyback) {  // the GPU goes on with the next chunk while this one is wrapped
-      if (rc_next == ZKSP_OK) rc_next = machine_activate_spare(ctx);
-      if (rc_next == ZKSP_OK) rc_next = machine_prove_resident(ctx);
-      if (rc_next == ZKSP_OK) in_flight = true;
-    }
+    const uint32_t* bodies = ctx->h_stage2[slot];
     for (size_t j = 0; j < cnt; ++j) {
       const size_t i = ck.idx[j];
       status[i] = machine_proof_from_parts(pk, traces[i]->t.rec, ck.lh.data(), traces[i]->handover_pc, traces[i]->t.agg_leaves, traces[i]->t.agg_keys,
-                                           bodies.data() + j * bw, bw, &out[i]);
+                                           bodies + j * bw, bw, &out[i]);
     }
     mark.mark("wrapped", cnt);
     if (piggyback && rc_next != ZKSP_OK) {
@@ -331,6 +361,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     }
   }
   if (!first_err.empty() && rc_all == ZKSP_OK) ctx->error = first_err;
+  ctx->body_free = nullptr;  // every copy has completed: later passes on this client need no wait
   mark.mark("done", n);
   for (auto& t : reaper.th)
     if (t.joinable()) t.join();
