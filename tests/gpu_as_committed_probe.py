@@ -1,4 +1,4 @@
-"""Probe (not a test): the as-committed acct-d8 machine proof (CPU instances 2^20 + 2^19) on the device against the
+"""Probe (not a test): the as-committed acct-d8 machine proof (six CPU instances of 2^18 rows) on the device against the
 oracle's bytes; prints the first differing body word and the section it lies in."""
 import importlib, os, sys, time
 import numpy as np
