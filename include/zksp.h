@@ -50,7 +50,8 @@ typedef struct {
   int32_t keccak_mode;    /* ZKSP_KECCAK_*; 0 = default (REPLACE) */
   uint32_t num_queries;   /* FRI queries; 0 = default 100 */
   uint32_t pow_bits;      /* proof-of-work bits; 0xffffffff = default 16 */
-  uint32_t max_batch;     /* proofs proven in lockstep per launch group; 0 = default 16 */
+  uint32_t max_batch;     /* most proofs proven in lockstep per launch group; 0 = default 192 (a chunk is also
+                             capped by the free HBM and by a quarter of the call) */
   int32_t proof_mode;     /* ZKSP_PROOF_*; 0 = default (MACHINE) */
 } zksp_options;
 /* What zksp_prove / zksp_prove_batch establish:

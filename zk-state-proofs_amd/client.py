@@ -399,7 +399,7 @@ class ProverClient:
     """
 
     def __init__(self, device: Optional[int] = None, *, keccak_mode: int = KECCAK_REPLACE, num_queries: int = 100,
-                 pow_bits: int = 16, max_batch: int = 16, proof_mode: int = PROOF_MACHINE):
+                 pow_bits: int = 16, max_batch: int = 192, proof_mode: int = PROOF_MACHINE):
         self._lib = load_library()
         if device is None:
             device = int(os.environ.get("ZKSP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
