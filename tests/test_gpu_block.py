@@ -26,7 +26,7 @@ def test_block_receipt_trie_batch(zk, oracle):
         assert p.public_values == receipts[i]
         client.verify(p, vk)
         heights.add(p.to_bytes()[8:8 + 4 * zk.MACHINE_CHIPS])  # the chip heights of the machine proof's header
-    assert len(heights) >= 2  # long receipts need more keccak-f permutations: several height groups in one call
+    assert len(heights) >= 1  # (a group of fewer than sixteen runs joins its neighbour: 48 receipts may share one shape)
 
 
 def test_storage_proof_composition(zk, oracle):
@@ -63,6 +63,8 @@ def test_full_block_receipt_trie(zk, oracle):
         assert p.public_values == receipts[i]
     for i in range(0, len(proofs), 7):  # the host verifier on a spread of them (each is ~1.5 MB of checks)
         client.verify(proofs[i], vk)
+    # long receipts need more keccak-f permutations, more cycles, more memory: several height groups in one call
+    assert len({p.to_bytes()[8:8 + 4 * zk.MACHINE_CHIPS] for p in proofs}) >= 2
 
 
 def test_batch_of_256_storage_slots(zk, oracle):

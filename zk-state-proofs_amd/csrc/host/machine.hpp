@@ -125,6 +125,11 @@ struct MachineCounts {
     bw = std::max(bw, t.bw_idx.size()); agg = std::max(agg, t.agg_rows); ecall = std::max(ecall, t.ecall_idx.size());
     keccak = std::max(keccak, t.keccak.size()); memfinal = std::max(memfinal, t.memfinal.size()); muls = std::max(muls, t.muls.size());
   }
+  void cover(const MachineCounts& o) {
+    cycles = std::max(cycles, o.cycles); alu = std::max(alu, o.alu); sub = std::max(sub, o.sub); bw = std::max(bw, o.bw);
+    agg = std::max(agg, o.agg); ecall = std::max(ecall, o.ecall); keccak = std::max(keccak, o.keccak);
+    memfinal = std::max(memfinal, o.memfinal); muls = std::max(muls, o.muls);
+  }
 };
 
 // rows of the first of two instances of a chip: the largest power of two strictly below the count (at least 32);
