@@ -229,9 +229,10 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
         const mach::ChipDef& d = mach::chip_def(ch);
         per_proof += ((size_t)(d.main_w + d.perm_width() + 8) * 16 + 64) << kv.first[ch];
       }
-      // trees, digests of injected groups, FRI layers and scratch come to about a third more; the budget is what the
-      // device has free right now plus what this client's arena already holds, less a fifth for everybody else
-      per_proof += per_proof / 2;
+      // 16 bytes per cell already cover trees, FRI layers and scratch (measured: an acct-d8 proof takes 702 MiB of arena where
+      // this sum says 900); a seventh more for safety.  The budget is what the device has free right now plus what this
+      // client's arena already holds, less a fifth for everybody else
+      per_proof += per_proof / 7;
       size_t mem_free = 0, mem_total = 0;
       if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = (size_t)64 << 30;
       const size_t budget = (mem_free + ctx->arena_bytes) / 5 * 4;
@@ -283,6 +284,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     if (!into_spare) ctx->batch_hint = (int)ck.group_size;
     const int rc = machine_load(ctx, pk->mprog, pk->mvk, ts.data(), ts.size(), into_spare, ck.lh.data());
     mark.mark(into_spare ? "next loaded" : "loaded", ts.size());
+    if (!into_spare && ctx->mws) mark.mark("arena MiB per proof of the workspace", (size_t)(ctx->arena_bytes >> 20) / (size_t)std::max(1, ctx->mws->batch));
     if (rc == ZKSP_OK) release_chunk(ck);
     return rc;
   };
@@ -387,11 +389,13 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     }
     mark.mark("proved and fetched", cnt);
     const uint32_t* bodies = ctx->h_stage2[slot];
-    for (size_t j = 0; j < cnt; ++j) {
+    // (a proof object is 2.6 MB of copying and header work: on one thread the wrapping of a chunk, with the upload of
+    // the next, takes as long as the GPU needs for a pass; the tracing threads are idle or few by now)
+    parallel_for(cnt, 8, [&](size_t j) {
       const size_t i = ck.idx[j];
       status[i] = machine_proof_from_parts(pk, traces[i]->t.rec, ck.lh.data(), traces[i]->handover_pc, traces[i]->t.agg_leaves, traces[i]->t.agg_keys,
                                            bodies + j * bw, bw, &out[i]);
-    }
+    });
     mark.mark("wrapped", cnt);
     if (piggyback && rc_next != ZKSP_OK) {
       fail_chunk(chunks[k + 1], rc_next);
