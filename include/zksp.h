@@ -51,7 +51,7 @@ typedef struct {
   uint32_t num_queries;   /* FRI queries; 0 = default 100 */
   uint32_t pow_bits;      /* proof-of-work bits; 0xffffffff = default 16 */
   uint32_t max_batch;     /* most proofs proven in lockstep per launch group; 0 = default 192 (a chunk is also
-                             capped by the free HBM and by a quarter of the call) */
+                             capped by the free HBM and by half of the call) */
   int32_t proof_mode;     /* ZKSP_PROOF_*; 0 = default (MACHINE) */
 } zksp_options;
 /* What zksp_prove / zksp_prove_batch establish:

@@ -236,9 +236,10 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       size_t mem_free = 0, mem_total = 0;
       if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = (size_t)64 << 30;
       const size_t budget = (mem_free + ctx->arena_bytes) / 5 * 4;
-      // ... and at least four chunks per call where the call is large enough, so that the upload of one chunk, the proving
-      // of another and the wrapping of a third overlap (256 runs with max_batch 128 go as four chunks of 64)
-      const size_t pipe = std::max<size_t>(16, (n + 3) / 4);
+      // ... and at least two chunks behind the first wave where the call is large enough, so that the upload of one chunk
+      // overlaps the proving of another (the bodies are fetched behind the next pass and wrapped on several threads, so
+      // more, smaller chunks only lower the rate of a pass)
+      const size_t pipe = std::max<size_t>(16, (n + 1) / 2);
       const size_t cap = std::max<size_t>(1, std::min({(size_t)ctx->params.max_batch, budget / std::max<size_t>(per_proof, 1), pipe}));
       // chunks of equal size (576 runs under a cap of 174 go as 4 x 144, not 3 x 174 + 54: a small last chunk proves at a
       // poor rate)

@@ -46,7 +46,7 @@ struct DeviceDomain {
 struct Params {
   uint32_t num_queries = 100;
   uint32_t pow_bits = 16;
-  uint32_t max_batch = 192;  // an upper bound: a chunk is also capped by the free HBM and by a quarter of the call
+  uint32_t max_batch = 192;  // an upper bound: a chunk is also capped by the free HBM and by half of the call
   int keccak_mode = 2;
   int proof_mode = 1;  // ZKSP_PROOF_MACHINE
 };
