@@ -1,8 +1,7 @@
 """Probe (not a test): one prove_batch call over the 300 receipts of a block-shaped trie (BASELINE config 4): rate, and the
 chip heights the proofs were made with (how many shapes the grouping left).  ZKSP_TRACE_BATCH=1 adds the timeline."""
 import importlib, os, sys, time
-sys.path.insert(0, "/root/repo" if os.path.isdir("/root/repo") else os.getcwd())
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 zk = importlib.import_module("zk-state-proofs_amd")
 mpt = importlib.import_module("zk-state-proofs_amd.mpt")
 client = zk.ProverClient(device=0, max_batch=192)
