@@ -1111,26 +1111,42 @@ __global__ __launch_bounds__(kMT) void perm_slice_scan_kernel(PermArgs a, const 
   }
   const Fp4 total = part[0], step = total * Fp::raw(a.h_inv);
   __syncthreads();
-  constexpr int chunk = kScanSlice / kMT;
-  const size_t r0 = (size_t)g * kScanSlice + (size_t)tid * chunk;
+  // phi[r] = sum over r' < r of (rowsum[r'] - step).  The slice is walked in rounds of kMT consecutive rows, lane = row,
+  // so that the row sums are read and the four phi columns written as consecutive words (a lane that owns sixteen
+  // consecutive rows writes single words 64 bytes apart); inside a round: an inclusive scan per wave with lane shuffles,
+  // the waves' totals through LDS.
+  __shared__ Fp4 wtot[kMT / 64];
+  const int lane = tid & 63, wave = tid >> 6;
+  const size_t r_base = (size_t)g * kScanSlice;
   const uint32_t* tm = a.rowsum + (size_t)b * h * 4;
-  Fp4 local = Fp4::zero();
-  for (int r = 0; r < chunk; ++r) local += m_load_fp4(tm + (r0 + r) * 4);
-  part[tid] = local;
-  __syncthreads();
-  for (int off = 1; off < kMT; off <<= 1) {
-    Fp4 v = part[tid];
-    if (tid >= off) v += part[tid - off];
-    __syncthreads();
-    part[tid] = v;
-    __syncthreads();
-  }
-  Fp4 acc = offset + (tid ? part[tid - 1] : Fp4::zero()) - step * Fp::from_canonical((uint32_t)r0);
   uint32_t* ph = a.perm + (size_t)b * a.perm_bstride + (size_t)(a.perm_width - 4) * h;
-  for (int r = 0; r < chunk; ++r) {
+  Fp4 carry = offset - step * Fp::from_canonical((uint32_t)r_base) - step * Fp::from_canonical((uint32_t)tid);
+  const Fp4 round_step = step * Fp::from_canonical((uint32_t)kMT);
+  for (int i = 0; i < kScanSlice / kMT; ++i) {
+    const size_t r = r_base + (size_t)i * kMT + tid;
+    const Fp4 v = m_load_fp4(tm + r * 4);
+    Fp4 incl = v;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ph[(size_t)j * h + r0 + r] = acc.c[j].v;
-    acc += m_load_fp4(tm + (r0 + r) * 4) - step;
+    for (int off = 1; off < 64; off <<= 1) {
+      Fp4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o.c[j] = Fp::raw((uint32_t)__shfl_up((int)incl.c[j].v, off, 64));
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    Fp4 before = Fp4::zero(), blk = Fp4::zero();
+#pragma unroll
+    for (int w = 0; w < kMT / 64; ++w) {
+      const Fp4 t = wtot[w];
+      if (w < wave) before += t;
+      blk += t;
+    }
+    __syncthreads();
+    const Fp4 phi = carry + before + (incl - v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ph[(size_t)j * h + r] = phi.c[j].v;
+    carry += blk - round_step;
   }
   if (g == 0 && tid == 0) m_store_fp4(a.cum + (size_t)b * a.cum_bstride, total);
 }
