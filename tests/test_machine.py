@@ -142,3 +142,26 @@ def test_unsupported_instruction_is_reported(zk, fx, built_lib):
     s = zk.SP1Stdin(); s.write(m.to_borsh())
     t = client.machine_trace(pk, s)  # the guest panics through HALT(1): a complete trace with exit code 1
     assert t["info"].exit_code == 1
+
+
+@pytest.mark.parametrize("mode,name", [(2, "acct8"), (1, "acct8"), (2, "tx"), (2, "slot")])
+def test_chip_heights_rule_agrees_with_the_oracle(zk, fx, built_lib, oracle, mode, name):
+    """The chip heights a run is proven with are the product's choice (machine_heights) and the oracle's
+    (orc_machine_heights) independently; format v13 spreads the cycles over CPU instances of one height."""
+    client = zk.ProverClient(device=-1, keccak_mode=mode)
+    pk, _ = client.setup(zk.merkle_elf())
+    m = fx.acct_fixture(8) if name == "acct8" else fx.tx_fixture() if name == "tx" else fx.slot_fixture(3)
+    s = zk.SP1Stdin()
+    s.write(m.to_borsh())
+    handle = client.machine_trace_handle(pk, s)
+    s2 = zk.SP1Stdin()
+    s2.write(m.to_borsh())
+    t = client.machine_trace(pk, s2)
+    heights = handle.heights()
+    assert heights == oracle.machine_heights(t)
+    cpu = [heights[zk.MACHINE_CHIP_NAMES.index(n)] for n in ("cpu", "cpu2", "cpu3", "cpu4", "cpu5", "cpu6", "cpu7", "cpu8")]
+    n = len(t["cycles"])
+    used = -(-n // (1 << cpu[0]))
+    assert 1 <= used <= 8 and cpu == [cpu[0]] * used + [5] * (8 - used)
+    assert (used << cpu[0]) >= n and (cpu[0] == 5 or 8 << (cpu[0] - 1) < n)  # the smallest common height that fits
+    assert zk.machine_cover_heights([handle]) == heights
