@@ -50,13 +50,14 @@ typedef struct {
   int32_t keccak_mode;    /* ZKSP_KECCAK_*; 0 = default (REPLACE) */
   uint32_t num_queries;   /* FRI queries; 0 = default 100 */
   uint32_t pow_bits;      /* proof-of-work bits; 0xffffffff = default 16 */
-  uint32_t max_batch;     /* most proofs proven in lockstep per launch group; 0 = default 192 (a chunk is also
-                             capped by the free HBM and by half of the call) */
+  uint32_t max_batch;     /* most proofs proven in lockstep per launch group; 0 = default 192 (a chunk is also capped by
+                             four fifths of the free HBM; a call starts with a first wave of an eighth of its runs and is cut
+                             into at least two chunks behind it) */
   int32_t proof_mode;     /* ZKSP_PROOF_*; 0 = default (MACHINE) */
 } zksp_options;
 /* What zksp_prove / zksp_prove_batch establish:
- * MACHINE      the guest's whole execution (CPU, memory, program, keccak, multiplier chips joined by
- *              LogUp buses; proof format v12): the statement of the reference's client.prove().
+ * MACHINE      the guest's whole execution (CPU instances, memory, program, ALU, keccak, multiplier ... chips joined by
+ *              LogUp buses; proof format v14): the statement of the reference's client.prove().
  * KECCAK_CHIP  only "these keccak-f outputs belong to these inputs" (round-1 format v2, a component
  *              benchmark; NOT a proof that the guest ran). */
 #define ZKSP_PROOF_MACHINE 1
@@ -90,6 +91,19 @@ void zksp_stdin_free(zksp_stdin* s);
  * proof farm all-gathers them.  n: a power of two >= 2 (0 clears the payload).  The leaves are not part of the proof: the
  * verifier names them (zksp_verify_aggregate) and the proof carries their root (zksp_proof_aggregation). */
 int zksp_stdin_set_aggregation(zksp_stdin* s, const uint32_t* leaves /* [n][8] */, size_t n);
+
+/* Leaf-proof check (stage 2a: a verifier-in-circuit for the query phase; the reference's
+ * circuits/sp1-merkle-proof-recursive/src/main.rs:3-5 is a todo!(), its in-circuit verifier would be sp1-recursion-*,
+ * Cargo.lock:7315-7417).  Besides the guest's run, the proof made from this stdin establishes that the QUERY PHASE of
+ * `leaf` verifies: for every FRI query, every opened row of the four commitment rounds hashes (Poseidon2 sponge) and
+ * climbs its mixed-height Merkle path - injections included - to that round's root at the query's position; every FRI
+ * layer's sibling pair hashes and climbs to that layer's root; and the folding chain from the tallest reduced opening
+ * through every layer (shorter reduced openings joining at their heights) ends in the final constant.  Roots, query
+ * positions, folding challenges, domain points, reduced openings and the final constant are PUBLIC (the verifier's, this
+ * round: the transcript, the reduced openings and the constraint identity at zeta are not yet in-circuit); the opened
+ * rows, the siblings and the pairs are the prover's witnesses.  The call verifies `leaf` on the host first and fails
+ * (ZKSP_ERR_VERIFY) if it does not verify: an honest prover has nothing to prove about a bad leaf.  leaf NULL clears. */
+int zksp_stdin_set_verified_leaf(zksp_client* c, zksp_stdin* s, const zksp_proof* leaf, const zksp_vk* leaf_vk);
 
 /* replaces client.prove(&pk, stdin).run()  (main.rs:71-74).  `stdin` is consumed
  * (emptied) as in the reference; pk is borrowed.  A guest panic (reference:
@@ -150,6 +164,9 @@ typedef struct zksp_mtrace zksp_mtrace;
 #define ZKSP_MT_SUB_IDX 9       /* u32 per sub-word-chip row: index of the cycle (lb lh lbu lhu sb sh) */
 #define ZKSP_MT_BW_IDX 10       /* u32 per bitwise-chip row: index of the cycle (xor or and) */
 #define ZKSP_MT_ECALL_IDX 11    /* u32 per ecall-chip row: index of the ecall cycle */
+#define ZKSP_MT_LEAF_P2_ROWS 12   /* leaf-proof check: 20 u32 per Poseidon2-chip row (flags, tag, key, mask, 16 input words) */
+#define ZKSP_MT_LEAF_FOLD_ROWS 13 /* leaf-proof check: 20 u32 per fold-chip row (flags, query, layer, 1/x, beta, lo, hi, ro) */
+#define ZKSP_MT_LEAF_PUB_TUPLES 14 /* leaf-proof check: 16 u32 per public bus tuple (ZKSP_PUB_TUPLE_WORDS) */
 typedef struct {
   uint64_t cycles;
   uint64_t memory_ops;
@@ -169,7 +186,7 @@ int zksp_mtrace_info(const zksp_mtrace* t, zksp_mtrace_info_t* info);
 /* Device-resident machine proving (bench.py, parity tests): upload the records of n traced runs (they are proven
  * with one shape: zksp_machine_cover_heights), enqueue one proving pass, fetch the proof bodies ([n][body_words]
  * canonical u32; body_words = zksp_machine_body_words of that shape). */
-#define ZKSP_MACHINE_CHIPS 23   /* cpu, keccak, keccak-mem, mem-final, image, program, mul, table, cpu2, alu, alu2, subword, subword2, bitwise, bitwise2, poseidon2, ecall, cpu3 .. cpu8 */
+#define ZKSP_MACHINE_CHIPS 24   /* cpu, keccak, keccak-mem, mem-final, image, program, mul, table, cpu2, alu, alu2, subword, subword2, bitwise, bitwise2, poseidon2, ecall, cpu3 .. cpu8, fri-fold */
 int zksp_mtrace_heights(const zksp_mtrace* t, int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 size_t zksp_machine_body_words(const zksp_client* c, const int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 /* The shape a batch of these runs is proven with: the chip heights that cover the largest cycle / event / address
@@ -197,6 +214,20 @@ int zksp_verify_aggregate(zksp_client* c, const zksp_proof* p, const zksp_vk* vk
 int zksp_stdin_set_aggregation_keyed(zksp_stdin* s, const uint32_t* keys /* [n] or NULL */, const uint32_t* digests /* [n][8] */, size_t n);
 int zksp_verify_aggregate_keyed(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const uint32_t* keys /* [n] or NULL */,
                                 const uint32_t* digests /* [n][8] */, size_t n);
+/* The statement of a leaf-proof check as the list of PUBLIC BUS TUPLES the proof's LogUp buses close with
+ * (ZKSP_PUB_TUPLE_WORDS canonical u32 each: bus, 1 = the verifier sends it / 0 = receives it, multiplicity, number of
+ * elements, up to 12 elements).  For a verified leaf they are, per query: four DIGEST tuples (tag, 0, position key,
+ * injection mask, root) for the commitment rounds and one per FRI layer; per layer a FRIQ tuple (query, layer, position
+ * bit, 1/x, beta); the RO tuples (query, 0 or layer + 1, reduced opening); one FIN tuple (query, last layer, final
+ * constant).  zksp_leaf_public derives them from a leaf proof (verifying it on the way; out may be NULL to size the
+ * buffer); zksp_verify_public checks a proof against a list; zksp_verify_with_leaf does both.  zksp_verify refuses a proof
+ * that carries public tuples: it cannot vouch for a statement it was not given.  The proof header holds the count and the
+ * sponge digest of the list (zksp_proof_public_tuples), which the transcript absorbs before any challenge. */
+#define ZKSP_PUB_TUPLE_WORDS 16
+int zksp_leaf_public(zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf_vk, uint32_t* out, size_t cap_words, size_t* n_tuples);
+int zksp_verify_public(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const uint32_t* tuples, size_t n_tuples);
+int zksp_verify_with_leaf(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const zksp_proof* leaf, const zksp_vk* leaf_vk);
+int zksp_proof_public_tuples(const zksp_proof* p, uint32_t* n_tuples, uint32_t* digest8);
 /* Kernel-level parity (tests): after zksp_hip_machine_prove, one intermediate matrix of resident proof `proof_index`, as
  * canonical u32, column-major [width][2^log_height]: stage 0 = a chip's main trace (trace expansion kernels; table chip:
  * the counted multiplicities), 1 = its LogUp permutation trace (helper columns + running sum), 2 = its quotient values
@@ -204,7 +235,7 @@ int zksp_verify_aggregate_keyed(zksp_client* c, const zksp_proof* p, const zksp_
  * cumulative sums (4 words each), as the device's transcript sampled / computed them. */
 int zksp_hip_machine_fetch_stage(zksp_client* c, int chip, int stage, size_t proof_index, uint32_t* out, size_t cap_words);
 int zksp_hip_machine_fetch_challenges(zksp_client* c, size_t proof_index, uint32_t* out /* [16 + 4 * ZKSP_MACHINE_CHIPS] */);
-/* Complete v12 proof object from one fetched body and the trace it belongs to.  log_heights: the shape the batch was
+/* Complete proof object (format v14) from one fetched body and the trace it belongs to.  log_heights: the shape the batch was
  * proven with (zksp_machine_cover_heights of the loaded traces), NULL = the trace's own minimal heights. */
 int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] or NULL */,
                                  const uint32_t* body, size_t body_words, zksp_proof** out);

@@ -103,7 +103,7 @@ static orc_lf lf_bits(int bits, int n) {
 
 #define CPU_INTER 19
 static orc_inter g_cpu[CPU_INTER], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7],
-    g_alu[1], g_sub[5], g_bw[5], g_p2[5], g_ecall[10];
+    g_alu[1], g_sub[5], g_bw[5], g_p2[7], g_ecall[10], g_fold[5];
 static orc_chip g_chips[N_CHIPS];
 static int g_ready = 0;
 
@@ -188,7 +188,7 @@ static void build(void) {
     orc_lf xoff = lf_col(C_X);
     lf_add(&xoff, C_O1, FP - 1); lf_add(&xoff, C_O2, FP - 2); lf_add(&xoff, C_O3, FP - 3);
     orc_lf top = lf_sum(top_c, 6);
-    for (int i = 0; i < top.n; ++i) top.coef[i] = 2; /* kind 2: the high limb of an address is at most ADDR_HI_MAX */
+    for (int i = 0; i < top.n; ++i) top.coef[i] = 2; /* kind 2: the high limb of an address is in 1 .. ADDR_HI_MAX */
     g_cpu[12] = range_inter(-1, chk, top, lf_col(C_X + 1));
     g_cpu[13] = range_inter(-1, chk, lf_sum(al_c, 5), xoff);
   }
@@ -283,9 +283,10 @@ static void build(void) {
                           lf_plus(lf_col(KM_TS), 2));
     g_kmem[4] = range_inter(-1, lf_col(KM_IS_REAL), zero, lf_col(KM_GL));
     g_kmem[5] = bytes_inter(-1, lf_col(KM_IS_REAL), lf_col(KM_GH), zero);
-    /* the state pointer is word-aligned and the 200 bytes end below 0x78000000 */
+    /* the state pointer is word-aligned, lies at 0x10000 or above (not in register space) and the 200 bytes end below
+     * 0x78000000: its high limb is looked up as kind 2 (1 .. ADDR_HI_MAX) */
     g_kmem[6] = range_inter(-1, lf_col(KM_CALL), one, lf_col(KM_PTR_LO));
-    g_kmem[7] = range_inter(-1, lf_col(KM_CALL), zero, lf_const_minus(ADDR_HI_MAX - 1, KM_PTR_HI));
+    g_kmem[7] = range_inter(-1, lf_col(KM_CALL), lf_const(2), lf_col(KM_PTR_HI));
   }
   /* ---- memory boundary ---- */
   {
@@ -372,30 +373,78 @@ static void build(void) {
       it->el[1] = lf_col(BW_B + i); it->el[2] = lf_col(BW_C + i); it->el[3] = lf_col(BW_A + i);
     }
   }
-  /* ---- Poseidon2: children in, parent out; the output digest is the external linear layer applied to the last round's
-   * S-box outputs (circ(2 M4, M4, M4, M4), M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]]) ---- */
+  /* ---- Poseidon2 (machine.h "Poseidon2 chip").  DIGEST tuples are (tag, type, key, mask, 8 words); type 2: a heap node
+   * (stage 1: children in, parent out), type 1: the hash of an injected matrix row (a sponge's last row -> the injection
+   * row with the same labels), type 0: the end of a run (-> the verifier, who knows the root).  The output words are the
+   * external linear layer applied to the last round's S-box outputs (circ(2 M4, M4, M4, M4),
+   * M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]]) ---- */
   {
     static const uint32_t m4[4][4] = {{2, 3, 1, 1}, {1, 2, 3, 1}, {1, 1, 2, 3}, {3, 1, 1, 2}};
     const int ylast = P2_EXT + 32 * 7 + 16;
+    const orc_lf tag = lf_col(P2_T), mask = lf_col(P2_M), key = lf_pair(P2_KL, P2_KH, 65536);
     for (int side = 0; side < 2; ++side) {
       orc_inter* it = &g_p2[side];
       memset(it, 0, sizeof *it);
-      it->bus = BUS_DIGEST; it->sign = -1; it->mult = lf_col(P2_IS_REAL); it->n_el = 9;
-      lf_zero(&it->el[0]); lf_add(&it->el[0], P2_KL, 2); lf_add(&it->el[0], P2_KH, 2 * 65536); it->el[0].c0 = (uint32_t)side;
-      for (int j = 0; j < 8; ++j) it->el[1 + j] = lf_col(P2_IN + 8 * side + j);
+      it->bus = BUS_DIGEST; it->sign = -1; it->mult = lf_col(P2_FN); it->n_el = 12;
+      it->el[0] = tag; it->el[1] = lf_const(2);
+      lf_zero(&it->el[2]); lf_add(&it->el[2], P2_KL, 2); lf_add(&it->el[2], P2_KH, 2 * 65536); it->el[2].c0 = (uint32_t)side;
+      it->el[3] = mask;
+      for (int j = 0; j < 8; ++j) it->el[4 + j] = lf_col(P2_IN + 8 * side + j);
     }
     orc_inter* it = &g_p2[2];
     memset(it, 0, sizeof *it);
-    it->bus = BUS_DIGEST; it->sign = +1; it->mult = lf_col(P2_IS_REAL); it->n_el = 9;
-    it->el[0] = lf_pair(P2_KL, P2_KH, 65536);
+    it->bus = BUS_DIGEST; it->sign = -1; it->mult = lf_col(P2_FJ); it->n_el = 12;
+    it->el[0] = tag; it->el[1] = lf_const(1); it->el[2] = key; it->el[3] = mask;
+    for (int j = 0; j < 8; ++j) it->el[4 + j] = lf_col(P2_IN + 8 + j);
+    it = &g_p2[3];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_DIGEST; it->sign = +1; it->mult = lf_pair(P2_FN, P2_SND, 1); it->n_el = 12;
+    it->el[0] = tag;
+    lf_zero(&it->el[1]); lf_add(&it->el[1], P2_FN, 2); lf_add(&it->el[1], P2_SZ, 1); lf_add(&it->el[1], P2_SC, 1);
+    it->el[2] = key; it->el[3] = mask;
     for (int j = 0; j < 8; ++j) {
-      lf_zero(&it->el[1 + j]);
-      for (int i = 0; i < 16; ++i) lf_add(&it->el[1 + j], ylast + i, m4[j & 3][i & 3] * ((i >> 2) == (j >> 2) ? 2u : 1u));
+      lf_zero(&it->el[4 + j]);
+      for (int i = 0; i < 16; ++i) lf_add(&it->el[4 + j], ylast + i, m4[j & 3][i & 3] * ((i >> 2) == (j >> 2) ? 2u : 1u));
     }
-    /* the key's limbs: 16 bits, and twice the high limb at most ADDR_HI_MAX (kind 2): the key stays below 0x3C000000 and
+    /* the pair a FRI leaf hashes goes to the fold chip */
+    it = &g_p2[4];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_PAIR; it->sign = +1; it->mult = lf_col(P2_FR); it->n_el = 9;
+    it->el[0] = tag;
+    for (int j = 0; j < 8; ++j) it->el[1 + j] = lf_col(P2_IN + j);
+    /* the key's limbs: 16 bits, and twice the high limb plus one in 1 .. ADDR_HI_MAX (kind 2): the key stays below 0x3C000000 and
      * its children's keys 2K, 2K + 1 below 0x78000000 < p - no key aliases another mod p */
-    g_p2[3] = range_inter(-1, lf_col(P2_IS_REAL), lf_const(0), lf_col(P2_KL));
-    { orc_lf kh2; lf_zero(&kh2); lf_add(&kh2, P2_KH, 2); g_p2[4] = range_inter(-1, lf_col(P2_IS_REAL), lf_const(2), kh2); }
+    g_p2[5] = range_inter(-1, lf_col(P2_IS_REAL), lf_const(0), lf_col(P2_KL));
+    { orc_lf kh2; lf_zero(&kh2); lf_add(&kh2, P2_KH, 2); kh2.c0 = 1; g_p2[6] = range_inter(-1, lf_col(P2_IS_REAL), lf_const(2), kh2); }
+  }
+  /* ---- FRI fold chip: the verifier's per-layer tuple, the hashed pair, the reduced openings, the end ---- */
+  {
+    const orc_lf q = lf_col(FO_Q), k = lf_col(FO_K);
+    orc_inter* it = &g_fold[0];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_FRIQ; it->sign = -1; it->mult = lf_col(FO_IS_REAL); it->n_el = 8;
+    it->el[0] = q; it->el[1] = k; it->el[2] = lf_col(FO_BIT); it->el[3] = lf_col(FO_XINV);
+    for (int j = 0; j < 4; ++j) it->el[4 + j] = lf_col(FO_BETA + j);
+    it = &g_fold[1];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_PAIR; it->sign = -1; it->mult = lf_col(FO_IS_REAL); it->n_el = 9;
+    lf_zero(&it->el[0]); lf_add(&it->el[0], FO_Q, LEAF_TAG_STRIDE); lf_add(&it->el[0], FO_K, 1); it->el[0].c0 = LEAF_TAG(0, 4);
+    for (int j = 0; j < 4; ++j) { it->el[1 + j] = lf_col(FO_LO + j); it->el[5 + j] = lf_col(FO_HI + j); }
+    it = &g_fold[2];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_RO; it->sign = -1; it->mult = lf_col(FO_FIRST); it->n_el = 6;
+    it->el[0] = q; it->el[1] = lf_const(0);
+    for (int j = 0; j < 4; ++j) it->el[2 + j] = lf_col(FO_E + j);
+    it = &g_fold[3];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_RO; it->sign = -1; it->mult = lf_col(FO_HASRO); it->n_el = 6;
+    it->el[0] = q; it->el[1] = lf_plus(k, 1);
+    for (int j = 0; j < 4; ++j) it->el[2 + j] = lf_col(FO_RO + j);
+    it = &g_fold[4];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_FIN; it->sign = +1; it->mult = lf_col(FO_LAST); it->n_el = 6;
+    it->el[0] = q; it->el[1] = k;
+    for (int j = 0; j < 4; ++j) it->el[2 + j] = lf_pair(FO_F + j, FO_RO + j, 1);
   }
   /* ---- sub-word ---- */
   {
@@ -438,7 +487,8 @@ static void build(void) {
   g_chips[CH_SUB2] = (orc_chip){"subword2", 0, SUB_WIDTH, 5, g_sub, 0, 0};
   g_chips[CH_BW] = (orc_chip){"bitwise", 0, BW_WIDTH, 5, g_bw, 0, 0};
   g_chips[CH_BW2] = (orc_chip){"bitwise2", 0, BW_WIDTH, 5, g_bw, 0, 0};
-  g_chips[CH_P2] = (orc_chip){"poseidon2", 0, P2CHIP_WIDTH, 5, g_p2, 0, 0};
+  g_chips[CH_P2] = (orc_chip){"poseidon2", 0, P2CHIP_WIDTH, 7, g_p2, 0, 0};
+  g_chips[CH_FOLD] = (orc_chip){"fri-fold", 0, FOLD_WIDTH, 5, g_fold, 0, 0};
   g_chips[CH_ECALL] = (orc_chip){"ecall", 0, ECALL_WIDTH, 10, g_ecall, 0, 0};
   g_ready = 1;
   for (int c = 0; c < N_CHIPS; ++c) g_chips[c].n_constraints = count_constraints(c);
@@ -542,8 +592,11 @@ void orc_machine_heights(const orc_machine_input* in, int logh[N_CHIPS]) {
   logh[CH_MUL] = at_least5(clog2(in->n_muls));
   logh[CH_TABLE] = TABLE_LOG_H;
   {
-    const size_t rows = orc_machine_agg_rows(in->agg_keys, in->agg_leaves, in->n_agg, NULL); /* one per ancestor of a supplied key */
-    logh[CH_P2] = at_least5(clog2(rows == (size_t)-1 || rows == 0 ? 1 : rows));
+    size_t rows = orc_machine_agg_rows(in->agg_keys, in->agg_leaves, in->n_agg, NULL); /* one per ancestor of a supplied key */
+    if (rows == (size_t)-1) rows = 0;
+    rows += in->n_leaf_p2; /* ... and one per permutation of a leaf-proof check */
+    logh[CH_P2] = at_least5(clog2(rows == 0 ? 1 : rows));
+    logh[CH_FOLD] = at_least5(clog2(in->n_leaf_fold ? in->n_leaf_fold : 1));
   }
   logh[CH_ECALL] = at_least5(clog2(orc_machine_events(in, 3, NULL)));
 }
@@ -821,7 +874,7 @@ static void fill_table_mults(const orc_machine_input* in, uint32_t* t) {
         }
         if (v[0] == 0) continue;
         if (it->bus == BUS_RANGE) {
-          if (v[2] >= ht || v[1] > 2 || (v[1] == 1 && (v[2] & 3)) || (v[1] == 2 && v[2] > ADDR_HI_MAX)) continue; /* no table row: the buses will not balance */
+          if (v[2] >= ht || v[1] > 2 || (v[1] == 1 && (v[2] & 3)) || (v[1] == 2 && (v[2] == 0 || v[2] > ADDR_HI_MAX))) continue; /* no table row: the buses will not balance */
           uint32_t* dst = &t[(size_t)(v[1] == 0 ? TB_M_R16 : v[1] == 1 ? TB_M_AL : TB_M_TOP) * ht + v[2]];
           *dst = f_add(*dst, v[0]);
         } else if (it->bus == BUS_BYTES) {
@@ -961,7 +1014,8 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
       }
       break;
     case CH_P2: {
-      /* one row per ancestor of a supplied key, ascending: the node's key, its children's digests in, its own out */
+      /* the aggregation payload's node rows (one per ancestor of a supplied key, ascending: the node's key, its children's
+       * digests in, its own out), then the rows of a leaf-proof check as recorded */
       size_t nr = orc_machine_agg_rows(in->agg_keys, in->agg_leaves, in->n_agg, NULL);
       if (nr == (size_t)-1) nr = 0;
       uint32_t* rows = (uint32_t*)calloc(25 * (nr ? nr : 1), 4);
@@ -971,8 +1025,16 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
       for (size_t r = 0; r < h; ++r) {
         uint32_t st[16] = {0};
         if (r < nr) {
-          T(P2_IS_REAL) = 1; T(P2_KL) = rows[25 * r] & 0xffff; T(P2_KH) = rows[25 * r] >> 16;
+          T(P2_IS_REAL) = 1; T(P2_KL) = rows[25 * r] & 0xffff; T(P2_KH) = rows[25 * r] >> 16; T(P2_FN) = 1;
           memcpy(st, rows + 25 * r + 1, 64);
+        } else if (r < nr + in->n_leaf_p2) {
+          const uint32_t* rc = in->leaf_p2_rows + P2_REC_WORDS * (r - nr);
+          const uint32_t kind = rc[0] & 15u;
+          T(P2_IS_REAL) = 1; T(P2_T) = rc[1] % FP; T(P2_KL) = rc[2] & 0xffff; T(P2_KH) = rc[2] >> 16; T(P2_M) = rc[3] % FP;
+          T(P2_FN) = kind == P2K_NODE; T(P2_SZ) = kind == P2K_SZ; T(P2_SC) = kind == P2K_SC; T(P2_PL) = kind == P2K_PL;
+          T(P2_PR) = kind == P2K_PR; T(P2_FJ) = kind == P2K_J;
+          T(P2_NEW) = (rc[0] & P2F_NEW) != 0; T(P2_SND) = (rc[0] & P2F_SND) != 0; T(P2_FR) = (rc[0] & P2F_FRI) != 0;
+          for (int i = 0; i < 16; ++i) st[i] = rc[4 + i] % FP;
         }
         for (int i = 0; i < 16; ++i) T(P2_IN + i) = st[i];
         orc_p2_external_linear(st);
@@ -996,12 +1058,29 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
       free(rows);
       break;
     }
+    case CH_FOLD:
+      /* one row per query and layer of a leaf-proof check, as recorded; E and F follow from the record */
+      for (size_t r = 0; r < in->n_leaf_fold && r < h; ++r) {
+        const uint32_t* rc = in->leaf_fold_rows + FOLD_REC_WORDS * r;
+        const uint32_t bit = (rc[0] >> 2) & 1u, xinv = rc[3] % FP;
+        T(FO_IS_REAL) = 1; T(FO_FIRST) = rc[0] & 1u; T(FO_LAST) = (rc[0] >> 1) & 1u; T(FO_BIT) = bit; T(FO_HASRO) = (rc[0] >> 3) & 1u;
+        T(FO_Q) = rc[1] % FP; T(FO_K) = rc[2] % FP; T(FO_XINV) = xinv;
+        fe4 beta, lo, hi;
+        for (int i = 0; i < 4; ++i) {
+          beta.c[i] = rc[4 + i] % FP; lo.c[i] = rc[8 + i] % FP; hi.c[i] = rc[12 + i] % FP;
+          T(FO_BETA + i) = beta.c[i]; T(FO_LO + i) = lo.c[i]; T(FO_HI + i) = hi.c[i]; T(FO_RO + i) = rc[16 + i] % FP;
+        }
+        const fe half = (FP + 1) / 2;
+        const fe4 f = e_add(e_mul_base(e_add(lo, hi), half), e_mul(beta, e_mul_base(e_sub(lo, hi), f_mul(half, xinv))));
+        for (int i = 0; i < 4; ++i) { T(FO_E + i) = bit ? hi.c[i] : lo.c[i]; T(FO_F + i) = f.c[i]; }
+      }
+      break;
     case CH_TABLE:
       for (size_t r = 0; r < h; ++r) {
         prep[(size_t)TB_P_X * h + r] = (uint32_t)(r & 255);
         prep[(size_t)TB_P_Y * h + r] = (uint32_t)(r >> 8);
         prep[(size_t)TB_P_NA * h + r] = (r & 3) != 0;
-        prep[(size_t)TB_P_NT * h + r] = r > ADDR_HI_MAX;
+        prep[(size_t)TB_P_NT * h + r] = r == 0 || r > ADDR_HI_MAX;
         prep[(size_t)TB_P_XOR * h + r] = (uint32_t)((r & 255) ^ (r >> 8));
         prep[(size_t)TB_P_AND * h + r] = (uint32_t)((r & 255) & (r >> 8));
       }
@@ -1255,13 +1334,15 @@ static void bw_constraints(const uint32_t* l, sink* s) {
   emit(s, f_sub(selsum, l[BW_IS_REAL]));
 }
 
-/* Poseidon2 chip: every S-box through its cube; the state between S-boxes is linear in the columns */
+/* Poseidon2 chip: every S-box through its cube; the state between S-boxes is linear in the columns.  Then the 67
+ * constraints that tie the rows of an opening together (machine.h "Poseidon2 chip"); they refer to the next row wherever
+ * that row takes over from this one, cyclically: row 0 takes over from nothing. */
 static void p2_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe is_trans, sink* s) {
   uint32_t ext_rc[8][16], int_rc[13];
   orc_poseidon2_constants(&ext_rc[0][0], int_rc);
-  (void)is_first;
-  emit(s, bool_c(l[P2_IS_REAL]));
-  emit(s, f_mul(f_mul(is_trans, n[P2_IS_REAL]), f_sub(1, l[P2_IS_REAL]))); /* the real rows are a prefix */
+  const fe real = l[P2_IS_REAL];
+  emit(s, bool_c(real));
+  emit(s, f_mul(f_mul(is_trans, n[P2_IS_REAL]), f_sub(1, real))); /* the real rows are a prefix */
   fe st[16];
   for (int i = 0; i < 16; ++i) st[i] = l[P2_IN + i];
   orc_p2_external_linear(st);
@@ -1282,6 +1363,77 @@ static void p2_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe
     }
     orc_p2_external_linear(st);
   }
+  /* st[] = the permutation's 16 output words.  Row kinds: one per real row; NEW lives on sponge rows, FR on first blocks,
+   * SND anywhere but on a node row (which always sends) or a padding row */
+  const fe fn = l[P2_FN], sz = l[P2_SZ], sc = l[P2_SC], pl = l[P2_PL], pr = l[P2_PR], fj = l[P2_FJ], nw = l[P2_NEW], snd = l[P2_SND],
+           fr = l[P2_FR];
+  emit(s, bool_c(fn)); emit(s, bool_c(sz)); emit(s, bool_c(sc)); emit(s, bool_c(pl)); emit(s, bool_c(pr));
+  emit(s, bool_c(fj)); emit(s, bool_c(nw)); emit(s, bool_c(snd)); emit(s, bool_c(fr));
+  const fe chain = f_add(f_add(sc, pl), f_add(pr, fj)); /* the kinds that take over from the row before */
+  emit(s, f_sub(f_add(f_add(fn, sz), chain), real));
+  emit(s, f_mul(nw, f_sub(f_sub(1, sz), sc)));
+  emit(s, f_mul(snd, f_sub(f_sub(1, sz), chain)));
+  emit(s, f_mul(fr, f_sub(1, sz)));
+  /* a first block starts from the zero state; the first block of a run from K = 1, M = 0 */
+  for (int i = 0; i < 8; ++i) emit(s, f_mul(sz, l[P2_IN + 8 + i]));
+  const fe key = f_add(l[P2_KL], f_mul(F65536, l[P2_KH])), m = l[P2_M];
+  emit(s, f_mul(f_mul(sz, nw), f_sub(key, 1)));
+  emit(s, f_mul(f_mul(sz, nw), m));
+  emit(s, f_mul(is_first, chain)); /* nothing precedes row 0 */
+  /* the next row, where it takes over from this one */
+  const fe nsc = n[P2_SC], npl = n[P2_PL], npr = n[P2_PR], nfj = n[P2_FJ], npath = f_add(npl, npr);
+  const fe nkey = f_add(n[P2_KL], f_mul(F65536, n[P2_KH])), nm = n[P2_M];
+  emit(s, f_mul(f_add(f_add(nsc, npath), nfj), f_sub(n[P2_T], l[P2_T])));
+  /* ... a sponge goes on: the capacity, the labels and the flag of its run; only a sponge row precedes it */
+  for (int i = 0; i < 8; ++i) emit(s, f_mul(nsc, f_sub(n[P2_IN + 8 + i], st[8 + i])));
+  emit(s, f_mul(nsc, f_sub(nkey, key)));
+  emit(s, f_mul(nsc, f_sub(nm, m)));
+  emit(s, f_mul(nsc, f_sub(n[P2_NEW], nw)));
+  emit(s, f_mul(nsc, f_sub(f_sub(1, sz), sc)));
+  /* ... a path step: the running digest on its side, one more position bit, one more level; it follows the leaf's sponge
+   * (a run's, not an injected matrix's), a path step or an injection */
+  for (int i = 0; i < 8; ++i) emit(s, f_mul(npl, f_sub(n[P2_IN + i], st[i])));
+  for (int i = 0; i < 8; ++i) emit(s, f_mul(npr, f_sub(n[P2_IN + 8 + i], st[i])));
+  emit(s, f_mul(npath, f_sub(f_sub(nkey, f_add(key, key)), npr)));
+  emit(s, f_mul(npath, f_sub(nm, f_add(m, m))));
+  emit(s, f_mul(npath, f_sub(f_sub(f_sub(f_sub(1, f_mul(f_add(sz, sc), nw)), pl), pr), fj)));
+  /* ... an injection: the running digest on the left, the level marked; only a path step precedes it */
+  for (int i = 0; i < 8; ++i) emit(s, f_mul(nfj, f_sub(n[P2_IN + i], st[i])));
+  emit(s, f_mul(nfj, f_sub(nkey, key)));
+  emit(s, f_mul(nfj, f_sub(f_sub(nm, m), 1)));
+  emit(s, f_mul(nfj, f_sub(f_sub(1, pl), pr)));
+}
+
+/* FRI fold chip (machine.h): 31 constraints; the extension field is F_p[x] / (x^4 - 11) */
+static void fold_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe is_trans, sink* s) {
+  const fe real = l[FO_IS_REAL], first = l[FO_FIRST], last = l[FO_LAST], bit = l[FO_BIT], hasro = l[FO_HASRO];
+  emit(s, bool_c(real)); emit(s, bool_c(first)); emit(s, bool_c(last)); emit(s, bool_c(bit)); emit(s, bool_c(hasro));
+  emit(s, f_mul(f_mul(is_trans, n[FO_IS_REAL]), f_sub(1, real))); /* the real rows are a prefix */
+  emit(s, f_mul(first, f_sub(1, real))); emit(s, f_mul(last, f_sub(1, real))); emit(s, f_mul(hasro, f_sub(1, real)));
+  emit(s, f_mul(first, l[FO_K]));
+  emit(s, f_mul(is_first, f_sub(real, first)));
+  fe lo[4], hi[4], d[4], be[4];
+  for (int i = 0; i < 4; ++i) { lo[i] = l[FO_LO + i]; hi[i] = l[FO_HI + i]; d[i] = f_sub(lo[i], hi[i]); be[i] = l[FO_BETA + i]; }
+  /* the value the layer shows at the query's position */
+  for (int i = 0; i < 4; ++i) emit(s, f_add(f_sub(l[FO_E + i], lo[i]), f_mul(bit, d[i])));
+  /* 2 F = LO + HI + XINV * BETA * (LO - HI) */
+  {
+    const fe xinv = l[FO_XINV];
+    const fe p0 = f_add(f_mul(be[0], d[0]), f_mul(11, f_add(f_add(f_mul(be[1], d[3]), f_mul(be[2], d[2])), f_mul(be[3], d[1]))));
+    const fe p1 = f_add(f_add(f_mul(be[0], d[1]), f_mul(be[1], d[0])), f_mul(11, f_add(f_mul(be[2], d[3]), f_mul(be[3], d[2]))));
+    const fe p2 = f_add(f_add(f_add(f_mul(be[0], d[2]), f_mul(be[1], d[1])), f_mul(be[2], d[0])), f_mul(11, f_mul(be[3], d[3])));
+    const fe p3 = f_add(f_add(f_mul(be[0], d[3]), f_mul(be[1], d[2])), f_add(f_mul(be[2], d[1]), f_mul(be[3], d[0])));
+    const fe pp[4] = {p0, p1, p2, p3};
+    for (int i = 0; i < 4; ++i) emit(s, f_sub(f_sub(f_sub(f_add(l[FO_F + i], l[FO_F + i]), lo[i]), hi[i]), f_mul(xinv, pp[i])));
+  }
+  for (int i = 0; i < 4; ++i) emit(s, f_mul(f_sub(1, hasro), l[FO_RO + i]));
+  /* the next row goes on with this query unless it starts one (or is padding) */
+  const fe cont = f_sub(n[FO_IS_REAL], n[FO_FIRST]);
+  emit(s, f_mul(cont, f_sub(n[FO_Q], l[FO_Q])));
+  emit(s, f_mul(cont, f_sub(f_sub(n[FO_K], l[FO_K]), 1)));
+  for (int i = 0; i < 4; ++i) emit(s, f_mul(cont, f_sub(f_sub(n[FO_E + i], l[FO_F + i]), l[FO_RO + i])));
+  emit(s, f_mul(last, cont));
+  emit(s, f_mul(f_sub(real, last), f_sub(1, cont)));
 }
 
 /* sub-word chip: M is the memory word, C the low limb of the stored register, both as bits */
@@ -1346,6 +1498,8 @@ static void ecall_constraints(const uint32_t* l, const uint32_t* pub, sink* s) {
   /* the next instruction, except that HALT goes to the padding instruction */
   const fe pc4 = f_add(l[EC_PC], 4);
   emit(s, f_sub(f_mul(real, f_sub(l[EC_NP], pc4)), f_mul(l[EC_SC + SC_HALT], f_sub(pub[CPUPUB_PAD_PC] % FP, pc4))));
+  /* COMMIT / COMMIT_DEFERRED: the word index in a0 is the whole register (the PUBC tuple carries its low limb only) */
+  emit(s, f_mul(f_add(l[EC_SC + SC_COMMIT], l[EC_SC + SC_DEFER]), l[EC_C_HI]));
 }
 
 static void run_constraints(int chip, const uint32_t* prep, const uint32_t* loc, const uint32_t* nxt, uint32_t is_first,
@@ -1368,7 +1522,8 @@ static void run_constraints(int chip, const uint32_t* prep, const uint32_t* loc,
     case CH_BW:
     case CH_BW2: bw_constraints(loc, s); break;
     case CH_P2: p2_constraints(loc, nxt, is_first, is_trans, s); break;
-    case CH_TABLE: /* only multiples of 4 answer aligned lookups, only values up to ADDR_HI_MAX high-address-limb lookups */
+    case CH_FOLD: fold_constraints(loc, nxt, is_first, is_trans, s); break;
+    case CH_TABLE: /* only multiples of 4 answer aligned lookups, only values 1 .. ADDR_HI_MAX high-address-limb lookups */
       emit(s, f_mul(loc[TB_M_AL], prep[TB_P_NA]));
       emit(s, f_mul(loc[TB_M_TOP], prep[TB_P_NT]));
       break;

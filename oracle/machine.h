@@ -11,7 +11,7 @@
  * (circuits/sp1-merkle-proof/src/main.rs:4-14, crypto-ops/src/lib.rs:8-23) ran to HALT(0) and
  * committed these public values.
  *
- * Format v12 (round 3).  The CPU row no longer carries its operands as bits: it holds 16-bit limbs,
+ * Format v14 (v12: round 3; v14: round 4 - address floor, leaf-proof check).  The CPU row no longer carries its operands as bits: it holds 16-bit limbs,
  * adds / subtracts / compares (equality, unsigned order) / moves words itself, and sends xor / or /
  * and to a bitwise chip (bytes, looked up in a byte-operation table), shifts and signed less-than to
  * an ALU chip (bits) and every sub-word load or store to a sub-word chip, each with one row per such
@@ -43,7 +43,7 @@ extern "C" {
 #define CPU_INST 8
 enum {
   CH_CPU = 0, CH_KECCAK, CH_KMEM, CH_MEMFINAL, CH_IMAGE, CH_PROGRAM, CH_MUL, CH_TABLE, CH_CPU2, CH_ALU, CH_ALU2, CH_SUB,
-  CH_SUB2, CH_BW, CH_BW2, CH_P2, CH_ECALL, CH_CPU3, CH_CPU4, CH_CPU5, CH_CPU6, CH_CPU7, CH_CPU8, N_CHIPS
+  CH_SUB2, CH_BW, CH_BW2, CH_P2, CH_ECALL, CH_CPU3, CH_CPU4, CH_CPU5, CH_CPU6, CH_CPU7, CH_CPU8, CH_FOLD, N_CHIPS
 };
 /* CPU instance i = 0 .. CPU_INST - 1 <-> chip (the first two keep their old places in the proof order) */
 static inline int orc_cpu_chip(int i) { return i == 0 ? CH_CPU : i == 1 ? CH_CPU2 : CH_CPU3 + (i - 2); }
@@ -136,26 +136,60 @@ enum {
   SW_S = SW_CB + 2 /* sign bit a signed load extends */, SW_SELB /* the byte that carries it */,
   SUB_WIDTH = SW_SELB + 1
 };
-/* ---- Poseidon2 chip (row f4, stage 1): one width-16 permutation per row = one 2-to-1 compression of a Merkle tree of
- *      8-word digests.  A row holds a node K of a binary heap (root 1, children 2K and 2K + 1; K as two range-checked limbs,
- *      below 0x78000000): it consumes its children's digests from the DIGEST bus and produces its own.  The verifier
- *      supplies digests at keys of its choice and takes the root: all n leaves of a tree (keys n .. 2n - 1: the aggregation
- *      root), or one leaf and the siblings along its path (a Merkle path).  The rows are the ancestors of the supplied
- *      keys, in ascending order.  Columns: the input state, and per S-box its cube and its seventh power (degree <= 3). ---- */
+/* ---- Poseidon2 chip (row f4): one width-16 permutation per row.  Six kinds of rows:
+ *   N   (stage 1) a node K of a binary heap of digests (root 1, children 2K and 2K + 1; K as two range-checked limbs): consumes
+ *       its children's digests from the DIGEST bus and produces its own; the verifier supplies digests at keys of its choice
+ *       and takes the root (all n leaves of a tree: the aggregation root; or one leaf and the siblings along its path);
+ *   SZ / SC  (stage 2a: the openings of a leaf proof) a sponge row: eight absorbed words over the capacity carried from the
+ *       row before (SC) or over the zero state (SZ: the first block of a hash; the last block of an input is zero-filled);
+ *   PL / PR  a step of a Merkle path: the running digest (the output of the row before) is the left / right input, the
+ *       sibling the other, free; K' = 2 K + [right], M' = 2 M;
+ *   J   an injection of a mixed-height tree: the running digest on the left, on the right the hash of the shorter matrices'
+ *       row, consumed from the DIGEST bus where the sponge that made it (a segment of sponge rows elsewhere, labelled with
+ *       this row's T, K, M) put it; K' = K, M' = M + 1.
+ * A run (one opening) starts with a sponge over the zero state flagged NEW (K = 1, M = 0): K collects the position bits, M
+ * the levels an injection followed, T names the opening; its last row sends (T, 0, K, M, digest), which the VERIFIER
+ * consumes with the root it knows - position, shape and root of every opening are the verifier's.  Columns: the labels and
+ * flags, the input state, and per S-box its cube and its seventh power (degree <= 3). ---- */
 enum {
-  P2_IS_REAL = 0, P2_KL, P2_KH /* the node's key, two limbs */, P2_IN /* 16 */, P2_EXT = P2_IN + 16 /* 8 external rounds x (16 cubes, 16 outputs) */,
+  P2_IS_REAL = 0, P2_KL, P2_KH /* the key / position accumulator, two limbs */, P2_T /* tag of the opening */, P2_M /* injection mask */,
+  P2_FN, P2_SZ, P2_SC, P2_PL, P2_PR, P2_FJ /* row kind, one-hot on real rows */, P2_NEW /* (sponge rows) the run's first hash */,
+  P2_SND /* the row sends its digest */, P2_FR /* a FRI leaf: the absorbed pair goes to the fold chip */,
+  P2_IN /* 16 */, P2_EXT = P2_IN + 16 /* 8 external rounds x (16 cubes, 16 outputs) */,
   P2_INT = P2_EXT + 256 /* 13 internal rounds x (cube, output) */, P2CHIP_WIDTH = P2_INT + 26
 };
+/* row records (P2_REC_WORDS each): flags = kind | P2F_*, tag, key, mask, the 16 input words */
+enum { P2K_NONE = 0, P2K_NODE, P2K_SZ, P2K_SC, P2K_PL, P2K_PR, P2K_J };
+#define P2_REC_WORDS 20
+#define P2F_NEW 16u
+#define P2F_SND 32u
+#define P2F_FRI 64u
+/* tags of a leaf proof's openings: query q, tree r (0 preprocessed, 1 main, 2 permutation, 3 quotient, 4 + k: FRI layer k) */
+#define LEAF_TAG_STRIDE 64u
+#define LEAF_TAG(q, r) (1u + LEAF_TAG_STRIDE * (q) + (r))
+/* ---- FRI fold chip (row f4, stage 2a): one row per query and layer of a leaf proof's FRI.  The sibling pair (LO, HI) arrives
+ *      from the sponge row that hashed it (PAIR bus); the layer's challenge, the inverse of the pair's domain point and the
+ *      position bit from the verifier (FRIQ bus); E - the value the layer must show at the query's position - is LO or HI by
+ *      the bit; F = (LO + HI) / 2 + BETA (LO - HI) XINV / 2 is the folded value; the next layer's E is F plus the reduced
+ *      opening that joins there (RO bus: the verifier's, in stage 2a); the last F goes to the verifier (FIN bus), who knows
+ *      the final constant. ---- */
+enum {
+  FO_IS_REAL = 0, FO_FIRST, FO_LAST, FO_Q, FO_K, FO_BIT, FO_XINV, FO_HASRO, FO_BETA /* 4 */, FO_LO = FO_BETA + 4, FO_HI = FO_LO + 4,
+  FO_E = FO_HI + 4, FO_F = FO_E + 4, FO_RO = FO_F + 4, FOLD_WIDTH = FO_RO + 4
+};
+/* row records (FOLD_REC_WORDS each): flags (first, last << 1, bit << 2, hasro << 3), query, layer, 1/x, beta, lo, hi, ro */
+#define FOLD_REC_WORDS 20
 /* ---- table chip: 2^16 rows; preprocessed (x = low byte, y = high byte, na = row index not a multiple of 4,
- *      nt = row index above ADDR_HI_MAX, x ^ y, x & y); main: multiplicities of range16 (kind 0), 4-aligned range16
- *      (kind 1), high address limb (kind 2: at most ADDR_HI_MAX), byte pair, and the byte operations xor / or / and ---- */
+ *      nt = row index zero or above ADDR_HI_MAX, x ^ y, x & y); main: multiplicities of range16 (kind 0), 4-aligned range16
+ *      (kind 1), high address limb (kind 2: 1 .. ADDR_HI_MAX), byte pair, and the byte operations xor / or / and ---- */
 enum { TB_P_X = 0, TB_P_Y, TB_P_NA, TB_P_NT, TB_P_XOR, TB_P_AND, TABLE_PREP_WIDTH };
 enum { TB_M_R16 = 0, TB_M_AL, TB_M_TOP, TB_M_BY, TB_M_XOR, TB_M_OR, TB_M_AND, TABLE_WIDTH };
 #define TABLE_LOG_H 16
-#define ADDR_HI_MAX 0x77FFu /* high limb of the largest address / jump target: values stay below 0x78000000 < p */
+#define ADDR_HI_MAX 0x77FEu /* high limb of the largest address / jump target: values stay below 0x78000000 < p; the
+                               smallest is 1: no load, store or keccak state can name a register (addresses 0 .. 31) */
 
 /* ---- buses ---- */
-enum { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP, BUS_DIGEST, BUS_ECALL };
+enum { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP, BUS_DIGEST, BUS_ECALL, BUS_PAIR, BUS_FRIQ, BUS_RO, BUS_FIN };
 
 /* A linear form over the row [preprocessed | main]: c0 + sum coef[i] * row[col[i]] (canonical words). */
 #define LF_MAX 40
@@ -216,7 +250,14 @@ typedef struct {
   const uint32_t* agg_keys;                    /* heap keys of the payload's digests (NULL: n_agg + j, the leaves of a full tree) */
   const uint32_t* agg_leaves; size_t n_agg;    /* aggregation payload: n_agg (0, or a power of two >= 2) digests of 8 words
                                                   whose Poseidon2 Merkle root the proof also establishes */
+  /* leaf-proof check (row f4, stage 2a): the records zksp_mtrace_section() exposes - the Poseidon2-chip rows after the
+   * aggregation payload's node rows, the fold-chip rows, and the public bus tuples (PUB_TUPLE_WORDS each: bus, 1 = the
+   * verifier sends it / 0 = receives it, multiplicity, number of elements, 12 element slots) that state what was checked */
+  const uint32_t* leaf_p2_rows; size_t n_leaf_p2;
+  const uint32_t* leaf_fold_rows; size_t n_leaf_fold;
+  const uint32_t* pub_tuples; size_t n_pub;
 } orc_machine_input;
+#define PUB_TUPLE_WORDS 16
 
 /* The oracle's own event lists (cycle indices of the ALU-chip and sub-word-chip rows, in execution order) and the
  * last access time of x0 by a real cycle; the product's tracer emits the same lists and tests compare them. */
@@ -262,7 +303,7 @@ int orc_machine_nodes_public(const uint32_t* keys, const uint32_t* digests, size
  * (key, left child's digest, right child's digest, own digest).  Returns the number of rows, (size_t)-1 if malformed;
  * rows may be NULL. */
 size_t orc_machine_agg_rows(const uint32_t* keys, const uint32_t* digests, size_t n, uint32_t* rows);
-#define ZKSP_VERSION_MACHINE 13u
+#define ZKSP_VERSION_MACHINE 14u
 /* vk: preprocessed commitment root + digest binding entry pc, table heights and keccak mode */
 void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t prep_root[8], uint32_t vk_digest[8]);
 size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_image, const orc_config* cfg, uint32_t pv_len);

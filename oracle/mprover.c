@@ -186,6 +186,36 @@ static void gather_row(const chipd* d, const uint32_t* const* src, int is_lde, s
       row[n++] = is_lde ? src[r][((size_t)col * 2 + cs) * d->h + m] : src[r][(size_t)col * d->h + m];
 }
 
+/* An honest prover's own check: every base constraint of `chip` holds on every row of its trace (the rows taken
+ * cyclically, with the selectors' values on the trace domain: is_first = [row 0], is_last = [last row], is_trans = 0 on the
+ * last row only).  Returns the number of rows that violate one.  (A violated constraint does not show in the FRI layers:
+ * with two quotient chunks over the two cosets of a blow-up of two, whatever was committed is of low degree - it shows in
+ * the verifier's identity at zeta.) */
+static size_t check_constraints(const chipd* d, int chip, const uint32_t* pub) {
+  const int nb = d->def->n_constraints, rw = d->w[R_PREP] + d->w[R_MAIN], pw = d->w[R_PREP];
+  const uint32_t* src[2] = {d->tr[R_PREP], d->tr[R_MAIN]};
+  size_t bad = 0;
+  if (nb == 0) return 0;
+#pragma omp parallel reduction(+ : bad)
+  {
+    uint32_t* loc = (uint32_t*)malloc((size_t)rw * 4 * 2);
+    uint32_t* nxt = loc + rw;
+    uint32_t* cons = (uint32_t*)malloc((size_t)(nb + 1) * 4);
+#pragma omp for schedule(static)
+    for (size_t m = 0; m < d->h; ++m) {
+      gather_row(d, src, 0, 0, m, loc);
+      gather_row(d, src, 0, 0, (m + 1) & (d->h - 1), nxt);
+      orc_machine_constraints(chip, loc, loc + pw, nxt + pw, m == 0, m == d->h - 1, m != d->h - 1, pub, cons);
+      int any = 0;
+      for (int k = 0; k < nb; ++k) any |= cons[k] != 0;
+      bad += (size_t)any;
+    }
+    free(loc);
+    free(cons);
+  }
+  return bad;
+}
+
 /* ---- LogUp slots (machine.h "LogUp layout") ---- */
 static fe signed_mult(const orc_inter* it, const uint32_t* row) {
   const fe m = lf_eval(&it->mult, row);
@@ -454,6 +484,8 @@ void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t pr
   tmp.agg_leaves = NULL;
   tmp.agg_keys = NULL;
   tmp.n_agg = 0;
+  tmp.leaf_p2_rows = tmp.leaf_fold_rows = tmp.pub_tuples = NULL;
+  tmp.n_leaf_p2 = tmp.n_leaf_fold = tmp.n_pub = 0;
   tmp.n_cycles = tmp.n_keccak = tmp.n_memfinal = tmp.n_muls = 0;
   init_chips(&tmp, cd, 1);
   mmcs t;
@@ -464,8 +496,9 @@ void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t pr
   free_chips(cd);
 }
 
-/* magic, version, heights, exit code, pv length, 3 digests, hand-over pc; aggregation: leaf count, root, digest of the leaf list */
-#define HEADER_WORDS (2 + N_CHIPS + 2 + 24 + (CPU_INST - 1) + 17)
+/* magic, version, heights, exit code, pv length, 3 digests, hand-over pc; aggregation: leaf count, root, digest of the leaf list;
+ * public bus tuples (the statement of a leaf-proof check): count, digest of the list */
+#define HEADER_WORDS (2 + N_CHIPS + 2 + 24 + (CPU_INST - 1) + 17 + 9)
 
 typedef struct { uint32_t key; int have; uint32_t d[8]; } agg_node;
 static int agg_node_cmp(const void* x, const void* y) {
@@ -593,6 +626,14 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
     if (logh[c] > lm) lm = logh[c];
   uint32_t agg_n = (uint32_t)in->n_agg, agg_root[8], agg_digest[8];
   if (!orc_machine_nodes_public(in->agg_keys, in->agg_leaves, in->n_agg, agg_root, agg_digest)) return 1; /* malformed payload */
+  /* the statement of a leaf-proof check: the list of public bus tuples stands in the header and the transcript by its digest */
+  uint32_t pub_n = (uint32_t)in->n_pub, pub_digest[8];
+  memset(pub_digest, 0, sizeof pub_digest);
+  if (in->n_pub) {
+    for (size_t i = 0; i < in->n_pub * PUB_TUPLE_WORDS; ++i)
+      if (in->pub_tuples[i] >= FP) return 1;
+    orc_hash_elems(in->pub_tuples, in->n_pub * PUB_TUPLE_WORDS, pub_digest);
+  }
   uint32_t cpu_pub[N_CHIPS][CPUPUB_N];
   memset(cpu_pub, 0, sizeof cpu_pub);
   uint32_t handover[CPU_INST - 1]; /* the pc every later CPU instance starts at: header words, absorbed into the transcript */
@@ -608,6 +649,13 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   mmcs_commit(cd, R_PREP, &t_prep);
   uint32_t vk[8];
   vk_digest_of(mmcs_root(&t_prep), in, keccak_mode, vk);
+  /* the records are consistent only if every chip's constraints hold on its trace.  ZKSP_ORACLE_FORCE lets soundness
+   * tests obtain the proof a cheating prover would send, to check that the verifier rejects it */
+  for (int c = 0; c < N_CHIPS; ++c) {
+    const size_t bad = check_constraints(&cd[c], c, cpu_pub[c]);
+    if (bad && getenv("ZKSP_ORACLE_TIMING")) fprintf(stderr, "[oracle] chip %-10s: %zu rows violate a constraint\n", cd[c].def->name, bad);
+    if (bad && !getenv("ZKSP_ORACLE_FORCE")) { free_chips(cd); return 3; }
+  }
   for (int c = 0; c < N_CHIPS; ++c) lde_round(&cd[c], R_MAIN);
   mmcs_commit(cd, R_MAIN, &t_main);
 
@@ -625,6 +673,8 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
     put(&pb, &agg_n, 1);
     put(&pb, agg_root, 8);
     put(&pb, agg_digest, 8);
+    put(&pb, &pub_n, 1);
+    put(&pb, pub_digest, 8);
     size_t pw = (pub->pv_len + 3) / 4;
     uint32_t* tmp = (uint32_t*)calloc(pw ? pw : 1, 4);
     memcpy(tmp, public_values, pub->pv_len);
@@ -643,6 +693,8 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   orc_ch_observe(&ch, agg_n);
   orc_ch_observe_many(&ch, agg_root, 8);
   orc_ch_observe_many(&ch, agg_digest, 8);
+  orc_ch_observe(&ch, pub_n);
+  orc_ch_observe_many(&ch, pub_digest, 8);
   orc_ch_observe_many(&ch, mmcs_root(&t_main), 8);
   put(&pb, mmcs_root(&t_main), 8);
 
@@ -683,13 +735,26 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
     total = e_sub(total, e_inv(a.c0));
     /* ... and the digest bus of the aggregation payload: the verifier hands in the supplied nodes (the leaves of a full tree
      * at heap nodes n .. 2n - 1, or a leaf and the siblings along its path) and takes the root (node 1) */
-    it.bus = BUS_DIGEST; it.n_el = 9;
+    it.bus = BUS_DIGEST; it.n_el = 12; /* (tag 0, type 2 = heap node, key, mask 0, the digest) */
     for (size_t i = 0; i <= in->n_agg && in->n_agg; ++i) {
       const uint32_t* d = i < in->n_agg ? in->agg_leaves + 8 * i : agg_root;
-      it.el[0].n = 0; it.el[0].c0 = i < in->n_agg ? (in->agg_keys ? in->agg_keys[i] : (uint32_t)(in->n_agg + i)) : 1u;
-      for (int j = 0; j < 8; ++j) { it.el[1 + j].n = 0; it.el[1 + j].c0 = d[j]; }
+      it.el[0].n = 0; it.el[0].c0 = 0;
+      it.el[1].n = 0; it.el[1].c0 = 2;
+      it.el[2].n = 0; it.el[2].c0 = i < in->n_agg ? (in->agg_keys ? in->agg_keys[i] : (uint32_t)(in->n_agg + i)) : 1u;
+      it.el[3].n = 0; it.el[3].c0 = 0;
+      for (int j = 0; j < 8; ++j) { it.el[4 + j].n = 0; it.el[4 + j].c0 = d[j]; }
       build_aff(&it, gamma, bpow, &a);
       total = i < in->n_agg ? e_add(total, e_inv(a.c0)) : e_sub(total, e_inv(a.c0));
+    }
+    /* ... and the public bus tuples of a leaf-proof check, each sent or received by the verifier with its multiplicity */
+    for (size_t i = 0; i < in->n_pub; ++i) {
+      const uint32_t* t = in->pub_tuples + PUB_TUPLE_WORDS * i;
+      if (t[3] > PUB_TUPLE_WORDS - 4) return 1;
+      it.bus = (int)t[0]; it.n_el = (int)t[3];
+      for (uint32_t j = 0; j < t[3]; ++j) { it.el[j].n = 0; it.el[j].c0 = t[4 + j]; }
+      build_aff(&it, gamma, bpow, &a);
+      const fe4 term = e_mul_base(e_inv(a.c0), t[2]);
+      total = t[1] ? e_add(total, term) : e_sub(total, term);
     }
   }
   if (!e_eq(total, e_zero())) {

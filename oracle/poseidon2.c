@@ -1,7 +1,7 @@
 /* ORACLE -- TEST INFRASTRUCTURE ONLY (see field.h).
  *
  * Poseidon2 over BabyBear, width 16, S-box x^7, 4+4 external and 13 internal
- * rounds; sponge (rate 8, overwrite mode, no padding) and 2-to-1 truncated-
+ * rounds; sponge (rate 8, overwrite mode, the last block zero-filled; inputs have fixed lengths) and 2-to-1 truncated-
  * permutation compression; restates p3-poseidon2 / p3-symmetric 0.1.4-succinct
  * (reference Cargo.lock:5353, :5367), called by the reference only beneath
  * prover/src/bin/main.rs:71-74.
@@ -151,7 +151,7 @@ void orc_hash_elems(const uint32_t* in, size_t n, uint32_t* out) {
   memset(st, 0, sizeof st);
   for (size_t off = 0; off < n; off += P2_RATE) {
     size_t m = n - off < P2_RATE ? n - off : P2_RATE;
-    for (size_t i = 0; i < m; ++i) st[i] = in[off + i];
+    for (size_t i = 0; i < P2_RATE; ++i) st[i] = i < m ? in[off + i] : 0; /* overwrite mode; the last block is zero-filled */
     orc_poseidon2_permute(st);
   }
   memcpy(out, st, P2_DIGEST * sizeof(uint32_t));

@@ -31,7 +31,7 @@ void orc_poseidon2_constants(uint32_t* ext_rc /*[8*16]*/, uint32_t* int_rc /*[13
 void orc_p2_external_linear(uint32_t* s /*[16]*/);
 void orc_p2_internal_linear(uint32_t* s /*[16]*/);
 void orc_poseidon2_permute(uint32_t* st /*[16]*/);
-/* sponge hash of n field elements (overwrite mode, no padding) */
+/* sponge hash of n field elements (overwrite mode, the last block zero-filled) */
 void orc_hash_elems(const uint32_t* in, size_t n, uint32_t* out /*[8]*/);
 void orc_compress(const uint32_t* l, const uint32_t* r, uint32_t* out /*[8]*/);
 

@@ -68,8 +68,8 @@ def permute(s):
 def hash_elems(v):
     st = [0] * 16
     for off in range(0, len(v), 8):
-        chunk = v[off:off + 8]
-        st[:len(chunk)] = chunk
+        chunk = list(v[off:off + 8])
+        st[:8] = chunk + [0] * (8 - len(chunk))  # overwrite mode; the last block is zero-filled
         st = permute(st)
     return st[:8]
 

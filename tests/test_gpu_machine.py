@@ -94,6 +94,34 @@ def test_as_committed_instruction_stream(zk, fx):
         other.verify(proof, vk2)
 
 
+def test_as_committed_acct_d8_matches_oracle(zk, fx, oracle):
+    """BASELINE config 2 on the binary exactly as the reference ships it (circuits/elf/riscv32im-succinct-zkvm-elf, software
+    keccak through the CPU, ALU and bitwise chips): 1 406 960 cycles in six CPU instances of 2^18 rows.  The device's proof
+    body equals the oracle's byte for byte, the wrapped proof equals the oracle's proof and a host-only verifier accepts it."""
+    nq, pw = 8, 6
+    client = zk.ProverClient(device=0, num_queries=nq, pow_bits=pw, keccak_mode=zk.KECCAK_OBSERVE, max_batch=2)
+    pk, vk = client.setup(zk.merkle_elf())
+    s = zk.SP1Stdin()
+    s.write(fx.acct_fixture(8, seed=2).to_borsh())
+    handle = client.machine_trace_handle(pk, s)
+    trace = client.machine_trace(pk, s)
+    assert 1_400_000 < trace["cycles"].shape[0] < 1_420_000 and trace["keccak"].shape[0] == 0
+    shape = zk.machine_cover_heights([handle])
+    names = zk.MACHINE_CHIP_NAMES
+    assert [shape[names.index(n)] for n in ("cpu", "cpu2", "cpu3", "cpu4", "cpu5", "cpu6", "cpu7", "cpu8")] == [18] * 6 + [5] * 2
+    assert shape[names.index("keccak")] == 5  # no precompile call: the keccak chips are all padding
+    body = client.machine_prove_resident(pk, [handle])[0]
+    exp = oracle.machine_prove(dict(trace, shape=shape), num_queries=nq, pow_bits=pw)
+    hw = zk.MACHINE_HEADER_WORDS + (len(trace["public_values"]) + 3) // 4
+    e = np.frombuffer(exp, dtype=np.uint32)[hw:]
+    assert e.shape == body.shape
+    assert first_difference(body, e) is None, first_difference(body, e)
+    proof = handle.proof_from_body(pk, body, shape)
+    assert proof.to_bytes() == exp
+    assert proof.public_values == fx.ACCOUNT_VALUE
+    zk.ProverClient(device=-1, num_queries=nq, pow_bits=pw, keccak_mode=zk.KECCAK_OBSERVE).verify(proof, vk)
+
+
 def test_batch_of_machine_proofs(zk, fx, oracle):
     """Several guest runs proven in lockstep (prove_batch): runs of different size classes fall into separate groups,
     runs of one class share the shape that covers the largest of them, every proof verifies, one proof of the largest
@@ -307,3 +335,47 @@ def test_aggregate_1024_commitments(zk, fx, oracle):
     n, root = agg.aggregation
     assert n == 1024 and root == oracle.machine_agg_public(leaves)[0]
     zk.ProverClient(device=-1).verify_aggregate(agg, vk, leaves)
+
+
+def test_leaf_check_matches_oracle(zk, fx, oracle):
+    """Row f4, stage 2a on the device: a proof that also establishes the query phase of ANOTHER proof - the leaf's openings as
+    rows of the Poseidon2 chip (sponges, path steps, injections: p2_trace_kernel, machine_quotient_kernel<poseidon2>, the
+    DIGEST and PAIR buses) and of the FRI fold chip (fold_trace_kernel, machine_quotient_kernel<fri-fold>) - byte-identical
+    to the oracle's, in one batch with a proof that has no payload; verified with the leaf, with the statement derived
+    from it, and not without."""
+    nq, pw = 8, 6
+    client = zk.ProverClient(device=0, num_queries=nq, pow_bits=pw, max_batch=2)
+    pk, vk = client.setup(zk.merkle_elf())
+    s = zk.SP1Stdin()
+    s.write(fx.acct_fixture(1, seed=50).to_borsh())
+    leaf = client.prove(pk, s).run()
+    host = zk.ProverClient(device=-1, num_queries=nq, pow_bits=pw)
+    host.verify(leaf, vk)
+    handles, traces = [], []
+    for i in range(2):
+        s = zk.SP1Stdin()
+        s.write(fx.acct_fixture(1, seed=51 + i).to_borsh())
+        if i == 0:
+            client.set_verified_leaf(s, leaf, vk)
+        handles.append(client.machine_trace_handle(pk, s))
+        traces.append(client.machine_trace(pk, s))
+    assert len(traces[0]["leaf_p2_rows"]) > 4000 and len(traces[1]["leaf_p2_rows"]) == 0
+    shape = zk.machine_cover_heights(handles)
+    names = zk.MACHINE_CHIP_NAMES
+    assert shape[names.index("poseidon2")] == 13 and shape[names.index("fri-fold")] >= 7
+    bodies = client.machine_prove_resident(pk, handles)
+    proofs = [handles[i].proof_from_body(pk, bodies[i], shape) for i in range(2)]
+    for i in range(2):
+        assert proofs[i].to_bytes() == oracle.machine_prove(dict(traces[i], shape=shape), num_queries=nq, pow_bits=pw), i
+    host.verify(proofs[1], vk)
+    host.verify_with_leaf(proofs[0], vk, leaf, vk)
+    host.verify_public(proofs[0], vk, host.leaf_public(leaf, vk))
+    with pytest.raises(zk.VerificationError):
+        host.verify(proofs[0], vk)
+    # the drop-in call gives the same proof
+    s = zk.SP1Stdin()
+    s.write(fx.acct_fixture(1, seed=51).to_borsh())
+    client.set_verified_leaf(s, leaf, vk)
+    again = client.prove(pk, s).run()
+    host.verify_with_leaf(again, vk, leaf, vk)
+    assert again.public_tuples == proofs[0].public_tuples

@@ -65,9 +65,9 @@ def test_every_region_is_bound(zk, setup):
     client, vk, t, proof = setup
     rng = np.random.default_rng(5)
     words = len(proof) // 4
-    hw = zk.MACHINE_HEADER_WORDS  # heights from word 2, exit code, pv length, three digests, hand-over pcs hw - 24 .. hw - 18, aggregation words, then the values
+    hw = zk.MACHINE_HEADER_WORDS  # heights from word 2, exit code, pv length, three digests, hand-over pcs hw - 33 .. hw - 27, 17 aggregation words, 9 public-tuple words, then the values
     nc = zk.MACHINE_CHIPS
-    positions = [2, 5, 9, 1 + nc, 2 + nc, 3 + nc, 11 + nc, 19 + nc, hw - 24, hw - 20, hw - 18, hw - 1, hw, hw + 1, hw + 18, hw + 18 + 8, hw + 18 + 16, hw + 18 + 48, hw + 18 + 56, words - 1]
+    positions = [2, 5, 9, 1 + nc, 2 + nc, 3 + nc, 11 + nc, 19 + nc, hw - 33, hw - 29, hw - 27, hw - 10, hw - 9, hw - 1, hw, hw + 1, hw + 18, hw + 18 + 8, hw + 18 + 16, hw + 18 + 48, hw + 18 + 56, words - 1]
     positions += [int(x) for x in rng.integers(hw, words, 40)]
     for w in positions:
         bad = bytearray(proof)
@@ -402,7 +402,7 @@ def test_cpu_instances_must_continue_one_another(zk, oracle, setup):
     h0 = 1 << heights[0]
     used = -(-len(cyc) // h0)
     assert 2 <= used <= 8 and all(heights[cpu[i]] == heights[0] for i in range(used))
-    hw = zk.MACHINE_HEADER_WORDS - 17 - 7  # seven hand-over pcs, then the 17 aggregation words
+    hw = zk.MACHINE_HEADER_WORDS - 9 - 17 - 7  # seven hand-over pcs, then the 17 aggregation words and the 9 public-tuple words
     for k in (1, used - 1):
         assert int.from_bytes(proof[4 * (hw + k - 1):4 * (hw + k)], "little") == int(cyc[k * h0, 0])
         c2 = cyc.copy()

@@ -29,16 +29,18 @@ ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_ELF, ERR_EXECUTOR, ERR_GUEST_PANIC,
     ERR_UNSUPPORTED = range(1, 10)
 KECCAK_SOFTWARE, KECCAK_OBSERVE, KECCAK_REPLACE = 0, 1, 2
 PROOF_MACHINE, PROOF_KECCAK_CHIP = 1, 2
-# machine proof (format version 13): chips in proof order and the fixed header in front of the public values
-MACHINE_VERSION = 13
+# machine proof (format version 14): chips in proof order and the fixed header in front of the public values
+MACHINE_VERSION = 14
 MACHINE_CHIP_NAMES = ("cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "table", "cpu2", "alu", "alu2",
                       "subword", "subword2", "bitwise", "bitwise2", "poseidon2", "ecall", "cpu3", "cpu4", "cpu5", "cpu6", "cpu7",
-                      "cpu8")
+                      "cpu8", "fri-fold")
 MACHINE_CHIPS = len(MACHINE_CHIP_NAMES)
 MACHINE_CPU_INSTANCES = 8  # cpu, cpu2 .. cpu8: one AIR, consecutive stretches of the run
 # magic, version, heights, exit code, pv length, three digests, the pcs at which the later CPU instances start, the
-# aggregation payload's leaf count, root and leaf-list digest
-MACHINE_HEADER_WORDS = 2 + MACHINE_CHIPS + 2 + 24 + (MACHINE_CPU_INSTANCES - 1) + 17
+# aggregation payload's leaf count, root and leaf-list digest, the count and digest of the public bus tuples
+MACHINE_HEADER_WORDS = 2 + MACHINE_CHIPS + 2 + 24 + (MACHINE_CPU_INSTANCES - 1) + 17 + 9
+PUB_TUPLE_WORDS = 16  # bus, verifier sends (1) / receives (0), multiplicity, number of elements, 12 element slots
+P2_REC_WORDS, FOLD_REC_WORDS = 20, 20
 
 
 def merkle_path_nodes(index: int, leaf, siblings):
@@ -153,6 +155,11 @@ def load_library() -> C.CDLL:
     lib.zksp_verify_aggregate.argtypes = [vp, vp, vp, vp, sz]
     lib.zksp_stdin_set_aggregation_keyed.argtypes = [vp, vp, vp, sz]
     lib.zksp_verify_aggregate_keyed.argtypes = [vp, vp, vp, vp, vp, sz]
+    lib.zksp_stdin_set_verified_leaf.argtypes = [vp, vp, vp, vp]
+    lib.zksp_leaf_public.argtypes = [vp, vp, vp, vp, sz, C.POINTER(sz)]
+    lib.zksp_verify_public.argtypes = [vp, vp, vp, vp, sz]
+    lib.zksp_verify_with_leaf.argtypes = [vp, vp, vp, vp, vp]
+    lib.zksp_proof_public_tuples.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.zksp_hip_machine_fetch_stage.argtypes = [vp, C.c_int, C.c_int, sz, vp, sz]
     lib.zksp_hip_machine_fetch_challenges.argtypes = [vp, sz, vp]
     lib.zksp_get_params.argtypes = [vp, C.POINTER(Params)]
@@ -195,7 +202,8 @@ ABI_SYMBOLS = [
     "zksp_execute", "zksp_execute_keccak", "zksp_opcode_name", "zksp_machine_trace", "zksp_mtrace_free",
     "zksp_mtrace_section", "zksp_mtrace_info", "zksp_vk_machine", "zksp_mtrace_heights", "zksp_machine_body_words",
     "zksp_machine_chip_widths", "zksp_machine_cover_heights", "zksp_stdin_set_aggregation", "zksp_proof_aggregation", "zksp_verify_aggregate",
-    "zksp_stdin_set_aggregation_keyed", "zksp_verify_aggregate_keyed", "zksp_hip_machine_fetch_stage", "zksp_hip_machine_fetch_challenges",
+    "zksp_stdin_set_aggregation_keyed", "zksp_verify_aggregate_keyed", "zksp_stdin_set_verified_leaf", "zksp_leaf_public", "zksp_verify_public",
+    "zksp_verify_with_leaf", "zksp_proof_public_tuples", "zksp_hip_machine_fetch_stage", "zksp_hip_machine_fetch_challenges",
     "zksp_hip_machine_load", "zksp_hip_machine_prove", "zksp_hip_machine_fetch_bodies", "zksp_hip_machine_fetch_roots", "zksp_machine_proof_from_body", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
     "zksp_hip_prove_resident", "zksp_proof_from_body", "zksp_hip_fetch_bodies", "zksp_hip_fetch_roots", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
     "zksp_hip_profile_enable", "zksp_hip_profile_read", "zksp_hip_profile_reset", "zksp_dev_malloc", "zksp_dev_free",
@@ -291,6 +299,16 @@ class SP1ProofWithPublicValues(_Handle):
         if rc:
             raise ZkspError(rc, "proof_aggregation")
         return int(n.value), [int(x) for x in root]
+
+    @property
+    def public_tuples(self):
+        """(number of public bus tuples the proof's buses close with, the sponge digest of their list as 8 canonical words);
+        (0, zeros) for a proof without a leaf-proof check."""
+        n, dg = C.c_uint32(), (C.c_uint32 * 8)()
+        rc = self._lib.zksp_proof_public_tuples(self._h, C.byref(n), dg)
+        if rc:
+            raise ZkspError(rc, "proof_public_tuples")
+        return int(n.value), [int(x) for x in dg]
 
     def to_bytes(self) -> bytes:
         p, n = C.POINTER(C.c_uint8)(), C.c_size_t()
@@ -472,6 +490,44 @@ class ProverClient:
         if rc:
             raise VerificationError(rc, self.last_error())
 
+    def set_verified_leaf(self, stdin: SP1Stdin, leaf: SP1ProofWithPublicValues, leaf_vk: VerifyingKey) -> None:
+        """Leaf-proof check (``zksp_stdin_set_verified_leaf``, SURVEY.md row f4 stage 2a): the proof made from ``stdin`` also
+        establishes that the query phase of ``leaf`` verifies - every Merkle opening of its four commitment rounds and of
+        its FRI layers, and the folding chain down to the final constant.  Raises VerificationError if ``leaf`` does not
+        verify under this client's parameters."""
+        rc = self._lib.zksp_stdin_set_verified_leaf(self._h, stdin._h, leaf._h, leaf_vk._h)
+        if rc:
+            raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
+
+    def leaf_public(self, leaf: SP1ProofWithPublicValues, leaf_vk: VerifyingKey):
+        """The statement of a leaf-proof check (``zksp_leaf_public``): the public bus tuples, numpy [n][16] canonical words."""
+        import numpy as np
+        n = C.c_size_t()
+        rc = self._lib.zksp_leaf_public(self._h, leaf._h, leaf_vk._h, None, 0, C.byref(n))
+        if rc:
+            raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
+        out = np.zeros((n.value, PUB_TUPLE_WORDS), np.uint32)
+        rc = self._lib.zksp_leaf_public(self._h, leaf._h, leaf_vk._h, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n))
+        if rc:
+            raise ZkspError(rc, self.last_error())
+        return out
+
+    def verify_public(self, proof: SP1ProofWithPublicValues, vk: VerifyingKey, tuples) -> None:
+        """``verify`` for a proof whose buses close with these public tuples ([n][16] canonical words)."""
+        import numpy as np
+        tv = np.ascontiguousarray(tuples, dtype=np.uint32).reshape(-1, PUB_TUPLE_WORDS)
+        rc = self._lib.zksp_verify_public(self._h, proof._h, vk._h, tv.ctypes.data_as(C.c_void_p), len(tv))
+        if rc:
+            raise VerificationError(rc, self.last_error())
+
+    def verify_with_leaf(self, proof: SP1ProofWithPublicValues, vk: VerifyingKey, leaf: SP1ProofWithPublicValues,
+                         leaf_vk: VerifyingKey) -> None:
+        """``verify`` for a proof with a leaf-proof check: additionally, the statement it closes its buses with is the one
+        ``leaf`` (which is verified on the way) gives."""
+        rc = self._lib.zksp_verify_with_leaf(self._h, proof._h, vk._h, leaf._h, leaf_vk._h)
+        if rc:
+            raise VerificationError(rc, self.last_error())
+
     def execute(self, pk: ProvingKey, stdin: SP1Stdin, keccak_mode: int = KECCAK_OBSERVE):
         """Runs the guest only; returns (ExecReport, public_values, stderr_text, rc)."""
         rep = ExecReport()
@@ -516,7 +572,9 @@ class ProverClient:
             return {"cycles": sec(0, np.uint32, 12), "keccak": sec(1, kdt), "memfinal": sec(2, np.uint32, 5),
                     "muls": sec(3, np.uint32, 3), "prog_mult": sec(4, np.uint32), "alu_idx": sec(5, np.uint32),
                     "sub_idx": sec(9, np.uint32), "bw_idx": sec(10, np.uint32), "ecall_idx": sec(11, np.uint32), "program": sec(6, np.uint32, 9), "image": sec(7, np.uint32, 2),
-                    "public_values": bytes(sec(8, np.uint8)), "info": info}
+                    "public_values": bytes(sec(8, np.uint8)), "info": info,
+                    "leaf_p2_rows": sec(12, np.uint32, P2_REC_WORDS), "leaf_fold_rows": sec(13, np.uint32, FOLD_REC_WORDS),
+                    "leaf_pub_tuples": sec(14, np.uint32, PUB_TUPLE_WORDS)}
         finally:
             self._lib.zksp_mtrace_free(h)
 

@@ -31,7 +31,7 @@ namespace mach {
 // so the trees, the quotient and the FRI domain have a quarter of the height and the per-row costs of a commitment are
 // shared by six instances.
 enum Chip { kCpu = 0, kKeccak, kKmem, kMemFinal, kImage, kProgram, kMul, kTable, kCpu2, kAlu, kAlu2, kSub, kSub2, kBw, kBw2, kP2, kEcall,
-            kCpu3, kCpu4, kCpu5, kCpu6, kCpu7, kCpu8, kNumChips };
+            kCpu3, kCpu4, kCpu5, kCpu6, kCpu7, kCpu8, kFold, kNumChips };
 constexpr int kNumCpuInst = 8;
 // CPU instance i <-> chip (the first two keep their old places in the proof order)
 ZKSP_HD constexpr int cpu_chip(int i) { return i == 0 ? kCpu : i == 1 ? kCpu2 : kCpu3 + (i - 2); }
@@ -118,20 +118,48 @@ static_assert(kBwWidth == 16, "bitwise chip layout");
 constexpr int SW_IS_REAL = 0, SW_SEL = 1, SW_O = SW_SEL + 6, SW_A = SW_O + 4, SW_MB = SW_A + 2, SW_CB = SW_MB + 4,
               SW_S = SW_CB + 2, SW_SELB = SW_S + 1, kSubWidth = SW_SELB + 1;
 static_assert(kSubWidth == 21, "sub-word chip layout");
-// ---- Poseidon2 chip (stage 1): one width-16 permutation per row = one 2-to-1 compression of
-//      a Merkle tree of 8-word digests.  Row r holds heap node K = r + 1 (root 1, children 2K and 2K + 1, the n leaves at
-//      n .. 2n - 1): it consumes its children's digests from the DIGEST bus and produces its own; the verifier supplies
-//      the leaves and takes the root.  Columns: the input state, and per S-box its cube and its seventh power. ----
-constexpr int P2_IS_REAL = 0, P2_KL = 1, P2_KH = 2, P2_IN = 3, P2_EXT = P2_IN + 16, P2_INT = P2_EXT + 256, kP2Width = P2_INT + 26;
-static_assert(kP2Width == 301, "Poseidon2 chip layout");
+// ---- Poseidon2 chip: one width-16 permutation per row.  Six kinds of rows:
+//   N   (stage 1) a node K of a heap of digests (root 1, children 2K and 2K + 1): consumes its children's digests from the
+//       DIGEST bus, produces its own; the verifier supplies the leaves and takes the root;
+//   SZ / SC  (stage 2a: the openings of a leaf proof) a sponge row: eight absorbed words over the capacity carried from the
+//       row before (SC) or over the zero state (SZ: the first block of a hash);
+//   PL / PR  a step of a Merkle path: the running digest (the output of the row before) is the left / right input, the
+//       sibling the other, free; K' = 2 K + [right], M' = 2 M;
+//   J   an injection of a mixed-height tree: the running digest on the left, on the right the hash of the shorter matrices'
+//       row, consumed from the DIGEST bus where the sponge that made it (a segment of S rows elsewhere, labelled with this
+//       row's T, K, M) put it; K' = K, M' = M + 1.
+// A run (one opening) starts with a sponge over the zero state flagged NEW (K = 1, M = 0): K collects the position bits,
+// M the levels an injection followed, T names the opening; its last row sends (T, 0, K, M, digest), which the verifier
+// consumes with the root it knows - so position, shape and root of every opening are the verifier's.  Columns: the
+// input state, and per S-box its cube and its seventh power. ----
+constexpr int P2_IS_REAL = 0, P2_KL = 1, P2_KH = 2, P2_T = 3, P2_M = 4, P2_FN = 5, P2_SZ = 6, P2_SC = 7, P2_PL = 8, P2_PR = 9, P2_FJ = 10,
+              P2_NEW = 11, P2_SND = 12, P2_FR = 13, P2_IN = 14, P2_EXT = P2_IN + 16, P2_INT = P2_EXT + 256, kP2Width = P2_INT + 26;
+static_assert(kP2Width == 312, "Poseidon2 chip layout");
+// records the rows are expanded from (20 words): flags, T, K, M, the 16 input words
+enum P2Kind { P2K_NONE = 0, P2K_NODE, P2K_SZ, P2K_SC, P2K_PL, P2K_PR, P2K_J };
+constexpr uint32_t kP2RecWords = 20, kP2FlagNew = 16, kP2FlagSnd = 32, kP2FlagFri = 64;  // flags = kind | ...
+// tags of a leaf proof's openings: query q, tree r (0 preprocessed, 1 main, 2 permutation, 3 quotient, 4 + k FRI layer k)
+constexpr uint32_t kLeafTagStride = 64;
+ZKSP_HD constexpr uint32_t leaf_tag(uint32_t q, uint32_t r) { return 1 + kLeafTagStride * q + r; }
+// ---- FRI fold chip (row f4, stage 2a): one row per query and layer of a leaf proof's FRI.  The sibling pair (LO, HI)
+//      arrives from the sponge row that hashed it (PAIR bus), the layer's challenge, the inverse of the pair's domain
+//      point and the position bit from the verifier (FRIQ bus); E - the value the layer must show at the query's
+//      position - is LO or HI by the bit; F = (LO + HI) / 2 + BETA (LO - HI) XINV / 2 is the folded value; the next layer's
+//      E is F plus the reduced opening that joins there (RO bus, the verifier's in stage 2a); the last layer's F goes to
+//      the verifier (FIN bus), who knows the final constant. ----
+constexpr int FO_IS_REAL = 0, FO_FIRST = 1, FO_LAST = 2, FO_Q = 3, FO_K = 4, FO_BIT = 5, FO_XINV = 6, FO_HASRO = 7, FO_BETA = 8,
+              FO_LO = 12, FO_HI = 16, FO_E = 20, FO_F = 24, FO_RO = 28, kFoldWidth = 32;
+constexpr uint32_t kFoldRecWords = 20;  // flags (first, last << 1, bit << 2, hasro << 3), q, k, xinv, beta, lo, hi, ro
 // ---- table chip: 2^16 rows; preprocessed (x, y: the row index's bytes; na: index not a multiple of 4; nt: index above
-//      kAddrHiMax; x ^ y; x & y); main: multiplicities of range16 (kind 0), 4-aligned range16 (kind 1), high address limb
+//      kAddrHiMax or zero; x ^ y; x & y); main: multiplicities of range16 (kind 0), 4-aligned range16 (kind 1), high address limb
 //      (kind 2), byte pair, and the byte operations xor / or / and ----
 constexpr int TB_P_X = 0, TB_P_Y = 1, TB_P_NA = 2, TB_P_NT = 3, TB_P_XOR = 4, TB_P_AND = 5, kTablePrepWidth = 6, TB_M_R16 = 0,
               TB_M_AL = 1, TB_M_TOP = 2, TB_M_BY = 3, TB_M_XOR = 4, TB_M_OR = 5, TB_M_AND = 6, kTableWidth = 7, kTableLogH = 16;
-constexpr uint32_t kAddrHiMax = 0x77FFu;  // high limb of the largest address / jump target
+// high limb of the largest address / jump target; the smallest is 1: a load, store or keccak state below 0x10000 has no
+// table row, so no memory access can name a register (addresses 0 .. 31 on the memory bus)
+constexpr uint32_t kAddrHiMax = 0x77FEu;
 
-enum Bus { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP, BUS_DIGEST, BUS_ECALL };
+enum Bus { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP, BUS_DIGEST, BUS_ECALL, BUS_PAIR, BUS_FRIQ, BUS_RO, BUS_FIN };
 
 // Ctx interface:
 //   using F;  F local(int col); F next(int col); F prep(int col) (preprocessed column of the row);
@@ -318,8 +346,10 @@ ZKSP_HD void eval_ecall(Ctx& ctx) {
   ctx.emit(same * L(EC_A_HI));
   const F pc4 = L(EC_PC) + ZKSP_K(4);
   ctx.emit(real * (L(EC_NP) - pc4) - L(EC_SC + SC_HALT) * (ctx.pub(kPubPadPc) - pc4));
+  // COMMIT / COMMIT_DEFERRED: the word index in a0 is the whole register (the PUBC tuple carries its low limb only)
+  ctx.emit((L(EC_SC + SC_COMMIT) + L(EC_SC + SC_DEFER)) * L(EC_C_HI));
 }
-constexpr int kEcallConstraints = 12;
+constexpr int kEcallConstraints = 13;
 
 template <class Ctx>
 ZKSP_HD void eval_kmem(Ctx& ctx) {
@@ -594,7 +624,8 @@ ZKSP_HD void eval_sub(Ctx& ctx) {
 constexpr int kSubConstraints = 31;
 
 // ---- Poseidon2 chip: every S-box through its cube (x^3, then x^7 = (x^3)^2 x: degree 3); between S-boxes the state is
-// linear in the columns.  Ctx::p2(): the permutation's constants (Montgomery words).  286 constraints. ----
+// linear in the columns.  Ctx::p2(): the permutation's constants (Montgomery words).  286 permutation constraints, then the
+// 67 that tie the rows of an opening together (layout comment above). ----
 template <class F>
 ZKSP_HD void p2air_external_linear(F* s) {
 #pragma unroll
@@ -617,10 +648,9 @@ template <class Ctx>
 ZKSP_HD void eval_p2(Ctx& ctx) {
   using F = typename Ctx::F;
   const P2Consts* kc = ctx.p2();
-  const F one = ctx.k(kR1);
-  ctx.emit(bool_c(L(P2_IS_REAL), one));
-  ctx.emit(ctx.is_trans() * ctx.next(P2_IS_REAL) * (one - L(P2_IS_REAL)));  // the real rows are a prefix
-  // (the node's key is free: two limbs, range-checked by lookups; the DIGEST bus ties the nodes together)
+  const F one = ctx.k(kR1), real = L(P2_IS_REAL);
+  ctx.emit(bool_c(real, one));
+  ctx.emit(ctx.is_trans() * ctx.next(P2_IS_REAL) * (one - real));  // the real rows are a prefix
   F st[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) st[i] = L(P2_IN + i);
@@ -648,15 +678,102 @@ ZKSP_HD void eval_p2(Ctx& ctx) {
     }
     p2air_external_linear(st);
   }
+  // st[] now holds the permutation's 16 output words, linear in the last round's columns.
+  // Row kinds: one per real row; NEW lives on sponge rows, FR on first blocks, SND anywhere but on a node row (which always
+  // sends) or a padding row.
+  const F fn = L(P2_FN), sz = L(P2_SZ), sc = L(P2_SC), pl = L(P2_PL), pr = L(P2_PR), fj = L(P2_FJ), nw = L(P2_NEW), snd = L(P2_SND),
+          fr = L(P2_FR);
+  ctx.emit(bool_c(fn, one)); ctx.emit(bool_c(sz, one)); ctx.emit(bool_c(sc, one)); ctx.emit(bool_c(pl, one)); ctx.emit(bool_c(pr, one));
+  ctx.emit(bool_c(fj, one)); ctx.emit(bool_c(nw, one)); ctx.emit(bool_c(snd, one)); ctx.emit(bool_c(fr, one));
+  const F chain = sc + pl + pr + fj;  // the kinds that take over from the row before
+  ctx.emit(fn + sz + chain - real);
+  ctx.emit(nw * (one - sz - sc));
+  ctx.emit(snd * (one - sz - chain));
+  ctx.emit(fr * (one - sz));
+  // a first block starts from the zero state; the first block of a run from K = 1, M = 0
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ctx.emit(sz * L(P2_IN + 8 + i));
+  const F key = L(P2_KL) + ZKSP_K(65536) * L(P2_KH), m = L(P2_M);
+  ctx.emit(sz * nw * (key - one));
+  ctx.emit(sz * nw * m);
+  ctx.emit(ctx.is_first() * chain);  // nothing precedes row 0 (so the constraints below hold cyclically)
+  // the next row, where it takes over from this one
+  const F nsc = ctx.next(P2_SC), npl = ctx.next(P2_PL), npr = ctx.next(P2_PR), nfj = ctx.next(P2_FJ), npath = npl + npr;
+  const F nkey = ctx.next(P2_KL) + ZKSP_K(65536) * ctx.next(P2_KH), nm = ctx.next(P2_M);
+  ctx.emit((nsc + npath + nfj) * (ctx.next(P2_T) - L(P2_T)));
+  // ... a sponge goes on: the capacity, the labels and the flag of its run; only a sponge row precedes it
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ctx.emit(nsc * (ctx.next(P2_IN + 8 + i) - st[8 + i]));
+  ctx.emit(nsc * (nkey - key));
+  ctx.emit(nsc * (nm - m));
+  ctx.emit(nsc * (ctx.next(P2_NEW) - nw));
+  ctx.emit(nsc * (one - sz - sc));
+  // ... a path step: the running digest on its side, one more position bit, one more level; it follows the leaf's sponge
+  // (a run's, not an injected matrix's), a path step or an injection
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ctx.emit(npl * (ctx.next(P2_IN + i) - st[i]));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ctx.emit(npr * (ctx.next(P2_IN + 8 + i) - st[i]));
+  ctx.emit(npath * (nkey - key.dbl() - npr));
+  ctx.emit(npath * (nm - m.dbl()));
+  ctx.emit(npath * (one - (sz + sc) * nw - pl - pr - fj));
+  // ... an injection: the running digest on the left, the level marked; only a path step precedes it
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ctx.emit(nfj * (ctx.next(P2_IN + i) - st[i]));
+  ctx.emit(nfj * (nkey - key));
+  ctx.emit(nfj * (nm - m - one));
+  ctx.emit(nfj * (one - pl - pr));
 }
-constexpr int kP2Constraints = 2 + 8 * 32 + 13 * 2;
+constexpr int kP2Constraints = 2 + 8 * 32 + 13 * 2 + 67;
+
+// ---- FRI fold chip: 31 constraints (layout comment above); the extension field is F_p[x] / (x^4 - 11) ----
+template <class Ctx>
+ZKSP_HD void eval_fold(Ctx& ctx) {
+  using F = typename Ctx::F;
+  const F one = ctx.k(kR1), real = L(FO_IS_REAL), first = L(FO_FIRST), last = L(FO_LAST), bit = L(FO_BIT), hasro = L(FO_HASRO);
+  ctx.emit(bool_c(real, one)); ctx.emit(bool_c(first, one)); ctx.emit(bool_c(last, one)); ctx.emit(bool_c(bit, one));
+  ctx.emit(bool_c(hasro, one));
+  ctx.emit(ctx.is_trans() * ctx.next(FO_IS_REAL) * (one - real));  // the real rows are a prefix
+  ctx.emit(first * (one - real)); ctx.emit(last * (one - real)); ctx.emit(hasro * (one - real));
+  ctx.emit(first * L(FO_K));
+  ctx.emit(ctx.is_first() * (real - first));
+  F lo[4], hi[4], d[4], be[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { lo[i] = L(FO_LO + i); hi[i] = L(FO_HI + i); d[i] = lo[i] - hi[i]; be[i] = L(FO_BETA + i); }
+  // the value the layer shows at the query's position
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ctx.emit(L(FO_E + i) - lo[i] + bit * d[i]);
+  // 2 F = LO + HI + XINV * BETA * (LO - HI)
+  {
+    const F k11 = ZKSP_K(11), xinv = L(FO_XINV);
+    const F p0 = be[0] * d[0] + k11 * (be[1] * d[3] + be[2] * d[2] + be[3] * d[1]);
+    const F p1 = be[0] * d[1] + be[1] * d[0] + k11 * (be[2] * d[3] + be[3] * d[2]);
+    const F p2 = be[0] * d[2] + be[1] * d[1] + be[2] * d[0] + k11 * (be[3] * d[3]);
+    const F p3 = be[0] * d[3] + be[1] * d[2] + be[2] * d[1] + be[3] * d[0];
+    ctx.emit(L(FO_F + 0).dbl() - lo[0] - hi[0] - xinv * p0);
+    ctx.emit(L(FO_F + 1).dbl() - lo[1] - hi[1] - xinv * p1);
+    ctx.emit(L(FO_F + 2).dbl() - lo[2] - hi[2] - xinv * p2);
+    ctx.emit(L(FO_F + 3).dbl() - lo[3] - hi[3] - xinv * p3);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ctx.emit((one - hasro) * L(FO_RO + i));
+  // the next row goes on with this query unless it starts one (or is padding)
+  const F cont = ctx.next(FO_IS_REAL) - ctx.next(FO_FIRST);
+  ctx.emit(cont * (ctx.next(FO_Q) - L(FO_Q)));
+  ctx.emit(cont * (ctx.next(FO_K) - L(FO_K) - one));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ctx.emit(cont * (ctx.next(FO_E + i) - L(FO_F + i) - L(FO_RO + i)));
+  ctx.emit(last * cont);
+  ctx.emit((real - last) * (one - cont));
+}
+constexpr int kFoldConstraints = 31;
 
 // every image word is sent exactly once
 template <class Ctx>
 ZKSP_HD void eval_image(Ctx& ctx) {
   ctx.emit(L(0) - ctx.prep(IMG_P_REAL));
 }
-// only multiples of 4 answer aligned lookups, only values up to kAddrHiMax high-address-limb lookups
+// only multiples of 4 answer aligned lookups, only values 1 .. kAddrHiMax high-address-limb lookups
 template <class Ctx>
 ZKSP_HD void eval_table(Ctx& ctx) {
   ctx.emit(L(TB_M_AL) * ctx.prep(TB_P_NA));
@@ -674,7 +791,7 @@ constexpr int kKeccakConstraints = ka::kNumConstraints + 1;
 ZKSP_HD constexpr int num_constraints(int chip) {
   return is_cpu_chip(chip) ? kCpuConstraints : chip == kKeccak ? kKeccakConstraints : chip == kKmem ? kKmemConstraints
        : chip == kMemFinal ? kMemFinalConstraints : chip == kImage ? 1 : chip == kProgram ? 0 : chip == kMul ? kMulConstraints
-       : chip == kTable ? 2 : is_alu_chip(chip) ? kAluConstraints : is_sub_chip(chip) ? kSubConstraints : is_bw_chip(chip) ? kBwConstraints : chip == kP2 ? kP2Constraints : chip == kEcall ? kEcallConstraints : 0;
+       : chip == kTable ? 2 : is_alu_chip(chip) ? kAluConstraints : is_sub_chip(chip) ? kSubConstraints : is_bw_chip(chip) ? kBwConstraints : chip == kP2 ? kP2Constraints : chip == kEcall ? kEcallConstraints : chip == kFold ? kFoldConstraints : 0;
 }
 
 }  // namespace mach

@@ -31,8 +31,7 @@ __device__ __forceinline__ void leaf_hash_body(const uint32_t* __restrict__ mat,
   }
   if (c0 < width) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (c0 + i < width) s[i] = Fp::raw(m[(size_t)(c0 + i) * n_rows]);
+    for (int i = 0; i < 8; ++i) s[i] = c0 + i < width ? Fp::raw(m[(size_t)(c0 + i) * n_rows]) : Fp::zero();  // the last block is zero-filled
     p2_permute(s, consts);
   }
   uint4* d = reinterpret_cast<uint4*>(tree + (size_t)blockIdx.y * tree_stride + (size_t)row * 8);
@@ -133,7 +132,7 @@ __global__ __launch_bounds__(kHashThreads) void leaf_hash_coop_kernel(const uint
     for (int j = 0; j < kPrefetch; ++j) {
       const int c = c0 + 8 * j;
       if (c < width) {  // uniform
-        if (e < 8 && c + e < width) x = (int32_t)cur[j];
+        if (e < 8) x = (int32_t)cur[j];  // (fetch() returns zero beyond the width: the last block is zero-filled)
         x = p2_permute_coop_signed(x, cc, consts);
       }
     }

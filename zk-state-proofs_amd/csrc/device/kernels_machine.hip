@@ -236,8 +236,8 @@ __global__ __launch_bounds__(kMT) void bw_trace_kernel(MachineRecords rec, uint3
   }
 }
 
-// Poseidon2 chip: row r is heap node K = r + 1 of the aggregation payload (real while K < n): its input state is its two
-// children's digests, its columns the cubes and seventh powers of every S-box of the permutation
+// Poseidon2 chip: row r is record r (air_machine.hpp: a heap node of an aggregation payload, or a sponge / path / injection
+// row of a leaf-proof check): its flags, labels and input state, and the cubes and seventh powers of every S-box
 __global__ __launch_bounds__(64) void p2_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh) {
   const size_t h = (size_t)1 << logh;
   const size_t r = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -245,18 +245,23 @@ __global__ __launch_bounds__(64) void p2_trace_kernel(MachineRecords rec, uint32
   const int b = blockIdx.y;
   const Col o{trace + (size_t)b * kP2Width * h + r, h};
   const P2Consts* kc = rec.consts;
-  // row r: the r-th ancestor (ascending keys) of the supplied nodes: its key and its children's digests
   const bool real = r < rec.counts[kCountWords * b + 8];
-  const uint32_t* row = rec.agg_heap + ((size_t)b * rec.cap_agg + (real ? r : 0)) * 17;
+  const uint32_t* row = rec.agg_heap + ((size_t)b * rec.cap_agg + (real ? r : 0)) * kP2RecWords;
+  const uint32_t flags = real ? row[0] : 0u, kind = flags & 15u;
   Fp st[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    st[i] = real ? Fp::from_canonical(row[1 + i]) : Fp::zero();
+    st[i] = real ? Fp::from_canonical(row[4 + i]) : Fp::zero();
     o.put(P2_IN + i, st[i].v);
   }
   o.flag(P2_IS_REAL, real);
-  o.val(P2_KL, real ? row[0] & 0xffff : 0u);
-  o.val(P2_KH, real ? row[0] >> 16 : 0u);
+  o.val(P2_KL, real ? row[2] & 0xffff : 0u);
+  o.val(P2_KH, real ? row[2] >> 16 : 0u);
+  o.val(P2_T, real ? row[1] : 0u);
+  o.val(P2_M, real ? row[3] : 0u);
+  o.flag(P2_FN, kind == P2K_NODE); o.flag(P2_SZ, kind == P2K_SZ); o.flag(P2_SC, kind == P2K_SC); o.flag(P2_PL, kind == P2K_PL);
+  o.flag(P2_PR, kind == P2K_PR); o.flag(P2_FJ, kind == P2K_J);
+  o.flag(P2_NEW, (flags & kP2FlagNew) != 0); o.flag(P2_SND, (flags & kP2FlagSnd) != 0); o.flag(P2_FR, (flags & kP2FlagFri) != 0);
   p2air_external_linear(st);
   for (int rd = 0; rd < 8; ++rd) {
     if (rd == 4) {
@@ -281,6 +286,34 @@ __global__ __launch_bounds__(64) void p2_trace_kernel(MachineRecords rec, uint32
     }
     p2air_external_linear(st);
   }
+}
+
+// FRI fold chip: row r is record r (one query and layer of a leaf proof's FRI): the verifier's layer tuple, the pair, the
+// value the layer shows at the query's position and the folded value
+__global__ __launch_bounds__(kMT) void fold_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh) {
+  const size_t h = (size_t)1 << logh;
+  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (r >= h) return;
+  const int b = blockIdx.y;
+  const Col o{trace + (size_t)b * kFoldWidth * h + r, h};
+  if (r >= rec.counts[kCountWords * b + 10]) { o.zero(0, kFoldWidth); return; }
+  const uint32_t* row = rec.fold_rows + ((size_t)b * rec.cap_fold + r) * kFoldRecWords;
+  const uint32_t flags = row[0];
+  const bool bit = (flags & 4u) != 0;
+  o.put(FO_IS_REAL, kR1);
+  o.flag(FO_FIRST, (flags & 1u) != 0); o.flag(FO_LAST, (flags & 2u) != 0); o.flag(FO_BIT, bit); o.flag(FO_HASRO, (flags & 8u) != 0);
+  o.val(FO_Q, row[1]); o.val(FO_K, row[2]); o.val(FO_XINV, row[3]);
+  Fp4 beta, lo, hi;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    beta.c[i] = Fp::from_canonical(row[4 + i]); lo.c[i] = Fp::from_canonical(row[8 + i]); hi.c[i] = Fp::from_canonical(row[12 + i]);
+    o.put(FO_BETA + i, beta.c[i].v); o.put(FO_LO + i, lo.c[i].v); o.put(FO_HI + i, hi.c[i].v);
+    o.val(FO_RO + i, row[16 + i]);
+  }
+  const Fp half = Fp::from_canonical((kP + 1) / 2), xinv = Fp::from_canonical(row[3]);
+  const Fp4 f = (lo + hi) * half + beta * ((lo - hi) * (half * xinv)), e = bit ? hi : lo;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { o.put(FO_E + i, e.c[i].v); o.put(FO_F + i, f.c[i].v); }
 }
 
 // One sub-word-chip instance: row r is event row0 + r of the list sub_idx
@@ -468,6 +501,7 @@ void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& re
       hipLaunchKernelGGL(p2_trace_kernel, dim3((unsigned)((h + 63) / 64), batch), dim3(64), 0, stream, rec, trace, logh);
       break;
     case kEcall: hipLaunchKernelGGL(ecall_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
+    case kFold: hipLaunchKernelGGL(fold_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
     case kMemFinal: hipLaunchKernelGGL(memfinal_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
     case kMul:
       hipLaunchKernelGGL(mul_trace_kernel, dim3((unsigned)((h + 63) / 64), batch), dim3(64), 0, stream, rec, trace, logh);
@@ -525,6 +559,8 @@ __global__ __launch_bounds__(kMT) void mmcs_leaf_kernel(LeafArgs a, const P2Cons
           base = a.seg[sg].p + (size_t)b * a.seg[sg].bstride + r;
         }
         s[i] = (int32_t)base[(size_t)(vc - a.start[sg]) * n];
+      } else {
+        s[i] = 0;  // the last block is zero-filled
       }
     }
     p2_permute_signed(s, consts);
@@ -573,7 +609,7 @@ __global__ __launch_bounds__(kMT) void mmcs_leaf_coop_kernel(LeafArgs a, const P
     for (int j = 0; j < kPrefetch; ++j) {
       const int c = c0 + 8 * j;
       if (c < total) {  // uniform
-        if (e < 8 && c + e < total) x = (int32_t)cur[j];
+        if (e < 8) x = (int32_t)cur[j];  // (fetch() returns zero beyond the width: the last block is zero-filled)
         x = p2_permute_coop_signed(x, cc, consts);
       }
     }
@@ -720,7 +756,7 @@ __global__ __launch_bounds__(kMT) void table_count_kernel(const Interaction* __r
       }
       // a value without a table row is not counted: the buses of such a (dishonest or unprovable) run do not balance
       if (it.bus == BUS_RANGE) {
-        const bool ok = m != 0 && v2 < kTableRows && v1 <= 2 && !(v1 == 1 && (v2 & 3)) && !(v1 == 2 && v2 > kAddrHiMax);
+        const bool ok = m != 0 && v2 < kTableRows && v1 <= 2 && !(v1 == 1 && (v2 & 3)) && !(v1 == 2 && (v2 == 0 || v2 > kAddrHiMax));
         const bool hot = v1 != 1 && v2 < kTableLdsBins;
         wave_hist_add(lds, (v1 == 2 ? kTableLdsBins : 0) + v2, m, ok && hot);  // (the kind differs between lanes)
         if (ok && !hot) atomicAdd(&hb[(size_t)(v1 == 0 ? TB_M_R16 : v1 == 1 ? TB_M_AL : TB_M_TOP) * kTableRows + v2], m);
@@ -752,7 +788,7 @@ __global__ __launch_bounds__(kMT) void cpu_table_count_kernel(const uint32_t* __
   uint32_t* hb = hist + (size_t)b * kTableWidth * kTableRows;
   const size_t r0 = (size_t)blockIdx.x * kTableRowsPerBlock;
   auto range = [&](uint32_t kind, uint32_t v, uint32_t m) {
-    const bool ok = m != 0 && v < kTableRows && kind <= 2 && !(kind == 1 && (v & 3)) && !(kind == 2 && v > kAddrHiMax);
+    const bool ok = m != 0 && v < kTableRows && kind <= 2 && !(kind == 1 && (v & 3)) && !(kind == 2 && (v == 0 || v > kAddrHiMax));
     const bool hot = kind != 1 && v < kTableLdsBins;
     wave_hist_add(lds, (kind == 2 ? kTableLdsBins : 0) + v, m, ok && hot);
     if (ok && !hot) atomicAdd(&hb[(size_t)(kind == 0 ? TB_M_R16 : kind == 1 ? TB_M_AL : TB_M_TOP) * kTableRows + v], m);
@@ -1366,6 +1402,7 @@ __global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
   else if constexpr (is_bw_chip(CHIP)) eval_bw(ctx);
   else if constexpr (CHIP == kP2) eval_p2(ctx);
   else if constexpr (CHIP == kEcall) eval_ecall(ctx);
+  else if constexpr (CHIP == kFold) eval_fold(ctx);
   ctx.flush();
   logup_constraints(a, pi, &ctx.acc);
   const Fp4 q = ctx.acc * Fp::raw(pi.c ? a.zh_inv[1] : a.zh_inv[0]);
@@ -1504,6 +1541,7 @@ void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a) {
     case kBw2: hipLaunchKernelGGL(machine_quotient_kernel<kBw>, grid, block, 0, stream, a); break;
     case kP2: hipLaunchKernelGGL(machine_quotient_kernel<kP2>, grid, block, 0, stream, a); break;
     case kEcall: hipLaunchKernelGGL(machine_quotient_kernel<kEcall>, grid, block, 0, stream, a); break;
+    case kFold: hipLaunchKernelGGL(machine_quotient_kernel<kFold>, grid, block, 0, stream, a); break;
     case kKmem: hipLaunchKernelGGL(machine_quotient_kernel<kKmem>, grid, block, 0, stream, a); break;
     case kMemFinal: hipLaunchKernelGGL(machine_quotient_kernel<kMemFinal>, grid, block, 0, stream, a); break;
     case kImage: hipLaunchKernelGGL(machine_quotient_kernel<kImage>, grid, block, 0, stream, a); break;

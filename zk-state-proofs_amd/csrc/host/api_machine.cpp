@@ -3,6 +3,7 @@
 #include "../../../include/zksp.h"
 
 #include <cstring>
+#include <memory>
 #include <new>
 
 #include "api_types.hpp"
@@ -11,10 +12,10 @@
 
 using namespace zksp;
 
-// Header (version, chip heights, exit code, digests, key digest), public values, body: the v12 proof object.
+// Header (version, chip heights, exit code, digests, key digest, payload words), public values, body: the proof object.
 int machine_proof_from_parts(const zksp_pk* pk, const ExecutionRecord& r, const int* lh, const uint32_t* handover_pc,
-                             const std::vector<uint32_t>& agg_leaves, const std::vector<uint32_t>& agg_keys, const uint32_t* body,
-                             size_t body_words, zksp_proof** out) {
+                             const std::vector<uint32_t>& agg_leaves, const std::vector<uint32_t>& agg_keys,
+                             const LeafCheckLog* leaf_check, const uint32_t* body, size_t body_words, zksp_proof** out) {
   zksp_proof* p = new (std::nothrow) zksp_proof();
   if (!p) return ZKSP_ERR_INVALID_ARG;
   try {
@@ -36,6 +37,11 @@ int machine_proof_from_parts(const zksp_pk* pk, const ExecutionRecord& r, const 
                               w + 29 + mach::kNumChips + kHo, w + 37 + mach::kNumChips + kHo, nullptr)) {
       delete p;
       return ZKSP_ERR_INVALID_ARG;
+    }
+    if (leaf_check) {  // the statement of the leaf-proof check: how many public bus tuples, and their digest
+      const size_t n_pub = leaf_check->pub_tuples.size() / mach::kPubTupleWords;
+      w[45 + mach::kNumChips + kHo] = (uint32_t)n_pub;
+      machine_pub_digest(leaf_check->pub_tuples.data(), n_pub, w + 46 + mach::kNumChips + kHo);
     }
     if (!r.public_values.empty()) memcpy(w + mach::kHeaderWords, r.public_values.data(), r.public_values.size());
     memcpy(w + mach::kHeaderWords + pvw, body, body_words * 4);
@@ -66,6 +72,7 @@ int zksp_machine_trace(zksp_client* c, const zksp_pk* pk, const zksp_stdin* stdi
     t->t.agg_leaves = stdin_->agg_leaves;
     t->t.agg_keys = stdin_->agg_keys;
     t->t.agg_rows = machine_agg_row_count(t->t.agg_keys.empty() ? nullptr : t->t.agg_keys.data(), t->t.agg_leaves.size() / 8);
+    t->t.leaf_check = stdin_->leaf_check;
   } catch (...) {
     delete t;
     return c->ctx.fail(ZKSP_ERR_EXECUTOR, "executor: out of memory while tracing the guest");
@@ -101,6 +108,9 @@ int zksp_mtrace_section(const zksp_mtrace* t, int which, const void** ptr, size_
     case ZKSP_MT_PROGRAM: *ptr = t->prog->rows.data(); *bytes = t->prog->rows.size() * sizeof(ProgramRow); break;
     case ZKSP_MT_IMAGE: *ptr = t->prog->image.data(); *bytes = t->prog->image.size() * sizeof(ImageRow); break;
     case ZKSP_MT_PUBLIC_VALUES: *ptr = m.rec.public_values.data(); *bytes = m.rec.public_values.size(); break;
+    case ZKSP_MT_LEAF_P2_ROWS: *ptr = m.leaf_check ? m.leaf_check->p2_rows.data() : nullptr; *bytes = m.leaf_check ? m.leaf_check->p2_rows.size() * 4 : 0; break;
+    case ZKSP_MT_LEAF_FOLD_ROWS: *ptr = m.leaf_check ? m.leaf_check->fold_rows.data() : nullptr; *bytes = m.leaf_check ? m.leaf_check->fold_rows.size() * 4 : 0; break;
+    case ZKSP_MT_LEAF_PUB_TUPLES: *ptr = m.leaf_check ? m.leaf_check->pub_tuples.data() : nullptr; *bytes = m.leaf_check ? m.leaf_check->pub_tuples.size() * 4 : 0; break;
     default: return ZKSP_ERR_INVALID_ARG;
   }
   return ZKSP_OK;
@@ -252,7 +262,7 @@ int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const 
   }
   uint32_t handover[mach::kNumCpuInst - 1];
   for (int k = 1; k < mach::kNumCpuInst; ++k) handover[k - 1] = machine_handover_pc(*t->prog, t->t, lh, k);
-  return machine_proof_from_parts(pk, t->t.rec, lh, handover, t->t.agg_leaves, t->t.agg_keys, body, body_words, out);
+  return machine_proof_from_parts(pk, t->t.rec, lh, handover, t->t.agg_leaves, t->t.agg_keys, t->t.leaf_check.get(), body, body_words, out);
 }
 
 int zksp_stdin_set_aggregation(zksp_stdin* s, const uint32_t* leaves, size_t n) {
@@ -300,6 +310,80 @@ int zksp_verify_aggregate_keyed(zksp_client* c, const zksp_proof* p, const zksp_
     return c->ctx.fail(ZKSP_ERR_VERIFY, "verify: out of memory");
   }
   if (rc) return c->ctx.fail(rc, "verify: " + err);
+  return ZKSP_OK;
+}
+
+// ---- leaf-proof check (stage 2a) ----
+static int leaf_check_of(zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf_vk, std::shared_ptr<LeafCheckLog>* out) {
+  if (c->ctx.params.proof_mode != ZKSP_PROOF_MACHINE || leaf->version != mach::kMachineVersion)
+    return c->ctx.fail(ZKSP_ERR_VERIFY, "leaf check: not a machine proof");
+  if (leaf->mhdr.agg_n || leaf->mhdr.pub_n) return c->ctx.fail(ZKSP_ERR_UNSUPPORTED, "leaf check: the leaf proof carries a payload of its own");
+  std::string err;
+  int rc;
+  try {
+    auto log = std::make_shared<LeafCheckLog>();
+    rc = verify_machine_proof(leaf->bytes.data(), leaf->bytes.size(), leaf_vk->machine, c->ctx.params.num_queries, c->ctx.params.pow_bits,
+                              &err, nullptr, 0, nullptr, nullptr, 0, log.get());
+    if (rc == 0) *out = std::move(log);
+  } catch (...) {
+    return c->ctx.fail(ZKSP_ERR_VERIFY, "leaf check: out of memory");
+  }
+  if (rc) return c->ctx.fail(rc, "leaf check: the leaf proof does not verify: " + err);
+  return ZKSP_OK;
+}
+
+int zksp_stdin_set_verified_leaf(zksp_client* c, zksp_stdin* s, const zksp_proof* leaf, const zksp_vk* leaf_vk) {
+  if (!c || !s) return ZKSP_ERR_INVALID_ARG;
+  if (!leaf) { s->leaf_check.reset(); return ZKSP_OK; }
+  if (!leaf_vk) return ZKSP_ERR_INVALID_ARG;
+  std::shared_ptr<LeafCheckLog> log;
+  const int rc = leaf_check_of(c, leaf, leaf_vk, &log);
+  if (rc) return rc;
+  s->leaf_check = std::move(log);
+  return ZKSP_OK;
+}
+
+int zksp_leaf_public(zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf_vk, uint32_t* out, size_t cap_words, size_t* n_tuples) {
+  if (!c || !leaf || !leaf_vk || !n_tuples) return ZKSP_ERR_INVALID_ARG;
+  std::shared_ptr<LeafCheckLog> log;
+  const int rc = leaf_check_of(c, leaf, leaf_vk, &log);
+  if (rc) return rc;
+  *n_tuples = log->pub_tuples.size() / mach::kPubTupleWords;
+  if (out) {
+    if (cap_words < log->pub_tuples.size()) return c->ctx.fail(ZKSP_ERR_INVALID_ARG, "leaf_public: buffer too small");
+    memcpy(out, log->pub_tuples.data(), log->pub_tuples.size() * 4);
+  }
+  return ZKSP_OK;
+}
+
+int zksp_verify_public(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const uint32_t* tuples, size_t n_tuples) {
+  if (!c || !p || !vk || (n_tuples && !tuples)) return ZKSP_ERR_INVALID_ARG;
+  if (c->ctx.params.proof_mode != ZKSP_PROOF_MACHINE || p->version != mach::kMachineVersion)
+    return c->ctx.fail(ZKSP_ERR_VERIFY, "verify: not a machine proof");
+  std::string err;
+  int rc;
+  try {
+    rc = verify_machine_proof(p->bytes.data(), p->bytes.size(), vk->machine, c->ctx.params.num_queries, c->ctx.params.pow_bits, &err,
+                              nullptr, 0, nullptr, tuples, n_tuples);
+  } catch (...) {
+    return c->ctx.fail(ZKSP_ERR_VERIFY, "verify: out of memory");
+  }
+  if (rc) return c->ctx.fail(rc, "verify: " + err);
+  return ZKSP_OK;
+}
+
+int zksp_verify_with_leaf(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const zksp_proof* leaf, const zksp_vk* leaf_vk) {
+  if (!c || !p || !vk || !leaf || !leaf_vk) return ZKSP_ERR_INVALID_ARG;
+  std::shared_ptr<LeafCheckLog> log;
+  const int rc = leaf_check_of(c, leaf, leaf_vk, &log);
+  if (rc) return rc;
+  return zksp_verify_public(c, p, vk, log->pub_tuples.data(), log->pub_tuples.size() / mach::kPubTupleWords);
+}
+
+int zksp_proof_public_tuples(const zksp_proof* p, uint32_t* n_tuples, uint32_t* digest8) {
+  if (!p || !n_tuples || !digest8 || p->version != mach::kMachineVersion) return ZKSP_ERR_INVALID_ARG;
+  *n_tuples = p->mhdr.pub_n;
+  memcpy(digest8, p->mhdr.pub_digest, 32);
   return ZKSP_OK;
 }
 

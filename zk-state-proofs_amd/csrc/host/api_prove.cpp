@@ -126,6 +126,8 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       traces[i]->t.agg_keys.swap(stdins[i]->agg_keys);
       traces[i]->t.agg_rows = machine_agg_row_count(traces[i]->t.agg_keys.empty() ? nullptr : traces[i]->t.agg_keys.data(),
                                                     traces[i]->t.agg_leaves.size() / 8);
+      traces[i]->t.leaf_check = std::move(stdins[i]->leaf_check);
+      stdins[i]->leaf_check.reset();
       stdins[i]->entries.clear();  // consumed, as SP1Stdin is by prove()
     } catch (...) {
       traces[i].reset(new zksp_mtrace());
@@ -173,7 +175,8 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       lh[mach::kAlu] = clog2(t.alu_idx.size()); lh[mach::kAlu2] = 0;
       lh[mach::kSub] = clog2(t.sub_idx.size()); lh[mach::kSub2] = 0;
       lh[mach::kBw] = clog2(t.bw_idx.size()); lh[mach::kBw2] = 0;
-      lh[mach::kP2] = clog2(t.agg_rows + 1);
+      lh[mach::kP2] = clog2(t.p2_rows() + 1);
+      lh[mach::kFold] = clog2(t.fold_rows() + 1);
       // (the small chips do not split a group: a run with 513 multiplications shares the shape of one with 511, the
       // cover gives both the taller multiplier chip)
       lh[mach::kEcall] = 0;
@@ -395,7 +398,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     parallel_for(cnt, 8, [&](size_t j) {
       const size_t i = ck.idx[j];
       status[i] = machine_proof_from_parts(pk, traces[i]->t.rec, ck.lh.data(), traces[i]->handover_pc, traces[i]->t.agg_leaves, traces[i]->t.agg_keys,
-                                           bodies + j * bw, bw, &out[i]);
+                                           traces[i]->t.leaf_check.get(), bodies + j * bw, bw, &out[i]);
     });
     mark.mark("wrapped", cnt);
     if (piggyback && rc_next != ZKSP_OK) {

@@ -21,10 +21,11 @@ struct zksp_stdin {
   std::vector<std::vector<uint8_t>> entries;
   std::vector<uint32_t> agg_leaves;  // aggregation payload to prove beside the run (zksp_stdin_set_aggregation), 8 words per digest
   std::vector<uint32_t> agg_keys;    // heap keys of those digests (empty: the leaves of a full tree)
+  std::shared_ptr<const zksp::LeafCheckLog> leaf_check;  // leaf-proof check to prove beside the run (zksp_stdin_set_verified_leaf)
 };
 struct zksp_proof { std::vector<uint8_t> bytes; zksp::ProofHeader hdr; zksp::MachineHeader mhdr; uint32_t version = 2; };
 
-// api_machine.cpp: the v12 proof object from an execution record, the chip heights, the aggregation leaves and a fetched body
+// api_machine.cpp: the proof object (format mach::kMachineVersion) from an execution record, the chip heights, the aggregation leaves and a fetched body
 int machine_proof_from_parts(const zksp_pk* pk, const zksp::ExecutionRecord& r, const int* log_heights, const uint32_t* handover_pc /* [kNumCpuInst - 1] */,
-                             const std::vector<uint32_t>& agg_leaves, const std::vector<uint32_t>& agg_keys, const uint32_t* body,
-                             size_t body_words, zksp_proof** out);
+                             const std::vector<uint32_t>& agg_leaves, const std::vector<uint32_t>& agg_keys,
+                             const zksp::LeafCheckLog* leaf_check, const uint32_t* body, size_t body_words, zksp_proof** out);

@@ -49,7 +49,7 @@ inline void hash_elems(const Fp* in, size_t n, Fp out[8], const P2Consts* k) {
   for (auto& s : st) s = Fp::zero();
   for (size_t off = 0; off < n; off += 8) {
     size_t m = n - off < 8 ? n - off : 8;
-    for (size_t i = 0; i < m; ++i) st[i] = in[off + i];
+    for (size_t i = 0; i < 8; ++i) st[i] = i < m ? in[off + i] : Fp::zero();  // overwrite mode; the last block is zero-filled
     p2_permute(st, k);
   }
   for (int i = 0; i < 8; ++i) out[i] = st[i];

@@ -64,7 +64,9 @@ void page_free(void* p, size_t bytes) noexcept {
 namespace {
 
 constexpr uint64_t kMemBytes = 0x78000000ull;
-constexpr uint32_t kRegSpace = 0x1000;  // guest accesses below this are refused: addresses 0..31 name registers
+// guest accesses below kRegSpace are refused (addresses 0..31 name registers on the memory bus) and so are accesses from
+// kDataTop up: the AIR looks an address's high limb up in 1 .. 0x77FE (air_machine.hpp kAddrHiMax), so they have no proof
+constexpr uint32_t kRegSpace = 0x10000, kDataTop = 0x77FF0000u;
 
 struct Map {
   uint8_t* base = nullptr;
@@ -225,7 +227,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
   uint64_t cycles = 0;
 
 #define FAULT(msg) do { rec.error = (msg); goto done; } while (0)
-#define CHECK_ADDR(ad, n) if ((uint64_t)(ad) + (n) > kMemBytes) FAULT("memory access out of range")
+#define CHECK_ADDR(ad, n) if ((uint64_t)(ad) + (n) > kDataTop) FAULT("memory access out of range")
 
   // previous access time of word w, which is touched at time `now`
   auto touch = [&](uint32_t w, uint32_t now) -> uint32_t {
@@ -300,7 +302,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
           const int sz = (r.op == AIR_LW) ? 4 : (r.op == AIR_LH || r.op == AIR_LHU) ? 2 : 1;
           if (ad & (sz - 1)) FAULT(sz == 4 ? "unaligned lw" : (r.op == AIR_LH ? "unaligned lh" : "unaligned lhu"));
           CHECK_ADDR(ad, sz);
-          if (ad < kRegSpace) FAULT("guest access below 0x1000 (register-mapped addresses)");
+          if (ad < kRegSpace) FAULT("guest access below 0x10000 (register-mapped addresses)");
           const uint32_t w = ad & ~3u;
           c.m_pts = touch(w, ts + 1);  // a load reads its word as the row's second access
           memcpy(&c.m, M + w, 4);
@@ -320,7 +322,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
           const int sz = (r.op == AIR_SW) ? 4 : (r.op == AIR_SH) ? 2 : 1;
           if (ad & (sz - 1)) FAULT(sz == 4 ? "unaligned sw" : "unaligned sh");
           CHECK_ADDR(ad, sz);
-          if (ad < kRegSpace) FAULT("guest access below 0x1000 (register-mapped addresses)");
+          if (ad < kRegSpace) FAULT("guest access below 0x10000 (register-mapped addresses)");
           const uint32_t w = ad & ~3u;
           c.m_pts = touch(w, ts + 2);
           memcpy(&c.m, M + w, 4);
@@ -381,7 +383,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
           const uint32_t ptr = b;  // a0
           if (ptr & 7) FAULT("keccakf state pointer not 8-byte aligned");
           CHECK_ADDR(ptr, 200);
-          if (ptr < kRegSpace) FAULT("guest access below 0x1000 (register-mapped addresses)");
+          if (ptr < kRegSpace) FAULT("guest access below 0x10000 (register-mapped addresses)");
           KeccakCall k;
           k.ts = ts; k.ptr = ptr;
           memcpy(k.in, M + ptr, 200);

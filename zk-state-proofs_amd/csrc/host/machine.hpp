@@ -13,6 +13,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -100,6 +101,17 @@ T* PageAllocator<T>::allocate(size_t n) { return static_cast<T*>(page_alloc(n * 
 template <class T>
 void PageAllocator<T>::deallocate(T* p, size_t n) noexcept { page_free(p, n * sizeof(T)); }
 
+// What verifying a leaf proof leaves behind for a proof ABOUT that verification (stage 2a; the
+// reference's circuits/sp1-merkle-proof-recursive/src/main.rs:3-5 is a todo!()): every Poseidon2 permutation of the query
+// phase as a row record of the Poseidon2 chip (20 words each: the sponges over the opened rows, the Merkle paths
+// with their injections, the FRI leaves and paths), every fold as a row record of the fold chip (20 words
+// each), and the public bus tuples (16 words each) that state WHAT was checked: per opening its tag, position,
+// shape and root; per query and layer the challenge, the domain point and the position bit; the reduced openings; the
+// final constant.  All canonical words.
+struct LeafCheckLog {
+  std::vector<uint32_t> p2_rows, fold_rows, pub_tuples;
+};
+
 struct MachineTrace {
   ExecutionRecord rec;  // cycles, exit code, public values, digests, error text
   std::vector<CycleRec, PageAllocator<CycleRec>> cycles;
@@ -114,20 +126,23 @@ struct MachineTrace {
   uint32_t x0_last = 0;               // last access time of x0 by a real cycle (the first padding row consumes it)
   std::vector<uint32_t> agg_leaves;   // aggregation payload (row f4): 8 canonical words per supplied digest, or none
   std::vector<uint32_t> agg_keys;     // their heap keys (empty: n + j, the leaves of a full tree of n = a power of two)
-  size_t agg_rows = 0;                // rows of the Poseidon2 chip: the ancestors of the supplied keys (set with the payload)
+  size_t agg_rows = 0;                // node rows of the Poseidon2 chip: the ancestors of the supplied keys (set with the payload)
+  std::shared_ptr<const LeafCheckLog> leaf_check;  // leaf-proof check to prove beside the run (row f4, stage 2a), or none
+  size_t p2_rows() const { return agg_rows + (leaf_check ? leaf_check->p2_rows.size() / 20 : 0); }
+  size_t fold_rows() const { return leaf_check ? leaf_check->fold_rows.size() / 20 : 0; }
 };
 
 // How many rows of each event-sized chip a run needs; a batch is proven with the heights of the element-wise maximum.
 struct MachineCounts {
-  size_t cycles = 0, alu = 0, sub = 0, bw = 0, keccak = 0, memfinal = 0, muls = 0, agg = 0, ecall = 0;
+  size_t cycles = 0, alu = 0, sub = 0, bw = 0, keccak = 0, memfinal = 0, muls = 0, agg = 0 /* Poseidon2 chip rows */, ecall = 0, fold = 0;
   void cover(const MachineTrace& t) {
     cycles = std::max(cycles, t.cycles.size()); alu = std::max(alu, t.alu_idx.size()); sub = std::max(sub, t.sub_idx.size());
-    bw = std::max(bw, t.bw_idx.size()); agg = std::max(agg, t.agg_rows); ecall = std::max(ecall, t.ecall_idx.size());
+    bw = std::max(bw, t.bw_idx.size()); agg = std::max(agg, t.p2_rows()); ecall = std::max(ecall, t.ecall_idx.size()); fold = std::max(fold, t.fold_rows());
     keccak = std::max(keccak, t.keccak.size()); memfinal = std::max(memfinal, t.memfinal.size()); muls = std::max(muls, t.muls.size());
   }
   void cover(const MachineCounts& o) {
     cycles = std::max(cycles, o.cycles); alu = std::max(alu, o.alu); sub = std::max(sub, o.sub); bw = std::max(bw, o.bw);
-    agg = std::max(agg, o.agg); ecall = std::max(ecall, o.ecall); keccak = std::max(keccak, o.keccak);
+    agg = std::max(agg, o.agg); ecall = std::max(ecall, o.ecall); keccak = std::max(keccak, o.keccak); fold = std::max(fold, o.fold);
     memfinal = std::max(memfinal, o.memfinal); muls = std::max(muls, o.muls);
   }
 };

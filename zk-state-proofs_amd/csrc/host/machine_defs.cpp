@@ -6,11 +6,16 @@
 //   ALU    (op, a_lo, a_hi, b_lo, b_hi, c_lo, c_hi)   CPU -> ALU chip / bitwise chip / multiplier
 //   SUB    (op, byte offset, a_lo, a_hi, m_lo, m_hi, c_lo, mv_lo, mv_hi)   CPU -> sub-word chip
 //   PUBC   (kind, index, lo, hi), PUBH (exit_lo, exit_hi)   CPU -> verifier
-//   RANGE  (kind, value)   value < 2^16 (kind 0), and a multiple of 4 (kind 1), or at most 0x77FF (kind 2): table chip
+//   RANGE  (kind, value)   value < 2^16 (kind 0), and a multiple of 4 (kind 1), or in 1 .. 0x77FE (kind 2): table chip
 //   BYTES  (x, y)   two bytes: table chip
 //   BYTEOP (kind, x, y, z)   z = x xor y (1), x or y (2), x and y (3): table chip <- bitwise chip
 //   IMG    (addr, lo, hi)   image chip -> memory boundary: the initial value of an image address
-//   DIGEST (heap index, 8 words)   Poseidon2 chip: children in, parent out; verifier: the leaves in, the root out
+//   DIGEST (tag, type, key, mask, 8 words)   Poseidon2 chip: heap nodes (type 2: children in, parent out; verifier: the leaves
+//          in, the root out), injected row hashes (type 1), the ends of the openings of a leaf proof (type 0: -> verifier)
+//   PAIR   (tag, lo[4], hi[4])   Poseidon2 chip (a FRI leaf's sponge row) -> fold chip
+//   FRIQ   (query, layer, bit, 1/x, beta[4])   verifier -> fold chip
+//   RO     (query, 0 or layer + 1, value[4])   verifier -> fold chip: the reduced opening that starts / joins the folding
+//   FIN    (query, layer, value[4])   fold chip -> verifier: the last folded value
 #include "machine_defs.hpp"
 
 #include <cstdlib>
@@ -89,7 +94,7 @@ Interaction bytes_inter(int sign, const LinForm& mult, const LinForm& x, const L
 }
 
 constexpr int kCpuInter = 19;
-Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7], g_alu[1], g_sub[5], g_bw[5], g_p2[5], g_ecall[10];
+Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7], g_alu[1], g_sub[5], g_bw[5], g_p2[7], g_ecall[10], g_fold[5];
 ChipDef g_chips[kNumChips];
 
 void build() {
@@ -139,7 +144,7 @@ void build() {
                                 selc(CL_ECALL), selc(CL_KECCAK), C_UC});
     LinForm xoff = lf_col(C_X);
     lf_add(xoff, C_O1, kP - 1); lf_add(xoff, C_O2, kP - 2); lf_add(xoff, C_O3, kP - 3);
-    LinForm top = lf_zero();  // kind 2: the high limb of an address is at most kAddrHiMax
+    LinForm top = lf_zero();  // kind 2: the high limb of an address is in 1 .. kAddrHiMax (0x10000 <= address < 0x77FF0000)
     for (int c : {selc(CL_JALR), selc(CL_LW), selc(CL_SW), selc(CL_LDS), selc(CL_STS), selc(CL_KECCAK)}) lf_add(top, c, 2);
     g_cpu[12] = range_inter(-1, chk, top, lf_col(C_X + 1));
     g_cpu[13] = range_inter(-1, chk, lf_sum({selc(CL_JALR), selc(CL_LW), selc(CL_SW), selc(CL_LDS), selc(CL_STS)}), xoff);
@@ -231,9 +236,10 @@ void build() {
     g_kmem[3] = mem_inter(+1, lf_col(KM_IS_REAL), lf_col(KM_ADDR), lf_col(KM_NEW_LO), lf_col(KM_NEW_HI), lf_plus(lf_col(KM_TS), 2));
     g_kmem[4] = range_inter(-1, lf_col(KM_IS_REAL), zero, lf_col(KM_GL));
     g_kmem[5] = bytes_inter(-1, lf_col(KM_IS_REAL), lf_col(KM_GH), zero);
-    // the state pointer is word-aligned and the 200 bytes end below 0x78000000
+    // the state pointer is word-aligned, lies at 0x10000 or above (not in register space) and the 200 bytes end below
+    // 0x78000000: its high limb is looked up as kind 2 (1 .. kAddrHiMax = 0x77FE)
     g_kmem[6] = range_inter(-1, lf_col(KM_CALL), one, lf_col(KM_PTR_LO));
-    g_kmem[7] = range_inter(-1, lf_col(KM_CALL), zero, lf_const_minus(kAddrHiMax - 1, KM_PTR_HI));
+    g_kmem[7] = range_inter(-1, lf_col(KM_CALL), lf_const(2), lf_col(KM_PTR_HI));
   }
   {
     const LinForm real = lf_col(MF_IS_REAL), init = lf_col(MF_IS_INIT), addr = lf_pair(MF_LO, MF_HI, 65536);
@@ -337,35 +343,85 @@ void build() {
     sg.el[3] = lf_zero(); lf_add(sg.el[3], SW_S, 128);
   }
   {
-    // Poseidon2: children in, parent out; the output digest is the external linear layer applied to the last round's
-    // S-box outputs (circ(2 M4, M4, M4, M4), M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]])
+    // Poseidon2 (air_machine.hpp "Poseidon2 chip").  DIGEST tuples are (tag, type, key, mask, 8 words); type 2: a heap
+    // node (stage 1: children in, parent out), type 1: the hash of an injected matrix row (a sponge's last row -> the
+    // injection row with the same labels), type 0: the end of a run (-> the verifier, who knows the root).  The output
+    // words are the external linear layer applied to the last round's S-box outputs (circ(2 M4, M4, M4, M4),
+    // M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]]).
     static const uint32_t m4[4][4] = {{2, 3, 1, 1}, {1, 2, 3, 1}, {1, 1, 2, 3}, {3, 1, 1, 2}};
     const int ylast = P2_EXT + 32 * 7 + 16;
+    const LinForm tag = lf_col(P2_T), mask = lf_col(P2_M), key = lf_pair(P2_KL, P2_KH, 65536);
     for (int side = 0; side < 2; ++side) {
       Interaction& it = g_p2[side];
       it = Interaction{};
-      it.bus = BUS_DIGEST; it.sign = -1; it.mult = lf_col(P2_IS_REAL); it.n_el = 9;
-      it.el[0] = lf_zero(); lf_add(it.el[0], P2_KL, 2); lf_add(it.el[0], P2_KH, 2 * 65536); it.el[0].c0 = mont((uint64_t)side);
-      for (int j = 0; j < 8; ++j) it.el[1 + j] = lf_col(P2_IN + 8 * side + j);
+      it.bus = BUS_DIGEST; it.sign = -1; it.mult = lf_col(P2_FN); it.n_el = 12;
+      it.el[0] = tag; it.el[1] = lf_const(2);
+      it.el[2] = lf_zero(); lf_add(it.el[2], P2_KL, 2); lf_add(it.el[2], P2_KH, 2 * 65536); it.el[2].c0 = mont((uint64_t)side);
+      it.el[3] = mask;
+      for (int j = 0; j < 8; ++j) it.el[4 + j] = lf_col(P2_IN + 8 * side + j);
     }
-    Interaction& out = g_p2[2];
+    Interaction& inj = g_p2[2];
+    inj = Interaction{};
+    inj.bus = BUS_DIGEST; inj.sign = -1; inj.mult = lf_col(P2_FJ); inj.n_el = 12;
+    inj.el[0] = tag; inj.el[1] = lf_const(1); inj.el[2] = key; inj.el[3] = mask;
+    for (int j = 0; j < 8; ++j) inj.el[4 + j] = lf_col(P2_IN + 8 + j);
+    Interaction& out = g_p2[3];
     out = Interaction{};
-    out.bus = BUS_DIGEST; out.sign = +1; out.mult = lf_col(P2_IS_REAL); out.n_el = 9;
-    out.el[0] = lf_pair(P2_KL, P2_KH, 65536);
+    out.bus = BUS_DIGEST; out.sign = +1; out.mult = lf_pair(P2_FN, P2_SND, 1); out.n_el = 12;
+    out.el[0] = tag;
+    out.el[1] = lf_zero(); lf_add(out.el[1], P2_FN, 2); lf_add(out.el[1], P2_SZ, 1); lf_add(out.el[1], P2_SC, 1);
+    out.el[2] = key; out.el[3] = mask;
     for (int j = 0; j < 8; ++j) {
-      out.el[1 + j] = lf_zero();
-      for (int i = 0; i < 16; ++i) lf_add(out.el[1 + j], ylast + i, (uint64_t)m4[j & 3][i & 3] * ((i >> 2) == (j >> 2) ? 2u : 1u));
+      out.el[4 + j] = lf_zero();
+      for (int i = 0; i < 16; ++i) lf_add(out.el[4 + j], ylast + i, (uint64_t)m4[j & 3][i & 3] * ((i >> 2) == (j >> 2) ? 2u : 1u));
     }
+    // the pair a FRI leaf hashes goes to the fold chip
+    Interaction& pair = g_p2[4];
+    pair = Interaction{};
+    pair.bus = BUS_PAIR; pair.sign = +1; pair.mult = lf_col(P2_FR); pair.n_el = 9;
+    pair.el[0] = tag;
+    for (int j = 0; j < 8; ++j) pair.el[1 + j] = lf_col(P2_IN + j);
   }
-  // the key's limbs: 16 bits, and twice the high limb at most kAddrHiMax (kind 2): the key stays below 0x3C000000 and its
-  // children's keys 2K, 2K + 1 below 0x78000000 < p - no key aliases another mod p
-  g_p2[3] = range_inter(-1, lf_col(P2_IS_REAL), lf_const(0), lf_col(P2_KL));
+  // the key's limbs: 16 bits, and twice the high limb plus one in 1 .. kAddrHiMax (kind 2): the key stays below 0x3C000000
+  // and its children's keys 2K, 2K + 1 below 0x78000000 < p - no key aliases another mod p
+  g_p2[5] = range_inter(-1, lf_col(P2_IS_REAL), lf_const(0), lf_col(P2_KL));
   {
     LinForm kh2 = lf_zero();
     lf_add(kh2, P2_KH, 2);
-    g_p2[4] = range_inter(-1, lf_col(P2_IS_REAL), lf_const(2), kh2);
+    kh2.c0 = mont(1);
+    g_p2[6] = range_inter(-1, lf_col(P2_IS_REAL), lf_const(2), kh2);
   }
-  g_chips[kP2] = {"poseidon2", 0, kP2Width, 5, g_p2, kP2Constraints, 0};
+  {
+    // FRI fold chip (air_machine.hpp): the verifier's per-layer tuple, the hashed pair, the reduced openings, the end
+    const LinForm q = lf_col(FO_Q), k = lf_col(FO_K);
+    Interaction& fq = g_fold[0];
+    fq = Interaction{};
+    fq.bus = BUS_FRIQ; fq.sign = -1; fq.mult = lf_col(FO_IS_REAL); fq.n_el = 8;
+    fq.el[0] = q; fq.el[1] = k; fq.el[2] = lf_col(FO_BIT); fq.el[3] = lf_col(FO_XINV);
+    for (int j = 0; j < 4; ++j) fq.el[4 + j] = lf_col(FO_BETA + j);
+    Interaction& pr = g_fold[1];
+    pr = Interaction{};
+    pr.bus = BUS_PAIR; pr.sign = -1; pr.mult = lf_col(FO_IS_REAL); pr.n_el = 9;
+    pr.el[0] = lf_zero(); lf_add(pr.el[0], FO_Q, kLeafTagStride); lf_add(pr.el[0], FO_K, 1); pr.el[0].c0 = mont(leaf_tag(0, 4));
+    for (int j = 0; j < 4; ++j) { pr.el[1 + j] = lf_col(FO_LO + j); pr.el[5 + j] = lf_col(FO_HI + j); }
+    Interaction& r0 = g_fold[2];
+    r0 = Interaction{};
+    r0.bus = BUS_RO; r0.sign = -1; r0.mult = lf_col(FO_FIRST); r0.n_el = 6;
+    r0.el[0] = q; r0.el[1] = lf_const(0);
+    for (int j = 0; j < 4; ++j) r0.el[2 + j] = lf_col(FO_E + j);
+    Interaction& r1 = g_fold[3];
+    r1 = Interaction{};
+    r1.bus = BUS_RO; r1.sign = -1; r1.mult = lf_col(FO_HASRO); r1.n_el = 6;
+    r1.el[0] = q; r1.el[1] = lf_plus(k, 1);
+    for (int j = 0; j < 4; ++j) r1.el[2 + j] = lf_col(FO_RO + j);
+    Interaction& fin = g_fold[4];
+    fin = Interaction{};
+    fin.bus = BUS_FIN; fin.sign = +1; fin.mult = lf_col(FO_LAST); fin.n_el = 6;
+    fin.el[0] = q; fin.el[1] = k;
+    for (int j = 0; j < 4; ++j) fin.el[2 + j] = lf_pair(FO_F + j, FO_RO + j, 1);
+  }
+  g_chips[kFold] = {"fri-fold", 0, kFoldWidth, 5, g_fold, kFoldConstraints, 0};
+  g_chips[kP2] = {"poseidon2", 0, kP2Width, 7, g_p2, kP2Constraints, 0};
   g_chips[kTable] = {"table", kTablePrepWidth, kTableWidth, 7, g_table, 2, 0};
   g_chips[kCpu] = {"cpu", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 5};
   g_chips[kCpu2] = {"cpu2", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 5};

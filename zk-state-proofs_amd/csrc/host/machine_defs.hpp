@@ -58,9 +58,13 @@ inline int quot_alpha_offset(const int* logh, int c) {
   return off;
 }
 
-// magic, version, heights, exit code, pv length, 3 digests, hand-over pc; aggregation payload: leaf count, root, digest of the leaf list
-constexpr int kHeaderWords = 2 + kNumChips + 2 + 24 + (kNumCpuInst - 1) + 17;
-constexpr uint32_t kMachineVersion = 13;
+// magic, version, heights, exit code, pv length, 3 digests, hand-over pc; aggregation payload: leaf count, root, digest of the
+// leaf list; public bus tuples (the statement of a leaf-proof check): count, digest of the list
+constexpr int kHeaderWords = 2 + kNumChips + 2 + 24 + (kNumCpuInst - 1) + 17 + 9;
+// A public bus tuple, as the verifier is given it (16 canonical words): bus, 1 if the verifier sends it (0: receives),
+// multiplicity, number of elements, the elements (zero padded).
+constexpr int kPubTupleWords = 16;
+constexpr uint32_t kMachineVersion = 14;
 
 }  // namespace mach
 }  // namespace zksp

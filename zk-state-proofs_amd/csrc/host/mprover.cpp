@@ -114,8 +114,9 @@ void machine_heights(const MachineProgram& prog, const MachineCounts& n, int log
   logh[kProgram] = prog.log_prog;
   logh[kMul] = at_least5(ceil_log2(n.muls));
   logh[kTable] = kTableLogH;
-  logh[kP2] = at_least5(ceil_log2(n.agg ? n.agg : 1));  // one row per ancestor of the payload's supplied nodes
+  logh[kP2] = at_least5(ceil_log2(n.agg ? n.agg : 1));  // a payload's rows: heap nodes, the permutations of a leaf-proof check
   logh[kEcall] = at_least5(ceil_log2(n.ecall));
+  logh[kFold] = at_least5(ceil_log2(n.fold ? n.fold : 1));
 }
 void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh[kNumChips]) {
   MachineCounts n;
@@ -126,7 +127,7 @@ bool machine_fits(const MachineTrace& t, const int* logh) {
   auto two = [&](int a, int b) { return ((size_t)1 << logh[a]) + ((size_t)1 << logh[b]); };
   auto one = [&](int a) { return (size_t)1 << logh[a]; };
   return t.cycles.size() <= machine_cpu_row0(logh, kNumCpuInst) && t.alu_idx.size() <= two(kAlu, kAlu2) && t.sub_idx.size() <= two(kSub, kSub2) &&
-         t.bw_idx.size() <= two(kBw, kBw2) && t.agg_rows <= one(kP2) &&
+         t.bw_idx.size() <= two(kBw, kBw2) && t.p2_rows() <= one(kP2) && t.fold_rows() <= one(kFold) &&
          24 * t.keccak.size() <= one(kKeccak) && 50 * t.keccak.size() <= one(kKmem) && t.memfinal.size() <= one(kMemFinal) &&
          t.muls.size() <= one(kMul) && t.ecall_idx.size() <= one(kEcall);
 }
@@ -195,11 +196,11 @@ int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineV
 }
 
 static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap_cycles, size_t cap_keccak, size_t cap_memfinal,
-                            size_t cap_muls, size_t cap_alu, size_t cap_sub, size_t cap_bw, size_t cap_agg) {
+                            size_t cap_muls, size_t cap_alu, size_t cap_sub, size_t cap_bw, size_t cap_agg, size_t cap_fold) {
   MachineWorkspace* w = ctx->mws.get();
   if (w && memcmp(w->logh, logh, sizeof w->logh) == 0 && w->batch >= batch && w->cap_cycles >= cap_cycles &&
       w->cap_keccak >= cap_keccak && w->cap_memfinal >= cap_memfinal && w->cap_muls >= cap_muls && w->cap_alu >= cap_alu &&
-      w->cap_sub >= cap_sub && w->cap_bw >= cap_bw && w->cap_agg >= cap_agg)
+      w->cap_sub >= cap_sub && w->cap_bw >= cap_bw && w->cap_agg >= cap_agg && w->cap_fold >= cap_fold)
     return 0;
   ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->mws.reset(new MachineWorkspace());
@@ -210,6 +211,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   w->cap_muls = std::max<size_t>(cap_muls, 1);
   w->cap_alu = std::max<size_t>(cap_alu, 1); w->cap_sub = std::max<size_t>(cap_sub, 1); w->cap_bw = std::max<size_t>(cap_bw, 1);
   w->cap_agg = std::max<size_t>(cap_agg, 2);
+  w->cap_fold = std::max<size_t>(cap_fold, 2);
   const size_t B = (size_t)batch;
   const uint32_t Q = ctx->params.num_queries;
   // The workspace lives in ONE device arena that survives re-shaping: a batch of other chip heights only lays the same
@@ -234,7 +236,8 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
     A(&w->sub_idx, B * w->cap_sub);
     A(&w->bw_idx, B * w->cap_bw);
     A(&w->ecall_idx, B << logh[kEcall]);  // (an ecall list is as long as the ecall chip is tall, at most)
-    A(&w->agg_heap, B * w->cap_agg * 17);
+    A(&w->agg_heap, B * w->cap_agg * kP2RecWords);
+    A(&w->fold_rows, B * w->cap_fold * kFoldRecWords);
     A(&w->prog_mult, B << logh[kProgram]);
     A(&w->table_hist, (B * kTableWidth) << kTableLogH);
     A(&w->counts, B * kCountWords);
@@ -250,7 +253,8 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
     A(&w->spare.sub_idx, B * w->cap_sub);
     A(&w->spare.bw_idx, B * w->cap_bw);
     A(&w->spare.ecall_idx, B << logh[kEcall]);
-    A(&w->spare.agg_heap, B * w->cap_agg * 17);
+    A(&w->spare.agg_heap, B * w->cap_agg * kP2RecWords);
+    A(&w->spare.fold_rows, B * w->cap_fold * kFoldRecWords);
     A(&w->spare.prog_mult, B << logh[kProgram]);
     A(&w->spare.counts, B * kCountWords);
     A(&w->spare.n_perms, B);
@@ -283,13 +287,21 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
     w->n_open = n_open;
     w->alpha_stride = max_total * 4;
     const size_t N = (size_t)2 << lm;
+    // (one buffer per distinct height, in both passes alike: the sizing pass cannot test pointers it has not assigned)
+    bool seen_inj[4][32] = {{false}}, seen_g[32] = {false};
     for (int r = 1; r < 4; ++r) {
       A(&w->tree[r], B * (2 * N - 1) * 8);
       for (int c = 0; c < kNumChips; ++c)
-        if (logh[c] < lm && !w->inj[r][logh[c] + 1]) A(&w->inj[r][logh[c] + 1], (B * 8) << (logh[c] + 1));
+        if (logh[c] < lm && !seen_inj[r][logh[c] + 1]) {
+          seen_inj[r][logh[c] + 1] = true;
+          A(&w->inj[r][logh[c] + 1], (B * 8) << (logh[c] + 1));
+        }
     }
     for (int c = 0; c < kNumChips; ++c)
-      if (logh[c] < lm && !w->G[logh[c]]) A(&w->G[logh[c]], (B * 2 * 4) << logh[c]);
+      if (logh[c] < lm && !seen_g[logh[c]]) {
+        seen_g[logh[c]] = true;
+        A(&w->G[logh[c]], (B * 2 * 4) << logh[c]);
+      }
     A(&w->ch, B);
     A(&w->bus_ch, B * 8);
     A(&w->bpow, B * (kInterMaxElems + 1) * 4);
@@ -357,7 +369,7 @@ namespace {
 void swap_records(MachineWorkspace* w) {
   MachineWorkspace::SpareRecords& p = w->spare;
   std::swap(w->cycles, p.cycles); std::swap(w->memfinal, p.memfinal); std::swap(w->muls, p.muls);
-  std::swap(w->prog_mult, p.prog_mult); std::swap(w->alu_idx, p.alu_idx); std::swap(w->sub_idx, p.sub_idx); std::swap(w->bw_idx, p.bw_idx); std::swap(w->ecall_idx, p.ecall_idx); std::swap(w->agg_heap, p.agg_heap);
+  std::swap(w->prog_mult, p.prog_mult); std::swap(w->alu_idx, p.alu_idx); std::swap(w->sub_idx, p.sub_idx); std::swap(w->bw_idx, p.bw_idx); std::swap(w->ecall_idx, p.ecall_idx); std::swap(w->agg_heap, p.agg_heap); std::swap(w->fold_rows, p.fold_rows);
   std::swap(w->counts, p.counts);
   std::swap(w->kcalls, p.kcalls); std::swap(w->kstates, p.kstates); std::swap(w->n_perms, p.n_perms);
   std::swap(w->init_obs, p.init_obs); std::swap(w->pub_words, p.pub_words); std::swap(w->n, p.n);
@@ -395,14 +407,14 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
                ck = std::min(((size_t)1 << logh[kKeccak]) / 24, ((size_t)1 << logh[kKmem]) / 50),
                ca = ((size_t)1 << logh[kAlu]) + ((size_t)1 << logh[kAlu2]), cs = ((size_t)1 << logh[kSub]) + ((size_t)1 << logh[kSub2]),
                cb = ((size_t)1 << logh[kBw]) + ((size_t)1 << logh[kBw2]),
-               cg = (size_t)1 << logh[kP2];  // one record per row of the Poseidon2 chip
+               cg = (size_t)1 << logh[kP2], cf = (size_t)1 << logh[kFold];  // one record per row of the Poseidon2 / fold chip
   if (logh[kCpu] > 20) return ctx->fail(9, "machine_load: more than 2^21 cycles");
   if (into_spare) {
     MachineWorkspace* w0 = ctx->mws.get();
     if (!w0 || memcmp(w0->logh, logh, sizeof w0->logh) != 0 || (size_t)w0->batch < n || !ctx->copy_stream)
       return ctx->fail(1, "machine_load: the spare set takes batches of the resident heights only");
   } else {
-    rc = workspace_ensure(ctx, logh, (int)std::max<size_t>(n, (size_t)ctx->batch_hint), cc, ck, cm, cu, ca, cs, cb, cg);
+    rc = workspace_ensure(ctx, logh, (int)std::max<size_t>(n, (size_t)ctx->batch_hint), cc, ck, cm, cu, ca, cs, cb, cg, cf);
     if (rc) return rc;
   }
   MachineWorkspace* w = ctx->mws.get();
@@ -436,9 +448,16 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     const size_t n_agg = t.agg_leaves.size() / 8;
     if (!machine_nodes_public(t.agg_keys.empty() ? nullptr : t.agg_keys.data(), t.agg_leaves.data(), n_agg, agg_root, agg_digest, &agg_heaps[i]))
       return ctx->fail(1, "machine_load: malformed aggregation payload");
-    cn[8] = (uint32_t)(agg_heaps[i].size() / 17);
-    if (n_agg)
-      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->agg_heap + i * w->cap_agg * 17, agg_heaps[i].data(), agg_heaps[i].size() * 4, hipMemcpyHostToDevice, s));
+    // ... then the rows of a leaf-proof check (the sponges, path steps and injections of its openings; the folds)
+    const LeafCheckLog* lc = t.leaf_check.get();
+    const size_t n_node = agg_heaps[i].size() / kP2RecWords, n_lc = lc ? lc->p2_rows.size() / kP2RecWords : 0;
+    cn[8] = (uint32_t)(n_node + n_lc);
+    cn[10] = (uint32_t)t.fold_rows();
+    uint32_t* d_p2 = w->agg_heap + i * w->cap_agg * kP2RecWords;
+    if (n_node) ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(d_p2, agg_heaps[i].data(), agg_heaps[i].size() * 4, hipMemcpyHostToDevice, s));
+    if (n_lc) ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(d_p2 + n_node * kP2RecWords, lc->p2_rows.data(), lc->p2_rows.size() * 4, hipMemcpyHostToDevice, s));
+    if (cn[10])
+      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->fold_rows + i * w->cap_fold * kFoldRecWords, lc->fold_rows.data(), lc->fold_rows.size() * 4, hipMemcpyHostToDevice, s));
     if (!t.alu_idx.empty())
       ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->alu_idx + i * w->cap_alu, t.alu_idx.data(), t.alu_idx.size() * 4, hipMemcpyHostToDevice, s));
     if (!t.sub_idx.empty())
@@ -489,6 +508,9 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
       o[42 + kNumChips + kHo] = (uint32_t)n_agg;
       memcpy(o + 43 + kNumChips + kHo, agg_root, 32);
       memcpy(o + 51 + kNumChips + kHo, agg_digest, 32);
+      const size_t n_pub = lc ? lc->pub_tuples.size() / kPubTupleWords : 0;
+      o[59 + kNumChips + kHo] = (uint32_t)n_pub;
+      machine_pub_digest(lc ? lc->pub_tuples.data() : nullptr, n_pub, o + 60 + kNumChips + kHo);
     }
   }
   ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->kstates, kst.data(), kst.size() * 8, hipMemcpyHostToDevice, s));
@@ -540,13 +562,13 @@ int machine_prove_resident(Context* ctx) {
   // ---- main traces ----
   MachineRecords rec;
   rec.cycles = w->cycles; rec.kcalls = w->kcalls; rec.memfinal = w->memfinal; rec.muls = w->muls;
-  rec.alu_idx = w->alu_idx; rec.sub_idx = w->sub_idx; rec.bw_idx = w->bw_idx; rec.ecall_idx = w->ecall_idx; rec.agg_heap = w->agg_heap; rec.consts = kc;
+  rec.alu_idx = w->alu_idx; rec.sub_idx = w->sub_idx; rec.bw_idx = w->bw_idx; rec.ecall_idx = w->ecall_idx; rec.agg_heap = w->agg_heap; rec.fold_rows = w->fold_rows; rec.consts = kc;
   rec.prog_mult = w->prog_mult; rec.counts = w->counts; rec.table_hist = w->table_hist;
   memset(rec.row0, 0, sizeof rec.row0);
   for (int k = 1; k < kNumCpuInst; ++k) rec.row0[cpu_chip(k)] = (uint32_t)machine_cpu_row0(logh, k);
   rec.row0[kAlu2] = (uint32_t)1 << logh[kAlu]; rec.row0[kSub2] = (uint32_t)1 << logh[kSub]; rec.row0[kBw2] = (uint32_t)1 << logh[kBw];
   rec.cap_cycles = w->cap_cycles; rec.cap_keccak = w->cap_keccak; rec.cap_memfinal = w->cap_memfinal; rec.cap_muls = w->cap_muls;
-  rec.cap_alu = w->cap_alu; rec.cap_sub = w->cap_sub; rec.cap_bw = w->cap_bw; rec.cap_agg = w->cap_agg; rec.cap_ecall = (size_t)1 << logh[kEcall];
+  rec.cap_alu = w->cap_alu; rec.cap_sub = w->cap_sub; rec.cap_bw = w->cap_bw; rec.cap_agg = w->cap_agg; rec.cap_fold = w->cap_fold; rec.cap_ecall = (size_t)1 << logh[kEcall];
   rec.program = prep->program; rec.text_base = prep->text_base; rec.n_program = prep->n_program; rec.n_image = prep->n_image;
   rec.cpu_rows = (uint32_t)machine_cpu_row0(logh, kNumCpuInst);
   {

@@ -1,5 +1,5 @@
 // Device prover of the machine proof: batch workspace in HBM and the launch sequence that turns
-// traced executions into proof bodies ("ZKSP v12") without a host round trip.  See mprover.cpp.
+// traced executions into proof bodies ("ZKSP v14") without a host round trip.  See mprover.cpp.
 #pragma once
 #include <array>
 #include <vector>
@@ -11,8 +11,9 @@
 
 namespace zksp {
 
-// vk digest, heights, exit halves, digest halves, hand-over pc halves, aggregation: leaf count, root, digest of the leaf list
-constexpr int kMachineInitObs = 8 + mach::kNumChips + 2 + 16 + 16 + 2 * (mach::kNumCpuInst - 1) + 17;
+// vk digest, heights, exit halves, digest halves, hand-over pc halves, aggregation: leaf count, root, digest of the leaf list;
+// public bus tuples: count, digest of the list
+constexpr int kMachineInitObs = 8 + mach::kNumChips + 2 + 16 + 16 + 2 * (mach::kNumCpuInst - 1) + 17 + 9;
 
 // Preprocessed tables of one program on the device (built once per verifying key).
 struct PrepDevice {
@@ -33,11 +34,11 @@ struct PrepDevice {
 struct MachineWorkspace {
   int logh[mach::kNumChips] = {0};
   int batch = 0, n = 0;
-  size_t cap_cycles = 0, cap_keccak = 0, cap_memfinal = 0, cap_muls = 0, cap_alu = 0, cap_sub = 0, cap_bw = 0, cap_agg = 0;
+  size_t cap_cycles = 0, cap_keccak = 0, cap_memfinal = 0, cap_muls = 0, cap_alu = 0, cap_sub = 0, cap_bw = 0, cap_agg = 0, cap_fold = 0;
   const PrepDevice* prep = nullptr;
   // records
   uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *alu_idx = nullptr, *sub_idx = nullptr,
-           *bw_idx = nullptr, *ecall_idx = nullptr, *agg_heap = nullptr, *counts = nullptr, *table_hist = nullptr;
+           *bw_idx = nullptr, *ecall_idx = nullptr, *agg_heap = nullptr, *fold_rows = nullptr, *counts = nullptr, *table_hist = nullptr;
   uint8_t* kcalls = nullptr;
   uint64_t* kstates = nullptr;
   uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;
@@ -45,7 +46,7 @@ struct MachineWorkspace {
   // being proven, then machine_activate_spare() swaps the sets.
   struct SpareRecords {
     uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *alu_idx = nullptr, *sub_idx = nullptr,
-             *bw_idx = nullptr, *ecall_idx = nullptr, *agg_heap = nullptr, *counts = nullptr;
+             *bw_idx = nullptr, *ecall_idx = nullptr, *agg_heap = nullptr, *fold_rows = nullptr, *counts = nullptr;
     uint8_t* kcalls = nullptr;
     uint64_t* kstates = nullptr;
     uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;

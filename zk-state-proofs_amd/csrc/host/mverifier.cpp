@@ -1,4 +1,4 @@
-// Host verifier of the machine proof ("ZKSP v12"): replaces `client.verify(&proof, &vk)` (reference
+// Host verifier of the machine proof ("ZKSP v14"): replaces `client.verify(&proof, &vk)` (reference
 // prover/src/bin/main.rs:80; sp1-stark 3.4.0's multi-chip verifier over p3-uni-stark / p3-fri,
 // Cargo.lock:7485, :5378, :5253) for proofs that bind the guest's whole execution.  Also the
 // host half of `client.setup(ELF)` (main.rs:70): the commitment to the preprocessed Program and
@@ -97,33 +97,102 @@ struct RoundShape {
   int lm;  // tallest log height in the round
 };
 
-// Recomputes the root of one mixed-height opening.  rows[c]: opened row of chip c (width[c] words).
+// ---- leaf-check log (mverifier.hpp LeafCheckLog): the permutations of the query phase as Poseidon2-chip row records ----
+void log_p2_row(LeafCheckLog* log, uint32_t flags, uint32_t tag, uint32_t key, uint32_t mask, const Fp in[16]) {
+  std::vector<uint32_t>& v = log->p2_rows;
+  v.push_back(flags); v.push_back(tag); v.push_back(key); v.push_back(mask);
+  for (int i = 0; i < 16; ++i) v.push_back(in[i].to_canonical());
+}
+void log_pub_tuple(LeafCheckLog* log, uint32_t bus, bool verifier_sends, const uint32_t* el, int n_el) {
+  std::vector<uint32_t>& v = log->pub_tuples;
+  v.push_back(bus); v.push_back(verifier_sends ? 1u : 0u); v.push_back(1u); v.push_back((uint32_t)n_el);
+  for (int i = 0; i < kPubTupleWords - 4; ++i) v.push_back(i < n_el ? el[i] : 0u);
+}
+// hash_elems, every block logged as a sponge row labelled (tag, key, mask): the first starts from the zero state
+void sponge_logged(const Fp* in, size_t n, Fp out[8], const P2Consts* kc, LeafCheckLog* log, uint32_t tag, uint32_t key, uint32_t mask,
+                   bool run_start, bool send, bool fri_leaf) {
+  Fp st[16];
+  for (auto& x : st) x = Fp::zero();
+  for (size_t off = 0; off < n; off += 8) {
+    const size_t m = n - off < 8 ? n - off : 8;
+    for (size_t i = 0; i < 8; ++i) st[i] = i < m ? in[off + i] : Fp::zero();
+    if (log) {
+      uint32_t flags = off == 0 ? (uint32_t)P2K_SZ : (uint32_t)P2K_SC;
+      if (run_start) flags |= kP2FlagNew;
+      if (send && off + 8 >= n) flags |= kP2FlagSnd;
+      if (fri_leaf && off == 0) flags |= kP2FlagFri;
+      log_p2_row(log, flags, tag, key, mask, st);
+    }
+    p2_permute(st, kc);
+  }
+  for (int i = 0; i < 8; ++i) out[i] = st[i];
+}
+// one step of a path: the running digest on the left or on the right of its sibling
+void compress_logged(const Fp* cur, const Fp* sib, bool cur_right, Fp out[8], const P2Consts* kc, LeafCheckLog* log, uint32_t kind,
+                     uint32_t tag, uint32_t key, uint32_t mask) {
+  Fp st[16];
+  for (int i = 0; i < 8; ++i) {
+    st[i] = cur_right ? sib[i] : cur[i];
+    st[8 + i] = cur_right ? cur[i] : sib[i];
+  }
+  if (log) log_p2_row(log, kind, tag, key, mask, st);
+  p2_permute(st, kc);
+  for (int i = 0; i < 8; ++i) out[i] = st[i];
+}
+
+// Recomputes the root of one mixed-height opening.  rows[c]: opened row of chip c (width[c] words).  With a log: the
+// opening as a run of the Poseidon2 chip (air_machine.hpp), tagged `tag`, and the public tuple that ends it.
 bool mmcs_verify(const RoundShape& sh, const int* logh, const std::vector<std::vector<Fp>>& rows, size_t cs, size_t m_max,
-                 const uint32_t* path_canon, const Fp root[8], const P2Consts* kc) {
+                 const uint32_t* path_canon, const Fp root[8], const P2Consts* kc, LeafCheckLog* log = nullptr, uint32_t tag = 0) {
   const int logn = sh.lm + 1;
   const size_t hm = (size_t)1 << sh.lm;
   const size_t pos = cs * hm + bitrev32((uint32_t)(m_max & (hm - 1)), sh.lm);
-  auto group_hash = [&](int group_logn, Fp out[8]) -> bool {
-    std::vector<Fp> cat;
+  auto group_row = [&](int group_logn, std::vector<Fp>* cat) {
+    cat->clear();
     for (int c = 0; c < kNumChips; ++c)
-      if (sh.width[c] && logh[c] + 1 == group_logn) cat.insert(cat.end(), rows[c].begin(), rows[c].end());
-    if (cat.empty()) return false;
-    hash_elems(cat.data(), cat.size(), out, kc);
-    return true;
+      if (sh.width[c] && logh[c] + 1 == group_logn) cat->insert(cat->end(), rows[c].begin(), rows[c].end());
+    return !cat->empty();
   };
+  std::vector<Fp> cat;
+  if (log) {
+    // the hashes of the injected rows come first, each labelled with the key and mask its injection row will hold
+    uint32_t key = 1, mask = 0;
+    for (int l = 0; l < logn; ++l) {
+      key = 2 * key + (uint32_t)((pos >> l) & 1);
+      mask = 2 * mask;
+      if (group_row(logn - l - 1, &cat)) {
+        Fp g[8];
+        sponge_logged(cat.data(), cat.size(), g, kc, log, tag, key, ++mask, false, true, false);
+      }
+    }
+  }
   Fp cur[8];
-  if (!group_hash(logn, cur)) return false;
+  if (!group_row(logn, &cat)) return false;
+  sponge_logged(cat.data(), cat.size(), cur, kc, log, tag, 1, 0, true, false, false);
+  uint32_t key = 1, mask = 0;
   for (int l = 0; l < logn; ++l) {
     Fp sib[8], nxt[8];
     for (int i = 0; i < 8; ++i) sib[i] = Fp::from_canonical(path_canon[8 * l + i]);
-    if ((pos >> l) & 1) compress(sib, cur, nxt, kc);
-    else compress(cur, sib, nxt, kc);
-    Fp g[8];
-    if (group_hash(logn - l - 1, g)) compress(nxt, g, cur, kc);
-    else for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+    const bool right = (pos >> l) & 1;
+    key = 2 * key + (right ? 1u : 0u);
+    mask = 2 * mask;
+    compress_logged(cur, sib, right, nxt, kc, log, right ? P2K_PR : P2K_PL, tag, key, mask);
+    if (group_row(logn - l - 1, &cat)) {
+      Fp g[8];
+      hash_elems(cat.data(), cat.size(), g, kc);
+      compress_logged(nxt, g, false, cur, kc, log, P2K_J, tag, key, ++mask);
+    } else {
+      for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+    }
   }
   for (int i = 0; i < 8; ++i)
     if (cur[i] != root[i]) return false;
+  if (log) {
+    log->p2_rows[log->p2_rows.size() - kP2RecWords] |= kP2FlagSnd;  // the run's last row hands its digest to the verifier
+    uint32_t el[12] = {tag, 0, key, mask};
+    for (int i = 0; i < 8; ++i) el[4 + i] = root[i].to_canonical();
+    log_pub_tuple(log, BUS_DIGEST, false, el, 12);
+  }
   return true;
 }
 
@@ -277,10 +346,10 @@ bool machine_nodes_public(const uint32_t* keys, const uint32_t* digests, size_t 
   hash_elems(flat.data(), 9 * n, dg, kc);
   for (int i = 0; i < 8; ++i) list_digest[i] = dg[i].to_canonical();
   if (rows) {
-    rows->reserve(17 * n_rows);
+    rows->reserve(kP2RecWords * n_rows);
     for (AggNode& a : v) {  // ascending keys: the root first
       if (a.have != 2) continue;
-      rows->push_back(a.key);
+      rows->push_back(P2K_NODE); rows->push_back(0u); rows->push_back(a.key); rows->push_back(0u);  // kind, tag, key, mask
       const AggNode *l = agg_find(v, 2 * a.key), *r = agg_find(v, 2 * a.key + 1);
       for (int i = 0; i < 8; ++i) rows->push_back(l->d[i].to_canonical());
       for (int i = 0; i < 8; ++i) rows->push_back(r->d[i].to_canonical());
@@ -299,7 +368,7 @@ void machine_prep_traces(const MachineProgram& prog, std::vector<uint32_t>* imag
     (*table_prep)[(size_t)TB_P_X * ht + r] = (uint32_t)(r & 255);
     (*table_prep)[(size_t)TB_P_Y * ht + r] = (uint32_t)(r >> 8);
     (*table_prep)[(size_t)TB_P_NA * ht + r] = (r & 3) != 0;
-    (*table_prep)[(size_t)TB_P_NT * ht + r] = r > kAddrHiMax;
+    (*table_prep)[(size_t)TB_P_NT * ht + r] = r == 0 || r > kAddrHiMax;
     (*table_prep)[(size_t)TB_P_XOR * ht + r] = (uint32_t)((r & 255) ^ (r >> 8));
     (*table_prep)[(size_t)TB_P_AND * ht + r] = (uint32_t)((r & 255) & (r >> 8));
   }
@@ -421,6 +490,11 @@ bool parse_machine_header(const uint8_t* bytes, size_t len, MachineHeader* h, st
   if (h->agg_n == 1 || h->agg_n > (1u << 20)) { *err = "aggregation payload of an impossible size"; return false; }
   for (int i = 0; i < 8; ++i)
     if (h->agg_root[i] >= kP || h->agg_digest[i] >= kP) { *err = "non-canonical aggregation digest"; return false; }
+  h->pub_n = w[45 + kNumChips + kHo];
+  memcpy(h->pub_digest, w + 46 + kNumChips + kHo, 32);
+  if (h->pub_n > (1u << 22)) { *err = "public tuple list of an impossible size"; return false; }
+  for (int i = 0; i < 8; ++i)
+    if (h->pub_digest[i] >= kP) { *err = "non-canonical public-tuple digest"; return false; }
   if (h->pv_len > (1u << 24)) { *err = "public values too long"; return false; }
   h->pv_offset = (size_t)kHeaderWords * 4;
   h->body_offset = ((size_t)kHeaderWords + (h->pv_len + 3) / 4) * 4;
@@ -430,10 +504,38 @@ bool parse_machine_header(const uint8_t* bytes, size_t len, MachineHeader* h, st
   return true;
 }
 
+void machine_pub_digest(const uint32_t* pub_tuples, size_t n_pub, uint32_t digest[8]) {
+  memset(digest, 0, 32);
+  if (n_pub == 0) return;
+  std::vector<Fp> flat(n_pub * kPubTupleWords);
+  for (size_t i = 0; i < flat.size(); ++i) flat[i] = Fp::from_canonical(pub_tuples[i] % kP);
+  Fp dg[8];
+  hash_elems(flat.data(), flat.size(), dg, &host_p2_consts());
+  for (int i = 0; i < 8; ++i) digest[i] = dg[i].to_canonical();
+}
+
 int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, uint32_t num_queries, uint32_t pow_bits,
-                         std::string* err, const uint32_t* agg_leaves, size_t n_agg, const uint32_t* agg_keys) {
+                         std::string* err, const uint32_t* agg_leaves, size_t n_agg, const uint32_t* agg_keys,
+                         const uint32_t* pub_tuples, size_t n_pub, LeafCheckLog* log) {
   MachineHeader hd;
   if (!parse_machine_header(bytes, len, &hd, err)) return 7;
+  // public bus tuples: the caller names the statement the proof's buses are claimed to close with; the transcript holds its digest
+  if (hd.pub_n != n_pub) {
+    *err = n_pub ? "the proof does not carry this many public bus tuples" : "the proof carries public bus tuples (a leaf-proof check): verify it with them";
+    return 8;
+  }
+  if (n_pub) {
+    for (size_t i = 0; i < n_pub; ++i) {
+      const uint32_t* t = pub_tuples + kPubTupleWords * i;
+      if (t[1] > 1 || t[3] > (uint32_t)(kPubTupleWords - 4)) { *err = "malformed public bus tuple"; return 7; }
+      for (int j = 0; j < kPubTupleWords; ++j)
+        if (t[j] >= kP) { *err = "non-canonical word in a public bus tuple"; return 7; }
+    }
+    uint32_t dg[8];
+    machine_pub_digest(pub_tuples, n_pub, dg);
+    if (memcmp(dg, hd.pub_digest, 32) != 0) { *err = "the proof was made for another list of public bus tuples"; return 8; }
+  }
+  if (log) { log->p2_rows.clear(); log->fold_rows.clear(); log->pub_tuples.clear(); }
   // the aggregation payload: the caller names the leaves the proof's root is claimed for; the transcript holds their digest
   if (hd.agg_n != n_agg) {
     *err = n_agg ? "the proof does not aggregate this many leaves" : "the proof carries an aggregation payload: verify it with its leaves";
@@ -504,6 +606,8 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   ch.observe_canon(hd.agg_n);
   for (int i = 0; i < 8; ++i) ch.observe_canon(hd.agg_root[i]);
   for (int i = 0; i < 8; ++i) ch.observe_canon(hd.agg_digest[i]);
+  ch.observe_canon(hd.pub_n);
+  for (int i = 0; i < 8; ++i) ch.observe_canon(hd.pub_digest[i]);
   Fp root[4][8];
   for (int i = 0; i < 8; ++i) root[0][i] = Fp::from_canonical(vk.prep_root[i]);
   for (int i = 0; i < 8; ++i) { root[1][i] = Fp::from_canonical(p_root_main[i]); ch.observe(root[1][i]); }
@@ -536,12 +640,22 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     total -= fh.inv();
     // ... and the digest bus of the aggregation payload: the supplied digests go in at their heap keys (the leaves of a full
     // tree at n .. 2n - 1, or a leaf and the siblings of its path), the root comes out at 1
+    // (DIGEST tuples: tag 0, type 2 = heap node, key, mask 0, the digest)
     for (size_t i = 0; i <= n_agg && n_agg; ++i) {
       const uint32_t* d = i < n_agg ? agg_leaves + 8 * i : hd.agg_root;
-      Fp4 f = gamma + fc(BUS_DIGEST) + bpow[1] * fc(i < n_agg ? (agg_keys ? agg_keys[i] : (uint32_t)(n_agg + i)) : 1u);
-      for (int j = 0; j < 8; ++j) f += bpow[2 + j] * fc(d[j]);
+      Fp4 f = gamma + fc(BUS_DIGEST) + bpow[2] * fc(2u) + bpow[3] * fc(i < n_agg ? (agg_keys ? agg_keys[i] : (uint32_t)(n_agg + i)) : 1u);
+      for (int j = 0; j < 8; ++j) f += bpow[5 + j] * fc(d[j]);
       if (i < n_agg) total += f.inv();
       else total -= f.inv();
+    }
+    // ... and the public bus tuples of a leaf-proof check, each sent or received by the verifier with its multiplicity
+    for (size_t i = 0; i < n_pub; ++i) {
+      const uint32_t* t = pub_tuples + kPubTupleWords * i;
+      Fp4 f = gamma + fc(t[0]);
+      for (uint32_t j = 0; j < t[3]; ++j) f += bpow[1 + j] * fc(t[4 + j]);
+      const Fp4 term = f.inv() * Fp::from_canonical(t[2]);
+      if (t[1]) total += term;
+      else total -= term;
     }
     if (total != Fp4::zero()) { *err = "LogUp buses do not balance against the public values and exit code"; return 8; }
   }
@@ -622,6 +736,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       case kBw2: eval_bw(zc); break;
       case kP2: eval_p2(zc); break;
       case kEcall: eval_ecall(zc); break;
+      case kFold: eval_fold(zc); break;
     }
     if (zc.k_ != nb) { *err = "internal: constraint count"; return 7; }
     // LogUp (machine_defs.hpp "LogUp layout"): row = [prep | main] at zeta
@@ -726,7 +841,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
         for (int i = 0; i < shape[r].width[c]; ++i) rows[r][c][i] = Fp::from_canonical(q[i]);
         q += shape[r].width[c];
       }
-      if (!mmcs_verify(shape[r], logh, rows[r], cs, m, q, root[r], kc)) {
+      if (!mmcs_verify(shape[r], logh, rows[r], cs, m, q, root[r], kc, log, leaf_tag(qi, (uint32_t)r))) {
         static const char* names[4] = {"preprocessed", "main", "permutation", "quotient"};
         *err = std::string(names[r]) + " Merkle opening rejected";
         return 8;
@@ -756,6 +871,12 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     };
     auto height_present = [&](int lh) { for (int c = 0; c < kNumChips; ++c) if (logh[c] == lh) return true; return false; };
     Fp4 expect = reduced(lm);
+    auto canon4 = [](const Fp4& v, uint32_t* out) { for (int i = 0; i < 4; ++i) out[i] = v.c[i].to_canonical(); };
+    if (log) {  // the reduced opening the folding starts from
+      uint32_t el[6] = {qi, 0};
+      canon4(expect, el + 2);
+      log_pub_tuple(log, BUS_RO, true, el, 6);
+    }
     Fp shift_k = g;
     for (int k = 0; k < lm; ++k) {
       const int loghk = lm - k;
@@ -763,17 +884,60 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       const size_t mk = m & (hk - 1), mlo = mk & (half - 1);
       const Fp4 lo = read_fp4(q), hi = read_fp4(q + 4);
       if ((mk >= half ? hi : lo) != expect) { *err = "FRI layer value inconsistent with previous fold"; return 8; }
-      Fp pair[8], leaf[8];
+      Fp pair[8], cur[8];
       for (int i = 0; i < 4; ++i) { pair[i] = lo.c[i]; pair[4 + i] = hi.c[i]; }
-      hash_elems(pair, 8, leaf, kc);
-      if (!verify_path(leaf, cs * half + mlo, q + 8, loghk, fri_roots[k].data(), kc)) { *err = "FRI Merkle path rejected"; return 8; }
+      // the layer's opening: the pair's hash, hashed up to the layer's root (with a log: a run of the Poseidon2 chip)
+      const uint32_t tag = leaf_tag(qi, 4 + (uint32_t)k);
+      sponge_logged(pair, 8, cur, kc, log, tag, 1, 0, true, false, true);
+      uint32_t key = 1;
+      const size_t leaf_pos = cs * half + mlo;
+      for (int l = 0; l < loghk; ++l) {
+        Fp sib[8], nxt[8];
+        for (int i = 0; i < 8; ++i) sib[i] = Fp::from_canonical(q[8 + 8 * l + i]);
+        const bool right = (leaf_pos >> l) & 1;
+        key = 2 * key + (right ? 1u : 0u);
+        compress_logged(cur, sib, right, nxt, kc, log, right ? P2K_PR : P2K_PL, tag, key, 0);
+        for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+      }
+      for (int i = 0; i < 8; ++i)
+        if (cur[i] != fri_roots[k][i]) { *err = "FRI Merkle path rejected"; return 8; }
       const Fp xk = (cs ? shift_k * fp_root_of_unity(loghk + 1) : shift_k) * fp_root_of_unity(loghk).pow(mlo);
-      expect = (lo + hi) * inv2 + betas[k] * ((lo - hi) * (inv2 * xk.inv()));
-      if (height_present(loghk - 1)) expect += reduced(loghk - 1);
+      const Fp xinv = xk.inv();
+      expect = (lo + hi) * inv2 + betas[k] * ((lo - hi) * (inv2 * xinv));
+      const bool joins = height_present(loghk - 1);
+      Fp4 ro = Fp4::zero();
+      if (joins) { ro = reduced(loghk - 1); expect += ro; }
+      if (log) {
+        log->p2_rows[log->p2_rows.size() - kP2RecWords] |= kP2FlagSnd;
+        uint32_t el[12] = {tag, 0, key, 0};
+        for (int i = 0; i < 8; ++i) el[4 + i] = fri_roots[k][i].to_canonical();
+        log_pub_tuple(log, BUS_DIGEST, false, el, 12);
+        uint32_t fq[8] = {qi, (uint32_t)k, mk >= half ? 1u : 0u, xinv.to_canonical()};
+        canon4(betas[k], fq + 4);
+        log_pub_tuple(log, BUS_FRIQ, true, fq, 8);
+        if (joins) {
+          uint32_t el2[6] = {qi, (uint32_t)k + 1};
+          canon4(ro, el2 + 2);
+          log_pub_tuple(log, BUS_RO, true, el2, 6);
+        }
+        std::vector<uint32_t>& fr = log->fold_rows;
+        fr.push_back((k == 0 ? 1u : 0u) | (k == lm - 1 ? 2u : 0u) | (mk >= half ? 4u : 0u) | (joins ? 8u : 0u));
+        fr.push_back(qi); fr.push_back((uint32_t)k); fr.push_back(xinv.to_canonical());
+        uint32_t w4[4];
+        canon4(betas[k], w4); fr.insert(fr.end(), w4, w4 + 4);
+        canon4(lo, w4); fr.insert(fr.end(), w4, w4 + 4);
+        canon4(hi, w4); fr.insert(fr.end(), w4, w4 + 4);
+        canon4(ro, w4); fr.insert(fr.end(), w4, w4 + 4);
+      }
       q += 8 + 8 * loghk;
       shift_k = shift_k * shift_k;
     }
     if (expect != final_poly) { *err = "FRI final value mismatch"; return 8; }
+    if (log) {  // the last folded value is the final constant
+      uint32_t el[6] = {qi, (uint32_t)lm - 1};
+      canon4(final_poly, el + 2);
+      log_pub_tuple(log, BUS_FIN, false, el, 6);
+    }
   }
   return 0;
 }

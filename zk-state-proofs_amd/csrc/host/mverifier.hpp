@@ -28,6 +28,7 @@ struct MachineHeader {
   uint32_t handover_pc[mach::kNumCpuInst - 1];  // the pc CPU instance i + 1 starts at
   uint32_t pv_digest[8], deferred_digest[8], vk_digest[8];
   uint32_t agg_n, agg_root[8], agg_digest[8];  // aggregation payload: leaf count (0: none), Merkle root, digest of the leaf list
+  uint32_t pub_n, pub_digest[8];               // public bus tuples (a leaf-proof check's statement): count, digest of the list
   size_t pv_offset, body_offset;
 };
 
@@ -40,14 +41,19 @@ size_t machine_proof_body_words(const int* logh, uint32_t num_queries);
 bool parse_machine_header(const uint8_t* bytes, size_t len, MachineHeader* h, std::string* err);
 // 0 = accepted; 7 = malformed; 8 = rejected.  agg_leaves / n_agg: the leaves ([n][8] canonical words) of the aggregation
 // payload the proof must carry (n_agg = 0: it must carry none).
+// pub_tuples / n_pub: the public bus tuples the proof must close its buses with (n_pub = 0: it must carry none).  log: if
+// given, receives the leaf-check records of THIS proof's query phase (so that another proof can establish them).
 int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, uint32_t num_queries, uint32_t pow_bits,
-                         std::string* err, const uint32_t* agg_leaves = nullptr, size_t n_agg = 0, const uint32_t* agg_keys = nullptr);
+                         std::string* err, const uint32_t* agg_leaves = nullptr, size_t n_agg = 0, const uint32_t* agg_keys = nullptr,
+                         const uint32_t* pub_tuples = nullptr, size_t n_pub = 0, LeafCheckLog* log = nullptr);
+// sponge digest of a list of public bus tuples (what stands for the list in the proof header and the transcript)
+void machine_pub_digest(const uint32_t* pub_tuples, size_t n_pub, uint32_t digest[8]);
 // The aggregation payload's public part and the heap of digests the Poseidon2 chip's rows are expanded from:
 // heap[8 k ..] = node k (root 1, children 2k and 2k + 1, leaf i at n + i; node 0 unused), canonical words.
 // Aggregation payload: n digests supplied at heap keys (keys == nullptr: n + j, the leaves of a full tree; otherwise e.g. a
 // leaf and the siblings along its Merkle path).  Root (node 1), the digest of the list (keys and digests) that stands for
-// it in the transcript, and the Poseidon2 chip's rows: every ancestor of a supplied key in ascending order, 17 words each
-// (key, left child's digest, right child's digest).  False if the set is malformed: a repeated or out-of-range key, a
+// it in the transcript, and the Poseidon2 chip's rows: every ancestor of a supplied key in ascending order, as node records
+// (mach::kP2RecWords words each: kind, tag 0, key, mask 0, left child's digest, right child's digest).  False if the set is malformed: a repeated or out-of-range key, a
 // non-canonical word, an ancestor that is itself supplied or lacks a child.
 bool machine_nodes_public(const uint32_t* keys, const uint32_t* digests, size_t n, uint32_t root[8], uint32_t list_digest[8],
                           std::vector<uint32_t>* rows);
