@@ -236,20 +236,31 @@ def keccak_chip_component(zk, fx, client_opts, pk_elf, seconds_budget=20.0):
             "note": "component only (round-1 format v2): binds keccak-f inputs to outputs, does not prove execution"}
 
 
-def as_committed_mode(zk, fx, device):
-    """The same acct-d8 input with the guest exactly as committed (software keccak, no precompile): 1 406 960
-    cycles, CPU instances of 2^20 and 2^19 rows, keccak chips empty.  Batch 4 resident, 2 timed steps; one proof verified."""
-    NB = 4
-    client = zk.ProverClient(device=device, keccak_mode=zk.KECCAK_OBSERVE, max_batch=NB)
+def as_committed_mode(zk, fx, device, with_oracle, batch=32):
+    """The same acct-d8 input with the guest exactly as committed (reference circuits/elf/riscv32im-succinct-zkvm-elf: software
+    keccak, no precompile): 1 406 960 cycles in six CPU instances of 2^18 rows, keccak chips empty.  `batch` proofs resident
+    (the largest the HBM left by the caller allows, at most 32), 2 timed steps; one proof verified on the host and, with
+    the oracle, compared byte for byte."""
+    from concurrent.futures import ThreadPoolExecutor
+    client = zk.ProverClient(device=device, keccak_mode=zk.KECCAK_OBSERVE, max_batch=batch)
     lib, h = client._lib, client._h
     pk, vk = client.setup(zk.merkle_elf())
-    handles = []
-    t0 = time.perf_counter()
-    for i in range(NB):
+    try:
+        import torch
+        free_b, _tot = torch.cuda.mem_get_info(device)
+    except Exception:
+        free_b = 200 << 30
+    NB = int(max(4, min(batch, (free_b * 4 // 5) // (4 << 30))))  # (an as-committed proof takes 3.6 GB of workspace)
+
+    def trace(i):
         s = zk.SP1Stdin()
         s.write(fx.acct_fixture(8, seed=1 + i).to_borsh())
-        handles.append(client.machine_trace_handle(pk, s))
-    trace_ms = (time.perf_counter() - t0) * 1e3 / NB
+        return client.machine_trace_handle(pk, s)
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=min(NB, usable_cores())) as ex:  # (the library releases the GIL while it traces)
+        handles = list(ex.map(trace, range(NB)))
+    trace_wall_ms = (time.perf_counter() - t0) * 1e3 / NB
     arr = (C.c_void_p * NB)(*[t._h for t in handles])
     if lib.zksp_hip_machine_load(h, pk._h, arr, NB) or lib.zksp_hip_machine_prove(h):
         return {"error": client.last_error()}
@@ -265,10 +276,80 @@ def as_committed_mode(zk, fx, device):
     bodies = np.zeros((NB, bw), np.uint32)
     if lib.zksp_hip_machine_fetch_bodies(h, bodies.ctypes.data_as(C.c_void_p), bodies.size):
         return {"error": client.last_error()}
-    zk.ProverClient(device=-1, keccak_mode=zk.KECCAK_OBSERVE).verify(handles[1].proof_from_body(pk, bodies[1], shape), vk)
+    client.release_workspace()
+    host = zk.ProverClient(device=-1, keccak_mode=zk.KECCAK_OBSERVE)
+    checked = [1, NB - 1]
+    for i in checked:
+        host.verify(handles[i].proof_from_body(pk, bodies[i], shape), vk)
+    equal_idx = None
+    if with_oracle:
+        import oracle
+        s = zk.SP1Stdin()
+        s.write(fx.acct_fixture(8, seed=1 + checked[0]).to_borsh())
+        t = client.machine_trace(pk, s)
+        exp = oracle.machine_prove(dict(t, shape=shape))
+        if handles[checked[0]].proof_from_body(pk, bodies[checked[0]], shape).to_bytes() != exp:
+            return {"error": "as-committed proof differs from the oracle's bytes"}
+        equal_idx = checked[0]
     return {"value": 2 * NB / el, "unit": "proofs/s", "batch": NB, "ms_per_proof": el * 1e3 / (2 * NB), "chip_log_heights": shape,
-            "host_trace_ms_per_proof": trace_ms,
-            "note": "guest as committed: software keccak-f inside the CPU chip (1 406 960 cycles); verified on the host"}
+            "host_trace_wall_ms_per_proof": trace_wall_ms, "host_verified_indices": checked, "oracle_byte_equal_index": equal_idx,
+            "note": "guest as committed: software keccak-f inside the CPU, ALU and bitwise chips (1 406 960 cycles, six CPU "
+                    "instances of 2^18 rows); full parameters (100 queries, 16 PoW bits)"}
+
+
+def leaf_check_mode(zk, fx, client, pk, vk, payload):
+    """Row f4, stage 2a at full parameters: an acct-d8 leaf proof, then ONE more acct-d8 run whose proof also establishes
+    the leaf's query phase (100 queries: every Merkle opening of its four rounds and of its FRI layers, the folding chain) -
+    the unit of a recursion tree's inner node.  Host part (verifying the leaf and logging its openings as chip records)
+    and device part timed apart; verified on the host with the leaf and with the statement alone."""
+    s = zk.SP1Stdin()
+    s.write(payload)
+    leaf = client.prove(pk, s).run()
+    s = zk.SP1Stdin()
+    s.write(payload)
+    t0 = time.perf_counter()
+    client.set_verified_leaf(s, leaf, vk)
+    log_ms = (time.perf_counter() - t0) * 1e3
+    probe = zk.SP1Stdin()
+    probe.write(payload)
+    client.set_verified_leaf(probe, leaf, vk)
+    t = client.machine_trace(pk, probe)
+    rows, folds, tuples = len(t["leaf_p2_rows"]), len(t["leaf_fold_rows"]), len(t["leaf_pub_tuples"])
+    del t, probe
+    times = []
+    outer = None
+    for _ in range(3):
+        s2 = zk.SP1Stdin()
+        s2.write(payload)
+        client.set_verified_leaf(s2, leaf, vk)
+        t1 = time.perf_counter()
+        outer = client.prove(pk, s2).run()
+        times.append((time.perf_counter() - t1) * 1e3)
+    plain = []
+    for _ in range(3):
+        s3 = zk.SP1Stdin()
+        s3.write(payload)
+        t1 = time.perf_counter()
+        client.prove(pk, s3).run()
+        plain.append((time.perf_counter() - t1) * 1e3)
+    host = zk.ProverClient(device=-1)
+    t2 = time.perf_counter()
+    host.verify_with_leaf(outer, vk, leaf, vk)
+    verify_ms = (time.perf_counter() - t2) * 1e3
+    host.verify_public(outer, vk, host.leaf_public(leaf, vk))
+    raw = outer.to_bytes()
+    shape = [int.from_bytes(raw[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
+    prove_ms, plain_ms = sorted(times)[1], sorted(plain)[1]
+    return {"poseidon2_rows": rows, "fold_rows": folds, "public_tuples": tuples,
+            "poseidon2_chip_log_height": shape[zk.MACHINE_CHIP_NAMES.index("poseidon2")],
+            "fold_chip_log_height": shape[zk.MACHINE_CHIP_NAMES.index("fri-fold")],
+            "host_log_ms": log_ms, "prove_end_to_end_ms": prove_ms, "plain_prove_end_to_end_ms": plain_ms,
+            "ms_per_verified_leaf": prove_ms - plain_ms + log_ms, "rows_per_ms": rows / max(prove_ms - plain_ms, 1e-3),
+            "proof_bytes": len(raw), "host_verify_with_leaf_ms": verify_ms,
+            "statement": "the proof also establishes the query phase of the leaf proof: 100 queries x (4 mixed-height Merkle openings "
+                         "with their sponges and injections + every FRI layer opening + the folding chain to the final constant); "
+                         "roots, positions, challenges, reduced openings public (stage 2a); verified on the host with the leaf and "
+                         "with the statement alone"}
 
 
 def workload_stdins(zk, fx, name):
@@ -567,7 +648,7 @@ def main():
         return
 
     # ---- latency, end-to-end and component figures (rank 0, after the timed region) ----
-    single_ms = e2e_ms = e2e_batch_rate = component = as_committed = None
+    single_ms = e2e_ms = e2e_batch_rate = component = as_committed = leaf_check = None
     pipelined = {}
     if not args.skip_single:
         # device time of one resident proof, on a client of its own sized for one proof (what zksp_prove uses)
@@ -615,10 +696,12 @@ def main():
         e2e_batch_rate = nb / e2e_batch_s
         del proofs
         component = keccak_chip_component(zk, fx, {"device": local_rank}, zk.merkle_elf())
-        as_committed = as_committed_mode(zk, fx, local_rank)
         wanted = ["slot-d5x256", "rcptx300", "acct-d8x1024"] if args.workload in ("acct-d8", "all") else [args.workload]
         for wname in wanted:
             pipelined[wname] = pipelined_workload(zk, fx, client, pk, vk, wname)
+        leaf_check = leaf_check_mode(zk, fx, client, pk, vk, payloads[0])
+        client.release_workspace()  # the as-committed batch needs the HBM the timed batch's arena holds
+        as_committed = as_committed_mode(zk, fx, local_rank, use_oracle)
 
     total_proofs = world * B * args.steps
     out = {
@@ -679,6 +762,7 @@ def main():
         "pipelined_workloads": pipelined,
         "keccak_chip_component": component,
         "as_committed_2p21": as_committed,
+        "leaf_check": leaf_check,
     }
     if use_oracle:
         out["cpu_baseline"] = cpu_baseline(trace_of, oracle_s, args.cpu_seconds)

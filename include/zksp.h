@@ -198,6 +198,9 @@ int zksp_machine_cover_heights(const zksp_mtrace* const* traces, size_t n, int32
 const char* zksp_machine_chip_widths(int chip, int32_t* widths3);
 int zksp_hip_machine_load(zksp_client* c, const zksp_pk* pk, const zksp_mtrace* const* traces, size_t n);
 int zksp_hip_machine_prove(zksp_client* c);
+/* Gives the client's batch workspace (one device arena, tens of gigabytes at large batches) and its pinned staging buffers
+ * back; the next load or prove_batch allocates again.  For a process that holds several clients on one GPU. */
+int zksp_hip_release_workspace(zksp_client* c);
 int zksp_hip_machine_fetch_bodies(zksp_client* c, uint32_t* out, size_t cap_words);
 /* Only the 8-word main-trace commitment of every resident proof ([n][8]): what the proof farm all-gathers. */
 int zksp_hip_machine_fetch_roots(zksp_client* c, uint32_t* out, size_t cap_words);

@@ -21,12 +21,25 @@ def test_block_receipt_trie_batch(zk, oracle):
         stdins.append(s)
     proofs, status = client.prove_batch(pk, stdins)
     assert status == [0] * len(receipts)
-    heights = set()
+    groups = {}
     for i, p in enumerate(proofs):
         assert p.public_values == receipts[i]
         client.verify(p, vk)
-        heights.add(p.to_bytes()[8:8 + 4 * zk.MACHINE_CHIPS])  # the chip heights of the machine proof's header
-    assert len(heights) >= 1  # (a group of fewer than sixteen runs joins its neighbour: 48 receipts may share one shape)
+        raw = p.to_bytes()  # the chip heights of the machine proof's header
+        groups.setdefault(tuple(int.from_bytes(raw[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)), []).append(i)
+    # the grouping (a group of fewer than sixteen runs joins the neighbour it disturbs least): every proof was made with the
+    # shape that COVERS the counts of the runs proven with it (the library's own rule, machine_cover_heights, over exactly the
+    # runs that share the shape), and merging only ever lowers the number of shapes below the number of size classes
+    handles = []
+    for i in range(len(receipts)):
+        s = zk.SP1Stdin()
+        s.write(mpt.block_proof_input(trie, i).to_borsh())
+        handles.append(client.machine_trace_handle(pk, s))
+    for shape, idx in groups.items():
+        assert list(shape) == zk.machine_cover_heights([handles[i] for i in idx])
+        cpu_rows = lambda hs: sum(1 << hs[zk.MACHINE_CHIP_NAMES.index(n)] for n in ("cpu", "cpu2", "cpu3", "cpu4", "cpu5", "cpu6", "cpu7", "cpu8"))
+        assert all(cpu_rows(shape) + 8 * 32 >= cpu_rows(handles[i].heights()) // 2 for i in idx)  # (no run was squeezed into a smaller shape)
+    assert 1 <= len(groups) <= len({tuple(h.heights()) for h in handles})
 
 
 def test_storage_proof_composition(zk, oracle):

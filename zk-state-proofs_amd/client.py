@@ -146,6 +146,7 @@ def load_library() -> C.CDLL:
     lib.zksp_machine_chip_widths.restype = C.c_char_p
     lib.zksp_hip_machine_load.argtypes = [vp, vp, C.POINTER(vp), sz]
     lib.zksp_hip_machine_prove.argtypes = [vp]
+    lib.zksp_hip_release_workspace.argtypes = [vp]
     lib.zksp_hip_machine_fetch_bodies.argtypes = [vp, vp, sz]
     lib.zksp_hip_machine_fetch_roots.argtypes = [vp, vp, sz]
     lib.zksp_machine_proof_from_body.argtypes = [vp, vp, vp, vp, sz, C.POINTER(vp)]
@@ -204,7 +205,7 @@ ABI_SYMBOLS = [
     "zksp_machine_chip_widths", "zksp_machine_cover_heights", "zksp_stdin_set_aggregation", "zksp_proof_aggregation", "zksp_verify_aggregate",
     "zksp_stdin_set_aggregation_keyed", "zksp_verify_aggregate_keyed", "zksp_stdin_set_verified_leaf", "zksp_leaf_public", "zksp_verify_public",
     "zksp_verify_with_leaf", "zksp_proof_public_tuples", "zksp_hip_machine_fetch_stage", "zksp_hip_machine_fetch_challenges",
-    "zksp_hip_machine_load", "zksp_hip_machine_prove", "zksp_hip_machine_fetch_bodies", "zksp_hip_machine_fetch_roots", "zksp_machine_proof_from_body", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
+    "zksp_hip_machine_load", "zksp_hip_machine_prove", "zksp_hip_release_workspace", "zksp_hip_machine_fetch_bodies", "zksp_hip_machine_fetch_roots", "zksp_machine_proof_from_body", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
     "zksp_hip_prove_resident", "zksp_proof_from_body", "zksp_hip_fetch_bodies", "zksp_hip_fetch_roots", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
     "zksp_hip_profile_enable", "zksp_hip_profile_read", "zksp_hip_profile_reset", "zksp_dev_malloc", "zksp_dev_free",
     "zksp_dev_upload", "zksp_dev_download", "zksp_dev_memset", "zksp_hip_lde", "zksp_hip_merkle_commit",
@@ -584,6 +585,12 @@ class ProverClient:
         if rc:
             raise ZkspError(rc, self.last_error())
         return MachineTraceHandle(self._lib, h, self._lib.zksp_mtrace_free)
+
+    def release_workspace(self) -> None:
+        """Frees the client's device arena and pinned staging buffers (``zksp_hip_release_workspace``)."""
+        rc = self._lib.zksp_hip_release_workspace(self._h)
+        if rc:
+            raise ZkspError(rc, self.last_error())
 
     def machine_prove_resident(self, pk: ProvingKey, traces):
         """Loads traced runs (MachineTraceHandle), proves them in lockstep on the GPU with one shape

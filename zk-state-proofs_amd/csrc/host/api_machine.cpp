@@ -186,6 +186,26 @@ int zksp_hip_machine_load(zksp_client* c, const zksp_pk* pk, const zksp_mtrace* 
   }
 }
 
+int zksp_hip_release_workspace(zksp_client* c) {
+  if (!c) return ZKSP_ERR_INVALID_ARG;
+  Context* ctx = &c->ctx;
+  if (!ctx->has_device()) return ZKSP_OK;
+  ZKSP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->copy_stream) ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->copy_stream));
+  ctx->mws.reset();
+  if (ctx->arena) (void)hipFree(ctx->arena);
+  ctx->arena = nullptr;
+  ctx->arena_bytes = 0;
+  for (int k = 0; k < 2; ++k) {
+    if (ctx->h_stage2[k]) (void)hipHostFree(ctx->h_stage2[k]);
+    ctx->h_stage2[k] = nullptr;
+    ctx->h_stage2_words[k] = 0;
+  }
+  ctx->body_free = nullptr;
+  return ZKSP_OK;
+}
+
 int zksp_hip_machine_prove(zksp_client* c) {
   if (!c) return ZKSP_ERR_INVALID_ARG;
   if (!c->ctx.has_device()) return c->ctx.fail(ZKSP_ERR_NO_DEVICE, "machine_prove: client has no GPU");

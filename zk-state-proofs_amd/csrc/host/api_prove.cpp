@@ -370,11 +370,21 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage2[slot]), cnt * bw * 4, hipHostMallocDefault) == hipSuccess)
         ctx->h_stage2_words[slot] = cnt * bw;
       else
+        (void)hipGetLastError();  // no pinned memory to be had: a shortage of the host, not a lost device
+    }
+    // the staging buffer: pinned if there is one of that size, else pageable memory (the copy is then not overlapped)
+    uint32_t* stage = ctx->h_stage2_words[slot] >= cnt * bw ? ctx->h_stage2[slot] : nullptr;
+    if (!stage) {
+      try {
+        ctx->h_stage2_pageable[slot].resize(cnt * bw);
+        stage = ctx->h_stage2_pageable[slot].data();
+      } catch (...) {
         copy_ok = false;
+      }
     }
     copy_ok = copy_ok && hipEventRecord(ctx->ev_proved[slot], ctx->stream) == hipSuccess &&
               hipStreamWaitEvent(ctx->copy_stream, ctx->ev_proved[slot], 0) == hipSuccess &&
-              hipMemcpyAsync(ctx->h_stage2[slot], ctx->mws->body, cnt * bw * 4, hipMemcpyDeviceToHost, ctx->copy_stream) == hipSuccess &&
+              hipMemcpyAsync(stage, ctx->mws->body, cnt * bw * 4, hipMemcpyDeviceToHost, ctx->copy_stream) == hipSuccess &&
               hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream) == hipSuccess;
     if (copy_ok) ctx->body_free = ctx->ev_copied[slot];
     if (copy_ok && piggyback) {  // the GPU goes on with the next chunk while this one is fetched and wrapped
@@ -392,7 +402,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       break;
     }
     mark.mark("proved and fetched", cnt);
-    const uint32_t* bodies = ctx->h_stage2[slot];
+    const uint32_t* bodies = stage;
     // (a proof object is 2.6 MB of copying and header work: on one thread the wrapping of a chunk, with the upload of
     // the next, takes as long as the GPU needs for a pass; the tracing threads are idle or few by now)
     parallel_for(cnt, 8, [&](size_t j) {
@@ -408,6 +418,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   }
   if (!first_err.empty() && rc_all == ZKSP_OK) ctx->error = first_err;
   ctx->body_free = nullptr;  // every copy has completed: later passes on this client need no wait
+  for (auto& v : ctx->h_stage2_pageable) std::vector<uint32_t>().swap(v);
   mark.mark("done", n);
   for (auto& t : reaper.th)
     if (t.joinable()) t.join();

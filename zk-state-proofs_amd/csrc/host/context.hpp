@@ -72,6 +72,7 @@ struct Context {
   void* d_inter[mach::kNumChips] = {nullptr};  // indexed by chip
   uint32_t* h_stage2[2] = {nullptr, nullptr};  // pinned host staging for proof bodies (double buffered)
   size_t h_stage2_words[2] = {0, 0};
+  std::vector<uint32_t> h_stage2_pageable[2];  // ... pageable stand-ins while no pinned memory of that size can be had
   // prove_batch copies a group's bodies to the host on its own stream while the next group is
   // proven: ev_proved[slot] marks the end of a pass, ev_copied[slot] the end of its copy.  The next
   // pass waits for body_free (the last copy) only right before its assemble kernel, the one launch
