@@ -136,7 +136,9 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   };
   // A first wave (an eighth of the call, at most max_batch) is traced before anything else so that the GPU starts early;
   // the rest are traced by host threads while it proves them.
-  const size_t w0 = std::min<size_t>(n, std::max<size_t>(1, std::min<size_t>(ctx->params.max_batch, std::max<size_t>(16, (n + 7) / 8))));
+  // (an eighth, at most sixty-four: sixty-four proofs already run at 95 % of the rate of a full batch, and they are traced
+  // and uploaded in a tenth of a second)
+  const size_t w0 = std::min<size_t>(n, std::max<size_t>(1, std::min<size_t>(std::min<size_t>(ctx->params.max_batch, 64), std::max<size_t>(16, (n + 7) / 8))));
   parallel_for(w0, 64, trace_one);
   mark.mark("traced", w0);
   std::string first_err;
@@ -151,6 +153,8 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     size_t group_size;  // runs of these heights in the same window (sizes the workspace once)
   };
   std::vector<Chunk> chunks;
+  size_t last_cap = 0;   // the largest chunk the HBM budget allowed the last group that was cut into chunks
+  size_t size_hint = 0;  // the largest chunk a homogeneous call will load: the workspace is sized for it at the first load
   auto build_chunks = [&](size_t lo, size_t hi) {
     std::map<std::array<int, mach::kNumChips>, std::vector<size_t>> groups;
     std::map<std::array<int, mach::kNumChips>, MachineCounts> covers;
@@ -244,6 +248,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       // more, smaller chunks only lower the rate of a pass)
       const size_t pipe = std::max<size_t>(16, (n + 1) / 2);
       const size_t cap = std::max<size_t>(1, std::min({(size_t)ctx->params.max_batch, budget / std::max<size_t>(per_proof, 1), pipe}));
+      last_cap = cap;
       // chunks of equal size (576 runs under a cap of 174 go as 4 x 144, not 3 x 174 + 54: a small last chunk proves at a
       // poor rate)
       const size_t m = kv.second.size(), nck = (m + cap - 1) / cap, per = (m + nck - 1) / nck;
@@ -266,18 +271,26 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
         if (t.joinable()) t.join();
     }
   } reaper;
-  auto release_chunk = [&](const Chunk& ck) {
+  // (`after`: the event behind an upload nobody has waited for yet, or null)
+  auto release_chunk = [&](const Chunk& ck, hipEvent_t after) {
     std::vector<MachineTrace> dead(ck.idx.size());
     for (size_t j = 0; j < ck.idx.size(); ++j) {
       MachineTrace& t = traces[ck.idx[j]]->t;
       dead[j].cycles.swap(t.cycles); dead[j].keccak.swap(t.keccak); dead[j].memfinal.swap(t.memfinal);
       dead[j].muls.swap(t.muls); dead[j].prog_mult.swap(t.prog_mult); dead[j].alu_idx.swap(t.alu_idx); dead[j].sub_idx.swap(t.sub_idx); dead[j].bw_idx.swap(t.bw_idx);
     }
+    auto bury = [after](std::vector<MachineTrace>& d) {
+      if (after) (void)hipEventSynchronize(after);
+      d.clear();
+    };
     try {
-      reaper.th.emplace_back([d = std::move(dead)]() mutable { d.clear(); });
+      reaper.th.emplace_back([bury, d = std::move(dead)]() mutable { bury(d); });
     } catch (...) {
-    }  // no thread: `dead` is destroyed here instead
+      bury(dead);  // no thread: here instead
+    }
   };
+  // events behind the asynchronous uploads of this call (destroyed when the call is over and the reaper has been joined)
+  std::vector<hipEvent_t> load_events;
   auto load_chunk = [&](const Chunk& ck, bool into_spare) {
     std::vector<const MachineTrace*> ts(ck.idx.size());
     for (size_t j = 0; j < ck.idx.size(); ++j) {
@@ -285,11 +298,25 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       for (int k = 1; k < mach::kNumCpuInst; ++k)
         traces[ck.idx[j]]->handover_pc[k - 1] = machine_handover_pc(pk->mprog, *ts[j], ck.lh.data(), k);
     }
-    if (!into_spare) ctx->batch_hint = (int)ck.group_size;
-    const int rc = machine_load(ctx, pk->mprog, pk->mvk, ts.data(), ts.size(), into_spare, ck.lh.data());
-    mark.mark(into_spare ? "next loaded" : "loaded", ts.size());
+    if (!into_spare) ctx->batch_hint = (int)std::max(ck.group_size, size_hint);
+    hipEvent_t ev = nullptr;
+    if (into_spare) {  // not waited for: the proving stream and the thread that frees the traces wait for this event
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+        try {
+          load_events.push_back(ev);
+        } catch (...) {
+          (void)hipEventDestroy(ev);
+          ev = nullptr;
+        }
+      } else {
+        ev = nullptr;
+      }
+    }
+    const int rc = machine_load(ctx, pk->mprog, pk->mvk, ts.data(), ts.size(), into_spare, ck.lh.data(), ev);
+    mark.mark(into_spare ? "next enqueued" : "loaded", ts.size());
     if (!into_spare && ctx->mws) mark.mark("arena MiB per proof of the workspace", (size_t)(ctx->arena_bytes >> 20) / (size_t)std::max(1, ctx->mws->batch));
-    if (rc == ZKSP_OK) release_chunk(ck);
+    if (rc == ZKSP_OK) release_chunk(ck, ev);
+    else if (ev) (void)hipStreamSynchronize(ctx->copy_stream);  // whatever was enqueued reads the traces: wait before they can go
     return rc;
   };
   auto fail_chunk = [&](const Chunk& ck, int rc) {
@@ -297,8 +324,6 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     rc_all = rc;
   };
 
-  std::promise<void> wave_done;  // (declared before the thread that sets it: destroyed after that thread is joined)
-  std::future<void> wave_ready = wave_done.get_future();
   // declared after `traces` and `reaper`: joined before either is destroyed, on every way out
   struct Joiner {
     std::thread t;
@@ -307,15 +332,31 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     }
   } rest;
   build_chunks(0, w0);
-  // A large batch whose first wave came out with one shape (a homogeneous workload): the next wave is traced and
-  // grouped on its own, before the rest, so that the GPU has a second chunk waiting when the first is proven - tracing
-  // several hundred runs takes longer than proving 64.  A mixed workload keeps one global grouping of the rest (waves
-  // grouped one by one would fragment into small chunks).
-  const size_t w1 = (chunks.size() == 1 && n >= 4 * w0) ? 2 * w0 : w0;
+  // The rest is traced by helper threads, in input order, while the GPU proves; it is GROUPED in waves.  A call whose first
+  // wave came out with one shape (a homogeneous workload) goes on wave by wave - a second wave of twice the first, then
+  // waves of a full chunk - each grouped as soon as its runs are traced, so that the GPU never waits for more than the next
+  // chunk's traces (the host threads trace about three times as fast as the GPU proves).  A mixed workload keeps one global
+  // grouping of everything behind the first wave (waves grouped one by one would fragment into small chunks).
+  std::vector<size_t> wave_end;  // exclusive ends of the waves behind the first
+  if (w0 < n) {
+    if (chunks.size() == 1 && n >= 4 * w0) {
+      wave_end.push_back(3 * w0);
+      const size_t left = n - 3 * w0, cap = std::max<size_t>(16, std::min<size_t>(ctx->params.max_batch, 192));
+      const size_t nw = (left + cap - 1) / cap, per = (left + nw - 1) / nw;  // waves of equal size
+      for (size_t e = 3 * w0 + per; e < n; e += per) wave_end.push_back(e);
+      wave_end.push_back(n);
+      size_hint = std::min(std::max(per, 2 * w0), std::max<size_t>(last_cap, 1));
+    } else {
+      wave_end.push_back(n);
+    }
+  }
+  std::unique_ptr<std::atomic<uint8_t>[]> traced(new std::atomic<uint8_t>[n]);
+  for (size_t i = 0; i < n; ++i) traced[i].store(i < w0 ? 1 : 0, std::memory_order_relaxed);
   auto trace_rest = [&]() {
-    if (w1 > w0) parallel_for(w1 - w0, 64, [&](size_t j) { trace_one(w0 + j); });
-    wave_done.set_value();
-    if (n > w1) parallel_for(n - w1, 64, [&](size_t j) { trace_one(w1 + j); });
+    parallel_for(n - w0, 64, [&](size_t j) {  // (the runs are claimed from one counter: traced in input order)
+      trace_one(w0 + j);
+      traced[w0 + j].store(1, std::memory_order_release);
+    });
   };
   if (w0 < n) {
     try {
@@ -323,27 +364,32 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     } catch (...) {
       trace_rest();  // no thread to spare: trace them here
     }
-  } else {
-    wave_done.set_value();
   }
-  bool wave_built = w1 == w0, rest_built = w0 == n;
-  auto have_chunk = [&](size_t k) {  // does chunk k exist?  (later runs are grouped once their traces are complete)
-    if (k >= chunks.size() && !wave_built) {
-      wave_ready.wait();
-      mark.mark("second wave traced", w1 - w0);
-      build_chunks(w0, w1);
-      wave_built = true;
-    }
-    if (k >= chunks.size() && !rest_built) {
-      if (rest.t.joinable()) rest.t.join();
-      mark.mark("rest traced", n - w1);
-      build_chunks(w1, n);
-      rest_built = true;
+  size_t next_wave = 0, grouped = w0;
+  auto have_chunk = [&](size_t k) {  // does chunk k exist?  (later runs are grouped once their wave's traces are complete)
+    while (k >= chunks.size() && next_wave < wave_end.size()) {
+      const size_t hi = wave_end[next_wave];
+      if (next_wave + 1 == wave_end.size()) {
+        if (rest.t.joinable()) rest.t.join();
+      } else {
+        for (size_t i = grouped; i < hi; ++i)
+          while (!traced[i].load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(200));
+      }
+      mark.mark("wave traced", hi - grouped);
+      build_chunks(grouped, hi);
+      grouped = hi;
+      ++next_wave;
     }
     return k < chunks.size();
   };
   // Chunk k is proven while chunk k + 1 (same heights) is uploaded into the spare record set and chunk k - 1 is
   // wrapped into proof objects; a chunk of other heights waits for the GPU and takes the plain path.
+  struct Joiner2 {
+    std::thread t;
+    ~Joiner2() {
+      if (t.joinable()) t.join();
+    }
+  } wrapper;  // (declared after everything its thread reads)
   bool in_flight = false;  // chunk k's records are resident and its proving pass is enqueued
   for (size_t k = 0; have_chunk(k); ++k) {
     const Chunk ck = chunks[k];  // a copy: grouping the rest may reallocate `chunks`
@@ -403,19 +449,30 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     }
     mark.mark("proved and fetched", cnt);
     const uint32_t* bodies = stage;
-    // (a proof object is 2.6 MB of copying and header work: on one thread the wrapping of a chunk, with the upload of
-    // the next, takes as long as the GPU needs for a pass; the tracing threads are idle or few by now)
-    parallel_for(cnt, 8, [&](size_t j) {
-      const size_t i = ck.idx[j];
-      status[i] = machine_proof_from_parts(pk, traces[i]->t.rec, ck.lh.data(), traces[i]->handover_pc, traces[i]->t.agg_leaves, traces[i]->t.agg_keys,
-                                           traces[i]->t.leaf_check.get(), bodies + j * bw, bw, &out[i]);
-    });
-    mark.mark("wrapped", cnt);
+    // A proof object is 2.6 MB of copying and header work.  The chunk is wrapped on helper threads while this thread goes
+    // on to upload the next one (the upload of a chunk and the wrapping of another, one after the other, took longer than
+    // the GPU needs for a pass).  One wrap is outstanding at a time: the staging slot it reads is written again two chunks
+    // later, after the wrap of the chunk in between has been started - i.e. after this one has been joined.
+    if (wrapper.t.joinable()) wrapper.t.join();
+    auto wrap = [&, ck, bodies, bw, cnt]() {
+      parallel_for(cnt, 8, [&](size_t j) {
+        const size_t i = ck.idx[j];
+        status[i] = machine_proof_from_parts(pk, traces[i]->t.rec, ck.lh.data(), traces[i]->handover_pc, traces[i]->t.agg_leaves, traces[i]->t.agg_keys,
+                                             traces[i]->t.leaf_check.get(), bodies + j * bw, bw, &out[i]);
+      });
+      mark.mark("wrapped", cnt);
+    };
+    try {
+      wrapper.t = std::thread(wrap);
+    } catch (...) {
+      wrap();
+    }
     if (piggyback && rc_next != ZKSP_OK) {
       fail_chunk(chunks[k + 1], rc_next);
       ++k;  // that chunk is lost (its traces may already be released): go on with the one after it
     }
   }
+  if (wrapper.t.joinable()) wrapper.t.join();
   if (!first_err.empty() && rc_all == ZKSP_OK) ctx->error = first_err;
   ctx->body_free = nullptr;  // every copy has completed: later passes on this client need no wait
   for (auto& v : ctx->h_stage2_pageable) std::vector<uint32_t>().swap(v);
@@ -423,6 +480,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   for (auto& t : reaper.th)
     if (t.joinable()) t.join();
   mark.mark("reaper joined", reaper.th.size());
+  for (hipEvent_t ev : load_events) (void)hipEventDestroy(ev);
   // what is left of the traces (execution records: a few hundred kilobytes each) is freed by a helper thread the next
   // call, or the client's destruction, joins: a tenth of a second per 512 runs that the caller does not wait for
   if (ctx->cleanup.joinable()) ctx->cleanup.join();

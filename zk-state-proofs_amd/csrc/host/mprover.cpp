@@ -379,13 +379,17 @@ void swap_records(MachineWorkspace* w) {
 int machine_activate_spare(Context* ctx) {
   MachineWorkspace* w = ctx->mws.get();
   if (!w || w->spare.n == 0) return ctx->fail(1, "machine_activate_spare: nothing was loaded into the spare set");
+  if (w->spare_loaded) {  // an upload nobody waited for: the passes enqueued from now on do
+    ZKSP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, w->spare_loaded, 0));
+    w->spare_loaded = nullptr;
+  }
   swap_records(w);
   w->spare.n = 0;
   return 0;
 }
 
 int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const MachineTrace* const* traces, size_t n,
-                 bool into_spare, const int* shape) {
+                 bool into_spare, const int* shape, hipEvent_t loaded) {
   if (n == 0) return ctx->fail(1, "machine_load: empty batch");
   const PrepDevice* prep = nullptr;
   int rc = machine_prep_ensure(ctx, prog, vk, &prep);
@@ -427,9 +431,15 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     ~SwapBack() { if (on) swap_records(w); }
   } swap_back{w, into_spare};
   if (into_spare) swap_records(w);
-  std::vector<uint32_t> counts(n * kCountWords, 0), nperms(n), obs(n * kMachineInitObs), pubw(n * kPubWords);
-  std::vector<uint64_t> kst(n * w->cap_keccak * 25, 0);
-  std::vector<std::vector<uint32_t>> agg_heaps(n);  // alive until the stream has been synchronised
+  // host staging that outlives the call (an upload into the spare set is not waited for here): the previous load into this
+  // record set has long completed
+  MachineWorkspace::LoadStage& st = w->stage[into_spare ? 1 : 0];
+  std::vector<uint32_t>&counts = st.counts, &nperms = st.nperms, &obs = st.obs, &pubw = st.pubw;
+  std::vector<uint64_t>& kst = st.kst;
+  std::vector<std::vector<uint32_t>>& agg_heaps = st.agg_heaps;
+  counts.assign(n * kCountWords, 0); nperms.assign(n, 0); obs.assign(n * kMachineInitObs, 0); pubw.assign(n * kPubWords, 0);
+  kst.assign(n * w->cap_keccak * 25, 0);
+  agg_heaps.assign(n, std::vector<uint32_t>());
   const size_t hp = (size_t)1 << logh[kProgram];
   for (size_t i = 0; i < n; ++i) {
     const MachineTrace& t = *traces[i];
@@ -518,7 +528,13 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
   ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->n_perms, nperms.data(), nperms.size() * 4, hipMemcpyHostToDevice, s));
   ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->init_obs, obs.data(), obs.size() * 4, hipMemcpyHostToDevice, s));
   ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->pub_words, pubw.data(), pubw.size() * 4, hipMemcpyHostToDevice, s));
-  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // host vectors go out of scope
+  if (into_spare && loaded) {
+    ZKSP_HIP_CHECK(ctx, hipEventRecord(loaded, s));
+    w->spare_loaded = loaded;
+  } else {
+    ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    if (into_spare) w->spare_loaded = nullptr;
+  }
   w->n = (int)n;
   return 0;
 }

@@ -52,6 +52,14 @@ struct MachineWorkspace {
     uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;
     int n = 0;
   } spare;
+  // Host-side staging of a load (counts, transcript words, keccak states, node rows): kept until the next load into the
+  // same record set, because an upload into the spare set is not waited for by the host.
+  struct LoadStage {
+    std::vector<uint32_t> counts, nperms, obs, pubw;
+    std::vector<uint64_t> kst;
+    std::vector<std::vector<uint32_t>> agg_heaps;
+  } stage[2];                     // [0] the resident set's load, [1] the spare set's
+  hipEvent_t spare_loaded = nullptr;  // not owned: recorded behind an asynchronous upload into the spare set (or null)
   // per chip: [0] main, [1] permutation, [2] quotient
   struct Mat { uint32_t *tr = nullptr, *coef = nullptr, *lde = nullptr; int w = 0; };
   Mat mat[mach::kNumChips][3];
@@ -76,9 +84,11 @@ int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineV
 // sizes the workspace for `n` traces and uploads their records.  The batch is proven with ONE shape (chip heights):
 // `shape` if given (every trace must fit it), else the heights of the element-wise maximum of the traces' counts.
 // With `into_spare` the upload goes to the spare record set on the copy stream (the resident batch and a proving pass
-// in flight are untouched; the shape must be the resident batch's).
+// in flight are untouched; the shape must be the resident batch's).  With `loaded` (spare loads only) the call does not
+// wait for the copies: it records `loaded` behind them on the copy stream - the caller keeps the traces alive until the
+// event has passed - and machine_activate_spare makes the proving stream wait for it.
 int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const MachineTrace* const* traces, size_t n,
-                 bool into_spare = false, const int* shape = nullptr);
+                 bool into_spare = false, const int* shape = nullptr, hipEvent_t loaded = nullptr);
 // makes the spare record set the resident batch (call when no proving pass is in flight)
 int machine_activate_spare(Context* ctx);
 // enqueues the whole proving pass over the resident batch
