@@ -730,15 +730,15 @@ __device__ __forceinline__ void wave_hist_add(uint32_t* bins, uint32_t idx, uint
 }
 __global__ __launch_bounds__(kMT) void table_count_kernel(const Interaction* __restrict__ inter, int n_inter,
                                                          const uint32_t* __restrict__ trace, int width, int logh,
-                                                         uint32_t* __restrict__ hist) {
+                                                         uint32_t* __restrict__ hist, int rows_per_block) {
   __shared__ uint32_t lds[3 * kTableLdsBins];  // range16, high address limb, byte pair
   const size_t h = (size_t)1 << logh;
   const int b = blockIdx.y;
   for (uint32_t i = threadIdx.x; i < 3 * kTableLdsBins; i += kMT) lds[i] = 0;
   __syncthreads();
   uint32_t* hb = hist + (size_t)b * kTableWidth * kTableRows;
-  const size_t r0 = (size_t)blockIdx.x * kTableRowsPerBlock;
-  for (size_t rr = threadIdx.x; rr < kTableRowsPerBlock; rr += kMT) {  // every lane of a wave takes every trip: the
+  const size_t r0 = (size_t)blockIdx.x * rows_per_block;
+  for (size_t rr = threadIdx.x; rr < (size_t)rows_per_block; rr += kMT) {  // every lane of a wave takes every trip: the
     const size_t r = r0 + rr;                                            // wave-level aggregation needs converged lanes
     const bool in_range = r < h;
     const RowView rv{nullptr, trace + (size_t)b * width * h + (in_range ? r : 0), 0, h};
@@ -779,14 +779,15 @@ __global__ __launch_bounds__(kMT) void table_count_kernel(const Interaction* __r
 // The CPU chip's seven lookups (machine_defs.cpp g_cpu[7..13]) read from the columns that hold them, instead of through
 // the generic linear forms: three range16 gaps, two pairs of high bytes, the adder output's high limb (kind 2 where it
 // is an address) and its low limb less the byte offset (kind 1 where aligned), the last two on the rows that check X.
-__global__ __launch_bounds__(kMT) void cpu_table_count_kernel(const uint32_t* __restrict__ trace, int logh, uint32_t* __restrict__ hist) {
+__global__ __launch_bounds__(kMT) void cpu_table_count_kernel(const uint32_t* __restrict__ trace, int logh, uint32_t* __restrict__ hist,
+                                                              int rows_per_block) {
   __shared__ uint32_t lds[3 * kTableLdsBins];
   const size_t h = (size_t)1 << logh;
   const int b = blockIdx.y;
   for (uint32_t i = threadIdx.x; i < 3 * kTableLdsBins; i += kMT) lds[i] = 0;
   __syncthreads();
   uint32_t* hb = hist + (size_t)b * kTableWidth * kTableRows;
-  const size_t r0 = (size_t)blockIdx.x * kTableRowsPerBlock;
+  const size_t r0 = (size_t)blockIdx.x * rows_per_block;
   auto range = [&](uint32_t kind, uint32_t v, uint32_t m) {
     const bool ok = m != 0 && v < kTableRows && kind <= 2 && !(kind == 1 && (v & 3)) && !(kind == 2 && (v == 0 || v > kAddrHiMax));
     const bool hot = kind != 1 && v < kTableLdsBins;
@@ -800,7 +801,7 @@ __global__ __launch_bounds__(kMT) void cpu_table_count_kernel(const uint32_t* __
     wave_hist_add(lds, 2 * kTableLdsBins + idx, 1u, ok && hot);
     if (ok && !hot) atomicAdd(&hb[(size_t)TB_M_BY * kTableRows + idx], 1u);
   };
-  for (size_t rr = threadIdx.x; rr < kTableRowsPerBlock; rr += kMT) {  // (converged lanes, as in table_count_kernel)
+  for (size_t rr = threadIdx.x; rr < (size_t)rows_per_block; rr += kMT) {  // (converged lanes, as in table_count_kernel)
     const size_t r = r0 + rr;
     const bool in_range = r < h;
     const uint32_t* row = trace + (size_t)b * kCpuWidth * h + (in_range ? r : 0);
@@ -827,10 +828,14 @@ __global__ __launch_bounds__(kMT) void cpu_table_count_kernel(const uint32_t* __
     if (lds[2 * kTableLdsBins + i]) atomicAdd(&hb[(size_t)TB_M_BY * kTableRows + i], lds[2 * kTableLdsBins + i]);
   }
 }
+// rows a workgroup counts before it adds its LDS histograms to the table's: 4 096, or 512 where a small batch would
+// otherwise run sixteen workgroups on the whole GPU
+static int table_rows_per_block(int batch) { return batch < 8 ? 512 : kTableRowsPerBlock; }
 void launch_cpu_table_count(hipStream_t stream, const uint32_t* trace, int logh, const MachineRecords& rec, int batch) {
   const size_t h = (size_t)1 << logh;
-  hipLaunchKernelGGL(cpu_table_count_kernel, dim3((unsigned)((h + kTableRowsPerBlock - 1) / kTableRowsPerBlock), batch), dim3(kMT), 0,
-                     stream, trace, logh, rec.table_hist);
+  const int rpb = table_rows_per_block(batch);
+  hipLaunchKernelGGL(cpu_table_count_kernel, dim3((unsigned)((h + rpb - 1) / rpb), batch), dim3(kMT), 0, stream, trace, logh,
+                     rec.table_hist, rpb);
 }
 void launch_table_clear(hipStream_t stream, const MachineRecords& rec, int batch) {
   (void)hipMemsetAsync(rec.table_hist, 0, (size_t)batch * kTableWidth * kTableRows * 4, stream);
@@ -838,8 +843,9 @@ void launch_table_clear(hipStream_t stream, const MachineRecords& rec, int batch
 void launch_table_count(hipStream_t stream, const Interaction* inter, int n_inter, const uint32_t* trace, int width, int logh,
                         const MachineRecords& rec, int batch) {
   const size_t h = (size_t)1 << logh;
-  hipLaunchKernelGGL(table_count_kernel, dim3((unsigned)((h + kTableRowsPerBlock - 1) / kTableRowsPerBlock), batch), dim3(kMT), 0, stream,
-                     inter, n_inter, trace, width, logh, rec.table_hist);
+  const int rpb = table_rows_per_block(batch);
+  hipLaunchKernelGGL(table_count_kernel, dim3((unsigned)((h + rpb - 1) / rpb), batch), dim3(kMT), 0, stream, inter, n_inter, trace,
+                     width, logh, rec.table_hist, rpb);
 }
 void launch_table_trace(hipStream_t stream, const MachineRecords& rec, uint32_t* trace, int batch) {
   const size_t n = kTableWidth * kTableRows;

@@ -757,18 +757,23 @@ __global__ __launch_bounds__(kThreads) void open_narrow_kernel(const uint32_t* _
   }
 }
 
-static int open_nsplit(int ncols, int logh) {
+// A batch of fewer than eight proofs splits finer (a single proof would otherwise run four workgroups of 4 096 evaluations
+// each): up to eight times as many splits, so that batch x splits never exceeds what eight proofs take - which is what the
+// scratch is sized for (open_tall_scratch_words) - and no split shorter than 256 evaluations (the narrow kernel's tile).
+static int open_nsplit(int ncols, int logh, int batch) {
   const int h = 1 << logh;
-  return ncols >= 64 ? std::max(1, std::min(128, h / 4096)) : std::max(1, std::min(128, h / 2048));
+  const int base = ncols >= 64 ? std::max(1, std::min(128, h / 4096)) : std::max(1, std::min(128, h / 2048));
+  if (batch >= 8) return base;
+  return std::max(base, std::min({128, h / 256, base * (8 / std::max(batch, 1))}));
 }
 size_t open_tall_scratch_words(int ncols, int logh, int batch) {
-  return (size_t)batch * 2 * open_nsplit(ncols, logh) * ncols * 4;
+  return (size_t)std::max(batch, 8) * 2 * open_nsplit(ncols, logh, 8) * ncols * 4;
 }
 void launch_open_tall(hipStream_t stream, const uint32_t* coefs_br, size_t coefs_stride, int ncols, int logh,
                       const uint32_t* zpow_br, size_t zpow_stride, int npoints, uint32_t* opened, size_t opened_stride,
                       size_t pt_stride, uint32_t* scratch, int batch) {
   const int h = 1 << logh;
-  const int nsplit = open_nsplit(ncols, logh), klen = h / nsplit;
+  const int nsplit = open_nsplit(ncols, logh, batch), klen = h / nsplit;
   if (ncols >= 64)
     hipLaunchKernelGGL(open_tall_kernel, dim3((ncols + kOpenTileCols - 1) / kOpenTileCols, nsplit, batch), dim3(kThreads), 0,
                        stream, coefs_br, coefs_stride, ncols, logh, zpow_br, zpow_stride, npoints, klen, scratch, nsplit);

@@ -35,6 +35,11 @@ Context::~Context() {
     for (hipEvent_t e : ev_copied)
       if (e) (void)hipEventDestroy(e);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    for (hipStream_t sd : side)
+      if (sd) (void)hipStreamDestroy(sd);
+    if (fork_ev) (void)hipEventDestroy(fork_ev);
+    for (hipEvent_t e : join_ev)
+      if (e) (void)hipEventDestroy(e);
     if (timer_a) (void)hipEventDestroy(timer_a);
     if (timer_b) (void)hipEventDestroy(timer_b);
     ws.reset();

@@ -77,6 +77,13 @@ struct Context {
   // proven: ev_proved[slot] marks the end of a pass, ev_copied[slot] the end of its copy.  The next
   // pass waits for body_free (the last copy) only right before its assemble kernel, the one launch
   // that overwrites the body buffer.
+  // Small batches (latency): the chips of a stage are independent, and one proof's kernels are far too small to fill the
+  // GPU one after the other - at batch <= kSideMaxBatch the per-chip loops of a pass fan out over the side streams, by
+  // chip height, and join again at the end of the stage (mprover.cpp StageFork).
+  // (two side streams: the runtime maps streams onto four hardware queues by default, and the copy stream wants one)
+  static constexpr int kSideStreams = 2, kSideMaxBatch = 8;
+  hipStream_t side[kSideStreams] = {nullptr, nullptr};
+  hipEvent_t fork_ev = nullptr, join_ev[kSideStreams] = {nullptr, nullptr};
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_proved[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
   hipEvent_t body_free = nullptr;  // not owned: one of ev_copied, or null

@@ -44,10 +44,85 @@ struct RoundMats {
   int logh[kNumChips];
 };
 
+// A stage whose chips are independent, fanned out over the side streams (Context::side) and joined again: begin() makes the
+// side streams wait for what the main stream has enqueued so far, lane(i) is the stream of lane i (0: the main stream),
+// end() makes the main stream wait for the side streams.  With one lane (large batches) all of it is the main stream and
+// nothing is recorded.  Chips go to lanes by HEIGHT (lane_of): the chips of a height share their quotient, their weight
+// tables and their reduced opening, so they stay in order on one stream.
+struct StageFork {
+  Context* ctx;
+  int lanes;
+  int lane_of_height[32];
+  int lane_of_chip[kNumChips];  // for the stages whose chips share nothing: balanced by cells (longest first)
+  bool ok = true;
+  StageFork(Context* c, int n_lanes, const int* logh) : ctx(c), lanes(n_lanes) {
+    for (int& v : lane_of_height) v = 0;
+    for (int& v : lane_of_chip) v = 0;
+    if (lanes <= 1) { lanes = 1; return; }
+    for (int i = 0; i < Context::kSideStreams && ok; ++i) {
+      if (!ctx->side[i] && hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking) != hipSuccess) ok = false;
+      if (!ctx->join_ev[i] && hipEventCreateWithFlags(&ctx->join_ev[i], hipEventDisableTiming) != hipSuccess) ok = false;
+    }
+    if (ok && !ctx->fork_ev && hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming) != hipSuccess) ok = false;
+    if (!ok) { (void)hipGetLastError(); lanes = 1; return; }
+    // heights and chips to lanes: the heaviest first, each to the lane with the least work so far (cells as the measure)
+    size_t load_h[8] = {0}, load_c[8] = {0}, cells_h[32] = {0}, cells_c[kNumChips];
+    for (int ch = 0; ch < kNumChips; ++ch) {
+      const ChipDef& d = chip_def(ch);
+      cells_c[ch] = (size_t)(d.main_w + d.perm_width() + 8) << logh[ch];
+      cells_h[logh[ch]] += cells_c[ch];
+    }
+    auto lightest = [&](const size_t* load) {
+      int best = 0;
+      for (int l = 1; l < lanes; ++l)
+        if (load[l] < load[best]) best = l;
+      return best;
+    };
+    bool done_h[32] = {false}, done_c[kNumChips] = {false};
+    for (;;) {
+      int h = -1;
+      for (int k = 0; k < 32; ++k)
+        if (cells_h[k] && !done_h[k] && (h < 0 || cells_h[k] > cells_h[h])) h = k;
+      if (h < 0) break;
+      done_h[h] = true;
+      const int l = lightest(load_h);
+      lane_of_height[h] = l;
+      load_h[l] += cells_h[h];
+    }
+    for (;;) {
+      int ch = -1;
+      for (int k = 0; k < kNumChips; ++k)
+        if (!done_c[k] && (ch < 0 || cells_c[k] > cells_c[ch])) ch = k;
+      if (ch < 0) break;
+      done_c[ch] = true;
+      const int l = lightest(load_c);
+      lane_of_chip[ch] = l;
+      load_c[l] += cells_c[ch];
+    }
+  }
+  hipStream_t lane(int i) const { return i == 0 || lanes == 1 ? ctx->stream : ctx->side[i - 1]; }
+  int lane_of(int logh) const { return lanes == 1 ? 0 : lane_of_height[logh]; }
+  int lane_of_a_chip(int chip) const { return lanes == 1 ? 0 : lane_of_chip[chip]; }
+  void begin() const {
+    if (lanes == 1) return;
+    (void)hipEventRecord(ctx->fork_ev, ctx->stream);
+    for (int i = 1; i < lanes; ++i) (void)hipStreamWaitEvent(ctx->side[i - 1], ctx->fork_ev, 0);
+  }
+  void end() const {
+    if (lanes == 1) return;
+    for (int i = 1; i < lanes; ++i) {
+      (void)hipEventRecord(ctx->join_ev[i - 1], ctx->side[i - 1]);
+      (void)hipStreamWaitEvent(ctx->stream, ctx->join_ev[i - 1], 0);
+    }
+  }
+};
+
 // Mixed-height commitment of one round (kernels_machine.h).  tree: [(2N - 1) * 8] words per proof with
-// N = 2 * 2^lm; inj[g]: scratch for the leaf digests of the group whose LDE has 2^g rows.
+// N = 2 * 2^lm; inj[g]: scratch for the leaf digests of the group whose LDE has 2^g rows.  The leaf digests of the height
+// groups are independent of one another (each group's go to a buffer of its own): with a fork they are hashed side by
+// side, before the levels - which depend on one another - are climbed on the main stream.
 int mmcs_commit(hipStream_t s, const RoundMats& rm, uint32_t* tree, size_t tree_bstride, uint32_t* const* inj, int batch,
-                const P2Consts* kc, Context* span_ctx = nullptr, const char* leaf_span = nullptr) {
+                const P2Consts* kc, Context* span_ctx = nullptr, const char* leaf_span = nullptr, const StageFork* fork = nullptr) {
   int lm = 0;
   for (int c = 0; c < kNumChips; ++c)
     if (rm.seg[c][0].width) lm = std::max(lm, rm.logh[c]);
@@ -61,12 +136,46 @@ int mmcs_commit(hipStream_t s, const RoundMats& rm, uint32_t* tree, size_t tree_
   };
   Seg segs[2 * kNumChips];
   int ns = group(logn, segs);
+  const bool side_by_side = fork && fork->lanes > 1;
+  if (side_by_side) {
+    // every group's leaf digests on the lane with the least hashing so far, the groups taken by their permutations (rows x
+    // blocks), the heaviest first; the tallest group stays on the main stream (lane 0) and counts as its first load
+    size_t load[8] = {0}, work[32] = {0};
+    auto blocks = [&](const Seg* sg, int n2) {
+      size_t wd = 0;
+      for (int i = 0; i < n2; ++i) wd += (size_t)sg[i].width;
+      return (wd + 7) / 8;
+    };
+    load[0] = blocks(segs, ns) << logn;
+    for (int l = 1; l < logn; ++l) {
+      Seg sg[2 * kNumChips];
+      const int n2 = group(logn - l, sg);
+      // (a sponge is a chain: a short group of many blocks is bound by its length, not by its rows - count at least 2^14 rows)
+      if (n2) work[l] = blocks(sg, n2) << std::max(logn - l, 14);
+    }
+    fork->begin();
+    for (;;) {
+      int l = -1;
+      for (int k = 1; k < logn; ++k)
+        if (work[k] && (l < 0 || work[k] > work[l])) l = k;
+      if (l < 0) break;
+      int best = 0;
+      for (int q = 1; q < fork->lanes; ++q)
+        if (load[q] < load[best]) best = q;
+      load[best] += work[l];
+      work[l] = 0;
+      Seg sg[2 * kNumChips];
+      const int n2 = group(logn - l, sg);
+      launch_mmcs_leaves(fork->lane(best), sg, n2, logn - l - 1, inj[logn - l], (size_t)8 << (logn - l), batch, kc);
+    }
+  }
   if (span_ctx && leaf_span) {
     ProfileSpan sp(span_ctx, leaf_span);  // exactly one launch: the leaf layer of the tallest matrices
     launch_mmcs_leaves(s, segs, ns, lm, tree, tree_bstride, batch, kc);
   } else {
     launch_mmcs_leaves(s, segs, ns, lm, tree, tree_bstride, batch, kc);
   }
+  if (side_by_side) fork->end();
   for (int l = 1; l <= logn; ++l) {
     const size_t count = (size_t)1 << (logn - l);
     const uint32_t* injp = nullptr;
@@ -74,7 +183,7 @@ int mmcs_commit(hipStream_t s, const RoundMats& rm, uint32_t* tree, size_t tree_
     ns = l < logn ? group(logn - l, segs) : 0;
     if (ns) {
       inj_bstride = (size_t)8 << (logn - l);
-      launch_mmcs_leaves(s, segs, ns, logn - l - 1, inj[logn - l], inj_bstride, batch, kc);
+      if (!side_by_side) launch_mmcs_leaves(s, segs, ns, logn - l - 1, inj[logn - l], inj_bstride, batch, kc);
       injp = inj[logn - l];
     }
     launch_mmcs_level(s, tree + layer_off(logn, l - 1) * 8, tree_bstride, tree + layer_off(logn, l) * 8, tree_bstride, injp,
@@ -309,6 +418,12 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
     A(&w->pubsum, B * 4);
     A(&w->rowsum, B * max_h * 4);
     A(&w->slice_sums, B * (max_h / 4096 + 1) * 4);
+    w->n_streams = batch <= Context::kSideMaxBatch ? 1 + Context::kSideStreams : 1;
+    for (int i = 0; i + 1 < w->n_streams; ++i) {
+      A(&w->side_rowsum[i], B * max_h * 4);
+      A(&w->side_slice_sums[i], B * (max_h / 4096 + 1) * 4);
+      A(&w->side_bsum[i], B * 2 * 4);
+    }
     A(&w->alpha, B * 4);
     A(&w->alpha_pows, B * w->alpha_stride);
     A(&w->zeta, B * 4);
@@ -327,8 +442,10 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
       }
       for (int c = 0; c < kNumChips; ++c)  // ... and of the tall openings
         for (int wdt : {chip_def(c).prep_w, chip_def(c).main_w, chip_def(c).perm_width(), 8})
-          if (wdt) need = std::max(need, open_tall_scratch_words(wdt, logh[c], 1));
-      A(&w->reduce_scratch, B * need);
+          if (wdt) need = std::max(need, open_tall_scratch_words(wdt, logh[c], 1) / 8);  // (words per proof, at eight proofs)
+      const size_t nb = std::max<size_t>(B, 8);  // (a batch below eight splits the tall openings finer: sized as for eight)
+      A(&w->reduce_scratch, nb * need);
+      for (int i = 0; i + 1 < w->n_streams; ++i) A(&w->side_reduce_scratch[i], nb * need);
     }
     A(&w->kpartial, B * 13 * (((size_t)2 << logh[kKeccak]) * 4));
     w->fri_layer_stride = 0;
@@ -587,30 +704,48 @@ int machine_prove_resident(Context* ctx) {
   rec.cap_alu = w->cap_alu; rec.cap_sub = w->cap_sub; rec.cap_bw = w->cap_bw; rec.cap_agg = w->cap_agg; rec.cap_fold = w->cap_fold; rec.cap_ecall = (size_t)1 << logh[kEcall];
   rec.program = prep->program; rec.text_base = prep->text_base; rec.n_program = prep->n_program; rec.n_image = prep->n_image;
   rec.cpu_rows = (uint32_t)machine_cpu_row0(logh, kNumCpuInst);
+  // Small batches: the chips of a stage go to the lanes of a fork (by height) and the stage joins again; large batches have
+  // one lane, the main stream, and everything below is enqueued exactly as it reads.
+  const StageFork fork(ctx, B <= Context::kSideMaxBatch ? w->n_streams : 1, logh);
+  auto SL = [&](int c) { return fork.lane(fork.lane_of(logh[c])); };       // the stream of chip c's height (shared state)
+  auto SC = [&](int c) { return fork.lane(fork.lane_of_a_chip(c)); };       // ... of chip c itself (nothing shared)
+  auto lane_scratch = [&](int c, uint32_t* main_buf, uint32_t* const* side_bufs) {
+    const int l = fork.lane_of(logh[c]);
+    return l == 0 ? main_buf : side_bufs[l - 1];
+  };
+  auto chip_scratch = [&](int c, uint32_t* main_buf, uint32_t* const* side_bufs) {
+    const int l = fork.lane_of_a_chip(c);
+    return l == 0 ? main_buf : side_bufs[l - 1];
+  };
   {
     ProfileSpan sp(ctx, "m_trace");
+    // the table chip answers what the others look up: their RANGE / BYTES receives are counted on their finished traces
+    launch_table_clear(s, rec, B);
+    fork.begin();
     for (int c = 0; c < kNumChips; ++c) {
       if (c == kKeccak) {
         const size_t bs = (size_t)kKeccakWidth * H(c);
-        launch_keccak_trace_strided(s, w->kstates, (int)w->cap_keccak, w->n_perms, w->mat[c][0].tr, bs, logh[c], B);
-        launch_keccak_ts(s, rec, w->mat[c][0].tr, bs, logh[c], B);
+        launch_keccak_trace_strided(SC(c), w->kstates, (int)w->cap_keccak, w->n_perms, w->mat[c][0].tr, bs, logh[c], B);
+        launch_keccak_ts(SC(c), rec, w->mat[c][0].tr, bs, logh[c], B);
       } else if (c != kTable) {
-        launch_machine_trace(s, c, rec, w->mat[c][0].tr, logh[c], B);
+        launch_machine_trace(SC(c), c, rec, w->mat[c][0].tr, logh[c], B);
       }
+      if (is_cpu_chip(c)) launch_cpu_table_count(SC(c), w->mat[c][0].tr, logh[c], rec, B);
+      for (int c2 : {(int)kKmem, (int)kMemFinal, (int)kBw, (int)kBw2, (int)kSub, (int)kSub2, (int)kEcall, (int)kP2})
+        if (c2 == c)
+          launch_table_count(SC(c), static_cast<const Interaction*>(ctx->d_inter[c]), chip_def(c).n_inter, w->mat[c][0].tr,
+                             chip_def(c).main_w, logh[c], rec, B);
     }
-    // the table chip answers what the others look up: count their RANGE / BYTES receives on their finished traces
-    launch_table_clear(s, rec, B);
-    for (int k = 0; k < kNumCpuInst; ++k) launch_cpu_table_count(s, w->mat[cpu_chip(k)][0].tr, logh[cpu_chip(k)], rec, B);
-    for (int c : {(int)kKmem, (int)kMemFinal, (int)kBw, (int)kBw2, (int)kSub, (int)kSub2, (int)kEcall, (int)kP2})
-      launch_table_count(s, static_cast<const Interaction*>(ctx->d_inter[c]), chip_def(c).n_inter, w->mat[c][0].tr, chip_def(c).main_w,
-                         logh[c], rec, B);
+    fork.end();
     launch_table_trace(s, rec, w->mat[kTable][0].tr, B);
   }
   {
     ProfileSpan sp(ctx, "m_lde_main");
+    fork.begin();
     for (int c = 0; c < kNumChips; ++c)
-      launch_lde(s, w->mat[c][0].tr, nullptr, w->mat[c][0].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br, 0,
+      launch_lde(SC(c), w->mat[c][0].tr, nullptr, w->mat[c][0].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br, 0,
                  0, dom[c]->out_scale_br, logh[c], (size_t)B * w->mat[c][0].w);
+    fork.end();
   }
   RoundMats rm[4];
   memset(rm, 0, sizeof rm);
@@ -624,7 +759,7 @@ int machine_prove_resident(Context* ctx) {
   }
   {
     ProfileSpan sp(ctx, "m_commit_main");
-    mmcs_commit(s, rm[1], w->tree[1], tree_stride, w->inj[1], B, kc, ctx, "m_leaf_main");
+    mmcs_commit(s, rm[1], w->tree[1], tree_stride, w->inj[1], B, kc, ctx, "m_leaf_main", &fork);
   }
   {
     ProfileSpan sp(ctx, "transcript");
@@ -635,6 +770,7 @@ int machine_prove_resident(Context* ctx) {
   // ---- LogUp permutation traces ----
   {
     ProfileSpan sp(ctx, "m_perm");
+    fork.begin();
     for (int c = 0; c < kNumChips; ++c) {
       const ChipDef& d = chip_def(c);
       PermArgs pa;
@@ -649,24 +785,27 @@ int machine_prove_resident(Context* ctx) {
       pa.perm_width = d.perm_width();
       pa.perm_bstride = (size_t)d.perm_width() * H(c);
       pa.h_inv = Fp::from_canonical((uint32_t)(H(c) % kP)).inv().v;
-      pa.rowsum = w->rowsum;
-      pa.slice_sums = w->slice_sums;
+      pa.rowsum = chip_scratch(c, w->rowsum, w->side_rowsum);
+      pa.slice_sums = chip_scratch(c, w->slice_sums, w->side_slice_sums);
       pa.cum = w->cum + 4 * c;
       pa.cum_bstride = (size_t)4 * kNumChips;
       pa.logh = logh[c];
       pa.batch = B;
-      launch_perm_trace(s, pa);
+      launch_perm_trace(SC(c), pa);
     }
+    fork.end();
   }
   {
     ProfileSpan sp(ctx, "m_lde_perm");
+    fork.begin();
     for (int c = 0; c < kNumChips; ++c)
-      launch_lde(s, w->mat[c][1].tr, nullptr, w->mat[c][1].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br, 0,
+      launch_lde(SC(c), w->mat[c][1].tr, nullptr, w->mat[c][1].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br, 0,
                  0, dom[c]->out_scale_br, logh[c], (size_t)B * w->mat[c][1].w);
+    fork.end();
   }
   {
     ProfileSpan sp(ctx, "m_commit_perm");
-    mmcs_commit(s, rm[2], w->tree[2], tree_stride, w->inj[2], B, kc);
+    mmcs_commit(s, rm[2], w->tree[2], tree_stride, w->inj[2], B, kc, nullptr, nullptr, &fork);
   }
   {
     ProfileSpan sp(ctx, "transcript");
@@ -678,6 +817,7 @@ int machine_prove_resident(Context* ctx) {
   const Fp g = Fp::from_canonical(kGen);
   {
     ProfileSpan sp(ctx, "m_quotient");
+    fork.begin();
     for (int c = 0; c < kNumChips; ++c) {
       const ChipDef& d = chip_def(c);
       const size_t h = H(c);
@@ -709,23 +849,27 @@ int machine_prove_resident(Context* ctx) {
       qa.pubs_bstride = kPubWords;
       qa.quot = w->mat[quot_leader(logh, c)][2].tr;
       qa.accumulate = quot_leader(logh, c) != c;
-      qa.partial = is_cpu_chip(c) ? w->reduce_scratch : w->kpartial;  // CPU: 8 H words per proof of the scratch's >= 16 H
+      // (CPU: 8 H words per proof of the scratch's >= 16 H; the chips of a height share a lane, so its scratch is theirs)
+      qa.partial = is_cpu_chip(c) ? lane_scratch(c, w->reduce_scratch, w->side_reduce_scratch) : w->kpartial;
       qa.logh = logh[c];
       qa.batch = B;
-      launch_machine_quotient(s, qa);
+      launch_machine_quotient(SL(c), qa);
     }
+    fork.end();
   }
   {
     ProfileSpan sp(ctx, "m_lde_quot");
     // columns 4c..4c+3 of every proof were evaluated over coset c: scale tables 1 and 2
+    fork.begin();
     for (int c = 0; c < kNumChips; ++c)
       if (w->mat[c][2].w)
-        launch_lde(s, w->mat[c][2].tr, nullptr, w->mat[c][2].lde, dom[c]->twc_fwd, dom[c]->twc_inv,
+        launch_lde(SC(c), w->mat[c][2].tr, nullptr, w->mat[c][2].lde, dom[c]->twc_fwd, dom[c]->twc_inv,
                    dom[c]->in_scale_br + H(c), 2, 1, dom[c]->out_scale_br, logh[c], (size_t)B * 8);
+    fork.end();
   }
   {
     ProfileSpan sp(ctx, "m_commit_quot");
-    mmcs_commit(s, rm[3], w->tree[3], tree_stride, w->inj[3], B, kc);
+    mmcs_commit(s, rm[3], w->tree[3], tree_stride, w->inj[3], B, kc, nullptr, nullptr, &fork);
   }
   const size_t R = (size_t)1 << w->open_rows_log;
   {
@@ -735,6 +879,20 @@ int machine_prove_resident(Context* ctx) {
   // ---- openings at zeta and zeta * w_H ----
   {
     ProfileSpan sp(ctx, "m_open");
+    // the weight tables first, one set per height; then every chip against its height's tables
+    fork.begin();
+    for (int c = 0; c < kNumChips; ++c) {
+      bool have = false;  // chips of one height share their tables
+      for (int c2 = 0; c2 < c; ++c2) have = have || logh[c2] == logh[c];
+      if (have) continue;
+      const size_t h = H(c), zs = 4 * h * 4;
+      const uint32_t h_inv = Fp::from_canonical((uint32_t)(h % kP)).inv().v;
+      const Fp g = Fp::from_canonical(kGen), gw = g * fp_root_of_unity(logh[c] + 1);
+      const uint32_t sinv[3] = {kR1, g.inv().v, gw.inv().v};
+      launch_bary_weights(SL(c), w->zeta, 4, sinv, dom[c]->tw_fwd, h_inv, w->zpow[c], zs, logh[c], B);
+    }
+    fork.end();
+    fork.begin();
     for (int c = 0; c < kNumChips; ++c) {
       const ChipDef& d = chip_def(c);
       const size_t h = H(c);
@@ -743,21 +901,14 @@ int machine_prove_resident(Context* ctx) {
       // barycentric weights: table 0 at zeta, table 1 at zeta * w_H (table 0 moved by one place), tables 2 and 3 at zeta
       // for columns given on the cosets g<w_H> and g w_2H <w_H> (the two quotient chunks).  No coefficient arrays.
       const size_t zs = 4 * h * 4;
-      const uint32_t h_inv = Fp::from_canonical((uint32_t)(h % kP)).inv().v;
-      const Fp g = Fp::from_canonical(kGen), gw = g * fp_root_of_unity(logh[c] + 1);
-      bool have = false;  // chips of one height share their tables
-      for (int c2 = 0; c2 < c; ++c2) have = have || logh[c2] == logh[c];
-      if (!have) {
-        const uint32_t sinv[3] = {kR1, g.inv().v, gw.inv().v};
-        launch_bary_weights(s, w->zeta, 4, sinv, dom[c]->tw_fwd, h_inv, w->zpow[c], zs, logh[c], B);
-      }
+      uint32_t* const scratch = chip_scratch(c, w->reduce_scratch, w->side_reduce_scratch);
       uint32_t* base = w->opened + w->open_off[c] * 4;
       const size_t pt_stride = (size_t)mw + ew + (size_t)w->mat[c][2].w;
       // tall columns: split the rows over workgroups (the partial sums live in the reduce scratch, which is not in
       // use yet)
       auto open = [&](const uint32_t* evals, size_t cstride, int ncols, int npts, const uint32_t* table, uint32_t* dst, size_t pts) {
-        if (logh[c] >= 12) launch_open_tall(s, evals, cstride, ncols, logh[c], table, zs, npts, dst, 8 * R, pts, w->reduce_scratch, B);
-        else launch_open(s, evals, cstride, ncols, logh[c], table, zs, npts, dst, 8 * R, pts, B);
+        if (logh[c] >= 12) launch_open_tall(SC(c), evals, cstride, ncols, logh[c], table, zs, npts, dst, 8 * R, pts, scratch, B);
+        else launch_open(SC(c), evals, cstride, ncols, logh[c], table, zs, npts, dst, 8 * R, pts, B);
       };
       if (pw) open(prep->tr[PrepDevice::index_of(c)], 0, pw, 1, w->zpow[c], base, 0);
       open(w->mat[c][0].tr, (size_t)mw * h, mw, 2, w->zpow[c], base + (size_t)pw * 4, pt_stride);
@@ -767,6 +918,7 @@ int machine_prove_resident(Context* ctx) {
         open(w->mat[c][2].tr + 4 * h, 8 * h, 4, 1, w->zpow[c] + 3 * h * 4, base + (size_t)(pw + mw + ew + 4) * 4, 0);
       }
     }
+    fork.end();
   }
   {
     ProfileSpan sp(ctx, "merkle_open");
@@ -781,6 +933,7 @@ int machine_prove_resident(Context* ctx) {
   {
     ProfileSpan sp(ctx, "m_reduce");
     bool seen[32] = {false};
+    fork.begin();
     for (int c = 0; c < kNumChips; ++c) {
       const ChipDef& d = chip_def(c);
       const size_t h = H(c);
@@ -800,8 +953,8 @@ int machine_prove_resident(Context* ctx) {
       ra.shift[0] = g.v;
       ra.shift[1] = (g * fp_root_of_unity(logh[c] + 1)).v;
       ra.w_h = dom[c]->w_h;
-      ra.partial = w->reduce_scratch;
-      ra.bsum = w->bsum;
+      ra.partial = lane_scratch(c, w->reduce_scratch, w->side_reduce_scratch);
+      ra.bsum = lane_scratch(c, w->bsum, w->side_bsum);
       if (logh[c] == lm) { ra.out = w->fri_layers; ra.out_bstride = w->fri_layer_stride; }
       else { ra.out = w->G[logh[c]]; ra.out_bstride = 2 * h * 4; }
       ra.accumulate = seen[logh[c]] ? 1 : 0;
@@ -809,8 +962,9 @@ int machine_prove_resident(Context* ctx) {
       ra.logh = logh[c];
       ra.batch = B;
       (void)d;
-      launch_machine_reduce(s, ra);
+      launch_machine_reduce(SL(c), ra);
     }
+    fork.end();
   }
   // ---- FRI commit phase; an input of height 2^k joins when the folded layer reaches that height ----
   size_t loff = 0, toff = 0;

@@ -71,6 +71,10 @@ struct MachineWorkspace {
   uint32_t *bus_ch = nullptr, *bpow = nullptr, *cum = nullptr, *pubsum = nullptr, *rowsum = nullptr, *slice_sums = nullptr;
   uint32_t *alpha = nullptr, *alpha_pows = nullptr, *zeta = nullptr, *opened = nullptr, *tree_o = nullptr;
   uint32_t *af = nullptr, *af_pows = nullptr, *bsum = nullptr, *kpartial = nullptr, *reduce_scratch = nullptr;
+  // scratch of the side streams (batches of at most Context::kSideMaxBatch proofs): [i] belongs to side stream i
+  int n_streams = 1;  // 1 + the side streams in use
+  uint32_t *side_rowsum[Context::kSideStreams] = {nullptr}, *side_slice_sums[Context::kSideStreams] = {nullptr},
+           *side_bsum[Context::kSideStreams] = {nullptr}, *side_reduce_scratch[Context::kSideStreams] = {nullptr};
   uint32_t *fri_layers = nullptr, *fri_trees = nullptr, *betas = nullptr, *witness = nullptr, *indices = nullptr, *body = nullptr;
   size_t n_open = 0, open_off[mach::kNumChips] = {0}, open_rows_log = 0, alpha_stride = 0;
   size_t fri_layer_stride = 0, fri_tree_stride = 0, body_words = 0;
