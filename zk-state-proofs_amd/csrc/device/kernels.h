@@ -135,9 +135,12 @@ struct FriTailArgs {
   uint32_t* betas;
   size_t beta_stride;
   const uint32_t* tw_inv;
-  uint32_t xinv[32];
+  uint32_t xinv[48];
   int logh, k_start;
   size_t loff_start, toff_start;
+  // machine proofs: the reduced opening that joins the folding after layer k ([B][2^(logh - k)] Fp4, proofs
+  // 4 * 2^(logh - k) words apart), or null
+  const uint32_t* join[24];
 };
 constexpr int kFriTailMaxLogLeaves = 9;
 void launch_fri_tail(hipStream_t stream, const FriTailArgs& a, int batch, const P2Consts* consts);

@@ -140,10 +140,30 @@ __global__ __launch_bounds__(kHashThreads) void leaf_hash_coop_kernel(const uint
   if (act && e < 8) tree[(size_t)blockIdx.y * tree_stride + (size_t)row * 8 + e] = fps_canon(x);
 }
 
+// One subtree of kSubtree digests per workgroup, eight levels in one launch (merkle_coop.hpp).
+constexpr int kSubtreeLog = 8, kSubtree = 1 << kSubtreeLog;
+__global__ __launch_bounds__(kTopThreads) void compress_subtree_kernel(uint32_t* __restrict__ tree, size_t tree_stride,
+                                                                      size_t in_off, int count,
+                                                                      const P2Consts* __restrict__ consts) {
+  const CoopConsts cc = coop_load_consts(consts, threadIdx.x & 15);
+  coop_subtree_levels(tree + (size_t)blockIdx.y * tree_stride, in_off, count, (int)blockIdx.x, kSubtree, cc, consts);
+}
+
 static void launch_upper_layers(hipStream_t stream, int logn, uint32_t* tree, size_t tree_stride, int batch,
                                 const P2Consts* consts) {
   size_t off = 0;
   int count = 1 << logn;
+  // A batch of a few proofs: the levels are a chain of launches that each leave most of the GPU idle - climb eight levels
+  // per launch, a subtree per workgroup, while the layer is wide enough (the cooperative permutation does twice the
+  // arithmetic, which a small batch does not feel).
+  while (batch <= 8 && count >= 4 * kSubtree) {
+    hipLaunchKernelGGL(compress_subtree_kernel, dim3(count / kSubtree, batch), dim3(kTopThreads), 0, stream, tree, tree_stride, off,
+                       count, consts);
+    for (int l = 0; l < kSubtreeLog; ++l) {
+      off += (size_t)count;
+      count >>= 1;
+    }
+  }
   // One lane per parent while a level is wide: always above 512 digests, and in a large batch for
   // as long as the level has 16 K parents batch-wide (the cooperative form below does about twice
   // the arithmetic; it is for the narrow, latency-bound levels).

@@ -1087,7 +1087,8 @@ __global__ __launch_bounds__(kTopThreads) void fri_tail_kernel(FriTailArgs a, co
       const int cset = i >= half ? 1 : 0, m = i - cset * half;
       const Fp4 lo = load_fp4(f + ((size_t)cset * hk + m) * 4), hi = load_fp4(f + ((size_t)cset * hk + m + half) * 4);
       const Fp xinv = Fp::raw(a.xinv[2 * kk + cset]) * Fp::raw(a.tw_inv[(size_t)m << kk]);
-      const Fp4 r = (lo + hi) * inv2 + be * ((lo - hi) * (inv2 * xinv));
+      Fp4 r = (lo + hi) * inv2 + be * ((lo - hi) * (inv2 * xinv));
+      if (a.join[kk]) r += load_fp4(a.join[kk] + ((size_t)b * hk + (size_t)cset * half + m) * 4);
       store_fp4(out + ((size_t)cset * half + m) * 4, r);
     }
     __syncthreads();  // the next layer is complete, and beta_s may be rewritten

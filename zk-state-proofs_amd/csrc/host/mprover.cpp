@@ -971,7 +971,9 @@ int machine_prove_resident(Context* ctx) {
   const size_t hmax = (size_t)1 << lm;
   const DeviceDomain* dmax = ctx->domain(lm);  // the tallest chip's domain (any chip may be the tallest)
   if (!dmax) return 3;
-  for (int k = 0; k < lm; ++k) {
+  // the layers of at most 2^kFriTailMaxLogLeaves leaves are committed, challenged and folded by ONE launch (fri_tail_kernel)
+  const int k_tail = std::max(0, lm - kFriTailMaxLogLeaves);
+  for (int k = 0; k < k_tail; ++k) {
     const int loghk = lm - k;
     const size_t hk = hmax >> k;
     {
@@ -992,6 +994,30 @@ int machine_prove_resident(Context* ctx) {
     }
     loff += 2 * hk * 4;
     toff += 2 * hk - 1;
+  }
+  if (k_tail < lm) {
+    ProfileSpan sp(ctx, "fri_commit");
+    FriTailArgs ta;
+    ta.layers = w->fri_layers;
+    ta.layer_stride = w->fri_layer_stride;
+    ta.trees = w->fri_trees;
+    ta.tree_stride = w->fri_tree_stride;
+    ta.ch = w->ch;
+    ta.betas = w->betas;
+    ta.beta_stride = (size_t)lm * 4;
+    ta.tw_inv = dmax->tw_inv;
+    for (int i = 0; i < 48; ++i) ta.xinv[i] = i < 2 * lm ? dmax->fold_xinv[i] : 0;
+    for (int k = 0; k < 24; ++k) ta.join[k] = k >= k_tail && k < lm && lm - k - 1 >= 0 ? w->G[lm - k - 1] : nullptr;
+    ta.logh = lm;
+    ta.k_start = k_tail;
+    ta.loff_start = loff;
+    ta.toff_start = toff;
+    launch_fri_tail(s, ta, B, kc);
+    for (int k = k_tail; k < lm; ++k) {
+      const size_t hk = hmax >> k;
+      loff += 2 * hk * 4;
+      toff += 2 * hk - 1;
+    }
   }
   {
     ProfileSpan sp(ctx, "transcript");

@@ -286,7 +286,8 @@ int prove_resident(Context* ctx) {
     ta.betas = ws->betas;
     ta.beta_stride = (size_t)logh * 4;
     ta.tw_inv = dom->tw_inv;
-    for (int i = 0; i < 32; ++i) ta.xinv[i] = i < 2 * logh ? dom->fold_xinv[i] : 0;
+    for (int i = 0; i < 48; ++i) ta.xinv[i] = i < 2 * logh ? dom->fold_xinv[i] : 0;
+    for (auto& j : ta.join) j = nullptr;
     ta.logh = logh;
     ta.k_start = k_tail;
     ta.loff_start = loff;
