@@ -662,20 +662,20 @@ def main():
             raise RuntimeError(sc.last_error())
         lib.zksp_hip_sync(sc._h)
         t1 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(20):
             if lib.zksp_hip_machine_prove(sc._h):
                 raise RuntimeError(sc.last_error())
         lib.zksp_hip_sync(sc._h)
-        single_ms = (time.perf_counter() - t1) * 1e3 / 5
+        single_ms = (time.perf_counter() - t1) * 1e3 / 20
         del sh, sc
         e2e = []
-        for _ in range(3):
+        for _ in range(5):
             s = zk.SP1Stdin()
             s.write(payloads[0])
             t2 = time.perf_counter()
             proof = client.prove(pk, s).run()
             e2e.append((time.perf_counter() - t2) * 1e3)
-        e2e_ms = sorted(e2e)[1]  # median of 3: guest tracing, H2D, proving, D2H, proof object
+        e2e_ms = sorted(e2e)[2]  # median of 5: guest tracing, H2D, proving, D2H, proof object
         client.verify(proof, vk)
         nb = 2 * B
         more = [fx.acct_fixture(8, seed=1000 + i).to_borsh() for i in range(nb)]

@@ -79,6 +79,13 @@ struct StageFork {
       return best;
     };
     bool done_h[32] = {false}, done_c[kNumChips] = {false};
+    for (int h = 31; h >= 0; --h)  // (the tallest height first: it stays on the main stream, whatever its share)
+      if (cells_h[h]) {
+        done_h[h] = true;
+        lane_of_height[h] = 0;
+        load_h[0] += cells_h[h];
+        break;
+      }
     for (;;) {
       int h = -1;
       for (int k = 0; k < 32; ++k)
@@ -121,8 +128,12 @@ struct StageFork {
 // N = 2 * 2^lm; inj[g]: scratch for the leaf digests of the group whose LDE has 2^g rows.  The leaf digests of the height
 // groups are independent of one another (each group's go to a buffer of its own): with a fork they are hashed side by
 // side, before the levels - which depend on one another - are climbed on the main stream.
+// With `joined_lde` the caller has OPENED the fork and put every chip's LDE on the lane of its height: each group's leaves
+// then follow their LDEs on that same lane, with no join in between, and the fork is closed here - so that one lane hashes
+// (bound by vector-ALU issue) while another still transforms (bound by memory and LDS), in large batches too.
 int mmcs_commit(hipStream_t s, const RoundMats& rm, uint32_t* tree, size_t tree_bstride, uint32_t* const* inj, int batch,
-                const P2Consts* kc, Context* span_ctx = nullptr, const char* leaf_span = nullptr, const StageFork* fork = nullptr) {
+                const P2Consts* kc, Context* span_ctx = nullptr, const char* leaf_span = nullptr, const StageFork* fork = nullptr,
+                bool joined_lde = false) {
   int lm = 0;
   for (int c = 0; c < kNumChips; ++c)
     if (rm.seg[c][0].width) lm = std::max(lm, rm.logh[c]);
@@ -137,7 +148,13 @@ int mmcs_commit(hipStream_t s, const RoundMats& rm, uint32_t* tree, size_t tree_
   Seg segs[2 * kNumChips];
   int ns = group(logn, segs);
   const bool side_by_side = fork && fork->lanes > 1;
-  if (side_by_side) {
+  if (side_by_side && joined_lde) {
+    for (int l = 1; l < logn; ++l) {
+      Seg sg[2 * kNumChips];
+      const int n2 = group(logn - l, sg);
+      if (n2) launch_mmcs_leaves(fork->lane(fork->lane_of(logn - l - 1)), sg, n2, logn - l - 1, inj[logn - l], (size_t)8 << (logn - l), batch, kc);
+    }
+  } else if (side_by_side) {
     // every group's leaf digests on the lane with the least hashing so far, the groups taken by their permutations (rows x
     // blocks), the heaviest first; the tallest group stays on the main stream (lane 0) and counts as its first load
     size_t load[8] = {0}, work[32] = {0};
@@ -418,11 +435,13 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
     A(&w->pubsum, B * 4);
     A(&w->rowsum, B * max_h * 4);
     A(&w->slice_sums, B * (max_h / 4096 + 1) * 4);
-    w->n_streams = batch <= Context::kSideMaxBatch ? 1 + Context::kSideStreams : 1;
+    // the side lanes' scratch, for as many proofs as a pass on side lanes has at most (any workspace can prove a small batch)
+    w->n_streams = 1 + Context::kSideStreams;
+    const size_t Bs = std::min<size_t>(B, Context::kSideMaxBatch);
     for (int i = 0; i + 1 < w->n_streams; ++i) {
-      A(&w->side_rowsum[i], B * max_h * 4);
-      A(&w->side_slice_sums[i], B * (max_h / 4096 + 1) * 4);
-      A(&w->side_bsum[i], B * 2 * 4);
+      A(&w->side_rowsum[i], Bs * max_h * 4);
+      A(&w->side_slice_sums[i], Bs * (max_h / 4096 + 1) * 4);
+      A(&w->side_bsum[i], Bs * 2 * 4);
     }
     A(&w->alpha, B * 4);
     A(&w->alpha_pows, B * w->alpha_stride);
@@ -445,7 +464,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
           if (wdt) need = std::max(need, open_tall_scratch_words(wdt, logh[c], 1) / 8);  // (words per proof, at eight proofs)
       const size_t nb = std::max<size_t>(B, 8);  // (a batch below eight splits the tall openings finer: sized as for eight)
       A(&w->reduce_scratch, nb * need);
-      for (int i = 0; i + 1 < w->n_streams; ++i) A(&w->side_reduce_scratch[i], nb * need);
+      for (int i = 0; i + 1 < w->n_streams; ++i) A(&w->side_reduce_scratch[i], (size_t)Context::kSideMaxBatch * need);
     }
     A(&w->kpartial, B * 13 * (((size_t)2 << logh[kKeccak]) * 4));
     w->fri_layer_stride = 0;
@@ -739,13 +758,20 @@ int machine_prove_resident(Context* ctx) {
     fork.end();
     launch_table_trace(s, rec, w->mat[kTable][0].tr, B);
   }
+  // A round's LDEs and leaf digests go by height over the lanes of ONE fork, each group's leaves behind its own LDEs with no
+  // join in between.  For small batches that is simply more work in flight.  For large ones it was measured as a way to
+  // run the hashing of the short chips (bound by vector-ALU issue) beside the transforms of the tall ones (ZKSP_OVERLAP=1:
+  // two lanes): 355.1 against 353.9 proofs/s at batch 192 - the chunk transform is bound by butterfly issue itself, the two
+  // kinds of kernels share the vector ALUs instead of complementing each other - so large batches keep one lane.
+  static const bool overlap = getenv("ZKSP_OVERLAP") != nullptr;
+  const StageFork fork2(ctx, B <= Context::kSideMaxBatch ? w->n_streams : (overlap ? 2 : 1), logh);
+  auto HL = [&](int c) { return fork2.lane(fork2.lane_of(logh[c])); };
   {
     ProfileSpan sp(ctx, "m_lde_main");
-    fork.begin();
+    fork2.begin();
     for (int c = 0; c < kNumChips; ++c)
-      launch_lde(SC(c), w->mat[c][0].tr, nullptr, w->mat[c][0].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br, 0,
+      launch_lde(HL(c), w->mat[c][0].tr, nullptr, w->mat[c][0].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br, 0,
                  0, dom[c]->out_scale_br, logh[c], (size_t)B * w->mat[c][0].w);
-    fork.end();
   }
   RoundMats rm[4];
   memset(rm, 0, sizeof rm);
@@ -759,7 +785,7 @@ int machine_prove_resident(Context* ctx) {
   }
   {
     ProfileSpan sp(ctx, "m_commit_main");
-    mmcs_commit(s, rm[1], w->tree[1], tree_stride, w->inj[1], B, kc, ctx, "m_leaf_main", &fork);
+    mmcs_commit(s, rm[1], w->tree[1], tree_stride, w->inj[1], B, kc, ctx, "m_leaf_main", &fork2, true);
   }
   {
     ProfileSpan sp(ctx, "transcript");
@@ -797,15 +823,14 @@ int machine_prove_resident(Context* ctx) {
   }
   {
     ProfileSpan sp(ctx, "m_lde_perm");
-    fork.begin();
+    fork2.begin();
     for (int c = 0; c < kNumChips; ++c)
-      launch_lde(SC(c), w->mat[c][1].tr, nullptr, w->mat[c][1].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br, 0,
+      launch_lde(HL(c), w->mat[c][1].tr, nullptr, w->mat[c][1].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br, 0,
                  0, dom[c]->out_scale_br, logh[c], (size_t)B * w->mat[c][1].w);
-    fork.end();
   }
   {
     ProfileSpan sp(ctx, "m_commit_perm");
-    mmcs_commit(s, rm[2], w->tree[2], tree_stride, w->inj[2], B, kc, nullptr, nullptr, &fork);
+    mmcs_commit(s, rm[2], w->tree[2], tree_stride, w->inj[2], B, kc, nullptr, nullptr, &fork2, true);
   }
   {
     ProfileSpan sp(ctx, "transcript");
@@ -860,16 +885,15 @@ int machine_prove_resident(Context* ctx) {
   {
     ProfileSpan sp(ctx, "m_lde_quot");
     // columns 4c..4c+3 of every proof were evaluated over coset c: scale tables 1 and 2
-    fork.begin();
+    fork2.begin();
     for (int c = 0; c < kNumChips; ++c)
       if (w->mat[c][2].w)
-        launch_lde(SC(c), w->mat[c][2].tr, nullptr, w->mat[c][2].lde, dom[c]->twc_fwd, dom[c]->twc_inv,
+        launch_lde(HL(c), w->mat[c][2].tr, nullptr, w->mat[c][2].lde, dom[c]->twc_fwd, dom[c]->twc_inv,
                    dom[c]->in_scale_br + H(c), 2, 1, dom[c]->out_scale_br, logh[c], (size_t)B * 8);
-    fork.end();
   }
   {
     ProfileSpan sp(ctx, "m_commit_quot");
-    mmcs_commit(s, rm[3], w->tree[3], tree_stride, w->inj[3], B, kc, nullptr, nullptr, &fork);
+    mmcs_commit(s, rm[3], w->tree[3], tree_stride, w->inj[3], B, kc, nullptr, nullptr, &fork2, true);
   }
   const size_t R = (size_t)1 << w->open_rows_log;
   {
