@@ -176,6 +176,9 @@ typedef struct {
   uint32_t keccak_mode;
   uint32_t pv_digest[8];
   uint32_t deferred_digest[8];
+  uint64_t uninit_reads; /* bytes-of-a-load events that read memory which was neither image, nor hinted, nor written before:
+                            such memory starts with prover-chosen contents in the proof (SP1's treatment); 0 = the run cannot
+                            be steered by them */
 } zksp_mtrace_info_t;
 /* Runs the guest with full tracing under the client's keccak mode (does not consume stdin). */
 int zksp_machine_trace(zksp_client* c, const zksp_pk* pk, const zksp_stdin* stdin_, zksp_mtrace** out);

@@ -439,3 +439,37 @@ def test_other_program_other_key(zk, fx, setup):
     assert vk2.machine[0] != vk.machine[0] and vk2.machine[1] != vk.machine[1]
     with pytest.raises(zk.VerificationError):
         other.verify(zk.SP1ProofWithPublicValues.from_bytes(proof), vk2)
+
+
+def test_register_space_has_no_address_lookup_and_commit_index_is_a_whole_register(zk, oracle, setup):
+    """The two properties round 3 left to the honest tracer are constraints now (format v14).
+    (1) A load, store or keccak state address is formed from the adder output whose high limb is looked up as RANGE kind 2;
+    the table chip answers kind 2 for 1 .. 0x77FE only: its multiplicity column for index 0 (an address below 0x10000 - the
+    registers live at addresses 0 .. 31 of the memory bus) and for 0x77FF up is forced to zero, so such a row's bus cannot
+    balance.  (2) COMMIT / COMMIT_DEFERRED put only the low limb of a0 on the PUBC bus; the ecall chip now forces the high
+    limb to zero, so a0 = 0x10000 + i cannot pass for word index i."""
+    client, vk, t, _ = setup
+    CH_TABLE, CH_ECALL = 7, 16
+    TB_P_NT, TB_M_TOP = 3, 2
+    prep, main = oracle.machine_fill(t, CH_TABLE)
+    assert prep[TB_P_NT, 0] == 1 and prep[TB_P_NT, 1] == 0 and prep[TB_P_NT, 0x77FE] == 0 and prep[TB_P_NT, 0x77FF] == 1
+    assert main[TB_M_TOP, 0] == 0  # the honest run looks no address below 0x10000 up
+    for idx in (0, 0x77FF, 0xFFFF):
+        row = main[:, idx].copy()
+        assert not oracle.machine_constraints(CH_TABLE, prep[:, idx], row, main[:, (idx + 1) % 65536], 0, 0, 1).any()
+        row[TB_M_TOP] = 1  # the table "answers" a kind-2 lookup of this index
+        assert oracle.machine_constraints(CH_TABLE, prep[:, idx], row, main[:, (idx + 1) % 65536], 0, 0, 1).any()
+    row = main[:, 0x20].copy()
+    row[TB_M_TOP] = 1
+    assert not oracle.machine_constraints(CH_TABLE, prep[:, 0x20], row, main[:, 0x21], 0, 0, 1).any()  # 0x00200000 is an address
+    # the ecall chip: a COMMIT row whose a0 has a high limb
+    EC_SC, SC_COMMIT, EC_C_HI = 1, 2, 14
+    _, ec = oracle.machine_fill(t, CH_ECALL)
+    pub = oracle.machine_cpu_pub(t, 0)
+    commits = np.nonzero(ec[EC_SC + SC_COMMIT] == 1)[0]
+    assert len(commits) == 8
+    r = int(commits[3])
+    assert not oracle.machine_constraints(CH_ECALL, None, ec[:, r], ec[:, r + 1], 0, 0, 1, pub).any()
+    bad = ec[:, r].copy()
+    bad[EC_C_HI] = 1
+    assert oracle.machine_constraints(CH_ECALL, None, bad, ec[:, r + 1], 0, 0, 1, pub).any()

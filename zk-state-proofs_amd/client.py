@@ -85,7 +85,7 @@ class ExecReport(C.Structure):
 class MTraceInfo(C.Structure):
     _fields_ = [("cycles", C.c_uint64), ("memory_ops", C.c_uint64), ("exit_code", C.c_uint32), ("entry", C.c_uint32),
                 ("log_prog", C.c_uint32), ("log_image", C.c_uint32), ("keccak_mode", C.c_uint32),
-                ("pv_digest", C.c_uint32 * 8), ("deferred_digest", C.c_uint32 * 8)]
+                ("pv_digest", C.c_uint32 * 8), ("deferred_digest", C.c_uint32 * 8), ("uninit_reads", C.c_uint64)]
 
 
 class Params(C.Structure):

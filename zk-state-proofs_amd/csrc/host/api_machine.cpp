@@ -128,6 +128,7 @@ int zksp_mtrace_info(const zksp_mtrace* t, zksp_mtrace_info_t* info) {
   info->keccak_mode = (uint32_t)t->prog->keccak_mode;
   memcpy(info->pv_digest, t->t.rec.pv_digest.data(), 32);
   memcpy(info->deferred_digest, t->t.rec.deferred_digest.data(), 32);
+  info->uninit_reads = t->t.rec.uninit_reads;
   return ZKSP_OK;
 }
 

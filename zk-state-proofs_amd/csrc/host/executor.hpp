@@ -62,6 +62,10 @@ struct ExecutionRecord {
   std::string stdout_text, stderr_text;
   std::vector<KeccakEvent> keccak_events;
   uint64_t memory_ops = 0;            // lw/lh/lb/lbu/lhu/sw/sh/sb executed
+  // traced runs only: loads (and keccak-state reads) of bytes that were neither in the program image, nor hinted, nor
+  // written before.  Memory outside the image starts with prover-chosen contents in the proof (as hinted input must); a run
+  // that never reads such a byte cannot be steered by them.  The committed guest never does (tests/test_machine.py).
+  uint64_t uninit_reads = 0;
   uint64_t syscall_counts[256] = {0}; // indexed by low byte of the code
   std::vector<uint64_t> opcode_hist;  // indexed by Op (filled when want_hist)
 };

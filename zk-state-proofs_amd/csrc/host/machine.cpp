@@ -8,6 +8,7 @@
 #include <sys/mman.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -217,8 +218,13 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
       if (w >= s.lo && w < s.hi) return (int64_t)s.row0 + ((w - s.lo) >> 2);
     return -1;
   };
-  struct Touched { uint32_t addr, init, last_ts, is_init; };
+  struct Touched { uint32_t addr, init, last_ts, is_init, valid /* bytes that are image, hinted or written */; };
   std::vector<Touched> touched;
+  std::vector<std::pair<uint32_t, uint32_t>> hinted;  // [lo, hi) of every HINT_READ
+  // ZKSP_UNINIT_FILL=<byte>: fresh memory (not image, not hinted) starts filled with that byte instead of zero - in the
+  // proof its contents are the prover's choice, and tests/test_machine.py uses this to show that the guest's public values
+  // do not depend on them
+  const int uninit_fill = getenv("ZKSP_UNINIT_FILL") ? (int)(strtoul(getenv("ZKSP_UNINIT_FILL"), nullptr, 0) & 0xff) : -1;
   out->cycles.reserve((size_t)1 << 19);  // virtual pages only: what is not written is never touched
   out->prog_mult.assign(prog.rows.size(), 0);
   uint32_t x[32] = {0}, reg_ts[32] = {0};
@@ -230,17 +236,26 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
 #define CHECK_ADDR(ad, n) if ((uint64_t)(ad) + (n) > kDataTop) FAULT("memory access out of range")
 
   // previous access time of word w, which is touched at time `now`
-  auto touch = [&](uint32_t w, uint32_t now) -> uint32_t {
+  // `reads` / `writes`: masks of the word's bytes the access reads and writes (uninitialised-read accounting)
+  auto touch = [&](uint32_t w, uint32_t now, uint32_t reads, uint32_t writes) -> uint32_t {
     uint32_t id = SH[w >> 2];
     if (id == 0) {
       uint32_t v;
       memcpy(&v, M + w, 4);
       const int64_t ir = image_row(w);
-      touched.push_back({w, v, 0, ir < 0 ? 1u : 0u});
+      bool known = ir >= 0;
+      for (const auto& hr : hinted) known = known || (w >= hr.first && w < hr.second);
+      if (!known && uninit_fill >= 0) {  // analysis aid: what a prover may choose as this word's initial contents
+        memset(M + w, uninit_fill, 4);
+        memcpy(&v, M + w, 4);
+      }
+      touched.push_back({w, v, 0, ir < 0 ? 1u : 0u, known ? 0xfu : 0u});
       id = (uint32_t)touched.size();
       SH[w >> 2] = id;
     }
     Touched& t = touched[id - 1];
+    if ((t.valid & reads) != reads) ++rec.uninit_reads;
+    t.valid |= writes;
     const uint32_t prev = t.last_ts;
     t.last_ts = now;
     return prev;
@@ -304,7 +319,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
           CHECK_ADDR(ad, sz);
           if (ad < kRegSpace) FAULT("guest access below 0x10000 (register-mapped addresses)");
           const uint32_t w = ad & ~3u;
-          c.m_pts = touch(w, ts + 1);  // a load reads its word as the row's second access
+          c.m_pts = touch(w, ts + 1, ((1u << sz) - 1) << (ad & 3), 0);  // a load reads its word as the row's second access
           memcpy(&c.m, M + w, 4);
           c.mv = c.m;
           const uint32_t sh = 8 * (ad & 3);
@@ -324,7 +339,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
           CHECK_ADDR(ad, sz);
           if (ad < kRegSpace) FAULT("guest access below 0x10000 (register-mapped addresses)");
           const uint32_t w = ad & ~3u;
-          c.m_pts = touch(w, ts + 2);
+          c.m_pts = touch(w, ts + 2, 0, ((1u << sz) - 1) << (ad & 3));
           memcpy(&c.m, M + w, 4);
           const uint32_t sh = 8 * (ad & 3);
           if (r.op == AIR_SW) c.mv = b;
@@ -372,6 +387,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
               for (uint32_t w = a0; w < a0 + ((a1 + 3) & ~3u); w += 4)
                 if (SH[w >> 2] != 0 || image_row(w) >= 0 || w < kRegSpace) FAULT("HINT_READ into memory that is already in use");
               memcpy(M + a0, e.data(), e.size());
+              hinted.emplace_back(a0, a0 + ((a1 + 3) & ~3u));
               ++stdin_pos;
               break;
             }
@@ -387,7 +403,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
           KeccakCall k;
           k.ts = ts; k.ptr = ptr;
           memcpy(k.in, M + ptr, 200);
-          for (int i = 0; i < 50; ++i) k.pts[i] = touch(ptr + 4 * (uint32_t)i, ts + 2);
+          for (int i = 0; i < 50; ++i) k.pts[i] = touch(ptr + 4 * (uint32_t)i, ts + 2, 0xf, 0xf);
           uint64_t st[25];
           memcpy(st, k.in, 200);
           keccak_f1600(st);
