@@ -69,3 +69,89 @@ def test_world1_needs_no_process_group():
     farm = importlib.import_module("zk-state-proofs_amd.farm")
     r = np.arange(24, dtype=np.uint32).reshape(3, 8)
     assert np.array_equal(farm.gather_roots(r, 3, 0, 1), r)
+
+
+class _OracleBackedClient:
+    """Stands in for a GPU client in CPU tests: the product's host side traces the guest (device -1), the CPU oracle proves.
+    Same call shape as ProverClient.prove_batch."""
+
+    def __init__(self, zk, oracle, nq, pw):
+        self.zk, self.oracle, self.nq, self.pw = zk, oracle, nq, pw
+        self.host = zk.ProverClient(device=-1, num_queries=nq, pow_bits=pw)
+
+    def setup(self, elf):
+        return self.host.setup(elf)
+
+    def prove_batch(self, pk, stdins):
+        proofs = []
+        for s in stdins:
+            t = self.host.machine_trace(pk, s)
+            proofs.append(self.zk.SP1ProofWithPublicValues.from_bytes(self.oracle.machine_prove(t, num_queries=self.nq, pow_bits=self.pw)))
+        return proofs, [0] * len(stdins)
+
+
+def _machine_worker(rank, world, port, n_total, out_dir):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    import torch.distributed as dist
+    import oracle
+    zk = importlib.import_module("zk-state-proofs_amd")
+    fx = importlib.import_module("zk-state-proofs_amd.fixtures")
+    farm = importlib.import_module("zk-state-proofs_amd.farm")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    client = _OracleBackedClient(zk, oracle, 2, 2)
+    pk, vk = client.setup(zk.merkle_elf())
+    stdins = []
+    for i in range(n_total):  # every rank builds the whole workload's inputs and proves its own shard of it
+        s = zk.SP1Stdin()
+        s.write(fx.acct_fixture(2, seed=70 + i).to_borsh())
+        stdins.append(s)
+    mine, proofs, status = farm.prove_sharded(client, pk, stdins, rank, world)
+    assert status == [0] * len(mine) and mine == farm.shard_indices(n_total, rank, world)
+    for p in proofs:
+        client.host.verify(p, vk)
+    local = np.array([farm.trace_root_of(p.to_bytes()) for p in proofs], np.uint32).reshape(-1, 8)
+    allr = farm.gather_roots(local, n_total, rank, world)
+    np.save(os.path.join(out_dir, f"mroots_{rank}.npy"), allr)
+    # what the gathered list is for: the aggregation payload of one more proof (made by rank 0 here)
+    if rank == 0:
+        leaves = np.vstack([allr, allr[: (1 << (n_total - 1).bit_length()) - n_total]])  # padded to a power of two
+        s = zk.SP1Stdin()
+        s.write(fx.acct_fixture(1, seed=99).to_borsh())
+        s.set_aggregation(leaves)
+        t = client.host.machine_trace(pk, s)
+        t["agg_leaves"] = leaves
+        agg = zk.SP1ProofWithPublicValues.from_bytes(oracle.machine_prove(t, num_queries=2, pow_bits=2))
+        client.host.verify_aggregate(agg, vk, leaves)
+        np.save(os.path.join(out_dir, "agg_root.npy"), np.array(agg.aggregation[1], np.uint32))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_prove_sharded_machine_proofs_world2_gloo(tmp_path, zk, fx, oracle):
+    """BASELINE configs 4 / 5 in miniature on the CPU: two gloo ranks shard a list of guest runs block-cyclically
+    (farm.prove_sharded; the oracle stands in for the GPU), every rank verifies its machine proofs, the 32-byte main-trace
+    commitments are all-gathered into proof order (farm.gather_roots: the path's one exchange), and rank 0 proves the
+    gathered list's Poseidon2 Merkle root as the aggregation payload of one more run."""
+    import torch.multiprocessing as mp
+    world, n_total = 2, 3  # uneven shards: 2 + 1
+    port = _free_port()
+    mp.spawn(_machine_worker, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(tmp_path / f"mroots_{r}.npy") for r in range(world)]
+    assert np.array_equal(got[0], got[1]) and got[0].shape == (n_total, 8)
+    assert len({tuple(x) for x in got[0]}) == n_total
+    # the same commitments, computed serially
+    client = _OracleBackedClient(zk, oracle, 2, 2)
+    pk, _ = client.setup(zk.merkle_elf())
+    farm = importlib.import_module("zk-state-proofs_amd.farm")
+    for i in (0, n_total - 1):
+        s = zk.SP1Stdin()
+        s.write(fx.acct_fixture(2, seed=70 + i).to_borsh())
+        p, _st = client.prove_batch(pk, [s])
+        assert np.array_equal(farm.trace_root_of(p[0].to_bytes()), got[0][i])
+    leaves = np.vstack([got[0], got[0][:1]])
+    assert [int(x) for x in np.load(tmp_path / "agg_root.npy")] == oracle.machine_agg_public(leaves)[0]
