@@ -11,6 +11,9 @@
 // mixed-height Merkle openings, the reduced openings per height, the folding chain.
 #include "mverifier.hpp"
 
+#include <atomic>
+#include <thread>
+
 #include <array>
 #include <cstring>
 
@@ -829,11 +832,15 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   }
   for (int k = 0; k < lm; ++k) perq += 8 + 8 * (size_t)(lm - k);
   const size_t hmax = (size_t)1 << lm;
-  std::vector<std::vector<Fp>> rows[4];
-  for (int r = 0; r < 4; ++r) rows[r].resize(kNumChips);
-  for (uint32_t qi = 0; qi < num_queries; ++qi) {
+  // The queries are independent of one another once their indices are drawn: they are checked on several threads (each with
+  // its own log, appended in query order afterwards), the first failure in query order is the one reported.
+  std::vector<size_t> indices(num_queries);
+  for (uint32_t qi = 0; qi < num_queries; ++qi) indices[qi] = ch.sample_bits(lm + 1);
+  auto check_query = [&](uint32_t qi, LeafCheckLog* log, std::string* err) -> int {
+    std::vector<std::vector<Fp>> rows[4];
+    for (int r = 0; r < 4; ++r) rows[r].resize(kNumChips);
     const uint32_t* q = p_queries + perq * qi;
-    const size_t idx = ch.sample_bits(lm + 1);
+    const size_t idx = indices[qi];
     const size_t cs = idx >> lm, m = idx & (hmax - 1);
     for (int r = 0; r < 4; ++r) {
       for (int c = 0; c < kNumChips; ++c) {
@@ -938,7 +945,33 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       canon4(final_poly, el + 2);
       log_pub_tuple(log, BUS_FIN, false, el, 6);
     }
+    return 0;
+  };
+  const unsigned n_thr = std::max(1u, std::min({std::thread::hardware_concurrency(), 8u, (unsigned)num_queries / 4u}));
+  std::vector<int> q_rc(num_queries, 0);
+  std::vector<std::string> q_err(num_queries);
+  std::vector<LeafCheckLog> q_log(log ? num_queries : 0);
+  std::atomic<uint32_t> next_q{0};
+  auto worker = [&]() {
+    for (uint32_t qi; (qi = next_q.fetch_add(1)) < num_queries;) q_rc[qi] = check_query(qi, log ? &q_log[qi] : nullptr, &q_err[qi]);
+  };
+  {
+    std::vector<std::thread> th;
+    try {
+      for (unsigned t = 1; t < n_thr; ++t) th.emplace_back(worker);
+    } catch (...) {
+    }  // fewer threads than wanted: the queries are claimed from one counter
+    worker();
+    for (auto& t : th) t.join();
   }
+  for (uint32_t qi = 0; qi < num_queries; ++qi)
+    if (q_rc[qi]) { *err = q_err[qi]; return q_rc[qi]; }
+  if (log)
+    for (uint32_t qi = 0; qi < num_queries; ++qi) {
+      log->p2_rows.insert(log->p2_rows.end(), q_log[qi].p2_rows.begin(), q_log[qi].p2_rows.end());
+      log->fold_rows.insert(log->fold_rows.end(), q_log[qi].fold_rows.begin(), q_log[qi].fold_rows.end());
+      log->pub_tuples.insert(log->pub_tuples.end(), q_log[qi].pub_tuples.begin(), q_log[qi].pub_tuples.end());
+    }
   return 0;
 }
 
