@@ -106,17 +106,19 @@ def source_sha256():
 
 def measured_hbm_traffic(batch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC collection
-    (profiles/collect_r03.sh -> profiles/r03_hbm_counters.json: FETCH_SIZE and WRITE_SIZE in separate passes,
+    (profiles/collect_r04.sh -> profiles/r04_hbm_counters.json (r03: the round before): FETCH_SIZE and WRITE_SIZE in separate passes,
     KB units, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  The collection records the
     sha256 of the libzksp.so it ran and its batch size: any other library or batch makes the figure stale
     and this returns None."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_counters.json")))
-        if int(d.get("batch", -1)) != batch or (d.get("lib_sha256") != lib_sha256() and d.get("source_sha256") != source_sha256()):
-            return None
-        return (2.0 * d["FETCH_SIZE"]["zksp::mmcs_leaf_kernel"][1] + d["WRITE_SIZE"]["zksp::mmcs_leaf_kernel"][1]) * 1024.0
-    except (OSError, KeyError, ValueError, TypeError):
-        return None
+    for name in ("r04_hbm_counters.json", "r03_hbm_counters.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if int(d.get("batch", -1)) != batch or (d.get("lib_sha256") != lib_sha256() and d.get("source_sha256") != source_sha256()):
+                continue
+            return (2.0 * d["FETCH_SIZE"]["zksp::mmcs_leaf_kernel"][1] + d["WRITE_SIZE"]["zksp::mmcs_leaf_kernel"][1]) * 1024.0
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None
 
 
 def valu_model(lib, h, achieved_gperm):
@@ -128,7 +130,7 @@ def valu_model(lib, h, achieved_gperm):
     cross-checked there against SQ_INSTS_VALU).  Saturated single-opcode chains measured live are reported beside it
     (they reach 75-90 % of these rates: profiles/r03_opcode_rates.txt has every opcode the kernel uses)."""
     try:
-        mix = json.load(open(os.path.join(ROOT, "profiles", "r03_leaf_opcode_mix.json")))["per_permutation_per_lane"]
+        mix = json.load(open(os.path.join(ROOT, "profiles", "r04_leaf_opcode_mix.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_leaf_opcode_mix.json")) else "r03_leaf_opcode_mix.json")))["per_permutation_per_lane"]
     except (OSError, KeyError, ValueError):
         return None
     simd_clocks = 256 * 4 * 2.4e9

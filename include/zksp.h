@@ -62,6 +62,21 @@ typedef struct {
  *              benchmark; NOT a proof that the guest ran). */
 #define ZKSP_PROOF_MACHINE 1
 #define ZKSP_PROOF_KECCAK_CHIP 2
+/* Layout of a serialized machine proof (zksp_proof_serialize; little-endian u32 words; csrc/host/machine_defs.hpp is the
+ * source of these numbers - kMachineVersion, kHeaderWords):
+ *   word 0           magic
+ *   word 1           format version (14)
+ *   words 2 .. 25    log2 height of each of the ZKSP_MACHINE_CHIPS = 24 chips, in proof order
+ *   word 26, 27      guest exit code, length of the public values in bytes
+ *   words 28 .. 51   sha256(public values) as 8 words, the deferred-proofs digest (8), the verifying-key digest (8)
+ *   words 52 .. 58   the pc at which each of the seven later CPU instances starts (hand-over pcs)
+ *   words 59 .. 75   aggregation payload: number of supplied digests (0: none), their Merkle root (8), digest of the list (8)
+ *   words 76 .. 84   public bus tuples (a leaf-proof check's statement): their number (0: none), digest of the list (8)
+ *   then             the public values, zero-padded to a word; then the proof body (commitment roots, cumulative sums,
+ *                    opened values, FRI roots, final constant, proof-of-work witness, the query openings):
+ *                    zksp_machine_body_words() words.
+ * Everything in the header is absorbed into the transcript before the first challenge is drawn. */
+#define ZKSP_MACHINE_HEADER_WORDS 85
 
 /* replaces ProverClient::new()  (main.rs:61).  Fails with ZKSP_ERR_NO_DEVICE when
  * device_ordinal >= 0 and no GPU is usable: there is no CPU proving fallback.

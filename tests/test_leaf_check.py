@@ -217,3 +217,60 @@ def test_check_of_another_leaf_is_refused(zk, fx, oracle, setup):
     assert other.to_bytes() != leaf.to_bytes()
     with pytest.raises(zk.VerificationError):
         client.verify_with_leaf(zk.SP1ProofWithPublicValues.from_bytes(outer), vk, other, vk)
+
+
+def _run_rows(rows, tag):
+    """Indices of the rows of the run tagged `tag`: its injected-row sponges first (not NEW), then the run proper."""
+    idx = np.nonzero(rows[:, 1] == tag)[0]
+    return idx
+
+
+def test_structural_forgeries_are_refused(zk, oracle, setup):
+    """Forgeries that keep every HASH consistent and change only what kind of step a row claims to be.
+    (1) An injection passed off as a path step with the injected hash as a free sibling - so that the shorter matrices'
+    opened row need not be shown: the same permutation, so every later digest is unchanged and the root is reached, but the
+    position key gains a level and the injection mask loses one - the run's last tuple is not the one the verifier
+    consumes (and the orphaned sponge's tuple is consumed by nobody).
+    (2) The sponge rows of an injected matrix row dropped altogether: the injection row finds nothing to consume.
+    (3) A run that ends one level early and claims the root there: its key is too short."""
+    client, pk, vk, leaf, _, t, _ = setup
+    K_PL, K_J = 4, 6
+    base = t["leaf_p2_rows"]
+    tag = 2  # query 0, main round: a mixed-height opening
+    idx = _run_rows(base, tag)
+    kinds = base[idx, 0] & 15
+
+    def refused(rows):
+        t2 = dict(t, leaf_p2_rows=rows)
+        with pytest.raises(RuntimeError):
+            oracle.machine_prove(t2, num_queries=NQ, pow_bits=POW)
+        bad = zk.SP1ProofWithPublicValues.from_bytes(forced(oracle, t2))
+        with pytest.raises(zk.VerificationError):
+            client.verify_with_leaf(bad, vk, leaf, vk)
+
+    # (1) the first injection of the run becomes a path step; keys and masks of the rest of the run follow the chip's rules
+    rows = base.copy()
+    run = [i for i in idx if (base[i, 0] & 16) or (base[i, 0] & 15) >= K_PL]  # the NEW sponge, then the steps
+    j0 = next(i for i in run if (base[i, 0] & 15) == K_J)
+    rows[j0, 0] = (rows[j0, 0] & ~np.uint32(15)) | K_PL
+    key, mask = int(rows[j0 - 1, 2]), int(rows[j0 - 1, 3])
+    for i in [r for r in run if r >= j0]:
+        k = int(rows[i, 0] & 15)
+        if k == K_J:
+            mask += 1
+        else:
+            key, mask = 2 * key + (1 if k == 5 else 0), 2 * mask
+        rows[i, 2], rows[i, 3] = key, mask % P
+    refused(rows)
+    # (2) the sponge that hashes the first injected row is cut out
+    first = int(idx[0])
+    seg = [first]
+    while not (base[seg[-1], 0] & 32):
+        seg.append(seg[-1] + 1)
+    refused(np.delete(base, seg, axis=0))
+    # (3) the run stops one step early: that row claims to be the end
+    last = int(run[-1])
+    rows = np.delete(base, [last], axis=0)
+    rows[last - 1, 0] |= 32
+    refused(rows)
+    assert (kinds == K_J).sum() >= 2  # (the opening does have several injections)

@@ -12,6 +12,10 @@
 
 using namespace zksp;
 
+static_assert(mach::kHeaderWords == ZKSP_MACHINE_HEADER_WORDS && mach::kNumChips == ZKSP_MACHINE_CHIPS &&
+                  mach::kPubTupleWords == ZKSP_PUB_TUPLE_WORDS,
+              "include/zksp.h describes the proof layout: keep it in step with machine_defs.hpp");
+
 // Header (version, chip heights, exit code, digests, key digest, payload words), public values, body: the proof object.
 int machine_proof_from_parts(const zksp_pk* pk, const ExecutionRecord& r, const int* lh, const uint32_t* handover_pc,
                              const std::vector<uint32_t>& agg_leaves, const std::vector<uint32_t>& agg_keys,
