@@ -57,7 +57,7 @@ typedef struct {
 } zksp_options;
 /* What zksp_prove / zksp_prove_batch establish:
  * MACHINE      the guest's whole execution (CPU instances, memory, program, ALU, keccak, multiplier ... chips joined by
- *              LogUp buses; proof format v14): the statement of the reference's client.prove().
+ *              LogUp buses; proof format v15): the statement of the reference's client.prove().
  * KECCAK_CHIP  only "these keccak-f outputs belong to these inputs" (round-1 format v2, a component
  *              benchmark; NOT a proof that the guest ran). */
 #define ZKSP_PROOF_MACHINE 1
@@ -65,18 +65,18 @@ typedef struct {
 /* Layout of a serialized machine proof (zksp_proof_serialize; little-endian u32 words; csrc/host/machine_defs.hpp is the
  * source of these numbers - kMachineVersion, kHeaderWords):
  *   word 0           magic
- *   word 1           format version (14)
- *   words 2 .. 25    log2 height of each of the ZKSP_MACHINE_CHIPS = 24 chips, in proof order
- *   word 26, 27      guest exit code, length of the public values in bytes
- *   words 28 .. 51   sha256(public values) as 8 words, the deferred-proofs digest (8), the verifying-key digest (8)
- *   words 52 .. 58   the pc at which each of the seven later CPU instances starts (hand-over pcs)
- *   words 59 .. 75   aggregation payload: number of supplied digests (0: none), their Merkle root (8), digest of the list (8)
- *   words 76 .. 84   public bus tuples (a leaf-proof check's statement): their number (0: none), digest of the list (8)
+ *   word 1           format version (15)
+ *   words 2 .. 26    log2 height of each of the ZKSP_MACHINE_CHIPS = 25 chips, in proof order
+ *   word 27, 28      guest exit code, length of the public values in bytes
+ *   words 29 .. 52   sha256(public values) as 8 words, the deferred-proofs digest (8), the verifying-key digest (8)
+ *   words 53 .. 59   the pc at which each of the seven later CPU instances starts (hand-over pcs)
+ *   words 60 .. 76   aggregation payload: number of supplied digests (0: none), their Merkle root (8), digest of the list (8)
+ *   words 77 .. 85   public bus tuples (a leaf-proof check's statement): their number (0: none), digest of the list (8)
  *   then             the public values, zero-padded to a word; then the proof body (commitment roots, cumulative sums,
  *                    opened values, FRI roots, final constant, proof-of-work witness, the query openings):
  *                    zksp_machine_body_words() words.
  * Everything in the header is absorbed into the transcript before the first challenge is drawn. */
-#define ZKSP_MACHINE_HEADER_WORDS 85
+#define ZKSP_MACHINE_HEADER_WORDS 86
 
 /* replaces ProverClient::new()  (main.rs:61).  Fails with ZKSP_ERR_NO_DEVICE when
  * device_ordinal >= 0 and no GPU is usable: there is no CPU proving fallback.
@@ -170,7 +170,7 @@ typedef struct zksp_mtrace zksp_mtrace;
 #define ZKSP_MT_CYCLES 0        /* 12 u32 per executed cycle */
 #define ZKSP_MT_KECCAK 1        /* 408 bytes per precompile call: ts, ptr, 25 u64 in, 50 u32 previous times */
 #define ZKSP_MT_MEMFINAL 2      /* 5 u32 per image address and per other touched address: addr, init, fin, fin_ts, is_init */
-#define ZKSP_MT_MULS 3          /* 3 u32 per mul/mulhu: hi, b, c */
+#define ZKSP_MT_MULS 3          /* 3 u32 per multiplier-chip row: kind (0 mul, 1 mulhu, 2 mulh, 3 mulhsu), b, c */
 #define ZKSP_MT_PROG_MULT 4     /* u32 per Program-table row */
 #define ZKSP_MT_ALU_IDX 5       /* u32 per ALU-chip row: index of the cycle (sll srl sra slt, blt bge) */
 #define ZKSP_MT_PROGRAM 6       /* 9 u32 per row: pc, op, wr, use2, rd, rs1, rs2, imm, tgt; the last row is the padding instruction */
@@ -181,6 +181,7 @@ typedef struct zksp_mtrace zksp_mtrace;
 #define ZKSP_MT_ECALL_IDX 11    /* u32 per ecall-chip row: index of the ecall cycle */
 #define ZKSP_MT_LEAF_P2_ROWS 12   /* leaf-proof check: 20 u32 per Poseidon2-chip row (flags, tag, key, mask, 16 input words) */
 #define ZKSP_MT_LEAF_FOLD_ROWS 13 /* leaf-proof check: 20 u32 per fold-chip row (flags, query, layer, 1/x, beta, lo, hi, ro) */
+#define ZKSP_MT_DIV_IDX 15         /* u32 per divider-chip row: index of the cycle (div divu rem remu) */
 #define ZKSP_MT_LEAF_PUB_TUPLES 14 /* leaf-proof check: 16 u32 per public bus tuple (ZKSP_PUB_TUPLE_WORDS) */
 typedef struct {
   uint64_t cycles;
@@ -204,7 +205,7 @@ int zksp_mtrace_info(const zksp_mtrace* t, zksp_mtrace_info_t* info);
 /* Device-resident machine proving (bench.py, parity tests): upload the records of n traced runs (they are proven
  * with one shape: zksp_machine_cover_heights), enqueue one proving pass, fetch the proof bodies ([n][body_words]
  * canonical u32; body_words = zksp_machine_body_words of that shape). */
-#define ZKSP_MACHINE_CHIPS 24   /* cpu, keccak, keccak-mem, mem-final, image, program, mul, table, cpu2, alu, alu2, subword, subword2, bitwise, bitwise2, poseidon2, ecall, cpu3 .. cpu8, fri-fold */
+#define ZKSP_MACHINE_CHIPS 25   /* cpu, keccak, keccak-mem, mem-final, image, program, mul, table, cpu2, alu, alu2, subword, subword2, bitwise, bitwise2, poseidon2, ecall, cpu3 .. cpu8, fri-fold, divider */
 int zksp_mtrace_heights(const zksp_mtrace* t, int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 size_t zksp_machine_body_words(const zksp_client* c, const int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 /* The shape a batch of these runs is proven with: the chip heights that cover the largest cycle / event / address
@@ -256,7 +257,7 @@ int zksp_proof_public_tuples(const zksp_proof* p, uint32_t* n_tuples, uint32_t* 
  * cumulative sums (4 words each), as the device's transcript sampled / computed them. */
 int zksp_hip_machine_fetch_stage(zksp_client* c, int chip, int stage, size_t proof_index, uint32_t* out, size_t cap_words);
 int zksp_hip_machine_fetch_challenges(zksp_client* c, size_t proof_index, uint32_t* out /* [16 + 4 * ZKSP_MACHINE_CHIPS] */);
-/* Complete proof object (format v14) from one fetched body and the trace it belongs to.  log_heights: the shape the batch was
+/* Complete proof object (format v15) from one fetched body and the trace it belongs to.  log_heights: the shape the batch was
  * proven with (zksp_machine_cover_heights of the loaded traces), NULL = the trace's own minimal heights. */
 int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] or NULL */,
                                  const uint32_t* body, size_t body_words, zksp_proof** out);

@@ -37,7 +37,7 @@ int orc_class_of(uint32_t op) {
     case OP_ADD: return CL_ADD;
     case OP_SUB: return CL_SUB;
     case OP_XOR: case OP_OR: case OP_AND: case OP_SLL: case OP_SRL: case OP_SRA: case OP_SLT: case OP_SLTU:
-    case OP_MUL: case OP_MULHU: return CL_ALU;
+    case OP_MUL: case OP_MULHU: case OP_MULH: case OP_MULHSU: case OP_DIV: case OP_DIVU: case OP_REM: case OP_REMU: return CL_ALU;
     case OP_JAL: return CL_JAL;
     case OP_JALR: return CL_JALR;
     case OP_BEQ: return CL_BEQ;
@@ -56,7 +56,8 @@ int orc_class_of(uint32_t op) {
 uint32_t orc_code_of(uint32_t op) {
   switch (op) {
     case OP_XOR: case OP_OR: case OP_AND: case OP_SLL: case OP_SRL: case OP_SRA: case OP_SLT: case OP_SLTU:
-    case OP_MUL: case OP_MULHU: case OP_LB: case OP_LH: case OP_LBU: case OP_LHU: case OP_SB: case OP_SH: return op;
+    case OP_MUL: case OP_MULHU: case OP_MULH: case OP_MULHSU: case OP_DIV: case OP_DIVU: case OP_REM: case OP_REMU:
+    case OP_LB: case OP_LH: case OP_LBU: case OP_LHU: case OP_SB: case OP_SH: return op;
     case OP_BLT: case OP_BGE: return OP_SLT;
     case OP_BLTU: case OP_BGEU: return OP_SLTU;
     default: return 0;
@@ -70,6 +71,7 @@ static int event_kind(uint32_t op) {
   if (code == OP_LB || code == OP_LH || code == OP_LBU || code == OP_LHU || code == OP_SB || code == OP_SH) return 1;
   if (code >= OP_XOR && code <= OP_AND) return 2;
   if (op == OP_ECALL) return 3;
+  if (op >= OP_DIV && op <= OP_REMU) return 4; /* the divider chip */
   return -1;
 }
 
@@ -102,7 +104,7 @@ static orc_lf lf_bits(int bits, int n) {
 #define SELC(cls) (C_SEL + (cls) - 1)
 
 #define CPU_INTER 19
-static orc_inter g_cpu[CPU_INTER], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7],
+static orc_inter g_cpu[CPU_INTER], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[5], g_div[13], g_table[7],
     g_alu[1], g_sub[5], g_bw[5], g_p2[7], g_ecall[10], g_fold[5];
 static orc_chip g_chips[N_CHIPS];
 static int g_ready = 0;
@@ -337,10 +339,49 @@ static void build(void) {
     memset(it, 0, sizeof *it);
     it->bus = BUS_ALU; it->sign = -1; it->n_el = 7;
     if (hi) it->mult = lf_col(MU_HI);
-    else it->mult = lf_pair(MU_IS_REAL, MU_HI, FP - 1);
+    else { it->mult = lf_pair(MU_IS_REAL, MU_HI, FP - 1); lf_add(&it->mult, MU_SH, FP - 1); lf_add(&it->mult, MU_SHU, FP - 1); }
     it->el[0] = lf_const(hi ? OP_MULHU : OP_MUL);
     it->el[1] = lf_bits(MU_P + 32 * hi, 16); it->el[2] = lf_bits(MU_P + 32 * hi + 16, 16);
     it->el[3] = lf_bits(MU_B, 16); it->el[4] = lf_bits(MU_B + 16, 16); it->el[5] = lf_bits(MU_C, 16); it->el[6] = lf_bits(MU_C + 16, 16);
+  }
+  {
+    /* mulh / mulhsu: the signed high word R, range-checked */
+    orc_inter* it = &g_mul[2];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_ALU; it->sign = -1; it->n_el = 7;
+    it->mult = lf_pair(MU_SH, MU_SHU, 1);
+    lf_zero(&it->el[0]); lf_add(&it->el[0], MU_SH, OP_MULH); lf_add(&it->el[0], MU_SHU, OP_MULHSU);
+    it->el[1] = lf_col(MU_R); it->el[2] = lf_col(MU_R + 1);
+    it->el[3] = lf_bits(MU_B, 16); it->el[4] = lf_bits(MU_B + 16, 16); it->el[5] = lf_bits(MU_C, 16); it->el[6] = lf_bits(MU_C + 16, 16);
+    g_mul[3] = range_inter(-1, lf_pair(MU_SH, MU_SHU, 1), zero, lf_col(MU_R));
+    g_mul[4] = range_inter(-1, lf_pair(MU_SH, MU_SHU, 1), zero, lf_col(MU_R + 1));
+  }
+  /* ---- divider: the instruction from the CPU row, the product |q| |d| from the multiplier chip (low word PL, high word
+   * zero), range lookups ---- */
+  {
+    const orc_lf real = lf_col(DV_IS_REAL), nzd = lf_col(DV_NZD), sgn = lf_pair(DV_F + 0, DV_F + 2, 1);
+    orc_inter* it = &g_div[0];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_ALU; it->sign = -1; it->mult = real; it->n_el = 7;
+    lf_zero(&it->el[0]);
+    lf_add(&it->el[0], DV_F + 0, OP_DIV); lf_add(&it->el[0], DV_F + 1, OP_DIVU); lf_add(&it->el[0], DV_F + 2, OP_REM); lf_add(&it->el[0], DV_F + 3, OP_REMU);
+    it->el[1] = lf_col(DV_A); it->el[2] = lf_col(DV_A + 1); it->el[3] = lf_col(DV_N); it->el[4] = lf_col(DV_N + 1);
+    it->el[5] = lf_col(DV_D); it->el[6] = lf_col(DV_D + 1);
+    for (int hi = 0; hi < 2; ++hi) {
+      it = &g_div[1 + hi];
+      memset(it, 0, sizeof *it);
+      it->bus = BUS_ALU; it->sign = +1; it->mult = nzd; it->n_el = 7;
+      it->el[0] = lf_const(hi ? OP_MULHU : OP_MUL);
+      it->el[1] = hi ? zero : lf_col(DV_PL); it->el[2] = hi ? zero : lf_col(DV_PL + 1);
+      it->el[3] = lf_col(DV_AQ); it->el[4] = lf_col(DV_AQ + 1); it->el[5] = lf_col(DV_AD); it->el[6] = lf_col(DV_AD + 1);
+    }
+    static const int checked[8] = {DV_A, DV_A + 1, DV_AN, DV_AN + 1, DV_AR, DV_AR + 1, DV_E, DV_E + 1};
+    for (int k = 0; k < 8; ++k) g_div[3 + k] = range_inter(-1, real, zero, lf_col(checked[k]));
+    orc_lf nh2, dh2;
+    lf_zero(&nh2); lf_add(&nh2, DV_NH, 2);
+    lf_zero(&dh2); lf_add(&dh2, DV_DH, 2);
+    g_div[11] = range_inter(-1, sgn, zero, nh2);
+    g_div[12] = range_inter(-1, sgn, zero, dh2);
   }
   /* ---- ALU ---- */
   {
@@ -480,7 +521,8 @@ static void build(void) {
   g_chips[CH_MEMFINAL] = (orc_chip){"mem-final", 0, MEMFINAL_WIDTH, 10, g_memfinal, 0, 0};
   g_chips[CH_IMAGE] = (orc_chip){"image", IMAGE_PREP_WIDTH, IMAGE_WIDTH, 1, g_image, 0, 0};
   g_chips[CH_PROGRAM] = (orc_chip){"program", PROGRAM_PREP_WIDTH, PROGRAM_WIDTH, 1, g_program, 0, 0};
-  g_chips[CH_MUL] = (orc_chip){"mul", 0, MUL_WIDTH, 2, g_mul, 0, 0};
+  g_chips[CH_MUL] = (orc_chip){"mul", 0, MUL_WIDTH, 5, g_mul, 0, 0};
+  g_chips[CH_DIV] = (orc_chip){"divider", 0, DIV_WIDTH, 13, g_div, 0, 0};
   g_chips[CH_ALU] = (orc_chip){"alu", 0, ALU_WIDTH, 1, g_alu, 0, 0};
   g_chips[CH_ALU2] = (orc_chip){"alu2", 0, ALU_WIDTH, 1, g_alu, 0, 0};
   g_chips[CH_SUB] = (orc_chip){"subword", 0, SUB_WIDTH, 5, g_sub, 0, 0};
@@ -599,6 +641,7 @@ void orc_machine_heights(const orc_machine_input* in, int logh[N_CHIPS]) {
     logh[CH_FOLD] = at_least5(clog2(in->n_leaf_fold ? in->n_leaf_fold : 1));
   }
   logh[CH_ECALL] = at_least5(clog2(orc_machine_events(in, 3, NULL)));
+  logh[CH_DIV] = at_least5(clog2(orc_machine_events(in, 4, NULL)));
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -852,9 +895,9 @@ static void fill_table_mults(const orc_machine_input* in, uint32_t* t) {
   const size_t ht = (size_t)1 << TABLE_LOG_H;
   int logh[N_CHIPS];
   orc_machine_heights(in, logh);
-  static const int users[8 + CPU_INST] = {CH_CPU, CH_CPU2, CH_KMEM, CH_MEMFINAL, CH_BW, CH_BW2, CH_SUB, CH_SUB2, CH_ECALL, CH_P2,
-                                          CH_CPU3, CH_CPU4, CH_CPU5, CH_CPU6, CH_CPU7, CH_CPU8};
-  for (int u = 0; u < 8 + CPU_INST; ++u) {
+  static const int users[10 + CPU_INST] = {CH_CPU, CH_CPU2, CH_KMEM, CH_MEMFINAL, CH_BW, CH_BW2, CH_SUB, CH_SUB2, CH_ECALL, CH_P2,
+                                           CH_CPU3, CH_CPU4, CH_CPU5, CH_CPU6, CH_CPU7, CH_CPU8, CH_MUL, CH_DIV};
+  for (int u = 0; u < 10 + CPU_INST; ++u) {
     const int chip = users[u];
     const orc_chip* ch = &g_chips[chip];
     const size_t h = (size_t)1 << logh[chip];
@@ -1003,7 +1046,17 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
         const uint32_t* mu = in->muls + 3 * r;
         const uint32_t b = mu[1], c = mu[2];
         const uint64_t prod = (uint64_t)b * c;
-        T(MU_IS_REAL) = 1; T(MU_HI) = mu[0];
+        T(MU_IS_REAL) = 1; T(MU_HI) = mu[0] == 1; T(MU_SH) = mu[0] == 2; T(MU_SHU) = mu[0] == 3;
+        if (mu[0] >= 2) { /* mulh / mulhsu: R + b31 * C + [mulh] c31 * B = P_hi + 2^32 k, limb by limb */
+          const uint32_t b31 = b >> 31, c31 = mu[0] == 2 ? c >> 31 : 0, phi = (uint32_t)(((uint64_t)b * c) >> 32);
+          const uint32_t rr = phi - (b31 ? c : 0) - (c31 ? b : 0);
+          const uint32_t lo = (rr & 0xffff) + (b31 ? (c & 0xffff) : 0) + (c31 ? (b & 0xffff) : 0);
+          const uint32_t k0 = (lo - (phi & 0xffff)) >> 16;
+          const uint32_t hi = (rr >> 16) + (b31 ? (c >> 16) : 0) + (c31 ? (b >> 16) : 0) + k0;
+          const uint32_t k1 = (hi - (phi >> 16)) >> 16;
+          put_limbs(t, h, r, MU_R, rr);
+          T(MU_K0) = k0 >= 1; T(MU_K0 + 1) = k0 >= 2; T(MU_K1) = k1 >= 1; T(MU_K1 + 1) = k1 >= 2;
+        }
         put_bits(t, h, r, MU_B, b, 32); put_bits(t, h, r, MU_C, c, 32);
         put_bits(t, h, r, MU_P, (uint32_t)prod, 32); put_bits(t, h, r, MU_P + 32, (uint32_t)(prod >> 32), 32);
         uint64_t s[7] = {0};
@@ -1056,6 +1109,48 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
         if (r < nr && memcmp(st, rows + 25 * r + 17, 32) != 0) abort(); /* the row's permutation is the node's compression */
       }
       free(rows);
+      break;
+    }
+    case CH_DIV: {
+      /* one row per div / divu / rem / remu cycle, in execution order (the oracle's own event list); the row holds the
+       * instruction's result computed from the operands - a cycle record claiming another one leaves the ALU bus open */
+      const size_t nd = orc_machine_events(in, 4, NULL);
+      uint32_t* ev = (uint32_t*)malloc((nd ? nd : 1) * 4);
+      orc_machine_events(in, 4, ev);
+      for (size_t r = 0; r < nd && r < h; ++r) {
+        const uint32_t* cy = in->cycles + 12 * (size_t)ev[r];
+        const uint32_t code = prog_row(in, cy[0])[1], n = cy[2], d = cy[3];
+        const int sg = code == OP_DIV || code == OP_REM, ovf = sg && n == 0x80000000u && d == 0xffffffffu;
+        uint32_t q, rm;
+        if (d == 0) { q = 0xffffffffu; rm = n; }
+        else if (ovf) { q = n; rm = 0; }
+        else if (sg) { q = (uint32_t)((int32_t)n / (int32_t)d); rm = (uint32_t)((int32_t)n % (int32_t)d); }
+        else { q = n / d; rm = n % d; }
+        const uint32_t sn = sg ? n >> 31 : 0, sd = sg ? d >> 31 : 0;
+        const uint32_t an = sn ? 0u - n : n, ad = sd ? 0u - d : d;
+        uint32_t sq, sr, aq, ar;
+        if (d == 0) { sq = 1; aq = 1; sr = sn; ar = an; }
+        else { aq = an / ad; ar = an % ad; sq = (sn ^ sd) & (aq != 0); sr = sn & (ar != 0); }
+        T(DV_IS_REAL) = 1;
+        T(DV_F + 0) = code == OP_DIV; T(DV_F + 1) = code == OP_DIVU; T(DV_F + 2) = code == OP_REM; T(DV_F + 3) = code == OP_REMU;
+        put_limbs(t, h, r, DV_N, n); put_limbs(t, h, r, DV_D, d);
+        put_limbs(t, h, r, DV_A, (code == OP_DIV || code == OP_DIVU) ? q : rm);
+        T(DV_SN) = sn; T(DV_SD) = sd; T(DV_NH) = (n >> 16) - 32768u * sn; T(DV_DH) = (d >> 16) - 32768u * sd;
+        put_limbs(t, h, r, DV_AN, an); put_limbs(t, h, r, DV_AD, ad); put_limbs(t, h, r, DV_AQ, aq); put_limbs(t, h, r, DV_AR, ar);
+        T(DV_CN) = sn && (n & 0xffff) != 0; T(DV_CD) = sd && (d & 0xffff) != 0;
+        T(DV_CQ) = sq && (q & 0xffff) != 0; T(DV_CR) = sr && (rm & 0xffff) != 0;
+        put_limbs(t, h, r, DV_Q, q); put_limbs(t, h, r, DV_R, rm);
+        T(DV_SQ) = sq; T(DV_SR) = sr; T(DV_XS) = sn ^ sd;
+        const uint32_t pl = d == 0 ? 0 : aq * ad, e = d == 0 ? 0 : ad - ar - 1;
+        put_limbs(t, h, r, DV_PL, pl);
+        T(DV_K) = d != 0 && (pl & 0xffff) + (ar & 0xffff) > 0xffff;
+        put_limbs(t, h, r, DV_E, e);
+        T(DV_BE) = d != 0 && (ad & 0xffff) < (ar & 0xffff) + 1;
+        T(DV_NZD) = d != 0; T(DV_INVD) = d ? f_inv(((d & 0xffff) + (d >> 16)) % FP) : 0;
+        T(DV_NZQ) = aq != 0; T(DV_INVQ) = aq ? f_inv(((aq & 0xffff) + (aq >> 16)) % FP) : 0;
+        T(DV_NZR) = ar != 0; T(DV_INVR) = ar ? f_inv(((ar & 0xffff) + (ar >> 16)) % FP) : 0;
+      }
+      free(ev);
       break;
     }
     case CH_FOLD:
@@ -1272,6 +1367,76 @@ static void mul_constraints(const uint32_t* l, sink* s) {
   emit(s, f_sub(f_add(f_add(sk[2], f_mul(256, sk[3])), q0), f_add(limb_of(l, MU_P, 1), f_mul(F65536, q1))));
   emit(s, f_sub(f_add(f_add(sk[4], f_mul(256, sk[5])), q1), f_add(limb_of(l, MU_P, 2), f_mul(F65536, q2))));
   emit(s, f_sub(f_add(sk[6], q2), limb_of(l, MU_P, 3)));
+  /* mulh (SH) / mulhsu (SHU): the signed high word from the unsigned one */
+  const fe sh = l[MU_SH], shu = l[MU_SHU], sg = f_add(sh, shu);
+  emit(s, bool_c(sh)); emit(s, bool_c(shu));
+  for (int i = 0; i < 4; ++i) emit(s, bool_c(l[MU_K0 + i]));
+  emit(s, bool_c(f_add(l[MU_HI], sg))); /* at most one of mulhu, mulh, mulhsu */
+  emit(s, f_mul(sg, f_sub(1, l[MU_IS_REAL])));
+  {
+    const fe b31 = l[MU_B + 31], c31 = l[MU_C + 31], k0 = f_add(l[MU_K0], l[MU_K0 + 1]), k1 = f_add(l[MU_K1], l[MU_K1 + 1]);
+    const fe b_lo = limb_of(l, MU_B, 0), b_hi = limb_of(l, MU_B, 1), c_lo = limb_of(l, MU_C, 0), c_hi = limb_of(l, MU_C, 1);
+    emit(s, f_add(f_add(f_mul(sg, f_sub(f_sub(l[MU_R], limb_of(l, MU_P, 2)), f_mul(F65536, k0))), f_mul(f_mul(sg, b31), c_lo)),
+                  f_mul(f_mul(sh, c31), b_lo)));
+    emit(s, f_add(f_add(f_mul(sg, f_sub(f_sub(f_add(l[MU_R + 1], k0), limb_of(l, MU_P, 3)), f_mul(F65536, k1))), f_mul(f_mul(sg, b31), c_hi)),
+                  f_mul(f_mul(sh, c31), b_hi)));
+  }
+}
+
+/* divider chip (machine.h): 52 constraints */
+static void div_constraints(const uint32_t* l, sink* s) {
+  const fe real = l[DV_IS_REAL];
+  emit(s, bool_c(real));
+  fe fsum = 0;
+  for (int k = 0; k < 4; ++k) { emit(s, bool_c(l[DV_F + k])); fsum = f_add(fsum, l[DV_F + k]); }
+  emit(s, f_sub(fsum, real));
+  {
+    static const int bools[14] = {DV_SN, DV_SD, DV_SQ, DV_SR, DV_CN, DV_CD, DV_CQ, DV_CR, DV_K, DV_BE, DV_NZD, DV_NZQ, DV_NZR, DV_XS};
+    for (int k = 0; k < 14; ++k) emit(s, bool_c(l[bools[k]]));
+  }
+  const fe sgn = f_add(l[DV_F + 0], l[DV_F + 2]); /* div, rem: signed */
+  const fe sn = l[DV_SN], sd = l[DV_SD], sq = l[DV_SQ], sr = l[DV_SR];
+  emit(s, f_mul(sn, f_sub(1, sgn)));
+  emit(s, f_mul(sd, f_sub(1, sgn)));
+  emit(s, f_sub(f_sub(l[DV_N + 1], f_mul(32768, sn)), l[DV_NH]));
+  emit(s, f_sub(f_sub(l[DV_D + 1], f_mul(32768, sd)), l[DV_DH]));
+  {
+    static const int xs[4] = {DV_N, DV_D, DV_Q, DV_R}, ax[4] = {DV_AN, DV_AD, DV_AQ, DV_AR}, cx[4] = {DV_CN, DV_CD, DV_CQ, DV_CR};
+    const fe sx[4] = {sn, sd, sq, sr};
+    for (int k = 0; k < 4; ++k) {
+      const fe x_lo = l[xs[k]], x_hi = l[xs[k] + 1], a_lo = l[ax[k]], a_hi = l[ax[k] + 1], c = l[cx[k]];
+      emit(s, f_add(f_mul(sx[k], f_sub(f_add(x_lo, a_lo), f_mul(F65536, c))), f_mul(f_sub(1, sx[k]), f_sub(x_lo, a_lo))));
+      emit(s, f_add(f_mul(sx[k], f_sub(f_add(f_add(x_hi, a_hi), c), F65536)), f_mul(f_sub(1, sx[k]), f_sub(x_hi, a_hi))));
+    }
+  }
+  emit(s, f_sub(l[DV_XS], f_sub(f_add(sn, sd), f_mul(2, f_mul(sn, sd)))));
+  const fe nzd = l[DV_NZD], nzq = l[DV_NZQ], nzr = l[DV_NZR];
+  {
+    const fe dsum = f_add(l[DV_D], l[DV_D + 1]), qsum = f_add(l[DV_AQ], l[DV_AQ + 1]), rsum = f_add(l[DV_AR], l[DV_AR + 1]);
+    emit(s, f_sub(f_mul(dsum, l[DV_INVD]), nzd));
+    emit(s, f_mul(f_sub(1, nzd), dsum));
+    emit(s, f_mul(nzd, f_sub(1, real)));
+    emit(s, f_sub(f_mul(qsum, l[DV_INVQ]), nzq));
+    emit(s, f_mul(f_sub(1, nzq), qsum));
+    emit(s, f_sub(f_mul(rsum, l[DV_INVR]), nzr));
+    emit(s, f_mul(f_sub(1, nzr), rsum));
+  }
+  emit(s, f_mul(nzd, f_sub(f_sub(f_add(l[DV_PL], l[DV_AR]), l[DV_AN]), f_mul(F65536, l[DV_K]))));
+  emit(s, f_mul(nzd, f_sub(f_add(f_add(l[DV_PL + 1], l[DV_AR + 1]), l[DV_K]), l[DV_AN + 1])));
+  emit(s, f_mul(nzd, f_sub(f_add(f_sub(f_sub(l[DV_AD], l[DV_AR]), 1), f_mul(F65536, l[DV_BE])), l[DV_E])));
+  emit(s, f_mul(nzd, f_sub(f_sub(f_sub(l[DV_AD + 1], l[DV_AR + 1]), l[DV_BE]), l[DV_E + 1])));
+  emit(s, f_mul(nzd, f_sub(sq, f_mul(l[DV_XS], nzq))));
+  emit(s, f_mul(nzd, f_sub(sr, f_mul(sn, nzr))));
+  const fe zd = f_sub(real, nzd);
+  emit(s, f_mul(zd, f_sub(l[DV_Q], 65535)));
+  emit(s, f_mul(zd, f_sub(l[DV_Q + 1], 65535)));
+  emit(s, f_mul(zd, f_sub(l[DV_R], l[DV_N])));
+  emit(s, f_mul(zd, f_sub(l[DV_R + 1], l[DV_N + 1])));
+  {
+    const fe wq = f_add(l[DV_F + 0], l[DV_F + 1]), wr = f_add(l[DV_F + 2], l[DV_F + 3]);
+    emit(s, f_sub(f_sub(l[DV_A], f_mul(wq, l[DV_Q])), f_mul(wr, l[DV_R])));
+    emit(s, f_sub(f_sub(l[DV_A + 1], f_mul(wq, l[DV_Q + 1])), f_mul(wr, l[DV_R + 1])));
+  }
 }
 
 /* ALU chip: operands as bits; X is the one-hot shift amount or the comparison difference */
@@ -1523,6 +1688,7 @@ static void run_constraints(int chip, const uint32_t* prep, const uint32_t* loc,
     case CH_BW2: bw_constraints(loc, s); break;
     case CH_P2: p2_constraints(loc, nxt, is_first, is_trans, s); break;
     case CH_FOLD: fold_constraints(loc, nxt, is_first, is_trans, s); break;
+    case CH_DIV: div_constraints(loc, s); break;
     case CH_TABLE: /* only multiples of 4 answer aligned lookups, only values 1 .. ADDR_HI_MAX high-address-limb lookups */
       emit(s, f_mul(loc[TB_M_AL], prep[TB_P_NA]));
       emit(s, f_mul(loc[TB_M_TOP], prep[TB_P_NT]));

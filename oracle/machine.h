@@ -43,7 +43,7 @@ extern "C" {
 #define CPU_INST 8
 enum {
   CH_CPU = 0, CH_KECCAK, CH_KMEM, CH_MEMFINAL, CH_IMAGE, CH_PROGRAM, CH_MUL, CH_TABLE, CH_CPU2, CH_ALU, CH_ALU2, CH_SUB,
-  CH_SUB2, CH_BW, CH_BW2, CH_P2, CH_ECALL, CH_CPU3, CH_CPU4, CH_CPU5, CH_CPU6, CH_CPU7, CH_CPU8, CH_FOLD, N_CHIPS
+  CH_SUB2, CH_BW, CH_BW2, CH_P2, CH_ECALL, CH_CPU3, CH_CPU4, CH_CPU5, CH_CPU6, CH_CPU7, CH_CPU8, CH_FOLD, CH_DIV, N_CHIPS
 };
 /* CPU instance i = 0 .. CPU_INST - 1 <-> chip (the first two keep their old places in the proof order) */
 static inline int orc_cpu_chip(int i) { return i == 0 ? CH_CPU : i == 1 ? CH_CPU2 : CH_CPU3 + (i - 2); }
@@ -53,7 +53,7 @@ static inline int orc_cpu_instance(int chip) { return chip == CH_CPU ? 0 : chip 
 enum {
   OP_ADD = 1, OP_SUB, OP_XOR, OP_OR, OP_AND, OP_SLL, OP_SRL, OP_SRA, OP_SLT, OP_SLTU, OP_JAL, OP_JALR, OP_BEQ, OP_BNE,
   OP_BLT, OP_BGE, OP_BLTU, OP_BGEU, OP_LB, OP_LH, OP_LW, OP_LBU, OP_LHU, OP_SB, OP_SH, OP_SW, OP_MUL, OP_MULHU,
-  OP_ECALL, OP_KECCAK, N_OPS_P1
+  OP_ECALL, OP_KECCAK, OP_MULH, OP_MULHSU, OP_DIV, OP_DIVU, OP_REM, OP_REMU, N_OPS_P1
 };
 /* ---- instruction classes: one selector column each in the CPU row; Program table column CLS ---- */
 enum {
@@ -118,7 +118,22 @@ enum { IMG_P_ADDR = 0, IMG_P_LO, IMG_P_HI, IMG_P_REAL, IMAGE_PREP_WIDTH };
 enum { PR_PC = 0, PR_CLS, PR_CODE, PR_UC, PR_WR, PR_USE2, PR_RD, PR_RS1, PR_RS2, PR_IMM_LO, PR_IMM_HI, PR_TGT_LO, PR_TGT_HI, PROGRAM_PREP_WIDTH };
 #define PROGRAM_WIDTH 1
 /* ---- multiplier chip ---- */
-enum { MU_IS_REAL = 0, MU_HI, MU_B, MU_C = MU_B + 32, MU_P = MU_C + 32, MU_Q0 = MU_P + 64, MU_Q1 = MU_Q0 + 10, MU_Q2 = MU_Q1 + 11, MUL_WIDTH = MU_Q2 + 10 };
+/*      (format v15: mulh / mulhsu as well - the signed high word R follows from the unsigned product's high word:
+ *      R + b31 * C + [mulh] c31 * B = P_hi + 2^32 k, limb by limb with carries K0, K1 in {0, 1, 2} as two bits each; R's limbs are
+ *      looked up in the range table) */
+enum {
+  MU_IS_REAL = 0, MU_HI, MU_B, MU_C = MU_B + 32, MU_P = MU_C + 32, MU_Q0 = MU_P + 64, MU_Q1 = MU_Q0 + 10, MU_Q2 = MU_Q1 + 11,
+  MU_SH = MU_Q2 + 10 /* mulh */, MU_SHU /* mulhsu */, MU_R /* 2 limbs */, MU_K0 = MU_R + 2 /* 2 bits */, MU_K1 = MU_K0 + 2, MUL_WIDTH = MU_K1 + 2
+};
+/* ---- divider chip (format v15): div divu rem remu, one row per instruction.  On absolute values |n| = |q| |d| + |r| with
+ *      |r| < |d|; the product comes from the multiplier chip over the ALU bus (low word PL, high word zero); signs: q has
+ *      sign(n) xor sign(d) unless it is zero, r the sign of n unless it is zero; a zero divisor gives q = 0xffffffff, r = n;
+ *      -2^31 / -1 gives q = -2^31, r = 0 by the same relations.  N, D the operands, A the result the CPU row gets ---- */
+enum {
+  DV_IS_REAL = 0, DV_F /* 4: div divu rem remu */, DV_N = 5, DV_D = 7, DV_A = 9, DV_SN = 11, DV_SD, DV_NH, DV_DH, DV_AN = 15, DV_AD = 17,
+  DV_AQ = 19, DV_AR = 21, DV_CN = 23, DV_CD, DV_CQ, DV_CR, DV_Q = 27, DV_R = 29, DV_SQ = 31, DV_SR, DV_XS, DV_PL = 34, DV_K = 36,
+  DV_E = 37, DV_BE = 39, DV_NZD, DV_INVD, DV_NZQ, DV_INVQ, DV_NZR, DV_INVR, DIV_WIDTH
+};
 /* ---- ALU chip: sll srl sra and the signed slt (slt, blt, bge) over bits ---- */
 enum {
   AL_IS_REAL = 0, AL_SEL /* 4 selectors, OP_SLL..OP_SLT */, AL_A = AL_SEL + 4, AL_B = AL_A + 2, AL_C = AL_B + 32,
@@ -243,7 +258,7 @@ typedef struct {
   const uint32_t* cycles; size_t n_cycles;     /* 12 u32 per cycle */
   const uint8_t* keccak; size_t n_keccak;      /* 408 bytes per call */
   const uint32_t* memfinal; size_t n_memfinal; /* 5 u32: addr, init, fin, fin_ts, is_init; row 0 is x0, closed at its last real access */
-  const uint32_t* muls; size_t n_muls;         /* 3 u32 */
+  const uint32_t* muls; size_t n_muls;         /* 3 u32: kind (0 mul, 1 mulhu, 2 mulh, 3 mulhsu), b, c */
   const uint32_t* prog_mult;                   /* n_program; the padding row holds 0 (its fetches depend on the heights) */
   const int* shape;                            /* NULL: the minimal heights; else N_CHIPS log heights the run fits (a batch of
                                                   runs is proven with one shape: the heights of their largest counts) */
@@ -261,7 +276,7 @@ typedef struct {
 
 /* The oracle's own event lists (cycle indices of the ALU-chip and sub-word-chip rows, in execution order) and the
  * last access time of x0 by a real cycle; the product's tracer emits the same lists and tests compare them. */
-size_t orc_machine_events(const orc_machine_input* in, int which /* 0 alu, 1 sub-word, 2 bitwise, 3 ecall */, uint32_t* out /* may be NULL */);
+size_t orc_machine_events(const orc_machine_input* in, int which /* 0 alu, 1 sub-word, 2 bitwise, 3 ecall, 4 divider */, uint32_t* out /* may be NULL */);
 uint32_t orc_machine_x0_last(const orc_machine_input* in);
 
 /* log2 trace height of every chip for this input (minimum 5) */
@@ -303,7 +318,7 @@ int orc_machine_nodes_public(const uint32_t* keys, const uint32_t* digests, size
  * (key, left child's digest, right child's digest, own digest).  Returns the number of rows, (size_t)-1 if malformed;
  * rows may be NULL. */
 size_t orc_machine_agg_rows(const uint32_t* keys, const uint32_t* digests, size_t n, uint32_t* rows);
-#define ZKSP_VERSION_MACHINE 14u
+#define ZKSP_VERSION_MACHINE 15u
 /* vk: preprocessed commitment root + digest binding entry pc, table heights and keccak mode */
 void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t prep_root[8], uint32_t vk_digest[8]);
 size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_image, const orc_config* cfg, uint32_t pv_len);

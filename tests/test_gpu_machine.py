@@ -379,3 +379,25 @@ def test_leaf_check_matches_oracle(zk, fx, oracle):
     again = client.prove(pk, s).run()
     host.verify_with_leaf(again, vk, leaf, vk)
     assert again.public_tuples == proofs[0].public_tuples
+
+
+def test_rv32m_guest_matches_oracle(zk, oracle):
+    """Format v15's rows for mulh / mulhsu (multiplier chip) and div / divu / rem / remu (divider chip): the committed guest
+    executes none of them, so a hand-assembled guest does, on the spec's corner cases (tests/test_rv32m.py).  The device's
+    proof - trace expansion of both chips, their quotients, their LogUp columns - is the oracle's byte for byte."""
+    import test_rv32m as rv
+    import toy_guest as tg
+    nq, pw = 8, 6
+    client = zk.ProverClient(device=0, num_queries=nq, pow_bits=pw, max_batch=2)
+    pk, vk = client.setup(tg.elf_of(rv.program()))
+    stdin = zk.SP1Stdin()
+    trace = client.machine_trace(pk, stdin)
+    proof = client.prove(pk, stdin).run()
+    assert proof.public_values == b""
+    exp = oracle.machine_prove(trace, num_queries=nq, pow_bits=pw)
+    got = np.frombuffer(proof.to_bytes(), dtype=np.uint32)
+    e = np.frombuffer(exp, dtype=np.uint32)
+    assert got.shape == e.shape and first_difference(got, e) is None, first_difference(got, e)
+    zk.ProverClient(device=-1, num_queries=nq, pow_bits=pw).verify(proof, vk)
+    hts = shape_of(zk, proof.to_bytes())
+    assert hts[zk.MACHINE_CHIP_NAMES.index("divider")] == 7

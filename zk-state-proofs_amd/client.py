@@ -29,11 +29,11 @@ ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_ELF, ERR_EXECUTOR, ERR_GUEST_PANIC,
     ERR_UNSUPPORTED = range(1, 10)
 KECCAK_SOFTWARE, KECCAK_OBSERVE, KECCAK_REPLACE = 0, 1, 2
 PROOF_MACHINE, PROOF_KECCAK_CHIP = 1, 2
-# machine proof (format version 14): chips in proof order and the fixed header in front of the public values
-MACHINE_VERSION = 14
+# machine proof (format version 15): chips in proof order and the fixed header in front of the public values
+MACHINE_VERSION = 15
 MACHINE_CHIP_NAMES = ("cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "table", "cpu2", "alu", "alu2",
                       "subword", "subword2", "bitwise", "bitwise2", "poseidon2", "ecall", "cpu3", "cpu4", "cpu5", "cpu6", "cpu7",
-                      "cpu8", "fri-fold")
+                      "cpu8", "fri-fold", "divider")
 MACHINE_CHIPS = len(MACHINE_CHIP_NAMES)
 MACHINE_CPU_INSTANCES = 8  # cpu, cpu2 .. cpu8: one AIR, consecutive stretches of the run
 # magic, version, heights, exit code, pv length, three digests, the pcs at which the later CPU instances start, the
@@ -572,7 +572,7 @@ class ProverClient:
             self._lib.zksp_mtrace_info(h, C.byref(info))
             return {"cycles": sec(0, np.uint32, 12), "keccak": sec(1, kdt), "memfinal": sec(2, np.uint32, 5),
                     "muls": sec(3, np.uint32, 3), "prog_mult": sec(4, np.uint32), "alu_idx": sec(5, np.uint32),
-                    "sub_idx": sec(9, np.uint32), "bw_idx": sec(10, np.uint32), "ecall_idx": sec(11, np.uint32), "program": sec(6, np.uint32, 9), "image": sec(7, np.uint32, 2),
+                    "sub_idx": sec(9, np.uint32), "bw_idx": sec(10, np.uint32), "ecall_idx": sec(11, np.uint32), "div_idx": sec(15, np.uint32), "program": sec(6, np.uint32, 9), "image": sec(7, np.uint32, 2),
                     "public_values": bytes(sec(8, np.uint8)), "info": info,
                     "leaf_p2_rows": sec(12, np.uint32, P2_REC_WORDS), "leaf_fold_rows": sec(13, np.uint32, FOLD_REC_WORDS),
                     "leaf_pub_tuples": sec(14, np.uint32, PUB_TUPLE_WORDS)}

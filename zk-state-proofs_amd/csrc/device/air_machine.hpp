@@ -31,7 +31,7 @@ namespace mach {
 // so the trees, the quotient and the FRI domain have a quarter of the height and the per-row costs of a commitment are
 // shared by six instances.
 enum Chip { kCpu = 0, kKeccak, kKmem, kMemFinal, kImage, kProgram, kMul, kTable, kCpu2, kAlu, kAlu2, kSub, kSub2, kBw, kBw2, kP2, kEcall,
-            kCpu3, kCpu4, kCpu5, kCpu6, kCpu7, kCpu8, kFold, kNumChips };
+            kCpu3, kCpu4, kCpu5, kCpu6, kCpu7, kCpu8, kFold, kDiv, kNumChips };
 constexpr int kNumCpuInst = 8;
 // CPU instance i <-> chip (the first two keep their old places in the proof order)
 ZKSP_HD constexpr int cpu_chip(int i) { return i == 0 ? kCpu : i == 1 ? kCpu2 : kCpu3 + (i - 2); }
@@ -47,13 +47,15 @@ ZKSP_HD constexpr bool is_bw_chip(int chip) { return chip == kBw || chip == kBw2
 // opcodes: Program table column CODE and the op element of the ALU / sub-word bus tuples
 enum Op {
   ADD = 1, SUB, XOR, OR, AND, SLL, SRL, SRA, SLT, SLTU, JAL, JALR, BEQ, BNE, BLT, BGE, BLTU, BGEU, LB, LH, LW, LBU, LHU,
-  SB, SH, SW, MUL, MULHU, ECALL, KECCAK
+  SB, SH, SW, MUL, MULHU, ECALL, KECCAK, MULH, MULHSU, DIV, DIVU, REM, REMU
 };
+ZKSP_HD constexpr bool is_divrem(uint32_t op) { return op >= DIV && op <= REMU; }
+ZKSP_HD constexpr bool is_mul_family(uint32_t op) { return op == MUL || op == MULHU || op == MULH || op == MULHSU; }
 // instruction classes: one selector column each in the CPU row; Program table column CLS
 enum Cls { CL_ADD = 1, CL_SUB, CL_ALU, CL_JAL, CL_JALR, CL_BEQ, CL_BNE, CL_BLT, CL_BGE, CL_LW, CL_SW, CL_LDS, CL_STS, CL_ECALL, CL_KECCAK };
 constexpr int kNumCls = 15;
 ZKSP_HD constexpr int class_of(uint32_t op) {
-  return op == ADD ? CL_ADD : op == SUB ? CL_SUB : (op >= XOR && op <= SLTU) || op == MUL || op == MULHU ? CL_ALU
+  return op == ADD ? CL_ADD : op == SUB ? CL_SUB : (op >= XOR && op <= SLTU) || is_mul_family(op) || is_divrem(op) ? CL_ALU
        : op == JAL ? CL_JAL : op == JALR ? CL_JALR : op == BEQ ? CL_BEQ : op == BNE ? CL_BNE
        : (op == BLT || op == BLTU) ? CL_BLT : (op == BGE || op == BGEU) ? CL_BGE : op == LW ? CL_LW : op == SW ? CL_SW
        : (op == LB || op == LH || op == LBU || op == LHU) ? CL_LDS : (op == SB || op == SH) ? CL_STS
@@ -61,18 +63,18 @@ ZKSP_HD constexpr int class_of(uint32_t op) {
 }
 // the op a row of that instruction puts on the ALU / sub-word bus (0: none)
 ZKSP_HD constexpr uint32_t code_of(uint32_t op) {
-  return ((op >= XOR && op <= SLTU) || op == MUL || op == MULHU || op == LB || op == LH || op == LBU || op == LHU || op == SB ||
-          op == SH) ? op
+  return ((op >= XOR && op <= SLTU) || is_mul_family(op) || is_divrem(op) || op == LB || op == LH || op == LBU || op == LHU ||
+          op == SB || op == SH) ? op
        : (op == BLT || op == BGE) ? (uint32_t)SLT : (op == BLTU || op == BGEU) ? (uint32_t)SLTU : 0u;
 }
 // sltu, bltu, bgeu: the unsigned comparison the CPU row does itself (Program column UC)
 ZKSP_HD constexpr bool ucmp_of(uint32_t op) { return op == SLTU || op == BLTU || op == BGEU; }
 // does a cycle of this op occupy a row of the ALU chip (0) / the sub-word chip (1) / the bitwise chip (2) / the ecall
-// chip (3)?  (-1: none)
+// chip (3) / the divider chip (4)?  (-1: none)
 ZKSP_HD constexpr int event_kind(uint32_t op) {
   return (code_of(op) >= SLL && code_of(op) <= SLT) ? 0
        : (op == LB || op == LH || op == LBU || op == LHU || op == SB || op == SH) ? 1
-       : (op >= XOR && op <= AND) ? 2 : op == ECALL ? 3 : -1;
+       : (op >= XOR && op <= AND) ? 2 : op == ECALL ? 3 : is_divrem(op) ? 4 : -1;
 }
 
 // ---- CPU chip ----
@@ -105,8 +107,21 @@ constexpr int IMG_P_ADDR = 0, IMG_P_LO = 1, IMG_P_HI = 2, IMG_P_REAL = 3, kImage
 constexpr int PR_PC = 0, PR_CLS = 1, PR_CODE = 2, PR_UC = 3, PR_WR = 4, PR_USE2 = 5, PR_RD = 6, PR_RS1 = 7, PR_RS2 = 8, PR_IMM_LO = 9,
               PR_IMM_HI = 10, PR_TGT_LO = 11, PR_TGT_HI = 12, kProgramPrepWidth = 13, kProgramWidth = 1;
 // ---- multiplier chip ----
+//      (format v15: mulh / mulhsu as well - the signed high words R follow from the unsigned product's high word P_hi:
+//      R + b31 * C + [mulh] c31 * B = P_hi + 2^32 k, limb by limb with carries K0, K1 in {0, 1, 2} as two bits each; R's limbs are
+//      looked up in the range table)
 constexpr int MU_IS_REAL = 0, MU_HI = 1, MU_B = 2, MU_C = MU_B + 32, MU_P = MU_C + 32, MU_Q0 = MU_P + 64, MU_Q1 = MU_Q0 + 10,
-              MU_Q2 = MU_Q1 + 11, kMulWidth = MU_Q2 + 10;
+              MU_Q2 = MU_Q1 + 11, MU_SH = MU_Q2 + 10, MU_SHU = MU_SH + 1, MU_R = MU_SH + 2, MU_K0 = MU_R + 2, MU_K1 = MU_K0 + 2,
+              kMulWidth = MU_K1 + 2;
+static_assert(kMulWidth == 169, "multiplier chip layout");
+// ---- divider chip (format v15): div divu rem remu, one row per instruction.  On absolute values |n| = |q| |d| + |r| with
+//      |r| < |d|; the product comes from the multiplier chip over the ALU bus (low word PL, high word zero); signs: q has
+//      sign(n) xor sign(d) unless it is zero, r the sign of n unless it is zero; a zero divisor gives q = 0xffffffff, r = n;
+//      -2^31 / -1 gives q = -2^31, r = 0 by the same relations.  N, D the operands, A the result the CPU row gets ----
+constexpr int DV_IS_REAL = 0, DV_F = 1, DV_N = 5, DV_D = 7, DV_A = 9, DV_SN = 11, DV_SD = 12, DV_NH = 13, DV_DH = 14, DV_AN = 15,
+              DV_AD = 17, DV_AQ = 19, DV_AR = 21, DV_CN = 23, DV_CD = 24, DV_CQ = 25, DV_CR = 26, DV_Q = 27, DV_R = 29, DV_SQ = 31,
+              DV_SR = 32, DV_XS = 33, DV_PL = 34, DV_K = 36, DV_E = 37, DV_BE = 39, DV_NZD = 40, DV_INVD = 41, DV_NZQ = 42,
+              DV_INVQ = 43, DV_NZR = 44, DV_INVR = 45, kDivWidth = 46;
 // ---- ALU chip: sll srl sra and the signed slt (slt, blt, bge) over bits ----
 constexpr int AL_IS_REAL = 0, AL_SEL = 1, AL_A = AL_SEL + 4, AL_B = AL_A + 2, AL_C = AL_B + 32, AL_X = AL_C + 32, AL_K0 = AL_X + 32,
               AL_K1 = AL_K0 + 1, kAluWidth = AL_K1 + 1;
@@ -414,8 +429,93 @@ ZKSP_HD void eval_mul(Ctx& ctx) {
   ctx.emit(sk[2] + k256 * sk[3] + q0 - (limb_of<F>(ctx, MU_P, 1) + k65536 * q1));
   ctx.emit(sk[4] + k256 * sk[5] + q1 - (limb_of<F>(ctx, MU_P, 2) + k65536 * q2));
   ctx.emit(sk[6] + q2 - limb_of<F>(ctx, MU_P, 3));
+  // mulh (SH) / mulhsu (SHU): the signed high word from the unsigned one
+  const F sh = L(MU_SH), shu = L(MU_SHU), sg = sh + shu;
+  ctx.emit(bool_c(sh, one));
+  ctx.emit(bool_c(shu, one));
+  for (int i = 0; i < 4; ++i) ctx.emit(bool_c(L(MU_K0 + i), one));
+  ctx.emit(bool_c(L(MU_HI) + sg, one));  // at most one of mulhu, mulh, mulhsu
+  ctx.emit(sg * (one - L(MU_IS_REAL)));
+  {
+    const F b31 = L(MU_B + 31), c31 = L(MU_C + 31), k0 = L(MU_K0) + L(MU_K0 + 1), k1 = L(MU_K1) + L(MU_K1 + 1);
+    const F b_lo = limb_of<F>(ctx, MU_B, 0), b_hi = limb_of<F>(ctx, MU_B, 1), c_lo = limb_of<F>(ctx, MU_C, 0), c_hi = limb_of<F>(ctx, MU_C, 1);
+    ctx.emit(sg * (L(MU_R) - limb_of<F>(ctx, MU_P, 2) - k65536 * k0) + sg * b31 * c_lo + sh * c31 * b_lo);
+    ctx.emit(sg * (L(MU_R + 1) + k0 - limb_of<F>(ctx, MU_P, 3) - k65536 * k1) + sg * b31 * c_hi + sh * c31 * b_hi);
+  }
 }
-constexpr int kMulConstraints = 166;
+constexpr int kMulConstraints = 166 + 10;
+
+// ---- divider chip: 52 constraints (layout comment above) ----
+template <class Ctx>
+ZKSP_HD void eval_div(Ctx& ctx) {
+  using F = typename Ctx::F;
+  const F one = ctx.k(kR1), real = L(DV_IS_REAL), k65536 = ZKSP_K(65536);
+  ctx.emit(bool_c(real, one));
+  F fsum = one - one;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    ctx.emit(bool_c(L(DV_F + k), one));
+    fsum = fsum + L(DV_F + k);
+  }
+  ctx.emit(fsum - real);
+  {
+    constexpr int bools[14] = {DV_SN, DV_SD, DV_SQ, DV_SR, DV_CN, DV_CD, DV_CQ, DV_CR, DV_K, DV_BE, DV_NZD, DV_NZQ, DV_NZR, DV_XS};
+#pragma unroll
+    for (int k = 0; k < 14; ++k) ctx.emit(bool_c(L(bools[k]), one));
+  }
+  const F sgn = L(DV_F + 0) + L(DV_F + 2);  // div, rem: signed
+  const F sn = L(DV_SN), sd = L(DV_SD), sq = L(DV_SQ), sr = L(DV_SR);
+  ctx.emit(sn * (one - sgn));
+  ctx.emit(sd * (one - sgn));
+  // the sign bits are the operands' top bits (NH, DH: the high limbs without them, looked up below 2^15 for signed operations)
+  ctx.emit(L(DV_N + 1) - ZKSP_K(32768) * sn - L(DV_NH));
+  ctx.emit(L(DV_D + 1) - ZKSP_K(32768) * sd - L(DV_DH));
+  // absolute values: X = AX, or X + AX = 2^32 (limb by limb with a carry) where the sign is set
+  {
+    constexpr int xs[4] = {DV_N, DV_D, DV_Q, DV_R}, ax[4] = {DV_AN, DV_AD, DV_AQ, DV_AR}, cx[4] = {DV_CN, DV_CD, DV_CQ, DV_CR};
+    const F sx[4] = {sn, sd, sq, sr};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const F x_lo = L(xs[k]), x_hi = L(xs[k] + 1), a_lo = L(ax[k]), a_hi = L(ax[k] + 1), c = L(cx[k]);
+      ctx.emit(sx[k] * (x_lo + a_lo - k65536 * c) + (one - sx[k]) * (x_lo - a_lo));
+      ctx.emit(sx[k] * (x_hi + a_hi + c - k65536) + (one - sx[k]) * (x_hi - a_hi));
+    }
+  }
+  ctx.emit(L(DV_XS) - (sn + sd - (sn * sd).dbl()));
+  // zero tests (the limbs are canonical, so their field sum is zero only if both are)
+  const F nzd = L(DV_NZD), nzq = L(DV_NZQ), nzr = L(DV_NZR);
+  {
+    const F dsum = L(DV_D) + L(DV_D + 1), qsum = L(DV_AQ) + L(DV_AQ + 1), rsum = L(DV_AR) + L(DV_AR + 1);
+    ctx.emit(dsum * L(DV_INVD) - nzd);
+    ctx.emit((one - nzd) * dsum);
+    ctx.emit(nzd * (one - real));
+    ctx.emit(qsum * L(DV_INVQ) - nzq);
+    ctx.emit((one - nzq) * qsum);
+    ctx.emit(rsum * L(DV_INVR) - nzr);
+    ctx.emit((one - nzr) * rsum);
+  }
+  // a non-zero divisor: |n| = |q| |d| + |r| (the product's low word from the multiplier chip, its high word zero), |r| < |d|,
+  // and the signs
+  ctx.emit(nzd * (L(DV_PL) + L(DV_AR) - L(DV_AN) - k65536 * L(DV_K)));
+  ctx.emit(nzd * (L(DV_PL + 1) + L(DV_AR + 1) + L(DV_K) - L(DV_AN + 1)));
+  ctx.emit(nzd * (L(DV_AD) - L(DV_AR) - one + k65536 * L(DV_BE) - L(DV_E)));
+  ctx.emit(nzd * (L(DV_AD + 1) - L(DV_AR + 1) - L(DV_BE) - L(DV_E + 1)));
+  ctx.emit(nzd * (sq - L(DV_XS) * nzq));
+  ctx.emit(nzd * (sr - sn * nzr));
+  // a zero divisor: q = 0xffffffff, r = n
+  const F zd = real - nzd;
+  ctx.emit(zd * (L(DV_Q) - ZKSP_K(65535)));
+  ctx.emit(zd * (L(DV_Q + 1) - ZKSP_K(65535)));
+  ctx.emit(zd * (L(DV_R) - L(DV_N)));
+  ctx.emit(zd * (L(DV_R + 1) - L(DV_N + 1)));
+  // the result: the quotient (div, divu) or the remainder (rem, remu)
+  {
+    const F wq = L(DV_F + 0) + L(DV_F + 1), wr = L(DV_F + 2) + L(DV_F + 3);
+    ctx.emit(L(DV_A) - wq * L(DV_Q) - wr * L(DV_R));
+    ctx.emit(L(DV_A + 1) - wq * L(DV_Q + 1) - wr * L(DV_R + 1));
+  }
+}
+constexpr int kDivConstraints = 52;
 
 // ---- ALU chip: 116 constraints in a fixed index space, evaluated as two tasks over disjoint work ----
 //   0 is_real, 1..4 selectors, 5..36 B bits, 37..68 C bits, 69..100 X bits, 101..102 K0 K1, 103 one selector per real row,
@@ -791,7 +891,7 @@ constexpr int kKeccakConstraints = ka::kNumConstraints + 1;
 ZKSP_HD constexpr int num_constraints(int chip) {
   return is_cpu_chip(chip) ? kCpuConstraints : chip == kKeccak ? kKeccakConstraints : chip == kKmem ? kKmemConstraints
        : chip == kMemFinal ? kMemFinalConstraints : chip == kImage ? 1 : chip == kProgram ? 0 : chip == kMul ? kMulConstraints
-       : chip == kTable ? 2 : is_alu_chip(chip) ? kAluConstraints : is_sub_chip(chip) ? kSubConstraints : is_bw_chip(chip) ? kBwConstraints : chip == kP2 ? kP2Constraints : chip == kEcall ? kEcallConstraints : chip == kFold ? kFoldConstraints : 0;
+       : chip == kTable ? 2 : is_alu_chip(chip) ? kAluConstraints : is_sub_chip(chip) ? kSubConstraints : is_bw_chip(chip) ? kBwConstraints : chip == kP2 ? kP2Constraints : chip == kEcall ? kEcallConstraints : chip == kFold ? kFoldConstraints : chip == kDiv ? kDivConstraints : 0;
 }
 
 }  // namespace mach

@@ -17,7 +17,7 @@ struct Seg {
   size_t bstride;
   int width;
 };
-constexpr int kMaxSegs = 24;  // at least kNumChips: every chip could have the same height
+constexpr int kMaxSegs = 25;  // at least kNumChips: every chip could have the same height
 static_assert(kMaxSegs >= mach::kNumChips, "a height group may hold every chip");
 
 // ---- trace expansion (row a3 of the machine proof) ----
@@ -30,6 +30,7 @@ struct MachineRecords {
   const uint32_t* sub_idx;     // [B][cap_sub]: cycle index of every sub-word-chip row
   const uint32_t* bw_idx;      // [B][cap_bw]: cycle index of every bitwise-chip row
   const uint32_t* ecall_idx;   // [B][cap_ecall]: cycle index of every ecall
+  const uint32_t* div_idx;     // [B][cap_div]: cycle index of every divider-chip row (div divu rem remu)
   const uint32_t* agg_heap;    // [B][cap_agg][kP2RecWords]: one record per row of the Poseidon2 chip (air_machine.hpp): flags, tag,
                                //          key, mask, the 16 input words (canonical) - heap nodes of an aggregation payload, then
                                //          the sponges and path steps of a leaf-proof check
@@ -37,10 +38,10 @@ struct MachineRecords {
   const P2Consts* consts;      // Poseidon2 constants (the Poseidon2 chip's rows are permutations)
   const uint32_t* prog_mult;   // [B][2^log_prog]; the padding row (n_program - 1) holds 0: its fetches follow from cpu_rows
   const uint32_t* counts;      // [B][12]: cycles, keccak calls, memfinal rows, muls, ALU rows, sub-word rows, last time x0 was
-                               //          accessed by a real cycle, bitwise rows, Poseidon2-chip rows, ecalls, fold-chip rows, 0
+                               //          accessed by a real cycle, bitwise rows, Poseidon2-chip rows, ecalls, fold-chip rows, divider rows
   uint32_t* table_hist;        // [B][kTableWidth][2^16] scratch: multiplicities of the table chip, counted on the device
   uint32_t row0[mach::kNumChips];  // first cycle / event of the chip's instance (second instances: rows of the first)
-  size_t cap_cycles, cap_keccak, cap_memfinal, cap_muls, cap_alu, cap_sub, cap_bw, cap_agg, cap_ecall, cap_fold;
+  size_t cap_cycles, cap_keccak, cap_memfinal, cap_muls, cap_alu, cap_sub, cap_bw, cap_agg, cap_ecall, cap_fold, cap_div;
   const uint32_t* program;     // [n_program][9] (shared); the last row is the padding instruction
   uint32_t text_base, n_program, n_image;
   uint32_t cpu_rows;           // rows of the two CPU instances together: the rows past the last cycle fetch the padding instruction

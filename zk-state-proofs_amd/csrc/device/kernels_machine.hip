@@ -447,7 +447,20 @@ __global__ __launch_bounds__(64) void mul_trace_kernel(MachineRecords rec, uint3
   const uint32_t bb = mu[1], c = mu[2];
   const uint64_t prod = (uint64_t)bb * c;
   o.put(MU_IS_REAL, kR1);
-  o.put(MU_HI, mu[0] ? kR1 : 0u);
+  o.put(MU_HI, mu[0] == 1 ? kR1 : 0u);
+  o.flag(MU_SH, mu[0] == 2); o.flag(MU_SHU, mu[0] == 3);
+  {
+    // mulh / mulhsu: R + b31 * C + [mulh] c31 * B = P_hi + 2^32 k, limb by limb
+    const bool sgd = mu[0] >= 2;
+    const uint32_t b31 = bb >> 31, c31 = mu[0] == 2 ? c >> 31 : 0u, phi = (uint32_t)(prod >> 32);
+    const uint32_t rr = sgd ? phi - (b31 ? c : 0u) - (c31 ? bb : 0u) : 0u;
+    const uint32_t lo = (rr & 0xffff) + (b31 ? (c & 0xffff) : 0u) + (c31 ? (bb & 0xffff) : 0u);
+    const uint32_t k0 = sgd ? (lo - (phi & 0xffff)) >> 16 : 0u;
+    const uint32_t hi = (rr >> 16) + (b31 ? (c >> 16) : 0u) + (c31 ? (bb >> 16) : 0u) + k0;
+    const uint32_t k1 = sgd ? (hi - (phi >> 16)) >> 16 : 0u;
+    o.limbs(MU_R, rr);
+    o.flag(MU_K0, k0 >= 1); o.flag(MU_K0 + 1, k0 >= 2); o.flag(MU_K1, k1 >= 1); o.flag(MU_K1 + 1, k1 >= 2);
+  }
   o.bits(MU_B, bb, 32); o.bits(MU_C, c, 32);
   o.bits(MU_P, (uint32_t)prod, 32); o.bits(MU_P + 32, (uint32_t)(prod >> 32), 32);
   uint64_t s[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -455,6 +468,58 @@ __global__ __launch_bounds__(64) void mul_trace_kernel(MachineRecords rec, uint3
     for (int j = 0; j < 4; ++j) s[i + j] += (uint64_t)((bb >> (8 * i)) & 0xff) * ((c >> (8 * j)) & 0xff);
   const uint64_t q0 = (s[0] + 256 * s[1]) >> 16, q1 = (s[2] + 256 * s[3] + q0) >> 16, q2 = (s[4] + 256 * s[5] + q1) >> 16;
   o.bits(MU_Q0, (uint32_t)q0, 10); o.bits(MU_Q1, (uint32_t)q1, 11); o.bits(MU_Q2, (uint32_t)q2, 10);
+}
+
+// Divider chip: row r is event r of the list div_idx (div divu rem remu): operands and result from the cycle record, the
+// absolute values, signs, carries, the product |q| |d| and the zero tests' inverses computed here (air_machine.hpp eval_div)
+__global__ __launch_bounds__(kMT) void div_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh) {
+  const size_t h = (size_t)1 << logh;
+  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (r >= h) return;
+  const int b = blockIdx.y;
+  const Col o{trace + (size_t)b * kDivWidth * h + r, h};
+  if (r >= rec.counts[kCountWords * b + 11]) { o.zero(0, kDivWidth); return; }
+  const uint32_t cyc = rec.div_idx[(size_t)b * rec.cap_div + r];
+  const uint32_t* cy = rec.cycles + ((size_t)b * rec.cap_cycles + cyc) * 12;
+  const uint32_t code = rec.program[9 * (size_t)((cy[0] - rec.text_base) >> 2) + 1], n = cy[2], d = cy[3];
+  const bool sg = code == DIV || code == REM, ovf = sg && n == 0x80000000u && d == 0xffffffffu;
+  uint32_t q, rm;
+  if (d == 0) { q = 0xffffffffu; rm = n; }
+  else if (ovf) { q = n; rm = 0; }
+  else if (sg) { q = (uint32_t)((int32_t)n / (int32_t)d); rm = (uint32_t)((int32_t)n % (int32_t)d); }
+  else { q = n / d; rm = n % d; }
+  const uint32_t sn = sg ? n >> 31 : 0u, sd = sg ? d >> 31 : 0u;
+  const uint32_t an = sn ? 0u - n : n, ad = sd ? 0u - d : d;
+  uint32_t sq, sr, aq, ar;
+  if (d == 0) {  // q = 0xffffffff as "minus one", r = n with n's sign
+    sq = 1; aq = 1; sr = sn; ar = an;
+  } else {
+    aq = an / ad; ar = an % ad;  // (|n| = 2^31, |d| = 1 included: |q| = 2^31, shown with the sign flag clear)
+    sq = (sn ^ sd) & (aq != 0 ? 1u : 0u);
+    sr = sn & (ar != 0 ? 1u : 0u);
+  }
+  o.put(DV_IS_REAL, kR1);
+  o.flag(DV_F + 0, code == DIV); o.flag(DV_F + 1, code == DIVU); o.flag(DV_F + 2, code == REM); o.flag(DV_F + 3, code == REMU);
+  o.limbs(DV_N, n); o.limbs(DV_D, d);
+  o.limbs(DV_A, (code == DIV || code == DIVU) ? q : rm);
+  o.flag(DV_SN, sn != 0); o.flag(DV_SD, sd != 0);
+  o.val(DV_NH, (n >> 16) - 32768u * sn); o.val(DV_DH, (d >> 16) - 32768u * sd);
+  o.limbs(DV_AN, an); o.limbs(DV_AD, ad); o.limbs(DV_AQ, aq); o.limbs(DV_AR, ar);
+  // X + AX = 2^32 where the sign is set: the carry out of the low limbs
+  o.flag(DV_CN, sn && (n & 0xffff) != 0); o.flag(DV_CD, sd && (d & 0xffff) != 0);
+  o.flag(DV_CQ, sq && (q & 0xffff) != 0); o.flag(DV_CR, sr && (rm & 0xffff) != 0);
+  o.limbs(DV_Q, q); o.limbs(DV_R, rm);
+  o.flag(DV_SQ, sq != 0); o.flag(DV_SR, sr != 0); o.flag(DV_XS, (sn ^ sd) != 0);
+  const uint32_t pl = d == 0 ? 0u : aq * ad;
+  o.limbs(DV_PL, pl);
+  o.flag(DV_K, d != 0 && (pl & 0xffff) + (ar & 0xffff) > 0xffff);
+  const uint32_t e = d == 0 ? 0u : ad - ar - 1;
+  o.limbs(DV_E, e);
+  o.flag(DV_BE, d != 0 && (ad & 0xffff) < (ar & 0xffff) + 1);
+  auto inv_of = [](uint32_t lo, uint32_t hi) { const uint32_t sm = lo + hi; return sm ? Fp::from_canonical(sm).inv().v : 0u; };
+  o.flag(DV_NZD, d != 0); o.put(DV_INVD, inv_of(d & 0xffff, d >> 16));
+  o.flag(DV_NZQ, aq != 0); o.put(DV_INVQ, inv_of(aq & 0xffff, aq >> 16));
+  o.flag(DV_NZR, ar != 0); o.put(DV_INVR, inv_of(ar & 0xffff, ar >> 16));
 }
 
 // one main column: multiplicities of the Program table / use flags of the Image table
@@ -502,6 +567,7 @@ void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& re
       break;
     case kEcall: hipLaunchKernelGGL(ecall_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
     case kFold: hipLaunchKernelGGL(fold_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
+    case kDiv: hipLaunchKernelGGL(div_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
     case kMemFinal: hipLaunchKernelGGL(memfinal_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
     case kMul:
       hipLaunchKernelGGL(mul_trace_kernel, dim3((unsigned)((h + 63) / 64), batch), dim3(64), 0, stream, rec, trace, logh);
@@ -1409,6 +1475,7 @@ __global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
   else if constexpr (CHIP == kP2) eval_p2(ctx);
   else if constexpr (CHIP == kEcall) eval_ecall(ctx);
   else if constexpr (CHIP == kFold) eval_fold(ctx);
+  else if constexpr (CHIP == kDiv) eval_div(ctx);
   ctx.flush();
   logup_constraints(a, pi, &ctx.acc);
   const Fp4 q = ctx.acc * Fp::raw(pi.c ? a.zh_inv[1] : a.zh_inv[0]);
@@ -1548,6 +1615,7 @@ void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a) {
     case kP2: hipLaunchKernelGGL(machine_quotient_kernel<kP2>, grid, block, 0, stream, a); break;
     case kEcall: hipLaunchKernelGGL(machine_quotient_kernel<kEcall>, grid, block, 0, stream, a); break;
     case kFold: hipLaunchKernelGGL(machine_quotient_kernel<kFold>, grid, block, 0, stream, a); break;
+    case kDiv: hipLaunchKernelGGL(machine_quotient_kernel<kDiv>, grid, block, 0, stream, a); break;
     case kKmem: hipLaunchKernelGGL(machine_quotient_kernel<kKmem>, grid, block, 0, stream, a); break;
     case kMemFinal: hipLaunchKernelGGL(machine_quotient_kernel<kMemFinal>, grid, block, 0, stream, a); break;
     case kImage: hipLaunchKernelGGL(machine_quotient_kernel<kImage>, grid, block, 0, stream, a); break;

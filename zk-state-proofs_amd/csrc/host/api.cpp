@@ -92,8 +92,8 @@ int zksp_setup(zksp_client* c, const uint8_t* elf, size_t elf_len, zksp_pk** pk,
   if (!p || !v) { delete p; delete v; return ZKSP_ERR_INVALID_ARG; }
   std::string e = load_elf(elf, elf_len, &p->elf);
   if (!e.empty()) { delete p; delete v; return c->ctx.fail(ZKSP_ERR_ELF, "setup: " + e); }
-  if (p->elf.keccakf_entries.empty()) {
-    delete p; delete v;
+  if (p->elf.keccakf_entries.empty() && c->ctx.params.proof_mode == ZKSP_PROOF_KECCAK_CHIP) {
+    delete p; delete v;  // a machine proof of a guest without keccak is a keccak chip of padding rows only
     return c->ctx.fail(ZKSP_ERR_ELF, "setup: ELF has no keccakf symbol; the keccak chip has nothing to prove");
   }
   {

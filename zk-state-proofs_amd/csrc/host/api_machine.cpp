@@ -109,6 +109,7 @@ int zksp_mtrace_section(const zksp_mtrace* t, int which, const void** ptr, size_
     case ZKSP_MT_SUB_IDX: *ptr = m.sub_idx.data(); *bytes = m.sub_idx.size() * 4; break;
     case ZKSP_MT_BW_IDX: *ptr = m.bw_idx.data(); *bytes = m.bw_idx.size() * 4; break;
     case ZKSP_MT_ECALL_IDX: *ptr = m.ecall_idx.data(); *bytes = m.ecall_idx.size() * 4; break;
+    case ZKSP_MT_DIV_IDX: *ptr = m.div_idx.data(); *bytes = m.div_idx.size() * 4; break;
     case ZKSP_MT_PROGRAM: *ptr = t->prog->rows.data(); *bytes = t->prog->rows.size() * sizeof(ProgramRow); break;
     case ZKSP_MT_IMAGE: *ptr = t->prog->image.data(); *bytes = t->prog->image.size() * sizeof(ImageRow); break;
     case ZKSP_MT_PUBLIC_VALUES: *ptr = m.rec.public_values.data(); *bytes = m.rec.public_values.size(); break;

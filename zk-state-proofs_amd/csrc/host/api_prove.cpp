@@ -185,6 +185,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       // cover gives both the taller multiplier chip)
       lh[mach::kEcall] = 0;
       lh[mach::kMul] = 0;
+      lh[mach::kDiv] = 0;
       groups[lh].push_back(i);
       covers[lh].cover(t);
     }
@@ -277,7 +278,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     for (size_t j = 0; j < ck.idx.size(); ++j) {
       MachineTrace& t = traces[ck.idx[j]]->t;
       dead[j].cycles.swap(t.cycles); dead[j].keccak.swap(t.keccak); dead[j].memfinal.swap(t.memfinal);
-      dead[j].muls.swap(t.muls); dead[j].prog_mult.swap(t.prog_mult); dead[j].alu_idx.swap(t.alu_idx); dead[j].sub_idx.swap(t.sub_idx); dead[j].bw_idx.swap(t.bw_idx);
+      dead[j].muls.swap(t.muls); dead[j].prog_mult.swap(t.prog_mult); dead[j].alu_idx.swap(t.alu_idx); dead[j].sub_idx.swap(t.sub_idx); dead[j].bw_idx.swap(t.bw_idx); dead[j].div_idx.swap(t.div_idx);
     }
     auto bury = [after](std::vector<MachineTrace>& d) {
       if (after) (void)hipEventSynchronize(after);

@@ -154,9 +154,15 @@ std::string build_machine_program(const ElfImage& elf, KeccakMode mode, MachineP
         case OP_AND: alu(AIR_AND, false); break;
         case OP_MUL: alu(AIR_MUL, false); break;
         case OP_MULHU: alu(AIR_MULHU, false); break;
+        case OP_MULH: alu(AIR_MULH, false); break;
+        case OP_MULHSU: alu(AIR_MULHSU, false); break;
+        case OP_DIV: alu(AIR_DIV, false); break;
+        case OP_DIVU: alu(AIR_DIVU, false); break;
+        case OP_REM: alu(AIR_REM, false); break;
+        case OP_REMU: alu(AIR_REMU, false); break;
         case OP_ECALL: r.op = AIR_ECALL; r.rd = 5; r.wr = 1; r.rs1 = 5; r.rs2 = 10; r.use2 = 1; break;
         case OP_FENCE: r.op = AIR_ADD; break;  // no architectural effect: x0 = x0 + 0, not written
-        default: break;  // mulh, mulhsu, div, divu, rem, remu, unimp, invalid: no AIR row can match
+        default: break;  // unimp, invalid: no AIR row can match
       }
     }
     out->rows[i] = r;
@@ -312,6 +318,26 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
         case AIR_BGEU: if (a >= b) next = r.tgt; break;
         case AIR_MUL: res = a * b; out->muls.push_back({0, a, b}); break;
         case AIR_MULHU: res = (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); out->muls.push_back({1, a, b}); break;
+        case AIR_MULH: res = (uint32_t)(((int64_t)(int32_t)a * (int64_t)(int32_t)b) >> 32); out->muls.push_back({2, a, b}); break;
+        case AIR_MULHSU: res = (uint32_t)(((int64_t)(int32_t)a * (int64_t)(uint64_t)b) >> 32); out->muls.push_back({3, a, b}); break;
+        case AIR_DIV: case AIR_DIVU: case AIR_REM: case AIR_REMU: {
+          // RISC-V: x / 0 = all ones, x % 0 = x; -2^31 / -1 = -2^31, remainder 0
+          const bool sg = r.op == AIR_DIV || r.op == AIR_REM;
+          uint32_t q, rm;
+          if (b == 0) { q = 0xffffffffu; rm = a; }
+          else if (sg && a == 0x80000000u && b == 0xffffffffu) { q = a; rm = 0; }
+          else if (sg) { q = (uint32_t)((int32_t)a / (int32_t)b); rm = (uint32_t)((int32_t)a % (int32_t)b); }
+          else { q = a / b; rm = a % b; }
+          res = (r.op == AIR_DIV || r.op == AIR_DIVU) ? q : rm;
+          out->div_idx.push_back((uint32_t)(cycles - 1));
+          if (b != 0) {  // the divider chip asks the multiplier chip for |q| * |d| (low word, and the high word: zero)
+            const uint32_t aq = sg && (int32_t)q < 0 && !(a == 0x80000000u && b == 0xffffffffu) ? 0u - q : q;
+            const uint32_t ad = sg && (int32_t)b < 0 ? 0u - b : b;
+            out->muls.push_back({0, aq, ad});
+            out->muls.push_back({1, aq, ad});
+          }
+          break;
+        }
         case AIR_LB: case AIR_LH: case AIR_LW: case AIR_LBU: case AIR_LHU: {
           const uint32_t ad = a + r.imm;
           const int sz = (r.op == AIR_LW) ? 4 : (r.op == AIR_LH || r.op == AIR_LHU) ? 2 : 1;

@@ -28,7 +28,8 @@ enum AirOp : uint32_t {
   AIR_JAL, AIR_JALR, AIR_BEQ, AIR_BNE, AIR_BLT, AIR_BGE, AIR_BLTU, AIR_BGEU,
   AIR_LB, AIR_LH, AIR_LW, AIR_LBU, AIR_LHU, AIR_SB, AIR_SH, AIR_SW,
   AIR_MUL, AIR_MULHU, AIR_ECALL, AIR_KECCAK,
-  AIR_NUM_OPS  // 31: ops are 1..30
+  AIR_MULH, AIR_MULHSU, AIR_DIV, AIR_DIVU, AIR_REM, AIR_REMU,
+  AIR_NUM_OPS  // 37: ops are 1..36
 };
 
 // One row of the preprocessed Program table (9 u32).  The table ends with the padding instruction: `jal x0, 0` at
@@ -75,7 +76,7 @@ struct MemFinalRec {
   uint32_t addr, init, fin, fin_ts, is_init;
 };
 struct MulRec {
-  uint32_t hi, b, c;
+  uint32_t hi, b, c;  // hi: 0 mul, 1 mulhu, 2 mulh, 3 mulhsu (also: the |q| * |d| products the divider chip asks for, as 0 and 1)
 };
 
 // Page-backed storage for the per-cycle records (19 MB and more per run): mapped and unmapped directly.  With
@@ -123,6 +124,7 @@ struct MachineTrace {
   std::vector<uint32_t> bw_idx;       // cycles that occupy a row of the bitwise chip (xor or and), in order
   std::vector<uint32_t> sub_idx;      // cycles that occupy a row of the sub-word chip (lb lh lbu lhu sb sh), in order
   std::vector<uint32_t> ecall_idx;    // the ecall cycles (one row of the ecall chip each), in order
+  std::vector<uint32_t> div_idx;      // cycles that occupy a row of the divider chip (div divu rem remu), in order
   uint32_t x0_last = 0;               // last access time of x0 by a real cycle (the first padding row consumes it)
   std::vector<uint32_t> agg_leaves;   // aggregation payload (row f4): 8 canonical words per supplied digest, or none
   std::vector<uint32_t> agg_keys;     // their heap keys (empty: n + j, the leaves of a full tree of n = a power of two)
@@ -134,15 +136,15 @@ struct MachineTrace {
 
 // How many rows of each event-sized chip a run needs; a batch is proven with the heights of the element-wise maximum.
 struct MachineCounts {
-  size_t cycles = 0, alu = 0, sub = 0, bw = 0, keccak = 0, memfinal = 0, muls = 0, agg = 0 /* Poseidon2 chip rows */, ecall = 0, fold = 0;
+  size_t cycles = 0, alu = 0, sub = 0, bw = 0, keccak = 0, memfinal = 0, muls = 0, agg = 0 /* Poseidon2 chip rows */, ecall = 0, fold = 0, div = 0;
   void cover(const MachineTrace& t) {
     cycles = std::max(cycles, t.cycles.size()); alu = std::max(alu, t.alu_idx.size()); sub = std::max(sub, t.sub_idx.size());
-    bw = std::max(bw, t.bw_idx.size()); agg = std::max(agg, t.p2_rows()); ecall = std::max(ecall, t.ecall_idx.size()); fold = std::max(fold, t.fold_rows());
+    bw = std::max(bw, t.bw_idx.size()); agg = std::max(agg, t.p2_rows()); ecall = std::max(ecall, t.ecall_idx.size()); fold = std::max(fold, t.fold_rows()); div = std::max(div, t.div_idx.size());
     keccak = std::max(keccak, t.keccak.size()); memfinal = std::max(memfinal, t.memfinal.size()); muls = std::max(muls, t.muls.size());
   }
   void cover(const MachineCounts& o) {
     cycles = std::max(cycles, o.cycles); alu = std::max(alu, o.alu); sub = std::max(sub, o.sub); bw = std::max(bw, o.bw);
-    agg = std::max(agg, o.agg); ecall = std::max(ecall, o.ecall); keccak = std::max(keccak, o.keccak); fold = std::max(fold, o.fold);
+    agg = std::max(agg, o.agg); ecall = std::max(ecall, o.ecall); keccak = std::max(keccak, o.keccak); fold = std::max(fold, o.fold); div = std::max(div, o.div);
     memfinal = std::max(memfinal, o.memfinal); muls = std::max(muls, o.muls);
   }
 };

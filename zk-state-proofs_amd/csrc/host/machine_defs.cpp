@@ -94,7 +94,7 @@ Interaction bytes_inter(int sign, const LinForm& mult, const LinForm& x, const L
 }
 
 constexpr int kCpuInter = 19;
-Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[2], g_table[7], g_alu[1], g_sub[5], g_bw[5], g_p2[7], g_ecall[10], g_fold[5];
+Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[5], g_div[13], g_table[7], g_alu[1], g_sub[5], g_bw[5], g_p2[7], g_ecall[10], g_fold[5];
 ChipDef g_chips[kNumChips];
 
 void build() {
@@ -287,10 +287,50 @@ void build() {
     it = Interaction{};
     it.bus = BUS_ALU; it.sign = -1; it.n_el = 7;
     it.mult = hi ? lf_col(MU_HI) : lf_pair(MU_IS_REAL, MU_HI, kP - 1);
+    if (!hi) { lf_add(it.mult, MU_SH, kP - 1); lf_add(it.mult, MU_SHU, kP - 1); }  // mul: the rows that are none of the high words
     it.el[0] = lf_const(hi ? (uint32_t)MULHU : (uint32_t)MUL);
     it.el[1] = lf_bits(MU_P + 32 * hi, 16); it.el[2] = lf_bits(MU_P + 32 * hi + 16, 16);
     it.el[3] = lf_bits(MU_B, 16); it.el[4] = lf_bits(MU_B + 16, 16); it.el[5] = lf_bits(MU_C, 16); it.el[6] = lf_bits(MU_C + 16, 16);
   }
+  {
+    // mulh / mulhsu: the signed high word R, range-checked
+    Interaction& it = g_mul[2];
+    it = Interaction{};
+    it.bus = BUS_ALU; it.sign = -1; it.n_el = 7;
+    it.mult = lf_pair(MU_SH, MU_SHU, 1);
+    it.el[0] = lf_zero(); lf_add(it.el[0], MU_SH, MULH); lf_add(it.el[0], MU_SHU, MULHSU);
+    it.el[1] = lf_col(MU_R); it.el[2] = lf_col(MU_R + 1);
+    it.el[3] = lf_bits(MU_B, 16); it.el[4] = lf_bits(MU_B + 16, 16); it.el[5] = lf_bits(MU_C, 16); it.el[6] = lf_bits(MU_C + 16, 16);
+    g_mul[3] = range_inter(-1, lf_pair(MU_SH, MU_SHU, 1), zero, lf_col(MU_R));
+    g_mul[4] = range_inter(-1, lf_pair(MU_SH, MU_SHU, 1), zero, lf_col(MU_R + 1));
+  }
+  {
+    // divider chip (air_machine.hpp): the instruction from the CPU row, the product |q| |d| from the multiplier chip (low
+    // word PL, high word zero), range lookups
+    const LinForm real = lf_col(DV_IS_REAL), nzd = lf_col(DV_NZD), sgn = lf_pair(DV_F + 0, DV_F + 2, 1);
+    Interaction& rc = g_div[0];
+    rc = Interaction{};
+    rc.bus = BUS_ALU; rc.sign = -1; rc.mult = real; rc.n_el = 7;
+    rc.el[0] = lf_zero();
+    lf_add(rc.el[0], DV_F + 0, DIV); lf_add(rc.el[0], DV_F + 1, DIVU); lf_add(rc.el[0], DV_F + 2, REM); lf_add(rc.el[0], DV_F + 3, REMU);
+    rc.el[1] = lf_col(DV_A); rc.el[2] = lf_col(DV_A + 1); rc.el[3] = lf_col(DV_N); rc.el[4] = lf_col(DV_N + 1);
+    rc.el[5] = lf_col(DV_D); rc.el[6] = lf_col(DV_D + 1);
+    for (int hi = 0; hi < 2; ++hi) {
+      Interaction& ml = g_div[1 + hi];
+      ml = Interaction{};
+      ml.bus = BUS_ALU; ml.sign = +1; ml.mult = nzd; ml.n_el = 7;
+      ml.el[0] = lf_const(hi ? (uint32_t)MULHU : (uint32_t)MUL);
+      ml.el[1] = hi ? zero : lf_col(DV_PL); ml.el[2] = hi ? zero : lf_col(DV_PL + 1);
+      ml.el[3] = lf_col(DV_AQ); ml.el[4] = lf_col(DV_AQ + 1); ml.el[5] = lf_col(DV_AD); ml.el[6] = lf_col(DV_AD + 1);
+    }
+    const int checked[8] = {DV_A, DV_A + 1, DV_AN, DV_AN + 1, DV_AR, DV_AR + 1, DV_E, DV_E + 1};
+    for (int k = 0; k < 8; ++k) g_div[3 + k] = range_inter(-1, real, zero, lf_col(checked[k]));
+    LinForm nh2 = lf_zero(), dh2 = lf_zero();
+    lf_add(nh2, DV_NH, 2); lf_add(dh2, DV_DH, 2);
+    g_div[11] = range_inter(-1, sgn, zero, nh2);
+    g_div[12] = range_inter(-1, sgn, zero, dh2);
+  }
+  g_chips[kDiv] = {"divider", 0, kDivWidth, 13, g_div, kDivConstraints, 0};
   {
     Interaction& it = g_alu[0];
     it = Interaction{};
@@ -435,7 +475,7 @@ void build() {
   g_chips[kMemFinal] = {"mem-final", 0, kMemFinalWidth, 10, g_memfinal, kMemFinalConstraints, 0};
   g_chips[kImage] = {"image", kImagePrepWidth, kImageWidth, 1, g_image, 1, 0};
   g_chips[kProgram] = {"program", kProgramPrepWidth, kProgramWidth, 1, g_program, 0, 0};
-  g_chips[kMul] = {"mul", 0, kMulWidth, 2, g_mul, kMulConstraints, 0};
+  g_chips[kMul] = {"mul", 0, kMulWidth, 5, g_mul, kMulConstraints, 0};
   g_chips[kAlu] = {"alu", 0, kAluWidth, 1, g_alu, kAluConstraints, 0};
   g_chips[kAlu2] = {"alu2", 0, kAluWidth, 1, g_alu, kAluConstraints, 0};
   g_chips[kSub] = {"subword", 0, kSubWidth, 5, g_sub, kSubConstraints, 0};

@@ -243,6 +243,7 @@ void machine_heights(const MachineProgram& prog, const MachineCounts& n, int log
   logh[kP2] = at_least5(ceil_log2(n.agg ? n.agg : 1));  // a payload's rows: heap nodes, the permutations of a leaf-proof check
   logh[kEcall] = at_least5(ceil_log2(n.ecall));
   logh[kFold] = at_least5(ceil_log2(n.fold ? n.fold : 1));
+  logh[kDiv] = at_least5(ceil_log2(n.div));
 }
 void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh[kNumChips]) {
   MachineCounts n;
@@ -255,7 +256,7 @@ bool machine_fits(const MachineTrace& t, const int* logh) {
   return t.cycles.size() <= machine_cpu_row0(logh, kNumCpuInst) && t.alu_idx.size() <= two(kAlu, kAlu2) && t.sub_idx.size() <= two(kSub, kSub2) &&
          t.bw_idx.size() <= two(kBw, kBw2) && t.p2_rows() <= one(kP2) && t.fold_rows() <= one(kFold) &&
          24 * t.keccak.size() <= one(kKeccak) && 50 * t.keccak.size() <= one(kKmem) && t.memfinal.size() <= one(kMemFinal) &&
-         t.muls.size() <= one(kMul) && t.ecall_idx.size() <= one(kEcall);
+         t.muls.size() <= one(kMul) && t.ecall_idx.size() <= one(kEcall) && t.div_idx.size() <= one(kDiv);
 }
 
 int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const PrepDevice** out) {
@@ -362,6 +363,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
     A(&w->sub_idx, B * w->cap_sub);
     A(&w->bw_idx, B * w->cap_bw);
     A(&w->ecall_idx, B << logh[kEcall]);  // (an ecall list is as long as the ecall chip is tall, at most)
+    A(&w->div_idx, B << logh[kDiv]);
     A(&w->agg_heap, B * w->cap_agg * kP2RecWords);
     A(&w->fold_rows, B * w->cap_fold * kFoldRecWords);
     A(&w->prog_mult, B << logh[kProgram]);
@@ -379,6 +381,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
     A(&w->spare.sub_idx, B * w->cap_sub);
     A(&w->spare.bw_idx, B * w->cap_bw);
     A(&w->spare.ecall_idx, B << logh[kEcall]);
+    A(&w->spare.div_idx, B << logh[kDiv]);
     A(&w->spare.agg_heap, B * w->cap_agg * kP2RecWords);
     A(&w->spare.fold_rows, B * w->cap_fold * kFoldRecWords);
     A(&w->spare.prog_mult, B << logh[kProgram]);
@@ -505,7 +508,7 @@ namespace {
 void swap_records(MachineWorkspace* w) {
   MachineWorkspace::SpareRecords& p = w->spare;
   std::swap(w->cycles, p.cycles); std::swap(w->memfinal, p.memfinal); std::swap(w->muls, p.muls);
-  std::swap(w->prog_mult, p.prog_mult); std::swap(w->alu_idx, p.alu_idx); std::swap(w->sub_idx, p.sub_idx); std::swap(w->bw_idx, p.bw_idx); std::swap(w->ecall_idx, p.ecall_idx); std::swap(w->agg_heap, p.agg_heap); std::swap(w->fold_rows, p.fold_rows);
+  std::swap(w->prog_mult, p.prog_mult); std::swap(w->alu_idx, p.alu_idx); std::swap(w->sub_idx, p.sub_idx); std::swap(w->bw_idx, p.bw_idx); std::swap(w->ecall_idx, p.ecall_idx); std::swap(w->div_idx, p.div_idx); std::swap(w->agg_heap, p.agg_heap); std::swap(w->fold_rows, p.fold_rows);
   std::swap(w->counts, p.counts);
   std::swap(w->kcalls, p.kcalls); std::swap(w->kstates, p.kstates); std::swap(w->n_perms, p.n_perms);
   std::swap(w->init_obs, p.init_obs); std::swap(w->pub_words, p.pub_words); std::swap(w->n, p.n);
@@ -588,6 +591,9 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     cn[9] = (uint32_t)t.ecall_idx.size();
     if (!t.ecall_idx.empty())
       ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->ecall_idx + (i << logh[kEcall]), t.ecall_idx.data(), t.ecall_idx.size() * 4, hipMemcpyHostToDevice, s));
+    cn[11] = (uint32_t)t.div_idx.size();
+    if (!t.div_idx.empty())
+      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->div_idx + (i << logh[kDiv]), t.div_idx.data(), t.div_idx.size() * 4, hipMemcpyHostToDevice, s));
     // aggregation payload: the rows (ancestors of the supplied nodes: key, children's digests) the Poseidon2 chip's
     // rows are expanded from, and its public part
     uint32_t agg_root[8], agg_digest[8];
@@ -714,13 +720,13 @@ int machine_prove_resident(Context* ctx) {
   // ---- main traces ----
   MachineRecords rec;
   rec.cycles = w->cycles; rec.kcalls = w->kcalls; rec.memfinal = w->memfinal; rec.muls = w->muls;
-  rec.alu_idx = w->alu_idx; rec.sub_idx = w->sub_idx; rec.bw_idx = w->bw_idx; rec.ecall_idx = w->ecall_idx; rec.agg_heap = w->agg_heap; rec.fold_rows = w->fold_rows; rec.consts = kc;
+  rec.alu_idx = w->alu_idx; rec.sub_idx = w->sub_idx; rec.bw_idx = w->bw_idx; rec.ecall_idx = w->ecall_idx; rec.div_idx = w->div_idx; rec.agg_heap = w->agg_heap; rec.fold_rows = w->fold_rows; rec.consts = kc;
   rec.prog_mult = w->prog_mult; rec.counts = w->counts; rec.table_hist = w->table_hist;
   memset(rec.row0, 0, sizeof rec.row0);
   for (int k = 1; k < kNumCpuInst; ++k) rec.row0[cpu_chip(k)] = (uint32_t)machine_cpu_row0(logh, k);
   rec.row0[kAlu2] = (uint32_t)1 << logh[kAlu]; rec.row0[kSub2] = (uint32_t)1 << logh[kSub]; rec.row0[kBw2] = (uint32_t)1 << logh[kBw];
   rec.cap_cycles = w->cap_cycles; rec.cap_keccak = w->cap_keccak; rec.cap_memfinal = w->cap_memfinal; rec.cap_muls = w->cap_muls;
-  rec.cap_alu = w->cap_alu; rec.cap_sub = w->cap_sub; rec.cap_bw = w->cap_bw; rec.cap_agg = w->cap_agg; rec.cap_fold = w->cap_fold; rec.cap_ecall = (size_t)1 << logh[kEcall];
+  rec.cap_alu = w->cap_alu; rec.cap_sub = w->cap_sub; rec.cap_bw = w->cap_bw; rec.cap_agg = w->cap_agg; rec.cap_fold = w->cap_fold; rec.cap_ecall = (size_t)1 << logh[kEcall]; rec.cap_div = (size_t)1 << logh[kDiv];
   rec.program = prep->program; rec.text_base = prep->text_base; rec.n_program = prep->n_program; rec.n_image = prep->n_image;
   rec.cpu_rows = (uint32_t)machine_cpu_row0(logh, kNumCpuInst);
   // Small batches: the chips of a stage go to the lanes of a fork (by height) and the stage joins again; large batches have
@@ -750,7 +756,7 @@ int machine_prove_resident(Context* ctx) {
         launch_machine_trace(SC(c), c, rec, w->mat[c][0].tr, logh[c], B);
       }
       if (is_cpu_chip(c)) launch_cpu_table_count(SC(c), w->mat[c][0].tr, logh[c], rec, B);
-      for (int c2 : {(int)kKmem, (int)kMemFinal, (int)kBw, (int)kBw2, (int)kSub, (int)kSub2, (int)kEcall, (int)kP2})
+      for (int c2 : {(int)kKmem, (int)kMemFinal, (int)kBw, (int)kBw2, (int)kSub, (int)kSub2, (int)kEcall, (int)kP2, (int)kMul, (int)kDiv})
         if (c2 == c)
           launch_table_count(SC(c), static_cast<const Interaction*>(ctx->d_inter[c]), chip_def(c).n_inter, w->mat[c][0].tr,
                              chip_def(c).main_w, logh[c], rec, B);

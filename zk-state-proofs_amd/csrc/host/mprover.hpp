@@ -1,5 +1,5 @@
 // Device prover of the machine proof: batch workspace in HBM and the launch sequence that turns
-// traced executions into proof bodies ("ZKSP v14") without a host round trip.  See mprover.cpp.
+// traced executions into proof bodies ("ZKSP v15") without a host round trip.  See mprover.cpp.
 #pragma once
 #include <array>
 #include <vector>
@@ -38,7 +38,7 @@ struct MachineWorkspace {
   const PrepDevice* prep = nullptr;
   // records
   uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *alu_idx = nullptr, *sub_idx = nullptr,
-           *bw_idx = nullptr, *ecall_idx = nullptr, *agg_heap = nullptr, *fold_rows = nullptr, *counts = nullptr, *table_hist = nullptr;
+           *bw_idx = nullptr, *ecall_idx = nullptr, *div_idx = nullptr, *agg_heap = nullptr, *fold_rows = nullptr, *counts = nullptr, *table_hist = nullptr;
   uint8_t* kcalls = nullptr;
   uint64_t* kstates = nullptr;
   uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;
@@ -46,7 +46,7 @@ struct MachineWorkspace {
   // being proven, then machine_activate_spare() swaps the sets.
   struct SpareRecords {
     uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *alu_idx = nullptr, *sub_idx = nullptr,
-             *bw_idx = nullptr, *ecall_idx = nullptr, *agg_heap = nullptr, *fold_rows = nullptr, *counts = nullptr;
+             *bw_idx = nullptr, *ecall_idx = nullptr, *div_idx = nullptr, *agg_heap = nullptr, *fold_rows = nullptr, *counts = nullptr;
     uint8_t* kcalls = nullptr;
     uint64_t* kstates = nullptr;
     uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;

@@ -1,4 +1,4 @@
-// Host verifier of the machine proof ("ZKSP v14"): replaces `client.verify(&proof, &vk)` (reference
+// Host verifier of the machine proof ("ZKSP v15"): replaces `client.verify(&proof, &vk)` (reference
 // prover/src/bin/main.rs:80; sp1-stark 3.4.0's multi-chip verifier over p3-uni-stark / p3-fri,
 // Cargo.lock:7485, :5378, :5253) for proofs that bind the guest's whole execution.  Also the
 // host half of `client.setup(ELF)` (main.rs:70): the commitment to the preprocessed Program and
@@ -740,6 +740,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       case kP2: eval_p2(zc); break;
       case kEcall: eval_ecall(zc); break;
       case kFold: eval_fold(zc); break;
+      case kDiv: eval_div(zc); break;
     }
     if (zc.k_ != nb) { *err = "internal: constraint count"; return 7; }
     // LogUp (machine_defs.hpp "LogUp layout"): row = [prep | main] at zeta
