@@ -33,6 +33,18 @@ for _ in range(steps):
 lib.zksp_hip_sync(h)
 el = time.perf_counter() - t0
 print(f"batch {B}: {el * 1e3 / steps:.2f} ms/step", flush=True)
+# host time to enqueue one pass (the call returns when everything is queued) against the synchronised pass
+enq, tot = [], []
+for _ in range(10):
+    t0 = time.perf_counter()
+    assert lib.zksp_hip_machine_prove(h) == 0
+    t1 = time.perf_counter()
+    lib.zksp_hip_sync(h)
+    t2 = time.perf_counter()
+    enq.append((t1 - t0) * 1e3)
+    tot.append((t2 - t0) * 1e3)
+print("enqueue ms " + " ".join(f"{x:.2f}" for x in enq), flush=True)
+print("one pass, synchronised, ms " + " ".join(f"{x:.2f}" for x in tot), flush=True)
 shape = zk.machine_cover_heights(handles)
 lh = (C.c_int32 * zk.MACHINE_CHIPS)(*shape)
 bw = lib.zksp_machine_body_words(h, lh)

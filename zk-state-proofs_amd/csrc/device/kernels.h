@@ -90,6 +90,23 @@ void launch_open(hipStream_t stream, const uint32_t* coefs_br, size_t coefs_stri
                  size_t pt_stride, int batch);
 
 // The same for tall matrices (log_h >= 12): the coefficient range is split over workgroups; `scratch` holds
+// A small batch opens all its matrices with one launch per kind of kernel (launch_open_multi) over a device table of
+// tasks.  The caller fills evals .. npts; open_task_plan chooses kind / nsplit / klen / blocks / cblocks as the
+// single-matrix launches below do and returns the words of partial sums the task needs; the caller then sorts the tasks
+// by kind, assigns `partial`, and numbers the workgroups (blk0 within the kind, cblk0 over the kinds 1..5).
+struct OpenTask {
+  const uint32_t* evals;
+  size_t cstride;
+  const uint32_t* table;
+  size_t zstride;
+  uint32_t* dst;  // the first proof's destination (opened + offset); proofs are opened_stride words apart
+  size_t pts;
+  uint32_t* partial;
+  int ncols, logh, npts, nsplit, klen, kind, blocks, cblocks, blk0, cblk0;
+};
+size_t open_task_plan(OpenTask* t, int batch);
+void launch_open_multi(hipStream_t stream, const OpenTask* tasks, const int first[6], const int count[6], const int blocks[6],
+                       int combine_blocks, size_t opened_stride);
 // open_tall_scratch_words(ncols, logh, batch) words of partial sums.
 size_t open_tall_scratch_words(int ncols, int logh, int batch);
 void launch_open_tall(hipStream_t stream, const uint32_t* coefs_br, size_t coefs_stride, int ncols, int logh,

@@ -68,6 +68,17 @@ void launch_table_trace(hipStream_t stream, const MachineRecords& rec, uint32_t*
 void launch_mmcs_leaves(hipStream_t stream, const Seg* segs, int nseg, int logh, uint32_t* digests, size_t out_bstride,
                         int batch, const P2Consts* consts);
 // One level: out[i] = compress(in[2i], in[2i+1]), then compress(out[i], inject[i]) when inject != null.
+// the last levels of a tree (at most 256 nodes each) in one launch; offsets in words from the proof's tree
+constexpr int kMmcsTopLevels = 9, kMmcsTopNodes = 256;
+struct MmcsTopArgs {
+  uint32_t* tree;
+  size_t tree_bstride;
+  int n_levels;
+  int count[kMmcsTopLevels];
+  size_t in_off[kMmcsTopLevels], out_off[kMmcsTopLevels], inj_bstride[kMmcsTopLevels];
+  const uint32_t* inject[kMmcsTopLevels];
+};
+void launch_mmcs_top(hipStream_t stream, const MmcsTopArgs& a, int batch, const P2Consts* consts);
 void launch_mmcs_level(hipStream_t stream, const uint32_t* in, size_t in_bstride, uint32_t* out, size_t out_bstride,
                        const uint32_t* inject, size_t inject_bstride, size_t count, int batch, const P2Consts* consts);
 
@@ -143,6 +154,35 @@ struct MReduceArgs {
 };
 int mreduce_nchunks(int total_width);
 void launch_machine_reduce(hipStream_t stream, const MReduceArgs& a);
+// A small batch reduces ALL its openings with two launches over device tables: the sums of alpha^i * opened_i per height,
+// then one pass per height over every column of every chip of that height (what the per-chip launches add up one chip
+// after the other: the sums are exact, their order does not matter).
+struct MRSeg {            // one LDE matrix of one chip
+  const uint32_t* p;
+  size_t bstride;
+  int width;
+  int pow1, pow2;         // index of alpha_f's power for column 0 at zeta, and at zeta * w (-1: opened at zeta only)
+};
+struct MRChip { int open_off, n1, n2; };  // the chip's opened values: n1 at zeta from open_off, then n2 at zeta * w
+struct MRHeight {
+  int logh, seg0, nseg, chip0, nchips, blk0;
+  uint32_t* out;          // [B][2H] Fp4
+  size_t out_bstride;
+  const uint32_t* tw_fwd;
+  uint32_t shift[2], w_h;
+};
+struct MReduceMulti {
+  const MRHeight* heights; int n_heights;
+  const MRSeg* segs;
+  const MRChip* chips;
+  const uint32_t* af_pows; size_t af_bstride;
+  const uint32_t* opened; size_t opened_bstride;
+  const uint32_t* zeta;
+  uint32_t* bsum;         // [B][n_heights][2] Fp4 scratch
+  int total_blocks, batch;
+};
+constexpr int kMReduceMultiPoints = 256;  // LDE points per workgroup: 64 lanes x 4 consecutive points, four such parts share the columns
+void launch_machine_reduce_multi(hipStream_t stream, const MReduceMulti& a);
 // layer[i] += g[i] (Fp4), n elements per proof
 void launch_fri_add(hipStream_t stream, uint32_t* layer, size_t layer_bstride, const uint32_t* g, size_t g_bstride, size_t n,
                     int batch);

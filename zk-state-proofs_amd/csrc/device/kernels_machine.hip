@@ -643,6 +643,9 @@ __global__ __launch_bounds__(kMT) void mmcs_leaf_kernel(LeafArgs a, const P2Cons
 // words fetched four steps ahead.  About twice the arithmetic of the lane-per-row kernel, so it is used only
 // while that kernel could not fill the chip.
 __global__ __launch_bounds__(kMT) void mmcs_leaf_coop_kernel(LeafArgs a, const P2Consts* __restrict__ consts) {
+  // a chain of dependent permutations that shares the CUs with the throughput kernels of other lanes (a small batch hashes
+  // its height groups side by side): its waves issue first, the others fill the gaps its dependencies leave
+  __builtin_amdgcn_s_setprio(3);
   const size_t h = (size_t)1 << a.logh, n = 2 * h;
   const int e = threadIdx.x & 15;
   const size_t row = (size_t)blockIdx.x * (kMT / 16) + (threadIdx.x >> 4);
@@ -750,6 +753,35 @@ void launch_mmcs_level(hipStream_t stream, const uint32_t* in, size_t in_bstride
                      out, out_bstride, inject, inject_bstride, count, consts);
 }
 
+// The levels of at most kMT nodes in ONE launch, one workgroup per proof: nine launches of a few microseconds' work each
+// were a fifth of a single proof's commitment.  (Stores to the tree are visible to the workgroup after the barrier's fence.)
+__global__ __launch_bounds__(kMT) void mmcs_top_kernel(MmcsTopArgs a, const P2Consts* __restrict__ consts) {
+  const int b = blockIdx.x, i = threadIdx.x;
+  uint32_t* tree = a.tree + (size_t)b * a.tree_bstride;
+  for (int lv = 0; lv < a.n_levels; ++lv) {
+    if (i < a.count[lv]) {
+      const uint4* src = reinterpret_cast<const uint4*>(tree + a.in_off[lv] + 16 * (size_t)i);
+      uint4 d[2];
+      m_compress(src, src + 2, d, consts);
+      if (a.inject[lv]) {
+        const uint4* g = reinterpret_cast<const uint4*>(a.inject[lv] + (size_t)b * a.inj_bstride[lv] + 8 * (size_t)i);
+        uint4 e[2];
+        m_compress(d, g, e, consts);
+        d[0] = e[0];
+        d[1] = e[1];
+      }
+      uint4* dst = reinterpret_cast<uint4*>(tree + a.out_off[lv] + 8 * (size_t)i);
+      dst[0] = d[0];
+      dst[1] = d[1];
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+void launch_mmcs_top(hipStream_t stream, const MmcsTopArgs& a, int batch, const P2Consts* consts) {
+  hipLaunchKernelGGL(mmcs_top_kernel, dim3(batch), dim3(kMT), 0, stream, a, consts);
+}
+
 // ===========================================================================================
 // LogUp: fingerprints and the permutation trace
 // ===========================================================================================
@@ -778,29 +810,36 @@ __device__ __forceinline__ Fp4 m_fingerprint(const Interaction& it, const RowVie
 // table chip multiplicities: the RANGE / BYTES receives of a chip's rows, counted per table row
 // ===========================================================================================
 constexpr int kTableRowsPerBlock = 4096;
-constexpr uint32_t kTableLdsBins = 4096;  // the low range16 values, the small high address limbs and the byte pairs with a
-                                          // small second byte are hot: counted in LDS, flushed once per workgroup
+constexpr uint32_t kTableLdsBins = 4096;  // the low range16 values, the small high address limbs, the aligned low limbs below
+                                          // 2^14 and the byte pairs with a small second byte are hot: counted in LDS, flushed
+                                          // once per workgroup
 constexpr size_t kTableRows = (size_t)1 << kTableLogH;
-// bins[idx] += m for the active lanes of a wave; the lanes that share the first active lane's bin (in these histograms
-// most of the wave: a zero high byte, a gap of 3) are added with one atomic
+// bins[idx] += m for the active lanes of a wave.  Lanes that share a bin (in these histograms most of the wave: a zero high
+// byte, a gap of 3, the one stack page a run's loads hit) are added with ONE atomic: up to four leaders in turn collect the
+// lanes that agree with them, whoever is left adds for itself.  Same-address atomics serialise in the memory system
+// (about 130 ns each at device scope: 4 096 keccak-state rows that look up the same pointer limb took 530 us).
 __device__ __forceinline__ void wave_hist_add(uint32_t* bins, uint32_t idx, uint32_t m, bool active) {
-  const unsigned long long act = __ballot(active);
-  if (act == 0) return;
-  const int leader = __ffsll((long long)act) - 1;
-  const uint32_t k0 = __shfl(idx, leader, 64), m0 = __shfl(m, leader, 64);
-  const bool same = active && idx == k0 && m == m0;
-  const unsigned long long sm = __ballot(same);
   const int lane = threadIdx.x & 63;
-  if (lane == leader) atomicAdd(&bins[k0], m0 * (uint32_t)__popcll(sm));
-  else if (active && !same) atomicAdd(&bins[idx], m);
+  unsigned long long act = __ballot(active);
+#pragma unroll 1
+  for (int round = 0; round < 4 && act; ++round) {
+    const int leader = __ffsll((long long)act) - 1;
+    const uint32_t k0 = __shfl(idx, leader, 64), m0 = __shfl(m, leader, 64);
+    const bool same = active && idx == k0 && m == m0;
+    const unsigned long long sm = __ballot(same);
+    if (lane == leader) atomicAdd(&bins[k0], m0 * (uint32_t)__popcll(sm));
+    active = active && !same;
+    act &= ~sm;
+  }
+  if (active) atomicAdd(&bins[idx], m);
 }
 __global__ __launch_bounds__(kMT) void table_count_kernel(const Interaction* __restrict__ inter, int n_inter,
                                                          const uint32_t* __restrict__ trace, int width, int logh,
                                                          uint32_t* __restrict__ hist, int rows_per_block) {
-  __shared__ uint32_t lds[3 * kTableLdsBins];  // range16, high address limb, byte pair
+  __shared__ uint32_t lds[4 * kTableLdsBins];  // range16, high address limb, byte pair, aligned low limb / 4
   const size_t h = (size_t)1 << logh;
   const int b = blockIdx.y;
-  for (uint32_t i = threadIdx.x; i < 3 * kTableLdsBins; i += kMT) lds[i] = 0;
+  for (uint32_t i = threadIdx.x; i < 4 * kTableLdsBins; i += kMT) lds[i] = 0;
   __syncthreads();
   uint32_t* hb = hist + (size_t)b * kTableWidth * kTableRows;
   const size_t r0 = (size_t)blockIdx.x * rows_per_block;
@@ -823,15 +862,15 @@ __global__ __launch_bounds__(kMT) void table_count_kernel(const Interaction* __r
       // a value without a table row is not counted: the buses of such a (dishonest or unprovable) run do not balance
       if (it.bus == BUS_RANGE) {
         const bool ok = m != 0 && v2 < kTableRows && v1 <= 2 && !(v1 == 1 && (v2 & 3)) && !(v1 == 2 && (v2 == 0 || v2 > kAddrHiMax));
-        const bool hot = v1 != 1 && v2 < kTableLdsBins;
-        wave_hist_add(lds, (v1 == 2 ? kTableLdsBins : 0) + v2, m, ok && hot);  // (the kind differs between lanes)
-        if (ok && !hot) atomicAdd(&hb[(size_t)(v1 == 0 ? TB_M_R16 : v1 == 1 ? TB_M_AL : TB_M_TOP) * kTableRows + v2], m);
+        const bool hot = v1 == 1 ? v2 < 4 * kTableLdsBins : v2 < kTableLdsBins;
+        wave_hist_add(lds, v1 == 1 ? 3 * kTableLdsBins + (v2 >> 2) : (v1 == 2 ? kTableLdsBins : 0) + v2, m, ok && hot);  // (the kind differs between lanes)
+        wave_hist_add(hb, (size_t)(v1 == 0 ? TB_M_R16 : v1 == 1 ? TB_M_AL : TB_M_TOP) * kTableRows + v2, m, ok && !hot);
       } else {
         const bool ok = m != 0 && v1 <= 255 && v2 <= 255;
         const uint32_t idx = v1 + 256 * v2;
         const bool hot = idx < kTableLdsBins;
         wave_hist_add(lds, 2 * kTableLdsBins + idx, m, ok && hot);
-        if (ok && !hot) atomicAdd(&hb[(size_t)TB_M_BY * kTableRows + idx], m);
+        wave_hist_add(hb, (uint32_t)(TB_M_BY * kTableRows) + idx, m, ok && !hot);
       }
     }
   }
@@ -840,6 +879,7 @@ __global__ __launch_bounds__(kMT) void table_count_kernel(const Interaction* __r
     if (lds[i]) atomicAdd(&hb[(size_t)TB_M_R16 * kTableRows + i], lds[i]);
     if (lds[kTableLdsBins + i]) atomicAdd(&hb[(size_t)TB_M_TOP * kTableRows + i], lds[kTableLdsBins + i]);
     if (lds[2 * kTableLdsBins + i]) atomicAdd(&hb[(size_t)TB_M_BY * kTableRows + i], lds[2 * kTableLdsBins + i]);
+    if (lds[3 * kTableLdsBins + i]) atomicAdd(&hb[(size_t)TB_M_AL * kTableRows + 4 * i], lds[3 * kTableLdsBins + i]);
   }
 }
 // The CPU chip's seven lookups (machine_defs.cpp g_cpu[7..13]) read from the columns that hold them, instead of through
@@ -847,25 +887,25 @@ __global__ __launch_bounds__(kMT) void table_count_kernel(const Interaction* __r
 // is an address) and its low limb less the byte offset (kind 1 where aligned), the last two on the rows that check X.
 __global__ __launch_bounds__(kMT) void cpu_table_count_kernel(const uint32_t* __restrict__ trace, int logh, uint32_t* __restrict__ hist,
                                                               int rows_per_block) {
-  __shared__ uint32_t lds[3 * kTableLdsBins];
+  __shared__ uint32_t lds[4 * kTableLdsBins];
   const size_t h = (size_t)1 << logh;
   const int b = blockIdx.y;
-  for (uint32_t i = threadIdx.x; i < 3 * kTableLdsBins; i += kMT) lds[i] = 0;
+  for (uint32_t i = threadIdx.x; i < 4 * kTableLdsBins; i += kMT) lds[i] = 0;
   __syncthreads();
   uint32_t* hb = hist + (size_t)b * kTableWidth * kTableRows;
   const size_t r0 = (size_t)blockIdx.x * rows_per_block;
   auto range = [&](uint32_t kind, uint32_t v, uint32_t m) {
     const bool ok = m != 0 && v < kTableRows && kind <= 2 && !(kind == 1 && (v & 3)) && !(kind == 2 && (v == 0 || v > kAddrHiMax));
-    const bool hot = kind != 1 && v < kTableLdsBins;
-    wave_hist_add(lds, (kind == 2 ? kTableLdsBins : 0) + v, m, ok && hot);
-    if (ok && !hot) atomicAdd(&hb[(size_t)(kind == 0 ? TB_M_R16 : kind == 1 ? TB_M_AL : TB_M_TOP) * kTableRows + v], m);
+    const bool hot = kind == 1 ? v < 4 * kTableLdsBins : v < kTableLdsBins;
+    wave_hist_add(lds, kind == 1 ? 3 * kTableLdsBins + (v >> 2) : (kind == 2 ? kTableLdsBins : 0) + v, m, ok && hot);
+    wave_hist_add(hb, (uint32_t)((kind == 0 ? TB_M_R16 : kind == 1 ? TB_M_AL : TB_M_TOP) * kTableRows) + v, m, ok && !hot);
   };
   auto bytes = [&](uint32_t v1, uint32_t v2, bool in_range) {
     const bool ok = in_range && v1 <= 255 && v2 <= 255;
     const uint32_t idx = v1 + 256 * v2;
     const bool hot = idx < kTableLdsBins;
     wave_hist_add(lds, 2 * kTableLdsBins + idx, 1u, ok && hot);
-    if (ok && !hot) atomicAdd(&hb[(size_t)TB_M_BY * kTableRows + idx], 1u);
+    wave_hist_add(hb, (uint32_t)(TB_M_BY * kTableRows) + idx, 1u, ok && !hot);
   };
   for (size_t rr = threadIdx.x; rr < (size_t)rows_per_block; rr += kMT) {  // (converged lanes, as in table_count_kernel)
     const size_t r = r0 + rr;
@@ -892,6 +932,7 @@ __global__ __launch_bounds__(kMT) void cpu_table_count_kernel(const uint32_t* __
     if (lds[i]) atomicAdd(&hb[(size_t)TB_M_R16 * kTableRows + i], lds[i]);
     if (lds[kTableLdsBins + i]) atomicAdd(&hb[(size_t)TB_M_TOP * kTableRows + i], lds[kTableLdsBins + i]);
     if (lds[2 * kTableLdsBins + i]) atomicAdd(&hb[(size_t)TB_M_BY * kTableRows + i], lds[2 * kTableLdsBins + i]);
+    if (lds[3 * kTableLdsBins + i]) atomicAdd(&hb[(size_t)TB_M_AL * kTableRows + 4 * i], lds[3 * kTableLdsBins + i]);
   }
 }
 // rows a workgroup counts before it adds its LDS histograms to the table's: 4 096, or 512 where a small batch would
@@ -1131,6 +1172,54 @@ __global__ __launch_bounds__(kMT) void perm_terms_kernel(PermArgs a) {
   m_store_fp4(a.rowsum + ((size_t)b * h + r) * 4, tot);
 }
 
+// The same over (row, group of slots): 32 rows x 8 groups per workgroup, group g takes the slots g, g + 8, ...; the row
+// sum is added up through LDS (exact additions, the order does not matter).  For a chip of many interactions and few rows
+// in a small batch - the keccak chip's 25 slots over 2 048 rows ran 450 us on eight workgroups.
+__global__ __launch_bounds__(kMT) void perm_terms_split_kernel(PermArgs a) {
+  constexpr int kRows = 32, kGroups = kMT / kRows;
+  __shared__ uint32_t part[kGroups][kRows][4];
+  const size_t h = (size_t)1 << a.logh;
+  const int lr = threadIdx.x % kRows, g = threadIdx.x / kRows;
+  const size_t r = (size_t)blockIdx.x * kRows + lr;
+  const bool in_range = r < h;
+  const size_t rr = in_range ? r : 0;
+  const int b = blockIdx.y;
+  RowView rv{a.prep.width ? a.prep.p + (size_t)b * a.prep.bstride + rr : nullptr, a.main_.p + (size_t)b * a.main_.bstride + rr,
+             a.prep.width, h};
+  const Fp4 gamma = m_load_fp4(a.bus_ch + (size_t)b * 8);
+  const uint32_t* bpow = a.bpow + (size_t)b * (kInterMaxElems + 1) * 4;
+  const int ns = (a.n_inter + 1) / 2;
+  uint32_t* p = a.perm + (size_t)b * a.perm_bstride + rr;
+  Fp4 tot = Fp4::zero();
+  for (int j = g; j < ns && in_range; j += kGroups) {
+    Fp4 hj = Fp4::zero();
+    for (int k = 2 * j; k < 2 * j + 2 && k < a.n_inter; ++k) {
+      const Interaction& it = a.inter[k];
+      Fp m = m_lf_eval(it.mult, rv);
+      if (m.v == 0) continue;
+      if (it.sign < 0) m = -m;
+      hj += m_fingerprint(it, rv, gamma, bpow).inv() * m;
+    }
+    if (j < ns - 1) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) p[(size_t)(4 * j + t) * h] = hj.c[t].v;
+    }
+    tot += hj;
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) part[g][lr][t] = tot.c[t].v;
+  __syncthreads();
+  if (g == 0 && in_range) {
+    for (int o = 1; o < kGroups; ++o) {
+      Fp4 v;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v.c[t] = Fp::raw(part[o][lr][t]);
+      tot += v;
+    }
+    m_store_fp4(a.rowsum + ((size_t)b * h + r) * 4, tot);
+  }
+}
+
 // one workgroup per proof: total of the row sums -> cum; phi_0 = 0, phi_{r+1} = phi_r + rowsum_r - cum / H
 __global__ __launch_bounds__(kMT) void perm_scan_kernel(PermArgs a) {
   __shared__ Fp4 part[kMT];
@@ -1266,7 +1355,9 @@ void launch_perm_trace(hipStream_t stream, const PermArgs& a) {
     hipLaunchKernelGGL(perm_terms_cpu_kernel<0>, grid, dim3(kMT), 0, stream, a);
     hipLaunchKernelGGL(perm_terms_cpu_kernel<1>, grid, dim3(kMT), 0, stream, a);
     static_assert(kCpuBusGroups == 2, "one launch per group of slots");
-  } else
+  } else if (a.n_inter >= 16 && h * (size_t)a.batch <= 32768)
+    hipLaunchKernelGGL(perm_terms_split_kernel, dim3((unsigned)((h + 31) / 32), a.batch), dim3(kMT), 0, stream, a);
+  else
     hipLaunchKernelGGL(perm_terms_kernel, dim3((unsigned)((h + kMT - 1) / kMT), a.batch), dim3(kMT), 0, stream, a);
   if (h >= (size_t)4 * kScanSlice && a.slice_sums) {
     const int nslices = (int)(h / kScanSlice);
@@ -1672,13 +1763,15 @@ __global__ __launch_bounds__(kMT) void mreduce_bsum_kernel(MReduceArgs a, int n1
 
 __device__ __forceinline__ int64_t m_lazy_shrink(int64_t t) { return (int64_t)fps_fold(t) * (int64_t)kRModP; }
 
-// lane = four consecutive LDE points; blockIdx.y = a chunk of kMReduceChunk columns of [prep | main | perm | quot]
-__global__ __launch_bounds__(kMT) void mreduce_partial_kernel(MReduceArgs a, int nchunks, int n1) {
+// lane = four consecutive LDE points; blockIdx.y = a chunk of `chunk_cols` columns of [prep | main | perm | quot]
+// (kMReduceChunk of them; a batch below eight takes chunks up to eight times shorter - the scratch is sized for eight
+// proofs - so that a single proof's 92-column CPU instance is 768 workgroups instead of 128)
+__global__ __launch_bounds__(kMT) void mreduce_partial_kernel(MReduceArgs a, int nchunks, int n1, int chunk_cols) {
   const size_t h = (size_t)1 << a.logh, n = 2 * h;
   const size_t pt = ((size_t)blockIdx.x * kMT + threadIdx.x) * 4;
   if (pt >= n) return;
   const int chunk = blockIdx.y, b = blockIdx.z;
-  const int i0 = chunk * kMReduceChunk, i1 = min(n1, i0 + kMReduceChunk);
+  const int i0 = chunk * chunk_cols, i1 = min(n1, i0 + chunk_cols);
   const int w0 = a.mats[0].width, w01 = w0 + a.mats[1].width, w012 = w01 + a.mats[2].width;
   const uint32_t* ap = a.af_pows + (size_t)b * a.af_bstride + a.pow_off * 4;
   int64_t acc1[4][4], acc2[4][4];
@@ -1783,11 +1876,143 @@ void launch_machine_reduce(hipStream_t stream, const MReduceArgs& a) {
   const size_t n = (size_t)2 << a.logh;
   const int n1 = a.mats[0].width + a.mats[1].width + a.mats[2].width + a.mats[3].width;
   const int n2 = a.mats[1].width + a.mats[2].width;
-  const int nchunks = mreduce_nchunks(n1);
+  // (chunk lengths are multiples of 8: the kernel brings its sums back to range every eight columns of a chunk)
+  const int split = a.batch >= 8 ? 1 : 8 / a.batch;
+  // (at most sixteen chunks: the final kernel adds a point's partial sums one after the other)
+  const int chunk_cols = std::min(kMReduceChunk, std::max({16, kMReduceChunk / split, (n1 / 16 + 7) & ~7}));
+  const int nchunks = (n1 + chunk_cols - 1) / chunk_cols;
   hipLaunchKernelGGL(mreduce_bsum_kernel, dim3(a.batch), dim3(kMT), 0, stream, a, n1, n2);
   hipLaunchKernelGGL(mreduce_partial_kernel, dim3((unsigned)((n / 4 + kMT - 1) / kMT), nchunks, a.batch), dim3(kMT), 0, stream, a,
-                     nchunks, n1);
+                     nchunks, n1, chunk_cols);
   hipLaunchKernelGGL(mreduce_final_kernel, dim3((unsigned)((n / 4 + kMT - 1) / kMT), a.batch), dim3(kMT), 0, stream, a, nchunks);
+}
+
+// ---- the same for a small batch, height by height (MReduceMulti, kernels_machine.h) ----
+__global__ __launch_bounds__(kMT) void mreduce_multi_bsum_kernel(MReduceMulti a) {
+  __shared__ Fp4 red[kMT / 64];
+  const MRHeight& hh = a.heights[blockIdx.x];
+  const int b = blockIdx.y;
+  const uint32_t* ap = a.af_pows + (size_t)b * a.af_bstride;
+  const uint32_t* op = a.opened + (size_t)b * a.opened_bstride;
+  Fp4 s1 = Fp4::zero(), s2 = Fp4::zero();
+  for (int c = 0; c < hh.nchips; ++c) {
+    const MRChip ch = a.chips[hh.chip0 + c];
+    for (int i = threadIdx.x; i < ch.n1; i += kMT) s1 += m_load_fp4(ap + (size_t)(ch.open_off + i) * 4) * m_load_fp4(op + (size_t)(ch.open_off + i) * 4);
+    for (int i = threadIdx.x; i < ch.n2; i += kMT)
+      s2 += m_load_fp4(ap + (size_t)(ch.open_off + ch.n1 + i) * 4) * m_load_fp4(op + (size_t)(ch.open_off + ch.n1 + i) * 4);
+  }
+  const Fp4 r1 = m_block_sum(s1, red), r2 = m_block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    m_store_fp4(a.bsum + (((size_t)b * a.n_heights + blockIdx.x) * 2 + 0) * 4, r1);
+    m_store_fp4(a.bsum + (((size_t)b * a.n_heights + blockIdx.x) * 2 + 1) * 4, r2);
+  }
+}
+// A workgroup takes kMReduceMultiPoints LDE points of one height of one proof; lane (quad of points, part) adds the
+// columns 4 part .. 4 part + 3, then sixteen further on, ... of every matrix of the height - four columns' loads in flight
+// per trip, both factors centred, the signed 64-bit sums brought back to range every eight terms - the four parts are added
+// through LDS and part 0 divides by the points' denominators (eight of them with one inversion).
+__global__ __launch_bounds__(kMT) void mreduce_multi_kernel(MReduceMulti a) {
+  constexpr int kQuads = kMReduceMultiPoints / 4, kParts = kMT / kQuads;
+  static_assert(kParts == 4 && kQuads == 64, "64 quads of points x 4 parts");
+  __shared__ uint32_t part_sum[kParts - 1][2][4][4][kQuads];  // [part][point of zeta / zeta w][point of the quad][limb][quad]
+  int t = 0;
+  while (t + 1 < a.n_heights && (int)blockIdx.x >= a.heights[t + 1].blk0) ++t;
+  const MRHeight& hh = a.heights[t];
+  const size_t h = (size_t)1 << hh.logh, n = 2 * h;
+  const int per_proof = (int)((n + kMReduceMultiPoints - 1) / kMReduceMultiPoints), local = (int)blockIdx.x - hh.blk0;
+  const int b = local / per_proof, lq = threadIdx.x % kQuads, part = threadIdx.x / kQuads;
+  const size_t pt = ((size_t)(local % per_proof) * kQuads + lq) * 4;
+  const bool in_range = pt < n;  // (n is a multiple of four)
+  const size_t ptc = in_range ? pt : 0;
+  const uint32_t* ap = a.af_pows + (size_t)b * a.af_bstride;
+  int64_t acc1[4][4], acc2[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc1[q][j] = acc2[q][j] = 0;
+  int pending = 0;
+  for (int sgi = 0; sgi < hh.nseg; ++sgi) {
+    const MRSeg sg = a.segs[hh.seg0 + sgi];
+    const uint32_t* col = sg.p + (size_t)b * sg.bstride + ptc;
+    const bool two = sg.pow2 >= 0;
+    for (int j0 = 4 * part; j0 < sg.width; j0 += 4 * kParts) {
+      uint4 v[4], p1[4], p2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = min(j0 + u, sg.width - 1);
+        v[u] = *reinterpret_cast<const uint4*>(col + (size_t)j * n);
+        if (j0 + u >= sg.width) v[u] = make_uint4(0u, 0u, 0u, 0u);
+        p1[u] = *reinterpret_cast<const uint4*>(ap + (size_t)(sg.pow1 + j) * 4);
+        p2[u] = two ? *reinterpret_cast<const uint4*>(ap + (size_t)(sg.pow2 + j) * 4) : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int32_t w[4] = {fps_centre(v[u].x), fps_centre(v[u].y), fps_centre(v[u].z), fps_centre(v[u].w)};
+        const int32_t al[4] = {fps_centre(p1[u].x), fps_centre(p1[u].y), fps_centre(p1[u].z), fps_centre(p1[u].w)};
+        const int32_t al2[4] = {two ? fps_centre(p2[u].x) : 0, two ? fps_centre(p2[u].y) : 0, two ? fps_centre(p2[u].z) : 0,
+                                two ? fps_centre(p2[u].w) : 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc1[q][j] += (int64_t)al[j] * (int64_t)w[q];
+            acc2[q][j] += (int64_t)al2[j] * (int64_t)w[q];
+          }
+      }
+      pending += 4;
+      if (pending >= 8) {  // |alpha|, |w| <= (p - 1) / 2: eight products and a shrunk sum (< 2^58.2) stay below 2^63
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { acc1[q][j] = m_lazy_shrink(acc1[q][j]); acc2[q][j] = m_lazy_shrink(acc2[q][j]); }
+        pending = 0;
+      }
+    }
+  }
+  if (part) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        part_sum[part - 1][0][q][j][lq] = fps_canon(fps_fold(acc1[q][j]));
+        part_sum[part - 1][1][q][j][lq] = fps_canon(fps_fold(acc2[q][j]));
+      }
+  }
+  __syncthreads();
+  if (part != 0 || !in_range) return;
+  const Fp4 b1 = m_load_fp4(a.bsum + (((size_t)b * a.n_heights + t) * 2 + 0) * 4), b2 = m_load_fp4(a.bsum + (((size_t)b * a.n_heights + t) * 2 + 1) * 4);
+  const Fp4 zeta = m_load_fp4(a.zeta + (size_t)b * 4), zn = zeta * Fp::raw(hh.w_h);
+  const int c = pt >= h ? 1 : 0;  // (h is a multiple of four: the four points lie on one coset)
+  const size_t half = h >> 1;
+  const Fp sh = Fp::raw(c ? hh.shift[1] : hh.shift[0]);
+  Fp4 d[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const size_t m = pt + i - (size_t)c * h;
+    const Fp wm = m < half ? Fp::raw(hh.tw_fwd[m]) : -Fp::raw(hh.tw_fwd[m - half]);
+    const Fp4 x = Fp4::from_base(sh * wm);
+    d[2 * i] = x - zeta;
+    d[2 * i + 1] = x - zn;
+  }
+  batch_inverse<8>(d);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    Fp4 s1, s2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s1.c[j] = Fp::raw(fps_canon(fps_fold(acc1[q][j]))); s2.c[j] = Fp::raw(fps_canon(fps_fold(acc2[q][j]))); }
+    for (int o = 0; o < kParts - 1; ++o) {
+      Fp4 u1, u2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { u1.c[j] = Fp::raw(part_sum[o][0][q][j][lq]); u2.c[j] = Fp::raw(part_sum[o][1][q][j][lq]); }
+      s1 += u1;
+      s2 += u2;
+    }
+    m_store_fp4(hh.out + (size_t)b * hh.out_bstride + (pt + q) * 4, (s1 - b1) * d[2 * q] + (s2 - b2) * d[2 * q + 1]);
+  }
+}
+void launch_machine_reduce_multi(hipStream_t stream, const MReduceMulti& a) {
+  hipLaunchKernelGGL(mreduce_multi_bsum_kernel, dim3(a.n_heights, a.batch), dim3(kMT), 0, stream, a);
+  hipLaunchKernelGGL(mreduce_multi_kernel, dim3(a.total_blocks), dim3(kMT), 0, stream, a);
 }
 
 __global__ __launch_bounds__(kMT) void fri_add_kernel(uint32_t* __restrict__ layer, size_t layer_bstride,

@@ -422,13 +422,12 @@ __device__ __forceinline__ int64_t lazy_shrink(int64_t t) { return (int64_t)fps_
 // so |term| < p^2 / 4 and eight terms fit a signed 64-bit accumulator between shrinks.
 constexpr int kOpenCols = 4;
 
-__global__ __launch_bounds__(kThreads) void open_kernel(const uint32_t* __restrict__ coefs, size_t coefs_stride,
-                                                       int ncols, int logh, const uint32_t* __restrict__ zpow,
-                                                       size_t zpow_stride, int npoints, uint32_t* __restrict__ opened,
-                                                       size_t opened_stride, size_t pt_stride) {
+__device__ __forceinline__ void open_body(const uint32_t* __restrict__ coefs, size_t coefs_stride, int ncols, int logh,
+                                          const uint32_t* __restrict__ zpow, size_t zpow_stride, int npoints,
+                                          uint32_t* __restrict__ opened, size_t opened_stride, size_t pt_stride, int bx, int b) {
   __shared__ Fp4 red[kThreads / 64];
   const int h = 1 << logh;
-  const int col0 = blockIdx.x * kOpenCols, b = blockIdx.y;
+  const int col0 = bx * kOpenCols;
   const int nc = min(kOpenCols, ncols - col0);
   const uint32_t* cf = coefs + (size_t)b * coefs_stride + (size_t)col0 * h;
   const uint32_t* z0 = zpow + (size_t)b * zpow_stride;
@@ -482,6 +481,13 @@ __global__ __launch_bounds__(kThreads) void open_kernel(const uint32_t* __restri
         store_fp4(opened + (size_t)b * opened_stride + ((size_t)q * pt_stride + (size_t)(col0 + c)) * 4, sum);
     }
   }
+}
+
+__global__ __launch_bounds__(kThreads) void open_kernel(const uint32_t* __restrict__ coefs, size_t coefs_stride,
+                                                       int ncols, int logh, const uint32_t* __restrict__ zpow,
+                                                       size_t zpow_stride, int npoints, uint32_t* __restrict__ opened,
+                                                       size_t opened_stride, size_t pt_stride) {
+  open_body(coefs, coefs_stride, ncols, logh, zpow, zpow_stride, npoints, opened, opened_stride, pt_stride, blockIdx.x, blockIdx.y);
 }
 
 // Wide matrices (the 2633-column trace): lane = column.  A workgroup stages a
@@ -570,16 +576,15 @@ __global__ __launch_bounds__(kThreads) void open_wide_kernel(const uint32_t* __r
 // workgroups.  Every workgroup covers 256 columns x `klen` coefficients and leaves one partial
 // extension-field sum per column and point; open_combine_kernel adds the partials (exact field
 // additions, so the split does not change the result).
-__global__ __launch_bounds__(kThreads) void open_tall_kernel(const uint32_t* __restrict__ coefs, size_t coefs_stride,
-                                                            int ncols, int logh, const uint32_t* __restrict__ zpow,
-                                                            size_t zpow_stride, int npoints, int klen,
-                                                            uint32_t* __restrict__ partial, int nsplit) {
+__device__ __forceinline__ void open_tall_body(const uint32_t* __restrict__ coefs, size_t coefs_stride, int ncols, int logh,
+                                               const uint32_t* __restrict__ zpow, size_t zpow_stride, int npoints, int klen,
+                                               uint32_t* __restrict__ partial, int nsplit, int bx, int split, int b) {
   __shared__ uint32_t tile[kOpenTileCols * kOpenPitch];
   // the powers of zeta of the current 32 coefficients: a 16 MB table per proof no longer lives in the
   // scalar cache, so a tile's 64 values are fetched by 64 lanes (coalesced) and broadcast from LDS
   __shared__ int4 ztile[2][kOpenTileK];
   const int h = 1 << logh;
-  const int col0 = blockIdx.x * kOpenTileCols, split = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int col0 = bx * kOpenTileCols, tid = threadIdx.x;
   const int kbeg = split * klen, kend = kbeg + klen;
   const uint32_t* cf = coefs + (size_t)b * coefs_stride + (size_t)col0 * h;
   const int4* z0 = reinterpret_cast<const int4*>(zpow + (size_t)b * zpow_stride);
@@ -647,16 +652,36 @@ __global__ __launch_bounds__(kThreads) void open_tall_kernel(const uint32_t* __r
     }
   }
 }
+__global__ __launch_bounds__(kThreads) void open_tall_kernel(const uint32_t* __restrict__ coefs, size_t coefs_stride,
+                                                            int ncols, int logh, const uint32_t* __restrict__ zpow,
+                                                            size_t zpow_stride, int npoints, int klen,
+                                                            uint32_t* __restrict__ partial, int nsplit) {
+  open_tall_body(coefs, coefs_stride, ncols, logh, zpow, zpow_stride, npoints, klen, partial, nsplit, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+// Sixteen lanes per (column, point): each adds every sixteenth partial, then the lanes are added (exact field additions, in
+// any order).  One lane per column walking up to 128 partials one dependent load after the other took 60-70 us of a single
+// proof's opening stage, fifty times over.
+__device__ __forceinline__ void open_combine_body(const uint32_t* __restrict__ partial, int ncols, int npoints, int nsplit,
+                                                  uint32_t* __restrict__ opened, size_t opened_stride, size_t pt_stride, int bx, int b) {
+  const int l = threadIdx.x & 15, item = bx * (kThreads / 16) + (threadIdx.x >> 4);
+  const bool ok = item < ncols * npoints;
+  const int q = ok ? item / ncols : 0, col = ok ? item % ncols : 0;
+  Fp4 s = Fp4::zero();
+  if (ok)
+    for (int sp = l; sp < nsplit; sp += 16) s += load_fp4(partial + ((((size_t)b * 2 + q) * nsplit + sp) * ncols + col) * 4);
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) {
+    Fp4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.c[j] = Fp::raw((uint32_t)__shfl_xor((int)s.c[j].v, off, 64));
+    s += o;
+  }
+  if (ok && l == 0) store_fp4(opened + (size_t)b * opened_stride + ((size_t)q * pt_stride + (size_t)col) * 4, s);
+}
 __global__ __launch_bounds__(kThreads) void open_combine_kernel(const uint32_t* __restrict__ partial, int ncols, int npoints,
                                                                int nsplit, uint32_t* __restrict__ opened,
                                                                size_t opened_stride, size_t pt_stride) {
-  const int col = blockIdx.x * kThreads + threadIdx.x, b = blockIdx.y;
-  if (col >= ncols) return;
-  for (int q = 0; q < npoints; ++q) {
-    Fp4 s = Fp4::zero();
-    for (int sp = 0; sp < nsplit; ++sp) s += load_fp4(partial + ((((size_t)b * 2 + q) * nsplit + sp) * ncols + col) * 4);
-    store_fp4(opened + (size_t)b * opened_stride + ((size_t)q * pt_stride + (size_t)col) * 4, s);
-  }
+  open_combine_body(partial, ncols, npoints, nsplit, opened, opened_stride, pt_stride, blockIdx.x, blockIdx.y);
 }
 // Narrow tall matrices, tiled: a workgroup covers CW columns (the whole matrix when it has at most 64) x `klen`
 // evaluations, so the two weight tables are read once per matrix instead of once per four columns (a lane-per-evaluation
@@ -665,17 +690,16 @@ __global__ __launch_bounds__(kThreads) void open_combine_kernel(const uint32_t* 
 // evaluations phase, phase + 256 / CW, ... of the tile with the weights broadcast from LDS; the phases of a column are
 // added at the end.  Partial sums in open_tall_kernel's layout.
 template <int CW>
-__global__ __launch_bounds__(kThreads) void open_narrow_kernel(const uint32_t* __restrict__ coefs, size_t coefs_stride,
-                                                              int ncols, int logh, const uint32_t* __restrict__ zpow,
-                                                              size_t zpow_stride, int npoints, int klen,
-                                                              uint32_t* __restrict__ partial, int nsplit) {
+__device__ __forceinline__ void open_narrow_body(const uint32_t* __restrict__ coefs, size_t coefs_stride, int ncols, int logh,
+                                                 const uint32_t* __restrict__ zpow, size_t zpow_stride, int npoints, int klen,
+                                                 uint32_t* __restrict__ partial, int nsplit, int bx, int split, int b) {
   constexpr int TK = 2048 / CW, kPitch = TK + 1, kPhases = kThreads / CW, kQuads = TK / 4;
   static_assert(kThreads == 256 && CW >= 8 && CW <= 64, "tile geometry");
   __shared__ uint32_t tile[CW * kPitch];
   __shared__ int4 ztile[2][TK];
   __shared__ uint32_t red[2][kThreads][4];
   const int h = 1 << logh;
-  const int col0 = blockIdx.x * CW, split = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int col0 = bx * CW, tid = threadIdx.x;
   const int kbeg = split * klen, kend = kbeg + klen;
   const uint32_t* cf = coefs + (size_t)b * coefs_stride + (size_t)col0 * h;
   const int4* z0 = reinterpret_cast<const int4*>(zpow + (size_t)b * zpow_stride);
@@ -757,6 +781,48 @@ __global__ __launch_bounds__(kThreads) void open_narrow_kernel(const uint32_t* _
   }
 }
 
+template <int CW>
+__global__ __launch_bounds__(kThreads) void open_narrow_kernel(const uint32_t* __restrict__ coefs, size_t coefs_stride,
+                                                              int ncols, int logh, const uint32_t* __restrict__ zpow,
+                                                              size_t zpow_stride, int npoints, int klen,
+                                                              uint32_t* __restrict__ partial, int nsplit) {
+  open_narrow_body<CW>(coefs, coefs_stride, ncols, logh, zpow, zpow_stride, npoints, klen, partial, nsplit, blockIdx.x, blockIdx.y,
+                       blockIdx.z);
+}
+
+// ---- a single proof's opening stage: ONE launch per kind of kernel over a table of tasks (OpenTask, kernels.h) instead of
+// two launches per matrix - 140 launches of 5-20 us of work each were 1.2 ms of a 10 ms proof.  A workgroup finds its task
+// from its index (the tasks' first workgroups are a prefix sum, in launch order); what it computes is the single-task
+// kernel's body, so the sums are the same words. ----
+__device__ __forceinline__ const OpenTask& open_task_of(const OpenTask* __restrict__ tasks, int n, int blk, int OpenTask::*first) {
+  int t = 0;
+  while (t + 1 < n && blk >= tasks[t + 1].*first) ++t;
+  return tasks[t];
+}
+__global__ __launch_bounds__(kThreads) void open_multi_short_kernel(const OpenTask* __restrict__ tasks, int n, size_t opened_stride) {
+  const OpenTask& t = open_task_of(tasks, n, blockIdx.x, &OpenTask::blk0);
+  const int local = blockIdx.x - t.blk0, groups = (t.ncols + kOpenCols - 1) / kOpenCols;
+  open_body(t.evals, t.cstride, t.ncols, t.logh, t.table, t.zstride, t.npts, t.dst, opened_stride, t.pts, local % groups, local / groups);
+}
+template <int CW>
+__global__ __launch_bounds__(kThreads) void open_multi_narrow_kernel(const OpenTask* __restrict__ tasks, int n) {
+  const OpenTask& t = open_task_of(tasks, n, blockIdx.x, &OpenTask::blk0);
+  const int local = blockIdx.x - t.blk0;
+  open_narrow_body<CW>(t.evals, t.cstride, t.ncols, t.logh, t.table, t.zstride, t.npts, t.klen, t.partial, t.nsplit, 0,
+                       local % t.nsplit, local / t.nsplit);
+}
+__global__ __launch_bounds__(kThreads) void open_multi_tall_kernel(const OpenTask* __restrict__ tasks, int n) {
+  const OpenTask& t = open_task_of(tasks, n, blockIdx.x, &OpenTask::blk0);
+  const int local = blockIdx.x - t.blk0, tiles = (t.ncols + kOpenTileCols - 1) / kOpenTileCols;
+  open_tall_body(t.evals, t.cstride, t.ncols, t.logh, t.table, t.zstride, t.npts, t.klen, t.partial, t.nsplit, local % tiles,
+                 (local / tiles) % t.nsplit, local / (tiles * t.nsplit));
+}
+__global__ __launch_bounds__(kThreads) void open_multi_combine_kernel(const OpenTask* __restrict__ tasks, int n, size_t opened_stride) {
+  const OpenTask& t = open_task_of(tasks, n, blockIdx.x, &OpenTask::cblk0);
+  const int local = blockIdx.x - t.cblk0, groups = (t.ncols * t.npts + kThreads / 16 - 1) / (kThreads / 16);
+  open_combine_body(t.partial, t.ncols, t.npts, t.nsplit, t.dst, opened_stride, t.pts, local % groups, local / groups);
+}
+
 // A batch of fewer than eight proofs splits finer (a single proof would otherwise run four workgroups of 4 096 evaluations
 // each): up to eight times as many splits, so that batch x splits never exceeds what eight proofs take - which is what the
 // scratch is sized for (open_tall_scratch_words) - and no split shorter than 256 evaluations (the narrow kernel's tile).
@@ -788,8 +854,48 @@ void launch_open_tall(hipStream_t stream, const uint32_t* coefs_br, size_t coefs
     else ZKSP_OPEN_NARROW(8);
 #undef ZKSP_OPEN_NARROW
   }
-  hipLaunchKernelGGL(open_combine_kernel, dim3((ncols + kThreads - 1) / kThreads, batch), dim3(kThreads), 0, stream, scratch,
-                     ncols, npoints, nsplit, opened, opened_stride, pt_stride);
+  hipLaunchKernelGGL(open_combine_kernel, dim3((ncols * npoints + kThreads / 16 - 1) / (kThreads / 16), batch), dim3(kThreads), 0,
+                     stream, scratch, ncols, npoints, nsplit, opened, opened_stride, pt_stride);
+}
+
+// Fills in a task's kind, split, partial-sum need and workgroup counts exactly as launch_open / launch_open_tall choose them.
+// Returns the words of partial sums the task needs (0 for the short kind).
+size_t open_task_plan(OpenTask* t, int batch) {
+  const int h = 1 << t->logh;
+  if (t->logh < 12) {
+    t->kind = 0;
+    t->nsplit = 1;
+    t->klen = h;
+    t->blocks = ((t->ncols + kOpenCols - 1) / kOpenCols) * batch;
+    t->cblocks = 0;
+    return 0;
+  }
+  t->nsplit = open_nsplit(t->ncols, t->logh, batch);
+  t->klen = h / t->nsplit;
+  if (t->ncols >= 64) {
+    t->kind = 5;
+    t->blocks = ((t->ncols + kOpenTileCols - 1) / kOpenTileCols) * t->nsplit * batch;
+  } else {
+    t->kind = t->ncols > 32 ? 4 : t->ncols > 16 ? 3 : t->ncols > 8 ? 2 : 1;
+    t->blocks = t->nsplit * batch;
+  }
+  t->cblocks = ((t->ncols * t->npts + kThreads / 16 - 1) / (kThreads / 16)) * batch;
+  return (size_t)batch * 2 * t->nsplit * t->ncols * 4;
+}
+// tasks: device array sorted by kind (0, 1..4, 5), `first[k]` / `count[k]` the tasks of kind k, blk0 counted per kind,
+// cblk0 over the kinds 1..5 together
+void launch_open_multi(hipStream_t stream, const OpenTask* tasks, const int first[6], const int count[6], const int blocks[6],
+                       int combine_blocks, size_t opened_stride) {
+  if (count[0])
+    hipLaunchKernelGGL(open_multi_short_kernel, dim3(blocks[0]), dim3(kThreads), 0, stream, tasks + first[0], count[0], opened_stride);
+  if (count[1]) hipLaunchKernelGGL(open_multi_narrow_kernel<8>, dim3(blocks[1]), dim3(kThreads), 0, stream, tasks + first[1], count[1]);
+  if (count[2]) hipLaunchKernelGGL(open_multi_narrow_kernel<16>, dim3(blocks[2]), dim3(kThreads), 0, stream, tasks + first[2], count[2]);
+  if (count[3]) hipLaunchKernelGGL(open_multi_narrow_kernel<32>, dim3(blocks[3]), dim3(kThreads), 0, stream, tasks + first[3], count[3]);
+  if (count[4]) hipLaunchKernelGGL(open_multi_narrow_kernel<64>, dim3(blocks[4]), dim3(kThreads), 0, stream, tasks + first[4], count[4]);
+  if (count[5]) hipLaunchKernelGGL(open_multi_tall_kernel, dim3(blocks[5]), dim3(kThreads), 0, stream, tasks + first[5], count[5]);
+  const int nc = count[1] + count[2] + count[3] + count[4] + count[5];
+  if (nc)
+    hipLaunchKernelGGL(open_multi_combine_kernel, dim3(combine_blocks), dim3(kThreads), 0, stream, tasks + first[1], nc, opened_stride);
 }
 
 void launch_open(hipStream_t stream, const uint32_t* coefs_br, size_t coefs_stride, int ncols, int logh,

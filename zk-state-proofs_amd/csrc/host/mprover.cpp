@@ -6,6 +6,7 @@
 #include "mprover.hpp"
 
 #include <algorithm>
+#include <functional>
 #include <cstring>
 #include <type_traits>
 
@@ -53,10 +54,12 @@ struct StageFork {
   Context* ctx;
   int lanes;
   int lane_of_height[32];
+  int lane_of_height_q[32];     // the quotient stage's own balance: its kernels cost by constraints, not by cells
   int lane_of_chip[kNumChips];  // for the stages whose chips share nothing: balanced by cells (longest first)
   bool ok = true;
   StageFork(Context* c, int n_lanes, const int* logh) : ctx(c), lanes(n_lanes) {
     for (int& v : lane_of_height) v = 0;
+    for (int& v : lane_of_height_q) v = 0;
     for (int& v : lane_of_chip) v = 0;
     if (lanes <= 1) { lanes = 1; return; }
     for (int i = 0; i < Context::kSideStreams && ok; ++i) {
@@ -69,7 +72,9 @@ struct StageFork {
     size_t load_h[8] = {0}, load_c[8] = {0}, cells_h[32] = {0}, cells_c[kNumChips];
     for (int ch = 0; ch < kNumChips; ++ch) {
       const ChipDef& d = chip_def(ch);
-      cells_c[ch] = (size_t)(d.main_w + d.perm_width() + 8) << logh[ch];
+      // (a chip costs its launches too: at a single proof's rate a launch is worth a quarter of a million cells, and the
+      // seven chips of the minimum height are seven dependent launches per stage whatever their 32 rows hold)
+      cells_c[ch] = ((size_t)(d.main_w + d.perm_width() + 8) << logh[ch]) + ((size_t)1 << 18);
       cells_h[logh[ch]] += cells_c[ch];
     }
     auto lightest = [&](const size_t* load) {
@@ -96,6 +101,28 @@ struct StageFork {
       lane_of_height[h] = l;
       load_h[l] += cells_h[h];
     }
+    {
+      // Quotients: a chip of few rows is one workgroup evaluating all its constraints point by point (the Poseidon2 chip's
+      // 353 take 210 us over 64 points), a tall one streams its cells; the chips of a height share their quotient and so a
+      // lane.  Microseconds of a single proof, measured: 45 + constraints / 2, or cells / 80 000; the keccak chip 335.
+      size_t cost_h[32] = {0}, load_q[8] = {0};
+      bool done_q[32] = {false};
+      for (int ch = 0; ch < kNumChips; ++ch) {
+        const ChipDef& d = chip_def(ch);
+        const size_t cells = (size_t)(d.prep_w + d.main_w + d.perm_width()) << logh[ch];
+        cost_h[logh[ch]] += ch == kKeccak ? std::max<size_t>(335, cells / 17000) : std::max<size_t>(45 + d.total_constraints() / 2, cells / 80000);
+      }
+      for (;;) {
+        int h = -1;
+        for (int k = 0; k < 32; ++k)
+          if (cost_h[k] && !done_q[k] && (h < 0 || cost_h[k] > cost_h[h])) h = k;
+        if (h < 0) break;
+        done_q[h] = true;
+        const int l = lightest(load_q);
+        lane_of_height_q[h] = l;
+        load_q[l] += cost_h[h];
+      }
+    }
     for (;;) {
       int ch = -1;
       for (int k = 0; k < kNumChips; ++k)
@@ -109,6 +136,7 @@ struct StageFork {
   }
   hipStream_t lane(int i) const { return i == 0 || lanes == 1 ? ctx->stream : ctx->side[i - 1]; }
   int lane_of(int logh) const { return lanes == 1 ? 0 : lane_of_height[logh]; }
+  int lane_of_q(int logh) const { return lanes == 1 ? 0 : lane_of_height_q[logh]; }
   int lane_of_a_chip(int chip) const { return lanes == 1 ? 0 : lane_of_chip[chip]; }
   void begin() const {
     if (lanes == 1) return;
@@ -131,9 +159,19 @@ struct StageFork {
 // With `joined_lde` the caller has OPENED the fork and put every chip's LDE on the lane of its height: each group's leaves
 // then follow their LDEs on that same lane, with no join in between, and the fork is closed here - so that one lane hashes
 // (bound by vector-ALU issue) while another still transforms (bound by memory and LDS), in large batches too.
+// With `lde` (small batches) the transforms are enqueued HERE, group by group, each group's leaves right behind its own
+// transforms, the groups in the order of their sponge chains: a row of the keccak chip is 330 permutations one after the
+// other (1.2 ms however many rows there are) and used to start after every other transform of its lane.
+// (the chips of a group whose matrices lie side by side in memory - the workspace lays them out so - go in ONE launch)
+struct LdeRound {
+  const uint32_t* tr[kNumChips];
+  uint32_t* lde[kNumChips];
+  size_t cols[kNumChips];  // batch x width; 0: the chip has no matrix in this round
+  std::function<void(int first_chip, size_t cols, hipStream_t lane)> launch;
+};
 int mmcs_commit(hipStream_t s, const RoundMats& rm, uint32_t* tree, size_t tree_bstride, uint32_t* const* inj, int batch,
                 const P2Consts* kc, Context* span_ctx = nullptr, const char* leaf_span = nullptr, const StageFork* fork = nullptr,
-                bool joined_lde = false) {
+                bool joined_lde = false, const LdeRound* lde = nullptr) {
   int lm = 0;
   for (int c = 0; c < kNumChips; ++c)
     if (rm.seg[c][0].width) lm = std::max(lm, rm.logh[c]);
@@ -148,7 +186,52 @@ int mmcs_commit(hipStream_t s, const RoundMats& rm, uint32_t* tree, size_t tree_
   Seg segs[2 * kNumChips];
   int ns = group(logn, segs);
   const bool side_by_side = fork && fork->lanes > 1;
-  if (side_by_side && joined_lde) {
+  bool tallest_done = false;
+  if (side_by_side && joined_lde && lde) {
+    struct Group { int l; size_t blocks; };
+    Group order[32];
+    int n_groups = 0;
+    for (int l = 0; l < logn; ++l) {
+      Seg sg[2 * kNumChips];
+      const int n2 = group(logn - l, sg);
+      size_t wd = 0;
+      for (int i = 0; i < n2; ++i) wd += (size_t)sg[i].width;
+      if (n2) order[n_groups++] = Group{l, (wd + 7) / 8};
+    }
+    std::stable_sort(order, order + n_groups, [](const Group& a, const Group& b) { return a.blocks > b.blocks; });
+    for (int k = 0; k < n_groups; ++k) {
+      const int l = order[k].l, g_logn = logn - l;
+      hipStream_t lane = fork->lane(fork->lane_of(g_logn - 1));
+      {
+        int chips[kNumChips], nch = 0;
+        for (int c = 0; c < kNumChips; ++c)
+          if (rm.seg[c][0].width && rm.logh[c] + 1 == g_logn && lde->cols[c]) chips[nch++] = c;
+        std::sort(chips, chips + nch, [&](int a, int b) { return lde->tr[a] < lde->tr[b]; });
+        const size_t hh = (size_t)1 << (g_logn - 1);
+        for (int i = 0; i < nch;) {
+          size_t cols = lde->cols[chips[i]];
+          int j = i + 1;
+          while (j < nch && lde->tr[chips[j]] == lde->tr[chips[i]] + cols * hh && lde->lde[chips[j]] == lde->lde[chips[i]] + cols * 2 * hh)
+            cols += lde->cols[chips[j++]];
+          lde->launch(chips[i], cols, lane);
+          i = j;
+        }
+      }
+      Seg sg[2 * kNumChips];
+      const int n2 = group(g_logn, sg);
+      if (l == 0) {  // (the tallest height is lane 0, the main stream)
+        if (span_ctx && leaf_span) {
+          ProfileSpan sp(span_ctx, leaf_span);
+          launch_mmcs_leaves(lane, sg, n2, lm, tree, tree_bstride, batch, kc);
+        } else {
+          launch_mmcs_leaves(lane, sg, n2, lm, tree, tree_bstride, batch, kc);
+        }
+        tallest_done = true;
+      } else {
+        launch_mmcs_leaves(lane, sg, n2, g_logn - 1, inj[g_logn], (size_t)8 << g_logn, batch, kc);
+      }
+    }
+  } else if (side_by_side && joined_lde) {
     for (int l = 1; l < logn; ++l) {
       Seg sg[2 * kNumChips];
       const int n2 = group(logn - l, sg);
@@ -186,13 +269,17 @@ int mmcs_commit(hipStream_t s, const RoundMats& rm, uint32_t* tree, size_t tree_
       launch_mmcs_leaves(fork->lane(best), sg, n2, logn - l - 1, inj[logn - l], (size_t)8 << (logn - l), batch, kc);
     }
   }
-  if (span_ctx && leaf_span) {
+  if (tallest_done) {
+  } else if (span_ctx && leaf_span) {
     ProfileSpan sp(span_ctx, leaf_span);  // exactly one launch: the leaf layer of the tallest matrices
     launch_mmcs_leaves(s, segs, ns, lm, tree, tree_bstride, batch, kc);
   } else {
     launch_mmcs_leaves(s, segs, ns, lm, tree, tree_bstride, batch, kc);
   }
   if (side_by_side) fork->end();
+  MmcsTopArgs top;
+  top.n_levels = 0;
+  static_assert(kMmcsTopNodes == 256 && kMmcsTopLevels == 9, "levels of 256, 128, ..., 1 nodes");
   for (int l = 1; l <= logn; ++l) {
     const size_t count = (size_t)1 << (logn - l);
     const uint32_t* injp = nullptr;
@@ -203,9 +290,20 @@ int mmcs_commit(hipStream_t s, const RoundMats& rm, uint32_t* tree, size_t tree_
       if (!side_by_side) launch_mmcs_leaves(s, segs, ns, logn - l - 1, inj[logn - l], inj_bstride, batch, kc);
       injp = inj[logn - l];
     }
+    if (side_by_side && count <= (size_t)kMmcsTopNodes) {  // small batches: the rest of the tree in one launch
+      if (top.n_levels == 0) { top.tree = tree; top.tree_bstride = tree_bstride; }
+      const int k = top.n_levels++;
+      top.count[k] = (int)count;
+      top.in_off[k] = layer_off(logn, l - 1) * 8;
+      top.out_off[k] = layer_off(logn, l) * 8;
+      top.inject[k] = injp;
+      top.inj_bstride[k] = inj_bstride;
+      continue;
+    }
     launch_mmcs_level(s, tree + layer_off(logn, l - 1) * 8, tree_bstride, tree + layer_off(logn, l) * 8, tree_bstride, injp,
                       inj_bstride, count, batch, kc);
   }
+  if (top.n_levels) launch_mmcs_top(s, top, batch, kc);
   return lm;
 }
 
@@ -389,6 +487,26 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
     A(&w->spare.n_perms, B);
     A(&w->spare.init_obs, B * kMachineInitObs);
     A(&w->spare.pub_words, B * kPubWords);
+    // The matrices of a round, the traces and the LDEs each, height by height: the columns of the chips of one height lie
+    // side by side, so that a small batch transforms them in ONE launch (six CPU instances one after the other were a
+    // millisecond of a single proof).  (No coefficient arrays: columns are opened from their evaluations.)
+    {
+      int order[kNumChips];
+      for (int c = 0; c < kNumChips; ++c) order[c] = c;
+      std::stable_sort(order, order + kNumChips, [&](int a, int b) { return logh[a] > logh[b]; });
+      for (int r = 0; r < 3; ++r) {
+        for (int k = 0; k < kNumChips; ++k) {
+          const int c = order[k];
+          const int wd = r == 0 ? chip_def(c).main_w : r == 1 ? chip_def(c).perm_width() : quot_width(logh, c);  // (one quotient per height: its first chip's)
+          w->mat[c][r].w = wd;
+          A(&w->mat[c][r].tr, (B * wd) << logh[c]);
+        }
+        for (int k = 0; k < kNumChips; ++k) {
+          const int c = order[k];
+          A(&w->mat[c][r].lde, (B * w->mat[c][r].w * 2) << logh[c]);
+        }
+      }
+    }
     int lm = 0;
     size_t n_open = 0, max_total = 0, max_h = 0;
     for (int c = 0; c < kNumChips; ++c) {
@@ -396,12 +514,6 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
       const size_t h = (size_t)1 << logh[c];
       lm = std::max(lm, logh[c]);
       max_h = std::max(max_h, h);
-      const int widths[3] = {d.main_w, d.perm_width(), quot_width(logh, c)};  // (one quotient per height: its first chip's)
-      for (int r = 0; r < 3; ++r) {
-        w->mat[c][r].w = widths[r];
-        A(&w->mat[c][r].tr, B * widths[r] * h);
-        A(&w->mat[c][r].lde, B * widths[r] * 2 * h);  // (no coefficient arrays: columns are opened from their evaluations)
-      }
       // barycentric weights: at zeta, at zeta * w_H, and for the two quotient cosets; one set per height
       int first = c;
       for (int c2 = c - 1; c2 >= 0; --c2)
@@ -470,6 +582,21 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
       for (int i = 0; i + 1 < w->n_streams; ++i) A(&w->side_reduce_scratch[i], (size_t)Context::kSideMaxBatch * need);
     }
     A(&w->kpartial, B * 13 * (((size_t)2 << logh[kKeccak]) * 4));
+    {
+      // the task table of a small batch's opening stage and the partial sums of all its tall matrices at once
+      size_t words = 0;
+      for (int c = 0; c < kNumChips; ++c)
+        if (logh[c] >= 12)
+          for (int wdt : {chip_def(c).prep_w, chip_def(c).main_w, chip_def(c).perm_width(), quot_width(logh, c) ? 4 : 0, quot_width(logh, c) ? 4 : 0})
+            if (wdt) words += open_tall_scratch_words(wdt, logh[c], 8);
+      A(&w->open_partial, words);
+      A(&w->open_tasks, (size_t)5 * kNumChips);
+      A(&w->mr_heights, (size_t)32);
+      A(&w->mr_segs, (size_t)4 * kNumChips);
+      A(&w->mr_chips, (size_t)kNumChips);
+      A(&w->mr_bsum, std::min<size_t>(B, Context::kSideMaxBatch) * 32 * 2 * 4);
+      w->open_tasks_batch = -1;
+    }
     w->fri_layer_stride = 0;
     w->fri_tree_stride = 0;
     for (int k = 0; k < lm; ++k) {
@@ -772,12 +899,36 @@ int machine_prove_resident(Context* ctx) {
   static const bool overlap = getenv("ZKSP_OVERLAP") != nullptr;
   const StageFork fork2(ctx, B <= Context::kSideMaxBatch ? w->n_streams : (overlap ? 2 : 1), logh);
   auto HL = [&](int c) { return fork2.lane(fork2.lane_of(logh[c])); };
+  // small batches: every group's transforms and leaves together, longest sponge first (mmcs_commit, `lde`)
+  const bool grouped = fork2.lanes > 1;
+  LdeRound lde_main, lde_perm, lde_quot;
+  for (int c = 0; c < kNumChips; ++c) {
+    LdeRound* rd[3] = {&lde_main, &lde_perm, &lde_quot};
+    for (int r = 0; r < 3; ++r) {
+      rd[r]->tr[c] = w->mat[c][r].tr;
+      rd[r]->lde[c] = w->mat[c][r].lde;
+      rd[r]->cols[c] = (size_t)B * w->mat[c][r].w;
+    }
+  }
+  lde_main.launch = [&](int c, size_t cols, hipStream_t lane) {
+    launch_lde(lane, w->mat[c][0].tr, nullptr, w->mat[c][0].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br, 0, 0,
+               dom[c]->out_scale_br, logh[c], cols);
+  };
+  lde_perm.launch = [&](int c, size_t cols, hipStream_t lane) {
+    launch_lde(lane, w->mat[c][1].tr, nullptr, w->mat[c][1].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br, 0, 0,
+               dom[c]->out_scale_br, logh[c], cols);
+  };
+  // (quotient: columns 4c..4c+3 of every proof were evaluated over coset c: scale tables 1 and 2)
+  lde_quot.launch = [&](int c, size_t cols, hipStream_t lane) {
+    if (cols)
+      launch_lde(lane, w->mat[c][2].tr, nullptr, w->mat[c][2].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br + H(c), 2,
+                 1, dom[c]->out_scale_br, logh[c], cols);
+  };
   {
     ProfileSpan sp(ctx, "m_lde_main");
     fork2.begin();
-    for (int c = 0; c < kNumChips; ++c)
-      launch_lde(HL(c), w->mat[c][0].tr, nullptr, w->mat[c][0].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br, 0,
-                 0, dom[c]->out_scale_br, logh[c], (size_t)B * w->mat[c][0].w);
+    if (!grouped)
+      for (int c = 0; c < kNumChips; ++c) lde_main.launch(c, lde_main.cols[c], HL(c));
   }
   RoundMats rm[4];
   memset(rm, 0, sizeof rm);
@@ -791,7 +942,7 @@ int machine_prove_resident(Context* ctx) {
   }
   {
     ProfileSpan sp(ctx, "m_commit_main");
-    mmcs_commit(s, rm[1], w->tree[1], tree_stride, w->inj[1], B, kc, ctx, "m_leaf_main", &fork2, true);
+    mmcs_commit(s, rm[1], w->tree[1], tree_stride, w->inj[1], B, kc, ctx, "m_leaf_main", &fork2, true, grouped ? &lde_main : nullptr);
   }
   {
     ProfileSpan sp(ctx, "transcript");
@@ -830,13 +981,12 @@ int machine_prove_resident(Context* ctx) {
   {
     ProfileSpan sp(ctx, "m_lde_perm");
     fork2.begin();
-    for (int c = 0; c < kNumChips; ++c)
-      launch_lde(HL(c), w->mat[c][1].tr, nullptr, w->mat[c][1].lde, dom[c]->twc_fwd, dom[c]->twc_inv, dom[c]->in_scale_br, 0,
-                 0, dom[c]->out_scale_br, logh[c], (size_t)B * w->mat[c][1].w);
+    if (!grouped)
+      for (int c = 0; c < kNumChips; ++c) lde_perm.launch(c, lde_perm.cols[c], HL(c));
   }
   {
     ProfileSpan sp(ctx, "m_commit_perm");
-    mmcs_commit(s, rm[2], w->tree[2], tree_stride, w->inj[2], B, kc, nullptr, nullptr, &fork2, true);
+    mmcs_commit(s, rm[2], w->tree[2], tree_stride, w->inj[2], B, kc, nullptr, nullptr, &fork2, true, grouped ? &lde_perm : nullptr);
   }
   {
     ProfileSpan sp(ctx, "transcript");
@@ -881,25 +1031,23 @@ int machine_prove_resident(Context* ctx) {
       qa.quot = w->mat[quot_leader(logh, c)][2].tr;
       qa.accumulate = quot_leader(logh, c) != c;
       // (CPU: 8 H words per proof of the scratch's >= 16 H; the chips of a height share a lane, so its scratch is theirs)
-      qa.partial = is_cpu_chip(c) ? lane_scratch(c, w->reduce_scratch, w->side_reduce_scratch) : w->kpartial;
+      const int ql = fork.lane_of_q(logh[c]);
+      qa.partial = is_cpu_chip(c) ? (ql == 0 ? w->reduce_scratch : w->side_reduce_scratch[ql - 1]) : w->kpartial;
       qa.logh = logh[c];
       qa.batch = B;
-      launch_machine_quotient(SL(c), qa);
+      launch_machine_quotient(fork.lane(ql), qa);
     }
     fork.end();
   }
   {
     ProfileSpan sp(ctx, "m_lde_quot");
-    // columns 4c..4c+3 of every proof were evaluated over coset c: scale tables 1 and 2
     fork2.begin();
-    for (int c = 0; c < kNumChips; ++c)
-      if (w->mat[c][2].w)
-        launch_lde(HL(c), w->mat[c][2].tr, nullptr, w->mat[c][2].lde, dom[c]->twc_fwd, dom[c]->twc_inv,
-                   dom[c]->in_scale_br + H(c), 2, 1, dom[c]->out_scale_br, logh[c], (size_t)B * 8);
+    if (!grouped)
+      for (int c = 0; c < kNumChips; ++c) lde_quot.launch(c, lde_quot.cols[c], HL(c));
   }
   {
     ProfileSpan sp(ctx, "m_commit_quot");
-    mmcs_commit(s, rm[3], w->tree[3], tree_stride, w->inj[3], B, kc, nullptr, nullptr, &fork2, true);
+    mmcs_commit(s, rm[3], w->tree[3], tree_stride, w->inj[3], B, kc, nullptr, nullptr, &fork2, true, grouped ? &lde_quot : nullptr);
   }
   const size_t R = (size_t)1 << w->open_rows_log;
   {
@@ -922,33 +1070,125 @@ int machine_prove_resident(Context* ctx) {
       launch_bary_weights(SL(c), w->zeta, 4, sinv, dom[c]->tw_fwd, h_inv, w->zpow[c], zs, logh[c], B);
     }
     fork.end();
-    fork.begin();
-    for (int c = 0; c < kNumChips; ++c) {
-      const ChipDef& d = chip_def(c);
-      const size_t h = H(c);
-      const int pw = d.prep_w, mw = d.main_w, ew = d.perm_width();
-      // Columns are opened from their evaluations (the traces, and the quotient values over their cosets) against
-      // barycentric weights: table 0 at zeta, table 1 at zeta * w_H (table 0 moved by one place), tables 2 and 3 at zeta
-      // for columns given on the cosets g<w_H> and g w_2H <w_H> (the two quotient chunks).  No coefficient arrays.
-      const size_t zs = 4 * h * 4;
-      uint32_t* const scratch = chip_scratch(c, w->reduce_scratch, w->side_reduce_scratch);
-      uint32_t* base = w->opened + w->open_off[c] * 4;
-      const size_t pt_stride = (size_t)mw + ew + (size_t)w->mat[c][2].w;
-      // tall columns: split the rows over workgroups (the partial sums live in the reduce scratch, which is not in
-      // use yet)
-      auto open = [&](const uint32_t* evals, size_t cstride, int ncols, int npts, const uint32_t* table, uint32_t* dst, size_t pts) {
-        if (logh[c] >= 12) launch_open_tall(SC(c), evals, cstride, ncols, logh[c], table, zs, npts, dst, 8 * R, pts, scratch, B);
-        else launch_open(SC(c), evals, cstride, ncols, logh[c], table, zs, npts, dst, 8 * R, pts, B);
-      };
-      if (pw) open(prep->tr[PrepDevice::index_of(c)], 0, pw, 1, w->zpow[c], base, 0);
-      open(w->mat[c][0].tr, (size_t)mw * h, mw, 2, w->zpow[c], base + (size_t)pw * 4, pt_stride);
-      open(w->mat[c][1].tr, (size_t)ew * h, ew, 2, w->zpow[c], base + (size_t)(pw + mw) * 4, pt_stride);
-      if (w->mat[c][2].w) {
-        open(w->mat[c][2].tr, 8 * h, 4, 1, w->zpow[c] + 2 * h * 4, base + (size_t)(pw + mw + ew) * 4, 0);
-        open(w->mat[c][2].tr + 4 * h, 8 * h, 4, 1, w->zpow[c] + 3 * h * 4, base + (size_t)(pw + mw + ew + 4) * 4, 0);
+    const bool tabled = fork.lanes > 1;  // small batches: the whole stage in one launch per kind of kernel
+    if (tabled && w->open_tasks_batch != B) {
+      std::vector<OpenTask>& tk = w->open_tasks_host;
+      tk.clear();
+      for (int c = 0; c < kNumChips; ++c) {
+        const ChipDef& d = chip_def(c);
+        const size_t h = H(c), zs = 4 * h * 4;
+        const int pw = d.prep_w, mw = d.main_w, ew = d.perm_width();
+        uint32_t* base = w->opened + w->open_off[c] * 4;
+        const size_t pt_stride = (size_t)mw + ew + (size_t)w->mat[c][2].w;
+        auto add = [&](const uint32_t* evals, size_t cstride, int ncols, int npts, const uint32_t* table, uint32_t* dst, size_t pts) {
+          OpenTask t{};
+          t.evals = evals; t.cstride = cstride; t.table = table; t.zstride = zs; t.dst = dst; t.pts = pts;
+          t.ncols = ncols; t.logh = logh[c]; t.npts = npts;
+          tk.push_back(t);
+        };
+        if (pw) add(prep->tr[PrepDevice::index_of(c)], 0, pw, 1, w->zpow[c], base, 0);
+        add(w->mat[c][0].tr, (size_t)mw * h, mw, 2, w->zpow[c], base + (size_t)pw * 4, pt_stride);
+        add(w->mat[c][1].tr, (size_t)ew * h, ew, 2, w->zpow[c], base + (size_t)(pw + mw) * 4, pt_stride);
+        if (w->mat[c][2].w) {
+          add(w->mat[c][2].tr, 8 * h, 4, 1, w->zpow[c] + 2 * h * 4, base + (size_t)(pw + mw + ew) * 4, 0);
+          add(w->mat[c][2].tr + 4 * h, 8 * h, 4, 1, w->zpow[c] + 3 * h * 4, base + (size_t)(pw + mw + ew + 4) * 4, 0);
+        }
       }
+      size_t part = 0;
+      for (OpenTask& t : tk) {
+        const size_t need = open_task_plan(&t, B);
+        t.partial = need ? w->open_partial + part : nullptr;
+        part += need;
+      }
+      std::stable_sort(tk.begin(), tk.end(), [](const OpenTask& a, const OpenTask& b) { return a.kind < b.kind; });
+      for (int k = 0; k < 6; ++k) w->open_first[k] = w->open_count[k] = w->open_blocks[k] = 0;
+      w->open_cblocks = 0;
+      for (size_t i = 0; i < tk.size(); ++i) {
+        OpenTask& t = tk[i];
+        if (w->open_count[t.kind]++ == 0) w->open_first[t.kind] = (int)i;
+        t.blk0 = w->open_blocks[t.kind];
+        w->open_blocks[t.kind] += t.blocks;
+        t.cblk0 = w->open_cblocks;
+        w->open_cblocks += t.cblocks;
+      }
+      if (tk.size() > (size_t)5 * kNumChips) return ctx->fail(3, "machine_prove: opening task table overflow");
+      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->open_tasks, tk.data(), tk.size() * sizeof(OpenTask), hipMemcpyHostToDevice, s));
+      // the reduced openings' tables: heights from the tallest down, every matrix of every chip of a height
+      w->mr_heights_host.clear(); w->mr_segs_host.clear(); w->mr_chips_host.clear();
+      w->mr_blocks = 0;
+      for (int lh = 31; lh >= 0; --lh) {
+        MRHeight hh{};
+        hh.logh = lh; hh.seg0 = (int)w->mr_segs_host.size(); hh.chip0 = (int)w->mr_chips_host.size(); hh.blk0 = w->mr_blocks;
+        int first = -1;
+        for (int c = 0; c < kNumChips; ++c) {
+          if (logh[c] != lh) continue;
+          if (first < 0) first = c;
+          const ChipDef& d = chip_def(c);
+          const Seg mats[4] = {prep_seg(c, true), rm[1].seg[c][0], rm[2].seg[c][0], rm[3].seg[c][0]};
+          const int w0 = mats[0].width, n1 = w0 + mats[1].width + mats[2].width + mats[3].width, n2 = mats[1].width + mats[2].width;
+          (void)d;
+          int col0 = 0;
+          for (int mi = 0; mi < 4; ++mi) {
+            if (mats[mi].width) {
+              MRSeg sg{};
+              sg.p = mats[mi].p; sg.bstride = mats[mi].bstride; sg.width = mats[mi].width;
+              sg.pow1 = (int)w->open_off[c] + col0;
+              sg.pow2 = mi == 1 || mi == 2 ? (int)w->open_off[c] + n1 + col0 - w0 : -1;
+              w->mr_segs_host.push_back(sg);
+            }
+            col0 += mats[mi].width;
+          }
+          w->mr_chips_host.push_back(MRChip{(int)w->open_off[c], n1, n2});
+        }
+        if (first < 0) continue;
+        hh.nseg = (int)w->mr_segs_host.size() - hh.seg0;
+        hh.nchips = (int)w->mr_chips_host.size() - hh.chip0;
+        const size_t hgt = (size_t)1 << lh;
+        if (lh == lm) { hh.out = w->fri_layers; hh.out_bstride = w->fri_layer_stride; }
+        else { hh.out = w->G[lh]; hh.out_bstride = 2 * hgt * 4; }
+        hh.tw_fwd = dom[first]->tw_fwd;
+        hh.shift[0] = Fp::from_canonical(kGen).v;
+        hh.shift[1] = (Fp::from_canonical(kGen) * fp_root_of_unity(lh + 1)).v;
+        hh.w_h = dom[first]->w_h;
+        w->mr_blocks += B * (int)((2 * hgt + kMReduceMultiPoints - 1) / kMReduceMultiPoints);
+        w->mr_heights_host.push_back(hh);
+      }
+      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->mr_heights, w->mr_heights_host.data(), w->mr_heights_host.size() * sizeof(MRHeight), hipMemcpyHostToDevice, s));
+      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->mr_segs, w->mr_segs_host.data(), w->mr_segs_host.size() * sizeof(MRSeg), hipMemcpyHostToDevice, s));
+      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->mr_chips, w->mr_chips_host.data(), w->mr_chips_host.size() * sizeof(MRChip), hipMemcpyHostToDevice, s));
+      w->open_tasks_batch = B;
     }
-    fork.end();
+    if (tabled) {
+      launch_open_multi(s, w->open_tasks, w->open_first, w->open_count, w->open_blocks, w->open_cblocks, 8 * R);
+    } else {
+      fork.begin();
+      for (int c = 0; c < kNumChips; ++c) {
+        const ChipDef& d = chip_def(c);
+        const size_t h = H(c);
+        const int pw = d.prep_w, mw = d.main_w, ew = d.perm_width();
+        // Columns are opened from their evaluations (the traces, and the quotient values over their cosets) against
+        // barycentric weights: table 0 at zeta, table 1 at zeta * w_H (table 0 moved by one place), tables 2 and 3 at zeta
+        // for columns given on the cosets g<w_H> and g w_2H <w_H> (the two quotient chunks).  No coefficient arrays.
+        const size_t zs = 4 * h * 4;
+        uint32_t* const scratch = chip_scratch(c, w->reduce_scratch, w->side_reduce_scratch);
+        uint32_t* base = w->opened + w->open_off[c] * 4;
+        const size_t pt_stride = (size_t)mw + ew + (size_t)w->mat[c][2].w;
+        // tall columns: split the rows over workgroups (the partial sums live in the reduce scratch, which is not in
+        // use yet)
+        auto open = [&](const uint32_t* evals, size_t cstride, int ncols, int npts, const uint32_t* table, uint32_t* dst, size_t pts) {
+          if (logh[c] >= 12) launch_open_tall(SC(c), evals, cstride, ncols, logh[c], table, zs, npts, dst, 8 * R, pts, scratch, B);
+          else launch_open(SC(c), evals, cstride, ncols, logh[c], table, zs, npts, dst, 8 * R, pts, B);
+        };
+        if (pw) open(prep->tr[PrepDevice::index_of(c)], 0, pw, 1, w->zpow[c], base, 0);
+        open(w->mat[c][0].tr, (size_t)mw * h, mw, 2, w->zpow[c], base + (size_t)pw * 4, pt_stride);
+        open(w->mat[c][1].tr, (size_t)ew * h, ew, 2, w->zpow[c], base + (size_t)(pw + mw) * 4, pt_stride);
+        if (w->mat[c][2].w) {
+          open(w->mat[c][2].tr, 8 * h, 4, 1, w->zpow[c] + 2 * h * 4, base + (size_t)(pw + mw + ew) * 4, 0);
+          open(w->mat[c][2].tr + 4 * h, 8 * h, 4, 1, w->zpow[c] + 3 * h * 4, base + (size_t)(pw + mw + ew + 4) * 4, 0);
+        }
+      }
+      fork.end();
+    }
   }
   {
     ProfileSpan sp(ctx, "merkle_open");
@@ -963,6 +1203,13 @@ int machine_prove_resident(Context* ctx) {
   {
     ProfileSpan sp(ctx, "m_reduce");
     bool seen[32] = {false};
+    if (fork.lanes > 1) {  // small batches: two launches over the tables built with the opening tasks
+      MReduceMulti ma{};
+      ma.heights = w->mr_heights; ma.n_heights = (int)w->mr_heights_host.size(); ma.segs = w->mr_segs; ma.chips = w->mr_chips;
+      ma.af_pows = w->af_pows; ma.af_bstride = w->n_open * 4; ma.opened = w->opened; ma.opened_bstride = 8 * R; ma.zeta = w->zeta;
+      ma.bsum = w->mr_bsum; ma.total_blocks = w->mr_blocks; ma.batch = B;
+      launch_machine_reduce_multi(s, ma);
+    } else {
     fork.begin();
     for (int c = 0; c < kNumChips; ++c) {
       const ChipDef& d = chip_def(c);
@@ -995,6 +1242,7 @@ int machine_prove_resident(Context* ctx) {
       launch_machine_reduce(SL(c), ra);
     }
     fork.end();
+    }
   }
   // ---- FRI commit phase; an input of height 2^k joins when the folded layer reaches that height ----
   size_t loff = 0, toff = 0;

@@ -79,6 +79,20 @@ struct MachineWorkspace {
   size_t n_open = 0, open_off[mach::kNumChips] = {0}, open_rows_log = 0, alpha_stride = 0;
   size_t fri_layer_stride = 0, fri_tree_stride = 0, body_words = 0;
   int lm = 0;
+  // a small batch's opening stage as a table of tasks (kernels.h OpenTask): built for `open_tasks_batch` proofs of this layout
+  OpenTask* open_tasks = nullptr;
+  uint32_t* open_partial = nullptr;
+  std::vector<OpenTask> open_tasks_host;
+  int open_tasks_batch = -1, open_first[6] = {0}, open_count[6] = {0}, open_blocks[6] = {0}, open_cblocks = 0;
+  // ... and its reduced openings height by height (kernels_machine.h MReduceMulti), built with the opening tasks
+  MRHeight* mr_heights = nullptr;
+  MRSeg* mr_segs = nullptr;
+  MRChip* mr_chips = nullptr;
+  uint32_t* mr_bsum = nullptr;
+  std::vector<MRHeight> mr_heights_host;
+  std::vector<MRSeg> mr_segs_host;
+  std::vector<MRChip> mr_chips_host;
+  int mr_blocks = 0;
   std::vector<void*> allocs;
   ~MachineWorkspace();
 };
