@@ -78,7 +78,8 @@ struct MmcsTopArgs {
   size_t in_off[kMmcsTopLevels], out_off[kMmcsTopLevels], inj_bstride[kMmcsTopLevels];
   const uint32_t* inject[kMmcsTopLevels];
 };
-void launch_mmcs_top(hipStream_t stream, const MmcsTopArgs& a, int batch, const P2Consts* consts);
+// subtrees = 1: the last levels (at most 256 nodes each); subtrees = S: levels whose node counts are multiples of S
+void launch_mmcs_top(hipStream_t stream, const MmcsTopArgs& a, int subtrees, int batch, const P2Consts* consts);
 void launch_mmcs_level(hipStream_t stream, const uint32_t* in, size_t in_bstride, uint32_t* out, size_t out_bstride,
                        const uint32_t* inject, size_t inject_bstride, size_t count, int batch, const P2Consts* consts);
 

@@ -753,24 +753,28 @@ void launch_mmcs_level(hipStream_t stream, const uint32_t* in, size_t in_bstride
                      out, out_bstride, inject, inject_bstride, count, consts);
 }
 
-// The levels of at most kMT nodes in ONE launch, one workgroup per proof: nine launches of a few microseconds' work each
-// were a fifth of a single proof's commitment.  (Stores to the tree are visible to the workgroup after the barrier's fence.)
+// Several levels in ONE launch.  gridDim.x = 1: the levels of at most kMT nodes, one workgroup per proof (nine launches of a
+// few microseconds' work each were a fifth of a single proof's commitment).  gridDim.x = S: the levels above those, S
+// subtrees side by side - workgroup s climbs nodes s * count / S .. of every level, which only depend on its own nodes of
+// the level below.  (Stores to the tree are visible to the workgroup after the barrier's fence.)
 __global__ __launch_bounds__(kMT) void mmcs_top_kernel(MmcsTopArgs a, const P2Consts* __restrict__ consts) {
-  const int b = blockIdx.x, i = threadIdx.x;
+  const int sub = blockIdx.x, b = blockIdx.y;
   uint32_t* tree = a.tree + (size_t)b * a.tree_bstride;
   for (int lv = 0; lv < a.n_levels; ++lv) {
-    if (i < a.count[lv]) {
-      const uint4* src = reinterpret_cast<const uint4*>(tree + a.in_off[lv] + 16 * (size_t)i);
+    const int per = a.count[lv] / (int)gridDim.x;
+    for (int k = threadIdx.x; k < per; k += kMT) {
+      const size_t i = (size_t)sub * per + k;
+      const uint4* src = reinterpret_cast<const uint4*>(tree + a.in_off[lv] + 16 * i);
       uint4 d[2];
       m_compress(src, src + 2, d, consts);
       if (a.inject[lv]) {
-        const uint4* g = reinterpret_cast<const uint4*>(a.inject[lv] + (size_t)b * a.inj_bstride[lv] + 8 * (size_t)i);
+        const uint4* g = reinterpret_cast<const uint4*>(a.inject[lv] + (size_t)b * a.inj_bstride[lv] + 8 * i);
         uint4 e[2];
         m_compress(d, g, e, consts);
         d[0] = e[0];
         d[1] = e[1];
       }
-      uint4* dst = reinterpret_cast<uint4*>(tree + a.out_off[lv] + 8 * (size_t)i);
+      uint4* dst = reinterpret_cast<uint4*>(tree + a.out_off[lv] + 8 * i);
       dst[0] = d[0];
       dst[1] = d[1];
     }
@@ -778,8 +782,8 @@ __global__ __launch_bounds__(kMT) void mmcs_top_kernel(MmcsTopArgs a, const P2Co
     __syncthreads();
   }
 }
-void launch_mmcs_top(hipStream_t stream, const MmcsTopArgs& a, int batch, const P2Consts* consts) {
-  hipLaunchKernelGGL(mmcs_top_kernel, dim3(batch), dim3(kMT), 0, stream, a, consts);
+void launch_mmcs_top(hipStream_t stream, const MmcsTopArgs& a, int subtrees, int batch, const P2Consts* consts) {
+  hipLaunchKernelGGL(mmcs_top_kernel, dim3(subtrees, batch), dim3(kMT), 0, stream, a, consts);
 }
 
 // ===========================================================================================

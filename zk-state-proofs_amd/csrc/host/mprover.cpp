@@ -277,9 +277,19 @@ int mmcs_commit(hipStream_t s, const RoundMats& rm, uint32_t* tree, size_t tree_
     launch_mmcs_leaves(s, segs, ns, lm, tree, tree_bstride, batch, kc);
   }
   if (side_by_side) fork->end();
-  MmcsTopArgs top;
-  top.n_levels = 0;
+  // small batches: the levels of 65 536 .. 256 nodes as 256 subtrees in one launch, the rest of the tree in another
+  MmcsTopArgs mid, top;
+  mid.n_levels = top.n_levels = 0;
   static_assert(kMmcsTopNodes == 256 && kMmcsTopLevels == 9, "levels of 256, 128, ..., 1 nodes");
+  auto add_level = [&](MmcsTopArgs& g, int l, size_t count, const uint32_t* injp, size_t inj_bstride) {
+    if (g.n_levels == 0) { g.tree = tree; g.tree_bstride = tree_bstride; }
+    const int k = g.n_levels++;
+    g.count[k] = (int)count;
+    g.in_off[k] = layer_off(logn, l - 1) * 8;
+    g.out_off[k] = layer_off(logn, l) * 8;
+    g.inject[k] = injp;
+    g.inj_bstride[k] = inj_bstride;
+  };
   for (int l = 1; l <= logn; ++l) {
     const size_t count = (size_t)1 << (logn - l);
     const uint32_t* injp = nullptr;
@@ -290,20 +300,19 @@ int mmcs_commit(hipStream_t s, const RoundMats& rm, uint32_t* tree, size_t tree_
       if (!side_by_side) launch_mmcs_leaves(s, segs, ns, logn - l - 1, inj[logn - l], inj_bstride, batch, kc);
       injp = inj[logn - l];
     }
-    if (side_by_side && count <= (size_t)kMmcsTopNodes) {  // small batches: the rest of the tree in one launch
-      if (top.n_levels == 0) { top.tree = tree; top.tree_bstride = tree_bstride; }
-      const int k = top.n_levels++;
-      top.count[k] = (int)count;
-      top.in_off[k] = layer_off(logn, l - 1) * 8;
-      top.out_off[k] = layer_off(logn, l) * 8;
-      top.inject[k] = injp;
-      top.inj_bstride[k] = inj_bstride;
+    if (side_by_side && count < (size_t)kMmcsTopNodes) {
+      add_level(top, l, count, injp, inj_bstride);
+      continue;
+    }
+    if (side_by_side && count <= (size_t)kMmcsTopNodes * kMmcsTopNodes) {
+      add_level(mid, l, count, injp, inj_bstride);
+      if (count == (size_t)kMmcsTopNodes) launch_mmcs_top(s, mid, kMmcsTopNodes, batch, kc);
       continue;
     }
     launch_mmcs_level(s, tree + layer_off(logn, l - 1) * 8, tree_bstride, tree + layer_off(logn, l) * 8, tree_bstride, injp,
                       inj_bstride, count, batch, kc);
   }
-  if (top.n_levels) launch_mmcs_top(s, top, batch, kc);
+  if (top.n_levels) launch_mmcs_top(s, top, 1, batch, kc);
   return lm;
 }
 
@@ -594,7 +603,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
       A(&w->mr_heights, (size_t)32);
       A(&w->mr_segs, (size_t)4 * kNumChips);
       A(&w->mr_chips, (size_t)kNumChips);
-      A(&w->mr_bsum, std::min<size_t>(B, Context::kSideMaxBatch) * 32 * 2 * 4);
+      A(&w->mr_bsum, B * 32 * 2 * 4);
       w->open_tasks_batch = -1;
     }
     w->fri_layer_stride = 0;
@@ -1071,7 +1080,7 @@ int machine_prove_resident(Context* ctx) {
     }
     fork.end();
     const bool tabled = fork.lanes > 1;  // small batches: the whole stage in one launch per kind of kernel
-    if (tabled && w->open_tasks_batch != B) {
+    if (w->open_tasks_batch != B) {  // (the reduced openings' tables serve every batch size)
       std::vector<OpenTask>& tk = w->open_tasks_host;
       tk.clear();
       for (int c = 0; c < kNumChips; ++c) {
@@ -1203,7 +1212,8 @@ int machine_prove_resident(Context* ctx) {
   {
     ProfileSpan sp(ctx, "m_reduce");
     bool seen[32] = {false};
-    if (fork.lanes > 1) {  // small batches: two launches over the tables built with the opening tasks
+    static const bool per_chip = getenv("ZKSP_REDUCE_PER_CHIP") != nullptr;  // measurement switch: the per-chip launches
+    if (fork.lanes > 1 || !per_chip) {  // two launches over the tables built with the opening tasks
       MReduceMulti ma{};
       ma.heights = w->mr_heights; ma.n_heights = (int)w->mr_heights_host.size(); ma.segs = w->mr_segs; ma.chips = w->mr_chips;
       ma.af_pows = w->af_pows; ma.af_bstride = w->n_open * 4; ma.opened = w->opened; ma.opened_bstride = 8 * R; ma.zeta = w->zeta;
