@@ -1595,20 +1595,25 @@ __global__ __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(4))) void c
   pi.b = blockIdx.y;
   point_selectors(a, pt, &pi);
   uint32_t* part = a.partial + ((size_t)pi.b * n + pt) * 4;
-  if constexpr (TASK == 0) {
+  // TASK 3: both in one launch - the base constraints' sum stays in registers and the row the LogUp terms read again is
+  // still in the cache (the two phases' registers do not add up: only the sum lives across them)
+  Fp4 base_acc = Fp4::zero();
+  if constexpr (TASK == 0 || TASK == 3) {
     MQCtx ctx;
     init_ctx(a, pi, &ctx);
     eval_cpu(ctx);
     ctx.flush();
-    m_store_fp4(part, ctx.acc);
-  } else {
-    constexpr int J0 = TASK == 1 ? 0 : kCpuQuotSplit, J1 = TASK == 1 ? kCpuQuotSplit : kCpuSlots, nh = kCpuHelpers;
+    if constexpr (TASK == 0) m_store_fp4(part, ctx.acc);
+    base_acc = ctx.acc;
+  }
+  if constexpr (TASK != 0) {
+    constexpr int J0 = TASK == 2 ? kCpuQuotSplit : 0, J1 = TASK == 1 ? kCpuQuotSplit : kCpuSlots, nh = kCpuHelpers;
     const int b = pi.b;
     const Fp4 gamma = m_load_fp4(a.bus_ch + (size_t)b * 8);
     const uint32_t* bpow = a.bpow + (size_t)b * (kInterMaxElems + 1) * 4;
     const uint32_t* ap = a.alpha_pows + (size_t)b * a.alpha_bstride;
     const uint32_t* pl = a.perm.p + (size_t)b * a.perm.bstride + (size_t)pi.c * h;
-    Fp4 acc = m_load_fp4(part);
+    Fp4 acc = TASK == 3 ? base_acc : m_load_fp4(part);
     cpu_bus_pairs<J0, J1>(a.main_.p + (size_t)b * a.main_.bstride + pt, n, gamma, bpow,
                           [&](int j, Fp ma, const Fp4& fa, Fp mb, const Fp4& fb) {
                             Fp4 hj;
@@ -1697,10 +1702,17 @@ void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a) {
   switch (a.chip) {
     case kCpu:
     case kCpu2: case kCpu3: case kCpu4: case kCpu5: case kCpu6: case kCpu7: case kCpu8:
+    {
+      static const bool fused = getenv("ZKSP_CPU_QUOT_FUSED") != nullptr;  // measurement switch
+      if (fused && kCpuQuotSplit == kCpuSlots) {
+        hipLaunchKernelGGL(cpu_quotient_task_kernel<3>, grid, block, 0, stream, a);
+        break;
+      }
       hipLaunchKernelGGL(cpu_quotient_task_kernel<0>, grid, block, 0, stream, a);
       hipLaunchKernelGGL(cpu_quotient_task_kernel<1>, grid, block, 0, stream, a);
       if (kCpuQuotSplit < kCpuSlots) hipLaunchKernelGGL(cpu_quotient_task_kernel<2>, grid, block, 0, stream, a);
       break;
+    }
     case kAlu:
     case kAlu2: hipLaunchKernelGGL(machine_quotient_kernel<kAlu>, grid, block, 0, stream, a); break;
     case kSub:
