@@ -653,12 +653,11 @@ def main():
     single_ms = single_sync_ms = e2e_ms = e2e_batch_rate = component = as_committed = leaf_check = None
     pipelined = {}
     if not args.skip_single:
-        # device time of one resident proof, on a client of its own sized for one proof (what zksp_prove uses)
-        sc = zk.ProverClient(device=local_rank, max_batch=1)
-        spk, _svk = sc.setup(zk.merkle_elf())
-        s1 = zk.SP1Stdin()
-        s1.write(payloads[0])
-        sh = sc.machine_trace_handle(spk, s1)
+        # device time of one resident proof: the timed batch's client takes a batch of one (the same launch sequence
+        # zksp_prove enqueues for a single run).  Not a second client: the runtime maps streams onto four hardware queues,
+        # and a second client's lanes would share queues with the first one's - its kernels would run one after the other.
+        sc, spk = client, pk
+        sh = handles[0]
         one = (C.c_void_p * 1)(sh._h)
         if lib.zksp_hip_machine_load(sc._h, spk._h, one, 1):
             raise RuntimeError(sc.last_error())
@@ -680,7 +679,7 @@ def main():
                 raise RuntimeError(sc.last_error())
             sync_ms.append((time.perf_counter() - t1) * 1e3)
         single_sync_ms = sorted(sync_ms)[len(sync_ms) // 2]
-        del sh, sc
+        del sh, sc, spk
         e2e = []
         for _ in range(5):
             s = zk.SP1Stdin()

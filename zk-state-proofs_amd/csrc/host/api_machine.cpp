@@ -200,9 +200,15 @@ int zksp_hip_release_workspace(zksp_client* c) {
   ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->copy_stream) ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->copy_stream));
   ctx->mws.reset();
+  ctx->retired.clear();
   if (ctx->arena) (void)hipFree(ctx->arena);
   ctx->arena = nullptr;
   ctx->arena_bytes = 0;
+  for (int k = 0; k < 2; ++k) {
+    if (ctx->rec_arena[k]) (void)hipFree(ctx->rec_arena[k]);
+    ctx->rec_arena[k] = nullptr;
+    ctx->rec_bytes[k] = 0;
+  }
   for (int k = 0; k < 2; ++k) {
     if (ctx->h_stage2[k]) (void)hipHostFree(ctx->h_stage2[k]);
     ctx->h_stage2[k] = nullptr;

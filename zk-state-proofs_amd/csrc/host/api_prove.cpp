@@ -300,6 +300,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
         traces[ck.idx[j]]->handover_pc[k - 1] = machine_handover_pc(pk->mprog, *ts[j], ck.lh.data(), k);
     }
     if (!into_spare) ctx->batch_hint = (int)std::max(ck.group_size, size_hint);
+    else ctx->spare_batch_hint = (int)std::max(ck.group_size, size_hint);
     hipEvent_t ev = nullptr;
     if (into_spare) {  // not waited for: the proving stream and the thread that frees the traces wait for this event
       if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
@@ -401,7 +402,10 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     }
     in_flight = false;
     const bool more = have_chunk(k + 1);
-    const bool piggyback = more && chunks[k + 1].lh == ck.lh && ctx->mws && (size_t)ctx->mws->batch >= chunks[k + 1].idx.size();
+    // (a chunk of ANOTHER shape is uploaded behind the current pass too - its records live outside the arena - and the
+    // arena is laid out for it when it is activated: a block of receipts goes through five shapes without the GPU waiting
+    // for an upload)
+    const bool piggyback = more && ctx->mws && ctx->copy_stream;
     int rc_next = ZKSP_OK;
     if (piggyback) rc_next = load_chunk(chunks[k + 1], true);
     // The bodies of this pass go to pinned host memory on the copy stream, behind the pass; the NEXT pass is enqueued at
@@ -476,6 +480,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   if (wrapper.t.joinable()) wrapper.t.join();
   if (!first_err.empty() && rc_all == ZKSP_OK) ctx->error = first_err;
   ctx->body_free = nullptr;  // every copy has completed: later passes on this client need no wait
+  ctx->retired.clear();      // ... and every pass has: the workspaces replaced on the way can go
   for (auto& v : ctx->h_stage2_pageable) std::vector<uint32_t>().swap(v);
   mark.mark("done", n);
   for (auto& t : reaper.th)

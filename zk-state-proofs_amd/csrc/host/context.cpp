@@ -44,7 +44,10 @@ Context::~Context() {
     if (timer_b) (void)hipEventDestroy(timer_b);
     ws.reset();
     mws.reset();
+    retired.clear();
     if (arena) (void)hipFree(arena);
+    for (void* p : rec_arena)
+      if (p) (void)hipFree(p);
     for (auto& kv : prep)
       for (void* p : kv.second->allocs)
         if (p) (void)hipFree(p);

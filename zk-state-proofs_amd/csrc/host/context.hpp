@@ -68,6 +68,14 @@ struct Context {
   std::unique_ptr<MachineWorkspace> mws;
   void* arena = nullptr;   // the machine workspace's device memory: laid out again per shape, grown when too small
   size_t arena_bytes = 0;
+  // The executor's records of a batch live OUTSIDE that arena, in two buffers of their own (the resident set and the spare
+  // set, MachineWorkspace::rec_slot says which is which): a chunk of ANOTHER shape can then be uploaded while the current
+  // one is proven, and laying the arena out for the new shape moves nothing that an upload in flight writes.
+  void* rec_arena[2] = {nullptr, nullptr};
+  size_t rec_bytes[2] = {0, 0};
+  // workspaces replaced while passes enqueued from them may still read their host-side tables: buried when the stream is idle
+  std::vector<std::unique_ptr<MachineWorkspace>> retired;
+  int spare_batch_hint = 0;  // prove_batch: the size of the group the spare set's chunk belongs to
   std::map<std::array<uint32_t, 8>, std::unique_ptr<PrepDevice>> prep;
   void* d_inter[mach::kNumChips] = {nullptr};  // indexed by chip
   uint32_t* h_stage2[2] = {nullptr, nullptr};  // pinned host staging for proof bodies (double buffered)

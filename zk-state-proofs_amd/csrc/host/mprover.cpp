@@ -429,15 +429,78 @@ int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineV
   return 0;
 }
 
+// The executor's records of `B` runs with the capacities `t` already holds (cap_*), placed from `base` on (null: sizing
+// only).  T: MachineWorkspace (the resident set) or its SpareRecords - the same member names.  Returns the bytes.
+template <class T>
+static size_t records_place(T* t, void* base, size_t B, const int* logh) {
+  size_t off = 0;
+  auto A = [&](auto** p, size_t count) {
+    using E = std::remove_pointer_t<std::remove_reference_t<decltype(*p)>>;
+    const size_t bytes = (std::max<size_t>(count, 4) * sizeof(E) + 255) & ~(size_t)255;
+    if (base) *p = reinterpret_cast<E*>(static_cast<char*>(base) + off);
+    off += bytes;
+  };
+  A(&t->cycles, B * t->cap_cycles * 12);
+  A(&t->kcalls, B * t->cap_keccak * 408);
+  A(&t->kstates, B * t->cap_keccak * 25);
+  A(&t->memfinal, B * t->cap_memfinal * 5);
+  A(&t->muls, B * t->cap_muls * 3);
+  A(&t->alu_idx, B * t->cap_alu);
+  A(&t->sub_idx, B * t->cap_sub);
+  A(&t->bw_idx, B * t->cap_bw);
+  A(&t->ecall_idx, B << logh[kEcall]);  // (an ecall list is as long as the ecall chip is tall, at most)
+  A(&t->div_idx, B << logh[kDiv]);
+  A(&t->agg_heap, B * t->cap_agg * kP2RecWords);
+  A(&t->fold_rows, B * t->cap_fold * kFoldRecWords);
+  A(&t->prog_mult, B << logh[kProgram]);
+  A(&t->counts, B * kCountWords);
+  A(&t->n_perms, B);
+  A(&t->init_obs, B * kMachineInitObs);
+  A(&t->pub_words, B * kPubWords);
+  return off;
+}
+// rec_arena[slot] of at least `bytes` (grown by a quarter more than asked for; growing frees, which waits for the device)
+static int records_ensure(Context* ctx, int slot, size_t bytes) {
+  if (ctx->rec_bytes[slot] >= bytes) return 0;
+  if (ctx->rec_arena[slot]) (void)hipFree(ctx->rec_arena[slot]);
+  ctx->rec_arena[slot] = nullptr;
+  ctx->rec_bytes[slot] = 0;
+  const size_t want = bytes + bytes / 4;
+  if (hipMalloc(&ctx->rec_arena[slot], want) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hipMalloc(&ctx->rec_arena[slot], bytes) != hipSuccess) return ctx->fail(3, "machine records: hipMalloc of " + std::to_string(bytes >> 20) + " MiB failed");
+    ctx->rec_bytes[slot] = bytes;
+    return 0;
+  }
+  ctx->rec_bytes[slot] = want;
+  return 0;
+}
+
+// `in_flight`: a pass enqueued from the current workspace may still be running (prove_batch going from one shape to the
+// next).  The arena is then laid out again WITHOUT waiting for the stream - kernels hold their pointers, and everything that
+// will reuse the memory is enqueued behind them - unless it has to grow; the old workspace object (host-side tables an
+// asynchronous copy may still read) is retired, not destroyed.
 static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap_cycles, size_t cap_keccak, size_t cap_memfinal,
-                            size_t cap_muls, size_t cap_alu, size_t cap_sub, size_t cap_bw, size_t cap_agg, size_t cap_fold) {
+                            size_t cap_muls, size_t cap_alu, size_t cap_sub, size_t cap_bw, size_t cap_agg, size_t cap_fold,
+                            bool in_flight = false) {
   MachineWorkspace* w = ctx->mws.get();
   if (w && memcmp(w->logh, logh, sizeof w->logh) == 0 && w->batch >= batch && w->cap_cycles >= cap_cycles &&
       w->cap_keccak >= cap_keccak && w->cap_memfinal >= cap_memfinal && w->cap_muls >= cap_muls && w->cap_alu >= cap_alu &&
       w->cap_sub >= cap_sub && w->cap_bw >= cap_bw && w->cap_agg >= cap_agg && w->cap_fold >= cap_fold)
     return 0;
-  ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->mws.reset(new MachineWorkspace());
+  if (!in_flight) {
+    ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->retired.clear();
+  }
+  {
+    std::unique_ptr<MachineWorkspace> fresh(new MachineWorkspace());
+    if (w) {
+      fresh->rec_slot = w->rec_slot;
+      for (int k = 0; k < 2; ++k) fresh->stage[k] = std::move(w->stage[k]);  // (uploads in flight read these vectors' buffers)
+      if (in_flight) ctx->retired.push_back(std::move(ctx->mws));
+    }
+    ctx->mws = std::move(fresh);
+  }
   w = ctx->mws.get();
   memcpy(w->logh, logh, sizeof w->logh);
   w->batch = batch;
@@ -461,41 +524,8 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
       if (pass == 1) *p = reinterpret_cast<T*>(static_cast<char*>(ctx->arena) + off);
       off += bytes;
     };
-    A(&w->cycles, B * w->cap_cycles * 12);
-    A(&w->kcalls, B * w->cap_keccak * 408);
-    A(&w->kstates, B * w->cap_keccak * 25);
-    A(&w->memfinal, B * w->cap_memfinal * 5);
-    A(&w->muls, B * w->cap_muls * 3);
-    A(&w->alu_idx, B * w->cap_alu);
-    A(&w->sub_idx, B * w->cap_sub);
-    A(&w->bw_idx, B * w->cap_bw);
-    A(&w->ecall_idx, B << logh[kEcall]);  // (an ecall list is as long as the ecall chip is tall, at most)
-    A(&w->div_idx, B << logh[kDiv]);
-    A(&w->agg_heap, B * w->cap_agg * kP2RecWords);
-    A(&w->fold_rows, B * w->cap_fold * kFoldRecWords);
-    A(&w->prog_mult, B << logh[kProgram]);
+    // (the executor's records are not in this arena: Context::rec_arena, records_place below)
     A(&w->table_hist, (B * kTableWidth) << kTableLogH);
-    A(&w->counts, B * kCountWords);
-    A(&w->n_perms, B);
-    A(&w->init_obs, B * kMachineInitObs);
-    A(&w->pub_words, B * kPubWords);
-    A(&w->spare.cycles, B * w->cap_cycles * 12);
-    A(&w->spare.kcalls, B * w->cap_keccak * 408);
-    A(&w->spare.kstates, B * w->cap_keccak * 25);
-    A(&w->spare.memfinal, B * w->cap_memfinal * 5);
-    A(&w->spare.muls, B * w->cap_muls * 3);
-    A(&w->spare.alu_idx, B * w->cap_alu);
-    A(&w->spare.sub_idx, B * w->cap_sub);
-    A(&w->spare.bw_idx, B * w->cap_bw);
-    A(&w->spare.ecall_idx, B << logh[kEcall]);
-    A(&w->spare.div_idx, B << logh[kDiv]);
-    A(&w->spare.agg_heap, B * w->cap_agg * kP2RecWords);
-    A(&w->spare.fold_rows, B * w->cap_fold * kFoldRecWords);
-    A(&w->spare.prog_mult, B << logh[kProgram]);
-    A(&w->spare.counts, B * kCountWords);
-    A(&w->spare.n_perms, B);
-    A(&w->spare.init_obs, B * kMachineInitObs);
-    A(&w->spare.pub_words, B * kPubWords);
     // The matrices of a round, the traces and the LDEs each, height by height: the columns of the chips of one height lie
     // side by side, so that a small batch transforms them in ONE launch (six CPU instances one after the other were a
     // millisecond of a single proof).  (No coefficient arrays: columns are opened from their evaluations.)
@@ -624,6 +654,10 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
     if (pass == 0) {
       arena_need = off;
       if (ctx->arena_bytes < arena_need) {
+        if (in_flight) {  // the memory goes back to the runtime: whatever is enqueued has to be over first
+          (void)hipStreamSynchronize(ctx->stream);
+          if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+        }
         if (ctx->arena) (void)hipFree(ctx->arena);
         ctx->arena = nullptr;
         ctx->arena_bytes = 0;
@@ -648,6 +682,10 @@ void swap_records(MachineWorkspace* w) {
   std::swap(w->counts, p.counts);
   std::swap(w->kcalls, p.kcalls); std::swap(w->kstates, p.kstates); std::swap(w->n_perms, p.n_perms);
   std::swap(w->init_obs, p.init_obs); std::swap(w->pub_words, p.pub_words); std::swap(w->n, p.n);
+  std::swap(w->cap_cycles, p.cap_cycles); std::swap(w->cap_keccak, p.cap_keccak); std::swap(w->cap_memfinal, p.cap_memfinal);
+  std::swap(w->cap_muls, p.cap_muls); std::swap(w->cap_alu, p.cap_alu); std::swap(w->cap_sub, p.cap_sub); std::swap(w->cap_bw, p.cap_bw);
+  std::swap(w->cap_agg, p.cap_agg); std::swap(w->cap_fold, p.cap_fold);
+  w->rec_slot ^= 1;
 }
 }  // namespace
 
@@ -657,6 +695,22 @@ int machine_activate_spare(Context* ctx) {
   if (w->spare_loaded) {  // an upload nobody waited for: the passes enqueued from now on do
     ZKSP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, w->spare_loaded, 0));
     w->spare_loaded = nullptr;
+  }
+  if (memcmp(w->spare.logh, w->logh, sizeof w->logh) != 0 || w->batch < w->spare.n) {
+    // another shape (or more runs than the arena is laid out for): lay the arena out again behind the pass in flight.  The
+    // spare set is not in the arena and stays where it is; the bodies of the last pass may still be on their way to the
+    // host out of the OLD layout, so what is enqueued from now on waits for that copy.
+    const MachineWorkspace::SpareRecords sp = w->spare;
+    const int slot = w->rec_slot;
+    const PrepDevice* prep = w->prep;
+    int rc = workspace_ensure(ctx, sp.logh, std::max(sp.n, sp.batch_hint), sp.cap_cycles, sp.cap_keccak, sp.cap_memfinal, sp.cap_muls,
+                              sp.cap_alu, sp.cap_sub, sp.cap_bw, sp.cap_agg, sp.cap_fold, /*in_flight=*/true);
+    if (rc) return rc;
+    w = ctx->mws.get();
+    w->prep = prep;
+    w->rec_slot = slot;
+    w->spare = sp;  // (swap_records below makes it the resident set; what it leaves in `spare` is stale and n = 0)
+    if (ctx->body_free) ZKSP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->body_free, 0));
   }
   swap_records(w);
   w->spare.n = 0;
@@ -690,11 +744,27 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
   if (logh[kCpu] > 20) return ctx->fail(9, "machine_load: more than 2^21 cycles");
   if (into_spare) {
     MachineWorkspace* w0 = ctx->mws.get();
-    if (!w0 || memcmp(w0->logh, logh, sizeof w0->logh) != 0 || (size_t)w0->batch < n || !ctx->copy_stream)
-      return ctx->fail(1, "machine_load: the spare set takes batches of the resident heights only");
+    if (!w0 || !ctx->copy_stream) return ctx->fail(1, "machine_load: the spare set needs a resident batch and a copy stream");
+    // the spare set's own capacities and place (any shape); the buffer it goes to was the resident set two loads ago
+    MachineWorkspace::SpareRecords& sp = w0->spare;
+    memcpy(sp.logh, logh, sizeof sp.logh);
+    sp.cap_cycles = cc; sp.cap_keccak = std::max<size_t>(ck, 1); sp.cap_memfinal = cm; sp.cap_muls = std::max<size_t>(cu, 1);
+    sp.cap_alu = std::max<size_t>(ca, 1); sp.cap_sub = std::max<size_t>(cs, 1); sp.cap_bw = std::max<size_t>(cb, 1);
+    sp.cap_agg = std::max<size_t>(cg, 2); sp.cap_fold = std::max<size_t>(cf, 2);
+    sp.batch_hint = ctx->spare_batch_hint;
+    rc = records_ensure(ctx, w0->rec_slot ^ 1, records_place(&sp, nullptr, n, logh));
+    if (rc) return rc;
+    records_place(&sp, ctx->rec_arena[w0->rec_slot ^ 1], n, logh);
   } else {
     rc = workspace_ensure(ctx, logh, (int)std::max<size_t>(n, (size_t)ctx->batch_hint), cc, ck, cm, cu, ca, cs, cb, cg, cf);
     if (rc) return rc;
+    MachineWorkspace* w0 = ctx->mws.get();
+    // (the buffer may be in use by a pass that reads the last resident batch: this path is the synchronous one)
+    if (ctx->rec_bytes[w0->rec_slot] < records_place(w0, nullptr, n, logh)) ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    rc = records_ensure(ctx, w0->rec_slot, records_place(w0, nullptr, n, logh));
+    if (rc) return rc;
+    records_place(w0, ctx->rec_arena[w0->rec_slot], n, logh);
+    w0->spare.n = 0;
   }
   MachineWorkspace* w = ctx->mws.get();
   w->prep = prep;
@@ -708,7 +778,7 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
   if (into_spare) swap_records(w);
   // host staging that outlives the call (an upload into the spare set is not waited for here): the previous load into this
   // record set has long completed
-  MachineWorkspace::LoadStage& st = w->stage[into_spare ? 1 : 0];
+  MachineWorkspace::LoadStage& st = w->stage[w->rec_slot];  // (after the swap above: the buffer being written)
   std::vector<uint32_t>&counts = st.counts, &nperms = st.nperms, &obs = st.obs, &pubw = st.pubw;
   std::vector<uint64_t>& kst = st.kst;
   std::vector<std::vector<uint32_t>>& agg_heaps = st.agg_heaps;

@@ -51,7 +51,13 @@ struct MachineWorkspace {
     uint64_t* kstates = nullptr;
     uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;
     int n = 0;
+    // its own shape: a chunk of other chip heights than the resident batch's is uploaded while that batch is proven, and
+    // machine_activate_spare lays the arena out for it
+    int logh[mach::kNumChips] = {0};
+    size_t cap_cycles = 0, cap_keccak = 0, cap_memfinal = 0, cap_muls = 0, cap_alu = 0, cap_sub = 0, cap_bw = 0, cap_agg = 0, cap_fold = 0;
+    int batch_hint = 0;
   } spare;
+  int rec_slot = 0;  // Context::rec_arena[rec_slot] holds the resident records, the other one the spare set
   // Host-side staging of a load (counts, transcript words, keccak states, node rows): kept until the next load into the
   // same record set, because an upload into the spare set is not waited for by the host.
   struct LoadStage {
@@ -102,12 +108,13 @@ int machine_prep_ensure(Context* ctx, const MachineProgram& prog, const MachineV
 // sizes the workspace for `n` traces and uploads their records.  The batch is proven with ONE shape (chip heights):
 // `shape` if given (every trace must fit it), else the heights of the element-wise maximum of the traces' counts.
 // With `into_spare` the upload goes to the spare record set on the copy stream (the resident batch and a proving pass
-// in flight are untouched; the shape must be the resident batch's).  With `loaded` (spare loads only) the call does not
+// in flight are untouched; the shape may be another one than the resident batch's).  With `loaded` (spare loads only) the call does not
 // wait for the copies: it records `loaded` behind them on the copy stream - the caller keeps the traces alive until the
 // event has passed - and machine_activate_spare makes the proving stream wait for it.
 int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const MachineTrace* const* traces, size_t n,
                  bool into_spare = false, const int* shape = nullptr, hipEvent_t loaded = nullptr);
-// makes the spare record set the resident batch (call when no proving pass is in flight)
+// makes the spare record set the resident batch; if its shape is another one the arena is laid out again (passes already
+// enqueued are unaffected: they hold their pointers, and the stream orders what reuses the memory behind them)
 int machine_activate_spare(Context* ctx);
 // enqueues the whole proving pass over the resident batch
 int machine_prove_resident(Context* ctx);
