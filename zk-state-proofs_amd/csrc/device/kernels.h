@@ -138,7 +138,8 @@ int reduce_nchunks(int width);  // column chunks -> size of ReduceArgs::partial
 // tw_inv: [H/2] (powers of w_H^-1, H the ORIGINAL height); xinv_c[2] = (shift_k * w_{2Hk}^c)^-1
 void launch_fri_fold(hipStream_t stream, const uint32_t* in, size_t in_stride, uint32_t* out, size_t out_stride,
                      const uint32_t* beta, size_t beta_stride, const uint32_t* tw_inv, int tw_shift, uint32_t xinv0,
-                     uint32_t xinv1, int loghk, int batch);
+                     uint32_t xinv1, int loghk, int batch, const uint32_t* join = nullptr, size_t join_stride = 0);
+// (`join`: [batch][2][Hk/2] Fp4 added to the folded layer - the machine proof's reduced opening of that height)
 // leaves of layer k: (f[c][m], f[c][m+Hk/2]) -> tree [batch][2*Hk-1][8], full tree built
 // Commit, transcript and fold of the FRI layers k_start .. logh-1 (each of at most 512 leaves)
 // in one launch, one workgroup per proof.  loff_start / toff_start: words into a proof's layer

@@ -149,10 +149,15 @@ __global__ __launch_bounds__(kTopThreads) void compress_subtree_kernel(uint32_t*
   coop_subtree_levels(tree + (size_t)blockIdx.y * tree_stride, in_off, count, (int)blockIdx.x, kSubtree, cc, consts);
 }
 
+// (from the layer of `count` digests that starts `off` digests into the tree)
+static void launch_upper_layers_from(hipStream_t stream, size_t off, int count, uint32_t* tree, size_t tree_stride, int batch,
+                                     const P2Consts* consts);
 static void launch_upper_layers(hipStream_t stream, int logn, uint32_t* tree, size_t tree_stride, int batch,
                                 const P2Consts* consts) {
-  size_t off = 0;
-  int count = 1 << logn;
+  launch_upper_layers_from(stream, 0, 1 << logn, tree, tree_stride, batch, consts);
+}
+static void launch_upper_layers_from(hipStream_t stream, size_t off, int count, uint32_t* tree, size_t tree_stride, int batch,
+                                     const P2Consts* consts) {
   // A batch of a few proofs: the levels are a chain of launches that each leave most of the GPU idle - climb eight levels
   // per launch, a subtree per workgroup, while the layer is wide enough (the cooperative permutation does twice the
   // arithmetic, which a small batch does not feel).
@@ -224,9 +229,44 @@ __global__ __launch_bounds__(kHashThreads) void fri_leaf_kernel(const uint32_t* 
   d[1] = make_uint4(s[4].v, s[5].v, s[6].v, s[7].v);
 }
 
+// A small batch's wide layer: a workgroup hashes the 256 leaves of its subtree (cooperative form) and climbs the eight
+// levels above them in the same launch (fri_leaf_kernel + compress_subtree_kernel, one launch less per layer).
+__global__ __launch_bounds__(kTopThreads) void fri_subtree_kernel(const uint32_t* __restrict__ layer, size_t layer_stride, int loghk,
+                                                                 uint32_t* __restrict__ tree, size_t tree_stride,
+                                                                 const P2Consts* __restrict__ consts) {
+  const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const CoopConsts cc = coop_load_consts(consts, e);
+  const uint32_t* f = layer + (size_t)blockIdx.y * layer_stride;
+  uint32_t* t = tree + (size_t)blockIdx.y * tree_stride;
+  const int hk = 1 << loghk, half = hk >> 1, leaf0 = (int)blockIdx.x * kSubtree;
+  for (int l0 = 0; l0 < kSubtree; l0 += kTopGroups) {
+    const int leaf = leaf0 + l0 + grp;  // (hk is a multiple of kSubtree here)
+    const int c = leaf >= half ? 1 : 0, m = leaf - c * half;
+    Fp x = Fp::zero();
+    if (e < 8) x = Fp::raw(f[((size_t)c * hk + m + (e >= 4 ? half : 0)) * 4 + (e & 3)]);
+    x = p2_permute_coop(x, cc, consts);
+    if (e < 8) t[(size_t)leaf * 8 + e] = x.v;
+  }
+  __threadfence_block();
+  __syncthreads();
+  coop_subtree_levels(t, 0, hk, (int)blockIdx.x, kSubtree, cc, consts);
+}
+
 void launch_fri_commit(hipStream_t stream, const uint32_t* layer, size_t layer_stride, int loghk, uint32_t* tree,
                        size_t tree_stride, int batch, const P2Consts* consts) {
   const int hk = 1 << loghk;
+  if (batch <= 8 && hk >= 4 * kSubtree) {
+    hipLaunchKernelGGL(fri_subtree_kernel, dim3(hk / kSubtree, batch), dim3(kTopThreads), 0, stream, layer, layer_stride, loghk, tree,
+                       tree_stride, consts);
+    size_t off = 0;
+    int count = hk;
+    for (int l = 0; l < kSubtreeLog; ++l) {
+      off += (size_t)count;
+      count >>= 1;
+    }
+    launch_upper_layers_from(stream, off, count, tree, tree_stride, batch, consts);
+    return;
+  }
   // small layer: one cooperative workgroup per proof, unless the batch makes it wide (then one lane
   // per leaf / per parent does half the arithmetic and fills the chip)
   if (hk <= 2 * kHashThreads && (size_t)hk * (size_t)batch < 32768) {

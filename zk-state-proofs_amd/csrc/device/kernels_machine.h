@@ -100,8 +100,22 @@ struct PermArgs {
   size_t cum_bstride;
   uint32_t h_inv;                  // 1 / H (Montgomery): the running sum steps by rowsum - cum / H, cyclically
   int logh, batch;
+  int blk0;                        // (tables of launch_perm_multi: the task's first workgroup in its launch)
 };
 void launch_perm_trace(hipStream_t stream, const PermArgs& a);
+// A small batch's LogUp stage over device tables (every chip needs its own rowsum / slice_sums scratch then): tasks[0] the
+// CPU instances, [1] the other chips' terms, [2] the sliced scans, [3] the single-workgroup scans; a chip with many
+// interactions takes launch_perm_terms_split by itself, before the scans.
+struct PermMulti {
+  const PermArgs* tasks[4];
+  int n[4], blocks[4];
+};
+int perm_task_kinds(const PermArgs& a);          // bits: 1 CPU terms, 2 generic terms, 4 split terms, 8 sliced scan, 16 scan
+int perm_task_blocks(const PermArgs& a, int kind_bit);
+void launch_perm_multi_cpu_terms(hipStream_t stream, const PermMulti& m);
+void launch_perm_multi_terms(hipStream_t stream, const PermMulti& m);
+void launch_perm_multi_scans(hipStream_t stream, const PermMulti& m);  // after every term kernel
+void launch_perm_terms_split(hipStream_t stream, const PermArgs& a);
 // public terms of the two verifier-closed buses: out[b] = -(sum over the 16 digest words and the exit code of 1/f)
 // per proof: pv digest 8, deferred digest 8, exit code (canonical), then the CpuPub words of the two CPU instances (Montgomery)
 constexpr int kPubWords = 17 + mach::kNumCpuInst * mach::kNumCpuPub;

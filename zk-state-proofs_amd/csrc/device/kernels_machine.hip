@@ -1115,12 +1115,11 @@ __device__ __forceinline__ void batch_inverse(Fp4* f) {
 // slots of group G (cpu_group_lo .. cpu_group_hi): their helper columns (the last slot has none) and their share of the
 // row sum, which accumulates over the three launches
 template <int G>
-__global__ __launch_bounds__(kMT) void perm_terms_cpu_kernel(PermArgs a) {
+__device__ __forceinline__ void perm_terms_cpu_body(const PermArgs& a, int bx, int b) {
   constexpr int J0 = cpu_group_lo(G), J1 = cpu_group_hi(G), NF = 2 * (J1 - J0);
   const size_t h = (size_t)1 << a.logh;
-  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
+  const size_t r = (size_t)bx * kMT + threadIdx.x;
   if (r >= h) return;
-  const int b = blockIdx.y;
   const Fp4 gamma = m_load_fp4(a.bus_ch + (size_t)b * 8);
   const uint32_t* bpow = a.bpow + (size_t)b * (kInterMaxElems + 1) * 4;
   uint32_t* p = a.perm + (size_t)b * a.perm_bstride + r;
@@ -1146,11 +1145,10 @@ __global__ __launch_bounds__(kMT) void perm_terms_cpu_kernel(PermArgs a) {
   m_store_fp4(rs, tot);
 }
 
-__global__ __launch_bounds__(kMT) void perm_terms_kernel(PermArgs a) {
+__device__ __forceinline__ void perm_terms_body(const PermArgs& a, int bx, int b) {
   const size_t h = (size_t)1 << a.logh;
-  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
+  const size_t r = (size_t)bx * kMT + threadIdx.x;
   if (r >= h) return;
-  const int b = blockIdx.y;
   RowView rv{a.prep.width ? a.prep.p + (size_t)b * a.prep.bstride + r : nullptr, a.main_.p + (size_t)b * a.main_.bstride + r,
              a.prep.width, h};
   const Fp4 gamma = m_load_fp4(a.bus_ch + (size_t)b * 8);
@@ -1225,10 +1223,10 @@ __global__ __launch_bounds__(kMT) void perm_terms_split_kernel(PermArgs a) {
 }
 
 // one workgroup per proof: total of the row sums -> cum; phi_0 = 0, phi_{r+1} = phi_r + rowsum_r - cum / H
-__global__ __launch_bounds__(kMT) void perm_scan_kernel(PermArgs a) {
+__device__ __forceinline__ void perm_scan_body(const PermArgs& a, int b) {
   __shared__ Fp4 part[kMT];
   const size_t h = (size_t)1 << a.logh;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const size_t chunk = (h + kMT - 1) / kMT;
   const size_t r0 = (size_t)tid * chunk, r1 = r0 + chunk < h ? r0 + chunk : h;
   const uint32_t* tm = a.rowsum + (size_t)b * h * 4;
@@ -1275,20 +1273,19 @@ __device__ __forceinline__ Fp4 m_block_sum_fwd(Fp4 v, Fp4* red) {
 // pass 2 gives a workgroup the total of the slices before its own (and of all, for the step cum / H) and scans the slice.  Field addition is
 // exact and associative, so the columns equal the single-workgroup scan's.
 constexpr int kScanSlice = 4096;
-__global__ __launch_bounds__(kMT) void perm_slice_sum_kernel(PermArgs a, uint32_t* __restrict__ slice_sums, int nslices) {
+__device__ __forceinline__ void perm_slice_sum_body(const PermArgs& a, uint32_t* __restrict__ slice_sums, int nslices, int g, int b) {
   __shared__ Fp4 red[kMT / 64];
   const size_t h = (size_t)1 << a.logh;
-  const int g = blockIdx.x, b = blockIdx.y;
   const uint32_t* tm = a.rowsum + ((size_t)b * h + (size_t)g * kScanSlice) * 4;
   Fp4 local = Fp4::zero();
   for (int r = threadIdx.x; r < kScanSlice; r += kMT) local += m_load_fp4(tm + (size_t)r * 4);
   const Fp4 tot = m_block_sum_fwd(local, red);
   if (threadIdx.x == 0) m_store_fp4(slice_sums + ((size_t)b * nslices + g) * 4, tot);
 }
-__global__ __launch_bounds__(kMT) void perm_slice_scan_kernel(PermArgs a, const uint32_t* __restrict__ slice_sums, int nslices) {
+__device__ __forceinline__ void perm_slice_scan_body(const PermArgs& a, const uint32_t* __restrict__ slice_sums, int nslices, int g, int b) {
   __shared__ Fp4 part[kMT];
   const size_t h = (size_t)1 << a.logh;
-  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   // offset = total of the slices before this one, total = of all of them (at most 512: one strided pass + a block sum each)
   Fp4 before = Fp4::zero(), all = Fp4::zero();
   for (int i = tid; i < nslices; i += kMT) {
@@ -1350,6 +1347,86 @@ __global__ __launch_bounds__(kMT) void perm_slice_scan_kernel(PermArgs a, const 
     carry += blk - round_step;
   }
   if (g == 0 && tid == 0) m_store_fp4(a.cum + (size_t)b * a.cum_bstride, total);
+}
+
+template <int G>
+__global__ __launch_bounds__(kMT) void perm_terms_cpu_kernel(PermArgs a) { perm_terms_cpu_body<G>(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(kMT) void perm_terms_kernel(PermArgs a) { perm_terms_body(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(kMT) void perm_scan_kernel(PermArgs a) { perm_scan_body(a, blockIdx.x); }
+__global__ __launch_bounds__(kMT) void perm_slice_sum_kernel(PermArgs a, uint32_t* __restrict__ slice_sums, int nslices) {
+  perm_slice_sum_body(a, slice_sums, nslices, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(kMT) void perm_slice_scan_kernel(PermArgs a, const uint32_t* __restrict__ slice_sums, int nslices) {
+  perm_slice_scan_body(a, slice_sums, nslices, blockIdx.x, blockIdx.y);
+}
+
+// ---- a small batch's LogUp stage: one launch per kind of kernel over device tables of PermArgs (PermArgs::blk0 = the
+// task's first workgroup in that launch), instead of three launches per chip on three lanes (90 launches, 0.57 ms of a
+// single proof).  The bodies are the single-chip kernels', so the columns are the same words. ----
+__device__ __forceinline__ const PermArgs& perm_task_of(const PermArgs* __restrict__ tasks, int n, int blk) {
+  int t = 0;
+  while (t + 1 < n && blk >= tasks[t + 1].blk0) ++t;
+  return tasks[t];
+}
+template <int G>
+__global__ __launch_bounds__(kMT) void perm_terms_cpu_multi_kernel(const PermArgs* __restrict__ tasks, int n) {
+  const PermArgs& a = perm_task_of(tasks, n, blockIdx.x);
+  const int local = blockIdx.x - a.blk0, nb = (int)((((size_t)1 << a.logh) + kMT - 1) / kMT);
+  perm_terms_cpu_body<G>(a, local % nb, local / nb);
+}
+__global__ __launch_bounds__(kMT) void perm_terms_multi_kernel(const PermArgs* __restrict__ tasks, int n) {
+  const PermArgs& a = perm_task_of(tasks, n, blockIdx.x);
+  const int local = blockIdx.x - a.blk0, nb = (int)((((size_t)1 << a.logh) + kMT - 1) / kMT);
+  perm_terms_body(a, local % nb, local / nb);
+}
+__global__ __launch_bounds__(kMT) void perm_scan_multi_kernel(const PermArgs* __restrict__ tasks, int n) {
+  const PermArgs& a = perm_task_of(tasks, n, blockIdx.x);
+  perm_scan_body(a, blockIdx.x - a.blk0);
+}
+__global__ __launch_bounds__(kMT) void perm_slice_sum_multi_kernel(const PermArgs* __restrict__ tasks, int n) {
+  const PermArgs& a = perm_task_of(tasks, n, blockIdx.x);
+  const int local = blockIdx.x - a.blk0, nslices = (int)(((size_t)1 << a.logh) / kScanSlice);
+  perm_slice_sum_body(a, a.slice_sums, nslices, local % nslices, local / nslices);
+}
+__global__ __launch_bounds__(kMT) void perm_slice_scan_multi_kernel(const PermArgs* __restrict__ tasks, int n) {
+  const PermArgs& a = perm_task_of(tasks, n, blockIdx.x);
+  const int local = blockIdx.x - a.blk0, nslices = (int)(((size_t)1 << a.logh) / kScanSlice);
+  perm_slice_scan_body(a, a.slice_sums, nslices, local % nslices, local / nslices);
+}
+// which launches a chip's LogUp trace takes (launch_perm_trace's choices): bit 0 the CPU kernels, bit 1 the generic terms,
+// bit 2 the split terms (its own launch), bit 3 the sliced scan, bit 4 the single-workgroup scan
+int perm_task_kinds(const PermArgs& a) {
+  const size_t h = (size_t)1 << a.logh;
+  int k = is_cpu_chip(a.chip) ? 1 : (a.n_inter >= 16 && h * (size_t)a.batch <= 32768) ? 4 : 2;
+  k |= (h >= (size_t)4 * kScanSlice && a.slice_sums) ? 8 : 16;
+  return k;
+}
+int perm_task_blocks(const PermArgs& a, int kind_bit) {
+  const size_t h = (size_t)1 << a.logh;
+  if (kind_bit == 1 || kind_bit == 2) return (int)((h + kMT - 1) / kMT) * a.batch;
+  if (kind_bit == 8) return (int)(h / kScanSlice) * a.batch;
+  return a.batch;
+}
+// (the three kinds of term kernels are independent of one another - the caller may put them on three streams - and the
+// scans follow all of them)
+void launch_perm_multi_cpu_terms(hipStream_t stream, const PermMulti& m) {
+  if (!m.n[0]) return;
+  hipLaunchKernelGGL(perm_terms_cpu_multi_kernel<0>, dim3(m.blocks[0]), dim3(kMT), 0, stream, m.tasks[0], m.n[0]);
+  hipLaunchKernelGGL(perm_terms_cpu_multi_kernel<1>, dim3(m.blocks[0]), dim3(kMT), 0, stream, m.tasks[0], m.n[0]);
+}
+void launch_perm_multi_terms(hipStream_t stream, const PermMulti& m) {
+  if (m.n[1]) hipLaunchKernelGGL(perm_terms_multi_kernel, dim3(m.blocks[1]), dim3(kMT), 0, stream, m.tasks[1], m.n[1]);
+}
+void launch_perm_multi_scans(hipStream_t stream, const PermMulti& m) {
+  if (m.n[2]) {
+    hipLaunchKernelGGL(perm_slice_sum_multi_kernel, dim3(m.blocks[2]), dim3(kMT), 0, stream, m.tasks[2], m.n[2]);
+    hipLaunchKernelGGL(perm_slice_scan_multi_kernel, dim3(m.blocks[2]), dim3(kMT), 0, stream, m.tasks[2], m.n[2]);
+  }
+  if (m.n[3]) hipLaunchKernelGGL(perm_scan_multi_kernel, dim3(m.blocks[3]), dim3(kMT), 0, stream, m.tasks[3], m.n[3]);
+}
+void launch_perm_terms_split(hipStream_t stream, const PermArgs& a) {
+  const size_t h = (size_t)1 << a.logh;
+  hipLaunchKernelGGL(perm_terms_split_kernel, dim3((unsigned)((h + 31) / 32), a.batch), dim3(kMT), 0, stream, a);
 }
 
 void launch_perm_trace(hipStream_t stream, const PermArgs& a) {

@@ -1043,7 +1043,8 @@ __global__ __launch_bounds__(kThreads) void fri_fold_kernel(const uint32_t* __re
                                                            uint32_t* __restrict__ out, size_t out_stride,
                                                            const uint32_t* __restrict__ beta, size_t beta_stride,
                                                            const uint32_t* __restrict__ tw_inv, int tw_shift,
-                                                           uint32_t xinv0, uint32_t xinv1, int loghk) {
+                                                           uint32_t xinv0, uint32_t xinv1, int loghk,
+                                                           const uint32_t* __restrict__ join, size_t join_stride) {
   const int hk = 1 << loghk, half = hk >> 1;
   const int i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= hk) return;  // 2 cosets * half
@@ -1055,15 +1056,17 @@ __global__ __launch_bounds__(kThreads) void fri_fold_kernel(const uint32_t* __re
   Fp xinv = Fp::raw(c ? xinv1 : xinv0) * Fp::raw(tw_inv[(size_t)m << tw_shift]);
   Fp4 be = load_fp4(beta + (size_t)b * beta_stride);
   Fp4 r = (lo + hi) * inv2 + be * ((lo - hi) * (inv2 * xinv));
+  // (`join`: the reduced opening of the height the folded layer has reached, same layout: added here instead of by a launch)
+  if (join) r += load_fp4(join + (size_t)b * join_stride + ((size_t)c * half + m) * 4);
   store_fp4(out + (size_t)b * out_stride + ((size_t)c * half + m) * 4, r);
 }
 
 void launch_fri_fold(hipStream_t stream, const uint32_t* in, size_t in_stride, uint32_t* out, size_t out_stride,
                      const uint32_t* beta, size_t beta_stride, const uint32_t* tw_inv, int tw_shift, uint32_t xinv0,
-                     uint32_t xinv1, int loghk, int batch) {
+                     uint32_t xinv1, int loghk, int batch, const uint32_t* join, size_t join_stride) {
   const int hk = 1 << loghk;
   hipLaunchKernelGGL(fri_fold_kernel, dim3((hk + kThreads - 1) / kThreads, batch), dim3(kThreads), 0, stream, in,
-                     in_stride, out, out_stride, beta, beta_stride, tw_inv, tw_shift, xinv0, xinv1, loghk);
+                     in_stride, out, out_stride, beta, beta_stride, tw_inv, tw_shift, xinv0, xinv1, loghk, join, join_stride);
 }
 
 // ===========================================================================

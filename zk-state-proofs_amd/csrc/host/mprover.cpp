@@ -634,6 +634,18 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
       A(&w->mr_segs, (size_t)4 * kNumChips);
       A(&w->mr_chips, (size_t)kNumChips);
       A(&w->mr_bsum, B * 32 * 2 * 4);
+      {
+        // the LogUp stage's tables, and row sums / slice sums of every chip at once (batches of at most kSideMaxBatch proofs)
+        const size_t Bsm = std::min<size_t>(B, Context::kSideMaxBatch);
+        size_t rows = 0, slices = 0;
+        for (int c = 0; c < kNumChips; ++c) {
+          rows += (size_t)1 << logh[c];
+          slices += (((size_t)1 << logh[c]) / 4096 + 1);
+        }
+        A(&w->perm_tasks, (size_t)4 * kNumChips);
+        A(&w->perm_rowsum_all, Bsm * rows * 4);
+        A(&w->perm_slices_all, Bsm * slices * 4);
+      }
       w->open_tasks_batch = -1;
     }
     w->fri_layer_stride = 0;
@@ -1032,7 +1044,11 @@ int machine_prove_resident(Context* ctx) {
   // ---- LogUp permutation traces ----
   {
     ProfileSpan sp(ctx, "m_perm");
-    fork.begin();
+    const bool tabled = fork.lanes > 1;  // small batches: one launch per kind of kernel over tables (launch_perm_multi)
+    const bool build = tabled && w->perm_tasks_batch != B;
+    std::vector<PermArgs> kinds[4], split;
+    size_t row_off = 0, slice_off = 0;
+    if (!tabled) fork.begin();
     for (int c = 0; c < kNumChips; ++c) {
       const ChipDef& d = chip_def(c);
       PermArgs pa;
@@ -1047,15 +1063,62 @@ int machine_prove_resident(Context* ctx) {
       pa.perm_width = d.perm_width();
       pa.perm_bstride = (size_t)d.perm_width() * H(c);
       pa.h_inv = Fp::from_canonical((uint32_t)(H(c) % kP)).inv().v;
-      pa.rowsum = chip_scratch(c, w->rowsum, w->side_rowsum);
-      pa.slice_sums = chip_scratch(c, w->slice_sums, w->side_slice_sums);
+      pa.rowsum = tabled ? w->perm_rowsum_all + row_off : chip_scratch(c, w->rowsum, w->side_rowsum);
+      pa.slice_sums = tabled ? w->perm_slices_all + slice_off : chip_scratch(c, w->slice_sums, w->side_slice_sums);
+      row_off += (size_t)B * H(c) * 4;
+      slice_off += (size_t)B * (H(c) / 4096 + 1) * 4;
       pa.cum = w->cum + 4 * c;
       pa.cum_bstride = (size_t)4 * kNumChips;
       pa.logh = logh[c];
       pa.batch = B;
-      launch_perm_trace(SC(c), pa);
+      pa.blk0 = 0;
+      if (!tabled) {
+        launch_perm_trace(SC(c), pa);
+        continue;
+      }
+      const int k = perm_task_kinds(pa);
+      if (k & 4) split.push_back(pa);  // (a launch of its own; its scan is in the tables)
+      if (build) {
+        if (k & 1) kinds[0].push_back(pa);
+        if (k & 2) kinds[1].push_back(pa);
+        if (k & 8) kinds[2].push_back(pa);
+        if (k & 16) kinds[3].push_back(pa);
+      }
     }
-    fork.end();
+    if (tabled) {
+      if (build) {
+        static const int bit[4] = {1, 2, 8, 16};
+        w->perm_tasks_host.clear();
+        for (int q = 0; q < 4; ++q) {
+          w->perm_n[q] = (int)kinds[q].size();
+          w->perm_blocks[q] = 0;
+          for (PermArgs& t : kinds[q]) {
+            t.blk0 = w->perm_blocks[q];
+            w->perm_blocks[q] += perm_task_blocks(t, bit[q]);
+            w->perm_tasks_host.push_back(t);
+          }
+        }
+        ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->perm_tasks, w->perm_tasks_host.data(), w->perm_tasks_host.size() * sizeof(PermArgs),
+                                           hipMemcpyHostToDevice, s));
+        w->perm_tasks_batch = B;
+      }
+      PermMulti pm;
+      const PermArgs* base = w->perm_tasks;
+      for (int q = 0; q < 4; ++q) {
+        pm.tasks[q] = base;
+        pm.n[q] = w->perm_n[q];
+        pm.blocks[q] = w->perm_blocks[q];
+        base += w->perm_n[q];
+      }
+      // the CPU instances' terms, the other chips' and the many-interaction chip's side by side, then the scans
+      fork.begin();
+      launch_perm_multi_cpu_terms(fork.lane(0), pm);
+      launch_perm_multi_terms(fork.lane(1 % fork.lanes), pm);
+      for (const PermArgs& t : split) launch_perm_terms_split(fork.lane(2 % fork.lanes), t);
+      fork.end();
+      launch_perm_multi_scans(s, pm);
+    }
+    if (!tabled) fork.end();
   }
   {
     ProfileSpan sp(ctx, "m_lde_perm");
@@ -1347,8 +1410,8 @@ int machine_prove_resident(Context* ctx) {
       ProfileSpan sp(ctx, "fri_fold");
       uint32_t* nxt = w->fri_layers + loff + 2 * hk * 4;
       launch_fri_fold(s, w->fri_layers + loff, w->fri_layer_stride, nxt, w->fri_layer_stride, w->betas + (size_t)k * 4,
-                      (size_t)lm * 4, dmax->tw_inv, k, dmax->fold_xinv[2 * k], dmax->fold_xinv[2 * k + 1], loghk, B);
-      if (loghk - 1 >= 0 && w->G[loghk - 1]) launch_fri_add(s, nxt, w->fri_layer_stride, w->G[loghk - 1], hk * 4, hk, B);
+                      (size_t)lm * 4, dmax->tw_inv, k, dmax->fold_xinv[2 * k], dmax->fold_xinv[2 * k + 1], loghk, B,
+                      loghk - 1 >= 0 ? w->G[loghk - 1] : nullptr, hk * 4);  // (the input of that height joins in the same launch)
     }
     loff += 2 * hk * 4;
     toff += 2 * hk - 1;

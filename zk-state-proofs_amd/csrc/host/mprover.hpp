@@ -99,6 +99,11 @@ struct MachineWorkspace {
   std::vector<MRSeg> mr_segs_host;
   std::vector<MRChip> mr_chips_host;
   int mr_blocks = 0;
+  // ... and its LogUp stage (kernels_machine.h PermMulti): four tables of PermArgs, every chip with its own row sums
+  PermArgs* perm_tasks = nullptr;
+  uint32_t *perm_rowsum_all = nullptr, *perm_slices_all = nullptr;
+  std::vector<PermArgs> perm_tasks_host;
+  int perm_n[4] = {0}, perm_blocks[4] = {0}, perm_tasks_batch = -1;
   std::vector<void*> allocs;
   ~MachineWorkspace();
 };
