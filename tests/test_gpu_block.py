@@ -40,6 +40,13 @@ def test_block_receipt_trie_batch(zk, oracle):
         cpu_rows = lambda hs: sum(1 << hs[zk.MACHINE_CHIP_NAMES.index(n)] for n in ("cpu", "cpu2", "cpu3", "cpu4", "cpu5", "cpu6", "cpu7", "cpu8"))
         assert all(cpu_rows(shape) + 8 * 32 >= cpu_rows(handles[i].heights()) // 2 for i in idx)  # (no run was squeezed into a smaller shape)
     assert 1 <= len(groups) <= len({tuple(h.heights()) for h in handles})
+    # A chunk of another shape is uploaded while the one before it is proven, and the arena is laid out for it behind the
+    # pass in flight (api_prove.cpp, machine_activate_spare): the LAST proof of every shape is the oracle's, byte for byte
+    for shape, idx in groups.items():
+        s = zk.SP1Stdin()
+        s.write(mpt.block_proof_input(trie, idx[-1]).to_borsh())
+        trace = client.machine_trace(pk, s)
+        assert proofs[idx[-1]].to_bytes() == oracle.machine_prove(dict(trace, shape=list(shape))), shape
 
 
 def test_storage_proof_composition(zk, oracle):
@@ -77,7 +84,17 @@ def test_full_block_receipt_trie(zk, oracle):
     for i in range(0, len(proofs), 7):  # the host verifier on a spread of them (each is ~1.5 MB of checks)
         client.verify(proofs[i], vk)
     # long receipts need more keccak-f permutations, more cycles, more memory: several height groups in one call
-    assert len({p.to_bytes()[8:8 + 4 * zk.MACHINE_CHIPS] for p in proofs}) >= 2
+    shapes = {}
+    for i, p in enumerate(proofs):
+        raw = p.to_bytes()
+        shapes.setdefault(tuple(int.from_bytes(raw[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)), []).append(i)
+    assert len(shapes) >= 2
+    # ... each uploaded while the chunk before it - of another shape - was being proven: the last proof of every shape equals
+    # the oracle's for that shape
+    for shape, idx in shapes.items():
+        s = zk.SP1Stdin()
+        s.write(mpt.block_proof_input(trie, idx[-1]).to_borsh())
+        assert proofs[idx[-1]].to_bytes() == oracle.machine_prove(dict(client.machine_trace(pk, s), shape=list(shape))), shape
 
 
 def test_batch_of_256_storage_slots(zk, oracle):
