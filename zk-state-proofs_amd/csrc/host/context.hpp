@@ -89,6 +89,10 @@ struct Context {
   // GPU one after the other - at batch <= kSideMaxBatch the per-chip loops of a pass fan out over the side streams, by
   // chip height, and join again at the end of the stage (mprover.cpp StageFork).
   // (two side streams: the runtime maps streams onto four hardware queues by default, and the copy stream wants one)
+  // (kSideMaxBatch: measured at 32, 64 and 128 too - resident passes of 9 .. 48 proofs gain 2-19 % from the lanes, the
+  // crossover with the one-lane path is near 64 - but prove_batch, whose chunks are uploaded and fetched on the copy stream
+  // meanwhile, LOSES: slot-d5x256 436 -> 350 proofs/s, acct-d8x1024 304 -> 288 at 64.  Eight keeps the lanes to the latency
+  // case they were built for.)
   static constexpr int kSideStreams = 2, kSideMaxBatch = 8;
   hipStream_t side[kSideStreams] = {nullptr, nullptr};
   hipEvent_t fork_ev = nullptr, join_ev[kSideStreams] = {nullptr, nullptr};

@@ -627,7 +627,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
       for (int c = 0; c < kNumChips; ++c)
         if (logh[c] >= 12)
           for (int wdt : {chip_def(c).prep_w, chip_def(c).main_w, chip_def(c).perm_width(), quot_width(logh, c) ? 4 : 0, quot_width(logh, c) ? 4 : 0})
-            if (wdt) words += open_tall_scratch_words(wdt, logh[c], 8);
+            if (wdt) words += open_tall_scratch_words(wdt, logh[c], Context::kSideMaxBatch);
       A(&w->open_partial, words);
       A(&w->open_tasks, (size_t)5 * kNumChips);
       A(&w->mr_heights, (size_t)32);
