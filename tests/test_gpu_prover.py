@@ -222,3 +222,39 @@ def test_benchmarked_configuration_matches_oracle_and_verifies(zk, fx, oracle):
     # a body attached to another proof's inputs must not verify
     with pytest.raises(zk.ZkspError):
         host.verify(zk.proof_from_body(bodies[5], logh, states[6], 0, pv, pvd, [0] * 8, vkw), vk)
+
+
+def test_batch_with_panicking_runs_in_a_mixed_call(zk, fx, oracle):
+    """prove_batch over runs of several shapes, chunked (max_batch 2: every chunk is uploaded behind the one before it, of
+    whatever shape), with two runs whose guest panics in the middle: their status is the guest's exit and they have no proof
+    (the reference's run() fails for such an input, prover/src/bin/main.rs:71-74), every other run has a proof that verifies
+    with the right public values, and one proof behind each failed run is the oracle's byte for byte."""
+    from oracle import verify_merkle_proof
+    client = zk.ProverClient(device=0, num_queries=6, pow_bits=5, max_batch=2)
+    pk, vk = client.setup(zk.merkle_elf())
+    inputs = [fx.acct_fixture(1, seed=3), fx.tx_fixture(), fx.acct_fixture(2, seed=5), fx.slot_fixture(0), fx.acct_fixture(1, seed=4),
+              fx.receipt_fixture(5), fx.acct_fixture(2, seed=6), fx.slot_fixture(1), fx.acct_fixture(1, seed=9)]
+    broken = (2, 5)
+    for k in broken:
+        node = bytearray(inputs[k].proof[-1])
+        node[-1] ^= 1
+        inputs[k].proof[-1] = bytes(node)
+    stdins = []
+    for m in inputs:
+        s = zk.SP1Stdin()
+        s.write(m.to_borsh())
+        stdins.append(s)
+    proofs, status = client.prove_batch(pk, stdins)
+    for i, (m, p, st) in enumerate(zip(inputs, proofs, status)):
+        if i in broken:
+            assert st != 0 and p is None
+            continue
+        assert st == 0
+        assert p.public_values == verify_merkle_proof(m.root_hash, m.proof, m.key)
+        client.verify(p, vk)
+    for i in (3, 6, 8):
+        s = zk.SP1Stdin()
+        s.write(inputs[i].to_borsh())
+        raw = proofs[i].to_bytes()
+        shape = [int.from_bytes(raw[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
+        assert raw == oracle.machine_prove(dict(client.machine_trace(pk, s), shape=shape), num_queries=6, pow_bits=5)
