@@ -21,6 +21,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 namespace zksp {
@@ -666,7 +667,11 @@ static void launch_lde_tall(hipStream_t stream, const uint32_t* in, uint32_t* co
   // quotient chunks alternate tables every 4 columns)
   if (slab_mb) slab = std::min<size_t>(slab, std::max<size_t>(8, ((slab_mb << 20) / (16 * h)) & ~(size_t)7));
   // TIMING ONLY (wrong results): what the strided top passes cost a step, i.e. the most a whole-column kernel could save
-  static const bool skip_top_env = getenv("ZKSP_LDE_SKIP_TOP_TIMING_ONLY") != nullptr;
+  static const bool skip_top_env = [] {
+    const bool on = getenv("ZKSP_LDE_SKIP_TOP_TIMING_ONLY") != nullptr;
+    if (on) fprintf(stderr, "zksp: ZKSP_LDE_SKIP_TOP_TIMING_ONLY is set - the LDEs of this process are WRONG (timing experiment); no proof it makes verifies\n");
+    return on;
+  }();
   const bool skip_top = skip_top_env && ncols >= 32;  // (not the preprocessed tables: their commitment is checked against the key)
   for (size_t c0 = 0; c0 < ncols; c0 += slab) {
     const size_t nc = ncols - c0 < slab ? ncols - c0 : slab;
