@@ -266,8 +266,8 @@ int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const 
  * (8 canonical u32 each). */
 int zksp_vk_machine(const zksp_vk* vk, uint32_t* prep_root8, uint32_t* digest8);
 
-/* ---- device-resident hot path (bench.py, parity tests) ---- */
-/* Proof-system parameters this build uses (for sizing buffers). */
+/* ---- device-resident hot path (bench.py, parity tests): zksp_hip_machine_* above; parameters, timing, profile ---- */
+/* Proof-system parameters this build uses (for sizing buffers; the two widths are the keccak chip's). */
 typedef struct {
   uint32_t trace_width;       /* 2633 */
   uint32_t num_constraints;   /* 3182 */
@@ -276,31 +276,10 @@ typedef struct {
   uint32_t max_batch;
 } zksp_params;
 int zksp_get_params(const zksp_client* c, zksp_params* out);
-size_t zksp_proof_body_words(const zksp_client* c, int log_h);
-
-/* Uploads a batch of keccak-f permutation inputs and transcript headers into the
- * client's HBM workspace: states [n][max_perms][25] u64 (row-major), n_perms [n],
- * init_obs [n][44] canonical u32 (vk digest, log_h, n_perms, exit code halves,
- * pv-digest halves, deferred-digest halves).  After this call the inputs are
- * resident; zksp_hip_prove_resident() can be timed on its own. */
-int zksp_hip_load_batch(zksp_client* c, int log_h, size_t n, size_t max_perms, const uint64_t* states,
-                        const uint32_t* n_perms, const uint32_t* init_obs);
-/* Enqueues one full proving pass over the resident batch on the client's stream
- * (trace generation -> proof bodies in HBM).  Asynchronous. */
-int zksp_hip_prove_resident(zksp_client* c);
-/* Copies proof bodies [n][body_words] (canonical u32) to the host; synchronises. */
-int zksp_hip_fetch_bodies(zksp_client* c, uint32_t* out, size_t cap_words);
-/* Copies only the 8-word main-trace commitment of every resident proof ([n][8],
- * canonical u32): the 32 bytes per proof the multi-GPU farm all-gathers. */
-int zksp_hip_fetch_roots(zksp_client* c, uint32_t* out, size_t cap_words);
-/* Wraps one fetched body (zksp_hip_fetch_bodies) into a complete proof object: header,
- * public values and the public I/O list (input state and keccak-f of it per permutation)
- * are rebuilt from the same inputs zksp_hip_load_batch was given.  What zksp_prove does
- * for its own batches, exposed so that callers of the resident path (bench.py, tests) can
- * run zksp_verify on what they timed. */
-int zksp_proof_from_body(const uint32_t* body, size_t body_words, uint32_t log_h, const uint64_t* states, uint32_t n_perms,
-                         uint32_t exit_code, const uint8_t* public_values, size_t pv_len, const uint32_t* pv_digest,
-                         const uint32_t* deferred_digest, const uint32_t* vk_digest, zksp_proof** out);
+/* The round-1 keccak-chip COMPONENT proofs (format v2: "these keccak-f outputs belong to these inputs", not a proof of
+ * execution) are a kernel benchmark and a test vehicle, not part of the drop-in surface: their entry points
+ * (zksp_hip_load_batch, zksp_hip_prove_resident, zksp_hip_fetch_bodies, zksp_hip_fetch_roots, zksp_proof_from_body,
+ * zksp_proof_body_words) are declared in zksp_component.h.  A default client neither makes nor accepts such proofs. */
 int zksp_hip_sync(zksp_client* c);
 /* HIP-event timing on the client's own stream. */
 int zksp_hip_timer_start(zksp_client* c);

@@ -1,5 +1,6 @@
-"""The C-ABI library loads without a GPU and exports every symbol include/zksp.h
-declares; the HIP path fails loudly (no CPU fallback) when no GPU is present."""
+"""The C-ABI library loads without a GPU and exports every symbol include/*.h
+declares (zksp.h: the drop-in surface and the machine-proof entry points; zksp_component.h: the keccak-chip component
+path kept for benchmarks and tests); the HIP path fails loudly (no CPU fallback) when no GPU is present."""
 import ctypes as C
 import os
 import re
@@ -10,9 +11,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "zksp.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(zksp_[a-z0-9_]+)\s*\(", text)))
+    names = set()
+    inc = os.path.join(ROOT, "include")
+    for f in sorted(os.listdir(inc)):
+        if not f.endswith(".h"):
+            continue
+        text = open(os.path.join(inc, f)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(zksp_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_the_component_path_is_not_in_the_drop_in_header():
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "zksp.h")).read(), flags=re.S)
+    for n in ("zksp_hip_load_batch", "zksp_hip_prove_resident", "zksp_proof_from_body", "zksp_hip_fetch_bodies"):
+        assert n not in text, n
 
 
 def test_every_declared_symbol_is_exported(zk, built_lib):
@@ -27,7 +40,7 @@ def test_every_declared_symbol_is_exported(zk, built_lib):
 
 def test_header_compiles_as_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "zksp.h"\nint main(void){ zksp_options o = {0}; (void)o; return ZKSP_OK; }\n')
+    src.write_text('#include "zksp.h"\n#include "zksp_component.h"\nint main(void){ zksp_options o = {0}; (void)o; return ZKSP_OK; }\n')
     assert os.system(f"gcc -std=c99 -Wall -Werror -I{ROOT}/include -c {src} -o {tmp_path}/t.o") == 0
 
 

@@ -1,5 +1,6 @@
 // C ABI of include/zksp.h.  Nothing here throws across the boundary.
 #include "../../../include/zksp.h"
+#include "../../../include/zksp_component.h"
 
 #include <algorithm>
 #include <atomic>

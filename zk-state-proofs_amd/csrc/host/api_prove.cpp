@@ -8,6 +8,7 @@
 // so that neither the executor nor the proof assembly sits on the critical path
 // once a few waves are in flight.
 #include "../../../include/zksp.h"
+#include "../../../include/zksp_component.h"
 
 #include <algorithm>
 #include <array>
