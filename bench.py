@@ -342,7 +342,35 @@ def leaf_check_mode(zk, fx, client, pk, vk, payload):
     raw = outer.to_bytes()
     shape = [int.from_bytes(raw[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
     prove_ms, plain_ms = sorted(times)[1], sorted(plain)[1]
-    return {"poseidon2_rows": rows, "fold_rows": folds, "public_tuples": tuples,
+    # the node of a recursion tree of arity 4: ONE run that checks four leaf proofs (zksp_stdin_add_verified_leaf)
+    arity = 4
+    more = [leaf]
+    for k in range(1, arity):
+        sk = zk.SP1Stdin()
+        sk.write(fx.acct_fixture(8, seed=4000 + k).to_borsh())
+        more.append(client.prove(pk, sk).run())
+    node_times, node_log = [], 0.0
+    node = None
+    for _ in range(2):
+        s4 = zk.SP1Stdin()
+        s4.write(payload)
+        t1 = time.perf_counter()
+        for lf in more:
+            client.add_verified_leaf(s4, lf, vk)
+        node_log = (time.perf_counter() - t1) * 1e3
+        t1 = time.perf_counter()
+        node = client.prove(pk, s4).run()
+        node_times.append((time.perf_counter() - t1) * 1e3)
+    host.verify_with_leaves(node, vk, more, [vk] * arity)
+    nraw = node.to_bytes()
+    nshape = [int.from_bytes(nraw[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
+    node_ms = min(node_times)
+    tree_node = {"leaves": arity, "poseidon2_chip_log_height": nshape[zk.MACHINE_CHIP_NAMES.index("poseidon2")],
+                 "host_log_ms": node_log, "prove_end_to_end_ms": node_ms,
+                 "ms_per_verified_leaf": (node_ms - plain_ms + node_log) / arity, "proof_bytes": len(nraw),
+                 "statement": "one run whose proof establishes the query phases of four leaf proofs (the leaves' public tuples one "
+                              "leaf after the other); verified on the host with the four leaves"}
+    return {"poseidon2_rows": rows, "fold_rows": folds, "public_tuples": tuples, "tree_node_of_4": tree_node,
             "poseidon2_chip_log_height": shape[zk.MACHINE_CHIP_NAMES.index("poseidon2")],
             "fold_chip_log_height": shape[zk.MACHINE_CHIP_NAMES.index("fri-fold")],
             "host_log_ms": log_ms, "prove_end_to_end_ms": prove_ms, "plain_prove_end_to_end_ms": plain_ms,

@@ -119,6 +119,12 @@ int zksp_stdin_set_aggregation(zksp_stdin* s, const uint32_t* leaves /* [n][8] *
  * rows, the siblings and the pairs are the prover's witnesses.  The call verifies `leaf` on the host first and fails
  * (ZKSP_ERR_VERIFY) if it does not verify: an honest prover has nothing to prove about a bad leaf.  leaf NULL clears. */
 int zksp_stdin_set_verified_leaf(zksp_client* c, zksp_stdin* s, const zksp_proof* leaf, const zksp_vk* leaf_vk);
+/* ... and one more: the proof made from this stdin checks the query phases of ALL the leaves added so far (the node of a
+ * recursion tree of that arity: config 5's 1024 leaf proofs are 128 such proofs of eight leaves each).  The k-th leaf's
+ * queries are numbered from k * num_queries on - tags, the query ids of the fold rows and of the public tuples - so the
+ * checks share the Poseidon2 and fold chips without sharing a tag; the statement is the leaves' public tuples one leaf
+ * after the other, in this order (zksp_leaves_public, zksp_verify_with_leaves). */
+int zksp_stdin_add_verified_leaf(zksp_client* c, zksp_stdin* s, const zksp_proof* leaf, const zksp_vk* leaf_vk);
 
 /* replaces client.prove(&pk, stdin).run()  (main.rs:71-74).  `stdin` is consumed
  * (emptied) as in the reference; pk is borrowed.  A guest panic (reference:
@@ -249,6 +255,11 @@ int zksp_verify_aggregate_keyed(zksp_client* c, const zksp_proof* p, const zksp_
 int zksp_leaf_public(zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf_vk, uint32_t* out, size_t cap_words, size_t* n_tuples);
 int zksp_verify_public(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const uint32_t* tuples, size_t n_tuples);
 int zksp_verify_with_leaf(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const zksp_proof* leaf, const zksp_vk* leaf_vk);
+/* the same for a proof that checks n leaves (zksp_stdin_add_verified_leaf), given in the order they were added */
+int zksp_leaves_public(zksp_client* c, const zksp_proof* const* leaves, const zksp_vk* const* leaf_vks, size_t n, uint32_t* out,
+                       size_t cap_words, size_t* n_tuples);
+int zksp_verify_with_leaves(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const zksp_proof* const* leaves,
+                            const zksp_vk* const* leaf_vks, size_t n);
 int zksp_proof_public_tuples(const zksp_proof* p, uint32_t* n_tuples, uint32_t* digest8);
 /* Kernel-level parity (tests): after zksp_hip_machine_prove, one intermediate matrix of resident proof `proof_index`, as
  * canonical u32, column-major [width][2^log_height]: stage 0 = a chip's main trace (trace expansion kernels; table chip:

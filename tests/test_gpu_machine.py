@@ -381,6 +381,33 @@ def test_leaf_check_matches_oracle(zk, fx, oracle):
     assert again.public_tuples == proofs[0].public_tuples
 
 
+def test_two_leaf_checks_match_oracle(zk, fx, oracle):
+    """Several leaves beside one run (zksp_stdin_add_verified_leaf: the node of a recursion tree of that arity): the device's
+    proof with the query phases of TWO leaf proofs - of different shapes - is the oracle's byte for byte, verifies with the
+    leaves in the order they were added and not in the other."""
+    nq, pw = 8, 6
+    client = zk.ProverClient(device=0, num_queries=nq, pow_bits=pw, max_batch=2)
+    pk, vk = client.setup(zk.merkle_elf())
+    leaves = []
+    for m in (fx.acct_fixture(1, seed=60), fx.slot_fixture(0)):
+        s = zk.SP1Stdin()
+        s.write(m.to_borsh())
+        leaves.append(client.prove(pk, s).run())
+    s = zk.SP1Stdin()
+    s.write(fx.acct_fixture(1, seed=61).to_borsh())
+    for lf in leaves:
+        client.add_verified_leaf(s, lf, vk)
+    trace = client.machine_trace(pk, s)
+    assert sorted(set(int(q) for q in trace["leaf_fold_rows"][:, 1])) == list(range(2 * nq))
+    proof = client.prove(pk, s).run()
+    raw = proof.to_bytes()
+    assert raw == oracle.machine_prove(dict(trace, shape=shape_of(zk, raw)), num_queries=nq, pow_bits=pw)
+    host = zk.ProverClient(device=-1, num_queries=nq, pow_bits=pw)
+    host.verify_with_leaves(proof, vk, leaves, [vk, vk])
+    with pytest.raises(zk.VerificationError):
+        host.verify_with_leaves(proof, vk, leaves[::-1], [vk, vk])
+
+
 def test_rv32m_guest_matches_oracle(zk, oracle):
     """Format v15's rows for mulh / mulhsu (multiplier chip) and div / divu / rem / remu (divider chip): the committed guest
     executes none of them, so a hand-assembled guest does, on the spec's corner cases (tests/test_rv32m.py).  The device's

@@ -274,3 +274,73 @@ def test_structural_forgeries_are_refused(zk, oracle, setup):
     rows[last - 1, 0] |= 32
     refused(rows)
     assert (kinds == K_J).sum() >= 2  # (the opening does have several injections)
+
+
+# ---- several leaves beside one run (zksp_stdin_add_verified_leaf): the node of a recursion tree of that arity ----
+@pytest.fixture(scope="module")
+def two_leaves(zk, fx, built_lib, oracle, setup):
+    client, pk, vk, leaf_a, _, _, _ = setup
+    s = zk.SP1Stdin()
+    s.write(fx.slot_fixture(0).to_borsh())
+    leaf_b = zk.SP1ProofWithPublicValues.from_bytes(oracle.machine_prove(client.machine_trace(pk, s), num_queries=NQ, pow_bits=POW))
+    client.verify(leaf_b, vk)
+    s2 = zk.SP1Stdin()
+    s2.write(fx.acct_fixture(1, seed=3).to_borsh())
+    client.add_verified_leaf(s2, leaf_a, vk)
+    client.add_verified_leaf(s2, leaf_b, vk)
+    t = client.machine_trace(pk, s2)
+    outer = oracle.machine_prove(t, num_queries=NQ, pow_bits=POW)
+    return client, pk, vk, leaf_a, leaf_b, t, outer
+
+
+def test_two_leaves_are_checked_by_one_proof(zk, two_leaves, setup):
+    client, pk, vk, leaf_a, leaf_b, t, outer = two_leaves
+    proof = zk.SP1ProofWithPublicValues.from_bytes(outer)
+    one = setup[5]
+    # the second leaf's rows follow the first one's; its queries are numbered from NQ on (tags 1 + 64 q + r, fold rows, tuples)
+    n1 = len(one["leaf_p2_rows"])
+    assert np.array_equal(t["leaf_p2_rows"][:n1], one["leaf_p2_rows"]) and len(t["leaf_p2_rows"]) > n1
+    assert np.array_equal(t["leaf_fold_rows"][:len(one["leaf_fold_rows"])], one["leaf_fold_rows"])
+    second = t["leaf_fold_rows"][len(one["leaf_fold_rows"]):]
+    assert sorted(set(int(q) for q in second[:, 1])) == list(range(NQ, 2 * NQ))
+    tags = t["leaf_p2_rows"][n1:, 1]
+    assert int(tags.min()) >= 1 + 64 * NQ and len(set(int(x) for x in t["leaf_p2_rows"][:n1, 1]) & set(int(x) for x in tags)) == 0
+    # the statement: the two leaves' tuples one after the other, in the order they were added
+    tuples = client.leaves_public([leaf_a, leaf_b], [vk, vk])
+    assert np.array_equal(tuples, t["leaf_pub_tuples"])
+    assert np.array_equal(tuples[:len(one["leaf_pub_tuples"])], client.leaf_public(leaf_a, vk))
+    assert proof.public_tuples[0] == len(tuples)
+    client.verify_with_leaves(proof, vk, [leaf_a, leaf_b], [vk, vk])
+    client.verify_public(proof, vk, tuples)
+    # the chips grew with the work: twice the permutations, twice the folds
+    hts = [int.from_bytes(outer[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
+    h1 = [int.from_bytes(setup[6][8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
+    p2 = zk.MACHINE_CHIP_NAMES.index("poseidon2")
+    assert hts[p2] >= h1[p2] and (1 << hts[p2]) >= len(t["leaf_p2_rows"])
+
+
+def test_other_leaves_another_order_or_one_leaf_less_are_refused(zk, two_leaves):
+    client, pk, vk, leaf_a, leaf_b, t, outer = two_leaves
+    proof = zk.SP1ProofWithPublicValues.from_bytes(outer)
+    for leaves in ([leaf_b, leaf_a], [leaf_a], [leaf_b], [leaf_a, leaf_a], [leaf_a, leaf_b, leaf_a]):
+        with pytest.raises(zk.VerificationError):
+            client.verify_with_leaves(proof, vk, leaves, [vk] * len(leaves))
+    with pytest.raises(zk.VerificationError):
+        client.verify_with_leaf(proof, vk, leaf_a, vk)
+    with pytest.raises(zk.VerificationError):
+        client.verify(proof, vk)
+
+
+def test_a_tampered_second_leaf_check_is_refused(zk, oracle, two_leaves, setup):
+    """An opened word of the SECOND leaf changed in the records: the honest oracle refuses, a forced proof is rejected (the
+    first leaf's check being intact does not help)."""
+    client, pk, vk, leaf_a, leaf_b, t, outer = two_leaves
+    n1 = len(setup[5]["leaf_p2_rows"])
+    rows = t["leaf_p2_rows"].copy()
+    k = n1 + int(np.nonzero((rows[n1:, 0] & 15) == 2)[0][5])  # a first sponge block of the second leaf
+    rows[k, 4 + 2] = (int(rows[k, 4 + 2]) + 1) % P
+    t2 = dict(t, leaf_p2_rows=rows)
+    with pytest.raises(RuntimeError):
+        oracle.machine_prove(t2, num_queries=NQ, pow_bits=POW)
+    with pytest.raises(zk.VerificationError):
+        client.verify_with_leaves(zk.SP1ProofWithPublicValues.from_bytes(forced(oracle, t2)), vk, [leaf_a, leaf_b], [vk, vk])

@@ -157,6 +157,9 @@ def load_library() -> C.CDLL:
     lib.zksp_stdin_set_aggregation_keyed.argtypes = [vp, vp, vp, sz]
     lib.zksp_verify_aggregate_keyed.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.zksp_stdin_set_verified_leaf.argtypes = [vp, vp, vp, vp]
+    lib.zksp_stdin_add_verified_leaf.argtypes = [vp, vp, vp, vp]
+    lib.zksp_leaves_public.argtypes = [vp, vp, vp, sz, vp, sz, C.POINTER(sz)]
+    lib.zksp_verify_with_leaves.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.zksp_leaf_public.argtypes = [vp, vp, vp, vp, sz, C.POINTER(sz)]
     lib.zksp_verify_public.argtypes = [vp, vp, vp, vp, sz]
     lib.zksp_verify_with_leaf.argtypes = [vp, vp, vp, vp, vp]
@@ -203,7 +206,7 @@ ABI_SYMBOLS = [
     "zksp_execute", "zksp_execute_keccak", "zksp_opcode_name", "zksp_machine_trace", "zksp_mtrace_free",
     "zksp_mtrace_section", "zksp_mtrace_info", "zksp_vk_machine", "zksp_mtrace_heights", "zksp_machine_body_words",
     "zksp_machine_chip_widths", "zksp_machine_cover_heights", "zksp_stdin_set_aggregation", "zksp_proof_aggregation", "zksp_verify_aggregate",
-    "zksp_stdin_set_aggregation_keyed", "zksp_verify_aggregate_keyed", "zksp_stdin_set_verified_leaf", "zksp_leaf_public", "zksp_verify_public",
+    "zksp_stdin_set_aggregation_keyed", "zksp_verify_aggregate_keyed", "zksp_stdin_set_verified_leaf", "zksp_stdin_add_verified_leaf", "zksp_leaves_public", "zksp_verify_with_leaves", "zksp_leaf_public", "zksp_verify_public",
     "zksp_verify_with_leaf", "zksp_proof_public_tuples", "zksp_hip_machine_fetch_stage", "zksp_hip_machine_fetch_challenges",
     "zksp_hip_machine_load", "zksp_hip_machine_prove", "zksp_hip_release_workspace", "zksp_hip_machine_fetch_bodies", "zksp_hip_machine_fetch_roots", "zksp_machine_proof_from_body", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
     "zksp_hip_prove_resident", "zksp_proof_from_body", "zksp_hip_fetch_bodies", "zksp_hip_fetch_roots", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
@@ -499,6 +502,41 @@ class ProverClient:
         rc = self._lib.zksp_stdin_set_verified_leaf(self._h, stdin._h, leaf._h, leaf_vk._h)
         if rc:
             raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
+
+    def add_verified_leaf(self, stdin: SP1Stdin, leaf: SP1ProofWithPublicValues, leaf_vk: VerifyingKey) -> None:
+        """One more leaf-proof check beside the run (``zksp_stdin_add_verified_leaf``): the proof made from ``stdin`` establishes
+        the query phases of ALL leaves added so far - the node of a recursion tree of that arity.  Its statement is the leaves'
+        public tuples one leaf after the other, in the order they were added (``leaves_public``, ``verify_with_leaves``)."""
+        rc = self._lib.zksp_stdin_add_verified_leaf(self._h, stdin._h, leaf._h, leaf_vk._h)
+        if rc:
+            raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
+
+    def _handle_arrays(self, leaves, leaf_vks):
+        n = len(leaves)
+        if n == 0 or len(leaf_vks) != n:
+            raise ValueError("as many verifying keys as leaves, and at least one")
+        return (C.c_void_p * n)(*[p._h for p in leaves]), (C.c_void_p * n)(*[v._h for v in leaf_vks]), n
+
+    def leaves_public(self, leaves, leaf_vks):
+        """The statement of a proof that checks several leaves (``zksp_leaves_public``): numpy [n][16] canonical words."""
+        import numpy as np
+        pa, va, k = self._handle_arrays(leaves, leaf_vks)
+        n = C.c_size_t()
+        rc = self._lib.zksp_leaves_public(self._h, pa, va, k, None, 0, C.byref(n))
+        if rc:
+            raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
+        out = np.zeros((n.value, PUB_TUPLE_WORDS), np.uint32)
+        rc = self._lib.zksp_leaves_public(self._h, pa, va, k, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n))
+        if rc:
+            raise ZkspError(rc, self.last_error())
+        return out
+
+    def verify_with_leaves(self, proof: SP1ProofWithPublicValues, vk: VerifyingKey, leaves, leaf_vks) -> None:
+        """``verify`` for a proof that checks several leaves: its statement is the one these leaves give, in this order."""
+        pa, va, k = self._handle_arrays(leaves, leaf_vks)
+        rc = self._lib.zksp_verify_with_leaves(self._h, proof._h, vk._h, pa, va, k)
+        if rc:
+            raise VerificationError(rc, self.last_error())
 
     def leaf_public(self, leaf: SP1ProofWithPublicValues, leaf_vk: VerifyingKey):
         """The statement of a leaf-proof check (``zksp_leaf_public``): the public bus tuples, numpy [n][16] canonical words."""

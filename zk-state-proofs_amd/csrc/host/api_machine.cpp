@@ -346,14 +346,21 @@ int zksp_verify_aggregate_keyed(zksp_client* c, const zksp_proof* p, const zksp_
 }
 
 // ---- leaf-proof check (stage 2a) ----
-static int leaf_check_of(zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf_vk, std::shared_ptr<LeafCheckLog>* out) {
+// (`index`: the leaf's place among the leaves checked beside one run - its queries are numbered from index * num_queries on)
+static int leaf_check_of(zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf_vk, std::shared_ptr<LeafCheckLog>* out,
+                         uint32_t index = 0) {
   if (c->ctx.params.proof_mode != ZKSP_PROOF_MACHINE || leaf->version != mach::kMachineVersion)
     return c->ctx.fail(ZKSP_ERR_VERIFY, "leaf check: not a machine proof");
   if (leaf->mhdr.agg_n || leaf->mhdr.pub_n) return c->ctx.fail(ZKSP_ERR_UNSUPPORTED, "leaf check: the leaf proof carries a payload of its own");
+  // (tags are field elements: 1 + 64 * query number + round)
+  if ((uint64_t)(index + 1) * c->ctx.params.num_queries * mach::kLeafTagStride >= 0x78000000ull)
+    return c->ctx.fail(ZKSP_ERR_UNSUPPORTED, "leaf check: too many leaves for the tag space");
   std::string err;
   int rc;
   try {
     auto log = std::make_shared<LeafCheckLog>();
+    log->query_base = index * c->ctx.params.num_queries;
+    log->n_leaves = 1;
     rc = verify_machine_proof(leaf->bytes.data(), leaf->bytes.size(), leaf_vk->machine, c->ctx.params.num_queries, c->ctx.params.pow_bits,
                               &err, nullptr, 0, nullptr, nullptr, 0, log.get());
     if (rc == 0) *out = std::move(log);
@@ -373,6 +380,78 @@ int zksp_stdin_set_verified_leaf(zksp_client* c, zksp_stdin* s, const zksp_proof
   if (rc) return rc;
   s->leaf_check = std::move(log);
   return ZKSP_OK;
+}
+
+// the checks of several leaves beside one run: the logs one after the other, in the order the leaves were added
+static int leaves_check_of(zksp_client* c, const zksp_proof* const* leaves, const zksp_vk* const* leaf_vks, size_t n,
+                           std::shared_ptr<LeafCheckLog>* out) {
+  auto all = std::make_shared<LeafCheckLog>();
+  for (size_t k = 0; k < n; ++k) {
+    if (!leaves[k] || !leaf_vks[k]) return ZKSP_ERR_INVALID_ARG;
+    std::shared_ptr<LeafCheckLog> one;
+    const int rc = leaf_check_of(c, leaves[k], leaf_vks[k], &one, (uint32_t)k);
+    if (rc) return rc;
+    all->p2_rows.insert(all->p2_rows.end(), one->p2_rows.begin(), one->p2_rows.end());
+    all->fold_rows.insert(all->fold_rows.end(), one->fold_rows.begin(), one->fold_rows.end());
+    all->pub_tuples.insert(all->pub_tuples.end(), one->pub_tuples.begin(), one->pub_tuples.end());
+  }
+  all->n_leaves = (uint32_t)n;
+  *out = std::move(all);
+  return ZKSP_OK;
+}
+
+int zksp_stdin_add_verified_leaf(zksp_client* c, zksp_stdin* s, const zksp_proof* leaf, const zksp_vk* leaf_vk) {
+  if (!c || !s || !leaf || !leaf_vk) return ZKSP_ERR_INVALID_ARG;
+  const uint32_t have = s->leaf_check ? s->leaf_check->n_leaves : 0;
+  std::shared_ptr<LeafCheckLog> one;
+  const int rc = leaf_check_of(c, leaf, leaf_vk, &one, have);
+  if (rc) return rc;
+  try {
+    auto all = std::make_shared<LeafCheckLog>();
+    if (s->leaf_check) *all = *s->leaf_check;
+    all->p2_rows.insert(all->p2_rows.end(), one->p2_rows.begin(), one->p2_rows.end());
+    all->fold_rows.insert(all->fold_rows.end(), one->fold_rows.begin(), one->fold_rows.end());
+    all->pub_tuples.insert(all->pub_tuples.end(), one->pub_tuples.begin(), one->pub_tuples.end());
+    all->query_base = 0;
+    all->n_leaves = have + 1;
+    s->leaf_check = std::move(all);
+  } catch (...) {
+    return c->ctx.fail(ZKSP_ERR_VERIFY, "leaf check: out of memory");
+  }
+  return ZKSP_OK;
+}
+
+int zksp_leaves_public(zksp_client* c, const zksp_proof* const* leaves, const zksp_vk* const* leaf_vks, size_t n, uint32_t* out,
+                       size_t cap_words, size_t* n_tuples) {
+  if (!c || !leaves || !leaf_vks || !n || !n_tuples) return ZKSP_ERR_INVALID_ARG;
+  std::shared_ptr<LeafCheckLog> log;
+  int rc;
+  try {
+    rc = leaves_check_of(c, leaves, leaf_vks, n, &log);
+  } catch (...) {
+    return c->ctx.fail(ZKSP_ERR_VERIFY, "leaf check: out of memory");
+  }
+  if (rc) return rc;
+  *n_tuples = log->pub_tuples.size() / mach::kPubTupleWords;
+  if (out) {
+    if (cap_words < log->pub_tuples.size()) return c->ctx.fail(ZKSP_ERR_INVALID_ARG, "leaves_public: buffer too small");
+    memcpy(out, log->pub_tuples.data(), log->pub_tuples.size() * 4);
+  }
+  return ZKSP_OK;
+}
+
+int zksp_verify_with_leaves(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const zksp_proof* const* leaves,
+                            const zksp_vk* const* leaf_vks, size_t n) {
+  if (!c || !p || !vk || !leaves || !leaf_vks || !n) return ZKSP_ERR_INVALID_ARG;
+  std::shared_ptr<LeafCheckLog> log;
+  int rc;
+  try {
+    rc = leaves_check_of(c, leaves, leaf_vks, n, &log);
+  } catch (...) {
+    return c->ctx.fail(ZKSP_ERR_VERIFY, "leaf check: out of memory");
+  }
+  if (rc) return rc;
+  return zksp_verify_public(c, p, vk, log->pub_tuples.data(), log->pub_tuples.size() / mach::kPubTupleWords);
 }
 
 int zksp_leaf_public(zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf_vk, uint32_t* out, size_t cap_words, size_t* n_tuples) {

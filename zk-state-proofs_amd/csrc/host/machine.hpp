@@ -111,6 +111,9 @@ void PageAllocator<T>::deallocate(T* p, size_t n) noexcept { page_free(p, n * si
 // final constant.  All canonical words.
 struct LeafCheckLog {
   std::vector<uint32_t> p2_rows, fold_rows, pub_tuples;
+  // several leaf proofs checked beside one run: the queries of the k-th leaf are numbered from k * num_queries on (tags,
+  // query ids of the fold rows and of the public tuples), so that the checks share the chips without sharing a tag
+  uint32_t query_base = 0, n_leaves = 0;
 };
 
 struct MachineTrace {

@@ -838,6 +838,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   std::vector<size_t> indices(num_queries);
   for (uint32_t qi = 0; qi < num_queries; ++qi) indices[qi] = ch.sample_bits(lm + 1);
   auto check_query = [&](uint32_t qi, LeafCheckLog* log, std::string* err) -> int {
+    const uint32_t qg = (log ? log->query_base : 0u) + qi;  // the query's number among all leaves checked beside one run
     std::vector<std::vector<Fp>> rows[4];
     for (int r = 0; r < 4; ++r) rows[r].resize(kNumChips);
     const uint32_t* q = p_queries + perq * qi;
@@ -849,7 +850,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
         for (int i = 0; i < shape[r].width[c]; ++i) rows[r][c][i] = Fp::from_canonical(q[i]);
         q += shape[r].width[c];
       }
-      if (!mmcs_verify(shape[r], logh, rows[r], cs, m, q, root[r], kc, log, leaf_tag(qi, (uint32_t)r))) {
+      if (!mmcs_verify(shape[r], logh, rows[r], cs, m, q, root[r], kc, log, leaf_tag(qg, (uint32_t)r))) {
         static const char* names[4] = {"preprocessed", "main", "permutation", "quotient"};
         *err = std::string(names[r]) + " Merkle opening rejected";
         return 8;
@@ -881,7 +882,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     Fp4 expect = reduced(lm);
     auto canon4 = [](const Fp4& v, uint32_t* out) { for (int i = 0; i < 4; ++i) out[i] = v.c[i].to_canonical(); };
     if (log) {  // the reduced opening the folding starts from
-      uint32_t el[6] = {qi, 0};
+      uint32_t el[6] = {qg, 0};
       canon4(expect, el + 2);
       log_pub_tuple(log, BUS_RO, true, el, 6);
     }
@@ -895,7 +896,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       Fp pair[8], cur[8];
       for (int i = 0; i < 4; ++i) { pair[i] = lo.c[i]; pair[4 + i] = hi.c[i]; }
       // the layer's opening: the pair's hash, hashed up to the layer's root (with a log: a run of the Poseidon2 chip)
-      const uint32_t tag = leaf_tag(qi, 4 + (uint32_t)k);
+      const uint32_t tag = leaf_tag(qg, 4 + (uint32_t)k);
       sponge_logged(pair, 8, cur, kc, log, tag, 1, 0, true, false, true);
       uint32_t key = 1;
       const size_t leaf_pos = cs * half + mlo;
@@ -920,17 +921,17 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
         uint32_t el[12] = {tag, 0, key, 0};
         for (int i = 0; i < 8; ++i) el[4 + i] = fri_roots[k][i].to_canonical();
         log_pub_tuple(log, BUS_DIGEST, false, el, 12);
-        uint32_t fq[8] = {qi, (uint32_t)k, mk >= half ? 1u : 0u, xinv.to_canonical()};
+        uint32_t fq[8] = {qg, (uint32_t)k, mk >= half ? 1u : 0u, xinv.to_canonical()};
         canon4(betas[k], fq + 4);
         log_pub_tuple(log, BUS_FRIQ, true, fq, 8);
         if (joins) {
-          uint32_t el2[6] = {qi, (uint32_t)k + 1};
+          uint32_t el2[6] = {qg, (uint32_t)k + 1};
           canon4(ro, el2 + 2);
           log_pub_tuple(log, BUS_RO, true, el2, 6);
         }
         std::vector<uint32_t>& fr = log->fold_rows;
         fr.push_back((k == 0 ? 1u : 0u) | (k == lm - 1 ? 2u : 0u) | (mk >= half ? 4u : 0u) | (joins ? 8u : 0u));
-        fr.push_back(qi); fr.push_back((uint32_t)k); fr.push_back(xinv.to_canonical());
+        fr.push_back(qg); fr.push_back((uint32_t)k); fr.push_back(xinv.to_canonical());
         uint32_t w4[4];
         canon4(betas[k], w4); fr.insert(fr.end(), w4, w4 + 4);
         canon4(lo, w4); fr.insert(fr.end(), w4, w4 + 4);
@@ -942,7 +943,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     }
     if (expect != final_poly) { *err = "FRI final value mismatch"; return 8; }
     if (log) {  // the last folded value is the final constant
-      uint32_t el[6] = {qi, (uint32_t)lm - 1};
+      uint32_t el[6] = {qg, (uint32_t)lm - 1};
       canon4(final_poly, el + 2);
       log_pub_tuple(log, BUS_FIN, false, el, 6);
     }
@@ -952,6 +953,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   std::vector<int> q_rc(num_queries, 0);
   std::vector<std::string> q_err(num_queries);
   std::vector<LeafCheckLog> q_log(log ? num_queries : 0);
+  for (LeafCheckLog& ql : q_log) ql.query_base = log->query_base;
   std::atomic<uint32_t> next_q{0};
   auto worker = [&]() {
     for (uint32_t qi; (qi = next_q.fetch_add(1)) < num_queries;) q_rc[qi] = check_query(qi, log ? &q_log[qi] : nullptr, &q_err[qi]);
