@@ -82,6 +82,12 @@ class _OracleBackedClient:
     def setup(self, elf):
         return self.host.setup(elf)
 
+    def add_verified_leaf(self, stdin, leaf, leaf_vk):
+        return self.host.add_verified_leaf(stdin, leaf, leaf_vk)
+
+    def verify_with_leaves(self, proof, vk, leaves, leaf_vks):
+        return self.host.verify_with_leaves(proof, vk, leaves, leaf_vks)
+
     def prove_batch(self, pk, stdins):
         proofs = []
         for s in stdins:
@@ -155,3 +161,36 @@ def test_prove_sharded_machine_proofs_world2_gloo(tmp_path, zk, fx, oracle):
         assert np.array_equal(farm.trace_root_of(p[0].to_bytes()), got[0][i])
     leaves = np.vstack([got[0], got[0][:1]])
     assert [int(x) for x in np.load(tmp_path / "agg_root.npy")] == oracle.machine_agg_public(leaves)[0]
+
+
+def test_tree_level_of_leaf_checks(zk, fx, oracle):
+    """One level of config 5's recursion tree through the farm's functions (CPU: the oracle proves): five leaf proofs, nodes of
+    arity two (the last node has one leaf), sharded over two ranks in turn; every node verifies with exactly its own leaves."""
+    farm = importlib.import_module("zk-state-proofs_amd.farm")
+    assert farm.tree_node_groups(5, 2) == [[0, 1], [2, 3], [4]] and farm.tree_node_groups(4, 4) == [[0, 1, 2, 3]]
+    client = _OracleBackedClient(zk, oracle, 3, 3)
+    pk, vk = client.setup(zk.merkle_elf())
+    leaf_stdins = []
+    for i in range(5):
+        s = zk.SP1Stdin()
+        s.write(fx.acct_fixture(2, seed=300 + i).to_borsh())  # (depth 2: the seed matters)
+        leaf_stdins.append(s)
+    leaves, status = client.prove_batch(pk, leaf_stdins)
+    assert status == [0] * 5 and len({p.to_bytes() for p in leaves}) == 5
+    nodes = [None] * 3
+    for rank in range(2):
+        node_stdins = []
+        for k in range(3):
+            s = zk.SP1Stdin()
+            s.write(fx.acct_fixture(1, seed=400 + k).to_borsh())
+            node_stdins.append(s)
+        mine, proofs, st = farm.prove_tree_level(client, pk, vk, leaves, node_stdins, 2, rank, 2)
+        assert st == [0] * len(mine) and mine == farm.shard_indices(3, rank, 2)
+        for k, p in zip(mine, proofs):
+            nodes[k] = p
+    farm.verify_tree_level(client, vk, vk, leaves, nodes, 2)
+    # a node does not verify with another node's leaves, and the level does not verify with the leaves in another order
+    with pytest.raises(zk.VerificationError):
+        client.verify_with_leaves(nodes[0], vk, [leaves[2], leaves[3]], [vk, vk])
+    with pytest.raises(zk.VerificationError):
+        farm.verify_tree_level(client, vk, vk, leaves[::-1], nodes, 2)

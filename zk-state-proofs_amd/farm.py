@@ -69,3 +69,40 @@ def prove_sharded(client, pk, stdins: Sequence, rank: int, world: int):
     mine = shard_indices(len(stdins), rank, world)
     proofs, status = client.prove_batch(pk, [stdins[i] for i in mine]) if mine else ([], [])
     return mine, proofs, status
+
+
+def tree_node_groups(n_leaves: int, arity: int) -> List[List[int]]:
+    """The leaves of node k of one level of a recursion tree of that arity: [k * arity, (k + 1) * arity), the last node
+    possibly shorter."""
+    if arity < 1:
+        raise ValueError("arity must be positive")
+    return [list(range(a, min(a + arity, n_leaves))) for a in range(0, n_leaves, arity)]
+
+
+def prove_tree_level(client, pk, leaf_vk, leaves: Sequence, node_stdins: Sequence, arity: int, rank: int, world: int):
+    """One level of BASELINE config 5's recursion tree over the farm (stage 2a): node k is one
+    more guest run (node_stdins[k]) whose proof also checks the query phases of its `arity` leaf proofs
+    (client.add_verified_leaf, in leaf order).  Nodes are independent of one another and shard block-cyclically over the
+    ranks like any other proofs; every rank holds all the leaves (they were all-gathered or are on shared storage - a node's
+    host part verifies its leaves before anything is proven).  Returns (node indices of this rank, their proofs, status)."""
+    groups = tree_node_groups(len(leaves), arity)
+    if len(node_stdins) != len(groups):
+        raise ValueError("one stdin per node")
+    mine = shard_indices(len(groups), rank, world)
+    stdins = []
+    for k in mine:
+        for i in groups[k]:
+            client.add_verified_leaf(node_stdins[k], leaves[i], leaf_vk)
+        stdins.append(node_stdins[k])
+    proofs, status = client.prove_batch(pk, stdins) if mine else ([], [])
+    return mine, proofs, status
+
+
+def verify_tree_level(client, vk, leaf_vk, leaves: Sequence, nodes: Sequence, arity: int) -> None:
+    """Every node proof of a level verifies, with the statement its own leaves give in leaf order (which verifies the leaves
+    on the way: in stage 2a the statement is derived from them)."""
+    groups = tree_node_groups(len(leaves), arity)
+    if len(nodes) != len(groups):
+        raise ValueError("one proof per node")
+    for k, g in enumerate(groups):
+        client.verify_with_leaves(nodes[k], vk, [leaves[i] for i in g], [leaf_vk] * len(g))
