@@ -91,8 +91,9 @@ struct Context {
   // (two side streams: the runtime maps streams onto four hardware queues by default, and the copy stream wants one)
   // (kSideMaxBatch: measured at 32, 64 and 128 too - resident passes of 9 .. 48 proofs gain 2-19 % from the lanes, the
   // crossover with the one-lane path is near 64 - but prove_batch, whose chunks are uploaded and fetched on the copy stream
-  // meanwhile, LOSES: slot-d5x256 436 -> 350 proofs/s, acct-d8x1024 304 -> 288 at 64.  Eight keeps the lanes to the latency
-  // case they were built for.)
+  // meanwhile, LOSES: slot-d5x256 436 -> 350 proofs/s, acct-d8x1024 304 -> 288 at 64; 435 -> 411 and 308 -> 298 at 48, with
+  // GPU_MAX_HW_QUEUES=8 as with the default 4 - it is not a shared hardware queue.  Eight keeps the lanes to the latency case
+  // they were built for.)
   static constexpr int kSideStreams = 2, kSideMaxBatch = 8;
   hipStream_t side[kSideStreams] = {nullptr, nullptr};
   hipEvent_t fork_ev = nullptr, join_ev[kSideStreams] = {nullptr, nullptr};
