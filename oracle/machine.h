@@ -318,9 +318,11 @@ int orc_machine_nodes_public(const uint32_t* keys, const uint32_t* digests, size
  * (key, left child's digest, right child's digest, own digest).  Returns the number of rows, (size_t)-1 if malformed;
  * rows may be NULL. */
 size_t orc_machine_agg_rows(const uint32_t* keys, const uint32_t* digests, size_t n, uint32_t* rows);
-#define ZKSP_VERSION_MACHINE 15u
+#define ZKSP_VERSION_MACHINE 16u
 /* vk: preprocessed commitment root + digest binding entry pc, table heights and keccak mode */
 void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t prep_root[8], uint32_t vk_digest[8]);
+/* coefficients of the reduced openings, one per opened value (mprover.c) */
+void orc_reduce_coefs(const int logh[N_CHIPS], fe4 af, fe4 delta, fe4* out);
 size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_image, const orc_config* cfg, uint32_t pv_len);
 int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_machine_public* pub, const uint8_t* public_values,
                       const orc_config* cfg, uint8_t* out, size_t cap, size_t* out_len);

@@ -589,6 +589,58 @@ void orc_machine_agg_public(const uint32_t* leaves, size_t n, uint32_t root[8], 
   if (!orc_machine_nodes_public(NULL, leaves, n, root, list_digest)) { memset(root, 0, 32); memset(list_digest, 0, 32); }
 }
 
+/* Coefficients of the reduced openings (format v16).  The input of height 2^lh at the LDE point x is
+ *   sum over rounds r of delta^r (H_r(x) - H_r(zeta)) / (x - zeta)  +  sum over r = main, permutation of
+ *   delta^(3 + r) (H_r(x) - H_r(zeta w)) / (x - zeta w),
+ * where H_r is Horner's rule in alpha_f over the SEGMENT (r, lh): the opened rows of the chips of that height in chip order,
+ * zero-filled to a multiple of eight words - exactly the words the opening's sponge absorbs, in the order it absorbs them,
+ * so that a proof ABOUT the opening can accumulate H_r block by block (machine.h, Poseidon2 chip).  Word i of a segment of
+ * n words has the coefficient delta^r alpha_f^(8 ceil(n / 8) - 1 - i).  out[open index]: as the opened values are laid
+ * out (per chip: prep, main, perm, quot at zeta, then main, perm at zeta w). */
+void orc_reduce_coefs(const int logh[N_CHIPS], fe4 af, fe4 delta, fe4* out) {
+  int wr[N_CHIPS][N_ROUNDS];
+  size_t off[N_CHIPS], o = 0;
+  int emax = 0;
+  for (int c = 0; c < N_CHIPS; ++c) {
+    const orc_chip* d = orc_machine_chip(c);
+    wr[c][R_PREP] = d->prep_width; wr[c][R_MAIN] = d->main_width; wr[c][R_PERM] = orc_chip_perm_width(d);
+    wr[c][R_QUOT] = orc_quot_leader(logh, c) == c ? 8 : 0;
+    off[c] = o;
+    o += (size_t)wr[c][R_PREP] + 2 * (size_t)wr[c][R_MAIN] + 2 * (size_t)wr[c][R_PERM] + (size_t)wr[c][R_QUOT];
+  }
+  int seg_len[32][N_ROUNDS];
+  memset(seg_len, 0, sizeof seg_len);
+  for (int c = 0; c < N_CHIPS; ++c)
+    for (int r = 0; r < N_ROUNDS; ++r) seg_len[logh[c]][r] += wr[c][r];
+  for (int l = 0; l < 32; ++l)
+    for (int r = 0; r < N_ROUNDS; ++r)
+      if (seg_len[l][r] > emax) emax = seg_len[l][r];
+  emax += 8;
+  fe4* ap = (fe4*)malloc((size_t)emax * sizeof(fe4));
+  ap[0] = e_one();
+  for (int i = 1; i < emax; ++i) ap[i] = e_mul(ap[i - 1], af);
+  fe4 dp[6];
+  dp[0] = e_one();
+  for (int i = 1; i < 6; ++i) dp[i] = e_mul(dp[i - 1], delta);
+  int pos[32][N_ROUNDS];
+  memset(pos, 0, sizeof pos);
+  for (int c = 0; c < N_CHIPS; ++c) {
+    const int lh = logh[c];
+    size_t i = 0, j = 0;
+    const size_t n1 = (size_t)wr[c][R_PREP] + wr[c][R_MAIN] + wr[c][R_PERM] + wr[c][R_QUOT];
+    for (int r = 0; r < N_ROUNDS; ++r) {
+      const int lpad = (seg_len[lh][r] + 7) / 8 * 8;
+      for (int col = 0; col < wr[c][r]; ++col, ++i) {
+        const fe4 a = ap[lpad - 1 - (pos[lh][r] + col)];
+        out[off[c] + i] = e_mul(dp[r], a);
+        if (r == R_MAIN || r == R_PERM) { out[off[c] + n1 + j] = e_mul(dp[3 + r], a); ++j; }
+      }
+      pos[lh][r] += wr[c][r];
+    }
+  }
+  free(ap);
+}
+
 size_t orc_machine_proof_size(const int logh[N_CHIPS], int log_prog, int log_image, const orc_config* cfg, uint32_t pv_len) {
   (void)log_prog; (void)log_image;
   size_t words = HEADER_WORDS + (pv_len + 3) / 4;
@@ -696,6 +748,7 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   orc_ch_observe(&ch, pub_n);
   orc_ch_observe_many(&ch, pub_digest, 8);
   orc_ch_observe_many(&ch, mmcs_root(&t_main), 8);
+  orc_ch_pad(&ch); /* (v16: a phase ends on a block boundary) */
   put(&pb, mmcs_root(&t_main), 8);
 
   /* ---- round 2: LogUp ---- */
@@ -777,6 +830,7 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
 
   /* ---- round 3: quotients ---- */
   fe4 alpha;
+  orc_ch_pad(&ch);
   orc_ch_sample_ext(&ch, alpha.c);
   for (int c = 0; c < N_CHIPS; ++c) { /* every chip adds its share to the quotient of its height's first chip */
     chipd* d = &cd[c];
@@ -814,12 +868,12 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   put(&pb, (const uint32_t*)opened, n_open * 4);
   observe_list_root(&ch, (const uint32_t*)opened, n_open * 4, ceil_log2((n_open * 4 + 7) / 8));
 
-  /* ---- reduced openings, one input per height ---- */
-  fe4 af;
+  /* ---- reduced openings, one input per height (v16: orc_reduce_coefs) ---- */
+  fe4 af, delta;
   orc_ch_sample_ext(&ch, af.c);
+  orc_ch_sample_ext(&ch, delta.c);
   fe4* afpow = (fe4*)malloc(n_open * sizeof(fe4));
-  afpow[0] = e_one();
-  for (size_t i = 1; i < n_open; ++i) afpow[i] = e_mul(afpow[i - 1], af);
+  orc_reduce_coefs(logh, af, delta, afpow);
   fe4* G[32];
   memset(G, 0, sizeof G);
   for (int c = 0; c < N_CHIPS; ++c) {
@@ -901,8 +955,9 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   for (int l = 0; l < 32; ++l) free(G[l]);
 
   /* ---- proof of work, queries ---- */
-  uint32_t witness = orc_ch_grind(&ch, (int)cfg->pow_bits);
+  uint32_t witness = orc_ch_grind_padded(&ch, (int)cfg->pow_bits);
   put(&pb, &witness, 1);
+  orc_ch_drop_outputs(&ch); /* (v16: the query indices start from a fresh squeeze) */
   const size_t hmax = (size_t)1 << lm;
   for (uint32_t q = 0; q < cfg->num_queries; ++q) {
     const size_t idx = orc_ch_sample_bits(&ch, lm + 1);

@@ -208,3 +208,20 @@ uint32_t orc_ch_grind(orc_challenger* c, int bits) {
   }
   return 0xffffffffu;
 }
+
+void orc_ch_pad(orc_challenger* c) {
+  while (c->n_in != 0) orc_ch_observe(c, 0);
+}
+void orc_ch_drop_outputs(orc_challenger* c) { c->n_out = 0; }
+uint32_t orc_ch_grind_padded(orc_challenger* c, int bits) {
+  for (uint32_t w = 0; w < FP; ++w) {
+    orc_challenger t = *c;
+    orc_ch_observe(&t, w);
+    orc_ch_pad(&t);
+    if (orc_ch_sample_bits(&t, bits) == 0) {
+      *c = t;
+      return w;
+    }
+  }
+  return 0xffffffffu;
+}

@@ -63,6 +63,12 @@ uint32_t orc_ch_sample(orc_challenger* c);
 void orc_ch_sample_ext(orc_challenger* c, uint32_t* out4);
 uint32_t orc_ch_sample_bits(orc_challenger* c, int bits);
 uint32_t orc_ch_grind(orc_challenger* c, int bits);
+/* machine proofs since format v16: every phase of the transcript ends on a block boundary (a pending block is
+ * zero-filled), so that a duplex is always "absorb eight words" or "squeeze" - the two row kinds of the in-circuit
+ * transcript (machine.h "transcript chip") */
+void orc_ch_pad(orc_challenger* c);          /* zero-fills and absorbs a pending block (no-op on a boundary) */
+void orc_ch_drop_outputs(orc_challenger* c); /* the next sample starts from a fresh squeeze */
+uint32_t orc_ch_grind_padded(orc_challenger* c, int bits); /* observe(w), pad, sample: the smallest such w */
 
 /* ---- keccak-f[1600] AIR (p3-keccak-air column layout, 2633 columns) ---- */
 #define KA_FLAGS 0

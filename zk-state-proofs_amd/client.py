@@ -29,8 +29,8 @@ ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_ELF, ERR_EXECUTOR, ERR_GUEST_PANIC,
     ERR_UNSUPPORTED = range(1, 10)
 KECCAK_SOFTWARE, KECCAK_OBSERVE, KECCAK_REPLACE = 0, 1, 2
 PROOF_MACHINE, PROOF_KECCAK_CHIP = 1, 2
-# machine proof (format version 15): chips in proof order and the fixed header in front of the public values
-MACHINE_VERSION = 15
+# machine proof (format version 16): chips in proof order and the fixed header in front of the public values
+MACHINE_VERSION = 16
 MACHINE_CHIP_NAMES = ("cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "table", "cpu2", "alu", "alu2",
                       "subword", "subword2", "bitwise", "bitwise2", "poseidon2", "ecall", "cpu3", "cpu4", "cpu5", "cpu6", "cpu7",
                       "cpu8", "fri-fold", "divider")
@@ -502,6 +502,12 @@ class ProverClient:
         rc = self._lib.zksp_stdin_set_verified_leaf(self._h, stdin._h, leaf._h, leaf_vk._h)
         if rc:
             raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
+
+    def clear_verified_leaves(self, stdin: SP1Stdin) -> None:
+        """Removes every leaf-proof check from ``stdin`` (``zksp_stdin_set_verified_leaf`` with a null leaf)."""
+        rc = self._lib.zksp_stdin_set_verified_leaf(self._h, stdin._h, None, None)
+        if rc:
+            raise ZkspError(rc, self.last_error())
 
     def add_verified_leaf(self, stdin: SP1Stdin, leaf: SP1ProofWithPublicValues, leaf_vk: VerifyingKey) -> None:
         """One more leaf-proof check beside the run (``zksp_stdin_add_verified_leaf``): the proof made from ``stdin`` establishes

@@ -171,13 +171,19 @@ void launch_ch_init(hipStream_t stream, DevChallenger* ch, const uint32_t* init_
 // observe `n_obs` words at obs[b*obs_stride ...] (Montgomery), then sample n_ext
 // extension elements to out[b*out_stride ...]
 void launch_ch_observe_sample(hipStream_t stream, DevChallenger* ch, const uint32_t* obs, size_t obs_stride, int n_obs,
-                              uint32_t* out, size_t out_stride, int n_ext, int batch, const P2Consts* consts);
+                              uint32_t* out, size_t out_stride, int n_ext, int batch, const P2Consts* consts, int align = 0);
+// (align / pad - machine proofs since format v16: a phase of the transcript ends on a block boundary, a pending block is
+// zero-filled before the samples are drawn; the query indices start from a fresh squeeze)
 // proof-of-work search: smallest w with sample_bits(bits) == 0 after observing w
 void launch_ch_grind(hipStream_t stream, DevChallenger* ch, uint32_t* witness, int bits, int batch,
-                     const P2Consts* consts);
+                     const P2Consts* consts, int pad = 0);
 // observe witness, then draw n_queries indices of `index_bits` bits
 void launch_ch_queries(hipStream_t stream, DevChallenger* ch, const uint32_t* witness, uint32_t* indices,
-                       int n_queries, int pow_bits, int index_bits, int batch, const P2Consts* consts);
+                       int n_queries, int pow_bits, int index_bits, int batch, const P2Consts* consts, int align = 0);
+// out[b][t] = delta[b]^(desc[t] >> 16) * af[b]^(desc[t] & 0xffff) (Fp4), af = chal[b][0..4], delta = chal[b][4..8]: the
+// coefficients of the reduced openings of a machine proof (mverifier.hpp machine_reduce_exponents)
+void launch_reduce_coefs(hipStream_t stream, const uint32_t* chal, size_t chal_stride, const uint32_t* desc, uint32_t* out,
+                         size_t out_stride, int n, int batch);
 
 // ---- proof assembly ----
 struct AssembleArgs {

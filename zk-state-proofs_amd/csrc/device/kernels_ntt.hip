@@ -666,21 +666,8 @@ static void launch_lde_tall(hipStream_t stream, const uint32_t* in, uint32_t* co
   // (a multiple of 8 columns: the chunk kernel picks the input scale table from the column index inside the slab, and
   // quotient chunks alternate tables every 4 columns)
   if (slab_mb) slab = std::min<size_t>(slab, std::max<size_t>(8, ((slab_mb << 20) / (16 * h)) & ~(size_t)7));
-  // TIMING ONLY (wrong results): what the strided top passes cost a step, i.e. the most a whole-column kernel could save
-  static const bool skip_top_env = [] {
-    const bool on = getenv("ZKSP_LDE_SKIP_TOP_TIMING_ONLY") != nullptr;
-    if (on) fprintf(stderr, "zksp: ZKSP_LDE_SKIP_TOP_TIMING_ONLY is set - the LDEs of this process are WRONG (timing experiment); no proof it makes verifies\n");
-    return on;
-  }();
-  const bool skip_top = skip_top_env && ncols >= 32;  // (not the preprocessed tables: their commitment is checked against the key)
   for (size_t c0 = 0; c0 < ncols; c0 += slab) {
     const size_t nc = ncols - c0 < slab ? ncols - c0 : slab;
-    if (skip_top) {
-      hipLaunchKernelGGL(lde_chunk_fixed_kernel<13>, dim3((unsigned)(h >> l2), (unsigned)nc), dim3(kLdeThreads), smem, stream,
-                         l1 ? scratch + c0 * 2 * h : in + c0 * h, l1 ? 2 * h : h, coefs_br ? coefs_br + c0 * h : nullptr, out + c0 * 2 * h,
-                         tw_fwd, tw_inv, in_scale_br, scale_sel_shift, scale_sel_mask, out_scale_br, logh);
-      continue;
-    }
     if (r_hi) launch_ntt_top<true>(stream, r_hi, logh, in + c0 * h, h, scratch + c0 * 2 * h, 2 * h, tw_inv, logh, nc);
     if (r_lo) launch_ntt_top<true>(stream, r_lo, logh - r_hi, scratch + c0 * 2 * h, 2 * h, scratch + c0 * 2 * h, 2 * h, tw_inv, logh, nc);
     if (fixed)  // (a 2^13 column is one chunk: no top passes, the chunk kernel reads the input itself)

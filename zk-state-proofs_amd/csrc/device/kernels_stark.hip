@@ -1141,12 +1141,15 @@ __global__ __launch_bounds__(kChThreads) void ch_observe_sample_kernel(DevChalle
                                                                       size_t obs_stride, int n_obs,
                                                                       uint32_t* __restrict__ out, size_t out_stride,
                                                                       int n_ext, int batch,
-                                                                      const P2Consts* __restrict__ k) {
+                                                                      const P2Consts* __restrict__ k, int align) {
   const int t = blockIdx.x * kChThreads + threadIdx.x, b = t >> 4, e = t & 15;
   if (b >= batch) return;
   Ch c;
   ch_load(ch + b, c, e, k);
   for (int i = 0; i < n_obs; ++i) ch_observe(c, Fp::raw(obs[(size_t)b * obs_stride + i]), k);
+  // machine proofs (format v16): a phase of the transcript ends on a block boundary - a pending block is zero-filled
+  if (align)
+    while (c.n_in != 0) ch_observe(c, Fp::zero(), k);
   for (int i = 0; i < 4 * n_ext; ++i) {
     Fp v = ch_sample(c, k);
     if (e == 0) out[(size_t)b * out_stride + i] = v.v;
@@ -1226,7 +1229,8 @@ void launch_fri_tail(hipStream_t stream, const FriTailArgs& a, int batch, const 
 constexpr uint32_t kGrindRange = 1u << 14;
 constexpr int kGrindLaunches = 64;  // covers 2^20 candidates: miss probability e^-16 at 16 bits
 
-__device__ __forceinline__ bool grind_try(const DevChallenger* d, uint32_t w, uint32_t mask, const P2Consts* k) {
+// (`pad`: the words behind the witness are zero-filled - machine proofs since format v16 - instead of left as they are)
+__device__ __forceinline__ bool grind_try(const DevChallenger* d, uint32_t w, uint32_t mask, const P2Consts* k, int pad) {
   const int pos = d->n_in;  // 0..7
   Fp st[16];
 #pragma unroll
@@ -1238,31 +1242,32 @@ __device__ __forceinline__ bool grind_try(const DevChallenger* d, uint32_t w, ui
 #pragma unroll
   for (int i = 0; i < 8; ++i)
     if (i == pos) st[i] = wm;
+    else if (pad && i > pos) st[i] = Fp::zero();
   p2_permute(st, k);
   return (st[7].to_canonical() & mask) == 0;
 }
 
 __global__ __launch_bounds__(kThreads) void ch_grind_kernel(const DevChallenger* __restrict__ ch,
                                                            uint32_t* __restrict__ witness, int bits, uint32_t range_lo,
-                                                           const P2Consts* __restrict__ k) {
+                                                           const P2Consts* __restrict__ k, int pad) {
   const int b = blockIdx.y;
   const uint32_t lo = range_lo + blockIdx.x * kThreads;
   if (witness[b] < lo) return;  // settled by an earlier launch (or an earlier chunk of this one)
   const uint32_t w = lo + threadIdx.x;
-  if (grind_try(ch + b, w, (1u << bits) - 1, k)) atomicMin(&witness[b], w);
+  if (grind_try(ch + b, w, (1u << bits) - 1, k, pad)) atomicMin(&witness[b], w);
 }
 
 // continuation for the (practically unreachable) case that 2^20 candidates all failed
 __global__ __launch_bounds__(kThreads) void ch_grind_tail_kernel(const DevChallenger* __restrict__ ch,
                                                                 uint32_t* __restrict__ witness, int bits,
-                                                                const P2Consts* __restrict__ k) {
+                                                                const P2Consts* __restrict__ k, int pad) {
   __shared__ uint32_t found;
   const int b = blockIdx.x;
   if (threadIdx.x == 0) found = witness[b];
   __syncthreads();
   for (uint32_t lo = kGrindRange * (uint32_t)kGrindLaunches; found == 0xffffffffu && lo < kP - kThreads; lo += kThreads) {
     const uint32_t w = lo + threadIdx.x;
-    const bool ok = grind_try(ch + b, w, (1u << bits) - 1, k);
+    const bool ok = grind_try(ch + b, w, (1u << bits) - 1, k, pad);
     __syncthreads();
     if (ok) atomicMin(&found, w);
     __syncthreads();
@@ -1273,13 +1278,16 @@ __global__ __launch_bounds__(kThreads) void ch_grind_tail_kernel(const DevChalle
 __global__ __launch_bounds__(kChThreads) void ch_queries_kernel(DevChallenger* ch, const uint32_t* __restrict__ witness,
                                                                uint32_t* __restrict__ indices, int n_queries,
                                                                int pow_bits, int index_bits, int batch,
-                                                               const P2Consts* __restrict__ k) {
+                                                               const P2Consts* __restrict__ k, int align) {
   const int t = blockIdx.x * kChThreads + threadIdx.x, b = t >> 4, e = t & 15;
   if (b >= batch) return;
   Ch c;
   ch_load(ch + b, c, e, k);
   ch_observe(c, Fp::from_canonical(witness[b]), k);
+  if (align)
+    while (c.n_in != 0) ch_observe(c, Fp::zero(), k);
   (void)ch_sample(c, k);  // the proof-of-work sample (zero in its low pow_bits by construction)
+  if (align) c.n_out = 0;  // (format v16: the query indices start from a fresh squeeze)
   (void)pow_bits;
   for (int q = 0; q < n_queries; ++q) {
     uint32_t v = ch_sample(c, k).to_canonical() & ((1u << index_bits) - 1);
@@ -1293,12 +1301,12 @@ void launch_ch_init(hipStream_t stream, DevChallenger* ch, const uint32_t* init_
   hipLaunchKernelGGL(ch_init_kernel, dim3((batch * 16 + kChThreads - 1) / kChThreads), dim3(kChThreads), 0, stream, ch, init_obs, n_obs, batch, consts);
 }
 void launch_ch_observe_sample(hipStream_t stream, DevChallenger* ch, const uint32_t* obs, size_t obs_stride, int n_obs,
-                              uint32_t* out, size_t out_stride, int n_ext, int batch, const P2Consts* consts) {
+                              uint32_t* out, size_t out_stride, int n_ext, int batch, const P2Consts* consts, int align) {
   hipLaunchKernelGGL(ch_observe_sample_kernel, dim3((batch * 16 + kChThreads - 1) / kChThreads), dim3(kChThreads), 0, stream, ch, obs, obs_stride,
-                     n_obs, out, out_stride, n_ext, batch, consts);
+                     n_obs, out, out_stride, n_ext, batch, consts, align);
 }
 void launch_ch_grind(hipStream_t stream, DevChallenger* ch, uint32_t* witness, int bits, int batch,
-                     const P2Consts* consts) {
+                     const P2Consts* consts, int pad) {
   (void)hipMemsetAsync(witness, 0xff, (size_t)batch * 4, stream);
   // The first kGrindRange * kGrindLaunches = 2^20 candidates are covered by launches of equal
   // ranges; a later launch returns at once for a proof whose witness is already known.  The
@@ -1312,13 +1320,40 @@ void launch_ch_grind(hipStream_t stream, DevChallenger* ch, uint32_t* witness, i
   const int launches = (int)((kGrindRange * (uint32_t)kGrindLaunches) >> log_range);
   for (int r = 0; r < launches; ++r)
     hipLaunchKernelGGL(ch_grind_kernel, dim3(range / kThreads, batch), dim3(kThreads), 0, stream, ch, witness, bits,
-                       range * (uint32_t)r, consts);
-  hipLaunchKernelGGL(ch_grind_tail_kernel, dim3(batch), dim3(kThreads), 0, stream, ch, witness, bits, consts);
+                       range * (uint32_t)r, consts, pad);
+  hipLaunchKernelGGL(ch_grind_tail_kernel, dim3(batch), dim3(kThreads), 0, stream, ch, witness, bits, consts, pad);
 }
 void launch_ch_queries(hipStream_t stream, DevChallenger* ch, const uint32_t* witness, uint32_t* indices,
-                       int n_queries, int pow_bits, int index_bits, int batch, const P2Consts* consts) {
+                       int n_queries, int pow_bits, int index_bits, int batch, const P2Consts* consts, int align) {
   hipLaunchKernelGGL(ch_queries_kernel, dim3((batch * 16 + kChThreads - 1) / kChThreads), dim3(kChThreads), 0, stream, ch, witness, indices, n_queries,
-                     pow_bits, index_bits, batch, consts);
+                     pow_bits, index_bits, batch, consts, align);
+}
+
+// Coefficients of the reduced openings (machine proofs, format v16; mverifier.cpp machine_reduce_exponents):
+// out[b][t] = delta[b]^(desc[t] >> 16) * af[b]^(desc[t] & 0xffff), af = chal[b][0..4], delta = chal[b][4..8]
+__global__ __launch_bounds__(kThreads) void reduce_coefs_kernel(const uint32_t* __restrict__ chal, size_t chal_stride,
+                                                               const uint32_t* __restrict__ desc, uint32_t* __restrict__ out,
+                                                               size_t out_stride, int n) {
+  const int t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= n) return;
+  const int b = blockIdx.y;
+  const uint32_t d = desc[t];
+  uint32_t e = d & 0xffffu;
+  Fp4 x = load_fp4(chal + (size_t)b * chal_stride);
+  const Fp4 dl = load_fp4(chal + (size_t)b * chal_stride + 4);
+  Fp4 r = Fp4::one();
+  for (uint32_t i = 0; i < (d >> 16); ++i) r = r * dl;
+  while (e) {
+    if (e & 1) r = r * x;
+    x = x.sqr();
+    e >>= 1;
+  }
+  store_fp4(out + (size_t)b * out_stride + (size_t)t * 4, r);
+}
+void launch_reduce_coefs(hipStream_t stream, const uint32_t* chal, size_t chal_stride, const uint32_t* desc, uint32_t* out,
+                         size_t out_stride, int n, int batch) {
+  hipLaunchKernelGGL(reduce_coefs_kernel, dim3((n + kThreads - 1) / kThreads, batch), dim3(kThreads), 0, stream, chal, chal_stride,
+                     desc, out, out_stride, n);
 }
 
 // ===========================================================================

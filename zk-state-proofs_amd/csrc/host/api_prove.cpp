@@ -115,6 +115,13 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
         (!ctx->ev_copied[k] && hipEventCreateWithFlags(&ctx->ev_copied[k], hipEventDisableTiming) != hipSuccess))
       return ctx->fail(ZKSP_ERR_HIP, "prove: could not create the copy events");
   ctx->body_free = nullptr;
+  // a call of several chunks copies records and bodies beside its passes: the side lanes then carry small batches only
+  // (Context::lane_max_batch); a call that fits one chunk proves like a resident pass
+  struct PipelinedScope {
+    Context* c;
+    ~PipelinedScope() { c->pipelined = false; }
+  } pipelined_scope{ctx};
+  ctx->pipelined = n > (size_t)Context::kSideMaxBatch;
   std::vector<std::unique_ptr<zksp_mtrace>> traces(n);
   const BatchTrace mark;
   auto trace_one = [&](size_t i) {

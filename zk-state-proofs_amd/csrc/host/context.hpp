@@ -90,11 +90,15 @@ struct Context {
   // chip height, and join again at the end of the stage (mprover.cpp StageFork).
   // (two side streams: the runtime maps streams onto four hardware queues by default, and the copy stream wants one)
   // (kSideMaxBatch: measured at 32, 64 and 128 too - resident passes of 9 .. 48 proofs gain 2-19 % from the lanes, the
-  // crossover with the one-lane path is near 64 - but prove_batch, whose chunks are uploaded and fetched on the copy stream
-  // meanwhile, LOSES: slot-d5x256 436 -> 350 proofs/s, acct-d8x1024 304 -> 288 at 64; 435 -> 411 and 308 -> 298 at 48, with
-  // GPU_MAX_HW_QUEUES=8 as with the default 4 - it is not a shared hardware queue.  Eight keeps the lanes to the latency case
-  // they were built for.)
-  static constexpr int kSideStreams = 2, kSideMaxBatch = 8;
+  // crossover with the one-lane path is near 64 - but a prove_batch call of SEVERAL chunks, whose chunks are uploaded and
+  // fetched on the copy stream while the one before is proven, LOSES: slot-d5x256 436 -> 350 proofs/s, acct-d8x1024 304 ->
+  // 288 at 64; 435 -> 411 and 308 -> 298 at 48, with GPU_MAX_HW_QUEUES=8 as with the default 4 - it is not a shared hardware
+  // queue.  So the lanes carry batches of at most 48 proofs when nothing is copied beside the pass (resident passes, a single
+  // proof, a prove_batch call of one chunk) and of at most eight inside a pipelined prove_batch (`pipelined`): round 4 had
+  // eight everywhere, which made a caller with 9 .. 15 runs slower than one with 8.)
+  static constexpr int kSideStreams = 2, kSideMaxBatch = 48, kSidePipelinedMaxBatch = 8;
+  bool pipelined = false;  // set by prove_batch while chunks are uploaded / fetched beside the passes
+  int lane_max_batch() const { return pipelined ? kSidePipelinedMaxBatch : kSideMaxBatch; }
   hipStream_t side[kSideStreams] = {nullptr, nullptr};
   hipEvent_t fork_ev = nullptr, join_ev[kSideStreams] = {nullptr, nullptr};
   hipStream_t copy_stream = nullptr;

@@ -66,6 +66,9 @@ struct ExecutionRecord {
   // written before.  Memory outside the image starts with prover-chosen contents in the proof (as hinted input must); a run
   // that never reads such a byte cannot be steered by them.  The committed guest never does (tests/test_machine.py).
   uint64_t uninit_reads = 0;
+  // traced with ZKSP_UNINIT_FILL (fresh memory filled with a chosen byte: an analysis aid of tests/test_machine.py): such a
+  // trace is for inspection only, the provers refuse it
+  bool analysis_fill = false;
   uint64_t syscall_counts[256] = {0}; // indexed by low byte of the code
   std::vector<uint64_t> opcode_hist;  // indexed by Op (filled when want_hist)
 };

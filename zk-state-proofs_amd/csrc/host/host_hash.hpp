@@ -42,6 +42,12 @@ struct HostChallenger {
     return r;
   }
   uint32_t sample_bits(int bits) { return sample().to_canonical() & ((1u << bits) - 1); }
+  // machine proofs since format v16: every phase of the transcript ends on a block boundary (a pending block is zero-filled),
+  // so that a duplex is always "absorb eight words" or "squeeze" - the two row kinds of the in-circuit transcript
+  void pad() {
+    while (n_in != 0) observe(Fp::zero());
+  }
+  void drop_outputs() { n_out = 0; }  // the next sample starts from a fresh squeeze
 };
 
 inline void hash_elems(const Fp* in, size_t n, Fp out[8], const P2Consts* k) {

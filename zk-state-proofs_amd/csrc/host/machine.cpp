@@ -231,6 +231,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
   // proof its contents are the prover's choice, and tests/test_machine.py uses this to show that the guest's public values
   // do not depend on them
   const int uninit_fill = getenv("ZKSP_UNINIT_FILL") ? (int)(strtoul(getenv("ZKSP_UNINIT_FILL"), nullptr, 0) & 0xff) : -1;
+  rec.analysis_fill = uninit_fill >= 0;
   out->cycles.reserve((size_t)1 << 19);  // virtual pages only: what is not written is never touched
   out->prog_mult.assign(prog.rows.size(), 0);
   uint32_t x[32] = {0}, reg_ts[32] = {0};

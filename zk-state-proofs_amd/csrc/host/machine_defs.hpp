@@ -64,7 +64,7 @@ constexpr int kHeaderWords = 2 + kNumChips + 2 + 24 + (kNumCpuInst - 1) + 17 + 9
 // A public bus tuple, as the verifier is given it (16 canonical words): bus, 1 if the verifier sends it (0: receives),
 // multiplicity, number of elements, the elements (zero padded).
 constexpr int kPubTupleWords = 16;
-constexpr uint32_t kMachineVersion = 15;
+constexpr uint32_t kMachineVersion = 16;
 
 }  // namespace mach
 }  // namespace zksp

@@ -604,7 +604,8 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
     const size_t R = (size_t)1 << w->open_rows_log;
     A(&w->opened, B * 8 * R);
     A(&w->tree_o, B * (2 * R - 1) * 8);
-    A(&w->af, B * 4);
+    A(&w->af, B * 8);  // alpha_f, delta
+    A(&w->reduce_desc, n_open);
     A(&w->af_pows, B * n_open * 4);
     A(&w->bsum, B * 2 * 4);
     {
@@ -618,7 +619,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
           if (wdt) need = std::max(need, open_tall_scratch_words(wdt, logh[c], 1) / 8);  // (words per proof, at eight proofs)
       const size_t nb = std::max<size_t>(B, 8);  // (a batch below eight splits the tall openings finer: sized as for eight)
       A(&w->reduce_scratch, nb * need);
-      for (int i = 0; i + 1 < w->n_streams; ++i) A(&w->side_reduce_scratch[i], (size_t)Context::kSideMaxBatch * need);
+      for (int i = 0; i + 1 < w->n_streams; ++i) A(&w->side_reduce_scratch[i], std::min<size_t>(nb, Context::kSideMaxBatch) * need);
     }
     A(&w->kpartial, B * 13 * (((size_t)2 << logh[kKeccak]) * 4));
     {
@@ -627,7 +628,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
       for (int c = 0; c < kNumChips; ++c)
         if (logh[c] >= 12)
           for (int wdt : {chip_def(c).prep_w, chip_def(c).main_w, chip_def(c).perm_width(), quot_width(logh, c) ? 4 : 0, quot_width(logh, c) ? 4 : 0})
-            if (wdt) words += open_tall_scratch_words(wdt, logh[c], Context::kSideMaxBatch);
+            if (wdt) words += open_tall_scratch_words(wdt, logh[c], (int)std::min<size_t>(std::max<size_t>(B, 8), Context::kSideMaxBatch));
       A(&w->open_partial, words);
       A(&w->open_tasks, (size_t)5 * kNumChips);
       A(&w->mr_heights, (size_t)32);
@@ -683,6 +684,8 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
     return ctx->fail(3, "machine workspace: hipMalloc of " + std::to_string(arena_need >> 20) + " MiB failed");
   }
   ZKSP_HIP_CHECK(ctx, hipMemsetAsync(w->opened, 0, (B * 8 * 4) << w->open_rows_log, ctx->stream));
+  machine_reduce_exponents(logh, &w->reduce_desc_host);
+  ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->reduce_desc, w->reduce_desc_host.data(), w->reduce_desc_host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   return 0;
 }
 
@@ -715,6 +718,9 @@ int machine_activate_spare(Context* ctx) {
     const MachineWorkspace::SpareRecords sp = w->spare;
     const int slot = w->rec_slot;
     const PrepDevice* prep = w->prep;
+    // (the wait goes in BEFORE the new layout's first enqueued work - workspace_ensure ends with a memset of the new `opened`,
+    // which may overlap the old layout's `body` that the copy stream is still reading)
+    if (ctx->body_free) ZKSP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->body_free, 0));
     int rc = workspace_ensure(ctx, sp.logh, std::max(sp.n, sp.batch_hint), sp.cap_cycles, sp.cap_keccak, sp.cap_memfinal, sp.cap_muls,
                               sp.cap_alu, sp.cap_sub, sp.cap_bw, sp.cap_agg, sp.cap_fold, /*in_flight=*/true);
     if (rc) return rc;
@@ -722,7 +728,6 @@ int machine_activate_spare(Context* ctx) {
     w->prep = prep;
     w->rec_slot = slot;
     w->spare = sp;  // (swap_records below makes it the resident set; what it leaves in `spare` is stale and n = 0)
-    if (ctx->body_free) ZKSP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->body_free, 0));
   }
   swap_records(w);
   w->spare.n = 0;
@@ -732,6 +737,9 @@ int machine_activate_spare(Context* ctx) {
 int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, const MachineTrace* const* traces, size_t n,
                  bool into_spare, const int* shape, hipEvent_t loaded) {
   if (n == 0) return ctx->fail(1, "machine_load: empty batch");
+  for (size_t i = 0; i < n; ++i)
+    if (traces[i]->rec.analysis_fill)
+      return ctx->fail(1, "machine_load: a trace was made with ZKSP_UNINIT_FILL set (an analysis aid): unset it to prove");
   const PrepDevice* prep = nullptr;
   int rc = machine_prep_ensure(ctx, prog, vk, &prep);
   if (rc) return rc;
@@ -949,7 +957,7 @@ int machine_prove_resident(Context* ctx) {
   rec.cpu_rows = (uint32_t)machine_cpu_row0(logh, kNumCpuInst);
   // Small batches: the chips of a stage go to the lanes of a fork (by height) and the stage joins again; large batches have
   // one lane, the main stream, and everything below is enqueued exactly as it reads.
-  const StageFork fork(ctx, B <= Context::kSideMaxBatch ? w->n_streams : 1, logh);
+  const StageFork fork(ctx, (int)B <= ctx->lane_max_batch() ? w->n_streams : 1, logh);
   auto SL = [&](int c) { return fork.lane(fork.lane_of(logh[c])); };       // the stream of chip c's height (shared state)
   auto SC = [&](int c) { return fork.lane(fork.lane_of_a_chip(c)); };       // ... of chip c itself (nothing shared)
   auto lane_scratch = [&](int c, uint32_t* main_buf, uint32_t* const* side_bufs) {
@@ -988,7 +996,7 @@ int machine_prove_resident(Context* ctx) {
   // two lanes): 355.1 against 353.9 proofs/s at batch 192 - the chunk transform is bound by butterfly issue itself, the two
   // kinds of kernels share the vector ALUs instead of complementing each other - so large batches keep one lane.
   static const bool overlap = getenv("ZKSP_OVERLAP") != nullptr;
-  const StageFork fork2(ctx, B <= Context::kSideMaxBatch ? w->n_streams : (overlap ? 2 : 1), logh);
+  const StageFork fork2(ctx, (int)B <= ctx->lane_max_batch() ? w->n_streams : (overlap ? 2 : 1), logh);
   auto HL = [&](int c) { return fork2.lane(fork2.lane_of(logh[c])); };
   // small batches: every group's transforms and leaves together, longest sponge first (mmcs_commit, `lde`)
   const bool grouped = fork2.lanes > 1;
@@ -1038,7 +1046,7 @@ int machine_prove_resident(Context* ctx) {
   {
     ProfileSpan sp(ctx, "transcript");
     launch_ch_init(s, w->ch, w->init_obs, kMachineInitObs, B, kc);
-    launch_ch_observe_sample(s, w->ch, w->tree[1] + root_off, tree_stride, 8, w->bus_ch, 8, 2, B, kc);
+    launch_ch_observe_sample(s, w->ch, w->tree[1] + root_off, tree_stride, 8, w->bus_ch, 8, 2, B, kc, 1);
     launch_ext_powers(s, w->bus_ch + 4, 8, kR1, w->bpow, (size_t)(kInterMaxElems + 1) * 4, kInterMaxElems + 1, 0, B);
   }
   // ---- LogUp permutation traces ----
@@ -1133,7 +1141,7 @@ int machine_prove_resident(Context* ctx) {
   {
     ProfileSpan sp(ctx, "transcript");
     launch_ch_observe_sample(s, w->ch, w->tree[2] + root_off, tree_stride, 8, w->alpha, 4, 0, B, kc);
-    launch_ch_observe_sample(s, w->ch, w->cum, (size_t)4 * kNumChips, 4 * kNumChips, w->alpha, 4, 1, B, kc);
+    launch_ch_observe_sample(s, w->ch, w->cum, (size_t)4 * kNumChips, 4 * kNumChips, w->alpha, 4, 1, B, kc, 1);
     launch_ext_powers(s, w->alpha, 4, kR1, w->alpha_pows, w->alpha_stride, (int)(w->alpha_stride / 4), 0, B);
   }
   // ---- quotients ----
@@ -1338,8 +1346,9 @@ int machine_prove_resident(Context* ctx) {
   }
   {
     ProfileSpan sp(ctx, "transcript");
-    launch_ch_observe_sample(s, w->ch, w->tree_o + (2 * R - 2) * 8, (2 * R - 1) * 8, 8, w->af, 4, 1, B, kc);
-    launch_ext_powers(s, w->af, 4, kR1, w->af_pows, w->n_open * 4, (int)w->n_open, 0, B);
+    // alpha_f and delta; the coefficient of every opened value in the reduced openings (format v16)
+    launch_ch_observe_sample(s, w->ch, w->tree_o + (2 * R - 2) * 8, (2 * R - 1) * 8, 8, w->af, 8, 2, B, kc);
+    launch_reduce_coefs(s, w->af, 8, w->reduce_desc, w->af_pows, w->n_open * 4, (int)w->n_open, B);
   }
   // ---- reduced openings: one FRI input per height; the tallest is layer 0 ----
   {
@@ -1446,11 +1455,11 @@ int machine_prove_resident(Context* ctx) {
   }
   {
     ProfileSpan sp(ctx, "grind");
-    launch_ch_grind(s, w->ch, w->witness, pow_bits, B, kc);
+    launch_ch_grind(s, w->ch, w->witness, pow_bits, B, kc, 1);
   }
   {
     ProfileSpan sp(ctx, "transcript");
-    launch_ch_queries(s, w->ch, w->witness, w->indices, Q, pow_bits, lm + 1, B, kc);
+    launch_ch_queries(s, w->ch, w->witness, w->indices, Q, pow_bits, lm + 1, B, kc, 1);
   }
   {
     ProfileSpan sp(ctx, "m_assemble");

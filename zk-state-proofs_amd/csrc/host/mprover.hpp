@@ -76,6 +76,8 @@ struct MachineWorkspace {
   DevChallenger* ch = nullptr;
   uint32_t *bus_ch = nullptr, *bpow = nullptr, *cum = nullptr, *pubsum = nullptr, *rowsum = nullptr, *slice_sums = nullptr;
   uint32_t *alpha = nullptr, *alpha_pows = nullptr, *zeta = nullptr, *opened = nullptr, *tree_o = nullptr;
+  uint32_t* reduce_desc = nullptr;           // [n_open] exponent descriptors of the reduced openings (machine_reduce_exponents)
+  std::vector<uint32_t> reduce_desc_host;    // (the upload reads it asynchronously)
   uint32_t *af = nullptr, *af_pows = nullptr, *bsum = nullptr, *kpartial = nullptr, *reduce_scratch = nullptr;
   // scratch of the side streams (batches of at most Context::kSideMaxBatch proofs): [i] belongs to side stream i
   int n_streams = 1;  // 1 + the side streams in use

@@ -446,6 +446,54 @@ void machine_host_setup(const MachineProgram& prog, MachineVk* vk) {
   vk_digest_of(vk->prep_root, vk->entry, vk->pad_pc, vk->log_prog, vk->log_image, vk->keccak_mode, vk->digest);
 }
 
+// Coefficients of the reduced openings (format v16; oracle/mprover.c orc_reduce_coefs is the normative text).  The input
+// of height 2^lh at the LDE point x is  sum_r delta^r (H_r(x) - H_r(zeta)) / (x - zeta)  +  sum_{r = main, perm}
+// delta^(3 + r) (H_r(x) - H_r(zeta w)) / (x - zeta w),  H_r = Horner's rule in alpha_f over the segment (r, lh): the opened
+// rows of the chips of that height in chip order, zero-filled to a multiple of eight words - the words the opening's sponge
+// absorbs, in its order.  Word i of a segment of n words: delta^r alpha_f^(8 ceil(n / 8) - 1 - i).
+void machine_reduce_exponents(const int* logh, std::vector<uint32_t>* desc) {
+  int wr[kNumChips][4], seg_len[32][4], pos[32][4];
+  memset(seg_len, 0, sizeof seg_len);
+  memset(pos, 0, sizeof pos);
+  size_t n_open = 0;
+  for (int c = 0; c < kNumChips; ++c) {
+    const ChipDef& d = chip_def(c);
+    wr[c][0] = d.prep_w; wr[c][1] = d.main_w; wr[c][2] = d.perm_width(); wr[c][3] = quot_width(logh, c);
+    for (int r = 0; r < 4; ++r) seg_len[logh[c]][r] += wr[c][r];
+    n_open += (size_t)wr[c][0] + 2 * (size_t)wr[c][1] + 2 * (size_t)wr[c][2] + (size_t)wr[c][3];
+  }
+  desc->assign(n_open, 0);
+  size_t off = 0;
+  for (int c = 0; c < kNumChips; ++c) {
+    const int lh = logh[c];
+    const size_t n1 = (size_t)wr[c][0] + wr[c][1] + wr[c][2] + wr[c][3];
+    size_t i = 0, j = 0;
+    for (int r = 0; r < 4; ++r) {
+      const int lpad = (seg_len[lh][r] + 7) / 8 * 8;
+      for (int col = 0; col < wr[c][r]; ++col, ++i) {
+        const uint32_t e = (uint32_t)(lpad - 1 - (pos[lh][r] + col));
+        (*desc)[off + i] = e | ((uint32_t)r << 16);
+        if (r == 1 || r == 2) { (*desc)[off + n1 + j] = e | ((uint32_t)(3 + r) << 16); ++j; }
+      }
+      pos[lh][r] += wr[c][r];
+    }
+    off += n1 + (size_t)wr[c][1] + wr[c][2];
+  }
+}
+void machine_reduce_coefs(const int* logh, const Fp4& af, const Fp4& delta, Fp4* out) {
+  std::vector<uint32_t> desc;
+  machine_reduce_exponents(logh, &desc);
+  uint32_t emax = 0;
+  for (uint32_t d : desc) emax = std::max(emax, d & 0xffffu);
+  std::vector<Fp4> ap(emax + 1);
+  ap[0] = Fp4::one();
+  for (uint32_t i = 1; i <= emax; ++i) ap[i] = ap[i - 1] * af;
+  Fp4 dp[6];
+  dp[0] = Fp4::one();
+  for (int i = 1; i < 6; ++i) dp[i] = dp[i - 1] * delta;
+  for (size_t t = 0; t < desc.size(); ++t) out[t] = dp[desc[t] >> 16] * ap[desc[t] & 0xffffu];
+}
+
 size_t machine_proof_body_words(const int* logh, uint32_t num_queries) {
   int lm = 0, lm_prep = 0;
   size_t opened = 0, rw[4] = {0, 0, 0, 0};
@@ -614,6 +662,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   Fp root[4][8];
   for (int i = 0; i < 8; ++i) root[0][i] = Fp::from_canonical(vk.prep_root[i]);
   for (int i = 0; i < 8; ++i) { root[1][i] = Fp::from_canonical(p_root_main[i]); ch.observe(root[1][i]); }
+  ch.pad();  // (v16: a phase of the transcript ends on a block boundary)
   const Fp4 gamma = ch.sample_ext(), beta = ch.sample_ext();
   for (int i = 0; i < 8; ++i) { root[2][i] = Fp::from_canonical(p_root_perm[i]); ch.observe(root[2][i]); }
   Fp4 cum[kNumChips];
@@ -621,6 +670,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     cum[c] = read_fp4(p_cum + 4 * c);
     for (int i = 0; i < 4; ++i) ch.observe(cum[c].c[i]);
   }
+  ch.pad();
   const Fp4 alpha = ch.sample_ext();
   for (int i = 0; i < 8; ++i) { root[3][i] = Fp::from_canonical(p_root_quot[i]); ch.observe(root[3][i]); }
   const Fp4 zeta = ch.sample_ext();
@@ -672,7 +722,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     list_root(words, ceil_log2((n_open * 4 + 7) / 8), open_root, kc);
     for (int i = 0; i < 8; ++i) ch.observe(open_root[i]);
   }
-  const Fp4 af = ch.sample_ext();
+  const Fp4 af = ch.sample_ext(), delta = ch.sample_ext();
 
   // ---- constraint identity at zeta: one per height (the chips of a height share a quotient: machine_defs.hpp) ----
   const Fp g = Fp::from_canonical(kGen);
@@ -808,12 +858,13 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   const Fp4 final_poly = read_fp4(p_final);
   for (int i = 0; i < 4; ++i) ch.observe(final_poly.c[i]);
   ch.observe_canon(p_witness[0]);
+  ch.pad();
   if (ch.sample_bits((int)pow_bits) != 0) { *err = "proof-of-work witness rejected"; return 8; }
+  ch.drop_outputs();  // (v16: the query indices start from a fresh squeeze)
 
-  // ---- reduced-opening constants per chip ----
+  // ---- reduced-opening constants per chip (v16: machine_reduce_coefs) ----
   std::vector<Fp4> afpow(n_open);
-  afpow[0] = Fp4::one();
-  for (size_t i = 1; i < n_open; ++i) afpow[i] = afpow[i - 1] * af;
+  machine_reduce_coefs(logh, af, delta, afpow.data());
   Fp4 b1[kNumChips], b2[kNumChips];
   size_t n1[kNumChips], n2[kNumChips];
   for (int c = 0; c < kNumChips; ++c) {
@@ -955,17 +1006,27 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   std::vector<LeafCheckLog> q_log(log ? num_queries : 0);
   for (LeafCheckLog& ql : q_log) ql.query_base = log->query_base;
   std::atomic<uint32_t> next_q{0};
-  auto worker = [&]() {
-    for (uint32_t qi; (qi = next_q.fetch_add(1)) < num_queries;) q_rc[qi] = check_query(qi, log ? &q_log[qi] : nullptr, &q_err[qi]);
+  // (a query that throws - out of memory in its vectors - is a malformed-input failure of that query, on whichever thread)
+  auto worker = [&]() noexcept {
+    for (uint32_t qi; (qi = next_q.fetch_add(1)) < num_queries;) {
+      try {
+        q_rc[qi] = check_query(qi, log ? &q_log[qi] : nullptr, &q_err[qi]);
+      } catch (...) {
+        q_rc[qi] = 7;
+        try { q_err[qi] = "query check ran out of memory"; } catch (...) {}
+      }
+    }
   };
   {
-    std::vector<std::thread> th;
+    struct Joiner {  // joins on every way out of the block
+      std::vector<std::thread> th;
+      ~Joiner() { for (auto& t : th) if (t.joinable()) t.join(); }
+    } pool;
     try {
-      for (unsigned t = 1; t < n_thr; ++t) th.emplace_back(worker);
+      for (unsigned t = 1; t < n_thr; ++t) pool.th.emplace_back(worker);
     } catch (...) {
     }  // fewer threads than wanted: the queries are claimed from one counter
     worker();
-    for (auto& t : th) t.join();
   }
   for (uint32_t qi = 0; qi < num_queries; ++qi)
     if (q_rc[qi]) { *err = q_err[qi]; return q_rc[qi]; }

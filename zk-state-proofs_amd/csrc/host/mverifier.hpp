@@ -38,6 +38,10 @@ void machine_prep_traces(const MachineProgram& prog, std::vector<uint32_t>* imag
 // host-side commitment of the preprocessed tables (setup; no GPU)
 void machine_host_setup(const MachineProgram& prog, MachineVk* vk);
 size_t machine_proof_body_words(const int* logh, uint32_t num_queries);
+// Coefficient of every opened value in the reduced openings (format v16): delta^(desc >> 16) * alpha_f^(desc & 0xffff), in the
+// order the opened values are laid out (per chip: prep, main, perm, quot at zeta, then main, perm at zeta w)
+void machine_reduce_exponents(const int* logh, std::vector<uint32_t>* desc);
+void machine_reduce_coefs(const int* logh, const Fp4& af, const Fp4& delta, Fp4* out);
 bool parse_machine_header(const uint8_t* bytes, size_t len, MachineHeader* h, std::string* err);
 // 0 = accepted; 7 = malformed; 8 = rejected.  agg_leaves / n_agg: the leaves ([n][8] canonical words) of the aggregation
 // payload the proof must carry (n_agg = 0: it must carry none).

@@ -84,13 +84,16 @@ def prove_tree_level(client, pk, leaf_vk, leaves: Sequence, node_stdins: Sequenc
     more guest run (node_stdins[k]) whose proof also checks the query phases of its `arity` leaf proofs
     (client.add_verified_leaf, in leaf order).  Nodes are independent of one another and shard block-cyclically over the
     ranks like any other proofs; every rank holds all the leaves (they were all-gathered or are on shared storage - a node's
-    host part verifies its leaves before anything is proven).  Returns (node indices of this rank, their proofs, status)."""
+    host part verifies its leaves before anything is proven).  The stdins of this rank's nodes are CONSUMED: whatever leaf
+    checks they carried are replaced by the node's own (so a retry of the level does not double them).  Returns (node
+    indices of this rank, their proofs, status)."""
     groups = tree_node_groups(len(leaves), arity)
     if len(node_stdins) != len(groups):
         raise ValueError("one stdin per node")
     mine = shard_indices(len(groups), rank, world)
     stdins = []
     for k in mine:
+        client.clear_verified_leaves(node_stdins[k])
         for i in groups[k]:
             client.add_verified_leaf(node_stdins[k], leaves[i], leaf_vk)
         stdins.append(node_stdins[k])
