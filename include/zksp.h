@@ -57,7 +57,7 @@ typedef struct {
 } zksp_options;
 /* What zksp_prove / zksp_prove_batch establish:
  * MACHINE      the guest's whole execution (CPU instances, memory, program, ALU, keccak, multiplier ... chips joined by
- *              LogUp buses; proof format v15): the statement of the reference's client.prove().
+ *              LogUp buses; proof format v16): the statement of the reference's client.prove().
  * KECCAK_CHIP  only "these keccak-f outputs belong to these inputs" (round-1 format v2, a component
  *              benchmark; NOT a proof that the guest ran). */
 #define ZKSP_PROOF_MACHINE 1
@@ -65,18 +65,18 @@ typedef struct {
 /* Layout of a serialized machine proof (zksp_proof_serialize; little-endian u32 words; csrc/host/machine_defs.hpp is the
  * source of these numbers - kMachineVersion, kHeaderWords):
  *   word 0           magic
- *   word 1           format version (15)
- *   words 2 .. 26    log2 height of each of the ZKSP_MACHINE_CHIPS = 25 chips, in proof order
- *   word 27, 28      guest exit code, length of the public values in bytes
- *   words 29 .. 52   sha256(public values) as 8 words, the deferred-proofs digest (8), the verifying-key digest (8)
- *   words 53 .. 59   the pc at which each of the seven later CPU instances starts (hand-over pcs)
- *   words 60 .. 76   aggregation payload: number of supplied digests (0: none), their Merkle root (8), digest of the list (8)
- *   words 77 .. 85   public bus tuples (a leaf-proof check's statement): their number (0: none), digest of the list (8)
+ *   word 1           format version (16)
+ *   words 2 .. 27    log2 height of each of the ZKSP_MACHINE_CHIPS = 26 chips, in proof order
+ *   word 28, 29      guest exit code, length of the public values in bytes
+ *   words 30 .. 53   sha256(public values) as 8 words, the deferred-proofs digest (8), the verifying-key digest (8)
+ *   words 54 .. 60   the pc at which each of the seven later CPU instances starts (hand-over pcs)
+ *   words 61 .. 77   aggregation payload: number of supplied digests (0: none), their Merkle root (8), digest of the list (8)
+ *   words 78 .. 86   public bus tuples (a leaf-proof check's statement): their number (0: none), digest of the list (8)
  *   then             the public values, zero-padded to a word; then the proof body (commitment roots, cumulative sums,
  *                    opened values, FRI roots, final constant, proof-of-work witness, the query openings):
- *                    zksp_machine_body_words() words.
+ *                    zksp_machine_body_words() words.  A proof STUB (zksp_proof_stub) ends in front of the query openings.
  * Everything in the header is absorbed into the transcript before the first challenge is drawn. */
-#define ZKSP_MACHINE_HEADER_WORDS 86
+#define ZKSP_MACHINE_HEADER_WORDS 87
 
 /* replaces ProverClient::new()  (main.rs:61).  Fails with ZKSP_ERR_NO_DEVICE when
  * device_ordinal >= 0 and no GPU is usable: there is no CPU proving fallback.
@@ -185,8 +185,10 @@ typedef struct zksp_mtrace zksp_mtrace;
 #define ZKSP_MT_SUB_IDX 9       /* u32 per sub-word-chip row: index of the cycle (lb lh lbu lhu sb sh) */
 #define ZKSP_MT_BW_IDX 10       /* u32 per bitwise-chip row: index of the cycle (xor or and) */
 #define ZKSP_MT_ECALL_IDX 11    /* u32 per ecall-chip row: index of the ecall cycle */
-#define ZKSP_MT_LEAF_P2_ROWS 12   /* leaf-proof check: 20 u32 per Poseidon2-chip row (flags, tag, key, mask, 16 input words) */
-#define ZKSP_MT_LEAF_FOLD_ROWS 13 /* leaf-proof check: 20 u32 per fold-chip row (flags, query, layer, 1/x, beta, lo, hi, ro) */
+#define ZKSP_MT_LEAF_P2_ROWS 12   /* leaf-proof check: 32 u32 per Poseidon2-chip row (flags, tag, key, mask, 16 input words, root id,
+                                     Horner sum, alpha_f) */
+#define ZKSP_MT_LEAF_QR_ROWS 13   /* leaf-proof check: 132 u32 per query-chip row (the row itself, 31 rows per query) */
+#define ZKSP_MT_LEAF_TR_ROWS 16   /* leaf-proof check: 32 u32 per transcript-chip row (flags, leaf, step, uses, 16 input words) */
 #define ZKSP_MT_DIV_IDX 15         /* u32 per divider-chip row: index of the cycle (div divu rem remu) */
 #define ZKSP_MT_LEAF_PUB_TUPLES 14 /* leaf-proof check: 16 u32 per public bus tuple (ZKSP_PUB_TUPLE_WORDS) */
 typedef struct {
@@ -211,7 +213,7 @@ int zksp_mtrace_info(const zksp_mtrace* t, zksp_mtrace_info_t* info);
 /* Device-resident machine proving (bench.py, parity tests): upload the records of n traced runs (they are proven
  * with one shape: zksp_machine_cover_heights), enqueue one proving pass, fetch the proof bodies ([n][body_words]
  * canonical u32; body_words = zksp_machine_body_words of that shape). */
-#define ZKSP_MACHINE_CHIPS 25   /* cpu, keccak, keccak-mem, mem-final, image, program, mul, table, cpu2, alu, alu2, subword, subword2, bitwise, bitwise2, poseidon2, ecall, cpu3 .. cpu8, fri-fold, divider */
+#define ZKSP_MACHINE_CHIPS 26   /* cpu, keccak, keccak-mem, mem-final, image, program, mul, table, cpu2, alu, alu2, subword, subword2, bitwise, bitwise2, poseidon2, ecall, cpu3 .. cpu8, query, divider, transcript */
 int zksp_mtrace_heights(const zksp_mtrace* t, int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 size_t zksp_machine_body_words(const zksp_client* c, const int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 /* The shape a batch of these runs is proven with: the chip heights that cover the largest cycle / event / address
@@ -242,15 +244,24 @@ int zksp_verify_aggregate(zksp_client* c, const zksp_proof* p, const zksp_vk* vk
 int zksp_stdin_set_aggregation_keyed(zksp_stdin* s, const uint32_t* keys /* [n] or NULL */, const uint32_t* digests /* [n][8] */, size_t n);
 int zksp_verify_aggregate_keyed(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const uint32_t* keys /* [n] or NULL */,
                                 const uint32_t* digests /* [n][8] */, size_t n);
-/* The statement of a leaf-proof check as the list of PUBLIC BUS TUPLES the proof's LogUp buses close with
- * (ZKSP_PUB_TUPLE_WORDS canonical u32 each: bus, 1 = the verifier sends it / 0 = receives it, multiplicity, number of
- * elements, up to 12 elements).  For a verified leaf they are, per query: four DIGEST tuples (tag, 0, position key,
- * injection mask, root) for the commitment rounds and one per FRI layer; per layer a FRIQ tuple (query, layer, position
- * bit, 1/x, beta); the RO tuples (query, 0 or layer + 1, reduced opening); one FIN tuple (query, last layer, final
- * constant).  zksp_leaf_public derives them from a leaf proof (verifying it on the way; out may be NULL to size the
- * buffer); zksp_verify_public checks a proof against a list; zksp_verify_with_leaf does both.  zksp_verify refuses a proof
- * that carries public tuples: it cannot vouch for a statement it was not given.  The proof header holds the count and the
- * sponge digest of the list (zksp_proof_public_tuples), which the transcript absorbs before any challenge. */
+/* The statement of a leaf-proof check (stage 2b) as the list of PUBLIC BUS TUPLES the proof's LogUp
+ * buses close with (ZKSP_PUB_TUPLE_WORDS canonical u32 each: bus, 1 = the verifier sends it / 0 = receives it, multiplicity,
+ * number of elements, up to 12 elements).  A proof made from a stdin with verified leaves establishes, for every leaf, that its
+ * Fiat-Shamir transcript over the blocks named in the statement yields challenges under which EVERY FRI QUERY of the leaf
+ * verifies: the index words drawn from the transcript, their canonical bits, the four mixed-height Merkle openings against
+ * the roots the transcript absorbed, every FRI layer opening, the reduced openings from the opened rows, the folding chain
+ * down to the final constant.  Per leaf the statement is: one TBLK tuple per absorbed block of the leaf's transcript (header
+ * words, commitment roots, cumulative sums, the root of the values opened at zeta, FRI roots, final constant, witness) and
+ * one TSQ tuple per squeeze; the preprocessed root (the key's); LEAFK and one BCONST per height (constants the verifier derives
+ * from the challenges and the values opened at zeta); the proof-of-work word.  What is NOT in-circuit yet and is checked by
+ * whoever derives the statement (zksp_leaf_public*): the leaf's bus balance and its constraint identity at zeta - for which
+ * a PROOF STUB suffices (zksp_proof_stub: the proof without its query phase, about 5 % of its bytes).
+ * zksp_leaf_public derives the list from a leaf proof or stub (checking everything but the queries on the way; out may be
+ * NULL to size the buffer); zksp_verify_public checks a proof against a list; zksp_verify_with_leaf(s) does both.
+ * zksp_verify refuses a proof that carries public tuples: it cannot vouch for a statement it was not given.  The proof header
+ * holds the count and the sponge digest of the list (zksp_proof_public_tuples), which the transcript absorbs before any
+ * challenge.  A leaf may itself check leaves (a NODE of a recursion tree): zksp_stdin_add_verified_node /
+ * zksp_leaf_public_at take the node's own statement, whose digest its header carries. */
 #define ZKSP_PUB_TUPLE_WORDS 16
 int zksp_leaf_public(zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf_vk, uint32_t* out, size_t cap_words, size_t* n_tuples);
 int zksp_verify_public(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const uint32_t* tuples, size_t n_tuples);
@@ -261,6 +272,15 @@ int zksp_leaves_public(zksp_client* c, const zksp_proof* const* leaves, const zk
 int zksp_verify_with_leaves(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const zksp_proof* const* leaves,
                             const zksp_vk* const* leaf_vks, size_t n);
 int zksp_proof_public_tuples(const zksp_proof* p, uint32_t* n_tuples, uint32_t* digest8);
+/* The proof without its query phase: header, public values, commitment roots, cumulative sums, the values opened at zeta, FRI
+ * roots, final constant, witness.  What zksp_leaf_public* needs of a leaf; serialises like a proof. */
+int zksp_proof_stub(const zksp_proof* p, zksp_proof** out);
+/* zksp_leaf_public for the leaf at place `leaf_index` beside one run, which itself closes its buses with own_tuples (a node) */
+int zksp_leaf_public_at(zksp_client* c, const zksp_proof* leaf_or_stub, const zksp_vk* leaf_vk, uint32_t leaf_index,
+                        const uint32_t* own_tuples, size_t n_own_tuples, uint32_t* out, size_t cap_words, size_t* n_tuples);
+/* zksp_stdin_add_verified_leaf for a leaf that is itself a node: own_tuples is the statement ITS proof was made for */
+int zksp_stdin_add_verified_node(zksp_client* c, zksp_stdin* s, const zksp_proof* leaf, const zksp_vk* leaf_vk,
+                                 const uint32_t* own_tuples, size_t n_own_tuples);
 /* Kernel-level parity (tests): after zksp_hip_machine_prove, one intermediate matrix of resident proof `proof_index`, as
  * canonical u32, column-major [width][2^log_height]: stage 0 = a chip's main trace (trace expansion kernels; table chip:
  * the counted multiplicities), 1 = its LogUp permutation trace (helper columns + running sum), 2 = its quotient values
@@ -268,7 +288,7 @@ int zksp_proof_public_tuples(const zksp_proof* p, uint32_t* n_tuples, uint32_t* 
  * cumulative sums (4 words each), as the device's transcript sampled / computed them. */
 int zksp_hip_machine_fetch_stage(zksp_client* c, int chip, int stage, size_t proof_index, uint32_t* out, size_t cap_words);
 int zksp_hip_machine_fetch_challenges(zksp_client* c, size_t proof_index, uint32_t* out /* [16 + 4 * ZKSP_MACHINE_CHIPS] */);
-/* Complete proof object (format v15) from one fetched body and the trace it belongs to.  log_heights: the shape the batch was
+/* Complete proof object (format v16) from one fetched body and the trace it belongs to.  log_heights: the shape the batch was
  * proven with (zksp_machine_cover_heights of the loaded traces), NULL = the trace's own minimal heights. */
 int zksp_machine_proof_from_body(const zksp_pk* pk, const zksp_mtrace* t, const int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] or NULL */,
                                  const uint32_t* body, size_t body_words, zksp_proof** out);

@@ -105,7 +105,7 @@ static orc_lf lf_bits(int bits, int n) {
 
 #define CPU_INTER 19
 static orc_inter g_cpu[CPU_INTER], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[5], g_div[13], g_table[7],
-    g_alu[1], g_sub[5], g_bw[5], g_p2[7], g_ecall[10], g_fold[5];
+    g_alu[1], g_sub[5], g_bw[5], g_p2[10], g_ecall[10], g_qr[17], g_tr[16];
 static orc_chip g_chips[N_CHIPS];
 static int g_ready = 0;
 
@@ -458,34 +458,166 @@ static void build(void) {
     g_p2[5] = range_inter(-1, lf_col(P2_IS_REAL), lf_const(0), lf_col(P2_KL));
     { orc_lf kh2; lf_zero(&kh2); lf_add(&kh2, P2_KH, 2); kh2.c0 = 1; g_p2[6] = range_inter(-1, lf_col(P2_IS_REAL), lf_const(2), kh2); }
   }
-  /* ---- FRI fold chip: the verifier's per-layer tuple, the hashed pair, the reduced openings, the end ---- */
+  /* ---- stage 2b: the Poseidon2 chip's run ends and hash ends ---- */
   {
-    const orc_lf q = lf_col(FO_Q), k = lf_col(FO_K);
-    orc_inter* it = &g_fold[0];
+    static const uint32_t m4[4][4] = {{2, 3, 1, 1}, {1, 2, 3, 1}, {1, 1, 2, 3}, {3, 1, 1, 2}};
+    const int ylast = P2_EXT + 32 * 7 + 16;
+    const orc_lf tag = lf_col(P2_T), mask = lf_col(P2_M), key = lf_pair(P2_KL, P2_KH, 65536);
+    orc_inter* it = &g_p2[7];
     memset(it, 0, sizeof *it);
-    it->bus = BUS_FRIQ; it->sign = -1; it->mult = lf_col(FO_IS_REAL); it->n_el = 8;
-    it->el[0] = q; it->el[1] = k; it->el[2] = lf_col(FO_BIT); it->el[3] = lf_col(FO_XINV);
-    for (int j = 0; j < 4; ++j) it->el[4 + j] = lf_col(FO_BETA + j);
-    it = &g_fold[1];
+    it->bus = BUS_POS; it->sign = +1; it->mult = lf_col(P2_RE); it->n_el = 4;
+    it->el[0] = tag; it->el[1] = key; it->el[2] = mask; it->el[3] = lf_col(P2_RID);
+    it = &g_p2[8];
     memset(it, 0, sizeof *it);
-    it->bus = BUS_PAIR; it->sign = -1; it->mult = lf_col(FO_IS_REAL); it->n_el = 9;
-    lf_zero(&it->el[0]); lf_add(&it->el[0], FO_Q, LEAF_TAG_STRIDE); lf_add(&it->el[0], FO_K, 1); it->el[0].c0 = LEAF_TAG(0, 4);
-    for (int j = 0; j < 4; ++j) { it->el[1 + j] = lf_col(FO_LO + j); it->el[5 + j] = lf_col(FO_HI + j); }
-    it = &g_fold[2];
+    it->bus = BUS_ROOT; it->sign = -1; it->mult = lf_col(P2_RE); it->n_el = 9;
+    it->el[0] = lf_col(P2_RID);
+    for (int j = 0; j < 8; ++j) {
+      lf_zero(&it->el[1 + j]);
+      for (int i = 0; i < 16; ++i) lf_add(&it->el[1 + j], ylast + i, m4[j & 3][i & 3] * ((i >> 2) == (j >> 2) ? 2u : 1u));
+    }
+    it = &g_p2[9];
     memset(it, 0, sizeof *it);
-    it->bus = BUS_RO; it->sign = -1; it->mult = lf_col(FO_FIRST); it->n_el = 6;
-    it->el[0] = q; it->el[1] = lf_const(0);
-    for (int j = 0; j < 4; ++j) it->el[2 + j] = lf_col(FO_E + j);
-    it = &g_fold[3];
+    it->bus = BUS_SEG; it->sign = +1; it->mult = lf_col(P2_SE); it->n_el = 11;
+    it->el[0] = tag; it->el[1] = key; it->el[2] = mask;
+    for (int j = 0; j < 4; ++j) { it->el[3 + j] = lf_col(P2_SO + j); it->el[7 + j] = lf_col(P2_AP + j); }
+  }
+  /* ---- query chip (machine.h).  T(r) = 1 + 64 QL + 2^18 LEAF + r, RID(r) = 64 LEAF + r ---- */
+  {
+#define QTAG(f, r, kcol) do { lf_zero(&(f)); lf_add(&(f), QR_QL, LEAF_TAG_STRIDE); lf_add(&(f), QR_LEAF, LEAF_TAG_LEAF_STRIDE); \
+                              if ((kcol) >= 0) lf_add(&(f), (kcol), 1); (f).c0 = 1 + (r); } while (0)
+#define QRID(f, r, kcol) do { lf_zero(&(f)); lf_add(&(f), QR_LEAF, 64); if ((kcol) >= 0) lf_add(&(f), (kcol), 1); (f).c0 = (r); } while (0)
+    const orc_lf leaf = lf_col(QR_LEAF), last = lf_col(QR_LAST), lay = lf_col(QR_LAY), hasro = lf_col(QR_HASRO);
+    int n = 0;
+    orc_inter* it = &g_qr[n++];
     memset(it, 0, sizeof *it);
-    it->bus = BUS_RO; it->sign = -1; it->mult = lf_col(FO_HASRO); it->n_el = 6;
-    it->el[0] = q; it->el[1] = lf_plus(k, 1);
-    for (int j = 0; j < 4; ++j) it->el[2 + j] = lf_col(FO_RO + j);
-    it = &g_fold[4];
+    it->bus = BUS_QIDX; it->sign = -1; it->mult = last; it->n_el = 3;
+    it->el[0] = leaf; it->el[1] = lf_col(QR_QL); it->el[2] = lf_col(QR_ACC);
+    it = &g_qr[n++];
     memset(it, 0, sizeof *it);
-    it->bus = BUS_FIN; it->sign = +1; it->mult = lf_col(FO_LAST); it->n_el = 6;
-    it->el[0] = q; it->el[1] = k;
-    for (int j = 0; j < 4; ++j) it->el[2 + j] = lf_pair(FO_F + j, FO_RO + j, 1);
+    it->bus = BUS_LEAFK; it->sign = -1; it->mult = last; it->n_el = 3;
+    it->el[0] = leaf; it->el[1] = lf_col(QR_K); it->el[2] = lf_col(QR_OMI);
+    it = &g_qr[n++];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_FINAL; it->sign = -1; it->mult = last; it->n_el = 5;
+    it->el[0] = leaf;
+    for (int j = 0; j < 4; ++j) it->el[1 + j] = lf_col(QR_F + j);
+    for (uint32_t r = 1; r <= 3; ++r) {
+      it = &g_qr[n++];
+      memset(it, 0, sizeof *it);
+      it->bus = BUS_POS; it->sign = -1; it->mult = lf_col(QR_CSR); it->n_el = 4;
+      QTAG(it->el[0], r, -1);
+      lf_zero(&it->el[1]); lf_add(&it->el[1], QR_POW, 2); lf_add(&it->el[1], QR_LOW, 2); lf_add(&it->el[1], QR_BIT, 1);
+      it->el[2] = lf_col(QR_MT); QRID(it->el[3], r, -1);
+    }
+    it = &g_qr[n++];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_POS; it->sign = -1; it->mult = lf_col(QR_PR0); it->n_el = 4;
+    QTAG(it->el[0], 0, -1);
+    lf_zero(&it->el[1]); lf_add(&it->el[1], QR_POW, 2); lf_add(&it->el[1], QR_LOW, 2); lf_add(&it->el[1], QR_CS, 1);
+    it->el[2] = lf_col(QR_MT0); QRID(it->el[3], 0, -1);
+    it = &g_qr[n++];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_POS; it->sign = -1; it->mult = lay; it->n_el = 4;
+    QTAG(it->el[0], 4, QR_K);
+    lf_zero(&it->el[1]); lf_add(&it->el[1], QR_POW, 2); lf_add(&it->el[1], QR_REV, 2); lf_add(&it->el[1], QR_CS, 1);
+    it->el[2] = lf_const(0); QRID(it->el[3], 4, QR_K);
+    it = &g_qr[n++];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_PAIR; it->sign = -1; it->mult = lay; it->n_el = 9;
+    QTAG(it->el[0], 4, QR_K);
+    for (int j = 0; j < 4; ++j) { it->el[1 + j] = lf_col(QR_LO + j); it->el[5 + j] = lf_col(QR_HI + j); }
+    it = &g_qr[n++];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_BETA; it->sign = -1; it->mult = lay; it->n_el = 6;
+    it->el[0] = leaf; it->el[1] = lf_col(QR_K);
+    for (int j = 0; j < 4; ++j) it->el[2 + j] = lf_col(QR_BETA + j);
+    for (uint32_t r = 0; r <= 3; ++r) {
+      it = &g_qr[n++];
+      memset(it, 0, sizeof *it);
+      it->bus = BUS_SEG; it->sign = -1; it->mult = r == 0 ? lf_col(QR_HAS0) : hasro; it->n_el = 11;
+      QTAG(it->el[0], r, -1);
+      it->el[1] = lf_col(r == 0 ? QR_KEY0 : QR_KEYJ); it->el[2] = lf_col(r == 0 ? QR_M0 : QR_MJ);
+      for (int j = 0; j < 4; ++j) { it->el[3 + j] = lf_col(QR_H + 4 * (int)r + j); it->el[7 + j] = lf_col(QR_AF + j); }
+    }
+    it = &g_qr[n++];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_ZETA; it->sign = -1; it->mult = hasro; it->n_el = 5;
+    it->el[0] = leaf;
+    for (int j = 0; j < 4; ++j) it->el[1 + j] = lf_col(QR_ZETA + j);
+    it = &g_qr[n++];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_AF; it->sign = -1; it->mult = hasro; it->n_el = 9;
+    it->el[0] = leaf;
+    for (int j = 0; j < 4; ++j) { it->el[1 + j] = lf_col(QR_AF + j); it->el[5 + j] = lf_col(QR_DL + j); }
+    it = &g_qr[n++];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_BCONST; it->sign = -1; it->mult = hasro; it->n_el = 12;
+    it->el[0] = leaf; it->el[1] = lf_col(QR_K); it->el[2] = lf_col(QR_HAS0); it->el[3] = lf_col(QR_WH);
+    for (int j = 0; j < 4; ++j) { it->el[4 + j] = lf_col(QR_B1 + j); it->el[8 + j] = lf_col(QR_B2 + j); }
+    if (n != 17) abort();
+#undef QTAG
+#undef QRID
+  }
+  /* ---- transcript chip (machine.h).  The output words of a row: the external linear layer of the last round's columns ---- */
+  {
+    static const uint32_t m4[4][4] = {{2, 3, 1, 1}, {1, 2, 3, 1}, {1, 1, 2, 3}, {3, 1, 1, 2}};
+    const int ylast = TR_EXT + 32 * 7 + 16;
+    orc_lf ow[8];
+    for (int j = 0; j < 8; ++j) {
+      lf_zero(&ow[j]);
+      for (int i = 0; i < 16; ++i) lf_add(&ow[j], ylast + i, m4[j & 3][i & 3] * ((i >> 2) == (j >> 2) ? 2u : 1u));
+    }
+    const orc_lf leaf = lf_col(TR_LEAF), step = lf_col(TR_STEP);
+    orc_lf flags;
+    lf_zero(&flags);
+    for (int k = 0; k < 7; ++k) lf_add(&flags, TR_UROOT + k, 1u << k);
+    for (int k = 0; k < 8; ++k) lf_add(&flags, TR_QM + k, 128u << k);
+    int n = 0;
+    orc_inter* it = &g_tr[n++];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_TBLK; it->sign = -1; it->mult = lf_col(TR_ABS); it->n_el = 12;
+    it->el[0] = leaf; it->el[1] = step; it->el[2] = flags; it->el[3] = lf_col(TR_RIDK);
+    for (int j = 0; j < 8; ++j) it->el[4 + j] = lf_col(TR_IN + j);
+    it = &g_tr[n++];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_TSQ; it->sign = -1; it->mult = lf_pair(TR_IS_REAL, TR_ABS, FP - 1); it->n_el = 4;
+    it->el[0] = leaf; it->el[1] = step; it->el[2] = flags; it->el[3] = lf_col(TR_QBASE);
+    it = &g_tr[n++];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_ROOT; it->sign = +1; it->mult = lf_col(TR_MROOT); it->n_el = 9;
+    lf_zero(&it->el[0]); lf_add(&it->el[0], TR_LEAF, 64); lf_add(&it->el[0], TR_RIDK, 1);
+    for (int j = 0; j < 8; ++j) it->el[1 + j] = lf_col(TR_IN + j);
+    it = &g_tr[n++];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_FINAL; it->sign = +1; it->mult = lf_col(TR_MFIN); it->n_el = 5;
+    it->el[0] = leaf;
+    for (int j = 0; j < 4; ++j) it->el[1 + j] = lf_col(TR_IN + j);
+    it = &g_tr[n++];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_ZETA; it->sign = +1; it->mult = lf_col(TR_MZETA); it->n_el = 5;
+    it->el[0] = leaf;
+    for (int j = 0; j < 4; ++j) it->el[1 + j] = ow[7 - j];
+    it = &g_tr[n++];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_AF; it->sign = +1; it->mult = lf_col(TR_MAF); it->n_el = 9;
+    it->el[0] = leaf;
+    for (int j = 0; j < 8; ++j) it->el[1 + j] = ow[7 - j];
+    it = &g_tr[n++];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_BETA; it->sign = +1; it->mult = lf_col(TR_MBETA); it->n_el = 6;
+    it->el[0] = leaf; it->el[1] = lf_plus(lf_col(TR_RIDK), FP - 4);
+    for (int j = 0; j < 4; ++j) it->el[2 + j] = ow[7 - j];
+    it = &g_tr[n++];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_POW; it->sign = +1; it->mult = lf_col(TR_UPOW); it->n_el = 2;
+    it->el[0] = leaf; it->el[1] = ow[7];
+    for (int j = 0; j < 8; ++j) {
+      it = &g_tr[n++];
+      memset(it, 0, sizeof *it);
+      it->bus = BUS_QIDX; it->sign = +1; it->mult = lf_col(TR_QM + j); it->n_el = 3;
+      it->el[0] = leaf; it->el[1] = lf_plus(lf_col(TR_QBASE), (uint32_t)j); it->el[2] = ow[7 - j];
+    }
+    if (n != 16) abort();
   }
   /* ---- sub-word ---- */
   {
@@ -529,8 +661,9 @@ static void build(void) {
   g_chips[CH_SUB2] = (orc_chip){"subword2", 0, SUB_WIDTH, 5, g_sub, 0, 0};
   g_chips[CH_BW] = (orc_chip){"bitwise", 0, BW_WIDTH, 5, g_bw, 0, 0};
   g_chips[CH_BW2] = (orc_chip){"bitwise2", 0, BW_WIDTH, 5, g_bw, 0, 0};
-  g_chips[CH_P2] = (orc_chip){"poseidon2", 0, P2CHIP_WIDTH, 7, g_p2, 0, 0};
-  g_chips[CH_FOLD] = (orc_chip){"fri-fold", 0, FOLD_WIDTH, 5, g_fold, 0, 0};
+  g_chips[CH_P2] = (orc_chip){"poseidon2", 0, P2CHIP_WIDTH, 10, g_p2, 0, 0};
+  g_chips[CH_QR] = (orc_chip){"query", 0, QR_WIDTH, 17, g_qr, 0, 0};
+  g_chips[CH_TR] = (orc_chip){"transcript", 0, TR_WIDTH, 16, g_tr, 0, 0};
   g_chips[CH_ECALL] = (orc_chip){"ecall", 0, ECALL_WIDTH, 10, g_ecall, 0, 0};
   g_ready = 1;
   for (int c = 0; c < N_CHIPS; ++c) g_chips[c].n_constraints = count_constraints(c);
@@ -638,7 +771,8 @@ void orc_machine_heights(const orc_machine_input* in, int logh[N_CHIPS]) {
     if (rows == (size_t)-1) rows = 0;
     rows += in->n_leaf_p2; /* ... and one per permutation of a leaf-proof check */
     logh[CH_P2] = at_least5(clog2(rows == 0 ? 1 : rows));
-    logh[CH_FOLD] = at_least5(clog2(in->n_leaf_fold ? in->n_leaf_fold : 1));
+    logh[CH_QR] = at_least5(clog2(in->n_leaf_qr ? in->n_leaf_qr : 1));
+    logh[CH_TR] = at_least5(clog2(in->n_leaf_tr ? in->n_leaf_tr : 1));
   }
   logh[CH_ECALL] = at_least5(clog2(orc_machine_events(in, 3, NULL)));
   logh[CH_DIV] = at_least5(clog2(orc_machine_events(in, 4, NULL)));
@@ -1087,6 +1221,14 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
           T(P2_FN) = kind == P2K_NODE; T(P2_SZ) = kind == P2K_SZ; T(P2_SC) = kind == P2K_SC; T(P2_PL) = kind == P2K_PL;
           T(P2_PR) = kind == P2K_PR; T(P2_FJ) = kind == P2K_J;
           T(P2_NEW) = (rc[0] & P2F_NEW) != 0; T(P2_SND) = (rc[0] & P2F_SND) != 0; T(P2_FR) = (rc[0] & P2F_FRI) != 0;
+          T(P2_RE) = (rc[0] & P2F_RE) != 0; T(P2_SE) = (rc[0] & P2F_SE) != 0; T(P2_RID) = rc[P2_REC_RID] % FP;
+          fe4 ap;
+          for (int i = 0; i < 4; ++i) { T(P2_SO + i) = rc[P2_REC_SO + i] % FP; ap.c[i] = rc[P2_REC_ALPHA + i] % FP; }
+          fe4 pw = ap; /* alpha^1 .. alpha^8 */
+          for (int j = 0; j < 8; ++j) {
+            for (int i = 0; i < 4; ++i) T(P2_AP + 4 * j + i) = pw.c[i];
+            pw = e_mul(pw, ap);
+          }
           for (int i = 0; i < 16; ++i) st[i] = rc[4 + i] % FP;
         }
         for (int i = 0; i < 16; ++i) T(P2_IN + i) = st[i];
@@ -1153,23 +1295,50 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
       free(ev);
       break;
     }
-    case CH_FOLD:
-      /* one row per query and layer of a leaf-proof check, as recorded; E and F follow from the record */
-      for (size_t r = 0; r < in->n_leaf_fold && r < h; ++r) {
-        const uint32_t* rc = in->leaf_fold_rows + FOLD_REC_WORDS * r;
-        const uint32_t bit = (rc[0] >> 2) & 1u, xinv = rc[3] % FP;
-        T(FO_IS_REAL) = 1; T(FO_FIRST) = rc[0] & 1u; T(FO_LAST) = (rc[0] >> 1) & 1u; T(FO_BIT) = bit; T(FO_HASRO) = (rc[0] >> 3) & 1u;
-        T(FO_Q) = rc[1] % FP; T(FO_K) = rc[2] % FP; T(FO_XINV) = xinv;
-        fe4 beta, lo, hi;
-        for (int i = 0; i < 4; ++i) {
-          beta.c[i] = rc[4 + i] % FP; lo.c[i] = rc[8 + i] % FP; hi.c[i] = rc[12 + i] % FP;
-          T(FO_BETA + i) = beta.c[i]; T(FO_LO + i) = lo.c[i]; T(FO_HI + i) = hi.c[i]; T(FO_RO + i) = rc[16 + i] % FP;
-        }
-        const fe half = (FP + 1) / 2;
-        const fe4 f = e_add(e_mul_base(e_add(lo, hi), half), e_mul(beta, e_mul_base(e_sub(lo, hi), f_mul(half, xinv))));
-        for (int i = 0; i < 4; ++i) { T(FO_E + i) = bit ? hi.c[i] : lo.c[i]; T(FO_F + i) = f.c[i]; }
+    case CH_QR:
+      /* 31 rows per query of a leaf-proof check: the record IS the row (the product's verifier computed it while it checked
+       * the query; check_constraints and the buses hold it to the AIR) */
+      for (size_t r = 0; r < in->n_leaf_qr && r < h; ++r) {
+        const uint32_t* rc = in->leaf_qr_rows + QR_REC_WORDS * r;
+        for (int c = 0; c < QR_WIDTH; ++c) T(c) = rc[c] % FP;
       }
       break;
+    case CH_TR: {
+      /* one duplex of a checked leaf's transcript per row, as recorded; the permutation's columns are filled in here */
+      uint32_t ext_rc[8][16], int_rc[13];
+      orc_poseidon2_constants(&ext_rc[0][0], int_rc);
+      for (size_t r = 0; r < h; ++r) {
+        uint32_t st[16] = {0};
+        if (r < in->n_leaf_tr) {
+          const uint32_t* rc = in->leaf_tr_rows + TR_REC_WORDS * r;
+          T(TR_IS_REAL) = 1; T(TR_LEAF) = rc[1] % FP; T(TR_STEP) = rc[2] % FP;
+          T(TR_FIRST) = (rc[0] >> 16) & 1u; T(TR_ABS) = (rc[0] >> 17) & 1u;
+          for (int k = 0; k < 7; ++k) T(TR_UROOT + k) = (rc[0] >> k) & 1u;
+          for (int k = 0; k < 8; ++k) T(TR_QM + k) = (rc[0] >> (7 + k)) & 1u;
+          T(TR_RIDK) = rc[3] % FP; T(TR_QBASE) = rc[4] % FP;
+          for (int k = 0; k < 5; ++k) T(TR_MROOT + k) = rc[5 + k] % FP;
+          for (int i = 0; i < 16; ++i) st[i] = rc[10 + i] % FP;
+        }
+        for (int i = 0; i < 16; ++i) T(TR_IN + i) = st[i];
+        orc_p2_external_linear(st);
+        for (int rd = 0; rd < 8; ++rd) {
+          if (rd == 4)
+            for (int ir = 0; ir < 13; ++ir) {
+              const fe x = f_add(st[0], int_rc[ir]), x3 = f_mul(f_mul(x, x), x), y = f_mul(f_mul(x3, x3), x);
+              T(TR_INT + 2 * ir) = x3; T(TR_INT + 2 * ir + 1) = y;
+              st[0] = y;
+              orc_p2_internal_linear(st);
+            }
+          for (int i = 0; i < 16; ++i) {
+            const fe x = f_add(st[i], ext_rc[rd][i]), x3 = f_mul(f_mul(x, x), x), y = f_mul(f_mul(x3, x3), x);
+            T(TR_EXT + 32 * rd + i) = x3; T(TR_EXT + 32 * rd + 16 + i) = y;
+            st[i] = y;
+          }
+          orc_p2_external_linear(st);
+        }
+      }
+      break;
+    }
     case CH_TABLE:
       for (size_t r = 0; r < h; ++r) {
         prep[(size_t)TB_P_X * h + r] = (uint32_t)(r & 255);
@@ -1499,37 +1668,47 @@ static void bw_constraints(const uint32_t* l, sink* s) {
   emit(s, f_sub(selsum, l[BW_IS_REAL]));
 }
 
-/* Poseidon2 chip: every S-box through its cube; the state between S-boxes is linear in the columns.  Then the 67
- * constraints that tie the rows of an opening together (machine.h "Poseidon2 chip"); they refer to the next row wherever
- * that row takes over from this one, cyclically: row 0 takes over from nothing. */
-static void p2_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe is_trans, sink* s) {
+/* The permutation of one row: the columns IN (16 words), EXT (8 rounds x (16 cubes, 16 seventh powers)), INT (13 x (cube,
+ * seventh power)); 282 constraints; st[] comes back as the 16 output words, linear in the last round's columns. */
+static void p2_perm_constraints(const uint32_t* l, int c_in, int c_ext, int c_int, fe st[16], sink* s) {
   uint32_t ext_rc[8][16], int_rc[13];
   orc_poseidon2_constants(&ext_rc[0][0], int_rc);
-  const fe real = l[P2_IS_REAL];
-  emit(s, bool_c(real));
-  emit(s, f_mul(f_mul(is_trans, n[P2_IS_REAL]), f_sub(1, real))); /* the real rows are a prefix */
-  fe st[16];
-  for (int i = 0; i < 16; ++i) st[i] = l[P2_IN + i];
+  for (int i = 0; i < 16; ++i) st[i] = l[c_in + i];
   orc_p2_external_linear(st);
   for (int rd = 0; rd < 8; ++rd) {
     if (rd == 4)
       for (int ir = 0; ir < 13; ++ir) {
-        const fe x = f_add(st[0], int_rc[ir]), x3 = l[P2_INT + 2 * ir], y = l[P2_INT + 2 * ir + 1];
+        const fe x = f_add(st[0], int_rc[ir]), x3 = l[c_int + 2 * ir], y = l[c_int + 2 * ir + 1];
         emit(s, f_sub(x3, f_mul(f_mul(x, x), x)));
         emit(s, f_sub(y, f_mul(f_mul(x3, x3), x)));
         st[0] = y;
         orc_p2_internal_linear(st);
       }
     for (int i = 0; i < 16; ++i) {
-      const fe x = f_add(st[i], ext_rc[rd][i]), x3 = l[P2_EXT + 32 * rd + i], y = l[P2_EXT + 32 * rd + 16 + i];
+      const fe x = f_add(st[i], ext_rc[rd][i]), x3 = l[c_ext + 32 * rd + i], y = l[c_ext + 32 * rd + 16 + i];
       emit(s, f_sub(x3, f_mul(f_mul(x, x), x)));
       emit(s, f_sub(y, f_mul(f_mul(x3, x3), x)));
       st[i] = y;
     }
     orc_p2_external_linear(st);
   }
+}
+static inline fe4 row4(const uint32_t* row, int col) { fe4 r; for (int i = 0; i < 4; ++i) r.c[i] = row[col + i]; return r; }
+static inline void emit4(sink* s, fe4 v) { for (int i = 0; i < 4; ++i) emit(s, v.c[i]); }
+static inline void emit4_sel(sink* s, fe sel, fe4 v) { for (int i = 0; i < 4; ++i) emit(s, f_mul(sel, v.c[i])); }
+
+/* Poseidon2 chip: every S-box through its cube; the state between S-boxes is linear in the columns.  Then the 67
+ * constraints that tie the rows of an opening together (machine.h "Poseidon2 chip"); they refer to the next row wherever
+ * that row takes over from this one, cyclically: row 0 takes over from nothing.  Then format v16's 45: the ends of runs and of
+ * hashes, and Horner's rule over the absorbed words. */
+static void p2_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe is_trans, sink* s) {
+  const fe real = l[P2_IS_REAL];
+  emit(s, bool_c(real));
+  emit(s, f_mul(f_mul(is_trans, n[P2_IS_REAL]), f_sub(1, real))); /* the real rows are a prefix */
+  fe st[16];
+  p2_perm_constraints(l, P2_IN, P2_EXT, P2_INT, st, s);
   /* st[] = the permutation's 16 output words.  Row kinds: one per real row; NEW lives on sponge rows, FR on first blocks,
-   * SND anywhere but on a node row (which always sends) or a padding row */
+   * SND and SE on sponge rows, RE on path and injection rows */
   const fe fn = l[P2_FN], sz = l[P2_SZ], sc = l[P2_SC], pl = l[P2_PL], pr = l[P2_PR], fj = l[P2_FJ], nw = l[P2_NEW], snd = l[P2_SND],
            fr = l[P2_FR];
   emit(s, bool_c(fn)); emit(s, bool_c(sz)); emit(s, bool_c(sc)); emit(s, bool_c(pl)); emit(s, bool_c(pr));
@@ -1537,7 +1716,7 @@ static void p2_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe
   const fe chain = f_add(f_add(sc, pl), f_add(pr, fj)); /* the kinds that take over from the row before */
   emit(s, f_sub(f_add(f_add(fn, sz), chain), real));
   emit(s, f_mul(nw, f_sub(f_sub(1, sz), sc)));
-  emit(s, f_mul(snd, f_sub(f_sub(1, sz), chain)));
+  emit(s, f_mul(snd, f_sub(f_sub(1, sz), sc)));
   emit(s, f_mul(fr, f_sub(1, sz)));
   /* a first block starts from the zero state; the first block of a run from K = 1, M = 0 */
   for (int i = 0; i < 8; ++i) emit(s, f_mul(sz, l[P2_IN + 8 + i]));
@@ -1567,38 +1746,201 @@ static void p2_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe
   emit(s, f_mul(nfj, f_sub(nkey, key)));
   emit(s, f_mul(nfj, f_sub(f_sub(nm, m), 1)));
   emit(s, f_mul(nfj, f_sub(f_sub(1, pl), pr)));
+  /* ---- format v16 (stage 2b) ---- */
+  const fe re = l[P2_RE], se = l[P2_SE];
+  emit(s, bool_c(re));
+  emit(s, bool_c(se));
+  emit(s, f_mul(re, f_sub(f_sub(f_sub(1, pl), pr), fj)));
+  emit(s, f_mul(se, f_sub(f_sub(1, sz), sc)));
+  emit(s, f_mul(se, nsc));
+  fe4 ap[8];
+  for (int j = 0; j < 8; ++j) ap[j] = row4(l, P2_AP + 4 * j);
+  for (int j = 0; j < 7; ++j) emit4(s, e_sub(ap[j + 1], e_mul(ap[j], ap[0])));
+  for (int i = 0; i < 4; ++i) emit(s, f_mul(nsc, f_sub(n[P2_AP + i], ap[0].c[i])));
+  {
+    fe4 bv = e_zero(); /* this row's block: sum_{i < 8} alpha^(7 - i) in_i */
+    for (int i = 0; i < 7; ++i) bv = e_add(bv, e_mul_base(ap[6 - i], l[P2_IN + i]));
+    bv.c[0] = f_add(bv.c[0], l[P2_IN + 7]);
+    emit4_sel(s, sz, e_sub(row4(l, P2_SO), bv));
+    fe4 nbv = e_zero();
+    for (int i = 0; i < 7; ++i) nbv = e_add(nbv, e_mul_base(row4(n, P2_AP + 4 * (6 - i)), n[P2_IN + i]));
+    nbv.c[0] = f_add(nbv.c[0], n[P2_IN + 7]);
+    emit4_sel(s, nsc, e_sub(e_sub(row4(n, P2_SO), e_mul(row4(l, P2_SO), row4(n, P2_AP + 28))), nbv));
+  }
 }
 
-/* FRI fold chip (machine.h): 31 constraints; the extension field is F_p[x] / (x^4 - 11) */
-static void fold_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe is_trans, sink* s) {
-  const fe real = l[FO_IS_REAL], first = l[FO_FIRST], last = l[FO_LAST], bit = l[FO_BIT], hasro = l[FO_HASRO];
-  emit(s, bool_c(real)); emit(s, bool_c(first)); emit(s, bool_c(last)); emit(s, bool_c(bit)); emit(s, bool_c(hasro));
-  emit(s, f_mul(f_mul(is_trans, n[FO_IS_REAL]), f_sub(1, real))); /* the real rows are a prefix */
-  emit(s, f_mul(first, f_sub(1, real))); emit(s, f_mul(last, f_sub(1, real))); emit(s, f_mul(hasro, f_sub(1, real)));
-  emit(s, f_mul(first, l[FO_K]));
-  emit(s, f_mul(is_first, f_sub(real, first)));
-  fe lo[4], hi[4], d[4], be[4];
-  for (int i = 0; i < 4; ++i) { lo[i] = l[FO_LO + i]; hi[i] = l[FO_HI + i]; d[i] = f_sub(lo[i], hi[i]); be[i] = l[FO_BETA + i]; }
-  /* the value the layer shows at the query's position */
-  for (int i = 0; i < 4; ++i) emit(s, f_add(f_sub(l[FO_E + i], lo[i]), f_mul(bit, d[i])));
-  /* 2 F = LO + HI + XINV * BETA * (LO - HI) */
+/* Query chip (machine.h): the constraints in the order of zk-state-proofs_amd/csrc/device/air_machine.hpp eval_qr */
+static void qr_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe is_trans, sink* s) {
+  const fe real = l[QR_IS_REAL], first = l[QR_FIRST], last = l[QR_LAST], bit = l[QR_BIT], eq = l[QR_EQ], f1 = l[QR_F1], f2 = l[QR_F2],
+           f3 = l[QR_F3], csr = l[QR_CSR], fl = l[QR_FL], lay = l[QR_LAY], cs = l[QR_CS], pr0 = l[QR_PR0], p0a = l[QR_P0A],
+           hasro = l[QR_HASRO], has0 = l[QR_HAS0];
   {
-    const fe xinv = l[FO_XINV];
-    const fe p0 = f_add(f_mul(be[0], d[0]), f_mul(11, f_add(f_add(f_mul(be[1], d[3]), f_mul(be[2], d[2])), f_mul(be[3], d[1]))));
-    const fe p1 = f_add(f_add(f_mul(be[0], d[1]), f_mul(be[1], d[0])), f_mul(11, f_add(f_mul(be[2], d[3]), f_mul(be[3], d[2]))));
-    const fe p2 = f_add(f_add(f_add(f_mul(be[0], d[2]), f_mul(be[1], d[1])), f_mul(be[2], d[0])), f_mul(11, f_mul(be[3], d[3])));
-    const fe p3 = f_add(f_add(f_mul(be[0], d[3]), f_mul(be[1], d[2])), f_add(f_mul(be[2], d[1]), f_mul(be[3], d[0])));
-    const fe pp[4] = {p0, p1, p2, p3};
-    for (int i = 0; i < 4; ++i) emit(s, f_sub(f_sub(f_sub(f_add(l[FO_F + i], l[FO_F + i]), lo[i]), hi[i]), f_mul(xinv, pp[i])));
+    const fe bools[17] = {real, first, last, bit, eq, f1, f2, f3, csr, fl, lay, cs, pr0, p0a, hasro, has0, l[QR_CNT0]};
+    for (int i = 0; i < 17; ++i) emit(s, bool_c(bools[i]));
   }
-  for (int i = 0; i < 4; ++i) emit(s, f_mul(f_sub(1, hasro), l[FO_RO + i]));
-  /* the next row goes on with this query unless it starts one (or is padding) */
-  const fe cont = f_sub(n[FO_IS_REAL], n[FO_FIRST]);
-  emit(s, f_mul(cont, f_sub(n[FO_Q], l[FO_Q])));
-  emit(s, f_mul(cont, f_sub(f_sub(n[FO_K], l[FO_K]), 1)));
-  for (int i = 0; i < 4; ++i) emit(s, f_mul(cont, f_sub(f_sub(n[FO_E + i], l[FO_F + i]), l[FO_RO + i])));
-  emit(s, f_mul(last, cont));
-  emit(s, f_mul(f_sub(real, last), f_sub(1, cont)));
+  const fe cont = f_sub(n[QR_IS_REAL], n[QR_FIRST]), nl1 = f_sub(n[QR_LAY], n[QR_FL]);
+#define ADD(a, b) f_add(a, b)
+#define SUB(a, b) f_sub(a, b)
+#define MUL(a, b) f_mul(a, b)
+#define DBL(a) f_add(a, a)
+  emit(s, MUL(MUL(is_trans, n[QR_IS_REAL]), SUB(1, real)));
+  emit(s, MUL(is_first, SUB(real, first)));
+  {
+    fe sum = first;
+    const fe fl_[14] = {last, csr, fl, lay, pr0, p0a, hasro, has0, bit, eq, f1, f2, f3, cs};
+    for (int i = 0; i < 14; ++i) sum = ADD(sum, fl_[i]);
+    emit(s, MUL(sum, SUB(1, real)));
+  }
+  const fe j = l[QR_J];
+  emit(s, MUL(first, SUB(j, 30)));
+  emit(s, MUL(last, j));
+  emit(s, MUL(cont, ADD(SUB(n[QR_J], j), 1)));
+  emit(s, MUL(last, cont));
+  emit(s, MUL(SUB(real, last), SUB(1, cont)));
+  emit(s, MUL(cont, SUB(n[QR_LEAF], l[QR_LEAF])));
+  emit(s, MUL(cont, SUB(n[QR_QL], l[QR_QL])));
+  emit(s, MUL(first, SUB(l[QR_ACC], bit)));
+  emit(s, MUL(cont, SUB(SUB(n[QR_ACC], DBL(l[QR_ACC])), n[QR_BIT])));
+  emit(s, MUL(first, ADD(ADD(f1, f2), f3)));
+  emit(s, MUL(cont, SUB(n[QR_F1], first)));
+  emit(s, MUL(cont, SUB(n[QR_F2], f1)));
+  emit(s, MUL(cont, SUB(n[QR_F3], f2)));
+  emit(s, MUL(first, SUB(eq, bit)));
+  {
+    const fe nf = ADD(ADD(n[QR_F1], n[QR_F2]), n[QR_F3]);
+    emit(s, MUL(nf, SUB(n[QR_EQ], MUL(eq, n[QR_BIT]))));
+    emit(s, MUL(SUB(cont, nf), SUB(n[QR_EQ], eq)));
+    emit(s, MUL(MUL(SUB(SUB(SUB(SUB(real, first), f1), f2), f3), eq), bit));
+  }
+  emit(s, MUL(csr, lay));
+  emit(s, MUL(fl, SUB(1, lay)));
+  emit(s, MUL(first, ADD(csr, lay)));
+  emit(s, MUL(cont, SUB(n[QR_FL], csr)));
+  emit(s, MUL(cont, SUB(SUB(n[QR_LAY], csr), lay)));
+  emit(s, MUL(last, SUB(1, lay)));
+  emit(s, MUL(fl, l[QR_K]));
+  emit(s, MUL(nl1, SUB(SUB(n[QR_K], l[QR_K]), 1)));
+  emit(s, MUL(csr, SUB(cs, bit)));
+  emit(s, MUL(MUL(cont, ADD(csr, lay)), SUB(n[QR_CS], cs)));
+  emit(s, MUL(last, SUB(l[QR_POW], 1)));
+  emit(s, MUL(last, l[QR_LOW]));
+  emit(s, MUL(last, l[QR_REV]));
+  emit(s, MUL(cont, SUB(l[QR_POW], DBL(n[QR_POW]))));
+  emit(s, MUL(cont, SUB(SUB(l[QR_LOW], n[QR_LOW]), MUL(n[QR_BIT], n[QR_POW]))));
+  emit(s, MUL(cont, SUB(SUB(l[QR_REV], DBL(n[QR_REV])), n[QR_BIT])));
+  emit(s, MUL(pr0, SUB(j, 16)));
+  emit(s, MUL(first, SUB(l[QR_CNT0], pr0)));
+  emit(s, MUL(cont, SUB(SUB(n[QR_CNT0], l[QR_CNT0]), n[QR_PR0])));
+  emit(s, MUL(last, SUB(l[QR_CNT0], 1)));
+  emit(s, MUL(first, p0a));
+  emit(s, MUL(cont, SUB(SUB(n[QR_P0A], p0a), pr0)));
+  emit(s, MUL(MUL(cont, pr0), SUB(n[QR_KEY0], 1)));
+  emit(s, MUL(MUL(cont, pr0), n[QR_M0]));
+  emit(s, MUL(MUL(cont, p0a), SUB(SUB(n[QR_KEY0], DBL(l[QR_KEY0])), bit)));
+  emit(s, MUL(MUL(cont, p0a), SUB(SUB(n[QR_M0], DBL(l[QR_M0])), n[QR_HAS0])));
+  emit(s, MUL(has0, SUB(1, p0a)));
+  emit(s, MUL(has0, SUB(1, hasro)));
+  emit(s, MUL(cont, SUB(n[QR_MT0], l[QR_MT0])));
+  emit(s, MUL(last, SUB(l[QR_MT0], MUL(4, l[QR_M0]))));
+  emit(s, MUL(fl, SUB(l[QR_KEYJ], 1)));
+  emit(s, MUL(fl, l[QR_MJ]));
+  emit(s, MUL(nl1, SUB(SUB(n[QR_KEYJ], DBL(l[QR_KEYJ])), bit)));
+  emit(s, MUL(nl1, SUB(SUB(n[QR_MJ], DBL(l[QR_MJ])), n[QR_HASRO])));
+  emit(s, MUL(cont, SUB(n[QR_MT], l[QR_MT])));
+  emit(s, MUL(last, SUB(l[QR_MT], MUL(4, l[QR_MJ]))));
+  emit(s, MUL(hasro, SUB(1, lay)));
+  emit(s, MUL(fl, SUB(1, hasro)));
+  const fe omi = l[QR_OMI];
+  emit(s, MUL(cont, SUB(n[QR_OMI], omi)));
+  emit(s, SUB(SUB(l[QR_MU], real), MUL(bit, SUB(omi, 1))));
+  emit(s, SUB(SUB(l[QR_CSM], real), MUL(cs, SUB(omi, 1))));
+  emit(s, SUB(l[QR_R2], MUL(l[QR_R], l[QR_R])));
+  emit(s, MUL(fl, SUB(l[QR_R], l[QR_MU])));
+  emit(s, MUL(nl1, SUB(n[QR_R], MUL(l[QR_R2], n[QR_MU]))));
+  emit(s, MUL(cont, SUB(n[QR_YT], l[QR_YT])));
+  emit(s, MUL(last, SUB(l[QR_YT], MUL(l[QR_R2], l[QR_CSM]))));
+  emit(s, MUL(fl, SUB(l[QR_YKI], l[QR_YT])));
+  emit(s, MUL(nl1, SUB(n[QR_YKI], MUL(l[QR_YKI], l[QR_YKI]))));
+  emit(s, MUL(fl, SUB(l[QR_GI], F_GEN_INV)));
+  emit(s, MUL(nl1, SUB(n[QR_GI], MUL(l[QR_GI], l[QR_GI]))));
+  emit(s, SUB(l[QR_XINV], MUL(MUL(l[QR_GI], l[QR_YKI]), SUB(1, DBL(bit)))));
+  /* the fold */
+  const fe4 lo = row4(l, QR_LO), hi = row4(l, QR_HI), be = row4(l, QR_BETA), d = e_sub(lo, hi);
+  for (int i = 0; i < 4; ++i) emit(s, ADD(SUB(l[QR_E + i], lo.c[i]), MUL(bit, d.c[i])));
+  {
+    const fe4 pd = e_mul(be, d);
+    for (int i = 0; i < 4; ++i) emit(s, SUB(SUB(SUB(DBL(l[QR_F + i]), lo.c[i]), hi.c[i]), MUL(l[QR_XINV], pd.c[i])));
+  }
+  for (int i = 0; i < 4; ++i) emit(s, MUL(SUB(1, hasro), l[QR_RO + i]));
+  for (int i = 0; i < 4; ++i) emit(s, MUL(fl, SUB(l[QR_E + i], l[QR_RO + i])));
+  for (int i = 0; i < 4; ++i) emit(s, MUL(nl1, SUB(SUB(n[QR_E + i], l[QR_F + i]), n[QR_RO + i])));
+  /* the reduced opening */
+  {
+    const fe4 dl = row4(l, QR_DL), d2 = row4(l, QR_D2), d3 = row4(l, QR_D3), d4 = row4(l, QR_D4), g2 = row4(l, QR_G2),
+              zeta = row4(l, QR_ZETA), zw = row4(l, QR_ZW), d0 = row4(l, QR_D0), d1 = row4(l, QR_D1), h0 = row4(l, QR_H),
+              h1 = row4(l, QR_H + 4), h2 = row4(l, QR_H + 8), h3 = row4(l, QR_H + 12);
+    emit4(s, e_sub(d2, e_mul(dl, dl)));
+    emit4(s, e_sub(d3, e_mul(d2, dl)));
+    emit4(s, e_sub(d4, e_mul(d2, d2)));
+    emit4(s, e_sub(g2, e_add(h1, e_mul(dl, h2))));
+    emit4(s, e_sub(zw, e_mul_base(zeta, l[QR_WH])));
+    const fe yki = l[QR_YKI], nyki = SUB(0, yki);
+    fe4 den0 = e_mul_base(zeta, nyki), den1 = e_mul_base(zw, nyki);
+    den0.c[0] = ADD(den0.c[0], F_GEN);
+    den1.c[0] = ADD(den1.c[0], F_GEN);
+    fe4 p0 = e_mul(d0, den0), p1 = e_mul(d1, den1);
+    p0.c[0] = SUB(p0.c[0], yki);
+    p1.c[0] = SUB(p1.c[0], yki);
+    emit4(s, p0);
+    emit4(s, p1);
+    fe4 hs = e_add(e_add(h0, e_mul(dl, h1)), e_add(e_mul(d2, h2), e_mul(d3, h3)));
+    hs = e_sub(hs, row4(l, QR_B1));
+    const fe4 t2 = e_sub(e_mul(d4, g2), row4(l, QR_B2));
+    emit4(s, e_sub(row4(l, QR_RO), e_add(e_mul(d0, hs), e_mul(d1, t2))));
+  }
+#undef ADD
+#undef SUB
+#undef MUL
+#undef DBL
+}
+
+/* Transcript chip (machine.h) */
+static void tr_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe is_trans, sink* s) {
+  const fe real = l[TR_IS_REAL], first = l[TR_FIRST], abs_ = l[TR_ABS];
+  emit(s, bool_c(real));
+  emit(s, f_mul(f_mul(is_trans, n[TR_IS_REAL]), f_sub(1, real)));
+  fe st[16];
+  p2_perm_constraints(l, TR_IN, TR_EXT, TR_INT, st, s);
+  fe fsum = f_add(first, abs_);
+  emit(s, bool_c(first));
+  emit(s, bool_c(abs_));
+  for (int k = 0; k < 7 + 8; ++k) {
+    emit(s, bool_c(l[TR_UROOT + k]));
+    fsum = f_add(fsum, l[TR_UROOT + k]);
+  }
+  emit(s, f_mul(fsum, f_sub(1, real)));
+  emit(s, f_mul(first, f_sub(1, abs_)));
+  emit(s, f_mul(first, l[TR_STEP]));
+  for (int i = 0; i < 8; ++i) emit(s, f_mul(first, l[TR_IN + 8 + i]));
+  emit(s, f_mul(is_first, f_sub(real, first)));
+  const fe cont = f_sub(n[TR_IS_REAL], n[TR_FIRST]);
+  emit(s, f_mul(cont, f_sub(n[TR_LEAF], l[TR_LEAF])));
+  emit(s, f_mul(cont, f_sub(f_sub(n[TR_STEP], l[TR_STEP]), 1)));
+  for (int i = 0; i < 8; ++i) emit(s, f_mul(cont, f_sub(n[TR_IN + 8 + i], st[8 + i])));
+  {
+    const fe sq = f_mul(cont, f_sub(1, n[TR_ABS]));
+    for (int i = 0; i < 8; ++i) emit(s, f_mul(sq, f_sub(n[TR_IN + i], st[i])));
+  }
+  {
+    fe qm = l[TR_QM];
+    for (int k = 1; k < 8; ++k) qm = f_add(qm, l[TR_QM + k]);
+    emit(s, f_mul(qm, f_sub(1, l[TR_UQ])));
+  }
+  emit(s, f_mul(l[TR_MROOT], f_sub(1, l[TR_UROOT])));
+  emit(s, f_mul(l[TR_MFIN], f_sub(1, l[TR_UFIN])));
+  emit(s, f_mul(l[TR_MZETA], f_sub(1, l[TR_UZETA])));
+  emit(s, f_mul(l[TR_MAF], f_sub(1, l[TR_UAF])));
+  emit(s, f_mul(l[TR_MBETA], f_sub(1, l[TR_UBETA])));
 }
 
 /* sub-word chip: M is the memory word, C the low limb of the stored register, both as bits */
@@ -1687,7 +2029,8 @@ static void run_constraints(int chip, const uint32_t* prep, const uint32_t* loc,
     case CH_BW:
     case CH_BW2: bw_constraints(loc, s); break;
     case CH_P2: p2_constraints(loc, nxt, is_first, is_trans, s); break;
-    case CH_FOLD: fold_constraints(loc, nxt, is_first, is_trans, s); break;
+    case CH_QR: qr_constraints(loc, nxt, is_first, is_trans, s); break;
+    case CH_TR: tr_constraints(loc, nxt, is_first, is_trans, s); break;
     case CH_DIV: div_constraints(loc, s); break;
     case CH_TABLE: /* only multiples of 4 answer aligned lookups, only values 1 .. ADDR_HI_MAX high-address-limb lookups */
       emit(s, f_mul(loc[TB_M_AL], prep[TB_P_NA]));

@@ -43,7 +43,7 @@ extern "C" {
 #define CPU_INST 8
 enum {
   CH_CPU = 0, CH_KECCAK, CH_KMEM, CH_MEMFINAL, CH_IMAGE, CH_PROGRAM, CH_MUL, CH_TABLE, CH_CPU2, CH_ALU, CH_ALU2, CH_SUB,
-  CH_SUB2, CH_BW, CH_BW2, CH_P2, CH_ECALL, CH_CPU3, CH_CPU4, CH_CPU5, CH_CPU6, CH_CPU7, CH_CPU8, CH_FOLD, CH_DIV, N_CHIPS
+  CH_SUB2, CH_BW, CH_BW2, CH_P2, CH_ECALL, CH_CPU3, CH_CPU4, CH_CPU5, CH_CPU6, CH_CPU7, CH_CPU8, CH_QR, CH_DIV, CH_TR, N_CHIPS
 };
 /* CPU instance i = 0 .. CPU_INST - 1 <-> chip (the first two keep their old places in the proof order) */
 static inline int orc_cpu_chip(int i) { return i == 0 ? CH_CPU : i == 1 ? CH_CPU2 : CH_CPU3 + (i - 2); }
@@ -169,31 +169,67 @@ enum {
 enum {
   P2_IS_REAL = 0, P2_KL, P2_KH /* the key / position accumulator, two limbs */, P2_T /* tag of the opening */, P2_M /* injection mask */,
   P2_FN, P2_SZ, P2_SC, P2_PL, P2_PR, P2_FJ /* row kind, one-hot on real rows */, P2_NEW /* (sponge rows) the run's first hash */,
-  P2_SND /* the row sends its digest */, P2_FR /* a FRI leaf: the absorbed pair goes to the fold chip */,
+  P2_SND /* (sponge rows) the hash goes to an injection row */, P2_FR /* a FRI leaf: the absorbed pair goes to the query chip */,
   P2_IN /* 16 */, P2_EXT = P2_IN + 16 /* 8 external rounds x (16 cubes, 16 outputs) */,
-  P2_INT = P2_EXT + 256 /* 13 internal rounds x (cube, output) */, P2CHIP_WIDTH = P2_INT + 26
+  P2_INT = P2_EXT + 256 /* 13 internal rounds x (cube, output) */,
+  /* format v16 (stage 2b): RE - the last row of a run: its digest is compared with the root RID names (ROOT bus: the transcript
+   * chip's, or the verifier's for the preprocessed tree), its position goes to the query chip (POS bus); SE - the last block of
+   * a matrix row's hash: the Horner sum SO (in alpha_f, over every absorbed word, block by block:
+   * SO' = SO alpha^8 + sum_{i<8} alpha^(7-i) in_i) goes to the query chip (SEG bus); AP: alpha_f^1 .. alpha_f^8 */
+  P2_RE = P2_INT + 26, P2_SE, P2_RID, P2_SO /* 4 */, P2_AP = P2_SO + 4 /* 8 x 4 */, P2CHIP_WIDTH = P2_AP + 32
 };
-/* row records (P2_REC_WORDS each): flags = kind | P2F_*, tag, key, mask, the 16 input words */
+/* row records (P2_REC_WORDS each): flags = kind | P2F_*, tag, key, mask, the 16 input words, RID, SO (4), alpha_f (4), padding */
 enum { P2K_NONE = 0, P2K_NODE, P2K_SZ, P2K_SC, P2K_PL, P2K_PR, P2K_J };
-#define P2_REC_WORDS 20
+#define P2_REC_WORDS 32
+#define P2_REC_RID 20
+#define P2_REC_SO 21
+#define P2_REC_ALPHA 25
 #define P2F_NEW 16u
 #define P2F_SND 32u
 #define P2F_FRI 64u
-/* tags of a leaf proof's openings: query q, tree r (0 preprocessed, 1 main, 2 permutation, 3 quotient, 4 + k: FRI layer k) */
+#define P2F_RE 128u
+#define P2F_SE 256u
+/* tags of a leaf proof's openings: leaf l (its place among the leaves checked beside one run), query q, tree r (0
+ * preprocessed, 1 main, 2 permutation, 3 quotient, 4 + k: FRI layer k); ids of its commitment roots */
 #define LEAF_TAG_STRIDE 64u
-#define LEAF_TAG(q, r) (1u + LEAF_TAG_STRIDE * (q) + (r))
-/* ---- FRI fold chip (row f4, stage 2a): one row per query and layer of a leaf proof's FRI.  The sibling pair (LO, HI) arrives
- *      from the sponge row that hashed it (PAIR bus); the layer's challenge, the inverse of the pair's domain point and the
- *      position bit from the verifier (FRIQ bus); E - the value the layer must show at the query's position - is LO or HI by
- *      the bit; F = (LO + HI) / 2 + BETA (LO - HI) XINV / 2 is the folded value; the next layer's E is F plus the reduced
- *      opening that joins there (RO bus: the verifier's, in stage 2a); the last F goes to the verifier (FIN bus), who knows
- *      the final constant. ---- */
+#define LEAF_TAG_LEAF_STRIDE (1u << 18)
+#define LEAF_TAG(l, q, r) (1u + LEAF_TAG_STRIDE * (q) + LEAF_TAG_LEAF_STRIDE * (l) + (r))
+#define LEAF_RID(l, r) (64u * (l) + (r))
+/* ---- query chip (row f4, stage 2b; it stands where stage 2a's fold chip stood): 31 rows per query of a checked leaf proof,
+ *      one per bit of the word the leaf's transcript drew for the query, from bit 30 down (J).  The bits are the canonical
+ *      decomposition of the word (ACC from the top; EQ: the bits so far equal those of p - 1 = 0x78000000; F1..F3 mark the rows of
+ *      bits 29..27).  Bit lm is the coset (row CSR), the bits below the position; the rows of the bits lm - 1 .. 0 are the FRI
+ *      layers K = 0 .. lm - 1 (LAY; FL: layer 0).  POW = 2^J, LOW = the word mod 2^J, REV = its low J bits reversed: the keys of
+ *      the openings are linear in them.  A layer row receives its layer's opening (POS, PAIR, BETA), folds (E, F, XINV), and -
+ *      where a height joins (HASRO; HAS0: with preprocessed columns) - forms the reduced opening RO of that height from the
+ *      Horner sums H0..H3 of the four trees' opened rows (SEG), zeta, alpha_f / delta and the verifier's constants B1, B2, w_H
+ *      (BCONST).  KEYJ / MJ (KEY0 / M0 for the 2^16-tall preprocessed tree, whose opening is received on the row of bit 16: PR0):
+ *      key and mask of the injected rows; MT / MT0: the masks of the whole runs.  The domain point: OMI = 1 / omega (order
+ *      2^(lm+1), the verifier's), R = omega^-(the position bits so far) by square and multiply, YT = 1 / y for the tallest
+ *      height, YKI its squares down the layers, GI = g^-(2^K). ---- */
 enum {
-  FO_IS_REAL = 0, FO_FIRST, FO_LAST, FO_Q, FO_K, FO_BIT, FO_XINV, FO_HASRO, FO_BETA /* 4 */, FO_LO = FO_BETA + 4, FO_HI = FO_LO + 4,
-  FO_E = FO_HI + 4, FO_F = FO_E + 4, FO_RO = FO_F + 4, FOLD_WIDTH = FO_RO + 4
+  QR_IS_REAL = 0, QR_FIRST, QR_LAST, QR_LEAF, QR_QL, QR_J, QR_BIT, QR_ACC, QR_EQ, QR_F1, QR_F2, QR_F3, QR_CSR, QR_FL, QR_LAY, QR_K,
+  QR_CS, QR_POW, QR_LOW, QR_REV, QR_PR0, QR_CNT0, QR_KEYJ, QR_MJ, QR_MT, QR_P0A, QR_KEY0, QR_M0, QR_MT0, QR_HASRO, QR_HAS0, QR_OMI,
+  QR_MU, QR_CSM, QR_R, QR_R2, QR_YT, QR_YKI, QR_GI, QR_XINV, QR_WH,
+  QR_BETA = 41, QR_LO = 45, QR_HI = 49, QR_E = 53, QR_F = 57, QR_RO = 61, QR_H = 65 /* 4 x 4 */, QR_AF = 81, QR_DL = 85, QR_D2 = 89,
+  QR_D3 = 93, QR_D4 = 97, QR_G2 = 101, QR_ZETA = 105, QR_ZW = 109, QR_D0 = 113, QR_D1 = 117, QR_B1 = 121, QR_B2 = 125, QR_WIDTH = 129
 };
-/* row records (FOLD_REC_WORDS each): flags (first, last << 1, bit << 2, hasro << 3), query, layer, 1/x, beta, lo, hi, ro */
-#define FOLD_REC_WORDS 20
+#define QR_REC_WORDS 132 /* a row record is the row: QR_WIDTH canonical words, then padding */
+#define F_GEN_INV 64944062u /* 1 / F_GEN mod p */
+/* ---- transcript chip (row f4, stage 2b): one duplex of a checked leaf proof's Fiat-Shamir transcript per row - "absorb eight
+ *      words" (ABS) or "squeeze" (since format v16 every phase of a transcript ends on a block boundary).  The verifier
+ *      dictates every row (TBLK / TSQ: what it absorbs, what its inputs and outputs are used for: the U flags, RIDK, QBASE); the
+ *      rows hand the commitment roots (ROOT), the final constant (FINAL), zeta, alpha_f / delta and the FRI betas to the chips
+ *      that check the queries, every query's index word to the query chip (QIDX: output word 7 - j is query QBASE + j), and the
+ *      proof-of-work word to the verifier. ---- */
+enum {
+  TR_IS_REAL = 0, TR_LEAF, TR_STEP, TR_FIRST, TR_ABS, TR_UROOT, TR_UZETA, TR_UAF, TR_UBETA, TR_UFIN, TR_UPOW, TR_UQ, TR_QM /* 8 */,
+  TR_RIDK = TR_QM + 8, TR_QBASE, TR_MROOT, TR_MFIN, TR_MZETA, TR_MAF, TR_MBETA, TR_IN /* 16 */, TR_EXT = TR_IN + 16, TR_INT = TR_EXT + 256,
+  TR_WIDTH = TR_INT + 26
+};
+/* row records (TR_REC_WORDS each): word 0 = the flags word of the verifier's tuple (UROOT + 2 UZETA + 4 UAF + 8 UBETA + 16 UFIN
+ * + 32 UPOW + 64 UQ + 128 * the QM bits) | FIRST << 16 | ABS << 17; leaf, step, RIDK, QBASE, the five multiplicities, the 16 input words */
+#define TR_REC_WORDS 32
 /* ---- table chip: 2^16 rows; preprocessed (x = low byte, y = high byte, na = row index not a multiple of 4,
  *      nt = row index zero or above ADDR_HI_MAX, x ^ y, x & y); main: multiplicities of range16 (kind 0), 4-aligned range16
  *      (kind 1), high address limb (kind 2: 1 .. ADDR_HI_MAX), byte pair, and the byte operations xor / or / and ---- */
@@ -204,7 +240,8 @@ enum { TB_M_R16 = 0, TB_M_AL, TB_M_TOP, TB_M_BY, TB_M_XOR, TB_M_OR, TB_M_AND, TA
                                smallest is 1: no load, store or keccak state can name a register (addresses 0 .. 31) */
 
 /* ---- buses ---- */
-enum { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP, BUS_DIGEST, BUS_ECALL, BUS_PAIR, BUS_FRIQ, BUS_RO, BUS_FIN };
+enum { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP, BUS_DIGEST, BUS_ECALL, BUS_PAIR,
+       BUS_POS, BUS_ROOT, BUS_SEG, BUS_TBLK, BUS_TSQ, BUS_FINAL, BUS_ZETA, BUS_AF, BUS_BETA, BUS_POW, BUS_QIDX, BUS_LEAFK, BUS_BCONST };
 
 /* A linear form over the row [preprocessed | main]: c0 + sum coef[i] * row[col[i]] (canonical words). */
 #define LF_MAX 40
@@ -269,7 +306,8 @@ typedef struct {
    * aggregation payload's node rows, the fold-chip rows, and the public bus tuples (PUB_TUPLE_WORDS each: bus, 1 = the
    * verifier sends it / 0 = receives it, multiplicity, number of elements, 12 element slots) that state what was checked */
   const uint32_t* leaf_p2_rows; size_t n_leaf_p2;
-  const uint32_t* leaf_fold_rows; size_t n_leaf_fold;
+  const uint32_t* leaf_qr_rows; size_t n_leaf_qr;   /* query chip rows (QR_REC_WORDS each) */
+  const uint32_t* leaf_tr_rows; size_t n_leaf_tr;   /* transcript chip rows (TR_REC_WORDS each) */
   const uint32_t* pub_tuples; size_t n_pub;
 } orc_machine_input;
 #define PUB_TUPLE_WORDS 16

@@ -484,8 +484,8 @@ void orc_machine_setup(const orc_machine_input* in, int keccak_mode, uint32_t pr
   tmp.agg_leaves = NULL;
   tmp.agg_keys = NULL;
   tmp.n_agg = 0;
-  tmp.leaf_p2_rows = tmp.leaf_fold_rows = tmp.pub_tuples = NULL;
-  tmp.n_leaf_p2 = tmp.n_leaf_fold = tmp.n_pub = 0;
+  tmp.leaf_p2_rows = tmp.leaf_qr_rows = tmp.leaf_tr_rows = tmp.pub_tuples = NULL;
+  tmp.n_leaf_p2 = tmp.n_leaf_qr = tmp.n_leaf_tr = tmp.n_pub = 0;
   tmp.n_cycles = tmp.n_keccak = tmp.n_memfinal = tmp.n_muls = 0;
   init_chips(&tmp, cd, 1);
   mmcs t;
@@ -747,6 +747,7 @@ int orc_machine_prove(const orc_machine_input* in, int keccak_mode, const orc_ma
   orc_ch_observe_many(&ch, agg_digest, 8);
   orc_ch_observe(&ch, pub_n);
   orc_ch_observe_many(&ch, pub_digest, 8);
+  orc_ch_pad(&ch); /* (v16: a commitment root is a block of its own) */
   orc_ch_observe_many(&ch, mmcs_root(&t_main), 8);
   orc_ch_pad(&ch); /* (v16: a phase ends on a block boundary) */
   put(&pb, mmcs_root(&t_main), 8);

@@ -280,7 +280,7 @@ def prove(states_in: np.ndarray, logh: int, *, exit_code: int = 0, public_values
 # ---------------------------------------------------------------------------
 # machine proof (oracle/machine.h): inputs are the arrays ProverClient.machine_trace() returns
 # ---------------------------------------------------------------------------
-N_CHIPS = 25
+N_CHIPS = 26
 CHIP_NAMES = ["cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "table", "cpu2", "alu", "alu2",
               "subword", "subword2", "bitwise", "bitwise2", "poseidon2", "ecall"]
 CPUPUB_N = 5
@@ -297,7 +297,8 @@ class MachineInput(C.Structure):
                 ("cycles", C.c_void_p), ("n_cycles", C.c_size_t), ("keccak", C.c_void_p), ("n_keccak", C.c_size_t),
                 ("memfinal", C.c_void_p), ("n_memfinal", C.c_size_t), ("muls", C.c_void_p), ("n_muls", C.c_size_t),
                 ("prog_mult", C.c_void_p), ("shape", C.c_void_p), ("agg_keys", C.c_void_p), ("agg_leaves", C.c_void_p), ("n_agg", C.c_size_t),
-                ("leaf_p2_rows", C.c_void_p), ("n_leaf_p2", C.c_size_t), ("leaf_fold_rows", C.c_void_p), ("n_leaf_fold", C.c_size_t),
+                ("leaf_p2_rows", C.c_void_p), ("n_leaf_p2", C.c_size_t), ("leaf_qr_rows", C.c_void_p), ("n_leaf_qr", C.c_size_t),
+                ("leaf_tr_rows", C.c_void_p), ("n_leaf_tr", C.c_size_t),
                 ("pub_tuples", C.c_void_p), ("n_pub", C.c_size_t)]
 
 
@@ -317,7 +318,7 @@ def machine_input(t: dict):
                       info.entry, int(keep["program"][0, 0]), info.log_prog, info.log_image,
                       _p(keep["cycles"]), len(keep["cycles"]), _p(keep["keccak"]), len(keep["keccak"]),
                       _p(keep["memfinal"]), len(keep["memfinal"]), _p(keep["muls"]), len(keep["muls"]),
-                      _p(keep["prog_mult"]), None, None, None, 0, None, 0, None, 0, None, 0)
+                      _p(keep["prog_mult"]), None, None, None, 0, None, 0, None, 0, None, 0, None, 0)
     if t.get("agg_leaves") is not None and len(t["agg_leaves"]):
         keep["agg_leaves"] = np.ascontiguousarray(t["agg_leaves"], dtype=np.uint32).reshape(-1, 8)
         mi.agg_leaves = keep["agg_leaves"].ctypes.data
@@ -326,9 +327,9 @@ def machine_input(t: dict):
             keep["agg_keys"] = np.ascontiguousarray(t["agg_keys"], dtype=np.uint32)
             assert len(keep["agg_keys"]) == mi.n_agg
             mi.agg_keys = keep["agg_keys"].ctypes.data
-    # leaf-proof check (row f4, stage 2a): the records of the product's host verifier (machine_trace's leaf_* sections)
-    for key, field, count, words in (("leaf_p2_rows", "leaf_p2_rows", "n_leaf_p2", 20), ("leaf_fold_rows", "leaf_fold_rows", "n_leaf_fold", 20),
-                                     ("leaf_pub_tuples", "pub_tuples", "n_pub", 16)):
+    # leaf-proof check (row f4, stage 2b): the records of the product's host verifier (machine_trace's leaf_* sections)
+    for key, field, count, words in (("leaf_p2_rows", "leaf_p2_rows", "n_leaf_p2", 32), ("leaf_qr_rows", "leaf_qr_rows", "n_leaf_qr", 132),
+                                     ("leaf_tr_rows", "leaf_tr_rows", "n_leaf_tr", 32), ("leaf_pub_tuples", "pub_tuples", "n_pub", 16)):
         if t.get(key) is not None and len(t[key]):
             keep[key] = np.ascontiguousarray(t[key], dtype=np.uint32).reshape(-1, words)
             setattr(mi, field, keep[key].ctypes.data)

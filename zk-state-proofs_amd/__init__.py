@@ -6,7 +6,7 @@ so import it with ``importlib.import_module("zk-state-proofs_amd")``.
 from .client import (  # noqa: F401
     GuestPanic, ProverClient, SP1ProofWithPublicValues, SP1Stdin, VerificationError, ZkspError, load_library, proof_from_body,
     KECCAK_OBSERVE, KECCAK_REPLACE, KECCAK_SOFTWARE, PROOF_MACHINE, PROOF_KECCAK_CHIP,
-    MACHINE_CHIPS, MACHINE_CHIP_NAMES, MACHINE_HEADER_WORDS, MACHINE_VERSION, PUB_TUPLE_WORDS, P2_REC_WORDS, FOLD_REC_WORDS, machine_chip_widths,
+    MACHINE_CHIPS, MACHINE_CHIP_NAMES, MACHINE_HEADER_WORDS, MACHINE_VERSION, PUB_TUPLE_WORDS, P2_REC_WORDS, QR_REC_WORDS, TR_REC_WORDS, machine_chip_widths,
     machine_cover_heights, merkle_path_nodes,
 )
 from .fixtures import MerkleProofInput, StorageProofInput  # noqa: F401

@@ -33,14 +33,14 @@ PROOF_MACHINE, PROOF_KECCAK_CHIP = 1, 2
 MACHINE_VERSION = 16
 MACHINE_CHIP_NAMES = ("cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "table", "cpu2", "alu", "alu2",
                       "subword", "subword2", "bitwise", "bitwise2", "poseidon2", "ecall", "cpu3", "cpu4", "cpu5", "cpu6", "cpu7",
-                      "cpu8", "fri-fold", "divider")
+                      "cpu8", "query", "divider", "transcript")
 MACHINE_CHIPS = len(MACHINE_CHIP_NAMES)
 MACHINE_CPU_INSTANCES = 8  # cpu, cpu2 .. cpu8: one AIR, consecutive stretches of the run
 # magic, version, heights, exit code, pv length, three digests, the pcs at which the later CPU instances start, the
 # aggregation payload's leaf count, root and leaf-list digest, the count and digest of the public bus tuples
 MACHINE_HEADER_WORDS = 2 + MACHINE_CHIPS + 2 + 24 + (MACHINE_CPU_INSTANCES - 1) + 17 + 9
 PUB_TUPLE_WORDS = 16  # bus, verifier sends (1) / receives (0), multiplicity, number of elements, 12 element slots
-P2_REC_WORDS, FOLD_REC_WORDS = 20, 20
+P2_REC_WORDS, QR_REC_WORDS, TR_REC_WORDS = 32, 132, 32
 
 
 def merkle_path_nodes(index: int, leaf, siblings):
@@ -161,6 +161,9 @@ def load_library() -> C.CDLL:
     lib.zksp_leaves_public.argtypes = [vp, vp, vp, sz, vp, sz, C.POINTER(sz)]
     lib.zksp_verify_with_leaves.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.zksp_leaf_public.argtypes = [vp, vp, vp, vp, sz, C.POINTER(sz)]
+    lib.zksp_leaf_public_at.argtypes = [vp, vp, vp, C.c_uint32, vp, sz, vp, sz, C.POINTER(sz)]
+    lib.zksp_stdin_add_verified_node.argtypes = [vp, vp, vp, vp, vp, sz]
+    lib.zksp_proof_stub.argtypes = [vp, C.POINTER(vp)]
     lib.zksp_verify_public.argtypes = [vp, vp, vp, vp, sz]
     lib.zksp_verify_with_leaf.argtypes = [vp, vp, vp, vp, vp]
     lib.zksp_proof_public_tuples.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -206,7 +209,7 @@ ABI_SYMBOLS = [
     "zksp_execute", "zksp_execute_keccak", "zksp_opcode_name", "zksp_machine_trace", "zksp_mtrace_free",
     "zksp_mtrace_section", "zksp_mtrace_info", "zksp_vk_machine", "zksp_mtrace_heights", "zksp_machine_body_words",
     "zksp_machine_chip_widths", "zksp_machine_cover_heights", "zksp_stdin_set_aggregation", "zksp_proof_aggregation", "zksp_verify_aggregate",
-    "zksp_stdin_set_aggregation_keyed", "zksp_verify_aggregate_keyed", "zksp_stdin_set_verified_leaf", "zksp_stdin_add_verified_leaf", "zksp_leaves_public", "zksp_verify_with_leaves", "zksp_leaf_public", "zksp_verify_public",
+    "zksp_stdin_set_aggregation_keyed", "zksp_verify_aggregate_keyed", "zksp_stdin_set_verified_leaf", "zksp_stdin_add_verified_leaf", "zksp_leaves_public", "zksp_verify_with_leaves", "zksp_leaf_public", "zksp_verify_public", "zksp_leaf_public_at", "zksp_stdin_add_verified_node", "zksp_proof_stub",
     "zksp_verify_with_leaf", "zksp_proof_public_tuples", "zksp_hip_machine_fetch_stage", "zksp_hip_machine_fetch_challenges",
     "zksp_hip_machine_load", "zksp_hip_machine_prove", "zksp_hip_release_workspace", "zksp_hip_machine_fetch_bodies", "zksp_hip_machine_fetch_roots", "zksp_machine_proof_from_body", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
     "zksp_hip_prove_resident", "zksp_proof_from_body", "zksp_hip_fetch_bodies", "zksp_hip_fetch_roots", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
@@ -313,6 +316,14 @@ class SP1ProofWithPublicValues(_Handle):
         if rc:
             raise ZkspError(rc, "proof_public_tuples")
         return int(n.value), [int(x) for x in dg]
+
+    def stub(self) -> "SP1ProofWithPublicValues":
+        """The proof without its query phase (``zksp_proof_stub``): what deriving a leaf's statement needs of it."""
+        h = C.c_void_p()
+        rc = self._lib.zksp_proof_stub(self._h, C.byref(h))
+        if rc:
+            raise ZkspError(rc, "proof_stub")
+        return SP1ProofWithPublicValues(self._lib, h, self._lib.zksp_proof_free)
 
     def to_bytes(self) -> bytes:
         p, n = C.POINTER(C.c_uint8)(), C.c_size_t()
@@ -495,8 +506,8 @@ class ProverClient:
             raise VerificationError(rc, self.last_error())
 
     def set_verified_leaf(self, stdin: SP1Stdin, leaf: SP1ProofWithPublicValues, leaf_vk: VerifyingKey) -> None:
-        """Leaf-proof check (``zksp_stdin_set_verified_leaf``, SURVEY.md row f4 stage 2a): the proof made from ``stdin`` also
-        establishes that the query phase of ``leaf`` verifies - every Merkle opening of its four commitment rounds and of
+        """Leaf-proof check (``zksp_stdin_set_verified_leaf``, SURVEY.md row f4 stage 2b): the proof made from ``stdin`` also
+        establishes that the query phase of ``leaf`` verifies under the challenges its own transcript yields - every Merkle opening of its four commitment rounds and of
         its FRI layers, and the folding chain down to the final constant.  Raises VerificationError if ``leaf`` does not
         verify under this client's parameters."""
         rc = self._lib.zksp_stdin_set_verified_leaf(self._h, stdin._h, leaf._h, leaf_vk._h)
@@ -516,6 +527,51 @@ class ProverClient:
         rc = self._lib.zksp_stdin_add_verified_leaf(self._h, stdin._h, leaf._h, leaf_vk._h)
         if rc:
             raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
+
+    def add_verified_node(self, stdin: SP1Stdin, node: SP1ProofWithPublicValues, node_vk: VerifyingKey, node_statement) -> None:
+        """``add_verified_leaf`` for a leaf that itself checks leaves (``zksp_stdin_add_verified_node``): ``node_statement`` is the
+        list of public tuples ITS proof was made for ([n][16] canonical words; ``leaves_public`` of its own leaves)."""
+        import numpy as np
+        tv = np.ascontiguousarray(node_statement, dtype=np.uint32).reshape(-1, PUB_TUPLE_WORDS)
+        rc = self._lib.zksp_stdin_add_verified_node(self._h, stdin._h, node._h, node_vk._h, tv.ctypes.data_as(C.c_void_p), len(tv))
+        if rc:
+            raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
+
+    def leaf_public_at(self, leaf: SP1ProofWithPublicValues, leaf_vk: VerifyingKey, index: int, own_statement=None):
+        """The statement tuples of the leaf at place ``index`` beside one run (``zksp_leaf_public_at``); ``leaf`` may be a stub;
+        ``own_statement``: the tuples the leaf's own proof was made for, if it is a node.  Everything of the leaf but its query
+        phase is checked on the way."""
+        import numpy as np
+        own = np.zeros((0, PUB_TUPLE_WORDS), np.uint32) if own_statement is None else \
+            np.ascontiguousarray(own_statement, dtype=np.uint32).reshape(-1, PUB_TUPLE_WORDS)
+        op = own.ctypes.data_as(C.c_void_p) if len(own) else None
+        n = C.c_size_t()
+        rc = self._lib.zksp_leaf_public_at(self._h, leaf._h, leaf_vk._h, index, op, len(own), None, 0, C.byref(n))
+        if rc:
+            raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
+        out = np.zeros((n.value, PUB_TUPLE_WORDS), np.uint32)
+        rc = self._lib.zksp_leaf_public_at(self._h, leaf._h, leaf_vk._h, index, op, len(own), out.ctypes.data_as(C.c_void_p), out.size,
+                                           C.byref(n))
+        if rc:
+            raise ZkspError(rc, self.last_error())
+        return out
+
+    def tree_statement(self, children, vk: VerifyingKey):
+        """The statement of a node of a recursion tree from its children, recursively: ``children`` is a list of
+        ``(proof_or_stub, grandchildren)`` with ``grandchildren`` a list of the same form ([] for a leaf of the tree).  All proofs
+        under ``vk``.  Stubs suffice everywhere: no query phase is read."""
+        import numpy as np
+        parts = []
+        for k, (proof, grand) in enumerate(children):
+            own = self.tree_statement(grand, vk) if grand else None
+            parts.append(self.leaf_public_at(proof, vk, k, own))
+        return np.concatenate(parts) if parts else np.zeros((0, PUB_TUPLE_WORDS), np.uint32)
+
+    def verify_tree(self, root: SP1ProofWithPublicValues, vk: VerifyingKey, children) -> None:
+        """``verify`` for the root of a recursion tree (``tree_statement`` for the form of ``children``): the root proof is verified
+        completely, of every proof below it the header, transcript, bus balance, constraint identity at zeta and proof of work
+        (from its stub) - their query phases are what the proofs above them establish."""
+        self.verify_public(root, vk, self.tree_statement(children, vk))
 
     def _handle_arrays(self, leaves, leaf_vks):
         n = len(leaves)
@@ -618,7 +674,8 @@ class ProverClient:
                     "muls": sec(3, np.uint32, 3), "prog_mult": sec(4, np.uint32), "alu_idx": sec(5, np.uint32),
                     "sub_idx": sec(9, np.uint32), "bw_idx": sec(10, np.uint32), "ecall_idx": sec(11, np.uint32), "div_idx": sec(15, np.uint32), "program": sec(6, np.uint32, 9), "image": sec(7, np.uint32, 2),
                     "public_values": bytes(sec(8, np.uint8)), "info": info,
-                    "leaf_p2_rows": sec(12, np.uint32, P2_REC_WORDS), "leaf_fold_rows": sec(13, np.uint32, FOLD_REC_WORDS),
+                    "leaf_p2_rows": sec(12, np.uint32, P2_REC_WORDS), "leaf_qr_rows": sec(13, np.uint32, QR_REC_WORDS),
+                    "leaf_tr_rows": sec(16, np.uint32, TR_REC_WORDS),
                     "leaf_pub_tuples": sec(14, np.uint32, PUB_TUPLE_WORDS)}
         finally:
             self._lib.zksp_mtrace_free(h)

@@ -31,7 +31,7 @@ namespace mach {
 // so the trees, the quotient and the FRI domain have a quarter of the height and the per-row costs of a commitment are
 // shared by six instances.
 enum Chip { kCpu = 0, kKeccak, kKmem, kMemFinal, kImage, kProgram, kMul, kTable, kCpu2, kAlu, kAlu2, kSub, kSub2, kBw, kBw2, kP2, kEcall,
-            kCpu3, kCpu4, kCpu5, kCpu6, kCpu7, kCpu8, kFold, kDiv, kNumChips };
+            kCpu3, kCpu4, kCpu5, kCpu6, kCpu7, kCpu8, kQr, kDiv, kTr, kNumChips };
 constexpr int kNumCpuInst = 8;
 // CPU instance i <-> chip (the first two keep their old places in the proof order)
 ZKSP_HD constexpr int cpu_chip(int i) { return i == 0 ? kCpu : i == 1 ? kCpu2 : kCpu3 + (i - 2); }
@@ -148,23 +148,48 @@ static_assert(kSubWidth == 21, "sub-word chip layout");
 // consumes with the root it knows - so position, shape and root of every opening are the verifier's.  Columns: the
 // input state, and per S-box its cube and its seventh power. ----
 constexpr int P2_IS_REAL = 0, P2_KL = 1, P2_KH = 2, P2_T = 3, P2_M = 4, P2_FN = 5, P2_SZ = 6, P2_SC = 7, P2_PL = 8, P2_PR = 9, P2_FJ = 10,
-              P2_NEW = 11, P2_SND = 12, P2_FR = 13, P2_IN = 14, P2_EXT = P2_IN + 16, P2_INT = P2_EXT + 256, kP2Width = P2_INT + 26;
-static_assert(kP2Width == 312, "Poseidon2 chip layout");
-// records the rows are expanded from (20 words): flags, T, K, M, the 16 input words
+              P2_NEW = 11, P2_SND = 12, P2_FR = 13, P2_IN = 14, P2_EXT = P2_IN + 16, P2_INT = P2_EXT + 256,
+              // format v16 (row f4, stage 2b): RE - the last row of a run (its digest is compared with the root the transcript
+              // chip holds, its position goes to the query chip); SE - the last block of a matrix row's hash (the Horner sum of
+              // the absorbed words goes to the query chip); RID - which root; SO - the Horner sum after this block; AP - the
+              // powers alpha_f^1 .. alpha_f^8 (eight extension elements)
+              P2_RE = P2_INT + 26, P2_SE = P2_RE + 1, P2_RID = P2_RE + 2, P2_SO = P2_RE + 3, P2_AP = P2_SO + 4, kP2Width = P2_AP + 32;
+static_assert(kP2Width == 351, "Poseidon2 chip layout");
+// records the rows are expanded from (32 words): flags, T, K, M, the 16 input words, RID, SO (4), alpha_f (4)
 enum P2Kind { P2K_NONE = 0, P2K_NODE, P2K_SZ, P2K_SC, P2K_PL, P2K_PR, P2K_J };
-constexpr uint32_t kP2RecWords = 20, kP2FlagNew = 16, kP2FlagSnd = 32, kP2FlagFri = 64;  // flags = kind | ...
-// tags of a leaf proof's openings: query q, tree r (0 preprocessed, 1 main, 2 permutation, 3 quotient, 4 + k FRI layer k)
-constexpr uint32_t kLeafTagStride = 64;
-ZKSP_HD constexpr uint32_t leaf_tag(uint32_t q, uint32_t r) { return 1 + kLeafTagStride * q + r; }
-// ---- FRI fold chip (row f4, stage 2a): one row per query and layer of a leaf proof's FRI.  The sibling pair (LO, HI)
-//      arrives from the sponge row that hashed it (PAIR bus), the layer's challenge, the inverse of the pair's domain
-//      point and the position bit from the verifier (FRIQ bus); E - the value the layer must show at the query's
-//      position - is LO or HI by the bit; F = (LO + HI) / 2 + BETA (LO - HI) XINV / 2 is the folded value; the next layer's
-//      E is F plus the reduced opening that joins there (RO bus, the verifier's in stage 2a); the last layer's F goes to
-//      the verifier (FIN bus), who knows the final constant. ----
-constexpr int FO_IS_REAL = 0, FO_FIRST = 1, FO_LAST = 2, FO_Q = 3, FO_K = 4, FO_BIT = 5, FO_XINV = 6, FO_HASRO = 7, FO_BETA = 8,
-              FO_LO = 12, FO_HI = 16, FO_E = 20, FO_F = 24, FO_RO = 28, kFoldWidth = 32;
-constexpr uint32_t kFoldRecWords = 20;  // flags (first, last << 1, bit << 2, hasro << 3), q, k, xinv, beta, lo, hi, ro
+constexpr uint32_t kP2RecWords = 32, kP2FlagNew = 16, kP2FlagSnd = 32, kP2FlagFri = 64, kP2FlagRe = 128, kP2FlagSe = 256;  // flags = kind | ...
+constexpr int kP2RecRid = 20, kP2RecSo = 21, kP2RecAlpha = 25;
+// tags of a leaf proof's openings: leaf l (its place among the leaves checked beside one run), query q, tree r (0 preprocessed,
+// 1 main, 2 permutation, 3 quotient, 4 + k FRI layer k); ids of its commitment roots
+constexpr uint32_t kLeafTagStride = 64, kLeafTagLeafStride = 1u << 18, kLeafMaxQueries = 4096;
+ZKSP_HD constexpr uint32_t leaf_tag(uint32_t l, uint32_t q, uint32_t r) { return 1 + kLeafTagStride * q + kLeafTagLeafStride * l + r; }
+ZKSP_HD constexpr uint32_t leaf_rid(uint32_t l, uint32_t r) { return 64 * l + r; }
+// ---- query chip (row f4, stage 2b; it stands where stage 2a's fold chip stood): 31 rows per query of a checked leaf proof, one
+//      per bit of the word the leaf's transcript drew for the query, from bit 30 down.  The bits are the canonical
+//      decomposition of the word; bit lm of it is the coset, the bits below the position.  The rows of the bits lm - 1 .. 0
+//      are the FRI layers 0 .. lm - 1: each receives its layer's opening (position, pair, challenge), folds, and - where a
+//      height joins - forms the reduced opening of that height from the Horner sums of the opened rows. ----
+constexpr int QR_IS_REAL = 0, QR_FIRST = 1, QR_LAST = 2, QR_LEAF = 3, QR_QL = 4, QR_J = 5, QR_BIT = 6, QR_ACC = 7, QR_EQ = 8, QR_F1 = 9,
+              QR_F2 = 10, QR_F3 = 11, QR_CSR = 12, QR_FL = 13, QR_LAY = 14, QR_K = 15, QR_CS = 16, QR_POW = 17, QR_LOW = 18, QR_REV = 19,
+              QR_PR0 = 20, QR_CNT0 = 21, QR_KEYJ = 22, QR_MJ = 23, QR_MT = 24, QR_P0A = 25, QR_KEY0 = 26, QR_M0 = 27, QR_MT0 = 28,
+              QR_HASRO = 29, QR_HAS0 = 30, QR_OMI = 31, QR_MU = 32, QR_CSM = 33, QR_R = 34, QR_R2 = 35, QR_YT = 36, QR_YKI = 37,
+              QR_GI = 38, QR_XINV = 39, QR_WH = 40,
+              QR_BETA = 41, QR_LO = 45, QR_HI = 49, QR_E = 53, QR_F = 57, QR_RO = 61, QR_H = 65 /* 4 x 4 */, QR_AF = 81, QR_DL = 85,
+              QR_D2 = 89, QR_D3 = 93, QR_D4 = 97, QR_G2 = 101, QR_ZETA = 105, QR_ZW = 109, QR_D0 = 113, QR_D1 = 117, QR_B1 = 121,
+              QR_B2 = 125, kQrWidth = 129;
+constexpr uint32_t kQrRecWords = 132;  // a row record is the row: kQrWidth canonical words (then padding)
+// ---- transcript chip (row f4, stage 2b): one duplex of a checked leaf proof's Fiat-Shamir transcript per row - "absorb eight
+//      words" or "squeeze" (since format v16 every phase of a transcript ends on a block boundary).  The verifier dictates
+//      every row (what it absorbs, what its inputs and outputs are used for); the rows hand the commitment roots, the final
+//      constant and the challenges zeta, alpha_f / delta and the FRI betas to the chips that check the queries, and every
+//      query's index word to the query chip. ----
+constexpr int TR_IS_REAL = 0, TR_LEAF = 1, TR_STEP = 2, TR_FIRST = 3, TR_ABS = 4, TR_UROOT = 5, TR_UZETA = 6, TR_UAF = 7, TR_UBETA = 8,
+              TR_UFIN = 9, TR_UPOW = 10, TR_UQ = 11, TR_QM = 12 /* 8 */, TR_RIDK = 20, TR_QBASE = 21, TR_MROOT = 22, TR_MFIN = 23,
+              TR_MZETA = 24, TR_MAF = 25, TR_MBETA = 26, TR_IN = 27, TR_EXT = TR_IN + 16, TR_INT = TR_EXT + 256, kTrWidth = TR_INT + 26;
+static_assert(kTrWidth == 325, "transcript chip layout");
+// row records (32 words): word 0 = the flags word of the verifier's tuple (UROOT + 2 UZETA + 4 UAF + 8 UBETA + 16 UFIN + 32 UPOW
+// + 64 UQ + 128 * the QM bits) | FIRST << 16 | ABS << 17; leaf, step, RIDK, QBASE, the five multiplicities, the 16 input words
+constexpr uint32_t kTrRecWords = 32, kTrRecFirst = 1u << 16, kTrRecAbs = 1u << 17;
 // ---- table chip: 2^16 rows; preprocessed (x, y: the row index's bytes; na: index not a multiple of 4; nt: index above
 //      kAddrHiMax or zero; x ^ y; x & y); main: multiplicities of range16 (kind 0), 4-aligned range16 (kind 1), high address limb
 //      (kind 2), byte pair, and the byte operations xor / or / and ----
@@ -173,8 +198,13 @@ constexpr int TB_P_X = 0, TB_P_Y = 1, TB_P_NA = 2, TB_P_NT = 3, TB_P_XOR = 4, TB
 // high limb of the largest address / jump target; the smallest is 1: a load, store or keccak state below 0x10000 has no
 // table row, so no memory access can name a register (addresses 0 .. 31 on the memory bus)
 constexpr uint32_t kAddrHiMax = 0x77FEu;
+constexpr uint32_t kGenInv = 64944062u;  // 1 / kGen mod p (the LDE cosets' shift is the generator)
 
-enum Bus { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP, BUS_DIGEST, BUS_ECALL, BUS_PAIR, BUS_FRIQ, BUS_RO, BUS_FIN };
+enum Bus { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP, BUS_DIGEST, BUS_ECALL, BUS_PAIR,
+           // stage 2b: a run's position -> query chip; commitment roots; a matrix row's Horner sum; the transcript's blocks and
+           // squeezes (verifier -> transcript chip); final constant; zeta; alpha_f, delta; FRI betas; the proof-of-work word
+           // (-> verifier); query index words; per leaf constants and per height constants (verifier -> query chip)
+           BUS_POS, BUS_ROOT, BUS_SEG, BUS_TBLK, BUS_TSQ, BUS_FINAL, BUS_ZETA, BUS_AF, BUS_BETA, BUS_POW, BUS_QIDX, BUS_LEAFK, BUS_BCONST };
 
 // Ctx interface:
 //   using F;  F local(int col); F next(int col); F prep(int col) (preprocessed column of the row);
@@ -744,21 +774,45 @@ ZKSP_HD void p2air_external_linear(F* s) {
     for (int c = 0; c < 4; ++c) s[4 * c + j] = s[4 * c + j] + col;
   }
 }
+// extension-field values over the constraint field F (F_p[x] / (x^4 - 11)): the device instantiates F = Fp (a lane is an LDE
+// point), the verifier F = Fp4 (the point zeta)
+template <class F>
+struct X4 {
+  F c[4];
+};
+template <class F>
+ZKSP_HD X4<F> x4_add(const X4<F>& a, const X4<F>& b) { X4<F> r; for (int i = 0; i < 4; ++i) r.c[i] = a.c[i] + b.c[i]; return r; }
+template <class F>
+ZKSP_HD X4<F> x4_sub(const X4<F>& a, const X4<F>& b) { X4<F> r; for (int i = 0; i < 4; ++i) r.c[i] = a.c[i] - b.c[i]; return r; }
+template <class F>
+ZKSP_HD X4<F> x4_scale(const X4<F>& a, const F& b) { X4<F> r; for (int i = 0; i < 4; ++i) r.c[i] = a.c[i] * b; return r; }
+template <class F>
+ZKSP_HD X4<F> x4_mul(const X4<F>& a, const X4<F>& b, const F& k11) {
+  X4<F> r;
+  r.c[0] = a.c[0] * b.c[0] + k11 * (a.c[1] * b.c[3] + a.c[2] * b.c[2] + a.c[3] * b.c[1]);
+  r.c[1] = a.c[0] * b.c[1] + a.c[1] * b.c[0] + k11 * (a.c[2] * b.c[3] + a.c[3] * b.c[2]);
+  r.c[2] = a.c[0] * b.c[2] + a.c[1] * b.c[1] + a.c[2] * b.c[0] + k11 * (a.c[3] * b.c[3]);
+  r.c[3] = a.c[0] * b.c[3] + a.c[1] * b.c[2] + a.c[2] * b.c[1] + a.c[3] * b.c[0];
+  return r;
+}
+template <class F, class Ctx>
+ZKSP_HD X4<F> x4_local(const Ctx& ctx, int col) { X4<F> r; for (int i = 0; i < 4; ++i) r.c[i] = ctx.local(col + i); return r; }
+template <class F, class Ctx>
+ZKSP_HD X4<F> x4_next(const Ctx& ctx, int col) { X4<F> r; for (int i = 0; i < 4; ++i) r.c[i] = ctx.next(col + i); return r; }
+
+// The permutation of one row: the columns IN (16 words), EXT (8 rounds x (16 cubes, 16 seventh powers)), INT (13 x (cube,
+// seventh power)); 282 constraints; st[] comes back as the 16 output words, linear in the last round's columns.
 template <class Ctx>
-ZKSP_HD void eval_p2(Ctx& ctx) {
+ZKSP_HD void p2_perm_constraints(Ctx& ctx, int c_in, int c_ext, int c_int, typename Ctx::F* st) {
   using F = typename Ctx::F;
   const P2Consts* kc = ctx.p2();
-  const F one = ctx.k(kR1), real = L(P2_IS_REAL);
-  ctx.emit(bool_c(real, one));
-  ctx.emit(ctx.is_trans() * ctx.next(P2_IS_REAL) * (one - real));  // the real rows are a prefix
-  F st[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) st[i] = L(P2_IN + i);
+  for (int i = 0; i < 16; ++i) st[i] = ctx.local(c_in + i);
   p2air_external_linear(st);
   for (int rd = 0; rd < 8; ++rd) {
     if (rd == 4) {  // the 13 internal rounds sit between the two halves of the external ones
       for (int ir = 0; ir < 13; ++ir) {
-        const F x = st[0] + ctx.k(kc->internal[ir]), x3 = L(P2_INT + 2 * ir), y = L(P2_INT + 2 * ir + 1);
+        const F x = st[0] + ctx.k(kc->internal[ir]), x3 = ctx.local(c_int + 2 * ir), y = ctx.local(c_int + 2 * ir + 1);
         ctx.emit(x3 - x * x * x);
         ctx.emit(y - x3 * x3 * x);
         st[0] = y;
@@ -771,16 +825,25 @@ ZKSP_HD void eval_p2(Ctx& ctx) {
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const F x = st[i] + ctx.k(kc->ext[rd][i]), x3 = L(P2_EXT + 32 * rd + i), y = L(P2_EXT + 32 * rd + 16 + i);
+      const F x = st[i] + ctx.k(kc->ext[rd][i]), x3 = ctx.local(c_ext + 32 * rd + i), y = ctx.local(c_ext + 32 * rd + 16 + i);
       ctx.emit(x3 - x * x * x);
       ctx.emit(y - x3 * x3 * x);
       st[i] = y;
     }
     p2air_external_linear(st);
   }
+}
+template <class Ctx>
+ZKSP_HD void eval_p2(Ctx& ctx) {
+  using F = typename Ctx::F;
+  const F one = ctx.k(kR1), real = L(P2_IS_REAL);
+  ctx.emit(bool_c(real, one));
+  ctx.emit(ctx.is_trans() * ctx.next(P2_IS_REAL) * (one - real));  // the real rows are a prefix
+  F st[16];
+  p2_perm_constraints(ctx, P2_IN, P2_EXT, P2_INT, st);
   // st[] now holds the permutation's 16 output words, linear in the last round's columns.
-  // Row kinds: one per real row; NEW lives on sponge rows, FR on first blocks, SND anywhere but on a node row (which always
-  // sends) or a padding row.
+  // Row kinds: one per real row; NEW lives on sponge rows, FR on first blocks, SND (the hash goes to an injection row) and SE
+  // (the Horner sum goes to the query chip) on sponge rows, RE (the end of a run) on path and injection rows.
   const F fn = L(P2_FN), sz = L(P2_SZ), sc = L(P2_SC), pl = L(P2_PL), pr = L(P2_PR), fj = L(P2_FJ), nw = L(P2_NEW), snd = L(P2_SND),
           fr = L(P2_FR);
   ctx.emit(bool_c(fn, one)); ctx.emit(bool_c(sz, one)); ctx.emit(bool_c(sc, one)); ctx.emit(bool_c(pl, one)); ctx.emit(bool_c(pr, one));
@@ -788,7 +851,7 @@ ZKSP_HD void eval_p2(Ctx& ctx) {
   const F chain = sc + pl + pr + fj;  // the kinds that take over from the row before
   ctx.emit(fn + sz + chain - real);
   ctx.emit(nw * (one - sz - sc));
-  ctx.emit(snd * (one - sz - chain));
+  ctx.emit(snd * (one - sz - sc));
   ctx.emit(fr * (one - sz));
   // a first block starts from the zero state; the first block of a run from K = 1, M = 0
 #pragma unroll
@@ -823,50 +886,263 @@ ZKSP_HD void eval_p2(Ctx& ctx) {
   ctx.emit(nfj * (nkey - key));
   ctx.emit(nfj * (nm - m - one));
   ctx.emit(nfj * (one - pl - pr));
-}
-constexpr int kP2Constraints = 2 + 8 * 32 + 13 * 2 + 67;
-
-// ---- FRI fold chip: 31 constraints (layout comment above); the extension field is F_p[x] / (x^4 - 11) ----
-template <class Ctx>
-ZKSP_HD void eval_fold(Ctx& ctx) {
-  using F = typename Ctx::F;
-  const F one = ctx.k(kR1), real = L(FO_IS_REAL), first = L(FO_FIRST), last = L(FO_LAST), bit = L(FO_BIT), hasro = L(FO_HASRO);
-  ctx.emit(bool_c(real, one)); ctx.emit(bool_c(first, one)); ctx.emit(bool_c(last, one)); ctx.emit(bool_c(bit, one));
-  ctx.emit(bool_c(hasro, one));
-  ctx.emit(ctx.is_trans() * ctx.next(FO_IS_REAL) * (one - real));  // the real rows are a prefix
-  ctx.emit(first * (one - real)); ctx.emit(last * (one - real)); ctx.emit(hasro * (one - real));
-  ctx.emit(first * L(FO_K));
-  ctx.emit(ctx.is_first() * (real - first));
-  F lo[4], hi[4], d[4], be[4];
+  // ---- format v16 (stage 2b) ----
+  // the end of a run is a path step or an injection; the end of a matrix row's hash is a sponge row that no block follows
+  const F re = L(P2_RE), se = L(P2_SE);
+  ctx.emit(bool_c(re, one));
+  ctx.emit(bool_c(se, one));
+  ctx.emit(re * (one - pl - pr - fj));
+  ctx.emit(se * (one - sz - sc));
+  ctx.emit(se * nsc);
+  // Horner's rule in alpha_f over the absorbed words, block by block: SO' = SO alpha^8 + sum_{i < 8} alpha^(7 - i) in_i.
+  // AP holds alpha^1 .. alpha^8 (each the one before times AP[0]); a sponge's rows share them.
+  const F k11 = ZKSP_K(11);
+  X4<F> ap[8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { lo[i] = L(FO_LO + i); hi[i] = L(FO_HI + i); d[i] = lo[i] - hi[i]; be[i] = L(FO_BETA + i); }
-  // the value the layer shows at the query's position
+  for (int j = 0; j < 8; ++j) ap[j] = x4_local<F>(ctx, P2_AP + 4 * j);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) ctx.emit(L(FO_E + i) - lo[i] + bit * d[i]);
-  // 2 F = LO + HI + XINV * BETA * (LO - HI)
-  {
-    const F k11 = ZKSP_K(11), xinv = L(FO_XINV);
-    const F p0 = be[0] * d[0] + k11 * (be[1] * d[3] + be[2] * d[2] + be[3] * d[1]);
-    const F p1 = be[0] * d[1] + be[1] * d[0] + k11 * (be[2] * d[3] + be[3] * d[2]);
-    const F p2 = be[0] * d[2] + be[1] * d[1] + be[2] * d[0] + k11 * (be[3] * d[3]);
-    const F p3 = be[0] * d[3] + be[1] * d[2] + be[2] * d[1] + be[3] * d[0];
-    ctx.emit(L(FO_F + 0).dbl() - lo[0] - hi[0] - xinv * p0);
-    ctx.emit(L(FO_F + 1).dbl() - lo[1] - hi[1] - xinv * p1);
-    ctx.emit(L(FO_F + 2).dbl() - lo[2] - hi[2] - xinv * p2);
-    ctx.emit(L(FO_F + 3).dbl() - lo[3] - hi[3] - xinv * p3);
+  for (int j = 0; j < 7; ++j) {
+    const X4<F> pj = x4_mul(ap[j], ap[0], k11);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ctx.emit(ap[j + 1].c[i] - pj.c[i]);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) ctx.emit((one - hasro) * L(FO_RO + i));
-  // the next row goes on with this query unless it starts one (or is padding)
-  const F cont = ctx.next(FO_IS_REAL) - ctx.next(FO_FIRST);
-  ctx.emit(cont * (ctx.next(FO_Q) - L(FO_Q)));
-  ctx.emit(cont * (ctx.next(FO_K) - L(FO_K) - one));
+  for (int i = 0; i < 4; ++i) ctx.emit(nsc * (ctx.next(P2_AP + i) - ap[0].c[i]));
+  {
+    X4<F> bv;  // this row's block
 #pragma unroll
-  for (int i = 0; i < 4; ++i) ctx.emit(cont * (ctx.next(FO_E + i) - L(FO_F + i) - L(FO_RO + i)));
+    for (int c = 0; c < 4; ++c) {
+      F v = ap[6].c[c] * L(P2_IN);
+#pragma unroll
+      for (int i = 1; i < 7; ++i) v = v + ap[6 - i].c[c] * L(P2_IN + i);
+      bv.c[c] = v;
+    }
+    bv.c[0] = bv.c[0] + L(P2_IN + 7);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ctx.emit(sz * (L(P2_SO + c) - bv.c[c]));
+    // the next row's block over the next row's powers (equal to this row's where the sponge goes on)
+    X4<F> nap7 = x4_next<F>(ctx, P2_AP + 28), so = x4_local<F>(ctx, P2_SO);
+    const X4<F> carried = x4_mul(so, nap7, k11);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      F v = ctx.next(P2_AP + 24 + c) * ctx.next(P2_IN);
+#pragma unroll
+      for (int i = 1; i < 7; ++i) v = v + ctx.next(P2_AP + 4 * (6 - i) + c) * ctx.next(P2_IN + i);
+      if (c == 0) v = v + ctx.next(P2_IN + 7);
+      ctx.emit(nsc * (ctx.next(P2_SO + c) - carried.c[c] - v));
+    }
+  }
+}
+constexpr int kP2Constraints = 2 + 8 * 32 + 13 * 2 + 67 + 5 + 28 + 4 + 4 + 4;
+
+// ---- query chip: the constraints in the order of the layout comment above (DESIGN.md "Query chip") ----
+template <class Ctx>
+ZKSP_HD void eval_qr(Ctx& ctx) {
+  using F = typename Ctx::F;
+#define N(c) ctx.next(c)
+  const F one = ctx.k(kR1), real = L(QR_IS_REAL), first = L(QR_FIRST), last = L(QR_LAST), bit = L(QR_BIT), eq = L(QR_EQ),
+          f1 = L(QR_F1), f2 = L(QR_F2), f3 = L(QR_F3), csr = L(QR_CSR), fl = L(QR_FL), lay = L(QR_LAY), cs = L(QR_CS), pr0 = L(QR_PR0),
+          p0a = L(QR_P0A), hasro = L(QR_HASRO), has0 = L(QR_HAS0);
+  {
+    const F bools[17] = {real, first, last, bit, eq, f1, f2, f3, csr, fl, lay, cs, pr0, p0a, hasro, has0, L(QR_CNT0)};
+#pragma unroll
+    for (int i = 0; i < 17; ++i) ctx.emit(bool_c(bools[i], one));
+  }
+  const F zero = one - one;
+  const F cont = N(QR_IS_REAL) - N(QR_FIRST);  // the next row goes on with this query
+  const F nl1 = N(QR_LAY) - N(QR_FL);         // ... and is a layer row other than layer 0 (so this row is a layer row too)
+  ctx.emit(ctx.is_trans() * N(QR_IS_REAL) * (one - real));  // the real rows are a prefix
+  ctx.emit(ctx.is_first() * (real - first));
+  ctx.emit((first + last + csr + fl + lay + pr0 + p0a + hasro + has0 + bit + eq + f1 + f2 + f3 + cs) * (one - real));
+  // 31 rows per query: bit 30 down to bit 0
+  const F j = L(QR_J);
+  ctx.emit(first * (j - ZKSP_K(30)));
+  ctx.emit(last * j);
+  ctx.emit(cont * (N(QR_J) - j + one));
   ctx.emit(last * cont);
   ctx.emit((real - last) * (one - cont));
+  ctx.emit(cont * (N(QR_LEAF) - L(QR_LEAF)));
+  ctx.emit(cont * (N(QR_QL) - L(QR_QL)));
+  // the word from its most significant bit; canonical: it does not exceed p - 1 = 0x78000000 (EQ: the bits so far are p - 1's)
+  ctx.emit(first * (L(QR_ACC) - bit));
+  ctx.emit(cont * (N(QR_ACC) - L(QR_ACC).dbl() - N(QR_BIT)));
+  ctx.emit(first * (f1 + f2 + f3));
+  ctx.emit(cont * (N(QR_F1) - first));
+  ctx.emit(cont * (N(QR_F2) - f1));
+  ctx.emit(cont * (N(QR_F3) - f2));
+  ctx.emit(first * (eq - bit));
+  {
+    const F nf = N(QR_F1) + N(QR_F2) + N(QR_F3);
+    ctx.emit(nf * (N(QR_EQ) - eq * N(QR_BIT)));
+    ctx.emit((cont - nf) * (N(QR_EQ) - eq));
+    ctx.emit((real - first - f1 - f2 - f3) * eq * bit);
+  }
+  // row kinds: the rows above the coset bit, the coset bit's row (CSR), the layer rows (FL: layer 0); the last row is a layer row
+  ctx.emit(csr * lay);
+  ctx.emit(fl * (one - lay));
+  ctx.emit(first * (csr + lay));
+  ctx.emit(cont * (N(QR_FL) - csr));
+  ctx.emit(cont * (N(QR_LAY) - csr - lay));
+  ctx.emit(last * (one - lay));
+  ctx.emit(fl * L(QR_K));
+  ctx.emit(nl1 * (N(QR_K) - L(QR_K) - one));
+  ctx.emit(csr * (cs - bit));
+  ctx.emit(cont * (csr + lay) * (N(QR_CS) - cs));
+  // 2^J, the bits below J as a number (LOW) and in reverse (REV): the positions of the openings are linear in them
+  ctx.emit(last * (L(QR_POW) - one));
+  ctx.emit(last * L(QR_LOW));
+  ctx.emit(last * L(QR_REV));
+  ctx.emit(cont * (L(QR_POW) - N(QR_POW).dbl()));
+  ctx.emit(cont * (L(QR_LOW) - N(QR_LOW) - N(QR_BIT) * N(QR_POW)));
+  ctx.emit(cont * (L(QR_REV) - N(QR_REV).dbl() - N(QR_BIT)));
+  // the preprocessed tree is 2^16 tall: its opening is received on the row of bit 16, exactly once
+  ctx.emit(pr0 * (j - ZKSP_K(16)));
+  ctx.emit(first * (L(QR_CNT0) - pr0));
+  ctx.emit(cont * (N(QR_CNT0) - L(QR_CNT0) - N(QR_PR0)));
+  ctx.emit(last * (L(QR_CNT0) - one));
+  ctx.emit(first * p0a);
+  ctx.emit(cont * (N(QR_P0A) - p0a - pr0));
+  ctx.emit(cont * pr0 * (N(QR_KEY0) - one));
+  ctx.emit(cont * pr0 * N(QR_M0));
+  ctx.emit(cont * p0a * (N(QR_KEY0) - L(QR_KEY0).dbl() - bit));
+  ctx.emit(cont * p0a * (N(QR_M0) - L(QR_M0).dbl() - N(QR_HAS0)));
+  ctx.emit(has0 * (one - p0a));
+  ctx.emit(has0 * (one - hasro));
+  ctx.emit(cont * (N(QR_MT0) - L(QR_MT0)));
+  ctx.emit(last * (L(QR_MT0) - ZKSP_K(4) * L(QR_M0)));
+  // keys and masks of the injected rows of the other three trees (as tall as the proof): the position bits above, and which
+  // heights joined on the way
+  ctx.emit(fl * (L(QR_KEYJ) - one));
+  ctx.emit(fl * L(QR_MJ));
+  ctx.emit(nl1 * (N(QR_KEYJ) - L(QR_KEYJ).dbl() - bit));
+  ctx.emit(nl1 * (N(QR_MJ) - L(QR_MJ).dbl() - N(QR_HASRO)));
+  ctx.emit(cont * (N(QR_MT) - L(QR_MT)));
+  ctx.emit(last * (L(QR_MT) - ZKSP_K(4) * L(QR_MJ)));
+  ctx.emit(hasro * (one - lay));
+  ctx.emit(fl * (one - hasro));
+  // the domain points: omega^-1 (the verifier's, of order 2^(lm + 1)) to the power cs + 2 m by square and multiply (R: omega^-m
+  // so far), its squares down the layers (YKI), the shift g^-(2^k) (GI), the inverse of the layer's point (XINV)
+  const F omi = L(QR_OMI);
+  ctx.emit(cont * (N(QR_OMI) - omi));
+  ctx.emit(L(QR_MU) - real - bit * (omi - one));  // (1 on a real row whose bit is clear; 0 on padding rows)
+  ctx.emit(L(QR_CSM) - real - cs * (omi - one));
+  ctx.emit(L(QR_R2) - L(QR_R) * L(QR_R));
+  ctx.emit(fl * (L(QR_R) - L(QR_MU)));
+  ctx.emit(nl1 * (N(QR_R) - L(QR_R2) * N(QR_MU)));
+  ctx.emit(cont * (N(QR_YT) - L(QR_YT)));
+  ctx.emit(last * (L(QR_YT) - L(QR_R2) * L(QR_CSM)));
+  ctx.emit(fl * (L(QR_YKI) - L(QR_YT)));
+  ctx.emit(nl1 * (N(QR_YKI) - L(QR_YKI) * L(QR_YKI)));
+  ctx.emit(fl * (L(QR_GI) - ctx.k(cmonty(kGenInv))));
+  ctx.emit(nl1 * (N(QR_GI) - L(QR_GI) * L(QR_GI)));
+  ctx.emit(L(QR_XINV) - L(QR_GI) * L(QR_YKI) * (one - bit.dbl()));
+  // the fold
+  const F k11 = ZKSP_K(11);
+  const X4<F> lo = x4_local<F>(ctx, QR_LO), hi = x4_local<F>(ctx, QR_HI), be = x4_local<F>(ctx, QR_BETA), d = x4_sub(lo, hi);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ctx.emit(L(QR_E + i) - lo.c[i] + bit * d.c[i]);
+  {
+    const X4<F> pd = x4_mul(be, d, k11);
+    const F xinv = L(QR_XINV);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ctx.emit(L(QR_F + i).dbl() - lo.c[i] - hi.c[i] - xinv * pd.c[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ctx.emit((one - hasro) * L(QR_RO + i));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ctx.emit(fl * (L(QR_E + i) - L(QR_RO + i)));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ctx.emit(nl1 * (N(QR_E + i) - L(QR_F + i) - N(QR_RO + i)));
+  // the reduced opening of the height that joins on this row (oracle/mprover.c orc_reduce_coefs): the Horner sums H_r of the
+  // four trees' opened rows, delta between the trees, the verifier's constants B1, B2, w_H
+  {
+    const X4<F> dl = x4_local<F>(ctx, QR_DL), d2 = x4_local<F>(ctx, QR_D2), d3 = x4_local<F>(ctx, QR_D3), d4 = x4_local<F>(ctx, QR_D4),
+                g2 = x4_local<F>(ctx, QR_G2), zeta = x4_local<F>(ctx, QR_ZETA), zw = x4_local<F>(ctx, QR_ZW), d0 = x4_local<F>(ctx, QR_D0),
+                d1 = x4_local<F>(ctx, QR_D1), h0 = x4_local<F>(ctx, QR_H), h1 = x4_local<F>(ctx, QR_H + 4), h2 = x4_local<F>(ctx, QR_H + 8),
+                h3 = x4_local<F>(ctx, QR_H + 12);
+    const X4<F> e2 = x4_mul(dl, dl, k11), e3 = x4_mul(d2, dl, k11), e4 = x4_mul(d2, d2, k11), eg = x4_add(h1, x4_mul(dl, h2, k11));
+    const X4<F> ez = x4_scale(zeta, L(QR_WH));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ctx.emit(d2.c[i] - e2.c[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ctx.emit(d3.c[i] - e3.c[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ctx.emit(d4.c[i] - e4.c[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ctx.emit(g2.c[i] - eg.c[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ctx.emit(zw.c[i] - ez.c[i]);
+    // D0 (g y - zeta) = 1 and D1 (g y - zeta w) = 1, multiplied through by 1 / y (the column YKI)
+    const F g = ctx.k(cmonty(kGen)), yki = L(QR_YKI);
+    X4<F> den0 = x4_scale(zeta, zero - yki), den1 = x4_scale(zw, zero - yki);
+    den0.c[0] = den0.c[0] + g;
+    den1.c[0] = den1.c[0] + g;
+    const X4<F> p0 = x4_mul(d0, den0, k11), p1 = x4_mul(d1, den1, k11);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ctx.emit(p0.c[i] - (i == 0 ? yki : zero));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ctx.emit(p1.c[i] - (i == 0 ? yki : zero));
+    X4<F> hs = x4_add(x4_add(h0, x4_mul(dl, h1, k11)), x4_add(x4_mul(d2, h2, k11), x4_mul(d3, h3, k11)));
+    hs = x4_sub(hs, x4_local<F>(ctx, QR_B1));
+    const X4<F> t2 = x4_sub(x4_mul(d4, g2, k11), x4_local<F>(ctx, QR_B2));
+    const X4<F> ro = x4_add(x4_mul(d0, hs, k11), x4_mul(d1, t2, k11));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ctx.emit(L(QR_RO + i) - ro.c[i]);
+  }
+#undef N
 }
-constexpr int kFoldConstraints = 31;
+constexpr int kQrConstraints = 140;  // (counted by running them: oracle/machine.c count_constraints)
+
+// ---- transcript chip ----
+template <class Ctx>
+ZKSP_HD void eval_tr(Ctx& ctx) {
+  using F = typename Ctx::F;
+  const F one = ctx.k(kR1), real = L(TR_IS_REAL), first = L(TR_FIRST), abs_ = L(TR_ABS);
+  ctx.emit(bool_c(real, one));
+  ctx.emit(ctx.is_trans() * ctx.next(TR_IS_REAL) * (one - real));  // the real rows are a prefix
+  F st[16];
+  p2_perm_constraints(ctx, TR_IN, TR_EXT, TR_INT, st);
+  F fsum = first + abs_;
+  ctx.emit(bool_c(first, one));
+  ctx.emit(bool_c(abs_, one));
+#pragma unroll
+  for (int k = 0; k < 7 + 8; ++k) {
+    const F v = L(TR_UROOT + k);
+    ctx.emit(bool_c(v, one));
+    fsum = fsum + v;
+  }
+  ctx.emit(fsum * (one - real));
+  // a transcript starts by absorbing over the zero state, at step 0
+  ctx.emit(first * (one - abs_));
+  ctx.emit(first * L(TR_STEP));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ctx.emit(first * L(TR_IN + 8 + i));
+  ctx.emit(ctx.is_first() * (real - first));
+  // the next duplex of the same transcript: the capacity goes on; a squeeze takes the whole state over
+  const F cont = ctx.next(TR_IS_REAL) - ctx.next(TR_FIRST);
+  ctx.emit(cont * (ctx.next(TR_LEAF) - L(TR_LEAF)));
+  ctx.emit(cont * (ctx.next(TR_STEP) - L(TR_STEP) - one));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ctx.emit(cont * (ctx.next(TR_IN + 8 + i) - st[8 + i]));
+  {
+    const F sq = cont * (one - ctx.next(TR_ABS));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ctx.emit(sq * (ctx.next(TR_IN + i) - st[i]));
+  }
+  // uses: query words only on query rows; a multiplicity only where the use is flagged
+  {
+    F qm = L(TR_QM);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) qm = qm + L(TR_QM + k);
+    ctx.emit(qm * (one - L(TR_UQ)));
+  }
+  ctx.emit(L(TR_MROOT) * (one - L(TR_UROOT)));
+  ctx.emit(L(TR_MFIN) * (one - L(TR_UFIN)));
+  ctx.emit(L(TR_MZETA) * (one - L(TR_UZETA)));
+  ctx.emit(L(TR_MAF) * (one - L(TR_UAF)));
+  ctx.emit(L(TR_MBETA) * (one - L(TR_UBETA)));
+}
+constexpr int kTrConstraints = 2 + 282 + 2 + 15 + 1 + 2 + 8 + 1 + 2 + 8 + 8 + 1 + 5;
 
 // every image word is sent exactly once
 template <class Ctx>
@@ -891,7 +1167,7 @@ constexpr int kKeccakConstraints = ka::kNumConstraints + 1;
 ZKSP_HD constexpr int num_constraints(int chip) {
   return is_cpu_chip(chip) ? kCpuConstraints : chip == kKeccak ? kKeccakConstraints : chip == kKmem ? kKmemConstraints
        : chip == kMemFinal ? kMemFinalConstraints : chip == kImage ? 1 : chip == kProgram ? 0 : chip == kMul ? kMulConstraints
-       : chip == kTable ? 2 : is_alu_chip(chip) ? kAluConstraints : is_sub_chip(chip) ? kSubConstraints : is_bw_chip(chip) ? kBwConstraints : chip == kP2 ? kP2Constraints : chip == kEcall ? kEcallConstraints : chip == kFold ? kFoldConstraints : chip == kDiv ? kDivConstraints : 0;
+       : chip == kTable ? 2 : is_alu_chip(chip) ? kAluConstraints : is_sub_chip(chip) ? kSubConstraints : is_bw_chip(chip) ? kBwConstraints : chip == kP2 ? kP2Constraints : chip == kEcall ? kEcallConstraints : chip == kQr ? kQrConstraints : chip == kTr ? kTrConstraints : chip == kDiv ? kDivConstraints : 0;
 }
 
 }  // namespace mach

@@ -17,7 +17,7 @@ struct Seg {
   size_t bstride;
   int width;
 };
-constexpr int kMaxSegs = 25;  // at least kNumChips: every chip could have the same height
+constexpr int kMaxSegs = 26;  // at least kNumChips: every chip could have the same height
 static_assert(kMaxSegs >= mach::kNumChips, "a height group may hold every chip");
 
 // ---- trace expansion (row a3 of the machine proof) ----
@@ -34,19 +34,20 @@ struct MachineRecords {
   const uint32_t* agg_heap;    // [B][cap_agg][kP2RecWords]: one record per row of the Poseidon2 chip (air_machine.hpp): flags, tag,
                                //          key, mask, the 16 input words (canonical) - heap nodes of an aggregation payload, then
                                //          the sponges and path steps of a leaf-proof check
-  const uint32_t* fold_rows;   // [B][cap_fold][kFoldRecWords]: one record per row of the FRI fold chip
+  const uint32_t* fold_rows;   // [B][cap_fold][kQrRecWords]: one record per row of the query chip (the row itself)
+  const uint32_t* tr_rows;     // [B][cap_tr][kTrRecWords]: one record per row of the transcript chip
   const P2Consts* consts;      // Poseidon2 constants (the Poseidon2 chip's rows are permutations)
   const uint32_t* prog_mult;   // [B][2^log_prog]; the padding row (n_program - 1) holds 0: its fetches follow from cpu_rows
-  const uint32_t* counts;      // [B][12]: cycles, keccak calls, memfinal rows, muls, ALU rows, sub-word rows, last time x0 was
-                               //          accessed by a real cycle, bitwise rows, Poseidon2-chip rows, ecalls, fold-chip rows, divider rows
+  const uint32_t* counts;      // [B][13]: cycles, keccak calls, memfinal rows, muls, ALU rows, sub-word rows, last time x0 was
+                               //          accessed by a real cycle, bitwise rows, Poseidon2-chip rows, ecalls, query-chip rows, divider rows, transcript-chip rows
   uint32_t* table_hist;        // [B][kTableWidth][2^16] scratch: multiplicities of the table chip, counted on the device
   uint32_t row0[mach::kNumChips];  // first cycle / event of the chip's instance (second instances: rows of the first)
-  size_t cap_cycles, cap_keccak, cap_memfinal, cap_muls, cap_alu, cap_sub, cap_bw, cap_agg, cap_ecall, cap_fold, cap_div;
+  size_t cap_cycles, cap_keccak, cap_memfinal, cap_muls, cap_alu, cap_sub, cap_bw, cap_agg, cap_ecall, cap_fold, cap_div, cap_tr;
   const uint32_t* program;     // [n_program][9] (shared); the last row is the padding instruction
   uint32_t text_base, n_program, n_image;
   uint32_t cpu_rows;           // rows of the two CPU instances together: the rows past the last cycle fetch the padding instruction
 };
-constexpr int kCountWords = 12;
+constexpr int kCountWords = 13;
 // trace: [B][main_width][2^logh] of the given chip (every chip but kKeccak and kTable)
 void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& rec, uint32_t* trace, int logh, int batch);
 // keccak chip: p3-keccak-air's columns by launch_keccak_trace (kernels.h, with a batch stride), then the call time

@@ -262,6 +262,23 @@ __global__ __launch_bounds__(64) void p2_trace_kernel(MachineRecords rec, uint32
   o.flag(P2_FN, kind == P2K_NODE); o.flag(P2_SZ, kind == P2K_SZ); o.flag(P2_SC, kind == P2K_SC); o.flag(P2_PL, kind == P2K_PL);
   o.flag(P2_PR, kind == P2K_PR); o.flag(P2_FJ, kind == P2K_J);
   o.flag(P2_NEW, (flags & kP2FlagNew) != 0); o.flag(P2_SND, (flags & kP2FlagSnd) != 0); o.flag(P2_FR, (flags & kP2FlagFri) != 0);
+  // format v16: the ends of runs and of matrix-row hashes, the Horner sum after this block, alpha_f^1 .. alpha_f^8
+  o.flag(P2_RE, (flags & kP2FlagRe) != 0); o.flag(P2_SE, (flags & kP2FlagSe) != 0);
+  o.val(P2_RID, real ? row[kP2RecRid] : 0u);
+  {
+    Fp4 ap;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o.val(P2_SO + i, real ? row[kP2RecSo + i] : 0u);
+      ap.c[i] = real ? Fp::from_canonical(row[kP2RecAlpha + i]) : Fp::zero();
+    }
+    Fp4 pw = ap;
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o.put(P2_AP + 4 * j + i, pw.c[i].v);
+      pw = pw * ap;
+    }
+  }
   p2air_external_linear(st);
   for (int rd = 0; rd < 8; ++rd) {
     if (rd == 4) {
@@ -288,32 +305,69 @@ __global__ __launch_bounds__(64) void p2_trace_kernel(MachineRecords rec, uint32
   }
 }
 
-// FRI fold chip: row r is record r (one query and layer of a leaf proof's FRI): the verifier's layer tuple, the pair, the
-// value the layer shows at the query's position and the folded value
-__global__ __launch_bounds__(kMT) void fold_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh) {
+// Query chip: row r is record r - the row itself, as the host verifier computed it while it checked the query (canonical words)
+__global__ __launch_bounds__(kMT) void qr_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh) {
   const size_t h = (size_t)1 << logh;
   const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
   if (r >= h) return;
   const int b = blockIdx.y;
-  const Col o{trace + (size_t)b * kFoldWidth * h + r, h};
-  if (r >= rec.counts[kCountWords * b + 10]) { o.zero(0, kFoldWidth); return; }
-  const uint32_t* row = rec.fold_rows + ((size_t)b * rec.cap_fold + r) * kFoldRecWords;
-  const uint32_t flags = row[0];
-  const bool bit = (flags & 4u) != 0;
-  o.put(FO_IS_REAL, kR1);
-  o.flag(FO_FIRST, (flags & 1u) != 0); o.flag(FO_LAST, (flags & 2u) != 0); o.flag(FO_BIT, bit); o.flag(FO_HASRO, (flags & 8u) != 0);
-  o.val(FO_Q, row[1]); o.val(FO_K, row[2]); o.val(FO_XINV, row[3]);
-  Fp4 beta, lo, hi;
+  const Col o{trace + (size_t)b * kQrWidth * h + r, h};
+  if (r >= rec.counts[kCountWords * b + 10]) { o.zero(0, kQrWidth); return; }
+  const uint32_t* row = rec.fold_rows + ((size_t)b * rec.cap_fold + r) * kQrRecWords;
+  for (int c = 0; c < kQrWidth; ++c) o.val(c, row[c]);
+}
+
+// Transcript chip: row r is record r (one duplex of a checked leaf's transcript): flags, labels, uses and the input state, and
+// the cubes and seventh powers of every S-box of its permutation
+__global__ __launch_bounds__(64) void tr_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh) {
+  const size_t h = (size_t)1 << logh;
+  const size_t r = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (r >= h) return;
+  const int b = blockIdx.y;
+  const Col o{trace + (size_t)b * kTrWidth * h + r, h};
+  const P2Consts* kc = rec.consts;
+  const bool real = r < rec.counts[kCountWords * b + 12];
+  const uint32_t* row = rec.tr_rows + ((size_t)b * rec.cap_tr + (real ? r : 0)) * kTrRecWords;
+  const uint32_t flags = real ? row[0] : 0u;
+  Fp st[16];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    beta.c[i] = Fp::from_canonical(row[4 + i]); lo.c[i] = Fp::from_canonical(row[8 + i]); hi.c[i] = Fp::from_canonical(row[12 + i]);
-    o.put(FO_BETA + i, beta.c[i].v); o.put(FO_LO + i, lo.c[i].v); o.put(FO_HI + i, hi.c[i].v);
-    o.val(FO_RO + i, row[16 + i]);
+  for (int i = 0; i < 16; ++i) {
+    st[i] = real ? Fp::from_canonical(row[10 + i]) : Fp::zero();
+    o.put(TR_IN + i, st[i].v);
   }
-  const Fp half = Fp::from_canonical((kP + 1) / 2), xinv = Fp::from_canonical(row[3]);
-  const Fp4 f = (lo + hi) * half + beta * ((lo - hi) * (half * xinv)), e = bit ? hi : lo;
+  o.flag(TR_IS_REAL, real);
+  o.val(TR_LEAF, real ? row[1] : 0u);
+  o.val(TR_STEP, real ? row[2] : 0u);
+  o.flag(TR_FIRST, (flags & kTrRecFirst) != 0); o.flag(TR_ABS, (flags & kTrRecAbs) != 0);
+  for (int k = 0; k < 7; ++k) o.flag(TR_UROOT + k, ((flags >> k) & 1u) != 0);
+  for (int k = 0; k < 8; ++k) o.flag(TR_QM + k, ((flags >> (7 + k)) & 1u) != 0);
+  o.val(TR_RIDK, real ? row[3] : 0u);
+  o.val(TR_QBASE, real ? row[4] : 0u);
+  for (int k = 0; k < 5; ++k) o.val(TR_MROOT + k, real ? row[5 + k] : 0u);
+  p2air_external_linear(st);
+  for (int rd = 0; rd < 8; ++rd) {
+    if (rd == 4) {
+      for (int ir = 0; ir < 13; ++ir) {
+        const Fp x = st[0] + Fp::raw(kc->internal[ir]), x3 = x * x * x, y = x3 * x3 * x;
+        o.put(TR_INT + 2 * ir, x3.v);
+        o.put(TR_INT + 2 * ir + 1, y.v);
+        st[0] = y;
+        Fp sum = st[0];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { o.put(FO_E + i, e.c[i].v); o.put(FO_F + i, f.c[i].v); }
+        for (int i = 1; i < 16; ++i) sum = sum + st[i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[i] = st[i] * Fp::raw(kc->diag[i]) + sum;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const Fp x = st[i] + Fp::raw(kc->ext[rd][i]), x3 = x * x * x, y = x3 * x3 * x;
+      o.put(TR_EXT + 32 * rd + i, x3.v);
+      o.put(TR_EXT + 32 * rd + 16 + i, y.v);
+      st[i] = y;
+    }
+    p2air_external_linear(st);
+  }
 }
 
 // One sub-word-chip instance: row r is event row0 + r of the list sub_idx
@@ -566,7 +620,10 @@ void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& re
       hipLaunchKernelGGL(p2_trace_kernel, dim3((unsigned)((h + 63) / 64), batch), dim3(64), 0, stream, rec, trace, logh);
       break;
     case kEcall: hipLaunchKernelGGL(ecall_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
-    case kFold: hipLaunchKernelGGL(fold_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
+    case kQr: hipLaunchKernelGGL(qr_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
+    case kTr:
+      hipLaunchKernelGGL(tr_trace_kernel, dim3((unsigned)((h + 63) / 64), batch), dim3(64), 0, stream, rec, trace, logh);
+      break;
     case kDiv: hipLaunchKernelGGL(div_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
     case kMemFinal: hipLaunchKernelGGL(memfinal_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
     case kMul:
@@ -1646,7 +1703,8 @@ __global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
   else if constexpr (is_bw_chip(CHIP)) eval_bw(ctx);
   else if constexpr (CHIP == kP2) eval_p2(ctx);
   else if constexpr (CHIP == kEcall) eval_ecall(ctx);
-  else if constexpr (CHIP == kFold) eval_fold(ctx);
+  else if constexpr (CHIP == kQr) eval_qr(ctx);
+  else if constexpr (CHIP == kTr) eval_tr(ctx);
   else if constexpr (CHIP == kDiv) eval_div(ctx);
   ctx.flush();
   logup_constraints(a, pi, &ctx.acc);
@@ -1798,7 +1856,8 @@ void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a) {
     case kBw2: hipLaunchKernelGGL(machine_quotient_kernel<kBw>, grid, block, 0, stream, a); break;
     case kP2: hipLaunchKernelGGL(machine_quotient_kernel<kP2>, grid, block, 0, stream, a); break;
     case kEcall: hipLaunchKernelGGL(machine_quotient_kernel<kEcall>, grid, block, 0, stream, a); break;
-    case kFold: hipLaunchKernelGGL(machine_quotient_kernel<kFold>, grid, block, 0, stream, a); break;
+    case kQr: hipLaunchKernelGGL(machine_quotient_kernel<kQr>, grid, block, 0, stream, a); break;
+    case kTr: hipLaunchKernelGGL(machine_quotient_kernel<kTr>, grid, block, 0, stream, a); break;
     case kDiv: hipLaunchKernelGGL(machine_quotient_kernel<kDiv>, grid, block, 0, stream, a); break;
     case kKmem: hipLaunchKernelGGL(machine_quotient_kernel<kKmem>, grid, block, 0, stream, a); break;
     case kMemFinal: hipLaunchKernelGGL(machine_quotient_kernel<kMemFinal>, grid, block, 0, stream, a); break;

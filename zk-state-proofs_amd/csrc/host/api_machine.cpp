@@ -114,7 +114,8 @@ int zksp_mtrace_section(const zksp_mtrace* t, int which, const void** ptr, size_
     case ZKSP_MT_IMAGE: *ptr = t->prog->image.data(); *bytes = t->prog->image.size() * sizeof(ImageRow); break;
     case ZKSP_MT_PUBLIC_VALUES: *ptr = m.rec.public_values.data(); *bytes = m.rec.public_values.size(); break;
     case ZKSP_MT_LEAF_P2_ROWS: *ptr = m.leaf_check ? m.leaf_check->p2_rows.data() : nullptr; *bytes = m.leaf_check ? m.leaf_check->p2_rows.size() * 4 : 0; break;
-    case ZKSP_MT_LEAF_FOLD_ROWS: *ptr = m.leaf_check ? m.leaf_check->fold_rows.data() : nullptr; *bytes = m.leaf_check ? m.leaf_check->fold_rows.size() * 4 : 0; break;
+    case ZKSP_MT_LEAF_QR_ROWS: *ptr = m.leaf_check ? m.leaf_check->qr_rows.data() : nullptr; *bytes = m.leaf_check ? m.leaf_check->qr_rows.size() * 4 : 0; break;
+    case ZKSP_MT_LEAF_TR_ROWS: *ptr = m.leaf_check ? m.leaf_check->tr_rows.data() : nullptr; *bytes = m.leaf_check ? m.leaf_check->tr_rows.size() * 4 : 0; break;
     case ZKSP_MT_LEAF_PUB_TUPLES: *ptr = m.leaf_check ? m.leaf_check->pub_tuples.data() : nullptr; *bytes = m.leaf_check ? m.leaf_check->pub_tuples.size() * 4 : 0; break;
     default: return ZKSP_ERR_INVALID_ARG;
   }
@@ -345,29 +346,51 @@ int zksp_verify_aggregate_keyed(zksp_client* c, const zksp_proof* p, const zksp_
   return ZKSP_OK;
 }
 
-// ---- leaf-proof check (stage 2a) ----
-// (`index`: the leaf's place among the leaves checked beside one run - its queries are numbered from index * num_queries on)
+// ---- leaf-proof check (stage 2b) ----
+// Verifies `leaf` - completely, or (stub_only) everything but its query phase - and leaves the records / the public tuples of a
+// proof ABOUT that verification in *out.  `index`: the leaf's place among the leaves checked beside one run.  own / n_own: the
+// public tuples `leaf` itself closes its buses with (a leaf that checks leaves of its own: a node of a recursion tree).
 static int leaf_check_of(zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf_vk, std::shared_ptr<LeafCheckLog>* out,
-                         uint32_t index = 0) {
+                         uint32_t index = 0, const uint32_t* own = nullptr, size_t n_own = 0, bool stub_only = false) {
   if (c->ctx.params.proof_mode != ZKSP_PROOF_MACHINE || leaf->version != mach::kMachineVersion)
     return c->ctx.fail(ZKSP_ERR_VERIFY, "leaf check: not a machine proof");
-  if (leaf->mhdr.agg_n || leaf->mhdr.pub_n) return c->ctx.fail(ZKSP_ERR_UNSUPPORTED, "leaf check: the leaf proof carries a payload of its own");
-  // (tags are field elements: 1 + 64 * query number + round)
-  if ((uint64_t)(index + 1) * c->ctx.params.num_queries * mach::kLeafTagStride >= 0x78000000ull)
-    return c->ctx.fail(ZKSP_ERR_UNSUPPORTED, "leaf check: too many leaves for the tag space");
+  if (leaf->mhdr.agg_n) return c->ctx.fail(ZKSP_ERR_UNSUPPORTED, "leaf check: the leaf proof carries an aggregation payload");
+  if (c->ctx.params.num_queries > mach::kLeafMaxQueries || index >= 4096)
+    return c->ctx.fail(ZKSP_ERR_UNSUPPORTED, "leaf check: too many queries or leaves for the tag space");
   std::string err;
   int rc;
   try {
     auto log = std::make_shared<LeafCheckLog>();
-    log->query_base = index * c->ctx.params.num_queries;
+    log->leaf_index = index;
     log->n_leaves = 1;
-    rc = verify_machine_proof(leaf->bytes.data(), leaf->bytes.size(), leaf_vk->machine, c->ctx.params.num_queries, c->ctx.params.pow_bits,
-                              &err, nullptr, 0, nullptr, nullptr, 0, log.get());
+    // a stub is recognised by its length; a complete proof is cut down to one where only the statement is wanted
+    const size_t stub_len = leaf->mhdr.body_offset + machine_proof_body_words(leaf->mhdr.logh, 0) * 4;
+    const bool is_stub = leaf->bytes.size() == stub_len;
+    if (is_stub && !stub_only) return c->ctx.fail(ZKSP_ERR_INVALID_ARG, "leaf check: a proof stub has no query phase to prove");
+    rc = verify_machine_proof(leaf->bytes.data(), stub_only ? stub_len : leaf->bytes.size(), leaf_vk->machine, c->ctx.params.num_queries,
+                              c->ctx.params.pow_bits, &err, nullptr, 0, nullptr, own, n_own, log.get(), stub_only);
     if (rc == 0) *out = std::move(log);
   } catch (...) {
     return c->ctx.fail(ZKSP_ERR_VERIFY, "leaf check: out of memory");
   }
   if (rc) return c->ctx.fail(rc, "leaf check: the leaf proof does not verify: " + err);
+  return ZKSP_OK;
+}
+
+int zksp_proof_stub(const zksp_proof* p, zksp_proof** out) {
+  if (!p || !out || p->version != mach::kMachineVersion) return ZKSP_ERR_INVALID_ARG;
+  const size_t stub_len = p->mhdr.body_offset + machine_proof_body_words(p->mhdr.logh, 0) * 4;
+  if (p->bytes.size() < stub_len) return ZKSP_ERR_INVALID_ARG;
+  zksp_proof* q = new (std::nothrow) zksp_proof();
+  if (!q) return ZKSP_ERR_INVALID_ARG;
+  try {
+    *q = *p;
+    q->bytes.resize(stub_len);
+  } catch (...) {
+    delete q;
+    return ZKSP_ERR_INVALID_ARG;
+  }
+  *out = q;
   return ZKSP_OK;
 }
 
@@ -382,37 +405,18 @@ int zksp_stdin_set_verified_leaf(zksp_client* c, zksp_stdin* s, const zksp_proof
   return ZKSP_OK;
 }
 
-// the checks of several leaves beside one run: the logs one after the other, in the order the leaves were added
-static int leaves_check_of(zksp_client* c, const zksp_proof* const* leaves, const zksp_vk* const* leaf_vks, size_t n,
-                           std::shared_ptr<LeafCheckLog>* out) {
-  auto all = std::make_shared<LeafCheckLog>();
-  for (size_t k = 0; k < n; ++k) {
-    if (!leaves[k] || !leaf_vks[k]) return ZKSP_ERR_INVALID_ARG;
-    std::shared_ptr<LeafCheckLog> one;
-    const int rc = leaf_check_of(c, leaves[k], leaf_vks[k], &one, (uint32_t)k);
-    if (rc) return rc;
-    all->p2_rows.insert(all->p2_rows.end(), one->p2_rows.begin(), one->p2_rows.end());
-    all->fold_rows.insert(all->fold_rows.end(), one->fold_rows.begin(), one->fold_rows.end());
-    all->pub_tuples.insert(all->pub_tuples.end(), one->pub_tuples.begin(), one->pub_tuples.end());
-  }
-  all->n_leaves = (uint32_t)n;
-  *out = std::move(all);
-  return ZKSP_OK;
-}
-
-int zksp_stdin_add_verified_leaf(zksp_client* c, zksp_stdin* s, const zksp_proof* leaf, const zksp_vk* leaf_vk) {
-  if (!c || !s || !leaf || !leaf_vk) return ZKSP_ERR_INVALID_ARG;
+int zksp_stdin_add_verified_node(zksp_client* c, zksp_stdin* s, const zksp_proof* leaf, const zksp_vk* leaf_vk, const uint32_t* own,
+                                 size_t n_own) {
+  if (!c || !s || !leaf || !leaf_vk || (n_own && !own)) return ZKSP_ERR_INVALID_ARG;
   const uint32_t have = s->leaf_check ? s->leaf_check->n_leaves : 0;
   std::shared_ptr<LeafCheckLog> one;
-  const int rc = leaf_check_of(c, leaf, leaf_vk, &one, have);
+  const int rc = leaf_check_of(c, leaf, leaf_vk, &one, have, own, n_own);
   if (rc) return rc;
   try {
     auto all = std::make_shared<LeafCheckLog>();
     if (s->leaf_check) *all = *s->leaf_check;
-    all->p2_rows.insert(all->p2_rows.end(), one->p2_rows.begin(), one->p2_rows.end());
-    all->fold_rows.insert(all->fold_rows.end(), one->fold_rows.begin(), one->fold_rows.end());
-    all->pub_tuples.insert(all->pub_tuples.end(), one->pub_tuples.begin(), one->pub_tuples.end());
-    all->query_base = 0;
+    all->append(*one);
+    all->leaf_index = 0;
     all->n_leaves = have + 1;
     s->leaf_check = std::move(all);
   } catch (...) {
@@ -421,43 +425,15 @@ int zksp_stdin_add_verified_leaf(zksp_client* c, zksp_stdin* s, const zksp_proof
   return ZKSP_OK;
 }
 
-int zksp_leaves_public(zksp_client* c, const zksp_proof* const* leaves, const zksp_vk* const* leaf_vks, size_t n, uint32_t* out,
-                       size_t cap_words, size_t* n_tuples) {
-  if (!c || !leaves || !leaf_vks || !n || !n_tuples) return ZKSP_ERR_INVALID_ARG;
-  std::shared_ptr<LeafCheckLog> log;
-  int rc;
-  try {
-    rc = leaves_check_of(c, leaves, leaf_vks, n, &log);
-  } catch (...) {
-    return c->ctx.fail(ZKSP_ERR_VERIFY, "leaf check: out of memory");
-  }
-  if (rc) return rc;
-  *n_tuples = log->pub_tuples.size() / mach::kPubTupleWords;
-  if (out) {
-    if (cap_words < log->pub_tuples.size()) return c->ctx.fail(ZKSP_ERR_INVALID_ARG, "leaves_public: buffer too small");
-    memcpy(out, log->pub_tuples.data(), log->pub_tuples.size() * 4);
-  }
-  return ZKSP_OK;
+int zksp_stdin_add_verified_leaf(zksp_client* c, zksp_stdin* s, const zksp_proof* leaf, const zksp_vk* leaf_vk) {
+  return zksp_stdin_add_verified_node(c, s, leaf, leaf_vk, nullptr, 0);
 }
 
-int zksp_verify_with_leaves(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const zksp_proof* const* leaves,
-                            const zksp_vk* const* leaf_vks, size_t n) {
-  if (!c || !p || !vk || !leaves || !leaf_vks || !n) return ZKSP_ERR_INVALID_ARG;
+int zksp_leaf_public_at(zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf_vk, uint32_t index, const uint32_t* own, size_t n_own,
+                        uint32_t* out, size_t cap_words, size_t* n_tuples) {
+  if (!c || !leaf || !leaf_vk || !n_tuples || (n_own && !own)) return ZKSP_ERR_INVALID_ARG;
   std::shared_ptr<LeafCheckLog> log;
-  int rc;
-  try {
-    rc = leaves_check_of(c, leaves, leaf_vks, n, &log);
-  } catch (...) {
-    return c->ctx.fail(ZKSP_ERR_VERIFY, "leaf check: out of memory");
-  }
-  if (rc) return rc;
-  return zksp_verify_public(c, p, vk, log->pub_tuples.data(), log->pub_tuples.size() / mach::kPubTupleWords);
-}
-
-int zksp_leaf_public(zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf_vk, uint32_t* out, size_t cap_words, size_t* n_tuples) {
-  if (!c || !leaf || !leaf_vk || !n_tuples) return ZKSP_ERR_INVALID_ARG;
-  std::shared_ptr<LeafCheckLog> log;
-  const int rc = leaf_check_of(c, leaf, leaf_vk, &log);
+  const int rc = leaf_check_of(c, leaf, leaf_vk, &log, index, own, n_own, /*stub_only=*/true);
   if (rc) return rc;
   *n_tuples = log->pub_tuples.size() / mach::kPubTupleWords;
   if (out) {
@@ -465,6 +441,57 @@ int zksp_leaf_public(zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf
     memcpy(out, log->pub_tuples.data(), log->pub_tuples.size() * 4);
   }
   return ZKSP_OK;
+}
+
+// the statements of several leaves beside one run, one after the other, in the order the leaves were added
+static int leaves_statement(zksp_client* c, const zksp_proof* const* leaves, const zksp_vk* const* leaf_vks, size_t n,
+                            std::vector<uint32_t>* out) {
+  out->clear();
+  for (size_t k = 0; k < n; ++k) {
+    if (!leaves[k] || !leaf_vks[k]) return ZKSP_ERR_INVALID_ARG;
+    std::shared_ptr<LeafCheckLog> one;
+    const int rc = leaf_check_of(c, leaves[k], leaf_vks[k], &one, (uint32_t)k, nullptr, 0, /*stub_only=*/true);
+    if (rc) return rc;
+    out->insert(out->end(), one->pub_tuples.begin(), one->pub_tuples.end());
+  }
+  return ZKSP_OK;
+}
+
+int zksp_leaves_public(zksp_client* c, const zksp_proof* const* leaves, const zksp_vk* const* leaf_vks, size_t n, uint32_t* out,
+                       size_t cap_words, size_t* n_tuples) {
+  if (!c || !leaves || !leaf_vks || !n || !n_tuples) return ZKSP_ERR_INVALID_ARG;
+  std::vector<uint32_t> st;
+  int rc;
+  try {
+    rc = leaves_statement(c, leaves, leaf_vks, n, &st);
+  } catch (...) {
+    return c->ctx.fail(ZKSP_ERR_VERIFY, "leaf check: out of memory");
+  }
+  if (rc) return rc;
+  *n_tuples = st.size() / mach::kPubTupleWords;
+  if (out) {
+    if (cap_words < st.size()) return c->ctx.fail(ZKSP_ERR_INVALID_ARG, "leaves_public: buffer too small");
+    memcpy(out, st.data(), st.size() * 4);
+  }
+  return ZKSP_OK;
+}
+
+int zksp_verify_with_leaves(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const zksp_proof* const* leaves,
+                            const zksp_vk* const* leaf_vks, size_t n) {
+  if (!c || !p || !vk || !leaves || !leaf_vks || !n) return ZKSP_ERR_INVALID_ARG;
+  std::vector<uint32_t> st;
+  int rc;
+  try {
+    rc = leaves_statement(c, leaves, leaf_vks, n, &st);
+  } catch (...) {
+    return c->ctx.fail(ZKSP_ERR_VERIFY, "leaf check: out of memory");
+  }
+  if (rc) return rc;
+  return zksp_verify_public(c, p, vk, st.data(), st.size() / mach::kPubTupleWords);
+}
+
+int zksp_leaf_public(zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf_vk, uint32_t* out, size_t cap_words, size_t* n_tuples) {
+  return zksp_leaf_public_at(c, leaf, leaf_vk, 0, nullptr, 0, out, cap_words, n_tuples);
 }
 
 int zksp_verify_public(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const uint32_t* tuples, size_t n_tuples) {
@@ -485,10 +512,7 @@ int zksp_verify_public(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, c
 
 int zksp_verify_with_leaf(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const zksp_proof* leaf, const zksp_vk* leaf_vk) {
   if (!c || !p || !vk || !leaf || !leaf_vk) return ZKSP_ERR_INVALID_ARG;
-  std::shared_ptr<LeafCheckLog> log;
-  const int rc = leaf_check_of(c, leaf, leaf_vk, &log);
-  if (rc) return rc;
-  return zksp_verify_public(c, p, vk, log->pub_tuples.data(), log->pub_tuples.size() / mach::kPubTupleWords);
+  return zksp_verify_with_leaves(c, p, vk, &leaf, &leaf_vk, 1);
 }
 
 int zksp_proof_public_tuples(const zksp_proof* p, uint32_t* n_tuples, uint32_t* digest8) {

@@ -16,11 +16,18 @@ struct HostChallenger {
   Fp outbuf[8];
   int n_in = 0, n_out = 0;
   const P2Consts* k;
+  // optional record of every duplex: 1 if it absorbed a block (0: a squeeze), then the 16 words the permutation started from
+  // (machine proofs since format v16 end every phase on a block boundary, so a duplex absorbs eight words or none)
+  std::vector<uint32_t>* record = nullptr;
   explicit HostChallenger(const P2Consts* kk) : k(kk) {
     for (auto& s : state) s = Fp::zero();
   }
   void duplex() {
     for (int i = 0; i < n_in; ++i) state[i] = inbuf[i];
+    if (record) {
+      record->push_back(n_in == 8 ? 1u : n_in == 0 ? 0u : 2u);  // (2: a partial block - not a machine-proof transcript)
+      for (int i = 0; i < 16; ++i) record->push_back(state[i].to_canonical());
+    }
     n_in = 0;
     p2_permute(state, k);
     for (int i = 0; i < 8; ++i) outbuf[i] = state[i];

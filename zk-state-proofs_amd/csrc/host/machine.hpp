@@ -102,18 +102,25 @@ T* PageAllocator<T>::allocate(size_t n) { return static_cast<T*>(page_alloc(n * 
 template <class T>
 void PageAllocator<T>::deallocate(T* p, size_t n) noexcept { page_free(p, n * sizeof(T)); }
 
-// What verifying a leaf proof leaves behind for a proof ABOUT that verification (stage 2a; the
+// What verifying a leaf proof leaves behind for a proof ABOUT that verification (stage 2b; the
 // reference's circuits/sp1-merkle-proof-recursive/src/main.rs:3-5 is a todo!()): every Poseidon2 permutation of the query
-// phase as a row record of the Poseidon2 chip (20 words each: the sponges over the opened rows, the Merkle paths
-// with their injections, the FRI leaves and paths), every fold as a row record of the fold chip (20 words
-// each), and the public bus tuples (16 words each) that state WHAT was checked: per opening its tag, position,
-// shape and root; per query and layer the challenge, the domain point and the position bit; the reduced openings; the
-// final constant.  All canonical words.
+// phase as a row record of the Poseidon2 chip (32 words each: the sponges over the opened rows with their Horner sums, the
+// Merkle paths with their injections, the FRI leaves and paths), every duplex of the leaf's Fiat-Shamir transcript as a row
+// record of the transcript chip (32 words), the 31 rows per query of the query chip (the canonical bits of the query's index
+// word, the folding chain, the reduced openings), and the public bus tuples (16 words each) that state WHAT was checked: the
+// transcript's blocks (header, commitment roots, cumulative sums, the root of the opened values, FRI roots, final constant,
+// witness), the preprocessed root, one tuple of constants per leaf and one per height (which depend on the leaf's challenges,
+// but on nothing the query phase opens), the proof-of-work word.  All canonical words.
 struct LeafCheckLog {
-  std::vector<uint32_t> p2_rows, fold_rows, pub_tuples;
-  // several leaf proofs checked beside one run: the queries of the k-th leaf are numbered from k * num_queries on (tags,
-  // query ids of the fold rows and of the public tuples), so that the checks share the chips without sharing a tag
-  uint32_t query_base = 0, n_leaves = 0;
+  std::vector<uint32_t> p2_rows, tr_rows, qr_rows, pub_tuples;
+  // several leaf proofs checked beside one run: the k-th leaf's tags, root ids and tuples carry the leaf index k
+  uint32_t leaf_index = 0, n_leaves = 0;
+  void append(const LeafCheckLog& o) {
+    p2_rows.insert(p2_rows.end(), o.p2_rows.begin(), o.p2_rows.end());
+    tr_rows.insert(tr_rows.end(), o.tr_rows.begin(), o.tr_rows.end());
+    qr_rows.insert(qr_rows.end(), o.qr_rows.begin(), o.qr_rows.end());
+    pub_tuples.insert(pub_tuples.end(), o.pub_tuples.begin(), o.pub_tuples.end());
+  }
 };
 
 struct MachineTrace {
@@ -133,21 +140,22 @@ struct MachineTrace {
   std::vector<uint32_t> agg_keys;     // their heap keys (empty: n + j, the leaves of a full tree of n = a power of two)
   size_t agg_rows = 0;                // node rows of the Poseidon2 chip: the ancestors of the supplied keys (set with the payload)
   std::shared_ptr<const LeafCheckLog> leaf_check;  // leaf-proof check to prove beside the run (row f4, stage 2a), or none
-  size_t p2_rows() const { return agg_rows + (leaf_check ? leaf_check->p2_rows.size() / 20 : 0); }
-  size_t fold_rows() const { return leaf_check ? leaf_check->fold_rows.size() / 20 : 0; }
+  size_t p2_rows() const { return agg_rows + (leaf_check ? leaf_check->p2_rows.size() / 32 : 0); }
+  size_t qr_rows() const { return leaf_check ? leaf_check->qr_rows.size() / 132 : 0; }
+  size_t tr_rows() const { return leaf_check ? leaf_check->tr_rows.size() / 32 : 0; }
 };
 
 // How many rows of each event-sized chip a run needs; a batch is proven with the heights of the element-wise maximum.
 struct MachineCounts {
-  size_t cycles = 0, alu = 0, sub = 0, bw = 0, keccak = 0, memfinal = 0, muls = 0, agg = 0 /* Poseidon2 chip rows */, ecall = 0, fold = 0, div = 0;
+  size_t cycles = 0, alu = 0, sub = 0, bw = 0, keccak = 0, memfinal = 0, muls = 0, agg = 0 /* Poseidon2 chip rows */, ecall = 0, fold = 0 /* query chip rows */, div = 0, tr = 0 /* transcript chip rows */;
   void cover(const MachineTrace& t) {
     cycles = std::max(cycles, t.cycles.size()); alu = std::max(alu, t.alu_idx.size()); sub = std::max(sub, t.sub_idx.size());
-    bw = std::max(bw, t.bw_idx.size()); agg = std::max(agg, t.p2_rows()); ecall = std::max(ecall, t.ecall_idx.size()); fold = std::max(fold, t.fold_rows()); div = std::max(div, t.div_idx.size());
+    bw = std::max(bw, t.bw_idx.size()); agg = std::max(agg, t.p2_rows()); ecall = std::max(ecall, t.ecall_idx.size()); fold = std::max(fold, t.qr_rows()); tr = std::max(tr, t.tr_rows()); div = std::max(div, t.div_idx.size());
     keccak = std::max(keccak, t.keccak.size()); memfinal = std::max(memfinal, t.memfinal.size()); muls = std::max(muls, t.muls.size());
   }
   void cover(const MachineCounts& o) {
     cycles = std::max(cycles, o.cycles); alu = std::max(alu, o.alu); sub = std::max(sub, o.sub); bw = std::max(bw, o.bw);
-    agg = std::max(agg, o.agg); ecall = std::max(ecall, o.ecall); keccak = std::max(keccak, o.keccak); fold = std::max(fold, o.fold); div = std::max(div, o.div);
+    agg = std::max(agg, o.agg); ecall = std::max(ecall, o.ecall); keccak = std::max(keccak, o.keccak); fold = std::max(fold, o.fold); tr = std::max(tr, o.tr); div = std::max(div, o.div);
     memfinal = std::max(memfinal, o.memfinal); muls = std::max(muls, o.muls);
   }
 };

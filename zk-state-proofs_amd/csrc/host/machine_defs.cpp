@@ -12,10 +12,17 @@
 //   IMG    (addr, lo, hi)   image chip -> memory boundary: the initial value of an image address
 //   DIGEST (tag, type, key, mask, 8 words)   Poseidon2 chip: heap nodes (type 2: children in, parent out; verifier: the leaves
 //          in, the root out), injected row hashes (type 1), the ends of the openings of a leaf proof (type 0: -> verifier)
-//   PAIR   (tag, lo[4], hi[4])   Poseidon2 chip (a FRI leaf's sponge row) -> fold chip
-//   FRIQ   (query, layer, bit, 1/x, beta[4])   verifier -> fold chip
-//   RO     (query, 0 or layer + 1, value[4])   verifier -> fold chip: the reduced opening that starts / joins the folding
-//   FIN    (query, layer, value[4])   fold chip -> verifier: the last folded value
+//   PAIR   (tag, lo[4], hi[4])   Poseidon2 chip (a FRI leaf's sponge row) -> query chip
+//   POS    (tag, key, mask, root id)   Poseidon2 chip (the end of a run) -> query chip: where the opening sits
+//   ROOT   (root id, 8 words)   transcript chip (the row that absorbed the root; the verifier for the preprocessed root) ->
+//          Poseidon2 chip (the end of a run)
+//   SEG    (tag, key, mask, sum[4], alpha_f[4])   Poseidon2 chip (the last block of a matrix row's hash) -> query chip
+//   TBLK   (leaf, step, flags, root id / layer + 4, 8 words), TSQ (leaf, step, flags, first query)   verifier -> transcript chip
+//   FINAL  (leaf, value[4]), ZETA (leaf, zeta[4]), AF (leaf, alpha_f[4], delta[4]), BETA (leaf, layer, beta[4])
+//          transcript chip -> query chip
+//   POW    (leaf, word)   transcript chip -> verifier: the proof-of-work sample
+//   QIDX   (leaf, query, word)   transcript chip -> query chip: the word a query's index is the low bits of
+//   LEAFK  (leaf, last layer, 1 / omega), BCONST (leaf, layer, has preprocessed, w_H, B1[4], B2[4])   verifier -> query chip
 #include "machine_defs.hpp"
 
 #include <cstdlib>
@@ -94,7 +101,7 @@ Interaction bytes_inter(int sign, const LinForm& mult, const LinForm& x, const L
 }
 
 constexpr int kCpuInter = 19;
-Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[5], g_div[13], g_table[7], g_alu[1], g_sub[5], g_bw[5], g_p2[7], g_ecall[10], g_fold[5];
+Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[5], g_div[13], g_table[7], g_alu[1], g_sub[5], g_bw[5], g_p2[10], g_ecall[10], g_qr[17], g_tr[16];
 ChipDef g_chips[kNumChips];
 
 void build() {
@@ -432,36 +439,213 @@ void build() {
     g_p2[6] = range_inter(-1, lf_col(P2_IS_REAL), lf_const(2), kh2);
   }
   {
-    // FRI fold chip (air_machine.hpp): the verifier's per-layer tuple, the hashed pair, the reduced openings, the end
-    const LinForm q = lf_col(FO_Q), k = lf_col(FO_K);
-    Interaction& fq = g_fold[0];
-    fq = Interaction{};
-    fq.bus = BUS_FRIQ; fq.sign = -1; fq.mult = lf_col(FO_IS_REAL); fq.n_el = 8;
-    fq.el[0] = q; fq.el[1] = k; fq.el[2] = lf_col(FO_BIT); fq.el[3] = lf_col(FO_XINV);
-    for (int j = 0; j < 4; ++j) fq.el[4 + j] = lf_col(FO_BETA + j);
-    Interaction& pr = g_fold[1];
-    pr = Interaction{};
-    pr.bus = BUS_PAIR; pr.sign = -1; pr.mult = lf_col(FO_IS_REAL); pr.n_el = 9;
-    pr.el[0] = lf_zero(); lf_add(pr.el[0], FO_Q, kLeafTagStride); lf_add(pr.el[0], FO_K, 1); pr.el[0].c0 = mont(leaf_tag(0, 4));
-    for (int j = 0; j < 4; ++j) { pr.el[1 + j] = lf_col(FO_LO + j); pr.el[5 + j] = lf_col(FO_HI + j); }
-    Interaction& r0 = g_fold[2];
-    r0 = Interaction{};
-    r0.bus = BUS_RO; r0.sign = -1; r0.mult = lf_col(FO_FIRST); r0.n_el = 6;
-    r0.el[0] = q; r0.el[1] = lf_const(0);
-    for (int j = 0; j < 4; ++j) r0.el[2 + j] = lf_col(FO_E + j);
-    Interaction& r1 = g_fold[3];
-    r1 = Interaction{};
-    r1.bus = BUS_RO; r1.sign = -1; r1.mult = lf_col(FO_HASRO); r1.n_el = 6;
-    r1.el[0] = q; r1.el[1] = lf_plus(k, 1);
-    for (int j = 0; j < 4; ++j) r1.el[2 + j] = lf_col(FO_RO + j);
-    Interaction& fin = g_fold[4];
-    fin = Interaction{};
-    fin.bus = BUS_FIN; fin.sign = +1; fin.mult = lf_col(FO_LAST); fin.n_el = 6;
-    fin.el[0] = q; fin.el[1] = k;
-    for (int j = 0; j < 4; ++j) fin.el[2 + j] = lf_pair(FO_F + j, FO_RO + j, 1);
+    // stage 2b: the end of a run tells the query chip where it sits and takes the root from the transcript chip; the end of a
+    // matrix row's hash hands over its Horner sum
+    static const uint32_t m4[4][4] = {{2, 3, 1, 1}, {1, 2, 3, 1}, {1, 1, 2, 3}, {3, 1, 1, 2}};
+    const int ylast = P2_EXT + 32 * 7 + 16;
+    const LinForm tag = lf_col(P2_T), mask = lf_col(P2_M), key = lf_pair(P2_KL, P2_KH, 65536);
+    Interaction& pos = g_p2[7];
+    pos = Interaction{};
+    pos.bus = BUS_POS; pos.sign = +1; pos.mult = lf_col(P2_RE); pos.n_el = 4;
+    pos.el[0] = tag; pos.el[1] = key; pos.el[2] = mask; pos.el[3] = lf_col(P2_RID);
+    Interaction& rt = g_p2[8];
+    rt = Interaction{};
+    rt.bus = BUS_ROOT; rt.sign = -1; rt.mult = lf_col(P2_RE); rt.n_el = 9;
+    rt.el[0] = lf_col(P2_RID);
+    for (int j = 0; j < 8; ++j) {
+      rt.el[1 + j] = lf_zero();
+      for (int i = 0; i < 16; ++i) lf_add(rt.el[1 + j], ylast + i, (uint64_t)m4[j & 3][i & 3] * ((i >> 2) == (j >> 2) ? 2u : 1u));
+    }
+    Interaction& sg = g_p2[9];
+    sg = Interaction{};
+    sg.bus = BUS_SEG; sg.sign = +1; sg.mult = lf_col(P2_SE); sg.n_el = 11;
+    sg.el[0] = tag; sg.el[1] = key; sg.el[2] = mask;
+    for (int j = 0; j < 4; ++j) { sg.el[3 + j] = lf_col(P2_SO + j); sg.el[7 + j] = lf_col(P2_AP + j); }
   }
-  g_chips[kFold] = {"fri-fold", 0, kFoldWidth, 5, g_fold, kFoldConstraints, 0};
-  g_chips[kP2] = {"poseidon2", 0, kP2Width, 7, g_p2, kP2Constraints, 0};
+  {
+    // query chip (air_machine.hpp).  T(r) = 1 + 64 QL + 2^18 LEAF + r, RID(r) = 64 LEAF + r.
+    auto tag_of = [&](uint32_t r, int kcol) {
+      LinForm f = lf_zero();
+      lf_add(f, QR_QL, kLeafTagStride); lf_add(f, QR_LEAF, kLeafTagLeafStride);
+      if (kcol >= 0) lf_add(f, kcol, 1);
+      f.c0 = mont(1 + r);
+      return f;
+    };
+    auto rid_of = [&](uint32_t r, int kcol) {
+      LinForm f = lf_zero();
+      lf_add(f, QR_LEAF, 64);
+      if (kcol >= 0) lf_add(f, kcol, 1);
+      f.c0 = mont(r);
+      return f;
+    };
+    const LinForm leaf = lf_col(QR_LEAF), last = lf_col(QR_LAST), lay = lf_col(QR_LAY), hasro = lf_col(QR_HASRO);
+    int n = 0;
+    {
+      Interaction& it = g_qr[n++];
+      it = Interaction{};
+      it.bus = BUS_QIDX; it.sign = -1; it.mult = last; it.n_el = 3;
+      it.el[0] = leaf; it.el[1] = lf_col(QR_QL); it.el[2] = lf_col(QR_ACC);
+    }
+    {
+      Interaction& it = g_qr[n++];
+      it = Interaction{};
+      it.bus = BUS_LEAFK; it.sign = -1; it.mult = last; it.n_el = 3;
+      it.el[0] = leaf; it.el[1] = lf_col(QR_K); it.el[2] = lf_col(QR_OMI);
+    }
+    {
+      Interaction& it = g_qr[n++];
+      it = Interaction{};
+      it.bus = BUS_FINAL; it.sign = -1; it.mult = last; it.n_el = 5;
+      it.el[0] = leaf;
+      for (int j = 0; j < 4; ++j) it.el[1 + j] = lf_col(QR_F + j);
+    }
+    for (uint32_t r = 1; r <= 3; ++r) {  // the three trees as tall as the proof: position 2^(lm + 1) + 2 m + cs on the coset bit's row
+      Interaction& it = g_qr[n++];
+      it = Interaction{};
+      it.bus = BUS_POS; it.sign = -1; it.mult = lf_col(QR_CSR); it.n_el = 4;
+      it.el[0] = tag_of(r, -1);
+      it.el[1] = lf_zero(); lf_add(it.el[1], QR_POW, 2); lf_add(it.el[1], QR_LOW, 2); lf_add(it.el[1], QR_BIT, 1);
+      it.el[2] = lf_col(QR_MT); it.el[3] = rid_of(r, -1);
+    }
+    {
+      Interaction& it = g_qr[n++];  // the preprocessed tree (2^16 tall)
+      it = Interaction{};
+      it.bus = BUS_POS; it.sign = -1; it.mult = lf_col(QR_PR0); it.n_el = 4;
+      it.el[0] = tag_of(0, -1);
+      it.el[1] = lf_zero(); lf_add(it.el[1], QR_POW, 2); lf_add(it.el[1], QR_LOW, 2); lf_add(it.el[1], QR_CS, 1);
+      it.el[2] = lf_col(QR_MT0); it.el[3] = rid_of(0, -1);
+    }
+    {
+      Interaction& it = g_qr[n++];  // the FRI layer's tree: 2^(J + 1) + 2 rev(m mod 2^J) + cs
+      it = Interaction{};
+      it.bus = BUS_POS; it.sign = -1; it.mult = lay; it.n_el = 4;
+      it.el[0] = tag_of(4, QR_K);
+      it.el[1] = lf_zero(); lf_add(it.el[1], QR_POW, 2); lf_add(it.el[1], QR_REV, 2); lf_add(it.el[1], QR_CS, 1);
+      it.el[2] = lf_const(0); it.el[3] = rid_of(4, QR_K);
+    }
+    {
+      Interaction& it = g_qr[n++];
+      it = Interaction{};
+      it.bus = BUS_PAIR; it.sign = -1; it.mult = lay; it.n_el = 9;
+      it.el[0] = tag_of(4, QR_K);
+      for (int j = 0; j < 4; ++j) { it.el[1 + j] = lf_col(QR_LO + j); it.el[5 + j] = lf_col(QR_HI + j); }
+    }
+    {
+      Interaction& it = g_qr[n++];
+      it = Interaction{};
+      it.bus = BUS_BETA; it.sign = -1; it.mult = lay; it.n_el = 6;
+      it.el[0] = leaf; it.el[1] = lf_col(QR_K);
+      for (int j = 0; j < 4; ++j) it.el[2 + j] = lf_col(QR_BETA + j);
+    }
+    for (uint32_t r = 0; r <= 3; ++r) {  // the Horner sums of the opened rows of the height that joins here
+      Interaction& it = g_qr[n++];
+      it = Interaction{};
+      it.bus = BUS_SEG; it.sign = -1; it.mult = r == 0 ? lf_col(QR_HAS0) : hasro; it.n_el = 11;
+      it.el[0] = tag_of(r, -1); it.el[1] = lf_col(r == 0 ? QR_KEY0 : QR_KEYJ); it.el[2] = lf_col(r == 0 ? QR_M0 : QR_MJ);
+      for (int j = 0; j < 4; ++j) { it.el[3 + j] = lf_col(QR_H + 4 * (int)r + j); it.el[7 + j] = lf_col(QR_AF + j); }
+    }
+    {
+      Interaction& it = g_qr[n++];
+      it = Interaction{};
+      it.bus = BUS_ZETA; it.sign = -1; it.mult = hasro; it.n_el = 5;
+      it.el[0] = leaf;
+      for (int j = 0; j < 4; ++j) it.el[1 + j] = lf_col(QR_ZETA + j);
+    }
+    {
+      Interaction& it = g_qr[n++];
+      it = Interaction{};
+      it.bus = BUS_AF; it.sign = -1; it.mult = hasro; it.n_el = 9;
+      it.el[0] = leaf;
+      for (int j = 0; j < 4; ++j) { it.el[1 + j] = lf_col(QR_AF + j); it.el[5 + j] = lf_col(QR_DL + j); }
+    }
+    {
+      Interaction& it = g_qr[n++];
+      it = Interaction{};
+      it.bus = BUS_BCONST; it.sign = -1; it.mult = hasro; it.n_el = 12;
+      it.el[0] = leaf; it.el[1] = lf_col(QR_K); it.el[2] = lf_col(QR_HAS0); it.el[3] = lf_col(QR_WH);
+      for (int j = 0; j < 4; ++j) { it.el[4 + j] = lf_col(QR_B1 + j); it.el[8 + j] = lf_col(QR_B2 + j); }
+    }
+    if (n != 17) abort();
+  }
+  {
+    // transcript chip (air_machine.hpp).  The output words of a row: the external linear layer of the last round's columns.
+    static const uint32_t m4[4][4] = {{2, 3, 1, 1}, {1, 2, 3, 1}, {1, 1, 2, 3}, {3, 1, 1, 2}};
+    const int ylast = TR_EXT + 32 * 7 + 16;
+    auto out_word = [&](int j) {
+      LinForm f = lf_zero();
+      for (int i = 0; i < 16; ++i) lf_add(f, ylast + i, (uint64_t)m4[j & 3][i & 3] * ((i >> 2) == (j >> 2) ? 2u : 1u));
+      return f;
+    };
+    const LinForm leaf = lf_col(TR_LEAF), step = lf_col(TR_STEP);
+    LinForm flags = lf_zero();
+    for (int k = 0; k < 7; ++k) lf_add(flags, TR_UROOT + k, (uint64_t)1 << k);
+    for (int k = 0; k < 8; ++k) lf_add(flags, TR_QM + k, (uint64_t)128 << k);
+    int n = 0;
+    {
+      Interaction& it = g_tr[n++];
+      it = Interaction{};
+      it.bus = BUS_TBLK; it.sign = -1; it.mult = lf_col(TR_ABS); it.n_el = 12;
+      it.el[0] = leaf; it.el[1] = step; it.el[2] = flags; it.el[3] = lf_col(TR_RIDK);
+      for (int j = 0; j < 8; ++j) it.el[4 + j] = lf_col(TR_IN + j);
+    }
+    {
+      Interaction& it = g_tr[n++];
+      it = Interaction{};
+      it.bus = BUS_TSQ; it.sign = -1; it.mult = lf_pair(TR_IS_REAL, TR_ABS, kP - 1); it.n_el = 4;
+      it.el[0] = leaf; it.el[1] = step; it.el[2] = flags; it.el[3] = lf_col(TR_QBASE);
+    }
+    {
+      Interaction& it = g_tr[n++];
+      it = Interaction{};
+      it.bus = BUS_ROOT; it.sign = +1; it.mult = lf_col(TR_MROOT); it.n_el = 9;
+      it.el[0] = lf_zero(); lf_add(it.el[0], TR_LEAF, 64); lf_add(it.el[0], TR_RIDK, 1);
+      for (int j = 0; j < 8; ++j) it.el[1 + j] = lf_col(TR_IN + j);
+    }
+    {
+      Interaction& it = g_tr[n++];
+      it = Interaction{};
+      it.bus = BUS_FINAL; it.sign = +1; it.mult = lf_col(TR_MFIN); it.n_el = 5;
+      it.el[0] = leaf;
+      for (int j = 0; j < 4; ++j) it.el[1 + j] = lf_col(TR_IN + j);
+    }
+    {
+      Interaction& it = g_tr[n++];
+      it = Interaction{};
+      it.bus = BUS_ZETA; it.sign = +1; it.mult = lf_col(TR_MZETA); it.n_el = 5;
+      it.el[0] = leaf;
+      for (int j = 0; j < 4; ++j) it.el[1 + j] = out_word(7 - j);
+    }
+    {
+      Interaction& it = g_tr[n++];
+      it = Interaction{};
+      it.bus = BUS_AF; it.sign = +1; it.mult = lf_col(TR_MAF); it.n_el = 9;
+      it.el[0] = leaf;
+      for (int j = 0; j < 8; ++j) it.el[1 + j] = out_word(7 - j);
+    }
+    {
+      Interaction& it = g_tr[n++];
+      it = Interaction{};
+      it.bus = BUS_BETA; it.sign = +1; it.mult = lf_col(TR_MBETA); it.n_el = 6;
+      it.el[0] = leaf; it.el[1] = lf_plus(lf_col(TR_RIDK), kP - 4);
+      for (int j = 0; j < 4; ++j) it.el[2 + j] = out_word(7 - j);
+    }
+    {
+      Interaction& it = g_tr[n++];
+      it = Interaction{};
+      it.bus = BUS_POW; it.sign = +1; it.mult = lf_col(TR_UPOW); it.n_el = 2;
+      it.el[0] = leaf; it.el[1] = out_word(7);
+    }
+    for (int j = 0; j < 8; ++j) {
+      Interaction& it = g_tr[n++];
+      it = Interaction{};
+      it.bus = BUS_QIDX; it.sign = +1; it.mult = lf_col(TR_QM + j); it.n_el = 3;
+      it.el[0] = leaf; it.el[1] = lf_plus(lf_col(TR_QBASE), (uint32_t)j); it.el[2] = out_word(7 - j);
+    }
+    if (n != 16) abort();
+  }
+  g_chips[kQr] = {"query", 0, kQrWidth, 17, g_qr, kQrConstraints, 0};
+  g_chips[kTr] = {"transcript", 0, kTrWidth, 16, g_tr, kTrConstraints, 0};
+  g_chips[kP2] = {"poseidon2", 0, kP2Width, 10, g_p2, kP2Constraints, 0};
   g_chips[kTable] = {"table", kTablePrepWidth, kTableWidth, 7, g_table, 2, 0};
   g_chips[kCpu] = {"cpu", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 5};
   g_chips[kCpu2] = {"cpu2", 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 5};

@@ -349,7 +349,8 @@ void machine_heights(const MachineProgram& prog, const MachineCounts& n, int log
   logh[kTable] = kTableLogH;
   logh[kP2] = at_least5(ceil_log2(n.agg ? n.agg : 1));  // a payload's rows: heap nodes, the permutations of a leaf-proof check
   logh[kEcall] = at_least5(ceil_log2(n.ecall));
-  logh[kFold] = at_least5(ceil_log2(n.fold ? n.fold : 1));
+  logh[kQr] = at_least5(ceil_log2(n.fold ? n.fold : 1));
+  logh[kTr] = at_least5(ceil_log2(n.tr ? n.tr : 1));
   logh[kDiv] = at_least5(ceil_log2(n.div));
 }
 void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh[kNumChips]) {
@@ -361,7 +362,7 @@ bool machine_fits(const MachineTrace& t, const int* logh) {
   auto two = [&](int a, int b) { return ((size_t)1 << logh[a]) + ((size_t)1 << logh[b]); };
   auto one = [&](int a) { return (size_t)1 << logh[a]; };
   return t.cycles.size() <= machine_cpu_row0(logh, kNumCpuInst) && t.alu_idx.size() <= two(kAlu, kAlu2) && t.sub_idx.size() <= two(kSub, kSub2) &&
-         t.bw_idx.size() <= two(kBw, kBw2) && t.p2_rows() <= one(kP2) && t.fold_rows() <= one(kFold) &&
+         t.bw_idx.size() <= two(kBw, kBw2) && t.p2_rows() <= one(kP2) && t.qr_rows() <= one(kQr) && t.tr_rows() <= one(kTr) &&
          24 * t.keccak.size() <= one(kKeccak) && 50 * t.keccak.size() <= one(kKmem) && t.memfinal.size() <= one(kMemFinal) &&
          t.muls.size() <= one(kMul) && t.ecall_idx.size() <= one(kEcall) && t.div_idx.size() <= one(kDiv);
 }
@@ -451,7 +452,8 @@ static size_t records_place(T* t, void* base, size_t B, const int* logh) {
   A(&t->ecall_idx, B << logh[kEcall]);  // (an ecall list is as long as the ecall chip is tall, at most)
   A(&t->div_idx, B << logh[kDiv]);
   A(&t->agg_heap, B * t->cap_agg * kP2RecWords);
-  A(&t->fold_rows, B * t->cap_fold * kFoldRecWords);
+  A(&t->fold_rows, B * t->cap_fold * kQrRecWords);
+  A(&t->tr_rows, B * t->cap_tr * kTrRecWords);
   A(&t->prog_mult, B << logh[kProgram]);
   A(&t->counts, B * kCountWords);
   A(&t->n_perms, B);
@@ -481,12 +483,12 @@ static int records_ensure(Context* ctx, int slot, size_t bytes) {
 // will reuse the memory is enqueued behind them - unless it has to grow; the old workspace object (host-side tables an
 // asynchronous copy may still read) is retired, not destroyed.
 static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap_cycles, size_t cap_keccak, size_t cap_memfinal,
-                            size_t cap_muls, size_t cap_alu, size_t cap_sub, size_t cap_bw, size_t cap_agg, size_t cap_fold,
+                            size_t cap_muls, size_t cap_alu, size_t cap_sub, size_t cap_bw, size_t cap_agg, size_t cap_fold, size_t cap_tr,
                             bool in_flight = false) {
   MachineWorkspace* w = ctx->mws.get();
   if (w && memcmp(w->logh, logh, sizeof w->logh) == 0 && w->batch >= batch && w->cap_cycles >= cap_cycles &&
       w->cap_keccak >= cap_keccak && w->cap_memfinal >= cap_memfinal && w->cap_muls >= cap_muls && w->cap_alu >= cap_alu &&
-      w->cap_sub >= cap_sub && w->cap_bw >= cap_bw && w->cap_agg >= cap_agg && w->cap_fold >= cap_fold)
+      w->cap_sub >= cap_sub && w->cap_bw >= cap_bw && w->cap_agg >= cap_agg && w->cap_fold >= cap_fold && w->cap_tr >= cap_tr)
     return 0;
   if (!in_flight) {
     ZKSP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -509,6 +511,7 @@ static int workspace_ensure(Context* ctx, const int* logh, int batch, size_t cap
   w->cap_alu = std::max<size_t>(cap_alu, 1); w->cap_sub = std::max<size_t>(cap_sub, 1); w->cap_bw = std::max<size_t>(cap_bw, 1);
   w->cap_agg = std::max<size_t>(cap_agg, 2);
   w->cap_fold = std::max<size_t>(cap_fold, 2);
+  w->cap_tr = std::max<size_t>(cap_tr, 2);
   const size_t B = (size_t)batch;
   const uint32_t Q = ctx->params.num_queries;
   // The workspace lives in ONE device arena that survives re-shaping: a batch of other chip heights only lays the same
@@ -693,13 +696,13 @@ namespace {
 void swap_records(MachineWorkspace* w) {
   MachineWorkspace::SpareRecords& p = w->spare;
   std::swap(w->cycles, p.cycles); std::swap(w->memfinal, p.memfinal); std::swap(w->muls, p.muls);
-  std::swap(w->prog_mult, p.prog_mult); std::swap(w->alu_idx, p.alu_idx); std::swap(w->sub_idx, p.sub_idx); std::swap(w->bw_idx, p.bw_idx); std::swap(w->ecall_idx, p.ecall_idx); std::swap(w->div_idx, p.div_idx); std::swap(w->agg_heap, p.agg_heap); std::swap(w->fold_rows, p.fold_rows);
+  std::swap(w->prog_mult, p.prog_mult); std::swap(w->alu_idx, p.alu_idx); std::swap(w->sub_idx, p.sub_idx); std::swap(w->bw_idx, p.bw_idx); std::swap(w->ecall_idx, p.ecall_idx); std::swap(w->div_idx, p.div_idx); std::swap(w->agg_heap, p.agg_heap); std::swap(w->fold_rows, p.fold_rows); std::swap(w->tr_rows, p.tr_rows);
   std::swap(w->counts, p.counts);
   std::swap(w->kcalls, p.kcalls); std::swap(w->kstates, p.kstates); std::swap(w->n_perms, p.n_perms);
   std::swap(w->init_obs, p.init_obs); std::swap(w->pub_words, p.pub_words); std::swap(w->n, p.n);
   std::swap(w->cap_cycles, p.cap_cycles); std::swap(w->cap_keccak, p.cap_keccak); std::swap(w->cap_memfinal, p.cap_memfinal);
   std::swap(w->cap_muls, p.cap_muls); std::swap(w->cap_alu, p.cap_alu); std::swap(w->cap_sub, p.cap_sub); std::swap(w->cap_bw, p.cap_bw);
-  std::swap(w->cap_agg, p.cap_agg); std::swap(w->cap_fold, p.cap_fold);
+  std::swap(w->cap_agg, p.cap_agg); std::swap(w->cap_fold, p.cap_fold); std::swap(w->cap_tr, p.cap_tr);
   w->rec_slot ^= 1;
 }
 }  // namespace
@@ -722,7 +725,7 @@ int machine_activate_spare(Context* ctx) {
     // which may overlap the old layout's `body` that the copy stream is still reading)
     if (ctx->body_free) ZKSP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->body_free, 0));
     int rc = workspace_ensure(ctx, sp.logh, std::max(sp.n, sp.batch_hint), sp.cap_cycles, sp.cap_keccak, sp.cap_memfinal, sp.cap_muls,
-                              sp.cap_alu, sp.cap_sub, sp.cap_bw, sp.cap_agg, sp.cap_fold, /*in_flight=*/true);
+                              sp.cap_alu, sp.cap_sub, sp.cap_bw, sp.cap_agg, sp.cap_fold, sp.cap_tr, /*in_flight=*/true);
     if (rc) return rc;
     w = ctx->mws.get();
     w->prep = prep;
@@ -760,7 +763,7 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
                ck = std::min(((size_t)1 << logh[kKeccak]) / 24, ((size_t)1 << logh[kKmem]) / 50),
                ca = ((size_t)1 << logh[kAlu]) + ((size_t)1 << logh[kAlu2]), cs = ((size_t)1 << logh[kSub]) + ((size_t)1 << logh[kSub2]),
                cb = ((size_t)1 << logh[kBw]) + ((size_t)1 << logh[kBw2]),
-               cg = (size_t)1 << logh[kP2], cf = (size_t)1 << logh[kFold];  // one record per row of the Poseidon2 / fold chip
+               cg = (size_t)1 << logh[kP2], cf = (size_t)1 << logh[kQr], ct = (size_t)1 << logh[kTr];  // one record per row of the Poseidon2 / query / transcript chip
   if (logh[kCpu] > 20) return ctx->fail(9, "machine_load: more than 2^21 cycles");
   if (into_spare) {
     MachineWorkspace* w0 = ctx->mws.get();
@@ -770,13 +773,13 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     memcpy(sp.logh, logh, sizeof sp.logh);
     sp.cap_cycles = cc; sp.cap_keccak = std::max<size_t>(ck, 1); sp.cap_memfinal = cm; sp.cap_muls = std::max<size_t>(cu, 1);
     sp.cap_alu = std::max<size_t>(ca, 1); sp.cap_sub = std::max<size_t>(cs, 1); sp.cap_bw = std::max<size_t>(cb, 1);
-    sp.cap_agg = std::max<size_t>(cg, 2); sp.cap_fold = std::max<size_t>(cf, 2);
+    sp.cap_agg = std::max<size_t>(cg, 2); sp.cap_fold = std::max<size_t>(cf, 2); sp.cap_tr = std::max<size_t>(ct, 2);
     sp.batch_hint = ctx->spare_batch_hint;
     rc = records_ensure(ctx, w0->rec_slot ^ 1, records_place(&sp, nullptr, n, logh));
     if (rc) return rc;
     records_place(&sp, ctx->rec_arena[w0->rec_slot ^ 1], n, logh);
   } else {
-    rc = workspace_ensure(ctx, logh, (int)std::max<size_t>(n, (size_t)ctx->batch_hint), cc, ck, cm, cu, ca, cs, cb, cg, cf);
+    rc = workspace_ensure(ctx, logh, (int)std::max<size_t>(n, (size_t)ctx->batch_hint), cc, ck, cm, cu, ca, cs, cb, cg, cf, ct);
     if (rc) return rc;
     MachineWorkspace* w0 = ctx->mws.get();
     // (the buffer may be in use by a pass that reads the last resident batch: this path is the synchronous one)
@@ -830,12 +833,15 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     const LeafCheckLog* lc = t.leaf_check.get();
     const size_t n_node = agg_heaps[i].size() / kP2RecWords, n_lc = lc ? lc->p2_rows.size() / kP2RecWords : 0;
     cn[8] = (uint32_t)(n_node + n_lc);
-    cn[10] = (uint32_t)t.fold_rows();
+    cn[10] = (uint32_t)t.qr_rows();
+    cn[12] = (uint32_t)t.tr_rows();
     uint32_t* d_p2 = w->agg_heap + i * w->cap_agg * kP2RecWords;
     if (n_node) ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(d_p2, agg_heaps[i].data(), agg_heaps[i].size() * 4, hipMemcpyHostToDevice, s));
     if (n_lc) ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(d_p2 + n_node * kP2RecWords, lc->p2_rows.data(), lc->p2_rows.size() * 4, hipMemcpyHostToDevice, s));
     if (cn[10])
-      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->fold_rows + i * w->cap_fold * kFoldRecWords, lc->fold_rows.data(), lc->fold_rows.size() * 4, hipMemcpyHostToDevice, s));
+      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->fold_rows + i * w->cap_fold * kQrRecWords, lc->qr_rows.data(), lc->qr_rows.size() * 4, hipMemcpyHostToDevice, s));
+    if (cn[12])
+      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->tr_rows + i * w->cap_tr * kTrRecWords, lc->tr_rows.data(), lc->tr_rows.size() * 4, hipMemcpyHostToDevice, s));
     if (!t.alu_idx.empty())
       ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->alu_idx + i * w->cap_alu, t.alu_idx.data(), t.alu_idx.size() * 4, hipMemcpyHostToDevice, s));
     if (!t.sub_idx.empty())
@@ -946,13 +952,13 @@ int machine_prove_resident(Context* ctx) {
   // ---- main traces ----
   MachineRecords rec;
   rec.cycles = w->cycles; rec.kcalls = w->kcalls; rec.memfinal = w->memfinal; rec.muls = w->muls;
-  rec.alu_idx = w->alu_idx; rec.sub_idx = w->sub_idx; rec.bw_idx = w->bw_idx; rec.ecall_idx = w->ecall_idx; rec.div_idx = w->div_idx; rec.agg_heap = w->agg_heap; rec.fold_rows = w->fold_rows; rec.consts = kc;
+  rec.alu_idx = w->alu_idx; rec.sub_idx = w->sub_idx; rec.bw_idx = w->bw_idx; rec.ecall_idx = w->ecall_idx; rec.div_idx = w->div_idx; rec.agg_heap = w->agg_heap; rec.fold_rows = w->fold_rows; rec.tr_rows = w->tr_rows; rec.consts = kc;
   rec.prog_mult = w->prog_mult; rec.counts = w->counts; rec.table_hist = w->table_hist;
   memset(rec.row0, 0, sizeof rec.row0);
   for (int k = 1; k < kNumCpuInst; ++k) rec.row0[cpu_chip(k)] = (uint32_t)machine_cpu_row0(logh, k);
   rec.row0[kAlu2] = (uint32_t)1 << logh[kAlu]; rec.row0[kSub2] = (uint32_t)1 << logh[kSub]; rec.row0[kBw2] = (uint32_t)1 << logh[kBw];
   rec.cap_cycles = w->cap_cycles; rec.cap_keccak = w->cap_keccak; rec.cap_memfinal = w->cap_memfinal; rec.cap_muls = w->cap_muls;
-  rec.cap_alu = w->cap_alu; rec.cap_sub = w->cap_sub; rec.cap_bw = w->cap_bw; rec.cap_agg = w->cap_agg; rec.cap_fold = w->cap_fold; rec.cap_ecall = (size_t)1 << logh[kEcall]; rec.cap_div = (size_t)1 << logh[kDiv];
+  rec.cap_alu = w->cap_alu; rec.cap_sub = w->cap_sub; rec.cap_bw = w->cap_bw; rec.cap_agg = w->cap_agg; rec.cap_fold = w->cap_fold; rec.cap_tr = w->cap_tr; rec.cap_ecall = (size_t)1 << logh[kEcall]; rec.cap_div = (size_t)1 << logh[kDiv];
   rec.program = prep->program; rec.text_base = prep->text_base; rec.n_program = prep->n_program; rec.n_image = prep->n_image;
   rec.cpu_rows = (uint32_t)machine_cpu_row0(logh, kNumCpuInst);
   // Small batches: the chips of a stage go to the lanes of a fork (by height) and the stage joins again; large batches have

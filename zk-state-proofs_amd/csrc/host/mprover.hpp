@@ -13,7 +13,8 @@ namespace zksp {
 
 // vk digest, heights, exit halves, digest halves, hand-over pc halves, aggregation: leaf count, root, digest of the leaf list;
 // public bus tuples: count, digest of the list
-constexpr int kMachineInitObs = 8 + mach::kNumChips + 2 + 16 + 16 + 2 * (mach::kNumCpuInst - 1) + 17 + 9;
+// (zero-filled to a block boundary: since format v16 the main root that follows is a block of its own)
+constexpr int kMachineInitObs = (8 + mach::kNumChips + 2 + 16 + 16 + 2 * (mach::kNumCpuInst - 1) + 17 + 9 + 7) / 8 * 8;
 
 // Preprocessed tables of one program on the device (built once per verifying key).
 struct PrepDevice {
@@ -34,11 +35,11 @@ struct PrepDevice {
 struct MachineWorkspace {
   int logh[mach::kNumChips] = {0};
   int batch = 0, n = 0;
-  size_t cap_cycles = 0, cap_keccak = 0, cap_memfinal = 0, cap_muls = 0, cap_alu = 0, cap_sub = 0, cap_bw = 0, cap_agg = 0, cap_fold = 0;
+  size_t cap_cycles = 0, cap_keccak = 0, cap_memfinal = 0, cap_muls = 0, cap_alu = 0, cap_sub = 0, cap_bw = 0, cap_agg = 0, cap_fold = 0 /* query chip rows */, cap_tr = 0 /* transcript chip rows */;
   const PrepDevice* prep = nullptr;
   // records
   uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *alu_idx = nullptr, *sub_idx = nullptr,
-           *bw_idx = nullptr, *ecall_idx = nullptr, *div_idx = nullptr, *agg_heap = nullptr, *fold_rows = nullptr, *counts = nullptr, *table_hist = nullptr;
+           *bw_idx = nullptr, *ecall_idx = nullptr, *div_idx = nullptr, *agg_heap = nullptr, *fold_rows = nullptr, *tr_rows = nullptr, *counts = nullptr, *table_hist = nullptr;
   uint8_t* kcalls = nullptr;
   uint64_t* kstates = nullptr;
   uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;
@@ -46,7 +47,7 @@ struct MachineWorkspace {
   // being proven, then machine_activate_spare() swaps the sets.
   struct SpareRecords {
     uint32_t *cycles = nullptr, *memfinal = nullptr, *muls = nullptr, *prog_mult = nullptr, *alu_idx = nullptr, *sub_idx = nullptr,
-             *bw_idx = nullptr, *ecall_idx = nullptr, *div_idx = nullptr, *agg_heap = nullptr, *fold_rows = nullptr, *counts = nullptr;
+             *bw_idx = nullptr, *ecall_idx = nullptr, *div_idx = nullptr, *agg_heap = nullptr, *fold_rows = nullptr, *tr_rows = nullptr, *counts = nullptr;
     uint8_t* kcalls = nullptr;
     uint64_t* kstates = nullptr;
     uint32_t *n_perms = nullptr, *init_obs = nullptr, *pub_words = nullptr;
@@ -54,7 +55,7 @@ struct MachineWorkspace {
     // its own shape: a chunk of other chip heights than the resident batch's is uploaded while that batch is proven, and
     // machine_activate_spare lays the arena out for it
     int logh[mach::kNumChips] = {0};
-    size_t cap_cycles = 0, cap_keccak = 0, cap_memfinal = 0, cap_muls = 0, cap_alu = 0, cap_sub = 0, cap_bw = 0, cap_agg = 0, cap_fold = 0;
+    size_t cap_cycles = 0, cap_keccak = 0, cap_memfinal = 0, cap_muls = 0, cap_alu = 0, cap_sub = 0, cap_bw = 0, cap_agg = 0, cap_fold = 0 /* query chip rows */, cap_tr = 0 /* transcript chip rows */;
     int batch_hint = 0;
   } spare;
   int rec_slot = 0;  // Context::rec_arena[rec_slot] holds the resident records, the other one the spare set

@@ -101,34 +101,53 @@ struct RoundShape {
 };
 
 // ---- leaf-check log (mverifier.hpp LeafCheckLog): the permutations of the query phase as Poseidon2-chip row records ----
-void log_p2_row(LeafCheckLog* log, uint32_t flags, uint32_t tag, uint32_t key, uint32_t mask, const Fp in[16]) {
+// (32 words: flags, tag, key, mask, the 16 input words, root id, the Horner sum after the block, alpha_f, padding)
+void log_p2_row(LeafCheckLog* log, uint32_t flags, uint32_t tag, uint32_t key, uint32_t mask, const Fp in[16], uint32_t rid = 0,
+                const Fp4* so = nullptr, const Fp4* alpha = nullptr) {
   std::vector<uint32_t>& v = log->p2_rows;
   v.push_back(flags); v.push_back(tag); v.push_back(key); v.push_back(mask);
   for (int i = 0; i < 16; ++i) v.push_back(in[i].to_canonical());
+  v.push_back(rid);
+  for (int i = 0; i < 4; ++i) v.push_back(so ? so->c[i].to_canonical() : 0u);
+  for (int i = 0; i < 4; ++i) v.push_back(alpha ? alpha->c[i].to_canonical() : 0u);
+  for (int i = 0; i < 3; ++i) v.push_back(0u);
 }
-void log_pub_tuple(LeafCheckLog* log, uint32_t bus, bool verifier_sends, const uint32_t* el, int n_el) {
+void log_pub_tuple(LeafCheckLog* log, uint32_t bus, bool verifier_sends, uint32_t mult, const uint32_t* el, int n_el) {
   std::vector<uint32_t>& v = log->pub_tuples;
-  v.push_back(bus); v.push_back(verifier_sends ? 1u : 0u); v.push_back(1u); v.push_back((uint32_t)n_el);
+  v.push_back(bus); v.push_back(verifier_sends ? 1u : 0u); v.push_back(mult); v.push_back((uint32_t)n_el);
   for (int i = 0; i < kPubTupleWords - 4; ++i) v.push_back(i < n_el ? el[i] : 0u);
 }
-// hash_elems, every block logged as a sponge row labelled (tag, key, mask): the first starts from the zero state
+// hash_elems, every block logged as a sponge row labelled (tag, key, mask): the first starts from the zero state.  With
+// `alpha` (the hash of a matrix row of a commitment): Horner's rule in alpha over the absorbed words, block by block; the last
+// row is flagged SE and the sum comes back in *sum.
 void sponge_logged(const Fp* in, size_t n, Fp out[8], const P2Consts* kc, LeafCheckLog* log, uint32_t tag, uint32_t key, uint32_t mask,
-                   bool run_start, bool send, bool fri_leaf) {
+                   bool run_start, bool send, bool fri_leaf, const Fp4* alpha = nullptr, Fp4* sum = nullptr) {
   Fp st[16];
   for (auto& x : st) x = Fp::zero();
+  Fp4 so = Fp4::zero(), a8 = Fp4::one();
+  if (alpha) a8 = alpha->pow(8);
   for (size_t off = 0; off < n; off += 8) {
     const size_t m = n - off < 8 ? n - off : 8;
     for (size_t i = 0; i < 8; ++i) st[i] = i < m ? in[off + i] : Fp::zero();
+    if (alpha) {
+      Fp4 bv = Fp4::zero();
+      for (int i = 0; i < 8; ++i) bv = bv * *alpha + Fp4::from_base(st[i]);
+      so = so * a8 + bv;
+    } else {
+      so = Fp4::from_base(st[7]);  // (a hash nobody reduces - a FRI pair: the row's alpha_f columns are zero, Horner's rule leaves the last word)
+    }
     if (log) {
       uint32_t flags = off == 0 ? (uint32_t)P2K_SZ : (uint32_t)P2K_SC;
       if (run_start) flags |= kP2FlagNew;
       if (send && off + 8 >= n) flags |= kP2FlagSnd;
       if (fri_leaf && off == 0) flags |= kP2FlagFri;
-      log_p2_row(log, flags, tag, key, mask, st);
+      if (alpha && off + 8 >= n) flags |= kP2FlagSe;
+      log_p2_row(log, flags, tag, key, mask, st, 0, &so, alpha);
     }
     p2_permute(st, kc);
   }
   for (int i = 0; i < 8; ++i) out[i] = st[i];
+  if (sum) *sum = so;
 }
 // one step of a path: the running digest on the left or on the right of its sibling
 void compress_logged(const Fp* cur, const Fp* sib, bool cur_right, Fp out[8], const P2Consts* kc, LeafCheckLog* log, uint32_t kind,
@@ -142,11 +161,19 @@ void compress_logged(const Fp* cur, const Fp* sib, bool cur_right, Fp out[8], co
   p2_permute(st, kc);
   for (int i = 0; i < 8; ++i) out[i] = st[i];
 }
+// the last logged row ends its run: its digest is compared with root `rid`, its position goes to the query chip
+void log_run_end(LeafCheckLog* log, uint32_t rid) {
+  uint32_t* r = log->p2_rows.data() + log->p2_rows.size() - kP2RecWords;
+  r[0] |= kP2FlagRe;
+  r[kP2RecRid] = rid;
+}
 
 // Recomputes the root of one mixed-height opening.  rows[c]: opened row of chip c (width[c] words).  With a log: the
-// opening as a run of the Poseidon2 chip (air_machine.hpp), tagged `tag`, and the public tuple that ends it.
+// opening as a run of the Poseidon2 chip (air_machine.hpp), tagged `tag`, its root named `rid`; hsum[lh]: the Horner sum (in
+// alpha) of the opened rows of the chips of height 2^lh, which the query chip turns into reduced openings.
 bool mmcs_verify(const RoundShape& sh, const int* logh, const std::vector<std::vector<Fp>>& rows, size_t cs, size_t m_max,
-                 const uint32_t* path_canon, const Fp root[8], const P2Consts* kc, LeafCheckLog* log = nullptr, uint32_t tag = 0) {
+                 const uint32_t* path_canon, const Fp root[8], const P2Consts* kc, LeafCheckLog* log = nullptr, uint32_t tag = 0,
+                 uint32_t rid = 0, const Fp4* alpha = nullptr, Fp4* hsum = nullptr) {
   const int logn = sh.lm + 1;
   const size_t hm = (size_t)1 << sh.lm;
   const size_t pos = cs * hm + bitrev32((uint32_t)(m_max & (hm - 1)), sh.lm);
@@ -165,13 +192,13 @@ bool mmcs_verify(const RoundShape& sh, const int* logh, const std::vector<std::v
       mask = 2 * mask;
       if (group_row(logn - l - 1, &cat)) {
         Fp g[8];
-        sponge_logged(cat.data(), cat.size(), g, kc, log, tag, key, ++mask, false, true, false);
+        sponge_logged(cat.data(), cat.size(), g, kc, log, tag, key, ++mask, false, true, false, alpha, hsum ? &hsum[logn - l - 2] : nullptr);
       }
     }
   }
   Fp cur[8];
   if (!group_row(logn, &cat)) return false;
-  sponge_logged(cat.data(), cat.size(), cur, kc, log, tag, 1, 0, true, false, false);
+  sponge_logged(cat.data(), cat.size(), cur, kc, log, tag, 1, 0, true, false, false, alpha, hsum ? &hsum[logn - 1] : nullptr);
   uint32_t key = 1, mask = 0;
   for (int l = 0; l < logn; ++l) {
     Fp sib[8], nxt[8];
@@ -190,12 +217,7 @@ bool mmcs_verify(const RoundShape& sh, const int* logh, const std::vector<std::v
   }
   for (int i = 0; i < 8; ++i)
     if (cur[i] != root[i]) return false;
-  if (log) {
-    log->p2_rows[log->p2_rows.size() - kP2RecWords] |= kP2FlagSnd;  // the run's last row hands its digest to the verifier
-    uint32_t el[12] = {tag, 0, key, mask};
-    for (int i = 0; i < 8; ++i) el[4 + i] = root[i].to_canonical();
-    log_pub_tuple(log, BUS_DIGEST, false, el, 12);
-  }
+  if (log) log_run_end(log, rid);
   return true;
 }
 
@@ -567,7 +589,7 @@ void machine_pub_digest(const uint32_t* pub_tuples, size_t n_pub, uint32_t diges
 
 int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, uint32_t num_queries, uint32_t pow_bits,
                          std::string* err, const uint32_t* agg_leaves, size_t n_agg, const uint32_t* agg_keys,
-                         const uint32_t* pub_tuples, size_t n_pub, LeafCheckLog* log) {
+                         const uint32_t* pub_tuples, size_t n_pub, LeafCheckLog* log, bool stub) {
   MachineHeader hd;
   if (!parse_machine_header(bytes, len, &hd, err)) return 7;
   // public bus tuples: the caller names the statement the proof's buses are claimed to close with; the transcript holds its digest
@@ -579,6 +601,9 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     for (size_t i = 0; i < n_pub; ++i) {
       const uint32_t* t = pub_tuples + kPubTupleWords * i;
       if (t[1] > 1 || t[3] > (uint32_t)(kPubTupleWords - 4)) { *err = "malformed public bus tuple"; return 7; }
+      // only the buses of a leaf-proof check have a public end: what the verifier sends, and the proof-of-work word it takes
+      const bool sent = t[0] == BUS_TBLK || t[0] == BUS_TSQ || t[0] == BUS_ROOT || t[0] == BUS_LEAFK || t[0] == BUS_BCONST;
+      if (t[1] ? !sent : t[0] != BUS_POW) { *err = "public bus tuple on a bus without a public end"; return 7; }
       for (int j = 0; j < kPubTupleWords; ++j)
         if (t[j] >= kP) { *err = "non-canonical word in a public bus tuple"; return 7; }
     }
@@ -586,7 +611,8 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     machine_pub_digest(pub_tuples, n_pub, dg);
     if (memcmp(dg, hd.pub_digest, 32) != 0) { *err = "the proof was made for another list of public bus tuples"; return 8; }
   }
-  if (log) { log->p2_rows.clear(); log->fold_rows.clear(); log->pub_tuples.clear(); }
+  if (log) { log->p2_rows.clear(); log->tr_rows.clear(); log->qr_rows.clear(); log->pub_tuples.clear(); }
+  if (log && (num_queries > kLeafMaxQueries || log->leaf_index >= 4096)) { *err = "leaf check: too many queries or leaves for the tag space"; return 7; }
   // the aggregation payload: the caller names the leaves the proof's root is claimed for; the transcript holds their digest
   if (hd.agg_n != n_agg) {
     *err = n_agg ? "the proof does not aggregate this many leaves" : "the proof carries an aggregation payload: verify it with its leaves";
@@ -598,8 +624,9 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     if (memcmp(dg, hd.agg_digest, 32) != 0) { *err = "the proof aggregates another list of leaves"; return 8; }
   }
   const int* logh = hd.logh;
-  const size_t body_words = machine_proof_body_words(logh, num_queries);
-  if (len != hd.body_offset + body_words * 4) { *err = "proof length mismatch"; return 7; }
+  // (a stub is a proof cut off in front of its query phase: everything the transcript absorbs, and the opened values)
+  const size_t body_words = stub ? machine_proof_body_words(logh, 0) : machine_proof_body_words(logh, num_queries);
+  if (len != hd.body_offset + body_words * 4) { *err = stub ? "proof stub length mismatch" : "proof length mismatch"; return 7; }
   if (memcmp(hd.vk_digest, vk.digest, 32) != 0) { *err = "verifying key mismatch"; return 8; }
   if (logh[kImage] != vk.log_image || logh[kProgram] != vk.log_prog || logh[kTable] != kTableLogH) {
     *err = "preprocessed table heights differ from the key";
@@ -644,6 +671,8 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
 
   // ---- transcript ----
   HostChallenger ch(kc);
+  std::vector<uint32_t> duplexes;  // with a log: every duplex of this transcript (17 words each), for the transcript chip
+  if (log) ch.record = &duplexes;
   for (int i = 0; i < 8; ++i) ch.observe_canon(hd.vk_digest[i]);
   for (int c = 0; c < kNumChips; ++c) ch.observe_canon((uint32_t)logh[c]);
   ch.observe_canon(hd.exit_code & 0xffff);
@@ -659,6 +688,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   for (int i = 0; i < 8; ++i) ch.observe_canon(hd.agg_digest[i]);
   ch.observe_canon(hd.pub_n);
   for (int i = 0; i < 8; ++i) ch.observe_canon(hd.pub_digest[i]);
+  ch.pad();  // (v16: a commitment root is a block of its own)
   Fp root[4][8];
   for (int i = 0; i < 8; ++i) root[0][i] = Fp::from_canonical(vk.prep_root[i]);
   for (int i = 0; i < 8; ++i) { root[1][i] = Fp::from_canonical(p_root_main[i]); ch.observe(root[1][i]); }
@@ -789,7 +819,8 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       case kBw2: eval_bw(zc); break;
       case kP2: eval_p2(zc); break;
       case kEcall: eval_ecall(zc); break;
-      case kFold: eval_fold(zc); break;
+      case kQr: eval_qr(zc); break;
+      case kTr: eval_tr(zc); break;
       case kDiv: eval_div(zc); break;
     }
     if (zc.k_ != nb) { *err = "internal: constraint count"; return 7; }
@@ -859,7 +890,8 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   for (int i = 0; i < 4; ++i) ch.observe(final_poly.c[i]);
   ch.observe_canon(p_witness[0]);
   ch.pad();
-  if (ch.sample_bits((int)pow_bits) != 0) { *err = "proof-of-work witness rejected"; return 8; }
+  const uint32_t pow_word = ch.sample().to_canonical();
+  if ((pow_word & ((1u << pow_bits) - 1)) != 0) { *err = "proof-of-work witness rejected"; return 8; }
   ch.drop_outputs();  // (v16: the query indices start from a fresh squeeze)
 
   // ---- reduced-opening constants per chip (v16: machine_reduce_coefs) ----
@@ -876,6 +908,10 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     for (size_t i = 0; i < n2[c]; ++i) b2[c] += afpow[open_off[c] + n1[c] + i] * opened[open_off[c] + n1[c] + i];
   }
   const Fp inv2 = Fp::from_canonical(2).inv();
+  auto height_present = [&](int lh) { for (int c = 0; c < kNumChips; ++c) if (logh[c] == lh) return true; return false; };
+  auto height_has_prep = [&](int lh) { for (int c = 0; c < kNumChips; ++c) if (logh[c] == lh && chip_def(c).prep_w) return true; return false; };
+  int n_heights = 0;
+  for (int lh = 0; lh <= lm; ++lh) n_heights += height_present(lh) ? 1 : 0;
 
   size_t perq = 0;
   for (int r = 0; r < 4; ++r) {
@@ -887,21 +923,94 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   // The queries are independent of one another once their indices are drawn: they are checked on several threads (each with
   // its own log, appended in query order afterwards), the first failure in query order is the one reported.
   std::vector<size_t> indices(num_queries);
-  for (uint32_t qi = 0; qi < num_queries; ++qi) indices[qi] = ch.sample_bits(lm + 1);
+  std::vector<uint32_t> index_words(num_queries);
+  for (uint32_t qi = 0; qi < num_queries; ++qi) {
+    index_words[qi] = ch.sample().to_canonical();
+    indices[qi] = index_words[qi] & (((uint32_t)2 << lm) - 1);
+  }
+  ch.record = nullptr;
+  const uint32_t leaf = log ? log->leaf_index : 0u;
+  auto canon4 = [](const Fp4& v, uint32_t* out) { for (int i = 0; i < 4; ++i) out[i] = v.c[i].to_canonical(); };
+
+  // ---- with a log: the statement a proof ABOUT this verification closes its buses with, and the transcript chip's rows ----
+  if (log) {
+    if (shape[0].lm != kTableLogH || lm < kTableLogH || lm > 21) { *err = "leaf check: unsupported shape"; return 7; }
+    const size_t n_dup = duplexes.size() / 17;
+    // the steps, in the order the transcript went through them
+    constexpr size_t kHeadObs = 8 + kNumChips + 2 + 16 + 16 + 2 * (kNumCpuInst - 1) + 1 + 8 + 8 + 1 + 8;  // words observed before the main root
+    const size_t s_main = (kHeadObs + 7) / 8, s_perm = s_main + 1, s_quot = s_perm + 1 + (4 * (size_t)kNumChips + 7) / 8, s_open = s_quot + 1,
+                 s_fri = s_open + 1, s_final = s_fri + (size_t)lm, s_q = s_final + 1, n_sq = (num_queries + 7) / 8;
+    if (n_dup != s_q + n_sq) { *err = "internal: transcript steps"; return 7; }
+    for (size_t st = 0; st < n_dup; ++st) {
+      const uint32_t* d = duplexes.data() + 17 * st;
+      if (d[0] > 1 || (d[0] == 1) != (st < s_q)) { *err = "internal: transcript is not block-aligned"; return 7; }
+      uint32_t flags = 0, ridk = 0, qbase = 0, mroot = 0, mfin = 0, mzeta = 0, maf = 0, mbeta = 0;
+      if (st == s_main) { flags |= 1; ridk = 1; mroot = num_queries; }
+      if (st == s_perm) { flags |= 1; ridk = 2; mroot = num_queries; }
+      if (st == s_quot) { flags |= 1 | 2; ridk = 3; mroot = num_queries; mzeta = num_queries * (uint32_t)n_heights; }
+      if (st == s_open) { flags |= 4; maf = num_queries * (uint32_t)n_heights; }
+      if (st >= s_fri && st < s_final) { flags |= 1 | 8; ridk = 4 + (uint32_t)(st - s_fri); mroot = num_queries; mbeta = num_queries; }
+      if (st == s_final) { flags |= 16 | 32; mfin = num_queries; }
+      if (st >= s_q) {
+        qbase = 8 * (uint32_t)(st - s_q);
+        const uint32_t nq = std::min<uint32_t>(8, num_queries - qbase);
+        flags |= 64 | (((1u << nq) - 1) << 7);
+      }
+      std::vector<uint32_t>& v = log->tr_rows;
+      v.push_back(flags | (st == 0 ? kTrRecFirst : 0u) | (d[0] ? kTrRecAbs : 0u));
+      v.push_back(leaf); v.push_back((uint32_t)st); v.push_back(ridk); v.push_back(qbase);
+      v.push_back(mroot); v.push_back(mfin); v.push_back(mzeta); v.push_back(maf); v.push_back(mbeta);
+      for (int i = 0; i < 16; ++i) v.push_back(d[1 + i]);
+      for (int i = 26; i < (int)kTrRecWords; ++i) v.push_back(0u);
+      if (d[0]) {
+        uint32_t el[12] = {leaf, (uint32_t)st, flags, ridk};
+        for (int i = 0; i < 8; ++i) el[4 + i] = d[1 + i];
+        log_pub_tuple(log, BUS_TBLK, true, 1, el, 12);
+      } else {
+        const uint32_t el[4] = {leaf, (uint32_t)st, flags, qbase};
+        log_pub_tuple(log, BUS_TSQ, true, 1, el, 4);
+      }
+    }
+    {
+      // the preprocessed commitment is the key's, not the transcript's: the verifier hands it to the runs that end there
+      uint32_t el[9] = {leaf_rid(leaf, 0)};
+      for (int i = 0; i < 8; ++i) el[1 + i] = vk.prep_root[i];
+      log_pub_tuple(log, BUS_ROOT, true, num_queries, el, 9);
+      const uint32_t lk[3] = {leaf, (uint32_t)lm - 1, fp_root_of_unity(lm + 1).inv().to_canonical()};
+      log_pub_tuple(log, BUS_LEAFK, true, num_queries, lk, 3);
+      for (int k = 0; k < lm; ++k) {
+        const int lh = lm - k;
+        if (!height_present(lh)) continue;
+        Fp4 B1 = Fp4::zero(), B2 = Fp4::zero();
+        for (int c = 0; c < kNumChips; ++c)
+          if (logh[c] == lh) { B1 += b1[c]; B2 += b2[c]; }
+        uint32_t el[12] = {leaf, (uint32_t)k, height_has_prep(lh) ? 1u : 0u, fp_root_of_unity(lh).to_canonical()};
+        canon4(B1, el + 4);
+        canon4(B2, el + 8);
+        log_pub_tuple(log, BUS_BCONST, true, num_queries, el, 12);
+      }
+      const uint32_t pw[2] = {leaf, pow_word};
+      log_pub_tuple(log, BUS_POW, false, 1, pw, 2);
+    }
+  }
+  if (stub) return 0;
+
   auto check_query = [&](uint32_t qi, LeafCheckLog* log, std::string* err) -> int {
-    const uint32_t qg = (log ? log->query_base : 0u) + qi;  // the query's number among all leaves checked beside one run
     std::vector<std::vector<Fp>> rows[4];
     for (int r = 0; r < 4; ++r) rows[r].resize(kNumChips);
     const uint32_t* q = p_queries + perq * qi;
     const size_t idx = indices[qi];
     const size_t cs = idx >> lm, m = idx & (hmax - 1);
+    Fp4 hsum[4][32];  // with a log: the Horner sums (in alpha_f) of the opened rows, per tree and height
     for (int r = 0; r < 4; ++r) {
       for (int c = 0; c < kNumChips; ++c) {
         rows[r][c].resize(shape[r].width[c]);
         for (int i = 0; i < shape[r].width[c]; ++i) rows[r][c][i] = Fp::from_canonical(q[i]);
         q += shape[r].width[c];
       }
-      if (!mmcs_verify(shape[r], logh, rows[r], cs, m, q, root[r], kc, log, leaf_tag(qg, (uint32_t)r))) {
+      for (auto& hv : hsum[r]) hv = Fp4::zero();
+      if (!mmcs_verify(shape[r], logh, rows[r], cs, m, q, root[r], kc, log, leaf_tag(leaf, qi, (uint32_t)r), leaf_rid(leaf, (uint32_t)r),
+                       log ? &af : nullptr, log ? hsum[r] : nullptr)) {
         static const char* names[4] = {"preprocessed", "main", "permutation", "quotient"};
         *err = std::string(names[r]) + " Merkle opening rejected";
         return 8;
@@ -929,14 +1038,70 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       }
       return gsum;
     };
-    auto height_present = [&](int lh) { for (int c = 0; c < kNumChips; ++c) if (logh[c] == lh) return true; return false; };
-    Fp4 expect = reduced(lm);
-    auto canon4 = [](const Fp4& v, uint32_t* out) { for (int i = 0; i < 4; ++i) out[i] = v.c[i].to_canonical(); };
-    if (log) {  // the reduced opening the folding starts from
-      uint32_t el[6] = {qg, 0};
-      canon4(expect, el + 2);
-      log_pub_tuple(log, BUS_RO, true, el, 6);
+    // with a log: the query chip's 31 rows (air_machine.hpp), bit 30 of the index word down to bit 0
+    std::vector<std::array<uint32_t, kQrRecWords>> qrow;
+    const uint32_t word = index_words[qi];
+    const Fp omi = fp_root_of_unity(lm + 1).inv(), gi0 = Fp::from_canonical(kGenInv);
+    Fp4 d2x = Fp4::zero(), d3x = Fp4::zero(), d4x = Fp4::zero();
+    if (log) {
+      qrow.resize(31);
+      d2x = delta * delta; d3x = d2x * delta; d4x = d2x * d2x;
+      uint32_t eqv = 0, cnt0 = 0, key0 = 0, m0 = 0, keyj = 0, mj = 0;
+      // (MT, MT0 and YT are the same on every row of the chain: filled in at the end)
+      Fp r_acc = Fp::one(), yki = Fp::zero(), gi = Fp::zero();
+      for (int j = 30; j >= 0; --j) {
+        std::array<uint32_t, kQrRecWords>& w = qrow[30 - j];
+        w.fill(0);
+        const uint32_t bit = (word >> j) & 1u;
+        const bool is_csr = j == lm, is_lay = j < lm, is_fl = j == lm - 1;
+        const int k = lm - 1 - j;
+        w[QR_IS_REAL] = 1; w[QR_FIRST] = j == 30; w[QR_LAST] = j == 0; w[QR_LEAF] = leaf; w[QR_QL] = qi; w[QR_J] = (uint32_t)j;
+        w[QR_BIT] = bit; w[QR_ACC] = word >> j;
+        eqv = j == 30 ? bit : (j >= 27 ? (eqv & bit) : eqv);
+        w[QR_EQ] = eqv;
+        w[QR_F1] = j == 29; w[QR_F2] = j == 28; w[QR_F3] = j == 27;
+        w[QR_CSR] = is_csr; w[QR_FL] = is_fl; w[QR_LAY] = is_lay; w[QR_K] = is_lay ? (uint32_t)k : 0u;
+        w[QR_CS] = j <= lm ? (uint32_t)cs : 0u;
+        w[QR_POW] = 1u << j; w[QR_LOW] = word & ((1u << j) - 1);
+        w[QR_REV] = j ? bitrev32(word & ((1u << j) - 1), j) : 0u;
+        w[QR_PR0] = j == kTableLogH;
+        cnt0 += w[QR_PR0];
+        w[QR_CNT0] = cnt0;
+        w[QR_P0A] = j < kTableLogH;
+        if (j == kTableLogH - 1) { key0 = 1; m0 = 0; }
+        if (j < kTableLogH - 1) { key0 = 2 * key0 + ((word >> (j + 1)) & 1u); m0 = 2 * m0 + (height_has_prep(j + 1) ? 1u : 0u); }
+        if (j < kTableLogH) { w[QR_KEY0] = key0; w[QR_M0] = m0; w[QR_HAS0] = height_has_prep(j + 1); }
+        if (is_fl) { keyj = 1; mj = 0; }
+        if (is_lay && !is_fl) { keyj = 2 * keyj + ((word >> (j + 1)) & 1u); mj = 2 * mj + (height_present(j + 1) ? 1u : 0u); }
+        if (is_lay) { w[QR_KEYJ] = keyj; w[QR_MJ] = mj; w[QR_HASRO] = height_present(j + 1); }
+        w[QR_OMI] = omi.to_canonical();
+        w[QR_MU] = bit ? omi.to_canonical() : 1u;
+        w[QR_CSM] = w[QR_CS] ? omi.to_canonical() : 1u;
+        if (is_lay) {
+          r_acc = is_fl ? Fp::from_canonical(w[QR_MU]) : r_acc * r_acc * Fp::from_canonical(w[QR_MU]);
+          w[QR_R] = r_acc.to_canonical();
+          w[QR_R2] = (r_acc * r_acc).to_canonical();
+        }
+      }
+      // the inverse of y = omega^(cs + 2 m), its squares down the layers, the shifts
+      const Fp yt = r_acc * r_acc * (cs ? omi : Fp::one());
+      for (int j = 30; j >= 0; --j) {
+        std::array<uint32_t, kQrRecWords>& w = qrow[30 - j];
+        w[QR_YT] = yt.to_canonical();
+        w[QR_MT] = 4 * mj;
+        w[QR_MT0] = 4 * m0;
+        if (j < lm) {
+          yki = j == lm - 1 ? yt : yki * yki;
+          gi = j == lm - 1 ? gi0 : gi * gi;
+          w[QR_YKI] = yki.to_canonical();
+          w[QR_GI] = gi.to_canonical();
+          const Fp xinv = gi * yki * (((word >> j) & 1u) ? -Fp::one() : Fp::one());
+          w[QR_XINV] = xinv.to_canonical();
+        }
+      }
     }
+    Fp4 expect = reduced(lm);
+    Fp4 ro_k = expect;  // the reduced opening that joins on the row of layer k (layer 0: the tallest height's)
     Fp shift_k = g;
     for (int k = 0; k < lm; ++k) {
       const int loghk = lm - k;
@@ -947,7 +1112,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       Fp pair[8], cur[8];
       for (int i = 0; i < 4; ++i) { pair[i] = lo.c[i]; pair[4 + i] = hi.c[i]; }
       // the layer's opening: the pair's hash, hashed up to the layer's root (with a log: a run of the Poseidon2 chip)
-      const uint32_t tag = leaf_tag(qg, 4 + (uint32_t)k);
+      const uint32_t tag = leaf_tag(leaf, qi, 4 + (uint32_t)k);
       sponge_logged(pair, 8, cur, kc, log, tag, 1, 0, true, false, true);
       uint32_t key = 1;
       const size_t leaf_pos = cs * half + mlo;
@@ -963,48 +1128,57 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
         if (cur[i] != fri_roots[k][i]) { *err = "FRI Merkle path rejected"; return 8; }
       const Fp xk = (cs ? shift_k * fp_root_of_unity(loghk + 1) : shift_k) * fp_root_of_unity(loghk).pow(mlo);
       const Fp xinv = xk.inv();
-      expect = (lo + hi) * inv2 + betas[k] * ((lo - hi) * (inv2 * xinv));
-      const bool joins = height_present(loghk - 1);
-      Fp4 ro = Fp4::zero();
-      if (joins) { ro = reduced(loghk - 1); expect += ro; }
+      const Fp4 folded = (lo + hi) * inv2 + betas[k] * ((lo - hi) * (inv2 * xinv));
       if (log) {
-        log->p2_rows[log->p2_rows.size() - kP2RecWords] |= kP2FlagSnd;
-        uint32_t el[12] = {tag, 0, key, 0};
-        for (int i = 0; i < 8; ++i) el[4 + i] = fri_roots[k][i].to_canonical();
-        log_pub_tuple(log, BUS_DIGEST, false, el, 12);
-        uint32_t fq[8] = {qg, (uint32_t)k, mk >= half ? 1u : 0u, xinv.to_canonical()};
-        canon4(betas[k], fq + 4);
-        log_pub_tuple(log, BUS_FRIQ, true, fq, 8);
-        if (joins) {
-          uint32_t el2[6] = {qg, (uint32_t)k + 1};
-          canon4(ro, el2 + 2);
-          log_pub_tuple(log, BUS_RO, true, el2, 6);
+        log_run_end(log, leaf_rid(leaf, 4 + (uint32_t)k));
+        std::array<uint32_t, kQrRecWords>& w = qrow[30 - (lm - 1 - k)];
+        if (w[QR_XINV] != xinv.to_canonical() || w[QR_POW] * 2 + w[QR_REV] * 2 + w[QR_CS] != key) { *err = "internal: query chip row"; return 7; }
+        canon4(betas[k], &w[QR_BETA]); canon4(lo, &w[QR_LO]); canon4(hi, &w[QR_HI]); canon4(expect, &w[QR_E]); canon4(folded, &w[QR_F]);
+        // the reduced opening of the height 2^loghk, which joined on THIS row (ro_k), from its parts
+        const Fp yki = Fp::from_canonical(w[QR_YKI]);
+        const Fp wh = fp_root_of_unity(loghk);
+        const Fp4 zw = zeta * wh;
+        Fp4 den0 = zeta * (-yki), den1 = zw * (-yki);
+        den0.c[0] = den0.c[0] + g;
+        den1.c[0] = den1.c[0] + g;
+        const Fp4 d0 = den0.inv() * yki, d1 = den1.inv() * yki;
+        canon4(d0, &w[QR_D0]); canon4(d1, &w[QR_D1]);
+        if (w[QR_HASRO]) {
+          Fp4 B1 = Fp4::zero(), B2 = Fp4::zero();
+          for (int c = 0; c < kNumChips; ++c)
+            if (logh[c] == loghk) { B1 += b1[c]; B2 += b2[c]; }
+          const Fp4 g2 = hsum[1][loghk] + delta * hsum[2][loghk];
+          for (int r = 0; r < 4; ++r) canon4(hsum[r][loghk], &w[QR_H + 4 * r]);
+          canon4(af, &w[QR_AF]); canon4(delta, &w[QR_DL]); canon4(d2x, &w[QR_D2]); canon4(d3x, &w[QR_D3]); canon4(d4x, &w[QR_D4]);
+          canon4(g2, &w[QR_G2]); canon4(zeta, &w[QR_ZETA]); canon4(zw, &w[QR_ZW]); canon4(B1, &w[QR_B1]); canon4(B2, &w[QR_B2]);
+          w[QR_WH] = wh.to_canonical();
+          const Fp4 ro = d0 * (hsum[0][loghk] + delta * hsum[1][loghk] + d2x * hsum[2][loghk] + d3x * hsum[3][loghk] - B1) +
+                         d1 * (d4x * g2 - B2);
+          if (ro != ro_k) { *err = "internal: reduced opening from the Horner sums"; return 7; }
+          canon4(ro, &w[QR_RO]);
+        } else {
+          // (no height joins: ZETA = 0 in the row, so D0 = D1 = 1 / (g y))
+          const Fp4 dz = Fp4::from_base(yki * gi0);
+          canon4(dz, &w[QR_D0]); canon4(dz, &w[QR_D1]);
         }
-        std::vector<uint32_t>& fr = log->fold_rows;
-        fr.push_back((k == 0 ? 1u : 0u) | (k == lm - 1 ? 2u : 0u) | (mk >= half ? 4u : 0u) | (joins ? 8u : 0u));
-        fr.push_back(qg); fr.push_back((uint32_t)k); fr.push_back(xinv.to_canonical());
-        uint32_t w4[4];
-        canon4(betas[k], w4); fr.insert(fr.end(), w4, w4 + 4);
-        canon4(lo, w4); fr.insert(fr.end(), w4, w4 + 4);
-        canon4(hi, w4); fr.insert(fr.end(), w4, w4 + 4);
-        canon4(ro, w4); fr.insert(fr.end(), w4, w4 + 4);
       }
+      expect = folded;
+      const bool joins = height_present(loghk - 1);
+      ro_k = Fp4::zero();
+      if (joins) { ro_k = reduced(loghk - 1); expect += ro_k; }
       q += 8 + 8 * loghk;
       shift_k = shift_k * shift_k;
     }
     if (expect != final_poly) { *err = "FRI final value mismatch"; return 8; }
-    if (log) {  // the last folded value is the final constant
-      uint32_t el[6] = {qg, (uint32_t)lm - 1};
-      canon4(final_poly, el + 2);
-      log_pub_tuple(log, BUS_FIN, false, el, 6);
-    }
+    if (log)
+      for (const auto& w : qrow) log->qr_rows.insert(log->qr_rows.end(), w.begin(), w.end());
     return 0;
   };
   const unsigned n_thr = std::max(1u, std::min({std::thread::hardware_concurrency(), 8u, (unsigned)num_queries / 4u}));
   std::vector<int> q_rc(num_queries, 0);
   std::vector<std::string> q_err(num_queries);
   std::vector<LeafCheckLog> q_log(log ? num_queries : 0);
-  for (LeafCheckLog& ql : q_log) ql.query_base = log->query_base;
+  for (LeafCheckLog& ql : q_log) ql.leaf_index = log->leaf_index;
   std::atomic<uint32_t> next_q{0};
   // (a query that throws - out of memory in its vectors - is a malformed-input failure of that query, on whichever thread)
   auto worker = [&]() noexcept {
@@ -1033,8 +1207,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   if (log)
     for (uint32_t qi = 0; qi < num_queries; ++qi) {
       log->p2_rows.insert(log->p2_rows.end(), q_log[qi].p2_rows.begin(), q_log[qi].p2_rows.end());
-      log->fold_rows.insert(log->fold_rows.end(), q_log[qi].fold_rows.begin(), q_log[qi].fold_rows.end());
-      log->pub_tuples.insert(log->pub_tuples.end(), q_log[qi].pub_tuples.begin(), q_log[qi].pub_tuples.end());
+      log->qr_rows.insert(log->qr_rows.end(), q_log[qi].qr_rows.begin(), q_log[qi].qr_rows.end());
     }
   return 0;
 }

@@ -46,10 +46,14 @@ bool parse_machine_header(const uint8_t* bytes, size_t len, MachineHeader* h, st
 // 0 = accepted; 7 = malformed; 8 = rejected.  agg_leaves / n_agg: the leaves ([n][8] canonical words) of the aggregation
 // payload the proof must carry (n_agg = 0: it must carry none).
 // pub_tuples / n_pub: the public bus tuples the proof must close its buses with (n_pub = 0: it must carry none).  log: if
-// given, receives the leaf-check records of THIS proof's query phase (so that another proof can establish them).
+// given, receives the leaf-check records of THIS proof's transcript and query phase (so that another proof can establish
+// them) and the public tuples such a proof closes its buses with (log->leaf_index names this proof among the leaves checked
+// beside one run).  stub: `bytes` is a proof cut off in front of its query phase (machine_proof_body_words(logh, 0) body words):
+// everything up to the proof of work is checked - header, transcript, bus balance, the constraint identity at zeta - the
+// queries are not (a proof about them does that), and a log receives the public tuples only.
 int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, uint32_t num_queries, uint32_t pow_bits,
                          std::string* err, const uint32_t* agg_leaves = nullptr, size_t n_agg = 0, const uint32_t* agg_keys = nullptr,
-                         const uint32_t* pub_tuples = nullptr, size_t n_pub = 0, LeafCheckLog* log = nullptr);
+                         const uint32_t* pub_tuples = nullptr, size_t n_pub = 0, LeafCheckLog* log = nullptr, bool stub = false);
 // sponge digest of a list of public bus tuples (what stands for the list in the proof header and the transcript)
 void machine_pub_digest(const uint32_t* pub_tuples, size_t n_pub, uint32_t digest[8]);
 // The aggregation payload's public part and the heap of digests the Poseidon2 chip's rows are expanded from:
