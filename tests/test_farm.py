@@ -85,6 +85,15 @@ class _OracleBackedClient:
     def add_verified_leaf(self, stdin, leaf, leaf_vk):
         return self.host.add_verified_leaf(stdin, leaf, leaf_vk)
 
+    def add_verified_node(self, stdin, node, node_vk, statement):
+        return self.host.add_verified_node(stdin, node, node_vk, statement)
+
+    def clear_verified_leaves(self, stdin):
+        return self.host.clear_verified_leaves(stdin)
+
+    def last_error(self):
+        return self.host.last_error()
+
     def verify_with_leaves(self, proof, vk, leaves, leaf_vks):
         return self.host.verify_with_leaves(proof, vk, leaves, leaf_vks)
 
@@ -194,3 +203,68 @@ def test_tree_level_of_leaf_checks(zk, fx, oracle):
         client.verify_with_leaves(nodes[0], vk, [leaves[2], leaves[3]], [vk, vk])
     with pytest.raises(zk.VerificationError):
         farm.verify_tree_level(client, vk, vk, leaves[::-1], nodes, 2)
+
+
+def _tree_worker(rank, world, port, out_dir):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    import torch.distributed as dist
+    import oracle
+    zk = importlib.import_module("zk-state-proofs_amd")
+    fx = importlib.import_module("zk-state-proofs_amd.fixtures")
+    farm = importlib.import_module("zk-state-proofs_amd.farm")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "3"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    client = _OracleBackedClient(zk, oracle, 3, 3)
+    pk, vk = client.setup(zk.merkle_elf())
+    # the leaves of the tree: proven by the farm (block-cyclic), all-gathered like any level of the tree
+    stdins = []
+    for i in range(4):
+        s = zk.SP1Stdin()
+        s.write((fx.acct_fixture(1, seed=500) if i % 2 == 0 else fx.slot_fixture(i)).to_borsh())
+        stdins.append(s)
+    mine, proofs, status = farm.prove_sharded(client, pk, stdins, rank, world)
+    assert status == [0] * len(mine)
+    leaves = [zk.SP1ProofWithPublicValues.from_bytes(b) for b in farm._gather_objects([p.to_bytes() for p in proofs], 4, rank, world)]
+
+    def make_stdin(depth, k):
+        s = zk.SP1Stdin()
+        s.write(fx.acct_fixture(1, seed=600 + 10 * depth + k).to_borsh())
+        return s
+
+    levels, statements = farm.prove_tree(client, client.host, pk, vk, leaves, make_stdin, 2, rank, world)
+    assert [len(l) for l in levels] == [4, 2, 1] and statements[0] == [None] * 4
+    root_proof = levels[-1][0]
+    client.host.verify_tree(root_proof, vk, farm.tree_of_stubs(levels, 2))
+    with open(os.path.join(out_dir, f"root_{rank}.bin"), "wb") as f:
+        f.write(root_proof.to_bytes())
+    if rank == 0:
+        stubs = farm.tree_of_stubs(levels, 2)
+        read = sum(len(p.to_bytes()) for p, kids in stubs) + sum(len(c.to_bytes()) for _, kids in stubs for c, _ in kids)
+        full = sum(len(p.to_bytes()) for lv in levels[:-1] for p in lv)
+        np.save(os.path.join(out_dir, "sizes.npy"), np.array([read, full, len(root_proof.to_bytes())]))
+        # the root does not verify over another tree: two leaves swapped
+        bad = [(stubs[1][0], stubs[0][1]), (stubs[0][0], stubs[1][1])]
+        try:
+            client.host.verify_tree(root_proof, vk, bad)
+            raise AssertionError("a root verified over another tree")
+        except zk.VerificationError:
+            pass
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_recursion_tree_world2_gloo(tmp_path, zk):
+    """BASELINE config 5 in miniature on the CPU (the oracle stands in for the GPU): two gloo ranks prove four leaves, then the
+    two nodes of arity two (one per rank), all-gather them with their statements, and the root over the two NODES (a node is a
+    valid leaf: stage 2b); every rank holds the same root, which verifies from the stubs of the six proofs below it."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_tree_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (open(tmp_path / f"root_{r}.bin", "rb").read() for r in range(2))
+    assert r0 == r1
+    read, full, root_len = (int(x) for x in np.load(tmp_path / "sizes.npy"))
+    assert read < full  # (3 queries here: at the full 100 the stubs are a twentieth of the proofs)

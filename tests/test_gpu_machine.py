@@ -338,11 +338,13 @@ def test_aggregate_1024_commitments(zk, fx, oracle):
 
 
 def test_leaf_check_matches_oracle(zk, fx, oracle):
-    """Row f4, stage 2a on the device: a proof that also establishes the query phase of ANOTHER proof - the leaf's openings as
-    rows of the Poseidon2 chip (sponges, path steps, injections: p2_trace_kernel, machine_quotient_kernel<poseidon2>, the
-    DIGEST and PAIR buses) and of the FRI fold chip (fold_trace_kernel, machine_quotient_kernel<fri-fold>) - byte-identical
-    to the oracle's, in one batch with a proof that has no payload; verified with the leaf, with the statement derived
-    from it, and not without."""
+    """Row f4, stage 2b on the device: a proof that also establishes the query phase of ANOTHER proof under the challenges that
+    proof's own transcript yields - the leaf's openings as rows of the Poseidon2 chip (sponges with their Horner sums, path
+    steps, injections: p2_trace_kernel, machine_quotient_kernel<poseidon2>, the DIGEST / PAIR / POS / ROOT / SEG buses), its
+    transcript as rows of the transcript chip (tr_trace_kernel), the canonical bits of every query's index word, the folding
+    chain and the reduced openings as rows of the query chip (qr_trace_kernel) - byte-identical to the oracle's, in one batch
+    with a proof that has no payload; verified with the leaf, with its stub, with the statement derived from it, and not
+    without."""
     nq, pw = 8, 6
     client = zk.ProverClient(device=0, num_queries=nq, pow_bits=pw, max_batch=2)
     pk, vk = client.setup(zk.merkle_elf())
@@ -362,14 +364,16 @@ def test_leaf_check_matches_oracle(zk, fx, oracle):
     assert len(traces[0]["leaf_p2_rows"]) > 4000 and len(traces[1]["leaf_p2_rows"]) == 0
     shape = zk.machine_cover_heights(handles)
     names = zk.MACHINE_CHIP_NAMES
-    assert shape[names.index("poseidon2")] == 13 and shape[names.index("fri-fold")] >= 7
+    assert shape[names.index("poseidon2")] == 13 and shape[names.index("query")] == 8 and shape[names.index("transcript")] >= 6
     bodies = client.machine_prove_resident(pk, handles)
     proofs = [handles[i].proof_from_body(pk, bodies[i], shape) for i in range(2)]
     for i in range(2):
         assert proofs[i].to_bytes() == oracle.machine_prove(dict(traces[i], shape=shape), num_queries=nq, pow_bits=pw), i
     host.verify(proofs[1], vk)
     host.verify_with_leaf(proofs[0], vk, leaf, vk)
+    host.verify_with_leaf(proofs[0], vk, leaf.stub(), vk)
     host.verify_public(proofs[0], vk, host.leaf_public(leaf, vk))
+    assert len(host.leaf_public(leaf, vk)) < 80  # (stage 2a: 356 at these parameters, 4 500 at the full ones)
     with pytest.raises(zk.VerificationError):
         host.verify(proofs[0], vk)
     # the drop-in call gives the same proof
@@ -398,7 +402,8 @@ def test_two_leaf_checks_match_oracle(zk, fx, oracle):
     for lf in leaves:
         client.add_verified_leaf(s, lf, vk)
     trace = client.machine_trace(pk, s)
-    assert sorted(set(int(q) for q in trace["leaf_fold_rows"][:, 1])) == list(range(2 * nq))
+    qr = trace["leaf_qr_rows"]
+    assert len(qr) == 2 * nq * 31 and sorted(set((int(l), int(q)) for l, q in qr[:, 3:5])) == [(l, q) for l in range(2) for q in range(nq)]
     proof = client.prove(pk, s).run()
     raw = proof.to_bytes()
     assert raw == oracle.machine_prove(dict(trace, shape=shape_of(zk, raw)), num_queries=nq, pow_bits=pw)
@@ -428,3 +433,44 @@ def test_rv32m_guest_matches_oracle(zk, oracle):
     zk.ProverClient(device=-1, num_queries=nq, pow_bits=pw).verify(proof, vk)
     hts = shape_of(zk, proof.to_bytes())
     assert hts[zk.MACHINE_CHIP_NAMES.index("divider")] == 7
+
+
+def test_two_level_tree_matches_oracle(zk, fx, oracle):
+    """A node is a valid leaf (stage 2b): two leaf proofs -> a node that checks both -> a root that checks the node (whose own
+    statement its header carries) and a third leaf.  Both inner proofs are the oracle's byte for byte; the root verifies from
+    STUBS of everything below it (no query phase of a lower proof is read), and not with the leaves of the node swapped."""
+    nq, pw = 8, 6
+    client = zk.ProverClient(device=0, num_queries=nq, pow_bits=pw, max_batch=2)
+    pk, vk = client.setup(zk.merkle_elf())
+    host = zk.ProverClient(device=-1, num_queries=nq, pow_bits=pw)
+
+    def stdin_of(m):
+        s = zk.SP1Stdin()
+        s.write(m.to_borsh())
+        return s
+
+    leaves = [client.prove(pk, stdin_of(m)).run() for m in (fx.acct_fixture(1, seed=70), fx.slot_fixture(1), fx.acct_fixture(2, seed=71))]
+    s = stdin_of(fx.acct_fixture(1, seed=72))
+    client.add_verified_leaf(s, leaves[0], vk)
+    client.add_verified_leaf(s, leaves[1], vk)
+    trace = client.machine_trace(pk, s)
+    node = client.prove(pk, s).run()
+    raw = node.to_bytes()
+    assert raw == oracle.machine_prove(dict(trace, shape=shape_of(zk, raw)), num_queries=nq, pow_bits=pw)
+    st_node = host.leaves_public(leaves[:2], [vk, vk])
+    host.verify_public(node, vk, st_node)
+    s = stdin_of(fx.acct_fixture(1, seed=73))
+    client.add_verified_node(s, node, vk, st_node)
+    client.add_verified_leaf(s, leaves[2], vk)
+    trace = client.machine_trace(pk, s)
+    root = client.prove(pk, s).run()
+    raw = root.to_bytes()
+    assert raw == oracle.machine_prove(dict(trace, shape=shape_of(zk, raw)), num_queries=nq, pow_bits=pw)
+    stubs = [p.stub() for p in leaves]
+    tree = [(node.stub(), [(stubs[0], []), (stubs[1], [])]), (stubs[2], [])]
+    host.verify_tree(root, vk, tree)
+    assert sum(len(p.to_bytes()) for p in stubs + [node.stub()]) < sum(len(p.to_bytes()) for p in leaves + [node]) // 2
+    with pytest.raises(zk.VerificationError):
+        host.verify_tree(root, vk, [(node.stub(), [(stubs[1], []), (stubs[0], [])]), (stubs[2], [])])
+    with pytest.raises(zk.VerificationError):
+        host.verify(root, vk)

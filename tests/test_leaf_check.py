@@ -1,12 +1,15 @@
-"""Leaf-proof check (stage 2a; reference stub circuits/sp1-merkle-proof-recursive/src/main.rs:3-5):
-a machine proof that also establishes that the QUERY PHASE of another machine proof verifies - every Merkle opening of its
-four commitment rounds (sponges over the opened rows, paths with their mixed-height injections), every FRI layer opening and
-the folding chain down to the final constant - as rows of the Poseidon2 chip and of the FRI fold chip, closed by public bus
-tuples that carry the leaf's roots, query positions, challenges and reduced openings.
+"""Leaf-proof check (stage 2b; reference stub circuits/sp1-merkle-proof-recursive/src/main.rs:3-5):
+a machine proof that also establishes that the QUERY PHASE of another machine proof verifies UNDER THE CHALLENGES THAT
+PROOF'S OWN TRANSCRIPT YIELDS - the transcript as rows of the transcript chip (its blocks are the statement), the canonical
+bits of every query's index word, every Merkle opening of the four commitment rounds (sponges over the opened rows with
+their Horner sums, paths with their mixed-height injections) against the roots the transcript absorbed, every FRI layer
+opening, the reduced openings and the folding chain down to the final constant as rows of the Poseidon2 and query chips.
 
 CPU tests: the records the host verifier logs are re-derived here from the leaf proof's bytes with the oracle's Poseidon2
-(an independent replay of the hash work); the oracle proves, the product's verifier accepts - with the leaf, or with the
-statement derived from it - and every tampering of an opened word, a path node, a pair or the statement is refused."""
+(an independent replay of the transcript, the hash work, the Horner sums, the reduced openings and the folds); the oracle
+proves, the product's verifier accepts - with the leaf, with its STUB (no query phase), or with the statement derived from it -
+and every tampering of an opened word, a path node, a pair, a challenge, a reduced opening or the statement is refused;
+a node is a valid leaf (a two-level tree verifies from stubs)."""
 import os
 
 import numpy as np
@@ -14,6 +17,62 @@ import pytest
 
 NQ, POW = 6, 5
 P = 2013265921
+GEN = 31
+# buses (air_machine.hpp)
+BUS_DIGEST, BUS_PAIR, BUS_POS, BUS_ROOT, BUS_SEG, BUS_TBLK, BUS_TSQ, BUS_FINAL, BUS_ZETA, BUS_AF, BUS_BETA, BUS_POW, BUS_QIDX, \
+    BUS_LEAFK, BUS_BCONST = 13, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28
+# query chip columns
+(QR_IS_REAL, QR_FIRST, QR_LAST, QR_LEAF, QR_QL, QR_J, QR_BIT, QR_ACC, QR_EQ, QR_F1, QR_F2, QR_F3, QR_CSR, QR_FL, QR_LAY, QR_K, QR_CS,
+ QR_POW, QR_LOW, QR_REV, QR_PR0, QR_CNT0, QR_KEYJ, QR_MJ, QR_MT, QR_P0A, QR_KEY0, QR_M0, QR_MT0, QR_HASRO, QR_HAS0, QR_OMI, QR_MU, QR_CSM,
+ QR_R, QR_R2, QR_YT, QR_YKI, QR_GI, QR_XINV, QR_WH) = range(41)
+QR_BETA, QR_LO, QR_HI, QR_E, QR_F, QR_RO, QR_H, QR_AF, QR_DL, QR_D2, QR_D3, QR_D4, QR_G2, QR_ZETA, QR_ZW, QR_D0, QR_D1, QR_B1, QR_B2 = \
+    41, 45, 49, 53, 57, 61, 65, 81, 85, 89, 93, 97, 101, 105, 109, 113, 117, 121, 125
+K_NODE, K_SZ, K_SC, K_PL, K_PR, K_J = 1, 2, 3, 4, 5, 6
+F_NEW, F_SND, F_FRI, F_RE, F_SE = 16, 32, 64, 128, 256
+
+
+def inv(v):
+    return pow(int(v) % P, P - 2, P)
+
+
+def e_mul(a, b):
+    r = [0] * 7
+    for i in range(4):
+        for j in range(4):
+            r[i + j] += int(a[i]) * int(b[j])
+    return [(r[i] + 11 * (r[i + 4] if i < 3 else 0)) % P for i in range(4)]
+
+
+def e_add(a, b):
+    return [(int(x) + int(y)) % P for x, y in zip(a, b)]
+
+
+def e_sub(a, b):
+    return [(int(x) - int(y)) % P for x, y in zip(a, b)]
+
+
+def e_scale(a, k):
+    return [int(x) * int(k) % P for x in a]
+
+
+def e_inv(a):
+    # by the norm: solve a * x = 1 over the basis (a 4 x 4 linear system mod p)
+    m = [[0] * 5 for _ in range(4)]
+    for j in range(4):
+        col = e_mul(a, [1 if i == j else 0 for i in range(4)])
+        for i in range(4):
+            m[i][j] = col[i]
+    m[0][4] = 1
+    for c in range(4):
+        piv = next(r for r in range(c, 4) if m[r][c] % P)
+        m[c], m[piv] = m[piv], m[c]
+        iv = inv(m[c][c])
+        m[c] = [x * iv % P for x in m[c]]
+        for r in range(4):
+            if r != c and m[r][c]:
+                f = m[r][c]
+                m[r] = [(x - f * y) % P for x, y in zip(m[r], m[c])]
+    return [m[i][4] for i in range(4)]
 
 
 @pytest.fixture(scope="module")
@@ -43,14 +102,23 @@ def forced(oracle, t):
 
 
 def test_outer_proof_verifies_with_its_leaf(zk, setup):
-    client, pk, vk, leaf, _, t, outer = setup
+    client, pk, vk, leaf, leaf_bytes, t, outer = setup
     proof = zk.SP1ProofWithPublicValues.from_bytes(outer)
     n_pub, digest = proof.public_tuples
     assert n_pub == len(t["leaf_pub_tuples"]) > 0 and any(digest)
     client.verify_with_leaf(proof, vk, leaf, vk)
-    # the statement alone (what a verifier that never sees the leaf's openings is given) does as well
+    # the leaf's STUB does as well: the proof without its query phase (what verifying a tree of such proofs reads of a leaf)
+    stub = leaf.stub()
+    assert len(stub.to_bytes()) < len(leaf_bytes) and leaf_bytes.startswith(stub.to_bytes())
+    client.verify_with_leaf(proof, vk, stub, vk)
+    with pytest.raises(zk.VerificationError):
+        client.verify(stub, vk)  # a stub is not a proof
+    with pytest.raises(zk.ZkspError):
+        client.set_verified_leaf(zk.SP1Stdin(), stub, vk)  # ... and has no query phase to prove
+    # the statement alone does as well; it is a few dozen tuples (stage 2a: one per opening, fold and reduced opening)
     tuples = client.leaf_public(leaf, vk)
-    assert np.array_equal(tuples, t["leaf_pub_tuples"])
+    assert np.array_equal(tuples, t["leaf_pub_tuples"]) and np.array_equal(tuples, client.leaf_public(stub, vk))
+    assert len(tuples) < 80 and set(int(b) for b in tuples[:, 0]) == {BUS_TBLK, BUS_TSQ, BUS_ROOT, BUS_LEAFK, BUS_BCONST, BUS_POW}
     client.verify_public(proof, vk, tuples)
     # a plain verify cannot vouch for a statement it was not given
     with pytest.raises(zk.VerificationError) as ei:
@@ -61,8 +129,9 @@ def test_outer_proof_verifies_with_its_leaf(zk, setup):
 
 
 def test_statement_is_bound(zk, setup):
-    """Any other statement - another root, position key, challenge, reduced opening, final constant, one tuple less - is
-    not what the proof closes its buses with: the header's digest (absorbed before any challenge) differs."""
+    """Any other statement - another header word, root, cumulative sum, witness, constant, one tuple less - is not what the proof
+    closes its buses with: the header's digest (absorbed before any challenge) differs; and with the digest patched into the
+    header to match, the buses do not balance.  A tuple on a bus without a public end is refused outright."""
     client, pk, vk, leaf, _, t, outer = setup
     proof = zk.SP1ProofWithPublicValues.from_bytes(outer)
     tuples = t["leaf_pub_tuples"]
@@ -75,40 +144,92 @@ def test_statement_is_bound(zk, setup):
             client.verify_public(proof, vk, bad)
     with pytest.raises(zk.VerificationError):
         client.verify_public(proof, vk, tuples[:-1])
-    # ... and with the digest patched into the header to match, the buses do not balance
-    bad = tuples.copy()
-    k = int(np.nonzero(bad[:, 0] == 13)[0][3])  # a DIGEST tuple: the root an opening must reach
-    bad[k, 4 + 5] = (int(bad[k, 4 + 5]) + 1) % P
-    raw = bytearray(outer)
-    hw = zk.MACHINE_HEADER_WORDS
     import importlib
     orc = importlib.import_module("oracle")
-    dg = orc.hash_elems(bad.reshape(-1))
-    raw[4 * (hw - 8):4 * hw] = np.asarray(dg, np.uint32).tobytes()
-    with pytest.raises(zk.VerificationError):
-        client.verify_public(zk.SP1ProofWithPublicValues.from_bytes(bytes(raw)), vk, bad)
+    hw = zk.MACHINE_HEADER_WORDS
+    for which in ("root", "bconst", "bus"):
+        bad = tuples.copy()
+        if which == "root":
+            k = int(np.nonzero((bad[:, 0] == BUS_TBLK) & (bad[:, 6] & 1 == 1))[0][1])  # a block that is a commitment root
+            bad[k, 4 + 6] = (int(bad[k, 4 + 6]) + 1) % P
+        elif which == "bconst":
+            k = int(np.nonzero(bad[:, 0] == BUS_BCONST)[0][0])
+            bad[k, 4 + 5] = (int(bad[k, 4 + 5]) + 1) % P
+        else:
+            bad[0, 0] = 1  # the memory bus has no public end
+        raw = bytearray(outer)
+        raw[4 * (hw - 8):4 * hw] = np.asarray(orc.hash_elems(bad.reshape(-1)), np.uint32).tobytes()
+        with pytest.raises(zk.ZkspError):
+            client.verify_public(zk.SP1ProofWithPublicValues.from_bytes(bytes(raw)), vk, bad)
 
 
 def test_records_replay_from_the_leaf_proof(zk, oracle, setup):
-    """The Poseidon2-chip records re-derived independently: every row's input state follows from the rows before it by the
-    oracle's permutation (sponges chain their capacity, path steps and injections take the running digest), every run ends
-    in the root its DIGEST tuple names, every absorbed word and every sibling is a word of the leaf proof's query section,
-    and the fold records chain to the final constant."""
+    """The records re-derived independently.  Transcript chip: every duplex follows from the one before by the oracle's
+    permutation (capacity carried, a squeeze takes the whole state), the blocks are the statement's and contain the leaf
+    proof's roots, final constant and witness, and the outputs are the challenges the other chips use.  Poseidon2 chip: every
+    row's input state follows from the rows before it, every run ends in the root the transcript absorbed (or the key's), the
+    Horner sums are Horner's rule in alpha_f over the absorbed words.  Query chip: the bits are the index word's, the positions
+    of the openings follow from them, the reduced openings follow from the Horner sums, the folds chain to the final
+    constant."""
     client, pk, vk, leaf, leaf_bytes, t, _ = setup
-    rows, folds, tuples = t["leaf_p2_rows"], t["leaf_fold_rows"], t["leaf_pub_tuples"]
-    K_NODE, K_SZ, K_SC, K_PL, K_PR, K_J = 1, 2, 3, 4, 5, 6
-    roots = {int(x[4]): x for x in tuples if x[0] == 13}  # tag -> DIGEST tuple
-    parked = {}
-    prev_out, prev = None, None
+    rows, qr, tr, tuples = t["leaf_p2_rows"], t["leaf_qr_rows"], t["leaf_tr_rows"], t["leaf_pub_tuples"]
+    words = np.frombuffer(leaf_bytes, np.uint32)
+    wset = set(words.tolist()) | {0}
+    # ---- transcript ----
+    blk = {int(x[5]): x for x in tuples if x[0] == BUS_TBLK}
+    sqz = {int(x[5]): x for x in tuples if x[0] == BUS_TSQ}
+    roots, betas, qwords = {}, {}, {}
+    prev_out = None
+    zeta = af = delta = final = pow_word = None
+    for i, r in enumerate(tr):
+        flags, leafi, step = int(r[0]), int(r[1]), int(r[2])
+        st = [int(v) for v in r[10:26]]
+        assert leafi == 0 and step == i and bool(flags & (1 << 16)) == (i == 0)
+        if flags & (1 << 17):  # absorbs a block: the statement's words, over the capacity carried from the duplex before
+            assert st[8:] == ([0] * 8 if i == 0 else prev_out[8:])
+            assert [int(v) for v in blk[i][4:16]] == [0, i, flags & 0xffff, int(r[3])] + st[:8]
+        else:
+            assert st == prev_out and [int(v) for v in sqz[i][4:8]] == [0, i, flags & 0xffff, int(r[4])]
+        out = [int(v) for v in oracle.poseidon2_permute(st)]
+        if flags & 1:
+            roots[int(r[3])] = st[:8]
+            assert set(st[:8]) <= wset
+        if flags & 2:
+            zeta = out[7:3:-1]
+        if flags & 4:
+            af, delta = out[7:3:-1], out[3::-1]
+        if flags & 8:
+            betas[int(r[3]) - 4] = out[7:3:-1]
+        if flags & 16:
+            final = st[:4]
+            assert set(st[:5]) <= wset and st[5:8] == [0, 0, 0]  # final constant, witness, zero fill
+        if flags & 32:
+            pow_word = out[7]
+        if flags & 64:
+            for j in range(8):
+                if flags & (128 << j):
+                    qwords[int(r[4]) + j] = out[7 - j]
+        prev_out = out
+    assert len(blk) + len(sqz) == len(tr) and sorted(qwords) == list(range(NQ)) and pow_word % (1 << POW) == 0
+    assert [int(v) for v in next(x for x in tuples if x[0] == BUS_POW)[4:6]] == [0, pow_word]
+    lm = max(betas) + 1
+    prep = next(x for x in tuples if x[0] == BUS_ROOT)
+    roots[0] = [int(v) for v in prep[5:13]]
+    assert sorted(roots) == list(range(4 + lm)) and int(prep[2]) == NQ
+    # ---- Poseidon2 chip ----
+    parked, sums = {}, {}
+    prev_out, prev, so = None, None, None
     ends = 0
+    a8 = e_mul(e_mul(e_mul(af, af), e_mul(af, af)), e_mul(e_mul(af, af), e_mul(af, af)))
     for r in rows:
         flags, tag, key, mask = (int(v) for v in r[:4])
-        kind, new, snd = flags & 15, bool(flags & 16), bool(flags & 32)
-        st = [int(v) for v in r[4:]]
+        kind, new, snd, fri, re_, se = flags & 15, bool(flags & F_NEW), bool(flags & F_SND), bool(flags & F_FRI), bool(flags & F_RE), bool(flags & F_SE)
+        st = [int(v) for v in r[4:20]]
+        alpha = [int(v) for v in r[25:29]]
         if kind == K_SZ:
             assert st[8:] == [0] * 8 and (not new or (key, mask) == (1, 0))
         elif kind == K_SC:
-            assert prev[0] in (K_SZ, K_SC) and st[8:] == prev_out[8:] and (tag, key, mask, new) == prev[1:]
+            assert prev[0] in (K_SZ, K_SC) and st[8:] == prev_out[8:] and (tag, key, mask, new) == prev[1:5]
         elif kind in (K_PL, K_PR):
             side = 8 if kind == K_PR else 0
             assert st[side:side + 8] == prev_out[:8] and tag == prev[1]
@@ -119,59 +240,110 @@ def test_records_replay_from_the_leaf_proof(zk, oracle, setup):
             assert parked.pop((tag, key, mask)) == st[8:]
         else:
             raise AssertionError(kind)
+        if kind in (K_SZ, K_SC):
+            # Horner's rule over the block, then over the blocks (a FRI pair's hash has alpha_f = 0: the last word remains)
+            assert alpha == ([0] * 4 if (tag - 1) % 64 >= 4 else af)
+            bv = [0, 0, 0, 0]
+            for i in range(8):
+                bv = e_add(e_mul(bv, alpha), [st[i], 0, 0, 0])
+            so = bv if kind == K_SZ else e_add(e_mul(so, a8 if any(alpha) else [0] * 4), bv)
+            assert [int(v) for v in r[21:25]] == so
+            assert not re_ and (not se or any(alpha))
+            if se:
+                sums[(tag, key, mask)] = so
         out = [int(v) for v in oracle.poseidon2_permute(st)]
         if snd:
-            if kind in (K_SZ, K_SC):
-                parked[(tag, key, mask)] = out[:8]  # the hash of an injected row, for the injection with these labels
-            else:
-                d = roots.pop(tag)
-                assert [int(v) for v in d[4:16]] == [tag, 0, key, mask] + out[:8]
-                ends += 1
+            assert kind in (K_SZ, K_SC)
+            parked[(tag, key, mask)] = out[:8]  # the hash of an injected row, for the injection with these labels
+        if re_:
+            assert kind in (K_PL, K_PR, K_J) and int(r[20]) == (tag - 1) % 64 and out[:8] == roots[int(r[20])]
+            ends += 1
         prev_out, prev = out, (kind, tag, key, mask, new)
-    assert not parked and not roots and ends == NQ * (4 + max(int(f[2]) for f in folds) + 1)
+    assert not parked and ends == NQ * (4 + lm)
     # the words: everything absorbed or used as a sibling comes out of the leaf proof's bytes
-    words = set(np.frombuffer(leaf_bytes, np.uint32).tolist()) | {0}
-    assert set(rows[:, 4:12][(rows[:, 0] & 15 <= K_SC) & (rows[:, 0] & 15 >= K_SZ)].reshape(-1).tolist()) <= words
-    sib_l = rows[(rows[:, 0] & 15) == K_PR][:, 4:12]
-    sib_r = rows[(rows[:, 0] & 15) == K_PL][:, 12:20]
-    assert set(sib_l.reshape(-1).tolist()) <= words and set(sib_r.reshape(-1).tolist()) <= words
-    # the folds: E chains to F + RO, the last F (+ RO) is the final constant
-    inv = lambda v: pow(int(v), P - 2, P)
+    kinds = rows[:, 0] & 15
+    assert set(rows[:, 4:12][(kinds <= K_SC) & (kinds >= K_SZ)].reshape(-1).tolist()) <= wset
+    assert set(rows[kinds == K_PR][:, 4:12].reshape(-1).tolist()) <= wset and set(rows[kinds == K_PL][:, 12:20].reshape(-1).tolist()) <= wset
+    # ---- query chip ----
+    bconst = {int(x[5]): x for x in tuples if x[0] == BUS_BCONST}
+    omega = pow(GEN, (P - 1) >> (lm + 1), P)
+    assert [int(v) for v in next(x for x in tuples if x[0] == BUS_LEAFK)[4:7]] == [0, lm - 1, inv(omega)]
+    d2 = e_mul(delta, delta)
+    d3, d4 = e_mul(d2, delta), e_mul(d2, d2)
+    assert len(qr) == 31 * NQ
+    used_sums = set()
+    for q in range(NQ):
+        w = qwords[q]
+        assert w < P
+        idx = w & ((2 << lm) - 1)
+        cs, m = idx >> lm, idx & ((1 << lm) - 1)
+        expect = None
+        for j in range(30, -1, -1):
+            r = [int(v) for v in qr[31 * q + 30 - j]]
+            assert r[QR_IS_REAL] == 1 and r[QR_LEAF] == 0 and r[QR_QL] == q and r[QR_J] == j and r[QR_BIT] == (w >> j) & 1 and r[QR_ACC] == w >> j
+            assert (r[QR_FIRST], r[QR_LAST], r[QR_CSR], r[QR_LAY], r[QR_FL]) == (j == 30, j == 0, j == lm, j < lm, j == lm - 1)
+            assert r[QR_POW] == 1 << j and r[QR_LOW] == w % (1 << j)
+            if j >= lm:
+                continue
+            k = lm - 1 - j
+            assert r[QR_K] == k and r[QR_CS] == cs and r[QR_BETA:QR_BETA + 4] == betas[k]
+            # the layer's point: x = g^(2^k) * y^(+-1) ... checked through its inverse
+            hk = 1 << (lm - k)
+            mlo = m % (hk // 2)
+            xk = pow(GEN, 1 << k, P) * (pow(GEN, (P - 1) // (2 * hk), P) if cs else 1) * pow(pow(GEN, (P - 1) // hk, P), mlo, P) % P
+            assert r[QR_XINV] == inv(xk)
+            lo, hi = r[QR_LO:QR_LO + 4], r[QR_HI:QR_HI + 4]
+            e = hi if r[QR_BIT] else lo
+            assert r[QR_E:QR_E + 4] == e and (k == 0 or e == expect)
+            half = inv(2)
+            f = e_add(e_scale(e_add(lo, hi), half), e_mul(betas[k], e_scale(e_sub(lo, hi), half * inv(xk))))
+            assert r[QR_F:QR_F + 4] == f
+            # the reduced opening of the height that joins here
+            lh = lm - k
+            present = k in bconst
+            assert r[QR_HASRO] == int(present)
+            if present:
+                bc = [int(v) for v in bconst[k][4:16]]
+                assert bc[3] == pow(GEN, (P - 1) >> lh, P) and r[QR_B1:QR_B1 + 4] == bc[4:8] and r[QR_B2:QR_B2 + 4] == bc[8:12]
+                hs = []
+                for rr in range(4):
+                    key = (r[QR_KEY0], r[QR_M0]) if rr == 0 else (r[QR_KEYJ], r[QR_MJ])
+                    tg = 1 + 64 * q + rr
+                    s_ = sums.get((tg,) + key, [0, 0, 0, 0]) if (rr or bc[2]) else [0, 0, 0, 0]
+                    if (rr or bc[2]):
+                        used_sums.add((tg,) + key)
+                    assert r[QR_H + 4 * rr:QR_H + 4 * rr + 4] == s_
+                    hs.append(s_)
+                x = GEN * (pow(GEN, (P - 1) >> (lh + 1), P) if cs else 1) * pow(pow(GEN, (P - 1) >> lh, P), m % (1 << lh), P) % P
+                d0 = e_inv(e_sub([x, 0, 0, 0], zeta))
+                d1 = e_inv(e_sub([x, 0, 0, 0], e_scale(zeta, bc[3])))
+                s1 = e_add(e_add(hs[0], e_mul(delta, hs[1])), e_add(e_mul(d2, hs[2]), e_mul(d3, hs[3])))
+                s2 = e_mul(d4, e_add(hs[1], e_mul(delta, hs[2])))
+                ro = e_add(e_mul(d0, e_sub(s1, bc[4:8])), e_mul(d1, e_sub(s2, bc[8:12])))
+                assert r[QR_RO:QR_RO + 4] == ro
+                if k == 0:
+                    assert e == ro
+            else:
+                assert r[QR_RO:QR_RO + 4] == [0, 0, 0, 0]
+            expect = f  # ... plus the next row's reduced opening
+            if j:
+                nxt = [int(v) for v in qr[31 * q + 30 - j + 1]]
+                expect = e_add(f, nxt[QR_RO:QR_RO + 4])
+        assert expect == final
+    assert used_sums == set(sums)  # every Horner sum the Poseidon2 chip hands over is one the query chip uses
 
-    def e_mul(a, b):
-        r = [0] * 7
-        for i in range(4):
-            for j in range(4):
-                r[i + j] += a[i] * b[j]
-        return [(r[i] + 11 * (r[i + 4] if i < 3 else 0)) % P for i in range(4)]
 
-    fin = {int(x[4]): [int(v) for v in x[6:10]] for x in tuples if x[0] == 18}
-    ro0 = {int(x[4]): [int(v) for v in x[6:10]] for x in tuples if x[0] == 17 and x[5] == 0}
-    expect = None
-    for f in folds:
-        flags, q, k, xinv = (int(v) for v in f[:4])
-        beta, lo, hi, ro = ([int(v) for v in f[4 + 4 * i:8 + 4 * i]] for i in range(4))
-        e = hi if flags & 4 else lo
-        if flags & 1:
-            assert k == 0 and e == ro0[q]
-        else:
-            assert e == expect
-        half = inv(2)
-        d = [(lo[i] - hi[i]) * half * xinv % P for i in range(4)]
-        bd = e_mul(beta, d)
-        expect = [((lo[i] + hi[i]) * half + bd[i] + ro[i]) % P for i in range(4)]
-        if flags & 2:
-            assert expect == fin[q]
-
-
-@pytest.mark.parametrize("what", ["absorbed word", "sibling", "pair", "fold bit"])
-def test_tampered_openings_are_refused(zk, oracle, setup, what):
-    """Flip an opened word, a path node or a FRI pair of the leaf's query phase in the records: the honest prover's buses
-    do not balance (it refuses), and the proof a cheating prover would send is rejected by the verifier that holds the
-    leaf's statement."""
+@pytest.mark.parametrize("what", ["absorbed word", "sibling", "pair", "index bit", "beta", "zeta", "reduced opening", "horner sum",
+                                  "transcript root", "squeeze"])
+def test_tampered_records_are_refused(zk, oracle, setup, what):
+    """Change an opened word, a path node or a FRI pair of the leaf's query phase, a bit of a query's index word, a challenge
+    (a FRI beta, zeta), a reduced opening, a Horner sum, a root the transcript absorbed or a squeezed state in the records: the
+    honest prover's constraints or buses fail (it refuses), and the proof a cheating prover would send is rejected by the
+    verifier that holds the leaf's statement."""
     client, pk, vk, leaf, _, t, _ = setup
-    rows, folds = t["leaf_p2_rows"].copy(), t["leaf_fold_rows"].copy()
+    rows, qr, tr = t["leaf_p2_rows"].copy(), t["leaf_qr_rows"].copy(), t["leaf_tr_rows"].copy()
     kind = rows[:, 0] & 15
+    lay = np.nonzero(qr[:, QR_LAY] == 1)[0]
     if what == "absorbed word":
         k = int(np.nonzero((kind == 3) & ((rows[:, 0] & 64) == 0))[0][5])  # a continuing sponge row: an opened row's words
         rows[k, 4 + 3] = (int(rows[k, 4 + 3]) + 1) % P
@@ -179,11 +351,28 @@ def test_tampered_openings_are_refused(zk, oracle, setup, what):
         k = int(np.nonzero(kind == 4)[0][7])  # a path step with the running digest on the left: the sibling on the right
         rows[k, 12 + 2] = (int(rows[k, 12 + 2]) + 1) % P
     elif what == "pair":
-        k = int(np.nonzero((rows[:, 0] & 64) != 0)[0][3])  # a FRI leaf: the fold chip holds the untampered pair
+        k = int(np.nonzero((rows[:, 0] & 64) != 0)[0][3])  # a FRI leaf: the query chip holds the untampered pair
         rows[k, 4 + 1] = (int(rows[k, 4 + 1]) + 1) % P
+    elif what == "index bit":
+        qr[int(lay[2]), QR_BIT] ^= 1
+    elif what == "beta":
+        qr[int(lay[3]), QR_BETA + 1] = (int(qr[int(lay[3]), QR_BETA + 1]) + 1) % P
+    elif what == "zeta":
+        k = int(np.nonzero(qr[:, QR_HASRO] == 1)[0][1])
+        qr[k, QR_ZETA] = (int(qr[k, QR_ZETA]) + 1) % P
+    elif what == "reduced opening":
+        k = int(np.nonzero(qr[:, QR_HASRO] == 1)[0][2])
+        qr[k, QR_RO + 2] = (int(qr[k, QR_RO + 2]) + 1) % P
+    elif what == "horner sum":
+        k = int(np.nonzero((rows[:, 0] & F_SE) != 0)[0][4])
+        rows[k, 21] = (int(rows[k, 21]) + 1) % P
+    elif what == "transcript root":
+        k = int(np.nonzero((tr[:, 0] & 1) != 0)[0][1])  # the permutation trace's root: a block of the transcript
+        tr[k, 10 + 4] = (int(tr[k, 10 + 4]) + 1) % P
     else:
-        folds[2, 0] ^= 4
-    t2 = dict(t, leaf_p2_rows=rows, leaf_fold_rows=folds)
+        k = int(np.nonzero((tr[:, 0] & 64) != 0)[0][0])  # the first squeeze of query index words
+        tr[k, 10 + 9] = (int(tr[k, 10 + 9]) + 1) % P
+    t2 = dict(t, leaf_p2_rows=rows, leaf_qr_rows=qr, leaf_tr_rows=tr)
     with pytest.raises(RuntimeError):
         oracle.machine_prove(t2, num_queries=NQ, pow_bits=POW)
     bad = zk.SP1ProofWithPublicValues.from_bytes(forced(oracle, t2))
@@ -193,11 +382,12 @@ def test_tampered_openings_are_refused(zk, oracle, setup, what):
 
 def test_a_bad_leaf_has_no_check(zk, fx, setup):
     """set_verified_leaf verifies the leaf first: flipping any opened word or path node of the leaf proof leaves the honest
-    prover with nothing to prove."""
+    prover with nothing to prove; flipping a word of the stub's part leaves the verifier with no statement."""
     client, pk, vk, leaf, leaf_bytes, _, _ = setup
     rng = np.random.default_rng(11)
     body0 = 4 * (zk.MACHINE_HEADER_WORDS + (len(leaf.public_values) + 3) // 4)
-    for pos in rng.integers(body0 + 4 * 3000, len(leaf_bytes), 6):
+    stub_len = len(leaf.stub().to_bytes())
+    for pos in rng.integers(stub_len, len(leaf_bytes), 6):
         raw = bytearray(leaf_bytes)
         raw[int(pos) & ~3] ^= 1
         bad = zk.SP1ProofWithPublicValues.from_bytes(bytes(raw))
@@ -205,6 +395,12 @@ def test_a_bad_leaf_has_no_check(zk, fx, setup):
         s.write(fx.acct_fixture(1).to_borsh())
         with pytest.raises(zk.VerificationError):
             client.set_verified_leaf(s, bad, vk)
+        client.leaf_public(bad, vk)  # (the statement does not depend on the query phase: the proof about it does)
+    for pos in rng.integers(body0, stub_len, 6):
+        raw = bytearray(leaf_bytes)
+        raw[int(pos) & ~3] ^= 1
+        with pytest.raises(zk.VerificationError):
+            client.leaf_public(zk.SP1ProofWithPublicValues.from_bytes(bytes(raw)).stub(), vk)
 
 
 def test_check_of_another_leaf_is_refused(zk, fx, oracle, setup):
@@ -219,25 +415,19 @@ def test_check_of_another_leaf_is_refused(zk, fx, oracle, setup):
         client.verify_with_leaf(zk.SP1ProofWithPublicValues.from_bytes(outer), vk, other, vk)
 
 
-def _run_rows(rows, tag):
-    """Indices of the rows of the run tagged `tag`: its injected-row sponges first (not NEW), then the run proper."""
-    idx = np.nonzero(rows[:, 1] == tag)[0]
-    return idx
-
-
 def test_structural_forgeries_are_refused(zk, oracle, setup):
     """Forgeries that keep every HASH consistent and change only what kind of step a row claims to be.
     (1) An injection passed off as a path step with the injected hash as a free sibling - so that the shorter matrices'
     opened row need not be shown: the same permutation, so every later digest is unchanged and the root is reached, but the
-    position key gains a level and the injection mask loses one - the run's last tuple is not the one the verifier
-    consumes (and the orphaned sponge's tuple is consumed by nobody).
-    (2) The sponge rows of an injected matrix row dropped altogether: the injection row finds nothing to consume.
-    (3) A run that ends one level early and claims the root there: its key is too short."""
+    position key gains a level and the injection mask loses one - the run's POS tuple is not the one the query chip
+    consumes (and the orphaned sponge's tuples are consumed by nobody).
+    (2) The sponge rows of an injected matrix row dropped altogether: the injection row finds nothing to consume, the query
+    chip no Horner sum.
+    (3) A run that ends one level early and claims the root there: its key is too short (and its digest is not the root)."""
     client, pk, vk, leaf, _, t, _ = setup
-    K_PL, K_J = 4, 6
     base = t["leaf_p2_rows"]
-    tag = 2  # query 0, main round: a mixed-height opening
-    idx = _run_rows(base, tag)
+    tag = 2  # leaf 0, query 0, main round: a mixed-height opening
+    idx = np.nonzero(base[:, 1] == tag)[0]
     kinds = base[idx, 0] & 15
 
     def refused(rows):
@@ -271,7 +461,8 @@ def test_structural_forgeries_are_refused(zk, oracle, setup):
     # (3) the run stops one step early: that row claims to be the end
     last = int(run[-1])
     rows = np.delete(base, [last], axis=0)
-    rows[last - 1, 0] |= 32
+    rows[last - 1, 0] |= F_RE
+    rows[last - 1, 20] = base[last, 20]
     refused(rows)
     assert (kinds == K_J).sum() >= 2  # (the opening does have several injections)
 
@@ -297,26 +488,29 @@ def test_two_leaves_are_checked_by_one_proof(zk, two_leaves, setup):
     client, pk, vk, leaf_a, leaf_b, t, outer = two_leaves
     proof = zk.SP1ProofWithPublicValues.from_bytes(outer)
     one = setup[5]
-    # the second leaf's rows follow the first one's; its queries are numbered from NQ on (tags 1 + 64 q + r, fold rows, tuples)
+    # the second leaf's rows follow the first one's; its tags, root ids, query rows and tuples carry the leaf index 1
     n1 = len(one["leaf_p2_rows"])
     assert np.array_equal(t["leaf_p2_rows"][:n1], one["leaf_p2_rows"]) and len(t["leaf_p2_rows"]) > n1
-    assert np.array_equal(t["leaf_fold_rows"][:len(one["leaf_fold_rows"])], one["leaf_fold_rows"])
-    second = t["leaf_fold_rows"][len(one["leaf_fold_rows"]):]
-    assert sorted(set(int(q) for q in second[:, 1])) == list(range(NQ, 2 * NQ))
+    assert np.array_equal(t["leaf_qr_rows"][:len(one["leaf_qr_rows"])], one["leaf_qr_rows"])
+    assert np.array_equal(t["leaf_tr_rows"][:len(one["leaf_tr_rows"])], one["leaf_tr_rows"])
+    second = t["leaf_qr_rows"][len(one["leaf_qr_rows"]):]
+    assert set(int(x) for x in second[:, QR_LEAF]) == {1} and sorted(set(int(x) for x in second[:, QR_QL])) == list(range(NQ))
     tags = t["leaf_p2_rows"][n1:, 1]
-    assert int(tags.min()) >= 1 + 64 * NQ and len(set(int(x) for x in t["leaf_p2_rows"][:n1, 1]) & set(int(x) for x in tags)) == 0
+    assert int(tags.min()) >= 1 + (1 << 18) and int(t["leaf_p2_rows"][:n1, 1].max()) < 1 << 18
+    assert set(int(x) for x in t["leaf_tr_rows"][len(one["leaf_tr_rows"]):, 1]) == {1}
     # the statement: the two leaves' tuples one after the other, in the order they were added
     tuples = client.leaves_public([leaf_a, leaf_b], [vk, vk])
     assert np.array_equal(tuples, t["leaf_pub_tuples"])
     assert np.array_equal(tuples[:len(one["leaf_pub_tuples"])], client.leaf_public(leaf_a, vk))
     assert proof.public_tuples[0] == len(tuples)
     client.verify_with_leaves(proof, vk, [leaf_a, leaf_b], [vk, vk])
+    client.verify_with_leaves(proof, vk, [leaf_a.stub(), leaf_b.stub()], [vk, vk])
     client.verify_public(proof, vk, tuples)
-    # the chips grew with the work: twice the permutations, twice the folds
+    # the chips grew with the work: twice the permutations, twice the query rows
     hts = [int.from_bytes(outer[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
     h1 = [int.from_bytes(setup[6][8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
-    p2 = zk.MACHINE_CHIP_NAMES.index("poseidon2")
-    assert hts[p2] >= h1[p2] and (1 << hts[p2]) >= len(t["leaf_p2_rows"])
+    p2, qc = zk.MACHINE_CHIP_NAMES.index("poseidon2"), zk.MACHINE_CHIP_NAMES.index("query")
+    assert hts[p2] >= h1[p2] and (1 << hts[p2]) >= len(t["leaf_p2_rows"]) and hts[qc] == h1[qc] + 1
 
 
 def test_other_leaves_another_order_or_one_leaf_less_are_refused(zk, two_leaves):
@@ -344,3 +538,32 @@ def test_a_tampered_second_leaf_check_is_refused(zk, oracle, two_leaves, setup):
         oracle.machine_prove(t2, num_queries=NQ, pow_bits=POW)
     with pytest.raises(zk.VerificationError):
         client.verify_with_leaves(zk.SP1ProofWithPublicValues.from_bytes(forced(oracle, t2)), vk, [leaf_a, leaf_b], [vk, vk])
+
+
+def test_a_node_is_a_valid_leaf(zk, fx, oracle, two_leaves):
+    """Two levels (stage 2b): the node of two leaves is itself checked, beside a third leaf, by a root proof - the node's own
+    statement (whose digest its header carries, absorbed by its transcript) is what zksp_stdin_add_verified_node is given.  The
+    root verifies from STUBS of everything below it; any other tree under it is refused."""
+    client, pk, vk, leaf_a, leaf_b, t, outer = two_leaves
+    node = zk.SP1ProofWithPublicValues.from_bytes(outer)
+    st_node = client.leaves_public([leaf_a, leaf_b], [vk, vk])
+    s = zk.SP1Stdin()
+    s.write(fx.acct_fixture(1, seed=9).to_borsh())
+    with pytest.raises(zk.VerificationError):
+        client.add_verified_leaf(s, node, vk)  # (without its statement the node does not verify)
+    client.add_verified_node(s, node, vk, st_node)
+    client.add_verified_leaf(s, leaf_b, vk)
+    root = zk.SP1ProofWithPublicValues.from_bytes(oracle.machine_prove(client.machine_trace(pk, s), num_queries=NQ, pow_bits=POW))
+    sa, sb, sn = leaf_a.stub(), leaf_b.stub(), node.stub()
+    tree = [(sn, [(sa, []), (sb, [])]), (sb, [])]
+    client.verify_tree(root, vk, tree)
+    client.verify_tree(root, vk, [(node, [(leaf_a, []), (leaf_b, [])]), (leaf_b, [])])  # (complete proofs do as stubs)
+    read = len(root.to_bytes()) + sum(len(p.to_bytes()) for p in (sn, sa, sb, sb))
+    full = len(root.to_bytes()) + sum(len(p.to_bytes()) for p in (node, leaf_a, leaf_b, leaf_b))
+    assert read < 0.7 * full  # (6 queries: at the full 100 a stub is a twentieth of a proof)
+    for bad in ([(sn, [(sb, []), (sa, [])]), (sb, [])], [(sn, [(sa, []), (sb, [])]), (sa, [])], [(sn, [(sa, []), (sb, [])])],
+                [(sb, []), (sn, [(sa, []), (sb, [])])], [(sn, []), (sb, [])]):
+        with pytest.raises(zk.VerificationError):
+            client.verify_tree(root, vk, bad)
+    with pytest.raises(zk.VerificationError):
+        client.verify(root, vk)

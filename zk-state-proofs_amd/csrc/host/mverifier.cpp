@@ -378,6 +378,7 @@ bool machine_nodes_public(const uint32_t* keys, const uint32_t* digests, size_t 
       const AggNode *l = agg_find(v, 2 * a.key), *r = agg_find(v, 2 * a.key + 1);
       for (int i = 0; i < 8; ++i) rows->push_back(l->d[i].to_canonical());
       for (int i = 0; i < 8; ++i) rows->push_back(r->d[i].to_canonical());
+      for (int i = 20; i < (int)kP2RecWords; ++i) rows->push_back(0u);  // (root id, Horner sum, alpha_f: a node row has none)
     }
   }
   return true;

@@ -10,7 +10,7 @@ would feed an aggregation tree (latency-bound: n * 32 bytes over xGMI).
 """
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import Callable, List, Optional, Sequence
 
 import numpy as np
 
@@ -79,10 +79,12 @@ def tree_node_groups(n_leaves: int, arity: int) -> List[List[int]]:
     return [list(range(a, min(a + arity, n_leaves))) for a in range(0, n_leaves, arity)]
 
 
-def prove_tree_level(client, pk, leaf_vk, leaves: Sequence, node_stdins: Sequence, arity: int, rank: int, world: int):
-    """One level of BASELINE config 5's recursion tree over the farm (stage 2a): node k is one
-    more guest run (node_stdins[k]) whose proof also checks the query phases of its `arity` leaf proofs
-    (client.add_verified_leaf, in leaf order).  Nodes are independent of one another and shard block-cyclically over the
+def prove_tree_level(client, pk, leaf_vk, leaves: Sequence, node_stdins: Sequence, arity: int, rank: int, world: int,
+                     statements: Optional[Sequence] = None):
+    """One level of BASELINE config 5's recursion tree over the farm (stage 2b): node k is one
+    more guest run (node_stdins[k]) whose proof also checks the query phases of its `arity` leaf proofs under the challenges
+    their own transcripts yield (client.add_verified_leaf, in leaf order; a leaf that is itself a node comes with the
+    statement its proof was made for: statements[i], client.add_verified_node).  Nodes are independent of one another and shard block-cyclically over the
     ranks like any other proofs; every rank holds all the leaves (they were all-gathered or are on shared storage - a node's
     host part verifies its leaves before anything is proven).  The stdins of this rank's nodes are CONSUMED: whatever leaf
     checks they carried are replaced by the node's own (so a retry of the level does not double them).  Returns (node
@@ -95,17 +97,77 @@ def prove_tree_level(client, pk, leaf_vk, leaves: Sequence, node_stdins: Sequenc
     for k in mine:
         client.clear_verified_leaves(node_stdins[k])
         for i in groups[k]:
-            client.add_verified_leaf(node_stdins[k], leaves[i], leaf_vk)
+            if statements is not None and statements[i] is not None:
+                client.add_verified_node(node_stdins[k], leaves[i], leaf_vk, statements[i])
+            else:
+                client.add_verified_leaf(node_stdins[k], leaves[i], leaf_vk)
         stdins.append(node_stdins[k])
     proofs, status = client.prove_batch(pk, stdins) if mine else ([], [])
     return mine, proofs, status
 
 
 def verify_tree_level(client, vk, leaf_vk, leaves: Sequence, nodes: Sequence, arity: int) -> None:
-    """Every node proof of a level verifies, with the statement its own leaves give in leaf order (which verifies the leaves
-    on the way: in stage 2a the statement is derived from them)."""
+    """Every node proof of a level verifies, with the statement its own leaves give in leaf order (leaves may be stubs: the
+    statement needs everything of a leaf but its query phase, which is what the node proves)."""
     groups = tree_node_groups(len(leaves), arity)
     if len(nodes) != len(groups):
         raise ValueError("one proof per node")
     for k, g in enumerate(groups):
         client.verify_with_leaves(nodes[k], vk, [leaves[i] for i in g], [leaf_vk] * len(g))
+
+
+def _gather_objects(local, n_total: int, rank: int, world: int):
+    """All-gathers a rank's block-cyclic shard of python objects into the global list ordered by index (the recursion tree's
+    inputs: every rank holds every proof of a level before the next one is proven)."""
+    if world == 1:
+        return list(local)
+    import torch.distributed as dist
+    parts = [None] * world
+    dist.all_gather_object(parts, list(local))
+    out = [None] * n_total
+    for r in range(world):
+        for j, i in enumerate(shard_indices(n_total, r, world)):
+            out[i] = parts[r][j]
+    return out
+
+
+def prove_tree(client, host, pk, vk, leaves: Sequence, make_stdin: Callable, arity: int, rank: int = 0, world: int = 1):
+    """BASELINE config 5's recursion tree, every level of it (stage 2b): the leaf proofs, then nodes
+    of `arity` children level by level until one root is left.  A node is one more guest run (make_stdin(level, k)) whose proof
+    checks the query phases of its children - leaves, or nodes with the statements their own proofs were made for.  The nodes
+    of a level shard block-cyclically over the ranks; between levels the ranks all-gather the level's proofs (serialized) and
+    statements - the farm's one exchange.  `host`: a client that derives statements (no GPU needed).  Returns
+    (levels, statements): levels[0] = the leaves, levels[-1] = [root]; statements[d][k] = the public tuples proof k of level d
+    was made for (None for a plain leaf)."""
+    from .client import SP1ProofWithPublicValues
+    levels, statements = [list(leaves)], [[None] * len(leaves)]
+    depth = 0
+    while len(levels[-1]) > 1:
+        depth += 1
+        below, st_below = levels[-1], statements[-1]
+        groups = tree_node_groups(len(below), arity)
+        node_stdins = [make_stdin(depth, k) for k in range(len(groups))]
+        mine, proofs, status = prove_tree_level(client, pk, vk, below, node_stdins, arity, rank, world, st_below)
+        if status != [0] * len(mine):
+            raise RuntimeError(f"level {depth}: a node of rank {rank} failed: {client.last_error()}")
+        local = []
+        for k, p in zip(mine, proofs):
+            stubs = [below[i].stub() for i in groups[k]]
+            st = np.concatenate([host.leaf_public_at(stubs[j], vk, j, st_below[i]) for j, i in enumerate(groups[k])])
+            local.append((p.to_bytes(), st))
+        gathered = _gather_objects(local, len(groups), rank, world)
+        levels.append([SP1ProofWithPublicValues.from_bytes(b) for b, _ in gathered])
+        statements.append([st for _, st in gathered])
+    return levels, statements
+
+
+def tree_of_stubs(levels: Sequence[Sequence], arity: int):
+    """The `children` argument of client.verify_tree for the root of prove_tree's levels: stubs of everything below the root."""
+    def node(d, k):
+        if d == 0:
+            return (levels[0][k].stub(), [])
+        groups = tree_node_groups(len(levels[d - 1]), arity)
+        return (levels[d][k].stub(), [node(d - 1, i) for i in groups[k]])
+    top = len(levels) - 1
+    groups = tree_node_groups(len(levels[top - 1]), arity)
+    return [node(top - 1, i) for i in groups[0]]
