@@ -305,10 +305,14 @@ def as_committed_mode(zk, fx, device, with_oracle, batch=32):
 
 
 def leaf_check_mode(zk, fx, client, pk, vk, payload):
-    """Row f4, stage 2a at full parameters: an acct-d8 leaf proof, then ONE more acct-d8 run whose proof also establishes
-    the leaf's query phase (100 queries: every Merkle opening of its four rounds and of its FRI layers, the folding chain) -
-    the unit of a recursion tree's inner node.  Host part (verifying the leaf and logging its openings as chip records)
-    and device part timed apart; verified on the host with the leaf and with the statement alone."""
+    """Row f4, stage 2b at full parameters: an acct-d8 leaf proof, then ONE more acct-d8 run whose proof also establishes the
+    leaf's query phase under the challenges the leaf's own transcript yields (100 queries: the index words and their
+    canonical bits, every Merkle opening of its four rounds and of its FRI layers against the roots the transcript absorbed,
+    the reduced openings from the opened rows, the folding chain) - the unit of a recursion tree's inner node.  Host part
+    (verifying the leaf and logging its transcript and openings as chip records) and device part timed apart; verified on the
+    host with the leaf's STUB and with the statement alone.  Then a node of four leaves, and a two-level tree (16 leaves -> 4
+    nodes -> 1 root, BASELINE config 5 in small) whose root verifies from the stubs of the 20 proofs below it."""
+    farm = importlib.import_module("zk-state-proofs_amd.farm")
     s = zk.SP1Stdin()
     s.write(payload)
     leaf = client.prove(pk, s).run()
@@ -321,7 +325,7 @@ def leaf_check_mode(zk, fx, client, pk, vk, payload):
     probe.write(payload)
     client.set_verified_leaf(probe, leaf, vk)
     t = client.machine_trace(pk, probe)
-    rows, folds, tuples = len(t["leaf_p2_rows"]), len(t["leaf_fold_rows"]), len(t["leaf_pub_tuples"])
+    rows, qrows, trows, tuples = len(t["leaf_p2_rows"]), len(t["leaf_qr_rows"]), len(t["leaf_tr_rows"]), len(t["leaf_pub_tuples"])
     del t, probe
     times = []
     outer = None
@@ -340,13 +344,15 @@ def leaf_check_mode(zk, fx, client, pk, vk, payload):
         client.prove(pk, s3).run()
         plain.append((time.perf_counter() - t1) * 1e3)
     host = zk.ProverClient(device=-1)
+    stub = leaf.stub()
     t2 = time.perf_counter()
-    host.verify_with_leaf(outer, vk, leaf, vk)
+    host.verify_with_leaf(outer, vk, stub, vk)
     verify_ms = (time.perf_counter() - t2) * 1e3
-    host.verify_public(outer, vk, host.leaf_public(leaf, vk))
+    host.verify_public(outer, vk, host.leaf_public(stub, vk))
     raw = outer.to_bytes()
     shape = [int.from_bytes(raw[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
     prove_ms, plain_ms = sorted(times)[1], sorted(plain)[1]
+    names = zk.MACHINE_CHIP_NAMES
     # the node of a recursion tree of arity 4: ONE run that checks four leaf proofs (zksp_stdin_add_verified_leaf)
     arity = 4
     more = [leaf]
@@ -360,30 +366,67 @@ def leaf_check_mode(zk, fx, client, pk, vk, payload):
         s4 = zk.SP1Stdin()
         s4.write(payload)
         t1 = time.perf_counter()
-        for lf in more:
-            client.add_verified_leaf(s4, lf, vk)
+        client.add_verified_leaves(s4, more, [vk] * arity)  # (verified and logged side by side on the host's threads)
         node_log = (time.perf_counter() - t1) * 1e3
         t1 = time.perf_counter()
         node = client.prove(pk, s4).run()
         node_times.append((time.perf_counter() - t1) * 1e3)
-    host.verify_with_leaves(node, vk, more, [vk] * arity)
+    host.verify_with_leaves(node, vk, [p.stub() for p in more], [vk] * arity)
     nraw = node.to_bytes()
     nshape = [int.from_bytes(nraw[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
     node_ms = min(node_times)
-    tree_node = {"leaves": arity, "poseidon2_chip_log_height": nshape[zk.MACHINE_CHIP_NAMES.index("poseidon2")],
+    tree_node = {"leaves": arity, "poseidon2_chip_log_height": nshape[names.index("poseidon2")],
                  "host_log_ms": node_log, "prove_end_to_end_ms": node_ms,
                  "ms_per_verified_leaf": (node_ms - plain_ms + node_log) / arity, "proof_bytes": len(nraw),
-                 "statement": "one run whose proof establishes the query phases of four leaf proofs (the leaves' public tuples one "
-                              "leaf after the other); verified on the host with the four leaves"}
-    return {"poseidon2_rows": rows, "fold_rows": folds, "public_tuples": tuples, "tree_node_of_4": tree_node,
-            "poseidon2_chip_log_height": shape[zk.MACHINE_CHIP_NAMES.index("poseidon2")],
-            "fold_chip_log_height": shape[zk.MACHINE_CHIP_NAMES.index("fri-fold")],
+                 "statement": "one run whose proof establishes the query phases of four leaf proofs under their own transcripts' "
+                              "challenges; verified on the host with the four leaves' stubs"}
+    # config 5 in small: 16 leaves -> 4 nodes -> 1 root; the nodes are leaves of the root (with their own statements)
+    n_tree = 16
+    tl = []
+    for i in range(n_tree):
+        si = zk.SP1Stdin()
+        si.write(fx.acct_fixture(8, seed=4100 + i).to_borsh())
+        tl.append(si)
+    t1 = time.perf_counter()
+    tleaves, status = client.prove_batch(pk, tl)
+    leaves_s = time.perf_counter() - t1
+    assert status == [0] * n_tree
+
+    def make_stdin(depth, k):
+        sdin = zk.SP1Stdin()
+        sdin.write(fx.acct_fixture(8, seed=4200 + 16 * depth + k).to_borsh())
+        return sdin
+
+    t1 = time.perf_counter()
+    levels, _statements = farm.prove_tree(client, host, pk, vk, tleaves, make_stdin, arity)
+    tree_s = time.perf_counter() - t1
+    root = levels[-1][0]
+    stubs = farm.tree_of_stubs(levels, arity)
+    t1 = time.perf_counter()
+    host.verify_tree(root, vk, stubs)
+    tree_verify_s = time.perf_counter() - t1
+    below = [p for lv in levels[:-1] for p in lv]
+    rraw = root.to_bytes()
+    rshape = [int.from_bytes(rraw[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
+    tree = {"levels": [len(lv) for lv in levels], "leaves_prove_batch_s": leaves_s, "nodes_and_root_s": tree_s,
+            "root_verify_from_stubs_s": tree_verify_s, "root_proof_bytes": len(rraw),
+            "stub_bytes_read": sum(len(p.stub().to_bytes()) for p in below), "full_proof_bytes_below_the_root": sum(len(p.to_bytes()) for p in below),
+            "root_poseidon2_chip_log_height": rshape[names.index("poseidon2")],
+            "statement": "the root's proof checks the query phases of its four nodes, each of which checks four leaves; verifying the "
+                         "root reads the root proof and the STUBS (no query phase) of the 20 proofs below it: their bus balance and "
+                         "constraint identity at zeta are still checked natively (stage 2b)"}
+    return {"poseidon2_rows": rows, "query_rows": qrows, "transcript_rows": trows, "public_tuples": tuples, "tree_node_of_4": tree_node,
+            "two_level_tree": tree,
+            "poseidon2_chip_log_height": shape[names.index("poseidon2")],
+            "query_chip_log_height": shape[names.index("query")],
             "host_log_ms": log_ms, "prove_end_to_end_ms": prove_ms, "plain_prove_end_to_end_ms": plain_ms,
             "ms_per_verified_leaf": prove_ms - plain_ms + log_ms, "rows_per_ms": rows / max(prove_ms - plain_ms, 1e-3),
-            "proof_bytes": len(raw), "host_verify_with_leaf_ms": verify_ms,
-            "statement": "the proof also establishes the query phase of the leaf proof: 100 queries x (4 mixed-height Merkle openings "
-                         "with their sponges and injections + every FRI layer opening + the folding chain to the final constant); "
-                         "roots, positions, challenges, reduced openings public (stage 2a); verified on the host with the leaf and "
+            "proof_bytes": len(raw), "stub_bytes": len(stub.to_bytes()), "host_verify_with_stub_ms": verify_ms,
+            "statement": "the proof also establishes the query phase of the leaf proof under the challenges the leaf's own transcript "
+                         "yields: 100 queries x (index word -> canonical bits -> positions; 4 mixed-height Merkle openings with their "
+                         "sponges, Horner sums and injections + every FRI layer opening against the absorbed roots; reduced openings; "
+                         "the folding chain to the final constant); public: the transcript's blocks and a few constants per leaf and "
+                         "height (stage 2b; stage 2a had 4 500 public tuples per leaf); verified on the host with the leaf's stub and "
                          "with the statement alone"}
 
 

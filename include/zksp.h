@@ -278,6 +278,10 @@ int zksp_proof_stub(const zksp_proof* p, zksp_proof** out);
 /* zksp_leaf_public for the leaf at place `leaf_index` beside one run, which itself closes its buses with own_tuples (a node) */
 int zksp_leaf_public_at(zksp_client* c, const zksp_proof* leaf_or_stub, const zksp_vk* leaf_vk, uint32_t leaf_index,
                         const uint32_t* own_tuples, size_t n_own_tuples, uint32_t* out, size_t cap_words, size_t* n_tuples);
+/* Several leaves at once, verified and logged side by side on the host's threads (a node of arity n in one call); own_tuples /
+ * n_own_tuples: NULL, or per leaf the statement its proof was made for (NULL / 0 for a plain leaf) */
+int zksp_stdin_add_verified_leaves(zksp_client* c, zksp_stdin* s, const zksp_proof* const* leaves, const zksp_vk* const* leaf_vks,
+                                   const uint32_t* const* own_tuples, const size_t* n_own_tuples, size_t n);
 /* zksp_stdin_add_verified_leaf for a leaf that is itself a node: own_tuples is the statement ITS proof was made for */
 int zksp_stdin_add_verified_node(zksp_client* c, zksp_stdin* s, const zksp_proof* leaf, const zksp_vk* leaf_vk,
                                  const uint32_t* own_tuples, size_t n_own_tuples);

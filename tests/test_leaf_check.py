@@ -506,6 +506,19 @@ def test_two_leaves_are_checked_by_one_proof(zk, two_leaves, setup):
     client.verify_with_leaves(proof, vk, [leaf_a, leaf_b], [vk, vk])
     client.verify_with_leaves(proof, vk, [leaf_a.stub(), leaf_b.stub()], [vk, vk])
     client.verify_public(proof, vk, tuples)
+    # the leaves added in one call (verified and logged side by side) leave the same records behind
+    s3 = zk.SP1Stdin()
+    client.add_verified_leaves(s3, [leaf_a, leaf_b], [vk, vk])
+    s4 = zk.SP1Stdin()
+    client.add_verified_leaf(s4, leaf_a, vk)
+    client.add_verified_leaf(s4, leaf_b, vk)
+    import importlib
+    fxm = importlib.import_module("zk-state-proofs_amd.fixtures")
+    for sx in (s3, s4):
+        sx.write(fxm.acct_fixture(1, seed=3).to_borsh())
+    ta, tb = client.machine_trace(pk, s3), client.machine_trace(pk, s4)
+    for key in ("leaf_p2_rows", "leaf_qr_rows", "leaf_tr_rows", "leaf_pub_tuples"):
+        assert np.array_equal(ta[key], tb[key]) and np.array_equal(ta[key], t[key]), key
     # the chips grew with the work: twice the permutations, twice the query rows
     hts = [int.from_bytes(outer[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
     h1 = [int.from_bytes(setup[6][8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]

@@ -164,6 +164,7 @@ def load_library() -> C.CDLL:
     lib.zksp_leaf_public_at.argtypes = [vp, vp, vp, C.c_uint32, vp, sz, vp, sz, C.POINTER(sz)]
     lib.zksp_stdin_add_verified_node.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.zksp_proof_stub.argtypes = [vp, C.POINTER(vp)]
+    lib.zksp_stdin_add_verified_leaves.argtypes = [vp, vp, vp, vp, vp, vp, sz]
     lib.zksp_verify_public.argtypes = [vp, vp, vp, vp, sz]
     lib.zksp_verify_with_leaf.argtypes = [vp, vp, vp, vp, vp]
     lib.zksp_proof_public_tuples.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -209,7 +210,7 @@ ABI_SYMBOLS = [
     "zksp_execute", "zksp_execute_keccak", "zksp_opcode_name", "zksp_machine_trace", "zksp_mtrace_free",
     "zksp_mtrace_section", "zksp_mtrace_info", "zksp_vk_machine", "zksp_mtrace_heights", "zksp_machine_body_words",
     "zksp_machine_chip_widths", "zksp_machine_cover_heights", "zksp_stdin_set_aggregation", "zksp_proof_aggregation", "zksp_verify_aggregate",
-    "zksp_stdin_set_aggregation_keyed", "zksp_verify_aggregate_keyed", "zksp_stdin_set_verified_leaf", "zksp_stdin_add_verified_leaf", "zksp_leaves_public", "zksp_verify_with_leaves", "zksp_leaf_public", "zksp_verify_public", "zksp_leaf_public_at", "zksp_stdin_add_verified_node", "zksp_proof_stub",
+    "zksp_stdin_set_aggregation_keyed", "zksp_verify_aggregate_keyed", "zksp_stdin_set_verified_leaf", "zksp_stdin_add_verified_leaf", "zksp_leaves_public", "zksp_verify_with_leaves", "zksp_leaf_public", "zksp_verify_public", "zksp_leaf_public_at", "zksp_stdin_add_verified_node", "zksp_proof_stub", "zksp_stdin_add_verified_leaves",
     "zksp_verify_with_leaf", "zksp_proof_public_tuples", "zksp_hip_machine_fetch_stage", "zksp_hip_machine_fetch_challenges",
     "zksp_hip_machine_load", "zksp_hip_machine_prove", "zksp_hip_release_workspace", "zksp_hip_machine_fetch_bodies", "zksp_hip_machine_fetch_roots", "zksp_machine_proof_from_body", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
     "zksp_hip_prove_resident", "zksp_proof_from_body", "zksp_hip_fetch_bodies", "zksp_hip_fetch_roots", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
@@ -534,6 +535,24 @@ class ProverClient:
         import numpy as np
         tv = np.ascontiguousarray(node_statement, dtype=np.uint32).reshape(-1, PUB_TUPLE_WORDS)
         rc = self._lib.zksp_stdin_add_verified_node(self._h, stdin._h, node._h, node_vk._h, tv.ctypes.data_as(C.c_void_p), len(tv))
+        if rc:
+            raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
+
+    def add_verified_leaves(self, stdin: SP1Stdin, leaves, leaf_vks, statements=None) -> None:
+        """``add_verified_leaf`` / ``add_verified_node`` for several leaves in one call (``zksp_stdin_add_verified_leaves``): they are
+        verified and logged side by side on the host's threads.  ``statements``: None, or per leaf its own statement (None for a
+        plain leaf)."""
+        import numpy as np
+        pa, va, k = self._handle_arrays(leaves, leaf_vks)
+        own_p, own_n, keep = None, None, []
+        if statements is not None and any(st is not None for st in statements):
+            own_p, own_n = (C.c_void_p * k)(), (C.c_size_t * k)()
+            for i, st in enumerate(statements):
+                if st is not None:
+                    tv = np.ascontiguousarray(st, dtype=np.uint32).reshape(-1, PUB_TUPLE_WORDS)
+                    keep.append(tv)
+                    own_p[i], own_n[i] = tv.ctypes.data, len(tv)
+        rc = self._lib.zksp_stdin_add_verified_leaves(self._h, stdin._h, pa, va, own_p, own_n, k)
         if rc:
             raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
 

@@ -1053,7 +1053,7 @@ ZKSP_HD void eval_qr(Ctx& ctx) {
   for (int i = 0; i < 4; ++i) ctx.emit(fl * (L(QR_E + i) - L(QR_RO + i)));
 #pragma unroll
   for (int i = 0; i < 4; ++i) ctx.emit(nl1 * (N(QR_E + i) - L(QR_F + i) - N(QR_RO + i)));
-  // the reduced opening of the height that joins on this row (oracle/mprover.c orc_reduce_coefs): the Horner sums H_r of the
+  // the reduced opening of the height that joins on this row (DESIGN.md "Reduced openings"): the Horner sums H_r of the
   // four trees' opened rows, delta between the trees, the verifier's constants B1, B2, w_H
   {
     const X4<F> dl = x4_local<F>(ctx, QR_DL), d2 = x4_local<F>(ctx, QR_D2), d3 = x4_local<F>(ctx, QR_D3), d4 = x4_local<F>(ctx, QR_D4),
@@ -1091,7 +1091,7 @@ ZKSP_HD void eval_qr(Ctx& ctx) {
   }
 #undef N
 }
-constexpr int kQrConstraints = 140;  // (counted by running them: oracle/machine.c count_constraints)
+constexpr int kQrConstraints = 140;  // (counted by running them: the verifier checks the count)
 
 // ---- transcript chip ----
 template <class Ctx>

@@ -6,6 +6,8 @@
 #include <memory>
 #include <new>
 
+#include <thread>
+
 #include "api_types.hpp"
 #include "machine_defs.hpp"
 #include "mprover.hpp"
@@ -350,14 +352,18 @@ int zksp_verify_aggregate_keyed(zksp_client* c, const zksp_proof* p, const zksp_
 // Verifies `leaf` - completely, or (stub_only) everything but its query phase - and leaves the records / the public tuples of a
 // proof ABOUT that verification in *out.  `index`: the leaf's place among the leaves checked beside one run.  own / n_own: the
 // public tuples `leaf` itself closes its buses with (a leaf that checks leaves of its own: a node of a recursion tree).
-static int leaf_check_of(zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf_vk, std::shared_ptr<LeafCheckLog>* out,
-                         uint32_t index = 0, const uint32_t* own = nullptr, size_t n_own = 0, bool stub_only = false) {
-  if (c->ctx.params.proof_mode != ZKSP_PROOF_MACHINE || leaf->version != mach::kMachineVersion)
-    return c->ctx.fail(ZKSP_ERR_VERIFY, "leaf check: not a machine proof");
-  if (leaf->mhdr.agg_n) return c->ctx.fail(ZKSP_ERR_UNSUPPORTED, "leaf check: the leaf proof carries an aggregation payload");
-  if (c->ctx.params.num_queries > mach::kLeafMaxQueries || index >= 4096)
-    return c->ctx.fail(ZKSP_ERR_UNSUPPORTED, "leaf check: too many queries or leaves for the tag space");
-  std::string err;
+// (no access to the client's error state: safe to run for several leaves at once)
+static int leaf_check_run(const zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf_vk, std::shared_ptr<LeafCheckLog>* out,
+                          uint32_t index, const uint32_t* own, size_t n_own, bool stub_only, std::string* err) {
+  if (c->ctx.params.proof_mode != ZKSP_PROOF_MACHINE || leaf->version != mach::kMachineVersion) {
+    *err = "leaf check: not a machine proof";
+    return ZKSP_ERR_VERIFY;
+  }
+  if (leaf->mhdr.agg_n) { *err = "leaf check: the leaf proof carries an aggregation payload"; return ZKSP_ERR_UNSUPPORTED; }
+  if (c->ctx.params.num_queries > mach::kLeafMaxQueries || index >= 4096) {
+    *err = "leaf check: too many queries or leaves for the tag space";
+    return ZKSP_ERR_UNSUPPORTED;
+  }
   int rc;
   try {
     auto log = std::make_shared<LeafCheckLog>();
@@ -366,14 +372,23 @@ static int leaf_check_of(zksp_client* c, const zksp_proof* leaf, const zksp_vk* 
     // a stub is recognised by its length; a complete proof is cut down to one where only the statement is wanted
     const size_t stub_len = leaf->mhdr.body_offset + machine_proof_body_words(leaf->mhdr.logh, 0) * 4;
     const bool is_stub = leaf->bytes.size() == stub_len;
-    if (is_stub && !stub_only) return c->ctx.fail(ZKSP_ERR_INVALID_ARG, "leaf check: a proof stub has no query phase to prove");
+    if (is_stub && !stub_only) { *err = "leaf check: a proof stub has no query phase to prove"; return ZKSP_ERR_INVALID_ARG; }
+    std::string verr;
     rc = verify_machine_proof(leaf->bytes.data(), stub_only ? stub_len : leaf->bytes.size(), leaf_vk->machine, c->ctx.params.num_queries,
-                              c->ctx.params.pow_bits, &err, nullptr, 0, nullptr, own, n_own, log.get(), stub_only);
+                              c->ctx.params.pow_bits, &verr, nullptr, 0, nullptr, own, n_own, log.get(), stub_only);
     if (rc == 0) *out = std::move(log);
+    else *err = "leaf check: the leaf proof does not verify: " + verr;
   } catch (...) {
-    return c->ctx.fail(ZKSP_ERR_VERIFY, "leaf check: out of memory");
+    *err = "leaf check: out of memory";
+    return ZKSP_ERR_VERIFY;
   }
-  if (rc) return c->ctx.fail(rc, "leaf check: the leaf proof does not verify: " + err);
+  return rc;
+}
+static int leaf_check_of(zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf_vk, std::shared_ptr<LeafCheckLog>* out,
+                         uint32_t index = 0, const uint32_t* own = nullptr, size_t n_own = 0, bool stub_only = false) {
+  std::string err;
+  const int rc = leaf_check_run(c, leaf, leaf_vk, out, index, own, n_own, stub_only, &err);
+  if (rc) return c->ctx.fail(rc, err);
   return ZKSP_OK;
 }
 
@@ -427,6 +442,54 @@ int zksp_stdin_add_verified_node(zksp_client* c, zksp_stdin* s, const zksp_proof
 
 int zksp_stdin_add_verified_leaf(zksp_client* c, zksp_stdin* s, const zksp_proof* leaf, const zksp_vk* leaf_vk) {
   return zksp_stdin_add_verified_node(c, s, leaf, leaf_vk, nullptr, 0);
+}
+
+int zksp_stdin_add_verified_leaves(zksp_client* c, zksp_stdin* s, const zksp_proof* const* leaves, const zksp_vk* const* leaf_vks,
+                                   const uint32_t* const* own, const size_t* n_own, size_t n) {
+  if (!c || !s || !leaves || !leaf_vks || !n) return ZKSP_ERR_INVALID_ARG;
+  for (size_t k = 0; k < n; ++k)
+    if (!leaves[k] || !leaf_vks[k] || (own && n_own && n_own[k] && !own[k])) return ZKSP_ERR_INVALID_ARG;
+  const uint32_t have = s->leaf_check ? s->leaf_check->n_leaves : 0;
+  // the leaves are independent of one another: verified and logged side by side (each on several threads of its own for the
+  // queries), appended in the order given
+  std::vector<std::shared_ptr<LeafCheckLog>> logs(n);
+  std::vector<int> rcs(n, ZKSP_OK);
+  std::vector<std::string> errs(n);
+  auto run = [&](size_t k) noexcept {
+    try {
+      rcs[k] = leaf_check_run(c, leaves[k], leaf_vks[k], &logs[k], have + (uint32_t)k, own ? own[k] : nullptr, own && n_own ? n_own[k] : 0,
+                              false, &errs[k]);
+    } catch (...) {
+      rcs[k] = ZKSP_ERR_VERIFY;
+    }
+  };
+  {
+    struct Joiner {
+      std::vector<std::thread> th;
+      ~Joiner() { for (auto& t : th) if (t.joinable()) t.join(); }
+    } pool;
+    for (size_t k = 1; k < n; ++k) {
+      try {
+        pool.th.emplace_back(run, k);
+      } catch (...) {
+        run(k);
+      }
+    }
+    run(0);
+  }
+  for (size_t k = 0; k < n; ++k)
+    if (rcs[k]) return c->ctx.fail(rcs[k], errs[k].empty() ? std::string("leaf check: out of memory") : errs[k]);
+  try {
+    auto all = std::make_shared<LeafCheckLog>();
+    if (s->leaf_check) *all = *s->leaf_check;
+    for (size_t k = 0; k < n; ++k) all->append(*logs[k]);
+    all->leaf_index = 0;
+    all->n_leaves = have + (uint32_t)n;
+    s->leaf_check = std::move(all);
+  } catch (...) {
+    return c->ctx.fail(ZKSP_ERR_VERIFY, "leaf check: out of memory");
+  }
+  return ZKSP_OK;
 }
 
 int zksp_leaf_public_at(zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf_vk, uint32_t index, const uint32_t* own, size_t n_own,

@@ -469,7 +469,7 @@ void machine_host_setup(const MachineProgram& prog, MachineVk* vk) {
   vk_digest_of(vk->prep_root, vk->entry, vk->pad_pc, vk->log_prog, vk->log_image, vk->keccak_mode, vk->digest);
 }
 
-// Coefficients of the reduced openings (format v16; oracle/mprover.c orc_reduce_coefs is the normative text).  The input
+// Coefficients of the reduced openings (format v16; DESIGN.md "Reduced openings").  The input
 // of height 2^lh at the LDE point x is  sum_r delta^r (H_r(x) - H_r(zeta)) / (x - zeta)  +  sum_{r = main, perm}
 // delta^(3 + r) (H_r(x) - H_r(zeta w)) / (x - zeta w),  H_r = Horner's rule in alpha_f over the segment (r, lh): the opened
 // rows of the chips of that height in chip order, zero-filled to a multiple of eight words - the words the opening's sponge

@@ -96,11 +96,16 @@ def prove_tree_level(client, pk, leaf_vk, leaves: Sequence, node_stdins: Sequenc
     stdins = []
     for k in mine:
         client.clear_verified_leaves(node_stdins[k])
-        for i in groups[k]:
-            if statements is not None and statements[i] is not None:
-                client.add_verified_node(node_stdins[k], leaves[i], leaf_vk, statements[i])
-            else:
-                client.add_verified_leaf(node_stdins[k], leaves[i], leaf_vk)
+        g = groups[k]
+        if hasattr(client, "add_verified_leaves"):  # (the leaves of a node are verified and logged side by side)
+            client.add_verified_leaves(node_stdins[k], [leaves[i] for i in g], [leaf_vk] * len(g),
+                                       None if statements is None else [statements[i] for i in g])
+        else:
+            for i in g:
+                if statements is not None and statements[i] is not None:
+                    client.add_verified_node(node_stdins[k], leaves[i], leaf_vk, statements[i])
+                else:
+                    client.add_verified_leaf(node_stdins[k], leaves[i], leaf_vk)
         stdins.append(node_stdins[k])
     proofs, status = client.prove_batch(pk, stdins) if mine else ([], [])
     return mine, proofs, status
