@@ -146,7 +146,10 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   // the rest are traced by host threads while it proves them.
   // (an eighth, at most sixty-four: sixty-four proofs already run at 95 % of the rate of a full batch, and they are traced
   // and uploaded in a tenth of a second)
-  const size_t w0 = std::min<size_t>(n, std::max<size_t>(1, std::min<size_t>(std::min<size_t>(ctx->params.max_batch, 64), std::max<size_t>(16, (n + 7) / 8))));
+  // (round 5: a large call starts with 24 and lets the waves grow by half each - the GPU starts after 40 ms instead of 135,
+  // and a wave of 1.5 x is uploaded, from pageable memory at about 10 GB/s, in the time the wave before it is proven)
+  const bool ramp = n >= 384 && ctx->params.max_batch >= 96;
+  const size_t w0 = ramp ? 24 : std::min<size_t>(n, std::max<size_t>(1, std::min<size_t>(std::min<size_t>(ctx->params.max_batch, 64), std::max<size_t>(16, (n + 7) / 8))));
   parallel_for(w0, 64, trace_one);
   mark.mark("traced", w0);
   std::string first_err;
@@ -351,12 +354,23 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   std::vector<size_t> wave_end;  // exclusive ends of the waves behind the first
   if (w0 < n) {
     if (chunks.size() == 1 && n >= 4 * w0) {
-      wave_end.push_back(3 * w0);
-      const size_t left = n - 3 * w0, cap = std::max<size_t>(16, std::min<size_t>(ctx->params.max_batch, 192));
+      const size_t cap = std::max<size_t>(16, std::min<size_t>(ctx->params.max_batch, 192));
+      size_t e0 = w0, biggest = 2 * w0;
+      if (ramp) {
+        for (size_t w = w0 * 3 / 2; w < cap && e0 + w + cap <= n; w = w * 3 / 2) {
+          e0 += w;
+          wave_end.push_back(e0);
+          biggest = w;
+        }
+      } else {
+        e0 = 3 * w0;
+        wave_end.push_back(e0);
+      }
+      const size_t left = n - e0;
       const size_t nw = (left + cap - 1) / cap, per = (left + nw - 1) / nw;  // waves of equal size
-      for (size_t e = 3 * w0 + per; e < n; e += per) wave_end.push_back(e);
+      for (size_t e = e0 + per; e < n; e += per) wave_end.push_back(e);
       wave_end.push_back(n);
-      size_hint = std::min(std::max(per, 2 * w0), std::max<size_t>(last_cap, 1));
+      size_hint = std::min(std::max(per, biggest), std::max<size_t>(last_cap, 1));
     } else {
       wave_end.push_back(n);
     }
