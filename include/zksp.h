@@ -66,17 +66,17 @@ typedef struct {
  * source of these numbers - kMachineVersion, kHeaderWords):
  *   word 0           magic
  *   word 1           format version (16)
- *   words 2 .. 27    log2 height of each of the ZKSP_MACHINE_CHIPS = 26 chips, in proof order
- *   word 28, 29      guest exit code, length of the public values in bytes
- *   words 30 .. 53   sha256(public values) as 8 words, the deferred-proofs digest (8), the verifying-key digest (8)
- *   words 54 .. 60   the pc at which each of the seven later CPU instances starts (hand-over pcs)
- *   words 61 .. 77   aggregation payload: number of supplied digests (0: none), their Merkle root (8), digest of the list (8)
- *   words 78 .. 86   public bus tuples (a leaf-proof check's statement): their number (0: none), digest of the list (8)
+ *   words 2 .. 28    log2 height of each of the ZKSP_MACHINE_CHIPS = 27 chips, in proof order
+ *   word 29, 30      guest exit code, length of the public values in bytes
+ *   words 31 .. 54   sha256(public values) as 8 words, the deferred-proofs digest (8), the verifying-key digest (8)
+ *   words 55 .. 61   the pc at which each of the seven later CPU instances starts (hand-over pcs)
+ *   words 62 .. 78   aggregation payload: number of supplied digests (0: none), their Merkle root (8), digest of the list (8)
+ *   words 79 .. 87   public bus tuples (a leaf-proof check's statement): their number (0: none), digest of the list (8)
  *   then             the public values, zero-padded to a word; then the proof body (commitment roots, cumulative sums,
  *                    opened values, FRI roots, final constant, proof-of-work witness, the query openings):
  *                    zksp_machine_body_words() words.  A proof STUB (zksp_proof_stub) ends in front of the query openings.
  * Everything in the header is absorbed into the transcript before the first challenge is drawn. */
-#define ZKSP_MACHINE_HEADER_WORDS 87
+#define ZKSP_MACHINE_HEADER_WORDS 88
 
 /* replaces ProverClient::new()  (main.rs:61).  Fails with ZKSP_ERR_NO_DEVICE when
  * device_ordinal >= 0 and no GPU is usable: there is no CPU proving fallback.
@@ -175,7 +175,8 @@ int zksp_execute_keccak(zksp_client* c, const zksp_pk* pk, const zksp_stdin* std
 typedef struct zksp_mtrace zksp_mtrace;
 #define ZKSP_MT_CYCLES 0        /* 12 u32 per executed cycle */
 #define ZKSP_MT_KECCAK 1        /* 408 bytes per precompile call: ts, ptr, 25 u64 in, 50 u32 previous times */
-#define ZKSP_MT_MEMFINAL 2      /* 5 u32 per image address and per other touched address: addr, init, fin, fin_ts, is_init */
+#define ZKSP_MT_MEMFINAL 2      /* 5 u32 per image address and per other touched address: addr, init, fin, fin_ts, is_init (0: image word, 1: a word a
+                                   HINT_READ covers - its initial value is the input's -, 2: any other address - it starts as zero) */
 #define ZKSP_MT_MULS 3          /* 3 u32 per multiplier-chip row: kind (0 mul, 1 mulhu, 2 mulh, 3 mulhsu), b, c */
 #define ZKSP_MT_PROG_MULT 4     /* u32 per Program-table row */
 #define ZKSP_MT_ALU_IDX 5       /* u32 per ALU-chip row: index of the cycle (sll srl sra slt, blt bge) */
@@ -213,7 +214,7 @@ int zksp_mtrace_info(const zksp_mtrace* t, zksp_mtrace_info_t* info);
 /* Device-resident machine proving (bench.py, parity tests): upload the records of n traced runs (they are proven
  * with one shape: zksp_machine_cover_heights), enqueue one proving pass, fetch the proof bodies ([n][body_words]
  * canonical u32; body_words = zksp_machine_body_words of that shape). */
-#define ZKSP_MACHINE_CHIPS 26   /* cpu, keccak, keccak-mem, mem-final, image, program, mul, table, cpu2, alu, alu2, subword, subword2, bitwise, bitwise2, poseidon2, ecall, cpu3 .. cpu8, query, divider, transcript */
+#define ZKSP_MACHINE_CHIPS 27   /* cpu, keccak, keccak-mem, mem-final, image, program, mul, table, cpu2, alu, alu2, subword, subword2, bitwise, bitwise2, poseidon2, ecall, cpu3 .. cpu8, query, divider, transcript, hint */
 int zksp_mtrace_heights(const zksp_mtrace* t, int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 size_t zksp_machine_body_words(const zksp_client* c, const int32_t* log_heights /* [ZKSP_MACHINE_CHIPS] */);
 /* The shape a batch of these runs is proven with: the chip heights that cover the largest cycle / event / address

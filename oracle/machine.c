@@ -105,7 +105,7 @@ static orc_lf lf_bits(int bits, int n) {
 
 #define CPU_INTER 19
 static orc_inter g_cpu[CPU_INTER], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[5], g_div[13], g_table[7],
-    g_alu[1], g_sub[5], g_bw[5], g_p2[10], g_ecall[10], g_qr[17], g_tr[16];
+    g_alu[1], g_sub[5], g_bw[5], g_p2[10], g_ecall[12], g_qr[17], g_tr[16], g_hint[2];
 static orc_chip g_chips[N_CHIPS];
 static int g_ready = 0;
 
@@ -257,6 +257,22 @@ static void build(void) {
     memset(it, 0, sizeof *it);
     it->bus = BUS_PUBH; it->sign = +1; it->mult = lf_col(EC_SC + SC_HALT); it->n_el = 2;
     it->el[0] = ec_lo; it->el[1] = ec_hi;
+    /* a HINT_READ announces (pointer, words) to the hint chip; the word count is a 16-bit value */
+    it = &g_ecall[10];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_HINTR; it->sign = +1; it->mult = lf_col(EC_SC + SC_HINT_READ); it->n_el = 2;
+    it->el[0] = lf_pair(EC_C_LO, EC_C_HI, 65536); it->el[1] = lf_col(EC_NW);
+    g_ecall[11] = range_inter(-1, lf_col(EC_SC + SC_HINT_READ), lf_const(0), lf_col(EC_NW));
+    /* hint chip: a read's first word takes the announcement; a word the run touches hands its initial value to the memory
+     * boundary chip over the IMG bus */
+    it = &g_hint[0];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_HINTR; it->sign = -1; it->mult = lf_col(HN_FIRST); it->n_el = 2;
+    it->el[0] = lf_col(HN_ADDR); it->el[1] = lf_col(HN_CNT);
+    it = &g_hint[1];
+    memset(it, 0, sizeof *it);
+    it->bus = BUS_IMG; it->sign = +1; it->mult = lf_col(HN_USED); it->n_el = 3;
+    it->el[0] = lf_col(HN_ADDR); it->el[1] = lf_col(HN_LO); it->el[2] = lf_col(HN_HI);
   }
   /* ---- keccak chip: on an export row, word i of the input and of the output state, i = 0..49 ---- */
   for (int i = 0; i < 50; ++i) {
@@ -297,7 +313,7 @@ static void build(void) {
     g_memfinal[1] = mem_inter(+1, real, addr, lf_col(MF_INIT_LO), lf_col(MF_INIT_HI), zero);
     orc_inter* it = &g_memfinal[2];
     memset(it, 0, sizeof *it);
-    it->bus = BUS_IMG; it->sign = -1; it->mult = lf_pair(MF_IS_REAL, MF_IS_INIT, FP - 1); it->n_el = 3;
+    it->bus = BUS_IMG; it->sign = -1; it->mult = lf_pair(MF_IS_REAL, MF_IS_ZERO, FP - 1); it->n_el = 3; /* an image word or a hinted one */
     it->el[0] = addr; it->el[1] = lf_col(MF_INIT_LO); it->el[2] = lf_col(MF_INIT_HI);
     g_memfinal[3] = range_inter(-1, real, zero, lf_col(MF_LO));
     g_memfinal[4] = range_inter(-1, real, zero, lf_col(MF_HI));
@@ -664,7 +680,8 @@ static void build(void) {
   g_chips[CH_P2] = (orc_chip){"poseidon2", 0, P2CHIP_WIDTH, 10, g_p2, 0, 0};
   g_chips[CH_QR] = (orc_chip){"query", 0, QR_WIDTH, 17, g_qr, 0, 0};
   g_chips[CH_TR] = (orc_chip){"transcript", 0, TR_WIDTH, 16, g_tr, 0, 0};
-  g_chips[CH_ECALL] = (orc_chip){"ecall", 0, ECALL_WIDTH, 10, g_ecall, 0, 0};
+  g_chips[CH_ECALL] = (orc_chip){"ecall", 0, ECALL_WIDTH, 12, g_ecall, 0, 0};
+  g_chips[CH_HINT] = (orc_chip){"hint", 0, HINT_WIDTH, 2, g_hint, 0, 0};
   g_ready = 1;
   for (int c = 0; c < N_CHIPS; ++c) g_chips[c].n_constraints = count_constraints(c);
 }
@@ -746,6 +763,20 @@ void orc_machine_cpu_pub(const orc_machine_input* in, int chip, uint32_t pub[CPU
   pub[CPUPUB_END_PC] = inst + 1 < CPU_INST ? (r1 < in->n_cycles ? in->cycles[12 * r1] : pad) : 0;
 }
 
+/* words covered by the run's HINT_READs (ecalls with t0 = 0xf1: pointer in a0, length in a1), in execution order */
+static size_t hint_words(const orc_machine_input* in) {
+  const size_t n = orc_machine_events(in, 3, NULL);
+  uint32_t* ev = (uint32_t*)malloc((n ? n : 1) * 4);
+  orc_machine_events(in, 3, ev);
+  size_t words = 0;
+  for (size_t e = 0; e < n; ++e) {
+    const uint32_t* cy = in->cycles + 12 * (size_t)ev[e];
+    if (cy[2] == 0xf1) words += (cy[4] + 3) / 4;
+  }
+  free(ev);
+  return words;
+}
+
 void orc_machine_heights(const orc_machine_input* in, int logh[N_CHIPS]) {
   if (in->shape) { memcpy(logh, in->shape, N_CHIPS * sizeof(int)); return; }
   const size_t na = orc_machine_events(in, 0, NULL), ns = orc_machine_events(in, 1, NULL), nb = orc_machine_events(in, 2, NULL);
@@ -773,6 +804,7 @@ void orc_machine_heights(const orc_machine_input* in, int logh[N_CHIPS]) {
     logh[CH_P2] = at_least5(clog2(rows == 0 ? 1 : rows));
     logh[CH_QR] = at_least5(clog2(in->n_leaf_qr ? in->n_leaf_qr : 1));
     logh[CH_TR] = at_least5(clog2(in->n_leaf_tr ? in->n_leaf_tr : 1));
+    logh[CH_HINT] = at_least5(clog2(hint_words(in) ? hint_words(in) : 1));
   }
   logh[CH_ECALL] = at_least5(clog2(orc_machine_events(in, 3, NULL)));
   logh[CH_DIV] = at_least5(clog2(orc_machine_events(in, 4, NULL)));
@@ -955,6 +987,10 @@ static void fill_ecall(const orc_machine_input* in, size_t h, uint32_t* t) {
     T(EC_C_LO) = c & 0xffff; T(EC_C_HI) = c >> 16; T(EC_M_LO) = m & 0xffff; T(EC_M_HI) = m >> 16;
     const uint32_t g0 = ts - cy[8], g1 = ts + 1 - cy[9];
     T(EC_GAP) = g0 & 0xffff; T(EC_GAP + 1) = g0 >> 16; T(EC_GAP + 2) = g1 & 0xffff; T(EC_GAP + 3) = g1 >> 16;
+    if (b == 0xf1) { /* a HINT_READ of m bytes covers NW = ceil(m / 4) words */
+      const uint32_t nw = (m + 3) / 4, padb = 4 * nw - m;
+      T(EC_NW) = nw; T(EC_P1) = padb & 1u; T(EC_P2) = (padb >> 1) & 1u;
+    }
     /* soundness tests: ZKSP_ORACLE_ECALL_NP=<row> sends that (non-HALT) ecall to the padding instruction - the CPU row
      * goes on at pc + 4, so the ECALL bus cannot balance; ZKSP_ORACLE_ECALL_FLAG=<row> decodes that ecall as the next
      * syscall in the list - the code in t0 no longer matches the flags */
@@ -1127,7 +1163,7 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
       const size_t crows = in->n_cycles ? cpu_rows(in) : 0;
       for (size_t r = 0; r < in->n_memfinal; ++r) {
         const uint32_t* f = in->memfinal + 5 * r;
-        T(MF_IS_REAL) = 1; T(MF_LO) = f[0] & 0xffff; T(MF_HI) = f[0] >> 16; T(MF_IS_INIT) = f[4];
+        T(MF_IS_REAL) = 1; T(MF_LO) = f[0] & 0xffff; T(MF_HI) = f[0] >> 16; T(MF_IS_INIT) = f[4] == 1; T(MF_IS_ZERO) = f[4] == 2;
         T(MF_INIT_LO) = f[1] & 0xffff; T(MF_INIT_HI) = f[1] >> 16;
         T(MF_FIN_LO) = f[2] & 0xffff; T(MF_FIN_HI) = f[2] >> 16; T(MF_FIN_TS) = f[3];
         /* x0 (row 0) is read once more by every CPU row after the last cycle: its last access is the last row's */
@@ -1291,6 +1327,32 @@ void orc_machine_fill(const orc_machine_input* in, int chip, int logh, uint32_t*
         T(DV_NZD) = d != 0; T(DV_INVD) = d ? f_inv(((d & 0xffff) + (d >> 16)) % FP) : 0;
         T(DV_NZQ) = aq != 0; T(DV_INVQ) = aq ? f_inv(((aq & 0xffff) + (aq >> 16)) % FP) : 0;
         T(DV_NZR) = ar != 0; T(DV_INVR) = ar ? f_inv(((ar & 0xffff) + (ar >> 16)) % FP) : 0;
+      }
+      free(ev);
+      break;
+    }
+    case CH_HINT: {
+      /* one row per word of every HINT_READ, in execution order of the reads; USED and the value from the memory boundary list */
+      const size_t ne = orc_machine_events(in, 3, NULL);
+      uint32_t* ev = (uint32_t*)malloc((ne ? ne : 1) * 4);
+      orc_machine_events(in, 3, ev);
+      size_t r = 0;
+      for (size_t e = 0; e < ne; ++e) {
+        const uint32_t* cy = in->cycles + 12 * (size_t)ev[e];
+        if (cy[2] != 0xf1) continue;
+        const uint32_t ptr = cy[3], nw = (cy[4] + 3) / 4;
+        for (uint32_t j = 0; j < nw && r < h; ++j, ++r) {
+          const uint32_t addr = ptr + 4 * j;
+          size_t lo = 0, hi = in->n_memfinal;
+          while (lo < hi) {
+            const size_t mid = (lo + hi) >> 1;
+            if (in->memfinal[5 * mid] < addr) lo = mid + 1; else hi = mid;
+          }
+          const int used = lo < in->n_memfinal && in->memfinal[5 * lo] == addr;
+          const uint32_t v = used ? in->memfinal[5 * lo + 1] : 0;
+          T(HN_IS_REAL) = 1; T(HN_FIRST) = j == 0; T(HN_LAST) = j + 1 == nw; T(HN_ADDR) = addr % FP; T(HN_CNT) = nw - j;
+          T(HN_LO) = v & 0xffff; T(HN_HI) = v >> 16; T(HN_USED) = used;
+        }
       }
       free(ev);
       break;
@@ -1521,6 +1583,29 @@ static void memfinal_constraints(const uint32_t* l, const uint32_t* n, fe is_tra
    * statement about integers (all six limbs are looked up in the range table) */
   emit(s, f_mul(tn, f_sub(f_add(f_sub(f_sub(n[MF_LO], l[MF_LO]), one), f_mul(F65536, l[MF_BW])), l[MF_D_LO])));
   emit(s, f_mul(tn, f_sub(f_sub(f_sub(n[MF_HI], l[MF_HI]), l[MF_BW]), l[MF_D_HI])));
+  /* an address outside the image is hinted (IS_INIT) or starts as zero (IS_ZERO) */
+  const fe z = l[MF_IS_ZERO];
+  emit(s, bool_c(z));
+  emit(s, f_mul(z, f_sub(one, l[MF_IS_REAL])));
+  emit(s, f_mul(z, l[MF_IS_INIT]));
+  emit(s, f_mul(z, l[MF_INIT_LO]));
+  emit(s, f_mul(z, l[MF_INIT_HI]));
+}
+
+/* hint chip (machine.h) */
+static void hint_constraints(const uint32_t* l, const uint32_t* n, fe is_first, fe is_last, fe is_trans, sink* s) {
+  const fe real = l[HN_IS_REAL], first = l[HN_FIRST], last = l[HN_LAST], used = l[HN_USED];
+  emit(s, bool_c(real)); emit(s, bool_c(first)); emit(s, bool_c(last)); emit(s, bool_c(used));
+  emit(s, f_mul(f_add(f_add(first, last), used), f_sub(1, real)));
+  emit(s, f_mul(f_mul(is_trans, n[HN_IS_REAL]), f_sub(1, real)));
+  emit(s, f_mul(is_first, f_sub(real, first)));
+  emit(s, f_mul(last, f_sub(l[HN_CNT], 1)));
+  const fe go = f_mul(is_trans, f_sub(real, last));
+  emit(s, f_mul(go, f_sub(1, n[HN_IS_REAL])));
+  emit(s, f_mul(go, f_sub(f_sub(n[HN_ADDR], l[HN_ADDR]), 4)));
+  emit(s, f_mul(go, f_add(f_sub(n[HN_CNT], l[HN_CNT]), 1)));
+  emit(s, f_mul(is_trans, f_sub(n[HN_FIRST], f_mul(last, n[HN_IS_REAL]))));
+  emit(s, f_mul(is_last, f_sub(real, last)));
 }
 
 static void mul_constraints(const uint32_t* l, sink* s) {
@@ -2007,6 +2092,13 @@ static void ecall_constraints(const uint32_t* l, const uint32_t* pub, sink* s) {
   emit(s, f_sub(f_mul(real, f_sub(l[EC_NP], pc4)), f_mul(l[EC_SC + SC_HALT], f_sub(pub[CPUPUB_PAD_PC] % FP, pc4))));
   /* COMMIT / COMMIT_DEFERRED: the word index in a0 is the whole register (the PUBC tuple carries its low limb only) */
   emit(s, f_mul(f_add(l[EC_SC + SC_COMMIT], l[EC_SC + SC_DEFER]), l[EC_C_HI]));
+  /* HINT_READ: the number of words the read covers (NW is looked up as 16 bits) */
+  const fe hr = l[EC_SC + SC_HINT_READ], p1 = l[EC_P1], p2 = l[EC_P2];
+  emit(s, bool_c(p1));
+  emit(s, bool_c(p2));
+  emit(s, f_mul(f_add(p1, p2), f_sub(1, hr)));
+  emit(s, f_mul(f_sub(1, hr), l[EC_NW]));
+  emit(s, f_mul(hr, f_sub(f_sub(f_sub(f_sub(f_mul(4, l[EC_NW]), p1), f_add(p2, p2)), l[EC_M_LO]), f_mul(F65536, l[EC_M_HI]))));
 }
 
 static void run_constraints(int chip, const uint32_t* prep, const uint32_t* loc, const uint32_t* nxt, uint32_t is_first,
@@ -2032,6 +2124,7 @@ static void run_constraints(int chip, const uint32_t* prep, const uint32_t* loc,
     case CH_QR: qr_constraints(loc, nxt, is_first, is_trans, s); break;
     case CH_TR: tr_constraints(loc, nxt, is_first, is_trans, s); break;
     case CH_DIV: div_constraints(loc, s); break;
+    case CH_HINT: hint_constraints(loc, nxt, is_first, is_last, is_trans, s); break;
     case CH_TABLE: /* only multiples of 4 answer aligned lookups, only values 1 .. ADDR_HI_MAX high-address-limb lookups */
       emit(s, f_mul(loc[TB_M_AL], prep[TB_P_NA]));
       emit(s, f_mul(loc[TB_M_TOP], prep[TB_P_NT]));

@@ -43,7 +43,7 @@ extern "C" {
 #define CPU_INST 8
 enum {
   CH_CPU = 0, CH_KECCAK, CH_KMEM, CH_MEMFINAL, CH_IMAGE, CH_PROGRAM, CH_MUL, CH_TABLE, CH_CPU2, CH_ALU, CH_ALU2, CH_SUB,
-  CH_SUB2, CH_BW, CH_BW2, CH_P2, CH_ECALL, CH_CPU3, CH_CPU4, CH_CPU5, CH_CPU6, CH_CPU7, CH_CPU8, CH_QR, CH_DIV, CH_TR, N_CHIPS
+  CH_SUB2, CH_BW, CH_BW2, CH_P2, CH_ECALL, CH_CPU3, CH_CPU4, CH_CPU5, CH_CPU6, CH_CPU7, CH_CPU8, CH_QR, CH_DIV, CH_TR, CH_HINT, N_CHIPS
 };
 /* CPU instance i = 0 .. CPU_INST - 1 <-> chip (the first two keep their old places in the proof order) */
 static inline int orc_cpu_chip(int i) { return i == 0 ? CH_CPU : i == 1 ? CH_CPU2 : CH_CPU3 + (i - 2); }
@@ -94,7 +94,9 @@ enum { SC_HALT = 0, SC_WRITE, SC_COMMIT, SC_DEFER, SC_HINT_LEN, SC_HINT_READ };
 enum {
   EC_IS_REAL = 0, EC_SC /* 6 flags */, EC_TS = EC_SC + 6, EC_PC, EC_NP, EC_B_LO /* t0: the code */, EC_A_LO, EC_A_HI /* t0 afterwards */,
   EC_C_LO, EC_C_HI /* a0 */, EC_M_LO, EC_M_HI /* a1 */, EC_GAP /* a0, a1: access-time differences, low 16 bits and high 8 */,
-  ECALL_WIDTH = EC_GAP + 4
+  EC_NW = EC_GAP + 4 /* (format v16) a HINT_READ of a1 bytes covers NW = ceil(a1 / 4) words: 4 NW = a1 + P1 + 2 P2; it announces
+                        (a0, NW) to the hint chip */, EC_P1, EC_P2,
+  ECALL_WIDTH
 };
 
 /* ---- keccak chip: p3-keccak-air's 2633 columns (zksp_oracle.h KA_*) + the call time ---- */
@@ -109,8 +111,15 @@ enum {
 /* ---- memory boundary chip: EVERY image address and every other touched address once, strictly increasing ---- */
 enum {
   MF_IS_REAL = 0, MF_LO, MF_HI, MF_IS_INIT /* free initial value (not an image address) */, MF_INIT_LO, MF_INIT_HI,
-  MF_FIN_LO, MF_FIN_HI, MF_FIN_TS, MF_D_LO, MF_D_HI, MF_BW, MEMFINAL_WIDTH
+  MF_FIN_LO, MF_FIN_HI, MF_FIN_TS, MF_D_LO, MF_D_HI, MF_BW,
+  MF_IS_ZERO /* (format v16) an address outside the image that no HINT_READ covers: it starts as zero.  IS_INIT now means
+                "hinted": the initial value comes over the IMG bus from the hint chip, as an image word's comes from the image chip */,
+  MEMFINAL_WIDTH
 };
+/* ---- hint chip (format v16): one row per word of every HINT_READ, in address order within a read.  A read's first row takes
+ *      (pointer, number of words) from the ecall chip (HINTR bus); a row the run touches (USED) puts (address, initial value) on
+ *      the IMG bus.  Memory outside the image therefore starts with the prover's choice only where a HINT_READ put input ---- */
+enum { HN_IS_REAL = 0, HN_FIRST, HN_LAST, HN_ADDR, HN_CNT /* words of the read left, this one included */, HN_LO, HN_HI, HN_USED, HINT_WIDTH };
 /* ---- image chip: preprocessed (addr, lo, hi, is_real), main (used = is_real) ---- */
 enum { IMG_P_ADDR = 0, IMG_P_LO, IMG_P_HI, IMG_P_REAL, IMAGE_PREP_WIDTH };
 #define IMAGE_WIDTH 1
@@ -241,7 +250,7 @@ enum { TB_M_R16 = 0, TB_M_AL, TB_M_TOP, TB_M_BY, TB_M_XOR, TB_M_OR, TB_M_AND, TA
 
 /* ---- buses ---- */
 enum { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUBH, BUS_RANGE, BUS_BYTES, BUS_SUB, BUS_IMG, BUS_BYTEOP, BUS_DIGEST, BUS_ECALL, BUS_PAIR,
-       BUS_POS, BUS_ROOT, BUS_SEG, BUS_TBLK, BUS_TSQ, BUS_FINAL, BUS_ZETA, BUS_AF, BUS_BETA, BUS_POW, BUS_QIDX, BUS_LEAFK, BUS_BCONST };
+       BUS_POS, BUS_ROOT, BUS_SEG, BUS_TBLK, BUS_TSQ, BUS_FINAL, BUS_ZETA, BUS_AF, BUS_BETA, BUS_POW, BUS_QIDX, BUS_LEAFK, BUS_BCONST, BUS_HINTR };
 
 /* A linear form over the row [preprocessed | main]: c0 + sum coef[i] * row[col[i]] (canonical words). */
 #define LF_MAX 40
@@ -294,7 +303,7 @@ typedef struct {
   int log_prog, log_image;
   const uint32_t* cycles; size_t n_cycles;     /* 12 u32 per cycle */
   const uint8_t* keccak; size_t n_keccak;      /* 408 bytes per call */
-  const uint32_t* memfinal; size_t n_memfinal; /* 5 u32: addr, init, fin, fin_ts, is_init; row 0 is x0, closed at its last real access */
+  const uint32_t* memfinal; size_t n_memfinal; /* 5 u32: addr, init, fin, fin_ts, is_init (0 image, 1 hinted, 2 starts as zero); row 0 is x0, closed at its last real access */
   const uint32_t* muls; size_t n_muls;         /* 3 u32: kind (0 mul, 1 mulhu, 2 mulh, 3 mulhsu), b, c */
   const uint32_t* prog_mult;                   /* n_program; the padding row holds 0 (its fetches depend on the heights) */
   const int* shape;                            /* NULL: the minimal heights; else N_CHIPS log heights the run fits (a batch of

@@ -280,7 +280,7 @@ def prove(states_in: np.ndarray, logh: int, *, exit_code: int = 0, public_values
 # ---------------------------------------------------------------------------
 # machine proof (oracle/machine.h): inputs are the arrays ProverClient.machine_trace() returns
 # ---------------------------------------------------------------------------
-N_CHIPS = 26
+N_CHIPS = 27
 CHIP_NAMES = ["cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "table", "cpu2", "alu", "alu2",
               "subword", "subword2", "bitwise", "bitwise2", "poseidon2", "ecall"]
 CPUPUB_N = 5

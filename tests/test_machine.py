@@ -81,7 +81,8 @@ def test_memory_argument_balances(zk, fx, built_lib, mode):
     assert np.all(np.diff(mf[:, 0]) > 0)
     cons.append(tup(mf[:, 0], mf[:, 2], mf[:, 3]))
     prod.append(tup(mf[:, 0], mf[:, 1], np.zeros(len(mf), np.int64)))
-    ini = mf[:, 4] == 1
+    ini = mf[:, 4] != 0  # outside the image: 1 a hinted word, 2 a word that starts as zero
+    assert np.all(mf[mf[:, 4] == 2, 1] == 0)
     assert np.array_equal(mf[~ini, 0], img[:, 0]) and np.array_equal(mf[~ini, 1], img[:, 1])
     assert not np.intersect1d(mf[ini, 0], img[:, 0]).size
     untouched = (~ini) & (mf[:, 3] == 0)

@@ -300,6 +300,39 @@ def test_second_initial_value_is_rejected(zk, oracle, setup):
     assert "mem-final" in str(ei.value) or "balance" in str(ei.value)
 
 
+def test_fresh_memory_starts_as_zero_by_constraint(zk, oracle, setup):
+    """Format v16, the hint chip: memory outside the program image starts with contents of the prover's choice ONLY where a
+    HINT_READ put input - every other address starts as zero, by constraint (round 4 left that to the tracer and to a test
+    showing the committed guest does not depend on it).  A stack / heap word given a non-zero initial value is refused by
+    the verifier whichever way the records claim it: as a word that starts as zero (the boundary chip's own constraint), or
+    as a hinted word (no row of the hint chip covers its address, so nobody puts its tuple on the IMG bus); and a hinted
+    word's value is the one the hint chip holds for it."""
+    client, vk, t, _ = setup
+    mf = t["memfinal"]
+    assert set(int(x) for x in mf[:, 4]) == {0, 1, 2} and np.all(mf[mf[:, 4] == 2, 1] == 0)
+    k = int(np.nonzero((mf[:, 4] == 2) & (mf[:, 3] > 0))[0][7])  # a fresh word the run touches
+    for claim in (2, 1):
+        m2 = mf.copy()
+        m2[k, 1] = 0x00C0FFEE
+        m2[k, 4] = claim
+        _rejected(zk, oracle, client, vk, dict(t, memfinal=m2))
+    # the hint chip's rows follow from the run's HINT_READs: their words are exactly the memory-boundary rows flagged 1
+    import importlib
+    zkm = importlib.import_module("zk-state-proofs_amd")
+    chip = zkm.MACHINE_CHIP_NAMES.index("hint")
+    _prep, tr = oracle.machine_fill(t, chip)
+    real = tr[0] == 1
+    assert real.sum() == sum((int(c[4]) + 3) // 4 for c in t["cycles"][t["ecall_idx"]] if c[2] == 0xF1)
+    used = tr[:, real & (tr[7] == 1)]
+    hinted = mf[mf[:, 4] == 1]
+    assert np.array_equal(used[3], hinted[:, 0]) and np.array_equal(used[5] + 65536 * used[6], hinted[:, 1])
+    # a hinted word claimed to start as zero: the hint chip's tuple for it is never received
+    kh = int(np.nonzero((mf[:, 4] == 1) & (mf[:, 1] != 0))[0][3])
+    m3 = mf.copy()
+    m3[kh, 1], m3[kh, 4] = 0, 2
+    _rejected(zk, oracle, client, vk, dict(t, memfinal=m3))
+
+
 def test_image_word_cannot_be_reinitialised(zk, oracle, setup):
     """The round-2 attack on the memory image: withhold a .rodata word (the stack-top constant at 0x228398, SURVEY
     appendix A.1) from the image chip and let the memory-boundary chip initialise it with a value of the prover's

@@ -33,7 +33,7 @@ PROOF_MACHINE, PROOF_KECCAK_CHIP = 1, 2
 MACHINE_VERSION = 16
 MACHINE_CHIP_NAMES = ("cpu", "keccak", "keccak-mem", "mem-final", "image", "program", "mul", "table", "cpu2", "alu", "alu2",
                       "subword", "subword2", "bitwise", "bitwise2", "poseidon2", "ecall", "cpu3", "cpu4", "cpu5", "cpu6", "cpu7",
-                      "cpu8", "query", "divider", "transcript")
+                      "cpu8", "query", "divider", "transcript", "hint")
 MACHINE_CHIPS = len(MACHINE_CHIP_NAMES)
 MACHINE_CPU_INSTANCES = 8  # cpu, cpu2 .. cpu8: one AIR, consecutive stretches of the run
 # magic, version, heights, exit code, pv length, three digests, the pcs at which the later CPU instances start, the

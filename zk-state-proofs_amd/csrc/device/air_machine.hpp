@@ -31,7 +31,7 @@ namespace mach {
 // so the trees, the quotient and the FRI domain have a quarter of the height and the per-row costs of a commitment are
 // shared by six instances.
 enum Chip { kCpu = 0, kKeccak, kKmem, kMemFinal, kImage, kProgram, kMul, kTable, kCpu2, kAlu, kAlu2, kSub, kSub2, kBw, kBw2, kP2, kEcall,
-            kCpu3, kCpu4, kCpu5, kCpu6, kCpu7, kCpu8, kQr, kDiv, kTr, kNumChips };
+            kCpu3, kCpu4, kCpu5, kCpu6, kCpu7, kCpu8, kQr, kDiv, kTr, kHint, kNumChips };
 constexpr int kNumCpuInst = 8;
 // CPU instance i <-> chip (the first two keep their old places in the proof order)
 ZKSP_HD constexpr int cpu_chip(int i) { return i == 0 ? kCpu : i == 1 ? kCpu2 : kCpu3 + (i - 2); }
@@ -87,10 +87,11 @@ constexpr int C_PC = 0, C_TS = 1, C_NEXT_PC = 2, C_SEL = 3, C_CODE = C_SEL + kNu
 static_assert(kCpuWidth == 52, "CPU chip layout: three accesses per row, seven Poseidon2 absorptions");
 // ---- ecall chip: one row per ecall (the CPU row of an ecall moves t0 only and hands the rest over on the ECALL bus) ----
 enum { SC_HALT = 0, SC_WRITE, SC_COMMIT, SC_DEFER, SC_HINT_LEN, SC_HINT_READ };
+//      (format v16: a HINT_READ of len bytes at ptr announces its NW = ceil(len / 4) words to the hint chip: 4 NW = len + P1 + 2 P2)
 constexpr int EC_IS_REAL = 0, EC_SC = 1, EC_TS = EC_SC + 6, EC_PC = EC_TS + 1, EC_NP = EC_TS + 2, EC_B_LO = EC_TS + 3, EC_A_LO = EC_TS + 4,
               EC_A_HI = EC_TS + 5, EC_C_LO = EC_TS + 6, EC_C_HI = EC_TS + 7, EC_M_LO = EC_TS + 8, EC_M_HI = EC_TS + 9, EC_GAP = EC_TS + 10,
-              kEcallWidth = EC_GAP + 4;
-static_assert(kEcallWidth == 21, "ecall chip layout");
+              EC_NW = EC_GAP + 4, EC_P1 = EC_NW + 1, EC_P2 = EC_NW + 2, kEcallWidth = EC_NW + 3;
+static_assert(kEcallWidth == 24, "ecall chip layout");
 ZKSP_HD constexpr int selc(int cls) { return C_SEL + cls - 1; }
 
 // ---- keccak chip: p3-keccak-air's columns + the call time ----
@@ -101,7 +102,15 @@ constexpr int KM_IS_REAL = 0, KM_TS = 1, KM_PTR_LO = 2, KM_PTR_HI = 3, KM_IDX = 
               kKmemWidth = 16;
 // ---- memory boundary chip: EVERY image address and every other touched address once, strictly increasing ----
 constexpr int MF_IS_REAL = 0, MF_LO = 1, MF_HI = 2, MF_IS_INIT = 3, MF_INIT_LO = 4, MF_INIT_HI = 5, MF_FIN_LO = 6, MF_FIN_HI = 7,
-              MF_FIN_TS = 8, MF_D_LO = 9, MF_D_HI = 10, MF_BW = 11, kMemFinalWidth = 12;
+              MF_FIN_TS = 8, MF_D_LO = 9, MF_D_HI = 10, MF_BW = 11,
+              // format v16: IS_INIT - a hinted word: its initial value comes from the hint chip (over the IMG bus, as an image
+              // word's comes from the image chip); IS_ZERO - any other address outside the image: it starts as zero
+              MF_IS_ZERO = 12, kMemFinalWidth = 13;
+// ---- hint chip (format v16): one row per word of every HINT_READ, in address order within a read: the read's first row takes
+//      (pointer, number of words) from the ecall chip; a row the run touches (USED) puts (address, initial value) on the IMG
+//      bus, where the memory boundary chip takes a hinted word's initial value from - so memory outside the image starts with
+//      the prover's choice ONLY where a HINT_READ put input, and with zero everywhere else ----
+constexpr int HN_IS_REAL = 0, HN_FIRST = 1, HN_LAST = 2, HN_ADDR = 3, HN_CNT = 4, HN_LO = 5, HN_HI = 6, HN_USED = 7, kHintWidth = 8;
 // ---- image / program chips: preprocessed columns, one main column ----
 constexpr int IMG_P_ADDR = 0, IMG_P_LO = 1, IMG_P_HI = 2, IMG_P_REAL = 3, kImagePrepWidth = 4, kImageWidth = 1;
 constexpr int PR_PC = 0, PR_CLS = 1, PR_CODE = 2, PR_UC = 3, PR_WR = 4, PR_USE2 = 5, PR_RD = 6, PR_RS1 = 7, PR_RS2 = 8, PR_IMM_LO = 9,
@@ -204,7 +213,8 @@ enum Bus { BUS_MEM = 1, BUS_PROG, BUS_KCALL, BUS_KIO, BUS_ALU, BUS_PUBC, BUS_PUB
            // stage 2b: a run's position -> query chip; commitment roots; a matrix row's Horner sum; the transcript's blocks and
            // squeezes (verifier -> transcript chip); final constant; zeta; alpha_f, delta; FRI betas; the proof-of-work word
            // (-> verifier); query index words; per leaf constants and per height constants (verifier -> query chip)
-           BUS_POS, BUS_ROOT, BUS_SEG, BUS_TBLK, BUS_TSQ, BUS_FINAL, BUS_ZETA, BUS_AF, BUS_BETA, BUS_POW, BUS_QIDX, BUS_LEAFK, BUS_BCONST };
+           BUS_POS, BUS_ROOT, BUS_SEG, BUS_TBLK, BUS_TSQ, BUS_FINAL, BUS_ZETA, BUS_AF, BUS_BETA, BUS_POW, BUS_QIDX, BUS_LEAFK, BUS_BCONST,
+           BUS_HINTR /* (pointer, words): ecall chip -> hint chip */ };
 
 // Ctx interface:
 //   using F;  F local(int col); F next(int col); F prep(int col) (preprocessed column of the row);
@@ -393,8 +403,15 @@ ZKSP_HD void eval_ecall(Ctx& ctx) {
   ctx.emit(real * (L(EC_NP) - pc4) - L(EC_SC + SC_HALT) * (ctx.pub(kPubPadPc) - pc4));
   // COMMIT / COMMIT_DEFERRED: the word index in a0 is the whole register (the PUBC tuple carries its low limb only)
   ctx.emit((L(EC_SC + SC_COMMIT) + L(EC_SC + SC_DEFER)) * L(EC_C_HI));
+  // HINT_READ: the number of words the read covers (NW is looked up as 16 bits: at most 2^18 bytes per read)
+  const F hr = L(EC_SC + SC_HINT_READ), p1 = L(EC_P1), p2 = L(EC_P2);
+  ctx.emit(bool_c(p1, one));
+  ctx.emit(bool_c(p2, one));
+  ctx.emit((p1 + p2) * (one - hr));
+  ctx.emit((one - hr) * L(EC_NW));
+  ctx.emit(hr * (ZKSP_K(4) * L(EC_NW) - p1 - p2.dbl() - L(EC_M_LO) - ZKSP_K(65536) * L(EC_M_HI)));
 }
-constexpr int kEcallConstraints = 13;
+constexpr int kEcallConstraints = 18;
 
 template <class Ctx>
 ZKSP_HD void eval_kmem(Ctx& ctx) {
@@ -434,8 +451,35 @@ ZKSP_HD void eval_memfinal(Ctx& ctx) {
   // statement about integers (all six limbs are looked up in the table chip)
   ctx.emit(tn * (ctx.next(MF_LO) - L(MF_LO) - one + ZKSP_K(65536) * L(MF_BW) - L(MF_D_LO)));
   ctx.emit(tn * (ctx.next(MF_HI) - L(MF_HI) - L(MF_BW) - L(MF_D_HI)));
+  // an address outside the image is hinted (IS_INIT) or starts as zero (IS_ZERO)
+  const F z = L(MF_IS_ZERO);
+  ctx.emit(bool_c(z, one));
+  ctx.emit(z * (one - L(MF_IS_REAL)));
+  ctx.emit(z * L(MF_IS_INIT));
+  ctx.emit(z * L(MF_INIT_LO));
+  ctx.emit(z * L(MF_INIT_HI));
 }
-constexpr int kMemFinalConstraints = 7;
+constexpr int kMemFinalConstraints = 12;
+
+// ---- hint chip ----
+template <class Ctx>
+ZKSP_HD void eval_hint(Ctx& ctx) {
+  using F = typename Ctx::F;
+  const F one = ctx.k(kR1), real = L(HN_IS_REAL), first = L(HN_FIRST), last = L(HN_LAST), used = L(HN_USED);
+  ctx.emit(bool_c(real, one)); ctx.emit(bool_c(first, one)); ctx.emit(bool_c(last, one)); ctx.emit(bool_c(used, one));
+  ctx.emit((first + last + used) * (one - real));
+  ctx.emit(ctx.is_trans() * ctx.next(HN_IS_REAL) * (one - real));  // the real rows are a prefix
+  ctx.emit(ctx.is_first() * (real - first));
+  ctx.emit(last * (L(HN_CNT) - one));
+  // a read goes on word by word until its count is used up; what follows a read's last word starts another (or is padding)
+  const F go = ctx.is_trans() * (real - last);
+  ctx.emit(go * (one - ctx.next(HN_IS_REAL)));
+  ctx.emit(go * (ctx.next(HN_ADDR) - L(HN_ADDR) - ZKSP_K(4)));
+  ctx.emit(go * (ctx.next(HN_CNT) - L(HN_CNT) + one));
+  ctx.emit(ctx.is_trans() * (ctx.next(HN_FIRST) - last * ctx.next(HN_IS_REAL)));
+  ctx.emit(ctx.is_last() * (real - last));
+}
+constexpr int kHintConstraints = 13;
 
 template <class Ctx>
 ZKSP_HD void eval_mul(Ctx& ctx) {
@@ -1167,7 +1211,7 @@ constexpr int kKeccakConstraints = ka::kNumConstraints + 1;
 ZKSP_HD constexpr int num_constraints(int chip) {
   return is_cpu_chip(chip) ? kCpuConstraints : chip == kKeccak ? kKeccakConstraints : chip == kKmem ? kKmemConstraints
        : chip == kMemFinal ? kMemFinalConstraints : chip == kImage ? 1 : chip == kProgram ? 0 : chip == kMul ? kMulConstraints
-       : chip == kTable ? 2 : is_alu_chip(chip) ? kAluConstraints : is_sub_chip(chip) ? kSubConstraints : is_bw_chip(chip) ? kBwConstraints : chip == kP2 ? kP2Constraints : chip == kEcall ? kEcallConstraints : chip == kQr ? kQrConstraints : chip == kTr ? kTrConstraints : chip == kDiv ? kDivConstraints : 0;
+       : chip == kTable ? 2 : is_alu_chip(chip) ? kAluConstraints : is_sub_chip(chip) ? kSubConstraints : is_bw_chip(chip) ? kBwConstraints : chip == kP2 ? kP2Constraints : chip == kEcall ? kEcallConstraints : chip == kQr ? kQrConstraints : chip == kTr ? kTrConstraints : chip == kHint ? kHintConstraints : chip == kDiv ? kDivConstraints : 0;
 }
 
 }  // namespace mach

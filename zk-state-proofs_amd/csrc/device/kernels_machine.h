@@ -17,7 +17,7 @@ struct Seg {
   size_t bstride;
   int width;
 };
-constexpr int kMaxSegs = 26;  // at least kNumChips: every chip could have the same height
+constexpr int kMaxSegs = 27;  // at least kNumChips: every chip could have the same height
 static_assert(kMaxSegs >= mach::kNumChips, "a height group may hold every chip");
 
 // ---- trace expansion (row a3 of the machine proof) ----
@@ -38,8 +38,8 @@ struct MachineRecords {
   const uint32_t* tr_rows;     // [B][cap_tr][kTrRecWords]: one record per row of the transcript chip
   const P2Consts* consts;      // Poseidon2 constants (the Poseidon2 chip's rows are permutations)
   const uint32_t* prog_mult;   // [B][2^log_prog]; the padding row (n_program - 1) holds 0: its fetches follow from cpu_rows
-  const uint32_t* counts;      // [B][13]: cycles, keccak calls, memfinal rows, muls, ALU rows, sub-word rows, last time x0 was
-                               //          accessed by a real cycle, bitwise rows, Poseidon2-chip rows, ecalls, query-chip rows, divider rows, transcript-chip rows
+  const uint32_t* counts;      // [B][14]: cycles, keccak calls, memfinal rows, muls, ALU rows, sub-word rows, last time x0 was
+                               //          accessed by a real cycle, bitwise rows, Poseidon2-chip rows, ecalls, query-chip rows, divider rows, transcript-chip rows, hint-chip rows
   uint32_t* table_hist;        // [B][kTableWidth][2^16] scratch: multiplicities of the table chip, counted on the device
   uint32_t row0[mach::kNumChips];  // first cycle / event of the chip's instance (second instances: rows of the first)
   size_t cap_cycles, cap_keccak, cap_memfinal, cap_muls, cap_alu, cap_sub, cap_bw, cap_agg, cap_ecall, cap_fold, cap_div, cap_tr;
@@ -47,7 +47,7 @@ struct MachineRecords {
   uint32_t text_base, n_program, n_image;
   uint32_t cpu_rows;           // rows of the two CPU instances together: the rows past the last cycle fetch the padding instruction
 };
-constexpr int kCountWords = 13;
+constexpr int kCountWords = 14;
 // trace: [B][main_width][2^logh] of the given chip (every chip but kKeccak and kTable)
 void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& rec, uint32_t* trace, int logh, int batch);
 // keccak chip: p3-keccak-air's columns by launch_keccak_trace (kernels.h, with a batch stride), then the call time

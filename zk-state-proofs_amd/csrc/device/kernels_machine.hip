@@ -182,6 +182,50 @@ __global__ __launch_bounds__(kMT) void ecall_trace_kernel(MachineRecords rec, ui
   o.limbs(EC_M_LO, m);
   o.limbs(EC_GAP, ts - cy[8]);
   o.limbs(EC_GAP + 2, ts + 1 - cy[9]);
+  // a HINT_READ of m bytes covers NW = ceil(m / 4) words: 4 NW = m + P1 + 2 P2
+  const uint32_t nw = sc == 5 ? (m + 3) / 4 : 0u, padb = sc == 5 ? 4 * nw - m : 0u;
+  o.val(EC_NW, nw);
+  o.flag(EC_P1, (padb & 1u) != 0);
+  o.flag(EC_P2, (padb & 2u) != 0);
+}
+
+// The hint chip: row r is the r-th word the run's HINT_READs cover, in the order of the reads: its address, how many words of its
+// read are left (itself included), and - where the run touches it (the memory boundary list has the address) - its initial value
+__global__ __launch_bounds__(kMT) void hint_trace_kernel(MachineRecords rec, uint32_t* __restrict__ trace, int logh) {
+  const size_t h = (size_t)1 << logh;
+  const size_t r = (size_t)blockIdx.x * kMT + threadIdx.x;
+  if (r >= h) return;
+  const int b = blockIdx.y;
+  const Col o{trace + (size_t)b * kHintWidth * h + r, h};
+  if (r >= rec.counts[kCountWords * b + 13]) { o.zero(0, kHintWidth); return; }
+  // which read: the HINT_READ ecalls in execution order (a run has one or two)
+  const uint32_t n_ecall = rec.counts[kCountWords * b + 9];
+  uint32_t before = 0, ptr = 0, nw = 0;
+  for (uint32_t e = 0; e < n_ecall; ++e) {
+    const uint32_t* cy = rec.cycles + ((size_t)b * rec.cap_cycles + rec.ecall_idx[(size_t)b * rec.cap_ecall + e]) * 12;
+    if (cy[2] != 0xf1) continue;
+    const uint32_t w = (cy[4] + 3) / 4;
+    if (r < before + w) { ptr = cy[3]; nw = w; break; }
+    before += w;
+  }
+  const uint32_t j = (uint32_t)r - before, addr = ptr + 4 * j;
+  // is the address on the memory boundary list (sorted by address)?
+  const uint32_t n = rec.counts[kCountWords * b + 2];
+  const uint32_t* mf = rec.memfinal + (size_t)b * rec.cap_memfinal * 5;
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (mf[5 * (size_t)mid] < addr) lo = mid + 1;
+    else hi = mid;
+  }
+  const bool used = lo < n && mf[5 * (size_t)lo] == addr;
+  o.put(HN_IS_REAL, kR1);
+  o.flag(HN_FIRST, j == 0);
+  o.flag(HN_LAST, j + 1 == nw);
+  o.val(HN_ADDR, addr);
+  o.val(HN_CNT, nw - j);
+  o.limbs(HN_LO, used ? mf[5 * (size_t)lo + 1] : 0u);
+  o.flag(HN_USED, used);
 }
 
 // One ALU-chip instance: row r is event row0 + r of the list alu_idx (cycle indices)
@@ -473,7 +517,8 @@ __global__ __launch_bounds__(kMT) void memfinal_trace_kernel(MachineRecords rec,
   const uint32_t* f = rec.memfinal + ((size_t)b * rec.cap_memfinal + r) * 5;
   o.put(MF_IS_REAL, kR1);
   o.limbs(MF_LO, f[0]);
-  o.flag(MF_IS_INIT, f[4] != 0);
+  o.flag(MF_IS_INIT, f[4] == 1);
+  o.flag(MF_IS_ZERO, f[4] == 2);
   o.limbs(MF_INIT_LO, f[1]);
   o.limbs(MF_FIN_LO, f[2]);
   // x0 (row 0) is read once more by every CPU row after the last cycle: its last access is the last row's
@@ -621,6 +666,7 @@ void launch_machine_trace(hipStream_t stream, int chip, const MachineRecords& re
       break;
     case kEcall: hipLaunchKernelGGL(ecall_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
     case kQr: hipLaunchKernelGGL(qr_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
+    case kHint: hipLaunchKernelGGL(hint_trace_kernel, grid, block, 0, stream, rec, trace, logh); break;
     case kTr:
       hipLaunchKernelGGL(tr_trace_kernel, dim3((unsigned)((h + 63) / 64), batch), dim3(64), 0, stream, rec, trace, logh);
       break;
@@ -1705,6 +1751,7 @@ __global__ __launch_bounds__(kMT) void machine_quotient_kernel(MQuotArgs a) {
   else if constexpr (CHIP == kEcall) eval_ecall(ctx);
   else if constexpr (CHIP == kQr) eval_qr(ctx);
   else if constexpr (CHIP == kTr) eval_tr(ctx);
+  else if constexpr (CHIP == kHint) eval_hint(ctx);
   else if constexpr (CHIP == kDiv) eval_div(ctx);
   ctx.flush();
   logup_constraints(a, pi, &ctx.acc);
@@ -1858,6 +1905,7 @@ void launch_machine_quotient(hipStream_t stream, const MQuotArgs& a) {
     case kEcall: hipLaunchKernelGGL(machine_quotient_kernel<kEcall>, grid, block, 0, stream, a); break;
     case kQr: hipLaunchKernelGGL(machine_quotient_kernel<kQr>, grid, block, 0, stream, a); break;
     case kTr: hipLaunchKernelGGL(machine_quotient_kernel<kTr>, grid, block, 0, stream, a); break;
+    case kHint: hipLaunchKernelGGL(machine_quotient_kernel<kHint>, grid, block, 0, stream, a); break;
     case kDiv: hipLaunchKernelGGL(machine_quotient_kernel<kDiv>, grid, block, 0, stream, a); break;
     case kKmem: hipLaunchKernelGGL(machine_quotient_kernel<kKmem>, grid, block, 0, stream, a); break;
     case kMemFinal: hipLaunchKernelGGL(machine_quotient_kernel<kMemFinal>, grid, block, 0, stream, a); break;

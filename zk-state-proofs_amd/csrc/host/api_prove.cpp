@@ -193,6 +193,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       lh[mach::kP2] = clog2(t.p2_rows() + 1);
       lh[mach::kQr] = clog2(t.qr_rows() + 1);
       lh[mach::kTr] = clog2(t.tr_rows() + 1);
+      lh[mach::kHint] = 0;
       // (the small chips do not split a group: a run with 513 multiplications shares the shape of one with 511, the
       // cover gives both the taller multiplier chip)
       lh[mach::kEcall] = 0;

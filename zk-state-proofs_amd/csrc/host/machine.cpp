@@ -256,7 +256,8 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
         memset(M + w, uninit_fill, 4);
         memcpy(&v, M + w, 4);
       }
-      touched.push_back({w, v, 0, ir < 0 ? 1u : 0u, known ? 0xfu : 0u});
+      // (is_init: 0 an image word, 1 a hinted word - its initial value is the input's -, 2 any other address: it starts as zero)
+      touched.push_back({w, v, 0, ir >= 0 ? 0u : known ? 1u : 2u, known ? 0xfu : 0u});
       id = (uint32_t)touched.size();
       SH[w >> 2] = id;
     }
@@ -408,6 +409,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
               const auto& e = stdin_entries[stdin_pos];
               if (a1 != e.size()) FAULT("HINT_READ: length mismatch");
               if (a0 & 3) FAULT("HINT_READ: unaligned pointer");
+              if (a1 == 0 || a1 > (1u << 18) - 4) FAULT("HINT_READ: a read of no bytes, or of more than 2^18, has no rows in the hint chip");
               CHECK_ADDR(a0, (a1 + 3) & ~3u);
               // hinted words become the INITIAL memory contents of the proof (SP1 treats hint_read the same
               // way): they must not have been accessed before, and must lie outside the program image
@@ -415,6 +417,7 @@ void trace_execute(const ElfImage& elf, const MachineProgram& prog, const std::v
                 if (SH[w >> 2] != 0 || image_row(w) >= 0 || w < kRegSpace) FAULT("HINT_READ into memory that is already in use");
               memcpy(M + a0, e.data(), e.size());
               hinted.emplace_back(a0, a0 + ((a1 + 3) & ~3u));
+              out->hint_words += (a1 + 3) / 4;
               ++stdin_pos;
               break;
             }

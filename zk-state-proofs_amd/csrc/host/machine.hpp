@@ -73,7 +73,7 @@ struct KeccakCall {
   uint32_t pts[50];
 };
 struct MemFinalRec {
-  uint32_t addr, init, fin, fin_ts, is_init;
+  uint32_t addr, init, fin, fin_ts, is_init;  // is_init: 0 an image word, 1 a hinted word (a HINT_READ covers it), 2 any other: starts as zero
 };
 struct MulRec {
   uint32_t hi, b, c;  // hi: 0 mul, 1 mulhu, 2 mulh, 3 mulhsu (also: the |q| * |d| products the divider chip asks for, as 0 and 1)
@@ -136,6 +136,7 @@ struct MachineTrace {
   std::vector<uint32_t> ecall_idx;    // the ecall cycles (one row of the ecall chip each), in order
   std::vector<uint32_t> div_idx;      // cycles that occupy a row of the divider chip (div divu rem remu), in order
   uint32_t x0_last = 0;               // last access time of x0 by a real cycle (the first padding row consumes it)
+  size_t hint_words = 0;              // words covered by the run's HINT_READs: the rows of the hint chip
   std::vector<uint32_t> agg_leaves;   // aggregation payload (row f4): 8 canonical words per supplied digest, or none
   std::vector<uint32_t> agg_keys;     // their heap keys (empty: n + j, the leaves of a full tree of n = a power of two)
   size_t agg_rows = 0;                // node rows of the Poseidon2 chip: the ancestors of the supplied keys (set with the payload)
@@ -147,15 +148,15 @@ struct MachineTrace {
 
 // How many rows of each event-sized chip a run needs; a batch is proven with the heights of the element-wise maximum.
 struct MachineCounts {
-  size_t cycles = 0, alu = 0, sub = 0, bw = 0, keccak = 0, memfinal = 0, muls = 0, agg = 0 /* Poseidon2 chip rows */, ecall = 0, fold = 0 /* query chip rows */, div = 0, tr = 0 /* transcript chip rows */;
+  size_t cycles = 0, alu = 0, sub = 0, bw = 0, keccak = 0, memfinal = 0, muls = 0, agg = 0 /* Poseidon2 chip rows */, ecall = 0, fold = 0 /* query chip rows */, div = 0, tr = 0 /* transcript chip rows */, hint = 0 /* hint chip rows */;
   void cover(const MachineTrace& t) {
     cycles = std::max(cycles, t.cycles.size()); alu = std::max(alu, t.alu_idx.size()); sub = std::max(sub, t.sub_idx.size());
-    bw = std::max(bw, t.bw_idx.size()); agg = std::max(agg, t.p2_rows()); ecall = std::max(ecall, t.ecall_idx.size()); fold = std::max(fold, t.qr_rows()); tr = std::max(tr, t.tr_rows()); div = std::max(div, t.div_idx.size());
+    bw = std::max(bw, t.bw_idx.size()); agg = std::max(agg, t.p2_rows()); ecall = std::max(ecall, t.ecall_idx.size()); fold = std::max(fold, t.qr_rows()); tr = std::max(tr, t.tr_rows()); hint = std::max(hint, t.hint_words); div = std::max(div, t.div_idx.size());
     keccak = std::max(keccak, t.keccak.size()); memfinal = std::max(memfinal, t.memfinal.size()); muls = std::max(muls, t.muls.size());
   }
   void cover(const MachineCounts& o) {
     cycles = std::max(cycles, o.cycles); alu = std::max(alu, o.alu); sub = std::max(sub, o.sub); bw = std::max(bw, o.bw);
-    agg = std::max(agg, o.agg); ecall = std::max(ecall, o.ecall); keccak = std::max(keccak, o.keccak); fold = std::max(fold, o.fold); tr = std::max(tr, o.tr); div = std::max(div, o.div);
+    agg = std::max(agg, o.agg); ecall = std::max(ecall, o.ecall); keccak = std::max(keccak, o.keccak); fold = std::max(fold, o.fold); tr = std::max(tr, o.tr); hint = std::max(hint, o.hint); div = std::max(div, o.div);
     memfinal = std::max(memfinal, o.memfinal); muls = std::max(muls, o.muls);
   }
 };

@@ -23,6 +23,7 @@
 //   POW    (leaf, word)   transcript chip -> verifier: the proof-of-work sample
 //   QIDX   (leaf, query, word)   transcript chip -> query chip: the word a query's index is the low bits of
 //   LEAFK  (leaf, last layer, 1 / omega), BCONST (leaf, layer, has preprocessed, w_H, B1[4], B2[4])   verifier -> query chip
+//   HINTR  (pointer, words)   ecall chip (a HINT_READ) -> hint chip, which puts the words it covers on the IMG bus
 #include "machine_defs.hpp"
 
 #include <cstdlib>
@@ -101,7 +102,7 @@ Interaction bytes_inter(int sign, const LinForm& mult, const LinForm& x, const L
 }
 
 constexpr int kCpuInter = 19;
-Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[5], g_div[13], g_table[7], g_alu[1], g_sub[5], g_bw[5], g_p2[10], g_ecall[10], g_qr[17], g_tr[16];
+Interaction g_cpu[kCpuInter], g_keccak[50], g_kmem[8], g_memfinal[10], g_image[1], g_program[1], g_mul[5], g_div[13], g_table[7], g_alu[1], g_sub[5], g_bw[5], g_p2[10], g_ecall[12], g_qr[17], g_tr[16], g_hint[2];
 ChipDef g_chips[kNumChips];
 
 void build() {
@@ -218,7 +219,26 @@ void build() {
     ph = Interaction{};
     ph.bus = BUS_PUBH; ph.sign = +1; ph.mult = lf_col(EC_SC + SC_HALT); ph.n_el = 2;
     ph.el[0] = ec_lo; ph.el[1] = ec_hi;
+    // a HINT_READ announces (pointer, words) to the hint chip; the word count is a 16-bit value
+    Interaction& hr = g_ecall[10];
+    hr = Interaction{};
+    hr.bus = BUS_HINTR; hr.sign = +1; hr.mult = lf_col(EC_SC + SC_HINT_READ); hr.n_el = 2;
+    hr.el[0] = lf_pair(EC_C_LO, EC_C_HI, 65536); hr.el[1] = lf_col(EC_NW);
+    g_ecall[11] = range_inter(-1, lf_col(EC_SC + SC_HINT_READ), lf_const(0), lf_col(EC_NW));
   }
+  {
+    // hint chip: a read's first word takes the announcement; a word the run touches hands its initial value to the memory
+    // boundary chip over the IMG bus
+    Interaction& rc = g_hint[0];
+    rc = Interaction{};
+    rc.bus = BUS_HINTR; rc.sign = -1; rc.mult = lf_col(HN_FIRST); rc.n_el = 2;
+    rc.el[0] = lf_col(HN_ADDR); rc.el[1] = lf_col(HN_CNT);
+    Interaction& im = g_hint[1];
+    im = Interaction{};
+    im.bus = BUS_IMG; im.sign = +1; im.mult = lf_col(HN_USED); im.n_el = 3;
+    im.el[0] = lf_col(HN_ADDR); im.el[1] = lf_col(HN_LO); im.el[2] = lf_col(HN_HI);
+  }
+  g_chips[kHint] = {"hint", 0, kHintWidth, 2, g_hint, kHintConstraints, 0};
   for (int i = 0; i < 50; ++i) {
     Interaction& it = g_keccak[i];
     it = Interaction{};
@@ -254,7 +274,7 @@ void build() {
     g_memfinal[1] = mem_inter(+1, real, addr, lf_col(MF_INIT_LO), lf_col(MF_INIT_HI), zero);
     Interaction& im = g_memfinal[2];
     im = Interaction{};
-    im.bus = BUS_IMG; im.sign = -1; im.mult = lf_pair(MF_IS_REAL, MF_IS_INIT, kP - 1); im.n_el = 3;
+    im.bus = BUS_IMG; im.sign = -1; im.mult = lf_pair(MF_IS_REAL, MF_IS_ZERO, kP - 1); im.n_el = 3;  // an image word (image chip) or a hinted one (hint chip)
     im.el[0] = addr; im.el[1] = lf_col(MF_INIT_LO); im.el[2] = lf_col(MF_INIT_HI);
     g_memfinal[3] = range_inter(-1, real, zero, lf_col(MF_LO));
     g_memfinal[4] = range_inter(-1, real, zero, lf_col(MF_HI));
@@ -653,7 +673,7 @@ void build() {
     static const char* const names[kNumCpuInst] = {"cpu", "cpu2", "cpu3", "cpu4", "cpu5", "cpu6", "cpu7", "cpu8"};
     for (int i = 2; i < kNumCpuInst; ++i) g_chips[cpu_chip(i)] = {names[i], 0, kCpuWidth, kCpuInter, g_cpu, kCpuConstraints, 5};
   }
-  g_chips[kEcall] = {"ecall", 0, kEcallWidth, 10, g_ecall, kEcallConstraints, 0};
+  g_chips[kEcall] = {"ecall", 0, kEcallWidth, 12, g_ecall, kEcallConstraints, 0};
   g_chips[kKeccak] = {"keccak", 0, kKeccakWidth, 50, g_keccak, kKeccakConstraints, 0};
   g_chips[kKmem] = {"keccak-mem", 0, kKmemWidth, 8, g_kmem, kKmemConstraints, 0};
   g_chips[kMemFinal] = {"mem-final", 0, kMemFinalWidth, 10, g_memfinal, kMemFinalConstraints, 0};

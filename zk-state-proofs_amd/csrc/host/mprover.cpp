@@ -351,6 +351,7 @@ void machine_heights(const MachineProgram& prog, const MachineCounts& n, int log
   logh[kEcall] = at_least5(ceil_log2(n.ecall));
   logh[kQr] = at_least5(ceil_log2(n.fold ? n.fold : 1));
   logh[kTr] = at_least5(ceil_log2(n.tr ? n.tr : 1));
+  logh[kHint] = at_least5(ceil_log2(n.hint ? n.hint : 1));
   logh[kDiv] = at_least5(ceil_log2(n.div));
 }
 void machine_heights(const MachineProgram& prog, const MachineTrace& t, int logh[kNumChips]) {
@@ -362,7 +363,7 @@ bool machine_fits(const MachineTrace& t, const int* logh) {
   auto two = [&](int a, int b) { return ((size_t)1 << logh[a]) + ((size_t)1 << logh[b]); };
   auto one = [&](int a) { return (size_t)1 << logh[a]; };
   return t.cycles.size() <= machine_cpu_row0(logh, kNumCpuInst) && t.alu_idx.size() <= two(kAlu, kAlu2) && t.sub_idx.size() <= two(kSub, kSub2) &&
-         t.bw_idx.size() <= two(kBw, kBw2) && t.p2_rows() <= one(kP2) && t.qr_rows() <= one(kQr) && t.tr_rows() <= one(kTr) &&
+         t.bw_idx.size() <= two(kBw, kBw2) && t.p2_rows() <= one(kP2) && t.qr_rows() <= one(kQr) && t.tr_rows() <= one(kTr) && t.hint_words <= one(kHint) &&
          24 * t.keccak.size() <= one(kKeccak) && 50 * t.keccak.size() <= one(kKmem) && t.memfinal.size() <= one(kMemFinal) &&
          t.muls.size() <= one(kMul) && t.ecall_idx.size() <= one(kEcall) && t.div_idx.size() <= one(kDiv);
 }
@@ -835,6 +836,7 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     cn[8] = (uint32_t)(n_node + n_lc);
     cn[10] = (uint32_t)t.qr_rows();
     cn[12] = (uint32_t)t.tr_rows();
+    cn[13] = (uint32_t)t.hint_words;
     uint32_t* d_p2 = w->agg_heap + i * w->cap_agg * kP2RecWords;
     if (n_node) ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(d_p2, agg_heaps[i].data(), agg_heaps[i].size() * 4, hipMemcpyHostToDevice, s));
     if (n_lc) ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(d_p2 + n_node * kP2RecWords, lc->p2_rows.data(), lc->p2_rows.size() * 4, hipMemcpyHostToDevice, s));

@@ -823,6 +823,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       case kQr: eval_qr(zc); break;
       case kTr: eval_tr(zc); break;
       case kDiv: eval_div(zc); break;
+      case kHint: eval_hint(zc); break;
     }
     if (zc.k_ != nb) { *err = "internal: constraint count"; return 7; }
     // LogUp (machine_defs.hpp "LogUp layout"): row = [prep | main] at zeta
