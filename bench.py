@@ -111,11 +111,11 @@ def source_sha256():
 
 def measured_hbm_traffic(batch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC collection
-    (profiles/collect_r04.sh -> profiles/r04_hbm_counters.json (r03: the round before): FETCH_SIZE and WRITE_SIZE in separate passes,
+    (profiles/collect_r05.sh -> profiles/r05_hbm_counters.json (r04, r03: the rounds before): FETCH_SIZE and WRITE_SIZE in separate passes,
     KB units, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  The collection records the
     sha256 of the libzksp.so it ran and its batch size: any other library or batch makes the figure stale
     and this returns None."""
-    for name in ("r04_hbm_counters.json", "r03_hbm_counters.json"):
+    for name in ("r05_hbm_counters.json", "r04_hbm_counters.json", "r03_hbm_counters.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             if int(d.get("batch", -1)) != batch or (d.get("lib_sha256") != lib_sha256() and d.get("source_sha256") != source_sha256()):
@@ -135,7 +135,7 @@ def valu_model(lib, h, achieved_gperm):
     cross-checked there against SQ_INSTS_VALU).  Saturated single-opcode chains measured live are reported beside it
     (they reach 75-90 % of these rates: profiles/r03_opcode_rates.txt has every opcode the kernel uses)."""
     try:
-        mix = json.load(open(os.path.join(ROOT, "profiles", "r04_leaf_opcode_mix.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_leaf_opcode_mix.json")) else "r03_leaf_opcode_mix.json")))["per_permutation_per_lane"]
+        mix = json.load(open(os.path.join(ROOT, "profiles", next(n for n in ("r05_leaf_opcode_mix.json", "r04_leaf_opcode_mix.json", "r03_leaf_opcode_mix.json") if os.path.exists(os.path.join(ROOT, "profiles", n))))))["per_permutation_per_lane"]
     except (OSError, KeyError, ValueError):
         return None
     simd_clocks = 256 * 4 * 2.4e9

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Static opcode mix of one Poseidon2 permutation inside mmcs_leaf_kernel (the dominant kernel of the
 machine proof), from the gfx950 ISA hipcc emits for kernels_machine.hip.  Runs anywhere hipcc does
-(no GPU needed).  Output: profiles/r04_leaf_opcode_mix.json + the raw per-block histogram.
+(no GPU needed).  Output: profiles/r05_leaf_opcode_mix.json + the raw per-block histogram.
 
 The permutation is three loops (basic blocks that branch back to themselves) and two straight-line pieces:
   initial linear layer (x1), external rounds 0-3 (one S-box layer + linear layer per trip, x4), internal rounds 0-11
   (one round per trip, x12), internal round 12 (x1), external rounds 4-7 (x4).
-The total is cross-checked against the PMC count of the same build (profiles/r04_valu_counters.json).
+The total is cross-checked against the PMC count of the same build (profiles/r05_valu_counters.json).
 """
 import collections
 import json
@@ -68,7 +68,7 @@ pmc = None
 try:
     import importlib
     sys.path.insert(0, ROOT)
-    v = json.load(open(os.path.join(ROOT, "profiles", "r04_valu_counters.json")))
+    v = json.load(open(os.path.join(ROOT, "profiles", "r05_valu_counters.json")))
     heights = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_under_rocprof.json")))["config"]["chip_log_heights"]
     widths = importlib.import_module("zk-state-proofs_amd.client").machine_chip_widths()
     top = max(heights)
@@ -83,5 +83,5 @@ out = {"kernel": "mmcs_leaf_kernel", "per_permutation_per_lane": dict(mix), "tot
        "note": "full_rate = plain 32-bit VOP1/VOP2 instructions (additions, shifts, moves, logic); half_rate = every other "
                "vector instruction (v_mad_i64_i32 / v_mad_u64_u32 of the Montgomery products, v_mul_lo_u32, v_lshl_add_u64 of the "
                "linear layers' 64-bit sums, v_alignbit, v_mad_i32_i24, v_add3, v_min, lane reads)"}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r04_leaf_opcode_mix.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", "r05_leaf_opcode_mix.json"), "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("per_permutation_per_lane", "total_valu", "pmc_valu_per_permutation_per_lane")}))

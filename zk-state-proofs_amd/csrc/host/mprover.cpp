@@ -704,6 +704,7 @@ void swap_records(MachineWorkspace* w) {
   std::swap(w->cap_cycles, p.cap_cycles); std::swap(w->cap_keccak, p.cap_keccak); std::swap(w->cap_memfinal, p.cap_memfinal);
   std::swap(w->cap_muls, p.cap_muls); std::swap(w->cap_alu, p.cap_alu); std::swap(w->cap_sub, p.cap_sub); std::swap(w->cap_bw, p.cap_bw);
   std::swap(w->cap_agg, p.cap_agg); std::swap(w->cap_fold, p.cap_fold); std::swap(w->cap_tr, p.cap_tr);
+  std::swap(w->idle_chips, p.idle_chips);
   w->rec_slot ^= 1;
 }
 }  // namespace
@@ -810,6 +811,7 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
   kst.assign(n * w->cap_keccak * 25, 0);
   agg_heaps.assign(n, std::vector<uint32_t>());
   const size_t hp = (size_t)1 << logh[kProgram];
+  uint32_t busy = 0;  // chips (of those that can be idle) with a real row in some run of the batch
   for (size_t i = 0; i < n; ++i) {
     const MachineTrace& t = *traces[i];
     uint32_t* cn = &counts[kCountWords * i];
@@ -837,6 +839,11 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     cn[10] = (uint32_t)t.qr_rows();
     cn[12] = (uint32_t)t.tr_rows();
     cn[13] = (uint32_t)t.hint_words;
+    if (cn[8]) busy |= 1u << kP2;
+    if (cn[10]) busy |= 1u << kQr;
+    if (cn[12]) busy |= 1u << kTr;
+    if (!t.div_idx.empty()) busy |= 1u << kDiv;
+    if (!t.muls.empty()) busy |= 1u << kMul;
     uint32_t* d_p2 = w->agg_heap + i * w->cap_agg * kP2RecWords;
     if (n_node) ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(d_p2, agg_heaps[i].data(), agg_heaps[i].size() * 4, hipMemcpyHostToDevice, s));
     if (n_lc) ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(d_p2 + n_node * kP2RecWords, lc->p2_rows.data(), lc->p2_rows.size() * 4, hipMemcpyHostToDevice, s));
@@ -912,6 +919,7 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     if (into_spare) w->spare_loaded = nullptr;
   }
   w->n = (int)n;
+  w->idle_chips = ((1u << kP2) | (1u << kQr) | (1u << kTr) | (1u << kDiv) | (1u << kMul)) & ~busy;
   return 0;
 }
 
@@ -1188,6 +1196,14 @@ int machine_prove_resident(Context* ctx) {
       qa.pubs_bstride = kPubWords;
       qa.quot = w->mat[quot_leader(logh, c)][2].tr;
       qa.accumulate = quot_leader(logh, c) != c;
+      if ((w->idle_chips >> c) & 1u) {
+        // not a real row in the whole batch and constant padding rows: every constraint polynomial of the chip vanishes
+        // identically (a selector times a constant that is zero on the trace domain), and so does its LogUp part (no
+        // multiplicity, a zero running sum): nothing to add to the height's quotient.  A single proof spent a tenth of its
+        // device time on the 925 constraints of the four chips that only a leaf-proof check or a division gives rows.
+        if (!qa.accumulate) ZKSP_HIP_CHECK(ctx, hipMemsetAsync(qa.quot, 0, (size_t)B * 8 * h * 4, fork.lane(fork.lane_of_q(logh[c]))));
+        continue;
+      }
       // (CPU: 8 H words per proof of the scratch's >= 16 H; the chips of a height share a lane, so its scratch is theirs)
       const int ql = fork.lane_of_q(logh[c]);
       qa.partial = is_cpu_chip(c) ? (ql == 0 ? w->reduce_scratch : w->side_reduce_scratch[ql - 1]) : w->kpartial;

@@ -57,8 +57,12 @@ struct MachineWorkspace {
     int logh[mach::kNumChips] = {0};
     size_t cap_cycles = 0, cap_keccak = 0, cap_memfinal = 0, cap_muls = 0, cap_alu = 0, cap_sub = 0, cap_bw = 0, cap_agg = 0, cap_fold = 0 /* query chip rows */, cap_tr = 0 /* transcript chip rows */;
     int batch_hint = 0;
+    uint32_t idle_chips = 0;
   } spare;
   int rec_slot = 0;  // Context::rec_arena[rec_slot] holds the resident records, the other one the spare set
+  // chips without a single real row in the whole resident batch (bit = chip), of those whose padding rows are constant: an idle
+  // chip's constraint polynomials vanish identically, so its share of its height's quotient is zero and need not be computed
+  uint32_t idle_chips = 0;
   // Host-side staging of a load (counts, transcript words, keccak states, node rows): kept until the next load into the
   // same record set, because an upload into the spare set is not waited for by the host.
   struct LoadStage {
