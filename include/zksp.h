@@ -341,6 +341,10 @@ int zksp_hip_lde(zksp_client* c, const uint32_t* d_in, int log_h, size_t ncols, 
 /* row a5: mat [width][2^log_n] column-major -> tree [(2^(log_n+1)-1)][8] */
 int zksp_hip_merkle_commit(zksp_client* c, const uint32_t* d_mat, int width, int log_n, uint32_t* d_tree);
 int zksp_hip_poseidon2_permute(zksp_client* c, uint32_t* d_states, size_t n);
+/* the HOST verifier's Poseidon2 permutation over n states of 16 canonical words, in place (no GPU): impl 0 = the scalar form,
+ * 1 = the 256-bit vector form the verifier uses where the CPU has AVX2 (ZKSP_ERR_UNSUPPORTED where it has not) - the two
+ * are the same function (csrc/host/p2_avx2.cpp) */
+int zksp_host_poseidon2_permute(uint32_t* states, size_t n, int impl);
 /* row a3: states [n_perms][25] u64 -> trace [2633][2^log_h] */
 int zksp_hip_keccak_trace(zksp_client* c, const uint64_t* d_states, uint32_t n_perms, int log_h, uint32_t* d_trace);
 /* row a6: lde [2633][2][H], running-sum lde_p [4][2][H], challenges = alpha, gamma, beta,

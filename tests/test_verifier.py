@@ -121,3 +121,33 @@ def test_rejects_nonzero_exit_code_and_oversized_height(zk, oracle, setup):
     tall[12:16] = (0).to_bytes(4, "little")   # n_perms
     with pytest.raises(zk.ZkspError):
         zk.SP1ProofWithPublicValues.from_bytes(bytes(tall))
+
+
+def test_host_poseidon2_vector_matches_scalar(zk, built_lib):
+    """The host verifier's permutation in 256-bit registers (csrc/host/p2_avx2.cpp, used where the CPU has AVX2) is the same
+    function as the scalar form: the independent restatement's known answers (tests/golden/stark_kat.json), random states and
+    states of extreme words, bit for bit."""
+    import ctypes as C
+    import json
+    import os
+    lib = zk.client.load_library()
+    lib.zksp_host_poseidon2_permute.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    P = 2013265921
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stark_kat.json")) as f:
+        kat = json.load(f)["permute"]
+    rng = np.random.default_rng(77)
+    words = np.array([0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 0x0ffffffe, 1 << 30], dtype=np.uint32)
+    states = np.concatenate([np.array([c["in"] for c in kat], dtype=np.uint32),
+                             rng.integers(0, P, size=(4000, 16), dtype=np.uint32),
+                             words[rng.integers(0, len(words), (1000, 16))],
+                             np.repeat(words[:, None], 16, axis=1)])
+    scalar, vector = states.copy(), states.copy()
+    assert lib.zksp_host_poseidon2_permute(scalar.ctypes.data, len(scalar), 0) == 0
+    assert scalar[:len(kat)].tolist() == [c["out"] for c in kat]
+    rc = lib.zksp_host_poseidon2_permute(vector.ctypes.data, len(vector), 1)
+    if rc == zk.client.ERR_UNSUPPORTED:
+        pytest.skip("this CPU has no AVX2: the verifier runs the scalar permutation")
+    assert rc == 0 and np.array_equal(scalar, vector)
+    bad = states[:1].copy()
+    bad[0, 3] = P  # not a canonical word
+    assert lib.zksp_host_poseidon2_permute(bad.ctypes.data, 1, 0) != 0

@@ -26,6 +26,7 @@ SOURCES = [
     "host/executor.cpp",
     "host/machine.cpp",
     "host/params.cpp",
+    "host/p2_avx2.cpp",
     "host/context.cpp",
     "host/prover.cpp",
     "host/mprover.cpp",
@@ -62,7 +63,11 @@ def _compile(src: str, force: bool, hdr_time: float) -> str:
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time):
         return obj
     cmd = [_hipcc(), *FLAGS, "-I", INCLUDE]
-    if src.endswith(".cpp") and src not in ("host/executor.cpp", "host/machine.cpp"):
+    if src == "host/p2_avx2.cpp":
+        # the host verifier's vector permutation: plain C++ (hipcc would compile a .cpp as HIP, for the GPU as well), AVX2 for
+        # this file only, entered after a CPU check
+        cmd = [os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-Wall", "-mavx2"]
+    elif src.endswith(".cpp") and src not in ("host/executor.cpp", "host/machine.cpp"):
         cmd += ["-x", "hip"]  # host code that shares the __host__ __device__ field/AIR headers
     cmd += ["-c", path, "-o", obj]
     subprocess.check_call(cmd)

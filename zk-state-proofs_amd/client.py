@@ -193,6 +193,7 @@ def load_library() -> C.CDLL:
     lib.zksp_hip_lde.argtypes = [vp, vp, C.c_int, sz, C.c_uint32, vp, vp]
     lib.zksp_hip_merkle_commit.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     lib.zksp_hip_poseidon2_permute.argtypes = [vp, vp, sz]
+    lib.zksp_host_poseidon2_permute.argtypes = [vp, sz, C.c_int]
     lib.zksp_hip_keccak_trace.argtypes = [vp, vp, C.c_uint32, C.c_int, vp]
     lib.zksp_hip_keccak_quotient.argtypes = [vp, vp, vp, C.c_int, vp, vp]
     lib.zksp_hip_bus_perm_trace.argtypes = [vp, vp, C.c_int, vp, vp, vp]
@@ -216,7 +217,7 @@ ABI_SYMBOLS = [
     "zksp_hip_prove_resident", "zksp_proof_from_body", "zksp_hip_fetch_bodies", "zksp_hip_fetch_roots", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
     "zksp_hip_profile_enable", "zksp_hip_profile_read", "zksp_hip_profile_reset", "zksp_dev_malloc", "zksp_dev_free",
     "zksp_dev_upload", "zksp_dev_download", "zksp_dev_memset", "zksp_hip_lde", "zksp_hip_merkle_commit",
-    "zksp_hip_poseidon2_permute", "zksp_hip_keccak_trace", "zksp_hip_keccak_quotient", "zksp_hip_bus_perm_trace", "zksp_hip_fri_fold",
+    "zksp_hip_poseidon2_permute", "zksp_host_poseidon2_permute", "zksp_hip_keccak_trace", "zksp_hip_keccak_quotient", "zksp_hip_bus_perm_trace", "zksp_hip_fri_fold",
     "zksp_hip_microbench",
 ]
 

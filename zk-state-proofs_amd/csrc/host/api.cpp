@@ -14,6 +14,7 @@
 #include "prover.hpp"
 #include "verifier.hpp"
 #include "machine_defs.hpp"
+#include "host_hash.hpp"
 
 #include "api_types.hpp"
 
@@ -498,6 +499,23 @@ int zksp_hip_poseidon2_permute(zksp_client* c, uint32_t* d_states, size_t n) {
   launch_poseidon2_permute(c->ctx.stream, d_states, n, c->ctx.d_consts);
   ZKSP_HIP_CHECK(&c->ctx, hipStreamSynchronize(c->ctx.stream));
   ZKSP_HIP_CHECK(&c->ctx, hipGetLastError());
+  return ZKSP_OK;
+}
+
+int zksp_host_poseidon2_permute(uint32_t* states, size_t n, int impl) {
+  if (!states || impl < 0 || impl > 1) return ZKSP_ERR_INVALID_ARG;
+  if (impl == 1 && !p2avx2::usable()) return ZKSP_ERR_UNSUPPORTED;
+  const P2Consts* k = &host_p2_consts();
+  for (size_t i = 0; i < n; ++i) {
+    Fp st[16];
+    for (int j = 0; j < 16; ++j) {
+      if (states[16 * i + j] >= kP) return ZKSP_ERR_INVALID_ARG;
+      st[j] = Fp::from_canonical(states[16 * i + j]);
+    }
+    if (impl == 1) p2avx2::permute(&st[0].v, k->ext, k->internal, k->diag);
+    else p2_permute(st, k);
+    for (int j = 0; j < 16; ++j) states[16 * i + j] = st[j].to_canonical();
+  }
   return ZKSP_OK;
 }
 

@@ -428,9 +428,13 @@ int zksp_stdin_add_verified_node(zksp_client* c, zksp_stdin* s, const zksp_proof
   const int rc = leaf_check_of(c, leaf, leaf_vk, &one, have, own, n_own);
   if (rc) return rc;
   try {
-    auto all = std::make_shared<LeafCheckLog>();
-    if (s->leaf_check) *all = *s->leaf_check;
-    all->append(*one);
+    std::shared_ptr<LeafCheckLog> all;
+    if (s->leaf_check) {
+      all = std::make_shared<LeafCheckLog>(*s->leaf_check);
+      all->append(*one);
+    } else {
+      all = std::move(one);  // (the first leaf: its log as it is)
+    }
     all->leaf_index = 0;
     all->n_leaves = have + 1;
     s->leaf_check = std::move(all);
@@ -480,9 +484,15 @@ int zksp_stdin_add_verified_leaves(zksp_client* c, zksp_stdin* s, const zksp_pro
   for (size_t k = 0; k < n; ++k)
     if (rcs[k]) return c->ctx.fail(rcs[k], errs[k].empty() ? std::string("leaf check: out of memory") : errs[k]);
   try {
-    auto all = std::make_shared<LeafCheckLog>();
-    if (s->leaf_check) *all = *s->leaf_check;
-    for (size_t k = 0; k < n; ++k) all->append(*logs[k]);
+    std::shared_ptr<LeafCheckLog> all;
+    if (!s->leaf_check && n == 1) {
+      all = std::move(logs[0]);
+    } else {
+      all = s->leaf_check ? std::make_shared<LeafCheckLog>(*s->leaf_check) : std::make_shared<LeafCheckLog>();
+      std::vector<const LeafCheckLog*> parts(n);
+      for (size_t k = 0; k < n; ++k) parts[k] = logs[k].get();
+      all->append_all(parts.data(), n);
+    }
     all->leaf_index = 0;
     all->n_leaves = have + (uint32_t)n;
     s->leaf_check = std::move(all);

@@ -3,12 +3,26 @@
 // device uses (poseidon2.hpp), instantiated on the host.
 #pragma once
 #include <cstddef>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../device/poseidon2.hpp"
 
 namespace zksp {
+namespace p2avx2 {  // p2_avx2.cpp: the permutation on the host's vector unit (same function, bit-identical results)
+void permute(uint32_t* s, const uint32_t (*ext)[16], const uint32_t* internal, const uint32_t* diag);
+bool usable();
+}  // namespace p2avx2
 namespace hosthash {
+
+// The host's permutation: in two 256-bit registers where the CPU has them (6 x the scalar form's rate), else the device's
+// signed lazy form on a core.  State: Montgomery words in [0, p).
+inline void permute(Fp* st, const P2Consts* k) {
+  static const bool vec = p2avx2::usable();
+  if (vec) p2avx2::permute(&st[0].v, k->ext, k->internal, k->diag);
+  else p2_permute(st, k);
+}
 
 struct HostChallenger {
   Fp state[16];
@@ -29,7 +43,7 @@ struct HostChallenger {
       for (int i = 0; i < 16; ++i) record->push_back(state[i].to_canonical());
     }
     n_in = 0;
-    p2_permute(state, k);
+    permute(state, k);
     for (int i = 0; i < 8; ++i) outbuf[i] = state[i];
     n_out = 8;
   }
@@ -63,7 +77,7 @@ inline void hash_elems(const Fp* in, size_t n, Fp out[8], const P2Consts* k) {
   for (size_t off = 0; off < n; off += 8) {
     size_t m = n - off < 8 ? n - off : 8;
     for (size_t i = 0; i < 8; ++i) st[i] = i < m ? in[off + i] : Fp::zero();  // overwrite mode; the last block is zero-filled
-    p2_permute(st, k);
+    permute(st, k);
   }
   for (int i = 0; i < 8; ++i) out[i] = st[i];
 }
@@ -74,7 +88,7 @@ inline void compress(const Fp* l, const Fp* r, Fp out[8], const P2Consts* k) {
     st[i] = l[i];
     st[8 + i] = r[i];
   }
-  p2_permute(st, k);
+  permute(st, k);
   for (int i = 0; i < 8; ++i) out[i] = st[i];
 }
 
@@ -96,22 +110,52 @@ inline bool verify_path(const Fp leaf[8], size_t idx, const uint32_t* path_canon
 
 // Merkle root of a flat word list laid out column-major as [8][2^logr], zero padded: the
 // form in which long lists (opened values, the public I/O limbs) enter the transcript.
-inline void list_root(const std::vector<Fp>& words, int logr, Fp out[8], const P2Consts* kc) {
+// n_threads > 1: the subtrees below the top levels are hashed side by side (a long list is 2^12 rows: 8 000 permutations).
+inline void list_root(const std::vector<Fp>& words, int logr, Fp out[8], const P2Consts* kc, unsigned n_threads = 1) {
   const size_t R = (size_t)1 << logr;
-  std::vector<Fp> pad(8 * R, Fp::zero());
-  for (size_t t = 0; t < words.size() && t < 8 * R; ++t) pad[t] = words[t];
-  std::vector<Fp> layer(8 * R), nxt;
-  for (size_t r = 0; r < R; ++r) {
-    Fp row[8];
-    for (int c = 0; c < 8; ++c) row[c] = pad[(size_t)c * R + r];
-    hash_elems(row, 8, &layer[8 * r], kc);
+  auto word = [&](size_t t) { return t < words.size() ? words[t] : Fp::zero(); };
+  // root of the subtree over rows [r0, r0 + cnt)
+  auto subtree = [&](size_t r0, size_t cnt, Fp* root) {
+    std::vector<Fp> layer(8 * cnt);
+    for (size_t r = 0; r < cnt; ++r) {
+      Fp row[8];
+      for (int c = 0; c < 8; ++c) row[c] = word((size_t)c * R + r0 + r);
+      hash_elems(row, 8, &layer[8 * r], kc);
+    }
+    for (size_t n = cnt; n > 1; n >>= 1)
+      for (size_t i = 0; i < n / 2; ++i) {  // (in place: node i of the next level overwrites slot i, which is already consumed)
+        Fp t[8];
+        compress(&layer[16 * i], &layer[16 * i + 8], t, kc);
+        for (int k = 0; k < 8; ++k) layer[8 * i + k] = t[k];
+      }
+    for (int i = 0; i < 8; ++i) root[i] = layer[i];
+  };
+  int lt = 0;
+  while (((size_t)2 << lt) <= n_threads && lt + 6 <= logr) ++lt;  // 2^lt subtrees of at least 64 rows each
+  const size_t parts = (size_t)1 << lt;
+  std::vector<Fp> top(8 * parts);
+  if (parts == 1) {
+    subtree(0, R, top.data());
+  } else {
+    struct Joiner {
+      std::vector<std::thread> th;
+      ~Joiner() { for (auto& t : th) if (t.joinable()) t.join(); }
+    } pool;
+    std::atomic<size_t> next{0};
+    auto worker = [&]() { for (size_t p; (p = next.fetch_add(1)) < parts;) subtree(p * (R / parts), R / parts, &top[8 * p]); };
+    try {
+      for (size_t t = 1; t < parts; ++t) pool.th.emplace_back(worker);
+    } catch (...) {
+    }  // fewer threads than wanted: the parts are claimed from one counter
+    worker();
   }
-  for (size_t cnt = R; cnt > 1; cnt >>= 1) {
-    nxt.assign(8 * (cnt / 2), Fp::zero());
-    for (size_t i = 0; i < cnt / 2; ++i) compress(&layer[16 * i], &layer[16 * i + 8], &nxt[8 * i], kc);
-    layer.swap(nxt);
-  }
-  for (int i = 0; i < 8; ++i) out[i] = layer[i];
+  for (size_t n = parts; n > 1; n >>= 1)
+    for (size_t i = 0; i < n / 2; ++i) {
+      Fp t[8];
+      compress(&top[16 * i], &top[16 * i + 8], t, kc);
+      for (int k = 0; k < 8; ++k) top[8 * i + k] = t[k];
+    }
+  for (int i = 0; i < 8; ++i) out[i] = top[i];
 }
 
 }  // namespace hosthash

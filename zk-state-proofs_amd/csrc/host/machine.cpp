@@ -13,6 +13,7 @@
 #include <mutex>
 #include <new>
 #include <utility>
+#include <thread>
 #include <vector>
 
 namespace zksp {
@@ -492,6 +493,36 @@ done:
     }
     while (ti < touched.size()) emit_touched(touched[ti++]);
   }
+}
+
+void LeafCheckLog::append_all(const LeafCheckLog* const* parts, size_t n) {
+  std::vector<size_t> at_p2(n + 1), at_qr(n + 1);
+  at_p2[0] = p2_rows.size();
+  at_qr[0] = qr_rows.size();
+  for (size_t k = 0; k < n; ++k) {
+    at_p2[k + 1] = at_p2[k] + parts[k]->p2_rows.size();
+    at_qr[k + 1] = at_qr[k] + parts[k]->qr_rows.size();
+    tr_rows.insert(tr_rows.end(), parts[k]->tr_rows.begin(), parts[k]->tr_rows.end());
+    pub_tuples.insert(pub_tuples.end(), parts[k]->pub_tuples.begin(), parts[k]->pub_tuples.end());
+  }
+  p2_rows.resize(at_p2[n]);
+  qr_rows.resize(at_qr[n]);
+  auto copy = [&](size_t k) noexcept {
+    if (!parts[k]->p2_rows.empty()) memcpy(p2_rows.data() + at_p2[k], parts[k]->p2_rows.data(), parts[k]->p2_rows.size() * 4);
+    if (!parts[k]->qr_rows.empty()) memcpy(qr_rows.data() + at_qr[k], parts[k]->qr_rows.data(), parts[k]->qr_rows.size() * 4);
+  };
+  struct Joiner {
+    std::vector<std::thread> th;
+    ~Joiner() { for (auto& t : th) if (t.joinable()) t.join(); }
+  } pool;
+  for (size_t k = 1; k < n; ++k) {
+    try {
+      pool.th.emplace_back(copy, k);
+    } catch (...) {
+      copy(k);
+    }
+  }
+  if (n) copy(0);
 }
 
 }  // namespace zksp

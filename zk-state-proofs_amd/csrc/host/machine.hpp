@@ -111,16 +111,29 @@ void PageAllocator<T>::deallocate(T* p, size_t n) noexcept { page_free(p, n * si
 // transcript's blocks (header, commitment roots, cumulative sums, the root of the opened values, FRI roots, final constant,
 // witness), the preprocessed root, one tuple of constants per leaf and one per height (which depend on the leaf's challenges,
 // but on nothing the query phase opens), the proof-of-work word.  All canonical words.
+// (storage whose resize() leaves new words unwritten: the 11 MB of row records per leaf are written by several threads, which
+// is also where their pages are first touched)
+template <class T>
+struct RawAllocator : std::allocator<T> {
+  template <class U>
+  struct rebind { using other = RawAllocator<U>; };
+  template <class U>
+  void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }
+  template <class U, class... A>
+  void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+using RowWords = std::vector<uint32_t, RawAllocator<uint32_t>>;
 struct LeafCheckLog {
-  std::vector<uint32_t> p2_rows, tr_rows, qr_rows, pub_tuples;
+  RowWords p2_rows, qr_rows;
+  std::vector<uint32_t> tr_rows, pub_tuples;
   // several leaf proofs checked beside one run: the k-th leaf's tags, root ids and tuples carry the leaf index k
   uint32_t leaf_index = 0, n_leaves = 0;
   void append(const LeafCheckLog& o) {
-    p2_rows.insert(p2_rows.end(), o.p2_rows.begin(), o.p2_rows.end());
-    tr_rows.insert(tr_rows.end(), o.tr_rows.begin(), o.tr_rows.end());
-    qr_rows.insert(qr_rows.end(), o.qr_rows.begin(), o.qr_rows.end());
-    pub_tuples.insert(pub_tuples.end(), o.pub_tuples.begin(), o.pub_tuples.end());
+    const LeafCheckLog* one[1] = {&o};
+    append_all(one, 1);
   }
+  // the logs of several leaves, in order; the big record lists are copied side by side
+  void append_all(const LeafCheckLog* const* parts, size_t n);
 };
 
 struct MachineTrace {

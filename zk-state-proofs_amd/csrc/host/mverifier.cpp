@@ -102,15 +102,30 @@ struct RoundShape {
 
 // ---- leaf-check log (mverifier.hpp LeafCheckLog): the permutations of the query phase as Poseidon2-chip row records ----
 // (32 words: flags, tag, key, mask, the 16 input words, root id, the Horner sum after the block, alpha_f, padding)
+// alpha_f as the sponge rows use it: its powers for Horner's rule over a block of eight words, and its canonical words
+struct AlphaPows {
+  Fp4 pw[8];  // alpha^7 .. alpha^0
+  Fp4 a8;
+  uint32_t canon[4];
+  explicit AlphaPows(const Fp4& a) {
+    pw[7] = Fp4::one();
+    for (int i = 6; i >= 0; --i) pw[i] = pw[i + 1] * a;
+    a8 = pw[0] * a;
+    for (int i = 0; i < 4; ++i) canon[i] = a.c[i].to_canonical();
+  }
+};
 void log_p2_row(LeafCheckLog* log, uint32_t flags, uint32_t tag, uint32_t key, uint32_t mask, const Fp in[16], uint32_t rid = 0,
-                const Fp4* so = nullptr, const Fp4* alpha = nullptr) {
-  std::vector<uint32_t>& v = log->p2_rows;
-  v.push_back(flags); v.push_back(tag); v.push_back(key); v.push_back(mask);
-  for (int i = 0; i < 16; ++i) v.push_back(in[i].to_canonical());
-  v.push_back(rid);
-  for (int i = 0; i < 4; ++i) v.push_back(so ? so->c[i].to_canonical() : 0u);
-  for (int i = 0; i < 4; ++i) v.push_back(alpha ? alpha->c[i].to_canonical() : 0u);
-  for (int i = 0; i < 3; ++i) v.push_back(0u);
+                const Fp4* so = nullptr, const AlphaPows* alpha = nullptr) {
+  RowWords& v = log->p2_rows;
+  const size_t at = v.size();
+  v.resize(at + kP2RecWords);  // (not zero-filled)
+  uint32_t* w = v.data() + at;
+  w[0] = flags; w[1] = tag; w[2] = key; w[3] = mask;
+  for (int i = 0; i < 16; ++i) w[4 + i] = in[i].to_canonical();
+  w[kP2RecRid] = rid;
+  for (int i = 0; i < 4; ++i) w[kP2RecSo + i] = so ? so->c[i].to_canonical() : 0u;
+  for (int i = 0; i < 4; ++i) w[kP2RecAlpha + i] = alpha ? alpha->canon[i] : 0u;
+  for (int i = kP2RecAlpha + 4; i < kP2RecWords; ++i) w[i] = 0u;
 }
 void log_pub_tuple(LeafCheckLog* log, uint32_t bus, bool verifier_sends, uint32_t mult, const uint32_t* el, int n_el) {
   std::vector<uint32_t>& v = log->pub_tuples;
@@ -121,18 +136,17 @@ void log_pub_tuple(LeafCheckLog* log, uint32_t bus, bool verifier_sends, uint32_
 // `alpha` (the hash of a matrix row of a commitment): Horner's rule in alpha over the absorbed words, block by block; the last
 // row is flagged SE and the sum comes back in *sum.
 void sponge_logged(const Fp* in, size_t n, Fp out[8], const P2Consts* kc, LeafCheckLog* log, uint32_t tag, uint32_t key, uint32_t mask,
-                   bool run_start, bool send, bool fri_leaf, const Fp4* alpha = nullptr, Fp4* sum = nullptr) {
+                   bool run_start, bool send, bool fri_leaf, const AlphaPows* alpha = nullptr, Fp4* sum = nullptr) {
   Fp st[16];
   for (auto& x : st) x = Fp::zero();
-  Fp4 so = Fp4::zero(), a8 = Fp4::one();
-  if (alpha) a8 = alpha->pow(8);
+  Fp4 so = Fp4::zero();
   for (size_t off = 0; off < n; off += 8) {
     const size_t m = n - off < 8 ? n - off : 8;
     for (size_t i = 0; i < 8; ++i) st[i] = i < m ? in[off + i] : Fp::zero();
     if (alpha) {
-      Fp4 bv = Fp4::zero();
-      for (int i = 0; i < 8; ++i) bv = bv * *alpha + Fp4::from_base(st[i]);
-      so = so * a8 + bv;
+      Fp4 bv = Fp4::from_base(st[7]);
+      for (int i = 0; i < 7; ++i) bv += alpha->pw[i] * st[i];
+      so = so * alpha->a8 + bv;
     } else {
       so = Fp4::from_base(st[7]);  // (a hash nobody reduces - a FRI pair: the row's alpha_f columns are zero, Horner's rule leaves the last word)
     }
@@ -144,7 +158,7 @@ void sponge_logged(const Fp* in, size_t n, Fp out[8], const P2Consts* kc, LeafCh
       if (alpha && off + 8 >= n) flags |= kP2FlagSe;
       log_p2_row(log, flags, tag, key, mask, st, 0, &so, alpha);
     }
-    p2_permute(st, kc);
+    permute(st, kc);
   }
   for (int i = 0; i < 8; ++i) out[i] = st[i];
   if (sum) *sum = so;
@@ -158,7 +172,7 @@ void compress_logged(const Fp* cur, const Fp* sib, bool cur_right, Fp out[8], co
     st[8 + i] = cur_right ? cur[i] : sib[i];
   }
   if (log) log_p2_row(log, kind, tag, key, mask, st);
-  p2_permute(st, kc);
+  permute(st, kc);
   for (int i = 0; i < 8; ++i) out[i] = st[i];
 }
 // the last logged row ends its run: its digest is compared with root `rid`, its position goes to the query chip
@@ -173,7 +187,7 @@ void log_run_end(LeafCheckLog* log, uint32_t rid) {
 // alpha) of the opened rows of the chips of height 2^lh, which the query chip turns into reduced openings.
 bool mmcs_verify(const RoundShape& sh, const int* logh, const std::vector<std::vector<Fp>>& rows, size_t cs, size_t m_max,
                  const uint32_t* path_canon, const Fp root[8], const P2Consts* kc, LeafCheckLog* log = nullptr, uint32_t tag = 0,
-                 uint32_t rid = 0, const Fp4* alpha = nullptr, Fp4* hsum = nullptr) {
+                 uint32_t rid = 0, const AlphaPows* alpha = nullptr, Fp4* hsum = nullptr) {
   const int logn = sh.lm + 1;
   const size_t hm = (size_t)1 << sh.lm;
   const size_t pos = cs * hm + bitrev32((uint32_t)(m_max & (hm - 1)), sh.lm);
@@ -184,16 +198,15 @@ bool mmcs_verify(const RoundShape& sh, const int* logh, const std::vector<std::v
     return !cat->empty();
   };
   std::vector<Fp> cat;
+  Fp inj[32][8];  // with a log: the hashes of the injected rows, by level
   if (log) {
     // the hashes of the injected rows come first, each labelled with the key and mask its injection row will hold
     uint32_t key = 1, mask = 0;
     for (int l = 0; l < logn; ++l) {
       key = 2 * key + (uint32_t)((pos >> l) & 1);
       mask = 2 * mask;
-      if (group_row(logn - l - 1, &cat)) {
-        Fp g[8];
-        sponge_logged(cat.data(), cat.size(), g, kc, log, tag, key, ++mask, false, true, false, alpha, hsum ? &hsum[logn - l - 2] : nullptr);
-      }
+      if (group_row(logn - l - 1, &cat))
+        sponge_logged(cat.data(), cat.size(), inj[l], kc, log, tag, key, ++mask, false, true, false, alpha, hsum ? &hsum[logn - l - 2] : nullptr);
     }
   }
   Fp cur[8];
@@ -209,7 +222,8 @@ bool mmcs_verify(const RoundShape& sh, const int* logh, const std::vector<std::v
     compress_logged(cur, sib, right, nxt, kc, log, right ? P2K_PR : P2K_PL, tag, key, mask);
     if (group_row(logn - l - 1, &cat)) {
       Fp g[8];
-      hash_elems(cat.data(), cat.size(), g, kc);
+      if (log) for (int i = 0; i < 8; ++i) g[i] = inj[l][i];
+      else hash_elems(cat.data(), cat.size(), g, kc);
       compress_logged(nxt, g, false, cur, kc, log, P2K_J, tag, key, ++mask);
     } else {
       for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
@@ -744,13 +758,14 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     if (total != Fp4::zero()) { *err = "LogUp buses do not balance against the public values and exit code"; return 8; }
   }
 
+  const unsigned n_thr = std::max(1u, std::min({std::thread::hardware_concurrency(), 8u, (unsigned)num_queries / 4u}));
   std::vector<Fp4> opened(n_open);
   for (size_t i = 0; i < n_open; ++i) opened[i] = read_fp4(p_opened + 4 * i);
   {
     std::vector<Fp> words(n_open * 4);
     for (size_t t = 0; t < n_open * 4; ++t) words[t] = Fp::from_canonical(p_opened[t]);
     Fp open_root[8];
-    list_root(words, ceil_log2((n_open * 4 + 7) / 8), open_root, kc);
+    list_root(words, ceil_log2((n_open * 4 + 7) / 8), open_root, kc, n_thr);  // (8 000 permutations: a third of a verification on one thread)
     for (int i = 0; i < 8; ++i) ch.observe(open_root[i]);
   }
   const Fp4 af = ch.sample_ext(), delta = ch.sample_ext();
@@ -997,6 +1012,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   }
   if (stub) return 0;
 
+  const AlphaPows af_pows(af);
   auto check_query = [&](uint32_t qi, LeafCheckLog* log, std::string* err) -> int {
     std::vector<std::vector<Fp>> rows[4];
     for (int r = 0; r < 4; ++r) rows[r].resize(kNumChips);
@@ -1012,7 +1028,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       }
       for (auto& hv : hsum[r]) hv = Fp4::zero();
       if (!mmcs_verify(shape[r], logh, rows[r], cs, m, q, root[r], kc, log, leaf_tag(leaf, qi, (uint32_t)r), leaf_rid(leaf, (uint32_t)r),
-                       log ? &af : nullptr, log ? hsum[r] : nullptr)) {
+                       log ? &af_pows : nullptr, log ? hsum[r] : nullptr)) {
         static const char* names[4] = {"preprocessed", "main", "permutation", "quotient"};
         *err = std::string(names[r]) + " Merkle opening rejected";
         return 8;
@@ -1176,7 +1192,6 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       for (const auto& w : qrow) log->qr_rows.insert(log->qr_rows.end(), w.begin(), w.end());
     return 0;
   };
-  const unsigned n_thr = std::max(1u, std::min({std::thread::hardware_concurrency(), 8u, (unsigned)num_queries / 4u}));
   std::vector<int> q_rc(num_queries, 0);
   std::vector<std::string> q_err(num_queries);
   std::vector<LeafCheckLog> q_log(log ? num_queries : 0);
@@ -1206,11 +1221,35 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   }
   for (uint32_t qi = 0; qi < num_queries; ++qi)
     if (q_rc[qi]) { *err = q_err[qi]; return q_rc[qi]; }
-  if (log)
+  if (log) {
+    // the queries' rows in query order: one allocation, copied side by side (11 MB of Poseidon2-chip records per leaf)
+    std::vector<size_t> at_p2(num_queries + 1), at_qr(num_queries + 1);
+    at_p2[0] = log->p2_rows.size();
+    at_qr[0] = log->qr_rows.size();
     for (uint32_t qi = 0; qi < num_queries; ++qi) {
-      log->p2_rows.insert(log->p2_rows.end(), q_log[qi].p2_rows.begin(), q_log[qi].p2_rows.end());
-      log->qr_rows.insert(log->qr_rows.end(), q_log[qi].qr_rows.begin(), q_log[qi].qr_rows.end());
+      at_p2[qi + 1] = at_p2[qi] + q_log[qi].p2_rows.size();
+      at_qr[qi + 1] = at_qr[qi] + q_log[qi].qr_rows.size();
     }
+    log->p2_rows.resize(at_p2[num_queries]);
+    log->qr_rows.resize(at_qr[num_queries]);
+    std::atomic<uint32_t> next_c{0};
+    auto copier = [&]() noexcept {
+      for (uint32_t qi; (qi = next_c.fetch_add(1)) < num_queries;) {
+        if (!q_log[qi].p2_rows.empty()) memcpy(log->p2_rows.data() + at_p2[qi], q_log[qi].p2_rows.data(), q_log[qi].p2_rows.size() * 4);
+        if (!q_log[qi].qr_rows.empty()) memcpy(log->qr_rows.data() + at_qr[qi], q_log[qi].qr_rows.data(), q_log[qi].qr_rows.size() * 4);
+        RowWords().swap(q_log[qi].p2_rows);
+      }
+    };
+    struct Joiner {
+      std::vector<std::thread> th;
+      ~Joiner() { for (auto& t : th) if (t.joinable()) t.join(); }
+    } pool;
+    try {
+      for (unsigned t = 1; t < std::min(n_thr, 4u); ++t) pool.th.emplace_back(copier);
+    } catch (...) {
+    }
+    copier();
+  }
   return 0;
 }
 
