@@ -840,7 +840,8 @@ def main():
             e2e.append((time.perf_counter() - t2) * 1e3)
         e2e_ms = sorted(e2e)[2]  # median of 5: guest tracing, H2D, proving, D2H, proof object
         client.verify(proof, vk)
-        component = keccak_chip_component(zk, fx, {"device": local_rank}, zk.merkle_elf())
+        # (round 1's keccak-chip component figure: only with the library built for that path, ZKSP_COMPONENT=1)
+        component = keccak_chip_component(zk, fx, {"device": local_rank}, zk.merkle_elf()) if zk.client.COMPONENT else None
         # (acct-d8x1024, config 5's substitute, IS the timed step since round 5)
         wanted = ["slot-d5x256", "rcptx300"] if args.workload in ("acct-d8", "all") else [args.workload]
         for wname in wanted:

@@ -59,7 +59,9 @@ typedef struct {
  * MACHINE      the guest's whole execution (CPU instances, memory, program, ALU, keccak, multiplier ... chips joined by
  *              LogUp buses; proof format v16): the statement of the reference's client.prove().
  * KECCAK_CHIP  only "these keccak-f outputs belong to these inputs" (round-1 format v2, a component
- *              benchmark; NOT a proof that the guest ran). */
+ *              benchmark; NOT a proof that the guest ran).  A build switch: only the library built with ZKSP_COMPONENT=1
+ *              (libzksp_component.so, zksp_component.h) has it; zksp_client_new of the default library answers
+ *              ZKSP_ERR_UNSUPPORTED. */
 #define ZKSP_PROOF_MACHINE 1
 #define ZKSP_PROOF_KECCAK_CHIP 2
 /* Layout of a serialized machine proof (zksp_proof_serialize; little-endian u32 words; csrc/host/machine_defs.hpp is the
@@ -315,7 +317,8 @@ int zksp_get_params(const zksp_client* c, zksp_params* out);
 /* The round-1 keccak-chip COMPONENT proofs (format v2: "these keccak-f outputs belong to these inputs", not a proof of
  * execution) are a kernel benchmark and a test vehicle, not part of the drop-in surface: their entry points
  * (zksp_hip_load_batch, zksp_hip_prove_resident, zksp_hip_fetch_bodies, zksp_hip_fetch_roots, zksp_proof_from_body,
- * zksp_proof_body_words) are declared in zksp_component.h.  A default client neither makes nor accepts such proofs. */
+ * zksp_proof_body_words, and the parity entry points of its keccak-only kernels) are declared in zksp_component.h and
+ * compiled only into libzksp_component.so (ZKSP_COMPONENT=1).  The default library neither makes nor accepts such proofs. */
 int zksp_hip_sync(zksp_client* c);
 /* HIP-event timing on the client's own stream. */
 int zksp_hip_timer_start(zksp_client* c);
@@ -345,16 +348,6 @@ int zksp_hip_poseidon2_permute(zksp_client* c, uint32_t* d_states, size_t n);
  * 1 = the 256-bit vector form the verifier uses where the CPU has AVX2 (ZKSP_ERR_UNSUPPORTED where it has not) - the two
  * are the same function (csrc/host/p2_avx2.cpp) */
 int zksp_host_poseidon2_permute(uint32_t* states, size_t n, int impl);
-/* row a3: states [n_perms][25] u64 -> trace [2633][2^log_h] */
-int zksp_hip_keccak_trace(zksp_client* c, const uint64_t* d_states, uint32_t n_perms, int log_h, uint32_t* d_trace);
-/* row a6: lde [2633][2][H], running-sum lde_p [4][2][H], challenges = alpha, gamma, beta,
- * cumulative sum (4 canonical words each) -> quotient values [8][H] */
-int zksp_hip_keccak_quotient(zksp_client* c, const uint32_t* d_lde, const uint32_t* d_lde_p, int log_h,
-                             const uint32_t* challenges, uint32_t* d_quot);
-/* row a6, lookup argument: trace [2633][H], gamma_beta (8 canonical words) -> running sum
- * phi [4][H] and the cumulative sum (4 words) */
-int zksp_hip_bus_perm_trace(zksp_client* c, const uint32_t* d_trace, int log_h, const uint32_t* gamma_beta, uint32_t* d_phi,
-                            uint32_t* d_cum_sum);
 /* row a7: one FRI fold of layer [2][Hk][4] with challenge beta (canonical) */
 int zksp_hip_fri_fold(zksp_client* c, const uint32_t* d_in, int log_hk, uint32_t shift_k, const uint32_t* beta,
                       uint32_t* d_out);

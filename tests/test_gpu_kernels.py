@@ -1,11 +1,15 @@
 """Parity of every HIP kernel against the CPU oracle, through the C-ABI.
 Bit-exact: all arithmetic is integer (BabyBear residues)."""
+import os
+
 import numpy as np
 import pytest
 
 from util import P
 
 pytestmark = pytest.mark.gpu
+# the keccak-only kernels belong to the round-1 component path: a build switch (ZKSP_COMPONENT=1; include/zksp_component.h)
+component = pytest.mark.skipif(os.environ.get("ZKSP_COMPONENT", "") != "1", reason="component path not built (ZKSP_COMPONENT=1)")
 
 
 def rnd(rng, shape):
@@ -72,6 +76,7 @@ def test_lde(gpu, oracle, logh):
         assert (lde == elde).all(), (logh, shift)
 
 
+@component
 def test_keccak_trace(gpu, oracle):
     rng = np.random.default_rng(7)
     st = rng.integers(0, 2**64, (5, 25), dtype=np.uint64)
@@ -81,6 +86,7 @@ def test_keccak_trace(gpu, oracle):
     assert (gpu.keccak_trace(st[:0], 5) == oracle.keccak_trace(st[:0], 5)).all()
 
 
+@component
 def test_keccak_quotient(gpu, oracle):
     rng = np.random.default_rng(8)
     st = rng.integers(0, 2**64, (2, 25), dtype=np.uint64)
@@ -101,6 +107,7 @@ def test_keccak_quotient(gpu, oracle):
     assert (gpu.keccak_quotient(lde, lde_p, alpha, gamma, beta, bad_cum) == exp).all()
 
 
+@component
 @pytest.mark.parametrize("logh,nperms", [(5, 1), (7, 4), (9, 21), (11, 62)])
 def test_bus_perm_trace(gpu, oracle, logh, nperms):
     """LogUp running sum (row a6, lookup argument): phi columns and cumulative sum."""

@@ -2,13 +2,16 @@
 exactly, and the host verifier must accept honest and reject tampered proofs."""
 import ctypes as C
 import hashlib
+import os
 
 import numpy as np
 import pytest
 
 from util import Gpu, P
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("ZKSP_COMPONENT", "") != "1",
+                                 reason="the keccak-chip component path is a build switch (ZKSP_COMPONENT=1; include/zksp_component.h)")]
 
 
 def init_obs(vk, logh, n_perms, exit_code, pv_digest, deferred):

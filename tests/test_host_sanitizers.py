@@ -20,8 +20,9 @@ def test_host_code_under_asan_ubsan(tmp_path, zk, fx, oracle, host_client):
     srcs = [os.path.join(ROOT, "tests", "host_fuzz.cpp")] + [os.path.join(HOST, f) for f in
                                                              ("executor.cpp", "verifier.cpp", "params.cpp", "machine.cpp",
                                                               "machine_defs.cpp", "mverifier.cpp")]
-    base = [hipcc, "-x", "hip", "--cuda-host-only", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-I", HOST, "-I",
-            os.path.join(ROOT, "include")]
+    # (-DZKSP_COMPONENT: the harness feeds the component verifier of verifier.cpp too, which the default library leaves out)
+    base = [hipcc, "-x", "hip", "--cuda-host-only", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-DZKSP_COMPONENT", "-I", HOST,
+            "-I", os.path.join(ROOT, "include")]
     both = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
     # the machine verifier instantiates every chip's constraints over the extension field: UBSan's per-operation
     # checks make that one file compile for four minutes, so it gets ASan only (memory safety on untrusted bytes)
@@ -29,9 +30,12 @@ def test_host_code_under_asan_ubsan(tmp_path, zk, fx, oracle, host_client):
     for i, src in enumerate(srcs):
         flags = ["-fsanitize=address"] if src.endswith("mverifier.cpp") else both
         procs.append(subprocess.Popen(base + flags + ["-c", src, "-o", str(tmp_path / f"o{i}.o")]))
+    # the verifier's vector permutation: plain C++ with AVX2, as build.py compiles it, sanitized like the rest
+    procs.append(subprocess.Popen(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-mavx2", *both, "-c",
+                                   os.path.join(HOST, "p2_avx2.cpp"), "-o", str(tmp_path / "p2.o")]))
     assert all(p.wait() == 0 for p in procs)
-    subprocess.check_call([hipcc, "-fsanitize=address,undefined", *[str(tmp_path / f"o{i}.o") for i in range(len(srcs))], "-o",
-                           str(exe)])
+    subprocess.check_call([hipcc, "-fsanitize=address,undefined", *[str(tmp_path / f"o{i}.o") for i in range(len(srcs))],
+                           str(tmp_path / "p2.o"), "-o", str(exe)])
     pk, vk = host_client.setup(zk.merkle_elf())
     stdin_bytes = fx.stdin_frame(fx.tx_fixture().to_borsh())
     (tmp_path / "stdin.bin").write_bytes(stdin_bytes)

@@ -1,4 +1,5 @@
-"""Host verifier of the keccak-chip COMPONENT proof (format v2; a kernel benchmark, not a proof of execution)
+"""(Component tests: run with ZKSP_COMPONENT=1, which builds and loads libzksp_component.so; skipped otherwise.)
+Host verifier of the keccak-chip COMPONENT proof (format v2; a kernel benchmark, not a proof of execution)
 against proofs made by the CPU oracle: accepts honest proofs, rejects every kind of tampering, wrong keys and
 wrong parameters.  Such proofs verify only on a client created with proof_mode=PROOF_KECCAK_CHIP: the default
 (MACHINE) client of the reference-shaped flow refuses them (test_default_client_rejects_component_proofs).
@@ -14,6 +15,8 @@ NQ, POW = 12, 8
 
 @pytest.fixture(scope="module")
 def setup(zk, oracle, built_lib):
+    if not zk.client.COMPONENT:
+        pytest.skip("the keccak-chip component path is a build switch (ZKSP_COMPONENT=1; include/zksp_component.h)")
     client = zk.ProverClient(device=-1, num_queries=NQ, pow_bits=POW, proof_mode=zk.PROOF_KECCAK_CHIP)
     pk, vk = client.setup(zk.merkle_elf())
     vk_words = [int(x) for x in np.frombuffer(vk.digest, dtype=np.uint32)]

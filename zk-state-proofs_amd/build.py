@@ -12,15 +12,20 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(CSRC, "_obj")
-LIB = os.path.join(HERE, "libzksp.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+# The round-1 keccak-chip COMPONENT path (include/zksp_component.h: proof format v2, its prover, verifier and keccak-only
+# kernels) is a build switch since round 5: the default libzksp.so does not contain it.  ZKSP_COMPONENT=1 in the
+# environment builds libzksp_component.so - every source below with -DZKSP_COMPONENT plus COMPONENT_SOURCES - which the
+# client loads under the same variable (tests/test_gpu_prover.py, the component tests of tests/test_verifier.py).
+COMPONENT = os.environ.get("ZKSP_COMPONENT", "") == "1"
+OBJ = os.path.join(CSRC, "_obj_component" if COMPONENT else "_obj")
+LIB = os.path.join(HERE, "libzksp_component.so" if COMPONENT else "libzksp.so")
 
 SOURCES = [
     "device/kernels_ntt.hip",
     "device/kernels_hash.hip",
     "device/kernels_stark.hip",
-    "device/kernels_bus.hip",
     "device/kernels_machine.hip",
     "device/kernels_bench.hip",
     "host/executor.cpp",
@@ -28,21 +33,22 @@ SOURCES = [
     "host/params.cpp",
     "host/p2_avx2.cpp",
     "host/context.cpp",
-    "host/prover.cpp",
     "host/mprover.cpp",
-    "host/verifier.cpp",
     "host/machine_defs.cpp",
     "host/mverifier.cpp",
     "host/api.cpp",
     "host/api_prove.cpp",
     "host/api_machine.cpp",
 ]
+COMPONENT_SOURCES = ["device/kernels_bus.hip", "host/prover.cpp", "host/verifier.cpp"]
+if COMPONENT:
+    SOURCES = SOURCES + COMPONENT_SOURCES
 HEADERS = [
     "device/field.hpp", "device/poseidon2.hpp", "device/air_keccak.hpp", "device/air_machine.hpp", "device/kernels.h", "device/kernels_machine.h",
     "host/machine_defs.hpp", "host/mverifier.hpp", "host/mprover.hpp", "host/host_hash.hpp",
     "host/executor.hpp", "host/machine.hpp", "host/context.hpp", "host/prover.hpp", "host/verifier.hpp", "host/api_types.hpp",
 ]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + (["-DZKSP_COMPONENT"] if COMPONENT else [])
 
 
 def _hipcc() -> str:

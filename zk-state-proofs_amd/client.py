@@ -22,7 +22,10 @@ import os
 from typing import List, Optional, Sequence, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libzksp.so")
+# ZKSP_COMPONENT=1: the library built with the round-1 keccak-chip component path (include/zksp_component.h, build.py); the
+# default library has no such path, and PROOF_KECCAK_CHIP clients cannot be created on it
+COMPONENT = os.environ.get("ZKSP_COMPONENT", "") == "1"
+_LIB_PATH = os.path.join(_HERE, "libzksp_component.so" if COMPONENT else "libzksp.so")
 
 OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_ELF, ERR_EXECUTOR, ERR_GUEST_PANIC, ERR_PROOF_FORMAT, ERR_VERIFY, \
@@ -171,14 +174,18 @@ def load_library() -> C.CDLL:
     lib.zksp_hip_machine_fetch_stage.argtypes = [vp, C.c_int, C.c_int, sz, vp, sz]
     lib.zksp_hip_machine_fetch_challenges.argtypes = [vp, sz, vp]
     lib.zksp_get_params.argtypes = [vp, C.POINTER(Params)]
-    lib.zksp_proof_body_words.argtypes = [vp, C.c_int]
-    lib.zksp_proof_body_words.restype = sz
-    lib.zksp_hip_load_batch.argtypes = [vp, C.c_int, sz, sz, vp, vp, vp]
-    lib.zksp_hip_prove_resident.argtypes = [vp]
-    lib.zksp_hip_fetch_bodies.argtypes = [vp, vp, sz]
-    lib.zksp_hip_fetch_roots.argtypes = [vp, vp, sz]
-    lib.zksp_proof_from_body.argtypes = [vp, sz, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_char_p, sz, vp, vp, vp,
-                                         C.POINTER(vp)]
+    if COMPONENT:
+        lib.zksp_proof_body_words.argtypes = [vp, C.c_int]
+        lib.zksp_proof_body_words.restype = sz
+        lib.zksp_hip_load_batch.argtypes = [vp, C.c_int, sz, sz, vp, vp, vp]
+        lib.zksp_hip_prove_resident.argtypes = [vp]
+        lib.zksp_hip_fetch_bodies.argtypes = [vp, vp, sz]
+        lib.zksp_hip_fetch_roots.argtypes = [vp, vp, sz]
+        lib.zksp_proof_from_body.argtypes = [vp, sz, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_char_p, sz, vp, vp, vp,
+                                             C.POINTER(vp)]
+        lib.zksp_hip_keccak_trace.argtypes = [vp, vp, C.c_uint32, C.c_int, vp]
+        lib.zksp_hip_keccak_quotient.argtypes = [vp, vp, vp, C.c_int, vp, vp]
+        lib.zksp_hip_bus_perm_trace.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     lib.zksp_hip_sync.argtypes = [vp]
     lib.zksp_hip_timer_start.argtypes = [vp]
     lib.zksp_hip_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
@@ -194,16 +201,13 @@ def load_library() -> C.CDLL:
     lib.zksp_hip_merkle_commit.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     lib.zksp_hip_poseidon2_permute.argtypes = [vp, vp, sz]
     lib.zksp_host_poseidon2_permute.argtypes = [vp, sz, C.c_int]
-    lib.zksp_hip_keccak_trace.argtypes = [vp, vp, C.c_uint32, C.c_int, vp]
-    lib.zksp_hip_keccak_quotient.argtypes = [vp, vp, vp, C.c_int, vp, vp]
-    lib.zksp_hip_bus_perm_trace.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     lib.zksp_hip_fri_fold.argtypes = [vp, vp, C.c_int, C.c_uint32, vp, vp]
     lib.zksp_hip_microbench.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     _lib = lib
     return lib
 
 
-# every symbol include/zksp.h declares (checked by tests/test_abi.py)
+# every symbol include/zksp.h declares (checked by tests/test_abi.py) ...
 ABI_SYMBOLS = [
     "zksp_client_new", "zksp_client_free", "zksp_last_error", "zksp_setup", "zksp_pk_free", "zksp_vk_free",
     "zksp_vk_digest", "zksp_stdin_new", "zksp_stdin_write", "zksp_stdin_free", "zksp_prove", "zksp_prove_batch",
@@ -213,12 +217,17 @@ ABI_SYMBOLS = [
     "zksp_machine_chip_widths", "zksp_machine_cover_heights", "zksp_stdin_set_aggregation", "zksp_proof_aggregation", "zksp_verify_aggregate",
     "zksp_stdin_set_aggregation_keyed", "zksp_verify_aggregate_keyed", "zksp_stdin_set_verified_leaf", "zksp_stdin_add_verified_leaf", "zksp_leaves_public", "zksp_verify_with_leaves", "zksp_leaf_public", "zksp_verify_public", "zksp_leaf_public_at", "zksp_stdin_add_verified_node", "zksp_proof_stub", "zksp_stdin_add_verified_leaves",
     "zksp_verify_with_leaf", "zksp_proof_public_tuples", "zksp_hip_machine_fetch_stage", "zksp_hip_machine_fetch_challenges",
-    "zksp_hip_machine_load", "zksp_hip_machine_prove", "zksp_hip_release_workspace", "zksp_hip_machine_fetch_bodies", "zksp_hip_machine_fetch_roots", "zksp_machine_proof_from_body", "zksp_get_params", "zksp_proof_body_words", "zksp_hip_load_batch",
-    "zksp_hip_prove_resident", "zksp_proof_from_body", "zksp_hip_fetch_bodies", "zksp_hip_fetch_roots", "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
+    "zksp_hip_machine_load", "zksp_hip_machine_prove", "zksp_hip_release_workspace", "zksp_hip_machine_fetch_bodies", "zksp_hip_machine_fetch_roots", "zksp_machine_proof_from_body", "zksp_get_params",
+    "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
     "zksp_hip_profile_enable", "zksp_hip_profile_read", "zksp_hip_profile_reset", "zksp_dev_malloc", "zksp_dev_free",
     "zksp_dev_upload", "zksp_dev_download", "zksp_dev_memset", "zksp_hip_lde", "zksp_hip_merkle_commit",
-    "zksp_hip_poseidon2_permute", "zksp_host_poseidon2_permute", "zksp_hip_keccak_trace", "zksp_hip_keccak_quotient", "zksp_hip_bus_perm_trace", "zksp_hip_fri_fold",
+    "zksp_hip_poseidon2_permute", "zksp_host_poseidon2_permute", "zksp_hip_fri_fold",
     "zksp_hip_microbench",
+]
+# ... and include/zksp_component.h (only in the library built with ZKSP_COMPONENT=1)
+COMPONENT_ABI_SYMBOLS = [
+    "zksp_proof_body_words", "zksp_hip_load_batch", "zksp_hip_prove_resident", "zksp_proof_from_body", "zksp_hip_fetch_bodies",
+    "zksp_hip_fetch_roots", "zksp_hip_keccak_trace", "zksp_hip_keccak_quotient", "zksp_hip_bus_perm_trace",
 ]
 
 

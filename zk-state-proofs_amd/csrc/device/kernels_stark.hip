@@ -107,12 +107,14 @@ __global__ __launch_bounds__(kThreads) void keccak_trace_kernel(const uint64_t* 
     t[(ka::kAppp00 + l) * cs] = Fp::from_canonical((uint32_t)((appp00 >> (16 * l)) & 0xffff)).v;
 }
 
+#ifdef ZKSP_COMPONENT  // the round-1 keccak-chip component path only (include/zksp_component.h)
 void launch_keccak_trace(hipStream_t stream, const uint64_t* states, int max_perms, const uint32_t* n_perms,
                          uint32_t* trace, int logh, int batch) {
   const int h = 1 << logh;
   hipLaunchKernelGGL(keccak_trace_kernel, dim3((h + kThreads - 1) / kThreads, batch), dim3(kThreads), 0, stream,
                      states, max_perms, n_perms, trace, (size_t)ka::kWidth * h, logh);
 }
+#endif  // ZKSP_COMPONENT
 // the same columns inside a wider per-proof matrix (the machine proof's keccak chip adds a column)
 void launch_keccak_trace_strided(hipStream_t stream, const uint64_t* states, int max_perms, const uint32_t* n_perms,
                                  uint32_t* trace, size_t trace_bstride, int logh, int batch) {
@@ -121,6 +123,7 @@ void launch_keccak_trace_strided(hipStream_t stream, const uint64_t* states, int
                      states, max_perms, n_perms, trace, trace_bstride, logh);
 }
 
+#ifdef ZKSP_COMPONENT  // the round-1 keccak-chip component path only (include/zksp_component.h)
 // ===========================================================================
 // constraint evaluation on the LDE domain -> quotient values
 // ===========================================================================
@@ -259,6 +262,8 @@ void launch_keccak_quotient(hipStream_t stream, const QuotientArgs& a) {
   hipLaunchKernelGGL(keccak_quotient_combine_kernel, dim3(blocks, a.batch), dim3(kThreads), 0, stream, a.partial,
                      a.zh_inv, a.quot, a.logh);
 }
+
+#endif  // ZKSP_COMPONENT
 
 // ===========================================================================
 // powers of an extension element (optionally stored in bit-reversed order)
@@ -915,6 +920,7 @@ void launch_open(hipStream_t stream, const uint32_t* coefs_br, size_t coefs_stri
                      coefs_stride, ncols, logh, zpow_br, zpow_stride, npoints, opened, opened_stride, pt_stride);
 }
 
+#ifdef ZKSP_COMPONENT  // the round-1 keccak-chip component path only (include/zksp_component.h)
 // ===========================================================================
 // reduced openings (DEEP quotient) over the LDE domain
 // ===========================================================================
@@ -1035,6 +1041,8 @@ void launch_reduce_openings(hipStream_t stream, const ReduceArgs& a) {
   hipLaunchKernelGGL(reduce_final_kernel, dim3(blocks, a.batch), dim3(kThreads), 0, stream, a, nchunks);
 }
 int reduce_nchunks(int width) { return (width + kReduceChunk - 1) / kReduceChunk; }
+
+#endif  // ZKSP_COMPONENT
 
 // ===========================================================================
 // FRI fold
@@ -1356,6 +1364,7 @@ void launch_reduce_coefs(hipStream_t stream, const uint32_t* chal, size_t chal_s
                      desc, out, out_stride, n);
 }
 
+#ifdef ZKSP_COMPONENT  // the round-1 keccak-chip component path only (include/zksp_component.h)
 // ===========================================================================
 // proof assembly: everything the verifier reads, canonical u32, one workgroup
 // per query plus one for the fixed part
@@ -1450,5 +1459,7 @@ __global__ __launch_bounds__(kThreads) void assemble_kernel(AssembleArgs a) {
 void launch_assemble(hipStream_t stream, const AssembleArgs& a) {
   hipLaunchKernelGGL(assemble_kernel, dim3(a.n_queries + 1, a.batch), dim3(kThreads), 0, stream, a);
 }
+
+#endif  // ZKSP_COMPONENT
 
 }  // namespace zksp

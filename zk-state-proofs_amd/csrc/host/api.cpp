@@ -1,6 +1,8 @@
 // C ABI of include/zksp.h.  Nothing here throws across the boundary.
 #include "../../../include/zksp.h"
+#ifdef ZKSP_COMPONENT
 #include "../../../include/zksp_component.h"
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -11,8 +13,10 @@
 #include <thread>
 
 #include "context.hpp"
+#ifdef ZKSP_COMPONENT
 #include "prover.hpp"
 #include "verifier.hpp"
+#endif
 #include "machine_defs.hpp"
 #include "host_hash.hpp"
 
@@ -67,6 +71,11 @@ int zksp_client_new(const zksp_options* opts, zksp_client** out) {
   if (ctx.params.keccak_mode != 1 && ctx.params.keccak_mode != 2) { delete c; return ZKSP_ERR_INVALID_ARG; }
   if (ctx.params.pow_bits > 30 || ctx.params.num_queries > 4096) { delete c; return ZKSP_ERR_INVALID_ARG; }
   if (ctx.params.proof_mode != ZKSP_PROOF_MACHINE && ctx.params.proof_mode != ZKSP_PROOF_KECCAK_CHIP) { delete c; return ZKSP_ERR_INVALID_ARG; }
+#ifndef ZKSP_COMPONENT
+  // (the round-1 keccak-chip component path is a build switch: `ZKSP_COMPONENT=1 python -m zk-state-proofs_amd.build` makes
+  // libzksp_component.so, which has it; include/zksp_component.h)
+  if (ctx.params.proof_mode == ZKSP_PROOF_KECCAK_CHIP) { delete c; return ZKSP_ERR_UNSUPPORTED; }
+#endif
   if (dev >= 0) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || dev >= count) { delete c; return ZKSP_ERR_NO_DEVICE; }
@@ -180,13 +189,14 @@ int zksp_execute_keccak(zksp_client* c, const zksp_pk* pk, const zksp_stdin* std
 
 int zksp_get_params(const zksp_client* c, zksp_params* out) {
   if (!c || !out) return ZKSP_ERR_INVALID_ARG;
-  out->trace_width = kTraceWidth;
-  out->num_constraints = kNumConstraints;
+  out->trace_width = ka::kWidth;          // the keccak chip's own columns
+  out->num_constraints = ka::kNumConstraints;
   out->num_queries = c->ctx.params.num_queries;
   out->pow_bits = c->ctx.params.pow_bits;
   out->max_batch = c->ctx.params.max_batch;
   return ZKSP_OK;
 }
+#ifdef ZKSP_COMPONENT
 size_t zksp_proof_body_words(const zksp_client* c, int log_h) {
   if (!c || log_h < 1 || log_h > 26) return 0;
   return proof_body_words(log_h, c->ctx.params.num_queries);
@@ -255,6 +265,8 @@ int zksp_hip_fetch_roots(zksp_client* c, uint32_t* out, size_t cap_words) {
   return ZKSP_OK;
 }
 
+#endif  // ZKSP_COMPONENT
+
 int zksp_hip_sync(zksp_client* c) {
   if (!c || !c->ctx.has_device()) return ZKSP_ERR_INVALID_ARG;
   ZKSP_HIP_CHECK(&c->ctx, hipStreamSynchronize(c->ctx.stream));
@@ -311,9 +323,13 @@ int zksp_proof_public_values(const zksp_proof* p, const uint8_t** ptr, size_t* l
     *len = p->mhdr.pv_len;
     return ZKSP_OK;
   }
+#ifdef ZKSP_COMPONENT
   *ptr = p->bytes.data() + p->hdr.pv_offset;
   *len = p->hdr.pv_len;
   return ZKSP_OK;
+#else
+  return ZKSP_ERR_PROOF_FORMAT;
+#endif
 }
 int zksp_proof_serialize(const zksp_proof* p, const uint8_t** ptr, size_t* len) {
   if (!p || !ptr || !len) return ZKSP_ERR_INVALID_ARG;
@@ -328,17 +344,26 @@ int zksp_proof_deserialize(const uint8_t* buf, size_t len, zksp_proof** out) {
   p->bytes.assign(buf, buf + len);
   std::string err;
   const bool machine = len >= 8 && reinterpret_cast<const uint32_t*>(p->bytes.data())[1] == mach::kMachineVersion;
+#ifdef ZKSP_COMPONENT
   p->version = machine ? mach::kMachineVersion : kProofVersion;
   if (!(machine ? parse_machine_header(p->bytes.data(), p->bytes.size(), &p->mhdr, &err)
                 : parse_proof_header(p->bytes.data(), p->bytes.size(), &p->hdr, &err))) {
     delete p;
     return ZKSP_ERR_PROOF_FORMAT;
   }
+#else
+  p->version = mach::kMachineVersion;
+  if (!machine || !parse_machine_header(p->bytes.data(), p->bytes.size(), &p->mhdr, &err)) {
+    delete p;
+    return ZKSP_ERR_PROOF_FORMAT;
+  }
+#endif
   *out = p;
   return ZKSP_OK;
 }
 void zksp_proof_free(zksp_proof* p) { delete p; }
 
+#ifdef ZKSP_COMPONENT
 int zksp_proof_from_body(const uint32_t* body, size_t body_words, uint32_t log_h, const uint64_t* states, uint32_t n_perms,
                          uint32_t exit_code, const uint8_t* public_values, size_t pv_len, const uint32_t* pv_digest,
                          const uint32_t* deferred_digest, const uint32_t* vk_digest, zksp_proof** out) {
@@ -369,6 +394,7 @@ int zksp_proof_from_body(const uint32_t* body, size_t body_words, uint32_t log_h
     delete p;
     return ZKSP_ERR_INVALID_ARG;
   }
+  p->version = kProofVersion;
   std::string err;
   if (!parse_proof_header(p->bytes.data(), p->bytes.size(), &p->hdr, &err)) {
     delete p;
@@ -377,6 +403,8 @@ int zksp_proof_from_body(const uint32_t* body, size_t body_words, uint32_t log_h
   *out = p;
   return ZKSP_OK;
 }
+
+#endif  // ZKSP_COMPONENT
 
 int zksp_verify(zksp_client* c, const zksp_proof* p, const zksp_vk* vk) {
   if (!c || !p || !vk) return ZKSP_ERR_INVALID_ARG;
@@ -391,10 +419,14 @@ int zksp_verify(zksp_client* c, const zksp_proof* p, const zksp_vk* vk) {
       return c->ctx.fail(ZKSP_ERR_VERIFY, want_machine
                                               ? "verify: not a machine proof (this client verifies proofs of execution only)"
                                               : "verify: not a keccak-chip component proof (client created with ZKSP_PROOF_KECCAK_CHIP)");
+#ifdef ZKSP_COMPONENT
     rc = want_machine ? verify_machine_proof(p->bytes.data(), p->bytes.size(), vk->machine, c->ctx.params.num_queries,
                                              c->ctx.params.pow_bits, &err)
                       : verify_proof(p->bytes.data(), p->bytes.size(), vk->digest, c->ctx.params.num_queries,
                                      c->ctx.params.pow_bits, &err);
+#else
+    rc = verify_machine_proof(p->bytes.data(), p->bytes.size(), vk->machine, c->ctx.params.num_queries, c->ctx.params.pow_bits, &err);
+#endif
   } catch (...) {
     return c->ctx.fail(ZKSP_ERR_VERIFY, "verify: out of memory");
   }
@@ -519,6 +551,7 @@ int zksp_host_poseidon2_permute(uint32_t* states, size_t n, int impl) {
   return ZKSP_OK;
 }
 
+#ifdef ZKSP_COMPONENT  // parity entry points of the component path's keccak-only kernels
 int zksp_hip_keccak_trace(zksp_client* c, const uint64_t* d_states, uint32_t n_perms, int log_h, uint32_t* d_trace) {
   NEED_GPU(c);
   Context* ctx = &c->ctx;
@@ -606,6 +639,8 @@ int zksp_hip_bus_perm_trace(zksp_client* c, const uint32_t* d_trace, int log_h, 
   ZKSP_HIP_CHECK(ctx, hipGetLastError());
   return ZKSP_OK;
 }
+
+#endif  // ZKSP_COMPONENT
 
 int zksp_hip_fri_fold(zksp_client* c, const uint32_t* d_in, int log_hk, uint32_t shift_k, const uint32_t* beta,
                       uint32_t* d_out) {

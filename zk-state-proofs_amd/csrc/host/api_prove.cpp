@@ -27,7 +27,9 @@
 #include "api_types.hpp"
 #include "machine_defs.hpp"
 #include "mprover.hpp"
+#ifdef ZKSP_COMPONENT
 #include "prover.hpp"
+#endif
 
 using namespace zksp;
 
@@ -39,6 +41,7 @@ int ceil_log2(size_t v) {
   return l;
 }
 
+#ifdef ZKSP_COMPONENT  // the round-1 keccak-chip component path (include/zksp_component.h): not in the default library
 int trace_log_height(size_t n_perms) { return ceil_log2(std::max<size_t>(24 * n_perms, 32)); }
 
 struct Job {
@@ -54,6 +57,7 @@ struct Group {
   size_t bw = 0;              // body words per proof
   int slot = 0;               // staging buffer holding its bodies
 };
+#endif
 
 // Host threads this process may use for guest execution and proof assembly.  A GPU box shows
 // every core of its host (hardware_concurrency() = 256) while one process per GPU owns a share of
@@ -534,6 +538,9 @@ static int prove_batch_impl(zksp_client* c, const zksp_pk* pk, zksp_stdin* const
     if (hipSetDevice(c->ctx.device) != hipSuccess) return c->ctx.fail(ZKSP_ERR_HIP, "prove: hipSetDevice failed");
     return prove_batch_machine(c, pk, stdins, n, out, status);
   }
+#ifndef ZKSP_COMPONENT
+  return c->ctx.fail(ZKSP_ERR_UNSUPPORTED, "prove: this library was built without the keccak-chip component path");
+#else
   Context* ctx = &c->ctx;
   if (!ctx->has_device())
     return ctx->fail(ZKSP_ERR_NO_DEVICE, "prove: this client was created without a GPU; there is no CPU proving path");
@@ -636,6 +643,7 @@ static int prove_batch_impl(zksp_client* c, const zksp_pk* pk, zksp_stdin* const
       const uint8_t* body = reinterpret_cast<const uint8_t*>(bodies + j * g.bw);
       p->bytes.insert(p->bytes.end(), body, body + g.bw * 4);
       std::string perr;
+      p->version = kProofVersion;
       if (!parse_proof_header(p->bytes.data(), p->bytes.size(), &p->hdr, &perr)) {
         delete p;
         status[i] = ZKSP_ERR_PROOF_FORMAT;
@@ -780,6 +788,7 @@ static int prove_batch_impl(zksp_client* c, const zksp_pk* pk, zksp_stdin* const
   trace.mark("all assembled", n);
   if (!first_err.empty() && rc_all == ZKSP_OK) ctx->error = first_err;
   return rc_all;
+#endif
 }
 
 int zksp_prove_batch(zksp_client* c, const zksp_pk* pk, zksp_stdin* const* stdins, size_t n, zksp_proof** out,

@@ -7,7 +7,9 @@
 #include "context.hpp"
 #include "machine.hpp"
 #include "mverifier.hpp"
+#ifdef ZKSP_COMPONENT
 #include "verifier.hpp"
+#endif
 
 struct zksp_client { zksp::Context ctx; };
 struct zksp_pk { zksp::ElfImage elf; uint32_t vk_digest[8]; zksp::MachineProgram mprog; zksp::MachineVk mvk; };
@@ -23,7 +25,14 @@ struct zksp_stdin {
   std::vector<uint32_t> agg_keys;    // heap keys of those digests (empty: the leaves of a full tree)
   std::shared_ptr<const zksp::LeafCheckLog> leaf_check;  // leaf-proof check to prove beside the run (zksp_stdin_set_verified_leaf)
 };
-struct zksp_proof { std::vector<uint8_t> bytes; zksp::ProofHeader hdr; zksp::MachineHeader mhdr; uint32_t version = 2; };
+struct zksp_proof {
+  std::vector<uint8_t> bytes;
+#ifdef ZKSP_COMPONENT
+  zksp::ProofHeader hdr;  // (a keccak-chip component proof, format v2)
+#endif
+  zksp::MachineHeader mhdr;
+  uint32_t version = 0;
+};
 
 // api_machine.cpp: the proof object (format mach::kMachineVersion) from an execution record, the chip heights, the aggregation leaves and a fetched body
 int machine_proof_from_parts(const zksp_pk* pk, const zksp::ExecutionRecord& r, const int* log_heights, const uint32_t* handover_pc /* [kNumCpuInst - 1] */,

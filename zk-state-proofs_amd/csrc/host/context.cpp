@@ -1,7 +1,9 @@
 #include "context.hpp"
 
 #include "mprover.hpp"  // MachineWorkspace, PrepDevice
+#ifdef ZKSP_COMPONENT
 #include "prover.hpp"  // Workspace must be complete for ~Context
+#endif
 
 #include <cstring>
 
@@ -42,7 +44,9 @@ Context::~Context() {
       if (e) (void)hipEventDestroy(e);
     if (timer_a) (void)hipEventDestroy(timer_a);
     if (timer_b) (void)hipEventDestroy(timer_b);
+#ifdef ZKSP_COMPONENT
     ws.reset();
+#endif
     mws.reset();
     retired.clear();
     if (arena) (void)hipFree(arena);
@@ -117,6 +121,22 @@ const DeviceDomain* Context::domain(int logh) {
   }
   auto res = domains.emplace(logh, dd);
   return &res.first->second;
+}
+
+ProfileSpan::ProfileSpan(Context* c, const char* name) : ctx(c) {
+  if (!c->profile) return;
+  if (c->event_used == c->event_pool.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    c->event_pool.emplace_back(a, b);
+  }
+  auto& ev = c->event_pool[c->event_used++];
+  idx = c->spans.size();
+  c->spans.push_back({name, ev.first, ev.second});
+  (void)hipEventRecord(ev.first, c->stream);
+}
+ProfileSpan::~ProfileSpan() {
+  if (idx != (size_t)-1) (void)hipEventRecord(ctx->spans[idx].b, ctx->stream);
 }
 
 }  // namespace zksp

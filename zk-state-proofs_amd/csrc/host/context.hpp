@@ -51,7 +51,9 @@ struct Params {
   int proof_mode = 1;  // ZKSP_PROOF_MACHINE
 };
 
-struct Workspace;  // prover.cpp
+#ifdef ZKSP_COMPONENT
+struct Workspace;  // prover.cpp: the round-1 keccak-chip component path (include/zksp_component.h)
+#endif
 struct MachineWorkspace;  // mprover.cpp
 struct PrepDevice;
 
@@ -62,7 +64,9 @@ struct Context {
   Params params;
   std::map<int, DeviceDomain> domains;
   std::map<uint32_t, std::vector<uint32_t*>> qscale;  // custom in_shift scale tables for zksp_hip_lde
+#ifdef ZKSP_COMPONENT
   std::unique_ptr<Workspace> ws;
+#endif
   // machine proof: batch workspace, per-program preprocessed tables (by verifying-key digest),
   // device copies of the chips' bus interactions
   std::unique_ptr<MachineWorkspace> mws;
@@ -122,9 +126,21 @@ struct Context {
   const DeviceDomain* domain(int logh);  // builds + uploads on first use; nullptr on error
 };
 
+constexpr uint32_t kProofMagic = 0x50534B5Au;  // "ZKSP": the first word of every proof
+
+// RAII span used when ctx->profile is on
+struct ProfileSpan {
+  Context* ctx;
+  size_t idx = (size_t)-1;
+  ProfileSpan(Context* c, const char* name);
+  ~ProfileSpan();
+};
+
+#ifdef ZKSP_COMPONENT
 size_t proof_body_words(int logh, uint32_t num_queries);
 size_t proof_header_words(uint32_t pv_len, uint32_t n_perms);
 int bus_io_log_rows(int logh);
+#endif
 
 #define ZKSP_HIP_CHECK(ctx, call)                                                         \
   do {                                                                                    \

@@ -7,7 +7,7 @@
 
 #include "machine.hpp"
 #include "machine_defs.hpp"
-#include "verifier.hpp"
+#include "context.hpp"
 
 namespace zksp {
 

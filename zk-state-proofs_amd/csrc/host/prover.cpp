@@ -13,22 +13,6 @@ Workspace::~Workspace() {
     if (p) (void)hipFree(p);
 }
 
-ProfileSpan::ProfileSpan(Context* c, const char* name) : ctx(c) {
-  if (!c->profile) return;
-  if (c->event_used == c->event_pool.size()) {
-    hipEvent_t a, b;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-    c->event_pool.emplace_back(a, b);
-  }
-  auto& ev = c->event_pool[c->event_used++];
-  idx = c->spans.size();
-  c->spans.push_back({name, ev.first, ev.second});
-  (void)hipEventRecord(ev.first, c->stream);
-}
-ProfileSpan::~ProfileSpan() {
-  if (idx != (size_t)-1) (void)hipEventRecord(ctx->spans[idx].b, ctx->stream);
-}
-
 template <class T>
 static bool dalloc(Workspace* ws, T** p, size_t count) {
   void* q = nullptr;

@@ -44,12 +44,4 @@ int workspace_ensure(Context* ctx, int logh, int batch, int max_perms);
 // enqueues the whole proving pass over the resident batch
 int prove_resident(Context* ctx);
 
-// RAII span used when ctx->profile is on
-struct ProfileSpan {
-  Context* ctx;
-  size_t idx = (size_t)-1;
-  ProfileSpan(Context* c, const char* name);
-  ~ProfileSpan();
-};
-
 }  // namespace zksp

@@ -9,7 +9,6 @@
 
 namespace zksp {
 
-constexpr uint32_t kProofMagic = 0x50534B5Au;  // "ZKSP"
 constexpr uint32_t kProofVersion = 2;  // 2: LogUp bus + public I/O list
 
 struct ProofHeader {
