@@ -13,7 +13,8 @@ zk = importlib.import_module("zk-state-proofs_amd")
 fx = importlib.import_module("zk-state-proofs_amd.fixtures")
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-client = zk.ProverClient(device=0, max_batch=B)
+CAP = int(sys.argv[2]) if len(sys.argv) > 2 else B  # the client's max_batch (bench.py measures a batch of one on a client of 192)
+client = zk.ProverClient(device=0, max_batch=CAP)
 lib, h = client._lib, client._h
 pk, vk = client.setup(zk.merkle_elf())
 handles = []
