@@ -168,3 +168,35 @@ def test_stale_json_guest_is_a_second_regression_input(zk, fx, host_client):
     # software and observed runs execute the same instruction stream
     rep0, _, _, _ = host_client.execute(pk, s, zk.KECCAK_SOFTWARE)
     assert rep0.cycles == rep.cycles
+
+
+def test_precompile_key_is_refused_for_a_function_that_is_not_keccak_f(zk, host_client):
+    """The precompile shape replaces calls of the functions an ELF names keccakf by the keccak chip, so its verifying key
+    stands for "those functions are keccak-f".  Key generation checks it: every such function is run by the executor on test
+    states and compared with keccak-f[1600] (executor.hpp check_keccakf_entries) - the committed guest's two pass (every
+    other test's setup), a function of that name that does something else is refused.  The as-committed shape, which
+    replaces nothing, takes any ELF."""
+    import toy_guest as tg
+    ret = tg.i_type(0, 1, 0, 0, opc=0x67)  # jalr x0, 0(ra)
+    body = tg.li(tg.A0, 0x00300000) + [0, 0] + tg.epilogue()  # (two slots for the call, patched below)
+    fn = tg.TEXT + 4 * len(body)
+    call = 2  # index of the first slot
+    # jal ra, fn
+    off = fn - (tg.TEXT + 4 * call)
+    jal = (((off >> 20) & 1) << 31) | (((off >> 1) & 0x3FF) << 21) | (((off >> 11) & 1) << 20) | (((off >> 12) & 0xFF) << 12) | (1 << 7) | 0x6F
+    body[call] = jal
+    body[call + 1] = tg.i_type(0, 0, 0, 0)  # nop
+    for name, fbody in (("tiny_keccak::keccakf::keccakf", [ret]),                                      # returns at once: the state is unchanged
+                        ("keccakf", [tg.i_type(1, tg.A0, 0, tg.A0), tg.r_type(0, 0, 0, 0, 0), ret])):   # clobbers a0, still not keccak-f
+        elf = tg.elf_of(body + fbody, symbols={name: fn})
+        with pytest.raises(zk.ZkspError) as ei:
+            host_client.setup(elf)
+        assert "does not compute keccak-f" in str(ei.value)
+        # a function that never returns properly is refused too
+    loop = tg.elf_of(body + [0x0000006F], symbols={"keccakf": fn})  # jal x0, 0: spins until the cycle limit
+    with pytest.raises(zk.ZkspError) as ei:
+        host_client.setup(loop)
+    assert "did not return" in str(ei.value)
+    # without the symbol the same program is an ordinary guest; with it, the as-committed shape (keccak_mode 1) replaces nothing
+    host_client.setup(tg.elf_of(body + [ret]))
+    zk.ProverClient(device=-1, keccak_mode=1).setup(tg.elf_of(body + [ret], symbols={"keccakf": fn}))

@@ -47,15 +47,30 @@ def epilogue():
     return out
 
 
-def elf_of(instrs):
-    """ELF32 little-endian RISC-V executable: one PT_LOAD (R+X) segment holding `instrs` at TEXT, entry at its start."""
+def elf_of(instrs, symbols=None):
+    """ELF32 little-endian RISC-V executable: one PT_LOAD (R+X) segment holding `instrs` at TEXT, entry at its start.
+    symbols: {name: address} of FUNC symbols (a .symtab / .strtab pair behind the code), or none."""
     code = b"".join(struct.pack("<I", w & M32) for w in instrs)
     ehsize, phsize = 52, 32
     off = ehsize + phsize
+    tail, shoff, shnum = b"", 0, 0
+    if symbols:
+        strtab = b"\0"
+        symtab = bytes(16)  # the null symbol
+        for name, addr in symbols.items():
+            symtab += struct.pack("<IIIBBH", len(strtab), addr, 4, 0x12, 0, 1)  # GLOBAL FUNC
+            strtab += name.encode() + b"\0"
+        sym_off = off + len(code)
+        str_off = sym_off + len(symtab)
+        shoff = str_off + len(strtab)
+        sh = bytes(40)  # the null section
+        sh += struct.pack("<IIIIIIIIII", 0, 2, 0, 0, sym_off, len(symtab), 2, 1, 4, 16)   # .symtab, linked to section 2
+        sh += struct.pack("<IIIIIIIIII", 0, 3, 0, 0, str_off, len(strtab), 0, 0, 1, 0)    # .strtab
+        tail, shnum = symtab + strtab + sh, 3
     eh = b"\x7fELF" + bytes([1, 1, 1, 0]) + bytes(8)
-    eh += struct.pack("<HHIIIIIHHHHHH", 2, 0xF3, 1, TEXT, ehsize, 0, 0, ehsize, phsize, 1, 40, 0, 0)
+    eh += struct.pack("<HHIIIIIHHHHHH", 2, 0xF3, 1, TEXT, ehsize, shoff, 0, ehsize, phsize, 1, 40, shnum, 0)
     ph = struct.pack("<IIIIIIII", 1, off, TEXT, TEXT, len(code), len(code), 5, 4)
-    return eh + ph + code
+    return eh + ph + code + tail
 
 
 def semantics(name, b, c):

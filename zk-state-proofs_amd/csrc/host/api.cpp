@@ -107,6 +107,12 @@ int zksp_setup(zksp_client* c, const uint8_t* elf, size_t elf_len, zksp_pk** pk,
     delete p; delete v;  // a machine proof of a guest without keccak is a keccak chip of padding rows only
     return c->ctx.fail(ZKSP_ERR_ELF, "setup: ELF has no keccakf symbol; the keccak chip has nothing to prove");
   }
+  if (c->ctx.params.keccak_mode == (int)KeccakMode::kReplace) {
+    // the precompile shape replaces calls of these addresses by the keccak chip: its key is only made for an ELF whose
+    // functions of that name are keccak-f on the test states (executor.hpp check_keccakf_entries)
+    const std::string ke = check_keccakf_entries(p->elf);
+    if (!ke.empty()) { delete p; delete v; return c->ctx.fail(ZKSP_ERR_ELF, "setup: " + ke); }
+  }
   {
     std::string me = build_machine_program(p->elf, (KeccakMode)c->ctx.params.keccak_mode, &p->mprog);
     if (!me.empty()) { delete p; delete v; return c->ctx.fail(ZKSP_ERR_ELF, "setup: " + me); }

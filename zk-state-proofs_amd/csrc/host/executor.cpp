@@ -4,6 +4,7 @@
 
 #include <sys/mman.h>
 
+#include <cstdio>
 #include <cstring>
 
 namespace zksp {
@@ -354,7 +355,7 @@ void run(const ElfImage& elf, const std::vector<std::vector<uint8_t>>& stdin_ent
 #define JUMP(t)                                                                      \
   do {                                                                               \
     const uint32_t t_ = (uint32_t)(t), off_ = t_ - text_lo;                          \
-    if (off_ >= text_bytes || (t_ & 3)) FAULT("pc outside text segment");            \
+    if (off_ >= text_bytes || (t_ & 3)) { rec.fault_target = t_; FAULT("pc outside text segment"); } \
     idx = off_ >> 2;                                                                 \
   } while (0)
 // fetch + dispatch, replicated in every handler so each has its own indirect jump
@@ -377,7 +378,14 @@ void run(const ElfImage& elf, const std::vector<std::vector<uint8_t>>& stdin_ent
   } while (0)
 
   uint8_t op = 0;
-  JUMP(elf.entry);
+  if (opt.call_pc) {  // one function of the guest: it returns to the address behind the text
+    x[10] = opt.call_a0;
+    x[2] = opt.call_sp;
+    x[1] = text_lo + text_bytes;
+    JUMP(opt.call_pc);
+  } else {
+    JUMP(elf.entry);
+  }
   FETCH();
 
 rare:  // a keccakf entry point, or the sentinel behind the last instruction
@@ -562,10 +570,55 @@ ExecutionRecord execute(const ElfImage& elf, const std::vector<std::vector<uint8
     rec.error = "ELF image was not decoded (load_elf)";
     return rec;
   }
+  if (opt.call_pc) {
+    if ((opt.call_a0 & 7) || (uint64_t)opt.call_a0 + 200 > kMemBytes || !opt.call_state) {
+      rec.error = "call: bad state pointer";
+      return rec;
+    }
+    memcpy(M + opt.call_a0, opt.call_state, 200);
+  }
   if (opt.want_hist) run<true>(elf, stdin_entries, opt, M, rec);
   else run<false>(elf, stdin_entries, opt, M, rec);
   if (opt.want_hist) rec.opcode_hist.resize(OP_COUNT);
+  if (opt.call_pc) memcpy(rec.call_state_out, M + opt.call_a0, 200);
   return rec;
+}
+
+std::string check_keccakf_entries(const ElfImage& elf) {
+  // the zero state, a state of all ones, and two states from a fixed xorshift stream
+  uint64_t vec[4][25];
+  uint64_t z = 0x9e3779b97f4a7c15ull;
+  for (int i = 0; i < 25; ++i) {
+    vec[0][i] = 0;
+    vec[1][i] = ~0ull;
+    for (int v = 2; v < 4; ++v) {
+      z ^= z << 13; z ^= z >> 7; z ^= z << 17;
+      vec[v][i] = z;
+    }
+  }
+  const uint32_t text_end = elf.text_base + 4 * (uint32_t)elf.text.size();
+  for (uint32_t e : elf.keccakf_entries) {
+    char where[32];
+    snprintf(where, sizeof where, "0x%x", e);
+    for (int v = 0; v < 4; ++v) {
+      ExecOptions o;
+      o.keccak_mode = KeccakMode::kSoftware;
+      o.max_cycles = 1u << 22;  // (a software keccak-f is some 30 000 cycles)
+      o.call_pc = e;
+      o.call_a0 = (uint32_t)(kMemBytes - 4096);
+      o.call_sp = (uint32_t)(kMemBytes - 65536);
+      o.call_state = vec[v];
+      const ExecutionRecord r = execute(elf, {}, o);
+      if (r.error != "pc outside text segment" || r.fault_target != text_end)
+        return std::string("the function at ") + where + " (named keccakf) did not return from a test call: " + r.error;
+      uint64_t want[25];
+      memcpy(want, vec[v], 200);
+      keccak_f1600(want);
+      if (memcmp(want, r.call_state_out, 200) != 0)
+        return std::string("the function at ") + where + " is named keccakf but does not compute keccak-f[1600] on the test states";
+    }
+  }
+  return "";
 }
 
 }  // namespace zksp

@@ -71,12 +71,21 @@ struct ExecutionRecord {
   bool analysis_fill = false;
   uint64_t syscall_counts[256] = {0}; // indexed by low byte of the code
   std::vector<uint64_t> opcode_hist;  // indexed by Op (filled when want_hist)
+  // a run that ended on a jump outside the text: where to (a function called through ExecOptions::call_pc returns to the
+  // address behind the text, which is how its return is told from a fault), and the 200 bytes at call_a0 when it ended
+  uint32_t fault_target = 0;
+  uint64_t call_state_out[25] = {0};
 };
 
 struct ExecOptions {
   KeccakMode keccak_mode = KeccakMode::kObserve;
   uint64_t max_cycles = 1ull << 28;
   bool want_hist = false;
+  // call ONE function of the guest instead of running it from its entry point: pc = call_pc, a0 = call_a0 pointing at
+  // the 200 bytes of call_state, sp = call_sp, ra = the address behind the text (key generation checks with this that a
+  // function the precompile shape replaces by the keccak chip computes keccak-f: check_keccakf_entries)
+  uint32_t call_pc = 0, call_a0 = 0, call_sp = 0;
+  const uint64_t* call_state = nullptr;
 };
 
 // Opcode ids (also indexes ExecutionRecord::opcode_hist).
@@ -98,6 +107,10 @@ const char* op_name(int op);
 // SP1Stdin::write buffer, already framed by the caller).
 ExecutionRecord execute(const ElfImage& elf, const std::vector<std::vector<uint8_t>>& stdin_entries,
                         const ExecOptions& opt);
+// Every function the ELF names keccakf, run on test states by the executor (software, nothing replaced) and compared with
+// keccak-f[1600]: "" if all agree, else what differs.  The precompile shape's verifying key stands for "calls of these
+// addresses are keccak-f"; this is the check, at key generation, that they are - on vectors, not a proof.
+std::string check_keccakf_entries(const ElfImage& elf);
 
 // keccak-f[1600] on 25 little-endian lanes (state[x + 5*y]).
 void keccak_f1600(uint64_t st[25]);
