@@ -381,42 +381,52 @@ def leaf_check_mode(zk, fx, client, pk, vk, payload):
                  "statement": "one run whose proof establishes the query phases of four leaf proofs under their own transcripts' "
                               "challenges; verified on the host with the four leaves' stubs"}
     # config 5 in small: 16 leaves -> 4 nodes -> 1 root; the nodes are leaves of the root (with their own statements)
-    n_tree = 16
-    tl = []
-    for i in range(n_tree):
-        si = zk.SP1Stdin()
-        si.write(fx.acct_fixture(8, seed=4100 + i).to_borsh())
-        tl.append(si)
-    t1 = time.perf_counter()
-    tleaves, status = client.prove_batch(pk, tl)
-    leaves_s = time.perf_counter() - t1
-    assert status == [0] * n_tree
+    def recursion_tree(n_tree, seed0):
+        tl = []
+        for i in range(n_tree):
+            si = zk.SP1Stdin()
+            si.write(fx.acct_fixture(8, seed=seed0 + i).to_borsh())
+            tl.append(si)
+        t1 = time.perf_counter()
+        tleaves, status = client.prove_batch(pk, tl)
+        leaves_s = time.perf_counter() - t1
+        assert status == [0] * n_tree
+        del tl
 
-    def make_stdin(depth, k):
-        sdin = zk.SP1Stdin()
-        sdin.write(fx.acct_fixture(8, seed=4200 + 16 * depth + k).to_borsh())
-        return sdin
+        def make_stdin(depth, k):
+            sdin = zk.SP1Stdin()
+            sdin.write(fx.acct_fixture(8, seed=seed0 + 100_000 + 4096 * depth + k).to_borsh())
+            return sdin
 
-    t1 = time.perf_counter()
-    levels, _statements = farm.prove_tree(client, host, pk, vk, tleaves, make_stdin, arity)
-    tree_s = time.perf_counter() - t1
-    root = levels[-1][0]
-    stubs = farm.tree_of_stubs(levels, arity)
-    t1 = time.perf_counter()
-    host.verify_tree(root, vk, stubs)
-    tree_verify_s = time.perf_counter() - t1
-    below = [p for lv in levels[:-1] for p in lv]
-    rraw = root.to_bytes()
-    rshape = [int.from_bytes(rraw[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
-    tree = {"levels": [len(lv) for lv in levels], "leaves_prove_batch_s": leaves_s, "nodes_and_root_s": tree_s,
-            "root_verify_from_stubs_s": tree_verify_s, "root_proof_bytes": len(rraw),
-            "stub_bytes_read": sum(len(p.stub().to_bytes()) for p in below), "full_proof_bytes_below_the_root": sum(len(p.to_bytes()) for p in below),
-            "root_poseidon2_chip_log_height": rshape[names.index("poseidon2")],
-            "statement": "the root's proof checks the query phases of its four nodes, each of which checks four leaves; verifying the "
-                         "root reads the root proof and the STUBS (no query phase) of the 20 proofs below it: their bus balance and "
-                         "constraint identity at zeta are still checked natively (stage 2b)"}
+        t1 = time.perf_counter()
+        levels, _statements = farm.prove_tree(client, host, pk, vk, tleaves, make_stdin, arity)
+        tree_s = time.perf_counter() - t1
+        root = levels[-1][0]
+        stubs = farm.tree_of_stubs(levels, arity)
+        t1 = time.perf_counter()
+        host.verify_tree(root, vk, stubs)
+        tree_verify_s = time.perf_counter() - t1
+        below = [p for lv in levels[:-1] for p in lv]
+        n_nodes = sum(len(lv) for lv in levels[1:])
+        rraw = root.to_bytes()
+        rshape = [int.from_bytes(rraw[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
+        return {"levels": [len(lv) for lv in levels], "leaves_prove_batch_s": leaves_s, "nodes_and_root_s": tree_s,
+                "ms_per_node": tree_s * 1e3 / n_nodes, "leaves_per_s_through_the_whole_tree": n_tree / (leaves_s + tree_s),
+                "root_verify_from_stubs_s": tree_verify_s, "root_proof_bytes": len(rraw),
+                "stub_bytes_read": sum(len(p.stub().to_bytes()) for p in below),
+                "full_proof_bytes_below_the_root": sum(len(p.to_bytes()) for p in below),
+                "root_poseidon2_chip_log_height": rshape[names.index("poseidon2")],
+                "statement": f"every node's proof checks the query phases of its {arity} children (leaves, or nodes with their own "
+                             "statements); verifying the root reads the root proof and the STUBS (no query phase) of the "
+                             f"{len(below)} proofs below it: their bus balance and constraint identity at zeta are still checked "
+                             "natively (stage 2b).  The host's leaf checks of a level run beside the proving of the nodes that are "
+                             "ready (farm.prove_tree_level)"}
+
+    tree = recursion_tree(16, 4100)
+    # BASELINE config 5 at a quarter of its size: 256 leaf proofs -> 64 -> 16 -> 4 -> 1 (85 node proofs)
+    tree256 = recursion_tree(256, 8000)
     return {"poseidon2_rows": rows, "query_rows": qrows, "transcript_rows": trows, "public_tuples": tuples, "tree_node_of_4": tree_node,
-            "two_level_tree": tree,
+            "two_level_tree": tree, "tree_of_256_leaves": tree256,
             "poseidon2_chip_log_height": shape[names.index("poseidon2")],
             "query_chip_log_height": shape[names.index("query")],
             "host_log_ms": log_ms, "prove_end_to_end_ms": prove_ms, "plain_prove_end_to_end_ms": plain_ms,

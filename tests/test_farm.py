@@ -268,3 +268,60 @@ def test_recursion_tree_world2_gloo(tmp_path, zk):
     assert r0 == r1
     read, full, root_len = (int(x) for x in np.load(tmp_path / "sizes.npy"))
     assert read < full  # (3 queries here: at the full 100 the stubs are a twentieth of the proofs)
+
+
+def test_tree_level_pipeline_orders_groups_and_fails_cleanly():
+    """farm.prove_tree_level with many nodes: the leaf checks of the next nodes run on a helper thread while the ready nodes
+    are proven, in calls of at most `group` nodes; proofs come back in node order whatever the grouping was; a failing check
+    surfaces in the caller and stops the helper; the unpipelined path gives the same result.  (A stand-in client: no
+    cryptography here - the real thing is tests/test_gpu_machine.py::test_two_level_tree_matches_oracle and bench.py.)"""
+    import threading
+    import time
+    farm = importlib.import_module("zk-state-proofs_amd.farm")
+
+    class Stub:
+        def __init__(self, fail_at=None, slow=0.0):
+            self.checked, self.calls, self.fail_at, self.slow, self.threads = [], [], fail_at, slow, set()
+
+        def clear_verified_leaves(self, stdin):
+            stdin["leaves"] = None
+
+        def add_verified_leaves(self, stdin, leaves, vks, statements):
+            self.threads.add(threading.get_ident())
+            if self.fail_at is not None and stdin["k"] == self.fail_at:
+                raise RuntimeError("leaf does not verify")
+            time.sleep(self.slow)
+            stdin["leaves"] = list(leaves)
+            self.checked.append(stdin["k"])
+
+        def prove_batch(self, pk, stdins):
+            assert all(s["leaves"] is not None for s in stdins)  # never proven before its leaves were checked
+            self.calls.append([s["k"] for s in stdins])
+            time.sleep(0.01)
+            return [("proof", s["k"], tuple(s["leaves"])) for s in stdins], [0] * len(stdins)
+
+    leaves = list(range(23))
+    for pipeline in (True, False):
+        c = Stub(slow=0.002)
+        stdins = [{"k": k} for k in range(6)]
+        mine, proofs, st = farm.prove_tree_level(c, None, "vk", leaves, stdins, 4, 0, 1, None, pipeline=pipeline, group=2)
+        assert mine == list(range(6)) and st == [0] * 6
+        assert proofs == [("proof", k, tuple(range(4 * k, min(4 * k + 4, 23)))) for k in range(6)]
+        assert sorted(k for call in c.calls for k in call) == list(range(6)) and c.checked == list(range(6))
+        if pipeline:
+            assert all(len(call) <= 2 for call in c.calls) and threading.get_ident() not in c.threads
+        else:
+            assert c.calls == [list(range(6))]
+    # sharded: rank 1 of 2 gets the odd nodes
+    c = Stub()
+    mine, proofs, st = farm.prove_tree_level(c, None, "vk", leaves, [{"k": k} for k in range(6)], 4, 1, 2, None, group=16)
+    assert mine == [1, 3, 5] and [p[1] for p in proofs] == [1, 3, 5]
+    # a separate checking client takes the checks, the proving client only proves
+    prover, checker = Stub(), Stub()
+    farm.prove_tree_level(prover, None, "vk", leaves, [{"k": k} for k in range(6)], 4, 0, 1, None, checker=checker)
+    assert checker.checked == list(range(6)) and not prover.checked and prover.calls
+    # a leaf that does not verify: the caller sees it, nothing hangs
+    c = Stub(fail_at=3)
+    with pytest.raises(RuntimeError, match="leaf does not verify"):
+        farm.prove_tree_level(c, None, "vk", leaves, [{"k": k} for k in range(6)], 4, 0, 1, None, group=1)
+    assert 4 not in c.checked and 5 not in c.checked

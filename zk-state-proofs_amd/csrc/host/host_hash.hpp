@@ -4,6 +4,7 @@
 #pragma once
 #include <cstddef>
 #include <atomic>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -142,12 +143,26 @@ inline void list_root(const std::vector<Fp>& words, int logr, Fp out[8], const P
       ~Joiner() { for (auto& t : th) if (t.joinable()) t.join(); }
     } pool;
     std::atomic<size_t> next{0};
-    auto worker = [&]() { for (size_t p; (p = next.fetch_add(1)) < parts;) subtree(p * (R / parts), R / parts, &top[8 * p]); };
-    try {
-      for (size_t t = 1; t < parts; ++t) pool.th.emplace_back(worker);
-    } catch (...) {
-    }  // fewer threads than wanted: the parts are claimed from one counter
-    worker();
+    std::atomic<bool> failed{false};  // (a part that ran out of memory: reported by the calling thread, never thrown on another)
+    auto worker = [&]() noexcept {
+      for (size_t p; (p = next.fetch_add(1)) < parts;) {
+        try {
+          subtree(p * (R / parts), R / parts, &top[8 * p]);
+        } catch (...) {
+          failed = true;
+        }
+      }
+    };
+    {
+      Joiner& jp = pool;
+      try {
+        for (size_t t = 1; t < parts; ++t) jp.th.emplace_back(worker);
+      } catch (...) {
+      }  // fewer threads than wanted: the parts are claimed from one counter
+      worker();
+      for (auto& t : jp.th) if (t.joinable()) t.join();
+    }
+    if (failed) throw std::bad_alloc();
   }
   for (size_t n = parts; n > 1; n >>= 1)
     for (size_t i = 0; i < n / 2; ++i) {

@@ -80,35 +80,92 @@ def tree_node_groups(n_leaves: int, arity: int) -> List[List[int]]:
 
 
 def prove_tree_level(client, pk, leaf_vk, leaves: Sequence, node_stdins: Sequence, arity: int, rank: int, world: int,
-                     statements: Optional[Sequence] = None):
+                     statements: Optional[Sequence] = None, pipeline: bool = True, group: int = 16, checker=None):
     """One level of BASELINE config 5's recursion tree over the farm (stage 2b): node k is one
     more guest run (node_stdins[k]) whose proof also checks the query phases of its `arity` leaf proofs under the challenges
     their own transcripts yield (client.add_verified_leaf, in leaf order; a leaf that is itself a node comes with the
     statement its proof was made for: statements[i], client.add_verified_node).  Nodes are independent of one another and shard block-cyclically over the
     ranks like any other proofs; every rank holds all the leaves (they were all-gathered or are on shared storage - a node's
-    host part verifies its leaves before anything is proven).  The stdins of this rank's nodes are CONSUMED: whatever leaf
+    host part verifies its leaves before the node is proven; with more than two nodes and `pipeline`, the checks of the next nodes
+    run beside the proving of the ready ones - on `checker`, a client of the same parameters that needs no GPU, if one is given:
+    the proving client's error state is then its own).  The stdins of this rank's nodes are CONSUMED: whatever leaf
     checks they carried are replaced by the node's own (so a retry of the level does not double them).  Returns (node
     indices of this rank, their proofs, status)."""
     groups = tree_node_groups(len(leaves), arity)
     if len(node_stdins) != len(groups):
         raise ValueError("one stdin per node")
     mine = shard_indices(len(groups), rank, world)
-    stdins = []
-    for k in mine:
-        client.clear_verified_leaves(node_stdins[k])
+
+    chk = checker if checker is not None else client
+
+    def check_leaves(k):
+        # the host's part of node k: its leaves verified and logged (side by side, on the library's threads)
+        chk.clear_verified_leaves(node_stdins[k])
         g = groups[k]
-        if hasattr(client, "add_verified_leaves"):  # (the leaves of a node are verified and logged side by side)
-            client.add_verified_leaves(node_stdins[k], [leaves[i] for i in g], [leaf_vk] * len(g),
-                                       None if statements is None else [statements[i] for i in g])
+        if hasattr(chk, "add_verified_leaves"):
+            chk.add_verified_leaves(node_stdins[k], [leaves[i] for i in g], [leaf_vk] * len(g),
+                                    None if statements is None else [statements[i] for i in g])
         else:
             for i in g:
                 if statements is not None and statements[i] is not None:
-                    client.add_verified_node(node_stdins[k], leaves[i], leaf_vk, statements[i])
+                    chk.add_verified_node(node_stdins[k], leaves[i], leaf_vk, statements[i])
                 else:
-                    client.add_verified_leaf(node_stdins[k], leaves[i], leaf_vk)
-        stdins.append(node_stdins[k])
-    proofs, status = client.prove_batch(pk, stdins) if mine else ([], [])
-    return mine, proofs, status
+                    chk.add_verified_leaf(node_stdins[k], leaves[i], leaf_vk)
+
+    if len(mine) <= 2 or not pipeline:
+        for k in mine:
+            check_leaves(k)
+        proofs, status = client.prove_batch(pk, [node_stdins[k] for k in mine]) if mine else ([], [])
+        return mine, proofs, status
+    # Many nodes: the host checks the leaves of the next nodes WHILE the GPU proves the ones that are ready (the library's
+    # calls release the interpreter lock) - a level then takes the longer of the two parts, not their sum: a node of four
+    # full-size leaves is 22 ms of host work and 35 ms of proving (bench.py leaf_check).  The nodes whose checks are done
+    # when the GPU comes back form the next prove_batch call (at most `group` of them: a node's Poseidon2 chip is 2^19 rows).
+    import queue
+    import threading
+    ready: "queue.Queue" = queue.Queue()
+
+    stop = threading.Event()
+
+    def producer():
+        try:
+            for k in mine:
+                if stop.is_set():
+                    break
+                check_leaves(k)
+                ready.put(k)
+            ready.put(None)
+        except BaseException as e:  # handed to the consuming thread
+            ready.put(e)
+
+    th = threading.Thread(target=producer, daemon=True)
+    th.start()
+    done, proofs_of, status_of = False, {}, {}
+    try:
+        while not done:
+            batch = []
+            item = ready.get()
+            while True:
+                if item is None:
+                    done = True
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                batch.append(item)
+                if len(batch) >= group:
+                    break
+                try:
+                    item = ready.get_nowait()
+                except queue.Empty:
+                    break
+            if batch:
+                pr, st = client.prove_batch(pk, [node_stdins[k] for k in batch])
+                for k, p_, s_ in zip(batch, pr, st):
+                    proofs_of[k], status_of[k] = p_, s_
+    finally:
+        stop.set()
+        th.join()
+    return mine, [proofs_of[k] for k in mine], [status_of[k] for k in mine]
 
 
 def verify_tree_level(client, vk, leaf_vk, leaves: Sequence, nodes: Sequence, arity: int) -> None:
@@ -152,7 +209,7 @@ def prove_tree(client, host, pk, vk, leaves: Sequence, make_stdin: Callable, ari
         below, st_below = levels[-1], statements[-1]
         groups = tree_node_groups(len(below), arity)
         node_stdins = [make_stdin(depth, k) for k in range(len(groups))]
-        mine, proofs, status = prove_tree_level(client, pk, vk, below, node_stdins, arity, rank, world, st_below)
+        mine, proofs, status = prove_tree_level(client, pk, vk, below, node_stdins, arity, rank, world, st_below, checker=host)
         if status != [0] * len(mine):
             raise RuntimeError(f"level {depth}: a node of rank {rank} failed: {client.last_error()}")
         local = []
