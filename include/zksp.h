@@ -281,6 +281,11 @@ int zksp_proof_stub(const zksp_proof* p, zksp_proof** out);
 /* zksp_leaf_public for the leaf at place `leaf_index` beside one run, which itself closes its buses with own_tuples (a node) */
 int zksp_leaf_public_at(zksp_client* c, const zksp_proof* leaf_or_stub, const zksp_vk* leaf_vk, uint32_t leaf_index,
                         const uint32_t* own_tuples, size_t n_own_tuples, uint32_t* out, size_t cap_words, size_t* n_tuples);
+/* The statement of the proof that will be made from this stdin - the public bus tuples of the leaf checks it carries so far, in
+ * the order they were added (zksp_stdin_add_verified_leaf(s) / _node computed them when they verified the leaves): what
+ * zksp_leaves_public would derive again from the leaves.  n_tuples = 0 for a stdin without leaf checks.  Read it BEFORE
+ * proving: zksp_prove(_batch) consumes a stdin's leaf checks. */
+int zksp_stdin_public_tuples(const zksp_stdin* s, uint32_t* out, size_t cap_words, size_t* n_tuples);
 /* Several leaves at once, verified and logged side by side on the host's threads (a node of arity n in one call); own_tuples /
  * n_own_tuples: NULL, or per leaf the statement its proof was made for (NULL / 0 for a plain leaf) */
 int zksp_stdin_add_verified_leaves(zksp_client* c, zksp_stdin* s, const zksp_proof* const* leaves, const zksp_vk* const* leaf_vks,

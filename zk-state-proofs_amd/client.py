@@ -165,6 +165,7 @@ def load_library() -> C.CDLL:
     lib.zksp_verify_with_leaves.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.zksp_leaf_public.argtypes = [vp, vp, vp, vp, sz, C.POINTER(sz)]
     lib.zksp_leaf_public_at.argtypes = [vp, vp, vp, C.c_uint32, vp, sz, vp, sz, C.POINTER(sz)]
+    lib.zksp_stdin_public_tuples.argtypes = [vp, vp, sz, C.POINTER(sz)]
     lib.zksp_stdin_add_verified_node.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.zksp_proof_stub.argtypes = [vp, C.POINTER(vp)]
     lib.zksp_stdin_add_verified_leaves.argtypes = [vp, vp, vp, vp, vp, vp, sz]
@@ -215,7 +216,7 @@ ABI_SYMBOLS = [
     "zksp_execute", "zksp_execute_keccak", "zksp_opcode_name", "zksp_machine_trace", "zksp_mtrace_free",
     "zksp_mtrace_section", "zksp_mtrace_info", "zksp_vk_machine", "zksp_mtrace_heights", "zksp_machine_body_words",
     "zksp_machine_chip_widths", "zksp_machine_cover_heights", "zksp_stdin_set_aggregation", "zksp_proof_aggregation", "zksp_verify_aggregate",
-    "zksp_stdin_set_aggregation_keyed", "zksp_verify_aggregate_keyed", "zksp_stdin_set_verified_leaf", "zksp_stdin_add_verified_leaf", "zksp_leaves_public", "zksp_verify_with_leaves", "zksp_leaf_public", "zksp_verify_public", "zksp_leaf_public_at", "zksp_stdin_add_verified_node", "zksp_proof_stub", "zksp_stdin_add_verified_leaves",
+    "zksp_stdin_set_aggregation_keyed", "zksp_verify_aggregate_keyed", "zksp_stdin_set_verified_leaf", "zksp_stdin_add_verified_leaf", "zksp_leaves_public", "zksp_verify_with_leaves", "zksp_leaf_public", "zksp_verify_public", "zksp_leaf_public_at", "zksp_stdin_public_tuples", "zksp_stdin_add_verified_node", "zksp_proof_stub", "zksp_stdin_add_verified_leaves",
     "zksp_verify_with_leaf", "zksp_proof_public_tuples", "zksp_hip_machine_fetch_stage", "zksp_hip_machine_fetch_challenges",
     "zksp_hip_machine_load", "zksp_hip_machine_prove", "zksp_hip_release_workspace", "zksp_hip_machine_fetch_bodies", "zksp_hip_machine_fetch_roots", "zksp_machine_proof_from_body", "zksp_get_params",
     "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
@@ -566,6 +567,26 @@ class ProverClient:
         if rc:
             raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
 
+    def _tuples(self, call, guess: int = 128):
+        """Runs ``call(out_ptr, cap_words, n_ref)`` - a C function that derives a list of public tuples - ONCE where the list
+        fits `guess` tuples (a leaf's statement is some 75; deriving it is a stub check of the leaf: milliseconds), twice
+        otherwise."""
+        import numpy as np
+        n = C.c_size_t()
+        out = np.zeros((guess, PUB_TUPLE_WORDS), np.uint32)
+        rc = call(out.ctypes.data_as(C.c_void_p), out.size, C.byref(n))
+        if rc and n.value > guess:  # (the count is set before the buffer is found too small)
+            out = np.zeros((n.value, PUB_TUPLE_WORDS), np.uint32)
+            rc = call(out.ctypes.data_as(C.c_void_p), out.size, C.byref(n))
+        if rc:
+            raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
+        return out[:n.value].copy()
+
+    def stdin_statement(self, stdin: SP1Stdin):
+        """The public tuples the proof made from ``stdin`` will carry (``zksp_stdin_public_tuples``): what the leaf checks added
+        so far state, [n][16] canonical words ([0][16] without leaf checks).  Before proving - proving consumes them."""
+        return self._tuples(lambda o, cap, n: self._lib.zksp_stdin_public_tuples(stdin._h, o, cap, n), guess=512)
+
     def leaf_public_at(self, leaf: SP1ProofWithPublicValues, leaf_vk: VerifyingKey, index: int, own_statement=None):
         """The statement tuples of the leaf at place ``index`` beside one run (``zksp_leaf_public_at``); ``leaf`` may be a stub;
         ``own_statement``: the tuples the leaf's own proof was made for, if it is a node.  Everything of the leaf but its query
@@ -574,16 +595,7 @@ class ProverClient:
         own = np.zeros((0, PUB_TUPLE_WORDS), np.uint32) if own_statement is None else \
             np.ascontiguousarray(own_statement, dtype=np.uint32).reshape(-1, PUB_TUPLE_WORDS)
         op = own.ctypes.data_as(C.c_void_p) if len(own) else None
-        n = C.c_size_t()
-        rc = self._lib.zksp_leaf_public_at(self._h, leaf._h, leaf_vk._h, index, op, len(own), None, 0, C.byref(n))
-        if rc:
-            raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
-        out = np.zeros((n.value, PUB_TUPLE_WORDS), np.uint32)
-        rc = self._lib.zksp_leaf_public_at(self._h, leaf._h, leaf_vk._h, index, op, len(own), out.ctypes.data_as(C.c_void_p), out.size,
-                                           C.byref(n))
-        if rc:
-            raise ZkspError(rc, self.last_error())
-        return out
+        return self._tuples(lambda o, cap, n: self._lib.zksp_leaf_public_at(self._h, leaf._h, leaf_vk._h, index, op, len(own), o, cap, n))
 
     def tree_statement(self, children, vk: VerifyingKey):
         """The statement of a node of a recursion tree from its children, recursively: ``children`` is a list of
@@ -612,15 +624,7 @@ class ProverClient:
         """The statement of a proof that checks several leaves (``zksp_leaves_public``): numpy [n][16] canonical words."""
         import numpy as np
         pa, va, k = self._handle_arrays(leaves, leaf_vks)
-        n = C.c_size_t()
-        rc = self._lib.zksp_leaves_public(self._h, pa, va, k, None, 0, C.byref(n))
-        if rc:
-            raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
-        out = np.zeros((n.value, PUB_TUPLE_WORDS), np.uint32)
-        rc = self._lib.zksp_leaves_public(self._h, pa, va, k, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n))
-        if rc:
-            raise ZkspError(rc, self.last_error())
-        return out
+        return self._tuples(lambda o, cap, n: self._lib.zksp_leaves_public(self._h, pa, va, k, o, cap, n), guess=128 * k)
 
     def verify_with_leaves(self, proof: SP1ProofWithPublicValues, vk: VerifyingKey, leaves, leaf_vks) -> None:
         """``verify`` for a proof that checks several leaves: its statement is the one these leaves give, in this order."""
@@ -632,15 +636,7 @@ class ProverClient:
     def leaf_public(self, leaf: SP1ProofWithPublicValues, leaf_vk: VerifyingKey):
         """The statement of a leaf-proof check (``zksp_leaf_public``): the public bus tuples, numpy [n][16] canonical words."""
         import numpy as np
-        n = C.c_size_t()
-        rc = self._lib.zksp_leaf_public(self._h, leaf._h, leaf_vk._h, None, 0, C.byref(n))
-        if rc:
-            raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
-        out = np.zeros((n.value, PUB_TUPLE_WORDS), np.uint32)
-        rc = self._lib.zksp_leaf_public(self._h, leaf._h, leaf_vk._h, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n))
-        if rc:
-            raise ZkspError(rc, self.last_error())
-        return out
+        return self._tuples(lambda o, cap, n: self._lib.zksp_leaf_public(self._h, leaf._h, leaf_vk._h, o, cap, n))
 
     def verify_public(self, proof: SP1ProofWithPublicValues, vk: VerifyingKey, tuples) -> None:
         """``verify`` for a proof whose buses close with these public tuples ([n][16] canonical words)."""

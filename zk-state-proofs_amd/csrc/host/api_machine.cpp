@@ -563,6 +563,17 @@ int zksp_verify_with_leaves(zksp_client* c, const zksp_proof* p, const zksp_vk* 
   return zksp_verify_public(c, p, vk, st.data(), st.size() / mach::kPubTupleWords);
 }
 
+int zksp_stdin_public_tuples(const zksp_stdin* s, uint32_t* out, size_t cap_words, size_t* n_tuples) {
+  if (!s || !n_tuples) return ZKSP_ERR_INVALID_ARG;
+  const size_t words = s->leaf_check ? s->leaf_check->pub_tuples.size() : 0;
+  *n_tuples = words / mach::kPubTupleWords;
+  if (out) {
+    if (cap_words < words) return ZKSP_ERR_INVALID_ARG;
+    if (words) memcpy(out, s->leaf_check->pub_tuples.data(), words * 4);
+  }
+  return ZKSP_OK;
+}
+
 int zksp_leaf_public(zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf_vk, uint32_t* out, size_t cap_words, size_t* n_tuples) {
   return zksp_leaf_public_at(c, leaf, leaf_vk, 0, nullptr, 0, out, cap_words, n_tuples);
 }

@@ -80,7 +80,8 @@ def tree_node_groups(n_leaves: int, arity: int) -> List[List[int]]:
 
 
 def prove_tree_level(client, pk, leaf_vk, leaves: Sequence, node_stdins: Sequence, arity: int, rank: int, world: int,
-                     statements: Optional[Sequence] = None, pipeline: bool = True, group: int = 16, checker=None):
+                     statements: Optional[Sequence] = None, pipeline: bool = True, group: int = 16, checker=None,
+                     statements_out: Optional[dict] = None):
     """One level of BASELINE config 5's recursion tree over the farm (stage 2b): node k is one
     more guest run (node_stdins[k]) whose proof also checks the query phases of its `arity` leaf proofs under the challenges
     their own transcripts yield (client.add_verified_leaf, in leaf order; a leaf that is itself a node comes with the
@@ -89,8 +90,10 @@ def prove_tree_level(client, pk, leaf_vk, leaves: Sequence, node_stdins: Sequenc
     host part verifies its leaves before the node is proven; with more than two nodes and `pipeline`, the checks of the next nodes
     run beside the proving of the ready ones - on `checker`, a client of the same parameters that needs no GPU, if one is given:
     the proving client's error state is then its own).  The stdins of this rank's nodes are CONSUMED: whatever leaf
-    checks they carried are replaced by the node's own (so a retry of the level does not double them).  Returns (node
-    indices of this rank, their proofs, status)."""
+    checks they carried are replaced by the node's own (so a retry of the level does not double them).  `statements_out`: a dict
+    that receives, per node index of this rank, the statement its proof is made for (the public tuples its leaf checks gave -
+    read from the stdin before it is proven, not derived a second time).  Returns (node indices of this rank, their proofs,
+    status)."""
     groups = tree_node_groups(len(leaves), arity)
     if len(node_stdins) != len(groups):
         raise ValueError("one stdin per node")
@@ -111,6 +114,8 @@ def prove_tree_level(client, pk, leaf_vk, leaves: Sequence, node_stdins: Sequenc
                     chk.add_verified_node(node_stdins[k], leaves[i], leaf_vk, statements[i])
                 else:
                     chk.add_verified_leaf(node_stdins[k], leaves[i], leaf_vk)
+        if statements_out is not None and hasattr(chk, "stdin_statement"):
+            statements_out[k] = chk.stdin_statement(node_stdins[k])
 
     if len(mine) <= 2 or not pipeline:
         for k in mine:
@@ -209,13 +214,17 @@ def prove_tree(client, host, pk, vk, leaves: Sequence, make_stdin: Callable, ari
         below, st_below = levels[-1], statements[-1]
         groups = tree_node_groups(len(below), arity)
         node_stdins = [make_stdin(depth, k) for k in range(len(groups))]
-        mine, proofs, status = prove_tree_level(client, pk, vk, below, node_stdins, arity, rank, world, st_below, checker=host)
+        st_of = {}
+        mine, proofs, status = prove_tree_level(client, pk, vk, below, node_stdins, arity, rank, world, st_below, checker=host,
+                                                statements_out=st_of)
         if status != [0] * len(mine):
             raise RuntimeError(f"level {depth}: a node of rank {rank} failed: {client.last_error()}")
         local = []
         for k, p in zip(mine, proofs):
-            stubs = [below[i].stub() for i in groups[k]]
-            st = np.concatenate([host.leaf_public_at(stubs[j], vk, j, st_below[i]) for j, i in enumerate(groups[k])])
+            st = st_of.get(k)
+            if st is None:  # (a checking client without stdin_statement: derived from the children's stubs)
+                stubs = [below[i].stub() for i in groups[k]]
+                st = np.concatenate([host.leaf_public_at(stubs[j], vk, j, st_below[i]) for j, i in enumerate(groups[k])])
             local.append((p.to_bytes(), st))
         gathered = _gather_objects(local, len(groups), rank, world)
         levels.append([SP1ProofWithPublicValues.from_bytes(b) for b, _ in gathered])
