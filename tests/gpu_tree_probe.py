@@ -1,0 +1,71 @@
+"""Scratch timing (not a test): BASELINE config 5 at a given size - n leaf proofs, then a recursion tree of arity 4 over them
+(farm.prove_tree: the host's leaf checks of a level beside the proving of the ready nodes), the root verified from stubs.
+  python tests/gpu_tree_probe.py [n_leaves=256] [group]"""
+import importlib
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+zk = importlib.import_module("zk-state-proofs_amd")
+fx = importlib.import_module("zk-state-proofs_amd.fixtures")
+farm = importlib.import_module("zk-state-proofs_amd.farm")
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+group = int(sys.argv[2]) if len(sys.argv) > 2 else None
+client = zk.ProverClient(device=0)
+host = zk.ProverClient(device=-1)
+pk, vk = client.setup(zk.merkle_elf())
+for rep in range(2):
+    tl = []
+    for i in range(n):
+        s = zk.SP1Stdin()
+        s.write(fx.acct_fixture(8, seed=9000 + 1000 * rep + i).to_borsh())
+        tl.append(s)
+    t0 = time.perf_counter()
+    leaves, status = client.prove_batch(pk, tl)
+    t_leaves = time.perf_counter() - t0
+    assert status == [0] * n
+
+    def make_stdin(depth, k):
+        s = zk.SP1Stdin()
+        s.write(fx.acct_fixture(8, seed=200_000 + 4096 * depth + k).to_borsh())
+        return s
+
+    if group is not None:
+        orig = farm.prove_tree_level
+        farm.prove_tree_level = lambda *a, **kw: orig(*a, **dict(kw, group=group))
+    acc = {"check": 0.0, "prove": 0.0, "calls": 0, "proved": 0}
+    o_check, o_prove = host.add_verified_leaves, client.prove_batch
+
+    def t_check(*a, **kw):
+        t = time.perf_counter()
+        try:
+            return o_check(*a, **kw)
+        finally:
+            acc["check"] += time.perf_counter() - t
+
+    def t_prove(pk_, stdins_):
+        t = time.perf_counter()
+        try:
+            return o_prove(pk_, stdins_)
+        finally:
+            acc["prove"] += time.perf_counter() - t
+            acc["calls"] += 1
+            acc["proved"] += len(stdins_)
+
+    host.add_verified_leaves, client.prove_batch = t_check, t_prove
+    t0 = time.perf_counter()
+    levels, statements = farm.prove_tree(client, host, pk, vk, leaves, make_stdin, 4)
+    host.add_verified_leaves, client.prove_batch = o_check, o_prove
+    print(f"   host checks {acc['check']:.2f} s in all (its own thread); prove_batch {acc['prove']:.2f} s in {acc['calls']} calls over {acc['proved']} nodes", flush=True)
+    t_tree = time.perf_counter() - t0
+    if group is not None:
+        farm.prove_tree_level = orig
+    nodes = sum(len(lv) for lv in levels[1:])
+    t0 = time.perf_counter()
+    host.verify_tree(levels[-1][0], vk, farm.tree_of_stubs(levels, 4))
+    t_ver = time.perf_counter() - t0
+    print(f"rep {rep}: {n} leaves in {t_leaves:.2f} s; {nodes} nodes in {t_tree:.2f} s ({t_tree * 1e3 / nodes:.1f} ms per node); "
+          f"{n / (t_leaves + t_tree):.1f} leaves/s through the whole tree; root verified from stubs in {t_ver:.2f} s", flush=True)
+    del leaves, levels

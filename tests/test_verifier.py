@@ -127,8 +127,8 @@ def test_rejects_nonzero_exit_code_and_oversized_height(zk, oracle, setup):
 
 
 def test_host_poseidon2_vector_matches_scalar(zk, built_lib):
-    """The host verifier's permutation in 256-bit registers (csrc/host/p2_avx2.cpp, used where the CPU has AVX2) is the same
-    function as the scalar form: the independent restatement's known answers (tests/golden/stark_kat.json), random states and
+    """The host verifier's permutation in 256-bit registers (csrc/host/p2_avx2.cpp, used where the CPU has AVX2), one state at a
+    time or two in lockstep, is the same function as the scalar form: the independent restatement's known answers (tests/golden/stark_kat.json), random states and
     states of extreme words, bit for bit."""
     import ctypes as C
     import json
@@ -151,6 +151,10 @@ def test_host_poseidon2_vector_matches_scalar(zk, built_lib):
     if rc == zk.client.ERR_UNSUPPORTED:
         pytest.skip("this CPU has no AVX2: the verifier runs the scalar permutation")
     assert rc == 0 and np.array_equal(scalar, vector)
+    for n_states in (len(states), len(states) - 1, 1):  # pairs in lockstep; an odd one out runs alone
+        paired = states[:n_states].copy()
+        assert lib.zksp_host_poseidon2_permute(paired.ctypes.data, n_states, 2) == 0
+        assert np.array_equal(paired, scalar[:n_states])
     bad = states[:1].copy()
     bad[0, 3] = P  # not a canonical word
     assert lib.zksp_host_poseidon2_permute(bad.ctypes.data, 1, 0) != 0

@@ -15,6 +15,7 @@
 #include <thread>
 
 #include <array>
+#include <type_traits>
 #include <cstring>
 
 #include "host_hash.hpp"
@@ -132,48 +133,65 @@ void log_pub_tuple(LeafCheckLog* log, uint32_t bus, bool verifier_sends, uint32_
   v.push_back(bus); v.push_back(verifier_sends ? 1u : 0u); v.push_back(mult); v.push_back((uint32_t)n_el);
   for (int i = 0; i < kPubTupleWords - 4; ++i) v.push_back(i < n_el ? el[i] : 0u);
 }
+// The hashing of the query phase works on L = 1 or 2 QUERIES in lockstep: two queries of one proof open rows of the same
+// widths along paths of the same lengths, so their permutations pair up one to one, and the host's vector permutation runs two
+// independent states almost as fast as one (host_hash.hpp permute_lanes).  Everything below takes per-lane arrays.
+//
 // hash_elems, every block logged as a sponge row labelled (tag, key, mask): the first starts from the zero state.  With
 // `alpha` (the hash of a matrix row of a commitment): Horner's rule in alpha over the absorbed words, block by block; the last
 // row is flagged SE and the sum comes back in *sum.
-void sponge_logged(const Fp* in, size_t n, Fp out[8], const P2Consts* kc, LeafCheckLog* log, uint32_t tag, uint32_t key, uint32_t mask,
-                   bool run_start, bool send, bool fri_leaf, const AlphaPows* alpha = nullptr, Fp4* sum = nullptr) {
-  Fp st[16];
-  for (auto& x : st) x = Fp::zero();
-  Fp4 so = Fp4::zero();
+template <int L>
+void sponge_logged(const Fp* const* in, size_t n, Fp (*out)[8], const P2Consts* kc, LeafCheckLog* const* log, const uint32_t* tag,
+                   const uint32_t* key, uint32_t mask, bool run_start, bool send, bool fri_leaf, const AlphaPows* alpha = nullptr,
+                   Fp4* const* sum = nullptr) {
+  Fp st[L][16];
+  Fp4 so[L];
+  for (int t = 0; t < L; ++t) {
+    for (auto& x : st[t]) x = Fp::zero();
+    so[t] = Fp4::zero();
+  }
   for (size_t off = 0; off < n; off += 8) {
     const size_t m = n - off < 8 ? n - off : 8;
-    for (size_t i = 0; i < 8; ++i) st[i] = i < m ? in[off + i] : Fp::zero();
-    if (alpha) {
-      Fp4 bv = Fp4::from_base(st[7]);
-      for (int i = 0; i < 7; ++i) bv += alpha->pw[i] * st[i];
-      so = so * alpha->a8 + bv;
-    } else {
-      so = Fp4::from_base(st[7]);  // (a hash nobody reduces - a FRI pair: the row's alpha_f columns are zero, Horner's rule leaves the last word)
+    for (int t = 0; t < L; ++t) {
+      for (size_t i = 0; i < 8; ++i) st[t][i] = i < m ? in[t][off + i] : Fp::zero();
+      if (alpha) {
+        Fp4 bv = Fp4::from_base(st[t][7]);
+        for (int i = 0; i < 7; ++i) bv += alpha->pw[i] * st[t][i];
+        so[t] = so[t] * alpha->a8 + bv;
+      } else {
+        so[t] = Fp4::from_base(st[t][7]);  // (a hash nobody reduces - a FRI pair: the row's alpha_f columns are zero, Horner's rule leaves the last word)
+      }
+      if (log[t]) {
+        uint32_t flags = off == 0 ? (uint32_t)P2K_SZ : (uint32_t)P2K_SC;
+        if (run_start) flags |= kP2FlagNew;
+        if (send && off + 8 >= n) flags |= kP2FlagSnd;
+        if (fri_leaf && off == 0) flags |= kP2FlagFri;
+        if (alpha && off + 8 >= n) flags |= kP2FlagSe;
+        log_p2_row(log[t], flags, tag[t], key[t], mask, st[t], 0, &so[t], alpha);
+      }
     }
-    if (log) {
-      uint32_t flags = off == 0 ? (uint32_t)P2K_SZ : (uint32_t)P2K_SC;
-      if (run_start) flags |= kP2FlagNew;
-      if (send && off + 8 >= n) flags |= kP2FlagSnd;
-      if (fri_leaf && off == 0) flags |= kP2FlagFri;
-      if (alpha && off + 8 >= n) flags |= kP2FlagSe;
-      log_p2_row(log, flags, tag, key, mask, st, 0, &so, alpha);
-    }
-    permute(st, kc);
+    permute_lanes<L>(st, kc);
   }
-  for (int i = 0; i < 8; ++i) out[i] = st[i];
-  if (sum) *sum = so;
+  for (int t = 0; t < L; ++t) {
+    for (int i = 0; i < 8; ++i) out[t][i] = st[t][i];
+    if (sum && sum[t]) *sum[t] = so[t];
+  }
 }
 // one step of a path: the running digest on the left or on the right of its sibling
-void compress_logged(const Fp* cur, const Fp* sib, bool cur_right, Fp out[8], const P2Consts* kc, LeafCheckLog* log, uint32_t kind,
-                     uint32_t tag, uint32_t key, uint32_t mask) {
-  Fp st[16];
-  for (int i = 0; i < 8; ++i) {
-    st[i] = cur_right ? sib[i] : cur[i];
-    st[8 + i] = cur_right ? cur[i] : sib[i];
+template <int L>
+void compress_logged(const Fp (*cur)[8], const Fp (*sib)[8], const bool* cur_right, Fp (*out)[8], const P2Consts* kc,
+                     LeafCheckLog* const* log, const uint32_t* kind, const uint32_t* tag, const uint32_t* key, uint32_t mask) {
+  Fp st[L][16];
+  for (int t = 0; t < L; ++t) {
+    for (int i = 0; i < 8; ++i) {
+      st[t][i] = cur_right[t] ? sib[t][i] : cur[t][i];
+      st[t][8 + i] = cur_right[t] ? cur[t][i] : sib[t][i];
+    }
+    if (log[t]) log_p2_row(log[t], kind[t], tag[t], key[t], mask, st[t]);
   }
-  if (log) log_p2_row(log, kind, tag, key, mask, st);
-  permute(st, kc);
-  for (int i = 0; i < 8; ++i) out[i] = st[i];
+  permute_lanes<L>(st, kc);
+  for (int t = 0; t < L; ++t)
+    for (int i = 0; i < 8; ++i) out[t][i] = st[t][i];
 }
 // the last logged row ends its run: its digest is compared with root `rid`, its position goes to the query chip
 void log_run_end(LeafCheckLog* log, uint32_t rid) {
@@ -182,56 +200,83 @@ void log_run_end(LeafCheckLog* log, uint32_t rid) {
   r[kP2RecRid] = rid;
 }
 
-// Recomputes the root of one mixed-height opening.  rows[c]: opened row of chip c (width[c] words).  With a log: the
-// opening as a run of the Poseidon2 chip (air_machine.hpp), tagged `tag`, its root named `rid`; hsum[lh]: the Horner sum (in
-// alpha) of the opened rows of the chips of height 2^lh, which the query chip turns into reduced openings.
-bool mmcs_verify(const RoundShape& sh, const int* logh, const std::vector<std::vector<Fp>>& rows, size_t cs, size_t m_max,
-                 const uint32_t* path_canon, const Fp root[8], const P2Consts* kc, LeafCheckLog* log = nullptr, uint32_t tag = 0,
-                 uint32_t rid = 0, const AlphaPows* alpha = nullptr, Fp4* hsum = nullptr) {
+// Recomputes the root of one mixed-height opening per lane.  rows[t][c]: opened row of chip c (width[c] words).  With a log: the
+// opening as a run of the Poseidon2 chip (air_machine.hpp), tagged `tag`, its root named `rid`; hsum[t][lh]: the Horner sum (in
+// alpha) of the opened rows of the chips of height 2^lh, which the query chip turns into reduced openings.  False if a lane's
+// root differs.
+template <int L>
+bool mmcs_verify(const RoundShape& sh, const int* logh, const std::vector<std::vector<Fp>>* const* rows, const size_t* cs,
+                 const size_t* m_max, const uint32_t* const* path_canon, const Fp root[8], const P2Consts* kc, LeafCheckLog* const* log,
+                 const uint32_t* tag, uint32_t rid, const AlphaPows* alpha, Fp4* const* hsum) {
   const int logn = sh.lm + 1;
   const size_t hm = (size_t)1 << sh.lm;
-  const size_t pos = cs * hm + bitrev32((uint32_t)(m_max & (hm - 1)), sh.lm);
-  auto group_row = [&](int group_logn, std::vector<Fp>* cat) {
-    cat->clear();
-    for (int c = 0; c < kNumChips; ++c)
-      if (sh.width[c] && logh[c] + 1 == group_logn) cat->insert(cat->end(), rows[c].begin(), rows[c].end());
-    return !cat->empty();
+  size_t pos[L];
+  for (int t = 0; t < L; ++t) pos[t] = cs[t] * hm + bitrev32((uint32_t)(m_max[t] & (hm - 1)), sh.lm);
+  std::vector<Fp> cat[L];
+  const Fp* catp[L];
+  auto group_row = [&](int group_logn) {  // the rows of the chips of that height, one after the other (the same widths in every lane)
+    for (int t = 0; t < L; ++t) {
+      cat[t].clear();
+      for (int c = 0; c < kNumChips; ++c)
+        if (sh.width[c] && logh[c] + 1 == group_logn) cat[t].insert(cat[t].end(), (*rows[t])[c].begin(), (*rows[t])[c].end());
+      catp[t] = cat[t].data();
+    }
+    return !cat[0].empty();
   };
-  std::vector<Fp> cat;
-  Fp inj[32][8];  // with a log: the hashes of the injected rows, by level
-  if (log) {
-    // the hashes of the injected rows come first, each labelled with the key and mask its injection row will hold
-    uint32_t key = 1, mask = 0;
+  // the hashes of the injected rows come first, each labelled with the key and mask its injection row will hold
+  Fp inj[32][L][8];
+  bool has_inj[32];
+  {
+    uint32_t key[L], mask = 0;
+    for (int t = 0; t < L; ++t) key[t] = 1;
     for (int l = 0; l < logn; ++l) {
-      key = 2 * key + (uint32_t)((pos >> l) & 1);
+      for (int t = 0; t < L; ++t) key[t] = 2 * key[t] + (uint32_t)((pos[t] >> l) & 1);
       mask = 2 * mask;
-      if (group_row(logn - l - 1, &cat))
-        sponge_logged(cat.data(), cat.size(), inj[l], kc, log, tag, key, ++mask, false, true, false, alpha, hsum ? &hsum[logn - l - 2] : nullptr);
+      has_inj[l] = group_row(logn - l - 1);
+      if (has_inj[l]) {
+        Fp4* sums[L];
+        for (int t = 0; t < L; ++t) sums[t] = hsum && hsum[t] ? &hsum[t][logn - l - 2] : nullptr;
+        sponge_logged<L>(catp, cat[0].size(), inj[l], kc, log, tag, key, ++mask, false, true, false, alpha, sums);
+      }
     }
   }
-  Fp cur[8];
-  if (!group_row(logn, &cat)) return false;
-  sponge_logged(cat.data(), cat.size(), cur, kc, log, tag, 1, 0, true, false, false, alpha, hsum ? &hsum[logn - 1] : nullptr);
-  uint32_t key = 1, mask = 0;
+  Fp cur[L][8];
+  if (!group_row(logn)) return false;
+  {
+    uint32_t key1[L];
+    Fp4* sums[L];
+    for (int t = 0; t < L; ++t) { key1[t] = 1; sums[t] = hsum && hsum[t] ? &hsum[t][logn - 1] : nullptr; }
+    sponge_logged<L>(catp, cat[0].size(), cur, kc, log, tag, key1, 0, true, false, false, alpha, sums);
+  }
+  uint32_t key[L], mask = 0;
+  for (int t = 0; t < L; ++t) key[t] = 1;
   for (int l = 0; l < logn; ++l) {
-    Fp sib[8], nxt[8];
-    for (int i = 0; i < 8; ++i) sib[i] = Fp::from_canonical(path_canon[8 * l + i]);
-    const bool right = (pos >> l) & 1;
-    key = 2 * key + (right ? 1u : 0u);
+    Fp sib[L][8], nxt[L][8];
+    bool right[L];
+    uint32_t kind[L];
+    for (int t = 0; t < L; ++t) {
+      for (int i = 0; i < 8; ++i) sib[t][i] = Fp::from_canonical(path_canon[t][8 * l + i]);
+      right[t] = (pos[t] >> l) & 1;
+      key[t] = 2 * key[t] + (right[t] ? 1u : 0u);
+      kind[t] = right[t] ? P2K_PR : P2K_PL;
+    }
     mask = 2 * mask;
-    compress_logged(cur, sib, right, nxt, kc, log, right ? P2K_PR : P2K_PL, tag, key, mask);
-    if (group_row(logn - l - 1, &cat)) {
-      Fp g[8];
-      if (log) for (int i = 0; i < 8; ++i) g[i] = inj[l][i];
-      else hash_elems(cat.data(), cat.size(), g, kc);
-      compress_logged(nxt, g, false, cur, kc, log, P2K_J, tag, key, ++mask);
+    compress_logged<L>(cur, sib, right, nxt, kc, log, kind, tag, key, mask);
+    if (has_inj[l]) {
+      bool left[L];
+      uint32_t kj[L];
+      for (int t = 0; t < L; ++t) { left[t] = false; kj[t] = P2K_J; }
+      compress_logged<L>(nxt, inj[l], left, cur, kc, log, kj, tag, key, ++mask);
     } else {
-      for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+      for (int t = 0; t < L; ++t)
+        for (int i = 0; i < 8; ++i) cur[t][i] = nxt[t][i];
     }
   }
-  for (int i = 0; i < 8; ++i)
-    if (cur[i] != root[i]) return false;
-  if (log) log_run_end(log, rid);
+  for (int t = 0; t < L; ++t) {
+    for (int i = 0; i < 8; ++i)
+      if (cur[t][i] != root[i]) return false;
+    if (log[t]) log_run_end(log[t], rid);
+  }
   return true;
 }
 
@@ -1012,184 +1057,241 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   }
   if (stub) return 0;
 
-  const AlphaPows af_pows(af);
-  auto check_query = [&](uint32_t qi, LeafCheckLog* log, std::string* err) -> int {
+  // One query's state while it is checked.  Two queries are checked in lockstep (check_queries<2>): their hashing pairs up
+  // permutation by permutation, the arithmetic between the hashes is done lane by lane.
+  struct QLane {
+    uint32_t qi = 0, word = 0;
+    LeafCheckLog* log = nullptr;
     std::vector<std::vector<Fp>> rows[4];
-    for (int r = 0; r < 4; ++r) rows[r].resize(kNumChips);
-    const uint32_t* q = p_queries + perq * qi;
-    const size_t idx = indices[qi];
-    const size_t cs = idx >> lm, m = idx & (hmax - 1);
+    const uint32_t* q = nullptr;
+    size_t cs = 0, m = 0;
     Fp4 hsum[4][32];  // with a log: the Horner sums (in alpha_f) of the opened rows, per tree and height
-    for (int r = 0; r < 4; ++r) {
-      for (int c = 0; c < kNumChips; ++c) {
-        rows[r][c].resize(shape[r].width[c]);
-        for (int i = 0; i < shape[r].width[c]; ++i) rows[r][c][i] = Fp::from_canonical(q[i]);
-        q += shape[r].width[c];
+    std::vector<std::array<uint32_t, kQrRecWords>> qrow;
+    Fp4 expect, ro_k;
+    Fp shift_k;
+  };
+  const AlphaPows af_pows(af);
+  const Fp omi = fp_root_of_unity(lm + 1).inv(), gi0 = Fp::from_canonical(kGenInv);
+  const Fp4 d2x = delta * delta, d3x = d2x * delta, d4x = d2x * d2x;
+  // reduced openings per height
+  auto reduced = [&](const QLane& a, int lh) -> Fp4 {
+    Fp4 gsum = Fp4::zero();
+    for (int c = 0; c < kNumChips; ++c) {
+      if (logh[c] != lh) continue;
+      const size_t h = (size_t)1 << lh, mm = a.m & (h - 1);
+      const Fp wh = fp_root_of_unity(lh), w2h = fp_root_of_unity(lh + 1);
+      const Fp x = (a.cs ? g * w2h : g) * wh.pow(mm);
+      Fp4 s1 = Fp4::zero(), s2 = Fp4::zero();
+      size_t i = 0, jj = 0;
+      for (int r = 0; r < 4; ++r)
+        for (int col = 0; col < shape[r].width[c]; ++col, ++i) {
+          const Fp v = a.rows[r][c][col];
+          s1 += afpow[open_off[c] + i] * v;
+          if (r == 1 || r == 2) { s2 += afpow[open_off[c] + n1[c] + jj] * v; ++jj; }
+        }
+      const Fp4 d0 = (Fp4::from_base(x) - zeta).inv(), d1 = (Fp4::from_base(x) - zeta * wh).inv();
+      gsum += (s1 - b1[c]) * d0 + (s2 - b2[c]) * d1;
+    }
+    return gsum;
+  };
+  // the query chip's 31 rows (air_machine.hpp), bit 30 of the index word down to bit 0: what does not depend on the openings
+  auto start_qrows = [&](QLane& a) {
+    a.qrow.resize(31);
+    const uint32_t word = a.word, qi = a.qi;
+    const size_t cs = a.cs;
+    uint32_t eqv = 0, cnt0 = 0, key0 = 0, m0 = 0, keyj = 0, mj = 0;
+    // (MT, MT0 and YT are the same on every row of the chain: filled in at the end)
+    Fp r_acc = Fp::one(), yki = Fp::zero(), gi = Fp::zero();
+    for (int j = 30; j >= 0; --j) {
+      std::array<uint32_t, kQrRecWords>& w = a.qrow[30 - j];
+      w.fill(0);
+      const uint32_t bit = (word >> j) & 1u;
+      const bool is_csr = j == lm, is_lay = j < lm, is_fl = j == lm - 1;
+      const int k = lm - 1 - j;
+      w[QR_IS_REAL] = 1; w[QR_FIRST] = j == 30; w[QR_LAST] = j == 0; w[QR_LEAF] = leaf; w[QR_QL] = qi; w[QR_J] = (uint32_t)j;
+      w[QR_BIT] = bit; w[QR_ACC] = word >> j;
+      eqv = j == 30 ? bit : (j >= 27 ? (eqv & bit) : eqv);
+      w[QR_EQ] = eqv;
+      w[QR_F1] = j == 29; w[QR_F2] = j == 28; w[QR_F3] = j == 27;
+      w[QR_CSR] = is_csr; w[QR_FL] = is_fl; w[QR_LAY] = is_lay; w[QR_K] = is_lay ? (uint32_t)k : 0u;
+      w[QR_CS] = j <= lm ? (uint32_t)cs : 0u;
+      w[QR_POW] = 1u << j; w[QR_LOW] = word & ((1u << j) - 1);
+      w[QR_REV] = j ? bitrev32(word & ((1u << j) - 1), j) : 0u;
+      w[QR_PR0] = j == kTableLogH;
+      cnt0 += w[QR_PR0];
+      w[QR_CNT0] = cnt0;
+      w[QR_P0A] = j < kTableLogH;
+      if (j == kTableLogH - 1) { key0 = 1; m0 = 0; }
+      if (j < kTableLogH - 1) { key0 = 2 * key0 + ((word >> (j + 1)) & 1u); m0 = 2 * m0 + (height_has_prep(j + 1) ? 1u : 0u); }
+      if (j < kTableLogH) { w[QR_KEY0] = key0; w[QR_M0] = m0; w[QR_HAS0] = height_has_prep(j + 1); }
+      if (is_fl) { keyj = 1; mj = 0; }
+      if (is_lay && !is_fl) { keyj = 2 * keyj + ((word >> (j + 1)) & 1u); mj = 2 * mj + (height_present(j + 1) ? 1u : 0u); }
+      if (is_lay) { w[QR_KEYJ] = keyj; w[QR_MJ] = mj; w[QR_HASRO] = height_present(j + 1); }
+      w[QR_OMI] = omi.to_canonical();
+      w[QR_MU] = bit ? omi.to_canonical() : 1u;
+      w[QR_CSM] = w[QR_CS] ? omi.to_canonical() : 1u;
+      if (is_lay) {
+        r_acc = is_fl ? Fp::from_canonical(w[QR_MU]) : r_acc * r_acc * Fp::from_canonical(w[QR_MU]);
+        w[QR_R] = r_acc.to_canonical();
+        w[QR_R2] = (r_acc * r_acc).to_canonical();
       }
-      for (auto& hv : hsum[r]) hv = Fp4::zero();
-      if (!mmcs_verify(shape[r], logh, rows[r], cs, m, q, root[r], kc, log, leaf_tag(leaf, qi, (uint32_t)r), leaf_rid(leaf, (uint32_t)r),
-                       log ? &af_pows : nullptr, log ? hsum[r] : nullptr)) {
+    }
+    // the inverse of y = omega^(cs + 2 m), its squares down the layers, the shifts
+    const Fp yt = r_acc * r_acc * (cs ? omi : Fp::one());
+    for (int j = 30; j >= 0; --j) {
+      std::array<uint32_t, kQrRecWords>& w = a.qrow[30 - j];
+      w[QR_YT] = yt.to_canonical();
+      w[QR_MT] = 4 * mj;
+      w[QR_MT0] = 4 * m0;
+      if (j < lm) {
+        yki = j == lm - 1 ? yt : yki * yki;
+        gi = j == lm - 1 ? gi0 : gi * gi;
+        w[QR_YKI] = yki.to_canonical();
+        w[QR_GI] = gi.to_canonical();
+        const Fp xinv = gi * yki * (((word >> j) & 1u) ? -Fp::one() : Fp::one());
+        w[QR_XINV] = xinv.to_canonical();
+      }
+    }
+  };
+  // L queries of this proof, checked in lockstep.  An error is the pair's: the caller checks the two one by one to name the query.
+  auto check_queries = [&](auto lanes, const uint32_t* qis, LeafCheckLog* const* logs, std::string* err) -> int {
+    constexpr int L = decltype(lanes)::value;
+    QLane ln[L];
+    LeafCheckLog* lg[L];
+    for (int t = 0; t < L; ++t) {
+      QLane& a = ln[t];
+      a.qi = qis[t];
+      a.log = lg[t] = logs[t];
+      a.q = p_queries + perq * a.qi;
+      a.word = index_words[a.qi];
+      const size_t idx = indices[a.qi];
+      a.cs = idx >> lm;
+      a.m = idx & (hmax - 1);
+      for (int r = 0; r < 4; ++r) a.rows[r].resize(kNumChips);
+    }
+    for (int r = 0; r < 4; ++r) {
+      const std::vector<std::vector<Fp>>* rowsp[L];
+      const uint32_t* pathp[L];
+      size_t csv[L], mv[L];
+      uint32_t tags[L];
+      Fp4* hs[L];
+      for (int t = 0; t < L; ++t) {
+        QLane& a = ln[t];
+        for (int c = 0; c < kNumChips; ++c) {
+          a.rows[r][c].resize(shape[r].width[c]);
+          for (int i = 0; i < shape[r].width[c]; ++i) a.rows[r][c][i] = Fp::from_canonical(a.q[i]);
+          a.q += shape[r].width[c];
+        }
+        for (auto& hv : a.hsum[r]) hv = Fp4::zero();
+        rowsp[t] = &a.rows[r]; pathp[t] = a.q; csv[t] = a.cs; mv[t] = a.m;
+        tags[t] = leaf_tag(leaf, a.qi, (uint32_t)r);
+        hs[t] = a.log ? a.hsum[r] : nullptr;
+      }
+      if (!mmcs_verify<L>(shape[r], logh, rowsp, csv, mv, pathp, root[r], kc, lg, tags, leaf_rid(leaf, (uint32_t)r), log ? &af_pows : nullptr,
+                          hs)) {
         static const char* names[4] = {"preprocessed", "main", "permutation", "quotient"};
         *err = std::string(names[r]) + " Merkle opening rejected";
         return 8;
       }
-      q += 8 * ((size_t)shape[r].lm + 1);
+      for (int t = 0; t < L; ++t) ln[t].q += 8 * ((size_t)shape[r].lm + 1);
     }
-    // reduced openings per height
-    auto reduced = [&](int lh) -> Fp4 {
-      Fp4 gsum = Fp4::zero();
-      for (int c = 0; c < kNumChips; ++c) {
-        if (logh[c] != lh) continue;
-        const size_t h = (size_t)1 << lh, mm = m & (h - 1);
-        const Fp wh = fp_root_of_unity(lh), w2h = fp_root_of_unity(lh + 1);
-        const Fp x = (cs ? g * w2h : g) * wh.pow(mm);
-        Fp4 s1 = Fp4::zero(), s2 = Fp4::zero();
-        size_t i = 0, j = 0;
-        for (int r = 0; r < 4; ++r)
-          for (int col = 0; col < shape[r].width[c]; ++col, ++i) {
-            const Fp v = rows[r][c][col];
-            s1 += afpow[open_off[c] + i] * v;
-            if (r == 1 || r == 2) { s2 += afpow[open_off[c] + n1[c] + j] * v; ++j; }
-          }
-        const Fp4 d0 = (Fp4::from_base(x) - zeta).inv(), d1 = (Fp4::from_base(x) - zeta * wh).inv();
-        gsum += (s1 - b1[c]) * d0 + (s2 - b2[c]) * d1;
-      }
-      return gsum;
-    };
-    // with a log: the query chip's 31 rows (air_machine.hpp), bit 30 of the index word down to bit 0
-    std::vector<std::array<uint32_t, kQrRecWords>> qrow;
-    const uint32_t word = index_words[qi];
-    const Fp omi = fp_root_of_unity(lm + 1).inv(), gi0 = Fp::from_canonical(kGenInv);
-    Fp4 d2x = Fp4::zero(), d3x = Fp4::zero(), d4x = Fp4::zero();
-    if (log) {
-      qrow.resize(31);
-      d2x = delta * delta; d3x = d2x * delta; d4x = d2x * d2x;
-      uint32_t eqv = 0, cnt0 = 0, key0 = 0, m0 = 0, keyj = 0, mj = 0;
-      // (MT, MT0 and YT are the same on every row of the chain: filled in at the end)
-      Fp r_acc = Fp::one(), yki = Fp::zero(), gi = Fp::zero();
-      for (int j = 30; j >= 0; --j) {
-        std::array<uint32_t, kQrRecWords>& w = qrow[30 - j];
-        w.fill(0);
-        const uint32_t bit = (word >> j) & 1u;
-        const bool is_csr = j == lm, is_lay = j < lm, is_fl = j == lm - 1;
-        const int k = lm - 1 - j;
-        w[QR_IS_REAL] = 1; w[QR_FIRST] = j == 30; w[QR_LAST] = j == 0; w[QR_LEAF] = leaf; w[QR_QL] = qi; w[QR_J] = (uint32_t)j;
-        w[QR_BIT] = bit; w[QR_ACC] = word >> j;
-        eqv = j == 30 ? bit : (j >= 27 ? (eqv & bit) : eqv);
-        w[QR_EQ] = eqv;
-        w[QR_F1] = j == 29; w[QR_F2] = j == 28; w[QR_F3] = j == 27;
-        w[QR_CSR] = is_csr; w[QR_FL] = is_fl; w[QR_LAY] = is_lay; w[QR_K] = is_lay ? (uint32_t)k : 0u;
-        w[QR_CS] = j <= lm ? (uint32_t)cs : 0u;
-        w[QR_POW] = 1u << j; w[QR_LOW] = word & ((1u << j) - 1);
-        w[QR_REV] = j ? bitrev32(word & ((1u << j) - 1), j) : 0u;
-        w[QR_PR0] = j == kTableLogH;
-        cnt0 += w[QR_PR0];
-        w[QR_CNT0] = cnt0;
-        w[QR_P0A] = j < kTableLogH;
-        if (j == kTableLogH - 1) { key0 = 1; m0 = 0; }
-        if (j < kTableLogH - 1) { key0 = 2 * key0 + ((word >> (j + 1)) & 1u); m0 = 2 * m0 + (height_has_prep(j + 1) ? 1u : 0u); }
-        if (j < kTableLogH) { w[QR_KEY0] = key0; w[QR_M0] = m0; w[QR_HAS0] = height_has_prep(j + 1); }
-        if (is_fl) { keyj = 1; mj = 0; }
-        if (is_lay && !is_fl) { keyj = 2 * keyj + ((word >> (j + 1)) & 1u); mj = 2 * mj + (height_present(j + 1) ? 1u : 0u); }
-        if (is_lay) { w[QR_KEYJ] = keyj; w[QR_MJ] = mj; w[QR_HASRO] = height_present(j + 1); }
-        w[QR_OMI] = omi.to_canonical();
-        w[QR_MU] = bit ? omi.to_canonical() : 1u;
-        w[QR_CSM] = w[QR_CS] ? omi.to_canonical() : 1u;
-        if (is_lay) {
-          r_acc = is_fl ? Fp::from_canonical(w[QR_MU]) : r_acc * r_acc * Fp::from_canonical(w[QR_MU]);
-          w[QR_R] = r_acc.to_canonical();
-          w[QR_R2] = (r_acc * r_acc).to_canonical();
-        }
-      }
-      // the inverse of y = omega^(cs + 2 m), its squares down the layers, the shifts
-      const Fp yt = r_acc * r_acc * (cs ? omi : Fp::one());
-      for (int j = 30; j >= 0; --j) {
-        std::array<uint32_t, kQrRecWords>& w = qrow[30 - j];
-        w[QR_YT] = yt.to_canonical();
-        w[QR_MT] = 4 * mj;
-        w[QR_MT0] = 4 * m0;
-        if (j < lm) {
-          yki = j == lm - 1 ? yt : yki * yki;
-          gi = j == lm - 1 ? gi0 : gi * gi;
-          w[QR_YKI] = yki.to_canonical();
-          w[QR_GI] = gi.to_canonical();
-          const Fp xinv = gi * yki * (((word >> j) & 1u) ? -Fp::one() : Fp::one());
-          w[QR_XINV] = xinv.to_canonical();
-        }
-      }
+    for (int t = 0; t < L; ++t) {
+      QLane& a = ln[t];
+      if (a.log) start_qrows(a);
+      a.expect = reduced(a, lm);
+      a.ro_k = a.expect;  // the reduced opening that joins on the row of layer k (layer 0: the tallest height's)
+      a.shift_k = g;
     }
-    Fp4 expect = reduced(lm);
-    Fp4 ro_k = expect;  // the reduced opening that joins on the row of layer k (layer 0: the tallest height's)
-    Fp shift_k = g;
     for (int k = 0; k < lm; ++k) {
       const int loghk = lm - k;
       const size_t hk = (size_t)1 << loghk, half = hk >> 1;
-      const size_t mk = m & (hk - 1), mlo = mk & (half - 1);
-      const Fp4 lo = read_fp4(q), hi = read_fp4(q + 4);
-      if ((mk >= half ? hi : lo) != expect) { *err = "FRI layer value inconsistent with previous fold"; return 8; }
-      Fp pair[8], cur[8];
-      for (int i = 0; i < 4; ++i) { pair[i] = lo.c[i]; pair[4 + i] = hi.c[i]; }
+      Fp pair[L][8], cur[L][8];
+      const Fp* pairp[L];
+      Fp4 lo[L], hi[L];
+      size_t leaf_pos[L], mlo[L];
+      uint32_t tags[L], key[L];
+      for (int t = 0; t < L; ++t) {
+        QLane& a = ln[t];
+        const size_t mk = a.m & (hk - 1);
+        mlo[t] = mk & (half - 1);
+        lo[t] = read_fp4(a.q); hi[t] = read_fp4(a.q + 4);
+        if ((mk >= half ? hi[t] : lo[t]) != a.expect) { *err = "FRI layer value inconsistent with previous fold"; return 8; }
+        for (int i = 0; i < 4; ++i) { pair[t][i] = lo[t].c[i]; pair[t][4 + i] = hi[t].c[i]; }
+        pairp[t] = pair[t];
+        tags[t] = leaf_tag(leaf, a.qi, 4 + (uint32_t)k);
+        key[t] = 1;
+        leaf_pos[t] = a.cs * half + mlo[t];
+      }
       // the layer's opening: the pair's hash, hashed up to the layer's root (with a log: a run of the Poseidon2 chip)
-      const uint32_t tag = leaf_tag(leaf, qi, 4 + (uint32_t)k);
-      sponge_logged(pair, 8, cur, kc, log, tag, 1, 0, true, false, true);
-      uint32_t key = 1;
-      const size_t leaf_pos = cs * half + mlo;
+      sponge_logged<L>(pairp, 8, cur, kc, lg, tags, key, 0, true, false, true);
       for (int l = 0; l < loghk; ++l) {
-        Fp sib[8], nxt[8];
-        for (int i = 0; i < 8; ++i) sib[i] = Fp::from_canonical(q[8 + 8 * l + i]);
-        const bool right = (leaf_pos >> l) & 1;
-        key = 2 * key + (right ? 1u : 0u);
-        compress_logged(cur, sib, right, nxt, kc, log, right ? P2K_PR : P2K_PL, tag, key, 0);
-        for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
-      }
-      for (int i = 0; i < 8; ++i)
-        if (cur[i] != fri_roots[k][i]) { *err = "FRI Merkle path rejected"; return 8; }
-      const Fp xk = (cs ? shift_k * fp_root_of_unity(loghk + 1) : shift_k) * fp_root_of_unity(loghk).pow(mlo);
-      const Fp xinv = xk.inv();
-      const Fp4 folded = (lo + hi) * inv2 + betas[k] * ((lo - hi) * (inv2 * xinv));
-      if (log) {
-        log_run_end(log, leaf_rid(leaf, 4 + (uint32_t)k));
-        std::array<uint32_t, kQrRecWords>& w = qrow[30 - (lm - 1 - k)];
-        if (w[QR_XINV] != xinv.to_canonical() || w[QR_POW] * 2 + w[QR_REV] * 2 + w[QR_CS] != key) { *err = "internal: query chip row"; return 7; }
-        canon4(betas[k], &w[QR_BETA]); canon4(lo, &w[QR_LO]); canon4(hi, &w[QR_HI]); canon4(expect, &w[QR_E]); canon4(folded, &w[QR_F]);
-        // the reduced opening of the height 2^loghk, which joined on THIS row (ro_k), from its parts
-        const Fp yki = Fp::from_canonical(w[QR_YKI]);
-        const Fp wh = fp_root_of_unity(loghk);
-        const Fp4 zw = zeta * wh;
-        Fp4 den0 = zeta * (-yki), den1 = zw * (-yki);
-        den0.c[0] = den0.c[0] + g;
-        den1.c[0] = den1.c[0] + g;
-        const Fp4 d0 = den0.inv() * yki, d1 = den1.inv() * yki;
-        canon4(d0, &w[QR_D0]); canon4(d1, &w[QR_D1]);
-        if (w[QR_HASRO]) {
-          Fp4 B1 = Fp4::zero(), B2 = Fp4::zero();
-          for (int c = 0; c < kNumChips; ++c)
-            if (logh[c] == loghk) { B1 += b1[c]; B2 += b2[c]; }
-          const Fp4 g2 = hsum[1][loghk] + delta * hsum[2][loghk];
-          for (int r = 0; r < 4; ++r) canon4(hsum[r][loghk], &w[QR_H + 4 * r]);
-          canon4(af, &w[QR_AF]); canon4(delta, &w[QR_DL]); canon4(d2x, &w[QR_D2]); canon4(d3x, &w[QR_D3]); canon4(d4x, &w[QR_D4]);
-          canon4(g2, &w[QR_G2]); canon4(zeta, &w[QR_ZETA]); canon4(zw, &w[QR_ZW]); canon4(B1, &w[QR_B1]); canon4(B2, &w[QR_B2]);
-          w[QR_WH] = wh.to_canonical();
-          const Fp4 ro = d0 * (hsum[0][loghk] + delta * hsum[1][loghk] + d2x * hsum[2][loghk] + d3x * hsum[3][loghk] - B1) +
-                         d1 * (d4x * g2 - B2);
-          if (ro != ro_k) { *err = "internal: reduced opening from the Horner sums"; return 7; }
-          canon4(ro, &w[QR_RO]);
-        } else {
-          // (no height joins: ZETA = 0 in the row, so D0 = D1 = 1 / (g y))
-          const Fp4 dz = Fp4::from_base(yki * gi0);
-          canon4(dz, &w[QR_D0]); canon4(dz, &w[QR_D1]);
+        Fp sib[L][8], nxt[L][8];
+        bool right[L];
+        uint32_t kind[L];
+        for (int t = 0; t < L; ++t) {
+          for (int i = 0; i < 8; ++i) sib[t][i] = Fp::from_canonical(ln[t].q[8 + 8 * l + i]);
+          right[t] = (leaf_pos[t] >> l) & 1;
+          key[t] = 2 * key[t] + (right[t] ? 1u : 0u);
+          kind[t] = right[t] ? P2K_PR : P2K_PL;
         }
+        compress_logged<L>(cur, sib, right, nxt, kc, lg, kind, tags, key, 0);
+        for (int t = 0; t < L; ++t)
+          for (int i = 0; i < 8; ++i) cur[t][i] = nxt[t][i];
       }
-      expect = folded;
-      const bool joins = height_present(loghk - 1);
-      ro_k = Fp4::zero();
-      if (joins) { ro_k = reduced(loghk - 1); expect += ro_k; }
-      q += 8 + 8 * loghk;
-      shift_k = shift_k * shift_k;
+      for (int t = 0; t < L; ++t) {
+        QLane& a = ln[t];
+        for (int i = 0; i < 8; ++i)
+          if (cur[t][i] != fri_roots[k][i]) { *err = "FRI Merkle path rejected"; return 8; }
+        const Fp xk = (a.cs ? a.shift_k * fp_root_of_unity(loghk + 1) : a.shift_k) * fp_root_of_unity(loghk).pow(mlo[t]);
+        const Fp xinv = xk.inv();
+        const Fp4 folded = (lo[t] + hi[t]) * inv2 + betas[k] * ((lo[t] - hi[t]) * (inv2 * xinv));
+        if (a.log) {
+          log_run_end(a.log, leaf_rid(leaf, 4 + (uint32_t)k));
+          std::array<uint32_t, kQrRecWords>& w = a.qrow[30 - (lm - 1 - k)];
+          if (w[QR_XINV] != xinv.to_canonical() || w[QR_POW] * 2 + w[QR_REV] * 2 + w[QR_CS] != key[t]) { *err = "internal: query chip row"; return 7; }
+          canon4(betas[k], &w[QR_BETA]); canon4(lo[t], &w[QR_LO]); canon4(hi[t], &w[QR_HI]); canon4(a.expect, &w[QR_E]); canon4(folded, &w[QR_F]);
+          // the reduced opening of the height 2^loghk, which joined on THIS row (ro_k), from its parts
+          const Fp yki = Fp::from_canonical(w[QR_YKI]);
+          const Fp wh = fp_root_of_unity(loghk);
+          const Fp4 zw = zeta * wh;
+          Fp4 den0 = zeta * (-yki), den1 = zw * (-yki);
+          den0.c[0] = den0.c[0] + g;
+          den1.c[0] = den1.c[0] + g;
+          const Fp4 d0 = den0.inv() * yki, d1 = den1.inv() * yki;
+          canon4(d0, &w[QR_D0]); canon4(d1, &w[QR_D1]);
+          if (w[QR_HASRO]) {
+            Fp4 B1 = Fp4::zero(), B2 = Fp4::zero();
+            for (int c = 0; c < kNumChips; ++c)
+              if (logh[c] == loghk) { B1 += b1[c]; B2 += b2[c]; }
+            const Fp4 g2 = a.hsum[1][loghk] + delta * a.hsum[2][loghk];
+            for (int r = 0; r < 4; ++r) canon4(a.hsum[r][loghk], &w[QR_H + 4 * r]);
+            canon4(af, &w[QR_AF]); canon4(delta, &w[QR_DL]); canon4(d2x, &w[QR_D2]); canon4(d3x, &w[QR_D3]); canon4(d4x, &w[QR_D4]);
+            canon4(g2, &w[QR_G2]); canon4(zeta, &w[QR_ZETA]); canon4(zw, &w[QR_ZW]); canon4(B1, &w[QR_B1]); canon4(B2, &w[QR_B2]);
+            w[QR_WH] = wh.to_canonical();
+            const Fp4 ro = d0 * (a.hsum[0][loghk] + delta * a.hsum[1][loghk] + d2x * a.hsum[2][loghk] + d3x * a.hsum[3][loghk] - B1) +
+                           d1 * (d4x * g2 - B2);
+            if (ro != a.ro_k) { *err = "internal: reduced opening from the Horner sums"; return 7; }
+            canon4(ro, &w[QR_RO]);
+          } else {
+            // (no height joins: ZETA = 0 in the row, so D0 = D1 = 1 / (g y))
+            const Fp4 dz = Fp4::from_base(yki * gi0);
+            canon4(dz, &w[QR_D0]); canon4(dz, &w[QR_D1]);
+          }
+        }
+        a.expect = folded;
+        const bool joins = height_present(loghk - 1);
+        a.ro_k = Fp4::zero();
+        if (joins) { a.ro_k = reduced(a, loghk - 1); a.expect += a.ro_k; }
+        a.q += 8 + 8 * loghk;
+        a.shift_k = a.shift_k * a.shift_k;
+      }
     }
-    if (expect != final_poly) { *err = "FRI final value mismatch"; return 8; }
-    if (log)
-      for (const auto& w : qrow) log->qr_rows.insert(log->qr_rows.end(), w.begin(), w.end());
+    for (int t = 0; t < L; ++t) {
+      QLane& a = ln[t];
+      if (a.expect != final_poly) { *err = "FRI final value mismatch"; return 8; }
+      if (a.log)
+        for (const auto& w : a.qrow) a.log->qr_rows.insert(a.log->qr_rows.end(), w.begin(), w.end());
+    }
     return 0;
   };
   std::vector<int> q_rc(num_queries, 0);
@@ -1198,14 +1300,28 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   for (LeafCheckLog& ql : q_log) ql.leaf_index = log->leaf_index;
   std::atomic<uint32_t> next_q{0};
   // (a query that throws - out of memory in its vectors - is a malformed-input failure of that query, on whichever thread)
+  auto check_one = [&](uint32_t qi) noexcept {
+    try {
+      if (log) { q_log[qi].p2_rows.clear(); q_log[qi].qr_rows.clear(); }
+      LeafCheckLog* one[1] = {log ? &q_log[qi] : nullptr};
+      q_rc[qi] = check_queries(std::integral_constant<int, 1>(), &qi, one, &q_err[qi]);
+    } catch (...) {
+      q_rc[qi] = 7;
+      try { q_err[qi] = "query check ran out of memory"; } catch (...) {}
+    }
+  };
   auto worker = [&]() noexcept {
-    for (uint32_t qi; (qi = next_q.fetch_add(1)) < num_queries;) {
+    for (uint32_t qi; (qi = next_q.fetch_add(2)) < num_queries;) {
+      if (qi + 1 >= num_queries) { check_one(qi); continue; }
+      int rc = 7;
       try {
-        q_rc[qi] = check_query(qi, log ? &q_log[qi] : nullptr, &q_err[qi]);
+        const uint32_t two[2] = {qi, qi + 1};
+        LeafCheckLog* logs2[2] = {log ? &q_log[qi] : nullptr, log ? &q_log[qi + 1] : nullptr};
+        std::string e;
+        rc = check_queries(std::integral_constant<int, 2>(), two, logs2, &e);
       } catch (...) {
-        q_rc[qi] = 7;
-        try { q_err[qi] = "query check ran out of memory"; } catch (...) {}
       }
+      if (rc) { check_one(qi); check_one(qi + 1); }  // one of the two fails: each on its own, so that the failure has a name
     }
   };
   {

@@ -80,7 +80,7 @@ def tree_node_groups(n_leaves: int, arity: int) -> List[List[int]]:
 
 
 def prove_tree_level(client, pk, leaf_vk, leaves: Sequence, node_stdins: Sequence, arity: int, rank: int, world: int,
-                     statements: Optional[Sequence] = None, pipeline: bool = True, group: int = 16, checker=None,
+                     statements: Optional[Sequence] = None, pipeline: bool = True, group: Optional[int] = None, checker=None,
                      statements_out: Optional[dict] = None):
     """One level of BASELINE config 5's recursion tree over the farm (stage 2b): node k is one
     more guest run (node_stdins[k]) whose proof also checks the query phases of its `arity` leaf proofs under the challenges
@@ -124,8 +124,11 @@ def prove_tree_level(client, pk, leaf_vk, leaves: Sequence, node_stdins: Sequenc
         return mine, proofs, status
     # Many nodes: the host checks the leaves of the next nodes WHILE the GPU proves the ones that are ready (the library's
     # calls release the interpreter lock) - a level then takes the longer of the two parts, not their sum: a node of four
-    # full-size leaves is 22 ms of host work and 35 ms of proving (bench.py leaf_check).  The nodes whose checks are done
-    # when the GPU comes back form the next prove_batch call (at most `group` of them: a node's Poseidon2 chip is 2^19 rows).
+    # full-size leaves is 20 ms of host work and 32 ms of proving alone, less in a batch (bench.py leaf_check).  The GPU
+    # proves `group` nodes per call (a third of the level, at most eight: a node's Poseidon2 chip is 2^19 rows, and nodes
+    # proven one at a time as they become ready keep the GPU at its batch-of-one rate, which is slower than the host).
+    if group is None:
+        group = min(8, max(1, len(mine) // 3))
     import queue
     import threading
     ready: "queue.Queue" = queue.Queue()
@@ -159,10 +162,7 @@ def prove_tree_level(client, pk, leaf_vk, leaves: Sequence, node_stdins: Sequenc
                 batch.append(item)
                 if len(batch) >= group:
                     break
-                try:
-                    item = ready.get_nowait()
-                except queue.Empty:
-                    break
+                item = ready.get()
             if batch:
                 pr, st = client.prove_batch(pk, [node_stdins[k] for k in batch])
                 for k, p_, s_ in zip(batch, pr, st):
