@@ -350,9 +350,10 @@ int zksp_hip_lde(zksp_client* c, const uint32_t* d_in, int log_h, size_t ncols, 
 int zksp_hip_merkle_commit(zksp_client* c, const uint32_t* d_mat, int width, int log_n, uint32_t* d_tree);
 int zksp_hip_poseidon2_permute(zksp_client* c, uint32_t* d_states, size_t n);
 /* the HOST verifier's Poseidon2 permutation over n states of 16 canonical words, in place (no GPU): impl 0 = the scalar form,
- * 1 = the 256-bit vector form, 2 = the vector form on two states in lockstep (how the verifier hashes the openings of two
- * queries side by side) - both where the CPU has AVX2 (ZKSP_ERR_UNSUPPORTED where it has not); the three are the same
- * function (csrc/host/p2_avx2.cpp) */
+ * 1 = the 256-bit vector form, 2 = that form on two states in lockstep (AVX2), 3 = a state per 512-bit register, 4 = four
+ * such states in lockstep (AVX-512: how the verifier hashes the openings of four queries side by side) -
+ * ZKSP_ERR_UNSUPPORTED where the CPU lacks the extension; all are the same function (csrc/host/p2_avx2.cpp, p2_avx512.cpp).
+ * The verifier picks the widest form the CPU has; ZKSP_HOST_P2=scalar|avx2 in the environment lowers it. */
 int zksp_host_poseidon2_permute(uint32_t* states, size_t n, int impl);
 /* row a7: one FRI fold of layer [2][Hk][4] with challenge beta (canonical) */
 int zksp_hip_fri_fold(zksp_client* c, const uint32_t* d_in, int log_hk, uint32_t shift_k, const uint32_t* beta,

@@ -31,11 +31,12 @@ def test_host_code_under_asan_ubsan(tmp_path, zk, fx, oracle, host_client):
         flags = ["-fsanitize=address"] if src.endswith("mverifier.cpp") else both
         procs.append(subprocess.Popen(base + flags + ["-c", src, "-o", str(tmp_path / f"o{i}.o")]))
     # the verifier's vector permutation: plain C++ with AVX2, as build.py compiles it, sanitized like the rest
-    procs.append(subprocess.Popen(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-mavx2", *both, "-c",
-                                   os.path.join(HOST, "p2_avx2.cpp"), "-o", str(tmp_path / "p2.o")]))
+    for name, flag in (("p2_avx2", "-mavx2"), ("p2_avx512", "-mavx512f")):
+        procs.append(subprocess.Popen(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", flag, *both, "-c",
+                                       os.path.join(HOST, name + ".cpp"), "-o", str(tmp_path / (name + ".o"))]))
     assert all(p.wait() == 0 for p in procs)
     subprocess.check_call([hipcc, "-fsanitize=address,undefined", *[str(tmp_path / f"o{i}.o") for i in range(len(srcs))],
-                           str(tmp_path / "p2.o"), "-o", str(exe)])
+                           str(tmp_path / "p2_avx2.o"), str(tmp_path / "p2_avx512.o"), "-o", str(exe)])
     pk, vk = host_client.setup(zk.merkle_elf())
     stdin_bytes = fx.stdin_frame(fx.tx_fixture().to_borsh())
     (tmp_path / "stdin.bin").write_bytes(stdin_bytes)

@@ -155,6 +155,14 @@ def test_host_poseidon2_vector_matches_scalar(zk, built_lib):
         paired = states[:n_states].copy()
         assert lib.zksp_host_poseidon2_permute(paired.ctypes.data, n_states, 2) == 0
         assert np.array_equal(paired, scalar[:n_states])
+    # the AVX-512 forms (a state per register; four states in lockstep), where the CPU has them
+    for impl, sizes in ((3, (len(states),)), (4, (len(states), len(states) - 1, len(states) - 2, 3))):
+        for n_states in sizes:
+            wide = states[:n_states].copy()
+            rc = lib.zksp_host_poseidon2_permute(wide.ctypes.data, n_states, impl)
+            if rc == zk.client.ERR_UNSUPPORTED:
+                break
+            assert rc == 0 and np.array_equal(wide, scalar[:n_states])
     bad = states[:1].copy()
     bad[0, 3] = P  # not a canonical word
     assert lib.zksp_host_poseidon2_permute(bad.ctypes.data, 1, 0) != 0

@@ -541,29 +541,26 @@ int zksp_hip_poseidon2_permute(zksp_client* c, uint32_t* d_states, size_t n) {
 }
 
 int zksp_host_poseidon2_permute(uint32_t* states, size_t n, int impl) {
-  if (!states || impl < 0 || impl > 2) return ZKSP_ERR_INVALID_ARG;
-  if (impl >= 1 && !p2avx2::usable()) return ZKSP_ERR_UNSUPPORTED;
+  if (!states || impl < 0 || impl > 4) return ZKSP_ERR_INVALID_ARG;
+  if ((impl == 1 || impl == 2) && !p2avx2::usable()) return ZKSP_ERR_UNSUPPORTED;
+  if (impl >= 3 && !p2avx512::usable()) return ZKSP_ERR_UNSUPPORTED;
+  for (size_t i = 0; i < 16 * n; ++i)
+    if (states[i] >= kP) return ZKSP_ERR_INVALID_ARG;
   const P2Consts* k = &host_p2_consts();
-  size_t i0 = 0;
-  if (impl == 2)  // pairs of states in lockstep (the odd one out alone, below)
-    for (; i0 + 2 <= n; i0 += 2) {
-      Fp st[2][16];
-      for (int j = 0; j < 32; ++j) {
-        if (states[16 * i0 + j] >= kP) return ZKSP_ERR_INVALID_ARG;
-        st[j / 16][j % 16] = Fp::from_canonical(states[16 * i0 + j]);
-      }
-      p2avx2::permute2(&st[0][0].v, &st[1][0].v, k->ext, k->internal, k->diag);
-      for (int j = 0; j < 32; ++j) states[16 * i0 + j] = st[j / 16][j % 16].to_canonical();
-    }
-  for (size_t i = i0; i < n; ++i) {
-    Fp st[16];
-    for (int j = 0; j < 16; ++j) {
-      if (states[16 * i + j] >= kP) return ZKSP_ERR_INVALID_ARG;
-      st[j] = Fp::from_canonical(states[16 * i + j]);
-    }
-    if (impl >= 1) p2avx2::permute(&st[0].v, k->ext, k->internal, k->diag);
-    else p2_permute(st, k);
-    for (int j = 0; j < 16; ++j) states[16 * i + j] = st[j].to_canonical();
+  const size_t group = impl == 4 ? 4 : impl == 2 ? 2 : 1;  // states in lockstep (the remainder one by one)
+  for (size_t i = 0; i < n;) {
+    const size_t cnt = i + group <= n ? group : 1;
+    Fp st[4][16];
+    for (size_t g = 0; g < cnt; ++g)
+      for (int j = 0; j < 16; ++j) st[g][j] = Fp::from_canonical(states[16 * (i + g) + j]);
+    if (cnt == 4) p2avx512::permute4(&st[0][0].v, &st[1][0].v, &st[2][0].v, &st[3][0].v, k->ext, k->internal, k->diag);
+    else if (cnt == 2) p2avx2::permute2(&st[0][0].v, &st[1][0].v, k->ext, k->internal, k->diag);
+    else if (impl >= 3) p2avx512::permute1(&st[0][0].v, k->ext, k->internal, k->diag);
+    else if (impl >= 1) p2avx2::permute(&st[0][0].v, k->ext, k->internal, k->diag);
+    else p2_permute(st[0], k);
+    for (size_t g = 0; g < cnt; ++g)
+      for (int j = 0; j < 16; ++j) states[16 * (i + g) + j] = st[g][j].to_canonical();
+    i += cnt;
   }
   return ZKSP_OK;
 }

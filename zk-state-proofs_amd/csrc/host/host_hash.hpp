@@ -3,8 +3,10 @@
 // device uses (poseidon2.hpp), instantiated on the host.
 #pragma once
 #include <cstddef>
+#include <cstdlib>
 #include <atomic>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -16,23 +18,51 @@ void permute(uint32_t* s, const uint32_t (*ext)[16], const uint32_t* internal, c
 void permute2(uint32_t* sa, uint32_t* sb, const uint32_t (*ext)[16], const uint32_t* internal, const uint32_t* diag);  // two states in lockstep
 bool usable();
 }  // namespace p2avx2
+namespace p2avx512 {  // p2_avx512.cpp: a state per 512-bit register, up to four states in lockstep
+void permute1(uint32_t* a, const uint32_t (*ext)[16], const uint32_t* internal, const uint32_t* diag);
+void permute2(uint32_t* a, uint32_t* b, const uint32_t (*ext)[16], const uint32_t* internal, const uint32_t* diag);
+void permute4(uint32_t* a, uint32_t* b, uint32_t* c, uint32_t* d, const uint32_t (*ext)[16], const uint32_t* internal, const uint32_t* diag);
+bool usable();
+}  // namespace p2avx512
 namespace hosthash {
 
-// The host's permutation: in two 256-bit registers where the CPU has them (6 x the scalar form's rate), else the device's
-// signed lazy form on a core.  State: Montgomery words in [0, p).
+// Which form of the permutation this host runs: 2 = AVX-512 (a state per register, four states in lockstep), 1 = AVX2 (two
+// registers per state, two states in lockstep), 0 = the device's signed lazy form on a core.  ZKSP_HOST_P2=scalar|avx2 lowers it
+// (measurements, and the tests' comparison of the forms through the whole verifier).
+inline int vector_level() {
+  static const int level = [] {
+    int l = p2avx512::usable() ? 2 : p2avx2::usable() ? 1 : 0;
+    if (const char* e = getenv("ZKSP_HOST_P2")) {
+      const std::string v(e);
+      if (v == "scalar") l = 0;
+      else if (v == "avx2") l = l < 1 ? l : 1;
+    }
+    return l;
+  }();
+  return level;
+}
+// how many queries the verifier checks in lockstep, so that their permutations fill the vector unit
+inline int lockstep_lanes() { return vector_level() == 2 ? 4 : 2; }
+
+// The host's permutation.  State: Montgomery words in [0, p).
 inline void permute(Fp* st, const P2Consts* k) {
-  static const bool vec = p2avx2::usable();
-  if (vec) p2avx2::permute(&st[0].v, k->ext, k->internal, k->diag);
+  const int level = vector_level();
+  if (level == 2) p2avx512::permute1(&st[0].v, k->ext, k->internal, k->diag);
+  else if (level == 1) p2avx2::permute(&st[0].v, k->ext, k->internal, k->diag);
   else p2_permute(st, k);
 }
-// L independent states: two of them in lockstep where the vector form exists (one permutation is a chain of dependent
-// operations; a second chain beside it costs a quarter more time, not twice)
+// L independent states in lockstep where a vector form exists (one permutation is a chain of dependent operations; further
+// chains beside it cost a fraction of the time each)
 template <int L>
 inline void permute_lanes(Fp (*st)[16], const P2Consts* k) {
-  static const bool vec = p2avx2::usable();
+  const int level = vector_level();
   int t = 0;
-  if (vec)
+  if (level == 2) {
+    for (; t + 4 <= L; t += 4) p2avx512::permute4(&st[t][0].v, &st[t + 1][0].v, &st[t + 2][0].v, &st[t + 3][0].v, k->ext, k->internal, k->diag);
+    for (; t + 2 <= L; t += 2) p2avx512::permute2(&st[t][0].v, &st[t + 1][0].v, k->ext, k->internal, k->diag);
+  } else if (level == 1) {
     for (; t + 2 <= L; t += 2) p2avx2::permute2(&st[t][0].v, &st[t + 1][0].v, k->ext, k->internal, k->diag);
+  }
   for (; t < L; ++t) permute(st[t], k);
 }
 

@@ -1310,18 +1310,27 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
       try { q_err[qi] = "query check ran out of memory"; } catch (...) {}
     }
   };
+  const uint32_t step = (uint32_t)lockstep_lanes();  // queries checked side by side: what fills the host's vector unit
+  auto check_group = [&](auto lanes, uint32_t q0) noexcept {
+    constexpr int L = decltype(lanes)::value;
+    int rc = 7;
+    try {
+      uint32_t qs[L];
+      LeafCheckLog* logs[L];
+      for (int t = 0; t < L; ++t) { qs[t] = q0 + (uint32_t)t; logs[t] = log ? &q_log[q0 + t] : nullptr; }
+      std::string e;
+      rc = check_queries(lanes, qs, logs, &e);
+    } catch (...) {
+    }
+    if (rc)  // one of them fails: each on its own, so that the failure has a name
+      for (int t = 0; t < L; ++t) check_one(q0 + (uint32_t)t);
+  };
   auto worker = [&]() noexcept {
-    for (uint32_t qi; (qi = next_q.fetch_add(2)) < num_queries;) {
-      if (qi + 1 >= num_queries) { check_one(qi); continue; }
-      int rc = 7;
-      try {
-        const uint32_t two[2] = {qi, qi + 1};
-        LeafCheckLog* logs2[2] = {log ? &q_log[qi] : nullptr, log ? &q_log[qi + 1] : nullptr};
-        std::string e;
-        rc = check_queries(std::integral_constant<int, 2>(), two, logs2, &e);
-      } catch (...) {
-      }
-      if (rc) { check_one(qi); check_one(qi + 1); }  // one of the two fails: each on its own, so that the failure has a name
+    for (uint32_t qi; (qi = next_q.fetch_add(step)) < num_queries;) {
+      uint32_t left = std::min(step, num_queries - qi);
+      if (left == 4) { check_group(std::integral_constant<int, 4>(), qi); continue; }
+      for (; left >= 2; left -= 2, qi += 2) check_group(std::integral_constant<int, 2>(), qi);
+      if (left) check_one(qi);
     }
   };
   {
