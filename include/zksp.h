@@ -281,10 +281,17 @@ int zksp_proof_stub(const zksp_proof* p, zksp_proof** out);
 /* zksp_leaf_public for the leaf at place `leaf_index` beside one run, which itself closes its buses with own_tuples (a node) */
 int zksp_leaf_public_at(zksp_client* c, const zksp_proof* leaf_or_stub, const zksp_vk* leaf_vk, uint32_t leaf_index,
                         const uint32_t* own_tuples, size_t n_own_tuples, uint32_t* out, size_t cap_words, size_t* n_tuples);
+/* The same checks as zksp_stdin_add_verified_leaves, made LATER: by the zksp_prove / zksp_prove_batch call that consumes the stdin,
+ * on its tracing threads, while the GPU proves the runs that are ready - so that the host's part of a recursion-tree level
+ * (15 ms of every core per node of four leaves) runs beside the proving instead of in front of it.  The leaves, their keys
+ * and the `own` tuples (copied) are only recorded here: the leaf proofs and keys must stay alive until that call returns.  A
+ * leaf that does not verify makes the run's status ZKSP_ERR_VERIFY.  All of a run's leaves are deferred, or none. */
+int zksp_stdin_defer_verified_leaves(zksp_client* c, zksp_stdin* s, const zksp_proof* const* leaves, const zksp_vk* const* leaf_vks,
+                                     const uint32_t* const* own, const size_t* n_own, size_t n);
 /* The statement of the proof that will be made from this stdin - the public bus tuples of the leaf checks it carries so far, in
  * the order they were added (zksp_stdin_add_verified_leaf(s) / _node computed them when they verified the leaves): what
- * zksp_leaves_public would derive again from the leaves.  n_tuples = 0 for a stdin without leaf checks.  Read it BEFORE
- * proving: zksp_prove(_batch) consumes a stdin's leaf checks. */
+ * zksp_leaves_public would derive again from the leaves.  n_tuples = 0 for a stdin without leaf checks.  A copy survives the
+ * proving that consumes the checks (and is how the statement of DEFERRED checks is read: after the call that made them). */
 int zksp_stdin_public_tuples(const zksp_stdin* s, uint32_t* out, size_t cap_words, size_t* n_tuples);
 /* Several leaves at once, verified and logged side by side on the host's threads (a node of arity n in one call); own_tuples /
  * n_own_tuples: NULL, or per leaf the statement its proof was made for (NULL / 0 for a plain leaf) */

@@ -166,6 +166,7 @@ def load_library() -> C.CDLL:
     lib.zksp_leaf_public.argtypes = [vp, vp, vp, vp, sz, C.POINTER(sz)]
     lib.zksp_leaf_public_at.argtypes = [vp, vp, vp, C.c_uint32, vp, sz, vp, sz, C.POINTER(sz)]
     lib.zksp_stdin_public_tuples.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    lib.zksp_stdin_defer_verified_leaves.argtypes = [vp, vp, vp, vp, vp, vp, sz]
     lib.zksp_stdin_add_verified_node.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.zksp_proof_stub.argtypes = [vp, C.POINTER(vp)]
     lib.zksp_stdin_add_verified_leaves.argtypes = [vp, vp, vp, vp, vp, vp, sz]
@@ -216,7 +217,7 @@ ABI_SYMBOLS = [
     "zksp_execute", "zksp_execute_keccak", "zksp_opcode_name", "zksp_machine_trace", "zksp_mtrace_free",
     "zksp_mtrace_section", "zksp_mtrace_info", "zksp_vk_machine", "zksp_mtrace_heights", "zksp_machine_body_words",
     "zksp_machine_chip_widths", "zksp_machine_cover_heights", "zksp_stdin_set_aggregation", "zksp_proof_aggregation", "zksp_verify_aggregate",
-    "zksp_stdin_set_aggregation_keyed", "zksp_verify_aggregate_keyed", "zksp_stdin_set_verified_leaf", "zksp_stdin_add_verified_leaf", "zksp_leaves_public", "zksp_verify_with_leaves", "zksp_leaf_public", "zksp_verify_public", "zksp_leaf_public_at", "zksp_stdin_public_tuples", "zksp_stdin_add_verified_node", "zksp_proof_stub", "zksp_stdin_add_verified_leaves",
+    "zksp_stdin_set_aggregation_keyed", "zksp_verify_aggregate_keyed", "zksp_stdin_set_verified_leaf", "zksp_stdin_add_verified_leaf", "zksp_leaves_public", "zksp_verify_with_leaves", "zksp_leaf_public", "zksp_verify_public", "zksp_leaf_public_at", "zksp_stdin_public_tuples", "zksp_stdin_defer_verified_leaves", "zksp_stdin_add_verified_node", "zksp_proof_stub", "zksp_stdin_add_verified_leaves",
     "zksp_verify_with_leaf", "zksp_proof_public_tuples", "zksp_hip_machine_fetch_stage", "zksp_hip_machine_fetch_challenges",
     "zksp_hip_machine_load", "zksp_hip_machine_prove", "zksp_hip_release_workspace", "zksp_hip_machine_fetch_bodies", "zksp_hip_machine_fetch_roots", "zksp_machine_proof_from_body", "zksp_get_params",
     "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
@@ -566,6 +567,26 @@ class ProverClient:
         rc = self._lib.zksp_stdin_add_verified_leaves(self._h, stdin._h, pa, va, own_p, own_n, k)
         if rc:
             raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
+
+    def defer_verified_leaves(self, stdin: SP1Stdin, leaves, leaf_vks, statements=None) -> None:
+        """``add_verified_leaves`` whose checks are made by the ``prove`` / ``prove_batch`` call that consumes ``stdin``
+        (``zksp_stdin_defer_verified_leaves``): on its tracing threads, beside the proving of the runs that are ready.  The stdin
+        keeps the leaves alive until then; a leaf that does not verify shows as that run's status (ERR_VERIFY).  The statement
+        is read with ``stdin_statement`` AFTER proving."""
+        import numpy as np
+        pa, va, k = self._handle_arrays(leaves, leaf_vks)
+        own_p, own_n, keep = None, None, []
+        if statements is not None and any(st is not None for st in statements):
+            own_p, own_n = (C.c_void_p * k)(), (C.c_size_t * k)()
+            for i, st in enumerate(statements):
+                if st is not None:
+                    tv = np.ascontiguousarray(st, dtype=np.uint32).reshape(-1, PUB_TUPLE_WORDS)
+                    keep.append(tv)
+                    own_p[i], own_n[i] = tv.ctypes.data, len(tv)
+        rc = self._lib.zksp_stdin_defer_verified_leaves(self._h, stdin._h, pa, va, own_p, own_n, k)
+        if rc:
+            raise ZkspError(rc, self.last_error())
+        stdin._deferred_keepalive = (list(leaves), list(leaf_vks))  # (the C side holds pointers to them until the prove call)
 
     def _tuples(self, call, guess: int = 128):
         """Runs ``call(out_ptr, cap_words, n_ref)`` - a C function that derives a list of public tuples - ONCE where the list

@@ -354,7 +354,7 @@ int zksp_verify_aggregate_keyed(zksp_client* c, const zksp_proof* p, const zksp_
 // public tuples `leaf` itself closes its buses with (a leaf that checks leaves of its own: a node of a recursion tree).
 // (no access to the client's error state: safe to run for several leaves at once)
 static int leaf_check_run(const zksp_client* c, const zksp_proof* leaf, const zksp_vk* leaf_vk, std::shared_ptr<LeafCheckLog>* out,
-                          uint32_t index, const uint32_t* own, size_t n_own, bool stub_only, std::string* err) {
+                          uint32_t index, const uint32_t* own, size_t n_own, bool stub_only, std::string* err, unsigned max_threads = 0) {
   if (c->ctx.params.proof_mode != ZKSP_PROOF_MACHINE || leaf->version != mach::kMachineVersion) {
     *err = "leaf check: not a machine proof";
     return ZKSP_ERR_VERIFY;
@@ -375,7 +375,7 @@ static int leaf_check_run(const zksp_client* c, const zksp_proof* leaf, const zk
     if (is_stub && !stub_only) { *err = "leaf check: a proof stub has no query phase to prove"; return ZKSP_ERR_INVALID_ARG; }
     std::string verr;
     rc = verify_machine_proof(leaf->bytes.data(), stub_only ? stub_len : leaf->bytes.size(), leaf_vk->machine, c->ctx.params.num_queries,
-                              c->ctx.params.pow_bits, &verr, nullptr, 0, nullptr, own, n_own, log.get(), stub_only);
+                              c->ctx.params.pow_bits, &verr, nullptr, 0, nullptr, own, n_own, log.get(), stub_only, max_threads);
     if (rc == 0) *out = std::move(log);
     else *err = "leaf check: the leaf proof does not verify: " + verr;
   } catch (...) {
@@ -411,7 +411,7 @@ int zksp_proof_stub(const zksp_proof* p, zksp_proof** out) {
 
 int zksp_stdin_set_verified_leaf(zksp_client* c, zksp_stdin* s, const zksp_proof* leaf, const zksp_vk* leaf_vk) {
   if (!c || !s) return ZKSP_ERR_INVALID_ARG;
-  if (!leaf) { s->leaf_check.reset(); return ZKSP_OK; }
+  if (!leaf) { s->leaf_check.reset(); s->deferred.clear(); s->statement.clear(); return ZKSP_OK; }
   if (!leaf_vk) return ZKSP_ERR_INVALID_ARG;
   std::shared_ptr<LeafCheckLog> log;
   const int rc = leaf_check_of(c, leaf, leaf_vk, &log);
@@ -563,13 +563,65 @@ int zksp_verify_with_leaves(zksp_client* c, const zksp_proof* p, const zksp_vk* 
   return zksp_verify_public(c, p, vk, st.data(), st.size() / mach::kPubTupleWords);
 }
 
+int zksp_stdin_defer_verified_leaves(zksp_client* c, zksp_stdin* s, const zksp_proof* const* leaves, const zksp_vk* const* leaf_vks,
+                                     const uint32_t* const* own, const size_t* n_own, size_t n) {
+  if (!c || !s || !leaves || !leaf_vks || !n) return ZKSP_ERR_INVALID_ARG;
+  for (size_t k = 0; k < n; ++k)
+    if (!leaves[k] || !leaf_vks[k] || (own && n_own && n_own[k] && !own[k])) return ZKSP_ERR_INVALID_ARG;
+  if (s->leaf_check) return c->ctx.fail(ZKSP_ERR_INVALID_ARG, "leaf check: the stdin already carries verified leaves; defer all of a run's leaves or none");
+  try {
+    for (size_t k = 0; k < n; ++k) {
+      zksp_stdin::Deferred d{leaves[k], leaf_vks[k], {}};
+      if (own && n_own && n_own[k]) d.own.assign(own[k], own[k] + n_own[k] * mach::kPubTupleWords);
+      s->deferred.push_back(std::move(d));
+    }
+  } catch (...) {
+    return c->ctx.fail(ZKSP_ERR_INVALID_ARG, "leaf check: out of memory");
+  }
+  return ZKSP_OK;
+}
+
+int stdin_resolve_deferred(const zksp_client* c, zksp_stdin* s, std::string* err) {
+  if (s->deferred.empty()) return ZKSP_OK;
+  const size_t n = s->deferred.size();
+  try {
+    // one leaf after the other, two threads each: the parallelism is the call's - many runs are traced at once
+    std::vector<std::shared_ptr<LeafCheckLog>> logs(n);
+    for (size_t k = 0; k < n; ++k) {
+      const zksp_stdin::Deferred& d = s->deferred[k];
+      const int rc = leaf_check_run(c, d.leaf, d.vk, &logs[k], (uint32_t)k, d.own.empty() ? nullptr : d.own.data(),
+                                    d.own.size() / mach::kPubTupleWords, false, err, /*max_threads=*/2);
+      if (rc) return rc;
+    }
+    std::shared_ptr<LeafCheckLog> all;
+    if (n == 1) {
+      all = std::move(logs[0]);
+    } else {
+      all = std::make_shared<LeafCheckLog>();
+      std::vector<const LeafCheckLog*> parts(n);
+      for (size_t k = 0; k < n; ++k) parts[k] = logs[k].get();
+      all->append_all(parts.data(), n);
+    }
+    all->leaf_index = 0;
+    all->n_leaves = (uint32_t)n;
+    s->statement = all->pub_tuples;
+    s->leaf_check = std::move(all);
+    s->deferred.clear();
+  } catch (...) {
+    *err = "leaf check: out of memory";
+    return ZKSP_ERR_VERIFY;
+  }
+  return ZKSP_OK;
+}
+
 int zksp_stdin_public_tuples(const zksp_stdin* s, uint32_t* out, size_t cap_words, size_t* n_tuples) {
   if (!s || !n_tuples) return ZKSP_ERR_INVALID_ARG;
-  const size_t words = s->leaf_check ? s->leaf_check->pub_tuples.size() : 0;
-  *n_tuples = words / mach::kPubTupleWords;
+  // (the attached checks' list; after proving consumed them - or made them, if they were deferred - the copy kept of it)
+  const std::vector<uint32_t>& st = s->leaf_check ? s->leaf_check->pub_tuples : s->statement;
+  *n_tuples = st.size() / mach::kPubTupleWords;
   if (out) {
-    if (cap_words < words) return ZKSP_ERR_INVALID_ARG;
-    if (words) memcpy(out, s->leaf_check->pub_tuples.data(), words * 4);
+    if (cap_words < st.size()) return ZKSP_ERR_INVALID_ARG;
+    if (!st.empty()) memcpy(out, st.data(), st.size() * 4);
   }
   return ZKSP_OK;
 }

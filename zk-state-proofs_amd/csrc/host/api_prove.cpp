@@ -133,6 +133,12 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     try {
       traces[i].reset(new zksp_mtrace());
       traces[i]->prog = &pk->mprog;
+      if (!stdins[i]->deferred.empty()) {
+        // the run's leaf checks, deferred to this call: made here, on a tracing thread, while the GPU proves the runs before
+        traces[i]->leaf_rc = stdin_resolve_deferred(c, stdins[i], &traces[i]->leaf_err);
+        if (traces[i]->leaf_rc) return;
+      }
+      if (stdins[i]->leaf_check) stdins[i]->statement = stdins[i]->leaf_check->pub_tuples;  // (kept: proving consumes the checks)
       trace_execute(pk->elf, pk->mprog, stdins[i]->entries, (uint64_t)1 << 21, &traces[i]->t);
       traces[i]->t.agg_leaves.swap(stdins[i]->agg_leaves);
       traces[i]->t.agg_keys.swap(stdins[i]->agg_keys);
@@ -153,8 +159,14 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   // (round 5: a large call starts with 24 and lets the waves grow by half each - the GPU starts after 40 ms instead of 135,
   // and a wave of 1.5 x is uploaded, from pageable memory at about 10 GB/s, in the time the wave before it is proven;
   // measured on 1 024 acct-d8 runs the warm call is 3 034 ms with the ramp and 3 042 ms without: kept, it costs nothing)
-  const bool ramp = n >= 384 && ctx->params.max_batch >= 96;
-  const size_t w0 = ramp ? 24 : std::min<size_t>(n, std::max<size_t>(1, std::min<size_t>(std::min<size_t>(ctx->params.max_batch, 64), std::max<size_t>(16, (n + 7) / 8))));
+  // (runs that bring deferred leaf checks - the nodes of a recursion tree - are traced at the pace of those checks, some 15 ms
+  // of all the host's cores each: the first wave is four of them, the later ones eight, so that the GPU starts early and never
+  // waits for a long wave's checks)
+  bool any_deferred = false;
+  for (size_t i = 0; i < n; ++i) any_deferred |= stdins[i] && !stdins[i]->deferred.empty();
+  const bool ramp = n >= 384 && ctx->params.max_batch >= 96 && !any_deferred;
+  const size_t w0 = any_deferred ? std::min<size_t>(n, 4)
+                    : ramp ? 24 : std::min<size_t>(n, std::max<size_t>(1, std::min<size_t>(std::min<size_t>(ctx->params.max_batch, 64), std::max<size_t>(16, (n + 7) / 8))));
   parallel_for(w0, 64, trace_one);
   mark.mark("traced", w0);
   std::string first_err;
@@ -177,6 +189,11 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
     auto clog2 = [](size_t v) { int l = 0; while (((size_t)1 << l) < v) ++l; return l; };
     for (size_t i = lo; i < hi; ++i) {
       if (!stdins[i] || !traces[i]) continue;
+      if (traces[i]->leaf_rc) {
+        status[i] = traces[i]->leaf_rc;
+        if (first_err.empty()) first_err = traces[i]->leaf_err;
+        continue;
+      }
       const ExecutionRecord& r = traces[i]->t.rec;
       if (!r.error.empty() || !r.halted) {
         status[i] = ZKSP_ERR_EXECUTOR;
@@ -360,7 +377,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   std::vector<size_t> wave_end;  // exclusive ends of the waves behind the first
   if (w0 < n) {
     if (chunks.size() == 1 && n >= 4 * w0) {
-      const size_t cap = std::max<size_t>(16, std::min<size_t>(ctx->params.max_batch, 192));
+      const size_t cap = any_deferred ? 8 : std::max<size_t>(16, std::min<size_t>(ctx->params.max_batch, 192));
       size_t e0 = w0, biggest = 2 * w0;
       if (ramp) {
         for (size_t w = w0 * 3 / 2; w < cap && e0 + w + cap <= n; w = w * 3 / 2) {

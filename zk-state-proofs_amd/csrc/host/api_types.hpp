@@ -11,10 +11,13 @@
 #include "verifier.hpp"
 #endif
 
+struct zksp_proof;
 struct zksp_client { zksp::Context ctx; };
 struct zksp_pk { zksp::ElfImage elf; uint32_t vk_digest[8]; zksp::MachineProgram mprog; zksp::MachineVk mvk; };
 struct zksp_mtrace {
   zksp::MachineTrace t;
+  int leaf_rc = 0;          // a deferred leaf check of this run failed (prove_batch): the code and what to say
+  std::string leaf_err;
   const zksp::MachineProgram* prog;
   uint32_t handover_pc[zksp::mach::kNumCpuInst - 1] = {};  // pc of the first cycle of every later CPU instance (kept when the cycle records are released)
 };
@@ -24,7 +27,15 @@ struct zksp_stdin {
   std::vector<uint32_t> agg_leaves;  // aggregation payload to prove beside the run (zksp_stdin_set_aggregation), 8 words per digest
   std::vector<uint32_t> agg_keys;    // heap keys of those digests (empty: the leaves of a full tree)
   std::shared_ptr<const zksp::LeafCheckLog> leaf_check;  // leaf-proof check to prove beside the run (zksp_stdin_set_verified_leaf)
+  // leaf checks the next zksp_prove(_batch) call makes itself, on its tracing threads, while the GPU proves what is ready
+  // (zksp_stdin_defer_verified_leaves): the leaves must outlive that call
+  struct Deferred { const zksp_proof* leaf; const zksp_vk* vk; std::vector<uint32_t> own; };
+  std::vector<Deferred> deferred;
+  std::vector<uint32_t> statement;  // the public tuples of the leaf checks last attached (kept when proving consumes them)
 };
+// api_machine.cpp: runs a stdin's deferred leaf checks (one leaf after the other, few threads each: many stdins are in flight),
+// attaches the result; 0, or an error code with *err
+extern "C" int stdin_resolve_deferred(const zksp_client* c, zksp_stdin* s, std::string* err);
 struct zksp_proof {
   std::vector<uint8_t> bytes;
 #ifdef ZKSP_COMPONENT

@@ -649,7 +649,7 @@ void machine_pub_digest(const uint32_t* pub_tuples, size_t n_pub, uint32_t diges
 
 int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, uint32_t num_queries, uint32_t pow_bits,
                          std::string* err, const uint32_t* agg_leaves, size_t n_agg, const uint32_t* agg_keys,
-                         const uint32_t* pub_tuples, size_t n_pub, LeafCheckLog* log, bool stub) {
+                         const uint32_t* pub_tuples, size_t n_pub, LeafCheckLog* log, bool stub, unsigned max_threads) {
   MachineHeader hd;
   if (!parse_machine_header(bytes, len, &hd, err)) return 7;
   // public bus tuples: the caller names the statement the proof's buses are claimed to close with; the transcript holds its digest
@@ -803,7 +803,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     if (total != Fp4::zero()) { *err = "LogUp buses do not balance against the public values and exit code"; return 8; }
   }
 
-  const unsigned n_thr = std::max(1u, std::min({std::thread::hardware_concurrency(), 8u, (unsigned)num_queries / 4u}));
+  const unsigned n_thr = std::max(1u, std::min({std::thread::hardware_concurrency(), max_threads ? max_threads : 8u, (unsigned)num_queries / 4u}));
   std::vector<Fp4> opened(n_open);
   for (size_t i = 0; i < n_open; ++i) opened[i] = read_fp4(p_opened + 4 * i);
   {

@@ -87,9 +87,10 @@ def prove_tree_level(client, pk, leaf_vk, leaves: Sequence, node_stdins: Sequenc
     their own transcripts yield (client.add_verified_leaf, in leaf order; a leaf that is itself a node comes with the
     statement its proof was made for: statements[i], client.add_verified_node).  Nodes are independent of one another and shard block-cyclically over the
     ranks like any other proofs; every rank holds all the leaves (they were all-gathered or are on shared storage - a node's
-    host part verifies its leaves before the node is proven; with more than two nodes and `pipeline`, the checks of the next nodes
-    run beside the proving of the ready ones - on `checker`, a client of the same parameters that needs no GPU, if one is given:
-    the proving client's error state is then its own).  The stdins of this rank's nodes are CONSUMED: whatever leaf
+    host part verifies its leaves before the node is proven; with `pipeline` the checks of the next nodes run beside the proving
+    of the ready ones: inside the level's one prove_batch call where the client can defer them (client.defer_verified_leaves),
+    else on a helper thread - on `checker`, a client of the same parameters that needs no GPU, if one is given - feeding
+    prove_batch calls of `group` nodes).  The stdins of this rank's nodes are CONSUMED: whatever leaf
     checks they carried are replaced by the node's own (so a retry of the level does not double them).  `statements_out`: a dict
     that receives, per node index of this rank, the statement its proof is made for (the public tuples its leaf checks gave -
     read from the stdin before it is proven, not derived a second time).  Returns (node indices of this rank, their proofs,
@@ -117,6 +118,20 @@ def prove_tree_level(client, pk, leaf_vk, leaves: Sequence, node_stdins: Sequenc
         if statements_out is not None and hasattr(chk, "stdin_statement"):
             statements_out[k] = chk.stdin_statement(node_stdins[k])
 
+    if pipeline and len(mine) > 1 and hasattr(client, "defer_verified_leaves") and hasattr(client, "stdin_statement"):
+        # the library's own pipeline: the checks are deferred to the ONE prove_batch call of the level, which makes them on its
+        # tracing threads while the GPU proves the nodes that are ready (uploads and downloads overlapped as for any batch)
+        for k in mine:
+            client.clear_verified_leaves(node_stdins[k])
+            g = groups[k]
+            client.defer_verified_leaves(node_stdins[k], [leaves[i] for i in g], [leaf_vk] * len(g),
+                                         None if statements is None else [statements[i] for i in g])
+        proofs, status = client.prove_batch(pk, [node_stdins[k] for k in mine])
+        if statements_out is not None:
+            for k, st in zip(mine, status):
+                if st == 0:
+                    statements_out[k] = client.stdin_statement(node_stdins[k])
+        return mine, proofs, status
     if len(mine) <= 2 or not pipeline:
         for k in mine:
             check_leaves(k)
