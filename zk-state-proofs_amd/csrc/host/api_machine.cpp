@@ -581,18 +581,49 @@ int zksp_stdin_defer_verified_leaves(zksp_client* c, zksp_stdin* s, const zksp_p
   return ZKSP_OK;
 }
 
-int stdin_resolve_deferred(const zksp_client* c, zksp_stdin* s, std::string* err) {
+int stdin_resolve_deferred(const zksp_client* c, zksp_stdin* s, std::string* err, unsigned budget) {
   if (s->deferred.empty()) return ZKSP_OK;
   const size_t n = s->deferred.size();
+  if (budget == 0) budget = 1;
   try {
-    // one leaf after the other, two threads each: the parallelism is the call's - many runs are traced at once
     std::vector<std::shared_ptr<LeafCheckLog>> logs(n);
-    for (size_t k = 0; k < n; ++k) {
-      const zksp_stdin::Deferred& d = s->deferred[k];
-      const int rc = leaf_check_run(c, d.leaf, d.vk, &logs[k], (uint32_t)k, d.own.empty() ? nullptr : d.own.data(),
-                                    d.own.size() / mach::kPubTupleWords, false, err, /*max_threads=*/2);
-      if (rc) return rc;
+    std::vector<int> rcs(n, ZKSP_OK);
+    std::vector<std::string> errs(n);
+    const bool side_by_side = budget >= n && n > 1;
+    const unsigned per_leaf = side_by_side ? std::max(1u, budget / (unsigned)n) : budget;
+    auto run = [&](size_t k) noexcept {
+      try {
+        const zksp_stdin::Deferred& d = s->deferred[k];
+        rcs[k] = leaf_check_run(c, d.leaf, d.vk, &logs[k], (uint32_t)k, d.own.empty() ? nullptr : d.own.data(),
+                                d.own.size() / mach::kPubTupleWords, false, &errs[k], per_leaf);
+      } catch (...) {
+        rcs[k] = ZKSP_ERR_VERIFY;
+      }
+    };
+    if (side_by_side) {
+      struct Joiner {
+        std::vector<std::thread> th;
+        ~Joiner() { for (auto& t : th) if (t.joinable()) t.join(); }
+      } pool;
+      for (size_t k = 1; k < n; ++k) {
+        try {
+          pool.th.emplace_back(run, k);
+        } catch (...) {
+          run(k);
+        }
+      }
+      run(0);
+    } else {
+      for (size_t k = 0; k < n; ++k) {
+        run(k);
+        if (rcs[k]) break;
+      }
     }
+    for (size_t k = 0; k < n; ++k)
+      if (rcs[k]) {
+        *err = errs[k].empty() ? std::string("leaf check: out of memory") : errs[k];
+        return rcs[k];
+      }
     std::shared_ptr<LeafCheckLog> all;
     if (n == 1) {
       all = std::move(logs[0]);

@@ -128,6 +128,9 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   ctx->pipelined = n > (size_t)Context::kSideMaxBatch;
   std::vector<std::unique_ptr<zksp_mtrace>> traces(n);
   const BatchTrace mark;
+  // threads a run's deferred leaf checks may use: the host's threads over the runs traced at once (the first wave is few
+  // runs whose latency the GPU waits for; the rest are many, traced for throughput)
+  std::atomic<unsigned> leaf_budget{2};
   auto trace_one = [&](size_t i) {
     if (!stdins[i]) return;
     try {
@@ -135,7 +138,7 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       traces[i]->prog = &pk->mprog;
       if (!stdins[i]->deferred.empty()) {
         // the run's leaf checks, deferred to this call: made here, on a tracing thread, while the GPU proves the runs before
-        traces[i]->leaf_rc = stdin_resolve_deferred(c, stdins[i], &traces[i]->leaf_err);
+        traces[i]->leaf_rc = stdin_resolve_deferred(c, stdins[i], &traces[i]->leaf_err, leaf_budget.load(std::memory_order_relaxed));
         if (traces[i]->leaf_rc) return;
       }
       if (stdins[i]->leaf_check) stdins[i]->statement = stdins[i]->leaf_check->pub_tuples;  // (kept: proving consumes the checks)
@@ -167,7 +170,9 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   const bool ramp = n >= 384 && ctx->params.max_batch >= 96 && !any_deferred;
   const size_t w0 = any_deferred ? std::min<size_t>(n, 4)
                     : ramp ? 24 : std::min<size_t>(n, std::max<size_t>(1, std::min<size_t>(std::min<size_t>(ctx->params.max_batch, 64), std::max<size_t>(16, (n + 7) / 8))));
+  leaf_budget = std::max(2u, host_threads() / (unsigned)std::max<size_t>(1, std::min<size_t>(w0, host_threads())));
   parallel_for(w0, 64, trace_one);
+  leaf_budget = 2;
   mark.mark("traced", w0);
   std::string first_err;
   int rc_all = ZKSP_OK;

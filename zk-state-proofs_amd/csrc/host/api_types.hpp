@@ -33,9 +33,9 @@ struct zksp_stdin {
   std::vector<Deferred> deferred;
   std::vector<uint32_t> statement;  // the public tuples of the leaf checks last attached (kept when proving consumes them)
 };
-// api_machine.cpp: runs a stdin's deferred leaf checks (one leaf after the other, few threads each: many stdins are in flight),
-// attaches the result; 0, or an error code with *err
-extern "C" int stdin_resolve_deferred(const zksp_client* c, zksp_stdin* s, std::string* err);
+// api_machine.cpp: runs a stdin's deferred leaf checks on at most `budget` threads (the leaves side by side where the budget
+// covers them, else one after the other: how many runs are in flight decides), attaches the result; 0, or an error code with *err
+extern "C" int stdin_resolve_deferred(const zksp_client* c, zksp_stdin* s, std::string* err, unsigned budget);
 struct zksp_proof {
   std::vector<uint8_t> bytes;
 #ifdef ZKSP_COMPONENT

@@ -118,7 +118,7 @@ def prove_tree_level(client, pk, leaf_vk, leaves: Sequence, node_stdins: Sequenc
         if statements_out is not None and hasattr(chk, "stdin_statement"):
             statements_out[k] = chk.stdin_statement(node_stdins[k])
 
-    if pipeline and len(mine) > 1 and hasattr(client, "defer_verified_leaves") and hasattr(client, "stdin_statement"):
+    if pipeline and mine and hasattr(client, "defer_verified_leaves") and hasattr(client, "stdin_statement"):
         # the library's own pipeline: the checks are deferred to the ONE prove_batch call of the level, which makes them on its
         # tracing threads while the GPU proves the nodes that are ready (uploads and downloads overlapped as for any batch)
         for k in mine:
