@@ -618,16 +618,60 @@ class ProverClient:
         op = own.ctypes.data_as(C.c_void_p) if len(own) else None
         return self._tuples(lambda o, cap, n: self._lib.zksp_leaf_public_at(self._h, leaf._h, leaf_vk._h, index, op, len(own), o, cap, n))
 
-    def tree_statement(self, children, vk: VerifyingKey):
+    def tree_statement(self, children, vk: VerifyingKey, workers: Optional[int] = None):
         """The statement of a node of a recursion tree from its children, recursively: ``children`` is a list of
         ``(proof_or_stub, grandchildren)`` with ``grandchildren`` a list of the same form ([] for a leaf of the tree).  All proofs
-        under ``vk``.  Stubs suffice everywhere: no query phase is read."""
+        under ``vk``.  Stubs suffice everywhere: no query phase is read.  The stub checks of one depth are independent of one
+        another: they run on ``workers`` threads (default: the host's cores, at most 16), each with a verifier client of its own
+        (same parameters, no GPU) - a tree over 1 024 leaves has 1 364 stubs below its root."""
         import numpy as np
-        parts = []
-        for k, (proof, grand) in enumerate(children):
-            own = self.tree_statement(grand, vk) if grand else None
-            parts.append(self.leaf_public_at(proof, vk, k, own))
-        return np.concatenate(parts) if parts else np.zeros((0, PUB_TUPLE_WORDS), np.uint32)
+        if not children:
+            return np.zeros((0, PUB_TUPLE_WORDS), np.uint32)
+        # the nodes by depth (the root's children are depth 0), each with its place among its siblings and its parent
+        levels, frontier = [], [(k, proof, grand, None) for k, (proof, grand) in enumerate(children)]
+        while frontier:
+            levels.append(frontier)
+            nxt = []
+            for idx, (_k, _proof, grand, _parent) in enumerate(frontier):
+                nxt += [(j, p2, g2, idx) for j, (p2, g2) in enumerate(grand)]
+            frontier = nxt
+        n_nodes = sum(len(lv) for lv in levels)
+        if workers is None:
+            workers = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        workers = max(1, min(workers, n_nodes))
+        prm = self.params()
+        clones = [self] if workers == 1 else [ProverClient(device=-1, num_queries=prm.num_queries, pow_bits=prm.pow_bits)
+                                              for _ in range(workers)]
+        import queue
+        from concurrent.futures import ThreadPoolExecutor
+        idle: "queue.Queue" = queue.Queue()
+        for c in clones:
+            idle.put(c)
+
+        def one(args):
+            k, proof, own = args
+            c = idle.get()
+            try:
+                return c.leaf_public_at(proof, vk, k, own)
+            finally:
+                idle.put(c)
+
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            below = None  # the statements of the level below, per node: lists of its children's tuples in sibling order
+            for depth in range(len(levels) - 1, -1, -1):
+                lv = levels[depth]
+                owns = [None] * len(lv)
+                if below is not None:
+                    for idx in range(len(lv)):
+                        parts = below.get(idx)
+                        if parts:
+                            owns[idx] = np.concatenate([parts[j] for j in sorted(parts)])
+                res = list(ex.map(one, [(k, proof, owns[idx]) for idx, (k, proof, _g, _p) in enumerate(lv)]))
+                below = {}
+                for (k, _proof, _g, parent), st in zip(lv, res):
+                    below.setdefault(parent, {})[k] = st
+        top = below.get(None, {})
+        return np.concatenate([top[j] for j in sorted(top)])
 
     def verify_tree(self, root: SP1ProofWithPublicValues, vk: VerifyingKey, children) -> None:
         """``verify`` for the root of a recursion tree (``tree_statement`` for the form of ``children``): the root proof is verified

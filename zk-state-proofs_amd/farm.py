@@ -240,7 +240,11 @@ def prove_tree(client, host, pk, vk, leaves: Sequence, make_stdin: Callable, ari
             if st is None:  # (a checking client without stdin_statement: derived from the children's stubs)
                 stubs = [below[i].stub() for i in groups[k]]
                 st = np.concatenate([host.leaf_public_at(stubs[j], vk, j, st_below[i]) for j, i in enumerate(groups[k])])
-            local.append((p.to_bytes(), st))
+            local.append((p if world == 1 else p.to_bytes(), st))
+        if world == 1:  # (nothing to exchange: the proof objects as they are)
+            levels.append([p for p, _ in local])
+            statements.append([st for _, st in local])
+            continue
         gathered = _gather_objects(local, len(groups), rank, world)
         levels.append([SP1ProofWithPublicValues.from_bytes(b) for b, _ in gathered])
         statements.append([st for _, st in gathered])
