@@ -427,14 +427,14 @@ def leaf_check_mode(zk, fx, client, pk, vk, payload):
                 "statement": f"every node's proof checks the query phases of its {arity} children (leaves, or nodes with their own "
                              "statements); verifying the root reads the root proof and the STUBS (no query phase) of the "
                              f"{len(below)} proofs below it: their bus balance and constraint identity at zeta are still checked "
-                             "natively (stage 2b).  The host's leaf checks of a level run beside the proving of the nodes that are "
-                             "ready (farm.prove_tree_level)"}
+                             "natively (stage 2b).  A level is ONE prove_batch call: the host's leaf checks are deferred to it and run "
+                             "on its tracing threads beside the proving of the nodes that are ready (zksp_stdin_defer_verified_leaves)"}
 
     tree = recursion_tree(16, 4100)
-    # BASELINE config 5 at a quarter of its size: 256 leaf proofs -> 64 -> 16 -> 4 -> 1 (85 node proofs)
-    tree256 = recursion_tree(256, 8000)
+    # BASELINE config 5 in full: 1 024 leaf proofs -> 256 -> 64 -> 16 -> 4 -> 1 (341 node proofs)
+    tree1024 = recursion_tree(1024, 8000)
     return {"poseidon2_rows": rows, "query_rows": qrows, "transcript_rows": trows, "public_tuples": tuples, "tree_node_of_4": tree_node,
-            "two_level_tree": tree, "tree_of_256_leaves": tree256,
+            "two_level_tree": tree, "tree_of_1024_leaves": tree1024,
             "poseidon2_chip_log_height": shape[names.index("poseidon2")],
             "query_chip_log_height": shape[names.index("query")],
             "host_log_ms": log_ms, "prove_end_to_end_ms": prove_ms, "plain_prove_end_to_end_ms": plain_ms,
