@@ -31,8 +31,13 @@ def test_host_code_under_asan_ubsan(tmp_path, zk, fx, oracle, host_client):
         flags = ["-fsanitize=address"] if src.endswith("mverifier.cpp") else both
         procs.append(subprocess.Popen(base + flags + ["-c", src, "-o", str(tmp_path / f"o{i}.o")]))
     # the verifier's vector permutation: plain C++ with AVX2, as build.py compiles it, sanitized like the rest
+    # (with the same compiler as the rest, so that one sanitizer runtime sees one kind of instrumentation: g++'s 64-byte
+    # aligned stack slots of the AVX-512 file do not survive clang's fake stack)
+    cxx = os.path.join(os.path.dirname(os.path.realpath(hipcc)), "..", "lib", "llvm", "bin", "clang++")
+    if not os.path.exists(cxx):
+        cxx = "/opt/rocm/lib/llvm/bin/clang++"
     for name, flag in (("p2_avx2", "-mavx2"), ("p2_avx512", "-mavx512f")):
-        procs.append(subprocess.Popen(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", flag, *both, "-c",
+        procs.append(subprocess.Popen([cxx, "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", flag, *both, "-c",
                                        os.path.join(HOST, name + ".cpp"), "-o", str(tmp_path / (name + ".o"))]))
     assert all(p.wait() == 0 for p in procs)
     subprocess.check_call([hipcc, "-fsanitize=address,undefined", *[str(tmp_path / f"o{i}.o") for i in range(len(srcs))],
