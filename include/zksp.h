@@ -109,23 +109,26 @@ void zksp_stdin_free(zksp_stdin* s);
  * verifier names them (zksp_verify_aggregate) and the proof carries their root (zksp_proof_aggregation). */
 int zksp_stdin_set_aggregation(zksp_stdin* s, const uint32_t* leaves /* [n][8] */, size_t n);
 
-/* Leaf-proof check (stage 2a: a verifier-in-circuit for the query phase; the reference's
- * circuits/sp1-merkle-proof-recursive/src/main.rs:3-5 is a todo!(), its in-circuit verifier would be sp1-recursion-*,
- * Cargo.lock:7315-7417).  Besides the guest's run, the proof made from this stdin establishes that the QUERY PHASE of
- * `leaf` verifies: for every FRI query, every opened row of the four commitment rounds hashes (Poseidon2 sponge) and
- * climbs its mixed-height Merkle path - injections included - to that round's root at the query's position; every FRI
- * layer's sibling pair hashes and climbs to that layer's root; and the folding chain from the tallest reduced opening
- * through every layer (shorter reduced openings joining at their heights) ends in the final constant.  Roots, query
- * positions, folding challenges, domain points, reduced openings and the final constant are PUBLIC (the verifier's, this
- * round: the transcript, the reduced openings and the constraint identity at zeta are not yet in-circuit); the opened
- * rows, the siblings and the pairs are the prover's witnesses.  The call verifies `leaf` on the host first and fails
- * (ZKSP_ERR_VERIFY) if it does not verify: an honest prover has nothing to prove about a bad leaf.  leaf NULL clears. */
+/* Leaf-proof check (stage 2b: the transcript and the query phase of a verifier-in-circuit; the
+ * reference's circuits/sp1-merkle-proof-recursive/src/main.rs:3-5 is a todo!(), its in-circuit verifier would be
+ * sp1-recursion-*, Cargo.lock:7315-7417).  Besides the guest's run, the proof made from this stdin establishes that the QUERY
+ * PHASE of `leaf` verifies UNDER THE CHALLENGES ITS OWN FIAT-SHAMIR TRANSCRIPT YIELDS: the transcript over the blocks named in
+ * the statement (a transcript chip, one duplex per row); the canonical bits of every query's index word, from which every
+ * opening's position follows (a query chip); for every FRI query, every opened row of the four commitment rounds hashed
+ * (Poseidon2 sponge) and climbing its mixed-height Merkle path - injections included - to the root the transcript absorbed;
+ * every FRI layer's sibling pair hashed and climbing to that layer's root; the reduced opening of every height (Horner sums
+ * of the opened rows accumulated beside their hashes); and the folding chain from the tallest reduced opening through every
+ * layer (shorter ones joining at their heights) to the final constant.  PUBLIC is a list of some 75 bus tuples
+ * (zksp_leaf_public): the transcript's blocks, the preprocessed root, and a dozen constants derived from the challenges and
+ * the values opened at zeta.  NOT in-circuit yet (checked by whoever derives that list, from the leaf or its STUB): the leaf's
+ * bus balance and its constraint identity at zeta.  The call verifies `leaf` on the host first and fails (ZKSP_ERR_VERIFY) if it
+ * does not verify: an honest prover has nothing to prove about a bad leaf.  leaf NULL clears every check of the stdin. */
 int zksp_stdin_set_verified_leaf(zksp_client* c, zksp_stdin* s, const zksp_proof* leaf, const zksp_vk* leaf_vk);
 /* ... and one more: the proof made from this stdin checks the query phases of ALL the leaves added so far (the node of a
- * recursion tree of that arity: config 5's 1024 leaf proofs are 128 such proofs of eight leaves each).  The k-th leaf's
- * queries are numbered from k * num_queries on - tags, the query ids of the fold rows and of the public tuples - so the
- * checks share the Poseidon2 and fold chips without sharing a tag; the statement is the leaves' public tuples one leaf
- * after the other, in this order (zksp_leaves_public, zksp_verify_with_leaves). */
+ * recursion tree of that arity: config 5's 1024 leaf proofs are 256 such proofs of four leaves each, bench.py
+ * tree_of_1024_leaves).  The k-th leaf's tags, root ids and tuples carry the leaf index k, so the checks share the Poseidon2,
+ * query and transcript chips without sharing a tag; the statement is the leaves' public tuples one leaf after the other, in
+ * this order (zksp_leaves_public, zksp_verify_with_leaves). */
 int zksp_stdin_add_verified_leaf(zksp_client* c, zksp_stdin* s, const zksp_proof* leaf, const zksp_vk* leaf_vk);
 
 /* replaces client.prove(&pk, stdin).run()  (main.rs:71-74).  `stdin` is consumed
