@@ -580,3 +580,26 @@ def test_a_node_is_a_valid_leaf(zk, fx, oracle, two_leaves):
             client.verify_tree(root, vk, bad)
     with pytest.raises(zk.VerificationError):
         client.verify(root, vk)
+
+
+def test_deferred_checks_are_recorded_not_made(zk, fx, setup):
+    """zksp_stdin_defer_verified_leaves only records the leaves (the prove_batch call that consumes the stdin makes the checks,
+    on the GPU box: tests/test_gpu_machine.py::test_deferred_leaf_checks_equal_attached_ones): nothing is verified yet, the
+    statement is empty, attached and deferred checks do not mix, clearing drops them."""
+    client, pk, vk, leaf, leaf_bytes, t, outer = setup
+    s = zk.SP1Stdin()
+    s.write(fx.acct_fixture(1, seed=2).to_borsh())
+    tampered = bytearray(leaf_bytes)
+    tampered[-20] ^= 1
+    bad = zk.SP1ProofWithPublicValues.from_bytes(bytes(tampered))
+    client.defer_verified_leaves(s, [leaf, bad], [vk, vk])  # (a leaf that does not verify is only found when the run is proven)
+    assert len(client.stdin_statement(s)) == 0
+    with pytest.raises(zk.ZkspError, match="deferred"):
+        client.add_verified_leaf(s, leaf, vk)
+    with pytest.raises(zk.ZkspError, match="deferred"):
+        client.add_verified_leaves(s, [leaf], [vk])
+    client.clear_verified_leaves(s)
+    client.add_verified_leaf(s, leaf, vk)  # after clearing: attached as usual, and then no deferring on top
+    assert len(client.stdin_statement(s)) > 0
+    with pytest.raises(zk.ZkspError):
+        client.defer_verified_leaves(s, [leaf], [vk])

@@ -413,6 +413,7 @@ int zksp_stdin_set_verified_leaf(zksp_client* c, zksp_stdin* s, const zksp_proof
   if (!c || !s) return ZKSP_ERR_INVALID_ARG;
   if (!leaf) { s->leaf_check.reset(); s->deferred.clear(); s->statement.clear(); return ZKSP_OK; }
   if (!leaf_vk) return ZKSP_ERR_INVALID_ARG;
+  if (!s->deferred.empty()) return c->ctx.fail(ZKSP_ERR_INVALID_ARG, "leaf check: the stdin carries deferred leaves; defer all of a run's leaves or none");
   std::shared_ptr<LeafCheckLog> log;
   const int rc = leaf_check_of(c, leaf, leaf_vk, &log);
   if (rc) return rc;
@@ -423,6 +424,7 @@ int zksp_stdin_set_verified_leaf(zksp_client* c, zksp_stdin* s, const zksp_proof
 int zksp_stdin_add_verified_node(zksp_client* c, zksp_stdin* s, const zksp_proof* leaf, const zksp_vk* leaf_vk, const uint32_t* own,
                                  size_t n_own) {
   if (!c || !s || !leaf || !leaf_vk || (n_own && !own)) return ZKSP_ERR_INVALID_ARG;
+  if (!s->deferred.empty()) return c->ctx.fail(ZKSP_ERR_INVALID_ARG, "leaf check: the stdin carries deferred leaves; defer all of a run's leaves or none");
   const uint32_t have = s->leaf_check ? s->leaf_check->n_leaves : 0;
   std::shared_ptr<LeafCheckLog> one;
   const int rc = leaf_check_of(c, leaf, leaf_vk, &one, have, own, n_own);
@@ -453,6 +455,7 @@ int zksp_stdin_add_verified_leaves(zksp_client* c, zksp_stdin* s, const zksp_pro
   if (!c || !s || !leaves || !leaf_vks || !n) return ZKSP_ERR_INVALID_ARG;
   for (size_t k = 0; k < n; ++k)
     if (!leaves[k] || !leaf_vks[k] || (own && n_own && n_own[k] && !own[k])) return ZKSP_ERR_INVALID_ARG;
+  if (!s->deferred.empty()) return c->ctx.fail(ZKSP_ERR_INVALID_ARG, "leaf check: the stdin carries deferred leaves; defer all of a run's leaves or none");
   const uint32_t have = s->leaf_check ? s->leaf_check->n_leaves : 0;
   // the leaves are independent of one another: verified and logged side by side (each on several threads of its own for the
   // queries), appended in the order given
