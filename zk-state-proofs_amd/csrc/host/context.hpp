@@ -98,8 +98,9 @@ struct Context {
   // fetched on the copy stream while the one before is proven, LOSES: slot-d5x256 436 -> 350 proofs/s, acct-d8x1024 304 ->
   // 288 at 64; 435 -> 411 and 308 -> 298 at 48, with GPU_MAX_HW_QUEUES=8 as with the default 4 - it is not a shared hardware
   // queue.  So the lanes carry batches of at most 48 proofs when nothing is copied beside the pass (resident passes, a single
-  // proof, a prove_batch call of one chunk) and of at most eight inside a pipelined prove_batch (`pipelined`): round 4 had
-  // eight everywhere, which made a caller with 9 .. 15 runs slower than one with 8.)
+  // proof, a prove_batch call of one chunk) and of at most eight inside a pipelined prove_batch (`pipelined`; the first two
+  // waves of a call that ramps up are exempt: api_prove.cpp): round 4 had eight everywhere, which made a caller with 9 .. 15
+  // runs slower than one with 8.)
   static constexpr int kSideStreams = 2, kSideMaxBatch = 48, kSidePipelinedMaxBatch = 8;
   bool pipelined = false;  // set by prove_batch while chunks are uploaded / fetched beside the passes
   int lane_max_batch() const { return pipelined ? kSidePipelinedMaxBatch : kSideMaxBatch; }
