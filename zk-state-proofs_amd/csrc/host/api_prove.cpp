@@ -159,8 +159,8 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
   // the rest are traced by host threads while it proves them.
   // (an eighth, at most sixty-four: sixty-four proofs already run at 95 % of the rate of a full batch, and they are traced
   // and uploaded in a tenth of a second)
-  // (round 5: a large call starts with 24 and lets the waves grow by half each - the GPU starts after 40 ms instead of 135,
-  // and a wave of 1.5 x is uploaded, from pageable memory at about 10 GB/s, in the time the wave before it is proven;
+  // (round 5: a large call starts with 24 and lets the waves grow - the GPU starts after 40 ms instead of 135, and the next
+  // wave is uploaded, from pageable memory at about 10 GB/s, in about the time the wave before it is proven;
   // measured on 1 024 acct-d8 runs the warm call is 3 034 ms with the ramp and 3 042 ms without: kept, it costs nothing)
   // (runs that bring deferred leaf checks - the nodes of a recursion tree - are traced at the pace of those checks, some 15 ms
   // of all the host's cores each: the first wave is four of them, the later ones eight, so that the GPU starts early and never
@@ -385,7 +385,9 @@ static int prove_batch_machine(zksp_client* c, const zksp_pk* pk, zksp_stdin* co
       const size_t cap = any_deferred ? 8 : std::max<size_t>(16, std::min<size_t>(ctx->params.max_batch, 192));
       size_t e0 = w0, biggest = 2 * w0;
       if (ramp) {
-        for (size_t w = w0 * 3 / 2; w < cap && e0 + w + cap <= n; w = w * 3 / 2) {
+        // (growth by 7/4: 24, 42, 73, 127 runs, then waves of a full chunk.  Measured against 3/2 - 24, 36, 54, 81, 121, 181 -
+        // on 1 024 acct-d8 runs, four calls each: 3 047-3 102 ms against 3 099-3 137; a first wave of 32 or 40 changes nothing)
+        for (size_t w = w0 * 7 / 4; w < cap && e0 + w + cap <= n; w = w * 7 / 4) {
           e0 += w;
           wave_end.push_back(e0);
           biggest = w;
