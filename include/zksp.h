@@ -284,6 +284,14 @@ int zksp_proof_stub(const zksp_proof* p, zksp_proof** out);
 /* zksp_leaf_public for the leaf at place `leaf_index` beside one run, which itself closes its buses with own_tuples (a node) */
 int zksp_leaf_public_at(zksp_client* c, const zksp_proof* leaf_or_stub, const zksp_vk* leaf_vk, uint32_t leaf_index,
                         const uint32_t* own_tuples, size_t n_own_tuples, uint32_t* out, size_t cap_words, size_t* n_tuples);
+/* Stage 2c, first piece: the constraint identity at zeta exists as a FIXED straight-line program of
+ * operations c = a * b + d over extension cells, recorded from the same AIR templates the verifier evaluates natively
+ * (csrc/host/zeta_program.hpp) - what an arithmetic chip will execute.  This verifies `proof_or_stub` (with its own statement
+ * `own`, if it is a node) and, on the way, runs the program on the proof's opened values and compares every chip's folded
+ * constraints and the final combination with the native evaluation.  info: [0] operations, [1] cells, [2] input cells,
+ * [3] constant cells, [4] the first chip that disagrees (0xffffffff: none). */
+int zksp_zeta_program_selftest(zksp_client* c, const zksp_proof* proof_or_stub, const zksp_vk* vk, const uint32_t* own, size_t n_own,
+                               uint32_t info[8]);
 /* The same checks as zksp_stdin_add_verified_leaves, made LATER: by the zksp_prove / zksp_prove_batch call that consumes the stdin,
  * on its tracing threads, while the GPU proves the runs that are ready - so that the host's part of a recursion-tree level
  * (15 ms of every core per node of four leaves) runs beside the proving instead of in front of it.  The leaves, their keys

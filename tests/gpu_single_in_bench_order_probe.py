@@ -43,13 +43,13 @@ def single(label):
 
 single("after torch initialised the device, fresh client of 192")
 stdins = []
-for i in range(256):
+for i in range(1024):
     s = zk.SP1Stdin()
     s.write(fx.acct_fixture(8, seed=100 + i).to_borsh())
     stdins.append(s)
 proofs, status = client.prove_batch(pk, stdins)
-assert status == [0] * 256
-single("after a prove_batch call of 256")
+assert status == [0] * 1024
+single("after a prove_batch call of 1 024 (ramped)")
 hs = [handle(1000 + i) for i in range(192)]
 arr = (C.c_void_p * 192)(*[t._h for t in hs])
 assert lib.zksp_hip_machine_load(h, pk._h, arr, 192) == 0

@@ -1,6 +1,6 @@
 """Scratch timing (not a test): BASELINE config 5 at a given size - n leaf proofs, then a recursion tree of arity 4 over them
 (farm.prove_tree: the host's leaf checks of a level beside the proving of the ready nodes), the root verified from stubs.
-  python tests/gpu_tree_probe.py [n_leaves=256] [group]"""
+  python tests/gpu_tree_probe.py [n_leaves=256] [group|0] [arity=4]"""
 import importlib
 import os
 import sys
@@ -12,7 +12,8 @@ fx = importlib.import_module("zk-state-proofs_amd.fixtures")
 farm = importlib.import_module("zk-state-proofs_amd.farm")
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-group = int(sys.argv[2]) if len(sys.argv) > 2 else None
+group = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else None
+ARITY = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 client = zk.ProverClient(device=0)
 host = zk.ProverClient(device=-1)
 pk, vk = client.setup(zk.merkle_elf())
@@ -31,7 +32,7 @@ for rep in range(2):
     payloads, cnt, depth = {}, n, 0
     while cnt > 1:
         depth += 1
-        cnt = (cnt + 3) // 4
+        cnt = (cnt + ARITY - 1) // ARITY
         for k in range(cnt):
             payloads[(depth, k)] = fx.acct_fixture(8, seed=200_000 + 4096 * depth + k).to_borsh()
 
@@ -64,7 +65,7 @@ for rep in range(2):
 
     host.add_verified_leaves, client.prove_batch = t_check, t_prove
     t0 = time.perf_counter()
-    levels, statements = farm.prove_tree(client, host, pk, vk, leaves, make_stdin, 4)
+    levels, statements = farm.prove_tree(client, host, pk, vk, leaves, make_stdin, ARITY)
     host.add_verified_leaves, client.prove_batch = o_check, o_prove
     print(f"   host checks {acc['check']:.2f} s in all (its own thread); prove_batch {acc['prove']:.2f} s in {acc['calls']} calls over {acc['proved']} nodes", flush=True)
     t_tree = time.perf_counter() - t0
@@ -72,7 +73,7 @@ for rep in range(2):
         farm.prove_tree_level = orig
     nodes = sum(len(lv) for lv in levels[1:])
     t0 = time.perf_counter()
-    host.verify_tree(levels[-1][0], vk, farm.tree_of_stubs(levels, 4))
+    host.verify_tree(levels[-1][0], vk, farm.tree_of_stubs(levels, ARITY))
     t_ver = time.perf_counter() - t0
     print(f"rep {rep}: {n} leaves in {t_leaves:.2f} s; {nodes} nodes in {t_tree:.2f} s ({t_tree * 1e3 / nodes:.1f} ms per node); "
           f"{n / (t_leaves + t_tree):.1f} leaves/s through the whole tree; root verified from stubs in {t_ver:.2f} s", flush=True)

@@ -37,6 +37,7 @@ SOURCES = [
     "host/mprover.cpp",
     "host/machine_defs.cpp",
     "host/mverifier.cpp",
+    "host/zeta_program.cpp",
     "host/api.cpp",
     "host/api_prove.cpp",
     "host/api_machine.cpp",
@@ -46,7 +47,7 @@ if COMPONENT:
     SOURCES = SOURCES + COMPONENT_SOURCES
 HEADERS = [
     "device/field.hpp", "device/poseidon2.hpp", "device/air_keccak.hpp", "device/air_machine.hpp", "device/kernels.h", "device/kernels_machine.h",
-    "host/machine_defs.hpp", "host/mverifier.hpp", "host/mprover.hpp", "host/host_hash.hpp",
+    "host/machine_defs.hpp", "host/mverifier.hpp", "host/zeta_program.hpp", "host/mprover.hpp", "host/host_hash.hpp",
     "host/executor.hpp", "host/machine.hpp", "host/context.hpp", "host/prover.hpp", "host/verifier.hpp", "host/api_types.hpp",
 ]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + (["-DZKSP_COMPONENT"] if COMPONENT else [])

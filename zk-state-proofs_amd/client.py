@@ -167,6 +167,7 @@ def load_library() -> C.CDLL:
     lib.zksp_leaf_public_at.argtypes = [vp, vp, vp, C.c_uint32, vp, sz, vp, sz, C.POINTER(sz)]
     lib.zksp_stdin_public_tuples.argtypes = [vp, vp, sz, C.POINTER(sz)]
     lib.zksp_stdin_defer_verified_leaves.argtypes = [vp, vp, vp, vp, vp, vp, sz]
+    lib.zksp_zeta_program_selftest.argtypes = [vp, vp, vp, vp, sz, vp]
     lib.zksp_stdin_add_verified_node.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.zksp_proof_stub.argtypes = [vp, C.POINTER(vp)]
     lib.zksp_stdin_add_verified_leaves.argtypes = [vp, vp, vp, vp, vp, vp, sz]
@@ -217,7 +218,7 @@ ABI_SYMBOLS = [
     "zksp_execute", "zksp_execute_keccak", "zksp_opcode_name", "zksp_machine_trace", "zksp_mtrace_free",
     "zksp_mtrace_section", "zksp_mtrace_info", "zksp_vk_machine", "zksp_mtrace_heights", "zksp_machine_body_words",
     "zksp_machine_chip_widths", "zksp_machine_cover_heights", "zksp_stdin_set_aggregation", "zksp_proof_aggregation", "zksp_verify_aggregate",
-    "zksp_stdin_set_aggregation_keyed", "zksp_verify_aggregate_keyed", "zksp_stdin_set_verified_leaf", "zksp_stdin_add_verified_leaf", "zksp_leaves_public", "zksp_verify_with_leaves", "zksp_leaf_public", "zksp_verify_public", "zksp_leaf_public_at", "zksp_stdin_public_tuples", "zksp_stdin_defer_verified_leaves", "zksp_stdin_add_verified_node", "zksp_proof_stub", "zksp_stdin_add_verified_leaves",
+    "zksp_stdin_set_aggregation_keyed", "zksp_verify_aggregate_keyed", "zksp_stdin_set_verified_leaf", "zksp_stdin_add_verified_leaf", "zksp_leaves_public", "zksp_verify_with_leaves", "zksp_leaf_public", "zksp_verify_public", "zksp_leaf_public_at", "zksp_stdin_public_tuples", "zksp_stdin_defer_verified_leaves", "zksp_zeta_program_selftest", "zksp_stdin_add_verified_node", "zksp_proof_stub", "zksp_stdin_add_verified_leaves",
     "zksp_verify_with_leaf", "zksp_proof_public_tuples", "zksp_hip_machine_fetch_stage", "zksp_hip_machine_fetch_challenges",
     "zksp_hip_machine_load", "zksp_hip_machine_prove", "zksp_hip_release_workspace", "zksp_hip_machine_fetch_bodies", "zksp_hip_machine_fetch_roots", "zksp_machine_proof_from_body", "zksp_get_params",
     "zksp_hip_sync", "zksp_hip_timer_start", "zksp_hip_timer_stop",
@@ -587,6 +588,18 @@ class ProverClient:
         if rc:
             raise ZkspError(rc, self.last_error())
         stdin._deferred_keepalive = (list(leaves), list(leaf_vks))  # (the C side holds pointers to them until the prove call)
+
+    def zeta_program_selftest(self, proof: SP1ProofWithPublicValues, vk: VerifyingKey, own_statement=None) -> dict:
+        """Verifies ``proof`` (or its stub) and cross-checks the recorded constraint-identity program against the native evaluation
+        (``zksp_zeta_program_selftest``); returns the program's sizes."""
+        import numpy as np
+        own = np.zeros((0, PUB_TUPLE_WORDS), np.uint32) if own_statement is None else \
+            np.ascontiguousarray(own_statement, dtype=np.uint32).reshape(-1, PUB_TUPLE_WORDS)
+        info = (C.c_uint32 * 8)()
+        rc = self._lib.zksp_zeta_program_selftest(self._h, proof._h, vk._h, own.ctypes.data_as(C.c_void_p) if len(own) else None, len(own), info)
+        if rc:
+            raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
+        return {"ops": info[0], "cells": info[1], "inputs": info[2], "constants": info[3]}
 
     def _tuples(self, call, guess: int = 128):
         """Runs ``call(out_ptr, cap_words, n_ref)`` - a C function that derives a list of public tuples - ONCE where the list

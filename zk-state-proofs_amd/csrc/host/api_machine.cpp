@@ -11,6 +11,7 @@
 #include "api_types.hpp"
 #include "machine_defs.hpp"
 #include "mprover.hpp"
+#include "zeta_program.hpp"
 
 using namespace zksp;
 
@@ -564,6 +565,29 @@ int zksp_verify_with_leaves(zksp_client* c, const zksp_proof* p, const zksp_vk* 
   }
   if (rc) return rc;
   return zksp_verify_public(c, p, vk, st.data(), st.size() / mach::kPubTupleWords);
+}
+
+int zksp_zeta_program_selftest(zksp_client* c, const zksp_proof* p, const zksp_vk* vk, const uint32_t* own, size_t n_own,
+                               uint32_t info[8]) {
+  if (!c || !p || !vk || !info || (n_own && !own)) return ZKSP_ERR_INVALID_ARG;
+  if (c->ctx.params.proof_mode != ZKSP_PROOF_MACHINE || p->version != mach::kMachineVersion)
+    return c->ctx.fail(ZKSP_ERR_VERIFY, "zeta program: not a machine proof");
+  const size_t stub_len = p->mhdr.body_offset + machine_proof_body_words(p->mhdr.logh, 0) * 4;
+  const bool is_stub = p->bytes.size() == stub_len;
+  ZetaSelfTest zst;
+  std::string err;
+  int rc;
+  try {
+    rc = verify_machine_proof(p->bytes.data(), p->bytes.size(), vk->machine, c->ctx.params.num_queries, c->ctx.params.pow_bits, &err,
+                              nullptr, 0, nullptr, own, n_own, nullptr, is_stub, 0, &zst);
+  } catch (...) {
+    return c->ctx.fail(ZKSP_ERR_VERIFY, "zeta program: out of memory");
+  }
+  memset(info, 0, 32);
+  info[0] = zst.n_ops; info[1] = zst.n_cells; info[2] = zst.n_inputs; info[3] = zst.n_consts;
+  info[4] = (uint32_t)zst.mismatch_chip;
+  if (rc) return c->ctx.fail(rc, "zeta program: " + err);
+  return ZKSP_OK;
 }
 
 int zksp_stdin_defer_verified_leaves(zksp_client* c, zksp_stdin* s, const zksp_proof* const* leaves, const zksp_vk* const* leaf_vks,

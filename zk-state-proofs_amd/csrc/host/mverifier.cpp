@@ -19,6 +19,7 @@
 #include <cstring>
 
 #include "host_hash.hpp"
+#include "zeta_program.hpp"
 #include "machine_defs.hpp"
 
 namespace zksp {
@@ -649,7 +650,8 @@ void machine_pub_digest(const uint32_t* pub_tuples, size_t n_pub, uint32_t diges
 
 int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, uint32_t num_queries, uint32_t pow_bits,
                          std::string* err, const uint32_t* agg_leaves, size_t n_agg, const uint32_t* agg_keys,
-                         const uint32_t* pub_tuples, size_t n_pub, LeafCheckLog* log, bool stub, unsigned max_threads) {
+                         const uint32_t* pub_tuples, size_t n_pub, LeafCheckLog* log, bool stub, unsigned max_threads,
+                         ZetaSelfTest* zeta_selftest) {
   MachineHeader hd;
   if (!parse_machine_header(bytes, len, &hd, err)) return 7;
   // public bus tuples: the caller names the statement the proof's buses are claimed to close with; the transcript holds its digest
@@ -819,6 +821,10 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
   const Fp g = Fp::from_canonical(kGen);
   Fp4 group_acc[kNumChips];  // indexed by the height's first chip
   for (int c = 0; c < kNumChips; ++c) group_acc[c] = Fp4::zero();
+  // (zeta_selftest: the same identity as the recorded program of zeta_program.hpp, on this proof's values)
+  const ZetaProgram* zprog = zeta_selftest ? &zeta_program() : nullptr;
+  std::vector<Fp4> zcells(zprog ? zprog->n_cells : 0, Fp4::zero());
+  Fp4 chip_acc[kNumChips];
   for (int c = 0; c < kNumChips; ++c) {
     const ChipDef& d = chip_def(c);
     const int pw = d.prep_w, mw = d.main_w, ew = d.perm_width(), nh = d.helpers(), nb = d.n_constraints, qw = quot_width(logh, c);
@@ -925,6 +931,19 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     const Fp4 cum_step = cum[c] * Fp::from_canonical((uint32_t)(h % kP)).inv();
     zc.acc += apow[nb + nh] * slot_constraint(nh, phin - phi + cum_step - hsum);
     group_acc[quot_leader(logh, c)] += zc.acc;
+    chip_acc[c] = zc.acc;
+    if (zprog) {  // this chip's inputs of the program
+      const ZetaChipCells& cc = zprog->chip[c];
+      for (int i = 0; i < pw; ++i) zcells[cc.prep + i] = o_prep[i];
+      for (int i = 0; i < mw; ++i) { zcells[cc.main + i] = o_main[i]; zcells[cc.main_next + i] = o_main_n[i]; }
+      for (int i = 0; i < ew; ++i) zcells[cc.perm + i] = o_perm[i];
+      for (int i = 0; i < 4; ++i) zcells[cc.perm_next_phi + i] = o_perm_n[4 * nh + i];
+      for (int i = 0; i < qw; ++i) zcells[cc.quot + i] = o_quot[i];
+      zcells[cc.first] = zc.first; zcells[cc.trans] = zc.trans; zcells[cc.last] = zc.last;
+      zcells[cc.apow0] = apow[0];
+      zcells[cc.cum_step] = cum_step;
+      for (int i = 0; i < kNumCpuPub; ++i) zcells[cc.pub[i]] = zc.pub_[i];
+    }
   }
   for (int c = 0; c < kNumChips; ++c) {
     if (!quot_width(logh, c)) continue;
@@ -941,6 +960,40 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     }
   }
 
+  if (zprog) {
+    // the final combination's weights: kappa_c = delta^(the place of c's height among the heights), and the recomposition
+    // coefficients of the height's two quotient chunks for the chip that carries them
+    Fp4 native = Fp4::zero(), kap = Fp4::one();
+    Fp4 kappa_of[kNumChips];
+    for (int c = 0; c < kNumChips; ++c) {
+      const ZetaChipCells& cc = zprog->chip[c];
+      if (quot_leader(logh, c) == c) {
+        const ChipDef& d = chip_def(c);
+        const size_t h = (size_t)1 << logh[c];
+        const Fp4* o_quot = opened.data() + open_off[c] + d.prep_w + d.main_w + d.perm_width();
+        const Fp4 zeta_h = zeta.pow(h), zh = zeta_h - Fp4::one();
+        const Fp sh = g.pow(h), inv_2sh = (sh + sh).inv();
+        kappa_of[c] = kap;
+        zcells[cc.u] = kap * zh * (zeta_h + Fp4::from_base(sh)) * inv_2sh;
+        zcells[cc.v] = kap * zh * (zeta_h - Fp4::from_base(sh)) * inv_2sh;
+        const Fp4 q0 = from_basis(o_quot), q1 = from_basis(o_quot + 4);
+        const Fp4 quot = q0 * (zeta_h + Fp4::from_base(sh)) * inv_2sh - q1 * (zeta_h - Fp4::from_base(sh)) * inv_2sh;
+        native += kap * (group_acc[c] - quot * zh);
+        kap = kap * delta;
+      }
+      zcells[cc.kappa] = kappa_of[quot_leader(logh, c)];
+    }
+    zcells[zprog->alpha] = alpha; zcells[zprog->gamma] = gamma; zcells[zprog->beta] = beta;
+    zeta_program_run(*zprog, zcells.data());
+    zeta_selftest->n_ops = (uint32_t)zprog->ops.size();
+    zeta_selftest->n_cells = zprog->n_cells;
+    zeta_selftest->n_inputs = zprog->n_inputs;
+    zeta_selftest->n_consts = (uint32_t)zprog->const_cell.size();
+    for (int c = 0; c < kNumChips && zeta_selftest->mismatch_chip < 0; ++c)
+      if (zcells[zprog->chip[c].acc] != chip_acc[c]) zeta_selftest->mismatch_chip = c;
+    if (zeta_selftest->mismatch_chip < 0 && (zcells[zprog->result] != native || native != Fp4::zero())) zeta_selftest->mismatch_chip = kNumChips;
+    if (zeta_selftest->mismatch_chip >= 0) { *err = "internal: the recorded zeta program disagrees with the native evaluation"; return 7; }
+  }
   // ---- FRI transcript ----
   std::vector<Fp4> betas(lm);
   std::vector<std::array<Fp, 8>> fri_roots(lm);

@@ -54,7 +54,13 @@ bool parse_machine_header(const uint8_t* bytes, size_t len, MachineHeader* h, st
 int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, uint32_t num_queries, uint32_t pow_bits,
                          std::string* err, const uint32_t* agg_leaves = nullptr, size_t n_agg = 0, const uint32_t* agg_keys = nullptr,
                          const uint32_t* pub_tuples = nullptr, size_t n_pub = 0, LeafCheckLog* log = nullptr, bool stub = false,
-                         unsigned max_threads = 0 /* of this call: 0 = up to eight */);
+                         unsigned max_threads = 0 /* of this call: 0 = up to eight */, struct ZetaSelfTest* zeta_selftest = nullptr);
+// verify_machine_proof with this also runs the constraint identity at zeta as the recorded program (zeta_program.hpp) on the
+// proof's values and compares every chip's folded constraints, and the final combination, with the native evaluation
+struct ZetaSelfTest {
+  uint32_t n_ops = 0, n_cells = 0, n_inputs = 0, n_consts = 0;
+  int mismatch_chip = -1;  // the first chip whose program value differs (-1: none; kNumChips: the final combination)
+};
 // sponge digest of a list of public bus tuples (what stands for the list in the proof header and the transcript)
 void machine_pub_digest(const uint32_t* pub_tuples, size_t n_pub, uint32_t digest[8]);
 // The aggregation payload's public part and the heap of digests the Poseidon2 chip's rows are expanded from:
