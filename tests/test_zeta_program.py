@@ -39,7 +39,8 @@ def test_program_agrees_with_the_native_evaluation(zk, proofs):
     # one program for every shape: the heights enter through input cells only
     assert len(sizes) == 1
     ops, cells, inputs, consts = sizes.pop()
-    assert 40_000 < ops < 120_000 and cells == inputs + consts + 3 + ops and inputs > 8_000
+    # (a product that only feeds one addition is fused into it: fewer operations than cells that were numbered)
+    assert 40_000 < ops < 120_000 and cells >= inputs + consts + 3 + ops and inputs > 8_000
 
 
 def test_selftest_still_verifies(zk, proofs):

@@ -79,6 +79,50 @@ Sym from_basis(uint32_t first_cell) {
   return r;
 }
 
+// A product that only feeds one addition becomes that addition's own product: x * y (+ 0), then t * 1 + d (or e * 1 + t), is
+// x * y + d - the chip's row is a multiply-add, and the recorder emits one operation per operator of the templates.
+void fuse(ZetaProgram* zp) {
+  std::vector<uint32_t> uses(zp->n_cells, 0), producer(zp->n_cells, 0xffffffffu);
+  for (size_t i = 0; i < zp->ops.size(); ++i) {
+    const ZetaOp& o = zp->ops[i];
+    ++uses[o.a]; ++uses[o.b]; ++uses[o.d];
+    producer[o.c] = (uint32_t)i;
+  }
+  for (int c = 0; c < kNumChips; ++c) ++uses[zp->chip[c].acc];
+  ++uses[zp->result];
+  std::vector<uint8_t> dead(zp->ops.size(), 0);
+  auto pure_product = [&](uint32_t cell) -> int64_t {  // the operation that made `cell`, if it is x * y + 0 used once
+    const uint32_t i = producer[cell];
+    if (i == 0xffffffffu || dead[i] || uses[cell] != 1) return -1;
+    const ZetaOp& o = zp->ops[i];
+    return o.d == zp->zero && o.b != zp->one && o.a != zp->one ? (int64_t)i : -1;
+  };
+  std::vector<size_t> removed_of_chip(kNumChips, 0);  // (the per-chip counts follow the operations that remain)
+  for (size_t j = 0; j < zp->ops.size(); ++j) {
+    ZetaOp& o = zp->ops[j];
+    if (o.b != zp->one) continue;  // not an addition
+    int64_t i = pure_product(o.a);
+    uint32_t other = o.d;
+    if (i < 0) { i = pure_product(o.d); other = o.a; }
+    if (i < 0) continue;
+    const ZetaOp& m = zp->ops[(size_t)i];
+    o = {m.a, m.b, other, o.c};
+    dead[(size_t)i] = 1;
+    // (which chip the removed product belonged to: the one whose range holds it)
+    size_t s2 = 0;
+    for (int c = 0; c < kNumChips; ++c) {
+      if ((size_t)i >= s2 && (size_t)i < s2 + zp->ops_of_chip[c]) { ++removed_of_chip[(size_t)c]; break; }
+      s2 += zp->ops_of_chip[c];
+    }
+  }
+  std::vector<ZetaOp> kept;
+  kept.reserve(zp->ops.size());
+  for (size_t i = 0; i < zp->ops.size(); ++i)
+    if (!dead[i]) kept.push_back(zp->ops[i]);
+  zp->ops.swap(kept);
+  for (int c = 0; c < kNumChips; ++c) zp->ops_of_chip[c] -= removed_of_chip[(size_t)c];
+}
+
 void build(ZetaProgram* zp) {
   Recorder rec;
   rec.zp = zp;
@@ -212,6 +256,7 @@ void build(ZetaProgram* zp) {
   }
   zp->result = r.cell;
   g_rec = nullptr;
+  fuse(zp);
 }
 
 }  // namespace
