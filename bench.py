@@ -430,11 +430,19 @@ def leaf_check_mode(zk, fx, client, pk, vk, payload):
                              "natively (stage 2b).  A level is ONE prove_batch call: the host's leaf checks are deferred to it and run "
                              "on its tracing threads beside the proving of the nodes that are ready (zksp_stdin_defer_verified_leaves)"}
 
+    # stage 2c, first piece: the constraint identity at zeta as the recorded straight-line program, cross-checked against the
+    # native evaluation on this leaf (zksp_zeta_program_selftest; the first call builds the program)
+    host.zeta_program_selftest(stub, vk)
+    t1 = time.perf_counter()
+    zinfo = host.zeta_program_selftest(stub, vk)
+    zinfo = dict(zinfo, stub_check_with_selftest_ms=(time.perf_counter() - t1) * 1e3,
+                 statement="the AIR templates instantiated over a recording value type: operations c = a * b + d over extension "
+                           "cells, the same program for every shape; what an arithmetic chip will execute (DESIGN.md section 7.1)")
     tree = recursion_tree(16, 4100)
     # BASELINE config 5 in full: 1 024 leaf proofs -> 256 -> 64 -> 16 -> 4 -> 1 (341 node proofs)
     tree1024 = recursion_tree(1024, 8000)
     return {"poseidon2_rows": rows, "query_rows": qrows, "transcript_rows": trows, "public_tuples": tuples, "tree_node_of_4": tree_node,
-            "two_level_tree": tree, "tree_of_1024_leaves": tree1024,
+            "two_level_tree": tree, "tree_of_1024_leaves": tree1024, "zeta_program": zinfo,
             "poseidon2_chip_log_height": shape[names.index("poseidon2")],
             "query_chip_log_height": shape[names.index("query")],
             "host_log_ms": log_ms, "prove_end_to_end_ms": prove_ms, "plain_prove_end_to_end_ms": plain_ms,
