@@ -96,14 +96,16 @@ def lib_sha256():
 
 
 def source_sha256():
-    """Content hash of the device code the library is built from (csrc/device/, build.py with its compiler flags).
-    The counter collection records it; a library rebuilt elsewhere from the same sources still matches (the .so
-    bytes embed the build path), an edited kernel does not, a host-only change does not invalidate the counters."""
+    """Content hash of the device code the library is built from: every file of csrc/device/, the device sources' names and
+    the compiler flags of build.py.  The counter collection records it; a library rebuilt elsewhere from the same sources
+    still matches (the .so bytes embed the build path), an edited kernel or flag does not, and a host-only change - a new
+    host source in build.py's list included - does not invalidate the counters."""
     h = hashlib.sha256()
     top = os.path.join(ROOT, "zk-state-proofs_amd", "csrc", "device")
-    files = [os.path.join(ROOT, "zk-state-proofs_amd", "build.py")]
-    files += [os.path.join(top, n) for n in os.listdir(top) if n.endswith((".hip", ".hpp", ".h"))]
-    for f in sorted(files):
+    build = importlib.import_module("zk-state-proofs_amd.build")
+    h.update(repr([f for f in build.FLAGS if f != "-DZKSP_COMPONENT"]).encode())
+    h.update(repr(sorted(x for x in build.SOURCES if x.startswith("device/") and x != "device/kernels_bus.hip")).encode())
+    for f in sorted(os.path.join(top, n) for n in os.listdir(top) if n.endswith((".hip", ".hpp", ".h"))):
         h.update(os.path.relpath(f, ROOT).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()
