@@ -19,7 +19,7 @@ def test_host_code_under_asan_ubsan(tmp_path, zk, fx, oracle, host_client):
     exe = tmp_path / "host_fuzz"
     srcs = [os.path.join(ROOT, "tests", "host_fuzz.cpp")] + [os.path.join(HOST, f) for f in
                                                              ("executor.cpp", "verifier.cpp", "params.cpp", "machine.cpp",
-                                                              "machine_defs.cpp", "mverifier.cpp")]
+                                                              "machine_defs.cpp", "mverifier.cpp", "zeta_program.cpp")]
     # (-DZKSP_COMPONENT: the harness feeds the component verifier of verifier.cpp too, which the default library leaves out)
     base = [hipcc, "-x", "hip", "--cuda-host-only", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-DZKSP_COMPONENT", "-I", HOST,
             "-I", os.path.join(ROOT, "include")]
@@ -28,7 +28,7 @@ def test_host_code_under_asan_ubsan(tmp_path, zk, fx, oracle, host_client):
     # checks make that one file compile for four minutes, so it gets ASan only (memory safety on untrusted bytes)
     procs = []
     for i, src in enumerate(srcs):
-        flags = ["-fsanitize=address"] if src.endswith("mverifier.cpp") else both
+        flags = ["-fsanitize=address"] if src.endswith(("mverifier.cpp", "zeta_program.cpp")) else both
         procs.append(subprocess.Popen(base + flags + ["-c", src, "-o", str(tmp_path / f"o{i}.o")]))
     # the verifier's vector permutation: plain C++ with AVX2, as build.py compiles it, sanitized like the rest
     # (with the same compiler as the rest, so that one sanitizer runtime sees one kind of instrumentation: g++'s 64-byte
