@@ -36,12 +36,12 @@ def test_host_code_under_asan_ubsan(tmp_path, zk, fx, oracle, host_client):
     cxx = os.path.join(os.path.dirname(os.path.realpath(hipcc)), "..", "lib", "llvm", "bin", "clang++")
     if not os.path.exists(cxx):
         cxx = "/opt/rocm/lib/llvm/bin/clang++"
-    for name, flag in (("p2_avx2", "-mavx2"), ("p2_avx512", "-mavx512f")):
+    for name, flag in (("p2_avx2", "-mavx2"), ("p2_avx512", "-mavx512f"), ("cpu_features", "-O1")):
         procs.append(subprocess.Popen([cxx, "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", flag, *both, "-c",
                                        os.path.join(HOST, name + ".cpp"), "-o", str(tmp_path / (name + ".o"))]))
     assert all(p.wait() == 0 for p in procs)
     subprocess.check_call([hipcc, "-fsanitize=address,undefined", *[str(tmp_path / f"o{i}.o") for i in range(len(srcs))],
-                           str(tmp_path / "p2_avx2.o"), str(tmp_path / "p2_avx512.o"), "-o", str(exe)])
+                           str(tmp_path / "p2_avx2.o"), str(tmp_path / "p2_avx512.o"), str(tmp_path / "cpu_features.o"), "-o", str(exe)])
     pk, vk = host_client.setup(zk.merkle_elf())
     stdin_bytes = fx.stdin_frame(fx.tx_fixture().to_borsh())
     (tmp_path / "stdin.bin").write_bytes(stdin_bytes)

@@ -33,6 +33,7 @@ SOURCES = [
     "host/params.cpp",
     "host/p2_avx2.cpp",
     "host/p2_avx512.cpp",
+    "host/cpu_features.cpp",
     "host/context.cpp",
     "host/mprover.cpp",
     "host/machine_defs.cpp",
@@ -71,10 +72,11 @@ def _compile(src: str, force: bool, hdr_time: float) -> str:
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time):
         return obj
     cmd = [_hipcc(), *FLAGS, "-I", INCLUDE]
-    if src in ("host/p2_avx2.cpp", "host/p2_avx512.cpp"):
+    if src in ("host/p2_avx2.cpp", "host/p2_avx512.cpp", "host/cpu_features.cpp"):
         # the host verifier's vector permutations: plain C++ (hipcc would compile a .cpp as HIP, for the GPU as well), the vector
-        # extension for that file only, entered after a CPU check
-        cmd = [os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-Wall", "-mavx2" if src.endswith("avx2.cpp") else "-mavx512f"]
+        # extension for that file only, entered after a CPU check (cpu_features.cpp, compiled without any)
+        vec = {"host/p2_avx2.cpp": ["-mavx2"], "host/p2_avx512.cpp": ["-mavx512f"]}.get(src, [])
+        cmd = [os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-Wall", *vec]
     elif src.endswith(".cpp") and src not in ("host/executor.cpp", "host/machine.cpp"):
         cmd += ["-x", "hip"]  # host code that shares the __host__ __device__ field/AIR headers
     cmd += ["-c", path, "-o", obj]

@@ -6,7 +6,7 @@
 // (P2Consts.ext / internal / diag, Montgomery form), every lane kept in [0, p): results are bit-identical to the scalar
 // permutation (tests/test_verifier.py::test_host_poseidon2_vector_matches_scalar, through zksp_host_permute).
 //
-// Compiled as plain C++ with -mavx2 for this file alone; p2_avx2_usable() asks the CPU before anything here runs.
+// Compiled as plain C++ with -mavx2 for this file alone; cpu_features.cpp (compiled without) asks the CPU before anything here runs.
 #include <immintrin.h>
 #include <stdint.h>
 
@@ -155,10 +155,6 @@ __attribute__((target("avx2"))) void permute2(uint32_t* sa, uint32_t* sb, const 
   _mm256_storeu_si256((__m256i*)(sb + 8), b1);
 }
 
-bool usable() {
-  __builtin_cpu_init();
-  return __builtin_cpu_supports("avx2");
-}
 
 }  // namespace p2avx2
 }  // namespace zksp

@@ -5,7 +5,7 @@
 // internal / diag, Montgomery form), every lane kept in [0, p): bit-identical results
 // (tests/test_verifier.py::test_host_poseidon2_vector_matches_scalar, through zksp_host_poseidon2_permute).
 //
-// Compiled as plain C++ with -mavx512f for this file alone; usable() asks the CPU before anything here runs.
+// Compiled as plain C++ with -mavx512f for this file alone; cpu_features.cpp (compiled without) asks the CPU before anything here runs.
 #include <immintrin.h>
 #include <stdint.h>
 
@@ -100,11 +100,6 @@ void permute4(uint32_t* a, uint32_t* b, uint32_t* c, uint32_t* d, const uint32_t
               const uint32_t* diag) {
   uint32_t* st[4] = {a, b, c, d};
   permute_n<4>(st, ext, internal, diag);
-}
-
-bool usable() {
-  __builtin_cpu_init();
-  return __builtin_cpu_supports("avx512f");
 }
 
 }  // namespace p2avx512
