@@ -289,7 +289,9 @@ int zksp_leaf_public_at(zksp_client* c, const zksp_proof* leaf_or_stub, const zk
  * (csrc/host/zeta_program.hpp) - what an arithmetic chip will execute.  This verifies `proof_or_stub` (with its own statement
  * `own`, if it is a node) and, on the way, runs the program on the proof's opened values and compares every chip's folded
  * constraints and the final combination with the native evaluation.  info: [0] operations, [1] cells, [2] input cells,
- * [3] constant cells, [4] the first chip that disagrees (0xffffffff: none). */
+ * [3] constant cells, [4] the first chip that disagrees (0xffffffff: none), [5] the largest number of reads of one cell, [6]
+ * the input cells the program reads at all.  The run's memory argument - every cell written once, read as often as the program
+ * says - is checked on the values as well. */
 int zksp_zeta_program_selftest(zksp_client* c, const zksp_proof* proof_or_stub, const zksp_vk* vk, const uint32_t* own, size_t n_own,
                                uint32_t info[8]);
 /* The same checks as zksp_stdin_add_verified_leaves, made LATER: by the zksp_prove / zksp_prove_batch call that consumes the stdin,

@@ -34,6 +34,8 @@ def test_program_agrees_with_the_native_evaluation(zk, proofs):
     for proof, own in cases:
         info = client.zeta_program_selftest(proof, vk, own)
         sizes.add((info["ops"], info["cells"], info["inputs"], info["constants"]))
+        # the run's memory argument balanced too (every cell written once, read as often as the program says): part of the call
+        assert 0 < info["inputs_read"] <= info["inputs"] and info["max_reads_of_a_cell"] > 1000  # (the constants 0 and 1)
         # ... and from the stub: the identity needs nothing of the query phase
         assert client.zeta_program_selftest(proof.stub(), vk, own) == info
     # one program for every shape: the heights enter through input cells only

@@ -599,7 +599,8 @@ class ProverClient:
         rc = self._lib.zksp_zeta_program_selftest(self._h, proof._h, vk._h, own.ctypes.data_as(C.c_void_p) if len(own) else None, len(own), info)
         if rc:
             raise (VerificationError if rc == ERR_VERIFY else ZkspError)(rc, self.last_error())
-        return {"ops": info[0], "cells": info[1], "inputs": info[2], "constants": info[3]}
+        return {"ops": info[0], "cells": info[1], "inputs": info[2], "constants": info[3], "max_reads_of_a_cell": info[5],
+                "inputs_read": info[6]}
 
     def _tuples(self, call, guess: int = 128):
         """Runs ``call(out_ptr, cap_words, n_ref)`` - a C function that derives a list of public tuples - ONCE where the list

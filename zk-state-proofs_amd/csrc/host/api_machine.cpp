@@ -586,6 +586,7 @@ int zksp_zeta_program_selftest(zksp_client* c, const zksp_proof* p, const zksp_v
   memset(info, 0, 32);
   info[0] = zst.n_ops; info[1] = zst.n_cells; info[2] = zst.n_inputs; info[3] = zst.n_consts;
   info[4] = (uint32_t)zst.mismatch_chip;
+  info[5] = zst.max_reads; info[6] = zst.inputs_read;
   if (rc) return c->ctx.fail(rc, "zeta program: " + err);
   return ZKSP_OK;
 }

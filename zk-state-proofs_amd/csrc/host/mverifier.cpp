@@ -989,6 +989,10 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
     zeta_selftest->n_cells = zprog->n_cells;
     zeta_selftest->n_inputs = zprog->n_inputs;
     zeta_selftest->n_consts = (uint32_t)zprog->const_cell.size();
+    zeta_selftest->max_reads = zprog->max_reads;
+    zeta_selftest->inputs_read = zprog->inputs_read;
+    // (the arithmetic chip's memory argument on these values: every cell written once, read as often as the program says)
+    if (!zeta_program_memory_balances(*zprog, zcells.data(), gamma, beta)) { *err = "internal: the zeta program's memory does not balance"; return 7; }
     for (int c = 0; c < kNumChips && zeta_selftest->mismatch_chip < 0; ++c)
       if (zcells[zprog->chip[c].acc] != chip_acc[c]) zeta_selftest->mismatch_chip = c;
     if (zeta_selftest->mismatch_chip < 0 && (zcells[zprog->result] != native || native != Fp4::zero())) zeta_selftest->mismatch_chip = kNumChips;

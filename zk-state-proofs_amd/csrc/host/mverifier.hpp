@@ -58,7 +58,7 @@ int verify_machine_proof(const uint8_t* bytes, size_t len, const MachineVk& vk, 
 // verify_machine_proof with this also runs the constraint identity at zeta as the recorded program (zeta_program.hpp) on the
 // proof's values and compares every chip's folded constraints, and the final combination, with the native evaluation
 struct ZetaSelfTest {
-  uint32_t n_ops = 0, n_cells = 0, n_inputs = 0, n_consts = 0;
+  uint32_t n_ops = 0, n_cells = 0, n_inputs = 0, n_consts = 0, max_reads = 0, inputs_read = 0;
   int mismatch_chip = -1;  // the first chip whose program value differs (-1: none; kNumChips: the final combination)
 };
 // sponge digest of a list of public bus tuples (what stands for the list in the proof header and the transcript)

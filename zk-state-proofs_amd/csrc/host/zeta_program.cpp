@@ -3,6 +3,7 @@
 // are cross-checked on real proofs: zksp_zeta_program_selftest).
 #include "zeta_program.hpp"
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 
@@ -121,6 +122,17 @@ void fuse(ZetaProgram* zp) {
     if (!dead[i]) kept.push_back(zp->ops[i]);
   zp->ops.swap(kept);
   for (int c = 0; c < kNumChips; ++c) zp->ops_of_chip[c] -= removed_of_chip[(size_t)c];
+  // read multiplicities of the fused program
+  zp->reads.assign(zp->n_cells, 0);
+  for (const ZetaOp& o : zp->ops) { ++zp->reads[o.a]; ++zp->reads[o.b]; ++zp->reads[o.d]; }
+  for (int c = 0; c < kNumChips; ++c) ++zp->reads[zp->chip[c].acc];
+  ++zp->reads[zp->result];
+  zp->max_reads = 0;
+  zp->inputs_read = 0;
+  for (uint32_t c = 0; c < zp->n_cells; ++c) {
+    zp->max_reads = std::max(zp->max_reads, zp->reads[c]);
+    if (c < zp->n_inputs && zp->reads[c]) ++zp->inputs_read;
+  }
 }
 
 void build(ZetaProgram* zp) {
@@ -276,6 +288,38 @@ void zeta_program_run(const ZetaProgram& zp, Fp4* cells) {
     cells[zp.basis[j]] = b;
   }
   for (const ZetaOp& o : zp.ops) cells[o.c] = cells[o.a] * cells[o.b] + cells[o.d];
+}
+
+bool zeta_program_memory_balances(const ZetaProgram& zp, const Fp4* cells, const Fp4& gamma, const Fp4& beta) {
+  Fp4 bp[5];
+  bp[0] = beta;
+  for (int j = 1; j < 5; ++j) bp[j] = bp[j - 1] * beta;
+  auto fp = [&](uint32_t cell) {
+    Fp4 f = gamma + bp[0] * Fp::from_canonical(cell);
+    for (int j = 0; j < 4; ++j) f += bp[j + 1] * cells[cell].c[j];
+    return f;
+  };
+  // (one inversion per cell: reads of a cell share its fingerprint)
+  Fp4 total = Fp4::zero();
+  std::vector<uint8_t> written(zp.n_cells, 0);
+  for (uint32_t c = 0; c < zp.n_inputs; ++c) written[c] = 1;
+  for (uint32_t c : zp.const_cell) written[c] = 1;
+  for (int j = 1; j < 4; ++j) written[zp.basis[j]] = 1;
+  std::vector<uint32_t> seen(zp.n_cells, 0);
+  for (const ZetaOp& o : zp.ops) {
+    if (!written[o.a] || !written[o.b] || !written[o.d] || written[o.c]) return false;  // read before written, or written twice
+    written[o.c] = 1;
+    ++seen[o.a]; ++seen[o.b]; ++seen[o.d];
+  }
+  for (int c = 0; c < kNumChips; ++c) ++seen[zp.chip[c].acc];
+  ++seen[zp.result];
+  for (uint32_t c = 0; c < zp.n_cells; ++c) {
+    if (!zp.reads[c] && !seen[c]) continue;
+    const Fp4 inv = fp(c).inv();
+    total += inv * Fp::from_canonical(zp.reads[c]);  // the write, with the program's multiplicity
+    total -= inv * Fp::from_canonical(seen[c]);      // the reads that happened
+  }
+  return total == Fp4::zero();
 }
 
 }  // namespace zksp

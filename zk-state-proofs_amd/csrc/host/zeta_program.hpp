@@ -39,11 +39,21 @@ struct ZetaProgram {
   uint32_t result = 0;  // output: sum_c kappa_c acc_c - sum_c (u_c Q0_c - v_c Q1_c), zero for a proof whose identity holds
   uint32_t n_inputs = 0;
   size_t ops_of_chip[mach::kNumChips] = {0};
+  // how often each cell is read (as a, b or d of an operation; the chips' acc cells and the result once more: by whoever
+  // checks them): the multiplicity with which the cell's one writer puts it on the arithmetic chip's memory bus - a property
+  // of the program, not of a proof
+  std::vector<uint32_t> reads;
+  uint32_t max_reads = 0, inputs_read = 0;
 };
 
 // built once per process (some 10^5 operations)
 const ZetaProgram& zeta_program();
 // cells: n_cells extension values with the inputs filled in (constants are filled here); runs every operation
 void zeta_program_run(const ZetaProgram& zp, Fp4* cells);
+// The arithmetic chip's memory argument on the values of a run, natively: every cell is written once - by an operation, or from
+// outside (inputs, constants) - with its read count as multiplicity, and read by the operations that use it;
+// sum reads[c] / (gamma + fp(c, cell)) over the writes - sum 1 / (gamma + fp(.)) over the reads must vanish (fp: the address and
+// the four words against powers of beta).  True if it does.
+bool zeta_program_memory_balances(const ZetaProgram& zp, const Fp4* cells, const Fp4& gamma, const Fp4& beta);
 
 }  // namespace zksp
