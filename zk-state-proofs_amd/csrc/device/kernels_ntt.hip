@@ -89,9 +89,12 @@ __device__ __forceinline__ void ntt_pass(const PassIo& io, const uint32_t* __res
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           if (DIF) {
+            // the difference goes into the product as a signed word: subtract (1), centred Montgomery product (3), canonical
+            // (2) - nine instructions a butterfly with the sum's three, where (u - v) * w on residues takes eleven.  |u - v| < p
+            // and w < p keep the product inside fps_redc's range and its result inside (-p, p).  (DESIGN.md section 4 "NTT, round 5")
             Fp u = x[c][k], v = x[c][k + hk];
             x[c][k] = u + v;
-            x[c][k + hk] = (u - v) * w;
+            x[c][k + hk] = Fp::raw(fps_canon(fps_mul((int32_t)u.v - (int32_t)v.v, (int32_t)w.v)));
           } else {
             Fp u = x[c][k], t = x[c][k + hk] * w;
             x[c][k] = u + t;
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(kLdeThreads) void ntt_strided_kernel(const uint32_t
       Fp u = buf[lo * kRow + t], v = buf[hi * kRow + t];
       if (DIF) {
         buf[lo * kRow + t] = u + v;
-        buf[hi * kRow + t] = (u - v) * w;
+        buf[hi * kRow + t] = Fp::raw(fps_canon(fps_mul((int32_t)u.v - (int32_t)v.v, (int32_t)w.v)));  // (as in ntt_pass)
       } else {
         Fp x = v * w;
         buf[lo * kRow + t] = u + x;
