@@ -12,9 +12,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 zk = importlib.import_module("zk-state-proofs_amd")
 fx = importlib.import_module("zk-state-proofs_amd.fixtures")
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-CAP = int(sys.argv[2]) if len(sys.argv) > 2 else B  # the client's max_batch (bench.py measures a batch of one on a client of 192)
-client = zk.ProverClient(device=0, max_batch=CAP)
+_args = [a for a in sys.argv[1:] if not a.startswith("--")]
+B = int(_args[0]) if len(_args) > 0 else 1
+CAP = int(_args[1]) if len(_args) > 1 else B  # the client's max_batch (bench.py measures a batch of one on a client of 192)
+client = zk.ProverClient(device=int(os.environ.get("ZKSP_DEVICE", "0")), max_batch=CAP)
 lib, h = client._lib, client._h
 pk, vk = client.setup(zk.merkle_elf())
 handles = []
@@ -27,7 +28,7 @@ assert lib.zksp_hip_machine_load(h, pk._h, arr, B) == 0, client.last_error()
 for _ in range(3):
     assert lib.zksp_hip_machine_prove(h) == 0, client.last_error()
 lib.zksp_hip_sync(h)
-steps = 20
+steps = 40 if "--json" in sys.argv else 20
 t0 = time.perf_counter()
 for _ in range(steps):
     assert lib.zksp_hip_machine_prove(h) == 0, client.last_error()
@@ -53,3 +54,7 @@ bodies = np.zeros((B, bw), np.uint32)
 assert lib.zksp_hip_machine_fetch_bodies(h, bodies.ctypes.data_as(C.c_void_p), bodies.size) == 0
 zk.ProverClient(device=-1).verify(handles[0].proof_from_body(pk, bodies[0], shape), vk)
 print("verified")
+if "--json" in sys.argv:  # (bench.py runs this file as a child process for its single-proof figure)
+    import json
+    print("JSON " + json.dumps({"batch": B, "ms_per_pass": el * 1e3 / steps, "synchronised_ms": sorted(tot)[len(tot) // 2],
+                               "enqueue_ms": sorted(enq)[len(enq) // 2], "verified": True}), flush=True)
