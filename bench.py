@@ -383,7 +383,7 @@ def leaf_check_mode(zk, fx, client, pk, vk, payload):
                  "statement": "one run whose proof establishes the query phases of four leaf proofs under their own transcripts' "
                               "challenges; verified on the host with the four leaves' stubs"}
     # config 5 in small: 16 leaves -> 4 nodes -> 1 root; the nodes are leaves of the root (with their own statements)
-    def recursion_tree(n_tree, seed0):
+    def recursion_tree(n_tree, seed0, arity=arity):
         tl = []
         for i in range(n_tree):
             si = zk.SP1Stdin()
@@ -420,7 +420,7 @@ def leaf_check_mode(zk, fx, client, pk, vk, payload):
         n_nodes = sum(len(lv) for lv in levels[1:])
         rraw = root.to_bytes()
         rshape = [int.from_bytes(rraw[8 + 4 * c:12 + 4 * c], "little") for c in range(zk.MACHINE_CHIPS)]
-        return {"levels": [len(lv) for lv in levels], "leaves_prove_batch_s": leaves_s, "nodes_and_root_s": tree_s,
+        return {"levels": [len(lv) for lv in levels], "arity": arity, "leaves_prove_batch_s": leaves_s, "nodes_and_root_s": tree_s,
                 "ms_per_node": tree_s * 1e3 / n_nodes, "leaves_per_s_through_the_whole_tree": n_tree / (leaves_s + tree_s),
                 "root_verify_from_stubs_s": tree_verify_s, "root_proof_bytes": len(rraw),
                 "stub_bytes_read": sum(len(p.stub().to_bytes()) for p in below),
@@ -443,8 +443,11 @@ def leaf_check_mode(zk, fx, client, pk, vk, payload):
     tree = recursion_tree(16, 4100)
     # BASELINE config 5 in full: 1 024 leaf proofs -> 256 -> 64 -> 16 -> 4 -> 1 (341 node proofs)
     tree1024 = recursion_tree(1024, 8000)
+    # ... and with nodes of five leaves: 258 nodes instead of 341, a node's Poseidon2 chip still 2^19 rows (448 000 of them used
+    # instead of 358 400) - fewer proofs for the GPU, more checking per node for the host
+    tree1024_5 = recursion_tree(1024, 60000, arity=5)
     return {"poseidon2_rows": rows, "query_rows": qrows, "transcript_rows": trows, "public_tuples": tuples, "tree_node_of_4": tree_node,
-            "two_level_tree": tree, "tree_of_1024_leaves": tree1024, "zeta_program": zinfo,
+            "two_level_tree": tree, "tree_of_1024_leaves": tree1024, "tree_of_1024_leaves_arity_5": tree1024_5, "zeta_program": zinfo,
             "poseidon2_chip_log_height": shape[names.index("poseidon2")],
             "query_chip_log_height": shape[names.index("query")],
             "host_log_ms": log_ms, "prove_end_to_end_ms": prove_ms, "plain_prove_end_to_end_ms": plain_ms,
