@@ -1,6 +1,6 @@
 """Scratch timing (not a test): BASELINE config 5 at a given size - n leaf proofs, then a recursion tree of arity 4 over them
 (farm.prove_tree: the host's leaf checks of a level beside the proving of the ready nodes), the root verified from stubs.
-  python tests/gpu_tree_probe.py [n_leaves=256] [group|0] [arity=4]"""
+  python tests/gpu_tree_probe.py [n_leaves=256] [group|0] [arity=4] [node fixture depth=1]"""
 import importlib
 import os
 import sys
@@ -14,6 +14,7 @@ farm = importlib.import_module("zk-state-proofs_amd.farm")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 group = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else None
 ARITY = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+NODE_DEPTH = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # the trie depth of a node's own (incidental) guest run
 client = zk.ProverClient(device=0)
 host = zk.ProverClient(device=-1)
 pk, vk = client.setup(zk.merkle_elf())
@@ -34,7 +35,7 @@ for rep in range(2):
         depth += 1
         cnt = (cnt + ARITY - 1) // ARITY
         for k in range(cnt):
-            payloads[(depth, k)] = fx.acct_fixture(8, seed=200_000 + 4096 * depth + k).to_borsh()
+            payloads[(depth, k)] = fx.acct_fixture(NODE_DEPTH, seed=200_000 + 4096 * depth + k).to_borsh()
 
     def make_stdin(depth, k):
         s = zk.SP1Stdin()
