@@ -535,3 +535,38 @@ def test_deferred_leaf_checks_equal_attached_ones(zk, fx):
     mine, nodes, status = farm.prove_tree_level(client, pk, vk, leaves, node_stdins, 2, 0, 1, statements_out=st_of)
     assert status == [0] * 6 and [p.to_bytes() for p in nodes] == [p.to_bytes() for p in want]
     assert all(np.array_equal(st_of[k], st_attached[k]) for k in range(6))
+
+
+def test_ramped_call_equals_plain_calls(zk, fx, oracle):
+    """A prove_batch call of 384 runs or more on a client of max_batch >= 96 ramps up (api_prove.cpp): a first wave of 24 runs,
+    waves growing by 7/4, the first two of them on the side lanes although chunks are copied beside them.  Every proof of such a
+    call equals, byte for byte, the proof of the same run made alone when the shapes agree, and the oracle's for its shape
+    otherwise; all verify and carry the right public values."""
+    nq, pw = 6, 5
+    client = zk.ProverClient(device=0, num_queries=nq, pow_bits=pw, max_batch=96)
+    pk, vk = client.setup(zk.merkle_elf())
+    n = 400
+    inputs = [fx.acct_fixture(1, seed=2000 + i) for i in range(n)]
+    stdins = []
+    for m in inputs:
+        s = zk.SP1Stdin()
+        s.write(m.to_borsh())
+        stdins.append(s)
+    proofs, status = client.prove_batch(pk, stdins)
+    assert status == [0] * n
+    host = zk.ProverClient(device=-1, num_queries=nq, pow_bits=pw)
+    single = zk.ProverClient(device=0, num_queries=nq, pow_bits=pw, max_batch=1)
+    pk1, vk1 = single.setup(zk.merkle_elf())
+    # one run of every wave of the ramp (24, 42, 73, 127, then the rest) and the call's ends
+    for i in (0, 23, 24, 65, 66, 138, 139, 265, 266, 330, n - 1):
+        assert proofs[i].public_values == fx.ACCOUNT_VALUE
+        host.verify(proofs[i], vk)
+        s = zk.SP1Stdin()
+        s.write(inputs[i].to_borsh())
+        trace = single.machine_trace(pk1, s)
+        q = single.prove(pk1, s).run()
+        raw = proofs[i].to_bytes()
+        if shape_of(zk, raw) == shape_of(zk, q.to_bytes()):
+            assert q.to_bytes() == raw
+        else:
+            assert raw == oracle.machine_prove(dict(trace, shape=shape_of(zk, raw)), num_queries=nq, pow_bits=pw)
