@@ -28,6 +28,10 @@ Context::~Context() {
     if (d_consts) (void)hipFree(d_consts);
     for (uint32_t* hs : h_stage2)
       if (hs) (void)hipHostFree(hs);
+    for (int k = 0; k < kH2dBuffers; ++k) {
+      if (h2d_ev[k]) { (void)hipEventSynchronize(h2d_ev[k]); (void)hipEventDestroy(h2d_ev[k]); }
+      if (h2d_buf[k]) (void)hipHostFree(h2d_buf[k]);
+    }
     for (auto& e : event_pool) {
       (void)hipEventDestroy(e.first);
       (void)hipEventDestroy(e.second);
@@ -137,6 +141,37 @@ ProfileSpan::ProfileSpan(Context* c, const char* name) : ctx(c) {
 }
 ProfileSpan::~ProfileSpan() {
   if (idx != (size_t)-1) (void)hipEventRecord(ctx->spans[idx].b, ctx->stream);
+}
+
+hipError_t Context::h2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
+  // small copies: the runtime stages them itself (it page-locks in place only from a size on)
+  if (bytes < ((size_t)64 << 10)) return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+  for (int k = 0; k < kH2dBuffers; ++k) {
+    if (h2d_buf[k]) continue;
+    if (hipHostMalloc(&h2d_buf[k], kH2dBytes, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&h2d_ev[k], hipEventDisableTiming) != hipSuccess) {
+      // no page-locked memory to be had: the runtime's own path
+      if (h2d_buf[k]) { (void)hipHostFree(h2d_buf[k]); h2d_buf[k] = nullptr; }
+      return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
+    }
+  }
+  const uint8_t* from = static_cast<const uint8_t*>(src);
+  uint8_t* to = static_cast<uint8_t*>(dst);
+  for (size_t off = 0; off < bytes; off += kH2dBytes) {
+    const size_t len = std::min(kH2dBytes, bytes - off);
+    const int k = h2d_next;
+    h2d_next = (h2d_next + 1) % kH2dBuffers;
+    if (h2d_busy[k]) {  // the transfer that last used this buffer
+      const hipError_t e = hipEventSynchronize(h2d_ev[k]);
+      if (e != hipSuccess) return e;
+    }
+    memcpy(h2d_buf[k], from + off, len);
+    hipError_t e = hipMemcpyAsync(to + off, h2d_buf[k], len, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipEventRecord(h2d_ev[k], s);
+    if (e != hipSuccess) return e;
+    h2d_busy[k] = true;
+  }
+  return hipSuccess;
 }
 
 }  // namespace zksp

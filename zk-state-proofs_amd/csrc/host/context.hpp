@@ -110,6 +110,19 @@ struct Context {
   hipEvent_t ev_proved[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
   hipEvent_t body_free = nullptr;  // not owned: one of ev_copied, or null
   int batch_hint = 0;  // prove_batch: the largest group it will load, so the workspace is sized once
+  // Host-to-device copies of the executor's records go through page-locked staging buffers of the client's own
+  // (Context::h2d): handed pageable memory, the runtime page-locks the caller's pages for the transfer and unlocks them
+  // afterwards, and a kernel that runs meanwhile stalls for tens of milliseconds on the page-table update (one 30 ms stall
+  // per uploaded chunk in a prove_batch call: rocprof showed a 0.3 ms kernel taking 31.7 ms; with the runtime told never
+  // to lock in place, GPU_PINNED_MIN_XFER_SIZE, a call of 1 024 runs took 2 990 ms instead of 3 055-3 097).
+  static constexpr int kH2dBuffers = 4;
+  static constexpr size_t kH2dBytes = (size_t)8 << 20;
+  void* h2d_buf[kH2dBuffers] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t h2d_ev[kH2dBuffers] = {nullptr, nullptr, nullptr, nullptr};
+  bool h2d_busy[kH2dBuffers] = {false, false, false, false};
+  int h2d_next = 0;
+  // dst (device) <- src (any host memory), enqueued on `s`; src may be freed when this returns.  hipSuccess, or the error.
+  hipError_t h2d(void* dst, const void* src, size_t bytes, hipStream_t s);
   std::string error;
   // profiling
   bool profile = false;

@@ -819,13 +819,13 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     cn[2] = (uint32_t)t.memfinal.size(); cn[3] = (uint32_t)t.muls.size();
     cn[4] = (uint32_t)t.alu_idx.size(); cn[5] = (uint32_t)t.sub_idx.size(); cn[6] = t.x0_last; cn[7] = (uint32_t)t.bw_idx.size();
     if (!t.bw_idx.empty())
-      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->bw_idx + i * w->cap_bw, t.bw_idx.data(), t.bw_idx.size() * 4, hipMemcpyHostToDevice, s));
+      ZKSP_HIP_CHECK(ctx, ctx->h2d(w->bw_idx + i * w->cap_bw, t.bw_idx.data(), t.bw_idx.size() * 4, s));
     cn[9] = (uint32_t)t.ecall_idx.size();
     if (!t.ecall_idx.empty())
-      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->ecall_idx + (i << logh[kEcall]), t.ecall_idx.data(), t.ecall_idx.size() * 4, hipMemcpyHostToDevice, s));
+      ZKSP_HIP_CHECK(ctx, ctx->h2d(w->ecall_idx + (i << logh[kEcall]), t.ecall_idx.data(), t.ecall_idx.size() * 4, s));
     cn[11] = (uint32_t)t.div_idx.size();
     if (!t.div_idx.empty())
-      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->div_idx + (i << logh[kDiv]), t.div_idx.data(), t.div_idx.size() * 4, hipMemcpyHostToDevice, s));
+      ZKSP_HIP_CHECK(ctx, ctx->h2d(w->div_idx + (i << logh[kDiv]), t.div_idx.data(), t.div_idx.size() * 4, s));
     // aggregation payload: the rows (ancestors of the supplied nodes: key, children's digests) the Poseidon2 chip's
     // rows are expanded from, and its public part
     uint32_t agg_root[8], agg_digest[8];
@@ -845,26 +845,26 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
     if (!t.div_idx.empty()) busy |= 1u << kDiv;
     if (!t.muls.empty()) busy |= 1u << kMul;
     uint32_t* d_p2 = w->agg_heap + i * w->cap_agg * kP2RecWords;
-    if (n_node) ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(d_p2, agg_heaps[i].data(), agg_heaps[i].size() * 4, hipMemcpyHostToDevice, s));
-    if (n_lc) ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(d_p2 + n_node * kP2RecWords, lc->p2_rows.data(), lc->p2_rows.size() * 4, hipMemcpyHostToDevice, s));
+    if (n_node) ZKSP_HIP_CHECK(ctx, ctx->h2d(d_p2, agg_heaps[i].data(), agg_heaps[i].size() * 4, s));
+    if (n_lc) ZKSP_HIP_CHECK(ctx, ctx->h2d(d_p2 + n_node * kP2RecWords, lc->p2_rows.data(), lc->p2_rows.size() * 4, s));
     if (cn[10])
-      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->fold_rows + i * w->cap_fold * kQrRecWords, lc->qr_rows.data(), lc->qr_rows.size() * 4, hipMemcpyHostToDevice, s));
+      ZKSP_HIP_CHECK(ctx, ctx->h2d(w->fold_rows + i * w->cap_fold * kQrRecWords, lc->qr_rows.data(), lc->qr_rows.size() * 4, s));
     if (cn[12])
-      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->tr_rows + i * w->cap_tr * kTrRecWords, lc->tr_rows.data(), lc->tr_rows.size() * 4, hipMemcpyHostToDevice, s));
+      ZKSP_HIP_CHECK(ctx, ctx->h2d(w->tr_rows + i * w->cap_tr * kTrRecWords, lc->tr_rows.data(), lc->tr_rows.size() * 4, s));
     if (!t.alu_idx.empty())
-      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->alu_idx + i * w->cap_alu, t.alu_idx.data(), t.alu_idx.size() * 4, hipMemcpyHostToDevice, s));
+      ZKSP_HIP_CHECK(ctx, ctx->h2d(w->alu_idx + i * w->cap_alu, t.alu_idx.data(), t.alu_idx.size() * 4, s));
     if (!t.sub_idx.empty())
-      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->sub_idx + i * w->cap_sub, t.sub_idx.data(), t.sub_idx.size() * 4, hipMemcpyHostToDevice, s));
+      ZKSP_HIP_CHECK(ctx, ctx->h2d(w->sub_idx + i * w->cap_sub, t.sub_idx.data(), t.sub_idx.size() * 4, s));
     nperms[i] = (uint32_t)t.keccak.size();
-    ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->cycles + i * w->cap_cycles * 12, t.cycles.data(), t.cycles.size() * 48, hipMemcpyHostToDevice, s));
+    ZKSP_HIP_CHECK(ctx, ctx->h2d(w->cycles + i * w->cap_cycles * 12, t.cycles.data(), t.cycles.size() * 48, s));
     if (!t.keccak.empty())
-      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->kcalls + i * w->cap_keccak * 408, t.keccak.data(), t.keccak.size() * 408, hipMemcpyHostToDevice, s));
+      ZKSP_HIP_CHECK(ctx, ctx->h2d(w->kcalls + i * w->cap_keccak * 408, t.keccak.data(), t.keccak.size() * 408, s));
     for (size_t p = 0; p < t.keccak.size(); ++p) memcpy(&kst[(i * w->cap_keccak + p) * 25], t.keccak[p].in, 200);
-    ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->memfinal + i * w->cap_memfinal * 5, t.memfinal.data(), t.memfinal.size() * 20, hipMemcpyHostToDevice, s));
+    ZKSP_HIP_CHECK(ctx, ctx->h2d(w->memfinal + i * w->cap_memfinal * 5, t.memfinal.data(), t.memfinal.size() * 20, s));
     if (!t.muls.empty())
-      ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->muls + i * w->cap_muls * 3, t.muls.data(), t.muls.size() * 12, hipMemcpyHostToDevice, s));
+      ZKSP_HIP_CHECK(ctx, ctx->h2d(w->muls + i * w->cap_muls * 3, t.muls.data(), t.muls.size() * 12, s));
     ZKSP_HIP_CHECK(ctx, hipMemsetAsync(w->prog_mult + i * hp, 0, hp * 4, s));
-    ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->prog_mult + i * hp, t.prog_mult.data(), t.prog_mult.size() * 4, hipMemcpyHostToDevice, s));
+    ZKSP_HIP_CHECK(ctx, ctx->h2d(w->prog_mult + i * hp, t.prog_mult.data(), t.prog_mult.size() * 4, s));
     uint32_t* o = &obs[i * kMachineInitObs];
     memcpy(o, vk.digest, 32);
     for (int c = 0; c < kNumChips; ++c) o[8 + c] = (uint32_t)logh[c];
@@ -906,7 +906,7 @@ int machine_load(Context* ctx, const MachineProgram& prog, const MachineVk& vk, 
       machine_pub_digest(lc ? lc->pub_tuples.data() : nullptr, n_pub, o + 60 + kNumChips + kHo);
     }
   }
-  ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->kstates, kst.data(), kst.size() * 8, hipMemcpyHostToDevice, s));
+  ZKSP_HIP_CHECK(ctx, ctx->h2d(w->kstates, kst.data(), kst.size() * 8, s));
   ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->counts, counts.data(), counts.size() * 4, hipMemcpyHostToDevice, s));
   ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->n_perms, nperms.data(), nperms.size() * 4, hipMemcpyHostToDevice, s));
   ZKSP_HIP_CHECK(ctx, hipMemcpyAsync(w->init_obs, obs.data(), obs.size() * 4, hipMemcpyHostToDevice, s));
