@@ -122,6 +122,8 @@ struct Context {
   bool h2d_busy[kH2dBuffers] = {false, false, false, false};
   int h2d_next = 0;
   // dst (device) <- src (any host memory), enqueued on `s`; src may be freed when this returns.  hipSuccess, or the error.
+  // (called by the thread that drives the client - a client is not re-entrant; a buffer of the ring is reused once the
+  // transfer that last read it has completed, whichever stream it was on)
   hipError_t h2d(void* dst, const void* src, size_t bytes, hipStream_t s);
   std::string error;
   // profiling
